@@ -1,0 +1,157 @@
+"""
+Pins the oracle against the LIVE reference (authoring container only; skipped on the GPU box where
+/root/reference does not exist).  Covers forward, inverse, log-det, the state the layers mutate
+(ActNorm init, flow-BN batch/running stats, BatchNorm running stats) and autograd gradients of every
+trainable parameter, for the four model families on the hot path.
+"""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import indexmaps as im
+from oracle import models as om
+from oracle import transforms as tf
+
+CASES = [
+    # name, kind, ref class, dims, datatype, layers, mixtures, batch
+    ('realnvp2d', 'realnvp', 'RealNVP', (2, ), '2d', 3, None, 64),
+    ('glow2d', 'glow', 'Glow', (2, ), '2d', 3, None, 64),
+    ('flowpp2d', 'flowpp', 'Flowpp', (2, ), '2d', 2, 8, 64),
+    ('maf2d', 'maf', 'MAF', (2, ), '2d', 3, None, 64),
+    ('realnvp6d', 'realnvp', 'RealNVP', (6, ), None, 2, None, 32),
+    ('glow_img', 'glow', 'Glow', (3, 16, 16), 'image', 1, None, 4),
+    ('realnvp_img', 'realnvp', 'RealNVP', (3, 16, 16), 'image', 1, None, 4),
+    ('flowpp_img', 'flowpp', 'Flowpp', (2, 8, 8), 'image', 1, 4, 3),
+]
+
+
+def _make(ref_flows, case, seed=0):
+    name, kind, cls, dims, datatype, layers, mix, B = case
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    ref = getattr(ref_flows, cls)(dims, datatype, NS(layers=layers, mixtures=mix))
+    sd = om.clone_state(ref.state_dict())
+    ora = om.FlowOracle(kind, dims, datatype, layers, sd, mixtures=mix)
+    g = torch.Generator().manual_seed(seed + 1)
+    if datatype == 'image':
+        y = torch.rand((B, ) + dims, generator=g)
+    else:
+        y = torch.randn((B, ) + dims, generator=g) * 0.5
+    return ref, ora, y
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_forward_grad_state_inverse(ref_flows, case):
+    ref, ora, y = _make(ref_flows, case)
+
+    # ---- training-mode forward + loss + grads ---------------------------------------------------------------------
+    ref.train()
+    ora.training = True
+    ora.requires_grad_(True)
+    z_ref, ld_ref = ref(y.clone())
+    z_ora, ld_ora = ora.forward(y.clone())
+    assert torch.allclose(z_ref, z_ora, atol=2e-6, rtol=1e-5), (z_ref - z_ora).abs().max()
+    assert torch.allclose(ld_ref, ld_ora, atol=2e-5, rtol=1e-5), (ld_ref - ld_ora).abs().max()
+
+    loss_ref = tf.nll_loss(z_ref, ld_ref)
+    loss_ora = tf.nll_loss(z_ora, ld_ora)
+    loss_ref.backward()
+    loss_ora.backward()
+    ref_params = dict(ref.named_parameters())
+    n_checked = 0
+    for k, v in ora.parameters().items():
+        gr = ref_params[k].grad
+        if gr is None:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+            continue
+        assert v.grad is not None, k
+        scale = max(1.0, float(gr.abs().max()))
+        assert float((gr - v.grad).abs().max()) <= 2e-5 * scale, (k, float((gr - v.grad).abs().max()), scale)
+        n_checked += 1
+    assert n_checked > 0
+
+    # ---- mutated state: ActNorm init, flow-BN stats, BN running stats --------------------------------------------
+    ref_sd = ref.state_dict()
+    for k, v in ora.sd.items():
+        a, b = ref_sd[k], v.detach()
+        if a.is_floating_point():
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), k
+        else:
+            assert torch.equal(a, b), k
+
+    # ---- eval forward + both inverses ----------------------------------------------------------------------------
+    ora.requires_grad_(False)
+    with torch.no_grad():
+        for training in (False, True):
+            ref.train(training)
+            ora.training = training
+            if not training or case[1] != 'maf':
+                z_ref, ld_ref = ref(y.clone())
+                z_ora, ld_ora = ora.forward(y.clone())
+                assert torch.allclose(z_ref, z_ora, atol=2e-6, rtol=1e-5)
+                assert torch.allclose(ld_ref, ld_ora, atol=2e-5, rtol=1e-5)
+            zin = z_ora.clone()
+            x_ref, ldi_ref = ref.backward(zin.clone())
+            x_ora, ldi_ora = ora.backward(zin.clone())
+            tol = 2e-4 if case[1] == 'flowpp' else 5e-6          # bisection bracket
+            assert torch.allclose(x_ref, x_ora, atol=tol, rtol=1e-5), (training, (x_ref - x_ora).abs().max())
+            assert torch.allclose(ldi_ref, ldi_ora, atol=max(tol, 2e-5) * 10, rtol=1e-5), \
+                (training, (ldi_ref - ldi_ora).abs().max())
+
+
+def test_index_maps_bit_exact(ref_flows):
+    import importlib
+    sq = importlib.import_module('ref_flows.squeeze')
+    for dims in [(3, 4, 4), (12, 4, 6), (2, 8, 8)]:
+        z = torch.arange(2 * int(np.prod(dims)), dtype=torch.float32).reshape((2, ) + dims)
+        for odd in (False, True):
+            a0, a1 = sq.checker_split(z, odd)
+            b0, b1 = im.split(z, im.MODE_CHECKER, odd)
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+            assert torch.equal(sq.checker_merge(a0, a1, odd), im.merge(b0, b1, im.MODE_CHECKER, odd, dims))
+            if dims[0] % 2 == 0:
+                a0, a1 = sq.channel_split(z, 1, odd)
+                b0, b1 = im.split(z, im.MODE_CHANNEL, odd)
+                assert torch.equal(a0, b0) and torch.equal(a1, b1)
+                assert torch.equal(sq.channel_merge(a0, a1, 1, odd), im.merge(b0, b1, im.MODE_CHANNEL, odd, dims))
+        s = sq.Squeeze2d()
+        u = sq.Unsqueeze2d()
+        zs, _ = s(z, None)
+        assert torch.equal(zs, im.squeeze2d(z))
+        assert torch.equal(s.backward(zs, None)[0], im.unsqueeze2d(zs))
+        assert torch.equal(u(zs, None)[0], im.unsqueeze2d(zs))
+        assert torch.equal(u.backward(z, None)[0], im.squeeze2d(z))
+    for D in (2, 6):
+        z = torch.arange(3 * D, dtype=torch.float32).reshape(3, D)
+        for odd in (False, True):
+            a0, a1 = sq.squeeze1d(z, odd)
+            b0, b1 = im.split(z, im.MODE_1D, odd)
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+            assert torch.equal(sq.unsqueeze1d(a0, a1, odd), im.merge(b0, b1, im.MODE_1D, odd, (D, )))
+
+
+def test_bisection_regimes(ref_flows):
+    """25 iterations normally, 100 when some element hits val == x exactly."""
+    import importlib
+    rm = importlib.import_module('ref_flows.modules')
+    g = torch.Generator().manual_seed(3)
+    B, K = 257, 8
+    logpi = torch.log_softmax(torch.randn(B, K, 1, generator=g), dim=1)
+    mu = torch.randn(B, K, 1, generator=g)
+    s = torch.randn(B, K, 1, generator=g) * 0.3
+    x = torch.rand(B, 1, generator=g) * 0.98 + 0.01
+    ld0 = torch.zeros(B)
+    ref = rm.MixLogCDF()
+    a, lda = ref.backward(x.clone(), logpi, mu, s, ld0.clone())
+    b, ldb, iters = tf.mixlogcdf_inverse(x.clone(), ld0.clone(), logpi, mu, s, return_iters=True)
+    assert torch.equal(a, b) and torch.allclose(lda, ldb, atol=1e-6)
+    assert iters in (25, 100)
+    # force the "stuck" regime: target exactly equal to a representable CDF value at the first midpoint (0.0)
+    x2 = x.clone()
+    x2[0, 0] = torch.exp(tf._mix_logcdf(torch.zeros(1, 1), logpi[:1], mu[:1], s[:1]))[0, 0]
+    a, lda = ref.backward(x2.clone(), logpi, mu, s, ld0.clone())
+    b, ldb, iters = tf.mixlogcdf_inverse(x2.clone(), ld0.clone(), logpi, mu, s, return_iters=True)
+    assert iters == 100
+    assert torch.equal(a, b) and torch.allclose(lda, ldb, atol=1e-6)
