@@ -1,0 +1,166 @@
+// Glow's invertible 1x1 convolution as a per-pixel small mat-vec.  Reference: flows/modules.py:441-497.
+//   apply : y[b,:,p] = M z[b,:,p]    (M = W forward, W^-1 inverse, W^T for the autograd of z), ld += +-P*sum(log_s)
+//   wgrad : g_M[r,c] = sum_{b,p} g_y[b,r,p] z[b,c,p]
+// HBM-bound (8 B/element; 2C FLOP/element, C <= 48 -> 12 FLOP/B, under the fp32 ridge of ~25 FLOP/B): the matrix is
+// read through wave-uniform addresses, so the compiler keeps it on the scalar path (s_load -> SGPR operands of
+// v_fmac) and the vector memory pipe carries only z and y, coalesced along the pixel axis of NCHW.
+#include "nf_common.h"
+
+template <int CT, bool TRANSPOSE>
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_apply(const float* __restrict__ z, const float* __restrict__ M,
+                                                            float* __restrict__ y, float* __restrict__ ld,
+                                                            const float* __restrict__ log_s, float ld_sign, int64_t B,
+                                                            int P) {
+    const int64_t npix = B * P;
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t t = gtid; t < npix; t += gstride) {
+        const int64_t b = t / P;
+        const int64_t base = b * CT * P + (t - b * P);
+        float in[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) in[c] = z[base + (int64_t)c * P];
+#pragma unroll
+        for (int r = 0; r < CT; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc = fmaf(TRANSPOSE ? M[c * CT + r] : M[r * CT + c], in[c], acc);
+            y[base + (int64_t)r * P] = acc;
+        }
+    }
+    if (ld != nullptr) {
+        float s = 0.f;
+        for (int c = 0; c < CT; ++c) s += log_s[c];
+        const float d = ld_sign * (float)P * s;                 // modules.py:479-480, :494-495
+        for (int64_t b = gtid; b < B; b += gstride) ld[b] += d;
+    }
+}
+
+// any C: inputs re-read per output row (L1-resident); correctness fallback for channel counts without a template
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_apply_any(const float* __restrict__ z, const float* __restrict__ M,
+                                                                float* __restrict__ y, float* __restrict__ ld,
+                                                                const float* __restrict__ log_s, float ld_sign,
+                                                                int64_t B, int C, int P) {
+    const int64_t npix = B * P;
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t t = gtid; t < npix; t += gstride) {
+        const int64_t b = t / P;
+        const int64_t base = b * C * P + (t - b * P);
+        for (int r = 0; r < C; ++r) {
+            float acc = 0.f;
+            for (int c = 0; c < C; ++c) acc = fmaf(TRANSPOSE ? M[c * C + r] : M[r * C + c], z[base + (int64_t)c * P], acc);
+            y[base + (int64_t)r * P] = acc;
+        }
+    }
+    if (ld != nullptr) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += log_s[c];
+        const float d = ld_sign * (float)P * s;
+        for (int64_t b = gtid; b < B; b += gstride) ld[b] += d;
+    }
+}
+
+// g_M = sum over pixels of g_y z^T.  A block stages NF_TP pixels x C channels of both operands in LDS (row stride
+// NF_TP+1 words: lanes walk the channel axis, +1 makes that conflict-free), every thread owns entries (r,c) of g_M.
+#define NF_TP 128
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad(const float* __restrict__ gy, const float* __restrict__ z,
+                                                            float* __restrict__ gM, int64_t B, int C, int P,
+                                                            int64_t tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int RS = NF_TP + 1;
+    float* gT = lds;
+    float* zT = lds + (size_t)C * RS;
+    const int64_t npix = B * P;
+    const int n_ent = C * C;
+    const int NE = 12;                                   // entries per thread: supports C*C <= 12*256 (C <= 55)
+    float acc[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) acc[k] = 0.f;
+    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_block;
+    for (int64_t tile = tile0; tile < tile0 + tiles_per_block; ++tile) {
+        const int64_t t0 = tile * NF_TP;
+        if (t0 >= npix) break;
+        const int np = (int)min((int64_t)NF_TP, npix - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * NF_TP; i += blockDim.x) {
+            const int c = i / NF_TP, q = i - c * NF_TP;
+            float a = 0.f, v = 0.f;
+            if (q < np) {
+                const int64_t t = t0 + q, b = t / P;
+                const int64_t addr = (b * C + c) * P + (t - b * P);
+                a = gy[addr];
+                v = z[addr];
+            }
+            gT[c * RS + q] = a;
+            zT[c * RS + q] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = threadIdx.x + k * NF_BLOCK;
+            if (e < n_ent) {
+                const int r = e / C, c = e - r * C;
+                const float* ga = gT + r * RS;
+                const float* za = zT + c * RS;
+                float s = 0.f;
+                for (int q = 0; q < NF_TP; ++q) s = fmaf(ga[q], za[q], s);
+                acc[k] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = threadIdx.x + k * NF_BLOCK;
+        if (e < n_ent) atomicAdd(gM + e, acc[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TR>
+static void nf_launch_apply(int C, dim3 grid, hipStream_t st, const float* z, const float* M, float* y, float* ld,
+                            const float* log_s, float ld_sign, int64_t B, int P) {
+#define NF_CASE(CT)                                                                                                   \
+    case CT:                                                                                                          \
+        hipLaunchKernelGGL((k_invconv_apply<CT, TR>), grid, dim3(NF_BLOCK), 0, st, z, M, y, ld, log_s, ld_sign, B, P); \
+        break;
+    switch (C) {
+        NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) NF_CASE(6) NF_CASE(8) NF_CASE(12) NF_CASE(16) NF_CASE(24)
+        NF_CASE(32) NF_CASE(48)
+        default:
+            hipLaunchKernelGGL(k_invconv_apply_any<TR>, grid, dim3(NF_BLOCK), 0, st, z, M, y, ld, log_s, ld_sign, B, C, P);
+    }
+#undef NF_CASE
+}
+
+extern "C" int nf_invconv_apply(const float* z, const float* M, int transpose, float* y, float* ld, const float* log_s,
+                                float ld_sign, int64_t B, int C, int P, nf_stream_t stream) {
+    if (C <= 0 || P <= 0 || C > 1024) return NF_E_BADARG;
+    if (ld != nullptr && log_s == nullptr) return NF_E_BADARG;
+    if (B == 0) return 0;
+    unsigned g = nf_grid_for(B * P);
+    const unsigned g_ld = nf_grid_for(B);
+    if (ld != nullptr && g < g_ld) g = g_ld;
+    if (transpose) nf_launch_apply<true>(C, dim3(g), (hipStream_t)stream, z, M, y, ld, log_s, ld_sign, B, P);
+    else nf_launch_apply<false>(C, dim3(g), (hipStream_t)stream, z, M, y, ld, log_s, ld_sign, B, P);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_invconv_wgrad(const float* g_y, const float* z, float* g_M, int64_t B, int C, int P,
+                                nf_stream_t stream) {
+    if (C <= 0 || P <= 0) return NF_E_BADARG;
+    if (C * C > 12 * NF_BLOCK) return NF_E_UNSUPPORTED;
+    if (B == 0) return 0;
+    const int64_t npix = B * P;
+    const int64_t tiles = (npix + NF_TP - 1) / NF_TP;
+    int64_t blocks = tiles < 512 ? tiles : 512;
+    const int64_t tpb = (tiles + blocks - 1) / blocks;
+    blocks = (tiles + tpb - 1) / tpb;
+    const size_t lds = (size_t)2 * C * (NF_TP + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_invconv_wgrad, dim3((unsigned)blocks), dim3(NF_BLOCK), lds, (hipStream_t)stream, g_y, z, g_M, B,
+                       C, P, tpb);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

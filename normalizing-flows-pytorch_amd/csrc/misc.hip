@@ -1,0 +1,47 @@
+// Library probes and the NLL reduction of the training harness (main.py:49-51, :85).
+#include <string.h>
+
+#include "nf_common.h"
+
+extern "C" int nf_version(void) { return 100; }
+
+extern "C" int nf_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return (int)e;
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (wave_size) *wave_size = p.warpSize;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, p.gcnArchName, (size_t)arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return 0;
+}
+
+// loss[0] += -(1/B) * sum_b ( -0.5 |z_b|^2 - 0.5 D log(2 pi) + ld[b] )
+__global__ void __launch_bounds__(NF_BLOCK) k_nll_loss(const float* __restrict__ z, const float* __restrict__ ld,
+                                                       float* __restrict__ loss, int64_t B, int64_t D) {
+    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (int64_t t = gtid; t < B * D; t += gstride) {
+        const float v = z[t];
+        acc = fmaf(-0.5f * v, v, acc);
+    }
+    const float cst = -0.5f * (float)D * 1.8378770664093453f;   // log(2 pi)
+    for (int64_t b = gtid; b < B; b += gstride) acc += ld[b] + cst;
+    const float tot = nf_block_sum(acc, scratch);
+    if (threadIdx.x == 0) atomicAdd(loss, -tot / (float)B);
+}
+
+extern "C" int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream) {
+    if (B <= 0 || D <= 0) return NF_E_BADARG;
+    unsigned g = nf_grid_for(B * D, NF_BLOCK * 8);
+    hipLaunchKernelGGL(k_nll_loss, dim3(g), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, ld, loss, B, D);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

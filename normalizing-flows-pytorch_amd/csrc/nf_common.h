@@ -1,0 +1,119 @@
+// Shared device helpers for libnfhip (gfx950 / CDNA4 only: wave64, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nfhip.h"
+
+#define NF_WAVE 64
+#define NF_BLOCK 256
+#define NF_MAX_GRID 4096  // >> 256 CUs x 8 resident blocks; grid-stride beyond (guide: guideline 11)
+
+#define NF_CHECK_LAUNCH()                 \
+    do {                                  \
+        hipError_t e_ = hipGetLastError(); \
+        if (e_ != hipSuccess) return (int)e_; \
+    } while (0)
+
+static inline unsigned nf_grid_for(int64_t work_items, int per_block = NF_BLOCK) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > NF_MAX_GRID) g = NF_MAX_GRID;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// split maps (reference flows/squeeze.py).  All per-sample offsets fit int32.
+// ---------------------------------------------------------------------------------------------------------------
+struct NfSplit {
+    int mode, odd;
+    int C, H, W;     // full tensor (per sample)
+    int Ch, h, w;    // half tensor (per sample)
+    int n_half;      // Ch*h*w
+    int n_full;      // C*H*W
+};
+
+static inline bool nf_make_split(NfSplit& s, int mode, int odd, int C, int H, int W) {
+    s.mode = mode; s.odd = odd ? 1 : 0; s.C = C; s.H = H; s.W = W;
+    switch (mode) {
+        case NF_SPLIT_1D:
+            if (H != 1 || W != 1 || (C & 1)) return false;
+            s.Ch = C / 2; s.h = 1; s.w = 1; break;
+        case NF_SPLIT_CHECKER:
+            if ((H & 1) || (W & 1)) return false;
+            s.Ch = 2 * C; s.h = H / 2; s.w = W / 2; break;
+        case NF_SPLIT_CHANNEL:
+            if (C & 1) return false;
+            s.Ch = C / 2; s.h = H; s.w = W; break;
+        case NF_SPLIT_NONE:
+            s.Ch = C; s.h = H; s.w = W; break;
+        default: return false;
+    }
+    s.n_half = s.Ch * s.h * s.w;
+    s.n_full = C * H * W;
+    return true;
+}
+
+// offset (inside one sample of the FULL tensor) of element e = (m*h + i)*w + j of half `which` (0 = z0, 1 = z1)
+__device__ __forceinline__ int nf_half_to_full(const NfSplit& s, int which, int e) {
+    const int sel = which ^ s.odd;  // 0: the reference's first-returned half before the odd swap
+    switch (s.mode) {
+        case NF_SPLIT_1D:  // squeeze.py:68-69: z.view(B, C/2, 2)[:, :, sel]
+            return 2 * e + sel;
+        case NF_SPLIT_CHANNEL:  // squeeze.py:7: halves of dim 1
+            return e + sel * s.n_half;
+        case NF_SPLIT_CHECKER: {  // squeeze.py:36-41: squeezed channel k = 4c + 2dy + dx, chunks [a b c d]
+            const int hw = s.h * s.w;
+            const int m = e / hw, r = e - m * hw;
+            const int i = r / s.w, j = r - i * s.w;
+            const int k = sel == 0 ? (m < s.C ? m : m + 2 * s.C) : (m + s.C);
+            const int c = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+            return (c * s.H + 2 * i + dy) * s.W + 2 * j + dx;
+        }
+        default:  // NF_SPLIT_NONE
+            return e;
+    }
+}
+
+// squeezed (space-to-depth) element e = (k*h + i)*w + j  ->  offset in the (C,H,W) sample   squeeze.py:90-92
+__device__ __forceinline__ int nf_squeezed_to_full(int e, int H, int W) {
+    const int h = H >> 1, w = W >> 1, hw = h * w;
+    const int k = e / hw, r = e - k * hw;
+    const int i = r / w, j = r - i * w;
+    const int c = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+    return (c * H + 2 * i + dy) * W + 2 * j + dx;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// reductions: wave64 shuffle -> LDS -> one value per block
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nf_wave_sum(float v) {
+#pragma unroll
+    for (int off = NF_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, NF_WAVE);
+    return v;
+}
+
+// sum over the block; result valid in thread 0.  `scratch` holds >= blockDim.x/64 floats.
+__device__ __forceinline__ float nf_block_sum(float v, float* scratch) {
+    const int lane = threadIdx.x & (NF_WAVE - 1), wid = threadIdx.x >> 6;
+    v = nf_wave_sum(v);
+    __syncthreads();  // protect scratch reuse across consecutive calls
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + NF_WAVE - 1) >> 6;
+        for (int i = 0; i < nw; ++i) r += scratch[i];
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// numerics matching the torch primitives the reference relies on
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nf_softplus(float x) {  // F.softplus: beta 1, threshold 20
+    return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float nf_logsigmoid(float x) {  // min(x,0) - log1p(exp(-|x|))
+    return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}

@@ -1,0 +1,369 @@
+"""
+torch.autograd.Function wrappers over the C ABI of libnfhip.so -- the only place where the product path touches
+the kernels.  Forward-direction ops carry hand-written autograd (backward kernels); inverse-direction ops
+(sampling, ``layer.backward`` in the reference's naming) run without building a graph, like the reference's
+own ``torch.no_grad`` inverse of the invertible 1x1 convolution (flows/modules.py:485).
+
+``ld`` (``log_df_dz``) is updated IN PLACE and returned, as the reference does (coupling.py:110,
+modules.py:249,305,480); only the returned tensor is contractual.
+"""
+import torch
+
+from . import _native as N
+
+MODE_OF = {'1d': N.SPLIT_1D, 'checkerboard': N.SPLIT_CHECKER, 'channelwise': N.SPLIT_CHANNEL, 'none': N.SPLIT_NONE}
+
+
+def _bchw(z):
+    """(B, C, H, W) view of the problem: 2-D data is (B, D, 1, 1)."""
+    if z.dim() == 2:
+        return z.shape[0], z.shape[1], 1, 1
+    if z.dim() == 4:
+        return tuple(z.shape)
+    raise ValueError('flow tensors are (B, D) or (B, C, H, W), got shape %s' % (tuple(z.shape), ))
+
+
+def _half_shape(z, mode):
+    B, C, H, W = _bchw(z)
+    if mode == N.SPLIT_1D:
+        return (B, C // 2)
+    if mode == N.SPLIT_CHECKER:
+        return (B, 2 * C, H // 2, W // 2)
+    if mode == N.SPLIT_CHANNEL:
+        return (B, C // 2, H, W)
+    return tuple(z.shape)
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _owned_ld(ld, *others):
+    """ld is mutated in place; a leaf that requires grad (never the case in the models) gets copied first."""
+    if ld.requires_grad and ld.is_leaf:
+        return ld.clone()
+    return ld
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# index maps
+# ----------------------------------------------------------------------------------------------------------------------
+class _HalfGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, which, mode, odd):
+        z = _contig(z)
+        B, C, H, W = _bchw(z)
+        out = torch.empty(_half_shape(z, mode), dtype=z.dtype, device=z.device)
+        N.call('nf_half_gather', N.ptr(z), N.ptr(out), which, mode, int(odd), B, C, H, W, N.stream())
+        ctx.meta = (which, mode, int(odd), tuple(z.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        which, mode, odd, shape = ctx.meta
+        g = _contig(g)
+        full = torch.empty(shape, dtype=g.dtype, device=g.device)
+        B, C, H, W = _bchw(full)
+        N.call('nf_half_scatter', N.ptr(g), N.ptr(full), which, mode, odd, B, C, H, W, N.stream())
+        return full, None, None, None
+
+
+def half_gather(z, which, mode, odd):
+    """contiguous z0 (which=0, transformed half) or z1 (which=1, conditioning half) of the split map."""
+    return _HalfGather.apply(z, which, mode, odd)
+
+
+class _SpaceDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, to_depth):
+        z = _contig(z)
+        B, C, H, W = z.shape
+        if to_depth:
+            out = torch.empty((B, 4 * C, H // 2, W // 2), dtype=z.dtype, device=z.device)
+            N.call('nf_squeeze2d', N.ptr(z), N.ptr(out), B, C, H, W, N.stream())
+        else:
+            out = torch.empty((B, C // 4, 2 * H, 2 * W), dtype=z.dtype, device=z.device)
+            N.call('nf_unsqueeze2d', N.ptr(z), N.ptr(out), B, C // 4, 2 * H, 2 * W, N.stream())
+        ctx.to_depth = to_depth
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _SpaceDepth.apply(g, not ctx.to_depth), None
+
+
+def squeeze2d(z):
+    if z.dim() != 4 or z.shape[2] % 2 or z.shape[3] % 2:
+        raise ValueError('squeeze2d needs (B, C, even H, even W)')
+    return _SpaceDepth.apply(z, True)
+
+
+def unsqueeze2d(z):
+    if z.dim() != 4 or z.shape[1] % 4:
+        raise ValueError('unsqueeze2d needs (B, 4C, h, w)')
+    return _SpaceDepth.apply(z, False)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# affine coupling
+# ----------------------------------------------------------------------------------------------------------------------
+class _AffineCoupling(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, t, s_raw, pbs, a, c, ld, mode, odd):
+        B, C, H, W = _bchw(z)
+        y = torch.empty_like(z)
+        N.call('nf_affine_coupling_fwd', N.ptr(z), N.ptr(t), N.ptr(s_raw), pbs, N.ptr(a), N.ptr(c), N.ptr(y),
+               N.ptr(ld), mode, int(odd), 0, B, C, H, W, N.stream())
+        ctx.save_for_backward(z, t, s_raw, a, c)
+        ctx.meta = (pbs, mode, int(odd))
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, t, s_raw, a, c = ctx.saved_tensors
+        pbs, mode, odd = ctx.meta
+        B, C, H, W = _bchw(z)
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_z = torch.empty_like(z)
+        g_t = torch.empty_like(t)
+        g_s = torch.empty_like(s_raw)
+        g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+        N.call('nf_affine_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(t), N.ptr(s_raw), pbs, N.ptr(a),
+               N.ptr(c), N.ptr(g_z), N.ptr(g_t), N.ptr(g_s), g_ac.data_ptr(), g_ac.data_ptr() + 4, mode, odd, B, C, H,
+               W, N.stream())
+        return g_z, g_t, g_s, None, g_ac[0:1].view_as(a), g_ac[1:2].view_as(c), g_ld, None, None
+
+
+class _AffineCouplingPacked(torch.autograd.Function):
+    """conditioner output packed as one tensor (B, 2*Ch, h, w): t = params[:, :Ch], s_raw = params[:, Ch:]."""
+
+    @staticmethod
+    def forward(ctx, z, params, a, c, ld, mode, odd):
+        B, C, H, W = _bchw(z)
+        n_half = params[0].numel() // 2
+        y = torch.empty_like(z)
+        N.call('nf_affine_coupling_fwd', N.ptr(z), N.ptr(params), params.data_ptr() + 4 * n_half, 2 * n_half, N.ptr(a),
+               N.ptr(c), N.ptr(y), N.ptr(ld), mode, int(odd), 0, B, C, H, W, N.stream())
+        ctx.save_for_backward(z, params, a, c)
+        ctx.meta = (n_half, mode, int(odd))
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, params, a, c = ctx.saved_tensors
+        n_half, mode, odd = ctx.meta
+        B, C, H, W = _bchw(z)
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_z = torch.empty_like(z)
+        g_p = torch.empty_like(params)
+        g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+        N.call('nf_affine_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params),
+               params.data_ptr() + 4 * n_half, 2 * n_half, N.ptr(a), N.ptr(c), N.ptr(g_z), N.ptr(g_p),
+               g_p.data_ptr() + 4 * n_half, g_ac.data_ptr(), g_ac.data_ptr() + 4, mode, odd, B, C, H, W, N.stream())
+        return g_z, g_p, g_ac[0:1].view_as(a), g_ac[1:2].view_as(c), g_ld, None, None
+
+
+def affine_coupling(z, params, s_log_scale, s_bias, ld, mode, odd, inverse=False):
+    """AbstractCoupling.forward/backward around AffineCoupling._transform/_inverse_transform, given ``params`` =
+    conditioner(z1).  (flows/coupling.py:32-43, :104-122)"""
+    z, params = _contig(z), _contig(params)
+    half = _half_shape(z, mode)
+    if tuple(params.shape) != (half[0], 2 * half[1]) + tuple(half[2:]):
+        raise ValueError('conditioner output has shape %s, expected %s' % (tuple(params.shape),
+                                                                         (half[0], 2 * half[1]) + tuple(half[2:])))
+    ld = _owned_ld(ld)
+    if not inverse:
+        return _AffineCouplingPacked.apply(z, params, s_log_scale, s_bias, ld, mode, odd)
+    with torch.no_grad():
+        B, C, H, W = _bchw(z)
+        n_half = params[0].numel() // 2
+        y = torch.empty_like(z)
+        N.call('nf_affine_coupling_fwd', N.ptr(z), N.ptr(params), params.data_ptr() + 4 * n_half, 2 * n_half,
+               N.ptr(s_log_scale), N.ptr(s_bias), N.ptr(y), N.ptr(ld), mode, int(odd), 1, B, C, H, W, N.stream())
+    return y, ld
+
+
+def affine_transform(z, s_raw, t, s_log_scale, s_bias, ld, inverse=False):
+    """un-split affine transform with separate scale / shift tensors (MAF: flows/maf.py:103-106, :114-115)."""
+    z, s_raw, t = _contig(z), _contig(s_raw), _contig(t)
+    ld = _owned_ld(ld)
+    pbs = s_raw[0].numel()
+    if not inverse:
+        return _AffineCoupling.apply(z, t, s_raw, pbs, s_log_scale, s_bias, ld, N.SPLIT_NONE, False)
+    with torch.no_grad():
+        B, C, H, W = _bchw(z)
+        y = torch.empty_like(z)
+        N.call('nf_affine_coupling_fwd', N.ptr(z), N.ptr(t), N.ptr(s_raw), pbs, N.ptr(s_log_scale), N.ptr(s_bias),
+               N.ptr(y), N.ptr(ld), N.SPLIT_NONE, 0, 1, B, C, H, W, N.stream())
+    return y, ld
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# per-channel affine bijectors (ActNorm, flow BatchNorm) and their statistics
+# ----------------------------------------------------------------------------------------------------------------------
+def _bcp(x):
+    B, C = x.shape[0], x.shape[1]
+    P = 1
+    for d in x.shape[2:]:
+        P *= int(d)
+    return B, C, P
+
+
+class _ChanAffine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, x, ld, p0, p1, p2, p3):
+        B, C, P = _bcp(x)
+        y = torch.empty_like(x)
+        N.call('nf_chan_affine_fwd', op, N.ptr(x), N.ptr(p0), N.ptr(p1), N.ptr(p2), N.ptr(p3), N.ptr(y), N.ptr(ld), 0,
+               B, C, P, N.stream())
+        ctx.op = op
+        ctx.save_for_backward(x, p0, p1, p2, p3)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        x, p0, p1, p2, p3 = ctx.saved_tensors
+        op = ctx.op
+        B, C, P = _bcp(x)
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_x = torch.empty_like(x)
+        pa, pb = (p0, p1) if op == N.OP_ACTNORM else (p2, p3)
+        want = ctx.needs_input_grad[3 if op == N.OP_ACTNORM else 5]
+        if want:
+            g_ab = torch.zeros((2, ) + tuple(pa.shape), dtype=x.dtype, device=x.device)
+            ga_ptr, gb_ptr = g_ab.data_ptr(), g_ab.data_ptr() + 4 * pa.numel()
+        else:
+            g_ab, ga_ptr, gb_ptr = None, None, None
+        N.call('nf_chan_affine_bwd', op, N.ptr(g_y), N.ptr(g_ld), N.ptr(x), N.ptr(p0), N.ptr(p1), N.ptr(p2), N.ptr(p3),
+               N.ptr(g_x), ga_ptr, gb_ptr, B, C, P, N.stream())
+        ga, gb = (g_ab[0], g_ab[1]) if want else (None, None)
+        if op == N.OP_ACTNORM:
+            return None, g_x, g_ld, ga, gb, None, None
+        return None, g_x, g_ld, None, None, ga, gb
+
+
+def chan_affine(op, x, ld, p0, p1, p2=None, p3=None, inverse=False):
+    x = _contig(x)
+    ld = _owned_ld(ld)
+    if not inverse:
+        return _ChanAffine.apply(op, x, ld, p0, p1, p2, p3)
+    with torch.no_grad():
+        B, C, P = _bcp(x)
+        y = torch.empty_like(x)
+        N.call('nf_chan_affine_fwd', op, N.ptr(x), N.ptr(p0), N.ptr(p1), N.ptr(p2), N.ptr(p3), N.ptr(y), N.ptr(ld), 1,
+               B, C, P, N.stream())
+    return y, ld
+
+
+def chan_stats(x):
+    """per-channel (sum, sum of squared deviations) over batch and pixels, two passes (no E[x^2]-E[x]^2)."""
+    x = _contig(x)
+    B, C, P = _bcp(x)
+    st = torch.zeros((2, C), dtype=x.dtype, device=x.device)
+    N.call('nf_chan_sum', N.ptr(x), st.data_ptr(), B, C, P, N.stream())
+    N.call('nf_chan_sqdev', N.ptr(x), st.data_ptr(), st.data_ptr() + 4 * C, B, C, P, N.stream())
+    return st, B * P
+
+
+def actnorm_init_(x, log_scale, bias, eps):
+    """data-dependent ActNorm initialisation, writes the parameters in place (flows/modules.py:238-244)."""
+    with torch.no_grad():
+        st, n = chan_stats(x)
+        C = st.shape[1]
+        N.call('nf_actnorm_init_finalize', st.data_ptr(), st.data_ptr() + 4 * C, N.ptr(log_scale.data),
+               N.ptr(bias.data), float(eps), n, C, N.stream())
+
+
+def flowbn_update_(x, batch_mean, batch_var, running_mean, running_var, eps, momentum):
+    """train-mode statistics of the flow BatchNorm, all buffers written in place (flows/modules.py:284-294)."""
+    with torch.no_grad():
+        st, n = chan_stats(x)
+        C = st.shape[1]
+        N.call('nf_flowbn_finalize', st.data_ptr(), st.data_ptr() + 4 * C, N.ptr(batch_mean), N.ptr(batch_var),
+               N.ptr(running_mean), N.ptr(running_var), float(eps), float(momentum), n, C, N.stream())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# invertible 1x1 convolution
+# ----------------------------------------------------------------------------------------------------------------------
+class _InvConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, W, ld, log_s):
+        B, C, P = _bcp(z)
+        y = torch.empty_like(z)
+        N.call('nf_invconv_apply', N.ptr(z), N.ptr(W), 0, N.ptr(y), N.ptr(ld), N.ptr(log_s), 1.0, B, C, P, N.stream())
+        ctx.save_for_backward(z, W)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, W = ctx.saved_tensors
+        B, C, P = _bcp(z)
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_z = g_W = g_ls = None
+        if ctx.needs_input_grad[0]:
+            g_z = torch.empty_like(z)
+            N.call('nf_invconv_apply', N.ptr(g_y), N.ptr(W), 1, N.ptr(g_z), None, None, 0.0, B, C, P, N.stream())
+        if ctx.needs_input_grad[1]:
+            g_W = torch.zeros_like(W)
+            N.call('nf_invconv_wgrad', N.ptr(g_y), N.ptr(z), N.ptr(g_W), B, C, P, N.stream())
+        if ctx.needs_input_grad[3]:
+            g_ls = (g_ld.sum() * float(P)).expand(C)
+        return g_z, g_W, g_ld, g_ls
+
+
+def invconv(z, W, ld, log_s):
+    """forward 1x1 convolution y = W z per pixel, ld += P * sum(log_s)  (flows/modules.py:475-480)."""
+    return _InvConv.apply(_contig(z), _contig(W), _owned_ld(ld), _contig(log_s))
+
+
+def invconv_inverse(y, W_inv, ld, log_s):
+    """z = W^-1 y per pixel, ld -= P * sum(log_s)  (flows/modules.py:484-497), no autograd like the reference."""
+    with torch.no_grad():
+        y, W_inv = _contig(y), _contig(W_inv)
+        ld = _owned_ld(ld)
+        B, C, P = _bcp(y)
+        z = torch.empty_like(y)
+        N.call('nf_invconv_apply', N.ptr(y), N.ptr(W_inv), 0, N.ptr(z), N.ptr(ld), N.ptr(_contig(log_s)), -1.0, B, C, P,
+               N.stream())
+    return z, ld
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# logit
+# ----------------------------------------------------------------------------------------------------------------------
+class _Logit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ld, eps):
+        B = x.shape[0]
+        n = x[0].numel()
+        y = torch.empty_like(x)
+        N.call('nf_logit_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), float(eps), 0, B, n, N.stream())
+        ctx.save_for_backward(x)
+        ctx.eps = float(eps)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        (x, ) = ctx.saved_tensors
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_x = torch.empty_like(x)
+        N.call('nf_logit_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(x), N.ptr(g_x), ctx.eps, x.shape[0], x[0].numel(),
+               N.stream())
+        return g_x, g_ld, None
+
+
+def logit(x, ld, eps, inverse=False):
+    x = _contig(x)
+    ld = _owned_ld(ld)
+    if not inverse:
+        return _Logit.apply(x, ld, eps)
+    with torch.no_grad():
+        y = torch.empty_like(x)
+        N.call('nf_logit_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), float(eps), 1, x.shape[0], x[0].numel(), N.stream())
+    return y, ld

@@ -1,0 +1,266 @@
+"""
+Bijective layers with the reference's nn.Module surface:
+
+    layer(z, log_df_dz)          -> (z', log_df_dz')      forward flow  (data -> latent)
+    layer.backward(y, log_df_dz) -> (y', log_df_dz')      INVERSE flow  (latent -> data; not autograd!)
+
+Same class names, constructor signatures, parameter / buffer names and shapes as flows/modules.py,
+flows/coupling.py, flows/squeeze.py and flows/maf.py, so reference ``state_dict``s load unchanged.  The
+transforms themselves run as HIP kernels (functional.py -> libnfhip.so); there is no CPU path.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native as N
+from . import functional as NF
+from .conditioners import MLP, ConvNet, flowpp_conditioner, made_degrees_to_masks
+
+
+class Identity(nn.Module):
+    def forward(self, x, log_df_dz):
+        return x, log_df_dz
+
+    def backward(self, x, log_df_dz):
+        return x, log_df_dz
+
+
+class Compose(nn.Module):
+    """flows/modules.py:325-339"""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, z, log_df_dz):
+        for layer in self.layers:
+            z, log_df_dz = layer(z, log_df_dz)
+        return z, log_df_dz
+
+    def backward(self, z, log_df_dz):
+        for layer in reversed(self.layers):
+            z, log_df_dz = layer.backward(z, log_df_dz)
+        return z, log_df_dz
+
+
+class Logit(nn.Module):
+    """flows/modules.py:141-156"""
+
+    def __init__(self, eps=1.0e-5):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, x, log_df_dz):
+        return NF.logit(x, log_df_dz, self.eps)
+
+    def backward(self, x, log_df_dz):
+        return NF.logit(x, log_df_dz, self.eps, inverse=True)
+
+
+def _param_shape(num_features):
+    dims = [1] + [1 for _ in num_features]
+    dims[1] = num_features[0]
+    return dims
+
+
+class ActNorm(nn.Module):
+    """flows/modules.py:225-256.  ``initialized`` is a plain attribute exactly like the reference's (it is not in
+    the state_dict, so the first batch after ``load_state_dict`` re-initialises -- appendix D Q2); set it to True to
+    keep loaded values."""
+
+    def __init__(self, num_features, eps=1.0e-5):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.dimensions = _param_shape(num_features)
+        self.log_scale = nn.Parameter(torch.zeros(self.dimensions))
+        self.bias = nn.Parameter(torch.zeros(self.dimensions))
+        self.initialized = False
+
+    def forward(self, z, log_df_dz):
+        if not self.initialized:
+            NF.actnorm_init_(z, self.log_scale, self.bias, self.eps)
+            self.initialized = True
+        return NF.chan_affine(N.OP_ACTNORM, z, log_df_dz, self.log_scale, self.bias)
+
+    def backward(self, y, log_df_dz):
+        return NF.chan_affine(N.OP_ACTNORM, y, log_df_dz, self.log_scale, self.bias, inverse=True)
+
+
+class BatchNorm(nn.Module):
+    """flow BatchNorm, flows/modules.py:259-322: batch statistics are constants for autograd; biased variance
+    with eps stored inside; inverse uses the batch buffers in train mode."""
+
+    def __init__(self, num_features, momentum=0.1, eps=1.0e-5, affine=True):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.momentum = momentum
+        self.dimensions = _param_shape(num_features)
+        if affine:
+            self.log_gamma = nn.Parameter(torch.zeros(self.dimensions))
+            self.beta = nn.Parameter(torch.zeros(self.dimensions))
+        else:
+            self.register_buffer('log_gamma', torch.zeros(self.dimensions))
+            self.register_buffer('beta', torch.zeros(self.dimensions))
+        self.register_buffer('running_mean', torch.zeros(self.dimensions))
+        self.register_buffer('running_var', torch.ones(self.dimensions))
+        self.register_buffer('batch_mean', torch.zeros(self.dimensions))
+        self.register_buffer('batch_var', torch.ones(self.dimensions))
+
+    def _stats(self):
+        if self.training:
+            return self.batch_mean, self.batch_var
+        return self.running_mean, self.running_var
+
+    def forward(self, x, log_det_jacob):
+        if self.training:
+            NF.flowbn_update_(x, self.batch_mean, self.batch_var, self.running_mean, self.running_var, self.eps,
+                              self.momentum)
+        mean, var = self._stats()
+        return NF.chan_affine(N.OP_FLOWBN, x, log_det_jacob, mean, var, self.log_gamma, self.beta)
+
+    def backward(self, x, log_det_jacob):
+        mean, var = self._stats()
+        return NF.chan_affine(N.OP_FLOWBN, x, log_det_jacob, mean, var, self.log_gamma, self.beta, inverse=True)
+
+
+class InvertibleConv1x1(nn.Module):
+    """Glow's PLU-parameterised 1x1 convolution, flows/modules.py:441-497.  Frozen constants are
+    ``nn.Parameter(requires_grad=False)`` like the reference, so they appear in the state_dict (appendix D Q3)."""
+
+    def __init__(self, in_out_channels):
+        super().__init__()
+        C = in_out_channels
+        W = torch.zeros((C, C), dtype=torch.float32)
+        nn.init.orthogonal_(W)
+        LU, pivots = torch.linalg.lu_factor(W)
+        P, L, U = torch.lu_unpack(LU, pivots)
+        self.P = nn.Parameter(P, requires_grad=False)
+        self.L = nn.Parameter(L, requires_grad=True)
+        self.U = nn.Parameter(U, requires_grad=True)
+        self.I = nn.Parameter(torch.eye(C), requires_grad=False)
+        self.pivots = nn.Parameter(pivots, requires_grad=False)
+        L_mask = np.tril(np.ones((C, C), dtype='float32'), k=-1)
+        self.L_mask = nn.Parameter(torch.from_numpy(L_mask), requires_grad=False)
+        self.U_mask = nn.Parameter(torch.from_numpy(L_mask.T.copy()), requires_grad=False)
+        s = torch.diag(U)
+        self.log_s = nn.Parameter(torch.log(torch.abs(s)), requires_grad=True)
+        self.sign_s = nn.Parameter(torch.sign(s), requires_grad=False)
+        self._perm_cache = None
+
+    def weight(self):
+        """W = P (L o L_mask + I) (U o U_mask + diag(sign_s exp(log_s)))   (modules.py:471-473)"""
+        Lp = self.L * self.L_mask + self.I
+        Up = self.U * self.U_mask + torch.diag(self.sign_s * torch.exp(self.log_s))
+        return self.P @ Lp @ Up
+
+    def _pivot_matrix(self):
+        """row-swap matrix of the stored LAPACK pivots (what torch.lu_solve applies to its right-hand side)."""
+        key = (self.pivots._version, self.pivots.device)
+        if self._perm_cache is None or self._perm_cache[0] != key:
+            piv = self.pivots.detach().cpu().numpy().astype(np.int64) - 1
+            perm = np.arange(piv.size)
+            for i, p in enumerate(piv):
+                perm[[i, p]] = perm[[p, i]]
+            M = torch.zeros(piv.size, piv.size)
+            M[torch.arange(piv.size), torch.from_numpy(perm)] = 1.0
+            self._perm_cache = (key, M.to(self.pivots.device))
+        return self._perm_cache[1]
+
+    def inverse_weight(self):
+        """W^-1 = U'^-1 L'^-1 Pp from the same LU factors / pivots the reference feeds torch.lu_solve
+        (modules.py:485-492)."""
+        Lp = self.L * self.L_mask + self.I
+        Up = self.U * self.U_mask + torch.diag(self.sign_s * torch.exp(self.log_s))
+        X = torch.linalg.solve_triangular(Lp, self._pivot_matrix(), upper=False, unitriangular=True)
+        return torch.linalg.solve_triangular(Up, X, upper=True)
+
+    def forward(self, z, log_df_dz):
+        return NF.invconv(z, self.weight(), log_df_dz, self.log_s)
+
+    def backward(self, y, log_df_dz):
+        with torch.no_grad():
+            return NF.invconv_inverse(y, self.inverse_weight(), log_df_dz, self.log_s)
+
+
+# ---- squeeze family (flows/squeeze.py:114-189) ---------------------------------------------------------------------
+
+class Squeeze2d(nn.Module):
+    def __init__(self, odd=False):
+        super().__init__()
+        if odd:
+            raise NotImplementedError('Squeeze2d(odd=True) is never built by the reference models')
+        self.odd = odd
+
+    def forward(self, z, log_df_dz):
+        return NF.squeeze2d(z), log_df_dz
+
+    def backward(self, z, log_df_dz):
+        return NF.unsqueeze2d(z), log_df_dz
+
+
+class Unsqueeze2d(nn.Module):
+    def __init__(self, odd=False):
+        super().__init__()
+        if odd:
+            raise NotImplementedError('Unsqueeze2d(odd=True) is never built by the reference models')
+        self.odd = odd
+
+    def forward(self, z, log_df_dz):
+        return NF.unsqueeze2d(z), log_df_dz
+
+    def backward(self, z, log_df_dz):
+        return NF.squeeze2d(z), log_df_dz
+
+
+# ---- coupling layers (flows/coupling.py) -----------------------------------------------------------------------------
+
+class AbstractCoupling(nn.Module):
+    def __init__(self, dims, masking='checkerboard', odd=False):
+        super().__init__()
+        self.dims = dims
+        self.odd = bool(odd)
+        if len(dims) == 1:
+            if dims[0] % 2 != 0:
+                raise Exception('coupling layers need an even feature count, got %s (flows/squeeze.py:67)' % str(dims))
+            self.mode = N.SPLIT_1D
+        elif len(dims) == 3 and masking == 'checkerboard':
+            self.mode = N.SPLIT_CHECKER
+        elif len(dims) == 3 and masking == 'channelwise':
+            self.mode = N.SPLIT_CHANNEL
+        else:
+            raise Exception('unsupported combination of masking and dimension: %s, %s' % (masking, str(dims)))
+
+    def squeeze(self, z):
+        return NF.half_gather(z, 0, self.mode, self.odd), NF.half_gather(z, 1, self.mode, self.odd)
+
+    def conditioner_input(self, z):
+        return NF.half_gather(z, 1, self.mode, self.odd)
+
+
+class AffineCoupling(AbstractCoupling):
+    """RealNVP / Glow affine coupling, flows/coupling.py:82-122; split + transform + merge + log-det are ONE kernel."""
+
+    def __init__(self, dims, masking='checkerboard', odd=False):
+        super().__init__(dims, masking, odd)
+        self.s_log_scale = nn.Parameter(torch.randn(1) * 0.01)
+        self.s_bias = nn.Parameter(torch.randn(1) * 0.01)
+        if len(dims) == 1:
+            in_chs = dims[0] // 2 if not odd else (dims[0] + 1) // 2
+            self.out_chs = dims[0] - in_chs
+            self.net = MLP(in_chs, self.out_chs * 2)
+        else:
+            in_out_chs = dims[0] * 2 if masking == 'checkerboard' else dims[0] // 2
+            self.out_chs = in_out_chs
+            self.net = ConvNet(in_out_chs, in_out_chs * 2)
+
+    def forward(self, z, log_df_dz):
+        params = self.net(self.conditioner_input(z))
+        return NF.affine_coupling(z, params, self.s_log_scale, self.s_bias, log_df_dz, self.mode, self.odd)
+
+    def backward(self, y, log_df_dz):
+        params = self.net(self.conditioner_input(y))
+        return NF.affine_coupling(y, params, self.s_log_scale, self.s_bias, log_df_dz, self.mode, self.odd,
+                                  inverse=True)

@@ -1,0 +1,68 @@
+"""
+Layer stacks with the reference's constructor and call surface:
+
+    net = Glow(dims, datatype, cfg)      cfg.layers (all), cfg.mixtures (Flowpp)
+    z, log_df_dz = net(y)                forward flow, log_df_dz of shape (B,)
+    y, log_df_dz = net.backward(z)       inverse flow (sampling)
+
+Reference: flows/realnvp.py:9-63, flows/glow.py:10-68, flows/flowpp.py:9-78, flows/maf.py:122-148.
+The multi-scale image recipe (shared by RealNVP / Glow / Flow++) is written once here.
+"""
+import torch
+import torch.nn as nn
+
+from .layers import (ActNorm, AffineCoupling, BatchNorm, Compose, InvertibleConv1x1, Logit, Squeeze2d, Unsqueeze2d)
+
+
+class _FlowModel(nn.Module):
+    def __init__(self, dims, datatype=None, cfg=None):
+        super().__init__()
+        self.dims = tuple(dims)
+        self.n_layers = cfg.layers
+        self.net = Compose(self._build(self.dims, datatype, cfg))
+
+    # one "flow step" = normalisation (+ 1x1 conv) + coupling; supplied by the subclass
+    def _step(self, dims, masking, odd, cfg):
+        raise NotImplementedError
+
+    def _build(self, dims, datatype, cfg):
+        K = self.n_layers
+        layers = []
+        if datatype == 'image':
+            layers.append(Logit(eps=0.01))
+            mid = dims
+            while max(mid[1], mid[2]) > 8:
+                for i in range(K):
+                    layers += self._step(mid, 'checkerboard', i % 2 != 0, cfg)
+                layers.append(Squeeze2d(odd=False))
+                mid = (mid[0] * 4, mid[1] // 2, mid[2] // 2)
+                for i in range(K):
+                    layers += self._step(mid, 'channelwise', i % 2 != 0, cfg)
+            for i in range(K + 1):
+                layers += self._step(mid, 'checkerboard', i % 2 != 0, cfg)
+            while mid[1] != dims[1] or mid[2] != dims[2]:
+                layers.append(Unsqueeze2d(odd=False))
+                mid = (mid[0] // 4, mid[1] * 2, mid[2] * 2)
+        else:
+            for i in range(K):
+                layers += self._step(dims, 'checkerboard', i % 2 != 0, cfg)
+        return layers
+
+    def _zero_ld(self, z):
+        return torch.zeros(z.size(0), dtype=z.dtype, device=z.device)
+
+    def forward(self, z):
+        return self.net(z, self._zero_ld(z))
+
+    def backward(self, z):
+        return self.net.backward(z, self._zero_ld(z))
+
+
+class RealNVP(_FlowModel):
+    def _step(self, dims, masking, odd, cfg):
+        return [BatchNorm(dims, affine=False), AffineCoupling(dims, masking=masking, odd=odd)]
+
+
+class Glow(_FlowModel):
+    def _step(self, dims, masking, odd, cfg):
+        return [ActNorm(dims), InvertibleConv1x1(dims[0]), AffineCoupling(dims, masking=masking, odd=odd)]

@@ -1,0 +1,64 @@
+"""
+End-to-end parity of the product models (HIP transforms + PyTorch-ROCm conditioners) against the golden vectors
+captured from the reference: forward (z, log-det), NLL loss, gradients of every parameter, the state the
+forward pass mutates, and both inverses.  Needs a real MI355X.
+"""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transforms as tf
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = 'cuda'
+
+
+def _build(pkg, name):
+    kind, cls, dims, datatype, layers, mix = G.MODEL_CASES[name]
+    if not hasattr(pkg, cls):
+        pytest.skip('%s not built yet' % cls)
+    net = getattr(pkg, cls)(dims, datatype, NS(layers=layers, mixtures=mix))
+    sd0 = G.group('model_' + name, 'sd0/')
+    missing = net.load_state_dict(sd0, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net.to(DEV), G.group('model_' + name, '', DEV), kind, dims
+
+
+@pytest.mark.parametrize('name', list(G.MODEL_CASES))
+def test_model_golden(pkg, name):
+    net, g, kind, dims = _build(pkg, name)
+    net.train()
+    np.random.seed(100)
+    z, ld = net(g['y'].clone())
+    G.assert_close(z, g['train/z'], TOL, what='z')
+    G.assert_close(ld, g['train/ld'], TOL, rtol=2e-6, what='ld')
+    loss = tf.nll_loss(z, ld)
+    G.assert_close(loss, g['train/loss'], TOL * max(1.0, abs(float(g['train/loss'])) / np.prod(dims)), what='loss')
+    loss.backward()
+    n = 0
+    for k, p in net.named_parameters():
+        if 'grad/' + k in g:
+            want = g['grad/' + k]
+            assert p.grad is not None, k
+            G.assert_close(p.grad, want, 2 * TOL * max(1.0, float(want.abs().max())), what=k)
+            n += 1
+    assert n > 4
+    sd = net.state_dict()
+    for k, want in G.group('model_' + name, 'sd1/').items():
+        G.assert_close(sd[k].float(), want.float(), 2e-6, what=k)
+    tol_inv = 2e-4 if kind == 'flowpp' else TOL
+    with torch.no_grad():
+        x, ldi = net.backward(g['train/z'].clone())
+        G.assert_close(x, g['train/x_inv'], tol_inv, what='train x_inv')
+        G.assert_close(ldi, g['train/ld_inv'], 10 * tol_inv, what='train ld_inv')
+        net.eval()
+        z, ld = net(g['y'].clone())
+        G.assert_close(z, g['eval/z'], TOL, what='eval z')
+        G.assert_close(ld, g['eval/ld'], TOL, rtol=2e-6, what='eval ld')
+        x, ldi = net.backward(g['eval/z'].clone())
+        G.assert_close(x, g['eval/x_inv'], tol_inv, what='eval x_inv')
+        G.assert_close(ldi, g['eval/ld_inv'], 10 * tol_inv, what='eval ld_inv')

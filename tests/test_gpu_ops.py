@@ -1,0 +1,264 @@
+"""
+Parity of the HIP kernels (called through the C ABI via the product's functional layer) against the golden
+vectors captured from the reference and against the oracle on fresh seeded inputs.  Needs a real MI355X.
+Tolerances: 1e-5 fp32 (north_star), bit-exact for index maps.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import indexmaps as im
+from oracle import transforms as tf
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def nf(pkg):
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    pkg._native.load()
+    return pkg
+
+
+def _scaled(want):
+    return TOL * max(1.0, float(want.abs().max()))
+
+
+# ---- index maps: bit exact ------------------------------------------------------------------------------------------
+def test_indexmaps_golden(nf):
+    NF = nf.functional
+    for key in G.keys('indexmaps'):
+        parts = key.split('/')
+        if parts[0] in ('checker', 'channel', '1d') and parts[-1] == 'z0':
+            tag, odd = parts[1], parts[2] == 'odd1'
+            z = G.group('indexmaps', 'in/' + tag, DEV)[''].float()
+            mode = {'checker': 1, 'channel': 2, '1d': 0}[parts[0]]
+            g = G.group('indexmaps', '/'.join(parts[:3]) + '/', DEV)
+            z0, z1 = NF.half_gather(z, 0, mode, odd), NF.half_gather(z, 1, mode, odd)
+            assert torch.equal(z0, g['z0'].float()) and torch.equal(z1, g['z1'].float()), key
+        if parts[0] == 'squeeze2d':
+            z = G.group('indexmaps', 'in/' + parts[1], DEV)[''].float()
+            want = G.group('indexmaps', key, DEV)[''].float()
+            assert torch.equal(NF.squeeze2d(z), want)
+            assert torch.equal(NF.unsqueeze2d(want), z)
+
+
+@pytest.mark.parametrize('dims,mode', [((6, ), 0), ((3, 32, 32), 1), ((12, 16, 16), 1), ((12, 16, 16), 2),
+                                       ((48, 8, 8), 2), ((5, 6, 10), 1)])
+@pytest.mark.parametrize('odd', [False, True])
+def test_indexmaps_vs_oracle(nf, dims, mode, odd):
+    NF = nf.functional
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn((7, ) + dims, generator=g)
+    zd = z.to(DEV).requires_grad_(True)
+    for which in (0, 1):
+        want = im.split(z, mode, odd)[which]
+        got = NF.half_gather(zd, which, mode, odd)
+        assert torch.equal(got.cpu(), want)
+        gh = torch.randn(want.shape, generator=g)
+        (gz, ) = torch.autograd.grad(got, zd, gh.to(DEV))
+        zr = z.clone().requires_grad_(True)
+        (gz_ref, ) = torch.autograd.grad(im.split(zr, mode, odd)[which], zr, gh)
+        assert torch.equal(gz.cpu(), gz_ref)
+    if len(dims) == 3:
+        assert torch.equal(NF.squeeze2d(zd).cpu(), im.squeeze2d(z))
+        zs = im.squeeze2d(z)
+        assert torch.equal(NF.unsqueeze2d(zs.to(DEV)).cpu(), z)
+
+
+# ---- affine coupling ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,mode', [('1d', 0), ('1d6', 0), ('checker', 1), ('channel', 2)])
+@pytest.mark.parametrize('odd', [False, True])
+def test_affine_coupling_golden(nf, tag, mode, odd):
+    NF = nf.functional
+    g = G.group('ops', 'affine/%s/odd%d/' % (tag, odd), DEV)
+    a = torch.tensor([float(g['meta'][0])], device=DEV, requires_grad=True)
+    c = torch.tensor([float(g['meta'][1])], device=DEV, requires_grad=True)
+    z, params = g['z'].requires_grad_(True), g['params'].requires_grad_(True)
+    y, ld = NF.affine_coupling(z, params, a, c, g['ld0'].clone(), mode, odd)
+    G.assert_close(y, g['y'], TOL, what='y')
+    G.assert_close(ld, g['ld'], TOL, what='ld')
+    gz, gp, ga, gc = torch.autograd.grad([y, ld], [z, params, a, c], [g['gy'], g['gld']])
+    for got, n in [(gz, 'gz'), (gp, 'gparams'), (ga, 'ga'), (gc, 'gc')]:
+        G.assert_close(got, g[n], _scaled(g[n]), what=n)
+    x, ldi = NF.affine_coupling(g['y'], g['params'], a.detach(), c.detach(), g['ld'].clone(), mode, odd, inverse=True)
+    G.assert_close(x, g['x_inv'], TOL, what='x_inv')
+    G.assert_close(ldi, g['ld_inv'], TOL, what='ld_inv')
+
+
+@pytest.mark.parametrize('dims,mode,B', [((2, ), 0, 4096), ((3, 32, 32), 1, 8), ((12, 16, 16), 2, 8),
+                                         ((48, 8, 8), 1, 5), ((24, 32, 32), 2, 3)])
+def test_affine_coupling_vs_oracle(nf, dims, mode, B):
+    NF = nf.functional
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn((B, ) + dims, generator=g)
+    half = im.split(z, mode, True)[0]
+    pshape = list(half.shape)
+    pshape[1] *= 2
+    params = torch.randn(pshape, generator=g) * 0.5
+    a, c = torch.tensor([0.4]), torch.tensor([-0.1])
+    ld0 = torch.randn(B, generator=g)
+    gy, gld = torch.randn(z.shape, generator=g), torch.randn(B, generator=g)
+    for odd in (False, True):
+        leaves = [t.clone().requires_grad_(True) for t in (z, params, a, c)]
+        y, ld = tf.affine_coupling(leaves[0], ld0, leaves[1], leaves[2], leaves[3], mode, odd)
+        want = torch.autograd.grad([y, ld], leaves, [gy, gld])
+        dl = [t.clone().to(DEV).requires_grad_(True) for t in (z, params, a, c)]
+        yd, ldd = NF.affine_coupling(dl[0], dl[1], dl[2], dl[3], ld0.to(DEV), mode, odd)
+        G.assert_close(yd, y, TOL)
+        G.assert_close(ldd, ld, TOL * max(1.0, float(ld.abs().max())))
+        got = torch.autograd.grad([yd, ldd], dl, [gy.to(DEV), gld.to(DEV)])
+        for gg, ww in zip(got, want):
+            G.assert_close(gg, ww, _scaled(ww) * 4)
+        xi, ldi = NF.affine_coupling(yd.detach(), dl[1].detach(), dl[2].detach(), dl[3].detach(), ldd.detach().clone(),
+                                     mode, odd, inverse=True)
+        G.assert_close(xi, z, 2e-5)                      # round trip
+        G.assert_close(ldi, ld0, 2e-5 * max(1.0, float(ld.abs().max())))
+
+
+# ---- ActNorm / flow BatchNorm --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['2d', 'img'])
+def test_actnorm_golden(nf, tag):
+    g = G.group('ops', 'actnorm/%s/' % tag, DEV)
+    dims = tuple(g['z'].shape[1:])
+    layer = nf.ActNorm(dims).to(DEV)
+    z = g['z'].requires_grad_(True)
+    y, ld = layer(z, g['ld0'].clone())
+    G.assert_close(layer.log_scale, g['log_scale'], 2e-6, what='init log_scale')
+    G.assert_close(layer.bias, g['bias'], 2e-6, what='init bias')
+    G.assert_close(y, g['y'], TOL)
+    G.assert_close(ld, g['ld'], TOL)
+    gz, gls, gb = torch.autograd.grad([y, ld], [z, layer.log_scale, layer.bias], [g['gy'], g['gld']])
+    G.assert_close(gz, g['gz'], TOL)
+    G.assert_close(gls, g['glog_scale'], _scaled(g['glog_scale']))
+    G.assert_close(gb, g['gbias'], _scaled(g['gbias']))
+    x, ldi = layer.backward(g['y'], g['ld'].clone())
+    G.assert_close(x, g['x_inv'], TOL)
+    G.assert_close(ldi, g['ld_inv'], TOL)
+
+
+@pytest.mark.parametrize('tag', ['2d', 'img'])
+def test_flow_bn_golden(nf, tag):
+    g0 = G.group('ops', 'flowbn/%s/step0/' % tag, DEV)
+    dims = tuple(g0['x'].shape[1:])
+    layer = nf.BatchNorm(dims, affine=False).to(DEV)
+    layer.train()
+    for step in range(2):
+        g = G.group('ops', 'flowbn/%s/step%d/' % (tag, step), DEV)
+        x = g['x'].requires_grad_(True)
+        y, ld = layer(x, g['ld0'].clone())
+        for n in ('batch_mean', 'batch_var', 'running_mean', 'running_var'):
+            G.assert_close(getattr(layer, n), g[n], 2e-6, what=n)
+        G.assert_close(y, g['y'], TOL)
+        G.assert_close(ld, g['ld'], TOL)
+        (gx, ) = torch.autograd.grad([y], [x], [g['gy']])
+        G.assert_close(gx, g['gx'], TOL)
+        xi, ldi = layer.backward(g['y'], g['ld'].clone())
+        G.assert_close(xi, g['x_inv'], TOL)
+        G.assert_close(ldi, g['ld_inv'], TOL)
+    layer.eval()
+    g = G.group('ops', 'flowbn/%s/eval/' % tag, DEV)
+    y, ld = layer(g['x'], g['ld0'].clone())
+    G.assert_close(y, g['y'], TOL)
+    G.assert_close(ld, g['ld'], TOL)
+    xi, ldi = layer.backward(g['y'], g['ld'].clone())
+    G.assert_close(xi, g['x_inv'], TOL)
+    G.assert_close(ldi, g['ld_inv'], TOL)
+
+
+def test_flow_bn_affine_grads_vs_oracle(nf):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 6, 4, 4, generator=g) * 2 + 1
+    lg, beta = torch.randn(1, 6, 1, 1, generator=g) * 0.3, torch.randn(1, 6, 1, 1, generator=g)
+    ld0, gy, gld = torch.randn(16, generator=g), torch.randn(x.shape, generator=g), torch.randn(16, generator=g)
+    mean, var = tf.flow_bn_stats(x)
+    leaves = [t.clone().requires_grad_(True) for t in (x, lg, beta)]
+    y, ld = tf.flow_bn(leaves[0], ld0, mean, var, leaves[1], leaves[2])
+    want = torch.autograd.grad([y, ld], leaves, [gy, gld])
+    layer = nf.BatchNorm((6, 4, 4), affine=True).to(DEV)
+    with torch.no_grad():
+        layer.log_gamma.copy_(lg)
+        layer.beta.copy_(beta)
+    xd = x.to(DEV).requires_grad_(True)
+    yd, ldd = layer(xd, ld0.to(DEV))
+    G.assert_close(yd, y, TOL)
+    G.assert_close(ldd, ld, TOL * 10)
+    got = torch.autograd.grad([yd, ldd], [xd, layer.log_gamma, layer.beta], [gy.to(DEV), gld.to(DEV)])
+    for gg, ww in zip(got, want):
+        G.assert_close(gg, ww, _scaled(ww) * 2)
+
+
+# ---- invertible 1x1 ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('C', [2, 3, 12, 48])
+def test_invconv_golden(nf, C):
+    g = G.group('ops', 'invconv/%d/' % C, DEV)
+    layer = nf.InvertibleConv1x1(C).to(DEV)
+    sd = {n: g[n] for n in ('P', 'L', 'U', 'I', 'pivots', 'L_mask', 'U_mask', 'log_s', 'sign_s')}
+    layer.load_state_dict(sd)
+    z = g['z'].requires_grad_(True)
+    y, ld = layer(z, g['ld0'].clone())
+    G.assert_close(y, g['y'], TOL)
+    G.assert_close(ld, g['ld'], TOL)
+    gz, gL, gU, gs = torch.autograd.grad([y, ld], [z, layer.L, layer.U, layer.log_s], [g['gy'], g['gld']])
+    for got, n in [(gz, 'gz'), (gL, 'gL'), (gU, 'gU'), (gs, 'glog_s')]:
+        G.assert_close(got, g[n], _scaled(g[n]), what=n)
+    x, ldi = layer.backward(g['y'], g['ld'].clone())
+    G.assert_close(x, g['x_inv'], TOL)
+    G.assert_close(ldi, g['ld_inv'], TOL)
+
+
+@pytest.mark.parametrize('C,P,B', [(5, 7, 9), (48, 64, 64), (12, 256, 16), (3, 1024, 4), (2, 1, 4096)])
+def test_invconv_vs_oracle(nf, C, P, B):
+    NF = nf.functional
+    g = torch.Generator().manual_seed(C)
+    z = torch.randn(B, C, P, generator=g)
+    W = torch.linalg.qr(torch.randn(C, C, generator=g))[0] + 0.05 * torch.randn(C, C, generator=g)
+    log_s = torch.randn(C, generator=g) * 0.1
+    ld0, gy, gld = torch.randn(B, generator=g), torch.randn(z.shape, generator=g), torch.randn(B, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (z, W, log_s)]
+    y, ld = tf.invconv(leaves[0], ld0, leaves[1], leaves[2])
+    want = torch.autograd.grad([y, ld], leaves, [gy, gld])
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (z, W, log_s)]
+    yd, ldd = NF.invconv(dl[0], dl[1], ld0.to(DEV), dl[2])
+    G.assert_close(yd, y, TOL)
+    G.assert_close(ldd, ld, TOL * max(1.0, float(ld.abs().max())))
+    got = torch.autograd.grad([yd, ldd], dl, [gy.to(DEV), gld.to(DEV)])
+    for gg, ww in zip(got, want):
+        G.assert_close(gg, ww, _scaled(ww) * 4)
+
+
+# ---- logit --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('eps', [1.0e-5, 0.01])
+def test_logit_golden(nf, eps):
+    NF = nf.functional
+    g = G.group('ops', 'logit/%g/' % eps, DEV)
+    x = g['x'].requires_grad_(True)
+    y, ld = NF.logit(x, g['ld0'].clone(), eps)
+    G.assert_close(y, g['y'], TOL)
+    G.assert_close(ld, g['ld'], TOL, rtol=2e-6)
+    (gx, ) = torch.autograd.grad([y, ld], [x], [g['gy'], g['gld']])
+    G.assert_close(gx, g['gx'], TOL, rtol=1e-5)
+    xi, ldi = NF.logit(g['yin'].detach(), g['ld0'].clone(), eps, inverse=True)
+    G.assert_close(xi, g['x_inv'], TOL)
+    G.assert_close(ldi, g['ld_inv'], TOL)
+
+
+def test_empty_batch(nf):
+    NF = nf.functional
+    z = torch.zeros(0, 2, device=DEV)
+    ld = torch.zeros(0, device=DEV)
+    y, ld2 = NF.affine_coupling(z, torch.zeros(0, 2, device=DEV), torch.ones(1, device=DEV), torch.zeros(1, device=DEV),
+                                ld, 0, False)
+    assert y.shape == (0, 2) and ld2.shape == (0, )
+    y, _ = NF.logit(torch.zeros(0, 3, 4, 4, device=DEV), ld, 0.01)
+    assert y.shape == (0, 3, 4, 4)
+
+
+def test_cpu_tensor_is_refused(nf):
+    with pytest.raises(RuntimeError):
+        nf.functional.logit(torch.rand(2, 3), torch.zeros(2), 0.01)
