@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""
+bench.py -- samples/sec (+ bits/dim) of one training step of the flow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config c2] [--no-graph] [--skip-cpu]
+
+A "step" is one full pass of the hot path over one batch of synthetic input: forward flow + log-det, NLL,
+autograd backward through every transform kernel, gradient all-reduce (N > 1), Adam -- main.py:78-92.
+Default workload = BASELINE.json configs[1]: Glow, moons 2-D, K=32 flow steps, batch 4096 per GPU (weak scaling).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+
+Timed region: inputs already resident in HBM; barrier + synchronize on both sides; max over ranks.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = 'normalizing-flows-pytorch_amd'
+
+CONFIGS = {
+    # name: model class, oracle kind, dims, datatype, layers, mixtures, data, per-GPU batch
+    'c1': dict(cls='RealNVP', kind='realnvp', dims=(2, ), datatype='2d', layers=32, mixtures=None, data='moons', batch=256,
+               desc='RealNVP moons-2D K=32 batch 256'),
+    'c2': dict(cls='Glow', kind='glow', dims=(2, ), datatype='2d', layers=32, mixtures=None, data='moons', batch=4096,
+               desc='Glow moons-2D K=32 batch 4096 per GPU'),
+    'c3': dict(cls='Flowpp', kind='flowpp', dims=(2, ), datatype='2d', layers=32, mixtures=8, data='circles', batch=65536,
+               desc='Flow++ circles-2D K=32 mixtures=8 batch 65536 per GPU'),
+    'c4': dict(cls='Glow', kind='glow', dims=(3, 32, 32), datatype='image', layers=32, mixtures=None, data='cifar',
+               batch=64, desc='Glow CIFAR-shape (3,32,32) L=3 K=32 batch 64 per GPU (512 over 8)'),
+    'c5': dict(cls='MAF', kind='maf', dims=(2, ), datatype='2d', layers=10, mixtures=None, data='normals', batch=16384,
+               desc='MAF normals-2D 10 AR layers batch 16384 per GPU (131072 over 8)'),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (asymptotic sweeps)')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--skip-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def event_time_ms(fn, reps, stream):
+    """average duration of `fn` over `reps` launches, HIP events recorded on `stream` (the launch stream)."""
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        fn()
+    start.record(stream)
+    for _ in range(reps):
+        fn()
+    stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def dominant_kernel_roofline(pkg, cfg, B, dev):
+    """the hot-path kernel that dominates our own kernels' time in this workload: the fused affine / mixture coupling.
+    achieved = algorithmic bytes per launch / average launch duration (HIP events, launch stream)."""
+    N, NF = pkg._native, pkg.functional
+    stream = torch.cuda.current_stream()
+    dims = cfg['dims']
+    g = torch.Generator(device='cpu').manual_seed(7)
+    if cfg['kind'] == 'maf':
+        z = torch.randn(B, dims[0], generator=g).to(dev)
+        s_raw, t = torch.randn_like(z), torch.randn_like(z)
+        a, c = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev)
+        ld, y = torch.zeros(B, device=dev), torch.empty_like(z)
+        n = z[0].numel()
+
+        def fn():
+            N.call('nf_affine_coupling_fwd', z.data_ptr(), t.data_ptr(), s_raw.data_ptr(), n, a.data_ptr(), c.data_ptr(),
+                   y.data_ptr(), ld.data_ptr(), N.SPLIT_NONE, 0, 0, B, dims[0], 1, 1, stream.cuda_stream)
+        name, nbytes = 'k_affine_rows_fwd (AR affine)', B * n * 16 + B * 8      # z, s, t, y + ld rmw
+    elif cfg['kind'] == 'flowpp':
+        K = cfg['mixtures']
+        z = torch.randn((B, ) + dims, generator=g).to(dev)
+        params = (torch.randn(B, 2 + 3 * K, generator=g) * 0.5).to(dev)
+        a, c = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev)
+        ld, y = torch.zeros(B, device=dev), torch.empty_like(z)
+
+        def fn():
+            N.call('nf_mixlog_coupling_fwd', z.data_ptr(), params.data_ptr(), a.data_ptr(), c.data_ptr(), y.data_ptr(),
+                   ld.data_ptr(), K, 1.0e-5, N.SPLIT_1D, 0, B, dims[0], 1, 1, stream.cuda_stream)
+        name = 'k_mixlog_rows_fwd'
+        nbytes = B * ((4 + 3 * K) * 4 + 8 + 8)                                   # (4+3K)*4 + pass-through r/w + ld rmw
+    else:
+        if len(dims) == 1:
+            shape, mode, pshape = (B, dims[0]), N.SPLIT_1D, (B, dims[0])
+        else:                                               # first-resolution checkerboard step of the image stack
+            shape, mode = (B, ) + dims, N.SPLIT_CHECKER
+            pshape = (B, 4 * dims[0], dims[1] // 2, dims[2] // 2)
+        z = torch.randn(shape, generator=g).to(dev)
+        params = (torch.randn(pshape, generator=g) * 0.5).to(dev)
+        a, c = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev)
+        ld, y = torch.zeros(B, device=dev), torch.empty_like(z)
+        n_half = z[0].numel() // 2
+        C, H, W = (dims[0], 1, 1) if len(dims) == 1 else dims
+
+        def fn():
+            N.call('nf_affine_coupling_fwd', z.data_ptr(), params.data_ptr(), params.data_ptr() + 4 * n_half, 2 * n_half,
+                   a.data_ptr(), c.data_ptr(), y.data_ptr(), ld.data_ptr(), mode, 0, 0, B, C, H, W, stream.cuda_stream)
+        name = 'k_affine_rows_fwd' if n_half <= 16 else 'k_affine_slab_fwd'
+        nbytes = z.numel() * 12 + B * 8                                          # 12 B / element of z + ld rmw
+    ms = event_time_ms(fn, 200, stream)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': None, 'bytes_per_launch': int(nbytes),
+            'us_per_launch': round(ms * 1e3, 3)}
+
+
+def cpu_baseline(cfg, state, y_cpu, seconds):
+    """the oracle (our CPU restatement of the reference, validated against it) timed on this box's host cores on the
+    same workload and weights: full train step incl. Adam, bounded to ~`seconds` of CPU work."""
+    from oracle import models as om
+    from oracle import transforms as tf
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in state.items()}
+    ora = om.FlowOracle(cfg['kind'], cfg['dims'], cfg['datatype'], cfg['layers'], sd, mixtures=cfg['mixtures'],
+                        training=True).requires_grad_(True)
+    params = list(ora.parameters().values())
+    opt = torch.optim.Adam(params, lr=1.0e-4)
+    B = y_cpu.shape[0]
+
+    def step():
+        opt.zero_grad()
+        z, ld = ora.forward(y_cpu)
+        loss = tf.nll_loss(z, ld)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    step()                                                   # ActNorm init + warm caches
+    t0 = time.perf_counter()
+    n, loss = 0, 0.0
+    while True:
+        loss = step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'value': round(B * n / el, 1), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d train steps of the same workload (batch %d, same weights) in %.1f s on %s' % (n, B, el, model),
+            'ms_per_step': round(1e3 * el / n, 2), 'loss': round(loss, 5)}
+
+
+def main():
+    args = parse()
+    pkg = importlib.import_module(PKG)
+    pkg._native.load()
+    nfdist = importlib.import_module(PKG + '.dist')
+    nftrain = importlib.import_module(PKG + '.train')
+    nfdata = importlib.import_module(PKG + '.data')
+    rank, world, local_rank = nfdist.init_from_env()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs a torchrun launch with that many ranks' % args.gpus)
+    assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no GPU visible'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg['batch']
+
+    torch.manual_seed(0)                                     # identical initial weights on every rank
+    np.random.seed(0)
+    net = getattr(pkg, cfg['cls'])(cfg['dims'], cfg['datatype'], NS(layers=cfg['layers'], mixtures=cfg['mixtures']))
+    state0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    nfdist.broadcast_parameters(net)
+    trainer = nftrain.FlowTrainer(net, graph=not args.no_graph, warmup=2)
+
+    y_cpu = nfdata.sample(cfg['data'], B, 1234 + rank)
+    if cfg['data'] == 'cifar':
+        y_cpu = y_cpu.reshape((B, ) + cfg['dims'])
+    y = y_cpu.to(dev)                                        # resident in HBM before the timed region
+
+    for _ in range(max(args.warmup, 4)):                     # >= 4 so that graph capture happens before timing
+        trainer.train_on_batch(y)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        z, loss = trainer.train_on_batch(y)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss)
+
+    # forward-only and inverse-only rates (eval mode, no autograd), informational
+    with torch.no_grad():
+        net.eval()
+        stream = torch.cuda.current_stream()
+        fwd_ms = event_time_ms(lambda: net(y), 10, stream)
+        zz, _ = net(y)
+        inv_ms = event_time_ms(lambda: net.backward(zz), 5, stream)
+        net.train()
+
+    if rank == 0:
+        roof = dominant_kernel_roofline(pkg, cfg, B, dev)
+        out = {
+            'metric': 'samples/sec (train step: forward flow + log-det + NLL + backward + Adam)',
+            'value': round(B * world * args.steps / elapsed, 1),
+            'unit': 'samples/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic (seeded %s restatement, random-init weights)' % cfg['data'],
+            'config': {'workload': cfg['desc'], 'name': args.config, 'per_gpu_batch': B, 'global_batch': B * world,
+                       'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph},
+            'loss_nats': round(loss_val, 5),
+            'bits_per_dim': round(nftrain.bits_per_dim(loss_val, cfg['dims']), 5),
+            'forward_samples_per_s': round(B * world / (fwd_ms * 1e-3), 1),
+            'inverse_samples_per_s': round(B * world / (inv_ms * 1e-3), 1),
+            'grad_bucket_bytes': trainer.bucket.nbytes(),
+            'roofline': roof,
+        }
+        if cfg['datatype'] == 'image':
+            out['bits_per_dim_plus_log2_255'] = round(out['bits_per_dim'] + math.log2(255.0), 5)
+        if world == 1 and not args.skip_cpu:
+            out['cpu_baseline'] = cpu_baseline(cfg, state0, y_cpu, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

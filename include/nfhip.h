@@ -121,6 +121,26 @@ int nf_logit_fwd(const float* x, float* y, float* ld, float eps, int inverse, in
 int nf_logit_bwd(const float* g_y, const float* g_ld, const float* x, float* g_x, float eps, int64_t B, int64_t n,
                  nf_stream_t stream);
 
+/* ---- Flow++ mixture-of-logistics coupling  coupling.py:172-210, modules.py:64-97, :186-212 ---------------------
+ * params: conditioner output (B, (2+3K)*Ch, h, w) with channel sections [a | b | logit(pi) | mu | s]
+ * (coupling.py:140,177); mixture k of transformed channel m lives at section channel k*Ch + m (coupling.py:180-182).
+ * forward : z0 -> MixLogCDF -> Logit(eps) -> * exp(a) + b,  a = tanh(a_raw)*a_log_scale + a_bias; ld accumulates
+ *           log pdf, the logit log-det and sum a.   inverse: the exact reverse with the bisection of
+ *           modules.py:196-212 (bracket +-1e3, <= 100 iterations, batch-global exit rule reproduced with the
+ *           device flag `stuck_flag` (int32[1], zeroed by the call): 25 iterations, then 75 more iff any element
+ *           still has |hi-lo| >= 1e-4, i.e. iff the reference would not have left the loop at iteration 25.
+ *           `scratch`: 3*B*Ch*h*w floats (bracket + target carried between the two phases).                       */
+int nf_mixlog_coupling_fwd(const float* z, const float* params, const float* a_log_scale, const float* a_bias,
+                           float* y, float* ld, int K, float logit_eps, int mode, int odd, int64_t B, int C, int H,
+                           int W, nf_stream_t stream);
+int nf_mixlog_coupling_inv(const float* z, const float* params, const float* a_log_scale, const float* a_bias,
+                           float* y, float* ld, float* scratch, int* stuck_flag, int K, int mode, int odd, int64_t B,
+                           int C, int H, int W, nf_stream_t stream);
+int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, const float* params,
+                           const float* a_log_scale, const float* a_bias, float* g_z, float* g_params,
+                           float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
+                           int C, int H, int W, nf_stream_t stream);
+
 /* ---- NLL of the training harness  main.py:49-51, :85 -------------------------------------------------------------
  * loss[0] += -(1/B) * sum_b ( -0.5*|z_b|^2 - 0.5*D*log(2 pi) + ld[b] );  g_z = z / B,  (g_ld = -1/B is constant) */
 int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream);

@@ -9,9 +9,10 @@ The directory name is not a Python identifier; import it with
 """
 from . import _native, functional  # noqa: F401
 from ._build import build  # noqa: F401
-from .layers import (ActNorm, AbstractCoupling, AffineCoupling, BatchNorm, Compose, Identity, InvertibleConv1x1, Logit,
-                     Squeeze2d, Unsqueeze2d)
-from .models import Glow, RealNVP
+from .layers import (MADE, ActNorm, AbstractCoupling, AffineCoupling, AutoregressiveTransfrom, BatchNorm, Compose, Identity,
+                     InvertibleConv1x1, Logit, MixLogAttnCoupling, Squeeze2d, Unsqueeze2d)
+from .models import MAF, Flowpp, Glow, RealNVP
 
 __all__ = ['ActNorm', 'AbstractCoupling', 'AffineCoupling', 'BatchNorm', 'Compose', 'Identity', 'InvertibleConv1x1',
-           'Logit', 'Squeeze2d', 'Unsqueeze2d', 'Glow', 'RealNVP', 'build', 'functional']
+           'Logit', 'Squeeze2d', 'Unsqueeze2d', 'Glow', 'RealNVP', 'Flowpp', 'MAF', 'MADE', 'AutoregressiveTransfrom',
+           'MixLogAttnCoupling', 'build', 'functional']

@@ -367,3 +367,54 @@ def logit(x, ld, eps, inverse=False):
         y = torch.empty_like(x)
         N.call('nf_logit_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), float(eps), 1, x.shape[0], x[0].numel(), N.stream())
     return y, ld
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Flow++ mixture-of-logistics coupling
+# ----------------------------------------------------------------------------------------------------------------------
+class _MixLogCoupling(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, params, a, c, ld, K, eps, mode, odd):
+        B, C, H, W = _bchw(z)
+        y = torch.empty_like(z)
+        N.call('nf_mixlog_coupling_fwd', N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(y), N.ptr(ld), K, float(eps),
+               mode, int(odd), B, C, H, W, N.stream())
+        ctx.save_for_backward(z, params, a, c)
+        ctx.meta = (K, float(eps), mode, int(odd))
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, params, a, c = ctx.saved_tensors
+        K, eps, mode, odd = ctx.meta
+        B, C, H, W = _bchw(z)
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_z = torch.empty_like(z)
+        g_p = torch.empty_like(params)
+        g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+        N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c),
+               N.ptr(g_z), N.ptr(g_p), g_ac.data_ptr(), g_ac.data_ptr() + 4, K, eps, mode, odd, B, C, H, W, N.stream())
+        return g_z, g_p, g_ac[0:1].view_as(a), g_ac[1:2].view_as(c), g_ld, None, None, None, None
+
+
+def mixlog_coupling(z, params, a_log_scale, a_bias, ld, n_mixtures, mode, odd, inverse=False, logit_eps=1.0e-5):
+    """MixLogAttnCoupling._transform / _inverse_transform + split + merge given ``params`` = conditioner(z1)
+    (flows/coupling.py:172-210).  The inverse reproduces the reference's 25-or-100 iteration bisection rule."""
+    z, params = _contig(z), _contig(params)
+    half = _half_shape(z, mode)
+    want = (half[0], (2 + 3 * n_mixtures) * half[1]) + tuple(half[2:])
+    if tuple(params.shape) != want:
+        raise ValueError('conditioner output has shape %s, expected %s' % (tuple(params.shape), want))
+    ld = _owned_ld(ld)
+    if not inverse:
+        return _MixLogCoupling.apply(z, params, a_log_scale, a_bias, ld, n_mixtures, logit_eps, mode, odd)
+    with torch.no_grad():
+        B, C, H, W = _bchw(z)
+        y = torch.empty_like(z)
+        n_el = z.numel() // 2
+        scratch = torch.empty(3 * max(n_el, 1), dtype=z.dtype, device=z.device)
+        flag = torch.empty(1, dtype=torch.int32, device=z.device)
+        N.call('nf_mixlog_coupling_inv', N.ptr(z), N.ptr(params), N.ptr(a_log_scale), N.ptr(a_bias), N.ptr(y), N.ptr(ld),
+               N.ptr(scratch), N.ptr(flag), n_mixtures, mode, int(odd), B, C, H, W, N.stream())
+    return y, ld

@@ -264,3 +264,114 @@ class AffineCoupling(AbstractCoupling):
         params = self.net(self.conditioner_input(y))
         return NF.affine_coupling(y, params, self.s_log_scale, self.s_bias, log_df_dz, self.mode, self.odd,
                                   inverse=True)
+
+
+class MixLogAttnCoupling(AbstractCoupling):
+    """Flow++ mixture-of-logistics coupling with the gated-attention conditioner, flows/coupling.py:125-210.
+    CDF -> logit -> affine and all three log-det terms are ONE kernel; the inverse bisection is two launches."""
+
+    def __init__(self, dims, masking='checkerboard', odd=False, base_filters=32, n_mixtures=4):
+        super().__init__(dims, masking, odd)
+        self.n_mixtures = n_mixtures
+        self.a_log_scale = nn.Parameter(torch.randn(1) * 0.01)
+        self.a_bias = nn.Parameter(torch.randn(1) * 0.01)
+        if len(dims) == 1:
+            in_chs = dims[0] // 2 if not odd else (dims[0] + 1) // 2
+            out_chs = dims[0] - in_chs
+            mid_shape = (base_filters, ) + tuple(d // 2 for d in dims[1:])
+        elif masking == 'checkerboard':
+            in_chs = out_chs = dims[0] * 2
+            mid_shape = (base_filters, ) + tuple(d // 2 for d in dims[1:])
+        else:
+            in_chs = out_chs = dims[0] // 2
+            mid_shape = (base_filters, ) + tuple(dims[1:])
+        self.sections = [out_chs] * 2 + [out_chs * n_mixtures] * 3
+        self.net = flowpp_conditioner(in_chs, sum(self.sections), mid_shape, base_filters, conv=(len(dims) == 3))
+        self.logit_eps = 1.0e-5                      # Logit() default inside the coupling (coupling.py:169)
+
+    def forward(self, z, log_df_dz):
+        params = self.net(self.conditioner_input(z))
+        return NF.mixlog_coupling(z, params, self.a_log_scale, self.a_bias, log_df_dz, self.n_mixtures, self.mode,
+                                  self.odd, logit_eps=self.logit_eps)
+
+    def backward(self, z, log_df_dz):
+        params = self.net(self.conditioner_input(z))
+        return NF.mixlog_coupling(z, params, self.a_log_scale, self.a_bias, log_df_dz, self.n_mixtures, self.mode,
+                                  self.odd, inverse=True)
+
+
+# ---- MAF (flows/maf.py) -------------------------------------------------------------------------------------------------
+
+class MADE(nn.Module):
+    """masked autoencoder conditioner, flows/maf.py:9-85.  Same parameter containers (weights / bnorms / biases).
+    Masks follow the reference's rule, including its re-draw from the global ``np.random`` on every call
+    (degenerate, i.e. constant, for D == 2 -- appendix D Q4)."""
+
+    def __init__(self, in_out_features, num_hidden=2, base_filters=32, use_companion=False):
+        super().__init__()
+        if use_companion:
+            raise NotImplementedError('use_companion=True is never built by the reference models')
+        self.in_out_chs = in_out_features
+        self.num_hidden = num_hidden
+        self.base_filters = base_filters
+        self.masks = None
+        weights, biases, bnorms = [], [], []
+        widths = [in_out_features] + [base_filters] * num_hidden
+        for i, o in zip(widths[:-1], widths[1:]):
+            scale = np.sqrt(2.0 / (o + i))
+            weights.append(nn.Parameter(torch.randn(o, i) * scale))
+            torch.randn(o, i)                        # the reference also draws the unused companion matrix U
+            biases.append(nn.Parameter(torch.randn(o) * 0.01))
+            bnorms.append(nn.BatchNorm1d(o))
+        scale = np.sqrt(2.0 / (in_out_features + widths[-1]))
+        weights.append(nn.Parameter(torch.randn(in_out_features, widths[-1]) * scale))
+        torch.randn(in_out_features, widths[-1])
+        biases.append(nn.Parameter(torch.randn(in_out_features) * 0.01))
+        self.weights = nn.ParameterList(weights)
+        self.bnorms = nn.ModuleList(bnorms)
+        self.biases = nn.ParameterList(biases)
+
+    def draw_masks(self, device):
+        m = made_degrees_to_masks(self.in_out_chs, self.num_hidden, self.base_filters, np.random)
+        self.masks = [torch.from_numpy(a).to(device) for a in m]
+        return self.masks
+
+    def forward(self, z):
+        masks = self.draw_masks(z.device)
+        h = z
+        for i in range(self.num_hidden):
+            h = torch.relu(self.bnorms[i](F.linear(h, self.weights[i] * masks[i], self.biases[i])))
+        return F.linear(h, self.weights[-1] * masks[-1], self.biases[-1])
+
+
+class AutoregressiveTransfrom(nn.Module):
+    """masked autoregressive affine transform (the reference's spelling), flows/maf.py:88-119."""
+
+    def __init__(self, in_out_features, num_hidden=3, base_filters=32):
+        super().__init__()
+        self.in_out_chs = in_out_features
+        self.register_buffer('perm', torch.eye(in_out_features)[:, torch.randperm(in_out_features)])
+        self.net_s = MADE(in_out_features, num_hidden, base_filters)
+        self.net_t = MADE(in_out_features, num_hidden, base_filters)
+        self.s_log_scale = nn.Parameter(torch.randn(1) * 0.01)
+        self.s_bias = nn.Parameter(torch.randn(1) * 0.01)
+
+    def forward(self, z, log_df_dz):
+        z = torch.mm(z, self.perm)
+        s_raw = self.net_s(z)
+        t = self.net_t(z)
+        return NF.affine_transform(z, s_raw, t, self.s_log_scale, self.s_bias, log_df_dz)
+
+    def backward(self, z, log_df_dz):
+        """D sequential passes; unlike the reference (maf.py:114) the caller's tensor is NOT mutated (appendix D Q5)."""
+        z = z.clone()
+        for i in range(self.in_out_chs):
+            s_raw = self.net_s(z)
+            t = self.net_t(z)
+            ld_i = log_df_dz.clone()
+            cand, ld_all = NF.affine_transform(z, s_raw, t, self.s_log_scale, self.s_bias, ld_i, inverse=True)
+            # only column i is taken from this pass (maf.py:114-115)
+            s = torch.tanh(s_raw[:, i]) * self.s_log_scale + self.s_bias
+            z[:, i] = cand[:, i]
+            log_df_dz = log_df_dz - s
+        return torch.mm(z, self.perm.t()), log_df_dz

@@ -11,7 +11,8 @@ The multi-scale image recipe (shared by RealNVP / Glow / Flow++) is written once
 import torch
 import torch.nn as nn
 
-from .layers import (ActNorm, AffineCoupling, BatchNorm, Compose, InvertibleConv1x1, Logit, Squeeze2d, Unsqueeze2d)
+from .layers import (ActNorm, AffineCoupling, AutoregressiveTransfrom, BatchNorm, Compose, InvertibleConv1x1, Logit,
+                     MixLogAttnCoupling, Squeeze2d, Unsqueeze2d)
 
 
 class _FlowModel(nn.Module):
@@ -66,3 +67,27 @@ class RealNVP(_FlowModel):
 class Glow(_FlowModel):
     def _step(self, dims, masking, odd, cfg):
         return [ActNorm(dims), InvertibleConv1x1(dims[0]), AffineCoupling(dims, masking=masking, odd=odd)]
+
+
+class Flowpp(_FlowModel):
+    """flows/flowpp.py:9-78: image steps are ActNorm + inv-1x1 + mixture coupling, density steps have no inv-1x1."""
+
+    def _step(self, dims, masking, odd, cfg):
+        layers = [ActNorm(dims)]
+        if len(dims) == 3:
+            layers.append(InvertibleConv1x1(dims[0]))
+        layers.append(MixLogAttnCoupling(dims, masking=masking, odd=odd, n_mixtures=cfg.mixtures))
+        return layers
+
+
+class MAF(_FlowModel):
+    """flows/maf.py:122-148: [flow BatchNorm, autoregressive transform] x layers; density data only."""
+
+    def _build(self, dims, datatype, cfg):
+        if datatype == 'image':
+            raise NotImplementedError('Sorry, MAF for image generation is not supported!')   # reference forgets to raise
+        layers = []
+        for _ in range(self.n_layers):
+            layers.append(BatchNorm(dims, affine=False))
+            layers.append(AutoregressiveTransfrom(dims[0]))
+        return layers
