@@ -130,7 +130,9 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
     same workload and weights: full train step incl. Adam, bounded to ~`seconds` of CPU work."""
     from oracle import models as om
     from oracle import transforms as tf
-    cores = os.cpu_count() or 1
+    # the flow step is thousands of tiny ops: torch's intra-op pool stops scaling (and then collapses) beyond a few
+    # threads, so the baseline uses 8 (what the reference was probed with, BASELINE.md) -- `cores` reports what ran
+    cores = min(os.cpu_count() or 1, int(os.environ.get('NF_CPU_THREADS', '8')))
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in state.items()}
     ora = om.FlowOracle(cfg['kind'], cfg['dims'], cfg['datatype'], cfg['layers'], sd, mixtures=cfg['mixtures'],
@@ -145,7 +147,7 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
         loss = tf.nll_loss(z, ld)
         loss.backward()
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     step()                                                   # ActNorm init + warm caches
     t0 = time.perf_counter()

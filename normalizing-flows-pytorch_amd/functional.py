@@ -141,7 +141,7 @@ class _AffineCouplingPacked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, params, a, c, ld, mode, odd):
         B, C, H, W = _bchw(z)
-        n_half = params[0].numel() // 2
+        n_half = params.numel() // (2 * B) if B else 0
         y = torch.empty_like(z)
         N.call('nf_affine_coupling_fwd', N.ptr(z), N.ptr(params), params.data_ptr() + 4 * n_half, 2 * n_half, N.ptr(a),
                N.ptr(c), N.ptr(y), N.ptr(ld), mode, int(odd), 0, B, C, H, W, N.stream())
@@ -178,7 +178,7 @@ def affine_coupling(z, params, s_log_scale, s_bias, ld, mode, odd, inverse=False
         return _AffineCouplingPacked.apply(z, params, s_log_scale, s_bias, ld, mode, odd)
     with torch.no_grad():
         B, C, H, W = _bchw(z)
-        n_half = params[0].numel() // 2
+        n_half = params.numel() // (2 * B) if B else 0
         y = torch.empty_like(z)
         N.call('nf_affine_coupling_fwd', N.ptr(z), N.ptr(params), params.data_ptr() + 4 * n_half, 2 * n_half,
                N.ptr(s_log_scale), N.ptr(s_bias), N.ptr(y), N.ptr(ld), mode, int(odd), 1, B, C, H, W, N.stream())
@@ -189,7 +189,7 @@ def affine_transform(z, s_raw, t, s_log_scale, s_bias, ld, inverse=False):
     """un-split affine transform with separate scale / shift tensors (MAF: flows/maf.py:103-106, :114-115)."""
     z, s_raw, t = _contig(z), _contig(s_raw), _contig(t)
     ld = _owned_ld(ld)
-    pbs = s_raw[0].numel()
+    pbs = s_raw.numel() // s_raw.shape[0] if s_raw.shape[0] else 0
     if not inverse:
         return _AffineCoupling.apply(z, t, s_raw, pbs, s_log_scale, s_bias, ld, N.SPLIT_NONE, False)
     with torch.no_grad():
@@ -340,7 +340,7 @@ class _Logit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ld, eps):
         B = x.shape[0]
-        n = x[0].numel()
+        n = x.numel() // B if B else 1
         y = torch.empty_like(x)
         N.call('nf_logit_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), float(eps), 0, B, n, N.stream())
         ctx.save_for_backward(x)
@@ -353,7 +353,7 @@ class _Logit(torch.autograd.Function):
         (x, ) = ctx.saved_tensors
         g_y, g_ld = _contig(g_y), _contig(g_ld)
         g_x = torch.empty_like(x)
-        N.call('nf_logit_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(x), N.ptr(g_x), ctx.eps, x.shape[0], x[0].numel(),
+        N.call('nf_logit_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(x), N.ptr(g_x), ctx.eps, x.shape[0], x.numel() // max(x.shape[0], 1),
                N.stream())
         return g_x, g_ld, None
 
@@ -365,7 +365,7 @@ def logit(x, ld, eps, inverse=False):
         return _Logit.apply(x, ld, eps)
     with torch.no_grad():
         y = torch.empty_like(x)
-        N.call('nf_logit_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), float(eps), 1, x.shape[0], x[0].numel(), N.stream())
+        N.call('nf_logit_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), float(eps), 1, x.shape[0], x.numel() // max(x.shape[0], 1), N.stream())
     return y, ld
 
 

@@ -44,7 +44,13 @@ def test_model_golden(pkg, name):
         if 'grad/' + k in g:
             want = g['grad/' + k]
             assert p.grad is not None, k
-            G.assert_close(p.grad, want, 2 * TOL * max(1.0, float(want.abs().max())), what=k)
+            # pre-BatchNorm biases of MADE: analytically zero gradient, the stored value is cancellation noise
+            noise = kind == 'maf' and '.biases.' in k and not k.endswith('.biases.3')
+            # MADE runs on rocBLAS + MIOpen BatchNorm (train mode: gradients flow through the batch statistics, a
+            # cancellation-heavy formula) -- 1e-4 of the largest entry for its weights, 2e-5 for everything else
+            scale = max(1.0, float(want.abs().max()))
+            tol = 2e-3 if noise else (1e-4 if kind == 'maf' else 2 * TOL) * scale
+            G.assert_close(p.grad, want, tol, what=k)
             n += 1
     assert n > 4
     sd = net.state_dict()

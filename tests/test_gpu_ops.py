@@ -363,7 +363,10 @@ def test_ar_transform_golden(nf, D):
     for n, got in zip(names, grads[1:]):
         want = g['grad/' + n]
         got = torch.zeros_like(want) if got is None else got
-        G.assert_close(got, want, _scaled(want) * 2, what=n)
+        # a bias in front of a train-mode BatchNorm has an analytically ZERO gradient (the batch mean removes it):
+        # what the reference stores there is fp32 cancellation noise of size ~1e-7 * sum|g_h|, not a value to match
+        pre_bn_bias = '.biases.' in n and not n.endswith('.biases.3')
+        G.assert_close(got, want, 2e-3 if pre_bn_bias else _scaled(want) * 2, what=n)
     sd = layer.state_dict()
     for k, want in G.group('ops', 'ar/%d/sd_after/' % D).items():
         G.assert_close(sd[k].float(), want.float(), 2e-6, what=k)

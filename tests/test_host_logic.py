@@ -1,0 +1,112 @@
+"""
+Host-side logic of the product package that needs no GPU: constructors, state_dict contract, error behaviour,
+mask rule, synthetic data generators, PLU inverse assembly.  (Transforms themselves are GPU-only.)
+"""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+from oracle import nets as onets
+from tests import _golden as G
+
+
+@pytest.mark.parametrize('name', list(G.MODEL_CASES))
+def test_state_dict_contract_matches_reference_fixture(pkg, name):
+    """the golden sd0 IS a reference state_dict: same keys, shapes and dtypes must load strictly."""
+    kind, cls, dims, datatype, layers, mix = G.MODEL_CASES[name]
+    net = getattr(pkg, cls)(dims, datatype, NS(layers=layers, mixtures=mix))
+    sd0 = G.group('model_' + name, 'sd0/')
+    own = net.state_dict()
+    assert list(own.keys()) == list(sd0.keys())
+    for k in own:
+        assert tuple(own[k].shape) == tuple(sd0[k].shape) and own[k].dtype == sd0[k].dtype, k
+    net.load_state_dict(sd0, strict=True)
+    frozen = [k for k, p in net.named_parameters() if not p.requires_grad]
+    if kind == 'glow':
+        assert any(k.endswith('.pivots') for k in frozen) and any(k.endswith('.P') for k in frozen)
+
+
+def test_layer_plan_matches_oracle_plan(pkg):
+    for kind, cls, dims, dt, layers, mix in [('glow', 'Glow', (3, 32, 32), 'image', 2, None),
+                                             ('realnvp', 'RealNVP', (1, 16, 16), 'image', 1, None),
+                                             ('flowpp', 'Flowpp', (3, 16, 16), 'image', 1, 4),
+                                             ('maf', 'MAF', (4, ), None, 3, None), ('glow', 'Glow', (2, ), '2d', 5, None)]:
+        net = getattr(pkg, cls)(dims, dt, NS(layers=layers, mixtures=mix))
+        plan = om.build_plan(kind, dims, dt, layers, mix)
+        names = {'actnorm': 'ActNorm', 'invconv': 'InvertibleConv1x1', 'affine': 'AffineCoupling', 'flow_bn': 'BatchNorm',
+                 'logit': 'Logit', 'squeeze2d': 'Squeeze2d', 'unsqueeze2d': 'Unsqueeze2d', 'mixlog': 'MixLogAttnCoupling',
+                 'ar': 'AutoregressiveTransfrom'}
+        assert [type(m).__name__ for m in net.net.layers] == [names[L['op']] for L in plan]
+        for m, L in zip(net.net.layers, plan):
+            if 'odd' in L:
+                assert m.odd == L['odd'] and m.mode == L['mode']
+
+
+def test_glow_cifar_layer_count(pkg):
+    net = pkg.Glow((3, 32, 32), 'image', NS(layers=32))
+    assert len(net.net.layers) == 488
+    n_train = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    assert n_train == 8380754
+
+
+def test_errors(pkg):
+    with pytest.raises(Exception, match='unsupported combination'):
+        pkg.AffineCoupling((3, 4), masking='checkerboard')
+    with pytest.raises(Exception, match='even'):
+        pkg.AffineCoupling((3, ))
+    with pytest.raises(NotImplementedError):
+        pkg.MAF((3, 8, 8), 'image', NS(layers=1))
+
+
+def test_made_mask_rule_matches_oracle(pkg):
+    from importlib import import_module
+    cond = import_module(pkg.__name__ + '.conditioners')
+    for D in (2, 3, 5, 8):
+        a = cond.made_degrees_to_masks(D, 3, 32, np.random.RandomState(5))
+        b = onets.made_masks(D, 3, 32, np.random.RandomState(5))
+        assert all(np.array_equal(x, y.numpy()) for x, y in zip(a, b))
+    m = cond.made_degrees_to_masks(2, 3, 32, np.random.RandomState(0))
+    assert (m[0] == np.array([[1.0, 0.0]] * 32)).all() and m[1].all() and m[2].all()
+    assert (m[3][0] == 0).all() and (m[3][1] == 1).all()   # constant masks for D=2
+
+
+def test_invconv_inverse_weight_is_lu_solve(pkg):
+    torch.manual_seed(3)
+    for C in (2, 3, 12, 48):
+        layer = pkg.InvertibleConv1x1(C)
+        with torch.no_grad():
+            layer.L.add_(torch.randn(C, C) * 0.05)
+            layer.U.add_(torch.randn(C, C) * 0.05)
+        W = layer.weight()
+        Winv = layer.inverse_weight()
+        LU = layer.L * layer.L_mask + layer.U * layer.U_mask + torch.diag(layer.sign_s * torch.exp(layer.log_s))
+        ref = torch.linalg.lu_solve(LU, layer.pivots, torch.eye(C))
+        assert torch.allclose(Winv, ref, atol=2e-5)
+        assert torch.allclose(Winv @ W, torch.eye(C), atol=2e-5)
+
+
+def test_synthetic_data(pkg):
+    from importlib import import_module
+    data = import_module(pkg.__name__ + '.data')
+    for name in ('moons', 'circles', 'normals'):
+        a, b = data.sample(name, 4097, 7), data.sample(name, 4097, 7)
+        assert a.shape == (4097, 2) and a.dtype == torch.float32 and torch.equal(a, b)
+        assert not torch.equal(a, data.sample(name, 4097, 8))
+        assert float(a.abs().max()) < 2.0
+    r = np.linalg.norm(data.sample('circles', 20000, 1).numpy() / 0.6, axis=1)
+    assert abs(np.median(r[r > 0.75]) - 1.0) < 0.05 and abs(np.median(r[r < 0.75]) - 0.5) < 0.05
+    img = data.sample('cifar', 3, 0)
+    assert img.shape == (3, 3, 32, 32) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
+def test_trainer_loss_matches_reference_formula(pkg):
+    from importlib import import_module
+    train = import_module(pkg.__name__ + '.train')
+    z, ld = torch.randn(16, 3, 4, 4), torch.randn(16)
+    mvn = torch.distributions.MultivariateNormal(torch.zeros(48), torch.eye(48))
+    want = -1.0 * torch.mean(mvn.log_prob(z.view(16, -1)) + ld)                  # main.py:85
+    assert torch.allclose(train.nll_loss(z, ld), want, atol=1e-5)
+    assert abs(train.bits_per_dim(7.0 * 48 * np.log(2.0), (3, 4, 4)) - 7.0) < 1e-9
