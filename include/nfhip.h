@@ -141,6 +141,103 @@ int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, 
                            float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
                            int C, int H, int W, nf_stream_t stream);
 
+/* ---- fused masked / weight-normed linear + BatchNorm1d + ReLU chain on fp32 MFMA --------------------------------------
+ * The building block of MADE (flows/maf.py:49-64: F.linear(z, W*M, b) -> BatchNorm1d -> relu) and of the MLP
+ * conditioner (flows/modules.py:342-413: BatchNorm1d -> ReLU -> WeightNorm(Linear), residual adds).  One launch =
+ * one linear layer of up to NF_MAX_NETS independent nets (MAF's s-net and t-net share a launch):
+ *
+ *     act[n,i] = in[n,i]                                      (no input BatchNorm)
+ *              = relu( (in[n,i] - mean_i) * invstd_i * gamma_i + beta_i )   ("normalise on load")
+ *     out[n,o] = sum_i act[n,i] * Weff[o,i] + bias[o] (+ residual[n,o])
+ *     Weff     = weight * mask                                (MADE: "mask baked into the tile loader")
+ *              = weight * weight_g / (||weight||_dim0 + wn_eps)   (flows/weight_norm.py:35-41)
+ *     stat_sum[o] += sum_n (out - bias[o]),  stat_sqsum[o] += sum_n (out - bias[o])^2     ("statistics on store")
+ *
+ * training != 0: mean/var of `in` come from bn_sum/bn_sqsum/bn_center (what the producing launch stored; biased
+ * variance, eps added under the root like nn.BatchNorm1d), block 0 updates running_mean / running_var (unbiased,
+ * momentum) / num_batches_tracked and writes save_mean / save_invstd for the backward pass.
+ * training == 0: running statistics are used.   Limits: I, O <= 32 (every reference conditioner is 32 wide).
+ * The GEMM runs on v_mfma_f32_32x32x2_f32 (exact fp32, 32 rows x 32 outputs per wave per 16 issues).            */
+#define NF_MAX_NETS 2
+typedef struct nf_linear_desc {
+    const float* in;          /* (N, I) */
+    const float* weight;      /* (O, I) */
+    const float* weight_g;    /* (I,)  weight-norm gain, or NULL */
+    const float* mask;        /* (O, I) MADE mask, or NULL */
+    const float* bias;        /* (O,) */
+    const float* residual;    /* (N, O) or NULL */
+    float* out;               /* (N, O) */
+    const float* bn_gamma;    /* (I,) input BatchNorm affine; NULL = no input BatchNorm/ReLU */
+    const float* bn_beta;
+    const float* bn_sum;      /* (I,) training: sum_n (in - bn_center) */
+    const float* bn_sqsum;    /* (I,) training: sum_n (in - bn_center)^2 */
+    const float* bn_center;   /* (I,) */
+    float* bn_running_mean;   /* (I,) */
+    float* bn_running_var;    /* (I,) */
+    int64_t* bn_num_batches;  /* scalar or NULL */
+    float* bn_save_mean;      /* (I,) training: written */
+    float* bn_save_invstd;    /* (I,) training: written */
+    float* stat_sum;          /* (O,) or NULL */
+    float* stat_sqsum;        /* (O,) or NULL */
+} nf_linear_desc;
+int nf_linear_bn_fwd(const nf_linear_desc* descs, int n_nets, int64_t N, int I, int O, int training, float bn_eps,
+                     float bn_momentum, float wn_eps, nf_stream_t stream);
+
+/* autograd of nf_linear_bn_fwd in training mode.  The gradient G of `out` is assembled on load:
+ *     G[n,o] = g_direct[n,o] + g_skip[n,o] + BNbwd(gn_src)[n,o]
+ *     BNbwd(gn)[n,o] = cbn_gamma_o * cbn_invstd_o * ( gn - cbn_sum_g_o / N - xhat * cbn_sum_gx_o / N ),
+ *     xhat = (out[n,o] - cbn_mean_o) * cbn_invstd_o         (the BatchNorm that CONSUMED `out`; batch statistics
+ *                                                            carry gradient)
+ * (each term optional: NULL pointer = absent).  Results:
+ *     g_store[n,o] = G                    (optional; needed where `out` also feeds a residual connection)
+ *     g_bias[o]   += sum_n G ;  g_weff[o,i] += sum_n G[n,o] act[n,i]      (gradient wrt the EFFECTIVE weight)
+ *     gn_out[n,i]  = (sum_o G[n,o] Weff[o,i]) * [act[n,i] > 0]   and  sum_g[i] += sum_n gn_out,
+ *     sum_gx[i]   += sum_n gn_out * xhat_in      (== g_beta, g_gamma of the input BatchNorm; the producer of `in`
+ *                                                 finishes the BatchNorm backward on load)
+ *     without input BatchNorm: gn_out = G Weff is the gradient of `in` itself.                                    */
+typedef struct nf_linear_bwd_desc {
+    const float* in;            /* (N, I) forward input */
+    const float* weight;        /* (O, I) */
+    const float* weight_g;      /* (I,) or NULL */
+    const float* mask;          /* (O, I) or NULL */
+    const float* bn_gamma;      /* (I,) input BatchNorm (NULL = none) */
+    const float* bn_beta;
+    const float* bn_save_mean;
+    const float* bn_save_invstd;
+    const float* g_direct;      /* (N, O) or NULL */
+    const float* g_skip;        /* (N, O) or NULL */
+    const float* gn_src;        /* (N, O) or NULL */
+    const float* out;           /* (N, O) forward output (needed with gn_src) */
+    const float* cbn_gamma;     /* (O,) consumer BatchNorm */
+    const float* cbn_save_mean;
+    const float* cbn_save_invstd;
+    const float* cbn_sum_g;     /* (O,) */
+    const float* cbn_sum_gx;    /* (O,) */
+    float* g_store;             /* (N, O) or NULL */
+    float* g_bias;              /* (O,) += */
+    float* g_weff;              /* (O, I) += */
+    float* gn_out;              /* (N, I) or NULL */
+    float* sum_g;               /* (I,) += (with input BatchNorm) */
+    float* sum_gx;              /* (I,) += */
+} nf_linear_bwd_desc;
+int nf_linear_bn_bwd(const nf_linear_bwd_desc* descs, int n_nets, int64_t N, int I, int O, float wn_eps,
+                     nf_stream_t stream);
+
+/* gradient of the effective weight -> gradients of the stored parameters, n_layers layers per launch:
+ *   mask != NULL    : g_weight = g_weff * mask                                         (maf.py:54)
+ *   weight_g != NULL: weight-norm backward, g_weight (= g_v) and g_weight_g             (weight_norm.py:35-41)  */
+typedef struct nf_weight_grad_desc {
+    const float* g_weff;    /* (O, I) */
+    const float* weight;    /* (O, I) */
+    const float* weight_g;  /* (I,) or NULL */
+    const float* mask;      /* (O, I) or NULL */
+    float* g_weight;        /* (O, I) written */
+    float* g_weight_g;      /* (I,) written, or NULL */
+    int I;
+    int O;
+} nf_weight_grad_desc;
+int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, float wn_eps, nf_stream_t stream);
+
 /* ---- NLL of the training harness  main.py:49-51, :85 -------------------------------------------------------------
  * loss[0] += -(1/B) * sum_b ( -0.5*|z_b|^2 - 0.5*D*log(2 pi) + ld[b] );  g_z = z / B,  (g_ld = -1/B is constant) */
 int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream);

@@ -42,9 +42,12 @@ def header_prototypes(path=HEADER):
                 a = ' '.join(a.split())
                 ty = a.rsplit(' ', 1)[0] if not a.endswith('*') else a
                 ty = ty.replace(' *', '*')
-                if ty not in _CTYPES:
+                if ty.endswith('*'):
+                    types.append(_P)
+                elif ty in _CTYPES:
+                    types.append(_CTYPES[ty])
+                else:
                     raise NativeLibraryError('unknown C type %r in prototype of %s' % (ty, name))
-                types.append(_CTYPES[ty])
         protos[name] = types
     return protos
 

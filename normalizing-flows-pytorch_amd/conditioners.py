@@ -84,9 +84,17 @@ class MLP(nn.Module):
                                          for _ in range(n_blocks)])
         self.out_block = nn.Sequential(nn.BatchNorm1d(base_filters), nn.ReLU(inplace=True),
                                        _wn(nn.Linear(base_filters, out_channels), weight_norm))
+        self.fused = bool(weight_norm) and base_filters == 32 and in_channels <= 32 and out_channels <= 32
+
+    def forward_reference(self, x):
+        """module-by-module PyTorch path (rocBLAS + MIOpen); used off-GPU and as the parity reference of the fused one."""
+        return self.out_block(self.mid_block(self.in_block(x)))
 
     def forward(self, x):
-        return self.out_block(self.mid_block(self.in_block(x)))
+        if self.fused and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+            from .fused import mlp_forward          # fp32-MFMA linear + BatchNorm kernels: 6 launches
+            return mlp_forward(self, x)
+        return self.forward_reference(x)
 
 
 class ConvNet(nn.Module):

@@ -1,0 +1,417 @@
+// Fused (masked | weight-normed) linear + BatchNorm1d + ReLU chain on fp32 MFMA -- the conditioner building block.
+//   MADE            : flows/maf.py:49-64     F.linear(z, W*M, b) -> BatchNorm1d -> relu      (mask baked into the tile loader)
+//   MLP conditioner : flows/modules.py:342-413, flows/weight_norm.py:35-41   BN -> ReLU -> WeightNorm(Linear) (+ residual)
+// One launch = one linear layer for up to NF_MAX_NETS independent nets.  "Normalise on load, statistics on store":
+// the BatchNorm that precedes a linear is folded into its operand load, the batch statistics the NEXT BatchNorm needs
+// are accumulated in the epilogue, so a BN-MLP costs one launch per linear instead of ~10 framework kernels.
+//
+// GEMM shape: rows (samples) x 32 outputs x <=32 inputs, fp32 exact -> v_mfma_f32_32x32x2_f32, one 32x32 tile per wave
+// per 16 issues (157 TF peak class, 1e-5 parity rules out bf16).  K is walked in the permuted order
+// k = half*KH + kk (half = lane>>5) so that a lane's A fragment is CONTIGUOUS in memory (one 64-byte run per row-half).
+// At the sizes of the reference models these launches are latency-bound (a 4096 x 32 x 32 layer is 8 MFLOP); the win
+// is the launch count and the removed HBM round trips of the intermediate tensors.
+#include "nf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct NfLinArgs { nf_linear_desc d[NF_MAX_NETS]; };
+struct NfLinBwdArgs { nf_linear_bwd_desc d[NF_MAX_NETS]; };
+#define NF_MAX_WG_LAYERS 16
+struct NfWGradArgs { nf_weight_grad_desc d[NF_MAX_WG_LAYERS]; };
+
+#define NF_LB_WAVES 4
+#define NF_TS 33  // padded row stride (words) of the 32x32 LDS tiles: column walks are conflict-free
+
+__device__ __forceinline__ float nf_half32_sum(float v) {  // sum over the 32 lanes of this wave half
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, NF_WAVE);
+    return v;
+}
+
+// row index of accumulator register r in the 32x32 C/D layout (col = lane & 31)
+__device__ __forceinline__ int nf_cd_row(int r, int hs) { return (r & 3) + 8 * (r >> 2) + 4 * hs; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int KH>
+__global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinArgs args, int64_t N, int I, int O,
+                                                                         int training, float eps, float mom,
+                                                                         float wn_eps, int64_t tiles) {
+    __shared__ float red[2][NF_LB_WAVES][32];
+    const nf_linear_desc& d = args.d[blockIdx.y];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, o = lane & 31, hs = lane >> 5;
+    const bool has_bn = d.bn_gamma != nullptr;
+    const float invN = 1.f / (float)N;
+
+    // ---- B fragment: effective weight Weff[o][k], k = hs*KH + kk  (mask / weight-norm applied while loading) ----
+    float b[KH], sc[KH], sh[KH];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+        const int k = hs * KH + kk;
+        const bool ok = (o < O) && (k < I);
+        float w = ok ? d.weight[o * I + k] : 0.f;
+        if (ok && d.mask != nullptr) w *= d.mask[o * I + k];                       // maf.py:54
+        b[kk] = w;
+    }
+    if (d.weight_g != nullptr) {                                                   // weight_norm.py:40
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            const int k = hs * KH + kk;
+            const float nrm = sqrtf(nf_half32_sum(b[kk] * b[kk]));                 // ||v||_dim0 of input column k
+            const float gk = (k < I) ? d.weight_g[k] : 0.f;
+            b[kk] = b[kk] * (gk / (nrm + wn_eps));
+        }
+    }
+    // ---- input BatchNorm folded into scale / shift per input feature ----
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+        const int k = hs * KH + kk;
+        sc[kk] = has_bn ? 0.f : 1.f;
+        sh[kk] = 0.f;
+        if (has_bn && k < I) {
+            float mean, invstd;
+            if (training) {
+                const float m1 = d.bn_sum[k] * invN;
+                mean = d.bn_center[k] + m1;
+                const float var = fmaxf(d.bn_sqsum[k] * invN - m1 * m1, 0.f);      // biased, as BatchNorm normalises
+                invstd = 1.f / sqrtf(var + eps);
+                if (blockIdx.x == 0 && wid == 0 && o == 0) {                       // bookkeeping, once per feature
+                    d.bn_running_mean[k] = (1.f - mom) * d.bn_running_mean[k] + mom * mean;
+                    const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+                    d.bn_running_var[k] = (1.f - mom) * d.bn_running_var[k] + mom * unb;
+                    d.bn_save_mean[k] = mean;
+                    d.bn_save_invstd[k] = invstd;
+                }
+            } else {
+                mean = d.bn_running_mean[k];
+                invstd = 1.f / sqrtf(d.bn_running_var[k] + eps);
+                if (blockIdx.x == 0 && wid == 0 && o == 0 && d.bn_save_mean != nullptr) {
+                    d.bn_save_mean[k] = mean;              // evaluation-mode backward treats them as constants
+                    d.bn_save_invstd[k] = invstd;
+                }
+            }
+            sc[kk] = d.bn_gamma[k] * invstd;
+            sh[kk] = d.bn_beta[k] - mean * sc[kk];
+        }
+    }
+    if (training && has_bn && d.bn_num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        d.bn_num_batches[0] += 1;
+
+    const float bias_o = (o < O) ? d.bias[o] : 0.f;
+    const bool want_stats = d.stat_sum != nullptr;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t tile = (int64_t)blockIdx.x * NF_LB_WAVES + wid; tile < tiles; tile += (int64_t)gridDim.x * NF_LB_WAVES) {
+        const int64_t row0 = tile * 32;
+        const int64_t row = row0 + o;                     // A fragment row of this lane (o doubles as row-in-tile)
+        const bool rv = row < N;
+        float a[KH];
+        if (KH == 16 && I == 32) {
+            const float4* p = reinterpret_cast<const float4*>(d.in + row * 32 + hs * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = rv ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+                const int k = hs * KH + kk;
+                a[kk] = (rv && k < I) ? d.in[row * I + k] : 0.f;
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            const float av = has_bn ? fmaxf(fmaf(a[kk], sc[kk], sh[kk]), 0.f) : a[kk];   // BN -> ReLU on load
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk], acc, 0, 0, 0);
+        }
+        if (o < O) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gr = row0 + nf_cd_row(r, hs);
+                if (gr < N) {
+                    float dv = acc[r];
+                    if (d.residual != nullptr) dv += d.residual[gr * O + o];
+                    d.out[gr * O + o] = dv + bias_o;
+                    s1 += dv;                                 // statistics centred at the bias (shifted sums)
+                    s2 = fmaf(dv, dv, s2);
+                }
+            }
+        }
+    }
+    if (want_stats) {                                         // block-uniform branch
+        s1 += __shfl_xor(s1, 32, NF_WAVE);
+        s2 += __shfl_xor(s2, 32, NF_WAVE);
+        if (hs == 0) { red[0][wid][o] = s1; red[1][wid][o] = s2; }
+        __syncthreads();
+        if (wid == 0 && hs == 0 && o < O) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NF_LB_WAVES; ++w) { t1 += red[0][w][o]; t2 += red[1][w][o]; }
+            atomicAdd(d.stat_sum + o, t1);
+            atomicAdd(d.stat_sqsum + o, t2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward (training mode)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBwdArgs args, int64_t N, int I, int O,
+                                                                         float wn_eps, int64_t tiles, int iters) {
+    // per wave: G tile and raw-input tile (32 x 32, padded); afterwards reused for the cross-wave reduction of g_weff
+    __shared__ float lds[NF_LB_WAVES * 2 * 32 * NF_TS];
+    __shared__ float cbn[5][32];     // consumer BatchNorm constants per output feature
+    __shared__ float red[3][NF_LB_WAVES][32];
+    const nf_linear_bwd_desc& d = args.d[blockIdx.y];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    float* Gt = lds + wid * 2 * 32 * NF_TS;
+    float* It = Gt + 32 * NF_TS;
+    const bool has_bn = d.bn_gamma != nullptr;
+    const bool has_src = d.gn_src != nullptr;
+    const float invN = 1.f / (float)N;
+
+    if (threadIdx.x < 32) {
+        const int oo = threadIdx.x;
+        float c1 = 0.f, mean = 0.f, invstd = 0.f, mg = 0.f, mgx = 0.f;
+        if (has_src && oo < O) {
+            invstd = d.cbn_save_invstd[oo];
+            mean = d.cbn_save_mean[oo];
+            c1 = d.cbn_gamma[oo] * invstd;
+            if (d.cbn_sum_g != nullptr) { mg = d.cbn_sum_g[oo] * invN; mgx = d.cbn_sum_gx[oo] * invN; }
+        }
+        cbn[0][oo] = c1; cbn[1][oo] = mean; cbn[2][oo] = invstd; cbn[3][oo] = mg; cbn[4][oo] = mgx;
+    }
+    // B fragment of the data-gradient GEMM: Weff[o = hs*16+kk][i = c32]
+    float bW[16];
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int oo = hs * 16 + kk;
+            const bool ok = (oo < O) && (c32 < I);
+            float w = ok ? d.weight[oo * I + c32] : 0.f;
+            if (ok && d.mask != nullptr) w *= d.mask[oo * I + c32];
+            bW[kk] = w;
+            ss = fmaf(w, w, ss);
+        }
+        if (d.weight_g != nullptr) {
+            ss += __shfl_xor(ss, 32, NF_WAVE);                    // full column norm over o
+            const float s_i = (c32 < I) ? d.weight_g[c32] / (sqrtf(ss) + wn_eps) : 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) bW[kk] *= s_i;
+        }
+    }
+    // input-side BatchNorm constants of column i = c32
+    float mean_i = 0.f, invstd_i = 0.f, sc_i = 1.f, sh_i = 0.f;
+    if (has_bn && c32 < I) {
+        mean_i = d.bn_save_mean[c32];
+        invstd_i = d.bn_save_invstd[c32];
+        sc_i = d.bn_gamma[c32] * invstd_i;
+        sh_i = d.bn_beta[c32] - mean_i * sc_i;
+    }
+    __syncthreads();
+
+    f32x16 accW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[r] = 0.f;
+    float gb = 0.f, sg = 0.f, sgx = 0.f;
+
+    for (int it = 0; it < iters; ++it) {
+        const int64_t tile = ((int64_t)it * gridDim.x + blockIdx.x) * NF_LB_WAVES + wid;
+        const bool active = tile < tiles;                         // wave-uniform
+        const int64_t row0 = tile * 32;
+        float a1[16];
+        if (active) {
+            // ---- assemble G[row][o] for o = hs*16 + kk (row = c32), stash it in LDS, keep it as the A fragment ----
+            const int64_t row = row0 + c32;
+            const bool rv = row < N;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int oo = hs * 16 + kk;
+                float g = 0.f;
+                if (rv && oo < O) {
+                    const int64_t idx = row * O + oo;
+                    if (d.g_direct != nullptr) g += d.g_direct[idx];
+                    if (d.g_skip != nullptr) g += d.g_skip[idx];
+                    if (has_src) {
+                        const float xh = (d.out[idx] - cbn[1][oo]) * cbn[2][oo];
+                        g += cbn[0][oo] * (d.gn_src[idx] - cbn[3][oo] - xh * cbn[4][oo]);   // BatchNorm backward on load
+                    }
+                    if (d.g_store != nullptr) d.g_store[idx] = g;
+                }
+                a1[kk] = g;
+                Gt[c32 * NF_TS + oo] = g;
+            }
+            // ---- raw input tile, coalesced ----
+            for (int idx = lane; idx < 32 * I; idx += NF_WAVE) {
+                const int rr = idx / I, cc = idx - rr * I;
+                It[rr * NF_TS + cc] = (row0 + rr < N) ? d.in[(row0 + rr) * I + cc] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // ---- data gradient: (G Weff)[row][i] -> ReLU mask -> pre-BatchNorm gradient + its two batch sums ----
+            f32x16 acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], bW[kk], acc1, 0, 0, 0);
+            if (d.gn_out != nullptr && c32 < I) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = nf_cd_row(r, hs);
+                    const int64_t gr = row0 + rr;
+                    if (gr < N) {
+                        float gn = acc1[r];
+                        if (has_bn) {
+                            const float xin = It[rr * NF_TS + c32];
+                            gn = (fmaf(xin, sc_i, sh_i) > 0.f) ? gn : 0.f;
+                            sg += gn;
+                            sgx = fmaf(gn, (xin - mean_i) * invstd_i, sgx);
+                        }
+                        d.gn_out[gr * I + c32] = gn;
+                    }
+                }
+            }
+            // ---- weight gradient: g_weff[o][i] += sum_n G[n][o] act[n][i]  (A = G^T, B = act, K = the tile's 32 rows) ----
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int n = hs * 16 + kk;
+                const float ga = Gt[n * NF_TS + c32];             // G[n][o = c32]
+                const float xin = It[n * NF_TS + c32];            // in[n][i = c32]
+                const float act = has_bn ? fmaxf(fmaf(xin, sc_i, sh_i), 0.f) : xin;
+                gb += ga;
+                accW = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, act, accW, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- block reductions, then one atomic per entry per block ----
+    gb += __shfl_xor(gb, 32, NF_WAVE);
+    sg += __shfl_xor(sg, 32, NF_WAVE);
+    sgx += __shfl_xor(sgx, 32, NF_WAVE);
+    if (hs == 0) { red[0][wid][c32] = gb; red[1][wid][c32] = sg; red[2][wid][c32] = sgx; }
+    float* Wred = lds;                                            // [wave][32][32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Wred[(wid * 32 + nf_cd_row(r, hs)) * 32 + c32] = accW[r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
+        const int oo = e >> 5, ii = e & 31;
+        if (oo < O && ii < I) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NF_LB_WAVES; ++w) t += Wred[(w * 32 + oo) * 32 + ii];
+            atomicAdd(d.g_weff + oo * I + ii, t);
+        }
+    }
+    if (wid == 0 && hs == 0) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NF_LB_WAVES; ++w) { t0 += red[0][w][c32]; t1 += red[1][w][c32]; t2 += red[2][w][c32]; }
+        if (c32 < O && d.g_bias != nullptr) atomicAdd(d.g_bias + c32, t0);
+        if (has_bn && c32 < I && d.sum_g != nullptr) {
+            atomicAdd(d.sum_g + c32, t1);
+            atomicAdd(d.sum_gx + c32, t2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// g_weff -> gradients of the stored parameters (mask / weight-norm), one block per layer
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NF_BLOCK) k_weight_grad_finalize(NfWGradArgs args, float wn_eps) {
+    __shared__ float nrm2[32], dot[32];
+    const nf_weight_grad_desc& d = args.d[blockIdx.x];
+    const int I = d.I, O = d.O;
+    if (d.weight_g != nullptr) {
+        if (threadIdx.x < 32) {
+            const int i = threadIdx.x;
+            float a = 0.f, b = 0.f;
+            if (i < I)
+                for (int o = 0; o < O; ++o) {
+                    const float v = d.weight[o * I + i];
+                    a = fmaf(v, v, a);
+                    b = fmaf(d.g_weff[o * I + i], v, b);
+                }
+            nrm2[i] = a;
+            dot[i] = b;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < O * I; e += blockDim.x) {
+            const int i = e % I;
+            const float nrm = sqrtf(nrm2[i]), den = nrm + wn_eps, g = d.weight_g[i];
+            float gv = d.g_weff[e] * (g / den);
+            if (nrm > 0.f) gv -= d.weight[e] * (dot[i] * g / (den * den * nrm));
+            d.g_weight[e] = gv;
+        }
+        if (d.g_weight_g != nullptr && threadIdx.x < I) {
+            const int i = threadIdx.x;
+            d.g_weight_g[i] = dot[i] / (sqrtf(nrm2[i]) + wn_eps);
+        }
+    } else {
+        for (int e = threadIdx.x; e < O * I; e += blockDim.x)
+            d.g_weight[e] = d.mask != nullptr ? d.g_weff[e] * d.mask[e] : d.g_weff[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static inline unsigned nf_lb_grid(int64_t tiles) {
+    int64_t g = (tiles + NF_LB_WAVES - 1) / NF_LB_WAVES;
+    if (g < 1) g = 1;
+    if (g > 1024) g = 1024;
+    return (unsigned)g;
+}
+
+extern "C" int nf_linear_bn_fwd(const nf_linear_desc* descs, int n_nets, int64_t N, int I, int O, int training,
+                                float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream) {
+    if (descs == nullptr || n_nets < 1 || n_nets > NF_MAX_NETS || I < 1 || O < 1 || I > 32 || O > 32) return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfLinArgs args;
+    for (int i = 0; i < n_nets; ++i) args.d[i] = descs[i];
+    const int64_t tiles = (N + 31) / 32;
+    const dim3 grid(nf_lb_grid(tiles), (unsigned)n_nets), block(NF_LB_WAVES * NF_WAVE);
+    hipStream_t st = (hipStream_t)stream;
+    const int kh = (I + 1) / 2;
+#define NF_LAUNCH(KH) hipLaunchKernelGGL(k_linear_bn_fwd<KH>, grid, block, 0, st, args, N, I, O, training, bn_eps, bn_momentum, wn_eps, tiles)
+    if (kh <= 1) NF_LAUNCH(1);
+    else if (kh <= 2) NF_LAUNCH(2);
+    else if (kh <= 4) NF_LAUNCH(4);
+    else if (kh <= 8) NF_LAUNCH(8);
+    else NF_LAUNCH(16);
+#undef NF_LAUNCH
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_linear_bn_bwd(const nf_linear_bwd_desc* descs, int n_nets, int64_t N, int I, int O, float wn_eps,
+                                nf_stream_t stream) {
+    if (descs == nullptr || n_nets < 1 || n_nets > NF_MAX_NETS || I < 1 || O < 1 || I > 32 || O > 32) return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfLinBwdArgs args;
+    for (int i = 0; i < n_nets; ++i) args.d[i] = descs[i];
+    const int64_t tiles = (N + 31) / 32;
+    const unsigned gx = nf_lb_grid(tiles);
+    const int iters = (int)((tiles + (int64_t)gx * NF_LB_WAVES - 1) / ((int64_t)gx * NF_LB_WAVES));
+    hipLaunchKernelGGL(k_linear_bn_bwd, dim3(gx, (unsigned)n_nets), dim3(NF_LB_WAVES * NF_WAVE), 0, (hipStream_t)stream,
+                       args, N, I, O, wn_eps, tiles, iters);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, float wn_eps,
+                                       nf_stream_t stream) {
+    if (descs == nullptr || n_layers < 1 || n_layers > NF_MAX_WG_LAYERS) return NF_E_BADARG;
+    NfWGradArgs args;
+    for (int i = 0; i < n_layers; ++i) {
+        if (descs[i].I < 1 || descs[i].O < 1 || descs[i].I > 32 || descs[i].O > 32) return NF_E_BADARG;
+        args.d[i] = descs[i];
+    }
+    hipLaunchKernelGGL(k_weight_grad_finalize, dim3((unsigned)n_layers), dim3(NF_BLOCK), 0, (hipStream_t)stream, args,
+                       wn_eps);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

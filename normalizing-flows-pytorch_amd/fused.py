@@ -1,0 +1,314 @@
+"""
+Fused conditioner networks on the fp32-MFMA linear + BatchNorm kernels (csrc/linear_bn.hip, C ABI
+``nf_linear_bn_fwd / nf_linear_bn_bwd / nf_weight_grad_finalize``):
+
+  * ``mlp_forward``  -- the MLP conditioner of AffineCoupling (flows/modules.py:393-413): 6 launches forward,
+                        6 + 1 backward, instead of ~60 / ~150 framework kernels;
+  * ``made_forward`` -- MAF's pair of MADE nets (flows/maf.py:49-64, :103-104), s-net and t-net in the SAME launches:
+                        4 forward, 4 + 1 backward.
+
+Both are exact restatements of the module math in training mode (batch statistics, gradients through the
+statistics, running-statistics bookkeeping) and in evaluation mode (running statistics).
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+
+BN_EPS, BN_MOMENTUM, WN_EPS = 1.0e-5, 0.1, 1.0e-5
+H = 32  # hidden width of every reference conditioner (base_filters=32)
+
+_LIN_FIELDS = ['in_', 'weight', 'weight_g', 'mask', 'bias', 'residual', 'out', 'bn_gamma', 'bn_beta', 'bn_sum', 'bn_sqsum',
+               'bn_center', 'bn_running_mean', 'bn_running_var', 'bn_num_batches', 'bn_save_mean', 'bn_save_invstd',
+               'stat_sum', 'stat_sqsum']
+_BWD_FIELDS = ['in_', 'weight', 'weight_g', 'mask', 'bn_gamma', 'bn_beta', 'bn_save_mean', 'bn_save_invstd', 'g_direct',
+               'g_skip', 'gn_src', 'out', 'cbn_gamma', 'cbn_save_mean', 'cbn_save_invstd', 'cbn_sum_g', 'cbn_sum_gx',
+               'g_store', 'g_bias', 'g_weff', 'gn_out', 'sum_g', 'sum_gx']
+_WG_FIELDS = ['g_weff', 'weight', 'weight_g', 'mask', 'g_weight', 'g_weight_g']
+
+
+class LinearDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in _LIN_FIELDS]
+
+
+class LinearBwdDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in _BWD_FIELDS]
+
+
+class WeightGradDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in _WG_FIELDS] + [('I', ctypes.c_int), ('O', ctypes.c_int)]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _desc(cls, **kw):
+    d = cls()
+    for k, v in kw.items():
+        setattr(d, k, _p(v) if isinstance(v, torch.Tensor) or v is None else v)
+    return d
+
+
+def _launch_fwd(descs, Nrows, I, O, training):
+    arr = (LinearDesc * len(descs))(*descs)
+    N.call('nf_linear_bn_fwd', ctypes.addressof(arr), len(descs), Nrows, I, O, int(training), BN_EPS, BN_MOMENTUM, WN_EPS,
+           N.stream())
+
+
+def _launch_bwd(descs, Nrows, I, O):
+    arr = (LinearBwdDesc * len(descs))(*descs)
+    N.call('nf_linear_bn_bwd', ctypes.addressof(arr), len(descs), Nrows, I, O, WN_EPS, N.stream())
+
+
+def _launch_wgrad(descs):
+    arr = (WeightGradDesc * len(descs))(*descs)
+    N.call('nf_weight_grad_finalize', ctypes.addressof(arr), len(descs), WN_EPS, N.stream())
+
+
+def fusable(*dims):
+    return all(1 <= d <= 32 for d in dims)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# MLP conditioner
+# ----------------------------------------------------------------------------------------------------------------------
+class _FusedMLP(torch.autograd.Function):
+    """x -> WN0 -> [BN,ReLU,WN, BN,ReLU,WN, +skip] * n_blocks -> BN,ReLU,WN_out.
+
+    tensors: per linear (v, g, bias) * (2*n_blocks + 2), then per BatchNorm (gamma, beta, running_mean, running_var,
+    num_batches_tracked) * (2*n_blocks + 1)."""
+
+    @staticmethod
+    def forward(ctx, x, training, n_blocks, *tensors):
+        nl, nb = 2 * n_blocks + 2, 2 * n_blocks + 1
+        lin = [tensors[3 * i:3 * i + 3] for i in range(nl)]
+        bns = [tensors[3 * nl + 5 * i:3 * nl + 5 * i + 5] for i in range(nb)]
+        x = x.contiguous()
+        Nrows, I0 = x.shape
+        O_out = lin[-1][0].shape[0]
+        dev = x.device
+        ws = torch.zeros(nb, 4, H, dtype=torch.float32, device=dev)          # [sum, sqsum, save_mean, save_invstd]
+        acts = [torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nb)]
+        out = torch.empty(Nrows, O_out, dtype=torch.float32, device=dev)
+
+        def bn_kw(j):
+            g, b, rm, rv, nbt = bns[j]
+            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[j, 0], bn_sqsum=ws[j, 1], bn_center=lin[j][2], bn_running_mean=rm,
+                        bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[j, 2], bn_save_invstd=ws[j, 3])
+
+        # K0
+        _launch_fwd([_desc(LinearDesc, in_=x, weight=lin[0][0], weight_g=lin[0][1], bias=lin[0][2], out=acts[0],
+                           stat_sum=ws[0, 0], stat_sqsum=ws[0, 1])], Nrows, I0, H, training)
+        for j in range(1, nb):                    # linear j consumes acts[j-1] through BatchNorm j-1
+            res = acts[j - 2] if j % 2 == 0 else None      # second linear of a residual block adds the block input
+            _launch_fwd([_desc(LinearDesc, in_=acts[j - 1], weight=lin[j][0], weight_g=lin[j][1], bias=lin[j][2],
+                               residual=res, out=acts[j], stat_sum=ws[j, 0], stat_sqsum=ws[j, 1], **bn_kw(j - 1))],
+                        Nrows, H, H, training)
+        _launch_fwd([_desc(LinearDesc, in_=acts[nb - 1], weight=lin[nl - 1][0], weight_g=lin[nl - 1][1],
+                           bias=lin[nl - 1][2], out=out, **bn_kw(nb - 1))], Nrows, H, O_out, training)
+        ctx.save_for_backward(x, ws, *acts, *[t for l in lin for t in l[:2]], *[t for b in bns for t in b[:2]])
+        ctx.meta = (n_blocks, Nrows, I0, O_out, bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        n_blocks, Nrows, I0, O_out, training = ctx.meta
+        nl, nb = 2 * n_blocks + 2, 2 * n_blocks + 1
+        saved = ctx.saved_tensors
+        x, ws = saved[0], saved[1]
+        acts = saved[2:2 + nb]
+        vg = saved[2 + nb:2 + nb + 2 * nl]
+        gb = saved[2 + nb + 2 * nl:]
+        V = [vg[2 * i] for i in range(nl)]
+        G = [vg[2 * i + 1] for i in range(nl)]
+        gamma = [gb[2 * i] for i in range(nb)]
+        beta = [gb[2 * i + 1] for i in range(nb)]
+        dev = x.device
+        g_out = g_out.contiguous()
+        # zero-initialised accumulators: g_weff / g_bias per linear, (sum_g, sum_gx) per BatchNorm
+        sizes = [V[i].numel() for i in range(nl)]
+        acc = torch.zeros(sum(sizes) + nl * H + nb * 2 * H, dtype=torch.float32, device=dev)
+        o = 0
+        g_weff = []
+        for i in range(nl):
+            g_weff.append(acc[o:o + sizes[i]])
+            o += sizes[i]
+        g_bias = [acc[o + i * H:o + i * H + V[i].shape[0]] for i in range(nl)]
+        o += nl * H
+        sums = acc[o:].view(nb, 2, H)
+        gn = [torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nb)]
+        g_x = torch.empty(Nrows, I0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        G_skip = None                              # assembled gradient of the latest residual-stream tensor
+
+        def in_bn(j):
+            return dict(bn_gamma=gamma[j], bn_beta=beta[j], bn_save_mean=ws[j, 2], bn_save_invstd=ws[j, 3])
+
+        def cons_bn(j):                            # evaluation mode: statistics are constants -> no mean terms
+            return dict(cbn_gamma=gamma[j], cbn_save_mean=ws[j, 2], cbn_save_invstd=ws[j, 3],
+                        cbn_sum_g=sums[j, 0] if training else None, cbn_sum_gx=sums[j, 1] if training else None)
+
+        # last linear: G = g_out
+        _launch_bwd([_desc(LinearBwdDesc, in_=acts[nb - 1], weight=V[nl - 1], weight_g=G[nl - 1], g_direct=g_out,
+                           g_bias=g_bias[nl - 1], g_weff=g_weff[nl - 1], gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0],
+                           sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))], Nrows, H, O_out)
+        for j in range(nb - 1, 0, -1):             # linear j produced acts[j]; its consumer BatchNorm is j
+            is_stream = (j % 2 == 0)               # acts[j] is a residual-stream tensor (block output)
+            store = torch.empty(Nrows, H, dtype=torch.float32, device=dev) if is_stream else None
+            _launch_bwd([_desc(LinearBwdDesc, in_=acts[j - 1], weight=V[j], weight_g=G[j], gn_src=gn[j], out=acts[j],
+                               g_skip=G_skip if is_stream else None, g_store=store, g_bias=g_bias[j], g_weff=g_weff[j],
+                               gn_out=gn[j - 1], sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1),
+                               **cons_bn(j))], Nrows, H, H)
+            if is_stream:
+                G_skip = store
+        _launch_bwd([_desc(LinearBwdDesc, in_=x, weight=V[0], weight_g=G[0], gn_src=gn[0], out=acts[0], g_skip=G_skip,
+                           g_bias=g_bias[0], g_weff=g_weff[0], gn_out=g_x, **cons_bn(0))], Nrows, I0, H)
+        g_v = [torch.empty_like(V[i]) for i in range(nl)]
+        g_g = [torch.empty_like(G[i]) for i in range(nl)]
+        _launch_wgrad([_desc(WeightGradDesc, g_weff=g_weff[i], weight=V[i], weight_g=G[i], g_weight=g_v[i],
+                             g_weight_g=g_g[i], I=V[i].shape[1], O=V[i].shape[0]) for i in range(nl)])
+        grads = []
+        for i in range(nl):
+            grads += [g_v[i], g_g[i], g_bias[i]]
+        for j in range(nb):
+            grads += [sums[j, 1], sums[j, 0], None, None, None]            # g_gamma, g_beta
+        return (g_x, None, None) + tuple(grads)
+
+
+def mlp_forward(mlp, x):
+    """``mlp``: conditioners.MLP with weight_norm=True.  Returns the conditioner output (N, out_channels)."""
+    lins = [mlp.in_block[0]]
+    bns = []
+    for blk in mlp.mid_block:
+        bns += [blk.net[0], blk.net[3]]
+        lins += [blk.net[2], blk.net[5]]
+    bns.append(mlp.out_block[0])
+    lins.append(mlp.out_block[2])
+    tensors = []
+    for wn in lins:
+        m = wn.module
+        tensors += [m.weight_v, m.weight_g, m.bias]
+    for bn in bns:
+        tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    return _FusedMLP.apply(x, mlp.training, len(mlp.mid_block), *tensors)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# MADE pair (MAF)
+# ----------------------------------------------------------------------------------------------------------------------
+class _FusedMADEPair(torch.autograd.Function):
+    """two MADE nets on the same input, same launches.  tensors per net: weights*(nh+1), biases*(nh+1),
+    masks*(nh+1), then per BatchNorm (gamma, beta, running_mean, running_var, num_batches_tracked)*nh."""
+
+    @staticmethod
+    def forward(ctx, z, training, nh, *tensors):
+        per = 3 * (nh + 1) + 5 * nh
+        nets = [tensors[i * per:(i + 1) * per] for i in range(2)]
+        z = z.contiguous()
+        Nrows, D = z.shape
+        dev = z.device
+        ws = torch.zeros(2, nh, 4, H, dtype=torch.float32, device=dev)
+        acts = [[torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nh)] for _ in range(2)]
+        outs = [torch.empty(Nrows, D, dtype=torch.float32, device=dev) for _ in range(2)]
+
+        def W(n, l): return nets[n][l]
+        def Bs(n, l): return nets[n][(nh + 1) + l]
+        def M(n, l): return nets[n][2 * (nh + 1) + l]
+        def BN(n, j): return nets[n][3 * (nh + 1) + 5 * j:3 * (nh + 1) + 5 * j + 5]
+
+        def bn_kw(n, j):
+            g, b, rm, rv, nbt = BN(n, j)
+            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[n, j, 0], bn_sqsum=ws[n, j, 1], bn_center=Bs(n, j),
+                        bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[n, j, 2],
+                        bn_save_invstd=ws[n, j, 3])
+
+        _launch_fwd([_desc(LinearDesc, in_=z, weight=W(n, 0), mask=M(n, 0), bias=Bs(n, 0), out=acts[n][0],
+                           stat_sum=ws[n, 0, 0], stat_sqsum=ws[n, 0, 1]) for n in range(2)], Nrows, D, H, training)
+        for l in range(1, nh):
+            _launch_fwd([_desc(LinearDesc, in_=acts[n][l - 1], weight=W(n, l), mask=M(n, l), bias=Bs(n, l), out=acts[n][l],
+                               stat_sum=ws[n, l, 0], stat_sqsum=ws[n, l, 1], **bn_kw(n, l - 1)) for n in range(2)],
+                        Nrows, H, H, training)
+        _launch_fwd([_desc(LinearDesc, in_=acts[n][nh - 1], weight=W(n, nh), mask=M(n, nh), bias=Bs(n, nh), out=outs[n],
+                           **bn_kw(n, nh - 1)) for n in range(2)], Nrows, H, D, training)
+        keep = [z, ws]
+        for n in range(2):
+            keep += acts[n]
+            keep += [W(n, l) for l in range(nh + 1)] + [M(n, l) for l in range(nh + 1)]
+            keep += [BN(n, j)[0] for j in range(nh)] + [BN(n, j)[1] for j in range(nh)]
+        ctx.save_for_backward(*keep)
+        ctx.meta = (nh, Nrows, D, bool(training))
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, g_s, g_t):
+        nh, Nrows, D, training = ctx.meta
+        saved = ctx.saved_tensors
+        z, ws = saved[0], saved[1]
+        per = nh + 2 * (nh + 1) + 2 * nh
+        dev = z.device
+        nets = []
+        for n in range(2):
+            blk = saved[2 + n * per:2 + (n + 1) * per]
+            nets.append(dict(acts=blk[:nh], W=blk[nh:2 * nh + 1], M=blk[2 * nh + 1:3 * nh + 2],
+                             gamma=blk[3 * nh + 2:4 * nh + 2], beta=blk[4 * nh + 2:5 * nh + 2]))
+        g_outs = [g_s.contiguous(), g_t.contiguous()]
+        sizes = [nets[0]['W'][l].numel() for l in range(nh + 1)]
+        per_acc = sum(sizes) + (nh + 1) * H + nh * 2 * H
+        acc = torch.zeros(2, per_acc, dtype=torch.float32, device=dev)
+        g_weff, g_bias, sums = [], [], []
+        for n in range(2):
+            o, gw = 0, []
+            for l in range(nh + 1):
+                gw.append(acc[n, o:o + sizes[l]])
+                o += sizes[l]
+            g_weff.append(gw)
+            g_bias.append([acc[n, o + l * H:o + l * H + nets[n]['W'][l].shape[0]] for l in range(nh + 1)])
+            o += (nh + 1) * H
+            sums.append(acc[n, o:].view(nh, 2, H))
+        gn = [[torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nh)] for _ in range(2)]
+        g_z = [torch.empty(Nrows, D, dtype=torch.float32, device=dev) for _ in range(2)]
+
+        def in_bn(n, j):
+            return dict(bn_gamma=nets[n]['gamma'][j], bn_beta=nets[n]['beta'][j], bn_save_mean=ws[n, j, 2],
+                        bn_save_invstd=ws[n, j, 3])
+
+        def cons_bn(n, j):
+            return dict(cbn_gamma=nets[n]['gamma'][j], cbn_save_mean=ws[n, j, 2], cbn_save_invstd=ws[n, j, 3],
+                        cbn_sum_g=sums[n][j, 0] if training else None, cbn_sum_gx=sums[n][j, 1] if training else None)
+
+        _launch_bwd([_desc(LinearBwdDesc, in_=nets[n]['acts'][nh - 1], weight=nets[n]['W'][nh], mask=nets[n]['M'][nh],
+                           g_direct=g_outs[n], g_bias=g_bias[n][nh], g_weff=g_weff[n][nh], gn_out=gn[n][nh - 1],
+                           sum_g=sums[n][nh - 1, 0], sum_gx=sums[n][nh - 1, 1], **in_bn(n, nh - 1)) for n in range(2)],
+                    Nrows, H, D)
+        for l in range(nh - 1, 0, -1):
+            _launch_bwd([_desc(LinearBwdDesc, in_=nets[n]['acts'][l - 1], weight=nets[n]['W'][l], mask=nets[n]['M'][l],
+                               gn_src=gn[n][l], out=nets[n]['acts'][l], g_bias=g_bias[n][l], g_weff=g_weff[n][l],
+                               gn_out=gn[n][l - 1], sum_g=sums[n][l - 1, 0], sum_gx=sums[n][l - 1, 1], **in_bn(n, l - 1),
+                               **cons_bn(n, l)) for n in range(2)], Nrows, H, H)
+        _launch_bwd([_desc(LinearBwdDesc, in_=z, weight=nets[n]['W'][0], mask=nets[n]['M'][0], gn_src=gn[n][0],
+                           out=nets[n]['acts'][0], g_bias=g_bias[n][0], g_weff=g_weff[n][0], gn_out=g_z[n],
+                           **cons_bn(n, 0)) for n in range(2)], Nrows, D, H)
+        g_W = [[torch.empty_like(nets[n]['W'][l]) for l in range(nh + 1)] for n in range(2)]
+        _launch_wgrad([_desc(WeightGradDesc, g_weff=g_weff[n][l], weight=nets[n]['W'][l], mask=nets[n]['M'][l],
+                             g_weight=g_W[n][l], I=nets[n]['W'][l].shape[1], O=nets[n]['W'][l].shape[0])
+                       for n in range(2) for l in range(nh + 1)])
+        grads = []
+        for n in range(2):
+            grads += g_W[n] + g_bias[n] + [None] * (nh + 1)
+            for j in range(nh):
+                grads += [sums[n][j, 1], sums[n][j, 0], None, None, None]
+        g_in = g_z[0] + g_z[1] if ctx.needs_input_grad[0] else None
+        return (g_in, None, None) + tuple(grads)
+
+
+def made_pair_forward(net_s, net_t, z, masks_s, masks_t):
+    """s_raw, t = MADE_s(z), MADE_t(z) with the given per-layer mask tensors (device, fp32)."""
+    nh = net_s.num_hidden
+    tensors = []
+    for net, masks in ((net_s, masks_s), (net_t, masks_t)):
+        tensors += list(net.weights) + list(net.biases) + list(masks)
+        for bn in net.bnorms:
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    training = net_s.training
+    return _FusedMADEPair.apply(z, training, nh, *tensors)

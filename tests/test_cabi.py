@@ -73,3 +73,17 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
                 assert 'from oracle' not in text and 'import oracle' not in text, f
+
+
+def test_ctypes_struct_layout_matches_header(pkg):
+    """fused.py mirrors the three descriptor structs by hand: field order and count must equal the header's."""
+    fused = __import__('importlib').import_module(pkg.__name__ + '.fused')
+    text = re.sub(r'/\*.*?\*/', ' ', open(HEADER).read(), flags=re.S)
+    for struct, cls in [('nf_linear_desc', fused.LinearDesc), ('nf_linear_bwd_desc', fused.LinearBwdDesc),
+                        ('nf_weight_grad_desc', fused.WeightGradDesc)]:
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct, struct), text, flags=re.S).group(1)
+        names = [re.sub(r'\W', '', f.strip().split()[-1]) for f in body.split(';') if f.strip()]
+        got = [n.rstrip('_') for n, _ in cls._fields_]
+        assert got == names, (struct, got, names)
+        for (n, ty), decl in zip(cls._fields_, [f.strip() for f in body.split(';') if f.strip()]):
+            assert ('*' in decl) == (ty is ctypes.c_void_p), decl

@@ -1,0 +1,109 @@
+"""
+Parity of the fused fp32-MFMA conditioner kernels (linear + BatchNorm + ReLU chains: csrc/linear_bn.hip) against the
+module-by-module PyTorch path of the same networks and against the oracle's CPU restatement.  Needs a real MI355X.
+"""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _grad_tol(w):
+    return 1e-4 * max(1.0, float(w.abs().max()))       # BatchNorm backward is cancellation-heavy
+
+
+@pytest.mark.parametrize('in_ch,out_ch,N', [(1, 2, 4096), (1, 2, 257), (3, 6, 1000), (16, 32, 64), (32, 32, 96)])
+@pytest.mark.parametrize('training', [True, False])
+def test_fused_mlp_vs_modules(pkg, in_ch, out_ch, N, training):
+    cond = importlib.import_module(pkg.__name__ + '.conditioners')
+    torch.manual_seed(in_ch * 100 + out_ch)
+    ref = cond.MLP(in_ch, out_ch).to(DEV)
+    with torch.no_grad():                                  # make BatchNorm affine / running stats non-trivial
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 2.0)
+    fus = copy.deepcopy(ref)
+    ref.train(training)
+    fus.train(training)
+    g = torch.Generator().manual_seed(N)
+    x = (torch.randn(N, in_ch, generator=g) * 0.7).to(DEV)
+    gout = torch.randn(N, out_ch, generator=g).to(DEV)
+    xr, xf = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yr = ref.forward_reference(xr)
+    yf = fus(xf)
+    G.assert_close(yf, yr, 2e-5, rtol=2e-5, what='output')
+    yr.backward(gout)
+    yf.backward(gout)
+    G.assert_close(xf.grad, xr.grad, _grad_tol(xr.grad), what='grad input')
+    pr, pf = dict(ref.named_parameters()), dict(fus.named_parameters())
+    for k in pr:
+        assert pf[k].grad is not None, k
+        pre_bn_bias = training and k.endswith('module.bias') and 'out_block' not in k
+        tol = 2e-3 if pre_bn_bias else _grad_tol(pr[k].grad)          # analytically-zero gradients: noise only
+        G.assert_close(pf[k].grad, pr[k].grad, tol, what='grad ' + k)
+    br, bf = dict(ref.named_buffers()), dict(fus.named_buffers())
+    for k in br:
+        G.assert_close(bf[k].float(), br[k].float(), 2e-6, rtol=1e-5, what='buffer ' + k)
+
+
+def test_fused_mlp_vs_oracle_cpu(pkg):
+    cond = importlib.import_module(pkg.__name__ + '.conditioners')
+    torch.manual_seed(0)
+    mlp = cond.MLP(1, 2)
+    sd = {k: v.clone() for k, v in mlp.state_dict().items()}
+    x = torch.randn(512, 1) * 0.5
+    want = onets.mlp(x, sd, '', training=True)
+    got = mlp.to(DEV).train()(x.to(DEV))
+    G.assert_close(got, want, 1e-5, what='mlp vs oracle')
+    for k, v in mlp.state_dict().items():
+        G.assert_close(v.float(), sd[k].float(), 2e-6, what=k)       # running statistics updated identically
+
+
+@pytest.mark.parametrize('D,N', [(2, 16384), (2, 100), (5, 333), (8, 64)])
+@pytest.mark.parametrize('training', [True, False])
+def test_fused_made_pair_vs_modules(pkg, D, N, training):
+    torch.manual_seed(D)
+    ref = pkg.AutoregressiveTransfrom(D).to(DEV)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 2.0)
+    fus = copy.deepcopy(ref)
+    ref.train(training)
+    fus.train(training)
+    g = torch.Generator().manual_seed(N)
+    z = torch.randn(N, D, generator=g).to(DEV)
+    gs, gt = torch.randn(N, D, generator=g).to(DEV), torch.randn(N, D, generator=g).to(DEV)
+    zr, zf = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    np.random.seed(11)
+    sr, tr = ref.net_s(zr), ref.net_t(zr)                  # module path (rocBLAS + MIOpen)
+    np.random.seed(11)
+    sf, tf_ = fus.conditioners(zf)                         # fused path
+    G.assert_close(sf, sr, 2e-5, rtol=2e-5, what='s')
+    G.assert_close(tf_, tr, 2e-5, rtol=2e-5, what='t')
+    torch.autograd.backward([sr, tr], [gs, gt])
+    torch.autograd.backward([sf, tf_], [gs, gt])
+    G.assert_close(zf.grad, zr.grad, _grad_tol(zr.grad), what='grad z')
+    pr, pf = dict(ref.named_parameters()), dict(fus.named_parameters())
+    for k in pr:
+        if pr[k].grad is None:
+            continue
+        pre_bn_bias = training and '.biases.' in k and not k.endswith('.biases.3')
+        G.assert_close(pf[k].grad, pr[k].grad, 2e-3 if pre_bn_bias else _grad_tol(pr[k].grad), what='grad ' + k)
+    br, bf = dict(ref.named_buffers()), dict(fus.named_buffers())
+    for k in br:
+        G.assert_close(bf[k].float(), br[k].float(), 2e-6, rtol=1e-5, what='buffer ' + k)
