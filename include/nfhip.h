@@ -113,6 +113,15 @@ int nf_invconv_apply(const float* z, const float* M, int transpose, float* y, fl
 /* g_M[r,c] += sum_{b,p} g_y[b,r,p] * z[b,c,p]   (appendix B3)                                                   */
 int nf_invconv_wgrad(const float* g_y, const float* z, float* g_M, int64_t B, int C, int P, nf_stream_t stream);
 
+/* PLU weight assembly W = P (L o L_mask + I) (U o U_mask + diag(sign_s exp(log_s)))  (modules.py:471-473) and its
+ * autograd: g_L, g_U (masked), g_log_s[i] = diag term + pixels * sum_b g_ld[b] (the log-det path, modules.py:480);
+ * g_ld may be NULL.  One workgroup, C <= 64.                                                                       */
+int nf_invconv_weight_fwd(const float* P, const float* L, const float* U, const float* L_mask, const float* U_mask,
+                          const float* sign_s, const float* log_s, float* W, int C, nf_stream_t stream);
+int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, const float* U, const float* L_mask,
+                          const float* U_mask, const float* sign_s, const float* log_s, const float* g_ld, float* g_L,
+                          float* g_U, float* g_log_s, int C, int64_t B, int pixels, nf_stream_t stream);
+
 /* ---- Logit  modules.py:141-156 --------------------------------------------------------------------------------
  * forward: xc = clamp(x, eps, 1-eps); y = log(xc/(1-xc)); ld[b] += sum -(y - 2 softplus(y))
  * inverse: y = sigmoid(x); ld[b] += sum (x - 2 softplus(x)).      n = elements per sample.                       */
@@ -239,8 +248,11 @@ typedef struct nf_weight_grad_desc {
 int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, float wn_eps, nf_stream_t stream);
 
 /* ---- NLL of the training harness  main.py:49-51, :85 -------------------------------------------------------------
- * loss[0] += -(1/B) * sum_b ( -0.5*|z_b|^2 - 0.5*D*log(2 pi) + ld[b] );  g_z = z / B,  (g_ld = -1/B is constant) */
+ * loss[0] += -(1/B) * sum_b ( -0.5*|z_b|^2 - 0.5*D*log(2 pi) + ld[b] )   (caller zero-fills loss)            */
 int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream);
+/* autograd: g_z = g_loss[0] * z / B,  g_ld[b] = -g_loss[0] / B   (g_loss: device scalar) */
+int nf_nll_loss_bwd(const float* z, const float* g_loss, float* g_z, float* g_ld, int64_t B, int64_t D,
+                    nf_stream_t stream);
 
 #ifdef __cplusplus
 }

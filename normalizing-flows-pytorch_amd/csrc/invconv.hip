@@ -118,6 +118,83 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// PLU weight assembly (modules.py:471-473) and its autograd, one workgroup (C <= 64: three C x C tiles in LDS).
+//   W = P L' U',  L' = L o L_mask + I,  U' = U o U_mask + diag(sign_s exp(log_s))
+//   g_L = (P^T g_W U'^T) o L_mask,  g_U = (L'^T P^T g_W) o U_mask,
+//   g_log_s[i] = (L'^T P^T g_W)[i][i] sign_s[i] exp(log_s[i]) + pixels * sum_b g_ld[b]      (appendix B3)
+#define NF_PLU_MAXC 64
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd(const float* __restrict__ Pm, const float* __restrict__ L,
+                                                                 const float* __restrict__ U, const float* __restrict__ Lmask,
+                                                                 const float* __restrict__ Umask,
+                                                                 const float* __restrict__ sign_s,
+                                                                 const float* __restrict__ log_s, float* __restrict__ W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Lp = sm;
+    float* Up = sm + C * C;
+    float* T = sm + 2 * C * C;
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        Lp[e] = L[e] * Lmask[e] + (r == c ? 1.f : 0.f);
+        Up[e] = U[e] * Umask[e] + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        float acc = 0.f;
+        for (int k = 0; k < C; ++k) acc = fmaf(Lp[r * C + k], Up[k * C + c], acc);
+        T[e] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        float acc = 0.f;
+        for (int k = 0; k < C; ++k) acc = fmaf(Pm[r * C + k], T[k * C + c], acc);
+        W[e] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __restrict__ gW, const float* __restrict__ Pm,
+                                                                 const float* __restrict__ L, const float* __restrict__ U,
+                                                                 const float* __restrict__ Lmask,
+                                                                 const float* __restrict__ Umask,
+                                                                 const float* __restrict__ sign_s,
+                                                                 const float* __restrict__ log_s, const float* __restrict__ gld,
+                                                                 float* __restrict__ gL, float* __restrict__ gU,
+                                                                 float* __restrict__ glog_s, int C, int64_t B, float pixels) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    __shared__ float sum_gld;
+    float* Lp = sm;
+    float* Up = sm + C * C;
+    float* A = sm + 2 * C * C;                                   // P^T g_W
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        Lp[e] = L[e] * Lmask[e] + (r == c ? 1.f : 0.f);
+        Up[e] = U[e] * Umask[e] + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
+        float acc = 0.f;
+        for (int k = 0; k < C; ++k) acc = fmaf(Pm[k * C + r], gW[k * C + c], acc);
+        A[e] = acc;
+    }
+    float part = 0.f;
+    if (gld != nullptr)
+        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) part += gld[b];
+    const float tot = nf_block_sum(part, scratch);
+    if (threadIdx.x == 0) sum_gld = tot;
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        float gl = 0.f, gu = 0.f;
+        for (int k = 0; k < C; ++k) {
+            gl = fmaf(A[r * C + k], Up[c * C + k], gl);          // (A U'^T)[r][c]
+            gu = fmaf(Lp[k * C + r], A[k * C + c], gu);          // (L'^T A)[r][c]
+        }
+        gL[e] = gl * Lmask[e];
+        gU[e] = gu * Umask[e];
+        if (r == c) glog_s[r] = gu * sign_s[r] * expf(log_s[r]) + pixels * sum_gld;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template <bool TR>
 static void nf_launch_apply(int C, dim3 grid, hipStream_t st, const float* z, const float* M, float* y, float* ld,
                             const float* log_s, float ld_sign, int64_t B, int P) {
@@ -161,6 +238,27 @@ extern "C" int nf_invconv_wgrad(const float* g_y, const float* z, float* g_M, in
     const size_t lds = (size_t)2 * C * (NF_TP + 1) * sizeof(float);
     hipLaunchKernelGGL(k_invconv_wgrad, dim3((unsigned)blocks), dim3(NF_BLOCK), lds, (hipStream_t)stream, g_y, z, g_M, B,
                        C, P, tpb);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_invconv_weight_fwd(const float* P, const float* L, const float* U, const float* L_mask,
+                                     const float* U_mask, const float* sign_s, const float* log_s, float* W, int C,
+                                     nf_stream_t stream) {
+    if (C <= 0 || C > NF_PLU_MAXC) return C <= 0 ? NF_E_BADARG : NF_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_invconv_weight_fwd, dim3(1), dim3(NF_BLOCK), (size_t)3 * C * C * sizeof(float), (hipStream_t)stream,
+                       P, L, U, L_mask, U_mask, sign_s, log_s, W, C);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, const float* U,
+                                     const float* L_mask, const float* U_mask, const float* sign_s, const float* log_s,
+                                     const float* g_ld, float* g_L, float* g_U, float* g_log_s, int C, int64_t B, int pixels,
+                                     nf_stream_t stream) {
+    if (C <= 0 || C > NF_PLU_MAXC) return C <= 0 ? NF_E_BADARG : NF_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_invconv_weight_bwd, dim3(1), dim3(NF_BLOCK), (size_t)3 * C * C * sizeof(float), (hipStream_t)stream,
+                       g_W, P, L, U, L_mask, U_mask, sign_s, log_s, g_ld, g_L, g_U, g_log_s, C, B, (float)pixels);
     NF_CHECK_LAUNCH();
     return 0;
 }

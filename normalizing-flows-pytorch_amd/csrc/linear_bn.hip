@@ -34,72 +34,83 @@ __device__ __forceinline__ int nf_cd_row(int r, int hs) { return (r & 3) + 8 * (
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
+// Prologue (once per block, ONE round of global loads, everything else through LDS):
+//   W tile (mask applied) -> LDS;  thread k < I: column norm of W (weight-norm) and the folded BatchNorm constants of
+//   input feature k;  the weight-norm column scale s_k = g_k / (||v_k|| + eps) is applied on the A side
+//   (out = sum_k (act_k s_k) v[o][k]), which keeps the B fragment a plain copy of the stored weight.
 template <int KH>
 __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinArgs args, int64_t N, int I, int O,
                                                                          int training, float eps, float mom,
                                                                          float wn_eps, int64_t tiles) {
+    __shared__ float Wl[32 * NF_TS];
+    __shared__ float kc[3][32];                       // per input feature: BN scale, BN shift, weight-norm scale
     __shared__ float red[2][NF_LB_WAVES][32];
     const nf_linear_desc& d = args.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, o = lane & 31, hs = lane >> 5;
     const bool has_bn = d.bn_gamma != nullptr;
     const float invN = 1.f / (float)N;
 
-    // ---- B fragment: effective weight Weff[o][k], k = hs*KH + kk  (mask / weight-norm applied while loading) ----
-    float b[KH], sc[KH], sh[KH];
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) {
-        const int k = hs * KH + kk;
-        const bool ok = (o < O) && (k < I);
-        float w = ok ? d.weight[o * I + k] : 0.f;
-        if (ok && d.mask != nullptr) w *= d.mask[o * I + k];                       // maf.py:54
-        b[kk] = w;
-    }
-    if (d.weight_g != nullptr) {                                                   // weight_norm.py:40
-#pragma unroll
-        for (int kk = 0; kk < KH; ++kk) {
-            const int k = hs * KH + kk;
-            const float nrm = sqrtf(nf_half32_sum(b[kk] * b[kk]));                 // ||v||_dim0 of input column k
-            const float gk = (k < I) ? d.weight_g[k] : 0.f;
-            b[kk] = b[kk] * (gk / (nrm + wn_eps));
+    for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
+        const int oo = e >> 5, k = e & 31;
+        float w = 0.f;
+        if (oo < O && k < I) {
+            w = d.weight[oo * I + k];
+            if (d.mask != nullptr) w *= d.mask[oo * I + k];                        // maf.py:54
         }
+        Wl[oo * NF_TS + k] = w;
     }
-    // ---- input BatchNorm folded into scale / shift per input feature ----
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) {
-        const int k = hs * KH + kk;
-        sc[kk] = has_bn ? 0.f : 1.f;
-        sh[kk] = 0.f;
-        if (has_bn && k < I) {
-            float mean, invstd;
-            if (training) {
-                const float m1 = d.bn_sum[k] * invN;
-                mean = d.bn_center[k] + m1;
-                const float var = fmaxf(d.bn_sqsum[k] * invN - m1 * m1, 0.f);      // biased, as BatchNorm normalises
-                invstd = 1.f / sqrtf(var + eps);
-                if (blockIdx.x == 0 && wid == 0 && o == 0) {                       // bookkeeping, once per feature
-                    d.bn_running_mean[k] = (1.f - mom) * d.bn_running_mean[k] + mom * mean;
-                    const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-                    d.bn_running_var[k] = (1.f - mom) * d.bn_running_var[k] + mom * unb;
-                    d.bn_save_mean[k] = mean;
-                    d.bn_save_invstd[k] = invstd;
-                }
-            } else {
-                mean = d.bn_running_mean[k];
-                invstd = 1.f / sqrtf(d.bn_running_var[k] + eps);
-                if (blockIdx.x == 0 && wid == 0 && o == 0 && d.bn_save_mean != nullptr) {
-                    d.bn_save_mean[k] = mean;              // evaluation-mode backward treats them as constants
-                    d.bn_save_invstd[k] = invstd;
-                }
+    float sc_k = has_bn ? 0.f : 1.f, sh_k = 0.f;
+    if (threadIdx.x < 32 && has_bn && (int)threadIdx.x < I) {
+        const int k = threadIdx.x;
+        float mean, invstd;
+        if (training) {
+            const float m1 = d.bn_sum[k] * invN;
+            mean = d.bn_center[k] + m1;
+            const float var = fmaxf(d.bn_sqsum[k] * invN - m1 * m1, 0.f);          // biased, as BatchNorm normalises
+            invstd = 1.f / sqrtf(var + eps);
+            if (blockIdx.x == 0) {                                                 // bookkeeping, once per feature
+                const float rm = d.bn_running_mean[k], rv = d.bn_running_var[k];
+                const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+                d.bn_running_mean[k] = (1.f - mom) * rm + mom * mean;
+                d.bn_running_var[k] = (1.f - mom) * rv + mom * unb;
             }
-            sc[kk] = d.bn_gamma[k] * invstd;
-            sh[kk] = d.bn_beta[k] - mean * sc[kk];
+        } else {
+            mean = d.bn_running_mean[k];
+            invstd = 1.f / sqrtf(d.bn_running_var[k] + eps);
         }
+        if (blockIdx.x == 0 && d.bn_save_mean != nullptr) {                        // constants of the backward pass
+            d.bn_save_mean[k] = mean;
+            d.bn_save_invstd[k] = invstd;
+        }
+        sc_k = d.bn_gamma[k] * invstd;
+        sh_k = d.bn_beta[k] - mean * sc_k;
     }
     if (training && has_bn && d.bn_num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
         d.bn_num_batches[0] += 1;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x;
+        float ws = 1.f;
+        if (d.weight_g != nullptr) {                                               // weight_norm.py:40
+            float ss = 0.f;
+#pragma unroll 8
+            for (int oo = 0; oo < 32; ++oo) ss = fmaf(Wl[oo * NF_TS + k], Wl[oo * NF_TS + k], ss);
+            ws = (k < I) ? d.weight_g[k] / (sqrtf(ss) + wn_eps) : 0.f;
+        }
+        kc[0][k] = sc_k; kc[1][k] = sh_k; kc[2][k] = ws;
+    }
+    __syncthreads();
+    float b[KH], sc[KH], sh[KH], wsc[KH];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) {
+        const int k = hs * KH + kk;                   // KH <= 16 -> k < 32
+        b[kk] = Wl[o * NF_TS + k];
+        sc[kk] = kc[0][k]; sh[kk] = kc[1][k]; wsc[kk] = kc[2][k];
+    }
 
     const float bias_o = (o < O) ? d.bias[o] : 0.f;
     const bool want_stats = d.stat_sum != nullptr;
+    const bool has_res = d.residual != nullptr;
     float s1 = 0.f, s2 = 0.f;
     for (int64_t tile = (int64_t)blockIdx.x * NF_LB_WAVES + wid; tile < tiles; tile += (int64_t)gridDim.x * NF_LB_WAVES) {
         const int64_t row0 = tile * 32;
@@ -120,12 +131,18 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
                 a[kk] = (rv && k < I) ? d.in[row * I + k] : 0.f;
             }
         }
+        float rres[16];                                   // residual tile prefetched: 16 loads in flight under the MFMAs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t gr = row0 + nf_cd_row(r, hs);
+            rres[r] = (has_res && o < O && gr < N) ? d.residual[gr * O + o] : 0.f;
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < KH; ++kk) {
-            const float av = has_bn ? fmaxf(fmaf(a[kk], sc[kk], sh[kk]), 0.f) : a[kk];   // BN -> ReLU on load
+            const float av = (has_bn ? fmaxf(fmaf(a[kk], sc[kk], sh[kk]), 0.f) : a[kk]) * wsc[kk];   // BN -> ReLU -> WN scale
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk], acc, 0, 0, 0);
         }
         if (o < O) {
@@ -133,8 +150,7 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
             for (int r = 0; r < 16; ++r) {
                 const int64_t gr = row0 + nf_cd_row(r, hs);
                 if (gr < N) {
-                    float dv = acc[r];
-                    if (d.residual != nullptr) dv += d.residual[gr * O + o];
+                    const float dv = acc[r] + rres[r];
                     d.out[gr * O + o] = dv + bias_o;
                     s1 += dv;                                 // statistics centred at the bias (shifted sums)
                     s2 = fmaf(dv, dv, s2);
@@ -229,27 +245,73 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
             // ---- assemble G[row][o] for o = hs*16 + kk (row = c32), stash it in LDS, keep it as the A fragment ----
             const int64_t row = row0 + c32;
             const bool rv = row < N;
+            if (O == 32) {                                         // 64-byte runs per lane: four 16-byte loads per tensor
+                const int64_t base = row * 32 + hs * 16;
+                float gd[16], gk[16], gs[16], ov[16];
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const int oo = hs * 16 + kk;
-                float g = 0.f;
-                if (rv && oo < O) {
-                    const int64_t idx = row * O + oo;
-                    if (d.g_direct != nullptr) g += d.g_direct[idx];
-                    if (d.g_skip != nullptr) g += d.g_skip[idx];
-                    if (has_src) {
-                        const float xh = (d.out[idx] - cbn[1][oo]) * cbn[2][oo];
-                        g += cbn[0][oo] * (d.gn_src[idx] - cbn[3][oo] - xh * cbn[4][oo]);   // BatchNorm backward on load
-                    }
-                    if (d.g_store != nullptr) d.g_store[idx] = g;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 v0 = (rv && d.g_direct != nullptr) ? reinterpret_cast<const float4*>(d.g_direct + base)[q] : z4;
+                    const float4 v1 = (rv && d.g_skip != nullptr) ? reinterpret_cast<const float4*>(d.g_skip + base)[q] : z4;
+                    const float4 v2 = (rv && has_src) ? reinterpret_cast<const float4*>(d.gn_src + base)[q] : z4;
+                    const float4 v3 = (rv && has_src) ? reinterpret_cast<const float4*>(d.out + base)[q] : z4;
+                    gd[4 * q] = v0.x; gd[4 * q + 1] = v0.y; gd[4 * q + 2] = v0.z; gd[4 * q + 3] = v0.w;
+                    gk[4 * q] = v1.x; gk[4 * q + 1] = v1.y; gk[4 * q + 2] = v1.z; gk[4 * q + 3] = v1.w;
+                    gs[4 * q] = v2.x; gs[4 * q + 1] = v2.y; gs[4 * q + 2] = v2.z; gs[4 * q + 3] = v2.w;
+                    ov[4 * q] = v3.x; ov[4 * q + 1] = v3.y; ov[4 * q + 2] = v3.z; ov[4 * q + 3] = v3.w;
                 }
-                a1[kk] = g;
-                Gt[c32 * NF_TS + oo] = g;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int oo = hs * 16 + kk;
+                    float g = gd[kk] + gk[kk];
+                    if (has_src) {
+                        const float xh = (ov[kk] - cbn[1][oo]) * cbn[2][oo];
+                        g += cbn[0][oo] * (gs[kk] - cbn[3][oo] - xh * cbn[4][oo]);          // BatchNorm backward on load
+                    }
+                    a1[kk] = rv ? g : 0.f;
+                    Gt[c32 * NF_TS + oo] = a1[kk];
+                }
+                if (rv && d.g_store != nullptr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        reinterpret_cast<float4*>(d.g_store + base)[q] =
+                            make_float4(a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int oo = hs * 16 + kk;
+                    float g = 0.f;
+                    if (rv && oo < O) {
+                        const int64_t idx = row * O + oo;
+                        if (d.g_direct != nullptr) g += d.g_direct[idx];
+                        if (d.g_skip != nullptr) g += d.g_skip[idx];
+                        if (has_src) {
+                            const float xh = (d.out[idx] - cbn[1][oo]) * cbn[2][oo];
+                            g += cbn[0][oo] * (d.gn_src[idx] - cbn[3][oo] - xh * cbn[4][oo]);
+                        }
+                        if (d.g_store != nullptr) d.g_store[idx] = g;
+                    }
+                    a1[kk] = g;
+                    Gt[c32 * NF_TS + oo] = g;
+                }
             }
             // ---- raw input tile, coalesced ----
-            for (int idx = lane; idx < 32 * I; idx += NF_WAVE) {
-                const int rr = idx / I, cc = idx - rr * I;
-                It[rr * NF_TS + cc] = (row0 + rr < N) ? d.in[(row0 + rr) * I + cc] : 0.f;
+            if (I == 32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx4 = lane + 64 * q;                // float4 index inside the 32 x 32 tile
+                    const int rr = idx4 >> 3, cc = (idx4 & 7) * 4;
+                    const float4 v = (row0 + rr < N) ? reinterpret_cast<const float4*>(d.in + (row0 + rr) * 32)[idx4 & 7]
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float* dst = It + rr * NF_TS + cc;
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                }
+            } else {
+                for (int idx = lane; idx < 32 * I; idx += NF_WAVE) {
+                    const int rr = idx / I, cc = idx - rr * I;
+                    It[rr * NF_TS + cc] = (row0 + rr < N) ? d.in[(row0 + rr) * I + cc] : 0.f;
+                }
             }
         }
         __syncthreads();

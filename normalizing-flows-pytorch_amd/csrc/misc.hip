@@ -45,3 +45,23 @@ extern "C" int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t
     NF_CHECK_LAUNCH();
     return 0;
 }
+
+// g_z = g * z / B ; g_ld = -g / B      (g = upstream gradient of the scalar loss, read from device memory)
+__global__ void __launch_bounds__(NF_BLOCK) k_nll_loss_bwd(const float* __restrict__ z, const float* __restrict__ g,
+                                                           float* __restrict__ gz, float* __restrict__ gld, int64_t B,
+                                                           int64_t D) {
+    const float s = g[0] / (float)B;
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t t = gtid; t < B * D; t += gstride) gz[t] = s * z[t];
+    for (int64_t b = gtid; b < B; b += gstride) gld[b] = -s;
+}
+
+extern "C" int nf_nll_loss_bwd(const float* z, const float* g_loss, float* g_z, float* g_ld, int64_t B, int64_t D,
+                               nf_stream_t stream) {
+    if (B <= 0 || D <= 0) return NF_E_BADARG;
+    hipLaunchKernelGGL(k_nll_loss_bwd, dim3(nf_grid_for(B * D)), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, g_loss, g_z,
+                       g_ld, B, D);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -333,6 +333,46 @@ def invconv_inverse(y, W_inv, ld, log_s):
     return z, ld
 
 
+class _InvConvPLU(torch.autograd.Function):
+    """whole InvertibleConv1x1.forward: PLU assembly + per-pixel mat-vec + log-det, 2 launches forward, 4 backward."""
+
+    @staticmethod
+    def forward(ctx, z, ld, P, L, U, L_mask, U_mask, sign_s, log_s):
+        B, C, Px = _bcp(z)
+        W = torch.empty((C, C), dtype=z.dtype, device=z.device)
+        N.call('nf_invconv_weight_fwd', N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask), N.ptr(sign_s),
+               N.ptr(log_s), N.ptr(W), C, N.stream())
+        y = torch.empty_like(z)
+        N.call('nf_invconv_apply', N.ptr(z), N.ptr(W), 0, N.ptr(y), N.ptr(ld), N.ptr(log_s), 1.0, B, C, Px, N.stream())
+        ctx.save_for_backward(z, W, P, L, U, L_mask, U_mask, sign_s, log_s)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, W, P, L, U, L_mask, U_mask, sign_s, log_s = ctx.saved_tensors
+        B, C, Px = _bcp(z)
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_z = None
+        if ctx.needs_input_grad[0]:
+            g_z = torch.empty_like(z)
+            N.call('nf_invconv_apply', N.ptr(g_y), N.ptr(W), 1, N.ptr(g_z), None, None, 0.0, B, C, Px, N.stream())
+        g_W = torch.zeros_like(W)
+        N.call('nf_invconv_wgrad', N.ptr(g_y), N.ptr(z), N.ptr(g_W), B, C, Px, N.stream())
+        g_L, g_U, g_ls = torch.empty_like(L), torch.empty_like(U), torch.empty_like(log_s)
+        N.call('nf_invconv_weight_bwd', N.ptr(g_W), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask),
+               N.ptr(sign_s), N.ptr(log_s), N.ptr(g_ld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_ls), C, B, Px, N.stream())
+        return g_z, g_ld, None, g_L, g_U, None, None, None, g_ls
+
+
+PLU_MAX_C = 64
+
+
+def invconv_plu(z, ld, P, L, U, L_mask, U_mask, sign_s, log_s):
+    """InvertibleConv1x1.forward from its stored PLU parameters (flows/modules.py:470-482)."""
+    return _InvConvPLU.apply(_contig(z), _owned_ld(ld), P, L, U, L_mask, U_mask, sign_s, log_s)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # logit
 # ----------------------------------------------------------------------------------------------------------------------
@@ -418,3 +458,33 @@ def mixlog_coupling(z, params, a_log_scale, a_bias, ld, n_mixtures, mode, odd, i
         N.call('nf_mixlog_coupling_inv', N.ptr(z), N.ptr(params), N.ptr(a_log_scale), N.ptr(a_bias), N.ptr(y), N.ptr(ld),
                N.ptr(scratch), N.ptr(flag), n_mixtures, mode, int(odd), B, C, H, W, N.stream())
     return y, ld
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# NLL under the standard-normal prior (training harness, main.py:49-51, :85)
+# ----------------------------------------------------------------------------------------------------------------------
+class _NLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, ld):
+        B = z.shape[0]
+        D = z.numel() // B
+        loss = torch.zeros((), dtype=z.dtype, device=z.device)
+        N.call('nf_nll_loss', N.ptr(z), N.ptr(ld), N.ptr(loss), B, D, N.stream())
+        ctx.save_for_backward(z)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (z, ) = ctx.saved_tensors
+        B = z.shape[0]
+        D = z.numel() // B
+        g = _contig(g)
+        g_z = torch.empty_like(z)
+        g_ld = torch.empty(B, dtype=z.dtype, device=z.device)
+        N.call('nf_nll_loss_bwd', N.ptr(z), N.ptr(g), N.ptr(g_z), N.ptr(g_ld), B, D, N.stream())
+        return g_z, g_ld
+
+
+def nll_loss(z, ld):
+    """-mean_b( log N(z_b; 0, I) + ld_b ): one reduction kernel (the reference builds a D x D MultivariateNormal)."""
+    return _NLL.apply(_contig(z), _contig(ld))

@@ -178,6 +178,9 @@ class InvertibleConv1x1(nn.Module):
         return torch.linalg.solve_triangular(Up, X, upper=True)
 
     def forward(self, z, log_df_dz):
+        if z.shape[1] <= NF.PLU_MAX_C:
+            return NF.invconv_plu(z, log_df_dz, self.P, self.L, self.U, self.L_mask, self.U_mask, self.sign_s,
+                                  self.log_s)
         return NF.invconv(z, self.weight(), log_df_dz, self.log_s)
 
     def backward(self, y, log_df_dz):

@@ -382,3 +382,20 @@ def test_ar_transform_golden(nf, D):
         assert torch.equal(zin, g['y_eval'])             # the caller's tensor is not mutated (appendix D Q5)
         G.assert_close(xi, g['x_inv'], TOL)
         G.assert_close(ldi, g['ld_inv'], TOL)
+
+
+def test_nll_loss_vs_reference_formula(nf):
+    g = torch.Generator().manual_seed(2)
+    for shape in [(4096, 2), (64, 3, 32, 32), (7, 5)]:
+        z = torch.randn(shape, generator=g)
+        ld = torch.randn(shape[0], generator=g)
+        zr, lr = z.clone().requires_grad_(True), ld.clone().requires_grad_(True)
+        want = tf.nll_loss(zr, lr)
+        want.backward()
+        zd, ldv = z.to(DEV).requires_grad_(True), ld.to(DEV).requires_grad_(True)
+        got = nf.functional.nll_loss(zd, ldv)
+        (got * 1.0).backward()
+        D = z[0].numel()
+        G.assert_close(got, want, 1e-5 * max(1.0, abs(float(want)) / D * D ** 0.5))
+        G.assert_close(zd.grad, zr.grad, 1e-7, rtol=1e-5)
+        G.assert_close(ldv.grad, lr.grad, 1e-7, rtol=1e-5)
