@@ -115,12 +115,12 @@ int nf_invconv_wgrad(const float* g_y, const float* z, float* g_M, int64_t B, in
 
 /* PLU weight assembly W = P (L o L_mask + I) (U o U_mask + diag(sign_s exp(log_s)))  (modules.py:471-473) and its
  * autograd: g_L, g_U (masked), g_log_s[i] = diag term + pixels * sum_b g_ld[b] (the log-det path, modules.py:480);
- * g_ld may be NULL.  One workgroup, C <= 64.                                                                       */
+ * g_ld may be NULL; accumulate != 0: g_L/g_U/g_log_s are +=.  One workgroup, C <= 64.                                                                       */
 int nf_invconv_weight_fwd(const float* P, const float* L, const float* U, const float* L_mask, const float* U_mask,
                           const float* sign_s, const float* log_s, float* W, int C, nf_stream_t stream);
 int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, const float* U, const float* L_mask,
                           const float* U_mask, const float* sign_s, const float* log_s, const float* g_ld, float* g_L,
-                          float* g_U, float* g_log_s, int C, int64_t B, int pixels, nf_stream_t stream);
+                          float* g_U, float* g_log_s, int accumulate, int C, int64_t B, int pixels, nf_stream_t stream);
 
 /* ---- Logit  modules.py:141-156 --------------------------------------------------------------------------------
  * forward: xc = clamp(x, eps, 1-eps); y = log(xc/(1-xc)); ld[b] += sum -(y - 2 softplus(y))
@@ -199,7 +199,8 @@ int nf_linear_bn_fwd(const nf_linear_desc* descs, int n_nets, int64_t N, int I, 
  *                                                            carry gradient)
  * (each term optional: NULL pointer = absent).  Results:
  *     g_store[n,o] = G                    (optional; needed where `out` also feeds a residual connection)
- *     g_bias[o]   += sum_n G ;  g_weff[o,i] += sum_n G[n,o] act[n,i]      (gradient wrt the EFFECTIVE weight)
+ *     g_bias[o]   += sum_n G ;  g_weff[slab][o,i] = this workgroup's part of sum_n G[n,o] act[n,i]  (gradient wrt
+ *                    the EFFECTIVE weight; nf_linear_bwd_slabs(N) slabs, no zero-fill needed)
  *     gn_out[n,i]  = (sum_o G[n,o] Weff[o,i]) * [act[n,i] > 0]   and  sum_g[i] += sum_n gn_out,
  *     sum_gx[i]   += sum_n gn_out * xhat_in      (== g_beta, g_gamma of the input BatchNorm; the producer of `in`
  *                                                 finishes the BatchNorm backward on load)
@@ -224,7 +225,7 @@ typedef struct nf_linear_bwd_desc {
     const float* cbn_sum_gx;    /* (O,) */
     float* g_store;             /* (N, O) or NULL */
     float* g_bias;              /* (O,) += */
-    float* g_weff;              /* (O, I) += */
+    float* g_weff;              /* (nf_linear_bwd_slabs(N), O, I) written */
     float* gn_out;              /* (N, I) or NULL */
     float* sum_g;               /* (I,) += (with input BatchNorm) */
     float* sum_gx;              /* (I,) += */
@@ -232,18 +233,34 @@ typedef struct nf_linear_bwd_desc {
 int nf_linear_bn_bwd(const nf_linear_bwd_desc* descs, int n_nets, int64_t N, int I, int O, float wn_eps,
                      nf_stream_t stream);
 
-/* gradient of the effective weight -> gradients of the stored parameters, n_layers layers per launch:
+/* number of partial-sum slabs nf_linear_bn_bwd writes into g_weff for N rows (one per workgroup: the weight gradient
+ * is reduced without atomics, deterministically, by nf_weight_grad_finalize).                                      */
+int nf_linear_bwd_slabs(int64_t N);
+
+/* gradient of the effective weight -> gradients of the stored parameters, n_layers jobs per launch (one workgroup
+ * each).  g_weff holds n_slabs partial (O, I) sums from nf_linear_bn_bwd.
  *   mask != NULL    : g_weight = g_weff * mask                                         (maf.py:54)
- *   weight_g != NULL: weight-norm backward, g_weight (= g_v) and g_weight_g             (weight_norm.py:35-41)  */
+ *   weight_g != NULL: weight-norm backward, g_weight (= g_v) and g_weight_g             (weight_norm.py:35-41)
+ * plus up to two plain vector gradients finished in the same launch (a bias, or a BatchNorm's g_gamma / g_beta):
+ * vec_dst = vec_src.  accumulate != 0 turns every store into += (direct accumulation into a .grad buffer).
+ * g_weff == NULL: vector jobs only.                                                                               */
 typedef struct nf_weight_grad_desc {
-    const float* g_weff;    /* (O, I) */
+    const float* g_weff;    /* (n_slabs, O, I) or NULL */
     const float* weight;    /* (O, I) */
     const float* weight_g;  /* (I,) or NULL */
     const float* mask;      /* (O, I) or NULL */
-    float* g_weight;        /* (O, I) written */
-    float* g_weight_g;      /* (I,) written, or NULL */
+    float* g_weight;        /* (O, I) */
+    float* g_weight_g;      /* (I,) or NULL */
+    const float* vec_src0;
+    float* vec_dst0;
+    const float* vec_src1;
+    float* vec_dst1;
+    int vec_n0;
+    int vec_n1;
     int I;
     int O;
+    int n_slabs;
+    int accumulate;
 } nf_weight_grad_desc;
 int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, float wn_eps, nf_stream_t stream);
 
@@ -253,6 +270,13 @@ int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t
 /* autograd: g_z = g_loss[0] * z / B,  g_ld[b] = -g_loss[0] / B   (g_loss: device scalar) */
 int nf_nll_loss_bwd(const float* z, const float* g_loss, float* g_z, float* g_ld, int64_t B, int64_t D,
                     nf_stream_t stream);
+
+/* ---- fused Adam over flat buffers (torch.optim.Adam semantics, main.py:56-64) --------------------------------------
+ * step[0] += 1 (device int32), then for every i < n:  g = grad[i]*grad_scale + wd*p ; m,v moments ; p update with the
+ * bias corrections of step[0] and the learning rate lr[0] (device float, so hipGraph replays see new values).     */
+int nf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int* step, const float* lr,
+                 float beta1, float beta2, float eps, float weight_decay, float grad_scale, int64_t n,
+                 nf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __
                                                                  const float* __restrict__ sign_s,
                                                                  const float* __restrict__ log_s, const float* __restrict__ gld,
                                                                  float* __restrict__ gL, float* __restrict__ gU,
-                                                                 float* __restrict__ glog_s, int C, int64_t B, float pixels) {
+                                                                 float* __restrict__ glog_s, int accumulate, int C, int64_t B, float pixels) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float scratch[NF_BLOCK / NF_WAVE];
     __shared__ float sum_gld;
@@ -188,9 +188,9 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __
             gl = fmaf(A[r * C + k], Up[c * C + k], gl);          // (A U'^T)[r][c]
             gu = fmaf(Lp[k * C + r], A[k * C + c], gu);          // (L'^T A)[r][c]
         }
-        gL[e] = gl * Lmask[e];
-        gU[e] = gu * Umask[e];
-        if (r == c) glog_s[r] = gu * sign_s[r] * expf(log_s[r]) + pixels * sum_gld;
+        gL[e] = (accumulate ? gL[e] : 0.f) + gl * Lmask[e];
+        gU[e] = (accumulate ? gU[e] : 0.f) + gu * Umask[e];
+        if (r == c) glog_s[r] = (accumulate ? glog_s[r] : 0.f) + gu * sign_s[r] * expf(log_s[r]) + pixels * sum_gld;
     }
 }
 
@@ -254,11 +254,11 @@ extern "C" int nf_invconv_weight_fwd(const float* P, const float* L, const float
 
 extern "C" int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, const float* U,
                                      const float* L_mask, const float* U_mask, const float* sign_s, const float* log_s,
-                                     const float* g_ld, float* g_L, float* g_U, float* g_log_s, int C, int64_t B, int pixels,
-                                     nf_stream_t stream) {
+                                     const float* g_ld, float* g_L, float* g_U, float* g_log_s, int accumulate, int C, int64_t B,
+                                     int pixels, nf_stream_t stream) {
     if (C <= 0 || C > NF_PLU_MAXC) return C <= 0 ? NF_E_BADARG : NF_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_invconv_weight_bwd, dim3(1), dim3(NF_BLOCK), (size_t)3 * C * C * sizeof(float), (hipStream_t)stream,
-                       g_W, P, L, U, L_mask, U_mask, sign_s, log_s, g_ld, g_L, g_U, g_log_s, C, B, (float)pixels);
+                       g_W, P, L, U, L_mask, U_mask, sign_s, log_s, g_ld, g_L, g_U, g_log_s, accumulate, C, B, (float)pixels);
     NF_CHECK_LAUNCH();
     return 0;
 }

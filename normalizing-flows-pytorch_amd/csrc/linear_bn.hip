@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NF_LB_WAVES; ++w) t += Wred[(w * 32 + oo) * 32 + ii];
-            atomicAdd(d.g_weff + oo * I + ii, t);
+            d.g_weff[((int64_t)blockIdx.x * O + oo) * I + ii] = t;       // this workgroup's slab (no atomics, no zero-fill)
         }
     }
     if (wid == 0 && hs == 0) {
@@ -383,49 +383,69 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// g_weff -> gradients of the stored parameters (mask / weight-norm), one block per layer
+// g_weff slabs -> gradients of the stored parameters (mask / weight-norm) + plain vector gradients, one block per job
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NF_BLOCK) k_weight_grad_finalize(NfWGradArgs args, float wn_eps) {
+    __shared__ float gW[32 * 32];
     __shared__ float nrm2[32], dot[32];
     const nf_weight_grad_desc& d = args.d[blockIdx.x];
     const int I = d.I, O = d.O;
-    if (d.weight_g != nullptr) {
-        if (threadIdx.x < 32) {
-            const int i = threadIdx.x;
-            float a = 0.f, b = 0.f;
-            if (i < I)
-                for (int o = 0; o < O; ++o) {
-                    const float v = d.weight[o * I + i];
-                    a = fmaf(v, v, a);
-                    b = fmaf(d.g_weff[o * I + i], v, b);
-                }
-            nrm2[i] = a;
-            dot[i] = b;
+    const bool acc = d.accumulate != 0;
+    if (d.g_weff != nullptr) {
+        for (int e = threadIdx.x; e < O * I; e += blockDim.x) {           // deterministic slab reduction
+            float t = 0.f;
+            for (int sl = 0; sl < d.n_slabs; ++sl) t += d.g_weff[(int64_t)sl * O * I + e];
+            gW[e] = t;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < O * I; e += blockDim.x) {
-            const int i = e % I;
-            const float nrm = sqrtf(nrm2[i]), den = nrm + wn_eps, g = d.weight_g[i];
-            float gv = d.g_weff[e] * (g / den);
-            if (nrm > 0.f) gv -= d.weight[e] * (dot[i] * g / (den * den * nrm));
-            d.g_weight[e] = gv;
+        if (d.weight_g != nullptr) {
+            if (threadIdx.x < 32) {
+                const int i = threadIdx.x;
+                float a = 0.f, b = 0.f;
+                if (i < I)
+                    for (int o = 0; o < O; ++o) {
+                        const float v = d.weight[o * I + i];
+                        a = fmaf(v, v, a);
+                        b = fmaf(gW[o * I + i], v, b);
+                    }
+                nrm2[i] = a;
+                dot[i] = b;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < O * I; e += blockDim.x) {
+                const int i = e % I;
+                const float nrm = sqrtf(nrm2[i]), den = nrm + wn_eps, g = d.weight_g[i];
+                float gv = gW[e] * (g / den);
+                if (nrm > 0.f) gv -= d.weight[e] * (dot[i] * g / (den * den * nrm));
+                d.g_weight[e] = (acc ? d.g_weight[e] : 0.f) + gv;
+            }
+            if (d.g_weight_g != nullptr && (int)threadIdx.x < I) {
+                const int i = threadIdx.x;
+                d.g_weight_g[i] = (acc ? d.g_weight_g[i] : 0.f) + dot[i] / (sqrtf(nrm2[i]) + wn_eps);
+            }
+        } else {
+            for (int e = threadIdx.x; e < O * I; e += blockDim.x)
+                d.g_weight[e] = (acc ? d.g_weight[e] : 0.f) + (d.mask != nullptr ? gW[e] * d.mask[e] : gW[e]);
         }
-        if (d.g_weight_g != nullptr && threadIdx.x < I) {
-            const int i = threadIdx.x;
-            d.g_weight_g[i] = dot[i] / (sqrtf(nrm2[i]) + wn_eps);
-        }
-    } else {
-        for (int e = threadIdx.x; e < O * I; e += blockDim.x)
-            d.g_weight[e] = d.mask != nullptr ? d.g_weff[e] * d.mask[e] : d.g_weff[e];
     }
+    if (d.vec_dst0 != nullptr)
+        for (int e = threadIdx.x; e < d.vec_n0; e += blockDim.x) d.vec_dst0[e] = (acc ? d.vec_dst0[e] : 0.f) + d.vec_src0[e];
+    if (d.vec_dst1 != nullptr)
+        for (int e = threadIdx.x; e < d.vec_n1; e += blockDim.x) d.vec_dst1[e] = (acc ? d.vec_dst1[e] : 0.f) + d.vec_src1[e];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static inline unsigned nf_lb_grid(int64_t tiles) {
+static inline unsigned nf_lb_grid(int64_t tiles, int64_t cap = 1024) {
     int64_t g = (tiles + NF_LB_WAVES - 1) / NF_LB_WAVES;
     if (g < 1) g = 1;
-    if (g > 1024) g = 1024;
+    if (g > cap) g = cap;
     return (unsigned)g;
+}
+
+#define NF_LB_BWD_MAX_SLABS 256
+extern "C" int nf_linear_bwd_slabs(int64_t N) {
+    if (N <= 0) return 0;
+    return (int)nf_lb_grid((N + 31) / 32, NF_LB_BWD_MAX_SLABS);
 }
 
 extern "C" int nf_linear_bn_fwd(const nf_linear_desc* descs, int n_nets, int64_t N, int I, int O, int training,
@@ -456,7 +476,7 @@ extern "C" int nf_linear_bn_bwd(const nf_linear_bwd_desc* descs, int n_nets, int
     NfLinBwdArgs args;
     for (int i = 0; i < n_nets; ++i) args.d[i] = descs[i];
     const int64_t tiles = (N + 31) / 32;
-    const unsigned gx = nf_lb_grid(tiles);
+    const unsigned gx = nf_lb_grid(tiles, NF_LB_BWD_MAX_SLABS);
     const int iters = (int)((tiles + (int64_t)gx * NF_LB_WAVES - 1) / ((int64_t)gx * NF_LB_WAVES));
     hipLaunchKernelGGL(k_linear_bn_bwd, dim3(gx, (unsigned)n_nets), dim3(NF_LB_WAVES * NF_WAVE), 0, (hipStream_t)stream,
                        args, N, I, O, wn_eps, tiles, iters);
@@ -469,7 +489,8 @@ extern "C" int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_l
     if (descs == nullptr || n_layers < 1 || n_layers > NF_MAX_WG_LAYERS) return NF_E_BADARG;
     NfWGradArgs args;
     for (int i = 0; i < n_layers; ++i) {
-        if (descs[i].I < 1 || descs[i].O < 1 || descs[i].I > 32 || descs[i].O > 32) return NF_E_BADARG;
+        if (descs[i].g_weff != nullptr && (descs[i].I < 1 || descs[i].O < 1 || descs[i].I > 32 || descs[i].O > 32))
+            return NF_E_BADARG;
         args.d[i] = descs[i];
     }
     hipLaunchKernelGGL(k_weight_grad_finalize, dim3((unsigned)n_layers), dim3(NF_BLOCK), 0, (hipStream_t)stream, args,

@@ -41,23 +41,35 @@ def shard(batch, rank, world):
 
 class GradBucket:
     """All trainable parameters' gradients live in ONE flat fp32 buffer (``p.grad`` are views into it), so the
-    gradient exchange is a single collective and zeroing the gradients is a single memset.
+    gradient exchange is a single collective and zeroing the gradients is a single memset.  With
+    ``flatten_params=True`` the parameters themselves are re-homed into one flat buffer too (``p.data`` become views;
+    values preserved), which lets the optimizer step be a single fused kernel (FlatAdam).
 
     Frozen parameters (``requires_grad=False``: P, I, masks, sign_s, int32 pivots of the invertible 1x1 convolution)
-    carry no gradient and are skipped."""
+    carry no gradient and are skipped.
 
-    def __init__(self, params, process_group=None):
+    Every bucketed parameter is tagged ``_nf_direct_grad = True``: the hand-written backward kernels may then
+    accumulate straight into ``p.grad`` (the same ``+=`` autograd's AccumulateGrad would perform) instead of
+    returning a temporary that costs one extra add launch per parameter."""
+
+    def __init__(self, params, process_group=None, flatten_params=False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
         dev, dt = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.flat_params = torch.empty(self.numel, dtype=dt, device=dev) if flatten_params else None
         self.group = process_group
         o = 0
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[o:o + n].view_as(p)
+            if flatten_params:
+                with torch.no_grad():
+                    self.flat_params[o:o + n].copy_(p.data.reshape(-1))
+                    p.data = self.flat_params[o:o + n].view_as(p)
+            p._nf_direct_grad = True
             o += n
 
     @property

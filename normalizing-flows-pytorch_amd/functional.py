@@ -38,6 +38,24 @@ def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def grad_sink(p):
+    """the buffer a hand-written backward may accumulate into directly instead of returning a temporary: ``p.grad`` of a
+    parameter that a GradBucket tagged (``_nf_direct_grad``).  Same ``+=`` semantics as autograd's AccumulateGrad, one
+    launch less per parameter.  None -> return the gradient to autograd as usual."""
+    if not getattr(p, '_nf_direct_grad', False):
+        return None
+    g = p.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.device != p.device:
+        return None
+    return g
+
+
+def _sinks(*params):
+    """all-or-nothing list of gradient sinks for the parameters of one op."""
+    out = [grad_sink(p) for p in params]
+    return out if all(t is not None for t in out) else None
+
+
 def _owned_ld(ld, *others):
     """ld is mutated in place; a leaf that requires grad (never the case in the models) gets copied first."""
     if ld.requires_grad and ld.is_leaf:
@@ -116,6 +134,7 @@ class _AffineCoupling(torch.autograd.Function):
                N.ptr(ld), mode, int(odd), 0, B, C, H, W, N.stream())
         ctx.save_for_backward(z, t, s_raw, a, c)
         ctx.meta = (pbs, mode, int(odd))
+        ctx.sinks = _sinks(a, c)
         ctx.mark_dirty(ld)
         return y, ld
 
@@ -128,11 +147,15 @@ class _AffineCoupling(torch.autograd.Function):
         g_z = torch.empty_like(z)
         g_t = torch.empty_like(t)
         g_s = torch.empty_like(s_raw)
-        g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+        if ctx.sinks is not None:
+            pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
+        else:
+            g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+            pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
+            ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
         N.call('nf_affine_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(t), N.ptr(s_raw), pbs, N.ptr(a),
-               N.ptr(c), N.ptr(g_z), N.ptr(g_t), N.ptr(g_s), g_ac.data_ptr(), g_ac.data_ptr() + 4, mode, odd, B, C, H,
-               W, N.stream())
-        return g_z, g_t, g_s, None, g_ac[0:1].view_as(a), g_ac[1:2].view_as(c), g_ld, None, None
+               N.ptr(c), N.ptr(g_z), N.ptr(g_t), N.ptr(g_s), pa, pc, mode, odd, B, C, H, W, N.stream())
+        return g_z, g_t, g_s, None, ga, gc, g_ld, None, None
 
 
 class _AffineCouplingPacked(torch.autograd.Function):
@@ -147,6 +170,7 @@ class _AffineCouplingPacked(torch.autograd.Function):
                N.ptr(c), N.ptr(y), N.ptr(ld), mode, int(odd), 0, B, C, H, W, N.stream())
         ctx.save_for_backward(z, params, a, c)
         ctx.meta = (n_half, mode, int(odd))
+        ctx.sinks = _sinks(a, c)
         ctx.mark_dirty(ld)
         return y, ld
 
@@ -158,11 +182,16 @@ class _AffineCouplingPacked(torch.autograd.Function):
         g_y, g_ld = _contig(g_y), _contig(g_ld)
         g_z = torch.empty_like(z)
         g_p = torch.empty_like(params)
-        g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+        if ctx.sinks is not None:
+            pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
+        else:
+            g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+            pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
+            ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
         N.call('nf_affine_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params),
                params.data_ptr() + 4 * n_half, 2 * n_half, N.ptr(a), N.ptr(c), N.ptr(g_z), N.ptr(g_p),
-               g_p.data_ptr() + 4 * n_half, g_ac.data_ptr(), g_ac.data_ptr() + 4, mode, odd, B, C, H, W, N.stream())
-        return g_z, g_p, g_ac[0:1].view_as(a), g_ac[1:2].view_as(c), g_ld, None, None
+               g_p.data_ptr() + 4 * n_half, pa, pc, mode, odd, B, C, H, W, N.stream())
+        return g_z, g_p, ga, gc, g_ld, None, None
 
 
 def affine_coupling(z, params, s_log_scale, s_bias, ld, mode, odd, inverse=False):
@@ -220,6 +249,7 @@ class _ChanAffine(torch.autograd.Function):
                B, C, P, N.stream())
         ctx.op = op
         ctx.save_for_backward(x, p0, p1, p2, p3)
+        ctx.sinks = _sinks(p0, p1) if op == N.OP_ACTNORM else (_sinks(p2, p3) if p2 is not None else None)
         ctx.mark_dirty(ld)
         return y, ld
 
@@ -232,14 +262,17 @@ class _ChanAffine(torch.autograd.Function):
         g_x = torch.empty_like(x)
         pa, pb = (p0, p1) if op == N.OP_ACTNORM else (p2, p3)
         want = ctx.needs_input_grad[3 if op == N.OP_ACTNORM else 5]
-        if want:
+        ga = gb = None
+        if want and ctx.sinks is not None:
+            ga_ptr, gb_ptr = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr()
+        elif want:
             g_ab = torch.zeros((2, ) + tuple(pa.shape), dtype=x.dtype, device=x.device)
             ga_ptr, gb_ptr = g_ab.data_ptr(), g_ab.data_ptr() + 4 * pa.numel()
+            ga, gb = g_ab[0], g_ab[1]
         else:
-            g_ab, ga_ptr, gb_ptr = None, None, None
+            ga_ptr, gb_ptr = None, None
         N.call('nf_chan_affine_bwd', op, N.ptr(g_y), N.ptr(g_ld), N.ptr(x), N.ptr(p0), N.ptr(p1), N.ptr(p2), N.ptr(p3),
                N.ptr(g_x), ga_ptr, gb_ptr, B, C, P, N.stream())
-        ga, gb = (g_ab[0], g_ab[1]) if want else (None, None)
         if op == N.OP_ACTNORM:
             return None, g_x, g_ld, ga, gb, None, None
         return None, g_x, g_ld, None, None, ga, gb
@@ -345,6 +378,7 @@ class _InvConvPLU(torch.autograd.Function):
         y = torch.empty_like(z)
         N.call('nf_invconv_apply', N.ptr(z), N.ptr(W), 0, N.ptr(y), N.ptr(ld), N.ptr(log_s), 1.0, B, C, Px, N.stream())
         ctx.save_for_backward(z, W, P, L, U, L_mask, U_mask, sign_s, log_s)
+        ctx.sinks = _sinks(L, U, log_s)
         ctx.mark_dirty(ld)
         return y, ld
 
@@ -359,9 +393,13 @@ class _InvConvPLU(torch.autograd.Function):
             N.call('nf_invconv_apply', N.ptr(g_y), N.ptr(W), 1, N.ptr(g_z), None, None, 0.0, B, C, Px, N.stream())
         g_W = torch.zeros_like(W)
         N.call('nf_invconv_wgrad', N.ptr(g_y), N.ptr(z), N.ptr(g_W), B, C, Px, N.stream())
-        g_L, g_U, g_ls = torch.empty_like(L), torch.empty_like(U), torch.empty_like(log_s)
+        direct = ctx.sinks is not None
+        g_L, g_U, g_ls = ctx.sinks if direct else (torch.empty_like(L), torch.empty_like(U), torch.empty_like(log_s))
         N.call('nf_invconv_weight_bwd', N.ptr(g_W), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask),
-               N.ptr(sign_s), N.ptr(log_s), N.ptr(g_ld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_ls), C, B, Px, N.stream())
+               N.ptr(sign_s), N.ptr(log_s), N.ptr(g_ld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_ls), int(direct), C, B, Px,
+               N.stream())
+        if direct:
+            return g_z, g_ld, None, None, None, None, None, None, None
         return g_z, g_ld, None, g_L, g_U, None, None, None, g_ls
 
 
@@ -421,6 +459,7 @@ class _MixLogCoupling(torch.autograd.Function):
                mode, int(odd), B, C, H, W, N.stream())
         ctx.save_for_backward(z, params, a, c)
         ctx.meta = (K, float(eps), mode, int(odd))
+        ctx.sinks = _sinks(a, c)
         ctx.mark_dirty(ld)
         return y, ld
 
@@ -432,10 +471,15 @@ class _MixLogCoupling(torch.autograd.Function):
         g_y, g_ld = _contig(g_y), _contig(g_ld)
         g_z = torch.empty_like(z)
         g_p = torch.empty_like(params)
-        g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+        if ctx.sinks is not None:
+            pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
+        else:
+            g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+            pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
+            ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
         N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c),
-               N.ptr(g_z), N.ptr(g_p), g_ac.data_ptr(), g_ac.data_ptr() + 4, K, eps, mode, odd, B, C, H, W, N.stream())
-        return g_z, g_p, g_ac[0:1].view_as(a), g_ac[1:2].view_as(c), g_ld, None, None, None, None
+               N.ptr(g_z), N.ptr(g_p), pa, pc, K, eps, mode, odd, B, C, H, W, N.stream())
+        return g_z, g_p, ga, gc, g_ld, None, None, None, None
 
 
 def mixlog_coupling(z, params, a_log_scale, a_bias, ld, n_mixtures, mode, odd, inverse=False, logit_eps=1.0e-5):

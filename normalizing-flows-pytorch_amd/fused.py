@@ -25,7 +25,9 @@ _LIN_FIELDS = ['in_', 'weight', 'weight_g', 'mask', 'bias', 'residual', 'out', '
 _BWD_FIELDS = ['in_', 'weight', 'weight_g', 'mask', 'bn_gamma', 'bn_beta', 'bn_save_mean', 'bn_save_invstd', 'g_direct',
                'g_skip', 'gn_src', 'out', 'cbn_gamma', 'cbn_save_mean', 'cbn_save_invstd', 'cbn_sum_g', 'cbn_sum_gx',
                'g_store', 'g_bias', 'g_weff', 'gn_out', 'sum_g', 'sum_gx']
-_WG_FIELDS = ['g_weff', 'weight', 'weight_g', 'mask', 'g_weight', 'g_weight_g']
+_WG_FIELDS = ['g_weff', 'weight', 'weight_g', 'mask', 'g_weight', 'g_weight_g', 'vec_src0', 'vec_dst0', 'vec_src1',
+              'vec_dst1']
+_WG_INTS = ['vec_n0', 'vec_n1', 'I', 'O', 'n_slabs', 'accumulate']
 
 
 class LinearDesc(ctypes.Structure):
@@ -37,7 +39,7 @@ class LinearBwdDesc(ctypes.Structure):
 
 
 class WeightGradDesc(ctypes.Structure):
-    _fields_ = [(f, ctypes.c_void_p) for f in _WG_FIELDS] + [('I', ctypes.c_int), ('O', ctypes.c_int)]
+    _fields_ = [(f, ctypes.c_void_p) for f in _WG_FIELDS] + [(f, ctypes.c_int) for f in _WG_INTS]
 
 
 def _p(t):
@@ -67,8 +69,22 @@ def _launch_wgrad(descs):
     N.call('nf_weight_grad_finalize', ctypes.addressof(arr), len(descs), WN_EPS, N.stream())
 
 
-def fusable(*dims):
-    return all(1 <= d <= 32 for d in dims)
+def bwd_slabs(Nrows):
+    return int(N.load().nf_linear_bwd_slabs(Nrows))
+
+
+def _finalize_jobs(lin_jobs, bn_jobs, slabs, direct):
+    """descriptor list of nf_weight_grad_finalize.  lin_jobs: (g_weff, weight, weight_g|None, mask|None, g_bias_src, dst
+    triple (g_weight, g_weight_g|None, g_bias)); bn_jobs: (sum_gx, sum_g, dst pair (g_gamma, g_beta))."""
+    descs = []
+    for g_weff, W, Wg, M, gb_src, (dW, dWg, dB) in lin_jobs:
+        descs.append(_desc(WeightGradDesc, g_weff=g_weff, weight=W, weight_g=Wg, mask=M, g_weight=dW, g_weight_g=dWg,
+                           vec_src0=gb_src, vec_dst0=dB, vec_n0=W.shape[0], I=W.shape[1], O=W.shape[0], n_slabs=slabs,
+                           accumulate=int(direct)))
+    for s_gx, s_g, (dG, dBt) in bn_jobs:
+        descs.append(_desc(WeightGradDesc, vec_src0=s_gx, vec_dst0=dG, vec_n0=dG.numel(), vec_src1=s_g, vec_dst1=dBt,
+                           vec_n1=dBt.numel(), I=1, O=1, n_slabs=0, accumulate=int(direct)))
+    return descs
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -110,6 +126,8 @@ class _FusedMLP(torch.autograd.Function):
                            bias=lin[nl - 1][2], out=out, **bn_kw(nb - 1))], Nrows, H, O_out, training)
         ctx.save_for_backward(x, ws, *acts, *[t for l in lin for t in l[:2]], *[t for b in bns for t in b[:2]])
         ctx.meta = (n_blocks, Nrows, I0, O_out, bool(training))
+        from .functional import _sinks
+        ctx.sinks = _sinks(*[t for l in lin for t in l], *[t for b in bns for t in b[:2]])
         return out
 
     @staticmethod
@@ -127,17 +145,13 @@ class _FusedMLP(torch.autograd.Function):
         beta = [gb[2 * i + 1] for i in range(nb)]
         dev = x.device
         g_out = g_out.contiguous()
-        # zero-initialised accumulators: g_weff / g_bias per linear, (sum_g, sum_gx) per BatchNorm
-        sizes = [V[i].numel() for i in range(nl)]
-        acc = torch.zeros(sum(sizes) + nl * H + nb * 2 * H, dtype=torch.float32, device=dev)
-        o = 0
-        g_weff = []
-        for i in range(nl):
-            g_weff.append(acc[o:o + sizes[i]])
-            o += sizes[i]
-        g_bias = [acc[o + i * H:o + i * H + V[i].shape[0]] for i in range(nl)]
-        o += nl * H
-        sums = acc[o:].view(nb, 2, H)
+        # g_weff: per-workgroup slabs (written, reduced by the finalize launch); zero-initialised atomically
+        # accumulated vectors: g_bias per linear, (sum_g, sum_gx) per BatchNorm
+        slabs = bwd_slabs(Nrows)
+        g_weff = list(torch.empty(nl, slabs * H * H, dtype=torch.float32, device=dev).unbind(0))
+        acc = torch.zeros(nl * H + nb * 2 * H, dtype=torch.float32, device=dev)
+        g_bias = [acc[i * H:i * H + V[i].shape[0]] for i in range(nl)]
+        sums = acc[nl * H:].view(nb, 2, H)
         gn = [torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nb)]
         g_x = torch.empty(Nrows, I0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         G_skip = None                              # assembled gradient of the latest residual-stream tensor
@@ -164,15 +178,24 @@ class _FusedMLP(torch.autograd.Function):
                 G_skip = store
         _launch_bwd([_desc(LinearBwdDesc, in_=x, weight=V[0], weight_g=G[0], gn_src=gn[0], out=acts[0], g_skip=G_skip,
                            g_bias=g_bias[0], g_weff=g_weff[0], gn_out=g_x, **cons_bn(0))], Nrows, I0, H)
-        g_v = [torch.empty_like(V[i]) for i in range(nl)]
-        g_g = [torch.empty_like(G[i]) for i in range(nl)]
-        _launch_wgrad([_desc(WeightGradDesc, g_weff=g_weff[i], weight=V[i], weight_g=G[i], g_weight=g_v[i],
-                             g_weight_g=g_g[i], I=V[i].shape[1], O=V[i].shape[0]) for i in range(nl)])
+        direct = ctx.sinks is not None
+        if direct:                                 # accumulate straight into the .grad buffers (GradBucket-tagged)
+            dst_lin = [tuple(ctx.sinks[3 * i:3 * i + 3]) for i in range(nl)]
+            dst_bn = [tuple(ctx.sinks[3 * nl + 2 * j:3 * nl + 2 * j + 2]) for j in range(nb)]
+        else:
+            dst_lin = [(torch.empty_like(V[i]), torch.empty_like(G[i]),
+                        torch.empty(V[i].shape[0], dtype=torch.float32, device=dev)) for i in range(nl)]
+            dst_bn = [(torch.empty(H, dtype=torch.float32, device=dev), torch.empty(H, dtype=torch.float32, device=dev))
+                      for _ in range(nb)]
+        _launch_wgrad(_finalize_jobs([(g_weff[i], V[i], G[i], None, g_bias[i], dst_lin[i]) for i in range(nl)],
+                                     [(sums[j, 1], sums[j, 0], dst_bn[j]) for j in range(nb)], slabs, direct))
+        if direct:
+            return (g_x, None, None) + (None, ) * (3 * nl + 5 * nb)
         grads = []
         for i in range(nl):
-            grads += [g_v[i], g_g[i], g_bias[i]]
+            grads += list(dst_lin[i])
         for j in range(nb):
-            grads += [sums[j, 1], sums[j, 0], None, None, None]            # g_gamma, g_beta
+            grads += [dst_bn[j][0], dst_bn[j][1], None, None, None]        # g_gamma, g_beta
         return (g_x, None, None) + tuple(grads)
 
 
@@ -238,6 +261,13 @@ class _FusedMADEPair(torch.autograd.Function):
             keep += [BN(n, j)[0] for j in range(nh)] + [BN(n, j)[1] for j in range(nh)]
         ctx.save_for_backward(*keep)
         ctx.meta = (nh, Nrows, D, bool(training))
+        from .functional import _sinks
+        sink_in = []
+        for n in range(2):
+            sink_in += [W(n, l) for l in range(nh + 1)] + [Bs(n, l) for l in range(nh + 1)]
+            for j in range(nh):
+                sink_in += list(BN(n, j)[:2])
+        ctx.sinks = _sinks(*sink_in)
         return outs[0], outs[1]
 
     @staticmethod
@@ -253,19 +283,15 @@ class _FusedMADEPair(torch.autograd.Function):
             nets.append(dict(acts=blk[:nh], W=blk[nh:2 * nh + 1], M=blk[2 * nh + 1:3 * nh + 2],
                              gamma=blk[3 * nh + 2:4 * nh + 2], beta=blk[4 * nh + 2:5 * nh + 2]))
         g_outs = [g_s.contiguous(), g_t.contiguous()]
-        sizes = [nets[0]['W'][l].numel() for l in range(nh + 1)]
-        per_acc = sum(sizes) + (nh + 1) * H + nh * 2 * H
+        slabs = bwd_slabs(Nrows)
+        gw_all = torch.empty(2, nh + 1, slabs * H * H, dtype=torch.float32, device=dev)
+        per_acc = (nh + 1) * H + nh * 2 * H
         acc = torch.zeros(2, per_acc, dtype=torch.float32, device=dev)
         g_weff, g_bias, sums = [], [], []
         for n in range(2):
-            o, gw = 0, []
-            for l in range(nh + 1):
-                gw.append(acc[n, o:o + sizes[l]])
-                o += sizes[l]
-            g_weff.append(gw)
-            g_bias.append([acc[n, o + l * H:o + l * H + nets[n]['W'][l].shape[0]] for l in range(nh + 1)])
-            o += (nh + 1) * H
-            sums.append(acc[n, o:].view(nh, 2, H))
+            g_weff.append([gw_all[n, l] for l in range(nh + 1)])
+            g_bias.append([acc[n, l * H:l * H + nets[n]['W'][l].shape[0]] for l in range(nh + 1)])
+            sums.append(acc[n, (nh + 1) * H:].view(nh, 2, H))
         gn = [[torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nh)] for _ in range(2)]
         g_z = [torch.empty(Nrows, D, dtype=torch.float32, device=dev) for _ in range(2)]
 
@@ -289,17 +315,29 @@ class _FusedMADEPair(torch.autograd.Function):
         _launch_bwd([_desc(LinearBwdDesc, in_=z, weight=nets[n]['W'][0], mask=nets[n]['M'][0], gn_src=gn[n][0],
                            out=nets[n]['acts'][0], g_bias=g_bias[n][0], g_weff=g_weff[n][0], gn_out=g_z[n],
                            **cons_bn(n, 0)) for n in range(2)], Nrows, D, H)
-        g_W = [[torch.empty_like(nets[n]['W'][l]) for l in range(nh + 1)] for n in range(2)]
-        _launch_wgrad([_desc(WeightGradDesc, g_weff=g_weff[n][l], weight=nets[n]['W'][l], mask=nets[n]['M'][l],
-                             g_weight=g_W[n][l], I=nets[n]['W'][l].shape[1], O=nets[n]['W'][l].shape[0])
-                       for n in range(2) for l in range(nh + 1)])
-        grads = []
+        direct = ctx.sinks is not None
+        per_sink = 2 * (nh + 1) + 2 * nh
+        lin_jobs, bn_jobs, ret = [], [], []
         for n in range(2):
-            grads += g_W[n] + g_bias[n] + [None] * (nh + 1)
+            if direct:
+                sk = ctx.sinks[n * per_sink:(n + 1) * per_sink]
+                dW, dB, dBN = sk[:nh + 1], sk[nh + 1:2 * nh + 2], sk[2 * nh + 2:]
+            else:
+                dW = [torch.empty_like(nets[n]['W'][l]) for l in range(nh + 1)]
+                dB = [torch.empty(nets[n]['W'][l].shape[0], dtype=torch.float32, device=dev) for l in range(nh + 1)]
+                dBN = [torch.empty(H, dtype=torch.float32, device=dev) for _ in range(2 * nh)]
+            for l in range(nh + 1):
+                lin_jobs.append((g_weff[n][l], nets[n]['W'][l], None, nets[n]['M'][l], g_bias[n][l], (dW[l], None, dB[l])))
             for j in range(nh):
-                grads += [sums[n][j, 1], sums[n][j, 0], None, None, None]
+                bn_jobs.append((sums[n][j, 1], sums[n][j, 0], (dBN[2 * j], dBN[2 * j + 1])))
+            ret += list(dW) + list(dB) + [None] * (nh + 1)
+            for j in range(nh):
+                ret += [dBN[2 * j], dBN[2 * j + 1], None, None, None]
+        _launch_wgrad(_finalize_jobs(lin_jobs, bn_jobs, slabs, direct))
         g_in = g_z[0] + g_z[1] if ctx.needs_input_grad[0] else None
-        return (g_in, None, None) + tuple(grads)
+        if direct:
+            return (g_in, None, None) + (None, ) * len(ret)
+        return (g_in, None, None) + tuple(ret)
 
 
 def made_pair_forward(net_s, net_t, z, masks_s, masks_t):

@@ -33,6 +33,41 @@ def bits_per_dim(loss, dims):
     return float(loss) / (D * math.log(2.0))
 
 
+class FlatAdam:
+    """torch.optim.Adam semantics (the reference's optimizer, main.py:56-64) as ONE fused HIP launch over the flat
+    parameter / gradient buffers of a GradBucket.  ``lr`` and the step counter live on the device, so a captured
+    hipGraph keeps working when a scheduler changes the rate (``set_lr``)."""
+
+    def __init__(self, bucket, lr=1.0e-4, betas=(0.9, 0.999), eps=1.0e-8, weight_decay=0.0):
+        if bucket.flat_params is None:
+            raise ValueError('FlatAdam needs GradBucket(..., flatten_params=True)')
+        from . import _native as N
+        self._N = N
+        self.bucket = bucket
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        dev = bucket.flat.device
+        self.exp_avg = torch.zeros_like(bucket.flat)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr = torch.full((1, ), float(lr), dtype=torch.float32, device=dev)
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    def step(self):
+        N, b = self._N, self.bucket
+        N.call('nf_adam_step', N.ptr(b.flat_params), N.ptr(b.flat), N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq),
+               N.ptr(self.step_count), N.ptr(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0,
+               b.numel, N.stream())
+
+    def state_dict(self):
+        return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'step': self.step_count, 'lr': self.lr}
+
+    def load_state_dict(self, sd):
+        for k, t in self.state_dict().items():
+            t.copy_(sd[k])
+
+
 class FlowTrainer:
     """Adam (lr 1e-4, betas (0.9, 0.999): configs/default.yaml:13-20) on the NLL, gradients in one flat bucket.
 
@@ -40,12 +75,18 @@ class FlowTrainer:
     (the gradient all-reduce runs between the two replays), after ``warmup`` eager steps that also perform the
     data-dependent ActNorm initialisation.  The batch shape is then fixed."""
 
-    def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None):
+    def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None,
+                 fused_adam=True):
         self.net = net
-        self.bucket = nfdist.GradBucket(net.parameters(), process_group)
+        on_gpu = next(net.parameters()).is_cuda
+        fused_adam = bool(fused_adam) and on_gpu
+        self.bucket = nfdist.GradBucket(net.parameters(), process_group, flatten_params=fused_adam)
         self.graph = bool(graph)
-        self.optim = torch.optim.Adam(self.bucket.params, lr=lr, betas=betas, weight_decay=weight_decay,
-                                      capturable=self.graph, foreach=True)
+        if fused_adam:
+            self.optim = FlatAdam(self.bucket, lr=lr, betas=betas, weight_decay=weight_decay)
+        else:
+            self.optim = torch.optim.Adam(self.bucket.params, lr=lr, betas=betas, weight_decay=weight_decay,
+                                          capturable=self.graph, foreach=True)
         self.warmup = warmup
         self._eager_steps = 0
         self._g_fb = self._g_opt = None

@@ -87,3 +87,5 @@ def test_ctypes_struct_layout_matches_header(pkg):
         assert got == names, (struct, got, names)
         for (n, ty), decl in zip(cls._fields_, [f.strip() for f in body.split(';') if f.strip()]):
             assert ('*' in decl) == (ty is ctypes.c_void_p), decl
+            if '*' not in decl:
+                assert decl.startswith('int ') and ty is ctypes.c_int, decl

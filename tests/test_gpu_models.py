@@ -68,3 +68,38 @@ def test_model_golden(pkg, name):
         x, ldi = net.backward(g['eval/z'].clone())
         G.assert_close(x, g['eval/x_inv'], tol_inv, what='eval x_inv')
         G.assert_close(ldi, g['eval/ld_inv'], 10 * tol_inv, what='eval ld_inv')
+
+
+@pytest.mark.parametrize('name', ['glow2d', 'realnvp2d', 'maf2d', 'flowpp2d', 'glow_img'])
+def test_model_golden_direct_grad_bucket(pkg, name):
+    """same gradients when the backward kernels accumulate straight into the flat GradBucket (parameters re-homed
+    into one flat buffer, fused NLL) -- the configuration the trainer and bench.py run."""
+    import importlib
+    nfdist = importlib.import_module(pkg.__name__ + '.dist')
+    train = importlib.import_module(pkg.__name__ + '.train')
+    net, g, kind, dims = _build(pkg, name)
+    bucket = nfdist.GradBucket(net.parameters(), flatten_params=True)
+    sd0 = G.group('model_' + name, 'sd0/', DEV)
+    for k, p in net.named_parameters():                       # re-homing preserved the values
+        assert torch.equal(p.detach(), sd0[k]), k
+    net.train()
+    np.random.seed(100)
+    for rep in range(2):                                      # twice: zeroing + accumulation semantics
+        if rep == 1:
+            net.load_state_dict(G.group('model_' + name, 'sd0/'))
+            for m in net.modules():
+                if hasattr(m, 'initialized'):
+                    m.initialized = False
+        bucket.zero_()
+        z, ld = net(g['y'].clone())
+        loss = train.nll_loss(z, ld)
+        loss.backward()
+        G.assert_close(loss, g['train/loss'], TOL * max(1.0, abs(float(g['train/loss'])) / np.prod(dims)), what='loss')
+        for k, p in net.named_parameters():
+            if 'grad/' + k in g:
+                want = g['grad/' + k]
+                noise = kind == 'maf' and '.biases.' in k and not k.endswith('.biases.3')
+                scale = max(1.0, float(want.abs().max()))
+                tol = 2e-3 if noise else (1e-4 if kind == 'maf' else 2 * TOL) * scale
+                G.assert_close(p.grad, want, tol, what='%s (rep %d)' % (k, rep))
+                assert p.grad.data_ptr() >= bucket.flat.data_ptr()

@@ -399,3 +399,28 @@ def test_nll_loss_vs_reference_formula(nf):
         G.assert_close(got, want, 1e-5 * max(1.0, abs(float(want)) / D * D ** 0.5))
         G.assert_close(zd.grad, zr.grad, 1e-7, rtol=1e-5)
         G.assert_close(ldv.grad, lr.grad, 1e-7, rtol=1e-5)
+
+
+def test_flat_adam_matches_torch_adam(pkg):
+    import importlib
+    nfdist = importlib.import_module(pkg.__name__ + '.dist')
+    train = importlib.import_module(pkg.__name__ + '.train')
+    torch.manual_seed(0)
+    shapes = [(32, 32), (32, ), (1, ), (2, 32), (1, 2, 1, 1)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    bucket = nfdist.GradBucket(pa, flatten_params=True)
+    opt_a = train.FlatAdam(bucket, lr=1e-2, weight_decay=0.01)
+    opt_b = torch.optim.Adam(pb, lr=1e-2, weight_decay=0.01)
+    for it in range(5):
+        bucket.zero_()
+        opt_b.zero_grad()
+        for a, b in zip(pa, pb):
+            g = torch.randn(a.shape, device=DEV)
+            a.grad.add_(g)
+            b.grad = g.clone()
+        opt_a.step()
+        opt_b.step()
+        for a, b in zip(pa, pb):
+            G.assert_close(a, b, 2e-6, rtol=2e-6, what='adam step %d' % it)
+    assert int(opt_a.step_count) == 5
