@@ -122,6 +122,23 @@ int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, cons
                           const float* U_mask, const float* sign_s, const float* log_s, const float* g_ld, float* g_L,
                           float* g_U, float* g_log_s, int accumulate, int C, int64_t B, int pixels, nf_stream_t stream);
 
+/* ---- fused head of a Glow flow step for C <= 4 (2-D data, 1..4 channel images) -------------------------------------
+ * forward : h = W ((z - bias) / exp(log_scale)) per pixel with W = P L' U' assembled in-kernel; z1c = the contiguous
+ *           conditioning half of h (what the coupling's conditioner reads); ld[b] += pixels*(sum log_s - sum
+ *           log_scale); W_out (C x C, nullable) receives W for the backward pass.
+ *           = ActNorm.forward + InvertibleConv1x1.forward + the split gather  (modules.py:246-250, :470-482,
+ *           coupling.py:33) in one launch.
+ * backward: G = g_h + scatter(g_z1c) (g_z1c nullable); g_z = (W^T G) / exp(log_scale); g_log_scale, g_bias, g_W are
+ *           ACCUMULATED (+=, caller zero-fills or passes .grad buffers); g_W then feeds nf_invconv_weight_bwd
+ *           (which also adds the pixels * sum g_ld term of log_s).                                                   */
+int nf_glow_head_fwd(const float* z, const float* log_scale, const float* bias, const float* P, const float* L,
+                     const float* U, const float* L_mask, const float* U_mask, const float* sign_s, const float* log_s,
+                     float* h, float* z1c, float* W_out, float* ld, int mode, int odd, int64_t B, int C, int H, int W,
+                     nf_stream_t stream);
+int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z, const float* log_scale,
+                     const float* bias, const float* W_saved, float* g_z, float* g_log_scale, float* g_bias, float* g_W,
+                     int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+
 /* ---- Logit  modules.py:141-156 --------------------------------------------------------------------------------
  * forward: xc = clamp(x, eps, 1-eps); y = log(xc/(1-xc)); ld[b] += sum -(y - 2 softplus(y))
  * inverse: y = sigmoid(x); ld[b] += sum (x - 2 softplus(x)).      n = elements per sample.                       */

@@ -1,0 +1,224 @@
+// Fused head of a Glow flow step for small channel counts (2-D data and C <= 4 images):
+//   ActNorm -> invertible 1x1 (PLU weight assembled in-kernel) -> gather of the conditioning half,
+//   flows/modules.py:246-250 + :470-482 + flows/coupling.py:33 / flows/squeeze.py  in ONE launch, and its autograd
+//   (scatter-add of the conditioner's input gradient + W^T apply + ActNorm backward + the C x C weight-gradient
+//   reduction) in ONE launch followed by the PLU backward.  At these sizes every launch is pure latency (~4 us for a
+//   131 KB problem), so the four launches forward / seven backward this replaces are the cost.
+#include "nf_common.h"
+
+#define NF_HEAD_MAXC 4
+
+// full-tensor element (c, pixel p = y*W + x) -> (which half, index inside the half)
+__device__ __forceinline__ void nf_full_to_half(const NfSplit& s, int c, int p, int& which, int& e) {
+    switch (s.mode) {
+        case NF_SPLIT_1D: { const int sel = c & 1; which = sel ^ s.odd; e = c >> 1; return; }
+        case NF_SPLIT_CHANNEL: {
+            const int hc = s.C >> 1, sel = c >= hc ? 1 : 0;
+            which = sel ^ s.odd; e = (c - sel * hc) * (s.H * s.W) + p; return;
+        }
+        default: {  // NF_SPLIT_CHECKER
+            const int y = p / s.W, x = p - y * s.W;
+            const int k = 4 * c + 2 * (y & 1) + (x & 1), q = k / s.C;
+            const int sel = (q == 1 || q == 2) ? 1 : 0;
+            const int m = sel ? k - s.C : (q == 0 ? k : k - 2 * s.C);
+            which = sel ^ s.odd; e = (m * s.h + (y >> 1)) * s.w + (x >> 1); return;
+        }
+    }
+}
+
+// W = P L' U' for C <= 4, computed redundantly by every thread that needs it (a few dozen FMAs)
+template <int CT>
+__device__ __forceinline__ void nf_small_plu(const float* __restrict__ Pm, const float* __restrict__ L,
+                                             const float* __restrict__ U, const float* __restrict__ Lm,
+                                             const float* __restrict__ Um, const float* __restrict__ sign_s,
+                                             const float* __restrict__ log_s, float (&Wm)[CT][CT]) {
+    float Lp[CT][CT], Up[CT][CT], T[CT][CT];
+#pragma unroll
+    for (int r = 0; r < CT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            Lp[r][c] = L[r * CT + c] * Lm[r * CT + c] + (r == c ? 1.f : 0.f);
+            Up[r][c] = U[r * CT + c] * Um[r * CT + c] + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
+        }
+#pragma unroll
+    for (int r = 0; r < CT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < CT; ++k) a = fmaf(Lp[r][k], Up[k][c], a);
+            T[r][c] = a;
+        }
+#pragma unroll
+    for (int r = 0; r < CT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < CT; ++k) a = fmaf(Pm[r * CT + k], T[k][c], a);
+            Wm[r][c] = a;
+        }
+}
+
+template <int CT>
+__global__ void __launch_bounds__(NF_BLOCK) k_glow_head_fwd(const float* __restrict__ z, const float* __restrict__ ls,
+                                                            const float* __restrict__ bs, const float* __restrict__ Pm,
+                                                            const float* __restrict__ L, const float* __restrict__ U,
+                                                            const float* __restrict__ Lm, const float* __restrict__ Um,
+                                                            const float* __restrict__ sign_s,
+                                                            const float* __restrict__ log_s, float* __restrict__ h,
+                                                            float* __restrict__ z1c, float* __restrict__ Wout,
+                                                            float* __restrict__ ld, NfSplit s, int64_t B, int P) {
+    float Wm[CT][CT], es[CT], bb[CT];
+    nf_small_plu<CT>(Pm, L, U, Lm, Um, sign_s, log_s, Wm);
+    float dld = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        es[c] = expf(ls[c]);
+        bb[c] = bs[c];
+        dld += log_s[c] - ls[c];                                   // modules.py:249, :480
+    }
+    dld *= (float)P;
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gtid == 0 && Wout != nullptr) {
+#pragma unroll
+        for (int r = 0; r < CT; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) Wout[r * CT + c] = Wm[r][c];   // saved for the backward pass
+    }
+    const int64_t npix = B * P;
+    for (int64_t t = gtid; t < npix; t += gstride) {
+        const int64_t b = t / P;
+        const int p = (int)(t - b * P);
+        const int64_t base = b * CT * P + p;
+        float zn[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) zn[c] = (z[base + (int64_t)c * P] - bb[c]) / es[c];     // modules.py:246
+#pragma unroll
+        for (int r = 0; r < CT; ++r) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) a = fmaf(Wm[r][c], zn[c], a);                       // modules.py:477
+            h[base + (int64_t)r * P] = a;
+            int which, e;
+            nf_full_to_half(s, r, p, which, e);
+            if (which == 1) z1c[b * s.n_half + e] = a;                                       // conditioner input
+        }
+    }
+    for (int64_t b = gtid; b < B; b += gstride) ld[b] += dld;
+}
+
+// backward.  G = g_h + scatter(g_z1c);  g_zn = W^T G;  g_z = g_zn / exp(ls);
+// g_bias[c] += -sum g_zn[c]/exp(ls[c]);  g_ls[c] += -sum g_zn[c] zn[c] - P sum_b g_ld;  g_W[r][c] += sum G[r] zn[c]
+template <int CT>
+__global__ void __launch_bounds__(NF_BLOCK) k_glow_head_bwd(const float* __restrict__ gh, const float* __restrict__ gz1c,
+                                                            const float* __restrict__ gld, const float* __restrict__ z,
+                                                            const float* __restrict__ ls, const float* __restrict__ bs,
+                                                            const float* __restrict__ Wsaved, float* __restrict__ gz,
+                                                            float* __restrict__ g_ls, float* __restrict__ g_bias,
+                                                            float* __restrict__ gW, NfSplit s, int64_t B, int P) {
+    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    float Wm[CT][CT], es[CT], bb[CT];
+#pragma unroll
+    for (int r = 0; r < CT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) Wm[r][c] = Wsaved[r * CT + c];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { es[c] = expf(ls[c]); bb[c] = bs[c]; }
+    float aW[CT][CT], aB[CT], aL[CT];
+#pragma unroll
+    for (int r = 0; r < CT; ++r) {
+        aB[r] = 0.f; aL[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) aW[r][c] = 0.f;
+    }
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t npix = B * P;
+    for (int64_t t = gtid; t < npix; t += gstride) {
+        const int64_t b = t / P;
+        const int p = (int)(t - b * P);
+        const int64_t base = b * CT * P + p;
+        float zn[CT], G[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            zn[c] = (z[base + (int64_t)c * P] - bb[c]) / es[c];
+            float g = gh[base + (int64_t)c * P];
+            int which, e;
+            nf_full_to_half(s, c, p, which, e);
+            if (which == 1 && gz1c != nullptr) g += gz1c[b * s.n_half + e];
+            G[c] = g;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < CT; ++r) {
+                a = fmaf(Wm[r][c], G[r], a);
+                aW[r][c] = fmaf(G[r], zn[c], aW[r][c]);
+            }
+            const float gzc = a / es[c];
+            gz[base + (int64_t)c * P] = gzc;
+            aB[c] -= gzc;
+            aL[c] = fmaf(-a, zn[c], aL[c]);
+        }
+    }
+    float sg = 0.f;
+    if (blockIdx.x == 0)
+        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) sg += gld[b];
+    const float SG = nf_block_sum(sg, scratch);
+#pragma unroll
+    for (int r = 0; r < CT; ++r) {
+        const float tb = nf_block_sum(aB[r], scratch);
+        const float tl = nf_block_sum(aL[r], scratch);
+        if (threadIdx.x == 0) {
+            atomicAdd(g_bias + r, tb);
+            atomicAdd(g_ls + r, tl - (blockIdx.x == 0 ? (float)P * SG : 0.f));
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float tw = nf_block_sum(aW[r][c], scratch);
+            if (threadIdx.x == 0) atomicAdd(gW + r * CT + c, tw);
+        }
+    }
+}
+
+extern "C" int nf_glow_head_fwd(const float* z, const float* log_scale, const float* bias, const float* P,
+                                const float* L, const float* U, const float* L_mask, const float* U_mask,
+                                const float* sign_s, const float* log_s, float* h, float* z1c, float* W_out, float* ld,
+                                int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_make_split(s, mode, odd, C, H, W) || mode == NF_SPLIT_NONE) return NF_E_BADARG;
+    if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
+    if (B == 0) return 0;
+    const int Px = H * W;
+    unsigned g = nf_grid_for(B * Px);
+    const unsigned g_ld = nf_grid_for(B);
+    if (g < g_ld) g = g_ld;
+    hipStream_t st = (hipStream_t)stream;
+#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_fwd<CT>, dim3(g), dim3(NF_BLOCK), 0, st, z, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, h, z1c, W_out, ld, s, B, Px); break;
+    switch (C) { NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) default: return NF_E_UNSUPPORTED; }
+#undef NF_CASE
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z,
+                                const float* log_scale, const float* bias, const float* W_saved, float* g_z,
+                                float* g_log_scale, float* g_bias, float* g_W, int mode, int odd, int64_t B, int C, int H,
+                                int W, nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_make_split(s, mode, odd, C, H, W) || mode == NF_SPLIT_NONE) return NF_E_BADARG;
+    if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
+    if (B == 0) return 0;
+    const int Px = H * W;
+    unsigned g = nf_grid_for(B * Px, NF_BLOCK * 2);
+    if (g > 256) g = 256;
+    hipStream_t st = (hipStream_t)stream;
+#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(NF_BLOCK), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, s, B, Px); break;
+    switch (C) { NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) default: return NF_E_UNSUPPORTED; }
+#undef NF_CASE
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -392,10 +392,35 @@ __global__ void __launch_bounds__(NF_BLOCK) k_weight_grad_finalize(NfWGradArgs a
     const int I = d.I, O = d.O;
     const bool acc = d.accumulate != 0;
     if (d.g_weff != nullptr) {
-        for (int e = threadIdx.x; e < O * I; e += blockDim.x) {           // deterministic slab reduction
-            float t = 0.f;
-            for (int sl = 0; sl < d.n_slabs; ++sl) t += d.g_weff[(int64_t)sl * O * I + e];
-            gW[e] = t;
+        {   // deterministic slab reduction; <= 4 entries per thread, 4 slabs per trip -> 16 loads in flight
+            const int OI = O * I;
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            int sl = 0;
+            for (; sl + 4 <= d.n_slabs; sl += 4) {
+                float v[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int e = threadIdx.x + q * NF_BLOCK;
+                        v[u][q] = e < OI ? d.g_weff[(int64_t)(sl + u) * OI + e] : 0.f;
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t[q] += v[u][q];
+            }
+            for (; sl < d.n_slabs; ++sl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = threadIdx.x + q * NF_BLOCK;
+                    if (e < OI) t[q] += d.g_weff[(int64_t)sl * OI + e];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = threadIdx.x + q * NF_BLOCK;
+                if (e < OI) gW[e] = t[q];
+            }
         }
         __syncthreads();
         if (d.weight_g != nullptr) {

@@ -10,6 +10,7 @@ modules.py:249,305,480); only the returned tensor is contractual.
 import torch
 
 from . import _native as N
+from . import workspace as WS
 
 MODE_OF = {'1d': N.SPLIT_1D, 'checkerboard': N.SPLIT_CHECKER, 'channelwise': N.SPLIT_CHANNEL, 'none': N.SPLIT_NONE}
 
@@ -150,7 +151,7 @@ class _AffineCoupling(torch.autograd.Function):
         if ctx.sinks is not None:
             pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
         else:
-            g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+            g_ac = WS.zeros(2, z.device)
             pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
             ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
         N.call('nf_affine_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(t), N.ptr(s_raw), pbs, N.ptr(a),
@@ -185,7 +186,7 @@ class _AffineCouplingPacked(torch.autograd.Function):
         if ctx.sinks is not None:
             pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
         else:
-            g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+            g_ac = WS.zeros(2, z.device)
             pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
             ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
         N.call('nf_affine_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params),
@@ -266,7 +267,7 @@ class _ChanAffine(torch.autograd.Function):
         if want and ctx.sinks is not None:
             ga_ptr, gb_ptr = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr()
         elif want:
-            g_ab = torch.zeros((2, ) + tuple(pa.shape), dtype=x.dtype, device=x.device)
+            g_ab = WS.zeros(2 * pa.numel(), x.device).view((2, ) + tuple(pa.shape))
             ga_ptr, gb_ptr = g_ab.data_ptr(), g_ab.data_ptr() + 4 * pa.numel()
             ga, gb = g_ab[0], g_ab[1]
         else:
@@ -391,7 +392,7 @@ class _InvConvPLU(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_z = torch.empty_like(z)
             N.call('nf_invconv_apply', N.ptr(g_y), N.ptr(W), 1, N.ptr(g_z), None, None, 0.0, B, C, Px, N.stream())
-        g_W = torch.zeros_like(W)
+        g_W = WS.zeros(W.numel(), W.device).view_as(W)
         N.call('nf_invconv_wgrad', N.ptr(g_y), N.ptr(z), N.ptr(g_W), B, C, Px, N.stream())
         direct = ctx.sinks is not None
         g_L, g_U, g_ls = ctx.sinks if direct else (torch.empty_like(L), torch.empty_like(U), torch.empty_like(log_s))
@@ -409,6 +410,57 @@ PLU_MAX_C = 64
 def invconv_plu(z, ld, P, L, U, L_mask, U_mask, sign_s, log_s):
     """InvertibleConv1x1.forward from its stored PLU parameters (flows/modules.py:470-482)."""
     return _InvConvPLU.apply(_contig(z), _owned_ld(ld), P, L, U, L_mask, U_mask, sign_s, log_s)
+
+
+class _GlowHead(torch.autograd.Function):
+    """ActNorm + invertible 1x1 (PLU assembled in-kernel) + conditioning-half gather: 1 launch forward, 2 backward."""
+
+    @staticmethod
+    def forward(ctx, z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd):
+        B, C, H, W = _bchw(z)
+        h = torch.empty_like(z)
+        z1c = torch.empty(_half_shape(z, mode), dtype=z.dtype, device=z.device)
+        Wm = torch.empty((C, C), dtype=z.dtype, device=z.device)
+        N.call('nf_glow_head_fwd', N.ptr(z), N.ptr(log_scale), N.ptr(bias), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask),
+               N.ptr(U_mask), N.ptr(sign_s), N.ptr(log_s), N.ptr(h), N.ptr(z1c), N.ptr(Wm), N.ptr(ld), mode, int(odd), B,
+               C, H, W, N.stream())
+        ctx.save_for_backward(z, log_scale, bias, Wm, P, L, U, L_mask, U_mask, sign_s, log_s)
+        ctx.meta = (mode, int(odd))
+        ctx.sinks = _sinks(log_scale, bias, L, U, log_s)
+        ctx.mark_dirty(ld)
+        return h, z1c, ld
+
+    @staticmethod
+    def backward(ctx, g_h, g_z1c, g_ld):
+        z, log_scale, bias, Wm, P, L, U, L_mask, U_mask, sign_s, log_s = ctx.saved_tensors
+        mode, odd = ctx.meta
+        B, C, H, W = _bchw(z)
+        g_h, g_z1c, g_ld = _contig(g_h), _contig(g_z1c), _contig(g_ld)
+        g_z = torch.empty_like(z)
+        direct = ctx.sinks is not None
+        tmp = WS.zeros(C * C + (0 if direct else 2 * C), z.device)
+        g_W = tmp[:C * C]
+        if direct:
+            g_ls, g_b, g_L, g_U, g_logs = ctx.sinks
+        else:
+            g_ls, g_b = tmp[C * C:C * C + C].view_as(log_scale), tmp[C * C + C:].view_as(bias)
+            g_L, g_U, g_logs = torch.empty_like(L), torch.empty_like(U), torch.empty_like(log_s)
+        N.call('nf_glow_head_bwd', N.ptr(g_h), N.ptr(g_z1c), N.ptr(g_ld), N.ptr(z), N.ptr(log_scale), N.ptr(bias),
+               N.ptr(Wm), N.ptr(g_z), N.ptr(g_ls), N.ptr(g_b), N.ptr(g_W), mode, odd, B, C, H, W, N.stream())
+        N.call('nf_invconv_weight_bwd', N.ptr(g_W), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask),
+               N.ptr(sign_s), N.ptr(log_s), N.ptr(g_ld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_logs), int(direct), C, B, H * W,
+               N.stream())
+        if direct:
+            return (g_z, g_ld) + (None, ) * 11
+        return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None
+
+
+HEAD_MAX_C = 4
+
+
+def glow_head(z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd):
+    """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward -> conditioning half of the split, fused (C <= 4)."""
+    return _GlowHead.apply(_contig(z), _owned_ld(ld), log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -474,7 +526,7 @@ class _MixLogCoupling(torch.autograd.Function):
         if ctx.sinks is not None:
             pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
         else:
-            g_ac = torch.zeros(2, dtype=z.dtype, device=z.device)
+            g_ac = WS.zeros(2, z.device)
             pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
             ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
         N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c),

@@ -15,6 +15,7 @@ import ctypes
 import torch
 
 from . import _native as N
+from . import workspace as WS
 
 BN_EPS, BN_MOMENTUM, WN_EPS = 1.0e-5, 0.1, 1.0e-5
 H = 32  # hidden width of every reference conditioner (base_filters=32)
@@ -105,7 +106,7 @@ class _FusedMLP(torch.autograd.Function):
         Nrows, I0 = x.shape
         O_out = lin[-1][0].shape[0]
         dev = x.device
-        ws = torch.zeros(nb, 4, H, dtype=torch.float32, device=dev)          # [sum, sqsum, save_mean, save_invstd]
+        ws = WS.zeros(nb * 4 * H, dev).view(nb, 4, H)                        # [sum, sqsum, save_mean, save_invstd]
         acts = [torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nb)]
         out = torch.empty(Nrows, O_out, dtype=torch.float32, device=dev)
 
@@ -149,7 +150,7 @@ class _FusedMLP(torch.autograd.Function):
         # accumulated vectors: g_bias per linear, (sum_g, sum_gx) per BatchNorm
         slabs = bwd_slabs(Nrows)
         g_weff = list(torch.empty(nl, slabs * H * H, dtype=torch.float32, device=dev).unbind(0))
-        acc = torch.zeros(nl * H + nb * 2 * H, dtype=torch.float32, device=dev)
+        acc = WS.zeros(nl * H + nb * 2 * H, dev)
         g_bias = [acc[i * H:i * H + V[i].shape[0]] for i in range(nl)]
         sums = acc[nl * H:].view(nb, 2, H)
         gn = [torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nb)]
@@ -231,7 +232,7 @@ class _FusedMADEPair(torch.autograd.Function):
         z = z.contiguous()
         Nrows, D = z.shape
         dev = z.device
-        ws = torch.zeros(2, nh, 4, H, dtype=torch.float32, device=dev)
+        ws = WS.zeros(2 * nh * 4 * H, dev).view(2, nh, 4, H)
         acts = [[torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nh)] for _ in range(2)]
         outs = [torch.empty(Nrows, D, dtype=torch.float32, device=dev) for _ in range(2)]
 
@@ -286,7 +287,7 @@ class _FusedMADEPair(torch.autograd.Function):
         slabs = bwd_slabs(Nrows)
         gw_all = torch.empty(2, nh + 1, slabs * H * H, dtype=torch.float32, device=dev)
         per_acc = (nh + 1) * H + nh * 2 * H
-        acc = torch.zeros(2, per_acc, dtype=torch.float32, device=dev)
+        acc = WS.zeros(2 * per_acc, dev).view(2, per_acc)
         g_weff, g_bias, sums = [], [], []
         for n in range(2):
             g_weff.append([gw_all[n, l] for l in range(nh + 1)])

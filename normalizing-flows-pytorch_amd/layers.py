@@ -27,15 +27,42 @@ class Identity(nn.Module):
 
 
 class Compose(nn.Module):
-    """flows/modules.py:325-339"""
+    """flows/modules.py:325-339.  The forward direction applies one peephole fusion: a Glow flow step
+    [ActNorm, InvertibleConv1x1, AffineCoupling] on <= 4 channels runs its first two layers and the coupling's
+    split-gather as ONE launch (functional.glow_head) -- same math, same parameters, same state_dict; skipped when a
+    member carries forward hooks (the reference's debug mode registers NaN hooks, main.py:312-313)."""
+
+    fuse = True
 
     def __init__(self, layers):
         super().__init__()
         self.layers = nn.ModuleList(layers)
 
+    def _glow_step_at(self, i, z):
+        L = self.layers
+        if not (self.fuse and z.is_cuda and i + 2 < len(L) and z.shape[1] <= NF.HEAD_MAX_C):
+            return False
+        a, c, k = L[i], L[i + 1], L[i + 2]
+        if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and type(k) is AffineCoupling):
+            return False
+        return not (a._forward_hooks or c._forward_hooks or k._forward_hooks or a._forward_pre_hooks
+                    or c._forward_pre_hooks or k._forward_pre_hooks)
+
     def forward(self, z, log_df_dz):
-        for layer in self.layers:
-            z, log_df_dz = layer(z, log_df_dz)
+        L, n, i = self.layers, len(self.layers), 0
+        while i < n:
+            if self._glow_step_at(i, z):
+                a, c, k = L[i], L[i + 1], L[i + 2]
+                if not a.initialized:
+                    NF.actnorm_init_(z, a.log_scale, a.bias, a.eps)
+                    a.initialized = True
+                h, z1c, log_df_dz = NF.glow_head(z, log_df_dz, a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask,
+                                                 c.sign_s, c.log_s, k.mode, k.odd)
+                z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
+                i += 3
+            else:
+                z, log_df_dz = L[i](z, log_df_dz)
+                i += 1
         return z, log_df_dz
 
     def backward(self, z, log_df_dz):

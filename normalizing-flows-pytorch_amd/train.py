@@ -94,10 +94,15 @@ class FlowTrainer:
 
     # -- one step, eager --------------------------------------------------------------------------------------------
     def _forward_backward(self, y):
+        from .workspace import ARENA
         self.bucket.zero_()
-        z, ld = self.net(y)
-        loss = nll_loss(z, ld)
-        loss.backward()
+        ARENA.begin(y.device)                           # one memset for every zero-initialised accumulator of the step
+        try:
+            z, ld = self.net(y)
+            loss = nll_loss(z, ld)
+            loss.backward()
+        finally:
+            ARENA.end()
         return z, loss
 
     def _capture(self, y):
