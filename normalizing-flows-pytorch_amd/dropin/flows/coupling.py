@@ -1,0 +1,5 @@
+"""flows.coupling of the reference -> the engine's coupling layers."""
+import importlib
+
+_pkg = importlib.import_module('normalizing-flows-pytorch_amd')
+AbstractCoupling, AffineCoupling, MixLogAttnCoupling = _pkg.AbstractCoupling, _pkg.AffineCoupling, _pkg.MixLogAttnCoupling
