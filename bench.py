@@ -70,24 +70,69 @@ def event_time_ms(fn, reps, stream):
     return start.elapsed_time(stop) / reps
 
 
-def dominant_kernel_roofline(pkg, cfg, B, dev):
-    """the hot-path kernel that dominates our own kernels' time in this workload: the fused affine / mixture coupling.
-    achieved = algorithmic bytes per launch / average launch duration (HIP events, launch stream)."""
-    N, NF = pkg._native, pkg.functional
+def graph_time_us(fn, dev, per_graph=50, replays=10):
+    """average duration of one launch of `fn` inside a hipGraph of `per_graph` back-to-back (dependent) launches: no host
+    launch cost in the number, HIP events recorded on the stream the graph is replayed on."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(per_graph):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record(stream)
+    for _ in range(replays):
+        g.replay()
+    stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e3 / (per_graph * replays)
+
+
+def dominant_kernel_roofline(pkg, cfg, B, dev):
+    """roofline of the kernel that dominates the timed region (rocprofv3 summaries under profiles/):
+      c1 / c2 / c5 -> k_linear_bn_bwd, the backward of one fused 32x32 linear + BatchNorm layer of the conditioner
+                       (MLP of the affine coupling; MADE pair of MAF: two nets per launch);
+      c3           -> k_mixlog_rows_fwd (the conditioner there is still framework code);
+      c4           -> k_affine_slab_fwd (first-resolution checkerboard step; convolutions are MIOpen's).
+    achieved = algorithmic bytes per launch / average launch duration at the workload's shape,
+    measured live with HIP events around hipGraph replays of that launch on the launch stream."""
+    N, NF = pkg._native, pkg.functional
+    F = importlib.import_module(PKG + '.fused')
     dims = cfg['dims']
     g = torch.Generator(device='cpu').manual_seed(7)
-    if cfg['kind'] == 'maf':
-        z = torch.randn(B, dims[0], generator=g).to(dev)
-        s_raw, t = torch.randn_like(z), torch.randn_like(z)
-        a, c = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev)
-        ld, y = torch.zeros(B, device=dev), torch.empty_like(z)
-        n = z[0].numel()
+    extra = {}
+    if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:
+        nets = 2 if cfg['kind'] == 'maf' else 1
+        T = lambda *sh: torch.randn(*sh, generator=g).to(dev)          # noqa: E731
+        descs, keep = [], []
+        slabs = F.bwd_slabs(B)
+        for _ in range(nets):
+            x, gn_src, out, gn_out = T(B, 32), T(B, 32), T(B, 32), torch.empty(B, 32, device=dev)
+            Wt, gam, bet = T(32, 32) * 0.2, torch.rand(32, generator=g).to(dev) + 0.5, T(32) * 0.1
+            ws = torch.zeros(8, 32, device=dev)
+            ws[3] += 1.0
+            wg = None if cfg['kind'] == 'maf' else torch.rand(32, generator=g).to(dev) + 0.5
+            mask = torch.ones(32, 32, device=dev) if cfg['kind'] == 'maf' else None
+            gweff = torch.empty(slabs * 1024, device=dev)
+            keep += [x, gn_src, out, gn_out, Wt, gam, bet, ws, wg, mask, gweff]
+            descs.append(F._desc(F.LinearBwdDesc, in_=x, weight=Wt, weight_g=wg, mask=mask, bn_gamma=gam, bn_beta=bet,
+                                 bn_save_mean=ws[2], bn_save_invstd=ws[3], gn_src=gn_src, out=out, cbn_gamma=gam,
+                                 cbn_save_mean=ws[2], cbn_save_invstd=ws[3], cbn_sum_g=ws[4], cbn_sum_gx=ws[5],
+                                 g_bias=ws[6], g_weff=gweff, gn_out=gn_out, sum_g=ws[0], sum_gx=ws[1]))
 
         def fn():
-            N.call('nf_affine_coupling_fwd', z.data_ptr(), t.data_ptr(), s_raw.data_ptr(), n, a.data_ptr(), c.data_ptr(),
-                   y.data_ptr(), ld.data_ptr(), N.SPLIT_NONE, 0, 0, B, dims[0], 1, 1, stream.cuda_stream)
-        name, nbytes = 'k_affine_rows_fwd (AR affine)', B * n * 16 + B * 8      # z, s, t, y + ld rmw
+            F._launch_bwd(descs, B, 32, 32)
+        name = 'k_linear_bn_bwd (32x32 hidden layer, %d net%s)' % (nets, 's' if nets > 1 else '')
+        nbytes = nets * B * 32 * 4 * 4                           # in, gn_src, out read; gn_out written
+        extra = {'flop_per_launch': int(nets * 2 * 2 * B * 32 * 32), 'mfma_peak_tflops': 157.3}
     elif cfg['kind'] == 'flowpp':
         K = cfg['mixtures']
         z = torch.randn((B, ) + dims, generator=g).to(dev)
@@ -97,13 +142,13 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
 
         def fn():
             N.call('nf_mixlog_coupling_fwd', z.data_ptr(), params.data_ptr(), a.data_ptr(), c.data_ptr(), y.data_ptr(),
-                   ld.data_ptr(), K, 1.0e-5, N.SPLIT_1D, 0, B, dims[0], 1, 1, stream.cuda_stream)
+                   ld.data_ptr(), K, 1.0e-5, N.SPLIT_1D, 0, B, dims[0], 1, 1, N.stream())
         name = 'k_mixlog_rows_fwd'
-        nbytes = B * ((4 + 3 * K) * 4 + 8 + 8)                                   # (4+3K)*4 + pass-through r/w + ld rmw
+        nbytes = B * ((4 + 3 * K) * 4 + 8 + 8)                   # (4+3K)*4 + pass-through r/w + ld rmw
     else:
         if len(dims) == 1:
             shape, mode, pshape = (B, dims[0]), N.SPLIT_1D, (B, dims[0])
-        else:                                               # first-resolution checkerboard step of the image stack
+        else:                                                    # first-resolution checkerboard step of the image stack
             shape, mode = (B, ) + dims, N.SPLIT_CHECKER
             pshape = (B, 4 * dims[0], dims[1] // 2, dims[2] // 2)
         z = torch.randn(shape, generator=g).to(dev)
@@ -115,14 +160,19 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
 
         def fn():
             N.call('nf_affine_coupling_fwd', z.data_ptr(), params.data_ptr(), params.data_ptr() + 4 * n_half, 2 * n_half,
-                   a.data_ptr(), c.data_ptr(), y.data_ptr(), ld.data_ptr(), mode, 0, 0, B, C, H, W, stream.cuda_stream)
+                   a.data_ptr(), c.data_ptr(), y.data_ptr(), ld.data_ptr(), mode, 0, 0, B, C, H, W, N.stream())
         name = 'k_affine_rows_fwd' if n_half <= 16 else 'k_affine_slab_fwd'
-        nbytes = z.numel() * 12 + B * 8                                          # 12 B / element of z + ld rmw
-    ms = event_time_ms(fn, 200, stream)
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': None, 'bytes_per_launch': int(nbytes),
-            'us_per_launch': round(ms * 1e3, 3)}
+        nbytes = z.numel() * 12 + B * 8                          # 12 B / element of z + ld rmw
+    us = graph_time_us(fn, dev)
+    gbs = nbytes / (us * 1e-6) / 1e9
+    out = {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': None, 'bytes_per_launch': int(nbytes),
+           'us_per_launch': round(us, 3),
+           'note': 'latency-bound at this batch size (DESIGN.md section 2); asymptotic rates in profiles/'}
+    if extra:
+        out['tflops'] = round(extra['flop_per_launch'] / (us * 1e-6) / 1e12, 3)
+        out.update(extra)
+    return out
 
 
 def cpu_baseline(cfg, state, y_cpu, seconds):

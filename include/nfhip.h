@@ -130,14 +130,15 @@ int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, cons
  *           coupling.py:33) in one launch.
  * backward: G = g_h + scatter(g_z1c) (g_z1c nullable); g_z = (W^T G) / exp(log_scale); g_log_scale, g_bias, g_W are
  *           ACCUMULATED (+=, caller zero-fills or passes .grad buffers); g_W then feeds nf_invconv_weight_bwd
- *           (which also adds the pixels * sum g_ld term of log_s).                                                   */
+ *           (which also adds the pixels * sum g_ld term of log_s; sum_g_ld (nullable, +=) receives sum_b g_ld so
+ *           that launch can be given the scalar with B = 1).                                                   */
 int nf_glow_head_fwd(const float* z, const float* log_scale, const float* bias, const float* P, const float* L,
                      const float* U, const float* L_mask, const float* U_mask, const float* sign_s, const float* log_s,
                      float* h, float* z1c, float* W_out, float* ld, int mode, int odd, int64_t B, int C, int H, int W,
                      nf_stream_t stream);
 int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z, const float* log_scale,
                      const float* bias, const float* W_saved, float* g_z, float* g_log_scale, float* g_bias, float* g_W,
-                     int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+                     float* sum_g_ld, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
 
 /* ---- Logit  modules.py:141-156 --------------------------------------------------------------------------------
  * forward: xc = clamp(x, eps, 1-eps); y = log(xc/(1-xc)); ld[b] += sum -(y - 2 softplus(y))

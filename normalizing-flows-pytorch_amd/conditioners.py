@@ -156,6 +156,14 @@ class GatedAttn(nn.Module):
         B, C = shape[0], shape[1]
         D = self.filters // self.heads
         assert C == self.channels
+        if x[0].numel() == C and self.filters == C:
+            # ONE position (2-D data): the softmax over a single key is exactly 1 (and has a zero Jacobian), so the
+            # attention output is the third projection itself.  Same function and same gradients as the general path
+            # below (the V/K rows of conv1 receive exact zeros either way), without B*heads 1x8x1 batched GEMMs.
+            t = (x + self.pos_emb).reshape(B, C)
+            q = F.linear(t, self.conv1.weight[2 * self.filters:, :, 0], self.conv1.bias[2 * self.filters:])
+            y, gate = torch.split(F.linear(q, self.conv2.weight[:, :, 0], self.conv2.bias), C, dim=1)
+            return x + (y * torch.sigmoid(gate)).view(shape)
         tokens = (x + self.pos_emb).view(B, C, -1)
         proj = self.conv1(tokens).view(B, 3 * self.heads, D, -1)
         V, K, Q = torch.split(proj, self.heads, dim=1)          # the reference's naming of the three projections

@@ -105,9 +105,9 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd(int op, const floa
         r1 += g;
         r2 += g * yv;
     }
-    float sg = 0.f;
-    if (blockIdx.y == 0)
-        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) sg += gld[b];
+    float sg = 0.f;                                  // this block's share of sum_b g_ld (every channel needs the total)
+    for (int64_t b = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.y * blockDim.x)
+        sg += gld[b];
     const float R1 = nf_block_sum(r1, scratch);
     const float R2 = nf_block_sum(r2, scratch);
     const float SG = nf_block_sum(sg, scratch);

@@ -11,6 +11,7 @@
 
 #define NF_ROWS_MAX 16
 #define NF_SLAB 2048
+#define NF_ATOMIC_GRID 512  // kernels ending in same-address atomics: <= 2 blocks per CU (an atomic costs ~23 ns serialised)
 
 __device__ __forceinline__ float nf_scale_of(float s_raw, float a, float c) { return tanhf(s_raw) * a + c; }
 
@@ -134,27 +135,30 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_slab_bwd(const float* __res
                                                               const float* __restrict__ p_c, float* __restrict__ gz,
                                                               float* __restrict__ gt, float* __restrict__ gs,
                                                               float* __restrict__ g_scale, float* __restrict__ g_bias,
-                                                              NfSplit s) {
+                                                              NfSplit s, int64_t B, int slabs) {
     __shared__ float scratch[NF_BLOCK / NF_WAVE];
     const float a = p_a[0], c = p_c[0];
     const bool has_pass = s.mode != NF_SPLIT_NONE;
-    const int64_t b = blockIdx.x;
-    const int e0 = blockIdx.y * NF_SLAB;
-    const int e1 = min(e0 + NF_SLAB, s.n_half);
-    const int64_t fb = b * s.n_full;
-    const float gl = gld[b];
     float acc_a = 0.f, acc_c = 0.f;
-    for (int e = e0 + threadIdx.x; e < e1; e += NF_BLOCK) {
-        const int o0 = nf_half_to_full(s, 0, e);
-        const float g0 = gy[fb + o0];
-        float g_z0, g_sr;
-        nf_affine_bwd_elem(g0, gl, z[fb + o0], sp[b * pbs + e], a, c, g_z0, g_sr, acc_a, acc_c);
-        gz[fb + o0] = g_z0;
-        gt[b * pbs + e] = g0;
-        gs[b * pbs + e] = g_sr;
-        if (has_pass) {
-            const int o1 = nf_half_to_full(s, 1, e);
-            gz[fb + o1] = gy[fb + o1];
+    const int64_t items = B * slabs;                      // persistent blocks: ONE pair of atomics per block
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t b = item / slabs;
+        const int e0 = (int)(item - b * slabs) * NF_SLAB;
+        const int e1 = min(e0 + NF_SLAB, s.n_half);
+        const int64_t fb = b * s.n_full;
+        const float gl = gld[b];
+        for (int e = e0 + threadIdx.x; e < e1; e += NF_BLOCK) {
+            const int o0 = nf_half_to_full(s, 0, e);
+            const float g0 = gy[fb + o0];
+            float g_z0, g_sr;
+            nf_affine_bwd_elem(g0, gl, z[fb + o0], sp[b * pbs + e], a, c, g_z0, g_sr, acc_a, acc_c);
+            gz[fb + o0] = g_z0;
+            gt[b * pbs + e] = g0;
+            gs[b * pbs + e] = g_sr;
+            if (has_pass) {
+                const int o1 = nf_half_to_full(s, 1, e);
+                gz[fb + o1] = gy[fb + o1];
+            }
         }
     }
     const float ta = nf_block_sum(acc_a, scratch);
@@ -198,13 +202,16 @@ extern "C" int nf_affine_coupling_bwd(const float* g_y, const float* g_ld, const
     if (B == 0 || s.n_half == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (s.n_half <= NF_ROWS_MAX) {
-        hipLaunchKernelGGL(k_affine_rows_bwd, dim3(nf_grid_for(B)), dim3(NF_BLOCK), 0, st, g_y, g_ld, z, s_ptr,
-                           param_bstride, s_log_scale, s_bias, g_z, g_t, g_s, g_scale, g_bias, s, B);
+        unsigned g = nf_grid_for(B);
+        if (g > NF_ATOMIC_GRID) g = NF_ATOMIC_GRID;
+        hipLaunchKernelGGL(k_affine_rows_bwd, dim3(g), dim3(NF_BLOCK), 0, st, g_y, g_ld, z, s_ptr, param_bstride,
+                           s_log_scale, s_bias, g_z, g_t, g_s, g_scale, g_bias, s, B);
     } else {
-        if (B > 0x7fffffffLL) return NF_E_BADARG;
-        dim3 grid((unsigned)B, (unsigned)((s.n_half + NF_SLAB - 1) / NF_SLAB));
-        hipLaunchKernelGGL(k_affine_slab_bwd, grid, dim3(NF_BLOCK), 0, st, g_y, g_ld, z, s_ptr, param_bstride,
-                           s_log_scale, s_bias, g_z, g_t, g_s, g_scale, g_bias, s);
+        const int slabs = (s.n_half + NF_SLAB - 1) / NF_SLAB;
+        const int64_t items = B * slabs;
+        const unsigned g = (unsigned)(items < 2 * NF_ATOMIC_GRID ? items : 2 * NF_ATOMIC_GRID);
+        hipLaunchKernelGGL(k_affine_slab_bwd, dim3(g), dim3(NF_BLOCK), 0, st, g_y, g_ld, z, s_ptr, param_bstride,
+                           s_log_scale, s_bias, g_z, g_t, g_s, g_scale, g_bias, s, B, slabs);
     }
     NF_CHECK_LAUNCH();
     return 0;

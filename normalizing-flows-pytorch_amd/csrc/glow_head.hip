@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_bwd(const float* __restr
                                                             const float* __restrict__ ls, const float* __restrict__ bs,
                                                             const float* __restrict__ Wsaved, float* __restrict__ gz,
                                                             float* __restrict__ g_ls, float* __restrict__ g_bias,
-                                                            float* __restrict__ gW, NfSplit s, int64_t B, int P) {
+                                                            float* __restrict__ gW, float* __restrict__ sum_gld, NfSplit s, int64_t B, int P) {
     __shared__ float scratch[NF_BLOCK / NF_WAVE];
     float Wm[CT][CT], es[CT], bb[CT];
 #pragma unroll
@@ -164,17 +164,17 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_bwd(const float* __restr
             aL[c] = fmaf(-a, zn[c], aL[c]);
         }
     }
-    float sg = 0.f;
-    if (blockIdx.x == 0)
-        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) sg += gld[b];
+    float sg = 0.f;                                  // this block's share of sum_b g_ld
+    for (int64_t b = gtid; b < B; b += gstride) sg += gld[b];
     const float SG = nf_block_sum(sg, scratch);
+    if (threadIdx.x == 0 && sum_gld != nullptr) atomicAdd(sum_gld, SG);
 #pragma unroll
     for (int r = 0; r < CT; ++r) {
         const float tb = nf_block_sum(aB[r], scratch);
         const float tl = nf_block_sum(aL[r], scratch);
         if (threadIdx.x == 0) {
             atomicAdd(g_bias + r, tb);
-            atomicAdd(g_ls + r, tl - (blockIdx.x == 0 ? (float)P * SG : 0.f));
+            atomicAdd(g_ls + r, tl - (float)P * SG);
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -206,8 +206,8 @@ extern "C" int nf_glow_head_fwd(const float* z, const float* log_scale, const fl
 
 extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z,
                                 const float* log_scale, const float* bias, const float* W_saved, float* g_z,
-                                float* g_log_scale, float* g_bias, float* g_W, int mode, int odd, int64_t B, int C, int H,
-                                int W, nf_stream_t stream) {
+                                float* g_log_scale, float* g_bias, float* g_W, float* sum_g_ld, int mode, int odd,
+                                int64_t B, int C, int H, int W, nf_stream_t stream) {
     NfSplit s;
     if (!nf_make_split(s, mode, odd, C, H, W) || mode == NF_SPLIT_NONE) return NF_E_BADARG;
     if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
@@ -216,7 +216,7 @@ extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const floa
     unsigned g = nf_grid_for(B * Px, NF_BLOCK * 2);
     if (g > 256) g = 256;
     hipStream_t st = (hipStream_t)stream;
-#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(NF_BLOCK), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, s, B, Px); break;
+#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(NF_BLOCK), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, s, B, Px); break;
     switch (C) { NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) default: return NF_E_UNSUPPORTED; }
 #undef NF_CASE
     NF_CHECK_LAUNCH();

@@ -438,18 +438,19 @@ class _GlowHead(torch.autograd.Function):
         g_h, g_z1c, g_ld = _contig(g_h), _contig(g_z1c), _contig(g_ld)
         g_z = torch.empty_like(z)
         direct = ctx.sinks is not None
-        tmp = WS.zeros(C * C + (0 if direct else 2 * C), z.device)
-        g_W = tmp[:C * C]
+        tmp = WS.zeros(C * C + 4 + (0 if direct else 2 * C), z.device)
+        g_W, sum_gld = tmp[:C * C], tmp[C * C:C * C + 1]
         if direct:
             g_ls, g_b, g_L, g_U, g_logs = ctx.sinks
         else:
-            g_ls, g_b = tmp[C * C:C * C + C].view_as(log_scale), tmp[C * C + C:].view_as(bias)
+            g_ls, g_b = tmp[C * C + 4:C * C + 4 + C].view_as(log_scale), tmp[C * C + 4 + C:].view_as(bias)
             g_L, g_U, g_logs = torch.empty_like(L), torch.empty_like(U), torch.empty_like(log_s)
         N.call('nf_glow_head_bwd', N.ptr(g_h), N.ptr(g_z1c), N.ptr(g_ld), N.ptr(z), N.ptr(log_scale), N.ptr(bias),
-               N.ptr(Wm), N.ptr(g_z), N.ptr(g_ls), N.ptr(g_b), N.ptr(g_W), mode, odd, B, C, H, W, N.stream())
-        N.call('nf_invconv_weight_bwd', N.ptr(g_W), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask),
-               N.ptr(sign_s), N.ptr(log_s), N.ptr(g_ld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_logs), int(direct), C, B, H * W,
+               N.ptr(Wm), N.ptr(g_z), N.ptr(g_ls), N.ptr(g_b), N.ptr(g_W), N.ptr(sum_gld), mode, odd, B, C, H, W,
                N.stream())
+        N.call('nf_invconv_weight_bwd', N.ptr(g_W), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask),
+               N.ptr(sign_s), N.ptr(log_s), N.ptr(sum_gld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_logs), int(direct), C, 1,
+               H * W, N.stream())
         if direct:
             return (g_z, g_ld) + (None, ) * 11
         return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None

@@ -1,0 +1,74 @@
+"""
+Workload for the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in SEPARATE runs, kernel-trace only):
+a calibration copy of known size, then the dominant kernel of the bench workload (k_linear_bn_bwd) at the bench shape
+(N = 4096) and at an asymptotic shape (N = 2^21), then the fused coupling.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -o fetch -- python tools/pmc_probe.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out -o write -- python tools/pmc_probe.py
+    python tools/pmc_probe.py --summarise out/fetch_counter_collection.csv out/write_counter_collection.csv
+"""
+import csv
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def summarise(paths):
+    agg = {}
+    for path in paths:
+        for r in csv.DictReader(open(path)):
+            name = r.get('Kernel_Name') or r.get('Kernel Name') or ''
+            key = (name.split('(')[0][:60], r['Counter_Name'], r.get('Grid_Size', ''))
+            a = agg.setdefault(key, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r['Counter_Value'])
+    print('%-60s %-12s %-10s %8s %14s' % ('kernel', 'counter', 'grid', 'calls', 'avg value'))
+    for (k, c, g), (n, v) in sorted(agg.items()):
+        if k.startswith('k_') or 'copy' in k.lower() or 'void k_' in k:
+            print('%-60s %-12s %-10s %8d %14.2f' % (k, c, g, n, v / n))
+
+
+def main():
+    import torch
+    pkg = importlib.import_module('normalizing-flows-pytorch_amd')
+    F = importlib.import_module('normalizing-flows-pytorch_amd.fused')
+    N = pkg._native
+    N.load()
+    dev = 'cuda'
+    x = torch.randn(2 ** 26, device=dev)                       # 256 MiB read + 256 MiB write: calibration
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    torch.cuda.synchronize()
+    del x, y
+    for Nr, reps in ((4096, 20), (2 ** 21, 3)):
+        xin, gn_src, out, gn_out = (torch.randn(Nr, 32, device=dev) for _ in range(4))
+        Wt, wg = torch.randn(32, 32, device=dev) * 0.2, torch.rand(32, device=dev) + 0.5
+        gam, bet = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+        ws = torch.zeros(8, 32, device=dev)
+        ws[3] += 1
+        gweff = torch.empty(F.bwd_slabs(Nr) * 1024, device=dev)
+        d = F._desc(F.LinearBwdDesc, in_=xin, weight=Wt, weight_g=wg, bn_gamma=gam, bn_beta=bet, bn_save_mean=ws[2],
+                    bn_save_invstd=ws[3], gn_src=gn_src, out=out, cbn_gamma=gam, cbn_save_mean=ws[2],
+                    cbn_save_invstd=ws[3], cbn_sum_g=ws[4], cbn_sum_gx=ws[5], g_bias=ws[6], g_weff=gweff, gn_out=gn_out,
+                    sum_g=ws[0], sum_gx=ws[1])
+        for _ in range(reps):
+            F._launch_bwd([d], Nr, 32, 32)
+        torch.cuda.synchronize()
+    for B, reps in ((4096, 20), (2 ** 24, 3)):
+        z, params = torch.randn(B, 2, device=dev), torch.randn(B, 2, device=dev)
+        a, c = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev)
+        yv, ld = torch.empty_like(z), torch.zeros(B, device=dev)
+        for _ in range(reps):
+            N.call('nf_affine_coupling_fwd', z.data_ptr(), params.data_ptr(), params.data_ptr() + 4, 2, a.data_ptr(),
+                   c.data_ptr(), yv.data_ptr(), ld.data_ptr(), 0, 0, 0, B, 2, 1, 1, N.stream())
+        torch.cuda.synchronize()
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == '--summarise':
+        summarise(sys.argv[2:])
+    else:
+        main()
