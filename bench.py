@@ -165,8 +165,17 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         nbytes = z.numel() * 12 + B * 8                          # 12 B / element of z + ld rmw
     us = graph_time_us(fn, dev)
     gbs = nbytes / (us * 1e-6) / 1e9
+    traffic = None                     # HBM bytes per launch from the committed rocprofv3 PMC passes, same kernel + shape
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')) as f:
+            pmc = json.load(f)
+        traffic = pmc.get(name.split(' ')[0], {}).get(str(B), {}).get('traffic_bytes')
+        if traffic is not None and 'net' in name:
+            traffic *= (2 if '2 nets' in name else 1)
+    except (OSError, ValueError):
+        pass
     out = {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-           'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': None, 'bytes_per_launch': int(nbytes),
+           'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'bytes_per_launch': int(nbytes),
            'us_per_launch': round(us, 3),
            'note': 'latency-bound at this batch size (DESIGN.md section 2); asymptotic rates in profiles/'}
     if extra:
