@@ -6,7 +6,7 @@ Drop-in shim: a package NAMED ``flows`` with the reference's module layout that 
 ``main.py`` of tatsy/normalizing-flows-pytorch imports ``from flows import MAF, Glow, Flowpp, RealNVP, ...`` and
 ``from flows.modules import Logit, Identity`` (main.py:12-17); with this directory ahead of the reference on
 ``sys.path`` those names resolve to the HIP-backed classes, everything else in main.py stays untouched.
-Families outside the accelerated hot path (PlanarFlow, Ffjord, ResFlow) are not provided here: import them from the
+Families outside the accelerated hot path (PlanarFlow, Ffjord) are not provided here: import them from the
 reference package under another name if needed.
 """
 import importlib
@@ -18,7 +18,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 _pkg = importlib.import_module('normalizing-flows-pytorch_amd')
 
-MAF, Glow, Flowpp, RealNVP = _pkg.MAF, _pkg.Glow, _pkg.Flowpp, _pkg.RealNVP
+MAF, Glow, Flowpp, RealNVP, ResFlow = _pkg.MAF, _pkg.Glow, _pkg.Flowpp, _pkg.RealNVP, _pkg.ResFlow
 
 
 def _missing(name):
@@ -30,6 +30,6 @@ def _missing(name):
     return _Missing
 
 
-PlanarFlow, Ffjord, ResFlow = _missing('PlanarFlow'), _missing('Ffjord'), _missing('ResFlow')
+PlanarFlow, Ffjord = _missing('PlanarFlow'), _missing('Ffjord')
 
 __all__ = ['PlanarFlow', 'RealNVP', 'Glow', 'Flowpp', 'MAF', 'ResFlow', 'Ffjord']

@@ -89,6 +89,7 @@ class FlowTrainer:
                                           capturable=self.graph, foreach=True)
         self.warmup = warmup
         self._eager_steps = 0
+        self._replicas_synced = False
         self._g_fb = self._g_opt = None
         self._static_y = self._static_z = self._static_loss = None
 
@@ -138,7 +139,22 @@ class FlowTrainer:
         self.bucket.all_reduce_mean_()
         self.optim.step()
         self._eager_steps += 1
+        if not self._replicas_synced:
+            self._sync_replicas_after_first_step()
         return z.detach(), loss.detach()
+
+    def _sync_replicas_after_first_step(self):
+        """The first forward performs the data-dependent ActNorm initialisation (modules.py:238-244) on each replica's OWN
+        shard, so the replicas' log_scale / bias differ after step 1.  Data parallelism needs identical replicas:
+        rank 0's parameters win (policy 2).  Running statistics stay per replica."""
+        self._replicas_synced = True
+        if self.bucket.world > 1:
+            with torch.no_grad():
+                if self.bucket.flat_params is not None:
+                    torch.distributed.broadcast(self.bucket.flat_params, src=0, group=self.bucket.group)
+                else:
+                    for p in self.bucket.params:
+                        torch.distributed.broadcast(p.data, src=0, group=self.bucket.group)
 
     # -- evaluation -----------------------------------------------------------------------------------------------------
     @torch.no_grad()

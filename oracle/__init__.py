@@ -24,4 +24,4 @@ Design: purely functional over a ``state_dict`` with the reference's key names
 (SURVEY.md section 8b), so the same oracle consumes the reference's weights
 (pinning) and the product's weights (parity) unchanged.
 """
-from . import indexmaps, transforms, nets, models  # noqa: F401
+from . import indexmaps, transforms, nets, iresblock, models  # noqa: F401

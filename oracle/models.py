@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import indexmaps as im
+from . import iresblock as ires
 from . import nets
 from . import transforms as tf
 
@@ -23,7 +24,7 @@ def _coupling_mode(dims, masking):
     raise Exception('unsupported combination of masking and dimension: %s, %s' % (masking, str(dims)))  # coupling.py:29
 
 
-def build_plan(kind, dims, datatype, layers, mixtures=None):
+def build_plan(kind, dims, datatype, layers, mixtures=None, spnorm_coeff=0.9, logdet='unbias'):
     """returns the list of layers exactly in ``Compose`` order; index == position in net.layers."""
     dims = tuple(dims)
     plan = []
@@ -46,6 +47,14 @@ def build_plan(kind, dims, datatype, layers, mixtures=None):
             add('mixlog', dims=d, mode=_coupling_mode(d, masking), odd=odd, mixtures=mixtures)
         else:
             raise ValueError(kind)
+
+    if kind == 'resflow':
+        if datatype == 'image':
+            raise NotImplementedError('residual flow for images is not supported (resflow.py:17-19)')
+        for _ in range(layers):                   # resflow.py:22-28
+            add('actnorm', dims=dims)
+            add('ires', dims=dims, coeff=spnorm_coeff, logdet=logdet)
+        return plan
 
     if kind == 'maf':
         if datatype == 'image':
@@ -81,9 +90,9 @@ class FlowOracle:
     plus ``self.actnorm_initialized`` (the reference keeps it as a plain attribute, modules.py:235)."""
 
     def __init__(self, kind, dims, datatype, layers, sd, mixtures=None, training=True, actnorm_initialized=False,
-                 mask_rng=None):
+                 mask_rng=None, spnorm_coeff=0.9, logdet='unbias'):
         self.kind, self.dims, self.datatype = kind, tuple(dims), datatype
-        self.plan = build_plan(kind, dims, datatype, layers, mixtures)
+        self.plan = build_plan(kind, dims, datatype, layers, mixtures, spnorm_coeff, logdet)
         self.sd = sd
         self.training = training
         self.actnorm_initialized = {L['prefix']: bool(actnorm_initialized) for L in self.plan if L['op'] == 'actnorm'}
@@ -93,12 +102,12 @@ class FlowOracle:
     def parameters(self):
         """trainable leaves, reference naming (requires_grad as in the reference)."""
         frozen = ('.P', '.I', '.pivots', '.L_mask', '.U_mask', '.sign_s', 'running_mean', 'running_var',
-                  'num_batches_tracked', 'batch_mean', 'batch_var', '.perm')
+                  'num_batches_tracked', 'batch_mean', 'batch_var', '.perm', 'weight_u', 'weight_v', 'module.weight')
         out = {}
         for k, v in self.sd.items():
             if any(k.endswith(f) for f in frozen) or not v.is_floating_point():
                 continue
-            if k.endswith('log_gamma') or k.endswith('.beta'):
+            if k.endswith('log_gamma') or (k.endswith('.beta') and (k[:-4] + 'log_gamma') in self.sd):
                 continue                              # models build BatchNorm(affine=False): buffers
             out[k] = v
         return out
@@ -177,6 +186,12 @@ class FlowOracle:
                                       sd[p + 'a_bias'], L['mode'], L['odd'], inverse)
         if op == 'ar':
             return self._ar(L, z, ld, inverse)
+        if op == 'ires':
+            if inverse:
+                return ires.iresblock_inverse(z, ld, sd, p, L['coeff'], self.training, L['logdet'])
+            if not z.requires_grad:
+                z = z.detach().requires_grad_(True)           # the estimators differentiate g w.r.t. its input
+            return ires.iresblock_forward(z, ld, sd, p, L['coeff'], self.training, L['logdet'])
         raise ValueError(op)
 
     def _ar(self, L, z, ld, inverse):

@@ -37,7 +37,15 @@ MODEL_CASES = {
     'flowpp2d': ('flowpp', 'Flowpp', (2, ), '2d', 2, 8),
     'maf2d': ('maf', 'MAF', (2, ), '2d', 2, None),
     'glow_img': ('glow', 'Glow', (3, 16, 16), 'image', 1, None),
+    'resflow2d': ('resflow', 'ResFlow', (2, ), '2d', 2, None),
 }
+
+
+def seed_noise(s):
+    """the seeds make_goldens.py sets before each stochastic pass (train forward 777, train inverse 778, eval 779)."""
+    import numpy as np
+    torch.manual_seed(s)
+    np.random.seed(s)
 
 
 def assert_close(a, b, atol, rtol=1e-5, what=''):

@@ -308,6 +308,7 @@ MODELS = [
     ('flowpp2d', 'Flowpp', (2, ), '2d', 2, 8, 64),
     ('maf2d', 'MAF', (2, ), '2d', 2, None, 64),
     ('glow_img', 'Glow', (3, 16, 16), 'image', 1, None, 4),
+    ('resflow2d', 'ResFlow', (2, ), '2d', 2, None, 64),          # logdet='exact' in eval; seeded noise in training
 ]
 
 
@@ -315,7 +316,7 @@ def make_models():
     for name, cls, dims, datatype, layers, mix, B in MODELS:
         torch.manual_seed(100)
         np.random.seed(100)
-        net = getattr(ref, cls)(dims, datatype, NS(layers=layers, mixtures=mix))
+        net = getattr(ref, cls)(dims, datatype, NS(layers=layers, mixtures=mix, logdet='exact', spnorm_coeff=0.9))
         out = {'meta/dims': np.array(dims), 'meta/layers': np.array(layers), 'meta/mixtures': np.array(mix or 0)}
         for k, v in net.state_dict().items():
             out['sd0/' + k] = npy(v)
@@ -323,6 +324,8 @@ def make_models():
         y = torch.rand((B, ) + dims, generator=g) if datatype == 'image' else torch.randn((B, ) + dims, generator=g) * 0.5
         out['y'] = npy(y)
         net.train()
+        torch.manual_seed(777)                                     # Hutchinson noise / series length of ResFlow
+        np.random.seed(777)
         z, ld = net(y.clone())
         zf = z.reshape(B, -1)
         D = zf.shape[1]
@@ -339,9 +342,13 @@ def make_models():
             if not np.array_equal(npy(v), out['sd0/' + k]):
                 out['sd1/' + k] = npy(v)
         with torch.no_grad():
+            torch.manual_seed(778)
+            np.random.seed(778)
             xt, ldt = net.backward(z.detach().clone())             # train-mode inverse (batch stats)
             out['train/x_inv'], out['train/ld_inv'] = npy(xt), npy(ldt)
             net.eval()
+            torch.manual_seed(779)
+            np.random.seed(779)
             ze, lde = net(y.clone())
             xe, ldie = net.backward(ze.clone())
             out['eval/z'], out['eval/ld'], out['eval/x_inv'], out['eval/ld_inv'] = npy(ze), npy(lde), npy(xe), npy(ldie)

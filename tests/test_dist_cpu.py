@@ -61,7 +61,7 @@ def _worker(rank, world, port, q):
     train.nll_loss(z, ld).backward()
     assert net.s.grad.data_ptr() == bucket.flat.data_ptr()      # grads are views of the flat bucket
     bucket.all_reduce_mean_()
-    q.put((rank, net.s.detach().clone(), bucket.flat.clone()))
+    q.put((rank, net.s.detach().tolist(), bucket.flat.tolist()))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -78,8 +78,9 @@ def test_dp_gradients_equal_global_batch():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, s0, g0), (_, s1, g1) = res
-    assert torch.equal(s0, s1)                      # broadcast made the replicas identical
-    assert torch.allclose(g0, g1, atol=0, rtol=0)   # all-reduce leaves identical buckets
+    assert s0 == s1                                 # broadcast made the replicas identical
+    assert g0 == g1                                 # all-reduce leaves identical buckets
+    s0, g0 = torch.tensor(s0), torch.tensor(g0)
     # single-process reference on the GLOBAL batch
     sys.path.insert(0, ROOT)
     train = importlib.import_module(PKG + '.train')
@@ -99,3 +100,59 @@ def test_shard_rejects_ragged_batch():
     with pytest.raises(ValueError):
         nfdist.shard(torch.zeros(10, 2), 0, 4)
     assert torch.equal(nfdist.shard(torch.arange(8).view(8, 1), 1, 2), torch.arange(4, 8).view(4, 1))
+
+
+class _InitFlow(torch.nn.Module):
+    """toy flow with a DATA-DEPENDENT first-batch initialisation (like ActNorm): replicas see different shards."""
+
+    def __init__(self):
+        super().__init__()
+        self.log_scale = torch.nn.Parameter(torch.zeros(3))
+        self.bias = torch.nn.Parameter(torch.zeros(3))
+        self.initialized = False
+
+    def forward(self, z):
+        if not self.initialized:
+            with torch.no_grad():
+                self.log_scale.copy_(torch.log(z.std(0) + 1e-5))
+                self.bias.copy_(z.mean(0))
+            self.initialized = True
+        y = (z - self.bias) / torch.exp(self.log_scale)
+        return y, (-self.log_scale.sum()).expand(z.shape[0])
+
+
+def _trainer_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    nfdist = importlib.import_module(PKG + '.dist')
+    train = importlib.import_module(PKG + '.train')
+    nfdist.init_from_env(backend='gloo')
+    net = _InitFlow()
+    tr = train.FlowTrainer(net, lr=1e-2, graph=False)          # CPU: torch Adam over the bucket, same control flow
+    g = torch.Generator().manual_seed(9)
+    y_global = torch.randn(32, 3, generator=g) * 2 + 1
+    y = nfdist.shard(y_global, rank, world)
+    losses = []
+    for _ in range(3):
+        _, loss = tr.train_on_batch(y)
+        losses.append(float(loss))
+    q.put((rank, net.log_scale.detach().tolist(), net.bias.detach().tolist(), losses))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_trainer_replicas_identical_after_data_dependent_init():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, ls0, b0, l0), (_, ls1, b1, l1) = res
+    assert ls0 == ls1 and b0 == b1                             # rank 0's initialisation won, updates identical since
+    assert l0[0] != l1[0]                                      # (step 1 really did run on different shards)

@@ -17,7 +17,7 @@ from tests import _golden as G
 def test_state_dict_contract_matches_reference_fixture(pkg, name):
     """the golden sd0 IS a reference state_dict: same keys, shapes and dtypes must load strictly."""
     kind, cls, dims, datatype, layers, mix = G.MODEL_CASES[name]
-    net = getattr(pkg, cls)(dims, datatype, NS(layers=layers, mixtures=mix))
+    net = getattr(pkg, cls)(dims, datatype, NS(layers=layers, mixtures=mix, logdet='exact', spnorm_coeff=0.9))
     sd0 = G.group('model_' + name, 'sd0/')
     own = net.state_dict()
     assert list(own.keys()) == list(sd0.keys())
