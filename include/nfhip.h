@@ -103,6 +103,21 @@ int nf_flowbn_finalize(const float* sum, const float* sqdev, float* batch_mean, 
 int nf_actnorm_init_finalize(const float* sum, const float* sqdev, float* log_scale, float* bias, float eps,
                              int64_t n, int C, nf_stream_t stream);
 
+/* ---- fused training-mode flow BatchNorm for the head of a RealNVP / MAF flow step (modules.py:283-307) -------------
+ * nf_flowbn_stats   : ws[0:C] += sum (x - center), ws[C:2C] += sum (x - center)^2, ws[2C:3C] = center  (ONE pass of
+ *                     shifted sums; center = the running mean; caller zero-fills ws[0:2C]).
+ * nf_flowbn_head_fwd: mean / biased variance (+eps inside) from ws, batch_* and running_* buffers written, y = BN(x),
+ *                     ld[b] += pixels * sum(log_gamma - 0.5 log var); z1c != NULL additionally gathers the conditioning
+ *                     half of the following coupling (mode / odd as above).
+ * nf_flowbn_head_bwd: g_x = (g_h + scatter(g_z1c)) * exp(log_gamma) / sqrt(var)   (affine=False: statistics are
+ *                     constants for autograd); g_z1c nullable.                                                       */
+int nf_flowbn_stats(const float* x, const float* center, float* ws, int64_t B, int C, int P, nf_stream_t stream);
+int nf_flowbn_head_fwd(const float* x, const float* ws, const float* log_gamma, const float* beta, float* batch_mean,
+                       float* batch_var, float* running_mean, float* running_var, float eps, float momentum, float* y,
+                       float* z1c, float* ld, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+int nf_flowbn_head_bwd(const float* g_h, const float* g_z1c, const float* var, const float* log_gamma, float* g_x,
+                       int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+
 /* ---- invertible 1x1 convolution: per-pixel C x C mat-vec  modules.py:470-497 ----------------------------------
  * y[b,:,p] = M z[b,:,p]  (M row-major C x C; transpose != 0 applies M^T: the autograd of z).
  * if ld != NULL: ld[b] += ld_sign * P * sum(log_s)   (modules.py:479-480, :494-495).

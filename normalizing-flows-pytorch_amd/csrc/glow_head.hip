@@ -8,24 +8,6 @@
 
 #define NF_HEAD_MAXC 4
 
-// full-tensor element (c, pixel p = y*W + x) -> (which half, index inside the half)
-__device__ __forceinline__ void nf_full_to_half(const NfSplit& s, int c, int p, int& which, int& e) {
-    switch (s.mode) {
-        case NF_SPLIT_1D: { const int sel = c & 1; which = sel ^ s.odd; e = c >> 1; return; }
-        case NF_SPLIT_CHANNEL: {
-            const int hc = s.C >> 1, sel = c >= hc ? 1 : 0;
-            which = sel ^ s.odd; e = (c - sel * hc) * (s.H * s.W) + p; return;
-        }
-        default: {  // NF_SPLIT_CHECKER
-            const int y = p / s.W, x = p - y * s.W;
-            const int k = 4 * c + 2 * (y & 1) + (x & 1), q = k / s.C;
-            const int sel = (q == 1 || q == 2) ? 1 : 0;
-            const int m = sel ? k - s.C : (q == 0 ? k : k - 2 * s.C);
-            which = sel ^ s.odd; e = (m * s.h + (y >> 1)) * s.w + (x >> 1); return;
-        }
-    }
-}
-
 // W = P L' U' for C <= 4, computed redundantly by every thread that needs it (a few dozen FMAs)
 template <int CT>
 __device__ __forceinline__ void nf_small_plu(const float* __restrict__ Pm, const float* __restrict__ L,

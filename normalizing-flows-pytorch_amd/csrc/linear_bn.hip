@@ -44,11 +44,39 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
                                                                          float wn_eps, int64_t tiles) {
     __shared__ float Wl[32 * NF_TS];
     __shared__ float kc[3][32];                       // per input feature: BN scale, BN shift, weight-norm scale
+    __shared__ float nrm_part[8][32];                 // weight-norm column sums of squares, 8 row groups
     __shared__ float red[2][NF_LB_WAVES][32];
     const nf_linear_desc& d = args.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, o = lane & 31, hs = lane >> 5;
     const bool has_bn = d.bn_gamma != nullptr;
     const float invN = 1.f / (float)N;
+
+    // A fragment of this wave's first tile: issued BEFORE the prologue so that its latency hides under it
+    auto load_a = [&](int64_t tile, float (&a)[KH]) {
+        const int64_t row = tile * 32 + o;                // o doubles as row-in-tile
+        const bool rv = row < N;
+        if (KH == 16 && I == 32) {
+            const float4* p = reinterpret_cast<const float4*>(d.in + (rv ? row : 0) * 32 + hs * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = p[q];
+                a[4 * q + 0] = rv ? v.x : 0.f; a[4 * q + 1] = rv ? v.y : 0.f;
+                a[4 * q + 2] = rv ? v.z : 0.f; a[4 * q + 3] = rv ? v.w : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+                const int k = hs * KH + kk;
+                a[kk] = (rv && k < I) ? d.in[row * I + k] : 0.f;
+            }
+        }
+    };
+    const int64_t tile_stride = (int64_t)gridDim.x * NF_LB_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * NF_LB_WAVES + wid;
+    float a[KH];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) a[kk] = 0.f;
+    if (tile < tiles) load_a(tile, a);
 
     for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
         const int oo = e >> 5, k = e & 31;
@@ -87,15 +115,27 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
     }
     if (training && has_bn && d.bn_num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
         d.bn_num_batches[0] += 1;
+    const float wg_k = (d.weight_g != nullptr && threadIdx.x < 32 && (int)threadIdx.x < I) ? d.weight_g[threadIdx.x] : 0.f;
     __syncthreads();
+    if (d.weight_g != nullptr) {                      // ||v||_dim0 per input column: 256 threads, 4 rows each
+        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float w = Wl[(part * 4 + j) * NF_TS + k];
+            ss = fmaf(w, w, ss);
+        }
+        nrm_part[part][k] = ss;
+        __syncthreads();
+    }
     if (threadIdx.x < 32) {
         const int k = threadIdx.x;
         float ws = 1.f;
         if (d.weight_g != nullptr) {                                               // weight_norm.py:40
             float ss = 0.f;
-#pragma unroll 8
-            for (int oo = 0; oo < 32; ++oo) ss = fmaf(Wl[oo * NF_TS + k], Wl[oo * NF_TS + k], ss);
-            ws = (k < I) ? d.weight_g[k] / (sqrtf(ss) + wn_eps) : 0.f;
+#pragma unroll
+            for (int part = 0; part < 8; ++part) ss += nrm_part[part][k];
+            ws = (k < I) ? wg_k / (sqrtf(ss) + wn_eps) : 0.f;
         }
         kc[0][k] = sc_k; kc[1][k] = sh_k; kc[2][k] = ws;
     }
@@ -112,25 +152,12 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
     const bool want_stats = d.stat_sum != nullptr;
     const bool has_res = d.residual != nullptr;
     float s1 = 0.f, s2 = 0.f;
-    for (int64_t tile = (int64_t)blockIdx.x * NF_LB_WAVES + wid; tile < tiles; tile += (int64_t)gridDim.x * NF_LB_WAVES) {
+    for (; tile < tiles; tile += tile_stride) {
         const int64_t row0 = tile * 32;
-        const int64_t row = row0 + o;                     // A fragment row of this lane (o doubles as row-in-tile)
-        const bool rv = row < N;
-        float a[KH];
-        if (KH == 16 && I == 32) {
-            const float4* p = reinterpret_cast<const float4*>(d.in + row * 32 + hs * 16);
+        float a_next[KH];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = rv ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < KH; ++kk) {
-                const int k = hs * KH + kk;
-                a[kk] = (rv && k < I) ? d.in[row * I + k] : 0.f;
-            }
-        }
+        for (int kk = 0; kk < KH; ++kk) a_next[kk] = 0.f;
+        if (tile + tile_stride < tiles) load_a(tile + tile_stride, a_next);       // software pipeline over tiles
         float rres[16];                                   // residual tile prefetched: 16 loads in flight under the MFMAs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -157,6 +184,8 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
                 }
             }
         }
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) a[kk] = a_next[kk];
     }
     if (want_stats) {                                         // block-uniform branch
         s1 += __shfl_xor(s1, 32, NF_WAVE);
@@ -246,36 +275,50 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
             const int64_t row = row0 + c32;
             const bool rv = row < N;
             if (O == 32) {                                         // 64-byte runs per lane: four 16-byte loads per tensor
-                const int64_t base = row * 32 + hs * 16;
-                float gd[16], gk[16], gs[16], ov[16];
+                const int64_t base = (rv ? row : 0) * 32 + hs * 16;    // invalid rows read row 0 and are zeroed below
+                float g[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 v0 = (rv && d.g_direct != nullptr) ? reinterpret_cast<const float4*>(d.g_direct + base)[q] : z4;
-                    const float4 v1 = (rv && d.g_skip != nullptr) ? reinterpret_cast<const float4*>(d.g_skip + base)[q] : z4;
-                    const float4 v2 = (rv && has_src) ? reinterpret_cast<const float4*>(d.gn_src + base)[q] : z4;
-                    const float4 v3 = (rv && has_src) ? reinterpret_cast<const float4*>(d.out + base)[q] : z4;
-                    gd[4 * q] = v0.x; gd[4 * q + 1] = v0.y; gd[4 * q + 2] = v0.z; gd[4 * q + 3] = v0.w;
-                    gk[4 * q] = v1.x; gk[4 * q + 1] = v1.y; gk[4 * q + 2] = v1.z; gk[4 * q + 3] = v1.w;
-                    gs[4 * q] = v2.x; gs[4 * q + 1] = v2.y; gs[4 * q + 2] = v2.z; gs[4 * q + 3] = v2.w;
-                    ov[4 * q] = v3.x; ov[4 * q + 1] = v3.y; ov[4 * q + 2] = v3.z; ov[4 * q + 3] = v3.w;
+                for (int kk = 0; kk < 16; ++kk) g[kk] = 0.f;
+                if (d.g_direct != nullptr) {
+                    const float4* p4 = reinterpret_cast<const float4*>(d.g_direct + base);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = p4[q];
+                        g[4 * q] += v.x; g[4 * q + 1] += v.y; g[4 * q + 2] += v.z; g[4 * q + 3] += v.w;
+                    }
+                }
+                if (d.g_skip != nullptr) {
+                    const float4* p4 = reinterpret_cast<const float4*>(d.g_skip + base);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = p4[q];
+                        g[4 * q] += v.x; g[4 * q + 1] += v.y; g[4 * q + 2] += v.z; g[4 * q + 3] += v.w;
+                    }
+                }
+                if (has_src) {
+                    const float4* s4 = reinterpret_cast<const float4*>(d.gn_src + base);
+                    const float4* o4 = reinterpret_cast<const float4*>(d.out + base);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 sv = s4[q], ov = o4[q];
+                        const float se[4] = {sv.x, sv.y, sv.z, sv.w}, oe[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int oo = hs * 16 + 4 * q + j;
+                            const float xh = (oe[j] - cbn[1][oo]) * cbn[2][oo];
+                            g[4 * q + j] += cbn[0][oo] * (se[j] - cbn[3][oo] - xh * cbn[4][oo]);   // BatchNorm backward on load
+                        }
+                    }
                 }
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
-                    const int oo = hs * 16 + kk;
-                    float g = gd[kk] + gk[kk];
-                    if (has_src) {
-                        const float xh = (ov[kk] - cbn[1][oo]) * cbn[2][oo];
-                        g += cbn[0][oo] * (gs[kk] - cbn[3][oo] - xh * cbn[4][oo]);          // BatchNorm backward on load
-                    }
-                    a1[kk] = rv ? g : 0.f;
-                    Gt[c32 * NF_TS + oo] = a1[kk];
+                    a1[kk] = rv ? g[kk] : 0.f;
+                    Gt[c32 * NF_TS + hs * 16 + kk] = a1[kk];
                 }
                 if (rv && d.g_store != nullptr) {
+                    float4* p4 = reinterpret_cast<float4*>(d.g_store + base);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        reinterpret_cast<float4*>(d.g_store + base)[q] =
-                            make_float4(a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]);
+                    for (int q = 0; q < 4; ++q) p4[q] = make_float4(a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]);
                 }
             } else {
 #pragma unroll
@@ -302,10 +345,10 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
                 for (int q = 0; q < 4; ++q) {
                     const int idx4 = lane + 64 * q;                // float4 index inside the 32 x 32 tile
                     const int rr = idx4 >> 3, cc = (idx4 & 7) * 4;
-                    const float4 v = (row0 + rr < N) ? reinterpret_cast<const float4*>(d.in + (row0 + rr) * 32)[idx4 & 7]
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const bool ok = row0 + rr < N;
+                    const float4 v = reinterpret_cast<const float4*>(d.in + (ok ? row0 + rr : 0) * 32)[idx4 & 7];
                     float* dst = It + rr * NF_TS + cc;
-                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                    dst[0] = ok ? v.x : 0.f; dst[1] = ok ? v.y : 0.f; dst[2] = ok ? v.z : 0.f; dst[3] = ok ? v.w : 0.f;
                 }
             } else {
                 for (int idx = lane; idx < 32 * I; idx += NF_WAVE) {

@@ -412,6 +412,51 @@ def invconv_plu(z, ld, P, L, U, L_mask, U_mask, sign_s, log_s):
     return _InvConvPLU.apply(_contig(z), _owned_ld(ld), P, L, U, L_mask, U_mask, sign_s, log_s)
 
 
+class _FlowBNHead(torch.autograd.Function):
+    """training-mode flow BatchNorm (affine=False) + optional conditioning-half gather: 2 launches forward, 1 backward."""
+
+    @staticmethod
+    def forward(ctx, x, ld, log_gamma, beta, batch_mean, batch_var, running_mean, running_var, eps, momentum, mode, odd,
+                gather):
+        B, C, H, W = _bchw(x)
+        ws = WS.zeros(3 * C, x.device)
+        N.call('nf_flowbn_stats', N.ptr(x), N.ptr(running_mean), N.ptr(ws), B, C, H * W, N.stream())
+        y = torch.empty_like(x)
+        z1c = torch.empty(_half_shape(x, mode), dtype=x.dtype, device=x.device) if gather else None
+        N.call('nf_flowbn_head_fwd', N.ptr(x), N.ptr(ws), N.ptr(log_gamma), N.ptr(beta), N.ptr(batch_mean),
+               N.ptr(batch_var), N.ptr(running_mean), N.ptr(running_var), float(eps), float(momentum), N.ptr(y),
+               N.ptr(z1c), N.ptr(ld), mode, int(odd), B, C, H, W, N.stream())
+        ctx.save_for_backward(batch_var, log_gamma)
+        ctx.meta = (mode, int(odd), tuple(x.shape), gather)
+        ctx.mark_dirty(ld)
+        if gather:
+            return y, z1c, ld
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, *grads):
+        batch_var, log_gamma = ctx.saved_tensors
+        mode, odd, shape, gather = ctx.meta
+        if gather:
+            g_h, g_z1c, g_ld = grads
+            g_z1c = _contig(g_z1c)
+        else:
+            (g_h, g_ld), g_z1c = grads, None
+        g_h = _contig(g_h)
+        B, C, H, W = shape if len(shape) == 4 else (shape[0], shape[1], 1, 1)
+        g_x = torch.empty_like(g_h)
+        N.call('nf_flowbn_head_bwd', N.ptr(g_h), N.ptr(g_z1c), N.ptr(batch_var), N.ptr(log_gamma), N.ptr(g_x), mode, odd,
+               B, C, H, W, N.stream())
+        return (g_x, g_ld) + (None, ) * 11
+
+
+def flowbn_head(x, ld, bn, mode=N.SPLIT_NONE, odd=False, gather=False):
+    """train-mode ``BatchNorm.forward`` of a flow BatchNorm with affine=False (+ the split gather of the coupling that
+    follows): (y, [z1c,] ld).  flows/modules.py:283-307, flows/coupling.py:33."""
+    return _FlowBNHead.apply(_contig(x), _owned_ld(ld), bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var,
+                             bn.running_mean, bn.running_var, bn.eps, bn.momentum, mode, odd, gather)
+
+
 class _GlowHead(torch.autograd.Function):
     """ActNorm + invertible 1x1 (PLU assembled in-kernel) + conditioning-half gather: 1 launch forward, 2 backward."""
 

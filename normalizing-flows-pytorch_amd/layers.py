@@ -48,10 +48,31 @@ class Compose(nn.Module):
         return not (a._forward_hooks or c._forward_hooks or k._forward_hooks or a._forward_pre_hooks
                     or c._forward_pre_hooks or k._forward_pre_hooks)
 
+    def _bn_step_at(self, i, z):
+        """[flow BatchNorm (training, affine=False), AffineCoupling | AutoregressiveTransfrom] -> fused BatchNorm head"""
+        L = self.layers
+        if not (self.fuse and z.is_cuda and i + 1 < len(L)):
+            return False
+        a, k = L[i], L[i + 1]
+        if not (type(a) is BatchNorm and a.training and not isinstance(a.log_gamma, nn.Parameter)):
+            return False
+        if not (type(k) is AffineCoupling or type(k) is AutoregressiveTransfrom):
+            return False
+        return not (a._forward_hooks or k._forward_hooks or a._forward_pre_hooks or k._forward_pre_hooks)
+
     def forward(self, z, log_df_dz):
         L, n, i = self.layers, len(self.layers), 0
         while i < n:
-            if self._glow_step_at(i, z):
+            if self._bn_step_at(i, z):
+                a, k = L[i], L[i + 1]
+                if type(k) is AffineCoupling:
+                    h, z1c, log_df_dz = NF.flowbn_head(z, log_df_dz, a, k.mode, k.odd, gather=True)
+                    z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
+                else:
+                    h, log_df_dz = NF.flowbn_head(z, log_df_dz, a)
+                    z, log_df_dz = k(h, log_df_dz)
+                i += 2
+            elif self._glow_step_at(i, z):
                 a, c, k = L[i], L[i + 1], L[i + 2]
                 if not a.initialized:
                     NF.actnorm_init_(z, a.log_scale, a.bias, a.eps)

@@ -1,5 +1,5 @@
-"""micro-benchmark of nf_linear_bn_fwd / bwd variants (HIP events on the launch stream)."""
-import importlib, sys, os, ctypes
+"""micro-benchmark of nf_linear_bn_fwd / bwd at the bench shape, timed as hipGraph replays (no host launch cost)."""
+import importlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 pkg = importlib.import_module('normalizing-flows-pytorch_amd')
@@ -9,49 +9,59 @@ N_.load()
 dev = 'cuda'
 
 
-def timeit(fn, reps=200):
+def graph_us(fn, per_graph=50, replays=10):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(per_graph):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(10):
-        fn()
-    st = torch.cuda.current_stream()
-    s.record(st)
-    for _ in range(reps):
-        fn()
-    e.record(st)
+    s.record()
+    for _ in range(replays):
+        g.replay()
+    e.record()
     e.synchronize()
-    return s.elapsed_time(e) / reps * 1e3
+    return s.elapsed_time(e) * 1e3 / (per_graph * replays)
 
 
-for N in (4096, 65536, 1048576):
-    x = torch.randn(N, 32, device=dev)
-    out = torch.empty(N, 32, device=dev)
-    res = torch.randn(N, 32, device=dev)
-    W = torch.randn(32, 32, device=dev) * 0.2
-    g = torch.rand(32, device=dev) + 0.5
-    b = torch.randn(32, device=dev) * 0.1
-    gamma, beta = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
-    ws = torch.zeros(8, 32, device=dev)
-    ws[1] += 1.0 * N
-    rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
-    nbt = torch.zeros((), dtype=torch.int64, device=dev)
-    variants = {
-        'plain': dict(),
-        'wn': dict(weight_g=g),
-        'bn': dict(bn_gamma=gamma, bn_beta=beta, bn_sum=ws[0], bn_sqsum=ws[1], bn_center=b, bn_running_mean=rm,
-                   bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[2], bn_save_invstd=ws[3]),
-        'stats': dict(stat_sum=ws[4], stat_sqsum=ws[5]),
-        'res': dict(residual=res),
-    }
-    variants['all'] = {k: v for d in variants.values() for k, v in d.items()}
-    for name, kw in variants.items():
-        d = F._desc(F.LinearDesc, in_=x, weight=W, bias=b, out=out, **kw)
-        for tr in (1, 0):
-            us = timeit(lambda: F._launch_fwd([d], N, 32, 32, tr))
-            gbs = N * 32 * 4 * (3 if 'residual' in kw else 2) / us / 1e3
-            print('N=%8d fwd %-6s training=%d  %8.2f us  %7.1f GB/s' % (N, name, tr, us, gbs))
-    # python-side launch cost (no GPU work): descriptor build + ctypes call
-    import time
-    t0 = time.perf_counter()
-    for _ in range(1000):
-        d = F._desc(F.LinearDesc, in_=x, weight=W, bias=b, out=out, **variants['all'])
-    print('desc build us', (time.perf_counter() - t0) * 1e3)
+def main():
+    for N in (256, 4096, 16384, 65536):
+        x, res, out, gn_src, gn_out, gst = (torch.randn(N, 32, device=dev) for _ in range(6))
+        W, g, b = torch.randn(32, 32, device=dev) * 0.2, torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+        gamma, beta = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+        ws = torch.zeros(8, 32, device=dev)
+        ws[1] += N
+        ws[3] += 1
+        rm, rv, nbt = torch.zeros(32, device=dev), torch.ones(32, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+        d = F._desc(F.LinearDesc, in_=x, weight=W, weight_g=g, bias=b, residual=res, out=out, bn_gamma=gamma, bn_beta=beta,
+                    bn_sum=ws[0], bn_sqsum=ws[1], bn_center=b, bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt,
+                    bn_save_mean=ws[2], bn_save_invstd=ws[3], stat_sum=ws[4], stat_sqsum=ws[5])
+        fwd = graph_us(lambda: F._launch_fwd([d], N, 32, 32, 1))
+        gweff = torch.empty(F.bwd_slabs(N) * 1024, device=dev)
+        acc = torch.zeros(8, 32, device=dev)
+        db = F._desc(F.LinearBwdDesc, in_=x, weight=W, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[2],
+                     bn_save_invstd=ws[3], gn_src=gn_src, out=out, cbn_gamma=gamma, cbn_save_mean=ws[2],
+                     cbn_save_invstd=ws[3], cbn_sum_g=acc[0], cbn_sum_gx=acc[1], g_bias=acc[2], g_weff=gweff, gn_out=gn_out,
+                     sum_g=acc[3], sum_gx=acc[4])
+        bwd = graph_us(lambda: F._launch_bwd([db], N, 32, 32))
+        db2 = F._desc(F.LinearBwdDesc, in_=x, weight=W, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[2],
+                      bn_save_invstd=ws[3], gn_src=gn_src, out=out, g_skip=res, g_store=gst, cbn_gamma=gamma,
+                      cbn_save_mean=ws[2], cbn_save_invstd=ws[3], cbn_sum_g=acc[0], cbn_sum_gx=acc[1], g_bias=acc[2],
+                      g_weff=gweff, gn_out=gn_out, sum_g=acc[3], sum_gx=acc[4])
+        bwd2 = graph_us(lambda: F._launch_bwd([db2], N, 32, 32))
+        one = torch.zeros(1, device=dev)
+        tiny = graph_us(lambda: one.add_(1.0))
+        print('N=%6d  fwd(all) %6.2f us   bwd %6.2f us   bwd(+skip,+store) %6.2f us   [trivial kernel %5.2f us]' %
+              (N, fwd, bwd, bwd2, tiny))
+
+
+if __name__ == '__main__':
+    main()
