@@ -117,16 +117,16 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         for _ in range(nets):
             x, gn_src, out, gn_out = T(B, 32), T(B, 32), T(B, 32), torch.empty(B, 32, device=dev)
             Wt, gam, bet = T(32, 32) * 0.2, torch.rand(32, generator=g).to(dev) + 0.5, T(32) * 0.1
-            ws = torch.zeros(8, 32, device=dev)
-            ws[3] += 1.0
+            ws = torch.zeros(64, 32, device=dev)
+            ws[24] += 1.0
             wg = None if cfg['kind'] == 'maf' else torch.rand(32, generator=g).to(dev) + 0.5
             mask = torch.ones(32, 32, device=dev) if cfg['kind'] == 'maf' else None
             gweff = torch.empty(slabs * 1024, device=dev)
             keep += [x, gn_src, out, gn_out, Wt, gam, bet, ws, wg, mask, gweff]
             descs.append(F._desc(F.LinearBwdDesc, in_=x, weight=Wt, weight_g=wg, mask=mask, bn_gamma=gam, bn_beta=bet,
-                                 bn_save_mean=ws[2], bn_save_invstd=ws[3], gn_src=gn_src, out=out, cbn_gamma=gam,
-                                 cbn_save_mean=ws[2], cbn_save_invstd=ws[3], cbn_sum_g=ws[4], cbn_sum_gx=ws[5],
-                                 g_bias=ws[6], g_weff=gweff, gn_out=gn_out, sum_g=ws[0], sum_gx=ws[1]))
+                                 bn_save_mean=ws[16], bn_save_invstd=ws[24], gn_src=gn_src, out=out, cbn_gamma=gam,
+                                 cbn_save_mean=ws[16], cbn_save_invstd=ws[24], cbn_sum_g=ws[32], cbn_sum_gx=ws[40],
+                                 g_bias=ws[48], g_weff=gweff, gn_out=gn_out, sum_g=ws[0], sum_gx=ws[8]))
 
         def fn():
             F._launch_bwd(descs, B, 32, 32)

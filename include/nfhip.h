@@ -201,6 +201,11 @@ int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, 
  * training == 0: running statistics are used.   Limits: I, O <= 32 (every reference conditioner is 32 wide).
  * The GEMM runs on v_mfma_f32_32x32x2_f32 (exact fp32, 32 rows x 32 outputs per wave per 16 issues).            */
 #define NF_MAX_NETS 2
+/* Atomically accumulated per-feature vectors (stat_sum/stat_sqsum, hence bn_sum/bn_sqsum; sum_g/sum_gx, hence
+ * cbn_sum_g/cbn_sum_gx; g_bias) are REPLICATED: NF_STAT_REPL replicas of 32 floats (replica r at offset 32*r), workgroup
+ * b adds into replica b % NF_STAT_REPL and every consumer sums the replicas -- same-address atomics cost ~23 ns each
+ * serialised, replication cuts that chain by NF_STAT_REPL.                                                          */
+#define NF_STAT_REPL 8
 typedef struct nf_linear_desc {
     const float* in;          /* (N, I) */
     const float* weight;      /* (O, I) */
@@ -294,6 +299,8 @@ typedef struct nf_weight_grad_desc {
     int O;
     int n_slabs;
     int accumulate;
+    int vec_repl;           /* replicas of vec_src0 / vec_src1 to sum (1 or NF_STAT_REPL, stride 32 floats) */
+    int reserved;
 } nf_weight_grad_desc;
 int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, float wn_eps, nf_stream_t stream);
 

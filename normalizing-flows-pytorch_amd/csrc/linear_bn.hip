@@ -44,39 +44,11 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
                                                                          float wn_eps, int64_t tiles) {
     __shared__ float Wl[32 * NF_TS];
     __shared__ float kc[3][32];                       // per input feature: BN scale, BN shift, weight-norm scale
-    __shared__ float nrm_part[8][32];                 // weight-norm column sums of squares, 8 row groups
     __shared__ float red[2][NF_LB_WAVES][32];
     const nf_linear_desc& d = args.d[blockIdx.y];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, o = lane & 31, hs = lane >> 5;
     const bool has_bn = d.bn_gamma != nullptr;
     const float invN = 1.f / (float)N;
-
-    // A fragment of this wave's first tile: issued BEFORE the prologue so that its latency hides under it
-    auto load_a = [&](int64_t tile, float (&a)[KH]) {
-        const int64_t row = tile * 32 + o;                // o doubles as row-in-tile
-        const bool rv = row < N;
-        if (KH == 16 && I == 32) {
-            const float4* p = reinterpret_cast<const float4*>(d.in + (rv ? row : 0) * 32 + hs * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = p[q];
-                a[4 * q + 0] = rv ? v.x : 0.f; a[4 * q + 1] = rv ? v.y : 0.f;
-                a[4 * q + 2] = rv ? v.z : 0.f; a[4 * q + 3] = rv ? v.w : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < KH; ++kk) {
-                const int k = hs * KH + kk;
-                a[kk] = (rv && k < I) ? d.in[row * I + k] : 0.f;
-            }
-        }
-    };
-    const int64_t tile_stride = (int64_t)gridDim.x * NF_LB_WAVES;
-    int64_t tile = (int64_t)blockIdx.x * NF_LB_WAVES + wid;
-    float a[KH];
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) a[kk] = 0.f;
-    if (tile < tiles) load_a(tile, a);
 
     for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
         const int oo = e >> 5, k = e & 31;
@@ -92,9 +64,12 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
         const int k = threadIdx.x;
         float mean, invstd;
         if (training) {
-            const float m1 = d.bn_sum[k] * invN;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < NF_STAT_REPL; ++r) { t1 += d.bn_sum[32 * r + k]; t2 += d.bn_sqsum[32 * r + k]; }
+            const float m1 = t1 * invN;
             mean = d.bn_center[k] + m1;
-            const float var = fmaxf(d.bn_sqsum[k] * invN - m1 * m1, 0.f);          // biased, as BatchNorm normalises
+            const float var = fmaxf(t2 * invN - m1 * m1, 0.f);                     // biased, as BatchNorm normalises
             invstd = 1.f / sqrtf(var + eps);
             if (blockIdx.x == 0) {                                                 // bookkeeping, once per feature
                 const float rm = d.bn_running_mean[k], rv = d.bn_running_var[k];
@@ -117,24 +92,13 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
         d.bn_num_batches[0] += 1;
     const float wg_k = (d.weight_g != nullptr && threadIdx.x < 32 && (int)threadIdx.x < I) ? d.weight_g[threadIdx.x] : 0.f;
     __syncthreads();
-    if (d.weight_g != nullptr) {                      // ||v||_dim0 per input column: 256 threads, 4 rows each
-        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float w = Wl[(part * 4 + j) * NF_TS + k];
-            ss = fmaf(w, w, ss);
-        }
-        nrm_part[part][k] = ss;
-        __syncthreads();
-    }
     if (threadIdx.x < 32) {
         const int k = threadIdx.x;
         float ws = 1.f;
         if (d.weight_g != nullptr) {                                               // weight_norm.py:40
             float ss = 0.f;
-#pragma unroll
-            for (int part = 0; part < 8; ++part) ss += nrm_part[part][k];
+#pragma unroll 8
+            for (int oo = 0; oo < 32; ++oo) ss = fmaf(Wl[oo * NF_TS + k], Wl[oo * NF_TS + k], ss);
             ws = (k < I) ? wg_k / (sqrtf(ss) + wn_eps) : 0.f;
         }
         kc[0][k] = sc_k; kc[1][k] = sh_k; kc[2][k] = ws;
@@ -152,12 +116,26 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
     const bool want_stats = d.stat_sum != nullptr;
     const bool has_res = d.residual != nullptr;
     float s1 = 0.f, s2 = 0.f;
-    for (; tile < tiles; tile += tile_stride) {
+    for (int64_t tile = (int64_t)blockIdx.x * NF_LB_WAVES + wid; tile < tiles; tile += (int64_t)gridDim.x * NF_LB_WAVES) {
         const int64_t row0 = tile * 32;
-        float a_next[KH];
+        const int64_t row = row0 + o;                     // A fragment row of this lane (o doubles as row-in-tile)
+        const bool rv = row < N;
+        float a[KH];
+        if (KH == 16 && I == 32) {
+            const float4* p = reinterpret_cast<const float4*>(d.in + (rv ? row : 0) * 32 + hs * 16);
 #pragma unroll
-        for (int kk = 0; kk < KH; ++kk) a_next[kk] = 0.f;
-        if (tile + tile_stride < tiles) load_a(tile + tile_stride, a_next);       // software pipeline over tiles
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = p[q];
+                a[4 * q + 0] = rv ? v.x : 0.f; a[4 * q + 1] = rv ? v.y : 0.f;
+                a[4 * q + 2] = rv ? v.z : 0.f; a[4 * q + 3] = rv ? v.w : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+                const int k = hs * KH + kk;
+                a[kk] = (rv && k < I) ? d.in[row * I + k] : 0.f;
+            }
+        }
         float rres[16];                                   // residual tile prefetched: 16 loads in flight under the MFMAs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -184,8 +162,6 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
                 }
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < KH; ++kk) a[kk] = a_next[kk];
     }
     if (want_stats) {                                         // block-uniform branch
         s1 += __shfl_xor(s1, 32, NF_WAVE);
@@ -196,8 +172,9 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < NF_LB_WAVES; ++w) { t1 += red[0][w][o]; t2 += red[1][w][o]; }
-            atomicAdd(d.stat_sum + o, t1);
-            atomicAdd(d.stat_sqsum + o, t2);
+            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+            atomicAdd(d.stat_sum + rep + o, t1);
+            atomicAdd(d.stat_sqsum + rep + o, t2);
         }
     }
 }
@@ -226,7 +203,12 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
             invstd = d.cbn_save_invstd[oo];
             mean = d.cbn_save_mean[oo];
             c1 = d.cbn_gamma[oo] * invstd;
-            if (d.cbn_sum_g != nullptr) { mg = d.cbn_sum_g[oo] * invN; mgx = d.cbn_sum_gx[oo] * invN; }
+            if (d.cbn_sum_g != nullptr) {
+#pragma unroll
+                for (int r = 0; r < NF_STAT_REPL; ++r) { mg += d.cbn_sum_g[32 * r + oo]; mgx += d.cbn_sum_gx[32 * r + oo]; }
+                mg *= invN;
+                mgx *= invN;
+            }
         }
         cbn[0][oo] = c1; cbn[1][oo] = mean; cbn[2][oo] = invstd; cbn[3][oo] = mg; cbn[4][oo] = mgx;
     }
@@ -417,10 +399,11 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
         float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int w = 0; w < NF_LB_WAVES; ++w) { t0 += red[0][w][c32]; t1 += red[1][w][c32]; t2 += red[2][w][c32]; }
-        if (c32 < O && d.g_bias != nullptr) atomicAdd(d.g_bias + c32, t0);
+        const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+        if (c32 < O && d.g_bias != nullptr) atomicAdd(d.g_bias + rep + c32, t0);
         if (has_bn && c32 < I && d.sum_g != nullptr) {
-            atomicAdd(d.sum_g + c32, t1);
-            atomicAdd(d.sum_gx + c32, t2);
+            atomicAdd(d.sum_g + rep + c32, t1);
+            atomicAdd(d.sum_gx + rep + c32, t2);
         }
     }
 }
@@ -496,10 +479,19 @@ __global__ void __launch_bounds__(NF_BLOCK) k_weight_grad_finalize(NfWGradArgs a
                 d.g_weight[e] = (acc ? d.g_weight[e] : 0.f) + (d.mask != nullptr ? gW[e] * d.mask[e] : gW[e]);
         }
     }
+    const int repl = d.vec_repl > 1 ? d.vec_repl : 1;
     if (d.vec_dst0 != nullptr)
-        for (int e = threadIdx.x; e < d.vec_n0; e += blockDim.x) d.vec_dst0[e] = (acc ? d.vec_dst0[e] : 0.f) + d.vec_src0[e];
+        for (int e = threadIdx.x; e < d.vec_n0; e += blockDim.x) {
+            float t = 0.f;
+            for (int r = 0; r < repl; ++r) t += d.vec_src0[32 * r + e];
+            d.vec_dst0[e] = (acc ? d.vec_dst0[e] : 0.f) + t;
+        }
     if (d.vec_dst1 != nullptr)
-        for (int e = threadIdx.x; e < d.vec_n1; e += blockDim.x) d.vec_dst1[e] = (acc ? d.vec_dst1[e] : 0.f) + d.vec_src1[e];
+        for (int e = threadIdx.x; e < d.vec_n1; e += blockDim.x) {
+            float t = 0.f;
+            for (int r = 0; r < repl; ++r) t += d.vec_src1[32 * r + e];
+            d.vec_dst1[e] = (acc ? d.vec_dst1[e] : 0.f) + t;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@ from . import workspace as WS
 
 BN_EPS, BN_MOMENTUM, WN_EPS = 1.0e-5, 0.1, 1.0e-5
 H = 32  # hidden width of every reference conditioner (base_filters=32)
+R = 8   # NF_STAT_REPL of include/nfhip.h: replicas of every atomically accumulated 32-vector
+WS_ROWS = 2 * R + 2   # per BatchNorm workspace rows of 32: sum[R], sqsum[R], save_mean, save_invstd
 
 _LIN_FIELDS = ['in_', 'weight', 'weight_g', 'mask', 'bias', 'residual', 'out', 'bn_gamma', 'bn_beta', 'bn_sum', 'bn_sqsum',
                'bn_center', 'bn_running_mean', 'bn_running_var', 'bn_num_batches', 'bn_save_mean', 'bn_save_invstd',
@@ -28,7 +30,7 @@ _BWD_FIELDS = ['in_', 'weight', 'weight_g', 'mask', 'bn_gamma', 'bn_beta', 'bn_s
                'g_store', 'g_bias', 'g_weff', 'gn_out', 'sum_g', 'sum_gx']
 _WG_FIELDS = ['g_weff', 'weight', 'weight_g', 'mask', 'g_weight', 'g_weight_g', 'vec_src0', 'vec_dst0', 'vec_src1',
               'vec_dst1']
-_WG_INTS = ['vec_n0', 'vec_n1', 'I', 'O', 'n_slabs', 'accumulate']
+_WG_INTS = ['vec_n0', 'vec_n1', 'I', 'O', 'n_slabs', 'accumulate', 'vec_repl', 'reserved']
 
 
 class LinearDesc(ctypes.Structure):
@@ -81,10 +83,10 @@ def _finalize_jobs(lin_jobs, bn_jobs, slabs, direct):
     for g_weff, W, Wg, M, gb_src, (dW, dWg, dB) in lin_jobs:
         descs.append(_desc(WeightGradDesc, g_weff=g_weff, weight=W, weight_g=Wg, mask=M, g_weight=dW, g_weight_g=dWg,
                            vec_src0=gb_src, vec_dst0=dB, vec_n0=W.shape[0], I=W.shape[1], O=W.shape[0], n_slabs=slabs,
-                           accumulate=int(direct)))
+                           accumulate=int(direct), vec_repl=R))
     for s_gx, s_g, (dG, dBt) in bn_jobs:
         descs.append(_desc(WeightGradDesc, vec_src0=s_gx, vec_dst0=dG, vec_n0=dG.numel(), vec_src1=s_g, vec_dst1=dBt,
-                           vec_n1=dBt.numel(), I=1, O=1, n_slabs=0, accumulate=int(direct)))
+                           vec_n1=dBt.numel(), I=1, O=1, n_slabs=0, accumulate=int(direct), vec_repl=R))
     return descs
 
 
@@ -106,22 +108,22 @@ class _FusedMLP(torch.autograd.Function):
         Nrows, I0 = x.shape
         O_out = lin[-1][0].shape[0]
         dev = x.device
-        ws = WS.zeros(nb * 4 * H, dev).view(nb, 4, H)                        # [sum, sqsum, save_mean, save_invstd]
+        ws = WS.zeros(nb * WS_ROWS * H, dev).view(nb, WS_ROWS, H)            # [sum*R, sqsum*R, save_mean, save_invstd]
         acts = [torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nb)]
         out = torch.empty(Nrows, O_out, dtype=torch.float32, device=dev)
 
         def bn_kw(j):
             g, b, rm, rv, nbt = bns[j]
-            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[j, 0], bn_sqsum=ws[j, 1], bn_center=lin[j][2], bn_running_mean=rm,
-                        bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[j, 2], bn_save_invstd=ws[j, 3])
+            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[j, 0], bn_sqsum=ws[j, R], bn_center=lin[j][2], bn_running_mean=rm,
+                        bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
 
         # K0
         _launch_fwd([_desc(LinearDesc, in_=x, weight=lin[0][0], weight_g=lin[0][1], bias=lin[0][2], out=acts[0],
-                           stat_sum=ws[0, 0], stat_sqsum=ws[0, 1])], Nrows, I0, H, training)
+                           stat_sum=ws[0, 0], stat_sqsum=ws[0, R])], Nrows, I0, H, training)
         for j in range(1, nb):                    # linear j consumes acts[j-1] through BatchNorm j-1
             res = acts[j - 2] if j % 2 == 0 else None      # second linear of a residual block adds the block input
             _launch_fwd([_desc(LinearDesc, in_=acts[j - 1], weight=lin[j][0], weight_g=lin[j][1], bias=lin[j][2],
-                               residual=res, out=acts[j], stat_sum=ws[j, 0], stat_sqsum=ws[j, 1], **bn_kw(j - 1))],
+                               residual=res, out=acts[j], stat_sum=ws[j, 0], stat_sqsum=ws[j, R], **bn_kw(j - 1))],
                         Nrows, H, H, training)
         _launch_fwd([_desc(LinearDesc, in_=acts[nb - 1], weight=lin[nl - 1][0], weight_g=lin[nl - 1][1],
                            bias=lin[nl - 1][2], out=out, **bn_kw(nb - 1))], Nrows, H, O_out, training)
@@ -150,18 +152,18 @@ class _FusedMLP(torch.autograd.Function):
         # accumulated vectors: g_bias per linear, (sum_g, sum_gx) per BatchNorm
         slabs = bwd_slabs(Nrows)
         g_weff = list(torch.empty(nl, slabs * H * H, dtype=torch.float32, device=dev).unbind(0))
-        acc = WS.zeros(nl * H + nb * 2 * H, dev)
-        g_bias = [acc[i * H:i * H + V[i].shape[0]] for i in range(nl)]
-        sums = acc[nl * H:].view(nb, 2, H)
+        acc = WS.zeros(nl * R * H + nb * 2 * R * H, dev)
+        g_bias = [acc[i * R * H:(i + 1) * R * H] for i in range(nl)]          # R replicas of 32
+        sums = acc[nl * R * H:].view(nb, 2, R * H)
         gn = [torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nb)]
         g_x = torch.empty(Nrows, I0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         G_skip = None                              # assembled gradient of the latest residual-stream tensor
 
         def in_bn(j):
-            return dict(bn_gamma=gamma[j], bn_beta=beta[j], bn_save_mean=ws[j, 2], bn_save_invstd=ws[j, 3])
+            return dict(bn_gamma=gamma[j], bn_beta=beta[j], bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
 
         def cons_bn(j):                            # evaluation mode: statistics are constants -> no mean terms
-            return dict(cbn_gamma=gamma[j], cbn_save_mean=ws[j, 2], cbn_save_invstd=ws[j, 3],
+            return dict(cbn_gamma=gamma[j], cbn_save_mean=ws[j, 2 * R], cbn_save_invstd=ws[j, 2 * R + 1],
                         cbn_sum_g=sums[j, 0] if training else None, cbn_sum_gx=sums[j, 1] if training else None)
 
         # last linear: G = g_out
@@ -232,7 +234,7 @@ class _FusedMADEPair(torch.autograd.Function):
         z = z.contiguous()
         Nrows, D = z.shape
         dev = z.device
-        ws = WS.zeros(2 * nh * 4 * H, dev).view(2, nh, 4, H)
+        ws = WS.zeros(2 * nh * WS_ROWS * H, dev).view(2, nh, WS_ROWS, H)
         acts = [[torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nh)] for _ in range(2)]
         outs = [torch.empty(Nrows, D, dtype=torch.float32, device=dev) for _ in range(2)]
 
@@ -243,15 +245,15 @@ class _FusedMADEPair(torch.autograd.Function):
 
         def bn_kw(n, j):
             g, b, rm, rv, nbt = BN(n, j)
-            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[n, j, 0], bn_sqsum=ws[n, j, 1], bn_center=Bs(n, j),
-                        bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[n, j, 2],
-                        bn_save_invstd=ws[n, j, 3])
+            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[n, j, 0], bn_sqsum=ws[n, j, R], bn_center=Bs(n, j),
+                        bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[n, j, 2 * R],
+                        bn_save_invstd=ws[n, j, 2 * R + 1])
 
         _launch_fwd([_desc(LinearDesc, in_=z, weight=W(n, 0), mask=M(n, 0), bias=Bs(n, 0), out=acts[n][0],
-                           stat_sum=ws[n, 0, 0], stat_sqsum=ws[n, 0, 1]) for n in range(2)], Nrows, D, H, training)
+                           stat_sum=ws[n, 0, 0], stat_sqsum=ws[n, 0, R]) for n in range(2)], Nrows, D, H, training)
         for l in range(1, nh):
             _launch_fwd([_desc(LinearDesc, in_=acts[n][l - 1], weight=W(n, l), mask=M(n, l), bias=Bs(n, l), out=acts[n][l],
-                               stat_sum=ws[n, l, 0], stat_sqsum=ws[n, l, 1], **bn_kw(n, l - 1)) for n in range(2)],
+                               stat_sum=ws[n, l, 0], stat_sqsum=ws[n, l, R], **bn_kw(n, l - 1)) for n in range(2)],
                         Nrows, H, H, training)
         _launch_fwd([_desc(LinearDesc, in_=acts[n][nh - 1], weight=W(n, nh), mask=M(n, nh), bias=Bs(n, nh), out=outs[n],
                            **bn_kw(n, nh - 1)) for n in range(2)], Nrows, H, D, training)
@@ -286,22 +288,22 @@ class _FusedMADEPair(torch.autograd.Function):
         g_outs = [g_s.contiguous(), g_t.contiguous()]
         slabs = bwd_slabs(Nrows)
         gw_all = torch.empty(2, nh + 1, slabs * H * H, dtype=torch.float32, device=dev)
-        per_acc = (nh + 1) * H + nh * 2 * H
+        per_acc = (nh + 1) * R * H + nh * 2 * R * H
         acc = WS.zeros(2 * per_acc, dev).view(2, per_acc)
         g_weff, g_bias, sums = [], [], []
         for n in range(2):
             g_weff.append([gw_all[n, l] for l in range(nh + 1)])
-            g_bias.append([acc[n, l * H:l * H + nets[n]['W'][l].shape[0]] for l in range(nh + 1)])
-            sums.append(acc[n, (nh + 1) * H:].view(nh, 2, H))
+            g_bias.append([acc[n, l * R * H:(l + 1) * R * H] for l in range(nh + 1)])
+            sums.append(acc[n, (nh + 1) * R * H:].view(nh, 2, R * H))
         gn = [[torch.empty(Nrows, H, dtype=torch.float32, device=dev) for _ in range(nh)] for _ in range(2)]
         g_z = [torch.empty(Nrows, D, dtype=torch.float32, device=dev) for _ in range(2)]
 
         def in_bn(n, j):
-            return dict(bn_gamma=nets[n]['gamma'][j], bn_beta=nets[n]['beta'][j], bn_save_mean=ws[n, j, 2],
-                        bn_save_invstd=ws[n, j, 3])
+            return dict(bn_gamma=nets[n]['gamma'][j], bn_beta=nets[n]['beta'][j], bn_save_mean=ws[n, j, 2 * R],
+                        bn_save_invstd=ws[n, j, 2 * R + 1])
 
         def cons_bn(n, j):
-            return dict(cbn_gamma=nets[n]['gamma'][j], cbn_save_mean=ws[n, j, 2], cbn_save_invstd=ws[n, j, 3],
+            return dict(cbn_gamma=nets[n]['gamma'][j], cbn_save_mean=ws[n, j, 2 * R], cbn_save_invstd=ws[n, j, 2 * R + 1],
                         cbn_sum_g=sums[n][j, 0] if training else None, cbn_sum_gx=sums[n][j, 1] if training else None)
 
         _launch_bwd([_desc(LinearBwdDesc, in_=nets[n]['acts'][nh - 1], weight=nets[n]['W'][nh], mask=nets[n]['M'][nh],

@@ -172,12 +172,12 @@ def main():
     out, res = torch.empty_like(x), torch.randn(Nr, 32, device=DEV)
     Wt, g, b = torch.randn(32, 32, device=DEV) * 0.2, torch.rand(32, device=DEV) + 0.5, torch.randn(32, device=DEV) * 0.1
     gamma, beta = torch.rand(32, device=DEV) + 0.5, torch.randn(32, device=DEV) * 0.1
-    ws = torch.zeros(8, 32, device=DEV)
-    ws[1] += Nr
+    ws = torch.zeros(64, 32, device=DEV)
+    ws[8] += Nr
     rm, rv, nbt = torch.zeros(32, device=DEV), torch.ones(32, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
     d = F._desc(F.LinearDesc, in_=x, weight=Wt, weight_g=g, bias=b, residual=res, out=out, bn_gamma=gamma, bn_beta=beta,
-                bn_sum=ws[0], bn_sqsum=ws[1], bn_center=b, bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt,
-                bn_save_mean=ws[2], bn_save_invstd=ws[3], stat_sum=ws[4], stat_sqsum=ws[5])
+                bn_sum=ws[0], bn_sqsum=ws[8], bn_center=b, bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt,
+                bn_save_mean=ws[16], bn_save_invstd=ws[24], stat_sum=ws[32], stat_sqsum=ws[40])
     report('linear_bn_fwd 32x32 (+BN,+WN,+res,+stats)', Nr * 32 * 4 * 3, lambda: F._launch_fwd([d], Nr, 32, 32, 1))
     flop = 2.0 * Nr * 32 * 32
     t = timeit(lambda: F._launch_fwd([d], Nr, 32, 32, 1))
@@ -185,11 +185,11 @@ def main():
     slabs = F.bwd_slabs(Nr)
     gn, gst = torch.empty_like(x), torch.empty_like(x)
     gweff = torch.empty(slabs * 1024, device=DEV)
-    acc = torch.zeros(8, 32, device=DEV)
-    db = F._desc(F.LinearBwdDesc, in_=x, weight=Wt, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[2],
-                 bn_save_invstd=ws[3], gn_src=res, out=out, g_skip=res, cbn_gamma=gamma, cbn_save_mean=ws[2],
-                 cbn_save_invstd=ws[3], cbn_sum_g=acc[0], cbn_sum_gx=acc[1], g_store=gst, g_bias=acc[2], g_weff=gweff,
-                 gn_out=gn, sum_g=acc[3], sum_gx=acc[4])
+    acc = torch.zeros(64, 32, device=DEV)
+    db = F._desc(F.LinearBwdDesc, in_=x, weight=Wt, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[16],
+                 bn_save_invstd=ws[24], gn_src=res, out=out, g_skip=res, cbn_gamma=gamma, cbn_save_mean=ws[16],
+                 cbn_save_invstd=ws[24], cbn_sum_g=acc[0], cbn_sum_gx=acc[8], g_store=gst, g_bias=acc[16], g_weff=gweff,
+                 gn_out=gn, sum_g=acc[24], sum_gx=acc[32])
     report('linear_bn_bwd 32x32 (all terms)', Nr * 32 * 4 * 6, lambda: F._launch_bwd([db], Nr, 32, 32))
     del x, out, res, gn, gst
 

@@ -37,25 +37,25 @@ def main():
         x, res, out, gn_src, gn_out, gst = (torch.randn(N, 32, device=dev) for _ in range(6))
         W, g, b = torch.randn(32, 32, device=dev) * 0.2, torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
         gamma, beta = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
-        ws = torch.zeros(8, 32, device=dev)
-        ws[1] += N
-        ws[3] += 1
+        ws = torch.zeros(64, 32, device=dev)
+        ws[8] += N
+        ws[24] += 1
         rm, rv, nbt = torch.zeros(32, device=dev), torch.ones(32, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
         d = F._desc(F.LinearDesc, in_=x, weight=W, weight_g=g, bias=b, residual=res, out=out, bn_gamma=gamma, bn_beta=beta,
-                    bn_sum=ws[0], bn_sqsum=ws[1], bn_center=b, bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt,
-                    bn_save_mean=ws[2], bn_save_invstd=ws[3], stat_sum=ws[4], stat_sqsum=ws[5])
+                    bn_sum=ws[0], bn_sqsum=ws[8], bn_center=b, bn_running_mean=rm, bn_running_var=rv, bn_num_batches=nbt,
+                    bn_save_mean=ws[16], bn_save_invstd=ws[24], stat_sum=ws[32], stat_sqsum=ws[40])
         fwd = graph_us(lambda: F._launch_fwd([d], N, 32, 32, 1))
         gweff = torch.empty(F.bwd_slabs(N) * 1024, device=dev)
-        acc = torch.zeros(8, 32, device=dev)
-        db = F._desc(F.LinearBwdDesc, in_=x, weight=W, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[2],
-                     bn_save_invstd=ws[3], gn_src=gn_src, out=out, cbn_gamma=gamma, cbn_save_mean=ws[2],
-                     cbn_save_invstd=ws[3], cbn_sum_g=acc[0], cbn_sum_gx=acc[1], g_bias=acc[2], g_weff=gweff, gn_out=gn_out,
-                     sum_g=acc[3], sum_gx=acc[4])
+        acc = torch.zeros(64, 32, device=dev)
+        db = F._desc(F.LinearBwdDesc, in_=x, weight=W, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[16],
+                     bn_save_invstd=ws[24], gn_src=gn_src, out=out, cbn_gamma=gamma, cbn_save_mean=ws[16],
+                     cbn_save_invstd=ws[24], cbn_sum_g=acc[0], cbn_sum_gx=acc[8], g_bias=acc[16], g_weff=gweff, gn_out=gn_out,
+                     sum_g=acc[24], sum_gx=acc[32])
         bwd = graph_us(lambda: F._launch_bwd([db], N, 32, 32))
-        db2 = F._desc(F.LinearBwdDesc, in_=x, weight=W, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[2],
-                      bn_save_invstd=ws[3], gn_src=gn_src, out=out, g_skip=res, g_store=gst, cbn_gamma=gamma,
-                      cbn_save_mean=ws[2], cbn_save_invstd=ws[3], cbn_sum_g=acc[0], cbn_sum_gx=acc[1], g_bias=acc[2],
-                      g_weff=gweff, gn_out=gn_out, sum_g=acc[3], sum_gx=acc[4])
+        db2 = F._desc(F.LinearBwdDesc, in_=x, weight=W, weight_g=g, bn_gamma=gamma, bn_beta=beta, bn_save_mean=ws[16],
+                      bn_save_invstd=ws[24], gn_src=gn_src, out=out, g_skip=res, g_store=gst, cbn_gamma=gamma,
+                      cbn_save_mean=ws[16], cbn_save_invstd=ws[24], cbn_sum_g=acc[0], cbn_sum_gx=acc[8], g_bias=acc[16],
+                      g_weff=gweff, gn_out=gn_out, sum_g=acc[24], sum_gx=acc[32])
         bwd2 = graph_us(lambda: F._launch_bwd([db2], N, 32, 32))
         one = torch.zeros(1, device=dev)
         tiny = graph_us(lambda: one.add_(1.0))
@@ -65,3 +65,30 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def variants():
+    N = 4096
+    x, res, out = (torch.randn(N, 32, device=dev) for _ in range(3))
+    W, g, b = torch.randn(32, 32, device=dev) * 0.2, torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+    gamma, beta = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+    ws = torch.zeros(64, 32, device=dev)
+    ws[8] += N
+    rm, rv, nbt = torch.zeros(32, device=dev), torch.ones(32, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    parts = {
+        'plain': dict(),
+        'wn': dict(weight_g=g),
+        'bn': dict(bn_gamma=gamma, bn_beta=beta, bn_sum=ws[0], bn_sqsum=ws[8], bn_center=b, bn_running_mean=rm,
+                   bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[16], bn_save_invstd=ws[24]),
+        'stats': dict(stat_sum=ws[32], stat_sqsum=ws[40]),
+        'res': dict(residual=res),
+    }
+    parts['all'] = {k: v for d in parts.values() for k, v in d.items()}
+    for name, kw in parts.items():
+        d = F._desc(F.LinearDesc, in_=x, weight=W, bias=b, out=out, **kw)
+        print('fwd N=4096 %-6s train %6.2f us   eval %6.2f us' % (name, graph_us(lambda: F._launch_fwd([d], N, 32, 32, 1)),
+                                                                 graph_us(lambda: F._launch_fwd([d], N, 32, 32, 0))))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'variants':
+    variants()

@@ -47,13 +47,13 @@ def main():
         xin, gn_src, out, gn_out = (torch.randn(Nr, 32, device=dev) for _ in range(4))
         Wt, wg = torch.randn(32, 32, device=dev) * 0.2, torch.rand(32, device=dev) + 0.5
         gam, bet = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
-        ws = torch.zeros(8, 32, device=dev)
-        ws[3] += 1
+        ws = torch.zeros(64, 32, device=dev)
+        ws[24] += 1
         gweff = torch.empty(F.bwd_slabs(Nr) * 1024, device=dev)
-        d = F._desc(F.LinearBwdDesc, in_=xin, weight=Wt, weight_g=wg, bn_gamma=gam, bn_beta=bet, bn_save_mean=ws[2],
-                    bn_save_invstd=ws[3], gn_src=gn_src, out=out, cbn_gamma=gam, cbn_save_mean=ws[2],
-                    cbn_save_invstd=ws[3], cbn_sum_g=ws[4], cbn_sum_gx=ws[5], g_bias=ws[6], g_weff=gweff, gn_out=gn_out,
-                    sum_g=ws[0], sum_gx=ws[1])
+        d = F._desc(F.LinearBwdDesc, in_=xin, weight=Wt, weight_g=wg, bn_gamma=gam, bn_beta=bet, bn_save_mean=ws[16],
+                    bn_save_invstd=ws[24], gn_src=gn_src, out=out, cbn_gamma=gam, cbn_save_mean=ws[16],
+                    cbn_save_invstd=ws[24], cbn_sum_g=ws[32], cbn_sum_gx=ws[40], g_bias=ws[48], g_weff=gweff, gn_out=gn_out,
+                    sum_g=ws[0], sum_gx=ws[8])
         for _ in range(reps):
             F._launch_bwd([d], Nr, 32, 32)
         torch.cuda.synchronize()
