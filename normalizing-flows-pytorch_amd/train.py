@@ -116,19 +116,28 @@ class FlowTrainer:
             self.optim.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb):
+        # thread_local: a collective watchdog / other host thread touching the runtime must not invalidate the capture
+        g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb, capture_error_mode='thread_local'):
             z, loss = self._forward_backward(self._static_y)
             self._static_z, self._static_loss = z.detach(), loss.detach()
-        self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt):
+        g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_opt, capture_error_mode='thread_local'):
             self.optim.step()
+        self._g_fb, self._g_opt = g_fb, g_opt
 
     def train_on_batch(self, y):
         """returns (z, loss) like main.py:78-92; with graph=True the returned tensors are the graph's static outputs."""
         self.net.train()
         if self.graph and self._g_fb is None and self._eager_steps >= self.warmup:
-            self._capture(y)
+            try:
+                self._capture(y)
+            except Exception as e:                      # keep training eagerly rather than dying on a capture problem
+                import warnings
+                warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
+                self.graph = False
+                self._g_fb = self._g_opt = None
+                torch.cuda.synchronize()
         if self._g_fb is not None:
             self._static_y.copy_(y, non_blocking=True)
             self._g_fb.replay()
