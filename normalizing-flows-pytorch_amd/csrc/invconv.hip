@@ -211,11 +211,21 @@ static void nf_launch_apply(int C, dim3 grid, hipStream_t st, const float* z, co
 #undef NF_CASE
 }
 
+// fp32-MFMA forms for 9 <= C <= 64 (invconv_mfma.hip); return 1 when they took the launch
+__attribute__((visibility("hidden"))) int nf_invconv_apply_mfma_try(const float* z, const float* M, int transpose, float* y, float* ld,
+                                         const float* log_s, float ld_sign, int64_t B, int C, int P, void* stream);
+__attribute__((visibility("hidden"))) int nf_invconv_wgrad_mfma_try(const float* g_y, const float* z, float* g_M, int64_t B, int C, int P,
+                                         void* stream);
+
 extern "C" int nf_invconv_apply(const float* z, const float* M, int transpose, float* y, float* ld, const float* log_s,
                                 float ld_sign, int64_t B, int C, int P, nf_stream_t stream) {
     if (C <= 0 || P <= 0 || C > 1024) return NF_E_BADARG;
     if (ld != nullptr && log_s == nullptr) return NF_E_BADARG;
     if (B == 0) return 0;
+    if (nf_invconv_apply_mfma_try(z, M, transpose, y, ld, log_s, ld_sign, B, C, P, stream) == 1) {
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     unsigned g = nf_grid_for(B * P);
     const unsigned g_ld = nf_grid_for(B);
     if (ld != nullptr && g < g_ld) g = g_ld;
@@ -228,8 +238,12 @@ extern "C" int nf_invconv_apply(const float* z, const float* M, int transpose, f
 extern "C" int nf_invconv_wgrad(const float* g_y, const float* z, float* g_M, int64_t B, int C, int P,
                                 nf_stream_t stream) {
     if (C <= 0 || P <= 0) return NF_E_BADARG;
-    if (C * C > 12 * NF_BLOCK) return NF_E_UNSUPPORTED;
     if (B == 0) return 0;
+    if (nf_invconv_wgrad_mfma_try(g_y, z, g_M, B, C, P, stream) == 1) {
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
+    if (C * C > 12 * NF_BLOCK) return NF_E_UNSUPPORTED;
     const int64_t npix = B * P;
     const int64_t tiles = (npix + NF_TP - 1) / NF_TP;
     int64_t blocks = tiles < 512 ? tiles : 512;
