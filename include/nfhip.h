@@ -304,6 +304,27 @@ typedef struct nf_weight_grad_desc {
 } nf_weight_grad_desc;
 int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, float wn_eps, nf_stream_t stream);
 
+/* ---- invertible residual block (Residual Flow), D <= 4 features, hidden width 32  iresblock.py:17-109, :229-278 ------
+ * g(x) = W3 lipswish(W2 lipswish(W1 x + b1) + b2) + b3 with the EFFECTIVE (spectrally normalised) weights.
+ * nf_resmlp_fwd: y = x + g(x) (y nullable) and, by `mode`: 0 nothing; 1 ld[b] += ld_sign * log|det(I + J_b)| (exact,
+ *   iresblock.py:17-32); 2 ld[b] += ld_sign * mean_s sum_{k<=n_terms[s]} coef[s*64 + k-1] * v_s^T (J_b^T)^k v_s with host-
+ *   drawn noise (B, S, D) -- the power-series / Russian-roulette estimators (iresblock.py:35-81) on the exact per-sample
+ *   Jacobian instead of nested autograd sweeps.
+ * nf_resmlp_fixed_point_step: one iteration x <- z - g(x) of the inverse (iresblock.py:243-249); flags (int32[>=it+1],
+ *   zeroed by the caller) carry the reference's batch-global exit: the step is a no-op when flags[it-1] == 0, and it sets
+ *   flags[it] when some |x_new - x| >= ftol.
+ * nf_spectral_weights: flows/spectral_norm.py:26-43 for up to 3 matrices in one launch (one power iteration, u / v
+ *   updated in place, W_eff = W_bar * min(coeff/(sigma+eps), 1)); gated by the same flags when flags != NULL.          */
+int nf_resmlp_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                  const float* b3, const float* beta1, const float* beta2, float* y, float* ld, float ld_sign, int mode,
+                  const float* noise, const float* coef, const int* n_terms, int S, int64_t B, int D, nf_stream_t stream);
+int nf_resmlp_fixed_point_step(const float* z, float* x, const float* W1, const float* b1, const float* W2, const float* b2,
+                               const float* W3, const float* b3, const float* beta1, const float* beta2, int* flags,
+                               int iteration, float ftol, int64_t B, int D, nf_stream_t stream);
+int nf_spectral_weights(const float* const* W_bar, float* const* u, float* const* v, float* const* W_eff, const int* rows,
+                        const int* cols, int n_mats, float coeff, float eps, const int* flags, int iteration,
+                        nf_stream_t stream);
+
 /* ---- NLL of the training harness  main.py:49-51, :85 -------------------------------------------------------------
  * loss[0] += -(1/B) * sum_b ( -0.5*|z_b|^2 - 0.5*D*log(2 pi) + ld[b] )   (caller zero-fills loss)            */
 int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream);

@@ -117,6 +117,37 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad(const float* __restr
     }
 }
 
+// small C (<= 4): every thread keeps the whole C x C partial in registers, one block reduction + C*C atomics per block
+template <int CT>
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad_small(const float* __restrict__ gy, const float* __restrict__ z,
+                                                                  float* __restrict__ gM, int64_t B, int P) {
+    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    float acc[CT][CT];
+#pragma unroll
+    for (int r = 0; r < CT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = 0.f;
+    const int64_t npix = B * P;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npix; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / P;
+        const int64_t base = b * CT * P + (t - b * P);
+        float g[CT], v[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { g[c] = gy[base + (int64_t)c * P]; v[c] = z[base + (int64_t)c * P]; }
+#pragma unroll
+        for (int r = 0; r < CT; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[r][c] = fmaf(g[r], v[c], acc[r][c]);
+    }
+#pragma unroll
+    for (int r = 0; r < CT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float t = nf_block_sum(acc[r][c], scratch);
+            if (threadIdx.x == 0) atomicAdd(gM + r * CT + c, t);
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // PLU weight assembly (modules.py:471-473) and its autograd, one workgroup (C <= 64: three C x C tiles in LDS).
 //   W = P L' U',  L' = L o L_mask + I,  U' = U o U_mask + diag(sign_s exp(log_s))
@@ -240,6 +271,19 @@ extern "C" int nf_invconv_wgrad(const float* g_y, const float* z, float* g_M, in
     if (C <= 0 || P <= 0) return NF_E_BADARG;
     if (B == 0) return 0;
     if (nf_invconv_wgrad_mfma_try(g_y, z, g_M, B, C, P, stream) == 1) {
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
+    if (C <= 4) {
+        unsigned g = nf_grid_for(B * P, NF_BLOCK * 4);
+        if (g > 512) g = 512;
+        hipStream_t st = (hipStream_t)stream;
+        switch (C) {
+            case 1: hipLaunchKernelGGL(k_invconv_wgrad_small<1>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
+            case 2: hipLaunchKernelGGL(k_invconv_wgrad_small<2>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
+            case 3: hipLaunchKernelGGL(k_invconv_wgrad_small<3>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
+            default: hipLaunchKernelGGL(k_invconv_wgrad_small<4>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
+        }
         NF_CHECK_LAUNCH();
         return 0;
     }

@@ -2,19 +2,25 @@
 Residual Flow (invertible residual blocks): flows/iresblock.py:17-301, flows/spectral_norm.py:5-72,
 flows/modules.py:215-222 (LipSwish), flows/resflow.py:9-38 -- SURVEY.md section 8(a) row a15.
 
-Status (round 1): the ActNorm in front of every block runs on the HIP path; the residual block itself is restated on
-PyTorch-ROCm autograd (the log-det estimators are nested vector-Jacobian products of a 2->32->32->2 LipSwish MLP; no
-BASELINE config exercises them).  Same module / parameter names as the reference, same estimator semantics
+Status (round 1): evaluation-mode forward (all three log-det estimators) and the fixed-point inverse run on HIP kernels
+(csrc/resmlp.hip: per-sample exact Jacobian of the 2->32->32->2 LipSwish MLP, spectral normalisation, flag-gated
+iteration launches) for D <= 4; TRAINING (the Neumann-series gradient estimator needs second derivatives) is restated on
+PyTorch-ROCm autograd.  No BASELINE config exercises this family.  Same module / parameter names as the reference, same estimator semantics
 (Russian-roulette series for training, `exact` / `fixed` / `unbias` for evaluation, fixed-point inverse with the
 batch-global exit), same RNG consumption order (np.random.geometric, then a normal draw) so seeded runs are
 comparable; `noise_on_cpu = True` draws the Hutchinson noise from the CPU generator (parity tests).
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _native as N
 from .layers import ActNorm, Compose
+
+HIP_MAX_D, SERIES_MAXK, SERIES_MAXS = 4, 64, 4
 
 
 class LipSwish(nn.Module):
@@ -142,13 +148,103 @@ class InvertibleResLinear(nn.Module):
             return self._unbias(g, z, 4, 8, False)
         raise Exception('Unknown log-det estimator: %s' % (self.estimator, ))
 
+    # ---- HIP path (evaluation / sampling) -----------------------------------------------------------------------------------
+    def _hip_ok(self, x):
+        sn = [m for m in self.g_fn if isinstance(m, SpectralNorm)]
+        return (x.is_cuda and x.dim() == 2 and x.shape[1] <= HIP_MAX_D and x.dtype == torch.float32 and len(sn) == 3
+                and sn[0].module.weight_bar.shape[0] == 32 and sn[1].module.weight_bar.shape == (32, 32))
+
+    def _hip_weights(self, flags=None, it=0):
+        """spectral normalisation of the three matrices in ONE launch (power iteration buffers updated in place)."""
+        sn = [m for m in self.g_fn if isinstance(m, SpectralNorm)]
+        for m in sn:
+            if 'weight' in m.module._parameters:
+                del m.module._parameters['weight']
+        if getattr(self, '_weff', None) is None or self._weff[0].device != sn[0].module.weight_bar.device:
+            self._weff = [torch.empty_like(m.module.weight_bar) for m in sn]
+        P3 = ctypes.c_void_p * 3
+        I3 = ctypes.c_int * 3
+        wb = P3(*[m.module.weight_bar.data_ptr() for m in sn])
+        uu = P3(*[m.module.weight_u.data_ptr() for m in sn])
+        vv = P3(*[m.module.weight_v.data_ptr() for m in sn])
+        we = P3(*[t.data_ptr() for t in self._weff])
+        rows = I3(*[m.module.weight_bar.shape[0] for m in sn])
+        cols = I3(*[m.module.weight_bar.shape[1] for m in sn])
+        N.call('nf_spectral_weights', ctypes.addressof(wb), ctypes.addressof(uu), ctypes.addressof(vv), ctypes.addressof(we),
+               ctypes.addressof(rows), ctypes.addressof(cols), 3, float(self.coeff), float(sn[0].eps),
+               None if flags is None else flags.data_ptr(), it, N.stream())
+        acts = [m for m in self.g_fn if isinstance(m, LipSwish)]
+        return [self._weff[0], sn[0].module.bias, self._weff[1], sn[1].module.bias, self._weff[2], sn[2].module.bias,
+                acts[0].beta, acts[1].beta]
+
+    def _series(self, g_like, training):
+        """(mode, noise, coef, n_terms, S): the estimator the reference would pick, noise drawn in its order."""
+        if not training and self.estimator == 'exact':
+            return 1, None, None, None, 0
+        B, D = g_like.shape
+        dev = g_like.device
+        coef = np.zeros((SERIES_MAXS, SERIES_MAXK), dtype=np.float32)
+        if not training and self.estimator == 'fixed':
+            S, nts = 4, [8] * 4
+            noise = self._randn_like(g_like, (B, S, D))
+            for s_ in range(S):
+                for k in range(1, 9):
+                    coef[s_, k - 1] = (-1) ** (k + 1) / k
+        else:
+            if training:
+                S, n_exact = 1, 1
+            elif self.estimator == 'unbias':
+                S, n_exact = 4, 8
+            else:
+                raise Exception('Unknown log-det estimator: %s' % (self.estimator, ))
+            nts, vs, p = [], [], 0.5
+            for s_ in range(S):
+                n = n_exact + np.random.geometric(p)
+                vs.append(self._randn_like(g_like))
+                n = min(int(n), SERIES_MAXK)
+                nts.append(n)
+                for k in range(1, n + 1):
+                    coef[s_, k - 1] = (-1) ** (k + 1) / (k * (1.0 - p) ** max(0, (k - n_exact) - 1))
+            noise = torch.stack(vs, dim=1)
+        return (2, noise.contiguous(), torch.from_numpy(coef).to(dev), torch.tensor(nts + [0] * (SERIES_MAXS - len(nts)),
+                                                                                  dtype=torch.int32, device=dev), S)
+
+    def _hip_logdet(self, w, x, y, ld, sign, training):
+        mode, noise, coef, nts, S = self._series(x, training)
+        B, D = x.shape
+        N.call('nf_resmlp_fwd', N.ptr(x), *[N.ptr(t.detach()) for t in w], None if y is None else N.ptr(y), N.ptr(ld),
+               float(sign), mode, None if noise is None else N.ptr(noise), None if coef is None else N.ptr(coef),
+               None if nts is None else nts.data_ptr(), S, B, D, N.stream())
+
     # ---- flow surface ---------------------------------------------------------------------------------------------------
     def forward(self, x, log_df_dz):
+        if not self.training and not torch.is_grad_enabled() and self._hip_ok(x):
+            x = x.contiguous()
+            w = self._hip_weights()
+            np.random.geometric(0.5)                     # the reference evaluates (and discards) the Neumann surrogate first:
+            self._randn_like(x)                          # keep the RNG streams aligned with it (iresblock.py:127)
+            y = torch.empty_like(x)
+            ld = log_df_dz.clone()
+            self._hip_logdet(w, x, y, ld, 1.0, False)
+            return y, ld
         params = [p for p in self.g_fn.parameters() if p.requires_grad]
         g, logdet = _ResidualBranch.apply(self, x, *params)
         return x + g, log_df_dz + logdet
 
     def backward(self, z, log_df_dz):
+        if self._hip_ok(z):
+            z = z.contiguous()
+            x = z.clone()
+            B, D = z.shape
+            flags = torch.zeros(101, dtype=torch.int32, device=z.device)
+            for it in range(100):                        # flag-gated single-iteration launches: batch-global exit, no sync
+                w = self._hip_weights(flags, it)
+                N.call('nf_resmlp_fixed_point_step', N.ptr(z), N.ptr(x), *[N.ptr(t.detach()) for t in w], flags.data_ptr(),
+                       it, float(self.ftol), B, D, N.stream())
+            w = self._hip_weights()                      # the final g_fn(x) of the reference (one more power iteration)
+            ld = log_df_dz.clone()
+            self._hip_logdet(w, x, None, ld, -1.0, self.training)
+            return x, ld
         x = z.clone()
         with torch.enable_grad():
             for _ in range(100):
