@@ -353,3 +353,96 @@ def made_pair_forward(net_s, net_t, z, masks_s, masks_t):
             tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
     training = net_s.training
     return _FusedMADEPair.apply(z, training, nh, *tensors)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Flow++ conditioner (density data): the whole gated-attention stack in one launch
+# ----------------------------------------------------------------------------------------------------------------------
+def flowpp_cond_fusable(net, x):
+    """net: the nn.Sequential of MixLogAttnCoupling for len(dims) == 1 (coupling.py:142-149)."""
+    try:
+        first, gated, ln1, attn, ln2, last = net
+    except (TypeError, ValueError):
+        return False
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and isinstance(first, torch.nn.Linear)
+            and first.in_features <= 4 and first.out_features == H and attn.filters == H and attn.channels == H
+            and isinstance(last, torch.nn.Linear) and last.out_features <= 64 and tuple(ln1.normalized_shape) == (H, ))
+
+
+def _flowpp_tensors(net):
+    first, gated, ln1, attn, ln2, last = net
+    F_ = attn.filters
+    return [first.weight, first.bias, gated.op.weight, gated.op.bias, ln1.weight, ln1.bias, attn.pos_emb,
+            attn.conv1.weight, attn.conv1.bias, attn.conv2.weight, attn.conv2.bias, ln2.weight, ln2.bias, last.weight,
+            last.bias], F_
+
+
+def _flowpp_fwd_args(ts, F_):
+    (W0, b0, Wg, bg, l1g, l1b, pos, c1w, c1b, c2w, c2b, l2g, l2b, W5, b5) = [t.detach() for t in ts]
+    # the single-position attention only sees conv1's Q rows [2F:3F] (the softmax over one key is identically 1)
+    return [N.ptr(W0), N.ptr(b0), N.ptr(Wg), N.ptr(bg), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), c1w.data_ptr() + 4 * 2 * F_ * H,
+            c1b.data_ptr() + 4 * 2 * F_, N.ptr(c2w), N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(W5), N.ptr(b5)]
+
+
+class _FusedFlowppCond(torch.autograd.Function):
+    """x (N, I0) -> the (N, O) coupling parameters; one launch forward, one launch backward (csrc/flowpp_cond.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, F_, *ts):
+        for t in ts:
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise RuntimeError('fused Flow++ conditioner needs contiguous fp32 device parameters')
+        x = x.contiguous()
+        Nrows, I0 = x.shape
+        O = ts[13].shape[0]
+        out = torch.empty(Nrows, O, dtype=torch.float32, device=x.device)
+        N.call('nf_flowpp_cond_fwd', N.ptr(x), *_flowpp_fwd_args(ts, F_), N.ptr(out), Nrows, I0, O, N.stream())
+        ctx.save_for_backward(x, *ts)
+        ctx.F_ = F_
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, *ts = ctx.saved_tensors
+        F_ = ctx.F_
+        Nrows, I0 = x.shape
+        O = ts[13].shape[0]
+        g_out = g_out.contiguous()
+        from .functional import _sinks
+        sinks = _sinks(*ts)
+        if sinks is not None:
+            dst, direct = sinks, True
+        else:                                                    # handed to autograd, which may keep them: not arena memory
+            flat = torch.zeros(sum(t.numel() for t in ts), dtype=torch.float32, device=x.device)
+            dst, o = [], 0
+            for t in ts:
+                dst.append(flat[o:o + t.numel()].view(t.shape))
+                o += t.numel()
+            direct = False
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d = [t.data_ptr() for t in dst]
+        d[7] += 4 * 2 * F_ * H                                   # conv1 gradient rows [2F:3F]; V / K rows stay exactly zero
+        d[8] += 4 * 2 * F_
+        N.call('nf_flowpp_cond_bwd', N.ptr(x), *_flowpp_fwd_args(ts, F_), N.ptr(g_out), _p(g_x), *d, Nrows, I0, O, N.stream())
+        if direct:
+            return (g_x, None) + (None, ) * len(ts)
+        return (g_x, None) + tuple(dst)
+
+
+def flowpp_cond_forward(net, x):
+    """the (N, O) output of the density Flow++ conditioner ``net`` (see flowpp_cond_fusable)."""
+    ts, F_ = _flowpp_tensors(net)
+    return _FusedFlowppCond.apply(x, F_, *ts)
+
+
+def flowpp_cond_forward_nograd(net, x):
+    (W0, b0, Wg, bg, l1g, l1b, pos, c1w, c1b, c2w, c2b, l2g, l2b, W5, b5), F_ = _flowpp_tensors(net)
+    x = x.contiguous()
+    Nrows, I0 = x.shape
+    O = W5.shape[0]
+    out = torch.empty(Nrows, O, dtype=torch.float32, device=x.device)
+    N.call('nf_flowpp_cond_fwd', N.ptr(x), N.ptr(W0.detach()), N.ptr(b0.detach()), N.ptr(Wg.detach()), N.ptr(bg.detach()),
+           N.ptr(l1g.detach()), N.ptr(l1b.detach()), N.ptr(pos.detach()), c1w.data_ptr() + 4 * 2 * F_ * H,
+           c1b.data_ptr() + 4 * 2 * F_, N.ptr(c2w.detach()), N.ptr(c2b.detach()), N.ptr(l2g.detach()), N.ptr(l2b.detach()),
+           N.ptr(W5.detach()), N.ptr(b5.detach()), N.ptr(out), Nrows, I0, O, N.stream())
+    return out

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import _native as N
 from . import functional as NF
+from . import fused as FUSED
 from .conditioners import MLP, ConvNet, flowpp_conditioner, made_degrees_to_masks
 
 
@@ -340,13 +341,21 @@ class MixLogAttnCoupling(AbstractCoupling):
         self.net = flowpp_conditioner(in_chs, sum(self.sections), mid_shape, base_filters, conv=(len(dims) == 3))
         self.logit_eps = 1.0e-5                      # Logit() default inside the coupling (coupling.py:169)
 
+    def conditioner(self, z):
+        """coupling parameters from the untouched half; density data runs the whole gated-attention stack as one
+        launch per direction (csrc/flowpp_cond.hip), image data the module stack."""
+        x = self.conditioner_input(z)
+        if FUSED.flowpp_cond_fusable(self.net, x):
+            return FUSED.flowpp_cond_forward(self.net, x)
+        return self.net(x)
+
     def forward(self, z, log_df_dz):
-        params = self.net(self.conditioner_input(z))
+        params = self.conditioner(z)
         return NF.mixlog_coupling(z, params, self.a_log_scale, self.a_bias, log_df_dz, self.n_mixtures, self.mode,
                                   self.odd, logit_eps=self.logit_eps)
 
     def backward(self, z, log_df_dz):
-        params = self.net(self.conditioner_input(z))
+        params = self.conditioner(z)
         return NF.mixlog_coupling(z, params, self.a_log_scale, self.a_bias, log_df_dz, self.n_mixtures, self.mode,
                                   self.odd, inverse=True)
 

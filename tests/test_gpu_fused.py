@@ -108,3 +108,57 @@ def test_fused_made_pair_vs_modules(pkg, D, N, training):
     br, bf = dict(ref.named_buffers()), dict(fus.named_buffers())
     for k in br:
         G.assert_close(bf[k].float(), br[k].float(), 2e-6, rtol=1e-5, what='buffer ' + k)
+
+
+@pytest.mark.parametrize('D,K,N', [(2, 8, 65536), (2, 8, 77), (2, 4, 1000), (4, 8, 300), (8, 4, 64)])
+def test_fused_flowpp_conditioner_forward(pkg, D, K, N):
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 10 + K)
+    layer = pkg.MixLogAttnCoupling((D, ), n_mixtures=K).to(DEV)
+    with torch.no_grad():
+        for m in layer.net.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+    x = (torch.randn(N, D // 2) * 0.8).to(DEV)
+    assert fused.flowpp_cond_fusable(layer.net, x)
+    with torch.no_grad():
+        want = layer.net(x)
+        got = fused.flowpp_cond_forward_nograd(layer.net, x)
+    G.assert_close(got, want, 2e-5, rtol=2e-5, what='flow++ conditioner forward')
+
+
+@pytest.mark.parametrize('direct', [False, True])
+@pytest.mark.parametrize('D,K,N', [(2, 8, 65536), (2, 8, 77), (2, 4, 1000), (4, 8, 300), (8, 4, 64), (2, 8, 1)])
+def test_fused_flowpp_conditioner_backward(pkg, D, K, N, direct):
+    """one-launch backward of the gated-attention conditioner against autograd through the module stack
+    (flows/coupling.py:142-149): input gradient and every parameter gradient, conv1's V/K rows exactly zero."""
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 10 + K)
+    layer = pkg.MixLogAttnCoupling((D, ), n_mixtures=K).to(DEV)
+    with torch.no_grad():
+        for m in layer.net.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+    x = (torch.randn(N, D // 2) * 0.8).to(DEV).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    w = torch.randn(N, layer.net[-1].out_features, device=DEV)
+    want = layer.net(x)
+    (want * w).sum().backward()
+    ref = {k: p.grad.clone() for k, p in layer.net.named_parameters()}
+    for p in layer.net.parameters():
+        p.grad = None
+    if direct:
+        for p in layer.net.parameters():
+            p.grad = torch.zeros_like(p)
+            p._nf_direct_grad = True
+    got = fused.flowpp_cond_forward(layer.net, x2)
+    G.assert_close(got, want, 2e-5, rtol=2e-5, what='forward')
+    (got * w).sum().backward()
+    G.assert_close(x2.grad, x.grad, _grad_tol(x.grad), what='input grad')
+    for k, p in layer.net.named_parameters():
+        G.assert_close(p.grad, ref[k], _grad_tol(ref[k]), what='grad ' + k)
+    F_ = layer.net[3].filters
+    assert torch.count_nonzero(layer.net[3].conv1.weight.grad[:2 * F_]) == 0
+    assert torch.count_nonzero(layer.net[3].conv1.bias.grad[:2 * F_]) == 0
