@@ -52,6 +52,17 @@ def header_prototypes(path=HEADER):
     return protos
 
 
+def header_constant(name):
+    """integer value of a ``#define NAME (expr)`` in include/nfhip.h (products of integer literals only)."""
+    m = re.search(r'^#define\s+%s\s+\(?([0-9\s\*]+)\)?\s*$' % re.escape(name), open(HEADER).read(), re.M)
+    if m is None:
+        raise NativeLibraryError('include/nfhip.h does not define %s' % name)
+    v = 1
+    for f in m.group(1).split('*'):
+        v *= int(f)
+    return v
+
+
 def load():
     """dlopen libnfhip.so (after torch, so that it binds to the HIP runtime torch already loaded)."""
     global _lib

@@ -5,37 +5,56 @@
 // Everything is per-sample independent (LayerNorm, not BatchNorm), so the whole network is ONE launch forward and ONE
 // launch backward (the backward recomputes the forward from the 4-byte input instead of saving eight activations).
 //
-// Work decomposition: a wave owns 32-row tiles.  Activations live in registers in the MFMA *A layout* (lane = row,
-// half-wave = feature half, 16 features per lane), every 32x32 GEMM is 16 issues of v_mfma_f32_32x32x2_f32 with the
-// B fragment read from LDS-resident weights (row stride +1: conflict-free for both W and W^T walks), and the C/D result
-// is turned back into the A layout through a padded LDS tile.  Element-wise work (concat-ELU, gates, LayerNorm) is done
-// in the A layout where a row's statistics are an in-lane sum + one cross-half shuffle.
-// Replaces ~40 framework kernels forward / ~80 backward per coupling layer (0.5 ms / 1.7 ms at B = 65536).
+// Work decomposition: a wave owns 16-row tiles and v_mfma_f32_16x16x4_f32.  Activations live in registers in a
+// row-per-lane layout "R": lane (row = l & 15, g = l >> 4) holds features 16 b + 4 g + r (b = 0..1, r = 0..3) of its
+// row, 8 registers per 32-wide vector.  R is at the same time
+//   * the B-operand layout  (B[k][j = row], k-group g)   and
+//   * the C/D layout of a product whose A operand is the weight matrix (D[i = out feature][j = row]: lane col = row,
+//     rows 4 g + r), i.e. of  out^T = W act^T,
+// so a chain of linears runs register to register: every GEMM takes the previous one's accumulators as its B operand and
+// reads only its weight fragment from LDS.  No layout conversion, no barrier; element-wise work (concat-ELU, gates,
+// LayerNorm) happens in R where a row's statistics are an in-lane sum and two cross-group shuffles.
+// Only the weight gradients (K = rows) need the transposed view: the two operands go through a wave-private LDS tile,
+// the 16x16 products accumulate in registers across the wave's tiles (LDS float atomics measured ~160 cycles per wave
+// instruction on gfx950 -- 140 us per launch -- so there are none), and each block leaves ONE partial-sum slab that a
+// small second kernel folds into the destinations (same-address global atomics from 256 blocks cost 45 us).
+#include <type_traits>
+
 #include "nf_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define NF_FP_WAVES 4
-#define NF_FP_TS 33
+#define NF_FP_ST 36          // LDS row stride of 32-wide matrices and tiles: 16-byte aligned rows, conflict-free b128 reads
+#define NF_FP_STG 68         // same for the 64-wide GatedLinear weight
+#define NF_FP_FWD_WAVES 8
+#define NF_FP_BWD_WAVES 8
+#define NF_FP_MAX_BLOCKS 256   // backward grid cap = number of partial-sum slabs in the workspace
+#define NF_FP_WAVE_LDS (2 * 16 * NF_FP_ST + 3 * 512)   // per backward wave: two 16 x 32 tiles + three stashed vectors
 #define NF_FP_LNEPS 1.0e-5f
-#define NF_FP_BWD_TILES 7   // per wave: conversion, gradient, five stashed activations
 
 struct NfFppW {   // device pointers (forward operands)
     const float *x, *W0, *b0, *Wg, *bg, *ln1g, *ln1b, *pos, *Wq, *bq, *W2, *b2, *ln2g, *ln2b, *W5, *b5;
     float* out;
 };
 
-// LDS layout (floats)
-struct NfFppL {
-    int Wg, Wq, W2, W5, W0, b0, bg, ln1g, ln1b, pos, bq, b2, ln2g, ln2b, b5, tiles, total;
+struct NfFppG {   // gradient destinations, all ACCUMULATED (+=): zero-filled temporaries or .grad buffers
+    const float* g_out;          // (N, O)
+    float* g_x;                  // (N, I0) written, nullable
+    float *g_W0, *g_b0, *g_Wg, *g_bg, *g_ln1g, *g_ln1b, *g_pos, *g_Wq, *g_bq, *g_W2, *g_b2, *g_ln2g, *g_ln2b, *g_W5, *g_b5;
 };
-__host__ __device__ inline NfFppL nf_fpp_layout(int I0, int tiles_per_wave) {
+
+// LDS layout (floats): the weights, then (backward) the per-wave tiles
+struct NfFppL {
+    int Wg, Wq, W2, W5, W0, b0, bg, ln1g, ln1b, pos, bq, b2, ln2g, ln2b, b5, wend;
+    int tiles, total;
+};
+__host__ __device__ inline NfFppL nf_fpp_layout(int bwd_waves) {
     NfFppL L;
     int o = 0;
-    L.Wg = o; o += 32 * 65;
-    L.Wq = o; o += 32 * 33;
-    L.W2 = o; o += 64 * 33;
-    L.W5 = o; o += 64 * 33;
+    L.Wg = o; o += 32 * NF_FP_STG;
+    L.Wq = o; o += 32 * NF_FP_ST;
+    L.W2 = o; o += 64 * NF_FP_ST;
+    L.W5 = o; o += 64 * NF_FP_ST;
     L.W0 = o; o += 32 * 4;
     L.b0 = o; o += 32;
     L.bg = o; o += 32;
@@ -47,22 +66,33 @@ __host__ __device__ inline NfFppL nf_fpp_layout(int I0, int tiles_per_wave) {
     L.ln2g = o; o += 32;
     L.ln2b = o; o += 32;
     L.b5 = o; o += 64;
-    L.tiles = o; o += NF_FP_WAVES * tiles_per_wave * 32 * NF_FP_TS;
+    L.wend = o;
+    L.tiles = o; o += bwd_waves * NF_FP_WAVE_LDS;
     L.total = o;
-    (void)I0;
     return L;
 }
 
-__device__ __forceinline__ int nf_fp_cdrow(int r, int hs) { return (r & 3) + 8 * (r >> 2) + 4 * hs; }
-__device__ __forceinline__ float nf_elu(float x) { return x > 0.f ? x : expf(x) - 1.f; }          // F.elu, alpha = 1
-__device__ __forceinline__ float nf_elu_grad(float x) { return x > 0.f ? 1.f : expf(x); }
-__device__ __forceinline__ float nf_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float nf_fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float nf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + nf_fexp(-x)); }
+// concat-ELU pair and its derivatives from ONE exponential: e = exp(-|h|)
+//   h > 0: elu(h) = h, elu(-h) = e - 1, elu'(h) = 1, elu'(-h) = e;   h <= 0: elu(h) = e - 1, elu(-h) = -h, elu'(h) = e, elu'(-h) = 1
+__device__ __forceinline__ void nf_celu(float h, float& c0, float& c1) {
+    const float e = nf_fexp(-fabsf(h)) - 1.f;
+    c0 = h > 0.f ? h : e;
+    c1 = h > 0.f ? e : -h;
+}
+__device__ __forceinline__ void nf_celu_grad(float h, float& d0, float& d1) {
+    const float e = nf_fexp(-fabsf(h));
+    d0 = h > 0.f ? 1.f : e;
+    d1 = h > 0.f ? e : 1.f;
+}
 
 __device__ __forceinline__ void nf_fpp_stage(const NfFppW& w, float* sm, const NfFppL& L, int I0, int O) {
-    for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) sm[L.Wg + (i >> 6) * 65 + (i & 63)] = w.Wg[i];
-    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) sm[L.Wq + (i >> 5) * 33 + (i & 31)] = w.Wq[i];
-    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) sm[L.W2 + (i >> 5) * 33 + (i & 31)] = w.W2[i];
-    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) sm[L.W5 + (i >> 5) * 33 + (i & 31)] = (i >> 5) < O ? w.W5[i] : 0.f;
+    for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) sm[L.Wg + (i >> 6) * NF_FP_STG + (i & 63)] = w.Wg[i];
+    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) sm[L.Wq + (i >> 5) * NF_FP_ST + (i & 31)] = w.Wq[i];
+    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) sm[L.W2 + (i >> 5) * NF_FP_ST + (i & 31)] = w.W2[i];
+    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x)
+        sm[L.W5 + (i >> 5) * NF_FP_ST + (i & 31)] = (i >> 5) < O ? w.W5[i] : 0.f;
     for (int i = threadIdx.x; i < 32 * 4; i += blockDim.x) sm[L.W0 + i] = ((i & 3) < I0) ? w.W0[(i >> 2) * I0 + (i & 3)] : 0.f;
     for (int i = threadIdx.x; i < 32; i += blockDim.x) {
         sm[L.b0 + i] = w.b0[i]; sm[L.bg + i] = w.bg[i]; sm[L.ln1g + i] = w.ln1g[i]; sm[L.ln1b + i] = w.ln1b[i];
@@ -72,165 +102,166 @@ __device__ __forceinline__ void nf_fpp_stage(const NfFppW& w, float* sm, const N
         sm[L.b2 + i] = w.b2[i];
         sm[L.b5 + i] = i < O ? w.b5[i] : 0.f;
     }
-    __syncthreads();
 }
 
-// acc += A(a, this lane's 16 features) x W[o][koff + k]^T, W in LDS with row stride `st`; output columns o = ooff + (l&31)
-__device__ __forceinline__ f32x16 nf_fp_gemm(f32x16 acc, const float (&a)[16], const float* W, int st, int ooff, int koff,
-                                             int c32, int hs) {
-    const float* wr = W + (ooff + c32) * st + koff + hs * 16;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wr[kk], acc, 0, 0, 0);
-    return acc;
-}
-// data-gradient GEMM: acc += A(g) x W[koff + k][ioff + i]  (i.e. g W), B fragment = column walk of W
-__device__ __forceinline__ f32x16 nf_fp_gemm_t(f32x16 acc, const float (&a)[16], const float* W, int st, int koff, int ioff,
-                                               int c32, int hs) {
-    const float* wc = W + (koff + hs * 16) * st + ioff + c32;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wc[kk * st], acc, 0, 0, 0);
-    return acc;
+// the 8 entries of a 32-vector in LDS that this lane's registers correspond to (features 16 b + 4 g + r)
+__device__ __forceinline__ void nf_fp_ldvec(const float* v, int g, float (&o)[8]) {
+    const float4 a = *(const float4*)(v + 4 * g), b = *(const float4*)(v + 16 + 4 * g);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
-// The staging tiles are private to one wave, and a wave's LDS operations execute in order: a wave-scope fence (compiler
-// ordering) is all a write -> cross-lane read needs.  No block barrier, so waves run their tiles independently.
-__device__ __forceinline__ void nf_fp_wsync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+__device__ __forceinline__ f32x4 nf_fp_zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// out^T = W act^T:  acc[ob][r] += sum_k W[16 ob + (4 g + r)][colofs + k] act[row][k]   (A = weights, B = activations in R)
+template <int NOB>
+__device__ __forceinline__ void nf_fp_gemm(const float* W, int st, int colofs, const float (&act)[8], f32x4 (&acc)[NOB], int c16,
+                                           int g) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        float4 wv[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) wv[ob] = *(const float4*)(W + (16 * ob + c16) * st + colofs + 16 * b + 4 * g);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].x, act[4 * b + 0], acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].y, act[4 * b + 1], acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].z, act[4 * b + 2], acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].w, act[4 * b + 3], acc[ob], 0, 0, 0);
+        }
+    }
+}
+// data gradient  g_in^T = W^T g^T:  acc[ib][r] += sum_o W[o][colofs + 16 ib + (4 g + r)] gv[row][o],  o over NB 16-blocks
+template <int NB>
+__device__ __forceinline__ void nf_fp_gemm_d(const float* W, int st, int colofs, const float (&gv)[4 * NB], f32x4 (&acc)[2],
+                                             int c16, int g) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* wr = W + (16 * b + 4 * g + r) * st + colofs + c16;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[0], gv[4 * b + r], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[16], gv[4 * b + r], acc[1], 0, 0, 0);
+        }
 }
 
-__device__ __forceinline__ f32x16 nf_fp_zero() {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    return z;
+// sum over the 32 features of each row (8 in this lane, the rest in the three other groups)
+__device__ __forceinline__ float nf_fp_rowsum(float s) {
+    s += __shfl_xor(s, 16, NF_WAVE);
+    s += __shfl_xor(s, 32, NF_WAVE);
+    return s;
 }
-
-// C/D layout (+ per-column bias) -> A layout through a padded (wave-private) tile
-__device__ __forceinline__ void nf_fp_cd_to_a(const f32x16& acc, const float* bias, float* tile, float (&a)[16], int c32,
-                                              int hs) {
-    const float bv = bias != nullptr ? bias[c32] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile[nf_fp_cdrow(r, hs) * NF_FP_TS + c32] = acc[r] + bv;
-    nf_fp_wsync();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) a[kk] = tile[c32 * NF_FP_TS + hs * 16 + kk];
-    nf_fp_wsync();
-}
-
-// row statistics of an A-layout vector: mean and 1/sqrt(biased var + eps)
-__device__ __forceinline__ void nf_fp_rowstats(const float (&v)[16], float& mean, float& rstd) {
+__device__ __forceinline__ void nf_fp_layernorm(const float (&v)[8], const float* gamma, const float* beta, int g, float (&xh)[8],
+                                                float& rstd, float (&y)[8]) {
     float s = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) s += v[kk];
-    s += __shfl_xor(s, 32, NF_WAVE);
-    mean = s * (1.f / 32.f);
+    for (int j = 0; j < 8; ++j) s += v[j];
+    const float mean = nf_fp_rowsum(s) * (1.f / 32.f);
     float q = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { const float d = v[kk] - mean; q = fmaf(d, d, q); }
-    q += __shfl_xor(q, 32, NF_WAVE);
-    rstd = 1.f / sqrtf(q * (1.f / 32.f) + NF_FP_LNEPS);
+    for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q = fmaf(d, d, q); }
+    rstd = 1.f / sqrtf(nf_fp_rowsum(q) * (1.f / 32.f) + NF_FP_LNEPS);
+    float ga[8], be[8];
+    nf_fp_ldvec(gamma, g, ga);
+    nf_fp_ldvec(beta, g, be);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        xh[j] = (v[j] - mean) * rstd;
+        y[j] = fmaf(xh[j], ga[j], be[j]);
+    }
 }
 
-// the whole forward of one 32-row tile in the A layout; keeps what the backward needs in the caller's registers
+// the whole forward of one 16-row tile in the R layout; keeps what the backward needs
 struct NfFppFwd {
-    float h0[16], u[16], h2[16], q[16], y2[16], a2[16], h4[16];
-    float xh1[16], xh2[16];     // LayerNorm-normalised values
+    float h0[8], u[8], q[8], y2[8], a2[8];
+    float xh1[8], xh2[8];       // LayerNorm-normalised values
+    float h2[8], h4[8];         // LayerNorm outputs (dead in the backward except as GEMM operands)
     float rstd1, rstd2;
 };
 
-// STASH: also leave the five activations the weight-gradient GEMMs multiply with (elu(h0), elu(-h0), t, q, h4) as
-// row-major tiles stash[0..4] so the backward does not carry them in registers.
-template <bool STASH>
-__device__ __forceinline__ void nf_fpp_forward_tile(const float* sm, const NfFppL& L, const float* __restrict__ x, int I0,
-                                                    int64_t row, bool rv, float* tile, float* stash, int c32, int hs,
+__device__ __forceinline__ void nf_fpp_forward_tile(const float* sm, const NfFppL& L, const float (&xin)[4], int c16, int g,
                                                     NfFppFwd& f) {
-    float xin[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < I0; ++i) xin[i] = rv ? x[row * I0 + i] : 0.f;
-    float c0[16], c1[16];
+    float c0[8], c1[8], tv[8];
+    nf_fp_ldvec(sm + L.b0, g, tv);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const int k = hs * 16 + kk;
-        float h = sm[L.b0 + k];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h = fmaf(sm[L.W0 + k * 4 + i], xin[i], h);
-        f.h0[kk] = h;
-        c0[kk] = nf_elu(h);                                            // concat-ELU (modules.py:509)
-        c1[kk] = nf_elu(-h);
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * (j >> 2) + 4 * g + (j & 3);
+        const float4 w0 = *(const float4*)(sm + L.W0 + 4 * k);
+        float h = tv[j];
+        h = fmaf(w0.x, xin[0], h); h = fmaf(w0.y, xin[1], h); h = fmaf(w0.z, xin[2], h); h = fmaf(w0.w, xin[3], h);
+        f.h0[j] = h;
+        nf_celu(h, c0[j], c1[j]);                                        // concat-ELU (modules.py:509)
     }
-    if (STASH) {
+    f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
+    nf_fp_gemm<2>(sm + L.Wg, NF_FP_STG, 0, c0, acc, c16, g);
+    nf_fp_gemm<2>(sm + L.Wg, NF_FP_STG, 32, c1, acc, c16, g);
+    nf_fp_ldvec(sm + L.bg, g, tv);
+    float h1[8];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            stash[0 * 32 * NF_FP_TS + c32 * NF_FP_TS + hs * 16 + kk] = c0[kk];
-            stash[1 * 32 * NF_FP_TS + c32 * NF_FP_TS + hs * 16 + kk] = c1[kk];
-        }
+    for (int j = 0; j < 8; ++j) {
+        f.u[j] = acc[j >> 2][j & 3] + tv[j];
+        float y, a;
+        nf_celu(f.u[j], y, a);
+        h1[j] = f.h0[j] + y * nf_sigmoid(a);                              // modules.py:513-518
     }
-    f32x16 acc = nf_fp_zero();
-    acc = nf_fp_gemm(acc, c0, sm + L.Wg, 65, 0, 0, c32, hs);
-    acc = nf_fp_gemm(acc, c1, sm + L.Wg, 65, 0, 32, c32, hs);
-    nf_fp_cd_to_a(acc, sm + L.bg, tile, f.u, c32, hs);
-    float h1[16];
+    nf_fp_layernorm(h1, sm + L.ln1g, sm + L.ln1b, g, f.xh1, f.rstd1, f.h2);
+    nf_fp_ldvec(sm + L.pos, g, tv);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) h1[kk] = f.h0[kk] + nf_elu(f.u[kk]) * nf_sigmoid(nf_elu(-f.u[kk]));   // modules.py:513-518
-    float mean;
-    nf_fp_rowstats(h1, mean, f.rstd1);
-    float t[16];
+    for (int j = 0; j < 8; ++j) tv[j] += f.h2[j];                         // modules.py:569
+    acc[0] = nf_fp_zero4(); acc[1] = nf_fp_zero4();
+    nf_fp_gemm<2>(sm + L.Wq, NF_FP_ST, 0, tv, acc, c16, g);
+    nf_fp_ldvec(sm + L.bq, g, tv);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const int k = hs * 16 + kk;
-        f.xh1[kk] = (h1[kk] - mean) * f.rstd1;
-        f.h2[kk] = f.xh1[kk] * sm[L.ln1g + k] + sm[L.ln1b + k];
-        t[kk] = f.h2[kk] + sm[L.pos + k];                              // modules.py:569
-        if (STASH) stash[2 * 32 * NF_FP_TS + c32 * NF_FP_TS + hs * 16 + kk] = t[kk];
+    for (int j = 0; j < 8; ++j) f.q[j] = acc[j >> 2][j & 3] + tv[j];
+    f32x4 acc4[4] = {nf_fp_zero4(), nf_fp_zero4(), nf_fp_zero4(), nf_fp_zero4()};
+    nf_fp_gemm<4>(sm + L.W2, NF_FP_ST, 0, f.q, acc4, c16, g);
+    nf_fp_ldvec(sm + L.b2, g, tv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.y2[j] = acc4[j >> 2][j & 3] + tv[j];
+    nf_fp_ldvec(sm + L.b2 + 32, g, tv);
+    float h3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f.a2[j] = acc4[2 + (j >> 2)][j & 3] + tv[j];
+        h3[j] = f.h2[j] + f.y2[j] * nf_sigmoid(f.a2[j]);                  // modules.py:574-578
     }
-    acc = nf_fp_gemm(nf_fp_zero(), t, sm + L.Wq, 33, 0, 0, c32, hs);
-    nf_fp_cd_to_a(acc, sm + L.bq, tile, f.q, c32, hs);
-    if (STASH) {
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) stash[3 * 32 * NF_FP_TS + c32 * NF_FP_TS + hs * 16 + kk] = f.q[kk];
-    }
-    acc = nf_fp_gemm(nf_fp_zero(), f.q, sm + L.W2, 33, 0, 0, c32, hs);
-    nf_fp_cd_to_a(acc, sm + L.b2, tile, f.y2, c32, hs);
-    acc = nf_fp_gemm(nf_fp_zero(), f.q, sm + L.W2, 33, 32, 0, c32, hs);
-    nf_fp_cd_to_a(acc, sm + L.b2 + 32, tile, f.a2, c32, hs);
-    float h3[16];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) h3[kk] = f.h2[kk] + f.y2[kk] * nf_sigmoid(f.a2[kk]);                 // modules.py:574-578
-    nf_fp_rowstats(h3, mean, f.rstd2);
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const int k = hs * 16 + kk;
-        f.xh2[kk] = (h3[kk] - mean) * f.rstd2;
-        f.h4[kk] = f.xh2[kk] * sm[L.ln2g + k] + sm[L.ln2b + k];
-        if (STASH) stash[4 * 32 * NF_FP_TS + c32 * NF_FP_TS + hs * 16 + kk] = f.h4[kk];
-    }
+    nf_fp_layernorm(h3, sm + L.ln2g, sm + L.ln2b, g, f.xh2, f.rstd2, f.h4);
 }
 
-__global__ void __launch_bounds__(NF_FP_WAVES * NF_WAVE) k_flowpp_cond_fwd(NfFppW w, int64_t N, int I0, int O, int64_t tiles,
-                                                                           int iters) {
+template <int NB>   // NB = ceil(O / 16)
+__global__ void __launch_bounds__(NF_FP_FWD_WAVES * NF_WAVE) k_flowpp_cond_fwd(NfFppW w, int64_t N, int I0, int O,
+                                                                               int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const NfFppL L = nf_fpp_layout(I0, 1);
+    const NfFppL L = nf_fpp_layout(0);
     nf_fpp_stage(w, sm, L, I0, O);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
-    float* tile = sm + L.tiles + wid * 32 * NF_FP_TS;
-    for (int it = 0; it < iters; ++it) {
-        const int64_t t = ((int64_t)it * gridDim.x + blockIdx.x) * NF_FP_WAVES + wid;      // may be >= tiles: row guards
-        const int64_t row0 = t * 32;
-        const int64_t row = row0 + c32;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * NF_FP_FWD_WAVES + wid; t < tiles; t += (int64_t)gridDim.x * NF_FP_FWD_WAVES) {
+        const int64_t row0 = t * 16, row = row0 + c16;
+        float xin[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I0 && row < N) xin[i] = w.x[row * I0 + i];
         NfFppFwd f;
-        nf_fpp_forward_tile<false>(sm, L, w.x, I0, row, row < N && t < tiles, tile, nullptr, c32, hs, f);
+        nf_fpp_forward_tile(sm, L, xin, c16, g, f);
+        // out = h4 W5^T + b5 with the activations as the A operand: D col = output feature -> coalesced row stores
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            if (nt * 32 < O) {                                                             // block-uniform
-                f32x16 acc = nf_fp_gemm(nf_fp_zero(), f.h4, sm + L.W5, 33, nt * 32, 0, c32, hs);
-                const int o = nt * 32 + c32;
-                if (o < O && t < tiles) {
-                    const float bv = sm[L.b5 + o];
+        for (int ob = 0; ob < NB; ++ob) {
+            f32x4 acc = nf_fp_zero4();
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t gr = row0 + nf_fp_cdrow(r, hs);
-                        if (gr < N) w.out[gr * O + o] = acc[r] + bv;
-                    }
+            for (int b = 0; b < 2; ++b) {
+                const float4 wv = *(const float4*)(sm + L.W5 + (16 * ob + c16) * NF_FP_ST + 16 * b + 4 * g);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.h4[4 * b + 0], wv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.h4[4 * b + 1], wv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.h4[4 * b + 2], wv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.h4[4 * b + 3], wv.w, acc, 0, 0, 0);
+            }
+            const int o = 16 * ob + c16;
+            if (o < O) {
+                const float bv = sm[L.b5 + o];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gr = row0 + 4 * g + r;
+                    if (gr < N) w.out[gr * O + o] = acc[r] + bv;
                 }
             }
         }
@@ -244,309 +275,457 @@ extern "C" int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* 
     if (I0 < 1 || I0 > 4 || O < 1 || O > 64) return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     NfFppW w{x, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, out};
-    const int64_t tiles = (N + 31) / 32;
-    int64_t g = (tiles + NF_FP_WAVES - 1) / NF_FP_WAVES;
-    if (g > 1024) g = 1024;
-    const int iters = (int)((tiles + g * NF_FP_WAVES - 1) / (g * NF_FP_WAVES));
-    const NfFppL L = nf_fpp_layout(I0, 1);
-    hipLaunchKernelGGL(k_flowpp_cond_fwd, dim3((unsigned)g), dim3(NF_FP_WAVES * NF_WAVE), (size_t)L.total * sizeof(float),
-                       (hipStream_t)stream, w, N, I0, O, tiles, iters);
+    const int64_t tiles = (N + 15) / 16;
+    int64_t gx = (tiles + NF_FP_FWD_WAVES - 1) / NF_FP_FWD_WAVES;
+    if (gx > 512) gx = 512;                                     // two 8-wave blocks per CU, weights staged once per block
+    const NfFppL L = nf_fpp_layout(0);
+    const size_t lds = (size_t)L.wend * sizeof(float);
+    const dim3 grid((unsigned)gx), block(NF_FP_FWD_WAVES * NF_WAVE);
+    switch ((O + 15) / 16) {
+        case 1: hipLaunchKernelGGL(k_flowpp_cond_fwd<1>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
+        case 2: hipLaunchKernelGGL(k_flowpp_cond_fwd<2>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
+        case 3: hipLaunchKernelGGL(k_flowpp_cond_fwd<3>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
+        default: hipLaunchKernelGGL(k_flowpp_cond_fwd<4>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
+    }
     NF_CHECK_LAUNCH();
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// backward: recompute the forward of the tile, then back-propagate in the A layout.
-//   data gradients : g W  via nf_fp_gemm_t (B fragment = column walk of the LDS-resident weight)
-//   weight gradients: G^T Act over the tile's 32 rows (A = column walk of G's row-major LDS tile, B = column walk of
-//                     Act's tile), accumulated in registers across the wave's tiles, reduced over the block at the end
-//   vector gradients (biases, LayerNorm gamma/beta, pos_emb, W0/b0): column sums of row-major LDS tiles
+// backward
 // ---------------------------------------------------------------------------------------------------------------
-struct NfFppG {   // gradient destinations, all ACCUMULATED (+=): zero-filled temporaries or .grad buffers
-    const float* g_out;          // (N, O)
-    float *g_x;                  // (N, I0) written, nullable
-    float *g_W0, *g_b0, *g_Wg, *g_bg, *g_ln1g, *g_ln1b, *g_pos, *g_Wq, *g_bq, *g_W2, *g_b2, *g_ln2g, *g_ln2b, *g_W5, *g_b5;
+// per-block partial sums ("slab", floats), dense row-major like the parameters
+enum {
+    NF_S_W5 = 0, NF_S_W2 = 2048, NF_S_WQ = 4096, NF_S_WG = 5120, NF_S_W0 = 7168, NF_S_B5 = 7296, NF_S_B2 = 7360,
+    NF_S_BQ = 7424, NF_S_BG = 7456, NF_S_LN2G = 7488, NF_S_LN2B = 7520, NF_S_LN1G = 7552, NF_S_LN1B = 7584, NF_S_POS = 7616,
+    NF_S_B0 = 7648, NF_S_END = 7680
 };
 
-// row-major store of an A-layout vector into a tile (no barrier)
-__device__ __forceinline__ void nf_fp_store_rows(const float (&v)[16], float* tile, int c32, int hs) {
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) tile[c32 * NF_FP_TS + hs * 16 + kk] = v[kk];
+// A wave's staging tiles are private to it and a wave's LDS operations execute in order: a wave-scope fence (compiler
+// ordering) is all a write -> cross-lane read needs.  No block barrier inside the tile loop.
+__device__ __forceinline__ void nf_fp_wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
-// column walk: element [row = hs*16 + kk][col = c32]
-__device__ __forceinline__ void nf_fp_load_cols(const float* tile, float (&v)[16], int c32, int hs) {
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) v[kk] = tile[(hs * 16 + kk) * NF_FP_TS + c32];
+// row-major store of an R-layout vector into a 16 x 32 tile
+__device__ __forceinline__ void nf_fp_store_rows(const float (&v)[8], float* tile, int c16, int g) {
+    *(float4*)(tile + c16 * NF_FP_ST + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(tile + c16 * NF_FP_ST + 16 + 4 * g) = make_float4(v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ float nf_fp_sum16(const float (&v)[16]) {
-    float s = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) s += v[kk];
-    return s;
+// register relief: park an R-layout vector in LDS (each lane reads back exactly what it wrote)
+__device__ __forceinline__ void nf_fp_park(const float (&v)[8], float* slot, int lane) {
+    *(float4*)(slot + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(slot + 256 + 4 * lane) = make_float4(v[4], v[5], v[6], v[7]);
 }
-// per-lane partial column sum (column c32, rows of this half) of an A-layout vector
-__device__ __forceinline__ float nf_fp_colsum(const float (&v)[16], float* tile, int c32, int hs) {
-    nf_fp_store_rows(v, tile, c32, hs);
-    nf_fp_wsync();
-    float t[16];
-    nf_fp_load_cols(tile, t, c32, hs);
-    const float s = nf_fp_sum16(t);
-    nf_fp_wsync();
-    return s;
+__device__ __forceinline__ void nf_fp_unpark(const float* slot, float (&v)[8], int lane) {
+    const float4 a = *(const float4*)(slot + 4 * lane), b = *(const float4*)(slot + 256 + 4 * lane);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-// weight-gradient tile: acc[o][i] += sum_rows G[row][o] Act[row][i]; returns this lane's partial bias sum (column o = c32)
-__device__ __forceinline__ float nf_fp_wgrad(f32x16& acc, const float* Gt, const float* At, int c32, int hs) {
-    float gs = 0.f;
+// column walk of a tile: element [row 4 s + g][column 16 cb + c16], the A / B fragment of a weight-gradient product
+template <int NCB>
+__device__ __forceinline__ void nf_fp_load_cols(const float* tile, float (&o)[NCB][4], int c16, int g) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        const float ga = Gt[(hs * 16 + kk) * NF_FP_TS + c32];
-        const float av = At[(hs * 16 + kk) * NF_FP_TS + c32];
-        gs += ga;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, av, acc, 0, 0, 0);
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[cb][s] = tile[(4 * s + g) * NF_FP_ST + 16 * cb + c16];
+}
+// acc[OBO + ob][IBO + ib] += sum_rows G[row][16 ob + .] Act[row][16 ib + .]  (D: lane col = 16 ib + c16, rows 4 g + r);
+// vb (nullable) += this lane's share of the column sums of G (the bias gradient)
+template <int NOB, int NIB, int TOB, int TIB, int OBO, int IBO>
+__device__ __forceinline__ void nf_fp_wgrad(const float (&ga)[NOB][4], const float (&av)[NIB][4], f32x4 (&acc)[TOB][TIB],
+                                            float* vb) {
+    if (vb != nullptr) {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) vb[ob] += (ga[ob][0] + ga[ob][1]) + (ga[ob][2] + ga[ob][3]);
     }
-    return gs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib)
+                acc[OBO + ob][IBO + ib] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ob][s], av[ib][s], acc[OBO + ob][IBO + ib], 0, 0, 0);
 }
-// LayerNorm backward in the A layout: g_in = rstd * (g_xh - mean(g_xh) - xh * mean(g_xh * xh)),  g_xh = g_out * gamma
-__device__ __forceinline__ void nf_fp_ln_bwd(const float (&g_out)[16], const float (&xh)[16], const float* gamma, float rstd,
-                                             float (&g_in)[16], int hs) {
-    float gx[16], s1 = 0.f, s2 = 0.f;
+// this lane's share (rows g, g + 4, ..; columns c16 and 16 + c16) of the column sums of an R-layout vector
+__device__ __forceinline__ void nf_fp_colsum(const float (&v)[8], float* tile, float (&acc)[2], int c16, int g) {
+    nf_fp_store_rows(v, tile, c16, g);
+    nf_fp_wsync();
+    float c[2][4];
+    nf_fp_load_cols<2>(tile, c, c16, g);
+    acc[0] += (c[0][0] + c[0][1]) + (c[0][2] + c[0][3]);
+    acc[1] += (c[1][0] + c[1][1]) + (c[1][2] + c[1][3]);
+    nf_fp_wsync();
+}
+// LayerNorm backward in R: g_in = rstd * (g_xh - mean(g_xh) - xh * mean(g_xh * xh)),  g_xh = g_out * gamma
+__device__ __forceinline__ void nf_fp_ln_bwd(const float (&g_out)[8], const float (&xh)[8], const float* gamma, float rstd,
+                                             float (&g_in)[8], int g) {
+    float ga[8], gx[8], s1 = 0.f, s2 = 0.f;
+    nf_fp_ldvec(gamma, g, ga);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        gx[kk] = g_out[kk] * gamma[hs * 16 + kk];
-        s1 += gx[kk];
-        s2 = fmaf(gx[kk], xh[kk], s2);
+    for (int j = 0; j < 8; ++j) {
+        gx[j] = g_out[j] * ga[j];
+        s1 += gx[j];
+        s2 = fmaf(gx[j], xh[j], s2);
     }
-    s1 += __shfl_xor(s1, 32, NF_WAVE);
-    s2 += __shfl_xor(s2, 32, NF_WAVE);
-    s1 *= (1.f / 32.f);
-    s2 *= (1.f / 32.f);
+    s1 = nf_fp_rowsum(s1) * (1.f / 32.f);
+    s2 = nf_fp_rowsum(s2) * (1.f / 32.f);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) g_in[kk] = rstd * (gx[kk] - s1 - xh[kk] * s2);
+    for (int j = 0; j < 8; ++j) g_in[j] = rstd * (gx[j] - s1 - xh[j] * s2);
 }
 
-__global__ void __launch_bounds__(NF_FP_WAVES * NF_WAVE) k_flowpp_cond_bwd(NfFppW w, NfFppG g, int64_t N, int I0, int O,
-                                                                           int64_t tiles) {
+template <bool FIRST>
+__device__ __forceinline__ void nf_fp_put(float* R, int idx, float v) {
+    R[idx] = FIRST ? v : R[idx] + v;
+}
+
+template <int NB>
+__global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(NfFppW w, NfFppG gr, float* __restrict__ slabs,
+                                                                               int64_t N, int I0, int O, int64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const NfFppL L = nf_fpp_layout(I0, NF_FP_BWD_TILES);
+    const NfFppL L = nf_fpp_layout(NF_FP_BWD_WAVES);
     nf_fpp_stage(w, sm, L, I0, O);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
-    float* T0 = sm + L.tiles + (wid * NF_FP_BWD_TILES + 0) * 32 * NF_FP_TS;   // conversion tile
-    float* TG = sm + L.tiles + (wid * NF_FP_BWD_TILES + 1) * 32 * NF_FP_TS;   // gradient tile (A operand of the weight GEMMs)
-    float* ST = sm + L.tiles + (wid * NF_FP_BWD_TILES + 2) * 32 * NF_FP_TS;   // stash: elu(h0), elu(-h0), t, q, h4
-    const int TSZ = 32 * NF_FP_TS;
-    const bool two = O > 32;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+    float* TG = sm + L.tiles + wid * NF_FP_WAVE_LDS;      // gradient-side tile (A fragment of the weight products)
+    float* TA = TG + 16 * NF_FP_ST;                       // activation-side tile (B fragment)
+    float* PK = TA + 16 * NF_FP_ST;                       // parked h0, u, xh1
 
-    f32x16 aW5a = nf_fp_zero(), aW5b = nf_fp_zero(), aW2a = nf_fp_zero(), aW2b = nf_fp_zero(), aWq = nf_fp_zero(),
-           aWg0 = nf_fp_zero(), aWg1 = nf_fp_zero();
-    float vb5a = 0.f, vb5b = 0.f, vb2a = 0.f, vb2b = 0.f, vbq = 0.f, vbg = 0.f, vg2 = 0.f, vbt2 = 0.f, vg1 = 0.f, vbt1 = 0.f,
-          vpos = 0.f, vb0 = 0.f, vW0[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 aW5[NB][2], aW2[4][2], aWq[2][2], aWg[2][4], aW0[2][1];
+    float vb5[NB], vb2[4], vbq[2] = {0.f, 0.f}, vbg[2] = {0.f, 0.f}, vln2g[2] = {0.f, 0.f}, vln2b[2] = {0.f, 0.f},
+          vln1g[2] = {0.f, 0.f}, vln1b[2] = {0.f, 0.f}, vpos[2] = {0.f, 0.f}, vb0[2] = {0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < NB; ++a) { aW5[a][0] = nf_fp_zero4(); aW5[a][1] = nf_fp_zero4(); vb5[a] = 0.f; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { aW2[a][0] = nf_fp_zero4(); aW2[a][1] = nf_fp_zero4(); vb2[a] = 0.f; }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        aWq[a][0] = nf_fp_zero4(); aWq[a][1] = nf_fp_zero4(); aW0[a][0] = nf_fp_zero4();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) aWg[a][b] = nf_fp_zero4();
+    }
 
-    for (int64_t t = (int64_t)blockIdx.x * NF_FP_WAVES + wid; t < tiles; t += (int64_t)gridDim.x * NF_FP_WAVES) {
-        const int64_t row = t * 32 + c32;
+    for (int64_t t = (int64_t)blockIdx.x * NF_FP_BWD_WAVES + wid; t < tiles; t += (int64_t)gridDim.x * NF_FP_BWD_WAVES) {
+        const int64_t row0 = t * 16, row = row0 + c16;
         const bool rv = row < N;
-        NfFppFwd f;
-        nf_fpp_forward_tile<true>(sm, L, w.x, I0, row, rv, T0, ST, c32, hs, f);
         float xin[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < I0; ++i) xin[i] = rv ? w.x[row * I0 + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < I0 && rv) xin[i] = w.x[row * I0 + i];
+        float q[8], y2[8], a2[8], xh2[8], g_h3[8], rstd1;
+        {
+            NfFppFwd f;
+            nf_fpp_forward_tile(sm, L, xin, c16, g, f);
+            nf_fp_park(f.h0, PK, lane);
+            nf_fp_park(f.u, PK + 512, lane);
+            nf_fp_park(f.xh1, PK + 1024, lane);
+            rstd1 = f.rstd1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { q[j] = f.q[j]; y2[j] = f.y2[j]; a2[j] = f.a2[j]; xh2[j] = f.xh2[j]; }
 
-        // ---- out = W5 h4 + b5 ----------------------------------------------------------------------------------
-        float g_h4[16];
-        {
-            float ga[16], gb[16];
-            const float* gp = g.g_out + (rv ? row : 0) * O;      // unconditional (clamped) loads + select: no branches
+            // ---- out = W5 h4 + b5 ------------------------------------------------------------------------------
+            float g_h4[8];
+            nf_fp_store_rows(f.h4, TA, c16, g);
+            {
+                float go[4 * NB];                                // g_out in R: features 16 b + 4 g + r of this lane's row
+                const float* gp = gr.g_out + (rv ? row : 0) * O; // unconditional (clamped) loads + select: no branches
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const int o0 = hs * 16 + kk, o1 = 32 + o0;
-                const float v0 = gp[o0 < O ? o0 : O - 1], v1 = gp[o1 < O ? o1 : O - 1];
-                ga[kk] = (rv && o0 < O) ? v0 : 0.f;
-                gb[kk] = (rv && o1 < O) ? v1 : 0.f;
-            }
-            f32x16 acc = nf_fp_gemm_t(nf_fp_zero(), ga, sm + L.W5, 33, 0, 0, c32, hs);
-            if (two) acc = nf_fp_gemm_t(acc, gb, sm + L.W5, 33, 32, 0, c32, hs);
-            nf_fp_store_rows(ga, TG, c32, hs);
-            nf_fp_wsync();
-            vb5a += nf_fp_wgrad(aW5a, TG, ST + 4 * TSZ, c32, hs);
-            nf_fp_wsync();
-            if (two) {
-                nf_fp_store_rows(gb, TG, c32, hs);
-                nf_fp_wsync();
-                vb5b += nf_fp_wgrad(aW5b, TG, ST + 4 * TSZ, c32, hs);
-                nf_fp_wsync();
-            }
-            nf_fp_cd_to_a(acc, nullptr, T0, g_h4, c32, hs);     // rows beyond N carry g_out = 0 -> exact zeros
-        }
-        // ---- LayerNorm 2 ---------------------------------------------------------------------------------------
-        float g_h3[16];
-        {
-            float tmp[16];
+                for (int j = 0; j < 4 * NB; ++j) {
+                    const int o = 16 * (j >> 2) + 4 * g + (j & 3);
+                    const float v = gp[o < O ? o : O - 1];
+                    go[j] = (rv && o < O) ? v : 0.f;
+                }
+                f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
+                nf_fp_gemm_d<NB>(sm + L.W5, NF_FP_ST, 0, go, acc, c16, g);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) tmp[kk] = g_h4[kk] * f.xh2[kk];
-            vg2 += nf_fp_colsum(tmp, TG, c32, hs);
-            vbt2 += nf_fp_colsum(g_h4, TG, c32, hs);
-            nf_fp_ln_bwd(g_h4, f.xh2, sm + L.ln2g, f.rstd2, g_h3, hs);
+                for (int j = 0; j < 8; ++j) g_h4[j] = acc[j >> 2][j & 3];
+            }
+            {   // weight gradient: A fragment straight from global (column walk of g_out = coalesced 64-byte rows)
+                float ga[NB][4], av[2][4];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int64_t r2 = row0 + 4 * s + g;
+                        const int o = 16 * ob + c16;
+                        const float v = gr.g_out[(r2 < N ? r2 : N - 1) * O + (o < O ? o : O - 1)];
+                        ga[ob][s] = (r2 < N && o < O) ? v : 0.f;
+                    }
+                nf_fp_wsync();
+                nf_fp_load_cols<2>(TA, av, c16, g);
+                nf_fp_wgrad<NB, 2, NB, 2, 0, 0>(ga, av, aW5, vb5);
+                nf_fp_wsync();
+            }
+            // ---- LayerNorm 2 -----------------------------------------------------------------------------------
+            float tmp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tmp[j] = g_h4[j] * xh2[j];
+            nf_fp_colsum(tmp, TG, vln2g, c16, g);
+            nf_fp_colsum(g_h4, TG, vln2b, c16, g);
+            nf_fp_ln_bwd(g_h4, xh2, sm + L.ln2g, f.rstd2, g_h3, g);
         }
         // ---- gate 2: h3 = h2 + y2 sigmoid(a2);  [y2, a2] = W2 q + b2 ------------------------------------------------
-        float g_q[16];
+        float g_q[8];
         {
-            float g_y2[16], g_a2[16];
+            float gcat[16];                                      // [g_y2 | g_a2]: the 64 outputs of conv2
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const float s2 = nf_sigmoid(f.a2[kk]);
-                g_y2[kk] = g_h3[kk] * s2;
-                g_a2[kk] = g_h3[kk] * f.y2[kk] * s2 * (1.f - s2);
+            for (int j = 0; j < 8; ++j) {
+                const float s2 = nf_sigmoid(a2[j]);
+                gcat[j] = g_h3[j] * s2;
+                gcat[8 + j] = g_h3[j] * y2[j] * s2 * (1.f - s2);
             }
-            f32x16 acc = nf_fp_gemm_t(nf_fp_zero(), g_y2, sm + L.W2, 33, 0, 0, c32, hs);
-            acc = nf_fp_gemm_t(acc, g_a2, sm + L.W2, 33, 32, 0, c32, hs);
-            nf_fp_store_rows(g_y2, TG, c32, hs);
+            f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
+            nf_fp_gemm_d<4>(sm + L.W2, NF_FP_ST, 0, gcat, acc, c16, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g_q[j] = acc[j >> 2][j & 3];
+            float ga[2][4], av[2][4], half[8];
+            nf_fp_store_rows(q, TA, c16, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) half[j] = gcat[j];
+            nf_fp_store_rows(half, TG, c16, g);
             nf_fp_wsync();
-            vb2a += nf_fp_wgrad(aW2a, TG, ST + 3 * TSZ, c32, hs);
+            nf_fp_load_cols<2>(TA, av, c16, g);
+            nf_fp_load_cols<2>(TG, ga, c16, g);
+            nf_fp_wgrad<2, 2, 4, 2, 0, 0>(ga, av, aW2, vb2);
             nf_fp_wsync();
-            nf_fp_store_rows(g_a2, TG, c32, hs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) half[j] = gcat[8 + j];
+            nf_fp_store_rows(half, TG, c16, g);
             nf_fp_wsync();
-            vb2b += nf_fp_wgrad(aW2b, TG, ST + 3 * TSZ, c32, hs);
+            nf_fp_load_cols<2>(TG, ga, c16, g);
+            nf_fp_wgrad<2, 2, 4, 2, 2, 0>(ga, av, aW2, vb2 + 2);
             nf_fp_wsync();
-            nf_fp_cd_to_a(acc, nullptr, T0, g_q, c32, hs);
         }
         // ---- q = Wq (h2 + pos) + bq ------------------------------------------------------------------------------------
-        float g_h2[16];
+        float g_h2[8], xh1[8];
+        nf_fp_unpark(PK + 1024, xh1, lane);
         {
-            f32x16 acc = nf_fp_gemm_t(nf_fp_zero(), g_q, sm + L.Wq, 33, 0, 0, c32, hs);
-            nf_fp_store_rows(g_q, TG, c32, hs);
-            nf_fp_wsync();
-            vbq += nf_fp_wgrad(aWq, TG, ST + 2 * TSZ, c32, hs);
-            nf_fp_wsync();
-            float g_t[16];
-            nf_fp_cd_to_a(acc, nullptr, T0, g_t, c32, hs);
-            vpos += nf_fp_colsum(g_t, TG, c32, hs);
+            f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
+            nf_fp_gemm_d<2>(sm + L.Wq, NF_FP_ST, 0, g_q, acc, c16, g);
+            float tv[8], ga8[8], be8[8], ga[2][4], av[2][4];
+            nf_fp_ldvec(sm + L.pos, g, tv);
+            nf_fp_ldvec(sm + L.ln1g, g, ga8);
+            nf_fp_ldvec(sm + L.ln1b, g, be8);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) g_h2[kk] = g_h3[kk] + g_t[kk];
+            for (int j = 0; j < 8; ++j) tv[j] += fmaf(xh1[j], ga8[j], be8[j]);          // t = h2 + pos
+            nf_fp_store_rows(tv, TA, c16, g);
+            nf_fp_store_rows(g_q, TG, c16, g);
+            nf_fp_wsync();
+            nf_fp_load_cols<2>(TA, av, c16, g);
+            nf_fp_load_cols<2>(TG, ga, c16, g);
+            nf_fp_wgrad<2, 2, 2, 2, 0, 0>(ga, av, aWq, vbq);
+            nf_fp_wsync();
+            float g_t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g_t[j] = acc[j >> 2][j & 3];
+            nf_fp_colsum(g_t, TG, vpos, c16, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g_h2[j] = g_h3[j] + g_t[j];
         }
         // ---- LayerNorm 1 ---------------------------------------------------------------------------------------
-        float g_h1[16];
+        float g_h1[8];
         {
-            float tmp[16];
+            float tmp[8];
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) tmp[kk] = g_h2[kk] * f.xh1[kk];
-            vg1 += nf_fp_colsum(tmp, TG, c32, hs);
-            vbt1 += nf_fp_colsum(g_h2, TG, c32, hs);
-            nf_fp_ln_bwd(g_h2, f.xh1, sm + L.ln1g, f.rstd1, g_h1, hs);
+            for (int j = 0; j < 8; ++j) tmp[j] = g_h2[j] * xh1[j];
+            nf_fp_colsum(tmp, TG, vln1g, c16, g);
+            nf_fp_colsum(g_h2, TG, vln1b, c16, g);
+            nf_fp_ln_bwd(g_h2, xh1, sm + L.ln1g, rstd1, g_h1, g);
         }
         // ---- gate 1: h1 = h0 + elu(u) sigmoid(elu(-u));  u = Wg [elu(h0), elu(-h0)] + bg ------------------------------
-        float g_h0[16];
+        float g_h0[8];
         {
-            float g_u[16];
+            float g_u[8], u[8];
+            nf_fp_unpark(PK + 512, u, lane);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const float uu = f.u[kk];
-                const float y = nf_elu(uu), a = nf_elu(-uu), sa = nf_sigmoid(a);
-                const float g_y = g_h1[kk] * sa, g_a = g_h1[kk] * y * sa * (1.f - sa);
-                g_u[kk] = g_y * nf_elu_grad(uu) - g_a * nf_elu_grad(-uu);
+            for (int j = 0; j < 8; ++j) {
+                float y, a, dy, da;
+                nf_celu(u[j], y, a);
+                nf_celu_grad(u[j], dy, da);
+                const float sa = nf_sigmoid(a);
+                g_u[j] = g_h1[j] * sa * (dy - y * (1.f - sa) * da);
             }
-            f32x16 acc0 = nf_fp_gemm_t(nf_fp_zero(), g_u, sm + L.Wg, 65, 0, 0, c32, hs);
-            f32x16 acc1 = nf_fp_gemm_t(nf_fp_zero(), g_u, sm + L.Wg, 65, 0, 32, c32, hs);
-            nf_fp_store_rows(g_u, TG, c32, hs);
-            nf_fp_wsync();
-            vbg += nf_fp_wgrad(aWg0, TG, ST + 0 * TSZ, c32, hs);
-            (void)nf_fp_wgrad(aWg1, TG, ST + 1 * TSZ, c32, hs);
-            nf_fp_wsync();
-            float g_c0[16], g_c1[16];
-            nf_fp_cd_to_a(acc0, nullptr, T0, g_c0, c32, hs);
-            nf_fp_cd_to_a(acc1, nullptr, T0, g_c1, c32, hs);
+            f32x4 acc0[2] = {nf_fp_zero4(), nf_fp_zero4()}, acc1[2] = {nf_fp_zero4(), nf_fp_zero4()};
+            nf_fp_gemm_d<2>(sm + L.Wg, NF_FP_STG, 0, g_u, acc0, c16, g);
+            nf_fp_gemm_d<2>(sm + L.Wg, NF_FP_STG, 32, g_u, acc1, c16, g);
+            float h0[8], c0[8], c1[8], d0[8], d1[8], ga[2][4], av[2][4];
+            nf_fp_unpark(PK, h0, lane);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-                g_h0[kk] = g_h1[kk] + g_c0[kk] * nf_elu_grad(f.h0[kk]) - g_c1[kk] * nf_elu_grad(-f.h0[kk]);
+            for (int j = 0; j < 8; ++j) {
+                nf_celu(h0[j], c0[j], c1[j]);
+                nf_celu_grad(h0[j], d0[j], d1[j]);
+            }
+            nf_fp_store_rows(g_u, TG, c16, g);
+            nf_fp_store_rows(c0, TA, c16, g);
+            nf_fp_wsync();
+            nf_fp_load_cols<2>(TG, ga, c16, g);
+            nf_fp_load_cols<2>(TA, av, c16, g);
+            nf_fp_wgrad<2, 2, 2, 4, 0, 0>(ga, av, aWg, vbg);
+            nf_fp_wsync();
+            nf_fp_store_rows(c1, TA, c16, g);
+            nf_fp_wsync();
+            nf_fp_load_cols<2>(TA, av, c16, g);
+            nf_fp_wgrad<2, 2, 2, 4, 0, 2>(ga, av, aWg, nullptr);
+            nf_fp_wsync();
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                g_h0[j] = g_h1[j] + acc0[j >> 2][j & 3] * d0[j] - acc1[j >> 2][j & 3] * d1[j];
         }
         // ---- h0 = W0 x + b0 --------------------------------------------------------------------------------------------
-        nf_fp_store_rows(g_h0, TG, c32, hs);
-        nf_fp_wsync();
         {
-            // column sums of g_h0 and of g_h0 * x_i: rows hs*16 .. hs*16+15, column c32 (x of those rows via shuffles)
-            float cs = 0.f, cw[4] = {0.f, 0.f, 0.f, 0.f};
+            nf_fp_store_rows(g_h0, TG, c16, g);
+            nf_fp_wsync();
+            float ga[2][4], av[1][4];
+            nf_fp_load_cols<2>(TG, ga, c16, g);
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const float gv = TG[(hs * 16 + kk) * NF_FP_TS + c32];
-                cs += gv;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cw[i] = fmaf(gv, __shfl(xin[i], hs * 16 + kk, NF_WAVE), cw[i]);
+            for (int s = 0; s < 4; ++s) {                        // B fragment: x[row 4 s + g][input c16], zero beyond I0 / N
+                const int64_t r2 = row0 + 4 * s + g;
+                const float v = w.x[(r2 < N ? r2 : N - 1) * I0 + (c16 < I0 ? c16 : 0)];
+                av[0][s] = (r2 < N && c16 < I0) ? v : 0.f;
             }
-            vb0 += cs;
+            nf_fp_wgrad<2, 1, 2, 1, 0, 0>(ga, av, aW0, vb0);
+            nf_fp_wsync();
+            if (gr.g_x != nullptr) {
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vW0[i] += cw[i];
-        }
-        nf_fp_wsync();
-        if (g.g_x != nullptr) {
-            for (int i = 0; i < I0; ++i) {
-                float s = 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * (j >> 2) + 4 * g + (j & 3);
+                    const float4 w0 = *(const float4*)(sm + L.W0 + 4 * k);
+                    s4[0] = fmaf(g_h0[j], w0.x, s4[0]); s4[1] = fmaf(g_h0[j], w0.y, s4[1]);
+                    s4[2] = fmaf(g_h0[j], w0.z, s4[2]); s4[3] = fmaf(g_h0[j], w0.w, s4[3]);
+                }
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) s = fmaf(g_h0[kk], sm[L.W0 + (hs * 16 + kk) * 4 + i], s);
-                s += __shfl_xor(s, 32, NF_WAVE);
-                if (hs == 0 && rv) g.g_x[row * I0 + i] = s;
+                for (int i = 0; i < 4; ++i) {
+                    const float s = nf_fp_rowsum(s4[i]);
+                    if (i < I0 && g == 0 && rv) gr.g_x[row * I0 + i] = s;
+                }
             }
         }
     }
 
-    // ---- block reduction and accumulation into the destinations -----------------------------------------------------
-    __syncthreads();
-    float* red = sm + L.tiles;                                   // [waves][32][32] floats (fits in the tile region)
-    auto flush_tile = [&](const f32x16& a, float* dst, int row_off, int n_rows, int ld, int col_off) {
+    // ---- block reduction (pairs of waves fold into two LDS images of the slab), then one coalesced slab store -----------
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wid * 32 + nf_fp_cdrow(r, hs)) * 32 + c32] = a[r];
-        __syncthreads();
-        for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
-            const int oo = e >> 5, ii = e & 31;
-            if (oo < n_rows) {
-                float s = 0.f;
+    for (int a = 0; a < NB; ++a) vb5[a] = nf_fp_rowsum(vb5[a]);
 #pragma unroll
-                for (int wv = 0; wv < NF_FP_WAVES; ++wv) s += red[(wv * 32 + oo) * 32 + ii];
-                atomicAdd(dst + (row_off + oo) * ld + col_off + ii, s);
+    for (int a = 0; a < 4; ++a) vb2[a] = nf_fp_rowsum(vb2[a]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        vbq[a] = nf_fp_rowsum(vbq[a]); vbg[a] = nf_fp_rowsum(vbg[a]); vln2g[a] = nf_fp_rowsum(vln2g[a]);
+        vln2b[a] = nf_fp_rowsum(vln2b[a]); vln1g[a] = nf_fp_rowsum(vln1g[a]); vln1b[a] = nf_fp_rowsum(vln1b[a]);
+        vpos[a] = nf_fp_rowsum(vpos[a]); vb0[a] = nf_fp_rowsum(vb0[a]);
+    }
+    __syncthreads();                                             // every wave is done with its tiles: the region is re-used
+    float* R = sm + L.tiles + (wid & 1) * NF_S_END;
+    auto fold = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * g + r;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) nf_fp_put<FIRST>(R, NF_S_W5 + (16 * ob + rr) * 32 + 16 * ib + c16, aW5[ob][ib][r]);
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) nf_fp_put<FIRST>(R, NF_S_W2 + (16 * ob + rr) * 32 + 16 * ib + c16, aW2[ob][ib][r]);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) nf_fp_put<FIRST>(R, NF_S_WQ + (16 * ob + rr) * 32 + 16 * ib + c16, aWq[ob][ib][r]);
+            }
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) nf_fp_put<FIRST>(R, NF_S_WG + (16 * ob + rr) * 64 + 16 * ib + c16, aWg[ob][ib][r]);
+            if (c16 < 4) {
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob) nf_fp_put<FIRST>(R, NF_S_W0 + (16 * ob + rr) * 4 + c16, aW0[ob][0][r]);
             }
         }
-        __syncthreads();
-    };
-    flush_tile(aW5a, g.g_W5, 0, O < 32 ? O : 32, 32, 0);
-    if (two) flush_tile(aW5b, g.g_W5, 32, O - 32, 32, 0);
-    flush_tile(aW2a, g.g_W2, 0, 32, 32, 0);
-    flush_tile(aW2b, g.g_W2, 32, 32, 32, 0);
-    flush_tile(aWq, g.g_Wq, 0, 32, 32, 0);
-    flush_tile(aWg0, g.g_Wg, 0, 32, 64, 0);
-    flush_tile(aWg1, g.g_Wg, 0, 32, 64, 32);
-    auto flush_vec = [&](float v, float* dst, int n) {
-        v += __shfl_xor(v, 32, NF_WAVE);
-        if (hs == 0) red[wid * 32 + c32] = v;
-        __syncthreads();
-        if (wid == 0 && hs == 0 && c32 < n) {
-            float s = 0.f;
+        if (g == 0) {
 #pragma unroll
-            for (int wv = 0; wv < NF_FP_WAVES; ++wv) s += red[wv * 32 + c32];
-            atomicAdd(dst + c32, s);
-        }
-        __syncthreads();
-    };
-    flush_vec(vb5a, g.g_b5, O < 32 ? O : 32);
-    if (two) flush_vec(vb5b, g.g_b5 + 32, O - 32);
-    flush_vec(vb2a, g.g_b2, 32);
-    flush_vec(vb2b, g.g_b2 + 32, 32);
-    flush_vec(vbq, g.g_bq, 32);
-    flush_vec(vbg, g.g_bg, 32);
-    flush_vec(vg2, g.g_ln2g, 32);
-    flush_vec(vbt2, g.g_ln2b, 32);
-    flush_vec(vg1, g.g_ln1g, 32);
-    flush_vec(vbt1, g.g_ln1b, 32);
-    flush_vec(vpos, g.g_pos, 32);
-    flush_vec(vb0, g.g_b0, 32);
-    for (int i = 0; i < I0; ++i) {                               // g_W0 is (32, I0): column i, stride I0
-        float v = vW0[i];
-        v += __shfl_xor(v, 32, NF_WAVE);
-        if (hs == 0) red[wid * 32 + c32] = v;
-        __syncthreads();
-        if (wid == 0 && hs == 0) {
-            float s = 0.f;
+            for (int a = 0; a < NB; ++a) nf_fp_put<FIRST>(R, NF_S_B5 + 16 * a + c16, vb5[a]);
 #pragma unroll
-            for (int wv = 0; wv < NF_FP_WAVES; ++wv) s += red[wv * 32 + c32];
-            atomicAdd(g.g_W0 + c32 * I0 + i, s);
+            for (int a = 0; a < 4; ++a) nf_fp_put<FIRST>(R, NF_S_B2 + 16 * a + c16, vb2[a]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                nf_fp_put<FIRST>(R, NF_S_BQ + 16 * a + c16, vbq[a]);
+                nf_fp_put<FIRST>(R, NF_S_BG + 16 * a + c16, vbg[a]);
+                nf_fp_put<FIRST>(R, NF_S_LN2G + 16 * a + c16, vln2g[a]);
+                nf_fp_put<FIRST>(R, NF_S_LN2B + 16 * a + c16, vln2b[a]);
+                nf_fp_put<FIRST>(R, NF_S_LN1G + 16 * a + c16, vln1g[a]);
+                nf_fp_put<FIRST>(R, NF_S_LN1B + 16 * a + c16, vln1b[a]);
+                nf_fp_put<FIRST>(R, NF_S_POS + 16 * a + c16, vpos[a]);
+                nf_fp_put<FIRST>(R, NF_S_B0 + 16 * a + c16, vb0[a]);
+            }
         }
+    };
+    if (NB < 4) {                                                // rows of W5 / b5 beyond 16 NB are never produced: zero them
+        for (int e = threadIdx.x; e < 2 * NF_S_END; e += blockDim.x) sm[L.tiles + e] = 0.f;
+        __syncthreads();
+        if ((wid >> 1) == NF_FP_BWD_WAVES / 2 - 1) fold(std::false_type{});
+    } else if ((wid >> 1) == NF_FP_BWD_WAVES / 2 - 1) {
+        fold(std::true_type{});
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int p = NF_FP_BWD_WAVES / 2 - 2; p >= 0; --p) {
+        if ((wid >> 1) == p) fold(std::false_type{});
         __syncthreads();
     }
+    float* slab = slabs + (size_t)blockIdx.x * NF_S_END;
+    for (int e = threadIdx.x; e < NF_S_END; e += blockDim.x) slab[e] = sm[L.tiles + e] + sm[L.tiles + NF_S_END + e];
+}
+
+// dst += sum over the blocks' slabs; 64 slab entries x 16 slab groups per block
+__global__ void __launch_bounds__(1024) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,
+                                                               int O) {
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float s = 0.f;
+    for (int b = grp; b < nblk; b += 16) s += slabs[(size_t)b * NF_S_END + e];
+    red[grp][el] = s;
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][el];
+    if (e < NF_S_W2) { if ((e >> 5) < O) gr.g_W5[e] += s; }
+    else if (e < NF_S_WQ) gr.g_W2[e - NF_S_W2] += s;
+    else if (e < NF_S_WG) gr.g_Wq[e - NF_S_WQ] += s;
+    else if (e < NF_S_W0) gr.g_Wg[e - NF_S_WG] += s;
+    else if (e < NF_S_B5) { const int k = (e - NF_S_W0) >> 2, i = (e - NF_S_W0) & 3; if (i < I0) gr.g_W0[k * I0 + i] += s; }
+    else if (e < NF_S_B2) { if (e - NF_S_B5 < O) gr.g_b5[e - NF_S_B5] += s; }
+    else if (e < NF_S_BQ) gr.g_b2[e - NF_S_B2] += s;
+    else if (e < NF_S_BG) gr.g_bq[e - NF_S_BQ] += s;
+    else if (e < NF_S_LN2G) gr.g_bg[e - NF_S_BG] += s;
+    else if (e < NF_S_LN2B) gr.g_ln2g[e - NF_S_LN2G] += s;
+    else if (e < NF_S_LN1G) gr.g_ln2b[e - NF_S_LN2B] += s;
+    else if (e < NF_S_LN1B) gr.g_ln1g[e - NF_S_LN1G] += s;
+    else if (e < NF_S_POS) gr.g_ln1b[e - NF_S_LN1B] += s;
+    else if (e < NF_S_B0) gr.g_pos[e - NF_S_POS] += s;
+    else gr.g_b0[e - NF_S_B0] += s;
+}
+
+static_assert(NF_FP_MAX_BLOCKS * NF_S_END == NF_FLOWPP_BWD_WS_FLOATS, "workspace size in include/nfhip.h");
+
+template <int NB>
+static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace, int64_t N, int I0, int O, hipStream_t stream) {
+    const int64_t tiles = (N + 15) / 16;
+    int64_t gx = (tiles + NF_FP_BWD_WAVES - 1) / NF_FP_BWD_WAVES;
+    if (gx > NF_FP_MAX_BLOCKS) gx = NF_FP_MAX_BLOCKS;            // one 8-wave block per CU
+    const NfFppL L = nf_fpp_layout(NF_FP_BWD_WAVES);
+    const size_t lds = (size_t)L.total * sizeof(float);
+    static bool attr_set = false;                                // > 64 KB of dynamic LDS needs the opt-in, once per kernel
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_flowpp_cond_bwd<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_flowpp_cond_bwd<NB>, dim3((unsigned)gx), dim3(NF_FP_BWD_WAVES * NF_WAVE), lds, stream, w, g, workspace,
+                       N, I0, O, tiles);
+    NF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_flowpp_cond_finalize, dim3(NF_S_END / 64), dim3(1024), 0, stream, (const float*)workspace, (int)gx, g,
+                       I0, O);
+    NF_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const float* Wg, const float* bg,
@@ -555,24 +734,15 @@ extern "C" int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* 
                                   const float* b5, const float* g_out, float* g_x, float* g_W0, float* g_b0, float* g_Wg,
                                   float* g_bg, float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_Wq, float* g_bq,
                                   float* g_W2, float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5,
-                                  int64_t N, int I0, int O, nf_stream_t stream) {
-    if (I0 < 1 || I0 > 4 || O < 1 || O > 64) return NF_E_BADARG;
+                                  float* workspace, int64_t N, int I0, int O, nf_stream_t stream) {
+    if (I0 < 1 || I0 > 4 || O < 1 || O > 64 || workspace == nullptr) return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     NfFppW w{x, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, nullptr};
     NfFppG g{g_out, g_x, g_W0, g_b0, g_Wg, g_bg, g_ln1_g, g_ln1_b, g_pos, g_Wq, g_bq, g_W2, g_b2, g_ln2_g, g_ln2_b, g_W5, g_b5};
-    const int64_t tiles = (N + 31) / 32;
-    int64_t gx = (tiles + NF_FP_WAVES - 1) / NF_FP_WAVES;
-    if (gx > 256) gx = 256;                                      // one pass of atomics per block: keep the block count low
-    const NfFppL L = nf_fpp_layout(I0, NF_FP_BWD_TILES);
-    const size_t lds = (size_t)L.total * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_flowpp_cond_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    switch ((O + 15) / 16) {
+        case 1: return nf_fpp_launch_bwd<1>(w, g, workspace, N, I0, O, (hipStream_t)stream);
+        case 2: return nf_fpp_launch_bwd<2>(w, g, workspace, N, I0, O, (hipStream_t)stream);
+        case 3: return nf_fpp_launch_bwd<3>(w, g, workspace, N, I0, O, (hipStream_t)stream);
+        default: return nf_fpp_launch_bwd<4>(w, g, workspace, N, I0, O, (hipStream_t)stream);
     }
-    hipLaunchKernelGGL(k_flowpp_cond_bwd, dim3((unsigned)gx), dim3(NF_FP_WAVES * NF_WAVE), lds, (hipStream_t)stream, w, g, N, I0,
-                       O, tiles);
-    NF_CHECK_LAUNCH();
-    return 0;
 }

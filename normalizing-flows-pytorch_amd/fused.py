@@ -384,6 +384,18 @@ def _flowpp_fwd_args(ts, F_):
             c1b.data_ptr() + 4 * 2 * F_, N.ptr(c2w), N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(W5), N.ptr(b5)]
 
 
+_FPP_WS = {}
+
+
+def flowpp_bwd_workspace(device):
+    """the partial-sum slabs of nf_flowpp_cond_bwd; one per device: backward launches on a stream are ordered, the next
+    call may overwrite what the previous call's second kernel has already folded."""
+    ws = _FPP_WS.get(device)
+    if ws is None:
+        ws = _FPP_WS[device] = torch.empty(N.header_constant('NF_FLOWPP_BWD_WS_FLOATS'), dtype=torch.float32, device=device)
+    return ws
+
+
 class _FusedFlowppCond(torch.autograd.Function):
     """x (N, I0) -> the (N, O) coupling parameters; one launch forward, one launch backward (csrc/flowpp_cond.hip)."""
 
@@ -423,7 +435,8 @@ class _FusedFlowppCond(torch.autograd.Function):
         d = [t.data_ptr() for t in dst]
         d[7] += 4 * 2 * F_ * H                                   # conv1 gradient rows [2F:3F]; V / K rows stay exactly zero
         d[8] += 4 * 2 * F_
-        N.call('nf_flowpp_cond_bwd', N.ptr(x), *_flowpp_fwd_args(ts, F_), N.ptr(g_out), _p(g_x), *d, Nrows, I0, O, N.stream())
+        N.call('nf_flowpp_cond_bwd', N.ptr(x), *_flowpp_fwd_args(ts, F_), N.ptr(g_out), _p(g_x), *d,
+               N.ptr(flowpp_bwd_workspace(x.device)), Nrows, I0, O, N.stream())
         if direct:
             return (g_x, None) + (None, ) * len(ts)
         return (g_x, None) + tuple(dst)
