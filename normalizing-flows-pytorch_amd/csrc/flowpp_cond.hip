@@ -32,6 +32,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NF_FP_WAVE_LDS (2 * 16 * NF_FP_ST + 3 * 512)   // per backward wave: two 16 x 32 tiles + three stashed vectors
 #define NF_FP_LNEPS 1.0e-5f
 
+static_assert(NF_FP_FWD_WAVES * NF_WAVE == 512 && NF_FP_BWD_WAVES * NF_WAVE == 512, "nf_fpp_stage assumes 512 threads");
+
 struct NfFppW {   // device pointers (forward operands)
     const float *x, *W0, *b0, *Wg, *bg, *ln1g, *ln1b, *pos, *Wq, *bq, *W2, *b2, *ln2g, *ln2b, *W5, *b5;
     float* out;
@@ -87,21 +89,59 @@ __device__ __forceinline__ void nf_celu_grad(float h, float& d0, float& d1) {
     d1 = h > 0.f ? e : 1.f;
 }
 
-__device__ __forceinline__ void nf_fpp_stage(const NfFppW& w, float* sm, const NfFppL& L, int I0, int O) {
-    for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) sm[L.Wg + (i >> 6) * NF_FP_STG + (i & 63)] = w.Wg[i];
-    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) sm[L.Wq + (i >> 5) * NF_FP_ST + (i & 31)] = w.Wq[i];
-    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) sm[L.W2 + (i >> 5) * NF_FP_ST + (i & 31)] = w.W2[i];
-    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x)
+// weights -> LDS.  Every global load is issued before the first LDS store, so the block pays ONE memory latency (the
+// obvious loop-per-tensor form pays ten in a row, ~10 us per launch).  512 threads; float4 loads when `vec` (all four
+// matrices 16-byte aligned), scalar loops otherwise.
+__device__ __forceinline__ void nf_fpp_stage(const NfFppW& w, float* sm, const NfFppL& L, int I0, int O, bool vec) {
+    const int tid = threadIdx.x;
+    if (vec) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vg = ((const float4*)w.Wg)[tid];                                  // 32 x 64 = 512 float4
+        const float4 v2 = ((const float4*)w.W2)[tid];                                  // 64 x 32
+        const float4 vq = tid < 256 ? ((const float4*)w.Wq)[tid] : z4;                 // 32 x 32
+        const float4 v5 = (tid >> 3) < O ? ((const float4*)w.W5)[tid] : z4;            // O x 32, zero rows beyond O
+        float v0 = 0.f, vv[8], vb2 = 0.f, vb5 = 0.f;
+        if (tid < 128) v0 = ((tid & 3) < I0) ? w.W0[(tid >> 2) * I0 + (tid & 3)] : 0.f;
+        if (tid < 32) {
+            vv[0] = w.b0[tid]; vv[1] = w.bg[tid]; vv[2] = w.ln1g[tid]; vv[3] = w.ln1b[tid];
+            vv[4] = w.pos[tid]; vv[5] = w.bq[tid]; vv[6] = w.ln2g[tid]; vv[7] = w.ln2b[tid];
+        }
+        if (tid >= 64 && tid < 128) {
+            vb2 = w.b2[tid - 64];
+            vb5 = (tid - 64) < O ? w.b5[tid - 64] : 0.f;
+        }
+        *(float4*)(sm + L.Wg + (tid >> 4) * NF_FP_STG + 4 * (tid & 15)) = vg;
+        *(float4*)(sm + L.W2 + (tid >> 3) * NF_FP_ST + 4 * (tid & 7)) = v2;
+        *(float4*)(sm + L.W5 + (tid >> 3) * NF_FP_ST + 4 * (tid & 7)) = v5;
+        if (tid < 256) *(float4*)(sm + L.Wq + (tid >> 3) * NF_FP_ST + 4 * (tid & 7)) = vq;
+        if (tid < 128) sm[L.W0 + tid] = v0;
+        if (tid < 32) {
+            sm[L.b0 + tid] = vv[0]; sm[L.bg + tid] = vv[1]; sm[L.ln1g + tid] = vv[2]; sm[L.ln1b + tid] = vv[3];
+            sm[L.pos + tid] = vv[4]; sm[L.bq + tid] = vv[5]; sm[L.ln2g + tid] = vv[6]; sm[L.ln2b + tid] = vv[7];
+        }
+        if (tid >= 64 && tid < 128) {
+            sm[L.b2 + tid - 64] = vb2;
+            sm[L.b5 + tid - 64] = vb5;
+        }
+        return;
+    }
+    for (int i = tid; i < 32 * 64; i += blockDim.x) sm[L.Wg + (i >> 6) * NF_FP_STG + (i & 63)] = w.Wg[i];
+    for (int i = tid; i < 32 * 32; i += blockDim.x) sm[L.Wq + (i >> 5) * NF_FP_ST + (i & 31)] = w.Wq[i];
+    for (int i = tid; i < 64 * 32; i += blockDim.x) sm[L.W2 + (i >> 5) * NF_FP_ST + (i & 31)] = w.W2[i];
+    for (int i = tid; i < 64 * 32; i += blockDim.x)
         sm[L.W5 + (i >> 5) * NF_FP_ST + (i & 31)] = (i >> 5) < O ? w.W5[i] : 0.f;
-    for (int i = threadIdx.x; i < 32 * 4; i += blockDim.x) sm[L.W0 + i] = ((i & 3) < I0) ? w.W0[(i >> 2) * I0 + (i & 3)] : 0.f;
-    for (int i = threadIdx.x; i < 32; i += blockDim.x) {
+    for (int i = tid; i < 32 * 4; i += blockDim.x) sm[L.W0 + i] = ((i & 3) < I0) ? w.W0[(i >> 2) * I0 + (i & 3)] : 0.f;
+    for (int i = tid; i < 32; i += blockDim.x) {
         sm[L.b0 + i] = w.b0[i]; sm[L.bg + i] = w.bg[i]; sm[L.ln1g + i] = w.ln1g[i]; sm[L.ln1b + i] = w.ln1b[i];
         sm[L.pos + i] = w.pos[i]; sm[L.bq + i] = w.bq[i]; sm[L.ln2g + i] = w.ln2g[i]; sm[L.ln2b + i] = w.ln2b[i];
     }
-    for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+    for (int i = tid; i < 64; i += blockDim.x) {
         sm[L.b2 + i] = w.b2[i];
         sm[L.b5 + i] = i < O ? w.b5[i] : 0.f;
     }
+}
+__host__ inline bool nf_fpp_vec_ok(const NfFppW& w) {
+    return ((((uintptr_t)w.Wg) | ((uintptr_t)w.Wq) | ((uintptr_t)w.W2) | ((uintptr_t)w.W5)) & 15) == 0;
 }
 
 // the 8 entries of a 32-vector in LDS that this lane's registers correspond to (features 16 b + 4 g + r)
@@ -228,14 +268,15 @@ __device__ __forceinline__ void nf_fpp_forward_tile(const float* sm, const NfFpp
 }
 
 template <int NB>   // NB = ceil(O / 16)
-__global__ void __launch_bounds__(NF_FP_FWD_WAVES * NF_WAVE) k_flowpp_cond_fwd(NfFppW w, int64_t N, int I0, int O,
-                                                                               int64_t tiles) {
+__global__ void __launch_bounds__(NF_FP_FWD_WAVES * NF_WAVE, 4) k_flowpp_cond_fwd(NfFppW w, int64_t N, int I0, int O,
+                                                                               int64_t tiles, int vec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const NfFppL L = nf_fpp_layout(0);
-    nf_fpp_stage(w, sm, L, I0, O);
+    nf_fpp_stage(w, sm, L, I0, O, vec != 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     for (int64_t t = (int64_t)blockIdx.x * NF_FP_FWD_WAVES + wid; t < tiles; t += (int64_t)gridDim.x * NF_FP_FWD_WAVES) {
+        asm volatile("" ::: "memory");   // keep the weight fragments in LDS: hoisted out of the loop they cost 256 registers
         const int64_t row0 = t * 16, row = row0 + c16;
         float xin[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -281,11 +322,12 @@ extern "C" int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* 
     const NfFppL L = nf_fpp_layout(0);
     const size_t lds = (size_t)L.wend * sizeof(float);
     const dim3 grid((unsigned)gx), block(NF_FP_FWD_WAVES * NF_WAVE);
+    const int vec = nf_fpp_vec_ok(w) ? 1 : 0;
     switch ((O + 15) / 16) {
-        case 1: hipLaunchKernelGGL(k_flowpp_cond_fwd<1>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
-        case 2: hipLaunchKernelGGL(k_flowpp_cond_fwd<2>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
-        case 3: hipLaunchKernelGGL(k_flowpp_cond_fwd<3>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
-        default: hipLaunchKernelGGL(k_flowpp_cond_fwd<4>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles); break;
+        case 1: hipLaunchKernelGGL(k_flowpp_cond_fwd<1>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
+        case 2: hipLaunchKernelGGL(k_flowpp_cond_fwd<2>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
+        case 3: hipLaunchKernelGGL(k_flowpp_cond_fwd<3>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
+        default: hipLaunchKernelGGL(k_flowpp_cond_fwd<4>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
     }
     NF_CHECK_LAUNCH();
     return 0;
@@ -381,10 +423,10 @@ __device__ __forceinline__ void nf_fp_put(float* R, int idx, float v) {
 
 template <int NB>
 __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(NfFppW w, NfFppG gr, float* __restrict__ slabs,
-                                                                               int64_t N, int I0, int O, int64_t tiles) {
+                                                                               int64_t N, int I0, int O, int64_t tiles, int vec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const NfFppL L = nf_fpp_layout(NF_FP_BWD_WAVES);
-    nf_fpp_stage(w, sm, L, I0, O);
+    nf_fpp_stage(w, sm, L, I0, O, vec != 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     float* TG = sm + L.tiles + wid * NF_FP_WAVE_LDS;      // gradient-side tile (A fragment of the weight products)
@@ -674,34 +716,41 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
     for (int e = threadIdx.x; e < NF_S_END; e += blockDim.x) slab[e] = sm[L.tiles + e] + sm[L.tiles + NF_S_END + e];
 }
 
-// dst += sum over the blocks' slabs; 64 slab entries x 16 slab groups per block
-__global__ void __launch_bounds__(1024) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,
-                                                               int O) {
-    __shared__ float red[16][64];
+// dst += sum over the blocks' slabs.  grid (NF_S_END / 64, 4): 64 slab entries x 4 slab groups per block, the y index picks
+// a quarter of the slabs (<= 16 independent loads per thread); the four partial sums meet in the destination by atomics.
+__global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,
+                                                              int O) {
+    __shared__ float red[4][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
+    float p[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int b = blockIdx.y * 64 + k * 4 + grp;
+        p[k] = b < nblk ? slabs[(size_t)b * NF_S_END + e] : 0.f;
+    }
     float s = 0.f;
-    for (int b = grp; b < nblk; b += 16) s += slabs[(size_t)b * NF_S_END + e];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += p[k];
     red[grp][el] = s;
     __syncthreads();
-    if (grp != 0) return;
-#pragma unroll
-    for (int k = 1; k < 16; ++k) s += red[k][el];
-    if (e < NF_S_W2) { if ((e >> 5) < O) gr.g_W5[e] += s; }
-    else if (e < NF_S_WQ) gr.g_W2[e - NF_S_W2] += s;
-    else if (e < NF_S_WG) gr.g_Wq[e - NF_S_WQ] += s;
-    else if (e < NF_S_W0) gr.g_Wg[e - NF_S_WG] += s;
-    else if (e < NF_S_B5) { const int k = (e - NF_S_W0) >> 2, i = (e - NF_S_W0) & 3; if (i < I0) gr.g_W0[k * I0 + i] += s; }
-    else if (e < NF_S_B2) { if (e - NF_S_B5 < O) gr.g_b5[e - NF_S_B5] += s; }
-    else if (e < NF_S_BQ) gr.g_b2[e - NF_S_B2] += s;
-    else if (e < NF_S_BG) gr.g_bq[e - NF_S_BQ] += s;
-    else if (e < NF_S_LN2G) gr.g_bg[e - NF_S_BG] += s;
-    else if (e < NF_S_LN2B) gr.g_ln2g[e - NF_S_LN2G] += s;
-    else if (e < NF_S_LN1G) gr.g_ln2b[e - NF_S_LN2B] += s;
-    else if (e < NF_S_LN1B) gr.g_ln1g[e - NF_S_LN1G] += s;
-    else if (e < NF_S_POS) gr.g_ln1b[e - NF_S_LN1B] += s;
-    else if (e < NF_S_B0) gr.g_pos[e - NF_S_POS] += s;
-    else gr.g_b0[e - NF_S_B0] += s;
+    if (grp != 0 || blockIdx.y * 64 >= nblk) return;
+    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    if (e < NF_S_W2) { if ((e >> 5) < O) atomicAdd(gr.g_W5 + e, s); }
+    else if (e < NF_S_WQ) atomicAdd(gr.g_W2 + e - NF_S_W2, s);
+    else if (e < NF_S_WG) atomicAdd(gr.g_Wq + e - NF_S_WQ, s);
+    else if (e < NF_S_W0) atomicAdd(gr.g_Wg + e - NF_S_WG, s);
+    else if (e < NF_S_B5) { const int k = (e - NF_S_W0) >> 2, i = (e - NF_S_W0) & 3; if (i < I0) atomicAdd(gr.g_W0 + k * I0 + i, s); }
+    else if (e < NF_S_B2) { if (e - NF_S_B5 < O) atomicAdd(gr.g_b5 + e - NF_S_B5, s); }
+    else if (e < NF_S_BQ) atomicAdd(gr.g_b2 + e - NF_S_B2, s);
+    else if (e < NF_S_BG) atomicAdd(gr.g_bq + e - NF_S_BQ, s);
+    else if (e < NF_S_LN2G) atomicAdd(gr.g_bg + e - NF_S_BG, s);
+    else if (e < NF_S_LN2B) atomicAdd(gr.g_ln2g + e - NF_S_LN2G, s);
+    else if (e < NF_S_LN1G) atomicAdd(gr.g_ln2b + e - NF_S_LN2B, s);
+    else if (e < NF_S_LN1B) atomicAdd(gr.g_ln1g + e - NF_S_LN1G, s);
+    else if (e < NF_S_POS) atomicAdd(gr.g_ln1b + e - NF_S_LN1B, s);
+    else if (e < NF_S_B0) atomicAdd(gr.g_pos + e - NF_S_POS, s);
+    else atomicAdd(gr.g_b0 + e - NF_S_B0, s);
 }
 
 static_assert(NF_FP_MAX_BLOCKS * NF_S_END == NF_FLOWPP_BWD_WS_FLOATS, "workspace size in include/nfhip.h");
@@ -720,9 +769,9 @@ static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace,
         attr_set = true;
     }
     hipLaunchKernelGGL(k_flowpp_cond_bwd<NB>, dim3((unsigned)gx), dim3(NF_FP_BWD_WAVES * NF_WAVE), lds, stream, w, g, workspace,
-                       N, I0, O, tiles);
+                       N, I0, O, tiles, nf_fpp_vec_ok(w) ? 1 : 0);
     NF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_flowpp_cond_finalize, dim3(NF_S_END / 64), dim3(1024), 0, stream, (const float*)workspace, (int)gx, g,
+    hipLaunchKernelGGL(k_flowpp_cond_finalize, dim3(NF_S_END / 64, (unsigned)((gx + 63) / 64)), dim3(256), 0, stream, (const float*)workspace, (int)gx, g,
                        I0, O);
     NF_CHECK_LAUNCH();
     return 0;
