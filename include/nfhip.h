@@ -325,6 +325,25 @@ int nf_spectral_weights(const float* const* W_bar, float* const* u, float* const
                         const int* cols, int n_mats, float coeff, float eps, const int* flags, int iteration,
                         nf_stream_t stream);
 
+/* ---- the whole MLP conditioner in one persistent launch (small / medium batches) ------------------------------------
+ * flows/modules.py:393-413 with n_blocks = 2: six weight-normed linears (width 32), five BatchNorm1d.  Same mathematics
+ * as the nf_linear_bn_* chain; used when N <= NF_MLP_MAX_ROWS, where those launches are latency-bound: one 16-wave
+ * workgroup per NF_MLP_ROWS_PER_BLOCK rows keeps every activation in registers, training-mode batch statistics cross
+ * the grid through NF_STAT_REPL-replicated atomics + a software grid barrier (all workgroups co-resident by construction).
+ * params: NF_MLP_N_PARAM_PTRS device pointers on the HOST, linear l = 0..5: weight_v (O_l, I_l), weight_g (I_l), bias (O_l);
+ *         then BatchNorm j = 0..4: gamma, beta, running_mean, running_var, num_batches_tracked (int64, may be NULL).
+ * save_stats (5, 2, 32): batch mean and 1/sqrt(var + eps) per BatchNorm, written in training mode (backward input).
+ * ws_zero: NF_MLP_WS_FLOATS floats that are ZERO at launch (statistics accumulators + barrier counter).               */
+#define NF_MLP_LINEARS 6
+#define NF_MLP_BNS 5
+#define NF_MLP_N_PARAM_PTRS 43
+#define NF_MLP_ROWS_PER_BLOCK 256
+#define NF_MLP_MAX_BLOCKS 64
+#define NF_MLP_MAX_ROWS 16384
+#define NF_MLP_WS_FLOATS 2624
+int nf_mlp_chain_fwd(const float* x, const void* const* params, float* out, float* save_stats, float* ws_zero, int64_t N,
+                     int I0, int O_out, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
+
 /* ---- Flow++ conditioner for density data, whole network in one launch  coupling.py:142-149, modules.py:500-578 ---------
  * out = Linear5(LN2(GatedAttn1(LN1(GatedLinear(Linear0(x))))))  for x (N, I0 <= 4), hidden width 32, O <= 64 outputs;
  * GatedAttn with ONE position: q = Wq (h + pos) + bq (rows 64..95 of conv1), v = W2 q + b2, h + v[:32]*sigmoid(v[32:]).  */

@@ -202,6 +202,55 @@ class _FusedMLP(torch.autograd.Function):
         return (g_x, None, None) + tuple(grads)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# MLP conditioner, persistent single-launch form (csrc/mlp_chain.hip) for N <= NF_MLP_MAX_ROWS
+# ----------------------------------------------------------------------------------------------------------------------
+def _mlp_modules(mlp):
+    lins = [mlp.in_block[0]]
+    bns = []
+    for blk in mlp.mid_block:
+        bns += [blk.net[0], blk.net[3]]
+        lins += [blk.net[2], blk.net[5]]
+    bns.append(mlp.out_block[0])
+    lins.append(mlp.out_block[2])
+    return lins, bns
+
+
+def _mlp_tensors(mlp):
+    lins, bns = _mlp_modules(mlp)
+    tensors = []
+    for wn in lins:
+        m = wn.module
+        tensors += [m.weight_v, m.weight_g, m.bias]
+    for bn in bns:
+        tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    return tensors
+
+
+def _ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def mlp_chain_usable(mlp, x):
+    return (len(mlp.mid_block) == 2 and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+            and 0 < x.shape[0] <= N.header_constant('NF_MLP_MAX_ROWS'))
+
+
+def mlp_chain_forward_nograd(mlp, x, training):
+    """forward only (no autograd graph); returns (out, save_stats)."""
+    ts = _mlp_tensors(mlp)
+    x = x.contiguous()
+    Nrows, I0 = x.shape
+    O_out = ts[15].shape[0]
+    out = torch.empty(Nrows, O_out, dtype=torch.float32, device=x.device)
+    save = torch.empty(5, 2, H, dtype=torch.float32, device=x.device)
+    ws = WS.zeros(N.header_constant('NF_MLP_WS_FLOATS'), x.device)
+    tab = _ptr_table([t.detach() for t in ts])
+    N.call('nf_mlp_chain_fwd', N.ptr(x), ctypes.addressof(tab), N.ptr(out), N.ptr(save), N.ptr(ws), Nrows, I0, O_out,
+           int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+    return out, save
+
+
 def mlp_forward(mlp, x):
     """``mlp``: conditioners.MLP with weight_norm=True.  Returns the conditioner output (N, out_channels)."""
     lins = [mlp.in_block[0]]

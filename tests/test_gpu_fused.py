@@ -20,9 +20,7 @@ def _grad_tol(w):
     return 1e-4 * max(1.0, float(w.abs().max()))       # BatchNorm backward is cancellation-heavy
 
 
-@pytest.mark.parametrize('in_ch,out_ch,N', [(1, 2, 4096), (1, 2, 257), (3, 6, 1000), (16, 32, 64), (32, 32, 96)])
-@pytest.mark.parametrize('training', [True, False])
-def test_fused_mlp_vs_modules(pkg, in_ch, out_ch, N, training):
+def _mlp_pair(pkg, in_ch, out_ch):
     cond = importlib.import_module(pkg.__name__ + '.conditioners')
     torch.manual_seed(in_ch * 100 + out_ch)
     ref = cond.MLP(in_ch, out_ch).to(DEV)
@@ -33,7 +31,13 @@ def test_fused_mlp_vs_modules(pkg, in_ch, out_ch, N, training):
                 m.bias.normal_(0, 0.3)
                 m.running_mean.normal_(0, 0.2)
                 m.running_var.uniform_(0.5, 2.0)
-    fus = copy.deepcopy(ref)
+    return ref, copy.deepcopy(ref)
+
+
+@pytest.mark.parametrize('in_ch,out_ch,N', [(1, 2, 4096), (1, 2, 257), (3, 6, 1000), (16, 32, 64), (32, 32, 96)])
+@pytest.mark.parametrize('training', [True, False])
+def test_fused_mlp_vs_modules(pkg, in_ch, out_ch, N, training):
+    ref, fus = _mlp_pair(pkg, in_ch, out_ch)
     ref.train(training)
     fus.train(training)
     g = torch.Generator().manual_seed(N)
@@ -162,3 +166,26 @@ def test_fused_flowpp_conditioner_backward(pkg, D, K, N, direct):
     F_ = layer.net[3].filters
     assert torch.count_nonzero(layer.net[3].conv1.weight.grad[:2 * F_]) == 0
     assert torch.count_nonzero(layer.net[3].conv1.bias.grad[:2 * F_]) == 0
+
+
+@pytest.mark.parametrize('in_ch,out_ch,N', [(1, 2, 4096), (1, 2, 257), (3, 6, 1000), (16, 32, 64), (32, 32, 96),
+                                            (1, 2, 1), (2, 4, 16384)])
+@pytest.mark.parametrize('training', [True, False])
+def test_mlp_chain_forward_vs_modules(pkg, in_ch, out_ch, N, training):
+    """persistent single-launch MLP conditioner (csrc/mlp_chain.hip) against the module-by-module path:
+    output, running statistics, num_batches_tracked."""
+    if N == 1 and training:
+        pytest.skip('BatchNorm1d refuses a single training sample')
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    ref, fus = _mlp_pair(pkg, in_ch, out_ch)
+    ref.train(training)
+    fus.train(training)
+    x = torch.randn(N, in_ch, device=DEV)
+    assert fused.mlp_chain_usable(fus, x)
+    with torch.no_grad():
+        want = ref.forward_reference(x)
+        got, _ = fused.mlp_chain_forward_nograd(fus, x, training)
+    G.assert_close(got, want, 2e-5, rtol=2e-5, what='mlp chain forward')
+    br, bf = dict(ref.named_buffers()), dict(fus.named_buffers())
+    for k in br:
+        G.assert_close(bf[k].float(), br[k].float(), 2e-6, rtol=1e-5, what='buffer ' + k)
