@@ -333,16 +333,26 @@ int nf_spectral_weights(const float* const* W_bar, float* const* u, float* const
  * params: NF_MLP_N_PARAM_PTRS device pointers on the HOST, linear l = 0..5: weight_v (O_l, I_l), weight_g (I_l), bias (O_l);
  *         then BatchNorm j = 0..4: gamma, beta, running_mean, running_var, num_batches_tracked (int64, may be NULL).
  * save_stats (5, 2, 32): batch mean and 1/sqrt(var + eps) per BatchNorm, written in training mode (backward input).
- * ws_zero: NF_MLP_WS_FLOATS floats that are ZERO at launch (statistics accumulators + barrier counter).               */
+ * ws_zero: NF_MLP_WS_FLOATS floats that are ZERO at launch (per-workgroup exchange slots + barrier counter).               */
 #define NF_MLP_LINEARS 6
 #define NF_MLP_BNS 5
 #define NF_MLP_N_PARAM_PTRS 43
 #define NF_MLP_ROWS_PER_BLOCK 256
 #define NF_MLP_MAX_BLOCKS 64
 #define NF_MLP_MAX_ROWS 16384
-#define NF_MLP_WS_FLOATS 2624
+#define NF_MLP_WS_FLOATS (5 * 64 * 64 * 2 + 64)
 int nf_mlp_chain_fwd(const float* x, const void* const* params, float* out, float* save_stats, float* ws_zero, int64_t N,
                      int I0, int O_out, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
+/* autograd of nf_mlp_chain_fwd, one launch (the forward is recomputed from x and save_stats; evaluation mode takes the
+ * running statistics as constants).  grads: NF_MLP_N_GRAD_PTRS device pointers on the HOST, linear l: g_weight_v, g_weight_g,
+ * g_bias; then BatchNorm j: g_gamma, g_beta -- written (accumulate = 0) or += (accumulate = 1, e.g. .grad buffers).
+ * g_x (N, I0) written, nullable.  ws_zero as above (a fresh zero region per call); slabs: NF_MLP_BWD_SLAB_FLOATS floats of
+ * scratch (contents irrelevant, re-usable by the next call on the stream).                                            */
+#define NF_MLP_N_GRAD_PTRS 28
+#define NF_MLP_BWD_SLAB_FLOATS (64 * 6 * 4 * 1056)
+int nf_mlp_chain_bwd(const float* x, const void* const* params, const float* save_stats, const float* g_out, float* g_x,
+                     void* const* grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int I0, int O_out,
+                     int training, float bn_eps, float wn_eps, nf_stream_t stream);
 
 /* ---- Flow++ conditioner for density data, whole network in one launch  coupling.py:142-149, modules.py:500-578 ---------
  * out = Linear5(LN2(GatedAttn1(LN1(GatedLinear(Linear0(x))))))  for x (N, I0 <= 4), hidden width 32, O <= 64 outputs;

@@ -53,14 +53,11 @@ def header_prototypes(path=HEADER):
 
 
 def header_constant(name):
-    """integer value of a ``#define NAME (expr)`` in include/nfhip.h (products of integer literals only)."""
-    m = re.search(r'^#define\s+%s\s+\(?([0-9\s\*]+)\)?\s*$' % re.escape(name), open(HEADER).read(), re.M)
+    """integer value of a ``#define NAME <expr>`` in include/nfhip.h (integer literals, + * and parentheses only)."""
+    m = re.search(r'^#define\s+%s\s+([0-9\s\*\+\(\)]+?)\s*(/\*.*)?$' % re.escape(name), open(HEADER).read(), re.M)
     if m is None:
-        raise NativeLibraryError('include/nfhip.h does not define %s' % name)
-    v = 1
-    for f in m.group(1).split('*'):
-        v *= int(f)
-    return v
+        raise NativeLibraryError('include/nfhip.h does not define %s as an integer expression' % name)
+    return int(eval(m.group(1), {'__builtins__': {}}, {}))       # the character class above admits arithmetic only
 
 
 def load():

@@ -251,22 +251,73 @@ def mlp_chain_forward_nograd(mlp, x, training):
     return out, save
 
 
-def mlp_forward(mlp, x):
-    """``mlp``: conditioners.MLP with weight_norm=True.  Returns the conditioner output (N, out_channels)."""
-    lins = [mlp.in_block[0]]
-    bns = []
-    for blk in mlp.mid_block:
-        bns += [blk.net[0], blk.net[3]]
-        lins += [blk.net[2], blk.net[5]]
-    bns.append(mlp.out_block[0])
-    lins.append(mlp.out_block[2])
-    tensors = []
-    for wn in lins:
-        m = wn.module
-        tensors += [m.weight_v, m.weight_g, m.bias]
-    for bn in bns:
-        tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+def mlp_forward(mlp, x, chain=None):
+    """``mlp``: conditioners.MLP with weight_norm=True.  Returns the conditioner output (N, out_channels).
+    chain: None = the persistent single-launch kernels when the batch fits them, else one launch per linear."""
+    if chain is None:
+        chain = mlp_chain_usable(mlp, x)
+    tensors = _mlp_tensors(mlp)
+    if chain:
+        return _FusedMLPChain.apply(x, mlp.training, *tensors)
     return _FusedMLP.apply(x, mlp.training, len(mlp.mid_block), *tensors)
+
+
+_MLP_SLABS = {}
+
+
+def _mlp_slabs(device):
+    """scratch of nf_mlp_chain_bwd (per-workgroup weight-gradient partials); launches on a stream are ordered, so one
+    buffer per device serves every layer."""
+    t = _MLP_SLABS.get(device)
+    if t is None:
+        t = _MLP_SLABS[device] = torch.empty(N.header_constant('NF_MLP_BWD_SLAB_FLOATS'), dtype=torch.float32, device=device)
+    return t
+
+
+class _FusedMLPChain(torch.autograd.Function):
+    """the MLP conditioner as one persistent launch per direction (csrc/mlp_chain.hip); same tensor list as _FusedMLP."""
+
+    @staticmethod
+    def forward(ctx, x, training, *tensors):
+        nl, nb = 6, 5
+        x = x.contiguous()
+        Nrows, I0 = x.shape
+        O_out = tensors[15].shape[0]
+        dev = x.device
+        out = torch.empty(Nrows, O_out, dtype=torch.float32, device=dev)
+        save = torch.empty(nb, 2, H, dtype=torch.float32, device=dev)
+        ws = WS.zeros(N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        tab = _ptr_table(tensors)
+        N.call('nf_mlp_chain_fwd', N.ptr(x), ctypes.addressof(tab), N.ptr(out), N.ptr(save), N.ptr(ws), Nrows, I0, O_out,
+               int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        ctx.save_for_backward(x, save, *tensors)
+        ctx.meta = (Nrows, I0, O_out, bool(training))
+        from .functional import _sinks
+        learn = list(tensors[:3 * nl]) + [t for j in range(nb) for t in tensors[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+        ctx.sinks = _sinks(*learn)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        nl, nb = 6, 5
+        Nrows, I0, O_out, training = ctx.meta
+        x, save, *tensors = ctx.saved_tensors
+        dev = x.device
+        g_out = g_out.contiguous()
+        learn = list(tensors[:3 * nl]) + [t for j in range(nb) for t in tensors[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+        direct = ctx.sinks is not None
+        dst = ctx.sinks if direct else [torch.empty_like(t) for t in learn]
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = WS.zeros(N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        tab, gtab = _ptr_table(tensors), _ptr_table(dst)
+        N.call('nf_mlp_chain_bwd', N.ptr(x), ctypes.addressof(tab), N.ptr(save), N.ptr(g_out), _p(g_x), ctypes.addressof(gtab),
+               int(direct), N.ptr(ws), N.ptr(_mlp_slabs(dev)), Nrows, I0, O_out, int(training), BN_EPS, WN_EPS, N.stream())
+        if direct:
+            return (g_x, None) + (None, ) * len(tensors)
+        grads = list(dst[:3 * nl])
+        for j in range(nb):
+            grads += [dst[3 * nl + 2 * j], dst[3 * nl + 2 * j + 1], None, None, None]
+        return (g_x, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

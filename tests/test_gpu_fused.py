@@ -189,3 +189,35 @@ def test_mlp_chain_forward_vs_modules(pkg, in_ch, out_ch, N, training):
     br, bf = dict(ref.named_buffers()), dict(fus.named_buffers())
     for k in br:
         G.assert_close(bf[k].float(), br[k].float(), 2e-6, rtol=1e-5, what='buffer ' + k)
+
+
+@pytest.mark.parametrize('direct', [False, True])
+@pytest.mark.parametrize('in_ch,out_ch,N', [(1, 2, 4096), (1, 2, 257), (3, 6, 1000), (16, 32, 64), (32, 32, 96),
+                                            (2, 4, 16384)])
+@pytest.mark.parametrize('training', [True, False])
+def test_mlp_chain_vs_modules(pkg, in_ch, out_ch, N, training, direct):
+    """persistent MLP conditioner, forward + backward, against autograd through the module stack."""
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    ref, fus = _mlp_pair(pkg, in_ch, out_ch)
+    ref.train(training)
+    fus.train(training)
+    g = torch.Generator().manual_seed(N)
+    x = (torch.randn(N, in_ch, generator=g) * 0.7).to(DEV)
+    gout = torch.randn(N, out_ch, generator=g).to(DEV)
+    xr, xf = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yr = ref.forward_reference(xr)
+    yr.backward(gout)
+    if direct:
+        for p in fus.parameters():
+            p.grad = torch.zeros_like(p)
+            p._nf_direct_grad = True
+    yf = fused.mlp_forward(fus, xf, chain=True)
+    G.assert_close(yf, yr, 2e-5, rtol=2e-5, what='output')
+    yf.backward(gout)
+    G.assert_close(xf.grad, xr.grad, _grad_tol(xr.grad), what='grad input')
+    pr, pf = dict(ref.named_parameters()), dict(fus.named_parameters())
+    for k in pr:
+        assert pf[k].grad is not None, k
+        pre_bn_bias = training and k.endswith('module.bias') and 'out_block' not in k
+        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(pr[k].grad)   # analytically-zero gradients: noise only
+        G.assert_close(pf[k].grad, pr[k].grad, tol, what='grad ' + k)
