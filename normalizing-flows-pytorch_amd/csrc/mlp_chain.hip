@@ -16,6 +16,20 @@
 #include "nf_common.h"
 #include "nf_mfma16.h"
 
+#ifndef NF_MC_PROF
+#define NF_MC_PROF 0      // 1 (tools/probes/mlp_chain_prof.py builds that variant): time stamps of workgroup 0 at phase boundaries
+#endif
+__device__ long long nf_mc_prof_buf[128];
+#define NF_MC_T(i)                                                                          \
+    do {                                                                                    \
+        if (NF_MC_PROF && blockIdx.x == 0 && threadIdx.x == 0) nf_mc_prof_buf[i] = wall_clock64(); \
+    } while (0)
+#if NF_MC_PROF
+extern "C" int nf_mlp_chain_prof_read(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nf_mc_prof_buf), sizeof(long long) * 128);
+}
+#endif
+
 #define NF_MC_WAVES 16
 #define NF_MC_THREADS (NF_MC_WAVES * NF_WAVE)
 #define NF_MC_NL NF_MLP_LINEARS
@@ -48,7 +62,8 @@ static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
 #define NF_MC_VAR (NF_MC_BNC + NF_MC_NB * 4 * 32)         // [5][32] biased batch variance (training bookkeeping)
 #define NF_MC_RED (NF_MC_VAR + NF_MC_NB * 32)             // [16][64] cross-wave reduction
 #define NF_MC_GB (NF_MC_RED + NF_MC_WAVES * 64)           // [5][64] backward: grid totals sum_g | sum_gx per BatchNorm (= g_beta | g_gamma)
-#define NF_MC_TILES (NF_MC_GB + NF_MC_NB * 64)            // per-wave 16 x 36 tiles; [blocks][64] exchange buffer aliases them
+#define NF_MC_TOT (NF_MC_GB + NF_MC_NB * 64)              // [2][64] grid totals of the exchange, double buffered by round parity
+#define NF_MC_TILES (NF_MC_TOT + 2 * 64)                  // per-wave 16 x 36 tiles; the [blocks][64] gather buffer aliases them
 
 // arrive + spin on a monotonically increasing counter (zero at launch); every workgroup of the grid is resident by
 // construction (grid <= NF_MLP_MAX_BLOCKS, one workgroup per CU fits), the spin is bounded so a mistake cannot hang the box
@@ -71,27 +86,36 @@ __device__ __forceinline__ void nf_grid_barrier(unsigned* counter, unsigned targ
 // 64-bit stores into its own slots of round `round`, then every workgroup polls all slots until they carry the
 // generation and adds them up in workgroup order (deterministic, no atomics, no fences: a slot is one naturally aligned
 // 8-byte word).  The slots are zero at launch, generations are >= 1.  Measured against atomics + counter barrier: 1.5 vs 4 us.
-//   in : red[w * 64 + i] per-wave partials (w < NF_MC_WAVES);  out: xs[i] (i < 64) totals, valid after the call
-__device__ __forceinline__ void nf_mc_exchange(float* sm, unsigned long long* slots, int round, unsigned gen) {
+// Split in two so that independent work (the backward's weight-gradient products) runs while the stores travel.
+//   publish: red[w * 64 + i] per-wave partials (w < NF_MC_WAVES) -> this workgroup's slots
+//   collect: sm[NF_MC_TOT + (round & 1) * 64 + i] (i < 64) = grid totals, valid after the call; double buffered because
+//            there is no barrier between a wave reading them and a faster wave starting the next round
+__device__ __forceinline__ void nf_mc_publish(float* sm, unsigned long long* slots, int round, unsigned gen) {
     float* red = sm + NF_MC_RED;
-    float* xs = sm + NF_MC_TILES;
-    const int G = gridDim.x;
-    __syncthreads();                                     // red complete; nobody still uses the tiles xs aliases
-    float mine = 0.f;
+    __syncthreads();                                     // red (and any LDS tile written before) complete
     if (threadIdx.x < 64) {
+        float mine = 0.f;
 #pragma unroll
         for (int w = 0; w < NF_MC_WAVES; ++w) mine += red[w * 64 + threadIdx.x];
+        if (gridDim.x == 1) {
+            red[threadIdx.x] = mine;                     // row 0 of red doubles as the result (its partial is consumed)
+        } else {
+            const unsigned long long pk = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(mine);
+            __hip_atomic_store(slots + ((size_t)round * NF_MLP_MAX_BLOCKS + blockIdx.x) * 64 + threadIdx.x, pk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if (G == 1) {
-        if (threadIdx.x < 64) xs[threadIdx.x] = mine;
+}
+__device__ __forceinline__ const float* nf_mc_collect(float* sm, unsigned long long* slots, int round, unsigned gen) {
+    float* xs = sm + NF_MC_TILES;                        // gather buffer: aliases the per-wave scratch tiles (idle here)
+    float* tot = sm + NF_MC_TOT + (round & 1) * 64;
+    const int G = gridDim.x;
+    if (G == 1) {                                        // red[i] was written by the thread that copies it
+        if (threadIdx.x < 64) tot[threadIdx.x] = sm[NF_MC_RED + threadIdx.x];
         __syncthreads();
-        return;
+        return tot;
     }
-    unsigned long long* rs = slots + (size_t)round * NF_MLP_MAX_BLOCKS * 64;
-    if (threadIdx.x < 64) {
-        const unsigned long long pk = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(mine);
-        __hip_atomic_store(rs + blockIdx.x * 64 + threadIdx.x, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const unsigned long long* rs = slots + (size_t)round * NF_MLP_MAX_BLOCKS * 64;
     for (int e = threadIdx.x; e < G * 64; e += blockDim.x) {
         unsigned long long v;
         unsigned spins = 0;
@@ -100,15 +124,16 @@ __device__ __forceinline__ void nf_mc_exchange(float* sm, unsigned long long* sl
             if ((unsigned)(v >> 32) == gen || ++spins > (1u << 22)) break;     // bounded: a mistake cannot hang the box
             __builtin_amdgcn_s_sleep(1);
         } while (true);
-        xs[e + 64] = __uint_as_float((unsigned)v);
+        xs[e] = __uint_as_float((unsigned)v);
     }
     __syncthreads();
     if (threadIdx.x < 64) {
         float t = 0.f;
-        for (int b = 0; b < G; ++b) t += xs[64 + b * 64 + threadIdx.x];
-        xs[threadIdx.x] = t;
+        for (int b = 0; b < G; ++b) t += xs[b * 64 + threadIdx.x];
+        tot[threadIdx.x] = t;
     }
     __syncthreads();
+    return tot;
 }
 
 __device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, int O_out, float wn_eps) {
@@ -160,11 +185,11 @@ __device__ __forceinline__ void nf_mc_activate(const float* sm, int j, int l, co
     for (int k = 0; k < 8; ++k) av[k] = fmaxf(fmaf(a[k], sc[k], sh[k]), 0.f) * ws[k];
 }
 
-// batch statistics of BatchNorm j over the whole grid (dv = pre-bias output of the producing linear, zero in invalid rows),
-// then its constants -> sm[NF_MC_BNC + 4 j ..]; workgroup 0 does the running-statistics bookkeeping
-__device__ __forceinline__ void nf_mc_batchnorm_stats(float* sm, const NfMlpP& p, int j, int lprod, const float (&dv)[8], bool rv,
-                                                      unsigned long long* slots, int64_t N, float eps, int c16, int g,
-                                                      int wid) {
+// batch statistics of BatchNorm j over the whole grid (dv = pre-bias output of the producing linear l = j), then its
+// constants -> sm[NF_MC_BNC + 4 j ..] (one half-wave derives them: per-lane redundancy costs more issue slots on the
+// 16-wave workgroup than the barrier it would save)
+__device__ __forceinline__ void nf_mc_batchnorm_train(float* sm, int j, const float (&dv)[8], bool rv, unsigned long long* slots,
+                                                      int64_t N, float eps, int c16, int g, int wid) {
     float* tile = sm + NF_MC_TILES + wid * 16 * NF_FP_ST;
     float m[8];
 #pragma unroll
@@ -187,15 +212,16 @@ __device__ __forceinline__ void nf_mc_batchnorm_stats(float* sm, const NfMlpP& p
         red[wid * 64 + c16] = s1[0]; red[wid * 64 + 16 + c16] = s1[1];
         red[wid * 64 + 32 + c16] = s2[0]; red[wid * 64 + 48 + c16] = s2[1];
     }
-    nf_mc_exchange(sm, slots, j, (unsigned)(j + 1));
-    const float* xs = sm + NF_MC_TILES;
+    if (j == 1) NF_MC_T(40);
+    nf_mc_publish(sm, slots, j, (unsigned)(j + 1));
+    const float* tot = nf_mc_collect(sm, slots, j, (unsigned)(j + 1));
+    if (j == 1) NF_MC_T(41);
     if (threadIdx.x < 32) {
         const int k = threadIdx.x;
-        const float t1 = xs[k], t2 = xs[32 + k];
         const float invN = 1.f / (float)N;
-        const float m1 = t1 * invN;
-        const float mean = sm[NF_MC_B + lprod * 32 + k] + m1;
-        const float var = fmaxf(t2 * invN - m1 * m1, 0.f);                         // biased, as BatchNorm normalises
+        const float m1 = tot[k] * invN;
+        const float mean = sm[NF_MC_B + j * 32 + k] + m1;                          // sums are centred at the bias
+        const float var = fmaxf(tot[32 + k] * invN - m1 * m1, 0.f);                // biased, as BatchNorm normalises
         const float invstd = 1.f / sqrtf(var + eps);
         const float sc = sm[NF_MC_GA + j * 32 + k] * invstd;
         sm[NF_MC_BNC + (4 * j + 0) * 32 + k] = sc;
@@ -229,10 +255,18 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
                                                                  float* save, float* stats, int64_t N, int I0, int O_out,
                                                                  int training, float eps, float mom, float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    nf_mc_stage(p, sm, I0, O_out, wn_eps);
+    NF_MC_T(0);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
     const bool rv = row < N;
+    float xa[8], rm_old = 0.f, rv_old = 0.f;              // issued before the staging: one memory latency for everything
+    nf_mc_load_x(x, row, rv, I0, xa, g);
+    if (training && blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
+        rm_old = p.rmean[threadIdx.x >> 5][threadIdx.x & 31];
+        rv_old = p.rvar[threadIdx.x >> 5][threadIdx.x & 31];
+    }
+    nf_mc_stage(p, sm, I0, O_out, wn_eps);
+    NF_MC_T(1);
     unsigned long long* slots = (unsigned long long*)stats;
     if (!training) {
         if (threadIdx.x < NF_MC_NB * 32) {
@@ -242,40 +276,43 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
         __syncthreads();
     }
     float a_in[8], av[8], dv[8], bias[8], stream[8];
-    nf_mc_load_x(x, row, rv, I0, a_in, g);
     {   // linear 0: no BatchNorm in front, only the weight-norm scale
         float ws[8];
         nf_fp_ldvec(sm + NF_MC_WS, g, ws);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) av[k] = a_in[k] * ws[k];
+        for (int k = 0; k < 8; ++k) av[k] = xa[k] * ws[k];
     }
     nf_mc_linear(sm, 0, av, dv, c16, g);
+    NF_MC_T(2);
 #pragma unroll 1
     for (int l = 0; l < NF_MC_NL - 1; ++l) {              // dv = pre-bias output of linear l = input of BatchNorm l
         if (l > 0 && (l & 1) == 0) {                      // second linear of a residual block: add the block input
 #pragma unroll
             for (int k = 0; k < 8; ++k) dv[k] += stream[k];
         }
-        if (training) nf_mc_batchnorm_stats(sm, p, l, l, dv, rv, slots, N, eps, c16, g, wid);
+        if (training) nf_mc_batchnorm_train(sm, l, dv, rv, slots, N, eps, c16, g, wid);
         nf_fp_ldvec(sm + NF_MC_B + l * 32, g, bias);
 #pragma unroll
         for (int k = 0; k < 8; ++k) a_in[k] = dv[k] + bias[k];
+        nf_mc_activate(sm, l, l + 1, a_in, av, g);
         if ((l & 1) == 0) {                               // acts[0], acts[2], acts[4] are the residual stream
 #pragma unroll
             for (int k = 0; k < 8; ++k) stream[k] = a_in[k];
         }
-        nf_mc_activate(sm, l, l + 1, a_in, av, g);
         nf_mc_linear(sm, l + 1, av, dv, c16, g);
+        NF_MC_T(3 + l);
     }
-    if (training && blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {        // BatchNorm bookkeeping, off the critical path
-        const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
-        const float mean = sm[NF_MC_BNC + (4 * j + 2) * 32 + k], var = sm[NF_MC_VAR + j * 32 + k];
-        const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-        p.rmean[j][k] = (1.f - mom) * p.rmean[j][k] + mom * mean;
-        p.rvar[j][k] = (1.f - mom) * p.rvar[j][k] + mom * unb;
-        save[(2 * j + 0) * 32 + k] = mean;
-        save[(2 * j + 1) * 32 + k] = sm[NF_MC_BNC + (4 * j + 3) * 32 + k];
-        if (k == 0 && p.nbt[j] != nullptr) p.nbt[j][0] += 1;
+    if (training && blockIdx.x == 0) {                    // BatchNorm bookkeeping (nn.BatchNorm1d semantics), off the chain
+        if (threadIdx.x < NF_MC_NB * 32) {
+            const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
+            const float mean = sm[NF_MC_BNC + (4 * j + 2) * 32 + k], var = sm[NF_MC_VAR + j * 32 + k];
+            const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+            p.rmean[j][k] = (1.f - mom) * rm_old + mom * mean;
+            p.rvar[j][k] = (1.f - mom) * rv_old + mom * unb;
+            save[(2 * j + 0) * 32 + k] = mean;
+            save[(2 * j + 1) * 32 + k] = sm[NF_MC_BNC + (4 * j + 3) * 32 + k];
+            if (k == 0 && p.nbt[j] != nullptr) p.nbt[j][0] += 1;
+        }
     }
     nf_fp_ldvec(sm + NF_MC_B + (NF_MC_NL - 1) * 32, g, bias);
     if (rv) {
@@ -285,10 +322,11 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
             if (k < O_out) out[row * O_out + k] = dv[j] + bias[j];
         }
     }
+    NF_MC_T(8);
 }
 
 static inline size_t nf_mc_lds_bytes(int tiles_per_wave) {
-    static_assert(NF_MC_WAVES * 16 * NF_FP_ST >= (NF_MLP_MAX_BLOCKS + 1) * 64, "exchange buffer aliases the first tiles");
+    static_assert(NF_MC_WAVES * 16 * NF_FP_ST >= NF_MLP_MAX_BLOCKS * 64, "exchange buffer aliases the first tiles");
     return (size_t)(NF_MC_TILES + NF_MC_WAVES * tiles_per_wave * 16 * NF_FP_ST) * sizeof(float);
 }
 
@@ -329,6 +367,33 @@ struct NfMlpG { float* v[NF_MC_NL]; float* g[NF_MC_NL]; float* b[NF_MC_NL]; floa
 #define NF_MC_SLAB (NF_MC_NL * NF_MC_SLAB_L)
 static_assert(NF_MC_SLAB * NF_MLP_MAX_BLOCKS == NF_MLP_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
 
+// this wave's share of g_Weff[L] and g_bias[L]: output block (wid & 1, (wid >> 1) & 1) over the rows of waves 4 (wid >> 2) .. + 3
+template <int L>
+__device__ __forceinline__ void nf_mc_wgrad_job(const float* sm, float* slab, int lane, int wid) {
+    const int c16 = lane & 15, g = lane >> 4;
+    const int ob = wid & 1, ib = (wid >> 1) & 1, kq = wid >> 2;
+    f32x4 d = nf_fp_zero4();
+    float bs = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* Gt = sm + NF_MC_TILES + (NF_MC_WAVES + 4 * kq + q) * 16 * NF_FP_ST + 16 * ob + c16;
+        const float* At = sm + NF_MC_TILES + (2 * NF_MC_WAVES + 4 * kq + q) * 16 * NF_FP_ST + 16 * ib + c16;
+        float ga[4], av[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { ga[s2] = Gt[(4 * s2 + g) * NF_FP_ST]; av[s2] = At[(4 * s2 + g) * NF_FP_ST]; }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            bs += ga[s2];
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], av[s2], d, 0, 0, 0);
+        }
+    }
+    float* sl = slab + L * NF_MC_SLAB_L + kq * NF_MC_SLAB_Q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sl[(16 * ob + 4 * g + r) * 32 + 16 * ib + c16] = d[r];
+    bs = nf_fp_rowsum(bs);
+    if (ib == 0 && g == 0) sl[1024 + 16 * ob + c16] = bs;
+}
+
 template <int L>
 __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8], const float (&a)[NF_MC_NB][8], float (&G)[8],
                                                 float (&Gs)[8], float* slab, unsigned long long* slots, float* g_x, int64_t row,
@@ -352,28 +417,7 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
         nf_fp_store_rows(G, TG, c16, g);
         nf_fp_store_rows(act, TA, c16, g);
     }
-    __syncthreads();
-    {   // this wave's share of g_Weff[L] and g_bias[L]
-        const int ob = wid & 1, ib = (wid >> 1) & 1, kq = wid >> 2;
-        f32x4 d = nf_fp_zero4();
-        float bs = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float* Gt = sm + NF_MC_TILES + (NF_MC_WAVES + 4 * kq + q) * 16 * NF_FP_ST + 16 * ob + c16;
-            const float* At = sm + NF_MC_TILES + (2 * NF_MC_WAVES + 4 * kq + q) * 16 * NF_FP_ST + 16 * ib + c16;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const float ga = Gt[(4 * s2 + g) * NF_FP_ST], av = At[(4 * s2 + g) * NF_FP_ST];
-                bs += ga;
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av, d, 0, 0, 0);
-            }
-        }
-        float* sl = slab + L * NF_MC_SLAB_L + kq * NF_MC_SLAB_Q;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sl[(16 * ob + 4 * g + r) * 32 + 16 * ib + c16] = d[r];
-        bs = nf_fp_rowsum(bs);
-        if (ib == 0 && g == 0) sl[1024 + 16 * ob + c16] = bs;
-    }
+    if (L == 4) NF_MC_T(80);
     float t[8];
     {   // G Weff_L
         f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
@@ -383,7 +427,7 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[k] = acc[k >> 2][k & 3] * ws[k];
     }
-    if (L == 0) {                                         // gradient of the conditioner input
+    if (L == 0) {                                         // gradient of the conditioner input; last weight-gradient products
         if (g_x != nullptr && rv) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -391,6 +435,8 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
                 if (k < I0) g_x[row * I0 + k] = t[j];
             }
         }
+        __syncthreads();
+        nf_mc_wgrad_job<L>(sm, slab, lane, wid);
         return;
     }
     constexpr int J = L > 0 ? L - 1 : 0;                  // the BatchNorm between a_J and linear L
@@ -425,12 +471,17 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
             red[wid * 64 + 32 + c16] = s2[0]; red[wid * 64 + 48 + c16] = s2[1];
         }
     }
-    nf_mc_exchange(sm, slots, NF_MC_NB - 1 - J, (unsigned)(NF_MC_NB - J));   // also fences the weight-gradient tile reads
-    const float* xs = sm + NF_MC_TILES;
-    if (threadIdx.x < 64) sm[NF_MC_GB + J * 64 + threadIdx.x] = xs[threadIdx.x];
+    if (L == 4) NF_MC_T(81);
+    nf_mc_publish(sm, slots, NF_MC_NB - 1 - J, (unsigned)(NF_MC_NB - J));    // its barrier also covers the G / act tiles
+    if (L == 4) NF_MC_T(82);
+    nf_mc_wgrad_job<L>(sm, slab, lane, wid);                                 // runs while the partial sums travel
+    if (L == 4) NF_MC_T(83);
+    const float* tot = nf_mc_collect(sm, slots, NF_MC_NB - 1 - J, (unsigned)(NF_MC_NB - J));
+    if (L == 4) NF_MC_T(84);
+    if (threadIdx.x < 64) sm[NF_MC_GB + J * 64 + threadIdx.x] = tot[threadIdx.x];
     float mg[8], mgx[8];
-    nf_fp_ldvec(xs, g, mg);
-    nf_fp_ldvec(xs + 32, g, mgx);
+    nf_fp_ldvec(tot, g, mg);
+    nf_fp_ldvec(tot + 32, g, mgx);
     const float invN = training ? 1.f / (float)N : 0.f;   // evaluation mode: the statistics are constants
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -447,24 +498,34 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
                                                                  int accumulate, float* ws, float* __restrict__ slabs, int64_t N,
                                                                  int I0, int O_out, int training, float eps, float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    nf_mc_stage(p, sm, I0, O_out, wn_eps);
-    if (threadIdx.x < NF_MC_NB * 32) {
-        const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
-        const float mean = training ? save[(2 * j + 0) * 32 + k] : p.rmean[j][k];
-        const float invstd = training ? save[(2 * j + 1) * 32 + k] : 1.f / sqrtf(p.rvar[j][k] + eps);
-        nf_mc_batchnorm_consts(sm, j, mean, invstd);
-    }
-    __syncthreads();
+    NF_MC_T(64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
     const bool rv = row < N;
+    float xa[8], a[NF_MC_NB][8], G[8], Gs[8];
+    nf_mc_load_x(x, row, rv, I0, xa, g);                  // both loads are in flight while the weights are staged
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * (j >> 2) + 4 * g + (j & 3);
+        const float v = g_out[(rv ? row : 0) * O_out + (k < O_out ? k : 0)];
+        G[j] = (rv && k < O_out) ? v : 0.f;
+        Gs[j] = 0.f;
+    }
+    float bn_mean = 0.f, bn_invstd = 0.f;
+    if (threadIdx.x < NF_MC_NB * 32) {
+        const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
+        bn_mean = training ? save[(2 * j + 0) * 32 + k] : p.rmean[j][k];
+        bn_invstd = training ? save[(2 * j + 1) * 32 + k] : 1.f / sqrtf(p.rvar[j][k] + eps);
+    }
+    nf_mc_stage(p, sm, I0, O_out, wn_eps);
+    NF_MC_T(65);
+    if (threadIdx.x < NF_MC_NB * 32) nf_mc_batchnorm_consts(sm, threadIdx.x >> 5, bn_mean, bn_invstd);
+    __syncthreads();
     unsigned long long* slots = (unsigned long long*)ws;
     unsigned* counter = (unsigned*)(ws + NF_MC_NB * NF_MLP_MAX_BLOCKS * 64 * 2);
     float* slab = slabs + (size_t)blockIdx.x * NF_MC_SLAB;
 
     // ---- forward, activations kept ------------------------------------------------------------------------------
-    float xa[8], a[NF_MC_NB][8];
-    nf_mc_load_x(x, row, rv, I0, xa, g);
     {
         float av[8], dv[8], bias[8], ws0[8];
         nf_fp_ldvec(sm + NF_MC_WS, g, ws0);
@@ -483,33 +544,42 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
             for (int k = 0; k < 8; ++k) a[l][k] = dv[k] + bias[k] + ((l & 1) == 0 ? a[l - 2][k] : 0.f);
         }
     }
+    NF_MC_T(66);
     // ---- backward -----------------------------------------------------------------------------------------------
-    float G[8], Gs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 16 * (j >> 2) + 4 * g + (j & 3);
-        const float v = g_out[(rv ? row : 0) * O_out + (k < O_out ? k : 0)];
-        G[j] = (rv && k < O_out) ? v : 0.f;
-        Gs[j] = 0.f;
-    }
     nf_mc_bwd_layer<5>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
+    NF_MC_T(67);
     nf_mc_bwd_layer<4>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
+    NF_MC_T(68);
     nf_mc_bwd_layer<3>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
+    NF_MC_T(69);
     nf_mc_bwd_layer<2>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
+    NF_MC_T(70);
     nf_mc_bwd_layer<1>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
+    NF_MC_T(71);
     nf_mc_bwd_layer<0>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
+    NF_MC_T(72);
 
     // ---- slabs -> parameter gradients: workgroup l (mod grid) owns linear l, workgroup 0 the BatchNorm affines ------------
     nf_grid_barrier(counter, gridDim.x);
+    NF_MC_T(73);
     float* gW = sm + NF_MC_TILES;                         // [1024 + 32] folded gradient of Weff and of the bias
     float* nd = gW + 1056;                                // [2][32] column norm^2 and <g_Weff, v>
     for (int l = blockIdx.x; l < NF_MC_NL; l += gridDim.x) {
         const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
         for (int e = threadIdx.x; e < NF_MC_SLAB_Q; e += blockDim.x) {
             float tsum = 0.f;
-            for (int b = 0; b < (int)gridDim.x; ++b) {
-                const float* sl = slabs + ((size_t)b * NF_MC_NL + l) * NF_MC_SLAB_L + e;
-                tsum += (sl[0] + sl[NF_MC_SLAB_Q]) + (sl[2 * NF_MC_SLAB_Q] + sl[3 * NF_MC_SLAB_Q]);
+            for (int b0 = 0; b0 < (int)gridDim.x; b0 += 8) {          // 32 independent loads in flight: one latency per trip
+                float v[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + u < (int)gridDim.x ? b0 + u : (int)gridDim.x - 1;
+                    const float* sl = slabs + ((size_t)b * NF_MC_NL + l) * NF_MC_SLAB_L + e;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[u][q] = sl[q * NF_MC_SLAB_Q];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + u < (int)gridDim.x) tsum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
             }
             gW[e] = tsum;
         }
@@ -546,6 +616,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         gr.beta[j][k] = (accumulate ? gr.beta[j][k] : 0.f) + sm[NF_MC_GB + j * 64 + k];
         gr.gamma[j][k] = (accumulate ? gr.gamma[j][k] : 0.f) + sm[NF_MC_GB + j * 64 + 32 + k];
     }
+    NF_MC_T(74);
 }
 
 extern "C" int nf_mlp_chain_bwd(const float* x, const void* const* params, const float* save_stats, const float* g_out, float* g_x,
