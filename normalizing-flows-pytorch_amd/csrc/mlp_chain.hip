@@ -55,7 +55,8 @@ static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
 // LDS (floats)
 #define NF_MC_W 0                                         // [6][32 * 36] weight_v, zero padded
 #define NF_MC_WS (NF_MC_W + NF_MC_NL * 32 * NF_FP_ST)     // [6][32] weight-norm column scales g_k / (||v[:, k]|| + eps)
-#define NF_MC_B (NF_MC_WS + NF_MC_NL * 32)                // [6][32] biases
+#define NF_MC_G (NF_MC_WS + NF_MC_NL * 32)                // [6][32] weight-norm gains g_k (the backward's fold reads them)
+#define NF_MC_B (NF_MC_G + NF_MC_NL * 32)                 // [6][32] biases
 #define NF_MC_GA (NF_MC_B + NF_MC_NL * 32)                // [5][32] gamma
 #define NF_MC_BE (NF_MC_GA + NF_MC_NB * 32)               // [5][32] beta
 #define NF_MC_BNC (NF_MC_BE + NF_MC_NB * 32)              // [5][4][32] per BatchNorm: scale, shift, mean, invstd
@@ -164,6 +165,7 @@ __device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, 
         for (int o = 0; o < 32; ++o) ss = fmaf(W[o * NF_FP_ST + k], W[o * NF_FP_ST + k], ss);
         const int I = (tid >> 5) == 0 ? I0 : 32;
         sm[NF_MC_WS + tid] = k < I ? gk / (sqrtf(ss) + wn_eps) : 0.f;
+        sm[NF_MC_G + tid] = gk;
     }
     __syncthreads();
 }
@@ -387,9 +389,8 @@ __device__ __forceinline__ void nf_mc_wgrad_job(const float* sm, float* slab, in
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], av[s2], d, 0, 0, 0);
         }
     }
-    float* sl = slab + L * NF_MC_SLAB_L + kq * NF_MC_SLAB_Q;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sl[(16 * ob + 4 * g + r) * 32 + 16 * ib + c16] = d[r];
+    float* sl = slab + L * NF_MC_SLAB_L + kq * NF_MC_SLAB_Q;       // [i][o]: the fold walks columns (fixed i) contiguously
+    *(float4*)(sl + (16 * ib + c16) * 32 + 16 * ob + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
     bs = nf_fp_rowsum(bs);
     if (ib == 0 && g == 0) sl[1024 + 16 * ob + c16] = bs;
 }
@@ -562,54 +563,68 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
     // ---- slabs -> parameter gradients: workgroup l (mod grid) owns linear l, workgroup 0 the BatchNorm affines ------------
     nf_grid_barrier(counter, gridDim.x);
     NF_MC_T(73);
-    float* gW = sm + NF_MC_TILES;                         // [1024 + 32] folded gradient of Weff and of the bias
-    float* nd = gW + 1056;                                // [2][32] column norm^2 and <g_Weff, v>
-    for (int l = blockIdx.x; l < NF_MC_NL; l += gridDim.x) {
-        const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
-        for (int e = threadIdx.x; e < NF_MC_SLAB_Q; e += blockDim.x) {
+    // unit = one column (l, i) of a weight matrix or one bias vector, owned by a half wave (lane = output index o): sums the
+    // partials (coalesced), reduces <g_Weff, v> and ||v||^2 over o by shuffles, applies the weight-norm backward.  No LDS.
+    {
+        const int o = threadIdx.x & 31;
+        const int G_ = gridDim.x;
+        constexpr int HW = NF_MC_THREADS / 32;                       // half waves per workgroup
+        constexpr int NU1 = (NF_MC_NL * 33 + HW - 1) / HW;           // units per half wave when there is one workgroup
+        float pre[NU1];
+        if (G_ == 1) {                                               // all of this half wave's partials in flight at once
+#pragma unroll
+            for (int k = 0; k < NU1; ++k) {
+                const int u = (threadIdx.x >> 5) + k * HW;
+                const int uu = u < NF_MC_NL * 33 ? u : 0;
+                const int l = uu / 33, i = uu - l * 33;
+                const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
+                pre[k] = (base[0] + base[NF_MC_SLAB_Q]) + (base[2 * NF_MC_SLAB_Q] + base[3 * NF_MC_SLAB_Q]);
+            }
+        }
+        int kk = 0;
+        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33; u += G_ * HW, ++kk) {
+            const int l = u / 33, i = u - l * 33;                    // i == 32: the bias
+            const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
+            if (i < 32 && i >= I) continue;                          // half-wave uniform
             float tsum = 0.f;
-            for (int b0 = 0; b0 < (int)gridDim.x; b0 += 8) {          // 32 independent loads in flight: one latency per trip
-                float v[8][4];
+            if (G_ == 1) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int b = b0 + u < (int)gridDim.x ? b0 + u : (int)gridDim.x - 1;
-                    const float* sl = slabs + ((size_t)b * NF_MC_NL + l) * NF_MC_SLAB_L + e;
+                for (int k = 0; k < NU1; ++k) tsum = k == kk ? pre[k] : tsum;
+            } else {
+                const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
+                for (int b0 = 0; b0 < G_; b0 += 8) {                 // 32 independent loads in flight: one latency per trip
+                    float v[8][4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[u][q] = sl[q * NF_MC_SLAB_Q];
+                    for (int q8 = 0; q8 < 8; ++q8) {
+                        const int b = b0 + q8 < G_ ? b0 + q8 : G_ - 1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q8][q] = base[(size_t)b * NF_MC_SLAB + q * NF_MC_SLAB_Q];
+                    }
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8)
+                        if (b0 + q8 < G_) tsum += (v[q8][0] + v[q8][1]) + (v[q8][2] + v[q8][3]);
                 }
+            }
+            if (i == 32) {
+                if (o < O) gr.b[l][o] = (accumulate ? gr.b[l][o] : 0.f) + tsum;
+                continue;
+            }
+            const float v = sm[NF_MC_W + l * 32 * NF_FP_ST + o * NF_FP_ST + i];
+            float n2 = v * v, dt = tsum * v;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (b0 + u < (int)gridDim.x) tsum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+            for (int off = 16; off > 0; off >>= 1) {
+                n2 += __shfl_xor(n2, off, NF_WAVE);
+                dt += __shfl_xor(dt, off, NF_WAVE);
             }
-            gW[e] = tsum;
-        }
-        __syncthreads();
-        const float* W = sm + NF_MC_W + l * 32 * NF_FP_ST;
-        if (threadIdx.x < 32) {
-            const int i = threadIdx.x;
-            float n2 = 0.f, dt = 0.f;
-#pragma unroll 8
-            for (int o = 0; o < 32; ++o) {
-                const float v = W[o * NF_FP_ST + i];
-                n2 = fmaf(v, v, n2);
-                dt = fmaf(gW[o * 32 + i], v, dt);
-            }
-            nd[i] = n2; nd[32 + i] = dt;
-        }
-        __syncthreads();
-        {
-            const int e = threadIdx.x, o = e >> 5, i = e & 31;
-            if (o < O && i < I) {
-                const float nrm = sqrtf(nd[i]), den = nrm + wn_eps, gi = p.g[l][i];
-                float gv = gW[e] * (gi / den);
-                if (nrm > 0.f) gv -= W[o * NF_FP_ST + i] * (nd[32 + i] * gi / (den * den * nrm));
+            const float nrm = sqrtf(n2), den = nrm + wn_eps, gi = sm[NF_MC_G + l * 32 + i];
+            if (o < O) {
+                float gv = tsum * (gi / den);
+                if (nrm > 0.f) gv -= v * (dt * gi / (den * den * nrm));
                 float* dst = gr.v[l] + o * I + i;
                 *dst = (accumulate ? *dst : 0.f) + gv;
             }
-            if (e < I) gr.g[l][e] = (accumulate ? gr.g[l][e] : 0.f) + nd[32 + e] / (sqrtf(nd[e]) + wn_eps);
-            if (e < O) gr.b[l][e] = (accumulate ? gr.b[l][e] : 0.f) + gW[1024 + e];
+            if (o == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + dt / den;
         }
-        __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
         const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
