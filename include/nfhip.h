@@ -337,10 +337,10 @@ int nf_spectral_weights(const float* const* W_bar, float* const* u, float* const
 #define NF_MLP_LINEARS 6
 #define NF_MLP_BNS 5
 #define NF_MLP_N_PARAM_PTRS 43
-#define NF_MLP_ROWS_PER_BLOCK 256
-#define NF_MLP_MAX_BLOCKS 64
+#define NF_MLP_ROWS_PER_BLOCK 128
+#define NF_MLP_MAX_BLOCKS 128
 #define NF_MLP_MAX_ROWS 16384
-#define NF_MLP_WS_FLOATS (5 * 64 * 64 * 2 + 64)
+#define NF_MLP_WS_FLOATS (5 * 128 * 64 * 2 + 64)
 int nf_mlp_chain_fwd(const float* x, const void* const* params, float* out, float* save_stats, float* ws_zero, int64_t N,
                      int I0, int O_out, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
 /* autograd of nf_mlp_chain_fwd, one launch (the forward is recomputed from x and save_stats; evaluation mode takes the
@@ -349,7 +349,7 @@ int nf_mlp_chain_fwd(const float* x, const void* const* params, float* out, floa
  * g_x (N, I0) written, nullable.  ws_zero as above (a fresh zero region per call); slabs: NF_MLP_BWD_SLAB_FLOATS floats of
  * scratch (contents irrelevant, re-usable by the next call on the stream).                                            */
 #define NF_MLP_N_GRAD_PTRS 28
-#define NF_MLP_BWD_SLAB_FLOATS (64 * 6 * 4 * 1056)
+#define NF_MLP_BWD_SLAB_FLOATS (128 * 6 * 2 * 1056)
 int nf_mlp_chain_bwd(const float* x, const void* const* params, const float* save_stats, const float* g_out, float* g_x,
                      void* const* grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int I0, int O_out,
                      int training, float bn_eps, float wn_eps, nf_stream_t stream);

@@ -30,7 +30,8 @@ extern "C" int nf_mlp_chain_prof_read(long long* host_out) {
 }
 #endif
 
-#define NF_MC_WAVES 16
+#define NF_MC_WAVES (NF_MLP_ROWS_PER_BLOCK / 16)         // 8 or 16 (multiple of 4: the weight-gradient jobs come in fours)
+#define NF_MC_NKQ (NF_MC_WAVES / 4)                       // row groups of 64 per workgroup
 #define NF_MC_THREADS (NF_MC_WAVES * NF_WAVE)
 #define NF_MC_NL NF_MLP_LINEARS
 #define NF_MC_NB NF_MLP_BNS
@@ -64,7 +65,11 @@ static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
 #define NF_MC_RED (NF_MC_VAR + NF_MC_NB * 32)             // [16][64] cross-wave reduction
 #define NF_MC_GB (NF_MC_RED + NF_MC_WAVES * 64)           // [5][64] backward: grid totals sum_g | sum_gx per BatchNorm (= g_beta | g_gamma)
 #define NF_MC_TOT (NF_MC_GB + NF_MC_NB * 64)              // [2][64] grid totals of the exchange, double buffered by round parity
-#define NF_MC_TILES (NF_MC_TOT + 2 * 64)                  // per-wave 16 x 36 tiles; the [blocks][64] gather buffer aliases them
+#define NF_MC_TILES (NF_MC_TOT + 2 * 64)                  // per-wave 16 x 36 tiles: scratch | (backward) G | activation
+// the [blocks][64] gather buffer of the exchange aliases the scratch tiles when it fits in them (they are idle while it is
+// live), else it follows the last tile
+#define NF_MC_GATHER_IN_SCRATCH (NF_MLP_MAX_BLOCKS * 64 <= NF_MC_WAVES * 16 * NF_FP_ST)
+#define NF_MC_GATHER(tiles_per_wave) (NF_MC_GATHER_IN_SCRATCH ? NF_MC_TILES : NF_MC_TILES + NF_MC_WAVES * (tiles_per_wave) * 16 * NF_FP_ST)
 
 // arrive + spin on a monotonically increasing counter (zero at launch); every workgroup of the grid is resident by
 // construction (grid <= NF_MLP_MAX_BLOCKS, one workgroup per CU fits), the spin is bounded so a mistake cannot hang the box
@@ -107,8 +112,8 @@ __device__ __forceinline__ void nf_mc_publish(float* sm, unsigned long long* slo
         }
     }
 }
-__device__ __forceinline__ const float* nf_mc_collect(float* sm, unsigned long long* slots, int round, unsigned gen) {
-    float* xs = sm + NF_MC_TILES;                        // gather buffer: aliases the per-wave scratch tiles (idle here)
+__device__ __forceinline__ const float* nf_mc_collect(float* sm, int gather, unsigned long long* slots, int round, unsigned gen) {
+    float* xs = sm + gather;                             // see NF_MC_GATHER
     float* tot = sm + NF_MC_TOT + (round & 1) * 64;
     const int G = gridDim.x;
     if (G == 1) {                                        // red[i] was written by the thread that copies it
@@ -138,12 +143,17 @@ __device__ __forceinline__ const float* nf_mc_collect(float* sm, unsigned long l
 }
 
 __device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, int O_out, float wn_eps) {
-    const int tid = threadIdx.x, oo = tid >> 5, k = tid & 31;
-    float w[NF_MC_NL];
+    const int tid = threadIdx.x, k = tid & 31;
+    constexpr int RPT = 32 * 32 / NF_MC_THREADS;           // rows of a 32 x 32 matrix per thread (1 or 2)
+    float w[NF_MC_NL][RPT];
 #pragma unroll
-    for (int l = 0; l < NF_MC_NL; ++l) {                  // six independent loads in flight, one latency
+    for (int l = 0; l < NF_MC_NL; ++l) {                  // 6 * RPT independent loads in flight, one latency
         const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
-        w[l] = (oo < O && k < I) ? p.v[l][oo * I + k] : 0.f;
+#pragma unroll
+        for (int h = 0; h < RPT; ++h) {
+            const int oo = (tid >> 5) + h * (NF_MC_THREADS / 32);
+            w[l][h] = (oo < O && k < I) ? p.v[l][oo * I + k] : 0.f;
+        }
     }
     float gk = 0.f, bk = 0.f, ga = 0.f, be = 0.f;
     if (tid < NF_MC_NL * 32) {
@@ -154,7 +164,10 @@ __device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, 
     }
     if (tid < NF_MC_NB * 32) { ga = p.gamma[tid >> 5][k]; be = p.beta[tid >> 5][k]; }
 #pragma unroll
-    for (int l = 0; l < NF_MC_NL; ++l) sm[NF_MC_W + l * 32 * NF_FP_ST + oo * NF_FP_ST + k] = w[l];
+    for (int l = 0; l < NF_MC_NL; ++l)
+#pragma unroll
+        for (int h = 0; h < RPT; ++h)
+            sm[NF_MC_W + l * 32 * NF_FP_ST + ((tid >> 5) + h * (NF_MC_THREADS / 32)) * NF_FP_ST + k] = w[l][h];
     if (tid < NF_MC_NL * 32) sm[NF_MC_B + tid] = bk;
     if (tid < NF_MC_NB * 32) { sm[NF_MC_GA + tid] = ga; sm[NF_MC_BE + tid] = be; }
     __syncthreads();
@@ -216,7 +229,7 @@ __device__ __forceinline__ void nf_mc_batchnorm_train(float* sm, int j, const fl
     }
     if (j == 1) NF_MC_T(40);
     nf_mc_publish(sm, slots, j, (unsigned)(j + 1));
-    const float* tot = nf_mc_collect(sm, slots, j, (unsigned)(j + 1));
+    const float* tot = nf_mc_collect(sm, NF_MC_GATHER(1), slots, j, (unsigned)(j + 1));
     if (j == 1) NF_MC_T(41);
     if (threadIdx.x < 32) {
         const int k = threadIdx.x;
@@ -328,8 +341,8 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
 }
 
 static inline size_t nf_mc_lds_bytes(int tiles_per_wave) {
-    static_assert(NF_MC_WAVES * 16 * NF_FP_ST >= NF_MLP_MAX_BLOCKS * 64, "exchange buffer aliases the first tiles");
-    return (size_t)(NF_MC_TILES + NF_MC_WAVES * tiles_per_wave * 16 * NF_FP_ST) * sizeof(float);
+    const size_t tiles = (size_t)NF_MC_WAVES * tiles_per_wave * 16 * NF_FP_ST;
+    return (NF_MC_TILES + tiles + (NF_MC_GATHER_IN_SCRATCH ? 0 : (size_t)NF_MLP_MAX_BLOCKS * 64)) * sizeof(float);
 }
 
 extern "C" int nf_mlp_chain_fwd(const float* x, const void* const* params, float* out, float* save_stats, float* ws_zero,
@@ -365,8 +378,10 @@ extern "C" int nf_mlp_chain_fwd(const float* x, const void* const* params, float
 struct NfMlpG { float* v[NF_MC_NL]; float* g[NF_MC_NL]; float* b[NF_MC_NL]; float* gamma[NF_MC_NB]; float* beta[NF_MC_NB]; };
 
 #define NF_MC_SLAB_Q 1056                                // 32 x 32 weight-gradient partial + 32 bias partial
-#define NF_MC_SLAB_L (4 * NF_MC_SLAB_Q)                  // four row quarters
+#define NF_MC_SLAB_L (NF_MC_NKQ * NF_MC_SLAB_Q)          // one partial per 64-row group
 #define NF_MC_SLAB (NF_MC_NL * NF_MC_SLAB_L)
+static_assert(NF_MC_WAVES % 4 == 0 && NF_MLP_MAX_BLOCKS * NF_MLP_ROWS_PER_BLOCK == NF_MLP_MAX_ROWS, "geometry in include/nfhip.h");
+static_assert(NF_MC_NB * NF_MLP_MAX_BLOCKS * 64 * 2 + 64 == NF_MLP_WS_FLOATS, "exchange workspace size in include/nfhip.h");
 static_assert(NF_MC_SLAB * NF_MLP_MAX_BLOCKS == NF_MLP_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
 
 // this wave's share of g_Weff[L] and g_bias[L]: output block (wid & 1, (wid >> 1) & 1) over the rows of waves 4 (wid >> 2) .. + 3
@@ -477,7 +492,7 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
     if (L == 4) NF_MC_T(82);
     nf_mc_wgrad_job<L>(sm, slab, lane, wid);                                 // runs while the partial sums travel
     if (L == 4) NF_MC_T(83);
-    const float* tot = nf_mc_collect(sm, slots, NF_MC_NB - 1 - J, (unsigned)(NF_MC_NB - J));
+    const float* tot = nf_mc_collect(sm, NF_MC_GATHER(3), slots, NF_MC_NB - 1 - J, (unsigned)(NF_MC_NB - J));
     if (L == 4) NF_MC_T(84);
     if (threadIdx.x < 64) sm[NF_MC_GB + J * 64 + threadIdx.x] = tot[threadIdx.x];
     float mg[8], mgx[8];
@@ -571,14 +586,20 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         constexpr int HW = NF_MC_THREADS / 32;                       // half waves per workgroup
         constexpr int NU1 = (NF_MC_NL * 33 + HW - 1) / HW;           // units per half wave when there is one workgroup
         float pre[NU1];
-        if (G_ == 1) {                                               // all of this half wave's partials in flight at once
+        if (G_ <= 2) {                                               // all of this half wave's partials in flight at once
 #pragma unroll
             for (int k = 0; k < NU1; ++k) {
-                const int u = (threadIdx.x >> 5) + k * HW;
+                const int u = blockIdx.x * HW + (threadIdx.x >> 5) + k * G_ * HW;
                 const int uu = u < NF_MC_NL * 33 ? u : 0;
                 const int l = uu / 33, i = uu - l * 33;
                 const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
-                pre[k] = (base[0] + base[NF_MC_SLAB_Q]) + (base[2 * NF_MC_SLAB_Q] + base[3 * NF_MC_SLAB_Q]);
+                float t4 = 0.f;
+#pragma unroll
+                for (int q = 0; q < NF_MC_NKQ; ++q) {
+                    t4 += base[q * NF_MC_SLAB_Q];
+                    if (G_ == 2) t4 += base[NF_MC_SLAB + q * NF_MC_SLAB_Q];
+                }
+                pre[k] = t4;
             }
         }
         int kk = 0;
@@ -587,22 +608,24 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
             const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
             if (i < 32 && i >= I) continue;                          // half-wave uniform
             float tsum = 0.f;
-            if (G_ == 1) {
+            if (G_ <= 2) {
 #pragma unroll
                 for (int k = 0; k < NU1; ++k) tsum = k == kk ? pre[k] : tsum;
             } else {
                 const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
-                for (int b0 = 0; b0 < G_; b0 += 8) {                 // 32 independent loads in flight: one latency per trip
-                    float v[8][4];
+                for (int b0 = 0; b0 < G_; b0 += 8) {                 // 8 NKQ independent loads in flight: one latency per trip
+                    float v[8][NF_MC_NKQ];
 #pragma unroll
                     for (int q8 = 0; q8 < 8; ++q8) {
                         const int b = b0 + q8 < G_ ? b0 + q8 : G_ - 1;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q8][q] = base[(size_t)b * NF_MC_SLAB + q * NF_MC_SLAB_Q];
+                        for (int q = 0; q < NF_MC_NKQ; ++q) v[q8][q] = base[(size_t)b * NF_MC_SLAB + q * NF_MC_SLAB_Q];
                     }
 #pragma unroll
                     for (int q8 = 0; q8 < 8; ++q8)
-                        if (b0 + q8 < G_) tsum += (v[q8][0] + v[q8][1]) + (v[q8][2] + v[q8][3]);
+#pragma unroll
+                        for (int q = 0; q < NF_MC_NKQ; ++q)
+                            if (b0 + q8 < G_) tsum += v[q8][q];
                 }
             }
             if (i == 32) {
