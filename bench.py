@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 Timed region: inputs already resident in HBM; barrier + synchronize on both sides; max over ranks.
 """
 import argparse
+import ctypes
 import importlib
 import json
 import math
@@ -98,18 +99,83 @@ def graph_time_us(fn, dev, per_graph=50, replays=10):
 
 def dominant_kernel_roofline(pkg, cfg, B, dev):
     """roofline of the kernel that dominates the timed region (rocprofv3 summaries under profiles/):
-      c1 / c2 / c5 -> k_linear_bn_bwd, the backward of one fused 32x32 linear + BatchNorm layer of the conditioner
-                       (MLP of the affine coupling; MADE pair of MAF: two nets per launch);
-      c3           -> k_mixlog_rows_fwd (the conditioner there is still framework code);
-      c4           -> k_affine_slab_fwd (first-resolution checkerboard step; convolutions are MIOpen's).
-    achieved = algorithmic bytes per launch / average launch duration at the workload's shape,
-    measured live with HIP events around hipGraph replays of that launch on the launch stream."""
+      c1 / c2 -> k_mlp_chain_bwd, the one-launch backward of the whole MLP conditioner (six 32-wide linears, five
+                 BatchNorms; csrc/mlp_chain.hip) -- fp32 MFMA work, bound by the five grid-wide BatchNorm exchanges;
+      c5      -> k_linear_bn_bwd, the backward of one fused 32x32 linear + BatchNorm layer of the MADE pair (two nets
+                 per launch);
+      c3      -> k_flowpp_cond_bwd, the one-launch backward of the gated-attention conditioner (fp32 MFMA);
+      c4      -> k_affine_slab_fwd (first-resolution checkerboard step; convolutions are MIOpen's).
+    achieved = algorithmic bytes or flops per launch / average launch duration at the workload's
+    shape, measured live with HIP events around hipGraph replays of that launch on the launch stream."""
     N, NF = pkg._native, pkg.functional
     F = importlib.import_module(PKG + '.fused')
     dims = cfg['dims']
     g = torch.Generator(device='cpu').manual_seed(7)
     extra = {}
-    if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:
+    MFMA_F32_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+    if cfg['kind'] in ('glow', 'realnvp') and len(dims) == 1 and B <= N.header_constant('NF_MLP_MAX_ROWS'):
+        cond = importlib.import_module(PKG + '.conditioners')
+        i0 = dims[0] // 2
+        mlp = cond.MLP(i0, 2 * (dims[0] - i0)).to(dev).train()
+        ts = F._mlp_tensors(mlp)
+        x = torch.randn(B, i0, generator=g).to(dev)
+        gout = torch.randn(B, 2 * (dims[0] - i0), generator=g).to(dev)
+        with torch.no_grad():
+            _, save = F.mlp_chain_forward_nograd(mlp, x, True)
+        gx = torch.empty_like(x)
+        learn = list(ts[:18]) + [t for j in range(5) for t in ts[18 + 5 * j:18 + 5 * j + 2]]
+        dst = [torch.zeros_like(t) for t in learn]
+        tab, gtab = F._ptr_table([t.detach() for t in ts]), F._ptr_table(dst)
+        slabs = F._mlp_slabs(dev)
+        nws = N.header_constant('NF_MLP_WS_FLOATS')
+        wss = torch.zeros(64, nws, device=dev)                  # a fresh zero workspace per launch inside the timing graph
+        it = [0]
+
+        def fn():
+            ws = wss[it[0] % 64]
+            it[0] += 1
+            N.call('nf_mlp_chain_bwd', x.data_ptr(), ctypes.addressof(tab), save.data_ptr(), gout.data_ptr(), gx.data_ptr(),
+                   ctypes.addressof(gtab), 1, ws.data_ptr(), slabs.data_ptr(), B, i0, gout.shape[1], 1, 1.0e-5, 1.0e-5,
+                   N.stream())
+        us = graph_time_us(fn, dev, per_graph=50, replays=1)     # 50 launches = 50 distinct zero workspaces, one replay
+        flop = 17 * 2 * 32 * 32 * B                              # 5 recomputed + 6 data-gradient + 6 weight-gradient 32x32 products
+        tf = flop / (us * 1e-6) / 1e12
+        return {'bound': 'mfma', 'kernel': 'k_mlp_chain_bwd (whole MLP conditioner, one launch)', 'achieved': round(tf, 3),
+                'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': None,
+                'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (2 * i0 + gout.shape[1]) * 4),
+                'us_per_launch': round(us, 3),
+                'note': 'neither MFMA- nor HBM-bound at this batch: five grid-wide BatchNorm exchanges (~2.3 us each) + '
+                        'a grid barrier serialise the launch (DESIGN.md section 2; tools/probes/mlp_chain_prof.py)'}
+    if cfg['kind'] == 'flowpp' and len(dims) == 1:
+        K = cfg['mixtures']
+        layer = pkg.MixLogAttnCoupling(dims, n_mixtures=K).to(dev)
+        ts, F_ = F._flowpp_tensors(layer.net)
+        I0 = ts[0].shape[1]
+        O = ts[13].shape[0]
+        x = torch.randn(B, I0, generator=g).to(dev)
+        gout = torch.randn(B, O, generator=g).to(dev)
+        gx = torch.empty_like(x)
+        dst = [torch.zeros_like(t) for t in ts]
+        d = [t.data_ptr() for t in dst]
+        d[7] += 4 * 2 * F_ * 32
+        d[8] += 4 * 2 * F_
+        wsb = F.flowpp_bwd_workspace(dev)
+        args = F._flowpp_fwd_args(ts, F_)
+
+        def fn():
+            N.call('nf_flowpp_cond_bwd', x.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), B, I0, O,
+                   N.stream())
+        us = graph_time_us(fn, dev, per_graph=20, replays=5) * 1.0
+        mac = (2048 + 1024 + 2048) + 2 * (O * 32 + 2048 + 1024 + 2048) + 32 * I0      # recompute + data + weight gradients
+        flop = 2 * mac * B
+        tf = flop / (us * 1e-6) / 1e12
+        return {'bound': 'mfma', 'kernel': 'k_flowpp_cond_bwd + k_flowpp_cond_finalize (gated-attention conditioner)',
+                'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
+                'traffic': None, 'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (2 * I0 + O) * 4),
+                'us_per_launch': round(us, 3),
+                'note': 'fp32-input MFMA (exact fp32, 1/16 of the bf16 rate); the rest is transcendental VALU work and the '
+                        'LDS transposes of the weight-gradient operands (DESIGN.md section 3)'}
+    if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:              # multi-launch linear + BatchNorm chain
         nets = 2 if cfg['kind'] == 'maf' else 1
         T = lambda *sh: torch.randn(*sh, generator=g).to(dev)          # noqa: E731
         descs, keep = [], []
