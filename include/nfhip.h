@@ -349,10 +349,29 @@ int nf_mlp_chain_fwd(const float* x, const void* const* params, float* out, floa
  * g_x (N, I0) written, nullable.  ws_zero as above (a fresh zero region per call); slabs: NF_MLP_BWD_SLAB_FLOATS floats of
  * scratch (contents irrelevant, re-usable by the next call on the stream).                                            */
 #define NF_MLP_N_GRAD_PTRS 28
-#define NF_MLP_BWD_SLAB_FLOATS (128 * 6 * 2 * 1056)
+#define NF_MLP_BWD_SLAB_FLOATS (128 * 7 * 2 * 1056)
 int nf_mlp_chain_bwd(const float* x, const void* const* params, const float* save_stats, const float* g_out, float* g_x,
                      void* const* grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int I0, int O_out,
                      int training, float bn_eps, float wn_eps, nf_stream_t stream);
+
+/* ---- one whole Glow flow step on vector data in one persistent launch per direction --------------------------------
+ * dims = (D,), D = 2 or 4: ActNorm (modules.py:246-250) -> invertible 1x1 with the PLU weight assembled in-kernel
+ * (modules.py:470-482) -> affine coupling (coupling.py:104-113, 1-D split squeeze.py:68-69) whose conditioner is the MLP
+ * of nf_mlp_chain_*.  Replaces glow head + conditioner + coupling launches (3 forward, 4 backward) for N <= NF_MLP_MAX_ROWS.
+ * head: NF_GLOW_HEAD_PTRS device pointers on the HOST: actnorm log_scale (D), bias (D); P, L, U, L_mask, U_mask (D, D);
+ *       sign_s, log_s (D); the coupling's s_log_scale, s_bias (1).   y (N, D) written; ld (N) += log-det of the step.
+ * backward: g_z (N, D) written; g_ld (N) nullable (the step adds to ld, so d/d ld passes through unchanged and also
+ * feeds log_scale, log_s and the coupling scale); head_grads: NF_GLOW_HEAD_GRAD_PTRS pointers: g_log_scale, g_bias, g_L,
+ * g_U, g_log_s, g_s_log_scale, g_s_bias; mlp_grads / accumulate / ws_zero / slabs as in nf_mlp_chain_bwd.          */
+#define NF_GLOW_HEAD_PTRS 11
+#define NF_GLOW_HEAD_GRAD_PTRS 7
+int nf_glow_step_vec_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* mlp_params,
+                         float* save_stats, float* ws_zero, int64_t N, int D, int odd, int training, float bn_eps,
+                         float bn_momentum, float wn_eps, nf_stream_t stream);
+int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                         const void* const* mlp_params, const float* save_stats, void* const* head_grads,
+                         void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
+                         int training, float bn_eps, float wn_eps, nf_stream_t stream);
 
 /* ---- Flow++ conditioner for density data, whole network in one launch  coupling.py:142-149, modules.py:500-578 ---------
  * out = Linear5(LN2(GatedAttn1(LN1(GatedLinear(Linear0(x))))))  for x (N, I0 <= 4), hidden width 32, O <= 64 outputs;

@@ -53,6 +53,20 @@ static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
     }
 }
 
+// ---- the fused vector Glow step (ActNorm -> invertible 1x1 -> affine coupling around this MLP), dims = (D,), D = 2 or 4 ----
+struct NfGlowV {
+    const float* z; float* y; float* ld;                                     // forward: input, output, log-det (in place +=)
+    const float* g_y; const float* g_ld; float* g_z;                         // backward
+    const float *ls, *bs, *P, *L, *U, *Lm, *Um, *sign_s, *log_s, *a, *c;     // ActNorm, PLU factors, coupling scale / shift
+    float *g_ls, *g_bs, *g_L, *g_U, *g_log_s, *g_a, *g_c;
+    int D, odd;
+};
+static inline void nf_glow_unpack(const void* const* t, NfGlowV& h) {
+    h.ls = (const float*)t[0]; h.bs = (const float*)t[1]; h.P = (const float*)t[2]; h.L = (const float*)t[3];
+    h.U = (const float*)t[4]; h.Lm = (const float*)t[5]; h.Um = (const float*)t[6]; h.sign_s = (const float*)t[7];
+    h.log_s = (const float*)t[8]; h.a = (const float*)t[9]; h.c = (const float*)t[10];
+}
+
 // LDS (floats)
 #define NF_MC_W 0                                         // [6][32 * 36] weight_v, zero padded
 #define NF_MC_WS (NF_MC_W + NF_MC_NL * 32 * NF_FP_ST)     // [6][32] weight-norm column scales g_k / (||v[:, k]|| + eps)
@@ -65,7 +79,8 @@ static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
 #define NF_MC_RED (NF_MC_VAR + NF_MC_NB * 32)             // [16][64] cross-wave reduction
 #define NF_MC_GB (NF_MC_RED + NF_MC_WAVES * 64)           // [5][64] backward: grid totals sum_g | sum_gx per BatchNorm (= g_beta | g_gamma)
 #define NF_MC_TOT (NF_MC_GB + NF_MC_NB * 64)              // [2][64] grid totals of the exchange, double buffered by round parity
-#define NF_MC_TILES (NF_MC_TOT + 2 * 64)                  // per-wave 16 x 36 tiles: scratch | (backward) G | activation
+#define NF_MC_HEAD (NF_MC_TOT + 2 * 64)                   // fused Glow step: W (4 x 4), exp(log_scale) [4], bias [4], dld, a, c | L' | U' | P
+#define NF_MC_TILES (NF_MC_HEAD + 32 + 48)                  // per-wave 16 x 36 tiles: scratch | (backward) G | activation
 // the [blocks][64] gather buffer of the exchange aliases the scratch tiles when it fits in them (they are idle while it is
 // live), else it follows the last tile
 #define NF_MC_GATHER_IN_SCRATCH (NF_MLP_MAX_BLOCKS * 64 <= NF_MC_WAVES * 16 * NF_FP_ST)
@@ -257,6 +272,72 @@ __device__ __forceinline__ void nf_mc_batchnorm_consts(float* sm, int j, float m
     sm[NF_MC_BNC + (4 * j + 3) * 32 + k] = invstd;
 }
 
+// W = P L' U' (flows/modules.py:470-476), exp(log_scale), bias, the per-sample log-det of the head and the coupling's
+// scale / shift scalars -> sm[NF_MC_HEAD ..]; threads 0..15 one W entry each (D <= 4: a few dozen FMAs)
+__device__ __forceinline__ void nf_glow_head_consts(float* sm, const NfGlowV& h) {
+    const int t = threadIdx.x, D = h.D;
+    if (t < 16) {
+        const int r = t >> 2, c = t & 3;
+        float w = 0.f;
+        if (r < D && c < D) {
+            for (int k = 0; k < D; ++k) {                             // W[r][c] = sum_k P[r][k] (L' U')[k][c]
+                float tk = 0.f;
+                for (int m = 0; m < D; ++m) {
+                    const float lp = h.L[k * D + m] * h.Lm[k * D + m] + (k == m ? 1.f : 0.f);
+                    const float up = h.U[m * D + c] * h.Um[m * D + c] + (m == c ? h.sign_s[m] * expf(h.log_s[m]) : 0.f);
+                    tk = fmaf(lp, up, tk);
+                }
+                w = fmaf(h.P[r * D + k], tk, w);
+            }
+        }
+        sm[NF_MC_HEAD + t] = w;
+    } else if (t < 20) {
+        const int c = t - 16;
+        sm[NF_MC_HEAD + 16 + c] = c < D ? expf(h.ls[c]) : 1.f;
+        sm[NF_MC_HEAD + 20 + c] = c < D ? h.bs[c] : 0.f;
+    } else if (t == 20) {
+        float dld = 0.f;
+        for (int c = 0; c < D; ++c) dld += h.log_s[c] - h.ls[c];      // modules.py:249, :480
+        sm[NF_MC_HEAD + 24] = dld;
+        sm[NF_MC_HEAD + 25] = h.a[0];
+        sm[NF_MC_HEAD + 26] = h.c[0];
+    } else if (t >= 32 && t < 48) {                                   // the backward's PLU chain rule reads these
+        const int r = (t - 32) >> 2, c = (t - 32) & 3;
+        const bool ok = r < D && c < D;
+        sm[NF_MC_HEAD + 32 + (t - 32)] = ok ? h.L[r * D + c] * h.Lm[r * D + c] + (r == c ? 1.f : 0.f) : 0.f;
+        sm[NF_MC_HEAD + 48 + (t - 32)] = ok ? h.U[r * D + c] * h.Um[r * D + c] + (r == c ? h.sign_s[r] * expf(h.log_s[r]) : 0.f) : 0.f;
+        sm[NF_MC_HEAD + 64 + (t - 32)] = ok ? h.P[r * D + c] : 0.f;
+    }
+}
+// zn = (z - bias) / exp(log_scale);  hh = W zn        (every lane of the row's four does this: D <= 4)
+__device__ __forceinline__ void nf_glow_head_row(const float* sm, const float (&zr)[4], float (&zn)[4], float (&hh)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) zn[c] = (zr[c] - sm[NF_MC_HEAD + 20 + c]) / sm[NF_MC_HEAD + 16 + c];      // modules.py:246
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = fmaf(sm[NF_MC_HEAD + 4 * r + c], zn[c], acc);                     // modules.py:477
+        hh[r] = acc;
+    }
+}
+// the conditioner input in R: feature e < D / 2 is element e of the conditioning half (squeeze.py:68-69: interleaved)
+__device__ __forceinline__ void nf_glow_cond_input(const float (&hh)[4], int D, int odd, float (&xa)[8], int g) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa[j] = 0.f;
+    if (g == 0) {
+        xa[0] = odd ? hh[0] : hh[1];
+        if (D == 4) xa[1] = odd ? hh[2] : hh[3];
+    }
+}
+__device__ __forceinline__ void nf_glow_load_row(const float* z, int64_t row, bool rv, int D, float (&zr)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float v = z[(rv ? row : 0) * D + (c < D ? c : 0)];
+        zr[c] = (rv && c < D) ? v : 0.f;
+    }
+}
+
 __device__ __forceinline__ void nf_mc_load_x(const float* x, int64_t row, bool rv, int I0, float (&xa)[8], int g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -266,21 +347,29 @@ __device__ __forceinline__ void nf_mc_load_x(const float* x, int64_t row, bool r
     }
 }
 
+template <bool GLOW>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __restrict__ x, NfMlpP p, float* __restrict__ out,
                                                                  float* save, float* stats, int64_t N, int I0, int O_out,
-                                                                 int training, float eps, float mom, float wn_eps) {
+                                                                 int training, float eps, float mom, float wn_eps, NfGlowV h) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     NF_MC_T(0);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
     const bool rv = row < N;
-    float xa[8], rm_old = 0.f, rv_old = 0.f;              // issued before the staging: one memory latency for everything
-    nf_mc_load_x(x, row, rv, I0, xa, g);
+    float xa[8], zr[4], hh[4], rm_old = 0.f, rv_old = 0.f;   // issued before the staging: one memory latency for everything
+    if (GLOW) nf_glow_load_row(h.z, row, rv, h.D, zr);
+    else nf_mc_load_x(x, row, rv, I0, xa, g);
     if (training && blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
         rm_old = p.rmean[threadIdx.x >> 5][threadIdx.x & 31];
         rv_old = p.rvar[threadIdx.x >> 5][threadIdx.x & 31];
     }
+    if (GLOW) nf_glow_head_consts(sm, h);                 // made visible by the barriers inside the staging
     nf_mc_stage(p, sm, I0, O_out, wn_eps);
+    if (GLOW) {
+        float zn[4];
+        nf_glow_head_row(sm, zr, zn, hh);
+        nf_glow_cond_input(hh, h.D, h.odd, xa, g);
+    }
     NF_MC_T(1);
     unsigned long long* slots = (unsigned long long*)stats;
     if (!training) {
@@ -330,7 +419,27 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
         }
     }
     nf_fp_ldvec(sm + NF_MC_B + (NF_MC_NL - 1) * 32, g, bias);
-    if (rv) {
+    if (GLOW) {                                           // the affine coupling itself, coupling.py:104-113 (lane g = 0 has t | s_raw)
+        if (rv && g == 0) {
+            const int D = h.D, nh = D >> 1, sel0 = h.odd, sel1 = 1 ^ h.odd;
+            const float ca = sm[NF_MC_HEAD + 25], cc = sm[NF_MC_HEAD + 26];
+            float o4[4], dld = sm[NF_MC_HEAD + 24];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o4[j] = dv[j] + bias[j];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (e < nh) {
+                    const float sv = tanhf(e == 0 ? o4[nh] : o4[nh + 1]) * ca + cc;
+                    const float t = e == 0 ? o4[0] : o4[1];
+                    const float h0 = sel0 ? hh[2 * e + 1] : hh[2 * e], h1 = sel0 ? hh[2 * e] : hh[2 * e + 1];
+                    h.y[row * D + 2 * e + sel0] = h0 * expf(sv) + t;
+                    h.y[row * D + 2 * e + sel1] = h1;
+                    dld += sv;
+                }
+            }
+            h.ld[row] += dld;
+        }
+    } else if (rv) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * (j >> 2) + 4 * g + (j & 3);
@@ -356,12 +465,12 @@ extern "C" int nf_mlp_chain_fwd(const float* x, const void* const* params, float
     const size_t lds = nf_mc_lds_bytes(1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_chain_fwd, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, out, save_stats, ws_zero,
-                       N, I0, O_out, training, bn_eps, bn_momentum, wn_eps);
+    hipLaunchKernelGGL(k_mlp_chain_fwd<false>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, out, save_stats,
+                       ws_zero, N, I0, O_out, training, bn_eps, bn_momentum, wn_eps, NfGlowV{});
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -379,7 +488,8 @@ struct NfMlpG { float* v[NF_MC_NL]; float* g[NF_MC_NL]; float* b[NF_MC_NL]; floa
 
 #define NF_MC_SLAB_Q 1056                                // 32 x 32 weight-gradient partial + 32 bias partial
 #define NF_MC_SLAB_L (NF_MC_NKQ * NF_MC_SLAB_Q)          // one partial per 64-row group
-#define NF_MC_SLAB (NF_MC_NL * NF_MC_SLAB_L)
+#define NF_MC_NLS (NF_MC_NL + 1)                         // + one product for the fused Glow step's scalar gradients
+#define NF_MC_SLAB (NF_MC_NLS * NF_MC_SLAB_L)
 static_assert(NF_MC_WAVES % 4 == 0 && NF_MLP_MAX_BLOCKS * NF_MLP_ROWS_PER_BLOCK == NF_MLP_MAX_ROWS, "geometry in include/nfhip.h");
 static_assert(NF_MC_NB * NF_MLP_MAX_BLOCKS * 64 * 2 + 64 == NF_MLP_WS_FLOATS, "exchange workspace size in include/nfhip.h");
 static_assert(NF_MC_SLAB * NF_MLP_MAX_BLOCKS == NF_MLP_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
@@ -413,7 +523,7 @@ __device__ __forceinline__ void nf_mc_wgrad_job(const float* sm, float* slab, in
 template <int L>
 __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8], const float (&a)[NF_MC_NB][8], float (&G)[8],
                                                 float (&Gs)[8], float* slab, unsigned long long* slots, float* g_x, int64_t row,
-                                                bool rv, int64_t N, int I0, int training, int lane, int wid) {
+                                                bool rv, int64_t N, int I0, int training, int lane, int wid) {   // L == 0: G <- g_x
     const int c16 = lane & 15, g = lane >> 4;
     float* TS = sm + NF_MC_TILES + wid * 16 * NF_FP_ST;
     float* TG = sm + NF_MC_TILES + (NF_MC_WAVES + wid) * 16 * NF_FP_ST;
@@ -453,6 +563,8 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
         }
         __syncthreads();
         nf_mc_wgrad_job<L>(sm, slab, lane, wid);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) G[k] = t[k];
         return;
     }
     constexpr int J = L > 0 ? L - 1 : 0;                  // the BatchNorm between a_J and linear L
@@ -509,23 +621,33 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
     }
 }
 
+template <bool GLOW>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __restrict__ x, NfMlpP p, const float* __restrict__ save,
                                                                  const float* __restrict__ g_out, float* __restrict__ g_x, NfMlpG gr,
                                                                  int accumulate, float* ws, float* __restrict__ slabs, int64_t N,
-                                                                 int I0, int O_out, int training, float eps, float wn_eps) {
+                                                                 int I0, int O_out, int training, float eps, float wn_eps, NfGlowV h) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     NF_MC_T(64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
     const bool rv = row < N;
     float xa[8], a[NF_MC_NB][8], G[8], Gs[8];
-    nf_mc_load_x(x, row, rv, I0, xa, g);                  // both loads are in flight while the weights are staged
+    float zr[4], gy[4], gld = 0.f;                        // fused Glow step: this row of z and of the incoming gradients
+    if (GLOW) {
+        nf_glow_load_row(h.z, row, rv, h.D, zr);
+        nf_glow_load_row(h.g_y, row, rv, h.D, gy);
+        if (h.g_ld != nullptr && rv) gld = h.g_ld[row];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 16 * (j >> 2) + 4 * g + (j & 3);
-        const float v = g_out[(rv ? row : 0) * O_out + (k < O_out ? k : 0)];
-        G[j] = (rv && k < O_out) ? v : 0.f;
-        Gs[j] = 0.f;
+        for (int j = 0; j < 8; ++j) Gs[j] = 0.f;
+    } else {
+        nf_mc_load_x(x, row, rv, I0, xa, g);              // both loads are in flight while the weights are staged
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * (j >> 2) + 4 * g + (j & 3);
+            const float v = g_out[(rv ? row : 0) * O_out + (k < O_out ? k : 0)];
+            G[j] = (rv && k < O_out) ? v : 0.f;
+            Gs[j] = 0.f;
+        }
     }
     float bn_mean = 0.f, bn_invstd = 0.f;
     if (threadIdx.x < NF_MC_NB * 32) {
@@ -533,10 +655,16 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         bn_mean = training ? save[(2 * j + 0) * 32 + k] : p.rmean[j][k];
         bn_invstd = training ? save[(2 * j + 1) * 32 + k] : 1.f / sqrtf(p.rvar[j][k] + eps);
     }
+    if (GLOW) nf_glow_head_consts(sm, h);
     nf_mc_stage(p, sm, I0, O_out, wn_eps);
     NF_MC_T(65);
     if (threadIdx.x < NF_MC_NB * 32) nf_mc_batchnorm_consts(sm, threadIdx.x >> 5, bn_mean, bn_invstd);
     __syncthreads();
+    float zn[4], hh[4];
+    if (GLOW) {
+        nf_glow_head_row(sm, zr, zn, hh);
+        nf_glow_cond_input(hh, h.D, h.odd, xa, g);
+    }
     unsigned long long* slots = (unsigned long long*)ws;
     unsigned* counter = (unsigned*)(ws + NF_MC_NB * NF_MLP_MAX_BLOCKS * 64 * 2);
     float* slab = slabs + (size_t)blockIdx.x * NF_MC_SLAB;
@@ -560,6 +688,36 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
             for (int k = 0; k < 8; ++k) a[l][k] = dv[k] + bias[k] + ((l & 1) == 0 ? a[l - 2][k] : 0.f);
         }
     }
+    float gsv[2] = {0.f, 0.f}, gsvth[2] = {0.f, 0.f}, Gh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (GLOW) {   // conditioner output (t | s_raw) once more, then the affine coupling's backward (coupling.py:104-113)
+        float av[8], dv[8], bias[8], o4[4];
+        nf_mc_activate(sm, NF_MC_NB - 1, NF_MC_NL - 1, a[NF_MC_NB - 1], av, g);
+        nf_mc_linear(sm, NF_MC_NL - 1, av, dv, c16, g);
+        nf_fp_ldvec(sm + NF_MC_B + (NF_MC_NL - 1) * 32, g, bias);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = __shfl(dv[j] + bias[j], c16, NF_WAVE);      // features 0..3 live in the g = 0 lane
+        const int D = h.D, nh = D >> 1, sel0 = h.odd;
+        const float ca = sm[NF_MC_HEAD + 25], cc = sm[NF_MC_HEAD + 26];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) G[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e < nh) {
+                const float th = tanhf(e == 0 ? o4[nh] : o4[nh + 1]);
+                const float ev = expf(th * ca + cc);
+                const float h0 = sel0 ? hh[2 * e + 1] : hh[2 * e];
+                const float gy0 = sel0 ? gy[2 * e + 1] : gy[2 * e], gy1 = sel0 ? gy[2 * e] : gy[2 * e + 1];
+                gsv[e] = gy0 * h0 * ev + gld;                                  // ld += s: the log-det gradient enters here
+                gsvth[e] = gsv[e] * th;
+                const float gsraw = gsv[e] * ca * (1.f - th * th);
+                if (sel0) { Gh[2 * e + 1] = gy0 * ev; Gh[2 * e] = gy1; } else { Gh[2 * e] = gy0 * ev; Gh[2 * e + 1] = gy1; }
+                if (g == 0 && rv) {                                            // R: feature e = g_t, feature nh + e = g_s_raw
+                    if (e == 0) { G[0] = gy0; if (nh == 1) G[1] = gsraw; else G[2] = gsraw; }
+                    else { G[1] = gy0; G[3] = gsraw; }
+                }
+            }
+        }
+    }
     NF_MC_T(66);
     // ---- backward -----------------------------------------------------------------------------------------------
     nf_mc_bwd_layer<5>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
@@ -573,6 +731,44 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
     nf_mc_bwd_layer<1>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
     NF_MC_T(71);
     nf_mc_bwd_layer<0>(sm, xa, a, G, Gs, slab, slots, g_x, row, rv, N, I0, training, lane, wid);
+    if (GLOW) {   // ActNorm + 1x1 backward per row; their parameter gradients are one more 32 x 32 product over the rows
+        const int D = h.D, sel0 = h.odd;
+        const float gz0 = __shfl(G[0], c16, NF_WAVE), gz1 = __shfl(G[1], c16, NF_WAVE);   // g_x of the conditioner (lane g = 0)
+        if (sel0) { Gh[0] += gz0; if (D == 4) Gh[2] += gz1; } else { Gh[1] += gz0; if (D == 4) Gh[3] += gz1; }
+        float gzn[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = fmaf(sm[NF_MC_HEAD + 4 * r + c], Gh[r], acc);
+            gzn[c] = rv ? acc : 0.f;
+        }
+        if (g == 0 && rv) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < D) h.g_z[row * D + c] = gzn[c] / sm[NF_MC_HEAD + 16 + c];
+        }
+        float u8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (rv) {
+            if (g == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { u8[c] = Gh[c]; v8[c] = c < D ? zn[c] : 0.f; }
+            } else if (g == 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) u8[c] = gzn[c];
+                v8[0] = 1.f;
+            } else if (g == 2) {
+                u8[0] = gsv[0]; u8[1] = gsv[1]; u8[2] = gsvth[0]; u8[3] = gsvth[1];
+            } else {
+                u8[0] = gld;
+            }
+        }
+        __syncthreads();                                  // every wave is done with the tiles of linear 0
+        nf_fp_store_rows(u8, sm + NF_MC_TILES + (NF_MC_WAVES + wid) * 16 * NF_FP_ST, c16, g);
+        nf_fp_store_rows(v8, sm + NF_MC_TILES + (2 * NF_MC_WAVES + wid) * 16 * NF_FP_ST, c16, g);
+        __syncthreads();
+        nf_mc_wgrad_job<NF_MC_NL>(sm, slab, lane, wid);
+    }
     NF_MC_T(72);
 
     // ---- slabs -> parameter gradients: workgroup l (mod grid) owns linear l, workgroup 0 the BatchNorm affines ------------
@@ -603,7 +799,80 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
             }
         }
         int kk = 0;
-        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33; u += G_ * HW, ++kk) {
+        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33 + (GLOW ? 1 : 0); u += G_ * HW, ++kk) {
+            if (GLOW && u == NF_MC_NL * 33) {                        // ActNorm, PLU and coupling-scalar gradients (one half wave)
+                float* hs = sm + NF_MC_TILES + (threadIdx.x >> 5) * 96;     // [16][5] sums, private to this half wave
+                const float* base = slabs + (size_t)NF_MC_NL * NF_MC_SLAB_L + o;
+                float m5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int b0 = 0; b0 < G_; b0 += 4) {                 // 20 NKQ independent loads in flight per trip
+                    float v[4][NF_MC_NKQ][5];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int b = b0 + q4 < G_ ? b0 + q4 : G_ - 1;
+#pragma unroll
+                        for (int q = 0; q < NF_MC_NKQ; ++q)
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) v[q4][q][i] = base[(size_t)b * NF_MC_SLAB + q * NF_MC_SLAB_Q + i * 32];
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                        for (int q = 0; q < NF_MC_NKQ; ++q)
+#pragma unroll
+                            for (int i = 0; i < 5; ++i)
+                                if (b0 + q4 < G_) m5[i] += v[q4][q][i];
+                }
+                if (o < 16) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) hs[o * 5 + i] = m5[i];   // M[o][i] = sum_rows U[row][o] V[row][i]
+                }
+                nf_fp_wsync();
+                if (o == 0) {
+                    const int D = h.D;
+                    const float sum_gld = hs[12 * 5 + 4];
+                    float ga = hs[10 * 5 + 4], gc = hs[8 * 5 + 4];
+                    if (D == 4) { ga += hs[11 * 5 + 4]; gc += hs[9 * 5 + 4]; }
+                    h.g_a[0] = (accumulate ? h.g_a[0] : 0.f) + ga;                       // d/d s_log_scale: sum g_s tanh(s_raw)
+                    h.g_c[0] = (accumulate ? h.g_c[0] : 0.f) + gc;                       // d/d s_bias
+                    const float* Lp = sm + NF_MC_HEAD + 32;          // [4][4] each, staged at kernel start
+                    const float* Up = sm + NF_MC_HEAD + 48;
+                    const float* Pm = sm + NF_MC_HEAD + 64;
+                    float A[4][4];
+                    for (int r = 0; r < D; ++r) {
+                        const float es = sm[NF_MC_HEAD + 16 + r];
+                        h.g_bs[r] = (accumulate ? h.g_bs[r] : 0.f) - hs[(4 + r) * 5 + 4] / es;          // modules.py:246
+                        h.g_ls[r] = (accumulate ? h.g_ls[r] : 0.f) - hs[(4 + r) * 5 + r] - sum_gld;     // pixels = 1
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {                // A = P^T g_W, g_W[k][c] = M[k][c]
+                            float acc = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc = fmaf(Pm[k * 4 + r], (k < D && c < D) ? hs[k * 5 + c] : 0.f, acc);
+                            A[r][c] = acc;
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float gl = 0.f, gu = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                gl = fmaf(A[r][k], Up[c * 4 + k], gl);   // (A U'^T)[r][c]
+                                gu = fmaf(Lp[k * 4 + r], A[k][c], gu);   // (L'^T A)[r][c]
+                            }
+                            if (r < D && c < D) {
+                                const int e = r * D + c;
+                                h.g_L[e] = (accumulate ? h.g_L[e] : 0.f) + gl * h.Lm[e];
+                                h.g_U[e] = (accumulate ? h.g_U[e] : 0.f) + gu * h.Um[e];
+                                if (r == c)
+                                    h.g_log_s[r] = (accumulate ? h.g_log_s[r] : 0.f) + gu * (Up[r * 4 + r] - h.U[e] * h.Um[e]) + sum_gld;
+                            }
+                        }
+                }
+                continue;
+            }
             const int l = u / 33, i = u - l * 33;                    // i == 32: the bias
             const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
             if (i < 32 && i >= I) continue;                          // half-wave uniform
@@ -673,12 +942,75 @@ extern "C" int nf_mlp_chain_bwd(const float* x, const void* const* params, const
     const size_t lds = nf_mc_lds_bytes(3);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_chain_bwd, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, save_stats, g_out, g_x, g,
-                       accumulate, ws_zero, slabs, N, I0, O_out, training, bn_eps, wn_eps);
+    hipLaunchKernelGGL(k_mlp_chain_bwd<false>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, save_stats, g_out,
+                       g_x, g, accumulate, ws_zero, slabs, N, I0, O_out, training, bn_eps, wn_eps, NfGlowV{});
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the fused vector Glow step: ActNorm -> invertible 1x1 -> affine coupling (MLP conditioner) in one launch per direction
+// ---------------------------------------------------------------------------------------------------------------
+static int nf_glow_args_ok(int64_t N, int D) { return (D == 2 || D == 4) && N <= NF_MLP_MAX_ROWS; }
+
+extern "C" int nf_glow_step_vec_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* mlp_params,
+                                    float* save_stats, float* ws_zero, int64_t N, int D, int odd, int training, float bn_eps,
+                                    float bn_momentum, float wn_eps, nf_stream_t stream) {
+    if (z == nullptr || y == nullptr || ld == nullptr || head == nullptr || mlp_params == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMlpP p;
+    nf_mlp_unpack(mlp_params, p);
+    NfGlowV h{};
+    nf_glow_unpack(head, h);
+    h.z = z; h.y = y; h.ld = ld; h.D = D; h.odd = odd ? 1 : 0;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_chain_fwd<true>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+                       (float*)nullptr, save_stats, ws_zero, N, D / 2, D, training, bn_eps, bn_momentum, wn_eps, h);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                                    const void* const* mlp_params, const float* save_stats, void* const* head_grads,
+                                    void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
+                                    int training, float bn_eps, float wn_eps, nf_stream_t stream) {
+    if (z == nullptr || g_y == nullptr || g_z == nullptr || head == nullptr || mlp_params == nullptr || head_grads == nullptr ||
+        mlp_grads == nullptr || ws_zero == nullptr || slabs == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMlpP p;
+    nf_mlp_unpack(mlp_params, p);
+    NfMlpG g;
+    for (int l = 0; l < NF_MC_NL; ++l) { g.v[l] = (float*)mlp_grads[3 * l]; g.g[l] = (float*)mlp_grads[3 * l + 1]; g.b[l] = (float*)mlp_grads[3 * l + 2]; }
+    for (int j = 0; j < NF_MC_NB; ++j) { g.gamma[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j]; g.beta[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j + 1]; }
+    NfGlowV h{};
+    nf_glow_unpack(head, h);
+    h.z = z; h.g_y = g_y; h.g_ld = g_ld; h.g_z = g_z; h.D = D; h.odd = odd ? 1 : 0;
+    h.g_ls = (float*)head_grads[0]; h.g_bs = (float*)head_grads[1]; h.g_L = (float*)head_grads[2]; h.g_U = (float*)head_grads[3];
+    h.g_log_s = (float*)head_grads[4]; h.g_a = (float*)head_grads[5]; h.g_c = (float*)head_grads[6];
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_chain_bwd<true>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+                       save_stats, (const float*)nullptr, (float*)nullptr, g, accumulate, ws_zero, slabs, N, D / 2, D, training, bn_eps,
+                       wn_eps, h);
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -559,3 +559,75 @@ def flowpp_cond_forward_nograd(net, x):
            c1b.data_ptr() + 4 * 2 * F_, N.ptr(c2w.detach()), N.ptr(c2b.detach()), N.ptr(l2g.detach()), N.ptr(l2b.detach()),
            N.ptr(W5.detach()), N.ptr(b5.detach()), N.ptr(out), Nrows, I0, O, N.stream())
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one whole Glow flow step on vector data (ActNorm -> invertible 1x1 -> affine coupling with the MLP conditioner)
+# ----------------------------------------------------------------------------------------------------------------------
+def glow_step_vec_usable(z, mlp):
+    """dims = (D,) with D in (2, 4) and a batch the persistent kernels hold (csrc/mlp_chain.hip, GLOW variant)."""
+    return (z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[1] in (2, 4) and mlp.fused
+            and len(mlp.mid_block) == 2 and 0 < z.shape[0] <= N.header_constant('NF_MLP_MAX_ROWS'))
+
+
+class _GlowStepVec(torch.autograd.Function):
+    """(y, ld) = coupling(invconv(actnorm(z))) in one launch, its autograd in one launch.
+    head: log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, s_log_scale, s_bias; then the 43 MLP tensors."""
+
+    @staticmethod
+    def forward(ctx, z, ld, odd, training, *tensors):
+        head, mlp = tensors[:11], tensors[11:]
+        z = z.contiguous()
+        Nrows, D = z.shape
+        y = torch.empty_like(z)
+        save = torch.empty(5, 2, H, dtype=torch.float32, device=z.device)
+        ws = WS.zeros(N.header_constant('NF_MLP_WS_FLOATS'), z.device)
+        htab, mtab = _ptr_table(head), _ptr_table(mlp)
+        N.call('nf_glow_step_vec_fwd', N.ptr(z), N.ptr(y), N.ptr(ld), ctypes.addressof(htab), ctypes.addressof(mtab),
+               N.ptr(save), N.ptr(ws), Nrows, D, int(odd), int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        ctx.save_for_backward(z, save, *tensors)
+        ctx.meta = (int(odd), bool(training))
+        from .functional import _sinks
+        nl, nb = 6, 5
+        learn_h = [head[0], head[1], head[3], head[4], head[8], head[9], head[10]]
+        learn_m = list(mlp[:3 * nl]) + [t for j in range(nb) for t in mlp[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+        ctx.sinks = _sinks(*(learn_h + learn_m))
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        nl, nb = 6, 5
+        odd, training = ctx.meta
+        z, save, *tensors = ctx.saved_tensors
+        head, mlp = tensors[:11], tensors[11:]
+        Nrows, D = z.shape
+        dev = z.device
+        g_y = g_y.contiguous()
+        g_ld = None if g_ld is None else g_ld.contiguous()
+        learn_h = [head[0], head[1], head[3], head[4], head[8], head[9], head[10]]
+        learn_m = list(mlp[:3 * nl]) + [t for j in range(nb) for t in mlp[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+        direct = ctx.sinks is not None
+        dst = ctx.sinks if direct else [torch.empty_like(t) for t in learn_h + learn_m]
+        g_z = torch.empty_like(z)
+        ws = WS.zeros(N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        htab, mtab = _ptr_table(head), _ptr_table(mlp)
+        hg, mg = _ptr_table(dst[:7]), _ptr_table(dst[7:])
+        N.call('nf_glow_step_vec_bwd', N.ptr(z), N.ptr(g_y), _p(g_ld), N.ptr(g_z), ctypes.addressof(htab), ctypes.addressof(mtab),
+               N.ptr(save), ctypes.addressof(hg), ctypes.addressof(mg), int(direct), N.ptr(ws), N.ptr(_mlp_slabs(dev)), Nrows, D,
+               odd, int(training), BN_EPS, WN_EPS, N.stream())
+        if direct:
+            return (g_z, g_ld, None, None) + (None, ) * len(tensors)
+        gh = [dst[0], dst[1], None, dst[2], dst[3], None, None, None, dst[4], dst[5], dst[6]]
+        gm = list(dst[7:7 + 3 * nl])
+        for j in range(nb):
+            gm += [dst[7 + 3 * nl + 2 * j], dst[7 + 3 * nl + 2 * j + 1], None, None, None]
+        return (g_z, g_ld, None, None) + tuple(gh) + tuple(gm)
+
+
+def glow_step_vec(z, ld, actnorm, conv, coupling):
+    """ActNorm ``actnorm`` -> InvertibleConv1x1 ``conv`` -> AffineCoupling ``coupling`` on (N, D) data, fused."""
+    from .functional import _owned_ld
+    head = [actnorm.log_scale, actnorm.bias, conv.P, conv.L, conv.U, conv.L_mask, conv.U_mask, conv.sign_s, conv.log_s,
+            coupling.s_log_scale, coupling.s_bias]
+    return _GlowStepVec.apply(z, _owned_ld(ld), int(coupling.odd), coupling.net.training, *(head + _mlp_tensors(coupling.net)))

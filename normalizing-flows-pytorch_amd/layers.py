@@ -78,9 +78,12 @@ class Compose(nn.Module):
                 if not a.initialized:
                     NF.actnorm_init_(z, a.log_scale, a.bias, a.eps)
                     a.initialized = True
-                h, z1c, log_df_dz = NF.glow_head(z, log_df_dz, a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask,
-                                                 c.sign_s, c.log_s, k.mode, k.odd)
-                z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
+                if k.mode == N.SPLIT_1D and isinstance(k.net, MLP) and FUSED.glow_step_vec_usable(z, k.net):
+                    z, log_df_dz = FUSED.glow_step_vec(z, log_df_dz, a, c, k)        # the whole step: one launch
+                else:
+                    h, z1c, log_df_dz = NF.glow_head(z, log_df_dz, a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask,
+                                                     c.U_mask, c.sign_s, c.log_s, k.mode, k.odd)
+                    z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
                 i += 3
             else:
                 z, log_df_dz = L[i](z, log_df_dz)

@@ -221,3 +221,77 @@ def test_mlp_chain_vs_modules(pkg, in_ch, out_ch, N, training, direct):
         pre_bn_bias = training and k.endswith('module.bias') and 'out_block' not in k
         tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(pr[k].grad)   # analytically-zero gradients: noise only
         G.assert_close(pf[k].grad, pr[k].grad, tol, what='grad ' + k)
+
+
+@pytest.mark.parametrize('direct', [False, True])
+@pytest.mark.parametrize('D,odd,N', [(2, False, 4096), (2, True, 300), (4, False, 1000), (4, True, 77), (2, False, 16384)])
+@pytest.mark.parametrize('training', [True, False])
+def test_glow_step_vec_vs_unfused(pkg, D, odd, N, training, direct):
+    """the one-launch Glow step (ActNorm -> 1x1 -> affine coupling + MLP) against the three-launch path it replaces:
+    output, log-det, input gradient and every parameter gradient (with a log-det gradient in play)."""
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    torch.manual_seed(D * 7 + int(odd))
+
+    def make():
+        torch.manual_seed(D * 7 + int(odd))
+        a, c, k = pkg.ActNorm((D, )), pkg.InvertibleConv1x1(D), pkg.AffineCoupling((D, ), odd=odd)
+        mods = torch.nn.ModuleList([a, c, k]).to(DEV)
+        with torch.no_grad():
+            a.log_scale.normal_(0, 0.2)
+            a.bias.normal_(0, 0.3)
+            k.s_log_scale.fill_(0.7)
+            k.s_bias.fill_(0.1)
+            for m in k.net.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.3)
+                    m.running_mean.normal_(0, 0.2)
+                    m.running_var.uniform_(0.5, 2.0)
+        a.initialized = True
+        mods.train(training)
+        return a, c, k, mods
+
+    a1, c1, k1, m1 = make()
+    a2, c2, k2, m2 = make()
+    g = torch.Generator().manual_seed(N + D)
+    z = (torch.randn(N, D, generator=g) * 0.8).to(DEV)
+    gy = torch.randn(N, D, generator=g).to(DEV)
+    wl = torch.randn(N, generator=g).to(DEV)
+    z1, z2 = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    ld0 = torch.randn(N, generator=g).to(DEV)
+    # reference: glow head + multi-launch conditioner + coupling kernel
+    h, zc, ld1 = NF.glow_head(z1, ld0.clone(), a1.log_scale, a1.bias, c1.P, c1.L, c1.U, c1.L_mask, c1.U_mask, c1.sign_s,
+                              c1.log_s, k1.mode, k1.odd)
+    y1, ld1 = NF.affine_coupling(h, fused.mlp_forward(k1.net, zc, chain=False), k1.s_log_scale, k1.s_bias, ld1, k1.mode,
+                                 k1.odd)
+    ((y1 * gy).sum() + (ld1 * wl).sum()).backward()
+    if direct:
+        for p in m2.parameters():
+            if p.requires_grad:
+                p.grad = torch.zeros_like(p)
+                p._nf_direct_grad = True
+    assert fused.glow_step_vec_usable(z2, k2.net)
+    y2, ld2 = fused.glow_step_vec(z2, ld0.clone(), a2, c2, k2)
+    G.assert_close(y2, y1, 2e-5, rtol=2e-5, what='y')
+    G.assert_close(ld2, ld1, 2e-5, rtol=2e-5, what='log-det')
+    ((y2 * gy).sum() + (ld2 * wl).sum()).backward()
+    # 16384 rows x 160 ReLU units: now and then ONE pre-activation sits within rounding of zero and the two paths (whose
+    # sums are ordered differently) mask it differently -- a legitimate discontinuity, not an error.  Tolerate two such rows.
+    big = N >= 16384
+    err = (z2.grad - z1.grad).abs().max(dim=1).values
+    bad = int((err > _grad_tol(z1.grad)).sum())
+    assert bad <= (2 if big else 0), 'grad z: %d rows beyond tolerance, max abs err %.3e' % (bad, float(err.max()))
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    for name, p in p1.items():
+        if not p.requires_grad:
+            continue
+        assert p2[name].grad is not None, name
+        pre_bn_bias = training and name.endswith('module.bias') and 'out_block' not in name
+        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(p.grad)
+        if big:
+            tol = max(tol, 1e-2 * float(p.grad.abs().max()))
+        G.assert_close(p2[name].grad, p.grad, tol, what='grad ' + name)
+    b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
+    for name in b1:
+        G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
