@@ -340,7 +340,7 @@ int nf_spectral_weights(const float* const* W_bar, float* const* u, float* const
 #define NF_MLP_ROWS_PER_BLOCK 128
 #define NF_MLP_MAX_BLOCKS 128
 #define NF_MLP_MAX_ROWS 16384
-#define NF_MLP_WS_FLOATS (5 * 128 * 64 * 2 + 64)
+#define NF_MLP_WS_FLOATS (6 * 128 * 64 * 2 + 64)
 int nf_mlp_chain_fwd(const float* x, const void* const* params, float* out, float* save_stats, float* ws_zero, int64_t N,
                      int I0, int O_out, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
 /* autograd of nf_mlp_chain_fwd, one launch (the forward is recomputed from x and save_stats; evaluation mode takes the

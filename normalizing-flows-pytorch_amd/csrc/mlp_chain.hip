@@ -157,7 +157,12 @@ __device__ __forceinline__ const float* nf_mc_collect(float* sm, int gather, uns
     return tot;
 }
 
-__device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, int O_out, float wn_eps) {
+struct NfGlowRaw;
+__device__ __forceinline__ void nf_glow_head_phase_a(float* sm, const NfGlowV& h, const NfGlowRaw& raw);
+__device__ __forceinline__ void nf_glow_head_phase_b(float* sm);
+
+__device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, int O_out, float wn_eps, const NfGlowV* head = nullptr,
+                                            const NfGlowRaw* raw = nullptr) {
     const int tid = threadIdx.x, k = tid & 31;
     constexpr int RPT = 32 * 32 / NF_MC_THREADS;           // rows of a 32 x 32 matrix per thread (1 or 2)
     float w[NF_MC_NL][RPT];
@@ -185,7 +190,9 @@ __device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, 
             sm[NF_MC_W + l * 32 * NF_FP_ST + ((tid >> 5) + h * (NF_MC_THREADS / 32)) * NF_FP_ST + k] = w[l][h];
     if (tid < NF_MC_NL * 32) sm[NF_MC_B + tid] = bk;
     if (tid < NF_MC_NB * 32) { sm[NF_MC_GA + tid] = ga; sm[NF_MC_BE + tid] = be; }
+    if (head != nullptr) nf_glow_head_phase_a(sm, *head, *raw);
     __syncthreads();
+    if (head != nullptr) nf_glow_head_phase_b(sm);
     if (tid < NF_MC_NL * 32) {                            // weight_norm.py:40: norm over the output index, per input column
         const float* W = sm + NF_MC_W + (tid >> 5) * 32 * NF_FP_ST;
         float ss = 0.f;
@@ -272,41 +279,62 @@ __device__ __forceinline__ void nf_mc_batchnorm_consts(float* sm, int j, float m
     sm[NF_MC_BNC + (4 * j + 3) * 32 + k] = invstd;
 }
 
-// W = P L' U' (flows/modules.py:470-476), exp(log_scale), bias, the per-sample log-det of the head and the coupling's
-// scale / shift scalars -> sm[NF_MC_HEAD ..]; threads 0..15 one W entry each (D <= 4: a few dozen FMAs)
-__device__ __forceinline__ void nf_glow_head_consts(float* sm, const NfGlowV& h) {
+// Head constants of the fused Glow step -> sm[NF_MC_HEAD ..], in two phases around the staging's first barrier so that every
+// global load of a thread is issued up front (one memory latency):
+//   phase A (threads 0..15: one entry each of L' = L o Lm + I, U' = U o Um + diag(sign_s exp(log_s)), P; threads 16..20: the
+//            ActNorm scale / bias, the per-sample log-det of the head (modules.py:249, :480), the coupling scalars)
+//   phase B (threads 0..15): W = P L' U' from LDS (modules.py:470-476)
+struct NfGlowRaw { float v[8]; };                        // what a thread of phase A needs from global memory
+__device__ __forceinline__ void nf_glow_head_load(const NfGlowV& h, NfGlowRaw& raw) {   // issued with the kernel's first loads
+    const int t = threadIdx.x, D = h.D;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw.v[k] = 0.f;
+    if (t < 16) {
+        const int r = t >> 2, c = t & 3;
+        const bool ok = r < D && c < D;
+        const int e = ok ? r * D + c : 0;
+        raw.v[0] = h.L[e]; raw.v[1] = h.Lm[e]; raw.v[2] = h.U[e]; raw.v[3] = h.Um[e]; raw.v[4] = h.P[e];
+        raw.v[5] = h.sign_s[r < D ? r : 0]; raw.v[6] = h.log_s[r < D ? r : 0];
+    } else if (t < 20) {
+        const int c = t - 16;
+        raw.v[0] = h.ls[c < D ? c : 0]; raw.v[1] = h.bs[c < D ? c : 0];
+    } else if (t == 20) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) raw.v[c] = c < D ? h.log_s[c] - h.ls[c] : 0.f;
+        raw.v[4] = h.a[0]; raw.v[5] = h.c[0];
+    }
+}
+__device__ __forceinline__ void nf_glow_head_phase_a(float* sm, const NfGlowV& h, const NfGlowRaw& raw) {
     const int t = threadIdx.x, D = h.D;
     if (t < 16) {
         const int r = t >> 2, c = t & 3;
-        float w = 0.f;
-        if (r < D && c < D) {
-            for (int k = 0; k < D; ++k) {                             // W[r][c] = sum_k P[r][k] (L' U')[k][c]
-                float tk = 0.f;
-                for (int m = 0; m < D; ++m) {
-                    const float lp = h.L[k * D + m] * h.Lm[k * D + m] + (k == m ? 1.f : 0.f);
-                    const float up = h.U[m * D + c] * h.Um[m * D + c] + (m == c ? h.sign_s[m] * expf(h.log_s[m]) : 0.f);
-                    tk = fmaf(lp, up, tk);
-                }
-                w = fmaf(h.P[r * D + k], tk, w);
-            }
-        }
-        sm[NF_MC_HEAD + t] = w;
+        const bool ok = r < D && c < D;
+        sm[NF_MC_HEAD + 32 + t] = ok ? raw.v[0] * raw.v[1] + (r == c ? 1.f : 0.f) : 0.f;
+        sm[NF_MC_HEAD + 48 + t] = ok ? raw.v[2] * raw.v[3] + (r == c ? raw.v[5] * expf(raw.v[6]) : 0.f) : 0.f;
+        sm[NF_MC_HEAD + 64 + t] = ok ? raw.v[4] : 0.f;
     } else if (t < 20) {
         const int c = t - 16;
-        sm[NF_MC_HEAD + 16 + c] = c < D ? expf(h.ls[c]) : 1.f;
-        sm[NF_MC_HEAD + 20 + c] = c < D ? h.bs[c] : 0.f;
+        sm[NF_MC_HEAD + 16 + c] = c < D ? expf(raw.v[0]) : 1.f;
+        sm[NF_MC_HEAD + 20 + c] = c < D ? raw.v[1] : 0.f;
     } else if (t == 20) {
-        float dld = 0.f;
-        for (int c = 0; c < D; ++c) dld += h.log_s[c] - h.ls[c];      // modules.py:249, :480
-        sm[NF_MC_HEAD + 24] = dld;
-        sm[NF_MC_HEAD + 25] = h.a[0];
-        sm[NF_MC_HEAD + 26] = h.c[0];
-    } else if (t >= 32 && t < 48) {                                   // the backward's PLU chain rule reads these
-        const int r = (t - 32) >> 2, c = (t - 32) & 3;
-        const bool ok = r < D && c < D;
-        sm[NF_MC_HEAD + 32 + (t - 32)] = ok ? h.L[r * D + c] * h.Lm[r * D + c] + (r == c ? 1.f : 0.f) : 0.f;
-        sm[NF_MC_HEAD + 48 + (t - 32)] = ok ? h.U[r * D + c] * h.Um[r * D + c] + (r == c ? h.sign_s[r] * expf(h.log_s[r]) : 0.f) : 0.f;
-        sm[NF_MC_HEAD + 64 + (t - 32)] = ok ? h.P[r * D + c] : 0.f;
+        sm[NF_MC_HEAD + 24] = (raw.v[0] + raw.v[1]) + (raw.v[2] + raw.v[3]);           // modules.py:249, :480
+        sm[NF_MC_HEAD + 25] = raw.v[4];
+        sm[NF_MC_HEAD + 26] = raw.v[5];
+    }
+}
+__device__ __forceinline__ void nf_glow_head_phase_b(float* sm) {
+    const int t = threadIdx.x;
+    if (t < 16) {
+        const int r = t >> 2, c = t & 3;
+        float w = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float tk = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) tk = fmaf(sm[NF_MC_HEAD + 32 + 4 * k + m], sm[NF_MC_HEAD + 48 + 4 * m + c], tk);
+            w = fmaf(sm[NF_MC_HEAD + 64 + 4 * r + k], tk, w);
+        }
+        sm[NF_MC_HEAD + t] = w;
     }
 }
 // zn = (z - bias) / exp(log_scale);  hh = W zn        (every lane of the row's four does this: D <= 4)
@@ -356,15 +384,19 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
     const bool rv = row < N;
-    float xa[8], zr[4], hh[4], rm_old = 0.f, rv_old = 0.f;   // issued before the staging: one memory latency for everything
-    if (GLOW) nf_glow_load_row(h.z, row, rv, h.D, zr);
+    float xa[8], zr[4], hh[4], rm_old = 0.f, rv_old = 0.f, ld_in = 0.f;   // issued before the staging: one memory latency
+    NfGlowRaw head_raw;
+    if (GLOW) {
+        nf_glow_head_load(h, head_raw);
+        nf_glow_load_row(h.z, row, rv, h.D, zr);
+        if (rv && g == 0) ld_in = h.ld[row];
+    }
     else nf_mc_load_x(x, row, rv, I0, xa, g);
     if (training && blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
         rm_old = p.rmean[threadIdx.x >> 5][threadIdx.x & 31];
         rv_old = p.rvar[threadIdx.x >> 5][threadIdx.x & 31];
     }
-    if (GLOW) nf_glow_head_consts(sm, h);                 // made visible by the barriers inside the staging
-    nf_mc_stage(p, sm, I0, O_out, wn_eps);
+    nf_mc_stage(p, sm, I0, O_out, wn_eps, GLOW ? &h : nullptr, GLOW ? &head_raw : nullptr);
     if (GLOW) {
         float zn[4];
         nf_glow_head_row(sm, zr, zn, hh);
@@ -437,7 +469,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
                     dld += sv;
                 }
             }
-            h.ld[row] += dld;
+            h.ld[row] = ld_in + dld;
         }
     } else if (rv) {
 #pragma unroll
@@ -491,7 +523,7 @@ struct NfMlpG { float* v[NF_MC_NL]; float* g[NF_MC_NL]; float* b[NF_MC_NL]; floa
 #define NF_MC_NLS (NF_MC_NL + 1)                         // + one product for the fused Glow step's scalar gradients
 #define NF_MC_SLAB (NF_MC_NLS * NF_MC_SLAB_L)
 static_assert(NF_MC_WAVES % 4 == 0 && NF_MLP_MAX_BLOCKS * NF_MLP_ROWS_PER_BLOCK == NF_MLP_MAX_ROWS, "geometry in include/nfhip.h");
-static_assert(NF_MC_NB * NF_MLP_MAX_BLOCKS * 64 * 2 + 64 == NF_MLP_WS_FLOATS, "exchange workspace size in include/nfhip.h");
+static_assert((NF_MC_NB + 1) * NF_MLP_MAX_BLOCKS * 64 * 2 + 64 == NF_MLP_WS_FLOATS, "exchange workspace size in include/nfhip.h");
 static_assert(NF_MC_SLAB * NF_MLP_MAX_BLOCKS == NF_MLP_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
 
 // this wave's share of g_Weff[L] and g_bias[L]: output block (wid & 1, (wid >> 1) & 1) over the rows of waves 4 (wid >> 2) .. + 3
@@ -518,6 +550,38 @@ __device__ __forceinline__ void nf_mc_wgrad_job(const float* sm, float* slab, in
     *(float4*)(sl + (16 * ib + c16) * 32 + 16 * ob + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
     bs = nf_fp_rowsum(bs);
     if (ib == 0 && g == 0) sl[1024 + 16 * ob + c16] = bs;
+}
+
+// fused Glow step: the 29 sums over the rows that the ActNorm / PLU / coupling-scalar gradients need, as entries of the
+// product U^T V of two parked 16 x 32 tiles (U: G_h | g_zn | g_s, g_s tanh | g_ld;  V: zn | 1) -> red[wid][slot]:
+//   slots 0..15 g_W[r][c] = sum G_h[r] zn[c];  16..19 sum g_zn[c] zn[c];  20..23 sum g_zn[c];  24..25 sum g_s[e];
+//   26..27 sum g_s[e] tanh(s_raw[e]);  28 sum g_ld.       Waves 0, 4, .. (output block (0, 0)) own 64 rows each.
+__device__ __forceinline__ void nf_glow_head_product(float* sm, int lane, int wid) {
+    const int c16 = lane & 15, g = lane >> 4;
+    float* red = sm + NF_MC_RED + wid * 64;
+    red[lane] = 0.f;
+    if ((wid & 3) != 0) return;
+    nf_fp_wsync();
+    const int kq = wid >> 2;
+    f32x4 d = nf_fp_zero4();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* Gt = sm + NF_MC_TILES + (NF_MC_WAVES + 4 * kq + q) * 16 * NF_FP_ST + c16;
+        const float* At = sm + NF_MC_TILES + (2 * NF_MC_WAVES + 4 * kq + q) * 16 * NF_FP_ST + c16;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) d = __builtin_amdgcn_mfma_f32_16x16x4f32(Gt[(4 * s2 + g) * NF_FP_ST], At[(4 * s2 + g) * NF_FP_ST], d, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                // d[r] = M[o = 4 g + r][i = c16]
+        const int o = 4 * g + r, i = c16;
+        int slot = -1;
+        if (o < 4 && i < 4) slot = 4 * o + i;
+        else if (o < 8 && i == o - 4) slot = 16 + (o - 4);
+        else if (o < 8 && o >= 4 && i == 4) slot = 20 + (o - 4);
+        else if (o >= 8 && o < 12 && i == 4) slot = 24 + (o - 8);
+        else if (o == 12 && i == 4) slot = 28;
+        if (slot >= 0) red[slot] = d[r];
+    }
 }
 
 template <int L>
@@ -633,7 +697,9 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
     const bool rv = row < N;
     float xa[8], a[NF_MC_NB][8], G[8], Gs[8];
     float zr[4], gy[4], gld = 0.f;                        // fused Glow step: this row of z and of the incoming gradients
+    NfGlowRaw head_raw;
     if (GLOW) {
+        nf_glow_head_load(h, head_raw);
         nf_glow_load_row(h.z, row, rv, h.D, zr);
         nf_glow_load_row(h.g_y, row, rv, h.D, gy);
         if (h.g_ld != nullptr && rv) gld = h.g_ld[row];
@@ -655,8 +721,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         bn_mean = training ? save[(2 * j + 0) * 32 + k] : p.rmean[j][k];
         bn_invstd = training ? save[(2 * j + 1) * 32 + k] : 1.f / sqrtf(p.rvar[j][k] + eps);
     }
-    if (GLOW) nf_glow_head_consts(sm, h);
-    nf_mc_stage(p, sm, I0, O_out, wn_eps);
+    nf_mc_stage(p, sm, I0, O_out, wn_eps, GLOW ? &h : nullptr, GLOW ? &head_raw : nullptr);
     NF_MC_T(65);
     if (threadIdx.x < NF_MC_NB * 32) nf_mc_batchnorm_consts(sm, threadIdx.x >> 5, bn_mean, bn_invstd);
     __syncthreads();
@@ -666,7 +731,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         nf_glow_cond_input(hh, h.D, h.odd, xa, g);
     }
     unsigned long long* slots = (unsigned long long*)ws;
-    unsigned* counter = (unsigned*)(ws + NF_MC_NB * NF_MLP_MAX_BLOCKS * 64 * 2);
+    unsigned* counter = (unsigned*)(ws + (NF_MC_NB + 1) * NF_MLP_MAX_BLOCKS * 64 * 2);
     float* slab = slabs + (size_t)blockIdx.x * NF_MC_SLAB;
 
     // ---- forward, activations kept ------------------------------------------------------------------------------
@@ -767,12 +832,22 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         nf_fp_store_rows(u8, sm + NF_MC_TILES + (NF_MC_WAVES + wid) * 16 * NF_FP_ST, c16, g);
         nf_fp_store_rows(v8, sm + NF_MC_TILES + (2 * NF_MC_WAVES + wid) * 16 * NF_FP_ST, c16, g);
         __syncthreads();
-        nf_mc_wgrad_job<NF_MC_NL>(sm, slab, lane, wid);
+        nf_glow_head_product(sm, lane, wid);
     }
     NF_MC_T(72);
 
     // ---- slabs -> parameter gradients: workgroup l (mod grid) owns linear l, workgroup 0 the BatchNorm affines ------------
-    nf_grid_barrier(counter, gridDim.x);
+    const float* head_tot = nullptr;
+    if (GLOW) {   // one more exchange carries the head sums AND, fenced on both sides, is the grid barrier in front of the fold
+        __syncthreads();
+        if (threadIdx.x == 0) __threadfence();            // release: the slabs of every wave (cumulative through the barrier)
+        nf_mc_publish(sm, slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1));
+        head_tot = nf_mc_collect(sm, NF_MC_GATHER(3), slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1));
+        if (threadIdx.x == 0) __threadfence();            // acquire
+        __syncthreads();
+    } else {
+        nf_grid_barrier(counter, gridDim.x);
+    }
     NF_MC_T(73);
     // unit = one column (l, i) of a weight matrix or one bias vector, owned by a half wave (lane = output index o): sums the
     // partials (coalesced), reduces <g_Weff, v> and ||v||^2 over o by shuffles, applies the weight-norm backward.  No LDS.
@@ -799,80 +874,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
             }
         }
         int kk = 0;
-        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33 + (GLOW ? 1 : 0); u += G_ * HW, ++kk) {
-            if (GLOW && u == NF_MC_NL * 33) {                        // ActNorm, PLU and coupling-scalar gradients (one half wave)
-                float* hs = sm + NF_MC_TILES + (threadIdx.x >> 5) * 96;     // [16][5] sums, private to this half wave
-                const float* base = slabs + (size_t)NF_MC_NL * NF_MC_SLAB_L + o;
-                float m5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int b0 = 0; b0 < G_; b0 += 4) {                 // 20 NKQ independent loads in flight per trip
-                    float v[4][NF_MC_NKQ][5];
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int b = b0 + q4 < G_ ? b0 + q4 : G_ - 1;
-#pragma unroll
-                        for (int q = 0; q < NF_MC_NKQ; ++q)
-#pragma unroll
-                            for (int i = 0; i < 5; ++i) v[q4][q][i] = base[(size_t)b * NF_MC_SLAB + q * NF_MC_SLAB_Q + i * 32];
-                    }
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                        for (int q = 0; q < NF_MC_NKQ; ++q)
-#pragma unroll
-                            for (int i = 0; i < 5; ++i)
-                                if (b0 + q4 < G_) m5[i] += v[q4][q][i];
-                }
-                if (o < 16) {
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) hs[o * 5 + i] = m5[i];   // M[o][i] = sum_rows U[row][o] V[row][i]
-                }
-                nf_fp_wsync();
-                if (o == 0) {
-                    const int D = h.D;
-                    const float sum_gld = hs[12 * 5 + 4];
-                    float ga = hs[10 * 5 + 4], gc = hs[8 * 5 + 4];
-                    if (D == 4) { ga += hs[11 * 5 + 4]; gc += hs[9 * 5 + 4]; }
-                    h.g_a[0] = (accumulate ? h.g_a[0] : 0.f) + ga;                       // d/d s_log_scale: sum g_s tanh(s_raw)
-                    h.g_c[0] = (accumulate ? h.g_c[0] : 0.f) + gc;                       // d/d s_bias
-                    const float* Lp = sm + NF_MC_HEAD + 32;          // [4][4] each, staged at kernel start
-                    const float* Up = sm + NF_MC_HEAD + 48;
-                    const float* Pm = sm + NF_MC_HEAD + 64;
-                    float A[4][4];
-                    for (int r = 0; r < D; ++r) {
-                        const float es = sm[NF_MC_HEAD + 16 + r];
-                        h.g_bs[r] = (accumulate ? h.g_bs[r] : 0.f) - hs[(4 + r) * 5 + 4] / es;          // modules.py:246
-                        h.g_ls[r] = (accumulate ? h.g_ls[r] : 0.f) - hs[(4 + r) * 5 + r] - sum_gld;     // pixels = 1
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {                // A = P^T g_W, g_W[k][c] = M[k][c]
-                            float acc = 0.f;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) acc = fmaf(Pm[k * 4 + r], (k < D && c < D) ? hs[k * 5 + c] : 0.f, acc);
-                            A[r][c] = acc;
-                        }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            float gl = 0.f, gu = 0.f;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                gl = fmaf(A[r][k], Up[c * 4 + k], gl);   // (A U'^T)[r][c]
-                                gu = fmaf(Lp[k * 4 + r], A[k][c], gu);   // (L'^T A)[r][c]
-                            }
-                            if (r < D && c < D) {
-                                const int e = r * D + c;
-                                h.g_L[e] = (accumulate ? h.g_L[e] : 0.f) + gl * h.Lm[e];
-                                h.g_U[e] = (accumulate ? h.g_U[e] : 0.f) + gu * h.Um[e];
-                                if (r == c)
-                                    h.g_log_s[r] = (accumulate ? h.g_log_s[r] : 0.f) + gu * (Up[r * 4 + r] - h.U[e] * h.Um[e]) + sum_gld;
-                            }
-                        }
-                }
-                continue;
-            }
+        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33; u += G_ * HW, ++kk) {
             const int l = u / 33, i = u - l * 33;                    // i == 32: the bias
             const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
             if (i < 32 && i >= I) continue;                          // half-wave uniform
@@ -917,6 +919,48 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
             }
             if (o == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + dt / den;
         }
+    }
+    if (GLOW && blockIdx.x == gridDim.x - 1 && threadIdx.x == NF_MC_THREADS - 1) {   // ActNorm, PLU, coupling scalars
+        const float* hs = head_tot;
+        const int D = h.D;
+        const float sum_gld = hs[28];
+        h.g_a[0] = (accumulate ? h.g_a[0] : 0.f) + hs[26] + hs[27];                  // d/d s_log_scale: sum g_s tanh(s_raw)
+        h.g_c[0] = (accumulate ? h.g_c[0] : 0.f) + hs[24] + hs[25];                  // d/d s_bias
+        const float* Lp = sm + NF_MC_HEAD + 32;                  // [4][4] each, staged at kernel start
+        const float* Up = sm + NF_MC_HEAD + 48;
+        const float* Pm = sm + NF_MC_HEAD + 64;
+        float A[4][4];
+        for (int r = 0; r < D; ++r) {
+            const float es = sm[NF_MC_HEAD + 16 + r];
+            h.g_bs[r] = (accumulate ? h.g_bs[r] : 0.f) - hs[20 + r] / es;            // modules.py:246
+            h.g_ls[r] = (accumulate ? h.g_ls[r] : 0.f) - hs[16 + r] - sum_gld;       // pixels = 1
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                        // A = P^T g_W
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = fmaf(Pm[k * 4 + r], hs[4 * k + c], acc);
+                A[r][c] = acc;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float gl = 0.f, gu = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gl = fmaf(A[r][k], Up[c * 4 + k], gl);       // (A U'^T)[r][c]
+                    gu = fmaf(Lp[k * 4 + r], A[k][c], gu);       // (L'^T A)[r][c]
+                }
+                if (r < D && c < D) {
+                    const int e = r * D + c;
+                    h.g_L[e] = (accumulate ? h.g_L[e] : 0.f) + gl * h.Lm[e];
+                    h.g_U[e] = (accumulate ? h.g_U[e] : 0.f) + gu * h.Um[e];
+                    if (r == c) h.g_log_s[r] = (accumulate ? h.g_log_s[r] : 0.f) + gu * Up[r * 4 + r] + sum_gld;
+                }
+            }
     }
     if (blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
         const int j = threadIdx.x >> 5, k = threadIdx.x & 31;

@@ -72,3 +72,37 @@ print('backward: stage %.2f | recompute %.2f | layers 5..0 %s | final barrier %.
     us(64, 65), us(65, 66), ' '.join('%.2f' % us(66 + i, 67 + i) for i in range(6)), us(72, 73), us(73, 74), us(64, 74)))
 print('          layer 4 detail: tiles %.2f | sync %.2f | wgrad job %.2f | dgrad + sums %.2f | exchange %.2f | BN bwd %.2f' % (
     us(67, 80), us(80, 81), us(81, 82), us(82, 83), us(83, 84), us(84, 68)))
+
+# ---- the fused vector Glow step (same kernels, GLOW variant) ------------------------------------------------------------
+a, c, k = pkg.ActNorm((2, )), pkg.InvertibleConv1x1(2), pkg.AffineCoupling((2, ))
+mods = torch.nn.ModuleList([a, c, k]).to(dev).train()
+head = [a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale, k.s_bias]
+mts = fused._mlp_tensors(k.net)
+htab, mtab = fused._ptr_table([t.detach() for t in head]), fused._ptr_table([t.detach() for t in mts])
+lh = [head[0], head[1], head[3], head[4], head[8], head[9], head[10]]
+lm = list(mts[:18]) + [t for j in range(5) for t in mts[18 + 5 * j:18 + 5 * j + 2]]
+dh, dm = [torch.empty_like(t) for t in lh], [torch.empty_like(t) for t in lm]
+hg, mg = fused._ptr_table(dh), fused._ptr_table(dm)
+z = torch.randn(n, 2, device=dev)
+y = torch.empty_like(z)
+ld = torch.zeros(n, device=dev)
+gy = torch.randn(n, 2, device=dev)
+gz = torch.empty_like(z)
+st = P(torch.cuda.current_stream().cuda_stream)
+for it in range(3):
+    ws = torch.zeros(N_.header_constant('NF_MLP_WS_FLOATS'), device=dev)
+    ws2 = torch.zeros(N_.header_constant('NF_MLP_WS_FLOATS'), device=dev)
+    torch.cuda.synchronize()
+    rc = lib.nf_glow_step_vec_fwd(P(z.data_ptr()), P(y.data_ptr()), P(ld.data_ptr()), htab, mtab, P(save.data_ptr()), P(ws.data_ptr()),
+                                  ctypes.c_int64(n), 2, 0, 1, F(1e-5), F(0.1), F(1e-5), st)
+    rc2 = lib.nf_glow_step_vec_bwd(P(z.data_ptr()), P(gy.data_ptr()), None, P(gz.data_ptr()), htab, mtab, P(save.data_ptr()), hg, mg, 0,
+                                   P(ws2.data_ptr()), P(slabs.data_ptr()), ctypes.c_int64(n), 2, 0, 1, F(1e-5), F(1e-5), st)
+    torch.cuda.synchronize()
+    assert rc == 0 and rc2 == 0, (rc, rc2)
+assert lib.nf_mlp_chain_prof_read(buf) == 0
+t = list(buf)
+print('--- fused Glow step ---')
+print('forward : stage %.2f | x + linear0 %.2f | layers %s | tail %.2f | total %.2f' % (
+    us(0, 1), us(1, 2), ' '.join('%.2f' % us(2 + i, 3 + i) for i in range(5)), us(7, 8), us(0, 8)))
+print('backward: stage %.2f | recompute %.2f | layers 5..0 %s | final barrier %.2f | fold %.2f | total %.2f' % (
+    us(64, 65), us(65, 66), ' '.join('%.2f' % us(66 + i, 67 + i) for i in range(6)), us(72, 73), us(73, 74), us(64, 74)))
