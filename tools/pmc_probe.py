@@ -26,7 +26,7 @@ def summarise(paths):
             a[1] += float(r['Counter_Value'])
     print('%-60s %-12s %-10s %8s %14s' % ('kernel', 'counter', 'grid', 'calls', 'avg value'))
     for (k, c, g), (n, v) in sorted(agg.items()):
-        if k.startswith('k_') or 'copy' in k.lower() or 'void k_' in k:
+        if k.startswith('k_') or 'copy' in k.lower() or 'void k_' in k or 'k_mlp' in k or 'k_flowpp' in k:
             print('%-60s %-12s %-10s %8d %14.2f' % (k, c, g, n, v / n))
 
 
@@ -64,6 +64,41 @@ def main():
         for _ in range(reps):
             N.call('nf_affine_coupling_fwd', z.data_ptr(), params.data_ptr(), params.data_ptr() + 4, 2, a.data_ptr(),
                    c.data_ptr(), yv.data_ptr(), ld.data_ptr(), 0, 0, 0, B, 2, 1, 1, N.stream())
+        torch.cuda.synchronize()
+    # the persistent MLP backward (dominant kernel of C1 / C2) at the bench shape, and the Flow++ conditioner backward (C3)
+    import ctypes
+    cond = importlib.import_module('normalizing-flows-pytorch_amd.conditioners')
+    for Nr, reps in ((4096, 20), ):
+        mlp = cond.MLP(1, 2).to(dev).train()
+        ts = F._mlp_tensors(mlp)
+        xin, gout = torch.randn(Nr, 1, device=dev), torch.randn(Nr, 2, device=dev)
+        with torch.no_grad():
+            _, save = F.mlp_chain_forward_nograd(mlp, xin, True)
+        gx = torch.empty_like(xin)
+        learn = list(ts[:18]) + [t for j in range(5) for t in ts[18 + 5 * j:18 + 5 * j + 2]]
+        dst = [torch.zeros_like(t) for t in learn]
+        tab, gtab = F._ptr_table([t.detach() for t in ts]), F._ptr_table(dst)
+        slabs = F._mlp_slabs(torch.device(dev, 0))
+        for _ in range(reps):
+            ws = torch.zeros(N.header_constant('NF_MLP_WS_FLOATS'), device=dev)
+            N.call('nf_mlp_chain_bwd', xin.data_ptr(), ctypes.addressof(tab), save.data_ptr(), gout.data_ptr(), gx.data_ptr(),
+                   ctypes.addressof(gtab), 1, ws.data_ptr(), slabs.data_ptr(), Nr, 1, 2, 1, 1.0e-5, 1.0e-5, N.stream())
+        torch.cuda.synchronize()
+    for Nr, reps in ((65536, 10), ):
+        layer = pkg.MixLogAttnCoupling((2, ), n_mixtures=8).to(dev)
+        ts, F_ = F._flowpp_tensors(layer.net)
+        O = ts[13].shape[0]
+        xin, gout = torch.randn(Nr, 1, device=dev), torch.randn(Nr, O, device=dev)
+        gx = torch.empty_like(xin)
+        dst = [torch.zeros_like(t) for t in ts]
+        d = [t.data_ptr() for t in dst]
+        d[7] += 4 * 2 * F_ * 32
+        d[8] += 4 * 2 * F_
+        wsb = F.flowpp_bwd_workspace(torch.device(dev, 0))
+        args = F._flowpp_fwd_args(ts, F_)
+        for _ in range(reps):
+            N.call('nf_flowpp_cond_bwd', xin.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), Nr, 1, O,
+                   N.stream())
         torch.cuda.synchronize()
 
 
