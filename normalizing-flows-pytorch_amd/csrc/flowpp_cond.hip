@@ -27,7 +27,7 @@
 #define NF_FP_FWD_WAVES 8
 #define NF_FP_BWD_WAVES 8
 #define NF_FP_MAX_BLOCKS 256   // backward grid cap = number of partial-sum slabs in the workspace
-#define NF_FP_WAVE_LDS (2 * 16 * NF_FP_ST + 3 * 512)   // per backward wave: two 16 x 32 tiles + three stashed vectors
+#define NF_FP_WAVE_LDS (2 * 3 * 16 * NF_FP_ST)   // per backward wave: two sets of {gradient-side, activation-side, spare} tiles
 #define NF_FP_LNEPS 1.0e-5f
 
 static_assert(NF_FP_FWD_WAVES * NF_WAVE == 512 && NF_FP_BWD_WAVES * NF_WAVE == 512, "nf_fpp_stage assumes 512 threads");
@@ -354,299 +354,307 @@ __device__ __forceinline__ void nf_fp_put(float* R, int idx, float v) {
     R[idx] = FIRST ? v : R[idx] + v;
 }
 
+// One output block (16 x 16) of a weight gradient over the rows of ALL the workgroup's waves:
+//   acc += sum_w sum_rows G_w[row][gcol + c16'] Act_w[row][acol + .]   (tiles of wave w at Gt + w * tstride, At + w * tstride)
+// returns this lane's share of the column sums of G (the bias gradient of outputs gcol ..)
+__device__ __forceinline__ float nf_fp_coop_block(const float* Gt, const float* At, int tstride, int gcol, int acol, f32x4& acc,
+                                                  int c16, int g) {
+    float bs = 0.f;
+#pragma unroll 2
+    for (int wv = 0; wv < NF_FP_BWD_WAVES; ++wv) {
+        const float* gp = Gt + wv * tstride + gcol + c16;
+        const float* ap = At + wv * tstride + acol + c16;
+        float ga[4], av[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { ga[s2] = gp[(4 * s2 + g) * NF_FP_ST]; av[s2] = ap[(4 * s2 + g) * NF_FP_ST]; }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            bs += ga[s2];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], av[s2], acc, 0, 0, 0);
+        }
+    }
+    return bs;
+}
+
+// Weight gradients are formed per workgroup: in each of five phases every wave parks the gradient-side and the
+// activation-side tile of its 16 rows in LDS, a barrier, then wave w owns ONE 16 x 16 output block of that matrix over the
+// rows of all eight waves (32 MFMAs), a barrier.  Five accumulators per wave instead of thirty: nothing spills (the first
+// version moved 286 MB of scratch per launch, profiles/r01_pmc_summary.txt), and the block results go to the slab as they are.
 template <int NB>
 __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(NfFppW w, NfFppG gr, float* __restrict__ slabs,
-                                                                               int64_t N, int I0, int O, int64_t tiles, int vec) {
+                                                                               int64_t N, int I0, int O, int64_t tiles, int iters,
+                                                                               int vec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const NfFppL L = nf_fpp_layout(NF_FP_BWD_WAVES);
     nf_fpp_stage(w, sm, L, I0, O, vec != 0);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
-    float* TG = sm + L.tiles + wid * NF_FP_WAVE_LDS;      // gradient-side tile (A fragment of the weight products)
-    float* TA = TG + 16 * NF_FP_ST;                       // activation-side tile (B fragment)
-    float* PK = TA + 16 * NF_FP_ST;                       // parked h0, u, xh1
+    const int lane0 = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int TSZ = 16 * NF_FP_ST;
+    // two sets of [waves] x {gradient-side tile (A fragments of the weight products), activation-side tile (B fragments),
+    // spare: second half of a 64-wide side, private scratch otherwise}.  Phases alternate between the sets, so ONE barrier per
+    // phase suffices: a set is overwritten two phases later, and every wave has passed the barrier in between only after it
+    // finished its share of the products that read it.
+    constexpr int SETSZ = 3 * NF_FP_BWD_WAVES * TSZ;
 
-    f32x4 aW5[NB][2], aW2[4][2], aWq[2][2], aWg[2][4], aW0[2][1];
-    float vb5[NB], vb2[4], vbq[2] = {0.f, 0.f}, vbg[2] = {0.f, 0.f}, vln2g[2] = {0.f, 0.f}, vln2b[2] = {0.f, 0.f},
-          vln1g[2] = {0.f, 0.f}, vln1b[2] = {0.f, 0.f}, vpos[2] = {0.f, 0.f}, vb0[2] = {0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < NB; ++a) { aW5[a][0] = nf_fp_zero4(); aW5[a][1] = nf_fp_zero4(); vb5[a] = 0.f; }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) { aW2[a][0] = nf_fp_zero4(); aW2[a][1] = nf_fp_zero4(); vb2[a] = 0.f; }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        aWq[a][0] = nf_fp_zero4(); aWq[a][1] = nf_fp_zero4(); aW0[a][0] = nf_fp_zero4();
-#pragma unroll
-        for (int b = 0; b < 4; ++b) aWg[a][b] = nf_fp_zero4();
-    }
+    f32x4 a5 = nf_fp_zero4(), a2 = nf_fp_zero4(), aq = nf_fp_zero4(), ag = nf_fp_zero4(), a0 = nf_fp_zero4();
+    float b5 = 0.f, b2 = 0.f, bq = 0.f, bg = 0.f, b0 = 0.f;
+    float vln2g[2] = {0.f, 0.f}, vln2b[2] = {0.f, 0.f}, vln1g[2] = {0.f, 0.f}, vln1b[2] = {0.f, 0.f}, vpos[2] = {0.f, 0.f};
 
-    for (int64_t t = (int64_t)blockIdx.x * NF_FP_BWD_WAVES + wid; t < tiles; t += (int64_t)gridDim.x * NF_FP_BWD_WAVES) {
-        const int64_t row0 = t * 16, row = row0 + c16;
+    for (int it = 0; it < iters; ++it) {                  // uniform trip count: the phases are workgroup barriers
+        // the lane index is laundered once per trip: otherwise ~100 loop-invariant LDS / global addresses derived from it are
+        // hoisted into registers for the whole loop and the kernel spills (seen: 256 VGPRs + 240 B scratch)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int c16 = lane & 15, g = lane >> 4;
+#define NF_FPP_SET(k)                                                                   \
+    float* TGs = sm + L.tiles + (((it + (k)) & 1) ? SETSZ : 0);                         \
+    float* TAs = TGs + NF_FP_BWD_WAVES * TSZ;                                           \
+    float* TXs = TAs + NF_FP_BWD_WAVES * TSZ;                                           \
+    float* TG = TGs + wid * TSZ;                                                        \
+    float* TA = TAs + wid * TSZ;                                                        \
+    float* TX = TXs + wid * TSZ;                                                        \
+    (void)TG; (void)TA; (void)TX; (void)TXs
+        const int64_t tile0 = ((int64_t)it * gridDim.x + blockIdx.x) * NF_FP_BWD_WAVES;
+        const int64_t row0 = (tile0 + wid) * 16, row = row0 + c16;
         const bool rv = row < N;
         float xin[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < I0 && rv) xin[i] = w.x[row * I0 + i];
-        float q[8], y2[8], a2[8], xh2[8], g_h3[8], rstd1;
-        {
-            NfFppFwd f;
-            nf_fpp_forward_tile(sm, L, xin, c16, g, f);
-            nf_fp_park(f.h0, PK, lane);
-            nf_fp_park(f.u, PK + 512, lane);
-            nf_fp_park(f.xh1, PK + 1024, lane);
-            rstd1 = f.rstd1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { q[j] = f.q[j]; y2[j] = f.y2[j]; a2[j] = f.a2[j]; xh2[j] = f.xh2[j]; }
+        NfFppFwd f;
+        nf_fpp_forward_tile(sm, L, xin, c16, g, f);
 
-            // ---- out = W5 h4 + b5 ------------------------------------------------------------------------------
-            float g_h4[8];
-            nf_fp_store_rows(f.h4, TA, c16, g);
-            {
-                float go[4 * NB];                                // g_out in R: features 16 b + 4 g + r of this lane's row
-                const float* gp = gr.g_out + (rv ? row : 0) * O; // unconditional (clamped) loads + select: no branches
+        // ---- phase 1: out = W5 h4 + b5 -----------------------------------------------------------------------------
+        float g_h4[8], g_h3[8];
+        {
+        NF_FPP_SET(0);
+        nf_fp_store_rows(f.h4, TA, c16, g);
+        {
+            float go[4 * NB];                                    // g_out in R: features 16 b + 4 g + r of this lane's row
+            const float* gp = gr.g_out + (rv ? row : 0) * O;     // unconditional (clamped) loads + select: no branches
 #pragma unroll
-                for (int j = 0; j < 4 * NB; ++j) {
-                    const int o = 16 * (j >> 2) + 4 * g + (j & 3);
-                    const float v = gp[o < O ? o : O - 1];
-                    go[j] = (rv && o < O) ? v : 0.f;
-                }
-                f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
-                nf_fp_gemm_d<NB>(sm + L.W5, NF_FP_ST, 0, go, acc, c16, g);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) g_h4[j] = acc[j >> 2][j & 3];
+            for (int j = 0; j < 4 * NB; ++j) {
+                const int o = 16 * (j >> 2) + 4 * g + (j & 3);
+                const float v = gp[o < O ? o : O - 1];
+                go[j] = (rv && o < O) ? v : 0.f;
             }
-            {   // weight gradient: A fragment straight from global (column walk of g_out = coalesced 64-byte rows)
-                float ga[NB][4], av[2][4];
+            f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
+            nf_fp_gemm_d<NB>(sm + L.W5, NF_FP_ST, 0, go, acc, c16, g);
 #pragma unroll
-                for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int64_t r2 = row0 + 4 * s + g;
-                        const int o = 16 * ob + c16;
-                        const float v = gr.g_out[(r2 < N ? r2 : N - 1) * O + (o < O ? o : O - 1)];
-                        ga[ob][s] = (r2 < N && o < O) ? v : 0.f;
-                    }
-                nf_fp_wsync();
-                nf_fp_load_cols<2>(TA, av, c16, g);
-                nf_fp_wgrad<NB, 2, NB, 2, 0, 0>(ga, av, aW5, vb5);
-                nf_fp_wsync();
-            }
-            // ---- LayerNorm 2 -----------------------------------------------------------------------------------
+            for (int j = 0; j < 8; ++j) g_h4[j] = acc[j >> 2][j & 3];
+        }
+        {   // LayerNorm 2 (its column sums use the private scratch tile)
             float tmp[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tmp[j] = g_h4[j] * xh2[j];
-            nf_fp_colsum(tmp, TG, vln2g, c16, g);
-            nf_fp_colsum(g_h4, TG, vln2b, c16, g);
-            nf_fp_ln_bwd(g_h4, xh2, sm + L.ln2g, f.rstd2, g_h3, g);
+            for (int j = 0; j < 8; ++j) tmp[j] = g_h4[j] * f.xh2[j];
+            nf_fp_colsum(tmp, TX, vln2g, c16, g);
+            nf_fp_colsum(g_h4, TX, vln2b, c16, g);
+            nf_fp_ln_bwd(g_h4, f.xh2, sm + L.ln2g, f.rstd2, g_h3, g);
         }
-        // ---- gate 2: h3 = h2 + y2 sigmoid(a2);  [y2, a2] = W2 q + b2 ------------------------------------------------
+        __syncthreads();
+        if (wid < 2 * NB) {   // owner of block (ob, ib) of g_W5: the G fragment comes straight from global (coalesced 64-byte rows)
+            const int ob = wid >> 1, ib = wid & 1;
+            const int o = 16 * ob + c16;
+#pragma unroll 2
+            for (int wv = 0; wv < NF_FP_BWD_WAVES; ++wv) {
+                const int64_t r0 = (tile0 + wv) * 16;
+                float ga[4], av[4];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int64_t r2 = r0 + 4 * s2 + g;
+                    const float v = gr.g_out[(r2 < N ? r2 : N - 1) * O + (o < O ? o : O - 1)];
+                    ga[s2] = (r2 < N && o < O) ? v : 0.f;
+                    av[s2] = TAs[wv * TSZ + (4 * s2 + g) * NF_FP_ST + 16 * ib + c16];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    b5 += ga[s2];
+                    a5 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], av[s2], a5, 0, 0, 0);
+                }
+            }
+        }
+        }
+        // ---- phase 2: gate 2: h3 = h2 + y2 sigmoid(a2);  [y2, a2] = W2 q + b2 ----------------------------------------------
         float g_q[8];
         {
+            NF_FPP_SET(1);
             float gcat[16];                                      // [g_y2 | g_a2]: the 64 outputs of conv2
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float s2 = nf_sigmoid(a2[j]);
+                const float s2 = nf_sigmoid(f.a2[j]);
                 gcat[j] = g_h3[j] * s2;
-                gcat[8 + j] = g_h3[j] * y2[j] * s2 * (1.f - s2);
+                gcat[8 + j] = g_h3[j] * f.y2[j] * s2 * (1.f - s2);
             }
             f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
             nf_fp_gemm_d<4>(sm + L.W2, NF_FP_ST, 0, gcat, acc, c16, g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) g_q[j] = acc[j >> 2][j & 3];
-            float ga[2][4], av[2][4], half[8];
-            nf_fp_store_rows(q, TA, c16, g);
+            float half[8];
+            nf_fp_store_rows(f.q, TA, c16, g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) half[j] = gcat[j];
             nf_fp_store_rows(half, TG, c16, g);
-            nf_fp_wsync();
-            nf_fp_load_cols<2>(TA, av, c16, g);
-            nf_fp_load_cols<2>(TG, ga, c16, g);
-            nf_fp_wgrad<2, 2, 4, 2, 0, 0>(ga, av, aW2, vb2);
-            nf_fp_wsync();
 #pragma unroll
             for (int j = 0; j < 8; ++j) half[j] = gcat[8 + j];
-            nf_fp_store_rows(half, TG, c16, g);
-            nf_fp_wsync();
-            nf_fp_load_cols<2>(TG, ga, c16, g);
-            nf_fp_wgrad<2, 2, 4, 2, 2, 0>(ga, av, aW2, vb2 + 2);
-            nf_fp_wsync();
+            nf_fp_store_rows(half, TX, c16, g);
+            __syncthreads();
+            // g_W2 is 64 x 32: eight blocks, one per wave
+            const int ob = wid >> 1, ib = wid & 1;
+            b2 += nf_fp_coop_block(ob < 2 ? TGs : TXs, TAs, TSZ, 16 * (ob & 1), 16 * ib, a2, c16, g);
         }
-        // ---- q = Wq (h2 + pos) + bq ------------------------------------------------------------------------------------
-        float g_h2[8], xh1[8];
-        nf_fp_unpark(PK + 1024, xh1, lane);
+        // ---- phase 3: q = Wq (h2 + pos) + bq ---------------------------------------------------------------------------
+        float g_h2[8], g_h1[8];
+        {
+        NF_FPP_SET(2);
         {
             f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
             nf_fp_gemm_d<2>(sm + L.Wq, NF_FP_ST, 0, g_q, acc, c16, g);
-            float tv[8], ga8[8], be8[8], ga[2][4], av[2][4];
+            float tv[8], g_t[8];
             nf_fp_ldvec(sm + L.pos, g, tv);
-            nf_fp_ldvec(sm + L.ln1g, g, ga8);
-            nf_fp_ldvec(sm + L.ln1b, g, be8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tv[j] += fmaf(xh1[j], ga8[j], be8[j]);          // t = h2 + pos
+            for (int j = 0; j < 8; ++j) { tv[j] += f.h2[j]; g_t[j] = acc[j >> 2][j & 3]; }
             nf_fp_store_rows(tv, TA, c16, g);
             nf_fp_store_rows(g_q, TG, c16, g);
-            nf_fp_wsync();
-            nf_fp_load_cols<2>(TA, av, c16, g);
-            nf_fp_load_cols<2>(TG, ga, c16, g);
-            nf_fp_wgrad<2, 2, 2, 2, 0, 0>(ga, av, aWq, vbq);
-            nf_fp_wsync();
-            float g_t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) g_t[j] = acc[j >> 2][j & 3];
-            nf_fp_colsum(g_t, TG, vpos, c16, g);
+            nf_fp_colsum(g_t, TX, vpos, c16, g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) g_h2[j] = g_h3[j] + g_t[j];
         }
-        // ---- LayerNorm 1 ---------------------------------------------------------------------------------------
-        float g_h1[8];
-        {
+        {   // LayerNorm 1
             float tmp[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tmp[j] = g_h2[j] * xh1[j];
-            nf_fp_colsum(tmp, TG, vln1g, c16, g);
-            nf_fp_colsum(g_h2, TG, vln1b, c16, g);
-            nf_fp_ln_bwd(g_h2, xh1, sm + L.ln1g, rstd1, g_h1, g);
+            for (int j = 0; j < 8; ++j) tmp[j] = g_h2[j] * f.xh1[j];
+            nf_fp_colsum(tmp, TX, vln1g, c16, g);
+            nf_fp_colsum(g_h2, TX, vln1b, c16, g);
+            nf_fp_ln_bwd(g_h2, f.xh1, sm + L.ln1g, f.rstd1, g_h1, g);
         }
-        // ---- gate 1: h1 = h0 + elu(u) sigmoid(elu(-u));  u = Wg [elu(h0), elu(-h0)] + bg ------------------------------
+        __syncthreads();
+        if (wid < 4) bq += nf_fp_coop_block(TGs, TAs, TSZ, 16 * (wid >> 1), 16 * (wid & 1), aq, c16, g);   // g_Wq: four blocks
+        }
+        // ---- phase 4: gate 1: h1 = h0 + elu(u) sigmoid(elu(-u));  u = Wg [elu(h0), elu(-h0)] + bg --------------------------
         float g_h0[8];
         {
-            float g_u[8], u[8];
-            nf_fp_unpark(PK + 512, u, lane);
+            NF_FPP_SET(3);
+            float g_u[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float y, a, dy, da;
-                nf_celu(u[j], y, a);
-                nf_celu_grad(u[j], dy, da);
+                nf_celu(f.u[j], y, a);
+                nf_celu_grad(f.u[j], dy, da);
                 const float sa = nf_sigmoid(a);
                 g_u[j] = g_h1[j] * sa * (dy - y * (1.f - sa) * da);
             }
             f32x4 acc0[2] = {nf_fp_zero4(), nf_fp_zero4()}, acc1[2] = {nf_fp_zero4(), nf_fp_zero4()};
             nf_fp_gemm_d<2>(sm + L.Wg, NF_FP_STG, 0, g_u, acc0, c16, g);
             nf_fp_gemm_d<2>(sm + L.Wg, NF_FP_STG, 32, g_u, acc1, c16, g);
-            float h0[8], c0[8], c1[8], d0[8], d1[8], ga[2][4], av[2][4];
-            nf_fp_unpark(PK, h0, lane);
+            float c0[8], c1[8], d0[8], d1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                nf_celu(h0[j], c0[j], c1[j]);
-                nf_celu_grad(h0[j], d0[j], d1[j]);
+                nf_celu(f.h0[j], c0[j], c1[j]);
+                nf_celu_grad(f.h0[j], d0[j], d1[j]);
+                g_h0[j] = g_h1[j] + acc0[j >> 2][j & 3] * d0[j] - acc1[j >> 2][j & 3] * d1[j];
             }
             nf_fp_store_rows(g_u, TG, c16, g);
             nf_fp_store_rows(c0, TA, c16, g);
-            nf_fp_wsync();
-            nf_fp_load_cols<2>(TG, ga, c16, g);
-            nf_fp_load_cols<2>(TA, av, c16, g);
-            nf_fp_wgrad<2, 2, 2, 4, 0, 0>(ga, av, aWg, vbg);
-            nf_fp_wsync();
-            nf_fp_store_rows(c1, TA, c16, g);
-            nf_fp_wsync();
-            nf_fp_load_cols<2>(TA, av, c16, g);
-            nf_fp_wgrad<2, 2, 2, 4, 0, 2>(ga, av, aWg, nullptr);
-            nf_fp_wsync();
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                g_h0[j] = g_h1[j] + acc0[j >> 2][j & 3] * d0[j] - acc1[j >> 2][j & 3] * d1[j];
+            nf_fp_store_rows(c1, TX, c16, g);
+            __syncthreads();
+            // g_Wg is 32 x 64: eight blocks, one per wave
+            const int ob = wid >> 2, ib = wid & 3;
+            const float bs = nf_fp_coop_block(TGs, ib < 2 ? TAs : TXs, TSZ, 16 * ob, 16 * (ib & 1), ag, c16, g);
+            if (ib == 0) bg += bs;
         }
-        // ---- h0 = W0 x + b0 --------------------------------------------------------------------------------------------
+        // ---- phase 5: h0 = W0 x + b0 ---------------------------------------------------------------------------------------
         {
-            nf_fp_store_rows(g_h0, TG, c16, g);
-            nf_fp_wsync();
-            float ga[2][4], av[1][4];
-            nf_fp_load_cols<2>(TG, ga, c16, g);
+        NF_FPP_SET(4);
+        nf_fp_store_rows(g_h0, TG, c16, g);
+        if (gr.g_x != nullptr) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {                        // B fragment: x[row 4 s + g][input c16], zero beyond I0 / N
-                const int64_t r2 = row0 + 4 * s + g;
-                const float v = w.x[(r2 < N ? r2 : N - 1) * I0 + (c16 < I0 ? c16 : 0)];
-                av[0][s] = (r2 < N && c16 < I0) ? v : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * (j >> 2) + 4 * g + (j & 3);
+                const float4 w0 = *(const float4*)(sm + L.W0 + 4 * k);
+                s4[0] = fmaf(g_h0[j], w0.x, s4[0]); s4[1] = fmaf(g_h0[j], w0.y, s4[1]);
+                s4[2] = fmaf(g_h0[j], w0.z, s4[2]); s4[3] = fmaf(g_h0[j], w0.w, s4[3]);
             }
-            nf_fp_wgrad<2, 1, 2, 1, 0, 0>(ga, av, aW0, vb0);
-            nf_fp_wsync();
-            if (gr.g_x != nullptr) {
-                float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * (j >> 2) + 4 * g + (j & 3);
-                    const float4 w0 = *(const float4*)(sm + L.W0 + 4 * k);
-                    s4[0] = fmaf(g_h0[j], w0.x, s4[0]); s4[1] = fmaf(g_h0[j], w0.y, s4[1]);
-                    s4[2] = fmaf(g_h0[j], w0.z, s4[2]); s4[3] = fmaf(g_h0[j], w0.w, s4[3]);
+            for (int i = 0; i < 4; ++i) {
+                const float sv = nf_fp_rowsum(s4[i]);
+                if (i < I0 && g == 0 && rv) gr.g_x[row * I0 + i] = sv;
+            }
+        }
+        __syncthreads();
+        if (wid < 2) {   // g_W0 (32 x I0): two blocks; B fragment = x straight from global, zero beyond I0 / N
+#pragma unroll 2
+            for (int wv = 0; wv < NF_FP_BWD_WAVES; ++wv) {
+                const int64_t r0 = (tile0 + wv) * 16;
+                float ga[4], av[4];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int64_t r2 = r0 + 4 * s2 + g;
+                    const float v = w.x[(r2 < N ? r2 : N - 1) * I0 + (c16 < I0 ? c16 : 0)];
+                    av[s2] = (r2 < N && c16 < I0) ? v : 0.f;
+                    ga[s2] = TGs[wv * TSZ + (4 * s2 + g) * NF_FP_ST + 16 * wid + c16];
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float s = nf_fp_rowsum(s4[i]);
-                    if (i < I0 && g == 0 && rv) gr.g_x[row * I0 + i] = s;
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    b0 += ga[s2];
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], av[s2], a0, 0, 0, 0);
                 }
             }
+        }
         }
     }
+#undef NF_FPP_SET
+    __syncthreads();                                      // the tiles are re-used for the final reduction
 
-    // ---- block reduction (pairs of waves fold into two LDS images of the slab), then one coalesced slab store -----------
+    // ---- this workgroup's slab: every weight block has exactly one owner; the LayerNorm / pos sums are folded over the waves ---
+    float* slab = slabs + (size_t)blockIdx.x * NF_S_END;
+    const int c16 = lane0 & 15, g = lane0 >> 4;
+    {
+        const int ob = wid >> 1, ib = wid & 1;
+        if (wid < 2 * NB) {
 #pragma unroll
-    for (int a = 0; a < NB; ++a) vb5[a] = nf_fp_rowsum(vb5[a]);
+            for (int r = 0; r < 4; ++r) slab[NF_S_W5 + (16 * ob + 4 * g + r) * 32 + 16 * ib + c16] = a5[r];
+        }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) vb2[a] = nf_fp_rowsum(vb2[a]);
+        for (int r = 0; r < 4; ++r) slab[NF_S_W2 + (16 * ob + 4 * g + r) * 32 + 16 * ib + c16] = a2[r];
+        if (wid < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[NF_S_WQ + (16 * ob + 4 * g + r) * 32 + 16 * ib + c16] = aq[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[NF_S_WG + (16 * (wid >> 2) + 4 * g + r) * 64 + 16 * (wid & 3) + c16] = ag[r];
+        if (wid < 2 && c16 < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[NF_S_W0 + (16 * wid + 4 * g + r) * 4 + c16] = a0[r];
+        }
+        b5 = nf_fp_rowsum(b5); b2 = nf_fp_rowsum(b2); bq = nf_fp_rowsum(bq); bg = nf_fp_rowsum(bg); b0 = nf_fp_rowsum(b0);
+        if (g == 0) {
+            if (wid < 2 * NB && ib == 0) slab[NF_S_B5 + 16 * ob + c16] = b5;
+            if (ib == 0) slab[NF_S_B2 + 16 * ob + c16] = b2;
+            if (wid < 4 && ib == 0) slab[NF_S_BQ + 16 * ob + c16] = bq;
+            if ((wid & 3) == 0) slab[NF_S_BG + 16 * (wid >> 2) + c16] = bg;
+            if (wid < 2) slab[NF_S_B0 + 16 * wid + c16] = b0;
+        }
+    }
+    float* red = sm + L.tiles;                            // [waves][5][32]; the tiles are idle after the last barrier
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        vbq[a] = nf_fp_rowsum(vbq[a]); vbg[a] = nf_fp_rowsum(vbg[a]); vln2g[a] = nf_fp_rowsum(vln2g[a]);
-        vln2b[a] = nf_fp_rowsum(vln2b[a]); vln1g[a] = nf_fp_rowsum(vln1g[a]); vln1b[a] = nf_fp_rowsum(vln1b[a]);
-        vpos[a] = nf_fp_rowsum(vpos[a]); vb0[a] = nf_fp_rowsum(vb0[a]);
-    }
-    __syncthreads();                                             // every wave is done with its tiles: the region is re-used
-    float* R = sm + L.tiles + (wid & 1) * NF_S_END;
-    auto fold = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = 4 * g + r;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-                for (int ob = 0; ob < NB; ++ob) nf_fp_put<FIRST>(R, NF_S_W5 + (16 * ob + rr) * 32 + 16 * ib + c16, aW5[ob][ib][r]);
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) nf_fp_put<FIRST>(R, NF_S_W2 + (16 * ob + rr) * 32 + 16 * ib + c16, aW2[ob][ib][r]);
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob) nf_fp_put<FIRST>(R, NF_S_WQ + (16 * ob + rr) * 32 + 16 * ib + c16, aWq[ob][ib][r]);
-            }
-#pragma unroll
-            for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob) nf_fp_put<FIRST>(R, NF_S_WG + (16 * ob + rr) * 64 + 16 * ib + c16, aWg[ob][ib][r]);
-            if (c16 < 4) {
-#pragma unroll
-                for (int ob = 0; ob < 2; ++ob) nf_fp_put<FIRST>(R, NF_S_W0 + (16 * ob + rr) * 4 + c16, aW0[ob][0][r]);
-            }
-        }
+        vln2g[a] = nf_fp_rowsum(vln2g[a]); vln2b[a] = nf_fp_rowsum(vln2b[a]); vln1g[a] = nf_fp_rowsum(vln1g[a]);
+        vln1b[a] = nf_fp_rowsum(vln1b[a]); vpos[a] = nf_fp_rowsum(vpos[a]);
         if (g == 0) {
-#pragma unroll
-            for (int a = 0; a < NB; ++a) nf_fp_put<FIRST>(R, NF_S_B5 + 16 * a + c16, vb5[a]);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) nf_fp_put<FIRST>(R, NF_S_B2 + 16 * a + c16, vb2[a]);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                nf_fp_put<FIRST>(R, NF_S_BQ + 16 * a + c16, vbq[a]);
-                nf_fp_put<FIRST>(R, NF_S_BG + 16 * a + c16, vbg[a]);
-                nf_fp_put<FIRST>(R, NF_S_LN2G + 16 * a + c16, vln2g[a]);
-                nf_fp_put<FIRST>(R, NF_S_LN2B + 16 * a + c16, vln2b[a]);
-                nf_fp_put<FIRST>(R, NF_S_LN1G + 16 * a + c16, vln1g[a]);
-                nf_fp_put<FIRST>(R, NF_S_LN1B + 16 * a + c16, vln1b[a]);
-                nf_fp_put<FIRST>(R, NF_S_POS + 16 * a + c16, vpos[a]);
-                nf_fp_put<FIRST>(R, NF_S_B0 + 16 * a + c16, vb0[a]);
-            }
+            float* rw = red + wid * 160 + 16 * a + c16;
+            rw[0] = vln2g[a]; rw[32] = vln2b[a]; rw[64] = vln1g[a]; rw[96] = vln1b[a]; rw[128] = vpos[a];
         }
-    };
-    if (NB < 4) {                                                // rows of W5 / b5 beyond 16 NB are never produced: zero them
-        for (int e = threadIdx.x; e < 2 * NF_S_END; e += blockDim.x) sm[L.tiles + e] = 0.f;
-        __syncthreads();
-        if ((wid >> 1) == NF_FP_BWD_WAVES / 2 - 1) fold(std::false_type{});
-    } else if ((wid >> 1) == NF_FP_BWD_WAVES / 2 - 1) {
-        fold(std::true_type{});
     }
     __syncthreads();
-#pragma unroll 1
-    for (int p = NF_FP_BWD_WAVES / 2 - 2; p >= 0; --p) {
-        if ((wid >> 1) == p) fold(std::false_type{});
-        __syncthreads();
+    if (threadIdx.x < 160) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NF_FP_BWD_WAVES; ++wv) t += red[wv * 160 + threadIdx.x];
+        const int v = threadIdx.x >> 5, k = threadIdx.x & 31;
+        const int base = v == 0 ? NF_S_LN2G : v == 1 ? NF_S_LN2B : v == 2 ? NF_S_LN1G : v == 3 ? NF_S_LN1B : NF_S_POS;
+        slab[base + k] = t;
     }
-    float* slab = slabs + (size_t)blockIdx.x * NF_S_END;
-    for (int e = threadIdx.x; e < NF_S_END; e += blockDim.x) slab[e] = sm[L.tiles + e] + sm[L.tiles + NF_S_END + e];
 }
 
 // dst += sum over the blocks' slabs.  grid (NF_S_END / 64, 4): 64 slab entries x 4 slab groups per block, the y index picks
@@ -701,8 +709,9 @@ static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace,
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    const int iters = (int)((tiles + gx * NF_FP_BWD_WAVES - 1) / (gx * NF_FP_BWD_WAVES));
     hipLaunchKernelGGL(k_flowpp_cond_bwd<NB>, dim3((unsigned)gx), dim3(NF_FP_BWD_WAVES * NF_WAVE), lds, stream, w, g, workspace,
-                       N, I0, O, tiles, nf_fpp_vec_ok(w) ? 1 : 0);
+                       N, I0, O, tiles, iters, nf_fpp_vec_ok(w) ? 1 : 0);
     NF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_flowpp_cond_finalize, dim3(NF_S_END / 64, (unsigned)((gx + 63) / 64)), dim3(256), 0, stream, (const float*)workspace, (int)gx, g,
                        I0, O);
