@@ -163,7 +163,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         args = F._flowpp_fwd_args(ts, F_)
 
         def fn():
-            N.call('nf_flowpp_cond_bwd', x.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), B, I0, O,
+            N.call('nf_flowpp_cond_bwd', x.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), I0, 1, I0, 1, 0, B, I0, O,
                    N.stream())
         us = graph_time_us(fn, dev, per_graph=20, replays=5) * 1.0
         mac = (2048 + 1024 + 2048) + 2 * (O * 32 + 2048 + 1024 + 2048) + 32 * I0      # recompute + data + weight gradients

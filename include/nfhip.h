@@ -375,13 +375,18 @@ int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, fl
 
 /* ---- Flow++ conditioner for density data, whole network in one launch  coupling.py:142-149, modules.py:500-578 ---------
  * out = Linear5(LN2(GatedAttn1(LN1(GatedLinear(Linear0(x))))))  for x (N, I0 <= 4), hidden width 32, O <= 64 outputs;
- * GatedAttn with ONE position: q = Wq (h + pos) + bq (rows 64..95 of conv1), v = W2 q + b2, h + v[:32]*sigmoid(v[32:]).  */
+ * GatedAttn with ONE position: q = Wq (h + pos) + bq (rows 64..95 of conv1), v = W2 q + b2, h + v[:32]*sigmoid(v[32:]).
+ * x may be a strided view: element (n, i) at x[n * x_row_stride + i * x_col_stride] -- e.g. the conditioning half of the
+ * coupling input itself (squeeze.py:68-69), which removes the gather launch.                                             */
 int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* b0, const float* Wg, const float* bg,
                        const float* ln1_g, const float* ln1_b, const float* pos, const float* Wq, const float* bq,
                        const float* W2, const float* b2, const float* ln2_g, const float* ln2_b, const float* W5,
-                       const float* b5, float* out, int64_t N, int I0, int O, nf_stream_t stream);
+                       const float* b5, float* out, int64_t x_row_stride, int x_col_stride, int64_t N, int I0, int O,
+                       nf_stream_t stream);
 /* autograd of nf_flowpp_cond_fwd: the forward is recomputed per 16-row tile from x, every parameter gradient is
- * ACCUMULATED (+=; zero-filled temporaries or .grad buffers), g_x (N, I0) is written (nullable).  Two launches: the tile
+ * ACCUMULATED (+=; zero-filled temporaries or .grad buffers); g_x element (n, i) at g_x[n * gx_row_stride + i * gx_col_stride]
+ * is written, or += when gx_accumulate (straight into the coupling's input gradient: no scatter, no add launch); nullable.
+ * Two launches: the tile
  * kernel leaves one partial-sum slab per block in `workspace` (>= NF_FLOWPP_BWD_WS_FLOATS floats, contents irrelevant,
  * re-usable by the next call on the same stream), a small kernel folds the slabs into the destinations.
  * g_Wq / g_bq address rows 64..95 of conv1's gradient (the V/K rows receive exact zeros, like the reference).          */
@@ -391,8 +396,9 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
                        const float* W2, const float* b2, const float* ln2_g, const float* ln2_b, const float* W5,
                        const float* b5, const float* g_out, float* g_x, float* g_W0, float* g_b0, float* g_Wg,
                        float* g_bg, float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_Wq, float* g_bq, float* g_W2,
-                       float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5, float* workspace, int64_t N,
-                       int I0, int O, nf_stream_t stream);
+                       float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5, float* workspace,
+                       int64_t x_row_stride, int x_col_stride, int64_t gx_row_stride, int gx_col_stride, int gx_accumulate,
+                       int64_t N, int I0, int O, nf_stream_t stream);
 
 /* ---- NLL of the training harness  main.py:49-51, :85 -------------------------------------------------------------
  * loss[0] += -(1/B) * sum_b ( -0.5*|z_b|^2 - 0.5*D*log(2 pi) + ld[b] )   (caller zero-fills loss)            */

@@ -35,12 +35,14 @@ static_assert(NF_FP_FWD_WAVES * NF_WAVE == 512 && NF_FP_BWD_WAVES * NF_WAVE == 5
 struct NfFppW {   // device pointers (forward operands)
     const float *x, *W0, *b0, *Wg, *bg, *ln1g, *ln1b, *pos, *Wq, *bq, *W2, *b2, *ln2g, *ln2b, *W5, *b5;
     float* out;
+    int64_t xrs; int xcs;                                 // x[row][i] lives at x[row * xrs + i * xcs] (a strided view of z is fine)
 };
 
 struct NfFppG {   // gradient destinations, all ACCUMULATED (+=): zero-filled temporaries or .grad buffers
     const float* g_out;          // (N, O)
     float* g_x;                  // (N, I0) written, nullable
     float *g_W0, *g_b0, *g_Wg, *g_bg, *g_ln1g, *g_ln1b, *g_pos, *g_Wq, *g_bq, *g_W2, *g_b2, *g_ln2g, *g_ln2b, *g_W5, *g_b5;
+    int64_t gxrs; int gxcs, gx_acc;                       // g_x[row][i] at g_x[row * gxrs + i * gxcs]; gx_acc: += instead of =
 };
 
 // LDS layout (floats): the weights, then (backward) the per-wave tiles
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(NF_FP_FWD_WAVES * NF_WAVE, 4) k_flowpp_cond_fw
         float xin[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < I0 && row < N) xin[i] = w.x[row * I0 + i];
+            if (i < I0 && row < N) xin[i] = w.x[row * w.xrs + i * w.xcs];
         NfFppFwd f;
         nf_fpp_forward_tile(sm, L, xin, c16, g, f);
         // out = h4 W5^T + b5 with the activations as the A operand: D col = output feature -> coalesced row stores
@@ -264,10 +266,11 @@ __global__ void __launch_bounds__(NF_FP_FWD_WAVES * NF_WAVE, 4) k_flowpp_cond_fw
 extern "C" int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* b0, const float* Wg, const float* bg,
                                   const float* ln1_g, const float* ln1_b, const float* pos, const float* Wq, const float* bq,
                                   const float* W2, const float* b2, const float* ln2_g, const float* ln2_b, const float* W5,
-                                  const float* b5, float* out, int64_t N, int I0, int O, nf_stream_t stream) {
+                                  const float* b5, float* out, int64_t x_row_stride, int x_col_stride, int64_t N, int I0, int O,
+                                  nf_stream_t stream) {
     if (I0 < 1 || I0 > 4 || O < 1 || O > 64) return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
-    NfFppW w{x, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, out};
+    NfFppW w{x, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, out, x_row_stride, x_col_stride};
     const int64_t tiles = (N + 15) / 16;
     int64_t gx = (tiles + NF_FP_FWD_WAVES - 1) / NF_FP_FWD_WAVES;
     if (gx > 512) gx = 512;                                     // two 8-wave blocks per CU, weights staged once per block
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
         float xin[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < I0 && rv) xin[i] = w.x[row * I0 + i];
+            if (i < I0 && rv) xin[i] = w.x[row * w.xrs + i * w.xcs];
         NfFppFwd f;
         nf_fpp_forward_tile(sm, L, xin, c16, g, f);
 
@@ -578,7 +581,10 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float sv = nf_fp_rowsum(s4[i]);
-                if (i < I0 && g == 0 && rv) gr.g_x[row * I0 + i] = sv;
+                if (i < I0 && g == 0 && rv) {
+                    float* dst = gr.g_x + row * gr.gxrs + i * gr.gxcs;
+                    *dst = gr.gx_acc ? *dst + sv : sv;
+                }
             }
         }
         __syncthreads();
@@ -590,7 +596,7 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
                     const int64_t r2 = r0 + 4 * s2 + g;
-                    const float v = w.x[(r2 < N ? r2 : N - 1) * I0 + (c16 < I0 ? c16 : 0)];
+                    const float v = w.x[(r2 < N ? r2 : N - 1) * w.xrs + (c16 < I0 ? c16 : 0) * w.xcs];
                     av[s2] = (r2 < N && c16 < I0) ? v : 0.f;
                     ga[s2] = TGs[wv * TSZ + (4 * s2 + g) * NF_FP_ST + 16 * wid + c16];
                 }
@@ -725,11 +731,13 @@ extern "C" int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* 
                                   const float* b5, const float* g_out, float* g_x, float* g_W0, float* g_b0, float* g_Wg,
                                   float* g_bg, float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_Wq, float* g_bq,
                                   float* g_W2, float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5,
-                                  float* workspace, int64_t N, int I0, int O, nf_stream_t stream) {
+                                  float* workspace, int64_t x_row_stride, int x_col_stride, int64_t gx_row_stride, int gx_col_stride,
+                                  int gx_accumulate, int64_t N, int I0, int O, nf_stream_t stream) {
     if (I0 < 1 || I0 > 4 || O < 1 || O > 64 || workspace == nullptr) return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
-    NfFppW w{x, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, nullptr};
-    NfFppG g{g_out, g_x, g_W0, g_b0, g_Wg, g_bg, g_ln1_g, g_ln1_b, g_pos, g_Wq, g_bq, g_W2, g_b2, g_ln2_g, g_ln2_b, g_W5, g_b5};
+    NfFppW w{x, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, nullptr, x_row_stride, x_col_stride};
+    NfFppG g{g_out, g_x, g_W0, g_b0, g_Wg, g_bg, g_ln1_g, g_ln1_b, g_pos, g_Wq, g_bq, g_W2, g_b2, g_ln2_g, g_ln2_b, g_W5, g_b5,
+             gx_row_stride, gx_col_stride, gx_accumulate};
     switch ((O + 15) / 16) {
         case 1: return nf_fpp_launch_bwd<1>(w, g, workspace, N, I0, O, (hipStream_t)stream);
         case 2: return nf_fpp_launch_bwd<2>(w, g, workspace, N, I0, O, (hipStream_t)stream);

@@ -508,7 +508,7 @@ class _FusedFlowppCond(torch.autograd.Function):
         Nrows, I0 = x.shape
         O = ts[13].shape[0]
         out = torch.empty(Nrows, O, dtype=torch.float32, device=x.device)
-        N.call('nf_flowpp_cond_fwd', N.ptr(x), *_flowpp_fwd_args(ts, F_), N.ptr(out), Nrows, I0, O, N.stream())
+        N.call('nf_flowpp_cond_fwd', N.ptr(x), *_flowpp_fwd_args(ts, F_), N.ptr(out), I0, 1, Nrows, I0, O, N.stream())
         ctx.save_for_backward(x, *ts)
         ctx.F_ = F_
         return out
@@ -536,7 +536,7 @@ class _FusedFlowppCond(torch.autograd.Function):
         d[7] += 4 * 2 * F_ * H                                   # conv1 gradient rows [2F:3F]; V / K rows stay exactly zero
         d[8] += 4 * 2 * F_
         N.call('nf_flowpp_cond_bwd', N.ptr(x), *_flowpp_fwd_args(ts, F_), N.ptr(g_out), _p(g_x), *d,
-               N.ptr(flowpp_bwd_workspace(x.device)), Nrows, I0, O, N.stream())
+               N.ptr(flowpp_bwd_workspace(x.device)), I0, 1, I0, 1, 0, Nrows, I0, O, N.stream())
         if direct:
             return (g_x, None) + (None, ) * len(ts)
         return (g_x, None) + tuple(dst)
@@ -557,7 +557,7 @@ def flowpp_cond_forward_nograd(net, x):
     N.call('nf_flowpp_cond_fwd', N.ptr(x), N.ptr(W0.detach()), N.ptr(b0.detach()), N.ptr(Wg.detach()), N.ptr(bg.detach()),
            N.ptr(l1g.detach()), N.ptr(l1b.detach()), N.ptr(pos.detach()), c1w.data_ptr() + 4 * 2 * F_ * H,
            c1b.data_ptr() + 4 * 2 * F_, N.ptr(c2w.detach()), N.ptr(c2b.detach()), N.ptr(l2g.detach()), N.ptr(l2b.detach()),
-           N.ptr(W5.detach()), N.ptr(b5.detach()), N.ptr(out), Nrows, I0, O, N.stream())
+           N.ptr(W5.detach()), N.ptr(b5.detach()), N.ptr(out), I0, 1, Nrows, I0, O, N.stream())
     return out
 
 
@@ -631,3 +631,82 @@ def glow_step_vec(z, ld, actnorm, conv, coupling):
     head = [actnorm.log_scale, actnorm.bias, conv.P, conv.L, conv.U, conv.L_mask, conv.U_mask, conv.sign_s, conv.log_s,
             coupling.s_log_scale, coupling.s_bias]
     return _GlowStepVec.apply(z, _owned_ld(ld), int(coupling.odd), coupling.net.training, *(head + _mlp_tensors(coupling.net)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# whole Flow++ coupling on vector data: conditioner (strided read of the conditioning half) + mixture-of-logistics coupling
+# ----------------------------------------------------------------------------------------------------------------------
+class _FlowppCouplingVec(torch.autograd.Function):
+    """(y, ld) = MixLogAttnCoupling.forward for dims = (D,): 2 launches forward (no gather), 3 backward (the conditioner's
+    input gradient is added in place into the coupling's, no scatter / add).  tensors: a_log_scale, a_bias, then the 15
+    conditioner tensors of _flowpp_tensors."""
+
+    @staticmethod
+    def forward(ctx, z, ld, K, eps, odd, F_, *tensors):
+        a, c = tensors[:2]
+        ts = tensors[2:]
+        z = z.contiguous()
+        Nrows, D = z.shape
+        I0 = ts[0].shape[1]
+        O = ts[13].shape[0]
+        sel1 = 1 ^ int(odd)                                   # conditioning half = elements 2 e + sel1 (squeeze.py:68-69)
+        params = torch.empty(Nrows, O, dtype=torch.float32, device=z.device)
+        N.call('nf_flowpp_cond_fwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(params), D, 2, Nrows, I0, O,
+               N.stream())
+        y = torch.empty_like(z)
+        N.call('nf_mixlog_coupling_fwd', N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(y), N.ptr(ld), K, float(eps),
+               N.SPLIT_1D, int(odd), Nrows, D, 1, 1, N.stream())
+        ctx.save_for_backward(z, params, *tensors)
+        ctx.meta = (K, float(eps), int(odd), F_)
+        from .functional import _sinks
+        ctx.sinks_ac = _sinks(a, c)
+        ctx.sinks_net = _sinks(*ts)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, params, *tensors = ctx.saved_tensors
+        a, c = tensors[:2]
+        ts = tensors[2:]
+        K, eps, odd, F_ = ctx.meta
+        Nrows, D = z.shape
+        I0 = ts[0].shape[1]
+        O = ts[13].shape[0]
+        sel1 = 1 ^ odd
+        dev = z.device
+        g_y, g_ld = g_y.contiguous(), g_ld.contiguous()
+        g_z = torch.empty_like(z)
+        g_p = torch.empty_like(params)
+        if ctx.sinks_ac is not None:
+            pa, pc, ga, gc = ctx.sinks_ac[0].data_ptr(), ctx.sinks_ac[1].data_ptr(), None, None
+        else:
+            g_ac = torch.zeros(2, dtype=torch.float32, device=dev)
+            pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
+            ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
+        N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(g_z),
+               N.ptr(g_p), pa, pc, K, eps, N.SPLIT_1D, odd, Nrows, D, 1, 1, N.stream())
+        if ctx.sinks_net is not None:
+            dst, direct = ctx.sinks_net, True
+        else:
+            flat = torch.zeros(sum(t.numel() for t in ts), dtype=torch.float32, device=dev)
+            dst, o = [], 0
+            for t in ts:
+                dst.append(flat[o:o + t.numel()].view(t.shape))
+                o += t.numel()
+            direct = False
+        d = [t.data_ptr() for t in dst]
+        d[7] += 4 * 2 * F_ * H
+        d[8] += 4 * 2 * F_
+        N.call('nf_flowpp_cond_bwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(g_p), g_z.data_ptr() + 4 * sel1,
+               *d, N.ptr(flowpp_bwd_workspace(dev)), D, 2, D, 2, 1, Nrows, I0, O, N.stream())
+        gnet = (None, ) * len(ts) if direct else tuple(dst)
+        return (g_z, g_ld, None, None, None, None, ga, gc) + gnet
+
+
+def flowpp_coupling_vec(z, ld, coupling):
+    """MixLogAttnCoupling.forward on (N, D) data with the fused conditioner (see flowpp_cond_fusable)."""
+    from .functional import _owned_ld
+    ts, F_ = _flowpp_tensors(coupling.net)
+    return _FlowppCouplingVec.apply(z, _owned_ld(ld), coupling.n_mixtures, coupling.logit_eps, int(coupling.odd), F_,
+                                    coupling.a_log_scale, coupling.a_bias, *ts)

@@ -353,6 +353,9 @@ class MixLogAttnCoupling(AbstractCoupling):
         return self.net(x)
 
     def forward(self, z, log_df_dz):
+        if (self.mode == N.SPLIT_1D and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[0] > 0
+                and FUSED.flowpp_cond_fusable(self.net, z[:, :z.shape[1] // 2])):
+            return FUSED.flowpp_coupling_vec(z, log_df_dz, self)          # conditioner + coupling, no gather / scatter
         params = self.conditioner(z)
         return NF.mixlog_coupling(z, params, self.a_log_scale, self.a_bias, log_df_dz, self.n_mixtures, self.mode,
                                   self.odd, logit_eps=self.logit_eps)

@@ -45,11 +45,11 @@ def main():
         args = fused._flowpp_fwd_args(ts, F_)
 
         def fwd():
-            N_.call('nf_flowpp_cond_fwd', N_.ptr(x), *args, N_.ptr(out), n, 1, O, N_.stream())
+            N_.call('nf_flowpp_cond_fwd', N_.ptr(x), *args, N_.ptr(out), 1, 1, n, 1, O, N_.stream())
 
         def bwd():
             N_.call('nf_flowpp_cond_bwd', N_.ptr(x), *args, N_.ptr(g_out), N_.ptr(g_x), *d,
-                    N_.ptr(fused.flowpp_bwd_workspace(dev)), n, 1, O, N_.stream())
+                    N_.ptr(fused.flowpp_bwd_workspace(dev)), 1, 1, 1, 1, 0, n, 1, O, N_.stream())
 
         print('%-8d %7.1f  %7.1f' % (n, timeit(fwd), timeit(bwd)))
 

@@ -97,7 +97,7 @@ def main():
         wsb = F.flowpp_bwd_workspace(torch.device(dev, 0))
         args = F._flowpp_fwd_args(ts, F_)
         for _ in range(reps):
-            N.call('nf_flowpp_cond_bwd', xin.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), Nr, 1, O,
+            N.call('nf_flowpp_cond_bwd', xin.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), 1, 1, 1, 1, 0, Nr, 1, O,
                    N.stream())
         torch.cuda.synchronize()
 
