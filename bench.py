@@ -356,6 +356,8 @@ def main():
         inv_ms = event_time_ms(lambda: net.backward(zz), 5, stream)
         net.train()
 
+    timeouts = pkg._native.persistent_timeouts()
+    assert timeouts == 0, 'persistent kernels timed out %d times: the GPU was shared, results invalid' % timeouts
     if rank == 0:
         roof = dominant_kernel_roofline(pkg, cfg, B, dev)
         out = {

@@ -373,6 +373,11 @@ int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, fl
                          void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
                          int training, float bn_eps, float wn_eps, nf_stream_t stream);
 
+/* The persistent kernels above wait on each other with BOUNDED spin loops (a grid of <= NF_MLP_MAX_BLOCKS workgroups is
+ * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some
+ * launch produced garbage (device shared with another job?).  Synchronises the device.                                    */
+int nf_persistent_timeouts(int* count);
+
 /* ---- Flow++ conditioner for density data, whole network in one launch  coupling.py:142-149, modules.py:500-578 ---------
  * out = Linear5(LN2(GatedAttn1(LN1(GatedLinear(Linear0(x))))))  for x (N, I0 <= 4), hidden width 32, O <= 64 outputs;
  * GatedAttn with ONE position: q = Wq (h + pos) + bq (rows 64..95 of conv1), v = W2 q + b2, h + v[:32]*sigmoid(v[32:]).

@@ -105,3 +105,11 @@ def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise NativeLibraryError('%s failed with code %d' % (name, rc))
+
+
+def persistent_timeouts():
+    """spin loops of the persistent kernels that gave up since load (must be 0); synchronises the device."""
+    import ctypes as _c
+    v = _c.c_int(0)
+    call('nf_persistent_timeouts', _c.byref(v))
+    return int(v.value)

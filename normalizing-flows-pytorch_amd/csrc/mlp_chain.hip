@@ -20,6 +20,7 @@
 #define NF_MC_PROF 0      // 1 (tools/probes/mlp_chain_prof.py builds that variant): time stamps of workgroup 0 at phase boundaries
 #endif
 __device__ long long nf_mc_prof_buf[128];
+__device__ unsigned nf_mc_timeouts;                       // spin loops that gave up (a grid that was not co-resident): must stay 0
 #define NF_MC_T(i)                                                                          \
     do {                                                                                    \
         if (NF_MC_PROF && blockIdx.x == 0 && threadIdx.x == 0) nf_mc_prof_buf[i] = wall_clock64(); \
@@ -96,7 +97,7 @@ __device__ __forceinline__ void nf_grid_barrier(unsigned* counter, unsigned targ
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22)) break;
+            if (++spins > (1u << 22)) { atomicAdd(&nf_mc_timeouts, 1u); break; }
         }
         __threadfence();
     }
@@ -142,7 +143,8 @@ __device__ __forceinline__ const float* nf_mc_collect(float* sm, int gather, uns
         unsigned spins = 0;
         do {
             v = __hip_atomic_load(rs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32) == gen || ++spins > (1u << 22)) break;     // bounded: a mistake cannot hang the box
+            if ((unsigned)(v >> 32) == gen) break;
+            if (++spins > (1u << 22)) { atomicAdd(&nf_mc_timeouts, 1u); break; }   // bounded: a mistake cannot hang the box
             __builtin_amdgcn_s_sleep(1);
         } while (true);
         xs[e] = __uint_as_float((unsigned)v);
@@ -1056,5 +1058,16 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
                        save_stats, (const float*)nullptr, (float*)nullptr, g, accumulate, ws_zero, slabs, N, D / 2, D, training, bn_eps,
                        wn_eps, h);
     NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// number of bounded spin loops that gave up since the library was loaded (0 unless a persistent grid was not co-resident:
+// results of such a launch are garbage).  Synchronises the device.
+extern "C" int nf_persistent_timeouts(int* count) {
+    if (count == nullptr) return NF_E_BADARG;
+    unsigned v = 0;
+    hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(nf_mc_timeouts), sizeof(v));
+    if (e != hipSuccess) return (int)e;
+    *count = (int)v;
     return 0;
 }

@@ -295,3 +295,8 @@ def test_glow_step_vec_vs_unfused(pkg, D, odd, N, training, direct):
     b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
     for name in b1:
         G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+
+
+def test_zz_persistent_kernels_never_timed_out(pkg):
+    """runs last in this file: no bounded spin loop of the persistent kernels gave up during the tests above."""
+    assert pkg._native.persistent_timeouts() == 0
