@@ -373,6 +373,35 @@ int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, fl
                          void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
                          int training, float bn_eps, float wn_eps, nf_stream_t stream);
 
+/* ---- one whole MAF flow step on vector data in one persistent launch per direction (training mode) ------------------
+ * dims = (D,), D <= 4, N <= NF_MAF_MAX_ROWS: flow BatchNorm with batch statistics (modules.py:283-307, affine=False) ->
+ * z @ perm (maf.py:100) -> the MADE pair (maf.py:49-64; masks applied while the weights are staged) -> affine transform of
+ * all features + log-det (maf.py:103-106).  Replaces 7 launches forward / 13 backward of the per-layer path.
+ * head: NF_MAF_HEAD_PTRS device pointers on the HOST: flow-BN log_gamma, beta, batch_mean, batch_var, running_mean,
+ *       running_var (D each; the four buffers are updated), perm (D, D), s_log_scale, s_bias (1).
+ * made_params: NF_MAF_PARAM_PTRS pointers: net s then net t, each: layer l = 0..3: weight (O_l, I_l), mask (O_l, I_l),
+ *       bias (O_l); then BatchNorm1d j = 0..2: gamma, beta, running_mean, running_var, num_batches_tracked (int64 / NULL).
+ * save_stats: NF_MAF_SAVE_FLOATS floats written by the forward, read by the backward.  ws_zero: NF_MAF_WS_FLOATS floats that
+ * are ZERO at launch.  Backward: g_z (N, D) written; g_ld nullable (passes through unchanged to the caller's graph);
+ * made_grads: NF_MAF_GRAD_PTRS pointers (net s, net t: per layer g_weight, g_bias; per BatchNorm g_gamma, g_beta) and the two
+ * scalars g_s_log_scale, g_s_bias are ACCUMULATED by atomics: pass .grad buffers or zero-filled temporaries.
+ * slabs: NF_MAF_BWD_SLAB_FLOATS floats of scratch.                                                                        */
+#define NF_MAF_HEAD_PTRS 9
+#define NF_MAF_PARAM_PTRS 54
+#define NF_MAF_GRAD_PTRS 28
+#define NF_MAF_ROWS_PER_BLOCK 128
+#define NF_MAF_MAX_BLOCKS 128
+#define NF_MAF_MAX_ROWS 16384
+#define NF_MAF_SAVE_FLOATS 392
+#define NF_MAF_WS_FLOATS (4 * 128 * 128 * 2 + 64)
+#define NF_MAF_BWD_SLAB_FLOATS (128 * 2 * 4 * 2 * 1056)
+int nf_maf_step_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* made_params,
+                    float* save_stats, float* ws_zero, int64_t N, int D, float flow_bn_eps, float flow_bn_momentum,
+                    float bn_eps, nf_stream_t stream);
+int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                    const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
+                    float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream);
+
 /* The persistent kernels above wait on each other with BOUNDED spin loops (a grid of <= NF_MLP_MAX_BLOCKS workgroups is
  * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some
  * launch produced garbage (device shared with another job?).  Synchronises the device.                                    */

@@ -1,0 +1,705 @@
+// One whole MAF flow step on vector data as ONE persistent launch per direction (training mode, N <= NF_MAF_MAX_ROWS):
+//   flow BatchNorm (flows/modules.py:283-307, batch statistics, affine=False) -> column permutation (maf.py:100, z @ perm)
+//   -> the two MADE conditioners s, t (maf.py:49-64: masked Linear -> BatchNorm1d -> ReLU, three hidden layers of 32)
+//   -> affine transform y = z exp(tanh(s) a + c) + t over ALL features, log-det += sum s (maf.py:103-106).
+// Same machinery as mlp_chain.hip (see there for the reasoning and the measurements): one 8-wave workgroup per 128 rows, a
+// 16-row tile per wave, activations in registers in the row-per-lane layout of nf_mfma16.h, the masked weights of both nets
+// in LDS, batch statistics across the grid through per-workgroup {value, generation} slots that every workgroup polls
+// (one memory round trip, deterministic order), weight gradients formed per workgroup from parked tiles and folded from
+// per-workgroup slabs after a final fenced exchange.  Both nets run in lockstep, so one exchange carries both nets'
+// statistics (128 values) and the two independent GEMM chains interleave.
+// Replaces 7 launches forward (statistics, head, rocBLAS permutation matmul, 4 linear+BN launches, transform) and 13
+// backward per flow step; numerics are those of linear_bn.hip / flowbn_head.hip.
+#include "nf_common.h"
+#include "nf_mfma16.h"
+
+#define NF_MD_WAVES (NF_MAF_ROWS_PER_BLOCK / 16)
+#define NF_MD_THREADS (NF_MD_WAVES * NF_WAVE)
+#define NF_MD_NKQ (NF_MD_WAVES / 4)
+#define NF_MD_NL 4
+#define NF_MD_NB 3
+#define NF_MD_XW 128                                      // exchange width: 2 nets x (32 sums + 32 square sums)
+static_assert(NF_MD_THREADS == 512 && NF_MD_WAVES % 4 == 0, "geometry");
+
+__device__ unsigned nf_md_timeouts;
+
+struct NfMadeP {                                          // [net][layer]
+    const float* w[2][NF_MD_NL]; const float* m[2][NF_MD_NL]; const float* b[2][NF_MD_NL];
+    const float* gamma[2][NF_MD_NB]; const float* beta[2][NF_MD_NB];
+    float* rmean[2][NF_MD_NB]; float* rvar[2][NF_MD_NB]; int64_t* nbt[2][NF_MD_NB];
+};
+struct NfMadeG { float* w[2][NF_MD_NL]; float* b[2][NF_MD_NL]; float* gamma[2][NF_MD_NB]; float* beta[2][NF_MD_NB]; };
+struct NfMafV {
+    const float* z; float* y; float* ld;                  // forward
+    const float* g_y; const float* g_ld; float* g_z;      // backward
+    const float *log_gamma, *bn_beta;                     // flow BatchNorm (affine=False: buffers)
+    float *bmean, *bvar, *rmean, *rvar;
+    const float* perm; const float *a, *c;                // permutation matrix (D, D); transform scale / shift scalars
+    float *g_a, *g_c;
+    float eps, mom;
+    int D;
+};
+
+static inline void nf_made_unpack(const void* const* t, NfMadeP& p) {
+    for (int n = 0; n < 2; ++n) {
+        const void* const* q = t + n * (3 * NF_MD_NL + 5 * NF_MD_NB);
+        for (int l = 0; l < NF_MD_NL; ++l) {
+            p.w[n][l] = (const float*)q[3 * l]; p.m[n][l] = (const float*)q[3 * l + 1]; p.b[n][l] = (const float*)q[3 * l + 2];
+        }
+        q += 3 * NF_MD_NL;
+        for (int j = 0; j < NF_MD_NB; ++j) {
+            p.gamma[n][j] = (const float*)q[5 * j]; p.beta[n][j] = (const float*)q[5 * j + 1];
+            p.rmean[n][j] = (float*)q[5 * j + 2]; p.rvar[n][j] = (float*)q[5 * j + 3]; p.nbt[n][j] = (int64_t*)q[5 * j + 4];
+        }
+    }
+}
+
+// LDS (floats)
+#define NF_MD_W 0                                         // [2][4][32 * 36] masked weights, zero padded
+#define NF_MD_B (NF_MD_W + 2 * NF_MD_NL * 32 * NF_FP_ST)  // [2][4][32] biases
+#define NF_MD_GA (NF_MD_B + 2 * NF_MD_NL * 32)            // [2][3][32] gamma
+#define NF_MD_BE (NF_MD_GA + 2 * NF_MD_NB * 32)           // [2][3][32] beta
+#define NF_MD_BNC (NF_MD_BE + 2 * NF_MD_NB * 32)          // [2][3][4][32] scale, shift, mean, invstd
+#define NF_MD_VAR (NF_MD_BNC + 2 * NF_MD_NB * 4 * 32)     // [2][3][32] biased batch variance (bookkeeping)
+#define NF_MD_HEAD (NF_MD_VAR + 2 * NF_MD_NB * 32)        // flow BN per feature: mean[4], sd[4], exp(log_gamma)[4], beta[4]; perm[16]; dld, a, c
+#define NF_MD_RED (NF_MD_HEAD + 48)                       // [waves][128] per-wave partials
+#define NF_MD_PART (NF_MD_RED + NF_MD_WAVES * NF_MD_XW)   // [4][128] partial totals of the poll groups
+#define NF_MD_TOT (NF_MD_PART + 4 * NF_MD_XW)             // [2][128] grid totals, double buffered by round parity
+#define NF_MD_GB (NF_MD_TOT + 2 * NF_MD_XW)               // [3][128] backward: sum_g | sum_gx of both nets per BatchNorm
+#define NF_MD_TILES (NF_MD_GB + NF_MD_NB * NF_MD_XW)      // per-wave 16 x 36 tiles
+
+static inline size_t nf_md_lds_bytes(int tiles_per_wave) {
+    return (size_t)(NF_MD_TILES + NF_MD_WAVES * tiles_per_wave * 16 * NF_FP_ST) * sizeof(float);
+}
+
+// ---- grid exchange of NF_MD_XW values per workgroup (see mlp_chain.hip: nf_mc_publish / nf_mc_collect) --------------------
+__device__ __forceinline__ void nf_md_publish(float* sm, unsigned long long* slots, int round, unsigned gen) {
+    float* red = sm + NF_MD_RED;
+    __syncthreads();
+    if (threadIdx.x < NF_MD_XW) {
+        float mine = 0.f;
+#pragma unroll
+        for (int w = 0; w < NF_MD_WAVES; ++w) mine += red[w * NF_MD_XW + threadIdx.x];
+        if (gridDim.x == 1) {
+            red[threadIdx.x] = mine;
+        } else {
+            const unsigned long long pk = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(mine);
+            __hip_atomic_store(slots + ((size_t)round * NF_MAF_MAX_BLOCKS + blockIdx.x) * NF_MD_XW + threadIdx.x, pk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// thread t owns value index i = t % 128 of the workgroups b = t / 128 (mod 4): up to 8 polls in flight per trip, partial sums
+// in workgroup order, then the four groups are added in order -- deterministic, and no gather buffer in LDS
+__device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long long* slots, int round, unsigned gen) {
+    float* tot = sm + NF_MD_TOT + (round & 1) * NF_MD_XW;
+    const int G = gridDim.x;
+    if (G == 1) {
+        if (threadIdx.x < NF_MD_XW) tot[threadIdx.x] = sm[NF_MD_RED + threadIdx.x];
+        __syncthreads();
+        return tot;
+    }
+    const int i = threadIdx.x & (NF_MD_XW - 1), grp = threadIdx.x >> 7;
+    const unsigned long long* rs = slots + (size_t)round * NF_MAF_MAX_BLOCKS * NF_MD_XW + i;
+    float acc = 0.f;
+    for (int b0 = grp; b0 < G; b0 += 4 * 8) {
+        unsigned long long v[8];
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int b = b0 + 4 * k;
+                v[k] = __hip_atomic_load(rs + (size_t)(b < G ? b : b0) * NF_MD_XW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
+            if (ok) break;
+            if (++spins > (1u << 22)) { atomicAdd(&nf_md_timeouts, 1u); break; }      // bounded: a mistake cannot hang the box
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (b0 + 4 * k < G) acc += __uint_as_float((unsigned)v[k]);
+    }
+    sm[NF_MD_PART + threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < NF_MD_XW)
+        tot[threadIdx.x] = (sm[NF_MD_PART + threadIdx.x] + sm[NF_MD_PART + NF_MD_XW + threadIdx.x]) +
+                           (sm[NF_MD_PART + 2 * NF_MD_XW + threadIdx.x] + sm[NF_MD_PART + 3 * NF_MD_XW + threadIdx.x]);
+    __syncthreads();
+    return tot;
+}
+
+// ---- staging: masked weights of both nets, biases, BatchNorm affines ------------------------------------------------------------
+__device__ __forceinline__ void nf_md_stage(const NfMadeP& p, float* sm, int D) {
+    const int tid = threadIdx.x, k = tid & 31;
+    float w[2][NF_MD_NL][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int l = 0; l < NF_MD_NL; ++l) {              // 16 independent (weight, mask) pairs in flight, one latency
+            const int I = l == 0 ? D : 32, O = l == NF_MD_NL - 1 ? D : 32;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int oo = (tid >> 5) + 16 * h2;
+                const bool ok = oo < O && k < I;
+                const int e = ok ? oo * I + k : 0;
+                const float wv = p.w[n][l][e], mv = p.m[n][l][e];
+                w[n][l][h2] = ok ? wv * mv : 0.f;                                    // maf.py:54: F.linear(h, W * M, b)
+            }
+        }
+    float bk = 0.f, ga = 0.f, be = 0.f;
+    if (tid < 2 * NF_MD_NL * 32) {
+        const int n = tid >> 7, l = (tid >> 5) & 3;
+        const int O = l == NF_MD_NL - 1 ? D : 32;
+        bk = k < O ? p.b[n][l][k] : 0.f;
+    }
+    if (tid < 2 * NF_MD_NB * 32) {
+        const int n = tid / 96, j = (tid / 32) % 3;
+        ga = p.gamma[n][j][k]; be = p.beta[n][j][k];
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int l = 0; l < NF_MD_NL; ++l)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                sm[NF_MD_W + (n * NF_MD_NL + l) * 32 * NF_FP_ST + ((tid >> 5) + 16 * h2) * NF_FP_ST + k] = w[n][l][h2];
+    if (tid < 2 * NF_MD_NL * 32) sm[NF_MD_B + tid] = bk;
+    if (tid < 2 * NF_MD_NB * 32) { sm[NF_MD_GA + tid] = ga; sm[NF_MD_BE + tid] = be; }
+}
+
+__device__ __forceinline__ void nf_md_linear(const float* sm, int n, int l, const float (&av)[8], float (&dv)[8], int c16, int g) {
+    f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
+    nf_fp_gemm<2>(sm + NF_MD_W + (n * NF_MD_NL + l) * 32 * NF_FP_ST, NF_FP_ST, 0, av, acc, c16, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dv[j] = acc[j >> 2][j & 3];
+}
+// ReLU(BatchNorm_j(a)) of net n
+__device__ __forceinline__ void nf_md_activate(const float* sm, int n, int j, const float (&a)[8], float (&av)[8], int g) {
+    float sc[8], sh[8];
+    nf_fp_ldvec(sm + NF_MD_BNC + ((n * NF_MD_NB + j) * 4 + 0) * 32, g, sc);
+    nf_fp_ldvec(sm + NF_MD_BNC + ((n * NF_MD_NB + j) * 4 + 1) * 32, g, sh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) av[k] = fmaxf(fmaf(a[k], sc[k], sh[k]), 0.f);
+}
+__device__ __forceinline__ void nf_md_bn_consts(float* sm, int n, int j, int k, float mean, float invstd) {
+    const int q = n * NF_MD_NB + j;
+    const float sc = sm[NF_MD_GA + q * 32 + k] * invstd;
+    sm[NF_MD_BNC + (q * 4 + 0) * 32 + k] = sc;
+    sm[NF_MD_BNC + (q * 4 + 1) * 32 + k] = sm[NF_MD_BE + q * 32 + k] - mean * sc;
+    sm[NF_MD_BNC + (q * 4 + 2) * 32 + k] = mean;
+    sm[NF_MD_BNC + (q * 4 + 3) * 32 + k] = invstd;
+}
+// this lane's share of the column sums of an R-layout vector and (SQ) of its squares, reduced over the four lane groups
+template <bool SQ>
+__device__ __forceinline__ void nf_md_colsums(const float (&v)[8], float* tile, float (&s1)[2], float (&s2)[2], int c16, int g) {
+    nf_fp_store_rows(v, tile, c16, g);
+    nf_fp_wsync();
+    float c[2][4];
+    nf_fp_load_cols<2>(tile, c, c16, g);
+    nf_fp_wsync();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        s1[cb] = nf_fp_rowsum((c[cb][0] + c[cb][1]) + (c[cb][2] + c[cb][3]));
+        if (SQ) s2[cb] = nf_fp_rowsum(fmaf(c[cb][0], c[cb][0], fmaf(c[cb][1], c[cb][1], fmaf(c[cb][2], c[cb][2], c[cb][3] * c[cb][3]))));
+    }
+}
+
+// flow BatchNorm constants of feature c from (mean, var incl. eps) -> HEAD
+__device__ __forceinline__ void nf_md_head_consts(float* sm, const NfMafV& h, int c, float mean, float var) {
+    sm[NF_MD_HEAD + c] = mean;
+    sm[NF_MD_HEAD + 4 + c] = sqrtf(var);
+    sm[NF_MD_HEAD + 8 + c] = c < h.D ? expf(h.log_gamma[c]) : 1.f;
+    sm[NF_MD_HEAD + 12 + c] = c < h.D ? h.bn_beta[c] : 0.f;
+    sm[NF_MD_HEAD + 36 + c] = c < h.D ? h.log_gamma[c] - 0.5f * logf(var) : 0.f;     // per-feature log-det (modules.py:303-305)
+}
+// h = BN(z), z' = h perm  (per row, every lane of the row's four)
+__device__ __forceinline__ void nf_md_head_row(const float* sm, const float (&zr)[4], int D, float (&zp)[4]) {
+    float hh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        hh[c] = c < D ? ((zr[c] - sm[NF_MD_HEAD + c]) / sm[NF_MD_HEAD + 4 + c]) * sm[NF_MD_HEAD + 8 + c] + sm[NF_MD_HEAD + 12 + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = fmaf(hh[c], sm[NF_MD_HEAD + 16 + 4 * c + j], acc);     // maf.py:100: z @ perm
+        zp[j] = acc;
+    }
+}
+__device__ __forceinline__ void nf_md_load_row(const float* z, int64_t row, bool rv, int D, float (&zr)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float v = z[(rv ? row : 0) * D + (c < D ? c : 0)];
+        zr[c] = (rv && c < D) ? v : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMafV h, float* save, float* ws, int64_t N, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+    const int64_t row = ((int64_t)blockIdx.x * NF_MD_WAVES + wid) * 16 + c16;
+    const bool rv = row < N;
+    const int D = h.D;
+    float zr[4], ld_in = 0.f, rm_old = 0.f, rv_old = 0.f, kc = 0.f, frm = 0.f, frv = 0.f;
+    nf_md_load_row(h.z, row, rv, D, zr);                  // issued before the staging: one memory latency for everything
+    if (rv && g == 0) ld_in = h.ld[row];
+    if (blockIdx.x == 0 && threadIdx.x < 2 * NF_MD_NB * 32) {
+        const int n = threadIdx.x / 96, j = (threadIdx.x / 32) % 3, k = threadIdx.x & 31;
+        rm_old = p.rmean[n][j][k]; rv_old = p.rvar[n][j][k];
+    }
+    if (threadIdx.x < 4 && (int)threadIdx.x < D) { frm = h.rmean[threadIdx.x]; frv = h.rvar[threadIdx.x]; }
+    if (threadIdx.x < 16) sm[NF_MD_HEAD + 16 + threadIdx.x] = ((threadIdx.x >> 2) < D && (threadIdx.x & 3) < D) ? h.perm[(threadIdx.x >> 2) * D + (threadIdx.x & 3)] : 0.f;
+    if (threadIdx.x == 16) { sm[NF_MD_HEAD + 33] = h.a[0]; sm[NF_MD_HEAD + 34] = h.c[0]; }
+    if (threadIdx.x >= 32 && threadIdx.x < 36) sm[NF_MD_HEAD + 40 + (threadIdx.x - 32)] = (int)(threadIdx.x - 32) < D ? h.rmean[threadIdx.x - 32] : 0.f;
+    nf_md_stage(p, sm, D);
+    __syncthreads();
+    unsigned long long* slots = (unsigned long long*)ws;
+    float* tile = sm + NF_MD_TILES + wid * 16 * NF_FP_ST;
+    float* red = sm + NF_MD_RED + wid * NF_MD_XW;
+
+    // ---- flow BatchNorm statistics: shifted sums around the running mean (flowbn_head.hip) ------------------------------
+    {
+        float v8[8], s1[2], s2[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = 0.f;
+        if (g == 0 && rv) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v8[c] = c < D ? zr[c] - sm[NF_MD_HEAD + 40 + c] : 0.f;
+        }
+        nf_md_colsums<true>(v8, tile, s1, s2, c16, g);
+        red[lane] = 0.f; red[64 + lane] = 0.f;
+        nf_fp_wsync();
+        if (g == 0 && c16 < 4) { red[c16] = s1[0]; red[4 + c16] = s2[0]; }
+        nf_md_publish(sm, slots, 0, 1u);
+        const float* tot = nf_md_collect(sm, slots, 0, 1u);
+        if (threadIdx.x < 4) {
+            const int c = threadIdx.x;
+            const float n = (float)N;
+            const float m1 = tot[c] / n;
+            kc = sm[NF_MD_HEAD + 40 + c];
+            const float mean = kc + m1;
+            const float var = fmaxf(tot[4 + c] / n - m1 * m1, 0.f) + eps;           // biased, eps inside (modules.py:287)
+            nf_md_head_consts(sm, h, c, mean, var);
+            if (blockIdx.x == 0 && c < D) {
+                h.bmean[c] = mean; h.bvar[c] = var;
+                h.rmean[c] = frm * (1.f - h.mom) + mean * h.mom;                    // modules.py:291-294
+                h.rvar[c] = frv * (1.f - h.mom) + var * h.mom;
+                save[2 * NF_MD_NB * 2 * 32 + c] = mean; save[2 * NF_MD_NB * 2 * 32 + 4 + c] = var;
+            }
+        }
+        __syncthreads();
+    }
+    float zp[4], xa[8];
+    nf_md_head_row(sm, zr, D, zp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa[j] = 0.f;
+    if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xa[c] = zp[c];
+    }
+    // ---- the two MADE nets in lockstep ------------------------------------------------------------------------------------
+    float av[2][8], dv[2][8];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) nf_md_linear(sm, n, 0, xa, dv[n], c16, g);
+#pragma unroll 1
+    for (int l = 0; l < NF_MD_NB; ++l) {                  // dv = pre-bias output of linear l = input of BatchNorm l
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float m8[8], s1[2], s2[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m8[k] = rv ? dv[n][k] : 0.f;
+            nf_md_colsums<true>(m8, tile, s1, s2, c16, g);
+            if (g == 0) {
+                red[n * 64 + c16] = s1[0]; red[n * 64 + 16 + c16] = s1[1];
+                red[n * 64 + 32 + c16] = s2[0]; red[n * 64 + 48 + c16] = s2[1];
+            }
+        }
+        nf_md_publish(sm, slots, 1 + l, (unsigned)(2 + l));
+        const float* tot = nf_md_collect(sm, slots, 1 + l, (unsigned)(2 + l));
+        if (threadIdx.x < 64) {
+            const int n = threadIdx.x >> 5, k = threadIdx.x & 31;
+            const float invN = 1.f / (float)N;
+            const float m1 = tot[n * 64 + k] * invN;
+            const float mean = sm[NF_MD_B + (n * NF_MD_NL + l) * 32 + k] + m1;      // sums are centred at the bias
+            const float var = fmaxf(tot[n * 64 + 32 + k] * invN - m1 * m1, 0.f);    // biased, as BatchNorm normalises
+            nf_md_bn_consts(sm, n, l, k, mean, 1.f / sqrtf(var + eps));
+            sm[NF_MD_VAR + (n * NF_MD_NB + l) * 32 + k] = var;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float bias[8], a_in[8];
+            nf_fp_ldvec(sm + NF_MD_B + (n * NF_MD_NL + l) * 32, g, bias);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a_in[k] = dv[n][k] + bias[k];
+            nf_md_activate(sm, n, l, a_in, av[n], g);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) nf_md_linear(sm, n, l + 1, av[n], dv[n], c16, g);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * NF_MD_NB * 32) {       // BatchNorm1d bookkeeping, off the chain
+        const int n = threadIdx.x / 96, j = (threadIdx.x / 32) % 3, k = threadIdx.x & 31, q = n * NF_MD_NB + j;
+        const float mean = sm[NF_MD_BNC + (q * 4 + 2) * 32 + k], var = sm[NF_MD_VAR + q * 32 + k];
+        const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+        p.rmean[n][j][k] = 0.9f * rm_old + 0.1f * mean;                               // nn.BatchNorm1d momentum 0.1
+        p.rvar[n][j][k] = 0.9f * rv_old + 0.1f * unb;
+        save[(q * 2 + 0) * 32 + k] = mean;
+        save[(q * 2 + 1) * 32 + k] = sm[NF_MD_BNC + (q * 4 + 3) * 32 + k];
+        if (k == 0 && p.nbt[n][j] != nullptr) p.nbt[n][j][0] += 1;
+    }
+    // ---- affine transform over all features (maf.py:103-106) ----------------------------------------------------------------
+    if (rv && g == 0) {
+        float bs[8], bt[8], dld = 0.f;
+        nf_fp_ldvec(sm + NF_MD_B + (0 * NF_MD_NL + 3) * 32, g, bs);
+        nf_fp_ldvec(sm + NF_MD_B + (1 * NF_MD_NL + 3) * 32, g, bt);
+        const float ca = sm[NF_MD_HEAD + 33], cc = sm[NF_MD_HEAD + 34];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < D) {
+                const float sv = tanhf(dv[0][c] + bs[c]) * ca + cc;
+                h.y[row * D + c] = zp[c] * expf(sv) + (dv[1][c] + bt[c]);
+                dld += sv + sm[NF_MD_HEAD + 36 + c];
+            }
+        }
+        h.ld[row] = ld_in + dld;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------
+#define NF_MD_SLAB_Q 1056
+#define NF_MD_SLAB_L (NF_MD_NKQ * NF_MD_SLAB_Q)
+#define NF_MD_SLAB (2 * NF_MD_NL * NF_MD_SLAB_L)
+static_assert(NF_MD_SLAB * NF_MAF_MAX_BLOCKS == NF_MAF_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
+static_assert(4 * NF_MAF_MAX_BLOCKS * NF_MD_XW * 2 + 64 == NF_MAF_WS_FLOATS, "exchange workspace size in include/nfhip.h");
+static_assert(NF_MAF_MAX_BLOCKS * NF_MAF_ROWS_PER_BLOCK == NF_MAF_MAX_ROWS, "geometry in include/nfhip.h");
+
+// wave w's share of g_W[n][L] and g_b[n][L]: output block (w & 1, (w >> 1) & 1) over the rows of waves 4 (w >> 2) .. + 3
+__device__ __forceinline__ void nf_md_wgrad_job(const float* sm, float* slab, int n, int L, int lane, int wid) {
+    const int c16 = lane & 15, g = lane >> 4;
+    const int ob = wid & 1, ib = (wid >> 1) & 1, kq = wid >> 2;
+    f32x4 d = nf_fp_zero4();
+    float bs = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* Gt = sm + NF_MD_TILES + ((1 + 2 * n) * NF_MD_WAVES + 4 * kq + q) * 16 * NF_FP_ST + 16 * ob + c16;
+        const float* At = sm + NF_MD_TILES + ((2 + 2 * n) * NF_MD_WAVES + 4 * kq + q) * 16 * NF_FP_ST + 16 * ib + c16;
+        float ga[4], av[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { ga[s2] = Gt[(4 * s2 + g) * NF_FP_ST]; av[s2] = At[(4 * s2 + g) * NF_FP_ST]; }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            bs += ga[s2];
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], av[s2], d, 0, 0, 0);
+        }
+    }
+    float* sl = slab + (n * NF_MD_NL + L) * NF_MD_SLAB_L + kq * NF_MD_SLAB_Q;     // [i][o]: the fold walks columns contiguously
+    *(float4*)(sl + (16 * ib + c16) * 32 + 16 * ob + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
+    bs = nf_fp_rowsum(bs);
+    if (ib == 0 && g == 0) sl[1024 + 16 * ob + c16] = bs;
+}
+
+template <int L>
+__device__ __forceinline__ void nf_md_bwd_layer(float* sm, const float (&xa)[8], const float (&a)[2][NF_MD_NB][8], float (&G)[2][8],
+                                                float* slab, unsigned long long* slots, bool rv, int64_t N, int lane, int wid) {
+    const int c16 = lane & 15, g = lane >> 4;
+    float* TS = sm + NF_MD_TILES + wid * 16 * NF_FP_ST;
+    float t[2][8];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        float* TG = sm + NF_MD_TILES + ((1 + 2 * n) * NF_MD_WAVES + wid) * 16 * NF_FP_ST;
+        float* TA = sm + NF_MD_TILES + ((2 + 2 * n) * NF_MD_WAVES + wid) * 16 * NF_FP_ST;
+        float act[8];
+        if (L == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) act[k] = xa[k];
+        } else {
+            nf_md_activate(sm, n, L > 0 ? L - 1 : 0, a[n][L > 0 ? L - 1 : 0], act, g);
+        }
+        nf_fp_store_rows(G[n], TG, c16, g);
+        nf_fp_store_rows(act, TA, c16, g);
+        f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
+        nf_fp_gemm_d<2>(sm + NF_MD_W + (n * NF_MD_NL + L) * 32 * NF_FP_ST, NF_FP_ST, 0, G[n], acc, c16, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[n][k] = acc[k >> 2][k & 3];
+    }
+    if (L == 0) {                                         // G <- gradient of the conditioner input (both nets)
+        __syncthreads();
+        nf_md_wgrad_job(sm, slab, 0, L, lane, wid);
+        nf_md_wgrad_job(sm, slab, 1, L, lane, wid);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { G[0][k] = t[0][k]; G[1][k] = t[1][k]; }
+        return;
+    }
+    constexpr int J = L > 0 ? L - 1 : 0;
+    float sc[2][8], gn[2][8], xh[2][8];
+    float* red = sm + NF_MD_RED + wid * NF_MD_XW;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        float sh[8], mean[8], invstd[8], gnx[8], s1[2], s2[2], dum[2];
+        const int q = n * NF_MD_NB + J;
+        nf_fp_ldvec(sm + NF_MD_BNC + (q * 4 + 0) * 32, g, sc[n]);
+        nf_fp_ldvec(sm + NF_MD_BNC + (q * 4 + 1) * 32, g, sh);
+        nf_fp_ldvec(sm + NF_MD_BNC + (q * 4 + 2) * 32, g, mean);
+        nf_fp_ldvec(sm + NF_MD_BNC + (q * 4 + 3) * 32, g, invstd);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            gn[n][k] = fmaf(a[n][J][k], sc[n][k], sh[k]) > 0.f ? t[n][k] : 0.f;    // ReLU mask; rows beyond N carry G = 0
+            xh[n][k] = (a[n][J][k] - mean[k]) * invstd[k];
+            gnx[k] = gn[n][k] * xh[n][k];
+        }
+        nf_md_colsums<false>(gn[n], TS, s1, dum, c16, g);
+        nf_md_colsums<false>(gnx, TS, s2, dum, c16, g);
+        if (g == 0) {
+            red[n * 64 + c16] = s1[0]; red[n * 64 + 16 + c16] = s1[1];
+            red[n * 64 + 32 + c16] = s2[0]; red[n * 64 + 48 + c16] = s2[1];
+        }
+    }
+    nf_md_publish(sm, slots, NF_MD_NB - 1 - J, (unsigned)(NF_MD_NB - J));     // its barrier also covers the parked tiles
+    nf_md_wgrad_job(sm, slab, 0, L, lane, wid);                              // runs while the partial sums travel
+    nf_md_wgrad_job(sm, slab, 1, L, lane, wid);
+    const float* tot = nf_md_collect(sm, slots, NF_MD_NB - 1 - J, (unsigned)(NF_MD_NB - J));
+    if (threadIdx.x < NF_MD_XW) sm[NF_MD_GB + J * NF_MD_XW + threadIdx.x] = tot[threadIdx.x];
+    const float invN = 1.f / (float)N;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        float mg[8], mgx[8];
+        nf_fp_ldvec(tot + n * 64, g, mg);
+        nf_fp_ldvec(tot + n * 64 + 32, g, mgx);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = sc[n][k] * (gn[n][k] - mg[k] * invN - xh[n][k] * (mgx[k] * invN));     // sc = gamma * invstd
+            G[n][k] = rv ? v : 0.f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_bwd(NfMadeP p, NfMafV h, const float* __restrict__ save, NfMadeG gr,
+                                                                float* ws, float* __restrict__ slabs, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+    const int64_t row = ((int64_t)blockIdx.x * NF_MD_WAVES + wid) * 16 + c16;
+    const bool rv = row < N;
+    const int D = h.D;
+    float zr[4], gy[4], gld = 0.f, bn_mean = 0.f, bn_invstd = 0.f, fm = 0.f, fv = 1.f;
+    nf_md_load_row(h.z, row, rv, D, zr);
+    nf_md_load_row(h.g_y, row, rv, D, gy);
+    if (h.g_ld != nullptr && rv) gld = h.g_ld[row];
+    if (threadIdx.x < 2 * NF_MD_NB * 32) {
+        const int q = threadIdx.x >> 5, k = threadIdx.x & 31;
+        bn_mean = save[(q * 2 + 0) * 32 + k];
+        bn_invstd = save[(q * 2 + 1) * 32 + k];
+    }
+    if (threadIdx.x < 4) { fm = save[2 * NF_MD_NB * 2 * 32 + threadIdx.x]; fv = save[2 * NF_MD_NB * 2 * 32 + 4 + threadIdx.x]; }
+    if (threadIdx.x >= 64 && threadIdx.x < 80) {
+        const int e = threadIdx.x - 64;
+        sm[NF_MD_HEAD + 16 + e] = ((e >> 2) < D && (e & 3) < D) ? h.perm[(e >> 2) * D + (e & 3)] : 0.f;
+    }
+    if (threadIdx.x == 80) { sm[NF_MD_HEAD + 33] = h.a[0]; sm[NF_MD_HEAD + 34] = h.c[0]; }
+    nf_md_stage(p, sm, D);
+    __syncthreads();
+    if (threadIdx.x < 2 * NF_MD_NB * 32) nf_md_bn_consts(sm, threadIdx.x / 96, (threadIdx.x / 32) % 3, threadIdx.x & 31, bn_mean, bn_invstd);
+    if (threadIdx.x < 4) nf_md_head_consts(sm, h, threadIdx.x, (int)threadIdx.x < D ? fm : 0.f, (int)threadIdx.x < D ? fv : 1.f);
+    __syncthreads();
+    unsigned long long* slots = (unsigned long long*)ws;
+    float* slab = slabs + (size_t)blockIdx.x * NF_MD_SLAB;
+
+    // ---- forward once more, pre-activations kept -------------------------------------------------------------------------------
+    float zp[4], xa[8], a[2][NF_MD_NB][8], out[2][4];
+    nf_md_head_row(sm, zr, D, zp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa[j] = 0.f;
+    if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xa[c] = zp[c];
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        float av[8], dv[8], bias[8];
+        nf_md_linear(sm, n, 0, xa, dv, c16, g);
+#pragma unroll
+        for (int l = 0; l < NF_MD_NB; ++l) {
+            nf_fp_ldvec(sm + NF_MD_B + (n * NF_MD_NL + l) * 32, g, bias);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[n][l][k] = dv[k] + bias[k];
+            nf_md_activate(sm, n, l, a[n][l], av, g);
+            nf_md_linear(sm, n, l + 1, av, dv, c16, g);
+        }
+        nf_fp_ldvec(sm + NF_MD_B + (n * NF_MD_NL + 3) * 32, g, bias);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[n][c] = dv[c] + bias[c];          // meaningful in the g = 0 lane
+    }
+    // ---- affine transform backward (lane g = 0 of each row), maf.py:103-106 ----------------------------------------------------
+    float G[2][8], gzp[4] = {0.f, 0.f, 0.f, 0.f}, sum_gsv = 0.f, sum_gsvth = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { G[0][j] = 0.f; G[1][j] = 0.f; }
+    if (g == 0 && rv) {
+        const float ca = sm[NF_MD_HEAD + 33], cc = sm[NF_MD_HEAD + 34];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < D) {
+                const float th = tanhf(out[0][c]);
+                const float ev = expf(th * ca + cc);
+                const float gsv = gy[c] * zp[c] * ev + gld;                   // ld += s: the log-det gradient enters here
+                gzp[c] = gy[c] * ev;
+                G[0][c] = gsv * ca * (1.f - th * th);                         // net s: gradient of s_raw
+                G[1][c] = gy[c];                                              // net t
+                sum_gsv += gsv;
+                sum_gsvth += gsv * th;
+            }
+        }
+    }
+    nf_md_bwd_layer<3>(sm, xa, a, G, slab, slots, rv, N, lane, wid);
+    nf_md_bwd_layer<2>(sm, xa, a, G, slab, slots, rv, N, lane, wid);
+    nf_md_bwd_layer<1>(sm, xa, a, G, slab, slots, rv, N, lane, wid);
+    nf_md_bwd_layer<0>(sm, xa, a, G, slab, slots, rv, N, lane, wid);
+    // ---- permutation and flow BatchNorm backward (statistics are constants for autograd, appendix B4) ------------------------
+    if (g == 0 && rv) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gzp[c] += G[0][c] + G[1][c];              // conditioner inputs = z'
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < D) {
+                float gh = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gh = fmaf(gzp[j], sm[NF_MD_HEAD + 16 + 4 * c + j], gh);
+                h.g_z[row * D + c] = gh / sm[NF_MD_HEAD + 4 + c] * sm[NF_MD_HEAD + 8 + c];
+            }
+        }
+    }
+    // ---- final exchange: the two scalar sums, and (fenced) the grid barrier in front of the fold -----------------------------------
+    {
+        float* red = sm + NF_MD_RED + wid * NF_MD_XW;
+        const float s0 = nf_wave_sum(sum_gsv), s1 = nf_wave_sum(sum_gsvth);
+        __syncthreads();                                  // the last weight-gradient jobs are done with RED? (RED is not theirs) -- tiles
+        red[lane] = 0.f; red[64 + lane] = 0.f;
+        nf_fp_wsync();
+        if (lane == 0) { red[0] = s0; red[1] = s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) __threadfence();            // release: the slabs of every wave (cumulative through the barrier)
+    }
+    nf_md_publish(sm, slots, NF_MD_NB, (unsigned)(NF_MD_NB + 1));
+    const float* htot = nf_md_collect(sm, slots, NF_MD_NB, (unsigned)(NF_MD_NB + 1));
+    if (threadIdx.x == 0) __threadfence();                // acquire
+    __syncthreads();
+    // ---- fold: half wave per (net, layer, column | bias, eighth of the workgroups); partial sums meet by atomics ---------------------
+    {
+        const int o = threadIdx.x & 31;
+        const int G_ = gridDim.x;
+        const int chunk = (G_ + 7) / 8;
+        constexpr int HW = NF_MD_THREADS / 32;
+        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * 8; u += G_ * HW) {
+            const int part = u & 7, uu = u >> 3;
+            const int nl = uu / 33, i = uu - nl * 33;     // i == 32: the bias
+            const int n = nl >> 2, l = nl & 3;
+            const int I = l == 0 ? D : 32, O = l == NF_MD_NL - 1 ? D : 32;
+            const int b_lo = part * chunk, b_hi = min(G_, b_lo + chunk);
+            if ((i < 32 && i >= I) || b_lo >= b_hi) continue;
+            float tsum = 0.f;
+            const float* base = slabs + (size_t)nl * NF_MD_SLAB_L + i * 32 + o;
+            for (int b0 = b_lo; b0 < b_hi; b0 += 8) {
+                float v[8][NF_MD_NKQ];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    const int b = b0 + q8 < b_hi ? b0 + q8 : b_hi - 1;
+#pragma unroll
+                    for (int q = 0; q < NF_MD_NKQ; ++q) v[q8][q] = base[(size_t)b * NF_MD_SLAB + q * NF_MD_SLAB_Q];
+                }
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+                    for (int q = 0; q < NF_MD_NKQ; ++q)
+                        if (b0 + q8 < b_hi) tsum += v[q8][q];
+            }
+            if (o < O) {
+                if (i == 32) atomicAdd(gr.b[n][l] + o, tsum);
+                else atomicAdd(gr.w[n][l] + o * I + i, tsum * p.m[n][l][o * I + i]);          // maf.py:54: d(W * M) = g * M
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * NF_MD_NB * 32) {
+        const int n = threadIdx.x / 96, j = (threadIdx.x / 32) % 3, k = threadIdx.x & 31;
+        atomicAdd(gr.beta[n][j] + k, sm[NF_MD_GB + j * NF_MD_XW + n * 64 + k]);
+        atomicAdd(gr.gamma[n][j] + k, sm[NF_MD_GB + j * NF_MD_XW + n * 64 + 32 + k]);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        atomicAdd(h.g_c, htot[0]);                        // d/d s_bias
+        atomicAdd(h.g_a, htot[1]);                        // d/d s_log_scale
+    }
+}
+
+static int nf_maf_ok(int64_t N, int D) { return D >= 1 && D <= 4 && N <= NF_MAF_MAX_ROWS; }
+
+static void nf_maf_head(const void* const* t, NfMafV& h) {
+    h.log_gamma = (const float*)t[0]; h.bn_beta = (const float*)t[1]; h.bmean = (float*)t[2]; h.bvar = (float*)t[3];
+    h.rmean = (float*)t[4]; h.rvar = (float*)t[5]; h.perm = (const float*)t[6]; h.a = (const float*)t[7]; h.c = (const float*)t[8];
+}
+
+extern "C" int nf_maf_step_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* made_params,
+                               float* save_stats, float* ws_zero, int64_t N, int D, float flow_bn_eps, float flow_bn_momentum,
+                               float bn_eps, nf_stream_t stream) {
+    if (z == nullptr || y == nullptr || ld == nullptr || head == nullptr || made_params == nullptr || save_stats == nullptr ||
+        ws_zero == nullptr || !nf_maf_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMadeP p;
+    nf_made_unpack(made_params, p);
+    NfMafV h{};
+    nf_maf_head(head, h);
+    h.z = z; h.y = y; h.ld = ld; h.D = D; h.eps = flow_bn_eps; h.mom = flow_bn_momentum;
+    const unsigned grid = (unsigned)((N + NF_MAF_ROWS_PER_BLOCK - 1) / NF_MAF_ROWS_PER_BLOCK);
+    const size_t lds = nf_md_lds_bytes(1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_maf_step_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_maf_step_fwd, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, save_stats, ws_zero, N, bn_eps);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                               const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
+                               float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream) {
+    if (z == nullptr || g_y == nullptr || g_z == nullptr || head == nullptr || made_params == nullptr || save_stats == nullptr ||
+        made_grads == nullptr || g_s_log_scale == nullptr || g_s_bias == nullptr || ws_zero == nullptr || slabs == nullptr ||
+        !nf_maf_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMadeP p;
+    nf_made_unpack(made_params, p);
+    NfMadeG g;
+    for (int n = 0; n < 2; ++n) {
+        void* const* q = made_grads + n * (2 * NF_MD_NL + 2 * NF_MD_NB);
+        for (int l = 0; l < NF_MD_NL; ++l) { g.w[n][l] = (float*)q[2 * l]; g.b[n][l] = (float*)q[2 * l + 1]; }
+        for (int j = 0; j < NF_MD_NB; ++j) { g.gamma[n][j] = (float*)q[2 * NF_MD_NL + 2 * j]; g.beta[n][j] = (float*)q[2 * NF_MD_NL + 2 * j + 1]; }
+    }
+    NfMafV h{};
+    nf_maf_head(head, h);
+    h.z = z; h.g_y = g_y; h.g_ld = g_ld; h.g_z = g_z; h.D = D; h.g_a = g_s_log_scale; h.g_c = g_s_bias;
+    const unsigned grid = (unsigned)((N + NF_MAF_ROWS_PER_BLOCK - 1) / NF_MAF_ROWS_PER_BLOCK);
+    const size_t lds = nf_md_lds_bytes(5);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_maf_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_maf_step_bwd, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, save_stats, g, ws_zero, slabs, N);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+__attribute__((visibility("hidden"))) int nf_made_timeouts_read(unsigned* v) {
+    return (int)hipMemcpyFromSymbol(v, HIP_SYMBOL(nf_md_timeouts), sizeof(unsigned));
+}

@@ -1077,11 +1077,15 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
 
 // number of bounded spin loops that gave up since the library was loaded (0 unless a persistent grid was not co-resident:
 // results of such a launch are garbage).  Synchronises the device.
+__attribute__((visibility("hidden"))) int nf_made_timeouts_read(unsigned* v);      // made_chain.hip
+
 extern "C" int nf_persistent_timeouts(int* count) {
     if (count == nullptr) return NF_E_BADARG;
-    unsigned v = 0;
+    unsigned v = 0, v2 = 0;
     hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(nf_mc_timeouts), sizeof(v));
     if (e != hipSuccess) return (int)e;
-    *count = (int)v;
+    const int e2 = nf_made_timeouts_read(&v2);
+    if (e2 != 0) return e2;
+    *count = (int)(v + v2);
     return 0;
 }

@@ -710,3 +710,104 @@ def flowpp_coupling_vec(z, ld, coupling):
     ts, F_ = _flowpp_tensors(coupling.net)
     return _FlowppCouplingVec.apply(z, _owned_ld(ld), coupling.n_mixtures, coupling.logit_eps, int(coupling.odd), F_,
                                     coupling.a_log_scale, coupling.a_bias, *ts)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one whole MAF flow step on vector data: flow BatchNorm -> permutation -> MADE pair -> affine transform
+# ----------------------------------------------------------------------------------------------------------------------
+def maf_step_usable(z, bn, ar):
+    """training-mode [flow BatchNorm(affine=False), AutoregressiveTransfrom] on (N, D <= 4) data, csrc/made_chain.hip."""
+    return (z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and 1 <= z.shape[1] <= 4 and bn.training
+            and ar.net_s.training and ar.net_s.num_hidden == 3 and ar.net_s.base_filters == H and ar.net_t.num_hidden == 3
+            and 1 < z.shape[0] <= N.header_constant('NF_MAF_MAX_ROWS'))
+
+
+_MAF_SLABS = {}
+
+
+def _maf_slabs(device):
+    t = _MAF_SLABS.get(device)
+    if t is None:
+        t = _MAF_SLABS[device] = torch.empty(N.header_constant('NF_MAF_BWD_SLAB_FLOATS'), dtype=torch.float32, device=device)
+    return t
+
+
+def _made_tensors(net, masks):
+    ts = []
+    for l in range(net.num_hidden + 1):
+        ts += [net.weights[l], masks[l], net.biases[l]]
+    for bn in net.bnorms:
+        ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    return ts
+
+
+def _made_learnables(ts):
+    """(weight, bias) * 4 then (gamma, beta) * 3 of one net's 27-tensor list."""
+    out = []
+    for l in range(4):
+        out += [ts[3 * l], ts[3 * l + 2]]
+    for j in range(3):
+        out += [ts[12 + 5 * j], ts[12 + 5 * j + 1]]
+    return out
+
+
+class _MAFStepVec(torch.autograd.Function):
+    """head: flow-BN log_gamma, beta, batch_mean, batch_var, running_mean, running_var, perm, s_log_scale, s_bias;
+    then the 27 tensors of net s and of net t (weight, mask, bias per layer; BatchNorm1d tensors)."""
+
+    @staticmethod
+    def forward(ctx, z, ld, bn_eps, bn_momentum, *tensors):
+        head, made = tensors[:9], tensors[9:]
+        z = z.contiguous()
+        Nrows, D = z.shape
+        y = torch.empty_like(z)
+        save = torch.empty(N.header_constant('NF_MAF_SAVE_FLOATS'), dtype=torch.float32, device=z.device)
+        ws = WS.zeros(N.header_constant('NF_MAF_WS_FLOATS'), z.device)
+        htab, mtab = _ptr_table(head), _ptr_table(made)
+        N.call('nf_maf_step_fwd', N.ptr(z), N.ptr(y), N.ptr(ld), ctypes.addressof(htab), ctypes.addressof(mtab), N.ptr(save),
+               N.ptr(ws), Nrows, D, float(bn_eps), float(bn_momentum), BN_EPS, N.stream())
+        ctx.save_for_backward(z, save, *tensors)
+        from .functional import _sinks
+        learn = _made_learnables(made[:27]) + _made_learnables(made[27:]) + [head[7], head[8]]
+        ctx.sinks = _sinks(*learn)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, save, *tensors = ctx.saved_tensors
+        head, made = tensors[:9], tensors[9:]
+        Nrows, D = z.shape
+        dev = z.device
+        g_y = g_y.contiguous()
+        g_ld = None if g_ld is None else g_ld.contiguous()
+        learn = _made_learnables(made[:27]) + _made_learnables(made[27:]) + [head[7], head[8]]
+        direct = ctx.sinks is not None
+        dst = ctx.sinks if direct else [torch.zeros_like(t) for t in learn]      # the kernel accumulates by atomics
+        g_z = torch.empty_like(z)
+        ws = WS.zeros(N.header_constant('NF_MAF_WS_FLOATS'), dev)
+        htab, mtab, gtab = _ptr_table(head), _ptr_table(made), _ptr_table(dst[:28])
+        N.call('nf_maf_step_bwd', N.ptr(z), N.ptr(g_y), _p(g_ld), N.ptr(g_z), ctypes.addressof(htab), ctypes.addressof(mtab),
+               N.ptr(save), ctypes.addressof(gtab), N.ptr(dst[28]), N.ptr(dst[29]), N.ptr(ws), N.ptr(_maf_slabs(dev)), Nrows, D,
+               N.stream())
+        if direct:
+            return (g_z, g_ld, None, None) + (None, ) * len(tensors)
+        gh = [None] * 7 + [dst[28], dst[29]]
+        gm = []
+        for n in range(2):
+            d = dst[14 * n:14 * n + 14]
+            for l in range(4):
+                gm += [d[2 * l], None, d[2 * l + 1]]
+            for j in range(3):
+                gm += [d[8 + 2 * j], d[8 + 2 * j + 1], None, None, None]
+        return (g_z, g_ld, None, None) + tuple(gh) + tuple(gm)
+
+
+def maf_step_vec(z, ld, bn, ar):
+    """[flow BatchNorm ``bn`` (training, affine=False), AutoregressiveTransfrom ``ar``] on (N, D) data, fused."""
+    from .functional import _owned_ld
+    ms = ar.net_s.draw_masks(z.device)                       # same RNG order as the reference: s-net, then t-net
+    mt = ar.net_t.draw_masks(z.device)
+    head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, ar.perm, ar.s_log_scale,
+            ar.s_bias]
+    return _MAFStepVec.apply(z, _owned_ld(ld), bn.eps, bn.momentum, *(head + _made_tensors(ar.net_s, ms) + _made_tensors(ar.net_t, mt)))

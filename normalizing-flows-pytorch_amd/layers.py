@@ -69,6 +69,8 @@ class Compose(nn.Module):
                 if type(k) is AffineCoupling:
                     h, z1c, log_df_dz = NF.flowbn_head(z, log_df_dz, a, k.mode, k.odd, gather=True)
                     z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
+                elif FUSED.maf_step_usable(z, a, k):
+                    z, log_df_dz = FUSED.maf_step_vec(z, log_df_dz, a, k)            # the whole step: one launch
                 else:
                     h, log_df_dz = NF.flowbn_head(z, log_df_dz, a)
                     z, log_df_dz = k(h, log_df_dz)

@@ -300,3 +300,72 @@ def test_glow_step_vec_vs_unfused(pkg, D, odd, N, training, direct):
 def test_zz_persistent_kernels_never_timed_out(pkg):
     """runs last in this file: no bounded spin loop of the persistent kernels gave up during the tests above."""
     assert pkg._native.persistent_timeouts() == 0
+
+
+@pytest.mark.parametrize('direct', [False, True])
+@pytest.mark.parametrize('D,N', [(2, 4096), (2, 300), (4, 1000), (2, 16384), (3, 77)])
+def test_maf_step_vec_vs_unfused(pkg, D, N, direct):
+    """the one-launch MAF step (flow BatchNorm -> perm -> MADE pair -> affine transform) against the per-layer path."""
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+
+    def make():
+        torch.manual_seed(D * 11)
+        np.random.seed(5)
+        bn = pkg.BatchNorm((D, ), affine=False)
+        ar = pkg.AutoregressiveTransfrom(D)
+        mods = torch.nn.ModuleList([bn, ar]).to(DEV)
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.2)
+            bn.running_var.uniform_(0.5, 2.0)
+            ar.s_log_scale.fill_(0.6)
+            ar.s_bias.fill_(0.1)
+            for m in ar.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.3)
+                    m.running_mean.normal_(0, 0.2)
+                    m.running_var.uniform_(0.5, 2.0)
+        mods.train(True)
+        return bn, ar, mods
+
+    bn1, ar1, m1 = make()
+    bn2, ar2, m2 = make()
+    g = torch.Generator().manual_seed(N + D)
+    z = (torch.randn(N, D, generator=g) * 0.8 + 0.3).to(DEV)
+    gy = torch.randn(N, D, generator=g).to(DEV)
+    wl = torch.randn(N, generator=g).to(DEV)
+    ld0 = torch.randn(N, generator=g).to(DEV)
+    z1, z2 = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    np.random.seed(9)                                        # MADE masks are drawn from the global numpy RNG
+    h, ld1 = NF.flowbn_head(z1, ld0.clone(), bn1)
+    y1, ld1 = ar1(h, ld1)
+    ((y1 * gy).sum() + (ld1 * wl).sum()).backward()
+    if direct:
+        for p in m2.parameters():
+            if p.requires_grad:
+                p.grad = torch.zeros_like(p)
+                p._nf_direct_grad = True
+    assert fused.maf_step_usable(z2, bn2, ar2)
+    np.random.seed(9)
+    y2, ld2 = fused.maf_step_vec(z2, ld0.clone(), bn2, ar2)
+    G.assert_close(y2, y1, 2e-5, rtol=2e-5, what='y')
+    G.assert_close(ld2, ld1, 2e-5, rtol=2e-5, what='log-det')
+    ((y2 * gy).sum() + (ld2 * wl).sum()).backward()
+    big = N >= 16384                                         # see test_glow_step_vec_vs_unfused: rare ReLU-mask flips
+    err = (z2.grad - z1.grad).abs().max(dim=1).values
+    bad = int((err > _grad_tol(z1.grad)).sum())
+    assert bad <= (2 if big else 0), 'grad z: %d rows beyond tolerance, max abs err %.3e' % (bad, float(err.max()))
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    for name, p in p1.items():
+        if not p.requires_grad:
+            continue
+        assert p2[name].grad is not None, name
+        pre_bn_bias = '.biases.' in name and not name.endswith('.biases.3')
+        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(p.grad)
+        if big:
+            tol = max(tol, 1e-2 * float(p.grad.abs().max()))
+        G.assert_close(p2[name].grad, p.grad, tol, what='grad ' + name)
+    b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
+    for name in b1:
+        G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
