@@ -101,8 +101,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
     """roofline of the kernel that dominates the timed region (rocprofv3 summaries under profiles/):
       c1 / c2 -> k_mlp_chain_bwd, the one-launch backward of the whole MLP conditioner (six 32-wide linears, five
                  BatchNorms; csrc/mlp_chain.hip) -- fp32 MFMA work, bound by the five grid-wide BatchNorm exchanges;
-      c5      -> k_linear_bn_bwd, the backward of one fused 32x32 linear + BatchNorm layer of the MADE pair (two nets
-                 per launch);
+      c5      -> k_maf_step_bwd, the one-launch backward of a whole MAF flow step (flow BatchNorm, MADE pair, transform);
       c3      -> k_flowpp_cond_bwd, the one-launch backward of the gated-attention conditioner (fp32 MFMA);
       c4      -> k_affine_slab_fwd (first-resolution checkerboard step; convolutions are MIOpen's).
     achieved = algorithmic bytes or flops per launch / average launch duration at the workload's
@@ -146,6 +145,48 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                 'us_per_launch': round(us, 3),
                 'note': 'neither MFMA- nor HBM-bound at this batch: five grid-wide BatchNorm exchanges (~2.3 us each) + '
                         'a grid barrier serialise the launch (DESIGN.md section 2; tools/probes/mlp_chain_prof.py)'}
+    if cfg['kind'] == 'maf' and len(dims) == 1 and dims[0] <= 4 and B <= N.header_constant('NF_MAF_MAX_ROWS'):
+        D = dims[0]
+        bn = pkg.BatchNorm((D, ), affine=False).to(dev).train()
+        ar = pkg.AutoregressiveTransfrom(D).to(dev).train()
+        ms, mt = ar.net_s.draw_masks(dev), ar.net_t.draw_masks(dev)
+        head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, ar.perm, ar.s_log_scale,
+                ar.s_bias]
+        made = F._made_tensors(ar.net_s, ms) + F._made_tensors(ar.net_t, mt)
+        z = torch.randn(B, D, generator=g).to(dev)
+        gy = torch.randn(B, D, generator=g).to(dev)
+        with torch.no_grad():
+            F.maf_step_vec(z, torch.zeros(B, device=dev), bn, ar)
+        save = torch.empty(N.header_constant('NF_MAF_SAVE_FLOATS'), device=dev)
+        y, ld = torch.empty_like(z), torch.zeros(B, device=dev)
+        htab, mtab = F._ptr_table([t.detach() for t in head]), F._ptr_table([t.detach() for t in made])
+        nws = N.header_constant('NF_MAF_WS_FLOATS')
+        ws0 = torch.zeros(nws, device=dev)
+        N.call('nf_maf_step_fwd', z.data_ptr(), y.data_ptr(), ld.data_ptr(), ctypes.addressof(htab), ctypes.addressof(mtab),
+               save.data_ptr(), ws0.data_ptr(), B, D, 1.0e-5, 0.1, 1.0e-5, N.stream())
+        learn = F._made_learnables(made[:27]) + F._made_learnables(made[27:])
+        dst = [torch.zeros_like(t) for t in learn]
+        gtab = F._ptr_table(dst)
+        ga, gc, gz = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.empty_like(z)
+        slabs = F._maf_slabs(dev)
+        wss = torch.zeros(32, nws, device=dev)                  # a fresh zero workspace per launch inside the timing graph
+        it = [0]
+
+        def fn():
+            ws = wss[it[0] % 32]
+            it[0] += 1
+            N.call('nf_maf_step_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
+                   ctypes.addressof(mtab), save.data_ptr(), ctypes.addressof(gtab), ga.data_ptr(), gc.data_ptr(), ws.data_ptr(),
+                   slabs.data_ptr(), B, D, N.stream())
+        us = graph_time_us(fn, dev, per_graph=25, replays=1)
+        mac = 2 * 3 * (32 * D + 1024 + 1024 + 32 * D)           # two nets x (recompute + data + weight gradients)
+        flop = 2 * mac * B
+        tf = flop / (us * 1e-6) / 1e12
+        return {'bound': 'mfma', 'kernel': 'k_maf_step_bwd (whole MAF flow step, one launch)', 'achieved': round(tf, 3),
+                'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': None,
+                'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (3 * D + 1) * 4), 'us_per_launch': round(us, 3),
+                'note': 'neither MFMA- nor HBM-bound at this batch: four grid-wide BatchNorm exchanges over 128 workgroups '
+                        'serialise the launch (DESIGN.md sections 2 and 3.13)'}
     if cfg['kind'] == 'flowpp' and len(dims) == 1:
         K = cfg['mixtures']
         layer = pkg.MixLogAttnCoupling(dims, n_mixtures=K).to(dev)

@@ -89,7 +89,8 @@ __device__ __forceinline__ void nf_md_publish(float* sm, unsigned long long* slo
         }
     }
 }
-// thread t owns value index i = t % 128 of the workgroups b = t / 128 (mod 4): up to 8 polls in flight per trip, partial sums
+#define NF_MD_POLL 16
+// thread t owns value index i = t % 128 of the workgroups b = t / 128 (mod 4): up to 16 polls in flight per trip, partial sums
 // in workgroup order, then the four groups are added in order -- deterministic, and no gather buffer in LDS
 __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long long* slots, int round, unsigned gen) {
     float* tot = sm + NF_MD_TOT + (round & 1) * NF_MD_XW;
@@ -102,25 +103,25 @@ __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long l
     const int i = threadIdx.x & (NF_MD_XW - 1), grp = threadIdx.x >> 7;
     const unsigned long long* rs = slots + (size_t)round * NF_MAF_MAX_BLOCKS * NF_MD_XW + i;
     float acc = 0.f;
-    for (int b0 = grp; b0 < G; b0 += 4 * 8) {
-        unsigned long long v[8];
+    for (int b0 = grp; b0 < G; b0 += 4 * NF_MD_POLL) {
+        unsigned long long v[NF_MD_POLL];
         unsigned spins = 0;
         bool ok;
         do {
             ok = true;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < NF_MD_POLL; ++k) {
                 const int b = b0 + 4 * k;
                 v[k] = __hip_atomic_load(rs + (size_t)(b < G ? b : b0) * NF_MD_XW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
+            for (int k = 0; k < NF_MD_POLL; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
             if (ok) break;
             if (++spins > (1u << 22)) { atomicAdd(&nf_md_timeouts, 1u); break; }      // bounded: a mistake cannot hang the box
             __builtin_amdgcn_s_sleep(1);
         } while (true);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < NF_MD_POLL; ++k)
             if (b0 + 4 * k < G) acc += __uint_as_float((unsigned)v[k]);
     }
     sm[NF_MD_PART + threadIdx.x] = acc;
