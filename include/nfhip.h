@@ -373,6 +373,21 @@ int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, fl
                          void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
                          int training, float bn_eps, float wn_eps, nf_stream_t stream);
 
+/* ---- one whole RealNVP flow step on vector data in one persistent launch per direction (training mode) -----------------
+ * dims = (D,), D = 2 or 4: flow BatchNorm with batch statistics (modules.py:283-307, affine=False) -> affine coupling whose
+ * conditioner is the MLP of nf_mlp_chain_* (coupling.py:104-113).  head: NF_REALNVP_HEAD_PTRS pointers on the HOST: flow-BN
+ * log_gamma, beta, batch_mean, batch_var, running_mean, running_var (D each; the four buffers are updated), s_log_scale,
+ * s_bias (1).  save_stats: NF_REALNVP_SAVE_FLOATS floats.  Everything else as in nf_glow_step_vec_*.                       */
+#define NF_REALNVP_HEAD_PTRS 8
+#define NF_REALNVP_SAVE_FLOATS 328
+int nf_realnvp_step_vec_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* mlp_params,
+                            float* save_stats, float* ws_zero, int64_t N, int D, int odd, float flow_bn_eps,
+                            float flow_bn_momentum, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
+int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                            const void* const* mlp_params, const float* save_stats, float* g_s_log_scale, float* g_s_bias,
+                            void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
+                            float bn_eps, float wn_eps, nf_stream_t stream);
+
 /* ---- one whole MAF flow step on vector data in one persistent launch per direction (training mode) ------------------
  * dims = (D,), D <= 4, N <= NF_MAF_MAX_ROWS: flow BatchNorm with batch statistics (modules.py:283-307, affine=False) ->
  * z @ perm (maf.py:100) -> the MADE pair (maf.py:49-64; masks applied while the weights are staged) -> affine transform of

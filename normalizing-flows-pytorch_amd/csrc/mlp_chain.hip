@@ -60,6 +60,8 @@ struct NfGlowV {
     const float* g_y; const float* g_ld; float* g_z;                         // backward
     const float *ls, *bs, *P, *L, *U, *Lm, *Um, *sign_s, *log_s, *a, *c;     // ActNorm, PLU factors, coupling scale / shift
     float *g_ls, *g_bs, *g_L, *g_U, *g_log_s, *g_a, *g_c;
+    float *bmean, *bvar, *rmean, *rvar;                                      // flow-BatchNorm head (HEAD == 2): ls = log_gamma, bs = beta
+    float fbn_eps, fbn_mom;
     int D, odd;
 };
 static inline void nf_glow_unpack(const void* const* t, NfGlowV& h) {
@@ -81,7 +83,7 @@ static inline void nf_glow_unpack(const void* const* t, NfGlowV& h) {
 #define NF_MC_GB (NF_MC_RED + NF_MC_WAVES * 64)           // [5][64] backward: grid totals sum_g | sum_gx per BatchNorm (= g_beta | g_gamma)
 #define NF_MC_TOT (NF_MC_GB + NF_MC_NB * 64)              // [2][64] grid totals of the exchange, double buffered by round parity
 #define NF_MC_HEAD (NF_MC_TOT + 2 * 64)                   // fused Glow step: W (4 x 4), exp(log_scale) [4], bias [4], dld, a, c | L' | U' | P
-#define NF_MC_TILES (NF_MC_HEAD + 32 + 48)                  // per-wave 16 x 36 tiles: scratch | (backward) G | activation
+#define NF_MC_TILES (NF_MC_HEAD + 32 + 48 + 16)           // + [80..83] statistics centre, [84..87] additive offset of the head                  // per-wave 16 x 36 tiles: scratch | (backward) G | activation
 // the [blocks][64] gather buffer of the exchange aliases the scratch tiles when it fits in them (they are idle while it is
 // live), else it follows the last tile
 #define NF_MC_GATHER_IN_SCRATCH (NF_MLP_MAX_BLOCKS * 64 <= NF_MC_WAVES * 16 * NF_FP_ST)
@@ -332,6 +334,8 @@ __device__ __forceinline__ void nf_glow_head_phase_a(float* sm, const NfGlowV& h
         const int c = t - 16;
         sm[NF_MC_HEAD + 16 + c] = c < D ? expf(raw.v[0]) : 1.f;
         sm[NF_MC_HEAD + 20 + c] = c < D ? raw.v[1] : 0.f;
+    } else if (t >= 24 && t < 28) {
+        sm[NF_MC_HEAD + 84 + (t - 24)] = 0.f;
     } else if (t == 20) {
         sm[NF_MC_HEAD + 24] = (raw.v[0] + raw.v[1]) + (raw.v[2] + raw.v[3]);           // modules.py:249, :480
         sm[NF_MC_HEAD + 25] = raw.v[4];
@@ -353,6 +357,20 @@ __device__ __forceinline__ void nf_glow_head_phase_b(float* sm) {
         sm[NF_MC_HEAD + t] = w;
     }
 }
+// flow-BatchNorm head (RealNVP step, modules.py:283-307, affine=False) expressed in the same per-row form: bias := batch
+// mean, exp(log_scale) := sqrt(var), W := diag(exp(log_gamma)), offset := beta, per-sample log-det sum(log_gamma - log(var)/2)
+__device__ __forceinline__ void nf_fbn_head_consts(float* sm, const NfGlowV& h, int c, float mean, float var) {
+    const bool ok = c < h.D;
+    const float lg = ok ? h.ls[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[NF_MC_HEAD + 4 * c + k] = (ok && k == c) ? expf(lg) : 0.f;
+    sm[NF_MC_HEAD + 16 + c] = ok ? sqrtf(var) : 1.f;
+    sm[NF_MC_HEAD + 20 + c] = ok ? mean : 0.f;
+    sm[NF_MC_HEAD + 84 + c] = ok ? h.bs[c] : 0.f;
+    sm[NF_MC_HEAD + 28 + c] = ok ? lg - 0.5f * logf(var) : 0.f;
+    if (c == 0) { sm[NF_MC_HEAD + 25] = h.a[0]; sm[NF_MC_HEAD + 26] = h.c[0]; }
+}
+
 // zn = (z - bias) / exp(log_scale);  hh = W zn        (every lane of the row's four does this: D <= 4)
 __device__ __forceinline__ void nf_glow_head_row(const float* sm, const float (&zr)[4], float (&zn)[4], float (&hh)[4]) {
 #pragma unroll
@@ -391,19 +409,26 @@ __device__ __forceinline__ void nf_mc_load_x(const float* x, int64_t row, bool r
     }
 }
 
-template <bool GLOW>
+template <int HEAD>   // 0: the conditioner alone; 1: whole Glow step (ActNorm + 1x1 head); 2: whole RealNVP step (flow-BatchNorm head)
 __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __restrict__ x, NfMlpP p, float* __restrict__ out,
                                                                  float* save, float* stats, int64_t N, int I0, int O_out,
                                                                  int training, float eps, float mom, float wn_eps, NfGlowV h) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;     // GLOW: a fused flow step (either head)
     NF_MC_T(0);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
     const bool rv = row < N;
     float xa[8], zr[4], hh[4], rm_old = 0.f, rv_old = 0.f, ld_in = 0.f;   // issued before the staging: one memory latency
+    float frm = 0.f, frv = 0.f;
     NfGlowRaw head_raw;
+    if (FBN && threadIdx.x < 4) {
+        frm = (int)threadIdx.x < h.D ? h.rmean[threadIdx.x] : 0.f;
+        frv = (int)threadIdx.x < h.D ? h.rvar[threadIdx.x] : 1.f;
+        sm[NF_MC_HEAD + 80 + threadIdx.x] = frm;          // the centre of the shifted sums (flowbn_head.hip)
+    }
     if (GLOW) {
-        nf_glow_head_load(h, head_raw);
+        if (!FBN) nf_glow_head_load(h, head_raw);
         nf_glow_load_row(h.z, row, rv, h.D, zr);
         if (rv && g == 0) ld_in = h.ld[row];
     }
@@ -412,14 +437,52 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
         rm_old = p.rmean[threadIdx.x >> 5][threadIdx.x & 31];
         rv_old = p.rvar[threadIdx.x >> 5][threadIdx.x & 31];
     }
-    nf_mc_stage(p, sm, I0, O_out, wn_eps, GLOW ? &h : nullptr, GLOW ? &head_raw : nullptr);
+    nf_mc_stage(p, sm, I0, O_out, wn_eps, (GLOW && !FBN) ? &h : nullptr, (GLOW && !FBN) ? &head_raw : nullptr);
+    unsigned long long* slots = (unsigned long long*)stats;
+    if (FBN) {   // batch statistics of z itself: one more exchange (round NF_MC_NB), then the head constants
+        float* tile = sm + NF_MC_TILES + wid * 16 * NF_FP_ST;
+        float v8[8], c4[2][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = 0.f;
+        if (g == 0 && rv) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v8[c] = c < h.D ? zr[c] - sm[NF_MC_HEAD + 80 + c] : 0.f;
+        }
+        nf_fp_store_rows(v8, tile, c16, g);
+        nf_fp_wsync();
+        nf_fp_load_cols<2>(tile, c4, c16, g);
+        nf_fp_wsync();
+        const float s1 = nf_fp_rowsum((c4[0][0] + c4[0][1]) + (c4[0][2] + c4[0][3]));
+        const float s2 = nf_fp_rowsum(fmaf(c4[0][0], c4[0][0], fmaf(c4[0][1], c4[0][1], fmaf(c4[0][2], c4[0][2], c4[0][3] * c4[0][3]))));
+        float* red = sm + NF_MC_RED + wid * 64;
+        red[lane] = 0.f;
+        nf_fp_wsync();
+        if (g == 0 && c16 < 4) { red[c16] = s1; red[4 + c16] = s2; }
+        nf_mc_publish(sm, slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1));
+        const float* tot = nf_mc_collect(sm, NF_MC_GATHER(1), slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1));
+        if (threadIdx.x < 4) {
+            const int c = threadIdx.x;
+            const float n = (float)N, m1 = tot[c] / n;
+            const float mean = sm[NF_MC_HEAD + 80 + c] + m1;
+            const float var = fmaxf(tot[4 + c] / n - m1 * m1, 0.f) + h.fbn_eps;      // biased, eps inside (modules.py:287)
+            nf_fbn_head_consts(sm, h, c, mean, var);
+            if (blockIdx.x == 0 && c < h.D) {
+                h.bmean[c] = mean; h.bvar[c] = var;
+                h.rmean[c] = frm * (1.f - h.fbn_mom) + mean * h.fbn_mom;             // modules.py:291-294
+                h.rvar[c] = frv * (1.f - h.fbn_mom) + var * h.fbn_mom;
+                save[2 * NF_MC_NB * 32 + c] = mean; save[2 * NF_MC_NB * 32 + 4 + c] = var;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sm[NF_MC_HEAD + 24] = (sm[NF_MC_HEAD + 28] + sm[NF_MC_HEAD + 29]) + (sm[NF_MC_HEAD + 30] + sm[NF_MC_HEAD + 31]);
+        __syncthreads();
+    }
     if (GLOW) {
         float zn[4];
         nf_glow_head_row(sm, zr, zn, hh);
         nf_glow_cond_input(hh, h.D, h.odd, xa, g);
     }
     NF_MC_T(1);
-    unsigned long long* slots = (unsigned long long*)stats;
     if (!training) {
         if (threadIdx.x < NF_MC_NB * 32) {
             const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
@@ -513,11 +576,11 @@ extern "C" int nf_mlp_chain_fwd(const float* x, const void* const* params, float
     const size_t lds = nf_mc_lds_bytes(1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_chain_fwd<false>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, out, save_stats,
+    hipLaunchKernelGGL(k_mlp_chain_fwd<0>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, out, save_stats,
                        ws_zero, N, I0, O_out, training, bn_eps, bn_momentum, wn_eps, NfGlowV{});
     NF_CHECK_LAUNCH();
     return 0;
@@ -701,12 +764,13 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
     }
 }
 
-template <bool GLOW>
+template <int HEAD>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __restrict__ x, NfMlpP p, const float* __restrict__ save,
                                                                  const float* __restrict__ g_out, float* __restrict__ g_x, NfMlpG gr,
                                                                  int accumulate, float* ws, float* __restrict__ slabs, int64_t N,
                                                                  int I0, int O_out, int training, float eps, float wn_eps, NfGlowV h) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;
     NF_MC_T(64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
@@ -714,8 +778,13 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
     float xa[8], a[NF_MC_NB][8], G[8], Gs[8];
     float zr[4], gy[4], gld = 0.f;                        // fused Glow step: this row of z and of the incoming gradients
     NfGlowRaw head_raw;
+    float fm = 0.f, fv = 1.f;
+    if (FBN && threadIdx.x < 4) {
+        fm = (int)threadIdx.x < h.D ? save[2 * NF_MC_NB * 32 + threadIdx.x] : 0.f;
+        fv = (int)threadIdx.x < h.D ? save[2 * NF_MC_NB * 32 + 4 + threadIdx.x] : 1.f;
+    }
     if (GLOW) {
-        nf_glow_head_load(h, head_raw);
+        if (!FBN) nf_glow_head_load(h, head_raw);
         nf_glow_load_row(h.z, row, rv, h.D, zr);
         nf_glow_load_row(h.g_y, row, rv, h.D, gy);
         if (h.g_ld != nullptr && rv) gld = h.g_ld[row];
@@ -737,9 +806,10 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         bn_mean = training ? save[(2 * j + 0) * 32 + k] : p.rmean[j][k];
         bn_invstd = training ? save[(2 * j + 1) * 32 + k] : 1.f / sqrtf(p.rvar[j][k] + eps);
     }
-    nf_mc_stage(p, sm, I0, O_out, wn_eps, GLOW ? &h : nullptr, GLOW ? &head_raw : nullptr);
+    nf_mc_stage(p, sm, I0, O_out, wn_eps, (GLOW && !FBN) ? &h : nullptr, (GLOW && !FBN) ? &head_raw : nullptr);
     NF_MC_T(65);
     if (threadIdx.x < NF_MC_NB * 32) nf_mc_batchnorm_consts(sm, threadIdx.x >> 5, bn_mean, bn_invstd);
+    if (FBN && threadIdx.x < 4) nf_fbn_head_consts(sm, h, threadIdx.x, fm, fv);
     __syncthreads();
     float zn[4], hh[4];
     if (GLOW) {
@@ -942,6 +1012,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         const float sum_gld = hs[28];
         h.g_a[0] = (accumulate ? h.g_a[0] : 0.f) + hs[26] + hs[27];                  // d/d s_log_scale: sum g_s tanh(s_raw)
         h.g_c[0] = (accumulate ? h.g_c[0] : 0.f) + hs[24] + hs[25];                  // d/d s_bias
+        if (!FBN) {
         const float* Lp = sm + NF_MC_HEAD + 32;                  // [4][4] each, staged at kernel start
         const float* Up = sm + NF_MC_HEAD + 48;
         const float* Pm = sm + NF_MC_HEAD + 64;
@@ -977,6 +1048,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
                     if (r == c) h.g_log_s[r] = (accumulate ? h.g_log_s[r] : 0.f) + gu * Up[r * 4 + r] + sum_gld;
                 }
             }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
         const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
@@ -1002,11 +1074,11 @@ extern "C" int nf_mlp_chain_bwd(const float* x, const void* const* params, const
     const size_t lds = nf_mc_lds_bytes(3);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_chain_bwd<false>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, save_stats, g_out,
+    hipLaunchKernelGGL(k_mlp_chain_bwd<0>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, save_stats, g_out,
                        g_x, g, accumulate, ws_zero, slabs, N, I0, O_out, training, bn_eps, wn_eps, NfGlowV{});
     NF_CHECK_LAUNCH();
     return 0;
@@ -1032,11 +1104,11 @@ extern "C" int nf_glow_step_vec_fwd(const float* z, float* y, float* ld, const v
     const size_t lds = nf_mc_lds_bytes(1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_chain_fwd<true>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+    hipLaunchKernelGGL(k_mlp_chain_fwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
                        (float*)nullptr, save_stats, ws_zero, N, D / 2, D, training, bn_eps, bn_momentum, wn_eps, h);
     NF_CHECK_LAUNCH();
     return 0;
@@ -1064,11 +1136,11 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
     const size_t lds = nf_mc_lds_bytes(3);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_mlp_chain_bwd<true>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+    hipLaunchKernelGGL(k_mlp_chain_bwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
                        save_stats, (const float*)nullptr, (float*)nullptr, g, accumulate, ws_zero, slabs, N, D / 2, D, training, bn_eps,
                        wn_eps, h);
     NF_CHECK_LAUNCH();
@@ -1077,6 +1149,70 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
 
 // number of bounded spin loops that gave up since the library was loaded (0 unless a persistent grid was not co-resident:
 // results of such a launch are garbage).  Synchronises the device.
+// ---------------------------------------------------------------------------------------------------------------
+// the fused vector RealNVP step: flow BatchNorm (batch statistics) -> affine coupling (MLP conditioner), HEAD == 2
+// ---------------------------------------------------------------------------------------------------------------
+static void nf_fbn_unpack(const void* const* t, NfGlowV& h) {
+    h.ls = (const float*)t[0]; h.bs = (const float*)t[1]; h.bmean = (float*)t[2]; h.bvar = (float*)t[3];
+    h.rmean = (float*)t[4]; h.rvar = (float*)t[5]; h.a = (const float*)t[6]; h.c = (const float*)t[7];
+}
+
+extern "C" int nf_realnvp_step_vec_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* mlp_params,
+                                       float* save_stats, float* ws_zero, int64_t N, int D, int odd, float flow_bn_eps,
+                                       float flow_bn_momentum, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream) {
+    if (z == nullptr || y == nullptr || ld == nullptr || head == nullptr || mlp_params == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMlpP p;
+    nf_mlp_unpack(mlp_params, p);
+    NfGlowV h{};
+    nf_fbn_unpack(head, h);
+    h.z = z; h.y = y; h.ld = ld; h.D = D; h.odd = odd ? 1 : 0; h.fbn_eps = flow_bn_eps; h.fbn_mom = flow_bn_momentum;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_chain_fwd<2>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+                       (float*)nullptr, save_stats, ws_zero, N, D / 2, D, 1, bn_eps, bn_momentum, wn_eps, h);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                                       const void* const* mlp_params, const float* save_stats, float* g_s_log_scale,
+                                       float* g_s_bias, void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs,
+                                       int64_t N, int D, int odd, float bn_eps, float wn_eps, nf_stream_t stream) {
+    if (z == nullptr || g_y == nullptr || g_z == nullptr || head == nullptr || mlp_params == nullptr || g_s_log_scale == nullptr ||
+        g_s_bias == nullptr || mlp_grads == nullptr || ws_zero == nullptr || slabs == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMlpP p;
+    nf_mlp_unpack(mlp_params, p);
+    NfMlpG g;
+    for (int l = 0; l < NF_MC_NL; ++l) { g.v[l] = (float*)mlp_grads[3 * l]; g.g[l] = (float*)mlp_grads[3 * l + 1]; g.b[l] = (float*)mlp_grads[3 * l + 2]; }
+    for (int j = 0; j < NF_MC_NB; ++j) { g.gamma[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j]; g.beta[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j + 1]; }
+    NfGlowV h{};
+    nf_fbn_unpack(head, h);
+    h.z = z; h.g_y = g_y; h.g_ld = g_ld; h.g_z = g_z; h.D = D; h.odd = odd ? 1 : 0; h.g_a = g_s_log_scale; h.g_c = g_s_bias;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlp_chain_bwd<2>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+                       save_stats, (const float*)nullptr, (float*)nullptr, g, accumulate, ws_zero, slabs, N, D / 2, D, 1, bn_eps,
+                       wn_eps, h);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
 __attribute__((visibility("hidden"))) int nf_made_timeouts_read(unsigned* v);      // made_chain.hip
 
 extern "C" int nf_persistent_timeouts(int* count) {

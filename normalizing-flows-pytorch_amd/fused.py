@@ -811,3 +811,70 @@ def maf_step_vec(z, ld, bn, ar):
     head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, ar.perm, ar.s_log_scale,
             ar.s_bias]
     return _MAFStepVec.apply(z, _owned_ld(ld), bn.eps, bn.momentum, *(head + _made_tensors(ar.net_s, ms) + _made_tensors(ar.net_t, mt)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one whole RealNVP flow step on vector data: flow BatchNorm (batch statistics) -> affine coupling with the MLP conditioner
+# ----------------------------------------------------------------------------------------------------------------------
+def realnvp_step_vec_usable(z, bn, mlp):
+    return (glow_step_vec_usable(z, mlp) and bn.training and mlp.training and z.shape[0] > 1)
+
+
+class _RealNVPStepVec(torch.autograd.Function):
+    """head: flow-BN log_gamma, beta, batch_mean, batch_var, running_mean, running_var, s_log_scale, s_bias; then the 43 MLP
+    tensors."""
+
+    @staticmethod
+    def forward(ctx, z, ld, odd, bn_eps, bn_momentum, *tensors):
+        head, mlp = tensors[:8], tensors[8:]
+        z = z.contiguous()
+        Nrows, D = z.shape
+        y = torch.empty_like(z)
+        save = torch.empty(N.header_constant('NF_REALNVP_SAVE_FLOATS'), dtype=torch.float32, device=z.device)
+        ws = WS.zeros(N.header_constant('NF_MLP_WS_FLOATS'), z.device)
+        htab, mtab = _ptr_table(head), _ptr_table(mlp)
+        N.call('nf_realnvp_step_vec_fwd', N.ptr(z), N.ptr(y), N.ptr(ld), ctypes.addressof(htab), ctypes.addressof(mtab),
+               N.ptr(save), N.ptr(ws), Nrows, D, int(odd), float(bn_eps), float(bn_momentum), BN_EPS, BN_MOMENTUM, WN_EPS,
+               N.stream())
+        ctx.save_for_backward(z, save, *tensors)
+        ctx.odd = int(odd)
+        from .functional import _sinks
+        nl, nb = 6, 5
+        learn = [head[6], head[7]] + list(mlp[:3 * nl]) + [t for j in range(nb) for t in mlp[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+        ctx.sinks = _sinks(*learn)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        nl, nb = 6, 5
+        z, save, *tensors = ctx.saved_tensors
+        head, mlp = tensors[:8], tensors[8:]
+        Nrows, D = z.shape
+        dev = z.device
+        g_y = g_y.contiguous()
+        g_ld = None if g_ld is None else g_ld.contiguous()
+        learn = [head[6], head[7]] + list(mlp[:3 * nl]) + [t for j in range(nb) for t in mlp[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+        direct = ctx.sinks is not None
+        dst = ctx.sinks if direct else [torch.empty_like(t) for t in learn]
+        g_z = torch.empty_like(z)
+        ws = WS.zeros(N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        htab, mtab, mg = _ptr_table(head), _ptr_table(mlp), _ptr_table(dst[2:])
+        N.call('nf_realnvp_step_vec_bwd', N.ptr(z), N.ptr(g_y), _p(g_ld), N.ptr(g_z), ctypes.addressof(htab),
+               ctypes.addressof(mtab), N.ptr(save), N.ptr(dst[0]), N.ptr(dst[1]), ctypes.addressof(mg), int(direct), N.ptr(ws),
+               N.ptr(_mlp_slabs(dev)), Nrows, D, ctx.odd, BN_EPS, WN_EPS, N.stream())
+        if direct:
+            return (g_z, g_ld, None, None, None) + (None, ) * len(tensors)
+        gh = [None] * 6 + [dst[0], dst[1]]
+        gm = list(dst[2:2 + 3 * nl])
+        for j in range(nb):
+            gm += [dst[2 + 3 * nl + 2 * j], dst[2 + 3 * nl + 2 * j + 1], None, None, None]
+        return (g_z, g_ld, None, None, None) + tuple(gh) + tuple(gm)
+
+
+def realnvp_step_vec(z, ld, bn, coupling):
+    """[flow BatchNorm ``bn`` (training, affine=False), AffineCoupling ``coupling``] on (N, D) data, fused."""
+    from .functional import _owned_ld
+    head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, coupling.s_log_scale,
+            coupling.s_bias]
+    return _RealNVPStepVec.apply(z, _owned_ld(ld), int(coupling.odd), bn.eps, bn.momentum, *(head + _mlp_tensors(coupling.net)))

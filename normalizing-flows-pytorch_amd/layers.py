@@ -66,7 +66,10 @@ class Compose(nn.Module):
         while i < n:
             if self._bn_step_at(i, z):
                 a, k = L[i], L[i + 1]
-                if type(k) is AffineCoupling:
+                if (type(k) is AffineCoupling and k.mode == N.SPLIT_1D and isinstance(k.net, MLP)
+                        and FUSED.realnvp_step_vec_usable(z, a, k.net)):
+                    z, log_df_dz = FUSED.realnvp_step_vec(z, log_df_dz, a, k)        # the whole step: one launch
+                elif type(k) is AffineCoupling:
                     h, z1c, log_df_dz = NF.flowbn_head(z, log_df_dz, a, k.mode, k.odd, gather=True)
                     z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
                 elif FUSED.maf_step_usable(z, a, k):

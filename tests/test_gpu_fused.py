@@ -369,3 +369,63 @@ def test_maf_step_vec_vs_unfused(pkg, D, N, direct):
     b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
     for name in b1:
         G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+
+
+@pytest.mark.parametrize('direct', [False, True])
+@pytest.mark.parametrize('D,odd,N', [(2, False, 256), (2, True, 300), (4, False, 1000), (4, True, 77), (2, False, 4096)])
+def test_realnvp_step_vec_vs_unfused(pkg, D, odd, N, direct):
+    """the one-launch RealNVP step (flow BatchNorm -> affine coupling + MLP) against the path it replaces."""
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+
+    def make():
+        torch.manual_seed(D * 13 + int(odd))
+        bn, k = pkg.BatchNorm((D, ), affine=False), pkg.AffineCoupling((D, ), odd=odd)
+        mods = torch.nn.ModuleList([bn, k]).to(DEV)
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.2)
+            bn.running_var.uniform_(0.5, 2.0)
+            k.s_log_scale.fill_(0.7)
+            k.s_bias.fill_(0.1)
+            for m in k.net.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.3)
+                    m.running_mean.normal_(0, 0.2)
+                    m.running_var.uniform_(0.5, 2.0)
+        mods.train(True)
+        return bn, k, mods
+
+    bn1, k1, m1 = make()
+    bn2, k2, m2 = make()
+    g = torch.Generator().manual_seed(N + D)
+    z = (torch.randn(N, D, generator=g) * 0.8 + 0.2).to(DEV)
+    gy = torch.randn(N, D, generator=g).to(DEV)
+    wl = torch.randn(N, generator=g).to(DEV)
+    ld0 = torch.randn(N, generator=g).to(DEV)
+    z1, z2 = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+    h, zc, ld1 = NF.flowbn_head(z1, ld0.clone(), bn1, k1.mode, k1.odd, gather=True)
+    y1, ld1 = NF.affine_coupling(h, fused.mlp_forward(k1.net, zc, chain=False), k1.s_log_scale, k1.s_bias, ld1, k1.mode, k1.odd)
+    ((y1 * gy).sum() + (ld1 * wl).sum()).backward()
+    if direct:
+        for p in m2.parameters():
+            if p.requires_grad:
+                p.grad = torch.zeros_like(p)
+                p._nf_direct_grad = True
+    assert fused.realnvp_step_vec_usable(z2, bn2, k2.net)
+    y2, ld2 = fused.realnvp_step_vec(z2, ld0.clone(), bn2, k2)
+    G.assert_close(y2, y1, 2e-5, rtol=2e-5, what='y')
+    G.assert_close(ld2, ld1, 2e-5, rtol=2e-5, what='log-det')
+    ((y2 * gy).sum() + (ld2 * wl).sum()).backward()
+    G.assert_close(z2.grad, z1.grad, _grad_tol(z1.grad), what='grad z')
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    for name, p in p1.items():
+        if not p.requires_grad:
+            continue
+        assert p2[name].grad is not None, name
+        pre_bn_bias = name.endswith('module.bias') and 'out_block' not in name
+        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(p.grad)
+        G.assert_close(p2[name].grad, p.grad, tol, what='grad ' + name)
+    b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
+    for name in b1:
+        G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
