@@ -97,6 +97,15 @@ def graph_time_us(fn, dev, per_graph=50, replays=10):
     return start.elapsed_time(stop) * 1e3 / (per_graph * replays)
 
 
+def pmc_traffic(kernel, B):
+    """HBM bytes per launch of `kernel` at batch B from the committed rocprofv3 PMC passes (profiles/r01_pmc.json), or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')) as f:
+            return json.load(f).get(kernel, {}).get(str(B), {}).get('traffic_bytes')
+    except (OSError, ValueError):
+        return None
+
+
 def dominant_kernel_roofline(pkg, cfg, B, dev):
     """roofline of the kernel that dominates the timed region (rocprofv3 summaries under profiles/):
       c1 / c2 -> k_mlp_chain_bwd, the one-launch backward of the whole MLP conditioner (six 32-wide linears, five
@@ -112,39 +121,62 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
     g = torch.Generator(device='cpu').manual_seed(7)
     extra = {}
     MFMA_F32_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
-    if cfg['kind'] in ('glow', 'realnvp') and len(dims) == 1 and B <= N.header_constant('NF_MLP_MAX_ROWS'):
-        cond = importlib.import_module(PKG + '.conditioners')
-        i0 = dims[0] // 2
-        mlp = cond.MLP(i0, 2 * (dims[0] - i0)).to(dev).train()
-        ts = F._mlp_tensors(mlp)
-        x = torch.randn(B, i0, generator=g).to(dev)
-        gout = torch.randn(B, 2 * (dims[0] - i0), generator=g).to(dev)
-        with torch.no_grad():
-            _, save = F.mlp_chain_forward_nograd(mlp, x, True)
-        gx = torch.empty_like(x)
-        learn = list(ts[:18]) + [t for j in range(5) for t in ts[18 + 5 * j:18 + 5 * j + 2]]
-        dst = [torch.zeros_like(t) for t in learn]
-        tab, gtab = F._ptr_table([t.detach() for t in ts]), F._ptr_table(dst)
-        slabs = F._mlp_slabs(dev)
+    if cfg['kind'] in ('glow', 'realnvp') and len(dims) == 1 and dims[0] in (2, 4) and B <= N.header_constant('NF_MLP_MAX_ROWS'):
+        D = dims[0]
+        glow = cfg['kind'] == 'glow'
+        k = pkg.AffineCoupling((D, )).to(dev).train()
+        if glow:
+            a, c = pkg.ActNorm((D, )).to(dev), pkg.InvertibleConv1x1(D).to(dev)
+            a.initialized = True
+            head = [a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale, k.s_bias]
+            lh = [head[0], head[1], head[3], head[4], head[8], head[9], head[10]]
+        else:
+            bn = pkg.BatchNorm((D, ), affine=False).to(dev).train()
+            head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, k.s_log_scale, k.s_bias]
+            lh = [head[6], head[7]]
+        mts = F._mlp_tensors(k.net)
+        lm = list(mts[:18]) + [t for j in range(5) for t in mts[18 + 5 * j:18 + 5 * j + 2]]
+        dh, dm = [torch.zeros_like(t) for t in lh], [torch.zeros_like(t) for t in lm]
+        htab, mtab = F._ptr_table([t.detach() for t in head]), F._ptr_table([t.detach() for t in mts])
+        hg, mg = F._ptr_table(dh), F._ptr_table(dm)
+        z = torch.randn(B, D, generator=g).to(dev)
+        gy = torch.randn(B, D, generator=g).to(dev)
+        y, ld, gz = torch.empty_like(z), torch.zeros(B, device=dev), torch.empty_like(z)
         nws = N.header_constant('NF_MLP_WS_FLOATS')
-        wss = torch.zeros(64, nws, device=dev)                  # a fresh zero workspace per launch inside the timing graph
+        save = torch.empty(N.header_constant('NF_REALNVP_SAVE_FLOATS'), device=dev)
+        ws0 = torch.zeros(nws, device=dev)
+        st = N.stream()
+        if glow:
+            N.call('nf_glow_step_vec_fwd', z.data_ptr(), y.data_ptr(), ld.data_ptr(), ctypes.addressof(htab), ctypes.addressof(mtab),
+                   save.data_ptr(), ws0.data_ptr(), B, D, 0, 1, 1.0e-5, 0.1, 1.0e-5, st)
+        else:
+            N.call('nf_realnvp_step_vec_fwd', z.data_ptr(), y.data_ptr(), ld.data_ptr(), ctypes.addressof(htab),
+                   ctypes.addressof(mtab), save.data_ptr(), ws0.data_ptr(), B, D, 0, 1.0e-5, 0.1, 1.0e-5, 0.1, 1.0e-5, st)
+        slabs = F._mlp_slabs(dev)
+        wss = torch.zeros(50, nws, device=dev)                  # a fresh zero workspace per launch inside the timing graph
         it = [0]
 
         def fn():
-            ws = wss[it[0] % 64]
+            ws = wss[it[0] % 50]
             it[0] += 1
-            N.call('nf_mlp_chain_bwd', x.data_ptr(), ctypes.addressof(tab), save.data_ptr(), gout.data_ptr(), gx.data_ptr(),
-                   ctypes.addressof(gtab), 1, ws.data_ptr(), slabs.data_ptr(), B, i0, gout.shape[1], 1, 1.0e-5, 1.0e-5,
-                   N.stream())
+            if glow:
+                N.call('nf_glow_step_vec_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
+                       ctypes.addressof(mtab), save.data_ptr(), ctypes.addressof(hg), ctypes.addressof(mg), 1, ws.data_ptr(),
+                       slabs.data_ptr(), B, D, 0, 1, 1.0e-5, 1.0e-5, N.stream())
+            else:
+                N.call('nf_realnvp_step_vec_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
+                       ctypes.addressof(mtab), save.data_ptr(), dh[0].data_ptr(), dh[1].data_ptr(), ctypes.addressof(mg), 1,
+                       ws.data_ptr(), slabs.data_ptr(), B, D, 0, 1.0e-5, 1.0e-5, N.stream())
         us = graph_time_us(fn, dev, per_graph=50, replays=1)     # 50 launches = 50 distinct zero workspaces, one replay
         flop = 17 * 2 * 32 * 32 * B                              # 5 recomputed + 6 data-gradient + 6 weight-gradient 32x32 products
         tf = flop / (us * 1e-6) / 1e12
-        return {'bound': 'mfma', 'kernel': 'k_mlp_chain_bwd (whole MLP conditioner, one launch)', 'achieved': round(tf, 3),
-                'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': None,
-                'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (2 * i0 + gout.shape[1]) * 4),
-                'us_per_launch': round(us, 3),
-                'note': 'neither MFMA- nor HBM-bound at this batch: five grid-wide BatchNorm exchanges (~2.3 us each) + '
-                        'a grid barrier serialise the launch (DESIGN.md section 2; tools/probes/mlp_chain_prof.py)'}
+        name = 'k_mlp_chain_bwd<%d> (whole %s flow step, one launch)' % (1 if glow else 2, 'Glow' if glow else 'RealNVP')
+        return {'bound': 'mfma', 'kernel': name, 'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': pmc_traffic('k_mlp_chain_bwd', B),
+                'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (3 * D + 1) * 4), 'us_per_launch': round(us, 3),
+                'note': 'neither MFMA- nor HBM-bound at this batch: six grid-wide exchanges (five BatchNorm reductions + the fenced '
+                        'barrier in front of the fold, ~1.6 us each at 32 workgroups) and single-tile issue latency serialise the '
+                        'launch (DESIGN.md section 2; tools/probes/mlp_chain_prof.py)'}
     if cfg['kind'] == 'maf' and len(dims) == 1 and dims[0] <= 4 and B <= N.header_constant('NF_MAF_MAX_ROWS'):
         D = dims[0]
         bn = pkg.BatchNorm((D, ), affine=False).to(dev).train()
@@ -183,7 +215,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         flop = 2 * mac * B
         tf = flop / (us * 1e-6) / 1e12
         return {'bound': 'mfma', 'kernel': 'k_maf_step_bwd (whole MAF flow step, one launch)', 'achieved': round(tf, 3),
-                'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': None,
+                'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': pmc_traffic('k_maf_step_bwd', B),
                 'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (3 * D + 1) * 4), 'us_per_launch': round(us, 3),
                 'note': 'neither MFMA- nor HBM-bound at this batch: four grid-wide BatchNorm exchanges over 128 workgroups '
                         'serialise the launch (DESIGN.md sections 2 and 3.13)'}
@@ -212,7 +244,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         tf = flop / (us * 1e-6) / 1e12
         return {'bound': 'mfma', 'kernel': 'k_flowpp_cond_bwd + k_flowpp_cond_finalize (gated-attention conditioner)',
                 'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
-                'traffic': None, 'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (2 * I0 + O) * 4),
+                'traffic': pmc_traffic('k_flowpp_cond_bwd', B), 'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (2 * I0 + O) * 4),
                 'us_per_launch': round(us, 3),
                 'note': 'fp32-input MFMA (exact fp32, 1/16 of the bf16 rate); the rest is transcendental VALU work and the '
                         'LDS transposes of the weight-gradient operands (DESIGN.md section 3)'}

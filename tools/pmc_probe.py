@@ -26,7 +26,7 @@ def summarise(paths):
             a[1] += float(r['Counter_Value'])
     print('%-60s %-12s %-10s %8s %14s' % ('kernel', 'counter', 'grid', 'calls', 'avg value'))
     for (k, c, g), (n, v) in sorted(agg.items()):
-        if k.startswith('k_') or 'copy' in k.lower() or 'void k_' in k or 'k_mlp' in k or 'k_flowpp' in k:
+        if k.startswith('k_') or 'copy' in k.lower() or 'void k_' in k or 'k_mlp' in k or 'k_flowpp' in k or 'k_maf' in k:
             print('%-60s %-12s %-10s %8d %14.2f' % (k, c, g, n, v / n))
 
 
@@ -65,24 +65,58 @@ def main():
             N.call('nf_affine_coupling_fwd', z.data_ptr(), params.data_ptr(), params.data_ptr() + 4, 2, a.data_ptr(),
                    c.data_ptr(), yv.data_ptr(), ld.data_ptr(), 0, 0, 0, B, 2, 1, 1, N.stream())
         torch.cuda.synchronize()
-    # the persistent MLP backward (dominant kernel of C1 / C2) at the bench shape, and the Flow++ conditioner backward (C3)
+    # the persistent flow-step backward kernels (dominant kernels of C2 and C5) at the bench shapes, and the Flow++
+    # conditioner backward (C3)
     import ctypes
-    cond = importlib.import_module('normalizing-flows-pytorch_amd.conditioners')
+    dv = torch.device(dev, 0)
     for Nr, reps in ((4096, 20), ):
-        mlp = cond.MLP(1, 2).to(dev).train()
-        ts = F._mlp_tensors(mlp)
-        xin, gout = torch.randn(Nr, 1, device=dev), torch.randn(Nr, 2, device=dev)
-        with torch.no_grad():
-            _, save = F.mlp_chain_forward_nograd(mlp, xin, True)
-        gx = torch.empty_like(xin)
-        learn = list(ts[:18]) + [t for j in range(5) for t in ts[18 + 5 * j:18 + 5 * j + 2]]
-        dst = [torch.zeros_like(t) for t in learn]
-        tab, gtab = F._ptr_table([t.detach() for t in ts]), F._ptr_table(dst)
-        slabs = F._mlp_slabs(torch.device(dev, 0))
+        D = 2
+        a, c, k = pkg.ActNorm((D, )).to(dev), pkg.InvertibleConv1x1(D).to(dev), pkg.AffineCoupling((D, )).to(dev).train()
+        head = [a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale, k.s_bias]
+        mts = F._mlp_tensors(k.net)
+        lh = [head[0], head[1], head[3], head[4], head[8], head[9], head[10]]
+        lm = list(mts[:18]) + [t for j in range(5) for t in mts[18 + 5 * j:18 + 5 * j + 2]]
+        dh, dm = [torch.zeros_like(t) for t in lh], [torch.zeros_like(t) for t in lm]
+        htab, mtab = F._ptr_table([t.detach() for t in head]), F._ptr_table([t.detach() for t in mts])
+        hg, mg = F._ptr_table(dh), F._ptr_table(dm)
+        z, gy = torch.randn(Nr, D, device=dev), torch.randn(Nr, D, device=dev)
+        y, ld, gz = torch.empty_like(z), torch.zeros(Nr, device=dev), torch.empty_like(z)
+        save = torch.empty(N.header_constant('NF_REALNVP_SAVE_FLOATS'), device=dev)
+        nws = N.header_constant('NF_MLP_WS_FLOATS')
+        N.call('nf_glow_step_vec_fwd', z.data_ptr(), y.data_ptr(), ld.data_ptr(), ctypes.addressof(htab), ctypes.addressof(mtab),
+               save.data_ptr(), torch.zeros(nws, device=dev).data_ptr(), Nr, D, 0, 1, 1.0e-5, 0.1, 1.0e-5, N.stream())
+        slabs = F._mlp_slabs(dv)
         for _ in range(reps):
-            ws = torch.zeros(N.header_constant('NF_MLP_WS_FLOATS'), device=dev)
-            N.call('nf_mlp_chain_bwd', xin.data_ptr(), ctypes.addressof(tab), save.data_ptr(), gout.data_ptr(), gx.data_ptr(),
-                   ctypes.addressof(gtab), 1, ws.data_ptr(), slabs.data_ptr(), Nr, 1, 2, 1, 1.0e-5, 1.0e-5, N.stream())
+            ws = torch.zeros(nws, device=dev)
+            N.call('nf_glow_step_vec_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
+                   ctypes.addressof(mtab), save.data_ptr(), ctypes.addressof(hg), ctypes.addressof(mg), 1, ws.data_ptr(),
+                   slabs.data_ptr(), Nr, D, 0, 1, 1.0e-5, 1.0e-5, N.stream())
+        torch.cuda.synchronize()
+    for Nr, reps in ((16384, 20), ):
+        D = 2
+        bn = pkg.BatchNorm((D, ), affine=False).to(dev).train()
+        ar = pkg.AutoregressiveTransfrom(D).to(dev).train()
+        ms, mt = ar.net_s.draw_masks(dv), ar.net_t.draw_masks(dv)
+        head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, ar.perm, ar.s_log_scale,
+                ar.s_bias]
+        made = F._made_tensors(ar.net_s, ms) + F._made_tensors(ar.net_t, mt)
+        z, gy = torch.randn(Nr, D, device=dev), torch.randn(Nr, D, device=dev)
+        y, ld, gz = torch.empty_like(z), torch.zeros(Nr, device=dev), torch.empty_like(z)
+        save = torch.empty(N.header_constant('NF_MAF_SAVE_FLOATS'), device=dev)
+        htab, mtab = F._ptr_table([t.detach() for t in head]), F._ptr_table([t.detach() for t in made])
+        nws = N.header_constant('NF_MAF_WS_FLOATS')
+        N.call('nf_maf_step_fwd', z.data_ptr(), y.data_ptr(), ld.data_ptr(), ctypes.addressof(htab), ctypes.addressof(mtab),
+               save.data_ptr(), torch.zeros(nws, device=dev).data_ptr(), Nr, D, 1.0e-5, 0.1, 1.0e-5, N.stream())
+        learn = F._made_learnables(made[:27]) + F._made_learnables(made[27:])
+        dst = [torch.zeros_like(t) for t in learn]
+        gtab = F._ptr_table(dst)
+        ga, gc = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        slabs = F._maf_slabs(dv)
+        for _ in range(reps):
+            ws = torch.zeros(nws, device=dev)
+            N.call('nf_maf_step_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
+                   ctypes.addressof(mtab), save.data_ptr(), ctypes.addressof(gtab), ga.data_ptr(), gc.data_ptr(), ws.data_ptr(),
+                   slabs.data_ptr(), Nr, D, N.stream())
         torch.cuda.synchronize()
     for Nr, reps in ((65536, 10), ):
         layer = pkg.MixLogAttnCoupling((2, ), n_mixtures=8).to(dev)
@@ -94,7 +128,7 @@ def main():
         d = [t.data_ptr() for t in dst]
         d[7] += 4 * 2 * F_ * 32
         d[8] += 4 * 2 * F_
-        wsb = F.flowpp_bwd_workspace(torch.device(dev, 0))
+        wsb = F.flowpp_bwd_workspace(dv)
         args = F._flowpp_fwd_args(ts, F_)
         for _ in range(reps):
             N.call('nf_flowpp_cond_bwd', xin.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), 1, 1, 1, 1, 0, Nr, 1, O,
