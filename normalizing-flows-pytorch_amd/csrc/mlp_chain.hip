@@ -959,52 +959,16 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
                 pre[k] = t4;
             }
         }
-        if (G_ <= 2) {   // few workgroups: every half wave owns several units -- run their reductions interleaved, not in sequence
-            float ts[NU1], vv[NU1], n2[NU1], dt[NU1];
-#pragma unroll
-            for (int k = 0; k < NU1; ++k) {
-                const int u = blockIdx.x * HW + (threadIdx.x >> 5) + k * G_ * HW;
-                const int uu = u < NF_MC_NL * 33 ? u : 0;
-                const int l = uu / 33, i = uu - l * 33;
-                ts[k] = pre[k];
-                vv[k] = i < 32 ? sm[NF_MC_W + l * 32 * NF_FP_ST + o * NF_FP_ST + i] : 0.f;
-                n2[k] = vv[k] * vv[k];
-                dt[k] = ts[k] * vv[k];
-            }
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1)
-#pragma unroll
-                for (int k = 0; k < NU1; ++k) {
-                    n2[k] += __shfl_xor(n2[k], off, NF_WAVE);
-                    dt[k] += __shfl_xor(dt[k], off, NF_WAVE);
-                }
-#pragma unroll
-            for (int k = 0; k < NU1; ++k) {
-                const int u = blockIdx.x * HW + (threadIdx.x >> 5) + k * G_ * HW;
-                if (u >= NF_MC_NL * 33) continue;
-                const int l = u / 33, i = u - l * 33;
-                const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
-                if (i == 32) {
-                    if (o < O) gr.b[l][o] = (accumulate ? gr.b[l][o] : 0.f) + ts[k];
-                    continue;
-                }
-                if (i >= I) continue;
-                const float nrm = sqrtf(n2[k]), den = nrm + wn_eps, gi = sm[NF_MC_G + l * 32 + i];
-                if (o < O) {
-                    float gv = ts[k] * (gi / den);
-                    if (nrm > 0.f) gv -= vv[k] * (dt[k] * gi / (den * den * nrm));
-                    float* dst = gr.v[l] + o * I + i;
-                    *dst = (accumulate ? *dst : 0.f) + gv;
-                }
-                if (o == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + dt[k] / den;
-            }
-        }
-        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); G_ > 2 && u < NF_MC_NL * 33; u += G_ * HW) {
+        int kk = 0;
+        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33; u += G_ * HW, ++kk) {
             const int l = u / 33, i = u - l * 33;                    // i == 32: the bias
             const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
             if (i < 32 && i >= I) continue;                          // half-wave uniform
             float tsum = 0.f;
-            {
+            if (G_ <= 2) {
+#pragma unroll
+                for (int k = 0; k < NU1; ++k) tsum = k == kk ? pre[k] : tsum;
+            } else {
                 const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
                 for (int b0 = 0; b0 < G_; b0 += 8) {                 // 8 NKQ independent loads in flight: one latency per trip
                     float v[8][NF_MC_NKQ];
