@@ -941,34 +941,60 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
         const int o = threadIdx.x & 31;
         const int G_ = gridDim.x;
         constexpr int HW = NF_MC_THREADS / 32;                       // half waves per workgroup
-        constexpr int NU1 = (NF_MC_NL * 33 + HW - 1) / HW;           // units per half wave when there is one workgroup
-        float pre[NU1];
-        if (G_ <= 2) {                                               // all of this half wave's partials in flight at once
-#pragma unroll
-            for (int k = 0; k < NU1; ++k) {
-                const int u = blockIdx.x * HW + (threadIdx.x >> 5) + k * G_ * HW;
-                const int uu = u < NF_MC_NL * 33 ? u : 0;
-                const int l = uu / 33, i = uu - l * 33;
-                const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
+        if (G_ <= 2) {   // one or two workgroups: too few half waves for the column scheme -- whole layers through LDS instead,
+                         // the workgroup's layers (l = blockIdx, blockIdx + G, ..) side by side: three barriers in all
+            float* gW = sm + NF_MC_TILES;                            // [layer slot][1024 (i-major) + 32 bias]
+            float* nd = gW + NF_MC_NL * NF_MC_SLAB_Q;                // [layer slot][3][32] per-column weight-norm backward factors
+            const int nown = (NF_MC_NL - (int)blockIdx.x + G_ - 1) / G_;
+            for (int e = threadIdx.x; e < nown * NF_MC_SLAB_Q; e += NF_MC_THREADS) {
+                const int sl = e / NF_MC_SLAB_Q, ee = e - sl * NF_MC_SLAB_Q, l = blockIdx.x + sl * G_;
                 float t4 = 0.f;
+                for (int b = 0; b < G_; ++b)
 #pragma unroll
-                for (int q = 0; q < NF_MC_NKQ; ++q) {
-                    t4 += base[q * NF_MC_SLAB_Q];
-                    if (G_ == 2) t4 += base[NF_MC_SLAB + q * NF_MC_SLAB_Q];
+                    for (int q = 0; q < NF_MC_NKQ; ++q) t4 += slabs[(size_t)b * NF_MC_SLAB + l * NF_MC_SLAB_L + q * NF_MC_SLAB_Q + ee];
+                gW[e] = t4;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < nown * 32) {
+                const int sl = threadIdx.x >> 5, i = threadIdx.x & 31, l = blockIdx.x + sl * G_;
+                const float* W = sm + NF_MC_W + l * 32 * NF_FP_ST;
+                float n2 = 0.f, dt = 0.f;
+#pragma unroll 8
+                for (int oo = 0; oo < 32; ++oo) {
+                    const float v = W[oo * NF_FP_ST + i];
+                    n2 = fmaf(v, v, n2);
+                    dt = fmaf(gW[sl * NF_MC_SLAB_Q + i * 32 + oo], v, dt);
                 }
-                pre[k] = t4;
+                const float nrm = sqrtf(n2), den = nrm + wn_eps, gi = sm[NF_MC_G + l * 32 + i];
+                nd[sl * 96 + i] = gi / den;                                          // weight_norm.py:35-41, per column
+                nd[sl * 96 + 32 + i] = nrm > 0.f ? dt * gi / (den * den * nrm) : 0.f;
+                nd[sl * 96 + 64 + i] = dt / den;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < nown * NF_MC_SLAB_Q; e += NF_MC_THREADS) {
+                const int sl = e / NF_MC_SLAB_Q, ee = e - sl * NF_MC_SLAB_Q, l = blockIdx.x + sl * G_;
+                const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
+                if (ee >= 1024) {                                    // bias
+                    const int oo = ee - 1024;
+                    if (oo < O) gr.b[l][oo] = (accumulate ? gr.b[l][oo] : 0.f) + gW[e];
+                    continue;
+                }
+                const int i = ee >> 5, oo = ee & 31;
+                if (i >= I) continue;
+                if (oo < O) {
+                    const float gv = gW[e] * nd[sl * 96 + i] - sm[NF_MC_W + l * 32 * NF_FP_ST + oo * NF_FP_ST + i] * nd[sl * 96 + 32 + i];
+                    float* dst = gr.v[l] + oo * I + i;
+                    *dst = (accumulate ? *dst : 0.f) + gv;
+                }
+                if (oo == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + nd[sl * 96 + 64 + i];
             }
         }
-        int kk = 0;
-        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33; u += G_ * HW, ++kk) {
+        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); G_ > 2 && u < NF_MC_NL * 33; u += G_ * HW) {
             const int l = u / 33, i = u - l * 33;                    // i == 32: the bias
             const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
             if (i < 32 && i >= I) continue;                          // half-wave uniform
             float tsum = 0.f;
-            if (G_ <= 2) {
-#pragma unroll
-                for (int k = 0; k < NU1; ++k) tsum = k == kk ? pre[k] : tsum;
-            } else {
+            {
                 const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
                 for (int b0 = 0; b0 < G_; b0 += 8) {                 // 8 NKQ independent loads in flight: one latency per trip
                     float v[8][NF_MC_NKQ];
