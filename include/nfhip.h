@@ -325,6 +325,25 @@ int nf_spectral_weights(const float* const* W_bar, float* const* u, float* const
                         const int* cols, int n_mats, float coeff, float eps, const int* flags, int iteration,
                         nf_stream_t stream);
 
+/* ---- weight normalisation of many layers per launch  flows/weight_norm.py:35-41 ----------------------------------------
+ * w[o, m] = v[o, m] * g[m] / (||v[:, m]|| + eps), m = (input channel, ky, kx) flattened, O = output channels.
+ * forward writes w; backward writes (accumulate = 0) or adds to (1) g_v, g_g from g_w.  <= NF_WN_MAX_LAYERS layers per call. */
+#define NF_WN_MAX_LAYERS 64
+typedef struct nf_wn_desc {
+    const float* v;        /* (O, M) weight_v */
+    const float* g;        /* (M,) weight_g */
+    float* w;              /* (O, M) effective weight (forward) */
+    const float* g_w;      /* (O, M) gradient of w (backward) */
+    float* g_v;            /* (O, M) */
+    float* g_g;            /* (M,) */
+    int O;
+    int M;
+    int accumulate;
+    int reserved;
+} nf_wn_desc;
+int nf_weight_norm_fwd(const nf_wn_desc* descs, int n_layers, float eps, nf_stream_t stream);
+int nf_weight_norm_bwd(const nf_wn_desc* descs, int n_layers, float eps, nf_stream_t stream);
+
 /* ---- the whole MLP conditioner in one persistent launch (small / medium batches) ------------------------------------
  * flows/modules.py:393-413 with n_blocks = 2: six weight-normed linears (width 32), five BatchNorm1d.  Same mathematics
  * as the nf_linear_bn_* chain; used when N <= NF_MLP_MAX_ROWS, where those launches are latency-bound: one 16-wave

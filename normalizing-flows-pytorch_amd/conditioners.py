@@ -31,7 +31,11 @@ class WeightNorm(nn.Module):
         module.register_parameter('weight_v', nn.Parameter(v.detach()))
         self._conv = isinstance(module, nn.Conv2d)
 
+    _w_eff = None      # set for the duration of ONE model forward by fused.weight_norm_all (all layers in a few launches)
+
     def effective_weight(self):
+        if self._w_eff is not None:
+            return self._w_eff
         m = self.module
         return m.weight_v * (m.weight_g / (torch.norm(m.weight_v, dim=0) + self.eps)).expand_as(m.weight_v)
 

@@ -41,6 +41,11 @@ class LinearBwdDesc(ctypes.Structure):
     _fields_ = [(f, ctypes.c_void_p) for f in _BWD_FIELDS]
 
 
+class WnDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in ('v', 'g', 'w', 'g_w', 'g_v', 'g_g')] + \
+               [(f, ctypes.c_int) for f in ('O', 'M', 'accumulate', 'reserved')]
+
+
 class WeightGradDesc(ctypes.Structure):
     _fields_ = [(f, ctypes.c_void_p) for f in _WG_FIELDS] + [(f, ctypes.c_int) for f in _WG_INTS]
 
@@ -878,3 +883,62 @@ def realnvp_step_vec(z, ld, bn, coupling):
     head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, coupling.s_log_scale,
             coupling.s_bias]
     return _RealNVPStepVec.apply(z, _owned_ld(ld), int(coupling.odd), bn.eps, bn.momentum, *(head + _mlp_tensors(coupling.net)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# weight normalisation of every weight-normed layer of a model in a handful of launches (csrc/weight_norm.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+WN_MAX = 64
+
+
+class _WeightNormMulti(torch.autograd.Function):
+    """(w_0, w_1, ...) = weight_norm(v_k, g_k) for tensors = v_0, g_0, v_1, g_1, ...; ceil(n / 64) launches each way."""
+
+    @staticmethod
+    def forward(ctx, eps, *tensors):
+        vs, gs = tensors[0::2], tensors[1::2]
+        outs = [torch.empty_like(v) for v in vs]
+        for k0 in range(0, len(vs), WN_MAX):
+            descs = [_desc(WnDesc, v=vs[k], g=gs[k], w=outs[k], O=vs[k].shape[0], M=vs[k].numel() // vs[k].shape[0])
+                     for k in range(k0, min(k0 + WN_MAX, len(vs)))]
+            arr = (WnDesc * len(descs))(*descs)
+            N.call('nf_weight_norm_fwd', ctypes.addressof(arr), len(descs), float(eps), N.stream())
+        ctx.save_for_backward(*tensors)
+        ctx.eps = float(eps)
+        from .functional import _sinks
+        ctx.sinks = _sinks(*tensors)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_ws):
+        tensors = ctx.saved_tensors
+        vs, gs = tensors[0::2], tensors[1::2]
+        direct = ctx.sinks is not None
+        dst = ctx.sinks if direct else [torch.empty_like(t) for t in tensors]
+        live = [k for k in range(len(vs)) if g_ws[k] is not None]
+        gws = {k: g_ws[k].contiguous() for k in live}
+        for k0 in range(0, len(live), WN_MAX):
+            ks = live[k0:k0 + WN_MAX]
+            descs = [_desc(WnDesc, v=vs[k], g=gs[k], g_w=gws[k], g_v=dst[2 * k], g_g=dst[2 * k + 1], O=vs[k].shape[0],
+                           M=vs[k].numel() // vs[k].shape[0], accumulate=int(direct)) for k in ks]
+            arr = (WnDesc * len(descs))(*descs)
+            N.call('nf_weight_norm_bwd', ctypes.addressof(arr), len(descs), ctx.eps, N.stream())
+        if direct:
+            return (None, ) + (None, ) * len(tensors)
+        out = []
+        for k in range(len(vs)):
+            out += [dst[2 * k], dst[2 * k + 1]] if k in gws else [None, None]
+        return (None, ) + tuple(out)
+
+
+def weight_norm_all(wn_modules):
+    """effective weights of the given conditioners.WeightNorm modules, stashed on them for the forward pass under way."""
+    if not wn_modules:
+        return
+    eps = wn_modules[0].eps
+    tensors = []
+    for m in wn_modules:
+        tensors += [m.module.weight_v, m.module.weight_g]
+    outs = _WeightNormMulti.apply(eps, *tensors)
+    for m, w in zip(wn_modules, outs):
+        m._w_eff = w

@@ -52,11 +52,31 @@ class _FlowModel(nn.Module):
     def _zero_ld(self, z):
         return torch.zeros(z.size(0), dtype=z.dtype, device=z.device)
 
+    def _wn_convs(self):
+        """the weight-normed convolutions of the image conditioners (their weight-norm arithmetic is batched per pass)."""
+        c = getattr(self, '_wn_cache', None)
+        if c is None:
+            from .conditioners import WeightNorm
+            c = self._wn_cache = [m for m in self.modules() if isinstance(m, WeightNorm) and m._conv]
+        return c
+
+    def _with_weight_norms(self, fn, z):
+        wns = self._wn_convs() if z.is_cuda else []
+        if not wns:
+            return fn(z, self._zero_ld(z))
+        from . import fused as FUSED
+        FUSED.weight_norm_all(wns)
+        try:
+            return fn(z, self._zero_ld(z))
+        finally:
+            for m in wns:
+                m._w_eff = None
+
     def forward(self, z):
-        return self.net(z, self._zero_ld(z))
+        return self._with_weight_norms(self.net, z)
 
     def backward(self, z):
-        return self.net.backward(z, self._zero_ld(z))
+        return self._with_weight_norms(self.net.backward, z)
 
 
 class RealNVP(_FlowModel):

@@ -80,7 +80,7 @@ def test_ctypes_struct_layout_matches_header(pkg):
     fused = __import__('importlib').import_module(pkg.__name__ + '.fused')
     text = re.sub(r'/\*.*?\*/', ' ', open(HEADER).read(), flags=re.S)
     for struct, cls in [('nf_linear_desc', fused.LinearDesc), ('nf_linear_bwd_desc', fused.LinearBwdDesc),
-                        ('nf_weight_grad_desc', fused.WeightGradDesc)]:
+                        ('nf_weight_grad_desc', fused.WeightGradDesc), ('nf_wn_desc', fused.WnDesc)]:
         body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct, struct), text, flags=re.S).group(1)
         names = [re.sub(r'\W', '', f.strip().split()[-1]) for f in body.split(';') if f.strip()]
         got = [n.rstrip('_') for n, _ in cls._fields_]
