@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd(const float* __
     float* Lp = sm;
     float* Up = sm + C * C;
     float* T = sm + 2 * C * C;
-    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+    float* Ps = Lp;                                              // P re-uses L' once T = L' U' exists (every operand of the
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {     // inner loops sits in LDS: a global load per k was ~1 us each)
         const int r = e / C, c = e - r * C;
         Lp[e] = L[e] * Lmask[e] + (r == c ? 1.f : 0.f);
         Up[e] = U[e] * Umask[e] + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
@@ -176,10 +177,12 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd(const float* __
         T[e] = acc;
     }
     __syncthreads();
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) Ps[e] = Pm[e];
+    __syncthreads();
     for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
         const int r = e / C, c = e - r * C;
         float acc = 0.f;
-        for (int k = 0; k < C; ++k) acc = fmaf(Pm[r * C + k], T[k * C + c], acc);
+        for (int k = 0; k < C; ++k) acc = fmaf(Ps[r * C + k], T[k * C + c], acc);
         W[e] = acc;
     }
 }
@@ -198,12 +201,20 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __
     float* Lp = sm;
     float* Up = sm + C * C;
     float* A = sm + 2 * C * C;                                   // P^T g_W
+    float* Ps = sm + 3 * C * C;                                  // P and g_W staged: no global load inside the k loops
+    float* Gs = sm + 4 * C * C;
     for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
         const int r = e / C, c = e - r * C;
         Lp[e] = L[e] * Lmask[e] + (r == c ? 1.f : 0.f);
         Up[e] = U[e] * Umask[e] + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
+        Ps[e] = Pm[e];
+        Gs[e] = gW[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
         float acc = 0.f;
-        for (int k = 0; k < C; ++k) acc = fmaf(Pm[k * C + r], gW[k * C + c], acc);
+        for (int k = 0; k < C; ++k) acc = fmaf(Ps[k * C + r], Gs[k * C + c], acc);
         A[e] = acc;
     }
     float part = 0.f;
@@ -315,7 +326,15 @@ extern "C" int nf_invconv_weight_bwd(const float* g_W, const float* P, const flo
                                      const float* g_ld, float* g_L, float* g_U, float* g_log_s, int accumulate, int C, int64_t B,
                                      int pixels, nf_stream_t stream) {
     if (C <= 0 || C > NF_PLU_MAXC) return C <= 0 ? NF_E_BADARG : NF_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_invconv_weight_bwd, dim3(1), dim3(NF_BLOCK), (size_t)3 * C * C * sizeof(float), (hipStream_t)stream,
+    const size_t lds_b = (size_t)5 * C * C * sizeof(float);      // 80 KB at C = 64: above the 64 KB default, opt in once
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_invconv_weight_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           5 * NF_PLU_MAXC * NF_PLU_MAXC * (int)sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_invconv_weight_bwd, dim3(1), dim3(NF_BLOCK), lds_b, (hipStream_t)stream,
                        g_W, P, L, U, L_mask, U_mask, sign_s, log_s, g_ld, g_L, g_U, g_log_s, accumulate, C, B, (float)pixels);
     NF_CHECK_LAUNCH();
     return 0;
