@@ -423,10 +423,16 @@ def main():
     # forward-only and inverse-only rates (eval mode, no autograd), informational
     with torch.no_grad():
         net.eval()
-        stream = torch.cuda.current_stream()
-        fwd_ms = event_time_ms(lambda: net(y), 10, stream)
         zz, _ = net(y)
-        inv_ms = event_time_ms(lambda: net.backward(zz), 5, stream)
+
+        def replay_ms(fn):
+            """one pass as a hipGraph replay (like the training step); eager launches if capture is refused"""
+            try:
+                return graph_time_us(fn, dev, per_graph=1, replays=10) / 1e3
+            except Exception:
+                return event_time_ms(fn, 5, torch.cuda.current_stream())
+        fwd_ms = replay_ms(lambda: net(y))
+        inv_ms = replay_ms(lambda: net.backward(zz))
         net.train()
 
     timeouts = pkg._native.persistent_timeouts()
