@@ -482,6 +482,15 @@ int nf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, int64_t n,
                  nf_stream_t stream);
 
+/* dst_k[0:n_k] = src_k[0:n_k] for up to NF_COPY_MAX tensors in one launch (gradient gather into the flat bucket)   */
+#define NF_COPY_MAX 128
+typedef struct nf_copy_desc {
+    const float* src;
+    float* dst;
+    int64_t n;
+} nf_copy_desc;
+int nf_multi_copy(const nf_copy_desc* descs, int n_tensors, nf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

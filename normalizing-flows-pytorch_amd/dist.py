@@ -62,9 +62,11 @@ class GradBucket:
         self.flat_params = torch.empty(self.numel, dtype=dt, device=dev) if flatten_params else None
         self.group = process_group
         o = 0
+        self.views = []                                   # the bucket's view for every parameter, in order
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[o:o + n].view_as(p)
+            self.views.append(p.grad)
             if flatten_params:
                 with torch.no_grad():
                     self.flat_params[o:o + n].copy_(p.data.reshape(-1))

@@ -41,6 +41,10 @@ class LinearBwdDesc(ctypes.Structure):
     _fields_ = [(f, ctypes.c_void_p) for f in _BWD_FIELDS]
 
 
+class CopyDesc(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('n', ctypes.c_int64)]
+
+
 class WnDesc(ctypes.Structure):
     _fields_ = [(f, ctypes.c_void_p) for f in ('v', 'g', 'w', 'g_w', 'g_v', 'g_g')] + \
                [(f, ctypes.c_int) for f in ('O', 'M', 'accumulate', 'reserved')]

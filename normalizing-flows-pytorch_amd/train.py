@@ -92,11 +92,23 @@ class FlowTrainer:
         self._replicas_synced = False
         self._g_fb = self._g_opt = None
         self._static_y = self._static_z = self._static_loss = None
+        # parameters whose gradient arrives from framework autograd (convolutions, BatchNorm2d ...) rather than from a kernel
+        # writing into the bucket: found in the first eager step, afterwards their AccumulateGrad adds (one launch per
+        # parameter) are replaced by one gather launch per 128 tensors
+        self._gather = on_gpu
+        self._indirect = None
 
     # -- one step, eager --------------------------------------------------------------------------------------------
     def _forward_backward(self, y):
         from .workspace import ARENA
         self.bucket.zero_()
+        hooks, seen = [], set()
+        if self._gather and self._indirect is None:     # first step: watch which parameters autograd itself produces
+            for i, p in enumerate(self.bucket.params):
+                hooks.append(p.register_hook(lambda g, i=i: seen.add(i)))
+        elif self._indirect:
+            for i in self._indirect:
+                self.bucket.params[i].grad = None       # AccumulateGrad then keeps the incoming tensor: no add launch
         ARENA.begin(y.device)                           # one memset for every zero-initialised accumulator of the step
         try:
             z, ld = self.net(y)
@@ -104,7 +116,31 @@ class FlowTrainer:
             loss.backward()
         finally:
             ARENA.end()
+            for h in hooks:
+                h.remove()
+        if hooks:
+            self._indirect = sorted(seen)
+        elif self._indirect:
+            self._gather_indirect()
         return z, loss
+
+    def _gather_indirect(self):
+        """copy the framework-produced gradients into their bucket slots (nf_multi_copy) and re-attach the views."""
+        import ctypes
+        from . import _native as N
+        from .fused import CopyDesc
+        descs = []
+        for i in self._indirect:
+            p, view = self.bucket.params[i], self.bucket.views[i]
+            g = p.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                g = g.contiguous()
+                descs.append((g, view))
+            p.grad = view
+        for k0 in range(0, len(descs), 128):
+            chunk = descs[k0:k0 + 128]
+            arr = (CopyDesc * len(chunk))(*[CopyDesc(g.data_ptr(), v.data_ptr(), g.numel()) for g, v in chunk])
+            N.call('nf_multi_copy', ctypes.addressof(arr), len(chunk), N.stream())
 
     def _capture(self, y):
         self._static_y = y.clone()

@@ -108,3 +108,27 @@ def test_model_golden_direct_grad_bucket(pkg, name):
                 tol = 2e-3 if noise else (1e-4 if kind == 'maf' else 2 * TOL) * scale
                 G.assert_close(p.grad, want, tol, what='%s (rep %d)' % (k, rep))
                 assert p.grad.data_ptr() >= bucket.flat.data_ptr()
+
+
+def test_trainer_gradient_gather_matches_accumulate(pkg):
+    """FlowTrainer's gather of framework-produced gradients (nf_multi_copy instead of one AccumulateGrad add per
+    parameter) leaves exactly the same flat gradient bucket as plain accumulation, step after step."""
+    import importlib
+    train = importlib.import_module(pkg.__name__ + '.train')
+    net, g, kind, dims = _build(pkg, 'glow_img')
+    net2, _, _, _ = _build(pkg, 'glow_img')
+    ta = train.FlowTrainer(net, graph=False)
+    tb = train.FlowTrainer(net2, graph=False)
+    tb._gather = False                                        # reference behaviour: AccumulateGrad into the bucket views
+    y = g['y'].clone()
+    for step in range(3):
+        for t in (ta, tb):
+            G.seed_noise(777 + step)
+            t.net.train()
+            t._forward_backward(y)
+        if step >= 1:
+            assert ta._indirect, 'an image Glow has convolution / BatchNorm2d parameters produced by autograd'
+        # not bit-equal: some backward kernels of the image path reduce through atomics (order varies run to run)
+        G.assert_close(ta.bucket.flat, tb.bucket.flat, 1e-5 * float(tb.bucket.flat.abs().max()), rtol=1e-4, what='flat grads, step %d' % step)
+        for p in ta.bucket.params:
+            assert p.grad is not None and p.grad.data_ptr() >= ta.bucket.flat.data_ptr()
