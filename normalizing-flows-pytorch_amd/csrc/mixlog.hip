@@ -327,6 +327,173 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_inv(const float* __restrict
 static inline bool nf_mixlog_args(NfSplit& s, int mode, int odd, int C, int H, int W, int K) {
     return nf_make_split(s, mode, odd, C, H, W) && mode != NF_SPLIT_NONE && K >= 1 && K <= 32;
 }
+// ---------------------------------------------------------------------------------------------------------------
+// K <= 8 on vector data (rows mode): ONE MIXTURE COMPONENT PER LANE, eight lanes ("octet") share an element.
+// At the reference's Flow++ density batch (65 536 elements) one thread per element is one wave per SIMD walking a
+// ~3000-instruction latency chain (13 us forward, 22 us backward, nothing to overlap with).  Split by component the
+// chain is ~8x shorter and there are 8x the waves; the log-sum-exp / softmax reductions over the components are three
+// DPP steps each (quad_perm xor 1, xor 2, row_half_mirror) -- VALU-speed, no LDS.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float nf_dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float nf_oct_sum(float v) {
+    v += nf_dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += nf_dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += nf_dpp_mov<0x141>(v);         // row_half_mirror: lane i <-> 7 - i of each group of eight
+    return v;
+}
+__device__ __forceinline__ float nf_oct_max(float v) {
+    v = fmaxf(v, nf_dpp_mov<0xB1>(v));
+    v = fmaxf(v, nf_dpp_mov<0x4E>(v));
+    v = fmaxf(v, nf_dpp_mov<0x141>(v));
+    return v;
+}
+// hardware transcendentals for the octet kernels (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): the libm forms are 30-60
+// instructions each, and with eight lanes per element the per-element scalar math is issued eight times as often
+__device__ __forceinline__ float nf_fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float nf_flog(float x) { return __logf(x); }
+__device__ __forceinline__ float nf_ftanh(float x) {              // 1 - 2 / (1 + e^{2x}), saturates cleanly
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+}
+struct NfOct { float lp, mu, s, es, a_raw, b; };     // this lane's component + the element's affine parameters
+
+__device__ __forceinline__ void nf_oct_load(const float* __restrict__ P, int64_t nh, int K, int kk, NfOct& m) {
+    const bool on = kk < K;
+    const int k = on ? kk : 0;
+    const float lp = P[(2 + k) * nh], mu = P[(2 + K + k) * nh], sv = P[(2 + 2 * K + k) * nh];
+    m.a_raw = P[0];
+    m.b = P[nh];
+    m.lp = on ? lp : -INFINITY;
+    m.mu = on ? mu : 0.f;
+    m.s = on ? sv : 0.f;
+    const float mx = nf_oct_max(m.lp);
+    const float lse = mx + nf_flog(nf_oct_sum(nf_fexp(m.lp - mx)));         // F.log_softmax over the mixture axis (coupling.py:180)
+    m.lp -= lse;
+    m.es = nf_fexp(-m.s);
+}
+// log CDF and log PDF of the mixture at x (modules.py:64-97), identical on the eight lanes; u, l of this lane's component
+__device__ __forceinline__ void nf_oct_eval(const NfOct& m, float x, float& lcdf, float& lpdf, float& u, float& l) {
+    u = (x - m.mu) * m.es;
+    l = nf_flog(1.f + nf_fexp(-fabsf(u)));
+    const float c = m.lp + (fminf(u, 0.f) - l);
+    const float d = m.lp + (u - m.s - 2.f * (fmaxf(u, 0.f) + l));
+    const float cm = nf_oct_max(c), dm = nf_oct_max(d);
+    lcdf = cm + nf_flog(nf_oct_sum(nf_fexp(c - cm)));
+    lpdf = dm + nf_flog(nf_oct_sum(nf_fexp(d - dm)));
+}
+
+__global__ void __launch_bounds__(NF_BLOCK) k_mixlog_oct_fwd(const float* __restrict__ z, const float* __restrict__ prm,
+                                                             const float* __restrict__ pA, const float* __restrict__ pC,
+                                                             float* __restrict__ y, float* __restrict__ ld, NfSplit s, int K,
+                                                             float eps, int64_t B) {
+    const float A = pA[0], Cb = pC[0];
+    const int kk = threadIdx.x & 7;
+    const int64_t PS = (int64_t)(2 + 3 * K) * s.n_half;
+    const int64_t per = (int64_t)gridDim.x * (blockDim.x >> 3);
+    for (int64_t b0 = (int64_t)blockIdx.x * (blockDim.x >> 3); b0 < B; b0 += per) {      // uniform trip count per wave (DPP)
+        const int64_t b = b0 + (threadIdx.x >> 3);
+        const bool live = b < B;
+        const int64_t bb = live ? b : B - 1;
+        const float* zb = z + bb * s.n_full;
+        float* yb = y + bb * s.n_full;
+        float acc = 0.f;
+        for (int e = 0; e < s.n_half; ++e) {
+            NfOct m;
+            nf_oct_load(prm + bb * PS + e, s.n_half, K, kk, m);
+            const int o0 = nf_half_to_full(s, 0, e), o1 = nf_half_to_full(s, 1, e);
+            const float x = zb[o0];
+            float lcdf, lpdf, u, l;
+            nf_oct_eval(m, x, lcdf, lpdf, u, l);
+            const float F = nf_fexp(lcdf);                                   // modules.py:194
+            const float xc = fminf(fmaxf(F, eps), 1.f - eps);             // modules.py:147
+            const float la = nf_flog(xc), lb = nf_flog(1.f - xc);               // logit and its log-det share the two logs
+            const float a = nf_ftanh(m.a_raw) * A + Cb;                      // coupling.py:178
+            acc += lpdf - (la + lb) + a;                                  // coupling.py:184-188
+            if (live && kk == 0) {
+                yb[o0] = (la - lb) * nf_fexp(a) + m.b;                       // coupling.py:187
+                yb[o1] = zb[o1];
+            }
+        }
+        if (live && kk == 0) ld[b] += acc;
+    }
+}
+
+// 1024-thread workgroups: every workgroup ends in one pair of same-address atomics, which the L2 serialises at about 20 ns
+// each (512 workgroups of 256 threads spent 10 of their 23 us there); 128 x 16 waves keeps the same number of waves in flight
+#define NF_OCT_BWD_THREADS 1024
+#define NF_OCT_BWD_MAX_BLOCKS 128
+__global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const float* __restrict__ gy, const float* __restrict__ gld,
+                                                             const float* __restrict__ z, const float* __restrict__ prm,
+                                                             const float* __restrict__ pA, const float* __restrict__ pC,
+                                                             float* __restrict__ gz, float* __restrict__ gprm,
+                                                             float* __restrict__ g_scale, float* __restrict__ g_bias, NfSplit s,
+                                                             int K, float eps, int64_t B) {
+    __shared__ float scratch[NF_OCT_BWD_THREADS / NF_WAVE];
+    const float A = pA[0], Cb = pC[0];
+    const int kk = threadIdx.x & 7;
+    const bool on = kk < K;
+    const int64_t PS = (int64_t)(2 + 3 * K) * s.n_half;
+    const int64_t per = (int64_t)gridDim.x * (blockDim.x >> 3);
+    float acc_A = 0.f, acc_C = 0.f;
+    for (int64_t b0 = (int64_t)blockIdx.x * (blockDim.x >> 3); b0 < B; b0 += per) {
+        const int64_t b = b0 + (threadIdx.x >> 3);
+        const bool live = b < B;
+        const int64_t bb = live ? b : B - 1;
+        const int64_t fb = bb * s.n_full;
+        const float g_ld = gld[bb];
+        for (int e = 0; e < s.n_half; ++e) {
+            NfOct m;
+            nf_oct_load(prm + bb * PS + e, s.n_half, K, kk, m);
+            float* GP = gprm + bb * PS + e;
+            const int64_t gnh = s.n_half;
+            const int o0 = nf_half_to_full(s, 0, e), o1 = nf_half_to_full(s, 1, e);
+            const float x = z[fb + o0], g_y = gy[fb + o0];
+            float lcdf, lpdf, u, l;
+            nf_oct_eval(m, x, lcdf, lpdf, u, l);
+            const float F = nf_fexp(lcdf), f = nf_fexp(lpdf);
+            const bool inside = (F >= eps) && (F <= 1.f - eps);          // torch.clamp passes the gradient on [min, max]
+            const float xc = fminf(fmaxf(F, eps), 1.f - eps);
+            const float y1 = nf_flog(xc) - nf_flog(1.f - xc);
+            const float th = nf_ftanh(m.a_raw);
+            const float ea = nf_fexp(th * A + Cb);
+            const float g_y1 = g_y * ea;                                 // y = y1 * exp(a) + b ; ld += a
+            const float g_a = g_y * y1 * ea + g_ld;
+            const float gF = inside ? (g_y1 - g_ld * (1.f - 2.f * xc)) / (xc * (1.f - xc)) : 0.f;   // logit + its log-det
+            const float tot = gF * F + g_ld;                             // sum_j g_logpi_j
+            // this lane's component (appendix B6, responsibilities form r_k = pi_k pdf_k / f)
+            const float r = on ? nf_fexp(m.lp + (u - m.s - 2.f * (fmaxf(u, 0.f) + l)) - lpdf) : 0.f;
+            const float omt = -nf_ftanh(0.5f * u);                          // 1 - 2 sigmoid(u)
+            const float w = g_ld * r * omt * m.es;
+            const float gx = gF * f + nf_oct_sum(w);
+            if (live) {
+                if (on) {
+                    GP[(2 + K + kk) * gnh] = -gF * f * r - w;                                          // g_mu_k
+                    GP[(2 + 2 * K + kk) * gnh] = -gF * f * r * (x - m.mu) + g_ld * r * (-omt * u - 1.f);   // g_s_k
+                    const float g_logpi = gF * nf_fexp(m.lp + (fminf(u, 0.f) - l)) + g_ld * r;
+                    GP[(2 + kk) * gnh] = g_logpi - nf_fexp(m.lp) * tot;                                    // through log_softmax
+                }
+                if (kk == 0) {
+                    GP[0] = g_a * A * (1.f - th * th);
+                    GP[gnh] = g_y;
+                    gz[fb + o0] = gx;
+                    gz[fb + o1] = gy[fb + o1];
+                    acc_A += g_a * th;
+                    acc_C += g_a;
+                }
+            }
+        }
+    }
+    const float ta = nf_block_sum(acc_A, scratch);
+    const float tc = nf_block_sum(acc_C, scratch);
+    if (threadIdx.x == 0) {
+        atomicAdd(g_scale, ta);
+        atomicAdd(g_bias, tc);
+    }
+}
+
 static inline int nf_mx_threads(int K) { return (2 + 3 * K) <= 50 ? 256 : 128; }        // rows tile <= 52 KB of LDS
 static inline size_t nf_mx_lds(const NfSplit& s, int K, int threads) {
     return s.n_half == 1 ? (size_t)threads * (2 + 3 * K + 1) * sizeof(float) : 0;
@@ -346,7 +513,11 @@ extern "C" int nf_mixlog_coupling_fwd(const float* z, const float* params, const
     if (!nf_mixlog_args(s, mode, odd, C, H, W, K)) return NF_E_BADARG;
     if (B == 0 || s.n_half == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (s.n_half <= NF_MX_ROWS_MAX) {
+    if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane (see k_mixlog_oct_fwd)
+        unsigned g = nf_grid_for(B * 8, NF_BLOCK);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(k_mixlog_oct_fwd, dim3(g), dim3(NF_BLOCK), 0, st, z, params, a_log_scale, a_bias, y, ld, s, K, logit_eps, B);
+    } else if (s.n_half <= NF_MX_ROWS_MAX) {
         const int th = nf_mx_threads(K);
         unsigned g = nf_grid_for(B, th);
         if (g > NF_MX_GRID) g = NF_MX_GRID;
@@ -372,10 +543,18 @@ extern "C" int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const
     if (!nf_mixlog_args(s, mode, odd, C, H, W, K)) return NF_E_BADARG;
     const int64_t total = B * s.n_half;
     if (total == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane
+        unsigned g2 = nf_grid_for(B * 8, NF_OCT_BWD_THREADS);
+        if (g2 > NF_OCT_BWD_MAX_BLOCKS) g2 = NF_OCT_BWD_MAX_BLOCKS;
+        hipLaunchKernelGGL(k_mixlog_oct_bwd, dim3(g2), dim3(NF_OCT_BWD_THREADS), 0, st, g_y, g_ld, z, params, a_log_scale, a_bias,
+                           g_z, g_params, g_scale, g_bias, s, K, logit_eps, B);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     const int th = nf_mx_threads(K);
     unsigned g = nf_grid_for(total, th);
     if (g > NF_MX_GRID) g = NF_MX_GRID;
-    hipStream_t st = (hipStream_t)stream;
 #define CALL(KT) hipLaunchKernelGGL(k_mixlog_bwd<KT>, dim3(g), dim3(th), nf_mx_lds(s, K, th), st, g_y, g_ld, z, params, a_log_scale, a_bias, g_z, g_params, g_scale, g_bias, s, K, logit_eps, total)
     NF_MX_DISPATCH(K, CALL);
 #undef CALL
