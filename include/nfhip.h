@@ -183,6 +183,21 @@ int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, 
                            float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
                            int C, int H, int W, nf_stream_t stream);
 
+/* ---- Flow++ density step pair: the coupling above on two features (NF_SPLIT_1D, D = 2, K <= 8), followed by the NEXT flow
+ * step's ActNorm (flows/flowpp.py:60-66 alternates ActNorm and coupling; flows/modules.py:246-249) in the same pass:
+ *     h = (y - next_bias) / exp(next_log_scale),   ld += coupling log-det - sum_c next_log_scale[c]
+ * backward takes g_h / g_ld for that output, ADDS the ActNorm's parameter gradients into g_next_log_scale / g_next_bias
+ * (g_log_scale_c = -sum g_h h - sum g_ld, g_bias_c = -sum g_h / exp(log_scale_c)) next to g_scale / g_bias, and writes the
+ * coupling's g_z, g_params as nf_mixlog_coupling_bwd does.  next_* are [2] device vectors and must not be NULL.          */
+int nf_flowpp_vec_couple_fwd(const float* z, const float* params, const float* a_log_scale, const float* a_bias,
+                             const float* next_log_scale, const float* next_bias, float* y, float* ld, int K,
+                             float logit_eps, int odd, int64_t B, nf_stream_t stream);
+int nf_flowpp_vec_couple_bwd(const float* g_h, const float* g_ld, const float* z, const float* params,
+                             const float* a_log_scale, const float* a_bias, const float* next_log_scale,
+                             const float* next_bias, float* g_z, float* g_params, float* g_scale, float* g_bias,
+                             float* g_next_log_scale, float* g_next_bias, int K, float logit_eps, int odd, int64_t B,
+                             nf_stream_t stream);
+
 /* ---- fused masked / weight-normed linear + BatchNorm1d + ReLU chain on fp32 MFMA --------------------------------------
  * The building block of MADE (flows/maf.py:49-64: F.linear(z, W*M, b) -> BatchNorm1d -> relu) and of the MLP
  * conditioner (flows/modules.py:342-413: BatchNorm1d -> ReLU -> WeightNorm(Linear), residual adds).  One launch =

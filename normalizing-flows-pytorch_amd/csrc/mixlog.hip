@@ -385,21 +385,32 @@ __device__ __forceinline__ void nf_oct_eval(const NfOct& m, float x, float& lcdf
     lpdf = dm + nf_flog(nf_oct_sum(nf_fexp(d - dm)));
 }
 
+// POST: the ActNorm of the NEXT flow step (flows/flowpp.py:60-66 alternates ActNorm and coupling on density data) is applied
+// to the coupling's output before it is stored -- h = (y - bias) / exp(log_scale), ld -= sum log_scale (modules.py:246-249) --
+// so the pair costs one pass over the rows instead of two.  n_half == 1 (two features) only.
+template <bool POST>
 __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_oct_fwd(const float* __restrict__ z, const float* __restrict__ prm,
                                                              const float* __restrict__ pA, const float* __restrict__ pC,
+                                                             const float* __restrict__ nls, const float* __restrict__ nb,
                                                              float* __restrict__ y, float* __restrict__ ld, NfSplit s, int K,
                                                              float eps, int64_t B) {
     const float A = pA[0], Cb = pC[0];
     const int kk = threadIdx.x & 7;
     const int64_t PS = (int64_t)(2 + 3 * K) * s.n_half;
     const int64_t per = (int64_t)gridDim.x * (blockDim.x >> 3);
+    float D0 = 1.f, D1 = 1.f, S0 = 0.f, S1 = 0.f, ldn = 0.f;             // next ActNorm on features o0 (transformed), o1
+    if (POST) {
+        const int o0 = nf_half_to_full(s, 0, 0), o1 = nf_half_to_full(s, 1, 0);
+        D0 = expf(nls[o0]); D1 = expf(nls[o1]); S0 = nb[o0]; S1 = nb[o1];
+        ldn = -(nls[0] + nls[1]);
+    }
     for (int64_t b0 = (int64_t)blockIdx.x * (blockDim.x >> 3); b0 < B; b0 += per) {      // uniform trip count per wave (DPP)
         const int64_t b = b0 + (threadIdx.x >> 3);
         const bool live = b < B;
         const int64_t bb = live ? b : B - 1;
         const float* zb = z + bb * s.n_full;
         float* yb = y + bb * s.n_full;
-        float acc = 0.f;
+        float acc = ldn;
         for (int e = 0; e < s.n_half; ++e) {
             NfOct m;
             nf_oct_load(prm + bb * PS + e, s.n_half, K, kk, m);
@@ -413,8 +424,9 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_oct_fwd(const float* __rest
             const float a = nf_ftanh(m.a_raw) * A + Cb;                      // coupling.py:178
             acc += lpdf - (la + lb) + a;                                  // coupling.py:184-188
             if (live && kk == 0) {
-                yb[o0] = (la - lb) * nf_fexp(a) + m.b;                       // coupling.py:187
-                yb[o1] = zb[o1];
+                const float yt = (la - lb) * nf_fexp(a) + m.b;               // coupling.py:187
+                yb[o0] = POST ? (yt - S0) / D0 : yt;
+                yb[o1] = POST ? (zb[o1] - S1) / D1 : zb[o1];
             }
         }
         if (live && kk == 0) ld[b] += acc;
@@ -425,19 +437,30 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_oct_fwd(const float* __rest
 // each (512 workgroups of 256 threads spent 10 of their 23 us there); 128 x 16 waves keeps the same number of waves in flight
 #define NF_OCT_BWD_THREADS 1024
 #define NF_OCT_BWD_MAX_BLOCKS 128
+// POST: g_y / g_ld arrive for the NEXT step's ActNorm output h; its parameter gradients (g_log_scale_c = -sum g_h h - sum g_ld,
+// g_bias_c = -sum g_h / exp(log_scale_c), appendix B2) are reduced here from the recomputed coupling output and the coupling
+// continues with g_y = g_h / exp(log_scale).  Seven block totals -> one cross-wave reduction, seven atomics per workgroup.
+template <bool POST>
 __global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const float* __restrict__ gy, const float* __restrict__ gld,
                                                              const float* __restrict__ z, const float* __restrict__ prm,
                                                              const float* __restrict__ pA, const float* __restrict__ pC,
+                                                             const float* __restrict__ nls, const float* __restrict__ nb,
                                                              float* __restrict__ gz, float* __restrict__ gprm,
-                                                             float* __restrict__ g_scale, float* __restrict__ g_bias, NfSplit s,
+                                                             float* __restrict__ g_scale, float* __restrict__ g_bias,
+                                                             float* __restrict__ g_nls, float* __restrict__ g_nb, NfSplit s,
                                                              int K, float eps, int64_t B) {
-    __shared__ float scratch[NF_OCT_BWD_THREADS / NF_WAVE];
+    __shared__ float scratch[NF_OCT_BWD_THREADS / NF_WAVE][8];
     const float A = pA[0], Cb = pC[0];
     const int kk = threadIdx.x & 7;
     const bool on = kk < K;
     const int64_t PS = (int64_t)(2 + 3 * K) * s.n_half;
     const int64_t per = (int64_t)gridDim.x * (blockDim.x >> 3);
-    float acc_A = 0.f, acc_C = 0.f;
+    float D0 = 1.f, D1 = 1.f, S0 = 0.f, S1 = 0.f;
+    if (POST) {
+        const int o0 = nf_half_to_full(s, 0, 0), o1 = nf_half_to_full(s, 1, 0);
+        D0 = expf(nls[o0]); D1 = expf(nls[o1]); S0 = nb[o0]; S1 = nb[o1];
+    }
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // g_a*th, g_a | sum g_h0, sum g_h0 h0, sum g_h1, sum g_h1 h1, sum g_ld
     for (int64_t b0 = (int64_t)blockIdx.x * (blockDim.x >> 3); b0 < B; b0 += per) {
         const int64_t b = b0 + (threadIdx.x >> 3);
         const bool live = b < B;
@@ -450,7 +473,9 @@ __global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const flo
             float* GP = gprm + bb * PS + e;
             const int64_t gnh = s.n_half;
             const int o0 = nf_half_to_full(s, 0, e), o1 = nf_half_to_full(s, 1, e);
-            const float x = z[fb + o0], g_y = gy[fb + o0];
+            const float x = z[fb + o0];
+            const float g_h0 = gy[fb + o0];
+            const float g_y = POST ? g_h0 / D0 : g_h0;
             float lcdf, lpdf, u, l;
             nf_oct_eval(m, x, lcdf, lpdf, u, l);
             const float F = nf_fexp(lcdf), f = nf_fexp(lpdf);
@@ -476,21 +501,52 @@ __global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const flo
                     GP[(2 + kk) * gnh] = g_logpi - nf_fexp(m.lp) * tot;                                    // through log_softmax
                 }
                 if (kk == 0) {
+                    const float zi = z[fb + o1], g_h1 = gy[fb + o1];
                     GP[0] = g_a * A * (1.f - th * th);
                     GP[gnh] = g_y;
                     gz[fb + o0] = gx;
-                    gz[fb + o1] = gy[fb + o1];
-                    acc_A += g_a * th;
-                    acc_C += g_a;
+                    gz[fb + o1] = POST ? g_h1 / D1 : g_h1;
+                    acc[0] += g_a * th;
+                    acc[1] += g_a;
+                    if (POST) {
+                        const float h0 = (y1 * ea + m.b - S0) / D0, h1 = (zi - S1) / D1;
+                        acc[2] += g_h0;
+                        acc[3] += g_h0 * h0;
+                        acc[4] += g_h1;
+                        acc[5] += g_h1 * h1;
+                        acc[6] += g_ld;
+                    }
                 }
             }
         }
     }
-    const float ta = nf_block_sum(acc_A, scratch);
-    const float tc = nf_block_sum(acc_C, scratch);
+    const int NA = POST ? 7 : 2;
+    const int lane = threadIdx.x & (NF_WAVE - 1), wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+        if (q < NA) {
+            const float v = nf_wave_sum(acc[q]);
+            if (lane == 0) scratch[wid][q] = v;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < NA) {
+        float t = 0.f;
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w) t += scratch[w][threadIdx.x];
+        scratch[0][threadIdx.x] = t;          // only rows read by the same thread were summed: no hazard on row 0
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
+        atomicAdd(g_scale, scratch[0][0]);
+        atomicAdd(g_bias, scratch[0][1]);
+        if (POST) {
+            const int o0 = nf_half_to_full(s, 0, 0), o1 = nf_half_to_full(s, 1, 0);
+            const float t0 = scratch[0][2], t0h = scratch[0][3], t1 = scratch[0][4], t1h = scratch[0][5], sg = scratch[0][6];
+            atomicAdd(g_nls + o0, -t0h - sg);
+            atomicAdd(g_nls + o1, -t1h - sg);
+            atomicAdd(g_nb + o0, -t0 / D0);
+            atomicAdd(g_nb + o1, -t1 / D1);
+        }
     }
 }
 
@@ -516,7 +572,8 @@ extern "C" int nf_mixlog_coupling_fwd(const float* z, const float* params, const
     if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane (see k_mixlog_oct_fwd)
         unsigned g = nf_grid_for(B * 8, NF_BLOCK);
         if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(k_mixlog_oct_fwd, dim3(g), dim3(NF_BLOCK), 0, st, z, params, a_log_scale, a_bias, y, ld, s, K, logit_eps, B);
+        hipLaunchKernelGGL(k_mixlog_oct_fwd<false>, dim3(g), dim3(NF_BLOCK), 0, st, z, params, a_log_scale, a_bias, nullptr, nullptr, y, ld, s, K,
+                           logit_eps, B);
     } else if (s.n_half <= NF_MX_ROWS_MAX) {
         const int th = nf_mx_threads(K);
         unsigned g = nf_grid_for(B, th);
@@ -547,8 +604,8 @@ extern "C" int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const
     if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane
         unsigned g2 = nf_grid_for(B * 8, NF_OCT_BWD_THREADS);
         if (g2 > NF_OCT_BWD_MAX_BLOCKS) g2 = NF_OCT_BWD_MAX_BLOCKS;
-        hipLaunchKernelGGL(k_mixlog_oct_bwd, dim3(g2), dim3(NF_OCT_BWD_THREADS), 0, st, g_y, g_ld, z, params, a_log_scale, a_bias,
-                           g_z, g_params, g_scale, g_bias, s, K, logit_eps, B);
+        hipLaunchKernelGGL(k_mixlog_oct_bwd<false>, dim3(g2), dim3(NF_OCT_BWD_THREADS), 0, st, g_y, g_ld, z, params, a_log_scale,
+                           a_bias, nullptr, nullptr, g_z, g_params, g_scale, g_bias, nullptr, nullptr, s, K, logit_eps, B);
         NF_CHECK_LAUNCH();
         return 0;
     }
@@ -580,6 +637,41 @@ extern "C" int nf_mixlog_coupling_inv(const float* z, const float* params, const
     hipLaunchKernelGGL((k_mixlog_inv<KT, 2>), dim3(g), dim3(th), lds, st, z, params, a_log_scale, a_bias, y, ld, scratch, stuck_flag, s, K, total)
     NF_MX_DISPATCH(K, CALL);
 #undef CALL
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- Flow++ density step pair: mixture coupling on two features, then the next step's ActNorm (nfhip.h) -------------------
+extern "C" int nf_flowpp_vec_couple_fwd(const float* z, const float* params, const float* a_log_scale, const float* a_bias,
+                                        const float* next_log_scale, const float* next_bias, float* y, float* ld, int K,
+                                        float logit_eps, int odd, int64_t B, nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_mixlog_args(s, NF_SPLIT_1D, odd, 2, 1, 1, K) || K > 8 || next_log_scale == nullptr || next_bias == nullptr)
+        return NF_E_BADARG;
+    if (B == 0) return 0;
+    unsigned g = nf_grid_for(B * 8, NF_BLOCK);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_mixlog_oct_fwd<true>, dim3(g), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, params, a_log_scale, a_bias,
+                       next_log_scale, next_bias, y, ld, s, K, logit_eps, B);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_flowpp_vec_couple_bwd(const float* g_h, const float* g_ld, const float* z, const float* params,
+                                        const float* a_log_scale, const float* a_bias, const float* next_log_scale,
+                                        const float* next_bias, float* g_z, float* g_params, float* g_scale, float* g_bias,
+                                        float* g_next_log_scale, float* g_next_bias, int K, float logit_eps, int odd, int64_t B,
+                                        nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_mixlog_args(s, NF_SPLIT_1D, odd, 2, 1, 1, K) || K > 8 || next_log_scale == nullptr || next_bias == nullptr ||
+        g_next_log_scale == nullptr || g_next_bias == nullptr)
+        return NF_E_BADARG;
+    if (B == 0) return 0;
+    unsigned g2 = nf_grid_for(B * 8, NF_OCT_BWD_THREADS);
+    if (g2 > NF_OCT_BWD_MAX_BLOCKS) g2 = NF_OCT_BWD_MAX_BLOCKS;
+    hipLaunchKernelGGL(k_mixlog_oct_bwd<true>, dim3(g2), dim3(NF_OCT_BWD_THREADS), 0, (hipStream_t)stream, g_h, g_ld, z, params,
+                       a_log_scale, a_bias, next_log_scale, next_bias, g_z, g_params, g_scale, g_bias, g_next_log_scale,
+                       g_next_bias, s, K, logit_eps, B);
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -648,12 +648,14 @@ def glow_step_vec(z, ld, actnorm, conv, coupling):
 class _FlowppCouplingVec(torch.autograd.Function):
     """(y, ld) = MixLogAttnCoupling.forward for dims = (D,): 2 launches forward (no gather), 3 backward (the conditioner's
     input gradient is added in place into the coupling's, no scatter / add).  tensors: a_log_scale, a_bias, then the 15
-    conditioner tensors of _flowpp_tensors."""
+    conditioner tensors of _flowpp_tensors.  post = (log_scale, bias) of the NEXT step's ActNorm (D = 2 only): applied by the
+    same coupling launches (nf_flowpp_vec_couple_fwd / _bwd), the pair then returns the ActNorm's output."""
 
     @staticmethod
-    def forward(ctx, z, ld, K, eps, odd, F_, *tensors):
-        a, c = tensors[:2]
-        ts = tensors[2:]
+    def forward(ctx, z, ld, K, eps, odd, F_, n_post, *tensors):
+        post = tensors[:n_post]
+        a, c = tensors[n_post:n_post + 2]
+        ts = tensors[n_post + 2:]
         z = z.contiguous()
         Nrows, D = z.shape
         I0 = ts[0].shape[1]
@@ -663,22 +665,28 @@ class _FlowppCouplingVec(torch.autograd.Function):
         N.call('nf_flowpp_cond_fwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(params), D, 2, Nrows, I0, O,
                N.stream())
         y = torch.empty_like(z)
-        N.call('nf_mixlog_coupling_fwd', N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(y), N.ptr(ld), K, float(eps),
-               N.SPLIT_1D, int(odd), Nrows, D, 1, 1, N.stream())
+        if n_post:
+            N.call('nf_flowpp_vec_couple_fwd', N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(post[0]), N.ptr(post[1]),
+                   N.ptr(y), N.ptr(ld), K, float(eps), int(odd), Nrows, N.stream())
+        else:
+            N.call('nf_mixlog_coupling_fwd', N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(y), N.ptr(ld), K, float(eps),
+                   N.SPLIT_1D, int(odd), Nrows, D, 1, 1, N.stream())
         ctx.save_for_backward(z, params, *tensors)
-        ctx.meta = (K, float(eps), int(odd), F_)
+        ctx.meta = (K, float(eps), int(odd), F_, n_post)
         from .functional import _sinks
         ctx.sinks_ac = _sinks(a, c)
         ctx.sinks_net = _sinks(*ts)
+        ctx.sinks_post = _sinks(*post) if n_post else None
         ctx.mark_dirty(ld)
         return y, ld
 
     @staticmethod
     def backward(ctx, g_y, g_ld):
         z, params, *tensors = ctx.saved_tensors
-        a, c = tensors[:2]
-        ts = tensors[2:]
-        K, eps, odd, F_ = ctx.meta
+        K, eps, odd, F_, n_post = ctx.meta
+        post = tensors[:n_post]
+        a, c = tensors[n_post:n_post + 2]
+        ts = tensors[n_post + 2:]
         Nrows, D = z.shape
         I0 = ts[0].shape[1]
         O = ts[13].shape[0]
@@ -693,8 +701,19 @@ class _FlowppCouplingVec(torch.autograd.Function):
             g_ac = torch.zeros(2, dtype=torch.float32, device=dev)
             pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
             ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
-        N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(g_z),
-               N.ptr(g_p), pa, pc, K, eps, N.SPLIT_1D, odd, Nrows, D, 1, 1, N.stream())
+        gpost = ()
+        if n_post:
+            if ctx.sinks_post is not None:
+                pls, pb, gpost = ctx.sinks_post[0].data_ptr(), ctx.sinks_post[1].data_ptr(), (None, None)
+            else:
+                g_n = torch.zeros(2, D, dtype=torch.float32, device=dev)
+                pls, pb = g_n[0].data_ptr(), g_n[1].data_ptr()
+                gpost = (g_n[0].view_as(post[0]), g_n[1].view_as(post[1]))
+            N.call('nf_flowpp_vec_couple_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c),
+                   N.ptr(post[0]), N.ptr(post[1]), N.ptr(g_z), N.ptr(g_p), pa, pc, pls, pb, K, eps, odd, Nrows, N.stream())
+        else:
+            N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(g_z),
+                   N.ptr(g_p), pa, pc, K, eps, N.SPLIT_1D, odd, Nrows, D, 1, 1, N.stream())
         if ctx.sinks_net is not None:
             dst, direct = ctx.sinks_net, True
         else:
@@ -710,15 +729,23 @@ class _FlowppCouplingVec(torch.autograd.Function):
         N.call('nf_flowpp_cond_bwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(g_p), g_z.data_ptr() + 4 * sel1,
                *d, N.ptr(flowpp_bwd_workspace(dev)), D, 2, D, 2, 1, Nrows, I0, O, N.stream())
         gnet = (None, ) * len(ts) if direct else tuple(dst)
-        return (g_z, g_ld, None, None, None, None, ga, gc) + gnet
+        return (g_z, g_ld, None, None, None, None, None) + gpost + (ga, gc) + gnet
 
 
-def flowpp_coupling_vec(z, ld, coupling):
-    """MixLogAttnCoupling.forward on (N, D) data with the fused conditioner (see flowpp_cond_fusable)."""
+def flowpp_post_actnorm_usable(z, coupling, actnorm):
+    """the (coupling, next ActNorm) pair of a 2-feature Flow++ density flow runs as the coupling's own launches"""
+    return (z.dim() == 2 and z.shape[1] == 2 and z.shape[0] > 0 and coupling.n_mixtures <= 8 and actnorm.initialized
+            and actnorm.log_scale.numel() == 2 and flowpp_cond_fusable(coupling.net, z[:, :1]))
+
+
+def flowpp_coupling_vec(z, ld, coupling, post=None):
+    """MixLogAttnCoupling.forward on (N, D) data with the fused conditioner (see flowpp_cond_fusable); post = the next flow
+    step's (initialised) ActNorm, applied in the same launches when flowpp_post_actnorm_usable."""
     from .functional import _owned_ld
     ts, F_ = _flowpp_tensors(coupling.net)
+    extra = () if post is None else (post.log_scale, post.bias)
     return _FlowppCouplingVec.apply(z, _owned_ld(ld), coupling.n_mixtures, coupling.logit_eps, int(coupling.odd), F_,
-                                    coupling.a_log_scale, coupling.a_bias, *ts)
+                                    len(extra), *extra, coupling.a_log_scale, coupling.a_bias, *ts)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -61,6 +61,18 @@ class Compose(nn.Module):
             return False
         return not (a._forward_hooks or k._forward_hooks or a._forward_pre_hooks or k._forward_pre_hooks)
 
+    def _flowpp_pair_at(self, i, z):
+        """[MixLogAttnCoupling, ActNorm (initialised)] on two features -> the next step's ActNorm rides the coupling's launches"""
+        L = self.layers
+        if not (self.fuse and z.is_cuda and i + 1 < len(L)):
+            return False
+        k, a = L[i], L[i + 1]
+        if not (type(k) is MixLogAttnCoupling and type(a) is ActNorm and k.mode == N.SPLIT_1D):
+            return False
+        if a._forward_hooks or k._forward_hooks or a._forward_pre_hooks or k._forward_pre_hooks:
+            return False
+        return FUSED.flowpp_post_actnorm_usable(z, k, a)
+
     def forward(self, z, log_df_dz):
         L, n, i = self.layers, len(self.layers), 0
         while i < n:
@@ -90,6 +102,9 @@ class Compose(nn.Module):
                                                      c.U_mask, c.sign_s, c.log_s, k.mode, k.odd)
                     z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
                 i += 3
+            elif self._flowpp_pair_at(i, z):
+                z, log_df_dz = FUSED.flowpp_coupling_vec(z, log_df_dz, L[i], post=L[i + 1])   # coupling + next ActNorm
+                i += 2
             else:
                 z, log_df_dz = L[i](z, log_df_dz)
                 i += 1

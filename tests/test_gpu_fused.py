@@ -168,6 +168,52 @@ def test_fused_flowpp_conditioner_backward(pkg, D, K, N, direct):
     assert torch.count_nonzero(layer.net[3].conv1.bias.grad[:2 * F_]) == 0
 
 
+@pytest.mark.parametrize('direct', [False, True])
+@pytest.mark.parametrize('K,N,odd', [(8, 65536, False), (8, 1001, True), (4, 77, False), (8, 1, True)])
+def test_flowpp_coupling_with_next_actnorm(pkg, K, N, odd, direct):
+    """[MixLogAttnCoupling, ActNorm] on two features: the Compose peephole runs the next step's ActNorm inside the coupling's
+    launches (nf_flowpp_vec_couple_fwd / _bwd); outputs, log-det, input gradient and every parameter gradient against the
+    layer-by-layer path (flows/flowpp.py:60-66, modules.py:246-249)."""
+    torch.manual_seed(K + N)
+    k = pkg.MixLogAttnCoupling((2, ), n_mixtures=K, odd=odd).to(DEV)
+    a = pkg.ActNorm((2, )).to(DEV)
+    with torch.no_grad():
+        a.log_scale.normal_(0, 0.4)
+        a.bias.normal_(0, 0.5)
+        k.a_log_scale.fill_(0.3)
+        k.a_bias.fill_(-0.2)
+        for p in k.net[-1].parameters():
+            p.normal_(0, 0.2)
+    a.initialized = True
+    comp = pkg.Compose([k, a]).to(DEV)
+    z = (torch.randn(N, 2) * 0.9).to(DEV).requires_grad_(True)
+    z2 = z.detach().clone().requires_grad_(True)
+    wy, wl = torch.randn(N, 2, device=DEV), torch.randn(N, device=DEV)
+
+    comp.fuse = False
+    y, ld = comp(z, torch.zeros(N, device=DEV))
+    ((y * wy).sum() + (ld * wl).sum()).backward()
+    ref = {n: p.grad.clone() for n, p in comp.named_parameters()}
+    for p in comp.parameters():
+        p.grad = None
+        if direct:
+            p.grad = torch.zeros_like(p)
+            p._nf_direct_grad = True
+    comp.fuse = True
+    assert comp._flowpp_pair_at(0, z2)
+    y2, ld2 = comp(z2, torch.zeros(N, device=DEV))
+    G.assert_close(y2, y, 2e-5, rtol=2e-5, what='pair output')
+    G.assert_close(ld2, ld, 2e-5, rtol=2e-5, what='pair log-det')
+    ((y2 * wy).sum() + (ld2 * wl).sum()).backward()
+    G.assert_close(z2.grad, z.grad, _grad_tol(z.grad), what='input grad')
+    for n, p in comp.named_parameters():
+        G.assert_close(p.grad, ref[n], _grad_tol(ref[n]), what='grad ' + n)
+
+    # an uninitialised ActNorm keeps its data-dependent init: no fusion
+    a.initialized = False
+    assert not comp._flowpp_pair_at(0, z2)
+
+
 @pytest.mark.parametrize('in_ch,out_ch,N', [(1, 2, 4096), (1, 2, 257), (3, 6, 1000), (16, 32, 64), (32, 32, 96),
                                             (1, 2, 1), (2, 4, 16384)])
 @pytest.mark.parametrize('training', [True, False])
@@ -295,7 +341,8 @@ def test_glow_step_vec_vs_unfused(pkg, D, odd, N, training, direct):
             continue
         assert p2[name].grad is not None, name
         pre_bn_bias = training and name.endswith('module.bias') and 'out_block' not in name
-        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(p.grad)
+        # a bias in front of a BatchNorm has gradient exactly 0; both paths return fp32 cancellation noise of N-term sums
+        tol = 5e-3 + 3e-6 * N if pre_bn_bias else _grad_tol(p.grad)
         if big:
             tol = max(tol, 1e-2 * float(p.grad.abs().max()))
         G.assert_close(p2[name].grad, p.grad, tol, what='grad ' + name)
@@ -369,7 +416,8 @@ def test_maf_step_vec_vs_unfused(pkg, D, N, direct):
             continue
         assert p2[name].grad is not None, name
         pre_bn_bias = '.biases.' in name and not name.endswith('.biases.3')
-        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(p.grad)
+        # a bias in front of a BatchNorm has gradient exactly 0; both paths return fp32 cancellation noise of N-term sums
+        tol = 5e-3 + 3e-6 * N if pre_bn_bias else _grad_tol(p.grad)
         if big:
             tol = max(tol, 1e-2 * float(p.grad.abs().max()))
         G.assert_close(p2[name].grad, p.grad, tol, what='grad ' + name)
@@ -431,7 +479,8 @@ def test_realnvp_step_vec_vs_unfused(pkg, D, odd, N, direct):
             continue
         assert p2[name].grad is not None, name
         pre_bn_bias = name.endswith('module.bias') and 'out_block' not in name
-        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(p.grad)
+        # a bias in front of a BatchNorm has gradient exactly 0; both paths return fp32 cancellation noise of N-term sums
+        tol = 5e-3 + 3e-6 * N if pre_bn_bias else _grad_tol(p.grad)
         G.assert_close(p2[name].grad, p.grad, tol, what='grad ' + name)
     b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
     for name in b1:
