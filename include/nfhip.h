@@ -319,6 +319,42 @@ typedef struct nf_weight_grad_desc {
 } nf_weight_grad_desc;
 int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, float wn_eps, nf_stream_t stream);
 
+/* ---- fused 3x3 / 1x1 convolution + BatchNorm2d + ReLU chain on fp32 MFMA (NCHW) ---------------------------------------
+ * The building block of the image conditioner ConvNet (flows/modules.py:416-438: WN(conv3x3) -> [BN -> ReLU -> WN(conv3x3)]
+ * x 4 with residual adds -> BN -> ReLU -> WN(conv1x1)); the convolutional twin of nf_linear_bn_fwd with the same contract:
+ *
+ *     act[b,i,y,x] = in[b,i,y,x]                                                    (no input BatchNorm)
+ *                  = relu( (in - mean_i) * invstd_i * gamma_i + beta_i )            ("normalise on load")
+ *     out[b,o,y,x] = sum_{i,dy,dx} act[b,i,y+dy,x+dx] * weight[o,i,dy,dx] + bias[o] (+ residual[b,o,y,x])   zero padding
+ *     stat_sum[o] += sum (out - bias[o]),  stat_sqsum[o] += sum (out - bias[o])^2   over (b, y, x)   ("statistics on store")
+ *
+ * weight is the EFFECTIVE weight (the weight-norm arithmetic of all convolutions of a model is one nf_weight_norm_fwd launch).
+ * training / running statistics / save_mean / save_invstd exactly as nf_linear_bn_fwd, the batch count is B*H*W.
+ * Limits: ksize 3 (pad 1) or 1, I <= 64, O <= 96; I <= 32 with an input BatchNorm, O <= 32 with statistics; the spatial size
+ * must tile into 128-pixel groups of whole rows or whole samples (nf_conv_bn_usable != 0).                              */
+typedef struct nf_conv_desc {
+    const float* in;          /* (B, I, H, W) */
+    const float* weight;      /* (O, I, k, k) effective weight */
+    const float* bias;        /* (O,) */
+    const float* residual;    /* (B, O, H, W) or NULL */
+    float* out;               /* (B, O, H, W) */
+    const float* bn_gamma;    /* (I,) input BatchNorm affine; NULL = no input BatchNorm/ReLU */
+    const float* bn_beta;
+    const float* bn_sum;      /* NF_STAT_REPL x 32, training: sum (in - bn_center) */
+    const float* bn_sqsum;
+    const float* bn_center;   /* (I,) */
+    float* bn_running_mean;   /* (I,) */
+    float* bn_running_var;    /* (I,) */
+    int64_t* bn_num_batches;  /* scalar or NULL */
+    float* bn_save_mean;      /* (I,) training: written */
+    float* bn_save_invstd;    /* (I,) training: written */
+    float* stat_sum;          /* NF_STAT_REPL x 32 or NULL */
+    float* stat_sqsum;
+} nf_conv_desc;
+int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksize);
+int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, int training, float bn_eps,
+                   float bn_momentum, nf_stream_t stream);
+
 /* ---- invertible residual block (Residual Flow), D <= 4 features, hidden width 32  iresblock.py:17-109, :229-278 ------
  * g(x) = W3 lipswish(W2 lipswish(W1 x + b1) + b2) + b3 with the EFFECTIVE (spectrally normalised) weights.
  * nf_resmlp_fwd: y = x + g(x) (y nullable) and, by `mode`: 0 nothing; 1 ld[b] += ld_sign * log|det(I + J_b)| (exact,

@@ -1,0 +1,70 @@
+"""forward check of nf_conv_bn_fwd against torch (conv2d + BatchNorm2d + relu), all Glow-CIFAR conditioner shapes."""
+import ctypes
+import importlib
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, '.')
+pkg = importlib.import_module('normalizing-flows-pytorch_amd')
+N = importlib.import_module('normalizing-flows-pytorch_amd._native')
+fused = importlib.import_module('normalizing-flows-pytorch_amd.fused')
+R = 8
+FIELDS = ['in_', 'weight', 'bias', 'residual', 'out', 'bn_gamma', 'bn_beta', 'bn_sum', 'bn_sqsum', 'bn_center',
+          'bn_running_mean', 'bn_running_var', 'bn_num_batches', 'bn_save_mean', 'bn_save_invstd', 'stat_sum', 'stat_sqsum']
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in FIELDS]
+
+
+def run(B, I, O, H, W, k, bn, res, dev='cuda'):
+    torch.manual_seed(B + I + O + H)
+    x = torch.randn(B, I, H, W, device=dev)
+    w = torch.randn(O, I, k, k, device=dev) * 0.2
+    b = torch.randn(O, device=dev)
+    r = torch.randn(B, O, H, W, device=dev) if res else None
+    out = torch.empty(B, O, H, W, device=dev)
+    kw = dict(in_=x, weight=w, bias=b, residual=r, out=out)
+    stat = torch.zeros(2, R, 32, device=dev)
+    if O <= 32:
+        kw.update(stat_sum=stat[0], stat_sqsum=stat[1])
+    if bn:
+        gamma, beta = torch.rand(I, device=dev) + 0.5, torch.randn(I, device=dev)
+        center = torch.randn(I, device=dev)
+        xs = (x - center.view(1, -1, 1, 1))
+        bsum = torch.zeros(R, 32, device=dev); bsq = torch.zeros(R, 32, device=dev)
+        bsum[0, :I] = xs.sum((0, 2, 3)); bsq[0, :I] = (xs * xs).sum((0, 2, 3))
+        rm, rv = torch.zeros(I, device=dev), torch.ones(I, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        sm, si = torch.empty(I, device=dev), torch.empty(I, device=dev)
+        kw.update(bn_gamma=gamma, bn_beta=beta, bn_sum=bsum, bn_sqsum=bsq, bn_center=center, bn_running_mean=rm,
+                  bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=sm, bn_save_invstd=si)
+    d = fused._desc(ConvDesc, **kw)
+    assert N.load().nf_conv_bn_usable(B, I, O, H, W, k)
+    N.call('nf_conv_bn_fwd', ctypes.addressof(d), B, I, O, H, W, k, 1, 1e-5, 0.1, N.stream())
+    torch.cuda.synchronize()
+    a = x
+    if bn:
+        a = F.relu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5))
+    want = F.conv2d(a.double(), w.double(), None, 1, k // 2).float()
+    if res:
+        want = want + r
+    err = float((out - (want + b.view(1, -1, 1, 1))).abs().max())
+    serr = 0.0
+    if O <= 32:
+        s1 = stat[0].sum(0)[:O]; s2 = stat[1].sum(0)[:O]
+        serr = max(float((s1 - want.sum((0, 2, 3))).abs().max() / max(1.0, float(want.sum((0, 2, 3)).abs().max()))),
+                   float((s2 - (want * want).sum((0, 2, 3))).abs().max() / float((want * want).sum((0, 2, 3)).abs().max())))
+    print('B%d I%d O%d %dx%d k%d bn%d res%d: out err %.2e stat relerr %.2e' % (B, I, O, H, W, k, bn, res, err, serr), flush=True)
+    assert err < 2e-4 and serr < 1e-4
+
+
+for (I, O, H, W) in [(3, 6, 32, 16), (6, 12, 16, 16), (12, 24, 16, 8), (24, 48, 8, 8), (48, 96, 8, 4)]:
+    for B in (64, 5):
+        run(B, I, 32, H, W, 3, False, False)
+        run(B, 32, 32, H, W, 3, True, False)
+        run(B, 32, 32, H, W, 3, True, True)
+        run(B, 32, O, H, W, 1, True, False)
+print('ok')
