@@ -330,8 +330,9 @@ int nf_weight_grad_finalize(const nf_weight_grad_desc* descs, int n_layers, floa
  *
  * weight is the EFFECTIVE weight (the weight-norm arithmetic of all convolutions of a model is one nf_weight_norm_fwd launch).
  * training / running statistics / save_mean / save_invstd exactly as nf_linear_bn_fwd, the batch count is B*H*W.
- * Limits: ksize 3 (pad 1) or 1, I <= 64, O <= 96; I <= 32 with an input BatchNorm, O <= 32 with statistics; the spatial size
- * must tile into 128-pixel groups of whole rows or whole samples (nf_conv_bn_usable != 0).                              */
+ * Limits: ksize 3 (pad 1): I <= 96, O <= 32;  ksize 1: I <= 32, O <= 192;  I <= 32 with an input BatchNorm, O <= 32 with
+ * statistics; W a power of two and the spatial size tiling into 128-pixel groups of whole rows or whole samples
+ * (nf_conv_bn_usable != 0).                              */
 typedef struct nf_conv_desc {
     const float* in;          /* (B, I, H, W) */
     const float* weight;      /* (O, I, k, k) effective weight */
@@ -354,6 +355,54 @@ typedef struct nf_conv_desc {
 int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksize);
 int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, int training, float bn_eps,
                    float bn_momentum, nf_stream_t stream);
+
+/* autograd of nf_conv_bn_fwd in training mode; the gradient G of `out` is assembled on load exactly as in
+ * nf_linear_bn_bwd (G = g_direct + g_skip + BNbwd(gn_src), each term optional).  Results:
+ *     g_store = G (optional);  g_bias[replica][o] += sum G  (NF_STAT_REPL replicas, stride 256 floats);
+ *     g_weff[slab] = this workgroup's part of the gradient of the effective weight, stored (k*k, O, I) so that the stores
+ *                    coalesce (nf_conv_bwd_slabs slabs, written; nf_slab_sum with taps = k*k sums them into (O, I, k, k));
+ *     gn_out = (transposed convolution of G) * [act > 0], sum_g / sum_gx += its batch sums (replicas, stride 32) -- or the
+ *     gradient of `in` itself without an input BatchNorm.                                                              */
+typedef struct nf_conv_bwd_desc {
+    const float* in;            /* (B, I, H, W) forward input */
+    const float* weight;        /* (O, I, k, k) effective weight */
+    const float* bn_gamma;      /* (I,) input BatchNorm (NULL = none) */
+    const float* bn_beta;
+    const float* bn_save_mean;
+    const float* bn_save_invstd;
+    const float* g_direct;      /* (B, O, H, W) or NULL */
+    const float* g_skip;
+    const float* gn_src;
+    const float* out;           /* forward output (needed with gn_src) */
+    const float* cbn_gamma;     /* (O,) consumer BatchNorm */
+    const float* cbn_save_mean;
+    const float* cbn_save_invstd;
+    const float* cbn_sum_g;     /* NF_STAT_REPL x 32, or NULL (evaluation-mode statistics are constants) */
+    const float* cbn_sum_gx;
+    float* g_store;             /* (B, O, H, W) or NULL */
+    float* g_bias;              /* NF_STAT_REPL x 256, += ; or NULL */
+    float* g_weff;              /* (nf_conv_bwd_slabs, k*k, O, I) written */
+    float* gn_out;              /* (B, I, H, W) or NULL */
+    float* sum_g;               /* NF_STAT_REPL x 32, += (with input BatchNorm) */
+    float* sum_gx;
+} nf_conv_bwd_desc;
+int nf_conv_bwd_slabs(int64_t B, int H, int W);
+int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, nf_stream_t stream);
+
+/* dst[e] (+)= sum_{s < n_slabs} src[s * stride + e], e < n: every slab / replica sum of one conditioner backward in ONE
+ * launch (weight-gradient slabs, bias and BatchNorm-parameter replicas).                                                */
+#define NF_SLAB_SUM_MAX 32
+typedef struct nf_slab_sum_desc {
+    const float* src;
+    float* dst;
+    int64_t n;
+    int64_t stride;
+    int n_slabs;
+    int accumulate;
+    int taps;       /* > 1: the slabs are nf_conv_bn_bwd's (taps, O, I) order and dst is the (O, I, taps) weight gradient */
+    int reserved;
+} nf_slab_sum_desc;
+int nf_slab_sum(const nf_slab_sum_desc* descs, int n_jobs, nf_stream_t stream);
 
 /* ---- invertible residual block (Residual Flow), D <= 4 features, hidden width 32  iresblock.py:17-109, :229-278 ------
  * g(x) = W3 lipswish(W2 lipswish(W1 x + b1) + b2) + b3 with the EFFECTIVE (spectrally normalised) weights.

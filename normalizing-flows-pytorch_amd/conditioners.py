@@ -10,6 +10,8 @@ GatedAttn), flows/coupling.py:142-166 (the Flow++ stack), flows/maf.py:9-85 (MAD
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -111,8 +113,20 @@ class ConvNet(nn.Module):
         self.out_block = nn.Sequential(nn.BatchNorm2d(base_filters), nn.ReLU(inplace=True),
                                        _wn(nn.Conv2d(base_filters, out_channels, 1, 1, 0), weight_norm))
 
-    def forward(self, x):
+    # csrc/conv_bn.hip: parity-complete, but at the reference's sizes (64 x 32 x 16 x 16 and smaller) still a few percent
+    # behind the MIOpen + ATen module path per training step -- opt-in until it wins
+    fused = os.environ.get('NF_FUSED_CONV', '0') == '1'
+
+    def forward_reference(self, x):
+        """module-by-module PyTorch path (MIOpen + ATen); used off-GPU and as the parity reference of the fused one."""
         return self.out_block(self.mid_block(self.in_block(x)))
+
+    def forward(self, x):
+        if self.fused and x.is_cuda and x.dtype == torch.float32:
+            from .fused_conv import convnet_forward, convnet_usable   # fp32-MFMA conv + BatchNorm kernels: 6 launches
+            if convnet_usable(self, x):
+                return convnet_forward(self, x)
+        return self.forward_reference(x)
 
 
 # ---- Flow++ conditioner ---------------------------------------------------------------------------------------------

@@ -10,15 +10,41 @@
 // 32x32 C/D layout a lane then holds ONE pixel and 16 output channels, so every store instruction writes 32 consecutive
 // pixels of a channel plane -- the NCHW-coalesced direction -- and the operand loads are conflict-free LDS rows.
 // v_mfma_f32_32x32x2_f32 (exact fp32: the 1e-5 parity bar rules out bf16 / xf32).
+//
+// These launches are LATENCY-bound (a 64 x 32 x 16 x 16 layer is 0.3 GFLOP over 128 workgroups, one wave per SIMD): what
+// matters is the length of the serial chain inside a workgroup.  Hence: every global load of a phase is issued before the
+// first dependent store (one memory latency per phase, not one per loop trip); no integer division on the per-element
+// paths (the spatial extents are powers of two, the weight decode is done once per lane); the MFMA operands are read from
+// LDS one group ahead of the MFMAs that consume them; the per-channel batch sums use a halving butterfly (16 shuffles per
+// statistic instead of 80).
 #include "nf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define NF_CV_WAVES 4
+// phase stamps of workgroup 0 (tools/probes/conv_prof.py builds this file with -DNF_CV_PROF=1; 100 MHz wall clock)
+#ifdef NF_CV_PROF
+__device__ long long nf_cv_prof[32];
+#define NF_CV_STAMP(i)                                                                 \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) nf_cv_prof[i] = wall_clock64();       \
+    } while (0)
+extern "C" int nf_cv_prof_read(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cv_prof), sizeof(long long) * 32);
+}
+#else
+#define NF_CV_STAMP(i)
+#endif
+
+#define NF_CV_WAVES 16               // four pixel blocks x four K quarters (3x3) / output-block groups (1x1)
+#define NF_CV_THREADS (NF_CV_WAVES * NF_WAVE)
 #define NF_CV_PX 128                 // pixels per tile
 #define NF_CV_MAX_FRAME 384          // frame positions per channel (all segments of a tile)
-#define NF_CV_MAX_I 64
-#define NF_CV_MAX_O 96
+#define NF_CV_FJ (NF_CV_MAX_FRAME / NF_WAVE)
+#define NF_CV_CU (32 / NF_CV_WAVES)  // channels of a 32-channel chunk a wave stages
+#define NF_CV_MAX_I 96
+#define NF_CV_MAX_O 192
+#define NF_CV_WS 33                  // row stride of the LDS weight tiles of 32 columns (odd: conflict-free both ways)
+#define NF_CV_RS (NF_CV_WAVES * 12 * NF_WAVE)   // floats of the K-quarter exchange
 
 struct NfCvGeo {
     int H, W, HW;
@@ -28,16 +54,24 @@ struct NfCvGeo {
     int FW, FS;    // frame width, frame positions per segment
     int FSZ;       // SEG * FS
     int CS;        // channel stride of a frame in LDS (odd)
-    int T;         // taps: 9 or 1
+    int lgW, lgSP; // log2 of W and of the pixels per segment
+    int lgHW;      // log2 of H*W (a power of two)
+    int nfj;       // frame positions per lane: ceil(FSZ / 64)
+    float invFS, invFW;
     int64_t B;
     int64_t tiles;
 };
+
+static inline int nf_cv_log2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
 
 static inline bool nf_cv_geometry(NfCvGeo& g, int64_t B, int H, int W, int ksize) {
     if (B < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3)) return false;
     g.H = H; g.W = W; g.HW = H * W; g.B = B;
     g.halo = ksize == 3 ? 1 : 0;
-    g.T = ksize * ksize;
     if (g.HW >= NF_CV_PX) {
         if (g.HW % NF_CV_PX != 0 || NF_CV_PX % W != 0 || g.HW > 32768) return false;
         g.TH = NF_CV_PX / W; g.SEG = 1;
@@ -45,11 +79,18 @@ static inline bool nf_cv_geometry(NfCvGeo& g, int64_t B, int H, int W, int ksize
         if (NF_CV_PX % g.HW != 0) return false;
         g.TH = H; g.SEG = NF_CV_PX / g.HW;
     }
+    g.lgW = nf_cv_log2(W);
+    g.lgSP = nf_cv_log2(g.TH * W);
+    g.lgHW = nf_cv_log2(g.HW);
+    if (g.lgW < 0 || g.lgSP < 0 || g.lgHW < 0) return false;
     g.FW = W + 2 * g.halo;
     g.FS = (g.TH + 2 * g.halo) * g.FW;
     g.FSZ = g.SEG * g.FS;
     if (g.FSZ > NF_CV_MAX_FRAME) return false;
     g.CS = g.FSZ | 1;
+    g.nfj = (g.FSZ + NF_WAVE - 1) / NF_WAVE;
+    g.invFS = 1.f / (float)g.FS;
+    g.invFW = 1.f / (float)g.FW;
     g.tiles = (B * g.HW + NF_CV_PX - 1) / NF_CV_PX;
     return true;
 }
@@ -57,69 +98,173 @@ static inline bool nf_cv_geometry(NfCvGeo& g, int64_t B, int H, int W, int ksize
 extern "C" int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksize) {
     NfCvGeo g;
     if (I < 1 || O < 1 || I > NF_CV_MAX_I || O > NF_CV_MAX_O) return 0;
+    if (ksize == 3 && O > 32) return 0;                  // the 3x3 layers of the reference produce 32 channels
+    if (ksize == 1 && I > 32) return 0;
     return nf_cv_geometry(g, B, H, W, ksize) ? 1 : 0;
 }
 
-__device__ __forceinline__ float nf_half32_sum_cv(float v) {  // sum over the 32 lanes of this wave half
+__device__ __forceinline__ int nf_cv_cd_row(int r, int hs) { return (r & 3) + 8 * (r >> 2) + 4 * hs; }
+
+// frame position of pixel px (0..127) of a tile: shifts only
+__device__ __forceinline__ int nf_cv_frame_of(const NfCvGeo& g, int px) {
+    const int s = px >> g.lgSP, q = px & ((1 << g.lgSP) - 1);
+    return s * g.FS + ((q >> g.lgW) + g.halo) * g.FW + (q & (g.W - 1)) + g.halo;
+}
+
+// frame position f -> (owned << 30 | segment << 16 | y*W + x) of the image, or -1 outside the image / batch
+#define NF_CV_SEG(t) (((t) >> 16) & 0x3fff)
+#define NF_CV_SP(t) ((t) & 0xffff)
+__device__ __forceinline__ int nf_cv_decode(const NfCvGeo& g, int64_t b0, int y0, int f) {
+    if (f >= g.FSZ) return -1;
+    // f / FS and q / FW for f < 384 by reciprocal multiplication (exact: the half-integer offset keeps the quotient
+    // 0.5 / FS away from every integer, far beyond fp32 rounding) -- an integer division is ~40 instructions
+    const int s = (int)(((float)f + 0.5f) * g.invFS), q = f - s * g.FS;
+    const int fy = (int)(((float)q + 0.5f) * g.invFW), fx = q - fy * g.FW;
+    const int gy = y0 + fy - g.halo, gx = fx - g.halo;
+    const bool ok = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (b0 + s) < g.B;
+    const bool owned = fy >= g.halo && fy < g.TH + g.halo && fx >= g.halo && fx < g.W + g.halo;
+    return ok ? (((int)owned << 30) | (s << 16) | (gy * g.W + gx)) : -1;
+}
+__device__ __forceinline__ void nf_cv_decode_all(int (&t)[NF_CV_FJ], const NfCvGeo& g, int64_t tile, int lane, int64_t& b0) {
+    const int64_t P0 = tile * NF_CV_PX;
+    b0 = P0 >> g.lgHW;
+    const int y0 = g.SEG == 1 ? (int)(P0 & (g.HW - 1)) >> g.lgW : 0;
+#pragma unroll
+    for (int j = 0; j < NF_CV_FJ; ++j) t[j] = j < g.nfj ? nf_cv_decode(g, b0, y0, lane + NF_WAVE * j) : -1;
+}
+
+// sum over the 32 lanes of a wave half
+__device__ __forceinline__ float nf_cv_half_sum(float v) {
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, NF_WAVE);
     return v;
 }
-__device__ __forceinline__ int nf_cv_cd_row(int r, int hs) { return (r & 3) + 8 * (r >> 2) + 4 * hs; }
+// sum of 16 per-lane values over the 32 lanes of a wave half in 16 shuffles: each step halves the values a lane carries.
+// Returns, in every lane, the total of register index (lane & 31) >> 1.
+__device__ __forceinline__ float nf_cv_butterfly16(const float (&s)[16], int c32) {
+    float t8[8], t4[4], t2[2];
+    const bool b4 = c32 & 16, b3 = c32 & 8, b2 = c32 & 4, b1 = c32 & 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b4 ? s[i + 8] : s[i], send = b4 ? s[i] : s[i + 8];
+        t8[i] = keep + __shfl_xor(send, 16, NF_WAVE);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b3 ? t8[i + 4] : t8[i], send = b3 ? t8[i] : t8[i + 4];
+        t4[i] = keep + __shfl_xor(send, 8, NF_WAVE);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b2 ? t4[i + 2] : t4[i], send = b2 ? t4[i] : t4[i + 2];
+        t2[i] = keep + __shfl_xor(send, 4, NF_WAVE);
+    }
+    const float keep = b1 ? t2[1] : t2[0], send = b1 ? t2[0] : t2[1];
+    float v = keep + __shfl_xor(send, 2, NF_WAVE);
+    v += __shfl_xor(v, 1, NF_WAVE);
+    return v;
+}
 
-// frame table: position f of the tile's frame -> (segment << 16 | y*W + x) of the image, or -1 outside the image / batch
-__device__ __forceinline__ void nf_cv_frame_table(int* tab, const NfCvGeo& g, int64_t tile) {
-    const int64_t P0 = tile * NF_CV_PX;
-    const int64_t b0 = P0 / g.HW;
-    const int y0 = g.SEG == 1 ? (int)((P0 - b0 * g.HW) / g.W) : 0;
-    for (int f = threadIdx.x; f < g.FSZ; f += blockDim.x) {
-        const int s = f / g.FS, q = f - s * g.FS;
-        const int fy = q / g.FW, fx = q - fy * g.FW;
-        const int gy = y0 + fy - g.halo, gx = fx - g.halo;
-        const bool ok = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (b0 + s) < g.B;
-        tab[f] = ok ? ((s << 16) | (gy * g.W + gx)) : -1;
+// ---------------------------------------------------------------------------------------------------------------
+// staging helpers.  A CHUNK is up to 32 input channels [i0, i0 + IC), padded to ICP (multiple of 16) rows of zeros.
+// ---------------------------------------------------------------------------------------------------------------
+// weights of a 3x3 chunk, global (O <= 32, I, 9) -> LDS rows k = tap * ICP + ic, columns oc (TRANSPOSED == false, forward) or
+// rows k = tap * OP + oc, columns ic (TRANSPOSED == true, data gradient).  A lane owns the entries r = lane + 64 j of the
+// (ic, tap) plane, which are CONTIGUOUS in global memory for every oc; wave w takes oc = w, w + 16.
+template <int T>
+struct NfCvW {
+    static constexpr int NJ = (32 * T + NF_WAVE - 1) / NF_WAVE;
+    float v[NJ][NF_CV_CU];
+    int rr[NJ], dst[NJ];
+};
+template <int T, bool TRANSPOSED>
+__device__ __forceinline__ void nf_cv_w_load(NfCvW<T>& w, const float* __restrict__ weight, int O, int I, int i0, int IC, int ICP,
+                                             int OP, int wid, int lane) {
+    const int ostride = I * T;
+    const float* src = weight + i0 * T;
+#pragma unroll
+    for (int j = 0; j < NfCvW<T>::NJ; ++j) {
+        const int r = lane + NF_WAVE * j;
+        const int ic = r / T, tap = r - ic * T;               // T is a compile-time constant
+        w.rr[j] = r < IC * T ? r : -1;
+        w.dst[j] = TRANSPOSED ? (tap * OP) * NF_CV_WS + ic : (tap * ICP + ic) * NF_CV_WS;
+#pragma unroll
+        for (int u = 0; u < NF_CV_CU; ++u) {
+            const int oc = wid + u * NF_CV_WAVES;
+            w.v[j][u] = (w.rr[j] >= 0 && oc < O) ? src[oc * ostride + r] : 0.f;
+        }
     }
 }
-// frame position of pixel r (0..127) of a tile
-__device__ __forceinline__ int nf_cv_frame_of(const NfCvGeo& g, int r) {
-    const int seg_px = g.TH * g.W;
-    const int s = r / seg_px, q = r - s * seg_px;
-    const int ly = q / g.W, x = q - ly * g.W;
-    return s * g.FS + (ly + g.halo) * g.FW + x + g.halo;
+template <int T, bool TRANSPOSED>
+__device__ __forceinline__ void nf_cv_w_store(const NfCvW<T>& w, float* Wl, int O, int wid) {
+#pragma unroll
+    for (int j = 0; j < NfCvW<T>::NJ; ++j)
+#pragma unroll
+        for (int u = 0; u < NF_CV_CU; ++u) {
+            const int oc = wid + u * NF_CV_WAVES;
+            if (w.rr[j] >= 0 && oc < O) Wl[w.dst[j] + (TRANSPOSED ? oc * NF_CV_WS : oc)] = w.v[j][u];
+        }
+}
+// zero rows [first, first + n_pad) of every tap's block of rows_per_tap rows (the K padding)
+template <int T>
+__device__ __forceinline__ void nf_cv_zero_pad_rows(float* Wl, int rows_per_tap, int first, int n_pad, int wcols) {
+    for (int e = threadIdx.x; e < T * n_pad * wcols; e += NF_CV_THREADS) {
+        const int tap = e / (n_pad * wcols), q = e - tap * (n_pad * wcols);
+        Wl[(tap * rows_per_tap + first) * wcols + q] = 0.f;
+    }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------------------------------------------
-// LDS: Wl[T * IP][32 * OCB]  (k = tap * IP + ic rows, oc contiguous: the A fragment of lane (oc, k) is a conflict-free row)
-//      Al[IP][CS]            (finished activations, zero padded; the B fragment of lane (pixel, k) walks a frame row)
-//      tab[FSZ], kc[2][64], red[2][4][32]
-template <int OCB>
-__global__ void __launch_bounds__(NF_CV_WAVES * NF_WAVE) k_conv_bn_fwd(nf_conv_desc d, NfCvGeo g, int I, int O, int IP,
-                                                                        int training, float eps, float mom) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int WS = 32 * OCB;
-    float* Wl = smem;
-    float* Al = Wl + g.T * IP * WS;
-    int* tab = reinterpret_cast<int*>(Al + IP * g.CS);
-    float* kc = reinterpret_cast<float*>(tab + NF_CV_MAX_FRAME);       // [2][64]
-    float* red = kc + 2 * NF_CV_MAX_I;                                 // [2][4][32]
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
-    const bool has_bn = d.bn_gamma != nullptr;
-    const int64_t Npx = g.B * g.HW;
-    const float invN = 1.f / (float)Npx;
+// activation frame of a chunk: wave w stages channels w, w + 16; lanes = consecutive frame positions (consecutive x);
+// ALL loads in flight at once, BatchNorm + ReLU applied on the way to LDS, zeros outside the image / in the padding
+struct NfCvA { float v[3][NF_CV_CU]; };            // frame positions are handled three per round (<= 192 of them at once)
+template <int JR>
+__device__ __forceinline__ void nf_cv_act_load(NfCvA& a, const int (&t)[NF_CV_FJ], const float* __restrict__ in, const NfCvGeo& g,
+                                               int I, int i0, int IC, int wid) {
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int tt = t[JR + jj];
+        const int base = tt >= 0 ? (NF_CV_SEG(tt) * I + i0) * g.HW + NF_CV_SP(tt) : 0;      // relative to sample b0
+#pragma unroll
+        for (int u = 0; u < NF_CV_CU; ++u) {
+            const int c = wid + u * NF_CV_WAVES;
+            a.v[jj][u] = (tt >= 0 && c < IC) ? in[base + c * g.HW] : 0.f;
+        }
+    }
+}
+template <int JR>
+__device__ __forceinline__ void nf_cv_act_store(const NfCvA& a, float* Al, const int (&t)[NF_CV_FJ], const float* kc,
+                                                const NfCvGeo& g, int IC, int ICP, bool has_bn, int wid, int lane) {
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int f = lane + NF_WAVE * (JR + jj);
+        const int tt = t[JR + jj];
+        if (f < g.FSZ) {
+#pragma unroll
+            for (int u = 0; u < NF_CV_CU; ++u) {
+                const int c = wid + u * NF_CV_WAVES;
+                if (c < ICP) {
+                    float x = a.v[jj][u];
+                    if (has_bn) x = (tt >= 0 && c < IC) ? fmaxf(fmaf(x, kc[c], kc[32 + c]), 0.f) : 0.f;
+                    Al[c * g.CS + f] = x;
+                }
+            }
+        }
+    }
+}
 
-    // ---- once per workgroup: weights, folded BatchNorm constants ----
-    for (int e = threadIdx.x; e < g.T * IP * WS; e += blockDim.x) Wl[e] = 0.f;
-    if ((int)threadIdx.x < NF_CV_MAX_I) {
+// folded constants of the input BatchNorm (threads 0..31): kc[0] scale, kc[1] shift
+__device__ __forceinline__ void nf_cv_bn_consts_fwd(float* kc, const nf_conv_desc& d, int I, int64_t Npx, int training,
+                                                    float eps, float mom) {
+    if (threadIdx.x < 32) {
         const int k = threadIdx.x;
-        float sc = has_bn ? 0.f : 1.f, sh = 0.f;
-        if (has_bn && k < I) {
+        float sc = 1.f, sh = 0.f;
+        if (d.bn_gamma != nullptr && k < I) {
             float mean, invstd;
             if (training) {
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < NF_STAT_REPL; ++r) { t1 += d.bn_sum[32 * r + k]; t2 += d.bn_sqsum[32 * r + k]; }
+                const float invN = 1.f / (float)Npx;
                 const float m1 = t1 * invN;
                 mean = d.bn_center[k] + m1;
                 const float var = fmaxf(t2 * invN - m1 * m1, 0.f);                 // biased, as BatchNorm normalises
@@ -142,111 +287,229 @@ __global__ void __launch_bounds__(NF_CV_WAVES * NF_WAVE) k_conv_bn_fwd(nf_conv_d
             sh = d.bn_beta[k] - mean * sc;
         }
         kc[k] = sc;
-        kc[NF_CV_MAX_I + k] = sh;
+        kc[32 + k] = sh;
     }
-    if (training && has_bn && d.bn_num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0) d.bn_num_batches[0] += 1;
-    __syncthreads();
-    for (int e = threadIdx.x; e < O * I * g.T; e += blockDim.x) {          // global (O, I, T) -> LDS [tap][ic][oc]
-        const int oc = e / (I * g.T), r = e - oc * (I * g.T);
-        const int ic = r / g.T, tap = r - ic * g.T;
-        Wl[(tap * IP + ic) * WS + oc] = d.weight[e];
-    }
-
-    float bias_r[OCB][16];
-#pragma unroll
-    for (int ob = 0; ob < OCB; ++ob)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int oc = ob * 32 + nf_cv_cd_row(r, hs);
-            bias_r[ob][r] = oc < O ? d.bias[oc] : 0.f;
-        }
-    const bool want_stats = d.stat_sum != nullptr;      // O <= 32 (OCB == 1) by contract
-    const bool has_res = d.residual != nullptr;
-    float s1[16], s2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-    const int px = wid * 32 + c32;                      // this lane's pixel of the tile
-    const int fpos = nf_cv_frame_of(g, px);
-
-    for (int64_t tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
-        __syncthreads();                                // previous tile's readers of Al / tab are done
-        nf_cv_frame_table(tab, g, tile);
-        __syncthreads();
-        const int64_t b0 = (tile * NF_CV_PX) / g.HW;
-        for (int c = wid; c < IP; c += NF_CV_WAVES) {   // one channel per wave per trip: consecutive lanes, consecutive x
-            const float sc = kc[c], sh = kc[NF_CV_MAX_I + c];
-            for (int f = lane; f < g.FSZ; f += NF_WAVE) {
-                const int t = tab[f];
-                float v = 0.f;
-                if (t >= 0 && c < I) {
-                    const float x = d.in[((b0 + (t >> 16)) * I + c) * g.HW + (t & 0xffff)];
-                    v = has_bn ? fmaxf(fmaf(x, sc, sh), 0.f) : x;
-                }
-                Al[c * g.CS + f] = v;
-            }
-        }
-        __syncthreads();
-
-        f32x16 acc[OCB];
-#pragma unroll
-        for (int ob = 0; ob < OCB; ++ob)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ob][r] = 0.f;
-        for (int tap = 0; tap < g.T; ++tap) {
-            const int dy = g.T == 9 ? tap / 3 - 1 : 0, dx = g.T == 9 ? tap - (tap / 3) * 3 - 1 : 0;
-            const float* ap = Al + hs * g.CS + fpos + dy * g.FW + dx;
-            const float* wp = Wl + (tap * IP + hs) * WS + c32;
-#pragma unroll 4
-            for (int kk = 0; kk < IP / 2; ++kk) {
-                const float bv = ap[2 * kk * g.CS];
-#pragma unroll
-                for (int ob = 0; ob < OCB; ++ob)
-                    acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[2 * kk * WS + ob * 32], bv, acc[ob], 0, 0, 0);
-            }
-        }
-        // ---- epilogue: bias, residual, store (32 consecutive pixels per instruction), shifted batch sums ----
-        const int64_t P = tile * NF_CV_PX + px;
-        const bool pv = P < Npx;
-        const int64_t b = pv ? P / g.HW : 0;
-        const int64_t q = pv ? P - b * g.HW : 0;
-#pragma unroll
-        for (int ob = 0; ob < OCB; ++ob)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int oc = ob * 32 + nf_cv_cd_row(r, hs);
-                if (pv && oc < O) {
-                    const int64_t idx = (b * O + oc) * g.HW + q;
-                    float dv = acc[ob][r];
-                    if (has_res) dv += d.residual[idx];
-                    d.out[idx] = dv + bias_r[ob][r];
-                    if (ob == 0) { s1[r] += dv; s2[r] = fmaf(dv, dv, s2[r]); }
-                }
-            }
-    }
-    if (want_stats) {                                   // block-uniform branch
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float t1 = nf_half32_sum_cv(s1[r]), t2 = nf_half32_sum_cv(s2[r]);
-            if (c32 == 0) {
-                const int oc = nf_cv_cd_row(r, hs);
-                red[(0 * NF_CV_WAVES + wid) * 32 + oc] = t1;
-                red[(1 * NF_CV_WAVES + wid) * 32 + oc] = t2;
-            }
-        }
-        __syncthreads();
-        if (wid == 0 && hs == 0 && c32 < O) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < NF_CV_WAVES; ++w) { t1 += red[(0 * NF_CV_WAVES + w) * 32 + c32]; t2 += red[(1 * NF_CV_WAVES + w) * 32 + c32]; }
-            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
-            atomicAdd(d.stat_sum + rep + c32, t1);
-            atomicAdd(d.stat_sqsum + rep + c32, t2);
-        }
-    }
+    if (training && d.bn_gamma != nullptr && d.bn_num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        d.bn_num_batches[0] += 1;
 }
 
-static inline size_t nf_cv_fwd_lds(const NfCvGeo& g, int IP, int OCB) {
-    return sizeof(float) * ((size_t)g.T * IP * 32 * OCB + (size_t)IP * g.CS + NF_CV_MAX_FRAME + 2 * NF_CV_MAX_I + 2 * NF_CV_WAVES * 32);
+// ---------------------------------------------------------------------------------------------------------------
+// the K loop shared by the forward pass and the data gradient: acc[nb] += A[k][32 nb + c32] * B_frame[k][pixel + tap]
+// over the groups [g0, g0 + gcount) of four k-pairs (8 rows); a tap has rows / 8 groups, rows a multiple of 16.
+//   Wl rows (tap * rows + row), stride wcols; Fl rows `row` (stride CS), column fpos + sign * tap offset.
+// The body is branch-free (the one-past-the-end prefetch re-reads a valid group) so that the operand reads of group g+1
+// are in flight under the MFMAs of group g with exact wait counts.
+// ---------------------------------------------------------------------------------------------------------------
+template <int T, int NB>
+__device__ __forceinline__ void nf_cv_kloop(f32x16 (&acc)[NB], const float* Wl, const float* Fl, const NfCvGeo& g, int rows,
+                                            int wcols, int fpos, int sign, int c32, int hs, int g0, int gcount) {
+    const int ngt = rows >> 3;                         // 3x3: rows is 16 or 32 -> ngt is 2 or 4
+    const int lgt = ngt == 4 ? 2 : 1;
+    const int glast = T * ngt - 1;
+    const float* wbase = Wl + hs * wcols + c32;
+    const float* fbase = Fl + hs * g.CS + fpos;
+    float a0[4][NB], b0[4], a1[4][NB], b1[4];
+    int gi = g0;
+#define NF_CV_LOAD(A_, B_)                                                                                 \
+    do {                                                                                                   \
+        const int gg = gi < glast ? gi : glast;                                                            \
+        const int tap = T == 1 ? 0 : gg >> lgt, q = gg - tap * ngt;                                        \
+        const int dy = T == 9 ? tap / 3 - 1 : 0, dx = T == 9 ? tap - (tap / 3) * 3 - 1 : 0;                \
+        const float* fp = fbase + sign * (dy * g.FW + dx) + 8 * q * g.CS;                                  \
+        const float* wq = wbase + 8 * gg * wcols;                                                          \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                    \
+            B_[u] = fp[2 * u * g.CS];                                                                      \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) A_[u][nb] = wq[2 * u * wcols + 32 * nb];     \
+        }                                                                                                  \
+        ++gi;                                                                                              \
+    } while (0)
+#define NF_CV_MFMA(A_, B_)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                          \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                  \
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[u][nb], B_[u], acc[nb], 0, 0, 0)
+    NF_CV_LOAD(a0, b0);
+    for (int i = 0; i < gcount; i += 2) {
+        NF_CV_LOAD(a1, b1);
+        NF_CV_MFMA(a0, b0);
+        NF_CV_LOAD(a0, b0);
+        if (i + 1 < gcount) NF_CV_MFMA(a1, b1);
+    }
+#undef NF_CV_LOAD
+#undef NF_CV_MFMA
+}
+
+// K-quarter exchange: the four waves (kq = 0..3) of a pixel block each hold a partial 32 x 32 accumulator; wave kq ends up
+// with the TOTAL of registers [4 kq, 4 kq + 4) (rows 8 kq + {0..3} + 4 hs).  RS: [pb][owner][slot 0..2][4][64] floats.
+// Callers bracket it: __syncthreads() before (RS may alias operand tiles) -- the function syncs between write and read.
+__device__ __forceinline__ void nf_cv_quarter_exchange(float (&own)[4], const f32x16& acc, float* RS, int pb, int kq, int lane) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o != kq) {                                 // wave-uniform
+            const int slot = kq < o ? kq : kq - 1;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) RS[(((pb * 4 + o) * 3 + slot) * 4 + rr) * NF_WAVE + lane] = acc[4 * o + rr];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) own[rr] = acc[4 * o + rr];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int slot = 0; slot < 3; ++slot)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) own[rr] += RS[(((pb * 4 + kq) * 3 + slot) * 4 + rr) * NF_WAVE + lane];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward.  Sixteen waves: wave w works on pixel block pb = w & 3 (32 pixels) and
+//   3x3 (O <= 32): K quarter kq = w >> 2 of the (tap, channel) axis; the quarters are exchanged through LDS and every wave
+//                  finishes FOUR output channels x two halves of its pixel block (bias, residual, store, batch sums);
+//   1x1 (I <= 32): output blocks ob = (w >> 2), (w >> 2) + 4 with the whole K (no exchange).
+// The staging work (weights, activation frame) is spread over all sixteen waves: four waves per SIMD hide each other's
+// issue and memory latency, which is what bounds these small launches.
+// ---------------------------------------------------------------------------------------------------------------
+// LDS: Wl[T * 32][WCOLS]  (one chunk)     Al[32][CS]     kc[2][32], red[2][4][32];   RS aliases Wl | Al
+template <int T, int OCB>
+__global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, NfCvGeo g, int I, int O, int training, float eps,
+                                                               float mom) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WCOLS = 32 * OCB + 1;
+    constexpr int NOB = T == 9 ? 1 : (OCB + 3) / 4;    // output blocks per wave
+    float* Wl = smem;
+    float* Al = Wl + T * 32 * WCOLS;
+    float* tail = smem + (T * 32 * WCOLS + 32 * g.CS > NF_CV_RS ? T * 32 * WCOLS + 32 * g.CS : NF_CV_RS);
+    float* kc = tail;                                   // [2][32]
+    float* red = kc + 64;                               // [2][4][32]
+    float* RS = smem;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    const int pb = wid & 3, kq = wid >> 2;
+    const bool has_bn = d.bn_gamma != nullptr;
+    const int64_t Npx = g.B * g.HW;
+    const int nchunks = (I + 31) / 32;
+
+    NF_CV_STAMP(0);
+    nf_cv_bn_consts_fwd(kc, d, I, Npx, training, eps, mom);
+    const bool want_stats = d.stat_sum != nullptr;      // O <= 32 by contract
+    const bool has_res = d.residual != nullptr;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};      // 3x3: this wave's four channels
+    const int px = pb * 32 + c32;                       // this lane's pixel of the tile
+    const int fpos = nf_cv_frame_of(g, px);
+    NF_CV_STAMP(1);
+
+    for (int64_t tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
+        int tdec[NF_CV_FJ];
+        int64_t b0;
+        nf_cv_decode_all(tdec, g, tile, lane, b0);
+        NF_CV_STAMP(20);
+        const float* in0 = d.in + b0 * I * g.HW;
+        const int64_t P = tile * NF_CV_PX + px;
+        const bool pv = P < Npx;
+        const int64_t b = pv ? P >> g.lgHW : 0;
+        const int64_t q = pv ? P & (g.HW - 1) : 0;
+        float rres[4], bias_r[4];                      // 3x3 epilogue operands, fetched under the staging and the K loop
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int oc = 8 * kq + rr + 4 * hs;
+            bias_r[rr] = (T == 9 && oc < O) ? d.bias[oc] : 0.f;
+            rres[rr] = (T == 9 && has_res && pv && oc < O) ? d.residual[(b * O + oc) * g.HW + q] : 0.f;
+        }
+        f32x16 acc[NOB];
+#pragma unroll
+        for (int n = 0; n < NOB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int i0 = 32 * ch, IC = min(32, I - i0), ICP = (IC + 15) & ~15;
+            // every global load of the chunk first (one memory latency), then the LDS stores
+            NfCvA av;
+            nf_cv_act_load<0>(av, tdec, in0, g, I, i0, IC, wid);
+            NfCvW<T> wv;
+            if (T == 9) nf_cv_w_load<T, false>(wv, d.weight, O, I, i0, IC, ICP, 0, wid, lane);
+            NF_CV_STAMP(21);
+            __syncthreads();                            // previous readers of Wl / Al / RS are done; kc is written
+            NF_CV_STAMP(22);
+            if (T == 9) {
+                nf_cv_w_store<T, false>(wv, Wl, O, wid);
+            } else {                                    // 1x1, I <= 32: row ic, column oc of the wide tile
+                for (int e = threadIdx.x; e < O * IC; e += NF_CV_THREADS) {
+                    const int oc = e / IC, ic = e - oc * IC;
+                    Wl[ic * WCOLS + oc] = d.weight[oc * I + i0 + ic];
+                }
+            }
+            if (ICP > IC) nf_cv_zero_pad_rows<T>(Wl, ICP, IC, ICP - IC, WCOLS);
+            NF_CV_STAMP(23);
+            nf_cv_act_store<0>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
+            if (g.nfj > 3) {                            // frames of the small levels (several samples per tile): second round
+                nf_cv_act_load<3>(av, tdec, in0, g, I, i0, IC, wid);
+                nf_cv_act_store<3>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
+            }
+            NF_CV_STAMP(24);
+            __syncthreads();
+            NF_CV_STAMP(2);
+            if (T == 9) {
+                const int ng = T * (ICP >> 3);
+                const int g0 = (kq * ng) >> 2, g1 = ((kq + 1) * ng) >> 2;
+                nf_cv_kloop<T, 1>(reinterpret_cast<f32x16(&)[1]>(acc[0]), Wl, Al, g, ICP, WCOLS, fpos, +1, c32, hs, g0, g1 - g0);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NOB; ++n) {
+                    const int ob = kq + 4 * n;
+                    if (ob < OCB)                       // wave-uniform
+                        nf_cv_kloop<T, 1>(reinterpret_cast<f32x16(&)[1]>(acc[n]), Wl + 32 * ob, Al, g, ICP, WCOLS, fpos, +1, c32,
+                                          hs, 0, ICP >> 3);
+                }
+            }
+        }
+        NF_CV_STAMP(3);
+        if (T == 9) {
+            // ---- exchange the K quarters, then finish four channels per half: bias, residual, store, shifted batch sums ----
+            __syncthreads();                            // every wave is done with Wl / Al: RS may overwrite them
+            float own[4];
+            nf_cv_quarter_exchange(own, acc[0], RS, pb, kq, lane);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int oc = 8 * kq + rr + 4 * hs;
+                if (pv && oc < O) {
+                    const float dv = own[rr] + rres[rr];
+                    d.out[(b * O + oc) * g.HW + q] = dv + bias_r[rr];
+                    s1[rr] += dv;
+                    s2[rr] = fmaf(dv, dv, s2[rr]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NOB; ++n) {
+                const int ob = kq + 4 * n;
+                if (ob < OCB) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int oc = ob * 32 + nf_cv_cd_row(r, hs);
+                        if (pv && oc < O) d.out[(b * O + oc) * g.HW + q] = acc[n][r] + d.bias[oc];
+                    }
+                }
+            }
+        }
+    }
+    NF_CV_STAMP(4);
+    if (T == 9 && want_stats) {                         // block-uniform branch
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float t1 = nf_cv_half_sum(s1[rr]), t2 = nf_cv_half_sum(s2[rr]);
+            if (c32 == 0) {
+                const int oc = 8 * kq + rr + 4 * hs;
+                red[(0 * 4 + pb) * 32 + oc] = t1;
+                red[(1 * 4 + pb) * 32 + oc] = t2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64 && c32 < O) {              // half 0: sums, half 1: squares
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
+            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+            atomicAdd((hs == 0 ? d.stat_sum : d.stat_sqsum) + rep + c32, t);
+        }
+    }
+    NF_CV_STAMP(5);
 }
 
 // dynamic LDS above the 64 KB default needs a per-kernel opt-in (160 KB per CU on gfx950); once per instantiation
@@ -262,29 +525,447 @@ static inline int nf_cv_optin(K kernel, size_t lds) {
     return 0;
 }
 
+static inline bool nf_cv_fits_int32(int64_t B, int C, int HW) { return B * C * HW < (int64_t)1 << 31; }
+
 extern "C" int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, int training,
                               float bn_eps, float bn_momentum, nf_stream_t stream) {
     NfCvGeo g;
-    if (desc == nullptr || I < 1 || O < 1 || I > NF_CV_MAX_I || O > NF_CV_MAX_O) return NF_E_BADARG;
+    if (desc == nullptr || !nf_conv_bn_usable(B > 0 ? B : 1, I, O, H, W, ksize)) return NF_E_BADARG;
     if (B == 0) return 0;
     if (!nf_cv_geometry(g, B, H, W, ksize)) return NF_E_BADARG;
     if (desc->bn_gamma != nullptr && I > 32) return NF_E_BADARG;          // statistics vectors are 32 wide
-    if (desc->stat_sum != nullptr && O > 32) return NF_E_BADARG;
-    const int IP = (I + 1) & ~1;
+    if (desc->stat_sum != nullptr && (O > 32 || ksize != 3)) return NF_E_BADARG;
+    if (desc->residual != nullptr && ksize != 3) return NF_E_BADARG;
     const int OCB = (O + 31) / 32;
-    const size_t lds = nf_cv_fwd_lds(g, IP, OCB);
+    const int T = ksize * ksize;
+    size_t tiles_f = (size_t)T * 32 * (32 * OCB + 1) + (size_t)32 * g.CS;
+    if (tiles_f < NF_CV_RS) tiles_f = NF_CV_RS;
+    if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
+    const size_t lds = sizeof(float) * (tiles_f + 64 + 2 * 4 * 32);
     unsigned grid = (unsigned)(g.tiles < 1024 ? g.tiles : 1024);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-#define NF_LAUNCH(N_)                                                                                                  \
-    rc = nf_cv_optin(k_conv_bn_fwd<N_>, lds);                                                                          \
-    if (rc) return rc;                                                                                                 \
-    hipLaunchKernelGGL(k_conv_bn_fwd<N_>, dim3(grid), dim3(NF_CV_WAVES * NF_WAVE), lds, st, *desc, g, I, O, IP, training, \
-                       bn_eps, bn_momentum)
-    if (OCB == 1) { NF_LAUNCH(1); }
-    else if (OCB == 2) { NF_LAUNCH(2); }
-    else { NF_LAUNCH(3); }
+#define NF_LAUNCH(T_, N_)                                                                                              \
+    do {                                                                                                               \
+        rc = nf_cv_optin(k_conv_bn_fwd<T_, N_>, lds);                                                                  \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL((k_conv_bn_fwd<T_, N_>), dim3(grid), dim3(NF_CV_THREADS), lds, st, *desc, g, I, O, training, bn_eps, \
+                           bn_momentum);                                                                               \
+    } while (0)
+    if (T == 9) NF_LAUNCH(9, 1);
+    else
+        switch (OCB) {
+            case 1: NF_LAUNCH(1, 1); break;
+            case 2: NF_LAUNCH(1, 2); break;
+            case 3: NF_LAUNCH(1, 3); break;
+            case 4: NF_LAUNCH(1, 4); break;
+            case 5: NF_LAUNCH(1, 5); break;
+            default: NF_LAUNCH(1, 6); break;
+        }
 #undef NF_LAUNCH
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward (training mode): the gradient G of `out` is assembled on load exactly as nf_linear_bn_bwd does
+//     G = g_direct + g_skip + BNbwd(gn_src)          (frame with halo: the data gradient reads G at the nine neighbours)
+//     gn_out[b,i,y,x] = ( sum_{o,tap} W[o,i,tap] G[b,o,(y,x) - tap] ) * [act > 0]     + its two batch sums
+//     g_weff[o,i,tap] = sum_px G[o,px] act[i,px + tap]                                 (K = the tile's 128 pixels)
+// Three GEMM families on the same LDS frames: data gradient (A = W^T rows ic, B = G frame rows oc), weight gradient
+// (A = G frame rows oc walked along pixels, B = act frame rows ic, shifted by the tap) -- the frames have an odd channel
+// stride, so lanes that walk channels (weight gradient) and lanes that walk pixels (data gradient) are both conflict-free.
+// Sixteen waves.  Weight gradient: the 32 x 32 tiles -- 9 taps (3x3) or OCB output blocks (1x1) -- go to waves 0..8, which
+// walk the tile's 128 pixels; the workgroup writes ONE slab (summed by nf_slab_sum: no atomics, deterministic).  Data
+// gradient: pixel block x K quarter like the forward pass; the waves without a weight-gradient tile start it early.
+// ---------------------------------------------------------------------------------------------------------------
+// LDS: Wd[T * 32 OCB][33]  (one input chunk; rows k = tap * OP + oc, columns ic)     Al[32][CS]     Gl[32 OCB][CS]
+//      cb[5][32] (consumer BatchNorm constants), kc[4][32] (input BatchNorm), red[2][4][32];
+//      the K-quarter exchange RS aliases the start of the tiles once their last reader is done
+template <int T, int ICB, int OCB>
+__global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc d, NfCvGeo g, int I, int O, int iters) {
+    static_assert(T == 1 || OCB == 1, "3x3 layers produce <= 32 channels");
+    static_assert(T == 9 || ICB == 1, "the 1x1 layer consumes <= 32 channels");
+    constexpr int NTC = T == 9 ? 9 : OCB;              // weight-gradient tiles per input chunk
+    constexpr int NU = NTC;
+    constexpr int NUW = (NU + NF_CV_WAVES - 1) / NF_CV_WAVES;
+    constexpr int OPmax = 32 * OCB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int OP = (O + 15) & ~15;                     // K rows of the data gradient, zero padded
+    float* Wd = smem;
+    float* Al = Wd + T * OPmax * NF_CV_WS;
+    float* Gl = Al + 32 * g.CS;
+    float* endf = Gl + OPmax * g.CS;
+    float* X = smem;                                   // K-quarter exchange: over Wd | Al (3x3; never reaches Gl) or all tiles (1x1)
+    if (endf < smem + NF_CV_RS) endf = smem + NF_CV_RS;
+    float* cb = endf;                                  // [5][32]
+    float* kc = cb + 5 * 32;                           // [4][32]
+    float* red = kc + 4 * 32;                          // [2][4][32]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    const int pb = wid & 3, kq = wid >> 2;
+    const bool has_bn = d.bn_gamma != nullptr;         // => ICB == 1
+    const bool has_src = d.gn_src != nullptr;          // => OCB == 1
+    const int64_t Npx = g.B * g.HW;
+    const float invN = 1.f / (float)Npx;
+
+    NF_CV_STAMP(8);
+    if (threadIdx.x < 32) {
+        const int oo = threadIdx.x;
+        float c1 = 0.f, mean = 0.f, invstd = 0.f, mg = 0.f, mgx = 0.f;
+        if (has_src && oo < O) {
+            invstd = d.cbn_save_invstd[oo];
+            mean = d.cbn_save_mean[oo];
+            c1 = d.cbn_gamma[oo] * invstd;
+            if (d.cbn_sum_g != nullptr) {
+#pragma unroll
+                for (int r = 0; r < NF_STAT_REPL; ++r) { mg += d.cbn_sum_g[32 * r + oo]; mgx += d.cbn_sum_gx[32 * r + oo]; }
+                mg *= invN;
+                mgx *= invN;
+            }
+        }
+        cb[oo] = c1; cb[32 + oo] = mean; cb[64 + oo] = invstd; cb[96 + oo] = mg; cb[128 + oo] = mgx;
+    } else if (threadIdx.x < 64) {
+        const int k = threadIdx.x - 32;
+        float sc = 1.f, sh = 0.f, mean = 0.f, invstd = 0.f;
+        if (has_bn && k < I) {
+            mean = d.bn_save_mean[k];
+            invstd = d.bn_save_invstd[k];
+            sc = d.bn_gamma[k] * invstd;
+            sh = d.bn_beta[k] - mean * sc;
+        }
+        kc[k] = sc; kc[32 + k] = sh; kc[64 + k] = mean; kc[96 + k] = invstd;
+    }
+    // weight-gradient tile of this wave: tl = wid + 16 v -> tap (3x3) or output block (1x1)
+    int aoff[NUW], boff[NUW];
+    bool uval[NUW];
+#pragma unroll
+    for (int v = 0; v < NUW; ++v) {
+        const int unit = wid + NF_CV_WAVES * v;
+        uval[v] = unit < NU;
+        const int tl = uval[v] ? unit : 0;
+        const int tap = T == 9 ? tl : 0, ob = T == 9 ? 0 : tl;
+        const int dy = T == 9 ? tap / 3 - 1 : 0, dx = T == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+        aoff[v] = (ob * 32 + c32) * g.CS;
+        boff[v] = c32 * g.CS + dy * g.FW + dx;
+    }
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+    float gbw[NUW];
+#pragma unroll
+    for (int v = 0; v < NUW; ++v) gbw[v] = 0.f;
+    const int px = pb * 32 + c32;
+    const int fpos = nf_cv_frame_of(g, px);
+    float* slab = d.g_weff + (int64_t)blockIdx.x * O * I * T;
+    NF_CV_STAMP(9);
+
+    for (int it = 0; it < iters; ++it) {
+        const int64_t tile = (int64_t)it * gridDim.x + blockIdx.x;
+        if (tile >= g.tiles) break;                    // block-uniform
+        int tdec[NF_CV_FJ];
+        int64_t b0;
+        nf_cv_decode_all(tdec, g, tile, lane, b0);
+        const float* in0 = d.in + b0 * I * g.HW;
+        const int64_t go0 = b0 * O * g.HW;             // sample b0 of the (B, O, H, W) tensors
+        const int64_t P = tile * NF_CV_PX + px;
+        const bool pv = P < Npx;
+        const int64_t pb64 = pv ? P >> g.lgHW : 0;
+        const int64_t pq = pv ? P & (g.HW - 1) : 0;
+#pragma unroll
+        for (int ib = 0; ib < ICB; ++ib) {
+            const int i0 = 32 * ib, IC = min(32, I - i0), ICP = (IC + 15) & ~15;
+            // every global load of a round first (one memory latency): activations, weights, the tensors G is assembled from;
+            // frame positions three per lane and round (one round unless the tile holds several small samples)
+            NfCvW<T> wv;
+            if (T == 9) nf_cv_w_load<T, true>(wv, d.weight, O, I, i0, IC, ICP, OP, wid, lane);
+#define NF_CV_G_LOAD(JR_, C0_)                                                                             \
+    _Pragma("unroll") for (int jj = 0; jj < 3; ++jj) {                                                     \
+        const int t = tdec[(JR_) + jj];                                                                    \
+        const int base = t >= 0 ? NF_CV_SEG(t) * O * g.HW + NF_CV_SP(t) : 0;                               \
+        _Pragma("unroll") for (int u = 0; u < NF_CV_CU; ++u) {                                             \
+            const int c = (C0_) + u * NF_CV_WAVES;                                                         \
+            const bool ok = t >= 0 && c < O;                                                               \
+            const int64_t idx = go0 + base + c * g.HW;                                                     \
+            w1[jj][u] = (ok && d.g_direct != nullptr) ? d.g_direct[idx] : 0.f;                             \
+            w2[jj][u] = (ok && d.g_skip != nullptr) ? d.g_skip[idx] : 0.f;                                 \
+            w3[jj][u] = (ok && has_src) ? d.gn_src[idx] : 0.f;                                             \
+            w4[jj][u] = (ok && has_src) ? d.out[idx] : 0.f;                                                \
+        }                                                                                                  \
+    }
+#define NF_CV_G_STORE(JR_, C0_)                                                                            \
+    _Pragma("unroll") for (int jj = 0; jj < 3; ++jj) {                                                     \
+        const int f = lane + NF_WAVE * ((JR_) + jj);                                                       \
+        const int t = tdec[(JR_) + jj];                                                                    \
+        const int base = t >= 0 ? NF_CV_SEG(t) * O * g.HW + NF_CV_SP(t) : 0;                               \
+        if (f < g.FSZ) {                                                                                   \
+            _Pragma("unroll") for (int u = 0; u < NF_CV_CU; ++u) {                                         \
+                const int c = (C0_) + u * NF_CV_WAVES;                                                     \
+                if (c < OPmax) {                                                                           \
+                    float v = 0.f;                                                                         \
+                    if (t >= 0 && c < O) {                                                                 \
+                        v = w1[jj][u] + w2[jj][u];                                                         \
+                        if (has_src) {                     /* BatchNorm backward on load */                \
+                            const float xh = (w4[jj][u] - cb[32 + c]) * cb[64 + c];                        \
+                            v += cb[c] * (w3[jj][u] - cb[96 + c] - xh * cb[128 + c]);                      \
+                        }                                                                                  \
+                        if (d.g_store != nullptr && (t >> 30)) d.g_store[go0 + base + c * g.HW] = v;       \
+                    }                                                                                      \
+                    Gl[c * g.CS + f] = v;                                                                  \
+                }                                                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+            float w1[3][NF_CV_CU], w2[3][NF_CV_CU], w3[3][NF_CV_CU], w4[3][NF_CV_CU];
+            NfCvA av;
+            nf_cv_act_load<0>(av, tdec, in0, g, I, i0, IC, wid);
+            if (ib == 0) NF_CV_G_LOAD(0, wid);
+            __syncthreads();                           // previous readers of the frames / Wd / exchange are done; cb, kc
+            if (ib == 0) {
+                // ---- G frame, assembled; g_store for the pixels this tile owns ----
+                NF_CV_G_STORE(0, wid);
+                for (int c0 = wid + NF_CV_CU * NF_CV_WAVES; c0 < OPmax; c0 += NF_CV_CU * NF_CV_WAVES) {   // 1x1 layers: O up to 192
+                    NF_CV_G_LOAD(0, c0);
+                    NF_CV_G_STORE(0, c0);
+                }
+                if (g.nfj > 3)
+                    for (int c0 = wid; c0 < OPmax; c0 += NF_CV_CU * NF_CV_WAVES) {
+                        NF_CV_G_LOAD(3, c0);
+                        NF_CV_G_STORE(3, c0);
+                    }
+            }
+#undef NF_CV_G_LOAD
+#undef NF_CV_G_STORE
+            if (T == 9) {
+                nf_cv_w_store<T, true>(wv, Wd, O, wid);
+            } else {                                   // 1x1: row oc, column ic
+                for (int e = threadIdx.x; e < O * IC; e += NF_CV_THREADS) {
+                    const int oc = e / IC, ic = e - oc * IC;
+                    Wd[oc * NF_CV_WS + ic] = d.weight[oc * I + i0 + ic];
+                }
+            }
+            if (OP > O) nf_cv_zero_pad_rows<T>(Wd, OP, O, OP - O, NF_CV_WS);
+            nf_cv_act_store<0>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
+            if (g.nfj > 3) {
+                nf_cv_act_load<3>(av, tdec, in0, g, I, i0, IC, wid);
+                nf_cv_act_store<3>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
+            }
+            __syncthreads();
+            NF_CV_STAMP(10);
+
+            // ---- weight gradient of this chunk: a tile walks the 128 pixels two at a time (64 MFMAs), operands of the next
+            //      four steps in flight (branch-free body, the one-past-the-end prefetch wraps around) ----
+            f32x16 accW[NUW];
+#pragma unroll
+            for (int v = 0; v < NUW; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW[v][r] = 0.f;
+            {
+                float av0[4][NUW], bv0[4][NUW], av1[4][NUW], bv1[4][NUW];
+#define NF_CV_WLOAD(A_, B_, J_)                                                                            \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                       \
+        _Pragma("unroll") for (int v = 0; v < NUW; ++v) {                                                  \
+            const int fp = nf_cv_frame_of(g, (2 * ((J_) + jj) + hs) & (NF_CV_PX - 1));                     \
+            A_[jj][v] = Gl[aoff[v] + fp];                                                                  \
+            B_[jj][v] = Al[boff[v] + fp];                                                                  \
+        }
+#define NF_CV_WMFMA(A_, B_)                                                                                \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                       \
+        _Pragma("unroll") for (int v = 0; v < NUW; ++v)                                                    \
+            if (uval[v]) {                                                                                 \
+                if (ib == 0) gbw[v] += A_[jj][v];                                                          \
+                accW[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[jj][v], B_[jj][v], accW[v], 0, 0, 0);    \
+            }
+                NF_CV_WLOAD(av0, bv0, 0);
+                for (int j0 = 0; j0 < NF_CV_PX / 2; j0 += 8) {
+                    NF_CV_WLOAD(av1, bv1, j0 + 4);
+                    NF_CV_WMFMA(av0, bv0);
+                    NF_CV_WLOAD(av0, bv0, j0 + 8);
+                    NF_CV_WMFMA(av1, bv1);
+                }
+#undef NF_CV_WLOAD
+#undef NF_CV_WMFMA
+            }
+            NF_CV_STAMP(11);
+            // ---- data gradient of this input chunk: rows ic, columns pixel, K = (tap, oc) split in quarters; taps mirrored ----
+            f32x16 accD[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accD[0][r] = 0.f;
+            float xin[4];
+            if (d.gn_out != nullptr) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ic = 8 * kq + rr + 4 * hs;
+                    xin[rr] = (has_bn && pv && ic < IC) ? d.in[(pb64 * I + i0 + ic) * g.HW + pq] : 0.f;
+                }
+                const int ng = T * (OP >> 3);
+                const int g0 = (kq * ng) >> 2, g1 = ((kq + 1) * ng) >> 2;
+                nf_cv_kloop<T, 1>(accD, Wd, Gl, g, OP, NF_CV_WS, fpos, -1, c32, hs, g0, g1 - g0);
+            }
+            NF_CV_STAMP(12);
+            // ---- this workgroup's slab of g_weff, in (T, O, I) order; first tile stores, later tiles add ----
+#pragma unroll
+            for (int v = 0; v < NUW; ++v)
+                if (uval[v]) {
+                    const int tl = wid + NF_CV_WAVES * v;
+                    const int tap = T == 9 ? tl : 0, ob = T == 9 ? 0 : tl;
+                    const int ic = i0 + c32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int oc = ob * 32 + nf_cv_cd_row(r, hs);
+                        if (oc < O && c32 < IC) {
+                            float* p = slab + (tap * O + oc) * I + ic;         // (T, O, I): consecutive lanes, consecutive floats
+                            if (it == 0) *p = accW[v][r];
+                            else *p += accW[v][r];
+                        }
+                    }
+                }
+            float own[4] = {0.f, 0.f, 0.f, 0.f};
+            if (d.gn_out != nullptr) {                 // block-uniform
+                __syncthreads();                       // every wave is done with Wd / Al / Gl reads of this chunk
+                nf_cv_quarter_exchange(own, accD[0], X, pb, kq, lane);
+            }
+            if (d.gn_out != nullptr) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int ic = 8 * kq + rr + 4 * hs;
+                    if (pv && ic < IC) {
+                        float gn = own[rr];
+                        if (has_bn) {
+                            const float x = xin[rr];
+                            gn = fmaf(x, kc[ic], kc[32 + ic]) > 0.f ? gn : 0.f;
+                            sg[rr] += gn;
+                            sgx[rr] = fmaf(gn, (x - kc[64 + ic]) * kc[96 + ic], sgx[rr]);
+                        }
+                        d.gn_out[(pb64 * I + i0 + ic) * g.HW + pq] = gn;
+                    }
+                }
+            }
+        }
+    }
+    NF_CV_STAMP(13);
+    // ---- bias and BatchNorm sums ----
+    if (d.g_bias != nullptr) {
+#pragma unroll
+        for (int v = 0; v < NUW; ++v) {
+            const int tl = wid + NF_CV_WAVES * v;
+            if (uval[v] && (T == 1 || tl == 0)) {      // 3x3: the tile of tap 0; 1x1: every output block
+                const int ob = T == 9 ? 0 : tl;
+                const float t = gbw[v] + __shfl_xor(gbw[v], 32, NF_WAVE);
+                const int oc = ob * 32 + c32;
+                if (hs == 0 && oc < O) atomicAdd(d.g_bias + 256 * (blockIdx.x % NF_STAT_REPL) + oc, t);
+            }
+        }
+    }
+    if (has_bn && d.sum_g != nullptr) {                // block-uniform
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float t1 = nf_cv_half_sum(sg[rr]), t2 = nf_cv_half_sum(sgx[rr]);
+            if (c32 == 0) {
+                const int ic = 8 * kq + rr + 4 * hs;
+                red[(0 * 4 + pb) * 32 + ic] = t1;
+                red[(1 * 4 + pb) * 32 + ic] = t2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64 && c32 < I) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
+            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+            atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
+        }
+    }
+    NF_CV_STAMP(14);
+}
+
+#define NF_CV_BWD_MAX_SLABS 128
+extern "C" int nf_conv_bwd_slabs(int64_t B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t tiles = (B * H * W + NF_CV_PX - 1) / NF_CV_PX;
+    return (int)(tiles < NF_CV_BWD_MAX_SLABS ? tiles : NF_CV_BWD_MAX_SLABS);
+}
+
+extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int O, int H, int W, int ksize,
+                              nf_stream_t stream) {
+    NfCvGeo g;
+    if (desc == nullptr || desc->g_weff == nullptr || !nf_conv_bn_usable(B > 0 ? B : 1, I, O, H, W, ksize)) return NF_E_BADARG;
+    if (B == 0) return 0;
+    if (!nf_cv_geometry(g, B, H, W, ksize)) return NF_E_BADARG;
+    if (desc->bn_gamma != nullptr && I > 32) return NF_E_BADARG;
+    if (desc->gn_src != nullptr && O > 32) return NF_E_BADARG;            // consumer BatchNorm sums are 32 wide
+    if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
+    const int ICB = (I + 31) / 32, OCB = (O + 31) / 32;
+    const int T = ksize * ksize;
+    size_t body = (size_t)T * 32 * OCB * NF_CV_WS + (size_t)32 * g.CS + (size_t)32 * OCB * g.CS;
+    if (body < NF_CV_RS) body = NF_CV_RS;             // the K-quarter exchange aliases the start of the tiles
+    const size_t lds = sizeof(float) * (body + 5 * 32 + 4 * 32 + 2 * 4 * 32);
+    const unsigned grid = (unsigned)nf_conv_bwd_slabs(B, H, W);
+    const int iters = (int)((g.tiles + grid - 1) / grid);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+#define NF_LAUNCH(T_, IB_, OB_)                                                                                        \
+    do {                                                                                                               \
+        rc = nf_cv_optin(k_conv_bn_bwd<T_, IB_, OB_>, lds);                                                            \
+        if (rc) return rc;                                                                                             \
+        hipLaunchKernelGGL((k_conv_bn_bwd<T_, IB_, OB_>), dim3(grid), dim3(NF_CV_THREADS), lds, st, *desc, g, I, O, iters); \
+    } while (0)
+    if (T == 9) {
+        if (ICB == 1) NF_LAUNCH(9, 1, 1);
+        else if (ICB == 2) NF_LAUNCH(9, 2, 1);
+        else NF_LAUNCH(9, 3, 1);
+    } else {
+        switch (OCB) {
+            case 1: NF_LAUNCH(1, 1, 1); break;
+            case 2: NF_LAUNCH(1, 1, 2); break;
+            case 3: NF_LAUNCH(1, 1, 3); break;
+            case 4: NF_LAUNCH(1, 1, 4); break;
+            case 5: NF_LAUNCH(1, 1, 5); break;
+            default: NF_LAUNCH(1, 1, 6); break;
+        }
+    }
+#undef NF_LAUNCH
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dst[e] (+)= sum_s src[s * stride + e]: the slab / replica sums of one conditioner backward in one launch
+// ---------------------------------------------------------------------------------------------------------------
+struct NfSlabArgs { nf_slab_sum_desc d[NF_SLAB_SUM_MAX]; };
+__global__ void __launch_bounds__(NF_BLOCK) k_slab_sum(NfSlabArgs args) {
+    const nf_slab_sum_desc& d = args.d[blockIdx.y];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < d.n; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t se = e;                                 // dst is (O, I, T), the slabs are (T, O, I) when taps > 1
+        if (d.taps > 1) {
+            const int64_t oi = e / d.taps;
+            const int tap = (int)(e - oi * d.taps);
+            se = (int64_t)tap * (d.n / d.taps) + oi;
+        }
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= d.n_slabs; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = d.src[(int64_t)(s + u) * d.stride + se];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u & 3] += v[u];
+        }
+        for (; s < d.n_slabs; ++s) t[0] += d.src[(int64_t)s * d.stride + se];
+        const float v = (t[0] + t[1]) + (t[2] + t[3]);
+        d.dst[e] = d.accumulate ? d.dst[e] + v : v;
+    }
+}
+
+extern "C" int nf_slab_sum(const nf_slab_sum_desc* descs, int n_jobs, nf_stream_t stream) {
+    if (descs == nullptr || n_jobs < 1 || n_jobs > NF_SLAB_SUM_MAX) return NF_E_BADARG;
+    NfSlabArgs args;
+    int64_t nmax = 1;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (descs[i].src == nullptr || descs[i].dst == nullptr || descs[i].n < 0 || descs[i].n_slabs < 0) return NF_E_BADARG;
+        args.d[i] = descs[i];
+        if (descs[i].n > nmax) nmax = descs[i].n;
+    }
+    unsigned gx = nf_grid_for(nmax);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(k_slab_sum, dim3(gx, (unsigned)n_jobs), dim3(NF_BLOCK), 0, (hipStream_t)stream, args);
     NF_CHECK_LAUNCH();
     return 0;
 }

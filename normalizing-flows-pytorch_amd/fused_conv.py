@@ -1,0 +1,211 @@
+"""
+The image conditioner ConvNet (flows/modules.py:416-438) on the fused convolution + BatchNorm2d kernels of
+csrc/conv_bn.hip (C ABI ``nf_conv_bn_fwd / nf_conv_bn_bwd / nf_slab_sum``): 6 launches forward, 6 + 1 backward, instead
+of ~25 / ~60 MIOpen + ATen kernels (convolution, bias add, BatchNorm, ReLU, residual add; their backward twins, the
+layout transposes MIOpen's weight-gradient kernels need and a reduction per bias).
+
+Exact restatement of the module math in training mode (batch statistics, gradients through the statistics, running
+statistics bookkeeping) and in evaluation mode.  The weight-norm arithmetic stays where it is: every convolution of a
+model gets its effective weight from ONE ``nf_weight_norm_fwd`` launch per pass (fused.weight_norm_all), the kernels
+here consume effective weights and return the gradient with respect to them.
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+from . import workspace as WS
+from .fused import BN_EPS, BN_MOMENTUM, H, R, _desc
+
+WS_ROWS = 2 * R + 2      # per BatchNorm: sum[R], sqsum[R], save_mean, save_invstd (rows of 32)
+GB = 256                 # replica stride of the bias-gradient accumulators (nfhip.h: nf_conv_bwd_desc.g_bias)
+
+_FWD_FIELDS = ['in_', 'weight', 'bias', 'residual', 'out', 'bn_gamma', 'bn_beta', 'bn_sum', 'bn_sqsum', 'bn_center',
+               'bn_running_mean', 'bn_running_var', 'bn_num_batches', 'bn_save_mean', 'bn_save_invstd', 'stat_sum',
+               'stat_sqsum']
+_BWD_FIELDS = ['in_', 'weight', 'bn_gamma', 'bn_beta', 'bn_save_mean', 'bn_save_invstd', 'g_direct', 'g_skip', 'gn_src',
+               'out', 'cbn_gamma', 'cbn_save_mean', 'cbn_save_invstd', 'cbn_sum_g', 'cbn_sum_gx', 'g_store', 'g_bias',
+               'g_weff', 'gn_out', 'sum_g', 'sum_gx']
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in _FWD_FIELDS]
+
+
+class ConvBwdDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in _BWD_FIELDS]
+
+
+class SlabSumDesc(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('n', ctypes.c_int64), ('stride', ctypes.c_int64),
+                ('n_slabs', ctypes.c_int), ('accumulate', ctypes.c_int), ('taps', ctypes.c_int), ('reserved', ctypes.c_int)]
+
+
+def _fwd(shape, I, O, k, training, **kw):
+    B, Hh, Ww = shape
+    d = _desc(ConvDesc, **kw)
+    N.call('nf_conv_bn_fwd', ctypes.addressof(d), B, I, O, Hh, Ww, k, int(training), BN_EPS, BN_MOMENTUM, N.stream())
+
+
+def _bwd(shape, I, O, k, **kw):
+    B, Hh, Ww = shape
+    d = _desc(ConvBwdDesc, **kw)
+    N.call('nf_conv_bn_bwd', ctypes.addressof(d), B, I, O, Hh, Ww, k, N.stream())
+
+
+def _slab_sum(jobs):
+    arr = (SlabSumDesc * len(jobs))()
+    for i, (src, dst, n, stride, n_slabs, acc, taps) in enumerate(jobs):
+        arr[i].src, arr[i].dst, arr[i].n, arr[i].stride = src.data_ptr(), dst.data_ptr(), n, stride
+        arr[i].n_slabs, arr[i].accumulate, arr[i].taps = n_slabs, int(acc), taps
+    N.call('nf_slab_sum', ctypes.addressof(arr), len(jobs), N.stream())
+
+
+def _convnet_modules(net):
+    convs = [net.in_block[0]]
+    bns = []
+    for blk in net.mid_block:
+        bns += [blk.net[0], blk.net[3]]
+        convs += [blk.net[2], blk.net[5]]
+    bns.append(net.out_block[0])
+    convs.append(net.out_block[2])
+    return convs, bns
+
+
+def convnet_usable(net, x):
+    """ConvNet with two residual blocks of 32 filters on an input whose spatial size tiles into the kernels' 128-pixel
+    groups (every level of the reference's CIFAR / MNIST-style pyramids does)."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0 and len(net.mid_block) == 2):
+        return False
+    convs, _ = _convnet_modules(net)
+    c0 = getattr(convs[0], 'module', convs[0])
+    c5 = getattr(convs[-1], 'module', convs[-1])
+    if c0.out_channels != H or c5.in_channels != H or c0.kernel_size != (3, 3) or c5.kernel_size != (1, 1):
+        return False
+    B, I, Hh, Ww = x.shape
+    lib = N.load()
+    return bool(lib.nf_conv_bn_usable(B, I, H, Hh, Ww, 3) and lib.nf_conv_bn_usable(B, H, c5.out_channels, Hh, Ww, 1))
+
+
+def _convnet_tensors(net):
+    convs, bns = _convnet_modules(net)
+    tensors = []
+    for c in convs:
+        if hasattr(c, 'effective_weight'):            # conditioners.WeightNorm
+            tensors += [c.effective_weight(), c.module.bias]
+        else:
+            tensors += [c.weight, c.bias]
+    for bn in bns:
+        tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    return tensors
+
+
+class _FusedConvNet(torch.autograd.Function):
+    """x -> conv0 -> [BN,ReLU,conv, BN,ReLU,conv, +skip] * 2 -> BN,ReLU,conv1x1.
+
+    tensors: per convolution (effective weight, bias) * 6, then per BatchNorm (gamma, beta, running_mean, running_var,
+    num_batches_tracked) * 5."""
+
+    @staticmethod
+    def forward(ctx, x, training, *tensors):
+        nl, nb = 6, 5
+        conv = [tensors[2 * i:2 * i + 2] for i in range(nl)]
+        bns = [tensors[2 * nl + 5 * i:2 * nl + 5 * i + 5] for i in range(nb)]
+        x = x.contiguous()
+        B, I0, Hh, Ww = x.shape
+        shape = (B, Hh, Ww)
+        O_out = conv[-1][0].shape[0]
+        dev = x.device
+        ws = WS.zeros(nb * WS_ROWS * H, dev).view(nb, WS_ROWS, H)
+        acts = [torch.empty(B, H, Hh, Ww, dtype=torch.float32, device=dev) for _ in range(nb)]
+        out = torch.empty(B, O_out, Hh, Ww, dtype=torch.float32, device=dev)
+        w = [c[0].contiguous() for c in conv]
+
+        def bn_kw(j):
+            g, b, rm, rv, nbt = bns[j]
+            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[j, 0], bn_sqsum=ws[j, R], bn_center=conv[j][1], bn_running_mean=rm,
+                        bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
+
+        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], stat_sum=ws[0, 0],
+             stat_sqsum=ws[0, R])
+        for j in range(1, nb):                    # convolution j consumes acts[j-1] through BatchNorm j-1
+            res = acts[j - 2] if j % 2 == 0 else None
+            _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j],
+                 stat_sum=ws[j, 0], stat_sqsum=ws[j, R], **bn_kw(j - 1))
+        _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
+             **bn_kw(nb - 1))
+        ctx.save_for_backward(x, ws, *acts, *w, *[t for b in bns for t in b[:2]])
+        ctx.meta = (shape, I0, O_out, bool(training))
+        from .functional import _sinks
+        ctx.sinks = _sinks(*[c[1] for c in conv], *[t for b in bns for t in b[:2]])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        shape, I0, O_out, training = ctx.meta
+        nl, nb = 6, 5
+        saved = ctx.saved_tensors
+        x, ws = saved[0], saved[1]
+        acts = saved[2:2 + nb]
+        w = saved[2 + nb:2 + nb + nl]
+        gb = saved[2 + nb + nl:]
+        gamma = [gb[2 * i] for i in range(nb)]
+        beta = [gb[2 * i + 1] for i in range(nb)]
+        dev = x.device
+        B, Hh, Ww = shape
+        g_out = g_out.contiguous()
+        slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
+        g_weff = [torch.empty(slabs, t.numel(), dtype=torch.float32, device=dev) for t in w]
+        acc = WS.zeros(nl * R * GB + nb * 2 * R * H, dev)
+        g_bias = [acc[i * R * GB:(i + 1) * R * GB] for i in range(nl)]
+        sums = acc[nl * R * GB:].view(nb, 2, R * H)
+        gn = [torch.empty_like(acts[0]) for _ in range(nb)]
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        G_skip = None
+
+        def in_bn(j):
+            return dict(bn_gamma=gamma[j], bn_beta=beta[j], bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
+
+        def cons_bn(j):                            # evaluation mode: statistics are constants -> no mean terms
+            return dict(cbn_gamma=gamma[j], cbn_save_mean=ws[j, 2 * R], cbn_save_invstd=ws[j, 2 * R + 1],
+                        cbn_sum_g=sums[j, 0] if training else None, cbn_sum_gx=sums[j, 1] if training else None)
+
+        _bwd(shape, H, O_out, 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, g_bias=g_bias[nl - 1],
+             g_weff=g_weff[nl - 1], gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0], sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))
+        for j in range(nb - 1, 0, -1):             # convolution j produced acts[j]; its consumer BatchNorm is j
+            is_stream = (j % 2 == 0)
+            store = torch.empty_like(acts[0]) if is_stream else None
+            _bwd(shape, H, H, 3, in_=acts[j - 1], weight=w[j], gn_src=gn[j], out=acts[j],
+                 g_skip=G_skip if is_stream else None, g_store=store, g_bias=g_bias[j], g_weff=g_weff[j], gn_out=gn[j - 1],
+                 sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1), **cons_bn(j))
+            if is_stream:
+                G_skip = store
+        _bwd(shape, I0, H, 3, in_=x, weight=w[0], gn_src=gn[0], out=acts[0], g_skip=G_skip, g_bias=g_bias[0],
+             g_weff=g_weff[0], gn_out=g_x, **cons_bn(0))
+
+        direct = ctx.sinks is not None
+        g_w = [torch.empty_like(t) for t in w]
+        if direct:
+            d_bias = ctx.sinks[:nl]
+            d_bn = [tuple(ctx.sinks[nl + 2 * j:nl + 2 * j + 2]) for j in range(nb)]
+        else:
+            d_bias = [torch.empty(t.shape[0], dtype=torch.float32, device=dev) for t in w]
+            d_bn = [(torch.empty(H, dtype=torch.float32, device=dev), torch.empty(H, dtype=torch.float32, device=dev))
+                    for _ in range(nb)]
+        jobs = [(g_weff[i], g_w[i], w[i].numel(), w[i].numel(), slabs, False, w[i].shape[2] * w[i].shape[3]) for i in range(nl)]
+        jobs += [(g_bias[i], d_bias[i], w[i].shape[0], GB, R, direct, 1) for i in range(nl)]
+        for j in range(nb):
+            jobs.append((sums[j, 1], d_bn[j][0], H, H, R, direct, 1))       # g_gamma = sum g * xhat
+            jobs.append((sums[j, 0], d_bn[j][1], H, H, R, direct, 1))       # g_beta  = sum g
+        _slab_sum(jobs)
+        grads = []
+        for i in range(nl):
+            grads += [g_w[i], None if direct else d_bias[i]]
+        for j in range(nb):
+            grads += [None if direct else d_bn[j][0], None if direct else d_bn[j][1], None, None, None]
+        return (g_x, None) + tuple(grads)
+
+
+def convnet_forward(net, x):
+    """``net``: conditioners.ConvNet; returns the conditioner output (B, out_channels, H, W)."""
+    return _FusedConvNet.apply(x, net.training, *_convnet_tensors(net))

@@ -1,0 +1,110 @@
+"""GPU parity of the fused image conditioner (csrc/conv_bn.hip) against the module-by-module ConvNet
+(flows/modules.py:416-438: WeightNorm convolutions, BatchNorm2d in train / eval mode, residual blocks)."""
+import copy
+import importlib
+
+import pytest
+import torch
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+# (in_channels, out_channels, H, W): the five conditioner shapes of Glow / RealNVP / Flow++ on CIFAR (checkerboard halves
+# are (C, H, W/2), channel halves (C/2, H, W)), plus an MNIST-like level
+SHAPES = [(3, 6, 32, 16), (6, 12, 16, 16), (12, 24, 16, 8), (24, 48, 8, 8), (48, 96, 8, 4), (96, 192, 4, 4), (1, 2, 28, 14)]
+
+
+def _risky_samples(net, x):
+    """samples in which some ReLU input of the module path lies within rounding of zero: the two paths may then take
+    different sides of the kink there (the forward value is unaffected, the gradient of that sample's neighbourhood and the
+    parameter gradients are not).  With ~5 M ReLU decisions per pass about one in five runs has such a unit."""
+    pre = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: pre.append(o.detach().clone()))
+             for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    with torch.no_grad():
+        net.forward_reference(x.detach())
+    for h in hooks:
+        h.remove()
+    risky = torch.zeros(x.shape[0], dtype=torch.bool, device=x.device)
+    for p in pre:
+        risky |= (p.abs() < 2e-5 * max(1.0, float(p.abs().max()))).flatten(1).any(1)
+    return risky
+
+
+def _close_but_for(a, b, atol, skip, what):
+    keep = ~skip
+    G.assert_close(a[keep], b[keep], atol, rtol=1e-4, what=what)
+
+
+def _nets(pkg, I, O):
+    cond = importlib.import_module(pkg.__name__ + '.conditioners')
+    torch.manual_seed(I * 100 + O)
+    a = cond.ConvNet(I, O).to(DEV)
+    with torch.no_grad():
+        for m in a.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+    b = copy.deepcopy(a)
+    a.fused = True                  # the fused kernels are opt-in (NF_FUSED_CONV=1); the tests always exercise them
+    b.fused = False
+    return a, b
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('B', [64, 5])
+@pytest.mark.parametrize('I,O,H,W', SHAPES)
+def test_convnet_fused_vs_modules(pkg, I, O, H, W, B, training):
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    a, b = _nets(pkg, I, O)
+    a.train(training)
+    b.train(training)
+    x1 = torch.randn(B, I, H, W, device=DEV).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    if (H, W) == (28, 14):
+        assert not fc.convnet_usable(a, x1)            # 392 pixels do not tile: the module path serves it
+        G.assert_close(a(x1), b(x2), 1e-6, what='fallback')
+        return
+    assert fc.convnet_usable(a, x1)
+    state = copy.deepcopy(b.state_dict())
+    risky = _risky_samples(b, x1)                      # (touches the running statistics in train mode: restored)
+    b.load_state_dict(state)
+    y1, y2 = a(x1), b(x2)
+    G.assert_close(y1, y2, 2e-4, rtol=1e-4, what='output')
+    w = torch.randn_like(y2)
+    (y1 * w).sum().backward()
+    (y2 * w).sum().backward()
+    tol = lambda t: 2e-4 * max(1.0, float(t.abs().max()))
+    _close_but_for(x1.grad, x2.grad, tol(x2.grad), risky, 'input grad')
+    loose = 2500.0 if bool(risky.any()) else 5.0      # a flipped unit moves parameter gradients by its whole share
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for name, p in pb.items():
+        assert pa[name].grad is not None, name
+        # a bias in front of a training-mode BatchNorm has gradient exactly 0: both sides return cancellation noise
+        pre_bn_bias = training and name.endswith('module.bias') and 'out_block' not in name
+        t = 5e-3 + 3e-6 * B * H * W if pre_bn_bias else loose * tol(p.grad)
+        G.assert_close(pa[name].grad, p.grad, t, what='grad ' + name)
+    ba, bb = dict(a.named_buffers()), dict(b.named_buffers())
+    for name in bb:
+        G.assert_close(ba[name].float(), bb[name].float(), 1e-5, rtol=1e-5, what='buffer ' + name)
+
+
+def test_glow_image_coupling_uses_the_fused_conditioner(pkg):
+    """AffineCoupling on image data: conditioner through the fused kernels == module path, forward and backward."""
+    torch.manual_seed(3)
+    k1 = pkg.AffineCoupling((12, 16, 16), masking='channelwise').to(DEV)
+    k2 = copy.deepcopy(k1)
+    k1.net.fused = True
+    k2.net.fused = False
+    z1 = torch.randn(16, 12, 16, 16, device=DEV).requires_grad_(True)
+    z2 = z1.detach().clone().requires_grad_(True)
+    y1, l1 = k1(z1, torch.zeros(16, device=DEV))
+    y2, l2 = k2(z2, torch.zeros(16, device=DEV))
+    G.assert_close(y1, y2, 2e-4, rtol=1e-4, what='y')
+    G.assert_close(l1, l2, 2e-3, rtol=1e-4, what='log-det')
+    (y1.sum() + l1.sum()).backward()
+    (y2.sum() + l2.sum()).backward()
+    bad = ((z1.grad - z2.grad).abs() > 2e-4 * max(1.0, float(z2.grad.abs().max()))).flatten(1).any(1)
+    assert int(bad.sum()) <= 1, 'grad z differs in %d samples' % int(bad.sum())      # one ReLU flip at most

@@ -28,7 +28,7 @@ def run(B, I, O, H, W, k, bn, res, dev='cuda'):
     out = torch.empty(B, O, H, W, device=dev)
     kw = dict(in_=x, weight=w, bias=b, residual=r, out=out)
     stat = torch.zeros(2, R, 32, device=dev)
-    if O <= 32:
+    if O <= 32 and k == 3:
         kw.update(stat_sum=stat[0], stat_sqsum=stat[1])
     if bn:
         gamma, beta = torch.rand(I, device=dev) + 0.5, torch.randn(I, device=dev)
@@ -53,7 +53,7 @@ def run(B, I, O, H, W, k, bn, res, dev='cuda'):
         want = want + r
     err = float((out - (want + b.view(1, -1, 1, 1))).abs().max())
     serr = 0.0
-    if O <= 32:
+    if O <= 32 and k == 3:
         s1 = stat[0].sum(0)[:O]; s2 = stat[1].sum(0)[:O]
         serr = max(float((s1 - want.sum((0, 2, 3))).abs().max() / max(1.0, float(want.sum((0, 2, 3)).abs().max()))),
                    float((s2 - (want * want).sum((0, 2, 3))).abs().max() / float((want * want).sum((0, 2, 3)).abs().max())))
@@ -61,7 +61,7 @@ def run(B, I, O, H, W, k, bn, res, dev='cuda'):
     assert err < 2e-4 and serr < 1e-4
 
 
-for (I, O, H, W) in [(3, 6, 32, 16), (6, 12, 16, 16), (12, 24, 16, 8), (24, 48, 8, 8), (48, 96, 8, 4)]:
+for (I, O, H, W) in [(3, 6, 32, 16), (6, 12, 16, 16), (12, 24, 16, 8), (24, 48, 8, 8), (48, 96, 8, 4), (96, 192, 4, 4)]:
     for B in (64, 5):
         run(B, I, 32, H, W, 3, False, False)
         run(B, 32, 32, H, W, 3, True, False)
