@@ -384,6 +384,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no GPU visible'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if os.environ.get('NF_MIOPEN_FIND', '0') == '1':
+        torch.backends.cudnn.benchmark = True                # MIOpen find mode for the image conditioner's convolutions
     cfg = CONFIGS[args.config]
     B = args.batch or cfg['batch']
 
