@@ -105,7 +105,8 @@ class FlowTrainer:
         hooks, seen = [], set()
         if self._gather and self._indirect is None:     # first step: watch which parameters autograd itself produces
             for i, p in enumerate(self.bucket.params):
-                hooks.append(p.register_hook(lambda g, i=i: seen.add(i)))
+                # (a tensor hook also fires, with None, when a hand-written backward wrote into the bucket and returned nothing)
+                hooks.append(p.register_hook(lambda g, i=i: seen.add(i) if g is not None else None))
         elif self._indirect:
             for i in self._indirect:
                 self.bucket.params[i].grad = None       # AccumulateGrad then keeps the incoming tensor: no add launch

@@ -132,3 +132,22 @@ def test_trainer_gradient_gather_matches_accumulate(pkg):
         G.assert_close(ta.bucket.flat, tb.bucket.flat, 1e-5 * float(tb.bucket.flat.abs().max()), rtol=1e-4, what='flat grads, step %d' % step)
         for p in ta.bucket.params:
             assert p.grad is not None and p.grad.data_ptr() >= ta.bucket.flat.data_ptr()
+
+
+def test_trainer_keeps_direct_gradient_sinks(pkg):
+    """parameters whose gradient a hand-written backward writes straight into the bucket must NOT be classified as
+    framework-produced (a tensor hook fires with None for them): a vector MAF keeps every sink, and its step stays at
+    two launches per flow layer."""
+    import importlib
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    F = importlib.import_module(pkg.__name__ + '.functional')
+    torch.manual_seed(0)
+    net = pkg.MAF((2, ), 'density', NS(layers=3, mixtures=8)).to(DEV)
+    t = train.FlowTrainer(net, graph=False)
+    y = torch.randn(512, 2, device=DEV)
+    for _ in range(2):
+        t.train_on_batch(y)
+        assert t._indirect == []
+        assert all(F.grad_sink(p) is not None for p in net.parameters())
+
