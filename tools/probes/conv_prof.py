@@ -22,6 +22,7 @@ for name in ('nf_conv_bn_fwd', 'nf_conv_bn_bwd', 'nf_slab_sum', 'nf_conv_bn_usab
     setattr(real, name, pf)
 I, O, H, W = [int(v) for v in sys.argv[1:5]]
 net = cond.ConvNet(I, O).cuda()
+net.fused = True
 x = torch.randn(64, I, H, W, device='cuda', requires_grad=True)
 for _ in range(3):
     y = net(x); y.sum().backward()
