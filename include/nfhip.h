@@ -536,6 +536,27 @@ int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* 
                     const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
                     float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream);
 
+/* ---- a whole flow of S fused vector Glow steps (nf_glow_step_vec_*) in ONE launch per direction ---------------------------
+ * flows/glow.py: the (N, D in {2, 4}) model IS a sequence of such steps; rows stay in their workgroup from step to step, the
+ * batch statistics are exchanged grid-wide inside the launch exactly as in the single-step kernels.
+ *   steps_dev : DEVICE array of S step records (nf_glow_flow_step_bytes() bytes each), packed on the host one by one with
+ *               nf_glow_flow_pack from the same pointer tables nf_glow_step_vec_fwd / _bwd take (grad tables may be NULL for
+ *               a forward-only flow) and copied to the device by the caller; pointers only, valid while the parameters live;
+ *   ys        : (S, N, D) every step's output (the last one is the flow's output; all of them are the backward's inputs);
+ *   saves     : S x NF_GLOW_FLOW_SAVE_FLOATS; ws_zero: S x NF_MLP_WS_FLOATS zero floats per direction;
+ *   backward  : g_y is the gradient of ys[S-1], gzs (S, N, D) scratch whose FIRST slice is the gradient of z0 on return;
+ *               slabs2 = 2 x NF_MLP_BWD_SLAB_FLOATS; gradients are accumulated (accumulate != 0) or stored into the sinks.   */
+#define NF_GLOW_FLOW_MAX_STEPS 1024
+#define NF_GLOW_FLOW_SAVE_FLOATS 320
+int nf_glow_flow_step_bytes(void);
+int nf_glow_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, void* const* head_grads,
+                      void* const* mlp_grads, int D, int odd);
+int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
+                         int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
+int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,
+                         float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2, int64_t N, int D,
+                         int training, float bn_eps, float wn_eps, nf_stream_t stream);
+
 /* The persistent kernels above wait on each other with BOUNDED spin loops (a grid of <= NF_MLP_MAX_BLOCKS workgroups is
  * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some
  * launch produced garbage (device shared with another job?).  Synchronises the device.                                    */

@@ -409,11 +409,18 @@ __device__ __forceinline__ void nf_mc_load_x(const float* x, int64_t row, bool r
     }
 }
 
+// what a whole-flow kernel hands from one step to the next in registers (every lane of a row holds the row's values): the
+// step's output row and log-det (forward) or the gradient of its input row (backward).  Going through global memory instead
+// would put a store drain and a load round trip (~4 us) between two steps of the same workgroup.
+struct NfMcCarry { float v[4]; float ld; int have; };
+
+// The body of one launch is a device function so that the whole-flow kernels (k_glow_flow_*) can run it once per flow step
+// inside ONE launch; hz / hy / hld are the step's input, output and log-det rows (h.z / h.y / h.ld of a single-step launch).
 template <int HEAD>   // 0: the conditioner alone; 1: whole Glow step (ActNorm + 1x1 head); 2: whole RealNVP step (flow-BatchNorm head)
-__global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __restrict__ x, NfMlpP p, float* __restrict__ out,
-                                                                 float* save, float* stats, int64_t N, int I0, int O_out,
-                                                                 int training, float eps, float mom, float wn_eps, NfGlowV h) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restrict__ x, const NfMlpP& p, float* __restrict__ out,
+                                               float* save, float* stats, int64_t N, int I0, int O_out, int training, float eps,
+                                               float mom, float wn_eps, const NfGlowV& h, const float* hz, float* hy, float* hld,
+                                               NfMcCarry* carry = nullptr) {
     constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;     // GLOW: a fused flow step (either head)
     NF_MC_T(0);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
@@ -429,8 +436,14 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
     }
     if (GLOW) {
         if (!FBN) nf_glow_head_load(h, head_raw);
-        nf_glow_load_row(h.z, row, rv, h.D, zr);
-        if (rv && g == 0) ld_in = h.ld[row];
+        if (carry != nullptr && carry->have) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zr[c] = carry->v[c];
+            ld_in = carry->ld;
+        } else {
+            nf_glow_load_row(hz, row, rv, h.D, zr);
+            if (rv && g == 0) ld_in = hld[row];
+        }
     }
     else nf_mc_load_x(x, row, rv, I0, xa, g);
     if (training && blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
@@ -531,6 +544,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
     }
     nf_fp_ldvec(sm + NF_MC_B + (NF_MC_NL - 1) * 32, g, bias);
     if (GLOW) {                                           // the affine coupling itself, coupling.py:104-113 (lane g = 0 has t | s_raw)
+        float yv[4] = {0.f, 0.f, 0.f, 0.f}, ld_out = 0.f;
         if (rv && g == 0) {
             const int D = h.D, nh = D >> 1, sel0 = h.odd, sel1 = 1 ^ h.odd;
             const float ca = sm[NF_MC_HEAD + 25], cc = sm[NF_MC_HEAD + 26];
@@ -543,12 +557,21 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
                     const float sv = tanhf(e == 0 ? o4[nh] : o4[nh + 1]) * ca + cc;
                     const float t = e == 0 ? o4[0] : o4[1];
                     const float h0 = sel0 ? hh[2 * e + 1] : hh[2 * e], h1 = sel0 ? hh[2 * e] : hh[2 * e + 1];
-                    h.y[row * D + 2 * e + sel0] = h0 * expf(sv) + t;
-                    h.y[row * D + 2 * e + sel1] = h1;
+                    const float y0 = h0 * expf(sv) + t;
+                    hy[row * D + 2 * e + sel0] = y0;
+                    hy[row * D + 2 * e + sel1] = h1;
+                    if (sel0) { yv[2 * e + 1] = y0; yv[2 * e] = h1; } else { yv[2 * e] = y0; yv[2 * e + 1] = h1; }
                     dld += sv;
                 }
             }
-            h.ld[row] = ld_in + dld;
+            ld_out = ld_in + dld;
+            hld[row] = ld_out;
+        }
+        if (carry != nullptr) {                           // the next step of a whole-flow launch takes its row from here
+#pragma unroll
+            for (int c = 0; c < 4; ++c) carry->v[c] = __shfl(yv[c], c16, NF_WAVE);
+            carry->ld = __shfl(ld_out, c16, NF_WAVE);
+            carry->have = 1;
         }
     } else if (rv) {
 #pragma unroll
@@ -558,6 +581,14 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __
         }
     }
     NF_MC_T(8);
+}
+
+template <int HEAD>
+__global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __restrict__ x, NfMlpP p, float* __restrict__ out,
+                                                                 float* save, float* stats, int64_t N, int I0, int O_out,
+                                                                 int training, float eps, float mom, float wn_eps, NfGlowV h) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    nf_mc_fwd_body<HEAD>(sm, x, p, out, save, stats, N, I0, O_out, training, eps, mom, wn_eps, h, h.z, h.y, h.ld);
 }
 
 static inline size_t nf_mc_lds_bytes(int tiles_per_wave) {
@@ -765,11 +796,11 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
 }
 
 template <int HEAD>
-__global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __restrict__ x, NfMlpP p, const float* __restrict__ save,
-                                                                 const float* __restrict__ g_out, float* __restrict__ g_x, NfMlpG gr,
-                                                                 int accumulate, float* ws, float* __restrict__ slabs, int64_t N,
-                                                                 int I0, int O_out, int training, float eps, float wn_eps, NfGlowV h) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restrict__ x, const NfMlpP& p, const float* __restrict__ save,
+                                               const float* __restrict__ g_out, float* __restrict__ g_x, const NfMlpG& gr,
+                                               int accumulate, float* ws, float* __restrict__ slabs, int64_t N, int I0, int O_out,
+                                               int training, float eps, float wn_eps, const NfGlowV& h, const float* hz,
+                                               const float* hgy, const float* hgld, float* hgz, NfMcCarry* carry = nullptr) {
     constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;
     NF_MC_T(64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
@@ -785,9 +816,14 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
     }
     if (GLOW) {
         if (!FBN) nf_glow_head_load(h, head_raw);
-        nf_glow_load_row(h.z, row, rv, h.D, zr);
-        nf_glow_load_row(h.g_y, row, rv, h.D, gy);
-        if (h.g_ld != nullptr && rv) gld = h.g_ld[row];
+        nf_glow_load_row(hz, row, rv, h.D, zr);
+        if (carry != nullptr && carry->have) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gy[c] = carry->v[c];
+        } else {
+            nf_glow_load_row(hgy, row, rv, h.D, gy);
+        }
+        if (hgld != nullptr && rv) gld = hgld[row];
 #pragma unroll
         for (int j = 0; j < 8; ++j) Gs[j] = 0.f;
     } else {
@@ -894,10 +930,19 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
             for (int r = 0; r < 4; ++r) acc = fmaf(sm[NF_MC_HEAD + 4 * r + c], Gh[r], acc);
             gzn[c] = rv ? acc : 0.f;
         }
+        float gzv[4] = {0.f, 0.f, 0.f, 0.f};
         if (g == 0 && rv) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c < D) h.g_z[row * D + c] = gzn[c] / sm[NF_MC_HEAD + 16 + c];
+                if (c < D) {
+                    gzv[c] = gzn[c] / sm[NF_MC_HEAD + 16 + c];
+                    hgz[row * D + c] = gzv[c];
+                }
+        }
+        if (carry != nullptr) {                           // = the incoming gradient of the previous step of a whole-flow launch
+#pragma unroll
+            for (int c = 0; c < 4; ++c) carry->v[c] = __shfl(gzv[c], c16, NF_WAVE);
+            carry->have = 1;
         }
         float u8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (rv) {
@@ -1084,6 +1129,16 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __
     NF_MC_T(74);
 }
 
+template <int HEAD>
+__global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __restrict__ x, NfMlpP p, const float* __restrict__ save,
+                                                                 const float* __restrict__ g_out, float* __restrict__ g_x, NfMlpG gr,
+                                                                 int accumulate, float* ws, float* __restrict__ slabs, int64_t N,
+                                                                 int I0, int O_out, int training, float eps, float wn_eps, NfGlowV h) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    nf_mc_bwd_body<HEAD>(sm, x, p, save, g_out, g_x, gr, accumulate, ws, slabs, N, I0, O_out, training, eps, wn_eps, h, h.z, h.g_y,
+                         h.g_ld, h.g_z);
+}
+
 extern "C" int nf_mlp_chain_bwd(const float* x, const void* const* params, const float* save_stats, const float* g_out, float* g_x,
                                 void* const* grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int I0, int O_out,
                                 int training, float bn_eps, float wn_eps, nf_stream_t stream) {
@@ -1169,6 +1224,147 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
     hipLaunchKernelGGL(k_mlp_chain_bwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
                        save_stats, (const float*)nullptr, (float*)nullptr, g, accumulate, ws_zero, slabs, N, D / 2, D, training, bn_eps,
                        wn_eps, h);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A whole flow of S fused vector Glow steps in ONE launch per direction.  Rows never leave their workgroup between steps
+// (a flow step is row-local apart from the batch statistics, which the step bodies already exchange grid-wide), so the
+// launch boundary between steps buys nothing: it costs ~2.7 us of dispatch / drain per step and direction (64 of them per
+// C2 train step).  The step bodies are the single-step kernels' bodies, run back to back on per-step exchange workspaces;
+// the backward's weight-gradient slabs alternate between two regions (a workgroup may start writing step s-1 while a
+// slower one still folds step s; it cannot get further ahead than that, the first exchange of a step needs everybody).
+// ---------------------------------------------------------------------------------------------------------------
+struct NfGlowFlowStep { NfMlpP p; NfMlpG g; NfGlowV h; };     // the static pointers of one step: parameters, gradient sinks
+
+extern "C" int nf_glow_flow_step_bytes(void) { return (int)sizeof(NfGlowFlowStep); }
+
+extern "C" int nf_glow_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, void* const* head_grads,
+                                 void* const* mlp_grads, int D, int odd) {
+    if (dst_host == nullptr || head == nullptr || mlp_params == nullptr || (D != 2 && D != 4)) return NF_E_BADARG;
+    NfGlowFlowStep st{};
+    nf_mlp_unpack(mlp_params, st.p);
+    nf_glow_unpack(head, st.h);
+    st.h.D = D; st.h.odd = odd ? 1 : 0;
+    if (mlp_grads != nullptr) {
+        for (int l = 0; l < NF_MC_NL; ++l) {
+            st.g.v[l] = (float*)mlp_grads[3 * l]; st.g.g[l] = (float*)mlp_grads[3 * l + 1]; st.g.b[l] = (float*)mlp_grads[3 * l + 2];
+        }
+        for (int j = 0; j < NF_MC_NB; ++j) {
+            st.g.gamma[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j]; st.g.beta[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j + 1];
+        }
+    }
+    if (head_grads != nullptr) {
+        st.h.g_ls = (float*)head_grads[0]; st.h.g_bs = (float*)head_grads[1]; st.h.g_L = (float*)head_grads[2];
+        st.h.g_U = (float*)head_grads[3]; st.h.g_log_s = (float*)head_grads[4]; st.h.g_a = (float*)head_grads[5];
+        st.h.g_c = (float*)head_grads[6];
+    }
+    *reinterpret_cast<NfGlowFlowStep*>(dst_host) = st;
+    return 0;
+}
+
+// The step records live in global memory; reading ~100 pointers from there at the top of every step would put a memory
+// round trip in front of each step (the single-step kernels get them in SGPRs from the kernarg segment).  So the record of
+// step s+1 is fetched by the first threads while step s runs and parked in LDS (double buffered) for its turn.
+#define NF_GF_REC_WORDS ((int)((sizeof(NfGlowFlowStep) + 7) / 8))
+static_assert(NF_GF_REC_WORDS <= NF_MC_THREADS, "one 8-byte word of a step record per thread");
+
+__global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_fwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* z0,
+                                                                 float* ys, float* ld, float* saves, float* ws, int64_t N, int D,
+                                                                 int training, float eps, float mom, float wn_eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ __attribute__((aligned(16))) unsigned long long rec[2][NF_GF_REC_WORDS];
+    const int64_t ND = N * D;
+    const bool rt = (int)threadIdx.x < NF_GF_REC_WORDS;
+    if (rt) rec[0][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps)[threadIdx.x];
+    __syncthreads();
+    NfMcCarry carry;
+    carry.have = 0;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        NF_MC_T(100);
+        unsigned long long nxt = 0;
+        if (rt && s + 1 < S) nxt = reinterpret_cast<const unsigned long long*>(steps + s + 1)[threadIdx.x];
+        const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
+        nf_mc_fwd_body<1>(sm, nullptr, st.p, nullptr, saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, ws + (int64_t)s * NF_MLP_WS_FLOATS, N,
+                          D / 2, D, training, eps, mom, wn_eps, st.h, s == 0 ? z0 : ys + (int64_t)(s - 1) * ND, ys + (int64_t)s * ND, ld,
+                          &carry);
+        NF_MC_T(101);
+        if (rt) rec[(s + 1) & 1][threadIdx.x] = nxt;
+        __syncthreads();                                // LDS is restaged; the rows travel in registers (carry)
+        NF_MC_T(102);
+    }
+}
+
+__global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* z0,
+                                                                 const float* ys, const float* g_y, const float* g_ld, float* gzs,
+                                                                 const float* saves, int accumulate, float* ws, float* slabs,
+                                                                 int64_t N, int D, int training, float eps, float wn_eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ __attribute__((aligned(16))) unsigned long long rec[2][NF_GF_REC_WORDS];
+    const int64_t ND = N * D;
+    const bool rt = (int)threadIdx.x < NF_GF_REC_WORDS;
+    if (rt) rec[(S - 1) & 1][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps + S - 1)[threadIdx.x];
+    __syncthreads();
+    NfMcCarry carry;
+    carry.have = 0;
+#pragma unroll 1
+    for (int s = S - 1; s >= 0; --s) {
+        NF_MC_T(104);
+        unsigned long long nxt = 0;
+        if (rt && s > 0) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 1)[threadIdx.x];
+        const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
+        nf_mc_bwd_body<1>(sm, nullptr, st.p, saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, nullptr, nullptr, st.g, accumulate,
+                          ws + (int64_t)s * NF_MLP_WS_FLOATS, slabs + (int64_t)(s & 1) * NF_MLP_BWD_SLAB_FLOATS, N, D / 2, D, training,
+                          eps, wn_eps, st.h, s == 0 ? z0 : ys + (int64_t)(s - 1) * ND, s == S - 1 ? g_y : gzs + (int64_t)(s + 1) * ND,
+                          g_ld, gzs + (int64_t)s * ND, &carry);
+        NF_MC_T(105);
+        if (rt) rec[(s + 1) & 1][threadIdx.x] = nxt;    // parity of s - 1
+        __syncthreads();
+        NF_MC_T(106);
+    }
+}
+
+extern "C" int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
+                                    int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                                    nf_stream_t stream) {
+    if (steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr || ld == nullptr ||
+        saves == nullptr || ws_zero == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (+ the static record buffers)
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_glow_flow_fwd, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
+                       (const NfGlowFlowStep*)steps_dev, S, z0, ys, ld, saves, ws_zero, N, D, training, bn_eps, bn_momentum, wn_eps);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
+                                    const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2,
+                                    int64_t N, int D, int training, float bn_eps, float wn_eps, nf_stream_t stream) {
+    if (steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr || g_y == nullptr ||
+        gzs == nullptr || saves == nullptr || ws_zero == nullptr || slabs2 == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_glow_flow_bwd, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
+                       (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, accumulate, ws_zero, slabs2, N, D, training,
+                       bn_eps, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -643,6 +643,131 @@ def glow_step_vec(z, ld, actnorm, conv, coupling):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# a whole flow of fused vector Glow steps in one launch per direction (csrc/mlp_chain.hip: k_glow_flow_fwd / _bwd)
+# ----------------------------------------------------------------------------------------------------------------------
+import os as _os
+
+# whole-flow launches: 'auto' = batches of at most GLOW_FLOW_AUTO_ROWS rows, where they are a measured win (C2 at B = 512:
+# 1.89 -> 1.78 ms, B = 1024: 1.80 -> 1.72 ms); from 32 workgroups on the in-kernel exchanges get slower than the launch
+# gaps they replace (B = 4096: 1.91 -> 1.94 ms, B = 16384: 3.05 -> 3.66 ms), DESIGN.md section 3.11.  '1' / '0' force it.
+GLOW_FLOW = _os.environ.get('NF_GLOW_FLOW', 'auto')
+GLOW_FLOW_AUTO_ROWS = 1024
+_GLOW_FLOW_TABLES = {}
+_GLOW_FLOW_SLABS = {}
+
+
+def _glow_flow_slabs(device):
+    t = _GLOW_FLOW_SLABS.get(device)
+    if t is None:
+        t = _GLOW_FLOW_SLABS[device] = torch.empty(2 * N.header_constant('NF_MLP_BWD_SLAB_FLOATS'), dtype=torch.float32,
+                                                   device=device)
+    return t
+
+
+def _glow_step_learnables(head, mlp):
+    nl, nb = 6, 5
+    learn_h = [head[0], head[1], head[3], head[4], head[8], head[9], head[10]]
+    learn_m = list(mlp[:3 * nl]) + [t for j in range(nb) for t in mlp[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+    return learn_h + learn_m
+
+
+def _glow_flow_table(steps, sinks, D, device):
+    """device array of the steps' pointer records (nf_glow_flow_pack), cached while every pointer stays where it is.
+    steps: [(odd, head tensors, mlp tensors)]; sinks: per step the 35 gradient buffers (or None: forward only)."""
+    key = (device, D, tuple(int(odd) for odd, _, _ in steps),
+           tuple(t.data_ptr() for _, h, m in steps for t in list(h) + list(m)),
+           None if sinks is None else tuple(t.data_ptr() for g in sinks for t in g))
+    hit = _GLOW_FLOW_TABLES.get(key)
+    if hit is not None:
+        return hit
+    lib = N.load()
+    nbytes = int(lib.nf_glow_flow_step_bytes())
+    host = (ctypes.c_ubyte * (nbytes * len(steps)))()
+    for i, (odd, head, mlp) in enumerate(steps):
+        htab, mtab = _ptr_table(head), _ptr_table(mlp)
+        if sinks is None:
+            hg = mg = None
+        else:
+            hgt, mgt = _ptr_table(sinks[i][:7]), _ptr_table(sinks[i][7:])
+            hg, mg = ctypes.addressof(hgt), ctypes.addressof(mgt)
+        N.call('nf_glow_flow_pack', ctypes.addressof(host) + i * nbytes, ctypes.addressof(htab), ctypes.addressof(mtab), hg, mg,
+               D, int(odd))
+    table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+    if len(_GLOW_FLOW_TABLES) > 64:
+        _GLOW_FLOW_TABLES.clear()
+    _GLOW_FLOW_TABLES[key] = table
+    return table
+
+
+class _GlowFlowVec(torch.autograd.Function):
+    """(y, ld) of S consecutive [ActNorm, InvertibleConv1x1, AffineCoupling] steps on (N, D) data: one launch forward, one
+    backward.  tensors: per step the 11 head tensors and the 43 MLP tensors of _GlowStepVec.  Needs the gradient sinks of
+    a GradBucket (the Compose peephole checks)."""
+
+    @staticmethod
+    def forward(ctx, z, ld, odds, training, *tensors):
+        S = len(odds)
+        per = 11 + 43
+        steps = [(odds[i], tensors[per * i:per * i + 11], tensors[per * i + 11:per * (i + 1)]) for i in range(S)]
+        from .functional import _sinks
+        sinks = [_sinks(*_glow_step_learnables(h, m)) for _, h, m in steps]
+        if any(g is None for g in sinks):
+            raise RuntimeError('glow_flow_vec needs direct gradient sinks (GradBucket) for every parameter')
+        z = z.contiguous()
+        Nrows, D = z.shape
+        dev = z.device
+        table = _glow_flow_table(steps, sinks, D, dev)
+        ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+        saves = torch.empty(S, N.header_constant('NF_GLOW_FLOW_SAVE_FLOATS'), dtype=torch.float32, device=dev)
+        ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        N.call('nf_glow_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
+               int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        ctx.save_for_backward(z, ys, saves, table)
+        ctx.meta = (S, bool(training), len(tensors))
+        ctx.mark_dirty(ld)
+        return ys[S - 1], ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        S, training, n_tensors = ctx.meta
+        z, ys, saves, table = ctx.saved_tensors
+        Nrows, D = z.shape
+        dev = z.device
+        g_y = g_y.contiguous()
+        g_ld = None if g_ld is None else g_ld.contiguous()
+        gzs = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+        ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        N.call('nf_glow_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves), 1,
+               N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, int(training), BN_EPS, WN_EPS, N.stream())
+        return (gzs[0], g_ld, None, None) + (None, ) * n_tensors
+
+
+def glow_flow_vec_usable(z, steps):
+    """steps: [(actnorm, conv, coupling)] -- at least two fused-step-capable steps whose parameters all have direct sinks."""
+    from .functional import grad_sink
+    on = GLOW_FLOW is True or GLOW_FLOW == '1' or (GLOW_FLOW == 'auto' and z.shape[0] <= GLOW_FLOW_AUTO_ROWS)
+    if not on or len(steps) < 2 or len(steps) > N.header_constant('NF_GLOW_FLOW_MAX_STEPS') or not torch.is_grad_enabled():
+        return False
+    for a, c, k in steps:
+        if not glow_step_vec_usable(z, k.net):
+            return False
+        head = [a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale, k.s_bias]
+        if any(grad_sink(t) is None for t in _glow_step_learnables(head, _mlp_tensors(k.net))):
+            return False
+    return True
+
+
+def glow_flow_vec(z, ld, steps):
+    from .functional import _owned_ld
+    tensors = []
+    for a, c, k in steps:
+        tensors += [a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale, k.s_bias]
+        tensors += _mlp_tensors(k.net)
+    odds = tuple(int(k.odd) for _, _, k in steps)
+    return _GlowFlowVec.apply(z, _owned_ld(ld), odds, steps[0][2].net.training, *tensors)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # whole Flow++ coupling on vector data: conditioner (strided read of the conditioning half) + mixture-of-logistics coupling
 # ----------------------------------------------------------------------------------------------------------------------
 class _FlowppCouplingVec(torch.autograd.Function):

@@ -49,6 +49,21 @@ class Compose(nn.Module):
         return not (a._forward_hooks or c._forward_hooks or k._forward_hooks or a._forward_pre_hooks
                     or c._forward_pre_hooks or k._forward_pre_hooks)
 
+    def _glow_run_at(self, i, z):
+        """the maximal run of fused-step-capable Glow steps on (N, 2 | 4) data that starts at layer i -- initialised ActNorms,
+        training-mode conditioners of one mind, every parameter with a direct gradient sink -- or None."""
+        L, run, j = self.layers, [], i
+        if z.dim() != 2:
+            return None
+        while self._glow_step_at(j, z):
+            a, c, k = L[j], L[j + 1], L[j + 2]
+            if not (a.initialized and k.mode == N.SPLIT_1D and isinstance(k.net, MLP)
+                    and k.net.training == L[i + 2].net.training):
+                break
+            run.append((a, c, k))
+            j += 3
+        return run if FUSED.glow_flow_vec_usable(z, run) else None
+
     def _bn_step_at(self, i, z):
         """[flow BatchNorm (training, affine=False), AffineCoupling | AutoregressiveTransfrom] -> fused BatchNorm head"""
         L = self.layers
@@ -92,6 +107,11 @@ class Compose(nn.Module):
                 i += 2
             elif self._glow_step_at(i, z):
                 a, c, k = L[i], L[i + 1], L[i + 2]
+                run = self._glow_run_at(i, z)
+                if run is not None:                                # the whole run of steps: one launch per direction
+                    z, log_df_dz = FUSED.glow_flow_vec(z, log_df_dz, run)
+                    i += 3 * len(run)
+                    continue
                 if not a.initialized:
                     NF.actnorm_init_(z, a.log_scale, a.bias, a.eps)
                     a.initialized = True

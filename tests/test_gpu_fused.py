@@ -485,3 +485,54 @@ def test_realnvp_step_vec_vs_unfused(pkg, D, odd, N, direct):
     b1, b2 = dict(m1.named_buffers()), dict(m2.named_buffers())
     for name in b1:
         G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+
+
+@pytest.mark.parametrize('D,B,K', [(2, 4096, 8), (2, 300, 3), (4, 1000, 4), (2, 16384, 2)])
+def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
+    """the whole run of vector Glow steps in one launch per direction (k_glow_flow_fwd / _bwd) against the same steps
+    launched one by one: outputs, log-det, every gradient in the flat bucket, BatchNorm running statistics."""
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 1000 + B)
+    net1 = pkg.Glow((D, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    net2 = copy.deepcopy(net1)
+    y = (torch.randn(B, D) * 0.7).to(DEV)
+    t1, t2 = train.FlowTrainer(net1, graph=False), train.FlowTrainer(net2, graph=False)
+    calls = {'n': 0}
+    real = fused.glow_flow_vec
+    monkeypatch.setattr(fused, 'GLOW_FLOW', True)           # opt-in path (NF_GLOW_FLOW=1)
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+
+    for step in range(3):                                   # step 0 initialises the ActNorms (no whole-flow launch yet)
+        monkeypatch.setattr(fused, 'glow_flow_vec', counted)
+        monkeypatch.setattr(fused, 'glow_flow_vec_usable', fused.__dict__['glow_flow_vec_usable'])
+        t1.net.train()
+        z1, l1 = t1._forward_backward(y)
+        n_flow = calls['n']
+        monkeypatch.setattr(fused, 'glow_flow_vec_usable', lambda z, steps: False)
+        t2.net.train()
+        z2, l2 = t2._forward_backward(y)
+        monkeypatch.undo()
+        monkeypatch.setattr(fused, 'GLOW_FLOW', True)
+        G.assert_close(z1, z2, 2e-5, rtol=2e-5, what='z, step %d' % step)
+        G.assert_close(l1, l2, 2e-5, rtol=2e-5, what='loss, step %d' % step)
+        scale = float(t2.bucket.flat.abs().max())
+        bad = ((t1.bucket.flat - t2.bucket.flat).abs() > 1e-4 * max(1.0, scale)).float().mean()
+        # (the biases in front of a BatchNorm have gradient 0: both paths return cancellation noise there; 16384 rows: ReLU flips)
+        assert float(bad) <= (5e-3 if B >= 16384 else 1e-3), 'flat gradients differ in %.2e of the entries (step %d)' % (float(bad), step)
+        G.assert_close(t1.bucket.flat, t2.bucket.flat, (5e-2 if B >= 16384 else 1e-2) * max(1.0, scale), what='flat grads, step %d' % step)
+        b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
+        for name in b2:
+            G.assert_close(b1[name].float(), b2[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+        t1.optim.step()
+        # Adam turns noise-level gradient differences (the atomics of the step-0 ActNorm init) into lr-sized parameter
+        # differences: keep the two replicas identical instead of comparing two diverging trainings
+        net2.load_state_dict(net1.state_dict())
+        t2.bucket.flat_params.copy_(t1.bucket.flat_params)
+    assert n_flow >= 2, 'the whole-flow launch was never taken'
+    assert fused.N.persistent_timeouts() == 0
+

@@ -106,3 +106,50 @@ print('forward : stage %.2f | x + linear0 %.2f | layers %s | tail %.2f | total %
     us(0, 1), us(1, 2), ' '.join('%.2f' % us(2 + i, 3 + i) for i in range(5)), us(7, 8), us(0, 8)))
 print('backward: stage %.2f | recompute %.2f | layers 5..0 %s | final barrier %.2f | fold %.2f | total %.2f' % (
     us(64, 65), us(65, 66), ' '.join('%.2f' % us(66 + i, 67 + i) for i in range(6)), us(72, 73), us(73, 74), us(64, 74)))
+
+# ---- a whole flow of S such steps in one launch per direction (k_glow_flow_*): the stamps are those of the LAST step run ----
+S = 8
+steps_m = []
+for i in range(S):
+    a, c, k = pkg.ActNorm((2, )), pkg.InvertibleConv1x1(2), pkg.AffineCoupling((2, ), odd=bool(i & 1))
+    steps_m.append(torch.nn.ModuleList([a, c, k]).to(dev).train())
+recs, sinks, keep = [], [], []
+nbytes = lib.nf_glow_flow_step_bytes()
+host = (ctypes.c_ubyte * (nbytes * S))()
+for i, (a, c, k) in enumerate(steps_m):
+    head = [a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale, k.s_bias]
+    mts = fused._mlp_tensors(k.net)
+    lh = [head[0], head[1], head[3], head[4], head[8], head[9], head[10]]
+    lm = list(mts[:18]) + [t for j in range(5) for t in mts[18 + 5 * j:18 + 5 * j + 2]]
+    dh, dm = [torch.zeros_like(t) for t in lh], [torch.zeros_like(t) for t in lm]
+    keep += [dh, dm]
+    htab, mtab = fused._ptr_table([t.detach() for t in head]), fused._ptr_table([t.detach() for t in mts])
+    hg, mg = fused._ptr_table(dh), fused._ptr_table(dm)
+    assert lib.nf_glow_flow_pack(P(ctypes.addressof(host) + i * nbytes), htab, mtab, hg, mg, 2, int(i & 1)) == 0
+table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+ys = torch.empty(S, n, 2, device=dev)
+gzs = torch.empty(S, n, 2, device=dev)
+saves = torch.empty(S, 320, device=dev)
+slabs2 = torch.empty(2 * N_.header_constant('NF_MLP_BWD_SLAB_FLOATS'), device=dev)
+for it in range(3):
+    ws = torch.zeros(S * N_.header_constant('NF_MLP_WS_FLOATS'), device=dev)
+    ws2 = torch.zeros(S * N_.header_constant('NF_MLP_WS_FLOATS'), device=dev)
+    ld.zero_()
+    torch.cuda.synchronize()
+    rc = lib.nf_glow_flow_vec_fwd(P(table.data_ptr()), S, P(z.data_ptr()), P(ys.data_ptr()), P(ld.data_ptr()), P(saves.data_ptr()),
+                                  P(ws.data_ptr()), ctypes.c_int64(n), 2, 1, F(1e-5), F(0.1), F(1e-5), st)
+    rc2 = lib.nf_glow_flow_vec_bwd(P(table.data_ptr()), S, P(z.data_ptr()), P(ys.data_ptr()), P(gy.data_ptr()), None, P(gzs.data_ptr()),
+                                   P(saves.data_ptr()), 1, P(ws2.data_ptr()), P(slabs2.data_ptr()), ctypes.c_int64(n), 2, 1, F(1e-5),
+                                   F(1e-5), st)
+    torch.cuda.synchronize()
+    assert rc == 0 and rc2 == 0, (rc, rc2)
+assert lib.nf_mlp_chain_prof_read(buf) == 0
+t = list(buf)
+print('--- whole flow, %d steps in one launch (last step run) ---' % S)
+print('forward : loop top -> body %.2f | stage %.2f | x + linear0 %.2f | layers %s | tail %.2f | body %.2f | sync %.2f' % (
+    us(100, 0), us(0, 1), us(1, 2), ' '.join('%.2f' % us(2 + i, 3 + i) for i in range(5)), us(7, 8), us(0, 8), us(101, 102)))
+print('backward: loop top -> body %.2f | stage %.2f | recompute %.2f | layers 5..0 %s | final barrier %.2f | fold %.2f | body %.2f | sync %.2f' % (
+    us(104, 64), us(64, 65), us(65, 66), ' '.join('%.2f' % us(66 + i, 67 + i) for i in range(6)), us(72, 73), us(73, 74), us(64, 74),
+    us(105, 106)))
+print('          layer 1 detail: to exchange entry %.2f | exchange %.2f | rest %.2f' % (us(3, 40), us(40, 41), us(41, 4)))
+
