@@ -37,20 +37,29 @@ extern "C" int nf_mlp_chain_prof_read(long long* host_out) {
 #define NF_MC_NL NF_MLP_LINEARS
 #define NF_MC_NB NF_MLP_BNS
 
+// Parameter pointers carry the GLOBAL address space on the device side: a whole-flow kernel reads them from a record in
+// memory, and a pointer loaded from memory is otherwise generic -> flat loads, whose completion counts on BOTH the vector-
+// memory and the LDS counters (43 flat instructions in k_glow_flow_fwd before this; none now).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NF_G __attribute__((address_space(1)))
+#else
+#define NF_G
+#endif
+#define NF_GSET(field, value) field = (decltype(field))(value)
 struct NfMlpP {
-    const float* v[NF_MC_NL]; const float* g[NF_MC_NL]; const float* b[NF_MC_NL];
-    const float* gamma[NF_MC_NB]; const float* beta[NF_MC_NB];
-    float* rmean[NF_MC_NB]; float* rvar[NF_MC_NB]; int64_t* nbt[NF_MC_NB];
+    const NF_G float* v[NF_MC_NL]; const NF_G float* g[NF_MC_NL]; const NF_G float* b[NF_MC_NL];
+    const NF_G float* gamma[NF_MC_NB]; const NF_G float* beta[NF_MC_NB];
+    NF_G float* rmean[NF_MC_NB]; NF_G float* rvar[NF_MC_NB]; NF_G int64_t* nbt[NF_MC_NB];
 };
 
 static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
     for (int l = 0; l < NF_MC_NL; ++l) {
-        p.v[l] = (const float*)t[3 * l]; p.g[l] = (const float*)t[3 * l + 1]; p.b[l] = (const float*)t[3 * l + 2];
+        NF_GSET(p.v[l], t[3 * l]); NF_GSET(p.g[l], t[3 * l + 1]); NF_GSET(p.b[l], t[3 * l + 2]);
     }
     for (int j = 0; j < NF_MC_NB; ++j) {
         const void* const* q = t + 3 * NF_MC_NL + 5 * j;
-        p.gamma[j] = (const float*)q[0]; p.beta[j] = (const float*)q[1];
-        p.rmean[j] = (float*)q[2]; p.rvar[j] = (float*)q[3]; p.nbt[j] = (int64_t*)q[4];
+        NF_GSET(p.gamma[j], q[0]); NF_GSET(p.beta[j], q[1]);
+        NF_GSET(p.rmean[j], q[2]); NF_GSET(p.rvar[j], q[3]); NF_GSET(p.nbt[j], q[4]);
     }
 }
 
@@ -58,16 +67,16 @@ static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
 struct NfGlowV {
     const float* z; float* y; float* ld;                                     // forward: input, output, log-det (in place +=)
     const float* g_y; const float* g_ld; float* g_z;                         // backward
-    const float *ls, *bs, *P, *L, *U, *Lm, *Um, *sign_s, *log_s, *a, *c;     // ActNorm, PLU factors, coupling scale / shift
-    float *g_ls, *g_bs, *g_L, *g_U, *g_log_s, *g_a, *g_c;
-    float *bmean, *bvar, *rmean, *rvar;                                      // flow-BatchNorm head (HEAD == 2): ls = log_gamma, bs = beta
+    const NF_G float *ls, *bs, *P, *L, *U, *Lm, *Um, *sign_s, *log_s, *a, *c;     // ActNorm, PLU factors, coupling scale / shift
+    NF_G float *g_ls, *g_bs, *g_L, *g_U, *g_log_s, *g_a, *g_c;
+    NF_G float *bmean, *bvar, *rmean, *rvar;                                 // flow-BatchNorm head (HEAD == 2): ls = log_gamma, bs = beta
     float fbn_eps, fbn_mom;
     int D, odd;
 };
 static inline void nf_glow_unpack(const void* const* t, NfGlowV& h) {
-    h.ls = (const float*)t[0]; h.bs = (const float*)t[1]; h.P = (const float*)t[2]; h.L = (const float*)t[3];
-    h.U = (const float*)t[4]; h.Lm = (const float*)t[5]; h.Um = (const float*)t[6]; h.sign_s = (const float*)t[7];
-    h.log_s = (const float*)t[8]; h.a = (const float*)t[9]; h.c = (const float*)t[10];
+    NF_GSET(h.ls, t[0]); NF_GSET(h.bs, t[1]); NF_GSET(h.P, t[2]); NF_GSET(h.L, t[3]);
+    NF_GSET(h.U, t[4]); NF_GSET(h.Lm, t[5]); NF_GSET(h.Um, t[6]); NF_GSET(h.sign_s, t[7]);
+    NF_GSET(h.log_s, t[8]); NF_GSET(h.a, t[9]); NF_GSET(h.c, t[10]);
 }
 
 // LDS (floats)
@@ -626,7 +635,7 @@ extern "C" int nf_mlp_chain_fwd(const float* x, const void* const* params, float
 // of waves 4 (w >> 2) .. +3 -- 16 MFMAs each, partial results to this workgroup's slab.  After a final grid barrier
 // workgroup l folds the slabs of linear l and applies the weight-norm backward (weight_norm.py:35-41).
 // ---------------------------------------------------------------------------------------------------------------
-struct NfMlpG { float* v[NF_MC_NL]; float* g[NF_MC_NL]; float* b[NF_MC_NL]; float* gamma[NF_MC_NB]; float* beta[NF_MC_NB]; };
+struct NfMlpG { NF_G float* v[NF_MC_NL]; NF_G float* g[NF_MC_NL]; NF_G float* b[NF_MC_NL]; NF_G float* gamma[NF_MC_NB]; NF_G float* beta[NF_MC_NB]; };
 
 #define NF_MC_SLAB_Q 1056                                // 32 x 32 weight-gradient partial + 32 bias partial
 #define NF_MC_SLAB_L (NF_MC_NKQ * NF_MC_SLAB_Q)          // one partial per 64-row group
@@ -1149,8 +1158,8 @@ extern "C" int nf_mlp_chain_bwd(const float* x, const void* const* params, const
     NfMlpP p;
     nf_mlp_unpack(params, p);
     NfMlpG g;
-    for (int l = 0; l < NF_MC_NL; ++l) { g.v[l] = (float*)grads[3 * l]; g.g[l] = (float*)grads[3 * l + 1]; g.b[l] = (float*)grads[3 * l + 2]; }
-    for (int j = 0; j < NF_MC_NB; ++j) { g.gamma[j] = (float*)grads[3 * NF_MC_NL + 2 * j]; g.beta[j] = (float*)grads[3 * NF_MC_NL + 2 * j + 1]; }
+    for (int l = 0; l < NF_MC_NL; ++l) { NF_GSET(g.v[l], grads[3 * l]); NF_GSET(g.g[l], grads[3 * l + 1]); NF_GSET(g.b[l], grads[3 * l + 2]); }
+    for (int j = 0; j < NF_MC_NB; ++j) { NF_GSET(g.gamma[j], grads[3 * NF_MC_NL + 2 * j]); NF_GSET(g.beta[j], grads[3 * NF_MC_NL + 2 * j + 1]); }
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t lds = nf_mc_lds_bytes(3);
     static bool attr_set = false;
@@ -1206,13 +1215,13 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
     NfMlpP p;
     nf_mlp_unpack(mlp_params, p);
     NfMlpG g;
-    for (int l = 0; l < NF_MC_NL; ++l) { g.v[l] = (float*)mlp_grads[3 * l]; g.g[l] = (float*)mlp_grads[3 * l + 1]; g.b[l] = (float*)mlp_grads[3 * l + 2]; }
-    for (int j = 0; j < NF_MC_NB; ++j) { g.gamma[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j]; g.beta[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j + 1]; }
+    for (int l = 0; l < NF_MC_NL; ++l) { NF_GSET(g.v[l], mlp_grads[3 * l]); NF_GSET(g.g[l], mlp_grads[3 * l + 1]); NF_GSET(g.b[l], mlp_grads[3 * l + 2]); }
+    for (int j = 0; j < NF_MC_NB; ++j) { NF_GSET(g.gamma[j], mlp_grads[3 * NF_MC_NL + 2 * j]); NF_GSET(g.beta[j], mlp_grads[3 * NF_MC_NL + 2 * j + 1]); }
     NfGlowV h{};
     nf_glow_unpack(head, h);
     h.z = z; h.g_y = g_y; h.g_ld = g_ld; h.g_z = g_z; h.D = D; h.odd = odd ? 1 : 0;
-    h.g_ls = (float*)head_grads[0]; h.g_bs = (float*)head_grads[1]; h.g_L = (float*)head_grads[2]; h.g_U = (float*)head_grads[3];
-    h.g_log_s = (float*)head_grads[4]; h.g_a = (float*)head_grads[5]; h.g_c = (float*)head_grads[6];
+    NF_GSET(h.g_ls, head_grads[0]); NF_GSET(h.g_bs, head_grads[1]); NF_GSET(h.g_L, head_grads[2]); NF_GSET(h.g_U, head_grads[3]);
+    NF_GSET(h.g_log_s, head_grads[4]); NF_GSET(h.g_a, head_grads[5]); NF_GSET(h.g_c, head_grads[6]);
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t lds = nf_mc_lds_bytes(3);
     static bool attr_set = false;
@@ -1249,16 +1258,16 @@ extern "C" int nf_glow_flow_pack(void* dst_host, const void* const* head, const 
     st.h.D = D; st.h.odd = odd ? 1 : 0;
     if (mlp_grads != nullptr) {
         for (int l = 0; l < NF_MC_NL; ++l) {
-            st.g.v[l] = (float*)mlp_grads[3 * l]; st.g.g[l] = (float*)mlp_grads[3 * l + 1]; st.g.b[l] = (float*)mlp_grads[3 * l + 2];
+            NF_GSET(st.g.v[l], mlp_grads[3 * l]); NF_GSET(st.g.g[l], mlp_grads[3 * l + 1]); NF_GSET(st.g.b[l], mlp_grads[3 * l + 2]);
         }
         for (int j = 0; j < NF_MC_NB; ++j) {
-            st.g.gamma[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j]; st.g.beta[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j + 1];
+            NF_GSET(st.g.gamma[j], mlp_grads[3 * NF_MC_NL + 2 * j]); NF_GSET(st.g.beta[j], mlp_grads[3 * NF_MC_NL + 2 * j + 1]);
         }
     }
     if (head_grads != nullptr) {
-        st.h.g_ls = (float*)head_grads[0]; st.h.g_bs = (float*)head_grads[1]; st.h.g_L = (float*)head_grads[2];
-        st.h.g_U = (float*)head_grads[3]; st.h.g_log_s = (float*)head_grads[4]; st.h.g_a = (float*)head_grads[5];
-        st.h.g_c = (float*)head_grads[6];
+        NF_GSET(st.h.g_ls, head_grads[0]); NF_GSET(st.h.g_bs, head_grads[1]); NF_GSET(st.h.g_L, head_grads[2]);
+        NF_GSET(st.h.g_U, head_grads[3]); NF_GSET(st.h.g_log_s, head_grads[4]); NF_GSET(st.h.g_a, head_grads[5]);
+        NF_GSET(st.h.g_c, head_grads[6]);
     }
     *reinterpret_cast<NfGlowFlowStep*>(dst_host) = st;
     return 0;
@@ -1375,8 +1384,8 @@ extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z
 // the fused vector RealNVP step: flow BatchNorm (batch statistics) -> affine coupling (MLP conditioner), HEAD == 2
 // ---------------------------------------------------------------------------------------------------------------
 static void nf_fbn_unpack(const void* const* t, NfGlowV& h) {
-    h.ls = (const float*)t[0]; h.bs = (const float*)t[1]; h.bmean = (float*)t[2]; h.bvar = (float*)t[3];
-    h.rmean = (float*)t[4]; h.rvar = (float*)t[5]; h.a = (const float*)t[6]; h.c = (const float*)t[7];
+    NF_GSET(h.ls, t[0]); NF_GSET(h.bs, t[1]); NF_GSET(h.bmean, t[2]); NF_GSET(h.bvar, t[3]);
+    NF_GSET(h.rmean, t[4]); NF_GSET(h.rvar, t[5]); NF_GSET(h.a, t[6]); NF_GSET(h.c, t[7]);
 }
 
 extern "C" int nf_realnvp_step_vec_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* mlp_params,
@@ -1415,11 +1424,11 @@ extern "C" int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const f
     NfMlpP p;
     nf_mlp_unpack(mlp_params, p);
     NfMlpG g;
-    for (int l = 0; l < NF_MC_NL; ++l) { g.v[l] = (float*)mlp_grads[3 * l]; g.g[l] = (float*)mlp_grads[3 * l + 1]; g.b[l] = (float*)mlp_grads[3 * l + 2]; }
-    for (int j = 0; j < NF_MC_NB; ++j) { g.gamma[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j]; g.beta[j] = (float*)mlp_grads[3 * NF_MC_NL + 2 * j + 1]; }
+    for (int l = 0; l < NF_MC_NL; ++l) { NF_GSET(g.v[l], mlp_grads[3 * l]); NF_GSET(g.g[l], mlp_grads[3 * l + 1]); NF_GSET(g.b[l], mlp_grads[3 * l + 2]); }
+    for (int j = 0; j < NF_MC_NB; ++j) { NF_GSET(g.gamma[j], mlp_grads[3 * NF_MC_NL + 2 * j]); NF_GSET(g.beta[j], mlp_grads[3 * NF_MC_NL + 2 * j + 1]); }
     NfGlowV h{};
     nf_fbn_unpack(head, h);
-    h.z = z; h.g_y = g_y; h.g_ld = g_ld; h.g_z = g_z; h.D = D; h.odd = odd ? 1 : 0; h.g_a = g_s_log_scale; h.g_c = g_s_bias;
+    h.z = z; h.g_y = g_y; h.g_ld = g_ld; h.g_z = g_z; h.D = D; h.odd = odd ? 1 : 0; NF_GSET(h.g_a, g_s_log_scale); NF_GSET(h.g_c, g_s_bias);
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t lds = nf_mc_lds_bytes(3);
     static bool attr_set = false;

@@ -108,7 +108,7 @@ print('backward: stage %.2f | recompute %.2f | layers 5..0 %s | final barrier %.
     us(64, 65), us(65, 66), ' '.join('%.2f' % us(66 + i, 67 + i) for i in range(6)), us(72, 73), us(73, 74), us(64, 74)))
 
 # ---- a whole flow of S such steps in one launch per direction (k_glow_flow_*): the stamps are those of the LAST step run ----
-S = 8
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 steps_m = []
 for i in range(S):
     a, c, k = pkg.ActNorm((2, )), pkg.InvertibleConv1x1(2), pkg.AffineCoupling((2, ), odd=bool(i & 1))
