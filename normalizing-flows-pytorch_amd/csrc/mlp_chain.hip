@@ -1245,6 +1245,7 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
 // the backward's weight-gradient slabs alternate between two regions (a workgroup may start writing step s-1 while a
 // slower one still folds step s; it cannot get further ahead than that, the first exchange of a step needs everybody).
 // ---------------------------------------------------------------------------------------------------------------
+static void nf_fbn_unpack(const void* const* t, NfGlowV& h);
 struct NfGlowFlowStep { NfMlpP p; NfMlpG g; NfGlowV h; };     // the static pointers of one step: parameters, gradient sinks
 
 extern "C" int nf_glow_flow_step_bytes(void) { return (int)sizeof(NfGlowFlowStep); }
@@ -1279,9 +1280,11 @@ extern "C" int nf_glow_flow_pack(void* dst_host, const void* const* head, const 
 #define NF_GF_REC_WORDS ((int)((sizeof(NfGlowFlowStep) + 7) / 8))
 static_assert(NF_GF_REC_WORDS <= NF_MC_THREADS, "one 8-byte word of a step record per thread");
 
+template <int HEAD>   // 1: Glow steps, 2: RealNVP steps (flow-BatchNorm head)
 __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_fwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* z0,
-                                                                 float* ys, float* ld, float* saves, float* ws, int64_t N, int D,
-                                                                 int training, float eps, float mom, float wn_eps) {
+                                                                 float* ys, float* ld, float* saves, int save_stride, float* ws,
+                                                                 int64_t N, int D, int training, float eps, float mom,
+                                                                 float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ __attribute__((aligned(16))) unsigned long long rec[2][NF_GF_REC_WORDS];
     const int64_t ND = N * D;
@@ -1296,7 +1299,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_fwd(const NfGlowFlo
         unsigned long long nxt = 0;
         if (rt && s + 1 < S) nxt = reinterpret_cast<const unsigned long long*>(steps + s + 1)[threadIdx.x];
         const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
-        nf_mc_fwd_body<1>(sm, nullptr, st.p, nullptr, saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, ws + (int64_t)s * NF_MLP_WS_FLOATS, N,
+        nf_mc_fwd_body<HEAD>(sm, nullptr, st.p, nullptr, saves + (int64_t)s * save_stride, ws + (int64_t)s * NF_MLP_WS_FLOATS, N,
                           D / 2, D, training, eps, mom, wn_eps, st.h, s == 0 ? z0 : ys + (int64_t)(s - 1) * ND, ys + (int64_t)s * ND, ld,
                           &carry);
         NF_MC_T(101);
@@ -1306,10 +1309,12 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_fwd(const NfGlowFlo
     }
 }
 
+template <int HEAD>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* z0,
                                                                  const float* ys, const float* g_y, const float* g_ld, float* gzs,
-                                                                 const float* saves, int accumulate, float* ws, float* slabs,
-                                                                 int64_t N, int D, int training, float eps, float wn_eps) {
+                                                                 const float* saves, int save_stride, int accumulate, float* ws,
+                                                                 float* slabs, int64_t N, int D, int training, float eps,
+                                                                 float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ __attribute__((aligned(16))) unsigned long long rec[2][NF_GF_REC_WORDS];
     const int64_t ND = N * D;
@@ -1324,7 +1329,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlo
         unsigned long long nxt = 0;
         if (rt && s > 0) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 1)[threadIdx.x];
         const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
-        nf_mc_bwd_body<1>(sm, nullptr, st.p, saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, nullptr, nullptr, st.g, accumulate,
+        nf_mc_bwd_body<HEAD>(sm, nullptr, st.p, saves + (int64_t)s * save_stride, nullptr, nullptr, st.g, accumulate,
                           ws + (int64_t)s * NF_MLP_WS_FLOATS, slabs + (int64_t)(s & 1) * NF_MLP_BWD_SLAB_FLOATS, N, D / 2, D, training,
                           eps, wn_eps, st.h, s == 0 ? z0 : ys + (int64_t)(s - 1) * ND, s == S - 1 ? g_y : gzs + (int64_t)(s + 1) * ND,
                           g_ld, gzs + (int64_t)s * ND, &carry);
@@ -1335,30 +1340,33 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlo
     }
 }
 
-extern "C" int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
-                                    int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
-                                    nf_stream_t stream) {
+template <int HEAD>
+static int nf_flow_launch_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, int save_stride,
+                              float* ws_zero, int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                              nf_stream_t stream) {
     if (steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr || ld == nullptr ||
         saves == nullptr || ws_zero == nullptr || !nf_glow_args_ok(N, D))
         return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t lds = nf_mc_lds_bytes(1);
-    static bool attr_set = false;
+    static bool attr_set = false;                       // one per HEAD
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (+ the static record buffers)
+        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_fwd<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_glow_flow_fwd, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
-                       (const NfGlowFlowStep*)steps_dev, S, z0, ys, ld, saves, ws_zero, N, D, training, bn_eps, bn_momentum, wn_eps);
+    hipLaunchKernelGGL(k_glow_flow_fwd<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
+                       (const NfGlowFlowStep*)steps_dev, S, z0, ys, ld, saves, save_stride, ws_zero, N, D, training, bn_eps,
+                       bn_momentum, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
-                                    const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2,
-                                    int64_t N, int D, int training, float bn_eps, float wn_eps, nf_stream_t stream) {
+template <int HEAD>
+static int nf_flow_launch_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,
+                              float* gzs, const float* saves, int save_stride, int accumulate, float* ws_zero, float* slabs2,
+                              int64_t N, int D, int training, float bn_eps, float wn_eps, nf_stream_t stream) {
     if (steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr || g_y == nullptr ||
         gzs == nullptr || saves == nullptr || ws_zero == nullptr || slabs2 == nullptr || !nf_glow_args_ok(N, D))
         return NF_E_BADARG;
@@ -1367,15 +1375,62 @@ extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z
     const size_t lds = nf_mc_lds_bytes(3);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_bwd<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_glow_flow_bwd, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
-                       (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, accumulate, ws_zero, slabs2, N, D, training,
-                       bn_eps, wn_eps);
+    hipLaunchKernelGGL(k_glow_flow_bwd<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
+                       (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, save_stride, accumulate, ws_zero, slabs2, N, D,
+                       training, bn_eps, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
+                                    int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                                    nf_stream_t stream) {
+    return nf_flow_launch_fwd<1>(steps_dev, S, z0, ys, ld, saves, NF_GLOW_FLOW_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum,
+                                 wn_eps, stream);
+}
+extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
+                                    const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2,
+                                    int64_t N, int D, int training, float bn_eps, float wn_eps, nf_stream_t stream) {
+    return nf_flow_launch_bwd<1>(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_GLOW_FLOW_SAVE_FLOATS, accumulate, ws_zero, slabs2, N, D,
+                                 training, bn_eps, wn_eps, stream);
+}
+
+// the same for a run of RealNVP steps [flow BatchNorm (batch statistics), AffineCoupling]: records packed by nf_realnvp_flow_pack
+extern "C" int nf_realnvp_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, float* g_s_log_scale,
+                                    float* g_s_bias, void* const* mlp_grads, int D, int odd, float flow_bn_eps,
+                                    float flow_bn_momentum) {
+    if (dst_host == nullptr || head == nullptr || mlp_params == nullptr || (D != 2 && D != 4)) return NF_E_BADARG;
+    NfGlowFlowStep st{};
+    nf_mlp_unpack(mlp_params, st.p);
+    nf_fbn_unpack(head, st.h);
+    st.h.D = D; st.h.odd = odd ? 1 : 0; st.h.fbn_eps = flow_bn_eps; st.h.fbn_mom = flow_bn_momentum;
+    if (mlp_grads != nullptr) {
+        for (int l = 0; l < NF_MC_NL; ++l) {
+            NF_GSET(st.g.v[l], mlp_grads[3 * l]); NF_GSET(st.g.g[l], mlp_grads[3 * l + 1]); NF_GSET(st.g.b[l], mlp_grads[3 * l + 2]);
+        }
+        for (int j = 0; j < NF_MC_NB; ++j) {
+            NF_GSET(st.g.gamma[j], mlp_grads[3 * NF_MC_NL + 2 * j]); NF_GSET(st.g.beta[j], mlp_grads[3 * NF_MC_NL + 2 * j + 1]);
+        }
+    }
+    NF_GSET(st.h.g_a, g_s_log_scale); NF_GSET(st.h.g_c, g_s_bias);
+    *reinterpret_cast<NfGlowFlowStep*>(dst_host) = st;
+    return 0;
+}
+extern "C" int nf_realnvp_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves,
+                                       float* ws_zero, int64_t N, int D, float bn_eps, float bn_momentum, float wn_eps,
+                                       nf_stream_t stream) {
+    return nf_flow_launch_fwd<2>(steps_dev, S, z0, ys, ld, saves, NF_REALNVP_SAVE_FLOATS, ws_zero, N, D, 1, bn_eps, bn_momentum, wn_eps,
+                                 stream);
+}
+extern "C" int nf_realnvp_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
+                                       const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
+                                       float* slabs2, int64_t N, int D, float bn_eps, float wn_eps, nf_stream_t stream) {
+    return nf_flow_launch_bwd<2>(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, ws_zero, slabs2, N, D,
+                                 1, bn_eps, wn_eps, stream);
 }
 
 // number of bounded spin loops that gave up since the library was loaded (0 unless a persistent grid was not co-resident:

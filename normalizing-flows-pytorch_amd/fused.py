@@ -767,6 +767,101 @@ def glow_flow_vec(z, ld, steps):
     return _GlowFlowVec.apply(z, _owned_ld(ld), odds, steps[0][2].net.training, *tensors)
 
 
+def _realnvp_step_learnables(head, mlp):
+    nl, nb = 6, 5
+    return [head[6], head[7]] + list(mlp[:3 * nl]) + [t for j in range(nb) for t in mlp[3 * nl + 5 * j:3 * nl + 5 * j + 2]]
+
+
+def _realnvp_flow_table(steps, sinks, D, device):
+    """steps: [(odd, flow_bn_eps, flow_bn_momentum, 8 head tensors, 43 MLP tensors)]; sinks: per step the 30 gradient buffers."""
+    key = ('realnvp', device, D, tuple((int(o), float(e), float(m)) for o, e, m, _, _ in steps),
+           tuple(t.data_ptr() for _, _, _, h, m in steps for t in list(h) + list(m)), tuple(t.data_ptr() for g in sinks for t in g))
+    hit = _GLOW_FLOW_TABLES.get(key)
+    if hit is not None:
+        return hit
+    nbytes = int(N.load().nf_glow_flow_step_bytes())
+    host = (ctypes.c_ubyte * (nbytes * len(steps)))()
+    for i, (odd, eps, mom, head, mlp) in enumerate(steps):
+        htab, mtab, mgt = _ptr_table(head), _ptr_table(mlp), _ptr_table(sinks[i][2:])
+        N.call('nf_realnvp_flow_pack', ctypes.addressof(host) + i * nbytes, ctypes.addressof(htab), ctypes.addressof(mtab),
+               N.ptr(sinks[i][0]), N.ptr(sinks[i][1]), ctypes.addressof(mgt), D, int(odd), float(eps), float(mom))
+    table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+    if len(_GLOW_FLOW_TABLES) > 64:
+        _GLOW_FLOW_TABLES.clear()
+    _GLOW_FLOW_TABLES[key] = table
+    return table
+
+
+class _RealNVPFlowVec(torch.autograd.Function):
+    """S consecutive [flow BatchNorm (training, affine=False), AffineCoupling] steps on (N, D) data: one launch per direction.
+    tensors: per step the 8 head tensors and the 43 MLP tensors of _RealNVPStepVec."""
+
+    @staticmethod
+    def forward(ctx, z, ld, metas, *tensors):
+        S = len(metas)
+        per = 8 + 43
+        steps = [metas[i] + (tensors[per * i:per * i + 8], tensors[per * i + 8:per * (i + 1)]) for i in range(S)]
+        from .functional import _sinks
+        sinks = [_sinks(*_realnvp_step_learnables(h, m)) for _, _, _, h, m in steps]
+        if any(g is None for g in sinks):
+            raise RuntimeError('realnvp_flow_vec needs direct gradient sinks (GradBucket) for every parameter')
+        z = z.contiguous()
+        Nrows, D = z.shape
+        dev = z.device
+        table = _realnvp_flow_table(steps, sinks, D, dev)
+        ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+        saves = torch.empty(S, N.header_constant('NF_REALNVP_SAVE_FLOATS'), dtype=torch.float32, device=dev)
+        ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        N.call('nf_realnvp_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
+               BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        ctx.save_for_backward(z, ys, saves, table)
+        ctx.meta = (S, len(tensors))
+        ctx.mark_dirty(ld)
+        return ys[S - 1], ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        S, n_tensors = ctx.meta
+        z, ys, saves, table = ctx.saved_tensors
+        Nrows, D = z.shape
+        dev = z.device
+        g_y = g_y.contiguous()
+        g_ld = None if g_ld is None else g_ld.contiguous()
+        gzs = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+        ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        N.call('nf_realnvp_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves),
+               1, N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, BN_EPS, WN_EPS, N.stream())
+        return (gzs[0], g_ld, None) + (None, ) * n_tensors
+
+
+def _flow_on(z):
+    return GLOW_FLOW is True or GLOW_FLOW == '1' or (GLOW_FLOW == 'auto' and z.shape[0] <= GLOW_FLOW_AUTO_ROWS)
+
+
+def realnvp_flow_vec_usable(z, steps):
+    """steps: [(flow BatchNorm, AffineCoupling)] -- at least two fused-step-capable steps, every parameter with a direct sink."""
+    from .functional import grad_sink
+    if not _flow_on(z) or len(steps) < 2 or len(steps) > N.header_constant('NF_GLOW_FLOW_MAX_STEPS') or not torch.is_grad_enabled():
+        return False
+    for bn, k in steps:
+        if not realnvp_step_vec_usable(z, bn, k.net):
+            return False
+        head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, k.s_log_scale, k.s_bias]
+        if any(grad_sink(t) is None for t in _realnvp_step_learnables(head, _mlp_tensors(k.net))):
+            return False
+    return True
+
+
+def realnvp_flow_vec(z, ld, steps):
+    from .functional import _owned_ld
+    tensors, metas = [], []
+    for bn, k in steps:
+        tensors += [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, k.s_log_scale, k.s_bias]
+        tensors += _mlp_tensors(k.net)
+        metas.append((int(k.odd), float(bn.eps), float(bn.momentum)))
+    return _RealNVPFlowVec.apply(z, _owned_ld(ld), tuple(metas), *tensors)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # whole Flow++ coupling on vector data: conditioner (strided read of the conditioning half) + mixture-of-logistics coupling
 # ----------------------------------------------------------------------------------------------------------------------

@@ -64,6 +64,19 @@ class Compose(nn.Module):
             j += 3
         return run if FUSED.glow_flow_vec_usable(z, run) else None
 
+    def _realnvp_run_at(self, i, z):
+        """the maximal run of fused-step-capable RealNVP steps [flow BatchNorm, AffineCoupling(MLP)] on (N, 2 | 4) data, or None"""
+        L, run, j = self.layers, [], i
+        if z.dim() != 2:
+            return None
+        while self._bn_step_at(j, z):
+            a, k = L[j], L[j + 1]
+            if not (type(k) is AffineCoupling and k.mode == N.SPLIT_1D and isinstance(k.net, MLP)):
+                break
+            run.append((a, k))
+            j += 2
+        return run if FUSED.realnvp_flow_vec_usable(z, run) else None
+
     def _bn_step_at(self, i, z):
         """[flow BatchNorm (training, affine=False), AffineCoupling | AutoregressiveTransfrom] -> fused BatchNorm head"""
         L = self.layers
@@ -93,6 +106,11 @@ class Compose(nn.Module):
         while i < n:
             if self._bn_step_at(i, z):
                 a, k = L[i], L[i + 1]
+                run = self._realnvp_run_at(i, z)
+                if run is not None:                                # the whole run of steps: one launch per direction
+                    z, log_df_dz = FUSED.realnvp_flow_vec(z, log_df_dz, run)
+                    i += 2 * len(run)
+                    continue
                 if (type(k) is AffineCoupling and k.mode == N.SPLIT_1D and isinstance(k.net, MLP)
                         and FUSED.realnvp_step_vec_usable(z, a, k.net)):
                     z, log_df_dz = FUSED.realnvp_step_vec(z, log_df_dz, a, k)        # the whole step: one launch

@@ -536,3 +536,44 @@ def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
     assert n_flow >= 2, 'the whole-flow launch was never taken'
     assert fused.N.persistent_timeouts() == 0
 
+
+@pytest.mark.parametrize('D,B,K', [(2, 256, 8), (4, 1000, 3), (2, 4096, 2)])
+def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
+    """a run of vector RealNVP steps in one launch per direction against the same steps launched one by one (bit-identical
+    step bodies): outputs, loss, flat gradients, flow-BatchNorm and BatchNorm1d buffers."""
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 1000 + B)
+    net1 = pkg.RealNVP((D, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    net2 = copy.deepcopy(net1)
+    y = (torch.randn(B, D) * 0.7).to(DEV)
+    t1, t2 = train.FlowTrainer(net1, graph=False), train.FlowTrainer(net2, graph=False)
+    calls = {'n': 0}
+    real = fused.realnvp_flow_vec
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+
+    for step in range(2):
+        monkeypatch.setattr(fused, 'GLOW_FLOW', True)
+        monkeypatch.setattr(fused, 'realnvp_flow_vec', counted)
+        t1.net.train()
+        z1, l1 = t1._forward_backward(y)
+        monkeypatch.setattr(fused, 'GLOW_FLOW', '0')
+        t2.net.train()
+        z2, l2 = t2._forward_backward(y)
+        monkeypatch.undo()
+        G.assert_close(z1, z2, 1e-6, rtol=1e-6, what='z, step %d' % step)
+        G.assert_close(l1, l2, 1e-6, rtol=1e-6, what='loss, step %d' % step)
+        G.assert_close(t1.bucket.flat, t2.bucket.flat, 1e-6 * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
+        b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
+        for name in b2:
+            G.assert_close(b1[name].float(), b2[name].float(), 1e-6, rtol=1e-6, what='buffer ' + name)
+        t1.optim.step()
+        net2.load_state_dict(net1.state_dict())
+        t2.bucket.flat_params.copy_(t1.bucket.flat_params)
+    assert calls['n'] == 2, 'the whole-flow launch was not taken'
+    assert fused.N.persistent_timeouts() == 0
+
