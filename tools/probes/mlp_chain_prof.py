@@ -153,3 +153,17 @@ print('backward: loop top -> body %.2f | stage %.2f | recompute %.2f | layers 5.
     us(105, 106)))
 print('          layer 1 detail: to exchange entry %.2f | exchange %.2f | rest %.2f' % (us(3, 40), us(40, 41), us(41, 4)))
 
+# ---- control: the single-step kernel once more, AFTER the whole-flow section (same process state) ----
+for it in range(3):
+    ws = torch.zeros(N_.header_constant('NF_MLP_WS_FLOATS'), device=dev)
+    torch.cuda.synchronize()
+    rc = lib.nf_glow_step_vec_fwd(P(z.data_ptr()), P(y.data_ptr()), P(ld.data_ptr()), htab, mtab, P(save.data_ptr()), P(ws.data_ptr()),
+                                  ctypes.c_int64(n), 2, 0, 1, F(1e-5), F(0.1), F(1e-5), st)
+    torch.cuda.synchronize()
+    assert rc == 0
+assert lib.nf_mlp_chain_prof_read(buf) == 0
+t = list(buf)
+print('--- control: single step again ---')
+print('forward : stage %.2f | x + linear0 %.2f | layers %s | tail %.2f | total %.2f' % (
+    us(0, 1), us(1, 2), ' '.join('%.2f' % us(2 + i, 3 + i) for i in range(5)), us(7, 8), us(0, 8)))
+
