@@ -46,6 +46,15 @@ extern "C" int nf_mlp_chain_prof_read(long long* host_out) {
 #define NF_G
 #endif
 #define NF_GSET(field, value) field = (decltype(field))(value)
+// gradient store of the fold: atomic += (barrier-free fold, `afold` in scope), += or = otherwise
+#define NF_MC_AFOLD_MAX_BLOCKS 2
+#define NF_MC_ACC(ptr, val)                                                            \
+    do {                                                                               \
+        auto* p_ = (ptr);                                                              \
+        const float v_ = (val);                                                        \
+        if (afold) atomicAdd((float*)p_, v_);                                          \
+        else *p_ = (accumulate ? *p_ : 0.f) + v_;                                      \
+    } while (0)
 struct NfMlpP {
     const NF_G float* v[NF_MC_NL]; const NF_G float* g[NF_MC_NL]; const NF_G float* b[NF_MC_NL];
     const NF_G float* gamma[NF_MC_NB]; const NF_G float* beta[NF_MC_NB];
@@ -977,8 +986,26 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
     NF_MC_T(72);
 
     // ---- slabs -> parameter gradients: workgroup l (mod grid) owns linear l, workgroup 0 the BatchNorm affines ------------
+    // One or two workgroups (and += semantics): NO grid barrier -- the weight-norm backward and the head's PLU algebra are
+    // linear in the summed partials, so every workgroup folds ITS OWN slab / head sums and adds the result into the gradient
+    // buffers with float atomics (C1, two workgroups: 1.84 -> 1.71 ms per step).  With more workgroups every one of them
+    // repeats the whole fold instead of a 1/G share and the shared addresses contend: measured 1.72 -> 1.88 ms at 8 and
+    // 1.90 -> 2.13 ms at 32 workgroups, so the barrier + owner fold below stays there.  The atomic order varies: gradients
+    // repeat to ~1e-7.
+    const bool afold = accumulate != 0 && gridDim.x <= NF_MC_AFOLD_MAX_BLOCKS;
     const float* head_tot = nullptr;
-    if (GLOW) {   // one more exchange carries the head sums AND, fenced on both sides, is the grid barrier in front of the fold
+    if (afold) {
+        __syncthreads();                                  // red rows of the head product / the tiles are complete
+        if (GLOW && threadIdx.x < 64) {
+            float mine = 0.f;
+#pragma unroll
+            for (int w = 0; w < NF_MC_WAVES; ++w) mine += sm[NF_MC_RED + w * 64 + threadIdx.x];
+            sm[NF_MC_TOT + threadIdx.x] = mine;           // this workgroup's part of the head sums
+        }
+        head_tot = sm + NF_MC_TOT;
+        __threadfence_block();                            // this workgroup's slab, written by all its waves
+        __syncthreads();
+    } else if (GLOW) {   // one more exchange carries the head sums AND, fenced on both sides, is the grid barrier in front of the fold
         __syncthreads();
         if (threadIdx.x == 0) __threadfence();            // release: the slabs of every wave (cumulative through the barrier)
         nf_mc_publish(sm, slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1));
@@ -993,24 +1020,25 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
     // partials (coalesced), reduces <g_Weff, v> and ||v||^2 over o by shuffles, applies the weight-norm backward.  No LDS.
     {
         const int o = threadIdx.x & 31;
-        const int G_ = gridDim.x;
+        const int G_ = afold ? 1 : (int)gridDim.x, blk = afold ? 0 : (int)blockIdx.x;
+        const float* sl_base = afold ? slabs + (size_t)blockIdx.x * NF_MC_SLAB : slabs;
         constexpr int HW = NF_MC_THREADS / 32;                       // half waves per workgroup
         if (G_ <= 2) {   // one or two workgroups: too few half waves for the column scheme -- whole layers through LDS instead,
                          // the workgroup's layers (l = blockIdx, blockIdx + G, ..) side by side: three barriers in all
             float* gW = sm + NF_MC_TILES;                            // [layer slot][1024 (i-major) + 32 bias]
             float* nd = gW + NF_MC_NL * NF_MC_SLAB_Q;                // [layer slot][3][32] per-column weight-norm backward factors
-            const int nown = (NF_MC_NL - (int)blockIdx.x + G_ - 1) / G_;
+            const int nown = (NF_MC_NL - blk + G_ - 1) / G_;
             for (int e = threadIdx.x; e < nown * NF_MC_SLAB_Q; e += NF_MC_THREADS) {
-                const int sl = e / NF_MC_SLAB_Q, ee = e - sl * NF_MC_SLAB_Q, l = blockIdx.x + sl * G_;
+                const int sl = e / NF_MC_SLAB_Q, ee = e - sl * NF_MC_SLAB_Q, l = blk + sl * G_;
                 float t4 = 0.f;
                 for (int b = 0; b < G_; ++b)
 #pragma unroll
-                    for (int q = 0; q < NF_MC_NKQ; ++q) t4 += slabs[(size_t)b * NF_MC_SLAB + l * NF_MC_SLAB_L + q * NF_MC_SLAB_Q + ee];
+                    for (int q = 0; q < NF_MC_NKQ; ++q) t4 += sl_base[(size_t)b * NF_MC_SLAB + l * NF_MC_SLAB_L + q * NF_MC_SLAB_Q + ee];
                 gW[e] = t4;
             }
             __syncthreads();
             if ((int)threadIdx.x < nown * 32) {
-                const int sl = threadIdx.x >> 5, i = threadIdx.x & 31, l = blockIdx.x + sl * G_;
+                const int sl = threadIdx.x >> 5, i = threadIdx.x & 31, l = blk + sl * G_;
                 const float* W = sm + NF_MC_W + l * 32 * NF_FP_ST;
                 float n2 = 0.f, dt = 0.f;
 #pragma unroll 8
@@ -1025,22 +1053,38 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
                 nd[sl * 96 + 64 + i] = dt / den;
             }
             __syncthreads();
-            for (int e = threadIdx.x; e < nown * NF_MC_SLAB_Q; e += NF_MC_THREADS) {
-                const int sl = e / NF_MC_SLAB_Q, ee = e - sl * NF_MC_SLAB_Q, l = blockIdx.x + sl * G_;
+            for (int e = threadIdx.x; afold && e < nown * NF_MC_SLAB_Q; e += NF_MC_THREADS) {
+                // atomic fold: consecutive threads -> consecutive addresses of the gradient (an atomic instruction that touches
+                // 64 cache lines instead of 4 costs sixteen times as much: the i-major order below it took 22 us per launch)
+                const int sl = e / NF_MC_SLAB_Q, ee = e - sl * NF_MC_SLAB_Q, l = blk + sl * G_;
+                const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
+                if (ee >= 1024) {
+                    const int oo = ee - 1024;
+                    if (oo < O) atomicAdd((float*)(gr.b[l] + oo), gW[e]);
+                    continue;
+                }
+                if (ee >= O * I) continue;
+                const int oo = ee / I, i = ee - oo * I;
+                const float gv = gW[sl * NF_MC_SLAB_Q + i * 32 + oo] * nd[sl * 96 + i] -
+                                 sm[NF_MC_W + l * 32 * NF_FP_ST + oo * NF_FP_ST + i] * nd[sl * 96 + 32 + i];
+                atomicAdd((float*)(gr.v[l] + ee), gv);
+                if (ee < I) atomicAdd((float*)(gr.g[l] + ee), nd[sl * 96 + 64 + ee]);
+            }
+            for (int e = threadIdx.x; !afold && e < nown * NF_MC_SLAB_Q; e += NF_MC_THREADS) {
+                const int sl = e / NF_MC_SLAB_Q, ee = e - sl * NF_MC_SLAB_Q, l = blk + sl * G_;
                 const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
                 if (ee >= 1024) {                                    // bias
                     const int oo = ee - 1024;
-                    if (oo < O) gr.b[l][oo] = (accumulate ? gr.b[l][oo] : 0.f) + gW[e];
+                    if (oo < O) NF_MC_ACC(gr.b[l] + oo, gW[e]);
                     continue;
                 }
                 const int i = ee >> 5, oo = ee & 31;
                 if (i >= I) continue;
                 if (oo < O) {
                     const float gv = gW[e] * nd[sl * 96 + i] - sm[NF_MC_W + l * 32 * NF_FP_ST + oo * NF_FP_ST + i] * nd[sl * 96 + 32 + i];
-                    float* dst = gr.v[l] + oo * I + i;
-                    *dst = (accumulate ? *dst : 0.f) + gv;
+                    NF_MC_ACC(gr.v[l] + oo * I + i, gv);
                 }
-                if (oo == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + nd[sl * 96 + 64 + i];
+                if (oo == 0) NF_MC_ACC(gr.g[l] + i, nd[sl * 96 + 64 + i]);
             }
         }
         for (int u = blockIdx.x * HW + (threadIdx.x >> 5); G_ > 2 && u < NF_MC_NL * 33; u += G_ * HW) {
@@ -1086,12 +1130,12 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
             if (o == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + dt / den;
         }
     }
-    if (GLOW && blockIdx.x == gridDim.x - 1 && threadIdx.x == NF_MC_THREADS - 1) {   // ActNorm, PLU, coupling scalars
+    if (GLOW && (afold || blockIdx.x == gridDim.x - 1) && threadIdx.x == NF_MC_THREADS - 1) {   // ActNorm, PLU, coupling scalars
         const float* hs = head_tot;
         const int D = h.D;
         const float sum_gld = hs[28];
-        h.g_a[0] = (accumulate ? h.g_a[0] : 0.f) + hs[26] + hs[27];                  // d/d s_log_scale: sum g_s tanh(s_raw)
-        h.g_c[0] = (accumulate ? h.g_c[0] : 0.f) + hs[24] + hs[25];                  // d/d s_bias
+        NF_MC_ACC(h.g_a, hs[26] + hs[27]);                                           // d/d s_log_scale: sum g_s tanh(s_raw)
+        NF_MC_ACC(h.g_c, hs[24] + hs[25]);                                           // d/d s_bias
         if (!FBN) {
         const float* Lp = sm + NF_MC_HEAD + 32;                  // [4][4] each, staged at kernel start
         const float* Up = sm + NF_MC_HEAD + 48;
@@ -1099,8 +1143,8 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
         float A[4][4];
         for (int r = 0; r < D; ++r) {
             const float es = sm[NF_MC_HEAD + 16 + r];
-            h.g_bs[r] = (accumulate ? h.g_bs[r] : 0.f) - hs[20 + r] / es;            // modules.py:246
-            h.g_ls[r] = (accumulate ? h.g_ls[r] : 0.f) - hs[16 + r] - sum_gld;       // pixels = 1
+            NF_MC_ACC(h.g_bs + r, -hs[20 + r] / es);                                 // modules.py:246
+            NF_MC_ACC(h.g_ls + r, -hs[16 + r] - sum_gld);                            // pixels = 1
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -1123,9 +1167,9 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
                 }
                 if (r < D && c < D) {
                     const int e = r * D + c;
-                    h.g_L[e] = (accumulate ? h.g_L[e] : 0.f) + gl * h.Lm[e];
-                    h.g_U[e] = (accumulate ? h.g_U[e] : 0.f) + gu * h.Um[e];
-                    if (r == c) h.g_log_s[r] = (accumulate ? h.g_log_s[r] : 0.f) + gu * Up[r * 4 + r] + sum_gld;
+                    NF_MC_ACC(h.g_L + e, gl * h.Lm[e]);
+                    NF_MC_ACC(h.g_U + e, gu * h.Um[e]);
+                    if (r == c) NF_MC_ACC(h.g_log_s + r, gu * Up[r * 4 + r] + sum_gld);
                 }
             }
         }

@@ -567,7 +567,8 @@ def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
         monkeypatch.undo()
         G.assert_close(z1, z2, 1e-6, rtol=1e-6, what='z, step %d' % step)
         G.assert_close(l1, l2, 1e-6, rtol=1e-6, what='loss, step %d' % step)
-        G.assert_close(t1.bucket.flat, t2.bucket.flat, 1e-6 * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
+        # (same step bodies; with <= 32 workgroups the fold adds by float atomics, whose order is not fixed)
+        G.assert_close(t1.bucket.flat, t2.bucket.flat, 1e-5 * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
         b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
         for name in b2:
             G.assert_close(b1[name].float(), b2[name].float(), 1e-6, rtol=1e-6, what='buffer ' + name)
