@@ -1328,9 +1328,10 @@ template <int HEAD>   // 1: Glow steps, 2: RealNVP steps (flow-BatchNorm head)
 __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_fwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* z0,
                                                                  float* ys, float* ld, float* saves, int save_stride, float* ws,
                                                                  int64_t N, int D, int training, float eps, float mom,
-                                                                 float wn_eps) {
+                                                                 float wn_eps, int rec_off) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ __attribute__((aligned(16))) unsigned long long rec[2][NF_GF_REC_WORDS];
+    // the records sit BEHIND the step body's LDS (a static array in front of it would shift every tile of the body)
+    unsigned long long (*rec)[NF_GF_REC_WORDS] = reinterpret_cast<unsigned long long (*)[NF_GF_REC_WORDS]>(sm + rec_off);
     const int64_t ND = N * D;
     const bool rt = (int)threadIdx.x < NF_GF_REC_WORDS;
     if (rt) rec[0][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps)[threadIdx.x];
@@ -1358,9 +1359,9 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlo
                                                                  const float* ys, const float* g_y, const float* g_ld, float* gzs,
                                                                  const float* saves, int save_stride, int accumulate, float* ws,
                                                                  float* slabs, int64_t N, int D, int training, float eps,
-                                                                 float wn_eps) {
+                                                                 float wn_eps, int rec_off) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ __attribute__((aligned(16))) unsigned long long rec[2][NF_GF_REC_WORDS];
+    unsigned long long (*rec)[NF_GF_REC_WORDS] = reinterpret_cast<unsigned long long (*)[NF_GF_REC_WORDS]>(sm + rec_off);
     const int64_t ND = N * D;
     const bool rt = (int)threadIdx.x < NF_GF_REC_WORDS;
     if (rt) rec[(S - 1) & 1][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps + S - 1)[threadIdx.x];
@@ -1393,7 +1394,7 @@ static int nf_flow_launch_fwd(const void* steps_dev, int S, const float* z0, flo
         return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
-    const size_t lds = nf_mc_lds_bytes(1);
+    const size_t body_lds = nf_mc_lds_bytes(1), lds = body_lds + 2 * NF_GF_REC_WORDS * 8;
     static bool attr_set = false;                       // one per HEAD
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_fwd<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1402,7 +1403,7 @@ static int nf_flow_launch_fwd(const void* steps_dev, int S, const float* z0, flo
     }
     hipLaunchKernelGGL(k_glow_flow_fwd<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
                        (const NfGlowFlowStep*)steps_dev, S, z0, ys, ld, saves, save_stride, ws_zero, N, D, training, bn_eps,
-                       bn_momentum, wn_eps);
+                       bn_momentum, wn_eps, (int)(body_lds / sizeof(float)));
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -1416,7 +1417,7 @@ static int nf_flow_launch_bwd(const void* steps_dev, int S, const float* z0, con
         return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
-    const size_t lds = nf_mc_lds_bytes(3);
+    const size_t body_lds = nf_mc_lds_bytes(3), lds = body_lds + 2 * NF_GF_REC_WORDS * 8;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_bwd<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1425,7 +1426,7 @@ static int nf_flow_launch_bwd(const void* steps_dev, int S, const float* z0, con
     }
     hipLaunchKernelGGL(k_glow_flow_bwd<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
                        (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, save_stride, accumulate, ws_zero, slabs2, N, D,
-                       training, bn_eps, wn_eps);
+                       training, bn_eps, wn_eps, (int)(body_lds / sizeof(float)));
     NF_CHECK_LAUNCH();
     return 0;
 }
