@@ -527,7 +527,7 @@ int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const float* g_ld,
 #define NF_MAF_MAX_BLOCKS 128
 #define NF_MAF_MAX_ROWS 16384
 #define NF_MAF_SAVE_FLOATS 392
-#define NF_MAF_WS_FLOATS (4 * 128 * 128 * 2 + 64)
+#define NF_MAF_WS_FLOATS ((4 * 128 * 128 + 4 * 8 * 128) * 2 + 64)
 #define NF_MAF_BWD_SLAB_FLOATS (128 * 2 * 4 * 2 * 1056)
 int nf_maf_step_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* made_params,
                     float* save_stats, float* ws_zero, int64_t N, int D, float flow_bn_eps, float flow_bn_momentum,

@@ -90,6 +90,14 @@ __device__ __forceinline__ void nf_md_publish(float* sm, unsigned long long* slo
     }
 }
 #define NF_MD_POLL 16
+// Two-level exchange for grids of more than NF_MD_2LVL workgroups.  All-to-all polling moves G x G x 1 KB per sweep (16.8 MB at
+// 128 workgroups: bandwidth-, not latency-bound, ~2.5x the cost at 32).  Instead the first workgroup of every group of
+// NF_MD_GRP polls its group's slots, publishes the group total, and everybody polls the <= 8 group totals: G x (16 + 8) KB
+// per sweep, two hops.  Fixed summation order (members in order, then groups in order): still deterministic.
+#define NF_MD_GRP 16
+#define NF_MD_2LVL 32
+#define NF_MD_MAX_GROUPS (NF_MAF_MAX_BLOCKS / NF_MD_GRP)
+#define NF_MD_ROUNDS 4
 // thread t owns value index i = t % 128 of the workgroups b = t / 128 (mod 4): up to 16 polls in flight per trip, partial sums
 // in workgroup order, then the four groups are added in order -- deterministic, and no gather buffer in LDS
 __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long long* slots, int round, unsigned gen) {
@@ -102,6 +110,70 @@ __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long l
     }
     const int i = threadIdx.x & (NF_MD_XW - 1), grp = threadIdx.x >> 7;
     const unsigned long long* rs = slots + (size_t)round * NF_MAF_MAX_BLOCKS * NF_MD_XW + i;
+    if (G > NF_MD_2LVL) {
+        unsigned long long* gs = slots + (size_t)NF_MD_ROUNDS * NF_MAF_MAX_BLOCKS * NF_MD_XW +
+                                 (size_t)round * NF_MD_MAX_GROUPS * NF_MD_XW + i;
+        const int j = blockIdx.x / NF_MD_GRP, ngroups = (G + NF_MD_GRP - 1) / NF_MD_GRP;
+        if (blockIdx.x % NF_MD_GRP == 0) {               // group leader (block-uniform): members j*GRP + grp + 4k
+            const int b_lo = j * NF_MD_GRP, b_hi = min(G, b_lo + NF_MD_GRP);
+            unsigned long long v[NF_MD_GRP / 4];
+            unsigned spins = 0;
+            bool ok;
+            do {
+                ok = true;
+#pragma unroll
+                for (int k = 0; k < NF_MD_GRP / 4; ++k) {
+                    const int b = b_lo + grp + 4 * k;
+                    v[k] = __hip_atomic_load(rs + (size_t)(b < b_hi ? b : b_lo) * NF_MD_XW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < NF_MD_GRP / 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
+                if (ok) break;
+                if (++spins > (1u << 22)) { atomicAdd(&nf_md_timeouts, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            } while (true);
+            float a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NF_MD_GRP / 4; ++k)
+                if (b_lo + grp + 4 * k < b_hi) a1 += __uint_as_float((unsigned)v[k]);
+            sm[NF_MD_PART + threadIdx.x] = a1;
+            __syncthreads();
+            if (threadIdx.x < NF_MD_XW) {
+                const float gt = (sm[NF_MD_PART + threadIdx.x] + sm[NF_MD_PART + NF_MD_XW + threadIdx.x]) +
+                                 (sm[NF_MD_PART + 2 * NF_MD_XW + threadIdx.x] + sm[NF_MD_PART + 3 * NF_MD_XW + threadIdx.x]);
+                const unsigned long long pk = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(gt);
+                __hip_atomic_store(gs + (size_t)j * NF_MD_XW, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                             // PART is reused below
+        }
+        unsigned long long v[NF_MD_MAX_GROUPS / 4];
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < NF_MD_MAX_GROUPS / 4; ++k) {
+                const int q = grp + 4 * k;
+                v[k] = __hip_atomic_load(gs + (size_t)(q < ngroups ? q : 0) * NF_MD_XW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < NF_MD_MAX_GROUPS / 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
+            if (ok) break;
+            if (++spins > (1u << 22)) { atomicAdd(&nf_md_timeouts, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+        float a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NF_MD_MAX_GROUPS / 4; ++k)
+            if (grp + 4 * k < ngroups) a2 += __uint_as_float((unsigned)v[k]);
+        sm[NF_MD_PART + threadIdx.x] = a2;
+        __syncthreads();
+        if (threadIdx.x < NF_MD_XW)
+            tot[threadIdx.x] = (sm[NF_MD_PART + threadIdx.x] + sm[NF_MD_PART + NF_MD_XW + threadIdx.x]) +
+                               (sm[NF_MD_PART + 2 * NF_MD_XW + threadIdx.x] + sm[NF_MD_PART + 3 * NF_MD_XW + threadIdx.x]);
+        __syncthreads();
+        return tot;
+    }
     float acc = 0.f;
     for (int b0 = grp; b0 < G; b0 += 4 * NF_MD_POLL) {
         unsigned long long v[NF_MD_POLL];
@@ -380,7 +452,8 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
 #define NF_MD_SLAB_L (NF_MD_NKQ * NF_MD_SLAB_Q)
 #define NF_MD_SLAB (2 * NF_MD_NL * NF_MD_SLAB_L)
 static_assert(NF_MD_SLAB * NF_MAF_MAX_BLOCKS == NF_MAF_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
-static_assert(4 * NF_MAF_MAX_BLOCKS * NF_MD_XW * 2 + 64 == NF_MAF_WS_FLOATS, "exchange workspace size in include/nfhip.h");
+static_assert((NF_MD_ROUNDS * NF_MAF_MAX_BLOCKS * NF_MD_XW + NF_MD_ROUNDS * NF_MD_MAX_GROUPS * NF_MD_XW) * 2 + 64 == NF_MAF_WS_FLOATS,
+              "exchange workspace size in include/nfhip.h");
 static_assert(NF_MAF_MAX_BLOCKS * NF_MAF_ROWS_PER_BLOCK == NF_MAF_MAX_ROWS, "geometry in include/nfhip.h");
 
 // wave w's share of g_W[n][L] and g_b[n][L]: output block (w & 1, (w >> 1) & 1) over the rows of waves 4 (w >> 2) .. + 3
