@@ -71,9 +71,11 @@ def event_time_ms(fn, reps, stream):
     return start.elapsed_time(stop) / reps
 
 
-def graph_time_us(fn, dev, per_graph=50, replays=10):
+def graph_time_us(fn, dev, per_graph=50, replays=10, reset=None):
     """average duration of one launch of `fn` inside a hipGraph of `per_graph` back-to-back (dependent) launches: no host
-    launch cost in the number, HIP events recorded on the stream the graph is replayed on."""
+    launch cost in the number, HIP events recorded on the stream the graph is replayed on.  reset(): re-zeroes the exchange
+    workspaces of persistent kernels after the untimed warm replay (a timed replay must not find the previous replay's
+    generation stamps in the slots: its exchanges would not wait for anybody)."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -87,6 +89,10 @@ def graph_time_us(fn, dev, per_graph=50, replays=10):
             fn()
     g.replay()
     torch.cuda.synchronize()
+    if reset is not None:
+        assert replays == 1, 'one timed replay per set of zeroed workspaces'
+        reset()
+        torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record(stream)
@@ -152,6 +158,58 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         else:
             N.call('nf_realnvp_step_vec_fwd', z.data_ptr(), y.data_ptr(), ld.data_ptr(), ctypes.addressof(htab),
                    ctypes.addressof(mtab), save.data_ptr(), ws0.data_ptr(), B, D, 0, 1.0e-5, 0.1, 1.0e-5, 0.1, 1.0e-5, st)
+        S = int(cfg['layers'])
+        if F._flow_on(z) and S >= 2:
+            # small batches train through the whole-flow launch (all S steps in one kernel per direction): that is the launch
+            # the timed region is made of, so that is the one measured here
+            steps, sinks, keep = [], [], []
+            for i in range(S):
+                ki = pkg.AffineCoupling((D, ), odd=bool(i & 1)).to(dev).train()
+                mi = F._mlp_tensors(ki.net)
+                if glow:
+                    ai, ci = pkg.ActNorm((D, )).to(dev), pkg.InvertibleConv1x1(D).to(dev)
+                    hi = [ai.log_scale, ai.bias, ci.P, ci.L, ci.U, ci.L_mask, ci.U_mask, ci.sign_s, ci.log_s, ki.s_log_scale, ki.s_bias]
+                    steps.append((int(i & 1), hi, mi))
+                    learn = F._glow_step_learnables(hi, mi)
+                else:
+                    bi = pkg.BatchNorm((D, ), affine=False).to(dev).train()
+                    hi = [bi.log_gamma, bi.beta, bi.batch_mean, bi.batch_var, bi.running_mean, bi.running_var, ki.s_log_scale, ki.s_bias]
+                    steps.append((int(i & 1), 1.0e-5, 0.1, hi, mi))
+                    learn = F._realnvp_step_learnables(hi, mi)
+                sinks.append([torch.zeros_like(t) for t in learn])
+                keep.append((ki, hi))
+            table = (F._glow_flow_table if glow else F._realnvp_flow_table)(steps, sinks, D, dev)
+            ys, gzs = torch.empty(S, B, D, device=dev), torch.empty(S, B, D, device=dev)
+            saves = torch.empty(S, N.header_constant('NF_REALNVP_SAVE_FLOATS'), device=dev)
+            ws1 = torch.zeros(S * nws, device=dev)
+            slabs2 = F._glow_flow_slabs(dev)
+            if glow:
+                N.call('nf_glow_flow_vec_fwd', table.data_ptr(), S, z.data_ptr(), ys.data_ptr(), ld.data_ptr(), saves.data_ptr(),
+                       ws1.data_ptr(), B, D, 1, 1.0e-5, 0.1, 1.0e-5, st)
+            else:
+                N.call('nf_realnvp_flow_vec_fwd', table.data_ptr(), S, z.data_ptr(), ys.data_ptr(), ld.data_ptr(), saves.data_ptr(),
+                       ws1.data_ptr(), B, D, 1.0e-5, 0.1, 1.0e-5, st)
+            wsf = torch.zeros(10, S * nws, device=dev)
+            itf = [0]
+
+            def fn_flow():
+                ws = wsf[itf[0] % 10]
+                itf[0] += 1
+                if glow:
+                    N.call('nf_glow_flow_vec_bwd', table.data_ptr(), S, z.data_ptr(), ys.data_ptr(), gy.data_ptr(), None,
+                           gzs.data_ptr(), saves.data_ptr(), 1, ws.data_ptr(), slabs2.data_ptr(), B, D, 1, 1.0e-5, 1.0e-5, N.stream())
+                else:
+                    N.call('nf_realnvp_flow_vec_bwd', table.data_ptr(), S, z.data_ptr(), ys.data_ptr(), gy.data_ptr(), None,
+                           gzs.data_ptr(), saves.data_ptr(), 1, ws.data_ptr(), slabs2.data_ptr(), B, D, 1.0e-5, 1.0e-5, N.stream())
+            us = graph_time_us(fn_flow, dev, per_graph=10, replays=1, reset=wsf.zero_)
+            flop = S * 17 * 2 * 32 * 32 * B
+            tf = flop / (us * 1e-6) / 1e12
+            name = 'k_glow_flow_bwd<%d> (backward of all %d %s flow steps, one launch)' % (1 if glow else 2, S, 'Glow' if glow else 'RealNVP')
+            return {'bound': 'mfma', 'kernel': name, 'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': None, 'flop_per_launch': int(flop),
+                    'bytes_per_launch': int(S * B * (3 * D + 1) * 4), 'us_per_launch': round(us, 3),
+                    'note': 'neither MFMA- nor HBM-bound at this batch: per step six grid-wide exchanges and single-tile issue latency '
+                            'serialise the launch (DESIGN.md sections 2 and 3.11)'}
         slabs = F._mlp_slabs(dev)
         wss = torch.zeros(50, nws, device=dev)                  # a fresh zero workspace per launch inside the timing graph
         it = [0]
@@ -167,7 +225,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                 N.call('nf_realnvp_step_vec_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
                        ctypes.addressof(mtab), save.data_ptr(), dh[0].data_ptr(), dh[1].data_ptr(), ctypes.addressof(mg), 1,
                        ws.data_ptr(), slabs.data_ptr(), B, D, 0, 1.0e-5, 1.0e-5, N.stream())
-        us = graph_time_us(fn, dev, per_graph=50, replays=1)     # 50 launches = 50 distinct zero workspaces, one replay
+        us = graph_time_us(fn, dev, per_graph=50, replays=1, reset=wss.zero_)   # 50 launches = 50 distinct zero workspaces
         flop = 17 * 2 * 32 * 32 * B                              # 5 recomputed + 6 data-gradient + 6 weight-gradient 32x32 products
         tf = flop / (us * 1e-6) / 1e12
         name = 'k_mlp_chain_bwd<%d> (whole %s flow step, one launch)' % (1 if glow else 2, 'Glow' if glow else 'RealNVP')
@@ -210,7 +268,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
             N.call('nf_maf_step_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
                    ctypes.addressof(mtab), save.data_ptr(), ctypes.addressof(gtab), ga.data_ptr(), gc.data_ptr(), ws.data_ptr(),
                    slabs.data_ptr(), B, D, N.stream())
-        us = graph_time_us(fn, dev, per_graph=25, replays=1)
+        us = graph_time_us(fn, dev, per_graph=25, replays=1, reset=wss.zero_)
         mac = 2 * 3 * (32 * D + 1024 + 1024 + 32 * D)           # two nets x (recompute + data + weight gradients)
         flop = 2 * mac * B
         tf = flop / (us * 1e-6) / 1e12
