@@ -137,6 +137,26 @@ int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, cons
                           const float* U_mask, const float* sign_s, const float* log_s, const float* g_ld, float* g_L,
                           float* g_U, float* g_log_s, int accumulate, int C, int64_t B, int pixels, nf_stream_t stream);
 
+/* the same for up to NF_PLU_MAX_LAYERS layers per launch, one workgroup per layer (an image Glow has 129 of these single-
+ * workgroup, latency-bound launches per direction).  forward uses P .. log_s, W, C; backward additionally g_W, g_ld (nullable),
+ * g_L, g_U, g_log_s, accumulate, B, pixels.                                                                               */
+#define NF_PLU_MAX_LAYERS 24
+typedef struct nf_plu_desc {
+    const float* P; const float* L; const float* U; const float* L_mask; const float* U_mask; const float* sign_s;
+    const float* log_s;
+    float* W;
+    const float* g_W;
+    const float* g_ld;
+    float* g_L; float* g_U; float* g_log_s;
+    int64_t B;
+    int C;
+    int accumulate;
+    float pixels;
+    int reserved;
+} nf_plu_desc;
+int nf_invconv_weight_fwd_multi(const nf_plu_desc* descs, int n_layers, nf_stream_t stream);
+int nf_invconv_weight_bwd_multi(const nf_plu_desc* descs, int n_layers, nf_stream_t stream);
+
 /* ---- fused head of a Glow flow step for C <= 4 (2-D data, 1..4 channel images) -------------------------------------
  * forward : h = W ((z - bias) / exp(log_scale)) per pixel with W = P L' U' assembled in-kernel; z1c = the contiguous
  *           conditioning half of h (what the coupling's conditioner reads); ld[b] += pixels*(sum log_s - sum

@@ -154,12 +154,10 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad_small(const float* _
 //   g_L = (P^T g_W U'^T) o L_mask,  g_U = (L'^T P^T g_W) o U_mask,
 //   g_log_s[i] = (L'^T P^T g_W)[i][i] sign_s[i] exp(log_s[i]) + pixels * sum_b g_ld[b]      (appendix B3)
 #define NF_PLU_MAXC 64
-__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd(const float* __restrict__ Pm, const float* __restrict__ L,
-                                                                 const float* __restrict__ U, const float* __restrict__ Lmask,
-                                                                 const float* __restrict__ Umask,
-                                                                 const float* __restrict__ sign_s,
-                                                                 const float* __restrict__ log_s, float* __restrict__ W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void nf_plu_weight_fwd_body(float* sm, const float* __restrict__ Pm, const float* __restrict__ L,
+                                                       const float* __restrict__ U, const float* __restrict__ Lmask,
+                                                       const float* __restrict__ Umask, const float* __restrict__ sign_s,
+                                                       const float* __restrict__ log_s, float* __restrict__ W, int C) {
     float* Lp = sm;
     float* Up = sm + C * C;
     float* T = sm + 2 * C * C;
@@ -186,18 +184,23 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd(const float* __
         W[e] = acc;
     }
 }
-
-__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __restrict__ gW, const float* __restrict__ Pm,
-                                                                 const float* __restrict__ L, const float* __restrict__ U,
-                                                                 const float* __restrict__ Lmask,
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd(const float* __restrict__ Pm, const float* __restrict__ L,
+                                                                 const float* __restrict__ U, const float* __restrict__ Lmask,
                                                                  const float* __restrict__ Umask,
                                                                  const float* __restrict__ sign_s,
-                                                                 const float* __restrict__ log_s, const float* __restrict__ gld,
-                                                                 float* __restrict__ gL, float* __restrict__ gU,
-                                                                 float* __restrict__ glog_s, int accumulate, int C, int64_t B, float pixels) {
+                                                                 const float* __restrict__ log_s, float* __restrict__ W, int C) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ float scratch[NF_BLOCK / NF_WAVE];
-    __shared__ float sum_gld;
+    nf_plu_weight_fwd_body(sm, Pm, L, U, Lmask, Umask, sign_s, log_s, W, C);
+}
+
+__device__ __forceinline__ void nf_plu_weight_bwd_body(float* sm, float* scratch, float* sum_gld_p, const float* __restrict__ gW,
+                                                       const float* __restrict__ Pm, const float* __restrict__ L,
+                                                       const float* __restrict__ U, const float* __restrict__ Lmask,
+                                                       const float* __restrict__ Umask, const float* __restrict__ sign_s,
+                                                       const float* __restrict__ log_s, const float* __restrict__ gld,
+                                                       float* __restrict__ gL, float* __restrict__ gU, float* __restrict__ glog_s,
+                                                       int accumulate, int C, int64_t B, float pixels) {
+    float& sum_gld = *sum_gld_p;
     float* Lp = sm;
     float* Up = sm + C * C;
     float* A = sm + 2 * C * C;                                   // P^T g_W
@@ -234,6 +237,37 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __
         gU[e] = (accumulate ? gU[e] : 0.f) + gu * Umask[e];
         if (r == c) glog_s[r] = (accumulate ? glog_s[r] : 0.f) + gu * sign_s[r] * expf(log_s[r]) + pixels * sum_gld;
     }
+}
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __restrict__ gW, const float* __restrict__ Pm,
+                                                                 const float* __restrict__ L, const float* __restrict__ U,
+                                                                 const float* __restrict__ Lmask,
+                                                                 const float* __restrict__ Umask,
+                                                                 const float* __restrict__ sign_s,
+                                                                 const float* __restrict__ log_s, const float* __restrict__ gld,
+                                                                 float* __restrict__ gL, float* __restrict__ gU,
+                                                                 float* __restrict__ glog_s, int accumulate, int C, int64_t B, float pixels) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    __shared__ float sum_gld;
+    nf_plu_weight_bwd_body(sm, scratch, &sum_gld, gW, Pm, L, U, Lmask, Umask, sign_s, log_s, gld, gL, gU, glog_s, accumulate, C, B,
+                           pixels);
+}
+
+// ---- every invertible 1x1 convolution of a model in a few launches: workgroup = layer (an image Glow has 129 of them, and a
+//      single-workgroup launch of three C x C x C products is 14 + 24 us of pure latency each) -------------------------------------
+struct NfPluArgs { nf_plu_desc d[NF_PLU_MAX_LAYERS]; };
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd_multi(NfPluArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const nf_plu_desc& d = args.d[blockIdx.x];
+    nf_plu_weight_fwd_body(sm, d.P, d.L, d.U, d.L_mask, d.U_mask, d.sign_s, d.log_s, d.W, d.C);
+}
+__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd_multi(NfPluArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    __shared__ float sum_gld;
+    const nf_plu_desc& d = args.d[blockIdx.x];
+    nf_plu_weight_bwd_body(sm, scratch, &sum_gld, d.g_W, d.P, d.L, d.U, d.L_mask, d.U_mask, d.sign_s, d.log_s, d.g_ld, d.g_L, d.g_U,
+                           d.g_log_s, d.accumulate, d.C, d.B, d.pixels);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -339,3 +373,46 @@ extern "C" int nf_invconv_weight_bwd(const float* g_W, const float* P, const flo
     NF_CHECK_LAUNCH();
     return 0;
 }
+
+static int nf_plu_multi_check(const nf_plu_desc* descs, int n, int& cmax) {
+    if (descs == nullptr || n < 1 || n > NF_PLU_MAX_LAYERS) return NF_E_BADARG;
+    cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (descs[i].C <= 0) return NF_E_BADARG;
+        if (descs[i].C > NF_PLU_MAXC) return NF_E_UNSUPPORTED;
+        if (descs[i].C > cmax) cmax = descs[i].C;
+    }
+    return 0;
+}
+
+extern "C" int nf_invconv_weight_fwd_multi(const nf_plu_desc* descs, int n_layers, nf_stream_t stream) {
+    int cmax;
+    const int rc = nf_plu_multi_check(descs, n_layers, cmax);
+    if (rc) return rc;
+    NfPluArgs args;
+    for (int i = 0; i < n_layers; ++i) args.d[i] = descs[i];
+    hipLaunchKernelGGL(k_invconv_weight_fwd_multi, dim3((unsigned)n_layers), dim3(NF_BLOCK), (size_t)3 * cmax * cmax * sizeof(float),
+                       (hipStream_t)stream, args);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_invconv_weight_bwd_multi(const nf_plu_desc* descs, int n_layers, nf_stream_t stream) {
+    int cmax;
+    const int rc = nf_plu_multi_check(descs, n_layers, cmax);
+    if (rc) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_invconv_weight_bwd_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           5 * NF_PLU_MAXC * NF_PLU_MAXC * (int)sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    NfPluArgs args;
+    for (int i = 0; i < n_layers; ++i) args.d[i] = descs[i];
+    hipLaunchKernelGGL(k_invconv_weight_bwd_multi, dim3((unsigned)n_layers), dim3(NF_BLOCK), (size_t)5 * cmax * cmax * sizeof(float),
+                       (hipStream_t)stream, args);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+

@@ -407,6 +407,49 @@ class _InvConvPLU(torch.autograd.Function):
 PLU_MAX_C = 64
 
 
+class PluHolder:
+    """what the per-layer applications leave for the batched PLU backward of the same pass: their incoming log-det gradient
+    (g_log_s has a pixels * sum_b g_ld term, modules.py:480) and their batch / pixel counts."""
+
+    def __init__(self, n):
+        self.g_ld = [None] * n
+        self.meta = [None] * n
+
+
+class _InvConvApplyW(torch.autograd.Function):
+    """InvertibleConv1x1.forward with the weight W = P L' U' computed elsewhere (fused.plu_weights_all: every layer of the model
+    in a few launches): per-pixel mat-vec + log-det forward, transposed mat-vec + weight gradient backward."""
+
+    @staticmethod
+    def forward(ctx, z, ld, W, log_s, holder, idx):
+        B, C, Px = _bcp(z)
+        y = torch.empty_like(z)
+        N.call('nf_invconv_apply', N.ptr(z), N.ptr(W), 0, N.ptr(y), N.ptr(ld), N.ptr(log_s), 1.0, B, C, Px, N.stream())
+        ctx.save_for_backward(z, W)
+        ctx.holder, ctx.idx = holder, idx
+        holder.meta[idx] = (B, Px)
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, W = ctx.saved_tensors
+        B, C, Px = _bcp(z)
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_z = None
+        if ctx.needs_input_grad[0]:
+            g_z = torch.empty_like(z)
+            N.call('nf_invconv_apply', N.ptr(g_y), N.ptr(W), 1, N.ptr(g_z), None, None, 0.0, B, C, Px, N.stream())
+        g_W = WS.zeros(W.numel(), W.device).view_as(W)
+        N.call('nf_invconv_wgrad', N.ptr(g_y), N.ptr(z), N.ptr(g_W), B, C, Px, N.stream())
+        ctx.holder.g_ld[ctx.idx] = g_ld
+        return g_z, g_ld, g_W, None, None, None
+
+
+def invconv_apply_w(z, ld, W, log_s, holder, idx):
+    return _InvConvApplyW.apply(_contig(z), _owned_ld(ld), W, log_s, holder, idx)
+
+
 def invconv_plu(z, ld, P, L, U, L_mask, U_mask, sign_s, log_s):
     """InvertibleConv1x1.forward from its stored PLU parameters (flows/modules.py:470-482)."""
     return _InvConvPLU.apply(_contig(z), _owned_ld(ld), P, L, U, L_mask, U_mask, sign_s, log_s)

@@ -1193,3 +1193,81 @@ def weight_norm_all(wn_modules):
     outs = _WeightNormMulti.apply(eps, *tensors)
     for m, w in zip(wn_modules, outs):
         m._w_eff = w
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the PLU weight W = P L' U' of every invertible 1x1 convolution of a model, and its autograd, in batched launches
+# ----------------------------------------------------------------------------------------------------------------------
+class PluDesc(ctypes.Structure):
+    _fields_ = [(f, ctypes.c_void_p) for f in ('P', 'L', 'U', 'L_mask', 'U_mask', 'sign_s', 'log_s', 'W', 'g_W', 'g_ld', 'g_L',
+                                                'g_U', 'g_log_s')] + \
+               [('B', ctypes.c_int64), ('C', ctypes.c_int), ('accumulate', ctypes.c_int), ('pixels', ctypes.c_float),
+                ('reserved', ctypes.c_int)]
+
+
+def _plu_launch(name, descs):
+    step = N.header_constant('NF_PLU_MAX_LAYERS')
+    for k0 in range(0, len(descs), step):
+        chunk = descs[k0:k0 + step]
+        arr = (PluDesc * len(chunk))(*chunk)
+        N.call(name, ctypes.addressof(arr), len(chunk), N.stream())
+
+
+class _PLUWeightsMulti(torch.autograd.Function):
+    """W_i = P_i (L_i o mask + I) (U_i o mask + diag(sign_s exp(log_s))) for n layers; tensors: per layer P, L, U, L_mask, U_mask,
+    sign_s, log_s.  The backward needs every layer's log-det gradient: the applications (functional._InvConvApplyW) leave it
+    in ``holder``."""
+
+    @staticmethod
+    def forward(ctx, holder, *tensors):
+        n = len(tensors) // 7
+        Ws, descs = [], []
+        for i in range(n):
+            P, L, U, Lm, Um, sg, ls = tensors[7 * i:7 * i + 7]
+            W = torch.empty_like(L)
+            Ws.append(W)
+            descs.append(_desc(PluDesc, P=P, L=L, U=U, L_mask=Lm, U_mask=Um, sign_s=sg, log_s=ls, W=W, C=L.shape[0]))
+        _plu_launch('nf_invconv_weight_fwd_multi', descs)
+        ctx.save_for_backward(*tensors)
+        ctx.holder = holder
+        from .functional import _sinks
+        ctx.sinks = [_sinks(tensors[7 * i + 1], tensors[7 * i + 2], tensors[7 * i + 6]) for i in range(n)]
+        return tuple(Ws)
+
+    @staticmethod
+    def backward(ctx, *g_Ws):
+        tensors = ctx.saved_tensors
+        n = len(tensors) // 7
+        holder = ctx.holder
+        descs, grads = [], [None]
+        for i in range(n):
+            P, L, U, Lm, Um, sg, ls = tensors[7 * i:7 * i + 7]
+            if g_Ws[i] is None or holder.meta[i] is None:
+                grads += [None] * 7
+                continue
+            B, Px = holder.meta[i]
+            direct = ctx.sinks[i] is not None
+            gL, gU, gls = ctx.sinks[i] if direct else (torch.empty_like(L), torch.empty_like(U), torch.empty_like(ls))
+            descs.append(_desc(PluDesc, P=P, L=L, U=U, L_mask=Lm, U_mask=Um, sign_s=sg, log_s=ls, g_W=g_Ws[i].contiguous(),
+                               g_ld=holder.g_ld[i], g_L=gL, g_U=gU, g_log_s=gls, B=B, C=L.shape[0], accumulate=int(direct),
+                               pixels=float(Px)))
+            grads += [None, None, None, None, None, None, None] if direct else [None, gL, gU, None, None, None, gls]
+        if descs:
+            _plu_launch('nf_invconv_weight_bwd_multi', descs)
+        return tuple(grads)
+
+
+def plu_weights_all(convs):
+    """W of the given layers.InvertibleConv1x1 modules in batched launches, stashed on them (with the holder the batched
+    backward reads) for the forward pass under way."""
+    if not convs:
+        return
+    from .functional import PluHolder
+    holder = PluHolder(len(convs))
+    tensors = []
+    for c in convs:
+        tensors += [c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s]
+    Ws = _PLUWeightsMulti.apply(holder, *tensors)
+    for i, (c, W) in enumerate(zip(convs, Ws)):
+        c._W_eff = (W, holder, i)
+

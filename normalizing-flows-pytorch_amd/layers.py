@@ -287,7 +287,12 @@ class InvertibleConv1x1(nn.Module):
         X = torch.linalg.solve_triangular(Lp, self._pivot_matrix(), upper=False, unitriangular=True)
         return torch.linalg.solve_triangular(Up, X, upper=True)
 
+    _W_eff = None      # (W, holder, index): set for the duration of ONE model forward by fused.plu_weights_all
+
     def forward(self, z, log_df_dz):
+        if self._W_eff is not None and z.is_cuda:
+            W, holder, idx = self._W_eff
+            return NF.invconv_apply_w(z, log_df_dz, W, self.log_s, holder, idx)
         if z.shape[1] <= NF.PLU_MAX_C:
             return NF.invconv_plu(z, log_df_dz, self.P, self.L, self.U, self.L_mask, self.U_mask, self.sign_s,
                                   self.log_s)

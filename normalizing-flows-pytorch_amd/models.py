@@ -60,17 +60,32 @@ class _FlowModel(nn.Module):
             c = self._wn_cache = [m for m in self.modules() if isinstance(m, WeightNorm) and m._conv]
         return c
 
+    def _plu_convs(self):
+        """the invertible 1x1 convolutions that run as modules in the forward direction (more than NF.HEAD_MAX_C channels: the
+        smaller ones are inside the fused Glow head): their PLU weights are computed in batched launches per pass."""
+        c = getattr(self, '_plu_cache', None)
+        if c is None:
+            from .layers import InvertibleConv1x1
+            from . import functional as NF
+            c = self._plu_cache = [m for m in self.modules() if isinstance(m, InvertibleConv1x1)
+                                   and NF.HEAD_MAX_C < m.L.shape[0] <= NF.PLU_MAX_C]
+        return c
+
     def _with_weight_norms(self, fn, z):
         wns = self._wn_convs() if z.is_cuda else []
-        if not wns:
+        plus = self._plu_convs() if (z.is_cuda and z.dim() == 4 and fn == self.net) else []
+        if not wns and not plus:
             return fn(z, self._zero_ld(z))
         from . import fused as FUSED
         FUSED.weight_norm_all(wns)
+        FUSED.plu_weights_all(plus)
         try:
             return fn(z, self._zero_ld(z))
         finally:
             for m in wns:
                 m._w_eff = None
+            for m in plus:
+                m._W_eff = None
 
     def forward(self, z):
         return self._with_weight_norms(self.net, z)
