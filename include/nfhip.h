@@ -556,6 +556,21 @@ int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* 
                     const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
                     float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream);
 
+/* ---- the whole backward of one Flow++ density flow step on (N, 2) data, K <= 8 -------------------------------------------
+ * = nf_flowpp_vec_couple_bwd (or nf_mixlog_coupling_bwd when next_* are NULL) followed by nf_flowpp_cond_bwd on the
+ * conditioning feature, as two launches: the coupling's backward runs inside the conditioner's backward kernel, which computes
+ * the gradient of the (N, 2 + 3K) conditioner output from the SAVED output `params` instead of reading it.  g_z (N, 2) is
+ * written; every parameter gradient is ACCUMULATED.  workspace: NF_FLOWPP_BWD_WS_FLOATS floats.                         */
+int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const float* z, const float* params, const float* W0,
+                           const float* b0, const float* Wg, const float* bg, const float* ln1_g, const float* ln1_b,
+                           const float* pos, const float* Wq, const float* bq, const float* W2, const float* b2,
+                           const float* ln2_g, const float* ln2_b, const float* W5, const float* b5, const float* a_log_scale,
+                           const float* a_bias, const float* next_log_scale, const float* next_bias, float* g_z, float* g_W0,
+                           float* g_b0, float* g_Wg, float* g_bg, float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_Wq,
+                           float* g_bq, float* g_W2, float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5,
+                           float* g_scale, float* g_bias, float* g_next_log_scale, float* g_next_bias, float* workspace, int K,
+                           float logit_eps, int odd, int64_t N, nf_stream_t stream);
+
 /* ---- a whole flow of S fused vector Glow steps (nf_glow_step_vec_*) in ONE launch per direction ---------------------------
  * flows/glow.py: the (N, D in {2, 4}) model IS a sequence of such steps; rows stay in their workgroup from step to step, the
  * batch statistics are exchanged grid-wide inside the launch exactly as in the single-step kernels.
@@ -608,7 +623,7 @@ int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* b0, const f
  * kernel leaves one partial-sum slab per block in `workspace` (>= NF_FLOWPP_BWD_WS_FLOATS floats, contents irrelevant,
  * re-usable by the next call on the same stream), a small kernel folds the slabs into the destinations.
  * g_Wq / g_bq address rows 64..95 of conv1's gradient (the V/K rows receive exact zeros, like the reference).          */
-#define NF_FLOWPP_BWD_WS_FLOATS (256 * 7680)
+#define NF_FLOWPP_BWD_WS_FLOATS (256 * 7744)
 int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const float* Wg, const float* bg,
                        const float* ln1_g, const float* ln1_b, const float* pos, const float* Wq, const float* bq,
                        const float* W2, const float* b2, const float* ln2_g, const float* ln2_b, const float* W5,

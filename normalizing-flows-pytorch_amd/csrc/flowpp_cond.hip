@@ -22,6 +22,7 @@
 
 #include "nf_common.h"
 #include "nf_mfma16.h"
+#include "nf_mixlog_oct.h"
 
 #define NF_FP_STG 68         // same for the 64-wide GatedLinear weight
 #define NF_FP_FWD_WAVES 8
@@ -43,6 +44,18 @@ struct NfFppG {   // gradient destinations, all ACCUMULATED (+=): zero-filled te
     float* g_x;                  // (N, I0) written, nullable
     float *g_W0, *g_b0, *g_Wg, *g_bg, *g_ln1g, *g_ln1b, *g_pos, *g_Wq, *g_bq, *g_W2, *g_b2, *g_ln2g, *g_ln2b, *g_W5, *g_b5;
     int64_t gxrs; int gxcs, gx_acc;                       // g_x[row][i] at g_x[row * gxrs + i * gxcs]; gx_acc: += instead of =
+};
+
+// the coupling itself, fused into the conditioner's backward (k_flowpp_cond_bwd<NB, true>): on (N, 2) data with K <= 8 mixture
+// components the gradient of the conditioner's output is COMPUTED from the saved parameters instead of being read, see the kernel
+struct NfFppMix {
+    const float* z; const float* params; const float* gy; const float* gld;    // (N, 2), (N, O), (N, 2), (N,)
+    const float* pA; const float* pC;                                          // coupling scale / shift scalars
+    const float* nls; const float* nb;                                         // the next step's ActNorm (nullable)
+    float* gz;                                                                 // (N, 2)
+    float *g_scale, *g_bias, *g_nls, *g_nb;                                    // += (g_nls / g_nb nullable with nls)
+    int odd, K;
+    float eps;
 };
 
 // LDS layout (floats): the weights, then (backward) the per-wave tiles
@@ -74,7 +87,10 @@ __host__ __device__ inline NfFppL nf_fpp_layout(int bwd_waves) {
     return L;
 }
 
+#ifndef NF_FEXP_DEFINED
+#define NF_FEXP_DEFINED
 __device__ __forceinline__ float nf_fexp(float x) { return __expf(x); }
+#endif
 __device__ __forceinline__ float nf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + nf_fexp(-x)); }
 // concat-ELU pair and its derivatives from ONE exponential: e = exp(-|h|)
 //   h > 0: elu(h) = h, elu(-h) = e - 1, elu'(h) = 1, elu'(-h) = e;   h <= 0: elu(h) = e - 1, elu(-h) = -h, elu'(h) = e, elu'(-h) = 1
@@ -295,7 +311,7 @@ extern "C" int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* 
 enum {
     NF_S_W5 = 0, NF_S_W2 = 2048, NF_S_WQ = 4096, NF_S_WG = 5120, NF_S_W0 = 7168, NF_S_B5 = 7296, NF_S_B2 = 7360,
     NF_S_BQ = 7424, NF_S_BG = 7456, NF_S_LN2G = 7488, NF_S_LN2B = 7520, NF_S_LN1G = 7552, NF_S_LN1B = 7584, NF_S_POS = 7616,
-    NF_S_B0 = 7648, NF_S_END = 7680
+    NF_S_B0 = 7648, NF_S_MIX = 7680, NF_S_END = 7744     // NF_S_MIX: the fused coupling's seven scalar sums (k_flowpp_cond_bwd<NB, true>)
 };
 
 // register relief: park an R-layout vector in LDS (each lane reads back exactly what it wrote)
@@ -383,10 +399,16 @@ __device__ __forceinline__ float nf_fp_coop_block(const float* Gt, const float* 
 // activation-side tile of its 16 rows in LDS, a barrier, then wave w owns ONE 16 x 16 output block of that matrix over the
 // rows of all eight waves (32 MFMAs), a barrier.  Five accumulators per wave instead of thirty: nothing spills (the first
 // version moved 286 MB of scratch per launch, profiles/r01_pmc_summary.txt), and the block results go to the slab as they are.
-template <int NB>
+// MIX: the Flow++ coupling step on two features (flows/coupling.py:172-210, K <= 8).  Per 16-row tile the wave first runs the
+// coupling's backward one mixture component per lane (two passes of eight rows x eight lanes, nf_mixlog_oct.h) from the SAVED
+// conditioner output, writes the gradient of the coupling's input, and leaves the gradient of the conditioner's output in its
+// LDS tile -- the 6.8 MB (N, 26) tensor that k_mixlog_oct_bwd wrote and this kernel read back twice never exists, and the
+// coupling's backward launch (22 us per flow step at C3) is gone.  Its seven scalar sums (coupling scale / shift, the next
+// step's ActNorm) ride the slab.
+template <int NB, bool MIX>
 __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(NfFppW w, NfFppG gr, float* __restrict__ slabs,
                                                                                int64_t N, int I0, int O, int64_t tiles, int iters,
-                                                                               int vec) {
+                                                                               int vec, NfFppMix mx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const NfFppL L = nf_fpp_layout(NF_FP_BWD_WAVES);
     nf_fpp_stage(w, sm, L, I0, O, vec != 0);
@@ -402,6 +424,7 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
     f32x4 a5 = nf_fp_zero4(), a2 = nf_fp_zero4(), aq = nf_fp_zero4(), ag = nf_fp_zero4(), a0 = nf_fp_zero4();
     float b5 = 0.f, b2 = 0.f, bq = 0.f, bg = 0.f, b0 = 0.f;
     float vln2g[2] = {0.f, 0.f}, vln2b[2] = {0.f, 0.f}, vln1g[2] = {0.f, 0.f}, vln1b[2] = {0.f, 0.f}, vpos[2] = {0.f, 0.f};
+    float macc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // MIX: g_a tanh, g_a | next ActNorm: sum g_h0, g_h0 h0, g_h1, g_h1 h1, g_ld
 
     for (int it = 0; it < iters; ++it) {                  // uniform trip count: the phases are workgroup barriers
         // the lane index is laundered once per trip: otherwise ~100 loop-invariant LDS / global addresses derived from it are
@@ -424,6 +447,73 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < I0 && rv) xin[i] = w.x[row * w.xrs + i * w.xcs];
+        if (MIX) {   // ---- the coupling's backward: g_out of the conditioner -> this wave's gradient tile of the phase-1 set ----
+            NF_FPP_SET(0);
+            const bool post = mx.nls != nullptr;
+            const int o0 = mx.odd, o1 = 1 ^ mx.odd;                // squeeze.py:68-69: transformed / conditioning feature
+            const float A = mx.pA[0], Cb = mx.pC[0];
+            const float D0 = post ? __expf(mx.nls[o0]) : 1.f, D1 = post ? __expf(mx.nls[o1]) : 1.f;
+            const float S0 = post ? mx.nb[o0] : 0.f, S1 = post ? mx.nb[o1] : 0.f;
+            const int K = mx.K, kk = lane & 7;
+            const bool on = kk < K;
+            for (int e = lane; e < 16 * NF_FP_ST; e += NF_WAVE) TG[e] = 0.f;     // features >= O and the rows past N stay zero
+            nf_fp_wsync();
+#pragma unroll 1
+            for (int p = 0; p < 2; ++p) {
+                const int rr = 8 * p + (lane >> 3);
+                const int64_t b = row0 + rr;
+                const bool live = b < N;
+                const int64_t bb = live ? b : N - 1;
+                NfOct m;
+                nf_oct_load(mx.params + bb * O, 1, K, kk, m);
+                const float x = mx.z[bb * 2 + o0], zi = mx.z[bb * 2 + o1];
+                const float g_h0 = mx.gy[bb * 2 + o0], g_h1 = mx.gy[bb * 2 + o1];
+                const float g_ld = mx.gld[bb];
+                const float g_y = post ? g_h0 / D0 : g_h0;
+                float lcdf, lpdf, u, l;
+                nf_oct_eval(m, x, lcdf, lpdf, u, l);
+                const float F = nf_fexp(lcdf), fd = nf_fexp(lpdf);
+                const bool inside = (F >= mx.eps) && (F <= 1.f - mx.eps);    // torch.clamp passes the gradient on [min, max]
+                const float xc = fminf(fmaxf(F, mx.eps), 1.f - mx.eps);
+                const float y1 = nf_flog(xc) - nf_flog(1.f - xc);
+                const float th = nf_ftanh(m.a_raw);
+                const float ea = nf_fexp(th * A + Cb);
+                const float g_y1 = g_y * ea;                                 // y = y1 * exp(a) + b ; ld += a
+                const float g_a = g_y * y1 * ea + g_ld;
+                const float gF = inside ? (g_y1 - g_ld * (1.f - 2.f * xc)) / (xc * (1.f - xc)) : 0.f;   // logit + its log-det
+                const float tot = gF * F + g_ld;                             // sum_j g_logpi_j
+                const float r = on ? nf_fexp(m.lp + (u - m.s - 2.f * (fmaxf(u, 0.f) + l)) - lpdf) : 0.f;   // responsibilities
+                const float omt = -nf_ftanh(0.5f * u);                       // 1 - 2 sigmoid(u)
+                const float wv_ = g_ld * r * omt * m.es;
+                const float gx = gF * fd + nf_oct_sum(wv_);
+                if (live) {
+                    float* Tr = TG + rr * NF_FP_ST;
+                    if (on) {
+                        Tr[2 + K + kk] = -gF * fd * r - wv_;                                            // g_mu_k
+                        Tr[2 + 2 * K + kk] = -gF * fd * r * (x - m.mu) + g_ld * r * (-omt * u - 1.f);   // g_s_k
+                        const float g_logpi = gF * nf_fexp(m.lp + (fminf(u, 0.f) - l)) + g_ld * r;
+                        Tr[2 + kk] = g_logpi - nf_fexp(m.lp) * tot;                                     // through log_softmax
+                    }
+                    if (kk == 0) {
+                        Tr[0] = g_a * A * (1.f - th * th);
+                        Tr[1] = g_y;
+                        mx.gz[b * 2 + o0] = gx;
+                        mx.gz[b * 2 + o1] = post ? g_h1 / D1 : g_h1;
+                        macc[0] += g_a * th;
+                        macc[1] += g_a;
+                        if (post) {
+                            const float h0 = (y1 * ea + m.b - S0) / D0, h1 = (zi - S1) / D1;
+                            macc[2] += g_h0;
+                            macc[3] += g_h0 * h0;
+                            macc[4] += g_h1;
+                            macc[5] += g_h1 * h1;
+                            macc[6] += g_ld;
+                        }
+                    }
+                }
+            }
+            nf_fp_wsync();
+        }
         NfFppFwd f;
         nf_fpp_forward_tile(sm, L, xin, c16, g, f);
 
@@ -434,12 +524,17 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
         nf_fp_store_rows(f.h4, TA, c16, g);
         {
             float go[4 * NB];                                    // g_out in R: features 16 b + 4 g + r of this lane's row
+            if (MIX) {
+#pragma unroll
+                for (int j = 0; j < 4 * NB; ++j) go[j] = TG[c16 * NF_FP_ST + 16 * (j >> 2) + 4 * g + (j & 3)];
+            } else {
             const float* gp = gr.g_out + (rv ? row : 0) * O;     // unconditional (clamped) loads + select: no branches
 #pragma unroll
             for (int j = 0; j < 4 * NB; ++j) {
                 const int o = 16 * (j >> 2) + 4 * g + (j & 3);
                 const float v = gp[o < O ? o : O - 1];
                 go[j] = (rv && o < O) ? v : 0.f;
+            }
             }
             f32x4 acc[2] = {nf_fp_zero4(), nf_fp_zero4()};
             nf_fp_gemm_d<NB>(sm + L.W5, NF_FP_ST, 0, go, acc, c16, g);
@@ -465,8 +560,12 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
                     const int64_t r2 = r0 + 4 * s2 + g;
-                    const float v = gr.g_out[(r2 < N ? r2 : N - 1) * O + (o < O ? o : O - 1)];
-                    ga[s2] = (r2 < N && o < O) ? v : 0.f;
+                    if (MIX) {
+                        ga[s2] = TGs[wv * TSZ + (4 * s2 + g) * NF_FP_ST + o];      // zero past O and past N by construction
+                    } else {
+                        const float v = gr.g_out[(r2 < N ? r2 : N - 1) * O + (o < O ? o : O - 1)];
+                        ga[s2] = (r2 < N && o < O) ? v : 0.f;
+                    }
                     av[s2] = TAs[wv * TSZ + (4 * s2 + g) * NF_FP_ST + 16 * ib + c16];
                 }
 #pragma unroll
@@ -652,6 +751,13 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
             rw[0] = vln2g[a]; rw[32] = vln2b[a]; rw[64] = vln1g[a]; rw[96] = vln1b[a]; rw[128] = vpos[a];
         }
     }
+    if (MIX) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const float t = nf_wave_sum(macc[q]);
+            if (lane0 == 0) red[NF_FP_BWD_WAVES * 160 + wid * 8 + q] = t;
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 160) {
         float t = 0.f;
@@ -660,13 +766,20 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
         const int v = threadIdx.x >> 5, k = threadIdx.x & 31;
         const int base = v == 0 ? NF_S_LN2G : v == 1 ? NF_S_LN2B : v == 2 ? NF_S_LN1G : v == 3 ? NF_S_LN1B : NF_S_POS;
         slab[base + k] = t;
+    } else if (threadIdx.x < 160 + 64) {                  // the slab is NF_S_END wide whether or not the coupling rides along
+        const int q = threadIdx.x - 160;
+        float t = 0.f;
+        if (MIX && q < 7)
+#pragma unroll
+            for (int wv = 0; wv < NF_FP_BWD_WAVES; ++wv) t += red[NF_FP_BWD_WAVES * 160 + wv * 8 + q];
+        slab[NF_S_MIX + q] = t;
     }
 }
 
 // dst += sum over the blocks' slabs.  grid (NF_S_END / 64, 4): 64 slab entries x 4 slab groups per block, the y index picks
 // a quarter of the slabs (<= 16 independent loads per thread); the four partial sums meet in the destination by atomics.
 __global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,
-                                                              int O) {
+                                                              int O, NfFppMix mx) {
     __shared__ float red[4][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -697,13 +810,26 @@ __global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __res
     else if (e < NF_S_LN1B) atomicAdd(gr.g_ln1g + e - NF_S_LN1G, s);
     else if (e < NF_S_POS) atomicAdd(gr.g_ln1b + e - NF_S_LN1B, s);
     else if (e < NF_S_B0) atomicAdd(gr.g_pos + e - NF_S_POS, s);
-    else atomicAdd(gr.g_b0 + e - NF_S_B0, s);
+    else if (e < NF_S_MIX) atomicAdd(gr.g_b0 + e - NF_S_B0, s);
+    else if (mx.g_scale != nullptr) {                     // the fused coupling's sums (mixlog.hip: k_mixlog_oct_bwd's tail)
+        const int q = e - NF_S_MIX, o0 = mx.odd, o1 = 1 ^ mx.odd;
+        if (q == 0) atomicAdd(mx.g_scale, s);
+        else if (q == 1) atomicAdd(mx.g_bias, s);
+        else if (mx.nls != nullptr && q < 7) {            // next ActNorm: g_log_scale_c = -sum g_h h - sum g_ld, g_bias_c = -sum g_h / e^ls
+            if (q == 2) atomicAdd(mx.g_nb + o0, -s / expf(mx.nls[o0]));
+            else if (q == 3) atomicAdd(mx.g_nls + o0, -s);
+            else if (q == 4) atomicAdd(mx.g_nb + o1, -s / expf(mx.nls[o1]));
+            else if (q == 5) atomicAdd(mx.g_nls + o1, -s);
+            else { atomicAdd(mx.g_nls + o0, -s); atomicAdd(mx.g_nls + o1, -s); }
+        }
+    }
 }
 
 static_assert(NF_FP_MAX_BLOCKS * NF_S_END == NF_FLOWPP_BWD_WS_FLOATS, "workspace size in include/nfhip.h");
 
-template <int NB>
-static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace, int64_t N, int I0, int O, hipStream_t stream) {
+template <int NB, bool MIX = false>
+static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace, int64_t N, int I0, int O, hipStream_t stream,
+                             const NfFppMix& mx = NfFppMix{}) {
     const int64_t tiles = (N + 15) / 16;
     int64_t gx = (tiles + NF_FP_BWD_WAVES - 1) / NF_FP_BWD_WAVES;
     if (gx > NF_FP_MAX_BLOCKS) gx = NF_FP_MAX_BLOCKS;            // one 8-wave block per CU
@@ -711,16 +837,16 @@ static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace,
     const size_t lds = (size_t)L.total * sizeof(float);
     static bool attr_set = false;                                // > 64 KB of dynamic LDS needs the opt-in, once per kernel
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_flowpp_cond_bwd<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_flowpp_cond_bwd<NB, MIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int iters = (int)((tiles + gx * NF_FP_BWD_WAVES - 1) / (gx * NF_FP_BWD_WAVES));
-    hipLaunchKernelGGL(k_flowpp_cond_bwd<NB>, dim3((unsigned)gx), dim3(NF_FP_BWD_WAVES * NF_WAVE), lds, stream, w, g, workspace,
-                       N, I0, O, tiles, iters, nf_fpp_vec_ok(w) ? 1 : 0);
+    hipLaunchKernelGGL((k_flowpp_cond_bwd<NB, MIX>), dim3((unsigned)gx), dim3(NF_FP_BWD_WAVES * NF_WAVE), lds, stream, w, g, workspace,
+                       N, I0, O, tiles, iters, nf_fpp_vec_ok(w) ? 1 : 0, mx);
     NF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_flowpp_cond_finalize, dim3(NF_S_END / 64, (unsigned)((gx + 63) / 64)), dim3(256), 0, stream, (const float*)workspace, (int)gx, g,
-                       I0, O);
+                       I0, O, mx);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -745,3 +871,33 @@ extern "C" int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* 
         default: return nf_fpp_launch_bwd<4>(w, g, workspace, N, I0, O, (hipStream_t)stream);
     }
 }
+
+// the whole backward of a Flow++ density flow step on (N, 2) data: coupling (flows/coupling.py:172-210) + conditioner + optionally
+// the next step's ActNorm, two launches (nfhip.h)
+extern "C" int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const float* z, const float* params, const float* W0,
+                                      const float* b0, const float* Wg, const float* bg, const float* ln1_g, const float* ln1_b,
+                                      const float* pos, const float* Wq, const float* bq, const float* W2, const float* b2,
+                                      const float* ln2_g, const float* ln2_b, const float* W5, const float* b5,
+                                      const float* a_log_scale, const float* a_bias, const float* next_log_scale,
+                                      const float* next_bias, float* g_z, float* g_W0, float* g_b0, float* g_Wg, float* g_bg,
+                                      float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_Wq, float* g_bq, float* g_W2,
+                                      float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5, float* g_scale,
+                                      float* g_bias, float* g_next_log_scale, float* g_next_bias, float* workspace, int K,
+                                      float logit_eps, int odd, int64_t N, nf_stream_t stream) {
+    const int O = 2 + 3 * K;
+    if (K < 1 || K > 8 || workspace == nullptr || g_h == nullptr || g_ld == nullptr || z == nullptr || params == nullptr ||
+        g_z == nullptr || g_scale == nullptr || g_bias == nullptr || a_log_scale == nullptr || a_bias == nullptr)
+        return NF_E_BADARG;
+    if ((next_log_scale == nullptr) != (next_bias == nullptr)) return NF_E_BADARG;
+    if (next_log_scale != nullptr && (g_next_log_scale == nullptr || g_next_bias == nullptr)) return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    const int sel1 = odd ? 0 : 1;                                            // the conditioning feature (squeeze.py:68-69)
+    NfFppW w{z + sel1, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, nullptr, 2, 2};
+    NfFppG g{nullptr, g_z + sel1, g_W0, g_b0, g_Wg, g_bg, g_ln1_g, g_ln1_b, g_pos, g_Wq, g_bq, g_W2, g_b2, g_ln2_g, g_ln2_b, g_W5, g_b5,
+             2, 2, 1};
+    NfFppMix mx{z, params, g_h, g_ld, a_log_scale, a_bias, next_log_scale, next_bias, g_z, g_scale, g_bias, g_next_log_scale,
+                g_next_bias, odd ? 1 : 0, K, logit_eps};
+    if (O <= 16) return nf_fpp_launch_bwd<1, true>(w, g, workspace, N, 1, O, (hipStream_t)stream, mx);
+    return nf_fpp_launch_bwd<2, true>(w, g, workspace, N, 1, O, (hipStream_t)stream, mx);
+}
+

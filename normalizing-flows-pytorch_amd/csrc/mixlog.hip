@@ -15,6 +15,7 @@
 // contiguous row: the block stages its rows through LDS (row stride 2+3K+1 words) so that global traffic is coalesced
 // both for the parameters and for their gradients.
 #include "nf_common.h"
+#include "nf_mixlog_oct.h"
 
 #define NF_MX_ROWS_MAX 16
 #define NF_MX_SLAB 1024
@@ -334,57 +335,6 @@ static inline bool nf_mixlog_args(NfSplit& s, int mode, int odd, int C, int H, i
 // chain is ~8x shorter and there are 8x the waves; the log-sum-exp / softmax reductions over the components are three
 // DPP steps each (quad_perm xor 1, xor 2, row_half_mirror) -- VALU-speed, no LDS.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float nf_dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float nf_oct_sum(float v) {
-    v += nf_dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
-    v += nf_dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
-    v += nf_dpp_mov<0x141>(v);         // row_half_mirror: lane i <-> 7 - i of each group of eight
-    return v;
-}
-__device__ __forceinline__ float nf_oct_max(float v) {
-    v = fmaxf(v, nf_dpp_mov<0xB1>(v));
-    v = fmaxf(v, nf_dpp_mov<0x4E>(v));
-    v = fmaxf(v, nf_dpp_mov<0x141>(v));
-    return v;
-}
-// hardware transcendentals for the octet kernels (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): the libm forms are 30-60
-// instructions each, and with eight lanes per element the per-element scalar math is issued eight times as often
-__device__ __forceinline__ float nf_fexp(float x) { return __expf(x); }
-__device__ __forceinline__ float nf_flog(float x) { return __logf(x); }
-__device__ __forceinline__ float nf_ftanh(float x) {              // 1 - 2 / (1 + e^{2x}), saturates cleanly
-    const float e = __expf(2.f * x);
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
-}
-struct NfOct { float lp, mu, s, es, a_raw, b; };     // this lane's component + the element's affine parameters
-
-__device__ __forceinline__ void nf_oct_load(const float* __restrict__ P, int64_t nh, int K, int kk, NfOct& m) {
-    const bool on = kk < K;
-    const int k = on ? kk : 0;
-    const float lp = P[(2 + k) * nh], mu = P[(2 + K + k) * nh], sv = P[(2 + 2 * K + k) * nh];
-    m.a_raw = P[0];
-    m.b = P[nh];
-    m.lp = on ? lp : -INFINITY;
-    m.mu = on ? mu : 0.f;
-    m.s = on ? sv : 0.f;
-    const float mx = nf_oct_max(m.lp);
-    const float lse = mx + nf_flog(nf_oct_sum(nf_fexp(m.lp - mx)));         // F.log_softmax over the mixture axis (coupling.py:180)
-    m.lp -= lse;
-    m.es = nf_fexp(-m.s);
-}
-// log CDF and log PDF of the mixture at x (modules.py:64-97), identical on the eight lanes; u, l of this lane's component
-__device__ __forceinline__ void nf_oct_eval(const NfOct& m, float x, float& lcdf, float& lpdf, float& u, float& l) {
-    u = (x - m.mu) * m.es;
-    l = nf_flog(1.f + nf_fexp(-fabsf(u)));
-    const float c = m.lp + (fminf(u, 0.f) - l);
-    const float d = m.lp + (u - m.s - 2.f * (fmaxf(u, 0.f) + l));
-    const float cm = nf_oct_max(c), dm = nf_oct_max(d);
-    lcdf = cm + nf_flog(nf_oct_sum(nf_fexp(c - cm)));
-    lpdf = dm + nf_flog(nf_oct_sum(nf_fexp(d - dm)));
-}
-
 // POST: the ActNorm of the NEXT flow step (flows/flowpp.py:60-66 alternates ActNorm and coupling on density data) is applied
 // to the coupling's output before it is stored -- h = (y - bias) / exp(log_scale), ld -= sum log_scale (modules.py:246-249) --
 // so the pair costs one pass over the rows instead of two.  n_half == 1 (two features) only.

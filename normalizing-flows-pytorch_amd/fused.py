@@ -865,6 +865,9 @@ def realnvp_flow_vec(z, ld, steps):
 # ----------------------------------------------------------------------------------------------------------------------
 # whole Flow++ coupling on vector data: conditioner (strided read of the conditioning half) + mixture-of-logistics coupling
 # ----------------------------------------------------------------------------------------------------------------------
+FLOWPP_FUSED_BWD = True      # tests flip it to compare against the separate coupling / conditioner backward launches
+
+
 class _FlowppCouplingVec(torch.autograd.Function):
     """(y, ld) = MixLogAttnCoupling.forward for dims = (D,): 2 launches forward (no gather), 3 backward (the conditioner's
     input gradient is added in place into the coupling's, no scatter / add).  tensors: a_log_scale, a_bias, then the 15
@@ -914,7 +917,6 @@ class _FlowppCouplingVec(torch.autograd.Function):
         dev = z.device
         g_y, g_ld = g_y.contiguous(), g_ld.contiguous()
         g_z = torch.empty_like(z)
-        g_p = torch.empty_like(params)
         if ctx.sinks_ac is not None:
             pa, pc, ga, gc = ctx.sinks_ac[0].data_ptr(), ctx.sinks_ac[1].data_ptr(), None, None
         else:
@@ -922,6 +924,7 @@ class _FlowppCouplingVec(torch.autograd.Function):
             pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
             ga, gc = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
         gpost = ()
+        pls = pb = None
         if n_post:
             if ctx.sinks_post is not None:
                 pls, pb, gpost = ctx.sinks_post[0].data_ptr(), ctx.sinks_post[1].data_ptr(), (None, None)
@@ -929,11 +932,6 @@ class _FlowppCouplingVec(torch.autograd.Function):
                 g_n = torch.zeros(2, D, dtype=torch.float32, device=dev)
                 pls, pb = g_n[0].data_ptr(), g_n[1].data_ptr()
                 gpost = (g_n[0].view_as(post[0]), g_n[1].view_as(post[1]))
-            N.call('nf_flowpp_vec_couple_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c),
-                   N.ptr(post[0]), N.ptr(post[1]), N.ptr(g_z), N.ptr(g_p), pa, pc, pls, pb, K, eps, odd, Nrows, N.stream())
-        else:
-            N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(g_z),
-                   N.ptr(g_p), pa, pc, K, eps, N.SPLIT_1D, odd, Nrows, D, 1, 1, N.stream())
         if ctx.sinks_net is not None:
             dst, direct = ctx.sinks_net, True
         else:
@@ -946,8 +944,21 @@ class _FlowppCouplingVec(torch.autograd.Function):
         d = [t.data_ptr() for t in dst]
         d[7] += 4 * 2 * F_ * H
         d[8] += 4 * 2 * F_
-        N.call('nf_flowpp_cond_bwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(g_p), g_z.data_ptr() + 4 * sel1,
-               *d, N.ptr(flowpp_bwd_workspace(dev)), D, 2, D, 2, 1, Nrows, I0, O, N.stream())
+        if D == 2 and K <= 8 and FLOWPP_FUSED_BWD:
+            # the coupling's backward runs inside the conditioner's backward kernel: the (N, 2 + 3K) gradient never exists
+            N.call('nf_flowpp_vec_step_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), *_flowpp_fwd_args(ts, F_),
+                   N.ptr(a), N.ptr(c), N.ptr(post[0]) if n_post else None, N.ptr(post[1]) if n_post else None, N.ptr(g_z), *d,
+                   pa, pc, pls, pb, N.ptr(flowpp_bwd_workspace(dev)), K, eps, odd, Nrows, N.stream())
+        else:
+            g_p = torch.empty_like(params)
+            if n_post:
+                N.call('nf_flowpp_vec_couple_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c),
+                       N.ptr(post[0]), N.ptr(post[1]), N.ptr(g_z), N.ptr(g_p), pa, pc, pls, pb, K, eps, odd, Nrows, N.stream())
+            else:
+                N.call('nf_mixlog_coupling_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c),
+                       N.ptr(g_z), N.ptr(g_p), pa, pc, K, eps, N.SPLIT_1D, odd, Nrows, D, 1, 1, N.stream())
+            N.call('nf_flowpp_cond_bwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(g_p), g_z.data_ptr() + 4 * sel1,
+                   *d, N.ptr(flowpp_bwd_workspace(dev)), D, 2, D, 2, 1, Nrows, I0, O, N.stream())
         gnet = (None, ) * len(ts) if direct else tuple(dst)
         return (g_z, g_ld, None, None, None, None, None) + gpost + (ga, gc) + gnet
 
