@@ -561,6 +561,12 @@ int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* 
  * conditioning feature, as two launches: the coupling's backward runs inside the conditioner's backward kernel, which computes
  * the gradient of the (N, 2 + 3K) conditioner output from the SAVED output `params` instead of reading it.  g_z (N, 2) is
  * written; every parameter gradient is ACCUMULATED.  workspace: NF_FLOWPP_BWD_WS_FLOATS floats.                         */
+/* forward of the same step in ONE launch: params (N, 2 + 3K) is written for the backward, y (N, 2) written, ld (N,) += .      */
+int nf_flowpp_vec_step_fwd(const float* z, const float* W0, const float* b0, const float* Wg, const float* bg, const float* ln1_g,
+                           const float* ln1_b, const float* pos, const float* Wq, const float* bq, const float* W2,
+                           const float* b2, const float* ln2_g, const float* ln2_b, const float* W5, const float* b5,
+                           const float* a_log_scale, const float* a_bias, const float* next_log_scale, const float* next_bias,
+                           float* params, float* y, float* ld, int K, float logit_eps, int odd, int64_t N, nf_stream_t stream);
 int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const float* z, const float* params, const float* W0,
                            const float* b0, const float* Wg, const float* bg, const float* ln1_g, const float* ln1_b,
                            const float* pos, const float* Wq, const float* bq, const float* W2, const float* b2,

@@ -237,14 +237,28 @@ __device__ __forceinline__ void nf_fpp_forward_tile(const float* sm, const NfFpp
     nf_fp_layernorm(h3, sm + L.ln2g, sm + L.ln2b, g, f.xh2, f.rstd2, f.h4);
 }
 
-template <int NB>   // NB = ceil(O / 16)
+// the coupling itself in the forward direction (k_flowpp_cond_fwd<NB, true>): what k_mixlog_oct_fwd does, on the tile the
+// conditioner just produced
+struct NfFppMixF {
+    const float* z;                                      // (N, 2) the step's input
+    const float* pA; const float* pC;                    // coupling scale / shift scalars
+    const float* nls; const float* nb;                   // the next step's ActNorm (nullable)
+    float* y; float* ld;                                 // (N, 2), (N,) +=
+    int odd, K;
+    float eps;
+};
+
+// MIX: the conditioner's output tile also goes to a per-wave LDS tile, and the wave runs the mixture coupling on it one
+// component per lane (two passes of eight rows x eight lanes): y and the log-det come out of the same launch.
+template <int NB, bool MIX>   // NB = ceil(O / 16)
 __global__ void __launch_bounds__(NF_FP_FWD_WAVES * NF_WAVE, 4) k_flowpp_cond_fwd(NfFppW w, int64_t N, int I0, int O,
-                                                                               int64_t tiles, int vec) {
+                                                                               int64_t tiles, int vec, NfFppMixF mx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const NfFppL L = nf_fpp_layout(0);
     nf_fpp_stage(w, sm, L, I0, O, vec != 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+    float* PT = sm + L.wend + wid * 16 * NF_FP_ST;       // MIX: this wave's (16 rows x 32 features) parameter tile
     for (int64_t t = (int64_t)blockIdx.x * NF_FP_FWD_WAVES + wid; t < tiles; t += (int64_t)gridDim.x * NF_FP_FWD_WAVES) {
         asm volatile("" ::: "memory");   // keep the weight fragments in LDS: hoisted out of the loop they cost 256 registers
         const int64_t row0 = t * 16, row = row0 + c16;
@@ -273,10 +287,62 @@ __global__ void __launch_bounds__(NF_FP_FWD_WAVES * NF_WAVE, 4) k_flowpp_cond_fw
                 for (int r = 0; r < 4; ++r) {
                     const int64_t gr = row0 + 4 * g + r;
                     if (gr < N) w.out[gr * O + o] = acc[r] + bv;
+                    if (MIX) PT[(4 * g + r) * NF_FP_ST + o] = acc[r] + bv;
                 }
             }
         }
+        if (MIX) {   // ---- the mixture coupling on this tile (mixlog.hip: k_mixlog_oct_fwd) ----
+            nf_fp_wsync();
+            const bool post = mx.nls != nullptr;
+            const int o0 = mx.odd, o1 = 1 ^ mx.odd, K = mx.K, kk = lane & 7;
+            const float A = mx.pA[0], Cb = mx.pC[0];
+            const float D0 = post ? expf(mx.nls[o0]) : 1.f, D1 = post ? expf(mx.nls[o1]) : 1.f;
+            const float S0 = post ? mx.nb[o0] : 0.f, S1 = post ? mx.nb[o1] : 0.f;
+            const float ldn = post ? -(mx.nls[0] + mx.nls[1]) : 0.f;
+#pragma unroll 1
+            for (int p = 0; p < 2; ++p) {
+                const int rr = 8 * p + (lane >> 3);
+                const int64_t b = row0 + rr;
+                const bool live = b < N;
+                const int64_t bb = live ? b : N - 1;
+                NfOct m;
+                nf_oct_load(PT + rr * NF_FP_ST, 1, K, kk, m);
+                const float x = mx.z[bb * 2 + o0], zi = mx.z[bb * 2 + o1];
+                float lcdf, lpdf, u, l;
+                nf_oct_eval(m, x, lcdf, lpdf, u, l);
+                const float F = nf_fexp(lcdf);                                  // modules.py:194
+                const float xc = fminf(fmaxf(F, mx.eps), 1.f - mx.eps);         // modules.py:147
+                const float la = nf_flog(xc), lb = nf_flog(1.f - xc);           // logit and its log-det share the two logs
+                const float a = nf_ftanh(m.a_raw) * A + Cb;                     // coupling.py:178
+                if (live && kk == 0) {
+                    const float yt = (la - lb) * nf_fexp(a) + m.b;              // coupling.py:187
+                    mx.y[b * 2 + o0] = post ? (yt - S0) / D0 : yt;
+                    mx.y[b * 2 + o1] = post ? (zi - S1) / D1 : zi;
+                    mx.ld[b] += ldn + lpdf - (la + lb) + a;                     // coupling.py:184-188
+                }
+            }
+            nf_fp_wsync();                                                      // the tile is rewritten by the next trip
+        }
     }
+}
+
+template <bool MIX>
+static int nf_fpp_launch_fwd(const NfFppW& w, int64_t N, int I0, int O, hipStream_t stream, const NfFppMixF& mx) {
+    const int64_t tiles = (N + 15) / 16;
+    int64_t gx = (tiles + NF_FP_FWD_WAVES - 1) / NF_FP_FWD_WAVES;
+    if (gx > 512) gx = 512;                                     // two 8-wave blocks per CU, weights staged once per block
+    const NfFppL L = nf_fpp_layout(0);
+    const size_t lds = ((size_t)L.wend + (MIX ? NF_FP_FWD_WAVES * 16 * NF_FP_ST : 0)) * sizeof(float);
+    const dim3 grid((unsigned)gx), block(NF_FP_FWD_WAVES * NF_WAVE);
+    const int vec = nf_fpp_vec_ok(w) ? 1 : 0;
+    switch ((O + 15) / 16) {
+        case 1: hipLaunchKernelGGL((k_flowpp_cond_fwd<1, MIX>), grid, block, lds, stream, w, N, I0, O, tiles, vec, mx); break;
+        case 2: hipLaunchKernelGGL((k_flowpp_cond_fwd<2, MIX>), grid, block, lds, stream, w, N, I0, O, tiles, vec, mx); break;
+        case 3: hipLaunchKernelGGL((k_flowpp_cond_fwd<3, false>), grid, block, lds, stream, w, N, I0, O, tiles, vec, mx); break;
+        default: hipLaunchKernelGGL((k_flowpp_cond_fwd<4, false>), grid, block, lds, stream, w, N, I0, O, tiles, vec, mx); break;
+    }
+    NF_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* b0, const float* Wg, const float* bg,
@@ -287,21 +353,26 @@ extern "C" int nf_flowpp_cond_fwd(const float* x, const float* W0, const float* 
     if (I0 < 1 || I0 > 4 || O < 1 || O > 64) return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     NfFppW w{x, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, out, x_row_stride, x_col_stride};
-    const int64_t tiles = (N + 15) / 16;
-    int64_t gx = (tiles + NF_FP_FWD_WAVES - 1) / NF_FP_FWD_WAVES;
-    if (gx > 512) gx = 512;                                     // two 8-wave blocks per CU, weights staged once per block
-    const NfFppL L = nf_fpp_layout(0);
-    const size_t lds = (size_t)L.wend * sizeof(float);
-    const dim3 grid((unsigned)gx), block(NF_FP_FWD_WAVES * NF_WAVE);
-    const int vec = nf_fpp_vec_ok(w) ? 1 : 0;
-    switch ((O + 15) / 16) {
-        case 1: hipLaunchKernelGGL(k_flowpp_cond_fwd<1>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
-        case 2: hipLaunchKernelGGL(k_flowpp_cond_fwd<2>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
-        case 3: hipLaunchKernelGGL(k_flowpp_cond_fwd<3>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
-        default: hipLaunchKernelGGL(k_flowpp_cond_fwd<4>, grid, block, lds, (hipStream_t)stream, w, N, I0, O, tiles, vec); break;
-    }
-    NF_CHECK_LAUNCH();
-    return 0;
+    return nf_fpp_launch_fwd<false>(w, N, I0, O, (hipStream_t)stream, NfFppMixF{});
+}
+
+// the whole forward of a Flow++ density flow step on (N, 2) data: conditioner + mixture coupling (+ the next step's ActNorm),
+// one launch (nfhip.h)
+extern "C" int nf_flowpp_vec_step_fwd(const float* z, const float* W0, const float* b0, const float* Wg, const float* bg,
+                                      const float* ln1_g, const float* ln1_b, const float* pos, const float* Wq, const float* bq,
+                                      const float* W2, const float* b2, const float* ln2_g, const float* ln2_b, const float* W5,
+                                      const float* b5, const float* a_log_scale, const float* a_bias, const float* next_log_scale,
+                                      const float* next_bias, float* params, float* y, float* ld, int K, float logit_eps, int odd,
+                                      int64_t N, nf_stream_t stream) {
+    const int O = 2 + 3 * K;
+    if (K < 1 || K > 8 || z == nullptr || params == nullptr || y == nullptr || ld == nullptr || a_log_scale == nullptr ||
+        a_bias == nullptr || (next_log_scale == nullptr) != (next_bias == nullptr))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    const int sel1 = odd ? 0 : 1;
+    NfFppW w{z + sel1, W0, b0, Wg, bg, ln1_g, ln1_b, pos, Wq, bq, W2, b2, ln2_g, ln2_b, W5, b5, params, 2, 2};
+    NfFppMixF mx{z, a_log_scale, a_bias, next_log_scale, next_bias, y, ld, odd ? 1 : 0, K, logit_eps};
+    return nf_fpp_launch_fwd<true>(w, N, 1, O, (hipStream_t)stream, mx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -885,10 +885,17 @@ class _FlowppCouplingVec(torch.autograd.Function):
         O = ts[13].shape[0]
         sel1 = 1 ^ int(odd)                                   # conditioning half = elements 2 e + sel1 (squeeze.py:68-69)
         params = torch.empty(Nrows, O, dtype=torch.float32, device=z.device)
-        N.call('nf_flowpp_cond_fwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(params), D, 2, Nrows, I0, O,
-               N.stream())
         y = torch.empty_like(z)
-        if n_post:
+        if D == 2 and K <= 8 and FLOWPP_FUSED_BWD:           # conditioner + coupling (+ next ActNorm) in one launch
+            N.call('nf_flowpp_vec_step_fwd', N.ptr(z), *_flowpp_fwd_args(ts, F_), N.ptr(a), N.ptr(c),
+                   N.ptr(post[0]) if n_post else None, N.ptr(post[1]) if n_post else None, N.ptr(params), N.ptr(y), N.ptr(ld), K,
+                   float(eps), int(odd), Nrows, N.stream())
+        else:
+            N.call('nf_flowpp_cond_fwd', z.data_ptr() + 4 * sel1, *_flowpp_fwd_args(ts, F_), N.ptr(params), D, 2, Nrows, I0, O,
+                   N.stream())
+        if D == 2 and K <= 8 and FLOWPP_FUSED_BWD:
+            pass
+        elif n_post:
             N.call('nf_flowpp_vec_couple_fwd', N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(post[0]), N.ptr(post[1]),
                    N.ptr(y), N.ptr(ld), K, float(eps), int(odd), Nrows, N.stream())
         else:
