@@ -560,7 +560,9 @@ int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* 
  * = nf_flowpp_vec_couple_bwd (or nf_mixlog_coupling_bwd when next_* are NULL) followed by nf_flowpp_cond_bwd on the
  * conditioning feature, as two launches: the coupling's backward runs inside the conditioner's backward kernel, which computes
  * the gradient of the (N, 2 + 3K) conditioner output from the SAVED output `params` instead of reading it.  g_z (N, 2) is
- * written; every parameter gradient is ACCUMULATED.  workspace: NF_FLOWPP_BWD_WS_FLOATS floats.                         */
+ * written; every parameter gradient is ACCUMULATED.  workspace: NF_FLOWPP_BWD_WS_FLOATS floats.  phase: 0 = both launches on
+ * `stream`; 1 = the backward kernel only, 2 = the slab finalize only (same arguments) -- a caller may put the finalize on a second
+ * stream so that it overlaps the next step's backward kernel; the workspace is then busy until that finalize has run.        */
 /* forward of the same step in ONE launch: params (N, 2 + 3K) is written for the backward, y (N, 2) written, ld (N,) += .      */
 int nf_flowpp_vec_step_fwd(const float* z, const float* W0, const float* b0, const float* Wg, const float* bg, const float* ln1_g,
                            const float* ln1_b, const float* pos, const float* Wq, const float* bq, const float* W2,
@@ -575,7 +577,7 @@ int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const float* z, 
                            float* g_b0, float* g_Wg, float* g_bg, float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_Wq,
                            float* g_bq, float* g_W2, float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5,
                            float* g_scale, float* g_bias, float* g_next_log_scale, float* g_next_bias, float* workspace, int K,
-                           float logit_eps, int odd, int64_t N, nf_stream_t stream);
+                           float logit_eps, int odd, int64_t N, int phase, nf_stream_t stream);
 
 /* ---- a whole flow of S fused vector Glow steps (nf_glow_step_vec_*) in ONE launch per direction ---------------------------
  * flows/glow.py: the (N, D in {2, 4}) model IS a sequence of such steps; rows stay in their workgroup from step to step, the

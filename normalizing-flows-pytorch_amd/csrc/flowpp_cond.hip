@@ -898,9 +898,11 @@ __global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __res
 
 static_assert(NF_FP_MAX_BLOCKS * NF_S_END == NF_FLOWPP_BWD_WS_FLOATS, "workspace size in include/nfhip.h");
 
+// phase: 0 = both kernels, 1 = the backward kernel only, 2 = the slab finalize only (so that the caller can put the finalize
+// on a second stream, where it overlaps the next flow step's backward kernel; it then owns the workspace until it is done)
 template <int NB, bool MIX = false>
 static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace, int64_t N, int I0, int O, hipStream_t stream,
-                             const NfFppMix& mx = NfFppMix{}) {
+                             const NfFppMix& mx = NfFppMix{}, int phase = 0) {
     const int64_t tiles = (N + 15) / 16;
     int64_t gx = (tiles + NF_FP_BWD_WAVES - 1) / NF_FP_BWD_WAVES;
     if (gx > NF_FP_MAX_BLOCKS) gx = NF_FP_MAX_BLOCKS;            // one 8-wave block per CU
@@ -913,9 +915,12 @@ static int nf_fpp_launch_bwd(const NfFppW& w, const NfFppG& g, float* workspace,
         attr_set = true;
     }
     const int iters = (int)((tiles + gx * NF_FP_BWD_WAVES - 1) / (gx * NF_FP_BWD_WAVES));
-    hipLaunchKernelGGL((k_flowpp_cond_bwd<NB, MIX>), dim3((unsigned)gx), dim3(NF_FP_BWD_WAVES * NF_WAVE), lds, stream, w, g, workspace,
-                       N, I0, O, tiles, iters, nf_fpp_vec_ok(w) ? 1 : 0, mx);
-    NF_CHECK_LAUNCH();
+    if (phase != 2) {
+        hipLaunchKernelGGL((k_flowpp_cond_bwd<NB, MIX>), dim3((unsigned)gx), dim3(NF_FP_BWD_WAVES * NF_WAVE), lds, stream, w, g,
+                           workspace, N, I0, O, tiles, iters, nf_fpp_vec_ok(w) ? 1 : 0, mx);
+        NF_CHECK_LAUNCH();
+    }
+    if (phase == 1) return 0;
     hipLaunchKernelGGL(k_flowpp_cond_finalize, dim3(NF_S_END / 64, (unsigned)((gx + 63) / 64)), dim3(256), 0, stream, (const float*)workspace, (int)gx, g,
                        I0, O, mx);
     NF_CHECK_LAUNCH();
@@ -954,8 +959,9 @@ extern "C" int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const
                                       float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_Wq, float* g_bq, float* g_W2,
                                       float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5, float* g_scale,
                                       float* g_bias, float* g_next_log_scale, float* g_next_bias, float* workspace, int K,
-                                      float logit_eps, int odd, int64_t N, nf_stream_t stream) {
+                                      float logit_eps, int odd, int64_t N, int phase, nf_stream_t stream) {
     const int O = 2 + 3 * K;
+    if (phase < 0 || phase > 2) return NF_E_BADARG;
     if (K < 1 || K > 8 || workspace == nullptr || g_h == nullptr || g_ld == nullptr || z == nullptr || params == nullptr ||
         g_z == nullptr || g_scale == nullptr || g_bias == nullptr || a_log_scale == nullptr || a_bias == nullptr)
         return NF_E_BADARG;
@@ -968,7 +974,7 @@ extern "C" int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const
              2, 2, 1};
     NfFppMix mx{z, params, g_h, g_ld, a_log_scale, a_bias, next_log_scale, next_bias, g_z, g_scale, g_bias, g_next_log_scale,
                 g_next_bias, odd ? 1 : 0, K, logit_eps};
-    if (O <= 16) return nf_fpp_launch_bwd<1, true>(w, g, workspace, N, 1, O, (hipStream_t)stream, mx);
-    return nf_fpp_launch_bwd<2, true>(w, g, workspace, N, 1, O, (hipStream_t)stream, mx);
+    if (O <= 16) return nf_fpp_launch_bwd<1, true>(w, g, workspace, N, 1, O, (hipStream_t)stream, mx, phase);
+    return nf_fpp_launch_bwd<2, true>(w, g, workspace, N, 1, O, (hipStream_t)stream, mx, phase);
 }
 

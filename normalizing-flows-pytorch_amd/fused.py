@@ -955,7 +955,7 @@ class _FlowppCouplingVec(torch.autograd.Function):
             # the coupling's backward runs inside the conditioner's backward kernel: the (N, 2 + 3K) gradient never exists
             N.call('nf_flowpp_vec_step_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), *_flowpp_fwd_args(ts, F_),
                    N.ptr(a), N.ptr(c), N.ptr(post[0]) if n_post else None, N.ptr(post[1]) if n_post else None, N.ptr(g_z), *d,
-                   pa, pc, pls, pb, N.ptr(flowpp_bwd_workspace(dev)), K, eps, odd, Nrows, N.stream())
+                   pa, pc, pls, pb, N.ptr(flowpp_bwd_workspace(dev)), K, eps, odd, Nrows, 0, N.stream())
         else:
             g_p = torch.empty_like(params)
             if n_post:
