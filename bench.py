@@ -293,14 +293,33 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         wsb = F.flowpp_bwd_workspace(dev)
         args = F._flowpp_fwd_args(ts, F_)
 
-        def fn():
-            N.call('nf_flowpp_cond_bwd', x.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), I0, 1, I0, 1, 0, B, I0, O,
-                   N.stream())
+        fused_step = dims[0] == 2 and K <= 8 and F.FLOWPP_FUSED_BWD
+        if fused_step:   # what the train step launches: the coupling's backward rides inside the conditioner's
+            zz = torch.randn(B, 2, generator=g).to(dev)
+            prm = torch.empty(B, O, device=dev)
+            yy, ldd = torch.empty_like(zz), torch.zeros(B, device=dev)
+            aa, cc = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev)
+            gaa, gcc = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            gyy, gld = torch.randn(B, 2, generator=g).to(dev), torch.full((B, ), -1.0 / B, device=dev)
+            gzz = torch.empty_like(zz)
+            N.call('nf_flowpp_vec_step_fwd', zz.data_ptr(), *args, aa.data_ptr(), cc.data_ptr(), None, None, prm.data_ptr(),
+                   yy.data_ptr(), ldd.data_ptr(), K, 1.0e-5, 0, B, N.stream())
+
+            def fn():
+                N.call('nf_flowpp_vec_step_bwd', gyy.data_ptr(), gld.data_ptr(), zz.data_ptr(), prm.data_ptr(), *args, aa.data_ptr(),
+                       cc.data_ptr(), None, None, gzz.data_ptr(), *d, gaa.data_ptr(), gcc.data_ptr(), None, None, wsb.data_ptr(), K,
+                       1.0e-5, 0, B, 0, N.stream())
+        else:
+            def fn():
+                N.call('nf_flowpp_cond_bwd', x.data_ptr(), *args, gout.data_ptr(), gx.data_ptr(), *d, wsb.data_ptr(), I0, 1, I0, 1, 0, B,
+                       I0, O, N.stream())
         us = graph_time_us(fn, dev, per_graph=20, replays=5) * 1.0
         mac = (2048 + 1024 + 2048) + 2 * (O * 32 + 2048 + 1024 + 2048) + 32 * I0      # recompute + data + weight gradients
         flop = 2 * mac * B
         tf = flop / (us * 1e-6) / 1e12
-        return {'bound': 'mfma', 'kernel': 'k_flowpp_cond_bwd + k_flowpp_cond_finalize (gated-attention conditioner)',
+        kname = ('k_flowpp_cond_bwd<2, true> + k_flowpp_cond_finalize (gated-attention conditioner + mixture coupling, backward)'
+                 if fused_step else 'k_flowpp_cond_bwd + k_flowpp_cond_finalize (gated-attention conditioner)')
+        return {'bound': 'mfma', 'kernel': kname,
                 'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
                 'traffic': pmc_traffic('k_flowpp_cond_bwd', B), 'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (2 * I0 + O) * 4),
                 'us_per_launch': round(us, 3),
