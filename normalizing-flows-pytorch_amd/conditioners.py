@@ -113,9 +113,8 @@ class ConvNet(nn.Module):
         self.out_block = nn.Sequential(nn.BatchNorm2d(base_filters), nn.ReLU(inplace=True),
                                        _wn(nn.Conv2d(base_filters, out_channels, 1, 1, 0), weight_norm))
 
-    # csrc/conv_bn.hip: parity-complete, but at the reference's sizes (64 x 32 x 16 x 16 and smaller) still a few percent
-    # behind the MIOpen + ATen module path per training step -- opt-in until it wins
-    fused = os.environ.get('NF_FUSED_CONV', '0') == '1'
+    # csrc/conv_bn.hip; NF_FUSED_CONV=0 falls back to the MIOpen + ATen module path
+    fused = os.environ.get('NF_FUSED_CONV', '1') != '0'
 
     def forward_reference(self, x):
         """module-by-module PyTorch path (MIOpen + ATen); used off-GPU and as the parity reference of the fused one."""

@@ -396,9 +396,9 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, N
     NF_CV_STAMP(1);
 
     for (int64_t tile = blockIdx.x; tile < g.tiles; tile += gridDim.x) {
-        int tdec[NF_CV_FJ];
-        int64_t b0;
-        nf_cv_decode_all(tdec, g, tile, lane, b0);
+        const int64_t P0t = tile * NF_CV_PX;
+        const int64_t b0 = P0t >> g.lgHW;
+        const int y0t = g.SEG == 1 ? (int)(P0t & (g.HW - 1)) >> g.lgW : 0;
         NF_CV_STAMP(20);
         const float* in0 = d.in + b0 * I * g.HW;
         const int64_t P = tile * NF_CV_PX + px;
@@ -419,28 +419,46 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, N
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
         for (int ch = 0; ch < nchunks; ++ch) {
             const int i0 = 32 * ch, IC = min(32, I - i0), ICP = (IC + 15) & ~15;
-            // every global load of the chunk first (one memory latency), then the LDS stores
-            NfCvA av;
-            nf_cv_act_load<0>(av, tdec, in0, g, I, i0, IC, wid);
+            // staging, one frame position per lane and trip (see the backward kernel): the weights ride the first trip
             NfCvW<T> wv;
             if (T == 9) nf_cv_w_load<T, false>(wv, d.weight, O, I, i0, IC, ICP, 0, wid, lane);
             NF_CV_STAMP(21);
-            __syncthreads();                            // previous readers of Wl / Al / RS are done; kc is written
-            NF_CV_STAMP(22);
-            if (T == 9) {
-                nf_cv_w_store<T, false>(wv, Wl, O, wid);
-            } else {                                    // 1x1, I <= 32: row ic, column oc of the wide tile
-                for (int e = threadIdx.x; e < O * IC; e += NF_CV_THREADS) {
-                    const int oc = e / IC, ic = e - oc * IC;
-                    Wl[ic * WCOLS + oc] = d.weight[oc * I + i0 + ic];
+#pragma unroll 1
+            for (int jj = 0; jj < g.nfj; ++jj) {
+                const int f = lane + NF_WAVE * jj;
+                const int t = nf_cv_decode(g, b0, y0t, f);
+                const int sp = t >= 0 ? NF_CV_SP(t) : 0, sg_ = t >= 0 ? NF_CV_SEG(t) : 0;
+                float xa[NF_CV_CU];
+#pragma unroll
+                for (int u = 0; u < NF_CV_CU; ++u) {
+                    const int c = wid + u * NF_CV_WAVES;
+                    xa[u] = (t >= 0 && c < IC) ? in0[(sg_ * I + i0 + c) * g.HW + sp] : 0.f;
                 }
-            }
-            if (ICP > IC) nf_cv_zero_pad_rows<T>(Wl, ICP, IC, ICP - IC, WCOLS);
-            NF_CV_STAMP(23);
-            nf_cv_act_store<0>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
-            if (g.nfj > 3) {                            // frames of the small levels (several samples per tile): second round
-                nf_cv_act_load<3>(av, tdec, in0, g, I, i0, IC, wid);
-                nf_cv_act_store<3>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
+                if (jj == 0) {
+                    __syncthreads();                    // previous readers of Wl / Al / RS are done; kc is written
+                    NF_CV_STAMP(22);
+                    if (T == 9) {
+                        nf_cv_w_store<T, false>(wv, Wl, O, wid);
+                    } else {                            // 1x1, I <= 32: row ic, column oc of the wide tile
+                        for (int e = threadIdx.x; e < O * IC; e += NF_CV_THREADS) {
+                            const int oc = e / IC, ic = e - oc * IC;
+                            Wl[ic * WCOLS + oc] = d.weight[oc * I + i0 + ic];
+                        }
+                    }
+                    if (ICP > IC) nf_cv_zero_pad_rows<T>(Wl, ICP, IC, ICP - IC, WCOLS);
+                    NF_CV_STAMP(23);
+                }
+                if (f < g.FSZ) {
+#pragma unroll
+                    for (int u = 0; u < NF_CV_CU; ++u) {
+                        const int c = wid + u * NF_CV_WAVES;
+                        if (c < ICP) {
+                            float x = xa[u];
+                            if (has_bn) x = (t >= 0 && c < IC) ? fmaxf(fmaf(x, kc[c], kc[32 + c]), 0.f) : 0.f;
+                            Al[c * g.CS + f] = x;
+                        }
+                    }
+                }
             }
             NF_CV_STAMP(24);
             __syncthreads();
@@ -660,9 +678,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
     for (int it = 0; it < iters; ++it) {
         const int64_t tile = (int64_t)it * gridDim.x + blockIdx.x;
         if (tile >= g.tiles) break;                    // block-uniform
-        int tdec[NF_CV_FJ];
-        int64_t b0;
-        nf_cv_decode_all(tdec, g, tile, lane, b0);
+        const int64_t b0 = (tile * NF_CV_PX) >> g.lgHW;
         const float* in0 = d.in + b0 * I * g.HW;
         const int64_t go0 = b0 * O * g.HW;             // sample b0 of the (B, O, H, W) tensors
         const int64_t P = tile * NF_CV_PX + px;
@@ -672,80 +688,82 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
 #pragma unroll
         for (int ib = 0; ib < ICB; ++ib) {
             const int i0 = 32 * ib, IC = min(32, I - i0), ICP = (IC + 15) & ~15;
-            // every global load of a round first (one memory latency): activations, weights, the tensors G is assembled from;
-            // frame positions three per lane and round (one round unless the tile holds several small samples)
+            // staging, one frame position per lane and trip (three trips at the 16 x 16 level): the loads of a trip -- two
+            // activation channels, two channels of each tensor G is assembled from, and in the first trip the weights -- are in
+            // flight together.  Everything at once needs ~70 live registers on top of the kernel's own state and spilled (120
+            // scratch operations, 25 us); three short round trips are cheaper than that.
             NfCvW<T> wv;
             if (T == 9) nf_cv_w_load<T, true>(wv, d.weight, O, I, i0, IC, ICP, OP, wid, lane);
-#define NF_CV_G_LOAD(JR_, C0_)                                                                             \
-    _Pragma("unroll") for (int jj = 0; jj < 3; ++jj) {                                                     \
-        const int t = tdec[(JR_) + jj];                                                                    \
-        const int base = t >= 0 ? NF_CV_SEG(t) * O * g.HW + NF_CV_SP(t) : 0;                               \
-        _Pragma("unroll") for (int u = 0; u < NF_CV_CU; ++u) {                                             \
-            const int c = (C0_) + u * NF_CV_WAVES;                                                         \
-            const bool ok = t >= 0 && c < O;                                                               \
-            const int64_t idx = go0 + base + c * g.HW;                                                     \
-            w1[jj][u] = (ok && d.g_direct != nullptr) ? d.g_direct[idx] : 0.f;                             \
-            w2[jj][u] = (ok && d.g_skip != nullptr) ? d.g_skip[idx] : 0.f;                                 \
-            w3[jj][u] = (ok && has_src) ? d.gn_src[idx] : 0.f;                                             \
-            w4[jj][u] = (ok && has_src) ? d.out[idx] : 0.f;                                                \
-        }                                                                                                  \
-    }
-#define NF_CV_G_STORE(JR_, C0_)                                                                            \
-    _Pragma("unroll") for (int jj = 0; jj < 3; ++jj) {                                                     \
-        const int f = lane + NF_WAVE * ((JR_) + jj);                                                       \
-        const int t = tdec[(JR_) + jj];                                                                    \
-        const int base = t >= 0 ? NF_CV_SEG(t) * O * g.HW + NF_CV_SP(t) : 0;                               \
-        if (f < g.FSZ) {                                                                                   \
-            _Pragma("unroll") for (int u = 0; u < NF_CV_CU; ++u) {                                         \
-                const int c = (C0_) + u * NF_CV_WAVES;                                                     \
-                if (c < OPmax) {                                                                           \
-                    float v = 0.f;                                                                         \
-                    if (t >= 0 && c < O) {                                                                 \
-                        v = w1[jj][u] + w2[jj][u];                                                         \
-                        if (has_src) {                     /* BatchNorm backward on load */                \
-                            const float xh = (w4[jj][u] - cb[32 + c]) * cb[64 + c];                        \
-                            v += cb[c] * (w3[jj][u] - cb[96 + c] - xh * cb[128 + c]);                      \
-                        }                                                                                  \
-                        if (d.g_store != nullptr && (t >> 30)) d.g_store[go0 + base + c * g.HW] = v;       \
-                    }                                                                                      \
-                    Gl[c * g.CS + f] = v;                                                                  \
-                }                                                                                          \
-            }                                                                                              \
-        }                                                                                                  \
-    }
-            float w1[3][NF_CV_CU], w2[3][NF_CV_CU], w3[3][NF_CV_CU], w4[3][NF_CV_CU];
-            NfCvA av;
-            nf_cv_act_load<0>(av, tdec, in0, g, I, i0, IC, wid);
-            if (ib == 0) NF_CV_G_LOAD(0, wid);
-            __syncthreads();                           // previous readers of the frames / Wd / exchange are done; cb, kc
-            if (ib == 0) {
-                // ---- G frame, assembled; g_store for the pixels this tile owns ----
-                NF_CV_G_STORE(0, wid);
-                for (int c0 = wid + NF_CV_CU * NF_CV_WAVES; c0 < OPmax; c0 += NF_CV_CU * NF_CV_WAVES) {   // 1x1 layers: O up to 192
-                    NF_CV_G_LOAD(0, c0);
-                    NF_CV_G_STORE(0, c0);
+            const int64_t P0t = tile * NF_CV_PX;
+            const int y0t = g.SEG == 1 ? (int)(P0t & (g.HW - 1)) >> g.lgW : 0;
+#pragma unroll 1
+            for (int jj = 0; jj < g.nfj; ++jj) {
+                const int f = lane + NF_WAVE * jj;
+                const int t = nf_cv_decode(g, b0, y0t, f);
+                const int sp = t >= 0 ? NF_CV_SP(t) : 0, sg_ = t >= 0 ? NF_CV_SEG(t) : 0;
+                float xa[NF_CV_CU];
+#pragma unroll
+                for (int u = 0; u < NF_CV_CU; ++u) {
+                    const int c = wid + u * NF_CV_WAVES;
+                    xa[u] = (t >= 0 && c < IC) ? in0[(sg_ * I + i0 + c) * g.HW + sp] : 0.f;
                 }
-                if (g.nfj > 3)
+                if (jj == 0) __syncthreads();          // previous readers of the frames / Wd / exchange are done; cb, kc
+                if (ib == 0) {
+                    // ---- G frame, assembled; g_store for the pixels this tile owns ----
                     for (int c0 = wid; c0 < OPmax; c0 += NF_CV_CU * NF_CV_WAVES) {
-                        NF_CV_G_LOAD(3, c0);
-                        NF_CV_G_STORE(3, c0);
+                        float w1[NF_CV_CU], w2[NF_CV_CU], w3[NF_CV_CU], w4[NF_CV_CU];
+#pragma unroll
+                        for (int u = 0; u < NF_CV_CU; ++u) {
+                            const int c = c0 + u * NF_CV_WAVES;
+                            const bool ok = t >= 0 && c < O;
+                            const int64_t idx = go0 + (sg_ * O + c) * g.HW + sp;
+                            w1[u] = (ok && d.g_direct != nullptr) ? d.g_direct[idx] : 0.f;
+                            w2[u] = (ok && d.g_skip != nullptr) ? d.g_skip[idx] : 0.f;
+                            w3[u] = (ok && has_src) ? d.gn_src[idx] : 0.f;
+                            w4[u] = (ok && has_src) ? d.out[idx] : 0.f;
+                        }
+                        if (f < g.FSZ) {
+#pragma unroll
+                            for (int u = 0; u < NF_CV_CU; ++u) {
+                                const int c = c0 + u * NF_CV_WAVES;
+                                if (c < OPmax) {
+                                    float v = 0.f;
+                                    if (t >= 0 && c < O) {
+                                        v = w1[u] + w2[u];
+                                        if (has_src) {                          // BatchNorm backward on load
+                                            const float xh = (w4[u] - cb[32 + c]) * cb[64 + c];
+                                            v += cb[c] * (w3[u] - cb[96 + c] - xh * cb[128 + c]);
+                                        }
+                                        if (d.g_store != nullptr && (t >> 30)) d.g_store[go0 + (sg_ * O + c) * g.HW + sp] = v;
+                                    }
+                                    Gl[c * g.CS + f] = v;
+                                }
+                            }
+                        }
                     }
-            }
-#undef NF_CV_G_LOAD
-#undef NF_CV_G_STORE
-            if (T == 9) {
-                nf_cv_w_store<T, true>(wv, Wd, O, wid);
-            } else {                                   // 1x1: row oc, column ic
-                for (int e = threadIdx.x; e < O * IC; e += NF_CV_THREADS) {
-                    const int oc = e / IC, ic = e - oc * IC;
-                    Wd[oc * NF_CV_WS + ic] = d.weight[oc * I + i0 + ic];
                 }
-            }
-            if (OP > O) nf_cv_zero_pad_rows<T>(Wd, OP, O, OP - O, NF_CV_WS);
-            nf_cv_act_store<0>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
-            if (g.nfj > 3) {
-                nf_cv_act_load<3>(av, tdec, in0, g, I, i0, IC, wid);
-                nf_cv_act_store<3>(av, Al, tdec, kc, g, IC, ICP, has_bn, wid, lane);
+                if (f < g.FSZ) {
+#pragma unroll
+                    for (int u = 0; u < NF_CV_CU; ++u) {
+                        const int c = wid + u * NF_CV_WAVES;
+                        if (c < ICP) {
+                            float x = xa[u];
+                            if (has_bn) x = (t >= 0 && c < IC) ? fmaxf(fmaf(x, kc[c], kc[32 + c]), 0.f) : 0.f;
+                            Al[c * g.CS + f] = x;
+                        }
+                    }
+                }
+                if (jj == 0) {
+                    if (T == 9) {
+                        nf_cv_w_store<T, true>(wv, Wd, O, wid);
+                    } else {                           // 1x1: row oc, column ic
+                        for (int e = threadIdx.x; e < O * IC; e += NF_CV_THREADS) {
+                            const int oc = e / IC, ic = e - oc * IC;
+                            Wd[oc * NF_CV_WS + ic] = d.weight[oc * I + i0 + ic];
+                        }
+                    }
+                    if (OP > O) nf_cv_zero_pad_rows<T>(Wd, OP, O, OP - O, NF_CV_WS);
+                }
             }
             __syncthreads();
             NF_CV_STAMP(10);
