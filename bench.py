@@ -118,7 +118,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                  BatchNorms; csrc/mlp_chain.hip) -- fp32 MFMA work, bound by the five grid-wide BatchNorm exchanges;
       c5      -> k_maf_step_bwd, the one-launch backward of a whole MAF flow step (flow BatchNorm, MADE pair, transform);
       c3      -> k_flowpp_cond_bwd, the one-launch backward of the gated-attention conditioner (fp32 MFMA);
-      c4      -> k_affine_slab_fwd (first-resolution checkerboard step; convolutions are MIOpen's).
+      c4      -> k_conv_bn_bwd, the 3x3 convolution + BatchNorm2d + ReLU backward of the image conditioner (fp32 MFMA).
     achieved = algorithmic bytes or flops per launch / average launch duration at the workload's
     shape, measured live with HIP events around hipGraph replays of that launch on the launch stream."""
     N, NF = pkg._native, pkg.functional
@@ -325,6 +325,39 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                 'us_per_launch': round(us, 3),
                 'note': 'fp32-input MFMA (exact fp32, 1/16 of the bf16 rate); the rest is transcendental VALU work and the '
                         'LDS transposes of the weight-gradient operands (DESIGN.md section 3)'}
+    if len(dims) == 3 and cfg['kind'] in ('glow', 'realnvp'):
+        # image flows: the train step is dominated by the conditioner's 3x3 convolution backward (profiles/r01_c4_final_kernel_stats.csv);
+        # measured at the first resolution of the pyramid (checkerboard half of the input: H/2 x W/2), 32 -> 32 channels
+        cond = importlib.import_module(PKG + '.conditioners')
+        FC = importlib.import_module(PKG + '.fused_conv')
+        Hh, Ww, Cc = dims[1] // 2, dims[2] // 2, 32
+        if cond.ConvNet.fused and N.load().nf_conv_bn_usable(B, Cc, Cc, Hh, Ww, 3):
+            R = FC.R
+            x = torch.randn(B, Cc, Hh, Ww, generator=g).to(dev)
+            out, gn_src = torch.randn(B, Cc, Hh, Ww, generator=g).to(dev), torch.randn(B, Cc, Hh, Ww, generator=g).to(dev)
+            wgt = (torch.randn(Cc, Cc, 3, 3, generator=g) * 0.1).to(dev)
+            ones, zeros = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+            slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
+            g_weff = torch.empty(slabs, wgt.numel(), device=dev)
+            acc = torch.zeros(R * FC.GB + 4 * R * 32, device=dev)
+            gn_out = torch.empty_like(x)
+
+            def fn():
+                FC._bwd((B, Hh, Ww), Cc, Cc, 3, in_=x, weight=wgt, bn_gamma=ones, bn_beta=zeros, bn_save_mean=zeros,
+                        bn_save_invstd=ones, gn_src=gn_src, out=out, cbn_gamma=ones, cbn_save_mean=zeros, cbn_save_invstd=ones,
+                        cbn_sum_g=acc[R * FC.GB:R * FC.GB + R * 32], cbn_sum_gx=acc[R * FC.GB + R * 32:R * FC.GB + 2 * R * 32],
+                        g_bias=acc[:R * FC.GB], g_weff=g_weff, gn_out=gn_out, sum_g=acc[R * FC.GB + 2 * R * 32:R * FC.GB + 3 * R * 32],
+                        sum_gx=acc[R * FC.GB + 3 * R * 32:])
+            us = graph_time_us(fn, dev, per_graph=20, replays=5)
+            M = B * Hh * Ww
+            flop = 2 * 2 * M * 9 * Cc * Cc                          # data gradient + weight gradient products
+            tf = flop / (us * 1e-6) / 1e12
+            return {'bound': 'mfma', 'kernel': 'k_conv_bn_bwd<9, 1, 1> (3x3 convolution + BatchNorm2d + ReLU backward, 32 -> 32 channels, '
+                                               '%d x %d)' % (Hh, Ww),
+                    'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
+                    'traffic': None, 'flop_per_launch': int(flop), 'bytes_per_launch': int(M * Cc * 4 * 5), 'us_per_launch': round(us, 3),
+                    'note': 'latency-bound at this size (0.6 GFLOP over 128 workgroups): ~7 us of MFMA work inside a serial chain of '
+                            'dependent memory round trips (DESIGN.md section 3.15; tools/probes/conv_prof.py)'}
     if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:              # multi-launch linear + BatchNorm chain
         nets = 2 if cfg['kind'] == 'maf' else 1
         T = lambda *sh: torch.randn(*sh, generator=g).to(dev)          # noqa: E731
