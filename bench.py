@@ -159,9 +159,11 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
             N.call('nf_realnvp_step_vec_fwd', z.data_ptr(), y.data_ptr(), ld.data_ptr(), ctypes.addressof(htab),
                    ctypes.addressof(mtab), save.data_ptr(), ws0.data_ptr(), B, D, 0, 1.0e-5, 0.1, 1.0e-5, 0.1, 1.0e-5, st)
         S = int(cfg['layers'])
-        if F._flow_on(z) and S >= 2:
-            # small batches train through the whole-flow launch (all S steps in one kernel per direction): that is the launch
-            # the timed region is made of, so that is the one measured here
+        per_step = glow and F._glow_steps_on(z)
+        if (F._flow_on(z) or per_step) and S >= 2:
+            # small batches train through the whole-flow launch (all S steps in one kernel per direction), larger Glow batches
+            # through S single-step launches with the gradient folds deferred to one more launch: that is what the timed region
+            # is made of, so that is what is measured here
             steps, sinks, keep = [], [], []
             for i in range(S):
                 ki = pkg.AffineCoupling((D, ), odd=bool(i & 1)).to(dev).train()
@@ -191,17 +193,39 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                        ws1.data_ptr(), B, D, 1.0e-5, 0.1, 1.0e-5, st)
             wsf = torch.zeros(10, S * nws, device=dev)
             itf = [0]
+            if per_step:
+                host = ctypes.addressof(F._GLOW_FLOW_HOST[table.data_ptr()])
+                slabs_all, rec = F._glow_steps_scratch(S, (B + 127) // 128, dev)
+                N.call('nf_glow_flow_steps_fwd', host, S, z.data_ptr(), ys.data_ptr(), ld.data_ptr(), saves.data_ptr(), ws1.data_ptr(),
+                       B, D, 1, 1.0e-5, 0.1, 1.0e-5, st)
 
             def fn_flow():
                 ws = wsf[itf[0] % 10]
                 itf[0] += 1
-                if glow:
+                if per_step:
+                    N.call('nf_glow_flow_steps_bwd', host, table.data_ptr(), S, z.data_ptr(), ys.data_ptr(), gy.data_ptr(), None,
+                           gzs.data_ptr(), saves.data_ptr(), 1, ws.data_ptr(), slabs_all.data_ptr(), rec.data_ptr(), B, D, 1, 1.0e-5,
+                           1.0e-5, N.stream())
+                elif glow:
                     N.call('nf_glow_flow_vec_bwd', table.data_ptr(), S, z.data_ptr(), ys.data_ptr(), gy.data_ptr(), None,
                            gzs.data_ptr(), saves.data_ptr(), 1, ws.data_ptr(), slabs2.data_ptr(), B, D, 1, 1.0e-5, 1.0e-5, N.stream())
                 else:
                     N.call('nf_realnvp_flow_vec_bwd', table.data_ptr(), S, z.data_ptr(), ys.data_ptr(), gy.data_ptr(), None,
                            gzs.data_ptr(), saves.data_ptr(), 1, ws.data_ptr(), slabs2.data_ptr(), B, D, 1.0e-5, 1.0e-5, N.stream())
             us = graph_time_us(fn_flow, dev, per_graph=10, replays=1, reset=wsf.zero_)
+            if per_step:
+                # S launches of k_mlp_chain_bwd<1> + the one fold launch: the average over the S + 1 back-to-back launches
+                us /= S + 1
+                flop = 17 * 2 * 32 * 32 * B                      # 5 recomputed + 6 data-gradient + 6 weight-gradient 32x32 products
+                tf = flop / (us * 1e-6) / 1e12
+                return {'bound': 'mfma', 'kernel': 'k_mlp_chain_bwd<1> (whole Glow flow step, one launch, gradient fold deferred)',
+                        'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
+                        'traffic': pmc_traffic('k_mlp_chain_bwd', B), 'flop_per_launch': int(flop),
+                        'bytes_per_launch': int(B * (3 * D + 1) * 4), 'us_per_launch': round(us, 3),
+                        'note': 'average over the %d step launches + 1 k_glow_fold_all launch of a backward pass, back to back in a '
+                                'hipGraph; neither MFMA- nor HBM-bound at this batch: five grid-wide BatchNorm exchanges (~1.6 us '
+                                'each at 32 workgroups) and single-tile issue latency serialise the launch (DESIGN.md sections 2 '
+                                'and 3.11; tools/probes/mlp_chain_prof.py)' % S}
             flop = S * 17 * 2 * 32 * 32 * B
             tf = flop / (us * 1e-6) / 1e12
             name = 'k_glow_flow_bwd<%d> (backward of all %d %s flow steps, one launch)' % (1 if glow else 2, S, 'Glow' if glow else 'RealNVP')

@@ -599,6 +599,19 @@ int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* y
 int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,
                          float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2, int64_t N, int D,
                          int training, float bn_eps, float wn_eps, nf_stream_t stream);
+/* The same run of Glow steps as S single-step launches per direction (records as kernel arguments: steps_host = the HOST copy
+ * of the packed table) with a DEFERRED fold in the backward: each step's launch ends right after its data gradient, leaving
+ * its weight-gradient slabs (slabs_all: S x blocks x NF_MLP_BWD_SLAB_WG_FLOATS, blocks = ceil(N / NF_MLP_ROWS_PER_BLOCK)) and
+ * its workgroups' head sums (head_rec: S x blocks x 64) behind; ONE more launch folds every step into the parameter
+ * gradients (steps_dev = the device copy of the same table).  For batches where the whole-flow launch loses;
+ * buffers and results as nf_glow_flow_vec_*.                                                                               */
+#define NF_MLP_BWD_SLAB_WG_FLOATS (7 * 2 * 1056)
+int nf_glow_flow_steps_fwd(const void* steps_host, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
+                           int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
+int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S, const float* z0, const float* ys,
+                           const float* g_y, const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
+                           float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps, float wn_eps,
+                           nf_stream_t stream);
 /* the same for a run of RealNVP steps (nf_realnvp_step_vec_*: training-mode flow BatchNorm + AffineCoupling, flows/realnvp.py);
  * records by nf_realnvp_flow_pack (head = the 8 pointers of nf_realnvp_step_vec_fwd), saves = S x NF_REALNVP_SAVE_FLOATS.     */
 int nf_realnvp_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, float* g_s_log_scale,

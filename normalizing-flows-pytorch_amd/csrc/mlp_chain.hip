@@ -653,6 +653,7 @@ struct NfMlpG { NF_G float* v[NF_MC_NL]; NF_G float* g[NF_MC_NL]; NF_G float* b[
 static_assert(NF_MC_WAVES % 4 == 0 && NF_MLP_MAX_BLOCKS * NF_MLP_ROWS_PER_BLOCK == NF_MLP_MAX_ROWS, "geometry in include/nfhip.h");
 static_assert((NF_MC_NB + 1) * NF_MLP_MAX_BLOCKS * 64 * 2 + 64 == NF_MLP_WS_FLOATS, "exchange workspace size in include/nfhip.h");
 static_assert(NF_MC_SLAB * NF_MLP_MAX_BLOCKS == NF_MLP_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
+static_assert(NF_MC_SLAB == NF_MLP_BWD_SLAB_WG_FLOATS, "per-workgroup slab size in include/nfhip.h");
 
 // this wave's share of g_Weff[L] and g_bias[L]: output block (wid & 1, (wid >> 1) & 1) over the rows of waves 4 (wid >> 2) .. + 3
 template <int L>
@@ -813,12 +814,118 @@ __device__ __forceinline__ void nf_mc_bwd_layer(float* sm, const float (&xa)[8],
     }
 }
 
+// the column-owner fold (more than two slabs) and the head gradients, shared by the backward body (fold workgroup = the
+// workgroup itself, after the grid barrier) and by k_glow_fold_all (the deferred fold of every step of a flow in one launch):
+// unit = one column (l, i) of a weight matrix or one bias vector, owned by a half wave (lane = output index o): sums the
+// nslabs partials (coalesced), reduces <g_Weff, v> and ||v||^2 over o by shuffles, applies the weight-norm backward.  Needs
+// the staged weights / gains / head constants of nf_mc_stage in sm.
+__device__ __forceinline__ void nf_mc_fold_units(const float* sm, const float* __restrict__ slabs, int nslabs, int fb, int nfb,
+                                                 const NfMlpG& gr, int accumulate, int I0, int O_out, float wn_eps) {
+    const int o = threadIdx.x & 31;
+    const int G_ = nslabs;
+    constexpr int HW = NF_MC_THREADS / 32;                           // half waves per workgroup
+    for (int u = fb * HW + (threadIdx.x >> 5); u < NF_MC_NL * 33; u += nfb * HW) {
+        const int l = u / 33, i = u - l * 33;                    // i == 32: the bias
+        const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
+        if (i < 32 && i >= I) continue;                          // half-wave uniform
+        float tsum = 0.f;
+        {
+            const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
+            for (int b0 = 0; b0 < G_; b0 += 8) {                 // 8 NKQ independent loads in flight: one latency per trip
+                float v[8][NF_MC_NKQ];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    const int b = b0 + q8 < G_ ? b0 + q8 : G_ - 1;
+#pragma unroll
+                    for (int q = 0; q < NF_MC_NKQ; ++q) v[q8][q] = base[(size_t)b * NF_MC_SLAB + q * NF_MC_SLAB_Q];
+                }
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+                    for (int q = 0; q < NF_MC_NKQ; ++q)
+                        if (b0 + q8 < G_) tsum += v[q8][q];
+            }
+        }
+        if (i == 32) {
+            if (o < O) gr.b[l][o] = (accumulate ? gr.b[l][o] : 0.f) + tsum;
+            continue;
+        }
+        const float v = sm[NF_MC_W + l * 32 * NF_FP_ST + o * NF_FP_ST + i];
+        float n2 = v * v, dt = tsum * v;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            n2 += __shfl_xor(n2, off, NF_WAVE);
+            dt += __shfl_xor(dt, off, NF_WAVE);
+        }
+        const float nrm = sqrtf(n2), den = nrm + wn_eps, gi = sm[NF_MC_G + l * 32 + i];
+        if (o < O) {
+            float gv = tsum * (gi / den);
+            if (nrm > 0.f) gv -= v * (dt * gi / (den * den * nrm));
+            float* dst = gr.v[l] + o * I + i;
+            *dst = (accumulate ? *dst : 0.f) + gv;
+        }
+        if (o == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + dt / den;
+    }
+}
+
+// ActNorm / PLU / coupling-scalar gradients of a fused Glow (HEAD 1) or RealNVP (HEAD 2) step from the 64 grid totals of the
+// head product (hs) and the staged head constants (nf_glow_head_phase_a / _b); one thread
+template <int HEAD>
+__device__ __forceinline__ void nf_mc_head_grads(const float* sm, const NfGlowV& h, const float* head_tot, int accumulate, bool afold) {
+    constexpr bool FBN = HEAD == 2;
+    {
+        const float* hs = head_tot;
+        const int D = h.D;
+        const float sum_gld = hs[28];
+        NF_MC_ACC(h.g_a, hs[26] + hs[27]);                                           // d/d s_log_scale: sum g_s tanh(s_raw)
+        NF_MC_ACC(h.g_c, hs[24] + hs[25]);                                           // d/d s_bias
+        if (!FBN) {
+        const float* Lp = sm + NF_MC_HEAD + 32;                  // [4][4] each, staged at kernel start
+        const float* Up = sm + NF_MC_HEAD + 48;
+        const float* Pm = sm + NF_MC_HEAD + 64;
+        float A[4][4];
+        for (int r = 0; r < D; ++r) {
+            const float es = sm[NF_MC_HEAD + 16 + r];
+            NF_MC_ACC(h.g_bs + r, -hs[20 + r] / es);                                 // modules.py:246
+            NF_MC_ACC(h.g_ls + r, -hs[16 + r] - sum_gld);                            // pixels = 1
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                        // A = P^T g_W
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = fmaf(Pm[k * 4 + r], hs[4 * k + c], acc);
+                A[r][c] = acc;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float gl = 0.f, gu = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gl = fmaf(A[r][k], Up[c * 4 + k], gl);       // (A U'^T)[r][c]
+                    gu = fmaf(Lp[k * 4 + r], A[k][c], gu);       // (L'^T A)[r][c]
+                }
+                if (r < D && c < D) {
+                    const int e = r * D + c;
+                    NF_MC_ACC(h.g_L + e, gl * h.Lm[e]);
+                    NF_MC_ACC(h.g_U + e, gu * h.Um[e]);
+                    if (r == c) NF_MC_ACC(h.g_log_s + r, gu * Up[r * 4 + r] + sum_gld);
+                }
+            }
+        }
+    }
+}
+
 template <int HEAD>
 __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restrict__ x, const NfMlpP& p, const float* __restrict__ save,
                                                const float* __restrict__ g_out, float* __restrict__ g_x, const NfMlpG& gr,
                                                int accumulate, float* ws, float* __restrict__ slabs, int64_t N, int I0, int O_out,
                                                int training, float eps, float wn_eps, const NfGlowV& h, const float* hz,
-                                               const float* hgy, const float* hgld, float* hgz, NfMcCarry* carry = nullptr) {
+                                               const float* hgy, const float* hgld, float* hgz, NfMcCarry* carry = nullptr,
+                                               float* head_rec = nullptr) {
     constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;
     NF_MC_T(64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
@@ -992,9 +1099,22 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
     // repeats the whole fold instead of a 1/G share and the shared addresses contend: measured 1.72 -> 1.88 ms at 8 and
     // 1.90 -> 2.13 ms at 32 workgroups, so the barrier + owner fold below stays there.  The atomic order varies: gradients
     // repeat to ~1e-7.
-    const bool afold = accumulate != 0 && gridDim.x <= NF_MC_AFOLD_MAX_BLOCKS;
+    // Deferred fold (head_rec != nullptr, a run of steps launched one by one: nf_glow_flow_steps_bwd): the grid barrier and the
+    // fold are the only part of a step nothing downstream waits for, yet they sit on the critical path of its launch (6.4 us
+    // of ~27 at 32 workgroups).  The workgroup leaves its slab and its 64 head sums in memory and ends; ONE launch after the
+    // last step folds every step of the run at once (k_glow_fold_all).
+    const bool defer = GLOW && head_rec != nullptr;
+    const bool afold = !defer && accumulate != 0 && gridDim.x <= NF_MC_AFOLD_MAX_BLOCKS;
     const float* head_tot = nullptr;
-    if (afold) {
+    if (defer) {
+        __syncthreads();                                  // red rows of the head product
+        if (threadIdx.x < 64) {
+            float mine = 0.f;
+#pragma unroll
+            for (int w = 0; w < NF_MC_WAVES; ++w) mine += sm[NF_MC_RED + w * 64 + threadIdx.x];
+            head_rec[(size_t)blockIdx.x * 64 + threadIdx.x] = mine;
+        }
+    } else if (afold) {
         __syncthreads();                                  // red rows of the head product / the tiles are complete
         if (GLOW && threadIdx.x < 64) {
             float mine = 0.f;
@@ -1018,8 +1138,7 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
     NF_MC_T(73);
     // unit = one column (l, i) of a weight matrix or one bias vector, owned by a half wave (lane = output index o): sums the
     // partials (coalesced), reduces <g_Weff, v> and ||v||^2 over o by shuffles, applies the weight-norm backward.  No LDS.
-    {
-        const int o = threadIdx.x & 31;
+    if (!defer) {
         const int G_ = afold ? 1 : (int)gridDim.x, blk = afold ? 0 : (int)blockIdx.x;
         const float* sl_base = afold ? slabs + (size_t)blockIdx.x * NF_MC_SLAB : slabs;
         constexpr int HW = NF_MC_THREADS / 32;                       // half waves per workgroup
@@ -1087,93 +1206,10 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
                 if (oo == 0) NF_MC_ACC(gr.g[l] + i, nd[sl * 96 + 64 + i]);
             }
         }
-        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); G_ > 2 && u < NF_MC_NL * 33; u += G_ * HW) {
-            const int l = u / 33, i = u - l * 33;                    // i == 32: the bias
-            const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
-            if (i < 32 && i >= I) continue;                          // half-wave uniform
-            float tsum = 0.f;
-            {
-                const float* base = slabs + (size_t)l * NF_MC_SLAB_L + i * 32 + o;
-                for (int b0 = 0; b0 < G_; b0 += 8) {                 // 8 NKQ independent loads in flight: one latency per trip
-                    float v[8][NF_MC_NKQ];
-#pragma unroll
-                    for (int q8 = 0; q8 < 8; ++q8) {
-                        const int b = b0 + q8 < G_ ? b0 + q8 : G_ - 1;
-#pragma unroll
-                        for (int q = 0; q < NF_MC_NKQ; ++q) v[q8][q] = base[(size_t)b * NF_MC_SLAB + q * NF_MC_SLAB_Q];
-                    }
-#pragma unroll
-                    for (int q8 = 0; q8 < 8; ++q8)
-#pragma unroll
-                        for (int q = 0; q < NF_MC_NKQ; ++q)
-                            if (b0 + q8 < G_) tsum += v[q8][q];
-                }
-            }
-            if (i == 32) {
-                if (o < O) gr.b[l][o] = (accumulate ? gr.b[l][o] : 0.f) + tsum;
-                continue;
-            }
-            const float v = sm[NF_MC_W + l * 32 * NF_FP_ST + o * NF_FP_ST + i];
-            float n2 = v * v, dt = tsum * v;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) {
-                n2 += __shfl_xor(n2, off, NF_WAVE);
-                dt += __shfl_xor(dt, off, NF_WAVE);
-            }
-            const float nrm = sqrtf(n2), den = nrm + wn_eps, gi = sm[NF_MC_G + l * 32 + i];
-            if (o < O) {
-                float gv = tsum * (gi / den);
-                if (nrm > 0.f) gv -= v * (dt * gi / (den * den * nrm));
-                float* dst = gr.v[l] + o * I + i;
-                *dst = (accumulate ? *dst : 0.f) + gv;
-            }
-            if (o == 0) gr.g[l][i] = (accumulate ? gr.g[l][i] : 0.f) + dt / den;
-        }
+        if (G_ > 2) nf_mc_fold_units(sm, slabs, G_, (int)blockIdx.x, G_, gr, accumulate, I0, O_out, wn_eps);
     }
-    if (GLOW && (afold || blockIdx.x == gridDim.x - 1) && threadIdx.x == NF_MC_THREADS - 1) {   // ActNorm, PLU, coupling scalars
-        const float* hs = head_tot;
-        const int D = h.D;
-        const float sum_gld = hs[28];
-        NF_MC_ACC(h.g_a, hs[26] + hs[27]);                                           // d/d s_log_scale: sum g_s tanh(s_raw)
-        NF_MC_ACC(h.g_c, hs[24] + hs[25]);                                           // d/d s_bias
-        if (!FBN) {
-        const float* Lp = sm + NF_MC_HEAD + 32;                  // [4][4] each, staged at kernel start
-        const float* Up = sm + NF_MC_HEAD + 48;
-        const float* Pm = sm + NF_MC_HEAD + 64;
-        float A[4][4];
-        for (int r = 0; r < D; ++r) {
-            const float es = sm[NF_MC_HEAD + 16 + r];
-            NF_MC_ACC(h.g_bs + r, -hs[20 + r] / es);                                 // modules.py:246
-            NF_MC_ACC(h.g_ls + r, -hs[16 + r] - sum_gld);                            // pixels = 1
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {                        // A = P^T g_W
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc = fmaf(Pm[k * 4 + r], hs[4 * k + c], acc);
-                A[r][c] = acc;
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float gl = 0.f, gu = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    gl = fmaf(A[r][k], Up[c * 4 + k], gl);       // (A U'^T)[r][c]
-                    gu = fmaf(Lp[k * 4 + r], A[k][c], gu);       // (L'^T A)[r][c]
-                }
-                if (r < D && c < D) {
-                    const int e = r * D + c;
-                    NF_MC_ACC(h.g_L + e, gl * h.Lm[e]);
-                    NF_MC_ACC(h.g_U + e, gu * h.Um[e]);
-                    if (r == c) NF_MC_ACC(h.g_log_s + r, gu * Up[r * 4 + r] + sum_gld);
-                }
-            }
-        }
-    }
+    if (!defer && GLOW && (afold || blockIdx.x == gridDim.x - 1) && threadIdx.x == NF_MC_THREADS - 1)
+        nf_mc_head_grads<HEAD>(sm, h, head_tot, accumulate, afold);
     if (blockIdx.x == 0 && threadIdx.x < NF_MC_NB * 32) {
         const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
         gr.beta[j][k] = (accumulate ? gr.beta[j][k] : 0.f) + sm[NF_MC_GB + j * 64 + k];
@@ -1186,10 +1222,11 @@ template <int HEAD>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_bwd(const float* __restrict__ x, NfMlpP p, const float* __restrict__ save,
                                                                  const float* __restrict__ g_out, float* __restrict__ g_x, NfMlpG gr,
                                                                  int accumulate, float* ws, float* __restrict__ slabs, int64_t N,
-                                                                 int I0, int O_out, int training, float eps, float wn_eps, NfGlowV h) {
+                                                                 int I0, int O_out, int training, float eps, float wn_eps, NfGlowV h,
+                                                                 float* head_rec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     nf_mc_bwd_body<HEAD>(sm, x, p, save, g_out, g_x, gr, accumulate, ws, slabs, N, I0, O_out, training, eps, wn_eps, h, h.z, h.g_y,
-                         h.g_ld, h.g_z);
+                         h.g_ld, h.g_z, nullptr, head_rec);
 }
 
 extern "C" int nf_mlp_chain_bwd(const float* x, const void* const* params, const float* save_stats, const float* g_out, float* g_x,
@@ -1213,7 +1250,7 @@ extern "C" int nf_mlp_chain_bwd(const float* x, const void* const* params, const
         attr_set = true;
     }
     hipLaunchKernelGGL(k_mlp_chain_bwd<0>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, x, p, save_stats, g_out,
-                       g_x, g, accumulate, ws_zero, slabs, N, I0, O_out, training, bn_eps, wn_eps, NfGlowV{});
+                       g_x, g, accumulate, ws_zero, slabs, N, I0, O_out, training, bn_eps, wn_eps, NfGlowV{}, (float*)nullptr);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -1276,7 +1313,7 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
     }
     hipLaunchKernelGGL(k_mlp_chain_bwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
                        save_stats, (const float*)nullptr, (float*)nullptr, g, accumulate, ws_zero, slabs, N, D / 2, D, training, bn_eps,
-                       wn_eps, h);
+                       wn_eps, h, (float*)nullptr);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -1444,6 +1481,96 @@ extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z
                                  training, bn_eps, wn_eps, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same run of Glow steps as S launches per direction + ONE fold launch, for batches where the whole-flow kernel's
+// in-kernel exchanges lose against the launch gaps (32 workgroups and up): the single-step kernels with the records of
+// nf_glow_flow_pack as kernel arguments (host copy of the table), the backward in deferred-fold mode -- every step leaves
+// its weight-gradient slabs (own region per step) and its workgroups' head sums behind, k_glow_fold_all turns all of
+// them into parameter gradients at once: grid (NF_GF_FOLD_BLOCKS, S), one column / bias vector per half wave.
+// ---------------------------------------------------------------------------------------------------------------
+#define NF_GF_FOLD_BLOCKS ((NF_MC_NL * 33 + NF_MC_THREADS / 32 - 1) / (NF_MC_THREADS / 32))
+
+__global__ void __launch_bounds__(NF_MC_THREADS) k_glow_fold_all(const NfGlowFlowStep* __restrict__ steps, const float* __restrict__ slabs,
+                                                                 const float* __restrict__ head_rec, int G, int accumulate, int D,
+                                                                 float wn_eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int s = blockIdx.y;
+    const NfGlowFlowStep& st = steps[s];                 // block-uniform: scalar loads
+    const bool last = blockIdx.x == gridDim.x - 1;       // the head gradients' workgroup
+    NfGlowRaw raw;
+    nf_glow_head_load(st.h, raw);
+    float hsum = 0.f;
+    if (last && threadIdx.x < 64) {
+        const float* r = head_rec + (size_t)s * G * 64 + threadIdx.x;
+        for (int b = 0; b < G; ++b) hsum += r[(size_t)b * 64];
+    }
+    nf_mc_stage(st.p, sm, D / 2, D, wn_eps, &st.h, &raw);
+    if (last && threadIdx.x < 64) sm[NF_MC_TOT + threadIdx.x] = hsum;
+    __syncthreads();
+    nf_mc_fold_units(sm, slabs + (size_t)s * G * NF_MC_SLAB, G, (int)blockIdx.x, (int)gridDim.x, st.g, accumulate, D / 2, D, wn_eps);
+    const bool afold = false;
+    (void)afold;
+    if (last && threadIdx.x == NF_MC_THREADS - 1) nf_mc_head_grads<1>(sm, st.h, sm + NF_MC_TOT, accumulate, false);
+}
+
+extern "C" int nf_glow_flow_steps_fwd(const void* steps_host, int S, const float* z0, float* ys, float* ld, float* saves,
+                                      float* ws_zero, int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                                      nf_stream_t stream) {
+    if (steps_host == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr || ld == nullptr ||
+        saves == nullptr || ws_zero == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(1);
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const NfGlowFlowStep* st = reinterpret_cast<const NfGlowFlowStep*>(steps_host);
+    const int64_t ND = N * D;
+    for (int s = 0; s < S; ++s) {
+        NfGlowV h = st[s].h;
+        h.z = s == 0 ? z0 : ys + (int64_t)(s - 1) * ND; h.y = ys + (int64_t)s * ND; h.ld = ld;
+        hipLaunchKernelGGL(k_mlp_chain_fwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, st[s].p,
+                           (float*)nullptr, saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, ws_zero + (int64_t)s * NF_MLP_WS_FLOATS, N, D / 2,
+                           D, training, bn_eps, bn_momentum, wn_eps, h);
+    }
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S, const float* z0, const float* ys,
+                                      const float* g_y, const float* g_ld, float* gzs, const float* saves, int accumulate,
+                                      float* ws_zero, float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps,
+                                      float wn_eps, nf_stream_t stream) {
+    if (steps_host == nullptr || steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr ||
+        g_y == nullptr || gzs == nullptr || saves == nullptr || ws_zero == nullptr || slabs_all == nullptr || head_rec == nullptr ||
+        !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(3), lds_fold = nf_mc_lds_bytes(1);
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)k_glow_fold_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fold);
+    if (e != hipSuccess) return (int)e;
+    const NfGlowFlowStep* st = reinterpret_cast<const NfGlowFlowStep*>(steps_host);
+    const int64_t ND = N * D;
+    for (int s = S - 1; s >= 0; --s) {
+        NfGlowV h = st[s].h;
+        h.z = s == 0 ? z0 : ys + (int64_t)(s - 1) * ND;
+        h.g_y = s == S - 1 ? g_y : gzs + (int64_t)(s + 1) * ND;
+        h.g_ld = g_ld;
+        h.g_z = gzs + (int64_t)s * ND;
+        hipLaunchKernelGGL(k_mlp_chain_bwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, st[s].p,
+                           saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, (const float*)nullptr, (float*)nullptr, st[s].g, accumulate,
+                           ws_zero + (int64_t)s * NF_MLP_WS_FLOATS, slabs_all + (size_t)s * grid * NF_MC_SLAB, N, D / 2, D, training,
+                           bn_eps, wn_eps, h, head_rec + (size_t)s * grid * 64);
+    }
+    hipLaunchKernelGGL(k_glow_fold_all, dim3(NF_GF_FOLD_BLOCKS, S), dim3(NF_MC_THREADS), lds_fold, (hipStream_t)stream,
+                       (const NfGlowFlowStep*)steps_dev, slabs_all, head_rec, (int)grid, accumulate, D, wn_eps);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
 // the same for a run of RealNVP steps [flow BatchNorm (batch statistics), AffineCoupling]: records packed by nf_realnvp_flow_pack
 extern "C" int nf_realnvp_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, float* g_s_log_scale,
                                     float* g_s_bias, void* const* mlp_grads, int D, int odd, float flow_bn_eps,
@@ -1539,7 +1666,7 @@ extern "C" int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const f
     }
     hipLaunchKernelGGL(k_mlp_chain_bwd<2>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
                        save_stats, (const float*)nullptr, (float*)nullptr, g, accumulate, ws_zero, slabs, N, D / 2, D, 1, bn_eps,
-                       wn_eps, h);
+                       wn_eps, h, (float*)nullptr);
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -652,8 +652,24 @@ import os as _os
 # gaps they replace (B = 4096: 1.91 -> 1.94 ms, B = 16384: 3.05 -> 3.66 ms), DESIGN.md section 3.11.  '1' / '0' force it.
 GLOW_FLOW = _os.environ.get('NF_GLOW_FLOW', 'auto')
 GLOW_FLOW_AUTO_ROWS = 1024
+# larger batches: the same run as ONE autograd node of S single-step launches per direction whose backward defers every
+# step's grid barrier + gradient fold to one launch at the end (nf_glow_flow_steps_*; C2 at B = 2048 / 4096 / 16384:
+# 1.77 -> 1.63 / 1.88 -> 1.71 / 3.02 -> 2.50 ms per train step)
+GLOW_FLOW_STEPS = _os.environ.get('NF_GLOW_FLOW_STEPS', '1') != '0'
 _GLOW_FLOW_TABLES = {}
+_GLOW_FLOW_HOST = {}          # device table pointer -> the host copy of the same records
 _GLOW_FLOW_SLABS = {}
+
+
+def _glow_steps_scratch(S, blocks, device):
+    """(slabs_all, head_rec) of the deferred fold: a slab region per step and workgroup, kept across calls."""
+    key = ('steps', device)
+    n = S * blocks * N.header_constant('NF_MLP_BWD_SLAB_WG_FLOATS')
+    t = _GLOW_FLOW_SLABS.get(key)
+    if t is None or t[0].numel() < n or t[1].numel() < S * blocks * 64:
+        t = _GLOW_FLOW_SLABS[key] = (torch.empty(n, dtype=torch.float32, device=device),
+                                     torch.empty(S * blocks * 64, dtype=torch.float32, device=device))
+    return t
 
 
 def _glow_flow_slabs(device):
@@ -695,7 +711,9 @@ def _glow_flow_table(steps, sinks, D, device):
     table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
     if len(_GLOW_FLOW_TABLES) > 64:
         _GLOW_FLOW_TABLES.clear()
+        _GLOW_FLOW_HOST.clear()
     _GLOW_FLOW_TABLES[key] = table
+    _GLOW_FLOW_HOST[table.data_ptr()] = host
     return table
 
 
@@ -705,7 +723,7 @@ class _GlowFlowVec(torch.autograd.Function):
     a GradBucket (the Compose peephole checks)."""
 
     @staticmethod
-    def forward(ctx, z, ld, odds, training, *tensors):
+    def forward(ctx, z, ld, odds, training, per_step, *tensors):
         S = len(odds)
         per = 11 + 43
         steps = [(odds[i], tensors[per * i:per * i + 11], tensors[per * i + 11:per * (i + 1)]) for i in range(S)]
@@ -720,16 +738,20 @@ class _GlowFlowVec(torch.autograd.Function):
         ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
         saves = torch.empty(S, N.header_constant('NF_GLOW_FLOW_SAVE_FLOATS'), dtype=torch.float32, device=dev)
         ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
-        N.call('nf_glow_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
-               int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        if per_step:
+            N.call('nf_glow_flow_steps_fwd', ctypes.addressof(_GLOW_FLOW_HOST[table.data_ptr()]), S, N.ptr(z), N.ptr(ys), N.ptr(ld),
+                   N.ptr(saves), N.ptr(ws), Nrows, D, int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        else:
+            N.call('nf_glow_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
+                   int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
         ctx.save_for_backward(z, ys, saves, table)
-        ctx.meta = (S, bool(training), len(tensors))
+        ctx.meta = (S, bool(training), len(tensors), bool(per_step))
         ctx.mark_dirty(ld)
         return ys[S - 1], ld
 
     @staticmethod
     def backward(ctx, g_y, g_ld):
-        S, training, n_tensors = ctx.meta
+        S, training, n_tensors, per_step = ctx.meta
         z, ys, saves, table = ctx.saved_tensors
         Nrows, D = z.shape
         dev = z.device
@@ -737,15 +759,22 @@ class _GlowFlowVec(torch.autograd.Function):
         g_ld = None if g_ld is None else g_ld.contiguous()
         gzs = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
         ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
-        N.call('nf_glow_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves), 1,
-               N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, int(training), BN_EPS, WN_EPS, N.stream())
-        return (gzs[0], g_ld, None, None) + (None, ) * n_tensors
+        if per_step:
+            rpb = N.header_constant('NF_MLP_ROWS_PER_BLOCK')
+            slabs, rec = _glow_steps_scratch(S, (Nrows + rpb - 1) // rpb, dev)
+            N.call('nf_glow_flow_steps_bwd', ctypes.addressof(_GLOW_FLOW_HOST[table.data_ptr()]), table.data_ptr(), S, N.ptr(z),
+                   N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D,
+                   int(training), BN_EPS, WN_EPS, N.stream())
+        else:
+            N.call('nf_glow_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves),
+                   1, N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, int(training), BN_EPS, WN_EPS, N.stream())
+        return (gzs[0], g_ld, None, None, None) + (None, ) * n_tensors
 
 
 def glow_flow_vec_usable(z, steps):
     """steps: [(actnorm, conv, coupling)] -- at least two fused-step-capable steps whose parameters all have direct sinks."""
     from .functional import grad_sink
-    on = GLOW_FLOW is True or GLOW_FLOW == '1' or (GLOW_FLOW == 'auto' and z.shape[0] <= GLOW_FLOW_AUTO_ROWS)
+    on = _flow_on(z) or _glow_steps_on(z)
     if not on or len(steps) < 2 or len(steps) > N.header_constant('NF_GLOW_FLOW_MAX_STEPS') or not torch.is_grad_enabled():
         return False
     for a, c, k in steps:
@@ -764,7 +793,7 @@ def glow_flow_vec(z, ld, steps):
         tensors += [a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale, k.s_bias]
         tensors += _mlp_tensors(k.net)
     odds = tuple(int(k.odd) for _, _, k in steps)
-    return _GlowFlowVec.apply(z, _owned_ld(ld), odds, steps[0][2].net.training, *tensors)
+    return _GlowFlowVec.apply(z, _owned_ld(ld), odds, steps[0][2].net.training, not _flow_on(z), *tensors)
 
 
 def _realnvp_step_learnables(head, mlp):
@@ -836,6 +865,14 @@ class _RealNVPFlowVec(torch.autograd.Function):
 
 def _flow_on(z):
     return GLOW_FLOW is True or GLOW_FLOW == '1' or (GLOW_FLOW == 'auto' and z.shape[0] <= GLOW_FLOW_AUTO_ROWS)
+
+
+def _glow_steps_on(z):
+    """per-step launches + deferred fold: where the whole-flow launch is off and the slabs are more than two (the atomic fold
+    of one or two workgroups has no barrier to defer)."""
+    if z.shape[0] <= 2 * N.header_constant('NF_MLP_ROWS_PER_BLOCK'):
+        return False
+    return GLOW_FLOW == 'steps' or (GLOW_FLOW == 'auto' and GLOW_FLOW_STEPS and not _flow_on(z))
 
 
 def realnvp_flow_vec_usable(z, steps):

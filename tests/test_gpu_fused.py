@@ -487,10 +487,13 @@ def test_realnvp_step_vec_vs_unfused(pkg, D, odd, N, direct):
         G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
 
 
+@pytest.mark.parametrize('mode', [True, 'steps'])
 @pytest.mark.parametrize('D,B,K', [(2, 4096, 8), (2, 300, 3), (4, 1000, 4), (2, 16384, 2)])
-def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
-    """the whole run of vector Glow steps in one launch per direction (k_glow_flow_fwd / _bwd) against the same steps
-    launched one by one: outputs, log-det, every gradient in the flat bucket, BatchNorm running statistics."""
+def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
+    """the whole run of vector Glow steps as one autograd node -- one launch per direction (k_glow_flow_fwd / _bwd, mode True)
+    or one launch per step with the gradient folds of all steps deferred to one launch (nf_glow_flow_steps_*, mode 'steps')
+    -- against the same steps launched one by one: outputs, log-det, every gradient in the flat bucket, BatchNorm running
+    statistics."""
     from types import SimpleNamespace as NS
     train = importlib.import_module(pkg.__name__ + '.train')
     fused = importlib.import_module(pkg.__name__ + '.fused')
@@ -501,7 +504,7 @@ def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
     t1, t2 = train.FlowTrainer(net1, graph=False), train.FlowTrainer(net2, graph=False)
     calls = {'n': 0}
     real = fused.glow_flow_vec
-    monkeypatch.setattr(fused, 'GLOW_FLOW', True)           # opt-in path (NF_GLOW_FLOW=1)
+    monkeypatch.setattr(fused, 'GLOW_FLOW', mode)           # opt-in paths (NF_GLOW_FLOW=1 / =steps)
 
     def counted(*a, **k):
         calls['n'] += 1
@@ -517,7 +520,7 @@ def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
         t2.net.train()
         z2, l2 = t2._forward_backward(y)
         monkeypatch.undo()
-        monkeypatch.setattr(fused, 'GLOW_FLOW', True)
+        monkeypatch.setattr(fused, 'GLOW_FLOW', mode)
         G.assert_close(z1, z2, 2e-5, rtol=2e-5, what='z, step %d' % step)
         G.assert_close(l1, l2, 2e-5, rtol=2e-5, what='loss, step %d' % step)
         scale = float(t2.bucket.flat.abs().max())
