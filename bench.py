@@ -283,20 +283,45 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         gtab = F._ptr_table(dst)
         ga, gc, gz = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.empty_like(z)
         slabs = F._maf_slabs(dev)
-        wss = torch.zeros(32, nws, device=dev)                  # a fresh zero workspace per launch inside the timing graph
+        S = int(cfg['layers'])
+        nwss = max(32, 2 * S)
+        wss = torch.zeros(nwss, nws, device=dev)                # a fresh zero workspace per launch inside the timing graph
         it = [0]
 
+        deferred = F.MAF_FLOW and S >= 2        # the train step runs the steps in deferred-fold mode (fused.maf_flow_vec)
+        if deferred:
+            slabs_all, rec = F._maf_steps_scratch(S, (B + 127) // 128, dev)
+            nsl = ((B + 127) // 128) * N.header_constant('NF_MAF_SLAB_WG_FLOATS')
+            nrec = ((B + 127) // 128) * N.header_constant('NF_MAF_HEAD_REC_WG')
+            pm, pg = F._ptr_table([t.detach() for t in made] * S), F._ptr_table(dst * S)
+            pa, pc = F._ptr_table([ga] * S), F._ptr_table([gc] * S)
+
         def fn():
-            ws = wss[it[0] % 32]
+            ws = wss[it[0] % nwss]
+            i = it[0] % S
             it[0] += 1
+            if deferred:
+                N.call('nf_maf_step_bwd_partial', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
+                       ctypes.addressof(mtab), save.data_ptr(), ctypes.addressof(gtab), ws.data_ptr(),
+                       slabs_all.data_ptr() + 4 * i * nsl, rec.data_ptr() + 4 * i * nrec, B, D, N.stream())
+                if i == S - 1:
+                    N.call('nf_maf_fold_all', ctypes.addressof(pm), ctypes.addressof(pg), ctypes.addressof(pa), ctypes.addressof(pc), S,
+                           slabs_all.data_ptr(), rec.data_ptr(), (B + 127) // 128, D, N.stream())
+                return
             N.call('nf_maf_step_bwd', z.data_ptr(), gy.data_ptr(), None, gz.data_ptr(), ctypes.addressof(htab),
                    ctypes.addressof(mtab), save.data_ptr(), ctypes.addressof(gtab), ga.data_ptr(), gc.data_ptr(), ws.data_ptr(),
                    slabs.data_ptr(), B, D, N.stream())
-        us = graph_time_us(fn, dev, per_graph=25, replays=1, reset=wss.zero_)
+        if deferred:                                             # 2 backward passes: 2 S step launches + 2 fold launches
+            us = graph_time_us(fn, dev, per_graph=2 * S, replays=1, reset=wss.zero_) * (2 * S) / (2 * S + 2)
+        else:
+            us = graph_time_us(fn, dev, per_graph=25, replays=1, reset=wss.zero_)
         mac = 2 * 3 * (32 * D + 1024 + 1024 + 32 * D)           # two nets x (recompute + data + weight gradients)
         flop = 2 * mac * B
         tf = flop / (us * 1e-6) / 1e12
-        return {'bound': 'mfma', 'kernel': 'k_maf_step_bwd (whole MAF flow step, one launch)', 'achieved': round(tf, 3),
+        name = 'k_maf_step_bwd (whole MAF flow step, one launch%s)' % (
+            '; gradient fold deferred: average over the %d step launches + 1 k_maf_fold_all launch of a backward pass' % S if deferred
+            else '')
+        return {'bound': 'mfma', 'kernel': name, 'achieved': round(tf, 3),
                 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': pmc_traffic('k_maf_step_bwd', B),
                 'flop_per_launch': int(flop), 'bytes_per_launch': int(B * (3 * D + 1) * 4), 'us_per_launch': round(us, 3),
                 'note': 'neither MFMA- nor HBM-bound at this batch: four grid-wide BatchNorm exchanges over 128 workgroups '

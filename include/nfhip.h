@@ -555,6 +555,22 @@ int nf_maf_step_fwd(const float* z, float* y, float* ld, const void* const* head
 int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
                     const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
                     float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream);
+/* Deferred fold for a flow of S such steps (flows/maf.py stacks them): nf_maf_step_bwd_partial is nf_maf_step_bwd without its
+ * last two phases (the fenced grid exchange and the fold of the weight-gradient slabs) -- g_z and the BatchNorm1d gamma / beta
+ * gradients are complete on return, the step's slabs (slabs_step: blocks x NF_MAF_SLAB_WG_FLOATS, blocks = ceil(N /
+ * NF_MAF_ROWS_PER_BLOCK), a region of its own per step) and scalar sums (head_rec_step: blocks x NF_MAF_HEAD_REC_WG floats) stay
+ * behind.  nf_maf_fold_all then ACCUMULATES the weight / bias / s_log_scale / s_bias gradients of all S steps in one launch
+ * (per 16 steps): made_params_all = S x NF_MAF_PARAM_PTRS and made_grads_all = S x NF_MAF_GRAD_PTRS pointers (host arrays, the
+ * steps' tables back to back), g_s_log_scale_all / g_s_bias_all = S pointers each; slabs_all / head_rec_all = the S regions
+ * back to back, in the same step order.                                                                                    */
+#define NF_MAF_SLAB_WG_FLOATS (2 * 4 * 2 * 1056)
+#define NF_MAF_HEAD_REC_WG 16
+int nf_maf_step_bwd_partial(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                            const void* const* made_params, const float* save_stats, void* const* made_grads, float* ws_zero,
+                            float* slabs_step, float* head_rec_step, int64_t N, int D, nf_stream_t stream);
+int nf_maf_fold_all(const void* const* made_params_all, void* const* made_grads_all, float* const* g_s_log_scale_all,
+                    float* const* g_s_bias_all, int S, const float* slabs_all, const float* head_rec_all, int blocks, int D,
+                    nf_stream_t stream);
 
 /* ---- the whole backward of one Flow++ density flow step on (N, 2) data, K <= 8 -------------------------------------------
  * = nf_flowpp_vec_couple_bwd (or nf_mixlog_coupling_bwd when next_* are NULL) followed by nf_flowpp_cond_bwd on the

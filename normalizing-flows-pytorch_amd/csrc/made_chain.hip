@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
 #define NF_MD_SLAB_Q 1056
 #define NF_MD_SLAB_L (NF_MD_NKQ * NF_MD_SLAB_Q)
 #define NF_MD_SLAB (2 * NF_MD_NL * NF_MD_SLAB_L)
+static_assert(NF_MD_SLAB == NF_MAF_SLAB_WG_FLOATS && NF_MD_WAVES * 2 == NF_MAF_HEAD_REC_WG, "per-workgroup sizes in include/nfhip.h");
 static_assert(NF_MD_SLAB * NF_MAF_MAX_BLOCKS == NF_MAF_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
 static_assert((NF_MD_ROUNDS * NF_MAF_MAX_BLOCKS * NF_MD_XW + NF_MD_ROUNDS * NF_MD_MAX_GROUPS * NF_MD_XW) * 2 + 64 == NF_MAF_WS_FLOATS,
               "exchange workspace size in include/nfhip.h");
@@ -557,7 +558,8 @@ __device__ __forceinline__ void nf_md_bwd_layer(float* sm, const float (&xa)[8],
 }
 
 __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_bwd(NfMadeP p, NfMafV h, const float* __restrict__ save, NfMadeG gr,
-                                                                float* ws, float* __restrict__ slabs, int64_t N) {
+                                                                float* ws, float* __restrict__ slabs, int64_t N,
+                                                                float* __restrict__ head_rec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MD_WAVES + wid) * 16 + c16;
@@ -649,53 +651,65 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_bwd(NfMadeP p, NfMaf
             }
         }
     }
-    // ---- final exchange: the two scalar sums, and (fenced) the grid barrier in front of the fold -----------------------------------
-    {
-        float* red = sm + NF_MD_RED + wid * NF_MD_XW;
+    // Deferred fold (head_rec != nullptr: nf_maf_step_bwd_partial): nothing downstream of this launch waits for the parameter
+    // gradients, yet the fenced exchange + fold below end every launch (and at 128 workgroups they are its slowest phases).
+    // Every wave leaves its two scalar sums, the workgroup its slab; k_maf_fold_all folds all steps of a flow in one launch.
+    const float* htot = nullptr;
+    if (head_rec != nullptr) {
         const float s0 = nf_wave_sum(sum_gsv), s1 = nf_wave_sum(sum_gsvth);
-        __syncthreads();                                  // the last weight-gradient jobs are done with RED? (RED is not theirs) -- tiles
-        red[lane] = 0.f; red[64 + lane] = 0.f;
-        nf_fp_wsync();
-        if (lane == 0) { red[0] = s0; red[1] = s1; }
+        if (lane == 0) {
+            head_rec[((size_t)blockIdx.x * NF_MD_WAVES + wid) * 2 + 0] = s0;
+            head_rec[((size_t)blockIdx.x * NF_MD_WAVES + wid) * 2 + 1] = s1;
+        }
+    } else {
+        // ---- final exchange: the two scalar sums, and (fenced) the grid barrier in front of the fold -----------------------------------
+        {
+            float* red = sm + NF_MD_RED + wid * NF_MD_XW;
+            const float s0 = nf_wave_sum(sum_gsv), s1 = nf_wave_sum(sum_gsvth);
+            __syncthreads();                                  // the last weight-gradient jobs are done with RED? (RED is not theirs) -- tiles
+            red[lane] = 0.f; red[64 + lane] = 0.f;
+            nf_fp_wsync();
+            if (lane == 0) { red[0] = s0; red[1] = s1; }
+            __syncthreads();
+            if (threadIdx.x == 0) __threadfence();            // release: the slabs of every wave (cumulative through the barrier)
+        }
+        nf_md_publish(sm, slots, NF_MD_NB, (unsigned)(NF_MD_NB + 1));
+        htot = nf_md_collect(sm, slots, NF_MD_NB, (unsigned)(NF_MD_NB + 1));
+        if (threadIdx.x == 0) __threadfence();                // acquire
         __syncthreads();
-        if (threadIdx.x == 0) __threadfence();            // release: the slabs of every wave (cumulative through the barrier)
-    }
-    nf_md_publish(sm, slots, NF_MD_NB, (unsigned)(NF_MD_NB + 1));
-    const float* htot = nf_md_collect(sm, slots, NF_MD_NB, (unsigned)(NF_MD_NB + 1));
-    if (threadIdx.x == 0) __threadfence();                // acquire
-    __syncthreads();
-    // ---- fold: half wave per (net, layer, column | bias, eighth of the workgroups); partial sums meet by atomics ---------------------
-    {
-        const int o = threadIdx.x & 31;
-        const int G_ = gridDim.x;
-        const int chunk = (G_ + 7) / 8;
-        constexpr int HW = NF_MD_THREADS / 32;
-        for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * 8; u += G_ * HW) {
-            const int part = u & 7, uu = u >> 3;
-            const int nl = uu / 33, i = uu - nl * 33;     // i == 32: the bias
-            const int n = nl >> 2, l = nl & 3;
-            const int I = l == 0 ? D : 32, O = l == NF_MD_NL - 1 ? D : 32;
-            const int b_lo = part * chunk, b_hi = min(G_, b_lo + chunk);
-            if ((i < 32 && i >= I) || b_lo >= b_hi) continue;
-            float tsum = 0.f;
-            const float* base = slabs + (size_t)nl * NF_MD_SLAB_L + i * 32 + o;
-            for (int b0 = b_lo; b0 < b_hi; b0 += 8) {
-                float v[8][NF_MD_NKQ];
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) {
-                    const int b = b0 + q8 < b_hi ? b0 + q8 : b_hi - 1;
-#pragma unroll
-                    for (int q = 0; q < NF_MD_NKQ; ++q) v[q8][q] = base[(size_t)b * NF_MD_SLAB + q * NF_MD_SLAB_Q];
+        // ---- fold: half wave per (net, layer, column | bias, eighth of the workgroups); partial sums meet by atomics ---------------------
+        {
+            const int o = threadIdx.x & 31;
+            const int G_ = gridDim.x;
+            const int chunk = (G_ + 7) / 8;
+            constexpr int HW = NF_MD_THREADS / 32;
+            for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * 8; u += G_ * HW) {
+                const int part = u & 7, uu = u >> 3;
+                const int nl = uu / 33, i = uu - nl * 33;     // i == 32: the bias
+                const int n = nl >> 2, l = nl & 3;
+                const int I = l == 0 ? D : 32, O = l == NF_MD_NL - 1 ? D : 32;
+                const int b_lo = part * chunk, b_hi = min(G_, b_lo + chunk);
+                if ((i < 32 && i >= I) || b_lo >= b_hi) continue;
+                float tsum = 0.f;
+                const float* base = slabs + (size_t)nl * NF_MD_SLAB_L + i * 32 + o;
+                for (int b0 = b_lo; b0 < b_hi; b0 += 8) {
+                    float v[8][NF_MD_NKQ];
+    #pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) {
+                        const int b = b0 + q8 < b_hi ? b0 + q8 : b_hi - 1;
+    #pragma unroll
+                        for (int q = 0; q < NF_MD_NKQ; ++q) v[q8][q] = base[(size_t)b * NF_MD_SLAB + q * NF_MD_SLAB_Q];
+                    }
+    #pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8)
+    #pragma unroll
+                        for (int q = 0; q < NF_MD_NKQ; ++q)
+                            if (b0 + q8 < b_hi) tsum += v[q8][q];
                 }
-#pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8)
-#pragma unroll
-                    for (int q = 0; q < NF_MD_NKQ; ++q)
-                        if (b0 + q8 < b_hi) tsum += v[q8][q];
-            }
-            if (o < O) {
-                if (i == 32) atomicAdd(gr.b[n][l] + o, tsum);
-                else atomicAdd(gr.w[n][l] + o * I + i, tsum * p.m[n][l][o * I + i]);          // maf.py:54: d(W * M) = g * M
+                if (o < O) {
+                    if (i == 32) atomicAdd(gr.b[n][l] + o, tsum);
+                    else atomicAdd(gr.w[n][l] + o * I + i, tsum * p.m[n][l][o * I + i]);          // maf.py:54: d(W * M) = g * M
+                }
             }
         }
     }
@@ -704,7 +718,7 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_bwd(NfMadeP p, NfMaf
         atomicAdd(gr.beta[n][j] + k, sm[NF_MD_GB + j * NF_MD_XW + n * 64 + k]);
         atomicAdd(gr.gamma[n][j] + k, sm[NF_MD_GB + j * NF_MD_XW + n * 64 + 32 + k]);
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (htot != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         atomicAdd(h.g_c, htot[0]);                        // d/d s_bias
         atomicAdd(h.g_a, htot[1]);                        // d/d s_log_scale
     }
@@ -742,12 +756,11 @@ extern "C" int nf_maf_step_fwd(const float* z, float* y, float* ld, const void* 
     return 0;
 }
 
-extern "C" int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
-                               const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
-                               float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream) {
+static int nf_maf_launch_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                             const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
+                             float* g_s_bias, float* ws_zero, float* slabs, float* head_rec, int64_t N, int D, nf_stream_t stream) {
     if (z == nullptr || g_y == nullptr || g_z == nullptr || head == nullptr || made_params == nullptr || save_stats == nullptr ||
-        made_grads == nullptr || g_s_log_scale == nullptr || g_s_bias == nullptr || ws_zero == nullptr || slabs == nullptr ||
-        !nf_maf_ok(N, D))
+        made_grads == nullptr || ws_zero == nullptr || slabs == nullptr || !nf_maf_ok(N, D))
         return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     NfMadeP p;
@@ -769,7 +782,109 @@ extern "C" int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_maf_step_bwd, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, save_stats, g, ws_zero, slabs, N);
+    hipLaunchKernelGGL(k_maf_step_bwd, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, save_stats, g, ws_zero, slabs, N,
+                       head_rec);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                               const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
+                               float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream) {
+    if (g_s_log_scale == nullptr || g_s_bias == nullptr) return NF_E_BADARG;
+    return nf_maf_launch_bwd(z, g_y, g_ld, g_z, head, made_params, save_stats, made_grads, g_s_log_scale, g_s_bias, ws_zero, slabs,
+                             nullptr, N, D, stream);
+}
+
+extern "C" int nf_maf_step_bwd_partial(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
+                                       const void* const* made_params, const float* save_stats, void* const* made_grads,
+                                       float* ws_zero, float* slabs_step, float* head_rec_step, int64_t N, int D,
+                                       nf_stream_t stream) {
+    if (head_rec_step == nullptr) return NF_E_BADARG;
+    return nf_maf_launch_bwd(z, g_y, g_ld, g_z, head, made_params, save_stats, made_grads, nullptr, nullptr, ws_zero, slabs_step,
+                             head_rec_step, N, D, stream);
+}
+
+// the folds of up to NF_MD_FOLD_STEPS deferred steps in one launch: half wave per (step, net, layer, column | bias, part of the
+// workgroups' slabs); the parts meet by atomics in the gradient (+= semantics, as in the in-kernel fold)
+#define NF_MD_FOLD_STEPS 16
+#define NF_MD_FOLD_PARTS 4
+struct NfMafFoldStep { const float* m[2][NF_MD_NL]; float* w[2][NF_MD_NL]; float* b[2][NF_MD_NL]; float* g_a; float* g_c; };
+struct NfMafFoldArgs { NfMafFoldStep st[NF_MD_FOLD_STEPS]; };
+static_assert(sizeof(NfMafFoldArgs) <= 3584, "fold descriptors travel in the kernel argument segment");
+
+__global__ void __launch_bounds__(NF_MD_THREADS) k_maf_fold_all(NfMafFoldArgs args, const float* __restrict__ slabs_all,
+                                                                const float* __restrict__ head_rec, int G, int D) {
+    const NfMafFoldStep& st = args.st[blockIdx.y];
+    const float* slabs = slabs_all + (size_t)blockIdx.y * G * NF_MD_SLAB;
+    const int o = threadIdx.x & 31;
+    const int chunk = (G + NF_MD_FOLD_PARTS - 1) / NF_MD_FOLD_PARTS;
+    constexpr int HW = NF_MD_THREADS / 32;
+    for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * NF_MD_FOLD_PARTS; u += gridDim.x * HW) {
+        const int part = u % NF_MD_FOLD_PARTS, uu = u / NF_MD_FOLD_PARTS;
+        const int nl = uu / 33, i = uu - nl * 33;         // i == 32: the bias
+        const int n = nl >> 2, l = nl & 3;
+        const int I = l == 0 ? D : 32, O = l == NF_MD_NL - 1 ? D : 32;
+        const int b_lo = part * chunk, b_hi = min(G, b_lo + chunk);
+        if ((i < 32 && i >= I) || b_lo >= b_hi) continue;
+        float tsum = 0.f;
+        const float* base = slabs + (size_t)nl * NF_MD_SLAB_L + i * 32 + o;
+        for (int b0 = b_lo; b0 < b_hi; b0 += 16) {        // 32 independent loads in flight
+            float v[16][NF_MD_NKQ];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int b = b0 + q < b_hi ? b0 + q : b_hi - 1;
+#pragma unroll
+                for (int k = 0; k < NF_MD_NKQ; ++k) v[q][k] = base[(size_t)b * NF_MD_SLAB + k * NF_MD_SLAB_Q];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int k = 0; k < NF_MD_NKQ; ++k)
+                    if (b0 + q < b_hi) tsum += v[q][k];
+        }
+        if (o < O) {
+            if (i == 32) atomicAdd(st.b[n][l] + o, tsum);
+            else atomicAdd(st.w[n][l] + o * I + i, tsum * st.m[n][l][o * I + i]);             // maf.py:54: d(W * M) = g * M
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {            // the transform's scalar gradients: sum over workgroups and waves
+        const float* r = head_rec + (size_t)blockIdx.y * G * NF_MD_WAVES * 2;
+        float s0 = 0.f, s1 = 0.f;
+        for (int e = threadIdx.x; e < G * NF_MD_WAVES; e += 64) { s0 += r[2 * e]; s1 += r[2 * e + 1]; }
+        s0 = nf_wave_sum(s0); s1 = nf_wave_sum(s1);
+        if (threadIdx.x == 0) {
+            atomicAdd(st.g_c, s0);                        // d/d s_bias
+            atomicAdd(st.g_a, s1);                        // d/d s_log_scale
+        }
+    }
+}
+
+extern "C" int nf_maf_fold_all(const void* const* made_params_all, void* const* made_grads_all, float* const* g_s_log_scale_all,
+                               float* const* g_s_bias_all, int S, const float* slabs_all, const float* head_rec_all, int blocks,
+                               int D, nf_stream_t stream) {
+    if (made_params_all == nullptr || made_grads_all == nullptr || g_s_log_scale_all == nullptr || g_s_bias_all == nullptr || S < 1 ||
+        slabs_all == nullptr || head_rec_all == nullptr || blocks < 1 || blocks > NF_MAF_MAX_BLOCKS || D < 1 || D > 4)
+        return NF_E_BADARG;
+    constexpr int jobs = 2 * NF_MD_NL * 33 * NF_MD_FOLD_PARTS, HW = NF_MD_THREADS / 32;
+    for (int s0 = 0; s0 < S; s0 += NF_MD_FOLD_STEPS) {
+        const int ns = S - s0 < NF_MD_FOLD_STEPS ? S - s0 : NF_MD_FOLD_STEPS;
+        NfMafFoldArgs a{};
+        for (int k = 0; k < ns; ++k) {
+            NfMadeP p;
+            nf_made_unpack(made_params_all + (size_t)(s0 + k) * NF_MAF_PARAM_PTRS, p);
+            void* const* q0 = made_grads_all + (size_t)(s0 + k) * NF_MAF_GRAD_PTRS;
+            for (int n = 0; n < 2; ++n) {
+                void* const* q = q0 + n * (2 * NF_MD_NL + 2 * NF_MD_NB);
+                for (int l = 0; l < NF_MD_NL; ++l) {
+                    a.st[k].m[n][l] = p.m[n][l]; a.st[k].w[n][l] = (float*)q[2 * l]; a.st[k].b[n][l] = (float*)q[2 * l + 1];
+                }
+            }
+            a.st[k].g_a = g_s_log_scale_all[s0 + k]; a.st[k].g_c = g_s_bias_all[s0 + k];
+        }
+        hipLaunchKernelGGL(k_maf_fold_all, dim3((jobs + HW - 1) / HW, ns), dim3(NF_MD_THREADS), 0, (hipStream_t)stream, a,
+                           slabs_all + (size_t)s0 * blocks * NF_MD_SLAB, head_rec_all + (size_t)s0 * blocks * NF_MD_WAVES * 2, blocks, D);
+    }
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -1124,6 +1124,118 @@ def maf_step_vec(z, ld, bn, ar):
     return _MAFStepVec.apply(z, _owned_ld(ld), bn.eps, bn.momentum, *(head + _made_tensors(ar.net_s, ms) + _made_tensors(ar.net_t, mt)))
 
 
+# a run of MAF steps as ONE autograd node: the step launches of _MAFStepVec, the backward's in deferred-fold mode -- every step
+# leaves its weight-gradient slabs behind and nf_maf_fold_all folds them all in one launch (C5: 0.725 -> 0.628 ms per train step)
+MAF_FLOW = _os.environ.get('NF_MAF_FLOW', '1') != '0'
+
+
+def _maf_steps_scratch(S, blocks, device):
+    key = ('maf_steps', device)
+    n = S * blocks * N.header_constant('NF_MAF_SLAB_WG_FLOATS')
+    m = S * blocks * N.header_constant('NF_MAF_HEAD_REC_WG')
+    t = _MAF_SLABS.get(key)
+    if t is None or t[0].numel() < n or t[1].numel() < m:
+        t = _MAF_SLABS[key] = (torch.empty(n, dtype=torch.float32, device=device), torch.empty(m, dtype=torch.float32, device=device))
+    return t
+
+
+def _maf_step_learnables(head, made):
+    return _made_learnables(made[:27]) + _made_learnables(made[27:]) + [head[7], head[8]]
+
+
+class _MAFFlowVec(torch.autograd.Function):
+    """S consecutive [flow BatchNorm (training, affine=False), AutoregressiveTransfrom] steps on (N, D) data.
+    metas: per step (flow_bn_eps, flow_bn_momentum); tensors: per step the 9 head + 54 MADE tensors of _MAFStepVec."""
+
+    @staticmethod
+    def forward(ctx, z, ld, metas, *tensors):
+        S, per = len(metas), 9 + 54
+        from .functional import _sinks
+        z = z.contiguous()
+        Nrows, D = z.shape
+        dev = z.device
+        ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+        saves = torch.empty(S, N.header_constant('NF_MAF_SAVE_FLOATS'), dtype=torch.float32, device=dev)
+        nws = N.header_constant('NF_MAF_WS_FLOATS')
+        ws = WS.zeros(S * nws, dev)
+        sinks = []
+        for i in range(S):
+            head, made = tensors[per * i:per * i + 9], tensors[per * i + 9:per * (i + 1)]
+            g = _sinks(*_maf_step_learnables(head, made))
+            if g is None:
+                raise RuntimeError('maf_flow_vec needs direct gradient sinks (GradBucket) for every parameter')
+            sinks.append(g)
+            htab, mtab = _ptr_table(head), _ptr_table(made)
+            N.call('nf_maf_step_fwd', N.ptr(z) if i == 0 else N.ptr(ys[i - 1]), N.ptr(ys[i]), N.ptr(ld), ctypes.addressof(htab),
+                   ctypes.addressof(mtab), N.ptr(saves[i]), N.ptr(ws[i * nws:(i + 1) * nws]), Nrows, D, float(metas[i][0]),
+                   float(metas[i][1]), BN_EPS, N.stream())
+        ctx.save_for_backward(z, ys, saves, *tensors)
+        ctx.sinks = sinks
+        ctx.mark_dirty(ld)
+        return ys[S - 1], ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        z, ys, saves, *tensors = ctx.saved_tensors
+        S, per = ys.shape[0], 9 + 54
+        Nrows, D = z.shape
+        dev = z.device
+        g_y = g_y.contiguous()
+        g_ld = None if g_ld is None else g_ld.contiguous()
+        gzs = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+        nws = N.header_constant('NF_MAF_WS_FLOATS')
+        ws = WS.zeros(S * nws, dev)
+        blocks = -(-Nrows // N.header_constant('NF_MAF_ROWS_PER_BLOCK'))
+        nsl, nrec = blocks * N.header_constant('NF_MAF_SLAB_WG_FLOATS'), blocks * N.header_constant('NF_MAF_HEAD_REC_WG')
+        slabs, rec = _maf_steps_scratch(S, blocks, dev)
+        all_made, all_grads, all_a, all_c = [], [], [], []
+        for i in range(S - 1, -1, -1):
+            head, made = tensors[per * i:per * i + 9], tensors[per * i + 9:per * (i + 1)]
+            dst = ctx.sinks[i]
+            htab, mtab, gtab = _ptr_table(head), _ptr_table(made), _ptr_table(dst[:28])
+            N.call('nf_maf_step_bwd_partial', N.ptr(z) if i == 0 else N.ptr(ys[i - 1]), N.ptr(g_y) if i == S - 1 else N.ptr(gzs[i + 1]),
+                   _p(g_ld), N.ptr(gzs[i]), ctypes.addressof(htab), ctypes.addressof(mtab), N.ptr(saves[i]), ctypes.addressof(gtab),
+                   N.ptr(ws[i * nws:(i + 1) * nws]), N.ptr(slabs[i * nsl:(i + 1) * nsl]), N.ptr(rec[i * nrec:(i + 1) * nrec]), Nrows, D,
+                   N.stream())
+        for i in range(S):
+            head, made = tensors[per * i:per * i + 9], tensors[per * i + 9:per * (i + 1)]
+            all_made += list(made)
+            all_grads += list(ctx.sinks[i][:28])
+            all_a.append(ctx.sinks[i][28])
+            all_c.append(ctx.sinks[i][29])
+        pm, pg, pa, pc = _ptr_table(all_made), _ptr_table(all_grads), _ptr_table(all_a), _ptr_table(all_c)
+        N.call('nf_maf_fold_all', ctypes.addressof(pm), ctypes.addressof(pg), ctypes.addressof(pa), ctypes.addressof(pc), S, N.ptr(slabs),
+               N.ptr(rec), blocks, D, N.stream())
+        return (gzs[0], g_ld, None) + (None, ) * len(tensors)
+
+
+def maf_flow_vec_usable(z, steps):
+    """steps: [(flow BatchNorm, AutoregressiveTransfrom)] -- at least two fused-step-capable steps, every parameter with a sink."""
+    from .functional import grad_sink
+    if not MAF_FLOW or len(steps) < 2 or not torch.is_grad_enabled():
+        return False
+    for bn, ar in steps:
+        if not maf_step_usable(z, bn, ar):
+            return False
+        ps = [p for net in (ar.net_s, ar.net_t) for p in list(net.weights) + list(net.biases)]
+        ps += [t for net in (ar.net_s, ar.net_t) for b in net.bnorms for t in (b.weight, b.bias)] + [ar.s_log_scale, ar.s_bias]
+        if any(grad_sink(t) is None for t in ps):
+            return False
+    return True
+
+
+def maf_flow_vec(z, ld, steps):
+    from .functional import _owned_ld
+    tensors, metas = [], []
+    for bn, ar in steps:
+        ms = ar.net_s.draw_masks(z.device)                   # same RNG order as the reference: per step s-net, then t-net
+        mt = ar.net_t.draw_masks(z.device)
+        tensors += [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, ar.perm, ar.s_log_scale,
+                    ar.s_bias] + _made_tensors(ar.net_s, ms) + _made_tensors(ar.net_t, mt)
+        metas.append((float(bn.eps), float(bn.momentum)))
+    return _MAFFlowVec.apply(z, _owned_ld(ld), tuple(metas), *tensors)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # one whole RealNVP flow step on vector data: flow BatchNorm (batch statistics) -> affine coupling with the MLP conditioner
 # ----------------------------------------------------------------------------------------------------------------------

@@ -77,6 +77,16 @@ class Compose(nn.Module):
             j += 2
         return run if FUSED.realnvp_flow_vec_usable(z, run) else None
 
+    def _maf_run_at(self, i, z):
+        """the maximal run of fused-step-capable MAF steps [flow BatchNorm, AutoregressiveTransfrom] on (N, D <= 4) data, or None"""
+        L, run, j = self.layers, [], i
+        if z.dim() != 2:
+            return None
+        while self._bn_step_at(j, z) and type(L[j + 1]) is AutoregressiveTransfrom:
+            run.append((L[j], L[j + 1]))
+            j += 2
+        return run if FUSED.maf_flow_vec_usable(z, run) else None
+
     def _bn_step_at(self, i, z):
         """[flow BatchNorm (training, affine=False), AffineCoupling | AutoregressiveTransfrom] -> fused BatchNorm head"""
         L = self.layers
@@ -118,6 +128,11 @@ class Compose(nn.Module):
                     h, z1c, log_df_dz = NF.flowbn_head(z, log_df_dz, a, k.mode, k.odd, gather=True)
                     z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
                 elif FUSED.maf_step_usable(z, a, k):
+                    run = self._maf_run_at(i, z)
+                    if run is not None:                            # the run as one autograd node, one fold for all steps
+                        z, log_df_dz = FUSED.maf_flow_vec(z, log_df_dz, run)
+                        i += 2 * len(run)
+                        continue
                     z, log_df_dz = FUSED.maf_step_vec(z, log_df_dz, a, k)            # the whole step: one launch
                 else:
                     h, log_df_dz = NF.flowbn_head(z, log_df_dz, a)

@@ -540,6 +540,52 @@ def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
     assert fused.N.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('D,B,K', [(2, 16384, 3), (4, 1000, 4), (2, 100, 18), (3, 4096, 2)])
+def test_maf_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
+    """a run of MAF steps as one autograd node whose backward defers the gradient folds of all steps to one launch
+    (nf_maf_step_bwd_partial + nf_maf_fold_all; 18 steps: two fold launches) against the same steps one by one: outputs, loss,
+    flat gradients, flow-BatchNorm and BatchNorm1d buffers."""
+    from types import SimpleNamespace as NS
+    import numpy as np
+    train = importlib.import_module(pkg.__name__ + '.train')
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 1000 + B)
+    net1 = pkg.MAF((D, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    net2 = copy.deepcopy(net1)
+    y = (torch.randn(B, D) * 0.7).to(DEV)
+    t1, t2 = train.FlowTrainer(net1, graph=False), train.FlowTrainer(net2, graph=False)
+    calls = {'n': 0}
+    real = fused.maf_flow_vec
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+
+    for step in range(2):
+        monkeypatch.setattr(fused, 'MAF_FLOW', True)
+        monkeypatch.setattr(fused, 'maf_flow_vec', counted)
+        t1.net.train()
+        np.random.seed(step)                                # the MADE masks are drawn with numpy's RNG on every forward
+        z1, l1 = t1._forward_backward(y)
+        monkeypatch.setattr(fused, 'MAF_FLOW', False)
+        t2.net.train()
+        np.random.seed(step)
+        z2, l2 = t2._forward_backward(y)
+        monkeypatch.undo()
+        G.assert_close(z1, z2, 1e-6, rtol=1e-6, what='z, step %d' % step)
+        G.assert_close(l1, l2, 1e-6, rtol=1e-6, what='loss, step %d' % step)
+        # (same step bodies; both folds add partial sums by float atomics, whose order is not fixed)
+        G.assert_close(t1.bucket.flat, t2.bucket.flat, 2e-5 * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
+        b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
+        for name in b2:
+            G.assert_close(b1[name].float(), b2[name].float(), 1e-6, rtol=1e-6, what='buffer ' + name)
+        t1.optim.step()
+        net2.load_state_dict(net1.state_dict())
+        t2.bucket.flat_params.copy_(t1.bucket.flat_params)
+    assert calls['n'] == 2, 'the deferred-fold run was not taken'
+    assert fused.N.persistent_timeouts() == 0
+
+
 @pytest.mark.parametrize('D,B,K', [(2, 256, 8), (4, 1000, 3), (2, 4096, 2)])
 def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
     """a run of vector RealNVP steps in one launch per direction against the same steps launched one by one (bit-identical
