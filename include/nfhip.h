@@ -594,6 +594,19 @@ int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const float* z, 
                            float* g_bq, float* g_W2, float* g_b2, float* g_ln2_g, float* g_ln2_b, float* g_W5, float* g_b5,
                            float* g_scale, float* g_bias, float* g_next_log_scale, float* g_next_bias, float* workspace, int K,
                            float logit_eps, int odd, int64_t N, int phase, nf_stream_t stream);
+/* Deferred finalize: a flow of such steps calls nf_flowpp_vec_step_bwd with phase = 1 (the backward kernel only: g_z complete,
+ * the parameter-gradient partials stay in `workspace` -- one NF_FLOWPP_BWD_WS_FLOATS region PER STEP, untouched until folded)
+ * and, after the last step, nf_flowpp_vec_step_finalize ONCE with every step's descriptor: the same accumulation into the
+ * gradient buffers as phase 2, eight steps per launch.  All steps share K and N.                                            */
+typedef struct nf_flowpp_fin_desc {
+    const float* workspace;
+    float *g_W0, *g_b0, *g_Wg, *g_bg, *g_ln1_g, *g_ln1_b, *g_pos, *g_Wq, *g_bq, *g_W2, *g_b2, *g_ln2_g, *g_ln2_b, *g_W5, *g_b5;
+    float *g_scale, *g_bias;
+    const float* next_log_scale;                          /* NULL: no ActNorm rides the step                                  */
+    float *g_next_log_scale, *g_next_bias;
+    int odd, reserved;
+} nf_flowpp_fin_desc;
+int nf_flowpp_vec_step_finalize(const nf_flowpp_fin_desc* descs, int n, int K, int64_t N, nf_stream_t stream);
 
 /* ---- a whole flow of S fused vector Glow steps (nf_glow_step_vec_*) in ONE launch per direction ---------------------------
  * flows/glow.py: the (N, D in {2, 4}) model IS a sequence of such steps; rows stay in their workgroup from step to step, the

@@ -849,8 +849,8 @@ __global__ void __launch_bounds__(NF_FP_BWD_WAVES * NF_WAVE) k_flowpp_cond_bwd(N
 
 // dst += sum over the blocks' slabs.  grid (NF_S_END / 64, 4): 64 slab entries x 4 slab groups per block, the y index picks
 // a quarter of the slabs (<= 16 independent loads per thread); the four partial sums meet in the destination by atomics.
-__global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,
-                                                              int O, NfFppMix mx) {
+__device__ __forceinline__ void nf_fpp_finalize_body(const float* __restrict__ slabs, int nblk, const NfFppG& gr, int I0, int O,
+                                                     const NfFppMix& mx) {
     __shared__ float red[4][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -894,6 +894,24 @@ __global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __res
             else { atomicAdd(mx.g_nls + o0, -s); atomicAdd(mx.g_nls + o1, -s); }
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,
+                                                              int O, NfFppMix mx) {
+    nf_fpp_finalize_body(slabs, nblk, gr, I0, O, mx);
+}
+
+// the finalizes of up to NF_FP_FIN_STEPS flow steps in one launch (blockIdx.z = step): nothing downstream of a step's backward
+// waits for its parameter gradients, so the per-step finalize launches (7 us + a launch gap each, 32 per C3 backward pass) are
+// deferred -- every step keeps its own slab workspace -- and run together after the last step (nf_flowpp_vec_step_finalize)
+#define NF_FP_FIN_STEPS 8
+struct NfFppFinStep { const float* slabs; NfFppG g; NfFppMix mx; };
+struct NfFppFinArgs { NfFppFinStep st[NF_FP_FIN_STEPS]; };
+static_assert(sizeof(NfFppFinArgs) <= 3584, "finalize descriptors travel in the kernel argument segment");
+
+__global__ void __launch_bounds__(256) k_flowpp_cond_finalize_multi(NfFppFinArgs a, int nblk, int I0, int O) {
+    const NfFppFinStep& st = a.st[blockIdx.z];
+    nf_fpp_finalize_body(st.slabs, nblk, st.g, I0, O, st.mx);
 }
 
 static_assert(NF_FP_MAX_BLOCKS * NF_S_END == NF_FLOWPP_BWD_WS_FLOATS, "workspace size in include/nfhip.h");
@@ -978,3 +996,30 @@ extern "C" int nf_flowpp_vec_step_bwd(const float* g_h, const float* g_ld, const
     return nf_fpp_launch_bwd<2, true>(w, g, workspace, N, 1, O, (hipStream_t)stream, mx, phase);
 }
 
+
+extern "C" int nf_flowpp_vec_step_finalize(const nf_flowpp_fin_desc* descs, int n, int K, int64_t N, nf_stream_t stream) {
+    if (descs == nullptr || n < 0 || K < 1 || K > 8) return NF_E_BADARG;
+    if (n == 0 || N <= 0) return (n == 0 || N == 0) ? 0 : NF_E_BADARG;
+    const int O = 2 + 3 * K;
+    const int64_t tiles = (N + 15) / 16;
+    int64_t gx = (tiles + NF_FP_BWD_WAVES - 1) / NF_FP_BWD_WAVES;
+    if (gx > NF_FP_MAX_BLOCKS) gx = NF_FP_MAX_BLOCKS;            // = the grid of the backward kernel that wrote the slabs
+    for (int s0 = 0; s0 < n; s0 += NF_FP_FIN_STEPS) {
+        const int ns = n - s0 < NF_FP_FIN_STEPS ? n - s0 : NF_FP_FIN_STEPS;
+        NfFppFinArgs a{};
+        for (int k = 0; k < ns; ++k) {
+            const nf_flowpp_fin_desc& d = descs[s0 + k];
+            if (d.workspace == nullptr || d.g_scale == nullptr || d.g_bias == nullptr) return NF_E_BADARG;
+            if (d.next_log_scale != nullptr && (d.g_next_log_scale == nullptr || d.g_next_bias == nullptr)) return NF_E_BADARG;
+            a.st[k].slabs = d.workspace;
+            a.st[k].g = NfFppG{nullptr, nullptr, d.g_W0, d.g_b0, d.g_Wg, d.g_bg, d.g_ln1_g, d.g_ln1_b, d.g_pos, d.g_Wq, d.g_bq, d.g_W2,
+                               d.g_b2, d.g_ln2_g, d.g_ln2_b, d.g_W5, d.g_b5, 2, 2, 1};
+            a.st[k].mx = NfFppMix{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.next_log_scale, nullptr, nullptr, d.g_scale,
+                                  d.g_bias, d.g_next_log_scale, d.g_next_bias, d.odd ? 1 : 0, K, 0.f};
+        }
+        hipLaunchKernelGGL(k_flowpp_cond_finalize_multi, dim3(NF_S_END / 64, (unsigned)((gx + 63) / 64), (unsigned)ns), dim3(256), 0,
+                           (hipStream_t)stream, a, (int)gx, 1, O);
+    }
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -11,6 +11,7 @@ Both are exact restatements of the module math in training mode (batch statistic
 statistics, running-statistics bookkeeping) and in evaluation mode (running statistics).
 """
 import ctypes
+import os as _os
 
 import torch
 
@@ -505,6 +506,54 @@ def flowpp_bwd_workspace(device):
     return ws
 
 
+class FlowppFinDesc(ctypes.Structure):
+    """nf_flowpp_fin_desc of include/nfhip.h"""
+    _fields_ = [(f, ctypes.c_void_p) for f in ('workspace', 'g_W0', 'g_b0', 'g_Wg', 'g_bg', 'g_ln1_g', 'g_ln1_b', 'g_pos', 'g_Wq',
+                                                'g_bq', 'g_W2', 'g_b2', 'g_ln2_g', 'g_ln2_b', 'g_W5', 'g_b5', 'g_scale', 'g_bias',
+                                                'next_log_scale', 'g_next_log_scale', 'g_next_bias')] + \
+               [('odd', ctypes.c_int), ('reserved', ctypes.c_int)]
+
+
+class FlowppDefer:
+    """Deferred slab finalizes of the fused Flow++ steps (nf_flowpp_vec_step_bwd phase 1 + nf_flowpp_vec_step_finalize).
+    A training step opens it around loss.backward() (FlowTrainer does): every step's backward then keeps its slab workspace
+    and queues a descriptor instead of launching its own finalize, ``flush`` folds all of them in one launch per eight
+    steps (C3: 32 finalize launches of 7 us + a launch gap each -> 4 launches).  Closed (the default) nothing is deferred:
+    a bare ``loss.backward()`` outside a trainer cannot leave gradients unfolded."""
+
+    def __init__(self):
+        self.active = False
+        self.queue = []         # (desc, K, N, tensors kept alive)
+        self.pool = {}          # device -> [workspace tensors]
+
+    def begin(self):
+        self.queue = []
+        self.active = FLOWPP_DEFER
+
+    def workspace(self, device):
+        pool = self.pool.setdefault(device, [])
+        i = len(self.queue)
+        while len(pool) <= i:
+            pool.append(torch.empty(N.header_constant('NF_FLOWPP_BWD_WS_FLOATS'), dtype=torch.float32, device=device))
+        return pool[i]
+
+    def flush(self):
+        """fold everything queued (also on the error path: the queue never survives a step)"""
+        q, self.queue, self.active = self.queue, [], False
+        i = 0
+        while i < len(q):
+            j = i
+            while j < len(q) and q[j][1:3] == q[i][1:3]:      # one call per run of equal (K, N)
+                j += 1
+            arr = (FlowppFinDesc * (j - i))(*[e[0] for e in q[i:j]])
+            N.call('nf_flowpp_vec_step_finalize', ctypes.addressof(arr), j - i, q[i][1], q[i][2], N.stream())
+            i = j
+
+
+FLOWPP_DEFER = _os.environ.get('NF_FLOWPP_DEFER', '1') != '0'
+FPP_DEFER = FlowppDefer()
+
+
 class _FusedFlowppCond(torch.autograd.Function):
     """x (N, I0) -> the (N, O) coupling parameters; one launch forward, one launch backward (csrc/flowpp_cond.hip)."""
 
@@ -645,8 +694,6 @@ def glow_step_vec(z, ld, actnorm, conv, coupling):
 # ----------------------------------------------------------------------------------------------------------------------
 # a whole flow of fused vector Glow steps in one launch per direction (csrc/mlp_chain.hip: k_glow_flow_fwd / _bwd)
 # ----------------------------------------------------------------------------------------------------------------------
-import os as _os
-
 # whole-flow launches: 'auto' = batches of at most GLOW_FLOW_AUTO_ROWS rows, where they are a measured win (C2 at B = 512:
 # 1.89 -> 1.78 ms, B = 1024: 1.80 -> 1.72 ms); from 32 workgroups on the in-kernel exchanges get slower than the launch
 # gaps they replace (B = 4096: 1.91 -> 1.94 ms, B = 16384: 3.05 -> 3.66 ms), DESIGN.md section 3.11.  '1' / '0' force it.
@@ -990,9 +1037,14 @@ class _FlowppCouplingVec(torch.autograd.Function):
         d[8] += 4 * 2 * F_
         if D == 2 and K <= 8 and FLOWPP_FUSED_BWD:
             # the coupling's backward runs inside the conditioner's backward kernel: the (N, 2 + 3K) gradient never exists
+            defer = (FPP_DEFER.active and direct and ctx.sinks_ac is not None and (not n_post or ctx.sinks_post is not None))
+            wsb = FPP_DEFER.workspace(dev) if defer else flowpp_bwd_workspace(dev)
             N.call('nf_flowpp_vec_step_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), *_flowpp_fwd_args(ts, F_),
                    N.ptr(a), N.ptr(c), N.ptr(post[0]) if n_post else None, N.ptr(post[1]) if n_post else None, N.ptr(g_z), *d,
-                   pa, pc, pls, pb, N.ptr(flowpp_bwd_workspace(dev)), K, eps, odd, Nrows, 0, N.stream())
+                   pa, pc, pls, pb, N.ptr(wsb), K, eps, odd, Nrows, 1 if defer else 0, N.stream())
+            if defer:                                         # the finalize of this step runs with everybody else's (flush)
+                desc = FlowppFinDesc(N.ptr(wsb), *d, pa, pc, N.ptr(post[0]) if n_post else None, pls, pb, odd, 0)
+                FPP_DEFER.queue.append((desc, K, Nrows, (wsb, post, dst)))
         else:
             g_p = torch.empty_like(params)
             if n_post:

@@ -110,12 +110,15 @@ class FlowTrainer:
         elif self._indirect:
             for i in self._indirect:
                 self.bucket.params[i].grad = None       # AccumulateGrad then keeps the incoming tensor: no add launch
+        from .fused import FPP_DEFER
         ARENA.begin(y.device)                           # one memset for every zero-initialised accumulator of the step
+        FPP_DEFER.begin()                               # the Flow++ steps' slab finalizes: all of them in one go after backward
         try:
             z, ld = self.net(y)
             loss = nll_loss(z, ld)
             loss.backward()
         finally:
+            FPP_DEFER.flush()
             ARENA.end()
             for h in hooks:
                 h.remove()

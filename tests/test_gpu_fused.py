@@ -540,6 +540,43 @@ def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
     assert fused.N.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('B,K,mix', [(65536, 11, 8), (1000, 3, 4), (40000, 9, 8)])
+def test_flowpp_deferred_finalize_matches_per_step(pkg, B, K, mix, monkeypatch):
+    """the trainer defers the slab finalizes of the fused Flow++ steps to one launch per eight steps after backward
+    (nf_flowpp_vec_step_bwd phase 1 + nf_flowpp_vec_step_finalize): same gradients as the per-step finalize launches."""
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(B + K)
+    net1 = pkg.Flowpp((2, ), 'density', NS(layers=K, mixtures=mix)).to(DEV)
+    net2 = copy.deepcopy(net1)
+    y = (torch.randn(B, 2) * 0.7).to(DEV)
+    t1, t2 = train.FlowTrainer(net1, graph=False), train.FlowTrainer(net2, graph=False)
+    queued = []
+    real_flush = fused.FlowppDefer.flush
+
+    def flush(self):
+        queued.append(len(self.queue))
+        return real_flush(self)
+
+    monkeypatch.setattr(fused.FlowppDefer, 'flush', flush)
+    for step in range(3):                                   # step 0 initialises the ActNorms
+        monkeypatch.setattr(fused, 'FLOWPP_DEFER', True)
+        z1, l1 = t1._forward_backward(y)
+        monkeypatch.setattr(fused, 'FLOWPP_DEFER', False)
+        z2, l2 = t2._forward_backward(y)
+        assert not fused.FPP_DEFER.queue and not fused.FPP_DEFER.active
+        if step > 0:   # (step 0: the data-dependent ActNorm init sums by atomics, the replicas differ at noise level until synced)
+            G.assert_close(z1, z2, 1e-6, rtol=1e-6, what='z, step %d' % step)
+            G.assert_close(l1, l2, 1e-6, rtol=1e-6, what='loss, step %d' % step)
+            # (identical kernels and slabs; the finalize adds by float atomics in either form)
+            G.assert_close(t1.bucket.flat, t2.bucket.flat, 2e-5 * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
+        t1.optim.step()
+        net2.load_state_dict(net1.state_dict())
+        t2.bucket.flat_params.copy_(t1.bucket.flat_params)
+    assert max(queued) == K, 'the finalizes were not deferred (queue lengths %r)' % (queued, )
+
+
 @pytest.mark.parametrize('D,B,K', [(2, 16384, 3), (4, 1000, 4), (2, 100, 18), (3, 4096, 2)])
 def test_maf_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
     """a run of MAF steps as one autograd node whose backward defers the gradient folds of all steps to one launch
