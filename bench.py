@@ -391,21 +391,27 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
             acc = torch.zeros(R * FC.GB + 4 * R * 32, device=dev)
             gn_out = torch.empty_like(x)
 
+            split = FC.CONV_DEFER_ON     # the train step launches the data-gradient pass alone (the weight-gradient passes of all
+                                         # layers run sixteen per launch at the end of the backward pass: nf_conv_bn_wgrad_multi)
+
             def fn():
                 FC._bwd((B, Hh, Ww), Cc, Cc, 3, in_=x, weight=wgt, bn_gamma=ones, bn_beta=zeros, bn_save_mean=zeros,
                         bn_save_invstd=ones, gn_src=gn_src, out=out, cbn_gamma=ones, cbn_save_mean=zeros, cbn_save_invstd=ones,
                         cbn_sum_g=acc[R * FC.GB:R * FC.GB + R * 32], cbn_sum_gx=acc[R * FC.GB + R * 32:R * FC.GB + 2 * R * 32],
-                        g_bias=acc[:R * FC.GB], g_weff=g_weff, gn_out=gn_out, sum_g=acc[R * FC.GB + 2 * R * 32:R * FC.GB + 3 * R * 32],
-                        sum_gx=acc[R * FC.GB + 3 * R * 32:])
+                        g_bias=None if split else acc[:R * FC.GB], g_weff=None if split else g_weff, gn_out=gn_out,
+                        sum_g=acc[R * FC.GB + 2 * R * 32:R * FC.GB + 3 * R * 32], sum_gx=acc[R * FC.GB + 3 * R * 32:])
             us = graph_time_us(fn, dev, per_graph=20, replays=5)
             M = B * Hh * Ww
-            flop = 2 * 2 * M * 9 * Cc * Cc                          # data gradient + weight gradient products
+            flop = (1 if split else 2) * 2 * M * 9 * Cc * Cc        # data gradient (+ weight gradient) products
             tf = flop / (us * 1e-6) / 1e12
-            return {'bound': 'mfma', 'kernel': 'k_conv_bn_bwd<9, 1, 1> (3x3 convolution + BatchNorm2d + ReLU backward, 32 -> 32 channels, '
-                                               '%d x %d)' % (Hh, Ww),
+            kname = ('k_conv_bn_bwd<9, 1, 1, 1> (3x3 convolution + BatchNorm2d + ReLU backward, data-gradient pass, 32 -> 32 channels, '
+                     '%d x %d)' if split else
+                     'k_conv_bn_bwd<9, 1, 1, 0> (3x3 convolution + BatchNorm2d + ReLU backward, 32 -> 32 channels, %d x %d)') % (Hh, Ww)
+            return {'bound': 'mfma', 'kernel': kname,
                     'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
-                    'traffic': None, 'flop_per_launch': int(flop), 'bytes_per_launch': int(M * Cc * 4 * 5), 'us_per_launch': round(us, 3),
-                    'note': 'latency-bound at this size (0.6 GFLOP over 128 workgroups): ~7 us of MFMA work inside a serial chain of '
+                    'traffic': None, 'flop_per_launch': int(flop), 'bytes_per_launch': int(M * Cc * 4 * (4 if split else 5)),
+                    'us_per_launch': round(us, 3),
+                    'note': 'latency-bound at this size (0.3 GFLOP over 128 workgroups): ~3 us of MFMA work inside a serial chain of '
                             'dependent memory round trips (DESIGN.md section 3.15; tools/probes/conv_prof.py)'}
     if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:              # multi-launch linear + BatchNorm chain
         nets = 2 if cfg['kind'] == 'maf' else 1

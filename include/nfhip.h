@@ -408,6 +408,15 @@ typedef struct nf_conv_bwd_desc {
 } nf_conv_bwd_desc;
 int nf_conv_bwd_slabs(int64_t B, int H, int W);
 int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, nf_stream_t stream);
+/* Split form for a model's backward pass: nf_conv_bn_bwd with g_weff == NULL (then g_bias must be NULL too) computes only what
+ * the next layer waits for -- g_store, gn_out, sum_g / sum_gx.  The weight-gradient slabs and bias sums of up to
+ * NF_CONV_WGRAD_MAX layers of one shape (B, I, O, H, W, ksize) are then produced by ONE launch of nf_conv_bn_wgrad_multi, any
+ * time after the layers' data passes (same descriptors, with g_weff / g_bias set; g_store, gn_out, sum_g, sum_gx are ignored).
+ * Nothing but the optimizer waits for them: deferred to the end of the backward pass they fill the machine instead of sitting
+ * on every layer's latency chain.                                                                                          */
+#define NF_CONV_WGRAD_MAX 16
+int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int O, int H, int W, int ksize,
+                           nf_stream_t stream);
 
 /* dst[e] (+)= sum_{s < n_slabs} src[s * stride + e], e < n: every slab / replica sum of one conditioner backward in ONE
  * launch (weight-gradient slabs, bias and BatchNorm-parameter replicas).                                                */

@@ -17,6 +17,8 @@
 // paths (the spatial extents are powers of two, the weight decode is done once per lane); the MFMA operands are read from
 // LDS one group ahead of the MFMAs that consume them; the per-channel batch sums use a halving butterfly (16 shuffles per
 // statistic instead of 80).
+#include <mutex>
+#include <unordered_set>
 #include "nf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -530,15 +532,19 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, N
     NF_CV_STAMP(5);
 }
 
-// dynamic LDS above the 64 KB default needs a per-kernel opt-in (160 KB per CU on gfx950); once per instantiation
+// dynamic LDS above the 64 KB default needs a per-kernel opt-in (160 KB per CU on gfx950), once per kernel (keyed by the
+// function's address: the instantiations of one template share their pointer TYPE)
 template <typename K>
 static inline int nf_cv_optin(K kernel, size_t lds) {
-    static bool done = false;          // one static per kernel type
+    static std::mutex mu;
+    static std::unordered_set<const void*> done;
     if (lds > 160 * 1024) return NF_E_BADARG;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.find(key) == done.end()) {
+        hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        done = true;
+        done.insert(key);
     }
     return 0;
 }
@@ -600,8 +606,18 @@ extern "C" int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O,
 // LDS: Wd[T * 32 OCB][33]  (one input chunk; rows k = tap * OP + oc, columns ic)     Al[32][CS]     Gl[32 OCB][CS]
 //      cb[5][32] (consumer BatchNorm constants), kc[4][32] (input BatchNorm), red[2][4][32];
 //      the K-quarter exchange RS aliases the start of the tiles once their last reader is done
-template <int T, int ICB, int OCB>
-__global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc d, NfCvGeo g, int I, int O, int iters) {
+// MODE 0: data and weight gradient (a stand-alone layer).  A conditioner backward inside a trainer step splits them: MODE 1 =
+// the data gradient only -- the chain the next layer waits for: no activation frame, no weight-gradient tiles, no slab, no
+// bias sums --, MODE 2 = the weight gradient only -- nothing but Adam waits for it, so the MODE 2 passes of every layer of
+// the model are deferred and run sixteen layers per launch (blockIdx.y = layer) after the last layer's data gradient, where
+// they fill the machine instead of sitting on the latency chain of 8 .. 128 workgroups (nf_conv_bn_wgrad_multi): no weights,
+// no K loop, no exchange, no stores of g_store / gn_out, no BatchNorm sums.
+#define NF_CV_WG_MAX NF_CONV_WGRAD_MAX
+struct NfCvBwdMulti { nf_conv_bwd_desc d[NF_CV_WG_MAX]; };
+
+template <int T, int ICB, int OCB, int MODE>
+__device__ __forceinline__ void nf_cv_bwd_body(const nf_conv_bwd_desc& d, const NfCvGeo& g, int I, int O, int iters) {
+    constexpr bool DG = MODE != 2, WG = MODE != 1;
     static_assert(T == 1 || OCB == 1, "3x3 layers produce <= 32 channels");
     static_assert(T == 9 || ICB == 1, "the 1x1 layer consumes <= 32 channels");
     constexpr int NTC = T == 9 ? 9 : OCB;              // weight-gradient tiles per input chunk
@@ -611,11 +627,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int OP = (O + 15) & ~15;                     // K rows of the data gradient, zero padded
     float* Wd = smem;
-    float* Al = Wd + T * OPmax * NF_CV_WS;
+    float* Al = Wd + (DG ? T * OPmax * NF_CV_WS : 0);  // (the weight-gradient pass stages no weights)
     float* Gl = Al + 32 * g.CS;
     float* endf = Gl + OPmax * g.CS;
     float* X = smem;                                   // K-quarter exchange: over Wd | Al (3x3; never reaches Gl) or all tiles (1x1)
-    if (endf < smem + NF_CV_RS) endf = smem + NF_CV_RS;
+    if (DG && endf < smem + NF_CV_RS) endf = smem + NF_CV_RS;
     float* cb = endf;                                  // [5][32]
     float* kc = cb + 5 * 32;                           // [4][32]
     float* red = kc + 4 * 32;                          // [2][4][32]
@@ -693,7 +709,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
             // flight together.  Everything at once needs ~70 live registers on top of the kernel's own state and spilled (120
             // scratch operations, 25 us); three short round trips are cheaper than that.
             NfCvW<T> wv;
-            if (T == 9) nf_cv_w_load<T, true>(wv, d.weight, O, I, i0, IC, ICP, OP, wid, lane);
+            if (DG && T == 9) nf_cv_w_load<T, true>(wv, d.weight, O, I, i0, IC, ICP, OP, wid, lane);
             const int64_t P0t = tile * NF_CV_PX;
             const int y0t = g.SEG == 1 ? (int)(P0t & (g.HW - 1)) >> g.lgW : 0;
 #pragma unroll 1
@@ -705,7 +721,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
 #pragma unroll
                 for (int u = 0; u < NF_CV_CU; ++u) {
                     const int c = wid + u * NF_CV_WAVES;
-                    xa[u] = (t >= 0 && c < IC) ? in0[(sg_ * I + i0 + c) * g.HW + sp] : 0.f;
+                    xa[u] = (WG && t >= 0 && c < IC) ? in0[(sg_ * I + i0 + c) * g.HW + sp] : 0.f;
                 }
                 if (jj == 0) __syncthreads();          // previous readers of the frames / Wd / exchange are done; cb, kc
                 if (ib == 0) {
@@ -734,7 +750,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
                                             const float xh = (w4[u] - cb[32 + c]) * cb[64 + c];
                                             v += cb[c] * (w3[u] - cb[96 + c] - xh * cb[128 + c]);
                                         }
-                                        if (d.g_store != nullptr && (t >> 30)) d.g_store[go0 + (sg_ * O + c) * g.HW + sp] = v;
+                                        if (DG && d.g_store != nullptr && (t >> 30)) d.g_store[go0 + (sg_ * O + c) * g.HW + sp] = v;
                                     }
                                     Gl[c * g.CS + f] = v;
                                 }
@@ -742,7 +758,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
                         }
                     }
                 }
-                if (f < g.FSZ) {
+                if (WG && f < g.FSZ) {
 #pragma unroll
                     for (int u = 0; u < NF_CV_CU; ++u) {
                         const int c = wid + u * NF_CV_WAVES;
@@ -753,7 +769,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
                         }
                     }
                 }
-                if (jj == 0) {
+                if (DG && jj == 0) {
                     if (T == 9) {
                         nf_cv_w_store<T, true>(wv, Wd, O, wid);
                     } else {                           // 1x1: row oc, column ic
@@ -775,7 +791,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
             for (int v = 0; v < NUW; ++v)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accW[v][r] = 0.f;
-            {
+            if (WG) {
                 float av0[4][NUW], bv0[4][NUW], av1[4][NUW], bv1[4][NUW];
 #define NF_CV_WLOAD(A_, B_, J_)                                                                            \
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                       \
@@ -807,7 +823,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
 #pragma unroll
             for (int r = 0; r < 16; ++r) accD[0][r] = 0.f;
             float xin[4];
-            if (d.gn_out != nullptr) {
+            if (DG && d.gn_out != nullptr) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int ic = 8 * kq + rr + 4 * hs;
@@ -821,7 +837,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
             // ---- this workgroup's slab of g_weff, in (T, O, I) order; first tile stores, later tiles add ----
 #pragma unroll
             for (int v = 0; v < NUW; ++v)
-                if (uval[v]) {
+                if (WG && uval[v]) {
                     const int tl = wid + NF_CV_WAVES * v;
                     const int tap = T == 9 ? tl : 0, ob = T == 9 ? 0 : tl;
                     const int ic = i0 + c32;
@@ -836,11 +852,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
                     }
                 }
             float own[4] = {0.f, 0.f, 0.f, 0.f};
-            if (d.gn_out != nullptr) {                 // block-uniform
+            if (DG && d.gn_out != nullptr) {           // block-uniform
                 __syncthreads();                       // every wave is done with Wd / Al / Gl reads of this chunk
                 nf_cv_quarter_exchange(own, accD[0], X, pb, kq, lane);
             }
-            if (d.gn_out != nullptr) {
+            if (DG && d.gn_out != nullptr) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int ic = 8 * kq + rr + 4 * hs;
@@ -860,7 +876,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
     }
     NF_CV_STAMP(13);
     // ---- bias and BatchNorm sums ----
-    if (d.g_bias != nullptr) {
+    if (WG && d.g_bias != nullptr) {
 #pragma unroll
         for (int v = 0; v < NUW; ++v) {
             const int tl = wid + NF_CV_WAVES * v;
@@ -872,7 +888,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
             }
         }
     }
-    if (has_bn && d.sum_g != nullptr) {                // block-uniform
+    if (DG && has_bn && d.sum_g != nullptr) {          // block-uniform
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const float t1 = nf_cv_half_sum(sg[rr]), t2 = nf_cv_half_sum(sgx[rr]);
@@ -894,6 +910,15 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
     NF_CV_STAMP(14);
 }
 
+template <int T, int ICB, int OCB, int MODE>
+__global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc d, NfCvGeo g, int I, int O, int iters) {
+    nf_cv_bwd_body<T, ICB, OCB, MODE>(d, g, I, O, iters);
+}
+template <int T, int ICB, int OCB>
+__global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_wgrad_multi(NfCvBwdMulti m, NfCvGeo g, int I, int O, int iters) {
+    nf_cv_bwd_body<T, ICB, OCB, 2>(m.d[blockIdx.y], g, I, O, iters);
+}
+
 #define NF_CV_BWD_MAX_SLABS 128
 extern "C" int nf_conv_bwd_slabs(int64_t B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -904,7 +929,8 @@ extern "C" int nf_conv_bwd_slabs(int64_t B, int H, int W) {
 extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int O, int H, int W, int ksize,
                               nf_stream_t stream) {
     NfCvGeo g;
-    if (desc == nullptr || desc->g_weff == nullptr || !nf_conv_bn_usable(B > 0 ? B : 1, I, O, H, W, ksize)) return NF_E_BADARG;
+    if (desc == nullptr || !nf_conv_bn_usable(B > 0 ? B : 1, I, O, H, W, ksize)) return NF_E_BADARG;
+    if (desc->g_weff == nullptr && desc->g_bias != nullptr) return NF_E_BADARG;   // the bias sums belong to the weight-gradient pass
     if (B == 0) return 0;
     if (!nf_cv_geometry(g, B, H, W, ksize)) return NF_E_BADARG;
     if (desc->bn_gamma != nullptr && I > 32) return NF_E_BADARG;
@@ -919,11 +945,66 @@ extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, in
     const int iters = (int)((g.tiles + grid - 1) / grid);
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    const bool dgrad_only = desc->g_weff == nullptr;  // MODE 1: the weight gradient follows in nf_conv_bn_wgrad_multi
 #define NF_LAUNCH(T_, IB_, OB_)                                                                                        \
     do {                                                                                                               \
-        rc = nf_cv_optin(k_conv_bn_bwd<T_, IB_, OB_>, lds);                                                            \
+        if (dgrad_only) {                                                                                              \
+            rc = nf_cv_optin(k_conv_bn_bwd<T_, IB_, OB_, 1>, lds);                                                     \
+            if (rc) return rc;                                                                                         \
+            hipLaunchKernelGGL((k_conv_bn_bwd<T_, IB_, OB_, 1>), dim3(grid), dim3(NF_CV_THREADS), lds, st, *desc, g, I, O, iters); \
+        } else {                                                                                                       \
+            rc = nf_cv_optin(k_conv_bn_bwd<T_, IB_, OB_, 0>, lds);                                                     \
+            if (rc) return rc;                                                                                         \
+            hipLaunchKernelGGL((k_conv_bn_bwd<T_, IB_, OB_, 0>), dim3(grid), dim3(NF_CV_THREADS), lds, st, *desc, g, I, O, iters); \
+        }                                                                                                              \
+    } while (0)
+    if (T == 9) {
+        if (ICB == 1) NF_LAUNCH(9, 1, 1);
+        else if (ICB == 2) NF_LAUNCH(9, 2, 1);
+        else NF_LAUNCH(9, 3, 1);
+    } else {
+        switch (OCB) {
+            case 1: NF_LAUNCH(1, 1, 1); break;
+            case 2: NF_LAUNCH(1, 1, 2); break;
+            case 3: NF_LAUNCH(1, 1, 3); break;
+            case 4: NF_LAUNCH(1, 1, 4); break;
+            case 5: NF_LAUNCH(1, 1, 5); break;
+            default: NF_LAUNCH(1, 1, 6); break;
+        }
+    }
+#undef NF_LAUNCH
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int O, int H, int W, int ksize,
+                                      nf_stream_t stream) {
+    NfCvGeo g;
+    if (descs == nullptr || n < 1 || n > NF_CV_WG_MAX || !nf_conv_bn_usable(B > 0 ? B : 1, I, O, H, W, ksize)) return NF_E_BADARG;
+    if (B == 0) return 0;
+    if (!nf_cv_geometry(g, B, H, W, ksize)) return NF_E_BADARG;
+    if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
+    NfCvBwdMulti m{};
+    for (int k = 0; k < n; ++k) {
+        if (descs[k].g_weff == nullptr || descs[k].in == nullptr) return NF_E_BADARG;
+        if (descs[k].bn_gamma != nullptr && I > 32) return NF_E_BADARG;
+        if (descs[k].gn_src != nullptr && O > 32) return NF_E_BADARG;
+        m.d[k] = descs[k];
+        m.d[k].g_store = nullptr; m.d[k].gn_out = nullptr; m.d[k].sum_g = nullptr; m.d[k].sum_gx = nullptr;   // the data pass did those
+    }
+    const int ICB = (I + 31) / 32, OCB = (O + 31) / 32;
+    const int T = ksize * ksize;
+    const size_t lds = sizeof(float) * ((size_t)32 * g.CS + (size_t)32 * OCB * g.CS + 5 * 32 + 4 * 32 + 2 * 4 * 32);
+    const unsigned grid = (unsigned)nf_conv_bwd_slabs(B, H, W);
+    const int iters = (int)((g.tiles + grid - 1) / grid);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+#define NF_LAUNCH(T_, IB_, OB_)                                                                                        \
+    do {                                                                                                               \
+        rc = nf_cv_optin(k_conv_bn_wgrad_multi<T_, IB_, OB_>, lds);                                                    \
         if (rc) return rc;                                                                                             \
-        hipLaunchKernelGGL((k_conv_bn_bwd<T_, IB_, OB_>), dim3(grid), dim3(NF_CV_THREADS), lds, st, *desc, g, I, O, iters); \
+        hipLaunchKernelGGL((k_conv_bn_wgrad_multi<T_, IB_, OB_>), dim3(grid, (unsigned)n), dim3(NF_CV_THREADS), lds, st, m, g, I, O, \
+                           iters);                                                                                     \
     } while (0)
     if (T == 9) {
         if (ICB == 1) NF_LAUNCH(9, 1, 1);

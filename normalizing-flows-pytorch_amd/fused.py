@@ -1377,10 +1377,14 @@ class _WeightNormMulti(torch.autograd.Function):
         ctx.eps = float(eps)
         from .functional import _sinks
         ctx.sinks = _sinks(*tensors)
+        from .fused_conv import CONV_DEFER
+        CONV_DEFER.arm(outs)                      # consumers may hand back gradients that are filled when backward() flushes
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *g_ws):
+        from .fused_conv import CONV_DEFER
+        CONV_DEFER.flush()                        # the deferred weight-gradient passes of the image conditioners fill g_ws
         tensors = ctx.saved_tensors
         vs, gs = tensors[0::2], tensors[1::2]
         direct = ctx.sinks is not None

@@ -61,6 +61,81 @@ def _slab_sum(jobs):
     N.call('nf_slab_sum', ctypes.addressof(arr), len(jobs), N.stream())
 
 
+def _slab_sum_all(jobs):
+    step = N.header_constant('NF_SLAB_SUM_MAX')
+    for k0 in range(0, len(jobs), step):
+        _slab_sum(jobs[k0:k0 + step])
+
+
+class ConvDefer:
+    """Deferred weight gradients of the fused image conditioners.  The weight-gradient tiles, slabs and bias sums of a
+    convolution's backward are on the latency chain of its launch (~10 of ~36 us on 8 .. 128 workgroups), yet only the
+    weight-norm backward at the very end of the pass and Adam wait for them.  Inside a trainer step whose effective weights
+    come from fused.weight_norm_all (which flushes before it reads the gradients), a conditioner's backward launches only
+    the data-gradient passes (nf_conv_bn_bwd with g_weff = NULL) and queues the rest; ``flush`` runs the queued layers
+    sixteen per launch (nf_conv_bn_wgrad_multi), where they fill the machine, then their slab sums.  Closed (the default)
+    nothing is deferred."""
+
+    def __init__(self):
+        self.active = False
+        self.armed = False
+        self.layers = []        # (key, desc kwargs, dst weight gradient, n_slabs)
+        self.sums = []          # slab-sum jobs that read accumulators the deferred passes fill, or that can wait as well
+        self.scratch = {}
+
+    def begin(self):
+        self.layers, self.sums = [], []
+        self.active, self.armed = CONV_DEFER_ON, False
+
+    def arm(self, weights):
+        """fused.weight_norm_all: these effective weights' gradients are consumed by a backward that flushes first"""
+        if self.active:
+            self.armed = True
+            for w in weights:
+                w._nf_deferred_grad_ok = True
+
+    def usable(self, weights):
+        return self.active and self.armed and all(getattr(w, '_nf_deferred_grad_ok', False) for w in weights)
+
+    def _slab_scratch(self, n, device):
+        t = self.scratch.get(device)
+        if t is None or t.numel() < n:
+            t = self.scratch[device] = torch.empty(n, dtype=torch.float32, device=device)
+        return t
+
+    def flush(self):
+        layers, sums = self.layers, self.sums
+        self.layers, self.sums, self.active, self.armed = [], [], False, False
+        if not layers and not sums:
+            return
+        step = N.header_constant('NF_CONV_WGRAD_MAX')
+        groups = {}
+        for e in layers:
+            groups.setdefault(e[0], []).append(e)
+        for key, es in groups.items():
+            (B, Hh, Ww), I, O, k = key
+            for k0 in range(0, len(es), step):
+                chunk = es[k0:k0 + step]
+                per = [e[3] * e[2].numel() for e in chunk]
+                dev = chunk[0][2].device
+                scratch = self._slab_scratch(sum(per), dev)
+                arr = (ConvBwdDesc * len(chunk))()
+                jobs, off = [], 0
+                for i, (_, kw, g_w, n_slabs) in enumerate(chunk):
+                    region = scratch[off:off + per[i]]
+                    off += per[i]
+                    d = _desc(ConvBwdDesc, g_weff=region, **kw)
+                    ctypes.memmove(ctypes.addressof(arr) + i * ctypes.sizeof(ConvBwdDesc), ctypes.addressof(d), ctypes.sizeof(ConvBwdDesc))
+                    jobs.append((region, g_w, g_w.numel(), g_w.numel(), n_slabs, False, k * k))
+                N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
+                _slab_sum_all(jobs)                  # before the next chunk overwrites the scratch (stream order)
+        _slab_sum_all(sums)
+
+
+CONV_DEFER_ON = __import__('os').environ.get('NF_CONV_DEFER', '1') != '0'
+CONV_DEFER = ConvDefer()
+
+
 def _convnet_modules(net):
     convs = [net.in_block[0]]
     bns = []
@@ -107,7 +182,7 @@ class _FusedConvNet(torch.autograd.Function):
     num_batches_tracked) * 5."""
 
     @staticmethod
-    def forward(ctx, x, training, *tensors):
+    def forward(ctx, x, training, defer, *tensors):
         nl, nb = 6, 5
         conv = [tensors[2 * i:2 * i + 2] for i in range(nl)]
         bns = [tensors[2 * nl + 5 * i:2 * nl + 5 * i + 5] for i in range(nb)]
@@ -138,6 +213,7 @@ class _FusedConvNet(torch.autograd.Function):
         ctx.meta = (shape, I0, O_out, bool(training))
         from .functional import _sinks
         ctx.sinks = _sinks(*[c[1] for c in conv], *[t for b in bns for t in b[:2]])
+        ctx.defer = bool(defer) and ctx.sinks is not None
         return out
 
     @staticmethod
@@ -155,7 +231,8 @@ class _FusedConvNet(torch.autograd.Function):
         B, Hh, Ww = shape
         g_out = g_out.contiguous()
         slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
-        g_weff = [torch.empty(slabs, t.numel(), dtype=torch.float32, device=dev) for t in w]
+        g_weff = [None] * nl if (ctx.defer and CONV_DEFER.active) else \
+            [torch.empty(slabs, t.numel(), dtype=torch.float32, device=dev) for t in w]
         acc = WS.zeros(nl * R * GB + nb * 2 * R * H, dev)
         g_bias = [acc[i * R * GB:(i + 1) * R * GB] for i in range(nl)]
         sums = acc[nl * R * GB:].view(nb, 2, R * H)
@@ -170,18 +247,29 @@ class _FusedConvNet(torch.autograd.Function):
             return dict(cbn_gamma=gamma[j], cbn_save_mean=ws[j, 2 * R], cbn_save_invstd=ws[j, 2 * R + 1],
                         cbn_sum_g=sums[j, 0] if training else None, cbn_sum_gx=sums[j, 1] if training else None)
 
-        _bwd(shape, H, O_out, 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, g_bias=g_bias[nl - 1],
-             g_weff=g_weff[nl - 1], gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0], sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))
+        defer = ctx.defer and CONV_DEFER.active
+        queued = []
+
+        def layer(I, O, k, i, **kw):
+            """convolution i's backward: both passes now, or the data pass now and the weight pass queued"""
+            if not defer:
+                _bwd(shape, I, O, k, g_bias=g_bias[i], g_weff=g_weff[i], **kw)
+                return
+            _bwd(shape, I, O, k, **kw)
+            wkw = {f: v for f, v in kw.items() if f not in ('g_store', 'gn_out', 'sum_g', 'sum_gx')}
+            wkw['g_bias'] = g_bias[i]
+            queued.append(((shape, I, O, k), wkw, i))
+
+        layer(H, O_out, 1, nl - 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0],
+              sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))
         for j in range(nb - 1, 0, -1):             # convolution j produced acts[j]; its consumer BatchNorm is j
             is_stream = (j % 2 == 0)
             store = torch.empty_like(acts[0]) if is_stream else None
-            _bwd(shape, H, H, 3, in_=acts[j - 1], weight=w[j], gn_src=gn[j], out=acts[j],
-                 g_skip=G_skip if is_stream else None, g_store=store, g_bias=g_bias[j], g_weff=g_weff[j], gn_out=gn[j - 1],
-                 sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1), **cons_bn(j))
+            layer(H, H, 3, j, in_=acts[j - 1], weight=w[j], gn_src=gn[j], out=acts[j], g_skip=G_skip if is_stream else None,
+                  g_store=store, gn_out=gn[j - 1], sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1), **cons_bn(j))
             if is_stream:
                 G_skip = store
-        _bwd(shape, I0, H, 3, in_=x, weight=w[0], gn_src=gn[0], out=acts[0], g_skip=G_skip, g_bias=g_bias[0],
-             g_weff=g_weff[0], gn_out=g_x, **cons_bn(0))
+        layer(I0, H, 3, 0, in_=x, weight=w[0], gn_src=gn[0], out=acts[0], g_skip=G_skip, gn_out=g_x, **cons_bn(0))
 
         direct = ctx.sinks is not None
         g_w = [torch.empty_like(t) for t in w]
@@ -197,15 +285,21 @@ class _FusedConvNet(torch.autograd.Function):
         for j in range(nb):
             jobs.append((sums[j, 1], d_bn[j][0], H, H, R, direct, 1))       # g_gamma = sum g * xhat
             jobs.append((sums[j, 0], d_bn[j][1], H, H, R, direct, 1))       # g_beta  = sum g
-        _slab_sum(jobs)
+        if defer:
+            for key, wkw, i in queued:             # (the tensors in wkw keep every operand alive until the flush)
+                CONV_DEFER.layers.append((key, wkw, g_w[i], slabs))
+            CONV_DEFER.sums += jobs[nl:]
+        else:
+            _slab_sum(jobs)
         grads = []
         for i in range(nl):
             grads += [g_w[i], None if direct else d_bias[i]]
         for j in range(nb):
             grads += [None if direct else d_bn[j][0], None if direct else d_bn[j][1], None, None, None]
-        return (g_x, None) + tuple(grads)
+        return (g_x, None, None) + tuple(grads)
 
 
 def convnet_forward(net, x):
     """``net``: conditioners.ConvNet; returns the conditioner output (B, out_channels, H, W)."""
-    return _FusedConvNet.apply(x, net.training, *_convnet_tensors(net))
+    tensors = _convnet_tensors(net)
+    return _FusedConvNet.apply(x, net.training, CONV_DEFER.usable(tensors[0:12:2]), *tensors)

@@ -111,14 +111,17 @@ class FlowTrainer:
             for i in self._indirect:
                 self.bucket.params[i].grad = None       # AccumulateGrad then keeps the incoming tensor: no add launch
         from .fused import FPP_DEFER
+        from .fused_conv import CONV_DEFER
         ARENA.begin(y.device)                           # one memset for every zero-initialised accumulator of the step
         FPP_DEFER.begin()                               # the Flow++ steps' slab finalizes: all of them in one go after backward
+        CONV_DEFER.begin()                              # the image conditioners' weight-gradient passes: sixteen layers per launch
         try:
             z, ld = self.net(y)
             loss = nll_loss(z, ld)
             loss.backward()
         finally:
             FPP_DEFER.flush()
+            CONV_DEFER.flush()
             ARENA.end()
             for h in hooks:
                 h.remove()

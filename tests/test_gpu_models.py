@@ -155,3 +155,45 @@ def test_trainer_keeps_direct_gradient_sinks(pkg):
         assert t._indirect == []
         assert all(F.grad_sink(p) is not None for p in net.parameters())
 
+
+
+@pytest.mark.parametrize('dims,B,K', [((3, 32, 32), 16, 2), ((3, 16, 16), 5, 3)])
+def test_trainer_deferred_conv_weight_gradients(pkg, dims, B, K, monkeypatch):
+    """inside a trainer step the image conditioners' backward launches only the data-gradient passes and the weight-gradient
+    passes of all layers run sixteen per launch when the weight-norm backward asks for them (nf_conv_bn_bwd with g_weff =
+    NULL + nf_conv_bn_wgrad_multi): same loss and the same flat gradient as the unsplit launches."""
+    import copy
+    import importlib
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    torch.manual_seed(7)
+    net1 = pkg.Glow(dims, 'image', NS(layers=K, mixtures=8)).to(DEV)
+    net2 = copy.deepcopy(net1)
+    y = torch.rand(B, *dims, device=DEV)
+    t1, t2 = train.FlowTrainer(net1, graph=False), train.FlowTrainer(net2, graph=False)
+    queued = []
+    real_flush = fc.ConvDefer.flush
+
+    def flush(self):
+        queued.append(len(self.layers))
+        return real_flush(self)
+
+    monkeypatch.setattr(fc.ConvDefer, 'flush', flush)
+    for step in range(3):                                   # step 0 initialises the ActNorms (atomics: replicas re-synced below)
+        monkeypatch.setattr(fc, 'CONV_DEFER_ON', True)
+        z1, l1 = t1._forward_backward(y)
+        monkeypatch.setattr(fc, 'CONV_DEFER_ON', False)
+        z2, l2 = t2._forward_backward(y)
+        assert not fc.CONV_DEFER.layers and not fc.CONV_DEFER.sums and not fc.CONV_DEFER.active
+        if step > 0:
+            G.assert_close(z1, z2, 1e-5, rtol=1e-5, what='z, step %d' % step)
+            G.assert_close(l1, l2, 1e-5, rtol=1e-5, what='loss, step %d' % step)
+            scale = float(t2.bucket.flat.abs().max())
+            # (same kernels and operands; the slab sums and bias atomics add in a different order)
+            G.assert_close(t1.bucket.flat, t2.bucket.flat, 2e-5 * max(1.0, scale), what='flat grads, step %d' % step)
+        t1.optim.step()
+        net2.load_state_dict(net1.state_dict())
+        t2.bucket.flat_params.copy_(t1.bucket.flat_params)
+    n_cond = sum(1 for m in net1.modules() if type(m).__name__ == 'ConvNet')
+    assert max(queued) == 6 * n_cond, 'weight-gradient passes were not deferred (queue lengths %r)' % (queued, )
