@@ -409,7 +409,8 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                      'k_conv_bn_bwd<9, 1, 1, 0> (3x3 convolution + BatchNorm2d + ReLU backward, 32 -> 32 channels, %d x %d)') % (Hh, Ww)
             return {'bound': 'mfma', 'kernel': kname,
                     'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
-                    'traffic': None, 'flop_per_launch': int(flop), 'bytes_per_launch': int(M * Cc * 4 * (4 if split else 5)),
+                    'traffic': pmc_traffic('k_conv_bn_bwd', B) if split else None, 'flop_per_launch': int(flop),
+                    'bytes_per_launch': int(M * Cc * 4 * (4 if split else 5)),
                     'us_per_launch': round(us, 3),
                     'note': 'latency-bound at this size (0.3 GFLOP over 128 workgroups): ~3 us of MFMA work inside a serial chain of '
                             'dependent memory round trips (DESIGN.md section 3.15; tools/probes/conv_prof.py)'}

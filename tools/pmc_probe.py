@@ -26,7 +26,7 @@ def summarise(paths):
             a[1] += float(r['Counter_Value'])
     print('%-60s %-12s %-10s %8s %14s' % ('kernel', 'counter', 'grid', 'calls', 'avg value'))
     for (k, c, g), (n, v) in sorted(agg.items()):
-        if k.startswith('k_') or 'copy' in k.lower() or 'void k_' in k or 'k_mlp' in k or 'k_flowpp' in k or 'k_maf' in k or 'k_glow' in k:
+        if k.startswith('k_') or 'copy' in k.lower() or 'void k_' in k or any(t in k for t in ('k_mlp', 'k_flowpp', 'k_maf', 'k_glow', 'k_conv')):
             print('%-60s %-12s %-10s %8d %14.2f' % (k, c, g, n, v / n))
 
 
