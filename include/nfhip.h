@@ -520,6 +520,14 @@ int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, fl
                          const void* const* mlp_params, const float* save_stats, void* const* head_grads,
                          void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
                          int training, float bn_eps, float wn_eps, nf_stream_t stream);
+/* the INVERSE of the same step in one launch (ActNorm.backward o InvertibleConv1x1.backward o AffineCoupling.backward,
+ * modules.py:250-256, :484-497, coupling.py:115-122): y (N, D) -> z, ld -= the step's log-det.  head as above EXCEPT slot 2:
+ * the row-swap matrix of the LAPACK pivots (what torch.lu_solve applies to its right-hand side; = P^T for consistent factors);
+ * W^-1 = U'^-1 L'^-1 Pp is formed inside.  The conditioner runs in the mode `training` says (batch statistics + running-
+ * statistics update, or running statistics); save_stats: NF_GLOW_FLOW_SAVE_FLOATS floats of scratch.                          */
+int nf_glow_step_vec_inv(const float* y, float* z, float* ld, const void* const* head, const void* const* mlp_params,
+                         float* save_stats, float* ws_zero, int64_t N, int D, int odd, int training, float bn_eps,
+                         float bn_momentum, float wn_eps, nf_stream_t stream);
 
 /* ---- one whole RealNVP flow step on vector data in one persistent launch per direction (training mode) -----------------
  * dims = (D,), D = 2 or 4: flow BatchNorm with batch statistics (modules.py:283-307, affine=False) -> affine coupling whose
@@ -633,6 +641,10 @@ int nf_glow_flow_step_bytes(void);
 int nf_glow_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, void* const* head_grads,
                       void* const* mlp_grads, int D, int odd);
 int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
+                         int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
+/* inverse of the whole run, last step first (records packed with the pivot matrix in head slot 2, see nf_glow_step_vec_inv);
+ * zs2: (2, N, D) scratch whose FIRST slice holds the flow's input on return; ld -= the run's log-det.                        */
+int nf_glow_flow_vec_inv(const void* steps_dev, int S, const float* y, float* zs2, float* ld, float* saves, float* ws_zero,
                          int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
 int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,
                          float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2, int64_t N, int D,

@@ -401,6 +401,38 @@ __device__ __forceinline__ void nf_glow_head_row(const float* sm, const float (&
         hh[r] = acc;
     }
 }
+// INVERSE step (modules.py:250-256, :484-497): W^-1 = U'^-1 L'^-1 Pp by two triangular solves on one thread (D <= 4), Pp = the
+// row-swap matrix of the LAPACK pivots (what torch.lu_solve applies to its right-hand side; the caller passes it in the P
+// slot of the head) -> sm[NF_MC_HEAD + 0 .. 15], replacing W; then z = (W^-1 h) exp(log_scale) + bias per row.
+__device__ __forceinline__ void nf_glow_head_inverse_weight(float* sm, int D) {
+    const float* Lp = sm + NF_MC_HEAD + 32;
+    const float* Up = sm + NF_MC_HEAD + 48;
+    const float* Pp = sm + NF_MC_HEAD + 64;
+    float X[4][4];
+    for (int c = 0; c < 4; ++c) {
+        for (int r = 0; r < 4; ++r) {                     // forward substitution, unit lower triangular
+            float v = (r < D && c < D) ? Pp[4 * r + c] : 0.f;
+            for (int k = 0; k < r; ++k) v -= Lp[4 * r + k] * X[k][c];
+            X[r][c] = v;
+        }
+        for (int r = 3; r >= 0; --r) {                    // back substitution
+            float v = X[r][c];
+            for (int k = r + 1; k < 4; ++k) v -= Up[4 * r + k] * X[k][c];
+            X[r][c] = r < D ? v / Up[4 * r + r] : 0.f;
+        }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) sm[NF_MC_HEAD + 4 * r + c] = X[r][c];
+}
+__device__ __forceinline__ void nf_glow_head_inverse_row(const float* sm, const float (&hh)[4], float (&zr)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = fmaf(sm[NF_MC_HEAD + 4 * r + c], hh[c], acc);
+        zr[r] = fmaf(acc, sm[NF_MC_HEAD + 16 + r], sm[NF_MC_HEAD + 20 + r]);
+    }
+}
 // the conditioner input in R: feature e < D / 2 is element e of the conditioning half (squeeze.py:68-69: interleaved)
 __device__ __forceinline__ void nf_glow_cond_input(const float (&hh)[4], int D, int odd, float (&xa)[8], int g) {
 #pragma unroll
@@ -434,12 +466,15 @@ struct NfMcCarry { float v[4]; float ld; int have; };
 
 // The body of one launch is a device function so that the whole-flow kernels (k_glow_flow_*) can run it once per flow step
 // inside ONE launch; hz / hy / hld are the step's input, output and log-det rows (h.z / h.y / h.ld of a single-step launch).
-template <int HEAD>   // 0: the conditioner alone; 1: whole Glow step (ActNorm + 1x1 head); 2: whole RealNVP step (flow-BatchNorm head)
+// INV (HEAD == 1 only): the INVERSE of the Glow step -- hz is the step's OUTPUT row y, the conditioner runs on its unchanged
+// half, then coupling^-1, (1x1)^-1, ActNorm^-1; hy receives the step's input, hld -= the step's log-det (coupling.py:115-122).
+template <int HEAD, bool INV = false>   // 0: the conditioner alone; 1: whole Glow step (ActNorm + 1x1 head); 2: whole RealNVP step (flow-BatchNorm head)
 __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restrict__ x, const NfMlpP& p, float* __restrict__ out,
                                                float* save, float* stats, int64_t N, int I0, int O_out, int training, float eps,
                                                float mom, float wn_eps, const NfGlowV& h, const float* hz, float* hy, float* hld,
                                                NfMcCarry* carry = nullptr) {
     constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;     // GLOW: a fused flow step (either head)
+    static_assert(!INV || HEAD == 1, "the inverse body is the Glow step's");
     NF_MC_T(0);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
@@ -508,7 +543,13 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
         if (threadIdx.x == 0) sm[NF_MC_HEAD + 24] = (sm[NF_MC_HEAD + 28] + sm[NF_MC_HEAD + 29]) + (sm[NF_MC_HEAD + 30] + sm[NF_MC_HEAD + 31]);
         __syncthreads();
     }
-    if (GLOW) {
+    if (INV) {
+        if (threadIdx.x == 0) nf_glow_head_inverse_weight(sm, h.D);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hh[c] = zr[c];         // y: its conditioning half is the head output's
+        nf_glow_cond_input(hh, h.D, h.odd, xa, g);
+        __syncthreads();
+    } else if (GLOW) {
         float zn[4];
         nf_glow_head_row(sm, zr, zn, hh);
         nf_glow_cond_input(hh, h.D, h.odd, xa, g);
@@ -571,7 +612,25 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
             for (int j = 0; j < 4; ++j) o4[j] = dv[j] + bias[j];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                if (e < nh) {
+                if (INV && e < nh) {                      // coupling^-1 (coupling.py:115-122): h0 = (y0 - t) exp(-s)
+                    const float sv = tanhf(e == 0 ? o4[nh] : o4[nh + 1]) * ca + cc;
+                    const float t = e == 0 ? o4[0] : o4[1];
+                    const float en = expf(-sv);
+                    if (sel0) hh[2 * e + 1] = (hh[2 * e + 1] - t) * en;
+                    else hh[2 * e] = (hh[2 * e] - t) * en;
+                    dld += sv;
+                }
+            }
+            if (INV) {                                    // (1x1)^-1, ActNorm^-1; the log-det of the whole step is subtracted
+                nf_glow_head_inverse_row(sm, hh, yv);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < D) hy[row * D + c] = yv[c];
+                dld = -dld;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (!INV && e < nh) {
                     const float sv = tanhf(e == 0 ? o4[nh] : o4[nh + 1]) * ca + cc;
                     const float t = e == 0 ? o4[0] : o4[1];
                     const float h0 = sel0 ? hh[2 * e + 1] : hh[2 * e], h1 = sel0 ? hh[2 * e] : hh[2 * e + 1];
@@ -601,12 +660,12 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
     NF_MC_T(8);
 }
 
-template <int HEAD>
+template <int HEAD, bool INV = false>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_mlp_chain_fwd(const float* __restrict__ x, NfMlpP p, float* __restrict__ out,
                                                                  float* save, float* stats, int64_t N, int I0, int O_out,
                                                                  int training, float eps, float mom, float wn_eps, NfGlowV h) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    nf_mc_fwd_body<HEAD>(sm, x, p, out, save, stats, N, I0, O_out, training, eps, mom, wn_eps, h, h.z, h.y, h.ld);
+    nf_mc_fwd_body<HEAD, INV>(sm, x, p, out, save, stats, N, I0, O_out, training, eps, mom, wn_eps, h, h.z, h.y, h.ld);
 }
 
 static inline size_t nf_mc_lds_bytes(int tiles_per_wave) {
@@ -1285,6 +1344,32 @@ extern "C" int nf_glow_step_vec_fwd(const float* z, float* y, float* ld, const v
     return 0;
 }
 
+extern "C" int nf_glow_step_vec_inv(const float* y, float* z, float* ld, const void* const* head, const void* const* mlp_params,
+                                    float* save_stats, float* ws_zero, int64_t N, int D, int odd, int training, float bn_eps,
+                                    float bn_momentum, float wn_eps, nf_stream_t stream) {
+    if (y == nullptr || z == nullptr || ld == nullptr || head == nullptr || mlp_params == nullptr || save_stats == nullptr ||
+        ws_zero == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMlpP p;
+    nf_mlp_unpack(mlp_params, p);
+    NfGlowV h{};
+    nf_glow_unpack(head, h);
+    h.z = y; h.y = z; h.ld = ld; h.D = D; h.odd = odd ? 1 : 0;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_mlp_chain_fwd<1, true>), dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+                       (float*)nullptr, save_stats, ws_zero, N, D / 2, D, training, bn_eps, bn_momentum, wn_eps, h);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
                                     const void* const* mlp_params, const float* save_stats, void* const* head_grads,
                                     void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
@@ -1391,6 +1476,32 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_fwd(const NfGlowFlo
     }
 }
 
+// the INVERSE of the whole run, last step first: rows travel in registers, zs (2, N, D) ping-pongs the steps' results (slice
+// s & 1: the flow's input ends up in slice 0)
+__global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_inv(const NfGlowFlowStep* __restrict__ steps, int S, const float* y,
+                                                                 float* zs, float* ld, float* saves, int save_stride, float* ws,
+                                                                 int64_t N, int D, int training, float eps, float mom,
+                                                                 float wn_eps, int rec_off) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    unsigned long long (*rec)[NF_GF_REC_WORDS] = reinterpret_cast<unsigned long long (*)[NF_GF_REC_WORDS]>(sm + rec_off);
+    const int64_t ND = N * D;
+    const bool rt = (int)threadIdx.x < NF_GF_REC_WORDS;
+    if (rt) rec[(S - 1) & 1][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps + S - 1)[threadIdx.x];
+    __syncthreads();
+    NfMcCarry carry;
+    carry.have = 0;
+#pragma unroll 1
+    for (int s = S - 1; s >= 0; --s) {
+        unsigned long long nxt = 0;
+        if (rt && s > 0) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 1)[threadIdx.x];
+        const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
+        nf_mc_fwd_body<1, true>(sm, nullptr, st.p, nullptr, saves + (int64_t)s * save_stride, ws + (int64_t)s * NF_MLP_WS_FLOATS, N,
+                                D / 2, D, training, eps, mom, wn_eps, st.h, y, zs + (int64_t)(s & 1) * ND, ld, &carry);
+        if (rt) rec[(s + 1) & 1][threadIdx.x] = nxt;    // parity of s - 1
+        __syncthreads();
+    }
+}
+
 template <int HEAD>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* z0,
                                                                  const float* ys, const float* g_y, const float* g_ld, float* gzs,
@@ -1473,6 +1584,27 @@ extern "C" int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z
                                     nf_stream_t stream) {
     return nf_flow_launch_fwd<1>(steps_dev, S, z0, ys, ld, saves, NF_GLOW_FLOW_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum,
                                  wn_eps, stream);
+}
+extern "C" int nf_glow_flow_vec_inv(const void* steps_dev, int S, const float* y, float* zs2, float* ld, float* saves, float* ws_zero,
+                                    int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                                    nf_stream_t stream) {
+    if (steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || y == nullptr || zs2 == nullptr || ld == nullptr ||
+        saves == nullptr || ws_zero == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t body_lds = nf_mc_lds_bytes(1), lds = body_lds + 2 * NF_GF_REC_WORDS * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_glow_flow_inv, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const NfGlowFlowStep*)steps_dev, S,
+                       y, zs2, ld, saves, NF_GLOW_FLOW_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum, wn_eps,
+                       (int)(body_lds / sizeof(float)));
+    NF_CHECK_LAUNCH();
+    return 0;
 }
 extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
                                     const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2,

@@ -843,6 +843,96 @@ def glow_flow_vec(z, ld, steps):
     return _GlowFlowVec.apply(z, _owned_ld(ld), odds, steps[0][2].net.training, not _flow_on(z), *tensors)
 
 
+def glow_flow_nograd_usable(z, steps):
+    """density evaluation (log_py under no_grad): the run of steps in ONE launch when that launch has no grid exchanges to pay
+    for (evaluation-mode conditioners) or the batch is small (training-mode statistics, see GLOW_FLOW)"""
+    if torch.is_grad_enabled() or len(steps) < 2 or len(steps) > N.header_constant('NF_GLOW_FLOW_MAX_STEPS') or GLOW_FLOW == '0':
+        return False
+    training = steps[0][2].net.training
+    if training and not _flow_on(z):
+        return False
+    return all(a.initialized and glow_step_vec_usable(z, k.net) and k.net.training == training for a, c, k in steps)
+
+
+def glow_flow_vec_nograd(z, ld, steps):
+    from .functional import _owned_ld
+    z = z.contiguous()
+    Nrows, D = z.shape
+    dev = z.device
+    S = len(steps)
+    training = bool(steps[0][2].net.training)
+    recs = [(int(k.odd), [t.detach() for t in (a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s,
+                                                 k.s_log_scale, k.s_bias)], [t.detach() for t in _mlp_tensors(k.net)])
+            for a, c, k in steps]
+    table = _glow_flow_table(recs, None, D, dev)
+    ld = _owned_ld(ld)
+    ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+    saves = torch.empty(S, N.header_constant('NF_GLOW_FLOW_SAVE_FLOATS'), dtype=torch.float32, device=dev)
+    nws = N.header_constant('NF_MLP_WS_FLOATS')
+    ws = WS.zeros(S * nws, dev) if training else torch.empty(S * nws, dtype=torch.float32, device=dev)
+    N.call('nf_glow_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
+           int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+    return ys[S - 1], ld
+
+
+# ---- the INVERSE of vector Glow steps (sampling: net.backward), one launch per step or per run --------------------------------
+GLOW_INVERSE = _os.environ.get('NF_GLOW_INVERSE', '1') != '0'
+
+
+def _glow_inverse_head(a, c, k):
+    """the 11 head tensors of _GlowStepVec with the pivots' row-swap matrix in the P slot (nf_glow_step_vec_inv)"""
+    return [a.log_scale, a.bias, c._pivot_matrix().contiguous(), c.L, c.U, c.L_mask, c.U_mask, c.sign_s, c.log_s, k.s_log_scale,
+            k.s_bias]
+
+
+def glow_inverse_usable(y, steps):
+    """steps: [(actnorm, conv, coupling)] of fused-step-capable Glow steps on (N, 2 | 4) data; no autograd through the inverse
+    (InvertibleConv1x1.backward runs under no_grad as well)."""
+    if not (GLOW_INVERSE and steps and len(steps) <= N.header_constant('NF_GLOW_FLOW_MAX_STEPS')):
+        return False
+    for a, c, k in steps:
+        if not (a.initialized and glow_step_vec_usable(y, k.net) and k.net.training == steps[0][2].net.training):
+            return False
+    return True
+
+
+def glow_flow_vec_inverse(y, ld, steps):
+    """y -> z through the inverses of ``steps`` (given in FORWARD order; applied last to first), ld -= the run's log-det:
+    one launch for the whole run in evaluation mode or on small batches (csrc/mlp_chain.hip: k_glow_flow_inv), one per step
+    otherwise (k_mlp_chain_fwd<1, true>)."""
+    with torch.no_grad():
+        y = y.contiguous()
+        Nrows, D = y.shape
+        dev = y.device
+        S = len(steps)
+        training = bool(steps[0][2].net.training)
+        ld = ld.clone()
+        nws = N.header_constant('NF_MLP_WS_FLOATS')
+        nsave = N.header_constant('NF_GLOW_FLOW_SAVE_FLOATS')
+        one_launch = S >= 2 and (not training or _flow_on(y))       # no exchanges in evaluation mode: nothing to lose
+        ws = WS.zeros(S * nws, dev) if training else torch.empty(nws, dtype=torch.float32, device=dev)
+        saves = torch.empty(S, nsave, dtype=torch.float32, device=dev)
+        if one_launch:
+            recs = [(int(k.odd), [t.detach() for t in _glow_inverse_head(a, c, k)], [t.detach() for t in _mlp_tensors(k.net)])
+                    for a, c, k in steps]
+            table = _glow_flow_table(recs, None, D, dev)
+            zs = torch.empty(2, Nrows, D, dtype=torch.float32, device=dev)
+            N.call('nf_glow_flow_vec_inv', table.data_ptr(), S, N.ptr(y), N.ptr(zs), N.ptr(ld), N.ptr(saves),
+                   N.ptr(ws), Nrows, D, int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+            return zs[0], ld
+        cur = y
+        for i in range(S - 1, -1, -1):
+            a, c, k = steps[i]
+            z = torch.empty_like(cur)
+            htab = _ptr_table([t.detach() for t in _glow_inverse_head(a, c, k)])
+            mtab = _ptr_table([t.detach() for t in _mlp_tensors(k.net)])
+            N.call('nf_glow_step_vec_inv', N.ptr(cur), N.ptr(z), N.ptr(ld), ctypes.addressof(htab), ctypes.addressof(mtab),
+                   N.ptr(saves[i]), N.ptr(ws[i * nws:(i + 1) * nws]) if training else N.ptr(ws), Nrows, D, int(k.odd), int(training),
+                   BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+            cur = z
+        return cur, ld
+
+
 def _realnvp_step_learnables(head, mlp):
     nl, nb = 6, 5
     return [head[6], head[7]] + list(mlp[:3 * nl]) + [t for j in range(nb) for t in mlp[3 * nl + 5 * j:3 * nl + 5 * j + 2]]

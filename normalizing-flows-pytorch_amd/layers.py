@@ -62,6 +62,8 @@ class Compose(nn.Module):
                 break
             run.append((a, c, k))
             j += 3
+        if FUSED.glow_flow_nograd_usable(z, run):            # density evaluation: no autograd node at all
+            return ('nograd', run)
         return run if FUSED.glow_flow_vec_usable(z, run) else None
 
     def _realnvp_run_at(self, i, z):
@@ -141,6 +143,10 @@ class Compose(nn.Module):
             elif self._glow_step_at(i, z):
                 a, c, k = L[i], L[i + 1], L[i + 2]
                 run = self._glow_run_at(i, z)
+                if run is not None and run[0] == 'nograd':
+                    z, log_df_dz = FUSED.glow_flow_vec_nograd(z, log_df_dz, run[1])
+                    i += 3 * len(run[1])
+                    continue
                 if run is not None:                                # the whole run of steps: one launch per direction
                     z, log_df_dz = FUSED.glow_flow_vec(z, log_df_dz, run)
                     i += 3 * len(run)
@@ -163,9 +169,31 @@ class Compose(nn.Module):
                 i += 1
         return z, log_df_dz
 
+    def _glow_inverse_run_ending_at(self, i, z):
+        """the maximal run of fused-step-capable Glow steps on (N, 2 | 4) data whose LAST layer is layer i (in forward order), or
+        None: its inverse is one launch per step, or one for the whole run (fused.glow_flow_vec_inverse)"""
+        L, run, j = self.layers, [], i
+        if z.dim() != 2 or torch.is_grad_enabled() and z.requires_grad:
+            return None
+        while j >= 2 and self._glow_step_at(j - 2, z):
+            a, c, k = L[j - 2], L[j - 1], L[j]
+            if not (k.mode == N.SPLIT_1D and isinstance(k.net, MLP) and not k._backward_hooks):
+                break
+            run.append((a, c, k))
+            j -= 3
+        run.reverse()
+        return run if run and FUSED.glow_inverse_usable(z, run) else None
+
     def backward(self, z, log_df_dz):
-        for layer in reversed(self.layers):
-            z, log_df_dz = layer.backward(z, log_df_dz)
+        i = len(self.layers) - 1
+        while i >= 0:
+            run = self._glow_inverse_run_ending_at(i, z)
+            if run is not None:
+                z, log_df_dz = FUSED.glow_flow_vec_inverse(z, log_df_dz, run)
+                i -= 3 * len(run)
+                continue
+            z, log_df_dz = self.layers[i].backward(z, log_df_dz)
+            i -= 1
         return z, log_df_dz
 
 

@@ -540,6 +540,90 @@ def test_glow_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
     assert fused.N.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('D,B,K', [(2, 4096, 8), (4, 333, 3), (2, 16384, 2)])
+def test_glow_flow_nograd_matches_step_by_step(pkg, D, B, K, training, monkeypatch):
+    """density evaluation under no_grad: the run of vector Glow steps in one launch (evaluation-mode statistics: no exchanges;
+    training-mode statistics: small batches) against one launch per step."""
+    from types import SimpleNamespace as NS
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 10 + B)
+    net1 = pkg.Glow((D, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    with torch.no_grad():
+        net1.train()
+        net1((torch.randn(max(B, 64), D) * 0.8).to(DEV))
+    net2 = copy.deepcopy(net1)
+    net1.train(training)
+    net2.train(training)
+    y = (torch.randn(B, D) * 0.9).to(DEV)
+    calls = {'n': 0}
+    real = fused.glow_flow_vec_nograd
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(fused, 'glow_flow_vec_nograd', counted)
+    with torch.no_grad():
+        z1, l1 = net1(y)
+        monkeypatch.setattr(fused, 'GLOW_FLOW', '0')
+        z2, l2 = net2(y)
+    expect = (not training) or B <= fused.GLOW_FLOW_AUTO_ROWS
+    assert (calls['n'] >= 1) == expect
+    G.assert_close(z1, z2, 1e-5, rtol=1e-5, what='z')
+    G.assert_close(l1, l2, 1e-5, rtol=1e-5, what='log-det')
+    b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
+    for name in b2:
+        G.assert_close(b1[name].float(), b2[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+    assert fused.N.persistent_timeouts() == 0
+
+
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('D,B,K', [(2, 4096, 8), (2, 300, 3), (4, 1000, 4), (2, 16384, 2), (4, 7, 1)])
+def test_glow_inverse_vec_matches_layerwise(pkg, D, B, K, training, monkeypatch):
+    """the inverse of a run of vector Glow steps -- one launch per step, or one for the whole run (k_mlp_chain_fwd<1, true>,
+    k_glow_flow_inv) -- against the layer-by-layer inverse (ActNorm^-1, lu_solve-style 1x1^-1, coupling^-1 with its MLP):
+    samples, log-det, the conditioner's running statistics; and forward(inverse(y)) = y."""
+    from types import SimpleNamespace as NS
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 100 + B)
+    net1 = pkg.Glow((D, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    with torch.no_grad():
+        net1.train()
+        net1((torch.randn(max(B, 64), D) * 0.8).to(DEV))     # data-dependent ActNorm init + some running statistics
+        for p in net1.parameters():
+            if p.requires_grad:
+                p.add_(torch.randn_like(p) * 0.05)           # away from the identity-like initialisation
+    net2 = copy.deepcopy(net1)
+    net1.train(training)
+    net2.train(training)
+    y = (torch.randn(B, D) * 0.9).to(DEV)
+    calls = {'n': 0}
+    real = fused.glow_flow_vec_inverse
+
+    def counted(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(fused, 'glow_flow_vec_inverse', counted)
+    with torch.no_grad():
+        z1, l1 = net1.backward(y.clone())
+        monkeypatch.setattr(fused, 'GLOW_INVERSE', False)
+        z2, l2 = net2.backward(y.clone())
+    assert calls['n'] >= 1, 'the fused inverse was not taken'
+    G.assert_close(z1, z2, 2e-5, rtol=2e-5, what='inverse samples')
+    G.assert_close(l1, l2, 2e-5, rtol=2e-5, what='inverse log-det')
+    b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
+    for name in b2:
+        G.assert_close(b1[name].float(), b2[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+    if not training:
+        with torch.no_grad():
+            yy, lf = net1(z1)
+        G.assert_close(yy, y, 1e-4, rtol=1e-4, what='forward(inverse(y))')
+        G.assert_close(lf + l1, torch.zeros_like(lf), 1e-4 * K, what='log-det of the round trip')
+    assert fused.N.persistent_timeouts() == 0
+
+
 @pytest.mark.parametrize('B,K,mix', [(65536, 11, 8), (1000, 3, 4), (40000, 9, 8)])
 def test_flowpp_deferred_finalize_matches_per_step(pkg, B, K, mix, monkeypatch):
     """the trainer defers the slab finalizes of the fused Flow++ steps to one launch per eight steps after backward
