@@ -543,6 +543,17 @@ int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const float* g_ld,
                             const void* const* mlp_params, const float* save_stats, float* g_s_log_scale, float* g_s_bias,
                             void* const* mlp_grads, int accumulate, float* ws_zero, float* slabs, int64_t N, int D, int odd,
                             float bn_eps, float wn_eps, nf_stream_t stream);
+/* Evaluation mode and the inverse.  flow_bn_momentum = NF_FBN_RUNNING in nf_realnvp_step_vec_fwd / nf_realnvp_flow_pack selects
+ * evaluation mode for the whole step (flow BatchNorm and conditioner on their running statistics, modules.py:296-298; no
+ * buffer is touched, no grid exchange).  nf_realnvp_step_vec_inv is the step's INVERSE in one launch (AffineCoupling.backward
+ * + BatchNorm.backward, coupling.py:115-122, modules.py:309-322): y -> z, ld -= the step's log-det; training != 0: the flow
+ * BatchNorm inverts with its stored BATCH buffers and the conditioner runs in training mode (what the reference does), else
+ * running statistics.  Records of an inverse run are packed with NF_FBN_BATCH_BUFFERS or NF_FBN_RUNNING accordingly.          */
+#define NF_FBN_RUNNING (-1.0f)
+#define NF_FBN_BATCH_BUFFERS (-2.0f)
+int nf_realnvp_step_vec_inv(const float* y, float* z, float* ld, const void* const* head, const void* const* mlp_params,
+                            float* save_stats, float* ws_zero, int64_t N, int D, int odd, int training, float bn_eps,
+                            float bn_momentum, float wn_eps, nf_stream_t stream);
 
 /* ---- one whole MAF flow step on vector data in one persistent launch per direction (training mode) ------------------
  * dims = (D,), D <= 4, N <= NF_MAF_MAX_ROWS: flow BatchNorm with batch statistics (modules.py:283-307, affine=False) ->
@@ -666,6 +677,10 @@ int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S,
  * records by nf_realnvp_flow_pack (head = the 8 pointers of nf_realnvp_step_vec_fwd), saves = S x NF_REALNVP_SAVE_FLOATS.     */
 int nf_realnvp_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, float* g_s_log_scale,
                          float* g_s_bias, void* const* mlp_grads, int D, int odd, float flow_bn_eps, float flow_bn_momentum);
+int nf_realnvp_flow_vec_fwd_eval(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves,
+                                 float* ws_zero, int64_t N, int D, float bn_eps, float wn_eps, nf_stream_t stream);
+int nf_realnvp_flow_vec_inv(const void* steps_dev, int S, const float* y, float* zs2, float* ld, float* saves, float* ws_zero,
+                            int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
 int nf_realnvp_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
                             int64_t N, int D, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
 int nf_realnvp_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,

@@ -80,6 +80,7 @@ struct NfGlowV {
     NF_G float *g_ls, *g_bs, *g_L, *g_U, *g_log_s, *g_a, *g_c;
     NF_G float *bmean, *bvar, *rmean, *rvar;                                 // flow-BatchNorm head (HEAD == 2): ls = log_gamma, bs = beta
     float fbn_eps, fbn_mom;
+    int fbn_mode;                                                            // 0: batch statistics computed here; 1: running statistics; 2: the stored batch buffers
     int D, odd;
 };
 static inline void nf_glow_unpack(const void* const* t, NfGlowV& h) {
@@ -398,7 +399,7 @@ __device__ __forceinline__ void nf_glow_head_row(const float* sm, const float (&
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc = fmaf(sm[NF_MC_HEAD + 4 * r + c], zn[c], acc);                     // modules.py:477
-        hh[r] = acc;
+        hh[r] = acc + sm[NF_MC_HEAD + 84 + r];             // (beta of the flow-BatchNorm head; 0 for the Glow head)
     }
 }
 // INVERSE step (modules.py:250-256, :484-497): W^-1 = U'^-1 L'^-1 Pp by two triangular solves on one thread (D <= 4), Pp = the
@@ -429,7 +430,7 @@ __device__ __forceinline__ void nf_glow_head_inverse_row(const float* sm, const 
     for (int r = 0; r < 4; ++r) {
         float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc = fmaf(sm[NF_MC_HEAD + 4 * r + c], hh[c], acc);
+        for (int c = 0; c < 4; ++c) acc = fmaf(sm[NF_MC_HEAD + 4 * r + c], hh[c] - sm[NF_MC_HEAD + 84 + c], acc);
         zr[r] = fmaf(acc, sm[NF_MC_HEAD + 16 + r], sm[NF_MC_HEAD + 20 + r]);
     }
 }
@@ -474,7 +475,7 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
                                                float mom, float wn_eps, const NfGlowV& h, const float* hz, float* hy, float* hld,
                                                NfMcCarry* carry = nullptr) {
     constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;     // GLOW: a fused flow step (either head)
-    static_assert(!INV || HEAD == 1, "the inverse body is the Glow step's");
+    static_assert(!INV || HEAD != 0, "the inverse body is a flow step's");
     NF_MC_T(0);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MC_WAVES + wid) * 16 + c16;
@@ -483,8 +484,10 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
     float frm = 0.f, frv = 0.f;
     NfGlowRaw head_raw;
     if (FBN && threadIdx.x < 4) {
-        frm = (int)threadIdx.x < h.D ? h.rmean[threadIdx.x] : 0.f;
-        frv = (int)threadIdx.x < h.D ? h.rvar[threadIdx.x] : 1.f;
+        const NF_G float* ms = h.fbn_mode == 2 ? h.bmean : h.rmean;         // constants of the evaluation / inverse modes
+        const NF_G float* vs = h.fbn_mode == 2 ? h.bvar : h.rvar;
+        frm = (int)threadIdx.x < h.D ? ms[threadIdx.x] : 0.f;
+        frv = (int)threadIdx.x < h.D ? vs[threadIdx.x] : 1.f;
         sm[NF_MC_HEAD + 80 + threadIdx.x] = frm;          // the centre of the shifted sums (flowbn_head.hip)
     }
     if (GLOW) {
@@ -505,7 +508,12 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
     }
     nf_mc_stage(p, sm, I0, O_out, wn_eps, (GLOW && !FBN) ? &h : nullptr, (GLOW && !FBN) ? &head_raw : nullptr);
     unsigned long long* slots = (unsigned long long*)stats;
-    if (FBN) {   // batch statistics of z itself: one more exchange (round NF_MC_NB), then the head constants
+    if (FBN && h.fbn_mode != 0) {   // evaluation mode / inverse (modules.py:296-298, :309-322): the statistics are buffers, no exchange
+        if (threadIdx.x < 4) nf_fbn_head_consts(sm, h, threadIdx.x, frm, frv);
+        __syncthreads();
+        if (threadIdx.x == 0) sm[NF_MC_HEAD + 24] = (sm[NF_MC_HEAD + 28] + sm[NF_MC_HEAD + 29]) + (sm[NF_MC_HEAD + 30] + sm[NF_MC_HEAD + 31]);
+        __syncthreads();
+    } else if (FBN) {   // batch statistics of z itself: one more exchange (round NF_MC_NB), then the head constants
         float* tile = sm + NF_MC_TILES + wid * 16 * NF_FP_ST;
         float v8[8], c4[2][4];
 #pragma unroll
@@ -544,7 +552,9 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
         __syncthreads();
     }
     if (INV) {
-        if (threadIdx.x == 0) nf_glow_head_inverse_weight(sm, h.D);
+        if (FBN) {                                        // W = diag(exp(log_gamma)): invert in place
+            if ((int)threadIdx.x < h.D) sm[NF_MC_HEAD + 5 * threadIdx.x] = 1.f / sm[NF_MC_HEAD + 5 * threadIdx.x];
+        } else if (threadIdx.x == 0) nf_glow_head_inverse_weight(sm, h.D);
 #pragma unroll
         for (int c = 0; c < 4; ++c) hh[c] = zr[c];         // y: its conditioning half is the head output's
         nf_glow_cond_input(hh, h.D, h.odd, xa, g);
@@ -1412,6 +1422,7 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
 // slower one still folds step s; it cannot get further ahead than that, the first exchange of a step needs everybody).
 // ---------------------------------------------------------------------------------------------------------------
 static void nf_fbn_unpack(const void* const* t, NfGlowV& h);
+static inline int nf_fbn_mode_of(float momentum) { return momentum == NF_FBN_RUNNING ? 1 : momentum == NF_FBN_BATCH_BUFFERS ? 2 : 0; }
 struct NfGlowFlowStep { NfMlpP p; NfMlpG g; NfGlowV h; };     // the static pointers of one step: parameters, gradient sinks
 
 extern "C" int nf_glow_flow_step_bytes(void) { return (int)sizeof(NfGlowFlowStep); }
@@ -1478,6 +1489,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_fwd(const NfGlowFlo
 
 // the INVERSE of the whole run, last step first: rows travel in registers, zs (2, N, D) ping-pongs the steps' results (slice
 // s & 1: the flow's input ends up in slice 0)
+template <int HEAD>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_inv(const NfGlowFlowStep* __restrict__ steps, int S, const float* y,
                                                                  float* zs, float* ld, float* saves, int save_stride, float* ws,
                                                                  int64_t N, int D, int training, float eps, float mom,
@@ -1495,7 +1507,7 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_inv(const NfGlowFlo
         unsigned long long nxt = 0;
         if (rt && s > 0) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 1)[threadIdx.x];
         const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
-        nf_mc_fwd_body<1, true>(sm, nullptr, st.p, nullptr, saves + (int64_t)s * save_stride, ws + (int64_t)s * NF_MLP_WS_FLOATS, N,
+        nf_mc_fwd_body<HEAD, true>(sm, nullptr, st.p, nullptr, saves + (int64_t)s * save_stride, ws + (int64_t)s * NF_MLP_WS_FLOATS, N,
                                 D / 2, D, training, eps, mom, wn_eps, st.h, y, zs + (int64_t)(s & 1) * ND, ld, &carry);
         if (rt) rec[(s + 1) & 1][threadIdx.x] = nxt;    // parity of s - 1
         __syncthreads();
@@ -1585,26 +1597,33 @@ extern "C" int nf_glow_flow_vec_fwd(const void* steps_dev, int S, const float* z
     return nf_flow_launch_fwd<1>(steps_dev, S, z0, ys, ld, saves, NF_GLOW_FLOW_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum,
                                  wn_eps, stream);
 }
-extern "C" int nf_glow_flow_vec_inv(const void* steps_dev, int S, const float* y, float* zs2, float* ld, float* saves, float* ws_zero,
-                                    int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
-                                    nf_stream_t stream) {
+template <int HEAD>
+static int nf_flow_launch_inv(const void* steps_dev, int S, const float* y, float* zs2, float* ld, float* saves, int save_stride,
+                              float* ws_zero, int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                              nf_stream_t stream) {
     if (steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || y == nullptr || zs2 == nullptr || ld == nullptr ||
         saves == nullptr || ws_zero == nullptr || !nf_glow_args_ok(N, D))
         return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t body_lds = nf_mc_lds_bytes(1), lds = body_lds + 2 * NF_GF_REC_WORDS * 8;
-    static bool attr_set = false;
+    static bool attr_set = false;                       // one per HEAD
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_inv<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_glow_flow_inv, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const NfGlowFlowStep*)steps_dev, S,
-                       y, zs2, ld, saves, NF_GLOW_FLOW_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum, wn_eps,
-                       (int)(body_lds / sizeof(float)));
+    hipLaunchKernelGGL(k_glow_flow_inv<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
+                       (const NfGlowFlowStep*)steps_dev, S, y, zs2, ld, saves, save_stride, ws_zero, N, D, training, bn_eps, bn_momentum,
+                       wn_eps, (int)(body_lds / sizeof(float)));
     NF_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int nf_glow_flow_vec_inv(const void* steps_dev, int S, const float* y, float* zs2, float* ld, float* saves, float* ws_zero,
+                                    int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                                    nf_stream_t stream) {
+    return nf_flow_launch_inv<1>(steps_dev, S, y, zs2, ld, saves, NF_GLOW_FLOW_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum,
+                                 wn_eps, stream);
 }
 extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
                                     const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2,
@@ -1712,6 +1731,7 @@ extern "C" int nf_realnvp_flow_pack(void* dst_host, const void* const* head, con
     nf_mlp_unpack(mlp_params, st.p);
     nf_fbn_unpack(head, st.h);
     st.h.D = D; st.h.odd = odd ? 1 : 0; st.h.fbn_eps = flow_bn_eps; st.h.fbn_mom = flow_bn_momentum;
+    st.h.fbn_mode = nf_fbn_mode_of(flow_bn_momentum);
     if (mlp_grads != nullptr) {
         for (int l = 0; l < NF_MC_NL; ++l) {
             NF_GSET(st.g.v[l], mlp_grads[3 * l]); NF_GSET(st.g.g[l], mlp_grads[3 * l + 1]); NF_GSET(st.g.b[l], mlp_grads[3 * l + 2]);
@@ -1723,6 +1743,18 @@ extern "C" int nf_realnvp_flow_pack(void* dst_host, const void* const* head, con
     NF_GSET(st.h.g_a, g_s_log_scale); NF_GSET(st.h.g_c, g_s_bias);
     *reinterpret_cast<NfGlowFlowStep*>(dst_host) = st;
     return 0;
+}
+// evaluation mode (records packed with flow_bn_momentum = NF_FBN_RUNNING: running statistics everywhere, no exchange) and the inverse
+// (NF_FBN_RUNNING, or NF_FBN_BATCH_BUFFERS for the training-mode inverse of modules.py:309-322)
+extern "C" int nf_realnvp_flow_vec_fwd_eval(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves,
+                                            float* ws_zero, int64_t N, int D, float bn_eps, float wn_eps, nf_stream_t stream) {
+    return nf_flow_launch_fwd<2>(steps_dev, S, z0, ys, ld, saves, NF_REALNVP_SAVE_FLOATS, ws_zero, N, D, 0, bn_eps, 0.f, wn_eps, stream);
+}
+extern "C" int nf_realnvp_flow_vec_inv(const void* steps_dev, int S, const float* y, float* zs2, float* ld, float* saves,
+                                       float* ws_zero, int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                                       nf_stream_t stream) {
+    return nf_flow_launch_inv<2>(steps_dev, S, y, zs2, ld, saves, NF_REALNVP_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum,
+                                 wn_eps, stream);
 }
 extern "C" int nf_realnvp_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves,
                                        float* ws_zero, int64_t N, int D, float bn_eps, float bn_momentum, float wn_eps,
@@ -1758,6 +1790,9 @@ extern "C" int nf_realnvp_step_vec_fwd(const float* z, float* y, float* ld, cons
     NfGlowV h{};
     nf_fbn_unpack(head, h);
     h.z = z; h.y = y; h.ld = ld; h.D = D; h.odd = odd ? 1 : 0; h.fbn_eps = flow_bn_eps; h.fbn_mom = flow_bn_momentum;
+    h.fbn_mode = nf_fbn_mode_of(flow_bn_momentum);
+    if (h.fbn_mode == 2) return NF_E_BADARG;           // the batch buffers serve the inverse only
+    const int cond_training = h.fbn_mode == 0 ? 1 : 0;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t lds = nf_mc_lds_bytes(1);
     static bool attr_set = false;
@@ -1767,7 +1802,34 @@ extern "C" int nf_realnvp_step_vec_fwd(const float* z, float* y, float* ld, cons
         attr_set = true;
     }
     hipLaunchKernelGGL(k_mlp_chain_fwd<2>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
-                       (float*)nullptr, save_stats, ws_zero, N, D / 2, D, 1, bn_eps, bn_momentum, wn_eps, h);
+                       (float*)nullptr, save_stats, ws_zero, N, D / 2, D, cond_training, bn_eps, bn_momentum, wn_eps, h);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_realnvp_step_vec_inv(const float* y, float* z, float* ld, const void* const* head, const void* const* mlp_params,
+                                       float* save_stats, float* ws_zero, int64_t N, int D, int odd, int training, float bn_eps,
+                                       float bn_momentum, float wn_eps, nf_stream_t stream) {
+    if (y == nullptr || z == nullptr || ld == nullptr || head == nullptr || mlp_params == nullptr || save_stats == nullptr ||
+        ws_zero == nullptr || !nf_glow_args_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMlpP p;
+    nf_mlp_unpack(mlp_params, p);
+    NfGlowV h{};
+    nf_fbn_unpack(head, h);
+    h.z = y; h.y = z; h.ld = ld; h.D = D; h.odd = odd ? 1 : 0;
+    h.fbn_mode = training ? 2 : 1;                     // modules.py:309-322: batch buffers in training mode, running statistics else
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds = nf_mc_lds_bytes(1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_mlp_chain_fwd<2, true>), dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, p,
+                       (float*)nullptr, save_stats, ws_zero, N, D / 2, D, training ? 1 : 0, bn_eps, bn_momentum, wn_eps, h);
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -1036,6 +1036,100 @@ def realnvp_flow_vec(z, ld, steps):
     return _RealNVPFlowVec.apply(z, _owned_ld(ld), tuple(metas), *tensors)
 
 
+# ---- RealNVP runs in evaluation mode (density evaluation under no_grad) and their inverse (sampling) ------------------------------
+FBN_RUNNING, FBN_BATCH_BUFFERS = -1.0, -2.0              # include/nfhip.h: NF_FBN_RUNNING, NF_FBN_BATCH_BUFFERS
+
+
+def _realnvp_const_table(steps, mode, D, device):
+    """records of [(flow BatchNorm, AffineCoupling)] whose flow BatchNorm reads constants (mode: FBN_RUNNING | FBN_BATCH_BUFFERS)"""
+    heads = [[t.detach() for t in (bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var,
+                                   k.s_log_scale, k.s_bias)] for bn, k in steps]
+    mlps = [[t.detach() for t in _mlp_tensors(k.net)] for _, k in steps]
+    key = ('realnvp-const', mode, device, D, tuple(int(k.odd) for _, k in steps),
+           tuple(t.data_ptr() for h, m in zip(heads, mlps) for t in h + m))
+    hit = _GLOW_FLOW_TABLES.get(key)
+    if hit is not None:
+        return hit
+    nbytes = int(N.load().nf_glow_flow_step_bytes())
+    host = (ctypes.c_ubyte * (nbytes * len(steps)))()
+    for i, (bn, k) in enumerate(steps):
+        htab, mtab = _ptr_table(heads[i]), _ptr_table(mlps[i])
+        N.call('nf_realnvp_flow_pack', ctypes.addressof(host) + i * nbytes, ctypes.addressof(htab), ctypes.addressof(mtab), None, None,
+               None, D, int(k.odd), float(bn.eps), float(mode))
+    table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+    if len(_GLOW_FLOW_TABLES) > 64:
+        _GLOW_FLOW_TABLES.clear()
+        _GLOW_FLOW_HOST.clear()
+    _GLOW_FLOW_TABLES[key] = table
+    return table
+
+
+def _realnvp_const_usable(z, steps):
+    if not (GLOW_INVERSE and steps and len(steps) <= N.header_constant('NF_GLOW_FLOW_MAX_STEPS')):
+        return False
+    training = steps[0][0].training
+    return all(glow_step_vec_usable(z, k.net) and bn.training == training and k.net.training == training and z.shape[0] > 1
+               for bn, k in steps)
+
+
+def realnvp_eval_usable(z, steps):
+    """[(flow BatchNorm, AffineCoupling)] in evaluation mode under no_grad: the run in one launch, no grid exchange"""
+    return (not torch.is_grad_enabled()) and _realnvp_const_usable(z, steps) and not steps[0][0].training and GLOW_FLOW != '0'
+
+
+def realnvp_flow_vec_eval(z, ld, steps):
+    from .functional import _owned_ld
+    z = z.contiguous()
+    Nrows, D = z.shape
+    dev = z.device
+    S = len(steps)
+    table = _realnvp_const_table(steps, FBN_RUNNING, D, dev)
+    ld = _owned_ld(ld)
+    ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
+    saves = torch.empty(S, N.header_constant('NF_REALNVP_SAVE_FLOATS'), dtype=torch.float32, device=dev)
+    ws = torch.empty(N.header_constant('NF_MLP_WS_FLOATS') * S, dtype=torch.float32, device=dev)
+    N.call('nf_realnvp_flow_vec_fwd_eval', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
+           BN_EPS, WN_EPS, N.stream())
+    return ys[S - 1], ld
+
+
+def realnvp_inverse_usable(y, steps):
+    return _realnvp_const_usable(y, steps)
+
+
+def realnvp_flow_vec_inverse(y, ld, steps):
+    """y -> z through the inverses of ``steps`` (forward order given, applied last to first); training mode: the flow BatchNorm
+    inverts with its batch buffers, the conditioner normalises with batch statistics (modules.py:309-322, coupling.py:115-122)."""
+    with torch.no_grad():
+        y = y.contiguous()
+        Nrows, D = y.shape
+        dev = y.device
+        S = len(steps)
+        training = bool(steps[0][0].training)
+        ld = ld.clone()
+        nws = N.header_constant('NF_MLP_WS_FLOATS')
+        saves = torch.empty(S, N.header_constant('NF_REALNVP_SAVE_FLOATS'), dtype=torch.float32, device=dev)
+        ws = WS.zeros(S * nws, dev) if training else torch.empty(S * nws, dtype=torch.float32, device=dev)
+        if not training or _flow_on(y):
+            table = _realnvp_const_table(steps, FBN_BATCH_BUFFERS if training else FBN_RUNNING, D, dev)
+            zs = torch.empty(2, Nrows, D, dtype=torch.float32, device=dev)
+            N.call('nf_realnvp_flow_vec_inv', table.data_ptr(), S, N.ptr(y), N.ptr(zs), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
+                   int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+            return zs[0], ld
+        cur = y
+        for i in range(S - 1, -1, -1):
+            bn, k = steps[i]
+            z = torch.empty_like(cur)
+            htab = _ptr_table([t.detach() for t in (bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean,
+                                                    bn.running_var, k.s_log_scale, k.s_bias)])
+            mtab = _ptr_table([t.detach() for t in _mlp_tensors(k.net)])
+            N.call('nf_realnvp_step_vec_inv', N.ptr(cur), N.ptr(z), N.ptr(ld), ctypes.addressof(htab), ctypes.addressof(mtab),
+                   N.ptr(saves[i]), N.ptr(ws[i * nws:(i + 1) * nws]), Nrows, D, int(k.odd), int(training), BN_EPS, BN_MOMENTUM, WN_EPS,
+                   N.stream())
+            cur = z
+        return cur, ld
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # whole Flow++ coupling on vector data: conditioner (strided read of the conditioning half) + mixture-of-logistics coupling
 # ----------------------------------------------------------------------------------------------------------------------

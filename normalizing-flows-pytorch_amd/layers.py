@@ -116,6 +116,11 @@ class Compose(nn.Module):
     def forward(self, z, log_df_dz):
         L, n, i = self.layers, len(self.layers), 0
         while i < n:
+            run = self._realnvp_eval_run_at(i, z) if not torch.is_grad_enabled() else None
+            if run is not None:                                    # density evaluation: the run in one launch, no exchange
+                z, log_df_dz = FUSED.realnvp_flow_vec_eval(z, log_df_dz, run)
+                i += 2 * len(run)
+                continue
             if self._bn_step_at(i, z):
                 a, k = L[i], L[i + 1]
                 run = self._realnvp_run_at(i, z)
@@ -184,6 +189,34 @@ class Compose(nn.Module):
         run.reverse()
         return run if run and FUSED.glow_inverse_usable(z, run) else None
 
+    def _realnvp_pair_at(self, j, z):
+        """[flow BatchNorm(affine=False), AffineCoupling(MLP)] at layers j, j + 1 on (N, 2 | 4) data, any mode, no hooks"""
+        L = self.layers
+        if not (self.fuse and z.is_cuda and z.dim() == 2 and j >= 0 and j + 1 < len(L)):
+            return False
+        a, k = L[j], L[j + 1]
+        if not (type(a) is BatchNorm and not isinstance(a.log_gamma, nn.Parameter) and type(k) is AffineCoupling
+                and k.mode == N.SPLIT_1D and isinstance(k.net, MLP)):
+            return False
+        return not (a._forward_hooks or k._forward_hooks or a._forward_pre_hooks or k._forward_pre_hooks)
+
+    def _realnvp_inverse_run_ending_at(self, i, z):
+        L, run, j = self.layers, [], i
+        if z.dim() != 2 or torch.is_grad_enabled() and z.requires_grad:
+            return None
+        while self._realnvp_pair_at(j - 1, z):
+            run.append((L[j - 1], L[j]))
+            j -= 2
+        run.reverse()
+        return run if run and FUSED.realnvp_inverse_usable(z, run) else None
+
+    def _realnvp_eval_run_at(self, i, z):
+        L, run, j = self.layers, [], i
+        while self._realnvp_pair_at(j, z):
+            run.append((L[j], L[j + 1]))
+            j += 2
+        return run if run and FUSED.realnvp_eval_usable(z, run) else None
+
     def backward(self, z, log_df_dz):
         i = len(self.layers) - 1
         while i >= 0:
@@ -191,6 +224,11 @@ class Compose(nn.Module):
             if run is not None:
                 z, log_df_dz = FUSED.glow_flow_vec_inverse(z, log_df_dz, run)
                 i -= 3 * len(run)
+                continue
+            run = self._realnvp_inverse_run_ending_at(i, z)
+            if run is not None:
+                z, log_df_dz = FUSED.realnvp_flow_vec_inverse(z, log_df_dz, run)
+                i -= 2 * len(run)
                 continue
             z, log_df_dz = self.layers[i].backward(z, log_df_dz)
             i -= 1

@@ -624,6 +624,62 @@ def test_glow_inverse_vec_matches_layerwise(pkg, D, B, K, training, monkeypatch)
     assert fused.N.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('D,B,K', [(2, 256, 8), (4, 1000, 3), (2, 4096, 2), (2, 5, 1)])
+def test_realnvp_eval_and_inverse_vec_match_layerwise(pkg, D, B, K, training, monkeypatch):
+    """RealNVP runs [flow BatchNorm, AffineCoupling] on vector data: the inverse (one launch per run or per step; training mode:
+    batch buffers + batch-statistics conditioner, evaluation mode: running statistics) and the evaluation-mode forward under
+    no_grad (one launch, no exchange) against the layer-by-layer path."""
+    from types import SimpleNamespace as NS
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 100 + B + 3)
+    net1 = pkg.RealNVP((D, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    with torch.no_grad():
+        net1.train()
+        for _ in range(2):
+            net1((torch.randn(max(B, 64), D) * 0.8 + 0.1).to(DEV))          # batch buffers and running statistics off their defaults
+        for p in net1.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    net2 = copy.deepcopy(net1)
+    net1.train(training)
+    net2.train(training)
+    y = (torch.randn(B, D) * 0.9).to(DEV)
+    calls = {'inv': 0, 'fwd': 0}
+    real_inv, real_fwd = fused.realnvp_flow_vec_inverse, fused.realnvp_flow_vec_eval
+
+    def c_inv(*a, **k):
+        calls['inv'] += 1
+        return real_inv(*a, **k)
+
+    def c_fwd(*a, **k):
+        calls['fwd'] += 1
+        return real_fwd(*a, **k)
+
+    monkeypatch.setattr(fused, 'realnvp_flow_vec_inverse', c_inv)
+    monkeypatch.setattr(fused, 'realnvp_flow_vec_eval', c_fwd)
+    with torch.no_grad():
+        z1, l1 = net1.backward(y.clone())
+        f1, lf1 = net1(y) if not training else (None, None)
+        monkeypatch.setattr(fused, 'GLOW_INVERSE', False)
+        z2, l2 = net2.backward(y.clone())
+        f2, lf2 = net2(y) if not training else (None, None)
+    assert calls['inv'] >= 1, 'the fused inverse was not taken'
+    G.assert_close(z1, z2, 2e-5, rtol=2e-5, what='inverse samples')
+    G.assert_close(l1, l2, 2e-5, rtol=2e-5, what='inverse log-det')
+    if not training:
+        assert calls['fwd'] >= 1, 'the one-launch evaluation forward was not taken'
+        G.assert_close(f1, f2, 1e-5, rtol=1e-5, what='evaluation forward')
+        G.assert_close(lf1, lf2, 1e-5, rtol=1e-5, what='evaluation log-det')
+        with torch.no_grad():
+            yy, lr = net1(z1)
+        G.assert_close(yy, y, 1e-4, rtol=1e-4, what='forward(inverse(y))')
+        G.assert_close(lr + l1, torch.zeros_like(lr), 1e-4 * K, what='log-det of the round trip')
+    b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
+    for name in b2:
+        G.assert_close(b1[name].float(), b2[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+    assert fused.N.persistent_timeouts() == 0
+
+
 @pytest.mark.parametrize('B,K,mix', [(65536, 11, 8), (1000, 3, 4), (40000, 9, 8)])
 def test_flowpp_deferred_finalize_matches_per_step(pkg, B, K, mix, monkeypatch):
     """the trainer defers the slab finalizes of the fused Flow++ steps to one launch per eight steps after backward
