@@ -580,6 +580,14 @@ int nf_realnvp_step_vec_inv(const float* y, float* z, float* ld, const void* con
 int nf_maf_step_fwd(const float* z, float* y, float* ld, const void* const* head, const void* const* made_params,
                     float* save_stats, float* ws_zero, int64_t N, int D, float flow_bn_eps, float flow_bn_momentum,
                     float bn_eps, nf_stream_t stream);
+/* nf_maf_step_fwd with flow_bn_momentum = NF_FBN_RUNNING: the evaluation-mode step (every BatchNorm on its running statistics,
+ * no buffer touched, no grid exchange; save_stats unused).  nf_maf_step_inv: the INVERSE step in one launch
+ * (AutoregressiveTransfrom.backward, maf.py:108-119: D sequential passes of both MADEs, pass i fixes feature i; then perm^T and
+ * BatchNorm.backward, modules.py:309-322): y -> z, ld -= the step's log-det.  training != 0: the MADE BatchNorms normalise with
+ * batch statistics and update their running statistics once per pass, the flow BatchNorm inverts with its batch buffers;
+ * ws_zero: D x NF_MAF_WS_FLOATS zero floats (one exchange workspace per pass).  Unlike the reference the input is not mutated. */
+int nf_maf_step_inv(const float* y, float* z, float* ld, const void* const* head, const void* const* made_params, float* ws_zero,
+                    int64_t N, int D, int training, float bn_eps, nf_stream_t stream);
 int nf_maf_step_bwd(const float* z, const float* g_y, const float* g_ld, float* g_z, const void* const* head,
                     const void* const* made_params, const float* save_stats, void* const* made_grads, float* g_s_log_scale,
                     float* g_s_bias, float* ws_zero, float* slabs, int64_t N, int D, nf_stream_t stream);

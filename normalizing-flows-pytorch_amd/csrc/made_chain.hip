@@ -314,7 +314,15 @@ __device__ __forceinline__ void nf_md_load_row(const float* z, int64_t row, bool
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMafV h, float* save, float* ws, int64_t N, float eps) {
+// MODE 0: the training-mode forward step.  MODE 1: the evaluation-mode forward (every BatchNorm on its running statistics: no
+// grid exchange, no buffer touched).  MODE 2: the INVERSE step (maf.py:108-119, modules.py:309-322): h.z is the step's output,
+// D sequential passes of the MADE pair each fix one feature, then perm^-1 and the flow BatchNorm's inverse (batch buffers when
+// `training`, running statistics otherwise); with `training` the MADE BatchNorms use batch statistics and update their running
+// statistics once per pass, exactly as D module calls do (pass i exchanges through ws + i * NF_MAF_WS_FLOATS).
+template <int MODE>
+__global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMafV h, float* save, float* ws, int64_t N, float eps,
+                                                                int training) {
+    const bool use_batch = MODE == 0 || (MODE == 2 && training != 0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NF_MD_WAVES + wid) * 16 + c16;
@@ -323,11 +331,16 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
     float zr[4], ld_in = 0.f, rm_old = 0.f, rv_old = 0.f, kc = 0.f, frm = 0.f, frv = 0.f;
     nf_md_load_row(h.z, row, rv, D, zr);                  // issued before the staging: one memory latency for everything
     if (rv && g == 0) ld_in = h.ld[row];
-    if (blockIdx.x == 0 && threadIdx.x < 2 * NF_MD_NB * 32) {
+    if ((blockIdx.x == 0 || !use_batch) && threadIdx.x < 2 * NF_MD_NB * 32) {
         const int n = threadIdx.x / 96, j = (threadIdx.x / 32) % 3, k = threadIdx.x & 31;
         rm_old = p.rmean[n][j][k]; rv_old = p.rvar[n][j][k];
     }
-    if (threadIdx.x < 4 && (int)threadIdx.x < D) { frm = h.rmean[threadIdx.x]; frv = h.rvar[threadIdx.x]; }
+    frv = 1.f;
+    if (threadIdx.x < 4 && (int)threadIdx.x < D) {
+        const bool buffers = MODE == 2 && training != 0;  // the inverse of a training-mode flow BatchNorm reads its batch buffers
+        frm = buffers ? h.bmean[threadIdx.x] : h.rmean[threadIdx.x];
+        frv = buffers ? h.bvar[threadIdx.x] : h.rvar[threadIdx.x];
+    }
     if (threadIdx.x < 16) sm[NF_MD_HEAD + 16 + threadIdx.x] = ((threadIdx.x >> 2) < D && (threadIdx.x & 3) < D) ? h.perm[(threadIdx.x >> 2) * D + (threadIdx.x & 3)] : 0.f;
     if (threadIdx.x == 16) { sm[NF_MD_HEAD + 33] = h.a[0]; sm[NF_MD_HEAD + 34] = h.c[0]; }
     if (threadIdx.x >= 32 && threadIdx.x < 36) sm[NF_MD_HEAD + 40 + (threadIdx.x - 32)] = (int)(threadIdx.x - 32) < D ? h.rmean[threadIdx.x - 32] : 0.f;
@@ -337,8 +350,16 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
     float* tile = sm + NF_MD_TILES + wid * 16 * NF_FP_ST;
     float* red = sm + NF_MD_RED + wid * NF_MD_XW;
 
+    if (MODE != 0) {                                      // constants: no exchange
+        if (threadIdx.x < 4) nf_md_head_consts(sm, h, threadIdx.x, frm, frv);
+        if (!use_batch && threadIdx.x < 2 * NF_MD_NB * 32) {
+            const int n = threadIdx.x / 96, j = (threadIdx.x / 32) % 3, k = threadIdx.x & 31;
+            nf_md_bn_consts(sm, n, j, k, rm_old, 1.f / sqrtf(rv_old + eps));
+        }
+        __syncthreads();
+    }
     // ---- flow BatchNorm statistics: shifted sums around the running mean (flowbn_head.hip) ------------------------------
-    {
+    if (MODE == 0) {
         float v8[8], s1[2], s2[2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v8[j] = 0.f;
@@ -369,8 +390,21 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
         }
         __syncthreads();
     }
-    float zp[4], xa[8];
-    nf_md_head_row(sm, zr, D, zp);
+    float zp[4], xa[8], inv_ld = 0.f;
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zp[c] = zr[c];          // the step's output; feature i is replaced by pass i
+    } else {
+        nf_md_head_row(sm, zr, D, zp);
+    }
+    const int passes = MODE == 2 ? D : 1;
+    float av[2][8], dv[2][8];
+#pragma unroll 1
+    for (int pass = 0; pass < passes; ++pass) {
+    if (MODE == 2 && pass > 0) {
+        slots += NF_MAF_WS_FLOATS / 2;                    // a fresh exchange workspace per pass
+        __syncthreads();                                  // the previous pass is done with the BatchNorm constants in LDS
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) xa[j] = 0.f;
     if (g == 0) {
@@ -378,13 +412,12 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
         for (int c = 0; c < 4; ++c) xa[c] = zp[c];
     }
     // ---- the two MADE nets in lockstep ------------------------------------------------------------------------------------
-    float av[2][8], dv[2][8];
 #pragma unroll
     for (int n = 0; n < 2; ++n) nf_md_linear(sm, n, 0, xa, dv[n], c16, g);
 #pragma unroll 1
     for (int l = 0; l < NF_MD_NB; ++l) {                  // dv = pre-bias output of linear l = input of BatchNorm l
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; use_batch && n < 2; ++n) {
             float m8[8], s1[2], s2[2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) m8[k] = rv ? dv[n][k] : 0.f;
@@ -394,9 +427,12 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
                 red[n * 64 + 32 + c16] = s2[0]; red[n * 64 + 48 + c16] = s2[1];
             }
         }
-        nf_md_publish(sm, slots, 1 + l, (unsigned)(2 + l));
-        const float* tot = nf_md_collect(sm, slots, 1 + l, (unsigned)(2 + l));
-        if (threadIdx.x < 64) {
+        const float* tot = nullptr;
+        if (use_batch) {                                  // kernel-uniform
+            nf_md_publish(sm, slots, 1 + l, (unsigned)(2 + l));
+            tot = nf_md_collect(sm, slots, 1 + l, (unsigned)(2 + l));
+        }
+        if (use_batch && threadIdx.x < 64) {
             const int n = threadIdx.x >> 5, k = threadIdx.x & 31;
             const float invN = 1.f / (float)N;
             const float m1 = tot[n * 64 + k] * invN;
@@ -405,7 +441,7 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
             nf_md_bn_consts(sm, n, l, k, mean, 1.f / sqrtf(var + eps));
             sm[NF_MD_VAR + (n * NF_MD_NB + l) * 32 + k] = var;
         }
-        __syncthreads();
+        if (use_batch) __syncthreads();
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             float bias[8], a_in[8];
@@ -417,15 +453,51 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
 #pragma unroll
         for (int n = 0; n < 2; ++n) nf_md_linear(sm, n, l + 1, av[n], dv[n], c16, g);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 2 * NF_MD_NB * 32) {       // BatchNorm1d bookkeeping, off the chain
+    if (use_batch && blockIdx.x == 0 && threadIdx.x < 2 * NF_MD_NB * 32) {       // BatchNorm1d bookkeeping, off the chain
         const int n = threadIdx.x / 96, j = (threadIdx.x / 32) % 3, k = threadIdx.x & 31, q = n * NF_MD_NB + j;
         const float mean = sm[NF_MD_BNC + (q * 4 + 2) * 32 + k], var = sm[NF_MD_VAR + q * 32 + k];
         const float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-        p.rmean[n][j][k] = 0.9f * rm_old + 0.1f * mean;                               // nn.BatchNorm1d momentum 0.1
-        p.rvar[n][j][k] = 0.9f * rv_old + 0.1f * unb;
-        save[(q * 2 + 0) * 32 + k] = mean;
-        save[(q * 2 + 1) * 32 + k] = sm[NF_MD_BNC + (q * 4 + 3) * 32 + k];
+        rm_old = 0.9f * rm_old + 0.1f * mean;                                         // nn.BatchNorm1d momentum 0.1
+        rv_old = 0.9f * rv_old + 0.1f * unb;
+        p.rmean[n][j][k] = rm_old;
+        p.rvar[n][j][k] = rv_old;
+        if (MODE == 0) {
+            save[(q * 2 + 0) * 32 + k] = mean;
+            save[(q * 2 + 1) * 32 + k] = sm[NF_MD_BNC + (q * 4 + 3) * 32 + k];
+        }
         if (k == 0 && p.nbt[n][j] != nullptr) p.nbt[n][j][0] += 1;
+    }
+    if (MODE == 2) {                                      // pass i fixes feature i (maf.py:112-115)
+        float bs[8], bt[8];
+        nf_fp_ldvec(sm + NF_MD_B + (0 * NF_MD_NL + 3) * 32, g, bs);
+        nf_fp_ldvec(sm + NF_MD_B + (1 * NF_MD_NL + 3) * 32, g, bt);
+        const float ca = sm[NF_MD_HEAD + 33], cc = sm[NF_MD_HEAD + 34];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c == pass && g == 0) {
+                const float sv = tanhf(dv[0][c] + bs[c]) * ca + cc;
+                zp[c] = (zp[c] - (dv[1][c] + bt[c])) * expf(-sv);
+                inv_ld -= sv;
+            }
+        }
+    }
+    }   // passes
+    if (MODE == 2) {                                      // perm^-1 (maf.py:118), then the flow BatchNorm's inverse (modules.py:309-322)
+        if (rv && g == 0) {
+            float dld = inv_ld;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < D) {
+                    float u = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) u = fmaf(zp[c], sm[NF_MD_HEAD + 16 + 4 * j + c], u);        // z @ perm^T
+                    h.y[row * D + j] = (u - sm[NF_MD_HEAD + 12 + j]) / sm[NF_MD_HEAD + 8 + j] * sm[NF_MD_HEAD + 4 + j] + sm[NF_MD_HEAD + j];
+                    dld -= sm[NF_MD_HEAD + 36 + j];
+                }
+            }
+            h.ld[row] = ld_in + dld;
+        }
+        return;
     }
     // ---- affine transform over all features (maf.py:103-106) ----------------------------------------------------------------
     if (rv && g == 0) {
@@ -747,11 +819,43 @@ extern "C" int nf_maf_step_fwd(const float* z, float* y, float* ld, const void* 
     const size_t lds = nf_md_lds_bytes(1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_maf_step_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_maf_step_fwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)k_maf_step_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_maf_step_fwd, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, save_stats, ws_zero, N, bn_eps);
+    if (flow_bn_momentum == NF_FBN_RUNNING)             // evaluation mode: running statistics everywhere, nothing updated
+        hipLaunchKernelGGL(k_maf_step_fwd<1>, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, save_stats, ws_zero, N,
+                           bn_eps, 0);
+    else
+        hipLaunchKernelGGL(k_maf_step_fwd<0>, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, save_stats, ws_zero, N,
+                           bn_eps, 1);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_maf_step_inv(const float* y, float* z, float* ld, const void* const* head, const void* const* made_params,
+                               float* ws_zero, int64_t N, int D, int training, float bn_eps, nf_stream_t stream) {
+    if (y == nullptr || z == nullptr || ld == nullptr || head == nullptr || made_params == nullptr || ws_zero == nullptr ||
+        !nf_maf_ok(N, D))
+        return NF_E_BADARG;
+    if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
+    NfMadeP p;
+    nf_made_unpack(made_params, p);
+    NfMafV h{};
+    nf_maf_head(head, h);
+    h.z = y; h.y = z; h.ld = ld; h.D = D;
+    const unsigned grid = (unsigned)((N + NF_MAF_ROWS_PER_BLOCK - 1) / NF_MAF_ROWS_PER_BLOCK);
+    const size_t lds = nf_md_lds_bytes(1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_maf_step_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_maf_step_fwd<2>, dim3(grid), dim3(NF_MD_THREADS), lds, (hipStream_t)stream, p, h, (float*)nullptr, ws_zero, N,
+                       bn_eps, training ? 1 : 0);
     NF_CHECK_LAUNCH();
     return 0;
 }

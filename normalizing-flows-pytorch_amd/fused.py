@@ -1036,8 +1036,69 @@ def realnvp_flow_vec(z, ld, steps):
     return _RealNVPFlowVec.apply(z, _owned_ld(ld), tuple(metas), *tensors)
 
 
-# ---- RealNVP runs in evaluation mode (density evaluation under no_grad) and their inverse (sampling) ------------------------------
 FBN_RUNNING, FBN_BATCH_BUFFERS = -1.0, -2.0              # include/nfhip.h: NF_FBN_RUNNING, NF_FBN_BATCH_BUFFERS
+
+
+# ---- MAF steps in evaluation mode (density evaluation under no_grad) and their inverse (sampling) ---------------------------------
+def _maf_struct_ok(z, bn, ar):
+    return (z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and 1 <= z.shape[1] <= 4 and ar.net_s.num_hidden == 3
+            and ar.net_s.base_filters == H and ar.net_t.num_hidden == 3 and bn.training == ar.net_s.training == ar.net_t.training
+            and 0 < z.shape[0] <= N.header_constant('NF_MAF_MAX_ROWS'))
+
+
+def _maf_tables(bn, ar, ms, mt):
+    head = [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, ar.perm, ar.s_log_scale, ar.s_bias]
+    made = _made_tensors(ar.net_s, ms) + _made_tensors(ar.net_t, mt)
+    return _ptr_table([t.detach() for t in head]), _ptr_table([t.detach() for t in made])
+
+
+def maf_step_eval_usable(z, bn, ar):
+    return GLOW_INVERSE and not torch.is_grad_enabled() and not bn.training and _maf_struct_ok(z, bn, ar)
+
+
+def maf_step_eval(z, ld, bn, ar):
+    """[flow BatchNorm, AutoregressiveTransfrom] in evaluation mode under no_grad: one launch, no grid exchange"""
+    from .functional import _owned_ld
+    z = z.contiguous()
+    Nrows, D = z.shape
+    ms = ar.net_s.draw_masks(z.device)                       # same RNG order as the reference: s-net, then t-net
+    mt = ar.net_t.draw_masks(z.device)
+    htab, mtab = _maf_tables(bn, ar, ms, mt)
+    ld = _owned_ld(ld)
+    y = torch.empty_like(z)
+    ws = torch.empty(N.header_constant('NF_MAF_WS_FLOATS'), dtype=torch.float32, device=z.device)
+    save = torch.empty(N.header_constant('NF_MAF_SAVE_FLOATS'), dtype=torch.float32, device=z.device)
+    N.call('nf_maf_step_fwd', N.ptr(z), N.ptr(y), N.ptr(ld), ctypes.addressof(htab), ctypes.addressof(mtab), N.ptr(save), N.ptr(ws),
+           Nrows, D, float(bn.eps), FBN_RUNNING, BN_EPS, N.stream())
+    return y, ld
+
+
+def maf_step_inverse_usable(y, bn, ar):
+    """D <= 2: the MADE masks of such nets do not depend on the draw, so the D passes of the reference's inverse (which draws
+    anew in every pass) share one set"""
+    return GLOW_INVERSE and _maf_struct_ok(y, bn, ar) and y.shape[1] <= 2 and (y.shape[0] > 1 or not bn.training)
+
+
+def maf_step_inverse(y, ld, bn, ar):
+    """the inverse of [flow BatchNorm, AutoregressiveTransfrom] in one launch (maf.py:108-119, modules.py:309-322)"""
+    with torch.no_grad():
+        y = y.contiguous()
+        Nrows, D = y.shape
+        for _ in range(D):                                   # the reference draws per pass and net: same RNG consumption
+            ms = ar.net_s.draw_masks(y.device)
+            mt = ar.net_t.draw_masks(y.device)
+        htab, mtab = _maf_tables(bn, ar, ms, mt)
+        training = bool(bn.training)
+        nws = D * N.header_constant('NF_MAF_WS_FLOATS')
+        ws = WS.zeros(nws, y.device) if training else torch.empty(nws, dtype=torch.float32, device=y.device)
+        ld = ld.clone()
+        z = torch.empty_like(y)
+        N.call('nf_maf_step_inv', N.ptr(y), N.ptr(z), N.ptr(ld), ctypes.addressof(htab), ctypes.addressof(mtab), N.ptr(ws), Nrows, D,
+               int(training), BN_EPS, N.stream())
+        return z, ld
+
+
+# ---- RealNVP runs in evaluation mode (density evaluation under no_grad) and their inverse (sampling) ------------------------------
 
 
 def _realnvp_const_table(steps, mode, D, device):

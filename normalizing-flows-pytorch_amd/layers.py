@@ -121,6 +121,10 @@ class Compose(nn.Module):
                 z, log_df_dz = FUSED.realnvp_flow_vec_eval(z, log_df_dz, run)
                 i += 2 * len(run)
                 continue
+            if self._maf_pair_at(i, z) and FUSED.maf_step_eval_usable(z, L[i], L[i + 1]):
+                z, log_df_dz = FUSED.maf_step_eval(z, log_df_dz, L[i], L[i + 1])   # density evaluation: one launch, no exchange
+                i += 2
+                continue
             if self._bn_step_at(i, z):
                 a, k = L[i], L[i + 1]
                 run = self._realnvp_run_at(i, z)
@@ -200,6 +204,16 @@ class Compose(nn.Module):
             return False
         return not (a._forward_hooks or k._forward_hooks or a._forward_pre_hooks or k._forward_pre_hooks)
 
+    def _maf_pair_at(self, j, z):
+        """[flow BatchNorm(affine=False), AutoregressiveTransfrom] at layers j, j + 1 on (N, D) data, any mode, no hooks"""
+        L = self.layers
+        if not (self.fuse and z.is_cuda and z.dim() == 2 and j >= 0 and j + 1 < len(L)):
+            return False
+        a, k = L[j], L[j + 1]
+        if not (type(a) is BatchNorm and not isinstance(a.log_gamma, nn.Parameter) and type(k) is AutoregressiveTransfrom):
+            return False
+        return not (a._forward_hooks or k._forward_hooks or a._forward_pre_hooks or k._forward_pre_hooks)
+
     def _realnvp_inverse_run_ending_at(self, i, z):
         L, run, j = self.layers, [], i
         if z.dim() != 2 or torch.is_grad_enabled() and z.requires_grad:
@@ -229,6 +243,11 @@ class Compose(nn.Module):
             if run is not None:
                 z, log_df_dz = FUSED.realnvp_flow_vec_inverse(z, log_df_dz, run)
                 i -= 2 * len(run)
+                continue
+            if self._maf_pair_at(i - 1, z) and not (torch.is_grad_enabled() and z.requires_grad) \
+                    and FUSED.maf_step_inverse_usable(z, self.layers[i - 1], self.layers[i]):
+                z, log_df_dz = FUSED.maf_step_inverse(z, log_df_dz, self.layers[i - 1], self.layers[i])
+                i -= 2
                 continue
             z, log_df_dz = self.layers[i].backward(z, log_df_dz)
             i -= 1

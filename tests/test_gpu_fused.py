@@ -680,6 +680,62 @@ def test_realnvp_eval_and_inverse_vec_match_layerwise(pkg, D, B, K, training, mo
     assert fused.N.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('D,B,K', [(2, 16384, 3), (2, 300, 5), (1, 1000, 2), (3, 4096, 2), (2, 9, 1)])
+def test_maf_eval_and_inverse_step_match_layerwise(pkg, D, B, K, training, monkeypatch):
+    """MAF steps [flow BatchNorm, AutoregressiveTransfrom]: the inverse in one launch per step (D <= 2: D sequential MADE passes
+    inside the kernel; training mode: batch statistics and one running-statistics update per pass) and the evaluation-mode
+    forward under no_grad (one launch, no exchange) against the layer-by-layer path."""
+    from types import SimpleNamespace as NS
+    import numpy as np
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    torch.manual_seed(D * 100 + B + 5)
+    np.random.seed(D + B)
+    net1 = pkg.MAF((D, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    with torch.no_grad():
+        net1.train()
+        for _ in range(2):
+            net1((torch.randn(max(B, 64), D) * 0.8 + 0.1).to(DEV))
+        for p in net1.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    net2 = copy.deepcopy(net1)
+    net1.train(training)
+    net2.train(training)
+    y = (torch.randn(B, D) * 0.9).to(DEV)
+    calls = {'inv': 0, 'fwd': 0}
+    real_inv, real_fwd = fused.maf_step_inverse, fused.maf_step_eval
+
+    def c_inv(*a, **k):
+        calls['inv'] += 1
+        return real_inv(*a, **k)
+
+    def c_fwd(*a, **k):
+        calls['fwd'] += 1
+        return real_fwd(*a, **k)
+
+    monkeypatch.setattr(fused, 'maf_step_inverse', c_inv)
+    monkeypatch.setattr(fused, 'maf_step_eval', c_fwd)
+    with torch.no_grad():
+        np.random.seed(1)
+        z1, l1 = net1.backward(y.clone())
+        f1, lf1 = net1(y) if not training else (None, None)
+        monkeypatch.setattr(fused, 'GLOW_INVERSE', False)
+        np.random.seed(1)
+        z2, l2 = net2.backward(y.clone())
+        f2, lf2 = net2(y) if not training else (None, None)
+    assert (calls['inv'] == K) == (D <= 2), 'fused inverse steps taken: %d' % calls['inv']
+    G.assert_close(z1, z2, 2e-5, rtol=2e-5, what='inverse samples')
+    G.assert_close(l1, l2, 2e-5, rtol=2e-5, what='inverse log-det')
+    if not training:
+        assert calls['fwd'] == K, 'the one-launch evaluation forward was not taken'
+        G.assert_close(f1, f2, 1e-5, rtol=1e-5, what='evaluation forward')
+        G.assert_close(lf1, lf2, 1e-5, rtol=1e-5, what='evaluation log-det')
+    b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
+    for name in b2:
+        G.assert_close(b1[name].float(), b2[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
+    assert fused.N.persistent_timeouts() == 0
+
+
 @pytest.mark.parametrize('B,K,mix', [(65536, 11, 8), (1000, 3, 4), (40000, 9, 8)])
 def test_flowpp_deferred_finalize_matches_per_step(pkg, B, K, mix, monkeypatch):
     """the trainer defers the slab finalizes of the fused Flow++ steps to one launch per eight steps after backward
