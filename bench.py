@@ -47,8 +47,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (asymptotic sweeps)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
