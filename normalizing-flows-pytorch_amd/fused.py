@@ -785,8 +785,9 @@ class _GlowFlowVec(torch.autograd.Function):
         ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
         saves = torch.empty(S, N.header_constant('NF_GLOW_FLOW_SAVE_FLOATS'), dtype=torch.float32, device=dev)
         ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
+        ctx.host = _GLOW_FLOW_HOST[table.data_ptr()] if per_step else None      # (kept: the cache may be recycled before backward)
         if per_step:
-            N.call('nf_glow_flow_steps_fwd', ctypes.addressof(_GLOW_FLOW_HOST[table.data_ptr()]), S, N.ptr(z), N.ptr(ys), N.ptr(ld),
+            N.call('nf_glow_flow_steps_fwd', ctypes.addressof(ctx.host), S, N.ptr(z), N.ptr(ys), N.ptr(ld),
                    N.ptr(saves), N.ptr(ws), Nrows, D, int(training), BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
         else:
             N.call('nf_glow_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
@@ -809,7 +810,7 @@ class _GlowFlowVec(torch.autograd.Function):
         if per_step:
             rpb = N.header_constant('NF_MLP_ROWS_PER_BLOCK')
             slabs, rec = _glow_steps_scratch(S, (Nrows + rpb - 1) // rpb, dev)
-            N.call('nf_glow_flow_steps_bwd', ctypes.addressof(_GLOW_FLOW_HOST[table.data_ptr()]), table.data_ptr(), S, N.ptr(z),
+            N.call('nf_glow_flow_steps_bwd', ctypes.addressof(ctx.host), table.data_ptr(), S, N.ptr(z),
                    N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D,
                    int(training), BN_EPS, WN_EPS, N.stream())
         else:
