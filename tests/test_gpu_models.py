@@ -197,3 +197,38 @@ def test_trainer_deferred_conv_weight_gradients(pkg, dims, B, K, monkeypatch):
         t2.bucket.flat_params.copy_(t1.bucket.flat_params)
     n_cond = sum(1 for m in net1.modules() if type(m).__name__ == 'ConvNet')
     assert max(queued) == 6 * n_cond, 'weight-gradient passes were not deferred (queue lengths %r)' % (queued, )
+
+
+@pytest.mark.parametrize('name,dims,datatype,B,K', [('Glow', (2, ), 'density', 4096, 4), ('Glow', (2, ), 'density', 512, 3),
+                                                    ('RealNVP', (2, ), 'density', 256, 4), ('MAF', (2, ), 'density', 2048, 3),
+                                                    ('Flowpp', (2, ), 'density', 4096, 3), ('Glow', (3, 16, 16), 'image', 8, 2)])
+def test_trainer_hipgraph_replay_matches_eager(pkg, name, dims, datatype, B, K):
+    """the whole-step hipGraph (what bench.py times: capture of zero-grad + forward + backward incl. every deferred fold /
+    finalize / weight-gradient pass, and of the Adam step) replays to the same training trajectory as eager launches."""
+    import copy
+    import importlib
+    from types import SimpleNamespace as NS
+    import numpy as np
+    train = importlib.import_module(pkg.__name__ + '.train')
+    torch.manual_seed(11)
+    np.random.seed(11)
+    net1 = getattr(pkg, name)(dims, datatype, NS(layers=K, mixtures=4)).to(DEV)
+    net2 = copy.deepcopy(net1)
+    te, tg = train.FlowTrainer(net1, graph=False), train.FlowTrainer(net2, graph=True, warmup=3)
+    g = torch.Generator().manual_seed(5)
+    for step in range(8):
+        y = (torch.rand(B, *dims, generator=g) if datatype == 'image' else torch.randn(B, *dims, generator=g) * 0.8).to(DEV)
+        if tg._g_fb is None and tg._eager_steps >= tg.warmup:
+            te.train_on_batch(y)                            # the capturing call takes one extra (eager) step on its batch
+        z1, l1 = te.train_on_batch(y)
+        z2, l2 = tg.train_on_batch(y)
+        if step == 0:      # the ActNorm init sums by atomics: start both trajectories from identical parameters
+            net2.load_state_dict(net1.state_dict())
+            tg.bucket.flat_params.copy_(te.bucket.flat_params)
+        else:
+            G.assert_close(l2, l1, 5e-4 * max(1.0, abs(float(l1))), what='loss, step %d' % step)
+            G.assert_close(z2, z1, 5e-3, rtol=5e-3, what='z, step %d' % step)
+    assert tg._g_fb is not None, 'the step was never captured'
+    scale = float(te.bucket.flat.abs().max())
+    bad = ((tg.bucket.flat - te.bucket.flat).abs() > 2e-3 * max(1.0, scale)).float().mean()
+    assert float(bad) < 2e-3, 'gradients of the replayed step differ in %.2e of the entries' % float(bad)
