@@ -681,6 +681,12 @@ int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S,
                            const float* g_y, const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
                            float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps, float wn_eps,
                            nf_stream_t stream);
+/* ... and for a run of RealNVP steps (training mode; records of nf_realnvp_flow_pack, saves = S x NF_REALNVP_SAVE_FLOATS)          */
+int nf_realnvp_flow_steps_fwd(const void* steps_host, int S, const float* z0, float* ys, float* ld, float* saves, float* ws_zero,
+                              int64_t N, int D, float bn_eps, float bn_momentum, float wn_eps, nf_stream_t stream);
+int nf_realnvp_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S, const float* z0, const float* ys,
+                              const float* g_y, const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
+                              float* slabs_all, float* head_rec, int64_t N, int D, float bn_eps, float wn_eps, nf_stream_t stream);
 /* the same for a run of RealNVP steps (nf_realnvp_step_vec_*: training-mode flow BatchNorm + AffineCoupling, flows/realnvp.py);
  * records by nf_realnvp_flow_pack (head = the 8 pointers of nf_realnvp_step_vec_fwd), saves = S x NF_REALNVP_SAVE_FLOATS.     */
 int nf_realnvp_flow_pack(void* dst_host, const void* const* head, const void* const* mlp_params, float* g_s_log_scale,

@@ -1641,6 +1641,7 @@ extern "C" int nf_glow_flow_vec_bwd(const void* steps_dev, int S, const float* z
 // ---------------------------------------------------------------------------------------------------------------
 #define NF_GF_FOLD_BLOCKS ((NF_MC_NL * 33 + NF_MC_THREADS / 32 - 1) / (NF_MC_THREADS / 32))
 
+template <int HEAD>
 __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_fold_all(const NfGlowFlowStep* __restrict__ steps, const float* __restrict__ slabs,
                                                                  const float* __restrict__ head_rec, int G, int accumulate, int D,
                                                                  float wn_eps) {
@@ -1649,49 +1650,51 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_fold_all(const NfGlowFlo
     const NfGlowFlowStep& st = steps[s];                 // block-uniform: scalar loads
     const bool last = blockIdx.x == gridDim.x - 1;       // the head gradients' workgroup
     NfGlowRaw raw;
-    nf_glow_head_load(st.h, raw);
+    if (HEAD == 1) nf_glow_head_load(st.h, raw);
     float hsum = 0.f;
     if (last && threadIdx.x < 64) {
         const float* r = head_rec + (size_t)s * G * 64 + threadIdx.x;
         for (int b = 0; b < G; ++b) hsum += r[(size_t)b * 64];
     }
-    nf_mc_stage(st.p, sm, D / 2, D, wn_eps, &st.h, &raw);
+    nf_mc_stage(st.p, sm, D / 2, D, wn_eps, HEAD == 1 ? &st.h : nullptr, HEAD == 1 ? &raw : nullptr);
     if (last && threadIdx.x < 64) sm[NF_MC_TOT + threadIdx.x] = hsum;
     __syncthreads();
     nf_mc_fold_units(sm, slabs + (size_t)s * G * NF_MC_SLAB, G, (int)blockIdx.x, (int)gridDim.x, st.g, accumulate, D / 2, D, wn_eps);
     const bool afold = false;
     (void)afold;
-    if (last && threadIdx.x == NF_MC_THREADS - 1) nf_mc_head_grads<1>(sm, st.h, sm + NF_MC_TOT, accumulate, false);
+    if (last && threadIdx.x == NF_MC_THREADS - 1) nf_mc_head_grads<HEAD>(sm, st.h, sm + NF_MC_TOT, accumulate, false);
 }
 
-extern "C" int nf_glow_flow_steps_fwd(const void* steps_host, int S, const float* z0, float* ys, float* ld, float* saves,
-                                      float* ws_zero, int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
-                                      nf_stream_t stream) {
+template <int HEAD>
+static int nf_flow_steps_fwd(const void* steps_host, int S, const float* z0, float* ys, float* ld, float* saves, int save_stride,
+                             float* ws_zero, int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                             nf_stream_t stream) {
     if (steps_host == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr || ld == nullptr ||
         saves == nullptr || ws_zero == nullptr || !nf_glow_args_ok(N, D))
         return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t lds = nf_mc_lds_bytes(1);
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_fwd<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const NfGlowFlowStep* st = reinterpret_cast<const NfGlowFlowStep*>(steps_host);
     const int64_t ND = N * D;
     for (int s = 0; s < S; ++s) {
         NfGlowV h = st[s].h;
         h.z = s == 0 ? z0 : ys + (int64_t)(s - 1) * ND; h.y = ys + (int64_t)s * ND; h.ld = ld;
-        hipLaunchKernelGGL(k_mlp_chain_fwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, st[s].p,
-                           (float*)nullptr, saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, ws_zero + (int64_t)s * NF_MLP_WS_FLOATS, N, D / 2,
+        hipLaunchKernelGGL(k_mlp_chain_fwd<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, st[s].p,
+                           (float*)nullptr, saves + (int64_t)s * save_stride, ws_zero + (int64_t)s * NF_MLP_WS_FLOATS, N, D / 2,
                            D, training, bn_eps, bn_momentum, wn_eps, h);
     }
     NF_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S, const float* z0, const float* ys,
-                                      const float* g_y, const float* g_ld, float* gzs, const float* saves, int accumulate,
-                                      float* ws_zero, float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps,
-                                      float wn_eps, nf_stream_t stream) {
+template <int HEAD>
+static int nf_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S, const float* z0, const float* ys,
+                             const float* g_y, const float* g_ld, float* gzs, const float* saves, int save_stride, int accumulate,
+                             float* ws_zero, float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps,
+                             float wn_eps, nf_stream_t stream) {
     if (steps_host == nullptr || steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr ||
         g_y == nullptr || gzs == nullptr || saves == nullptr || ws_zero == nullptr || slabs_all == nullptr || head_rec == nullptr ||
         !nf_glow_args_ok(N, D))
@@ -1699,9 +1702,9 @@ extern "C" int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
     const size_t lds = nf_mc_lds_bytes(3), lds_fold = nf_mc_lds_bytes(1);
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_chain_bwd<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)k_glow_fold_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fold);
+    e = hipFuncSetAttribute((const void*)k_glow_fold_all<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fold);
     if (e != hipSuccess) return (int)e;
     const NfGlowFlowStep* st = reinterpret_cast<const NfGlowFlowStep*>(steps_host);
     const int64_t ND = N * D;
@@ -1711,15 +1714,43 @@ extern "C" int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_
         h.g_y = s == S - 1 ? g_y : gzs + (int64_t)(s + 1) * ND;
         h.g_ld = g_ld;
         h.g_z = gzs + (int64_t)s * ND;
-        hipLaunchKernelGGL(k_mlp_chain_bwd<1>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, st[s].p,
-                           saves + (int64_t)s * NF_GLOW_FLOW_SAVE_FLOATS, (const float*)nullptr, (float*)nullptr, st[s].g, accumulate,
+        hipLaunchKernelGGL(k_mlp_chain_bwd<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream, (const float*)nullptr, st[s].p,
+                           saves + (int64_t)s * save_stride, (const float*)nullptr, (float*)nullptr, st[s].g, accumulate,
                            ws_zero + (int64_t)s * NF_MLP_WS_FLOATS, slabs_all + (size_t)s * grid * NF_MC_SLAB, N, D / 2, D, training,
                            bn_eps, wn_eps, h, head_rec + (size_t)s * grid * 64);
     }
-    hipLaunchKernelGGL(k_glow_fold_all, dim3(NF_GF_FOLD_BLOCKS, S), dim3(NF_MC_THREADS), lds_fold, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_glow_fold_all<HEAD>, dim3(NF_GF_FOLD_BLOCKS, S), dim3(NF_MC_THREADS), lds_fold, (hipStream_t)stream,
                        (const NfGlowFlowStep*)steps_dev, slabs_all, head_rec, (int)grid, accumulate, D, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int nf_glow_flow_steps_fwd(const void* steps_host, int S, const float* z0, float* ys, float* ld, float* saves,
+                                      float* ws_zero, int64_t N, int D, int training, float bn_eps, float bn_momentum, float wn_eps,
+                                      nf_stream_t stream) {
+    return nf_flow_steps_fwd<1>(steps_host, S, z0, ys, ld, saves, NF_GLOW_FLOW_SAVE_FLOATS, ws_zero, N, D, training, bn_eps, bn_momentum,
+                                wn_eps, stream);
+}
+extern "C" int nf_glow_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S, const float* z0, const float* ys,
+                                      const float* g_y, const float* g_ld, float* gzs, const float* saves, int accumulate,
+                                      float* ws_zero, float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps,
+                                      float wn_eps, nf_stream_t stream) {
+    return nf_flow_steps_bwd<1>(steps_host, steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_GLOW_FLOW_SAVE_FLOATS, accumulate, ws_zero,
+                                slabs_all, head_rec, N, D, training, bn_eps, wn_eps, stream);
+}
+// the RealNVP steps likewise (training mode; records of nf_realnvp_flow_pack, saves = S x NF_REALNVP_SAVE_FLOATS)
+extern "C" int nf_realnvp_flow_steps_fwd(const void* steps_host, int S, const float* z0, float* ys, float* ld, float* saves,
+                                         float* ws_zero, int64_t N, int D, float bn_eps, float bn_momentum, float wn_eps,
+                                         nf_stream_t stream) {
+    return nf_flow_steps_fwd<2>(steps_host, S, z0, ys, ld, saves, NF_REALNVP_SAVE_FLOATS, ws_zero, N, D, 1, bn_eps, bn_momentum, wn_eps,
+                                stream);
+}
+extern "C" int nf_realnvp_flow_steps_bwd(const void* steps_host, const void* steps_dev, int S, const float* z0, const float* ys,
+                                         const float* g_y, const float* g_ld, float* gzs, const float* saves, int accumulate,
+                                         float* ws_zero, float* slabs_all, float* head_rec, int64_t N, int D, float bn_eps,
+                                         float wn_eps, nf_stream_t stream) {
+    return nf_flow_steps_bwd<2>(steps_host, steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, ws_zero,
+                                slabs_all, head_rec, N, D, 1, bn_eps, wn_eps, stream);
 }
 
 // the same for a run of RealNVP steps [flow BatchNorm (batch statistics), AffineCoupling]: records packed by nf_realnvp_flow_pack

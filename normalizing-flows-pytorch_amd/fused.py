@@ -955,7 +955,9 @@ def _realnvp_flow_table(steps, sinks, D, device):
     table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
     if len(_GLOW_FLOW_TABLES) > 64:
         _GLOW_FLOW_TABLES.clear()
+        _GLOW_FLOW_HOST.clear()
     _GLOW_FLOW_TABLES[key] = table
+    _GLOW_FLOW_HOST[table.data_ptr()] = host
     return table
 
 
@@ -964,7 +966,7 @@ class _RealNVPFlowVec(torch.autograd.Function):
     tensors: per step the 8 head tensors and the 43 MLP tensors of _RealNVPStepVec."""
 
     @staticmethod
-    def forward(ctx, z, ld, metas, *tensors):
+    def forward(ctx, z, ld, metas, per_step, *tensors):
         S = len(metas)
         per = 8 + 43
         steps = [metas[i] + (tensors[per * i:per * i + 8], tensors[per * i + 8:per * (i + 1)]) for i in range(S)]
@@ -979,8 +981,13 @@ class _RealNVPFlowVec(torch.autograd.Function):
         ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
         saves = torch.empty(S, N.header_constant('NF_REALNVP_SAVE_FLOATS'), dtype=torch.float32, device=dev)
         ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
-        N.call('nf_realnvp_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
-               BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        ctx.host = _GLOW_FLOW_HOST[table.data_ptr()] if per_step else None
+        if per_step:       # one launch per step, the backward's gradient folds deferred to one launch (as for the Glow steps)
+            N.call('nf_realnvp_flow_steps_fwd', ctypes.addressof(ctx.host), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws),
+                   Nrows, D, BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
+        else:
+            N.call('nf_realnvp_flow_vec_fwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(ld), N.ptr(saves), N.ptr(ws), Nrows, D,
+                   BN_EPS, BN_MOMENTUM, WN_EPS, N.stream())
         ctx.save_for_backward(z, ys, saves, table)
         ctx.meta = (S, len(tensors))
         ctx.mark_dirty(ld)
@@ -996,9 +1003,15 @@ class _RealNVPFlowVec(torch.autograd.Function):
         g_ld = None if g_ld is None else g_ld.contiguous()
         gzs = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
         ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
-        N.call('nf_realnvp_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves),
-               1, N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, BN_EPS, WN_EPS, N.stream())
-        return (gzs[0], g_ld, None) + (None, ) * n_tensors
+        if ctx.host is not None:
+            rpb = N.header_constant('NF_MLP_ROWS_PER_BLOCK')
+            slabs, rec = _glow_steps_scratch(S, (Nrows + rpb - 1) // rpb, dev)
+            N.call('nf_realnvp_flow_steps_bwd', ctypes.addressof(ctx.host), table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y),
+                   _p(g_ld), N.ptr(gzs), N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, BN_EPS, WN_EPS, N.stream())
+        else:
+            N.call('nf_realnvp_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves),
+                   1, N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, BN_EPS, WN_EPS, N.stream())
+        return (gzs[0], g_ld, None, None) + (None, ) * n_tensors
 
 
 def _flow_on(z):
@@ -1016,7 +1029,8 @@ def _glow_steps_on(z):
 def realnvp_flow_vec_usable(z, steps):
     """steps: [(flow BatchNorm, AffineCoupling)] -- at least two fused-step-capable steps, every parameter with a direct sink."""
     from .functional import grad_sink
-    if not _flow_on(z) or len(steps) < 2 or len(steps) > N.header_constant('NF_GLOW_FLOW_MAX_STEPS') or not torch.is_grad_enabled():
+    if not (_flow_on(z) or _glow_steps_on(z)) or len(steps) < 2 or len(steps) > N.header_constant('NF_GLOW_FLOW_MAX_STEPS') \
+            or not torch.is_grad_enabled():
         return False
     for bn, k in steps:
         if not realnvp_step_vec_usable(z, bn, k.net):
@@ -1034,7 +1048,7 @@ def realnvp_flow_vec(z, ld, steps):
         tensors += [bn.log_gamma, bn.beta, bn.batch_mean, bn.batch_var, bn.running_mean, bn.running_var, k.s_log_scale, k.s_bias]
         tensors += _mlp_tensors(k.net)
         metas.append((int(k.odd), float(bn.eps), float(bn.momentum)))
-    return _RealNVPFlowVec.apply(z, _owned_ld(ld), tuple(metas), *tensors)
+    return _RealNVPFlowVec.apply(z, _owned_ld(ld), tuple(metas), not _flow_on(z), *tensors)
 
 
 FBN_RUNNING, FBN_BATCH_BUFFERS = -1.0, -2.0              # include/nfhip.h: NF_FBN_RUNNING, NF_FBN_BATCH_BUFFERS

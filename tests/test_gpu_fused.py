@@ -819,10 +819,14 @@ def test_maf_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
     assert fused.N.persistent_timeouts() == 0
 
 
-@pytest.mark.parametrize('D,B,K', [(2, 256, 8), (4, 1000, 3), (2, 4096, 2)])
-def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
-    """a run of vector RealNVP steps in one launch per direction against the same steps launched one by one (bit-identical
-    step bodies): outputs, loss, flat gradients, flow-BatchNorm and BatchNorm1d buffers."""
+@pytest.mark.parametrize('mode', [True, 'steps'])
+@pytest.mark.parametrize('D,B,K', [(2, 256, 8), (4, 1000, 3), (2, 4096, 2), (2, 16384, 3)])
+def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
+    """a run of vector RealNVP steps as one autograd node -- one launch per direction (mode True), or one launch per step with
+    the gradient folds of all steps deferred to one launch (nf_realnvp_flow_steps_*, mode 'steps') -- against the same steps
+    launched one by one (bit-identical step bodies): outputs, loss, flat gradients, flow-BatchNorm and BatchNorm1d buffers."""
+    if mode == 'steps' and B <= 256:
+        pytest.skip('one or two workgroups fold without a barrier: nothing to defer')
     from types import SimpleNamespace as NS
     train = importlib.import_module(pkg.__name__ + '.train')
     fused = importlib.import_module(pkg.__name__ + '.fused')
@@ -839,7 +843,7 @@ def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
         return real(*a, **k)
 
     for step in range(2):
-        monkeypatch.setattr(fused, 'GLOW_FLOW', True)
+        monkeypatch.setattr(fused, 'GLOW_FLOW', mode)
         monkeypatch.setattr(fused, 'realnvp_flow_vec', counted)
         t1.net.train()
         z1, l1 = t1._forward_backward(y)
@@ -850,7 +854,7 @@ def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, monkeypatch):
         G.assert_close(z1, z2, 1e-6, rtol=1e-6, what='z, step %d' % step)
         G.assert_close(l1, l2, 1e-6, rtol=1e-6, what='loss, step %d' % step)
         # (same step bodies; with <= 32 workgroups the fold adds by float atomics, whose order is not fixed)
-        G.assert_close(t1.bucket.flat, t2.bucket.flat, 1e-5 * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
+        G.assert_close(t1.bucket.flat, t2.bucket.flat, (1e-5 if mode is True else 5e-5) * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
         b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
         for name in b2:
             G.assert_close(b1[name].float(), b2[name].float(), 1e-6, rtol=1e-6, what='buffer ' + name)
