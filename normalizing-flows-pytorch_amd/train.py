@@ -72,8 +72,9 @@ class FlowTrainer:
     """Adam (lr 1e-4, betas (0.9, 0.999): configs/default.yaml:13-20) on the NLL, gradients in one flat bucket.
 
     ``graph=True`` captures zero-grad + forward + backward into one hipGraph and the optimizer step into a second one
-    (the gradient all-reduce runs between the two replays), after ``warmup`` eager steps that also perform the
-    data-dependent ActNorm initialisation.  The batch shape is then fixed."""
+    (the gradient all-reduce runs between the two replays; a single process captures both into ONE graph), after
+    ``warmup`` eager steps that also perform the data-dependent ActNorm initialisation.  The batch shape is then fixed.
+    The call that captures also takes one extra eager step on its batch (allocator warm-up on the capture stream)."""
 
     def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None,
                  fused_adam=True):
@@ -160,13 +161,18 @@ class FlowTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # thread_local: a collective watchdog / other host thread touching the runtime must not invalidate the capture
+        single = self.bucket.world == 1                 # no all-reduce between backward and Adam: one graph, one replay
         g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_fb, capture_error_mode='thread_local'):
             z, loss = self._forward_backward(self._static_y)
             self._static_z, self._static_loss = z.detach(), loss.detach()
-        g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_opt, capture_error_mode='thread_local'):
-            self.optim.step()
+            if single:
+                self.optim.step()
+        g_opt = None
+        if not single:
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt, capture_error_mode='thread_local'):
+                self.optim.step()
         self._g_fb, self._g_opt = g_fb, g_opt
 
     def train_on_batch(self, y):
@@ -184,8 +190,9 @@ class FlowTrainer:
         if self._g_fb is not None:
             self._static_y.copy_(y, non_blocking=True)
             self._g_fb.replay()
-            self.bucket.all_reduce_mean_()
-            self._g_opt.replay()
+            if self._g_opt is not None:
+                self.bucket.all_reduce_mean_()
+                self._g_opt.replay()
             return self._static_z, self._static_loss
         z, loss = self._forward_backward(y)
         self.bucket.all_reduce_mean_()
