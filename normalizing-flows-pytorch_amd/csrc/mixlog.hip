@@ -383,6 +383,81 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_oct_fwd(const float* __rest
     }
 }
 
+// The inverse with one mixture component per lane (density data, K <= 8; see k_mixlog_oct_fwd): the bisection's mixture CDF is one
+// sigmoid per lane and three DPP adds (the same sum on all eight lanes: the butterfly adds commute), eight times the waves of the
+// element-per-thread form in flight.  PHASE 1 runs the 25 steps every batch needs and WRITES THE RESULT -- x = mid, ld += the
+// affine / sigmoid terms - log pdf(x) -- and raises the flag when some bracket is still >= 1e-4; PHASE 2 returns at once unless
+// the flag is set (the reference then runs all 100 iterations for the whole batch, modules.py:205): it takes the saved brackets
+// 75 steps further and replaces x and the log-pdf term.
+template <int PHASE>
+__global__ void __launch_bounds__(NF_BLOCK) k_mixlog_oct_inv(const float* __restrict__ yin, const float* __restrict__ prm,
+                                                             const float* __restrict__ pA, const float* __restrict__ pC,
+                                                             float* __restrict__ y, float* __restrict__ ld, float* __restrict__ lohi,
+                                                             int* __restrict__ flag, NfSplit s, int K, int64_t B) {
+    if (PHASE == 2 && flag[0] == 0) return;
+    const float A = pA[0], Cb = pC[0];
+    const int kk = threadIdx.x & 7;
+    const int64_t PS = (int64_t)(2 + 3 * K) * s.n_half;
+    const int64_t per = (int64_t)gridDim.x * (blockDim.x >> 3);
+    const int64_t total = B * s.n_half;
+    bool stuck = false;
+    for (int64_t b0 = (int64_t)blockIdx.x * (blockDim.x >> 3); b0 < B; b0 += per) {      // uniform trip count per wave (DPP)
+        const int64_t b = b0 + (threadIdx.x >> 3);
+        const bool live = b < B;
+        const int64_t bb = live ? b : B - 1;
+        const float* zb = yin + bb * s.n_full;
+        float* yb = y + bb * s.n_full;
+        float acc = 0.f;
+        for (int e = 0; e < s.n_half; ++e) {
+            NfOct m;
+            nf_oct_load(prm + bb * PS + e, s.n_half, K, kk, m);
+            const float pik = nf_fexp(m.lp);                                 // 0 for the padding lanes (lp = -inf)
+            const int o0 = nf_half_to_full(s, 0, e), o1 = nf_half_to_full(s, 1, e);
+            const int64_t t = bb * s.n_half + e;
+            float lo, hi, target, lpdf_old = 0.f;
+            if (PHASE == 1) {
+                const float a = tanhf(m.a_raw) * A + Cb;
+                const float v = expf(-a) * (zb[o0] - m.b);                    // coupling.py:204
+                target = 1.f / (1.f + expf(-v));                             // modules.py:155
+                acc += -a + (v - 2.f * nf_softplus(v));                      // coupling.py:205, modules.py:153
+                lo = -1.0e3f;                                                // modules.py:197-198
+                hi = 1.0e3f;
+            } else {
+                lo = lohi[t];
+                hi = lohi[total + t];
+                target = lohi[2 * total + t];
+                float lcdf, u, l;
+                nf_oct_eval(m, (lo + hi) * 0.5f, lcdf, lpdf_old, u, l);      // what phase 1 subtracted
+            }
+            for (int it = 0; it < (PHASE == 1 ? 25 : 75); ++it) {
+                const float mid = (lo + hi) * 0.5f;
+                const float val = nf_oct_sum(pik * __builtin_amdgcn_rcpf(1.f + nf_fexp(-(mid - m.mu) * m.es)));
+                // a bracket that has collapsed to neighbouring floats (mid is one of its ends) or sits on val == target cannot
+                // change any more: once that holds for the whole wave the remaining iterations are no-ops
+                if (PHASE == 2 && __all(mid == lo || mid == hi || val == target)) break;
+                lo = val < target ? mid : lo;                                // modules.py:202-203
+                hi = val > target ? mid : hi;
+            }
+            const float x = (lo + hi) * 0.5f;                                // modules.py:208
+            float lcdf, lpdf, u, l;
+            nf_oct_eval(m, x, lcdf, lpdf, u, l);
+            acc += PHASE == 1 ? -lpdf : lpdf_old - lpdf;                     // modules.py:209-212
+            if (PHASE == 1) stuck |= live && !(fabsf(hi - lo) < 1.0e-4f);    // modules.py:205
+            if (live && kk == 0) {
+                if (PHASE == 1) {
+                    lohi[t] = lo;
+                    lohi[total + t] = hi;
+                    lohi[2 * total + t] = target;
+                    yb[o1] = zb[o1];
+                }
+                yb[o0] = x;
+            }
+        }
+        if (live && kk == 0) ld[b] += acc;
+    }
+    if (PHASE == 1 && __any(stuck) && (threadIdx.x & (NF_WAVE - 1)) == 0) atomicOr(flag, 1);
+}
+
 // 1024-thread workgroups: every workgroup ends in one pair of same-address atomics, which the L2 serialises at about 20 ns
 // each (512 workgroups of 256 threads spent 10 of their 23 us there); 128 x 16 waves keeps the same number of waves in flight
 #define NF_OCT_BWD_THREADS 1024
@@ -579,6 +654,16 @@ extern "C" int nf_mixlog_coupling_inv(const float* z, const float* params, const
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(stuck_flag, 0, sizeof(int), st);
     if (e != hipSuccess) return (int)e;
+    if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane (see k_mixlog_oct_inv)
+        unsigned go = nf_grid_for(B * 8, NF_BLOCK);
+        if (go > 2048) go = 2048;
+        hipLaunchKernelGGL(k_mixlog_oct_inv<1>, dim3(go), dim3(NF_BLOCK), 0, st, z, params, a_log_scale, a_bias, y, ld, scratch, stuck_flag,
+                           s, K, B);
+        hipLaunchKernelGGL(k_mixlog_oct_inv<2>, dim3(go), dim3(NF_BLOCK), 0, st, z, params, a_log_scale, a_bias, y, ld, scratch, stuck_flag,
+                           s, K, B);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     const int th = nf_mx_threads(K);
     const unsigned g = nf_grid_for(total, th);
     const size_t lds = nf_mx_lds(s, K, th);
