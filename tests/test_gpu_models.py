@@ -226,9 +226,11 @@ def test_trainer_hipgraph_replay_matches_eager(pkg, name, dims, datatype, B, K):
             net2.load_state_dict(net1.state_dict())
             tg.bucket.flat_params.copy_(te.bucket.flat_params)
         else:
-            G.assert_close(l2, l1, 5e-4 * max(1.0, abs(float(l1))), what='loss, step %d' % step)
-            G.assert_close(z2, z1, 5e-3, rtol=5e-3, what='z, step %d' % step)
+            # (two trainings: summation-order noise of the atomics passes through Adam, so the bars are wide -- a fold, finalize or
+            #  weight-gradient pass missing from the captured graph moves the trajectory by orders of magnitude more)
+            G.assert_close(l2, l1, 2e-3 * max(1.0, abs(float(l1))), what='loss, step %d' % step)
+            G.assert_close(z2, z1, 2e-2, rtol=2e-2, what='z, step %d' % step)
     assert tg._g_fb is not None, 'the step was never captured'
     scale = float(te.bucket.flat.abs().max())
     bad = ((tg.bucket.flat - te.bucket.flat).abs() > 2e-3 * max(1.0, scale)).float().mean()
-    assert float(bad) < 2e-3, 'gradients of the replayed step differ in %.2e of the entries' % float(bad)
+    assert float(bad) < 1e-2, 'gradients of the replayed step differ in %.2e of the entries' % float(bad)
