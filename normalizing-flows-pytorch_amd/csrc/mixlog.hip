@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_inv(const float* __restrict
             for (int it = 0; it < steps; ++it) {
                 const float mid = (lo + hi) * 0.5f;
                 const float val = nf_mix_cdf<KT>(m, pi, mid);
+                if (PHASE == 2 && (mid == lo || mid == hi || val == target)) break;                 // collapsed: the rest are no-ops
                 lo = val < target ? mid : lo;                                                       // modules.py:202-203
                 hi = val > target ? mid : hi;
             }
