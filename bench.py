@@ -230,7 +230,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
             tf = flop / (us * 1e-6) / 1e12
             name = 'k_glow_flow_bwd<%d> (backward of all %d %s flow steps, one launch)' % (1 if glow else 2, S, 'Glow' if glow else 'RealNVP')
             return {'bound': 'mfma', 'kernel': name, 'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': None, 'flop_per_launch': int(flop),
+                    'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': pmc_traffic('k_glow_flow_bwd', B), 'flop_per_launch': int(flop),
                     'bytes_per_launch': int(S * B * (3 * D + 1) * 4), 'us_per_launch': round(us, 3),
                     'note': 'neither MFMA- nor HBM-bound at this batch: per step six grid-wide exchanges and single-tile issue latency '
                             'serialise the launch (DESIGN.md sections 2 and 3.11)'}
