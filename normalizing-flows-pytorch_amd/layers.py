@@ -398,9 +398,12 @@ class InvertibleConv1x1(nn.Module):
                                   self.log_s)
         return NF.invconv(z, self.weight(), log_df_dz, self.log_s)
 
+    _W_inv = None      # set for the duration of ONE model inverse pass by models._inverse_weights_all (all layers of a width at once)
+
     def backward(self, y, log_df_dz):
         with torch.no_grad():
-            return NF.invconv_inverse(y, self.inverse_weight(), log_df_dz, self.log_s)
+            W_inv = self._W_inv if (self._W_inv is not None and y.is_cuda) else self.inverse_weight()
+            return NF.invconv_inverse(y, W_inv, log_df_dz, self.log_s)
 
 
 # ---- squeeze family (flows/squeeze.py:114-189) ---------------------------------------------------------------------

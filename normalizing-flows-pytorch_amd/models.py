@@ -71,10 +71,36 @@ class _FlowModel(nn.Module):
                                    and NF.HEAD_MAX_C < m.L.shape[0] <= NF.PLU_MAX_C]
         return c
 
+    def _inverse_weights_all(self):
+        """W^-1 = U'^-1 L'^-1 Pp of every invertible 1x1 convolution of an image model (modules.py:485-492), the layers of one
+        width solved as ONE batch: two triangular solves per width instead of two per layer (~10 small launches each, 129
+        layers in the CIFAR Glow).  Stashed on the modules for the inverse pass under way."""
+        from .layers import InvertibleConv1x1
+        convs = getattr(self, '_inv_cache', None)
+        if convs is None:
+            convs = self._inv_cache = [m for m in self.modules() if isinstance(m, InvertibleConv1x1)]
+        groups = {}
+        for m in convs:
+            groups.setdefault(m.L.shape[0], []).append(m)
+        with torch.no_grad():
+            for C, ms in groups.items():
+                L = torch.stack([m.L for m in ms]) * torch.stack([m.L_mask for m in ms])
+                U = torch.stack([m.U for m in ms]) * torch.stack([m.U_mask for m in ms])
+                d = torch.stack([m.sign_s * torch.exp(m.log_s) for m in ms])
+                Lp = L + torch.eye(C, dtype=L.dtype, device=L.device)
+                Up = U + torch.diag_embed(d)
+                Pp = torch.stack([m._pivot_matrix() for m in ms])
+                X = torch.linalg.solve_triangular(Lp, Pp, upper=False, unitriangular=True)
+                Winv = torch.linalg.solve_triangular(Up, X, upper=True)
+                for i, m in enumerate(ms):
+                    m._W_inv = Winv[i]
+        return convs
+
     def _with_weight_norms(self, fn, z):
         wns = self._wn_convs() if z.is_cuda else []
         plus = self._plu_convs() if (z.is_cuda and z.dim() == 4 and fn == self.net) else []
-        if not wns and not plus:
+        invs = self._inverse_weights_all() if (z.is_cuda and z.dim() == 4 and fn != self.net) else []
+        if not wns and not plus and not invs:
             return fn(z, self._zero_ld(z))
         from . import fused as FUSED
         FUSED.weight_norm_all(wns)
@@ -86,6 +112,8 @@ class _FlowModel(nn.Module):
                 m._w_eff = None
             for m in plus:
                 m._W_eff = None
+            for m in invs:
+                m._W_inv = None
 
     def forward(self, z):
         return self._with_weight_norms(self.net, z)
