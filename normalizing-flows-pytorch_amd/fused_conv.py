@@ -201,12 +201,14 @@ class _FusedConvNet(torch.autograd.Function):
             return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[j, 0], bn_sqsum=ws[j, R], bn_center=conv[j][1], bn_running_mean=rm,
                         bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
 
-        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], stat_sum=ws[0, 0],
-             stat_sqsum=ws[0, R])
+        def stats(j):                             # evaluation mode normalises with running statistics: no batch sums
+            return dict(stat_sum=ws[j, 0], stat_sqsum=ws[j, R]) if training else {}
+
+        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], **stats(0))
         for j in range(1, nb):                    # convolution j consumes acts[j-1] through BatchNorm j-1
             res = acts[j - 2] if j % 2 == 0 else None
             _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j],
-                 stat_sum=ws[j, 0], stat_sqsum=ws[j, R], **bn_kw(j - 1))
+                 **stats(j), **bn_kw(j - 1))
         _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
              **bn_kw(nb - 1))
         ctx.save_for_backward(x, ws, *acts, *w, *[t for b in bns for t in b[:2]])
