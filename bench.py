@@ -6,8 +6,10 @@ bench.py -- samples/sec (+ bits/dim) of one training step of the flow hot path o
 
 A "step" is one full pass of the hot path over one batch of synthetic input: forward flow + log-det, NLL,
 autograd backward through every transform kernel, gradient all-reduce (N > 1), Adam -- main.py:78-92.
-Default workload = BASELINE.json configs[1]: Glow, moons 2-D, K=32 flow steps, batch 4096 per GPU (weak scaling).
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+Default workloads = the two configs BASELINE.json's metric is quoted on: Glow CIFAR-10 (3,32,32) L=3 K=32, batch 64 per GPU
+(= 512 over 8, configs[3]) on the top level of the line, and RealNVP moons-2D K=32 batch 256 (configs[0]) under "also".
+`--config c1..c5` measures one workload.  `--gpus N` outside torchrun re-executes itself under torch.distributed.run.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline` and `parity` objects.
 
 Timed region: inputs already resident in HBM; barrier + synchronize on both sides; max over ranks.
 """
@@ -47,13 +49,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default=None, choices=sorted(CONFIGS),
+                    help='one workload; default: c4 (Glow CIFAR-10) on the top level + c1 (RealNVP moons) under "also"')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (asymptotic sweeps)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--skip-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
 
 
@@ -127,7 +130,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
     g = torch.Generator(device='cpu').manual_seed(7)
     extra = {}
     MFMA_F32_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
-    if cfg['kind'] in ('glow', 'realnvp') and len(dims) == 1 and dims[0] in (2, 4) and B <= N.header_constant('NF_MLP_MAX_ROWS'):
+    if cfg['kind'] in ('glow', 'realnvp') and len(dims) == 1 and dims[0] in (2, 4) and B <= N.mlp_max_rows():
         D = dims[0]
         glow = cfg['kind'] == 'glow'
         k = pkg.AffineCoupling((D, )).to(dev).train()
@@ -259,7 +262,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                 'note': 'neither MFMA- nor HBM-bound at this batch: six grid-wide exchanges (five BatchNorm reductions + the fenced '
                         'barrier in front of the fold, ~1.6 us each at 32 workgroups) and single-tile issue latency serialise the '
                         'launch (DESIGN.md section 2; tools/probes/mlp_chain_prof.py)'}
-    if cfg['kind'] == 'maf' and len(dims) == 1 and dims[0] <= 4 and B <= N.header_constant('NF_MAF_MAX_ROWS'):
+    if cfg['kind'] == 'maf' and len(dims) == 1 and dims[0] <= 4 and B <= N.maf_max_rows():
         D = dims[0]
         bn = pkg.BatchNorm((D, ), affine=False).to(dev).train()
         ar = pkg.AutoregressiveTransfrom(D).to(dev).train()
@@ -491,7 +494,9 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
 
 def cpu_baseline(cfg, state, y_cpu, seconds):
     """the oracle (our CPU restatement of the reference, validated against it) timed on this box's host cores on the
-    same workload and weights: full train step incl. Adam, bounded to ~`seconds` of CPU work."""
+    same workload and weights: full train step incl. Adam, bounded to ~`seconds` of CPU work.  Returns (object, first):
+    ``first`` = (z, loss) of the FIRST step from the initial weights -- the same step the GPU trainer's first call performs
+    (data-dependent ActNorm initialisation included), which is what the bench line's ``parity`` object compares."""
     from oracle import models as om
     from oracle import transforms as tf
     # the flow step is thousands of tiny ops: torch's intra-op pool stops scaling (and then collapses) beyond a few
@@ -504,6 +509,7 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
     params = list(ora.parameters().values())
     opt = torch.optim.Adam(params, lr=1.0e-4)
     B = y_cpu.shape[0]
+    last = {}
 
     def step():
         opt.zero_grad()
@@ -511,13 +517,15 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
         loss = tf.nll_loss(z, ld)
         loss.backward()
         opt.step()
+        last['z'] = z.detach()
         return float(loss.detach())
 
-    step()                                                   # ActNorm init + warm caches
+    loss1 = step()                                           # ActNorm init + warm caches (untimed); parity is taken here
+    first = (last['z'].clone(), loss1)
     t0 = time.perf_counter()
-    n, loss = 0, 0.0
+    n = 0
     while True:
-        loss = step()
+        step()
         n += 1
         el = time.perf_counter() - t0
         if el >= seconds or n >= 200:
@@ -531,28 +539,18 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
                     break
     except OSError:
         pass
-    return {'value': round(B * n / el, 1), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d train steps of the same workload (batch %d, same weights) in %.1f s on %s' % (n, B, el, model),
-            'ms_per_step': round(1e3 * el / n, 2), 'loss': round(loss, 5)}
+    return ({'value': round(B * n / el, 1), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+             'sample': '%d train steps of the same workload (batch %d, same initial weights) in %.1f s on %s' % (n, B, el, model),
+             'ms_per_step': round(1e3 * el / n, 2)}, first)
 
 
-def main():
-    args = parse()
-    pkg = importlib.import_module(PKG)
-    pkg._native.load()
+def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
+    """one workload: W warm-up steps, K timed steps (barrier + synchronize on both sides, max over ranks), then on rank 0
+    the dominant kernel's roofline, the CPU baseline and the step-1 parity; returns the JSON object (None off rank 0)."""
     nfdist = importlib.import_module(PKG + '.dist')
     nftrain = importlib.import_module(PKG + '.train')
     nfdata = importlib.import_module(PKG + '.data')
-    rank, world, local_rank = nfdist.init_from_env()
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs a torchrun launch with that many ranks' % args.gpus)
-    assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no GPU visible'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if os.environ.get('NF_MIOPEN_FIND', '0') == '1':
-        torch.backends.cudnn.benchmark = True                # MIOpen find mode for the image conditioner's convolutions
-    cfg = CONFIGS[args.config]
+    cfg = CONFIGS[name]
     B = args.batch or cfg['batch']
 
     torch.manual_seed(0)                                     # identical initial weights on every rank
@@ -568,14 +566,16 @@ def main():
         y_cpu = y_cpu.reshape((B, ) + cfg['dims'])
     y = y_cpu.to(dev)                                        # resident in HBM before the timed region
 
-    for _ in range(max(args.warmup, 4)):                     # >= 4 so that graph capture happens before timing
+    z1, loss1 = trainer.train_on_batch(y)                    # step 1 (the parity object below compares THIS step with the CPU)
+    z1, loss1 = z1.detach().cpu().clone(), float(loss1)
+    for _ in range(max(warmup, 4) - 1):                      # >= 4 so that graph capture happens before timing
         trainer.train_on_batch(y)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         z, loss = trainer.train_on_batch(y)
     torch.cuda.synchronize()
     if world > 1:
@@ -605,36 +605,91 @@ def main():
 
     timeouts = pkg._native.persistent_timeouts()
     assert timeouts == 0, 'persistent kernels timed out %d times: the GPU was shared, results invalid' % timeouts
+    if rank != 0:
+        return None
+    out = {
+        'metric': 'samples/sec (train step: forward flow + log-det + NLL + backward + Adam)',
+        'value': round(B * world * steps / elapsed, 1),
+        'unit': 'samples/s',
+        'n_gpus': world,
+        'steps': steps,
+        'warmup': warmup,
+        'ms_per_step': round(1e3 * elapsed / steps, 4),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic (seeded %s restatement, random-init weights)' % cfg['data'],
+        'config': {'workload': cfg['desc'], 'name': name, 'per_gpu_batch': B, 'global_batch': B * world,
+                   'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None},
+        'loss_nats': round(loss_val, 5),
+        'bits_per_dim': round(nftrain.bits_per_dim(loss_val, cfg['dims']), 5),
+        'forward_samples_per_s': round(B * world / (fwd_ms * 1e-3), 1),
+        'inverse_samples_per_s': round(B * world / (inv_ms * 1e-3), 1),
+        'grad_bucket_bytes': trainer.bucket.nbytes(),
+        'roofline': dominant_kernel_roofline(pkg, cfg, B, dev),
+    }
+    if cfg['datatype'] == 'image':
+        out['bits_per_dim_plus_log2_255'] = round(out['bits_per_dim'] + math.log2(255.0), 5)
+    if world == 1 and not args.skip_cpu:
+        out['cpu_baseline'], (zc, lc) = cpu_baseline(cfg, state0, y_cpu, cpu_seconds)
+        D = float(np.prod(cfg['dims']))
+        # the SAME first train step from the SAME initial weights and batch on both sides (forward incl. the data-dependent
+        # ActNorm initialisation); the full-size parity tests (tests/test_gpu_fullsize_parity.py) bound these differences by the
+        # distance of the fp32 CPU path from float64 arithmetic
+        out['parity'] = {'loss_gpu_step1': round(loss1, 6), 'loss_cpu_step1': round(lc, 6),
+                         'abs_dloss_per_dim': float('%.3e' % (abs(loss1 - lc) / D)),
+                         'max_abs_dz': float('%.3e' % float((z1 - zc).abs().max())),
+                         'max_abs_z': float('%.3e' % float(zc.abs().max())),
+                         'note': 'step 1 from identical initial weights and batch: GPU trainer vs the oracle on the host cores'}
+    else:
+        out['cpu_baseline'] = None
+    del trainer, net
+    torch.cuda.empty_cache()
+    return out
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torchrun: re-exec under torch.distributed.run with N ranks on this node."""
+    import socket
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus:
+        raise SystemExit('bench.py --gpus %d: this node exposes %d GPU(s); the bench measures the MI355X path only '
+                         '(no CPU / gloo stand-in is timed)' % (args.gpus, n_dev))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execve(sys.executable, cmd, env)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_spawn(args)                                     # does not return
+    pkg = importlib.import_module(PKG)
+    pkg._native.load()
+    nfdist = importlib.import_module(PKG + '.dist')
+    rank, world, local_rank = nfdist.init_from_env()
+    if args.gpus != world:
+        raise SystemExit('--gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
+    assert torch.cuda.is_available(), 'bench.py measures the MI355X path; no GPU visible'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if os.environ.get('NF_MIOPEN_FIND', '0') == '1':
+        torch.backends.cudnn.benchmark = True                # MIOpen find mode for the image conditioner's convolutions
+    # BASELINE.json quotes the metric on RealNVP moons-2D (c1) and Glow CIFAR-10 (c4): the default run measures both -- the
+    # line's top level is c4 (the larger one), c1 rides along as a second object of the same shape under "also"
+    primary = args.config or 'c4'
+    out = run_workload(primary, args, pkg, rank, world, dev, args.steps, args.warmup, args.cpu_seconds)
+    if args.config is None and args.batch is None:
+        also = run_workload('c1', args, pkg, rank, world, dev, max(args.steps, 50), args.warmup, min(args.cpu_seconds, 6.0))
+        if rank == 0:
+            out['also'] = {'c1': also}
     if rank == 0:
-        roof = dominant_kernel_roofline(pkg, cfg, B, dev)
-        out = {
-            'metric': 'samples/sec (train step: forward flow + log-det + NLL + backward + Adam)',
-            'value': round(B * world * args.steps / elapsed, 1),
-            'unit': 'samples/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f32',
-            'data': 'synthetic (seeded %s restatement, random-init weights)' % cfg['data'],
-            'config': {'workload': cfg['desc'], 'name': args.config, 'per_gpu_batch': B, 'global_batch': B * world,
-                       'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph},
-            'loss_nats': round(loss_val, 5),
-            'bits_per_dim': round(nftrain.bits_per_dim(loss_val, cfg['dims']), 5),
-            'forward_samples_per_s': round(B * world / (fwd_ms * 1e-3), 1),
-            'inverse_samples_per_s': round(B * world / (inv_ms * 1e-3), 1),
-            'grad_bucket_bytes': trainer.bucket.nbytes(),
-            'roofline': roof,
-        }
-        if cfg['datatype'] == 'image':
-            out['bits_per_dim_plus_log2_255'] = round(out['bits_per_dim'] + math.log2(255.0), 5)
-        if world == 1 and not args.skip_cpu:
-            out['cpu_baseline'] = cpu_baseline(cfg, state0, y_cpu, args.cpu_seconds)
-        else:
-            out['cpu_baseline'] = None
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

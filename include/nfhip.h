@@ -203,6 +203,20 @@ int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, 
                            float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
                            int C, int H, int W, nf_stream_t stream);
 
+/* ---- standalone MixLogCDF  modules.py:186-212 (module surface forward / backward(x, log_pi, mu, s, log_df_dz)) -----
+ * x, out (B, n); log_pi, mu, s (B, K, n) with n = the non-batch extent of x and log_pi already normalised over K
+ * (coupling.py:180).  fwd: out = exp(logsumexp_k(log_pi + logsigmoid(u_k))), ld[b] += sum_e logsumexp_k(log_pi + logpdf_k).
+ * inv: the bisection of modules.py:196-212 (bracket +-1e3, 25 iterations, 75 more iff some |hi-lo| >= 1e-4 after 25 -- the
+ * reference's batch-global rule, device flag `stuck_flag` int32[1]), x = mid, ld[b] -= sum_e log pdf(x).  scratch: 2*B*n
+ * floats.  bwd: analytic gradients with respect to x, log_pi, mu and s.  K <= 32.               */
+int nf_mixlogcdf_fwd(const float* x, const float* log_pi, const float* mu, const float* s, float* out, float* ld, int K,
+                     int64_t B, int64_t n, nf_stream_t stream);
+int nf_mixlogcdf_bwd(const float* g_out, const float* g_ld, const float* x, const float* log_pi, const float* mu,
+                     const float* s, float* g_x, float* g_log_pi, float* g_mu, float* g_s, int K, int64_t B, int64_t n,
+                     nf_stream_t stream);
+int nf_mixlogcdf_inv(const float* target, const float* log_pi, const float* mu, const float* s, float* x, float* ld,
+                     float* scratch, int* stuck_flag, int K, int64_t B, int64_t n, nf_stream_t stream);
+
 /* ---- Flow++ density step pair: the coupling above on two features (NF_SPLIT_1D, D = 2, K <= 8), followed by the NEXT flow
  * step's ActNorm (flows/flowpp.py:60-66 alternates ActNorm and coupling; flows/modules.py:246-249) in the same pass:
  *     h = (y - next_bias) / exp(next_log_scale),   ld += coupling log-det - sum_c next_log_scale[c]
@@ -705,6 +719,17 @@ int nf_realnvp_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const
  * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some
  * launch produced garbage (device shared with another job?).  Synchronises the device.                                    */
 int nf_persistent_timeouts(int* count);
+
+/* Makes that failure LOUD.  Sets the poll budget of every spin loop (default 2^22; tests lower it to provoke a failure),
+ * optionally clears the counters (reset != 0; synchronises), and returns the address of ONE pinned host word that a loop
+ * which gives up sets to 1 with system scope: the host can look at it after every launch without synchronising
+ * (_native.call and FlowTrainer.train_on_batch raise when it is non-zero).                                                */
+int nf_persistent_config(int64_t spin_limit, int reset, void** host_error_word);
+
+/* Launch-time residency check: how many workgroups of the largest persistent kernel of the MLP-chain family / the MAF-step
+ * family the current device holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units).  The host side
+ * keeps grids within it (min with NF_MLP_MAX_BLOCKS / NF_MAF_MAX_BLOCKS), else it takes the multi-launch path.           */
+int nf_persistent_capacity(int* mlp_blocks, int* maf_blocks);
 
 /* ---- Flow++ conditioner for density data, whole network in one launch  coupling.py:142-149, modules.py:500-578 ---------
  * out = Linear5(LN2(GatedAttn1(LN1(GatedLinear(Linear0(x))))))  for x (N, I0 <= 4), hidden width 32, O <= 64 outputs;

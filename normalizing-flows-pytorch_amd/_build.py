@@ -65,6 +65,11 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link of libnfhip.so failed:\n' + r.stderr)
+    # the C header is the single source of the ctypes prototypes and constants: keep a copy next to the library, so that the
+    # package directory alone (without the repository's include/) is loadable
+    src = os.path.join(HERE, '..', 'include', 'nfhip.h')
+    if os.path.exists(src):
+        shutil.copyfile(src, os.path.join(HERE, 'nfhip.h'))
     return LIB
 
 

@@ -5,6 +5,7 @@ There is NO fallback: if the library is missing or a tensor is not on the GPU, t
 only for device memory and the current HIP stream; the library itself links nothing of torch.
 """
 import ctypes
+import functools
 import os
 import re
 
@@ -13,6 +14,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libnfhip.so')
 HEADER = os.path.join(HERE, '..', 'include', 'nfhip.h')
+if not os.path.exists(HEADER):
+    HEADER = os.path.join(HERE, 'nfhip.h')               # the copy _build.build() leaves next to the library
 
 # enum mirrors of include/nfhip.h
 SPLIT_1D, SPLIT_CHECKER, SPLIT_CHANNEL, SPLIT_NONE = 0, 1, 2, 3
@@ -52,12 +55,25 @@ def header_prototypes(path=HEADER):
     return protos
 
 
+@functools.lru_cache(maxsize=None)
+def _header_constants():
+    """every ``#define NAME <integer expression>`` of include/nfhip.h (integer literals, + * and parentheses only), parsed ONCE:
+    the fused Functions ask for these on every call (a regex scan of the 40 KB header cost ~250 us each time)."""
+    out = {}
+    for m in re.finditer(r'^#define\s+(\w+)\s+([0-9\s\*\+\(\)]+?)\s*(/\*.*)?$', open(HEADER).read(), re.M):
+        try:
+            out[m.group(1)] = int(eval(m.group(2), {'__builtins__': {}}, {}))   # the character class admits arithmetic only
+        except SyntaxError:
+            pass
+    return out
+
+
 def header_constant(name):
-    """integer value of a ``#define NAME <expr>`` in include/nfhip.h (integer literals, + * and parentheses only)."""
-    m = re.search(r'^#define\s+%s\s+([0-9\s\*\+\(\)]+?)\s*(/\*.*)?$' % re.escape(name), open(HEADER).read(), re.M)
-    if m is None:
+    """integer value of a ``#define NAME <expr>`` in include/nfhip.h."""
+    try:
+        return _header_constants()[name]
+    except KeyError:
         raise NativeLibraryError('include/nfhip.h does not define %s as an integer expression' % name)
-    return int(eval(m.group(1), {'__builtins__': {}}, {}))       # the character class above admits arithmetic only
 
 
 def load():
@@ -76,6 +92,8 @@ def load():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         _lib = lib
+        if torch.cuda.is_available():
+            _error_word()                 # arm the sticky error word of the persistent kernels
     return _lib
 
 
@@ -101,15 +119,84 @@ def ptr(t):
     return t.data_ptr()
 
 
+class PersistentKernelTimeout(NativeLibraryError):
+    """a software grid exchange of a persistent kernel gave up waiting: some launch since the last reset produced garbage
+    (its workgroups were not co-resident: GPU shared with another job, CU mask, work on another stream)."""
+
+
+_err_word = None      # ctypes view of the pinned host word the kernels set when a spin loop gives up (nf_persistent_config)
+
+
+def _error_word():
+    global _err_word
+    if _err_word is None:
+        if not torch.cuda.is_available():
+            return None
+        p = ctypes.c_void_p()
+        rc = load().nf_persistent_config(int(os.environ.get('NF_SPIN_LIMIT', 1 << 22)), 0, ctypes.byref(p))
+        if rc != 0:
+            raise NativeLibraryError('nf_persistent_config failed with code %d' % rc)
+        _err_word = ctypes.c_uint.from_address(p.value)
+    return _err_word
+
+
+def check_persistent():
+    """raise if any persistent kernel launched so far gave up on a grid exchange (no device synchronisation: the word is
+    pinned host memory, so a failure surfaces at the first check after the kernel hit it)."""
+    w = _error_word()
+    if w is not None and w.value != 0:
+        raise PersistentKernelTimeout(
+            'a persistent kernel timed out in a grid-wide exchange (%d spin loops gave up): its workgroups were not co-resident, '
+            'the results since are invalid.  Is the GPU shared or CU-masked?  NF_GLOW_FLOW=0 NF_MAF_FLOW=0 select the '
+            'multi-launch paths; _native.persistent_reset() clears the flag' % persistent_timeouts())
+
+
+def persistent_reset(spin_limit=None):
+    """clear the counters and the error word (synchronises); optionally set the poll budget of the spin loops."""
+    global _err_word
+    p = ctypes.c_void_p()
+    lim = int(spin_limit) if spin_limit is not None else int(os.environ.get('NF_SPIN_LIMIT', 1 << 22))
+    rc = load().nf_persistent_config(lim, 1, ctypes.byref(p))
+    if rc != 0:
+        raise NativeLibraryError('nf_persistent_config failed with code %d' % rc)
+    _err_word = ctypes.c_uint.from_address(p.value)
+
+
+@functools.lru_cache(maxsize=None)
+def persistent_capacity():
+    """(mlp_blocks, maf_blocks): workgroups of the persistent kernel families the device holds at once (occupancy x CUs)."""
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    rc = load().nf_persistent_capacity(ctypes.byref(a), ctypes.byref(b))
+    if rc != 0:
+        raise NativeLibraryError('nf_persistent_capacity failed with code %d' % rc)
+    return int(a.value), int(b.value)
+
+
+def mlp_max_rows():
+    """largest batch the MLP-chain family of persistent kernels takes: the header's cap, lowered to what is co-resident"""
+    return min(header_constant('NF_MLP_MAX_ROWS'),
+               min(header_constant('NF_MLP_MAX_BLOCKS'), persistent_capacity()[0]) * header_constant('NF_MLP_ROWS_PER_BLOCK'))
+
+
+def maf_max_rows():
+    return min(header_constant('NF_MAF_MAX_ROWS'),
+               min(header_constant('NF_MAF_MAX_BLOCKS'), persistent_capacity()[1]) * header_constant('NF_MAF_ROWS_PER_BLOCK'))
+
+
 def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise NativeLibraryError('%s failed with code %d' % (name, rc))
+    w = _err_word
+    if w is not None and w.value != 0:
+        check_persistent()
 
 
 def persistent_timeouts():
-    """spin loops of the persistent kernels that gave up since load (must be 0); synchronises the device."""
+    """spin loops of the persistent kernels that gave up since load / the last reset (must be 0); synchronises the device."""
     import ctypes as _c
     v = _c.c_int(0)
-    call('nf_persistent_timeouts', _c.byref(v))
+    rc = load().nf_persistent_timeouts(_c.byref(v))
+    if rc != 0:
+        raise NativeLibraryError('nf_persistent_timeouts failed with code %d' % rc)
     return int(v.value)

@@ -21,7 +21,7 @@
 #define NF_MD_XW 128                                      // exchange width: 2 nets x (32 sums + 32 square sums)
 static_assert(NF_MD_THREADS == 512 && NF_MD_WAVES % 4 == 0, "geometry");
 
-__device__ unsigned nf_md_timeouts;
+NF_PERSIST_STATE(nf_md)
 
 struct NfMadeP {                                          // [net][layer]
     const float* w[2][NF_MD_NL]; const float* m[2][NF_MD_NL]; const float* b[2][NF_MD_NL];
@@ -129,7 +129,7 @@ __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long l
 #pragma unroll
                 for (int k = 0; k < NF_MD_GRP / 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
                 if (ok) break;
-                if (++spins > (1u << 22)) { atomicAdd(&nf_md_timeouts, 1u); break; }
+                if (++spins > nf_md_spin_limit) { NF_PERSIST_GIVE_UP(nf_md); break; }
                 __builtin_amdgcn_s_sleep(1);
             } while (true);
             float a1 = 0.f;
@@ -159,7 +159,7 @@ __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long l
 #pragma unroll
             for (int k = 0; k < NF_MD_MAX_GROUPS / 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
             if (ok) break;
-            if (++spins > (1u << 22)) { atomicAdd(&nf_md_timeouts, 1u); break; }
+            if (++spins > nf_md_spin_limit) { NF_PERSIST_GIVE_UP(nf_md); break; }
             __builtin_amdgcn_s_sleep(1);
         } while (true);
         float a2 = 0.f;
@@ -189,7 +189,7 @@ __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long l
 #pragma unroll
             for (int k = 0; k < NF_MD_POLL; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
             if (ok) break;
-            if (++spins > (1u << 22)) { atomicAdd(&nf_md_timeouts, 1u); break; }      // bounded: a mistake cannot hang the box
+            if (++spins > nf_md_spin_limit) { NF_PERSIST_GIVE_UP(nf_md); break; }      // bounded: a mistake cannot hang the box
             __builtin_amdgcn_s_sleep(1);
         } while (true);
 #pragma unroll
@@ -993,6 +993,16 @@ extern "C" int nf_maf_fold_all(const void* const* made_params_all, void* const* 
     return 0;
 }
 
-__attribute__((visibility("hidden"))) int nf_made_timeouts_read(unsigned* v) {
-    return (int)hipMemcpyFromSymbol(v, HIP_SYMBOL(nf_md_timeouts), sizeof(unsigned));
+NF_PERSIST_HOST_API(nf_md)
+
+__attribute__((visibility("hidden"))) int nf_md_persist_capacity(int* blocks) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t lds = nf_md_lds_bytes(5);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_maf_step_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_maf_step_bwd, NF_MD_THREADS, lds);
+    if (e != hipSuccess) return (int)e;
+    *blocks = per_cu * cus;
+    return 0;
 }

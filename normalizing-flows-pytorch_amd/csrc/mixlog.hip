@@ -711,3 +711,154 @@ extern "C" int nf_flowpp_vec_couple_bwd(const float* g_h, const float* g_ld, con
     NF_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Standalone MixLogCDF (flows/modules.py:186-212): x (B, n), log_pi / mu / s (B, K, n) with log_pi ALREADY normalised by the
+// caller (coupling.py:180) -- the module surface `forward / backward(x, log_pi, mu, s, log_df_dz)` of SURVEY.md section 8(b).
+// One thread per element, the 3K parameters of the element in registers; per-sample log-det by one atomic per element
+// (n == 1: a plain add).  The bisection compares exp(logsumexp(log pi + logsigmoid)) -- the reference's own expression
+// (modules.py:201) -- with the target, so that the batch-global 25-or-100 rule sees the same kind of `val == x` ties.
+template <int KT>
+__device__ __forceinline__ void nf_cdf_load(const float* __restrict__ lp, const float* __restrict__ mu, const float* __restrict__ s,
+                                            int64_t n, int K, NfMix<KT>& m) {
+    m.a_raw = 0.f;
+    m.b = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        m.lp[k] = k < K ? lp[k * n] : -INFINITY;
+        m.mu[k] = k < K ? mu[k * n] : 0.f;
+        m.s[k] = k < K ? s[k * n] : 0.f;
+        m.es[k] = expf(-m.s[k]);
+    }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_fwd(const float* __restrict__ x, const float* __restrict__ lp, const float* __restrict__ mu,
+                                                            const float* __restrict__ s, float* __restrict__ out, float* __restrict__ ld,
+                                                            int64_t n, int K, int64_t total) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / n, e = t - b * n, p = b * K * n + e;
+        NfMix<KT> m;
+        nf_cdf_load<KT>(lp + p, mu + p, s + p, n, K, m);
+        float lcdf, lpdf;
+        nf_mix_eval<KT>(m, x[t], lcdf, lpdf);
+        out[t] = expf(lcdf);                                                                        // modules.py:193-194
+        if (n == 1) ld[b] += lpdf;
+        else atomicAdd(ld + b, lpdf);
+    }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_bwd(const float* __restrict__ g_out, const float* __restrict__ g_ld, const float* __restrict__ x,
+                                                            const float* __restrict__ lp, const float* __restrict__ mu, const float* __restrict__ s,
+                                                            float* __restrict__ g_x, float* __restrict__ g_lp, float* __restrict__ g_mu,
+                                                            float* __restrict__ g_s, int64_t n, int K, int64_t total) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / n, e = t - b * n, p = b * K * n + e;
+        NfMix<KT> m;
+        nf_cdf_load<KT>(lp + p, mu + p, s + p, n, K, m);
+        const float xv = x[t], gF = g_out[t], gl = g_ld[b];
+        float lcdf, lpdf;
+        nf_mix_eval<KT>(m, xv, lcdf, lpdf);
+        const float f = expf(lpdf);
+        float gx = gF * f;                                       // appendix B6, responsibilities form r_k = pi_k pdf_k / f
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            if (k < K) {
+                const float u = (xv - m.mu[k]) * m.es[k];
+                const float l = log1pf(expf(-fabsf(u)));
+                const float r = expf(m.lp[k] + (u - m.s[k] - 2.f * (fmaxf(u, 0.f) + l)) - lpdf);
+                const float omt = -tanhf(0.5f * u);              // 1 - 2 sigmoid(u)
+                const float w = gl * r * omt * m.es[k];
+                gx += w;
+                g_mu[p + k * n] = -gF * f * r - w;
+                g_s[p + k * n] = -gF * f * r * (xv - m.mu[k]) + gl * r * (-omt * u - 1.f);
+                g_lp[p + k * n] = gF * expf(m.lp[k] + (fminf(u, 0.f) - l)) + gl * r;
+            }
+        }
+        g_x[t] = gx;
+    }
+}
+
+template <int KT, int PHASE>
+__global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_inv(const float* __restrict__ target, const float* __restrict__ lp, const float* __restrict__ mu,
+                                                            const float* __restrict__ s, float* __restrict__ x, float* __restrict__ ld,
+                                                            float* __restrict__ lohi, int* __restrict__ flag, int64_t n, int K, int64_t total) {
+    const int steps = PHASE == 1 ? 25 : (flag[0] ? 75 : 0);
+    bool stuck = false;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / n, e = t - b * n, p = b * K * n + e;
+        NfMix<KT> m;
+        nf_cdf_load<KT>(lp + p, mu + p, s + p, n, K, m);
+        const float tg = target[t];
+        float lo = PHASE == 1 ? -1.0e3f : lohi[t];                                                  // modules.py:197-198
+        float hi = PHASE == 1 ? 1.0e3f : lohi[total + t];
+        for (int it = 0; it < steps; ++it) {
+            const float mid = (lo + hi) * 0.5f;
+            float lcdf, lpdf;
+            nf_mix_eval<KT>(m, mid, lcdf, lpdf);
+            const float val = expf(lcdf);                                                           // modules.py:201
+            if (PHASE == 2 && (mid == lo || mid == hi || val == tg)) break;                         // collapsed: the rest are no-ops
+            lo = val < tg ? mid : lo;                                                               // modules.py:202-203
+            hi = val > tg ? mid : hi;
+        }
+        if (PHASE == 1) {
+            lohi[t] = lo;
+            lohi[total + t] = hi;
+            stuck |= !(fabsf(hi - lo) < 1.0e-4f);                                                   // modules.py:205
+        } else {
+            const float xv = (lo + hi) * 0.5f;                                                      // modules.py:208
+            float lcdf, lpdf;
+            nf_mix_eval<KT>(m, xv, lcdf, lpdf);
+            x[t] = xv;
+            if (n == 1) ld[b] -= lpdf;                                                              // modules.py:209-212
+            else atomicAdd(ld + b, -lpdf);
+        }
+    }
+    if (PHASE == 1 && __any(stuck) && (threadIdx.x & (NF_WAVE - 1)) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int nf_mixlogcdf_fwd(const float* x, const float* log_pi, const float* mu, const float* s, float* out, float* ld, int K,
+                                int64_t B, int64_t n, nf_stream_t stream) {
+    if (K < 1 || K > 32 || B < 0 || n < 0) return NF_E_BADARG;
+    const int64_t total = B * n;
+    if (total == 0) return 0;
+    const unsigned g = nf_grid_for(total, NF_BLOCK);
+#define CALL(KT) hipLaunchKernelGGL(k_mixlogcdf_fwd<KT>, dim3(g), dim3(NF_BLOCK), 0, (hipStream_t)stream, x, log_pi, mu, s, out, ld, n, K, total)
+    NF_MX_DISPATCH(K, CALL);
+#undef CALL
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_mixlogcdf_bwd(const float* g_out, const float* g_ld, const float* x, const float* log_pi, const float* mu,
+                                const float* s, float* g_x, float* g_log_pi, float* g_mu, float* g_s, int K, int64_t B, int64_t n,
+                                nf_stream_t stream) {
+    if (K < 1 || K > 32 || B < 0 || n < 0) return NF_E_BADARG;
+    const int64_t total = B * n;
+    if (total == 0) return 0;
+    const unsigned g = nf_grid_for(total, NF_BLOCK);
+#define CALL(KT) hipLaunchKernelGGL(k_mixlogcdf_bwd<KT>, dim3(g), dim3(NF_BLOCK), 0, (hipStream_t)stream, g_out, g_ld, x, log_pi, mu, s, g_x, g_log_pi, g_mu, g_s, n, K, total)
+    NF_MX_DISPATCH(K, CALL);
+#undef CALL
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_mixlogcdf_inv(const float* target, const float* log_pi, const float* mu, const float* s, float* x, float* ld,
+                                float* scratch, int* stuck_flag, int K, int64_t B, int64_t n, nf_stream_t stream) {
+    if (K < 1 || K > 32 || B < 0 || n < 0) return NF_E_BADARG;
+    const int64_t total = B * n;
+    if (total == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stuck_flag, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    const unsigned g = nf_grid_for(total, NF_BLOCK);
+#define CALL(KT)                                                                                                                     \
+    hipLaunchKernelGGL((k_mixlogcdf_inv<KT, 1>), dim3(g), dim3(NF_BLOCK), 0, st, target, log_pi, mu, s, x, ld, scratch, stuck_flag, n, K, total); \
+    hipLaunchKernelGGL((k_mixlogcdf_inv<KT, 2>), dim3(g), dim3(NF_BLOCK), 0, st, target, log_pi, mu, s, x, ld, scratch, stuck_flag, n, K, total)
+    NF_MX_DISPATCH(K, CALL);
+#undef CALL
+    NF_CHECK_LAUNCH();
+    return 0;
+}

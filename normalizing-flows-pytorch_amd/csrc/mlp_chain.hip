@@ -20,7 +20,7 @@
 #define NF_MC_PROF 0      // 1 (tools/probes/mlp_chain_prof.py builds that variant): time stamps of workgroup 0 at phase boundaries
 #endif
 __device__ long long nf_mc_prof_buf[128];
-__device__ unsigned nf_mc_timeouts;                       // spin loops that gave up (a grid that was not co-resident): must stay 0
+NF_PERSIST_STATE(nf_mc)                                   // spin loops that gave up (a grid that was not co-resident): must stay 0
 #define NF_MC_T(i)                                                                          \
     do {                                                                                    \
         if (NF_MC_PROF && blockIdx.x == 0 && threadIdx.x == 0) nf_mc_prof_buf[i] = wall_clock64(); \
@@ -118,7 +118,7 @@ __device__ __forceinline__ void nf_grid_barrier(unsigned* counter, unsigned targ
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22)) { atomicAdd(&nf_mc_timeouts, 1u); break; }
+            if (++spins > nf_mc_spin_limit) { NF_PERSIST_GIVE_UP(nf_mc); break; }
         }
         __threadfence();
     }
@@ -175,7 +175,7 @@ __device__ __forceinline__ const float* nf_mc_collect(float* sm, int gather, uns
 #pragma unroll
             for (int k = 0; k < 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
             if (ok) break;
-            if (++spins > (1u << 22)) { atomicAdd(&nf_mc_timeouts, 1u); break; }   // bounded: a mistake cannot hang the box
+            if (++spins > nf_mc_spin_limit) { NF_PERSIST_GIVE_UP(nf_mc); break; }   // bounded: a mistake cannot hang the box
             __builtin_amdgcn_s_sleep(1);
         } while (true);
 #pragma unroll
@@ -1896,15 +1896,62 @@ extern "C" int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const f
     return 0;
 }
 
-__attribute__((visibility("hidden"))) int nf_made_timeouts_read(unsigned* v);      // made_chain.hip
+NF_PERSIST_HOST_API(nf_mc)
+__attribute__((visibility("hidden"))) int nf_md_persist_read(unsigned* v);                                 // made_chain.hip
+__attribute__((visibility("hidden"))) int nf_md_persist_set(unsigned limit, unsigned* flag_dev, int reset);
 
 extern "C" int nf_persistent_timeouts(int* count) {
     if (count == nullptr) return NF_E_BADARG;
     unsigned v = 0, v2 = 0;
-    hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(nf_mc_timeouts), sizeof(v));
-    if (e != hipSuccess) return (int)e;
-    const int e2 = nf_made_timeouts_read(&v2);
-    if (e2 != 0) return e2;
+    int e = nf_mc_persist_read(&v);
+    if (e == 0) e = nf_md_persist_read(&v2);
+    if (e != 0) return e;
     *count = (int)(v + v2);
     return 0;
+}
+
+static unsigned* g_persist_host_word = nullptr;          // pinned + mapped; the kernels' sticky error word
+static unsigned* g_persist_dev_word = nullptr;
+
+extern "C" int nf_persistent_config(int64_t spin_limit, int reset, void** host_error_word) {
+    if (spin_limit < 0 || spin_limit > 0xffffffffLL) return NF_E_BADARG;
+    if (g_persist_host_word == nullptr) {
+        void* hp = nullptr;
+        hipError_t e = hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable);
+        if (e != hipSuccess) return (int)e;
+        void* dp = nullptr;
+        e = hipHostGetDevicePointer(&dp, hp, 0);
+        if (e != hipSuccess) return (int)e;
+        g_persist_host_word = (unsigned*)hp;
+        g_persist_dev_word = (unsigned*)dp;
+        *(volatile unsigned*)g_persist_host_word = 0u;
+    }
+    if (reset) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return (int)e;
+        *(volatile unsigned*)g_persist_host_word = 0u;
+    }
+    const unsigned lim = (unsigned)spin_limit;
+    int e = nf_mc_persist_set(lim, g_persist_dev_word, reset);
+    if (e == 0) e = nf_md_persist_set(lim, g_persist_dev_word, reset);
+    if (e != 0) return e;
+    if (host_error_word != nullptr) *host_error_word = (void*)g_persist_host_word;
+    return 0;
+}
+
+__attribute__((visibility("hidden"))) int nf_md_persist_capacity(int* blocks);                            // made_chain.hip
+
+// co-resident workgroups of the largest persistent kernel of each family on the current device: occupancy x compute units.
+// A grid above that would wait on workgroups that cannot start: the host side then takes the multi-launch path instead.
+extern "C" int nf_persistent_capacity(int* mlp_blocks, int* maf_blocks) {
+    if (mlp_blocks == nullptr || maf_blocks == nullptr) return NF_E_BADARG;
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t lds = nf_mc_lds_bytes(3) + 2 * NF_GF_REC_WORDS * 8;
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_glow_flow_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_glow_flow_bwd<1>, NF_MC_THREADS, lds);
+    if (e != hipSuccess) return (int)e;
+    *mlp_blocks = per_cu * cus;
+    return nf_md_persist_capacity(maf_blocks);
 }

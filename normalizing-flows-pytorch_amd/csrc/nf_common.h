@@ -135,3 +135,33 @@ __device__ __forceinline__ float nf_softplus(float x) {  // F.softplus: beta 1, 
 __device__ __forceinline__ float nf_logsigmoid(float x) {  // min(x,0) - log1p(exp(-|x|))
     return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
 }
+
+// ---- persistent kernels: bounded spin loops with a LOUD failure ---------------------------------------------------------------------
+// Every translation unit with software grid exchanges declares its own state (device globals are per TU without -fgpu-rdc):
+//   <p>_timeouts    count of spin loops that gave up
+//   <p>_spin_limit  poll budget of one spin loop (default 2^22 polls ~ seconds; nf_persistent_config lowers it for the tests)
+//   <p>_host_flag   device pointer of ONE pinned, host-mapped word shared by all TUs: a loop that gives up stores 1 there with
+//                   system scope, so the host sees the failure WITHOUT synchronising (checked by _native.call / FlowTrainer)
+#define NF_PERSIST_STATE(p)                              \
+    __device__ unsigned p##_timeouts;                    \
+    __device__ unsigned p##_spin_limit = (1u << 22);     \
+    __device__ unsigned* p##_host_flag;
+#define NF_PERSIST_GIVE_UP(p)                                                                         \
+    do {                                                                                              \
+        atomicAdd(&p##_timeouts, 1u);                                                                 \
+        unsigned* hf_ = p##_host_flag;                                                                \
+        if (hf_) __hip_atomic_store(hf_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);            \
+    } while (0)
+#define NF_PERSIST_HOST_API(p)                                                                        \
+    __attribute__((visibility("hidden"))) int p##_persist_read(unsigned* v) {                         \
+        return (int)hipMemcpyFromSymbol(v, HIP_SYMBOL(p##_timeouts), sizeof(unsigned));               \
+    }                                                                                                 \
+    __attribute__((visibility("hidden"))) int p##_persist_set(unsigned limit, unsigned* flag_dev, int reset) { \
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(p##_spin_limit), &limit, sizeof(unsigned));       \
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(p##_host_flag), &flag_dev, sizeof(unsigned*)); \
+        if (e == hipSuccess && reset) {                                                               \
+            const unsigned zero = 0;                                                                  \
+            e = hipMemcpyToSymbol(HIP_SYMBOL(p##_timeouts), &zero, sizeof(unsigned));                 \
+        }                                                                                             \
+        return (int)e;                                                                                \
+    }

@@ -646,6 +646,58 @@ def mixlog_coupling(z, params, a_log_scale, a_bias, ld, n_mixtures, mode, odd, i
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# standalone MixLogCDF (flows/modules.py:186-212)
+# ----------------------------------------------------------------------------------------------------------------------
+def _mixcdf_shapes(x, log_pi):
+    B = x.shape[0]
+    n = x.numel() // B if B else 0
+    if log_pi.dim() != x.dim() + 1 or log_pi.shape[0] != B or tuple(log_pi.shape[2:]) != tuple(x.shape[1:]):
+        raise ValueError('MixLogCDF: x %s needs log_pi / mu / s of shape (B, K) + x.shape[1:], got %s'
+                         % (tuple(x.shape), tuple(log_pi.shape)))
+    return B, n, log_pi.shape[1]
+
+
+class _MixLogCDF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, log_pi, mu, s, ld):
+        B, n, K = _mixcdf_shapes(x, log_pi)
+        out = torch.empty_like(x)
+        N.call('nf_mixlogcdf_fwd', N.ptr(x), N.ptr(log_pi), N.ptr(mu), N.ptr(s), N.ptr(out), N.ptr(ld), K, B, n, N.stream())
+        ctx.save_for_backward(x, log_pi, mu, s)
+        ctx.mark_dirty(ld)
+        return out, ld
+
+    @staticmethod
+    def backward(ctx, g_out, g_ld):
+        x, log_pi, mu, s = ctx.saved_tensors
+        B, n, K = _mixcdf_shapes(x, log_pi)
+        g_out, g_ld = _contig(g_out), _contig(g_ld)
+        g_x, g_lp, g_mu, g_s = torch.empty_like(x), torch.empty_like(log_pi), torch.empty_like(mu), torch.empty_like(s)
+        N.call('nf_mixlogcdf_bwd', N.ptr(g_out), N.ptr(g_ld), N.ptr(x), N.ptr(log_pi), N.ptr(mu), N.ptr(s), N.ptr(g_x),
+               N.ptr(g_lp), N.ptr(g_mu), N.ptr(g_s), K, B, n, N.stream())
+        return g_x, g_lp, g_mu, g_s, g_ld
+
+
+def mixlogcdf(x, log_pi, mu, s, ld, inverse=False):
+    """MixLogCDF.forward / .backward (flows/modules.py:190-212): ``log_pi`` is already log-softmaxed over the mixture axis.
+    Unlike the in-place transforms, the reference returns a NEW log-det tensor here (modules.py:194): so does this."""
+    x, log_pi, mu, s = _contig(x), _contig(log_pi), _contig(mu), _contig(s)
+    if mu.shape != log_pi.shape or s.shape != log_pi.shape:
+        raise ValueError('MixLogCDF: log_pi, mu and s must have one shape')
+    ld = ld.clone()
+    if not inverse:
+        return _MixLogCDF.apply(x, log_pi, mu, s, ld)
+    with torch.no_grad():
+        B, n, K = _mixcdf_shapes(x, log_pi)
+        out = torch.empty_like(x)
+        scratch = torch.empty(2 * max(x.numel(), 1), dtype=x.dtype, device=x.device)
+        flag = torch.empty(1, dtype=torch.int32, device=x.device)
+        N.call('nf_mixlogcdf_inv', N.ptr(x), N.ptr(log_pi), N.ptr(mu), N.ptr(s), N.ptr(out), N.ptr(ld), N.ptr(scratch),
+               N.ptr(flag), K, B, n, N.stream())
+    return out, ld
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # NLL under the standard-normal prior (training harness, main.py:49-51, :85)
 # ----------------------------------------------------------------------------------------------------------------------
 class _NLL(torch.autograd.Function):

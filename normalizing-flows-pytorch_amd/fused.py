@@ -243,7 +243,7 @@ def _ptr_table(tensors):
 
 def mlp_chain_usable(mlp, x):
     return (len(mlp.mid_block) == 2 and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
-            and 0 < x.shape[0] <= N.header_constant('NF_MLP_MAX_ROWS'))
+            and 0 < x.shape[0] <= N.mlp_max_rows())
 
 
 def mlp_chain_forward_nograd(mlp, x, training):
@@ -625,7 +625,7 @@ def flowpp_cond_forward_nograd(net, x):
 def glow_step_vec_usable(z, mlp):
     """dims = (D,) with D in (2, 4) and a batch the persistent kernels hold (csrc/mlp_chain.hip, GLOW variant)."""
     return (z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and z.shape[1] in (2, 4) and mlp.fused
-            and len(mlp.mid_block) == 2 and 0 < z.shape[0] <= N.header_constant('NF_MLP_MAX_ROWS'))
+            and len(mlp.mid_block) == 2 and 0 < z.shape[0] <= N.mlp_max_rows())
 
 
 class _GlowStepVec(torch.autograd.Function):
@@ -703,6 +703,10 @@ GLOW_FLOW_AUTO_ROWS = 1024
 # step's grid barrier + gradient fold to one launch at the end (nf_glow_flow_steps_*; C2 at B = 2048 / 4096 / 16384:
 # 1.77 -> 1.63 / 1.88 -> 1.71 / 3.02 -> 2.50 ms per train step)
 GLOW_FLOW_STEPS = _os.environ.get('NF_GLOW_FLOW_STEPS', '1') != '0'
+# Device tables of per-step pointer records.  NEVER evicted: a captured hipGraph (FlowTrainer._capture) has the table's address
+# baked into its kernel arguments, and freeing a table would let the allocator recycle the memory under a later replay.  An
+# entry is ~100 pointers per flow step (25 KB for 32 steps), keyed by the addresses it contains -- if a later model lands on the
+# same addresses the stale entry is, by construction, still correct.
 _GLOW_FLOW_TABLES = {}
 _GLOW_FLOW_HOST = {}          # device table pointer -> the host copy of the same records
 _GLOW_FLOW_SLABS = {}
@@ -756,9 +760,6 @@ def _glow_flow_table(steps, sinks, D, device):
         N.call('nf_glow_flow_pack', ctypes.addressof(host) + i * nbytes, ctypes.addressof(htab), ctypes.addressof(mtab), hg, mg,
                D, int(odd))
     table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
-    if len(_GLOW_FLOW_TABLES) > 64:
-        _GLOW_FLOW_TABLES.clear()
-        _GLOW_FLOW_HOST.clear()
     _GLOW_FLOW_TABLES[key] = table
     _GLOW_FLOW_HOST[table.data_ptr()] = host
     return table
@@ -953,9 +954,6 @@ def _realnvp_flow_table(steps, sinks, D, device):
         N.call('nf_realnvp_flow_pack', ctypes.addressof(host) + i * nbytes, ctypes.addressof(htab), ctypes.addressof(mtab),
                N.ptr(sinks[i][0]), N.ptr(sinks[i][1]), ctypes.addressof(mgt), D, int(odd), float(eps), float(mom))
     table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
-    if len(_GLOW_FLOW_TABLES) > 64:
-        _GLOW_FLOW_TABLES.clear()
-        _GLOW_FLOW_HOST.clear()
     _GLOW_FLOW_TABLES[key] = table
     _GLOW_FLOW_HOST[table.data_ptr()] = host
     return table
@@ -1058,7 +1056,7 @@ FBN_RUNNING, FBN_BATCH_BUFFERS = -1.0, -2.0              # include/nfhip.h: NF_F
 def _maf_struct_ok(z, bn, ar):
     return (z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and 1 <= z.shape[1] <= 4 and ar.net_s.num_hidden == 3
             and ar.net_s.base_filters == H and ar.net_t.num_hidden == 3 and bn.training == ar.net_s.training == ar.net_t.training
-            and 0 < z.shape[0] <= N.header_constant('NF_MAF_MAX_ROWS'))
+            and 0 < z.shape[0] <= N.maf_max_rows())
 
 
 def _maf_tables(bn, ar, ms, mt):
@@ -1133,9 +1131,6 @@ def _realnvp_const_table(steps, mode, D, device):
         N.call('nf_realnvp_flow_pack', ctypes.addressof(host) + i * nbytes, ctypes.addressof(htab), ctypes.addressof(mtab), None, None,
                None, D, int(k.odd), float(bn.eps), float(mode))
     table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
-    if len(_GLOW_FLOW_TABLES) > 64:
-        _GLOW_FLOW_TABLES.clear()
-        _GLOW_FLOW_HOST.clear()
     _GLOW_FLOW_TABLES[key] = table
     return table
 
@@ -1342,7 +1337,7 @@ def maf_step_usable(z, bn, ar):
     """training-mode [flow BatchNorm(affine=False), AutoregressiveTransfrom] on (N, D <= 4) data, csrc/made_chain.hip."""
     return (z.is_cuda and z.dim() == 2 and z.dtype == torch.float32 and 1 <= z.shape[1] <= 4 and bn.training
             and ar.net_s.training and ar.net_s.num_hidden == 3 and ar.net_s.base_filters == H and ar.net_t.num_hidden == 3
-            and 1 < z.shape[0] <= N.header_constant('NF_MAF_MAX_ROWS'))
+            and 1 < z.shape[0] <= N.maf_max_rows())
 
 
 _MAF_SLABS = {}

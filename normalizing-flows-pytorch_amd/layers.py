@@ -232,6 +232,15 @@ class Compose(nn.Module):
         return run if run and FUSED.realnvp_eval_usable(z, run) else None
 
     def backward(self, z, log_df_dz):
+        """INVERSE flow (sampling).  The inverse kernels build no autograd graph: asking for gradients
+        THROUGH the inverse (an input that requires grad, e.g. a reverse-KL loss) raises instead of silently returning
+        constants; otherwise the whole pass runs under no_grad, so the conditioners do not record a graph nobody can use."""
+        if torch.is_grad_enabled():
+            if z.requires_grad or log_df_dz.requires_grad:
+                raise NotImplementedError('the inverse flow (net.backward) is not differentiable in this engine: its kernels '
+                                          'build no autograd graph; detach the input or differentiate the forward direction')
+            with torch.no_grad():
+                return self.backward(z, log_df_dz)
         i = len(self.layers) - 1
         while i >= 0:
             run = self._glow_inverse_run_ending_at(i, z)
@@ -266,6 +275,17 @@ class Logit(nn.Module):
 
     def backward(self, x, log_df_dz):
         return NF.logit(x, log_df_dz, self.eps, inverse=True)
+
+
+class MixLogCDF(nn.Module):
+    """flows/modules.py:186-212: CDF of a mixture of logistics as a bijector of x given (log_pi, mu, s); the inverse is the
+    reference's bisection (25 or 100 iterations by its batch-global exit rule).  One HIP launch forward, two inverse."""
+
+    def forward(self, x, log_pi, mu, s, log_df_dz):
+        return NF.mixlogcdf(x, log_pi, mu, s, log_df_dz)
+
+    def backward(self, x, log_pi, mu, s, log_df_dz):
+        return NF.mixlogcdf(x, log_pi, mu, s, log_df_dz, inverse=True)
 
 
 def _param_shape(num_features):

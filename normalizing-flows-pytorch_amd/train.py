@@ -56,6 +56,12 @@ class FlatAdam:
 
     def step(self):
         N, b = self._N, self.bucket
+        # the parameters must still live in the flat buffer (net.to() / .cpu() after construction re-homes p.data silently)
+        p0, p1 = b.params[0], b.params[-1]
+        if (p0.data_ptr() != b.flat_params.data_ptr()
+                or p1.data_ptr() + p1.numel() * 4 != b.flat_params.data_ptr() + b.numel * 4):
+            raise RuntimeError('FlatAdam: the parameters no longer live in the GradBucket\'s flat buffer (was the model moved '
+                               'with .to() / .cpu() after the trainer was built?); build a new FlowTrainer')
         N.call('nf_adam_step', N.ptr(b.flat_params), N.ptr(b.flat), N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq),
                N.ptr(self.step_count), N.ptr(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, 1.0,
                b.numel, N.stream())
@@ -176,7 +182,12 @@ class FlowTrainer:
         self._g_fb, self._g_opt = g_fb, g_opt
 
     def train_on_batch(self, y):
-        """returns (z, loss) like main.py:78-92; with graph=True the returned tensors are the graph's static outputs."""
+        """returns (z, loss) like main.py:78-92; with graph=True the returned tensors are the graph's static outputs.
+        Raises _native.PersistentKernelTimeout as soon as the host sees that a persistent kernel of an EARLIER launch gave up on
+        a grid exchange (sticky pinned error word, no synchronisation: at most one step late)."""
+        from . import _native as N
+        if y.is_cuda:
+            N.check_persistent()
         self.net.train()
         if self.graph and self._g_fb is None and self._eager_steps >= self.warmup:
             try:
@@ -188,6 +199,8 @@ class FlowTrainer:
                 self._g_fb = self._g_opt = None
                 torch.cuda.synchronize()
         if self._g_fb is not None:
+            if not self._replicas_synced:               # warmup=0: no eager step ran before the capture
+                self._sync_replicas_after_first_step()
             self._static_y.copy_(y, non_blocking=True)
             self._g_fb.replay()
             if self._g_opt is not None:
@@ -205,15 +218,13 @@ class FlowTrainer:
     def _sync_replicas_after_first_step(self):
         """The first forward performs the data-dependent ActNorm initialisation (modules.py:238-244) on each replica's OWN
         shard, so the replicas' log_scale / bias differ after step 1.  Data parallelism needs identical replicas:
-        rank 0's parameters win (policy 2).  Running statistics stay per replica."""
+        rank 0's parameters and buffers win (policy 2); afterwards running statistics evolve per replica
+        unless the trainer runs in sync-statistics mode."""
         self._replicas_synced = True
         if self.bucket.world > 1:
-            with torch.no_grad():
-                if self.bucket.flat_params is not None:
-                    torch.distributed.broadcast(self.bucket.flat_params, src=0, group=self.bucket.group)
-                else:
-                    for p in self.bucket.params:
-                        torch.distributed.broadcast(p.data, src=0, group=self.bucket.group)
+            # every parameter AND buffer: the frozen PLU constants (P, pivots, sign_s), MAF's perm and the running statistics
+            # too, so that replicas built from different seeds cannot keep private copies of those
+            nfdist.broadcast_parameters(self.net, src=0, group=self.bucket.group)
 
     # -- evaluation -----------------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -1,5 +1,6 @@
 """
-Size-independent properties at the FULL sizes of the five BASELINE.json configs (the oracle is too slow there):
+Size-independent properties at the FULL sizes of the five BASELINE.json configs (oracle parity at these sizes:
+tests/test_gpu_fullsize_parity.py):
   * round trip      backward(forward(y)) == y        (inverse flow undoes the forward flow)
   * log-det balance ld_forward + ld_inverse == 0
   * linearity of the index maps / determinism: two forward passes give bit-identical results

@@ -344,6 +344,106 @@ def test_mixlog_bisection_stuck_rule(nf):
     assert err100 <= err25 + 1e-6
 
 
+@pytest.mark.parametrize('tag', ['K4_2d', 'K8_2d', 'K4_4d'])
+def test_mixlogcdf_module_golden(nf, tag):
+    """the standalone MixLogCDF module (modules.py:186-212, reference signature) against the reference-captured goldens:
+    forward, autograd (through log_softmax as the reference test harness did), and the HIP bisection in BOTH regimes -- the 25-
+    iteration one and the 100-iteration one (``x_inv100`` / ``ld_inv100``: one element of ``target100`` is exactly the CPU's CDF at
+    the first midpoint, which keeps its bracket open and makes the reference run all 100 steps for the whole batch)."""
+    g = G.group('ops', 'mixlogcdf/%s/' % tag, DEV)
+    layer = nf.MixLogCDF()
+    x = g['x'].clone().requires_grad_(True)
+    raw = g['logpi_raw'].clone().requires_grad_(True)
+    mu, s = g['mu'].clone().requires_grad_(True), g['s'].clone().requires_grad_(True)
+    ld0 = g['ld0'].clone()
+    y, ld = layer(x, torch.log_softmax(raw, dim=1), mu, s, ld0)
+    assert torch.equal(ld0, g['ld0']), 'the reference returns a NEW log-det tensor here (modules.py:194)'
+    G.assert_close(y, g['y'], TOL, what='y')
+    G.assert_close(ld, g['ld'], _ld_tol(g), what='ld')
+    grads = torch.autograd.grad([y, ld], [x, raw, mu, s], [g['gy'], g['gld']])
+    for got, n in zip(grads, ['gx', 'glogpi_raw', 'gmu', 'gs']):
+        G.assert_close(got, g[n], _scaled(g[n]), what=n)
+    logpi = torch.log_softmax(g['logpi_raw'], dim=1)
+    n_per = g['x'][0].numel()
+    # 25-iteration regime: the answer is only defined up to the bracket the reference stops at (2000 * 2^-25 = 6e-5)
+    xi, ldi = layer.backward(g['target'].clone(), logpi, g['mu'], g['s'], g['ld0'].clone())
+    G.assert_close(xi, g['x_inv'], 1e-4, what='x_inv (25-step bracket)')
+    G.assert_close(ldi, g['ld_inv'], 2e-3 * n_per, what='ld_inv')
+    # 100-iteration regime.  Whether the kernel's own `val == target` tie fires depends on the last bit of its CDF at 0.0, so the
+    # planted element may resolve to within the 25-step bracket of the reference's 0.0 instead of exactly 0.0; every other element
+    # of the reference's answer is converged to float precision, and the kernel's must be within the bracket of that.
+    xi, ldi = layer.backward(g['target100'].clone(), logpi, g['mu'], g['s'], g['ld0'].clone())
+    G.assert_close(xi, g['x_inv100'], 1e-4, what='x_inv100')
+    G.assert_close(ldi, g['ld_inv100'], 2e-3 * n_per, what='ld_inv100')
+    # planted with the KERNEL's own CDF value the tie is exact: the bracket of that element never moves (x = 0.0 exactly) and the
+    # whole batch runs 100 steps -- every other element then agrees with the reference's converged answer far below the bracket
+    t_own = g['target100'].clone()
+    first = (0, ) * t_own.dim()
+    zero = torch.zeros_like(g['x'])
+    t_own[first] = layer(zero, logpi, g['mu'], g['s'], g['ld0'].clone())[0][first]
+    xi, _ = layer.backward(t_own, logpi, g['mu'], g['s'], g['ld0'].clone())
+    assert float(xi[first]) == 0.0
+    mask = torch.ones_like(xi, dtype=torch.bool)
+    mask[first] = False
+    assert float((xi - g['x_inv100'])[mask].abs().max()) < 2e-5, 'converged (100-step) answers must agree far below the 25-step bracket'
+
+
+def test_mixlogcdf_module_vs_oracle_large(nf):
+    """B = 65536, K = 8 (C3's mixture shape): forward and gradients against the oracle, round trip through the bisection."""
+    g = torch.Generator().manual_seed(5)
+    B, K = 65536, 8
+    x = torch.randn(B, 1, generator=g)
+    raw, mu, s = (torch.randn(B, K, 1, generator=g) * 0.7 for _ in range(3))
+    ld0 = torch.randn(B, generator=g)
+    gy, gld = torch.randn(B, 1, generator=g), torch.randn(B, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, raw, mu, s)]
+    y, ld = tf.mixlogcdf(leaves[0], ld0, torch.log_softmax(leaves[1], dim=1), leaves[2], leaves[3])
+    want = torch.autograd.grad([y, ld], leaves, [gy, gld])
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (x, raw, mu, s)]
+    layer = nf.MixLogCDF()
+    yd, ldd = layer(dl[0], torch.log_softmax(dl[1], dim=1), dl[2], dl[3], ld0.to(DEV))
+    G.assert_close(yd, y, TOL)
+    G.assert_close(ldd, ld, TOL * max(1.0, float(ld.detach().abs().max())))
+    got = torch.autograd.grad([yd, ldd], dl, [gy.to(DEV), gld.to(DEV)])
+    for gg, ww in zip(got, want):
+        G.assert_close(gg, ww, _scaled(ww), rtol=1e-4)
+    with torch.no_grad():
+        xi, ldi = layer.backward(yd.detach(), torch.log_softmax(dl[1], dim=1), dl[2].detach(), dl[3].detach(), ldd.detach())
+    ok = (yd.detach() > 1e-4) & (yd.detach() < 1 - 1e-4)            # outside, the CDF is flat to fp32 and x is not identifiable
+    assert float((xi - dl[0].detach())[ok].abs().max()) < 2e-4
+    assert float((ldi - ld0.to(DEV))[ok.reshape(-1)].abs().max()) < 5e-3
+
+
+def test_persistent_kernel_timeout_is_loud(nf, pkg):
+    """a grid exchange that gives up must surface as an exception, not as silently wrong numbers: with a poll budget of zero
+    every workgroup of a multi-workgroup persistent launch gives up at once; the sticky host-mapped error word then makes the
+    next native call (and FlowTrainer.train_on_batch) raise."""
+    import importlib
+    from types import SimpleNamespace as NS
+    Nn = pkg._native
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    torch.manual_seed(0)
+    net = pkg.Glow((2, ), '2d', NS(layers=2)).to(DEV)
+    trainer = nftrain.FlowTrainer(net, graph=False)
+    y = torch.randn(4096, 2, device=DEV) * 0.5
+    trainer.train_on_batch(y)                                    # ActNorm init
+    trainer.train_on_batch(y)                                    # fused persistent step kernels, 32 workgroups: fine
+    torch.cuda.synchronize()
+    Nn.check_persistent()
+    assert Nn.persistent_timeouts() == 0
+    try:
+        Nn.persistent_reset(spin_limit=0)                        # every wait that is not satisfied at once gives up
+        with pytest.raises(Nn.PersistentKernelTimeout):
+            for _ in range(3):
+                trainer.train_on_batch(y)
+                torch.cuda.synchronize()
+        assert Nn.persistent_timeouts() > 0
+    finally:
+        Nn.persistent_reset(spin_limit=1 << 22)
+    Nn.check_persistent()
+    assert Nn.persistent_timeouts() == 0
+
+
 # ---- MAF autoregressive transform -------------------------------------------------------------------------------------
 @pytest.mark.parametrize('D', [2, 5])
 def test_ar_transform_golden(nf, D):
