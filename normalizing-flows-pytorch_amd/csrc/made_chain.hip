@@ -205,6 +205,126 @@ __device__ __forceinline__ const float* nf_md_collect(float* sm, unsigned long l
     return tot;
 }
 
+// ---- batch STATISTICS through the exchange (see mlp_chain.hip, nf_mc_publish_stats): no E[x^2] - E[x]^2 anywhere --------------------
+// Feature f = n * 32 + k (net n, f < 64) travels as ONE 64-bit slot {sum : M2 | 1}: the workgroup's sum and its sum of squared
+// deviations about the workgroup's OWN mean (wave tiles merged by the parallel-variance rule).  The workspace is zero at launch
+// and every round has its own slots, so "non-zero" means "published" (the forced low mantissa bit of M2 makes it so: 1 ulp).
+// A collector turns each pair into deviations about ONE common centre c = the mean of workgroup 0,
+//     T_b = M2_b + n_b (mean_b - c)^2 = sum over the rows of b of (x - c)^2,   which is additive,
+// and finishes with  M2 = sum_b T_b - N (mean - c)^2:  c is within ~ std / sqrt(128) of the mean, so that last subtraction is
+// between terms ~ 1 / 128 of the result -- harmless, unlike the (mean / std)^2 blow-up of a one-pass variance.
+//   tile:    red[w][n * 64 + k] = tile sum, red[w][n * 64 + 32 + k] = tile M2 about the tile mean (rows beyond N excluded)
+//   collect: tot[n * 64 + k] = grid sum, tot[n * 64 + 32 + k] = grid M2      (thread t: feature t & 63, workgroups (t >> 6) + 8 j)
+__device__ __forceinline__ int nf_md_rows_of_block(int64_t N, int b) {
+    const int64_t left = N - (int64_t)b * NF_MAF_ROWS_PER_BLOCK;
+    return (int)(left < NF_MAF_ROWS_PER_BLOCK ? (left > 0 ? left : 0) : NF_MAF_ROWS_PER_BLOCK);
+}
+__device__ __forceinline__ void nf_md_publish_stats(float* sm, unsigned long long* slots, int round, int64_t N) {
+    float* red = sm + NF_MD_RED;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int f = (threadIdx.x >> 5) * 64 + (threadIdx.x & 31);
+        const int nb = nf_md_rows_of_block(N, blockIdx.x);
+        float S = 0.f;
+#pragma unroll
+        for (int w = 0; w < NF_MD_WAVES; ++w) S += red[w * NF_MD_XW + f];
+        const float mb = S / (float)max(nb, 1);
+        float M2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NF_MD_WAVES; ++w) {
+            const int nw = min(max(nb - 16 * w, 0), 16);
+            const float d = red[w * NF_MD_XW + f] / (float)max(nw, 1) - mb;
+            M2 += nw > 0 ? fmaf((float)nw * d, d, red[w * NF_MD_XW + 32 + f]) : 0.f;
+        }
+        if (gridDim.x == 1) {
+            red[f] = S; red[32 + f] = M2;                 // threads 0..63 are ONE wave: every read above precedes these stores
+        } else {
+            const unsigned long long pk = ((unsigned long long)__float_as_uint(S) << 32) | (unsigned long long)(__float_as_uint(M2) | 1u);
+            __hip_atomic_store(slots + ((size_t)round * NF_MAF_MAX_BLOCKS + blockIdx.x) * NF_MD_XW + threadIdx.x, pk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+#define NF_MD_SPOLL (NF_MAF_MAX_BLOCKS / 8)
+__device__ __forceinline__ const float* nf_md_collect_stats(float* sm, unsigned long long* slots, int round, int64_t N) {
+    float* tot = sm + NF_MD_TOT + (round & 1) * NF_MD_XW;
+    const int G = gridDim.x;
+    if (G == 1) {
+        __syncthreads();                                  // wave 0 wrote row 0 of RED for both waves' readers (publish_stats)
+        if (threadIdx.x < NF_MD_XW) tot[threadIdx.x] = sm[NF_MD_RED + threadIdx.x];
+        __syncthreads();
+        return tot;
+    }
+    const int i = threadIdx.x & 63, grp = threadIdx.x >> 6;                    // 512 threads: 8 poll groups
+    const unsigned long long* rs = slots + (size_t)round * NF_MAF_MAX_BLOCKS * NF_MD_XW + i;
+    unsigned long long v[NF_MD_SPOLL], v0;
+    unsigned spins = 0;
+    bool ok;
+    do {                                                  // every poll of the thread in flight at once: one latency per round
+        ok = true;
+        v0 = __hip_atomic_load(rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < NF_MD_SPOLL; ++k) {
+            const int b = grp + 8 * k;
+            v[k] = __hip_atomic_load(rs + (size_t)(b < G ? b : 0) * NF_MD_XW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ok = v0 != 0ull;
+#pragma unroll
+        for (int k = 0; k < NF_MD_SPOLL; ++k) ok = ok && v[k] != 0ull;
+        if (ok) break;
+        if (++spins > nf_md_spin_limit) { NF_PERSIST_GIVE_UP(nf_md); break; }
+        __builtin_amdgcn_s_sleep(1);
+    } while (true);
+    const float c = __uint_as_float((unsigned)(v0 >> 32)) / (float)nf_md_rows_of_block(N, 0);
+    float aS = 0.f, aT = 0.f;
+#pragma unroll
+    for (int k = 0; k < NF_MD_SPOLL; ++k) {
+        const int b = grp + 8 * k;
+        if (b < G) {
+            const int nb = nf_md_rows_of_block(N, b);
+            const float Sb = __uint_as_float((unsigned)(v[k] >> 32)), Mb = __uint_as_float((unsigned)v[k]);
+            const float d = Sb / (float)max(nb, 1) - c;
+            aS += Sb;
+            aT += fmaf((float)nb * d, d, Mb);
+        }
+    }
+    __syncthreads();                                      // wave 0 is done reading RED (publish) before it is reused below
+    sm[NF_MD_PART + grp * 64 + i] = aS;
+    sm[NF_MD_RED + grp * 64 + i] = aT;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float S = 0.f, T = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { S += sm[NF_MD_PART + q * 64 + i]; T += sm[NF_MD_RED + q * 64 + i]; }
+        const float dm = S / (float)N - c;
+        const int f = (i >> 5) * 64 + (i & 31);
+        tot[f] = S;
+        tot[32 + f] = fmaxf(T - (float)N * dm * dm, 0.f);
+    }
+    __syncthreads();
+    return tot;
+}
+// tile sums and M2 about the tile mean of an R-layout vector (nt = valid rows of the tile; rows beyond hold zeros)
+__device__ __forceinline__ void nf_md_colstats(const float (&v)[8], float* tile, float (&s1)[2], float (&m2)[2], int c16, int g, int nt) {
+    nf_fp_store_rows(v, tile, c16, g);
+    nf_fp_wsync();
+    float c[2][4];
+    nf_fp_load_cols<2>(tile, c, c16, g);
+    nf_fp_wsync();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        s1[cb] = nf_fp_rowsum((c[cb][0] + c[cb][1]) + (c[cb][2] + c[cb][3]));
+        const float mt = s1[cb] / (float)max(nt, 1);
+        float q = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float d = (4 * s + g < nt) ? c[cb][s] - mt : 0.f;
+            q = fmaf(d, d, q);
+        }
+        m2[cb] = nf_fp_rowsum(q);
+    }
+}
+
 // ---- staging: masked weights of both nets, biases, BatchNorm affines ------------------------------------------------------------
 __device__ __forceinline__ void nf_md_stage(const NfMadeP& p, float* sm, int D) {
     const int tid = threadIdx.x, k = tid & 31;
@@ -367,19 +487,20 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
 #pragma unroll
             for (int c = 0; c < 4; ++c) v8[c] = c < D ? zr[c] - sm[NF_MD_HEAD + 40 + c] : 0.f;
         }
-        nf_md_colsums<true>(v8, tile, s1, s2, c16, g);
+        const int nt = min(max(nf_md_rows_of_block(N, blockIdx.x) - 16 * wid, 0), 16);
+        nf_md_colstats(v8, tile, s1, s2, c16, g, nt);
         red[lane] = 0.f; red[64 + lane] = 0.f;
         nf_fp_wsync();
-        if (g == 0 && c16 < 4) { red[c16] = s1[0]; red[4 + c16] = s2[0]; }
-        nf_md_publish(sm, slots, 0, 1u);
-        const float* tot = nf_md_collect(sm, slots, 0, 1u);
+        if (g == 0 && c16 < 4) { red[c16] = s1[0]; red[32 + c16] = s2[0]; }
+        nf_md_publish_stats(sm, slots, 0, N);
+        const float* tot = nf_md_collect_stats(sm, slots, 0, N);
         if (threadIdx.x < 4) {
             const int c = threadIdx.x;
             const float n = (float)N;
             const float m1 = tot[c] / n;
             kc = sm[NF_MD_HEAD + 40 + c];
             const float mean = kc + m1;
-            const float var = fmaxf(tot[4 + c] / n - m1 * m1, 0.f) + eps;           // biased, eps inside (modules.py:287)
+            const float var = tot[32 + c] / n + eps;                                 // biased, eps inside (modules.py:287)
             nf_md_head_consts(sm, h, c, mean, var);
             if (blockIdx.x == 0 && c < D) {
                 h.bmean[c] = mean; h.bvar[c] = var;
@@ -421,7 +542,7 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
             float m8[8], s1[2], s2[2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) m8[k] = rv ? dv[n][k] : 0.f;
-            nf_md_colsums<true>(m8, tile, s1, s2, c16, g);
+            nf_md_colstats(m8, tile, s1, s2, c16, g, min(max(nf_md_rows_of_block(N, blockIdx.x) - 16 * wid, 0), 16));
             if (g == 0) {
                 red[n * 64 + c16] = s1[0]; red[n * 64 + 16 + c16] = s1[1];
                 red[n * 64 + 32 + c16] = s2[0]; red[n * 64 + 48 + c16] = s2[1];
@@ -429,15 +550,15 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_fwd(NfMadeP p, NfMaf
         }
         const float* tot = nullptr;
         if (use_batch) {                                  // kernel-uniform
-            nf_md_publish(sm, slots, 1 + l, (unsigned)(2 + l));
-            tot = nf_md_collect(sm, slots, 1 + l, (unsigned)(2 + l));
+            nf_md_publish_stats(sm, slots, 1 + l, N);
+            tot = nf_md_collect_stats(sm, slots, 1 + l, N);
         }
         if (use_batch && threadIdx.x < 64) {
             const int n = threadIdx.x >> 5, k = threadIdx.x & 31;
             const float invN = 1.f / (float)N;
             const float m1 = tot[n * 64 + k] * invN;
-            const float mean = sm[NF_MD_B + (n * NF_MD_NL + l) * 32 + k] + m1;      // sums are centred at the bias
-            const float var = fmaxf(tot[n * 64 + 32 + k] * invN - m1 * m1, 0.f);    // biased, as BatchNorm normalises
+            const float mean = sm[NF_MD_B + (n * NF_MD_NL + l) * 32 + k] + m1;      // the linear's output is pre-bias
+            const float var = tot[n * 64 + 32 + k] * invN;                          // biased, as BatchNorm normalises; M2 >= 0
             nf_md_bn_consts(sm, n, l, k, mean, 1.f / sqrtf(var + eps));
             sm[NF_MD_VAR + (n * NF_MD_NB + l) * 32 + k] = var;
         }

@@ -194,6 +194,117 @@ __device__ __forceinline__ const float* nf_mc_collect(float* sm, int gather, uns
     return tot;
 }
 
+// ---- batch STATISTICS through the exchange: (sum, M2) pairs combined by the parallel-variance rule -----------------------------------
+// A one-pass E[x^2] - E[x]^2 (even centred at the producing linear's bias) loses (mean / std)^2 * 6e-8 of the variance, and the
+// conditioner of a 2-D flow is full of features with |mean| >> std (its first linear has ONE input, all 32 outputs are affine in
+// the same scalar): measured on C1 (RealNVP, B = 256) that cost 6e-4 per flow step in the backward's data gradient, 50x the fp32
+// CPU path's own distance from float64 (tools/probes/parity_depth.py).  So every level keeps M2 = sum (x - mean_level)^2 about
+// ITS OWN mean and levels are merged with  M2 = sum_i M2_i + sum_i n_i (mean_i - mean)^2  (Chan et al.): wave tile (16 rows) ->
+// workgroup -> grid.  Same slots, same single memory round trip as the plain sums.
+//   tile:    red[w * 64 + i] = tile sum, red[w * 64 + 32 + i] = tile M2 (i < 32 features), rows beyond N contribute nothing
+//   publish: slots[i] = workgroup sum, slots[32 + i] = workgroup M2
+//   collect: tot[i] = grid sum, tot[32 + i] = grid M2  (var = M2 / N, biased, as BatchNorm normalises)
+__device__ __forceinline__ void nf_mc_tile_stats(const float (&c)[4], int g, int nt, float& s1, float& m2) {
+    s1 = nf_fp_rowsum((c[0] + c[1]) + (c[2] + c[3]));
+    const float mt = s1 / (float)max(nt, 1);
+    float q = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float d = (4 * s + g < nt) ? c[s] - mt : 0.f;                       // element [row 4 s + g] of the tile (nf_fp_load_cols)
+        q = fmaf(d, d, q);
+    }
+    m2 = nf_fp_rowsum(q);
+}
+__device__ __forceinline__ int nf_mc_rows_of_block(int64_t N, int b) {
+    const int64_t left = N - (int64_t)b * NF_MLP_ROWS_PER_BLOCK;
+    return (int)(left < NF_MLP_ROWS_PER_BLOCK ? (left > 0 ? left : 0) : NF_MLP_ROWS_PER_BLOCK);
+}
+__device__ __forceinline__ void nf_mc_publish_stats(float* sm, unsigned long long* slots, int round, unsigned gen, int64_t N) {
+    float* red = sm + NF_MC_RED;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x & 31;
+        const int nb = nf_mc_rows_of_block(N, blockIdx.x);
+        float S = 0.f;
+#pragma unroll
+        for (int w = 0; w < NF_MC_WAVES; ++w) S += red[w * 64 + i];
+        float out = S;
+        if (threadIdx.x >= 32) {
+            const float mb = S / (float)max(nb, 1);
+            float M2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NF_MC_WAVES; ++w) {
+                const int nw = min(max(nb - 16 * w, 0), 16);
+                const float d = red[w * 64 + i] / (float)max(nw, 1) - mb;
+                M2 += nw > 0 ? fmaf((float)nw * d, d, red[w * 64 + 32 + i]) : 0.f;
+            }
+            out = M2;
+        }
+        if (gridDim.x == 1) {
+            red[threadIdx.x] = out;                      // threads 0..63 are ONE wave: every read above precedes this store
+        } else {
+            const unsigned long long pk = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(out);
+            __hip_atomic_store(slots + ((size_t)round * NF_MLP_MAX_BLOCKS + blockIdx.x) * 64 + threadIdx.x, pk, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ const float* nf_mc_collect_stats(float* sm, int gather, unsigned long long* slots, int round, unsigned gen,
+                                                            int64_t N) {
+    float* xs = sm + gather;
+    float* tot = sm + NF_MC_TOT + (round & 1) * 64;
+    const int G = gridDim.x;
+    if (G == 1) {
+        if (threadIdx.x < 64) tot[threadIdx.x] = sm[NF_MC_RED + threadIdx.x];
+        __syncthreads();
+        return tot;
+    }
+    const unsigned long long* rs = slots + (size_t)round * NF_MLP_MAX_BLOCKS * 64;
+    for (int e0 = threadIdx.x; e0 < G * 64; e0 += 4 * NF_MC_THREADS) {
+        unsigned long long v[4];
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * NF_MC_THREADS;
+                v[k] = __hip_atomic_load(rs + (e < G * 64 ? e : e0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
+            if (ok) break;
+            if (++spins > nf_mc_spin_limit) { NF_PERSIST_GIVE_UP(nf_mc); break; }
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * NF_MC_THREADS;
+            if (e < G * 64) xs[e] = __uint_as_float((unsigned)v[k]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x & 31;
+        float S = 0.f;
+        for (int b = 0; b < G; ++b) S += xs[b * 64 + i];
+        float out = S;
+        if (threadIdx.x >= 32) {
+            const float mean = S / (float)N;
+            float M2 = 0.f;
+            for (int b = 0; b < G; ++b) {
+                const int nb = nf_mc_rows_of_block(N, b);
+                const float d = xs[b * 64 + i] / (float)max(nb, 1) - mean;
+                M2 += fmaf((float)nb * d, d, xs[b * 64 + 32 + i]);
+            }
+            out = M2;
+        }
+        tot[threadIdx.x] = out;
+    }
+    __syncthreads();
+    return tot;
+}
+
 struct NfGlowRaw;
 __device__ __forceinline__ void nf_glow_head_phase_a(float* sm, const NfGlowV& h, const NfGlowRaw& raw);
 __device__ __forceinline__ void nf_glow_head_phase_b(float* sm);
@@ -274,28 +385,24 @@ __device__ __forceinline__ void nf_mc_batchnorm_train(float* sm, int j, const fl
     nf_fp_load_cols<2>(tile, c, c16, g);
     nf_fp_wsync();
     float s1[2], s2[2];
+    const int nt = min(max(nf_mc_rows_of_block(N, blockIdx.x) - 16 * wid, 0), 16);  // valid rows of this wave's tile
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        s1[cb] = (c[cb][0] + c[cb][1]) + (c[cb][2] + c[cb][3]);
-        s2[cb] = fmaf(c[cb][0], c[cb][0], fmaf(c[cb][1], c[cb][1], fmaf(c[cb][2], c[cb][2], c[cb][3] * c[cb][3])));
-        s1[cb] = nf_fp_rowsum(s1[cb]);
-        s2[cb] = nf_fp_rowsum(s2[cb]);
-    }
+    for (int cb = 0; cb < 2; ++cb) nf_mc_tile_stats(c[cb], g, nt, s1[cb], s2[cb]);
     float* red = sm + NF_MC_RED;
     if (g == 0) {
         red[wid * 64 + c16] = s1[0]; red[wid * 64 + 16 + c16] = s1[1];
         red[wid * 64 + 32 + c16] = s2[0]; red[wid * 64 + 48 + c16] = s2[1];
     }
     if (j == 1) NF_MC_T(40);
-    nf_mc_publish(sm, slots, j, (unsigned)(j + 1));
-    const float* tot = nf_mc_collect(sm, NF_MC_GATHER(1), slots, j, (unsigned)(j + 1));
+    nf_mc_publish_stats(sm, slots, j, (unsigned)(j + 1), N);
+    const float* tot = nf_mc_collect_stats(sm, NF_MC_GATHER(1), slots, j, (unsigned)(j + 1), N);
     if (j == 1) NF_MC_T(41);
     if (threadIdx.x < 32) {
         const int k = threadIdx.x;
         const float invN = 1.f / (float)N;
         const float m1 = tot[k] * invN;
-        const float mean = sm[NF_MC_B + j * 32 + k] + m1;                          // sums are centred at the bias
-        const float var = fmaxf(tot[32 + k] * invN - m1 * m1, 0.f);                // biased, as BatchNorm normalises
+        const float mean = sm[NF_MC_B + j * 32 + k] + m1;                          // the linear's output is pre-bias
+        const float var = tot[32 + k] * invN;                                      // biased, as BatchNorm normalises; M2 >= 0
         const float invstd = 1.f / sqrtf(var + eps);
         const float sc = sm[NF_MC_GA + j * 32 + k] * invstd;
         sm[NF_MC_BNC + (4 * j + 0) * 32 + k] = sc;
@@ -526,19 +633,19 @@ __device__ __forceinline__ void nf_mc_fwd_body(float* sm, const float* __restric
         nf_fp_wsync();
         nf_fp_load_cols<2>(tile, c4, c16, g);
         nf_fp_wsync();
-        const float s1 = nf_fp_rowsum((c4[0][0] + c4[0][1]) + (c4[0][2] + c4[0][3]));
-        const float s2 = nf_fp_rowsum(fmaf(c4[0][0], c4[0][0], fmaf(c4[0][1], c4[0][1], fmaf(c4[0][2], c4[0][2], c4[0][3] * c4[0][3]))));
+        float s1, s2;
+        nf_mc_tile_stats(c4[0], g, min(max(nf_mc_rows_of_block(N, blockIdx.x) - 16 * wid, 0), 16), s1, s2);
         float* red = sm + NF_MC_RED + wid * 64;
         red[lane] = 0.f;
         nf_fp_wsync();
-        if (g == 0 && c16 < 4) { red[c16] = s1; red[4 + c16] = s2; }
-        nf_mc_publish(sm, slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1));
-        const float* tot = nf_mc_collect(sm, NF_MC_GATHER(1), slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1));
+        if (g == 0 && c16 < 4) { red[c16] = s1; red[32 + c16] = s2; }
+        nf_mc_publish_stats(sm, slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1), N);
+        const float* tot = nf_mc_collect_stats(sm, NF_MC_GATHER(1), slots, NF_MC_NB, (unsigned)(NF_MC_NB + 1), N);
         if (threadIdx.x < 4) {
             const int c = threadIdx.x;
             const float n = (float)N, m1 = tot[c] / n;
             const float mean = sm[NF_MC_HEAD + 80 + c] + m1;
-            const float var = fmaxf(tot[4 + c] / n - m1 * m1, 0.f) + h.fbn_eps;      // biased, eps inside (modules.py:287)
+            const float var = tot[32 + c] / n + h.fbn_eps;                           // biased, eps inside (modules.py:287)
             nf_fbn_head_consts(sm, h, c, mean, var);
             if (blockIdx.x == 0 && c < h.D) {
                 h.bmean[c] = mean; h.bvar[c] = var;

@@ -115,6 +115,30 @@ class _FlowModel(nn.Module):
             for m in invs:
                 m._W_inv = None
 
+    def forward_slice(self, z, log_df_dz, a, b):
+        """layers[a:b] of the stack in the forward direction on (z, log_df_dz) -- the same Compose peepholes, weight-norm and PLU
+        pre-passes as a whole forward, restricted to those layers (they share this model's parameters).  Lets a test feed a
+        slice of a full-size model with the oracle's activations at that depth (tests/test_gpu_slices.py)."""
+        sub = Compose(list(self.net.layers[a:b]))
+        if not z.is_cuda:
+            return sub(z, log_df_dz)
+        from . import functional as NF
+        from . import fused as FUSED
+        from .conditioners import WeightNorm
+        from .layers import InvertibleConv1x1
+        wns = [m for m in sub.modules() if isinstance(m, WeightNorm) and m._conv]
+        plus = [m for m in sub.modules() if isinstance(m, InvertibleConv1x1)
+                and NF.HEAD_MAX_C < m.L.shape[0] <= NF.PLU_MAX_C] if z.dim() == 4 else []
+        FUSED.weight_norm_all(wns)
+        FUSED.plu_weights_all(plus)
+        try:
+            return sub(z, log_df_dz)
+        finally:
+            for m in wns:
+                m._w_eff = None
+            for m in plus:
+                m._W_eff = None
+
     def forward(self, z):
         return self._with_weight_norms(self.net, z)
 

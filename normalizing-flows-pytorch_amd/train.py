@@ -107,6 +107,15 @@ class FlowTrainer:
 
     # -- one step, eager --------------------------------------------------------------------------------------------
     def _forward_backward(self, y):
+        return self._run_step(y.device, lambda: self._forward_loss(y))
+
+    def _forward_loss(self, y):
+        z, ld = self.net(y)
+        return z, nll_loss(z, ld)
+
+    def _run_step(self, device, forward_loss):
+        """zero the bucket, open the step's scratch arena and the deferred-work queues, run ``forward_loss() -> (z, loss)`` and
+        ``loss.backward()``, flush.  ``_forward_backward`` is this with the whole model; tests run slices of a model through it."""
         from .workspace import ARENA
         self.bucket.zero_()
         hooks, seen = [], set()
@@ -119,12 +128,11 @@ class FlowTrainer:
                 self.bucket.params[i].grad = None       # AccumulateGrad then keeps the incoming tensor: no add launch
         from .fused import FPP_DEFER
         from .fused_conv import CONV_DEFER
-        ARENA.begin(y.device)                           # one memset for every zero-initialised accumulator of the step
+        ARENA.begin(device)                             # one memset for every zero-initialised accumulator of the step
         FPP_DEFER.begin()                               # the Flow++ steps' slab finalizes: all of them in one go after backward
         CONV_DEFER.begin()                              # the image conditioners' weight-gradient passes: sixteen layers per launch
         try:
-            z, ld = self.net(y)
-            loss = nll_loss(z, ld)
+            z, loss = forward_loss()
             loss.backward()
         finally:
             FPP_DEFER.flush()

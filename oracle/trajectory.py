@@ -49,3 +49,27 @@ def forward_only(kind, dims, datatype, layers, sd, y, mixtures=None, dtype=torch
                         actnorm_initialized=True)
     with torch.no_grad():
         return ora.forward(y.detach().cpu().to(dtype))
+
+
+def run_slice(kind, dims, datatype, layers, sd, a, b, z_in, ld_in, mixtures=None, dtype=torch.float64, y=None):
+    """layers[a:b] of the stack (``FlowOracle.plan`` indices = positions in ``net.layers``) on (z_in, ld_in), then the NLL of
+    the slice's own output: returns dict(z, ld, loss, g_in, grads{name}).  With ``y`` given instead of ``z_in``, the slice input
+    is computed first: layers[:a] on ``y`` in the same dtype (no graph)."""
+    ora = om.FlowOracle(kind, dims, datatype, layers, cast_state(sd, dtype), mixtures=mixtures, training=True,
+                        actnorm_initialized=True).requires_grad_(True)
+    if y is not None:
+        with torch.no_grad():
+            z_in = y.detach().cpu().to(dtype)
+            ld_in = torch.zeros(z_in.shape[0], dtype=dtype)
+            for L in ora.plan[:a]:
+                z_in, ld_in = ora._apply(L, z_in, ld_in, False)
+    z0 = z_in.detach().cpu().to(dtype).clone().requires_grad_(True)
+    z, ld = z0, ld_in.detach().cpu().to(dtype).clone()
+    for L in ora.plan[a:b]:
+        z, ld = ora._apply(L, z, ld, False)
+    loss = tf.nll_loss(z, ld)
+    loss.backward()
+    pre = tuple(L['prefix'] for L in ora.plan[a:b])
+    grads = {k: v.grad.detach().clone() for k, v in ora.parameters().items() if v.grad is not None and k.startswith(pre)}
+    return dict(z_in=z0.detach().clone(), ld_in=ld_in.detach().clone(), z=z.detach().clone(), ld=ld.detach().clone(),
+                loss=loss.detach().clone(), g_in=z0.grad.detach().clone(), grads=grads)

@@ -242,38 +242,49 @@ def test_mlp_chain_forward_vs_modules(pkg, in_ch, out_ch, N, training):
                                             (2, 4, 16384)])
 @pytest.mark.parametrize('training', [True, False])
 def test_mlp_chain_vs_modules(pkg, in_ch, out_ch, N, training, direct):
-    """persistent MLP conditioner, forward + backward, against autograd through the module stack."""
+    """persistent MLP conditioner, forward + backward, against autograd through the module stack evaluated on the CPU in
+    FLOAT64 (exact-arithmetic yard-stick) -- bar: 2e-5 * max|.| + 4 x the distance of the same module stack in float32 on the
+    CPU from that yard-stick (the cancellation in BatchNorm's backward is a property of the problem, measured here, not a
+    hand-picked tolerance).  At most two rows may sit on the other side of a ReLU kink (pre-activation within rounding of 0)."""
     fused = importlib.import_module(pkg.__name__ + '.fused')
     ref, fus = _mlp_pair(pkg, in_ch, out_ch)
-    ref.train(training)
     fus.train(training)
     g = torch.Generator().manual_seed(N)
-    x = (torch.randn(N, in_ch, generator=g) * 0.7).to(DEV)
-    gout = torch.randn(N, out_ch, generator=g).to(DEV)
-    xr, xf = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    yr = ref.forward_reference(xr)
-    yr.backward(gout)
+    x = torch.randn(N, in_ch, generator=g) * 0.7
+    gout = torch.randn(N, out_ch, generator=g)
+    cpu = {}
+    for dt in (torch.float32, torch.float64):
+        m = copy.deepcopy(ref).cpu().to(dt).train(training)
+        xr = x.detach().clone().to(dt).requires_grad_(True)
+        yr = m.forward_reference(xr)
+        yr.backward(gout.to(dt))
+        cpu[dt] = (yr.detach(), xr.grad.detach(), {k: p.grad.detach() for k, p in m.named_parameters()})
+    y64, gx64, gp64 = cpu[torch.float64]
+    y32, gx32, gp32 = cpu[torch.float32]
+
+    def bar(want64, got32):
+        return 2e-5 * max(1.0, float(want64.abs().max())) + 4.0 * float((got32.double() - want64).abs().max())
+
     if direct:
         for p in fus.parameters():
             p.grad = torch.zeros_like(p)
             p._nf_direct_grad = True
+    xf = x.detach().clone().to(DEV).requires_grad_(True)
     yf = fused.mlp_forward(fus, xf, chain=True)
-    G.assert_close(yf, yr, 2e-5, rtol=2e-5, what='output')
-    yf.backward(gout)
-    # 16384 rows x 160 ReLU units: now and then one pre-activation sits within rounding of zero and the two paths mask it
-    # differently (a legitimate discontinuity): tolerate two such rows and their footprint in the parameter gradients
-    big = N >= 16384
-    err = (xf.grad - xr.grad).abs().max(dim=1).values
-    bad = int((err > _grad_tol(xr.grad)).sum())
-    assert bad <= (2 if big else 0), 'grad input: %d rows beyond tolerance, max abs err %.3e' % (bad, float(err.max()))
-    pr, pf = dict(ref.named_parameters()), dict(fus.named_parameters())
-    for k in pr:
+    assert float((yf.detach().cpu().double() - y64).abs().max()) <= bar(y64, y32), 'output'
+    yf.backward(gout.to(DEV))
+    err = (xf.grad.cpu().double() - gx64).abs().max(dim=1).values
+    flipped = int((err > bar(gx64, gx32)).sum())
+    assert flipped <= 2, 'grad input: %d rows beyond the bar, max abs err %.3e (bar %.3e)' % (flipped, float(err.max()), bar(gx64, gx32))
+    pf = dict(fus.named_parameters())
+    for k, want in gp64.items():
         assert pf[k].grad is not None, k
         pre_bn_bias = training and k.endswith('module.bias') and 'out_block' not in k
-        tol = 2e-3 + 1e-6 * N if pre_bn_bias else _grad_tol(pr[k].grad)   # analytically-zero gradients: noise only
-        if big:
-            tol = max(tol, 1e-2 * float(pr[k].grad.abs().max()))
-        G.assert_close(pf[k].grad, pr[k].grad, tol, what='grad ' + k)
+        tol = bar(want, gp32[k]) + flipped * 8.0 / N * max(1.0, float(want.abs().max()))
+        if pre_bn_bias:
+            tol = max(tol, 2e-3 + 1e-6 * N)                # analytically-zero gradients: rounding noise only
+        e = float((pf[k].grad.cpu().double() - want).abs().max())
+        assert e <= tol, 'grad %s: max abs err %.3e (bar %.3e, cpu32 itself %.3e)' % (k, e, tol, float((gp32[k].double() - want).abs().max()))
 
 
 @pytest.mark.parametrize('direct', [False, True])
