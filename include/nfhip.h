@@ -390,6 +390,36 @@ int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksize);
 int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, int training, float bn_eps,
                    float bn_momentum, nf_stream_t stream);
 
+/* ---- the whole ConvNet conditioner in ONE persistent launch (csrc/conv_chain.hip)  modules.py:416-438 ---------------------
+ * x (B, I0, H, W) -> conv3x3 -> 2 x [BN, ReLU, conv3x3, BN, ReLU, conv3x3, + skip] -> BN, ReLU, conv1x1 -> out (B, O, H, W), with
+ * the effective (weight-normed) weights w[0..5] and biases b[0..5] of the six convolutions and the five BatchNorm2d layers
+ * (training: batch statistics exchanged across the grid in-kernel, running statistics / num_batches_tracked updated; evaluation:
+ * running statistics, no exchange).  Same results and the same by-products as six nf_conv_bn_fwd launches: acts[l] = output of
+ * convolution l (bias and residual included), save_mean[l] / save_invstd[l] = what BatchNorm l normalised with -- what
+ * nf_conv_bn_bwd reads.  A workgroup owns whole samples: H * W <= 256 and a power of two, ceil(B * H * W / tile) <=
+ * NF_CONVNET_MAX_BLOCKS co-resident workgroups (nf_convnet_chain_usable != 0), tile = 256 pixels for 16 x 16 maps, 128 below.
+ * ws_zero: NF_CONVNET_WS_FLOATS floats that are ZERO at launch (exchange slots).                                             */
+#define NF_CONVNET_MAX_BLOCKS 128
+#define NF_CONVNET_WS_FLOATS (5 * 128 * 64 * 2)
+typedef struct nf_convnet_desc {
+    const float* x;
+    const float* w[6];
+    const float* b[6];
+    const float* gamma[5];
+    const float* beta[5];
+    float* rmean[5];
+    float* rvar[5];
+    int64_t* nbt[5];          /* each scalar or NULL */
+    float* acts[5];           /* (B, 32, H, W), written */
+    float* out;               /* (B, O, H, W), written */
+    float* save_mean[5];      /* (32,), training: written */
+    float* save_invstd[5];
+    float* ws_zero;
+} nf_convnet_desc;
+int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W);
+int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training, float bn_eps,
+                         float bn_momentum, nf_stream_t stream);
+
 /* autograd of nf_conv_bn_fwd in training mode; the gradient G of `out` is assembled on load exactly as in
  * nf_linear_bn_bwd (G = g_direct + g_skip + BNbwd(gn_src), each term optional).  Results:
  *     g_store = G (optional);  g_bias[replica][o] += sum G  (NF_STAT_REPL replicas, stride 256 floats);

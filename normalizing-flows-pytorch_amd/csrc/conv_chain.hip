@@ -1,0 +1,613 @@
+// The image conditioner ConvNet (flows/modules.py:416-438: WN(conv3x3) -> 2 x [BN, ReLU, WN(conv3x3), BN, ReLU, WN(conv3x3), + skip]
+// -> BN, ReLU, WN(conv1x1)) as ONE persistent launch -- the convolutional twin of mlp_chain.hip.
+//
+// Why: at the reference's batch (64 samples per GPU) a conv + BatchNorm launch is pure latency: 0.3 GFLOP over <= 128
+// workgroups, ~3 us of MFMA work inside ~19 us of dependent memory round trips (conv_bn.hip), six launches per
+// conditioner, 161 conditioners per step.  Here a workgroup owns WHOLE SAMPLES (one 16 x 16 sample, two 8 x 8, eight 4 x 4:
+// no halo between workgroups), keeps the activations of consecutive layers in two zero-padded LDS frames (normalise + ReLU on
+// the way in, so the nine taps read finished values), and the only traffic between two layers is the grid-wide exchange of the
+// BatchNorm statistics that training mode imposes (one memory round trip, mlp_chain.hip's publish / collect protocol).  The
+// pre-BatchNorm outputs of every layer are still written to global memory -- the backward pass needs them -- but nothing waits
+// for those stores.
+//
+//   16 waves = NPB pixel blocks (32 pixels) x NKQ splits of the (tap, channel) axis:  <8, 2> for 256-pixel tiles (16 x 16),
+//   <4, 4> for 128-pixel tiles (8 x 8, 4 x 4).  GEMMs as in conv_bn.hip: out^T[oc][pixel] on v_mfma_f32_32x32x2_f32 (exact fp32),
+//   the K splits meet in LDS, every wave finishes 16 / NKQ output channels of its pixel block: bias, residual (kept in
+//   registers: the lane that finishes (channel, pixel) of layer l also finishes it for layer l + 2), store, statistics.
+//   Batch statistics are (sum, M2) pairs merged by the parallel-variance rule: half wave -> workgroup -> grid (no E[x^2] - E[x]^2).
+#include <mutex>
+#include <unordered_set>
+#include "nf_conv_core.h"
+
+#define NF_CC_NL 6
+#define NF_CC_NB 5
+#define NF_CC_MAX_BLOCKS NF_CONVNET_MAX_BLOCKS
+
+NF_PERSIST_STATE(nf_cc)
+NF_PERSIST_HOST_API(nf_cc)
+
+// phase stamps of workgroup 0 (tools/probes/chain_prof.py builds this file with -DNF_CC_PROF=1; 100 MHz wall clock)
+#ifdef NF_CC_PROF
+__device__ long long nf_cc_prof[64];
+__device__ long long nf_cc_arrive[128];
+extern "C" int nf_cc_arrive_read(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cc_arrive), sizeof(long long) * 128);
+}
+#define NF_CC_STAMP(i)                                                                 \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) nf_cc_prof[i] = wall_clock64();       \
+    } while (0)
+extern "C" int nf_cc_prof_read(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cc_prof), sizeof(long long) * 64);
+}
+#else
+#define NF_CC_STAMP(i)
+#endif
+
+// LDS layouts ("4-packed": the MFMA K index runs over groups of 8 = two channel quads, a lane's four consecutive K values are one
+// float4, so a group costs TWO ds_read_b128 instead of eight ds_read_b32):
+//   frame  F4[cg][f][4]            channel quad cg = c >> 2, frame position f, c & 3            quad stride CS4 = 4 * CS
+//   weight W4[tap][cg][oc][4]      W[oc][4 cg + j][tap]: quad stride RSW = 4 * WC + 4, tap stride TS = NCG * RSW + 4 (WC = 32 * OCB
+//                                  output columns; the + 4 keep the staging stores of neighbouring taps / quads on different banks)
+#define NF_CC_RSW(WC) (4 * (WC) + 4)
+#define NF_CC_TS(NCG, WC) ((NCG) * NF_CC_RSW(WC) + 4)
+struct NfCcLds {            // offsets in floats
+    int FA, FB, WL, RS, KC, KB, RED, TOT, total;
+};
+template <int NPB, int NKQ>
+__host__ __device__ inline NfCcLds nf_cc_lds(int CS, int OCB) {
+    NfCcLds L;
+    const int w3 = 9 * NF_CC_TS(8, 32), w1 = NF_CC_TS(8, 32 * OCB);
+    L.FA = 0;
+    L.FB = L.FA + 32 * CS;
+    L.WL = L.FB + 32 * CS;
+    L.RS = L.WL + (w3 > w1 ? w3 : w1);
+    int rs = NPB * (NKQ - 1) * 16 * NF_WAVE;
+    if (rs < NF_CC_MAX_BLOCKS * 64) rs = NF_CC_MAX_BLOCKS * 64;       // the gather buffer of the grid exchange aliases RS
+    L.KC = L.RS + rs;
+    L.KB = L.KC + 64;
+    L.RED = L.KB + 32;
+    L.TOT = L.RED + 2 * NPB * 32;
+    L.total = L.TOT + 64;
+    return L;
+}
+
+// the K loop: acc += sum over the groups [g0, g0 + gcount) of W4(tap, quads 2 q + hs)[oc] * F4(quads 2 q + hs)[pixel + tap offset];
+// a tap has `gpt` groups (NCG / 2: 2 or 4, a power of two, lgg = log2).  Operand reads of group g + 1 are in flight under the MFMAs
+// of group g (the one-past-the-end prefetch re-reads a valid group: branch-free body).
+template <int T>
+__device__ __forceinline__ void nf_cc_kloop(f32x16& acc, const float* W4, const float* F4, int TS, int RSW, int CS4, int FW, int lgg,
+                                            int fpos, int col, int hs, int g0, int gcount) {
+    const int gpt = 1 << lgg;
+    const int glast = T * gpt - 1;
+    const float* wbase = W4 + hs * RSW + 4 * col;
+    const float* fbase = F4 + hs * CS4 + 4 * fpos;
+    float4 a0, b0, a1, b1;
+    int gi = g0;
+#define NF_CC_LOAD(A_, B_)                                                                     \
+    do {                                                                                       \
+        const int gg = gi < glast ? gi : glast;                                                \
+        const int tap = T == 1 ? 0 : gg >> lgg, q = gg - (tap << lgg);                         \
+        const int dy = T == 9 ? tap / 3 - 1 : 0, dx = T == 9 ? tap - (tap / 3) * 3 - 1 : 0;    \
+        A_ = *(const float4*)(wbase + tap * TS + 2 * q * RSW);                                 \
+        B_ = *(const float4*)(fbase + 4 * (dy * FW + dx) + 2 * q * CS4);                       \
+        ++gi;                                                                                  \
+    } while (0)
+#define NF_CC_MFMA(A_, B_)                                                                     \
+    do {                                                                                       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B_.x, acc, 0, 0, 0);                  \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B_.y, acc, 0, 0, 0);                  \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B_.z, acc, 0, 0, 0);                  \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B_.w, acc, 0, 0, 0);                  \
+    } while (0)
+    NF_CC_LOAD(a0, b0);
+    for (int i = 0; i < gcount; i += 2) {
+        NF_CC_LOAD(a1, b1);
+        NF_CC_MFMA(a0, b0);
+        NF_CC_LOAD(a0, b0);
+        if (i + 1 < gcount) NF_CC_MFMA(a1, b1);
+    }
+#undef NF_CC_LOAD
+#undef NF_CC_MFMA
+}
+
+// 3x3 weights of one chunk of IC (padded ICP, NCG = ICP / 4 quads) input channels, global (32, I, 3, 3) -> W4: lane entries r = ic * 9 + tap
+// (contiguous in global memory for every oc), wave w takes oc = w, w + 16
+struct NfCcW { float v[5][NF_CV_CU]; };
+__device__ __forceinline__ void nf_cc_w_load(NfCcW& w, const float* __restrict__ weight, int I, int i0, int IC, int wid, int lane) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = lane + NF_WAVE * j;
+#pragma unroll
+        for (int u = 0; u < NF_CV_CU; ++u) w.v[j][u] = r < IC * 9 ? weight[((wid + u * NF_CV_WAVES) * I + i0) * 9 + r] : 0.f;
+    }
+}
+__device__ __forceinline__ void nf_cc_w_store(const NfCcW& w, float* W4, int ICP, int wid, int lane) {
+    const int RSW = NF_CC_RSW(32), TS = NF_CC_TS(ICP >> 2, 32);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = lane + NF_WAVE * j;
+        const int ic = r / 9, tap = r - ic * 9;
+        if (r < ICP * 9) {                              // entries of the padding channels [IC, ICP) were loaded as zeros
+#pragma unroll
+            for (int u = 0; u < NF_CV_CU; ++u) W4[tap * TS + (ic >> 2) * RSW + 4 * (wid + u * NF_CV_WAVES) + (ic & 3)] = w.v[j][u];
+        }
+    }
+}
+
+// K-split exchange: the NKQ waves of a pixel block each hold a partial 32 x 32 accumulator; wave kq ends up with the TOTAL of
+// registers [OWN kq, OWN kq + OWN).  RS: [pb][owner][slot][OWN][64].  Callers sync before (RS readers of the previous round done).
+template <int NKQ>
+__device__ __forceinline__ void nf_cc_ksplit_exchange(float (&own)[16 / NKQ], const f32x16& acc, float* RS, int pb, int kq, int lane) {
+    constexpr int OWN = 16 / NKQ;
+#pragma unroll
+    for (int o = 0; o < NKQ; ++o)
+        if (o != kq) {                                 // wave-uniform
+            const int slot = kq < o ? kq : kq - 1;
+#pragma unroll
+            for (int rr = 0; rr < OWN; ++rr) RS[(((pb * NKQ + o) * (NKQ - 1) + slot) * OWN + rr) * NF_WAVE + lane] = acc[OWN * o + rr];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < OWN; ++rr) own[rr] = acc[OWN * o + rr];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int slot = 0; slot < NKQ - 1; ++slot)
+#pragma unroll
+        for (int rr = 0; rr < OWN; ++rr) own[rr] += RS[(((pb * NKQ + kq) * (NKQ - 1) + slot) * OWN + rr) * NF_WAVE + lane];
+}
+
+__device__ __forceinline__ int nf_cc_valid_px(int64_t Npx, int64_t first, int count) {
+    const int64_t left = Npx - first;
+    return (int)(left < count ? (left > 0 ? left : 0) : count);
+}
+
+// ---- (sum, M2) of OWN per-lane values over the 32 lanes of a wave half, by PAIRWISE merging (Chan et al.) ----------------------------
+// Two blocks of m pixels each with sums S, S' and squared deviations M2, M2' about their own means merge into
+//     S + S',   M2 + M2' + (S' - S)^2 / (2 m)
+// -- a tree reduction, no mean needed in advance, no cancellation.  Halving butterfly: at the lane masks 1, 2 (, 4) a lane keeps
+// half of its values and hands the other half to its partner, so a step's shuffles halve as well (14 shuffles for OWN = 8, 9 for
+// OWN = 4, against 10 per value for two plain reductions: 80 / 40, which were 3.8 / 2.0 us per layer); the remaining masks merge the
+// one value left.  Pixels beyond the batch come in whole samples, i.e. whole 16-lane groups (a map has >= 16 pixels), and hold
+// zeros: inside a group the rule above is exact as it stands; at mask 16 an empty group is skipped (lo_ok / hi_ok).
+// Result: lane c32 holds S and M2 of value index `which` (a function of its low bits) over the half's valid pixels.
+__device__ __forceinline__ void nf_cc_merge(float& S, float& M2, float So, float Mo, float half_inv_m) {
+    const float dl = So - S;
+    M2 = (M2 + Mo) + dl * dl * half_inv_m;
+    S += So;
+}
+template <int OWN>
+__device__ __forceinline__ void nf_cc_half_stats(const float (&v)[OWN], bool lo_ok, bool hi_ok, int c32, float& S, float& M2,
+                                                 int& which) {
+    static_assert(OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    float s4[4], q4[4];
+    int w = 0, m = 1;                                   // m: pixels merged so far
+    if (OWN == 8) {
+        const bool up = c32 & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float keep = up ? v[k + 4] : v[k], send = up ? v[k] : v[k + 4];
+            s4[k] = keep; q4[k] = 0.f;
+            nf_cc_merge(s4[k], q4[k], __shfl_xor(send, 1, NF_WAVE), 0.f, 0.5f);
+        }
+        w = up ? 4 : 0;
+        m = 2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s4[k] = v[k]; q4[k] = 0.f; }
+    }
+    float s2[2], q2[2];
+    {
+        const bool up = c32 & m;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float ks = up ? s4[k + 2] : s4[k], ss = up ? s4[k] : s4[k + 2];
+            const float kq_ = up ? q4[k + 2] : q4[k], sq = up ? q4[k] : q4[k + 2];
+            s2[k] = ks; q2[k] = kq_;
+            const float os = __shfl_xor(ss, m, NF_WAVE);
+            const float oq = OWN == 8 ? __shfl_xor(sq, m, NF_WAVE) : 0.f;      // OWN = 4: first merge, the partner's M2 is zero
+            nf_cc_merge(s2[k], q2[k], os, oq, 0.5f / (float)m);
+        }
+        w += up ? 2 : 0;
+        m *= 2;
+    }
+    {
+        const bool up = c32 & m;
+        const float ks = up ? s2[1] : s2[0], ss = up ? s2[0] : s2[1];
+        const float kq_ = up ? q2[1] : q2[0], sq = up ? q2[0] : q2[1];
+        S = ks; M2 = kq_;
+        nf_cc_merge(S, M2, __shfl_xor(ss, m, NF_WAVE), __shfl_xor(sq, m, NF_WAVE), 0.5f / (float)m);
+        w += up ? 1 : 0;
+        m *= 2;
+    }
+    for (; m < 16; m *= 2) nf_cc_merge(S, M2, __shfl_xor(S, m, NF_WAVE), __shfl_xor(M2, m, NF_WAVE), 0.5f / (float)m);
+    {   // the two 16-lane groups: either may be empty (beyond the batch)
+        const float So = __shfl_xor(S, 16, NF_WAVE), Mo = __shfl_xor(M2, 16, NF_WAVE);
+        const bool me_ok = (c32 & 16) ? hi_ok : lo_ok, ot_ok = (c32 & 16) ? lo_ok : hi_ok;
+        if (me_ok && ot_ok) nf_cc_merge(S, M2, So, Mo, 0.5f / 16.f);
+        else if (ot_ok) { S = So; M2 = Mo; }
+    }
+    which = w;
+}
+
+// grid-wide (sum, M2) of 32 channels: red[0][pb][c] = sums, red[1][pb][c] = M2 about the pixel block's mean -> tot[c], tot[32 + c].
+// The merges are spread over the whole workgroup (a 64-iteration loop of divisions on 64 threads cost 7.4 us at 64 workgroups):
+// thread (channel i = t & 31, part p = t >> 5) takes the workgroups p, p + 32, ...; parts meet in `part` (aliases Wl, idle here).
+template <int NPB>
+__device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, int round,
+                                                             int64_t Npx, int PXW) {
+    float* red = sm + L.RED;
+    float* xs = sm + L.RS;
+    float* part = sm + L.WL;                            // [32 parts][32 channels]
+    float* tot = sm + L.TOT;
+    const int G = gridDim.x;
+    const int i = threadIdx.x & 31, p = threadIdx.x >> 5;
+    __syncthreads();                                    // red complete; RS / Wl no longer read by anybody
+    if (round == 1) NF_CC_STAMP(56);
+    if (threadIdx.x < 32) {
+        const int nb = nf_cc_valid_px(Npx, (int64_t)blockIdx.x * PXW, PXW);
+        float S, M2;
+        if (nb == PXW) {                                // every pixel block full: pairwise tree, no division
+            float sv[NPB], mv[NPB];
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) { sv[q] = red[q * 32 + i]; mv[q] = red[NPB * 32 + q * 32 + i]; }
+#pragma unroll
+            for (int w = 1; w < NPB; w *= 2)
+#pragma unroll
+                for (int q = 0; q < NPB; q += 2 * w) nf_cc_merge(sv[q], mv[q], sv[q + w], mv[q + w], 0.5f / (float)(32 * w));
+            S = sv[0]; M2 = mv[0];
+        } else {                                        // the last workgroup of a batch that does not fill it
+            S = 0.f; M2 = 0.f;
+            for (int q = 0; q < NPB; ++q) S += red[q * 32 + i];
+            const float mb = S / (float)max(nb, 1);
+            for (int q = 0; q < NPB; ++q) {
+                const int np = nf_cc_valid_px(Npx, (int64_t)blockIdx.x * PXW + 32 * q, 32);
+                const float dlt = red[q * 32 + i] / (float)max(np, 1) - mb;
+                M2 += np > 0 ? fmaf((float)np * dlt, dlt, red[NPB * 32 + q * 32 + i]) : 0.f;
+            }
+        }
+        if (G == 1) {
+            tot[i] = S; tot[32 + i] = M2;
+        } else {
+            unsigned long long* dst = slots + ((size_t)round * NF_CC_MAX_BLOCKS + blockIdx.x) * 64 + i;
+            __hip_atomic_store(dst, ((unsigned long long)(round + 1) << 32) | (unsigned long long)__float_as_uint(S), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 32, ((unsigned long long)(round + 1) << 32) | (unsigned long long)__float_as_uint(M2),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (G == 1) {
+        __syncthreads();
+        return tot;
+    }
+    const unsigned long long* rs = slots + (size_t)round * NF_CC_MAX_BLOCKS * 64;
+    const unsigned gen = (unsigned)(round + 1);
+    if (round == 1) NF_CC_STAMP(57);
+#ifdef NF_CC_PROF
+    if (round == 1 && threadIdx.x == 0) nf_cc_arrive[blockIdx.x] = wall_clock64();
+#endif
+    for (int e0 = threadIdx.x; e0 < G * 64; e0 += 4 * NF_CV_THREADS) {
+        unsigned long long v[4];
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * NF_CV_THREADS;
+                v[k] = __hip_atomic_load(rs + (e < G * 64 ? e : e0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
+            if (ok) break;
+            if (++spins > nf_cc_spin_limit) { NF_PERSIST_GIVE_UP(nf_cc); break; }
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * NF_CV_THREADS;
+            if (e < G * 64) xs[e] = __uint_as_float((unsigned)v[k]);
+        }
+    }
+    if (round == 1) NF_CC_STAMP(58);
+    __syncthreads();
+    if (round == 1) NF_CC_STAMP(59);
+    // sums: parts, then everybody adds the 32 parts of its channel (fixed order: deterministic)
+    float ps = 0.f;
+    for (int b = p; b < G; b += 32) ps += xs[b * 64 + i];
+    part[p * 32 + i] = ps;
+    __syncthreads();
+    float S = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) S += part[q * 32 + i];
+    const float mean = S / (float)Npx;
+    float pm = 0.f;
+    const float inv_full = 1.f / (float)PXW;
+    for (int b = p; b < G; b += 32) {
+        const int nb = nf_cc_valid_px(Npx, (int64_t)b * PXW, PXW);
+        const float dlt = xs[b * 64 + i] * (nb == PXW ? inv_full : 1.f / (float)max(nb, 1)) - mean;
+        pm += fmaf((float)nb * dlt, dlt, xs[b * 64 + 32 + i]);
+    }
+    __syncthreads();                                    // every thread has read the sums' parts
+    part[p * 32 + i] = pm;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float M2 = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) M2 += part[q * 32 + i];
+        tot[i] = S;
+        tot[32 + i] = M2;
+    }
+    __syncthreads();
+    return tot;
+}
+
+// LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[2][32] | kb[32] | red[2][NPB][32] | tot[64]
+template <int NPB, int NKQ>
+__global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
+                                                                     float eps, float mom) {
+    static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
+    constexpr int OWN = 16 / NKQ, PXW = 32 * NPB;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int OCB = (O_out + 31) / 32;
+    const NfCcLds L = nf_cc_lds<NPB, NKQ>(g.CS, OCB);
+    float* Wl = sm + L.WL;
+    float* RS = sm + L.RS;
+    float* kc = sm + L.KC;
+    float* kb = sm + L.KB;
+    float* red = sm + L.RED;
+    const int CS4 = 4 * g.CS;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    const int pb = wid % NPB, kq = wid / NPB;
+    const int64_t Npx = g.B * g.HW;
+    const int64_t tile = blockIdx.x;
+    const int64_t b0 = (tile * PXW) >> g.lgHW;          // first sample of the tile (whole samples per tile: y0 = 0)
+    const int px = pb * 32 + c32;
+    const int fpos = nf_cv_frame_of(g, px);
+    const int64_t P = tile * PXW + px;
+    const bool pv = P < Npx;
+    const int64_t b = pv ? P >> g.lgHW : 0;
+    const int64_t q = pv ? P & (g.HW - 1) : 0;
+    const int npb = nf_cc_valid_px(Npx, tile * PXW + 32 * pb, 32);
+    unsigned long long* slots = (unsigned long long*)d.ws_zero;
+
+    NF_CC_STAMP(0);
+    // ---- zero both frames (halo and padding stay zero for the whole launch) ------------------------------------------------
+    for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
+    float* Fin = sm + L.FA;
+    float* Fout = sm + L.FB;
+
+    float stream[OWN], own[OWN];
+#pragma unroll
+    for (int rr = 0; rr < OWN; ++rr) stream[rr] = 0.f;
+
+    // ---- convolution 0: input from global memory, chunks of 32 channels --------------------------------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const int nchunks = (I0 + 31) / 32;
+        const float* in0 = d.x + b0 * I0 * g.HW;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int i0 = 32 * ch, IC = min(32, I0 - i0), ICP = (IC + 15) & ~15;
+            NfCcW wv;
+            nf_cc_w_load(wv, d.w[0], I0, i0, IC, wid, lane);
+            __syncthreads();                            // the previous chunk's readers of Wl / Fin are done (and the zero fill)
+            nf_cc_w_store(wv, Wl, ICP, wid, lane);
+#pragma unroll 1
+            for (int jj = 0; jj < g.nfj; ++jj) {       // one frame position per lane and trip (register budget, see conv_bn.hip)
+                const int f = lane + NF_WAVE * jj;
+                const int t = nf_cv_decode(g, b0, 0, f);
+                const int sp = t >= 0 ? NF_CV_SP(t) : 0, sg_ = t >= 0 ? NF_CV_SEG(t) : 0;
+                float xa[NF_CV_CU];
+#pragma unroll
+                for (int u = 0; u < NF_CV_CU; ++u) {
+                    const int c = wid + u * NF_CV_WAVES;
+                    xa[u] = (t >= 0 && c < IC) ? in0[(sg_ * I0 + i0 + c) * g.HW + sp] : 0.f;
+                }
+                if (f < g.FSZ) {
+#pragma unroll
+                    for (int u = 0; u < NF_CV_CU; ++u) {
+                        const int c = wid + u * NF_CV_WAVES;
+                        if (c < ICP) Fin[(c >> 2) * CS4 + 4 * f + (c & 3)] = xa[u];
+                    }
+                }
+            }
+            __syncthreads();
+            const int lgg = ICP == 32 ? 2 : 1;          // groups of 8 channels per tap
+            const int ng = 9 << lgg;
+            const int g0 = (kq * ng) / NKQ, g1 = ((kq + 1) * ng) / NKQ;
+            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(ICP >> 2, 32), NF_CC_RSW(32), CS4, g.FW, lgg, fpos, c32, hs, g0, g1 - g0);
+        }
+    }
+
+    // ---- layers 0 .. 4: finish, statistics, normalise into the other frame, next 3x3 convolution ---------------------------------
+    // (register budget: 128 VGPRs at sixteen waves -- the per-layer vectors live in LDS, the weight prefetch keeps values only)
+    NF_CC_STAMP(1);
+#pragma unroll 1
+    for (int l = 0; l < NF_CC_NB; ++l) {
+        // next layer's 32 x 32 x 9 weights: loads in flight under the exchanges of this layer
+        constexpr bool PREFETCH_W = OWN <= 4;           // OWN = 8 has no registers to spare: it loads at the point of use
+        NfCcW wv;
+        if (PREFETCH_W && l < NF_CC_NB - 1) nf_cc_w_load(wv, d.w[l + 1], 32, 0, 32, wid, lane);
+        if (threadIdx.x < 32) kb[threadIdx.x] = d.b[l][threadIdx.x];
+        __syncthreads();                                // every wave is done with Wl / Fin of this layer; kb is written
+        NF_CC_STAMP(2 + 8 * l);
+        nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
+        NF_CC_STAMP(3 + 8 * l);
+        float* act = d.acts[l];
+#pragma unroll
+        for (int rr = 0; rr < OWN; ++rr) own[rr] = pv ? own[rr] + (((l & 1) == 0 && l > 0) ? stream[rr] : 0.f) : 0.f;   // + block input
+        if (training) {                                 // statistics of the pre-bias output: pairwise (sum, M2) over the wave half
+            float S, M2;
+            int which;
+            nf_cc_half_stats<OWN>(own, npb > 0, npb > 16, c32, S, M2, which);
+            if (c32 < OWN) {
+                const int oc = nf_cv_cd_row(OWN * kq + which, hs);
+                red[pb * 32 + oc] = S;
+                red[NPB * 32 + pb * 32 + oc] = M2;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < OWN; ++rr) {
+            const int oc = nf_cv_cd_row(OWN * kq + rr, hs);
+            const float a = own[rr] + kb[oc];
+            own[rr] = a;
+            if (pv) act[(b * 32 + oc) * g.HW + q] = a;
+            if ((l & 1) == 0) stream[rr] = a;           // acts[0], acts[2] are the residual stream
+        }
+        NF_CC_STAMP(4 + 8 * l);
+        if (training) {
+            const float* tot = nf_cc_stats_exchange<NPB>(sm, L, slots, l, Npx, PXW);
+            NF_CC_STAMP(5 + 8 * l);
+            if (threadIdx.x < 32) {
+                const int k = threadIdx.x;
+                const float invN = 1.f / (float)Npx;
+                const float mean = kb[k] + tot[k] * invN;                     // statistics of the pre-bias output
+                const float var = tot[32 + k] * invN;                         // biased, as BatchNorm normalises
+                const float invstd = 1.f / sqrtf(var + eps);
+                const float sc = d.gamma[l][k] * invstd;
+                kc[k] = sc;
+                kc[32 + k] = d.beta[l][k] - mean * sc;
+                if (blockIdx.x == 0) {
+                    d.save_mean[l][k] = mean;
+                    d.save_invstd[l][k] = invstd;
+                    const float unb = Npx > 1 ? var * ((float)Npx / (float)(Npx - 1)) : var;
+                    d.rmean[l][k] = (1.f - mom) * d.rmean[l][k] + mom * mean;
+                    d.rvar[l][k] = (1.f - mom) * d.rvar[l][k] + mom * unb;
+                    if (k == 0 && d.nbt[l] != nullptr) d.nbt[l][0] += 1;
+                }
+            }
+        } else {
+            __syncthreads();                            // RS readers done before the frames are written
+            if (threadIdx.x < 32) {
+                const int k = threadIdx.x;
+                const float mean = d.rmean[l][k], invstd = 1.f / sqrtf(d.rvar[l][k] + eps);
+                const float sc = d.gamma[l][k] * invstd;
+                kc[k] = sc;
+                kc[32 + k] = d.beta[l][k] - mean * sc;
+                if (blockIdx.x == 0) {                  // what the backward kernels normalise with (constants in this mode)
+                    d.save_mean[l][k] = mean;
+                    d.save_invstd[l][k] = invstd;
+                }
+            }
+        }
+        __syncthreads();
+        NF_CC_STAMP(6 + 8 * l);
+        // normalise + ReLU into the other frame (a lane's values are whole channel quads: one 16-byte store each); next weights into Wl
+#pragma unroll
+        for (int j = 0; j < OWN / 4; ++j) {
+            const int c0 = nf_cv_cd_row(OWN * kq + 4 * j, hs);          // channels c0 .. c0 + 3
+            float4 v;
+            v.x = pv ? fmaxf(fmaf(own[4 * j + 0], kc[c0 + 0], kc[32 + c0 + 0]), 0.f) : 0.f;
+            v.y = pv ? fmaxf(fmaf(own[4 * j + 1], kc[c0 + 1], kc[32 + c0 + 1]), 0.f) : 0.f;
+            v.z = pv ? fmaxf(fmaf(own[4 * j + 2], kc[c0 + 2], kc[32 + c0 + 2]), 0.f) : 0.f;
+            v.w = pv ? fmaxf(fmaf(own[4 * j + 3], kc[c0 + 3], kc[32 + c0 + 3]), 0.f) : 0.f;
+            *(float4*)(Fout + (c0 >> 2) * CS4 + 4 * fpos) = v;
+        }
+        { float* t = Fin; Fin = Fout; Fout = t; }
+        if (l < NF_CC_NB - 1) {
+            if (!PREFETCH_W) nf_cc_w_load(wv, d.w[l + 1], 32, 0, 32, wid, lane);
+            nf_cc_w_store(wv, Wl, 32, wid, lane);
+            __syncthreads();
+            NF_CC_STAMP(7 + 8 * l);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int ng = 9 * 4;
+            const int g0 = (kq * ng) / NKQ;
+            int gcount = ng / NKQ;
+            // opaque trip count: fully unrolled, the K loop's LDS addresses become loop invariants of the LAYER loop that the
+            // compiler keeps in (and spills from) VGPRs
+            asm volatile("" : "+s"(gcount));
+            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            NF_CC_STAMP(8 + 8 * l);
+        }
+    }
+    NF_CC_STAMP(50);
+
+    // ---- the 1 x 1 output convolution: wave (pb, kq) takes output blocks kq, kq + NKQ, ... ------------------------------------
+    const int WC = 32 * OCB, RSW5 = NF_CC_RSW(WC);
+    for (int e = threadIdx.x; e < O_out * 32; e += NF_CV_THREADS) {
+        const int oc = e >> 5, ic = e & 31;
+        Wl[(ic >> 2) * RSW5 + 4 * oc + (ic & 3)] = d.w[5][e];
+    }
+    __syncthreads();
+    for (int ob = kq; ob < OCB; ob += NKQ) {            // wave-uniform
+        f32x16 a5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a5[r] = 0.f;
+        nf_cc_kloop<1>(a5, Wl, Fin, 0, RSW5, CS4, g.FW, 2, fpos, 32 * ob + c32, hs, 0, 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = ob * 32 + nf_cv_cd_row(r, hs);
+            if (pv && oc < O_out) d.out[(b * O_out + oc) * g.HW + q] = a5[r] + d.b[5][oc];
+        }
+    }
+    NF_CC_STAMP(51);
+}
+
+template <typename K>
+static inline int nf_cc_optin(K kernel) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> done;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.find(key) == done.end()) {
+        hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done.insert(key);
+    }
+    return 0;
+}
+
+// tile of whole samples: 256 pixels for 16 x 16 (one sample), 128 for smaller maps (two 8 x 8, eight 4 x 4 ...)
+static inline int nf_cc_tile_px(int H, int W) { return H * W >= 256 ? 256 : 128; }
+
+static int nf_cc_capacity() {
+    static int cap = -1;
+    if (cap < 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cap = cus;                                      // one 1024-thread workgroup with > 80 KB of LDS per compute unit
+    }
+    return cap;
+}
+
+extern "C" int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W) {
+    NfCvGeo g;
+    if (B < 1 || I0 < 1 || I0 > NF_CV_MAX_I || O_out < 1 || O_out > NF_CV_MAX_O) return 0;
+    const int PX = nf_cc_tile_px(H, W);
+    if (H * W > PX) return 0;                           // whole samples per workgroup only
+    if (!nf_cv_geometry(g, B, H, W, 3, PX)) return 0;
+    if (g.tiles > NF_CC_MAX_BLOCKS || g.tiles > nf_cc_capacity()) return 0;
+    if (!(B * 192 * (int64_t)H * W < (int64_t)1 << 31)) return 0;
+    return 1;
+}
+
+extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
+                                    float bn_eps, float bn_momentum, nf_stream_t stream) {
+    if (desc == nullptr || !nf_convnet_chain_usable(B, I0, O_out, H, W)) return NF_E_BADARG;
+    NfCvGeo g;
+    const int PX = nf_cc_tile_px(H, W);
+    if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
+    const int OCB = (O_out + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (PX == 256) {
+        const size_t lds = sizeof(float) * (size_t)nf_cc_lds<8, 2>(g.CS, OCB).total;
+        if (lds > 160 * 1024) return NF_E_BADARG;
+        rc = nf_cc_optin(k_convnet_chain_fwd<8, 2>);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), lds, st, *desc, g, I0, O_out,
+                           training, bn_eps, bn_momentum);
+    } else {
+        const size_t lds = sizeof(float) * (size_t)nf_cc_lds<4, 4>(g.CS, OCB).total;
+        if (lds > 160 * 1024) return NF_E_BADARG;
+        rc = nf_cc_optin(k_convnet_chain_fwd<4, 4>);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), lds, st, *desc, g, I0, O_out,
+                           training, bn_eps, bn_momentum);
+    }
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -2006,14 +2006,17 @@ extern "C" int nf_realnvp_step_vec_bwd(const float* z, const float* g_y, const f
 NF_PERSIST_HOST_API(nf_mc)
 __attribute__((visibility("hidden"))) int nf_md_persist_read(unsigned* v);                                 // made_chain.hip
 __attribute__((visibility("hidden"))) int nf_md_persist_set(unsigned limit, unsigned* flag_dev, int reset);
+__attribute__((visibility("hidden"))) int nf_cc_persist_read(unsigned* v);                                 // conv_chain.hip
+__attribute__((visibility("hidden"))) int nf_cc_persist_set(unsigned limit, unsigned* flag_dev, int reset);
 
 extern "C" int nf_persistent_timeouts(int* count) {
     if (count == nullptr) return NF_E_BADARG;
-    unsigned v = 0, v2 = 0;
+    unsigned v = 0, v2 = 0, v3 = 0;
     int e = nf_mc_persist_read(&v);
     if (e == 0) e = nf_md_persist_read(&v2);
+    if (e == 0) e = nf_cc_persist_read(&v3);
     if (e != 0) return e;
-    *count = (int)(v + v2);
+    *count = (int)(v + v2 + v3);
     return 0;
 }
 
@@ -2041,6 +2044,7 @@ extern "C" int nf_persistent_config(int64_t spin_limit, int reset, void** host_e
     const unsigned lim = (unsigned)spin_limit;
     int e = nf_mc_persist_set(lim, g_persist_dev_word, reset);
     if (e == 0) e = nf_md_persist_set(lim, g_persist_dev_word, reset);
+    if (e == 0) e = nf_cc_persist_set(lim, g_persist_dev_word, reset);
     if (e != 0) return e;
     if (host_error_word != nullptr) *host_error_word = (void*)g_persist_host_word;
     return 0;

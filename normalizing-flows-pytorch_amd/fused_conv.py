@@ -41,6 +41,21 @@ class SlabSumDesc(ctypes.Structure):
                 ('n_slabs', ctypes.c_int), ('accumulate', ctypes.c_int), ('taps', ctypes.c_int), ('reserved', ctypes.c_int)]
 
 
+class ConvNetDesc(ctypes.Structure):
+    """nf_convnet_desc of include/nfhip.h (csrc/conv_chain.hip: the whole conditioner in one persistent launch)"""
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p * 6), ('b', ctypes.c_void_p * 6), ('gamma', ctypes.c_void_p * 5),
+                ('beta', ctypes.c_void_p * 5), ('rmean', ctypes.c_void_p * 5), ('rvar', ctypes.c_void_p * 5),
+                ('nbt', ctypes.c_void_p * 5), ('acts', ctypes.c_void_p * 5), ('out', ctypes.c_void_p),
+                ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('ws_zero', ctypes.c_void_p)]
+
+
+CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
+
+
+def _chain_usable(B, I0, O_out, Hh, Ww):
+    return CONV_CHAIN_ON and bool(N.load().nf_convnet_chain_usable(B, I0, O_out, Hh, Ww))
+
+
 def _fwd(shape, I, O, k, training, **kw):
     B, Hh, Ww = shape
     d = _desc(ConvDesc, **kw)
@@ -204,13 +219,28 @@ class _FusedConvNet(torch.autograd.Function):
         def stats(j):                             # evaluation mode normalises with running statistics: no batch sums
             return dict(stat_sum=ws[j, 0], stat_sqsum=ws[j, R]) if training else {}
 
-        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], **stats(0))
-        for j in range(1, nb):                    # convolution j consumes acts[j-1] through BatchNorm j-1
-            res = acts[j - 2] if j % 2 == 0 else None
-            _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j],
-                 **stats(j), **bn_kw(j - 1))
-        _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
-             **bn_kw(nb - 1))
+        if _chain_usable(B, I0, O_out, Hh, Ww):   # the whole conditioner: ONE persistent launch (csrc/conv_chain.hip)
+            d = ConvNetDesc()
+            d.x = x.data_ptr()
+            for i in range(nl):
+                d.w[i], d.b[i] = w[i].data_ptr(), conv[i][1].data_ptr()
+            for j in range(nb):
+                g_, b_, rm, rv, nbt = bns[j]
+                d.gamma[j], d.beta[j], d.rmean[j], d.rvar[j] = g_.data_ptr(), b_.data_ptr(), rm.data_ptr(), rv.data_ptr()
+                d.nbt[j] = nbt.data_ptr() if nbt is not None else None
+                d.acts[j] = acts[j].data_ptr()
+                d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
+            d.out = out.data_ptr()
+            d.ws_zero = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev).data_ptr() if training else None
+            N.call('nf_convnet_chain_fwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), BN_EPS, BN_MOMENTUM, N.stream())
+        else:
+            _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], **stats(0))
+            for j in range(1, nb):                # convolution j consumes acts[j-1] through BatchNorm j-1
+                res = acts[j - 2] if j % 2 == 0 else None
+                _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j],
+                     **stats(j), **bn_kw(j - 1))
+            _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
+                 **bn_kw(nb - 1))
         ctx.save_for_backward(x, ws, *acts, *w, *[t for b in bns for t in b[:2]])
         ctx.meta = (shape, I0, O_out, bool(training))
         from .functional import _sinks

@@ -1,0 +1,48 @@
+"""phase stamps of workgroup 0 of the persistent ConvNet kernel (csrc/conv_chain.hip built with -DNF_CC_PROF=1 into build/).
+   python tools/probes/chain_prof.py --build ;  python tools/probes/chain_prof.py I O H W [B]"""
+import ctypes, importlib, os, subprocess, sys
+import torch
+sys.path.insert(0, '.')
+pkg = importlib.import_module('normalizing-flows-pytorch_amd')
+N = importlib.import_module('normalizing-flows-pytorch_amd._native')
+cond = importlib.import_module('normalizing-flows-pytorch_amd.conditioners')
+here = os.path.dirname(os.path.abspath(pkg.__file__))
+lib_path = os.path.join(here, 'build', 'libccprof.so')
+if '--build' in sys.argv:
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on',
+                           '-DNF_CC_PROF=1', '-shared', '-o', lib_path, os.path.join(here, 'csrc', 'conv_chain.hip')])
+    print('built', lib_path)
+    sys.exit(0)
+prof = ctypes.CDLL(lib_path)
+real = N.load()
+for name in ('nf_convnet_chain_fwd', 'nf_convnet_chain_usable'):
+    fn = getattr(real, name)
+    pf = getattr(prof, name)
+    pf.argtypes, pf.restype = fn.argtypes, fn.restype
+    setattr(real, name, pf)
+I, O, H, W = [int(v) for v in sys.argv[1:5]]
+B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+net = cond.ConvNet(I, O).cuda().train()
+net.fused = True
+x = torch.randn(B, I, H, W, device='cuda')
+with torch.no_grad():
+    for _ in range(3):
+        y = net(x)
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 64)()
+prof.nf_cc_prof_read(buf)
+t = [v / 100.0 for v in buf]   # us
+print('B %d  %d -> %d  %d x %d   total %.1f us: zero+conv0 %.1f' % (B, I, O, H, W, t[51] - t[0], t[1] - t[0]))
+for l in range(5):
+    o = 8 * l
+    print('  layer %d: wait/sync %.1f | k-split %.1f | finish+tile stats %.1f | grid exchange %.1f | consts %.1f | normalise+weights %.1f | K loop %.1f'
+          % (l, t[2 + o] - (t[1] if l == 0 else t[8 + o - 8]), t[3 + o] - t[2 + o], t[4 + o] - t[3 + o], t[5 + o] - t[4 + o], t[6 + o] - t[5 + o],
+             (t[7 + o] - t[6 + o]) if l < 4 else 0.0, (t[8 + o] - t[7 + o]) if l < 4 else 0.0))
+print('  1x1 out conv %.1f' % (t[51] - t[50]))
+print('  exchange of layer 1: sync %.1f | combine+publish %.1f | poll %.1f | sync %.1f | merge %.1f' % (
+    t[56] - t[12], t[57] - t[56], t[58] - t[57], t[59] - t[58], t[13] - t[59]))
+arr = (ctypes.c_longlong * 128)()
+prof.nf_cc_arrive_read(arr)
+G = (B * H * W + (255 if H * W >= 256 else 127)) // (256 if H * W >= 256 else 128)
+a = [arr[i] / 100.0 for i in range(G)]
+print('  arrival of the workgroups at the poll of layer 1, us after the first: ' + ' '.join('%.1f' % (v - min(a)) for v in a))
