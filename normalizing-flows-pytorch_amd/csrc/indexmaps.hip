@@ -35,12 +35,106 @@ __global__ void __launch_bounds__(NF_BLOCK) k_space_depth(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Vectorised image variants (W % 4 == 0, 16-byte aligned bases).  A thread owns ONE float4 of a row (c, y) of the FULL tensor:
+// its even-x components belong to squeezed channel k0 = 4 c + 2 (y & 1), the odd-x ones to k0 + 1 (squeeze.py:36-41, :90-92),
+// and the two elements of a parity are consecutive columns j = 2 x4, 2 x4 + 1 of the squeezed / half tensor: one float2.
+// So the full tensor is always touched in whole 16-byte vectors and the half / squeezed one in 8-byte pairs that consecutive
+// threads lay end to end.  Same maps as nf_half_to_full / nf_squeezed_to_full (the bit-exact tests cover both paths).
+// ---------------------------------------------------------------------------------------------------------------
+#define NF_IVSLAB 1024
+__device__ __forceinline__ void nf_ck_sel(const NfSplit& s, int k, int i, int j0, int& which, int& e) {
+    const int q = k / s.C;
+    const int sel = (q == 1 || q == 2) ? 1 : 0;
+    const int m = sel ? k - s.C : (q == 0 ? k : k - 2 * s.C);
+    which = sel ^ s.odd;
+    e = (m * s.h + i) * s.w + j0;
+}
+
+// MODE 0: gather half `which` (rows that hold none of it are not read); 1: scatter half `which`, zeros elsewhere
+template <int MODE, bool CHECKER>
+__global__ void __launch_bounds__(NF_BLOCK) k_half_move_v4(const float* __restrict__ src, float* __restrict__ dst, NfSplit s, int which) {
+    const int64_t b = blockIdx.x;
+    const int n4 = s.n_full >> 2, W4 = s.W >> 2, h4 = s.n_half >> 2;
+    const float* full_r = src + b * s.n_full;            // MODE 0: source is the full tensor
+    float* full_w = dst + b * s.n_full;                  // MODE 1: destination is the full tensor
+    const float* half_r = src + b * s.n_half;
+    float* half_w = dst + b * s.n_half;
+    const int v1 = min((int)(blockIdx.y + 1) * NF_IVSLAB, n4);
+    for (int v = blockIdx.y * NF_IVSLAB + threadIdx.x; v < v1; v += NF_BLOCK) {
+        if (!CHECKER) {
+            const int sel = v >= h4 ? 1 : 0;
+            const bool mine = (sel ^ s.odd) == which;
+            const int e4 = v - sel * h4;
+            if (MODE == 0) {
+                if (mine) reinterpret_cast<float4*>(half_w)[e4] = reinterpret_cast<const float4*>(full_r)[v];
+            } else {
+                reinterpret_cast<float4*>(full_w)[v] = mine ? reinterpret_cast<const float4*>(half_r)[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int r = v / W4, x4 = v - r * W4;
+            const int cc = r / s.H, yy = r - cc * s.H;
+            const int k0 = 4 * cc + 2 * (yy & 1);
+            int w0, e0, w1, e1;
+            nf_ck_sel(s, k0, yy >> 1, 2 * x4, w0, e0);
+            nf_ck_sel(s, k0 + 1, yy >> 1, 2 * x4, w1, e1);
+            if (MODE == 0) {
+                if (w0 == which || w1 == which) {
+                    const float4 zv = reinterpret_cast<const float4*>(full_r)[v];
+                    if (w0 == which) *reinterpret_cast<float2*>(half_w + e0) = make_float2(zv.x, zv.z);
+                    if (w1 == which) *reinterpret_cast<float2*>(half_w + e1) = make_float2(zv.y, zv.w);
+                }
+            } else {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (w0 == which) { const float2 t = *reinterpret_cast<const float2*>(half_r + e0); o.x = t.x; o.z = t.y; }
+                if (w1 == which) { const float2 t = *reinterpret_cast<const float2*>(half_r + e1); o.y = t.x; o.w = t.y; }
+                reinterpret_cast<float4*>(full_w)[v] = o;
+            }
+        }
+    }
+}
+
+// space-to-depth: `full` is (C, H, W), `deep` is (4 C, H / 2, W / 2) with channel k = 4 c + 2 dy + dx
+template <bool TO_DEPTH>
+__global__ void __launch_bounds__(NF_BLOCK) k_space_depth_v4(const float* __restrict__ in, float* __restrict__ out, int H, int W, int n) {
+    const int64_t b = blockIdx.x;
+    const int n4 = n >> 2, W4 = W >> 2, h = H >> 1, w = W >> 1;
+    const float* ib = in + b * n;
+    float* ob = out + b * n;
+    const int v1 = min((int)(blockIdx.y + 1) * NF_IVSLAB, n4);
+    for (int v = blockIdx.y * NF_IVSLAB + threadIdx.x; v < v1; v += NF_BLOCK) {
+        const int r = v / W4, x4 = v - r * W4;
+        const int cc = r / H, yy = r - cc * H;
+        const int k0 = 4 * cc + 2 * (yy & 1);
+        const int e0 = (k0 * h + (yy >> 1)) * w + 2 * x4, e1 = e0 + h * w;        // channel k0 + 1 is one plane further
+        if (TO_DEPTH) {
+            const float4 zv = reinterpret_cast<const float4*>(ib)[v];
+            *reinterpret_cast<float2*>(ob + e0) = make_float2(zv.x, zv.z);
+            *reinterpret_cast<float2*>(ob + e1) = make_float2(zv.y, zv.w);
+        } else {
+            const float2 a = *reinterpret_cast<const float2*>(ib + e0), c2 = *reinterpret_cast<const float2*>(ib + e1);
+            reinterpret_cast<float4*>(ob)[v] = make_float4(a.x, c2.x, a.y, c2.y);
+        }
+    }
+}
+
+static inline bool nf_iv_ok(const void* a, const void* b2, int W, int n_full, int n_half, int64_t B) {
+    return (((uintptr_t)a | (uintptr_t)b2) & 15) == 0 && W % 4 == 0 && n_half % 4 == 0 && n_full < (1 << 30) && B <= 0x7fffffffLL;
+}
+
 extern "C" int nf_half_gather(const float* z, float* half, int which, int mode, int odd, int64_t B, int C, int H,
                               int W, nf_stream_t stream) {
     NfSplit s;
     if (!nf_make_split(s, mode, odd, C, H, W) || mode == NF_SPLIT_NONE || (which & ~1)) return NF_E_BADARG;
     const int64_t total = B * s.n_half;
     if (total == 0) return 0;
+    if ((mode == NF_SPLIT_CHANNEL || mode == NF_SPLIT_CHECKER) && nf_iv_ok(z, half, W, s.n_full, s.n_half, B)) {
+        dim3 grid((unsigned)B, (unsigned)((s.n_full / 4 + NF_IVSLAB - 1) / NF_IVSLAB));
+        if (mode == NF_SPLIT_CHECKER) hipLaunchKernelGGL((k_half_move_v4<0, true>), grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, z, half, s, which);
+        else hipLaunchKernelGGL((k_half_move_v4<0, false>), grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, z, half, s, which);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_half_gather, dim3(nf_grid_for(total)), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, half, s,
                        which, total);
     NF_CHECK_LAUNCH();
@@ -53,6 +147,13 @@ extern "C" int nf_half_scatter(const float* half, float* full, int which, int mo
     if (!nf_make_split(s, mode, odd, C, H, W) || mode == NF_SPLIT_NONE || (which & ~1)) return NF_E_BADARG;
     const int64_t total = B * s.n_half;
     if (total == 0) return 0;
+    if ((mode == NF_SPLIT_CHANNEL || mode == NF_SPLIT_CHECKER) && nf_iv_ok(half, full, W, s.n_full, s.n_half, B)) {
+        dim3 grid((unsigned)B, (unsigned)((s.n_full / 4 + NF_IVSLAB - 1) / NF_IVSLAB));
+        if (mode == NF_SPLIT_CHECKER) hipLaunchKernelGGL((k_half_move_v4<1, true>), grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, half, full, s, which);
+        else hipLaunchKernelGGL((k_half_move_v4<1, false>), grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, half, full, s, which);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_half_scatter, dim3(nf_grid_for(total)), dim3(NF_BLOCK), 0, (hipStream_t)stream, half, full, s,
                        which, total);
     NF_CHECK_LAUNCH();
@@ -64,6 +165,12 @@ extern "C" int nf_squeeze2d(const float* z, float* out, int64_t B, int C, int H,
     const int n = C * H * W;
     const int64_t total = B * n;
     if (total == 0) return 0;
+    if (nf_iv_ok(z, out, W, n, 4, B)) {
+        dim3 grid((unsigned)B, (unsigned)((n / 4 + NF_IVSLAB - 1) / NF_IVSLAB));
+        hipLaunchKernelGGL(k_space_depth_v4<true>, grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, z, out, H, W, n);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_space_depth<true>, dim3(nf_grid_for(total)), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, out, H,
                        W, n, total);
     NF_CHECK_LAUNCH();
@@ -75,6 +182,12 @@ extern "C" int nf_unsqueeze2d(const float* z, float* out, int64_t B, int C, int 
     const int n = C * H * W;
     const int64_t total = B * n;
     if (total == 0) return 0;
+    if (nf_iv_ok(z, out, W, n, 4, B)) {
+        dim3 grid((unsigned)B, (unsigned)((n / 4 + NF_IVSLAB - 1) / NF_IVSLAB));
+        hipLaunchKernelGGL(k_space_depth_v4<false>, grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, z, out, H, W, n);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_space_depth<false>, dim3(nf_grid_for(total)), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, out,
                        H, W, n, total);
     NF_CHECK_LAUNCH();
