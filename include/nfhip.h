@@ -788,6 +788,13 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
                        int64_t x_row_stride, int x_col_stride, int64_t gx_row_stride, int gx_col_stride, int gx_accumulate,
                        int64_t N, int I0, int O, nf_stream_t stream);
 
+/* ---- on-device synthetic batches (csrc/datagen.hip)  flows/dataset.py:13-34, :120; replaces the per-step H2D copy main.py:79 --
+ * kind 0 moons, 1 circles, 2 normals: out (n, 2), per_sample = 2;  3 cifar-like uniform uint8 / 255: out (n, per_sample).
+ * Counter-based Philox4x32-10 keyed by (seed, *step, sample): stateless and reproducible; `step` (device int64, NULL = 0) is read
+ * by the kernel, so a captured graph draws a fresh batch per replay once nf_sample_advance (step += 1) follows it.             */
+int nf_sample_data(int kind, float* out, int64_t n, int per_sample, int64_t seed, const int64_t* step, nf_stream_t stream);
+int nf_sample_advance(int64_t* step, nf_stream_t stream);
+
 /* ---- NLL of the training harness  main.py:49-51, :85 -------------------------------------------------------------
  * loss[0] += -(1/B) * sum_b ( -0.5*|z_b|^2 - 0.5*D*log(2 pi) + ld[b] )   (caller zero-fills loss)            */
 int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream);

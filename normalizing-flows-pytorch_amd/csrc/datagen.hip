@@ -1,0 +1,95 @@
+// On-device synthetic data of the benchmark configurations: the reference builds its toy sets on the host with
+// sklearn / numpy (flows/dataset.py:13-34) and copies every batch to the device (main.py:79).  Here a batch is drawn where it is
+// consumed: a counter-based Philox4x32-10 stream keyed by (seed, step, sample) -- stateless, so the same (seed, step) always
+// gives the same batch, and a captured hipGraph draws a FRESH batch on every replay because `step` is read from device memory
+// (nf_sample_advance bumps it).  Same distributions as normalizing-flows-pytorch_amd/data.py (the host restatement the tests
+// compare against, distribution-level):
+//   moons   two half circles (sklearn make_moons geometry), gaussian noise 0.08, then (x - 0.5) / 2        dataset.py:18-21
+//   circles radii 1 and 0.5, noise 0.08, times 0.6                                                      dataset.py:13-15
+//   normals 8 gaussians (sigma 0.1) on a circle of radius 0.7                                           dataset.py:24-34
+//   cifar   uniform uint8 pixels / 255 (the reference feeds uint8 / 255 without dequantisation noise)   dataset.py:120
+#include "nf_common.h"
+
+struct NfPhilox { unsigned c[4]; };
+__device__ __forceinline__ NfPhilox nf_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    NfPhilox o;
+    o.c[0] = c0; o.c[1] = c1; o.c[2] = c2; o.c[3] = c3;
+    return o;
+}
+__device__ __forceinline__ float nf_u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f); }   // (0, 1)
+__device__ __forceinline__ void nf_box_muller(unsigned a, unsigned b, float& n0, float& n1) {
+    const float r = sqrtf(-2.f * logf(nf_u01(a))), t = 6.283185307179586f * nf_u01(b);
+    n0 = r * cosf(t);
+    n1 = r * sinf(t);
+}
+
+// kind 0 moons, 1 circles, 2 normals: out (n, 2);  kind 3 cifar: out (n, per) with per = C * H * W values per sample
+__global__ void __launch_bounds__(NF_BLOCK) k_sample_data(int kind, float* __restrict__ out, int64_t n, int per, unsigned seed_lo,
+                                                          unsigned seed_hi, const int64_t* __restrict__ step_ptr) {
+    const unsigned long long step = step_ptr != nullptr ? (unsigned long long)step_ptr[0] : 0ull;
+    const unsigned s_lo = (unsigned)step, s_hi = (unsigned)(step >> 32);
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    if (kind == 3) {
+        const int64_t total4 = (n * per + 3) / 4;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += gstride) {
+            const NfPhilox r = nf_philox((unsigned)t, (unsigned)(t >> 32), s_lo, s_hi, seed_lo, seed_hi ^ 0x3c6ef372u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * t + j < n * per) out[4 * t + j] = (float)(r.c[j] >> 24) * (1.f / 255.f);
+        }
+        return;
+    }
+    const int64_t n_out = n / 2, n_in = n - n_out;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+        const NfPhilox r = nf_philox((unsigned)i, (unsigned)(i >> 32), s_lo, s_hi, seed_lo, seed_hi);
+        float g0, g1;
+        nf_box_muller(r.c[0], r.c[1], g0, g1);
+        float x, y;
+        if (kind == 2) {                                  // eight gaussians
+            const float a = 0.7853981633974483f * (float)(r.c[2] >> 29);
+            x = 0.7f * cosf(a) + 0.1f * g0;
+            y = 0.7f * sinf(a) + 0.1f * g1;
+        } else {
+            const bool outer = i < n_out;                 // the host version shuffles the points; a batch is exchangeable either way
+            const int64_t m = outer ? n_out : n_in;
+            const int64_t k = (int64_t)(nf_u01(r.c[2]) * (float)m);
+            if (kind == 0) {                              // linspace(0, pi, m)
+                const float t = m > 1 ? 3.141592653589793f * (float)k / (float)(m - 1) : 0.f;
+                const float px = outer ? cosf(t) : 1.f - cosf(t), py = outer ? sinf(t) : 1.f - sinf(t) - 0.5f;
+                x = ((px + 0.08f * g0) - 0.5f) * 0.5f;
+                y = ((py + 0.08f * g1) - 0.5f) * 0.5f;
+            } else {                                      // linspace(0, 2 pi, m, endpoint = False)
+                const float t = 6.283185307179586f * (float)k / (float)m, f = outer ? 1.f : 0.5f;
+                x = (cosf(t) * f + 0.08f * g0) * 0.6f;
+                y = (sinf(t) * f + 0.08f * g1) * 0.6f;
+            }
+        }
+        out[2 * i] = x;
+        out[2 * i + 1] = y;
+    }
+}
+__global__ void k_sample_advance(int64_t* step) { step[0] += 1; }
+
+extern "C" int nf_sample_data(int kind, float* out, int64_t n, int per_sample, int64_t seed, const int64_t* step, nf_stream_t stream) {
+    if (kind < 0 || kind > 3 || n < 0 || (kind == 3 ? per_sample < 1 : per_sample != 2)) return NF_E_BADARG;
+    if (n == 0) return 0;
+    const int64_t work = kind == 3 ? (n * per_sample + 3) / 4 : n;
+    hipLaunchKernelGGL(k_sample_data, dim3(nf_grid_for(work)), dim3(NF_BLOCK), 0, (hipStream_t)stream, kind, out, n, per_sample,
+                       (unsigned)seed, (unsigned)((unsigned long long)seed >> 32), step);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int nf_sample_advance(int64_t* step, nf_stream_t stream) {
+    if (step == nullptr) return NF_E_BADARG;
+    hipLaunchKernelGGL(k_sample_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

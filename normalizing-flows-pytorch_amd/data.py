@@ -54,3 +54,37 @@ GENERATORS = {'moons': moons, 'circles': circles, 'normals': normals, 'cifar': c
 
 def sample(name, n, seed):
     return torch.from_numpy(GENERATORS[name](n, np.random.default_rng(seed)))
+
+
+# ---- on-device generation (csrc/datagen.hip): same distributions, drawn where they are consumed --------------------------------------
+KINDS = {'moons': 0, 'circles': 1, 'normals': 2, 'cifar': 3}
+
+
+class DeviceSampler:
+    """A stream of synthetic batches generated ON the GPU: ``next()`` fills (and returns) one static tensor with a fresh batch.
+    The step counter lives in device memory and the draw is a pure function of (seed, step, sample index), so the two launches
+    can be captured into a hipGraph (FlowTrainer(sampler=...)): every replay trains on a new batch without any host-to-device
+    copy -- the reference copies each batch from the host (main.py:79)."""
+
+    def __init__(self, name, batch, dims, seed=0, device='cuda'):
+        import torch as _t
+        from . import _native as N
+        self._N = N
+        self.kind = KINDS[name]
+        self.batch = int(batch)
+        self.dims = tuple(dims)
+        per = 1
+        for d_ in self.dims:
+            per *= int(d_)
+        if self.kind != 3 and per != 2:
+            raise ValueError('%s is a 2-D data set' % name)
+        self.per = per
+        self.seed = int(seed)
+        self.out = _t.empty((self.batch, ) + self.dims, dtype=_t.float32, device=device)
+        self.step = _t.zeros(1, dtype=_t.int64, device=device)
+
+    def next(self):
+        N = self._N
+        N.call('nf_sample_data', self.kind, self.out.data_ptr(), self.batch, self.per, self.seed, self.step.data_ptr(), N.stream())
+        N.call('nf_sample_advance', self.step.data_ptr(), N.stream())
+        return self.out

@@ -83,8 +83,9 @@ class FlowTrainer:
     The call that captures also takes one extra eager step on its batch (allocator warm-up on the capture stream)."""
 
     def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None,
-                 fused_adam=True):
+                 fused_adam=True, sampler=None):
         self.net = net
+        self.sampler = sampler      # data.DeviceSampler: train_on_batch() without a batch draws one on the device, inside the graph
         on_gpu = next(net.parameters()).is_cuda
         fused_adam = bool(fused_adam) and on_gpu
         self.bucket = nfdist.GradBucket(net.parameters(), process_group, flatten_params=fused_adam)
@@ -107,6 +108,8 @@ class FlowTrainer:
 
     # -- one step, eager --------------------------------------------------------------------------------------------
     def _forward_backward(self, y):
+        if y is None:                                   # on-device data: the draw is part of the step (and of its hipGraph)
+            y = self.sampler.next()
         return self._run_step(y.device, lambda: self._forward_loss(y))
 
     def _forward_loss(self, y):
@@ -165,7 +168,7 @@ class FlowTrainer:
             N.call('nf_multi_copy', ctypes.addressof(arr), len(chunk), N.stream())
 
     def _capture(self, y):
-        self._static_y = y.clone()
+        self._static_y = y.clone() if y is not None else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                   # one more eager step on the side stream (capture etiquette)
@@ -189,12 +192,14 @@ class FlowTrainer:
                 self.optim.step()
         self._g_fb, self._g_opt = g_fb, g_opt
 
-    def train_on_batch(self, y):
+    def train_on_batch(self, y=None):
         """returns (z, loss) like main.py:78-92; with graph=True the returned tensors are the graph's static outputs.
         Raises _native.PersistentKernelTimeout as soon as the host sees that a persistent kernel of an EARLIER launch gave up on
         a grid exchange (sticky pinned error word, no synchronisation: at most one step late)."""
         from . import _native as N
-        if y.is_cuda:
+        if y is None and self.sampler is None:
+            raise ValueError('train_on_batch() without a batch needs FlowTrainer(..., sampler=data.DeviceSampler(...))')
+        if y is None or y.is_cuda:
             N.check_persistent()
         self.net.train()
         if self.graph and self._g_fb is None and self._eager_steps >= self.warmup:
@@ -209,7 +214,8 @@ class FlowTrainer:
         if self._g_fb is not None:
             if not self._replicas_synced:               # warmup=0: no eager step ran before the capture
                 self._sync_replicas_after_first_step()
-            self._static_y.copy_(y, non_blocking=True)
+            if self._static_y is not None:
+                self._static_y.copy_(y, non_blocking=True)
             self._g_fb.replay()
             if self._g_opt is not None:
                 self.bucket.all_reduce_mean_()
