@@ -498,6 +498,21 @@ int nf_spectral_weights(const float* const* W_bar, float* const* u, float* const
                         const int* cols, int n_mats, float coeff, float eps, const int* flags, int iteration,
                         nf_stream_t stream);
 
+/* Training backward of the block (iresblock.py:84-109, :112-185): gradients of  <d_g, g(x)> + d_ld[0] * s^T J v  with
+ * s = v + sum_{k <= n_terms} coef[k-1] (J^T)^k v held constant (the Neumann-series gradient estimator; v = noise (B, D), coef
+ * from the host's Russian-roulette draw), second derivatives of the LipSwish network in closed form.  d_x (B, D) = gradient of
+ * x through g and the surrogate (the residual connection's identity term is the caller's); g_params, ZERO at launch, receives
+ * the gradients of the EFFECTIVE parameters: W1 (32 x D) | b1 (32) | W2 (32 x 32) | b2 (32) | W3 (D x 32) | b3 (D) | beta1 | beta2.
+ * nf_spectral_weights_bwd maps gradients of effective weights to the stored ones (spectral_norm.py:36-43, u / v constant),
+ * ACCUMULATING into g_W_bar.                                                                                                */
+int nf_resmlp_train_bwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                        const float* b3, const float* beta1, const float* beta2, const float* noise, const float* coef,
+                        int n_terms, const float* d_g, const float* d_ld, float* d_x, float* g_params, int64_t B, int D,
+                        nf_stream_t stream);
+int nf_spectral_weights_bwd(const float* const* W_bar, const float* const* u, const float* const* v,
+                            const float* const* g_W_eff, float* const* g_W_bar, const int* rows, const int* cols, int n_mats,
+                            float coeff, float eps, nf_stream_t stream);
+
 /* ---- weight normalisation of many layers per launch  flows/weight_norm.py:35-41 ----------------------------------------
  * w[o, m] = v[o, m] * g[m] / (||v[:, m]|| + eps), m = (input channel, ky, kx) flattened, O = output channels.
  * forward writes w; backward writes (accumulate = 0) or adds to (1) g_v, g_g from g_w.  <= NF_WN_MAX_LAYERS layers per call. */

@@ -290,3 +290,283 @@ extern "C" int nf_spectral_weights(const float* const* W_bar, float* const* u, f
     NF_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// TRAINING backward of the block (iresblock.py:84-109 Neumann gradient estimator, :112-185 memory-saving autograd Function).
+// The reference differentiates, per block and step,
+//     L  =  < dL/dg , g(x) >  +  c * S(x, theta),      S = s^T J(x, theta) v,   s = v + sum_k coef_k (J^T)^k v  (held constant),
+// where c is the upstream gradient of the log-det taken from the FIRST sample (iresblock.py:166) and v the Hutchinson noise:
+// S needs second derivatives of g, which nested autograd sweeps provide there.  For the 2 -> 32 -> 32 -> 2 LipSwish network they
+// are closed form.  With h1 = W1 x + b1, a1 = phi(h1), h2 = W2 a1 + b2, a = W1 v, p1 = phi'(h1) a, q = W2 p1, p2 = phi'(h2) q:
+//     S = (W3^T s) . p2,   and with r3 = W3^T s, g3 = W3^T dL/dg the combined signals are
+//     GQ  = c r3 phi'(h2)                                  (gradient of q)
+//     GH2 = g3 phi'(h2) + c r3 phi''(h2) q                 (gradient of h2)
+//     GP1 = W2^T GQ,  GA1 = W2^T GH2,  GH1 = GA1 phi'(h1) + GP1 phi''(h1) a   (gradient of h1)
+//     dW3 = dL/dg a2^T + c s p2^T,  dW2 = GQ p1^T + GH2 a1^T,  db2 = GH2,  dW1 = GH1 x^T + (GP1 phi'(h1)) v^T,  db1 = GH1,  db3 = dL/dg,
+//     dx = W1^T GH1  (the residual connection's identity term is added by the caller), and the two LipSwish slopes beta get
+//     dbeta2 = sum g3 dphi/dbeta(h2) + c r3 q dphi'/dbeta(h2),   dbeta1 = sum GA1 dphi/dbeta(h1) + GP1 a dphi'/dbeta(h1).
+// Work decomposition: lane = (sample slot, hidden unit): a wave works on TWO samples at a time, every per-unit quantity is one
+// register, matrix-vector products read the other units' values as LDS broadcasts; a lane accumulates ITS row of dW2 (32
+// registers) and its entries of the other gradients over all the samples of its wave, and the block adds its totals to the
+// (zeroed) output with one atomic per entry.
+struct NfLipD { float f, d1, d2, db, d1b; };              // phi, phi', phi'', dphi/dbeta, dphi'/dbeta
+__device__ __forceinline__ NfLipD nf_lipswish_all(float h, float beta) {
+    const float u = beta * h;
+    const float s = 1.f / (1.f + expf(-u));
+    const float sp = s * (1.f - s), spp = sp * (1.f - 2.f * s);
+    const float k = 1.f / 1.1f;
+    NfLipD r;
+    r.f = h * s * k;
+    r.d1 = (s + u * sp) * k;
+    r.d2 = (2.f * beta * sp + beta * u * spp) * k;
+    r.db = h * h * sp * k;
+    r.d1b = h * (2.f * sp + u * spp) * k;
+    return r;
+}
+__device__ __forceinline__ float nf_half_allsum(float v) {     // sum over the 32 lanes of a wave half, result in every lane
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, NF_WAVE);
+    return v;
+}
+
+#define NF_RT_WAVES 4
+#define NF_RT_THREADS (NF_RT_WAVES * NF_WAVE)
+// g_out layout: W1 (32 x D) | b1 (32) | W2 (32 x 32) | b2 (32) | W3 (D x 32) | b3 (D) | beta1 | beta2
+template <int D>
+__global__ void __launch_bounds__(NF_RT_THREADS) k_resmlp_train_bwd(NfResW w, const float* __restrict__ x, const float* __restrict__ vn,
+                                                                    const float* __restrict__ coef, int n_terms,
+                                                                    const float* __restrict__ d_g, const float* __restrict__ d_ld,
+                                                                    float* __restrict__ d_x, float* __restrict__ g_out, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    nf_res_stage<D>(w, sm);
+    const float* W1 = sm;
+    const float* b1 = W1 + NF_RES_H * D;
+    const float* W2 = b1 + NF_RES_H;
+    const float* b2 = W2 + NF_RES_H * (NF_RES_H + 1);
+    const float* W3 = b2 + NF_RES_H;
+    float* xb = sm + NF_RES_LDS(D) / sizeof(float);          // per (wave, slot): a1[32] | p1[32] | t1[D][32] | GQ[32] | GH2[32]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, slot = lane >> 5, u = lane & 31;
+    constexpr int PER = (4 + D) * NF_RES_H;
+    float* my = xb + (wid * 2 + slot) * PER;
+    float* A1 = my;
+    float* P1 = my + NF_RES_H;
+    float* T1 = my + 2 * NF_RES_H;
+    float* GQl = my + (2 + D) * NF_RES_H;
+    float* GHl = my + (3 + D) * NF_RES_H;
+    const float beta1 = w.beta1[0], beta2 = w.beta2[0], cs = d_ld[0];
+
+    float accW2[NF_RES_H], accW1[D], accW3[D], acc_b1 = 0.f, acc_b2 = 0.f, acc_be1 = 0.f, acc_be2 = 0.f, acc_b3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF_RES_H; ++i) accW2[i] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { accW1[d] = 0.f; accW3[d] = 0.f; }
+
+    const int64_t pairs = (B + 1) / 2;
+    for (int64_t pr = (int64_t)blockIdx.x * NF_RT_WAVES + wid; pr < pairs; pr += (int64_t)gridDim.x * NF_RT_WAVES) {
+        const int64_t b = 2 * pr + slot;
+        const bool ok = b < B;
+        float xv[D], vv[D], dg[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            xv[d] = ok ? x[b * D + d] : 0.f;
+            vv[d] = ok ? vn[b * D + d] : 0.f;
+            dg[d] = ok ? d_g[b * D + d] : 0.f;
+        }
+        // ---- layer 1 (lane = unit u) --------------------------------------------------------------------------------------
+        float h1 = b1[u], aV = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { h1 = fmaf(W1[u * D + d], xv[d], h1); aV = fmaf(W1[u * D + d], vv[d], aV); }
+        const NfLipD l1 = nf_lipswish_all(h1, beta1);
+        const float p1 = l1.d1 * aV;
+        A1[u] = l1.f;
+        P1[u] = p1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) T1[d * NF_RES_H + u] = l1.d1 * W1[u * D + d];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- layer 2 (lane = unit u): h2, q, Jacobian row pieces -----------------------------------------------------------------
+        float h2 = b2[u], q = 0.f, jt[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) jt[d] = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < NF_RES_H; ++i) {
+            const float wv = W2[u * (NF_RES_H + 1) + i];
+            h2 = fmaf(wv, A1[i], h2);
+            q = fmaf(wv, P1[i], q);
+#pragma unroll
+            for (int d = 0; d < D; ++d) jt[d] = fmaf(wv, T1[d * NF_RES_H + i], jt[d]);
+        }
+        const NfLipD l2 = nf_lipswish_all(h2, beta2);
+        float J[D][D];
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int d = 0; d < D; ++d) J[r][d] = nf_half_allsum(W3[r * NF_RES_H + u] * l2.d1 * jt[d]);
+        // ---- s = v + sum_k coef_k (J^T)^k v  (every lane, D x D) ----------------------------------------------------------------------
+        float sv[D], wv2[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { sv[d] = vv[d]; wv2[d] = vv[d]; }
+        for (int k = 1; k <= n_terms; ++k) {
+            float nw[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < D; ++r) a = fmaf(J[r][c], wv2[r], a);
+                nw[c] = a;
+            }
+            const float ck = coef[k - 1];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { wv2[d] = nw[d]; sv[d] = fmaf(ck, nw[d], sv[d]); }
+        }
+        // ---- signals of layer 2 ------------------------------------------------------------------------------------------------------
+        float r3 = 0.f, g3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < D; ++r) { r3 = fmaf(W3[r * NF_RES_H + u], sv[r], r3); g3 = fmaf(W3[r * NF_RES_H + u], dg[r], g3); }
+        const float p2 = l2.d1 * q;
+        const float GQ = ok ? cs * r3 * l2.d1 : 0.f;
+        const float GH2 = ok ? fmaf(cs * r3 * l2.d2, q, g3 * l2.d1) : 0.f;
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < D; ++r) accW3[r] += fmaf(cs * sv[r], p2, dg[r] * l2.f);
+            acc_b2 += GH2;
+            acc_be2 += fmaf(cs * r3 * q, l2.d1b, g3 * l2.db);
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (u == d) acc_b3 += dg[d];
+        }
+#pragma unroll 8
+        for (int i = 0; i < NF_RES_H; ++i) accW2[i] += fmaf(GQ, P1[i], GH2 * A1[i]);
+        GQl[u] = GQ;
+        GHl[u] = GH2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- back to layer 1 (lane = unit u): W2^T products walk a COLUMN of W2 (row stride 33: conflict-free) --------------------------
+        float gp1 = 0.f, ga1 = 0.f;
+#pragma unroll 8
+        for (int o = 0; o < NF_RES_H; ++o) {
+            const float wv = W2[o * (NF_RES_H + 1) + u];
+            gp1 = fmaf(wv, GQl[o], gp1);
+            ga1 = fmaf(wv, GHl[o], ga1);
+        }
+        const float GH1 = fmaf(gp1 * l1.d2, aV, ga1 * l1.d1);
+        if (ok) {
+            acc_b1 += GH1;
+            acc_be1 += fmaf(gp1 * aV, l1.d1b, ga1 * l1.db);
+#pragma unroll
+            for (int d = 0; d < D; ++d) accW1[d] += fmaf(gp1 * l1.d1, vv[d], GH1 * xv[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float dx = nf_half_allsum(W1[u * D + d] * GH1);
+            if (ok && u == 0) d_x[b * D + d] = dx;
+        }
+        __builtin_amdgcn_wave_barrier();                  // the slot buffers are rewritten by the next pair
+    }
+    // ---- totals: the two slots of a wave, then one atomic per entry and wave ------------------------------------------------------------
+    float* gW1 = g_out;
+    float* gb1 = gW1 + NF_RES_H * D;
+    float* gW2 = gb1 + NF_RES_H;
+    float* gb2 = gW2 + NF_RES_H * NF_RES_H;
+    float* gW3 = gb2 + NF_RES_H;
+    float* gb3 = gW3 + D * NF_RES_H;
+    float* gbe = gb3 + D;
+#pragma unroll
+    for (int i = 0; i < NF_RES_H; ++i) {
+        const float t = accW2[i] + __shfl_xor(accW2[i], 32, NF_WAVE);
+        if (slot == 0) atomicAdd(gW2 + u * NF_RES_H + i, t);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float t1 = accW1[d] + __shfl_xor(accW1[d], 32, NF_WAVE), t3 = accW3[d] + __shfl_xor(accW3[d], 32, NF_WAVE);
+        if (slot == 0) { atomicAdd(gW1 + u * D + d, t1); atomicAdd(gW3 + d * NF_RES_H + u, t3); }
+    }
+    {
+        const float tb1 = acc_b1 + __shfl_xor(acc_b1, 32, NF_WAVE), tb2 = acc_b2 + __shfl_xor(acc_b2, 32, NF_WAVE);
+        const float tb3 = acc_b3 + __shfl_xor(acc_b3, 32, NF_WAVE);
+        if (slot == 0) { atomicAdd(gb1 + u, tb1); atomicAdd(gb2 + u, tb2); if (u < D) atomicAdd(gb3 + u, tb3); }
+        float e1 = nf_half_allsum(acc_be1), e2 = nf_half_allsum(acc_be2);
+        e1 += __shfl_xor(e1, 32, NF_WAVE);
+        e2 += __shfl_xor(e2, 32, NF_WAVE);
+        if (lane == 0) { atomicAdd(gbe, e1); atomicAdd(gbe + 1, e2); }
+    }
+}
+
+extern "C" int nf_resmlp_train_bwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                   const float* b3, const float* beta1, const float* beta2, const float* noise, const float* coef,
+                                   int n_terms, const float* d_g, const float* d_ld, float* d_x, float* g_params, int64_t B, int D,
+                                   nf_stream_t stream) {
+    if (D < 1 || D > NF_RES_MAXD || n_terms < 0 || n_terms > NF_RES_MAXK || B < 0) return NF_E_BADARG;
+    if (B == 0) return 0;
+    NfResW w = {W1, b1, W2, b2, W3, b3, beta1, beta2};
+    int64_t pairs = (B + 1) / 2;
+    unsigned grid = (unsigned)((pairs + NF_RT_WAVES - 1) / NF_RT_WAVES);
+    if (grid > 256) grid = 256;
+    hipStream_t st = (hipStream_t)stream;
+#define NF_L(D_)                                                                                                              \
+    hipLaunchKernelGGL(k_resmlp_train_bwd<D_>, dim3(grid), dim3(NF_RT_THREADS),                                               \
+                       NF_RES_LDS(D_) + NF_RT_WAVES * 2 * (4 + D_) * NF_RES_H * sizeof(float), st, w, x, noise, coef, n_terms, d_g, \
+                       d_ld, d_x, g_params, B)
+    switch (D) {
+        case 1: NF_L(1); break;
+        case 2: NF_L(2); break;
+        case 3: NF_L(3); break;
+        default: NF_L(4); break;
+    }
+#undef NF_L
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// autograd of nf_spectral_weights (spectral_norm.py:36-43): W_eff = W_bar * min(coeff / (sigma + eps), 1), sigma = u^T W_bar v with the
+// power-iteration vectors held constant.  g_W_bar += g_W_eff * scale  -  [scale < 1] <g_W_eff, W_bar> coeff / (sigma + eps)^2 * u v^T
+struct NfSnBwdArgs {
+    const float* Wbar[3];
+    const float* u[3];
+    const float* v[3];
+    const float* gWeff[3];
+    float* gWbar[3];
+    int h[3];
+    int w[3];
+};
+__global__ void __launch_bounds__(NF_BLOCK) k_spectral_bwd(NfSnBwdArgs a, float coeff, float eps) {
+    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    __shared__ float bc[2];
+    const int m = blockIdx.x;
+    const float* W = a.Wbar[m];
+    const float* u = a.u[m];
+    const float* v = a.v[m];
+    const float* g = a.gWeff[m];
+    float* out = a.gWbar[m];
+    const int C = a.w[m], n = a.h[m] * C;
+    float ps = 0.f, pd = 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        ps = fmaf(u[r] * v[c], W[e], ps);
+        pd = fmaf(g[e], W[e], pd);
+    }
+    const float sigma = nf_block_sum(ps, scratch);
+    const float dot = nf_block_sum(pd, scratch);
+    if (threadIdx.x == 0) { bc[0] = sigma; bc[1] = dot; }
+    __syncthreads();
+    const float sg = bc[0], scale = coeff / (sg + eps);
+    const bool active = scale < 1.f;
+    const float k2 = active ? -bc[1] * coeff / ((sg + eps) * (sg + eps)) : 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        out[e] += (active ? g[e] * scale : g[e]) + k2 * u[r] * v[c];
+    }
+}
+extern "C" int nf_spectral_weights_bwd(const float* const* W_bar, const float* const* u, const float* const* v,
+                                       const float* const* g_W_eff, float* const* g_W_bar, const int* rows, const int* cols, int n_mats,
+                                       float coeff, float eps, nf_stream_t stream) {
+    if (n_mats < 1 || n_mats > 3) return NF_E_BADARG;
+    NfSnBwdArgs a;
+    for (int i = 0; i < n_mats; ++i) {
+        if (rows[i] < 1 || cols[i] < 1 || rows[i] > 64 || cols[i] > 64) return NF_E_BADARG;
+        a.Wbar[i] = W_bar[i]; a.u[i] = u[i]; a.v[i] = v[i]; a.gWeff[i] = g_W_eff[i]; a.gWbar[i] = g_W_bar[i]; a.h[i] = rows[i]; a.w[i] = cols[i];
+    }
+    hipLaunchKernelGGL(k_spectral_bwd, dim3((unsigned)n_mats), dim3(NF_BLOCK), 0, (hipStream_t)stream, a, coeff, eps);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -2,10 +2,12 @@
 Residual Flow (invertible residual blocks): flows/iresblock.py:17-301, flows/spectral_norm.py:5-72,
 flows/modules.py:215-222 (LipSwish), flows/resflow.py:9-38 -- SURVEY.md section 8(a) row a15.
 
-Status (round 1): evaluation-mode forward (all three log-det estimators) and the fixed-point inverse run on HIP kernels
-(csrc/resmlp.hip: per-sample exact Jacobian of the 2->32->32->2 LipSwish MLP, spectral normalisation, flag-gated
-iteration launches) for D <= 4; TRAINING (the Neumann-series gradient estimator needs second derivatives) is restated on
-PyTorch-ROCm autograd.  No BASELINE config exercises this family.  Same module / parameter names as the reference, same estimator semantics
+Everything runs on HIP kernels (csrc/resmlp.hip) for D <= 4: the evaluation-mode forward with all three log-det estimators
+on the per-sample exact Jacobian of the 2->32->32->2 LipSwish MLP, the fixed-point inverse (flag-gated iteration launches),
+spectral normalisation -- and the TRAINING step: the Russian-roulette value and the Neumann-series gradient estimator
+(iresblock.py:59-109, :112-185) with the network's second derivatives in closed form (nf_resmlp_train_bwd) instead of nested
+autograd sweeps; `hip_training = False` selects the PyTorch-autograd restatement (kept as the parity reference of the tests).
+No BASELINE config exercises this family.  Same module / parameter names as the reference, same estimator semantics
 (Russian-roulette series for training, `exact` / `fixed` / `unbias` for evaluation, fixed-point inverse with the
 batch-global exit), same RNG consumption order (np.random.geometric, then a normal draw) so seeded runs are
 comparable; `noise_on_cpu = True` draws the Hutchinson noise from the CPU generator (parity tests).
@@ -81,6 +83,7 @@ class InvertibleResLinear(nn.Module):
             raise NotImplementedError('only the LipSwish residual branch is built by the reference models')
         self.coeff, self.ftol, self.estimator = coeff, ftol, logdet_estimator
         self.noise_on_cpu = False
+        self.hip_training = True            # training step on csrc/resmlp.hip (closed-form second derivatives); False: PyTorch autograd
         dims = [in_features] + [base_filters] * n_layers + [out_features]
         layers = []
         for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
@@ -227,6 +230,12 @@ class InvertibleResLinear(nn.Module):
             ld = log_df_dz.clone()
             self._hip_logdet(w, x, y, ld, 1.0, False)
             return y, ld
+        if self.training and torch.is_grad_enabled() and self.hip_training and self._hip_ok(x):
+            sn = [m for m in self.g_fn if isinstance(m, SpectralNorm)]
+            acts = [m for m in self.g_fn if isinstance(m, LipSwish)]
+            params = [sn[0].module.weight_bar, sn[0].module.bias, sn[1].module.weight_bar, sn[1].module.bias,
+                      sn[2].module.weight_bar, sn[2].module.bias, acts[0].beta, acts[1].beta]
+            return _ResidualBranchHip.apply(self, x.contiguous(), log_df_dz, *params)
         params = [p for p in self.g_fn.parameters() if p.requires_grad]
         g, logdet = _ResidualBranch.apply(self, x, *params)
         return x + g, log_df_dz + logdet
@@ -294,6 +303,66 @@ class _ResidualBranch(torch.autograd.Function):
             else:
                 out.append(a + b * scale)
         return (None, ) + tuple(out)
+
+
+class _ResidualBranchHip(torch.autograd.Function):
+    """(x + g(x), log_df_dz + log-det estimate) of a training-mode block on HIP kernels, and its autograd (iresblock.py:112-185):
+    forward = spectral normalisation (one launch) + the Russian-roulette value on the per-sample Jacobian (nf_resmlp_fwd);
+    backward = nf_resmlp_train_bwd (the Neumann-series gradient estimator with closed-form second derivatives) +
+    nf_spectral_weights_bwd.  Noise and series lengths are drawn on the host in the reference's order: first the Neumann
+    surrogate's (np.random.geometric, normal draw), then the value estimator's (iresblock.py:127-137)."""
+
+    @staticmethod
+    def forward(ctx, block, x, ld, *params):
+        w = block._hip_weights()
+        B, D = x.shape
+        dev = x.device
+        p = 0.5
+        n1 = min(int(1 + np.random.geometric(p)), SERIES_MAXK)           # log_df_dz_neumann: n_exact = 1
+        v1 = block._randn_like(x).contiguous()
+        coef1 = np.zeros(SERIES_MAXK, dtype=np.float32)
+        for k in range(1, n1 + 1):
+            coef1[k - 1] = (-1) ** k / (1.0 - p) ** max(0, (k - 1) - 1)
+        y = torch.empty_like(x)
+        ld_out = ld.clone()
+        block._hip_logdet(w, x, y, ld_out, 1.0, True)                     # draws (n, v) of the value estimator
+        ctx.block = block
+        ctx.n1 = n1
+        ctx.save_for_backward(x, v1, torch.from_numpy(coef1).to(dev), *[t.detach().clone() for t in w])
+        return y, ld_out
+
+    @staticmethod
+    def backward(ctx, d_y, d_ld):
+        block = ctx.block
+        x, v1, coef1 = ctx.saved_tensors[:3]
+        w = ctx.saved_tensors[3:]
+        B, D = x.shape
+        d_y, d_ld = d_y.contiguous(), d_ld.contiguous()
+        n_par = 32 * D + 32 + 1024 + 32 + D * 32 + D + 2
+        from . import workspace as WS
+        gp = WS.zeros(n_par, x.device)
+        d_x = torch.empty_like(x)
+        N.call('nf_resmlp_train_bwd', N.ptr(x), *[N.ptr(t) for t in w], N.ptr(v1), N.ptr(coef1), ctx.n1, N.ptr(d_y), N.ptr(d_ld),
+               N.ptr(d_x), N.ptr(gp), B, D, N.stream())
+        o = 0
+        parts = []
+        for n in (32 * D, 32, 1024, 32, D * 32, D, 1, 1):
+            parts.append(gp[o:o + n])
+            o += n
+        gW1, gb1, gW2, gb2, gW3, gb3, gbe1, gbe2 = parts
+        sn = [m for m in block.g_fn if isinstance(m, SpectralNorm)]
+        gbar = [torch.zeros_like(m.module.weight_bar) for m in sn]
+        P3, I3 = ctypes.c_void_p * 3, ctypes.c_int * 3
+        wb = P3(*[m.module.weight_bar.data_ptr() for m in sn])
+        uu = P3(*[m.module.weight_u.data_ptr() for m in sn])
+        vv = P3(*[m.module.weight_v.data_ptr() for m in sn])
+        ge = P3(gW1.data_ptr(), gW2.data_ptr(), gW3.data_ptr())
+        gb = P3(*[t.data_ptr() for t in gbar])
+        rows = I3(*[m.module.weight_bar.shape[0] for m in sn])
+        cols = I3(*[m.module.weight_bar.shape[1] for m in sn])
+        N.call('nf_spectral_weights_bwd', ctypes.addressof(wb), ctypes.addressof(uu), ctypes.addressof(vv), ctypes.addressof(ge),
+               ctypes.addressof(gb), ctypes.addressof(rows), ctypes.addressof(cols), 3, float(block.coeff), float(sn[0].eps), N.stream())
+        return (None, d_y + d_x, d_ld, gbar[0], gb1.clone(), gbar[1], gb2.clone(), gbar[2], gb3.clone(), gbe1.clone(), gbe2.clone())
 
 
 class ResFlow(nn.Module):

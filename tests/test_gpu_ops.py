@@ -524,3 +524,49 @@ def test_flat_adam_matches_torch_adam(pkg):
         for a, b in zip(pa, pb):
             G.assert_close(a, b, 2e-6, rtol=2e-6, what='adam step %d' % it)
     assert int(opt_a.step_count) == 5
+
+
+# ---- invertible residual block: the training step on HIP (closed-form second derivatives) ------------------------------------------------
+@pytest.mark.parametrize('B,D', [(64, 2), (1001, 2), (4096, 4), (37, 3)])
+def test_iresblock_training_hip_matches_autograd(nf, B, D):
+    """value, input gradient and every parameter gradient of a training-mode InvertibleResLinear: csrc/resmlp.hip (the Russian-
+    roulette value on the per-sample Jacobian, the Neumann-series gradient estimator with closed-form second derivatives,
+    iresblock.py:59-109) against the same block differentiated by nested PyTorch autograd sweeps in FLOAT64 on the CPU -- the
+    formulation the reference uses -- with identical noise and series lengths (bar: 2e-5 of the largest entry + 4 x the distance
+    of the float32 CPU evaluation from the float64 one)."""
+    import copy
+    torch.manual_seed(5)
+    blk = nf.InvertibleResLinear(D, D, coeff=0.9).train()
+    blk.noise_on_cpu = True
+    with torch.no_grad():
+        for m in blk.g_fn:
+            if isinstance(m, nf.LipSwish):
+                m.beta.fill_(0.8 + 0.3 * torch.rand(()).item())
+    x = torch.randn(B, D) * 0.7
+    ld0 = torch.randn(B) * 0.1
+    gy, gld = torch.randn(B, D), torch.full((B, ), -1.0 / B)     # the reference takes the log-det gradient of the FIRST sample for all
+    res = {}
+    for tag, dev, dt, hip in (('cpu64', 'cpu', torch.float64, False), ('cpu32', 'cpu', torch.float32, False), ('gpu', DEV, torch.float32, True)):
+        b2 = copy.deepcopy(blk).to(dev).to(dt)
+        b2.hip_training = hip
+        torch.manual_seed(123)
+        np.random.seed(123)
+        if dt == torch.float64:                          # same float32 noise values in every run
+            b2._randn_like = lambda t, shape=None: torch.randn(tuple(t.shape) if shape is None else shape).double()
+        xx = x.detach().clone().to(dev).to(dt).requires_grad_(True)
+        y, ld = b2(xx, ld0.to(dev).to(dt).clone())
+        torch.autograd.backward([y, ld], [gy.to(dev).to(dt), gld.to(dev).to(dt)])
+        grads = {k: p.grad.detach().cpu().double() for k, p in b2.named_parameters() if p.grad is not None}
+        res[tag] = (y.detach().cpu().double(), ld.detach().cpu().double(), xx.grad.detach().cpu().double(), grads)
+    ref, c32, gpu = res['cpu64'], res['cpu32'], res['gpu']
+
+    def check(what, got, want, fp32):
+        bar = 2e-5 * max(1.0, float(want.abs().max())) + 4.0 * float((fp32 - want).abs().max())
+        err = float((got - want).abs().max())
+        assert err <= bar, '%s: |gpu - cpu64| %.3e > %.3e (cpu32 itself %.3e)' % (what, err, bar, float((fp32 - want).abs().max()))
+    check('y', gpu[0], ref[0], c32[0])
+    check('ld', gpu[1], ref[1], c32[1])
+    check('grad x', gpu[2], ref[2], c32[2])
+    assert set(gpu[3]) == set(ref[3]), (sorted(gpu[3]), sorted(ref[3]))
+    for k in ref[3]:
+        check('grad ' + k, gpu[3][k], ref[3][k], c32[3][k])
