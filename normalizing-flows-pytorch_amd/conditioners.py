@@ -52,6 +52,27 @@ def _wn(module, wrap=True):
     return WeightNorm(module) if wrap else module
 
 
+def _sync_on():
+    from . import dist as nfdist
+    return nfdist.sync_stats_active()
+
+
+def _run_seq(seq, x):
+    """nn.Sequential.forward with the training-mode BatchNorm layers on statistics of the GLOBAL batch when the parity mode of
+    dist.sync_statistics is on; otherwise exactly ``seq(x)``."""
+    if not _sync_on():
+        return seq(x)
+    from . import dist as nfdist
+    for m in seq:
+        if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training:
+            x = nfdist.sync_batch_norm(m, x)
+        elif isinstance(m, (_ResBlock, )):
+            x = m(x)
+        else:
+            x = m(x)
+    return x
+
+
 class _ResBlock(nn.Module):
     def __init__(self, make_norm, make_op, in_channels, out_channels, weight_norm):
         super().__init__()
@@ -67,7 +88,7 @@ class _ResBlock(nn.Module):
             else nn.Sequential()
 
     def forward(self, x):
-        return self.bridge(x) + self.net(x)
+        return self.bridge(x) + _run_seq(self.net, x)
 
 
 class ResBlockLinear(_ResBlock):
@@ -94,10 +115,10 @@ class MLP(nn.Module):
 
     def forward_reference(self, x):
         """module-by-module PyTorch path (rocBLAS + MIOpen); used off-GPU and as the parity reference of the fused one."""
-        return self.out_block(self.mid_block(self.in_block(x)))
+        return _run_seq(self.out_block, self.mid_block(self.in_block(x)))
 
     def forward(self, x):
-        if self.fused and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+        if self.fused and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not _sync_on():
             from .fused import mlp_forward          # fp32-MFMA linear + BatchNorm kernels: 6 launches
             return mlp_forward(self, x)
         return self.forward_reference(x)
@@ -118,10 +139,10 @@ class ConvNet(nn.Module):
 
     def forward_reference(self, x):
         """module-by-module PyTorch path (MIOpen + ATen); used off-GPU and as the parity reference of the fused one."""
-        return self.out_block(self.mid_block(self.in_block(x)))
+        return _run_seq(self.out_block, self.mid_block(self.in_block(x)))
 
     def forward(self, x):
-        if self.fused and x.is_cuda and x.dtype == torch.float32:
+        if self.fused and x.is_cuda and x.dtype == torch.float32 and not _sync_on():
             from .fused_conv import convnet_forward, convnet_usable   # fp32-MFMA conv + BatchNorm kernels: 6 launches
             if convnet_usable(self, x):
                 return convnet_forward(self, x)

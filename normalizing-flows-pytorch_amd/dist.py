@@ -4,8 +4,11 @@ gradient bucket per step over RCCL/xGMI (``torch.distributed`` backend ``nccl`` 
 the tests).  The reference is single-device (main.py:40-43), so this is new; every transform on the hot path is
 per-sample independent, the only cross-sample couplings are batch statistics (policy below).
 
-Statistic policy: per-replica batch statistics (standard DDP behaviour).  ``sync_buffers()``
-averages the running statistics across ranks for evaluation / checkpointing.
+Statistic policy (SURVEY.md section 8e): per-replica batch statistics by default (standard DDP behaviour; throughput runs);
+``sync_buffers()`` averages the running statistics across ranks for evaluation / checkpointing.  The PARITY mode
+(``FlowTrainer(sync_stats=True)`` / ``with sync_statistics():``) all-reduces every batch statistic on the path -- flow BatchNorm,
+the BatchNorm1d / 2d layers of the conditioners (forward moments and the two sums of their backward), the data-dependent
+ActNorm initialisation -- so that W-way data parallelism reproduces the single-process result on the global batch.
 """
 import os
 
@@ -111,3 +114,97 @@ def sync_buffers(module, group=None):
             if b.is_floating_point():
                 dist.all_reduce(b.data, op=dist.ReduceOp.SUM, group=group)
                 b.data.mul_(1.0 / w)
+
+
+# ---- synchronised batch statistics (parity mode) -----------------------------------------------------------------------------------
+_SYNC = {'on': False, 'group': None}
+
+
+class sync_statistics:
+    """context: every batch statistic of the flow is computed over the GLOBAL batch (all ranks of ``group``).  The layers then
+    take their layer-by-layer launch paths (the fused persistent kernels compute their statistics in-kernel, per replica) and the
+    conditioners their module paths with ``sync_batch_norm``; meant for the parity run, not for throughput.  Works with one
+    process too (the collectives are no-ops), which is how the GPU test checks it against the fused path."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __enter__(self):
+        self._old = dict(_SYNC)
+        _SYNC['on'], _SYNC['group'] = True, self.group
+        return self
+
+    def __exit__(self, *exc):
+        _SYNC.update(self._old)
+        return False
+
+
+def sync_stats_active():
+    return _SYNC['on']
+
+
+def _all_reduce_sum(t, group):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def global_moments(x, group=None):
+    """(mean, biased variance, n) per channel (dim 1) over the batch and pixel dims of ALL ranks: two passes, two all-reduces --
+    the squared deviations are taken about the GLOBAL mean, so nothing is computed as E[x^2] - E[x]^2."""
+    group = _SYNC['group'] if group is None else group
+    dims = [0] + list(range(2, x.dim()))
+    n = torch.tensor([float(x.numel() // x.shape[1])], dtype=x.dtype, device=x.device)
+    s = x.sum(dim=dims)
+    packed = torch.cat([s, n])
+    _all_reduce_sum(packed, group)
+    n_g = packed[-1]
+    mean = packed[:-1] / n_g
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    m2 = ((x - mean.view(shape)) ** 2).sum(dim=dims)
+    _all_reduce_sum(m2, group)
+    return mean, m2 / n_g, n_g
+
+
+class _SyncBatchNorm(torch.autograd.Function):
+    """training-mode nn.BatchNorm1d / 2d with statistics over all ranks; the gradient flows through the statistics (the two batch
+    sums of the backward are all-reduced), exactly what the single-process layer computes on the concatenated batch."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, group):
+        mean, var, n_g = global_moments(x, group)
+        invstd = torch.rsqrt(var + eps)
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        xhat = (x - mean.view(shape)) * invstd.view(shape)
+        ctx.save_for_backward(xhat, gamma, invstd, n_g)
+        ctx.group = group
+        ctx.stats = (mean, var, n_g)
+        return xhat * gamma.view(shape) + beta.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, gamma, invstd, n_g = ctx.saved_tensors
+        dims = [0] + list(range(2, g.dim()))
+        shape = [1, -1] + [1] * (g.dim() - 2)
+        sg, sgx = g.sum(dim=dims), (g * xhat).sum(dim=dims)
+        packed = torch.cat([sg, sgx])
+        _all_reduce_sum(packed, ctx.group)
+        C = sg.numel()
+        mg, mgx = packed[:C] / n_g, packed[C:] / n_g
+        g_x = (gamma * invstd).view(shape) * (g - mg.view(shape) - xhat * mgx.view(shape))
+        return g_x, sgx, sg, None, None
+
+
+def sync_batch_norm(bn, x):
+    """``bn``: an nn.BatchNorm1d / 2d module in training mode; same result, running-statistics and num_batches_tracked bookkeeping
+    as ``bn(x)`` would give on the concatenation of all ranks' batches."""
+    group = _SYNC['group']
+    y = _SyncBatchNorm.apply(x, bn.weight, bn.bias, bn.eps, group)
+    with torch.no_grad():
+        mean, var, n_g = global_moments(x, group)
+        unb = var * (n_g / torch.clamp(n_g - 1.0, min=1.0))
+        m = bn.momentum
+        bn.running_mean.mul_(1.0 - m).add_(mean * m)
+        bn.running_var.mul_(1.0 - m).add_(unb * m)
+        bn.num_batches_tracked += 1
+    return y

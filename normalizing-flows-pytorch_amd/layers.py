@@ -39,9 +39,16 @@ class Compose(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList(layers)
 
+    @property
+    def _fuse_now(self):
+        """peephole fusion is off in the synchronised-statistics parity mode: the fused kernels take their batch statistics
+        in-kernel, per replica (dist.sync_statistics)"""
+        from . import dist as nfdist
+        return self.fuse and not nfdist.sync_stats_active()
+
     def _glow_step_at(self, i, z):
         L = self.layers
-        if not (self.fuse and z.is_cuda and i + 2 < len(L) and z.shape[1] <= NF.HEAD_MAX_C):
+        if not (self._fuse_now and z.is_cuda and i + 2 < len(L) and z.shape[1] <= NF.HEAD_MAX_C):
             return False
         a, c, k = L[i], L[i + 1], L[i + 2]
         if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and type(k) is AffineCoupling):
@@ -92,7 +99,7 @@ class Compose(nn.Module):
     def _bn_step_at(self, i, z):
         """[flow BatchNorm (training, affine=False), AffineCoupling | AutoregressiveTransfrom] -> fused BatchNorm head"""
         L = self.layers
-        if not (self.fuse and z.is_cuda and i + 1 < len(L)):
+        if not (self._fuse_now and z.is_cuda and i + 1 < len(L)):
             return False
         a, k = L[i], L[i + 1]
         if not (type(a) is BatchNorm and a.training and not isinstance(a.log_gamma, nn.Parameter)):
@@ -104,7 +111,7 @@ class Compose(nn.Module):
     def _flowpp_pair_at(self, i, z):
         """[MixLogAttnCoupling, ActNorm (initialised)] on two features -> the next step's ActNorm rides the coupling's launches"""
         L = self.layers
-        if not (self.fuse and z.is_cuda and i + 1 < len(L)):
+        if not (self._fuse_now and z.is_cuda and i + 1 < len(L)):
             return False
         k, a = L[i], L[i + 1]
         if not (type(k) is MixLogAttnCoupling and type(a) is ActNorm and k.mode == N.SPLIT_1D):
@@ -196,7 +203,7 @@ class Compose(nn.Module):
     def _realnvp_pair_at(self, j, z):
         """[flow BatchNorm(affine=False), AffineCoupling(MLP)] at layers j, j + 1 on (N, 2 | 4) data, any mode, no hooks"""
         L = self.layers
-        if not (self.fuse and z.is_cuda and z.dim() == 2 and j >= 0 and j + 1 < len(L)):
+        if not (self._fuse_now and z.is_cuda and z.dim() == 2 and j >= 0 and j + 1 < len(L)):
             return False
         a, k = L[j], L[j + 1]
         if not (type(a) is BatchNorm and not isinstance(a.log_gamma, nn.Parameter) and type(k) is AffineCoupling
@@ -207,7 +214,7 @@ class Compose(nn.Module):
     def _maf_pair_at(self, j, z):
         """[flow BatchNorm(affine=False), AutoregressiveTransfrom] at layers j, j + 1 on (N, D) data, any mode, no hooks"""
         L = self.layers
-        if not (self.fuse and z.is_cuda and z.dim() == 2 and j >= 0 and j + 1 < len(L)):
+        if not (self._fuse_now and z.is_cuda and z.dim() == 2 and j >= 0 and j + 1 < len(L)):
             return False
         a, k = L[j], L[j + 1]
         if not (type(a) is BatchNorm and not isinstance(a.log_gamma, nn.Parameter) and type(k) is AutoregressiveTransfrom):
@@ -310,7 +317,15 @@ class ActNorm(nn.Module):
 
     def forward(self, z, log_df_dz):
         if not self.initialized:
-            NF.actnorm_init_(z, self.log_scale, self.bias, self.eps)
+            from . import dist as nfdist
+            if nfdist.sync_stats_active():              # parity mode: the initialisation statistics of the GLOBAL batch
+                with torch.no_grad():
+                    mean, var, n = nfdist.global_moments(z)
+                    std = torch.sqrt(var * (n / (n - 1.0)))                  # unbiased, modules.py:240
+                    self.log_scale.data.copy_(torch.log(std + self.eps).view(self.dimensions))
+                    self.bias.data.copy_(mean.view(self.dimensions))
+            else:
+                NF.actnorm_init_(z, self.log_scale, self.bias, self.eps)
             self.initialized = True
         return NF.chan_affine(N.OP_ACTNORM, z, log_df_dz, self.log_scale, self.bias)
 
@@ -345,7 +360,15 @@ class BatchNorm(nn.Module):
         return self.running_mean, self.running_var
 
     def forward(self, x, log_det_jacob):
-        if self.training:
+        from . import dist as nfdist
+        if self.training and nfdist.sync_stats_active():    # parity mode: statistics of the GLOBAL batch (modules.py:284-294)
+            with torch.no_grad():
+                mean, var, _ = nfdist.global_moments(x)
+                self.batch_mean.copy_(mean.view(self.dimensions))
+                self.batch_var.copy_((var + self.eps).view(self.dimensions))
+                self.running_mean.mul_(1.0 - self.momentum).add_(self.batch_mean * self.momentum)
+                self.running_var.mul_(1.0 - self.momentum).add_(self.batch_var * self.momentum)
+        elif self.training:
             NF.flowbn_update_(x, self.batch_mean, self.batch_var, self.running_mean, self.running_var, self.eps,
                               self.momentum)
         mean, var = self._stats()
@@ -596,8 +619,11 @@ class MADE(nn.Module):
     def forward(self, z):
         masks = self.draw_masks(z.device)
         h = z
+        from . import dist as nfdist
+        sync = nfdist.sync_stats_active()
         for i in range(self.num_hidden):
-            h = torch.relu(self.bnorms[i](F.linear(h, self.weights[i] * masks[i], self.biases[i])))
+            pre = F.linear(h, self.weights[i] * masks[i], self.biases[i])
+            h = torch.relu(nfdist.sync_batch_norm(self.bnorms[i], pre) if (sync and self.bnorms[i].training) else self.bnorms[i](pre))
         return F.linear(h, self.weights[-1] * masks[-1], self.biases[-1])
 
 
@@ -615,7 +641,9 @@ class AutoregressiveTransfrom(nn.Module):
 
     def conditioners(self, z):
         """(s_raw, t) = (net_s(z), net_t(z)); on the GPU both MADEs run in the same fp32-MFMA launches."""
-        if z.is_cuda and self.in_out_chs <= 32 and self.net_s.base_filters == 32 and z.dtype == torch.float32:
+        from . import dist as nfdist
+        if (z.is_cuda and self.in_out_chs <= 32 and self.net_s.base_filters == 32 and z.dtype == torch.float32
+                and not nfdist.sync_stats_active()):
             from .fused import made_pair_forward
             ms = self.net_s.draw_masks(z.device)             # same RNG order as the reference: s-net, then t-net
             mt = self.net_t.draw_masks(z.device)

@@ -83,8 +83,13 @@ class FlowTrainer:
     The call that captures also takes one extra eager step on its batch (allocator warm-up on the capture stream)."""
 
     def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None,
-                 fused_adam=True, sampler=None):
+                 fused_adam=True, sampler=None, sync_stats=False):
         self.net = net
+        # parity mode (SURVEY.md section 8e): every batch statistic over the GLOBAL batch -- W-way data parallelism then reproduces
+        # the single-process result on the concatenated batch.  Layer-by-layer launches with collectives in between: no hipGraph.
+        self.sync_stats = bool(sync_stats)
+        if self.sync_stats:
+            graph = False
         self.sampler = sampler      # data.DeviceSampler: train_on_batch() without a batch draws one on the device, inside the graph
         on_gpu = next(net.parameters()).is_cuda
         fused_adam = bool(fused_adam) and on_gpu
@@ -110,6 +115,9 @@ class FlowTrainer:
     def _forward_backward(self, y):
         if y is None:                                   # on-device data: the draw is part of the step (and of its hipGraph)
             y = self.sampler.next()
+        if self.sync_stats:
+            with nfdist.sync_statistics(self.bucket.group):
+                return self._run_step(y.device, lambda: self._forward_loss(y))
         return self._run_step(y.device, lambda: self._forward_loss(y))
 
     def _forward_loss(self, y):

@@ -237,3 +237,34 @@ def test_trainer_hipgraph_replay_matches_eager(pkg, name, dims, datatype, B, K):
     scale = float(te.bucket.flat.abs().max())
     bad = ((tg.bucket.flat - te.bucket.flat).abs() > 2e-3 * max(1.0, scale)).float().mean()
     assert float(bad) < 1e-2, 'gradients of the replayed step differ in %.2e of the entries' % float(bad)
+
+
+@pytest.mark.parametrize('name', ['glow2d', 'realnvp2d', 'maf2d', 'glow_img'])
+def test_sync_statistics_mode_matches_goldens(pkg, name):
+    """the parity mode of data parallelism (dist.sync_statistics: every batch statistic through global moments + all-reduce, the
+    conditioners' BatchNorm layers through dist.sync_batch_norm, layer-by-layer launches) on ONE process must give what the
+    reference gives on that batch: forward, loss and every gradient against the goldens.  (Two ranks are covered on CPU / gloo by
+    tests/test_dist_cpu.py; with one rank the collectives are no-ops and this pins the arithmetic of the GPU code path.)"""
+    import importlib
+    nfdist = importlib.import_module(pkg.__name__ + '.dist')
+    net, g, kind, dims = _build(pkg, name)
+    net.train()
+    with nfdist.sync_statistics():
+        z, ld = net(g['y'].clone())
+        loss = tf.nll_loss(z, ld)
+        loss.backward()
+    G.assert_close(z, g['train/z'], TOL, what='z')
+    G.assert_close(ld, g['train/ld'], TOL, rtol=2e-6, what='ld')
+    n = 0
+    for k, p in net.named_parameters():
+        if 'grad/' + k in g:
+            want = g['grad/' + k]
+            noise = kind == 'maf' and '.biases.' in k and not k.endswith('.biases.3')
+            scale = max(1.0, float(want.abs().max()))
+            tol = 2e-3 if noise else (1e-4 if kind == 'maf' else (4 if name == 'glow_img' else 2) * TOL) * scale   # image conditioner here = MIOpen convolutions + ATen (their summation order): 2.6e-5 measured
+            G.assert_close(p.grad, want, tol, what=k)
+            n += 1
+    assert n > 4
+    sd = net.state_dict()
+    for k, want in G.group('model_' + name, 'sd1/').items():
+        G.assert_close(sd[k].float(), want.float(), 2e-6, what=k)
