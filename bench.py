@@ -107,12 +107,21 @@ def graph_time_us(fn, dev, per_graph=50, replays=10, reset=None):
 
 
 def pmc_traffic(kernel, B):
-    """HBM bytes per launch of `kernel` at batch B from the committed rocprofv3 PMC passes (profiles/r01_pmc.json), or None."""
+    """HBM bytes per launch of `kernel` at batch B from THIS round's committed rocprofv3 PMC passes (the newest profiles/rNN_pmc.json,
+    written by tools/pmc_round.py from separate FETCH_SIZE / WRITE_SIZE runs of these very launches), or None.  PMC collection needs
+    its own profiler runs, so it cannot happen inside the timed bench process; the kernel's DURATION in the same object is measured
+    live, and tests/test_cabi.py checks that the file belongs to the current round's kernels."""
+    import glob
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')) as f:
-            return json.load(f).get(kernel, {}).get(str(B), {}).get('traffic_bytes')
-    except (OSError, ValueError):
-        return None
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc.json')))
+        with open(files[-1]) as f:
+            sub = json.load(f).get(kernel, {})
+        for key, e in sub.items():
+            if key.split(':')[0] == str(B) and 'traffic_bytes' in e:
+                return e['traffic_bytes']
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
 
 
 def dominant_kernel_roofline(pkg, cfg, B, dev):
@@ -473,15 +482,9 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
         nbytes = z.numel() * 12 + B * 8                          # 12 B / element of z + ld rmw
     us = graph_time_us(fn, dev)
     gbs = nbytes / (us * 1e-6) / 1e9
-    traffic = None                     # HBM bytes per launch from the committed rocprofv3 PMC passes, same kernel + shape
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')) as f:
-            pmc = json.load(f)
-        traffic = pmc.get(name.split(' ')[0], {}).get(str(B), {}).get('traffic_bytes')
-        if traffic is not None and 'net' in name:
-            traffic *= (2 if '2 nets' in name else 1)
-    except (OSError, ValueError):
-        pass
+    traffic = pmc_traffic(name.split(' ')[0], B)   # HBM bytes per launch from this round's rocprofv3 PMC passes, same kernel + shape
+    if traffic is not None and 'net' in name:
+        traffic *= (2 if '2 nets' in name else 1)
     out = {'bound': 'hbm', 'kernel': name, 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic, 'bytes_per_launch': int(nbytes),
            'us_per_launch': round(us, 3),

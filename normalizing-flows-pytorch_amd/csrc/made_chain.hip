@@ -225,16 +225,29 @@ __device__ __forceinline__ void nf_md_publish_stats(float* sm, unsigned long lon
     if (threadIdx.x < 64) {
         const int f = (threadIdx.x >> 5) * 64 + (threadIdx.x & 31);
         const int nb = nf_md_rows_of_block(N, blockIdx.x);
-        float S = 0.f;
+        float S, M2;
+        if (nb == NF_MAF_ROWS_PER_BLOCK) {               // every tile full: pairwise tree over the waves, no division
+            float sv[NF_MD_WAVES], mv[NF_MD_WAVES];
 #pragma unroll
-        for (int w = 0; w < NF_MD_WAVES; ++w) S += red[w * NF_MD_XW + f];
-        const float mb = S / (float)max(nb, 1);
-        float M2 = 0.f;
+            for (int w = 0; w < NF_MD_WAVES; ++w) { sv[w] = red[w * NF_MD_XW + f]; mv[w] = red[w * NF_MD_XW + 32 + f]; }
 #pragma unroll
-        for (int w = 0; w < NF_MD_WAVES; ++w) {
-            const int nw = min(max(nb - 16 * w, 0), 16);
-            const float d = red[w * NF_MD_XW + f] / (float)max(nw, 1) - mb;
-            M2 += nw > 0 ? fmaf((float)nw * d, d, red[w * NF_MD_XW + 32 + f]) : 0.f;
+            for (int st = 1; st < NF_MD_WAVES; st *= 2)
+#pragma unroll
+                for (int w = 0; w < NF_MD_WAVES; w += 2 * st) {
+                    const float dl = sv[w + st] - sv[w];
+                    mv[w] = (mv[w] + mv[w + st]) + dl * dl * (0.5f / (float)(16 * st));
+                    sv[w] += sv[w + st];
+                }
+            S = sv[0]; M2 = mv[0];
+        } else {
+            S = 0.f; M2 = 0.f;
+            for (int w = 0; w < NF_MD_WAVES; ++w) S += red[w * NF_MD_XW + f];
+            const float mb = S / (float)max(nb, 1);
+            for (int w = 0; w < NF_MD_WAVES; ++w) {
+                const int nw = min(max(nb - 16 * w, 0), 16);
+                const float d = red[w * NF_MD_XW + f] / (float)max(nw, 1) - mb;
+                M2 += nw > 0 ? fmaf((float)nw * d, d, red[w * NF_MD_XW + 32 + f]) : 0.f;
+            }
         }
         if (gridDim.x == 1) {
             red[f] = S; red[32 + f] = M2;                 // threads 0..63 are ONE wave: every read above precedes these stores
@@ -283,7 +296,7 @@ __device__ __forceinline__ const float* nf_md_collect_stats(float* sm, unsigned 
         if (b < G) {
             const int nb = nf_md_rows_of_block(N, b);
             const float Sb = __uint_as_float((unsigned)(v[k] >> 32)), Mb = __uint_as_float((unsigned)v[k]);
-            const float d = Sb / (float)max(nb, 1) - c;
+            const float d = Sb * (nb == NF_MAF_ROWS_PER_BLOCK ? 1.f / (float)NF_MAF_ROWS_PER_BLOCK : 1.f / (float)max(nb, 1)) - c;
             aS += Sb;
             aT += fmaf((float)nb * d, d, Mb);
         }

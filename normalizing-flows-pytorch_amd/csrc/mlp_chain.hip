@@ -219,39 +219,55 @@ __device__ __forceinline__ int nf_mc_rows_of_block(int64_t N, int b) {
     const int64_t left = N - (int64_t)b * NF_MLP_ROWS_PER_BLOCK;
     return (int)(left < NF_MLP_ROWS_PER_BLOCK ? (left > 0 ? left : 0) : NF_MLP_ROWS_PER_BLOCK);
 }
+// two blocks of m rows each (sums S, S', squared deviations M2, M2' about their own means) merge into S + S', M2 + M2' + (S' - S)^2 / (2 m)
+__device__ __forceinline__ void nf_mc_merge(float& S, float& M2, float So, float Mo, float half_inv_m) {
+    const float dl = So - S;
+    M2 = (M2 + Mo) + dl * dl * half_inv_m;
+    S += So;
+}
 __device__ __forceinline__ void nf_mc_publish_stats(float* sm, unsigned long long* slots, int round, unsigned gen, int64_t N) {
     float* red = sm + NF_MC_RED;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x & 31;
+    if (threadIdx.x < 32) {
+        const int i = threadIdx.x;
         const int nb = nf_mc_rows_of_block(N, blockIdx.x);
-        float S = 0.f;
+        float S, M2;
+        if (nb == NF_MLP_ROWS_PER_BLOCK) {               // every tile full: pairwise tree over the waves, no division
+            float sv[NF_MC_WAVES], mv[NF_MC_WAVES];
 #pragma unroll
-        for (int w = 0; w < NF_MC_WAVES; ++w) S += red[w * 64 + i];
-        float out = S;
-        if (threadIdx.x >= 32) {
+            for (int w = 0; w < NF_MC_WAVES; ++w) { sv[w] = red[w * 64 + i]; mv[w] = red[w * 64 + 32 + i]; }
+#pragma unroll
+            for (int st = 1; st < NF_MC_WAVES; st *= 2)
+#pragma unroll
+                for (int w = 0; w < NF_MC_WAVES; w += 2 * st) nf_mc_merge(sv[w], mv[w], sv[w + st], mv[w + st], 0.5f / (float)(16 * st));
+            S = sv[0]; M2 = mv[0];
+        } else {                                         // the last workgroup of a batch that does not fill it
+            S = 0.f; M2 = 0.f;
+            for (int w = 0; w < NF_MC_WAVES; ++w) S += red[w * 64 + i];
             const float mb = S / (float)max(nb, 1);
-            float M2 = 0.f;
-#pragma unroll
             for (int w = 0; w < NF_MC_WAVES; ++w) {
                 const int nw = min(max(nb - 16 * w, 0), 16);
                 const float d = red[w * 64 + i] / (float)max(nw, 1) - mb;
                 M2 += nw > 0 ? fmaf((float)nw * d, d, red[w * 64 + 32 + i]) : 0.f;
             }
-            out = M2;
         }
         if (gridDim.x == 1) {
-            red[threadIdx.x] = out;                      // threads 0..63 are ONE wave: every read above precedes this store
+            red[i] = S; red[32 + i] = M2;                // one wave: every read above precedes these stores
         } else {
-            const unsigned long long pk = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(out);
-            __hip_atomic_store(slots + ((size_t)round * NF_MLP_MAX_BLOCKS + blockIdx.x) * 64 + threadIdx.x, pk, __ATOMIC_RELAXED,
+            unsigned long long* dst = slots + ((size_t)round * NF_MLP_MAX_BLOCKS + blockIdx.x) * 64 + i;
+            __hip_atomic_store(dst, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(S), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 32, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(M2), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
+// collect: the merge over the workgroups is spread over the whole workgroup (thread = (channel i, part p): workgroups p, p + NP, ...);
+// the parts meet in `red` (consumed by publish).  No division per workgroup: every block but the last holds NF_MLP_ROWS_PER_BLOCK rows.
 __device__ __forceinline__ const float* nf_mc_collect_stats(float* sm, int gather, unsigned long long* slots, int round, unsigned gen,
                                                             int64_t N) {
     float* xs = sm + gather;
+    float* part = sm + NF_MC_RED;                        // [NP][32]
     float* tot = sm + NF_MC_TOT + (round & 1) * 64;
     const int G = gridDim.x;
     if (G == 1) {
@@ -284,22 +300,32 @@ __device__ __forceinline__ const float* nf_mc_collect_stats(float* sm, int gathe
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x & 31;
-        float S = 0.f;
-        for (int b = 0; b < G; ++b) S += xs[b * 64 + i];
-        float out = S;
-        if (threadIdx.x >= 32) {
-            const float mean = S / (float)N;
-            float M2 = 0.f;
-            for (int b = 0; b < G; ++b) {
-                const int nb = nf_mc_rows_of_block(N, b);
-                const float d = xs[b * 64 + i] / (float)max(nb, 1) - mean;
-                M2 += fmaf((float)nb * d, d, xs[b * 64 + 32 + i]);
-            }
-            out = M2;
-        }
-        tot[threadIdx.x] = out;
+    constexpr int NP = NF_MC_THREADS / 32;
+    const int i = threadIdx.x & 31, p = threadIdx.x >> 5;
+    float ps = 0.f;
+    for (int b = p; b < G; b += NP) ps += xs[b * 64 + i];
+    part[p * 32 + i] = ps;
+    __syncthreads();
+    float S = 0.f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) S += part[q * 32 + i];
+    const float mean = S / (float)N;
+    const float inv_full = 1.f / (float)NF_MLP_ROWS_PER_BLOCK;
+    float pm = 0.f;
+    for (int b = p; b < G; b += NP) {
+        const int nb = nf_mc_rows_of_block(N, b);
+        const float d = xs[b * 64 + i] * (nb == NF_MLP_ROWS_PER_BLOCK ? inv_full : 1.f / (float)max(nb, 1)) - mean;
+        pm += fmaf((float)nb * d, d, xs[b * 64 + 32 + i]);
+    }
+    __syncthreads();                                     // every thread has read the sums' parts
+    part[p * 32 + i] = pm;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float M2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) M2 += part[q * 32 + i];
+        tot[i] = S;
+        tot[32 + i] = M2;
     }
     __syncthreads();
     return tot;

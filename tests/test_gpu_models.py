@@ -261,7 +261,7 @@ def test_sync_statistics_mode_matches_goldens(pkg, name):
             want = g['grad/' + k]
             noise = kind == 'maf' and '.biases.' in k and not k.endswith('.biases.3')
             scale = max(1.0, float(want.abs().max()))
-            tol = 2e-3 if noise else (1e-4 if kind == 'maf' else (4 if name == 'glow_img' else 2) * TOL) * scale   # image conditioner here = MIOpen convolutions + ATen (their summation order): 2.6e-5 measured
+            tol = 2e-3 if noise else (1e-4 if kind == 'maf' else 4 * TOL) * scale   # the conditioners run as rocBLAS / MIOpen + ATen modules in this mode (their summation order): 2.6e-5 measured
             G.assert_close(p.grad, want, tol, what=k)
             n += 1
     assert n > 4
