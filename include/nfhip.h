@@ -419,6 +419,27 @@ typedef struct nf_convnet_desc {
 int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W);
 int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training, float bn_eps,
                          float bn_momentum, nf_stream_t stream);
+/* The data gradient of the same conditioner in one persistent launch (the six nf_conv_bn_bwd data passes of the split form below):
+ * reads the forward's by-products, writes what the deferred weight-gradient launches (nf_conv_bn_wgrad_multi) read afterwards.
+ * Deterministic (the batch sums are exchanged in a fixed order, no atomics).  training == 0: the statistics are constants (no mean
+ * terms in the BatchNorm backward); the sums are still produced -- they are the gradients of beta and gamma.                    */
+typedef struct nf_convnet_bwd_desc {
+    const float* w[6];          /* effective weights */
+    const float* gamma[5];
+    const float* beta[5];
+    const float* save_mean[5];
+    const float* save_invstd[5];
+    const float* acts[5];       /* (B, 32, H, W) pre-BatchNorm outputs of the forward pass */
+    const float* g_out;         /* (B, O, H, W) */
+    float* gn[5];               /* (B, 32, H, W) written: gradient at BatchNorm l's output, ReLU mask applied */
+    float* sum_g[5];            /* NF_STAT_REPL x 32, ZERO at launch; replica 0 receives the batch sum of gn[l] */
+    float* sum_gx[5];           /* ... of gn[l] * xhat_l */
+    float* g_store[2];          /* (B, 32, H, W) written: gradients of acts[4] and acts[2] (the g_skip operands of layers 2 and 0) */
+    float* g_x;                 /* (B, I0, H, W) written, or NULL */
+    float* ws_zero;             /* NF_CONVNET_WS_FLOATS zeros (exchange slots) */
+} nf_convnet_bwd_desc;
+int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
+                         nf_stream_t stream);
 
 /* autograd of nf_conv_bn_fwd in training mode; the gradient G of `out` is assembled on load exactly as in
  * nf_linear_bn_bwd (G = g_direct + g_skip + BNbwd(gn_src), each term optional).  Results:

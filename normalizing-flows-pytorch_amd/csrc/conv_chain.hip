@@ -65,7 +65,7 @@ __host__ __device__ inline NfCcLds nf_cc_lds(int CS, int OCB) {
     int rs = NPB * (NKQ - 1) * 16 * NF_WAVE;
     if (rs < NF_CC_MAX_BLOCKS * 64) rs = NF_CC_MAX_BLOCKS * 64;       // the gather buffer of the grid exchange aliases RS
     L.KC = L.RS + rs;
-    L.KB = L.KC + 64;
+    L.KB = L.KC + 128;                                 // kc[4][32]: scale, shift (forward) + mean, invstd (backward)
     L.RED = L.KB + 32;
     L.TOT = L.RED + 2 * NPB * 32;
     L.total = L.TOT + 64;
@@ -230,6 +230,34 @@ __device__ __forceinline__ void nf_cc_half_stats(const float (&v)[OWN], bool lo_
     which = w;
 }
 
+// gather the G x 64 published values of one exchange round into LDS (xs[workgroup][64]); a slot is {generation : value}, four polled per
+// trip.  A workgroup that never arrives (not co-resident, lost) ends the wait after nf_cc_spin_limit polls: sticky error word, loud on the host.
+__device__ __forceinline__ void nf_cc_collect_slots(float* xs, const unsigned long long* rs, unsigned gen, int G) {
+    for (int e0 = threadIdx.x; e0 < G * 64; e0 += 4 * NF_CV_THREADS) {
+        unsigned long long v[4];
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * NF_CV_THREADS;
+                v[k] = __hip_atomic_load(rs + (e < G * 64 ? e : e0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
+            if (ok) break;
+            if (++spins > nf_cc_spin_limit) { NF_PERSIST_GIVE_UP(nf_cc); break; }
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * NF_CV_THREADS;
+            if (e < G * 64) xs[e] = __uint_as_float((unsigned)v[k]);
+        }
+    }
+}
+
 // grid-wide (sum, M2) of 32 channels: red[0][pb][c] = sums, red[1][pb][c] = M2 about the pixel block's mean -> tot[c], tot[32 + c].
 // The merges are spread over the whole workgroup (a 64-iteration loop of divisions on 64 threads cost 7.4 us at 64 workgroups):
 // thread (channel i = t & 31, part p = t >> 5) takes the workgroups p, p + 32, ...; parts meet in `part` (aliases Wl, idle here).
@@ -286,29 +314,7 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
 #ifdef NF_CC_PROF
     if (round == 1 && threadIdx.x == 0) nf_cc_arrive[blockIdx.x] = wall_clock64();
 #endif
-    for (int e0 = threadIdx.x; e0 < G * 64; e0 += 4 * NF_CV_THREADS) {
-        unsigned long long v[4];
-        unsigned spins = 0;
-        bool ok;
-        do {
-            ok = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + k * NF_CV_THREADS;
-                v[k] = __hip_atomic_load(rs + (e < G * 64 ? e : e0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ok = ok && (unsigned)(v[k] >> 32) == gen;
-            if (ok) break;
-            if (++spins > nf_cc_spin_limit) { NF_PERSIST_GIVE_UP(nf_cc); break; }
-            __builtin_amdgcn_s_sleep(1);
-        } while (true);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = e0 + k * NF_CV_THREADS;
-            if (e < G * 64) xs[e] = __uint_as_float((unsigned)v[k]);
-        }
-    }
+    nf_cc_collect_slots(xs, rs, gen, G);
     if (round == 1) NF_CC_STAMP(58);
     __syncthreads();
     if (round == 1) NF_CC_STAMP(59);
@@ -342,7 +348,7 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
     return tot;
 }
 
-// LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[2][32] | kb[32] | red[2][NPB][32] | tot[64]
+// LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
 template <int NPB, int NKQ>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      float eps, float mom) {
@@ -546,6 +552,306 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     NF_CC_STAMP(51);
 }
 
+// =====================================================================================================================================
+// The backward twin: the DATA gradient of the whole conditioner in one persistent launch.  What a layer's data pass hands to the
+// next (nf_conv_bn_bwd with g_weff == NULL, six launches): gn_l = (W_{l+1}^T * G_{l+1}) . [ReLU mask of BatchNorm l], its batch sums
+// sum gn_l and sum gn_l xhat_l, and G_l = BNbwd_l(gn_l) (+ G_{l+2} on the residual stream) -- here G_l never leaves the workgroup: it
+// is written into the LDS frame the next transposed convolution reads.  The grid-wide exchange per layer carries the two PLAIN sums
+// (fixed order: this pass is deterministic, where the per-layer kernels add into replicas with atomics).  Global memory receives
+// exactly what the deferred weight-gradient launches (nf_conv_bn_wgrad_multi, unchanged) read afterwards: gn_0 .. gn_4, the sums
+// (totals in replica 0 of the zero-initialised replica arrays), G_4 and G_2 (the g_skip operands), and the input gradient.
+// Transposed convolutions reuse the forward K loop: the weights are staged as W4T[8 - tap][oc quad][ic][4].
+// =====================================================================================================================================
+__device__ __forceinline__ void nf_cc_wT_store(const NfCcW& w, float* W4, int wid, int lane) {
+    const int RSW = NF_CC_RSW(32), TS = NF_CC_TS(8, 32);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = lane + NF_WAVE * j;
+        const int ic = r / 9, tap = r - ic * 9;
+        if (r < 32 * 9) {                               // rows beyond the chunk's channels were loaded as zeros
+#pragma unroll
+            for (int u = 0; u < NF_CV_CU; ++u) {
+                const int oc = wid + u * NF_CV_WAVES;
+                W4[(8 - tap) * TS + (oc >> 2) * RSW + 4 * ic + (oc & 3)] = w.v[j][u];
+            }
+        }
+    }
+}
+
+// plain sums of two sets of OWN per-lane values over the 32 lanes of a wave half (halving butterfly, see nf_cc_half_stats)
+template <int OWN>
+__device__ __forceinline__ void nf_cc_half_sums2(const float (&u)[OWN], const float (&v)[OWN], int c32, float& S1, float& S2, int& which) {
+    static_assert(OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    float a4[4], b4[4];
+    int w = 0, m = 1;
+    if (OWN == 8) {
+        const bool up = c32 & 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a4[k] = (up ? u[k + 4] : u[k]) + __shfl_xor(up ? u[k] : u[k + 4], 1, NF_WAVE);
+            b4[k] = (up ? v[k + 4] : v[k]) + __shfl_xor(up ? v[k] : v[k + 4], 1, NF_WAVE);
+        }
+        w = up ? 4 : 0;
+        m = 2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a4[k] = u[k]; b4[k] = v[k]; }
+    }
+    float a2[2], b2[2];
+    {
+        const bool up = c32 & m;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            a2[k] = (up ? a4[k + 2] : a4[k]) + __shfl_xor(up ? a4[k] : a4[k + 2], m, NF_WAVE);
+            b2[k] = (up ? b4[k + 2] : b4[k]) + __shfl_xor(up ? b4[k] : b4[k + 2], m, NF_WAVE);
+        }
+        w += up ? 2 : 0;
+        m *= 2;
+    }
+    {
+        const bool up = c32 & m;
+        S1 = (up ? a2[1] : a2[0]) + __shfl_xor(up ? a2[0] : a2[1], m, NF_WAVE);
+        S2 = (up ? b2[1] : b2[0]) + __shfl_xor(up ? b2[0] : b2[1], m, NF_WAVE);
+        w += up ? 1 : 0;
+        m *= 2;
+    }
+    for (; m < 32; m *= 2) {
+        S1 += __shfl_xor(S1, m, NF_WAVE);
+        S2 += __shfl_xor(S2, m, NF_WAVE);
+    }
+    which = w;
+}
+
+// grid-wide plain sums of 2 x 32 values: red[h][pb][c] -> tot[32 h + c]; fixed summation order
+template <int NPB>
+__device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, int round) {
+    float* red = sm + L.RED;
+    float* xs = sm + L.RS;
+    float* part = sm + L.WL;                            // [16 parts][64]
+    float* tot = sm + L.TOT;
+    const int G = gridDim.x;
+    __syncthreads();                                    // red complete; RS / Wl no longer read by anybody
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x & 31, h = threadIdx.x >> 5;
+        float sv[NPB];
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) sv[q] = red[(h * NPB + q) * 32 + i];
+#pragma unroll
+        for (int w = 1; w < NPB; w *= 2)
+#pragma unroll
+            for (int q = 0; q < NPB; q += 2 * w) sv[q] += sv[q + w];
+        if (G == 1) tot[threadIdx.x] = sv[0];
+        else
+            __hip_atomic_store(slots + ((size_t)round * NF_CC_MAX_BLOCKS + blockIdx.x) * 64 + threadIdx.x,
+                               ((unsigned long long)(round + 1) << 32) | (unsigned long long)__float_as_uint(sv[0]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (G == 1) {
+        __syncthreads();
+        return tot;
+    }
+    nf_cc_collect_slots(xs, slots + (size_t)round * NF_CC_MAX_BLOCKS * 64, (unsigned)(round + 1), G);
+    __syncthreads();
+    const int i = threadIdx.x & 63, p = threadIdx.x >> 6;
+    float ps = 0.f;
+    for (int b = p; b < G; b += NF_CV_WAVES) ps += xs[b * 64 + i];
+    part[p * 64 + i] = ps;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float S = 0.f;
+#pragma unroll
+        for (int q = 0; q < NF_CV_WAVES; ++q) S += part[q * 64 + i];
+        tot[i] = S;
+    }
+    __syncthreads();
+    return tot;
+}
+
+template <int NPB, int NKQ>
+__global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_bwd_desc d, NfCvGeo g, int I0, int O_out, int training) {
+    static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
+    constexpr int OWN = 16 / NKQ, PXW = 32 * NPB;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const NfCcLds L = nf_cc_lds<NPB, NKQ>(g.CS, 1);
+    float* Wl = sm + L.WL;
+    float* RS = sm + L.RS;
+    float* kc = sm + L.KC;
+    float* red = sm + L.RED;
+    const int CS4 = 4 * g.CS;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    const int pb = wid % NPB, kq = wid / NPB;
+    const int64_t Npx = g.B * g.HW;
+    const int64_t tile = blockIdx.x;
+    const int px = pb * 32 + c32;
+    const int fpos = nf_cv_frame_of(g, px);
+    const int64_t P = tile * PXW + px;
+    const bool pv = P < Npx;
+    const int64_t b = pv ? P >> g.lgHW : 0;
+    const int64_t q = pv ? P & (g.HW - 1) : 0;
+    const float invN = 1.f / (float)Npx;
+    unsigned long long* slots = (unsigned long long*)d.ws_zero;
+
+    for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
+    float* Fin = sm + L.FA;
+    float* Fout = sm + L.FB;
+
+    // ---- the 1 x 1 output convolution, transposed: acc[ic][pixel] = sum_oc W5[oc][ic] g_out[oc][pixel].  No halo: the B operand comes
+    //      straight from global memory (a lane's own pixel; 4 x 128-byte segments per K group), K = oc split over the NKQ waves ----
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const int ng = (O_out + 7) >> 3;
+        for (int e = threadIdx.x; e < ng * 8 * 32; e += NF_CV_THREADS) {
+            const int oc = e >> 5, ic = e & 31;
+            Wl[(oc >> 2) * NF_CC_RSW(32) + 4 * ic + (oc & 3)] = oc < O_out ? d.w[5][e] : 0.f;
+        }
+        __syncthreads();
+        const int g0 = (kq * ng) / NKQ, g1 = ((kq + 1) * ng) / NKQ;
+        const float* go = d.g_out + b * O_out * g.HW + q;
+#pragma unroll 1
+        for (int gi = g0; gi < g1; gi += 4) {
+            float bv[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int oc = 8 * (gi + k) + 4 * hs + j;
+                    bv[k][j] = (gi + k < g1 && pv && oc < O_out) ? go[(int64_t)oc * g.HW] : 0.f;
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (gi + k < g1) {                      // wave-uniform
+                    const float4 a = *(const float4*)(Wl + (2 * (gi + k) + hs) * NF_CC_RSW(32) + 4 * c32);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[k][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[k][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[k][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[k][3], acc, 0, 0, 0);
+                }
+        }
+    }
+
+    float gstream[OWN], own[OWN];
+#pragma unroll
+    for (int rr = 0; rr < OWN; ++rr) gstream[rr] = 0.f;
+
+#pragma unroll 1
+    for (int l = NF_CC_NB - 1; l >= 0; --l) {
+        // BatchNorm l (input of the convolution whose transpose just ran): scale / shift exactly as the forward kernel computed them
+        if (threadIdx.x < 32) {
+            const int k = threadIdx.x;
+            const float mean = d.save_mean[l][k], invstd = d.save_invstd[l][k];
+            const float sc = d.gamma[l][k] * invstd;
+            kc[k] = sc;
+            kc[32 + k] = d.beta[l][k] - mean * sc;
+            kc[64 + k] = mean;
+            kc[96 + k] = invstd;
+        }
+        float xh[OWN];                                  // the forward activation, then its normalised value
+        {
+            const float* act = d.acts[l];
+#pragma unroll
+            for (int rr = 0; rr < OWN; ++rr) {
+                const int oc = nf_cv_cd_row(OWN * kq + rr, hs);
+                xh[rr] = pv ? act[(b * 32 + oc) * g.HW + q] : 0.f;
+            }
+        }
+        __syncthreads();                                // every wave is done with Wl / the frames of the K loop; kc is written
+        nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
+        float* gn = d.gn[l];
+#pragma unroll
+        for (int rr = 0; rr < OWN; ++rr) {
+            const int oc = nf_cv_cd_row(OWN * kq + rr, hs);
+            const float a = xh[rr];
+            const bool keep = pv && fmaf(a, kc[oc], kc[32 + oc]) > 0.f;
+            const float v = keep ? own[rr] : 0.f;
+            own[rr] = v;
+            xh[rr] = (a - kc[64 + oc]) * kc[96 + oc];
+            if (pv) gn[(b * 32 + oc) * g.HW + q] = v;
+        }
+        float mg[OWN], mgx[OWN];
+        {   // batch sums of gn and gn * xhat: the gradients of beta and gamma in either mode, the mean terms of the BatchNorm backward
+            // in training mode (evaluation mode normalises with constants: no mean terms)
+            float p2[OWN], S1, S2;
+            int which;
+#pragma unroll
+            for (int rr = 0; rr < OWN; ++rr) p2[rr] = own[rr] * xh[rr];
+            nf_cc_half_sums2<OWN>(own, p2, c32, S1, S2, which);
+            if (c32 < OWN) {
+                const int oc = nf_cv_cd_row(OWN * kq + which, hs);
+                red[pb * 32 + oc] = S1;
+                red[NPB * 32 + pb * 32 + oc] = S2;
+            }
+            const float* tot = nf_cc_sum_exchange<NPB>(sm, L, slots, l);
+            if (blockIdx.x == 0 && threadIdx.x < 64) (threadIdx.x < 32 ? d.sum_g[l] : d.sum_gx[l])[threadIdx.x & 31] = tot[threadIdx.x];
+#pragma unroll
+            for (int rr = 0; rr < OWN; ++rr) {
+                const int oc = nf_cv_cd_row(OWN * kq + rr, hs);
+                mg[rr] = training ? tot[oc] * invN : 0.f;
+                mgx[rr] = training ? tot[32 + oc] * invN : 0.f;
+            }
+        }
+        // G_l = BatchNorm backward (+ the residual stream's gradient), into the other frame
+        const bool on_stream = (l & 1) == 0;
+        float* gs = (l == 4) ? d.g_store[0] : (l == 2 ? d.g_store[1] : nullptr);
+#pragma unroll
+        for (int rr = 0; rr < OWN; ++rr) {
+            const int oc = nf_cv_cd_row(OWN * kq + rr, hs);
+            float G = kc[oc] * (own[rr] - mg[rr] - xh[rr] * mgx[rr]);
+            if (on_stream) G += gstream[rr];
+            G = pv ? G : 0.f;
+            own[rr] = G;
+            if (on_stream) gstream[rr] = G;
+            if (gs != nullptr && pv) gs[(b * 32 + oc) * g.HW + q] = G;
+        }
+#pragma unroll
+        for (int j = 0; j < OWN / 4; ++j) {
+            const int c0 = nf_cv_cd_row(OWN * kq + 4 * j, hs);
+            *(float4*)(Fout + (c0 >> 2) * CS4 + 4 * fpos) = make_float4(own[4 * j], own[4 * j + 1], own[4 * j + 2], own[4 * j + 3]);
+        }
+        { float* t = Fin; Fin = Fout; Fout = t; }
+        if (l >= 1) {                                   // transposed 3 x 3 convolution l: G_l -> layer l - 1
+            NfCcW wv;
+            nf_cc_w_load(wv, d.w[l], 32, 0, 32, wid, lane);
+            nf_cc_wT_store(wv, Wl, wid, lane);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int ng = 9 * 4;
+            const int g0 = (kq * ng) / NKQ;
+            int gcount = ng / NKQ;
+            asm volatile("" : "+s"(gcount));            // see the forward kernel
+            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+        }
+    }
+
+    // ---- gradient of the conditioner's input: convolution 0 transposed, 32 input channels per pass ----
+    if (d.g_x != nullptr) {
+        for (int i0 = 0; i0 < I0; i0 += 32) {
+            const int IC = min(32, I0 - i0);
+            NfCcW wv;
+            nf_cc_w_load(wv, d.w[0], I0, i0, IC, wid, lane);
+            __syncthreads();                            // readers of Wl / RS of the previous pass are done
+            nf_cc_wT_store(wv, Wl, wid, lane);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int ng = 9 * 4;
+            const int g0 = (kq * ng) / NKQ;
+            int gcount = ng / NKQ;
+            asm volatile("" : "+s"(gcount));
+            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            __syncthreads();
+            nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
+#pragma unroll
+            for (int rr = 0; rr < OWN; ++rr) {
+                const int ic = nf_cv_cd_row(OWN * kq + rr, hs);
+                if (pv && ic < IC) d.g_x[(b * I0 + i0 + ic) * g.HW + q] = own[rr];
+            }
+        }
+    }
+}
+
 template <typename K>
 static inline int nf_cc_optin(K kernel) {
     static std::mutex mu;
@@ -573,6 +879,9 @@ static int nf_cc_capacity() {
     return cap;
 }
 
+template <int NPB, int NKQ>
+static inline size_t nf_cc_lds_bytes(const NfCvGeo& g, int OCB) { return sizeof(float) * (size_t)nf_cc_lds<NPB, NKQ>(g.CS, OCB).total; }
+
 extern "C" int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W) {
     NfCvGeo g;
     if (B < 1 || I0 < 1 || I0 > NF_CV_MAX_I || O_out < 1 || O_out > NF_CV_MAX_O) return 0;
@@ -581,6 +890,8 @@ extern "C" int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int 
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return 0;
     if (g.tiles > NF_CC_MAX_BLOCKS || g.tiles > nf_cc_capacity()) return 0;
     if (!(B * 192 * (int64_t)H * W < (int64_t)1 << 31)) return 0;
+    const int OCB = (O_out + 31) / 32;
+    if ((PX == 256 ? nf_cc_lds_bytes<8, 2>(g, OCB) : nf_cc_lds_bytes<4, 4>(g, OCB)) > 160 * 1024) return 0;
     return 1;
 }
 
@@ -594,19 +905,38 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (PX == 256) {
-        const size_t lds = sizeof(float) * (size_t)nf_cc_lds<8, 2>(g.CS, OCB).total;
-        if (lds > 160 * 1024) return NF_E_BADARG;
         rc = nf_cc_optin(k_convnet_chain_fwd<8, 2>);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), lds, st, *desc, g, I0, O_out,
-                           training, bn_eps, bn_momentum);
+        hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
+                           g, I0, O_out, training, bn_eps, bn_momentum);
     } else {
-        const size_t lds = sizeof(float) * (size_t)nf_cc_lds<4, 4>(g.CS, OCB).total;
-        if (lds > 160 * 1024) return NF_E_BADARG;
         rc = nf_cc_optin(k_convnet_chain_fwd<4, 4>);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), lds, st, *desc, g, I0, O_out,
-                           training, bn_eps, bn_momentum);
+        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st, *desc,
+                           g, I0, O_out, training, bn_eps, bn_momentum);
+    }
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
+                                    nf_stream_t stream) {
+    if (desc == nullptr || !nf_convnet_chain_usable(B, I0, O_out, H, W)) return NF_E_BADARG;
+    NfCvGeo g;
+    const int PX = nf_cc_tile_px(H, W);
+    if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (PX == 256) {
+        rc = nf_cc_optin(k_convnet_chain_bwd<8, 2>);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
+                           I0, O_out, training);
+    } else {
+        rc = nf_cc_optin(k_convnet_chain_bwd<4, 4>);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc, g,
+                           I0, O_out, training);
     }
     NF_CHECK_LAUNCH();
     return 0;

@@ -49,7 +49,17 @@ class ConvNetDesc(ctypes.Structure):
                 ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('ws_zero', ctypes.c_void_p)]
 
 
+class ConvNetBwdDesc(ctypes.Structure):
+    """nf_convnet_bwd_desc of include/nfhip.h (the data gradient of the whole conditioner in one persistent launch)"""
+    _fields_ = [('w', ctypes.c_void_p * 6), ('gamma', ctypes.c_void_p * 5), ('beta', ctypes.c_void_p * 5),
+                ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('acts', ctypes.c_void_p * 5),
+                ('g_out', ctypes.c_void_p), ('gn', ctypes.c_void_p * 5), ('sum_g', ctypes.c_void_p * 5),
+                ('sum_gx', ctypes.c_void_p * 5), ('g_store', ctypes.c_void_p * 2), ('g_x', ctypes.c_void_p),
+                ('ws_zero', ctypes.c_void_p)]
+
+
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
+CONV_CHAIN_BWD_ON = __import__('os').environ.get('NF_CONV_CHAIN_BWD', '1') != '0'
 
 
 def _chain_usable(B, I0, O_out, Hh, Ww):
@@ -118,11 +128,9 @@ class ConvDefer:
             t = self.scratch[device] = torch.empty(n, dtype=torch.float32, device=device)
         return t
 
-    def flush(self):
-        layers, sums = self.layers, self.sums
-        self.layers, self.sums, self.active, self.armed = [], [], False, False
-        if not layers and not sums:
-            return
+    def launch_layers(self, layers):
+        """the weight-gradient passes of ``layers`` (entries as in self.layers), sixteen layers of one shape per launch, then their
+        slab sums"""
         step = N.header_constant('NF_CONV_WGRAD_MAX')
         groups = {}
         for e in layers:
@@ -144,6 +152,13 @@ class ConvDefer:
                     jobs.append((region, g_w, g_w.numel(), g_w.numel(), n_slabs, False, k * k))
                 N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
                 _slab_sum_all(jobs)                  # before the next chunk overwrites the scratch (stream order)
+
+    def flush(self):
+        layers, sums = self.layers, self.sums
+        self.layers, self.sums, self.active, self.armed = [], [], False, False
+        if not layers and not sums:
+            return
+        self.launch_layers(layers)
         _slab_sum_all(sums)
 
 
@@ -263,7 +278,7 @@ class _FusedConvNet(torch.autograd.Function):
         B, Hh, Ww = shape
         g_out = g_out.contiguous()
         slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
-        g_weff = [None] * nl if (ctx.defer and CONV_DEFER.active) else \
+        g_weff = [None] * nl if ((ctx.defer and CONV_DEFER.active) or (CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww))) else \
             [torch.empty(slabs, t.numel(), dtype=torch.float32, device=dev) for t in w]
         acc = WS.zeros(nl * R * GB + nb * 2 * R * H, dev)
         g_bias = [acc[i * R * GB:(i + 1) * R * GB] for i in range(nl)]
@@ -280,23 +295,44 @@ class _FusedConvNet(torch.autograd.Function):
                         cbn_sum_g=sums[j, 0] if training else None, cbn_sum_gx=sums[j, 1] if training else None)
 
         defer = ctx.defer and CONV_DEFER.active
+        # the data gradient of the whole conditioner in ONE persistent launch (csrc/conv_chain.hip); the weight passes follow as
+        # deferred (or, outside a trainer step, immediate) nf_conv_bn_wgrad_multi launches over the same descriptors
+        chained = CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww)
         queued = []
+        stores = [torch.empty_like(acts[0]) for _ in range(2)] if chained else None
 
         def layer(I, O, k, i, **kw):
-            """convolution i's backward: both passes now, or the data pass now and the weight pass queued"""
-            if not defer:
+            """convolution i's backward: both passes now, or the data pass now (unless the chain launch covers it) and the weight
+            pass queued"""
+            if not defer and not chained:
                 _bwd(shape, I, O, k, g_bias=g_bias[i], g_weff=g_weff[i], **kw)
                 return
-            _bwd(shape, I, O, k, **kw)
+            if not chained:
+                _bwd(shape, I, O, k, **kw)
             wkw = {f: v for f, v in kw.items() if f not in ('g_store', 'gn_out', 'sum_g', 'sum_gx')}
             wkw['g_bias'] = g_bias[i]
             queued.append(((shape, I, O, k), wkw, i))
+
+        if chained:
+            d = ConvNetBwdDesc()
+            for i in range(nl):
+                d.w[i] = w[i].data_ptr()
+            for j in range(nb):
+                d.gamma[j], d.beta[j] = gamma[j].data_ptr(), beta[j].data_ptr()
+                d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
+                d.acts[j], d.gn[j] = acts[j].data_ptr(), gn[j].data_ptr()
+                d.sum_g[j], d.sum_gx[j] = sums[j, 0].data_ptr(), sums[j, 1].data_ptr()
+            d.g_out = g_out.data_ptr()
+            d.g_store[0], d.g_store[1] = stores[0].data_ptr(), stores[1].data_ptr()
+            d.g_x = g_x.data_ptr() if g_x is not None else None
+            d.ws_zero = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev).data_ptr()
+            N.call('nf_convnet_chain_bwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), N.stream())
 
         layer(H, O_out, 1, nl - 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0],
               sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))
         for j in range(nb - 1, 0, -1):             # convolution j produced acts[j]; its consumer BatchNorm is j
             is_stream = (j % 2 == 0)
-            store = torch.empty_like(acts[0]) if is_stream else None
+            store = (stores[(nb - 1 - j) // 2] if chained else torch.empty_like(acts[0])) if is_stream else None
             layer(H, H, 3, j, in_=acts[j - 1], weight=w[j], gn_src=gn[j], out=acts[j], g_skip=G_skip if is_stream else None,
                   g_store=store, gn_out=gn[j - 1], sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1), **cons_bn(j))
             if is_stream:
@@ -321,6 +357,9 @@ class _FusedConvNet(torch.autograd.Function):
             for key, wkw, i in queued:             # (the tensors in wkw keep every operand alive until the flush)
                 CONV_DEFER.layers.append((key, wkw, g_w[i], slabs))
             CONV_DEFER.sums += jobs[nl:]
+        elif chained:
+            CONV_DEFER.launch_layers([(key, wkw, g_w[i], slabs) for key, wkw, i in queued])
+            _slab_sum(jobs[nl:])
         else:
             _slab_sum(jobs)
         grads = []
