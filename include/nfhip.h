@@ -415,6 +415,17 @@ typedef struct nf_convnet_desc {
     float* save_mean[5];      /* (32,), training: written */
     float* save_invstd[5];
     float* ws_zero;
+    /* Optional (cp_z != NULL): the affine coupling the conditioner belongs to (flows/coupling.py:104-122), in the epilogue of the
+     * output convolution.  The conditioner's input x is half 1 of the split map (cp_mode, cp_odd) of cp_z; with [shift | raw] the
+     * convolution's O = 2 I0 outputs, s = cp_a tanh(raw) + cp_c and `out` receives [exp(s) | tanh(raw)] (exp(-s) when cp_inverse) --
+     * what nf_convnet_chain_bwd reads as cp_out:
+     *     cp_y = merge(z0 exp(s) + shift, z1),  cp_ld[b] += sum s      (cp_inverse: (z0 - shift) exp(-s), cp_ld[b] -= sum s).    */
+    const float* cp_z;        /* (B, cp_C, Hf, Wf): Hf, Wf = H, W (NF_SPLIT_CHANNEL) or 2 H, 2 W (NF_SPLIT_CHECKER) */
+    float* cp_y;              /* (B, cp_C, Hf, Wf) written */
+    float* cp_ld;             /* (B,) += */
+    const float* cp_a;        /* scalars */
+    const float* cp_c;
+    int cp_mode, cp_odd, cp_C, cp_inverse;
 } nf_convnet_desc;
 int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W);
 int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training, float bn_eps,
@@ -437,6 +448,21 @@ typedef struct nf_convnet_bwd_desc {
     float* g_store[2];          /* (B, 32, H, W) written: gradients of acts[4] and acts[2] (the g_skip operands of layers 2 and 0) */
     float* g_x;                 /* (B, I0, H, W) written, or NULL */
     float* ws_zero;             /* NF_CONVNET_WS_FLOATS zeros (exchange slots) */
+    /* Optional (cp_g_y != NULL): the backward of the fused coupling.  g_out is then not read: the gradient of the conditioner's
+     * output is computed from (cp_g_y, cp_g_ld, cp_z, cp_out) on the way into the first transposed convolution and WRITTEN to
+     * cp_g_out (the deferred weight-gradient pass of the 1 x 1 convolution reads it); cp_g_z receives the full gradient of cp_z:
+     * g_y0 exp(s) on the transformed half, g_y1 + (gradient of the conditioner's input) on the other (g_x is not written).    */
+    const float* cp_g_y;        /* (B, cp_C, Hf, Wf) */
+    const float* cp_g_ld;       /* (B,) */
+    const float* cp_z;
+    const float* cp_out;        /* (B, O, H, W) the forward's out: [exp(s) | tanh(raw)] */
+    const float* cp_a;
+    const float* cp_c;          /* (not read: the forward left exp(s)) */
+    float* cp_g_z;              /* (B, cp_C, Hf, Wf) written */
+    float* cp_g_out;            /* (B, O, H, W) written */
+    float* cp_g_a;              /* scalars, += (atomic) */
+    float* cp_g_c;
+    int cp_mode, cp_odd, cp_C, cp_reserved;
 } nf_convnet_bwd_desc;
 int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
                          nf_stream_t stream);

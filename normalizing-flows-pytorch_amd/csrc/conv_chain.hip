@@ -15,6 +15,7 @@
 //   the K splits meet in LDS, every wave finishes 16 / NKQ output channels of its pixel block: bias, residual (kept in
 //   registers: the lane that finishes (channel, pixel) of layer l also finishes it for layer l + 2), store, statistics.
 //   Batch statistics are (sum, M2) pairs merged by the parallel-variance rule: half wave -> workgroup -> grid (no E[x^2] - E[x]^2).
+#include <cstring>
 #include <mutex>
 #include <unordered_set>
 #include "nf_conv_core.h"
@@ -348,10 +349,22 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
     return tot;
 }
 
+// ---- the affine coupling around the conditioner (flows/coupling.py:104-122), fused into the chain kernels ------------------------------
+// element (half channel m, half pixel q) of half `which` -> offset inside one sample of the full tensor (nf_half_to_full without the
+// divisions: the half's width is a power of two here)
+__device__ __forceinline__ int nf_cc_half_to_full(const NfSplit& s, int which, int m, int q, int lgw) {
+    const int sel = which ^ s.odd;
+    if (s.mode == NF_SPLIT_CHANNEL) return (m + sel * s.Ch) * (s.h * s.w) + q;
+    const int i = q >> lgw, j = q & (s.w - 1);
+    const int k = sel == 0 ? (m < s.C ? m : m + 2 * s.C) : (m + s.C);
+    const int c = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+    return (c * s.H + 2 * i + dy) * s.W + 2 * j + dx;
+}
+
 // LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
 template <int NPB, int NKQ>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
-                                                                     float eps, float mom) {
+                                                                     float eps, float mom, NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
     constexpr int OWN = 16 / NKQ, PXW = 32 * NPB;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -382,6 +395,17 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fin = sm + L.FA;
     float* Fout = sm + L.FB;
+    const bool cpl = d.cp_z != nullptr;                 // the coupling rides the epilogue of the output convolution
+    if (cpl) {
+        // y <- z for this workgroup's (contiguous) samples, whole 16-byte vectors, no index arithmetic; the transformed half is
+        // overwritten by the epilogue at the far end of the launch (same workgroup, barriers in between).  Nothing waits for it.
+        const int nsamp = g.HW < PXW ? PXW >> g.lgHW : 1;
+        const int64_t left = g.B - b0;
+        const int n4 = (int)(left < nsamp ? (left > 0 ? left : 0) : nsamp) * (cs.n_full >> 2);
+        const float4* src = reinterpret_cast<const float4*>(d.cp_z + b0 * cs.n_full);
+        float4* dst = reinterpret_cast<float4*>(d.cp_y + b0 * cs.n_full);
+        for (int idx = threadIdx.x; idx < n4; idx += NF_CV_THREADS) dst[idx] = src[idx];
+    }
 
     float stream[OWN], own[OWN];
 #pragma unroll
@@ -532,21 +556,78 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     NF_CC_STAMP(50);
 
     // ---- the 1 x 1 output convolution: wave (pb, kq) takes output blocks kq, kq + NKQ, ... ------------------------------------
+    // With the coupling fused, the rows are staged interleaved -- row 2 p of block ob = shift channel m = 16 ob + p, row 2 p + 1 =
+    // scale channel Ch + m -- so that a lane holds both parameters of the elements it transforms.
     const int WC = 32 * OCB, RSW5 = NF_CC_RSW(WC);
+    const int Ch = O_out >> 1;
     for (int e = threadIdx.x; e < O_out * 32; e += NF_CV_THREADS) {
         const int oc = e >> 5, ic = e & 31;
-        Wl[(ic >> 2) * RSW5 + 4 * oc + (ic & 3)] = d.w[5][e];
+        int row = oc;
+        if (cpl) {
+            const int m = oc < Ch ? oc : oc - Ch;
+            row = 32 * (m >> 4) + 2 * (m & 15) + (oc < Ch ? 0 : 1);
+        }
+        Wl[(ic >> 2) * RSW5 + 4 * row + (ic & 3)] = d.w[5][e];
     }
     __syncthreads();
+    float ls = 0.f;                                     // this lane's part of its sample's sum of scales
+    const float ca = cpl ? d.cp_a[0] : 0.f, cc = cpl ? d.cp_c[0] : 0.f;
+    const int lgw = cpl ? 31 - __clz(cs.w) : 0;
     for (int ob = kq; ob < OCB; ob += NKQ) {            // wave-uniform
         f32x16 a5;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a5[r] = 0.f;
         nf_cc_kloop<1>(a5, Wl, Fin, 0, RSW5, CS4, g.FW, 2, fpos, 32 * ob + c32, hs, 0, 4);
+        if (!cpl) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int oc = ob * 32 + nf_cv_cd_row(r, hs);
-            if (pv && oc < O_out) d.out[(b * O_out + oc) * g.HW + q] = a5[r] + d.b[5][oc];
+            for (int r = 0; r < 16; ++r) {
+                const int oc = ob * 32 + nf_cv_cd_row(r, hs);
+                if (pv && oc < O_out) d.out[(b * O_out + oc) * g.HW + q] = a5[r] + d.b[5][oc];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int m = 16 * ob + (nf_cv_cd_row(r, hs) >> 1);
+                if (pv && m < Ch) {
+                    const float t = a5[r] + d.b[5][m], sr = a5[r + 1] + d.b[5][Ch + m];
+                    const float th = tanhf(sr), sv = th * ca + cc;
+                    const float es = expf(d.cp_inverse ? -sv : sv);
+                    // what the backward needs of the conditioner's output is exp(s) and tanh(raw): `out` is private to the fused
+                    // coupling, so they are what it keeps (8 of 256 compute units redo 12 k transcendentals otherwise)
+                    d.out[(b * O_out + m) * g.HW + q] = es;
+                    d.out[(b * O_out + Ch + m) * g.HW + q] = th;
+                    const int64_t o = b * cs.n_full + nf_cc_half_to_full(cs, 0, m, (int)q, lgw);
+                    const float z0 = d.cp_z[o];
+                    d.cp_y[o] = d.cp_inverse ? es * (z0 - t) : z0 * es + t;
+                    ls += sv;
+                }
+            }
+        }
+    }
+    if (cpl) {                                          // log-det: per-sample sums inside the workgroup (it owns whole samples), fixed order
+        __syncthreads();
+        RS[(kq * 2 + hs) * PXW + px] = ls;
+        __syncthreads();
+        if (threadIdx.x < PXW) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2 * NKQ; ++k) v += RS[k * PXW + threadIdx.x];
+            const int seg = g.HW < NF_WAVE ? g.HW : NF_WAVE;
+            for (int off = seg >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, NF_WAVE);
+            if (g.HW <= NF_WAVE) {
+                const int64_t bb = b0 + ((int)threadIdx.x >> g.lgHW);
+                if ((threadIdx.x & (g.HW - 1)) == 0 && bb < g.B) atomicAdd(d.cp_ld + bb, d.cp_inverse ? -v : v);   // (no return value: nothing waits)
+            } else if (lane == 0) {
+                red[wid] = v;
+            }
+        }
+        if (g.HW > NF_WAVE) {                           // block-uniform: one sample per workgroup
+            __syncthreads();
+            if (threadIdx.x == 0 && b0 < g.B) {
+                float v = 0.f;
+                for (int k = 0; k < (g.HW >> 6); ++k) v += red[k];
+                atomicAdd(d.cp_ld + b0, d.cp_inverse ? -v : v);
+            }
         }
     }
     NF_CC_STAMP(51);
@@ -668,7 +749,8 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
 }
 
 template <int NPB, int NKQ>
-__global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_bwd_desc d, NfCvGeo g, int I0, int O_out, int training) {
+__global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_bwd_desc d, NfCvGeo g, int I0, int O_out, int training,
+                                                                     NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
     constexpr int OWN = 16 / NKQ, PXW = 32 * NPB;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -697,6 +779,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
 
     // ---- the 1 x 1 output convolution, transposed: acc[ic][pixel] = sum_oc W5[oc][ic] g_out[oc][pixel].  No halo: the B operand comes
     //      straight from global memory (a lane's own pixel; 4 x 128-byte segments per K group), K = oc split over the NKQ waves ----
+    const bool cpl = d.cp_g_y != nullptr;
+    const int Ch = O_out >> 1;
+    const int lgw = cpl ? 31 - __clz(cs.w) : 0;
+    const float ca = cpl ? d.cp_a[0] : 0.f;
+    float acc_a = 0.f, acc_c = 0.f;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -708,7 +795,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
         }
         __syncthreads();
         const int g0 = (kq * ng) / NKQ, g1 = ((kq + 1) * ng) / NKQ;
-        const float* go = d.g_out + b * O_out * g.HW + q;
+        const float* go = cpl ? nullptr : d.g_out + b * O_out * g.HW + q;
+        const float gl = (cpl && pv) ? d.cp_g_ld[b] : 0.f;
 #pragma unroll 1
         for (int gi = g0; gi < g1; gi += 4) {
             float bv[4][4];
@@ -717,7 +805,28 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int oc = 8 * (gi + k) + 4 * hs + j;
-                    bv[k][j] = (gi + k < g1 && pv && oc < O_out) ? go[(int64_t)oc * g.HW] : 0.f;
+                    const bool ok = gi + k < g1 && pv && oc < O_out;
+                    float v = 0.f;
+                    if (!cpl) {
+                        v = ok ? go[(int64_t)oc * g.HW] : 0.f;
+                    } else if (ok) {                    // the coupling's backward produces the conditioner's output gradient on the fly
+                        const bool is_s = oc >= Ch;
+                        const int m = is_s ? oc - Ch : oc;
+                        const int64_t o = b * cs.n_full + nf_cc_half_to_full(cs, 0, m, (int)q, lgw);
+                        const float gy0 = d.cp_g_y[o];
+                        v = gy0;                        // gradient of the shift
+                        if (is_s) {                     // cp_out = [exp(s) | tanh(raw)], left by the forward launch
+                            const float th = d.cp_out[(b * O_out + oc) * g.HW + q];
+                            const float es = d.cp_out[(b * O_out + m) * g.HW + q];
+                            d.cp_g_z[o] = gy0 * es;
+                            const float gs = gy0 * d.cp_z[o] * es + gl;
+                            v = gs * ca * (1.f - th * th);
+                            acc_a += gs * th;
+                            acc_c += gs;
+                        }
+                        d.cp_g_out[(b * O_out + oc) * g.HW + q] = v;   // the deferred weight-gradient pass of the 1 x 1 convolution reads it
+                    }
+                    bv[k][j] = v;
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -728,6 +837,14 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[k][2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[k][3], acc, 0, 0, 0);
                 }
+        }
+        if (cpl) {                                      // gradients of the coupling's two scalars: wave sums now, one atomic pair per workgroup below
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                acc_a += __shfl_xor(acc_a, off, NF_WAVE);
+                acc_c += __shfl_xor(acc_c, off, NF_WAVE);
+            }
+            if (lane == 0) { red[wid] = acc_a; red[NF_CV_WAVES + wid] = acc_c; }
         }
     }
 
@@ -757,6 +874,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             }
         }
         __syncthreads();                                // every wave is done with Wl / the frames of the K loop; kc is written
+        if (cpl && l == NF_CC_NB - 1 && threadIdx.x == 0) {
+            float ta = 0.f, tc = 0.f;
+            for (int k = 0; k < NF_CV_WAVES; ++k) { ta += red[k]; tc += red[NF_CV_WAVES + k]; }
+            atomicAdd(d.cp_g_a, ta);
+            atomicAdd(d.cp_g_c, tc);
+        }
         nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
         float* gn = d.gn[l];
 #pragma unroll
@@ -826,7 +949,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     }
 
     // ---- gradient of the conditioner's input: convolution 0 transposed, 32 input channels per pass ----
-    if (d.g_x != nullptr) {
+    if (d.g_x != nullptr || cpl) {
         for (int i0 = 0; i0 < I0; i0 += 32) {
             const int IC = min(32, I0 - i0);
             NfCcW wv;
@@ -840,13 +963,25 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             const int g0 = (kq * ng) / NKQ;
             int gcount = ng / NKQ;
             asm volatile("" : "+s"(gcount));
+            float gyv[OWN];                             // pass-through gradient of the untouched half: in flight under the K loop
+            if (cpl) {
+#pragma unroll
+                for (int rr = 0; rr < OWN; ++rr) {
+                    const int ic = nf_cv_cd_row(OWN * kq + rr, hs);
+                    gyv[rr] = (pv && ic < IC) ? d.cp_g_y[b * cs.n_full + nf_cc_half_to_full(cs, 1, i0 + ic, (int)q, lgw)] : 0.f;
+                }
+            }
             nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
             __syncthreads();
             nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
 #pragma unroll
             for (int rr = 0; rr < OWN; ++rr) {
                 const int ic = nf_cv_cd_row(OWN * kq + rr, hs);
-                if (pv && ic < IC) d.g_x[(b * I0 + i0 + ic) * g.HW + q] = own[rr];
+                if (pv && ic < IC) {
+                    if (!cpl) d.g_x[(b * I0 + i0 + ic) * g.HW + q] = own[rr];
+                    else      // the untouched half: its pass-through gradient + the conditioner's input gradient
+                        d.cp_g_z[b * cs.n_full + nf_cc_half_to_full(cs, 1, i0 + ic, (int)q, lgw)] = gyv[rr] + own[rr];
+                }
             }
         }
     }
@@ -895,9 +1030,23 @@ extern "C" int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int 
     return 1;
 }
 
+// the split map of the coupling fused into a chain launch (the conditioner runs on the half's shape (Ch, H, W))
+static bool nf_cc_coupling_split(NfSplit& cs, int mode, int odd, int C, int I0, int O_out, int H, int W) {
+    if (mode != NF_SPLIT_CHANNEL && mode != NF_SPLIT_CHECKER) return false;
+    const bool ck = mode == NF_SPLIT_CHECKER;
+    if (!nf_make_split(cs, mode, odd, C, ck ? 2 * H : H, ck ? 2 * W : W)) return false;
+    return cs.Ch == I0 && O_out == 2 * I0 && cs.h == H && cs.w == W;
+}
+
 extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
                                     float bn_eps, float bn_momentum, nf_stream_t stream) {
     if (desc == nullptr || !nf_convnet_chain_usable(B, I0, O_out, H, W)) return NF_E_BADARG;
+    NfSplit cs;
+    memset(&cs, 0, sizeof(cs));
+    if (desc->cp_z != nullptr) {
+        if (desc->cp_y == nullptr || desc->cp_ld == nullptr || desc->cp_a == nullptr || desc->cp_c == nullptr) return NF_E_BADARG;
+        if (!nf_cc_coupling_split(cs, desc->cp_mode, desc->cp_odd, desc->cp_C, I0, O_out, H, W)) return NF_E_BADARG;
+    }
     NfCvGeo g;
     const int PX = nf_cc_tile_px(H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
@@ -908,12 +1057,12 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
         rc = nf_cc_optin(k_convnet_chain_fwd<8, 2>);
         if (rc) return rc;
         hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
-                           g, I0, O_out, training, bn_eps, bn_momentum);
+                           g, I0, O_out, training, bn_eps, bn_momentum, cs);
     } else {
         rc = nf_cc_optin(k_convnet_chain_fwd<4, 4>);
         if (rc) return rc;
         hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st, *desc,
-                           g, I0, O_out, training, bn_eps, bn_momentum);
+                           g, I0, O_out, training, bn_eps, bn_momentum, cs);
     }
     NF_CHECK_LAUNCH();
     return 0;
@@ -922,6 +1071,16 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
 extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
                                     nf_stream_t stream) {
     if (desc == nullptr || !nf_convnet_chain_usable(B, I0, O_out, H, W)) return NF_E_BADARG;
+    NfSplit cs;
+    memset(&cs, 0, sizeof(cs));
+    if (desc->cp_g_y != nullptr) {
+        if (desc->cp_g_ld == nullptr || desc->cp_z == nullptr || desc->cp_out == nullptr || desc->cp_a == nullptr || desc->cp_c == nullptr ||
+            desc->cp_g_z == nullptr || desc->cp_g_out == nullptr || desc->cp_g_a == nullptr || desc->cp_g_c == nullptr)
+            return NF_E_BADARG;
+        if (!nf_cc_coupling_split(cs, desc->cp_mode, desc->cp_odd, desc->cp_C, I0, O_out, H, W)) return NF_E_BADARG;
+    } else if (desc->g_out == nullptr) {
+        return NF_E_BADARG;
+    }
     NfCvGeo g;
     const int PX = nf_cc_tile_px(H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
@@ -931,12 +1090,12 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
         rc = nf_cc_optin(k_convnet_chain_bwd<8, 2>);
         if (rc) return rc;
         hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
-                           I0, O_out, training);
+                           I0, O_out, training, cs);
     } else {
         rc = nf_cc_optin(k_convnet_chain_bwd<4, 4>);
         if (rc) return rc;
         hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc, g,
-                           I0, O_out, training);
+                           I0, O_out, training, cs);
     }
     NF_CHECK_LAUNCH();
     return 0;

@@ -472,6 +472,7 @@ class _FlowBNHead(torch.autograd.Function):
         ctx.save_for_backward(batch_var, log_gamma)
         ctx.meta = (mode, int(odd), tuple(x.shape), gather)
         ctx.mark_dirty(ld)
+        ctx.set_materialize_grads(False)          # the gathered half has no gradient of its own under the fused image coupling
         if gather:
             return y, z1c, ld
         return y, ld
@@ -482,9 +483,11 @@ class _FlowBNHead(torch.autograd.Function):
         mode, odd, shape, gather = ctx.meta
         if gather:
             g_h, g_z1c, g_ld = grads
-            g_z1c = _contig(g_z1c)
+            g_z1c = _contig(g_z1c) if g_z1c is not None else None
         else:
             (g_h, g_ld), g_z1c = grads, None
+        if g_h is None:                            # (grads are not materialised: an unused output arrives as None)
+            g_h = torch.zeros(shape, dtype=batch_var.dtype, device=batch_var.device)
         g_h = _contig(g_h)
         B, C, H, W = shape if len(shape) == 4 else (shape[0], shape[1], 1, 1)
         g_x = torch.empty_like(g_h)
@@ -516,6 +519,7 @@ class _GlowHead(torch.autograd.Function):
         ctx.meta = (mode, int(odd))
         ctx.sinks = _sinks(log_scale, bias, L, U, log_s)
         ctx.mark_dirty(ld)
+        ctx.set_materialize_grads(False)          # the gathered half has no gradient of its own under the fused image coupling
         return h, z1c, ld
 
     @staticmethod
@@ -523,7 +527,11 @@ class _GlowHead(torch.autograd.Function):
         z, log_scale, bias, Wm, P, L, U, L_mask, U_mask, sign_s, log_s = ctx.saved_tensors
         mode, odd = ctx.meta
         B, C, H, W = _bchw(z)
-        g_h, g_z1c, g_ld = _contig(g_h), _contig(g_z1c), _contig(g_ld)
+        if g_h is None:                            # (grads are not materialised: an unused output arrives as None)
+            g_h = torch.zeros_like(z)
+        if g_ld is None:
+            g_ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+        g_h, g_z1c, g_ld = _contig(g_h), (_contig(g_z1c) if g_z1c is not None else None), _contig(g_ld)
         g_z = torch.empty_like(z)
         direct = ctx.sinks is not None
         tmp = WS.zeros(C * C + 4 + (0 if direct else 2 * C), z.device)

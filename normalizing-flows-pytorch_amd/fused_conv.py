@@ -46,7 +46,10 @@ class ConvNetDesc(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p * 6), ('b', ctypes.c_void_p * 6), ('gamma', ctypes.c_void_p * 5),
                 ('beta', ctypes.c_void_p * 5), ('rmean', ctypes.c_void_p * 5), ('rvar', ctypes.c_void_p * 5),
                 ('nbt', ctypes.c_void_p * 5), ('acts', ctypes.c_void_p * 5), ('out', ctypes.c_void_p),
-                ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('ws_zero', ctypes.c_void_p)]
+                ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('ws_zero', ctypes.c_void_p),
+                ('cp_z', ctypes.c_void_p), ('cp_y', ctypes.c_void_p), ('cp_ld', ctypes.c_void_p), ('cp_a', ctypes.c_void_p),
+                ('cp_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int), ('cp_C', ctypes.c_int),
+                ('cp_inverse', ctypes.c_int)]
 
 
 class ConvNetBwdDesc(ctypes.Structure):
@@ -55,11 +58,16 @@ class ConvNetBwdDesc(ctypes.Structure):
                 ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('acts', ctypes.c_void_p * 5),
                 ('g_out', ctypes.c_void_p), ('gn', ctypes.c_void_p * 5), ('sum_g', ctypes.c_void_p * 5),
                 ('sum_gx', ctypes.c_void_p * 5), ('g_store', ctypes.c_void_p * 2), ('g_x', ctypes.c_void_p),
-                ('ws_zero', ctypes.c_void_p)]
+                ('ws_zero', ctypes.c_void_p),
+                ('cp_g_y', ctypes.c_void_p), ('cp_g_ld', ctypes.c_void_p), ('cp_z', ctypes.c_void_p), ('cp_out', ctypes.c_void_p),
+                ('cp_a', ctypes.c_void_p), ('cp_c', ctypes.c_void_p), ('cp_g_z', ctypes.c_void_p), ('cp_g_out', ctypes.c_void_p),
+                ('cp_g_a', ctypes.c_void_p), ('cp_g_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int),
+                ('cp_C', ctypes.c_int), ('cp_reserved', ctypes.c_int)]
 
 
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
 CONV_CHAIN_BWD_ON = __import__('os').environ.get('NF_CONV_CHAIN_BWD', '1') != '0'
+CONV_COUPLING_ON = __import__('os').environ.get('NF_CONV_COUPLING', '1') != '0'
 
 
 def _chain_usable(B, I0, O_out, Hh, Ww):
@@ -180,14 +188,20 @@ def _convnet_modules(net):
 def convnet_usable(net, x):
     """ConvNet with two residual blocks of 32 filters on an input whose spatial size tiles into the kernels' 128-pixel
     groups (every level of the reference's CIFAR / MNIST-style pyramids does)."""
-    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0 and len(net.mid_block) == 2):
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        return False
+    return _convnet_usable_shape(net, tuple(x.shape))
+
+
+def _convnet_usable_shape(net, shape):
+    if not (shape[0] > 0 and len(net.mid_block) == 2):
         return False
     convs, _ = _convnet_modules(net)
     c0 = getattr(convs[0], 'module', convs[0])
     c5 = getattr(convs[-1], 'module', convs[-1])
     if c0.out_channels != H or c5.in_channels != H or c0.kernel_size != (3, 3) or c5.kernel_size != (1, 1):
         return False
-    B, I, Hh, Ww = x.shape
+    B, I, Hh, Ww = shape
     lib = N.load()
     return bool(lib.nf_conv_bn_usable(B, I, H, Hh, Ww, 3) and lib.nf_conv_bn_usable(B, H, c5.out_channels, Hh, Ww, 1))
 
@@ -205,6 +219,75 @@ def _convnet_tensors(net):
     return tensors
 
 
+def _cn_forward(ctx, x, training, defer, tensors, cpl=None):
+    """forward of the conditioner; ``cpl`` = (z, ld, a, c, mode, odd, inverse): the affine coupling it parameterises rides the
+    epilogue of the chain launch (returns y; ld is updated in place), else returns the conditioner's output."""
+    nl, nb = 6, 5
+    conv = [tensors[2 * i:2 * i + 2] for i in range(nl)]
+    bns = [tensors[2 * nl + 5 * i:2 * nl + 5 * i + 5] for i in range(nb)]
+    x = x.contiguous()
+    B, I0, Hh, Ww = x.shape
+    shape = (B, Hh, Ww)
+    O_out = conv[-1][0].shape[0]
+    dev = x.device
+    ws = WS.zeros(nb * WS_ROWS * H, dev).view(nb, WS_ROWS, H)
+    acts = [torch.empty(B, H, Hh, Ww, dtype=torch.float32, device=dev) for _ in range(nb)]
+    out = torch.empty(B, O_out, Hh, Ww, dtype=torch.float32, device=dev)
+    w = [c[0].contiguous() for c in conv]
+    y = None
+
+    def bn_kw(j):
+        g, b, rm, rv, nbt = bns[j]
+        return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[j, 0], bn_sqsum=ws[j, R], bn_center=conv[j][1], bn_running_mean=rm,
+                    bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
+
+    def stats(j):                             # evaluation mode normalises with running statistics: no batch sums
+        return dict(stat_sum=ws[j, 0], stat_sqsum=ws[j, R]) if training else {}
+
+    if _chain_usable(B, I0, O_out, Hh, Ww):   # the whole conditioner: ONE persistent launch (csrc/conv_chain.hip)
+        d = ConvNetDesc()
+        d.x = x.data_ptr()
+        for i in range(nl):
+            d.w[i], d.b[i] = w[i].data_ptr(), conv[i][1].data_ptr()
+        for j in range(nb):
+            g_, b_, rm, rv, nbt = bns[j]
+            d.gamma[j], d.beta[j], d.rmean[j], d.rvar[j] = g_.data_ptr(), b_.data_ptr(), rm.data_ptr(), rv.data_ptr()
+            d.nbt[j] = nbt.data_ptr() if nbt is not None else None
+            d.acts[j] = acts[j].data_ptr()
+            d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
+        d.out = out.data_ptr()
+        # (the slots' tensor must outlive every allocation up to the launch: a freed block is handed to the next torch.empty)
+        slots = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev) if training else None
+        d.ws_zero = slots.data_ptr() if training else None
+        if cpl is not None:
+            z, ld, a, c, mode, odd, inverse = cpl
+            y = torch.empty_like(z)
+            d.cp_z, d.cp_y, d.cp_ld, d.cp_a, d.cp_c = z.data_ptr(), y.data_ptr(), ld.data_ptr(), a.data_ptr(), c.data_ptr()
+            d.cp_mode, d.cp_odd, d.cp_C, d.cp_inverse = int(mode), int(odd), z.shape[1], int(inverse)
+        N.call('nf_convnet_chain_fwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), BN_EPS, BN_MOMENTUM, N.stream())
+    else:
+        if cpl is not None:
+            raise RuntimeError('the fused coupling needs the chain kernel (coupling_fusable was not consulted)')
+        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], **stats(0))
+        for j in range(1, nb):                # convolution j consumes acts[j-1] through BatchNorm j-1
+            res = acts[j - 2] if j % 2 == 0 else None
+            _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j],
+                 **stats(j), **bn_kw(j - 1))
+        _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
+             **bn_kw(nb - 1))
+    from .functional import _sinks
+    extra = ()
+    if cpl is not None:
+        extra = (cpl[0], out, cpl[2], cpl[3])
+        ctx.cpl_meta = (int(cpl[4]), int(cpl[5]))
+        ctx.cpl_sinks = _sinks(cpl[2], cpl[3])
+    ctx.save_for_backward(x, ws, *acts, *w, *[t for b in bns for t in b[:2]], *extra)
+    ctx.meta = (shape, I0, O_out, bool(training))
+    ctx.sinks = _sinks(*[c[1] for c in conv], *[t for b in bns for t in b[:2]])
+    ctx.defer = bool(defer) and ctx.sinks is not None
+    return out if cpl is None else y
+
+
 class _FusedConvNet(torch.autograd.Function):
     """x -> conv0 -> [BN,ReLU,conv, BN,ReLU,conv, +skip] * 2 -> BN,ReLU,conv1x1.
 
@@ -213,164 +296,196 @@ class _FusedConvNet(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, training, defer, *tensors):
-        nl, nb = 6, 5
-        conv = [tensors[2 * i:2 * i + 2] for i in range(nl)]
-        bns = [tensors[2 * nl + 5 * i:2 * nl + 5 * i + 5] for i in range(nb)]
-        x = x.contiguous()
-        B, I0, Hh, Ww = x.shape
-        shape = (B, Hh, Ww)
-        O_out = conv[-1][0].shape[0]
-        dev = x.device
-        ws = WS.zeros(nb * WS_ROWS * H, dev).view(nb, WS_ROWS, H)
-        acts = [torch.empty(B, H, Hh, Ww, dtype=torch.float32, device=dev) for _ in range(nb)]
-        out = torch.empty(B, O_out, Hh, Ww, dtype=torch.float32, device=dev)
-        w = [c[0].contiguous() for c in conv]
-
-        def bn_kw(j):
-            g, b, rm, rv, nbt = bns[j]
-            return dict(bn_gamma=g, bn_beta=b, bn_sum=ws[j, 0], bn_sqsum=ws[j, R], bn_center=conv[j][1], bn_running_mean=rm,
-                        bn_running_var=rv, bn_num_batches=nbt, bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
-
-        def stats(j):                             # evaluation mode normalises with running statistics: no batch sums
-            return dict(stat_sum=ws[j, 0], stat_sqsum=ws[j, R]) if training else {}
-
-        if _chain_usable(B, I0, O_out, Hh, Ww):   # the whole conditioner: ONE persistent launch (csrc/conv_chain.hip)
-            d = ConvNetDesc()
-            d.x = x.data_ptr()
-            for i in range(nl):
-                d.w[i], d.b[i] = w[i].data_ptr(), conv[i][1].data_ptr()
-            for j in range(nb):
-                g_, b_, rm, rv, nbt = bns[j]
-                d.gamma[j], d.beta[j], d.rmean[j], d.rvar[j] = g_.data_ptr(), b_.data_ptr(), rm.data_ptr(), rv.data_ptr()
-                d.nbt[j] = nbt.data_ptr() if nbt is not None else None
-                d.acts[j] = acts[j].data_ptr()
-                d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
-            d.out = out.data_ptr()
-            d.ws_zero = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev).data_ptr() if training else None
-            N.call('nf_convnet_chain_fwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), BN_EPS, BN_MOMENTUM, N.stream())
-        else:
-            _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], **stats(0))
-            for j in range(1, nb):                # convolution j consumes acts[j-1] through BatchNorm j-1
-                res = acts[j - 2] if j % 2 == 0 else None
-                _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j],
-                     **stats(j), **bn_kw(j - 1))
-            _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
-                 **bn_kw(nb - 1))
-        ctx.save_for_backward(x, ws, *acts, *w, *[t for b in bns for t in b[:2]])
-        ctx.meta = (shape, I0, O_out, bool(training))
-        from .functional import _sinks
-        ctx.sinks = _sinks(*[c[1] for c in conv], *[t for b in bns for t in b[:2]])
-        ctx.defer = bool(defer) and ctx.sinks is not None
-        return out
+        return _cn_forward(ctx, x, training, defer, tensors)
 
     @staticmethod
     def backward(ctx, g_out):
-        shape, I0, O_out, training = ctx.meta
-        nl, nb = 6, 5
-        saved = ctx.saved_tensors
-        x, ws = saved[0], saved[1]
-        acts = saved[2:2 + nb]
-        w = saved[2 + nb:2 + nb + nl]
-        gb = saved[2 + nb + nl:]
-        gamma = [gb[2 * i] for i in range(nb)]
-        beta = [gb[2 * i + 1] for i in range(nb)]
-        dev = x.device
-        B, Hh, Ww = shape
-        g_out = g_out.contiguous()
-        slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
-        g_weff = [None] * nl if ((ctx.defer and CONV_DEFER.active) or (CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww))) else \
-            [torch.empty(slabs, t.numel(), dtype=torch.float32, device=dev) for t in w]
-        acc = WS.zeros(nl * R * GB + nb * 2 * R * H, dev)
-        g_bias = [acc[i * R * GB:(i + 1) * R * GB] for i in range(nl)]
-        sums = acc[nl * R * GB:].view(nb, 2, R * H)
-        gn = [torch.empty_like(acts[0]) for _ in range(nb)]
-        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        G_skip = None
+        lead, grads = _cn_backward(ctx, g_out)
+        return (lead[0], None, None) + grads
 
-        def in_bn(j):
-            return dict(bn_gamma=gamma[j], bn_beta=beta[j], bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
 
-        def cons_bn(j):                            # evaluation mode: statistics are constants -> no mean terms
-            return dict(cbn_gamma=gamma[j], cbn_save_mean=ws[j, 2 * R], cbn_save_invstd=ws[j, 2 * R + 1],
-                        cbn_sum_g=sums[j, 0] if training else None, cbn_sum_gx=sums[j, 1] if training else None)
+class _FusedConvCoupling(torch.autograd.Function):
+    """the affine coupling of an image model WITH its conditioner: y, ld = coupling(z, ConvNet(x)) where x is the untouched half of
+    z (gathered by the caller: the fused Glow head produces it anyway).  One launch per direction: the transform, the merge and the
+    log-det sums ride the epilogue of the conditioner's output convolution; backward, the coupling's gradient is formed on the way
+    into the first transposed convolution and the conditioner's input gradient lands directly in the gradient of z -- so the
+    gradient of x is reported as None (it is contained in that of z)."""
 
-        defer = ctx.defer and CONV_DEFER.active
-        # the data gradient of the whole conditioner in ONE persistent launch (csrc/conv_chain.hip); the weight passes follow as
-        # deferred (or, outside a trainer step, immediate) nf_conv_bn_wgrad_multi launches over the same descriptors
-        chained = CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww)
-        queued = []
-        stores = [torch.empty_like(acts[0]) for _ in range(2)] if chained else None
+    @staticmethod
+    def forward(ctx, z, x, ld, a, c, mode, odd, training, defer, *tensors):
+        y = _cn_forward(ctx, x, training, defer, tensors, cpl=(z, ld, a, c, mode, odd, 0))
+        ctx.mark_dirty(ld)
+        return y, ld
 
-        def layer(I, O, k, i, **kw):
-            """convolution i's backward: both passes now, or the data pass now (unless the chain launch covers it) and the weight
-            pass queued"""
-            if not defer and not chained:
-                _bwd(shape, I, O, k, g_bias=g_bias[i], g_weff=g_weff[i], **kw)
-                return
-            if not chained:
-                _bwd(shape, I, O, k, **kw)
-            wkw = {f: v for f, v in kw.items() if f not in ('g_store', 'gn_out', 'sum_g', 'sum_gx')}
-            wkw['g_bias'] = g_bias[i]
-            queued.append(((shape, I, O, k), wkw, i))
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        (g_z, g_a, g_c), grads = _cn_backward(ctx, None, cpl_grads=(g_y.contiguous(), g_ld.contiguous()))
+        return (g_z, None, g_ld, g_a, g_c, None, None, None, None) + grads
 
-        if chained:
-            d = ConvNetBwdDesc()
-            for i in range(nl):
-                d.w[i] = w[i].data_ptr()
-            for j in range(nb):
-                d.gamma[j], d.beta[j] = gamma[j].data_ptr(), beta[j].data_ptr()
-                d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
-                d.acts[j], d.gn[j] = acts[j].data_ptr(), gn[j].data_ptr()
-                d.sum_g[j], d.sum_gx[j] = sums[j, 0].data_ptr(), sums[j, 1].data_ptr()
-            d.g_out = g_out.data_ptr()
-            d.g_store[0], d.g_store[1] = stores[0].data_ptr(), stores[1].data_ptr()
-            d.g_x = g_x.data_ptr() if g_x is not None else None
-            d.ws_zero = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev).data_ptr()
-            N.call('nf_convnet_chain_bwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), N.stream())
 
-        layer(H, O_out, 1, nl - 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0],
-              sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))
-        for j in range(nb - 1, 0, -1):             # convolution j produced acts[j]; its consumer BatchNorm is j
-            is_stream = (j % 2 == 0)
-            store = (stores[(nb - 1 - j) // 2] if chained else torch.empty_like(acts[0])) if is_stream else None
-            layer(H, H, 3, j, in_=acts[j - 1], weight=w[j], gn_src=gn[j], out=acts[j], g_skip=G_skip if is_stream else None,
-                  g_store=store, gn_out=gn[j - 1], sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1), **cons_bn(j))
-            if is_stream:
-                G_skip = store
-        layer(I0, H, 3, 0, in_=x, weight=w[0], gn_src=gn[0], out=acts[0], g_skip=G_skip, gn_out=g_x, **cons_bn(0))
+def _cn_backward(ctx, g_out, cpl_grads=None):
+    """backward of _cn_forward: returns (leading gradients, parameter gradients).  Leading = (g_x,) for the bare conditioner,
+    (g_z, g_a, g_c) with the fused coupling (``cpl_grads`` = (g_y, g_ld); g_x is folded into g_z)."""
+    shape, I0, O_out, training = ctx.meta
+    nl, nb = 6, 5
+    saved = ctx.saved_tensors
+    x, ws = saved[0], saved[1]
+    acts = saved[2:2 + nb]
+    w = saved[2 + nb:2 + nb + nl]
+    gb = saved[2 + nb + nl:2 + nb + nl + 2 * nb]
+    cpl = saved[2 + nb + nl + 2 * nb:] if cpl_grads is not None else None      # (z, out, a, c)
+    gamma = [gb[2 * i] for i in range(nb)]
+    beta = [gb[2 * i + 1] for i in range(nb)]
+    dev = x.device
+    B, Hh, Ww = shape
+    g_out = g_out.contiguous() if cpl is None else torch.empty_like(cpl[1])    # fused coupling: written by the chain launch
+    slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
+    g_weff = [None] * nl if ((ctx.defer and CONV_DEFER.active) or (CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww))) else \
+        [torch.empty(slabs, t.numel(), dtype=torch.float32, device=dev) for t in w]
+    acc = WS.zeros(nl * R * GB + nb * 2 * R * H, dev)
+    g_bias = [acc[i * R * GB:(i + 1) * R * GB] for i in range(nl)]
+    sums = acc[nl * R * GB:].view(nb, 2, R * H)
+    gn = [torch.empty_like(acts[0]) for _ in range(nb)]
+    g_x = torch.empty_like(x) if (cpl is None and ctx.needs_input_grad[0]) else None
+    G_skip = None
 
-        direct = ctx.sinks is not None
-        g_w = [torch.empty_like(t) for t in w]
-        if direct:
-            d_bias = ctx.sinks[:nl]
-            d_bn = [tuple(ctx.sinks[nl + 2 * j:nl + 2 * j + 2]) for j in range(nb)]
-        else:
-            d_bias = [torch.empty(t.shape[0], dtype=torch.float32, device=dev) for t in w]
-            d_bn = [(torch.empty(H, dtype=torch.float32, device=dev), torch.empty(H, dtype=torch.float32, device=dev))
-                    for _ in range(nb)]
-        jobs = [(g_weff[i], g_w[i], w[i].numel(), w[i].numel(), slabs, False, w[i].shape[2] * w[i].shape[3]) for i in range(nl)]
-        jobs += [(g_bias[i], d_bias[i], w[i].shape[0], GB, R, direct, 1) for i in range(nl)]
-        for j in range(nb):
-            jobs.append((sums[j, 1], d_bn[j][0], H, H, R, direct, 1))       # g_gamma = sum g * xhat
-            jobs.append((sums[j, 0], d_bn[j][1], H, H, R, direct, 1))       # g_beta  = sum g
-        if defer:
-            for key, wkw, i in queued:             # (the tensors in wkw keep every operand alive until the flush)
-                CONV_DEFER.layers.append((key, wkw, g_w[i], slabs))
-            CONV_DEFER.sums += jobs[nl:]
-        elif chained:
-            CONV_DEFER.launch_layers([(key, wkw, g_w[i], slabs) for key, wkw, i in queued])
-            _slab_sum(jobs[nl:])
-        else:
-            _slab_sum(jobs)
-        grads = []
+    def in_bn(j):
+        return dict(bn_gamma=gamma[j], bn_beta=beta[j], bn_save_mean=ws[j, 2 * R], bn_save_invstd=ws[j, 2 * R + 1])
+
+    def cons_bn(j):                            # evaluation mode: statistics are constants -> no mean terms
+        return dict(cbn_gamma=gamma[j], cbn_save_mean=ws[j, 2 * R], cbn_save_invstd=ws[j, 2 * R + 1],
+                    cbn_sum_g=sums[j, 0] if training else None, cbn_sum_gx=sums[j, 1] if training else None)
+
+    defer = ctx.defer and CONV_DEFER.active
+    # the data gradient of the whole conditioner in ONE persistent launch (csrc/conv_chain.hip); the weight passes follow as
+    # deferred (or, outside a trainer step, immediate) nf_conv_bn_wgrad_multi launches over the same descriptors
+    chained = CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww)
+    if cpl is not None and not chained:
+        raise RuntimeError('the fused coupling needs the chain kernels in both directions')
+    queued = []
+    stores = [torch.empty_like(acts[0]) for _ in range(2)] if chained else None
+
+    def layer(I, O, k, i, **kw):
+        """convolution i's backward: both passes now, or the data pass now (unless the chain launch covers it) and the weight
+        pass queued"""
+        if not defer and not chained:
+            _bwd(shape, I, O, k, g_bias=g_bias[i], g_weff=g_weff[i], **kw)
+            return
+        if not chained:
+            _bwd(shape, I, O, k, **kw)
+        wkw = {f: v for f, v in kw.items() if f not in ('g_store', 'gn_out', 'sum_g', 'sum_gx')}
+        wkw['g_bias'] = g_bias[i]
+        queued.append(((shape, I, O, k), wkw, i))
+
+    if chained:
+        d = ConvNetBwdDesc()
         for i in range(nl):
-            grads += [g_w[i], None if direct else d_bias[i]]
+            d.w[i] = w[i].data_ptr()
         for j in range(nb):
-            grads += [None if direct else d_bn[j][0], None if direct else d_bn[j][1], None, None, None]
-        return (g_x, None, None) + tuple(grads)
+            d.gamma[j], d.beta[j] = gamma[j].data_ptr(), beta[j].data_ptr()
+            d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
+            d.acts[j], d.gn[j] = acts[j].data_ptr(), gn[j].data_ptr()
+            d.sum_g[j], d.sum_gx[j] = sums[j, 0].data_ptr(), sums[j, 1].data_ptr()
+        d.g_out = g_out.data_ptr()
+        d.g_store[0], d.g_store[1] = stores[0].data_ptr(), stores[1].data_ptr()
+        d.g_x = g_x.data_ptr() if g_x is not None else None
+        slots = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev)     # (kept alive up to the launch, see the forward)
+        d.ws_zero = slots.data_ptr()
+        if cpl is not None:
+            z, out, a, c = cpl
+            g_y, g_ld = cpl_grads
+            g_z = torch.empty_like(z)
+            if ctx.cpl_sinks is not None:
+                pa, pc, g_a, g_c = ctx.cpl_sinks[0].data_ptr(), ctx.cpl_sinks[1].data_ptr(), None, None
+            else:
+                g_ac = WS.zeros(2, dev)
+                pa, pc = g_ac.data_ptr(), g_ac.data_ptr() + 4
+                g_a, g_c = g_ac[0:1].view_as(a), g_ac[1:2].view_as(c)
+            d.g_out = None
+            d.cp_g_y, d.cp_g_ld, d.cp_z, d.cp_out = g_y.data_ptr(), g_ld.data_ptr(), z.data_ptr(), out.data_ptr()
+            d.cp_a, d.cp_c, d.cp_g_z, d.cp_g_out, d.cp_g_a, d.cp_g_c = a.data_ptr(), c.data_ptr(), g_z.data_ptr(), g_out.data_ptr(), pa, pc
+            d.cp_mode, d.cp_odd = ctx.cpl_meta
+            d.cp_C = z.shape[1]
+        N.call('nf_convnet_chain_bwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), N.stream())
+
+    layer(H, O_out, 1, nl - 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0],
+          sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))
+    for j in range(nb - 1, 0, -1):             # convolution j produced acts[j]; its consumer BatchNorm is j
+        is_stream = (j % 2 == 0)
+        store = (stores[(nb - 1 - j) // 2] if chained else torch.empty_like(acts[0])) if is_stream else None
+        layer(H, H, 3, j, in_=acts[j - 1], weight=w[j], gn_src=gn[j], out=acts[j], g_skip=G_skip if is_stream else None,
+              g_store=store, gn_out=gn[j - 1], sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1), **cons_bn(j))
+        if is_stream:
+            G_skip = store
+    layer(I0, H, 3, 0, in_=x, weight=w[0], gn_src=gn[0], out=acts[0], g_skip=G_skip, gn_out=g_x, **cons_bn(0))
+
+    direct = ctx.sinks is not None
+    g_w = [torch.empty_like(t) for t in w]
+    if direct:
+        d_bias = ctx.sinks[:nl]
+        d_bn = [tuple(ctx.sinks[nl + 2 * j:nl + 2 * j + 2]) for j in range(nb)]
+    else:
+        d_bias = [torch.empty(t.shape[0], dtype=torch.float32, device=dev) for t in w]
+        d_bn = [(torch.empty(H, dtype=torch.float32, device=dev), torch.empty(H, dtype=torch.float32, device=dev))
+                for _ in range(nb)]
+    jobs = [(g_weff[i], g_w[i], w[i].numel(), w[i].numel(), slabs, False, w[i].shape[2] * w[i].shape[3]) for i in range(nl)]
+    jobs += [(g_bias[i], d_bias[i], w[i].shape[0], GB, R, direct, 1) for i in range(nl)]
+    for j in range(nb):
+        jobs.append((sums[j, 1], d_bn[j][0], H, H, R, direct, 1))       # g_gamma = sum g * xhat
+        jobs.append((sums[j, 0], d_bn[j][1], H, H, R, direct, 1))       # g_beta  = sum g
+    if defer:
+        for key, wkw, i in queued:             # (the tensors in wkw keep every operand alive until the flush)
+            CONV_DEFER.layers.append((key, wkw, g_w[i], slabs))
+        CONV_DEFER.sums += jobs[nl:]
+    elif chained:
+        CONV_DEFER.launch_layers([(key, wkw, g_w[i], slabs) for key, wkw, i in queued])
+        _slab_sum(jobs[nl:])
+    else:
+        _slab_sum(jobs)
+    grads = []
+    for i in range(nl):
+        grads += [g_w[i], None if direct else d_bias[i]]
+    for j in range(nb):
+        grads += [None if direct else d_bn[j][0], None if direct else d_bn[j][1], None, None, None]
+    return ((g_x, ) if cpl is None else (g_z, g_a, g_c)), tuple(grads)
 
 
 def convnet_forward(net, x):
     """``net``: conditioners.ConvNet; returns the conditioner output (B, out_channels, H, W)."""
     tensors = _convnet_tensors(net)
     return _FusedConvNet.apply(x, net.training, CONV_DEFER.usable(tensors[0:12:2]), *tensors)
+
+
+def coupling_fusable(net, z, mode):
+    """the affine coupling (split map ``mode``) of an image tensor z can ride its conditioner's chain launches, both directions"""
+    if not (CONV_COUPLING_ON and CONV_CHAIN_ON and CONV_CHAIN_BWD_ON and getattr(net, 'fused', False)):
+        return False
+    if not (z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and z.is_contiguous()):
+        return False
+    B, C, Hf, Wf = z.shape
+    if mode == N.SPLIT_CHANNEL and C % 2 == 0:
+        half = (B, C // 2, Hf, Wf)
+    elif mode == N.SPLIT_CHECKER and Hf % 2 == 0 and Wf % 2 == 0:
+        half = (B, 2 * C, Hf // 2, Wf // 2)
+    else:
+        return False
+    from .conditioners import _sync_on
+    if _sync_on() or not _convnet_usable_shape(net, half):
+        return False
+    convs, _ = _convnet_modules(net)
+    c0 = getattr(convs[0], 'module', convs[0])
+    c5 = getattr(convs[-1], 'module', convs[-1])
+    return c0.in_channels == half[1] and c5.out_channels == 2 * half[1] and _chain_usable(B, half[1], 2 * half[1], half[2], half[3])
+
+
+def convnet_coupling(net, x, z, ld, a, c, mode, odd, inverse=False):
+    """y, ld = AffineCoupling(z; net(x)) with x = the untouched half of z, in the conditioner's own launch (coupling_fusable)."""
+    tensors = _convnet_tensors(net)
+    if inverse or not torch.is_grad_enabled():
+        with torch.no_grad():
+            class _Ctx:                                   # no graph: nothing is kept
+                def save_for_backward(self, *t):
+                    pass
+            y = _cn_forward(_Ctx(), x, net.training, False, tensors, cpl=(z, ld, a, c, mode, odd, int(inverse)))
+        return y, ld
+    return _FusedConvCoupling.apply(z, x, ld, a, c, mode, odd, net.training, CONV_DEFER.usable(tensors[0:12:2]), *tensors)

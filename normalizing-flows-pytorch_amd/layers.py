@@ -144,7 +144,7 @@ class Compose(nn.Module):
                     z, log_df_dz = FUSED.realnvp_step_vec(z, log_df_dz, a, k)        # the whole step: one launch
                 elif type(k) is AffineCoupling:
                     h, z1c, log_df_dz = NF.flowbn_head(z, log_df_dz, a, k.mode, k.odd, gather=True)
-                    z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
+                    z, log_df_dz = k.couple(h, z1c, log_df_dz)
                 elif FUSED.maf_step_usable(z, a, k):
                     run = self._maf_run_at(i, z)
                     if run is not None:                            # the run as one autograd node, one fold for all steps
@@ -175,7 +175,7 @@ class Compose(nn.Module):
                 else:
                     h, z1c, log_df_dz = NF.glow_head(z, log_df_dz, a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask,
                                                      c.U_mask, c.sign_s, c.log_s, k.mode, k.odd)
-                    z, log_df_dz = NF.affine_coupling(h, k.net(z1c), k.s_log_scale, k.s_bias, log_df_dz, k.mode, k.odd)
+                    z, log_df_dz = k.couple(h, z1c, log_df_dz)
                 i += 3
             elif self._flowpp_pair_at(i, z):
                 z, log_df_dz = FUSED.flowpp_coupling_vec(z, log_df_dz, L[i], post=L[i + 1])   # coupling + next ActNorm
@@ -520,14 +520,27 @@ class AffineCoupling(AbstractCoupling):
             self.out_chs = in_out_chs
             self.net = ConvNet(in_out_chs, in_out_chs * 2)
 
+    def couple(self, z, x, log_df_dz, inverse=False):
+        """the coupling given the conditioner's input ``x`` (the untouched half of z; None = gather it here).  Image models whose
+        conditioner runs as the persistent chain kernel take conditioner + transform + merge + log-det in ONE launch per direction;
+        the gradient of x is then part of the gradient of z (the gather here is done outside the graph)."""
+        if z.dim() == 4 and z.is_cuda and isinstance(self.net, ConvNet):
+            from . import fused_conv as FC
+            z = z.contiguous()
+            if FC.coupling_fusable(self.net, z, self.mode):
+                if x is None:
+                    x = self.conditioner_input(z.detach())
+                return FC.convnet_coupling(self.net, x, z, NF._owned_ld(log_df_dz), self.s_log_scale, self.s_bias, self.mode,
+                                           self.odd, inverse=inverse)
+        if x is None:
+            x = self.conditioner_input(z)
+        return NF.affine_coupling(z, self.net(x), self.s_log_scale, self.s_bias, log_df_dz, self.mode, self.odd, inverse=inverse)
+
     def forward(self, z, log_df_dz):
-        params = self.net(self.conditioner_input(z))
-        return NF.affine_coupling(z, params, self.s_log_scale, self.s_bias, log_df_dz, self.mode, self.odd)
+        return self.couple(z, None, log_df_dz)
 
     def backward(self, y, log_df_dz):
-        params = self.net(self.conditioner_input(y))
-        return NF.affine_coupling(y, params, self.s_log_scale, self.s_bias, log_df_dz, self.mode, self.odd,
-                                  inverse=True)
+        return self.couple(y, None, log_df_dz, inverse=True)
 
 
 class MixLogAttnCoupling(AbstractCoupling):

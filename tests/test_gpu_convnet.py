@@ -108,3 +108,65 @@ def test_glow_image_coupling_uses_the_fused_conditioner(pkg):
     (y2.sum() + l2.sum()).backward()
     bad = ((z1.grad - z2.grad).abs() > 2e-4 * max(1.0, float(z2.grad.abs().max()))).flatten(1).any(1)
     assert int(bad.sum()) <= 1, 'grad z differs in %d samples' % int(bad.sum())      # one ReLU flip at most
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('dims,masking,odd,B', [((12, 16, 16), 'channelwise', False, 64), ((12, 16, 16), 'channelwise', True, 5),
+                                                ((3, 32, 32), 'checkerboard', False, 64), ((12, 16, 16), 'checkerboard', True, 64),
+                                                ((48, 8, 8), 'channelwise', False, 64), ((48, 8, 8), 'checkerboard', True, 64),
+                                                ((48, 8, 8), 'checkerboard', False, 3)])
+def test_coupling_fused_into_the_conditioner_launch(pkg, dims, masking, odd, B, training):
+    """AffineCoupling of an image model with the transform, merge and log-det inside the conditioner's chain launches (one launch
+    per direction) == conditioner launch + coupling kernel + gather / scatter, forward, backward and inverse."""
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    torch.manual_seed(11)
+    k1 = pkg.AffineCoupling(dims, masking=masking, odd=odd).to(DEV)
+    with torch.no_grad():
+        for p in k1.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+        k1.s_log_scale.fill_(0.7)
+        k1.s_bias.fill_(-0.2)
+    k2 = copy.deepcopy(k1)
+    k1.net.fused = k2.net.fused = True
+    k1.train(training)
+    k2.train(training)
+    z1 = torch.randn((B, ) + dims, device=DEV).requires_grad_(True)
+    z2 = z1.detach().clone().requires_grad_(True)
+    ld0 = torch.randn(B, device=DEV)
+    assert fc.coupling_fusable(k1.net, z1, k1.mode)
+    y1, l1 = k1(z1, ld0.clone())
+    assert type(y1.grad_fn).__name__.startswith('_FusedConvCoupling'), type(y1.grad_fn).__name__
+    old = fc.CONV_COUPLING_ON
+    fc.CONV_COUPLING_ON = False
+    try:
+        y2, l2 = k2(z2, ld0.clone())
+        assert not type(y2.grad_fn).__name__.startswith('_FusedConvCoupling')
+        G.assert_close(y1, y2, 2e-5, rtol=1e-5, what='y')
+        G.assert_close(l1, l2, 1e-4, rtol=1e-5, what='log-det')
+        w, wl = torch.randn_like(y1), torch.randn_like(l1)
+        ((y1 * w).sum() + (l1 * wl).sum()).backward()
+        ((y2 * w).sum() + (l2 * wl).sum()).backward()
+        s = max(1.0, float(z2.grad.abs().max()))
+        bad = ((z1.grad - z2.grad).abs() > 2e-5 * s).flatten(1).any(1)
+        assert int(bad.sum()) <= (1 if training else 0), 'grad z differs in %d samples' % int(bad.sum())   # one ReLU flip at most
+        flip = bool(bad.any())
+        for (n, p1), (_, p2) in zip(k1.named_parameters(), k2.named_parameters()):
+            assert p1.grad is not None, n
+            pre_bn_bias = training and n.endswith('module.bias') and 'out_block' not in n
+            t = 5e-3 + 3e-6 * B * dims[1] * dims[2] if pre_bn_bias else (1e-2 if flip else 1e-4) * max(1.0, float(p2.grad.abs().max()))
+            G.assert_close(p1.grad, p2.grad, t, what='grad ' + n)
+        # inverse: the fused epilogue in its inverse form == the unfused inverse, and it undoes the forward
+        k1.eval()
+        k2.eval()
+        with torch.no_grad():
+            yy = torch.randn((B, ) + dims, device=DEV)
+            x2, m2 = k2.backward(yy, ld0.clone())
+            fc.CONV_COUPLING_ON = True
+            x1, m1 = k1.backward(yy, ld0.clone())
+            G.assert_close(x1, x2, 2e-5, rtol=1e-5, what='inverse')
+            G.assert_close(m1, m2, 1e-4, rtol=1e-5, what='inverse log-det')
+            back, lb = k1(x1, m1.clone())
+            G.assert_close(back, yy, 1e-4, rtol=1e-4, what='round trip')
+            G.assert_close(lb, ld0, 1e-3, rtol=1e-4, what='round trip log-det')
+    finally:
+        fc.CONV_COUPLING_ON = old
