@@ -174,6 +174,18 @@ int nf_glow_head_fwd(const float* z, const float* log_scale, const float* bias, 
 int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z, const float* log_scale,
                      const float* bias, const float* W_saved, float* g_z, float* g_log_scale, float* g_bias, float* g_W,
                      float* sum_g_ld, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+/* The same head for 9 <= C <= 64 channels of image data with the 1x1 weight W given assembled (nf_invconv_weight_fwd_multi), on
+ * the fp32 matrix cores; (H * W) % 16 == 0, mode NF_SPLIT_CHANNEL | NF_SPLIT_CHECKER.  (flows/modules.py:246-249, :470-482,
+ * flows/coupling.py:33)
+ *   fwd: h = W ((x - bias) / exp(log_scale)),  z1c = untouched half of h under the split map,  ld += H W (sum log_s - sum log_scale)
+ *   bwd: g_x, and  g_log_scale / g_bias / g_W += their gradients (atomic: zero or accumulate-into at launch); the gradient of log_s
+ *        and the PLU factors follows from g_W and sum g_ld as for nf_invconv_apply (nf_invconv_weight_bwd_multi).              */
+int nf_glow_head_w_usable(int64_t B, int C, int H, int W, int mode);
+int nf_glow_head_w_fwd(const float* x, const float* act_log_scale, const float* act_bias, const float* Wm, const float* log_s,
+                       float* h, float* z1c, float* ld, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const float* x, const float* act_log_scale, const float* act_bias,
+                       const float* Wm, float* g_x, float* g_log_scale, float* g_bias, float* g_W, int64_t B, int C, int H, int W,
+                       nf_stream_t stream);
 
 /* ---- Logit  modules.py:141-156 --------------------------------------------------------------------------------
  * forward: xc = clamp(x, eps, 1-eps); y = log(xc/(1-xc)); ld[b] += sum -(y - 2 softplus(y))

@@ -1,0 +1,318 @@
+// The head of a Glow flow step on 9 <= C <= 64 channels of image data -- ActNorm, invertible 1x1 convolution and the gather of the
+// coupling's conditioner input (flows/modules.py:246-249, :470-482; flows/coupling.py:33) -- as ONE launch per direction on the fp32
+// matrix cores.  (glow_head.hip is the C <= 4 form with the PLU product assembled in-kernel; here W arrives assembled, see
+// nf_invconv_weight_fwd_multi.)  The three layers are HBM-bound elementwise / small-matrix work: fused, x is read once and the
+// ActNorm output never exists in memory.
+//   forward :  a = (x - bias) / exp(log_scale)  on the way into the B operand;  h = W a  (v_mfma_f32_16x16x4_f32, W in registers);
+//              h -> global, the untouched half of the split map -> z1c;  ld += P (sum log_s - sum log_scale)
+//   backward:  per 128-pixel tile, g_h and a staged through LDS:  g_W += g_h a^T  (all (C/16)^2 tiles per wave over its quarter of
+//              the pixels),  g_a = W^T g_h,  g_x = g_a / exp(log_scale),  g_log_scale -= sum g_a a (+ P sum g_ld),
+//              g_bias -= sum g_a / exp(log_scale)
+#include "nf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// which half (0 = transformed, 1 = the conditioner's input) full-tensor element (c, y, x) belongs to and its offset inside the half
+__device__ __forceinline__ void nf_gh_full_to_half(const NfSplit& s, int c, int p, int y, int x, int& which, int& e) {
+    if (s.mode == NF_SPLIT_CHANNEL) {
+        const int hc = s.C >> 1, sel = c >= hc ? 1 : 0;
+        which = sel ^ s.odd;
+        e = (c - sel * hc) * (s.H * s.W) + p;
+    } else {                                                // NF_SPLIT_CHECKER, squeeze.py:36-41 (k / C without the division)
+        const int k = 4 * c + 2 * (y & 1) + (x & 1);
+        const int q = (k >= s.C ? 1 : 0) + (k >= 2 * s.C ? 1 : 0) + (k >= 3 * s.C ? 1 : 0);
+        const int sel = (q == 1 || q == 2) ? 1 : 0;
+        const int m = sel ? k - s.C : (q == 0 ? k : k - 2 * s.C);
+        which = sel ^ s.odd;
+        e = (m * s.h + (y >> 1)) * s.w + (x >> 1);
+    }
+}
+
+template <int RT, int KQ>
+__global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __restrict__ x, const float* __restrict__ als,
+                                                              const float* __restrict__ abias, const float* __restrict__ M,
+                                                              const float* __restrict__ log_s, float* __restrict__ h,
+                                                              float* __restrict__ z1c, float* __restrict__ ld, NfSplit s, int64_t B,
+                                                              int C, int P) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    float a[RT][KQ], ab[KQ], ad[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const int c = 4 * q + lk;
+        ab[q] = c < C ? abias[c] : 0.f;
+        ad[q] = c < C ? expf(als[c]) : 1.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = 16 * rt + li;
+            a[rt][q] = (r < C && c < C) ? M[r * C + c] : 0.f;
+        }
+    }
+    const int64_t nblk = B * (P / 16);                       // 16-pixel blocks (P % 16 == 0: never straddle samples)
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int bpp = P / 16;
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t b = blk / bpp;
+        const int p = (int)(blk - b * bpp) * 16 + li;
+        const float* xb = x + b * C * P + p;
+        float* hb = h + b * C * P + p;
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float bv[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {                       // B[k = lk][j = li] = ActNorm(x)[c = 4q + lk][pixel]
+            const int c = 4 * q + lk;
+            bv[q] = c < C ? (xb[(int64_t)c * P] - ab[q]) / ad[q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], bv[q], acc[rt], 0, 0, 0);
+        const int yy = p / s.W, xx = p - yy * s.W;
+        float* zb = z1c + b * s.n_half;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                    // D: col = li (pixel), row = 4 lk + j
+                const int r = 16 * rt + 4 * lk + j;
+                if (r < C) {
+                    hb[(int64_t)r * P] = acc[rt][j];
+                    int which, e;
+                    nf_gh_full_to_half(s, r, p, yy, xx, which, e);
+                    if (which == 1) zb[e] = acc[rt][j];
+                }
+            }
+    }
+    float sl = 0.f;
+    for (int c = 0; c < C; ++c) sl += log_s[c] - als[c];
+    const float dl = (float)P * sl;
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += dl;
+}
+
+#define NF_GH_TP 128  // pixels per staged tile
+template <int RT, int KQ>
+__global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __restrict__ gh, const float* __restrict__ gld,
+                                                              const float* __restrict__ x, const float* __restrict__ als,
+                                                              const float* __restrict__ abias, const float* __restrict__ M,
+                                                              float* __restrict__ gx, float* __restrict__ g_ls, float* __restrict__ g_b,
+                                                              float* __restrict__ gM, int64_t B, int C, int P,
+                                                              int64_t tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int RS = NF_GH_TP + 1;
+    const int CP = RT * 16;
+    float* gT = lds;                       // [CP][RS]  g_h
+    float* aT = lds + (size_t)CP * RS;     // [CP][RS]  ActNorm(x)
+    float* cst = aT + (size_t)CP * RS;     // [2][CP]   bias, exp(log_scale)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+    const int64_t npix = B * P;
+    for (int c = threadIdx.x; c < CP; c += blockDim.x) {
+        cst[c] = c < C ? abias[c] : 0.f;
+        cst[CP + c] = c < C ? expf(als[c]) : 1.f;
+    }
+    // A fragments of W^T: A[i = li][k = lk] of row tile rt, k-step q -> W[4 q + lk][16 rt + li]
+    float wt[RT][KQ];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int r = 16 * rt + li, c = 4 * q + lk;
+            wt[rt][q] = (r < C && c < C) ? M[c * C + r] : 0.f;
+        }
+    f32x4 acc[RT][RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < RT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float s1[RT][4], s2[RT][4];            // this lane's sums of g_a a and g_a over its pixels, rows 16 rt + 4 lk + j
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1[i][j] = s2[i][j] = 0.f;
+    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_block;
+    for (int64_t tile = tile0; tile < tile0 + tiles_per_block; ++tile) {
+        const int64_t t0 = tile * NF_GH_TP;
+        if (t0 >= npix) break;
+        const int np = (int)min((int64_t)NF_GH_TP, npix - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < CP * NF_GH_TP; i += blockDim.x) {
+            const int c = i / NF_GH_TP, q = i - c * NF_GH_TP;
+            float gv = 0.f, av = 0.f;
+            if (q < np && c < C) {
+                const int64_t t = t0 + q, b = t / P;
+                const int64_t addr = (b * C + c) * P + (t - b * P);
+                gv = gh[addr];
+                av = (x[addr] - cst[c]) / cst[CP + c];
+            }
+            gT[c * RS + q] = gv;
+            aT[c * RS + q] = av;
+        }
+        __syncthreads();
+        // ---- g_W: this wave's quarter of the tile, pixels [32 wid, 32 wid + 32), 8 k-steps of 4 pixels ----
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int pix = 32 * wid + 4 * ks + lk;
+            float av[RT], bv[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                av[i] = gT[(16 * i + li) * RS + pix];            // A[i = r][k = pix] = g_h[r][pix]
+                bv[i] = aT[(16 * i + li) * RS + pix];            // B[k = pix][j = c] = a[c][pix]
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < RT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        // ---- g_a = W^T g_h for the same 32 pixels (two blocks of 16), g_x, and the ActNorm sums ----
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int pix = 32 * wid + 16 * half + li;
+            f32x4 ga[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) ga[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const float bq = gT[(4 * q + lk) * RS + pix];      // B[k = lk][j = li] = g_h[c = 4q + lk][pixel]   (rows >= C are zero)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) ga[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[rt][q], bq, ga[rt], 0, 0, 0);
+            }
+            if (pix < np) {
+                const int64_t t = t0 + pix, b = t / P;
+                float* gxb = gx + b * C * P + (t - b * P);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 16 * rt + 4 * lk + j;
+                        if (r < C) {
+                            const float g = ga[rt][j];
+                            gxb[(int64_t)r * P] = g / cst[CP + r];
+                            s1[rt][j] = fmaf(g, aT[r * RS + pix], s1[rt][j]);
+                            s2[rt][j] += g;
+                        }
+                    }
+            }
+        }
+    }
+    // ---- cross-wave reductions through LDS, then one atomic per entry per block ----
+    __syncthreads();
+    float* red = lds;                      // [4][CP][CP]  (CP*CP*4 <= 2*CP*RS for CP <= 64)
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)              // D: row = 4 lk + e (r), col = li (c)
+                red[(wid * CP + 16 * i + 4 * lk + e) * CP + 16 * j + li] = acc[i][j][e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int r = e / C, c = e - r * C;
+        const float t = red[(0 * CP + r) * CP + c] + red[(1 * CP + r) * CP + c] + red[(2 * CP + r) * CP + c] +
+                        red[(3 * CP + r) * CP + c];
+        atomicAdd(gM + e, t);
+    }
+    __syncthreads();
+    // per-channel sums: over the 16 pixel lanes by shuffles, over the four waves through LDS
+    float* rs = lds;                       // [2][4][CP]
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float u = s1[i][j], v = s2[i][j];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                u += __shfl_xor(u, off, NF_WAVE);
+                v += __shfl_xor(v, off, NF_WAVE);
+            }
+            if (li == 0) {
+                rs[(0 * 4 + wid) * CP + 16 * i + 4 * lk + j] = u;
+                rs[(1 * 4 + wid) * CP + 16 * i + 4 * lk + j] = v;
+            }
+        }
+    float sg = 0.f;                        // block 0: sum_b g_ld (every channel's log_scale gradient carries P times it)
+    if (blockIdx.x == 0) {
+        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) sg += gld[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, NF_WAVE);
+        if (lane == 0) rs[2 * 4 * CP + wid] = sg;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float R2 = (rs[(0 * 4 + 0) * CP + c] + rs[(0 * 4 + 1) * CP + c]) + (rs[(0 * 4 + 2) * CP + c] + rs[(0 * 4 + 3) * CP + c]);
+        const float R1 = (rs[(1 * 4 + 0) * CP + c] + rs[(1 * 4 + 1) * CP + c]) + (rs[(1 * 4 + 2) * CP + c] + rs[(1 * 4 + 3) * CP + c]);
+        float SG = 0.f;
+        if (blockIdx.x == 0) SG = (rs[8 * CP] + rs[8 * CP + 1]) + (rs[8 * CP + 2] + rs[8 * CP + 3]);
+        atomicAdd(g_ls + c, -R2 - (float)P * SG);        // modules.py:246-249 differentiated
+        atomicAdd(g_b + c, -R1 / cst[CP + c]);
+    }
+}
+
+static inline bool nf_gh_shape_ok(int64_t B, int C, int H, int W) {
+    return B > 0 && C >= 9 && C <= 64 && H > 0 && W > 0 && ((H * W) % 16) == 0 && B * (int64_t)C * H * W < ((int64_t)1 << 40);
+}
+
+extern "C" int nf_glow_head_w_usable(int64_t B, int C, int H, int W, int mode) {
+    if (mode != NF_SPLIT_CHANNEL && mode != NF_SPLIT_CHECKER) return 0;
+    NfSplit s;
+    return nf_gh_shape_ok(B, C, H, W) && nf_make_split(s, mode, 0, C, H, W) ? 1 : 0;
+}
+
+extern "C" int nf_glow_head_w_fwd(const float* x, const float* act_log_scale, const float* act_bias, const float* Wm,
+                                  const float* log_s, float* h, float* z1c, float* ld, int mode, int odd, int64_t B, int C, int H,
+                                  int W, nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_glow_head_w_usable(B, C, H, W, mode) || !nf_make_split(s, mode, odd, C, H, W)) return NF_E_BADARG;
+    if (x == nullptr || act_log_scale == nullptr || act_bias == nullptr || Wm == nullptr || log_s == nullptr || h == nullptr ||
+        z1c == nullptr || ld == nullptr)
+        return NF_E_BADARG;
+    const int P = H * W;
+    const int64_t nblk = B * (P / 16);
+    int64_t g = (nblk + 3) / 4;                              // 4 waves per block, >= 1 block of 16 pixels per wave
+    if (g > 2048) g = 2048;
+    const int64_t g_ld = (B + NF_BLOCK - 1) / NF_BLOCK;
+    if (g < g_ld) g = g_ld > 4096 ? 4096 : g_ld;
+    const int rt = (C + 15) / 16, kq = (C + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+#define NF_CASE(RT, KQ)                                                                                                         \
+    if (rt == RT && kq == KQ) {                                                                                                 \
+        hipLaunchKernelGGL((k_glow_head_w_fwd<RT, KQ>), dim3((unsigned)g), dim3(NF_BLOCK), 0, st, x, act_log_scale, act_bias, Wm, \
+                           log_s, h, z1c, ld, s, B, C, P);                                                                      \
+        NF_CHECK_LAUNCH();                                                                                                      \
+        return 0;                                                                                                               \
+    }
+    NF_CASE(1, 3) NF_CASE(1, 4) NF_CASE(2, 5) NF_CASE(2, 6) NF_CASE(2, 7) NF_CASE(2, 8) NF_CASE(3, 9) NF_CASE(3, 10)
+    NF_CASE(3, 11) NF_CASE(3, 12) NF_CASE(4, 13) NF_CASE(4, 14) NF_CASE(4, 15) NF_CASE(4, 16)
+#undef NF_CASE
+    return NF_E_BADARG;
+}
+
+extern "C" int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const float* x, const float* act_log_scale,
+                                  const float* act_bias, const float* Wm, float* g_x, float* g_log_scale, float* g_bias, float* g_W,
+                                  int64_t B, int C, int H, int W, nf_stream_t stream) {
+    if (!nf_gh_shape_ok(B, C, H, W)) return NF_E_BADARG;
+    if (g_h == nullptr || g_ld == nullptr || x == nullptr || act_log_scale == nullptr || act_bias == nullptr || Wm == nullptr ||
+        g_x == nullptr || g_log_scale == nullptr || g_bias == nullptr || g_W == nullptr)
+        return NF_E_BADARG;
+    const int P = H * W;
+    const int rt = (C + 15) / 16, kq = (C + 3) / 4;
+    const int64_t npix = B * P;
+    const int64_t tiles = (npix + NF_GH_TP - 1) / NF_GH_TP;
+    int64_t blocks = tiles < 1024 ? tiles : 1024;
+    const int64_t tpb = (tiles + blocks - 1) / blocks;
+    blocks = (tiles + tpb - 1) / tpb;
+    const size_t lds = ((size_t)2 * rt * 16 * (NF_GH_TP + 1) + 2 * rt * 16) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define NF_CASE(RT, KQ)                                                                                                         \
+    if (rt == RT && kq == KQ) {                                                                                                 \
+        hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ>), dim3((unsigned)blocks), dim3(NF_BLOCK), lds, st, g_h, g_ld, x,          \
+                           act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, tpb);                           \
+        NF_CHECK_LAUNCH();                                                                                                      \
+        return 0;                                                                                                               \
+    }
+    NF_CASE(1, 3) NF_CASE(1, 4) NF_CASE(2, 5) NF_CASE(2, 6) NF_CASE(2, 7) NF_CASE(2, 8) NF_CASE(3, 9) NF_CASE(3, 10)
+    NF_CASE(3, 11) NF_CASE(3, 12) NF_CASE(4, 13) NF_CASE(4, 14) NF_CASE(4, 15) NF_CASE(4, 16)
+#undef NF_CASE
+    return NF_E_BADARG;
+}

@@ -552,6 +552,64 @@ class _GlowHead(torch.autograd.Function):
         return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None
 
 
+class _GlowHeadW(torch.autograd.Function):
+    """ActNorm + invertible 1x1 with its weight W given assembled (fused.plu_weights_all) + conditioning-half gather on 9 .. 64
+    channels of image data: one MFMA launch per direction (csrc/glow_head_mfma.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, ld, log_scale, bias, W, log_s, holder, idx, mode, odd):
+        B, C, H, Wd = x.shape
+        h = torch.empty_like(x)
+        z1c = torch.empty(_half_shape(x, mode), dtype=x.dtype, device=x.device)
+        N.call('nf_glow_head_w_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(log_s), N.ptr(h), N.ptr(z1c),
+               N.ptr(ld), mode, int(odd), B, C, H, Wd, N.stream())
+        ctx.save_for_backward(x, log_scale, bias, W)
+        ctx.holder, ctx.idx, ctx.meta = holder, idx, (mode, int(odd))
+        holder.meta[idx] = (B, H * Wd)
+        ctx.sinks = _sinks(log_scale, bias)
+        ctx.mark_dirty(ld)
+        ctx.set_materialize_grads(False)          # the gathered half has no gradient of its own under the fused image coupling
+        return h, z1c, ld
+
+    @staticmethod
+    def backward(ctx, g_h, g_z1c, g_ld):
+        x, log_scale, bias, W = ctx.saved_tensors
+        mode, odd = ctx.meta
+        B, C, H, Wd = x.shape
+        if g_h is None:
+            g_h = torch.zeros_like(x)
+        if g_ld is None:
+            g_ld = torch.zeros(B, dtype=x.dtype, device=x.device)
+        g_h, g_ld = _contig(g_h), _contig(g_ld)
+        if g_z1c is not None:                       # (a coupling that was not fused into its conditioner's launches)
+            full = torch.empty_like(x)
+            N.call('nf_half_scatter', N.ptr(_contig(g_z1c)), N.ptr(full), 1, mode, odd, B, C, H, Wd, N.stream())
+            g_h = g_h + full
+        g_x = torch.empty_like(x)
+        direct = ctx.sinks is not None
+        tmp = WS.zeros(C * C + (0 if direct else 2 * C), x.device)
+        g_W = tmp[:C * C].view_as(W)
+        if direct:
+            p_ls, p_b, g_ls, g_b = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
+        else:
+            g_ls, g_b = tmp[C * C:C * C + C].view_as(log_scale), tmp[C * C + C:].view_as(bias)
+            p_ls, p_b = g_ls.data_ptr(), g_b.data_ptr()
+        N.call('nf_glow_head_w_bwd', N.ptr(g_h), N.ptr(g_ld), N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(g_x), p_ls,
+               p_b, N.ptr(g_W), B, C, H, Wd, N.stream())
+        ctx.holder.g_ld[ctx.idx] = g_ld
+        return g_x, g_ld, g_ls, g_b, g_W, None, None, None, None, None
+
+
+def glow_head_w_usable(z, mode):
+    return (z.is_cuda and z.dim() == 4 and z.dtype == torch.float32
+            and bool(N.load().nf_glow_head_w_usable(z.shape[0], z.shape[1], z.shape[2], z.shape[3], int(mode))))
+
+
+def glow_head_w(z, ld, log_scale, bias, W, log_s, holder, idx, mode, odd):
+    """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward (weight given) -> conditioning half of the split, fused."""
+    return _GlowHeadW.apply(_contig(z), _owned_ld(ld), log_scale, bias, W, log_s, holder, idx, mode, odd)
+
+
 HEAD_MAX_C = 4
 
 

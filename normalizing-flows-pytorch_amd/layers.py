@@ -8,6 +8,8 @@ Same class names, constructor signatures, parameter / buffer names and shapes as
 flows/coupling.py, flows/squeeze.py and flows/maf.py, so reference ``state_dict``s load unchanged.  The
 transforms themselves run as HIP kernels (functional.py -> libnfhip.so); there is no CPU path.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -25,6 +27,9 @@ class Identity(nn.Module):
 
     def backward(self, x, log_df_dz):
         return x, log_df_dz
+
+
+GLOW_HEAD_W_ON = os.environ.get('NF_GLOW_HEAD_W', '1') != '0'
 
 
 class Compose(nn.Module):
@@ -52,6 +57,20 @@ class Compose(nn.Module):
             return False
         a, c, k = L[i], L[i + 1], L[i + 2]
         if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and type(k) is AffineCoupling):
+            return False
+        return not (a._forward_hooks or c._forward_hooks or k._forward_hooks or a._forward_pre_hooks
+                    or c._forward_pre_hooks or k._forward_pre_hooks)
+
+    def _glow_step_w_at(self, i, z):
+        """[ActNorm, InvertibleConv1x1 (weight assembled by the model's batched PLU pre-pass), AffineCoupling] on image data with
+        more channels than the in-kernel PLU head takes"""
+        L = self.layers
+        if not (GLOW_HEAD_W_ON and self._fuse_now and z.is_cuda and z.dim() == 4 and i + 2 < len(L) and z.shape[1] > NF.HEAD_MAX_C):
+            return False
+        a, c, k = L[i], L[i + 1], L[i + 2]
+        if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and type(k) is AffineCoupling):
+            return False
+        if c._W_eff is None or k.mode not in (N.SPLIT_CHANNEL, N.SPLIT_CHECKER) or not NF.glow_head_w_usable(z, k.mode):
             return False
         return not (a._forward_hooks or c._forward_hooks or k._forward_hooks or a._forward_pre_hooks
                     or c._forward_pre_hooks or k._forward_pre_hooks)
@@ -176,6 +195,15 @@ class Compose(nn.Module):
                     h, z1c, log_df_dz = NF.glow_head(z, log_df_dz, a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask,
                                                      c.U_mask, c.sign_s, c.log_s, k.mode, k.odd)
                     z, log_df_dz = k.couple(h, z1c, log_df_dz)
+                i += 3
+            elif self._glow_step_w_at(i, z):                      # image data, 9 .. 64 channels: head in one MFMA launch
+                a, c, k = L[i], L[i + 1], L[i + 2]
+                if not a.initialized:
+                    NF.actnorm_init_(z, a.log_scale, a.bias, a.eps)
+                    a.initialized = True
+                W, holder, idx = c._W_eff
+                h, z1c, log_df_dz = NF.glow_head_w(z, log_df_dz, a.log_scale, a.bias, W, c.log_s, holder, idx, k.mode, k.odd)
+                z, log_df_dz = k.couple(h, z1c, log_df_dz)
                 i += 3
             elif self._flowpp_pair_at(i, z):
                 z, log_df_dz = FUSED.flowpp_coupling_vec(z, log_df_dz, L[i], post=L[i + 1])   # coupling + next ActNorm

@@ -170,3 +170,72 @@ def test_coupling_fused_into_the_conditioner_launch(pkg, dims, masking, odd, B, 
             G.assert_close(lb, ld0, 1e-3, rtol=1e-4, what='round trip log-det')
     finally:
         fc.CONV_COUPLING_ON = old
+
+
+@pytest.mark.parametrize('C,H,W,mode_name,odd,B', [(12, 16, 16, 'channelwise', False, 64), (12, 16, 16, 'checkerboard', True, 7),
+                                                   (48, 8, 8, 'channelwise', True, 64), (48, 8, 8, 'checkerboard', False, 64),
+                                                   (10, 4, 8, 'checkerboard', False, 3), (64, 4, 4, 'channelwise', False, 9)])
+def test_glow_head_w_matches_the_three_layers(pkg, C, H, W, mode_name, odd, B):
+    """ActNorm + invertible 1x1 (assembled weight) + conditioner-input gather in one MFMA launch per direction == the three layers'
+    own launches: outputs, log-det, input gradient, ActNorm gradients and the gradient handed to the batched PLU backward."""
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    Nn = importlib.import_module(pkg.__name__ + '._native')
+    mode = Nn.SPLIT_CHANNEL if mode_name == 'channelwise' else Nn.SPLIT_CHECKER
+    torch.manual_seed(5)
+    x1 = torch.randn(B, C, H, W, device=DEV).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    ls1 = (0.3 * torch.randn(1, C, 1, 1, device=DEV)).requires_grad_(True)
+    b1 = torch.randn(1, C, 1, 1, device=DEV).requires_grad_(True)
+    Wm1 = (torch.linalg.qr(torch.randn(C, C, device=DEV))[0] + 0.05 * torch.randn(C, C, device=DEV)).contiguous().requires_grad_(True)
+    ls2, b2, Wm2 = (t.detach().clone().requires_grad_(True) for t in (ls1, b1, Wm1))
+    log_s = torch.randn(C, device=DEV) * 0.1
+    ld0 = torch.randn(B, device=DEV)
+    assert NF.glow_head_w_usable(x1, mode)
+    h1, z1c1, l1 = NF.glow_head_w(x1, ld0.clone(), ls1, b1, Wm1, log_s, NF.PluHolder(1), 0, mode, odd)
+    hold = NF.PluHolder(1)
+    a2, l2 = NF.chan_affine(Nn.OP_ACTNORM, x2, ld0.clone(), ls2, b2)
+    h2, l2 = NF.invconv_apply_w(a2, l2, Wm2, log_s, hold, 0)
+    z1c2 = NF.half_gather(h2, 1, mode, odd)
+    G.assert_close(h1, h2, 2e-5, rtol=1e-5, what='h')
+    assert torch.equal(z1c1, NF.half_gather(h1.detach(), 1, mode, odd)), 'the gathered half is not the half of h'
+    G.assert_close(l1, l2, 1e-4, rtol=1e-5, what='log-det')
+    wh, wz, wl = torch.randn_like(h1), torch.randn_like(z1c1), torch.randn_like(l1)
+    ((h1 * wh).sum() + (z1c1 * wz).sum() + (l1 * wl).sum()).backward()
+    ((h2 * wh).sum() + (z1c2 * wz).sum() + (l2 * wl).sum()).backward()
+    for what, g1, g2 in (('x', x1.grad, x2.grad), ('log_scale', ls1.grad, ls2.grad), ('bias', b1.grad, b2.grad), ('W', Wm1.grad, Wm2.grad)):
+        G.assert_close(g1, g2, 2e-5 * max(1.0, float(g2.abs().max())), rtol=1e-5, what='grad ' + what)
+
+
+def test_cifar_glow_with_and_without_the_fused_heads(pkg, monkeypatch):
+    """a (3, 32, 32) Glow with two steps per level: the fused heads (C = 12, 48) and the fused couplings against the per-layer
+    launches -- z, log-det and every parameter gradient of one training-mode pass."""
+    layers_mod = importlib.import_module(pkg.__name__ + '.layers')
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    from types import SimpleNamespace as NS
+    torch.manual_seed(2)
+    net1 = pkg.Glow((3, 32, 32), 'image', NS(layers=2, mixtures=None)).to(DEV)
+    y = torch.rand(16, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        net1(y)                                         # data-dependent ActNorm initialisation
+    net2 = copy.deepcopy(net1)
+    for m in net2.modules():
+        if hasattr(m, 'initialized'):
+            m.initialized = True
+    outs = []
+    for net, on in ((net1, True), (net2, False)):
+        monkeypatch.setattr(layers_mod, 'GLOW_HEAD_W_ON', on)
+        monkeypatch.setattr(fc, 'CONV_COUPLING_ON', on)
+        net.train()
+        z, ld = net(y)
+        (0.5 * (z ** 2).sum() - ld.sum()).backward()
+        outs.append((z.detach(), ld.detach(), type(z.grad_fn).__name__))
+    G.assert_close(outs[0][0], outs[1][0], 5e-5, rtol=1e-5, what='z')
+    G.assert_close(outs[0][1], outs[1][1], 2e-3, rtol=1e-5, what='log-det')
+    worst = 0.0
+    for (n, p1), (_, p2) in zip(net1.named_parameters(), net2.named_parameters()):
+        if p2.grad is None:                             # (the pivot matrices and masks)
+            assert p1.grad is None, n
+            continue
+        assert p1.grad is not None, n
+        worst = max(worst, float((p1.grad - p2.grad).abs().max()) / max(1.0, float(p2.grad.abs().max())))
+    assert worst < 2e-2, worst                          # (a ReLU flip between the two roundings moves a conditioner's gradients)
