@@ -115,10 +115,14 @@ class ConvDefer:
         self.layers = []        # (key, desc kwargs, dst weight gradient, n_slabs)
         self.sums = []          # slab-sum jobs that read accumulators the deferred passes fill, or that can wait as well
         self.scratch = {}
+        self.side = {}          # device -> the stream the overlapped weight-gradient launches run on
+        self.forked = False
+        self.keep = []          # operands of launches in flight on the side stream (alive until the join)
 
     def begin(self):
         self.layers, self.sums = [], []
         self.active, self.armed = CONV_DEFER_ON, False
+        self.forked, self.keep = False, []
 
     def arm(self, weights):
         """fused.weight_norm_all: these effective weights' gradients are consumed by a backward that flushes first"""
@@ -161,9 +165,45 @@ class ConvDefer:
                 N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
                 _slab_sum_all(jobs)                  # before the next chunk overwrites the scratch (stream order)
 
+    def offload(self):
+        """Overlap: as soon as sixteen queued layers share a shape, their weight-gradient launch goes to a side stream, behind
+        everything the main stream has issued so far.  The data-gradient chain that continues on the main stream occupies 8 .. 64
+        of the 256 compute units; the bulk launches fill the rest instead of queueing up behind the last layer.  Joined in flush."""
+        if not (CONV_OVERLAP_ON and self.active and self.layers):
+            return
+        step = N.header_constant('NF_CONV_WGRAD_MAX')
+        groups = {}
+        for e in self.layers:
+            groups.setdefault(e[0], []).append(e)
+        ready = [es[:step] for es in groups.values() if len(es) >= step]
+        if not ready:
+            return
+        main = torch.cuda.current_stream()
+        dev = main.device
+        side = self.side.get(dev)
+        if side is None:
+            side = self.side[dev] = torch.cuda.Stream(device=dev)
+        for chunk in ready:                         # (the slab scratch is grown on the main stream, never inside the side context)
+            self._slab_scratch(sum(e[3] * e[2].numel() for e in chunk), dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for chunk in ready:
+                self.launch_layers(chunk)
+        done = set(id(e) for chunk in ready for e in chunk)
+        self.keep += [e for e in self.layers if id(e) in done]
+        self.layers = [e for e in self.layers if id(e) not in done]
+        self.forked = True
+
     def flush(self):
         layers, sums = self.layers, self.sums
+        forked, keep = self.forked, self.keep
         self.layers, self.sums, self.active, self.armed = [], [], False, False
+        self.forked, self.keep = False, []
+        if forked:                                  # the tail runs behind the side stream's launches (they share the slab scratch)
+            main = torch.cuda.current_stream()
+            side = self.side[main.device]
+            main.wait_stream(side)
+        del keep
         if not layers and not sums:
             return
         self.launch_layers(layers)
@@ -171,6 +211,7 @@ class ConvDefer:
 
 
 CONV_DEFER_ON = __import__('os').environ.get('NF_CONV_DEFER', '1') != '0'
+CONV_OVERLAP_ON = __import__('os').environ.get('NF_CONV_OVERLAP', '1') != '0'
 CONV_DEFER = ConvDefer()
 
 
@@ -437,6 +478,7 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         for key, wkw, i in queued:             # (the tensors in wkw keep every operand alive until the flush)
             CONV_DEFER.layers.append((key, wkw, g_w[i], slabs))
         CONV_DEFER.sums += jobs[nl:]
+        CONV_DEFER.offload()
     elif chained:
         CONV_DEFER.launch_layers([(key, wkw, g_w[i], slabs) for key, wkw, i in queued])
         _slab_sum(jobs[nl:])
