@@ -130,7 +130,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                  BatchNorms; csrc/mlp_chain.hip) -- fp32 MFMA work, bound by the five grid-wide BatchNorm exchanges;
       c5      -> k_maf_step_bwd, the one-launch backward of a whole MAF flow step (flow BatchNorm, MADE pair, transform);
       c3      -> k_flowpp_cond_bwd, the one-launch backward of the gated-attention conditioner (fp32 MFMA);
-      c4      -> k_conv_bn_bwd, the 3x3 convolution + BatchNorm2d + ReLU backward of the image conditioner (fp32 MFMA).
+      c4      -> k_convnet_chain_bwd, the data gradient of a whole image conditioner (+ coupling backward) in one persistent launch.
     achieved = algorithmic bytes or flops per launch / average launch duration at the workload's
     shape, measured live with HIP events around hipGraph replays of that launch on the launch stream."""
     N, NF = pkg._native, pkg.functional
@@ -387,45 +387,64 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                 'note': 'fp32-input MFMA (exact fp32, 1/16 of the bf16 rate); the rest is transcendental VALU work and the '
                         'LDS transposes of the weight-gradient operands (DESIGN.md section 3)'}
     if len(dims) == 3 and cfg['kind'] in ('glow', 'realnvp'):
-        # image flows: the train step is dominated by the conditioner's 3x3 convolution backward (profiles/r01_c4_final_kernel_stats.csv);
-        # measured at the first resolution of the pyramid (checkerboard half of the input: H/2 x W/2), 32 -> 32 channels
-        cond = importlib.import_module(PKG + '.conditioners')
+        # image flows: 72 % of the train step is the conditioner's persistent chain kernels (profiles/rNN_c4_kernel_stats.csv); the
+        # largest single-shape share is the data-gradient chain of the 16 x 16 conditioners (64 of the 161 per step; with the coupling's
+        # backward fused in, exactly as the step launches it): 6 -> 32 -> ... -> 32 -> 12 channels on (B, ., 16, 16)
         FC = importlib.import_module(PKG + '.fused_conv')
-        Hh, Ww, Cc = dims[1] // 2, dims[2] // 2, 32
-        if cond.ConvNet.fused and N.load().nf_conv_bn_usable(B, Cc, Cc, Hh, Ww, 3):
+        Hh, Ww = dims[1] // 2, dims[2] // 2
+        I0, O = 2 * dims[0], 4 * dims[0]
+        if FC.CONV_CHAIN_ON and FC.CONV_CHAIN_BWD_ON and N.load().nf_convnet_chain_usable(B, I0, O, Hh, Ww):
             R = FC.R
-            x = torch.randn(B, Cc, Hh, Ww, generator=g).to(dev)
-            out, gn_src = torch.randn(B, Cc, Hh, Ww, generator=g).to(dev), torch.randn(B, Cc, Hh, Ww, generator=g).to(dev)
-            wgt = (torch.randn(Cc, Cc, 3, 3, generator=g) * 0.1).to(dev)
-            ones, zeros = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
-            slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
-            g_weff = torch.empty(slabs, wgt.numel(), device=dev)
-            acc = torch.zeros(R * FC.GB + 4 * R * 32, device=dev)
-            gn_out = torch.empty_like(x)
+            T = lambda *sh: torch.randn(*sh, generator=g).to(dev)          # noqa: E731
+            w = [T(32, I0, 3, 3) * 0.1] + [T(32, 32, 3, 3) * 0.06 for _ in range(4)] + [T(O, 32, 1, 1) * 0.1]
+            ones, zeros = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+            acts = [T(B, 32, Hh, Ww) for _ in range(5)]
+            gn = [torch.empty(B, 32, Hh, Ww, device=dev) for _ in range(5)]
+            stores = [torch.empty(B, 32, Hh, Ww, device=dev) for _ in range(2)]
+            sums = torch.zeros(5, 2, R * 32, device=dev)
+            z, gy = T(B, dims[0], dims[1], dims[2]), T(B, dims[0], dims[1], dims[2])
+            out = torch.cat([torch.exp(0.1 * T(B, O // 2, Hh, Ww)), torch.tanh(T(B, O // 2, Hh, Ww))], 1).contiguous()
+            gld = torch.full((B, ), -1.0, device=dev)
+            gz, gout = torch.empty_like(z), torch.empty_like(out)
+            a, c, gac = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev), torch.zeros(2, device=dev)
+            nws = N.header_constant('NF_CONVNET_WS_FLOATS')
+            per = 20
+            wsf = torch.zeros(per + 3, nws, device=dev)
+            it = [0]
+            d = FC.ConvNetBwdDesc()
+            for i in range(6):
+                d.w[i] = w[i].data_ptr()
+            for j in range(5):
+                d.gamma[j], d.beta[j], d.save_mean[j], d.save_invstd[j] = ones.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), ones.data_ptr()
+                d.acts[j], d.gn[j] = acts[j].data_ptr(), gn[j].data_ptr()
+                d.sum_g[j], d.sum_gx[j] = sums[j, 0].data_ptr(), sums[j, 1].data_ptr()
+            d.g_store[0], d.g_store[1] = stores[0].data_ptr(), stores[1].data_ptr()
+            d.cp_g_y, d.cp_g_ld, d.cp_z, d.cp_out = gy.data_ptr(), gld.data_ptr(), z.data_ptr(), out.data_ptr()
+            d.cp_a, d.cp_c, d.cp_g_z, d.cp_g_out = a.data_ptr(), c.data_ptr(), gz.data_ptr(), gout.data_ptr()
+            d.cp_g_a, d.cp_g_c = gac.data_ptr(), gac.data_ptr() + 4
+            d.cp_mode, d.cp_odd, d.cp_C = N.SPLIT_CHECKER, 0, dims[0]
 
-            split = FC.CONV_DEFER_ON     # the train step launches the data-gradient pass alone (the weight-gradient passes of all
-                                         # layers run sixteen per launch at the end of the backward pass: nf_conv_bn_wgrad_multi)
+            def fn():                      # every launch of a graph gets its own zeroed exchange slots (generation stamps)
+                d.ws_zero = wsf[it[0] % (per + 3)].data_ptr()
+                it[0] += 1
+                N.call('nf_convnet_chain_bwd', ctypes.addressof(d), B, I0, O, Hh, Ww, 1, N.stream())
 
-            def fn():
-                FC._bwd((B, Hh, Ww), Cc, Cc, 3, in_=x, weight=wgt, bn_gamma=ones, bn_beta=zeros, bn_save_mean=zeros,
-                        bn_save_invstd=ones, gn_src=gn_src, out=out, cbn_gamma=ones, cbn_save_mean=zeros, cbn_save_invstd=ones,
-                        cbn_sum_g=acc[R * FC.GB:R * FC.GB + R * 32], cbn_sum_gx=acc[R * FC.GB + R * 32:R * FC.GB + 2 * R * 32],
-                        g_bias=None if split else acc[:R * FC.GB], g_weff=None if split else g_weff, gn_out=gn_out,
-                        sum_g=acc[R * FC.GB + 2 * R * 32:R * FC.GB + 3 * R * 32], sum_gx=acc[R * FC.GB + 3 * R * 32:])
-            us = graph_time_us(fn, dev, per_graph=20, replays=5)
+            def reset():
+                wsf.zero_()
+                it[0] = 0
+            us = graph_time_us(fn, dev, per_graph=per, replays=1, reset=reset)
             M = B * Hh * Ww
-            flop = (1 if split else 2) * 2 * M * 9 * Cc * Cc        # data gradient (+ weight gradient) products
+            flop = 2 * M * (4 * 9 * 32 * 32 + 9 * 32 * I0 + 32 * O)          # five transposed convolutions, data gradient only
             tf = flop / (us * 1e-6) / 1e12
-            kname = ('k_conv_bn_bwd<9, 1, 1, 1> (3x3 convolution + BatchNorm2d + ReLU backward, data-gradient pass, 32 -> 32 channels, '
-                     '%d x %d)' if split else
-                     'k_conv_bn_bwd<9, 1, 1, 0> (3x3 convolution + BatchNorm2d + ReLU backward, 32 -> 32 channels, %d x %d)') % (Hh, Ww)
-            return {'bound': 'mfma', 'kernel': kname,
+            bytes_alg = 4 * (M * 32 * (5 + 5 + 2) + 2 * M * O + 3 * z.numel())
+            return {'bound': 'mfma', 'kernel': 'k_convnet_chain_bwd<8, 2> (data gradient of the whole ConvNet conditioner + coupling backward in '
+                                               'one persistent launch: %d -> 32 x 5 -> %d channels, %d x %d)' % (I0, O, Hh, Ww),
                     'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
-                    'traffic': pmc_traffic('k_conv_bn_bwd', B) if split else None, 'flop_per_launch': int(flop),
-                    'bytes_per_launch': int(M * Cc * 4 * (4 if split else 5)),
-                    'us_per_launch': round(us, 3),
-                    'note': 'latency-bound at this size (0.3 GFLOP over 128 workgroups): ~3 us of MFMA work inside a serial chain of '
-                            'dependent memory round trips (DESIGN.md section 3.15; tools/probes/conv_prof.py)'}
+                    'traffic': pmc_traffic('k_convnet_chain_bwd', B), 'flop_per_launch': int(flop), 'bytes_per_launch': int(bytes_alg),
+                    'us_per_launch': round(us, 3), 'workgroups': int((M + 255) // 256),
+                    'note': 'one 1024-thread workgroup per sample: %d of 256 compute units hold the whole launch (peak reachable by it: %d / 256 '
+                            'of the chip), ~40 us of fp32 MFMA work per CU inside five grid-wide BatchNorm exchanges (DESIGN.md section '
+                            '3.17)' % ((M + 255) // 256, (M + 255) // 256)}
     if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:              # multi-launch linear + BatchNorm chain
         nets = 2 if cfg['kind'] == 'maf' else 1
         T = lambda *sh: torch.randn(*sh, generator=g).to(dev)          # noqa: E731

@@ -89,3 +89,46 @@ def test_ctypes_struct_layout_matches_header(pkg):
             assert ('*' in decl) == (ty is ctypes.c_void_p), decl
             if '*' not in decl:
                 assert decl.startswith('int ') and ty is ctypes.c_int, decl
+
+
+def test_committed_pmc_summary_names_current_kernels():
+    """bench.pmc_traffic reads the newest profiles/rNN_pmc.json: every kernel it holds traffic for must still exist in csrc/ (a
+    stale file from an earlier round would silently attach old counters to new launches)."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc.json')))
+    if not files:
+        pytest.skip('no PMC summary committed yet')
+    src = ''.join(open(f).read() for f in glob.glob(os.path.join(ROOT, 'normalizing-flows-pytorch_amd', 'csrc', '*.hip')))
+    data = json.load(open(files[-1]))
+    kernels = [k for k, v in data.items() if isinstance(v, dict) and k.startswith('k_')]
+    assert kernels, files[-1]
+    for k in kernels:
+        assert re.search(r'\b%s\b' % re.escape(k), src), '%s holds counters of %s, which no longer exists' % (os.path.basename(files[-1]), k)
+        for key, e in data[k].items():
+            assert key.split(':')[0].isdigit() and e.get('traffic_bytes', 1) > 0, (k, key)
+    # the default bench line's C4 kernel must be covered once the round's collection has run
+    bench_src = open(os.path.join(ROOT, 'bench.py')).read()
+    for k in re.findall(r"pmc_traffic\('(k_\w+)'", bench_src):
+        assert re.search(r'\b%s\b' % re.escape(k), src), k
+
+
+def test_convnet_descriptor_layouts_match_header(pkg):
+    """fused_conv.py mirrors the chain kernels' descriptors (arrays of pointers + a few ints) by hand"""
+    fc = __import__('importlib').import_module(pkg.__name__ + '.fused_conv')
+    text = re.sub(r'/\*.*?\*/', ' ', open(HEADER).read(), flags=re.S)
+    for struct, cls in [('nf_convnet_desc', fc.ConvNetDesc), ('nf_convnet_bwd_desc', fc.ConvNetBwdDesc)]:
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct, struct), text, flags=re.S).group(1)
+        want = []
+        for decl in [f.strip() for f in body.split(';') if f.strip()]:
+            ptr = '*' in decl
+            for part in decl.split(','):                         # "int cp_mode, cp_odd, cp_C, cp_inverse"
+                m = re.search(r'(\w+)\s*(?:\[(\d+)\])?\s*$', part.strip())
+                want.append((m.group(1), int(m.group(2)) if m.group(2) else 0, ptr))
+        got = []
+        for n, ty in cls._fields_:
+            if hasattr(ty, '_length_'):
+                got.append((n, ty._length_, ty._type_ is ctypes.c_void_p))
+            else:
+                got.append((n, 0, ty is ctypes.c_void_p))
+        assert got == want, (struct, [g for g, w in zip(got, want) if g != w], len(got), len(want))

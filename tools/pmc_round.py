@@ -18,6 +18,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIDECAR = os.environ.get('NF_PMC_SIDECAR', '/tmp/nf_pmc_kernels.json')
 sys.path.insert(0, ROOT)
 
 
@@ -43,15 +44,16 @@ def to_json(fetch_csv, write_csv, out_path):
     for cfg_name, batch in [(a.split(':')[0], a.split(':')[1] if ':' in a else None) for a in os.environ.get('NF_PMC_CONFIGS', 'c4,c1').split(',')]:
         cfg = bench.CONFIGS[cfg_name]
         B = int(batch) if batch else cfg['batch']
-        want = os.environ.get('NF_PMC_KERNEL_' + cfg_name.upper())
+        try:
+            named = json.load(open(SIDECAR)).get(cfg_name)
+        except (OSError, ValueError):
+            named = None
         for (name, ctr), (n, v) in agg.items():
             short = name.split('(')[0].replace('void ', '')
             base = short.split('<')[0]
-            if want is not None and base != want:
-                continue
-            if want is None and not base.startswith('k_'):
-                continue
-            e = out.setdefault(base, {}).setdefault(str(B) + ('' if want else ':' + short), {})
+            if not base.startswith('k_') or (named is not None and base not in named):
+                continue                                 # only the kernels this config's roofline object names
+            e = out.setdefault(base, {}).setdefault(str(B) + ':' + short, {})
             e['fetch_kib' if ctr == 'FETCH_SIZE' else 'write_kib'] = round(v / n, 2)
             e['calls'] = n
     for k, sub in list(out.items()):
@@ -77,11 +79,16 @@ def main(names):
         y.copy_(x)
     torch.cuda.synchronize()
     del x, y
+    import re
+    which = {}
     for name in names:
         cfg = bench.CONFIGS[name]
         r = bench.dominant_kernel_roofline(pkg, cfg, cfg['batch'], dev)
         print(name, r['kernel'], r['us_per_launch'])
+        which[name] = sorted(set(re.findall(r'k_[a-z0-9_]+', r['kernel'])))
     torch.cuda.synchronize()
+    with open(SIDECAR, 'w') as f:                       # config -> the kernels its roofline object names (read back by --json)
+        json.dump(which, f)
 
 
 if __name__ == '__main__':
