@@ -444,7 +444,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
                     'us_per_launch': round(us, 3), 'workgroups': int((M + 255) // 256),
                     'note': 'one 1024-thread workgroup per sample: %d of 256 compute units hold the whole launch (peak reachable by it: %d / 256 '
                             'of the chip), ~40 us of fp32 MFMA work per CU inside five grid-wide BatchNorm exchanges (DESIGN.md section '
-                            '3.17)' % ((M + 255) // 256, (M + 255) // 256)}
+                            '3.16)' % ((M + 255) // 256, (M + 255) // 256)}
     if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:              # multi-launch linear + BatchNorm chain
         nets = 2 if cfg['kind'] == 'maf' else 1
         T = lambda *sh: torch.randn(*sh, generator=g).to(dev)          # noqa: E731

@@ -84,8 +84,9 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
                 }
             }
     }
-    float sl = 0.f;
-    for (int c = 0; c < C; ++c) sl += log_s[c] - als[c];
+    float sl = lane < C ? log_s[lane] - als[lane] : 0.f;     // C <= 64: one value per lane, wave sum (a serial loop of scalar loads was 10 us)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, NF_WAVE);
     const float dl = (float)P * sl;
     const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += dl;
@@ -136,17 +137,20 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
         if (t0 >= npix) break;
         const int np = (int)min((int64_t)NF_GH_TP, npix - t0);
         __syncthreads();
-        for (int i = threadIdx.x; i < CP * NF_GH_TP; i += blockDim.x) {
-            const int c = i / NF_GH_TP, q = i - c * NF_GH_TP;
-            float gv = 0.f, av = 0.f;
-            if (q < np && c < C) {
-                const int64_t t = t0 + q, b = t / P;
-                const int64_t addr = (b * C + c) * P + (t - b * P);
-                gv = gh[addr];
-                av = (x[addr] - cst[c]) / cst[CP + c];
+        {   // a thread stages ONE pixel column of the tile (256 threads = 128 pixels x 2 channel phases): its sample / offset once
+            const int q = threadIdx.x & (NF_GH_TP - 1);
+            const int64_t t = t0 + q, b = t / P;
+            const int64_t base = b * C * P + (t - b * P);
+            for (int c = threadIdx.x >> 7; c < CP; c += NF_BLOCK / NF_GH_TP) {
+                float gv = 0.f, av = 0.f;
+                if (q < np && c < C) {
+                    const int64_t addr = base + (int64_t)c * P;
+                    gv = gh[addr];
+                    av = (x[addr] - cst[c]) / cst[CP + c];
+                }
+                gT[c * RS + q] = gv;
+                aT[c * RS + q] = av;
             }
-            gT[c * RS + q] = gv;
-            aT[c * RS + q] = av;
         }
         __syncthreads();
         // ---- g_W: this wave's quarter of the tile, pixels [32 wid, 32 wid + 32), 8 k-steps of 4 pixels ----

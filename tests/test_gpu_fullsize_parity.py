@@ -110,12 +110,16 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B):
     per_step = 3 if any(k.endswith('.log_s') for k in names) else 2            # Glow / Flow++-image steps have three layers
     first_of_last = last_layer - per_step + 1
     worst, strict, n, dot, n_g, n_c = (0.0, 0.0, ''), 0, 0, 0.0, 0.0, 0.0
+    d_gpu, d_ref, n_64 = 0.0, 0.0, 0.0                      # squared flat distances to the float64 gradient
     grads = dict(net.named_parameters())
     for k in names:
         p = grads[k]
         assert p.grad is not None, k
         g, c = p.grad.detach().double().cpu().reshape(-1), rec32['grads'][k].double().reshape(-1)
         dot += float(g @ c); n_g += float(g @ g); n_c += float(c @ c)
+        if k in r64['grads']:
+            e = r64['grads'][k].double().reshape(-1)
+            d_gpu += float((g - e) @ (g - e)); d_ref += float((c - e) @ (c - e)); n_64 += float(e @ e)
         # strict gradient bar: 2e-5 of the largest entry of the tensor (as tests/test_gpu_models.py) + the measured fp32 uncertainty
         s = max(1.0, float(rec32['grads'][k].abs().max()))
         ok, err, ref, _ = _check(gaps, 'grad/' + k, p.grad, rec32['grads'][k], r64['grads'].get(k), scale=2.0 * s)
@@ -132,8 +136,14 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B):
     _report('%-18s %-14s grads %d tensors: %d inside the strict bar; worst |gpu-cpu32|/max %.3e (|cpu32-cpu64|/max %.3e) at %s; '
             'flat gradient cos %.6f norm ratio %.4f' % (name, tag, n, strict, worst[0], worst[1], worst[2], cos, ratio))
     assert n >= 2 * 2, 'no gradients compared'
-    if cos < 0.9 or not 0.8 < ratio < 1.25:
-        bad.append(('flat gradient', cos, ratio))
+    # The flat gradient as a whole: cosine >= 0.9 and norm ratio within 0.8 .. 1.25 against the fp32 oracle -- unless the fp32 oracle
+    # is itself far from the float64 one at this state (a 32-step RealNVP at B = 256 occasionally sits on a ReLU kink that the
+    # BatchNorm backward spreads over the whole batch: then cpu32 and cpu64 disagree by tens of percent and no fp32 result can be
+    # judged against either); then the GPU must be no farther from float64 than four times the fp32 oracle is.
+    rel_gpu, rel_ref = (d_gpu / max(n_64, 1e-300)) ** 0.5, (d_ref / max(n_64, 1e-300)) ** 0.5
+    _report('%-18s %-14s flat gradient distance to float64: gpu %.3e  cpu32 %.3e' % (name, tag, rel_gpu, rel_ref))
+    if (cos < 0.9 or not 0.8 < ratio < 1.25) and rel_gpu > 4.0 * rel_ref:
+        bad.append(('flat gradient', cos, ratio, rel_gpu, rel_ref))
     assert not bad, '%s %s: %d quantities outside their bar, first %s' % (name, tag, len(bad), bad[:6])
 
 
