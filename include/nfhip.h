@@ -475,6 +475,9 @@ typedef struct nf_convnet_bwd_desc {
     float* cp_g_a;              /* scalars, += (atomic) */
     float* cp_g_c;
     int cp_mode, cp_odd, cp_C, cp_reserved;
+    /* Optional: gradient accumulators of the BatchNorm parameters, (32,) each, += (one workgroup adds: no atomics). */
+    float* g_gamma[5];
+    float* g_beta[5];
 } nf_convnet_bwd_desc;
 int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
                          nf_stream_t stream);

@@ -906,7 +906,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                 red[NPB * 32 + pb * 32 + oc] = S2;
             }
             const float* tot = nf_cc_sum_exchange<NPB>(sm, L, slots, l);
-            if (blockIdx.x == 0 && threadIdx.x < 64) (threadIdx.x < 32 ? d.sum_g[l] : d.sum_gx[l])[threadIdx.x & 31] = tot[threadIdx.x];
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                (threadIdx.x < 32 ? d.sum_g[l] : d.sum_gx[l])[threadIdx.x & 31] = tot[threadIdx.x];
+                // the sums ARE the gradients of beta (sum gn) and gamma (sum gn xhat): straight into the caller's accumulators
+                float* sink = threadIdx.x < 32 ? d.g_beta[l] : d.g_gamma[l];
+                if (sink != nullptr) sink[threadIdx.x & 31] += tot[threadIdx.x];
+            }
 #pragma unroll
             for (int rr = 0; rr < OWN; ++rr) {
                 const int oc = nf_cv_cd_row(OWN * kq + rr, hs);

@@ -62,7 +62,7 @@ class ConvNetBwdDesc(ctypes.Structure):
                 ('cp_g_y', ctypes.c_void_p), ('cp_g_ld', ctypes.c_void_p), ('cp_z', ctypes.c_void_p), ('cp_out', ctypes.c_void_p),
                 ('cp_a', ctypes.c_void_p), ('cp_c', ctypes.c_void_p), ('cp_g_z', ctypes.c_void_p), ('cp_g_out', ctypes.c_void_p),
                 ('cp_g_a', ctypes.c_void_p), ('cp_g_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int),
-                ('cp_C', ctypes.c_int), ('cp_reserved', ctypes.c_int)]
+                ('cp_C', ctypes.c_int), ('cp_reserved', ctypes.c_int), ('g_gamma', ctypes.c_void_p * 5), ('g_beta', ctypes.c_void_p * 5)]
 
 
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
@@ -156,12 +156,15 @@ class ConvDefer:
                 scratch = self._slab_scratch(sum(per), dev)
                 arr = (ConvBwdDesc * len(chunk))()
                 jobs, off = [], 0
-                for i, (_, kw, g_w, n_slabs) in enumerate(chunk):
+                for i, e in enumerate(chunk):
+                    _, kw, g_w, n_slabs = e[:4]
                     region = scratch[off:off + per[i]]
                     off += per[i]
                     d = _desc(ConvBwdDesc, g_weff=region, **kw)
                     ctypes.memmove(ctypes.addressof(arr) + i * ctypes.sizeof(ConvBwdDesc), ctypes.addressof(d), ctypes.sizeof(ConvBwdDesc))
                     jobs.append((region, g_w, g_w.numel(), g_w.numel(), n_slabs, False, k * k))
+                    if len(e) > 4 and e[4] is not None:      # the layer's bias sums (filled by this very launch) ride the same slab sum
+                        jobs.append(e[4])
                 N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
                 _slab_sum_all(jobs)                  # before the next chunk overwrites the scratch (stream order)
 
@@ -432,6 +435,9 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         d.g_x = g_x.data_ptr() if g_x is not None else None
         slots = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev)     # (kept alive up to the launch, see the forward)
         d.ws_zero = slots.data_ptr()
+        if ctx.sinks is not None:                   # BatchNorm parameter gradients: added by the launch itself
+            for j in range(nb):
+                d.g_gamma[j], d.g_beta[j] = ctx.sinks[nl + 2 * j].data_ptr(), ctx.sinks[nl + 2 * j + 1].data_ptr()
         if cpl is not None:
             z, out, a, c = cpl
             g_y, g_ld = cpl_grads
@@ -471,19 +477,22 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
                 for _ in range(nb)]
     jobs = [(g_weff[i], g_w[i], w[i].numel(), w[i].numel(), slabs, False, w[i].shape[2] * w[i].shape[3]) for i in range(nl)]
     jobs += [(g_bias[i], d_bias[i], w[i].shape[0], GB, R, direct, 1) for i in range(nl)]
-    for j in range(nb):
-        jobs.append((sums[j, 1], d_bn[j][0], H, H, R, direct, 1))       # g_gamma = sum g * xhat
-        jobs.append((sums[j, 0], d_bn[j][1], H, H, R, direct, 1))       # g_beta  = sum g
+    bn_jobs = []
+    if not (chained and direct):                # (the chain launch adds them into the sinks itself)
+        for j in range(nb):
+            bn_jobs.append((sums[j, 1], d_bn[j][0], H, H, R, direct, 1))       # g_gamma = sum g * xhat
+            bn_jobs.append((sums[j, 0], d_bn[j][1], H, H, R, direct, 1))       # g_beta  = sum g
     if defer:
         for key, wkw, i in queued:             # (the tensors in wkw keep every operand alive until the flush)
-            CONV_DEFER.layers.append((key, wkw, g_w[i], slabs))
-        CONV_DEFER.sums += jobs[nl:]
+            CONV_DEFER.layers.append((key, wkw, g_w[i], slabs, jobs[nl + i]))
+        CONV_DEFER.sums += bn_jobs
         CONV_DEFER.offload()
     elif chained:
-        CONV_DEFER.launch_layers([(key, wkw, g_w[i], slabs) for key, wkw, i in queued])
-        _slab_sum(jobs[nl:])
+        CONV_DEFER.launch_layers([(key, wkw, g_w[i], slabs, jobs[nl + i]) for key, wkw, i in queued])
+        if bn_jobs:
+            _slab_sum(bn_jobs)
     else:
-        _slab_sum(jobs)
+        _slab_sum(jobs + bn_jobs)
     grads = []
     for i in range(nl):
         grads += [g_w[i], None if direct else d_bias[i]]
