@@ -93,14 +93,32 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_fwd(const float* __restr
 
 // backward.  G = g_h + scatter(g_z1c);  g_zn = W^T G;  g_z = g_zn / exp(ls);
 // g_bias[c] += -sum g_zn[c]/exp(ls[c]);  g_ls[c] += -sum g_zn[c] zn[c] - P sum_b g_ld;  g_W[r][c] += sum G[r] zn[c]
+#define NF_GH_BIG 1024     // threads of the backward kernel: it ends in same-address atomics (256 blocks of sixteen waves, see coupling.hip)
 template <int CT>
-__global__ void __launch_bounds__(NF_BLOCK) k_glow_head_bwd(const float* __restrict__ gh, const float* __restrict__ gz1c,
-                                                            const float* __restrict__ gld, const float* __restrict__ z,
-                                                            const float* __restrict__ ls, const float* __restrict__ bs,
-                                                            const float* __restrict__ Wsaved, float* __restrict__ gz,
-                                                            float* __restrict__ g_ls, float* __restrict__ g_bias,
-                                                            float* __restrict__ gW, float* __restrict__ sum_gld, NfSplit s, int64_t B, int P) {
-    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+__device__ __forceinline__ void nf_gh_bwd_load(const float* __restrict__ gh, const float* __restrict__ gz1c, const float* __restrict__ z,
+                                               const NfSplit& s, int64_t t, int P, int64_t& base, float (&zr)[CT], float (&G)[CT]) {
+    const int64_t b = t / P;
+    const int p = (int)(t - b * P);
+    base = b * CT * P + p;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        zr[c] = z[base + (int64_t)c * P];
+        float g = gh[base + (int64_t)c * P];
+        int which, e;
+        nf_full_to_half(s, c, p, which, e);
+        if (which == 1 && gz1c != nullptr) g += gz1c[b * s.n_half + e];
+        G[c] = g;
+    }
+}
+
+template <int CT>
+__global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __restrict__ gh, const float* __restrict__ gz1c,
+                                                             const float* __restrict__ gld, const float* __restrict__ z,
+                                                             const float* __restrict__ ls, const float* __restrict__ bs,
+                                                             const float* __restrict__ Wsaved, float* __restrict__ gz,
+                                                             float* __restrict__ g_ls, float* __restrict__ g_bias,
+                                                             float* __restrict__ gW, float* __restrict__ sum_gld, NfSplit s, int64_t B, int P) {
+    __shared__ float scratch[NF_GH_BIG / NF_WAVE];
     float Wm[CT][CT], es[CT], bb[CT];
 #pragma unroll
     for (int r = 0; r < CT; ++r)
@@ -118,32 +136,32 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_bwd(const float* __restr
     const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t npix = B * P;
-    for (int64_t t = gtid; t < npix; t += gstride) {
-        const int64_t b = t / P;
-        const int p = (int)(t - b * P);
-        const int64_t base = b * CT * P + p;
-        float zn[CT], G[CT];
+    for (int64_t t = gtid; t < npix; t += 2 * gstride) {     // two pixels per trip: their loads are in flight together
+        const int64_t t2 = t + gstride;
+        const bool has2 = t2 < npix;
+        int64_t base[2];
+        float zr[2][CT], G[2][CT];
+        nf_gh_bwd_load<CT>(gh, gz1c, z, s, t, P, base[0], zr[0], G[0]);
+        nf_gh_bwd_load<CT>(gh, gz1c, z, s, has2 ? t2 : t, P, base[1], zr[1], G[1]);
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            zn[c] = (z[base + (int64_t)c * P] - bb[c]) / es[c];
-            float g = gh[base + (int64_t)c * P];
-            int which, e;
-            nf_full_to_half(s, c, p, which, e);
-            if (which == 1 && gz1c != nullptr) g += gz1c[b * s.n_half + e];
-            G[c] = g;
-        }
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !has2) break;
+            float zn[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            float a = 0.f;
+            for (int c = 0; c < CT; ++c) zn[c] = (zr[u][c] - bb[c]) / es[c];
 #pragma unroll
-            for (int r = 0; r < CT; ++r) {
-                a = fmaf(Wm[r][c], G[r], a);
-                aW[r][c] = fmaf(G[r], zn[c], aW[r][c]);
+            for (int c = 0; c < CT; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < CT; ++r) {
+                    a = fmaf(Wm[r][c], G[u][r], a);
+                    aW[r][c] = fmaf(G[u][r], zn[c], aW[r][c]);
+                }
+                const float gzc = a / es[c];
+                gz[base[u] + (int64_t)c * P] = gzc;
+                aB[c] -= gzc;
+                aL[c] = fmaf(-a, zn[c], aL[c]);
             }
-            const float gzc = a / es[c];
-            gz[base + (int64_t)c * P] = gzc;
-            aB[c] -= gzc;
-            aL[c] = fmaf(-a, zn[c], aL[c]);
         }
     }
     float sg = 0.f;                                  // this block's share of sum_b g_ld
@@ -195,10 +213,10 @@ extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const floa
     if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
     if (B == 0) return 0;
     const int Px = H * W;
-    unsigned g = nf_grid_for(B * Px, NF_BLOCK * 2);
+    unsigned g = nf_grid_for(B * Px, NF_GH_BIG * 2);
     if (g > 256) g = 256;
     hipStream_t st = (hipStream_t)stream;
-#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(NF_BLOCK), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, s, B, Px); break;
+#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(NF_GH_BIG), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, s, B, Px); break;
     switch (C) { NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) default: return NF_E_UNSUPPORTED; }
 #undef NF_CASE
     NF_CHECK_LAUNCH();

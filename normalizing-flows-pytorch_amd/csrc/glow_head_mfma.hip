@@ -131,28 +131,39 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) s1[i][j] = s2[i][j] = 0.f;
+    // Staging: a thread owns ONE pixel column of the tile (256 threads = 128 pixels x 2 channel phases); the loads of tile i + 1 are
+    // issued into registers before the MFMAs of tile i.
+    constexpr int NCH = RT * 16 / (NF_BLOCK / NF_GH_TP);   // channel rows per thread
+    const int sq = threadIdx.x & (NF_GH_TP - 1), ph = threadIdx.x >> 7;
+    float rg[NCH], rx[NCH];
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_block;
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile * NF_GH_TP + sq;
+        const bool ok = tile < tile0 + tiles_per_block && t < npix;
+        const int64_t b = ok ? t / P : 0;
+        const int64_t base = b * C * P + (ok ? t - b * P : 0);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = ph + 2 * k;
+            const bool in = ok && c < C;
+            rg[k] = in ? gh[base + (int64_t)c * P] : 0.f;
+            rx[k] = in ? x[base + (int64_t)c * P] : 0.f;
+        }
+    };
+    fetch(tile0);
     for (int64_t tile = tile0; tile < tile0 + tiles_per_block; ++tile) {
         const int64_t t0 = tile * NF_GH_TP;
         if (t0 >= npix) break;
         const int np = (int)min((int64_t)NF_GH_TP, npix - t0);
         __syncthreads();
-        {   // a thread stages ONE pixel column of the tile (256 threads = 128 pixels x 2 channel phases): its sample / offset once
-            const int q = threadIdx.x & (NF_GH_TP - 1);
-            const int64_t t = t0 + q, b = t / P;
-            const int64_t base = b * C * P + (t - b * P);
-            for (int c = threadIdx.x >> 7; c < CP; c += NF_BLOCK / NF_GH_TP) {
-                float gv = 0.f, av = 0.f;
-                if (q < np && c < C) {
-                    const int64_t addr = base + (int64_t)c * P;
-                    gv = gh[addr];
-                    av = (x[addr] - cst[c]) / cst[CP + c];
-                }
-                gT[c * RS + q] = gv;
-                aT[c * RS + q] = av;
-            }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = ph + 2 * k;
+            gT[c * RS + sq] = rg[k];
+            aT[c * RS + sq] = (sq < np && c < C) ? (rx[k] - cst[c]) / cst[CP + c] : 0.f;
         }
         __syncthreads();
+        fetch(tile + 1);
         // ---- g_W: this wave's quarter of the tile, pixels [32 wid, 32 wid + 32), 8 k-steps of 4 pixels ----
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -303,7 +314,7 @@ extern "C" int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const flo
     const int rt = (C + 15) / 16, kq = (C + 3) / 4;
     const int64_t npix = B * P;
     const int64_t tiles = (npix + NF_GH_TP - 1) / NF_GH_TP;
-    int64_t blocks = tiles < 1024 ? tiles : 1024;
+    int64_t blocks = tiles < 512 ? tiles : 512;              // ends in C * C + 2 C same-address atomics per block
     const int64_t tpb = (tiles + blocks - 1) / blocks;
     blocks = (tiles + tpb - 1) / tpb;
     const size_t lds = ((size_t)2 * rt * 16 * (NF_GH_TP + 1) + 2 * rt * 16) * sizeof(float);

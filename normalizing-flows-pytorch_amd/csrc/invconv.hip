@@ -117,27 +117,35 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad(const float* __restr
     }
 }
 
-// small C (<= 4): every thread keeps the whole C x C partial in registers, one block reduction + C*C atomics per block
+// small C (<= 4): every thread keeps the whole C x C partial in registers, one block reduction + C*C atomics per block.
+// 256 blocks of 1024 threads (sixteen waves per CU; the kernel ends in same-address atomics), two pixels' loads in flight per trip.
+#define NF_IW_BIG 1024
 template <int CT>
-__global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad_small(const float* __restrict__ gy, const float* __restrict__ z,
-                                                                  float* __restrict__ gM, int64_t B, int P) {
-    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+__global__ void __launch_bounds__(NF_IW_BIG) k_invconv_wgrad_small(const float* __restrict__ gy, const float* __restrict__ z,
+                                                                   float* __restrict__ gM, int64_t B, int P) {
+    __shared__ float scratch[NF_IW_BIG / NF_WAVE];
     float acc[CT][CT];
 #pragma unroll
     for (int r = 0; r < CT; ++r)
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[r][c] = 0.f;
     const int64_t npix = B * P;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npix; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = t / P;
-        const int64_t base = b * CT * P + (t - b * P);
-        float g[CT], v[CT];
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npix; t += 2 * gstride) {
+        const int64_t t2 = t + gstride < npix ? t + gstride : t;
+        const float w2 = t + gstride < npix ? 1.f : 0.f;
+        const int64_t b = t / P, b2 = t2 / P;
+        const int64_t base = b * CT * P + (t - b * P), base2 = b2 * CT * P + (t2 - b2 * P);
+        float g[CT], v[CT], g2[CT], v2[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { g[c] = gy[base + (int64_t)c * P]; v[c] = z[base + (int64_t)c * P]; }
+        for (int c = 0; c < CT; ++c) {
+            g[c] = gy[base + (int64_t)c * P]; v[c] = z[base + (int64_t)c * P];
+            g2[c] = gy[base2 + (int64_t)c * P] * w2; v2[c] = z[base2 + (int64_t)c * P];
+        }
 #pragma unroll
         for (int r = 0; r < CT; ++r)
 #pragma unroll
-            for (int c = 0; c < CT; ++c) acc[r][c] = fmaf(g[r], v[c], acc[r][c]);
+            for (int c = 0; c < CT; ++c) acc[r][c] = fmaf(g2[r], v2[c], fmaf(g[r], v[c], acc[r][c]));
     }
 #pragma unroll
     for (int r = 0; r < CT; ++r)
@@ -320,14 +328,14 @@ extern "C" int nf_invconv_wgrad(const float* g_y, const float* z, float* g_M, in
         return 0;
     }
     if (C <= 4) {
-        unsigned g = nf_grid_for(B * P, NF_BLOCK * 4);
-        if (g > 512) g = 512;
+        unsigned g = nf_grid_for(B * P, NF_IW_BIG * 2);
+        if (g > 256) g = 256;
         hipStream_t st = (hipStream_t)stream;
         switch (C) {
-            case 1: hipLaunchKernelGGL(k_invconv_wgrad_small<1>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
-            case 2: hipLaunchKernelGGL(k_invconv_wgrad_small<2>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
-            case 3: hipLaunchKernelGGL(k_invconv_wgrad_small<3>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
-            default: hipLaunchKernelGGL(k_invconv_wgrad_small<4>, dim3(g), dim3(NF_BLOCK), 0, st, g_y, z, g_M, B, P); break;
+            case 1: hipLaunchKernelGGL(k_invconv_wgrad_small<1>, dim3(g), dim3(NF_IW_BIG), 0, st, g_y, z, g_M, B, P); break;
+            case 2: hipLaunchKernelGGL(k_invconv_wgrad_small<2>, dim3(g), dim3(NF_IW_BIG), 0, st, g_y, z, g_M, B, P); break;
+            case 3: hipLaunchKernelGGL(k_invconv_wgrad_small<3>, dim3(g), dim3(NF_IW_BIG), 0, st, g_y, z, g_M, B, P); break;
+            default: hipLaunchKernelGGL(k_invconv_wgrad_small<4>, dim3(g), dim3(NF_IW_BIG), 0, st, g_y, z, g_M, B, P); break;
         }
         NF_CHECK_LAUNCH();
         return 0;

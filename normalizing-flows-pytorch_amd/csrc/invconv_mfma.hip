@@ -83,25 +83,37 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad_mfma(const float* __
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < RT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Staging: a thread owns ONE pixel column of the tile (256 threads = 128 pixels x 2 channel phases) and the channels c = phase,
+    // phase + 2, ...; the loads of tile i + 1 are issued into registers before the MFMAs of tile i (the kernel is a stream of
+    // 8 bytes per element: what limits it is how much of that stream is in flight).
+    constexpr int NCH = RT * 16 / (NF_BLOCK / NF_WTP);     // channel rows per thread
+    const int q = threadIdx.x & (NF_WTP - 1), ph = threadIdx.x >> 7;
+    float ra[NCH], rz[NCH];
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_block;
+    auto fetch = [&](int64_t tile) {
+        const int64_t t = tile * NF_WTP + q;
+        const bool ok = tile < tile0 + tiles_per_block && t < npix;
+        const int64_t b = ok ? t / P : 0;
+        const int64_t base = b * C * P + (ok ? t - b * P : 0);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = ph + 2 * k;
+            const bool in = ok && c < C;
+            ra[k] = in ? gy[base + (int64_t)c * P] : 0.f;
+            rz[k] = in ? z[base + (int64_t)c * P] : 0.f;
+        }
+    };
+    fetch(tile0);
     for (int64_t tile = tile0; tile < tile0 + tiles_per_block; ++tile) {
-        const int64_t t0 = tile * NF_WTP;
-        if (t0 >= npix) break;
-        const int np = (int)min((int64_t)NF_WTP, npix - t0);
+        if (tile * NF_WTP >= npix) break;
         __syncthreads();
-        for (int i = threadIdx.x; i < CP * NF_WTP; i += blockDim.x) {
-            const int c = i / NF_WTP, q = i - c * NF_WTP;
-            float av = 0.f, zv = 0.f;
-            if (q < np && c < C) {
-                const int64_t t = t0 + q, b = t / P;
-                const int64_t addr = (b * C + c) * P + (t - b * P);
-                av = gy[addr];
-                zv = z[addr];
-            }
-            gT[c * RS + q] = av;
-            zT[c * RS + q] = zv;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            gT[(ph + 2 * k) * RS + q] = ra[k];
+            zT[(ph + 2 * k) * RS + q] = rz[k];
         }
         __syncthreads();
+        fetch(tile + 1);
         // this wave's quarter of the tile: pixels [32 wid, 32 wid + 32), 8 k-steps of 4 pixels
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -174,7 +186,7 @@ __attribute__((visibility("hidden"))) int nf_invconv_wgrad_mfma_try(const float*
     const int rt = (C + 15) / 16;
     const int64_t npix = B * P;
     const int64_t tiles = (npix + NF_WTP - 1) / NF_WTP;
-    int64_t blocks = tiles < 1024 ? tiles : 1024;
+    int64_t blocks = tiles < 1024 ? tiles : 1024;            // (the kernel ends in C * C same-address atomics per block)
     const int64_t tpb = (tiles + blocks - 1) / blocks;
     blocks = (tiles + tpb - 1) / tpb;
     const size_t lds = (size_t)2 * rt * 16 * (NF_WTP + 1) * sizeof(float);

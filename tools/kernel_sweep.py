@@ -117,6 +117,22 @@ def main():
                lambda: N.call('nf_invconv_wgrad', yv.data_ptr(), z.data_ptr(), gW.data_ptr(), B, C, P, st()))
         del z, yv
 
+    # ---- fused Glow head for 9 .. 64 channels (ActNorm + 1x1 + gather, MFMA) ------------------------------------------------------
+    for C, Hh, B in [(12, 16, int(8192 * sc)), (48, 8, int(8192 * sc))]:
+        x = torch.randn(B, C, Hh, Hh, device=DEV)
+        W = torch.linalg.qr(torch.randn(C, C))[0].to(DEV).contiguous()
+        ls, bs, lsv = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        h, z1c, ld = torch.empty_like(x), torch.empty(B, C // 2, Hh, Hh, device=DEV), torch.zeros(B, device=DEV)
+        gx, acc = torch.empty_like(x), torch.zeros(C * C + 2 * C, device=DEV)
+        report('glow_head_w_fwd (%d,%d,%d)' % (C, Hh, Hh), x.numel() * 10,
+               lambda: N.call('nf_glow_head_w_fwd', x.data_ptr(), ls.data_ptr(), bs.data_ptr(), W.data_ptr(), lsv.data_ptr(), h.data_ptr(),
+                              z1c.data_ptr(), ld.data_ptr(), 2, 0, B, C, Hh, Hh, st()))
+        report('glow_head_w_bwd (%d,%d,%d)' % (C, Hh, Hh), x.numel() * 12,
+               lambda: N.call('nf_glow_head_w_bwd', h.data_ptr(), ld.data_ptr(), x.data_ptr(), ls.data_ptr(), bs.data_ptr(), W.data_ptr(),
+                              gx.data_ptr(), acc.data_ptr() + 4 * C * C, acc.data_ptr() + 4 * C * C + 4 * C, acc.data_ptr(), B, C, Hh, Hh,
+                              st()))
+        del x, h, z1c, gx
+
     # ---- fused Glow head (2-D) ------------------------------------------------------------------------------------------------
     B = int(2 ** 24 * sc)
     z = torch.randn(B, 2, device=DEV)
