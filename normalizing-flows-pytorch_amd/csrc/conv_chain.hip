@@ -231,9 +231,10 @@ __device__ __forceinline__ void nf_cc_half_stats(const float (&v)[OWN], bool lo_
     which = w;
 }
 
-// gather the G x 64 published values of one exchange round into LDS (xs[workgroup][64]); a slot is {generation : value}, four polled per
+// gather the G x 64 published values of one exchange round into LDS (xs[workgroup][XS]: row stride 65 keeps the per-channel walks over
+// workgroups off one bank); a slot is {generation : value}, four polled per
 // trip.  A workgroup that never arrives (not co-resident, lost) ends the wait after nf_cc_spin_limit polls: sticky error word, loud on the host.
-__device__ __forceinline__ void nf_cc_collect_slots(float* xs, const unsigned long long* rs, unsigned gen, int G) {
+__device__ __forceinline__ void nf_cc_collect_slots(float* xs, const unsigned long long* rs, unsigned gen, int G, int XS) {
     for (int e0 = threadIdx.x; e0 < G * 64; e0 += 4 * NF_CV_THREADS) {
         unsigned long long v[4];
         unsigned spins = 0;
@@ -254,9 +255,15 @@ __device__ __forceinline__ void nf_cc_collect_slots(float* xs, const unsigned lo
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int e = e0 + k * NF_CV_THREADS;
-            if (e < G * 64) xs[e] = __uint_as_float((unsigned)v[k]);
+            if (e < G * 64) xs[(e >> 6) * XS + (e & 63)] = __uint_as_float((unsigned)v[k]);
         }
     }
+}
+
+__device__ __forceinline__ float nf_cc_sum32(float v) {      // over the 32 lanes of a wave half, fixed order
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v += __shfl_xor(v, off, NF_WAVE);
+    return v;
 }
 
 // grid-wide (sum, M2) of 32 channels: red[0][pb][c] = sums, red[1][pb][c] = M2 about the pixel block's mean -> tot[c], tot[32 + c].
@@ -267,11 +274,10 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
                                                              int64_t Npx, int PXW) {
     float* red = sm + L.RED;
     float* xs = sm + L.RS;
-    float* part = sm + L.WL;                            // [32 parts][32 channels]
     float* tot = sm + L.TOT;
     const int G = gridDim.x;
-    const int i = threadIdx.x & 31, p = threadIdx.x >> 5;
-    __syncthreads();                                    // red complete; RS / Wl no longer read by anybody
+    const int i = threadIdx.x & 31;
+    __syncthreads();                                    // red complete; RS no longer read by anybody
     if (round == 1) NF_CC_STAMP(56);
     if (threadIdx.x < 32) {
         const int nb = nf_cc_valid_px(Npx, (int64_t)blockIdx.x * PXW, PXW);
@@ -315,35 +321,29 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
 #ifdef NF_CC_PROF
     if (round == 1 && threadIdx.x == 0) nf_cc_arrive[blockIdx.x] = wall_clock64();
 #endif
-    nf_cc_collect_slots(xs, rs, gen, G);
+    const int XS = G * 65 <= L.KC - L.RS ? 65 : 64;
+    nf_cc_collect_slots(xs, rs, gen, G, XS);
     if (round == 1) NF_CC_STAMP(58);
     __syncthreads();
     if (round == 1) NF_CC_STAMP(59);
-    // sums: parts, then everybody adds the 32 parts of its channel (fixed order: deterministic)
-    float ps = 0.f;
-    for (int b = p; b < G; b += 32) ps += xs[b * 64 + i];
-    part[p * 32 + i] = ps;
-    __syncthreads();
-    float S = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) S += part[q * 32 + i];
-    const float mean = S / (float)Npx;
-    float pm = 0.f;
-    const float inv_full = 1.f / (float)PXW;
-    for (int b = p; b < G; b += 32) {
-        const int nb = nf_cc_valid_px(Npx, (int64_t)b * PXW, PXW);
-        const float dlt = xs[b * 64 + i] * (nb == PXW ? inv_full : 1.f / (float)max(nb, 1)) - mean;
-        pm += fmaf((float)nb * dlt, dlt, xs[b * 64 + 32 + i]);
-    }
-    __syncthreads();                                    // every thread has read the sums' parts
-    part[p * 32 + i] = pm;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float M2 = 0.f;
-#pragma unroll 8
-        for (int q = 0; q < 32; ++q) M2 += part[q * 32 + i];
-        tot[i] = S;
-        tot[32 + i] = M2;
+    // Thread (wave w, half h, lane l) reduces channel i = 2 w + h over the workgroups b = l, l + 32, ...: per-lane partials in a fixed
+    // order, then a butterfly over the 32 lanes -- no further barrier until the totals are written (the version with two passes of
+    // LDS partials took four more barriers).
+    {
+        const int lane = threadIdx.x & 63, ci = 2 * (threadIdx.x >> 6) + (lane >> 5), l = lane & 31;
+        float ps = 0.f;
+        for (int b = l; b < G; b += 32) ps += xs[b * XS + ci];
+        const float S = nf_cc_sum32(ps);
+        const float mean = S / (float)Npx;
+        const float inv_full = 1.f / (float)PXW;
+        float pm = 0.f;
+        for (int b = l; b < G; b += 32) {
+            const int nb = nf_cc_valid_px(Npx, (int64_t)b * PXW, PXW);
+            const float dlt = xs[b * XS + ci] * (nb == PXW ? inv_full : 1.f / (float)max(nb, 1)) - mean;
+            pm += fmaf((float)nb * dlt, dlt, xs[b * XS + 32 + ci]);
+        }
+        const float M2 = nf_cc_sum32(pm);
+        if (l == 0) { tot[ci] = S; tot[32 + ci] = M2; }
     }
     __syncthreads();
     return tot;
@@ -708,7 +708,6 @@ template <int NPB>
 __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, int round) {
     float* red = sm + L.RED;
     float* xs = sm + L.RS;
-    float* part = sm + L.WL;                            // [16 parts][64]
     float* tot = sm + L.TOT;
     const int G = gridDim.x;
     __syncthreads();                                    // red complete; RS / Wl no longer read by anybody
@@ -731,18 +730,15 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
         __syncthreads();
         return tot;
     }
-    nf_cc_collect_slots(xs, slots + (size_t)round * NF_CC_MAX_BLOCKS * 64, (unsigned)(round + 1), G);
+    const int XS = G * 65 <= L.KC - L.RS ? 65 : 64;
+    nf_cc_collect_slots(xs, slots + (size_t)round * NF_CC_MAX_BLOCKS * 64, (unsigned)(round + 1), G, XS);
     __syncthreads();
-    const int i = threadIdx.x & 63, p = threadIdx.x >> 6;
-    float ps = 0.f;
-    for (int b = p; b < G; b += NF_CV_WAVES) ps += xs[b * 64 + i];
-    part[p * 64 + i] = ps;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        float S = 0.f;
-#pragma unroll
-        for (int q = 0; q < NF_CV_WAVES; ++q) S += part[q * 64 + i];
-        tot[i] = S;
+    {
+        const int lane = threadIdx.x & 63, ci = 2 * (threadIdx.x >> 6) + (lane >> 5), l = lane & 31;
+        float pa = 0.f, pb = 0.f;
+        for (int b = l; b < G; b += 32) { pa += xs[b * XS + ci]; pb += xs[b * XS + 32 + ci]; }
+        const float A = nf_cc_sum32(pa), Bs = nf_cc_sum32(pb);
+        if (l == 0) { tot[ci] = A; tot[32 + ci] = Bs; }
     }
     __syncthreads();
     return tot;
