@@ -407,7 +407,8 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
             gld = torch.full((B, ), -1.0, device=dev)
             gz, gout = torch.empty_like(z), torch.empty_like(out)
             a, c, gac = torch.full((1, ), 0.5, device=dev), torch.zeros(1, device=dev), torch.zeros(2, device=dev)
-            nws = N.header_constant('NF_CONVNET_WS_FLOATS')
+            nws = int(N.load().nf_convnet_chain_ws_floats(B, I0, O, Hh, Ww))
+            split = nws > N.header_constant('NF_CONVNET_WS_FLOATS')     # a sample over two workgroups (halo rows handed over per layer)
             per = 20
             wsf = torch.zeros(per + 3, nws, device=dev)
             it = [0]
@@ -437,14 +438,16 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
             flop = 2 * M * (4 * 9 * 32 * 32 + 9 * 32 * I0 + 32 * O)          # five transposed convolutions, data gradient only
             tf = flop / (us * 1e-6) / 1e12
             bytes_alg = 4 * (M * 32 * (5 + 5 + 2) + 2 * M * O + 3 * z.numel())
-            return {'bound': 'mfma', 'kernel': 'k_convnet_chain_bwd<8, 2> (data gradient of the whole ConvNet conditioner + coupling backward in '
-                                               'one persistent launch: %d -> 32 x 5 -> %d channels, %d x %d)' % (I0, O, Hh, Ww),
+            wgs = int((M + (127 if split else 255)) // (128 if split else 256))
+            return {'bound': 'mfma', 'kernel': 'k_convnet_chain_bwd<%s> (data gradient of the whole ConvNet conditioner + coupling backward in '
+                                               'one persistent launch: %d -> 32 x 5 -> %d channels, %d x %d)' % ('4, 4' if split else '8, 2', I0, O, Hh, Ww),
                     'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
                     'traffic': pmc_traffic('k_convnet_chain_bwd', B), 'flop_per_launch': int(flop), 'bytes_per_launch': int(bytes_alg),
-                    'us_per_launch': round(us, 3), 'workgroups': int((M + 255) // 256),
-                    'note': 'one 1024-thread workgroup per sample: %d of 256 compute units hold the whole launch (peak reachable by it: %d / 256 '
-                            'of the chip), ~40 us of fp32 MFMA work per CU inside five grid-wide BatchNorm exchanges (DESIGN.md section '
-                            '3.16)' % ((M + 255) // 256, (M + 255) // 256)}
+                    'us_per_launch': round(us, 3), 'workgroups': wgs,
+                    'note': '%s: %d of 256 compute units hold the whole launch (peak reachable by it: %d / 256 of the chip), five dependent '
+                            'convolutions inside five grid-wide BatchNorm exchanges (DESIGN.md section 3.16)'
+                            % ('two 1024-thread workgroups per sample, boundary rows handed over per layer' if split
+                               else 'one 1024-thread workgroup per sample', wgs, wgs)}
     if cfg['kind'] in ('maf', 'glow', 'realnvp') and len(dims) == 1:              # multi-launch linear + BatchNorm chain
         nets = 2 if cfg['kind'] == 'maf' else 1
         T = lambda *sh: torch.randn(*sh, generator=g).to(dev)          # noqa: E731

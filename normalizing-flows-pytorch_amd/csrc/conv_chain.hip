@@ -15,6 +15,7 @@
 //   the K splits meet in LDS, every wave finishes 16 / NKQ output channels of its pixel block: bias, residual (kept in
 //   registers: the lane that finishes (channel, pixel) of layer l also finishes it for layer l + 2), store, statistics.
 //   Batch statistics are (sum, M2) pairs merged by the parallel-variance rule: half wave -> workgroup -> grid (no E[x^2] - E[x]^2).
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_set>
@@ -361,6 +362,50 @@ __device__ __forceinline__ int nf_cc_half_to_full(const NfSplit& s, int which, i
     return (c * s.H + 2 * i + dy) * s.W + 2 * j + dx;
 }
 
+// ---- halo rows between the workgroups of one sample (16 x 16 maps on 128-pixel tiles) ---------------------------------------------------
+// A tile owns TH image rows; the 3 x 3 taps of its first / last row read one row of the neighbouring tile.  The owner of a boundary row
+// publishes its 32 x W values of the layer as 64-bit {generation : value} slots addressed to the neighbour -- [layer][destination tile]
+// [slot s][channel][x], s = 0: the row above the destination's first row, s = 1: the row below its last -- BEFORE the layer's grid-wide
+// statistics exchange, which the hand-over hides behind; the receiver polls its own slots after the exchange (they are there by then) and
+// finishes the values exactly as its own pixels.  Self-synchronising: no ordering between these stores and the statistics slots is assumed.
+#define NF_CC_STAT_SLOTS (NF_CC_NB * NF_CC_MAX_BLOCKS * 64)                 // 64-bit slots of the statistics exchanges (before the halo slots)
+#define NF_CC_HALO_SLOTS(W) (2 * 32 * (W))                                  // per layer and destination tile
+template <int OWN>
+__device__ __forceinline__ void nf_cc_halo_publish(unsigned long long* hslots, int layer, const NfCvGeo& g, int tile, int y0, int px, int kq,
+                                                   int hs, const float (&v)[OWN]) {
+    const int row = px >> g.lgW, x = px & (g.W - 1);
+    const bool first = row == 0 && y0 > 0;                       // our first row is the row BELOW the previous tile's last row
+    const bool last = row == g.TH - 1 && y0 + g.TH < g.H;        // our last row is the row ABOVE the next tile's first row
+    if (!(first || last)) return;
+    const int dst = first ? tile - 1 : tile + 1, s = first ? 1 : 0;
+    unsigned long long* base = hslots + ((size_t)layer * NF_CC_MAX_BLOCKS + dst) * NF_CC_HALO_SLOTS(g.W) + s * 32 * g.W + x;
+    const unsigned long long gen = (unsigned long long)(layer + 1) << 32;
+#pragma unroll
+    for (int rr = 0; rr < OWN; ++rr) {
+        const int c = nf_cv_cd_row(OWN * kq + rr, hs);
+        __hip_atomic_store(base + c * g.W, gen | (unsigned long long)__float_as_uint(v[rr]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// thread t < 32 W: channel t / W, column t % W of BOTH halo rows (s = 0, 1; an image border has none).  Returns the frame position of
+// the value this call delivers in `v`, or -1; call once per row s.
+__device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots, int layer, const NfCvGeo& g, int tile, int y0, int s, float& v) {
+    const bool has = s == 0 ? y0 > 0 : y0 + g.TH < g.H;
+    if (!has) return -1;
+    const int t = threadIdx.x, x = t & (g.W - 1);
+    const unsigned long long* p = hslots + ((size_t)layer * NF_CC_MAX_BLOCKS + tile) * NF_CC_HALO_SLOTS(g.W) + s * 32 * g.W + t;
+    const unsigned gen = (unsigned)(layer + 1);
+    unsigned long long w;
+    unsigned spins = 0;
+    do {
+        w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w >> 32) == gen) break;
+        if (++spins > nf_cc_spin_limit) { NF_PERSIST_GIVE_UP(nf_cc); break; }
+        __builtin_amdgcn_s_sleep(1);
+    } while (true);
+    v = __uint_as_float((unsigned)w);
+    return (s == 0 ? 0 : (g.TH + 1) * g.FW) + x + 1;             // frame row 0 / TH + 1, column x + halo
+}
+
 // LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
 template <int NPB, int NKQ>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
@@ -380,7 +425,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     const int pb = wid % NPB, kq = wid / NPB;
     const int64_t Npx = g.B * g.HW;
     const int64_t tile = blockIdx.x;
-    const int64_t b0 = (tile * PXW) >> g.lgHW;          // first sample of the tile (whole samples per tile: y0 = 0)
+    const int64_t b0 = (tile * PXW) >> g.lgHW;          // first sample of the tile
+    // A sample larger than the tile (16 x 16 on 128-pixel tiles) is split over HW / PXW workgroups, rows y0 .. y0 + TH - 1 each: the
+    // frame's halo rows then belong to the neighbours, which hand them over layer by layer (nf_cc_halo_*, below).
+    const bool halo = g.HW > PXW;
+    const int y0 = halo ? (int)((tile * PXW) & (g.HW - 1)) >> g.lgW : 0;
+    unsigned long long* hslots = halo ? (unsigned long long*)d.ws_zero + NF_CC_STAT_SLOTS : nullptr;
     const int px = pb * 32 + c32;
     const int fpos = nf_cv_frame_of(g, px);
     const int64_t P = tile * PXW + px;
@@ -399,12 +449,25 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     if (cpl) {
         // y <- z for this workgroup's (contiguous) samples, whole 16-byte vectors, no index arithmetic; the transformed half is
         // overwritten by the epilogue at the far end of the launch (same workgroup, barriers in between).  Nothing waits for it.
-        const int nsamp = g.HW < PXW ? PXW >> g.lgHW : 1;
-        const int64_t left = g.B - b0;
-        const int n4 = (int)(left < nsamp ? (left > 0 ? left : 0) : nsamp) * (cs.n_full >> 2);
-        const float4* src = reinterpret_cast<const float4*>(d.cp_z + b0 * cs.n_full);
-        float4* dst = reinterpret_cast<float4*>(d.cp_y + b0 * cs.n_full);
-        for (int idx = threadIdx.x; idx < n4; idx += NF_CV_THREADS) dst[idx] = src[idx];
+        if (!halo) {
+            const int nsamp = g.HW < PXW ? PXW >> g.lgHW : 1;
+            const int64_t left = g.B - b0;
+            const int n4 = (int)(left < nsamp ? (left > 0 ? left : 0) : nsamp) * (cs.n_full >> 2);
+            const float4* src = reinterpret_cast<const float4*>(d.cp_z + b0 * cs.n_full);
+            float4* dst = reinterpret_cast<float4*>(d.cp_y + b0 * cs.n_full);
+            for (int idx = threadIdx.x; idx < n4; idx += NF_CV_THREADS) dst[idx] = src[idx];
+        } else if (b0 < g.B) {
+            // this workgroup's share of its sample: the rows of every channel plane that its pixels map to -- one contiguous chunk of
+            // PXW / HW of the plane per channel (both split maps keep conditioner rows in order)
+            const int plane4 = (cs.H * cs.W) >> 2, chunk4 = (int)(((int64_t)plane4 * PXW) >> g.lgHW);
+            const int part = (int)((tile * PXW) & (g.HW - 1)) / PXW;
+            const float4* src = reinterpret_cast<const float4*>(d.cp_z + b0 * cs.n_full);
+            float4* dst = reinterpret_cast<float4*>(d.cp_y + b0 * cs.n_full);
+            for (int idx = threadIdx.x; idx < cs.C * chunk4; idx += NF_CV_THREADS) {
+                const int c = idx / chunk4, r = idx - c * chunk4;
+                dst[c * plane4 + part * chunk4 + r] = src[c * plane4 + part * chunk4 + r];
+            }
+        }
     }
 
     float stream[OWN], own[OWN];
@@ -427,7 +490,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
 #pragma unroll 1
             for (int jj = 0; jj < g.nfj; ++jj) {       // one frame position per lane and trip (register budget, see conv_bn.hip)
                 const int f = lane + NF_WAVE * jj;
-                const int t = nf_cv_decode(g, b0, 0, f);
+                const int t = nf_cv_decode(g, b0, y0, f);
                 const int sp = t >= 0 ? NF_CV_SP(t) : 0, sg_ = t >= 0 ? NF_CV_SEG(t) : 0;
                 float xa[NF_CV_CU];
 #pragma unroll
@@ -486,6 +549,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             if (pv) act[(b * 32 + oc) * g.HW + q] = a;
             if ((l & 1) == 0) stream[rr] = a;           // acts[0], acts[2] are the residual stream
         }
+        if (halo) nf_cc_halo_publish<OWN>(hslots, l, g, (int)tile, y0, px, kq, hs, own);
         NF_CC_STAMP(4 + 8 * l);
         if (training) {
             const float* tot = nf_cc_stats_exchange<NPB>(sm, L, slots, l, Npx, PXW);
@@ -524,6 +588,15 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         }
         __syncthreads();
         NF_CC_STAMP(6 + 8 * l);
+        if (halo && threadIdx.x < 32 * g.W) {           // the neighbours' boundary rows, normalised like our own pixels
+            const int c = threadIdx.x >> g.lgW;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v = 0.f;
+                const int f = nf_cc_halo_poll(hslots, l, g, (int)tile, y0, s2, v);
+                if (f >= 0) Fout[(c >> 2) * CS4 + 4 * f + (c & 3)] = fmaxf(fmaf(v, kc[c], kc[32 + c]), 0.f);
+            }
+        }
         // normalise + ReLU into the other frame (a lane's values are whole channel quads: one 16-byte store each); next weights into Wl
 #pragma unroll
         for (int j = 0; j < OWN / 4; ++j) {
@@ -625,8 +698,33 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             __syncthreads();
             if (threadIdx.x == 0 && b0 < g.B) {
                 float v = 0.f;
-                for (int k = 0; k < (g.HW >> 6); ++k) v += red[k];
-                atomicAdd(d.cp_ld + b0, d.cp_inverse ? -v : v);
+                for (int k = 0; k < (min(g.HW, PXW) >> 6); ++k) v += red[k];
+                if (halo) {
+                    // a sample's tiles add their parts in a fixed order (bit-reproducible log-det): the later tiles hand theirs to
+                    // the first one through never-used layer-0 halo slots of that tile (its upper border has no neighbour)
+                    const int nparts = g.HW / PXW, part = (int)((tile * PXW) & (g.HW - 1)) / PXW;
+                    unsigned long long* hs0 = hslots + (size_t)(tile - part) * NF_CC_HALO_SLOTS(g.W);
+                    const unsigned long long gen = 7ull << 32;
+                    if (part > 0) {
+                        __hip_atomic_store(hs0 + part, gen | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = 0.f;
+                    } else {
+                        for (int p2 = 1; p2 < nparts; ++p2) {
+                            unsigned long long w;
+                            unsigned spins = 0;
+                            do {
+                                w = __hip_atomic_load(hs0 + p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((w >> 32) == 7ull) break;
+                                if (++spins > nf_cc_spin_limit) { NF_PERSIST_GIVE_UP(nf_cc); break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            } while (true);
+                            v += __uint_as_float((unsigned)w);
+                        }
+                    }
+                    if (part == 0) atomicAdd(d.cp_ld + b0, d.cp_inverse ? -v : v);
+                } else {
+                    atomicAdd(d.cp_ld + b0, d.cp_inverse ? -v : v);
+                }
             }
         }
     }
@@ -768,6 +866,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     const int64_t q = pv ? P & (g.HW - 1) : 0;
     const float invN = 1.f / (float)Npx;
     unsigned long long* slots = (unsigned long long*)d.ws_zero;
+    const int64_t b0 = (tile * PXW) >> g.lgHW;
+    const bool halo = g.HW > PXW;                       // a sample split over several workgroups (see the forward kernel)
+    const int y0 = halo ? (int)((tile * PXW) & (g.HW - 1)) >> g.lgW : 0;
+    unsigned long long* hslots = halo ? slots + NF_CC_STAT_SLOTS : nullptr;
+    float gstream_h[2] = {0.f, 0.f};                    // halo rows of the residual stream's gradient (threads < 32 W)
 
     for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fin = sm + L.FA;
@@ -869,6 +972,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                 xh[rr] = pv ? act[(b * 32 + oc) * g.HW + q] : 0.f;
             }
         }
+        float a_h[2] = {0.f, 0.f};                      // forward activations at our halo pixels (threads < 32 W; loads in flight early)
+        if (halo && threadIdx.x < 32 * g.W) {
+            const int c = threadIdx.x >> g.lgW, x = threadIdx.x & (g.W - 1);
+            if (y0 > 0) a_h[0] = d.acts[l][(b0 * 32 + c) * g.HW + (y0 - 1) * g.W + x];
+            if (y0 + g.TH < g.H) a_h[1] = d.acts[l][(b0 * 32 + c) * g.HW + (y0 + g.TH) * g.W + x];
+        }
         __syncthreads();                                // every wave is done with Wl / the frames of the K loop; kc is written
         if (cpl && l == NF_CC_NB - 1 && threadIdx.x == 0) {
             float ta = 0.f, tc = 0.f;
@@ -888,6 +997,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             xh[rr] = (a - kc[64 + oc]) * kc[96 + oc];
             if (pv) gn[(b * 32 + oc) * g.HW + q] = v;
         }
+        if (halo) nf_cc_halo_publish<OWN>(hslots, l, g, (int)tile, y0, px, kq, hs, own);   // gn of our boundary rows, to the neighbours
         float mg[OWN], mgx[OWN];
         {   // batch sums of gn and gn * xhat: the gradients of beta and gamma in either mode, the mean terms of the BatchNorm backward
             // in training mode (evaluation mode normalises with constants: no mean terms)
@@ -913,6 +1023,21 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                 const int oc = nf_cv_cd_row(OWN * kq + rr, hs);
                 mg[rr] = training ? tot[oc] * invN : 0.f;
                 mgx[rr] = training ? tot[32 + oc] * invN : 0.f;
+            }
+            if (halo && threadIdx.x < 32 * g.W) {       // G_l at the neighbours' boundary rows: the same per-pixel formula, their gn
+                const int c = threadIdx.x >> g.lgW;
+                const float mgc = training ? tot[c] * invN : 0.f, mgxc = training ? tot[32 + c] * invN : 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float v = 0.f;
+                    const int f = nf_cc_halo_poll(hslots, l, g, (int)tile, y0, s2, v);
+                    if (f >= 0) {
+                        const float xhh = (a_h[s2] - kc[64 + c]) * kc[96 + c];
+                        float G = kc[c] * (v - mgc - xhh * mgxc);
+                        if ((l & 1) == 0) { G += gstream_h[s2]; gstream_h[s2] = G; }
+                        Fout[(c >> 2) * CS4 + 4 * f + (c & 3)] = G;
+                    }
+                }
             }
         }
         // G_l = BatchNorm backward (+ the residual stream's gradient), into the other frame
@@ -1003,7 +1128,19 @@ static inline int nf_cc_optin(K kernel) {
 }
 
 // tile of whole samples: 256 pixels for 16 x 16 (one sample), 128 for smaller maps (two 8 x 8, eight 4 x 4 ...)
-static inline int nf_cc_tile_px(int H, int W) { return H * W >= 256 ? 256 : 128; }
+static int nf_cc_capacity();
+// 16 x 16 maps split a sample over two 128-pixel tiles (halo rows handed over between the two workgroups: 2 B <= 128 workgroups on twice
+// the compute units) when the grid fits, else one 256-pixel tile per sample
+static int nf_cc_halo_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NF_CONV_HALO"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
+    return on;
+}
+static inline int nf_cc_tile_px(int64_t B, int H, int W) {
+    if (H * W < 256) return 128;
+    if (H * W == 256 && W == 16 && nf_cc_halo_on() && 2 * B <= NF_CC_MAX_BLOCKS && 2 * B <= nf_cc_capacity()) return 128;
+    return 256;
+}
 
 static int nf_cc_capacity() {
     static int cap = -1;
@@ -1021,8 +1158,8 @@ static inline size_t nf_cc_lds_bytes(const NfCvGeo& g, int OCB) { return sizeof(
 extern "C" int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W) {
     NfCvGeo g;
     if (B < 1 || I0 < 1 || I0 > NF_CV_MAX_I || O_out < 1 || O_out > NF_CV_MAX_O) return 0;
-    const int PX = nf_cc_tile_px(H, W);
-    if (H * W > PX) return 0;                           // whole samples per workgroup only
+    const int PX = nf_cc_tile_px(B, H, W);
+    if (H * W > PX && !(H * W == 256 && PX == 128)) return 0;   // whole samples per workgroup, or the two-tile split of 16 x 16
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return 0;
     if (g.tiles > NF_CC_MAX_BLOCKS || g.tiles > nf_cc_capacity()) return 0;
     if (!(B * 192 * (int64_t)H * W < (int64_t)1 << 31)) return 0;
@@ -1039,6 +1176,14 @@ static bool nf_cc_coupling_split(NfSplit& cs, int mode, int odd, int C, int I0, 
     return cs.Ch == I0 && O_out == 2 * I0 && cs.h == H && cs.w == W;
 }
 
+extern "C" int nf_convnet_chain_ws_floats(int64_t B, int I0, int O_out, int H, int W) {
+    if (!nf_convnet_chain_usable(B, I0, O_out, H, W)) return 0;
+    const int PX = nf_cc_tile_px(B, H, W);
+    int64_t slots = NF_CC_STAT_SLOTS;
+    if (H * W > PX) slots += (int64_t)NF_CC_NB * NF_CC_MAX_BLOCKS * NF_CC_HALO_SLOTS(W);
+    return (int)(2 * slots);
+}
+
 extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
                                     float bn_eps, float bn_momentum, nf_stream_t stream) {
     if (desc == nullptr || !nf_convnet_chain_usable(B, I0, O_out, H, W)) return NF_E_BADARG;
@@ -1049,8 +1194,9 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
         if (!nf_cc_coupling_split(cs, desc->cp_mode, desc->cp_odd, desc->cp_C, I0, O_out, H, W)) return NF_E_BADARG;
     }
     NfCvGeo g;
-    const int PX = nf_cc_tile_px(H, W);
+    const int PX = nf_cc_tile_px(B, H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
+    if ((training || H * W > PX) && desc->ws_zero == nullptr) return NF_E_BADARG;     // exchange slots (statistics; halo rows)
     const int OCB = (O_out + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -1083,7 +1229,7 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
         return NF_E_BADARG;
     }
     NfCvGeo g;
-    const int PX = nf_cc_tile_px(H, W);
+    const int PX = nf_cc_tile_px(B, H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     int rc;

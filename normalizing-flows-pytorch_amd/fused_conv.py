@@ -10,6 +10,7 @@ model gets its effective weight from ONE ``nf_weight_norm_fwd`` launch per pass 
 here consume effective weights and return the gradient with respect to them.
 """
 import ctypes
+import functools
 
 import torch
 
@@ -68,6 +69,11 @@ class ConvNetBwdDesc(ctypes.Structure):
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
 CONV_CHAIN_BWD_ON = __import__('os').environ.get('NF_CONV_CHAIN_BWD', '1') != '0'
 CONV_COUPLING_ON = __import__('os').environ.get('NF_CONV_COUPLING', '1') != '0'
+
+
+@functools.lru_cache(maxsize=None)
+def _chain_ws_floats(B, I0, O_out, Hh, Ww):
+    return int(N.load().nf_convnet_chain_ws_floats(B, I0, O_out, Hh, Ww))
 
 
 def _chain_usable(B, I0, O_out, Hh, Ww):
@@ -301,8 +307,10 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None):
             d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
         d.out = out.data_ptr()
         # (the slots' tensor must outlive every allocation up to the launch: a freed block is handed to the next torch.empty)
-        slots = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev) if training else None
-        d.ws_zero = slots.data_ptr() if training else None
+        nws = _chain_ws_floats(B, I0, O_out, Hh, Ww)
+        need = training or nws > N.header_constant('NF_CONVNET_WS_FLOATS')           # (halo hand-over: in evaluation mode too)
+        slots = WS.zeros(nws, dev) if need else None
+        d.ws_zero = slots.data_ptr() if need else None
         if cpl is not None:
             z, ld, a, c, mode, odd, inverse = cpl
             y = torch.empty_like(z)
@@ -433,7 +441,7 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         d.g_out = g_out.data_ptr()
         d.g_store[0], d.g_store[1] = stores[0].data_ptr(), stores[1].data_ptr()
         d.g_x = g_x.data_ptr() if g_x is not None else None
-        slots = WS.zeros(N.header_constant('NF_CONVNET_WS_FLOATS'), dev)     # (kept alive up to the launch, see the forward)
+        slots = WS.zeros(_chain_ws_floats(B, I0, O_out, Hh, Ww), dev)        # (kept alive up to the launch, see the forward)
         d.ws_zero = slots.data_ptr()
         if ctx.sinks is not None:                   # BatchNorm parameter gradients: added by the launch itself
             for j in range(nb):
