@@ -2,7 +2,7 @@
    python tools/probes/chain_prof.py --build ;  python tools/probes/chain_prof.py I O H W [B]"""
 import ctypes, importlib, os, subprocess, sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 pkg = importlib.import_module('normalizing-flows-pytorch_amd')
 N = importlib.import_module('normalizing-flows-pytorch_amd._native')
 cond = importlib.import_module('normalizing-flows-pytorch_amd.conditioners')
@@ -15,7 +15,7 @@ if '--build' in sys.argv:
     sys.exit(0)
 prof = ctypes.CDLL(lib_path)
 real = N.load()
-for name in ('nf_convnet_chain_fwd', 'nf_convnet_chain_usable'):
+for name in ('nf_convnet_chain_fwd', 'nf_convnet_chain_usable', 'nf_convnet_chain_ws_floats'):
     fn = getattr(real, name)
     pf = getattr(prof, name)
     pf.argtypes, pf.restype = fn.argtypes, fn.restype
