@@ -17,6 +17,38 @@ TOL = 1e-5
 DEV = 'cuda'
 
 
+SLACK = 4.0
+
+
+def _oracle_gradient_gaps(name):
+    """max |fp32 - float64| per parameter gradient of the oracle's own first training step on the golden's weights and batch: how far a
+    correct fp32 implementation is from exact arithmetic on this model (empty for the stochastic ResFlow estimators)"""
+    from oracle import trajectory as traj
+    kind, cls, dims, datatype, layers, mix = G.MODEL_CASES[name]
+    if kind == 'resflow':
+        return {}
+    sd0 = G.group('model_' + name, 'sd0/')
+    y = G.group('model_' + name, '')['y']
+    out = {}
+    recs = []
+    for dt in (torch.float32, torch.float64):
+        np.random.seed(0)                                  # MADE draws its masks from the global numpy stream (constant for D = 2)
+        r, _ = traj.run(kind, dims, datatype, layers, sd0, y, 1, mixtures=mix, dtype=dt)
+        recs.append(r[1]['grads'])
+    for k, g32 in recs[0].items():
+        if k in recs[1]:
+            out['net.' + k if not k.startswith('net.') else k] = float((g32.double() - recs[1][k]).abs().max())
+    return out
+
+
+def _cancelling(kind, k):
+    """MADE's FIRST masked linear sees one live input (D = 2: mask [[1, 0]] x 32), so every unit's pre-activation is affine in the same
+    scalar and the BatchNorm backward makes its gradient orthogonal to that scalar up to eps / (var + eps): the weight gradient is a sum
+    whose terms cancel to a few percent of their size.  Two correct fp32 summation orders differ by ~1e-4 of the largest entry there
+    (measured: the fp32 oracle itself sits 3.6e-6 .. 3.5e-5 from float64 depending on the host CPU's BLAS; the GPU 1.0e-4)."""
+    return kind == 'maf' and k.endswith('.weights.0')
+
+
 def _build(pkg, name):
     kind, cls, dims, datatype, layers, mix = G.MODEL_CASES[name]
     if not hasattr(pkg, cls):
@@ -42,6 +74,7 @@ def test_model_golden(pkg, name):
     loss = tf.nll_loss(z, ld)
     G.assert_close(loss, g['train/loss'], TOL * max(1.0, abs(float(g['train/loss'])) / np.prod(dims)), what='loss')
     loss.backward()
+    gaps = _oracle_gradient_gaps(name)
     n = 0
     for k, p in net.named_parameters():
         if 'grad/' + k in g:
@@ -49,10 +82,10 @@ def test_model_golden(pkg, name):
             assert p.grad is not None, k
             # pre-BatchNorm biases of MADE: analytically zero gradient, the stored value is cancellation noise
             noise = kind == 'maf' and '.biases.' in k and not k.endswith('.biases.3')
-            # MADE runs on rocBLAS + MIOpen BatchNorm (train mode: gradients flow through the batch statistics, a
-            # cancellation-heavy formula) -- 1e-4 of the largest entry for its weights, 2e-5 for everything else
+            # 2e-5 of the largest entry + SLACK x the fp32 oracle's own distance from float64 for this tensor (measured below: MADE's
+            # training-mode BatchNorm backward is cancellation-heavy, its weight gradients sit ~1e-5 relative from float64 themselves)
             scale = max(1.0, float(want.abs().max()))
-            tol = 2e-3 if noise else (1e-4 if kind == 'maf' else 2 * TOL) * scale
+            tol = 2e-3 if noise else (1e-4 * scale if _cancelling(kind, k) else 2 * TOL * scale + SLACK * gaps.get(k, 0.0))
             G.assert_close(p.grad, want, tol, what=k)
             n += 1
     assert n > 4
@@ -88,6 +121,7 @@ def test_model_golden_direct_grad_bucket(pkg, name):
     for k, p in net.named_parameters():                       # re-homing preserved the values
         assert torch.equal(p.detach(), sd0[k]), k
     net.train()
+    gaps = _oracle_gradient_gaps(name)
     for rep in range(2):                                      # twice: zeroing + accumulation semantics
         G.seed_noise(777)
         if rep == 1:
@@ -105,7 +139,7 @@ def test_model_golden_direct_grad_bucket(pkg, name):
                 want = g['grad/' + k]
                 noise = kind == 'maf' and '.biases.' in k and not k.endswith('.biases.3')
                 scale = max(1.0, float(want.abs().max()))
-                tol = 2e-3 if noise else (1e-4 if kind == 'maf' else 2 * TOL) * scale
+                tol = 2e-3 if noise else (1e-4 * scale if _cancelling(kind, k) else 2 * TOL * scale + SLACK * gaps.get(k, 0.0))
                 G.assert_close(p.grad, want, tol, what='%s (rep %d)' % (k, rep))
                 assert p.grad.data_ptr() >= bucket.flat.data_ptr()
 
@@ -261,13 +295,14 @@ def test_sync_statistics_mode_matches_goldens(pkg, name):
         loss.backward()
     G.assert_close(z, g['train/z'], TOL, what='z')
     G.assert_close(ld, g['train/ld'], TOL, rtol=2e-6, what='ld')
+    gaps = _oracle_gradient_gaps(name)
     n = 0
     for k, p in net.named_parameters():
         if 'grad/' + k in g:
             want = g['grad/' + k]
             noise = kind == 'maf' and '.biases.' in k and not k.endswith('.biases.3')
             scale = max(1.0, float(want.abs().max()))
-            tol = 2e-3 if noise else (1e-4 if kind == 'maf' else 4 * TOL) * scale   # the conditioners run as rocBLAS / MIOpen + ATen modules in this mode (their summation order): 2.6e-5 measured
+            tol = 2e-3 if noise else (1e-4 * scale if _cancelling(kind, k) else 4 * TOL * scale + SLACK * gaps.get(k, 0.0))   # the conditioners run as rocBLAS / MIOpen + ATen modules in this mode (their summation order): 2.6e-5 measured
             G.assert_close(p.grad, want, tol, what=k)
             n += 1
     assert n > 4
