@@ -479,32 +479,40 @@ class InvertibleConv1x1(nn.Module):
 
 # ---- squeeze family (flows/squeeze.py:114-189) ---------------------------------------------------------------------
 
+def _swap_halves(z):
+    h = z.shape[1] // 2
+    return torch.cat([z[:, h:], z[:, :h]], dim=1)
+
+
 class Squeeze2d(nn.Module):
+    """flows/squeeze.py:153-170: space-to-depth, channel order k = 4 c + 2 dy + dx; ``odd`` swaps the two channel halves of the result
+    (squeeze.py:94-95; no reference model builds it: one extra copy here)."""
+
     def __init__(self, odd=False):
         super().__init__()
-        if odd:
-            raise NotImplementedError('Squeeze2d(odd=True) is never built by the reference models')
-        self.odd = odd
+        self.odd = bool(odd)
 
     def forward(self, z, log_df_dz):
-        return NF.squeeze2d(z), log_df_dz
+        out = NF.squeeze2d(z)
+        return (_swap_halves(out) if self.odd else out), log_df_dz
 
     def backward(self, z, log_df_dz):
-        return NF.unsqueeze2d(z), log_df_dz
+        return NF.unsqueeze2d(_swap_halves(z) if self.odd else z), log_df_dz
 
 
 class Unsqueeze2d(nn.Module):
+    """flows/squeeze.py:173-189: the inverse map of Squeeze2d as a forward layer."""
+
     def __init__(self, odd=False):
         super().__init__()
-        if odd:
-            raise NotImplementedError('Unsqueeze2d(odd=True) is never built by the reference models')
-        self.odd = odd
+        self.odd = bool(odd)
 
     def forward(self, z, log_df_dz):
-        return NF.unsqueeze2d(z), log_df_dz
+        return NF.unsqueeze2d(_swap_halves(z) if self.odd else z), log_df_dz
 
     def backward(self, z, log_df_dz):
-        return NF.squeeze2d(z), log_df_dz
+        out = NF.squeeze2d(z)
+        return (_swap_halves(out) if self.odd else out), log_df_dz
 
 
 # ---- coupling layers (flows/coupling.py) -----------------------------------------------------------------------------
@@ -530,6 +538,33 @@ class AbstractCoupling(nn.Module):
 
     def conditioner_input(self, z):
         return NF.half_gather(z, 1, self.mode, self.odd)
+
+
+class AdditiveCoupling(AbstractCoupling):
+    """NICE additive coupling, flows/coupling.py:52-79 (no reference model builds it): z0 <- z0 + net_t(z1), log-det unchanged.
+    Runs on the affine coupling kernels with the scale pinned to zero (s = 0 * tanh(0) + 0): split + shift + merge in one launch.
+    The conditioner's widths are the reference's -- including its checkerboard width (dims[0] instead of 2 * dims[0]), which cannot run
+    on image data there either."""
+
+    def __init__(self, dims, masking='checkerboard', odd=False):
+        super().__init__(dims, masking, odd)
+        if len(dims) == 1:
+            in_chs = dims[0] // 2 if not odd else (dims[0] + 1) // 2
+            self.net_t = MLP(in_chs, dims[0] - in_chs)
+        else:
+            in_out_chs = dims[0] if masking == 'checkerboard' else dims[0] // 2
+            self.net_t = ConvNet(in_out_chs, in_out_chs)
+        self.register_buffer('_zero', torch.zeros(1), persistent=False)
+
+    def _params(self, z):
+        t = self.net_t(self.conditioner_input(z))
+        return torch.cat([t, torch.zeros_like(t)], dim=1)         # [shift | raw scale = 0]
+
+    def forward(self, z, log_df_dz):
+        return NF.affine_coupling(z, self._params(z), self._zero, self._zero, log_df_dz, self.mode, self.odd)
+
+    def backward(self, y, log_df_dz):
+        return NF.affine_coupling(y, self._params(y), self._zero, self._zero, log_df_dz, self.mode, self.odd, inverse=True)
 
 
 class AffineCoupling(AbstractCoupling):

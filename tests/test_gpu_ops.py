@@ -603,3 +603,52 @@ def test_iresblock_training_hip_matches_autograd(nf, B, D):
     assert set(gpu[3]) == set(ref[3]), (sorted(gpu[3]), sorted(ref[3]))
     for k in ref[3]:
         check('grad ' + k, gpu[3][k], ref[3][k], c32[3][k])
+
+
+@pytest.mark.parametrize('dims,masking,odd', [((6, ), 'checkerboard', False), ((6, ), 'checkerboard', True), ((12, 8, 8), 'channelwise', False),
+                                              ((12, 8, 8), 'channelwise', True)])
+def test_additive_coupling(nf, dims, masking, odd):
+    """NICE additive coupling (flows/coupling.py:52-79): z0 + net_t(z1), merged; log-det untouched; inverse; gradient of z."""
+    torch.manual_seed(4)
+    layer = nf.AdditiveCoupling(dims, masking=masking, odd=odd).to(DEV).eval()      # eval: the conditioner's BatchNorm uses constants
+    B = 16
+    z = torch.randn((B, ) + dims, device=DEV, requires_grad=True)
+    ld0 = torch.randn(B, device=DEV)
+    y, ld = layer(z, ld0.clone())
+    z0, z1 = im.split(z.detach().cpu(), layer.mode, odd)
+    with torch.no_grad():
+        t = layer.net_t(z1.to(DEV)).cpu()
+    want = im.merge(z0 + t, z1, layer.mode, odd, dims)
+    G.assert_close(y, want, TOL, what='y')
+    assert torch.equal(ld, ld0), 'additive coupling has a unit Jacobian'
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    zr = z.detach().clone().requires_grad_(True)                                    # reference gradient: the same net through torch ops
+    r0, r1 = layer.squeeze(zr)
+    yr0 = r0 + layer.net_t(r1)
+    w0, w1 = im.split(w.cpu(), layer.mode, odd)
+    ((yr0 * w0.to(DEV)).sum() + (r1 * w1.to(DEV)).sum()).backward()
+    G.assert_close(z.grad, zr.grad, _scaled(zr.grad), what='grad z')
+    with torch.no_grad():
+        x, ldi = layer.backward(y.detach(), ld.clone())
+    G.assert_close(x, z, 2 * TOL, what='round trip')
+    assert torch.equal(ldi, ld0)
+
+
+@pytest.mark.parametrize('odd', [False, True])
+def test_squeeze2d_layers_incl_odd(nf, odd):
+    """Squeeze2d / Unsqueeze2d as layers, with the half swap of ``odd`` (flows/squeeze.py:86-111, :153-189): bit-exact vs the oracle."""
+    z = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    ld = torch.zeros(2)
+    full = im.squeeze2d(z)                                       # (B, 4 C, H / 2, W / 2) in the odd = False order
+    h = full.shape[1] // 2
+    want = torch.cat([full[:, h:], full[:, :h]], dim=1) if odd else full
+    sq, un = nf.Squeeze2d(odd=odd), nf.Unsqueeze2d(odd=odd)
+    got, ld1 = sq(z.to(DEV), ld.to(DEV))
+    assert torch.equal(got.cpu(), want) and torch.equal(ld1.cpu(), ld)
+    back, _ = sq.backward(got, ld1)
+    assert torch.equal(back.cpu(), z)
+    f, _ = un(got, ld1)
+    assert torch.equal(f.cpu(), z)
+    b, _ = un.backward(z.to(DEV), ld.to(DEV))
+    assert torch.equal(b.cpu(), want)
