@@ -169,3 +169,26 @@ def test_bisection_regimes(ref_flows):
     b, ldb, iters = tf.mixlogcdf_inverse(x2.clone(), ld0.clone(), logpi, mu, s, return_iters=True)
     assert iters == 100
     assert torch.equal(a, b) and torch.allclose(lda, ldb, atol=1e-6)
+
+
+def test_product_additive_coupling_and_odd_squeeze_match_reference_construction(ref_flows, pkg):
+    """the two layers no reference MODEL builds (flows/coupling.py:52-79, Squeeze2d(odd=True)): same constructor arguments, same
+    state_dict keys / shapes and -- same seed -- bit-identical initial weights; the odd squeeze is the reference's map on the CPU side
+    of the index arithmetic (the GPU test checks the kernel against the oracle's table)."""
+    import importlib
+    rc = importlib.import_module('ref_flows.coupling')
+    sq = importlib.import_module('ref_flows.squeeze')
+    for dims, masking, odd in [((6, ), 'checkerboard', False), ((6, ), 'checkerboard', True), ((12, 8, 8), 'channelwise', False)]:
+        torch.manual_seed(9)
+        a = rc.AdditiveCoupling(dims, masking=masking, odd=odd)
+        torch.manual_seed(9)
+        b = pkg.AdditiveCoupling(dims, masking=masking, odd=odd)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+    z = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    z0, z1 = sq.squeeze2d(z, odd=True)
+    full = im.squeeze2d(z)
+    h = full.shape[1] // 2
+    assert torch.equal(torch.cat([z0, z1], 1), torch.cat([full[:, h:], full[:, :h]], 1))
