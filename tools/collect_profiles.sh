@@ -20,6 +20,7 @@ FC=$(find /tmp/pmc_f -name "fetch_counter_collection.csv" | head -1)
 WC=$(find /tmp/pmc_w -name "write_counter_collection.csv" | head -1)
 cd $GRAFT_REPO_ROOT
 NF_PMC_CONFIGS=c4,c1,c2,c3,c5 python tools/pmc_round.py --json $FC $WC $OUT/${R}_pmc.json > $OUT/pmc_json.log 2>&1
+cp $OUT/${R}_pmc.json $GRAFT_REPO_ROOT/profiles/${R}_pmc.json   # (the bench lines below read the round's PMC file from profiles/)
 python tools/kernel_sweep.py > $OUT/${R}_kernel_sweep.txt 2> $OUT/sweep.err
 for c in c1 c2 c3 c4 c5; do
   python bench.py --config $c --steps 50 --cpu-seconds 15 > $OUT/${R}_bench_$c.json 2> /dev/null
