@@ -517,13 +517,18 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     // ---- layers 0 .. 4: finish, statistics, normalise into the other frame, next 3x3 convolution ---------------------------------
     // (register budget: 128 VGPRs at sixteen waves -- the per-layer vectors live in LDS, the weight prefetch keeps values only)
     NF_CC_STAMP(1);
+    // bias, gamma, beta of a layer are loaded by threads < 32 BEFORE the K loop that precedes their use (a global load at the point of
+    // use is ~0.7 us of exposed latency on the serial chain, twice per layer)
+    float nb_ = 0.f, ng_ = 0.f, nbe_ = 0.f;
+    if (threadIdx.x < 32) { nb_ = d.b[0][threadIdx.x]; ng_ = d.gamma[0][threadIdx.x]; nbe_ = d.beta[0][threadIdx.x]; }
 #pragma unroll 1
     for (int l = 0; l < NF_CC_NB; ++l) {
         // next layer's 32 x 32 x 9 weights: loads in flight under the exchanges of this layer
         constexpr bool PREFETCH_W = OWN <= 4;           // OWN = 8 has no registers to spare: it loads at the point of use
         NfCcW wv;
         if (PREFETCH_W && l < NF_CC_NB - 1) nf_cc_w_load(wv, d.w[l + 1], 32, 0, 32, wid, lane);
-        if (threadIdx.x < 32) kb[threadIdx.x] = d.b[l][threadIdx.x];
+        const float cg_ = ng_, cbe_ = nbe_;
+        if (threadIdx.x < 32) kb[threadIdx.x] = nb_;
         __syncthreads();                                // every wave is done with Wl / Fin of this layer; kb is written
         NF_CC_STAMP(2 + 8 * l);
         nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
@@ -560,9 +565,9 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
                 const float mean = kb[k] + tot[k] * invN;                     // statistics of the pre-bias output
                 const float var = tot[32 + k] * invN;                         // biased, as BatchNorm normalises
                 const float invstd = 1.f / sqrtf(var + eps);
-                const float sc = d.gamma[l][k] * invstd;
+                const float sc = cg_ * invstd;
                 kc[k] = sc;
-                kc[32 + k] = d.beta[l][k] - mean * sc;
+                kc[32 + k] = cbe_ - mean * sc;
                 if (blockIdx.x == 0) {
                     d.save_mean[l][k] = mean;
                     d.save_invstd[l][k] = invstd;
@@ -577,9 +582,9 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             if (threadIdx.x < 32) {
                 const int k = threadIdx.x;
                 const float mean = d.rmean[l][k], invstd = 1.f / sqrtf(d.rvar[l][k] + eps);
-                const float sc = d.gamma[l][k] * invstd;
+                const float sc = cg_ * invstd;
                 kc[k] = sc;
-                kc[32 + k] = d.beta[l][k] - mean * sc;
+                kc[32 + k] = cbe_ - mean * sc;
                 if (blockIdx.x == 0) {                  // what the backward kernels normalise with (constants in this mode)
                     d.save_mean[l][k] = mean;
                     d.save_invstd[l][k] = invstd;
@@ -610,6 +615,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         }
         { float* t = Fin; Fin = Fout; Fout = t; }
         if (l < NF_CC_NB - 1) {
+            if (threadIdx.x < 32) { nb_ = d.b[l + 1][threadIdx.x]; ng_ = d.gamma[l + 1][threadIdx.x]; nbe_ = d.beta[l + 1][threadIdx.x]; }
             if (!PREFETCH_W) nf_cc_w_load(wv, d.w[l + 1], 32, 0, 32, wid, lane);
             nf_cc_w_store(wv, Wl, 32, wid, lane);
             __syncthreads();

@@ -184,7 +184,7 @@ class ConvDefer:
         groups = {}
         for e in self.layers:
             groups.setdefault(e[0], []).append(e)
-        ready = [es[:step] for es in groups.values() if len(es) >= step]
+        ready = [es[:step] for es in groups.values() if len(es) >= min(step, CONV_OFFLOAD_MIN)]
         if not ready:
             return
         main = torch.cuda.current_stream()
@@ -221,6 +221,7 @@ class ConvDefer:
 
 CONV_DEFER_ON = __import__('os').environ.get('NF_CONV_DEFER', '1') != '0'
 CONV_OVERLAP_ON = __import__('os').environ.get('NF_CONV_OVERLAP', '1') != '0'
+CONV_OFFLOAD_MIN = int(__import__('os').environ.get('NF_CONV_OFFLOAD_MIN', '16'))   # layers of one shape queued before a launch leaves
 CONV_DEFER = ConvDefer()
 
 
