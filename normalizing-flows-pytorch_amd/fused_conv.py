@@ -69,6 +69,7 @@ class ConvNetBwdDesc(ctypes.Structure):
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
 CONV_CHAIN_BWD_ON = __import__('os').environ.get('NF_CONV_CHAIN_BWD', '1') != '0'
 CONV_COUPLING_ON = __import__('os').environ.get('NF_CONV_COUPLING', '1') != '0'
+CONV_COUPLING_MIN_PX = int(__import__('os').environ.get('NF_CONV_COUPLING_MIN_PX', '0'))
 
 
 @functools.lru_cache(maxsize=None)
@@ -535,6 +536,8 @@ def coupling_fusable(net, z, mode):
     convs, _ = _convnet_modules(net)
     c0 = getattr(convs[0], 'module', convs[0])
     c5 = getattr(convs[-1], 'module', convs[-1])
+    if B * half[2] * half[3] < CONV_COUPLING_MIN_PX:       # (experiment knob: a level whose launch has very few workgroups)
+        return False
     return c0.in_channels == half[1] and c5.out_channels == 2 * half[1] and _chain_usable(B, half[1], 2 * half[1], half[2], half[3])
 
 
