@@ -407,7 +407,7 @@ __device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots,
 }
 
 // LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
-template <int NPB, int NKQ>
+template <int NPB, int NKQ, bool HALO>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      float eps, float mom, NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     const int64_t b0 = (tile * PXW) >> g.lgHW;          // first sample of the tile
     // A sample larger than the tile (16 x 16 on 128-pixel tiles) is split over HW / PXW workgroups, rows y0 .. y0 + TH - 1 each: the
     // frame's halo rows then belong to the neighbours, which hand them over layer by layer (nf_cc_halo_*, below).
-    const bool halo = g.HW > PXW;
+    constexpr bool halo = HALO;                         // compile-time: the whole-sample variants carry none of its registers
     const int y0 = halo ? (int)((tile * PXW) & (g.HW - 1)) >> g.lgW : 0;
     unsigned long long* hslots = halo ? (unsigned long long*)d.ws_zero + NF_CC_STAT_SLOTS : nullptr;
     const int px = pb * 32 + c32;
@@ -848,7 +848,7 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
     return tot;
 }
 
-template <int NPB, int NKQ>
+template <int NPB, int NKQ, bool HALO>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_bwd_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     const float invN = 1.f / (float)Npx;
     unsigned long long* slots = (unsigned long long*)d.ws_zero;
     const int64_t b0 = (tile * PXW) >> g.lgHW;
-    const bool halo = g.HW > PXW;                       // a sample split over several workgroups (see the forward kernel)
+    constexpr bool halo = HALO;                         // compile-time: the whole-sample variants carry none of its registers                       // a sample split over several workgroups (see the forward kernel)
     const int y0 = halo ? (int)((tile * PXW) & (g.HW - 1)) >> g.lgW : 0;
     unsigned long long* hslots = halo ? slots + NF_CC_STAT_SLOTS : nullptr;
     float gstream_h[2] = {0.f, 0.f};                    // halo rows of the residual stream's gradient (threads < 32 W)
@@ -1207,15 +1207,20 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (PX == 256) {
-        rc = nf_cc_optin(k_convnet_chain_fwd<8, 2>);
+        rc = nf_cc_optin(k_convnet_chain_fwd<8, 2, false>);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
+        hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
                            g, I0, O_out, training, bn_eps, bn_momentum, cs);
+    } else if (H * W > PX) {                            // a sample over several workgroups: the variant with the halo hand-over
+        rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, true>);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
+                           *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
     } else {
-        rc = nf_cc_optin(k_convnet_chain_fwd<4, 4>);
+        rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, false>);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st, *desc,
-                           g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
+                           *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
     }
     NF_CHECK_LAUNCH();
     return 0;
@@ -1240,15 +1245,20 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (PX == 256) {
-        rc = nf_cc_optin(k_convnet_chain_bwd<8, 2>);
+        rc = nf_cc_optin(k_convnet_chain_bwd<8, 2, false>);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
+        hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
                            I0, O_out, training, cs);
+    } else if (H * W > PX) {
+        rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, true>);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
+                           g, I0, O_out, training, cs);
     } else {
-        rc = nf_cc_optin(k_convnet_chain_bwd<4, 4>);
+        rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, false>);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc, g,
-                           I0, O_out, training, cs);
+        hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
+                           g, I0, O_out, training, cs);
     }
     NF_CHECK_LAUNCH();
     return 0;
