@@ -407,7 +407,7 @@ __device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots,
 }
 
 // LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
-template <int NPB, int NKQ, bool HALO>
+template <int NPB, int NKQ, bool HALO, bool CPL>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      float eps, float mom, NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fin = sm + L.FA;
     float* Fout = sm + L.FB;
-    const bool cpl = d.cp_z != nullptr;                 // the coupling rides the epilogue of the output convolution
+    constexpr bool cpl = CPL;                           // the coupling rides the epilogue of the output convolution (d.cp_z != NULL)
     if (cpl) {
         // y <- z for this workgroup's (contiguous) samples, whole 16-byte vectors, no index arithmetic; the transformed half is
         // overwritten by the epilogue at the far end of the launch (same workgroup, barriers in between).  Nothing waits for it.
@@ -848,7 +848,7 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
     return tot;
 }
 
-template <int NPB, int NKQ, bool HALO>
+template <int NPB, int NKQ, bool HALO, bool CPL>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_bwd_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
 
     // ---- the 1 x 1 output convolution, transposed: acc[ic][pixel] = sum_oc W5[oc][ic] g_out[oc][pixel].  No halo: the B operand comes
     //      straight from global memory (a lane's own pixel; 4 x 128-byte segments per K group), K = oc split over the NKQ waves ----
-    const bool cpl = d.cp_g_y != nullptr;
+    constexpr bool cpl = CPL;                           // (d.cp_g_y != NULL)
     const int Ch = O_out >> 1;
     const int lgw = cpl ? 31 - __clz(cs.w) : 0;
     const float ca = cpl ? d.cp_a[0] : 0.f;
@@ -1207,20 +1207,41 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (PX == 256) {
-        rc = nf_cc_optin(k_convnet_chain_fwd<8, 2, false>);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
-                           g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        if (desc->cp_z != nullptr) {
+            rc = nf_cc_optin(k_convnet_chain_fwd<8, 2, false, true>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
+                               g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        } else {
+            rc = nf_cc_optin(k_convnet_chain_fwd<8, 2, false, false>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
+                               g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        }
     } else if (H * W > PX) {                            // a sample over several workgroups: the variant with the halo hand-over
-        rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, true>);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
-                           *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        if (desc->cp_z != nullptr) {
+            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, true, true>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, true, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
+                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        } else {
+            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, true, false>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, true, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
+                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        }
     } else {
-        rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, false>);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
-                           *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        if (desc->cp_z != nullptr) {
+            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, false, true>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
+                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        } else {
+            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, false, false>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
+                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
+        }
     }
     NF_CHECK_LAUNCH();
     return 0;
@@ -1245,20 +1266,41 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (PX == 256) {
-        rc = nf_cc_optin(k_convnet_chain_bwd<8, 2, false>);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
-                           I0, O_out, training, cs);
+        if (desc->cp_g_y != nullptr) {
+            rc = nf_cc_optin(k_convnet_chain_bwd<8, 2, false, true>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
+                               I0, O_out, training, cs);
+        } else {
+            rc = nf_cc_optin(k_convnet_chain_bwd<8, 2, false, false>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
+                               I0, O_out, training, cs);
+        }
     } else if (H * W > PX) {
-        rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, true>);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
-                           g, I0, O_out, training, cs);
+        if (desc->cp_g_y != nullptr) {
+            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, true, true>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, true, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
+                               g, I0, O_out, training, cs);
+        } else {
+            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, true, false>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, true, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
+                               g, I0, O_out, training, cs);
+        }
     } else {
-        rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, false>);
-        if (rc) return rc;
-        hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
-                           g, I0, O_out, training, cs);
+        if (desc->cp_g_y != nullptr) {
+            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, false, true>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
+                               g, I0, O_out, training, cs);
+        } else {
+            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, false, false>);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
+                               g, I0, O_out, training, cs);
+        }
     }
     NF_CHECK_LAUNCH();
     return 0;
