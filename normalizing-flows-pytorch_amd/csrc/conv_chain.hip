@@ -54,7 +54,7 @@ extern "C" int nf_cc_prof_read(long long* out) {
 #define NF_CC_RSW(WC) (4 * (WC) + 4)
 #define NF_CC_TS(NCG, WC) ((NCG) * NF_CC_RSW(WC) + 4)
 struct NfCcLds {            // offsets in floats
-    int FA, FB, WL, RS, KC, KB, RED, TOT, total;
+    int FA, FB, WL, RS, KC, KB, RED, TOT, BNV, total;
 };
 template <int NPB, int NKQ>
 __host__ __device__ inline NfCcLds nf_cc_lds(int CS, int OCB) {
@@ -71,6 +71,10 @@ __host__ __device__ inline NfCcLds nf_cc_lds(int CS, int OCB) {
     L.RED = L.KB + 32;
     L.TOT = L.RED + 2 * NPB * 32;
     L.total = L.TOT + 64;
+    // the backward kernel keeps the saved statistics and parameters of all five BatchNorms here when the geometry leaves room (every
+    // level but 4 x 4): a global load at each layer's top is ~0.7 us of exposed latency on the serial chain
+    L.BNV = (L.total + NF_CC_NB * 128) * (int)sizeof(float) <= 160 * 1024 ? L.total : -1;
+    if (L.BNV >= 0) L.total += NF_CC_NB * 128;
     return L;
 }
 
@@ -881,6 +885,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fin = sm + L.FA;
     float* Fout = sm + L.FB;
+    const bool bnv = L.BNV >= 0;                        // block-uniform
+    if (bnv && threadIdx.x < NF_CC_NB * 128) {          // [layer][mean | invstd | gamma | beta][32]; first read after the barrier below
+        const int l2 = threadIdx.x >> 7, j = (threadIdx.x >> 5) & 3, k = threadIdx.x & 31;
+        const float* src = j == 0 ? d.save_mean[l2] : (j == 1 ? d.save_invstd[l2] : (j == 2 ? d.gamma[l2] : d.beta[l2]));
+        sm[L.BNV + threadIdx.x] = src[k];
+    }
 
     // ---- the 1 x 1 output convolution, transposed: acc[ic][pixel] = sum_oc W5[oc][ic] g_out[oc][pixel].  No halo: the B operand comes
     //      straight from global memory (a lane's own pixel; 4 x 128-byte segments per K group), K = oc split over the NKQ waves ----
@@ -962,10 +972,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
         // BatchNorm l (input of the convolution whose transpose just ran): scale / shift exactly as the forward kernel computed them
         if (threadIdx.x < 32) {
             const int k = threadIdx.x;
-            const float mean = d.save_mean[l][k], invstd = d.save_invstd[l][k];
-            const float sc = d.gamma[l][k] * invstd;
+            const float* v = sm + L.BNV + 128 * l;
+            const float mean = bnv ? v[k] : d.save_mean[l][k], invstd = bnv ? v[32 + k] : d.save_invstd[l][k];
+            const float sc = (bnv ? v[64 + k] : d.gamma[l][k]) * invstd;
             kc[k] = sc;
-            kc[32 + k] = d.beta[l][k] - mean * sc;
+            kc[32 + k] = (bnv ? v[96 + k] : d.beta[l][k]) - mean * sc;
             kc[64 + k] = mean;
             kc[96 + k] = invstd;
         }
