@@ -117,6 +117,44 @@ __device__ __forceinline__ void nf_cc_kloop(f32x16& acc, const float* W4, const 
 #undef NF_CC_MFMA
 }
 
+// The same K loop for the 32 -> 32 channel 3 x 3 layers with the frame geometry known at compile time (FW, CS: one instantiation per
+// pyramid level): every operand address is base + IMMEDIATE (the ds_read offset field), so a K group is two ds_read_b128 and four
+// MFMAs with no address arithmetic in between; the generic loop above spends a third of the K phase on it (5.4 us against the 3.8 us
+// MFMA floor of four waves per SIMD).  Straight-line, one group of operands in flight ahead of the MFMAs.
+template <int FW, int CS, int G0, int GC>
+__device__ __forceinline__ void nf_cc_kloop_fixed(f32x16& acc, const float* wbase, const float* fbase) {
+    constexpr int TS = NF_CC_TS(8, 32), RSW = NF_CC_RSW(32), CS4 = 4 * CS;
+    float4 a[2], b[2];
+#define NF_CC_OFFA(gg) (((gg) >> 2) * TS + 2 * ((gg) & 3) * RSW)
+#define NF_CC_OFFB(gg) (4 * (((((gg) >> 2) / 3) - 1) * FW + ((((gg) >> 2) % 3) - 1)) + 2 * ((gg) & 3) * CS4)
+    a[0] = *(const float4*)(wbase + NF_CC_OFFA(G0));
+    b[0] = *(const float4*)(fbase + NF_CC_OFFB(G0));
+#pragma unroll
+    for (int i = 0; i < GC; ++i) {
+        if (i + 1 < GC) {
+            a[(i + 1) & 1] = *(const float4*)(wbase + NF_CC_OFFA(G0 + i + 1));
+            b[(i + 1) & 1] = *(const float4*)(fbase + NF_CC_OFFB(G0 + i + 1));
+        }
+        const float4 A_ = a[i & 1], B_ = b[i & 1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B_.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B_.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B_.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B_.w, acc, 0, 0, 0);
+    }
+#undef NF_CC_OFFA
+#undef NF_CC_OFFB
+}
+template <int FW, int CS, int NKQ>
+__device__ __forceinline__ void nf_cc_kloop_level(f32x16& acc, const float* W4, const float* F4, int fpos, int col, int hs, int kq) {
+    constexpr int GC = 36 / NKQ;
+    const float* wbase = W4 + hs * NF_CC_RSW(32) + 4 * col;
+    const float* fbase = F4 + hs * 4 * CS + 4 * fpos;
+    if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, GC>(acc, wbase, fbase);             // wave-uniform
+    else if (kq == 1) nf_cc_kloop_fixed<FW, CS, GC, GC>(acc, wbase, fbase);
+    else if (NKQ > 2 && kq == 2) nf_cc_kloop_fixed<FW, CS, (NKQ > 2 ? 2 : 0) * GC, GC>(acc, wbase, fbase);
+    else if (NKQ > 2) nf_cc_kloop_fixed<FW, CS, (NKQ > 2 ? 3 : 0) * GC, GC>(acc, wbase, fbase);
+}
+
 // 3x3 weights of one chunk of IC (padded ICP, NCG = ICP / 4 quads) input channels, global (32, I, 3, 3) -> W4: lane entries r = ic * 9 + tap
 // (contiguous in global memory for every oc), wave w takes oc = w, w + 16
 struct NfCcW { float v[5][NF_CV_CU]; };
@@ -411,7 +449,7 @@ __device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots,
 }
 
 // LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
-template <int NPB, int NKQ, bool HALO, bool CPL>
+template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      float eps, float mom, NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -632,7 +670,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             // opaque trip count: fully unrolled, the K loop's LDS addresses become loop invariants of the LAYER loop that the
             // compiler keeps in (and spills from) VGPRs
             asm volatile("" : "+s"(gcount));
-            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);        // geometry known at compile time
+            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
             NF_CC_STAMP(8 + 8 * l);
         }
     }
@@ -852,7 +891,7 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
     return tot;
 }
 
-template <int NPB, int NKQ, bool HALO, bool CPL>
+template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_bwd_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -1087,7 +1126,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             const int g0 = (kq * ng) / NKQ;
             int gcount = ng / NKQ;
             asm volatile("" : "+s"(gcount));            // see the forward kernel
-            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);        // geometry known at compile time
+            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
         }
     }
 
@@ -1114,7 +1154,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                     gyv[rr] = (pv && ic < IC) ? d.cp_g_y[b * cs.n_full + nf_cc_half_to_full(cs, 1, i0 + ic, (int)q, lgw)] : 0.f;
                 }
             }
-            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);        // geometry known at compile time
+            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
             __syncthreads();
             nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
 #pragma unroll
@@ -1216,44 +1257,31 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
     if ((training || H * W > PX) && desc->ws_zero == nullptr) return NF_E_BADARG;     // exchange slots (statistics; halo rows)
     const int OCB = (O_out + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (PX == 256) {
-        if (desc->cp_z != nullptr) {
-            rc = nf_cc_optin(k_convnet_chain_fwd<8, 2, false, true>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
-                               g, I0, O_out, training, bn_eps, bn_momentum, cs);
-        } else {
-            rc = nf_cc_optin(k_convnet_chain_fwd<8, 2, false, false>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_fwd<8, 2, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, OCB)), st, *desc,
-                               g, I0, O_out, training, bn_eps, bn_momentum, cs);
-        }
-    } else if (H * W > PX) {                            // a sample over several workgroups: the variant with the halo hand-over
-        if (desc->cp_z != nullptr) {
-            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, true, true>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, true, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
-                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
-        } else {
-            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, true, false>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, true, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
-                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
-        }
-    } else {
-        if (desc->cp_z != nullptr) {
-            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, false, true>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
-                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
-        } else {
-            rc = nf_cc_optin(k_convnet_chain_fwd<4, 4, false, false>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_fwd<4, 4, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, OCB)), st,
-                               *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);
-        }
-    }
+    int rc = 0;
+    const bool cp = desc->cp_z != nullptr;
+#define NF_CC_FWD(NPB_, NKQ_, HALO_, CP_, FW_, CS_)                                                                                         \
+    do {                                                                                                                                    \
+        rc = nf_cc_optin(k_convnet_chain_fwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>);                                                            \
+        if (rc == 0)                                                                                                                        \
+            hipLaunchKernelGGL((k_convnet_chain_fwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS),       \
+                               (nf_cc_lds_bytes<NPB_, NKQ_>(g, OCB)), st, *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);          \
+    } while (0)
+#define NF_CC_FWD2(NPB_, NKQ_, HALO_, FW_, CS_)                                                                                             \
+    do {                                                                                                                                    \
+        if (cp) NF_CC_FWD(NPB_, NKQ_, HALO_, true, FW_, CS_);                                                                               \
+        else NF_CC_FWD(NPB_, NKQ_, HALO_, false, FW_, CS_);                                                                                 \
+    } while (0)
+    // one instantiation per level of the CIFAR pyramid (frame width / channel stride as compile-time constants), a generic one for the rest
+    if (PX == 256) NF_CC_FWD2(8, 2, false, 0, 0);
+    else if (H * W > PX) {                              // a sample over several workgroups: the variant with the halo hand-over
+        if (g.FW == 18 && g.CS == 181) NF_CC_FWD2(4, 4, true, 18, 181);
+        else NF_CC_FWD2(4, 4, true, 0, 0);
+    } else if (g.FW == 10 && g.CS == 201) NF_CC_FWD2(4, 4, false, 10, 201);
+    else if (g.FW == 6 && g.CS == 289) NF_CC_FWD2(4, 4, false, 6, 289);
+    else NF_CC_FWD2(4, 4, false, 0, 0);
+#undef NF_CC_FWD2
+#undef NF_CC_FWD
+    if (rc) return rc;
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -1275,44 +1303,30 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
     const int PX = nf_cc_tile_px(B, H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (PX == 256) {
-        if (desc->cp_g_y != nullptr) {
-            rc = nf_cc_optin(k_convnet_chain_bwd<8, 2, false, true>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
-                               I0, O_out, training, cs);
-        } else {
-            rc = nf_cc_optin(k_convnet_chain_bwd<8, 2, false, false>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_bwd<8, 2, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<8, 2>(g, 1)), st, *desc, g,
-                               I0, O_out, training, cs);
-        }
-    } else if (H * W > PX) {
-        if (desc->cp_g_y != nullptr) {
-            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, true, true>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, true, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
-                               g, I0, O_out, training, cs);
-        } else {
-            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, true, false>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, true, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
-                               g, I0, O_out, training, cs);
-        }
-    } else {
-        if (desc->cp_g_y != nullptr) {
-            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, false, true>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, false, true>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
-                               g, I0, O_out, training, cs);
-        } else {
-            rc = nf_cc_optin(k_convnet_chain_bwd<4, 4, false, false>);
-            if (rc) return rc;
-            hipLaunchKernelGGL((k_convnet_chain_bwd<4, 4, false, false>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS), (nf_cc_lds_bytes<4, 4>(g, 1)), st, *desc,
-                               g, I0, O_out, training, cs);
-        }
-    }
+    int rc = 0;
+    const bool cp = desc->cp_g_y != nullptr;
+#define NF_CC_BWD(NPB_, NKQ_, HALO_, CP_, FW_, CS_)                                                                                         \
+    do {                                                                                                                                    \
+        rc = nf_cc_optin(k_convnet_chain_bwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>);                                                            \
+        if (rc == 0)                                                                                                                        \
+            hipLaunchKernelGGL((k_convnet_chain_bwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS),       \
+                               (nf_cc_lds_bytes<NPB_, NKQ_>(g, 1)), st, *desc, g, I0, O_out, training, cs);                                 \
+    } while (0)
+#define NF_CC_BWD2(NPB_, NKQ_, HALO_, FW_, CS_)                                                                                             \
+    do {                                                                                                                                    \
+        if (cp) NF_CC_BWD(NPB_, NKQ_, HALO_, true, FW_, CS_);                                                                               \
+        else NF_CC_BWD(NPB_, NKQ_, HALO_, false, FW_, CS_);                                                                                 \
+    } while (0)
+    if (PX == 256) NF_CC_BWD2(8, 2, false, 0, 0);
+    else if (H * W > PX) {
+        if (g.FW == 18 && g.CS == 181) NF_CC_BWD2(4, 4, true, 18, 181);
+        else NF_CC_BWD2(4, 4, true, 0, 0);
+    } else if (g.FW == 10 && g.CS == 201) NF_CC_BWD2(4, 4, false, 10, 201);
+    else if (g.FW == 6 && g.CS == 289) NF_CC_BWD2(4, 4, false, 6, 289);
+    else NF_CC_BWD2(4, 4, false, 0, 0);
+#undef NF_CC_BWD2
+#undef NF_CC_BWD
+    if (rc) return rc;
     NF_CHECK_LAUNCH();
     return 0;
 }
