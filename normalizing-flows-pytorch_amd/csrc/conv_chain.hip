@@ -552,7 +552,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             const int lgg = ICP == 32 ? 2 : 1;          // groups of 8 channels per tap
             const int ng = 9 << lgg;
             const int g0 = (kq * ng) / NKQ, g1 = ((kq + 1) * ng) / NKQ;
-            nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(ICP >> 2, 32), NF_CC_RSW(32), CS4, g.FW, lgg, fpos, c32, hs, g0, g1 - g0);
+            if (FWc > 0 && ICP == 32) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);   // (block-uniform)
+            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(ICP >> 2, 32), NF_CC_RSW(32), CS4, g.FW, lgg, fpos, c32, hs, g0, g1 - g0);
         }
     }
 
