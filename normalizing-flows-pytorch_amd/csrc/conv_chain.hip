@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     float* kc = sm + L.KC;
     float* kb = sm + L.KB;
     float* red = sm + L.RED;
-    const int CS4 = 4 * g.CS;
+    const int CS4 = FWc > 0 ? 4 * CSc : 4 * g.CS;       // (a literal in the per-level instantiations)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
     const int pb = wid % NPB, kq = wid / NPB;
     const int64_t Npx = g.B * g.HW;
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     float* RS = sm + L.RS;
     float* kc = sm + L.KC;
     float* red = sm + L.RED;
-    const int CS4 = 4 * g.CS;
+    const int CS4 = FWc > 0 ? 4 * CSc : 4 * g.CS;       // (a literal in the per-level instantiations)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
     const int pb = wid % NPB, kq = wid / NPB;
     const int64_t Npx = g.B * g.HW;
