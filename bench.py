@@ -440,7 +440,7 @@ def dominant_kernel_roofline(pkg, cfg, B, dev):
             bytes_alg = 4 * (M * 32 * (5 + 5 + 2) + 2 * M * O + 3 * z.numel())
             wgs = int((M + (127 if split else 255)) // (128 if split else 256))
             return {'bound': 'mfma', 'kernel': 'k_convnet_chain_bwd<%s> (data gradient of the whole ConvNet conditioner + coupling backward in '
-                                               'one persistent launch: %d -> 32 x 5 -> %d channels, %d x %d)' % ('4, 4, true, true' if split else '8, 2, false, true', I0, O, Hh, Ww),
+                                               'one persistent launch: %d -> 32 x 5 -> %d channels, %d x %d)' % ('4, 4, true, true, 18, 181' if split and Ww == 16 else ('4, 4, true, true, 0, 0' if split else '8, 2, false, true, 0, 0'), I0, O, Hh, Ww),
                     'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_TFLOPS, 5),
                     'traffic': pmc_traffic('k_convnet_chain_bwd', B), 'flop_per_launch': int(flop), 'bytes_per_launch': int(bytes_alg),
                     'us_per_launch': round(us, 3), 'workgroups': wgs,
