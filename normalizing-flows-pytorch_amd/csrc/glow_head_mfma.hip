@@ -35,22 +35,50 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
                                                               float* __restrict__ z1c, float* __restrict__ ld, NfSplit s, int64_t B,
                                                               int C, int P) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    float a[RT][KQ], ab[KQ], ad[KQ];
+    // log-det first: its loads (and the read-modify-write of ld) travel under the matrix work instead of after it
+    {
+        float sl = lane < C ? log_s[lane] - als[lane] : 0.f;     // C <= 64: one value per lane, wave sum
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-        const int c = 4 * q + lk;
-        ab[q] = c < C ? abias[c] : 0.f;
-        ad[q] = c < C ? expf(als[c]) : 1.f;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int r = 16 * rt + li;
-            a[rt][q] = (r < C && c < C) ? M[r * C + c] : 0.f;
-        }
+        for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, NF_WAVE);
+        const float dl = (float)P * sl;
+        const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += dl;
     }
+    // W through LDS: read from memory row by row (coalesced), fragments from LDS -- a lane's fragment elements M[16 rt + li][4 q + lk]
+    // sit C floats apart across lanes: gathered straight from memory that was 64 cache lines per load instruction, 36 instructions
+    // per wave, ~10 of the kernel's 14 us at C = 48
+    __shared__ float Ws[64 * 65];
     const int64_t nblk = B * (P / 16);                       // 16-pixel blocks (P % 16 == 0: never straddle samples)
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int bpp = P / 16;
+    // everything a wave needs from memory is requested up front -- the first block's pixels, the ActNorm vectors, W -- so that the
+    // launch is ONE memory round trip deep (at the BASELINE sizes a wave has one block: loads issued where they are used made it four)
+    float xv[KQ], ab[KQ], ad[KQ];
+    {
+        const int64_t blk = wave < nblk ? wave : 0, b = blk / bpp;
+        const float* xb = x + b * C * P + (int)(blk - b * bpp) * 16 + li;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            xv[q] = c < C ? xb[(int64_t)c * P] : 0.f;
+            ab[q] = c < C ? abias[c] : 0.f;
+            ad[q] = c < C ? als[c] : 0.f;
+        }
+    }
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) Ws[(e / C) * 65 + (e - (e / C) * C)] = M[e];
+    __syncthreads();
+    float a[RT][KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        const int c = 4 * q + lk;
+        ad[q] = expf(ad[q]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = 16 * rt + li;
+            a[rt][q] = (r < C && c < C) ? Ws[r * 65 + c] : 0.f;
+        }
+    }
     for (int64_t blk = wave; blk < nblk; blk += nwaves) {
         const int64_t b = blk / bpp;
         const int p = (int)(blk - b * bpp) * 16 + li;
@@ -63,7 +91,8 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {                       // B[k = lk][j = li] = ActNorm(x)[c = 4q + lk][pixel]
             const int c = 4 * q + lk;
-            bv[q] = c < C ? (xb[(int64_t)c * P] - ab[q]) / ad[q] : 0.f;
+            const float xq = blk == wave ? xv[q] : (c < C ? xb[(int64_t)c * P] : 0.f);
+            bv[q] = c < C ? (xq - ab[q]) / ad[q] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
@@ -84,12 +113,6 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
                 }
             }
     }
-    float sl = lane < C ? log_s[lane] - als[lane] : 0.f;     // C <= 64: one value per lane, wave sum (a serial loop of scalar loads was 10 us)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, NF_WAVE);
-    const float dl = (float)P * sl;
-    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += dl;
 }
 
 #define NF_GH_TP 128  // pixels per staged tile
