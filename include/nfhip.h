@@ -526,6 +526,10 @@ int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int O, int H,
 #define NF_CONV_WGRAD_MAX 16
 int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int O, int H, int W, int ksize,
                            nf_stream_t stream);
+/* Slabs per layer of an nf_conv_bn_wgrad_multi launch of n_layers layers -- g_weff of each descriptor holds THIS many slabs (not
+ * nf_conv_bwd_slabs): one workgroup per compute unit over the whole launch, each keeping its tap tiles in registers over
+ * tiles / slabs tiles.                                                                                                     */
+int nf_conv_wgrad_slabs(int64_t B, int H, int W, int n_layers);
 
 /* dst[e] (+)= sum_{s < n_slabs} src[s * stride + e], e < n: every slab / replica sum of one conditioner backward in ONE
  * launch (weight-gradient slabs, bias and BatchNorm-parameter replicas).                                                */

@@ -93,6 +93,11 @@ def _bwd(shape, I, O, k, **kw):
     N.call('nf_conv_bn_bwd', ctypes.addressof(d), B, I, O, Hh, Ww, k, N.stream())
 
 
+@functools.lru_cache(maxsize=None)
+def _wgrad_slabs(B, Hh, Ww, n_layers):
+    return int(N.load().nf_conv_wgrad_slabs(B, Hh, Ww, n_layers))
+
+
 def _slab_sum(jobs):
     arr = (SlabSumDesc * len(jobs))()
     for i, (src, dst, n, stride, n_slabs, acc, taps) in enumerate(jobs):
@@ -158,27 +163,32 @@ class ConvDefer:
             (B, Hh, Ww), I, O, k = key
             for k0 in range(0, len(es), step):
                 chunk = es[k0:k0 + step]
-                per = [e[3] * e[2].numel() for e in chunk]
+                slabs = _wgrad_slabs(B, Hh, Ww, len(chunk))       # (per launch: one workgroup per compute unit over all its layers)
+                per = [slabs * e[2].numel() for e in chunk]
                 dev = chunk[0][2].device
                 scratch = self._slab_scratch(sum(per), dev)
                 arr = (ConvBwdDesc * len(chunk))()
                 jobs, off = [], 0
                 for i, e in enumerate(chunk):
-                    _, kw, g_w, n_slabs = e[:4]
+                    _, kw, g_w = e[:3]
                     region = scratch[off:off + per[i]]
                     off += per[i]
                     d = _desc(ConvBwdDesc, g_weff=region, **kw)
                     ctypes.memmove(ctypes.addressof(arr) + i * ctypes.sizeof(ConvBwdDesc), ctypes.addressof(d), ctypes.sizeof(ConvBwdDesc))
-                    jobs.append((region, g_w, g_w.numel(), g_w.numel(), n_slabs, False, k * k))
+                    jobs.append((region, g_w, g_w.numel(), g_w.numel(), slabs, False, k * k))
                     if len(e) > 4 and e[4] is not None:      # the layer's bias sums (filled by this very launch) ride the same slab sum
                         jobs.append(e[4])
                 N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
                 _slab_sum_all(jobs)                  # before the next chunk overwrites the scratch (stream order)
 
     def offload(self):
-        """Overlap: as soon as sixteen queued layers share a shape, their weight-gradient launch goes to a side stream, behind
-        everything the main stream has issued so far.  The data-gradient chain that continues on the main stream occupies 8 .. 64
-        of the 256 compute units; the bulk launches fill the rest instead of queueing up behind the last layer.  Joined in flush."""
+        """Overlap (NF_CONV_OVERLAP=1; OFF by default since the round-2 measurement below): as soon as sixteen queued layers share
+        a shape, their weight-gradient launch goes to a side stream, behind everything the main stream has issued so far, joined in
+        flush.  The idea -- the data-gradient chain occupies 8 .. 128 of the 256 compute units, the bulk launches fill the rest --
+        does not survive the hardware's placement: a chain workgroup needs a WHOLE compute unit (1024 threads, > 80 KB of LDS, every
+        VGPR), so each chain launch waits until the weight-gradient workgroups that took its compute units have retired, and the
+        persistent chain pays that wait on its latency chain 161 times per backward.  Glow CIFAR-shape, B = 64, one box: no weight
+        gradients at all 30.5 ms / step; side stream 34.5 - 34.8; everything behind the last data gradient (this flag off) 34.0."""
         if not (CONV_OVERLAP_ON and self.active and self.layers):
             return
         step = N.header_constant('NF_CONV_WGRAD_MAX')
@@ -194,7 +204,8 @@ class ConvDefer:
         if side is None:
             side = self.side[dev] = torch.cuda.Stream(device=dev)
         for chunk in ready:                         # (the slab scratch is grown on the main stream, never inside the side context)
-            self._slab_scratch(sum(e[3] * e[2].numel() for e in chunk), dev)
+            (B, Hh, Ww) = chunk[0][0][0]
+            self._slab_scratch(_wgrad_slabs(B, Hh, Ww, len(chunk)) * sum(e[2].numel() for e in chunk), dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             for chunk in ready:
@@ -221,7 +232,7 @@ class ConvDefer:
 
 
 CONV_DEFER_ON = __import__('os').environ.get('NF_CONV_DEFER', '1') != '0'
-CONV_OVERLAP_ON = __import__('os').environ.get('NF_CONV_OVERLAP', '1') != '0'
+CONV_OVERLAP_ON = __import__('os').environ.get('NF_CONV_OVERLAP', '0') != '0'
 CONV_OFFLOAD_MIN = int(__import__('os').environ.get('NF_CONV_OFFLOAD_MIN', '16'))   # layers of one shape queued before a launch leaves
 CONV_DEFER = ConvDefer()
 

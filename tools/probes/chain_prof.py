@@ -46,3 +46,6 @@ prof.nf_cc_arrive_read(arr)
 G = (B * H * W + (255 if H * W >= 256 else 127)) // (256 if H * W >= 256 else 128)
 a = [arr[i] / 100.0 for i in range(G)]
 print('  arrival of the workgroups at the poll of layer 1, us after the first: ' + ' '.join('%.1f' % (v - min(a)) for v in a))
+if I > 32:
+    print('  chunk 1 of conv0: weights requested, barrier %.1f | weights to LDS %.1f | frame loads + stores %.1f | barrier %.1f | K loop %.1f   (chunk 0 began %.1f us before)'
+          % (t[53] - t[52], t[54] - t[53], t[55] - t[54], t[60] - t[55], t[61] - t[60], t[52] - t[0]))

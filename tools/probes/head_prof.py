@@ -1,0 +1,35 @@
+"""phase stamps of workgroup 0 of k_glow_head_w_fwd (csrc/glow_head_mfma.hip built with -DNF_GH_PROF=1 into build/):
+   python tools/probes/head_prof.py --build ; python tools/probes/head_prof.py C H [B]"""
+import ctypes, importlib, os, subprocess, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+pkg = importlib.import_module('normalizing-flows-pytorch_amd')
+N = importlib.import_module('normalizing-flows-pytorch_amd._native')
+here = os.path.dirname(os.path.abspath(pkg.__file__))
+lib_path = os.path.join(here, 'build', 'libghprof.so')
+if '--build' in sys.argv:
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-DNF_GH_PROF=1',
+                           '-shared', '-o', lib_path, os.path.join(here, 'csrc', 'glow_head_mfma.hip')])
+    print('built', lib_path)
+    sys.exit(0)
+prof = ctypes.CDLL(lib_path)
+real = N.load()
+fn = real.nf_glow_head_w_fwd
+pf = prof.nf_glow_head_w_fwd
+pf.argtypes, pf.restype = fn.argtypes, fn.restype
+C, H = int(sys.argv[1]), int(sys.argv[2])
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+x = torch.randn(B, C, H, H, device='cuda')
+W = torch.linalg.qr(torch.randn(C, C))[0].cuda().contiguous()
+ls, bs, lsv = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+h, z1c, ld = torch.empty_like(x), torch.empty(B, C // 2, H, H, device='cuda'), torch.zeros(B, device='cuda')
+for _ in range(3):
+    rc = pf(x.data_ptr(), ls.data_ptr(), bs.data_ptr(), W.data_ptr(), lsv.data_ptr(), h.data_ptr(), z1c.data_ptr(), ld.data_ptr(), 2, 0, B, C, H, H,
+            N.stream())
+    assert rc == 0, rc
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 16)()
+prof.nf_gh_prof_read(buf)
+t = [v / 100.0 for v in buf]
+print('C %d  %d x %d  B %d: log-det %.1f | loads issued %.1f | W staged + barrier %.1f | fragments, exp %.1f | block: loads waited, divide, MFMA %.1f | stores issued %.1f   total %.1f us'
+      % (C, H, H, B, 0.0, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]))

@@ -28,3 +28,43 @@ for n, t in per.most_common(22):
 print('-- idle time charged to the kernel that follows it')
 for n, t in gaps.most_common(12):
     print('%9.1f us %5d x %7.2f  %s' % (t, cnt[n], t / cnt[n], n[-90:]))
+# the step's serial spine is its chain launches: what sits in front of the first, between them, and behind the last
+ch = [(s, e, n) for s, e, n in st if 'convnet_chain' in n]
+if ch:
+    print('-- chain launches: %d, %.1f us; before the first %.1f us, after the last %.1f us' % (
+        len(ch), sum(e - s for s, e, _ in ch) / 1e3, (ch[0][0] - st[0][0]) / 1e3, (max(e[1] for e in st) - ch[-1][1]) / 1e3))
+    between = collections.Counter(); bt = 0.0
+    for (s0, e0, _), (s1, e1, _) in zip(ch[:-1], ch[1:]):
+        bt += (s1 - e0) / 1e3
+    print('   between consecutive chain launches %.1f us in total (heads, glue; the side stream runs under all of it)' % bt)
+    tail = [(s, e, n) for s, e, n in st if s >= ch[-1][1]]
+    for s, e, n in tail[:40]:
+        print('   tail +%7.1f us  %7.1f us  %s' % ((s - ch[-1][1]) / 1e3, (e - s) / 1e3, n[-70:]))
+    # one typical interval per (kind of chain launch): everything that starts between two consecutive launches of the same kernel
+    q = {(int(r['Start_Timestamp']), r['Kernel_Name'].split('(')[0]): r.get('Queue_Id', '?') for r in rows}
+    shown = set()
+    for i in range(len(ch) // 2 - 40, len(ch) - 1):
+        (s0, e0, n0), (s1, e1, n1) = ch[i], ch[i + 1]
+        if n0 != n1 or n0 in shown or i < 3 or ch[i - 1][2] != n0:
+            continue
+        shown.add(n0)
+        print('-- %s: launch %.1f us, then %.1f us to the next' % (n0[-60:], (e0 - s0) / 1e3, (s1 - e0) / 1e3))
+        for s, e, n in st:
+            if s0 < s < s1:
+                print('      +%6.1f .. %6.1f us  q%s  %s' % ((s - e0) / 1e3, (e - e0) / 1e3, q.get((s, n), '?'), n[-70:]))
+    for i in range(3, len(ch) // 2 - 1):
+        (s0, e0, n0), (s1, e1, n1) = ch[i], ch[i + 1]
+        if n0 != n1 or n0 in shown or ch[i - 1][2] != n0:
+            continue
+        shown.add(n0)
+        print('-- %s: launch %.1f us, then %.1f us to the next' % (n0[-60:], (e0 - s0) / 1e3, (s1 - e0) / 1e3))
+        for s, e, n in st:
+            if s0 < s < s1:
+                print('      +%6.1f .. %6.1f us  q%s  %s' % ((s - e0) / 1e3, (e - e0) / 1e3, q.get((s, n), '?'), n[-70:]))
+    big = sorted(range(len(ch) - 1), key=lambda i: ch[i][1] - ch[i + 1][0])[:6]
+    for i in sorted(big):
+        (s0, e0, n0), (s1, e1, n1) = ch[i], ch[i + 1]
+        print('== interval %d: %.1f us between %s and %s' % (i, (s1 - e0) / 1e3, n0[-42:], n1[-42:]))
+        for s, e, n in st:
+            if s0 < s < s1:
+                print('      +%6.1f .. %6.1f us  q%s  %s' % ((s - e0) / 1e3, (e - e0) / 1e3, q.get((s, n), '?'), n[-80:]))
