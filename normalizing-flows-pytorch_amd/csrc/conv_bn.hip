@@ -779,10 +779,12 @@ __device__ __forceinline__ float nf_cv_uniform(float v) { return __int_as_float(
 __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, const NfCvGeo& g, int I, int O, int iters) {
     constexpr int T = 9;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Al = smem;
-    float* Gl = Al + 32 * g.CS;
-    float* cb = Gl + 32 * g.CS;                        // [5][32]
-    float* kc = cb + 5 * 32;                           // [4][32]
+    // two (activation, G) frame pairs: pair it & 1 is walked while pair (it + 1) & 1 is filled -- ONE barrier per tile, and no barrier
+    // between a wave's transforms and its walk: half of a SIMD's waves walk first and fill afterwards, so that their VALU work
+    // runs under the other half's MFMAs (phase-aligned behind two barriers per tile the walk was 6.5 of a tile's 10.4 us)
+    const int FP = 64 * g.CS;                          // floats per pair: Al [32][CS] | Gl [32][CS]
+    float* cb = smem + 2 * FP;                         // [5][32]
+    float* kc = cb + 5 * 32;                           // [2][32]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
     const bool has_bn = d.bn_gamma != nullptr;
     const bool has_src = d.gn_src != nullptr;
@@ -853,13 +855,10 @@ __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, con
         const int c = wid + u * NF_CV_WAVES;
         xsc[u] = nf_cv_uniform(kc[c]); xsh[u] = nf_cv_uniform(kc[32 + c]);
     }
-    for (int it = 0; it < iters; ++it) {
-        if (it == 1) NF_CV_STAMP(15);
-        if (it == 2) NF_CV_STAMP(14);
-        const int64_t tile = (int64_t)it * gridDim.x + blockIdx.x;
-        if (tile >= g.tiles) break;                    // block-uniform
-        __syncthreads();                               // the previous tile's walks (the constants' readers) are done with the frames
-        if (it == 1) NF_CV_STAMP(10);
+    // G of the owned pixels and the activation frame of the tile in flight -> frame pair pr
+    auto fill = [&](int pr) {
+        float* Alp = smem + pr * FP;
+        float* Glp = Alp + 32 * g.CS;
         const bool pv = (tl.okm >> 31) != 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -872,7 +871,7 @@ __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, con
                     v += c1[k] * (tl.w3[k] - cmg[k] - xh * cmgx[k]);
                 }
             }
-            Gl[c * g.CS + gfpos] = v;
+            Glp[c * g.CS + gfpos] = v;
         }
         const int ICP = (min(32, I) + 15) & ~15;
 #pragma unroll
@@ -886,25 +885,42 @@ __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, con
                         float x = tl.xa[jj][u];
                         if (!((tl.okm >> (2 * jj + u)) & 1u)) x = 0.f;         // outside the image / beyond the layer's channels
                         else if (has_bn) x = fmaxf(fmaf(x, xsc[u], xsh[u]), 0.f);
-                        Al[c * g.CS + f] = x;
+                        Alp[c * g.CS + f] = x;
                     }
                 }
             }
         }
-        if (it == 1) NF_CV_STAMP(11);
-        __syncthreads();
-        if (it == 1) NF_CV_STAMP(12);
-        {                                              // the next tile's batch flies under this tile's walk
-            const int64_t nt = tile + gridDim.x;
-            if (it + 1 < iters && nt < g.tiles) nf_cv_wg_issue(tl, inv, d, g, I, O, nt, gp, gq, wid);
-        }
-        if (it == 1) NF_CV_STAMP(9);
+    };
+    auto walk = [&](int pr) {
+        const float* Alp = smem + pr * FP;
+        const float* Glp = Alp + 32 * g.CS;
         for (int un = 0; un < nA; ++un) {
-            if (tA == 0) nf_cv_wg_unit<true>(accA, gbw, Gl, Al, g, aoff, boffA, sA + un, hs);
-            else nf_cv_wg_unit<false>(accA, gbw, Gl, Al, g, aoff, boffA, sA + un, hs);
+            if (tA == 0) nf_cv_wg_unit<true>(accA, gbw, Glp, Alp, g, aoff, boffA, sA + un, hs);
+            else nf_cv_wg_unit<false>(accA, gbw, Glp, Alp, g, aoff, boffA, sA + un, hs);
         }
-        for (int un = 0; un < nB; ++un) nf_cv_wg_unit<false>(accB, gbw, Gl, Al, g, aoff, boffB, un, hs);
-        if (it == 1) NF_CV_STAMP(13);
+        for (int un = 0; un < nB; ++un) nf_cv_wg_unit<false>(accB, gbw, Glp, Alp, g, aoff, boffB, un, hs);
+    };
+    const int64_t tile0 = blockIdx.x, tstep = gridDim.x;
+    fill(0);
+    if (1 < iters && tile0 + tstep < g.tiles) nf_cv_wg_issue(tl, inv, d, g, I, O, tile0 + tstep, gp, gq, wid);
+    const bool fill_first = ((wid >> 2) & 1) == 0;     // two of a SIMD's four waves (wave w sits on SIMD w & 3)
+    for (int it = 0; it < iters; ++it) {
+        if (it == 1) NF_CV_STAMP(15);
+        if (it == 2) NF_CV_STAMP(14);
+        const int64_t tile = (int64_t)it * tstep + tile0;
+        if (tile >= g.tiles) break;                    // block-uniform
+        __syncthreads();                               // pair it & 1 is complete; the walks of the other pair are done
+        const bool next = it + 1 < iters && tile + tstep < g.tiles;              // its batch is in flight
+        const bool next2 = it + 2 < iters && tile + 2 * tstep < g.tiles;
+        if (fill_first) {
+            if (next) fill((it + 1) & 1);
+            if (next2) nf_cv_wg_issue(tl, inv, d, g, I, O, tile + 2 * tstep, gp, gq, wid);
+            walk(it & 1);
+        } else {
+            walk(it & 1);
+            if (next) fill((it + 1) & 1);
+            if (next2) nf_cv_wg_issue(tl, inv, d, g, I, O, tile + 2 * tstep, gp, gq, wid);
+        }
     }
     // ---- the partial tiles meet: red[tap][oc][ic] over the frames, pieces in fixed order ----
     float* red = smem;                                 // 9 x 1024 floats <= 64 CS (host-checked)
@@ -1048,13 +1064,16 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
     hipStream_t st = (hipStream_t)stream;
     int rc;
     // the lean body addresses with 32-bit byte offsets (3x3, one input chunk: every hidden layer)
-    const bool lean = T == 9 && ICB == 1 && B * (int64_t)(I > O ? I : O) * H * W < ((int64_t)1 << 30) && 64 * g.CS >= 9 * 1024;
+    const size_t lds_lean = sizeof(float) * ((size_t)2 * 64 * g.CS + 5 * 32 + 2 * 32);       // two frame pairs
+    const bool lean = T == 9 && ICB == 1 && B * (int64_t)(I > O ? I : O) * H * W < ((int64_t)1 << 30) && 64 * g.CS >= 9 * 1024 &&
+                      lds_lean <= 160 * 1024;
 #define NF_LAUNCH(T_, IB_, OB_, LEAN_)                                                                                 \
     do {                                                                                                               \
-        rc = nf_cv_optin(k_conv_bn_wgrad_multi<T_, IB_, OB_, LEAN_>, lds);                                             \
+        const size_t lds_ = LEAN_ ? lds_lean : lds;                                                                    \
+        rc = nf_cv_optin(k_conv_bn_wgrad_multi<T_, IB_, OB_, LEAN_>, lds_);                                            \
         if (rc) return rc;                                                                                             \
-        hipLaunchKernelGGL((k_conv_bn_wgrad_multi<T_, IB_, OB_, LEAN_>), dim3(grid, (unsigned)n), dim3(NF_CV_THREADS), lds, st, m, g, \
-                           I, O, iters);                                                                               \
+        hipLaunchKernelGGL((k_conv_bn_wgrad_multi<T_, IB_, OB_, LEAN_>), dim3(grid, (unsigned)n), dim3(NF_CV_THREADS), lds_, st, m, \
+                           g, I, O, iters);                                                                            \
     } while (0)
     if (T == 9) {
         if (ICB == 1 && lean) NF_LAUNCH(9, 1, 1, true);

@@ -38,8 +38,11 @@ if ch:
         bt += (s1 - e0) / 1e3
     print('   between consecutive chain launches %.1f us in total (heads, glue; the side stream runs under all of it)' % bt)
     tail = [(s, e, n) for s, e, n in st if s >= ch[-1][1]]
-    for s, e, n in tail[:40]:
-        print('   tail +%7.1f us  %7.1f us  %s' % ((s - ch[-1][1]) / 1e3, (e - s) / 1e3, n[-70:]))
+    agg, cnt2 = collections.Counter(), collections.Counter()
+    for s, e, n in tail:
+        agg[n] += (e - s) / 1e3; cnt2[n] += 1
+    for n, t in agg.most_common(16):
+        print('   tail %8.1f us %4d x %7.2f  %s' % (t, cnt2[n], t / cnt2[n], n[-80:]))
     # one typical interval per (kind of chain launch): everything that starts between two consecutive launches of the same kernel
     q = {(int(r['Start_Timestamp']), r['Kernel_Name'].split('(')[0]): r.get('Queue_Id', '?') for r in rows}
     shown = set()
