@@ -652,3 +652,37 @@ def test_squeeze2d_layers_incl_odd(nf, odd):
     assert torch.equal(f.cpu(), z)
     b, _ = un.backward(z.to(DEV), ld.to(DEV))
     assert torch.equal(b.cpu(), want)
+
+
+def test_weight_norm_multi_ragged_shapes(nf):
+    """nf_weight_norm_fwd / _bwd (csrc/weight_norm.hip: 32 columns x 8 row groups per workgroup) on layers whose rows / columns are not
+    multiples of the tile, 70 layers in one call (two launches of <= 64), against w = v g / (||v||_dim0 + eps) (flows/weight_norm.py:35-41)
+    and its autograd in float64; the accumulate form (gradient sinks) through a second backward."""
+    fused = importlib.import_module(nf.__name__ + '.fused')
+    torch.manual_seed(3)
+    shapes = [(32, 32, 3, 3), (12, 32, 1, 1), (32, 3, 3, 3), (192, 32, 1, 1), (32, 96, 3, 3), (5, 7), (1, 33), (33, 1), (9, 40, 3, 3), (64, 2)]
+    shapes = shapes * 7
+    eps = 1e-5
+    vs = [torch.randn(*s, device=DEV, requires_grad=True) for s in shapes]
+    gs = [torch.rand(*((1, ) + s[1:]), device=DEV) + 0.5 for s in shapes]
+    for g in gs:
+        g.requires_grad_(True)
+    tensors = []
+    for v, g in zip(vs, gs):
+        tensors += [v, g]
+    outs = fused._WeightNormMulti.apply(eps, *tensors)
+    cot = [torch.randn_like(o) for o in outs]
+    grads = torch.autograd.grad(outs, tensors, cot)
+    for k, s in enumerate(shapes):
+        v64, g64 = vs[k].detach().double().requires_grad_(True), gs[k].detach().double().requires_grad_(True)
+        w64 = v64 * g64 / (torch.sqrt((v64 * v64).sum(0, keepdim=True)) + eps)
+        gv64, gg64 = torch.autograd.grad(w64, (v64, g64), cot[k].double())
+        # the same formula through torch in fp32: its distance from fp64 is the yard-stick (one-row layers differentiate to
+        # g_w g eps / den^2 by cancellation: no fp32 evaluation of the formula is within 1e-5 absolute there)
+        v32, g32 = vs[k].detach().clone().requires_grad_(True), gs[k].detach().clone().requires_grad_(True)
+        w32 = v32 * g32 / (torch.sqrt((v32 * v32).sum(0, keepdim=True)) + eps)
+        gv32, gg32 = torch.autograd.grad(w32, (v32, g32), cot[k])
+        for got, want, ref32 in ((outs[k], w64.detach(), w32), (grads[2 * k], gv64, gv32), (grads[2 * k + 1], gg64, gg32)):
+            assert got.shape == want.shape, (s, got.shape, want.shape)
+            bar = TOL * max(1.0, float(want.abs().max())) + SLACK * _gap(ref32, want)
+            assert float((got.detach().double() - want).abs().max()) <= bar, s
