@@ -776,8 +776,11 @@ __device__ __forceinline__ void nf_cv_wg_unit(f32x16& acc, float& gsum, const fl
     }
 }
 __device__ __forceinline__ float nf_cv_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// T = 9: the 3x3 hidden layers.  T = 1: a 1x1 layer of <= 32 output channels (the output convolution of the 16 x 16 and 8 x 8 levels):
+// one tile, sixteen units, one per wave -- sixteen pieces meet at the end.
+template <int T>
 __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, const NfCvGeo& g, int I, int O, int iters) {
-    constexpr int T = 9;
+    static_assert(T == 9 || T == 1, "taps");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // two (activation, G) frame pairs: pair it & 1 is walked while pair (it + 1) & 1 is filled -- ONE barrier per tile, and no barrier
     // between a wave's transforms and its walk: half of a SIMD's waves walk first and fill afterwards, so that their VALU work
@@ -814,11 +817,11 @@ __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, con
         }
     }
     // the wave's nine units 9 wid .. 9 wid + 8 of (tap = unit >> 4, pixel group = unit & 15): nA of them in tap tA, the rest in tA + 1
-    const int u0 = 9 * wid, tA = u0 >> 4, sA = u0 & 15;
-    const int nA = min(9, 16 - sA), nB = 9 - nA;
-    const int dyA = tA / 3 - 1, dxA = tA - (tA / 3) * 3 - 1;
-    const int tB = tA + 1 < T ? tA + 1 : tA;           // (wave 15 ends on the last unit of tap 8: nB = 0)
-    const int dyB = tB / 3 - 1, dxB = tB - (tB / 3) * 3 - 1;
+    const int u0 = T * wid, tA = u0 >> 4, sA = u0 & 15;
+    const int nA = min(T, 16 - sA), nB = T - nA;
+    const int dyA = T == 9 ? tA / 3 - 1 : 0, dxA = T == 9 ? tA - (tA / 3) * 3 - 1 : 0;
+    const int tB = tA + 1 < T ? tA + 1 : tA;           // (wave 15 ends on the last unit of the last tap: nB = 0)
+    const int dyB = T == 9 ? tB / 3 - 1 : 0, dxB = T == 9 ? tB - (tB / 3) * 3 - 1 : 0;
     const int aoff = c32 * g.CS;
     const int boffA = c32 * g.CS + dyA * g.FW + dxA, boffB = c32 * g.CS + dyB * g.FW + dxB;
     f32x16 accA, accB;
@@ -924,9 +927,10 @@ __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, con
     }
     // ---- the partial tiles meet: red[tap][oc][ic] over the frames, pieces in fixed order ----
     float* red = smem;                                 // 9 x 1024 floats <= 64 CS (host-checked)
-    const int pieceA = wid - (16 * tA) / 9, pieceB = wid - (16 * tB) / 9;     // waves before this one that walk the same tap
+    const int pieceA = wid - (16 * tA) / T, pieceB = wid - (16 * tB) / T;     // waves before this one that walk the same tap
+    constexpr int NPASS = T == 9 ? 3 : 16;
 #pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         __syncthreads();                               // (first: the last walk is done with the frames)
         if (pieceA == pass) {
 #pragma unroll
@@ -961,7 +965,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
 }
 template <int T, int ICB, int OCB, bool LEAN>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_wgrad_multi(NfCvBwdMulti m, NfCvGeo g, int I, int O, int iters) {
-    if constexpr (LEAN) nf_cv_wgrad3_body(m.d[blockIdx.y], g, I, O, iters);
+    if constexpr (LEAN) nf_cv_wgrad3_body<T>(m.d[blockIdx.y], g, I, O, iters);
     else nf_cv_bwd_body<T, ICB, OCB, 2>(m.d[blockIdx.y], g, I, O, iters);
 }
 
@@ -1065,7 +1069,7 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
     int rc;
     // the lean body addresses with 32-bit byte offsets (3x3, one input chunk: every hidden layer)
     const size_t lds_lean = sizeof(float) * ((size_t)2 * 64 * g.CS + 5 * 32 + 2 * 32);       // two frame pairs
-    const bool lean = T == 9 && ICB == 1 && B * (int64_t)(I > O ? I : O) * H * W < ((int64_t)1 << 30) && 64 * g.CS >= 9 * 1024 &&
+    const bool lean = ICB == 1 && OCB == 1 && B * (int64_t)(I > O ? I : O) * H * W < ((int64_t)1 << 30) && 64 * g.CS >= T * 1024 &&
                       lds_lean <= 160 * 1024;
 #define NF_LAUNCH(T_, IB_, OB_, LEAN_)                                                                                 \
     do {                                                                                                               \
@@ -1082,7 +1086,10 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
         else NF_LAUNCH(9, 3, 1, false);
     } else {
         switch (OCB) {
-            case 1: NF_LAUNCH(1, 1, 1, false); break;
+            case 1:
+                if (lean) NF_LAUNCH(1, 1, 1, true);
+                else NF_LAUNCH(1, 1, 1, false);
+                break;
             case 2: NF_LAUNCH(1, 1, 2, false); break;
             case 3: NF_LAUNCH(1, 1, 3, false); break;
             case 4: NF_LAUNCH(1, 1, 4, false); break;
