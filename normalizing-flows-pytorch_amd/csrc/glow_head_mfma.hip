@@ -12,6 +12,14 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef NF_GH_PROF     // phase stamps of workgroup 0 (tools/probes/head_prof.py builds this file with -DNF_GH_PROF=1; 100 MHz wall clock)
+__device__ long long nf_gh_prof[16];
+extern "C" int nf_gh_prof_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_gh_prof), sizeof(long long) * 16); }
+#define NF_GH_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) nf_gh_prof[i] = wall_clock64(); } while (0)
+#else
+#define NF_GH_STAMP(i)
+#endif
+
 // which half (0 = transformed, 1 = the conditioner's input) full-tensor element (c, y, x) belongs to and its offset inside the half
 __device__ __forceinline__ void nf_gh_full_to_half(const NfSplit& s, int c, int p, int y, int x, int& which, int& e) {
     if (s.mode == NF_SPLIT_CHANNEL) {
@@ -124,6 +132,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
                                                               float* __restrict__ gM, int64_t B, int C, int P,
                                                               int64_t tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    NF_GH_STAMP(8);
     const int RS = NF_GH_TP + 1;
     const int CP = RT * 16;
     float* gT = lds;                       // [CP][RS]  g_h
@@ -174,6 +183,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
         }
     };
     fetch(tile0);
+    NF_GH_STAMP(9);
     for (int64_t tile = tile0; tile < tile0 + tiles_per_block; ++tile) {
         const int64_t t0 = tile * NF_GH_TP;
         if (t0 >= npix) break;
@@ -186,6 +196,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
             aT[c * RS + sq] = (sq < np && c < C) ? (rx[k] - cst[c]) / cst[CP + c] : 0.f;
         }
         __syncthreads();
+        NF_GH_STAMP(10);
         fetch(tile + 1);
         // ---- g_W: this wave's quarter of the tile, pixels [32 wid, 32 wid + 32), 8 k-steps of 4 pixels ----
 #pragma unroll
@@ -203,6 +214,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
                 for (int j = 0; j < RT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
+        NF_GH_STAMP(11);
         // ---- g_a = W^T g_h for the same 32 pixels (two blocks of 16), g_x, and the ActNorm sums ----
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -234,6 +246,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
             }
         }
     }
+    NF_GH_STAMP(12);
     // ---- cross-wave reductions through LDS, then one atomic per entry per block ----
     __syncthreads();
     float* red = lds;                      // [4][CP][CP]  (CP*CP*4 <= 2*CP*RS for CP <= 64)
@@ -252,6 +265,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
         atomicAdd(gM + e, t);
     }
     __syncthreads();
+    NF_GH_STAMP(13);
     // per-channel sums: over the 16 pixel lanes by shuffles, over the four waves through LDS
     float* rs = lds;                       // [2][4][CP]
 #pragma unroll
@@ -285,6 +299,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
         atomicAdd(g_ls + c, -R2 - (float)P * SG);        // modules.py:246-249 differentiated
         atomicAdd(g_b + c, -R1 / cst[CP + c]);
     }
+    NF_GH_STAMP(14);
 }
 
 static inline bool nf_gh_shape_ok(int64_t B, int C, int H, int W) {
