@@ -81,6 +81,4 @@ if os.environ.get('NF_WGRAD_PROF') == '1':      # phase stamps of workgroup 0, s
     buf = (ctypes.c_longlong * 32)()
     prof.nf_cv_prof_read(buf)
     t = [v / 100.0 for v in buf]
-    print('   tile 1 of workgroup 0: first tile + launch %.1f | barrier %.1f | transforms, LDS stores %.1f | barrier %.1f | next tile: loads issued %.1f | MFMA walk %.1f | loop %.1f'
-          % (t[15] - t[8], t[10] - t[15], t[11] - t[10], t[12] - t[11], t[9] - t[12], t[13] - t[9], t[14] - t[13]))
-
+    print('   workgroup 0: launch, constants, first tile (fill + walk) %.1f us | second tile, barrier to barrier %.1f us' % (t[15] - t[8], t[14] - t[15]))
