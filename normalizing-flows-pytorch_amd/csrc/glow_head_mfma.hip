@@ -123,8 +123,9 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
     }
 }
 
-#define NF_GH_TP 128  // pixels per staged tile
-template <int RT, int KQ>
+// TP = pixels per staged tile: 128, or 64 where 128 would leave fewer than 64 workgroups (the 8 x 8 level at B = 64: 32 -> 64 workgroups,
+// each wave 16 pixels instead of 32 -- the launch is a latency chain, a wave's part of it halves)
+template <int RT, int KQ, int TP>
 __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __restrict__ gh, const float* __restrict__ gld,
                                                               const float* __restrict__ x, const float* __restrict__ als,
                                                               const float* __restrict__ abias, const float* __restrict__ M,
@@ -133,11 +134,13 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
                                                               int64_t tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     NF_GH_STAMP(8);
-    const int RS = NF_GH_TP + 1;
+    constexpr int PW = TP / 4;            // pixels per wave
+    const int RS = TP + 1;
     const int CP = RT * 16;
     float* gT = lds;                       // [CP][RS]  g_h
     float* aT = lds + (size_t)CP * RS;     // [CP][RS]  ActNorm(x)
-    float* cst = aT + (size_t)CP * RS;     // [2][CP]   bias, exp(log_scale)
+    float* cst = lds + (size_t)2 * CP * 129;   // [2][CP]   bias, exp(log_scale): behind the 128-pixel layout for either tile (the
+                                           // reductions at the end alias [0, 4 CP CP) of the buffer and still read it)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
     const int64_t npix = B * P;
     for (int c = threadIdx.x; c < CP; c += blockDim.x) {
@@ -165,18 +168,19 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
         for (int j = 0; j < 4; ++j) s1[i][j] = s2[i][j] = 0.f;
     // Staging: a thread owns ONE pixel column of the tile (256 threads = 128 pixels x 2 channel phases); the loads of tile i + 1 are
     // issued into registers before the MFMAs of tile i.
-    constexpr int NCH = RT * 16 / (NF_BLOCK / NF_GH_TP);   // channel rows per thread
-    const int sq = threadIdx.x & (NF_GH_TP - 1), ph = threadIdx.x >> 7;
+    constexpr int NPH = NF_BLOCK / TP;     // channel phases
+    constexpr int NCH = RT * 16 / NPH;     // channel rows per thread
+    const int sq = threadIdx.x & (TP - 1), ph = threadIdx.x / TP;
     float rg[NCH], rx[NCH];
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_block;
     auto fetch = [&](int64_t tile) {
-        const int64_t t = tile * NF_GH_TP + sq;
+        const int64_t t = tile * TP + sq;
         const bool ok = tile < tile0 + tiles_per_block && t < npix;
         const int64_t b = ok ? t / P : 0;
         const int64_t base = b * C * P + (ok ? t - b * P : 0);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            const int c = ph + 2 * k;
+            const int c = ph + NPH * k;
             const bool in = ok && c < C;
             rg[k] = in ? gh[base + (int64_t)c * P] : 0.f;
             rx[k] = in ? x[base + (int64_t)c * P] : 0.f;
@@ -185,23 +189,23 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
     fetch(tile0);
     NF_GH_STAMP(9);
     for (int64_t tile = tile0; tile < tile0 + tiles_per_block; ++tile) {
-        const int64_t t0 = tile * NF_GH_TP;
+        const int64_t t0 = tile * TP;
         if (t0 >= npix) break;
-        const int np = (int)min((int64_t)NF_GH_TP, npix - t0);
+        const int np = (int)min((int64_t)TP, npix - t0);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            const int c = ph + 2 * k;
+            const int c = ph + NPH * k;
             gT[c * RS + sq] = rg[k];
             aT[c * RS + sq] = (sq < np && c < C) ? (rx[k] - cst[c]) / cst[CP + c] : 0.f;
         }
         __syncthreads();
         NF_GH_STAMP(10);
         fetch(tile + 1);
-        // ---- g_W: this wave's quarter of the tile, pixels [32 wid, 32 wid + 32), 8 k-steps of 4 pixels ----
+        // ---- g_W: this wave's quarter of the tile, pixels [PW wid, PW wid + PW), k-steps of 4 pixels ----
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int pix = 32 * wid + 4 * ks + lk;
+        for (int ks = 0; ks < PW / 4; ++ks) {
+            const int pix = PW * wid + 4 * ks + lk;
             float av[RT], bv[RT];
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
@@ -217,8 +221,8 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
         NF_GH_STAMP(11);
         // ---- g_a = W^T g_h for the same 32 pixels (two blocks of 16), g_x, and the ActNorm sums ----
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int pix = 32 * wid + 16 * half + li;
+        for (int half = 0; half < PW / 16; ++half) {
+            const int pix = PW * wid + 16 * half + li;
             f32x4 ga[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) ga[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -351,16 +355,21 @@ extern "C" int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const flo
     const int P = H * W;
     const int rt = (C + 15) / 16, kq = (C + 3) / 4;
     const int64_t npix = B * P;
-    const int64_t tiles = (npix + NF_GH_TP - 1) / NF_GH_TP;
+    const int TP = (npix + 127) / 128 < 64 ? 64 : 128;
+    const int64_t tiles = (npix + TP - 1) / TP;
     int64_t blocks = tiles < 512 ? tiles : 512;              // ends in C * C + 2 C same-address atomics per block
     const int64_t tpb = (tiles + blocks - 1) / blocks;
     blocks = (tiles + tpb - 1) / tpb;
-    const size_t lds = ((size_t)2 * rt * 16 * (NF_GH_TP + 1) + 2 * rt * 16) * sizeof(float);
+    const size_t lds = ((size_t)2 * rt * 16 * (128 + 1) + 2 * rt * 16) * sizeof(float);   // (sized for either tile; the reductions alias it)
     hipStream_t st = (hipStream_t)stream;
 #define NF_CASE(RT, KQ)                                                                                                         \
     if (rt == RT && kq == KQ) {                                                                                                 \
-        hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ>), dim3((unsigned)blocks), dim3(NF_BLOCK), lds, st, g_h, g_ld, x,          \
-                           act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, tpb);                           \
+        if (TP == 64)                                                                                                           \
+            hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ, 64>), dim3((unsigned)blocks), dim3(NF_BLOCK), lds, st, g_h, g_ld, x,  \
+                               act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, tpb);                       \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ, 128>), dim3((unsigned)blocks), dim3(NF_BLOCK), lds, st, g_h, g_ld, x, \
+                               act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, tpb);                       \
         NF_CHECK_LAUNCH();                                                                                                      \
         return 0;                                                                                                               \
     }
