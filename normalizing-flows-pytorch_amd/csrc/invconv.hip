@@ -210,14 +210,15 @@ __device__ __forceinline__ void nf_plu_weight_bwd_body(float* sm, float* scratch
                                                        int accumulate, int C, int64_t B, float pixels) {
     float& sum_gld = *sum_gld_p;
     float* Lp = sm;
-    float* Up = sm + C * C;
+    float* UpT = sm + C * C;                                     // U' TRANSPOSED: the product below walks U' rows with the lane
+                                                                 // index as the ROW -- a stride of C floats (C = 48: two banks)
     float* A = sm + 2 * C * C;                                   // P^T g_W
     float* Ps = sm + 3 * C * C;                                  // P and g_W staged: no global load inside the k loops
     float* Gs = sm + 4 * C * C;
     for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
         const int r = e / C, c = e - r * C;
         Lp[e] = L[e] * Lmask[e] + (r == c ? 1.f : 0.f);
-        Up[e] = U[e] * Umask[e] + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
+        UpT[c * C + r] = U[e] * Umask[e] + (r == c ? sign_s[r] * expf(log_s[r]) : 0.f);
         Ps[e] = Pm[e];
         Gs[e] = gW[e];
     }
@@ -238,7 +239,7 @@ __device__ __forceinline__ void nf_plu_weight_bwd_body(float* sm, float* scratch
         const int r = e / C, c = e - r * C;
         float gl = 0.f, gu = 0.f;
         for (int k = 0; k < C; ++k) {
-            gl = fmaf(A[r * C + k], Up[c * C + k], gl);          // (A U'^T)[r][c]
+            gl = fmaf(A[r * C + k], UpT[k * C + c], gl);         // (A U'^T)[r][c]
             gu = fmaf(Lp[k * C + r], A[k * C + c], gu);          // (L'^T A)[r][c]
         }
         gL[e] = (accumulate ? gL[e] : 0.f) + gl * Lmask[e];
