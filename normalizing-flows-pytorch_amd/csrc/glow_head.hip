@@ -118,7 +118,6 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
                                                              const float* __restrict__ Wsaved, float* __restrict__ gz,
                                                              float* __restrict__ g_ls, float* __restrict__ g_bias,
                                                              float* __restrict__ gW, float* __restrict__ sum_gld, NfSplit s, int64_t B, int P) {
-    __shared__ float scratch[NF_GH_BIG / NF_WAVE];
     float Wm[CT][CT], es[CT], bb[CT];
 #pragma unroll
     for (int r = 0; r < CT; ++r)
@@ -166,20 +165,43 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
     }
     float sg = 0.f;                                  // this block's share of sum_b g_ld
     for (int64_t b = gtid; b < B; b += gstride) sg += gld[b];
-    const float SG = nf_block_sum(sg, scratch);
-    if (threadIdx.x == 0 && sum_gld != nullptr) atomicAdd(sum_gld, SG);
+    // the block's 1 + CT (2 + CT) sums in ONE pass: wave sums by shuffles, the sixteen wave partials of every value side by side in
+    // LDS, one barrier, thread i finishes value i (one nf_block_sum per value was 2 barriers each: 32 in a row at CT = 3, ~8 of the
+    // launch's 19 us); partials are added in wave order, as nf_block_sum does
+    constexpr int NV = 1 + CT * (2 + CT);
+    constexpr int NWV = NF_GH_BIG / NF_WAVE;
+    __shared__ float part[NWV][NV + 1];
+    const int lane = threadIdx.x & (NF_WAVE - 1), wid = threadIdx.x >> 6;
+    {
+        float v = nf_wave_sum(sg);
+        if (lane == 0) part[wid][0] = v;
 #pragma unroll
-    for (int r = 0; r < CT; ++r) {
-        const float tb = nf_block_sum(aB[r], scratch);
-        const float tl = nf_block_sum(aL[r], scratch);
-        if (threadIdx.x == 0) {
-            atomicAdd(g_bias + r, tb);
-            atomicAdd(g_ls + r, tl - (float)P * SG);
+        for (int r = 0; r < CT; ++r) {
+            const int i0 = 1 + r * (2 + CT);
+            v = nf_wave_sum(aB[r]);
+            if (lane == 0) part[wid][i0] = v;
+            v = nf_wave_sum(aL[r]);
+            if (lane == 0) part[wid][i0 + 1] = v;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                v = nf_wave_sum(aW[r][c]);
+                if (lane == 0) part[wid][i0 + 2 + c] = v;
+            }
         }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const float tw = nf_block_sum(aW[r][c], scratch);
-            if (threadIdx.x == 0) atomicAdd(gW + r * CT + c, tw);
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int i = threadIdx.x;
+        const int nw = (blockDim.x + NF_WAVE - 1) >> 6;
+        float t = 0.f, SG = 0.f;
+        for (int w = 0; w < nw; ++w) { t += part[w][i]; SG += part[w][0]; }
+        if (i == 0) {
+            if (sum_gld != nullptr) atomicAdd(sum_gld, SG);
+        } else {
+            const int r = (i - 1) / (2 + CT), k = (i - 1) - r * (2 + CT);
+            if (k == 0) atomicAdd(g_bias + r, t);
+            else if (k == 1) atomicAdd(g_ls + r, t - (float)P * SG);
+            else atomicAdd(gW + r * CT + (k - 2), t);
         }
     }
 }
