@@ -544,9 +544,15 @@ class _GlowHead(torch.autograd.Function):
         N.call('nf_glow_head_bwd', N.ptr(g_h), N.ptr(g_z1c), N.ptr(g_ld), N.ptr(z), N.ptr(log_scale), N.ptr(bias),
                N.ptr(Wm), N.ptr(g_z), N.ptr(g_ls), N.ptr(g_b), N.ptr(g_W), N.ptr(sum_gld), mode, odd, B, C, H, W,
                N.stream())
-        N.call('nf_invconv_weight_bwd', N.ptr(g_W), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask),
-               N.ptr(sign_s), N.ptr(log_s), N.ptr(sum_gld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_logs), int(direct), C, 1,
-               H * W, N.stream())
+        from .fused_conv import CONV_DEFER
+        if direct and CONV_DEFER.active:
+            # inside a trainer step the PLU backward (8 us per layer on the backward pass's latency chain, nothing but Adam waits for
+            # it) joins the end-of-pass flush: all queued layers in one nf_invconv_weight_bwd_multi launch per 24
+            CONV_DEFER.plu_jobs.append((g_W, P, L, U, L_mask, U_mask, sign_s, log_s, sum_gld, g_L, g_U, g_logs, C, H * W))
+        else:
+            N.call('nf_invconv_weight_bwd', N.ptr(g_W), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask), N.ptr(U_mask),
+                   N.ptr(sign_s), N.ptr(log_s), N.ptr(sum_gld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_logs), int(direct), C, 1,
+                   H * W, N.stream())
         if direct:
             return (g_z, g_ld) + (None, ) * 11
         return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None

@@ -130,11 +130,13 @@ class ConvDefer:
         self.side = {}          # device -> the stream the overlapped weight-gradient launches run on
         self.forked = False
         self.keep = []          # operands of launches in flight on the side stream (alive until the join)
+        self.plu_jobs = []      # PLU weight backward of the C <= 4 heads (functional._GlowHead): batched at the flush
 
     def begin(self):
         self.layers, self.sums = [], []
         self.active, self.armed = CONV_DEFER_ON, False
         self.forked, self.keep = False, []
+        self.plu_jobs = []
 
     def arm(self, weights):
         """fused.weight_norm_all: these effective weights' gradients are consumed by a backward that flushes first"""
@@ -225,6 +227,14 @@ class ConvDefer:
             side = self.side[main.device]
             main.wait_stream(side)
         del keep
+        plu, self.plu_jobs = self.plu_jobs, []
+        if plu:
+            from .fused import PluDesc, _plu_launch
+            from .fused import _desc as _fdesc
+            _plu_launch('nf_invconv_weight_bwd_multi',
+                        [_fdesc(PluDesc, g_W=gW, P=P, L=L, U=U, L_mask=Lm, U_mask=Um, sign_s=sg, log_s=ls, g_ld=sgld, g_L=gL, g_U=gU,
+                                g_log_s=gls, B=1, C=C, accumulate=1, pixels=float(px))
+                         for gW, P, L, U, Lm, Um, sg, ls, sgld, gL, gU, gls, C, px in plu])
         if not layers and not sums:
             return
         self.launch_layers(layers)
