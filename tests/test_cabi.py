@@ -132,3 +132,23 @@ def test_convnet_descriptor_layouts_match_header(pkg):
             else:
                 got.append((n, 0, ty is ctypes.c_void_p))
         assert got == want, (struct, [g for g, w in zip(got, want) if g != w], len(got), len(want))
+
+
+def test_conv_wgrad_slabs_host_logic(pkg):
+    """nf_conv_wgrad_slabs (host only): one workgroup per compute unit over a launch -- 256 / layers slabs per layer, never more than the
+    layer's 128-pixel tiles or the 128-slab cap; 0 for an empty problem."""
+    import ctypes
+    lib = pkg._native.load()
+    f = lib.nf_conv_wgrad_slabs
+    f.argtypes, f.restype = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int], ctypes.c_int
+    import os
+    if os.environ.get('NF_CONV_WGRAD_SLABS'):
+        import pytest
+        pytest.skip('NF_CONV_WGRAD_SLABS overrides the rule')
+    assert f(64, 16, 16, 16) == 16          # 128 tiles, 16 layers
+    assert f(64, 8, 8, 16) == 16            # 32 tiles
+    assert f(64, 4, 4, 16) == 8             # 8 tiles in all
+    assert f(64, 16, 16, 4) == 64
+    assert f(64, 16, 16, 1) == 128          # the cap of nf_conv_bwd_slabs
+    assert f(512, 32, 32, 16) == 16
+    assert f(0, 16, 16, 16) == 0 and f(64, 16, 16, 0) == 0
