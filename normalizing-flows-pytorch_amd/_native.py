@@ -91,9 +91,7 @@ def load():
                 raise NativeLibraryError('libnfhip.so does not export %s (stale build?)' % name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
-        _lib = lib
-        if torch.cuda.is_available():
-            _error_word()                 # arm the sticky error word of the persistent kernels
+        _lib = lib               # no HIP runtime call here: the sticky error word is armed per DEVICE, lazily (_arm_device)
     return _lib
 
 
@@ -125,18 +123,28 @@ class PersistentKernelTimeout(NativeLibraryError):
 
 
 _err_word = None      # ctypes view of the pinned host word the kernels set when a spin loop gives up (nf_persistent_config)
+_armed = set()        # device ordinals whose copies of the spin limit / error-word pointer have been written
 
 
-def _error_word():
+def _arm_device():
+    """nf_persistent_config writes device globals (hipMemcpyToSymbol): they exist once per DEVICE, so every device a kernel is
+    launched on is armed when the first launch on it happens -- not at load(), which under torchrun runs before
+    torch.cuda.set_device(local_rank) and would arm (and open a context on) GPU 0 from every rank."""
     global _err_word
-    if _err_word is None:
-        if not torch.cuda.is_available():
-            return None
+    dev = torch.cuda.current_device()
+    if dev not in _armed:
         p = ctypes.c_void_p()
         rc = load().nf_persistent_config(int(os.environ.get('NF_SPIN_LIMIT', 1 << 22)), 0, ctypes.byref(p))
         if rc != 0:
-            raise NativeLibraryError('nf_persistent_config failed with code %d' % rc)
-        _err_word = ctypes.c_uint.from_address(p.value)
+            raise NativeLibraryError('nf_persistent_config failed with code %d on device %d' % (rc, dev))
+        _err_word = ctypes.c_uint.from_address(p.value)     # ONE pinned, portable host word shared by all devices
+        _armed.add(dev)
+
+
+def _error_word():
+    if not torch.cuda.is_available():
+        return None
+    _arm_device()
     return _err_word
 
 
@@ -160,6 +168,7 @@ def persistent_reset(spin_limit=None):
     if rc != 0:
         raise NativeLibraryError('nf_persistent_config failed with code %d' % rc)
     _err_word = ctypes.c_uint.from_address(p.value)
+    _armed.add(torch.cuda.current_device())
 
 
 @functools.lru_cache(maxsize=None)
@@ -183,8 +192,44 @@ def maf_max_rows():
                min(header_constant('NF_MAF_MAX_BLOCKS'), persistent_capacity()[1]) * header_constant('NF_MAF_ROWS_PER_BLOCK'))
 
 
+_timing = None        # measurement hook (bench.py): {'name': entry point, 'match': f(args) -> bool, 'events': [(start, stop)]}
+
+
+class timed_launches:
+    """context: every call of the C-ABI entry point ``name`` whose arguments satisfy ``match`` is bracketed by two HIP events
+    recorded on the launch stream (the current torch stream = the stream handed to the launcher), so that a real train step can
+    report the duration of its dominant kernel AS THE STEP LAUNCHES IT.  ``mean_us()`` after a synchronise."""
+
+    def __init__(self, name, match=None):
+        self.rec = {'name': name, 'match': match, 'events': []}
+
+    def __enter__(self):
+        global _timing
+        self._old, _timing = _timing, self.rec
+        return self
+
+    def __exit__(self, *exc):
+        global _timing
+        _timing = self._old
+        return False
+
+    def durations_us(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) * 1e3 for a, b in self.rec['events']]
+
+
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    if torch.cuda.current_device() not in _armed:
+        _arm_device()
+    t = _timing
+    if t is not None and t['name'] == name and (t['match'] is None or t['match'](args)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(load(), name)(*args)
+        b.record()
+        t['events'].append((a, b))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise NativeLibraryError('%s failed with code %d' % (name, rc))
     w = _err_word

@@ -24,7 +24,8 @@ __device__ __forceinline__ NfPhilox nf_philox(unsigned c0, unsigned c1, unsigned
     o.c[0] = c0; o.c[1] = c1; o.c[2] = c2; o.c[3] = c3;
     return o;
 }
-__device__ __forceinline__ float nf_u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f); }   // (0, 1)
+// (0, 1): 23 random bits + a half -- (float)(x >> 9) + 0.5f is exact for every x (no round-up to 1.0 at the top of the range)
+__device__ __forceinline__ float nf_u01(unsigned x) { return ((float)(x >> 9) + 0.5f) * (1.f / 8388608.f); }
 __device__ __forceinline__ void nf_box_muller(unsigned a, unsigned b, float& n0, float& n1) {
     const float r = sqrtf(-2.f * logf(nf_u01(a))), t = 6.283185307179586f * nf_u01(b);
     n0 = r * cosf(t);
@@ -60,7 +61,8 @@ __global__ void __launch_bounds__(NF_BLOCK) k_sample_data(int kind, float* __res
         } else {
             const bool outer = i < n_out;                 // the host version shuffles the points; a batch is exchangeable either way
             const int64_t m = outer ? n_out : n_in;
-            const int64_t k = (int64_t)(nf_u01(r.c[2]) * (float)m);
+            int64_t k = (int64_t)(nf_u01(r.c[2]) * (float)m);
+            k = k < m ? k : m - 1;                        // the product can round up to m for m beyond 2^23
             if (kind == 0) {                              // linspace(0, pi, m)
                 const float t = m > 1 ? 3.141592653589793f * (float)k / (float)(m - 1) : 0.f;
                 const float px = outer ? cosf(t) : 1.f - cosf(t), py = outer ? sinf(t) : 1.f - sinf(t) - 0.5f;

@@ -64,9 +64,13 @@ class DeviceSampler:
     """A stream of synthetic batches generated ON the GPU: ``next()`` fills (and returns) one static tensor with a fresh batch.
     The step counter lives in device memory and the draw is a pure function of (seed, step, sample index), so the two launches
     can be captured into a hipGraph (FlowTrainer(sampler=...)): every replay trains on a new batch without any host-to-device
-    copy -- the reference copies each batch from the host (main.py:79)."""
+    copy -- the reference copies each batch from the host (main.py:79).
 
-    def __init__(self, name, batch, dims, seed=0, device='cuda'):
+    ``rank``: under data parallelism every replica must draw a DIFFERENT shard of the global batch; the rank (default: the
+    process group's, 0 without one) is folded into the Philox key, so W replicas built with the same seed see W distinct
+    streams and the effective global batch is B * W."""
+
+    def __init__(self, name, batch, dims, seed=0, device='cuda', rank=None):
         import torch as _t
         from . import _native as N
         self._N = N
@@ -79,7 +83,11 @@ class DeviceSampler:
         if self.kind != 3 and per != 2:
             raise ValueError('%s is a 2-D data set' % name)
         self.per = per
-        self.seed = int(seed)
+        if rank is None:
+            import torch.distributed as _d
+            rank = _d.get_rank() if _d.is_available() and _d.is_initialized() else 0
+        self.rank = int(rank)
+        self.seed = (int(seed) ^ (self.rank * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF    # 63-bit key, distinct per rank
         self.out = _t.empty((self.batch, ) + self.dims, dtype=_t.float32, device=device)
         self.step = _t.zeros(1, dtype=_t.int64, device=device)
 

@@ -703,12 +703,44 @@ GLOW_FLOW_AUTO_ROWS = 1024
 # step's grid barrier + gradient fold to one launch at the end (nf_glow_flow_steps_*; C2 at B = 2048 / 4096 / 16384:
 # 1.77 -> 1.63 / 1.88 -> 1.71 / 3.02 -> 2.50 ms per train step)
 GLOW_FLOW_STEPS = _os.environ.get('NF_GLOW_FLOW_STEPS', '1') != '0'
-# Device tables of per-step pointer records.  NEVER evicted: a captured hipGraph (FlowTrainer._capture) has the table's address
-# baked into its kernel arguments, and freeing a table would let the allocator recycle the memory under a later replay.  An
-# entry is ~100 pointers per flow step (25 KB for 32 steps), keyed by the addresses it contains -- if a later model lands on the
-# same addresses the stale entry is, by construction, still correct.
-_GLOW_FLOW_TABLES = {}
-_GLOW_FLOW_HOST = {}          # device table pointer -> the host copy of the same records
+# Device tables of per-step pointer records, keyed by the addresses they contain (if a later model lands on the same addresses
+# the entry is, by construction, still correct).  A captured hipGraph (FlowTrainer._capture) has the table's address baked into its
+# kernel arguments, so an entry that was looked up or created WHILE A STREAM WAS CAPTURING is pinned for the life of the process;
+# everything else (eager models that come and go: tests, bench.py running several workloads) is least-recently-used beyond
+# NF_FLOW_TABLE_CACHE entries (~25 KB each for 32 steps).
+class _FlowTableCache:
+    def __init__(self, limit):
+        import collections
+        self.limit = int(limit)
+        self.entries = collections.OrderedDict()      # key -> [table, pinned]
+        self.host = {}                                # device table pointer -> host copy of the same records
+
+    def get(self, key):
+        e = self.entries.get(key)
+        if e is None:
+            return None
+        self.entries.move_to_end(key)
+        if torch.cuda.is_current_stream_capturing():
+            e[1] = True
+        return e[0]
+
+    def __setitem__(self, key, table):
+        self.entries[key] = [table, bool(torch.cuda.is_current_stream_capturing())]
+        if len(self.entries) > self.limit:
+            for k in list(self.entries):
+                if len(self.entries) <= self.limit:
+                    break
+                t, pinned = self.entries[k]
+                if not pinned and k != key:
+                    del self.entries[k]
+                    self.host.pop(t.data_ptr(), None)
+
+    def __len__(self):
+        return len(self.entries)
+
+
+_GLOW_FLOW_TABLES = _FlowTableCache(_os.environ.get('NF_FLOW_TABLE_CACHE', '32'))
+_GLOW_FLOW_HOST = _GLOW_FLOW_TABLES.host          # device table pointer -> the host copy of the same records
 _GLOW_FLOW_SLABS = {}
 
 

@@ -565,6 +565,10 @@ def coupling_fusable(net, z, mode):
 def convnet_coupling(net, x, z, ld, a, c, mode, odd, inverse=False):
     """y, ld = AffineCoupling(z; net(x)) with x = the untouched half of z, in the conditioner's own launch (coupling_fusable)."""
     tensors = _convnet_tensors(net)
+    if inverse and torch.is_grad_enabled() and (z.requires_grad or x.requires_grad or ld.requires_grad):
+        # the inverse-direction kernels build no graph (DESIGN.md section 7): say so instead of returning detached results
+        raise NotImplementedError('differentiating through the inverse direction of a fused image coupling is not supported '
+                                  '(the reference never does: sampling runs under no_grad, main.py:109-116)')
     if inverse or not torch.is_grad_enabled():
         with torch.no_grad():
             class _Ctx:                                   # no graph: nothing is kept

@@ -74,6 +74,23 @@ class FlatAdam:
             t.copy_(sd[k])
 
 
+class _HipStepGraph:
+    """one captured piece of a train step: a torch.cuda.CUDAGraph (= hipGraph on ROCm).  ``FlowTrainer(graph_factory=...)`` takes any
+    class with the same two methods; the world-size-2 gloo test passes one that re-runs the closure, so that the capture / replay /
+    all-reduce-between-two-graphs control flow of the N > 1 path is exercised without a GPU."""
+
+    def __init__(self):
+        self.g = torch.cuda.CUDAGraph()
+
+    def capture(self, fn):
+        # thread_local: a collective watchdog / other host thread touching the runtime must not invalidate the capture
+        with torch.cuda.graph(self.g, capture_error_mode='thread_local'):
+            return fn()
+
+    def replay(self):
+        self.g.replay()
+
+
 class FlowTrainer:
     """Adam (lr 1e-4, betas (0.9, 0.999): configs/default.yaml:13-20) on the NLL, gradients in one flat bucket.
 
@@ -83,7 +100,7 @@ class FlowTrainer:
     The call that captures also takes one extra eager step on its batch (allocator warm-up on the capture stream)."""
 
     def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None,
-                 fused_adam=True, sampler=None, sync_stats=False):
+                 fused_adam=True, sampler=None, sync_stats=False, graph_factory=None):
         self.net = net
         # parity mode (SURVEY.md section 8e): every batch statistic over the GLOBAL batch -- W-way data parallelism then reproduces
         # the single-process result on the concatenated batch.  Layer-by-layer launches with collectives in between: no hipGraph.
@@ -95,11 +112,12 @@ class FlowTrainer:
         fused_adam = bool(fused_adam) and on_gpu
         self.bucket = nfdist.GradBucket(net.parameters(), process_group, flatten_params=fused_adam)
         self.graph = bool(graph)
+        self._graph_factory = graph_factory or _HipStepGraph
         if fused_adam:
             self.optim = FlatAdam(self.bucket, lr=lr, betas=betas, weight_decay=weight_decay)
         else:
             self.optim = torch.optim.Adam(self.bucket.params, lr=lr, betas=betas, weight_decay=weight_decay,
-                                          capturable=self.graph, foreach=True)
+                                          capturable=self.graph and on_gpu, foreach=True)
         self.warmup = warmup
         self._eager_steps = 0
         self._replicas_synced = False
@@ -177,27 +195,32 @@ class FlowTrainer:
 
     def _capture(self, y):
         self._static_y = y.clone() if y is not None else None
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                   # one more eager step on the side stream (capture etiquette)
+        if torch.cuda.is_available() and (y is None or y.is_cuda):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):               # one more eager step on the side stream (capture etiquette)
+                self._forward_backward(self._static_y)
+                self.bucket.all_reduce_mean_()
+                self.optim.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        else:                                           # (a CPU stand-in graph factory: the same extra eager step, no streams)
             self._forward_backward(self._static_y)
             self.bucket.all_reduce_mean_()
             self.optim.step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        # thread_local: a collective watchdog / other host thread touching the runtime must not invalidate the capture
         single = self.bucket.world == 1                 # no all-reduce between backward and Adam: one graph, one replay
-        g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb, capture_error_mode='thread_local'):
+
+        def forward_backward():
             z, loss = self._forward_backward(self._static_y)
-            self._static_z, self._static_loss = z.detach(), loss.detach()
             if single:
                 self.optim.step()
+            return z.detach(), loss.detach()
+        g_fb = self._graph_factory()
+        self._static_z, self._static_loss = g_fb.capture(forward_backward)
         g_opt = None
-        if not single:
-            g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt, capture_error_mode='thread_local'):
-                self.optim.step()
+        if not single:                                  # N > 1: graph A, the flat bucket's all-reduce (eager, RCCL), graph B = Adam
+            g_opt = self._graph_factory()
+            g_opt.capture(self.optim.step)
         self._g_fb, self._g_opt = g_fb, g_opt
 
     def train_on_batch(self, y=None):
@@ -218,7 +241,8 @@ class FlowTrainer:
                 warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
                 self.graph = False
                 self._g_fb = self._g_opt = None
-                torch.cuda.synchronize()
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
         if self._g_fb is not None:
             if not self._replicas_synced:               # warmup=0: no eager step ran before the capture
                 self._sync_replicas_after_first_step()

@@ -17,7 +17,8 @@ class ZeroArena:
         self.zeroed = 0         # elements of buf that are zero for the step under way
         self.high = 0
         self.active = False
-        self.retired = []       # outgrown buffers: a hipGraph captured earlier may still point into them
+        self.retired = []       # outgrown buffers a hipGraph was captured against: its kernel arguments still point into them
+        self.captured = False   # a capture happened while the CURRENT buffer was the arena
 
     def begin(self, device):
         """start a step: zero as much of the arena as the PREVIOUS step used (+ 25 %).  Sizing by the all-time maximum would make a
@@ -25,13 +26,16 @@ class ZeroArena:
         0.2 ms, in front of every 1.9 ms step)."""
         need = max(int(self.last * 1.25), 1 << 14)
         if self.buf is None or self.buf.device != device or (self.buf.numel() < need and not _capturing()):
-            if self.buf is not None:
+            if self.buf is not None and self.captured:   # only a buffer some captured graph replays against must outlive its use
                 self.retired.append(self.buf)
             self.buf = torch.zeros(need, dtype=torch.float32, device=device)
+            self.captured = False
             self.zeroed = need
         else:
             self.zeroed = min(need, self.buf.numel())
             self.buf[:self.zeroed].zero_()
+        if _capturing():
+            self.captured = True
         self.off = 0
         self.active = True
 

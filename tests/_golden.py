@@ -38,6 +38,8 @@ MODEL_CASES = {
     'maf2d': ('maf', 'MAF', (2, ), '2d', 2, None),
     'glow_img': ('glow', 'Glow', (3, 16, 16), 'image', 1, None),
     'resflow2d': ('resflow', 'ResFlow', (2, ), '2d', 2, None),
+    'realnvp_img': ('realnvp', 'RealNVP', (3, 16, 16), 'image', 1, None),
+    'flowpp_img': ('flowpp', 'Flowpp', (3, 16, 16), 'image', 1, 4),
 }
 
 

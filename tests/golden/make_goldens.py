@@ -309,11 +309,16 @@ MODELS = [
     ('maf2d', 'MAF', (2, ), '2d', 2, None, 64),
     ('glow_img', 'Glow', (3, 16, 16), 'image', 1, None, 4),
     ('resflow2d', 'ResFlow', (2, ), '2d', 2, None, 64),          # logdet='exact' in eval; seeded noise in training
+    # round 3: the image stacks of the two other flows north_star names (realnvp.py:17-47, flowpp.py:17-62)
+    ('realnvp_img', 'RealNVP', (3, 16, 16), 'image', 1, None, 4),
+    ('flowpp_img', 'Flowpp', (3, 16, 16), 'image', 1, 4, 4),
 ]
 
 
-def make_models():
+def make_models(only=None):
     for name, cls, dims, datatype, layers, mix, B in MODELS:
+        if only and name not in only:
+            continue
         torch.manual_seed(100)
         np.random.seed(100)
         net = getattr(ref, cls)(dims, datatype, NS(layers=layers, mixtures=mix, logdet='exact', spnorm_coeff=0.9))
@@ -358,9 +363,12 @@ def make_models():
 if __name__ == '__main__':
     import warnings
     warnings.filterwarnings('ignore')
-    make_indexmaps()
-    make_ops()
-    make_models()
+    if len(sys.argv) > 1:                                          # python make_goldens.py realnvp_img flowpp_img: only these models
+        make_models(set(sys.argv[1:]))
+    else:
+        make_indexmaps()
+        make_ops()
+        make_models()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print('%-24s %8.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

@@ -266,3 +266,113 @@ def test_sync_statistics_reproduce_the_single_process_global_batch():
             assert torch.allclose(torch.from_numpy(two[r][2][k]), torch.from_numpy(v), atol=1e-3, rtol=1e-4), (r, k)
             n += 1
     assert n >= 2 * 30
+
+
+# ---- the N > 1 hipGraph control flow of FlowTrainer (graph A, all-reduce, graph B) on gloo --------------------------------------------
+class _OracleBackedGlow(torch.nn.Module):
+    """The PRODUCT's Glow((2,), '2d') module tree -- its parameters, buffers and state_dict layout, i.e. exactly what GradBucket,
+    the broadcasts and Adam see on C2 -- executed on CPU by the oracle over the LIVE tensors (the HIP transforms are GPU-only;
+    tests may use the oracle)."""
+
+    def __init__(self, layers):
+        super().__init__()
+        from types import SimpleNamespace as NS
+        from oracle import models as om
+        pkg = importlib.import_module(PKG)
+        self.net = pkg.Glow((2, ), '2d', NS(layers=layers, mixtures=None)).net
+        sd = {'net.' + k: v for k, v in self.net.named_parameters()}
+        sd.update({'net.' + k: v for k, v in self.net.named_buffers()})
+        self.ora = om.FlowOracle('glow', (2, ), '2d', layers, sd, training=True)
+
+    def forward(self, y):
+        return self.ora.forward(y)
+
+
+class _RerunGraph:
+    """stand-in for a hipGraph on CPU: ``capture`` records the closure WITHOUT leaving a trace (a real capture executes nothing: the
+    parameters, buffers, optimizer state and the oracle's ActNorm flags are restored after the run that is needed to obtain the static
+    outputs), ``replay`` re-runs it and refreshes the static outputs in place."""
+    trainer = None
+
+    def capture(self, fn):
+        import copy
+        tr = type(self).trainer
+        keep = [t.detach().clone() for t in list(tr.net.parameters()) + list(tr.net.buffers())]
+        opt = copy.deepcopy(tr.optim.state_dict())
+        flat = tr.bucket.flat.clone()
+        self.fn = fn
+        self.out = fn()
+        with torch.no_grad():
+            for t, k in zip(list(tr.net.parameters()) + list(tr.net.buffers()), keep):
+                t.copy_(k)
+            tr.bucket.flat.copy_(flat)
+        tr.optim.load_state_dict(opt)
+        return self.out
+
+    def replay(self):
+        new = self.fn()
+        if new is not None:
+            for o, n in zip(self.out, new):
+                o.copy_(n)
+
+
+def _graph_worker(rank, world, port, q, use_graph):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    nfdist = importlib.import_module(PKG + '.dist')
+    train = importlib.import_module(PKG + '.train')
+    nfdata = importlib.import_module(PKG + '.data')
+    nfdist.init_from_env(backend='gloo')
+    torch.set_num_threads(2)
+    torch.manual_seed(3 + rank)                          # DIFFERENT initial weights per rank: the coalesced broadcast must fix that
+    import numpy as np
+    np.random.seed(3 + rank)
+    net = _OracleBackedGlow(4).train()
+    n_coll = nfdist.broadcast_parameters(net)
+    tr = train.FlowTrainer(net, lr=1e-3, graph=use_graph, warmup=2, graph_factory=_RerunGraph)
+    _RerunGraph.trainer = tr
+    y_global = nfdata.sample('moons', 256, 77)
+    y = nfdist.shard(y_global, rank, world)
+    losses = []
+    for i in range(6):
+        if not use_graph and i == 2:
+            tr.train_on_batch(y + 0.01 * i)              # the capturing call of the graph run takes one extra eager step on its batch
+        z, loss = tr.train_on_batch(y + 0.01 * i)        # a different batch every step: the static input must be refreshed
+        losses.append(float(loss))
+    params = torch.cat([p.detach().reshape(-1) for p in net.parameters() if p.requires_grad]).numpy().copy()
+    q.put((rank, losses, params, n_coll, tr._g_fb is not None, tr._g_opt is not None, int(tr.optim.state_dict()['state'][0]['step'])))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _run_graph(use_graph):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q, use_graph)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_trainer_two_graph_path_matches_eager_over_two_ranks():
+    """FlowTrainer(graph=True) at world size 2 (train.py: graph A = zero + forward + NLL + backward, then the flat bucket's
+    all-reduce, then graph B = Adam) against FlowTrainer(graph=False) on the same two ranks, shards and batches, with the product's
+    own Glow-2D module tree (C2's parameter layout): every loss of six steps and the final parameters must agree, the replicas must
+    stay identical, and start-up must need a handful of broadcasts (one per dtype), not one per tensor."""
+    import numpy as np
+    eager = _run_graph(False)
+    graph = _run_graph(True)
+    for r in range(2):
+        assert graph[r][4] and graph[r][5], 'the two-graph path (graph A + graph B) was not taken at world size 2'
+        assert not eager[r][4]
+        assert graph[r][3] <= 4, '%d broadcasts at start-up' % graph[r][3]
+        assert graph[r][6] == eager[r][6] == 7, (graph[r][6], eager[r][6])   # six calls + the capture's extra step
+        assert np.allclose(graph[r][1], eager[r][1], rtol=1e-6, atol=1e-6), (graph[r][1], eager[r][1])
+        assert np.allclose(graph[r][2], eager[r][2], rtol=1e-5, atol=1e-6), float(np.abs(graph[r][2] - eager[r][2]).max())
+    assert np.array_equal(graph[0][2], graph[1][2]), 'replicas diverged on the graph path'
+    assert graph[0][1][0] != graph[1][1][0]              # (the ranks really trained on different shards)

@@ -24,18 +24,29 @@ term vanishes and the plain 1e-5 bar applies.  For C3 and C4 the float64 pass (4
 replay check and the final forward re-use the gaps measured at step 2.
 
 GRADIENTS of a full-depth model cannot meet a max-norm bar against ANY other fp32 implementation, and the test says so instead
-of pretending: the loss is only piecewise smooth.  A pass takes 1.3 M (C1) .. 100 M (C4) ReLU decisions; a pre-activation
-within rounding of zero (probability ~ 1e-7 each) is masked differently by two correct implementations, which changes that
-sample's gradient by O(1), i.e. a step's parameter gradients by O(1/B) -- and the backward pass through the remaining steps
-amplifies the perturbation by ~ 1.3x per step (measured: tools/probes/parity_depth.py; on C1 one flipped sample in the last
-step puts 6e-4 into step 30 and 0.3 of the largest entry into step 0, while the forward values stay inside 2x the fp32 / fp64
-gap; the CPU's own fp32 and fp64 runs flip against each other just as often -- C2 at B = 256: 0.2).  So here:
-  * the LAST flow step's gradient tensors (nothing amplifies them) meet the strict bar 2e-5 * max|g| + SLACK * gap, plus the
-    footprint FLIPS / B * max|g| of at most FLIPS flipped samples;
-  * the whole flat gradient has cosine >= 0.9 with and 0.8 .. 1.25 of the norm of the CPU's;
-  * how many tensors meet the strict bar is REPORTED (gpurun_out/fullsize_parity.txt), not asserted.
-The tight, deterministic gradient check on these launch paths at full batch is tests/test_gpu_slices.py: two-step slices of
-the same models at several depths, fed with the oracle's float64 activations and upstream gradients.
+of pretending: the loss is only piecewise smooth.  A pass takes 1.3 M (C1) .. 100 M (C4) ReLU decisions, and the forward values two
+fp32 implementations feed into them differ by the accumulated rounding of the steps before (C1: the CPU's own fp32 and fp64
+pre-activations are 1e-2 apart at step 31, tools/kink_seed.py).  A unit whose pre-activation is closer to zero than that is masked
+differently by two correct implementations ("kink event"): that sample's gradient changes by O(1), a step's parameter gradients by
+O(1/B), and the backward pass through the remaining steps amplifies the perturbation by ~ 1.3x per step.  The census of
+tools/kink_seed.py counts 93 .. 521 such units per C1 pass over six seeds (profiles/r03_c1_kink_census.txt): a kink-free seed does
+not exist at full depth.  What the test asserts instead:
+  * THE YARD-STICK IS AN ENSEMBLE.  Permuting the rows of the batch is a symmetry of the exact problem (batch statistics, mean
+    loss), but it changes every fp32 summation order: the reference's own fp32 CPU path, run on K row permutations of the SAME
+    batch and weights, lands anywhere between 5.6e-3 and 1.6e-1 of float64 on C1 (flat gradient).  For the configs whose oracle
+    step is cheap (C1, C2, C5: K = 6) the GPU's flat-gradient distance to float64 must be <= 4 x the LARGEST distance of the
+    ensemble; for C3 / C4 (one 45 s float64 pass) <= 4 x the unpermuted fp32 oracle's.
+  * THE PER-STEP PROFILE.  For every flow step s the worst gradient entry (relative to the tensor's largest) must be inside
+        2e-5  +  SLACK * ensemble envelope(s)  +  FLIPS / B * AMP ** (last - s)
+    i.e. the strict bar plus the footprint of at most FLIPS kink events per pass, amplified by AMP = 1.3 per step on the way back
+    (measured, tools/probes/parity_depth.py).  The profile is written to gpurun_out/fullsize_parity.txt (committed per round under
+    profiles/).
+  * the LAST flow step's gradient tensors (nothing amplifies them) meet the strict bar + the footprint of FLIPS samples;
+  * a KINK-FREE case meets the strict bar on EVERY tensor: test_c1_kink_free_seed_meets_the_strict_bar_on_every_tensor runs the
+    C1 launch path (whole-flow RealNVP kernel, B = 256) at the largest depth where the census finds a seed without a single unit
+    at risk (K = 8, seed 6).
+The tight, deterministic gradient check on these launch paths at full batch and FULL depth is tests/test_gpu_slices.py: two-step
+slices of the same models at several depths, fed with the oracle's float64 activations and upstream gradients.
 The measured errors are appended to gpurun_out/fullsize_parity.txt.  Needs a real MI355X.
 """
 import importlib
@@ -52,7 +63,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 TOL = 1.0e-5
 SLACK = 4.0
-FLIPS = 4          # samples per flow step allowed on the other side of a ReLU kink (see the docstring)
+FLIPS = 4          # kink events per pass whose footprint the per-step profile may carry (see the docstring)
+AMP = 1.3          # amplification of a gradient perturbation per flow step of the backward pass (measured)
+ENSEMBLE = 6       # row permutations of the batch the fp32 oracle is run on where that is cheap (C1, C2, C5)
 
 CONFIGS = [
     # name, oracle kind, class, dims, datatype, layers, mixtures, per-GPU batch, data
@@ -90,9 +103,32 @@ def _check(gaps, what, gpu, r32, r64, scale=None):
     return err <= TOL * s + SLACK * ref + ulp, err, ref, s
 
 
-def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B):
-    """z and loss: the strict bar.  Gradients: see the module docstring -- strict on the LAST flow step (nothing downstream
-    amplifies its error), direction + magnitude of the whole flat gradient, and the strict-bar census as a report."""
+def _flat_distance(grads, r64):
+    """relative L2 distance of a {name: gradient} set to the float64 record, over the tensors both hold"""
+    num = den = 0.0
+    for k, e in r64['grads'].items():
+        if k in grads:
+            d = grads[k].detach().double().cpu().reshape(-1) - e.double().reshape(-1)
+            num += float(d @ d)
+            den += float(e.double().reshape(-1) @ e.double().reshape(-1))
+    return (num / max(den, 1e-300)) ** 0.5
+
+
+def _step_profile(grads, r64, per_step):
+    """{flow step: worst |g - g64| / max(1, max|g64|) over the step's gradient tensors}"""
+    prof = {}
+    for k, e in r64['grads'].items():
+        if k in grads and k.startswith('net.layers.'):
+            st = int(k.split('.')[2]) // per_step
+            w = float((grads[k].detach().double().cpu() - e.double()).abs().max()) / max(1.0, float(e.abs().max()))
+            prof[st] = max(prof.get(st, 0.0), w)
+    return prof
+
+
+def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble=()):
+    """z and loss: the strict bar.  Gradients: see the module docstring -- strict on the LAST flow step, the per-step profile inside
+    strict + ensemble envelope + the footprint of FLIPS kink events, the flat gradient no farther from float64 than 4 x the fp32
+    oracle ensemble's worst member.  ``ensemble``: records of the fp32 oracle on row permutations of the same batch."""
     bad = []
     r64 = rec64 if rec64 is not None else {'z': None, 'loss': None, 'grads': {}}
     ok, err, ref, s = _check(gaps, 'z', z, rec32['z'], r64['z'])
@@ -109,20 +145,13 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B):
     last_layer = max(int(k.split('.')[2]) for k in names)
     per_step = 3 if any(k.endswith('.log_s') for k in names) else 2            # Glow / Flow++-image steps have three layers
     first_of_last = last_layer - per_step + 1
-    worst, strict, n, dot, n_g, n_c = (0.0, 0.0, ''), 0, 0, 0.0, 0.0, 0.0
-    d_gpu, d_ref, n_64 = 0.0, 0.0, 0.0                      # squared flat distances to the float64 gradient
-    grads = dict(net.named_parameters())
+    worst, strict, n = (0.0, 0.0, ''), 0, 0
+    grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
     for k in names:
-        p = grads[k]
-        assert p.grad is not None, k
-        g, c = p.grad.detach().double().cpu().reshape(-1), rec32['grads'][k].double().reshape(-1)
-        dot += float(g @ c); n_g += float(g @ g); n_c += float(c @ c)
-        if k in r64['grads']:
-            e = r64['grads'][k].double().reshape(-1)
-            d_gpu += float((g - e) @ (g - e)); d_ref += float((c - e) @ (c - e)); n_64 += float(e @ e)
+        assert k in grads, k
         # strict gradient bar: 2e-5 of the largest entry of the tensor (as tests/test_gpu_models.py) + the measured fp32 uncertainty
         s = max(1.0, float(rec32['grads'][k].abs().max()))
-        ok, err, ref, _ = _check(gaps, 'grad/' + k, p.grad, rec32['grads'][k], r64['grads'].get(k), scale=2.0 * s)
+        ok, err, ref, _ = _check(gaps, 'grad/' + k, grads[k], rec32['grads'][k], r64['grads'].get(k), scale=2.0 * s)
         n += 1
         strict += int(ok)
         if err / s >= worst[0]:
@@ -131,19 +160,35 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B):
             # the last step: strict bar + the footprint of at most FLIPS samples whose ReLU decisions fell on the other side of a kink
             if err > TOL * 2.0 * s + SLACK * ref + FLIPS / float(B) * s:
                 bad.append((k, err, ref))
-    cos = dot / max((n_g * n_c) ** 0.5, 1e-300)
-    ratio = (n_g / max(n_c, 1e-300)) ** 0.5
-    _report('%-18s %-14s grads %d tensors: %d inside the strict bar; worst |gpu-cpu32|/max %.3e (|cpu32-cpu64|/max %.3e) at %s; '
-            'flat gradient cos %.6f norm ratio %.4f' % (name, tag, n, strict, worst[0], worst[1], worst[2], cos, ratio))
+    _report('%-18s %-14s grads %d tensors: %d inside the strict bar; worst |gpu-cpu32|/max %.3e (|cpu32-cpu64|/max %.3e) at %s'
+            % (name, tag, n, strict, worst[0], worst[1], worst[2]))
     assert n >= 2 * 2, 'no gradients compared'
-    # The flat gradient as a whole: cosine >= 0.9 and norm ratio within 0.8 .. 1.25 against the fp32 oracle -- unless the fp32 oracle
-    # is itself far from the float64 one at this state (a 32-step RealNVP at B = 256 occasionally sits on a ReLU kink that the
-    # BatchNorm backward spreads over the whole batch: then cpu32 and cpu64 disagree by tens of percent and no fp32 result can be
-    # judged against either); then the GPU must be no farther from float64 than four times the fp32 oracle is.
-    rel_gpu, rel_ref = (d_gpu / max(n_64, 1e-300)) ** 0.5, (d_ref / max(n_64, 1e-300)) ** 0.5
-    _report('%-18s %-14s flat gradient distance to float64: gpu %.3e  cpu32 %.3e' % (name, tag, rel_gpu, rel_ref))
-    if (cos < 0.9 or not 0.8 < ratio < 1.25) and rel_gpu > 4.0 * rel_ref:
-        bad.append(('flat gradient', cos, ratio, rel_gpu, rel_ref))
+    if rec64 is not None:
+        members = [rec32] + list(ensemble)
+        rel_gpu = _flat_distance(grads, r64)
+        rel_ens = [_flat_distance(m['grads'], r64) for m in members]
+        gaps['flat'] = max(rel_ens)
+        _report('%-18s %-14s flat gradient distance to float64: gpu %.3e  cpu32 %.3e  fp32 oracle on %d row permutations: %s'
+                % (name, tag, rel_gpu, rel_ens[0], len(members) - 1, ' '.join('%.2e' % v for v in rel_ens[1:])))
+        if rel_gpu > 4.0 * max(rel_ens) + 1.0e-6:
+            bad.append(('flat gradient distance to float64', rel_gpu, max(rel_ens)))
+        pg = _step_profile(grads, r64, per_step)
+        pe = [_step_profile(m['grads'], r64, per_step) for m in members]
+        last = max(pg)
+        _report('%-18s %-14s per-step gradient error vs float64 (worst entry / max entry): step gpu | fp32 ensemble max | bar' % (name, tag))
+        for st in sorted(pg):
+            env = max(p_.get(st, 0.0) for p_ in pe)
+            bar = 2.0 * TOL + SLACK * env + min(1.0, FLIPS / float(B) * AMP ** min(last - st, 64))
+            _report('%-18s %-14s   %3d  %.3e | %.3e | %.3e%s' % (name, tag, st, pg[st], env, bar, '' if pg[st] <= bar else '  <-- OUTSIDE'))
+            if pg[st] > bar:
+                bad.append(('profile step %d' % st, pg[st], env, bar))
+    else:
+        # no float64 pass for this step (C3 / C4 replay): the GPU must stay within 4 x the fp32 oracle's measured distance to float64
+        rel = _flat_distance(grads, rec32)
+        _report('%-18s %-14s flat gradient distance gpu to cpu32 %.3e (bar: 4 x %.3e measured at the last float64 pass)'
+                % (name, tag, rel, gaps.get('flat', float('nan'))))
+        if 'flat' in gaps and rel > 4.0 * gaps['flat'] + 1.0e-6:
+            bad.append(('flat gradient distance to cpu32', rel, gaps['flat']))
     assert not bad, '%s %s: %d quantities outside their bar, first %s' % (name, tag, len(bad), bad[:6])
 
 
@@ -168,27 +213,38 @@ def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg):
     slow64 = name.startswith(('c3', 'c4'))          # float64 oracle pass: 45 s each there, steps 1 and 2 only
     gaps = {}
 
+    perms = []
+    if not slow64:
+        gp = torch.Generator().manual_seed(99)
+        perms = [torch.randperm(B, generator=gp) for _ in range(ENSEMBLE)]
+
     def oracle_step(sd, initialised, want64):
         r32, _ = traj.run(kind, dims, datatype, layers, sd, y, 1, mixtures=mix, dtype=torch.float32,
                           actnorm_initialized=initialised)
-        r64 = None
+        r64, ens = None, []
         if want64:
             r64, _ = traj.run(kind, dims, datatype, layers, sd, y, 1, mixtures=mix, dtype=torch.float64,
                               actnorm_initialized=initialised)
-        return r32[1], (r64[1] if r64 is not None else None)
+            # the reference's fp32 CPU path on row permutations of the same batch: a symmetry of the exact problem, a different
+            # rounding order -- how far apart two correct fp32 evaluations of this very step are
+            for pm in perms:
+                rp, _ = traj.run(kind, dims, datatype, layers, sd, y[pm], 1, mixtures=mix, dtype=torch.float32,
+                                 actnorm_initialized=initialised)
+                ens.append({'grads': rp[1]['grads']})
+        return r32[1], (r64[1] if r64 is not None else None), ens
 
     sd = _snapshot(net)
     z, loss = trainer.train_on_batch(yd)                      # step 1: ActNorm init, layer by layer where that is needed
     torch.cuda.synchronize()
-    r32, r64 = oracle_step(sd, False, True)
-    _compare_step(name, 'eager step 1', net, z, loss, r32, r64, dims, gaps, B)
+    r32, r64, ens = oracle_step(sd, False, True)
+    _compare_step(name, 'eager step 1', net, z, loss, r32, r64, dims, gaps, B, ens)
 
     sd = _snapshot(net)
     z, loss = trainer.train_on_batch(yd)                      # step 2: the fused eager launch paths
     torch.cuda.synchronize()
     assert int(trainer.optim.step_count.item()) == 2
-    r32, r64 = oracle_step(sd, True, True)
-    _compare_step(name, 'eager step 2', net, z, loss, r32, r64, dims, gaps, B)
+    r32, r64, ens = oracle_step(sd, True, True)
+    _compare_step(name, 'eager step 2', net, z, loss, r32, r64, dims, gaps, B, ens)
 
     trainer.train_on_batch(yd)                                # capture (eager step 3 on the side stream) + first replay (step 4)
     torch.cuda.synchronize()
@@ -199,18 +255,16 @@ def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg):
     z, loss = trainer.train_on_batch(yd)                      # step 5: a pure hipGraph replay -- bench.py's timed region
     torch.cuda.synchronize()
     assert int(trainer.optim.step_count.item()) == 5
-    r32, r64 = oracle_step(sd, True, not slow64)
-    _compare_step(name, 'graph replay', net, z, loss, r32, r64, dims, gaps, B)
+    r32, r64, ens = oracle_step(sd, True, not slow64)
+    _compare_step(name, 'graph replay', net, z, loss, r32, r64, dims, gaps, B, ens)
     assert pkg._native.persistent_timeouts() == 0
 
     # one more training-mode forward on the trained weights: z and the log-det VECTOR (the trainer only returns the loss)
     sd = _snapshot(net)
     z32, ld32 = traj.forward_only(kind, dims, datatype, layers, sd, y, mixtures=mix, dtype=torch.float32)
-    z64 = ld64 = None
-    if not slow64:
-        z64, ld64 = traj.forward_only(kind, dims, datatype, layers, sd, y, mixtures=mix, dtype=torch.float64)
-    else:
-        gaps['ld'] = gaps['z'] * float(np.prod(dims))   # not measured separately there: every element's error can add up
+    # the float64 gap of z AND of the log-det vector is measured for every config (a forward-only pass; C4: ~15 s): the log-det
+    # check has its own measured slack, not a bound derived from z
+    z64, ld64 = traj.forward_only(kind, dims, datatype, layers, sd, y, mixtures=mix, dtype=torch.float64)
     net.train()
     with torch.no_grad():
         zg, ldg = net(yd)
@@ -221,3 +275,109 @@ def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg):
         if not ok:
             bad.append((what, err, ref))
     assert not bad, bad
+
+
+KINK_FREE = dict(layers=8, seed=6, batch=256)     # tools/kink_seed.py: LAYERS=8 python tools/kink_seed.py c1 24 -> seed 6: 0 flips, 0 units at risk
+
+
+def test_c1_kink_free_seed_meets_the_strict_bar_on_every_tensor(pkg):
+    """The C1 launch path (whole-flow RealNVP kernel, B = 256: one launch per direction) on a case WITHOUT kink events: at K = 8 flow
+    steps the census of tools/kink_seed.py finds seeds where no ReLU pre-activation of the float64 pass is closer to zero than 8 x
+    the fp32 / fp64 difference at that unit (re-checked here), so every correct fp32 implementation takes the same 327 680 ReLU
+    decisions and the gradient is a smooth function of the rounding: EVERY gradient tensor must meet
+    2e-5 * max|g| + SLACK * |cpu32 - cpu64|, and so must z and the loss.  (At the full K = 32 no such seed exists: 93 .. 521
+    units at risk per pass over six seeds, profiles/r03_c1_kink_census.txt -- there the ensemble bars above apply.)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kink_seed', os.path.join(root, 'tools', 'kink_seed.py'))
+    ks = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ks)
+    nfdata = importlib.import_module(pkg.__name__ + '.data')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    F = importlib.import_module(pkg.__name__ + '.fused')
+    L, seed, B = KINK_FREE['layers'], KINK_FREE['seed'], KINK_FREE['batch']
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    net = pkg.RealNVP((2, ), '2d', NS(layers=L, mixtures=None))
+    y = nfdata.sample('moons', B, 1234 + seed)
+    sd = _snapshot(net)
+    st = ks.per_step(ks.census('realnvp', (2, ), '2d', L, sd, y))
+    assert sum(e['flips'] for e in st.values()) == 0 and sum(e['risk'] for e in st.values()) == 0, st
+    r32 = traj.run('realnvp', (2, ), '2d', L, sd, y, 1, dtype=torch.float32)[0][1]
+    r64 = traj.run('realnvp', (2, ), '2d', L, sd, y, 1, dtype=torch.float64)[0][1]
+    net = net.to(DEV)
+    assert F._flow_on(torch.empty(B, 2, device=DEV)), 'B = 256 must take the whole-flow launch (the C1 path)'
+    trainer = nftrain.FlowTrainer(net, graph=False)
+    z, loss = trainer.train_on_batch(y.to(DEV))
+    torch.cuda.synchronize()
+    bad = []
+    gz = float((r32['z'].double() - r64['z']).abs().max())
+    ez = float((z.double().cpu() - r32['z'].double()).abs().max())
+    if ez > TOL * max(1.0, float(r32['z'].abs().max())) + SLACK * gz:
+        bad.append(('z', ez, gz))
+    if abs(float(loss) - float(r32['loss'])) > TOL * max(1.0, abs(float(r32['loss']))) + SLACK * abs(float(r32['loss']) - float(r64['loss'])):
+        bad.append(('loss', float(loss), float(r32['loss'])))
+    grads = {k: p.grad.detach().double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    G = max(float(v.abs().max()) for v in r64['grads'].values())
+    n, worst = 0, (0.0, '')
+    for k, g64 in r64['grads'].items():
+        assert k in grads, k
+        s = max(float(g64.abs().max()), 1.0e-3 * G)             # the tensor's own largest entry (floor: 1e-3 of the largest of all)
+        err = float((grads[k] - r32['grads'][k].double()).abs().max())
+        gap = float((r32['grads'][k].double() - g64).abs().max())
+        if err > 2.0 * TOL * s + SLACK * gap:
+            bad.append((k, err / s, gap / s))
+        worst = max(worst, (err / s, k))
+        n += 1
+    _report('c1_kink_free       K=%d seed %d      %d gradient tensors, worst |gpu-cpu32|/max|g| %.3e at %s; z %.3e (gap %.3e)'
+            % (L, seed, n, worst[0], worst[1], ez, gz))
+    assert n >= 20 * L, n
+    assert not bad, bad[:8]
+    assert pkg._native.persistent_timeouts() == 0
+
+
+IMAGE_CASES = [
+    # the image stacks of the two other flows north_star names, CIFAR shape, B = 64 (realnvp.py:17-47, flowpp.py:17-62)
+    ('realnvp_cifar', 'realnvp', 'RealNVP', (3, 32, 32), 'image', 4, None, 64),
+    ('flowpp_cifar', 'flowpp', 'Flowpp', (3, 32, 32), 'image', 2, 8, 64),
+]
+
+
+@pytest.mark.parametrize('cfg', IMAGE_CASES, ids=[c[0] for c in IMAGE_CASES])
+def test_image_realnvp_and_flowpp_steps_match_oracle_at_cifar_shape(pkg, cfg):
+    """RealNVP((3, 32, 32), 'image') and Flowpp((3, 32, 32), 'image') at B = 64 through the trainer: eager step 1 (data-dependent
+    ActNorm initialisation for Flow++) and eager step 2 (the fused launch paths) against ONE oracle step from the identical state
+    in float32 and float64 -- z, loss, the per-step gradient profile, the flat gradient -- and one training-mode forward for the
+    log-det vector, with the bars of the BASELINE configs above."""
+    name, kind, cls, dims, datatype, layers, mix, B = cfg
+    nfdata = importlib.import_module(pkg.__name__ + '.data')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = getattr(pkg, cls)(dims, datatype, NS(layers=layers, mixtures=mix))
+    y = nfdata.sample('cifar', B, 1234).reshape((B, ) + dims)
+    net = net.to(DEV)
+    trainer = nftrain.FlowTrainer(net, graph=False)
+    yd = y.to(DEV)
+    gaps = {}
+    for step, initialised in ((1, False), (2, True)):
+        sd = _snapshot(net)
+        z, loss = trainer.train_on_batch(yd)
+        torch.cuda.synchronize()
+        r32 = traj.run(kind, dims, datatype, layers, sd, y, 1, mixtures=mix, dtype=torch.float32, actnorm_initialized=initialised)[0][1]
+        r64 = traj.run(kind, dims, datatype, layers, sd, y, 1, mixtures=mix, dtype=torch.float64, actnorm_initialized=initialised)[0][1]
+        _compare_step(name, 'eager step %d' % step, net, z, loss, r32, r64, dims, gaps, B)
+    sd = _snapshot(net)
+    z32, ld32 = traj.forward_only(kind, dims, datatype, layers, sd, y, mixtures=mix, dtype=torch.float32)
+    z64, ld64 = traj.forward_only(kind, dims, datatype, layers, sd, y, mixtures=mix, dtype=torch.float64)
+    net.train()
+    with torch.no_grad():
+        zg, ldg = net(yd)
+    bad = []
+    for what, g, a, b in (('z', zg, z32, z64), ('ld', ldg, ld32, ld64)):
+        ok, err, ref, s = _check(gaps, what, g, a, b)
+        _report('%-18s %-14s %-5s |gpu-cpu32| %.3e  |cpu32-cpu64| %.3e  scale %.2f' % (name, 'same weights', what, err, ref, s))
+        if not ok:
+            bad.append((what, err, ref))
+    assert not bad, bad
+    assert pkg._native.persistent_timeouts() == 0

@@ -108,7 +108,7 @@ def test_model_golden(pkg, name):
         G.assert_close(ldi, g['eval/ld_inv'], 10 * tol_inv, what='eval ld_inv')
 
 
-@pytest.mark.parametrize('name', ['glow2d', 'realnvp2d', 'maf2d', 'flowpp2d', 'glow_img', 'resflow2d'])
+@pytest.mark.parametrize('name', ['glow2d', 'realnvp2d', 'maf2d', 'flowpp2d', 'glow_img', 'resflow2d', 'realnvp_img', 'flowpp_img'])
 def test_model_golden_direct_grad_bucket(pkg, name):
     """same gradients when the backward kernels accumulate straight into the flat GradBucket (parameters re-homed
     into one flat buffer, fused NLL) -- the configuration the trainer and bench.py run."""

@@ -8,7 +8,7 @@ on a 256 MiB device copy), WRITE_SIZE as reported (KiB).
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out -o write -- python tools/pmc_round.py c4 c1
     python tools/pmc_round.py --json out/.../fetch_counter_collection.csv out/.../write_counter_collection.csv profiles/rNN_pmc.json
 
-The workload is bench.dominant_kernel_roofline itself (the launches whose duration the bench line reports), so the kernel names
+The workload is the bench's own train step (eager launches of the trainer bench.py times, via bench.dominant_kernel_roofline), so the kernel names
 and shapes are the bench's.  The JSON maps kernel name (up to '<' / '(') -> {batch: {fetch_kib, write_kib, traffic_bytes}}.
 """
 import csv
@@ -80,12 +80,28 @@ def main(names):
     torch.cuda.synchronize()
     del x, y
     import re
+    from types import SimpleNamespace as NS
+    import numpy as np
+    nftrain = importlib.import_module(bench.PKG + '.train')
+    nfdata = importlib.import_module(bench.PKG + '.data')
     which = {}
     for name in names:
         cfg = bench.CONFIGS[name]
-        r = bench.dominant_kernel_roofline(pkg, cfg, cfg['batch'], dev)
+        B = cfg['batch']
+        torch.manual_seed(0)
+        np.random.seed(0)
+        net = getattr(pkg, cfg['cls'])(cfg['dims'], cfg['datatype'], NS(layers=cfg['layers'], mixtures=cfg['mixtures'])).to(dev)
+        trainer = nftrain.FlowTrainer(net, graph=False)
+        y = nfdata.sample(cfg['data'], B, 1234)
+        if cfg['data'] == 'cifar':
+            y = y.reshape((B, ) + cfg['dims'])
+        y = y.to(dev)
+        for _ in range(3):
+            trainer.train_on_batch(y)
+        r = bench.dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y)     # three more eager steps: the counted launches
         print(name, r['kernel'], r['us_per_launch'])
         which[name] = sorted(set(re.findall(r'k_[a-z0-9_]+', r['kernel'])))
+        del trainer, net
     torch.cuda.synchronize()
     with open(SIDECAR, 'w') as f:                       # config -> the kernels its roofline object names (read back by --json)
         json.dump(which, f)

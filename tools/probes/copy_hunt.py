@@ -6,12 +6,18 @@ import bench
 pkg = importlib.import_module(bench.PKG)
 nftrain = importlib.import_module(bench.PKG + '.train')
 nfdata = importlib.import_module(bench.PKG + '.data')
-cfg = bench.CONFIGS['c4']
+NAME = sys.argv[1] if len(sys.argv) > 1 else 'c4'
+cfg = bench.CONFIGS[NAME]
 dev = torch.device('cuda:0')
 torch.manual_seed(0); np.random.seed(0)
 net = getattr(pkg, cfg['cls'])(cfg['dims'], cfg['datatype'], NS(layers=cfg['layers'], mixtures=cfg['mixtures'])).to(dev)
 trainer = nftrain.FlowTrainer(net, graph=False, warmup=2)
 y = nfdata.sample(cfg['data'], cfg['batch'], 1234).reshape((cfg['batch'], ) + cfg['dims']).to(dev)
+GRAPH = len(sys.argv) > 2 and sys.argv[2] == 'graph'
+if GRAPH:
+    trainer = nftrain.FlowTrainer(net, graph=True, warmup=2)
+    for _ in range(3):
+        trainer.train_on_batch(y)
 for _ in range(3):
     trainer.train_on_batch(y)
 torch.cuda.synchronize()
