@@ -441,6 +441,9 @@ typedef struct nf_convnet_desc {
     const float* cp_a;        /* scalars */
     const float* cp_c;
     int cp_mode, cp_odd, cp_C, cp_inverse;
+    /* Optional: the weights of layer l as LDS images (nf_conv_weight_pack below), NULL = the kernel splits w[l] itself.  With the
+     * images a layer's weights reach LDS as direct global -> LDS loads issued under the previous layer's exchanges.            */
+    const float* wpk[6];
 } nf_convnet_desc;
 int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W);
 int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training, float bn_eps,
@@ -481,9 +484,29 @@ typedef struct nf_convnet_bwd_desc {
     /* Optional: gradient accumulators of the BatchNorm parameters, (32,) each, += (one workgroup adds: no atomics). */
     float* g_gamma[5];
     float* g_beta[5];
+    const float* wpk[6];        /* optional, as in nf_convnet_desc (the backward reads the transposed images of the same buffers) */
 } nf_convnet_bwd_desc;
 int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training,
                          nf_stream_t stream);
+
+/* The chain kernels run their fp32 convolutions on the bf16 matrix pipe: every operand is split into three bf16 values (x = h + m + l
+ * exactly), six of the nine partial products are accumulated in fp32 -- fp32 accuracy (measured error against float64 below that of
+ * v_mfma_f32_32x32x2_f32, tools/probes/bf16x3_probe.hip) at 0.375 of the matrix-pipe time.  nf_conv_weight_pack writes, for n
+ * effective weights, the split weights in the exact LDS layout the kernels read (an "image": 3 planes x 36 slots x 32 rows x 8 bf16 =
+ * NF_CONV_PACK_IMAGE_FLOATS floats), once per pass instead of once per workgroup and launch:
+ *   3 x 3 (O = 32, I <= 96):  ceil(I / 32) forward images (K = input channel chunk), then as many transposed ones (K = output channel)
+ *   1 x 1 (I = 32, O <= 192): one forward image in the row order of the fused coupling (row 2 p = shift channel, 2 p + 1 = its
+ *                             scale channel), one transposed image.
+ * dst: nf_conv_weight_pack_images(O, I, ksize) * NF_CONV_PACK_IMAGE_FLOATS floats per weight (0 images = shape not packable).       */
+#define NF_CONV_PACK_IMAGE_FLOATS (3 * 36 * 128)
+#define NF_CONV_PACK_MAX_LAYERS 64
+typedef struct nf_conv_pack_desc {
+    const float* w;             /* (O, I, k, k) effective weight */
+    float* dst;
+    int O, I, ksize, reserved;
+} nf_conv_pack_desc;
+int nf_conv_weight_pack_images(int O, int I, int ksize);
+int nf_conv_weight_pack(const nf_conv_pack_desc* descs, int n, nf_stream_t stream);
 
 /* autograd of nf_conv_bn_fwd in training mode; the gradient G of `out` is assembled on load exactly as in
  * nf_linear_bn_bwd (G = g_direct + g_skip + BNbwd(gn_src), each term optional).  Results:

@@ -46,26 +46,45 @@ extern "C" int nf_cc_prof_read(long long* out) {
 #define NF_CC_STAMP(i)
 #endif
 
-// LDS layouts ("4-packed": the MFMA K index runs over groups of 8 = two channel quads, a lane's four consecutive K values are one
-// float4, so a group costs TWO ds_read_b128 instead of eight ds_read_b32):
-//   frame  F4[cg][f][4]            channel quad cg = c >> 2, frame position f, c & 3            quad stride CS4 = 4 * CS
-//   weight W4[tap][cg][oc][4]      W[oc][4 cg + j][tap]: quad stride RSW = 4 * WC + 4, tap stride TS = NCG * RSW + 4 (WC = 32 * OCB
-//                                  output columns; the + 4 keep the staging stores of neighbouring taps / quads on different banks)
-#define NF_CC_RSW(WC) (4 * (WC) + 4)
-#define NF_CC_TS(NCG, WC) ((NCG) * NF_CC_RSW(WC) + 4)
+// ---- fp32 convolutions on the bf16 matrix pipe: the three-way split ------------------------------------------------------------------
+// A 32 -> 32 channel 3 x 3 layer over a 128-pixel tile is 36 x v_mfma_f32_32x32x2_f32 per wave, 3.9 us per layer with four waves per
+// SIMD (the fp32 MFMA runs at the fp32 VECTOR rate: 1/16 of the bf16 rate) -- the largest single phase of a layer.  An fp32 value is
+// EXACTLY the sum of three bf16 values (x = h + m + l: 3 x 8 significand bits, h = rne(x), m = rne(x - h), l = rne(x - h - m)), a
+// product of two bf16 values is exact in fp32, and the bf16 MFMA accumulates in fp32.  So
+//       a b  =  ah bh + (ah bm + am bh) + (ah bl + am bm + al bh)  +  O(2^-24 |a b|)        (the three dropped terms)
+// is an fp32 product to fp32 accuracy on SIX bf16 MFMAs of K = 16 each: 6 x 32 cycles per 16 K against 8 x 64 for fp32 -- 0.375 of
+// the matrix-pipe time.  Measured (tools/probes/bf16x3_probe.hip, K = 288 conditioner-like operands): max error against float64
+// 6.5e-7 for the split form, 9.3e-7 for v_mfma_f32_32x32x2_f32 itself; K loop of a layer 3.94 -> 1.77 us per workgroup.
+// Operands are split ONCE where they are written to LDS (an activation is read by nine taps), into three planes:
+//   frame   F8[plane][octet o][frame position f][8 bf16]     channel c = 8 o + j; 16 B per (o, f): one ds_read_b128 per operand
+//   weights W8[plane][slot][row][8 bf16]                     slot = (tap, octet of the K channel), row = output channel (forward) or
+//                                                            input channel (transposed); slot stride 32 rows x 16 B
+// v_mfma_f32_32x32x16_bf16: lane l supplies row / column l & 31 and the K indices 8 (l >> 5) + [0, 8): the two wave halves take the
+// two slots of a PAIR (2 p, 2 p + 1) -- always the same tap, neighbouring octets, so every operand address is base(hs) + literal.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NF_CC_WSLOT 128                              // floats per weight slot: 32 rows x 8 bf16
+#define NF_CC_WSLOTS 36                              // (tap, octet) slots of a 32-channel 3 x 3 layer (a ragged first chunk has 9 or 27
+                                                     // live slots and zeroes the one behind them; the 1 x 1 layers use <= 24)
+#define NF_CC_FP(CS) (16 * (CS))                     // floats per frame plane: 4 octets x CS positions x 16 B
 struct NfCcLds {            // offsets in floats
-    int FA, FB, WL, RS, KC, KB, RED, TOT, BNV, total;
+    int FA, WL, RS, KC, KB, RED, TOT, BNV, total, WPs;
 };
 template <int NPB, int NKQ>
 __host__ __device__ inline NfCcLds nf_cc_lds(int CS, int OCB) {
     NfCcLds L;
-    const int w3 = 9 * NF_CC_TS(8, 32), w1 = NF_CC_TS(8, 32 * OCB);
-    L.FA = 0;
-    L.FB = L.FA + 32 * CS;
-    L.WL = L.FB + 32 * CS;
-    L.RS = L.WL + (w3 > w1 ? w3 : w1);
+    L.FA = 0;                                          // ONE frame, rewritten in place: a layer's output is written after every wave
+    L.WL = L.FA + 3 * NF_CC_FP(CS);                    // has left the K loop that read its input (the exchanges' barriers lie between)
+    L.WPs = NF_CC_WSLOTS * NF_CC_WSLOT;                // one weight image = NF_CONV_PACK_IMAGE_FLOATS: what nf_conv_weight_pack writes
+    // the K-split exchange and the gather buffer of the grid exchange have their own region: the NEXT layer's weight image streams
+    // into WL (direct global -> LDS loads) while they run
+    L.RS = L.WL + 3 * L.WPs;
     int rs = NPB * (NKQ - 1) * 16 * NF_WAVE;
-    if (rs < NF_CC_MAX_BLOCKS * 64) rs = NF_CC_MAX_BLOCKS * 64;       // the gather buffer of the grid exchange aliases RS
+    if (rs < NF_CC_MAX_BLOCKS * 65) rs = NF_CC_MAX_BLOCKS * 65;
     L.KC = L.RS + rs;
     L.KB = L.KC + 128;                                 // kc[4][32]: scale, shift (forward) + mean, invstd (backward)
     L.RED = L.KB + 32;
@@ -75,108 +94,212 @@ __host__ __device__ inline NfCcLds nf_cc_lds(int CS, int OCB) {
     // level but 4 x 4): a global load at each layer's top is ~0.7 us of exposed latency on the serial chain
     L.BNV = (L.total + NF_CC_NB * 128) * (int)sizeof(float) <= 160 * 1024 ? L.total : -1;
     if (L.BNV >= 0) L.total += NF_CC_NB * 128;
+    (void)OCB;
     return L;
 }
+static_assert(3 * NF_CC_WSLOTS * NF_CC_WSLOT == NF_CONV_PACK_IMAGE_FLOATS, "image size of include/nfhip.h");
 
-// the K loop: acc += sum over the groups [g0, g0 + gcount) of W4(tap, quads 2 q + hs)[oc] * F4(quads 2 q + hs)[pixel + tap offset];
-// a tap has `gpt` groups (NCG / 2: 2 or 4, a power of two, lgg = log2).  Operand reads of group g + 1 are in flight under the MFMAs
-// of group g (the one-past-the-end prefetch re-reads a valid group: branch-free body).
-template <int T>
-__device__ __forceinline__ void nf_cc_kloop(f32x16& acc, const float* W4, const float* F4, int TS, int RSW, int CS4, int FW, int lgg,
-                                            int fpos, int col, int hs, int g0, int gcount) {
-    const int gpt = 1 << lgg;
-    const int glast = T * gpt - 1;
-    const float* wbase = W4 + hs * RSW + 4 * col;
-    const float* fbase = F4 + hs * CS4 + 4 * fpos;
-    float4 a0, b0, a1, b1;
-    int gi = g0;
-#define NF_CC_LOAD(A_, B_)                                                                     \
-    do {                                                                                       \
-        const int gg = gi < glast ? gi : glast;                                                \
-        const int tap = T == 1 ? 0 : gg >> lgg, q = gg - (tap << lgg);                         \
-        const int dy = T == 9 ? tap / 3 - 1 : 0, dx = T == 9 ? tap - (tap / 3) * 3 - 1 : 0;    \
-        A_ = *(const float4*)(wbase + tap * TS + 2 * q * RSW);                                 \
-        B_ = *(const float4*)(fbase + 4 * (dy * FW + dx) + 2 * q * CS4);                       \
-        ++gi;                                                                                  \
-    } while (0)
-#define NF_CC_MFMA(A_, B_)                                                                     \
-    do {                                                                                       \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B_.x, acc, 0, 0, 0);                  \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B_.y, acc, 0, 0, 0);                  \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B_.z, acc, 0, 0, 0);                  \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B_.w, acc, 0, 0, 0);                  \
-    } while (0)
-    NF_CC_LOAD(a0, b0);
-    for (int i = 0; i < gcount; i += 2) {
-        NF_CC_LOAD(a1, b1);
-        NF_CC_MFMA(a0, b0);
-        NF_CC_LOAD(a0, b0);
-        if (i + 1 < gcount) NF_CC_MFMA(a1, b1);
-    }
-#undef NF_CC_LOAD
-#undef NF_CC_MFMA
+// one packed weight image (nf_conv_weight_pack) global -> LDS without passing through registers: 54 wave-instructions of 1 KiB
+// (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i), 3 or 4 per wave.  Completion: nf_cc_dma_wait + a barrier.
+__device__ __forceinline__ void nf_cc_dma_image(float* W8, const float* __restrict__ img, int wid, int lane) {
+    constexpr int CH = NF_CONV_PACK_IMAGE_FLOATS / 256;
+    for (int c = wid; c < CH; c += NF_CV_WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(W8 + c * 256), 16, 0, 0);
+}
+__device__ __forceinline__ void nf_cc_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// x = h + m + l with three bf16 values (round to nearest each): pairs, so that the conversions are v_cvt_pk_bf16_f32
+__device__ __forceinline__ void nf_cc_split2(f32x2 x, bf16x2& h, bf16x2& m, bf16x2& l) {
+    h = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h, f32x2);
+    m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    l = __builtin_convertvector(r2, bf16x2);
+}
+__device__ __forceinline__ void nf_cc_split1(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+// four consecutive channels c0 .. c0 + 3 (c0 a multiple of 4) of frame position f: one 8-byte store per plane
+__device__ __forceinline__ void nf_cc_frame_store4(float* F, int CS, int c0, int f, float v0, float v1, float v2, float v3) {
+    bf16x2 h0, m0, l0, h1, m1, l1;
+    nf_cc_split2(f32x2{v0, v1}, h0, m0, l0);
+    nf_cc_split2(f32x2{v2, v3}, h1, m1, l1);
+    float* p = F + (c0 >> 3) * 4 * CS + 4 * f + ((c0 >> 2) & 1) * 2;
+    *(bf16x4*)(p) = bf16x4{h0[0], h0[1], h1[0], h1[1]};
+    *(bf16x4*)(p + NF_CC_FP(CS)) = bf16x4{m0[0], m0[1], m1[0], m1[1]};
+    *(bf16x4*)(p + 2 * NF_CC_FP(CS)) = bf16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+// one channel c of frame position f: three 2-byte stores
+__device__ __forceinline__ void nf_cc_frame_store1(float* F, int CS, int c, int f, float v) {
+    __bf16 h, m, l;
+    nf_cc_split1(v, h, m, l);
+    __bf16* p = (__bf16*)(F + (c >> 3) * 4 * CS + 4 * f) + (c & 7);
+    p[0] = h;
+    p[2 * NF_CC_FP(CS)] = m;
+    p[4 * NF_CC_FP(CS)] = l;
+}
+// one weight: row r, K channel k of slot `slot` (plane stride WPs floats)
+__device__ __forceinline__ void nf_cc_w_put(float* W8, int WPs, int slot, int row, int k8, float v) {
+    __bf16 h, m, l;
+    nf_cc_split1(v, h, m, l);
+    __bf16* p = (__bf16*)(W8 + slot * NF_CC_WSLOT + 4 * row) + k8;
+    p[0] = h;
+    p[2 * WPs] = m;
+    p[4 * WPs] = l;
 }
 
-// The same K loop for the 32 -> 32 channel 3 x 3 layers with the frame geometry known at compile time (FW, CS: one instantiation per
-// pyramid level): every operand address is base + IMMEDIATE (the ds_read offset field), so a K group is two ds_read_b128 and four
-// MFMAs with no address arithmetic in between; the generic loop above spends a third of the K phase on it (5.4 us against the 3.8 us
-// MFMA floor of four waves per SIMD).  Straight-line, one group of operands in flight ahead of the MFMAs.
-template <int FW, int CS, int G0, int GC>
+#define NF_CC_MFMA6(AH, AM, AL, BH, BM, BL)                                              \
+    do {                                                                                 \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BL, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, BH, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BM, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BM, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, BH, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, BH, acc, 0, 0, 0);             \
+    } while (0)
+
+// the generic K loop: acc += sum over the pairs [p0, p0 + np) of W8(slot)[row] * F8(tap offset, octet)[pixel]; slot = tap * noct + octet
+// (noct octets of K channels per tap: 1 .. 4), a wave half takes slot 2 p + hs.  Slots >= T * noct read the zero slot of the weights
+// (their B operand is any valid frame position).  Addresses are computed per pair: this version serves the first convolution's
+// ragged chunks and the 1 x 1 output layer (T = 1); the hidden layers run nf_cc_kloop_fixed.
+template <int T>
+__device__ __forceinline__ void nf_cc_kloop(f32x16& acc, const float* W8, const float* F8, int WPs, int CS, int FW, int noct, int fpos, int row,
+                                            int hs, int p0, int np) {
+    const int nslots = T * noct;
+    const int FPs = NF_CC_FP(CS);
+    for (int p = p0; p < p0 + np; ++p) {
+        const int slot = 2 * p + hs;
+        const bool live = slot < nslots;
+        const int sl = live ? slot : 0;
+        const int tap = T == 1 ? 0 : sl / noct, o = sl - tap * noct;
+        const int dy = T == 9 ? tap / 3 - 1 : 0, dx = T == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+        const float* wa = W8 + (live ? slot : nslots) * NF_CC_WSLOT + 4 * row;
+        const float* fb = F8 + o * 4 * CS + 4 * (fpos + dy * FW + dx);
+        const bf16x8 ah = *(const bf16x8*)(wa), am = *(const bf16x8*)(wa + WPs), al = *(const bf16x8*)(wa + 2 * WPs);
+        const bf16x8 bh = *(const bf16x8*)(fb), bm = *(const bf16x8*)(fb + FPs), bl = *(const bf16x8*)(fb + 2 * FPs);
+        NF_CC_MFMA6(ah, am, al, bh, bm, bl);
+    }
+}
+
+// The K loop of the 32 -> 32 channel 3 x 3 layers with the frame geometry known at compile time (FW, CS: one instantiation per pyramid
+// level): every operand address is base + IMMEDIATE (the ds_read offset field), six ds_read_b128 and six MFMAs per pair with no address
+// arithmetic in between.  Pair p = slots (2 p, 2 p + 1) = tap p >> 1, octets 2 (p & 1) + hs.  Straight-line, one pair of operands in
+// flight ahead of the MFMAs.
+template <int FW, int CS, int P0, int NP>
 __device__ __forceinline__ void nf_cc_kloop_fixed(f32x16& acc, const float* wbase, const float* fbase) {
-    constexpr int TS = NF_CC_TS(8, 32), RSW = NF_CC_RSW(32), CS4 = 4 * CS;
-    float4 a[2], b[2];
-#define NF_CC_OFFA(gg) (((gg) >> 2) * TS + 2 * ((gg) & 3) * RSW)
-#define NF_CC_OFFB(gg) (4 * (((((gg) >> 2) / 3) - 1) * FW + ((((gg) >> 2) % 3) - 1)) + 2 * ((gg) & 3) * CS4)
-    a[0] = *(const float4*)(wbase + NF_CC_OFFA(G0));
-    b[0] = *(const float4*)(fbase + NF_CC_OFFB(G0));
+    constexpr int WPs = NF_CC_WSLOTS * NF_CC_WSLOT, FPs = NF_CC_FP(CS);
+    bf16x8 a[2][3], b[2][3];
+#define NF_CC_OFFA(pp) (2 * (pp) * NF_CC_WSLOT)
+#define NF_CC_OFFB(pp) (4 * (((((pp) >> 1) / 3) - 1) * FW + ((((pp) >> 1) % 3) - 1)) + 2 * ((pp) & 1) * 4 * CS)
 #pragma unroll
-    for (int i = 0; i < GC; ++i) {
-        if (i + 1 < GC) {
-            a[(i + 1) & 1] = *(const float4*)(wbase + NF_CC_OFFA(G0 + i + 1));
-            b[(i + 1) & 1] = *(const float4*)(fbase + NF_CC_OFFB(G0 + i + 1));
+    for (int q = 0; q < 3; ++q) {
+        a[0][q] = *(const bf16x8*)(wbase + NF_CC_OFFA(P0) + q * WPs);
+        b[0][q] = *(const bf16x8*)(fbase + NF_CC_OFFB(P0) + q * FPs);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i + 1 < NP) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                a[(i + 1) & 1][q] = *(const bf16x8*)(wbase + NF_CC_OFFA(P0 + i + 1) + q * WPs);
+                b[(i + 1) & 1][q] = *(const bf16x8*)(fbase + NF_CC_OFFB(P0 + i + 1) + q * FPs);
+            }
         }
-        const float4 A_ = a[i & 1], B_ = b[i & 1];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B_.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B_.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B_.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B_.w, acc, 0, 0, 0);
+        NF_CC_MFMA6(a[i & 1][0], a[i & 1][1], a[i & 1][2], b[i & 1][0], b[i & 1][1], b[i & 1][2]);
     }
 #undef NF_CC_OFFA
 #undef NF_CC_OFFB
 }
+// 18 pairs over the NKQ waves of a pixel block: 9 + 9, or 5 + 5 + 4 + 4 (a SIMD holds one wave of every quarter: 18 pairs per SIMD
+// either way)
 template <int FW, int CS, int NKQ>
-__device__ __forceinline__ void nf_cc_kloop_level(f32x16& acc, const float* W4, const float* F4, int fpos, int col, int hs, int kq) {
-    constexpr int GC = 36 / NKQ;
-    const float* wbase = W4 + hs * NF_CC_RSW(32) + 4 * col;
-    const float* fbase = F4 + hs * 4 * CS + 4 * fpos;
-    if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, GC>(acc, wbase, fbase);             // wave-uniform
-    else if (kq == 1) nf_cc_kloop_fixed<FW, CS, GC, GC>(acc, wbase, fbase);
-    else if (NKQ > 2 && kq == 2) nf_cc_kloop_fixed<FW, CS, (NKQ > 2 ? 2 : 0) * GC, GC>(acc, wbase, fbase);
-    else if (NKQ > 2) nf_cc_kloop_fixed<FW, CS, (NKQ > 2 ? 3 : 0) * GC, GC>(acc, wbase, fbase);
+__device__ __forceinline__ void nf_cc_kloop_level(f32x16& acc, const float* W8, const float* F8, int fpos, int row, int hs, int kq) {
+    const float* wbase = W8 + hs * NF_CC_WSLOT + 4 * row;
+    const float* fbase = F8 + hs * 4 * CS + 4 * fpos;
+    if (NKQ == 2) {
+        if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, 9>(acc, wbase, fbase);            // wave-uniform
+        else nf_cc_kloop_fixed<FW, CS, 9, 9>(acc, wbase, fbase);
+    } else {
+        if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, 5>(acc, wbase, fbase);
+        else if (kq == 1) nf_cc_kloop_fixed<FW, CS, 5, 5>(acc, wbase, fbase);
+        else if (kq == 2) nf_cc_kloop_fixed<FW, CS, 10, 4>(acc, wbase, fbase);
+        else nf_cc_kloop_fixed<FW, CS, 14, 4>(acc, wbase, fbase);
+    }
+}
+// the same split for the generic loop: first pair and pair count of quarter kq out of `pairs`
+__device__ __forceinline__ void nf_cc_pair_range(int pairs, int nkq, int kq, int& p0, int& np) {
+    const int base = pairs / nkq, extra = pairs - base * nkq;
+    p0 = __builtin_amdgcn_readfirstlane(kq * base + (kq < extra ? kq : extra));      // wave-uniform: scalar registers
+    np = __builtin_amdgcn_readfirstlane(base + (kq < extra ? 1 : 0));
 }
 
-// 3x3 weights of one chunk of IC (padded ICP, NCG = ICP / 4 quads) input channels, global (32, I, 3, 3) -> W4: lane entries r = ic * 9 + tap
-// (contiguous in global memory for every oc), wave w takes oc = w, w + 16
-struct NfCcW { float v[5][NF_CV_CU]; };
-__device__ __forceinline__ void nf_cc_w_load(NfCcW& w, const float* __restrict__ weight, int I, int i0, int IC, int wid, int lane) {
+// eight K values of one weight row, split into the three planes: one 16-byte store per plane
+__device__ __forceinline__ void nf_cc_w_put8(float* W8, int WPs, int slot, int row, const float (&v)[8]) {
+    bf16x8 h, m, l;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int r = lane + NF_WAVE * j;
-#pragma unroll
-        for (int u = 0; u < NF_CV_CU; ++u) w.v[j][u] = r < IC * 9 ? weight[((wid + u * NF_CV_WAVES) * I + i0) * 9 + r] : 0.f;
+    for (int j = 0; j < 8; j += 2) {
+        bf16x2 h2, m2, l2;
+        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
+        h[j] = h2[0]; h[j + 1] = h2[1];
+        m[j] = m2[0]; m[j + 1] = m2[1];
+        l[j] = l2[0]; l[j + 1] = l2[1];
     }
+    float* p = W8 + slot * NF_CC_WSLOT + 4 * row;
+    *(bf16x8*)(p) = h;
+    *(bf16x8*)(p + WPs) = m;
+    *(bf16x8*)(p + 2 * WPs) = l;
 }
-__device__ __forceinline__ void nf_cc_w_store(const NfCcW& w, float* W4, int ICP, int wid, int lane) {
-    const int RSW = NF_CC_RSW(32), TS = NF_CC_TS(ICP >> 2, 32);
+// 3x3 weights of one chunk of IC (padded to ICP = 8 noct) input channels, global (32, I, 3, 3), as W8 ITEMS: an item is the eight K
+// values of one (slot, row) -- what one lane-half consumes per MFMA -- so staging is eight loads, a split and three 16-byte stores.
+//   forward     K = input channel:  item (oc, octet o, tap) -> slot tap * noct + o, row oc;   values W[oc][i0 + 8 o + j][tap]
+//   transposed  K = output channel: item (octet o, r = ic * 9 + tap) -> slot (8 - tap) * 4 + o, row ic;   values W[8 o + j][i0 + ic][tap]
+//               (lanes run over r: contiguous in global memory for every output channel)
+// 32 * 9 * noct items (<= 1152) over 1024 threads: threads < 128 hold a second one.  Channels beyond IC load zeros.
+struct NfCcW { float v[2][8]; };
+template <bool TR>
+__device__ __forceinline__ void nf_cc_w_load(NfCcW& w, const float* __restrict__ weight, int I, int i0, int IC, int noct) {
+    const int nitems = 32 * 9 * (TR ? 4 : noct);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int r = lane + NF_WAVE * j;
-        const int ic = r / 9, tap = r - ic * 9;
-        if (r < ICP * 9) {                              // entries of the padding channels [IC, ICP) were loaded as zeros
+    for (int t = 0; t < 2; ++t) {
+        const int item = threadIdx.x + NF_CV_THREADS * t;
+        if (TR) {
+            const int o = item / 288, r = item - o * 288;
 #pragma unroll
-            for (int u = 0; u < NF_CV_CU; ++u) W4[tap * TS + (ic >> 2) * RSW + 4 * (wid + u * NF_CV_WAVES) + (ic & 3)] = w.v[j][u];
+            for (int j = 0; j < 8; ++j) w.v[t][j] = (item < nitems && r < IC * 9) ? weight[((8 * o + j) * I + i0) * 9 + r] : 0.f;
+        } else {
+            const int per = 9 * noct;
+            const int oc = item / per, rem = item - oc * per, o = rem / 9, tap = rem - o * 9;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                w.v[t][j] = (item < nitems && 8 * o + j < IC) ? weight[((oc * I + i0 + 8 * o + j) * 9) + tap] : 0.f;
         }
     }
+}
+template <bool TR>
+__device__ __forceinline__ void nf_cc_w_store(const NfCcW& w, float* W8, int WPs, int noct) {
+    const int nitems = 32 * 9 * (TR ? 4 : noct);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int item = threadIdx.x + NF_CV_THREADS * t;
+        if (item < nitems) {
+            if (TR) {
+                const int o = item / 288, r = item - o * 288, ic = r / 9, tap = r - ic * 9;
+                nf_cc_w_put8(W8, WPs, (8 - tap) * 4 + o, ic, w.v[t]);
+            } else {
+                const int per = 9 * noct;
+                const int oc = item / per, rem = item - oc * per, o = rem / 9, tap = rem - o * 9;
+                nf_cc_w_put8(W8, WPs, tap * noct + o, oc, w.v[t]);
+            }
+        }
+    }
+}
+// slot `slot` of all three planes <- 0 (what the half of an odd last pair multiplies with)
+__device__ __forceinline__ void nf_cc_w_zero_slot(float* W8, int WPs, int slot) {
+    if (threadIdx.x < 3 * NF_CC_WSLOT) W8[(threadIdx.x / NF_CC_WSLOT) * WPs + slot * NF_CC_WSLOT + (threadIdx.x % NF_CC_WSLOT)] = 0.f;
 }
 
 // K-split exchange: the NKQ waves of a pixel block each hold a partial 32 x 32 accumulator; wave kq ends up with the TOTAL of
@@ -448,8 +571,9 @@ __device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots,
     return (s == 0 ? 0 : (g.TH + 1) * g.FW) + x + 1;             // frame row 0 / TH + 1, column x + halo
 }
 
-// LDS: two frames F4 [8][CS][4] | W4 | RS (K-split exchange; gather buffer of the grid exchange) | kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
-template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc>
+// LDS: ONE frame F8 (three bf16 planes) | W8 (three planes; aliased by the K-split exchange and the gather buffer of the grid exchange) |
+//      kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
+template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc, bool PK>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      float eps, float mom, NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -462,7 +586,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     float* kc = sm + L.KC;
     float* kb = sm + L.KB;
     float* red = sm + L.RED;
-    const int CS4 = FWc > 0 ? 4 * CSc : 4 * g.CS;       // (a literal in the per-level instantiations)
+    const int CSr = FWc > 0 ? CSc : g.CS;               // (a literal in the per-level instantiations)
+    const int WPs = L.WPs;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
     const int pb = wid % NPB, kq = wid / NPB;
     const int64_t Npx = g.B * g.HW;
@@ -482,11 +607,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     const int npb = nf_cc_valid_px(Npx, tile * PXW + 32 * pb, 32);
     unsigned long long* slots = (unsigned long long*)d.ws_zero;
 
+    constexpr bool packed = PK;                         // compile-time: the weights arrive as LDS images (nf_conv_weight_pack)
     NF_CC_STAMP(0);
-    // ---- zero both frames (halo and padding stay zero for the whole launch) ------------------------------------------------
-    for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
-    float* Fin = sm + L.FA;
-    float* Fout = sm + L.FB;
+    // ---- zero the frame (halo and padding stay zero for the whole launch) ---------------------------------------------------
+    for (int e = threadIdx.x; e < 3 * NF_CC_FP(g.CS); e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
+    float* Fr = sm + L.FA;
     constexpr bool cpl = CPL;                           // the coupling rides the epilogue of the output convolution (d.cp_z != NULL)
     if (cpl) {
         // y <- z for this workgroup's (contiguous) samples, whole 16-byte vectors, no index arithmetic; the transformed half is
@@ -524,11 +649,16 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         const int nchunks = (I0 + 31) / 32;
         const float* in0 = d.x + b0 * I0 * g.HW;
         for (int ch = 0; ch < nchunks; ++ch) {
-            const int i0 = 32 * ch, IC = min(32, I0 - i0), ICP = (IC + 15) & ~15;
+            const int i0 = 32 * ch, IC = min(32, I0 - i0), ICP = (IC + 7) & ~7, noct = ICP >> 3;
             NfCcW wv;
-            nf_cc_w_load(wv, d.w[0], I0, i0, IC, wid, lane);
-            __syncthreads();                            // the previous chunk's readers of Wl / Fin are done (and the zero fill)
-            nf_cc_w_store(wv, Wl, ICP, wid, lane);
+            if (!packed) nf_cc_w_load<false>(wv, d.w[0], I0, i0, IC, noct);
+            __syncthreads();                            // the previous chunk's readers of Wl / the frame are done (and the zero fill)
+            if (packed) {
+                nf_cc_dma_image(Wl, d.wpk[0] + (size_t)ch * NF_CONV_PACK_IMAGE_FLOATS, wid, lane);   // lands under the frame staging
+            } else {
+                nf_cc_w_store<false>(wv, Wl, WPs, noct);
+                if ((9 * noct) & 1) nf_cc_w_zero_slot(Wl, WPs, 9 * noct);
+            }
 #pragma unroll 1
             for (int jj = 0; jj < g.nfj; ++jj) {       // one frame position per lane and trip (register budget, see conv_bn.hip)
                 const int f = lane + NF_WAVE * jj;
@@ -544,16 +674,18 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
 #pragma unroll
                     for (int u = 0; u < NF_CV_CU; ++u) {
                         const int c = wid + u * NF_CV_WAVES;
-                        if (c < ICP) Fin[(c >> 2) * CS4 + 4 * f + (c & 3)] = xa[u];
+                        if (c < ICP) nf_cc_frame_store1(Fr, CSr, c, f, xa[u]);
                     }
                 }
             }
+            if (packed) nf_cc_dma_wait();
             __syncthreads();
-            const int lgg = ICP == 32 ? 2 : 1;          // groups of 8 channels per tap
-            const int ng = 9 << lgg;
-            const int g0 = (kq * ng) / NKQ, g1 = ((kq + 1) * ng) / NKQ;
-            if (FWc > 0 && ICP == 32) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);   // (block-uniform)
-            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(ICP >> 2, 32), NF_CC_RSW(32), CS4, g.FW, lgg, fpos, c32, hs, g0, g1 - g0);
+            if (FWc > 0 && ICP == 32) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fr, fpos, c32, hs, kq);   // (block-uniform)
+            else {
+                int p0, np;
+                nf_cc_pair_range((9 * noct + 1) >> 1, NKQ, kq, p0, np);
+                nf_cc_kloop<9>(acc, Wl, Fr, WPs, CSr, g.FW, noct, fpos, c32, hs, p0, np);
+            }
         }
     }
 
@@ -569,10 +701,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         // next layer's 32 x 32 x 9 weights: loads in flight under the exchanges of this layer
         constexpr bool PREFETCH_W = OWN <= 4;           // OWN = 8 has no registers to spare: it loads at the point of use
         NfCcW wv;
-        if (PREFETCH_W && l < NF_CC_NB - 1) nf_cc_w_load(wv, d.w[l + 1], 32, 0, 32, wid, lane);
+        if (!packed && PREFETCH_W && l < NF_CC_NB - 1) nf_cc_w_load<false>(wv, d.w[l + 1], 32, 0, 32, 4);
         const float cg_ = ng_, cbe_ = nbe_;
         if (threadIdx.x < 32) kb[threadIdx.x] = nb_;
-        __syncthreads();                                // every wave is done with Wl / Fin of this layer; kb is written
+        __syncthreads();                                // every wave is done with Wl / the frame of this layer; kb is written
+        // the next layer's weight image streams into Wl under this layer's exchanges (the 1 x 1's under the last layer's)
+        if (packed && (l < NF_CC_NB - 1 || cpl)) nf_cc_dma_image(Wl, d.wpk[l + 1], wid, lane);   // (the 1 x 1 image has the coupling's row order)
         NF_CC_STAMP(2 + 8 * l);
         nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
         NF_CC_STAMP(3 + 8 * l);
@@ -642,10 +776,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             for (int s2 = 0; s2 < 2; ++s2) {
                 float v = 0.f;
                 const int f = nf_cc_halo_poll(hslots, l, g, (int)tile, y0, s2, v);
-                if (f >= 0) Fout[(c >> 2) * CS4 + 4 * f + (c & 3)] = fmaxf(fmaf(v, kc[c], kc[32 + c]), 0.f);
+                if (f >= 0) nf_cc_frame_store1(Fr, CSr, c, f, fmaxf(fmaf(v, kc[c], kc[32 + c]), 0.f));
             }
         }
-        // normalise + ReLU into the other frame (a lane's values are whole channel quads: one 16-byte store each); next weights into Wl
+        // normalise + ReLU back into the frame, split into the three bf16 planes (a lane's values are whole channel quads: one 8-byte
+        // store per plane); next weights into Wl
 #pragma unroll
         for (int j = 0; j < OWN / 4; ++j) {
             const int c0 = nf_cv_cd_row(OWN * kq + 4 * j, hs);          // channels c0 .. c0 + 3
@@ -654,25 +789,29 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             v.y = pv ? fmaxf(fmaf(own[4 * j + 1], kc[c0 + 1], kc[32 + c0 + 1]), 0.f) : 0.f;
             v.z = pv ? fmaxf(fmaf(own[4 * j + 2], kc[c0 + 2], kc[32 + c0 + 2]), 0.f) : 0.f;
             v.w = pv ? fmaxf(fmaf(own[4 * j + 3], kc[c0 + 3], kc[32 + c0 + 3]), 0.f) : 0.f;
-            *(float4*)(Fout + (c0 >> 2) * CS4 + 4 * fpos) = v;
+            nf_cc_frame_store4(Fr, CSr, c0, fpos, v.x, v.y, v.z, v.w);
         }
-        { float* t = Fin; Fin = Fout; Fout = t; }
         if (l < NF_CC_NB - 1) {
             if (threadIdx.x < 32) { nb_ = d.b[l + 1][threadIdx.x]; ng_ = d.gamma[l + 1][threadIdx.x]; nbe_ = d.beta[l + 1][threadIdx.x]; }
-            if (!PREFETCH_W) nf_cc_w_load(wv, d.w[l + 1], 32, 0, 32, wid, lane);
-            nf_cc_w_store(wv, Wl, 32, wid, lane);
+            if (!packed) {
+                if (!PREFETCH_W) nf_cc_w_load<false>(wv, d.w[l + 1], 32, 0, 32, 4);
+                nf_cc_w_store<false>(wv, Wl, WPs, 4);
+            } else {
+                nf_cc_dma_wait();
+            }
             __syncthreads();
             NF_CC_STAMP(7 + 8 * l);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int ng = 9 * 4;
-            const int g0 = (kq * ng) / NKQ;
-            int gcount = ng / NKQ;
-            // opaque trip count: fully unrolled, the K loop's LDS addresses become loop invariants of the LAYER loop that the
-            // compiler keeps in (and spills from) VGPRs
-            asm volatile("" : "+s"(gcount));
-            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);        // geometry known at compile time
-            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fr, fpos, c32, hs, kq);        // geometry known at compile time
+            else {
+                int p0, np;
+                nf_cc_pair_range(18, NKQ, kq, p0, np);
+                // opaque trip count: fully unrolled, the K loop's LDS addresses become loop invariants of the LAYER loop that the
+                // compiler keeps in (and spills from) VGPRs
+                asm volatile("" : "+s"(np));
+                nf_cc_kloop<9>(acc, Wl, Fr, WPs, CSr, g.FW, 4, fpos, c32, hs, p0, np);
+            }
             NF_CC_STAMP(8 + 8 * l);
         }
     }
@@ -681,16 +820,24 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     // ---- the 1 x 1 output convolution: wave (pb, kq) takes output blocks kq, kq + NKQ, ... ------------------------------------
     // With the coupling fused, the rows are staged interleaved -- row 2 p of block ob = shift channel m = 16 ob + p, row 2 p + 1 =
     // scale channel Ch + m -- so that a lane holds both parameters of the elements it transforms.
-    const int WC = 32 * OCB, RSW5 = NF_CC_RSW(WC);
+    // W8 of the 1 x 1: slot = 4 (output block) + (octet of the input channel), rows = the block's 32 output channels; rows beyond
+    // O_out multiply with zeros
     const int Ch = O_out >> 1;
-    for (int e = threadIdx.x; e < O_out * 32; e += NF_CV_THREADS) {
-        const int oc = e >> 5, ic = e & 31;
-        int row = oc;
+    const bool packed5 = packed && cpl;                 // the packed 1 x 1 image has the row order of the fused coupling
+    if (packed5) nf_cc_dma_wait();
+    for (int e = threadIdx.x; e < (packed5 ? 0 : 32 * OCB * 4); e += NF_CV_THREADS) {
+        const int row = e >> 2, o = e & 3;              // staged row -> the output channel it holds; octet o of its 32 input channels
+        int oc = row;
         if (cpl) {
-            const int m = oc < Ch ? oc : oc - Ch;
-            row = 32 * (m >> 4) + 2 * (m & 15) + (oc < Ch ? 0 : 1);
+            const int m = 16 * (row >> 5) + ((row & 31) >> 1);
+            oc = (row & 1) ? Ch + m : m;
+            if (m >= Ch) oc = O_out;
         }
-        Wl[(ic >> 2) * RSW5 + 4 * row + (ic & 3)] = d.w[5][e];
+        float v[8];
+        const float4 lo = oc < O_out ? *(const float4*)(d.w[5] + oc * 32 + 8 * o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 hi = oc < O_out ? *(const float4*)(d.w[5] + oc * 32 + 8 * o + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        nf_cc_w_put8(Wl, WPs, 4 * (row >> 5) + o, row & 31, v);
     }
     __syncthreads();
     float ls = 0.f;                                     // this lane's part of its sample's sum of scales
@@ -700,7 +847,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         f32x16 a5;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a5[r] = 0.f;
-        nf_cc_kloop<1>(a5, Wl, Fin, 0, RSW5, CS4, g.FW, 2, fpos, 32 * ob + c32, hs, 0, 4);
+        nf_cc_kloop<1>(a5, Wl + 4 * ob * NF_CC_WSLOT, Fr, WPs, CSr, g.FW, 4, fpos, c32, hs, 0, 2);
         if (!cpl) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -791,22 +938,6 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
 // (totals in replica 0 of the zero-initialised replica arrays), G_4 and G_2 (the g_skip operands), and the input gradient.
 // Transposed convolutions reuse the forward K loop: the weights are staged as W4T[8 - tap][oc quad][ic][4].
 // =====================================================================================================================================
-__device__ __forceinline__ void nf_cc_wT_store(const NfCcW& w, float* W4, int wid, int lane) {
-    const int RSW = NF_CC_RSW(32), TS = NF_CC_TS(8, 32);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int r = lane + NF_WAVE * j;
-        const int ic = r / 9, tap = r - ic * 9;
-        if (r < 32 * 9) {                               // rows beyond the chunk's channels were loaded as zeros
-#pragma unroll
-            for (int u = 0; u < NF_CV_CU; ++u) {
-                const int oc = wid + u * NF_CV_WAVES;
-                W4[(8 - tap) * TS + (oc >> 2) * RSW + 4 * ic + (oc & 3)] = w.v[j][u];
-            }
-        }
-    }
-}
-
 // plain sums of two sets of OWN per-lane values over the 32 lanes of a wave half (halving butterfly, see nf_cc_half_stats)
 template <int OWN>
 __device__ __forceinline__ void nf_cc_half_sums2(const float (&u)[OWN], const float (&v)[OWN], int c32, float& S1, float& S2, int& which) {
@@ -892,7 +1023,7 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
     return tot;
 }
 
-template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc>
+template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc, bool PK>
 __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_bwd_desc d, NfCvGeo g, int I0, int O_out, int training,
                                                                      NfSplit cs) {
     static_assert(NPB * NKQ == NF_CV_WAVES, "sixteen waves");
@@ -903,7 +1034,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     float* RS = sm + L.RS;
     float* kc = sm + L.KC;
     float* red = sm + L.RED;
-    const int CS4 = FWc > 0 ? 4 * CSc : 4 * g.CS;       // (a literal in the per-level instantiations)
+    const int CSr = FWc > 0 ? CSc : g.CS;               // (a literal in the per-level instantiations)
+    const int WPs = L.WPs;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
     const int pb = wid % NPB, kq = wid / NPB;
     const int64_t Npx = g.B * g.HW;
@@ -922,10 +1054,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     unsigned long long* hslots = halo ? slots + NF_CC_STAT_SLOTS : nullptr;
     float gstream_h[2] = {0.f, 0.f};                    // halo rows of the residual stream's gradient (threads < 32 W)
 
-    for (int e = threadIdx.x; e < 2 * 32 * g.CS; e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
-    float* Fin = sm + L.FA;
-    float* Fout = sm + L.FB;
+    for (int e = threadIdx.x; e < 3 * NF_CC_FP(g.CS); e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
+    float* Fr = sm + L.FA;                              // ONE frame: G_l is written over G_{l+1} after every wave has left the K loop
     const bool bnv = L.BNV >= 0;                        // block-uniform
+    constexpr bool packed = PK;                         // compile-time: transposed weight images (nf_conv_weight_pack)
+    const int nch0 = (I0 + 31) / 32;                    // a 3 x 3 layer's buffer: its forward images, then the transposed ones
+    if (packed) nf_cc_dma_image(Wl, d.wpk[5] + NF_CONV_PACK_IMAGE_FLOATS, wid, lane);
     if (bnv && threadIdx.x < NF_CC_NB * 128) {          // [layer][mean | invstd | gamma | beta][32]; first read after the barrier below
         const int l2 = threadIdx.x >> 7, j = (threadIdx.x >> 5) & 3, k = threadIdx.x & 31;
         const float* src = j == 0 ? d.save_mean[l2] : (j == 1 ? d.save_invstd[l2] : (j == 2 ? d.gamma[l2] : d.beta[l2]));
@@ -943,55 +1077,61 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     {
-        const int ng = (O_out + 7) >> 3;
-        for (int e = threadIdx.x; e < ng * 8 * 32; e += NF_CV_THREADS) {
-            const int oc = e >> 5, ic = e & 31;
-            Wl[(oc >> 2) * NF_CC_RSW(32) + 4 * ic + (oc & 3)] = oc < O_out ? d.w[5][e] : 0.f;
+        const int npair = (O_out + 15) >> 4;            // pairs of octets of the K axis (= output channels of the 1 x 1)
+        if (packed) nf_cc_dma_wait();
+        for (int e = threadIdx.x; e < (packed ? 0 : npair * 2 * 32); e += NF_CV_THREADS) {
+            const int o = e >> 5, ic = e & 31;          // W8T[plane][octet o of the output channel][ic][oc & 7]
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 8 * o + j < O_out ? d.w[5][(8 * o + j) * 32 + ic] : 0.f;
+            nf_cc_w_put8(Wl, WPs, o, ic, v);
         }
         __syncthreads();
-        const int g0 = (kq * ng) / NKQ, g1 = ((kq + 1) * ng) / NKQ;
+        int p0, np;
+        nf_cc_pair_range(npair, NKQ, kq, p0, np);
         const float* go = cpl ? nullptr : d.g_out + b * O_out * g.HW + q;
         const float gl = (cpl && pv) ? d.cp_g_ld[b] : 0.f;
 #pragma unroll 1
-        for (int gi = g0; gi < g1; gi += 4) {
-            float bv[4][4];
+        for (int pi = p0; pi < p0 + np; ++pi) {
+            float bv[8];                                // this lane's eight K values: output channels 16 pi + 8 hs + j of its pixel
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int oc = 8 * (gi + k) + 4 * hs + j;
-                    const bool ok = gi + k < g1 && pv && oc < O_out;
-                    float v = 0.f;
-                    if (!cpl) {
-                        v = ok ? go[(int64_t)oc * g.HW] : 0.f;
-                    } else if (ok) {                    // the coupling's backward produces the conditioner's output gradient on the fly
-                        const bool is_s = oc >= Ch;
-                        const int m = is_s ? oc - Ch : oc;
-                        const int64_t o = b * cs.n_full + nf_cc_half_to_full(cs, 0, m, (int)q, lgw);
-                        const float gy0 = d.cp_g_y[o];
-                        v = gy0;                        // gradient of the shift
-                        if (is_s) {                     // cp_out = [exp(s) | tanh(raw)], left by the forward launch
-                            const float th = d.cp_out[(b * O_out + oc) * g.HW + q];
-                            const float es = d.cp_out[(b * O_out + m) * g.HW + q];
-                            d.cp_g_z[o] = gy0 * es;
-                            const float gs = gy0 * d.cp_z[o] * es + gl;
-                            v = gs * ca * (1.f - th * th);
-                            acc_a += gs * th;
-                            acc_c += gs;
-                        }
-                        d.cp_g_out[(b * O_out + oc) * g.HW + q] = v;   // the deferred weight-gradient pass of the 1 x 1 convolution reads it
+            for (int j = 0; j < 8; ++j) {
+                const int oc = 16 * pi + 8 * hs + j;
+                const bool ok = pv && oc < O_out;
+                float v = 0.f;
+                if (!cpl) {
+                    v = ok ? go[(int64_t)oc * g.HW] : 0.f;
+                } else if (ok) {                        // the coupling's backward produces the conditioner's output gradient on the fly
+                    const bool is_s = oc >= Ch;
+                    const int m = is_s ? oc - Ch : oc;
+                    const int64_t o = b * cs.n_full + nf_cc_half_to_full(cs, 0, m, (int)q, lgw);
+                    const float gy0 = d.cp_g_y[o];
+                    v = gy0;                            // gradient of the shift
+                    if (is_s) {                         // cp_out = [exp(s) | tanh(raw)], left by the forward launch
+                        const float th = d.cp_out[(b * O_out + oc) * g.HW + q];
+                        const float es = d.cp_out[(b * O_out + m) * g.HW + q];
+                        d.cp_g_z[o] = gy0 * es;
+                        const float gs = gy0 * d.cp_z[o] * es + gl;
+                        v = gs * ca * (1.f - th * th);
+                        acc_a += gs * th;
+                        acc_c += gs;
                     }
-                    bv[k][j] = v;
+                    d.cp_g_out[(b * O_out + oc) * g.HW + q] = v;   // the deferred weight-gradient pass of the 1 x 1 convolution reads it
                 }
+                bv[j] = v;
+            }
+            bf16x8 bh, bm, bl;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (gi + k < g1) {                      // wave-uniform
-                    const float4 a = *(const float4*)(Wl + (2 * (gi + k) + hs) * NF_CC_RSW(32) + 4 * c32);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[k][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[k][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[k][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[k][3], acc, 0, 0, 0);
-                }
+            for (int j = 0; j < 8; j += 2) {
+                bf16x2 h2, m2, l2;
+                nf_cc_split2(f32x2{bv[j], bv[j + 1]}, h2, m2, l2);
+                bh[j] = h2[0]; bh[j + 1] = h2[1];
+                bm[j] = m2[0]; bm[j + 1] = m2[1];
+                bl[j] = l2[0]; bl[j + 1] = l2[1];
+            }
+            const float* wa = Wl + (2 * pi + hs) * NF_CC_WSLOT + 4 * c32;
+            const bf16x8 ah = *(const bf16x8*)(wa), am = *(const bf16x8*)(wa + WPs), al = *(const bf16x8*)(wa + 2 * WPs);
+            NF_CC_MFMA6(ah, am, al, bh, bm, bl);
         }
         if (cpl) {                                      // gradients of the coupling's two scalars: wave sums now, one atomic pair per workgroup below
 #pragma unroll
@@ -1036,6 +1176,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             if (y0 + g.TH < g.H) a_h[1] = d.acts[l][(b0 * 32 + c) * g.HW + (y0 + g.TH) * g.W + x];
         }
         __syncthreads();                                // every wave is done with Wl / the frames of the K loop; kc is written
+        // the transposed weights of the convolution at the end of this iteration stream into Wl under the exchange
+        if (packed) {
+            if (l >= 1) nf_cc_dma_image(Wl, d.wpk[l] + NF_CONV_PACK_IMAGE_FLOATS, wid, lane);
+            else if (d.g_x != nullptr || cpl) nf_cc_dma_image(Wl, d.wpk[0] + (size_t)nch0 * NF_CONV_PACK_IMAGE_FLOATS, wid, lane);
+        }
         if (cpl && l == NF_CC_NB - 1 && threadIdx.x == 0) {
             float ta = 0.f, tc = 0.f;
             for (int k = 0; k < NF_CV_WAVES; ++k) { ta += red[k]; tc += red[NF_CV_WAVES + k]; }
@@ -1092,7 +1237,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                         const float xhh = (a_h[s2] - kc[64 + c]) * kc[96 + c];
                         float G = kc[c] * (v - mgc - xhh * mgxc);
                         if ((l & 1) == 0) { G += gstream_h[s2]; gstream_h[s2] = G; }
-                        Fout[(c >> 2) * CS4 + 4 * f + (c & 3)] = G;
+                        nf_cc_frame_store1(Fr, CSr, c, f, G);
                     }
                 }
             }
@@ -1113,22 +1258,26 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
 #pragma unroll
         for (int j = 0; j < OWN / 4; ++j) {
             const int c0 = nf_cv_cd_row(OWN * kq + 4 * j, hs);
-            *(float4*)(Fout + (c0 >> 2) * CS4 + 4 * fpos) = make_float4(own[4 * j], own[4 * j + 1], own[4 * j + 2], own[4 * j + 3]);
+            nf_cc_frame_store4(Fr, CSr, c0, fpos, own[4 * j], own[4 * j + 1], own[4 * j + 2], own[4 * j + 3]);
         }
-        { float* t = Fin; Fin = Fout; Fout = t; }
         if (l >= 1) {                                   // transposed 3 x 3 convolution l: G_l -> layer l - 1
-            NfCcW wv;
-            nf_cc_w_load(wv, d.w[l], 32, 0, 32, wid, lane);
-            nf_cc_wT_store(wv, Wl, wid, lane);
+            if (!packed) {
+                NfCcW wv;
+                nf_cc_w_load<true>(wv, d.w[l], 32, 0, 32, 4);
+                nf_cc_w_store<true>(wv, Wl, WPs, 4);
+            } else {
+                nf_cc_dma_wait();
+            }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int ng = 9 * 4;
-            const int g0 = (kq * ng) / NKQ;
-            int gcount = ng / NKQ;
-            asm volatile("" : "+s"(gcount));            // see the forward kernel
-            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);        // geometry known at compile time
-            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fr, fpos, c32, hs, kq);        // geometry known at compile time
+            else {
+                int p0, np;
+                nf_cc_pair_range(18, NKQ, kq, p0, np);
+                asm volatile("" : "+s"(np));            // see the forward kernel
+                nf_cc_kloop<9>(acc, Wl, Fr, WPs, CSr, g.FW, 4, fpos, c32, hs, p0, np);
+            }
         }
     }
 
@@ -1136,17 +1285,17 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     if (d.g_x != nullptr || cpl) {
         for (int i0 = 0; i0 < I0; i0 += 32) {
             const int IC = min(32, I0 - i0);
-            NfCcW wv;
-            nf_cc_w_load(wv, d.w[0], I0, i0, IC, wid, lane);
-            __syncthreads();                            // readers of Wl / RS of the previous pass are done
-            nf_cc_wT_store(wv, Wl, wid, lane);
+            if (!packed) {
+                NfCcW wv;
+                nf_cc_w_load<true>(wv, d.w[0], I0, i0, IC, 4);
+                __syncthreads();                        // readers of Wl / RS of the previous pass are done
+                nf_cc_w_store<true>(wv, Wl, WPs, 4);
+            } else {
+                nf_cc_dma_wait();                       // (chunk 0 was requested in the l = 0 iteration, the others behind the previous K loop)
+            }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int ng = 9 * 4;
-            const int g0 = (kq * ng) / NKQ;
-            int gcount = ng / NKQ;
-            asm volatile("" : "+s"(gcount));
             float gyv[OWN];                             // pass-through gradient of the untouched half: in flight under the K loop
             if (cpl) {
 #pragma unroll
@@ -1155,9 +1304,15 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                     gyv[rr] = (pv && ic < IC) ? d.cp_g_y[b * cs.n_full + nf_cc_half_to_full(cs, 1, i0 + ic, (int)q, lgw)] : 0.f;
                 }
             }
-            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fin, fpos, c32, hs, kq);        // geometry known at compile time
-            else nf_cc_kloop<9>(acc, Wl, Fin, NF_CC_TS(8, 32), NF_CC_RSW(32), CS4, g.FW, 2, fpos, c32, hs, g0, gcount);
+            if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fr, fpos, c32, hs, kq);        // geometry known at compile time
+            else {
+                int p0, np;
+                nf_cc_pair_range(18, NKQ, kq, p0, np);
+                asm volatile("" : "+s"(np));
+                nf_cc_kloop<9>(acc, Wl, Fr, WPs, CSr, g.FW, 4, fpos, c32, hs, p0, np);
+            }
             __syncthreads();
+            if (packed && i0 + 32 < I0) nf_cc_dma_image(Wl, d.wpk[0] + (size_t)(nch0 + (i0 >> 5) + 1) * NF_CONV_PACK_IMAGE_FLOATS, wid, lane);
             nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
 #pragma unroll
             for (int rr = 0; rr < OWN; ++rr) {
@@ -1170,6 +1325,77 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             }
         }
     }
+}
+
+// =====================================================================================================================================
+// nf_conv_weight_pack: effective weights -> LDS images of the split form (layouts in the header of this file / include/nfhip.h)
+// =====================================================================================================================================
+struct NfCcPackArgs { nf_conv_pack_desc d[NF_CONV_PACK_MAX_LAYERS]; };
+__host__ __device__ static inline int nf_cc_pack_images(int O, int I, int ksize) {
+    if (ksize == 3 && O == 32 && I >= 1 && I <= NF_CV_MAX_I) return 2 * ((I + 31) / 32);
+    if (ksize == 1 && I == 32 && O >= 2 && O <= NF_CV_MAX_O && (O & 1) == 0) return 2;
+    return 0;
+}
+// grid (images of the largest layer, layers), 256 threads: an image is 36 x 32 items of eight K values
+__global__ void __launch_bounds__(256) k_conv_weight_pack(NfCcPackArgs a) {
+    const nf_conv_pack_desc d = a.d[blockIdx.y];
+    const int nimg = nf_cc_pack_images(d.O, d.I, d.ksize);
+    const int img = blockIdx.x;
+    if (img >= nimg) return;
+    float* dst = d.dst + (size_t)img * NF_CONV_PACK_IMAGE_FLOATS;
+    constexpr int WPs = NF_CC_WSLOTS * NF_CC_WSLOT;
+    const bool tr = img >= nimg / 2;
+    const int ch = tr ? img - nimg / 2 : img;
+    for (int item = threadIdx.x; item < NF_CC_WSLOTS * 32; item += 256) {
+        const int slot = item >> 5, row = item & 31;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (d.ksize == 3) {
+            const int i0 = 32 * ch, IC = min(32, d.I - i0);
+            if (!tr) {                                  // slot = tap * noct + o, row = oc, K = input channel i0 + 8 o + j
+                const int noct = (IC + 7) >> 3;
+                const int tap = slot / noct, o = slot - tap * noct;
+                if (tap < 9)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (8 * o + j < IC) v[j] = d.w[((size_t)row * d.I + i0 + 8 * o + j) * 9 + tap];
+            } else {                                    // slot = (8 - tap) * 4 + o, row = ic, K = output channel 8 o + j
+                const int tap = 8 - (slot >> 2), o = slot & 3;
+                if (row < IC)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = d.w[((size_t)(8 * o + j) * d.I + i0 + row) * 9 + tap];
+            }
+        } else if (!tr) {                               // 1 x 1 forward, the fused coupling's row order: slot = 4 ob + o
+            const int ob = slot >> 2, o = slot & 3, Ch = d.O >> 1;
+            const int m = 16 * ob + (row >> 1), oc = (row & 1) ? Ch + m : m;
+            if (m < Ch)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = d.w[(size_t)oc * 32 + 8 * o + j];
+        } else {                                        // 1 x 1 transposed: slot = octet of the output channel, row = ic
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (8 * slot + j < d.O) v[j] = d.w[(size_t)(8 * slot + j) * 32 + row];
+        }
+        nf_cc_w_put8(dst, WPs, slot, row, v);
+    }
+}
+
+extern "C" int nf_conv_weight_pack_images(int O, int I, int ksize) { return nf_cc_pack_images(O, I, ksize); }
+
+extern "C" int nf_conv_weight_pack(const nf_conv_pack_desc* descs, int n, nf_stream_t stream) {
+    if (descs == nullptr || n < 1 || n > NF_CONV_PACK_MAX_LAYERS) return NF_E_BADARG;
+    NfCcPackArgs a;
+    int most = 0;
+    for (int i = 0; i < n; ++i) {
+        const int k = nf_cc_pack_images(descs[i].O, descs[i].I, descs[i].ksize);
+        if (k == 0 || descs[i].w == nullptr || descs[i].dst == nullptr) return NF_E_BADARG;
+        if (k > most) most = k;
+        a.d[i] = descs[i];
+    }
+    hipLaunchKernelGGL(k_conv_weight_pack, dim3((unsigned)most, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    NF_CHECK_LAUNCH();
+    return 0;
 }
 
 template <typename K>
@@ -1260,17 +1486,22 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     const bool cp = desc->cp_z != nullptr;
-#define NF_CC_FWD(NPB_, NKQ_, HALO_, CP_, FW_, CS_)                                                                                         \
+    bool pk = desc->wpk[0] != nullptr;                  // all six images or none
+    for (int i = 1; i < NF_CC_NL; ++i)
+        if ((desc->wpk[i] != nullptr) != pk) return NF_E_BADARG;
+#define NF_CC_FWD(NPB_, NKQ_, HALO_, CP_, FW_, CS_, PK_)                                                                                    \
     do {                                                                                                                                    \
-        rc = nf_cc_optin(k_convnet_chain_fwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>);                                                            \
+        rc = nf_cc_optin(k_convnet_chain_fwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_, PK_>);                                                       \
         if (rc == 0)                                                                                                                        \
-            hipLaunchKernelGGL((k_convnet_chain_fwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS),       \
+            hipLaunchKernelGGL((k_convnet_chain_fwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_, PK_>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS),  \
                                (nf_cc_lds_bytes<NPB_, NKQ_>(g, OCB)), st, *desc, g, I0, O_out, training, bn_eps, bn_momentum, cs);          \
     } while (0)
 #define NF_CC_FWD2(NPB_, NKQ_, HALO_, FW_, CS_)                                                                                             \
     do {                                                                                                                                    \
-        if (cp) NF_CC_FWD(NPB_, NKQ_, HALO_, true, FW_, CS_);                                                                               \
-        else NF_CC_FWD(NPB_, NKQ_, HALO_, false, FW_, CS_);                                                                                 \
+        if (cp && pk) NF_CC_FWD(NPB_, NKQ_, HALO_, true, FW_, CS_, true);                                                                   \
+        else if (cp) NF_CC_FWD(NPB_, NKQ_, HALO_, true, FW_, CS_, false);                                                                   \
+        else if (pk) NF_CC_FWD(NPB_, NKQ_, HALO_, false, FW_, CS_, true);                                                                   \
+        else NF_CC_FWD(NPB_, NKQ_, HALO_, false, FW_, CS_, false);                                                                          \
     } while (0)
     // one instantiation per level of the CIFAR pyramid (frame width / channel stride as compile-time constants), a generic one for the rest
     if (PX == 256) NF_CC_FWD2(8, 2, false, 0, 0);
@@ -1306,17 +1537,22 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     const bool cp = desc->cp_g_y != nullptr;
-#define NF_CC_BWD(NPB_, NKQ_, HALO_, CP_, FW_, CS_)                                                                                         \
+    bool pk = desc->wpk[0] != nullptr;
+    for (int i = 1; i < NF_CC_NL; ++i)
+        if ((desc->wpk[i] != nullptr) != pk) return NF_E_BADARG;
+#define NF_CC_BWD(NPB_, NKQ_, HALO_, CP_, FW_, CS_, PK_)                                                                                    \
     do {                                                                                                                                    \
-        rc = nf_cc_optin(k_convnet_chain_bwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>);                                                            \
+        rc = nf_cc_optin(k_convnet_chain_bwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_, PK_>);                                                       \
         if (rc == 0)                                                                                                                        \
-            hipLaunchKernelGGL((k_convnet_chain_bwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS),       \
+            hipLaunchKernelGGL((k_convnet_chain_bwd<NPB_, NKQ_, HALO_, CP_, FW_, CS_, PK_>), dim3((unsigned)g.tiles), dim3(NF_CV_THREADS),  \
                                (nf_cc_lds_bytes<NPB_, NKQ_>(g, 1)), st, *desc, g, I0, O_out, training, cs);                                 \
     } while (0)
 #define NF_CC_BWD2(NPB_, NKQ_, HALO_, FW_, CS_)                                                                                             \
     do {                                                                                                                                    \
-        if (cp) NF_CC_BWD(NPB_, NKQ_, HALO_, true, FW_, CS_);                                                                               \
-        else NF_CC_BWD(NPB_, NKQ_, HALO_, false, FW_, CS_);                                                                                 \
+        if (cp && pk) NF_CC_BWD(NPB_, NKQ_, HALO_, true, FW_, CS_, true);                                                                   \
+        else if (cp) NF_CC_BWD(NPB_, NKQ_, HALO_, true, FW_, CS_, false);                                                                   \
+        else if (pk) NF_CC_BWD(NPB_, NKQ_, HALO_, false, FW_, CS_, true);                                                                   \
+        else NF_CC_BWD(NPB_, NKQ_, HALO_, false, FW_, CS_, false);                                                                          \
     } while (0)
     if (PX == 256) NF_CC_BWD2(8, 2, false, 0, 0);
     else if (H * W > PX) {

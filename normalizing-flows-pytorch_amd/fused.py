@@ -1703,6 +1703,8 @@ def weight_norm_all(wn_modules):
     outs = _WeightNormMulti.apply(eps, *tensors)
     for m, w in zip(wn_modules, outs):
         m._w_eff = w
+    from .fused_conv import pack_conv_weights
+    pack_conv_weights(wn_modules, outs)               # the chain kernels' LDS images of these weights (three-way bf16 split)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

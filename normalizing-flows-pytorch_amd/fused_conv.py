@@ -50,7 +50,7 @@ class ConvNetDesc(ctypes.Structure):
                 ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('ws_zero', ctypes.c_void_p),
                 ('cp_z', ctypes.c_void_p), ('cp_y', ctypes.c_void_p), ('cp_ld', ctypes.c_void_p), ('cp_a', ctypes.c_void_p),
                 ('cp_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int), ('cp_C', ctypes.c_int),
-                ('cp_inverse', ctypes.c_int)]
+                ('cp_inverse', ctypes.c_int), ('wpk', ctypes.c_void_p * 6)]
 
 
 class ConvNetBwdDesc(ctypes.Structure):
@@ -63,7 +63,59 @@ class ConvNetBwdDesc(ctypes.Structure):
                 ('cp_g_y', ctypes.c_void_p), ('cp_g_ld', ctypes.c_void_p), ('cp_z', ctypes.c_void_p), ('cp_out', ctypes.c_void_p),
                 ('cp_a', ctypes.c_void_p), ('cp_c', ctypes.c_void_p), ('cp_g_z', ctypes.c_void_p), ('cp_g_out', ctypes.c_void_p),
                 ('cp_g_a', ctypes.c_void_p), ('cp_g_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int),
-                ('cp_C', ctypes.c_int), ('cp_reserved', ctypes.c_int), ('g_gamma', ctypes.c_void_p * 5), ('g_beta', ctypes.c_void_p * 5)]
+                ('cp_C', ctypes.c_int), ('cp_reserved', ctypes.c_int), ('g_gamma', ctypes.c_void_p * 5), ('g_beta', ctypes.c_void_p * 5),
+                ('wpk', ctypes.c_void_p * 6)]
+
+
+class ConvPackDesc(ctypes.Structure):
+    """nf_conv_pack_desc of include/nfhip.h"""
+    _fields_ = [('w', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('O', ctypes.c_int), ('I', ctypes.c_int), ('ksize', ctypes.c_int),
+                ('reserved', ctypes.c_int)]
+
+
+CONV_PACK_ON = __import__('os').environ.get('NF_CONV_PACK', '1') != '0'
+
+
+def pack_conv_weights(wn_modules, w_effs):
+    """The chain kernels read their weights as LDS images of the three-way bf16 split (csrc/conv_chain.hip): written here once per
+    pass for every weight-normed convolution whose shape the kernels take (nf_conv_weight_pack, 64 layers per launch), into one
+    persistent buffer per module (static addresses: hipGraph-safe).  A conditioner uses its images only while they belong to the
+    effective weights of the pass under way (``_w_pack_of is _w_eff``)."""
+    if not CONV_PACK_ON:
+        return
+    lib = N.load()
+    img = N.header_constant('NF_CONV_PACK_IMAGE_FLOATS')
+    step = N.header_constant('NF_CONV_PACK_MAX_LAYERS')
+    descs = []
+    for m, w in zip(wn_modules, w_effs):
+        if not (w.is_cuda and w.dim() == 4 and w.dtype == torch.float32 and w.is_contiguous()):
+            continue
+        n = getattr(m, '_w_pack_n', None)
+        if n is None:
+            n = m._w_pack_n = int(lib.nf_conv_weight_pack_images(w.shape[0], w.shape[1], w.shape[2]))
+        if n == 0:
+            continue
+        buf = getattr(m, '_w_pack', None)
+        if buf is None or buf.device != w.device:
+            buf = m._w_pack = torch.empty(n * img, dtype=torch.float32, device=w.device)
+        m._w_pack_of = w
+        descs.append(ConvPackDesc(w.data_ptr(), buf.data_ptr(), w.shape[0], w.shape[1], w.shape[2], 0))
+    for k0 in range(0, len(descs), step):
+        chunk = descs[k0:k0 + step]
+        arr = (ConvPackDesc * len(chunk))(*chunk)
+        N.call('nf_conv_weight_pack', ctypes.addressof(arr), len(chunk), N.stream())
+
+
+def _convnet_packs(net):
+    """the six weight-image buffers of a ConvNet if all of them belong to the pass under way, else None"""
+    convs, _ = _convnet_modules(net)
+    packs = []
+    for c in convs:
+        w = getattr(c, '_w_eff', None)
+        if w is None or getattr(c, '_w_pack_of', None) is not w:
+            return None
+        packs.append(c._w_pack)
+    return tuple(packs)
 
 
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
@@ -292,7 +344,7 @@ def _convnet_tensors(net):
     return tensors
 
 
-def _cn_forward(ctx, x, training, defer, tensors, cpl=None):
+def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
     """forward of the conditioner; ``cpl`` = (z, ld, a, c, mode, odd, inverse): the affine coupling it parameterises rides the
     epilogue of the chain launch (returns y; ld is updated in place), else returns the conditioner's output."""
     nl, nb = 6, 5
@@ -329,6 +381,9 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None):
             d.acts[j] = acts[j].data_ptr()
             d.save_mean[j], d.save_invstd[j] = ws[j, 2 * R].data_ptr(), ws[j, 2 * R + 1].data_ptr()
         d.out = out.data_ptr()
+        if packs is not None:
+            for i in range(nl):
+                d.wpk[i] = packs[i].data_ptr()
         # (the slots' tensor must outlive every allocation up to the launch: a freed block is handed to the next torch.empty)
         nws = _chain_ws_floats(B, I0, O_out, Hh, Ww)
         need = training or nws > N.header_constant('NF_CONVNET_WS_FLOATS')           # (halo hand-over: in evaluation mode too)
@@ -358,6 +413,7 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None):
         ctx.cpl_sinks = _sinks(cpl[2], cpl[3])
     ctx.save_for_backward(x, ws, *acts, *w, *[t for b in bns for t in b[:2]], *extra)
     ctx.meta = (shape, I0, O_out, bool(training))
+    ctx.packs = packs
     ctx.sinks = _sinks(*[c[1] for c in conv], *[t for b in bns for t in b[:2]])
     ctx.defer = bool(defer) and ctx.sinks is not None
     return out if cpl is None else y
@@ -370,13 +426,13 @@ class _FusedConvNet(torch.autograd.Function):
     num_batches_tracked) * 5."""
 
     @staticmethod
-    def forward(ctx, x, training, defer, *tensors):
-        return _cn_forward(ctx, x, training, defer, tensors)
+    def forward(ctx, x, training, defer, packs, *tensors):
+        return _cn_forward(ctx, x, training, defer, tensors, packs=packs)
 
     @staticmethod
     def backward(ctx, g_out):
         lead, grads = _cn_backward(ctx, g_out)
-        return (lead[0], None, None) + grads
+        return (lead[0], None, None, None) + grads
 
 
 class _FusedConvCoupling(torch.autograd.Function):
@@ -387,15 +443,15 @@ class _FusedConvCoupling(torch.autograd.Function):
     gradient of x is reported as None (it is contained in that of z)."""
 
     @staticmethod
-    def forward(ctx, z, x, ld, a, c, mode, odd, training, defer, *tensors):
-        y = _cn_forward(ctx, x, training, defer, tensors, cpl=(z, ld, a, c, mode, odd, 0))
+    def forward(ctx, z, x, ld, a, c, mode, odd, training, defer, packs, *tensors):
+        y = _cn_forward(ctx, x, training, defer, tensors, cpl=(z, ld, a, c, mode, odd, 0), packs=packs)
         ctx.mark_dirty(ld)
         return y, ld
 
     @staticmethod
     def backward(ctx, g_y, g_ld):
         (g_z, g_a, g_c), grads = _cn_backward(ctx, None, cpl_grads=(g_y.contiguous(), g_ld.contiguous()))
-        return (g_z, None, g_ld, g_a, g_c, None, None, None, None) + grads
+        return (g_z, None, g_ld, g_a, g_c, None, None, None, None, None) + grads
 
 
 def _cn_backward(ctx, g_out, cpl_grads=None):
@@ -464,6 +520,9 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         d.g_out = g_out.data_ptr()
         d.g_store[0], d.g_store[1] = stores[0].data_ptr(), stores[1].data_ptr()
         d.g_x = g_x.data_ptr() if g_x is not None else None
+        if getattr(ctx, 'packs', None) is not None:
+            for i in range(nl):
+                d.wpk[i] = ctx.packs[i].data_ptr()
         slots = WS.zeros(_chain_ws_floats(B, I0, O_out, Hh, Ww), dev)        # (kept alive up to the launch, see the forward)
         d.ws_zero = slots.data_ptr()
         if ctx.sinks is not None:                   # BatchNorm parameter gradients: added by the launch itself
@@ -535,7 +594,7 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
 def convnet_forward(net, x):
     """``net``: conditioners.ConvNet; returns the conditioner output (B, out_channels, H, W)."""
     tensors = _convnet_tensors(net)
-    return _FusedConvNet.apply(x, net.training, CONV_DEFER.usable(tensors[0:12:2]), *tensors)
+    return _FusedConvNet.apply(x, net.training, CONV_DEFER.usable(tensors[0:12:2]), _convnet_packs(net), *tensors)
 
 
 def coupling_fusable(net, z, mode):
@@ -574,6 +633,7 @@ def convnet_coupling(net, x, z, ld, a, c, mode, odd, inverse=False):
             class _Ctx:                                   # no graph: nothing is kept
                 def save_for_backward(self, *t):
                     pass
-            y = _cn_forward(_Ctx(), x, net.training, False, tensors, cpl=(z, ld, a, c, mode, odd, int(inverse)))
+            y = _cn_forward(_Ctx(), x, net.training, False, tensors, cpl=(z, ld, a, c, mode, odd, int(inverse)), packs=_convnet_packs(net))
         return y, ld
-    return _FusedConvCoupling.apply(z, x, ld, a, c, mode, odd, net.training, CONV_DEFER.usable(tensors[0:12:2]), *tensors)
+    return _FusedConvCoupling.apply(z, x, ld, a, c, mode, odd, net.training, CONV_DEFER.usable(tensors[0:12:2]), _convnet_packs(net),
+                                    *tensors)

@@ -239,3 +239,47 @@ def test_cifar_glow_with_and_without_the_fused_heads(pkg, monkeypatch):
         assert p1.grad is not None, n
         worst = max(worst, float((p1.grad - p2.grad).abs().max()) / max(1.0, float(p2.grad.abs().max())))
     assert worst < 2e-2, worst                          # (a ReLU flip between the two roundings moves a conditioner's gradients)
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('I,O,H,W,B', [(6, 12, 16, 16, 64), (24, 48, 8, 8, 64), (96, 192, 4, 4, 64), (24, 48, 8, 8, 5), (6, 12, 16, 16, 3)])
+def test_packed_weight_images_give_the_same_bits(pkg, I, O, H, W, B, training):
+    """The chain kernels take a layer's weights either as effective fp32 weights (every workgroup splits them into the three bf16 planes
+    itself) or as the LDS images nf_conv_weight_pack wrote once for the pass (direct global -> LDS loads under the previous layer's
+    exchanges: the path a model takes).  Same split, same products, same order: outputs and gradients must agree BITWISE, with the
+    fused coupling (the packed 1 x 1 image has the coupling's row order) and without."""
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    cond = importlib.import_module(pkg.__name__ + '.conditioners')
+    N = pkg._native
+    if not fc._chain_usable(B, I, O, H, W):
+        pytest.skip('shape outside the chain kernels')
+    results = []
+    for use_pack in (False, True):
+        a, _ = _nets(pkg, I, O)
+        a.train(training)
+        wns = [m for m in a.modules() if isinstance(m, cond.WeightNorm)]
+        torch.manual_seed(3)
+        x = torch.randn(B, I, H, W, device=DEV, requires_grad=True)
+        with torch.no_grad():
+            effs = [m.effective_weight().contiguous() for m in wns]
+        for m, w in zip(wns, effs):
+            m._w_eff = w.clone().requires_grad_(True)
+        if use_pack:
+            fc.pack_conv_weights(wns, [m._w_eff for m in wns])
+            assert fc._convnet_packs(a) is not None
+        else:
+            assert fc._convnet_packs(a) is None
+        y = fc.convnet_forward(a, x)
+        g = torch.randn(y.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        y.backward(g)
+        torch.cuda.synchronize()
+        results.append((y.detach().clone(), x.grad.detach().clone(), [m._w_eff.grad.detach().clone() for m in wns],
+                        [bn.weight.grad.detach().clone() for bn in a.modules() if isinstance(bn, torch.nn.BatchNorm2d)]))
+        for m in wns:
+            m._w_eff = None
+    (y0, gx0, gw0, gb0), (y1, gx1, gw1, gb1) = results
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    assert torch.equal(gx0, gx1), float((gx0 - gx1).abs().max())
+    for u, v in zip(gw0 + gb0, gw1 + gb1):
+        assert torch.equal(u, v), float((u - v).abs().max())
+    assert N.persistent_timeouts() == 0

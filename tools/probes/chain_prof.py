@@ -15,7 +15,7 @@ if '--build' in sys.argv:
     sys.exit(0)
 prof = ctypes.CDLL(lib_path)
 real = N.load()
-for name in ('nf_convnet_chain_fwd', 'nf_convnet_chain_usable', 'nf_convnet_chain_ws_floats'):
+for name in ('nf_convnet_chain_fwd', 'nf_convnet_chain_usable', 'nf_convnet_chain_ws_floats', 'nf_conv_weight_pack', 'nf_conv_weight_pack_images'):
     fn = getattr(real, name)
     pf = getattr(prof, name)
     pf.argtypes, pf.restype = fn.argtypes, fn.restype
@@ -24,6 +24,14 @@ I, O, H, W = [int(v) for v in sys.argv[1:5]]
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 net = cond.ConvNet(I, O).cuda().train()
 net.fused = True
+fc = importlib.import_module('normalizing-flows-pytorch_amd.fused_conv')
+if '--nopack' not in sys.argv:                       # the path a model takes: weight images written once, streamed by the kernel
+    wns = [m for m in net.modules() if isinstance(m, cond.WeightNorm)]
+    with torch.no_grad():
+        for m in wns:
+            m._w_eff = m.effective_weight().contiguous()
+    fc.pack_conv_weights(wns, [m._w_eff for m in wns])
+    assert fc._convnet_packs(net) is not None
 x = torch.randn(B, I, H, W, device='cuda')
 with torch.no_grad():
     for _ in range(3):
