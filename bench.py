@@ -185,7 +185,7 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
         M = B * Hh * Ww
         flop = 2 * M * (4 * 9 * 32 * 32 + 9 * 32 * I0 + 32 * O)          # five transposed convolutions, data gradient only
         nbytes = 4 * (M * 32 * (5 + 5 + 2) + 2 * M * O + 3 * B * dims[0] * dims[1] * dims[2])
-        wgs = (M + 127) // 128                                            # 128-pixel tiles, one 1024-thread workgroup each
+        wgs = int(N.load().nf_convnet_chain_blocks(B, I0, O, Hh, Ww))     # one 1024-thread workgroup per tile
         kname = ('k_convnet_chain_bwd (data gradient of the whole ConvNet conditioner + coupling backward in one persistent launch: '
                  '%d -> 32 x 5 -> %d channels, %d x %d)' % (I0, O, Hh, Ww))
         pmc = ('k_convnet_chain_bwd', '18, 181')

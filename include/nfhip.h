@@ -409,13 +409,15 @@ int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int
  * running statistics, no exchange).  Same results and the same by-products as six nf_conv_bn_fwd launches: acts[l] = output of
  * convolution l (bias and residual included), save_mean[l] / save_invstd[l] = what BatchNorm l normalised with -- what
  * nf_conv_bn_bwd reads.  A workgroup owns whole samples: H * W <= 256 and a power of two, ceil(B * H * W / tile) <=
- * NF_CONVNET_MAX_BLOCKS co-resident workgroups (nf_convnet_chain_usable != 0), tile = 256 pixels for 16 x 16 maps, 128 below.
+ * NF_CONVNET_MAX_BLOCKS co-resident workgroups (nf_convnet_chain_usable != 0), tile = 256 / 128 pixels for 16 x 16 maps, 64 below
+ * (128 when 64-pixel tiles would exceed the co-residency limit).
  * ws_zero: nf_convnet_chain_ws_floats(...) floats that are ZERO at launch (exchange slots: NF_CONVNET_WS_FLOATS for the BatchNorm
  * statistics; 16 x 16 maps at 2 B <= 128 split every sample over two workgroups, which hand their boundary rows to each other through
  * further slots -- then ws_zero is needed in evaluation mode too).  NF_CONV_HALO=0 in the environment selects one workgroup per sample. */
 #define NF_CONVNET_MAX_BLOCKS 128
 #define NF_CONVNET_WS_FLOATS (5 * 128 * 64 * 2)
 int nf_convnet_chain_ws_floats(int64_t B, int I0, int O_out, int H, int W);
+int nf_convnet_chain_blocks(int64_t B, int I0, int O_out, int H, int W);   /* workgroups of a launch (0: shape not taken) */
 typedef struct nf_convnet_desc {
     const float* x;
     const float* w[6];

@@ -30,7 +30,7 @@ NF_PERSIST_HOST_API(nf_cc)
 
 // phase stamps of workgroup 0 (tools/probes/chain_prof.py builds this file with -DNF_CC_PROF=1; 100 MHz wall clock)
 #ifdef NF_CC_PROF
-__device__ long long nf_cc_prof[64];
+__device__ long long nf_cc_prof[128];
 __device__ long long nf_cc_arrive[128];
 extern "C" int nf_cc_arrive_read(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cc_arrive), sizeof(long long) * 128);
@@ -40,7 +40,7 @@ extern "C" int nf_cc_arrive_read(long long* out) {
         if (blockIdx.x == 0 && threadIdx.x == 0) nf_cc_prof[i] = wall_clock64();       \
     } while (0)
 extern "C" int nf_cc_prof_read(long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cc_prof), sizeof(long long) * 64);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cc_prof), sizeof(long long) * 128);
 }
 #else
 #define NF_CC_STAMP(i)
@@ -133,6 +133,31 @@ __device__ __forceinline__ void nf_cc_frame_store4(float* F, int CS, int c0, int
     *(bf16x4*)(p + NF_CC_FP(CS)) = bf16x4{m0[0], m0[1], m1[0], m1[1]};
     *(bf16x4*)(p + 2 * NF_CC_FP(CS)) = bf16x4{l0[0], l0[1], l1[0], l1[1]};
 }
+// two consecutive channels c0, c0 + 1 (c0 even) of frame position f: one 4-byte store per plane
+__device__ __forceinline__ void nf_cc_frame_store2(float* F, int CS, int c0, int f, float v0, float v1) {
+    bf16x2 h, m, l;
+    nf_cc_split2(f32x2{v0, v1}, h, m, l);
+    float* p = F + (c0 >> 3) * 4 * CS + 4 * f + ((c0 & 7) >> 1);
+    *(bf16x2*)(p) = h;
+    *(bf16x2*)(p + NF_CC_FP(CS)) = m;
+    *(bf16x2*)(p + 2 * NF_CC_FP(CS)) = l;
+}
+// the eight channels of octet o at frame position f: one 16-byte store per plane
+__device__ __forceinline__ void nf_cc_frame_store8(float* F, int CS, int o, int f, const float (&v)[8]) {
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        bf16x2 h2, m2, l2;
+        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
+        h[j] = h2[0]; h[j + 1] = h2[1];
+        m[j] = m2[0]; m[j + 1] = m2[1];
+        l[j] = l2[0]; l[j + 1] = l2[1];
+    }
+    float* p = F + o * 4 * CS + 4 * f;
+    *(bf16x8*)(p) = h;
+    *(bf16x8*)(p + NF_CC_FP(CS)) = m;
+    *(bf16x8*)(p + 2 * NF_CC_FP(CS)) = l;
+}
 // one channel c of frame position f: three 2-byte stores
 __device__ __forceinline__ void nf_cc_frame_store1(float* F, int CS, int c, int f, float v) {
     __bf16 h, m, l;
@@ -223,6 +248,15 @@ __device__ __forceinline__ void nf_cc_kloop_level(f32x16& acc, const float* W8, 
     if (NKQ == 2) {
         if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, 9>(acc, wbase, fbase);            // wave-uniform
         else nf_cc_kloop_fixed<FW, CS, 9, 9>(acc, wbase, fbase);
+    } else if (NKQ == 8) {                              // 3 + 3 + 2 x 6
+        if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, 3>(acc, wbase, fbase);
+        else if (kq == 1) nf_cc_kloop_fixed<FW, CS, 3, 3>(acc, wbase, fbase);
+        else if (kq == 2) nf_cc_kloop_fixed<FW, CS, 6, 2>(acc, wbase, fbase);
+        else if (kq == 3) nf_cc_kloop_fixed<FW, CS, 8, 2>(acc, wbase, fbase);
+        else if (kq == 4) nf_cc_kloop_fixed<FW, CS, 10, 2>(acc, wbase, fbase);
+        else if (kq == 5) nf_cc_kloop_fixed<FW, CS, 12, 2>(acc, wbase, fbase);
+        else if (kq == 6) nf_cc_kloop_fixed<FW, CS, 14, 2>(acc, wbase, fbase);
+        else nf_cc_kloop_fixed<FW, CS, 16, 2>(acc, wbase, fbase);
     } else {
         if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, 5>(acc, wbase, fbase);
         else if (kq == 1) nf_cc_kloop_fixed<FW, CS, 5, 5>(acc, wbase, fbase);
@@ -346,7 +380,20 @@ __device__ __forceinline__ void nf_cc_merge(float& S, float& M2, float So, float
 template <int OWN>
 __device__ __forceinline__ void nf_cc_half_stats(const float (&v)[OWN], bool lo_ok, bool hi_ok, int c32, float& S, float& M2,
                                                  int& which) {
-    static_assert(OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    static_assert(OWN == 2 || OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    if constexpr (OWN == 2) {                           // one halving step, then whole merges
+        const bool up = c32 & 1;
+        S = up ? v[1] : v[0];
+        M2 = 0.f;
+        nf_cc_merge(S, M2, __shfl_xor(up ? v[0] : v[1], 1, NF_WAVE), 0.f, 0.5f);
+        for (int m = 2; m < 16; m *= 2) nf_cc_merge(S, M2, __shfl_xor(S, m, NF_WAVE), __shfl_xor(M2, m, NF_WAVE), 0.5f / (float)m);
+        const float So = __shfl_xor(S, 16, NF_WAVE), Mo = __shfl_xor(M2, 16, NF_WAVE);
+        const bool me_ok = (c32 & 16) ? hi_ok : lo_ok, ot_ok = (c32 & 16) ? lo_ok : hi_ok;
+        if (me_ok && ot_ok) nf_cc_merge(S, M2, So, Mo, 0.5f / 16.f);
+        else if (ot_ok) { S = So; M2 = Mo; }
+        which = up ? 1 : 0;
+        return;
+    }
     float s4[4], q4[4];
     int w = 0, m = 1;                                   // m: pixels merged so far
     if (OWN == 8) {
@@ -659,24 +706,16 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
                 nf_cc_w_store<false>(wv, Wl, WPs, noct);
                 if ((9 * noct) & 1) nf_cc_w_zero_slot(Wl, WPs, 9 * noct);
             }
-#pragma unroll 1
-            for (int jj = 0; jj < g.nfj; ++jj) {       // one frame position per lane and trip (register budget, see conv_bn.hip)
-                const int f = lane + NF_WAVE * jj;
+            // the chunk's input frame as ITEMS: the eight channels of octet o at frame position f -- eight loads in flight per item (one
+            // memory round trip per chunk), a split, three 16-byte stores (a position outside the image / batch stores zeros)
+            for (int item = threadIdx.x; item < noct * g.FSZ; item += NF_CV_THREADS) {
+                const int o = item / g.FSZ, f = item - o * g.FSZ;
                 const int t = nf_cv_decode(g, b0, y0, f);
                 const int sp = t >= 0 ? NF_CV_SP(t) : 0, sg_ = t >= 0 ? NF_CV_SEG(t) : 0;
-                float xa[NF_CV_CU];
+                float v[8];
 #pragma unroll
-                for (int u = 0; u < NF_CV_CU; ++u) {
-                    const int c = wid + u * NF_CV_WAVES;
-                    xa[u] = (t >= 0 && c < IC) ? in0[(sg_ * I0 + i0 + c) * g.HW + sp] : 0.f;
-                }
-                if (f < g.FSZ) {
-#pragma unroll
-                    for (int u = 0; u < NF_CV_CU; ++u) {
-                        const int c = wid + u * NF_CV_WAVES;
-                        if (c < ICP) nf_cc_frame_store1(Fr, CSr, c, f, xa[u]);
-                    }
-                }
+                for (int j = 0; j < 8; ++j) v[j] = (t >= 0 && 8 * o + j < IC) ? in0[(sg_ * I0 + i0 + 8 * o + j) * g.HW + sp] : 0.f;
+                nf_cc_frame_store8(Fr, CSr, o, f, v);
             }
             if (packed) nf_cc_dma_wait();
             __syncthreads();
@@ -790,6 +829,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             v.z = pv ? fmaxf(fmaf(own[4 * j + 2], kc[c0 + 2], kc[32 + c0 + 2]), 0.f) : 0.f;
             v.w = pv ? fmaxf(fmaf(own[4 * j + 3], kc[c0 + 3], kc[32 + c0 + 3]), 0.f) : 0.f;
             nf_cc_frame_store4(Fr, CSr, c0, fpos, v.x, v.y, v.z, v.w);
+        }
+        if constexpr (OWN == 2) {
+            const int c0 = nf_cv_cd_row(OWN * kq, hs);                  // channels c0, c0 + 1
+            nf_cc_frame_store2(Fr, CSr, c0, fpos, pv ? fmaxf(fmaf(own[0], kc[c0], kc[32 + c0]), 0.f) : 0.f,
+                               pv ? fmaxf(fmaf(own[1], kc[c0 + 1], kc[32 + c0 + 1]), 0.f) : 0.f);
         }
         if (l < NF_CC_NB - 1) {
             if (threadIdx.x < 32) { nb_ = d.b[l + 1][threadIdx.x]; ng_ = d.gamma[l + 1][threadIdx.x]; nbe_ = d.beta[l + 1][threadIdx.x]; }
@@ -941,7 +985,18 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
 // plain sums of two sets of OWN per-lane values over the 32 lanes of a wave half (halving butterfly, see nf_cc_half_stats)
 template <int OWN>
 __device__ __forceinline__ void nf_cc_half_sums2(const float (&u)[OWN], const float (&v)[OWN], int c32, float& S1, float& S2, int& which) {
-    static_assert(OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    static_assert(OWN == 2 || OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    if constexpr (OWN == 2) {
+        const bool up = c32 & 1;
+        S1 = (up ? u[1] : u[0]) + __shfl_xor(up ? u[0] : u[1], 1, NF_WAVE);
+        S2 = (up ? v[1] : v[0]) + __shfl_xor(up ? v[0] : v[1], 1, NF_WAVE);
+        for (int m = 2; m < 32; m *= 2) {
+            S1 += __shfl_xor(S1, m, NF_WAVE);
+            S2 += __shfl_xor(S2, m, NF_WAVE);
+        }
+        which = up ? 1 : 0;
+        return;
+    }
     float a4[4], b4[4];
     int w = 0, m = 1;
     if (OWN == 8) {
@@ -1054,6 +1109,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     unsigned long long* hslots = halo ? slots + NF_CC_STAT_SLOTS : nullptr;
     float gstream_h[2] = {0.f, 0.f};                    // halo rows of the residual stream's gradient (threads < 32 W)
 
+    NF_CC_STAMP(64);
     for (int e = threadIdx.x; e < 3 * NF_CC_FP(g.CS); e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fr = sm + L.FA;                              // ONE frame: G_l is written over G_{l+1} after every wave has left the K loop
     const bool bnv = L.BNV >= 0;                        // block-uniform
@@ -1146,6 +1202,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     float gstream[OWN], own[OWN];
 #pragma unroll
     for (int rr = 0; rr < OWN; ++rr) gstream[rr] = 0.f;
+    NF_CC_STAMP(65);
 
 #pragma unroll 1
     for (int l = NF_CC_NB - 1; l >= 0; --l) {
@@ -1181,6 +1238,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             if (l >= 1) nf_cc_dma_image(Wl, d.wpk[l] + NF_CONV_PACK_IMAGE_FLOATS, wid, lane);
             else if (d.g_x != nullptr || cpl) nf_cc_dma_image(Wl, d.wpk[0] + (size_t)nch0 * NF_CONV_PACK_IMAGE_FLOATS, wid, lane);
         }
+        NF_CC_STAMP(66 + 6 * (4 - l));
         if (cpl && l == NF_CC_NB - 1 && threadIdx.x == 0) {
             float ta = 0.f, tc = 0.f;
             for (int k = 0; k < NF_CV_WAVES; ++k) { ta += red[k]; tc += red[NF_CV_WAVES + k]; }
@@ -1188,6 +1246,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             atomicAdd(d.cp_g_c, tc);
         }
         nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
+        NF_CC_STAMP(67 + 6 * (4 - l));
         float* gn = d.gn[l];
 #pragma unroll
         for (int rr = 0; rr < OWN; ++rr) {
@@ -1214,6 +1273,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                 red[NPB * 32 + pb * 32 + oc] = S2;
             }
             const float* tot = nf_cc_sum_exchange<NPB>(sm, L, slots, l);
+            NF_CC_STAMP(68 + 6 * (4 - l));
             if (blockIdx.x == 0 && threadIdx.x < 64) {
                 (threadIdx.x < 32 ? d.sum_g[l] : d.sum_gx[l])[threadIdx.x & 31] = tot[threadIdx.x];
                 // the sums ARE the gradients of beta (sum gn) and gamma (sum gn xhat): straight into the caller's accumulators
@@ -1260,6 +1320,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             const int c0 = nf_cv_cd_row(OWN * kq + 4 * j, hs);
             nf_cc_frame_store4(Fr, CSr, c0, fpos, own[4 * j], own[4 * j + 1], own[4 * j + 2], own[4 * j + 3]);
         }
+        if constexpr (OWN == 2) nf_cc_frame_store2(Fr, CSr, nf_cv_cd_row(OWN * kq, hs), fpos, own[0], own[1]);
+        NF_CC_STAMP(69 + 6 * (4 - l));
         if (l >= 1) {                                   // transposed 3 x 3 convolution l: G_l -> layer l - 1
             if (!packed) {
                 NfCcW wv;
@@ -1269,6 +1331,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                 nf_cc_dma_wait();
             }
             __syncthreads();
+            NF_CC_STAMP(70 + 6 * (4 - l));
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             if (FWc > 0) nf_cc_kloop_level<FWc, CSc, NKQ>(acc, Wl, Fr, fpos, c32, hs, kq);        // geometry known at compile time
@@ -1278,8 +1341,10 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                 asm volatile("" : "+s"(np));            // see the forward kernel
                 nf_cc_kloop<9>(acc, Wl, Fr, WPs, CSr, g.FW, 4, fpos, c32, hs, p0, np);
             }
+            NF_CC_STAMP(71 + 6 * (4 - l));
         }
     }
+    NF_CC_STAMP(96);
 
     // ---- gradient of the conditioner's input: convolution 0 transposed, 32 input channels per pass ----
     if (d.g_x != nullptr || cpl) {
@@ -1325,6 +1390,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             }
         }
     }
+    NF_CC_STAMP(97);
 }
 
 // =====================================================================================================================================
@@ -1421,7 +1487,19 @@ static int nf_cc_halo_on() {
     if (on < 0) { const char* e = getenv("NF_CONV_HALO"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
     return on;
 }
+// maps below 16 x 16 run on 64-pixel tiles (<2, 8>: two pixel blocks x eight K splits) where that doubles the workgroups within the
+// co-residency limits -- the prologue / epilogue phases of a launch (input frame, 1 x 1 convolution, the coupling and its backward) are
+// per-pixel work of 8 .. 32 compute units at the 4 x 4 and 8 x 8 levels; NF_CONV_TILE64=0 keeps 128-pixel tiles
+static int nf_cc_tile64_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NF_CONV_TILE64"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
+    return on;
+}
 static inline int nf_cc_tile_px(int64_t B, int H, int W) {
+    if (H * W <= 64 && nf_cc_tile64_on()) {
+        const int64_t t64 = (B * H * W + 63) / 64;
+        if (t64 <= NF_CC_MAX_BLOCKS && t64 <= nf_cc_capacity()) return 64;
+    }
     if (H * W < 256) return 128;
     if (H * W == 256 && W == 16 && nf_cc_halo_on() && 2 * B <= NF_CC_MAX_BLOCKS && 2 * B <= nf_cc_capacity()) return 128;
     return 256;
@@ -1449,7 +1527,8 @@ extern "C" int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int 
     if (g.tiles > NF_CC_MAX_BLOCKS || g.tiles > nf_cc_capacity()) return 0;
     if (!(B * 192 * (int64_t)H * W < (int64_t)1 << 31)) return 0;
     const int OCB = (O_out + 31) / 32;
-    if ((PX == 256 ? nf_cc_lds_bytes<8, 2>(g, OCB) : nf_cc_lds_bytes<4, 4>(g, OCB)) > 160 * 1024) return 0;
+    if ((PX == 256 ? nf_cc_lds_bytes<8, 2>(g, OCB) : (PX == 64 ? nf_cc_lds_bytes<2, 8>(g, OCB) : nf_cc_lds_bytes<4, 4>(g, OCB))) > 160 * 1024)
+        return 0;
     return 1;
 }
 
@@ -1459,6 +1538,12 @@ static bool nf_cc_coupling_split(NfSplit& cs, int mode, int odd, int C, int I0, 
     const bool ck = mode == NF_SPLIT_CHECKER;
     if (!nf_make_split(cs, mode, odd, C, ck ? 2 * H : H, ck ? 2 * W : W)) return false;
     return cs.Ch == I0 && O_out == 2 * I0 && cs.h == H && cs.w == W;
+}
+
+extern "C" int nf_convnet_chain_blocks(int64_t B, int I0, int O_out, int H, int W) {
+    if (!nf_convnet_chain_usable(B, I0, O_out, H, W)) return 0;
+    const int PX = nf_cc_tile_px(B, H, W);
+    return (int)((B * H * W + PX - 1) / PX);
 }
 
 extern "C" int nf_convnet_chain_ws_floats(int64_t B, int I0, int O_out, int H, int W) {
@@ -1505,7 +1590,11 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
     } while (0)
     // one instantiation per level of the CIFAR pyramid (frame width / channel stride as compile-time constants), a generic one for the rest
     if (PX == 256) NF_CC_FWD2(8, 2, false, 0, 0);
-    else if (H * W > PX) {                              // a sample over several workgroups: the variant with the halo hand-over
+    else if (PX == 64) {
+        if (g.FW == 10 && g.CS == 101) NF_CC_FWD2(2, 8, false, 10, 101);
+        else if (g.FW == 6 && g.CS == 145) NF_CC_FWD2(2, 8, false, 6, 145);
+        else NF_CC_FWD2(2, 8, false, 0, 0);
+    } else if (H * W > PX) {                              // a sample over several workgroups: the variant with the halo hand-over
         if (g.FW == 18 && g.CS == 181) NF_CC_FWD2(4, 4, true, 18, 181);
         else NF_CC_FWD2(4, 4, true, 0, 0);
     } else if (g.FW == 10 && g.CS == 201) NF_CC_FWD2(4, 4, false, 10, 201);
@@ -1555,7 +1644,11 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
         else NF_CC_BWD(NPB_, NKQ_, HALO_, false, FW_, CS_, false);                                                                          \
     } while (0)
     if (PX == 256) NF_CC_BWD2(8, 2, false, 0, 0);
-    else if (H * W > PX) {
+    else if (PX == 64) {
+        if (g.FW == 10 && g.CS == 101) NF_CC_BWD2(2, 8, false, 10, 101);
+        else if (g.FW == 6 && g.CS == 145) NF_CC_BWD2(2, 8, false, 6, 145);
+        else NF_CC_BWD2(2, 8, false, 0, 0);
+    } else if (H * W > PX) {
         if (g.FW == 18 && g.CS == 181) NF_CC_BWD2(4, 4, true, 18, 181);
         else NF_CC_BWD2(4, 4, true, 0, 0);
     } else if (g.FW == 10 && g.CS == 201) NF_CC_BWD2(4, 4, false, 10, 201);

@@ -15,7 +15,7 @@ if '--build' in sys.argv:
     sys.exit(0)
 prof = ctypes.CDLL(lib_path)
 real = N.load()
-for name in ('nf_convnet_chain_fwd', 'nf_convnet_chain_usable', 'nf_convnet_chain_ws_floats', 'nf_conv_weight_pack', 'nf_conv_weight_pack_images'):
+for name in ('nf_convnet_chain_fwd', 'nf_convnet_chain_bwd', 'nf_convnet_chain_usable', 'nf_convnet_chain_ws_floats', 'nf_conv_weight_pack', 'nf_conv_weight_pack_images'):
     fn = getattr(real, name)
     pf = getattr(prof, name)
     pf.argtypes, pf.restype = fn.argtypes, fn.restype
@@ -33,11 +33,26 @@ if '--nopack' not in sys.argv:                       # the path a model takes: w
     fc.pack_conv_weights(wns, [m._w_eff for m in wns])
     assert fc._convnet_packs(net) is not None
 x = torch.randn(B, I, H, W, device='cuda')
-with torch.no_grad():
+CPL = '--cpl' in sys.argv                           # with the fused coupling: the launch a model makes (checkerboard split of (I/2, 2H, 2W))
+if CPL:
+    NF = importlib.import_module('normalizing-flows-pytorch_amd.functional')
+    z = torch.randn(B, I // 2, 2 * H, 2 * W, device='cuda')
+    a, c = torch.full((1, ), 0.5, device='cuda'), torch.zeros(1, device='cuda')
+    BWD = '--bwd' in sys.argv
     for _ in range(3):
-        y = net(x)
+        with torch.set_grad_enabled(BWD):
+            zz = z.clone().requires_grad_(BWD)
+            xx = NF.half_gather(zz.detach(), 1, N.SPLIT_CHECKER, 0)
+            ld = torch.zeros(B, device='cuda')
+            y, ld2 = fc.convnet_coupling(net, xx, zz, ld, a, c, N.SPLIT_CHECKER, 0)
+            if BWD:
+                (y.square().sum() * 1e-3 + ld2.sum()).backward()
+else:
+    with torch.no_grad():
+        for _ in range(3):
+            y = net(x)
 torch.cuda.synchronize()
-buf = (ctypes.c_longlong * 64)()
+buf = (ctypes.c_longlong * 128)()
 prof.nf_cc_prof_read(buf)
 t = [v / 100.0 for v in buf]   # us
 print('B %d  %d -> %d  %d x %d   total %.1f us: zero+conv0 %.1f' % (B, I, O, H, W, t[51] - t[0], t[1] - t[0]))
@@ -49,6 +64,15 @@ for l in range(5):
 print('  1x1 out conv %.1f' % (t[51] - t[50]))
 print('  exchange of layer 1: sync %.1f | combine+publish %.1f | poll %.1f | sync %.1f | merge %.1f' % (
     t[56] - t[12], t[57] - t[56], t[58] - t[57], t[59] - t[58], t[13] - t[59]))
+if '--bwd' in sys.argv:
+    print('backward total %.1f us: zero + 1x1^T (coupling backward on the fly) %.1f' % (t[97] - t[64], t[65] - t[64]))
+    for l in range(4, -1, -1):
+        o = 66 + 6 * (4 - l)
+        prev = t[65] if l == 4 else t[o - 1]
+        print('  layer %d: loads+sync %.1f | k-split %.1f | gn, sums, exchange %.1f | G -> frame %.1f | weights wait+sync %.1f | K loop %.1f'
+              % (l, t[o] - prev, t[o + 1] - t[o], t[o + 2] - t[o + 1], t[o + 3] - t[o + 2], (t[o + 4] - t[o + 3]) if l >= 1 else 0.0,
+                 (t[o + 5] - t[o + 4]) if l >= 1 else 0.0))
+    print('  conv0^T chunks + stores %.1f' % (t[97] - t[96]))
 arr = (ctypes.c_longlong * 128)()
 prof.nf_cc_arrive_read(arr)
 G = (B * H * W + (255 if H * W >= 256 else 127)) // (256 if H * W >= 256 else 128)
