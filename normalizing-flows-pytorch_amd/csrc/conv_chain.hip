@@ -87,7 +87,7 @@ __host__ __device__ inline NfCcLds nf_cc_lds(int CS, int OCB) {
     if (rs < NF_CC_MAX_BLOCKS * 65) rs = NF_CC_MAX_BLOCKS * 65;
     L.KC = L.RS + rs;
     L.KB = L.KC + 128;                                 // kc[4][32]: scale, shift (forward) + mean, invstd (backward)
-    L.RED = L.KB + 32;
+    L.RED = L.KB + 96;                                 // kb[3][32]: bias | gamma | beta of the layer under way
     L.TOT = L.RED + 2 * NPB * 32;
     L.total = L.TOT + 64;
     // the backward kernel keeps the saved statistics and parameters of all five BatchNorms here when the geometry leaves room (every
@@ -482,9 +482,11 @@ __device__ __forceinline__ float nf_cc_sum32(float v) {      // over the 32 lane
 // grid-wide (sum, M2) of 32 channels: red[0][pb][c] = sums, red[1][pb][c] = M2 about the pixel block's mean -> tot[c], tot[32 + c].
 // The merges are spread over the whole workgroup (a 64-iteration loop of divisions on 64 threads cost 7.4 us at 64 workgroups):
 // thread (channel i = t & 31, part p = t >> 5) takes the workgroups p, p + 32, ...; parts meet in `part` (aliases Wl, idle here).
+// Returns true in the ONE lane per channel that holds the channel's totals (ci, S, M2) -- the caller finishes the BatchNorm constants
+// there and then synchronises: no barrier between the merge and the constants.
 template <int NPB>
-__device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, int round,
-                                                             int64_t Npx, int PXW) {
+__device__ __forceinline__ bool nf_cc_stats_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, int round,
+                                                     int64_t Npx, int PXW, int& ci_out, float& S_out, float& M2_out) {
     float* red = sm + L.RED;
     float* xs = sm + L.RS;
     float* tot = sm + L.TOT;
@@ -515,7 +517,7 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
             }
         }
         if (G == 1) {
-            tot[i] = S; tot[32 + i] = M2;
+            ci_out = i; S_out = S; M2_out = M2;
         } else {
             unsigned long long* dst = slots + ((size_t)round * NF_CC_MAX_BLOCKS + blockIdx.x) * 64 + i;
             __hip_atomic_store(dst, ((unsigned long long)(round + 1) << 32) | (unsigned long long)__float_as_uint(S), __ATOMIC_RELAXED,
@@ -524,10 +526,7 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (G == 1) {
-        __syncthreads();
-        return tot;
-    }
+    if (G == 1) return threadIdx.x < 32;
     const unsigned long long* rs = slots + (size_t)round * NF_CC_MAX_BLOCKS * 64;
     const unsigned gen = (unsigned)(round + 1);
     if (round == 1) NF_CC_STAMP(57);
@@ -550,16 +549,24 @@ __device__ __forceinline__ const float* nf_cc_stats_exchange(float* sm, const Nf
         const float mean = S / (float)Npx;
         const float inv_full = 1.f / (float)PXW;
         float pm = 0.f;
-        for (int b = l; b < G; b += 32) {
-            const int nb = nf_cc_valid_px(Npx, (int64_t)b * PXW, PXW);
-            const float dlt = xs[b * XS + ci] * (nb == PXW ? inv_full : 1.f / (float)max(nb, 1)) - mean;
-            pm += fmaf((float)nb * dlt, dlt, xs[b * XS + 32 + ci]);
+        if (Npx == (int64_t)G * PXW) {                  // every tile full (block-uniform): no per-tile pixel counts
+            const float fpx = (float)PXW;
+            for (int b = l; b < G; b += 32) {
+                const float dlt = xs[b * XS + ci] * inv_full - mean;
+                pm += fmaf(fpx * dlt, dlt, xs[b * XS + 32 + ci]);
+            }
+        } else {
+            for (int b = l; b < G; b += 32) {
+                const int nb = nf_cc_valid_px(Npx, (int64_t)b * PXW, PXW);
+                const float dlt = xs[b * XS + ci] * (nb == PXW ? inv_full : 1.f / (float)max(nb, 1)) - mean;
+                pm += fmaf((float)nb * dlt, dlt, xs[b * XS + 32 + ci]);
+            }
         }
         const float M2 = nf_cc_sum32(pm);
-        if (l == 0) { tot[ci] = S; tot[32 + ci] = M2; }
+        ci_out = ci; S_out = S; M2_out = M2;
+        (void)tot;
+        return l == 0;
     }
-    __syncthreads();
-    return tot;
 }
 
 // ---- the affine coupling around the conditioner (flows/coupling.py:104-122), fused into the chain kernels ------------------------------
@@ -741,8 +748,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         constexpr bool PREFETCH_W = OWN <= 4;           // OWN = 8 has no registers to spare: it loads at the point of use
         NfCcW wv;
         if (!packed && PREFETCH_W && l < NF_CC_NB - 1) nf_cc_w_load<false>(wv, d.w[l + 1], 32, 0, 32, 4);
-        const float cg_ = ng_, cbe_ = nbe_;
-        if (threadIdx.x < 32) kb[threadIdx.x] = nb_;
+        if (threadIdx.x < 32) { kb[threadIdx.x] = nb_; kb[32 + threadIdx.x] = ng_; kb[64 + threadIdx.x] = nbe_; }
         __syncthreads();                                // every wave is done with Wl / the frame of this layer; kb is written
         // the next layer's weight image streams into Wl under this layer's exchanges (the 1 x 1's under the last layer's)
         if (packed && (l < NF_CC_NB - 1 || cpl)) nf_cc_dma_image(Wl, d.wpk[l + 1], wid, lane);   // (the 1 x 1 image has the coupling's row order)
@@ -773,17 +779,18 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         if (halo) nf_cc_halo_publish<OWN>(hslots, l, g, (int)tile, y0, px, kq, hs, own);
         NF_CC_STAMP(4 + 8 * l);
         if (training) {
-            const float* tot = nf_cc_stats_exchange<NPB>(sm, L, slots, l, Npx, PXW);
+            int k;
+            float tS, tM2;
+            const bool fin = nf_cc_stats_exchange<NPB>(sm, L, slots, l, Npx, PXW, k, tS, tM2);
             NF_CC_STAMP(5 + 8 * l);
-            if (threadIdx.x < 32) {
-                const int k = threadIdx.x;
+            if (fin) {                                  // the lane that holds channel k's totals finishes its constants
                 const float invN = 1.f / (float)Npx;
-                const float mean = kb[k] + tot[k] * invN;                     // statistics of the pre-bias output
-                const float var = tot[32 + k] * invN;                         // biased, as BatchNorm normalises
+                const float mean = kb[k] + tS * invN;                         // statistics of the pre-bias output
+                const float var = tM2 * invN;                                 // biased, as BatchNorm normalises
                 const float invstd = 1.f / sqrtf(var + eps);
-                const float sc = cg_ * invstd;
+                const float sc = kb[32 + k] * invstd;
                 kc[k] = sc;
-                kc[32 + k] = cbe_ - mean * sc;
+                kc[32 + k] = kb[64 + k] - mean * sc;
                 if (blockIdx.x == 0) {
                     d.save_mean[l][k] = mean;
                     d.save_invstd[l][k] = invstd;
@@ -798,9 +805,9 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             if (threadIdx.x < 32) {
                 const int k = threadIdx.x;
                 const float mean = d.rmean[l][k], invstd = 1.f / sqrtf(d.rvar[l][k] + eps);
-                const float sc = cg_ * invstd;
+                const float sc = kb[32 + k] * invstd;
                 kc[k] = sc;
-                kc[32 + k] = cbe_ - mean * sc;
+                kc[32 + k] = kb[64 + k] - mean * sc;
                 if (blockIdx.x == 0) {                  // what the backward kernels normalise with (constants in this mode)
                     d.save_mean[l][k] = mean;
                     d.save_invstd[l][k] = invstd;
