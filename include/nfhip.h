@@ -415,7 +415,7 @@ int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int
  * statistics; 16 x 16 maps at 2 B <= 128 split every sample over two workgroups, which hand their boundary rows to each other through
  * further slots -- then ws_zero is needed in evaluation mode too).  NF_CONV_HALO=0 in the environment selects one workgroup per sample. */
 #define NF_CONVNET_MAX_BLOCKS 128
-#define NF_CONVNET_WS_FLOATS (5 * 128 * 64 * 2)
+#define NF_CONVNET_WS_FLOATS (5 * (128 + 8) * 64 * 2)     /* a row of 64 eight-byte slots per workgroup and per group of 16, per BatchNorm */
 int nf_convnet_chain_ws_floats(int64_t B, int I0, int O_out, int H, int W);
 int nf_convnet_chain_blocks(int64_t B, int I0, int O_out, int H, int W);   /* workgroups of a launch (0: shape not taken) */
 typedef struct nf_convnet_desc {

@@ -25,6 +25,16 @@
 #define NF_CC_NB 5
 #define NF_CC_MAX_BLOCKS NF_CONVNET_MAX_BLOCKS
 
+#define NF_CC_WG_SLOTS (NF_CC_NB * NF_CC_MAX_BLOCKS * 64)                   // 64-bit slots of the statistics exchanges, one row per workgroup
+#define NF_CC_GROUP 16                                                      // two-level exchange above NF_CC_FLAT_MAX workgroups: groups of 16
+#define NF_CC_MAX_GROUPS ((NF_CC_MAX_BLOCKS + NF_CC_GROUP - 1) / NF_CC_GROUP)
+// Measured (tools/probes/chain_prof.py, B = 64): two levels cost 7 - 9 us per exchange at 128 workgroups and 4.4 at 64, against 4.3 and
+// 2.5 us for all-to-all polling -- the second hop is a second full memory round trip behind the slowest group leader.  So the flat
+// exchange serves every grid the kernels admit today; the two-level path only exists for grids beyond it (compiled out otherwise).
+#define NF_CC_FLAT_MAX 128
+#define NF_CC_STAT_SLOTS (NF_CC_WG_SLOTS + NF_CC_NB * NF_CC_MAX_GROUPS * 64) // + one row per group (before the halo slots)
+static_assert(2 * NF_CC_STAT_SLOTS == NF_CONVNET_WS_FLOATS, "exchange workspace size in include/nfhip.h");
+
 NF_PERSIST_STATE(nf_cc)
 NF_PERSIST_HOST_API(nf_cc)
 
@@ -482,6 +492,34 @@ __device__ __forceinline__ float nf_cc_sum32(float v) {      // over the 32 lane
 // grid-wide (sum, M2) of 32 channels: red[0][pb][c] = sums, red[1][pb][c] = M2 about the pixel block's mean -> tot[c], tot[32 + c].
 // The merges are spread over the whole workgroup (a 64-iteration loop of divisions on 64 threads cost 7.4 us at 64 workgroups):
 // thread (channel i = t & 31, part p = t >> 5) takes the workgroups p, p + 32, ...; parts meet in `part` (aliases Wl, idle here).
+// (sum, M2 about the overall mean) of channel ci over n rows of the gather buffer -- row b = (sum, M2 about its own mean) of the rowpx
+// pixels that start at pixel px0 + b rowpx of the batch (the last row may hold fewer, or none) -- by the 32 lanes l of a wave half:
+// per-lane partials in a fixed order, then a butterfly.  Every lane returns the totals.
+__device__ __forceinline__ void nf_cc_merge_rows(const float* xs, int XS, int n, int64_t Npx, int64_t px0, int rowpx, int ci, int l,
+                                                 float& S, float& M2) {
+    float ps = 0.f;
+    for (int b = l; b < n; b += 32) ps += xs[b * XS + ci];
+    S = nf_cc_sum32(ps);
+    const int64_t left = Npx - px0;
+    const int64_t ntot = left < (int64_t)n * rowpx ? left : (int64_t)n * rowpx;
+    const float mean = S / (float)ntot;
+    float pm = 0.f;
+    if (ntot == (int64_t)n * rowpx) {                   // every row full (uniform): no per-row pixel counts
+        const float inv_full = 1.f / (float)rowpx, fpx = (float)rowpx;
+        for (int b = l; b < n; b += 32) {
+            const float dlt = xs[b * XS + ci] * inv_full - mean;
+            pm += fmaf(fpx * dlt, dlt, xs[b * XS + 32 + ci]);
+        }
+    } else {
+        for (int b = l; b < n; b += 32) {
+            const int nb = nf_cc_valid_px(Npx, px0 + (int64_t)b * rowpx, rowpx);
+            const float dlt = xs[b * XS + ci] / (float)max(nb, 1) - mean;
+            pm += nb > 0 ? fmaf((float)nb * dlt, dlt, xs[b * XS + 32 + ci]) : 0.f;
+        }
+    }
+    M2 = nf_cc_sum32(pm);
+}
+
 // Returns true in the ONE lane per channel that holds the channel's totals (ci, S, M2) -- the caller finishes the BatchNorm constants
 // there and then synchronises: no barrier between the merge and the constants.
 template <int NPB>
@@ -533,40 +571,46 @@ __device__ __forceinline__ bool nf_cc_stats_exchange(float* sm, const NfCcLds& L
 #ifdef NF_CC_PROF
     if (round == 1 && threadIdx.x == 0) nf_cc_arrive[blockIdx.x] = wall_clock64();
 #endif
-    const int XS = G * 65 <= L.KC - L.RS ? 65 : 64;
-    nf_cc_collect_slots(xs, rs, gen, G, XS);
-    if (round == 1) NF_CC_STAMP(58);
-    __syncthreads();
-    if (round == 1) NF_CC_STAMP(59);
-    // Thread (wave w, half h, lane l) reduces channel i = 2 w + h over the workgroups b = l, l + 32, ...: per-lane partials in a fixed
-    // order, then a butterfly over the 32 lanes -- no further barrier until the totals are written (the version with two passes of
-    // LDS partials took four more barriers).
-    {
-        const int lane = threadIdx.x & 63, ci = 2 * (threadIdx.x >> 6) + (lane >> 5), l = lane & 31;
-        float ps = 0.f;
-        for (int b = l; b < G; b += 32) ps += xs[b * XS + ci];
-        const float S = nf_cc_sum32(ps);
-        const float mean = S / (float)Npx;
-        const float inv_full = 1.f / (float)PXW;
-        float pm = 0.f;
-        if (Npx == (int64_t)G * PXW) {                  // every tile full (block-uniform): no per-tile pixel counts
-            const float fpx = (float)PXW;
-            for (int b = l; b < G; b += 32) {
-                const float dlt = xs[b * XS + ci] * inv_full - mean;
-                pm += fmaf(fpx * dlt, dlt, xs[b * XS + 32 + ci]);
+    const int XS = 65;
+    const int lane = threadIdx.x & 63, ci = 2 * (threadIdx.x >> 6) + (lane >> 5), l = lane & 31;
+    float S, M2;
+    if (NF_CC_MAX_BLOCKS <= NF_CC_FLAT_MAX || G <= NF_CC_FLAT_MAX) {
+        // every workgroup polls every row: thread (wave w, half h, lane l) reduces channel ci = 2 w + h over the workgroups b = l,
+        // l + 32, ... in a fixed order, then a butterfly over the 32 lanes
+        nf_cc_collect_slots(xs, rs, gen, G, XS);
+        if (round == 1) NF_CC_STAMP(58);
+        __syncthreads();
+        if (round == 1) NF_CC_STAMP(59);
+        nf_cc_merge_rows(xs, XS, G, Npx, 0, PXW, ci, l, S, M2);
+    } else {
+        // two levels (all-to-all polling moves G x G x 512 bytes per round: 8 MB at 128 workgroups): the first workgroup of every
+        // group of 16 merges its group's rows and publishes the group's (sum, M2 about the group mean); everybody polls the <= 16
+        // group rows.  Fixed order on both levels: deterministic.
+        const int grp = blockIdx.x / NF_CC_GROUP, NG = (G + NF_CC_GROUP - 1) / NF_CC_GROUP;
+        unsigned long long* gs = slots + NF_CC_WG_SLOTS + (size_t)round * NF_CC_MAX_GROUPS * 64;
+        if (blockIdx.x % NF_CC_GROUP == 0) {            // block-uniform
+            const int nmem = min(NF_CC_GROUP, G - grp * NF_CC_GROUP);
+            nf_cc_collect_slots(xs, rs + (size_t)grp * NF_CC_GROUP * 64, gen, nmem, XS);
+            __syncthreads();
+            float Sg, Mg;
+            nf_cc_merge_rows(xs, XS, nmem, Npx, (int64_t)grp * NF_CC_GROUP * PXW, PXW, ci, l, Sg, Mg);
+            if (l == 0) {
+                __hip_atomic_store(gs + grp * 64 + ci, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(Sg),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + grp * 64 + 32 + ci, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(Mg),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        } else {
-            for (int b = l; b < G; b += 32) {
-                const int nb = nf_cc_valid_px(Npx, (int64_t)b * PXW, PXW);
-                const float dlt = xs[b * XS + ci] * (nb == PXW ? inv_full : 1.f / (float)max(nb, 1)) - mean;
-                pm += fmaf((float)nb * dlt, dlt, xs[b * XS + 32 + ci]);
-            }
+            __syncthreads();                            // the group's rows are read before the gather buffer is reused
         }
-        const float M2 = nf_cc_sum32(pm);
-        ci_out = ci; S_out = S; M2_out = M2;
-        (void)tot;
-        return l == 0;
+        nf_cc_collect_slots(xs, gs, gen, NG, XS);
+        if (round == 1) NF_CC_STAMP(58);
+        __syncthreads();
+        if (round == 1) NF_CC_STAMP(59);
+        nf_cc_merge_rows(xs, XS, NG, Npx, 0, NF_CC_GROUP * PXW, ci, l, S, M2);
     }
+    ci_out = ci; S_out = S; M2_out = M2;
+    (void)tot;
+    return l == 0;
 }
 
 // ---- the affine coupling around the conditioner (flows/coupling.py:104-122), fused into the chain kernels ------------------------------
@@ -587,7 +631,7 @@ __device__ __forceinline__ int nf_cc_half_to_full(const NfSplit& s, int which, i
 // [slot s][channel][x], s = 0: the row above the destination's first row, s = 1: the row below its last -- BEFORE the layer's grid-wide
 // statistics exchange, which the hand-over hides behind; the receiver polls its own slots after the exchange (they are there by then) and
 // finishes the values exactly as its own pixels.  Self-synchronising: no ordering between these stores and the statistics slots is assumed.
-#define NF_CC_STAT_SLOTS (NF_CC_NB * NF_CC_MAX_BLOCKS * 64)                 // 64-bit slots of the statistics exchanges (before the halo slots)
+
 #define NF_CC_HALO_SLOTS(W) (2 * 32 * (W))                                  // per layer and destination tile
 template <int OWN>
 __device__ __forceinline__ void nf_cc_halo_publish(unsigned long long* hslots, int layer, const NfCvGeo& g, int tile, int y0, int px, int kq,
@@ -1071,13 +1115,37 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
         __syncthreads();
         return tot;
     }
-    const int XS = G * 65 <= L.KC - L.RS ? 65 : 64;
-    nf_cc_collect_slots(xs, slots + (size_t)round * NF_CC_MAX_BLOCKS * 64, (unsigned)(round + 1), G, XS);
+    const int XS = 65;
+    const unsigned gen = (unsigned)(round + 1);
+    const unsigned long long* rs = slots + (size_t)round * NF_CC_MAX_BLOCKS * 64;
+    const int lane = threadIdx.x & 63, ci = 2 * (threadIdx.x >> 6) + (lane >> 5), l = lane & 31;
+    int nrows = G;
+    if (NF_CC_MAX_BLOCKS > NF_CC_FLAT_MAX && G > NF_CC_FLAT_MAX) {     // two levels, as in the forward kernel's statistics exchange
+        const int grp = blockIdx.x / NF_CC_GROUP;
+        unsigned long long* gs = slots + NF_CC_WG_SLOTS + (size_t)round * NF_CC_MAX_GROUPS * 64;
+        if (blockIdx.x % NF_CC_GROUP == 0) {
+            const int nmem = min(NF_CC_GROUP, G - grp * NF_CC_GROUP);
+            nf_cc_collect_slots(xs, rs + (size_t)grp * NF_CC_GROUP * 64, gen, nmem, XS);
+            __syncthreads();
+            float pa = 0.f, pb = 0.f;
+            for (int b = l; b < nmem; b += 32) { pa += xs[b * XS + ci]; pb += xs[b * XS + 32 + ci]; }
+            const float A = nf_cc_sum32(pa), Bs = nf_cc_sum32(pb);
+            if (l == 0) {
+                __hip_atomic_store(gs + grp * 64 + ci, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(A),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + grp * 64 + 32 + ci, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(Bs),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        rs = gs;
+        nrows = (G + NF_CC_GROUP - 1) / NF_CC_GROUP;
+    }
+    nf_cc_collect_slots(xs, rs, gen, nrows, XS);
     __syncthreads();
     {
-        const int lane = threadIdx.x & 63, ci = 2 * (threadIdx.x >> 6) + (lane >> 5), l = lane & 31;
         float pa = 0.f, pb = 0.f;
-        for (int b = l; b < G; b += 32) { pa += xs[b * XS + ci]; pb += xs[b * XS + 32 + ci]; }
+        for (int b = l; b < nrows; b += 32) { pa += xs[b * XS + ci]; pb += xs[b * XS + 32 + ci]; }
         const float A = nf_cc_sum32(pa), Bs = nf_cc_sum32(pb);
         if (l == 0) { tot[ci] = A; tot[32 + ci] = Bs; }
     }
