@@ -258,6 +258,25 @@ __device__ __forceinline__ void nf_cc_kloop_level(f32x16& acc, const float* W8, 
     if (NKQ == 2) {
         if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, 9>(acc, wbase, fbase);            // wave-uniform
         else nf_cc_kloop_fixed<FW, CS, 9, 9>(acc, wbase, fbase);
+    } else if (NKQ == 16) {                             // 2 + 2 + 1 x 14 (wave-uniform switch)
+        switch (kq) {
+            case 0: nf_cc_kloop_fixed<FW, CS, 0, 2>(acc, wbase, fbase); break;
+            case 1: nf_cc_kloop_fixed<FW, CS, 2, 2>(acc, wbase, fbase); break;
+            case 2: nf_cc_kloop_fixed<FW, CS, 4, 1>(acc, wbase, fbase); break;
+            case 3: nf_cc_kloop_fixed<FW, CS, 5, 1>(acc, wbase, fbase); break;
+            case 4: nf_cc_kloop_fixed<FW, CS, 6, 1>(acc, wbase, fbase); break;
+            case 5: nf_cc_kloop_fixed<FW, CS, 7, 1>(acc, wbase, fbase); break;
+            case 6: nf_cc_kloop_fixed<FW, CS, 8, 1>(acc, wbase, fbase); break;
+            case 7: nf_cc_kloop_fixed<FW, CS, 9, 1>(acc, wbase, fbase); break;
+            case 8: nf_cc_kloop_fixed<FW, CS, 10, 1>(acc, wbase, fbase); break;
+            case 9: nf_cc_kloop_fixed<FW, CS, 11, 1>(acc, wbase, fbase); break;
+            case 10: nf_cc_kloop_fixed<FW, CS, 12, 1>(acc, wbase, fbase); break;
+            case 11: nf_cc_kloop_fixed<FW, CS, 13, 1>(acc, wbase, fbase); break;
+            case 12: nf_cc_kloop_fixed<FW, CS, 14, 1>(acc, wbase, fbase); break;
+            case 13: nf_cc_kloop_fixed<FW, CS, 15, 1>(acc, wbase, fbase); break;
+            case 14: nf_cc_kloop_fixed<FW, CS, 16, 1>(acc, wbase, fbase); break;
+            default: nf_cc_kloop_fixed<FW, CS, 17, 1>(acc, wbase, fbase); break;
+        }
     } else if (NKQ == 8) {                              // 3 + 3 + 2 x 6
         if (kq == 0) nf_cc_kloop_fixed<FW, CS, 0, 3>(acc, wbase, fbase);
         else if (kq == 1) nf_cc_kloop_fixed<FW, CS, 3, 3>(acc, wbase, fbase);
@@ -390,7 +409,18 @@ __device__ __forceinline__ void nf_cc_merge(float& S, float& M2, float So, float
 template <int OWN>
 __device__ __forceinline__ void nf_cc_half_stats(const float (&v)[OWN], bool lo_ok, bool hi_ok, int c32, float& S, float& M2,
                                                  int& which) {
-    static_assert(OWN == 2 || OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    static_assert(OWN == 1 || OWN == 2 || OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    if constexpr (OWN == 1) {                           // whole merges only
+        S = v[0];
+        M2 = 0.f;
+        for (int m = 1; m < 16; m *= 2) nf_cc_merge(S, M2, __shfl_xor(S, m, NF_WAVE), __shfl_xor(M2, m, NF_WAVE), 0.5f / (float)m);
+        const float So = __shfl_xor(S, 16, NF_WAVE), Mo = __shfl_xor(M2, 16, NF_WAVE);
+        const bool me_ok = (c32 & 16) ? hi_ok : lo_ok, ot_ok = (c32 & 16) ? lo_ok : hi_ok;
+        if (me_ok && ot_ok) nf_cc_merge(S, M2, So, Mo, 0.5f / 16.f);
+        else if (ot_ok) { S = So; M2 = Mo; }
+        which = 0;
+        return;
+    }
     if constexpr (OWN == 2) {                           // one halving step, then whole merges
         const bool up = c32 & 1;
         S = up ? v[1] : v[0];
@@ -881,6 +911,10 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             v.w = pv ? fmaxf(fmaf(own[4 * j + 3], kc[c0 + 3], kc[32 + c0 + 3]), 0.f) : 0.f;
             nf_cc_frame_store4(Fr, CSr, c0, fpos, v.x, v.y, v.z, v.w);
         }
+        if constexpr (OWN == 1) {
+            const int c0 = nf_cv_cd_row(kq, hs);
+            nf_cc_frame_store1(Fr, CSr, c0, fpos, pv ? fmaxf(fmaf(own[0], kc[c0], kc[32 + c0]), 0.f) : 0.f);
+        }
         if constexpr (OWN == 2) {
             const int c0 = nf_cv_cd_row(OWN * kq, hs);                  // channels c0, c0 + 1
             nf_cc_frame_store2(Fr, CSr, c0, fpos, pv ? fmaxf(fmaf(own[0], kc[c0], kc[32 + c0]), 0.f) : 0.f,
@@ -1036,7 +1070,17 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
 // plain sums of two sets of OWN per-lane values over the 32 lanes of a wave half (halving butterfly, see nf_cc_half_stats)
 template <int OWN>
 __device__ __forceinline__ void nf_cc_half_sums2(const float (&u)[OWN], const float (&v)[OWN], int c32, float& S1, float& S2, int& which) {
-    static_assert(OWN == 2 || OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    static_assert(OWN == 1 || OWN == 2 || OWN == 4 || OWN == 8, "16 / NKQ values per lane");
+    if constexpr (OWN == 1) {
+        S1 = u[0];
+        S2 = v[0];
+        for (int m = 1; m < 32; m *= 2) {
+            S1 += __shfl_xor(S1, m, NF_WAVE);
+            S2 += __shfl_xor(S2, m, NF_WAVE);
+        }
+        which = 0;
+        return;
+    }
     if constexpr (OWN == 2) {
         const bool up = c32 & 1;
         S1 = (up ? u[1] : u[0]) + __shfl_xor(up ? u[0] : u[1], 1, NF_WAVE);
@@ -1396,6 +1440,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             nf_cc_frame_store4(Fr, CSr, c0, fpos, own[4 * j], own[4 * j + 1], own[4 * j + 2], own[4 * j + 3]);
         }
         if constexpr (OWN == 2) nf_cc_frame_store2(Fr, CSr, nf_cv_cd_row(OWN * kq, hs), fpos, own[0], own[1]);
+        if constexpr (OWN == 1) nf_cc_frame_store1(Fr, CSr, nf_cv_cd_row(kq, hs), fpos, own[0]);
         NF_CC_STAMP(69 + 6 * (4 - l));
         if (l >= 1) {                                   // transposed 3 x 3 convolution l: G_l -> layer l - 1
             if (!packed) {
@@ -1570,9 +1615,16 @@ static int nf_cc_tile64_on() {
     if (on < 0) { const char* e = getenv("NF_CONV_TILE64"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
     return on;
 }
+static int nf_cc_tile32_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NF_CONV_TILE32"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
+    return on;
+}
 static inline int nf_cc_tile_px(int64_t B, int H, int W) {
     if (H * W <= 64 && nf_cc_tile64_on()) {
-        const int64_t t64 = (B * H * W + 63) / 64;
+        const int64_t t64 = (B * H * W + 63) / 64, t32 = (B * H * W + 31) / 32;
+        // 32-pixel tiles (<1, 16>) where 64-pixel ones leave fewer than 32 workgroups (the 4 x 4 level at B = 64: 16 -> 32)
+        if (H * W <= 32 && t64 < 32 && t32 <= NF_CC_MAX_BLOCKS && t32 <= nf_cc_capacity() && nf_cc_tile32_on()) return 32;
         if (t64 <= NF_CC_MAX_BLOCKS && t64 <= nf_cc_capacity()) return 64;
     }
     if (H * W < 256) return 128;
@@ -1602,7 +1654,9 @@ extern "C" int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int 
     if (g.tiles > NF_CC_MAX_BLOCKS || g.tiles > nf_cc_capacity()) return 0;
     if (!(B * 192 * (int64_t)H * W < (int64_t)1 << 31)) return 0;
     const int OCB = (O_out + 31) / 32;
-    if ((PX == 256 ? nf_cc_lds_bytes<8, 2>(g, OCB) : (PX == 64 ? nf_cc_lds_bytes<2, 8>(g, OCB) : nf_cc_lds_bytes<4, 4>(g, OCB))) > 160 * 1024)
+    if ((PX == 256 ? nf_cc_lds_bytes<8, 2>(g, OCB)
+                   : (PX == 64 ? nf_cc_lds_bytes<2, 8>(g, OCB) : (PX == 32 ? nf_cc_lds_bytes<1, 16>(g, OCB) : nf_cc_lds_bytes<4, 4>(g, OCB)))) >
+        160 * 1024)
         return 0;
     return 1;
 }
@@ -1665,7 +1719,10 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
     } while (0)
     // one instantiation per level of the CIFAR pyramid (frame width / channel stride as compile-time constants), a generic one for the rest
     if (PX == 256) NF_CC_FWD2(8, 2, false, 0, 0);
-    else if (PX == 64) {
+    else if (PX == 32) {
+        if (g.FW == 6 && g.CS == 73) NF_CC_FWD2(1, 16, false, 6, 73);
+        else NF_CC_FWD2(1, 16, false, 0, 0);
+    } else if (PX == 64) {
         if (g.FW == 10 && g.CS == 101) NF_CC_FWD2(2, 8, false, 10, 101);
         else if (g.FW == 6 && g.CS == 145) NF_CC_FWD2(2, 8, false, 6, 145);
         else NF_CC_FWD2(2, 8, false, 0, 0);
@@ -1719,7 +1776,10 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
         else NF_CC_BWD(NPB_, NKQ_, HALO_, false, FW_, CS_, false);                                                                          \
     } while (0)
     if (PX == 256) NF_CC_BWD2(8, 2, false, 0, 0);
-    else if (PX == 64) {
+    else if (PX == 32) {
+        if (g.FW == 6 && g.CS == 73) NF_CC_BWD2(1, 16, false, 6, 73);
+        else NF_CC_BWD2(1, 16, false, 0, 0);
+    } else if (PX == 64) {
         if (g.FW == 10 && g.CS == 101) NF_CC_BWD2(2, 8, false, 10, 101);
         else if (g.FW == 6 && g.CS == 145) NF_CC_BWD2(2, 8, false, 6, 145);
         else NF_CC_BWD2(2, 8, false, 0, 0);

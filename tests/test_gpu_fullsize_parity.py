@@ -332,7 +332,11 @@ def test_c1_kink_free_seed_meets_the_strict_bar_on_every_tensor(pkg):
         s = max(float(g64.abs().max()), 1.0e-3 * G)             # the tensor's own largest entry (floor: 1e-3 of the largest of all)
         err = float((grads[k] - r32['grads'][k].double()).abs().max())
         gap = float((r32['grads'][k].double() - g64).abs().max())
-        if err > 2.0 * TOL * s + SLACK * gap:
+        # every linear of the conditioner but the last feeds a BatchNorm: its bias has an ANALYTICALLY zero gradient, what any
+        # implementation returns there is rounding noise around zero -- bounded against the largest gradient
+        # entry of the model, not matched
+        noise = k.endswith('module.bias') and 'out_block' not in k
+        if err > (2.0 * TOL * G if noise else 2.0 * TOL * s + SLACK * gap):
             bad.append((k, err / s, gap / s))
         worst = max(worst, (err / s, k))
         n += 1
