@@ -190,9 +190,17 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
                  '%d -> 32 x 5 -> %d channels, %d x %d)' % (I0, O, Hh, Ww))
         pmc = ('k_convnet_chain_bwd', '18, 181')
         per_call = 1
+        if wgs == 0:
+            # batches beyond the persistent chain's co-residency limit at this level (B = 512 on one GPU): the conditioners run as one
+            # launch per layer (csrc/conv_bn.hip); the dominant one is the forward of a 32 -> 32 channel 3 x 3 layer at 16 x 16
+            entry, match = 'nf_conv_bn_fwd', (lambda a: int(a[2]) == 32 and int(a[3]) == 32 and int(a[4]) == Hh and int(a[6]) == 3)
+            flop = 2 * M * 9 * 32 * 32
+            nbytes = 4 * M * 32 * 3
+            kname = 'k_conv_bn_fwd (one 32 -> 32 channel 3 x 3 layer + BatchNorm statistics per launch, %d x %d, fp32 MFMA)' % (Hh, Ww)
+            pmc = ('k_conv_bn_fwd', '')
         note = ('%s of 256 compute units hold the launch; five dependent convolutions inside five grid-wide BatchNorm exchanges '
-                '(DESIGN.md section 3.16)' % (wgs if wgs is not None else '<= 128'))
-        extra['workgroups'] = wgs
+                '(DESIGN.md section 3.16)' % wgs) if wgs else 'per-layer launches: the batch exceeds the persistent chain at this level'
+        extra['workgroups'] = wgs or None
     elif cfg['kind'] in ('glow', 'realnvp') and len(dims) == 1:
         glow = cfg['kind'] == 'glow'
         F = importlib.import_module(PKG + '.fused')
@@ -402,7 +410,7 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic (seeded %s restatement, random-init weights)' % cfg['data'],
-        'config': {'workload': cfg['desc'], 'name': name, 'per_gpu_batch': B, 'global_batch': B * world,
+        'config': {'workload': cfg['desc'] if not args.batch else cfg['desc'] + ' -- measured at per-GPU batch %d' % B, 'name': name, 'per_gpu_batch': B, 'global_batch': B * world,
                    'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None, 'collective': collective_info(world)},
         'loss_nats': round(loss_val, 5),
         'bits_per_dim': round(nftrain.bits_per_dim(loss_val, cfg['dims']), 5),
@@ -482,8 +490,17 @@ def main():
     out = run_workload(primary, args, pkg, rank, world, dev, args.steps, args.warmup, args.cpu_seconds)
     if args.config is None and args.batch is None:
         also = run_workload('c1', args, pkg, rank, world, dev, max(args.steps, 50), args.warmup, min(args.cpu_seconds, 6.0))
+        # config 4's literal batch (512) on ONE GPU: informational -- the 4 x 4 level runs the persistent chain, the 8 x 8 and 16 x 16
+        # levels exceed its co-residency limit at this batch and run one launch per layer (single-GPU runs only: the DP runs shard 512)
+        b512 = None
+        if world == 1:
+            args.batch = 512
+            b512 = run_workload('c4', args, pkg, rank, world, dev, min(args.steps, 8), args.warmup, min(args.cpu_seconds, 12.0))
+            args.batch = None
         if rank == 0:
             out['also'] = {'c1': also}
+            if b512 is not None:
+                out['also']['c4_b512'] = b512
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
