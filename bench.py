@@ -212,7 +212,10 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
             pmc = ('k_mlp_chain_bwd', '')
             nbytes = B * (3 * D + 1) * 4
         else:
-            entry, per_call = ('nf_glow_flow_vec_bwd' if glow else 'nf_realnvp_flow_vec_bwd'), 1
+            entry = 'nf_glow_flow_vec_bwd' if glow else 'nf_realnvp_flow_vec_bwd'
+            if F.FLOW_DEFER_FOLD:
+                entry += '_deferred'                         # (+ the one k_glow_fold_all launch behind it, inside the bracket)
+            per_call = 1
             flop = S * 17 * 2 * 32 * 32 * B
             kname = 'k_glow_flow_bwd<%d> (backward of all %d %s flow steps, one launch)' % (1 if glow else 2, S, 'Glow' if glow else 'RealNVP')
             pmc = ('k_glow_flow_bwd', '')

@@ -853,6 +853,16 @@ int nf_realnvp_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float
 int nf_realnvp_flow_vec_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,
                             float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs2, int64_t N, int D,
                             float bn_eps, float wn_eps, nf_stream_t stream);
+/* The whole-flow backward with the gradient fold DEFERRED: the launch ends every step after its data gradient and leaves the step's
+ * weight-gradient slabs (slabs_all: S x blocks x NF_MLP_BWD_SLAB_WG_FLOATS, blocks = ceil(N / NF_MLP_ROWS_PER_BLOCK)) and head sums
+ * (head_rec: S x blocks x 64) behind; one fold launch for all S steps follows it on the same stream.  In-kernel the fold is 8.4 of a
+ * step's 34 us at two workgroups (C1: 1.89 -> 1.6 ms per train step).  Same results up to the summation order of the fold.           */
+int nf_glow_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,
+                                  float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs_all, float* head_rec,
+                                  int64_t N, int D, int training, float bn_eps, float wn_eps, nf_stream_t stream);
+int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
+                                     const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs_all,
+                                     float* head_rec, int64_t N, int D, float bn_eps, float wn_eps, nf_stream_t stream);
 
 /* The persistent kernels above wait on each other with BOUNDED spin loops (a grid of <= NF_MLP_MAX_BLOCKS workgroups is
  * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some

@@ -1652,11 +1652,14 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlo
                                                                  const float* ys, const float* g_y, const float* g_ld, float* gzs,
                                                                  const float* saves, int save_stride, int accumulate, float* ws,
                                                                  float* slabs, int64_t N, int D, int training, float eps,
-                                                                 float wn_eps, int rec_off) {
+                                                                 float wn_eps, int rec_off, float* head_rec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     unsigned long long (*rec)[NF_GF_REC_WORDS] = reinterpret_cast<unsigned long long (*)[NF_GF_REC_WORDS]>(sm + rec_off);
     const int64_t ND = N * D;
     const bool rt = (int)threadIdx.x < NF_GF_REC_WORDS;
+    // head_rec != nullptr: deferred fold -- `slabs` then holds a region per step and workgroup (S x grid x NF_MC_SLAB), every step
+    // leaves its slab and head sums behind and ONE k_glow_fold_all launch after this kernel turns them into parameter gradients (the
+    // in-kernel fold is 8.4 of a step's 34 us at two workgroups: tools/probes/mlp_chain_prof.py)
     if (rt) rec[(S - 1) & 1][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps + S - 1)[threadIdx.x];
     __syncthreads();
     NfMcCarry carry;
@@ -1668,9 +1671,11 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlo
         if (rt && s > 0) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 1)[threadIdx.x];
         const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
         nf_mc_bwd_body<HEAD>(sm, nullptr, st.p, saves + (int64_t)s * save_stride, nullptr, nullptr, st.g, accumulate,
-                          ws + (int64_t)s * NF_MLP_WS_FLOATS, slabs + (int64_t)(s & 1) * NF_MLP_BWD_SLAB_FLOATS, N, D / 2, D, training,
-                          eps, wn_eps, st.h, s == 0 ? z0 : ys + (int64_t)(s - 1) * ND, s == S - 1 ? g_y : gzs + (int64_t)(s + 1) * ND,
-                          g_ld, gzs + (int64_t)s * ND, &carry);
+                          ws + (int64_t)s * NF_MLP_WS_FLOATS,
+                          head_rec != nullptr ? slabs + (size_t)s * gridDim.x * NF_MC_SLAB : slabs + (int64_t)(s & 1) * NF_MLP_BWD_SLAB_FLOATS,
+                          N, D / 2, D, training, eps, wn_eps, st.h, s == 0 ? z0 : ys + (int64_t)(s - 1) * ND,
+                          s == S - 1 ? g_y : gzs + (int64_t)(s + 1) * ND, g_ld, gzs + (int64_t)s * ND, &carry,
+                          head_rec != nullptr ? head_rec + (size_t)s * gridDim.x * 64 : nullptr);
         NF_MC_T(105);
         if (rt) rec[(s + 1) & 1][threadIdx.x] = nxt;    // parity of s - 1
         __syncthreads();
@@ -1704,7 +1709,7 @@ static int nf_flow_launch_fwd(const void* steps_dev, int S, const float* z0, flo
 template <int HEAD>
 static int nf_flow_launch_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld,
                               float* gzs, const float* saves, int save_stride, int accumulate, float* ws_zero, float* slabs2,
-                              int64_t N, int D, int training, float bn_eps, float wn_eps, nf_stream_t stream) {
+                              int64_t N, int D, int training, float bn_eps, float wn_eps, nf_stream_t stream, float* head_rec = nullptr) {
     if (steps_dev == nullptr || S < 1 || S > NF_GLOW_FLOW_MAX_STEPS || z0 == nullptr || ys == nullptr || g_y == nullptr ||
         gzs == nullptr || saves == nullptr || ws_zero == nullptr || slabs2 == nullptr || !nf_glow_args_ok(N, D))
         return NF_E_BADARG;
@@ -1719,7 +1724,7 @@ static int nf_flow_launch_bwd(const void* steps_dev, int S, const float* z0, con
     }
     hipLaunchKernelGGL(k_glow_flow_bwd<HEAD>, dim3(grid), dim3(NF_MC_THREADS), lds, (hipStream_t)stream,
                        (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, save_stride, accumulate, ws_zero, slabs2, N, D,
-                       training, bn_eps, wn_eps, (int)(body_lds / sizeof(float)));
+                       training, bn_eps, wn_eps, (int)(body_lds / sizeof(float)), head_rec);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -1884,6 +1889,41 @@ extern "C" int nf_realnvp_flow_steps_bwd(const void* steps_host, const void* ste
                                          float wn_eps, nf_stream_t stream) {
     return nf_flow_steps_bwd<2>(steps_host, steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, ws_zero,
                                 slabs_all, head_rec, N, D, 1, bn_eps, wn_eps, stream);
+}
+
+// whole-flow backward with the DEFERRED fold: one launch for the data gradients of all S steps (slabs_all: a region per step and
+// workgroup, head_rec: the steps' head sums), one k_glow_fold_all launch behind it
+template <int HEAD>
+static int nf_flow_launch_bwd_deferred(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
+                                       const float* g_ld, float* gzs, const float* saves, int save_stride, int accumulate,
+                                       float* ws_zero, float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps,
+                                       float wn_eps, nf_stream_t stream) {
+    if (head_rec == nullptr) return NF_E_BADARG;
+    const int rc = nf_flow_launch_bwd<HEAD>(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, save_stride, accumulate, ws_zero, slabs_all, N, D,
+                                            training, bn_eps, wn_eps, stream, head_rec);
+    if (rc != 0 || N <= 0) return rc;
+    const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const size_t lds_fold = nf_mc_lds_bytes(1);
+    hipError_t e = hipFuncSetAttribute((const void*)k_glow_fold_all<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fold);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_glow_fold_all<HEAD>, dim3(NF_GF_FOLD_BLOCKS, S), dim3(NF_MC_THREADS), lds_fold, (hipStream_t)stream,
+                       (const NfGlowFlowStep*)steps_dev, slabs_all, head_rec, (int)grid, accumulate, D, wn_eps);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int nf_glow_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
+                                             const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
+                                             float* slabs_all, float* head_rec, int64_t N, int D, int training, float bn_eps,
+                                             float wn_eps, nf_stream_t stream) {
+    return nf_flow_launch_bwd_deferred<1>(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_GLOW_FLOW_SAVE_FLOATS, accumulate, ws_zero,
+                                          slabs_all, head_rec, N, D, training, bn_eps, wn_eps, stream);
+}
+extern "C" int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y,
+                                                const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
+                                                float* slabs_all, float* head_rec, int64_t N, int D, float bn_eps, float wn_eps,
+                                                nf_stream_t stream) {
+    return nf_flow_launch_bwd_deferred<2>(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, ws_zero,
+                                          slabs_all, head_rec, N, D, 1, bn_eps, wn_eps, stream);
 }
 
 // the same for a run of RealNVP steps [flow BatchNorm (batch statistics), AffineCoupling]: records packed by nf_realnvp_flow_pack

@@ -703,6 +703,9 @@ GLOW_FLOW_AUTO_ROWS = 1024
 # step's grid barrier + gradient fold to one launch at the end (nf_glow_flow_steps_*; C2 at B = 2048 / 4096 / 16384:
 # 1.77 -> 1.63 / 1.88 -> 1.71 / 3.02 -> 2.50 ms per train step)
 GLOW_FLOW_STEPS = _os.environ.get('NF_GLOW_FLOW_STEPS', '1') != '0'
+# the whole-flow backward leaves every step's weight-gradient slabs behind and ONE launch folds them all (nf_*_flow_vec_bwd_deferred):
+# the in-kernel fold is 8.4 of a step's 34 us at two workgroups (C1 1.89 -> 1.6 ms per train step); NF_FLOW_DEFER_FOLD=0: in-kernel
+FLOW_DEFER_FOLD = _os.environ.get('NF_FLOW_DEFER_FOLD', '1') != '0'
 # Device tables of per-step pointer records, keyed by the addresses they contain (if a later model lands on the same addresses
 # the entry is, by construction, still correct).  A captured hipGraph (FlowTrainer._capture) has the table's address baked into its
 # kernel arguments, so an entry that was looked up or created WHILE A STREAM WAS CAPTURING is pinned for the life of the process;
@@ -846,6 +849,11 @@ class _GlowFlowVec(torch.autograd.Function):
             N.call('nf_glow_flow_steps_bwd', ctypes.addressof(ctx.host), table.data_ptr(), S, N.ptr(z),
                    N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D,
                    int(training), BN_EPS, WN_EPS, N.stream())
+        elif FLOW_DEFER_FOLD:                  # whole-flow launch, every step's gradient fold in ONE launch behind it
+            rpb = N.header_constant('NF_MLP_ROWS_PER_BLOCK')
+            slabs, rec = _glow_steps_scratch(S, (Nrows + rpb - 1) // rpb, dev)
+            N.call('nf_glow_flow_vec_bwd_deferred', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs),
+                   N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, int(training), BN_EPS, WN_EPS, N.stream())
         else:
             N.call('nf_glow_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves),
                    1, N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, int(training), BN_EPS, WN_EPS, N.stream())
@@ -1038,6 +1046,11 @@ class _RealNVPFlowVec(torch.autograd.Function):
             slabs, rec = _glow_steps_scratch(S, (Nrows + rpb - 1) // rpb, dev)
             N.call('nf_realnvp_flow_steps_bwd', ctypes.addressof(ctx.host), table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y),
                    _p(g_ld), N.ptr(gzs), N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, BN_EPS, WN_EPS, N.stream())
+        elif FLOW_DEFER_FOLD:
+            rpb = N.header_constant('NF_MLP_ROWS_PER_BLOCK')
+            slabs, rec = _glow_steps_scratch(S, (Nrows + rpb - 1) // rpb, dev)
+            N.call('nf_realnvp_flow_vec_bwd_deferred', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs),
+                   N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, BN_EPS, WN_EPS, N.stream())
         else:
             N.call('nf_realnvp_flow_vec_bwd', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs), N.ptr(saves),
                    1, N.ptr(ws), N.ptr(_glow_flow_slabs(dev)), Nrows, D, BN_EPS, WN_EPS, N.stream())

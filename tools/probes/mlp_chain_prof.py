@@ -15,7 +15,8 @@ SO = os.path.join(PKG, 'build', 'libmcprof.so')
 if len(sys.argv) > 1 and sys.argv[1] == 'build':
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DNF_MC_PROF=1', '-o', SO,
-                           os.path.join(PKG, 'csrc', 'mlp_chain.hip'), os.path.join(PKG, 'csrc', 'made_chain.hip')])
+                           os.path.join(PKG, 'csrc', 'mlp_chain.hip'), os.path.join(PKG, 'csrc', 'made_chain.hip'),
+                           os.path.join(PKG, 'csrc', 'conv_chain.hip')])
     print('built', SO)
     sys.exit(0)
 
