@@ -133,6 +133,18 @@ __device__ __forceinline__ void nf_grid_barrier(unsigned* counter, unsigned targ
 //   publish: red[w * 64 + i] per-wave partials (w < NF_MC_WAVES) -> this workgroup's slots
 //   collect: sm[NF_MC_TOT + (round & 1) * 64 + i] (i < 64) = grid totals, valid after the call; double buffered because
 //            there is no barrier between a wave reading them and a faster wave starting the next round
+// one slot of the partner workgroup (two-workgroup grids): bounded poll, returns the value
+__device__ __forceinline__ float nf_mc_poll1(const unsigned long long* p, unsigned gen) {
+    unsigned long long v;
+    unsigned spins = 0;
+    do {
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == gen) break;
+        if (++spins > nf_mc_spin_limit) { NF_PERSIST_GIVE_UP(nf_mc); break; }
+        __builtin_amdgcn_s_sleep(1);
+    } while (true);
+    return __uint_as_float((unsigned)v);
+}
 __device__ __forceinline__ void nf_mc_publish(float* sm, unsigned long long* slots, int round, unsigned gen) {
     float* red = sm + NF_MC_RED;
     __syncthreads();                                     // red (and any LDS tile written before) complete
@@ -140,9 +152,8 @@ __device__ __forceinline__ void nf_mc_publish(float* sm, unsigned long long* slo
         float mine = 0.f;
 #pragma unroll
         for (int w = 0; w < NF_MC_WAVES; ++w) mine += red[w * 64 + threadIdx.x];
-        if (gridDim.x == 1) {
-            red[threadIdx.x] = mine;                     // row 0 of red doubles as the result (its partial is consumed)
-        } else {
+        if (gridDim.x <= 2) red[threadIdx.x] = mine;     // row 0 of red doubles as the result / keeps this workgroup's part (its partial is consumed)
+        if (gridDim.x > 1) {
             const unsigned long long pk = ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(mine);
             __hip_atomic_store(slots + ((size_t)round * NF_MLP_MAX_BLOCKS + blockIdx.x) * 64 + threadIdx.x, pk, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -159,6 +170,17 @@ __device__ __forceinline__ const float* nf_mc_collect(float* sm, int gather, uns
         return tot;
     }
     const unsigned long long* rs = slots + (size_t)round * NF_MLP_MAX_BLOCKS * 64;
+    if (G == 2) {
+        // two workgroups (C1: 256 rows): the 64 publishing threads poll the partner's slot themselves and add their own part -- no
+        // gather through LDS, one barrier (the general path below: 2.1 us per exchange at two workgroups, tools/probes/mlp_chain_prof.py)
+        if (threadIdx.x < 64) {
+            const float other = nf_mc_poll1(rs + (size_t)(1 - blockIdx.x) * 64 + threadIdx.x, gen);
+            const float mine = sm[NF_MC_RED + threadIdx.x];
+            tot[threadIdx.x] = blockIdx.x == 0 ? mine + other : other + mine;       // workgroup order, as below
+        }
+        __syncthreads();
+        return tot;
+    }
     // four slots per thread and trip, all four loads in flight before any is looked at: a poll round costs ONE memory latency
     // (polling them one after the other cost four: 2.2 us per exchange at 32 workgroups instead of ~1.3)
     for (int e0 = threadIdx.x; e0 < G * 64; e0 += 4 * NF_MC_THREADS) {
@@ -251,9 +273,8 @@ __device__ __forceinline__ void nf_mc_publish_stats(float* sm, unsigned long lon
                 M2 += nw > 0 ? fmaf((float)nw * d, d, red[w * 64 + 32 + i]) : 0.f;
             }
         }
-        if (gridDim.x == 1) {
-            red[i] = S; red[32 + i] = M2;                // one wave: every read above precedes these stores
-        } else {
+        if (gridDim.x <= 2) { red[i] = S; red[32 + i] = M2; }     // one wave: every read above precedes these stores
+        if (gridDim.x > 1) {
             unsigned long long* dst = slots + ((size_t)round * NF_MLP_MAX_BLOCKS + blockIdx.x) * 64 + i;
             __hip_atomic_store(dst, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(S), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -276,6 +297,27 @@ __device__ __forceinline__ const float* nf_mc_collect_stats(float* sm, int gathe
         return tot;
     }
     const unsigned long long* rs = slots + (size_t)round * NF_MLP_MAX_BLOCKS * 64;
+    if (G == 2) {
+        // two workgroups: the publishing lanes poll the partner's (sum, M2) themselves and merge -- same formula, same order as the
+        // general path (block 0, then block 1), one barrier instead of five
+        if (threadIdx.x < 32) {
+            const int i = threadIdx.x;
+            const unsigned long long* po = rs + (size_t)(1 - blockIdx.x) * 64 + i;
+            const float So = nf_mc_poll1(po, gen), Mo = nf_mc_poll1(po + 32, gen);
+            const float Sm = sm[NF_MC_RED + i], Mm = sm[NF_MC_RED + 32 + i];
+            const float S0 = blockIdx.x == 0 ? Sm : So, M0 = blockIdx.x == 0 ? Mm : Mo;
+            const float S1 = blockIdx.x == 0 ? So : Sm, M1 = blockIdx.x == 0 ? Mo : Mm;
+            const int n0 = nf_mc_rows_of_block(N, 0), n1 = nf_mc_rows_of_block(N, 1);
+            const float S = S0 + S1, mean = S / (float)N;
+            const float inv_full = 1.f / (float)NF_MLP_ROWS_PER_BLOCK;
+            const float d0 = S0 * (n0 == NF_MLP_ROWS_PER_BLOCK ? inv_full : 1.f / (float)max(n0, 1)) - mean;
+            const float d1 = S1 * (n1 == NF_MLP_ROWS_PER_BLOCK ? inv_full : 1.f / (float)max(n1, 1)) - mean;
+            tot[i] = S;
+            tot[32 + i] = fmaf((float)n0 * d0, d0, M0) + fmaf((float)n1 * d1, d1, M1);
+        }
+        __syncthreads();
+        return tot;
+    }
     for (int e0 = threadIdx.x; e0 < G * 64; e0 += 4 * NF_MC_THREADS) {
         unsigned long long v[4];
         unsigned spins = 0;
