@@ -3,7 +3,7 @@
 # --kernel-trace only) of the dominant kernels, the asymptotic kernel sweep and the per-config bench lines -> gpurun_out/prof_rNN/.
 #   bash tools/collect_profiles.sh r02
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -26,4 +26,21 @@ for c in c1 c2 c3 c4 c5; do
   python bench.py --config $c --steps 50 --cpu-seconds 15 > $OUT/${R}_bench_$c.json 2> /dev/null
 done
 python bench.py > $OUT/${R}_bench_default.json 2> $OUT/bench_default.err
+# per-step launch census of the two metric configs (steady-state window between marker launches) and per-grid chain launch times
+cd /tmp
+for c in c4 c1; do
+  rm -rf /tmp/sk_$c
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/sk_$c -o st -- python $GRAFT_REPO_ROOT/tools/step_kernels.py $c > /dev/null 2> $OUT/sk_$c.err
+  T=$(find /tmp/sk_$c -name "st_kernel_trace.csv" | head -1)
+  TOP=45 python $GRAFT_REPO_ROOT/tools/step_kernels.py --census $T > $OUT/${R}_${c}_step_kernels.txt
+  python $GRAFT_REPO_ROOT/tools/step_kernels.py --by-grid $T chain >> $OUT/${R}_${c}_step_kernels.txt
+  python $GRAFT_REPO_ROOT/tools/step_kernels.py --by-grid $T head >> $OUT/${R}_${c}_step_kernels.txt
+done
+cd $GRAFT_REPO_ROOT
+# the reference path's own spread under row permutations and the per-step error profile of C1; the kink census runs on the host
+python tools/probes/parity_depth.py c1 > $OUT/${R}_c1_parity_depth.txt 2>&1
+python tools/cpu_threads.py c4 8 16 32 64 > $OUT/${R}_cpu_threads.txt 2>&1
+SECONDS_PER=4 python tools/cpu_threads.py c1 1 4 8 16 32 >> $OUT/${R}_cpu_threads.txt 2>&1
+python -m pytest tests/test_gpu_fullsize_parity.py -q > $OUT/pytest_fullsize.log 2>&1
+cp gpurun_out/fullsize_parity.txt $OUT/${R}_fullsize_parity.txt
 ls -la $OUT
