@@ -711,6 +711,13 @@ FLOW_DEFER_FOLD = _os.environ.get('NF_FLOW_DEFER_FOLD', '1') != '0'
 # kernel arguments, so an entry that was looked up or created WHILE A STREAM WAS CAPTURING is pinned for the life of the process;
 # everything else (eager models that come and go: tests, bench.py running several workloads) is least-recently-used beyond
 # NF_FLOW_TABLE_CACHE entries (~25 KB each for 32 steps).
+def _capturing():
+    try:
+        return bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+    except Exception:
+        return False
+
+
 class _FlowTableCache:
     def __init__(self, limit):
         import collections
@@ -723,12 +730,12 @@ class _FlowTableCache:
         if e is None:
             return None
         self.entries.move_to_end(key)
-        if torch.cuda.is_current_stream_capturing():
+        if _capturing():
             e[1] = True
         return e[0]
 
     def __setitem__(self, key, table):
-        self.entries[key] = [table, bool(torch.cuda.is_current_stream_capturing())]
+        self.entries[key] = [table, _capturing()]
         if len(self.entries) > self.limit:
             for k in list(self.entries):
                 if len(self.entries) <= self.limit:

@@ -110,3 +110,46 @@ def test_trainer_loss_matches_reference_formula(pkg):
     want = -1.0 * torch.mean(mvn.log_prob(z.view(16, -1)) + ld)                  # main.py:85
     assert torch.allclose(train.nll_loss(z, ld), want, atol=1e-5)
     assert abs(train.bits_per_dim(7.0 * 48 * np.log(2.0), (3, 4, 4)) - 7.0) < 1e-9
+
+
+def test_flow_table_cache_is_bounded_and_keeps_pinned_entries(pkg):
+    """fused._FlowTableCache: least-recently-used beyond its limit, except entries that were touched while a stream was capturing
+    (a captured hipGraph has their device address baked into its kernel arguments)."""
+    import importlib
+    import torch
+    fused = importlib.import_module(pkg.__name__ + '.fused')
+    cache = fused._FlowTableCache(4)
+    tables = [torch.zeros(8, dtype=torch.uint8) for _ in range(10)]
+    for i in range(3):
+        cache[('k', i)] = tables[i]
+        cache.host[tables[i].data_ptr()] = object()
+    cache.entries[('k', 1)][1] = True                   # as if looked up during a capture
+    assert cache.get(('k', 0)) is tables[0]             # refreshes entry 0
+    for i in range(3, 10):
+        cache[('k', i)] = tables[i]
+        cache.host[tables[i].data_ptr()] = object()
+    assert len(cache) == 4
+    assert cache.get(('k', 1)) is tables[1], 'a pinned entry was evicted'
+    assert cache.get(('k', 0)) is None and cache.get(('k', 2)) is None
+    assert cache.get(('k', 9)) is tables[9]
+    assert tables[0].data_ptr() not in cache.host and tables[1].data_ptr() in cache.host
+
+
+def test_zero_arena_retires_only_buffers_a_graph_was_captured_against(pkg):
+    import importlib
+    import torch
+    ws = importlib.import_module(pkg.__name__ + '.workspace')
+    arena = ws.ZeroArena()
+    dev = torch.device('cpu')
+    arena.begin(dev)
+    arena.zeros(1 << 16, dev)
+    arena.end()
+    first = arena.buf
+    arena.begin(dev)                                     # outgrown, never captured against: dropped, not retired
+    assert arena.buf is not first and arena.retired == []
+    arena.zeros(1 << 18, dev)
+    arena.end()
+    arena.captured = True                                # as if a capture had happened on the current buffer
+    second = arena.buf
+    arena.begin(dev)
+    assert arena.buf is not second and arena.retired == [second]
