@@ -123,6 +123,101 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
     }
 }
 
+// The same forward on 64-PIXEL blocks (large batches): a wave's lane li owns the four pixels 4 li .. 4 li + 3 of the block -- 16-byte loads
+// and stores, 256 contiguous bytes per channel row and wave instruction instead of 64 (an 8 x 8 plane is ONE row; with 16-pixel blocks
+// every access is a 64-byte segment and the kernel reaches 25 % of the HBM rate at C = 48).  The four MFMA column tiles are the
+// pixel sets {4 li + t}: columns are independent, so any assignment of pixels to columns is a valid GEMM.
+template <int RT, int KQ>
+__global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd4(const float* __restrict__ x, const float* __restrict__ als,
+                                                               const float* __restrict__ abias, const float* __restrict__ M,
+                                                               const float* __restrict__ log_s, float* __restrict__ h,
+                                                               float* __restrict__ z1c, float* __restrict__ ld, NfSplit s, int64_t B,
+                                                               int C, int P) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    {
+        float sl = lane < C ? log_s[lane] - als[lane] : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, NF_WAVE);
+        const float dl = (float)P * sl;
+        const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += dl;
+    }
+    // W, the ActNorm bias and 1 / exp(log_scale) stay in LDS: with the A fragments (RT * KQ registers) and the vectors in registers
+    // next to 48 accumulators and 48 pixel registers a wave needs 256 VGPRs at C = 48 -- one wave per SIMD, 38 % of the HBM rate;
+    // from LDS (five reads per k-step) it is four waves per SIMD, and the waves hide each other's memory latency
+    __shared__ float Ws[64 * 65 + 128];
+    float* sab = Ws + 64 * 65;
+    float* sad = sab + 64;
+    const int bpp = P / 64;
+    const int64_t nblk = B * bpp;                            // 64-pixel blocks (P % 64 == 0: never straddle samples)
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int e = threadIdx.x; e < 64 * 65; e += blockDim.x) {
+        const int r = e / 65, c = e - r * 65;
+        Ws[e] = (r < C && c < C) ? M[r * C + c] : 0.f;
+    }
+    if (threadIdx.x < 64) {
+        sab[threadIdx.x] = threadIdx.x < C ? abias[threadIdx.x] : 0.f;
+        sad[threadIdx.x] = threadIdx.x < C ? expf(-als[threadIdx.x]) : 0.f;     // (x - b) / e^ls as (x - b) * e^-ls: within 1 ulp of the division
+    }
+    __syncthreads();
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t b = blk / bpp;
+        const int p0 = (int)(blk - b * bpp) * 64 + 4 * li;   // this lane's first pixel
+        const float* xb = x + b * C * P + p0;
+        float* hb = h + b * C * P + p0;
+        float4 xv[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            xv[q] = c < C ? *(const float4*)(xb + (int64_t)c * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        f32x4 acc[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;                        // (c >= C: bias 0, scale 0 -> B operand 0)
+            const float ab = sab[c], ad = sad[c];
+            const float b0 = (xv[q].x - ab) * ad, b1 = (xv[q].y - ab) * ad, b2 = (xv[q].z - ab) * ad, b3 = (xv[q].w - ab) * ad;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float a = Ws[(16 * rt + li) * 65 + c];
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[rt][1], 0, 0, 0);
+                acc[rt][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc[rt][2], 0, 0, 0);
+                acc[rt][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b3, acc[rt][3], 0, 0, 0);
+            }
+        }
+        float* zb = z1c + b * s.n_half;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                    // D of tile t: col = li (pixel 4 li + t), row = 4 lk + j
+                const int r = 16 * rt + 4 * lk + j;
+                if (r < C) {
+                    const float4 v = make_float4(acc[rt][0][j], acc[rt][1][j], acc[rt][2][j], acc[rt][3][j]);
+                    *(float4*)(hb + (int64_t)r * P) = v;
+                    if (s.mode == NF_SPLIT_CHANNEL) {        // the half is a channel range: the same four pixels, one 16-byte store
+                        const int hc = s.C >> 1, sel = r >= hc ? 1 : 0;
+                        if ((sel ^ s.odd) == 1) *(float4*)(zb + (int64_t)(r - sel * hc) * P + p0) = v;
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int p = p0 + t, yy = p / s.W, xx = p - yy * s.W;
+                            int which, e;
+                            nf_gh_full_to_half(s, r, p, yy, xx, which, e);
+                            if (which == 1) zb[e] = vv[t];
+                        }
+                    }
+                }
+            }
+    }
+}
+
 // TP = pixels per staged tile: 128, or 64 where 128 would leave fewer than 64 workgroups (the 8 x 8 level at B = 64: 32 -> 64 workgroups,
 // each wave 16 pixels instead of 32 -- the launch is a latency chain, a wave's part of it halves)
 template <int RT, int KQ, int TP>
@@ -338,6 +433,23 @@ extern "C" int nf_glow_head_w_fwd(const float* x, const float* act_log_scale, co
                            log_s, h, z1c, ld, s, B, C, P);                                                                      \
         NF_CHECK_LAUNCH();                                                                                                      \
         return 0;                                                                                                               \
+    }
+    // large batches (>= 4 blocks of 64 pixels per compute unit): 64-pixel blocks, 16-byte accesses
+    const int64_t nblk64 = (P % 64 == 0) ? B * (P / 64) : 0;
+    if (nblk64 >= 1024) {
+        int64_t g4 = (nblk64 + 3) / 4;
+        if (g4 > 1024) g4 = 1024;                            // four workgroups per compute unit: a wave walks several blocks per W staging
+        if (g4 < g_ld) g4 = g_ld > 4096 ? 4096 : g_ld;
+#define NF_CASE4(RT, KQ)                                                                                                        \
+        if (rt == RT && kq == KQ) {                                                                                             \
+            hipLaunchKernelGGL((k_glow_head_w_fwd4<RT, KQ>), dim3((unsigned)g4), dim3(NF_BLOCK), 0, st, x, act_log_scale, act_bias, Wm, \
+                               log_s, h, z1c, ld, s, B, C, P);                                                                  \
+            NF_CHECK_LAUNCH();                                                                                                  \
+            return 0;                                                                                                           \
+        }
+        NF_CASE4(1, 3) NF_CASE4(1, 4) NF_CASE4(2, 5) NF_CASE4(2, 6) NF_CASE4(2, 7) NF_CASE4(2, 8) NF_CASE4(3, 9) NF_CASE4(3, 10)
+        NF_CASE4(3, 11) NF_CASE4(3, 12) NF_CASE4(4, 13) NF_CASE4(4, 14) NF_CASE4(4, 15) NF_CASE4(4, 16)
+#undef NF_CASE4
     }
     NF_CASE(1, 3) NF_CASE(1, 4) NF_CASE(2, 5) NF_CASE(2, 6) NF_CASE(2, 7) NF_CASE(2, 8) NF_CASE(3, 9) NF_CASE(3, 10)
     NF_CASE(3, 11) NF_CASE(3, 12) NF_CASE(4, 13) NF_CASE(4, 14) NF_CASE(4, 15) NF_CASE(4, 16)

@@ -174,7 +174,10 @@ def test_coupling_fused_into_the_conditioner_launch(pkg, dims, masking, odd, B, 
 
 @pytest.mark.parametrize('C,H,W,mode_name,odd,B', [(12, 16, 16, 'channelwise', False, 64), (12, 16, 16, 'checkerboard', True, 7),
                                                    (48, 8, 8, 'channelwise', True, 64), (48, 8, 8, 'checkerboard', False, 64),
-                                                   (10, 4, 8, 'checkerboard', False, 3), (64, 4, 4, 'channelwise', False, 9)])
+                                                   (10, 4, 8, 'checkerboard', False, 3), (64, 4, 4, 'channelwise', False, 9),
+                                                   # large batches: the forward on 64-pixel blocks (k_glow_head_w_fwd4)
+                                                   (48, 8, 8, 'channelwise', False, 1100), (48, 8, 8, 'checkerboard', True, 1030),
+                                                   (12, 16, 16, 'checkerboard', False, 260), (12, 16, 16, 'channelwise', True, 257)])
 def test_glow_head_w_matches_the_three_layers(pkg, C, H, W, mode_name, odd, B):
     """ActNorm + invertible 1x1 (assembled weight) + conditioner-input gather in one MFMA launch per direction == the three layers'
     own launches: outputs, log-det, input gradient, ActNorm gradients and the gradient handed to the batched PLU backward."""
