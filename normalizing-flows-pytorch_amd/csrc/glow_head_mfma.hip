@@ -438,7 +438,7 @@ extern "C" int nf_glow_head_w_fwd(const float* x, const float* act_log_scale, co
     const int64_t nblk64 = (P % 64 == 0) ? B * (P / 64) : 0;
     if (nblk64 >= 1024) {
         int64_t g4 = (nblk64 + 3) / 4;
-        if (g4 > 1024) g4 = 1024;                            // four workgroups per compute unit: a wave walks several blocks per W staging
+        if (g4 > 512) g4 = 512;                            // two workgroups per compute unit (256: 61 %, 512: 64 %, 1024: 60 % of 8 TB/s at (48,8,8)): a wave walks several blocks per W staging
         if (g4 < g_ld) g4 = g_ld > 4096 ? 4096 : g_ld;
 #define NF_CASE4(RT, KQ)                                                                                                        \
         if (rt == RT && kq == KQ) {                                                                                             \

@@ -66,6 +66,79 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_apply_mfma(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Large-batch form: a wave owns 64 consecutive pixels of a sample.  Lane (lk, li) reads ONE float4 per k-step (channel 4q + lk,
+// pixels 4 li .. 4 li + 3: 256 contiguous bytes per channel row and instruction instead of 64) and treats its four components as four
+// 16-pixel MFMA blocks {4 li + pb}; the D fragments of the four blocks hold, per lane and output row, exactly the four consecutive
+// pixels of a float4 store.  Same products, same k order as the 16-pixel kernel: the bits do not change.
+template <int RT, int KQ, bool TRANSPOSE>
+__global__ void __launch_bounds__(NF_BLOCK, 2) k_invconv_apply_mfma4(const float* __restrict__ z, const float* __restrict__ M,
+                                                                  float* __restrict__ y, float* __restrict__ ld,
+                                                                  const float* __restrict__ log_s, float ld_sign, int64_t B,
+                                                                  int C, int P) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    float a[RT][KQ];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int r = 16 * rt + li, c = 4 * q + lk;
+            a[rt][q] = (r < C && c < C) ? (TRANSPOSE ? M[c * C + r] : M[r * C + c]) : 0.f;
+        }
+    const int bpp = P / 64;
+    const int64_t nblk = B * bpp;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // software pipeline: the loads of block i + 1 are in flight while the 12 RT KQ matrix instructions of block i issue
+    f32x4 bv[KQ], nx[KQ];
+    auto fetch = [&](int64_t blk, f32x4* dst) {
+        const bool ok = blk < nblk;
+        const int64_t b = ok ? blk / bpp : 0;
+        const float* zb = z + b * C * P + (int)(ok ? blk - b * bpp : 0) * 64 + 4 * li;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            dst[q] = (ok && c < C) ? *reinterpret_cast<const f32x4*>(zb + (int64_t)c * P) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(wave, nx);
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t b = blk / bpp;
+        const int p0 = (int)(blk - b * bpp) * 64 + 4 * li;
+        float* yb = y + b * C * P + p0;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) bv[q] = nx[q];
+        fetch(blk + nwaves, nx);
+        f32x4 acc[4][RT];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[pb][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q)
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[pb][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], bv[q][pb], acc[pb][rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 16 * rt + 4 * lk + j;
+                if (r < C)
+                    *reinterpret_cast<f32x4*>(yb + (int64_t)r * P) = (f32x4){acc[0][rt][j], acc[1][rt][j], acc[2][rt][j], acc[3][rt][j]};
+            }
+    }
+    if (ld != nullptr) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += log_s[c];
+        const float d = ld_sign * (float)P * s;
+        const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 #define NF_WTP 128  // pixels per staged tile
 template <int RT>
 __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad_mfma(const float* __restrict__ gy, const float* __restrict__ z,
@@ -153,11 +226,14 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad_mfma(const float* __
 // ---------------------------------------------------------------------------------------------------------------
 template <bool TR>
 static bool nf_launch_apply_mfma(int C, dim3 grid, hipStream_t st, const float* z, const float* M, float* y, float* ld,
-                                 const float* log_s, float ld_sign, int64_t B, int P) {
+                                 const float* log_s, float ld_sign, int64_t B, int P, bool wide) {
     const int rt = (C + 15) / 16, kq = (C + 3) / 4;
 #define NF_CASE(RT, KQ)                                                                                                \
     if (rt == RT && kq == KQ) {                                                                                        \
-        hipLaunchKernelGGL((k_invconv_apply_mfma<RT, KQ, TR>), grid, dim3(NF_BLOCK), 0, st, z, M, y, ld, log_s, ld_sign, B, C, P); \
+        if (wide)                                                                                                      \
+            hipLaunchKernelGGL((k_invconv_apply_mfma4<RT, KQ, TR>), grid, dim3(NF_BLOCK), 0, st, z, M, y, ld, log_s, ld_sign, B, C, P); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_invconv_apply_mfma<RT, KQ, TR>), grid, dim3(NF_BLOCK), 0, st, z, M, y, ld, log_s, ld_sign, B, C, P); \
         return true;                                                                                                   \
     }
     NF_CASE(1, 3) NF_CASE(1, 4) NF_CASE(2, 5) NF_CASE(2, 6) NF_CASE(2, 7) NF_CASE(2, 8) NF_CASE(3, 9) NF_CASE(3, 10)
@@ -170,13 +246,17 @@ static bool nf_launch_apply_mfma(int C, dim3 grid, hipStream_t st, const float* 
 __attribute__((visibility("hidden"))) int nf_invconv_apply_mfma_try(const float* z, const float* M, int transpose, float* y, float* ld,
                                          const float* log_s, float ld_sign, int64_t B, int C, int P, void* stream) {
     if (C < 9 || C > 64 || (P % 16) != 0 || B == 0) return 0;
-    const int64_t nblk = B * (P / 16);
-    int64_t g = (nblk + 3) / 4;                              // 4 waves per block, >= 1 block of 16 pixels per wave
+    // 64-pixel blocks once there are enough of them to give every SIMD of the chip two waves
+    const bool wide = (P % 64) == 0 && B * (P / 64) >= 2048 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    const int64_t nblk = wide ? B * (P / 64) : B * (P / 16);
+    int64_t g = (nblk + 3) / 4;                              // 4 waves per block, >= 1 pixel block per wave
     if (g > 2048) g = 2048;
+    if (wide && g > 256) g = 256;                            // one workgroup per CU, every wave pipelines over its blocks (probe:
+                                                             // tools/probes/invconv_apply_probe.hip -- 256: 32 us, 512: 40, 2048: 48 at B = 8192)
     const int64_t g_ld = (B + NF_BLOCK - 1) / NF_BLOCK;
     if (ld != nullptr && g < g_ld) g = g_ld > 4096 ? 4096 : g_ld;
-    const bool ok = transpose ? nf_launch_apply_mfma<true>(C, dim3((unsigned)g), (hipStream_t)stream, z, M, y, ld, log_s, ld_sign, B, P)
-                              : nf_launch_apply_mfma<false>(C, dim3((unsigned)g), (hipStream_t)stream, z, M, y, ld, log_s, ld_sign, B, P);
+    const bool ok = transpose ? nf_launch_apply_mfma<true>(C, dim3((unsigned)g), (hipStream_t)stream, z, M, y, ld, log_s, ld_sign, B, P, wide)
+                              : nf_launch_apply_mfma<false>(C, dim3((unsigned)g), (hipStream_t)stream, z, M, y, ld, log_s, ld_sign, B, P, wide);
     return ok ? 1 : 0;
 }
 

@@ -229,7 +229,8 @@ def test_invconv_golden(nf, C):
     G.assert_close(ldi, g['ld_inv'], _ld_tol(g))
 
 
-@pytest.mark.parametrize('C,P,B', [(5, 7, 9), (48, 64, 64), (12, 256, 16), (3, 1024, 4), (2, 1, 4096)])
+@pytest.mark.parametrize('C,P,B', [(5, 7, 9), (48, 64, 64), (12, 256, 16), (3, 1024, 4), (2, 1, 4096),
+                                   (48, 64, 2050), (12, 256, 513), (20, 64, 2100)])   # the last three: 64-pixel-block apply
 def test_invconv_vs_oracle(nf, C, P, B):
     NF = nf.functional
     g = torch.Generator().manual_seed(C)
