@@ -907,6 +907,36 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
                        int64_t x_row_stride, int x_col_stride, int64_t gx_row_stride, int gx_col_stride, int gx_accumulate,
                        int64_t N, int I0, int O, nf_stream_t stream);
 
+/* ---- Flow++ conditioner for IMAGE data (csrc/flowpp_img.hip)  coupling.py:159-166, modules.py:519-578 ------------------------
+ * net = Conv2d(I0, 32, 3) -> GatedConv2d(32) -> LayerNorm(32,H,W) -> GatedAttn(32, 4 heads) -> LayerNorm -> Conv2d(32, O, 3) on
+ * H = W in {4, 8, 16} maps (nf_flowpp_img_usable != 0; the mid shapes of flows/flowpp.py:22-57 on 16 x 16 and 32 x 32 images).
+ * Per-sample work throughout (no batch statistics): four launches forward, nine backward, all NCHW fp32.
+ *
+ * nf_flowpp_img_conv: out (B, Co, H, W) = conv3x3(in, pad 1) + bias (bias nullable), exact-fp32 matrix-core GEMM.
+ *   in_mode 0: in is (B, Ci, H, W);   in_mode 1: in is (B, Ci / 2, H, W) and the convolution sees concat_elu(in) = elu([in, -in])
+ *   (GatedConv2d's inner convolution, modules.py:500-517);   transposed 0: weight (Co, Ci, 3, 3);   transposed 1: weight (Ci, Co, 3, 3)
+ *   read transposed with flipped taps -- the DATA GRADIENT of the convolution that owns `weight`, `in` being the gradient of its
+ *   output (in_mode 0, bias NULL).
+ * nf_flowpp_img_conv_wgrad: g_weight (Co, Ci, 3, 3) += sum_b g_out (x) in,  g_bias (Co) += sum g_out (nullable); in / in_mode as above.
+ * nf_flowpp_img_celu_bwd: g_x += elu'(x) * g_cat[:, :C] - elu'(-x) * g_cat[:, C:]  (x (B, C, H, W), g_cat (B, 2 C, H, W)).
+ * nf_flowpp_img_mid_fwd: x = conv0 output, a = the gated convolution's output (both (B, 32, H, W)) ->
+ *   LN2( A(LN1(x + elu(a) * sigmoid(elu(-a)))) ),  A(t) = t + y * sigmoid(gate), [y, gate] = conv2(attention(conv1(t + pos))).
+ * nf_flowpp_img_mid_bwd: its autograd, recomputing the forward from x and a; g_x / g_a written, parameter gradients ACCUMULATED.  */
+int nf_flowpp_img_usable(int64_t B, int Ci, int Co, int H, int W);
+int nf_flowpp_img_conv(const float* in, const float* weight, const float* bias, float* out, int64_t B, int Ci, int Co, int H, int W,
+                       int in_mode, int transposed, nf_stream_t stream);
+int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* g_weight, float* g_bias, int64_t B, int Ci, int Co, int H,
+                             int W, int in_mode, nf_stream_t stream);
+int nf_flowpp_img_celu_bwd(const float* x, const float* g_cat, float* g_x, int64_t B, int C, int H, int W, nf_stream_t stream);
+int nf_flowpp_img_mid_fwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
+                          const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
+                          const float* ln2_g, const float* ln2_b, float* out, int64_t B, int H, int W, nf_stream_t stream);
+int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
+                          const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
+                          const float* ln2_g, const float* ln2_b, const float* g_out, float* g_x, float* g_a, float* g_ln1_g,
+                          float* g_ln1_b, float* g_pos, float* g_conv1_w, float* g_conv1_b, float* g_conv2_w, float* g_conv2_b,
+                          float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W, nf_stream_t stream);
+
 /* ---- on-device synthetic batches (csrc/datagen.hip)  flows/dataset.py:13-34, :120; replaces the per-step H2D copy main.py:79 --
  * kind 0 moons, 1 circles, 2 normals: out (n, 2), per_sample = 2;  3 cifar-like uniform uint8 / 255: out (n, per_sample).
  * Counter-based Philox4x32-10 keyed by (seed, *step, sample): stateless and reproducible; `step` (device int64, NULL = 0) is read

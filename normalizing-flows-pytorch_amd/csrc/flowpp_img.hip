@@ -1,0 +1,693 @@
+// Flow++ conditioner for IMAGE data (flows/coupling.py:159-166, flows/modules.py:519-578):
+//     Conv2d(I0, 32, 3) -> GatedConv2d(32) -> LayerNorm(32,H,W) -> GatedAttn(4 heads over the H*W positions) -> LayerNorm -> Conv2d(32, O, 3)
+// with H = W in {4, 8, 16} (the mid shapes of Flowpp on 32 x 32 and 16 x 16 images, flows/flowpp.py:22-57) and O up to 1344.
+//
+// Nothing on this path couples samples (LayerNorm and the attention are per sample), so there is no grid exchange: the work is cut
+// per sample and the kernels are plain launches.
+//   k_fi_conv        3 x 3 convolution as a GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+//                    accumulation).  A workgroup owns 256 pixels (1 / 4 / 16 whole samples) x 32 output channels: the input
+//                    frame (32 channels with a zero halo) and the 32 x 288 weight block sit in LDS, each of the 8 waves finishes
+//                    a 32-pixel block.  The same kernel is the data gradient (weight block read transposed and tap-flipped)
+//                    and applies concat-ELU to its input while staging (the GatedConv2d input never exists in HBM).
+//   k_fi_conv_wgrad  weight + bias gradient of the same convolutions: D[o][c] per tap, K = the tile's 256 pixels split over the
+//                    8 waves, the waves' partial tiles are summed through LDS and leave as one atomic per element.
+//   k_fi_mid         everything between the convolutions for one sample per workgroup, thread (head, position): gate, LayerNorm,
+//                    1x1 projections, softmax attention (two sweeps over the keys held in LDS), gate, LayerNorm; the backward
+//                    variant recomputes that from the two 4-byte inputs and walks it in reverse (no activation is saved).
+// Algorithmic HBM bytes per sample and direction: (I0 + 2 * 32 + 32 + 32 + O) * H * W * 4 for the forward (inputs and outputs of the
+// four launches) -- the activations between the layers of `mid` stay in LDS / registers.
+#include "nf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NF_FI_THREADS 512
+#define NF_FI_WS 289            // row stride of the LDS weight block (288 = 32 channels x 9 taps, odd stride: conflict-free rows)
+#define NF_FI_GS 257            // row stride of the LDS gradient tile of the weight-gradient kernel
+#define NF_FI_LNEPS 1.0e-5f
+
+template <int LGW>
+struct NfFiGeo {
+    static constexpr int W = 1 << LGW, N = W * W, S = 256 / N, PW = W + 2, FS = PW * PW, CS = (S * FS) | 1;
+};
+
+template <int LGW>
+__device__ __forceinline__ int nf_fi_fpos(int p) {          // frame position of pixel p (0..255) of the tile
+    using G = NfFiGeo<LGW>;
+    const int s = p >> (2 * LGW), y = (p >> LGW) & (G::W - 1), x = p & (G::W - 1);
+    return s * G::FS + (y + 1) * G::PW + x + 1;
+}
+
+__device__ __forceinline__ int nf_fi_cd_row(int r, int hs) { return (r & 3) + 8 * (r >> 2) + 4 * hs; }
+__device__ __forceinline__ float nf_fi_elu(float v) { return v > 0.f ? v : expm1f(v); }
+__device__ __forceinline__ float nf_fi_elu_grad(float v) { return v > 0.f ? 1.f : expf(v); }
+__device__ __forceinline__ float nf_fi_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+// 32 channels [c0, c0 + 32) of the tile's samples [b0, b0 + S) with a zero halo; INMODE 1: the convolution sees
+// concat_elu(in) = elu([in, -in]) of a (B, Ci / 2, H, W) tensor (flows/modules.py:500-517)
+template <int LGW, int INMODE>
+__device__ __forceinline__ void nf_fi_stage_frame(float* F, const float* __restrict__ in, int64_t b0, int64_t B, int Ci, int c0) {
+    using G = NfFiGeo<LGW>;
+    constexpr int PER = G::S * G::FS;
+    for (int e = threadIdx.x; e < 32 * PER; e += NF_FI_THREADS) {
+        const int c = e / PER, f = e - c * PER;
+        const int s = f / G::FS, r = f - s * G::FS;
+        const int yy = r / G::PW, xx = r - yy * G::PW;
+        const int cc = c0 + c;
+        float v = 0.f;
+        if (yy >= 1 && yy <= G::W && xx >= 1 && xx <= G::W && cc < Ci && b0 + s < B) {
+            const int q = (yy - 1) * G::W + xx - 1;
+            if (INMODE == 0) {
+                v = in[((b0 + s) * Ci + cc) * G::N + q];
+            } else {
+                const int Ch = Ci >> 1;
+                const float t = in[((b0 + s) * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + q];
+                v = nf_fi_elu(cc < Ch ? t : -t);
+            }
+        }
+        F[c * G::CS + f] = v;
+    }
+}
+
+// Wl[r][k]: row r = output channel o0 + r of this GEMM, k = 9 * (local input channel) + tap.
+//   TR = false: weight (Co, Ci, 3, 3);   TR = true: weight (Ci, Co, 3, 3) read transposed with the taps flipped (data gradient)
+template <bool TR>
+__device__ __forceinline__ void nf_fi_stage_w(float* Wl, const float* __restrict__ w, int Ci, int Co, int o0, int c0) {
+    const int cc = min(32, Ci - c0);
+    for (int e = threadIdx.x; e < 32 * 288; e += NF_FI_THREADS) {
+        if (!TR) {
+            const int r = e / 288, k = e - r * 288;
+            Wl[r * NF_FI_WS + k] = (o0 + r < Co && k < cc * 9) ? w[((int64_t)(o0 + r) * Ci + c0) * 9 + k] : 0.f;
+        } else {
+            const int cl = e / 288, rem = e - cl * 288;
+            const int r = rem / 9, t = rem - r * 9;
+            Wl[r * NF_FI_WS + cl * 9 + 8 - t] = (cl < cc && o0 + r < Co) ? w[((int64_t)(c0 + cl) * Co + o0) * 9 + rem] : 0.f;
+        }
+    }
+}
+
+// one 32-channel chunk of the K axis: groups of 8 channels x 9 taps = 36 two-deep matrix instructions, half hs of the wave
+// supplies k = 72 j + 36 hs + s (any fixed pairing of the k's is a valid order of the sum)
+template <int LGW>
+__device__ __forceinline__ void nf_fi_kchunk(f32x16& acc, const float* Wl, const float* F, int ngroups, int fpos, int r32, int hs) {
+    using G = NfFiGeo<LGW>;
+    const float* wp = Wl + r32 * NF_FI_WS + 36 * hs;
+    const float* fp = F + 4 * hs * G::CS + fpos;
+    for (int j = 0; j < ngroups; ++j) {
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            const int t = s % 9, dy = t / 3 - 1, dx = t % 3 - 1;
+            const float a = wp[72 * j + s];
+            const float b = fp[(8 * j + s / 9) * G::CS + dy * G::PW + dx];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+}
+
+template <int LGW, int INMODE, bool TR>
+__global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int64_t B, int Ci,
+                                                           int Co) {
+    using G = NfFiGeo<LGW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* F = smem;                       // [32][CS]
+    float* Wl = smem + 32 * G::CS;         // [32][NF_FI_WS]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, hs = lane >> 5;
+    const int64_t b0 = (int64_t)blockIdx.x * G::S;
+    const int o0 = 32 * blockIdx.y;
+    const int p = 32 * wid + r32;
+    const int fpos = nf_fi_fpos<LGW>(p);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < Ci; c0 += 32) {
+        __syncthreads();
+        nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
+        nf_fi_stage_w<TR>(Wl, w, Ci, Co, o0, c0);
+        __syncthreads();
+        nf_fi_kchunk<LGW>(acc, Wl, F, (min(32, Ci - c0) + 7) >> 3, fpos, r32, hs);
+    }
+    const int64_t b = b0 + (p >> (2 * LGW));
+    const int q = p & (G::N - 1);
+    if (b < B) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = o0 + nf_fi_cd_row(r, hs);
+            if (oc < Co) out[(b * Co + oc) * G::N + q] = acc[r] + (bias != nullptr ? bias[oc] : 0.f);
+        }
+    }
+}
+
+// g_w[o][c][t] += sum_{b, p} g[b][o][p] * act[b][c][p + off(t)],  g_b[o] += sum g[b][o][p]
+template <int LGW, int INMODE>
+__global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __restrict__ in, const float* __restrict__ g,
+                                                                 float* __restrict__ gw, float* __restrict__ gb, int64_t B, int Ci,
+                                                                 int Co) {
+    using G = NfFiGeo<LGW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* F = smem;                       // [32][CS]; the per-wave partial tiles [8][1024] alias it afterwards
+    float* Gt = smem + 32 * G::CS;         // [32][NF_FI_GS]
+    static_assert(32 * G::CS >= 8 * 1024, "partial tiles alias the frame");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, hs = lane >> 5;
+    const int64_t b0 = (int64_t)blockIdx.x * G::S;
+    const int o0 = 32 * blockIdx.y, c0 = 32 * blockIdx.z;
+    nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
+    for (int e = threadIdx.x; e < 32 * 256; e += NF_FI_THREADS) {
+        const int o = e >> 8, p = e & 255;
+        const int64_t b = b0 + (p >> (2 * LGW));
+        Gt[o * NF_FI_GS + p] = (b < B && o0 + o < Co) ? g[(b * Co + o0 + o) * G::N + (p & (G::N - 1))] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 2
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int p = 32 * wid + 2 * s2 + hs;
+        const float a = Gt[r32 * NF_FI_GS + p];
+        const float* fp = F + r32 * G::CS + nf_fi_fpos<LGW>(p);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float b = fp[(t / 3 - 1) * G::PW + (t % 3) - 1];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    if (gb != nullptr && blockIdx.z == 0 && threadIdx.x < 32 && o0 + (int)threadIdx.x < Co) {
+        float s = 0.f;
+        for (int p = 0; p < 256; ++p) s += Gt[threadIdx.x * NF_FI_GS + p];
+        atomicAdd(gb + o0 + threadIdx.x, s);
+    }
+    float* RED = F;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) RED[wid * 1024 + nf_fi_cd_row(r, hs) * 32 + r32] = acc[t][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 1024; e += NF_FI_THREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += RED[w8 * 1024 + e];
+            const int o = e >> 5, c = e & 31;
+            if (o0 + o < Co && c0 + c < Ci) atomicAdd(gw + ((int64_t)(o0 + o) * Ci + c0 + c) * 9 + t, s);
+        }
+    }
+}
+
+// g_x += elu'(x) * g_cat[:, :C] - elu'(-x) * g_cat[:, C:]   (the concat-ELU in front of the gated convolution)
+__global__ void __launch_bounds__(NF_BLOCK) k_fi_celu_bwd(const float* __restrict__ x, const float* __restrict__ gcat,
+                                                          float* __restrict__ gx, int64_t B, int CN) {
+    const int64_t total = B * CN, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / CN, r = e - b * CN;
+        const float v = x[e];
+        gx[e] += nf_fi_elu_grad(v) * gcat[b * 2 * CN + r] - nf_fi_elu_grad(-v) * gcat[b * 2 * CN + CN + r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the middle of the conditioner, one sample per workgroup, thread = (head h, position j), 8 channels 8 h .. 8 h + 7 of position j
+// ---------------------------------------------------------------------------------------------------------------
+struct NfFiMid {
+    const float *x, *a, *ln1g, *ln1b, *pos, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
+    float* out;
+    const float* g_out;
+    float *g_x, *g_a, *g_ln1g, *g_ln1b, *g_pos, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2g, *g_ln2b;
+};
+
+template <int NT>
+__device__ __forceinline__ float nf_fi_block_sum_all(float v, float* scr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (NT <= 64) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += scr[i];
+    return r;
+}
+
+__device__ __forceinline__ float nf_fi_dot8(const f32x4& a0, const f32x4& a1, const float* b) {
+    return a0[0] * b[0] + a0[1] * b[1] + a0[2] * b[2] + a0[3] * b[3] + a1[0] * b[4] + a1[1] * b[5] + a1[2] * b[6] + a1[3] * b[7];
+}
+
+// channel-major plane [32][N] with a per-row rotation: conflict-free both for (fixed c, lanes over p) and (fixed p, lanes over c)
+#define NF_FI_IDX(c, p) ((c) * N + (((p) + (c)) & (N - 1)))
+
+template <int N, bool BWD>
+__global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
+    constexpr int NT = 4 * N, PL = 32 * N;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* PA = smem;
+    float* PB = PA + PL;
+    float* PC = PB + PL;
+    float* PD = PC + PL;
+    float* W1s = PD + PL;          // conv1 weight transposed [32][96]
+    float* W2s = W1s + 3072;       // conv2 weight transposed [32][64]; dead after the conv2 backward: CJ[4 N] | DL[4 N] alias it (4 N <= 1024)
+    float* Bs = W2s + 2048;        // b1[96] | b2[64]
+    float* scr = Bs + 160;         // [16]
+    float* CJ = W2s;
+    float* DL = W2s + NT;
+    const int tid = threadIdx.x, h = tid / N, j = tid & (N - 1);
+    const int64_t b = blockIdx.x;
+    const float invn = 1.f / (float)(32 * N);
+    const float scale = 0.35355339059327373f;            // 1 / sqrt(D), D = 8 (flows/modules.py:571)
+
+    for (int e = tid; e < 3072; e += NT) W1s[(e & 31) * 96 + (e >> 5)] = m.w1[e];      // transposed: [c][o], o contiguous
+    for (int e = tid; e < 2048; e += NT) W2s[(e & 31) * 64 + (e >> 5)] = m.w2[e];
+    for (int e = tid; e < 160; e += NT) Bs[e] = e < 96 ? m.b1[e] : m.b2[e - 96];
+
+    const int64_t base = (b * 32 + 8 * h) * N + j;         // this thread's elements: base + d * N
+    const int pbase = 8 * h * N + j;                       // the same inside a (32, H, W) parameter
+    float m1, r1;
+    // u = x + elu(a) * sigmoid(elu(-a))  (GatedConv2d, flows/modules.py:519-538), LayerNorm 1
+    auto ln1 = [&](float* xh1, float* x2) {
+        float u[8], s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const float av = m.a[base + d * N];
+            u[d] = m.x[base + d * N] + nf_fi_elu(av) * nf_fi_sigmoid(nf_fi_elu(-av));
+            s += u[d];
+        }
+        m1 = nf_fi_block_sum_all<NT>(s, scr) * invn;
+        float s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s2 += (u[d] - m1) * (u[d] - m1);
+        r1 = 1.f / sqrtf(nf_fi_block_sum_all<NT>(s2, scr) * invn + NF_FI_LNEPS);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            xh1[d] = (u[d] - m1) * r1;
+            x2[d] = xh1[d] * m.ln1g[pbase + d * N] + m.ln1b[pbase + d * N];
+        }
+    };
+    float x2[8], v[8], k[8], q[8];
+    {
+        float xh1[8];
+        ln1(xh1, x2);
+    }
+    // tokens = x2 + pos_emb -> PA ; proj = conv1 (1x1, 32 -> 96): rows 8 h + d of the three groups ("V", "K", "Q" in the reference's naming)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) PA[NF_FI_IDX(8 * h + d, j)] = x2[d] + m.pos[pbase + d * N];
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        v[d] = Bs[8 * h + d];
+        k[d] = Bs[32 + 8 * h + d];
+        q[d] = Bs[64 + 8 * h + d];
+    }
+#pragma unroll 2
+    for (int c = 0; c < 32; ++c) {
+        const float tc = PA[NF_FI_IDX(c, j)];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W1s + c * 96 + 8 * h);
+        const f32x4 a0 = wr[0], a1 = wr[1], b0 = wr[8], b1 = wr[9], c0 = wr[16], c1 = wr[17];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += a0[e] * tc; v[4 + e] += a1[e] * tc;
+            k[e] += b0[e] * tc; k[4 + e] += b1[e] * tc;
+            q[e] += c0[e] * tc; q[4 + e] += c1[e] * tc;
+        }
+    }
+    // attention: P[i][j] = softmax_i(V_i . K_j / sqrt(D)),  mixed_j = sum_i Q_i P[i][j]   (flows/modules.py:566-574)
+    f32x4* PB4 = reinterpret_cast<f32x4*>(PB);
+    f32x4* PC4 = reinterpret_cast<f32x4*>(PC);
+    PB4[(h * N + j) * 2] = (f32x4){v[0], v[1], v[2], v[3]};
+    PB4[(h * N + j) * 2 + 1] = (f32x4){v[4], v[5], v[6], v[7]};
+    PC4[(h * N + j) * 2] = (f32x4){q[0], q[1], q[2], q[3]};
+    PC4[(h * N + j) * 2 + 1] = (f32x4){q[4], q[5], q[6], q[7]};
+    __syncthreads();
+    float mx = -INFINITY, l = 0.f, mix[8];
+#pragma unroll 2
+    for (int i = 0; i < N; ++i) mx = fmaxf(mx, nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], k) * scale);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) mix[d] = 0.f;
+#pragma unroll 2
+    for (int i = 0; i < N; ++i) {
+        const float p = expf(nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], k) * scale - mx);
+        const f32x4 q0 = PC4[(h * N + i) * 2], q1 = PC4[(h * N + i) * 2 + 1];
+        l += p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mix[e] += p * q0[e];
+            mix[4 + e] += p * q1[e];
+        }
+    }
+    {
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) mix[d] *= inv;
+    }
+    __syncthreads();                                     // every thread is done with the tokens and the V / Q planes
+#pragma unroll
+    for (int d = 0; d < 8; ++d) PA[NF_FI_IDX(8 * h + d, j)] = mix[d];
+    __syncthreads();
+    // conv2 (1x1, 32 -> 64): y = rows 8 h + d, gate = rows 32 + 8 h + d ;  x3 = x2 + y * sigmoid(gate)
+    float y[8], sg[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        y[d] = Bs[96 + 8 * h + d];
+        sg[d] = Bs[96 + 32 + 8 * h + d];
+    }
+#pragma unroll 2
+    for (int c = 0; c < 32; ++c) {
+        const float tc = PA[NF_FI_IDX(c, j)];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W2s + c * 64 + 8 * h);
+        const f32x4 a0 = wr[0], a1 = wr[1], b0 = wr[8], b1 = wr[9];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] += a0[e] * tc; y[4 + e] += a1[e] * tc;
+            sg[e] += b0[e] * tc; sg[4 + e] += b1[e] * tc;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) sg[d] = nf_fi_sigmoid(sg[d]);
+    float xh2[8], m2, r2;
+    {
+        float x3[8], s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            x3[d] = x2[d] + y[d] * sg[d];
+            s += x3[d];
+        }
+        m2 = nf_fi_block_sum_all<NT>(s, scr) * invn;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s2 += (x3[d] - m2) * (x3[d] - m2);
+        r2 = 1.f / sqrtf(nf_fi_block_sum_all<NT>(s2, scr) * invn + NF_FI_LNEPS);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) xh2[d] = (x3[d] - m2) * r2;
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) m.out[base + d * N] = xh2[d] * m.ln2g[pbase + d * N] + m.ln2b[pbase + d * N];
+        return;
+    }
+
+    // ================================================= backward =================================================
+    float g3[8];                                         // gradient of x3 (= of the attention block's residual input and of y * sg)
+    {
+        float gh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const float g4 = m.g_out[base + d * N];
+            atomicAdd(m.g_ln2g + pbase + d * N, g4 * xh2[d]);
+            atomicAdd(m.g_ln2b + pbase + d * N, g4);
+            gh[d] = g4 * m.ln2g[pbase + d * N];
+            s1 += gh[d];
+            s2 += gh[d] * xh2[d];
+        }
+        const float S1 = nf_fi_block_sum_all<NT>(s1, scr) * invn, S2 = nf_fi_block_sum_all<NT>(s2, scr) * invn;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) g3[d] = r2 * (gh[d] - S1 - xh2[d] * S2);
+    }
+    // conv2 backward in two rounds through PB (y rows, then gate rows); PA still holds `mixed`
+    float gm[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) gm[d] = 0.f;
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            PB[NF_FI_IDX(8 * h + d, j)] = part == 0 ? g3[d] * sg[d] : g3[d] * y[d] * sg[d] * (1.f - sg[d]);
+        __syncthreads();
+#pragma unroll 1
+        for (int o4 = 0; o4 < 8; ++o4) {
+            const float e0 = PB[NF_FI_IDX(4 * o4, j)], e1 = PB[NF_FI_IDX(4 * o4 + 1, j)], e2 = PB[NF_FI_IDX(4 * o4 + 2, j)],
+                        e3 = PB[NF_FI_IDX(4 * o4 + 3, j)];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W2s + (8 * h + d) * 64 + 32 * part + 4 * o4);
+                gm[d] += w4[0] * e0 + w4[1] * e1 + w4[2] * e2 + w4[3] * e3;
+            }
+        }
+#pragma unroll 1
+        for (int e = tid; e < 1024; e += NT) {
+            const int o = e >> 5, c = e & 31;
+            float acc = 0.f, bs = 0.f;
+#pragma unroll 4
+            for (int p = 0; p < N; ++p) {
+                const float gv_ = PB[NF_FI_IDX(o, p)];
+                acc += gv_ * PA[NF_FI_IDX(c, p)];
+                bs += gv_;
+            }
+            atomicAdd(m.g_w2 + (32 * part + o) * 32 + c, acc);
+            if (c == 0) atomicAdd(m.g_b2 + 32 * part + o, bs);
+        }
+    }
+    // attention backward.  delta_j = sum_i P[i][j] gP[i][j] = mixed_j . g_mixed_j ;  g_s[i][j] = P[i][j] (gP[i][j] - delta_j)
+    __syncthreads();                                     // PA / PB / W2s are free
+    float delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) delta += mix[d] * gm[d];
+    const float cj = mx + logf(l);                       // P[i][j] = exp(s[i][j] - cj)
+    f32x4* PA4 = reinterpret_cast<f32x4*>(PA);
+    f32x4* PD4 = reinterpret_cast<f32x4*>(PD);
+    PA4[(h * N + j) * 2] = (f32x4){v[0], v[1], v[2], v[3]};
+    PA4[(h * N + j) * 2 + 1] = (f32x4){v[4], v[5], v[6], v[7]};
+    PB4[(h * N + j) * 2] = (f32x4){q[0], q[1], q[2], q[3]};
+    PB4[(h * N + j) * 2 + 1] = (f32x4){q[4], q[5], q[6], q[7]};
+    PC4[(h * N + j) * 2] = (f32x4){k[0], k[1], k[2], k[3]};
+    PC4[(h * N + j) * 2 + 1] = (f32x4){k[4], k[5], k[6], k[7]};
+    PD4[(h * N + j) * 2] = (f32x4){gm[0], gm[1], gm[2], gm[3]};
+    PD4[(h * N + j) * 2 + 1] = (f32x4){gm[4], gm[5], gm[6], gm[7]};
+    CJ[h * N + j] = cj;
+    DL[h * N + j] = delta;
+    __syncthreads();
+    float gk[8], gv[8], gq[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) gk[d] = gv[d] = gq[d] = 0.f;
+#pragma unroll 2
+    for (int i = 0; i < N; ++i) {                        // this thread as the column j: gradient of K_j
+        const f32x4 v0 = PA4[(h * N + i) * 2], v1 = PA4[(h * N + i) * 2 + 1];
+        const float p = expf(nf_fi_dot8(v0, v1, k) * scale - cj);
+        const float gs = p * (nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], gm) - delta);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gk[e] += gs * v0[e];
+            gk[4 + e] += gs * v1[e];
+        }
+    }
+#pragma unroll 2
+    for (int jj = 0; jj < N; ++jj) {                     // this thread as the row i = j: gradients of V_i and Q_i
+        const f32x4 k0 = PC4[(h * N + jj) * 2], k1 = PC4[(h * N + jj) * 2 + 1];
+        const f32x4 g0 = PD4[(h * N + jj) * 2], g1 = PD4[(h * N + jj) * 2 + 1];
+        const float p = expf(nf_fi_dot8(k0, k1, v) * scale - CJ[h * N + jj]);
+        const float gs = p * (nf_fi_dot8(g0, g1, q) - DL[h * N + jj]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gv[e] += gs * k0[e];
+            gv[4 + e] += gs * k1[e];
+            gq[e] += p * g0[e];
+            gq[4 + e] += p * g1[e];
+        }
+    }
+    // conv1 backward: the three gradient groups -> PA / PB / PC, the tokens again -> PD
+    float xh1[8];
+    ln1(xh1, x2);                                        // (recomputed: x2 / xh1 were not kept over the attention; ends in barriers)
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        PA[NF_FI_IDX(8 * h + d, j)] = gv[d] * scale;
+        PB[NF_FI_IDX(8 * h + d, j)] = gk[d] * scale;
+        PC[NF_FI_IDX(8 * h + d, j)] = gq[d];
+        PD[NF_FI_IDX(8 * h + d, j)] = x2[d] + m.pos[pbase + d * N];
+    }
+    __syncthreads();
+    float gt[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) gt[d] = 0.f;
+#pragma unroll 1
+    for (int part = 0; part < 3; ++part) {
+        const float* P = part == 0 ? PA : (part == 1 ? PB : PC);
+#pragma unroll 1
+        for (int o4 = 0; o4 < 8; ++o4) {
+            const float e0 = P[NF_FI_IDX(4 * o4, j)], e1 = P[NF_FI_IDX(4 * o4 + 1, j)], e2 = P[NF_FI_IDX(4 * o4 + 2, j)],
+                        e3 = P[NF_FI_IDX(4 * o4 + 3, j)];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(W1s + (8 * h + d) * 96 + 32 * part + 4 * o4);
+                gt[d] += w4[0] * e0 + w4[1] * e1 + w4[2] * e2 + w4[3] * e3;
+            }
+        }
+#pragma unroll 1
+        for (int e = tid; e < 1024; e += NT) {
+            const int o = e >> 5, c = e & 31;
+            float acc = 0.f, bs = 0.f;
+#pragma unroll 4
+            for (int p = 0; p < N; ++p) {
+                const float gv_ = P[NF_FI_IDX(o, p)];
+                acc += gv_ * PD[NF_FI_IDX(c, p)];
+                bs += gv_;
+            }
+            atomicAdd(m.g_w1 + (32 * part + o) * 32 + c, acc);
+            if (c == 0) atomicAdd(m.g_b1 + 32 * part + o, bs);
+        }
+    }
+    // LayerNorm 1 and the gate
+    {
+        float gh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const float g2_ = g3[d] + gt[d];
+            atomicAdd(m.g_pos + pbase + d * N, gt[d]);
+            atomicAdd(m.g_ln1g + pbase + d * N, g2_ * xh1[d]);
+            atomicAdd(m.g_ln1b + pbase + d * N, g2_);
+            gh[d] = g2_ * m.ln1g[pbase + d * N];
+            s1 += gh[d];
+            s2 += gh[d] * xh1[d];
+        }
+        const float S1 = nf_fi_block_sum_all<NT>(s1, scr) * invn, S2 = nf_fi_block_sum_all<NT>(s2, scr) * invn;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const float gu = r1 * (gh[d] - S1 - xh1[d] * S2);
+            const float av = m.a[base + d * N];
+            const float e1 = nf_fi_elu(av), s2_ = nf_fi_sigmoid(nf_fi_elu(-av));
+            m.g_x[base + d * N] = gu;
+            m.g_a[base + d * N] = gu * (nf_fi_elu_grad(av) * s2_ - e1 * s2_ * (1.f - s2_) * nf_fi_elu_grad(-av));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename K>
+static inline int nf_fi_optin(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+static inline int nf_fi_lgw(int H, int W) {
+    if (H != W) return -1;
+    return W == 16 ? 4 : (W == 8 ? 3 : (W == 4 ? 2 : -1));
+}
+
+extern "C" int nf_flowpp_img_usable(int64_t B, int Ci, int Co, int H, int W) {
+    if (B < 1 || Ci < 1 || Co < 1 || nf_fi_lgw(H, W) < 0) return 0;
+    const int64_t tiles = (B * H * W + 255) / 256;
+    if (tiles > 65535 * 32 || (Co + 31) / 32 > 65535 || B * (int64_t)(Ci > Co ? Ci : Co) * H * W >= ((int64_t)1 << 31)) return 0;
+    return 1;
+}
+
+template <int LGW>
+static int nf_fi_conv_launch(const float* in, const float* w, const float* bias, float* out, int64_t B, int Ci, int Co, int in_mode,
+                             int transposed, hipStream_t st) {
+    using G = NfFiGeo<LGW>;
+    const size_t lds = (size_t)(32 * G::CS + 32 * NF_FI_WS) * sizeof(float);
+    const dim3 grid((unsigned)((B + G::S - 1) / G::S), (unsigned)((Co + 31) / 32));
+    int rc;
+#define NF_FI_GO(M_, T_)                                                                                            \
+    do {                                                                                                            \
+        if ((rc = nf_fi_optin(k_fi_conv<LGW, M_, T_>, lds)) != 0) return rc;                                        \
+        hipLaunchKernelGGL((k_fi_conv<LGW, M_, T_>), grid, dim3(NF_FI_THREADS), lds, st, in, w, bias, out, B, Ci, Co); \
+    } while (0)
+    if (transposed) NF_FI_GO(0, true);
+    else if (in_mode == 1) NF_FI_GO(1, false);
+    else NF_FI_GO(0, false);
+#undef NF_FI_GO
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_flowpp_img_conv(const float* in, const float* weight, const float* bias, float* out, int64_t B, int Ci, int Co,
+                                  int H, int W, int in_mode, int transposed, nf_stream_t stream) {
+    if (in == nullptr || weight == nullptr || out == nullptr || !nf_flowpp_img_usable(B, Ci, Co, H, W)) return NF_E_BADARG;
+    if (in_mode < 0 || in_mode > 1 || (in_mode == 1 && ((Ci & 1) || transposed))) return NF_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nf_fi_lgw(H, W)) {
+        case 4: return nf_fi_conv_launch<4>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, st);
+        case 3: return nf_fi_conv_launch<3>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, st);
+        default: return nf_fi_conv_launch<2>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, st);
+    }
+}
+
+template <int LGW>
+static int nf_fi_wgrad_launch(const float* in, const float* g, float* gw, float* gb, int64_t B, int Ci, int Co, int in_mode,
+                              hipStream_t st) {
+    using G = NfFiGeo<LGW>;
+    const size_t lds = (size_t)(32 * G::CS + 32 * NF_FI_GS) * sizeof(float);
+    const dim3 grid((unsigned)((B + G::S - 1) / G::S), (unsigned)((Co + 31) / 32), (unsigned)((Ci + 31) / 32));
+    int rc;
+    if (in_mode == 1) {
+        if ((rc = nf_fi_optin(k_fi_conv_wgrad<LGW, 1>, lds)) != 0) return rc;
+        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, gw, gb, B, Ci, Co);
+    } else {
+        if ((rc = nf_fi_optin(k_fi_conv_wgrad<LGW, 0>, lds)) != 0) return rc;
+        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, gw, gb, B, Ci, Co);
+    }
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* g_weight, float* g_bias, int64_t B, int Ci,
+                                        int Co, int H, int W, int in_mode, nf_stream_t stream) {
+    if (in == nullptr || g_out == nullptr || g_weight == nullptr || !nf_flowpp_img_usable(B, Ci, Co, H, W)) return NF_E_BADARG;
+    if (in_mode < 0 || in_mode > 1 || (in_mode == 1 && (Ci & 1))) return NF_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nf_fi_lgw(H, W)) {
+        case 4: return nf_fi_wgrad_launch<4>(in, g_out, g_weight, g_bias, B, Ci, Co, in_mode, st);
+        case 3: return nf_fi_wgrad_launch<3>(in, g_out, g_weight, g_bias, B, Ci, Co, in_mode, st);
+        default: return nf_fi_wgrad_launch<2>(in, g_out, g_weight, g_bias, B, Ci, Co, in_mode, st);
+    }
+}
+
+extern "C" int nf_flowpp_img_celu_bwd(const float* x, const float* g_cat, float* g_x, int64_t B, int C, int H, int W,
+                                      nf_stream_t stream) {
+    if (x == nullptr || g_cat == nullptr || g_x == nullptr || B < 0 || C < 1 || H < 1 || W < 1) return NF_E_BADARG;
+    if (B == 0) return 0;
+    const int CN = C * H * W;
+    hipLaunchKernelGGL(k_fi_celu_bwd, dim3(nf_grid_for(B * CN)), dim3(NF_BLOCK), 0, (hipStream_t)stream, x, g_cat, g_x, B, CN);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int N, bool BWD>
+static int nf_fi_mid_launch(const NfFiMid& m, int64_t B, hipStream_t st) {
+    const size_t lds = (size_t)(4 * 32 * N + 3072 + 2048 + 160 + 16) * sizeof(float);
+    int rc;
+    if ((rc = nf_fi_optin(k_fi_mid<N, BWD>, lds)) != 0) return rc;
+    hipLaunchKernelGGL((k_fi_mid<N, BWD>), dim3((unsigned)B), dim3(4 * N), lds, st, m);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_flowpp_img_mid_fwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
+                                     const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
+                                     const float* ln2_g, const float* ln2_b, float* out, int64_t B, int H, int W,
+                                     nf_stream_t stream) {
+    if (x == nullptr || a == nullptr || ln1_g == nullptr || ln1_b == nullptr || pos == nullptr || conv1_w == nullptr ||
+        conv1_b == nullptr || conv2_w == nullptr || conv2_b == nullptr || ln2_g == nullptr || ln2_b == nullptr || out == nullptr)
+        return NF_E_BADARG;
+    if (!nf_flowpp_img_usable(B, 32, 32, H, W) || B > 0x7fffffff) return NF_E_BADARG;
+    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, out, nullptr, nullptr, nullptr,
+                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st = (hipStream_t)stream;
+    switch (nf_fi_lgw(H, W)) {
+        case 4: return nf_fi_mid_launch<256, false>(m, B, st);
+        case 3: return nf_fi_mid_launch<64, false>(m, B, st);
+        default: return nf_fi_mid_launch<16, false>(m, B, st);
+    }
+}
+
+extern "C" int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
+                                     const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
+                                     const float* ln2_g, const float* ln2_b, const float* g_out, float* g_x, float* g_a,
+                                     float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_conv1_w, float* g_conv1_b,
+                                     float* g_conv2_w, float* g_conv2_b, float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W,
+                                     nf_stream_t stream) {
+    if (x == nullptr || a == nullptr || ln1_g == nullptr || ln1_b == nullptr || pos == nullptr || conv1_w == nullptr ||
+        conv1_b == nullptr || conv2_w == nullptr || conv2_b == nullptr || ln2_g == nullptr || ln2_b == nullptr || g_out == nullptr ||
+        g_x == nullptr || g_a == nullptr || g_ln1_g == nullptr || g_ln1_b == nullptr || g_pos == nullptr || g_conv1_w == nullptr ||
+        g_conv1_b == nullptr || g_conv2_w == nullptr || g_conv2_b == nullptr || g_ln2_g == nullptr || g_ln2_b == nullptr)
+        return NF_E_BADARG;
+    if (!nf_flowpp_img_usable(B, 32, 32, H, W) || B > 0x7fffffff) return NF_E_BADARG;
+    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, nullptr, g_out, g_x, g_a, g_ln1_g,
+                 g_ln1_b, g_pos, g_conv1_w, g_conv1_b, g_conv2_w, g_conv2_b, g_ln2_g, g_ln2_b};
+    hipStream_t st = (hipStream_t)stream;
+    switch (nf_fi_lgw(H, W)) {
+        case 4: return nf_fi_mid_launch<256, true>(m, B, st);
+        case 3: return nf_fi_mid_launch<64, true>(m, B, st);
+        default: return nf_fi_mid_launch<16, true>(m, B, st);
+    }
+}

@@ -1,0 +1,126 @@
+"""
+The Flow++ conditioner of IMAGE data (flows/coupling.py:159-166: Conv2d -> GatedConv2d -> LayerNorm -> GatedAttn -> LayerNorm ->
+Conv2d, flows/modules.py:519-578) on the kernels of csrc/flowpp_img.hip -- C ABI ``nf_flowpp_img_conv / _conv_wgrad / _mid_fwd /
+_mid_bwd / _celu_bwd``: 4 launches forward and 9 backward, no MIOpen / ATen convolution, matmul, softmax or LayerNorm kernel.
+
+Only the two convolution outputs in front of the gate are kept for the backward (x = conv0's output, a = the gated
+convolution's output): everything between the gate and the last convolution is recomputed per sample inside the backward kernel.
+"""
+import os
+
+import torch
+
+from . import _native as N
+from .functional import _sinks
+
+FLOWPP_IMG_ON = os.environ.get('NF_FLOWPP_IMG', '1') != '0'
+HID = 32
+
+
+def _tensors(net):
+    first, gated, ln1, attn, ln2, last = net
+    return [first.weight, first.bias, gated.op.weight, gated.op.bias, ln1.weight, ln1.bias, attn.pos_emb, attn.conv1.weight,
+            attn.conv1.bias, attn.conv2.weight, attn.conv2.bias, ln2.weight, ln2.bias, last.weight, last.bias]
+
+
+def flowpp_img_fusable(net, x):
+    """net: the nn.Sequential of MixLogAttnCoupling for image data (coupling.py:159-166) with the reference's widths (32 filters,
+    4 heads) on an H = W in {4, 8, 16} map."""
+    if not (FLOWPP_IMG_ON and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0):
+        return False
+    try:
+        first, gated, ln1, attn, ln2, last = net
+    except (TypeError, ValueError):
+        return False
+    B, I0, Hh, Ww = x.shape
+    nn = torch.nn
+    if not (isinstance(first, nn.Conv2d) and isinstance(last, nn.Conv2d) and isinstance(ln1, nn.LayerNorm)
+            and isinstance(ln2, nn.LayerNorm) and isinstance(getattr(gated, 'op', None), nn.Conv2d)):
+        return False
+    for cv in (first, gated.op, last):
+        if cv.kernel_size != (3, 3) or cv.padding != (1, 1) or cv.stride != (1, 1) or cv.bias is None or cv.groups != 1:
+            return False
+    shape = (HID, Hh, Ww)
+    if not (first.in_channels == I0 and first.out_channels == HID and gated.op.in_channels == 2 * HID
+            and gated.op.out_channels == HID and last.in_channels == HID and attn.filters == HID and attn.channels == HID
+            and attn.heads == 4 and tuple(ln1.normalized_shape) == shape and tuple(ln2.normalized_shape) == shape
+            and ln1.elementwise_affine and ln2.elementwise_affine and ln1.eps == 1.0e-5 and ln2.eps == 1.0e-5
+            and tuple(attn.pos_emb.shape) == (1, ) + shape):
+        return False
+    from .dist import sync_stats_active
+    if sync_stats_active():           # (nothing to synchronise -- LayerNorm is per sample -- but the parity mode runs the module path)
+        return False
+    return bool(N.load().nf_flowpp_img_usable(B, max(I0, 2 * HID), max(last.out_channels, 2 * HID), Hh, Ww))
+
+
+class _FusedFlowppImg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_in, *ts):
+        for t in ts:
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise RuntimeError('fused image Flow++ conditioner needs contiguous fp32 device parameters')
+        (W0, b0, Wg, bg, l1g, l1b, pos, c1w, c1b, c2w, c2b, l2g, l2b, W5, b5) = [t.detach() for t in ts]
+        x_in = x_in.contiguous()
+        B, I0, Hh, Ww = x_in.shape
+        O = W5.shape[0]
+        dev, st = x_in.device, N.stream()
+        x = torch.empty(B, HID, Hh, Ww, dtype=torch.float32, device=dev)
+        a = torch.empty_like(x)
+        x4 = torch.empty_like(x)
+        out = torch.empty(B, O, Hh, Ww, dtype=torch.float32, device=dev)
+        N.call('nf_flowpp_img_conv', N.ptr(x_in), N.ptr(W0), N.ptr(b0), N.ptr(x), B, I0, HID, Hh, Ww, 0, 0, st)
+        N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(Wg), N.ptr(bg), N.ptr(a), B, 2 * HID, HID, Hh, Ww, 1, 0, st)
+        N.call('nf_flowpp_img_mid_fwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
+               N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(x4), B, Hh, Ww, st)
+        N.call('nf_flowpp_img_conv', N.ptr(x4), N.ptr(W5), N.ptr(b5), N.ptr(out), B, HID, O, Hh, Ww, 0, 0, st)
+        ctx.save_for_backward(x_in, x, a, x4, *ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_in, x, a, x4, *ts = ctx.saved_tensors
+        (W0, b0, Wg, bg, l1g, l1b, pos, c1w, c1b, c2w, c2b, l2g, l2b, W5, b5) = [t.detach() for t in ts]
+        B, I0, Hh, Ww = x_in.shape
+        O = W5.shape[0]
+        dev, st = x_in.device, N.stream()
+        g_out = g_out.contiguous()
+        sinks = _sinks(*ts)
+        if sinks is not None:
+            dst, direct = sinks, True
+        else:                                                    # handed to autograd, which may keep them
+            flat = torch.zeros(sum(t.numel() for t in ts), dtype=torch.float32, device=dev)
+            dst, o = [], 0
+            for t in ts:
+                dst.append(flat[o:o + t.numel()].view(t.shape))
+                o += t.numel()
+            direct = False
+        (gW0, gb0, gWg, gbg, gl1g, gl1b, gpos, gc1w, gc1b, gc2w, gc2b, gl2g, gl2b, gW5, gb5) = dst
+        # last convolution
+        g4 = torch.empty_like(x)
+        N.call('nf_flowpp_img_conv', N.ptr(g_out), N.ptr(W5), None, N.ptr(g4), B, O, HID, Hh, Ww, 0, 1, st)
+        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x4), N.ptr(g_out), N.ptr(gW5), N.ptr(gb5), B, HID, O, Hh, Ww, 0, st)
+        # gate / LayerNorm / attention / LayerNorm
+        g_x = torch.empty_like(x)
+        g_a = torch.empty_like(x)
+        N.call('nf_flowpp_img_mid_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
+               N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(g4), N.ptr(g_x), N.ptr(g_a), N.ptr(gl1g), N.ptr(gl1b), N.ptr(gpos),
+               N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), B, Hh, Ww, st)
+        # gated convolution (its input is concat_elu(x), applied while staging)
+        g_cat = torch.empty(B, 2 * HID, Hh, Ww, dtype=torch.float32, device=dev)
+        N.call('nf_flowpp_img_conv', N.ptr(g_a), N.ptr(Wg), None, N.ptr(g_cat), B, HID, 2 * HID, Hh, Ww, 0, 1, st)
+        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(g_a), N.ptr(gWg), N.ptr(gbg), B, 2 * HID, HID, Hh, Ww, 1, st)
+        N.call('nf_flowpp_img_celu_bwd', N.ptr(x), N.ptr(g_cat), N.ptr(g_x), B, HID, Hh, Ww, st)
+        # first convolution
+        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x_in), N.ptr(g_x), N.ptr(gW0), N.ptr(gb0), B, I0, HID, Hh, Ww, 0, st)
+        g_in = None
+        if ctx.needs_input_grad[0]:
+            g_in = torch.empty_like(x_in)
+            N.call('nf_flowpp_img_conv', N.ptr(g_x), N.ptr(W0), None, N.ptr(g_in), B, HID, I0, Hh, Ww, 0, 1, st)
+        if direct:
+            return (g_in, ) + (None, ) * len(ts)
+        return (g_in, ) + tuple(dst)
+
+
+def flowpp_img_forward(net, x):
+    """the (B, O, H, W) coupling parameters of the image Flow++ conditioner ``net`` (see flowpp_img_fusable)."""
+    return _FusedFlowppImg.apply(x, *_tensors(net))

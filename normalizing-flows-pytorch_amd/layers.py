@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from . import _native as N
 from . import functional as NF
 from . import fused as FUSED
+from . import fused_flowpp_img as FPI
 from .conditioners import MLP, ConvNet, flowpp_conditioner, made_degrees_to_masks
 
 
@@ -631,10 +632,13 @@ class MixLogAttnCoupling(AbstractCoupling):
 
     def conditioner(self, z):
         """coupling parameters from the untouched half; density data runs the whole gated-attention stack as one
-        launch per direction (csrc/flowpp_cond.hip), image data the module stack."""
+        launch per direction (csrc/flowpp_cond.hip), image data on the per-sample kernels of csrc/flowpp_img.hip (4 launches
+        forward, 9 backward); the module stack remains for shapes neither takes and off the GPU."""
         x = self.conditioner_input(z)
         if FUSED.flowpp_cond_fusable(self.net, x):
             return FUSED.flowpp_cond_forward(self.net, x)
+        if FPI.flowpp_img_fusable(self.net, x):
+            return FPI.flowpp_img_forward(self.net, x)
         return self.net(x)
 
     def forward(self, z, log_df_dz):

@@ -1,0 +1,153 @@
+"""GPU parity of the image Flow++ conditioner kernels (csrc/flowpp_img.hip) against the module stack they replace
+(flows/coupling.py:159-166: Conv2d -> GatedConv2d -> LayerNorm -> GatedAttn -> LayerNorm -> Conv2d, flows/modules.py:519-578) and,
+kernel by kernel, against plain fp32 PyTorch restatements of the same operators."""
+import copy
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1.0e-5
+
+
+def _scaled(t, k=4.0):
+    return TOL * k * max(1.0, float(t.detach().abs().max()))
+
+
+def _native(pkg):
+    return importlib.import_module(pkg.__name__ + '._native')
+
+
+# (in channels, out channels, H = W): the conditioner shapes of Flowpp on CIFAR (flows/flowpp.py:22-57: in 6 / 6 / 24 / 24 / 96 with
+# 14 x in outputs) and on the 16 x 16 golden model, plus ragged channel counts
+CONV_CASES = [(6, 32, 16, 3), (64, 32, 16, 2), (32, 84, 16, 5), (24, 32, 8, 9), (32, 336, 8, 6), (96, 32, 4, 33), (32, 1344, 4, 17),
+              (5, 7, 8, 1), (40, 70, 4, 16)]
+
+
+@pytest.mark.parametrize('Ci,Co,HW,B', CONV_CASES)
+def test_conv_forward_data_and_weight_gradient_vs_torch(pkg, Ci, Co, HW, B):
+    N = _native(pkg)
+    g = torch.Generator().manual_seed(Ci * 1000 + Co)
+    x = torch.randn(B, Ci, HW, HW, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3.0 * Ci ** 0.5)).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    gy = torch.randn(B, Co, HW, HW, generator=g).to(DEV)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    y_ref = F.conv2d(xr, wr, br, padding=1)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [xr, wr, br], gy)
+    st = N.stream()
+    y = torch.empty_like(y_ref)
+    N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(y), B, Ci, Co, HW, HW, 0, 0, st)
+    G.assert_close(y, y_ref, _scaled(y_ref), what='conv forward')
+    gx = torch.empty_like(x)
+    N.call('nf_flowpp_img_conv', N.ptr(gy), N.ptr(w), None, N.ptr(gx), B, Co, Ci, HW, HW, 0, 1, st)
+    G.assert_close(gx, gx_ref, _scaled(gx_ref), what='conv data gradient')
+    gw = torch.full_like(w, 0.5)                       # accumulated into, not overwritten
+    gb = torch.full_like(b, -1.0)
+    N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(gy), N.ptr(gw), N.ptr(gb), B, Ci, Co, HW, HW, 0, st)
+    G.assert_close(gw - 0.5, gw_ref, _scaled(gw_ref), what='conv weight gradient')
+    G.assert_close(gb + 1.0, gb_ref, _scaled(gb_ref), what='conv bias gradient')
+
+
+@pytest.mark.parametrize('HW,B', [(16, 3), (8, 6), (4, 19)])
+def test_gated_convolution_applies_concat_elu_while_staging(pkg, HW, B):
+    N = _native(pkg)
+    g = torch.Generator().manual_seed(HW)
+    x = torch.randn(B, 32, HW, HW, generator=g).to(DEV)
+    w = (torch.randn(32, 64, 3, 3, generator=g) / 24.0).to(DEV)
+    b = torch.randn(32, generator=g).to(DEV)
+    ga = torch.randn(B, 32, HW, HW, generator=g).to(DEV)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    a_ref = F.conv2d(F.elu(torch.cat([xr, -xr], dim=1)), wr, br, padding=1)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(a_ref, [xr, wr, br], ga)
+    st = N.stream()
+    a = torch.empty_like(a_ref)
+    N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(a), B, 64, 32, HW, HW, 1, 0, st)
+    G.assert_close(a, a_ref, _scaled(a_ref), what='gated conv forward')
+    gcat = torch.empty(B, 64, HW, HW, device=DEV)
+    N.call('nf_flowpp_img_conv', N.ptr(ga), N.ptr(w), None, N.ptr(gcat), B, 32, 64, HW, HW, 0, 1, st)
+    gx = torch.zeros_like(x)
+    N.call('nf_flowpp_img_celu_bwd', N.ptr(x), N.ptr(gcat), N.ptr(gx), B, 32, HW, HW, st)
+    G.assert_close(gx, gx_ref, _scaled(gx_ref), what='gated conv input gradient')
+    gw, gb = torch.zeros_like(w), torch.zeros_like(b)
+    N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(ga), N.ptr(gw), N.ptr(gb), B, 64, 32, HW, HW, 1, st)
+    G.assert_close(gw, gw_ref, _scaled(gw_ref), what='gated conv weight gradient')
+    G.assert_close(gb, gb_ref, _scaled(gb_ref), what='gated conv bias gradient')
+
+
+def _cond_pair(pkg, in_chs, n_out, HW, seed):
+    cond = importlib.import_module(pkg.__name__ + '.conditioners')
+    torch.manual_seed(seed)
+    net = cond.flowpp_conditioner(in_chs, n_out, (32, HW, HW), 32, conv=True).to(DEV)
+    with torch.no_grad():                               # away from the initial values (LayerNorm affine = 1 / 0, pos_emb ~ 0.01)
+        for m in net.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+        net[3].pos_emb.normal_(0, 0.5)
+        net[3].conv1.weight.mul_(3.0)                   # attention logits of order one: a softmax that is not uniform
+    return net, copy.deepcopy(net)
+
+
+@pytest.mark.parametrize('in_chs,n_out,HW,B', [(6, 84, 16, 5), (24, 336, 8, 7), (96, 1344, 4, 18), (4, 56, 4, 3), (6, 84, 8, 64)])
+def test_conditioner_vs_module_stack(pkg, in_chs, n_out, HW, B):
+    fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    net, ref = _cond_pair(pkg, in_chs, n_out, HW, seed=in_chs + HW)
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, in_chs, HW, HW, generator=g).to(DEV)
+    gy = torch.randn(B, n_out, HW, HW, generator=g).to(DEV)
+    assert fpi.flowpp_img_fusable(net, x)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = fpi.flowpp_img_forward(net, xa)
+    yb = ref(xb)
+    G.assert_close(ya, yb, _scaled(yb), what='conditioner output')
+    ga = torch.autograd.grad(ya, [xa] + list(net.parameters()), gy)
+    gb = torch.autograd.grad(yb, [xb] + list(ref.parameters()), gy)
+    names = ['input'] + [n for n, _ in net.named_parameters()]
+    for n, a, b in zip(names, ga, gb):
+        G.assert_close(a, b, _scaled(b, 8.0), rtol=1e-4, what='gradient of ' + n)
+
+
+def test_direct_gradient_sinks_accumulate(pkg):
+    """with a GradBucket the backward adds straight into p.grad (same += as AccumulateGrad)"""
+    fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    dist = importlib.import_module(pkg.__name__ + '.dist')
+    net, ref = _cond_pair(pkg, 6, 84, 8, seed=3)
+    bucket = dist.GradBucket(net.parameters())
+    x = torch.randn(4, 6, 8, 8, device=DEV)
+    gy = torch.randn(4, 84, 8, 8, device=DEV)
+    for _ in range(2):                                  # two backward passes: the second adds to the first
+        fpi.flowpp_img_forward(net, x).backward(gy)
+        ref(x).backward(gy)
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        G.assert_close(p.grad, q.grad, _scaled(q.grad, 8.0), rtol=1e-4, what='accumulated gradient of ' + n)
+    assert bucket.flat.abs().sum() > 0
+
+
+def test_layer_takes_the_fused_path_and_matches_the_module_path(pkg, monkeypatch):
+    """MixLogAttnCoupling on image data: same y, log-det and gradients with NF_FLOWPP_IMG on and off"""
+    layers = importlib.import_module(pkg.__name__ + '.layers')
+    fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    torch.manual_seed(5)
+    cp = layers.MixLogAttnCoupling((12, 16, 16), masking='channelwise', odd=False, n_mixtures=4).to(DEV)
+    z = torch.rand(6, 12, 16, 16, device=DEV) * 0.9 + 0.05
+    calls = []
+    real = fpi.flowpp_img_forward
+    monkeypatch.setattr(fpi, 'flowpp_img_forward', lambda net, x: (calls.append(1), real(net, x))[1])
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(fpi, 'FLOWPP_IMG_ON', on)
+        zz = z.clone().requires_grad_(True)
+        y, ld = cp(zz, torch.zeros(6, device=DEV))
+        gr = torch.autograd.grad((y * y).sum() + ld.sum(), [zz] + list(cp.parameters()))
+        res.append((y, ld, gr))
+    assert len(calls) == 1
+    G.assert_close(res[0][0], res[1][0], _scaled(res[1][0]), what='y')
+    G.assert_close(res[0][1], res[1][1], _scaled(res[1][1]), what='log-det')
+    for a, b in zip(res[0][2], res[1][2]):
+        G.assert_close(a, b, _scaled(b, 8.0), rtol=1e-4, what='gradient')
