@@ -917,16 +917,26 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
  *   (GatedConv2d's inner convolution, modules.py:500-517);   transposed 0: weight (Co, Ci, 3, 3);   transposed 1: weight (Ci, Co, 3, 3)
  *   read transposed with flipped taps -- the DATA GRADIENT of the convolution that owns `weight`, `in` being the gradient of its
  *   output (in_mode 0, bias NULL).
- * nf_flowpp_img_conv_wgrad: g_weight (Co, Ci, 3, 3) += sum_b g_out (x) in,  g_bias (Co) += sum g_out (nullable); in / in_mode as above.
+ *   ksplit >= 1 cuts the input-channel axis into that many ranges of 32-channel chunks, one workgroup row each: `out` then holds
+ *   ksplit partial-sum slabs (ksplit, B, Co, H, W) whose sum is the result (bias in slab 0); nf_flowpp_img_conv_ksplit proposes
+ *   a count that fills the chip (the 32 -> O convolution's data gradient at 4 x 4 has K = 9 * 1344 and four pixel tiles).
+ * nf_flowpp_img_conv_wgrad: partial sums of the weight gradient sum_b g_out (x) in  and of the bias gradient sum g_out (slab_b nullable)
+ *   in n_slabs slabs, (n_slabs, Co, Ci, 3, 3) and (n_slabs, Co), every element WRITTEN; nf_slab_sum (stride Co*Ci*9 / Co, taps 1) folds
+ *   them into the destinations; nf_flowpp_img_wgrad_slabs proposes the count (<= NF_FLOWPP_IMG_MAX_SLABS); in / in_mode as above.
  * nf_flowpp_img_celu_bwd: g_x += elu'(x) * g_cat[:, :C] - elu'(-x) * g_cat[:, C:]  (x (B, C, H, W), g_cat (B, 2 C, H, W)).
  * nf_flowpp_img_mid_fwd: x = conv0 output, a = the gated convolution's output (both (B, 32, H, W)) ->
  *   LN2( A(LN1(x + elu(a) * sigmoid(elu(-a)))) ),  A(t) = t + y * sigmoid(gate), [y, gate] = conv2(attention(conv1(t + pos))).
- * nf_flowpp_img_mid_bwd: its autograd, recomputing the forward from x and a; g_x / g_a written, parameter gradients ACCUMULATED.  */
+ * nf_flowpp_img_mid_bwd: its autograd, recomputing the forward from x and a; g_x / g_a written, parameter gradients ACCUMULATED;
+ *   g_out may be g_out_slabs partial-sum slabs (g_out_slabs, B, 32, H, W) of a K-split nf_flowpp_img_conv, summed on load.          */
+#define NF_FLOWPP_IMG_MAX_KSPLIT 64
+#define NF_FLOWPP_IMG_MAX_SLABS 64
 int nf_flowpp_img_usable(int64_t B, int Ci, int Co, int H, int W);
+int nf_flowpp_img_conv_ksplit(int64_t B, int Ci, int Co, int H, int W);
 int nf_flowpp_img_conv(const float* in, const float* weight, const float* bias, float* out, int64_t B, int Ci, int Co, int H, int W,
-                       int in_mode, int transposed, nf_stream_t stream);
-int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* g_weight, float* g_bias, int64_t B, int Ci, int Co, int H,
-                             int W, int in_mode, nf_stream_t stream);
+                       int in_mode, int transposed, int ksplit, nf_stream_t stream);
+int nf_flowpp_img_wgrad_slabs(int64_t B, int Ci, int Co, int H, int W);
+int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* slab_w, float* slab_b, int n_slabs, int64_t B, int Ci, int Co,
+                             int H, int W, int in_mode, nf_stream_t stream);
 int nf_flowpp_img_celu_bwd(const float* x, const float* g_cat, float* g_x, int64_t B, int C, int H, int W, nf_stream_t stream);
 int nf_flowpp_img_mid_fwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
                           const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
@@ -935,7 +945,7 @@ int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float* ln1_g, co
                           const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
                           const float* ln2_g, const float* ln2_b, const float* g_out, float* g_x, float* g_a, float* g_ln1_g,
                           float* g_ln1_b, float* g_pos, float* g_conv1_w, float* g_conv1_b, float* g_conv2_w, float* g_conv2_b,
-                          float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W, nf_stream_t stream);
+                          float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W, int g_out_slabs, nf_stream_t stream);
 
 /* ---- on-device synthetic batches (csrc/datagen.hip)  flows/dataset.py:13-34, :120; replaces the per-step H2D copy main.py:79 --
  * kind 0 moons, 1 circles, 2 normals: out (n, 2), per_sample = 2;  3 cifar-like uniform uint8 / 255: out (n, per_sample).

@@ -40,6 +40,8 @@ __device__ __forceinline__ int nf_fi_fpos(int p) {          // frame position of
 
 __device__ __forceinline__ int nf_fi_cd_row(int r, int hs) { return (r & 3) + 8 * (r >> 2) + 4 * hs; }
 __device__ __forceinline__ float nf_fi_elu(float v) { return v > 0.f ? v : expm1f(v); }
+// inside the convolution staging: v_exp_f32 (absolute error ~1e-7 on an O(1) value that then enters a K = 576 dot product)
+__device__ __forceinline__ float nf_fi_elu_fast(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 __device__ __forceinline__ float nf_fi_elu_grad(float v) { return v > 0.f ? 1.f : expf(v); }
 __device__ __forceinline__ float nf_fi_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
 
@@ -62,7 +64,7 @@ __device__ __forceinline__ void nf_fi_stage_frame(float* F, const float* __restr
             } else {
                 const int Ch = Ci >> 1;
                 const float t = in[((b0 + s) * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + q];
-                v = nf_fi_elu(cc < Ch ? t : -t);
+                v = nf_fi_elu_fast(cc < Ch ? t : -t);
             }
         }
         F[c * G::CS + f] = v;
@@ -120,7 +122,11 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restri
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int c0 = 0; c0 < Ci; c0 += 32) {
+    // K split: workgroup z of gridDim.z takes the 32-channel chunks [z * cps, (z + 1) * cps) and leaves its partial sums in slab z
+    const int nchunks = (Ci + 31) >> 5, cps = (nchunks + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int ch0 = (int)blockIdx.z * cps, ch1 = min(nchunks, ch0 + cps);
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int c0 = 32 * ch;
         __syncthreads();
         nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
         nf_fi_stage_w<TR>(Wl, w, Ci, Co, o0, c0);
@@ -129,19 +135,23 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restri
     }
     const int64_t b = b0 + (p >> (2 * LGW));
     const int q = p & (G::N - 1);
+    float* slab = out + (int64_t)blockIdx.z * B * Co * G::N;
+    const bool add_bias = bias != nullptr && blockIdx.z == 0;
     if (b < B) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int oc = o0 + nf_fi_cd_row(r, hs);
-            if (oc < Co) out[(b * Co + oc) * G::N + q] = acc[r] + (bias != nullptr ? bias[oc] : 0.f);
+            if (oc < Co) slab[(b * Co + oc) * G::N + q] = acc[r] + (add_bias ? bias[oc] : 0.f);
         }
     }
 }
 
-// g_w[o][c][t] += sum_{b, p} g[b][o][p] * act[b][c][p + off(t)],  g_b[o] += sum g[b][o][p]
+// slab_w[blockIdx.x][o][c][t] = sum over this workgroup's tiles of  g[b][o][p] * act[b][c][p + off(t)],  slab_b[blockIdx.x][o] = sum g:
+// workgroup (x, y, z) walks the pixel tiles x, x + gridDim.x, ... for its (32 output, 32 input) channel block with the nine tap tiles
+// in registers; the eight waves (32 pixels each) meet in LDS once, at the end.  nf_slab_sum folds the slabs (no atomics).
 template <int LGW, int INMODE>
 __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __restrict__ in, const float* __restrict__ g,
-                                                                 float* __restrict__ gw, float* __restrict__ gb, int64_t B, int Ci,
+                                                                 float* __restrict__ slab_w, float* __restrict__ slab_b, int64_t B, int Ci,
                                                                  int Co) {
     using G = NfFiGeo<LGW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -149,37 +159,42 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __
     float* Gt = smem + 32 * G::CS;         // [32][NF_FI_GS]
     static_assert(32 * G::CS >= 8 * 1024, "partial tiles alias the frame");
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, hs = lane >> 5;
-    const int64_t b0 = (int64_t)blockIdx.x * G::S;
     const int o0 = 32 * blockIdx.y, c0 = 32 * blockIdx.z;
-    nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
-    for (int e = threadIdx.x; e < 32 * 256; e += NF_FI_THREADS) {
-        const int o = e >> 8, p = e & 255;
-        const int64_t b = b0 + (p >> (2 * LGW));
-        Gt[o * NF_FI_GS + p] = (b < B && o0 + o < Co) ? g[(b * Co + o0 + o) * G::N + (p & (G::N - 1))] : 0.f;
-    }
-    __syncthreads();
+    const int64_t tiles = (B + G::S - 1) / G::S;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll 2
-    for (int s2 = 0; s2 < 16; ++s2) {
-        const int p = 32 * wid + 2 * s2 + hs;
-        const float a = Gt[r32 * NF_FI_GS + p];
-        const float* fp = F + r32 * G::CS + nf_fi_fpos<LGW>(p);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float b = fp[(t / 3 - 1) * G::PW + (t % 3) - 1];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    float bsum = 0.f;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * G::S;
+        __syncthreads();
+        nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
+        for (int e = threadIdx.x; e < 32 * 256; e += NF_FI_THREADS) {
+            const int o = e >> 8, p = e & 255;
+            const int64_t b = b0 + (p >> (2 * LGW));
+            Gt[o * NF_FI_GS + p] = (b < B && o0 + o < Co) ? g[(b * Co + o0 + o) * G::N + (p & (G::N - 1))] : 0.f;
         }
+        __syncthreads();
+#pragma unroll 2
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int p = 32 * wid + 2 * s2 + hs;
+            const float a = Gt[r32 * NF_FI_GS + p];
+            const float* fp = F + r32 * G::CS + nf_fi_fpos<LGW>(p);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float bq = fp[(t / 3 - 1) * G::PW + (t % 3) - 1];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
+            }
+        }
+        if (slab_b != nullptr && blockIdx.z == 0 && threadIdx.x < 32)
+            for (int p = 0; p < 256; ++p) bsum += Gt[threadIdx.x * NF_FI_GS + p];
     }
-    if (gb != nullptr && blockIdx.z == 0 && threadIdx.x < 32 && o0 + (int)threadIdx.x < Co) {
-        float s = 0.f;
-        for (int p = 0; p < 256; ++p) s += Gt[threadIdx.x * NF_FI_GS + p];
-        atomicAdd(gb + o0 + threadIdx.x, s);
-    }
+    if (slab_b != nullptr && blockIdx.z == 0 && threadIdx.x < 32 && o0 + (int)threadIdx.x < Co)
+        slab_b[(int64_t)blockIdx.x * Co + o0 + threadIdx.x] = bsum;
     float* RED = F;
+    float* sw = slab_w + (int64_t)blockIdx.x * Co * Ci * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
@@ -191,7 +206,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) s += RED[w8 * 1024 + e];
             const int o = e >> 5, c = e & 31;
-            if (o0 + o < Co && c0 + c < Ci) atomicAdd(gw + ((int64_t)(o0 + o) * Ci + c0 + c) * 9 + t, s);
+            if (o0 + o < Co && c0 + c < Ci) sw[((int64_t)(o0 + o) * Ci + c0 + c) * 9 + t] = s;
         }
     }
 }
@@ -214,6 +229,8 @@ struct NfFiMid {
     const float *x, *a, *ln1g, *ln1b, *pos, *w1, *b1, *w2, *b2, *ln2g, *ln2b;
     float* out;
     const float* g_out;
+    int g_slabs;
+    int64_t g_slab_stride;
     float *g_x, *g_a, *g_ln1g, *g_ln1b, *g_pos, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2g, *g_ln2b;
 };
 
@@ -391,7 +408,8 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
         float gh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            const float g4 = m.g_out[base + d * N];
+            float g4 = m.g_out[base + d * N];
+            for (int z = 1; z < m.g_slabs; ++z) g4 += m.g_out[z * m.g_slab_stride + base + d * N];
             atomicAdd(m.g_ln2g + pbase + d * N, g4 * xh2[d]);
             atomicAdd(m.g_ln2b + pbase + d * N, g4);
             gh[d] = g4 * m.ln2g[pbase + d * N];
@@ -572,10 +590,10 @@ extern "C" int nf_flowpp_img_usable(int64_t B, int Ci, int Co, int H, int W) {
 
 template <int LGW>
 static int nf_fi_conv_launch(const float* in, const float* w, const float* bias, float* out, int64_t B, int Ci, int Co, int in_mode,
-                             int transposed, hipStream_t st) {
+                             int transposed, int ksplit, hipStream_t st) {
     using G = NfFiGeo<LGW>;
     const size_t lds = (size_t)(32 * G::CS + 32 * NF_FI_WS) * sizeof(float);
-    const dim3 grid((unsigned)((B + G::S - 1) / G::S), (unsigned)((Co + 31) / 32));
+    const dim3 grid((unsigned)((B + G::S - 1) / G::S), (unsigned)((Co + 31) / 32), (unsigned)ksplit);
     int rc;
 #define NF_FI_GO(M_, T_)                                                                                            \
     do {                                                                                                            \
@@ -590,45 +608,68 @@ static int nf_fi_conv_launch(const float* in, const float* w, const float* bias,
     return 0;
 }
 
+// K slabs a launch of nf_flowpp_img_conv may be cut into: enough workgroups for the chip, never more than the 32-channel chunks
+extern "C" int nf_flowpp_img_conv_ksplit(int64_t B, int Ci, int Co, int H, int W) {
+    if (!nf_flowpp_img_usable(B, Ci, Co, H, W)) return 0;
+    const int64_t wgs = ((B * H * W + 255) / 256) * ((Co + 31) / 32);
+    const int nchunks = (Ci + 31) / 32;
+    int64_t k = (256 + wgs - 1) / wgs;
+    if (k > nchunks) k = nchunks;
+    if (k > NF_FLOWPP_IMG_MAX_KSPLIT) k = NF_FLOWPP_IMG_MAX_KSPLIT;
+    return (int)(k < 1 ? 1 : k);
+}
+
 extern "C" int nf_flowpp_img_conv(const float* in, const float* weight, const float* bias, float* out, int64_t B, int Ci, int Co,
-                                  int H, int W, int in_mode, int transposed, nf_stream_t stream) {
+                                  int H, int W, int in_mode, int transposed, int ksplit, nf_stream_t stream) {
     if (in == nullptr || weight == nullptr || out == nullptr || !nf_flowpp_img_usable(B, Ci, Co, H, W)) return NF_E_BADARG;
     if (in_mode < 0 || in_mode > 1 || (in_mode == 1 && ((Ci & 1) || transposed))) return NF_E_BADARG;
+    if (ksplit < 1 || ksplit > NF_FLOWPP_IMG_MAX_KSPLIT || ksplit > (Ci + 31) / 32) return NF_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
-        case 4: return nf_fi_conv_launch<4>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, st);
-        case 3: return nf_fi_conv_launch<3>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, st);
-        default: return nf_fi_conv_launch<2>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, st);
+        case 4: return nf_fi_conv_launch<4>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, ksplit, st);
+        case 3: return nf_fi_conv_launch<3>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, ksplit, st);
+        default: return nf_fi_conv_launch<2>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, ksplit, st);
     }
 }
 
 template <int LGW>
-static int nf_fi_wgrad_launch(const float* in, const float* g, float* gw, float* gb, int64_t B, int Ci, int Co, int in_mode,
+static int nf_fi_wgrad_launch(const float* in, const float* g, float* sw, float* sb, int n_slabs, int64_t B, int Ci, int Co, int in_mode,
                               hipStream_t st) {
     using G = NfFiGeo<LGW>;
     const size_t lds = (size_t)(32 * G::CS + 32 * NF_FI_GS) * sizeof(float);
-    const dim3 grid((unsigned)((B + G::S - 1) / G::S), (unsigned)((Co + 31) / 32), (unsigned)((Ci + 31) / 32));
+    const dim3 grid((unsigned)n_slabs, (unsigned)((Co + 31) / 32), (unsigned)((Ci + 31) / 32));
     int rc;
     if (in_mode == 1) {
         if ((rc = nf_fi_optin(k_fi_conv_wgrad<LGW, 1>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, gw, gb, B, Ci, Co);
+        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
     } else {
         if ((rc = nf_fi_optin(k_fi_conv_wgrad<LGW, 0>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, gw, gb, B, Ci, Co);
+        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
     }
     NF_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* g_weight, float* g_bias, int64_t B, int Ci,
-                                        int Co, int H, int W, int in_mode, nf_stream_t stream) {
-    if (in == nullptr || g_out == nullptr || g_weight == nullptr || !nf_flowpp_img_usable(B, Ci, Co, H, W)) return NF_E_BADARG;
-    if (in_mode < 0 || in_mode > 1 || (in_mode == 1 && (Ci & 1))) return NF_E_BADARG;
+// slabs of an nf_flowpp_img_conv_wgrad launch: about one workgroup per compute unit over the (output, input) channel blocks, never more
+// than the pixel tiles
+extern "C" int nf_flowpp_img_wgrad_slabs(int64_t B, int Ci, int Co, int H, int W) {
+    if (!nf_flowpp_img_usable(B, Ci, Co, H, W)) return 0;
+    const int64_t tiles = (B * H * W + 255) / 256, blocks = (int64_t)((Co + 31) / 32) * ((Ci + 31) / 32);
+    int64_t k = (256 + blocks - 1) / blocks;
+    if (k > tiles) k = tiles;
+    if (k > NF_FLOWPP_IMG_MAX_SLABS) k = NF_FLOWPP_IMG_MAX_SLABS;
+    return (int)(k < 1 ? 1 : k);
+}
+
+extern "C" int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* slab_w, float* slab_b, int n_slabs, int64_t B,
+                                        int Ci, int Co, int H, int W, int in_mode, nf_stream_t stream) {
+    if (in == nullptr || g_out == nullptr || slab_w == nullptr || !nf_flowpp_img_usable(B, Ci, Co, H, W)) return NF_E_BADARG;
+    if (in_mode < 0 || in_mode > 1 || (in_mode == 1 && (Ci & 1)) || n_slabs < 1 || n_slabs > NF_FLOWPP_IMG_MAX_SLABS) return NF_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
-        case 4: return nf_fi_wgrad_launch<4>(in, g_out, g_weight, g_bias, B, Ci, Co, in_mode, st);
-        case 3: return nf_fi_wgrad_launch<3>(in, g_out, g_weight, g_bias, B, Ci, Co, in_mode, st);
-        default: return nf_fi_wgrad_launch<2>(in, g_out, g_weight, g_bias, B, Ci, Co, in_mode, st);
+        case 4: return nf_fi_wgrad_launch<4>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, in_mode, st);
+        case 3: return nf_fi_wgrad_launch<3>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, in_mode, st);
+        default: return nf_fi_wgrad_launch<2>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, in_mode, st);
     }
 }
 
@@ -660,7 +701,7 @@ extern "C" int nf_flowpp_img_mid_fwd(const float* x, const float* a, const float
         conv1_b == nullptr || conv2_w == nullptr || conv2_b == nullptr || ln2_g == nullptr || ln2_b == nullptr || out == nullptr)
         return NF_E_BADARG;
     if (!nf_flowpp_img_usable(B, 32, 32, H, W) || B > 0x7fffffff) return NF_E_BADARG;
-    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, out, nullptr, nullptr, nullptr,
+    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, out, nullptr, 1, 0, nullptr, nullptr,
                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
@@ -675,14 +716,14 @@ extern "C" int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float
                                      const float* ln2_g, const float* ln2_b, const float* g_out, float* g_x, float* g_a,
                                      float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_conv1_w, float* g_conv1_b,
                                      float* g_conv2_w, float* g_conv2_b, float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W,
-                                     nf_stream_t stream) {
+                                     int g_out_slabs, nf_stream_t stream) {
     if (x == nullptr || a == nullptr || ln1_g == nullptr || ln1_b == nullptr || pos == nullptr || conv1_w == nullptr ||
         conv1_b == nullptr || conv2_w == nullptr || conv2_b == nullptr || ln2_g == nullptr || ln2_b == nullptr || g_out == nullptr ||
         g_x == nullptr || g_a == nullptr || g_ln1_g == nullptr || g_ln1_b == nullptr || g_pos == nullptr || g_conv1_w == nullptr ||
         g_conv1_b == nullptr || g_conv2_w == nullptr || g_conv2_b == nullptr || g_ln2_g == nullptr || g_ln2_b == nullptr)
         return NF_E_BADARG;
-    if (!nf_flowpp_img_usable(B, 32, 32, H, W) || B > 0x7fffffff) return NF_E_BADARG;
-    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, nullptr, g_out, g_x, g_a, g_ln1_g,
+    if (!nf_flowpp_img_usable(B, 32, 32, H, W) || B > 0x7fffffff || g_out_slabs < 1 || g_out_slabs > NF_FLOWPP_IMG_MAX_KSPLIT) return NF_E_BADARG;
+    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, nullptr, g_out, g_out_slabs, B * 32 * H * W, g_x, g_a, g_ln1_g,
                  g_ln1_b, g_pos, g_conv1_w, g_conv1_b, g_conv2_w, g_conv2_b, g_ln2_g, g_ln2_b};
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {

@@ -1,7 +1,7 @@
 """
 The Flow++ conditioner of IMAGE data (flows/coupling.py:159-166: Conv2d -> GatedConv2d -> LayerNorm -> GatedAttn -> LayerNorm ->
 Conv2d, flows/modules.py:519-578) on the kernels of csrc/flowpp_img.hip -- C ABI ``nf_flowpp_img_conv / _conv_wgrad / _mid_fwd /
-_mid_bwd / _celu_bwd``: 4 launches forward and 9 backward, no MIOpen / ATen convolution, matmul, softmax or LayerNorm kernel.
+_mid_bwd / _celu_bwd``: 4 launches forward and 10 backward, no MIOpen / ATen convolution, matmul, softmax or LayerNorm kernel.
 
 Only the two convolution outputs in front of the gate are kept for the backward (x = conv0's output, a = the gated
 convolution's output): everything between the gate and the last convolution is recomputed per sample inside the backward kernel.
@@ -68,11 +68,11 @@ class _FusedFlowppImg(torch.autograd.Function):
         a = torch.empty_like(x)
         x4 = torch.empty_like(x)
         out = torch.empty(B, O, Hh, Ww, dtype=torch.float32, device=dev)
-        N.call('nf_flowpp_img_conv', N.ptr(x_in), N.ptr(W0), N.ptr(b0), N.ptr(x), B, I0, HID, Hh, Ww, 0, 0, st)
-        N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(Wg), N.ptr(bg), N.ptr(a), B, 2 * HID, HID, Hh, Ww, 1, 0, st)
+        N.call('nf_flowpp_img_conv', N.ptr(x_in), N.ptr(W0), N.ptr(b0), N.ptr(x), B, I0, HID, Hh, Ww, 0, 0, 1, st)
+        N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(Wg), N.ptr(bg), N.ptr(a), B, 2 * HID, HID, Hh, Ww, 1, 0, 1, st)
         N.call('nf_flowpp_img_mid_fwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
                N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(x4), B, Hh, Ww, st)
-        N.call('nf_flowpp_img_conv', N.ptr(x4), N.ptr(W5), N.ptr(b5), N.ptr(out), B, HID, O, Hh, Ww, 0, 0, st)
+        N.call('nf_flowpp_img_conv', N.ptr(x4), N.ptr(W5), N.ptr(b5), N.ptr(out), B, HID, O, Hh, Ww, 0, 0, 1, st)
         ctx.save_for_backward(x_in, x, a, x4, *ts)
         return out
 
@@ -95,27 +95,42 @@ class _FusedFlowppImg(torch.autograd.Function):
                 o += t.numel()
             direct = False
         (gW0, gb0, gWg, gbg, gl1g, gl1b, gpos, gc1w, gc1b, gc2w, gc2b, gl2g, gl2b, gW5, gb5) = dst
-        # last convolution
-        g4 = torch.empty_like(x)
-        N.call('nf_flowpp_img_conv', N.ptr(g_out), N.ptr(W5), None, N.ptr(g4), B, O, HID, Hh, Ww, 0, 1, st)
-        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x4), N.ptr(g_out), N.ptr(gW5), N.ptr(gb5), B, HID, O, Hh, Ww, 0, st)
+        lib = N.load()
+        jobs = []
+
+        def wgrad(inp, g, gw, gb, Ci, Co, mode):
+            """slabs of one convolution's weight / bias gradient; folded into gw / gb (+=) by the one nf_slab_sum below"""
+            ns = int(lib.nf_flowpp_img_wgrad_slabs(B, Ci, Co, Hh, Ww))
+            sw = torch.empty(ns * Co * Ci * 9 + ns * Co, dtype=torch.float32, device=dev)
+            sb = sw[ns * Co * Ci * 9:]
+            N.call('nf_flowpp_img_conv_wgrad', N.ptr(inp), N.ptr(g), N.ptr(sw), sb.data_ptr(), ns, B, Ci, Co, Hh, Ww, mode, st)
+            jobs.append((sw, gw, Co * Ci * 9, Co * Ci * 9, ns, True, 1))
+            jobs.append((sb, gb, Co, Co, ns, True, 1))
+
+        # last convolution: K = 9 O is cut into slabs that the next kernel sums on load
+        ks = int(lib.nf_flowpp_img_conv_ksplit(B, O, HID, Hh, Ww))
+        g4 = torch.empty(ks, B, HID, Hh, Ww, dtype=torch.float32, device=dev)
+        N.call('nf_flowpp_img_conv', N.ptr(g_out), N.ptr(W5), None, N.ptr(g4), B, O, HID, Hh, Ww, 0, 1, ks, st)
+        wgrad(x4, g_out, gW5, gb5, HID, O, 0)
         # gate / LayerNorm / attention / LayerNorm
         g_x = torch.empty_like(x)
         g_a = torch.empty_like(x)
         N.call('nf_flowpp_img_mid_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
                N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(g4), N.ptr(g_x), N.ptr(g_a), N.ptr(gl1g), N.ptr(gl1b), N.ptr(gpos),
-               N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), B, Hh, Ww, st)
+               N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), B, Hh, Ww, ks, st)
         # gated convolution (its input is concat_elu(x), applied while staging)
         g_cat = torch.empty(B, 2 * HID, Hh, Ww, dtype=torch.float32, device=dev)
-        N.call('nf_flowpp_img_conv', N.ptr(g_a), N.ptr(Wg), None, N.ptr(g_cat), B, HID, 2 * HID, Hh, Ww, 0, 1, st)
-        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(g_a), N.ptr(gWg), N.ptr(gbg), B, 2 * HID, HID, Hh, Ww, 1, st)
+        N.call('nf_flowpp_img_conv', N.ptr(g_a), N.ptr(Wg), None, N.ptr(g_cat), B, HID, 2 * HID, Hh, Ww, 0, 1, 1, st)
+        wgrad(x, g_a, gWg, gbg, 2 * HID, HID, 1)
         N.call('nf_flowpp_img_celu_bwd', N.ptr(x), N.ptr(g_cat), N.ptr(g_x), B, HID, Hh, Ww, st)
         # first convolution
-        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x_in), N.ptr(g_x), N.ptr(gW0), N.ptr(gb0), B, I0, HID, Hh, Ww, 0, st)
+        wgrad(x_in, g_x, gW0, gb0, I0, HID, 0)
         g_in = None
         if ctx.needs_input_grad[0]:
             g_in = torch.empty_like(x_in)
-            N.call('nf_flowpp_img_conv', N.ptr(g_x), N.ptr(W0), None, N.ptr(g_in), B, HID, I0, Hh, Ww, 0, 1, st)
+            N.call('nf_flowpp_img_conv', N.ptr(g_x), N.ptr(W0), None, N.ptr(g_in), B, HID, I0, Hh, Ww, 0, 1, 1, st)
+        from .fused_conv import _slab_sum_all
+        _slab_sum_all(jobs)
         if direct:
             return (g_in, ) + (None, ) * len(ts)
         return (g_in, ) + tuple(dst)

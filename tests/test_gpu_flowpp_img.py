@@ -42,16 +42,19 @@ def test_conv_forward_data_and_weight_gradient_vs_torch(pkg, Ci, Co, HW, B):
     gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [xr, wr, br], gy)
     st = N.stream()
     y = torch.empty_like(y_ref)
-    N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(y), B, Ci, Co, HW, HW, 0, 0, st)
+    N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(y), B, Ci, Co, HW, HW, 0, 0, 1, st)
     G.assert_close(y, y_ref, _scaled(y_ref), what='conv forward')
-    gx = torch.empty_like(x)
-    N.call('nf_flowpp_img_conv', N.ptr(gy), N.ptr(w), None, N.ptr(gx), B, Co, Ci, HW, HW, 0, 1, st)
-    G.assert_close(gx, gx_ref, _scaled(gx_ref), what='conv data gradient')
-    gw = torch.full_like(w, 0.5)                       # accumulated into, not overwritten
-    gb = torch.full_like(b, -1.0)
-    N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(gy), N.ptr(gw), N.ptr(gb), B, Ci, Co, HW, HW, 0, st)
-    G.assert_close(gw - 0.5, gw_ref, _scaled(gw_ref), what='conv weight gradient')
-    G.assert_close(gb + 1.0, gb_ref, _scaled(gb_ref), what='conv bias gradient')
+    lib = N.load()
+    for ks in sorted({1, int(lib.nf_flowpp_img_conv_ksplit(B, Co, Ci, HW, HW)), (Co + 31) // 32}):    # K-split data gradient: the slabs sum to it
+        gx = torch.full((ks, ) + tuple(x.shape), 7.0, device=DEV)
+        N.call('nf_flowpp_img_conv', N.ptr(gy), N.ptr(w), None, N.ptr(gx), B, Co, Ci, HW, HW, 0, 1, ks, st)
+        G.assert_close(gx.sum(0), gx_ref, _scaled(gx_ref), what='conv data gradient, %d slabs' % ks)
+    for ns in sorted({1, int(lib.nf_flowpp_img_wgrad_slabs(B, Ci, Co, HW, HW))}):
+        sw = torch.full((ns, ) + tuple(w.shape), 7.0, device=DEV)           # every element written
+        sb = torch.full((ns, Co), 7.0, device=DEV)
+        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(gy), N.ptr(sw), N.ptr(sb), ns, B, Ci, Co, HW, HW, 0, st)
+        G.assert_close(sw.sum(0), gw_ref, _scaled(gw_ref), what='conv weight gradient, %d slabs' % ns)
+        G.assert_close(sb.sum(0), gb_ref, _scaled(gb_ref), what='conv bias gradient, %d slabs' % ns)
 
 
 @pytest.mark.parametrize('HW,B', [(16, 3), (8, 6), (4, 19)])
@@ -67,17 +70,18 @@ def test_gated_convolution_applies_concat_elu_while_staging(pkg, HW, B):
     gx_ref, gw_ref, gb_ref = torch.autograd.grad(a_ref, [xr, wr, br], ga)
     st = N.stream()
     a = torch.empty_like(a_ref)
-    N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(a), B, 64, 32, HW, HW, 1, 0, st)
+    N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(a), B, 64, 32, HW, HW, 1, 0, 1, st)
     G.assert_close(a, a_ref, _scaled(a_ref), what='gated conv forward')
     gcat = torch.empty(B, 64, HW, HW, device=DEV)
-    N.call('nf_flowpp_img_conv', N.ptr(ga), N.ptr(w), None, N.ptr(gcat), B, 32, 64, HW, HW, 0, 1, st)
+    N.call('nf_flowpp_img_conv', N.ptr(ga), N.ptr(w), None, N.ptr(gcat), B, 32, 64, HW, HW, 0, 1, 1, st)
     gx = torch.zeros_like(x)
     N.call('nf_flowpp_img_celu_bwd', N.ptr(x), N.ptr(gcat), N.ptr(gx), B, 32, HW, HW, st)
     G.assert_close(gx, gx_ref, _scaled(gx_ref), what='gated conv input gradient')
-    gw, gb = torch.zeros_like(w), torch.zeros_like(b)
-    N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(ga), N.ptr(gw), N.ptr(gb), B, 64, 32, HW, HW, 1, st)
-    G.assert_close(gw, gw_ref, _scaled(gw_ref), what='gated conv weight gradient')
-    G.assert_close(gb, gb_ref, _scaled(gb_ref), what='gated conv bias gradient')
+    ns = int(N.load().nf_flowpp_img_wgrad_slabs(B, 64, 32, HW, HW))
+    sw, sb = torch.empty((ns, ) + tuple(w.shape), device=DEV), torch.empty(ns, 32, device=DEV)
+    N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(ga), N.ptr(sw), N.ptr(sb), ns, B, 64, 32, HW, HW, 1, st)
+    G.assert_close(sw.sum(0), gw_ref, _scaled(gw_ref), what='gated conv weight gradient')
+    G.assert_close(sb.sum(0), gb_ref, _scaled(gb_ref), what='gated conv bias gradient')
 
 
 def _cond_pair(pkg, in_chs, n_out, HW, seed):
