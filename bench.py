@@ -42,6 +42,9 @@ CONFIGS = {
                batch=64, desc='Glow CIFAR-shape (3,32,32) L=3 K=32 batch 64 per GPU (512 over 8)', cpu_threads=16),
     'c5': dict(cls='MAF', kind='maf', dims=(2, ), datatype='2d', layers=10, mixtures=None, data='normals', batch=16384,
                desc='MAF normals-2D 10 AR layers batch 16384 per GPU (131072 over 8)'),
+    # not a BASELINE.json config: the third model north_star names on CIFAR-shape batches (flows/flowpp.py:17-62), --config fpp_img only
+    'fpp_img': dict(cls='Flowpp', kind='flowpp', dims=(3, 32, 32), datatype='image', layers=2, mixtures=8, data='cifar', batch=64,
+                    desc='Flow++ CIFAR-shape (3,32,32) layers=2 mixtures=8 batch 64 per GPU', cpu_threads=16),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -241,6 +244,18 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
         pmc = ('k_flowpp_cond_bwd', '')
         note = ('fp32-input MFMA (exact fp32, 1/16 of the bf16 rate); the rest is transcendental VALU work and the LDS transposes of '
                 'the weight-gradient operands (DESIGN.md section 3.12)')
+    elif cfg['kind'] == 'flowpp' and len(dims) == 3:
+        # image Flow++ (csrc/flowpp_img.hip): the longest launch is the backward of gate + LayerNorm + 4-head attention + LayerNorm at the
+        # 16 x 16 level, one workgroup per sample, VALU work (the fp32 vector peak equals the fp32 matrix peak on gfx950)
+        Np = (dims[1] // 2) * (dims[2] // 2)
+        entry, match, per_call = 'nf_flowpp_img_mid_bwd', (lambda a: int(a[-4]) * int(a[-3]) == Np), 1
+        mac = 3 * Np * (96 * 32 + 64 * 32) + 4 * Np * Np * (16 + 16 + 32)      # recompute + data + weight gradients; attention sweeps
+        flop = 2 * mac * B
+        nbytes = 4 * B * 32 * Np * 5
+        kname = 'k_fi_mid<256, true> (gate + LayerNorm + attention over %d positions + LayerNorm, backward, one workgroup per sample)' % Np
+        pmc = ('k_fi_mid', '')
+        note = ('vector-ALU kernel (softmax sweeps with one exp per score, 8-wide dot products from LDS): %d of 256 compute units hold '
+                'the launch at this batch' % min(B, 256))
     else:
         return None
     with N.timed_launches(entry, match) as t:

@@ -51,6 +51,7 @@ template <int LGW, int INMODE>
 __device__ __forceinline__ void nf_fi_stage_frame(float* F, const float* __restrict__ in, int64_t b0, int64_t B, int Ci, int c0) {
     using G = NfFiGeo<LGW>;
     constexpr int PER = G::S * G::FS;
+#pragma unroll 6
     for (int e = threadIdx.x; e < 32 * PER; e += NF_FI_THREADS) {
         const int c = e / PER, f = e - c * PER;
         const int s = f / G::FS, r = f - s * G::FS;
@@ -76,6 +77,7 @@ __device__ __forceinline__ void nf_fi_stage_frame(float* F, const float* __restr
 template <bool TR>
 __device__ __forceinline__ void nf_fi_stage_w(float* Wl, const float* __restrict__ w, int Ci, int Co, int o0, int c0) {
     const int cc = min(32, Ci - c0);
+#pragma unroll 6
     for (int e = threadIdx.x; e < 32 * 288; e += NF_FI_THREADS) {
         if (!TR) {
             const int r = e / 288, k = e - r * 288;
@@ -171,6 +173,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __
         const int64_t b0 = tile * G::S;
         __syncthreads();
         nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
+#pragma unroll 8
         for (int e = threadIdx.x; e < 32 * 256; e += NF_FI_THREADS) {
             const int o = e >> 8, p = e & 255;
             const int64_t b = b0 + (p >> (2 * LGW));
@@ -343,7 +346,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     for (int d = 0; d < 8; ++d) mix[d] = 0.f;
 #pragma unroll 2
     for (int i = 0; i < N; ++i) {
-        const float p = expf(nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], k) * scale - mx);
+        const float p = __expf(nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], k) * scale - mx);
         const f32x4 q0 = PC4[(h * N + i) * 2], q1 = PC4[(h * N + i) * 2 + 1];
         l += p;
 #pragma unroll
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     float delta = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) delta += mix[d] * gm[d];
-    const float cj = mx + logf(l);                       // P[i][j] = exp(s[i][j] - cj)
+    const float cj = mx + __logf(l);                     // P[i][j] = exp(s[i][j] - cj)   (v_exp / v_log: ~1e-7 relative on the probabilities)
     f32x4* PA4 = reinterpret_cast<f32x4*>(PA);
     f32x4* PD4 = reinterpret_cast<f32x4*>(PD);
     PA4[(h * N + j) * 2] = (f32x4){v[0], v[1], v[2], v[3]};
@@ -480,7 +483,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
 #pragma unroll 2
     for (int i = 0; i < N; ++i) {                        // this thread as the column j: gradient of K_j
         const f32x4 v0 = PA4[(h * N + i) * 2], v1 = PA4[(h * N + i) * 2 + 1];
-        const float p = expf(nf_fi_dot8(v0, v1, k) * scale - cj);
+        const float p = __expf(nf_fi_dot8(v0, v1, k) * scale - cj);
         const float gs = p * (nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], gm) - delta);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -492,7 +495,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     for (int jj = 0; jj < N; ++jj) {                     // this thread as the row i = j: gradients of V_i and Q_i
         const f32x4 k0 = PC4[(h * N + jj) * 2], k1 = PC4[(h * N + jj) * 2 + 1];
         const f32x4 g0 = PD4[(h * N + jj) * 2], g1 = PD4[(h * N + jj) * 2 + 1];
-        const float p = expf(nf_fi_dot8(k0, k1, v) * scale - CJ[h * N + jj]);
+        const float p = __expf(nf_fi_dot8(k0, k1, v) * scale - CJ[h * N + jj]);
         const float gs = p * (nf_fi_dot8(g0, g1, q) - DL[h * N + jj]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
