@@ -16,6 +16,9 @@
 //                    variant recomputes that from the two 4-byte inputs and walks it in reverse (no activation is saved).
 // Algorithmic HBM bytes per sample and direction: (I0 + 2 * 32 + 32 + 32 + O) * H * W * 4 for the forward (inputs and outputs of the
 // four launches) -- the activations between the layers of `mid` stay in LDS / registers.
+#include <mutex>
+#include <unordered_set>
+
 #include "nf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,28 +50,35 @@ __device__ __forceinline__ float nf_fi_sigmoid(float v) { return 1.f / (1.f + ex
 
 // 32 channels [c0, c0 + 32) of the tile's samples [b0, b0 + S) with a zero halo; INMODE 1: the convolution sees
 // concat_elu(in) = elu([in, -in]) of a (B, Ci / 2, H, W) tensor (flows/modules.py:500-517)
+// (the staging loops load in batches of NF_FI_U through clamped addresses: the loads of a batch are unconditional and in flight
+// together -- a predicated load per trip serialises one HBM / L2 round trip per element)
+#define NF_FI_U 8
 template <int LGW, int INMODE>
 __device__ __forceinline__ void nf_fi_stage_frame(float* F, const float* __restrict__ in, int64_t b0, int64_t B, int Ci, int c0) {
     using G = NfFiGeo<LGW>;
-    constexpr int PER = G::S * G::FS;
-#pragma unroll 6
-    for (int e = threadIdx.x; e < 32 * PER; e += NF_FI_THREADS) {
-        const int c = e / PER, f = e - c * PER;
-        const int s = f / G::FS, r = f - s * G::FS;
-        const int yy = r / G::PW, xx = r - yy * G::PW;
-        const int cc = c0 + c;
-        float v = 0.f;
-        if (yy >= 1 && yy <= G::W && xx >= 1 && xx <= G::W && cc < Ci && b0 + s < B) {
+    constexpr int PER = G::S * G::FS, TOT = 32 * PER, IT = (TOT + NF_FI_THREADS - 1) / NF_FI_THREADS;
+    const int Ch = Ci >> 1;
+    for (int it0 = 0; it0 < IT; it0 += NF_FI_U) {
+        float tmp[NF_FI_U];
+#pragma unroll
+        for (int u = 0; u < NF_FI_U; ++u) {
+            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
+            const int c = e / PER, f = e - c * PER;
+            const int s = f / G::FS, r = f - s * G::FS;
+            const int yy = r / G::PW, xx = r - yy * G::PW;
+            const int cc = c0 + c;
+            const bool ok = e < TOT && yy >= 1 && yy <= G::W && xx >= 1 && xx <= G::W && cc < Ci && b0 + s < B;
             const int q = (yy - 1) * G::W + xx - 1;
-            if (INMODE == 0) {
-                v = in[((b0 + s) * Ci + cc) * G::N + q];
-            } else {
-                const int Ch = Ci >> 1;
-                const float t = in[((b0 + s) * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + q];
-                v = nf_fi_elu_fast(cc < Ch ? t : -t);
-            }
+            const int64_t idx = INMODE == 0 ? ((b0 + s) * Ci + cc) * G::N + q : ((b0 + s) * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + q;
+            float v = in[ok ? idx : 0];
+            if (INMODE == 1) v = nf_fi_elu_fast(cc < Ch ? v : -v);
+            tmp[u] = ok ? v : 0.f;
         }
-        F[c * G::CS + f] = v;
+#pragma unroll
+        for (int u = 0; u < NF_FI_U; ++u) {
+            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
+            if (e < TOT) F[(e / PER) * G::CS + (e % PER)] = tmp[u];
+        }
     }
 }
 
@@ -77,15 +87,35 @@ __device__ __forceinline__ void nf_fi_stage_frame(float* F, const float* __restr
 template <bool TR>
 __device__ __forceinline__ void nf_fi_stage_w(float* Wl, const float* __restrict__ w, int Ci, int Co, int o0, int c0) {
     const int cc = min(32, Ci - c0);
-#pragma unroll 6
-    for (int e = threadIdx.x; e < 32 * 288; e += NF_FI_THREADS) {
-        if (!TR) {
-            const int r = e / 288, k = e - r * 288;
-            Wl[r * NF_FI_WS + k] = (o0 + r < Co && k < cc * 9) ? w[((int64_t)(o0 + r) * Ci + c0) * 9 + k] : 0.f;
-        } else {
-            const int cl = e / 288, rem = e - cl * 288;
-            const int r = rem / 9, t = rem - r * 9;
-            Wl[r * NF_FI_WS + cl * 9 + 8 - t] = (cl < cc && o0 + r < Co) ? w[((int64_t)(c0 + cl) * Co + o0) * 9 + rem] : 0.f;
+    constexpr int IT = 32 * 288 / NF_FI_THREADS;          // 18 trips
+    for (int it0 = 0; it0 < IT; it0 += 6) {
+        float tmp[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
+            if (!TR) {
+                const int r = e / 288, k = e - r * 288;
+                const bool ok = o0 + r < Co && k < cc * 9;
+                const float v = w[ok ? ((int64_t)(o0 + r) * Ci + c0) * 9 + k : 0];
+                tmp[u] = ok ? v : 0.f;
+            } else {
+                const int cl = e / 288, rem = e - cl * 288;
+                const bool ok = cl < cc && o0 + rem / 9 < Co;
+                const float v = w[ok ? ((int64_t)(c0 + cl) * Co + o0) * 9 + rem : 0];
+                tmp[u] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
+            if (!TR) {
+                const int r = e / 288, k = e - r * 288;
+                Wl[r * NF_FI_WS + k] = tmp[u];
+            } else {
+                const int cl = e / 288, rem = e - cl * 288;
+                const int r = rem / 9, t = rem - r * 9;
+                Wl[r * NF_FI_WS + cl * 9 + 8 - t] = tmp[u];
+            }
         }
     }
 }
@@ -173,11 +203,22 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __
         const int64_t b0 = tile * G::S;
         __syncthreads();
         nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
-#pragma unroll 8
-        for (int e = threadIdx.x; e < 32 * 256; e += NF_FI_THREADS) {
-            const int o = e >> 8, p = e & 255;
-            const int64_t b = b0 + (p >> (2 * LGW));
-            Gt[o * NF_FI_GS + p] = (b < B && o0 + o < Co) ? g[(b * Co + o0 + o) * G::N + (p & (G::N - 1))] : 0.f;
+        for (int it0 = 0; it0 < 16; it0 += 8) {
+            float tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
+                const int o = e >> 8, p = e & 255;
+                const int64_t b = b0 + (p >> (2 * LGW));
+                const bool ok = b < B && o0 + o < Co;
+                const float v = g[ok ? (b * Co + o0 + o) * G::N + (p & (G::N - 1)) : 0];
+                tmp[u] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
+                Gt[(e >> 8) * NF_FI_GS + (e & 255)] = tmp[u];
+            }
         }
         __syncthreads();
 #pragma unroll 2
@@ -257,6 +298,29 @@ __device__ __forceinline__ float nf_fi_dot8(const f32x4& a0, const f32x4& a1, co
 
 // channel-major plane [32][N] with a per-row rotation: conflict-free both for (fixed c, lanes over p) and (fixed p, lanes over c)
 #define NF_FI_IDX(c, p) ((c) * N + (((p) + (c)) & (N - 1)))
+
+// weight / bias gradient of a 1x1 convolution block:  gw[o][c] += sum_p GP[o][p] * T[c][p]  (o, c < 32),  gb[o] += sum_p GP[o][p],
+// GP and T rotated planes.  ONE wave on the matrix cores, K = the N positions (the VALU form -- a thread per (o, c) pair walking N
+// positions with two LDS reads per product -- was 60 % of the backward at 4 x 4, where the workgroup is a single wave).
+template <int N>
+__device__ __forceinline__ void nf_fi_pair_mfma(const float* GP, const float* T, float* __restrict__ gw, float* __restrict__ gb) {
+    const int lane = threadIdx.x & 63, r32 = lane & 31, hs = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bs = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < N / 2; ++s) {
+        const int p = 2 * s + hs;
+        const float a = GP[NF_FI_IDX(r32, p)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, T[NF_FI_IDX(r32, p)], acc, 0, 0, 0);
+        bs += a;
+    }
+    bs += __shfl_xor(bs, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(gw + nf_fi_cd_row(r, hs) * 32 + r32, acc[r]);
+    if (hs == 0) atomicAdd(gb + r32, bs);
+}
 
 template <int N, bool BWD>
 __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
@@ -444,19 +508,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
                 gm[d] += w4[0] * e0 + w4[1] * e1 + w4[2] * e2 + w4[3] * e3;
             }
         }
-#pragma unroll 1
-        for (int e = tid; e < 1024; e += NT) {
-            const int o = e >> 5, c = e & 31;
-            float acc = 0.f, bs = 0.f;
-#pragma unroll 4
-            for (int p = 0; p < N; ++p) {
-                const float gv_ = PB[NF_FI_IDX(o, p)];
-                acc += gv_ * PA[NF_FI_IDX(c, p)];
-                bs += gv_;
-            }
-            atomicAdd(m.g_w2 + (32 * part + o) * 32 + c, acc);
-            if (c == 0) atomicAdd(m.g_b2 + 32 * part + o, bs);
-        }
+        if ((tid >> 6) == part % (NT / 64)) nf_fi_pair_mfma<N>(PB, PA, m.g_w2 + 32 * part * 32, m.g_b2 + 32 * part);
     }
     // attention backward.  delta_j = sum_i P[i][j] gP[i][j] = mixed_j . g_mixed_j ;  g_s[i][j] = P[i][j] (gP[i][j] - delta_j)
     __syncthreads();                                     // PA / PB / W2s are free
@@ -533,19 +585,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
                 gt[d] += w4[0] * e0 + w4[1] * e1 + w4[2] * e2 + w4[3] * e3;
             }
         }
-#pragma unroll 1
-        for (int e = tid; e < 1024; e += NT) {
-            const int o = e >> 5, c = e & 31;
-            float acc = 0.f, bs = 0.f;
-#pragma unroll 4
-            for (int p = 0; p < N; ++p) {
-                const float gv_ = P[NF_FI_IDX(o, p)];
-                acc += gv_ * PD[NF_FI_IDX(c, p)];
-                bs += gv_;
-            }
-            atomicAdd(m.g_w1 + (32 * part + o) * 32 + c, acc);
-            if (c == 0) atomicAdd(m.g_b1 + 32 * part + o, bs);
-        }
+        if ((tid >> 6) == (part + 2) % (NT / 64)) nf_fi_pair_mfma<N>(P, PD, m.g_w1 + 32 * part * 32, m.g_b1 + 32 * part);
     }
     // LayerNorm 1 and the gate
     {
@@ -573,10 +613,21 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// dynamic LDS above the 64 KB default needs a per-kernel opt-in, once per kernel (keyed by the function's address)
 template <typename K>
 static inline int nf_fi_optin(K kernel, size_t lds) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> done;
+    if (lds > 160 * 1024) return NF_E_BADARG;
     if (lds <= 64 * 1024) return 0;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.find(key) == done.end()) {
+        hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done.insert(key);
+    }
+    return 0;
 }
 
 static inline int nf_fi_lgw(int H, int W) {
