@@ -50,73 +50,71 @@ __device__ __forceinline__ float nf_fi_sigmoid(float v) { return 1.f / (1.f + ex
 
 // 32 channels [c0, c0 + 32) of the tile's samples [b0, b0 + S) with a zero halo; INMODE 1: the convolution sees
 // concat_elu(in) = elu([in, -in]) of a (B, Ci / 2, H, W) tensor (flows/modules.py:500-517)
-// (the staging loops load in batches of NF_FI_U through clamped addresses: the loads of a batch are unconditional and in flight
-// together -- a predicated load per trip serialises one HBM / L2 round trip per element)
-#define NF_FI_U 8
+// Staging.  The halo of the frame is zeroed ONCE per workgroup (nf_fi_zero_frame); a chunk then brings only the 32 x 256 interior
+// values: thread t owns pixel t & 255 of the tile and the channels (t >> 8) + 2 u, u < 16 -- shifts only, coalesced along the pixels.
+// Loading (global -> registers, all 16 + 18 loads of a chunk unconditional through clamped 32-bit offsets, so they are in flight
+// together) is split from storing (registers -> LDS, where concat-ELU is applied): the loads of chunk i + 1 are issued before the
+// matrix instructions of chunk i.
+template <int LGW>
+__device__ __forceinline__ void nf_fi_zero_frame(float* F) {
+    for (int e = threadIdx.x; e < 32 * NfFiGeo<LGW>::CS; e += NF_FI_THREADS) F[e] = 0.f;
+}
+
+// INMODE 1: the convolution sees concat_elu(in) = elu([in, -in]) of a (B, Ci / 2, H, W) tensor (flows/modules.py:500-517)
 template <int LGW, int INMODE>
-__device__ __forceinline__ void nf_fi_stage_frame(float* F, const float* __restrict__ in, int64_t b0, int64_t B, int Ci, int c0) {
+__device__ __forceinline__ void nf_fi_frame_load(float (&tmp)[16], const float* __restrict__ in, int64_t b0, int64_t B, int Ci, int c0) {
     using G = NfFiGeo<LGW>;
-    constexpr int PER = G::S * G::FS, TOT = 32 * PER, IT = (TOT + NF_FI_THREADS - 1) / NF_FI_THREADS;
-    const int Ch = Ci >> 1;
-    for (int it0 = 0; it0 < IT; it0 += NF_FI_U) {
-        float tmp[NF_FI_U];
+    const int p = threadIdx.x & 255, ch = threadIdx.x >> 8;
+    const int bs = (int)b0 + (p >> (2 * LGW)), q = p & (G::N - 1), Ch = Ci >> 1;
+    const bool bok = bs < B;
 #pragma unroll
-        for (int u = 0; u < NF_FI_U; ++u) {
-            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
-            const int c = e / PER, f = e - c * PER;
-            const int s = f / G::FS, r = f - s * G::FS;
-            const int yy = r / G::PW, xx = r - yy * G::PW;
-            const int cc = c0 + c;
-            const bool ok = e < TOT && yy >= 1 && yy <= G::W && xx >= 1 && xx <= G::W && cc < Ci && b0 + s < B;
-            const int q = (yy - 1) * G::W + xx - 1;
-            const int64_t idx = INMODE == 0 ? ((b0 + s) * Ci + cc) * G::N + q : ((b0 + s) * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + q;
-            float v = in[ok ? idx : 0];
-            if (INMODE == 1) v = nf_fi_elu_fast(cc < Ch ? v : -v);
-            tmp[u] = ok ? v : 0.f;
-        }
+    for (int u = 0; u < 16; ++u) {
+        const int cc = c0 + ch + 2 * u;
+        const bool ok = bok && cc < Ci;
+        const unsigned idx = INMODE == 0 ? (unsigned)((bs * Ci + cc) * G::N + q) : (unsigned)((bs * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + q);
+        const float v = in[ok ? idx : 0u];
+        tmp[u] = ok ? v : 0.f;
+    }
+}
+
+template <int LGW, int INMODE>
+__device__ __forceinline__ void nf_fi_frame_store(float* F, const float (&tmp)[16], int Ci, int c0) {
+    using G = NfFiGeo<LGW>;
+    const int p = threadIdx.x & 255, ch = threadIdx.x >> 8;
+    float* dst = F + nf_fi_fpos<LGW>(p);
 #pragma unroll
-        for (int u = 0; u < NF_FI_U; ++u) {
-            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
-            if (e < TOT) F[(e / PER) * G::CS + (e % PER)] = tmp[u];
-        }
+    for (int u = 0; u < 16; ++u) {
+        float v = tmp[u];
+        if (INMODE == 1) v = nf_fi_elu_fast(c0 + ch + 2 * u < (Ci >> 1) ? v : -v);     // (elu(0) = 0: padding stays zero)
+        dst[(ch + 2 * u) * G::CS] = v;
     }
 }
 
 // Wl[r][k]: row r = output channel o0 + r of this GEMM, k = 9 * (local input channel) + tap.
-//   TR = false: weight (Co, Ci, 3, 3);   TR = true: weight (Ci, Co, 3, 3) read transposed with the taps flipped (data gradient)
+//   TR = false: weight (Co, Ci, 3, 3): thread t reads row t >> 4, k = (t & 15) + 16 u;
+//   TR = true : weight (Ci, Co, 3, 3) read transposed with the taps flipped (data gradient): thread t reads local input channel t >> 4
+//               and the 288 (output row, tap) values (t & 15) + 16 u of it
 template <bool TR>
-__device__ __forceinline__ void nf_fi_stage_w(float* Wl, const float* __restrict__ w, int Ci, int Co, int o0, int c0) {
-    const int cc = min(32, Ci - c0);
-    constexpr int IT = 32 * 288 / NF_FI_THREADS;          // 18 trips
-    for (int it0 = 0; it0 < IT; it0 += 6) {
-        float tmp[6];
+__device__ __forceinline__ void nf_fi_w_load(float (&tmp)[18], const float* __restrict__ w, int Ci, int Co, int o0, int c0) {
+    const int cc = min(32, Ci - c0), r = threadIdx.x >> 4, l16 = threadIdx.x & 15;
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
-            if (!TR) {
-                const int r = e / 288, k = e - r * 288;
-                const bool ok = o0 + r < Co && k < cc * 9;
-                const float v = w[ok ? ((int64_t)(o0 + r) * Ci + c0) * 9 + k : 0];
-                tmp[u] = ok ? v : 0.f;
-            } else {
-                const int cl = e / 288, rem = e - cl * 288;
-                const bool ok = cl < cc && o0 + rem / 9 < Co;
-                const float v = w[ok ? ((int64_t)(c0 + cl) * Co + o0) * 9 + rem : 0];
-                tmp[u] = ok ? v : 0.f;
-            }
-        }
+    for (int u = 0; u < 18; ++u) {
+        const int k = l16 + 16 * u;
+        const bool ok = TR ? (r < cc && o0 + k / 9 < Co) : (o0 + r < Co && k < cc * 9);
+        const unsigned idx = TR ? (unsigned)(((c0 + r) * Co + o0) * 9 + k) : (unsigned)(((o0 + r) * Ci + c0) * 9 + k);
+        const float v = w[ok ? idx : 0u];
+        tmp[u] = ok ? v : 0.f;
+    }
+}
+
+template <bool TR>
+__device__ __forceinline__ void nf_fi_w_store(float* Wl, const float (&tmp)[18]) {
+    const int r = threadIdx.x >> 4, l16 = threadIdx.x & 15;
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
-            if (!TR) {
-                const int r = e / 288, k = e - r * 288;
-                Wl[r * NF_FI_WS + k] = tmp[u];
-            } else {
-                const int cl = e / 288, rem = e - cl * 288;
-                const int r = rem / 9, t = rem - r * 9;
-                Wl[r * NF_FI_WS + cl * 9 + 8 - t] = tmp[u];
-            }
-        }
+    for (int u = 0; u < 18; ++u) {
+        const int k = l16 + 16 * u;
+        if (!TR) Wl[r * NF_FI_WS + k] = tmp[u];
+        else Wl[(k / 9) * NF_FI_WS + r * 9 + 8 - (k % 9)] = tmp[u];
     }
 }
 
@@ -157,12 +155,22 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restri
     // K split: workgroup z of gridDim.z takes the 32-channel chunks [z * cps, (z + 1) * cps) and leaves its partial sums in slab z
     const int nchunks = (Ci + 31) >> 5, cps = (nchunks + (int)gridDim.z - 1) / (int)gridDim.z;
     const int ch0 = (int)blockIdx.z * cps, ch1 = min(nchunks, ch0 + cps);
+    float tf[16], tw[18];
+    if (ch0 < ch1) {
+        nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, 32 * ch0);
+        nf_fi_w_load<TR>(tw, w, Ci, Co, o0, 32 * ch0);
+    }
+    nf_fi_zero_frame<LGW>(F);                                // (under the first loads' latency)
     for (int ch = ch0; ch < ch1; ++ch) {
         const int c0 = 32 * ch;
         __syncthreads();
-        nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
-        nf_fi_stage_w<TR>(Wl, w, Ci, Co, o0, c0);
+        nf_fi_frame_store<LGW, INMODE>(F, tf, Ci, c0);
+        nf_fi_w_store<TR>(Wl, tw);
         __syncthreads();
+        if (ch + 1 < ch1) {                                  // the next chunk's operands travel while this chunk's products issue
+            nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, c0 + 32);
+            nf_fi_w_load<TR>(tw, w, Ci, Co, o0, c0 + 32);
+        }
         nf_fi_kchunk<LGW>(acc, Wl, F, (min(32, Ci - c0) + 7) >> 3, fpos, r32, hs);
     }
     const int64_t b = b0 + (p >> (2 * LGW));
@@ -199,27 +207,26 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
+    nf_fi_zero_frame<LGW>(F);
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t b0 = tile * G::S;
-        __syncthreads();
-        nf_fi_stage_frame<LGW, INMODE>(F, in, b0, B, Ci, c0);
-        for (int it0 = 0; it0 < 16; it0 += 8) {
-            float tmp[8];
+        float tf[16], tg[16];
+        nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, c0);
+        {
+            const int p = threadIdx.x & 255, ch = threadIdx.x >> 8;
+            const int bs = (int)b0 + (p >> (2 * LGW)), q = p & (G::N - 1);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
-                const int o = e >> 8, p = e & 255;
-                const int64_t b = b0 + (p >> (2 * LGW));
-                const bool ok = b < B && o0 + o < Co;
-                const float v = g[ok ? (b * Co + o0 + o) * G::N + (p & (G::N - 1)) : 0];
-                tmp[u] = ok ? v : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = threadIdx.x + (it0 + u) * NF_FI_THREADS;
-                Gt[(e >> 8) * NF_FI_GS + (e & 255)] = tmp[u];
+            for (int u = 0; u < 16; ++u) {
+                const int o = o0 + ch + 2 * u;
+                const bool ok = bs < B && o < Co;
+                const float v = g[ok ? (unsigned)((bs * Co + o) * G::N + q) : 0u];
+                tg[u] = ok ? v : 0.f;
             }
         }
+        __syncthreads();                                     // the previous tile's readers are done (and the halo is zero)
+        nf_fi_frame_store<LGW, INMODE>(F, tf, Ci, c0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) Gt[((threadIdx.x >> 8) + 2 * u) * NF_FI_GS + (threadIdx.x & 255)] = tg[u];
         __syncthreads();
 #pragma unroll 2
         for (int s2 = 0; s2 < 16; ++s2) {
