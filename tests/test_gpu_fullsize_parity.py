@@ -37,7 +37,9 @@ not exist at full depth.  What the test asserts instead:
     step is cheap (C1, C2, C5: K = 6) the GPU's flat-gradient distance to float64 must be <= 4 x the LARGEST distance of the
     ensemble; for C3 / C4 (one 45 s float64 pass) <= 4 x the unpermuted fp32 oracle's.
   * THE PER-STEP PROFILE.  For every flow step s the worst gradient entry (relative to the tensor's largest) must be inside
-        2e-5  +  SLACK * ensemble envelope(s)  +  max(FLIPS, B / 1024) / B * AMP ** (last - s)
+        2e-5  +  SLACK * ensemble envelope(s .. last)  +  max(FLIPS, B / 1024) / B * AMP ** (last - s)
+    (envelope(s .. last): the ensemble's worst error over the steps s .. last -- an event in a later step reaches every earlier step's
+    gradients through the backward pass, and six permutations sample WHICH step is hit only sparsely)
     i.e. the strict bar plus the footprint of at most FLIPS kink events per pass, amplified by AMP = 1.3 per step on the way back
     (measured, tools/probes/parity_depth.py).  The profile is written to gpurun_out/fullsize_parity.txt (committed per round under
     profiles/).
@@ -184,7 +186,9 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         last = max(pg)
         _report('%-18s %-14s per-step gradient error vs float64 (worst entry / max entry): step gpu | fp32 ensemble max | bar' % (name, tag))
         for st in sorted(pg):
-            env = max(p_.get(st, 0.0) for p_ in pe)
+            # a kink event in flow step s' perturbs the gradients of s' AND of every step before it (the backward pass carries it on):
+            # the envelope of step st is the ensemble's worst over the steps st .. last, not over st alone
+            env = max(p_.get(s2, 0.0) for p_ in pe for s2 in pg if s2 >= st)
             # (the number of near-kink units of a pass grows with the batch, the footprint of one shrinks with it: at least FLIPS events,
             #  one per 1024 rows beyond that)
             bar = 2.0 * TOL + SLACK * env + min(1.0, max(FLIPS, B // 1024) / float(B) * AMP ** min(last - st, 64))
