@@ -155,3 +155,23 @@ def test_layer_takes_the_fused_path_and_matches_the_module_path(pkg, monkeypatch
     G.assert_close(res[0][1], res[1][1], _scaled(res[1][1]), what='log-det')
     for a, b in zip(res[0][2], res[1][2]):
         G.assert_close(a, b, _scaled(b, 8.0), rtol=1e-4, what='gradient')
+
+
+def test_no_framework_convolution_matmul_softmax_or_layernorm_in_the_conditioner(pkg):
+    """the fused conditioner's forward + backward dispatch no ATen / MIOpen operator of the module stack it replaces (the module
+    stack itself, profiled the same way, does -- so the check sees what it should)"""
+    fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    net, ref = _cond_pair(pkg, 6, 84, 16, seed=1)
+    x = torch.randn(4, 6, 16, 16, device=DEV)
+    gy = torch.randn(4, 84, 16, 16, device=DEV)
+    banned = ('conv', 'matmul', 'bmm', 'softmax', 'layer_norm', 'elu', 'sigmoid', 'addmm', 'mm')
+
+    def ops(fn):
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            fn(x.clone().requires_grad_(True)).backward(gy)
+            torch.cuda.synchronize()
+        names = {e.key for e in prof.key_averages()}
+        return sorted(n for n in names if n.startswith('aten::') and any(b in n.split('::')[1] for b in banned))
+
+    assert ops(lambda t: fpi.flowpp_img_forward(net, t)) == []
+    assert any('conv' in n for n in ops(ref)) and any('softmax' in n for n in ops(ref))

@@ -21,6 +21,16 @@ WC=$(find /tmp/pmc_w -name "write_counter_collection.csv" | head -1)
 cd $GRAFT_REPO_ROOT
 NF_PMC_CONFIGS=c4,c1,c2,c3,c5 python tools/pmc_round.py --json $FC $WC $OUT/${R}_pmc.json > $OUT/pmc_json.log 2>&1
 cp $OUT/${R}_pmc.json $GRAFT_REPO_ROOT/profiles/${R}_pmc.json   # (the bench lines below read the round's PMC file from profiles/)
+# the image Flow++ path (row f4): kernel stats of its bench command, its bench line, per-launch device times, fused vs module stack
+cd /tmp
+rm -rf /tmp/ks_f
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_f -o st -- python $GRAFT_REPO_ROOT/bench.py --config fpp_img --skip-cpu --steps 20 > $OUT/${R}_rocprof_bench_fpp_img.json 2> /dev/null
+F=$(find /tmp/ks_f -name "st_kernel_stats.csv" | head -1)
+[ -n "$F" ] && head -45 $F > $OUT/${R}_fpp_img_kernel_stats.csv
+cd $GRAFT_REPO_ROOT
+python bench.py --config fpp_img --steps 50 --cpu-seconds 15 > $OUT/${R}_bench_fpp_img.json 2> /dev/null
+python tools/probes/flowpp_img_kernels.py 64 > $OUT/${R}_fpp_img_launch_times.txt 2>&1
+python tools/probes/flowpp_img_step.py 2 64 10 > $OUT/${R}_fpp_img_step.txt 2>&1
 python tools/kernel_sweep.py > $OUT/${R}_kernel_sweep.txt 2> $OUT/sweep.err
 for c in c1 c2 c3 c4 c5; do
   python bench.py --config $c --steps 50 --cpu-seconds 15 > $OUT/${R}_bench_$c.json 2> /dev/null

@@ -81,7 +81,9 @@ def main(name):
     pkg = importlib.import_module(bench.PKG)
     nftrain = importlib.import_module(bench.PKG + '.train')
     nfdata = importlib.import_module(bench.PKG + '.data')
-    cfg = bench.CONFIGS[name]
+    cfg = dict(bench.CONFIGS[name])
+    if os.environ.get('NF_BATCH'):           # per-GPU batch override (e.g. config 4's literal 512 on one GPU)
+        cfg['batch'] = int(os.environ['NF_BATCH'])
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     np.random.seed(0)
