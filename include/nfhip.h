@@ -947,6 +947,32 @@ int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float* ln1_g, co
                           float* g_ln1_b, float* g_pos, float* g_conv1_w, float* g_conv1_b, float* g_conv2_w, float* g_conv2_b,
                           float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W, int g_out_slabs, nf_stream_t stream);
 
+/* The same middle cut BY ATTENTION HEAD (csrc/flowpp_img_att.hip), for batches that leave most of the chip idle with one workgroup per
+ * sample: H = W in {8, 16} (nf_flowpp_img_att_usable != 0).  Forward = att_fwd (B x 4 workgroups: gate, LayerNorm 1, a head's rows of
+ * conv1, the softmax sweeps -> mixed (B, 32, H, W) and cj (B, 4, H*W), cj = max + log sum of a column's scores) + post_fwd (conv2, gate,
+ * LayerNorm 2).  Backward = post_bwd (LayerNorm 2 / conv2 backward -> g3, g_mixed (B, 32, H, W)) + att_bwd (B x 4: softmax backward, the
+ * head's conv1 rows, gt_part (B, 4, 32, H*W) = its part of the tokens' gradient) + pre_bwd (sum of the parts, position embedding,
+ * LayerNorm 1, gate -> g_x, g_a).  Parameter gradients ACCUMULATED; with per_sample != 0 the (32, H, W) ones (LayerNorm affines, position
+ * embedding) are instead WRITTEN per sample into (B, 32, H, W) buffers that nf_slab_sum folds (n_slabs = B).  Every kernel recomputes
+ * what it needs from x and a.                                                                                                       */
+int nf_flowpp_img_att_usable(int64_t B, int H, int W);
+int nf_flowpp_img_att_fwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
+                          const float* conv1_w, const float* conv1_b, float* mixed, float* cj, int64_t B, int H, int W,
+                          nf_stream_t stream);
+int nf_flowpp_img_post_fwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* mixed,
+                           const float* conv2_w, const float* conv2_b, const float* ln2_g, const float* ln2_b, float* out, int64_t B,
+                           int H, int W, nf_stream_t stream);
+int nf_flowpp_img_post_bwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* mixed,
+                           const float* conv2_w, const float* conv2_b, const float* ln2_g, const float* ln2_b, const float* g_out,
+                           int g_out_slabs, float* g3, float* g_mixed, float* g_conv2_w, float* g_conv2_b, float* g_ln2_g,
+                           float* g_ln2_b, int per_sample, int64_t B, int H, int W, nf_stream_t stream);
+int nf_flowpp_img_att_bwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
+                          const float* conv1_w, const float* conv1_b, const float* mixed, const float* cj, const float* g_mixed,
+                          float* gt_part, float* g_conv1_w, float* g_conv1_b, int64_t B, int H, int W, nf_stream_t stream);
+int nf_flowpp_img_pre_bwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* g3,
+                          const float* gt_part, float* g_x, float* g_a, float* g_ln1_g, float* g_ln1_b, float* g_pos, int per_sample,
+                          int64_t B, int H, int W, nf_stream_t stream);
+
 /* ---- on-device synthetic batches (csrc/datagen.hip)  flows/dataset.py:13-34, :120; replaces the per-step H2D copy main.py:79 --
  * kind 0 moons, 1 circles, 2 normals: out (n, 2), per_sample = 2;  3 cifar-like uniform uint8 / 255: out (n, per_sample).
  * Counter-based Philox4x32-10 keyed by (seed, *step, sample): stateless and reproducible; `step` (device int64, NULL = 0) is read

@@ -14,6 +14,8 @@ from . import _native as N
 from .functional import _sinks
 
 FLOWPP_IMG_ON = os.environ.get('NF_FLOWPP_IMG', '1') != '0'
+# the middle cut by attention head (B x 4 workgroups) for batches below this many samples; 0 = never (csrc/flowpp_img_att.hip)
+SPLIT_BELOW = int(os.environ.get('NF_FLOWPP_IMG_SPLIT_BELOW', '160'))
 HID = 32
 
 
@@ -70,15 +72,27 @@ class _FusedFlowppImg(torch.autograd.Function):
         out = torch.empty(B, O, Hh, Ww, dtype=torch.float32, device=dev)
         N.call('nf_flowpp_img_conv', N.ptr(x_in), N.ptr(W0), N.ptr(b0), N.ptr(x), B, I0, HID, Hh, Ww, 0, 0, 1, st)
         N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(Wg), N.ptr(bg), N.ptr(a), B, 2 * HID, HID, Hh, Ww, 1, 0, 1, st)
-        N.call('nf_flowpp_img_mid_fwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
-               N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(x4), B, Hh, Ww, st)
+        # (8 x 8 maps: measured slower cut by head -- 64-thread workgroups, one wave per SIMD -- than one workgroup per sample)
+        split = B < SPLIT_BELOW and Hh == 16 and bool(N.load().nf_flowpp_img_att_usable(B, Hh, Ww))
+        if split:
+            mixed = torch.empty_like(x)
+            cj = torch.empty(B, 4, Hh * Ww, dtype=torch.float32, device=dev)
+            N.call('nf_flowpp_img_att_fwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(mixed),
+                   N.ptr(cj), B, Hh, Ww, st)
+            N.call('nf_flowpp_img_post_fwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(mixed), N.ptr(c2w), N.ptr(c2b), N.ptr(l2g),
+                   N.ptr(l2b), N.ptr(x4), B, Hh, Ww, st)
+        else:
+            mixed = cj = x.new_empty(0)
+            N.call('nf_flowpp_img_mid_fwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
+                   N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(x4), B, Hh, Ww, st)
         N.call('nf_flowpp_img_conv', N.ptr(x4), N.ptr(W5), N.ptr(b5), N.ptr(out), B, HID, O, Hh, Ww, 0, 0, 1, st)
-        ctx.save_for_backward(x_in, x, a, x4, *ts)
+        ctx.save_for_backward(x_in, x, a, x4, mixed, cj, *ts)
+        ctx.split = split
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x_in, x, a, x4, *ts = ctx.saved_tensors
+        x_in, x, a, x4, mixed, cj, *ts = ctx.saved_tensors
         (W0, b0, Wg, bg, l1g, l1b, pos, c1w, c1b, c2w, c2b, l2g, l2b, W5, b5) = [t.detach() for t in ts]
         B, I0, Hh, Ww = x_in.shape
         O = W5.shape[0]
@@ -115,9 +129,26 @@ class _FusedFlowppImg(torch.autograd.Function):
         # gate / LayerNorm / attention / LayerNorm
         g_x = torch.empty_like(x)
         g_a = torch.empty_like(x)
-        N.call('nf_flowpp_img_mid_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
-               N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(g4), N.ptr(g_x), N.ptr(g_a), N.ptr(gl1g), N.ptr(gl1b), N.ptr(gpos),
-               N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), B, Hh, Ww, ks, st)
+        if ctx.split:
+            g3 = torch.empty_like(x)
+            g_mixed = torch.empty_like(x)
+            gt_part = torch.empty(B, 4, HID, Hh * Ww, dtype=torch.float32, device=dev)
+            # the (32, H, W) parameter gradients leave per sample and are folded with the convolutions' slabs (no same-address atomics)
+            ps = torch.empty(5, B, HID, Hh, Ww, dtype=torch.float32, device=dev)
+            n = HID * Hh * Ww
+            for k_, dst_ in enumerate((gl2g, gl2b, gl1g, gl1b, gpos)):
+                jobs.append((ps[k_], dst_, n, n, B, True, 1))
+            N.call('nf_flowpp_img_post_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(mixed), N.ptr(c2w), N.ptr(c2b), N.ptr(l2g),
+                   N.ptr(l2b), N.ptr(g4), ks, N.ptr(g3), N.ptr(g_mixed), N.ptr(gc2w), N.ptr(gc2b), N.ptr(ps[0]), N.ptr(ps[1]), 1, B, Hh,
+                   Ww, st)
+            N.call('nf_flowpp_img_att_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(mixed),
+                   N.ptr(cj), N.ptr(g_mixed), N.ptr(gt_part), N.ptr(gc1w), N.ptr(gc1b), B, Hh, Ww, st)
+            N.call('nf_flowpp_img_pre_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(g3), N.ptr(gt_part), N.ptr(g_x), N.ptr(g_a),
+                   N.ptr(ps[2]), N.ptr(ps[3]), N.ptr(ps[4]), 1, B, Hh, Ww, st)
+        else:
+            N.call('nf_flowpp_img_mid_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
+                   N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(g4), N.ptr(g_x), N.ptr(g_a), N.ptr(gl1g), N.ptr(gl1b), N.ptr(gpos),
+                   N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), B, Hh, Ww, ks, st)
         # gated convolution (its input is concat_elu(x), applied while staging)
         g_cat = torch.empty(B, 2 * HID, Hh, Ww, dtype=torch.float32, device=dev)
         N.call('nf_flowpp_img_conv', N.ptr(g_a), N.ptr(Wg), None, N.ptr(g_cat), B, HID, 2 * HID, Hh, Ww, 0, 1, 1, st)

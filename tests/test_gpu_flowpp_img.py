@@ -98,9 +98,14 @@ def _cond_pair(pkg, in_chs, n_out, HW, seed):
     return net, copy.deepcopy(net)
 
 
+@pytest.mark.parametrize('split', [True, False], ids=['by_head', 'per_sample'])
 @pytest.mark.parametrize('in_chs,n_out,HW,B', [(6, 84, 16, 5), (24, 336, 8, 7), (96, 1344, 4, 18), (4, 56, 4, 3), (6, 84, 8, 64)])
-def test_conditioner_vs_module_stack(pkg, in_chs, n_out, HW, B):
+def test_conditioner_vs_module_stack(pkg, monkeypatch, in_chs, n_out, HW, B, split):
+    """split: the middle of the conditioner cut by attention head (csrc/flowpp_img_att.hip, H = W in {8, 16}) or one workgroup per sample"""
     fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    if split and HW == 4:
+        pytest.skip('4 x 4 maps always run one workgroup per sample')
+    monkeypatch.setattr(fpi, 'SPLIT_BELOW', 10 ** 9 if split else 0)
     net, ref = _cond_pair(pkg, in_chs, n_out, HW, seed=in_chs + HW)
     g = torch.Generator().manual_seed(B)
     x = torch.randn(B, in_chs, HW, HW, generator=g).to(DEV)
