@@ -365,10 +365,19 @@ __global__ void __launch_bounds__(4 * N) k_fi_post(NfFiAtt m) {
     float g3[8];
     {
         float gh[8], s1 = 0.f, s2 = 0.f;
+        // the incoming gradient as the sum of its K-split slabs: slab-outer, so that the eight loads of a slab (and, unrolled, of four
+        // slabs) are in flight together -- element-outer it was up to 8 x 42 dependent round trips to memory the previous kernel just wrote
+        float g4v[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) g4v[d] = m.g_out[base + d * N];
+#pragma unroll 4
+        for (int z = 1; z < m.g_slabs; ++z) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) g4v[d] += m.g_out[z * m.g_slab_stride + base + d * N];
+        }
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            float g4 = m.g_out[base + d * N];
-            for (int z = 1; z < m.g_slabs; ++z) g4 += m.g_out[z * m.g_slab_stride + base + d * N];
+            const float g4 = g4v[d];
             if (m.per_sample) {
                 m.g_ln2g[base + d * N] = g4 * xh2[d];
                 m.g_ln2b[base + d * N] = g4;
