@@ -948,7 +948,7 @@ int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float* ln1_g, co
                           float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W, int g_out_slabs, nf_stream_t stream);
 
 /* The same middle cut BY ATTENTION HEAD (csrc/flowpp_img_att.hip), for batches that leave most of the chip idle with one workgroup per
- * sample: H = W in {8, 16} (nf_flowpp_img_att_usable != 0).  Forward = att_fwd (B x 4 workgroups: gate, LayerNorm 1, a head's rows of
+ * sample: H = W = 16 (nf_flowpp_img_att_usable != 0).  Forward = att_fwd (B x 4 workgroups: gate, LayerNorm 1, a head's rows of
  * conv1, the softmax sweeps -> mixed (B, 32, H, W) and cj (B, 4, H*W), cj = max + log sum of a column's scores) + post_fwd (conv2, gate,
  * LayerNorm 2).  Backward = post_bwd (LayerNorm 2 / conv2 backward -> g3, g_mixed (B, 32, H, W)) + att_bwd (B x 4: softmax backward, the
  * head's conv1 rows, gt_part (B, 4, 32, H*W) = its part of the tokens' gradient) + pre_bwd (sum of the parts, position embedding,

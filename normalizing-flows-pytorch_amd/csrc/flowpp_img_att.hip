@@ -1,7 +1,7 @@
 // The middle of the image Flow++ conditioner (gate -> LayerNorm -> GatedAttn -> LayerNorm, flows/modules.py:519-578) cut BY ATTENTION HEAD,
 // for batches that do not fill the chip with one workgroup per sample (csrc/flowpp_img.hip: k_fi_mid holds B of 256 compute units, and its
 // softmax sweeps -- 4 heads x N x N scores of 8-deep dot products on the vector ALUs -- are 80 % of its time at N = 256):
-//     forward   k_fi_att_fwd  (B x 4 workgroups of N threads)  gate, LayerNorm 1, this head's 24 rows of conv1, the two sweeps -> mixed, c_j
+//     forward   k_fi_att_fwd  (B x 4 workgroups of 4 N threads)  gate, LayerNorm 1, this head's 24 rows of conv1, the two sweeps -> mixed, c_j
 //               k_fi_post_fwd (B workgroups of 4 N threads)    conv2, gate, LayerNorm 2 -> out
 //     backward  k_fi_post_bwd (B)      LayerNorm 2 and conv2 backward -> g3 (gradient of the attention block's residual input), g_mixed
 //               k_fi_att_bwd  (B x 4)  the softmax backward sweeps, this head's rows of conv1's weight gradient, its part of g_tokens
@@ -49,77 +49,105 @@ struct NfFiAtt {
     int per_sample;      // the (32, H, W) parameter gradients (LayerNorm affines, position embedding) are WRITTEN per sample, (B, 32, H, W),
 };                   // for nf_slab_sum to fold: as 1.5 M same-address atomics they were ~20 us of these 30-50 us kernels at B = 64
 
-// ---- per (sample, head), thread = position j: tokens of position j (all 32 channels) and this head's 24 rows of conv1 -------------------
+// ---- per (sample, head): 4 N threads, thread = (position j = tid >> 2, quarter qz = tid & 3) ----------------------------------------------
+// The four quarter-threads of a position are adjacent lanes: they share the position's column of the score matrix -- each walks every
+// fourth key -- and meet through two lane exchanges; in the prologue each owns 8 of the 32 token channels and 6 of the head's 24 conv1
+// rows.  (With one thread per position the workgroup was 4 waves, one per SIMD, and the sweeps ran at the latency of their own
+// LDS -> FMA chains: 45 / 76 us forward / backward at N = 256.)
 // Wh[24][32]: rows 0..7 = "V" rows 8 h + r of conv1, 8..15 = "K" rows 32 + 8 h + r, 16..23 = "Q" rows 64 + 8 h + r;  Bh[24] their biases
-template <int N>
+template <int NT>
 __device__ __forceinline__ void nf_fa_stage_head(float* Wh, float* Bh, const NfFiAtt& m, int h) {
-    for (int e = threadIdx.x; e < 768; e += N) {
+    for (int e = threadIdx.x; e < 768; e += NT) {
         const int r = e >> 5, c = e & 31;
         Wh[e] = m.w1[((r >> 3) * 32 + 8 * h + (r & 7)) * 32 + c];
     }
-    for (int e = threadIdx.x; e < 24; e += N) Bh[e] = m.b1[(e >> 3) * 32 + 8 * h + (e & 7)];
+    for (int e = threadIdx.x; e < 24; e += NT) Bh[e] = m.b1[(e >> 3) * 32 + 8 * h + (e & 7)];
 }
 
+__device__ __forceinline__ float nf_fa_quad_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    return v + __shfl_xor(v, 2, 64);
+}
+
+// tokens of position j into the rotated plane TP (this thread: channels 8 qz .. 8 qz + 7), then rows 6 qz .. 6 qz + 5 of the head's conv1
+// into the [position][8] planes Vs / Ks / Qs.  Ends with a barrier.
 template <int N>
-__device__ __forceinline__ void nf_fa_tokens(float (&t)[32], const NfFiAtt& m, int64_t b, int j, float* scr) {
+__device__ __forceinline__ void nf_fa_prologue(const NfFiAtt& m, int64_t b, int j, int qz, float* TP, float* Vs, float* Ks, float* Qs,
+                                               const float* Wh, const float* Bh, float* scr) {
+    constexpr int NT = 4 * N;
     const float invn = 1.f / (float)(32 * N);
-    float s = 0.f;
+    const int64_t base = (b * 32 + 8 * qz) * N + j;
+    const int pbase = 8 * qz * N + j;
+    float u[8], s = 0.f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        const float av = m.a[(b * 32 + c) * N + j];
-        t[c] = m.x[(b * 32 + c) * N + j] + nf_fa_elu(av) * nf_fa_sigmoid(nf_fa_elu(-av));
-        s += t[c];
+    for (int d = 0; d < 8; ++d) {
+        const float av = m.a[base + d * N];
+        u[d] = m.x[base + d * N] + nf_fa_elu(av) * nf_fa_sigmoid(nf_fa_elu(-av));
+        s += u[d];
     }
-    const float m1 = nf_fa_block_sum_all<N>(s, scr) * invn;
+    const float m1 = nf_fa_block_sum_all<NT>(s, scr) * invn;
     float s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) s2 += (t[c] - m1) * (t[c] - m1);
-    const float r1 = 1.f / sqrtf(nf_fa_block_sum_all<N>(s2, scr) * invn + NF_FA_LNEPS);
+    for (int d = 0; d < 8; ++d) s2 += (u[d] - m1) * (u[d] - m1);
+    const float r1 = 1.f / sqrtf(nf_fa_block_sum_all<NT>(s2, scr) * invn + NF_FA_LNEPS);
 #pragma unroll
-    for (int c = 0; c < 32; ++c) t[c] = (t[c] - m1) * r1 * m.ln1g[c * N + j] + m.ln1b[c * N + j] + m.pos[c * N + j];
-}
-
-__device__ __forceinline__ void nf_fa_proj(float (&o)[24], const float (&t)[32], const float* Wh, const float* Bh) {
+    for (int d = 0; d < 8; ++d)
+        TP[NF_FA_IDX(8 * qz + d, j)] = (u[d] - m1) * r1 * m.ln1g[pbase + d * N] + m.ln1b[pbase + d * N] + m.pos[pbase + d * N];
+    __syncthreads();                                     // (Wh / Bh are staged as well)
+    float t[32];
 #pragma unroll
-    for (int r = 0; r < 24; ++r) {
-        float s = Bh[r];
+    for (int c = 0; c < 32; ++c) t[c] = TP[NF_FA_IDX(c, j)];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+        const int r = 6 * qz + rr;
+        float acc = Bh[r];
         const f32x4* w = reinterpret_cast<const f32x4*>(Wh + r * 32);
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
             const f32x4 wv = w[c4];
-            s += wv[0] * t[4 * c4] + wv[1] * t[4 * c4 + 1] + wv[2] * t[4 * c4 + 2] + wv[3] * t[4 * c4 + 3];
+            acc += wv[0] * t[4 * c4] + wv[1] * t[4 * c4 + 1] + wv[2] * t[4 * c4 + 2] + wv[3] * t[4 * c4 + 3];
         }
-        o[r] = s;
+        float* dst = r < 8 ? Vs : (r < 16 ? Ks : Qs);
+        dst[j * 8 + (r & 7)] = acc;
     }
+    __syncthreads();
 }
 
 template <int N>
-__global__ void __launch_bounds__(N) k_fi_att_fwd(NfFiAtt m) {
-    __shared__ __attribute__((aligned(16))) float Vs[N * 8], Qs[N * 8], Wh[768], Bh[24], scr[8];
-    const int j = threadIdx.x, h = blockIdx.y;
+__global__ void __launch_bounds__(4 * N) k_fi_att_fwd(NfFiAtt m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* TP = smem;               // tokens, rotated plane [32][N]
+    float* Vs = TP + 32 * N;        // [N][8] x 3: V | K | Q
+    float* Ks = Vs + 8 * N;
+    float* Qs = Ks + 8 * N;
+    float* Wh = Qs + 8 * N;         // [24][32]
+    float* Bh = Wh + 768;           // [24]
+    float* scr = Bh + 24;           // [16]
+    const int j = threadIdx.x >> 2, qz = threadIdx.x & 3, h = blockIdx.y;
     const int64_t b = blockIdx.x;
-    nf_fa_stage_head<N>(Wh, Bh, m, h);
-    float p[24];
+    nf_fa_stage_head<4 * N>(Wh, Bh, m, h);
+    nf_fa_prologue<N>(m, b, j, qz, TP, Vs, Ks, Qs, Wh, Bh, scr);
+    const f32x4* V4 = reinterpret_cast<const f32x4*>(Vs);
+    const f32x4* K4 = reinterpret_cast<const f32x4*>(Ks);
+    const f32x4* Q4 = reinterpret_cast<const f32x4*>(Qs);
+    float k[8];
     {
-        float t[32];
-        nf_fa_tokens<N>(t, m, b, j, scr);                // (ends in barriers: Wh / Bh are staged)
-        nf_fa_proj(p, t, Wh, Bh);
+        const f32x4 k0 = K4[2 * j], k1 = K4[2 * j + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            k[e] = k0[e];
+            k[4 + e] = k1[e];
+        }
     }
-    f32x4* V4 = reinterpret_cast<f32x4*>(Vs);
-    f32x4* Q4 = reinterpret_cast<f32x4*>(Qs);
-    V4[2 * j] = (f32x4){p[0], p[1], p[2], p[3]};
-    V4[2 * j + 1] = (f32x4){p[4], p[5], p[6], p[7]};
-    Q4[2 * j] = (f32x4){p[16], p[17], p[18], p[19]};
-    Q4[2 * j + 1] = (f32x4){p[20], p[21], p[22], p[23]};
-    __syncthreads();
-    const float* k = p + 8;
     float mx = -INFINITY, l = 0.f, mix[8];
-#pragma unroll 8
-    for (int i = 0; i < N; ++i) mx = fmaxf(mx, nf_fa_dot8(V4[2 * i], V4[2 * i + 1], k) * NF_FA_SCALE);
+#pragma unroll 4
+    for (int i = qz; i < N; i += 4) mx = fmaxf(mx, nf_fa_dot8(V4[2 * i], V4[2 * i + 1], k) * NF_FA_SCALE);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
 #pragma unroll
     for (int d = 0; d < 8; ++d) mix[d] = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < N; ++i) {
+#pragma unroll 2
+    for (int i = qz; i < N; i += 4) {
         const float pr = __expf(nf_fa_dot8(V4[2 * i], V4[2 * i + 1], k) * NF_FA_SCALE - mx);
         const f32x4 q0 = Q4[2 * i], q1 = Q4[2 * i + 1];
         l += pr;
@@ -129,10 +157,14 @@ __global__ void __launch_bounds__(N) k_fi_att_fwd(NfFiAtt m) {
             mix[4 + e] += pr * q1[e];
         }
     }
+    l = nf_fa_quad_sum(l);
     const float inv = 1.f / l;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) m.mixed[(b * 32 + 8 * h + d) * N + j] = mix[d] * inv;
-    m.cj[(b * 4 + h) * N + j] = mx + __logf(l);
+    for (int d = 0; d < 8; ++d) {
+        const float v = nf_fa_quad_sum(mix[d]) * inv;
+        if ((d >> 1) == qz) m.mixed[(b * 32 + 8 * h + d) * N + j] = v;
+    }
+    if (qz == 0) m.cj[(b * 4 + h) * N + j] = mx + __logf(l);
 }
 
 // one wave: gw[o(row)][c] += sum_p GP[row][p] * T[c][p] for the 24 rows of a head (rows 24..31 of GP are zero), gb[o(row)] += sum_p GP[row][p]
@@ -160,110 +192,108 @@ __device__ __forceinline__ void nf_fa_pair_head(const float* GP, const float* T,
 }
 
 template <int N>
-__global__ void __launch_bounds__(N) k_fi_att_bwd(NfFiAtt m) {
+__global__ void __launch_bounds__(4 * N) k_fi_att_bwd(NfFiAtt m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Vs = smem;               // [N][8] x 4: V | Q | K | g_mixed
-    float* Qs = Vs + 8 * N;
-    float* Ks = Qs + 8 * N;
-    float* Gs = Ks + 8 * N;
+    float* TP = smem;               // tokens, rotated plane [32][N]
+    float* GP = TP + 32 * N;        // gradient of this head's 24 conv1 rows, rotated plane [32][N] (rows 24..31 zero)
+    float* Vs = GP + 32 * N;        // [N][8] x 4: V | K | Q | g_mixed
+    float* Ks = Vs + 8 * N;
+    float* Qs = Ks + 8 * N;
+    float* Gs = Qs + 8 * N;
     float* CJ = Gs + 8 * N;         // [N]
     float* DL = CJ + N;             // [N]
-    float* TP = DL + N;             // tokens, rotated plane [32][N]
-    float* GP = TP + 32 * N;        // gradient of this head's 24 conv1 rows, rotated plane [32][N] (rows 24..31 zero)
-    float* Wh = GP + 32 * N;        // [24][32]
+    float* Wh = DL + N;             // [24][32]
     float* Bh = Wh + 768;           // [24]
-    float* scr = Bh + 24;           // [8]
-    const int j = threadIdx.x, h = blockIdx.y;
+    float* scr = Bh + 24;           // [16]
+    const int j = threadIdx.x >> 2, qz = threadIdx.x & 3, h = blockIdx.y;
     const int64_t b = blockIdx.x;
-    nf_fa_stage_head<N>(Wh, Bh, m, h);
-    float p[24];
+    nf_fa_stage_head<4 * N>(Wh, Bh, m, h);
+    // this thread's two channels of g_mixed / mixed at position j (d = 2 qz, 2 qz + 1): delta_j = mixed_j . g_mixed_j over the quad
     {
-        float t[32];
-        nf_fa_tokens<N>(t, m, b, j, scr);
-        nf_fa_proj(p, t, Wh, Bh);
+        float dl = 0.f;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) TP[NF_FA_IDX(c, j)] = t[c];
+        for (int e = 0; e < 2; ++e) {
+            const int d = 2 * qz + e;
+            const float g = m.g_mixed_in[(b * 32 + 8 * h + d) * N + j];
+            Gs[j * 8 + d] = g;
+            dl += m.mixed_in[(b * 32 + 8 * h + d) * N + j] * g;
+        }
+        dl = nf_fa_quad_sum(dl);
+        if (qz == 0) {
+            DL[j] = dl;
+            CJ[j] = m.cj_in[(b * 4 + h) * N + j];
+        }
     }
-    float gm[8], delta = 0.f;
+    nf_fa_prologue<N>(m, b, j, qz, TP, Vs, Ks, Qs, Wh, Bh, scr);      // (its barriers cover Gs / CJ / DL)
+    const f32x4* V4 = reinterpret_cast<const f32x4*>(Vs);
+    const f32x4* K4 = reinterpret_cast<const f32x4*>(Ks);
+    const f32x4* Q4 = reinterpret_cast<const f32x4*>(Qs);
+    const f32x4* G4 = reinterpret_cast<const f32x4*>(Gs);
+    float v[8], k[8], q[8], gm[8];
+    {
+        const f32x4 a0 = V4[2 * j], a1 = V4[2 * j + 1], b0 = K4[2 * j], b1 = K4[2 * j + 1], c0 = Q4[2 * j], c1 = Q4[2 * j + 1],
+                    d0 = G4[2 * j], d1 = G4[2 * j + 1];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        gm[d] = m.g_mixed_in[(b * 32 + 8 * h + d) * N + j];
-        delta += m.mixed_in[(b * 32 + 8 * h + d) * N + j] * gm[d];
+        for (int e = 0; e < 4; ++e) {
+            v[e] = a0[e]; v[4 + e] = a1[e];
+            k[e] = b0[e]; k[4 + e] = b1[e];
+            q[e] = c0[e]; q[4 + e] = c1[e];
+            gm[e] = d0[e]; gm[4 + e] = d1[e];
+        }
     }
-    const float cj = m.cj_in[(b * 4 + h) * N + j];
-    f32x4* V4 = reinterpret_cast<f32x4*>(Vs);
-    f32x4* Q4 = reinterpret_cast<f32x4*>(Qs);
-    f32x4* K4 = reinterpret_cast<f32x4*>(Ks);
-    f32x4* G4 = reinterpret_cast<f32x4*>(Gs);
-    V4[2 * j] = (f32x4){p[0], p[1], p[2], p[3]};
-    V4[2 * j + 1] = (f32x4){p[4], p[5], p[6], p[7]};
-    K4[2 * j] = (f32x4){p[8], p[9], p[10], p[11]};
-    K4[2 * j + 1] = (f32x4){p[12], p[13], p[14], p[15]};
-    Q4[2 * j] = (f32x4){p[16], p[17], p[18], p[19]};
-    Q4[2 * j + 1] = (f32x4){p[20], p[21], p[22], p[23]};
-    G4[2 * j] = (f32x4){gm[0], gm[1], gm[2], gm[3]};
-    G4[2 * j + 1] = (f32x4){gm[4], gm[5], gm[6], gm[7]};
-    CJ[j] = cj;
-    DL[j] = delta;
-    __syncthreads();
-    // delta_j = sum_i P[i][j] gP[i][j] = mixed_j . g_mixed_j ;  g_s[i][j] = P[i][j] (gP[i][j] - delta_j), P[i][j] = exp(s[i][j] - c_j)
-    const float* v = p;
-    const float* k = p + 8;
-    const float* q = p + 16;
-    float gk[8], gv[8], gq[8];
+    const float cj = CJ[j], delta = DL[j];
+    // g_s[i][j] = P[i][j] (gP[i][j] - delta_j), P[i][j] = exp(s[i][j] - c_j), gP[i][j] = Q_i . g_mixed_j
+    float gp[24];                                        // gradient of the head's conv1 rows at position j: V rows | K rows | Q rows
 #pragma unroll
-    for (int d = 0; d < 8; ++d) gk[d] = gv[d] = gq[d] = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < N; ++i) {                        // this thread as the column j: gradient of K_j
+    for (int r = 0; r < 24; ++r) gp[r] = 0.f;
+#pragma unroll 2
+    for (int i = qz; i < N; i += 4) {                    // the column j: gradient of K_j
         const f32x4 v0 = V4[2 * i], v1 = V4[2 * i + 1];
         const float gs = __expf(nf_fa_dot8(v0, v1, k) * NF_FA_SCALE - cj) * (nf_fa_dot8(Q4[2 * i], Q4[2 * i + 1], gm) - delta);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            gk[e] += gs * v0[e];
-            gk[4 + e] += gs * v1[e];
+            gp[8 + e] += gs * v0[e];
+            gp[12 + e] += gs * v1[e];
         }
     }
-#pragma unroll 4
-    for (int jj = 0; jj < N; ++jj) {                     // this thread as the row i = j: gradients of V_i and Q_i
+#pragma unroll 2
+    for (int jj = qz; jj < N; jj += 4) {                 // the row i = j: gradients of V_i and Q_i
         const f32x4 k0 = K4[2 * jj], k1 = K4[2 * jj + 1];
         const f32x4 g0 = G4[2 * jj], g1 = G4[2 * jj + 1];
         const float pr = __expf(nf_fa_dot8(k0, k1, v) * NF_FA_SCALE - CJ[jj]);
         const float gs = pr * (nf_fa_dot8(g0, g1, q) - DL[jj]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            gv[e] += gs * k0[e];
-            gv[4 + e] += gs * k1[e];
-            gq[e] += pr * g0[e];
-            gq[4 + e] += pr * g1[e];
+            gp[e] += gs * k0[e];
+            gp[4 + e] += gs * k1[e];
+            gp[16 + e] += pr * g0[e];
+            gp[20 + e] += pr * g1[e];
         }
     }
-    // gradient of this head's conv1 rows at position j: V rows, K rows, Q rows
-    float gp[24];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        gp[d] = gv[d] * NF_FA_SCALE;
-        gp[8 + d] = gk[d] * NF_FA_SCALE;
-        gp[16 + d] = gq[d];
-    }
+    for (int r = 0; r < 24; ++r) gp[r] = nf_fa_quad_sum(gp[r]) * (r < 16 ? NF_FA_SCALE : 1.f);
+    // rows 6 qz .. 6 qz + 5 (and two of the zero rows) of the gradient plane; this quarter's 8 channels of the tokens' gradient
 #pragma unroll
-    for (int r = 0; r < 32; ++r) GP[NF_FA_IDX(r, j)] = r < 24 ? gp[r < 24 ? r : 0] : 0.f;
-    // this head's part of the gradient of the tokens: gt[c] = sum_r Wh[r][c] gp[r]
+    for (int r = 0; r < 24; ++r)
+        if (r / 6 == qz) GP[NF_FA_IDX(r, j)] = gp[r];
+    GP[NF_FA_IDX(24 + 2 * qz, j)] = 0.f;
+    GP[NF_FA_IDX(25 + 2 * qz, j)] = 0.f;
     {
-        float gt[32];
+        float gt[8];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) gt[c] = 0.f;
+        for (int d = 0; d < 8; ++d) gt[d] = 0.f;
 #pragma unroll
         for (int r = 0; r < 24; ++r) {
-            const f32x4* w = reinterpret_cast<const f32x4*>(Wh + r * 32);
+            const f32x4* w = reinterpret_cast<const f32x4*>(Wh + r * 32 + 8 * qz);
+            const f32x4 w0 = w[0], w1 = w[1];
 #pragma unroll
-            for (int c4 = 0; c4 < 8; ++c4) {
-                const f32x4 wv = w[c4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gt[4 * c4 + e] += wv[e] * gp[r];
+            for (int e = 0; e < 4; ++e) {
+                gt[e] += w0[e] * gp[r];
+                gt[4 + e] += w1[e] * gp[r];
             }
         }
 #pragma unroll
-        for (int c = 0; c < 32; ++c) m.gt_part[((b * 4 + h) * 32 + c) * N + j] = gt[c];
+        for (int d = 0; d < 8; ++d) m.gt_part[((b * 4 + h) * 32 + 8 * qz + d) * N + j] = gt[d];
     }
     __syncthreads();
     if (threadIdx.x < 64) nf_fa_pair_head<N>(GP, TP, m.g_w1, m.g_b1, h);
@@ -503,7 +533,7 @@ static inline int nf_fa_optin(K kernel, size_t lds) {
 
 static inline int nf_fa_n(int64_t B, int H, int W) {
     if (B < 1 || B > 0x7fffffff || H != W) return 0;
-    return W == 16 ? 256 : (W == 8 ? 64 : 0);
+    return W == 16 ? 256 : 0;        // (8 x 8 maps measured slower cut by head than one workgroup per sample: not offered)
 }
 
 extern "C" int nf_flowpp_img_att_usable(int64_t B, int H, int W) { return nf_fa_n(B, H, W) != 0 && B * 32 * H * W < ((int64_t)1 << 31) ? 1 : 0; }
@@ -522,9 +552,11 @@ extern "C" int nf_flowpp_img_att_fwd(const float* x, const float* a, const float
     if (!nf_flowpp_img_att_usable(B, H, W)) return NF_E_BADARG;
     NfFiAtt m = {};
     m.x = x; m.a = a; m.ln1g = ln1_g; m.ln1b = ln1_b; m.pos = pos; m.w1 = conv1_w; m.b1 = conv1_b; m.mixed = mixed; m.cj = cj;
-    const dim3 grid((unsigned)B, 4);
-    if (nf_fa_n(B, H, W) == 256) hipLaunchKernelGGL(k_fi_att_fwd<256>, grid, dim3(256), 0, (hipStream_t)stream, m);
-    else hipLaunchKernelGGL(k_fi_att_fwd<64>, grid, dim3(64), 0, (hipStream_t)stream, m);
+    constexpr int N = 256;
+    const size_t lds = (size_t)(32 * N + 3 * 8 * N + 768 + 24 + 16) * sizeof(float);
+    int rc;
+    if ((rc = nf_fa_optin(k_fi_att_fwd<N>, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k_fi_att_fwd<N>, dim3((unsigned)B, 4), dim3(4 * N), lds, (hipStream_t)stream, m);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -547,8 +579,7 @@ extern "C" int nf_flowpp_img_post_fwd(const float* x, const float* a, const floa
     NfFiAtt m = {};
     m.x = x; m.a = a; m.ln1g = ln1_g; m.ln1b = ln1_b; m.mixed_in = mixed; m.w2 = conv2_w; m.b2 = conv2_b; m.ln2g = ln2_g; m.ln2b = ln2_b;
     m.out = out;
-    return nf_fa_n(B, H, W) == 256 ? nf_fa_post_launch<256, false>(m, B, (hipStream_t)stream)
-                                   : nf_fa_post_launch<64, false>(m, B, (hipStream_t)stream);
+    return nf_fa_post_launch<256, false>(m, B, (hipStream_t)stream);
 }
 
 extern "C" int nf_flowpp_img_post_bwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* mixed,
@@ -561,16 +592,15 @@ extern "C" int nf_flowpp_img_post_bwd(const float* x, const float* a, const floa
     m.x = x; m.a = a; m.ln1g = ln1_g; m.ln1b = ln1_b; m.mixed_in = mixed; m.w2 = conv2_w; m.b2 = conv2_b; m.ln2g = ln2_g; m.ln2b = ln2_b;
     m.g_out = g_out; m.g_slabs = g_out_slabs; m.g_slab_stride = B * 32 * H * W; m.g3 = g3; m.g_mixed = g_mixed; m.g_w2 = g_conv2_w;
     m.g_b2 = g_conv2_b; m.g_ln2g = g_ln2_g; m.g_ln2b = g_ln2_b; m.per_sample = per_sample;
-    return nf_fa_n(B, H, W) == 256 ? nf_fa_post_launch<256, true>(m, B, (hipStream_t)stream)
-                                   : nf_fa_post_launch<64, true>(m, B, (hipStream_t)stream);
+    return nf_fa_post_launch<256, true>(m, B, (hipStream_t)stream);
 }
 
 template <int N>
 static int nf_fa_att_bwd_launch(const NfFiAtt& m, int64_t B, hipStream_t st) {
-    const size_t lds = (size_t)(4 * 8 * N + 2 * N + 2 * 32 * N + 768 + 24 + 8) * sizeof(float);
+    const size_t lds = (size_t)(4 * 8 * N + 2 * N + 2 * 32 * N + 768 + 24 + 16) * sizeof(float);
     int rc;
     if ((rc = nf_fa_optin(k_fi_att_bwd<N>, lds)) != 0) return rc;
-    hipLaunchKernelGGL(k_fi_att_bwd<N>, dim3((unsigned)B, 4), dim3(N), lds, st, m);
+    hipLaunchKernelGGL(k_fi_att_bwd<N>, dim3((unsigned)B, 4), dim3(4 * N), lds, st, m);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -584,7 +614,7 @@ extern "C" int nf_flowpp_img_att_bwd(const float* x, const float* a, const float
     NfFiAtt m = {};
     m.x = x; m.a = a; m.ln1g = ln1_g; m.ln1b = ln1_b; m.pos = pos; m.w1 = conv1_w; m.b1 = conv1_b; m.mixed_in = mixed; m.cj_in = cj;
     m.g_mixed_in = g_mixed; m.gt_part = gt_part; m.g_w1 = g_conv1_w; m.g_b1 = g_conv1_b;
-    return nf_fa_n(B, H, W) == 256 ? nf_fa_att_bwd_launch<256>(m, B, (hipStream_t)stream) : nf_fa_att_bwd_launch<64>(m, B, (hipStream_t)stream);
+    return nf_fa_att_bwd_launch<256>(m, B, (hipStream_t)stream);
 }
 
 extern "C" int nf_flowpp_img_pre_bwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* g3,
@@ -595,8 +625,7 @@ extern "C" int nf_flowpp_img_pre_bwd(const float* x, const float* a, const float
     NfFiAtt m = {};
     m.x = x; m.a = a; m.ln1g = ln1_g; m.ln1b = ln1_b; m.g3_in = g3; m.gt_in = gt_part; m.g_x = g_x; m.g_a = g_a; m.g_ln1g = g_ln1_g;
     m.g_ln1b = g_ln1_b; m.g_pos = g_pos; m.per_sample = per_sample;
-    if (nf_fa_n(B, H, W) == 256) hipLaunchKernelGGL(k_fi_pre_bwd<256>, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, m);
-    else hipLaunchKernelGGL(k_fi_pre_bwd<64>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, m);
+    hipLaunchKernelGGL(k_fi_pre_bwd<256>, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, m);
     NF_CHECK_LAUNCH();
     return 0;
 }
