@@ -921,7 +921,8 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
  *   ksplit partial-sum slabs (ksplit, B, Co, H, W) whose sum is the result (bias in slab 0); nf_flowpp_img_conv_ksplit proposes
  *   a count that fills the chip (the 32 -> O convolution's data gradient at 4 x 4 has K = 9 * 1344 and four pixel tiles).
  * nf_flowpp_img_conv_wgrad: partial sums of the weight gradient sum_b g_out (x) in  and of the bias gradient sum g_out (slab_b nullable)
- *   in n_slabs slabs, (n_slabs, Co, Ci, 3, 3) and (n_slabs, Co), every element WRITTEN; nf_slab_sum (stride Co*Ci*9 / Co, taps 1) folds
+ *   in n_slabs slabs, TAP-MAJOR (n_slabs, 9, Co, Ci) and (n_slabs, Co), every element WRITTEN; nf_slab_sum (stride Co*Ci*9, taps 9 /
+ *   stride Co, taps 1) folds
  *   them into the destinations; nf_flowpp_img_wgrad_slabs proposes the count (<= NF_FLOWPP_IMG_MAX_SLABS); in / in_mode as above.
  * nf_flowpp_img_celu_bwd: g_x += elu'(x) * g_cat[:, :C] - elu'(-x) * g_cat[:, C:]  (x (B, C, H, W), g_cat (B, 2 C, H, W)).
  * nf_flowpp_img_mid_fwd: x = conv0 output, a = the gated convolution's output (both (B, 32, H, W)) ->

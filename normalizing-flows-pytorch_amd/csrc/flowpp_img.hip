@@ -186,7 +186,9 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restri
     }
 }
 
-// slab_w[blockIdx.x][o][c][t] = sum over this workgroup's tiles of  g[b][o][p] * act[b][c][p + off(t)],  slab_b[blockIdx.x][o] = sum g:
+// slab_w[blockIdx.x][t][o][c] = sum over this workgroup's tiles of  g[b][o][p] * act[b][c][p + off(t)],  slab_b[blockIdx.x][o] = sum g
+// (tap-major: a reduction round stores whole 128-byte runs; in the weight's own (o, c, t) order every round scattered 4-byte stores
+// 36 bytes apart over lines that are not in cache -- +10 us per launch inside a real step):
 // workgroup (x, y, z) walks the pixel tiles x, x + gridDim.x, ... for its (32 output, 32 input) channel block with the nine tap tiles
 // in registers; the eight waves (32 pixels each) meet in LDS once, at the end.  nf_slab_sum folds the slabs (no atomics).
 template <int LGW, int INMODE>
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) s += RED[w8 * 1024 + e];
             const int o = e >> 5, c = e & 31;
-            if (o0 + o < Co && c0 + c < Ci) sw[((int64_t)(o0 + o) * Ci + c0 + c) * 9 + t] = s;
+            if (o0 + o < Co && c0 + c < Ci) sw[((int64_t)t * Co + o0 + o) * Ci + c0 + c] = s;      // tap-major: 128-byte runs per (tap, o)
         }
     }
 }

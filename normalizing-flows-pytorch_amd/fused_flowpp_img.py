@@ -140,7 +140,7 @@ class _FusedFlowppImg(torch.autograd.Function):
                     N.call('nf_flowpp_img_conv_wgrad', N.ptr(inp), N.ptr(g), N.ptr(sw), sb.data_ptr(), ns, B, Ci, Co, Hh, Ww, mode, N.stream())
             else:
                 N.call('nf_flowpp_img_conv_wgrad', N.ptr(inp), N.ptr(g), N.ptr(sw), sb.data_ptr(), ns, B, Ci, Co, Hh, Ww, mode, st)
-            jobs.append((sw, gw, Co * Ci * 9, Co * Ci * 9, ns, True, 1))
+            jobs.append((sw, gw, Co * Ci * 9, Co * Ci * 9, ns, True, 9))              # the slabs are tap-major (9, Co, Ci)
             jobs.append((sb, gb, Co, Co, ns, True, 1))
 
         # last convolution: K = 9 O is cut into slabs that the next kernel sums on load

@@ -50,10 +50,10 @@ def test_conv_forward_data_and_weight_gradient_vs_torch(pkg, Ci, Co, HW, B):
         N.call('nf_flowpp_img_conv', N.ptr(gy), N.ptr(w), None, N.ptr(gx), B, Co, Ci, HW, HW, 0, 1, ks, st)
         G.assert_close(gx.sum(0), gx_ref, _scaled(gx_ref), what='conv data gradient, %d slabs' % ks)
     for ns in sorted({1, int(lib.nf_flowpp_img_wgrad_slabs(B, Ci, Co, HW, HW))}):
-        sw = torch.full((ns, ) + tuple(w.shape), 7.0, device=DEV)           # every element written
+        sw = torch.full((ns, 9, Co, Ci), 7.0, device=DEV)                   # tap-major slabs, every element written
         sb = torch.full((ns, Co), 7.0, device=DEV)
         N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(gy), N.ptr(sw), N.ptr(sb), ns, B, Ci, Co, HW, HW, 0, st)
-        G.assert_close(sw.sum(0), gw_ref, _scaled(gw_ref), what='conv weight gradient, %d slabs' % ns)
+        G.assert_close(sw.sum(0).permute(1, 2, 0).reshape(w.shape), gw_ref, _scaled(gw_ref), what='conv weight gradient, %d slabs' % ns)
         G.assert_close(sb.sum(0), gb_ref, _scaled(gb_ref), what='conv bias gradient, %d slabs' % ns)
 
 
@@ -78,9 +78,9 @@ def test_gated_convolution_applies_concat_elu_while_staging(pkg, HW, B):
     N.call('nf_flowpp_img_celu_bwd', N.ptr(x), N.ptr(gcat), N.ptr(gx), B, 32, HW, HW, st)
     G.assert_close(gx, gx_ref, _scaled(gx_ref), what='gated conv input gradient')
     ns = int(N.load().nf_flowpp_img_wgrad_slabs(B, 64, 32, HW, HW))
-    sw, sb = torch.empty((ns, ) + tuple(w.shape), device=DEV), torch.empty(ns, 32, device=DEV)
+    sw, sb = torch.empty(ns, 9, 32, 64, device=DEV), torch.empty(ns, 32, device=DEV)
     N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(ga), N.ptr(sw), N.ptr(sb), ns, B, 64, 32, HW, HW, 1, st)
-    G.assert_close(sw.sum(0), gw_ref, _scaled(gw_ref), what='gated conv weight gradient')
+    G.assert_close(sw.sum(0).permute(1, 2, 0).reshape(w.shape), gw_ref, _scaled(gw_ref), what='gated conv weight gradient')
     G.assert_close(sb.sum(0), gb_ref, _scaled(gb_ref), what='gated conv bias gradient')
 
 

@@ -11,9 +11,17 @@ dev = torch.device('cuda:0')
 st = N.stream()
 
 
+COLD = os.environ.get('NF_PROBE_COLD', '0') != '0'      # evict L2 / MALL between launches (a 512 MB fill): operands come from HBM, as
+_flush = torch.empty(128 * 1024 * 1024, device=dev) if COLD else None     # in a real step, where another kernel wrote them
+
+
 def timed(what, fn, reps=20):
-    """device time per launch inside a hipGraph of 50 back-to-back launches (no host launch cost in the number)"""
-    us = bench.graph_time_us(fn, dev, per_graph=50, replays=4)
+    """device time per launch inside a hipGraph of back-to-back launches (no host launch cost in the number)"""
+    if COLD:
+        both = bench.graph_time_us(lambda: (_flush.fill_(1.0), fn()), dev, per_graph=10, replays=3)
+        us = both - bench.graph_time_us(lambda: _flush.fill_(1.0), dev, per_graph=10, replays=3)
+    else:
+        us = bench.graph_time_us(fn, dev, per_graph=50, replays=4)
     print('    %-34s %8.1f us' % (what, us))
     return us
 
