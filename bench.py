@@ -245,17 +245,28 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
         note = ('fp32-input MFMA (exact fp32, 1/16 of the bf16 rate); the rest is transcendental VALU work and the LDS transposes of '
                 'the weight-gradient operands (DESIGN.md section 3.12)')
     elif cfg['kind'] == 'flowpp' and len(dims) == 3:
-        # image Flow++ (csrc/flowpp_img.hip): the longest launch is the backward of gate + LayerNorm + 4-head attention + LayerNorm at the
-        # 16 x 16 level, one workgroup per sample, VALU work (the fp32 vector peak equals the fp32 matrix peak on gfx950)
+        # image Flow++ (csrc/flowpp_img.hip, flowpp_img_att.hip): the longest launch is the softmax backward of the 16 x 16 level -- per
+        # (sample, head) workgroup the two sweeps over the 256 x 256 scores, VALU work (the fp32 vector peak equals the fp32 matrix peak)
         Np = (dims[1] // 2) * (dims[2] // 2)
-        entry, match, per_call = 'nf_flowpp_img_mid_bwd', (lambda a: int(a[-4]) * int(a[-3]) == Np), 1
-        mac = 3 * Np * (96 * 32 + 64 * 32) + 4 * Np * Np * (16 + 16 + 32)      # recompute + data + weight gradients; attention sweeps
+        fpi = importlib.import_module(PKG + '.fused_flowpp_img')
+        if B < fpi.SPLIT_BELOW:
+            entry, match, per_call = 'nf_flowpp_img_att_bwd', (lambda a: int(a[-3]) * int(a[-2]) == Np), 1
+            mac = 4 * Np * Np * (24 + 32) + 4 * Np * (2 * 24 * 32 + 24 * 32)          # two sweeps; conv1 rows forward, data and weight gradient
+            nbytes = 4 * B * Np * (32 * 2 + 32 * 2 + 4 + 4 * 32)
+            kname = ('k_fi_att_bwd<256> (softmax backward of one attention head over %d positions + the head\'s conv1 rows, one '
+                     'workgroup per (sample, head))' % Np)
+            pmc = ('k_fi_att_bwd', '')
+            wgs = 4 * B
+        else:
+            entry, match, per_call = 'nf_flowpp_img_mid_bwd', (lambda a: int(a[-4]) * int(a[-3]) == Np), 1
+            mac = 3 * Np * (96 * 32 + 64 * 32) + 4 * Np * Np * (16 + 16 + 32)
+            nbytes = 4 * B * 32 * Np * 5
+            kname = 'k_fi_mid<256, true> (gate + LayerNorm + attention over %d positions + LayerNorm, backward, one workgroup per sample)' % Np
+            pmc = ('k_fi_mid', '')
+            wgs = B
         flop = 2 * mac * B
-        nbytes = 4 * B * 32 * Np * 5
-        kname = 'k_fi_mid<256, true> (gate + LayerNorm + attention over %d positions + LayerNorm, backward, one workgroup per sample)' % Np
-        pmc = ('k_fi_mid', '')
-        note = ('vector-ALU kernel (softmax sweeps with one exp per score, 8-wide dot products from LDS): %d of 256 compute units hold '
-                'the launch at this batch' % min(B, 256))
+        note = ('vector-ALU kernel (softmax sweeps with one exp per score, 8-wide dot products from LDS): %d workgroups on 256 compute '
+                'units at this batch' % wgs)
     else:
         return None
     with N.timed_launches(entry, match) as t:
