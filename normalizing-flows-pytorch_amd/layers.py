@@ -670,6 +670,9 @@ class MADE(nn.Module):
         self.num_hidden = num_hidden
         self.base_filters = base_filters
         self.masks = None
+        # the draw changes from call to call for D > 2 (constant for D == 2): a captured graph would freeze it -- FlowTrainer then
+        # keeps such a model on eager launches (train.py)
+        self.masks_redrawn_per_call = in_out_features > 2
         weights, biases, bnorms = [], [], []
         widths = [in_out_features] + [base_filters] * num_hidden
         for i, o in zip(widths[:-1], widths[1:]):

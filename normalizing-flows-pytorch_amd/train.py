@@ -107,6 +107,10 @@ class FlowTrainer:
         self.sync_stats = bool(sync_stats)
         if self.sync_stats:
             graph = False
+        if graph and any(getattr(m_, 'masks_redrawn_per_call', False) for m_ in net.modules()):
+            # MADE re-draws its masks from the host's np.random on every call (flows/maf.py:50,72); for D > 2 the draw varies, and a
+            # replayed graph would repeat the masks of the captured step: such models train on eager launches
+            graph = False
         self.sampler = sampler      # data.DeviceSampler: train_on_batch() without a batch draws one on the device, inside the graph
         on_gpu = next(net.parameters()).is_cuda
         fused_adam = bool(fused_adam) and on_gpu

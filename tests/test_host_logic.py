@@ -153,3 +153,15 @@ def test_zero_arena_retires_only_buffers_a_graph_was_captured_against(pkg):
     second = arena.buf
     arena.begin(dev)
     assert arena.buf is not second and arena.retired == [second]
+
+
+def test_trainer_keeps_models_with_host_drawn_masks_off_the_graph(pkg):
+    """MADE draws its masks from np.random on every call (flows/maf.py:50,72): constant for D = 2, varying for D > 2 -- a replayed
+    graph would freeze the draw of the captured step, so FlowTrainer(graph=True) falls back to eager launches for such a model"""
+    import importlib
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    for D, expect in ((2, True), (3, False)):
+        net = pkg.MAF((D, ), '2d', NS(layers=2, mixtures=None))
+        tr = train.FlowTrainer(net, graph=True, graph_factory=lambda: None)
+        assert tr.graph is expect, (D, tr.graph)
