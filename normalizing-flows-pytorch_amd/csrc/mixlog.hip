@@ -18,7 +18,7 @@
 #include "nf_mixlog_oct.h"
 
 #define NF_MX_ROWS_MAX 16
-#define NF_MX_SLAB 1024
+#define NF_MX_SLAB 256      // elements per workgroup of the image forward: 256 = one per thread (1024: four sequential 26-load round trips per thread, 20 us against 12 at Flowpp CIFAR shape B = 64)
 #define NF_MX_GRID 1024
 
 template <int KT>
