@@ -189,6 +189,11 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
             # a kink event in flow step s' perturbs the gradients of s' AND of every step before it (the backward pass carries it on):
             # the envelope of step st is the ensemble's worst over the steps st .. last, not over st alone
             env = max(p_.get(s2, 0.0) for p_ in pe for s2 in pg if s2 >= st)
+            if len(pe) == 1:
+                # no ensemble (C3 / C4: one 45 s float64 pass): the single fp32 oracle run shows how LARGE an event on an ill-conditioned
+                # tensor gets (the scalar s_log_scale gradients of the image couplings: the oracle's own fp32 error reaches 2.2 x the
+                # tensor's value), not at which step the next one falls -- its worst step stands for every step
+                env = max(pe[0].values())
             # (the number of near-kink units of a pass grows with the batch, the footprint of one shrinks with it: at least FLIPS events,
             #  one per 1024 rows beyond that)
             bar = 2.0 * TOL + SLACK * env + min(1.0, max(FLIPS, B // 1024) / float(B) * AMP ** min(last - st, 64))
