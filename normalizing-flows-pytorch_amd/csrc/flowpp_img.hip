@@ -186,6 +186,132 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restri
     }
 }
 
+// The same convolution on 64-PIXEL tiles when 256-pixel tiles leave the chip nearly empty (B = 64: 64 / 16 / 4 tiles per 32 output
+// channels): a workgroup owns four rows of a 16 x 16 sample (the halo rows are read from the same tensor) or 1 / 4 whole samples, its eight waves are 2 pixel blocks x 4 K quarters (wave (pb, kq) multiplies
+// the 8-channel group kq of every chunk), the quarters meet in LDS once, at the end.  Four times the workgroups, a quarter of the
+// matrix instructions per wave.
+template <int LGW>
+struct NfFiGeo64 {
+    // N <= 64: S = 64 / N whole samples per tile.  16 x 16 maps: a tile is ROWS = 4 rows of ONE sample (TPS = 4 tiles per sample); the
+    // rows above and below come from the same global tensor (zero outside the image)
+    static constexpr int W = 1 << LGW, N = W * W, PW = W + 2;
+    static constexpr int S = N <= 64 ? 64 / N : 1, ROWS = N <= 64 ? W : 64 / W, LGR = N <= 64 ? LGW : 2, TPS = N <= 64 ? 1 : N / 64;
+    static constexpr int FS = (ROWS + 2) * PW, CS = (S * FS) | 1;
+    static_assert(LGW >= 2 && LGW <= 4, "4 x 4, 8 x 8 or 16 x 16 maps");
+};
+
+template <int LGW, int INMODE, bool TR>
+__global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv64(const float* __restrict__ in, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int64_t B, int Ci,
+                                                             int Co) {
+    using G = NfFiGeo64<LGW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* F = smem;                       // [32][CS]
+    float* Wl = smem + 32 * G::CS;         // [32][NF_FI_WS]
+    float* RED = Wl + 32 * NF_FI_WS;       // [3][2][16][64]: the K quarters 1..3 of both pixel blocks
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, hs = lane >> 5;
+    const int pb = wid & 1, kq = wid >> 1;
+    const int64_t b0 = (int64_t)(blockIdx.x / G::TPS) * G::S;
+    const int rb = blockIdx.x % G::TPS;                                    // row block of the sample (16 x 16 maps)
+    const int o0 = 32 * blockIdx.y;
+    const int p = 32 * pb + r32;                                           // this lane's pixel of the tile (matrix phase)
+    const int fpos = (p >> (LGW + G::LGR)) * G::FS + (((p >> LGW) & (G::ROWS - 1)) + 1) * G::PW + (p & (G::W - 1)) + 1;
+    // staging: thread t owns pixel t & 63 and the channels (t >> 6) + 8 u, u < 4
+    const int sp = threadIdx.x & 63, sch = threadIdx.x >> 6;
+    const int sbs = (int)b0 + (sp >> (LGW + G::LGR)), sq = G::TPS == 1 ? (sp & (G::N - 1)) : 64 * rb + sp, Ch = Ci >> 1;
+    const int sfpos = (sp >> (LGW + G::LGR)) * G::FS + (((sp >> LGW) & (G::ROWS - 1)) + 1) * G::PW + (sp & (G::W - 1)) + 1;
+    // 16 x 16: the two halo rows -- thread t owns halo pixel t & 31 (x = t & 15 of the row above (t & 16 == 0) or below) and the channels
+    // (t >> 5) + 16 u, u < 2
+    const int hx = threadIdx.x & 15, hbot = (threadIdx.x >> 4) & 1, hch = threadIdx.x >> 5;
+    const int hy = hbot ? G::ROWS * rb + G::ROWS : G::ROWS * rb - 1;
+    const bool hrow = G::TPS > 1 && hy >= 0 && hy < G::W;
+    const int hfpos = (hbot ? G::ROWS + 1 : 0) * G::PW + hx + 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunks = (Ci + 31) >> 5, cps = (nchunks + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int ch0 = (int)blockIdx.z * cps, ch1 = min(nchunks, ch0 + cps);
+    float tf[4], th[2], tw[18];
+    auto frame_load = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cc = c0 + sch + 8 * u;
+            const bool ok = sbs < B && cc < Ci;
+            const unsigned idx = INMODE == 0 ? (unsigned)((sbs * Ci + cc) * G::N + sq) : (unsigned)((sbs * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + sq);
+            const float v = in[ok ? idx : 0u];
+            tf[u] = ok ? v : 0.f;
+        }
+        if (G::TPS > 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cc = c0 + hch + 16 * u;
+                const bool ok = hrow && cc < Ci;
+                const int hq = hy * G::W + hx;
+                const unsigned idx = INMODE == 0 ? (unsigned)(((int)b0 * Ci + cc) * G::N + hq) : (unsigned)(((int)b0 * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + hq);
+                const float v = in[ok ? idx : 0u];
+                th[u] = ok ? v : 0.f;
+            }
+        }
+    };
+    if (ch0 < ch1) {
+        frame_load(32 * ch0);
+        nf_fi_w_load<TR>(tw, w, Ci, Co, o0, 32 * ch0);
+    }
+    for (int e = threadIdx.x; e < 32 * G::CS; e += NF_FI_THREADS) F[e] = 0.f;
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int c0 = 32 * ch;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = tf[u];
+            if (INMODE == 1) v = nf_fi_elu_fast(c0 + sch + 8 * u < Ch ? v : -v);
+            F[(sch + 8 * u) * G::CS + sfpos] = v;
+        }
+        if (G::TPS > 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v = th[u];
+                if (INMODE == 1) v = nf_fi_elu_fast(c0 + hch + 16 * u < Ch ? v : -v);
+                F[(hch + 16 * u) * G::CS + hfpos] = v;
+            }
+        }
+        nf_fi_w_store<TR>(Wl, tw);
+        __syncthreads();
+        if (ch + 1 < ch1) {
+            frame_load(c0 + 32);
+            nf_fi_w_load<TR>(tw, w, Ci, Co, o0, c0 + 32);
+        }
+        if (8 * kq < min(32, Ci - c0)) {                                   // this wave's 8-channel group of the chunk (wave-uniform)
+            const float* wp = Wl + r32 * NF_FI_WS + 72 * kq + 36 * hs;
+            const float* fp = F + (8 * kq + 4 * hs) * G::CS + fpos;
+#pragma unroll
+            for (int s2 = 0; s2 < 36; ++s2) {
+                const int t = s2 % 9, dy = t / 3 - 1, dx = t % 3 - 1;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[s2], fp[(s2 / 9) * G::CS + dy * G::PW + dx], acc, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (kq > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) RED[(((kq - 1) * 2 + pb) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kq == 0) {
+        const int64_t b = b0 + (p >> (LGW + G::LGR));
+        const int q = G::TPS == 1 ? (p & (G::N - 1)) : 64 * rb + p;
+        float* slab = out + (int64_t)blockIdx.z * B * Co * G::N;
+        const bool add_bias = bias != nullptr && blockIdx.z == 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + RED[((0 * 2 + pb) * 16 + r) * 64 + lane] + RED[((1 * 2 + pb) * 16 + r) * 64 + lane] +
+                            RED[((2 * 2 + pb) * 16 + r) * 64 + lane];
+            const int oc = o0 + nf_fi_cd_row(r, hs);
+            if (b < B && oc < Co) slab[(b * Co + oc) * G::N + q] = v + (add_bias ? bias[oc] : 0.f);
+        }
+    }
+}
+
 // slab_w[blockIdx.x][t][o][c] = sum over this workgroup's tiles of  g[b][o][p] * act[b][c][p + off(t)],  slab_b[blockIdx.x][o] = sum g
 // (tap-major: a reduction round stores whole 128-byte runs; in the weight's own (o, c, t) order every round scattered 4-byte stores
 // 36 bytes apart over lines that are not in cache -- +10 us per launch inside a real step):
@@ -664,9 +790,31 @@ template <int LGW>
 static int nf_fi_conv_launch(const float* in, const float* w, const float* bias, float* out, int64_t B, int Ci, int Co, int in_mode,
                              int transposed, int ksplit, hipStream_t st) {
     using G = NfFiGeo<LGW>;
+    int rc;
+    {
+        // 64-pixel tiles while 256-pixel ones hold at most 128 workgroups (measured at B = 64: 129 best, wider launches gain nothing)
+        static int t64 = -1;                            // NF_FLOWPP_IMG_TILE64 = the workgroup count below which the small tiles run
+        if (t64 < 0) { const char* e = getenv("NF_FLOWPP_IMG_TILE64"); t64 = e == nullptr ? 129 : atoi(e); }
+        const int64_t wgs = ((B + G::S - 1) / G::S) * ((Co + 31) / 32) * ksplit;
+        if (wgs < t64) {
+            using G6 = NfFiGeo64<LGW>;
+            const size_t lds6 = (size_t)(32 * G6::CS + 32 * NF_FI_WS + 3 * 2 * 16 * 64) * sizeof(float);
+            const dim3 grid6((unsigned)(((B + G6::S - 1) / G6::S) * G6::TPS), (unsigned)((Co + 31) / 32), (unsigned)ksplit);
+#define NF_FI_GO6(M_, T_)                                                                                             \
+    do {                                                                                                              \
+        if ((rc = nf_fi_optin(k_fi_conv64<LGW, M_, T_>, lds6)) != 0) return rc;                                       \
+        hipLaunchKernelGGL((k_fi_conv64<LGW, M_, T_>), grid6, dim3(NF_FI_THREADS), lds6, st, in, w, bias, out, B, Ci, Co); \
+    } while (0)
+            if (transposed) NF_FI_GO6(0, true);
+            else if (in_mode == 1) NF_FI_GO6(1, false);
+            else NF_FI_GO6(0, false);
+#undef NF_FI_GO6
+            NF_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const size_t lds = (size_t)(32 * G::CS + 32 * NF_FI_WS) * sizeof(float);
     const dim3 grid((unsigned)((B + G::S - 1) / G::S), (unsigned)((Co + 31) / 32), (unsigned)ksplit);
-    int rc;
 #define NF_FI_GO(M_, T_)                                                                                            \
     do {                                                                                                            \
         if ((rc = nf_fi_optin(k_fi_conv<LGW, M_, T_>, lds)) != 0) return rc;                                        \

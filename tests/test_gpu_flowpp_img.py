@@ -26,7 +26,9 @@ def _native(pkg):
 # (in channels, out channels, H = W): the conditioner shapes of Flowpp on CIFAR (flows/flowpp.py:22-57: in 6 / 6 / 24 / 24 / 96 with
 # 14 x in outputs) and on the 16 x 16 golden model, plus ragged channel counts
 CONV_CASES = [(6, 32, 16, 3), (64, 32, 16, 2), (32, 84, 16, 5), (24, 32, 8, 9), (32, 336, 8, 6), (96, 32, 4, 33), (32, 1344, 4, 17),
-              (5, 7, 8, 1), (40, 70, 4, 16)]
+              (5, 7, 8, 1), (40, 70, 4, 16),
+              # launches of >= 128 workgroups keep the 256-pixel tiles (below that the 64-pixel form runs): both forms at every map size
+              (32, 84, 16, 64), (6, 32, 16, 130), (32, 336, 8, 64), (32, 1344, 4, 64), (24, 32, 8, 520)]
 
 
 @pytest.mark.parametrize('Ci,Co,HW,B', CONV_CASES)
