@@ -9,8 +9,9 @@
 //                    frame (32 channels with a zero halo) and the 32 x 288 weight block sit in LDS, each of the 8 waves finishes
 //                    a 32-pixel block.  The same kernel is the data gradient (weight block read transposed and tap-flipped)
 //                    and applies concat-ELU to its input while staging (the GatedConv2d input never exists in HBM).
-//   k_fi_conv_wgrad  weight + bias gradient of the same convolutions: D[o][c] per tap, K = the tile's 256 pixels split over the
-//                    8 waves, the waves' partial tiles are summed through LDS and leave as one atomic per element.
+//   k_fi_conv64      the same on 64-pixel tiles (2 pixel blocks x 4 K quarters per workgroup) for launches of at most 128 workgroups.
+//   k_fi_conv_wgrad2 weight + bias gradient of the same convolutions: D[o][c] per tap, waves = 2 pixel halves x 4 tap groups, one LDS
+//                    meeting of the halves; partial-sum slabs per workgroup, folded by nf_slab_sum (no atomics).
 //   k_fi_mid         everything between the convolutions for one sample per workgroup, thread (head, position): gate, LayerNorm,
 //                    1x1 projections, softmax attention (two sweeps over the keys held in LDS), gate, LayerNorm; the backward
 //                    variant recomputes that from the two 4-byte inputs and walks it in reverse (no activation is saved).
@@ -313,79 +314,103 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv64(const float* __rest
 }
 
 // slab_w[blockIdx.x][t][o][c] = sum over this workgroup's tiles of  g[b][o][p] * act[b][c][p + off(t)],  slab_b[blockIdx.x][o] = sum g
-// (tap-major: a reduction round stores whole 128-byte runs; in the weight's own (o, c, t) order every round scattered 4-byte stores
-// 36 bytes apart over lines that are not in cache -- +10 us per launch inside a real step):
-// workgroup (x, y, z) walks the pixel tiles x, x + gridDim.x, ... for its (32 output, 32 input) channel block with the nine tap tiles
-// in registers; the eight waves (32 pixels each) meet in LDS once, at the end.  nf_slab_sum folds the slabs (no atomics).
+// (tap-major slabs: whole 128-byte runs per (tap, o); nf_slab_sum folds them in its taps mode -- no atomics).  Workgroup (x, y, z) walks
+// the pixel tiles x, x + gridDim.x, ... for its (32 output, 32 input) channel block.  The first form of this kernel gave every wave 32
+// pixels and all nine tap tiles (144 accumulator registers) and met in nine LDS rounds over eight waves: 22 - 25 us per launch (33 with
+// cold caches) at every map size.
+// The waves are cut by TAP: wave (half ph, tap group tg) walks half of the tile's pixels for the taps
+// {0,1,2} / {3,4} / {5,6} / {7,8} -- three or two accumulator tiles per wave instead of nine, and ONE meeting of the two halves in LDS
+// instead of nine rounds over eight waves.  Tiles are 256 pixels on 16 x 16 maps and 64 pixels (1 / 4 whole samples) below, where
+// 256-pixel tiles leave 4 - 16 workgroups per channel block at B = 64.
+template <int LGW>
+struct NfFiGeoW {
+    static constexpr int W = 1 << LGW, N = W * W, PW = W + 2, TPX = N <= 64 ? 64 : 256, S = TPX / N, FS = PW * PW, CS = (S * FS) | 1,
+                         GS = TPX + 1, CPT = NF_FI_THREADS / TPX, NU = 32 / CPT;     // staging: thread = (pixel t % TPX, channels t / TPX + CPT u)
+};
+
 template <int LGW, int INMODE>
-__global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad(const float* __restrict__ in, const float* __restrict__ g,
-                                                                 float* __restrict__ slab_w, float* __restrict__ slab_b, int64_t B, int Ci,
-                                                                 int Co) {
-    using G = NfFiGeo<LGW>;
+__global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* __restrict__ in, const float* __restrict__ g,
+                                                                  float* __restrict__ slab_w, float* __restrict__ slab_b, int64_t B, int Ci,
+                                                                  int Co) {
+    using G = NfFiGeoW<LGW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* F = smem;                       // [32][CS]; the per-wave partial tiles [8][1024] alias it afterwards
-    float* Gt = smem + 32 * G::CS;         // [32][NF_FI_GS]
-    static_assert(32 * G::CS >= 8 * 1024, "partial tiles alias the frame");
+    float* F = smem;                       // [32][CS]
+    float* Gt = F + 32 * G::CS;            // [32][GS]
+    float* RED = Gt + 32 * G::GS;          // [4 tap groups][3][1024]: the second half's tiles
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, hs = lane >> 5;
+    const int ph = wid & 1, tg = wid >> 1;
+    const int t0 = tg == 0 ? 0 : 2 * tg + 1, nt = tg == 0 ? 3 : 2;         // taps t0 .. t0 + nt - 1
     const int o0 = 32 * blockIdx.y, c0 = 32 * blockIdx.z;
     const int64_t tiles = (B + G::S - 1) / G::S;
-    f32x16 acc[9];
+    const int Ch = Ci >> 1;
+    // staging: this thread's pixel of the tile and its frame position
+    const int sp = threadIdx.x % G::TPX, sch = threadIdx.x / G::TPX;
+    const int ss = sp >> (2 * LGW), sq = sp & (G::N - 1);
+    const int sfpos = ss * G::FS + (((sp >> LGW) & (G::W - 1)) + 1) * G::PW + (sp & (G::W - 1)) + 1;
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
-    nf_fi_zero_frame<LGW>(F);
+    for (int e = threadIdx.x; e < 32 * G::CS; e += NF_FI_THREADS) F[e] = 0.f;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t b0 = tile * G::S;
-        float tf[16], tg[16];
-        nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, c0);
-        {
-            const int p = threadIdx.x & 255, ch = threadIdx.x >> 8;
-            const int bs = (int)b0 + (p >> (2 * LGW)), q = p & (G::N - 1);
+        const int bs = (int)(tile * G::S) + ss;
+        float tf[G::NU], tgv[G::NU];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int o = o0 + ch + 2 * u;
-                const bool ok = bs < B && o < Co;
-                const float v = g[ok ? (unsigned)((bs * Co + o) * G::N + q) : 0u];
-                tg[u] = ok ? v : 0.f;
-            }
+        for (int u = 0; u < G::NU; ++u) {
+            const int cc = c0 + sch + G::CPT * u, o = o0 + sch + G::CPT * u;
+            const bool okf = bs < B && cc < Ci, okg = bs < B && o < Co;
+            const unsigned fi = INMODE == 0 ? (unsigned)((bs * Ci + cc) * G::N + sq) : (unsigned)((bs * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + sq);
+            const float vf = in[okf ? fi : 0u], vg = g[okg ? (unsigned)((bs * Co + o) * G::N + sq) : 0u];
+            tf[u] = okf ? vf : 0.f;
+            tgv[u] = okg ? vg : 0.f;
         }
         __syncthreads();                                     // the previous tile's readers are done (and the halo is zero)
-        nf_fi_frame_store<LGW, INMODE>(F, tf, Ci, c0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) Gt[((threadIdx.x >> 8) + 2 * u) * NF_FI_GS + (threadIdx.x & 255)] = tg[u];
+        for (int u = 0; u < G::NU; ++u) {
+            float v = tf[u];
+            if (INMODE == 1) v = nf_fi_elu_fast(c0 + sch + G::CPT * u < Ch ? v : -v);
+            F[(sch + G::CPT * u) * G::CS + sfpos] = v;
+            Gt[(sch + G::CPT * u) * G::GS + sp] = tgv[u];
+        }
         __syncthreads();
 #pragma unroll 2
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int p = 32 * wid + 2 * s2 + hs;
-            const float a = Gt[r32 * NF_FI_GS + p];
-            const float* fp = F + r32 * G::CS + nf_fi_fpos<LGW>(p);
+        for (int s2 = 0; s2 < G::TPX / 4; ++s2) {
+            const int p = ph * (G::TPX / 2) + 2 * s2 + hs;
+            const float a = Gt[r32 * G::GS + p];
+            const float* fp = F + r32 * G::CS + (p >> (2 * LGW)) * G::FS + (((p >> LGW) & (G::W - 1)) + 1) * G::PW + (p & (G::W - 1)) + 1;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float bq = fp[(t / 3 - 1) * G::PW + (t % 3) - 1];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) {
+                if (t < nt) {                                // (wave-uniform)
+                    const int tap = t0 + t;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, fp[(tap / 3 - 1) * G::PW + (tap % 3) - 1], acc[t], 0, 0, 0);
+                }
             }
         }
         if (slab_b != nullptr && blockIdx.z == 0 && threadIdx.x < 32)
-            for (int p = 0; p < 256; ++p) bsum += Gt[threadIdx.x * NF_FI_GS + p];
+            for (int p = 0; p < G::TPX; ++p) bsum += Gt[threadIdx.x * G::GS + p];
     }
     if (slab_b != nullptr && blockIdx.z == 0 && threadIdx.x < 32 && o0 + (int)threadIdx.x < Co)
         slab_b[(int64_t)blockIdx.x * Co + o0 + threadIdx.x] = bsum;
-    float* RED = F;
-    float* sw = slab_w + (int64_t)blockIdx.x * Co * Ci * 9;
+    if (ph == 1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        __syncthreads();
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) RED[wid * 1024 + nf_fi_cd_row(r, hs) * 32 + r32] = acc[t][r];
-        __syncthreads();
-        for (int e = threadIdx.x; e < 1024; e += NF_FI_THREADS) {
-            float s = 0.f;
+            for (int r = 0; r < 16; ++r) RED[((tg * 3 + t) * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (ph == 0) {
+        float* sw = slab_w + (int64_t)blockIdx.x * Co * Ci * 9;
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) s += RED[w8 * 1024 + e];
-            const int o = e >> 5, c = e & 31;
-            if (o0 + o < Co && c0 + c < Ci) sw[((int64_t)t * Co + o0 + o) * Ci + c0 + c] = s;      // tap-major: 128-byte runs per (tap, o)
+        for (int t = 0; t < 3; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + nf_fi_cd_row(r, hs), c = c0 + r32;
+                    if (o < Co && c < Ci) sw[((int64_t)(t0 + t) * Co + o) * Ci + c] = acc[t][r] + RED[((tg * 3 + t) * 16 + r) * 64 + lane];
+                }
+            }
         }
     }
 }
@@ -855,16 +880,16 @@ extern "C" int nf_flowpp_img_conv(const float* in, const float* weight, const fl
 template <int LGW>
 static int nf_fi_wgrad_launch(const float* in, const float* g, float* sw, float* sb, int n_slabs, int64_t B, int Ci, int Co, int in_mode,
                               hipStream_t st) {
-    using G = NfFiGeo<LGW>;
-    const size_t lds = (size_t)(32 * G::CS + 32 * NF_FI_GS) * sizeof(float);
+    using G = NfFiGeoW<LGW>;
+    const size_t lds = (size_t)(32 * G::CS + 32 * G::GS + 4 * 3 * 1024) * sizeof(float);
     const dim3 grid((unsigned)n_slabs, (unsigned)((Co + 31) / 32), (unsigned)((Ci + 31) / 32));
     int rc;
     if (in_mode == 1) {
-        if ((rc = nf_fi_optin(k_fi_conv_wgrad<LGW, 1>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
+        if ((rc = nf_fi_optin(k_fi_conv_wgrad2<LGW, 1>, lds)) != 0) return rc;
+        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
     } else {
-        if ((rc = nf_fi_optin(k_fi_conv_wgrad<LGW, 0>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
+        if ((rc = nf_fi_optin(k_fi_conv_wgrad2<LGW, 0>, lds)) != 0) return rc;
+        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
     }
     NF_CHECK_LAUNCH();
     return 0;
@@ -874,8 +899,9 @@ static int nf_fi_wgrad_launch(const float* in, const float* g, float* sw, float*
 // than the pixel tiles
 extern "C" int nf_flowpp_img_wgrad_slabs(int64_t B, int Ci, int Co, int H, int W) {
     if (!nf_flowpp_img_usable(B, Ci, Co, H, W)) return 0;
-    const int64_t tiles = (B * H * W + 255) / 256, blocks = (int64_t)((Co + 31) / 32) * ((Ci + 31) / 32);
-    int64_t k = (256 + blocks - 1) / blocks;
+    const int tpx = H * W <= 64 ? 64 : 256;                  // pixels per tile of k_fi_conv_wgrad2
+    const int64_t tiles = (B * H * W + tpx - 1) / tpx, blocks = (int64_t)((Co + 31) / 32) * ((Ci + 31) / 32);
+    int64_t k = (256 + blocks - 1) / blocks;                 // (512 / 1024 workgroups measured no better)
     if (k > tiles) k = tiles;
     if (k > NF_FLOWPP_IMG_MAX_SLABS) k = NF_FLOWPP_IMG_MAX_SLABS;
     return (int)(k < 1 ? 1 : k);
