@@ -1140,7 +1140,7 @@ extern "C" int nf_slab_sum(const nf_slab_sum_desc* descs, int n_jobs, nf_stream_
         if (descs[i].n > nmax) nmax = descs[i].n;
     }
     unsigned gx = nf_grid_for(nmax);
-    if (gx > 128) gx = 128;
+    if (gx > 1024) gx = 1024;                           // (128 until round 3: the 387 k-element weight gradients of the image Flow++ output convolution took 27 us)
     hipLaunchKernelGGL(k_slab_sum, dim3(gx, (unsigned)n_jobs), dim3(NF_BLOCK), 0, (hipStream_t)stream, args);
     NF_CHECK_LAUNCH();
     return 0;
