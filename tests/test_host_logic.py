@@ -165,3 +165,16 @@ def test_trainer_keeps_models_with_host_drawn_masks_off_the_graph(pkg):
         net = pkg.MAF((D, ), '2d', NS(layers=2, mixtures=None))
         tr = train.FlowTrainer(net, graph=True, graph_factory=lambda: None)
         assert tr.graph is expect, (D, tr.graph)
+
+
+def test_image_flowpp_conditioner_is_not_taken_off_the_gpu_or_for_other_shapes(pkg):
+    """fused_flowpp_img.flowpp_img_fusable: CPU tensors, other widths, rectangular or large maps keep the module stack (the HIP path has no
+    CPU fallback to fall into: the decision is made before any kernel is called)"""
+    import importlib
+    fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    cond = importlib.import_module(pkg.__name__ + '.conditioners')
+    net = cond.flowpp_conditioner(6, 84, (32, 8, 8), 32, conv=True)
+    assert not fpi.flowpp_img_fusable(net, torch.zeros(2, 6, 8, 8))                     # not a GPU tensor
+    assert not fpi.flowpp_img_fusable(net, torch.zeros(2, 6))                           # density data
+    wide = cond.flowpp_conditioner(6, 84, (64, 8, 8), 64, conv=True)
+    assert not fpi.flowpp_img_fusable(wide, torch.zeros(2, 6, 8, 8))
