@@ -509,6 +509,10 @@ typedef struct nf_conv_pack_desc {
 } nf_conv_pack_desc;
 int nf_conv_weight_pack_images(int O, int I, int ksize);
 int nf_conv_weight_pack(const nf_conv_pack_desc* descs, int n, nf_stream_t stream);
+/* Self-test of that arithmetic (no reference counterpart: flows/modules.py:416-438's convolutions are plain fp32): D (32, 32) =
+ * A (32, K) * B (K, 32) on one wave, K a multiple of 16; mode 0 = v_mfma_f32_32x32x2_f32, mode 1 = the chain kernels' own split
+ * and six-product accumulation.  tests/test_gpu_ops.py asserts error(mode 1) <= error(mode 0) against float64.                        */
+int nf_selftest_gemm32(const float* A, const float* B, float* D, int K, int mode, nf_stream_t stream);
 
 /* autograd of nf_conv_bn_fwd in training mode; the gradient G of `out` is assembled on load exactly as in
  * nf_linear_bn_bwd (G = g_direct + g_skip + BNbwd(gn_src), each term optional).  Results:

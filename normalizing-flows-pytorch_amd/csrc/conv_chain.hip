@@ -1795,3 +1795,40 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
     NF_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- self-test of the three-way split (tests/test_gpu_ops.py::test_bf16_split_is_no_precision_reduction) ------------------------------
+// D[32][32] = A[32][K] * B[K][32] on ONE wave, K a multiple of 16: mode 0 = v_mfma_f32_32x32x2_f32 (the exact fp32 instruction),
+// mode 1 = the six-product form of the chain kernels -- the SAME nf_cc_split2 and the SAME NF_CC_MFMA6 accumulation order they use.
+__global__ void __launch_bounds__(64) k_selftest_gemm32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ D,
+                                                        int K, int mode) {
+    const int lane = threadIdx.x, c32 = lane & 31, hs = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (mode == 0) {
+        for (int k = 0; k < K; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c32 * K + k + hs], B[(k + hs) * 32 + c32], acc, 0, 0, 0);
+    } else {
+        for (int k = 0; k < K; k += 16) {
+            bf16x8 ah, am, al, bh, bm, bl;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                bf16x2 h2, m2, l2;
+                nf_cc_split2(f32x2{A[c32 * K + k + 8 * hs + j], A[c32 * K + k + 8 * hs + j + 1]}, h2, m2, l2);
+                ah[j] = h2[0]; ah[j + 1] = h2[1]; am[j] = m2[0]; am[j + 1] = m2[1]; al[j] = l2[0]; al[j + 1] = l2[1];
+                nf_cc_split2(f32x2{B[(k + 8 * hs + j) * 32 + c32], B[(k + 8 * hs + j + 1) * 32 + c32]}, h2, m2, l2);
+                bh[j] = h2[0]; bh[j + 1] = h2[1]; bm[j] = m2[0]; bm[j + 1] = m2[1]; bl[j] = l2[0]; bl[j + 1] = l2[1];
+            }
+            NF_CC_MFMA6(ah, am, al, bh, bm, bl);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * hs) * 32 + c32] = acc[r];
+}
+
+extern "C" int nf_selftest_gemm32(const float* A, const float* B, float* D, int K, int mode, nf_stream_t stream) {
+    if (!A || !B || !D || K <= 0 || (K & 15) || (mode != 0 && mode != 1)) return NF_E_BADARG;
+    hipLaunchKernelGGL(k_selftest_gemm32, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D, K, mode);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -49,11 +49,18 @@ def test_version_and_argument_errors_without_gpu(pkg, built):
     assert rc == 10001
 
 
-def test_gfx950_code_object(built):
-    r = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', built], capture_output=True, text=True)
+def test_gfx950_code_object(built, tmp_path):
+    # llvm-objdump --offloading EXTRACTS every code object next to the file it is given: run it on a temporary copy, so that the
+    # package directory (which travels to the GPU box) stays free of the ~9 MB of libnfhip.so.N.hipv4-* dumps
+    import shutil
+    work = tmp_path / 'libnfhip.so'
+    shutil.copyfile(built, work)
+    r = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', str(work)], capture_output=True, text=True,
+                       cwd=str(tmp_path))
     if r.returncode != 0:
         pytest.skip('llvm-objdump --offloading unavailable')
     assert 'gfx950' in r.stdout
+    assert not [f for f in os.listdir(os.path.dirname(built)) if f.startswith('libnfhip.so.')], 'code-object dumps in the package'
 
 
 def test_no_cpu_fallback(pkg, built):

@@ -35,14 +35,17 @@ not exist at full depth.  What the test asserts instead:
     loss), but it changes every fp32 summation order: the reference's own fp32 CPU path, run on K row permutations of the SAME
     batch and weights, lands anywhere between 5.6e-3 and 1.6e-1 of float64 on C1 (flat gradient).  For the configs whose oracle
     step is cheap (C1, C2, C5: K = 6) the GPU's flat-gradient distance to float64 must be <= 4 x the LARGEST distance of the
-    ensemble; for C3 / C4 (one 45 s float64 pass) <= 4 x the unpermuted fp32 oracle's.
-  * THE PER-STEP PROFILE.  For every flow step s the worst gradient entry (relative to the tensor's largest) must be inside
-        2e-5  +  SLACK * ensemble envelope(s .. last)  +  max(FLIPS, B / 1024) / B * AMP ** (last - s)
-    (envelope(s .. last): the ensemble's worst error over the steps s .. last -- an event in a later step reaches every earlier step's
-    gradients through the backward pass, and six permutations sample WHICH step is hit only sparsely)
-    i.e. the strict bar plus the footprint of at most FLIPS kink events per pass, amplified by AMP = 1.3 per step on the way back
-    (measured, tools/probes/parity_depth.py).  The profile is written to gpurun_out/fullsize_parity.txt (committed per round under
-    profiles/).
+    ensemble (C3 / C4: the unpermuted fp32 run and two row permutations).
+  * THE PER-STEP PROFILE (round 4: bars with teeth).  Per flow step s and parameter class the worst gradient entry -- relative to the
+    tensor's own largest entry, or, for the one-element coupling scalars (s_log_scale, s_bias, ...), whose exact values are sums of
+    ~1e5 cancelling terms, relative to the largest gradient of that class in the model -- must be inside
+        2e-5  +  2 x ensemble envelope(class, s .. last)  +  min(0.05, max(FLIPS, B / 1024) / B * AMP ** (last - s))
+    (envelope(s .. last): the fp32 ensemble's worst error over the steps s .. last of the same class -- an event in a later step reaches
+    every earlier step's gradients through the backward pass; the kink term allows for FLIPS events the ensemble did not sample and is
+    CAPPED at 0.05: it never carries a bar).  Every config has an ensemble now (C3 / C4: the unpermuted run + 2 row permutations).
+    Where the reference's own fp32 spread exceeds 0.2 of the tensor's largest entry (C1: the early steps of a 32-step flow) no fp32
+    implementation can be told apart from another; there the GPU must stay inside 1.25 x the spread, the row is marked in the report
+    and the report counts such rows.  The profile is written to gpurun_out/fullsize_parity.txt (committed per round under profiles/).
   * the LAST flow step's gradient tensors (nothing amplifies them) meet the strict bar + the footprint of FLIPS samples;
   * a KINK-FREE case meets the strict bar on EVERY tensor: test_c1_kink_free_seed_meets_the_strict_bar_on_every_tensor runs the
     C1 launch path (whole-flow RealNVP kernel, B = 256) at the largest depth where the census finds a seed without a single unit
@@ -68,6 +71,9 @@ SLACK = 4.0
 FLIPS = 4          # kink events per pass whose footprint the per-step profile may carry (see the docstring)
 AMP = 1.3          # amplification of a gradient perturbation per flow step of the backward pass (measured)
 ENSEMBLE = 6       # row permutations of the batch the fp32 oracle is run on where that is cheap (C1, C2, C5)
+ENSEMBLE_SLOW = 2  # ... and for C3 / C4 (one fp32 oracle step is 3 - 6 s there)
+KINK_CAP = 0.05    # the per-step kink allowance never exceeds this
+WIDE = 0.2         # ensemble envelope beyond which the bar is 1.25 x the envelope instead of 2 x
 
 CONFIGS = [
     # name, oracle kind, class, dims, datatype, layers, mixtures, per-GPU batch, data
@@ -116,14 +122,33 @@ def _flat_distance(grads, r64):
     return (num / max(den, 1e-300)) ** 0.5
 
 
+SCALAR_KINDS = ('s_log_scale', 's_bias', 'a_log_scale', 'a_bias')     # one-element coupling parameters: ill-conditioned sums
+
+
+def _kind(k):
+    return 'scalar' if k.endswith(SCALAR_KINDS) else 'tensor'
+
+
+def _class_scale(r64):
+    """the scalar coupling parameters' gradients are sums of B * C * H * W cancelling terms: a layer whose exact value happens to be
+    near zero has no meaningful RELATIVE error of its own (the fp32 oracle itself is 2.2 x the value off at C4's layer 112).  They
+    are measured against the largest gradient of that parameter class in the model instead; every other tensor against its own
+    largest entry."""
+    return max([1.0] + [float(e.abs().max()) for k, e in r64['grads'].items() if _kind(k) == 'scalar'])
+
+
 def _step_profile(grads, r64, per_step):
-    """{flow step: worst |g - g64| / max(1, max|g64|) over the step's gradient tensors}"""
+    """{(class, flow step): worst |g - g64| / scale over the step's gradient tensors of that class}; scale = max(1, max|g64|) of the
+    tensor itself ('tensor' class) or of the whole scalar class (see _class_scale)"""
     prof = {}
+    cs = _class_scale(r64)
     for k, e in r64['grads'].items():
         if k in grads and k.startswith('net.layers.'):
             st = int(k.split('.')[2]) // per_step
-            w = float((grads[k].detach().double().cpu() - e.double()).abs().max()) / max(1.0, float(e.abs().max()))
-            prof[st] = max(prof.get(st, 0.0), w)
+            c = _kind(k)
+            sc = cs if c == 'scalar' else max(1.0, float(e.abs().max()))
+            w = float((grads[k].detach().double().cpu() - e.double()).abs().max()) / sc
+            prof[(c, st)] = max(prof.get((c, st), 0.0), w)
     return prof
 
 
@@ -183,23 +208,30 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
             bad.append(('flat gradient distance to float64', rel_gpu, max(rel_ens)))
         pg = _step_profile(grads, r64, per_step)
         pe = [_step_profile(m['grads'], r64, per_step) for m in members]
-        last = max(pg)
-        _report('%-18s %-14s per-step gradient error vs float64 (worst entry / max entry): step gpu | fp32 ensemble max | bar' % (name, tag))
-        for st in sorted(pg):
+        last = max(st for _, st in pg)
+        _report('%-18s %-14s per-step gradient error vs float64 (worst entry / scale) per class: class step gpu | fp32 ensemble max over '
+                'steps s..last (%d members) | bar' % (name, tag, len(members)))
+        n_wide = 0
+        for c, st in sorted(pg):
             # a kink event in flow step s' perturbs the gradients of s' AND of every step before it (the backward pass carries it on):
-            # the envelope of step st is the ensemble's worst over the steps st .. last, not over st alone
-            env = max(p_.get(s2, 0.0) for p_ in pe for s2 in pg if s2 >= st)
-            if len(pe) == 1:
-                # no ensemble (C3 / C4: one 45 s float64 pass): the single fp32 oracle run shows how LARGE an event on an ill-conditioned
-                # tensor gets (the scalar s_log_scale gradients of the image couplings: the oracle's own fp32 error reaches 2.2 x the
-                # tensor's value), not at which step the next one falls -- its worst step stands for every step
-                env = max(pe[0].values())
-            # (the number of near-kink units of a pass grows with the batch, the footprint of one shrinks with it: at least FLIPS events,
-            #  one per 1024 rows beyond that)
-            bar = 2.0 * TOL + SLACK * env + min(1.0, max(FLIPS, B // 1024) / float(B) * AMP ** min(last - st, 64))
-            _report('%-18s %-14s   %3d  %.3e | %.3e | %.3e%s' % (name, tag, st, pg[st], env, bar, '' if pg[st] <= bar else '  <-- OUTSIDE'))
-            if pg[st] > bar:
-                bad.append(('profile step %d' % st, pg[st], env, bar))
+            # the envelope of step st is the ensemble's worst over the steps st .. last of the same class, not over st alone
+            env = max(p_.get((c, s2), 0.0) for p_ in pe for c2, s2 in pg if c2 == c and s2 >= st)
+            # the footprint of at most FLIPS kink events beyond what the ensemble happened to sample, capped: it never carries a bar
+            kink = min(KINK_CAP, max(FLIPS, B // 1024) / float(B) * AMP ** min(last - st, 64))
+            if env <= WIDE:
+                bar = 2.0 * TOL + 2.0 * env + kink
+            else:
+                # the reference's own fp32 path is more than WIDE of the tensor's largest entry away from float64 on this very step and
+                # weights (row permutations of the same batch): no fp32 implementation can be told apart from another there -- the GPU
+                # must stay inside 1.25 x that spread; the decisive bars are the later steps', where the spread is small
+                bar = 2.0 * TOL + 1.25 * env + kink
+                n_wide += 1
+            _report('%-18s %-14s   %-6s %3d  %.3e | %.3e | %.3e%s%s' % (name, tag, c, st, pg[(c, st)], env, bar,
+                                                                      '  (fp32 spread > %.1f)' % WIDE if env > WIDE else '',
+                                                                      '' if pg[(c, st)] <= bar else '  <-- OUTSIDE'))
+            if pg[(c, st)] > bar:
+                bad.append(('profile %s step %d' % (c, st), pg[(c, st)], env, bar))
+        _report('%-18s %-14s   %d of %d profile rows sit where the fp32 ensemble itself is > %.1f from float64' % (name, tag, n_wide, len(pg), WIDE))
     else:
         # no float64 pass for this step (C3 / C4 replay): the GPU must stay within 4 x the fp32 oracle's measured distance to float64
         rel = _flat_distance(grads, rec32)
@@ -231,10 +263,8 @@ def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg):
     slow64 = name.startswith(('c3', 'c4'))          # float64 oracle pass: 45 s each there, steps 1 and 2 only
     gaps = {}
 
-    perms = []
-    if not slow64:
-        gp = torch.Generator().manual_seed(99)
-        perms = [torch.randperm(B, generator=gp) for _ in range(ENSEMBLE)]
+    gp = torch.Generator().manual_seed(99)
+    perms = [torch.randperm(B, generator=gp) for _ in range(ENSEMBLE_SLOW if slow64 else ENSEMBLE)]
 
     def oracle_step(sd, initialised, want64):
         r32, _ = traj.run(kind, dims, datatype, layers, sd, y, 1, mixtures=mix, dtype=torch.float32,

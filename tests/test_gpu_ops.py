@@ -687,3 +687,35 @@ def test_weight_norm_multi_ragged_shapes(nf):
             assert got.shape == want.shape, (s, got.shape, want.shape)
             bar = TOL * max(1.0, float(want.abs().max())) + SLACK * _gap(ref32, want)
             assert float((got.detach().double() - want).abs().max()) <= bar, s
+
+
+@pytest.mark.parametrize('K', [288, 864, 32])
+def test_bf16_split_is_no_precision_reduction(nf, K):
+    """the persistent image-conditioner kernels form every fp32 product as six bf16 x bf16 partial products of three-way
+    splits (x = h + m + l exactly), accumulated in fp32 on v_mfma_f32_32x32x16_bf16.  Asserted here, not just probed: on conditioner-like
+    operands (weights ~ U(-0.06, 0.06), ReLU-like activations; K = 288 = one 32-channel 3 x 3 layer, 864 = the 96-channel first layer of
+    the 4 x 4 level) the split form's max error against float64 is no larger than that of v_mfma_f32_32x32x2_f32 -- the exact fp32
+    instruction -- times 1.25 (both are a few ulp of the accumulated magnitude), and both meet the 1e-5 bar relative to max sum|a||b|.
+    nf_selftest_gemm32 runs the chain kernels' own nf_cc_split2 / NF_CC_MFMA6 (csrc/conv_chain.hip)."""
+    N = nf._native
+    worst = []
+    for seed in range(8):
+        g = torch.Generator().manual_seed(100 + seed)
+        A = (torch.rand(32, K, generator=g) * 2 - 1) * 0.06
+        Bm = torch.clamp(torch.rand(K, 32, generator=g) * 3 - 1, min=0.0)
+        if seed >= 4:                                         # wide dynamic range: normal activations, weights over three decades
+            Bm = torch.randn(K, 32, generator=g)
+            A = A * torch.pow(10.0, torch.rand(32, K, generator=g) * 3 - 2)
+        ref = A.double() @ Bm.double()
+        mag = float((A.double().abs() @ Bm.double().abs()).max())
+        out = []
+        for mode in (0, 1):
+            D = torch.empty(32, 32, device=DEV)
+            N.call('nf_selftest_gemm32', N.ptr(A.to(DEV).contiguous()), N.ptr(Bm.to(DEV).contiguous()), N.ptr(D), K, mode, N.stream())
+            torch.cuda.synchronize()
+            out.append(float((D.cpu().double() - ref).abs().max()))
+        e_fp32, e_split = out
+        worst.append((e_fp32, e_split, mag))
+        assert e_split <= 1.25 * e_fp32 + 1e-7 * mag, (K, seed, e_fp32, e_split, mag)
+        assert e_split <= 1e-5 * mag and e_fp32 <= 1e-5 * mag, (K, seed, e_fp32, e_split, mag)
+    print('K = %d: max |fp32 MFMA - f64| %.3e   max |bf16 x 3 - f64| %.3e' % (K, max(w[0] for w in worst), max(w[1] for w in worst)))
