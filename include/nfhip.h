@@ -397,8 +397,15 @@ typedef struct nf_conv_desc {
     float* bn_save_invstd;    /* (I,) training: written */
     float* stat_sum;          /* NF_STAT_REPL x 32 or NULL */
     float* stat_sqsum;
+    const float* wpk;         /* optional: the weight's LDS images (nf_conv_weight_pack of this very weight); read by the large-batch
+                               * 3x3 kernels (csrc/conv_bulk.hip), which split the weight themselves when it is NULL */
 } nf_conv_desc;
 int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksize);
+/* Large batches (B*H*W > min_pixels, default 16384: beyond the persistent chain's 128 tiles): the 3x3 layers with <= 32 input and 32
+ * output channels run on csrc/conv_bulk.hip -- independent waves, three-way bf16 split on the matrix pipe -- behind nf_conv_bn_fwd /
+ * nf_conv_bn_bwd (data pass); same results to fp32 rounding.  Switches for tests and A/B runs (-1 = keep): on, min_pixels, nblk
+ * (pixel blocks per wave: 0 automatic, 1, 2).  Environment: NF_CONV_BULK=0, NF_CONV_BULK_MIN_PX, NF_CONV_BULK_NBLK.                */
+int nf_conv_bulk_config(int on, int64_t min_pixels, int nblk);
 int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, int training, float bn_eps,
                    float bn_momentum, nf_stream_t stream);
 
@@ -543,6 +550,7 @@ typedef struct nf_conv_bwd_desc {
     float* gn_out;              /* (B, I, H, W) or NULL */
     float* sum_g;               /* NF_STAT_REPL x 32, += (with input BatchNorm) */
     float* sum_gx;
+    const float* wpk;           /* optional, as in nf_conv_desc (the data gradient reads the transposed image of the same buffer) */
 } nf_conv_bwd_desc;
 int nf_conv_bwd_slabs(int64_t B, int H, int W);
 int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, nf_stream_t stream);

@@ -45,47 +45,6 @@ extern "C" int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksiz
     return nf_cv_geometry(g, B, H, W, ksize) ? 1 : 0;
 }
 
-// folded constants of the input BatchNorm (threads 0..31): kc[0] scale, kc[1] shift
-__device__ __forceinline__ void nf_cv_bn_consts_fwd(float* kc, const nf_conv_desc& d, int I, int64_t Npx, int training,
-                                                    float eps, float mom) {
-    if (threadIdx.x < 32) {
-        const int k = threadIdx.x;
-        float sc = 1.f, sh = 0.f;
-        if (d.bn_gamma != nullptr && k < I) {
-            float mean, invstd;
-            if (training) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < NF_STAT_REPL; ++r) { t1 += d.bn_sum[32 * r + k]; t2 += d.bn_sqsum[32 * r + k]; }
-                const float invN = 1.f / (float)Npx;
-                const float m1 = t1 * invN;
-                mean = d.bn_center[k] + m1;
-                const float var = fmaxf(t2 * invN - m1 * m1, 0.f);                 // biased, as BatchNorm normalises
-                invstd = 1.f / sqrtf(var + eps);
-                if (blockIdx.x == 0) {
-                    const float rm = d.bn_running_mean[k], rv = d.bn_running_var[k];
-                    const float unb = Npx > 1 ? var * ((float)Npx / (float)(Npx - 1)) : var;
-                    d.bn_running_mean[k] = (1.f - mom) * rm + mom * mean;
-                    d.bn_running_var[k] = (1.f - mom) * rv + mom * unb;
-                }
-            } else {
-                mean = d.bn_running_mean[k];
-                invstd = 1.f / sqrtf(d.bn_running_var[k] + eps);
-            }
-            if (blockIdx.x == 0 && d.bn_save_mean != nullptr) {
-                d.bn_save_mean[k] = mean;
-                d.bn_save_invstd[k] = invstd;
-            }
-            sc = d.bn_gamma[k] * invstd;
-            sh = d.bn_beta[k] - mean * sc;
-        }
-        kc[k] = sc;
-        kc[32 + k] = sh;
-    }
-    if (training && d.bn_gamma != nullptr && d.bn_num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-        d.bn_num_batches[0] += 1;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // forward.  Sixteen waves: wave w works on pixel block pb = w & 3 (32 pixels) and
 //   3x3 (O <= 32): K quarter kq = w >> 2 of the (tap, channel) axis; the quarters are exchanged through LDS and every wave
@@ -285,6 +244,8 @@ extern "C" int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O,
     if (desc->bn_gamma != nullptr && I > 32) return NF_E_BADARG;          // statistics vectors are 32 wide
     if (desc->stat_sum != nullptr && (O > 32 || ksize != 3)) return NF_E_BADARG;
     if (desc->residual != nullptr && ksize != 3) return NF_E_BADARG;
+    if (nf_conv_bulk_fwd_plan(desc, B, I, O, H, W, ksize))          // large batches: independent waves on the bf16 matrix pipe (conv_bulk.hip)
+        return nf_conv_bulk_fwd(desc, B, I, H, W, training, bn_eps, bn_momentum, (hipStream_t)stream);
     const int OCB = (O + 31) / 32;
     const int T = ksize * ksize;
     size_t tiles_f = (size_t)T * 32 * (32 * OCB + 1) + (size_t)32 * g.CS;
@@ -1004,6 +965,8 @@ extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, in
     if (desc->bn_gamma != nullptr && I > 32) return NF_E_BADARG;
     if (desc->gn_src != nullptr && O > 32) return NF_E_BADARG;            // consumer BatchNorm sums are 32 wide
     if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
+    if (nf_conv_bulk_bwd_plan(desc, B, I, O, H, W, ksize))          // large batches, data pass: conv_bulk.hip
+        return nf_conv_bulk_bwd(desc, B, I, H, W, (hipStream_t)stream);
     const int ICB = (I + 31) / 32, OCB = (O + 31) / 32;
     const int T = ksize * ksize;
     size_t body = (size_t)T * 32 * OCB * NF_CV_WS + (size_t)32 * g.CS + (size_t)32 * OCB * g.CS;

@@ -1,0 +1,651 @@
+// Large-batch form of the 3x3 convolution + BatchNorm2d + ReLU building block (flows/modules.py:416-438; contract of conv_bn.hip:
+// "normalise on load, statistics on store", BatchNorm backward finished by the producer on load) for the launches that are THROUGHPUT-
+// bound: batches beyond the persistent chain (conv_chain.hip: <= 128 co-resident workgroups), e.g. config 4's literal batch 512 on one
+// GPU, where a 32 -> 32 channel layer at 16 x 16 is 2.4 GFLOP per launch.  The per-layer kernels of conv_bn.hip are built for latency
+// (sixteen waves share one 128-pixel tile, barriers between its phases, v_mfma_f32_32x32x2_f32); they reach 22 % of the fp32 matrix
+// peak there because nothing overlaps a tile's global loads with another tile's matrix work.  Here:
+//   * WAVES ARE INDEPENDENT.  A 256-thread workgroup (one per compute unit, persistent) is four waves, one per SIMD.  After the
+//     prologue (weight image + BatchNorm constants in LDS, ONE barrier) a wave owns UNITS of 32 NBLK consecutive pixels: its own
+//     zero-padded activation frame in LDS (halo rows re-read from global memory / L2), its own accumulators, no barrier in the loop;
+//   * the unit's inputs for the NEXT unit are requested (<= 56 values per lane and tensor, all in flight) before the K loop of the
+//     current one, and converted / split / stored into the frame after it: one wave per SIMD has 512 registers to hold them;
+//   * the products run on the bf16 matrix pipe as three-way splits (nf_bf16x3.h, DESIGN.md 3.21: fp32 accuracy, 0.375 of the fp32
+//     instruction's pipe time); the weights are read from ONE shared image (nf_conv_weight_pack, or split here when none is given);
+//     NBLK = 2 pixel blocks per wave share every weight read (9 LDS reads per 12 matrix instructions);
+//   * statistics / BatchNorm-backward sums are kept per lane over all units of the wave and leave once per workgroup.
+// Forward: k_conv3_bulk_fwd (I <= 32 -> 32 channels).  Backward, data gradient only (the weight gradient is nf_conv_bn_wgrad_multi's):
+// k_conv3_bulk_bwd (32 -> I <= 32 channels, transposed image).  Same results as conv_bn.hip's kernels to fp32 rounding.
+#include <cstdlib>
+#include <mutex>
+#include <unordered_set>
+
+#include "nf_common.h"
+
+#include "nf_conv_core.h"
+
+#include "nf_bf16x3.h"
+
+#define NF_CB_WAVES 4
+#define NF_CB_THREADS (NF_CB_WAVES * NF_WAVE)
+#define NF_CB_MAXIT 7                                 // items (channel octet, frame position) per lane: ceil(4 * FSZ / 64), FSZ <= 112
+#define NF_CB_WP (NF_CC_WSLOTS * NF_CC_WSLOT)         // floats per plane of a weight image
+
+struct NfCbGeo {
+    NfCvGeo g;          // geometry of a UNIT (nf_cv_geometry with PX = 32 NBLK pixels)
+    int64_t units;
+    int noct;           // channel octets of the frame (forward: ceil(I / 8); backward: 4)
+    int nit;            // items per lane
+    int C;              // channels of the tensors the frame is built from (forward: I, backward: O = 32)
+};
+
+// switches: the environment (NF_CONV_BULK=0 off, NF_CONV_BULK_MIN_PX, NF_CONV_BULK_NBLK) at first use, nf_conv_bulk_config afterwards
+static int nf_cb_cfg_on = -1, nf_cb_cfg_nblk = -1;
+static int64_t nf_cb_cfg_min_px = -1;
+static void nf_cb_cfg_init() {
+    if (nf_cb_cfg_on >= 0) return;
+    const char* e = getenv("NF_CONV_BULK");
+    const char* m = getenv("NF_CONV_BULK_MIN_PX");
+    const char* n = getenv("NF_CONV_BULK_NBLK");
+    nf_cb_cfg_min_px = m != nullptr ? atoll(m) : 16384 + 1;      // beyond 128 tiles of 128 pixels: where the persistent chain ends
+    nf_cb_cfg_nblk = n != nullptr ? atoi(n) : 0;
+    nf_cb_cfg_on = (e == nullptr || e[0] != '0') ? 1 : 0;
+}
+static int nf_cb_on() { nf_cb_cfg_init(); return nf_cb_cfg_on; }
+static int64_t nf_cb_min_px() { nf_cb_cfg_init(); return nf_cb_cfg_min_px; }
+static int nf_cb_force_nblk() { nf_cb_cfg_init(); return nf_cb_cfg_nblk; }
+extern "C" int nf_conv_bulk_config(int on, int64_t min_pixels, int nblk) {
+    nf_cb_cfg_init();
+    if (on >= 0) nf_cb_cfg_on = on ? 1 : 0;
+    if (min_pixels >= 0) nf_cb_cfg_min_px = min_pixels;
+    if (nblk >= 0) nf_cb_cfg_nblk = nblk <= 2 ? nblk : 0;
+    return 0;
+}
+
+// LDS (floats): W8[3 planes][36 slots][128] | frames[4 waves][3 planes][16 CS] | consts[9][32] | red[2][4][32]
+static inline size_t nf_cb_lds_floats(int CS) { return (size_t)3 * NF_CB_WP + (size_t)NF_CB_WAVES * 3 * NF_CC_FP(CS) + 9 * 32 + 2 * 4 * 32; }
+
+// NBLK for a shape, 0 = the bulk kernels do not take it
+static int nf_cb_plan(NfCbGeo& cg, int64_t B, int C, int H, int W, int noct, int force_nblk = 0) {
+    for (int nblk = 2; nblk >= 1; --nblk) {
+        if (force_nblk && nblk != force_nblk) continue;
+        const int UPX = 32 * nblk;
+        if (!nf_cv_geometry(cg.g, B, H, W, 3, UPX)) continue;
+        if (noct * cg.g.FSZ > NF_CB_MAXIT * NF_WAVE) continue;
+        if (sizeof(float) * nf_cb_lds_floats(cg.g.CS) > 160 * 1024) continue;
+        cg.units = cg.g.tiles;
+        // two pixel blocks per wave while that still gives every wave of the machine >= 1.5 units (256 CUs x 4 waves)
+        if (!force_nblk && nblk == 2 && cg.units < 1536) continue;
+        cg.noct = noct;
+        cg.nit = (noct * cg.g.FSZ + NF_WAVE - 1) / NF_WAVE;
+        cg.C = C;
+        return nblk;
+    }
+    return 0;
+}
+
+// ---- per-lane description of the frame items, invariant over the units of a launch -------------------------------------------------
+struct NfCbItems {
+    int off[NF_CB_MAXIT];        // element offset of channel 8 o of the item from the unit's base pointer (channel stride HW)
+    unsigned lds[NF_CB_MAXIT];   // float offset of the item's 16 bytes inside a frame plane
+    unsigned meta;               // 4 bits per item: class (0 never valid, 1 inside, 2 top halo row, 3 bottom halo row) | 4 * (channel mask short)
+    unsigned seg;                // 4 bits per item: sample of the unit (units of several whole samples)
+    unsigned nch;                // 4 bits per item: valid channels of the octet - 1 (0 .. 7)
+    unsigned oct;                // 4 bits per item: channel octet
+};
+__device__ __forceinline__ void nf_cb_items(NfCbItems& it, const NfCbGeo& cg, int lane) {
+    const NfCvGeo& g = cg.g;
+    it.meta = 0u; it.seg = 0u; it.nch = 0u; it.oct = 0u;
+    const int total = cg.noct * g.FSZ;
+#pragma unroll
+    for (int k = 0; k < NF_CB_MAXIT; ++k) {
+        const int id = lane + NF_WAVE * k;
+        int off = 0; unsigned lds = 0u, cls = 0u, sj = 0u, nch = 0u, oc_ = 0u;
+        if (k < cg.nit && id < total) {
+            const int o = id / g.FSZ, f = id - o * g.FSZ;
+            const int sm = (int)(((float)f + 0.5f) * g.invFS), q = f - sm * g.FS;            // (as nf_cv_decode)
+            const int fy = (int)(((float)q + 0.5f) * g.invFW), fx = q - fy * g.FW;
+            const int gx = fx - 1, fyh = fy - 1;
+            lds = (unsigned)(o * 4 * g.CS + 4 * f);
+            oc_ = (unsigned)o;
+            const int left = cg.C - 8 * o;
+            nch = (unsigned)((left > 8 ? 8 : left) - 1);
+            if (gx >= 0 && gx < g.W) {
+                if (g.SEG == 1) cls = fyh < 0 ? 2u : (fyh >= g.TH ? 3u : 1u);
+                else cls = (fyh >= 0 && fyh < g.TH) ? 1u : 0u;
+                off = (sm * cg.C + 8 * o) * g.HW + fyh * g.W + gx;
+                sj = (unsigned)sm;
+            }
+            cls |= 4u;                                 // bit 2: the item exists (its frame entry is written, zeros when not valid)
+        }
+        it.off[k] = off;
+        it.lds[k] = lds;
+        it.meta |= cls << (4 * k);
+        it.seg |= sj << (4 * k);
+        it.nch |= nch << (4 * k);
+        it.oct |= oc_ << (4 * k);
+    }
+}
+// validity of item k for a unit: top / bottom halo rows exist inside the sample, the sample exists inside the batch
+__device__ __forceinline__ bool nf_cb_valid(const NfCbItems& it, int k, bool top, bool bottom, int nsamp) {
+    const unsigned cls = (it.meta >> (4 * k)) & 3u;
+    const int s = (int)((it.seg >> (4 * k)) & 15u);
+    return (cls == 1u || (cls == 2u && top) || (cls == 3u && bottom)) && s < nsamp;
+}
+
+struct NfCbUnit {            // where a unit lies
+    int64_t base;            // element offset of (sample b0, channel 0, row y0, column 0) in a (B, C, H, W) tensor of cg.C channels
+    bool top, bottom;        // halo rows inside the sample (units of whole rows)
+    int nsamp;               // samples of the unit inside the batch (units of whole samples), else 1
+};
+__device__ __forceinline__ NfCbUnit nf_cb_unit(const NfCbGeo& cg, int64_t u, int C, int UPX) {
+    const NfCvGeo& g = cg.g;
+    NfCbUnit un;
+    const int64_t P0 = u * UPX;
+    const int64_t b0 = P0 >> g.lgHW;
+    const int y0 = g.SEG == 1 ? (int)(P0 & (g.HW - 1)) >> g.lgW : 0;
+    un.base = b0 * C * g.HW + (int64_t)y0 * g.W;
+    un.top = g.SEG == 1 && y0 > 0;
+    un.bottom = g.SEG == 1 && y0 + g.TH < g.H;
+    const int64_t left = g.B - b0;
+    un.nsamp = g.SEG == 1 ? 1 : (int)(left < g.SEG ? left : g.SEG);
+    return un;
+}
+
+// raw values of one tensor for a unit: every load unconditional (clamped to the unit's first element) and in flight together
+struct NfCbRaw { float v[NF_CB_MAXIT][8]; };
+__device__ __forceinline__ void nf_cb_issue(NfCbRaw& r, const float* __restrict__ t, const NfCbItems& it, const NfCbGeo& cg, const NfCbUnit& un) {
+    const float* base = t + un.base;
+    const int HW = cg.g.HW;
+#pragma unroll
+    for (int k = 0; k < NF_CB_MAXIT; ++k)
+        if (k < cg.nit) {                              // wave-uniform
+            const bool ok = nf_cb_valid(it, k, un.top, un.bottom, un.nsamp);
+            const int nch = (int)((it.nch >> (4 * k)) & 15u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = (ok && j <= nch) ? it.off[k] + j * HW : 0;
+                r.v[k][j] = base[e];
+            }
+        }
+}
+
+// the weight image of the layer -> LDS: direct global -> LDS loads of a packed image, or split here from the (32, I, 3, 3) / (32 = O, I,
+// 3, 3) weights (forward: slot tap * noct + o, row oc, K = input channel; transposed: slot (8 - tap) * 4 + o, row ic, K = output channel)
+template <bool TR>
+__device__ __forceinline__ void nf_cb_weights(float* W8, const float* __restrict__ wpk, const float* __restrict__ w, int I, int noct) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (wpk != nullptr) {
+        constexpr int CH = 3 * NF_CB_WP / 256;
+        for (int c = wid; c < CH; c += NF_CB_WAVES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wpk + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(W8 + c * 256), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    for (int item = threadIdx.x; item < NF_CC_WSLOTS * 32; item += NF_CB_THREADS) {
+        const int slot = item >> 5, row = item & 31;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (!TR) {
+            const int tap = slot / noct, o = slot - tap * noct;
+            if (tap < 9)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (8 * o + j < I) v[j] = w[((size_t)row * I + 8 * o + j) * 9 + tap];
+        } else {
+            const int tap = 8 - (slot >> 2), o = slot & 3;
+            if (row < I)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = w[((size_t)(8 * o + j) * I + row) * 9 + tap];
+        }
+        nf_cc_w_put8(W8, NF_CB_WP, slot, row, v);
+    }
+}
+
+// ---- the K loop of a unit: acc[nb] += W8(slot)[row] * F8(tap offset, octet)[pixel of block nb] over the pairs of slots (2 p, 2 p + 1) ----
+// NOCT octets of K channels per tap; the wave half hs takes slot 2 p + hs; a dead second slot of an odd last pair reads the image's
+// zero slot.  One pair of operands in flight ahead of the matrix instructions; the two pixel blocks share every weight read.
+template <int NOCT, int NBLK>
+__device__ __forceinline__ void nf_cb_kloop(f32x16 (&accs)[NBLK], const float* W8, const float* F8, int CS, int FW, const int (&fpos)[NBLK],
+                                            int row, int hs) {
+    constexpr int NSLOT = 9 * NOCT, NP = (NSLOT + 1) / 2;
+    const int FPs = NF_CC_FP(CS);
+    bf16x8 a[2][3], b[2][NBLK][3];
+#define NF_CB_LOAD(BUF, P)                                                                                     \
+    do {                                                                                                       \
+        const int s0 = 2 * (P), s1 = 2 * (P) + 1;                                                              \
+        const int t0 = s0 / NOCT, o0 = s0 - t0 * NOCT;                                                         \
+        const int t1 = s1 < NSLOT ? s1 / NOCT : 4, o1 = s1 < NSLOT ? s1 - (s1 / NOCT) * NOCT : 0;             \
+        const int d0 = (t0 / 3 - 1) * FW + (t0 % 3 - 1), d1 = (t1 / 3 - 1) * FW + (t1 % 3 - 1);                \
+        const int fo = hs ? o1 * 4 * CS + 4 * d1 : o0 * 4 * CS + 4 * d0;                                       \
+        const float* wa = W8 + (2 * (P) + hs) * NF_CC_WSLOT + 4 * row;                                         \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) a[BUF][q] = *(const bf16x8*)(wa + q * NF_CB_WP);         \
+        _Pragma("unroll") for (int nb = 0; nb < NBLK; ++nb) {                                                  \
+            const float* fb = F8 + fo + 4 * fpos[nb];                                                          \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) b[BUF][nb][q] = *(const bf16x8*)(fb + q * FPs);      \
+        }                                                                                                      \
+    } while (0)
+    NF_CB_LOAD(0, 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p + 1 < NP) NF_CB_LOAD((p + 1) & 1, p + 1);
+        // the six products of a pair, the pixel blocks interleaved (independent accumulators back to back)
+#define NF_CB_STEP(AQ, BQ)                                                                                                   \
+    _Pragma("unroll") for (int nb = 0; nb < NBLK; ++nb)                                                                      \
+        accs[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p & 1][AQ], b[p & 1][nb][BQ], accs[nb], 0, 0, 0)
+        NF_CB_STEP(0, 2);
+        NF_CB_STEP(2, 0);
+        NF_CB_STEP(1, 1);
+        NF_CB_STEP(0, 1);
+        NF_CB_STEP(1, 0);
+        NF_CB_STEP(0, 0);
+#undef NF_CB_STEP
+    }
+#undef NF_CB_LOAD
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NOCT, int NBLK>
+__global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_fwd(nf_conv_desc d, NfCbGeo cg, int I, int training, float eps, float mom) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NfCvGeo& g = cg.g;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    float* W8 = smem;
+    float* F8 = W8 + 3 * NF_CB_WP + wid * 3 * NF_CC_FP(g.CS);
+    float* kc = smem + 3 * NF_CB_WP + NF_CB_WAVES * 3 * NF_CC_FP(g.CS);      // [2][32] scale, shift (+ 7 unused rows)
+    float* red = kc + 9 * 32;
+    const bool has_bn = d.bn_gamma != nullptr;
+    const bool has_res = d.residual != nullptr;
+    const int64_t Npx = g.B * g.HW;
+    constexpr int UPX = 32 * NBLK;
+
+    nf_cv_bn_consts_fwd(kc, d, I, Npx, training, eps, mom);
+    nf_cb_weights<false>(W8, d.wpk, d.weight, I, NOCT);
+    NfCbItems it;
+    nf_cb_items(it, cg, lane);
+    int fpos[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) fpos[nb] = nf_cv_frame_of(g, nb * 32 + c32);
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = d.bias[nf_cv_cd_row(r, hs)];
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    // zero the frame once: entries that are no item (none: every (octet < NOCT, position < FSZ) is one) and the octets >= NOCT are never read
+    __syncthreads();                                   // weights and constants are in LDS; the only barrier of the launch
+
+    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
+    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
+    NfCbRaw raw;
+    NfCbUnit un;
+    if (u < cg.units) {
+        un = nf_cb_unit(cg, u, I, UPX);
+        nf_cb_issue(raw, d.in, it, cg, un);
+    }
+    for (; u < cg.units; u += stride) {
+        // ---- the unit's frame: BatchNorm + ReLU, zeros outside the image, split, three 16-byte stores per item ----
+#pragma unroll
+        for (int k = 0; k < NF_CB_MAXIT; ++k)
+            if (k < cg.nit) {
+                const unsigned meta = (it.meta >> (4 * k)) & 15u;
+                if (meta & 4u) {
+                    const bool ok = nf_cb_valid(it, k, un.top, un.bottom, un.nsamp);
+                    const int nch = (int)((it.nch >> (4 * k)) & 15u);
+                    const int o = (int)((it.oct >> (4 * k)) & 15u);
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float x = raw.v[k][j];
+                        if (has_bn) x = fmaxf(fmaf(x, kc[8 * o + j], kc[32 + 8 * o + j]), 0.f);
+                        v[j] = (ok && j <= nch) ? x : 0.f;
+                    }
+                    float* p = F8 + it.lds[k];
+                    bf16x8 h, m, l;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        bf16x2 h2, m2, l2;
+                        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
+                        h[j] = h2[0]; h[j + 1] = h2[1]; m[j] = m2[0]; m[j + 1] = m2[1]; l[j] = l2[0]; l[j + 1] = l2[1];
+                    }
+                    *(bf16x8*)(p) = h;
+                    *(bf16x8*)(p + NF_CC_FP(g.CS)) = m;
+                    *(bf16x8*)(p + 2 * NF_CC_FP(g.CS)) = l;
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- requests of the next unit, and this unit's residual, in flight under the K loop ----
+        const int64_t un_next = u + stride;
+        const int64_t P0 = u * UPX;
+        if (un_next < cg.units) {
+            un = nf_cb_unit(cg, un_next, I, UPX);
+            nf_cb_issue(raw, d.in, it, cg, un);
+        }
+        float res[NBLK][16];
+        int64_t oidx[NBLK];
+        bool pv[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            const int64_t P = P0 + nb * 32 + c32;
+            pv[nb] = P < Npx;
+            const int64_t b = pv[nb] ? P >> g.lgHW : 0, q = pv[nb] ? P & (g.HW - 1) : 0;
+            oidx[nb] = b * 32 * g.HW + q;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[nb][r] = has_res ? d.residual[oidx[nb] + (int64_t)nf_cv_cd_row(r, hs) * g.HW] : 0.f;
+        }
+        f32x16 acc[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        nf_cb_kloop<NOCT, NBLK>(acc, W8, F8, g.CS, g.FW, fpos, c32, hs);
+        __builtin_amdgcn_wave_barrier();               // (the frame is rewritten only after the last operand read was issued)
+        // ---- bias, residual, store (32 consecutive pixels of a channel plane per instruction), batch sums shifted by the bias ----
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+            if (pv[nb]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dv = acc[nb][r] + res[nb][r];
+                    d.out[oidx[nb] + (int64_t)nf_cv_cd_row(r, hs) * g.HW] = dv + bias_r[r];
+                    s1[r] += dv;
+                    s2[r] = fmaf(dv, dv, s2[r]);
+                }
+            }
+    }
+    if (d.stat_sum != nullptr) {                       // block-uniform
+        const float t1 = nf_cv_butterfly16(s1, c32), t2 = nf_cv_butterfly16(s2, c32);
+        if ((c32 & 1) == 0) {
+            const int oc = nf_cv_cd_row(c32 >> 1, hs);
+            red[(0 * 4 + wid) * 32 + oc] = t1;
+            red[(1 * 4 + wid) * 32 + oc] = t2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                        // half 0: sums, half 1: squares
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
+            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+            atomicAdd((hs == 0 ? d.stat_sum : d.stat_sqsum) + rep + c32, t);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward, data gradient: G = g_skip + BNbwd(gn_src; out) assembled into the frame (g_store = G at the pixels the unit owns),
+// gn_out = (transposed convolution of G) * [act > 0] with its two batch sums, or the plain input gradient without an input BatchNorm
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NBLK, bool SKIP>
+__global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_desc d, NfCbGeo cg, int I) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const NfCvGeo& g = cg.g;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    float* W8 = smem;
+    float* F8 = W8 + 3 * NF_CB_WP + wid * 3 * NF_CC_FP(g.CS);
+    float* cb = smem + 3 * NF_CB_WP + NF_CB_WAVES * 3 * NF_CC_FP(g.CS);      // [5][32] consumer BatchNorm: c1, mean, invstd, mean g, mean g xhat
+    float* kc = cb + 5 * 32;                                                   // [4][32] input BatchNorm: scale, shift, mean, invstd
+    float* red = kc + 4 * 32;
+    const bool has_bn = d.bn_gamma != nullptr;
+    const int64_t Npx = g.B * g.HW;
+    const float invN = 1.f / (float)Npx;
+    constexpr int UPX = 32 * NBLK;
+
+    if (threadIdx.x < 32) {
+        const int oo = threadIdx.x;
+        const float invstd = d.cbn_save_invstd[oo], mean = d.cbn_save_mean[oo];
+        float mg = 0.f, mgx = 0.f;
+        if (d.cbn_sum_g != nullptr) {
+#pragma unroll
+            for (int r = 0; r < NF_STAT_REPL; ++r) { mg += d.cbn_sum_g[32 * r + oo]; mgx += d.cbn_sum_gx[32 * r + oo]; }
+            mg *= invN;
+            mgx *= invN;
+        }
+        cb[oo] = d.cbn_gamma[oo] * invstd; cb[32 + oo] = mean; cb[64 + oo] = invstd; cb[96 + oo] = mg; cb[128 + oo] = mgx;
+    } else if (threadIdx.x < 64) {
+        const int k = threadIdx.x - 32;
+        float sc = 1.f, sh = 0.f, mean = 0.f, invstd = 0.f;
+        if (has_bn && k < I) {
+            mean = d.bn_save_mean[k];
+            invstd = d.bn_save_invstd[k];
+            sc = d.bn_gamma[k] * invstd;
+            sh = d.bn_beta[k] - mean * sc;
+        }
+        kc[k] = sc; kc[32 + k] = sh; kc[64 + k] = mean; kc[96 + k] = invstd;
+    }
+    nf_cb_weights<true>(W8, d.wpk, d.weight, I, 4);
+    NfCbItems it;
+    nf_cb_items(it, cg, lane);
+    int fpos[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) fpos[nb] = nf_cv_frame_of(g, nb * 32 + c32);
+    float sg[16], sgx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sg[r] = 0.f; sgx[r] = 0.f; }
+    __syncthreads();
+
+    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
+    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
+    NfCbRaw rs, ro, rk;                                // gn_src, out, g_skip of the unit whose frame is built next
+    NfCbUnit un;
+    if (u < cg.units) {
+        un = nf_cb_unit(cg, u, 32, UPX);
+        nf_cb_issue(rs, d.gn_src, it, cg, un);
+        nf_cb_issue(ro, d.out, it, cg, un);
+        if (SKIP) nf_cb_issue(rk, d.g_skip, it, cg, un);
+    }
+    for (; u < cg.units; u += stride) {
+#pragma unroll
+        for (int k = 0; k < NF_CB_MAXIT; ++k)
+            if (k < cg.nit) {
+                const unsigned meta = (it.meta >> (4 * k)) & 15u;
+                if (meta & 4u) {
+                    const bool ok = nf_cb_valid(it, k, un.top, un.bottom, un.nsamp);
+                    const int o = (int)((it.oct >> (4 * k)) & 15u);
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = 8 * o + j;
+                        const float xh = (ro.v[k][j] - cb[32 + c]) * cb[64 + c];
+                        float G = cb[c] * (rs.v[k][j] - cb[96 + c] - xh * cb[128 + c]);
+                        if (SKIP) G = rk.v[k][j] + G;
+                        v[j] = ok ? G : 0.f;
+                    }
+                    if (d.g_store != nullptr && ok && (meta & 3u) == 1u) {
+                        float* gs = d.g_store + un.base + it.off[k];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) gs[j * g.HW] = v[j];
+                    }
+                    float* p = F8 + it.lds[k];
+                    bf16x8 h, m, l;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        bf16x2 h2, m2, l2;
+                        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
+                        h[j] = h2[0]; h[j + 1] = h2[1]; m[j] = m2[0]; m[j + 1] = m2[1]; l[j] = l2[0]; l[j + 1] = l2[1];
+                    }
+                    *(bf16x8*)(p) = h;
+                    *(bf16x8*)(p + NF_CC_FP(g.CS)) = m;
+                    *(bf16x8*)(p + 2 * NF_CC_FP(g.CS)) = l;
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t un_next = u + stride;
+        const int64_t P0 = u * UPX;
+        if (un_next < cg.units) {
+            un = nf_cb_unit(cg, un_next, 32, UPX);
+            nf_cb_issue(rs, d.gn_src, it, cg, un);
+            nf_cb_issue(ro, d.out, it, cg, un);
+            if (SKIP) nf_cb_issue(rk, d.g_skip, it, cg, un);
+        }
+        // forward input of the pixels this lane finishes (rows of the result = input channels)
+        float xin[NBLK][16];
+        int64_t iidx[NBLK];
+        bool pv[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            const int64_t P = P0 + nb * 32 + c32;
+            pv[nb] = P < Npx;
+            const int64_t b = pv[nb] ? P >> g.lgHW : 0, q = pv[nb] ? P & (g.HW - 1) : 0;
+            iidx[nb] = b * I * g.HW + q;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ic = nf_cv_cd_row(r, hs);
+                xin[nb][r] = (has_bn && ic < I) ? d.in[iidx[nb] + (int64_t)ic * g.HW] : 0.f;
+            }
+        }
+        f32x16 acc[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        nf_cb_kloop<4, NBLK>(acc, W8, F8, g.CS, g.FW, fpos, c32, hs);
+        __builtin_amdgcn_wave_barrier();
+        if (d.gn_out != nullptr) {
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+                if (pv[nb]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ic = nf_cv_cd_row(r, hs);
+                        if (ic < I) {
+                            float gn = acc[nb][r];
+                            if (has_bn) {
+                                const float x = xin[nb][r];
+                                gn = fmaf(x, kc[ic], kc[32 + ic]) > 0.f ? gn : 0.f;
+                                sg[r] += gn;
+                                sgx[r] = fmaf(gn, (x - kc[64 + ic]) * kc[96 + ic], sgx[r]);
+                            }
+                            d.gn_out[iidx[nb] + (int64_t)ic * g.HW] = gn;
+                        }
+                    }
+                }
+        }
+    }
+    if (has_bn && d.sum_g != nullptr) {                // block-uniform
+        const float t1 = nf_cv_butterfly16(sg, c32), t2 = nf_cv_butterfly16(sgx, c32);
+        if ((c32 & 1) == 0) {
+            const int ic = nf_cv_cd_row(c32 >> 1, hs);
+            red[(0 * 4 + wid) * 32 + ic] = t1;
+            red[(1 * 4 + wid) * 32 + ic] = t2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64 && c32 < I) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
+            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+            atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
+        }
+    }
+}
+
+template <typename K>
+static inline int nf_cb_optin(K kernel) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> done;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.find(key) == done.end()) {
+        hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done.insert(key);
+    }
+    return 0;
+}
+static int nf_cb_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 256;
+        cus = n > 0 ? n : 256;
+    }
+    return cus;
+}
+// does the large-batch kernel take this forward launch?  (called by nf_conv_bn_fwd; 0 = no, else NBLK)
+int nf_conv_bulk_fwd_plan(const nf_conv_desc* d, int64_t B, int I, int O, int H, int W, int ksize) {
+    if (!nf_cb_on() || ksize != 3 || O != 32 || I < 1 || I > 32 || B * H * W < nf_cb_min_px()) return 0;
+    if (!(B * 32 * (int64_t)H * W < (int64_t)1 << 31)) return 0;
+    NfCbGeo cg;
+    return nf_cb_plan(cg, B, I, H, W, (I + 7) / 8, nf_cb_force_nblk());
+}
+
+int nf_conv_bulk_fwd(const nf_conv_desc* desc, int64_t B, int I, int H, int W, int training, float eps, float mom, hipStream_t st) {
+    NfCbGeo cg;
+    const int noct = (I + 7) / 8;
+    const int nblk = nf_cb_plan(cg, B, I, H, W, noct, nf_cb_force_nblk());
+    if (nblk == 0) return NF_E_BADARG;
+    const size_t lds = sizeof(float) * nf_cb_lds_floats(cg.g.CS);
+    const int64_t wgs = (cg.units + NF_CB_WAVES - 1) / NF_CB_WAVES;
+    const unsigned grid = (unsigned)(wgs < nf_cb_cus() ? wgs : nf_cb_cus());
+    int rc = 0;
+#define NF_CB_FWD(NOCT_, NBLK_)                                                                                                         \
+    do {                                                                                                                                \
+        rc = nf_cb_optin(k_conv3_bulk_fwd<NOCT_, NBLK_>);                                                                               \
+        if (rc == 0)                                                                                                                    \
+            hipLaunchKernelGGL((k_conv3_bulk_fwd<NOCT_, NBLK_>), dim3(grid), dim3(NF_CB_THREADS), lds, st, *desc, cg, I, training, eps, mom); \
+    } while (0)
+    if (nblk == 2) {
+        switch (noct) {
+            case 1: NF_CB_FWD(1, 2); break;
+            case 2: NF_CB_FWD(2, 2); break;
+            case 3: NF_CB_FWD(3, 2); break;
+            default: NF_CB_FWD(4, 2); break;
+        }
+    } else {
+        switch (noct) {
+            case 1: NF_CB_FWD(1, 1); break;
+            case 2: NF_CB_FWD(2, 1); break;
+            case 3: NF_CB_FWD(3, 1); break;
+            default: NF_CB_FWD(4, 1); break;
+        }
+    }
+#undef NF_CB_FWD
+    if (rc) return rc;
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// backward data pass (g_weff == NULL): 3 x 3, O = 32, I <= 32, G = [g_skip +] BNbwd(gn_src)
+int nf_conv_bulk_bwd_plan(const nf_conv_bwd_desc* d, int64_t B, int I, int O, int H, int W, int ksize) {
+    if (!nf_cb_on() || ksize != 3 || O != 32 || I < 1 || I > 32 || B * H * W < nf_cb_min_px()) return 0;
+    if (d->g_weff != nullptr || d->g_bias != nullptr || d->g_direct != nullptr || d->gn_src == nullptr || d->out == nullptr) return 0;
+    if (!(B * 32 * (int64_t)H * W < (int64_t)1 << 31)) return 0;
+    NfCbGeo cg;
+    return nf_cb_plan(cg, B, 32, H, W, 4, nf_cb_force_nblk());
+}
+
+int nf_conv_bulk_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int H, int W, hipStream_t st) {
+    NfCbGeo cg;
+    const int nblk = nf_cb_plan(cg, B, 32, H, W, 4, nf_cb_force_nblk());
+    if (nblk == 0) return NF_E_BADARG;
+    const size_t lds = sizeof(float) * nf_cb_lds_floats(cg.g.CS);
+    const int64_t wgs = (cg.units + NF_CB_WAVES - 1) / NF_CB_WAVES;
+    const unsigned grid = (unsigned)(wgs < nf_cb_cus() ? wgs : nf_cb_cus());
+    const bool skip = desc->g_skip != nullptr;
+    nf_conv_bwd_desc dd = *desc;
+    if (dd.wpk != nullptr) dd.wpk += NF_CONV_PACK_IMAGE_FLOATS;    // I <= 32: image 0 = forward, image 1 = transposed
+    desc = &dd;
+    int rc = 0;
+#define NF_CB_BWD(NBLK_, SKIP_)                                                                                                \
+    do {                                                                                                                       \
+        rc = nf_cb_optin(k_conv3_bulk_bwd<NBLK_, SKIP_>);                                                                      \
+        if (rc == 0)                                                                                                           \
+            hipLaunchKernelGGL((k_conv3_bulk_bwd<NBLK_, SKIP_>), dim3(grid), dim3(NF_CB_THREADS), lds, st, *desc, cg, I);      \
+    } while (0)
+    if (nblk == 2) {
+        if (skip) NF_CB_BWD(2, true);
+        else NF_CB_BWD(2, false);
+    } else {
+        if (skip) NF_CB_BWD(1, true);
+        else NF_CB_BWD(1, false);
+    }
+#undef NF_CB_BWD
+    if (rc) return rc;
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -436,7 +436,9 @@ extern "C" int nf_glow_head_w_fwd(const float* x, const float* act_log_scale, co
     }
     // large batches (>= 4 blocks of 64 pixels per compute unit): 64-pixel blocks, 16-byte accesses
     const int64_t nblk64 = (P % 64 == 0) ? B * (P / 64) : 0;
-    if (nblk64 >= 1024) {
+    // (float4 accesses: a contiguous tensor that is a view at an odd storage offset takes the 16-pixel kernel below)
+    const bool al16 = (((uintptr_t)x | (uintptr_t)h | (uintptr_t)z1c) & 15) == 0;
+    if (nblk64 >= 1024 && al16) {
         int64_t g4 = (nblk64 + 3) / 4;
         if (g4 > 512) g4 = 512;                            // two workgroups per compute unit (256: 61 %, 512: 64 %, 1024: 60 % of 8 TB/s at (48,8,8)): a wave walks several blocks per W staging
         if (g4 < g_ld) g4 = g_ld > 4096 ? 4096 : g_ld;

@@ -280,3 +280,50 @@ __device__ __forceinline__ void nf_cv_quarter_exchange(float (&own)[4], const f3
         for (int rr = 0; rr < 4; ++rr) own[rr] += RS[(((pb * 4 + kq) * 3 + slot) * 4 + rr) * NF_WAVE + lane];
 }
 
+
+// folded constants of the input BatchNorm (threads 0..31): kc[0] scale, kc[1] shift
+__device__ __forceinline__ void nf_cv_bn_consts_fwd(float* kc, const nf_conv_desc& d, int I, int64_t Npx, int training,
+                                                    float eps, float mom) {
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x;
+        float sc = 1.f, sh = 0.f;
+        if (d.bn_gamma != nullptr && k < I) {
+            float mean, invstd;
+            if (training) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < NF_STAT_REPL; ++r) { t1 += d.bn_sum[32 * r + k]; t2 += d.bn_sqsum[32 * r + k]; }
+                const float invN = 1.f / (float)Npx;
+                const float m1 = t1 * invN;
+                mean = d.bn_center[k] + m1;
+                const float var = fmaxf(t2 * invN - m1 * m1, 0.f);                 // biased, as BatchNorm normalises
+                invstd = 1.f / sqrtf(var + eps);
+                if (blockIdx.x == 0) {
+                    const float rm = d.bn_running_mean[k], rv = d.bn_running_var[k];
+                    const float unb = Npx > 1 ? var * ((float)Npx / (float)(Npx - 1)) : var;
+                    d.bn_running_mean[k] = (1.f - mom) * rm + mom * mean;
+                    d.bn_running_var[k] = (1.f - mom) * rv + mom * unb;
+                }
+            } else {
+                mean = d.bn_running_mean[k];
+                invstd = 1.f / sqrtf(d.bn_running_var[k] + eps);
+            }
+            if (blockIdx.x == 0 && d.bn_save_mean != nullptr) {
+                d.bn_save_mean[k] = mean;
+                d.bn_save_invstd[k] = invstd;
+            }
+            sc = d.bn_gamma[k] * invstd;
+            sh = d.bn_beta[k] - mean * sc;
+        }
+        kc[k] = sc;
+        kc[32 + k] = sh;
+    }
+    if (training && d.bn_gamma != nullptr && d.bn_num_batches != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        d.bn_num_batches[0] += 1;
+}
+
+// the large-batch 3x3 kernels (conv_bulk.hip); the plans return 0 when the per-layer kernels of conv_bn.hip serve the launch
+int nf_conv_bulk_fwd_plan(const nf_conv_desc* d, int64_t B, int I, int O, int H, int W, int ksize);
+int nf_conv_bulk_fwd(const nf_conv_desc* desc, int64_t B, int I, int H, int W, int training, float eps, float mom, hipStream_t st);
+int nf_conv_bulk_bwd_plan(const nf_conv_bwd_desc* d, int64_t B, int I, int O, int H, int W, int ksize);
+int nf_conv_bulk_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int H, int W, hipStream_t st);

@@ -760,6 +760,10 @@ def _glow_steps_scratch(S, blocks, device):
     n = S * blocks * N.header_constant('NF_MLP_BWD_SLAB_WG_FLOATS')
     t = _GLOW_FLOW_SLABS.get(key)
     if t is None or t[0].numel() < n or t[1].numel() < S * blocks * 64:
+        if t is not None:
+            # an outgrown pair may be in the kernel arguments of a captured hipGraph (the whole-flow backward with its deferred fold):
+            # it is retired, not freed -- a later replay must not scribble over whatever the allocator placed there
+            _GLOW_FLOW_SLABS.setdefault(('retired', device), []).append(t)
         t = _GLOW_FLOW_SLABS[key] = (torch.empty(n, dtype=torch.float32, device=device),
                                      torch.empty(S * blocks * 64, dtype=torch.float32, device=device))
     return t

@@ -23,10 +23,10 @@ GB = 256                 # replica stride of the bias-gradient accumulators (nfh
 
 _FWD_FIELDS = ['in_', 'weight', 'bias', 'residual', 'out', 'bn_gamma', 'bn_beta', 'bn_sum', 'bn_sqsum', 'bn_center',
                'bn_running_mean', 'bn_running_var', 'bn_num_batches', 'bn_save_mean', 'bn_save_invstd', 'stat_sum',
-               'stat_sqsum']
+               'stat_sqsum', 'wpk']
 _BWD_FIELDS = ['in_', 'weight', 'bn_gamma', 'bn_beta', 'bn_save_mean', 'bn_save_invstd', 'g_direct', 'g_skip', 'gn_src',
                'out', 'cbn_gamma', 'cbn_save_mean', 'cbn_save_invstd', 'cbn_sum_g', 'cbn_sum_gx', 'g_store', 'g_bias',
-               'g_weff', 'gn_out', 'sum_g', 'sum_gx']
+               'g_weff', 'gn_out', 'sum_g', 'sum_gx', 'wpk']
 
 
 class ConvDesc(ctypes.Structure):
@@ -99,6 +99,7 @@ def pack_conv_weights(wn_modules, w_effs):
         if buf is None or buf.device != w.device:
             buf = m._w_pack = torch.empty(n * img, dtype=torch.float32, device=w.device)
         m._w_pack_of = w
+        m._w_pack_gen = getattr(m, '_w_pack_gen', 0) + 1        # a backward that saved an earlier pass's images must not read these
         descs.append(ConvPackDesc(w.data_ptr(), buf.data_ptr(), w.shape[0], w.shape[1], w.shape[2], 0))
     for k0 in range(0, len(descs), step):
         chunk = descs[k0:k0 + step]
@@ -114,8 +115,24 @@ def _convnet_packs(net):
         w = getattr(c, '_w_eff', None)
         if w is None or getattr(c, '_w_pack_of', None) is not w:
             return None
-        packs.append(c._w_pack)
+        packs.append(_Pack(c._w_pack, c, c._w_pack_gen))
     return tuple(packs)
+
+
+class _Pack:
+    """a module's weight-image buffer as of one pass: the buffer is persistent (static address under hipGraph replay) and is REWRITTEN by
+    the next pass's pack_conv_weights, so a backward that runs after a later forward (forward, step, forward, backward of the first)
+    must not read it -- ``current()`` says whether the images still belong to the weights this pass saved"""
+    __slots__ = ('buf', 'module', 'gen')
+
+    def __init__(self, buf, module, gen):
+        self.buf, self.module, self.gen = buf, module, gen
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def current(self):
+        return getattr(self.module, '_w_pack_gen', None) == self.gen and self.module._w_pack is self.buf
 
 
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
@@ -398,10 +415,12 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
     else:
         if cpl is not None:
             raise RuntimeError('the fused coupling needs the chain kernel (coupling_fusable was not consulted)')
-        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], **stats(0))
+        # (large batches: the 3x3 layers run on csrc/conv_bulk.hip, which reads the pass's weight images when they exist)
+        pk = (lambda i: packs[i].buf) if packs is not None else (lambda i: None)
+        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], wpk=pk(0), **stats(0))
         for j in range(1, nb):                # convolution j consumes acts[j-1] through BatchNorm j-1
             res = acts[j - 2] if j % 2 == 0 else None
-            _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j],
+            _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j], wpk=pk(j),
                  **stats(j), **bn_kw(j - 1))
         _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
              **bn_kw(nb - 1))
@@ -520,8 +539,8 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         d.g_out = g_out.data_ptr()
         d.g_store[0], d.g_store[1] = stores[0].data_ptr(), stores[1].data_ptr()
         d.g_x = g_x.data_ptr() if g_x is not None else None
-        if getattr(ctx, 'packs', None) is not None:
-            for i in range(nl):
+        if getattr(ctx, 'packs', None) is not None and all(p.current() for p in ctx.packs):
+            for i in range(nl):                     # (stale images: the kernel splits the saved weights itself, bitwise the same)
                 d.wpk[i] = ctx.packs[i].data_ptr()
         slots = WS.zeros(_chain_ws_floats(B, I0, O_out, Hh, Ww), dev)        # (kept alive up to the launch, see the forward)
         d.ws_zero = slots.data_ptr()
@@ -547,14 +566,16 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
 
     layer(H, O_out, 1, nl - 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0],
           sum_gx=sums[nb - 1, 1], **in_bn(nb - 1))
+    cpk = getattr(ctx, 'packs', None)
+    pk = (lambda i: cpk[i].buf) if (cpk is not None and all(p.current() for p in cpk)) else (lambda i: None)
     for j in range(nb - 1, 0, -1):             # convolution j produced acts[j]; its consumer BatchNorm is j
         is_stream = (j % 2 == 0)
         store = (stores[(nb - 1 - j) // 2] if chained else torch.empty_like(acts[0])) if is_stream else None
         layer(H, H, 3, j, in_=acts[j - 1], weight=w[j], gn_src=gn[j], out=acts[j], g_skip=G_skip if is_stream else None,
-              g_store=store, gn_out=gn[j - 1], sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], **in_bn(j - 1), **cons_bn(j))
+              g_store=store, gn_out=gn[j - 1], sum_g=sums[j - 1, 0], sum_gx=sums[j - 1, 1], wpk=pk(j), **in_bn(j - 1), **cons_bn(j))
         if is_stream:
             G_skip = store
-    layer(I0, H, 3, 0, in_=x, weight=w[0], gn_src=gn[0], out=acts[0], g_skip=G_skip, gn_out=g_x, **cons_bn(0))
+    layer(I0, H, 3, 0, in_=x, weight=w[0], gn_src=gn[0], out=acts[0], g_skip=G_skip, gn_out=g_x, wpk=pk(0), **cons_bn(0))
 
     direct = ctx.sinks is not None
     g_w = [torch.empty_like(t) for t in w]

@@ -1,0 +1,230 @@
+"""GPU parity of the large-batch 3x3 convolution kernels (csrc/conv_bulk.hip: independent waves, three-way bf16 split on the matrix
+pipe) behind nf_conv_bn_fwd / nf_conv_bn_bwd: against a float64 torch restatement of the launch's contract (flows/modules.py:416-438:
+BatchNorm2d + ReLU on load, convolution, bias, residual, batch sums; the BatchNorm backward assembled on load, transposed convolution,
+ReLU mask, batch sums), against the per-layer kernels of csrc/conv_bn.hip on the same operands, and through the whole conditioner at a
+batch beyond the persistent chain."""
+import copy
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+R = 8            # NF_STAT_REPL
+
+
+def _cfg(pkg, on, min_px=-1, nblk=-1):
+    pkg._native.call('nf_conv_bulk_config', int(on), int(min_px), int(nblk))
+
+
+@pytest.fixture()
+def bulk(pkg):
+    pkg._native.load()
+    _cfg(pkg, 1, 0, 0)
+    yield pkg
+    _cfg(pkg, 1, 16385, 0)
+
+
+def _replicas(n=32):
+    return torch.zeros(R * 32, device=DEV)
+
+
+# B, I, H, W, nblk (0 = automatic), packed weights, residual
+FWD = [(72, 32, 16, 16, 0, True, True), (72, 32, 16, 16, 1, False, False), (72, 32, 16, 16, 2, True, True), (70, 6, 16, 16, 2, True, False),
+       (300, 24, 8, 8, 0, True, False), (37, 24, 8, 8, 2, False, True), (37, 32, 8, 8, 1, True, True), (133, 32, 4, 4, 1, False, True),
+       (9, 17, 32, 32, 1, False, False), (3, 32, 16, 16, 2, True, True), (1, 32, 8, 8, 2, True, False)]
+
+
+@pytest.mark.parametrize('B,I,H,W,nblk,packed,res', FWD)
+def test_bulk_forward_matches_float64_and_the_per_layer_kernel(bulk, B, I, H, W, nblk, packed, res):
+    fc = importlib.import_module(bulk.__name__ + '.fused_conv')
+    N = bulk._native
+    torch.manual_seed(B + I)
+    has_bn = I == 32
+    x = torch.randn(B, I, H, W, device=DEV) * 1.5 + 0.3
+    w = torch.randn(32, I, 3, 3, device=DEV) * 0.08
+    bias = torch.randn(32, device=DEV) * 0.2
+    resid = torch.randn(B, 32, H, W, device=DEV) if res else None
+    gamma, beta = torch.rand(I, device=DEV) + 0.5, torch.randn(I, device=DEV) * 0.3
+    center = torch.randn(I, device=DEV) * 0.1
+    n = B * H * W
+    # the input BatchNorm's batch sums, as the producing launch leaves them: shifted by `center`, spread over the replicas
+    xs = (x - center.view(1, -1, 1, 1)).double()
+    s1 = torch.zeros(R, 32, device=DEV)
+    s2 = torch.zeros(R, 32, device=DEV)
+    s1[0, :I] = xs.sum((0, 2, 3)).float() * 0.25
+    s1[3, :I] = xs.sum((0, 2, 3)).float() * 0.75
+    s2[5, :I] = (xs * xs).sum((0, 2, 3)).float()
+    pack = None
+    if packed:
+        nimg = int(N.load().nf_conv_weight_pack_images(32, I, 3))
+        pack = torch.empty(nimg * N.header_constant('NF_CONV_PACK_IMAGE_FLOATS'), device=DEV)
+        import ctypes
+        d = fc.ConvPackDesc(w.data_ptr(), pack.data_ptr(), 32, I, 3, 0)
+        N.call('nf_conv_weight_pack', ctypes.addressof(d), 1, N.stream())
+
+    def run(on):
+        _cfg(bulk, on, 0, nblk)
+        out = torch.empty(B, 32, H, W, device=DEV)
+        st1, st2 = _replicas(), _replicas()
+        rm, rv = torch.zeros(I, device=DEV), torch.ones(I, device=DEV)
+        sm, si = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+        kw = dict(in_=x, weight=w, bias=bias, residual=resid, out=out, stat_sum=st1, stat_sqsum=st2, wpk=pack if on else None)
+        if has_bn:
+            kw.update(bn_gamma=gamma, bn_beta=beta, bn_sum=s1.view(-1), bn_sqsum=s2.view(-1), bn_center=center, bn_running_mean=rm,
+                      bn_running_var=rv, bn_save_mean=sm, bn_save_invstd=si)
+        fc._fwd((B, H, W), I, 32, 3, True, **kw)
+        torch.cuda.synchronize()
+        return out, st1.view(R, 32).sum(0), st2.view(R, 32).sum(0), rm, rv, sm, si
+
+    got = run(1)
+    old = run(0)
+    # float64 restatement
+    xd = x.double()
+    if has_bn:
+        mean = xd.mean((0, 2, 3))
+        var = xd.var((0, 2, 3), unbiased=False)
+        act = torch.relu((xd - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5) * gamma.double().view(1, -1, 1, 1)
+                         + beta.double().view(1, -1, 1, 1))
+    else:
+        act = xd
+    conv = TF.conv2d(act, w.double(), None, padding=1)
+    dv = conv + (resid.double() if res else 0.0)
+    want = dv + bias.double().view(1, -1, 1, 1)
+    scale = max(1.0, float(want.abs().max()))
+    # one-pass batch statistics of the per-layer contract (E[x^2] - E[x]^2 of shifted sums) limit how well the normalised input of
+    # EITHER kernel agrees with the two-pass float64 restatement; the two kernels see the same constants and agree much better
+    tol64 = 3e-5 * scale if has_bn else 1e-5 * scale
+    assert float((got[0].double() - want).abs().max()) <= tol64, ('vs float64', float((got[0].double() - want).abs().max()), tol64)
+    assert float((got[0] - old[0]).abs().max()) <= 1e-5 * scale, ('vs per-layer kernel', float((got[0] - old[0]).abs().max()))
+    G.assert_close(got[1], dv.sum((0, 2, 3)).float(), 2e-5 * max(1.0, float(dv.abs().sum((0, 2, 3)).max())), what='stat_sum')
+    G.assert_close(got[2], (dv * dv).sum((0, 2, 3)).float(), 2e-5 * float((dv * dv).sum((0, 2, 3)).max()), what='stat_sqsum')
+    if has_bn:
+        for a, b, what in zip(got[3:], old[3:], ('running_mean', 'running_var', 'save_mean', 'save_invstd')):
+            G.assert_close(a, b, 1e-6, rtol=1e-6, what=what)
+    assert n == B * H * W
+
+
+BWD = [(72, 32, 16, 16, 0, True, True), (72, 32, 16, 16, 2, False, False), (72, 32, 16, 16, 1, True, True), (70, 6, 16, 16, 2, True, True),
+       (300, 24, 8, 8, 0, True, True), (37, 32, 8, 8, 2, False, True), (37, 32, 8, 8, 1, True, False), (133, 32, 4, 4, 1, False, True),
+       (3, 32, 16, 16, 2, True, True), (5, 32, 32, 32, 1, True, False)]
+
+
+@pytest.mark.parametrize('B,I,H,W,nblk,packed,skip', BWD)
+def test_bulk_backward_data_pass_matches_float64_and_the_per_layer_kernel(bulk, B, I, H, W, nblk, packed, skip):
+    fc = importlib.import_module(bulk.__name__ + '.fused_conv')
+    N = bulk._native
+    torch.manual_seed(B * 3 + I)
+    has_bn = I == 32
+    n = B * H * W
+    x = torch.randn(B, I, H, W, device=DEV)                  # forward input of the layer (pre-BatchNorm when has_bn)
+    w = torch.randn(32, I, 3, 3, device=DEV) * 0.08
+    out = torch.randn(B, 32, H, W, device=DEV) * 2.0 + 0.5     # forward output = the consumer BatchNorm's input
+    gn_src = torch.randn(B, 32, H, W, device=DEV)
+    g_skip = torch.randn(B, 32, H, W, device=DEV) if skip else None
+    gamma, beta = torch.rand(I, device=DEV) + 0.5, torch.randn(I, device=DEV) * 0.3
+    cgamma = torch.rand(32, device=DEV) + 0.5
+    xd, od, gd = x.double(), out.double(), gn_src.double()
+    mean = xd.mean((0, 2, 3)) if has_bn else None
+    invstd = 1.0 / torch.sqrt(xd.var((0, 2, 3), unbiased=False) + 1e-5) if has_bn else None
+    cmean = od.mean((0, 2, 3))
+    cinvstd = 1.0 / torch.sqrt(od.var((0, 2, 3), unbiased=False) + 1e-5)
+    xh = (od - cmean.view(1, -1, 1, 1)) * cinvstd.view(1, -1, 1, 1)
+    sum_g_c = gd.sum((0, 2, 3))
+    sum_gx_c = (gd * xh).sum((0, 2, 3))
+    cs1, cs2 = torch.zeros(R, 32, device=DEV), torch.zeros(R, 32, device=DEV)
+    cs1[1] = sum_g_c.float() * 0.5
+    cs1[6] = sum_g_c.float() * 0.5
+    cs2[2] = sum_gx_c.float()
+    pack = None
+    if packed:
+        import ctypes
+        nimg = int(N.load().nf_conv_weight_pack_images(32, I, 3))
+        pack = torch.empty(nimg * N.header_constant('NF_CONV_PACK_IMAGE_FLOATS'), device=DEV)
+        d = fc.ConvPackDesc(w.data_ptr(), pack.data_ptr(), 32, I, 3, 0)
+        N.call('nf_conv_weight_pack', ctypes.addressof(d), 1, N.stream())
+
+    def run(on):
+        _cfg(bulk, on, 0, nblk)
+        g_store = torch.zeros(B, 32, H, W, device=DEV)
+        gn_out = torch.zeros(B, I, H, W, device=DEV)
+        sg, sgx = _replicas(), _replicas()
+        kw = dict(in_=x, weight=w, gn_src=gn_src, out=out, g_skip=g_skip, g_store=g_store, gn_out=gn_out, cbn_gamma=cgamma,
+                  cbn_save_mean=cmean.float(), cbn_save_invstd=cinvstd.float(), cbn_sum_g=cs1.view(-1), cbn_sum_gx=cs2.view(-1),
+                  wpk=pack if on else None)
+        if has_bn:
+            kw.update(bn_gamma=gamma, bn_beta=beta, bn_save_mean=mean.float(), bn_save_invstd=invstd.float(), sum_g=sg, sum_gx=sgx)
+        fc._bwd((B, H, W), I, 32, 3, **kw)
+        torch.cuda.synchronize()
+        return g_store, gn_out, sg.view(R, 32).sum(0), sgx.view(R, 32).sum(0)
+
+    got = run(1)
+    old = run(0)
+    Gd = cgamma.double().view(1, -1, 1, 1) * cinvstd.view(1, -1, 1, 1) * (gd - (sum_g_c / n).view(1, -1, 1, 1) - xh * (sum_gx_c / n).view(1, -1, 1, 1))
+    if skip:
+        Gd = Gd + g_skip.double()
+    gin = TF.conv_transpose2d(Gd, w.double(), None, padding=1)
+    if has_bn:
+        xhat = (xd - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        pre = xhat * gamma.double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)
+        risky = pre.abs() < 1e-5                         # ReLU decisions within fp32 rounding of the kink: either side is correct
+        gn = torch.where(pre > 0, gin, torch.zeros_like(gin))
+    else:
+        risky = torch.zeros_like(gin, dtype=torch.bool)
+        gn = gin
+    sG = max(1.0, float(Gd.abs().max()))
+    assert float((got[0].double() - Gd).abs().max()) <= 1e-5 * sG, ('g_store vs float64', float((got[0].double() - Gd).abs().max()))
+    assert float((got[0] - old[0]).abs().max()) <= 1e-5 * sG
+    sg_ = max(1.0, float(gn.abs().max()))
+    err = (got[1].double() - gn).abs()
+    err[risky] = 0.0
+    assert float(err.max()) <= 1e-5 * sg_, ('gn_out vs float64', float(err.max()), sg_)
+    err = (got[1] - old[1]).abs()
+    err[risky] = 0.0
+    assert float(err.max()) <= 1e-5 * sg_, ('gn_out vs per-layer kernel', float(err.max()))
+    if has_bn:
+        nr = int(risky.sum())
+        slack = nr * sg_ * 4.0
+        want_sg, want_sgx = gn.sum((0, 2, 3)), (gn * xhat).sum((0, 2, 3))
+        G.assert_close(got[2][:I], want_sg.float(), 2e-5 * max(1.0, float(gn.abs().sum((0, 2, 3)).max())) + slack, what='sum_g')
+        G.assert_close(got[3][:I], want_sgx.float(), 2e-5 * max(1.0, float((gn * xhat).abs().sum((0, 2, 3)).max())) + slack, what='sum_gx')
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('I,O,H,W,B', [(6, 12, 16, 16, 160), (24, 48, 8, 8, 520), (12, 24, 16, 8, 300)])
+def test_convnet_beyond_the_chain_matches_modules(bulk, I, O, H, W, B, training):
+    """the whole conditioner at a batch beyond the persistent chain (per-layer launches: the 3x3 layers on conv_bulk.hip), forward,
+    input gradient, every parameter gradient and the running statistics against the module stack"""
+    from tests.test_gpu_convnet import _close_but_for, _nets, _risky_samples
+    fc = importlib.import_module(bulk.__name__ + '.fused_conv')
+    _cfg(bulk, 1, 16385, 0)
+    a, b = _nets(bulk, I, O)
+    a.train(training)
+    b.train(training)
+    x1 = (torch.randn(B, I, H, W, device=DEV)).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    assert fc.convnet_usable(a, x1) and not fc._chain_usable(B, I, O, H, W)
+    state = copy.deepcopy(b.state_dict())
+    risky = _risky_samples(b, x1)
+    b.load_state_dict(state)
+    y1, y2 = a(x1), b(x2)
+    G.assert_close(y1, y2, 2e-4, rtol=1e-4, what='output')
+    wgt = torch.randn_like(y2)
+    (y1 * wgt).sum().backward()
+    (y2 * wgt).sum().backward()
+    tol = lambda t: 2e-4 * max(1.0, float(t.abs().max()))
+    _close_but_for(x1.grad, x2.grad, tol(x2.grad), risky, 'input grad')
+    loose = 2500.0 if bool(risky.any()) else 5.0
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for name, p in pb.items():
+        assert pa[name].grad is not None, name
+        pre_bn_bias = training and name.endswith('module.bias') and 'out_block' not in name
+        t = 5e-3 + 3e-6 * B * H * W if pre_bn_bias else loose * tol(p.grad)
+        G.assert_close(pa[name].grad, p.grad, t, what='grad ' + name)
+    ba, bb = dict(a.named_buffers()), dict(b.named_buffers())
+    for name in bb:
+        G.assert_close(ba[name].float(), bb[name].float(), 1e-5, rtol=1e-5, what='buffer ' + name)
