@@ -25,6 +25,18 @@
 
 #include "nf_bf16x3.h"
 
+// phase stamps of wave 0 of workgroup 0 (tools/probes/bulk_prof.py builds this file with -DNF_CB_PROF=1; 100 MHz wall clock)
+#ifdef NF_CB_PROF
+__device__ long long nf_cb_prof[64];
+#define NF_CB_STAMP(i)                                                                 \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 64) nf_cb_prof[i] = wall_clock64(); \
+    } while (0)
+extern "C" int nf_cb_prof_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cb_prof), sizeof(long long) * 64); }
+#else
+#define NF_CB_STAMP(i)
+#endif
+
 #define NF_CB_WAVES 4
 #define NF_CB_THREADS (NF_CB_WAVES * NF_WAVE)
 #define NF_CB_MAXIT 7                                 // items (channel octet, frame position) per lane: ceil(4 * FSZ / 64), FSZ <= 112
@@ -84,10 +96,16 @@ static int nf_cb_plan(NfCbGeo& cg, int64_t B, int C, int H, int W, int noct, int
 }
 
 // ---- per-lane description of the frame items, invariant over the units of a launch -------------------------------------------------
+// All global traffic of the unit loop goes through buffer descriptors (base = a wave-uniform pointer per unit, 2 GB window): a lane's
+// part of an address is a 32-bit byte offset that does not depend on the unit, an entry that does not exist for a unit (halo row
+// outside the sample, sample outside the batch, channel beyond the tensor) gets the offset 0xffffffff -- out of range: the load
+// returns 0, the store is dropped -- so there is no branch and no 64-bit address arithmetic in the loop.
+#define NF_CB_OOB 0xffffffffu
+#define NF_CB_WINDOW 0x7fffffff
 struct NfCbItems {
-    int off[NF_CB_MAXIT];        // element offset of channel 8 o of the item from the unit's base pointer (channel stride HW)
+    unsigned voff[NF_CB_MAXIT];  // byte offset of (channel 8 o, frame position) from the unit's base - (W + 1) elements (channel stride HW)
     unsigned lds[NF_CB_MAXIT];   // float offset of the item's 16 bytes inside a frame plane
-    unsigned meta;               // 4 bits per item: class (0 never valid, 1 inside, 2 top halo row, 3 bottom halo row) | 4 * (channel mask short)
+    unsigned meta;               // 4 bits per item: class (0 never valid, 1 inside, 2 top halo row, 3 bottom halo row) | 4: the item exists
     unsigned seg;                // 4 bits per item: sample of the unit (units of several whole samples)
     unsigned nch;                // 4 bits per item: valid channels of the octet - 1 (0 .. 7)
     unsigned oct;                // 4 bits per item: channel octet
@@ -99,7 +117,7 @@ __device__ __forceinline__ void nf_cb_items(NfCbItems& it, const NfCbGeo& cg, in
 #pragma unroll
     for (int k = 0; k < NF_CB_MAXIT; ++k) {
         const int id = lane + NF_WAVE * k;
-        int off = 0; unsigned lds = 0u, cls = 0u, sj = 0u, nch = 0u, oc_ = 0u;
+        unsigned off = 0u, lds = 0u, cls = 0u, sj = 0u, nch = 0u, oc_ = 0u;
         if (k < cg.nit && id < total) {
             const int o = id / g.FSZ, f = id - o * g.FSZ;
             const int sm = (int)(((float)f + 0.5f) * g.invFS), q = f - sm * g.FS;            // (as nf_cv_decode)
@@ -112,12 +130,12 @@ __device__ __forceinline__ void nf_cb_items(NfCbItems& it, const NfCbGeo& cg, in
             if (gx >= 0 && gx < g.W) {
                 if (g.SEG == 1) cls = fyh < 0 ? 2u : (fyh >= g.TH ? 3u : 1u);
                 else cls = (fyh >= 0 && fyh < g.TH) ? 1u : 0u;
-                off = (sm * cg.C + 8 * o) * g.HW + fyh * g.W + gx;
+                off = 4u * (unsigned)((sm * cg.C + 8 * o) * g.HW + (fyh + 1) * g.W + gx + 1);
                 sj = (unsigned)sm;
             }
-            cls |= 4u;                                 // bit 2: the item exists (its frame entry is written, zeros when not valid)
+            cls |= 4u;
         }
-        it.off[k] = off;
+        it.voff[k] = off;
         it.lds[k] = lds;
         it.meta |= cls << (4 * k);
         it.seg |= sj << (4 * k);
@@ -125,15 +143,9 @@ __device__ __forceinline__ void nf_cb_items(NfCbItems& it, const NfCbGeo& cg, in
         it.oct |= oc_ << (4 * k);
     }
 }
-// validity of item k for a unit: top / bottom halo rows exist inside the sample, the sample exists inside the batch
-__device__ __forceinline__ bool nf_cb_valid(const NfCbItems& it, int k, bool top, bool bottom, int nsamp) {
-    const unsigned cls = (it.meta >> (4 * k)) & 3u;
-    const int s = (int)((it.seg >> (4 * k)) & 15u);
-    return (cls == 1u || (cls == 2u && top) || (cls == 3u && bottom)) && s < nsamp;
-}
 
-struct NfCbUnit {            // where a unit lies
-    int64_t base;            // element offset of (sample b0, channel 0, row y0, column 0) in a (B, C, H, W) tensor of cg.C channels
+struct NfCbUnit {            // where a unit lies (wave-uniform)
+    int64_t base;            // element offset of (sample b0, channel 0, row y0, column 0) in a (B, C, H, W) tensor
     bool top, bottom;        // halo rows inside the sample (units of whole rows)
     int nsamp;               // samples of the unit inside the batch (units of whole samples), else 1
 };
@@ -150,27 +162,51 @@ __device__ __forceinline__ NfCbUnit nf_cb_unit(const NfCbGeo& cg, int64_t u, int
     un.nsamp = g.SEG == 1 ? 1 : (int)(left < g.SEG ? left : g.SEG);
     return un;
 }
+// the items' byte offsets for a unit (0xffffffff where the entry does not exist) and the mask of the existing ones
+struct NfCbVo { unsigned v[NF_CB_MAXIT]; unsigned ok; };
+__device__ __forceinline__ void nf_cb_offsets(NfCbVo& vo, const NfCbItems& it, const NfCbGeo& cg, const NfCbUnit& un) {
+    vo.ok = 0u;
+#pragma unroll
+    for (int k = 0; k < NF_CB_MAXIT; ++k) {
+        const unsigned cls = (it.meta >> (4 * k)) & 3u;
+        const int s = (int)((it.seg >> (4 * k)) & 15u);
+        const bool ok = (cls == 1u || (cls == 2u && un.top) || (cls == 3u && un.bottom)) && s < un.nsamp;
+        vo.v[k] = ok ? it.voff[k] : NF_CB_OOB;
+        vo.ok |= (ok ? 1u : 0u) << k;
+    }
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t nf_cb_rsrc(const float* p) {
+    // (the pointer is wave-uniform -- it derives from the wave's unit -- but not provably so: pin it to scalar registers)
+    const uint64_t a = (uint64_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, NF_CB_WINDOW, 0x00020000);
+}
+__device__ __forceinline__ float nf_cb_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void nf_cb_st(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, soff, 0);
+}
 
-// raw values of one tensor for a unit: every load unconditional (clamped to the unit's first element) and in flight together
+// raw values of one tensor for a unit: <= 56 unconditional loads per lane, all in flight together.  RAGGED: the last octet holds
+// fewer than eight channels (the first layer of a conditioner): those loads are switched off like the missing frame entries.
 struct NfCbRaw { float v[NF_CB_MAXIT][8]; };
-__device__ __forceinline__ void nf_cb_issue(NfCbRaw& r, const float* __restrict__ t, const NfCbItems& it, const NfCbGeo& cg, const NfCbUnit& un) {
-    const float* base = t + un.base;
-    const int HW = cg.g.HW;
+template <bool RAGGED>
+__device__ __forceinline__ void nf_cb_issue(NfCbRaw& r, const float* __restrict__ t, const NfCbVo& vo, const NfCbItems& it, const NfCbGeo& cg,
+                                            const NfCbUnit& un) {
+    const __amdgpu_buffer_rsrc_t rs = nf_cb_rsrc(t + un.base - (cg.g.W + 1));
+    const int cstride = 4 * cg.g.HW;
 #pragma unroll
     for (int k = 0; k < NF_CB_MAXIT; ++k)
         if (k < cg.nit) {                              // wave-uniform
-            const bool ok = nf_cb_valid(it, k, un.top, un.bottom, un.nsamp);
             const int nch = (int)((it.nch >> (4 * k)) & 15u);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = (ok && j <= nch) ? it.off[k] + j * HW : 0;
-                r.v[k][j] = base[e];
-            }
+            for (int j = 0; j < 8; ++j) r.v[k][j] = nf_cb_ld(rs, (RAGGED && j > nch) ? NF_CB_OOB : vo.v[k], j * cstride);
         }
 }
 
-// the weight image of the layer -> LDS: direct global -> LDS loads of a packed image, or split here from the (32, I, 3, 3) / (32 = O, I,
-// 3, 3) weights (forward: slot tap * noct + o, row oc, K = input channel; transposed: slot (8 - tap) * 4 + o, row ic, K = output channel)
+// the weight image of the layer -> LDS: direct global -> LDS loads of a packed image, or split here from the (32, I, 3, 3) weights
+// (forward: slot tap * noct + o, row oc, K = input channel; transposed: slot (8 - tap) * 4 + o, row ic, K = output channel)
 template <bool TR>
 __device__ __forceinline__ void nf_cb_weights(float* W8, const float* __restrict__ wpk, const float* __restrict__ w, int I, int noct) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -179,8 +215,7 @@ __device__ __forceinline__ void nf_cb_weights(float* W8, const float* __restrict
         for (int c = wid; c < CH; c += NF_CB_WAVES)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wpk + c * 256 + lane * 4),
                                              (__attribute__((address_space(3))) void*)(W8 + c * 256), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
+        return;                                        // (the caller waits: s_waitcnt vmcnt(0) in front of its barrier)
     }
     for (int item = threadIdx.x; item < NF_CC_WSLOTS * 32; item += NF_CB_THREADS) {
         const int slot = item >> 5, row = item & 31;
@@ -203,160 +238,235 @@ __device__ __forceinline__ void nf_cb_weights(float* W8, const float* __restrict
     }
 }
 
+// eight values -> the three bf16 planes of a frame entry (16-byte stores)
+__device__ __forceinline__ void nf_cb_put8(float* p, int FPs, const float (&v)[8]) {
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        bf16x2 h2, m2, l2;
+        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
+        h[j] = h2[0]; h[j + 1] = h2[1]; m[j] = m2[0]; m[j + 1] = m2[1]; l[j] = l2[0]; l[j + 1] = l2[1];
+    }
+    *(bf16x8*)(p) = h;
+    *(bf16x8*)(p + FPs) = m;
+    *(bf16x8*)(p + 2 * FPs) = l;
+}
+
 // ---- the K loop of a unit: acc[nb] += W8(slot)[row] * F8(tap offset, octet)[pixel of block nb] over the pairs of slots (2 p, 2 p + 1) ----
 // NOCT octets of K channels per tap; the wave half hs takes slot 2 p + hs; a dead second slot of an odd last pair reads the image's
-// zero slot.  One pair of operands in flight ahead of the matrix instructions; the two pixel blocks share every weight read.
+// zero slot.  The operands of pair p + 1 are requested BEFORE the matrix instructions of pair p (scheduling barriers keep the
+// compiler from sinking the reads to their use: with one wave per SIMD nothing else hides an LDS round trip); the two pixel blocks
+// share every weight read and alternate in the matrix pipe (independent accumulators back to back).
+//   wa = W8 + hs * 128 + 4 * row (floats);  fb[nb] = F8 + 4 * fpos[nb] (+ hs * 4 * CS when NOCT is even)
 template <int NOCT, int NBLK>
-__device__ __forceinline__ void nf_cb_kloop(f32x16 (&accs)[NBLK], const float* W8, const float* F8, int CS, int FW, const int (&fpos)[NBLK],
-                                            int row, int hs) {
+__device__ __forceinline__ void nf_cb_kloop(f32x16 (&accs)[NBLK], const float* wa, const float* const (&fb)[NBLK], int CS, int FW, int hs) {
     constexpr int NSLOT = 9 * NOCT, NP = (NSLOT + 1) / 2;
     const int FPs = NF_CC_FP(CS);
-    bf16x8 a[2][3], b[2][NBLK][3];
-#define NF_CB_LOAD(BUF, P)                                                                                     \
+    bf16x8 a[3][3], b[3][NBLK][3];
+    // operand reads of a pair in two halves: the weights + the first pixel block's planes, then the remaining blocks
+#define NF_CB_FO(P)                                                                                            \
+    const int s0 = 2 * (P), s1 = 2 * (P) + 1;                                                                  \
+    const int t0 = s0 / NOCT, o0 = s0 - t0 * NOCT;                                                             \
+    const int t1 = s1 < NSLOT ? s1 / NOCT : 4, o1 = s1 < NSLOT ? s1 - (s1 / NOCT) * NOCT : 0;                 \
+    const int d0 = 4 * ((t0 / 3 - 1) * FW + (t0 % 3 - 1)) + o0 * 4 * CS;                                       \
+    const int d1 = 4 * ((t1 / 3 - 1) * FW + (t1 % 3 - 1)) + o1 * 4 * CS;                                       \
+    const int fo = (NOCT % 2 == 0) ? d0 : (hs ? d1 : d0);
+#define NF_CB_LOAD_A(BUF, P)                                                                                   \
     do {                                                                                                       \
-        const int s0 = 2 * (P), s1 = 2 * (P) + 1;                                                              \
-        const int t0 = s0 / NOCT, o0 = s0 - t0 * NOCT;                                                         \
-        const int t1 = s1 < NSLOT ? s1 / NOCT : 4, o1 = s1 < NSLOT ? s1 - (s1 / NOCT) * NOCT : 0;             \
-        const int d0 = (t0 / 3 - 1) * FW + (t0 % 3 - 1), d1 = (t1 / 3 - 1) * FW + (t1 % 3 - 1);                \
-        const int fo = hs ? o1 * 4 * CS + 4 * d1 : o0 * 4 * CS + 4 * d0;                                       \
-        const float* wa = W8 + (2 * (P) + hs) * NF_CC_WSLOT + 4 * row;                                         \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) a[BUF][q] = *(const bf16x8*)(wa + q * NF_CB_WP);         \
-        _Pragma("unroll") for (int nb = 0; nb < NBLK; ++nb) {                                                  \
-            const float* fb = F8 + fo + 4 * fpos[nb];                                                          \
-            _Pragma("unroll") for (int q = 0; q < 3; ++q) b[BUF][nb][q] = *(const bf16x8*)(fb + q * FPs);      \
-        }                                                                                                      \
+        NF_CB_FO(P)                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) a[BUF][q] = *(const bf16x8*)(wa + (P) * 2 * NF_CC_WSLOT + q * NF_CB_WP); \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) b[BUF][0][q] = *(const bf16x8*)(fb[0] + fo + q * FPs);   \
     } while (0)
-    NF_CB_LOAD(0, 0);
+#define NF_CB_LOAD_B(BUF, P)                                                                                   \
+    do {                                                                                                       \
+        NF_CB_FO(P)                                                                                            \
+        _Pragma("unroll") for (int nb = 1; nb < NBLK; ++nb)                                                    \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) b[BUF][nb][q] = *(const bf16x8*)(fb[nb] + fo + q * FPs); \
+    } while (0)
+#define NF_CB_STEP(BUF, AQ, BQ)                                                                                              \
+    _Pragma("unroll") for (int nb = 0; nb < NBLK; ++nb)                                                                      \
+        accs[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BUF][AQ], b[BUF][nb][BQ], accs[nb], 0, 0, 0)
+    // The operands of pair p + 2 are requested in the middle of the matrix instructions of pair p: a wave issues in order, so reads
+    // placed behind a pair's last matrix instruction would only start when that instruction has issued, and the next pair would wait
+    // a full LDS round trip for them; two pairs ahead, every read has a pair's worth of matrix time (>= 190 cycles) to come back.
+    NF_CB_LOAD_A(0, 0); NF_CB_LOAD_B(0, 0);
+    if (NP > 1) { NF_CB_LOAD_A(1, 1); NF_CB_LOAD_B(1, 1); }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (p + 1 < NP) NF_CB_LOAD((p + 1) & 1, p + 1);
-        // the six products of a pair, the pixel blocks interleaved (independent accumulators back to back)
-#define NF_CB_STEP(AQ, BQ)                                                                                                   \
-    _Pragma("unroll") for (int nb = 0; nb < NBLK; ++nb)                                                                      \
-        accs[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p & 1][AQ], b[p & 1][nb][BQ], accs[nb], 0, 0, 0)
-        NF_CB_STEP(0, 2);
-        NF_CB_STEP(2, 0);
-        NF_CB_STEP(1, 1);
-        NF_CB_STEP(0, 1);
-        NF_CB_STEP(1, 0);
-        NF_CB_STEP(0, 0);
-#undef NF_CB_STEP
+        NF_CB_STEP(p % 3, 0, 2); NF_CB_STEP(p % 3, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 2 < NP) NF_CB_LOAD_A((p + 2) % 3, p + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        NF_CB_STEP(p % 3, 1, 1); NF_CB_STEP(p % 3, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 2 < NP && NBLK > 1) NF_CB_LOAD_B((p + 2) % 3, p + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        NF_CB_STEP(p % 3, 1, 0); NF_CB_STEP(p % 3, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
-#undef NF_CB_LOAD
+#undef NF_CB_FO
+#undef NF_CB_LOAD_A
+#undef NF_CB_LOAD_B
+#undef NF_CB_STEP
+}
+
+// per-lane byte offsets of the pixels a lane finishes (rows of the 32 x 32 result = channels, columns = the block's pixels), from the
+// unit's base in a (B, C, H, W) tensor: pixel p of the unit -> (sample p >> lgHW) * C * HW + (p & (HW - 1)), + the lane half's rows
+__device__ __forceinline__ unsigned nf_cb_pix_off(const NfCvGeo& g, int C, int p, int hs) {
+    const int s = g.SEG == 1 ? 0 : p >> g.lgHW, q = g.SEG == 1 ? p : p & (g.HW - 1);
+    return 4u * (unsigned)(s * C * g.HW + q + 4 * hs * g.HW);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NOCT, int NBLK>
+template <int NOCT, int NBLK, bool RAGGED, bool HAS_BN, bool HAS_RES>
 __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_fwd(nf_conv_desc d, NfCbGeo cg, int I, int training, float eps, float mom) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const NfCvGeo& g = cg.g;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c32 = lane & 31, hs = lane >> 5;
     float* W8 = smem;
     float* F8 = W8 + 3 * NF_CB_WP + wid * 3 * NF_CC_FP(g.CS);
     float* kc = smem + 3 * NF_CB_WP + NF_CB_WAVES * 3 * NF_CC_FP(g.CS);      // [2][32] scale, shift (+ 7 unused rows)
     float* red = kc + 9 * 32;
-    const bool has_bn = d.bn_gamma != nullptr;
-    const bool has_res = d.residual != nullptr;
+    constexpr bool has_bn = HAS_BN, has_res = HAS_RES;
     const int64_t Npx = g.B * g.HW;
+    const int FPs = NF_CC_FP(g.CS);
     constexpr int UPX = 32 * NBLK;
 
-    nf_cv_bn_consts_fwd(kc, d, I, Npx, training, eps, mom);
-    nf_cb_weights<false>(W8, d.wpk, d.weight, I, NOCT);
+    NF_CB_STAMP(0);
+    nf_cb_weights<false>(W8, d.wpk, d.weight, I, NOCT);      // (a packed image: asynchronous global -> LDS loads, waited for below)
     NfCbItems it;
     nf_cb_items(it, cg, lane);
-    int fpos[NBLK];
+    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
+    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
+    NfCbRaw raw;
+    NfCbUnit un;
+    NfCbVo vo;
+    unsigned okm = 0u;                                 // existing items of the unit whose raw values are in flight
+    if (u < cg.units) {                                // the first unit's requests travel under the weight staging
+        un = nf_cb_unit(cg, u, I, UPX);
+        nf_cb_offsets(vo, it, cg, un);
+        okm = vo.ok;
+        nf_cb_issue<RAGGED>(raw, d.in, vo, it, cg, un);
+    }
+    NF_CB_STAMP(1);
+    nf_cv_bn_consts_fwd(kc, d, I, Npx, training, eps, mom);
+    const float* wa = W8 + hs * NF_CC_WSLOT + 4 * c32;
+    const float* fb[NBLK];
+    unsigned poff[NBLK];
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) fpos[nb] = nf_cv_frame_of(g, nb * 32 + c32);
+    for (int nb = 0; nb < NBLK; ++nb) {
+        fb[nb] = F8 + 4 * nf_cv_frame_of(g, nb * 32 + c32) + ((NOCT % 2 == 0) ? hs * 4 * g.CS : 0);
+        poff[nb] = nf_cb_pix_off(g, 32, nb * 32 + c32, hs);
+    }
     float bias_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias_r[r] = d.bias[nf_cv_cd_row(r, hs)];
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-    // zero the frame once: entries that are no item (none: every (octet < NOCT, position < FSZ) is one) and the octets >= NOCT are never read
+    const int rstride = 4 * g.HW;                      // bytes between channel planes
+    NF_CB_STAMP(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight image (direct global -> LDS loads) has landed
     __syncthreads();                                   // weights and constants are in LDS; the only barrier of the launch
-
-    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
-    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
-    NfCbRaw raw;
-    NfCbUnit un;
-    if (u < cg.units) {
-        un = nf_cb_unit(cg, u, I, UPX);
-        nf_cb_issue(raw, d.in, it, cg, un);
-    }
+    NF_CB_STAMP(3);
+#ifdef NF_CB_PROF
+    int pu = 0;
+#endif
     for (; u < cg.units; u += stride) {
+#ifdef NF_CB_PROF
+        NF_CB_STAMP(4 + 8 * pu);
+#endif
         // ---- the unit's frame: BatchNorm + ReLU, zeros outside the image, split, three 16-byte stores per item ----
 #pragma unroll
         for (int k = 0; k < NF_CB_MAXIT; ++k)
-            if (k < cg.nit) {
-                const unsigned meta = (it.meta >> (4 * k)) & 15u;
-                if (meta & 4u) {
-                    const bool ok = nf_cb_valid(it, k, un.top, un.bottom, un.nsamp);
-                    const int nch = (int)((it.nch >> (4 * k)) & 15u);
+            if (k < cg.nit) {                          // wave-uniform
+                if ((it.meta >> (4 * k)) & 4u) {
+                    const bool ok = (okm >> k) & 1u;
                     const int o = (int)((it.oct >> (4 * k)) & 15u);
+                    const int nch = (int)((it.nch >> (4 * k)) & 15u);
                     float v[8];
+                    if (has_bn) {                      // (compile time) the octet's constants: four 16-byte reads, one wait
+                        const f32x4 sc0 = *(const f32x4*)(kc + 8 * o), sc1 = *(const f32x4*)(kc + 8 * o + 4);
+                        const f32x4 sh0 = *(const f32x4*)(kc + 32 + 8 * o), sh1 = *(const f32x4*)(kc + 32 + 8 * o + 4);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float x = raw.v[k][j];
-                        if (has_bn) x = fmaxf(fmaf(x, kc[8 * o + j], kc[32 + 8 * o + j]), 0.f);
-                        v[j] = (ok && j <= nch) ? x : 0.f;
-                    }
-                    float* p = F8 + it.lds[k];
-                    bf16x8 h, m, l;
+                        for (int j = 0; j < 8; ++j) {
+                            const float x = fmaxf(fmaf(raw.v[k][j], j < 4 ? sc0[j & 3] : sc1[j & 3], j < 4 ? sh0[j & 3] : sh1[j & 3]), 0.f);
+                            v[j] = (ok && (!RAGGED || j <= nch)) ? x : 0.f;
+                        }
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        bf16x2 h2, m2, l2;
-                        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
-                        h[j] = h2[0]; h[j + 1] = h2[1]; m[j] = m2[0]; m[j + 1] = m2[1]; l[j] = l2[0]; l[j + 1] = l2[1];
+                        for (int j = 0; j < 8; ++j) v[j] = raw.v[k][j];      // (0 where the entry does not exist)
                     }
-                    *(bf16x8*)(p) = h;
-                    *(bf16x8*)(p + NF_CC_FP(g.CS)) = m;
-                    *(bf16x8*)(p + 2 * NF_CC_FP(g.CS)) = l;
+                    nf_cb_put8(F8 + it.lds[k], FPs, v);
                 }
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef NF_CB_PROF
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        NF_CB_STAMP(5 + 8 * pu);
+#endif
         // ---- requests of the next unit, and this unit's residual, in flight under the K loop ----
-        const int64_t un_next = u + stride;
+        const int64_t obase = nf_cb_unit(cg, u, 32, UPX).base;
         const int64_t P0 = u * UPX;
+        const int64_t un_next = u + stride;
         if (un_next < cg.units) {
             un = nf_cb_unit(cg, un_next, I, UPX);
-            nf_cb_issue(raw, d.in, it, cg, un);
+            nf_cb_offsets(vo, it, cg, un);
+            okm = vo.ok;
+            nf_cb_issue<RAGGED>(raw, d.in, vo, it, cg, un);
         }
+        unsigned po[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) po[nb] = (P0 + nb * 32 + c32 < Npx) ? poff[nb] : NF_CB_OOB;
         float res[NBLK][16];
-        int64_t oidx[NBLK];
-        bool pv[NBLK];
+        if (has_res) {
+            const __amdgpu_buffer_rsrc_t rr = nf_cb_rsrc(d.residual + obase);
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) {
-            const int64_t P = P0 + nb * 32 + c32;
-            pv[nb] = P < Npx;
-            const int64_t b = pv[nb] ? P >> g.lgHW : 0, q = pv[nb] ? P & (g.HW - 1) : 0;
-            oidx[nb] = b * 32 * g.HW + q;
+            for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) res[nb][r] = has_res ? d.residual[oidx[nb] + (int64_t)nf_cv_cd_row(r, hs) * g.HW] : 0.f;
+                for (int r = 0; r < 16; ++r) res[nb][r] = nf_cb_ld(rr, po[nb], ((r & 3) + 8 * (r >> 2)) * rstride);
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[nb][r] = 0.f;
         }
         f32x16 acc[NBLK];
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        nf_cb_kloop<NOCT, NBLK>(acc, W8, F8, g.CS, g.FW, fpos, c32, hs);
+#ifdef NF_CB_PROF
+        NF_CB_STAMP(6 + 8 * pu);
+#endif
+        nf_cb_kloop<NOCT, NBLK>(acc, wa, fb, g.CS, g.FW, hs);
         __builtin_amdgcn_wave_barrier();               // (the frame is rewritten only after the last operand read was issued)
+#ifdef NF_CB_PROF
+        if (acc[0][0] == 123.456f) bias_r[0] += 1.f;   // (the stamp waits for the accumulators)
+        NF_CB_STAMP(7 + 8 * pu);
+#endif
         // ---- bias, residual, store (32 consecutive pixels of a channel plane per instruction), batch sums shifted by the bias ----
+        // (pixels outside the batch: their frame is zero, their residual reads 0 -> they add nothing to the sums; their store is dropped)
+        const __amdgpu_buffer_rsrc_t ro = nf_cb_rsrc(d.out + obase);
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
-            if (pv[nb]) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float dv = acc[nb][r] + res[nb][r];
-                    d.out[oidx[nb] + (int64_t)nf_cv_cd_row(r, hs) * g.HW] = dv + bias_r[r];
-                    s1[r] += dv;
-                    s2[r] = fmaf(dv, dv, s2[r]);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float dv = acc[nb][r] + res[nb][r];
+                nf_cb_st(ro, po[nb], ((r & 3) + 8 * (r >> 2)) * rstride, dv + bias_r[r]);
+                s1[r] += dv;
+                s2[r] = fmaf(dv, dv, s2[r]);
             }
+#ifdef NF_CB_PROF
+        NF_CB_STAMP(8 + 8 * pu);
+        ++pu;
+#endif
     }
+    NF_CB_STAMP(60);
     if (d.stat_sum != nullptr) {                       // block-uniform
         const float t1 = nf_cv_butterfly16(s1, c32), t2 = nf_cv_butterfly16(s2, c32);
         if ((c32 & 1) == 0) {
@@ -373,27 +483,46 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_fwd(nf_conv_desc d
             atomicAdd((hs == 0 ? d.stat_sum : d.stat_sqsum) + rep + c32, t);
         }
     }
+    NF_CB_STAMP(61);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // backward, data gradient: G = g_skip + BNbwd(gn_src; out) assembled into the frame (g_store = G at the pixels the unit owns),
 // gn_out = (transposed convolution of G) * [act > 0] with its two batch sums, or the plain input gradient without an input BatchNorm
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int NBLK, bool SKIP>
+template <int NBLK, bool SKIP, bool HAS_BN>
 __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_desc d, NfCbGeo cg, int I) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const NfCvGeo& g = cg.g;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c32 = lane & 31, hs = lane >> 5;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c32 = lane & 31, hs = lane >> 5;
     float* W8 = smem;
     float* F8 = W8 + 3 * NF_CB_WP + wid * 3 * NF_CC_FP(g.CS);
     float* cb = smem + 3 * NF_CB_WP + NF_CB_WAVES * 3 * NF_CC_FP(g.CS);      // [5][32] consumer BatchNorm: c1, mean, invstd, mean g, mean g xhat
     float* kc = cb + 5 * 32;                                                   // [4][32] input BatchNorm: scale, shift, mean, invstd
     float* red = kc + 4 * 32;
-    const bool has_bn = d.bn_gamma != nullptr;
+    constexpr bool has_bn = HAS_BN;
     const int64_t Npx = g.B * g.HW;
     const float invN = 1.f / (float)Npx;
+    const int FPs = NF_CC_FP(g.CS);
     constexpr int UPX = 32 * NBLK;
 
+    nf_cb_weights<true>(W8, d.wpk, d.weight, I, 4);
+    NfCbItems it;
+    nf_cb_items(it, cg, lane);
+    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
+    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
+    NfCbRaw rs, ro, rk;                                // gn_src, out, g_skip of the unit whose frame is built next
+    NfCbUnit un;
+    NfCbVo vo;
+    unsigned okm = 0u;
+    if (u < cg.units) {
+        un = nf_cb_unit(cg, u, 32, UPX);
+        nf_cb_offsets(vo, it, cg, un);
+        okm = vo.ok;
+        nf_cb_issue<false>(rs, d.gn_src, vo, it, cg, un);
+        nf_cb_issue<false>(ro, d.out, vo, it, cg, un);
+        if (SKIP) nf_cb_issue<false>(rk, d.g_skip, vo, it, cg, un);
+    }
     if (threadIdx.x < 32) {
         const int oo = threadIdx.x;
         const float invstd = d.cbn_save_invstd[oo], mean = d.cbn_save_mean[oo];
@@ -416,113 +545,106 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_de
         }
         kc[k] = sc; kc[32 + k] = sh; kc[64 + k] = mean; kc[96 + k] = invstd;
     }
-    nf_cb_weights<true>(W8, d.wpk, d.weight, I, 4);
-    NfCbItems it;
-    nf_cb_items(it, cg, lane);
-    int fpos[NBLK];
+    const float* wa = W8 + hs * NF_CC_WSLOT + 4 * c32;
+    const float* fb[NBLK];
+    unsigned poff[NBLK];
 #pragma unroll
-    for (int nb = 0; nb < NBLK; ++nb) fpos[nb] = nf_cv_frame_of(g, nb * 32 + c32);
+    for (int nb = 0; nb < NBLK; ++nb) {
+        fb[nb] = F8 + 4 * nf_cv_frame_of(g, nb * 32 + c32) + hs * 4 * g.CS;
+        poff[nb] = nf_cb_pix_off(g, I, nb * 32 + c32, hs);
+    }
     float sg[16], sgx[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sg[r] = 0.f; sgx[r] = 0.f; }
+    const int rstride = 4 * g.HW;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
-    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
-    NfCbRaw rs, ro, rk;                                // gn_src, out, g_skip of the unit whose frame is built next
-    NfCbUnit un;
-    if (u < cg.units) {
-        un = nf_cb_unit(cg, u, 32, UPX);
-        nf_cb_issue(rs, d.gn_src, it, cg, un);
-        nf_cb_issue(ro, d.out, it, cg, un);
-        if (SKIP) nf_cb_issue(rk, d.g_skip, it, cg, un);
-    }
     for (; u < cg.units; u += stride) {
+        const int64_t gbase = nf_cb_unit(cg, u, 32, UPX).base;               // this unit in the 32-channel tensors
+        const __amdgpu_buffer_rsrc_t rg = nf_cb_rsrc(d.g_store != nullptr ? d.g_store + gbase - (g.W + 1) : d.out);
 #pragma unroll
         for (int k = 0; k < NF_CB_MAXIT; ++k)
             if (k < cg.nit) {
                 const unsigned meta = (it.meta >> (4 * k)) & 15u;
                 if (meta & 4u) {
-                    const bool ok = nf_cb_valid(it, k, un.top, un.bottom, un.nsamp);
+                    const bool ok = (okm >> k) & 1u;
                     const int o = (int)((it.oct >> (4 * k)) & 15u);
                     float v[8];
+                    f32x4 q[5][2];                     // the octet's five constants: ten 16-byte reads, one wait
+#pragma unroll
+                    for (int a = 0; a < 5; ++a) { q[a][0] = *(const f32x4*)(cb + 32 * a + 8 * o); q[a][1] = *(const f32x4*)(cb + 32 * a + 8 * o + 4); }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int c = 8 * o + j;
-                        const float xh = (ro.v[k][j] - cb[32 + c]) * cb[64 + c];
-                        float G = cb[c] * (rs.v[k][j] - cb[96 + c] - xh * cb[128 + c]);
+                        const float xh = (ro.v[k][j] - q[1][j >> 2][j & 3]) * q[2][j >> 2][j & 3];
+                        float G = q[0][j >> 2][j & 3] * (rs.v[k][j] - q[3][j >> 2][j & 3] - xh * q[4][j >> 2][j & 3]);
                         if (SKIP) G = rk.v[k][j] + G;
                         v[j] = ok ? G : 0.f;
                     }
-                    if (d.g_store != nullptr && ok && (meta & 3u) == 1u) {
-                        float* gs = d.g_store + un.base + it.off[k];
+                    if (d.g_store != nullptr) {        // G at the pixels the unit owns (class 1: inside, never a halo row)
+                        const unsigned so = (ok && (meta & 3u) == 1u) ? it.voff[k] : NF_CB_OOB;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) gs[j * g.HW] = v[j];
+                        for (int j = 0; j < 8; ++j) nf_cb_st(rg, so, j * rstride, v[j]);
                     }
-                    float* p = F8 + it.lds[k];
-                    bf16x8 h, m, l;
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        bf16x2 h2, m2, l2;
-                        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
-                        h[j] = h2[0]; h[j + 1] = h2[1]; m[j] = m2[0]; m[j + 1] = m2[1]; l[j] = l2[0]; l[j + 1] = l2[1];
-                    }
-                    *(bf16x8*)(p) = h;
-                    *(bf16x8*)(p + NF_CC_FP(g.CS)) = m;
-                    *(bf16x8*)(p + 2 * NF_CC_FP(g.CS)) = l;
+                    nf_cb_put8(F8 + it.lds[k], FPs, v);
                 }
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int64_t un_next = u + stride;
+        const int64_t ibase = nf_cb_unit(cg, u, I, UPX).base;
         const int64_t P0 = u * UPX;
+        const int64_t un_next = u + stride;
         if (un_next < cg.units) {
             un = nf_cb_unit(cg, un_next, 32, UPX);
-            nf_cb_issue(rs, d.gn_src, it, cg, un);
-            nf_cb_issue(ro, d.out, it, cg, un);
-            if (SKIP) nf_cb_issue(rk, d.g_skip, it, cg, un);
+            nf_cb_offsets(vo, it, cg, un);
+            okm = vo.ok;
+            nf_cb_issue<false>(rs, d.gn_src, vo, it, cg, un);
+            nf_cb_issue<false>(ro, d.out, vo, it, cg, un);
+            if (SKIP) nf_cb_issue<false>(rk, d.g_skip, vo, it, cg, un);
         }
         // forward input of the pixels this lane finishes (rows of the result = input channels)
+        unsigned po[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) po[nb] = (P0 + nb * 32 + c32 < Npx) ? poff[nb] : NF_CB_OOB;
         float xin[NBLK][16];
-        int64_t iidx[NBLK];
-        bool pv[NBLK];
+        if (has_bn) {
+            const __amdgpu_buffer_rsrc_t ri = nf_cb_rsrc(d.in + ibase);
 #pragma unroll
-        for (int nb = 0; nb < NBLK; ++nb) {
-            const int64_t P = P0 + nb * 32 + c32;
-            pv[nb] = P < Npx;
-            const int64_t b = pv[nb] ? P >> g.lgHW : 0, q = pv[nb] ? P & (g.HW - 1) : 0;
-            iidx[nb] = b * I * g.HW + q;
+            for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ic = nf_cv_cd_row(r, hs);
-                xin[nb][r] = (has_bn && ic < I) ? d.in[iidx[nb] + (int64_t)ic * g.HW] : 0.f;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int ic = nf_cv_cd_row(r, hs);
+                    xin[nb][r] = nf_cb_ld(ri, ic < I ? po[nb] : NF_CB_OOB, ((r & 3) + 8 * (r >> 2)) * rstride);
+                }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xin[nb][r] = 0.f;
         }
         f32x16 acc[NBLK];
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        nf_cb_kloop<4, NBLK>(acc, W8, F8, g.CS, g.FW, fpos, c32, hs);
+        nf_cb_kloop<4, NBLK>(acc, wa, fb, g.CS, g.FW, hs);
         __builtin_amdgcn_wave_barrier();
-        if (d.gn_out != nullptr) {
+        if (d.gn_out != nullptr) {                     // block-uniform
+            const __amdgpu_buffer_rsrc_t rn = nf_cb_rsrc(d.gn_out + ibase);
 #pragma unroll
             for (int nb = 0; nb < NBLK; ++nb)
-                if (pv[nb]) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ic = nf_cv_cd_row(r, hs);
-                        if (ic < I) {
-                            float gn = acc[nb][r];
-                            if (has_bn) {
-                                const float x = xin[nb][r];
-                                gn = fmaf(x, kc[ic], kc[32 + ic]) > 0.f ? gn : 0.f;
-                                sg[r] += gn;
-                                sgx[r] = fmaf(gn, (x - kc[64 + ic]) * kc[96 + ic], sgx[r]);
-                            }
-                            d.gn_out[iidx[nb] + (int64_t)ic * g.HW] = gn;
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int ic = nf_cv_cd_row(r, hs);
+                    float gn = acc[nb][r];
+                    if (has_bn) {
+                        const float x = xin[nb][r];
+                        gn = fmaf(x, kc[ic], kc[32 + ic]) > 0.f ? gn : 0.f;
+                        gn = po[nb] != NF_CB_OOB ? gn : 0.f;       // (a pixel outside the batch: x read 0, but shift alone may be > 0)
+                        sg[r] += gn;
+                        sgx[r] = fmaf(gn, (x - kc[64 + ic]) * kc[96 + ic], sgx[r]);
                     }
+                    nf_cb_st(rn, ic < I ? po[nb] : NF_CB_OOB, ((r & 3) + 8 * (r >> 2)) * rstride, gn);
                 }
         }
     }
@@ -582,12 +704,25 @@ int nf_conv_bulk_fwd(const nf_conv_desc* desc, int64_t B, int I, int H, int W, i
     const size_t lds = sizeof(float) * nf_cb_lds_floats(cg.g.CS);
     const int64_t wgs = (cg.units + NF_CB_WAVES - 1) / NF_CB_WAVES;
     const unsigned grid = (unsigned)(wgs < nf_cb_cus() ? wgs : nf_cb_cus());
+    const bool has_bn = desc->bn_gamma != nullptr, has_res = desc->residual != nullptr;
     int rc = 0;
+#define NF_CB_FWD3(NOCT_, NBLK_, RG_, BN_, RS_)                                                                                         \
+    do {                                                                                                                                \
+        rc = nf_cb_optin(k_conv3_bulk_fwd<NOCT_, NBLK_, RG_, BN_, RS_>);                                                                \
+        if (rc == 0)                                                                                                                    \
+            hipLaunchKernelGGL((k_conv3_bulk_fwd<NOCT_, NBLK_, RG_, BN_, RS_>), dim3(grid), dim3(NF_CB_THREADS), lds, st, *desc, cg, I, training, eps, mom); \
+    } while (0)
+#define NF_CB_FWD2(NOCT_, NBLK_, RG_)                                                                                                   \
+    do {                                                                                                                                \
+        if (has_bn && has_res) NF_CB_FWD3(NOCT_, NBLK_, RG_, true, true);                                                               \
+        else if (has_bn) NF_CB_FWD3(NOCT_, NBLK_, RG_, true, false);                                                                    \
+        else if (has_res) NF_CB_FWD3(NOCT_, NBLK_, RG_, false, true);                                                                   \
+        else NF_CB_FWD3(NOCT_, NBLK_, RG_, false, false);                                                                               \
+    } while (0)
 #define NF_CB_FWD(NOCT_, NBLK_)                                                                                                         \
     do {                                                                                                                                \
-        rc = nf_cb_optin(k_conv3_bulk_fwd<NOCT_, NBLK_>);                                                                               \
-        if (rc == 0)                                                                                                                    \
-            hipLaunchKernelGGL((k_conv3_bulk_fwd<NOCT_, NBLK_>), dim3(grid), dim3(NF_CB_THREADS), lds, st, *desc, cg, I, training, eps, mom); \
+        if (I % 8) NF_CB_FWD2(NOCT_, NBLK_, true);                                                                                      \
+        else NF_CB_FWD2(NOCT_, NBLK_, false);                                                                                           \
     } while (0)
     if (nblk == 2) {
         switch (noct) {
@@ -605,6 +740,8 @@ int nf_conv_bulk_fwd(const nf_conv_desc* desc, int64_t B, int I, int H, int W, i
         }
     }
 #undef NF_CB_FWD
+#undef NF_CB_FWD2
+#undef NF_CB_FWD3
     if (rc) return rc;
     NF_CHECK_LAUNCH();
     return 0;
@@ -633,9 +770,15 @@ int nf_conv_bulk_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int H, int 
     int rc = 0;
 #define NF_CB_BWD(NBLK_, SKIP_)                                                                                                \
     do {                                                                                                                       \
-        rc = nf_cb_optin(k_conv3_bulk_bwd<NBLK_, SKIP_>);                                                                      \
-        if (rc == 0)                                                                                                           \
-            hipLaunchKernelGGL((k_conv3_bulk_bwd<NBLK_, SKIP_>), dim3(grid), dim3(NF_CB_THREADS), lds, st, *desc, cg, I);      \
+        if (desc->bn_gamma != nullptr) {                                                                                       \
+            rc = nf_cb_optin(k_conv3_bulk_bwd<NBLK_, SKIP_, true>);                                                            \
+            if (rc == 0)                                                                                                       \
+                hipLaunchKernelGGL((k_conv3_bulk_bwd<NBLK_, SKIP_, true>), dim3(grid), dim3(NF_CB_THREADS), lds, st, *desc, cg, I); \
+        } else {                                                                                                               \
+            rc = nf_cb_optin(k_conv3_bulk_bwd<NBLK_, SKIP_, false>);                                                           \
+            if (rc == 0)                                                                                                       \
+                hipLaunchKernelGGL((k_conv3_bulk_bwd<NBLK_, SKIP_, false>), dim3(grid), dim3(NF_CB_THREADS), lds, st, *desc, cg, I); \
+        }                                                                                                                      \
     } while (0)
     if (nblk == 2) {
         if (skip) NF_CB_BWD(2, true);
