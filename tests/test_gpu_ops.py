@@ -709,9 +709,10 @@ def test_bf16_split_is_no_precision_reduction(nf, K):
         ref = A.double() @ Bm.double()
         mag = float((A.double().abs() @ Bm.double().abs()).max())
         out = []
+        Ad, Bd = A.to(DEV).contiguous(), Bm.to(DEV).contiguous()     # (held: a temporary's block would be handed to the next temporary)
         for mode in (0, 1):
             D = torch.empty(32, 32, device=DEV)
-            N.call('nf_selftest_gemm32', N.ptr(A.to(DEV).contiguous()), N.ptr(Bm.to(DEV).contiguous()), N.ptr(D), K, mode, N.stream())
+            N.call('nf_selftest_gemm32', N.ptr(Ad), N.ptr(Bd), N.ptr(D), K, mode, N.stream())
             torch.cuda.synchronize()
             out.append(float((D.cpu().double() - ref).abs().max()))
         e_fp32, e_split = out
