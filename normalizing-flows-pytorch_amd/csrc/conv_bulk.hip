@@ -666,6 +666,346 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_de
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight gradient: g_weff[tap][oc][ic] = sum_px G[oc][px] act[ic][px + tap], G and act as in the data pass.  The contraction runs
+// over PIXELS, so both operands of v_mfma_f32_32x32x16_bf16 are eight consecutive pixels of one channel per lane: frames in LDS are
+// bf16 planes [channel][row][pixel] (three planes per tensor: the three-way split).  A tap's dy is a row offset of the activation
+// operand; its dx = +-1 would break the 16-byte groups, so the operand is read ONCE per (row, plane) with the dword on either side
+// and the two shifted variants are formed in registers (v_alignbit_b32: 8 VALU per plane and row against 18 matrix instructions).
+// A workgroup is eight waves with two jobs (one of each per SIMD, so the hardware overlaps them without any software pipelining):
+//   waves 0..3 WALK: wave w owns K steps 2 w, 2 w + 1 (16 pixels each) of every 128-pixel tile for all nine taps -- nine 32 x 32
+//     accumulators (144 registers), the G operand read once per K step and used by nine taps x six products;
+//   waves 4..7 FILL: the next tile's loads (16-byte, coalesced: a lane takes four pixels of a channel), BatchNorm backward on G /
+//     BatchNorm + ReLU on the activations, the split, 8-byte LDS stores into the other frame pair; the tile after that is requested
+//     before the barrier, so its loads have a whole tile's matrix time to land.
+// ONE barrier per tile.  The workgroup walks tiles blockIdx.x + k gridDim.x of layer blockIdx.y and leaves one slab (T, O, I) and
+// its bias sums, exactly as k_conv_bn_wgrad_multi does (same slab count: nf_conv_wgrad_slabs), so nf_slab_sum is unchanged.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define NF_CBW_THREADS 512
+#define NF_CBW_FILL 256                                // filling threads
+#define NF_CBW_GCH 272                                 // bytes per channel of a G plane: 128 pixels x 2 B + 16 (17 x 16: b128 reads conflict-free)
+#define NF_CBW_MAXR 6                                  // activation items (channel, four pixels) per filling thread: ceil(32 NQ / 256), NQ <= 48
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct NfCbwGeo {
+    int H, W, HW, lgW, lgHW, lgSP;
+    int TH, SEG;                                       // rows per segment, segments (samples) per 128-pixel tile
+    int RSB;                                           // bytes per activation frame row: 2 (W + 4) -- four zero pixels behind every row
+    int ACH;                                           // bytes per channel of an activation plane: 8 + SEG (TH + 2) RSB (+ 8 if needed: 8 x odd)
+    int NQ;                                            // (row, four-pixel) items per channel and tile: SEG (TH + 2) W / 4
+    int nr;                                            // activation items per filling thread
+    int64_t B, tiles;
+};
+struct NfCbwMulti { nf_conv_bwd_desc d[NF_CONV_WGRAD_MAX]; };
+static inline size_t nf_cbw_buf_bytes(const NfCbwGeo& g) { return (size_t)3 * 32 * (g.ACH + NF_CBW_GCH); }
+static inline size_t nf_cbw_lds_bytes(const NfCbwGeo& g) { return 2 * nf_cbw_buf_bytes(g) + 7 * 32 * sizeof(float); }
+static bool nf_cbw_geometry(NfCbwGeo& g, int64_t B, int H, int W) {
+    if (B < 1 || H < 1 || W < 8 || W > 64) return false;
+    g.H = H; g.W = W; g.HW = H * W; g.B = B;
+    g.lgW = nf_cv_log2(W); g.lgHW = nf_cv_log2(g.HW);
+    if (g.lgW < 0 || g.lgHW < 0) return false;
+    if (g.HW >= 128) { g.TH = 128 / W; g.SEG = 1; }
+    else { if (g.HW < 16) return false; g.TH = H; g.SEG = 128 / g.HW; }
+    g.lgSP = nf_cv_log2(g.TH * W);
+    g.RSB = 2 * (W + 4);
+    g.ACH = 8 + g.SEG * (g.TH + 2) * g.RSB;
+    if (((g.ACH >> 3) & 1) == 0) g.ACH += 8;
+    g.NQ = g.SEG * (g.TH + 2) * (W / 4);
+    g.nr = (32 * g.NQ + NF_CBW_FILL - 1) / NF_CBW_FILL;
+    if (g.nr > NF_CBW_MAXR) return false;
+    g.tiles = (B * g.HW + 127) / 128;
+    return nf_cbw_lds_bytes(g) <= 160 * 1024 && 2 * nf_cbw_buf_bytes(g) >= 9 * 1024 * sizeof(float);
+}
+// 16 bytes at a wave-uniform base + a per-lane 32-bit byte offset; entries that do not exist read a safe offset and are zeroed by
+// their mask.  (Loaded as f32x4: __builtin_bit_cast(float, v[j]) on an ELEMENT of an integer vector reads element 0 with this
+// toolchain -- a one-dword load whose value fills all four pixels.)
+typedef const __attribute__((address_space(1))) char* nf_gptr;     // (a pointer rebuilt from integers is generic otherwise: flat loads)
+__device__ __forceinline__ nf_gptr nf_cbw_base(const float* p) {
+    const uint64_t a = (uint64_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (nf_gptr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ f32x4 nf_cbw_ld128(nf_gptr base, unsigned off) {
+    return *(const __attribute__((address_space(1))) f32x4*)(base + off);
+}
+// four consecutive pixels of one channel -> 8 bytes in each of the three planes
+__device__ __forceinline__ void nf_cbw_put4(char* p, int plane_bytes, const float (&v)[4]) {
+    bf16x2 h0, m0, l0, h1, m1, l1;
+    nf_cc_split2(f32x2{v[0], v[1]}, h0, m0, l0);
+    nf_cc_split2(f32x2{v[2], v[3]}, h1, m1, l1);
+    *(bf16x4*)(p) = bf16x4{h0[0], h0[1], h1[0], h1[1]};
+    *(bf16x4*)(p + plane_bytes) = bf16x4{m0[0], m0[1], m1[0], m1[1]};
+    *(bf16x4*)(p + 2 * plane_bytes) = bf16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+__global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti m, NfCbwGeo g, int I) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const nf_conv_bwd_desc& d = m.d[blockIdx.y];
+    char* const lds = (char*)smem;
+    const int PA = 32 * g.ACH, PG = 32 * NF_CBW_GCH;  // bytes per activation / G plane
+    const int BUF = 3 * (PA + PG);                     // a frame pair: act planes h | m | l, G planes h | m | l
+    float* cst = (float*)(lds + 2 * BUF);              // [5][32] consumer BatchNorm: c1, mean, invstd, mean g, mean g xhat | [2][32] input BatchNorm: scale, shift
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), c32 = lane & 31, hs = lane >> 5;
+    const bool walker = wid < 4;
+    const bool has_bn = d.bn_gamma != nullptr, has_src = d.gn_src != nullptr;
+    const int64_t Npx = g.B * g.HW;
+
+    // ---- prologue: zero the frames (the padding is never written again), constants ----
+    for (int e = tid; e < 2 * BUF / 16; e += NF_CBW_THREADS) *(u32x4*)(lds + 16 * e) = u32x4{0u, 0u, 0u, 0u};
+    if (tid < 32) {
+        const int oo = tid;
+        float c1 = 0.f, mean = 0.f, invstd = 0.f, mg = 0.f, mgx = 0.f;
+        if (has_src) {
+            invstd = d.cbn_save_invstd[oo]; mean = d.cbn_save_mean[oo]; c1 = d.cbn_gamma[oo] * invstd;
+            if (d.cbn_sum_g != nullptr) {
+#pragma unroll
+                for (int r = 0; r < NF_STAT_REPL; ++r) { mg += d.cbn_sum_g[32 * r + oo]; mgx += d.cbn_sum_gx[32 * r + oo]; }
+                const float invN = 1.f / (float)Npx;
+                mg *= invN; mgx *= invN;
+            }
+        }
+        cst[oo] = c1; cst[32 + oo] = mean; cst[64 + oo] = invstd; cst[96 + oo] = mg; cst[128 + oo] = mgx;
+    } else if (tid < 64) {
+        const int k = tid - 32;
+        float sc = 1.f, sh = 0.f;
+        if (has_bn && k < I) {
+            const float mean = d.bn_save_mean[k], invstd = d.bn_save_invstd[k];
+            sc = d.bn_gamma[k] * invstd;
+            sh = d.bn_beta[k] - mean * sc;
+        }
+        cst[160 + k] = sc; cst[192 + k] = sh;
+    }
+    __syncthreads();
+
+    const int64_t tile0 = blockIdx.x, tstep = gridDim.x;
+    f32x16 acc[9];
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (walker) {
+        // =========================================== WALK ===========================================
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // the wave's two K steps: pixels 16 k + 8 hs .. + 7 of the tile -> byte offsets of the operands inside a plane
+        int aoff[2], boff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = 16 * (2 * wid + j) + 8 * hs;
+            const int sg = pp >> g.lgSP, q = pp & ((1 << g.lgSP) - 1), row = q >> g.lgW, x0 = q & (g.W - 1);
+            aoff[j] = c32 * NF_CBW_GCH + 2 * pp;
+            boff[j] = c32 * g.ACH + 8 + (sg * (g.TH + 2) + row + 1) * g.RSB + 2 * x0;
+        }
+        __syncthreads();                               // frame pair 0 is complete (the fillers' matching barrier follows their first convert)
+        int it = 0;
+        for (int64_t tile = tile0; tile < g.tiles; tile += tstep, ++it) {
+            const char* fa = lds + (it & 1) * BUF;     // activation planes
+            const char* fg = fa + 3 * PA;              // G planes
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = *(const bf16x8*)(fg + q * PG + aoff[j]);
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    bf16x8 b[3][3];                    // [dx + 1][plane]
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const char* bp = fa + q * PA + boff[j] + dy * g.RSB;
+                        const u32x2 lo = *(const u32x2*)(bp), hi = *(const u32x2*)(bp + 8);
+                        const unsigned prev = *(const unsigned*)(bp - 4), next = *(const unsigned*)(bp + 16);
+                        b[1][q] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+                        b[0][q] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(lo[0], prev, 16), __builtin_amdgcn_alignbit(lo[1], lo[0], 16),
+                                                                   __builtin_amdgcn_alignbit(hi[0], lo[1], 16), __builtin_amdgcn_alignbit(hi[1], hi[0], 16)});
+                        b[2][q] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(hi[0], lo[1], 16),
+                                                                   __builtin_amdgcn_alignbit(hi[1], hi[0], 16), __builtin_amdgcn_alignbit(next, hi[1], 16)});
+                    }
+                    // six products per tap (NF_CC_MFMA6's order), the three taps of the row interleaved: independent accumulators back to back
+#define NF_CBW_STEP(AQ, BQ)                                                                                                                  \
+    _Pragma("unroll") for (int dx = 0; dx < 3; ++dx)                                                                                         \
+        acc[3 * (dy + 1) + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[AQ], b[dx][BQ], acc[3 * (dy + 1) + dx], 0, 0, 0)
+                    NF_CBW_STEP(0, 2); NF_CBW_STEP(2, 0); NF_CBW_STEP(1, 1); NF_CBW_STEP(0, 1); NF_CBW_STEP(1, 0); NF_CBW_STEP(0, 0);
+#undef NF_CBW_STEP
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // =========================================== FILL ===========================================
+        const int ft = tid - NF_CBW_FILL;              // 0 .. 255
+        // G items: round r -> channel 8 r + ft / 32, pixels 4 (ft % 32) .. + 3 of the tile
+        const int gq4 = ft & 31, gch0 = ft >> 5;
+        const int gpx = 4 * gq4;
+        const int gsg = g.SEG == 1 ? 0 : gpx >> g.lgHW, gqq = g.SEG == 1 ? gpx : gpx & (g.HW - 1);
+        const unsigned goff0 = 4u * (unsigned)((gsg * 32 + gch0) * g.HW + gqq);       // + r * 8 channels
+        const unsigned gcstep = 4u * 8u * (unsigned)g.HW;
+        const int glds0 = gch0 * NF_CBW_GCH + 8 * gq4;                                 // + r * 8 * GCH
+        float kc1[4], kmean[4], kinv[4], kmg[4], kmgx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 8 * r + gch0;
+            kc1[r] = cst[c]; kmean[r] = cst[32 + c]; kinv[r] = cst[64 + c]; kmg[r] = cst[96 + c]; kmgx[r] = cst[128 + c];
+        }
+        // activation items: i = 256 r + ft -> channel i / NQ, item j = i % NQ -> (segment, frame row, four-pixel group)
+        unsigned xoff[NF_CBW_MAXR];
+        int xlds[NF_CBW_MAXR];
+        float xsc[NF_CBW_MAXR], xsh[NF_CBW_MAXR];
+        unsigned xmeta = 0u;                           // 4 bits per item: class (0 never, 1 inside, 2 top halo row, 3 bottom halo row) | 4: exists; segment in xseg
+        unsigned xseg = 0u;
+        const int QW = g.W >> 2, RW = g.TH + 2;
+#pragma unroll
+        for (int r = 0; r < NF_CBW_MAXR; ++r) {
+            const int i = NF_CBW_FILL * r + ft;
+            unsigned off = 0u, cls = 0u, sg = 0u;
+            int ldo = 0;
+            float sc = 1.f, sh = 0.f;
+            if (r < g.nr && i < 32 * g.NQ) {
+                const int ch = i / g.NQ, j = i - ch * g.NQ;
+                const int rw = j / QW, xq = j - rw * QW;
+                const int sm = rw / RW, frow = rw - sm * RW;
+                ldo = ch * g.ACH + 8 + rw * g.RSB + 8 * xq;
+                cls = 4u;
+                if (ch < I) {
+                    cls |= frow == 0 ? 2u : (frow == g.TH + 1 ? 3u : 1u);
+                    off = 4u * (unsigned)((sm * I + ch) * g.HW + frow * g.W + 4 * xq);   // from (sample b0, channel 0, row y0 - 1)
+                    sg = (unsigned)sm;
+                    sc = cst[160 + ch]; sh = cst[192 + ch];
+                }
+            }
+            xoff[r] = off; xlds[r] = ldo; xsc[r] = sc; xsh[r] = sh;
+            xmeta |= cls << (4 * r);
+            xseg |= sg << (4 * r);
+        }
+        f32x4 rd[4], rk[4], rs[4], ro[4], rx[NF_CBW_MAXR];
+        unsigned gok = 0u, xok = 0u;                   // validity of the tile in flight
+        auto issue = [&](int64_t tile) {
+            const int64_t P0 = tile * 128;
+            const int64_t b0 = P0 >> g.lgHW;
+            const int q0 = g.SEG == 1 ? (int)(P0 & (g.HW - 1)) : 0;
+            const int y0 = q0 >> g.lgW;
+            const int64_t gbase = b0 * 32 * g.HW + q0;
+            const bool pv = b0 + gsg < g.B;
+            gok = pv ? 1u : 0u;
+            unsigned go[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) go[r] = pv ? goff0 + (unsigned)r * gcstep : 0u;      // (offset 0: the tile's first pixel exists)
+            if (d.g_direct != nullptr) {
+                nf_gptr rr = nf_cbw_base(d.g_direct + gbase);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rd[r] = nf_cbw_ld128(rr, go[r]);
+            }
+            if (d.g_skip != nullptr) {
+                nf_gptr rr = nf_cbw_base(d.g_skip + gbase);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rk[r] = nf_cbw_ld128(rr, go[r]);
+            }
+            if (has_src) {
+                nf_gptr r3 = nf_cbw_base(d.gn_src + gbase);
+                nf_gptr r4 = nf_cbw_base(d.out + gbase);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rs[r] = nf_cbw_ld128(r3, go[r]); ro[r] = nf_cbw_ld128(r4, go[r]); }
+            }
+            nf_gptr rxs = nf_cbw_base(d.in + b0 * I * g.HW + (int64_t)(y0 - 1) * g.W);
+            const unsigned xsafe = 4u * (unsigned)g.W;     // row y0 of channel 0 of sample b0: exists
+            const bool top = g.SEG == 1 && y0 > 0, bot = g.SEG == 1 && y0 + g.TH < g.H;
+            xok = 0u;
+#pragma unroll
+            for (int r = 0; r < NF_CBW_MAXR; ++r)
+                if (r < g.nr) {                        // uniform
+                    const unsigned cls = (xmeta >> (4 * r)) & 3u;
+                    const int64_t sm = (int64_t)((xseg >> (4 * r)) & 15u);
+                    const bool ok = (cls == 1u || (cls == 2u && top) || (cls == 3u && bot)) && b0 + sm < g.B;
+                    xok |= (ok ? 1u : 0u) << r;
+                    rx[r] = nf_cbw_ld128(rxs, ok ? xoff[r] : xsafe);
+                }
+        };
+        auto convert = [&](int buf) {
+            char* fa = lds + buf * BUF;
+            char* fg = fa + 3 * PA;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (d.g_direct != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = rd[r][j];
+                }
+                if (d.g_skip != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += rk[r][j];
+                }
+                if (has_src) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xh = (ro[r][j] - kmean[r]) * kinv[r];
+                        v[j] += kc1[r] * (rs[r][j] - kmg[r] - xh * kmgx[r]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gok ? v[j] : 0.f;
+                gsum[r] += (v[0] + v[1]) + (v[2] + v[3]);
+                nf_cbw_put4(fg + glds0 + r * 8 * NF_CBW_GCH, PG, v);
+            }
+#pragma unroll
+            for (int r = 0; r < NF_CBW_MAXR; ++r)
+                if (r < g.nr && ((xmeta >> (4 * r)) & 4u)) {
+                    const bool ok = (xok >> r) & 1u;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = rx[r][j];
+                        if (has_bn) x = fmaxf(fmaf(x, xsc[r], xsh[r]), 0.f);
+                        v[j] = ok ? x : 0.f;
+                    }
+                    nf_cbw_put4(fa + xlds[r], PA, v);
+                }
+        };
+        if (tile0 < g.tiles) {
+            issue(tile0);
+            convert(0);
+            if (tile0 + tstep < g.tiles) issue(tile0 + tstep);
+        }
+        __syncthreads();                               // frame pair 0 is complete
+        int it = 0;
+        for (int64_t tile = tile0; tile < g.tiles; tile += tstep, ++it) {
+            if (tile + tstep < g.tiles) {
+                convert((it + 1) & 1);
+                if (tile + 2 * tstep < g.tiles) issue(tile + 2 * tstep);
+            }
+            __syncthreads();
+        }
+    }
+    // (both roles have executed the same number of barriers: one before the loop, one per tile)
+    // ---- the four walkers' tap tiles meet in LDS (fixed order), one slab per workgroup ----
+    float* red = smem;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        if (walker && wid == pass) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* q = red + t * 1024 + nf_cv_cd_row(r, hs) * 32 + c32;
+                    *q = pass == 0 ? acc[t][r] : *q + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* slab = d.g_weff + (int64_t)blockIdx.x * 9 * 32 * I;
+    for (int e = tid; e < 9 * 1024; e += NF_CBW_THREADS) {
+        const int tap = e >> 10, oc = (e >> 5) & 31, ic = e & 31;
+        if (ic < I) slab[(tap * 32 + oc) * I + ic] = red[e];
+    }
+    if (!walker && d.g_bias != nullptr) {
+        const int ft = tid - NF_CBW_FILL;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = gsum[r];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, NF_WAVE);
+            if ((ft & 31) == 0) atomicAdd(d.g_bias + 256 * (blockIdx.x % NF_STAT_REPL) + 8 * r + (ft >> 5), v);
+        }
+    }
+}
+
 template <typename K>
 static inline int nf_cb_optin(K kernel) {
     static std::mutex mu;
@@ -743,6 +1083,29 @@ int nf_conv_bulk_fwd(const nf_conv_desc* desc, int64_t B, int I, int H, int W, i
 #undef NF_CB_FWD2
 #undef NF_CB_FWD3
     if (rc) return rc;
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// weight-gradient pass of up to NF_CONV_WGRAD_MAX layers of one shape (called by nf_conv_bn_wgrad_multi; 0 = the kernels of conv_bn.hip)
+int nf_conv_bulk_wgrad_plan(int64_t B, int I, int O, int H, int W, int ksize) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NF_CONV_BULK_WGRAD"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
+    if (!on || !nf_cb_on() || ksize != 3 || O != 32 || I < 1 || I > 32 || B * H * W < nf_cb_min_px()) return 0;
+    NfCbwGeo g;
+    return nf_cbw_geometry(g, B, H, W) ? 1 : 0;
+}
+int nf_conv_bulk_wgrad(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int H, int W, int slabs, hipStream_t st) {
+    NfCbwGeo g;
+    if (!nf_cbw_geometry(g, B, H, W) || n < 1 || n > NF_CONV_WGRAD_MAX || slabs < 1) return NF_E_BADARG;
+    NfCbwMulti m{};
+    for (int k = 0; k < n; ++k) m.d[k] = descs[k];
+    const size_t lds = nf_cbw_lds_bytes(g);
+    int rc = nf_cb_optin(k_conv3_bulk_wgrad);
+    if (rc) return rc;
+    const unsigned gx = (unsigned)(g.tiles < slabs ? g.tiles : slabs);
+    if ((int)gx != slabs) return NF_E_BADARG;          // (every slab the caller sums must be written)
+    hipLaunchKernelGGL(k_conv3_bulk_wgrad, dim3(gx, (unsigned)n), dim3(NF_CBW_THREADS), lds, st, m, g, I);
     NF_CHECK_LAUNCH();
     return 0;
 }

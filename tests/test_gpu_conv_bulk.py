@@ -228,3 +228,92 @@ def test_convnet_beyond_the_chain_matches_modules(bulk, I, O, H, W, B, training)
     ba, bb = dict(a.named_buffers()), dict(b.named_buffers())
     for name in bb:
         G.assert_close(ba[name].float(), bb[name].float(), 1e-5, rtol=1e-5, what='buffer ' + name)
+
+
+# B, I, H, W, layers in the launch, skip gradient, direct gradient, consumer BatchNorm (gn_src)
+WGRAD = [(72, 32, 16, 16, 3, True, False, True), (70, 6, 16, 16, 1, False, False, True), (301, 24, 8, 8, 2, True, False, True),
+         (37, 32, 8, 8, 16, False, True, False), (9, 17, 32, 32, 2, True, True, True), (3, 32, 16, 16, 1, True, False, True),
+         (130, 12, 16, 8, 2, False, False, True), (1, 32, 8, 8, 1, True, False, True)]
+
+
+@pytest.mark.parametrize('B,I,H,W,nl,skip,direct,src', WGRAD)
+def test_bulk_weight_gradient_matches_float64_and_the_per_layer_kernel(bulk, B, I, H, W, nl, skip, direct, src):
+    """nf_conv_bn_wgrad_multi on the pixel-contraction kernel (k_conv3_bulk_wgrad: bf16 planes [channel][row][pixel], dx taps by register
+    shifts, walking / filling waves): weight-gradient slabs (summed by nf_slab_sum into (O, I, 3, 3)) and bias sums of every layer of the
+    launch against float64 and against the per-layer kernel of conv_bn.hip on the same descriptors."""
+    import ctypes
+    fc = importlib.import_module(bulk.__name__ + '.fused_conv')
+    N = bulk._native
+    torch.manual_seed(B * 7 + I + nl)
+    has_bn = I == 32
+    n = B * H * W
+    layers = []
+    for _ in range(nl):
+        x = torch.randn(B, I, H, W, device=DEV)
+        out = torch.randn(B, 32, H, W, device=DEV) * 2.0 + 0.5
+        gn_src = torch.randn(B, 32, H, W, device=DEV) if src else None
+        g_skip = torch.randn(B, 32, H, W, device=DEV) if skip else None
+        g_direct = torch.randn(B, 32, H, W, device=DEV) if direct else None
+        gamma, beta = torch.rand(I, device=DEV) + 0.5, torch.randn(I, device=DEV) * 0.3
+        cgamma = torch.rand(32, device=DEV) + 0.5
+        xd, od = x.double(), out.double()
+        mean = xd.mean((0, 2, 3))
+        invstd = 1.0 / torch.sqrt(xd.var((0, 2, 3), unbiased=False) + 1e-5)
+        cmean = od.mean((0, 2, 3))
+        cinvstd = 1.0 / torch.sqrt(od.var((0, 2, 3), unbiased=False) + 1e-5)
+        Gd = torch.zeros(B, 32, H, W, dtype=torch.float64, device=DEV)
+        cs1, cs2 = torch.zeros(R, 32, device=DEV), torch.zeros(R, 32, device=DEV)
+        if src:
+            gd = gn_src.double()
+            xh = (od - cmean.view(1, -1, 1, 1)) * cinvstd.view(1, -1, 1, 1)
+            sg_c, sgx_c = gd.sum((0, 2, 3)), (gd * xh).sum((0, 2, 3))
+            cs1[2] = sg_c.float() * 0.5
+            cs1[7] = sg_c.float() * 0.5
+            cs2[4] = sgx_c.float()
+            Gd = cgamma.double().view(1, -1, 1, 1) * cinvstd.view(1, -1, 1, 1) * (gd - (sg_c / n).view(1, -1, 1, 1) - xh * (sgx_c / n).view(1, -1, 1, 1))
+        if skip:
+            Gd = Gd + g_skip.double()
+        if direct:
+            Gd = Gd + g_direct.double()
+        act = torch.relu((xd - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gamma.double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)) if has_bn else xd
+        want_w = torch.nn.grad.conv2d_weight(act, (32, I, 3, 3), Gd, padding=1)
+        want_b = Gd.sum((0, 2, 3))
+        kw = dict(in_=x, weight=torch.zeros(32, I, 3, 3, device=DEV), out=out, g_skip=g_skip, g_direct=g_direct)
+        if src:
+            kw.update(gn_src=gn_src, cbn_gamma=cgamma, cbn_save_mean=cmean.float(), cbn_save_invstd=cinvstd.float(), cbn_sum_g=cs1.view(-1), cbn_sum_gx=cs2.view(-1))
+        if has_bn:
+            kw.update(bn_gamma=gamma, bn_beta=beta, bn_save_mean=mean.float(), bn_save_invstd=invstd.float())
+        layers.append((kw, want_w, want_b, float((act.abs().sum() * 0 + 1)), act, Gd))
+
+    def run(on):
+        _cfg(bulk, on, 0, 0)
+        slabs = int(N.load().nf_conv_wgrad_slabs(B, H, W, nl))
+        arr = (fc.ConvBwdDesc * nl)()
+        regions, gbs, keep = [], [], []
+        for i, (kw, *_rest) in enumerate(layers):
+            region = torch.full((slabs * 32 * I * 9, ), float('nan'), device=DEV)
+            gb = torch.zeros(R * 256, device=DEV)
+            d = fc._desc(fc.ConvBwdDesc, g_weff=region, g_bias=gb, **kw)
+            ctypes.memmove(ctypes.addressof(arr) + i * ctypes.sizeof(fc.ConvBwdDesc), ctypes.addressof(d), ctypes.sizeof(fc.ConvBwdDesc))
+            regions.append(region)
+            gbs.append(gb)
+            keep.append(d)
+        N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), nl, B, I, 32, H, W, 3, N.stream())
+        outs = []
+        for region, gb in zip(regions, gbs):
+            g_w = torch.empty(32, I, 3, 3, device=DEV)
+            fc._slab_sum([(region, g_w, g_w.numel(), g_w.numel(), slabs, False, 9)])
+            outs.append((g_w, gb.view(R, 256).sum(0)[:32].clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    got, old = run(1), run(0)
+    for (kw, want_w, want_b, _, act, Gd), (gw, gb), (ow, ob) in zip(layers, got, old):
+        # the bar of a sum of n products: 1e-5 of the largest sum of |G| |act| over a tap
+        mag = float(torch.nn.grad.conv2d_weight(act.abs(), (32, I, 3, 3), Gd.abs(), padding=1).max())
+        assert bool(torch.isfinite(gw).all())
+        assert float((gw.double() - want_w).abs().max()) <= 1e-5 * max(1.0, mag), ('g_weff vs float64', float((gw.double() - want_w).abs().max()), mag)
+        assert float((gw - ow).abs().max()) <= 1e-5 * max(1.0, mag), ('g_weff vs per-layer kernel', float((gw - ow).abs().max()), mag)
+        magb = float(Gd.abs().sum((0, 2, 3)).max())
+        assert float((gb.double() - want_b).abs().max()) <= 2e-5 * max(1.0, magb), ('g_bias vs float64', float((gb.double() - want_b).abs().max()), magb)
+        assert float((gb - ob).abs().max()) <= 2e-5 * max(1.0, magb)

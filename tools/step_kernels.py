@@ -11,7 +11,7 @@ import os
 import sys
 from types import SimpleNamespace as NS
 
-STEPS = 10
+STEPS = int(os.environ.get("NF_STEPS", 10))
 
 
 def summarise(path):
