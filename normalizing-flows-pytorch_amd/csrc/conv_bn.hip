@@ -1027,7 +1027,9 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
     const int T = ksize * ksize;
     const size_t lds = sizeof(float) * ((size_t)32 * g.CS + (size_t)32 * OCB * g.CS + 5 * 32 + 4 * 32 + 2 * 4 * 32);
     const unsigned grid = (unsigned)nf_conv_wgrad_slabs(B, H, W, n);
-    if (nf_conv_bulk_wgrad_plan(B, I, O, H, W, ksize))  // large batches: the pixel-contraction kernel of conv_bulk.hip (bf16 matrix pipe)
+    bool one_plain = true;                             // (conv_bulk.hip keeps ONE plain gradient tensor per layer in flight)
+    for (int k = 0; k < n; ++k) one_plain = one_plain && !(m.d[k].g_direct != nullptr && m.d[k].g_skip != nullptr);
+    if (one_plain && nf_conv_bulk_wgrad_plan(B, I, O, H, W, ksize))  // large batches: the pixel-contraction kernel of conv_bulk.hip (bf16 matrix pipe)
         return nf_conv_bulk_wgrad(m.d, n, B, I, H, W, (int)grid, (hipStream_t)stream);
     const int iters = (int)((g.tiles + grid - 1) / grid);
     hipStream_t st = (hipStream_t)stream;

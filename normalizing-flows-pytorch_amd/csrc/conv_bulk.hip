@@ -17,6 +17,7 @@
 // k_conv3_bulk_bwd (32 -> I <= 32 channels, transposed image).  Same results as conv_bn.hip's kernels to fp32 rounding.
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <unordered_set>
 
 #include "nf_common.h"
@@ -33,8 +34,13 @@ __device__ long long nf_cb_prof[64];
         if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 64) nf_cb_prof[i] = wall_clock64(); \
     } while (0)
 extern "C" int nf_cb_prof_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(nf_cb_prof), sizeof(long long) * 64); }
+#define NF_CBW_STAMP(T, i)                                                             \
+    do {                                                                               \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == (T) && (i) >= 0 && (i) < 64) nf_cb_prof[i] = wall_clock64(); \
+    } while (0)
 #else
 #define NF_CB_STAMP(i)
+#define NF_CBW_STAMP(T, i)
 #endif
 
 #define NF_CB_WAVES 4
@@ -684,7 +690,7 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_de
 #define NF_CBW_THREADS 512
 #define NF_CBW_FILL 256                                // filling threads
 #define NF_CBW_GCH 272                                 // bytes per channel of a G plane: 128 pixels x 2 B + 16 (17 x 16: b128 reads conflict-free)
-#define NF_CBW_MAXR 6                                  // activation items (channel, four pixels) per filling thread: ceil(32 NQ / 256), NQ <= 48
+#define NF_CBW_MAXR 5                                  // activation items (channel, four pixels) per filling thread: ceil(32 NQ / 256), NQ <= 40 (W = 8, 16)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct NfCbwGeo {
@@ -716,17 +722,11 @@ static bool nf_cbw_geometry(NfCbwGeo& g, int64_t B, int H, int W) {
     g.tiles = (B * g.HW + 127) / 128;
     return nf_cbw_lds_bytes(g) <= 160 * 1024 && 2 * nf_cbw_buf_bytes(g) >= 9 * 1024 * sizeof(float);
 }
-// 16 bytes at a wave-uniform base + a per-lane 32-bit byte offset; entries that do not exist read a safe offset and are zeroed by
-// their mask.  (Loaded as f32x4: __builtin_bit_cast(float, v[j]) on an ELEMENT of an integer vector reads element 0 with this
-// toolchain -- a one-dword load whose value fills all four pixels.)
-typedef const __attribute__((address_space(1))) char* nf_gptr;     // (a pointer rebuilt from integers is generic otherwise: flat loads)
-__device__ __forceinline__ nf_gptr nf_cbw_base(const float* p) {
-    const uint64_t a = (uint64_t)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return (nf_gptr)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ f32x4 nf_cbw_ld128(nf_gptr base, unsigned off) {
-    return *(const __attribute__((address_space(1))) f32x4*)(base + off);
+// 16 bytes through a buffer descriptor (wave-uniform base in scalar registers, per-lane 32-bit byte offset, entries that do not exist
+// read 0 at the offset 0xffffffff: no 64-bit address arithmetic, no clamping).  The vector is converted WHOLE: __builtin_bit_cast(float,
+// v[j]) on an element of an integer vector reads element 0 with this toolchain -- one dword whose value fills all four pixels.
+__device__ __forceinline__ f32x4 nf_cbw_ld128(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
 }
 // four consecutive pixels of one channel -> 8 bytes in each of the three planes
 __device__ __forceinline__ void nf_cbw_put4(char* p, int plane_bytes, const float (&v)[4]) {
@@ -800,6 +800,7 @@ __global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti 
         for (int64_t tile = tile0; tile < g.tiles; tile += tstep, ++it) {
             const char* fa = lds + (it & 1) * BUF;     // activation planes
             const char* fg = fa + 3 * PA;              // G planes
+            NF_CBW_STAMP(0, it >= 2 && it < 10 ? 3 * (it - 2) : -1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bf16x8 a[3];
@@ -827,7 +828,12 @@ __global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti 
 #undef NF_CBW_STEP
                 }
             }
+#ifdef NF_CB_PROF
+            if (acc[0][0] == 123.456f) acc[1][0] += 1.f;   // (the stamp waits for the accumulators)
+            NF_CBW_STAMP(0, it >= 2 && it < 10 ? 3 * (it - 2) + 1 : -1);
+#endif
             __syncthreads();
+            NF_CBW_STAMP(0, it >= 2 && it < 10 ? 3 * (it - 2) + 2 : -1);
         }
     } else {
         // =========================================== FILL ===========================================
@@ -839,16 +845,10 @@ __global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti 
         const unsigned goff0 = 4u * (unsigned)((gsg * 32 + gch0) * g.HW + gqq);       // + r * 8 channels
         const unsigned gcstep = 4u * 8u * (unsigned)g.HW;
         const int glds0 = gch0 * NF_CBW_GCH + 8 * gq4;                                 // + r * 8 * GCH
-        float kc1[4], kmean[4], kinv[4], kmg[4], kmgx[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 8 * r + gch0;
-            kc1[r] = cst[c]; kmean[r] = cst[32 + c]; kinv[r] = cst[64 + c]; kmg[r] = cst[96 + c]; kmgx[r] = cst[128 + c];
-        }
         // activation items: i = 256 r + ft -> channel i / NQ, item j = i % NQ -> (segment, frame row, four-pixel group)
         unsigned xoff[NF_CBW_MAXR];
         int xlds[NF_CBW_MAXR];
-        float xsc[NF_CBW_MAXR], xsh[NF_CBW_MAXR];
+        unsigned xchn = 0u;                            // 6 bits per item: channel (the BatchNorm constants are read from LDS per tile: registers hold two tiles of loads)
         unsigned xmeta = 0u;                           // 4 bits per item: class (0 never, 1 inside, 2 top halo row, 3 bottom halo row) | 4: exists; segment in xseg
         unsigned xseg = 0u;
         const int QW = g.W >> 2, RW = g.TH + 2;
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti 
             const int i = NF_CBW_FILL * r + ft;
             unsigned off = 0u, cls = 0u, sg = 0u;
             int ldo = 0;
-            float sc = 1.f, sh = 0.f;
+            unsigned chn = 0u;
             if (r < g.nr && i < 32 * g.NQ) {
                 const int ch = i / g.NQ, j = i - ch * g.NQ;
                 const int rw = j / QW, xq = j - rw * QW;
@@ -868,109 +868,130 @@ __global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti 
                     cls |= frow == 0 ? 2u : (frow == g.TH + 1 ? 3u : 1u);
                     off = 4u * (unsigned)((sm * I + ch) * g.HW + frow * g.W + 4 * xq);   // from (sample b0, channel 0, row y0 - 1)
                     sg = (unsigned)sm;
-                    sc = cst[160 + ch]; sh = cst[192 + ch];
+                    chn = (unsigned)ch;
                 }
             }
-            xoff[r] = off; xlds[r] = ldo; xsc[r] = sc; xsh[r] = sh;
+            xoff[r] = off; xlds[r] = ldo;
+            xchn |= chn << (6 * r);
             xmeta |= cls << (4 * r);
             xseg |= sg << (4 * r);
         }
-        f32x4 rd[4], rk[4], rs[4], ro[4], rx[NF_CBW_MAXR];
-        unsigned gok = 0u, xok = 0u;                   // validity of the tile in flight
-        auto issue = [&](int64_t tile) {
+        // TWO register sets: the loads of tiles k + 1 and k + 2 are in flight while tile k is walked (one set was 68 KB per compute
+        // unit in flight for one round trip per tile: 2.7 TB/s; the set index is a compile-time constant: the tile loop is unrolled by two)
+        f32x4 rp[2][4], rs[2][4], ro[2][4], rx[2][NF_CBW_MAXR];       // plain gradient (g_direct or g_skip), gn_src, out, activations
+        unsigned gok[2] = {0u, 0u}, xok[2] = {0u, 0u};                // validity of the tile in flight
+        const float* const plain = d.g_direct != nullptr ? d.g_direct : d.g_skip;   // (the host routes layers with both elsewhere)
+        auto issue = [&](auto SET, int64_t tile) {
+            constexpr int S = decltype(SET)::value;
             const int64_t P0 = tile * 128;
             const int64_t b0 = P0 >> g.lgHW;
             const int q0 = g.SEG == 1 ? (int)(P0 & (g.HW - 1)) : 0;
             const int y0 = q0 >> g.lgW;
             const int64_t gbase = b0 * 32 * g.HW + q0;
             const bool pv = b0 + gsg < g.B;
-            gok = pv ? 1u : 0u;
+            gok[S] = pv ? 1u : 0u;
             unsigned go[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) go[r] = pv ? goff0 + (unsigned)r * gcstep : 0u;      // (offset 0: the tile's first pixel exists)
-            if (d.g_direct != nullptr) {
-                nf_gptr rr = nf_cbw_base(d.g_direct + gbase);
+            for (int r = 0; r < 4; ++r) go[r] = pv ? goff0 + (unsigned)r * gcstep : NF_CB_OOB;
+            if (plain != nullptr) {
+                const __amdgpu_buffer_rsrc_t rr = nf_cb_rsrc(plain + gbase);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rd[r] = nf_cbw_ld128(rr, go[r]);
-            }
-            if (d.g_skip != nullptr) {
-                nf_gptr rr = nf_cbw_base(d.g_skip + gbase);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rk[r] = nf_cbw_ld128(rr, go[r]);
+                for (int r = 0; r < 4; ++r) rp[S][r] = nf_cbw_ld128(rr, go[r]);
             }
             if (has_src) {
-                nf_gptr r3 = nf_cbw_base(d.gn_src + gbase);
-                nf_gptr r4 = nf_cbw_base(d.out + gbase);
+                const __amdgpu_buffer_rsrc_t r3 = nf_cb_rsrc(d.gn_src + gbase), r4 = nf_cb_rsrc(d.out + gbase);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { rs[r] = nf_cbw_ld128(r3, go[r]); ro[r] = nf_cbw_ld128(r4, go[r]); }
+                for (int r = 0; r < 4; ++r) { rs[S][r] = nf_cbw_ld128(r3, go[r]); ro[S][r] = nf_cbw_ld128(r4, go[r]); }
             }
-            nf_gptr rxs = nf_cbw_base(d.in + b0 * I * g.HW + (int64_t)(y0 - 1) * g.W);
-            const unsigned xsafe = 4u * (unsigned)g.W;     // row y0 of channel 0 of sample b0: exists
+            const __amdgpu_buffer_rsrc_t rxs = nf_cb_rsrc(d.in + b0 * I * g.HW + (int64_t)(y0 - 1) * g.W);
             const bool top = g.SEG == 1 && y0 > 0, bot = g.SEG == 1 && y0 + g.TH < g.H;
-            xok = 0u;
+            unsigned okm = 0u;
 #pragma unroll
             for (int r = 0; r < NF_CBW_MAXR; ++r)
                 if (r < g.nr) {                        // uniform
                     const unsigned cls = (xmeta >> (4 * r)) & 3u;
                     const int64_t sm = (int64_t)((xseg >> (4 * r)) & 15u);
                     const bool ok = (cls == 1u || (cls == 2u && top) || (cls == 3u && bot)) && b0 + sm < g.B;
-                    xok |= (ok ? 1u : 0u) << r;
-                    rx[r] = nf_cbw_ld128(rxs, ok ? xoff[r] : xsafe);
+                    okm |= (ok ? 1u : 0u) << r;
+                    rx[S][r] = nf_cbw_ld128(rxs, ok ? xoff[r] : NF_CB_OOB);
                 }
+            xok[S] = okm;
         };
-        auto convert = [&](int buf) {
-            char* fa = lds + buf * BUF;
+        auto convert = [&](auto SET) {                 // register set S -> frame pair S
+            constexpr int S = decltype(SET)::value;
+            char* fa = lds + S * BUF;
             char* fg = fa + 3 * PA;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (d.g_direct != nullptr) {
+                if (plain != nullptr) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = rd[r][j];
-                }
-                if (d.g_skip != nullptr) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += rk[r][j];
+                    for (int j = 0; j < 4; ++j) v[j] = rp[S][r][j];
                 }
                 if (has_src) {
+                    const int c = 8 * r + gch0;
+                    const float kc1 = cst[c], kmean = cst[32 + c], kinv = cst[64 + c], kmg = cst[96 + c], kmgx = cst[128 + c];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float xh = (ro[r][j] - kmean[r]) * kinv[r];
-                        v[j] += kc1[r] * (rs[r][j] - kmg[r] - xh * kmgx[r]);
+                        const float xh = (ro[S][r][j] - kmean) * kinv;
+                        v[j] += kc1 * (rs[S][r][j] - kmg - xh * kmgx);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gok ? v[j] : 0.f;
+                for (int j = 0; j < 4; ++j) v[j] = gok[S] ? v[j] : 0.f;
                 gsum[r] += (v[0] + v[1]) + (v[2] + v[3]);
                 nf_cbw_put4(fg + glds0 + r * 8 * NF_CBW_GCH, PG, v);
             }
 #pragma unroll
             for (int r = 0; r < NF_CBW_MAXR; ++r)
                 if (r < g.nr && ((xmeta >> (4 * r)) & 4u)) {
-                    const bool ok = (xok >> r) & 1u;
+                    const bool ok = (xok[S] >> r) & 1u;
+                    const int ch = (int)((xchn >> (6 * r)) & 63u);
+                    const float xsc = cst[160 + ch], xsh = cst[192 + ch];
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float x = rx[r][j];
-                        if (has_bn) x = fmaxf(fmaf(x, xsc[r], xsh[r]), 0.f);
+                        float x = rx[S][r][j];
+                        if (has_bn) x = fmaxf(fmaf(x, xsc, xsh), 0.f);
                         v[j] = ok ? x : 0.f;
                     }
                     nf_cbw_put4(fa + xlds[r], PA, v);
                 }
         };
-        if (tile0 < g.tiles) {
-            issue(tile0);
-            convert(0);
-            if (tile0 + tstep < g.tiles) issue(tile0 + tstep);
-        }
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        const int64_t n = tile0 < g.tiles ? (g.tiles - tile0 + tstep - 1) / tstep : 0;      // tiles of this workgroup: k -> tile0 + k tstep, set k & 1
+        if (n > 0) issue(S0{}, tile0);
+        if (n > 1) issue(S1{}, tile0 + tstep);
+        if (n > 0) convert(S0{});
+        if (n > 2) issue(S0{}, tile0 + 2 * tstep);
         __syncthreads();                               // frame pair 0 is complete
-        int it = 0;
-        for (int64_t tile = tile0; tile < g.tiles; tile += tstep, ++it) {
-            if (tile + tstep < g.tiles) {
-                convert((it + 1) & 1);
-                if (tile + 2 * tstep < g.tiles) issue(tile + 2 * tstep);
+        for (int64_t k = 0; k < n; k += 2) {           // while the walkers are on tile k (pair 0) / k + 1 (pair 1)
+            NF_CBW_STAMP(256, k >= 2 && k < 10 ? 24 + 4 * (int)(k - 2) : -1);
+            if (k + 1 < n) {
+                convert(S1{});
+#ifdef NF_CB_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                NF_CBW_STAMP(256, k >= 2 && k < 10 ? 24 + 4 * (int)(k - 2) + 1 : -1);
+#endif
+                if (k + 3 < n) issue(S1{}, tile0 + (k + 3) * tstep);
             }
+            NF_CBW_STAMP(256, k >= 2 && k < 10 ? 24 + 4 * (int)(k - 2) + 2 : -1);
             __syncthreads();
+            NF_CBW_STAMP(256, k >= 2 && k < 10 ? 24 + 4 * (int)(k - 2) + 3 : -1);
+            if (k + 1 >= n) break;
+            NF_CBW_STAMP(256, k + 1 >= 2 && k + 1 < 10 ? 24 + 4 * (int)(k + 1 - 2) : -1);
+            if (k + 2 < n) {
+                convert(S0{});
+#ifdef NF_CB_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                NF_CBW_STAMP(256, k + 1 >= 2 && k + 1 < 10 ? 24 + 4 * (int)(k + 1 - 2) + 1 : -1);
+#endif
+                if (k + 4 < n) issue(S0{}, tile0 + (k + 4) * tstep);
+            }
+            NF_CBW_STAMP(256, k + 1 >= 2 && k + 1 < 10 ? 24 + 4 * (int)(k + 1 - 2) + 2 : -1);
+            __syncthreads();
+            NF_CBW_STAMP(256, k + 1 >= 2 && k + 1 < 10 ? 24 + 4 * (int)(k + 1 - 2) + 3 : -1);
         }
     }
     // (both roles have executed the same number of barriers: one before the loop, one per tile)
@@ -1098,6 +1119,8 @@ int nf_conv_bulk_wgrad_plan(int64_t B, int I, int O, int H, int W, int ksize) {
 int nf_conv_bulk_wgrad(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int H, int W, int slabs, hipStream_t st) {
     NfCbwGeo g;
     if (!nf_cbw_geometry(g, B, H, W) || n < 1 || n > NF_CONV_WGRAD_MAX || slabs < 1) return NF_E_BADARG;
+    for (int k = 0; k < n; ++k)
+        if (descs[k].g_direct != nullptr && descs[k].g_skip != nullptr) return NF_E_BADARG;   // (one plain gradient per layer: the caller checks)
     NfCbwMulti m{};
     for (int k = 0; k < n; ++k) m.d[k] = descs[k];
     const size_t lds = nf_cbw_lds_bytes(g);

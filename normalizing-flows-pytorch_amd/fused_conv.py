@@ -310,6 +310,7 @@ class ConvDefer:
         _slab_sum_all(sums)
 
 
+WGRAD_FROM_STORE = __import__('os').environ.get('NF_CONV_WGRAD_FROM_STORE', '1') != '0'
 CONV_DEFER_ON = __import__('os').environ.get('NF_CONV_DEFER', '1') != '0'
 CONV_OVERLAP_ON = __import__('os').environ.get('NF_CONV_OVERLAP', '0') != '0'
 CONV_OFFLOAD_MIN = int(__import__('os').environ.get('NF_CONV_OFFLOAD_MIN', '16'))   # layers of one shape queued before a launch leaves
@@ -524,6 +525,11 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         if not chained:
             _bwd(shape, I, O, k, **kw)
         wkw = {f: v for f, v in kw.items() if f not in ('g_store', 'gn_out', 'sum_g', 'sum_gx')}
+        if WGRAD_FROM_STORE and kw.get('g_store') is not None:
+            # the data pass has left this layer's G (= g_skip + BatchNorm backward of gn_src at out) in g_store: the weight pass reads
+            # that ONE tensor as its plain gradient instead of assembling G again from three (the pass is HBM-bound at large batches)
+            wkw = {f: v for f, v in wkw.items() if f not in ('gn_src', 'out', 'g_skip') and not f.startswith('cbn_')}
+            wkw['g_direct'] = kw['g_store']
         wkw['g_bias'] = g_bias[i]
         queued.append(((shape, I, O, k), wkw, i))
 
