@@ -196,16 +196,21 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
         per_call = 1
         if wgs == 0:
             # batches beyond the persistent chain's co-residency limit at this level (B = 512 on one GPU): the conditioners run as one
-            # launch per layer (csrc/conv_bn.hip); the dominant one is the forward of a 32 -> 32 channel 3 x 3 layer at 16 x 16
-            entry, match = 'nf_conv_bn_fwd', (lambda a: int(a[2]) == 32 and int(a[3]) == 32 and int(a[4]) == Hh and int(a[6]) == 3)
+            # launch per layer; the 3 x 3 layers on the large-batch kernels of csrc/conv_bulk.hip (independent waves, three-way bf16
+            # split).  The dominant one by time per step is the data-gradient pass of a 32 -> 32 channel layer at 16 x 16
+            entry, match = 'nf_conv_bn_bwd', (lambda a: int(a[2]) == 32 and int(a[3]) == 32 and int(a[4]) == Hh and int(a[6]) == 3)
             flop = 2 * M * 9 * 32 * 32
-            nbytes = 4 * M * 32 * 3
-            kname = 'k_conv_bn_fwd (one 32 -> 32 channel 3 x 3 layer + BatchNorm statistics per launch, %d x %d, fp32 MFMA)' % (Hh, Ww)
-            pmc = ('k_conv_bn_fwd', '')
+            nbytes = int(4 * M * 32 * 4.5)          # gn_src, out, in read + gn_out written (+ g_skip read, g_store written: every fourth launch)
+            kname = ('k_conv3_bulk_bwd (data gradient of one 32 -> 32 channel 3 x 3 layer: BatchNorm backward on load, transposed '
+                     'convolution on the bf16 pipe, ReLU mask, batch sums; %d x %d)' % (Hh, Ww))
+            pmc = ('k_conv3_bulk_bwd', '<2, ')
+            extra['bf16_split'] = True
+            extra['hbm'] = True
         note = ('%s of 256 compute units hold the launch; five dependent convolutions inside five grid-wide BatchNorm exchanges '
                 '(DESIGN.md section 3.16)' % wgs) if wgs else 'per-layer launches: the batch exceeds the persistent chain at this level'
         extra['workgroups'] = wgs or None
-        extra['bf16_split'] = True if wgs else None
+        if wgs:
+            extra['bf16_split'] = True
     elif cfg['kind'] in ('glow', 'realnvp') and len(dims) == 1:
         glow = cfg['kind'] == 'glow'
         F = importlib.import_module(PKG + '.fused')
@@ -294,6 +299,11 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
         out['bf16_pipe'] = {'hardware_tflops': round(6.0 * tf, 2), 'peak': MFMA_BF16_TFLOPS, 'frac': round(6.0 * tf / MFMA_BF16_TFLOPS, 5),
                             'note': 'six v_mfma_f32_32x32x16_bf16 per fp32 product: hardware flops = 6 x algorithmic, against the dense bf16 peak'}
         extra.pop('bf16_split')
+    if extra.pop('hbm', None):
+        # the large-batch kernels move whole activation tensors per launch: the same launch against the HBM roof (algorithmic bytes)
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out['hbm'] = {'achieved_gbs': round(gbs, 1), 'peak_gbs': HBM_PEAK_GBS, 'frac': round(gbs / HBM_PEAK_GBS, 5),
+                      'note': 'algorithmic bytes per launch (DESIGN.md 3.24) over the measured duration: this launch sits between the two roofs'}
     out.update({k: v for k, v in extra.items() if v is not None})
     return out
 

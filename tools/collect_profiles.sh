@@ -3,7 +3,7 @@
 # --kernel-trace only) of the dominant kernels, the asymptotic kernel sweep and the per-config bench lines -> gpurun_out/prof_rNN/.
 #   bash tools/collect_profiles.sh r02
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -14,12 +14,12 @@ for c in c4 c1 c2 c3 c5; do
   [ -n "$F" ] && head -40 $F > $OUT/${R}_${c}_kernel_stats.csv
 done
 rm -rf /tmp/pmc_f /tmp/pmc_w
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o fetch -- python $GRAFT_REPO_ROOT/tools/pmc_round.py c4 c1 c2 c3 c5 fpp_img > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o write -- python $GRAFT_REPO_ROOT/tools/pmc_round.py c4 c1 c2 c3 c5 fpp_img > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o fetch -- python $GRAFT_REPO_ROOT/tools/pmc_round.py c4 c1 c2 c3 c5 fpp_img c4:512 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o write -- python $GRAFT_REPO_ROOT/tools/pmc_round.py c4 c1 c2 c3 c5 fpp_img c4:512 > $OUT/pmc_write.log 2>&1
 FC=$(find /tmp/pmc_f -name "fetch_counter_collection.csv" | head -1)
 WC=$(find /tmp/pmc_w -name "write_counter_collection.csv" | head -1)
 cd $GRAFT_REPO_ROOT
-NF_PMC_CONFIGS=c4,c1,c2,c3,c5,fpp_img python tools/pmc_round.py --json $FC $WC $OUT/${R}_pmc.json > $OUT/pmc_json.log 2>&1
+NF_PMC_CONFIGS=c4,c1,c2,c3,c5,fpp_img,c4:512 python tools/pmc_round.py --json $FC $WC $OUT/${R}_pmc.json > $OUT/pmc_json.log 2>&1
 cp $OUT/${R}_pmc.json $GRAFT_REPO_ROOT/profiles/${R}_pmc.json   # (the bench lines below read the round's PMC file from profiles/)
 # the image Flow++ path (row f4): kernel stats of its bench command, its bench line, per-launch device times, fused vs module stack
 cd /tmp

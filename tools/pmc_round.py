@@ -45,7 +45,7 @@ def to_json(fetch_csv, write_csv, out_path):
         cfg = bench.CONFIGS[cfg_name]
         B = int(batch) if batch else cfg['batch']
         try:
-            named = json.load(open(SIDECAR)).get(cfg_name)
+            named = json.load(open(SIDECAR)).get(cfg_name + (':' + batch if batch else ''))
         except (OSError, ValueError):
             named = None
         for (name, ctr), (n, v) in agg.items():
@@ -86,8 +86,9 @@ def main(names):
     nfdata = importlib.import_module(bench.PKG + '.data')
     which = {}
     for name in names:
+        name, _, batch = name.partition(':')                   # 'c4:512' = config 4 at its literal batch on one GPU
         cfg = bench.CONFIGS[name]
-        B = cfg['batch']
+        B = int(batch) if batch else cfg['batch']
         torch.manual_seed(0)
         np.random.seed(0)
         net = getattr(pkg, cfg['cls'])(cfg['dims'], cfg['datatype'], NS(layers=cfg['layers'], mixtures=cfg['mixtures'])).to(dev)
@@ -100,7 +101,7 @@ def main(names):
             trainer.train_on_batch(y)
         r = bench.dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y)     # three more eager steps: the counted launches
         print(name, r['kernel'], r['us_per_launch'])
-        which[name] = sorted(set(re.findall(r'k_[a-z0-9_]+', r['kernel'])))
+        which[name + (':' + batch if batch else '')] = sorted(set(re.findall(r'k_[a-z0-9_]+', r['kernel'])))
         del trainer, net
     torch.cuda.synchronize()
     with open(SIDECAR, 'w') as f:                       # config -> the kernels its roofline object names (read back by --json)
