@@ -876,6 +876,11 @@ int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* 
                                      const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs_all,
                                      float* head_rec, int64_t N, int D, float bn_eps, float wn_eps, nf_stream_t stream);
 
+/* RealNVP runs with D = 2 and N <= 256 (training mode: nf_realnvp_flow_vec_fwd / nf_realnvp_flow_vec_bwd_deferred) are served by ONE
+ * workgroup that holds the whole batch (csrc/flow_solo.hip): no meeting in global memory.  on = 1 / 0 switches that path (the
+ * environment variable NF_FLOW_SOLO=0 switches it off at load); returns 0.                                                        */
+int nf_flow_solo_config(int on);
+
 /* The persistent kernels above wait on each other with BOUNDED spin loops (a grid of <= NF_MLP_MAX_BLOCKS workgroups is
  * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some
  * launch produced garbage (device shared with another job?).  Synchronises the device.                                    */

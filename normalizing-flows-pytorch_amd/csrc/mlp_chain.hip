@@ -15,6 +15,7 @@
 // the activation column (weight_norm.py:40).
 #include "nf_common.h"
 #include "nf_mfma16.h"
+#include "nf_flow_rec.h"
 
 #ifndef NF_MC_PROF
 #define NF_MC_PROF 0      // 1 (tools/probes/mlp_chain_prof.py builds that variant): time stamps of workgroup 0 at phase boundaries
@@ -31,21 +32,7 @@ extern "C" int nf_mlp_chain_prof_read(long long* host_out) {
 }
 #endif
 
-#define NF_MC_WAVES (NF_MLP_ROWS_PER_BLOCK / 16)         // 8 or 16 (multiple of 4: the weight-gradient jobs come in fours)
-#define NF_MC_NKQ (NF_MC_WAVES / 4)                       // row groups of 64 per workgroup
-#define NF_MC_THREADS (NF_MC_WAVES * NF_WAVE)
-#define NF_MC_NL NF_MLP_LINEARS
-#define NF_MC_NB NF_MLP_BNS
 
-// Parameter pointers carry the GLOBAL address space on the device side: a whole-flow kernel reads them from a record in
-// memory, and a pointer loaded from memory is otherwise generic -> flat loads, whose completion counts on BOTH the vector-
-// memory and the LDS counters (43 flat instructions in k_glow_flow_fwd before this; none now).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define NF_G __attribute__((address_space(1)))
-#else
-#define NF_G
-#endif
-#define NF_GSET(field, value) field = (decltype(field))(value)
 // gradient store of the fold: atomic += (barrier-free fold, `afold` in scope), += or = otherwise
 #define NF_MC_AFOLD_MAX_BLOCKS 2
 #define NF_MC_ACC(ptr, val)                                                            \
@@ -55,12 +42,6 @@ extern "C" int nf_mlp_chain_prof_read(long long* host_out) {
         if (afold) atomicAdd((float*)p_, v_);                                          \
         else *p_ = (accumulate ? *p_ : 0.f) + v_;                                      \
     } while (0)
-struct NfMlpP {
-    const NF_G float* v[NF_MC_NL]; const NF_G float* g[NF_MC_NL]; const NF_G float* b[NF_MC_NL];
-    const NF_G float* gamma[NF_MC_NB]; const NF_G float* beta[NF_MC_NB];
-    NF_G float* rmean[NF_MC_NB]; NF_G float* rvar[NF_MC_NB]; NF_G int64_t* nbt[NF_MC_NB];
-};
-
 static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
     for (int l = 0; l < NF_MC_NL; ++l) {
         NF_GSET(p.v[l], t[3 * l]); NF_GSET(p.g[l], t[3 * l + 1]); NF_GSET(p.b[l], t[3 * l + 2]);
@@ -72,17 +53,6 @@ static inline void nf_mlp_unpack(const void* const* t, NfMlpP& p) {
     }
 }
 
-// ---- the fused vector Glow step (ActNorm -> invertible 1x1 -> affine coupling around this MLP), dims = (D,), D = 2 or 4 ----
-struct NfGlowV {
-    const float* z; float* y; float* ld;                                     // forward: input, output, log-det (in place +=)
-    const float* g_y; const float* g_ld; float* g_z;                         // backward
-    const NF_G float *ls, *bs, *P, *L, *U, *Lm, *Um, *sign_s, *log_s, *a, *c;     // ActNorm, PLU factors, coupling scale / shift
-    NF_G float *g_ls, *g_bs, *g_L, *g_U, *g_log_s, *g_a, *g_c;
-    NF_G float *bmean, *bvar, *rmean, *rvar;                                 // flow-BatchNorm head (HEAD == 2): ls = log_gamma, bs = beta
-    float fbn_eps, fbn_mom;
-    int fbn_mode;                                                            // 0: batch statistics computed here; 1: running statistics; 2: the stored batch buffers
-    int D, odd;
-};
 static inline void nf_glow_unpack(const void* const* t, NfGlowV& h) {
     NF_GSET(h.ls, t[0]); NF_GSET(h.bs, t[1]); NF_GSET(h.P, t[2]); NF_GSET(h.L, t[3]);
     NF_GSET(h.U, t[4]); NF_GSET(h.Lm, t[5]); NF_GSET(h.Um, t[6]); NF_GSET(h.sign_s, t[7]);
@@ -888,12 +858,7 @@ extern "C" int nf_mlp_chain_fwd(const float* x, const void* const* params, float
 // of waves 4 (w >> 2) .. +3 -- 16 MFMAs each, partial results to this workgroup's slab.  After a final grid barrier
 // workgroup l folds the slabs of linear l and applies the weight-norm backward (weight_norm.py:35-41).
 // ---------------------------------------------------------------------------------------------------------------
-struct NfMlpG { NF_G float* v[NF_MC_NL]; NF_G float* g[NF_MC_NL]; NF_G float* b[NF_MC_NL]; NF_G float* gamma[NF_MC_NB]; NF_G float* beta[NF_MC_NB]; };
 
-#define NF_MC_SLAB_Q 1056                                // 32 x 32 weight-gradient partial + 32 bias partial
-#define NF_MC_SLAB_L (NF_MC_NKQ * NF_MC_SLAB_Q)          // one partial per 64-row group
-#define NF_MC_NLS (NF_MC_NL + 1)                         // + one product for the fused Glow step's scalar gradients
-#define NF_MC_SLAB (NF_MC_NLS * NF_MC_SLAB_L)
 static_assert(NF_MC_WAVES % 4 == 0 && NF_MLP_MAX_BLOCKS * NF_MLP_ROWS_PER_BLOCK == NF_MLP_MAX_ROWS, "geometry in include/nfhip.h");
 static_assert((NF_MC_NB + 1) * NF_MLP_MAX_BLOCKS * 64 * 2 + 64 == NF_MLP_WS_FLOATS, "exchange workspace size in include/nfhip.h");
 static_assert(NF_MC_SLAB * NF_MLP_MAX_BLOCKS == NF_MLP_BWD_SLAB_FLOATS, "slab workspace size in include/nfhip.h");
@@ -1598,7 +1563,6 @@ extern "C" int nf_glow_step_vec_bwd(const float* z, const float* g_y, const floa
 // ---------------------------------------------------------------------------------------------------------------
 static void nf_fbn_unpack(const void* const* t, NfGlowV& h);
 static inline int nf_fbn_mode_of(float momentum) { return momentum == NF_FBN_RUNNING ? 1 : momentum == NF_FBN_BATCH_BUFFERS ? 2 : 0; }
-struct NfGlowFlowStep { NfMlpP p; NfMlpG g; NfGlowV h; };     // the static pointers of one step: parameters, gradient sinks
 
 extern "C" int nf_glow_flow_step_bytes(void) { return (int)sizeof(NfGlowFlowStep); }
 
@@ -1964,6 +1928,21 @@ extern "C" int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, co
                                                 const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
                                                 float* slabs_all, float* head_rec, int64_t N, int D, float bn_eps, float wn_eps,
                                                 nf_stream_t stream) {
+    if (nf_solo_plan(N, D) && steps_dev != nullptr && S >= 1 && S <= NF_GLOW_FLOW_MAX_STEPS && z0 != nullptr && ys != nullptr &&
+        g_y != nullptr && gzs != nullptr && saves != nullptr && slabs_all != nullptr && head_rec != nullptr) {
+        // the whole batch in one workgroup (flow_solo.hip); its slabs and head sums are folded by the same launch as the grid kernel's
+        const int rc = nf_solo_bwd(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, slabs_all, head_rec, N,
+                                   wn_eps, (hipStream_t)stream);
+        if (rc != 0) return rc;
+        const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+        const size_t lds_fold = nf_mc_lds_bytes(1);
+        hipError_t e = hipFuncSetAttribute((const void*)k_glow_fold_all<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fold);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k_glow_fold_all<2>, dim3(NF_GF_FOLD_BLOCKS, S), dim3(NF_MC_THREADS), lds_fold, (hipStream_t)stream,
+                           (const NfGlowFlowStep*)steps_dev, slabs_all, head_rec, (int)grid, accumulate, D, wn_eps);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     return nf_flow_launch_bwd_deferred<2>(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, ws_zero,
                                           slabs_all, head_rec, N, D, 1, bn_eps, wn_eps, stream);
 }
@@ -2005,6 +1984,9 @@ extern "C" int nf_realnvp_flow_vec_inv(const void* steps_dev, int S, const float
 extern "C" int nf_realnvp_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves,
                                        float* ws_zero, int64_t N, int D, float bn_eps, float bn_momentum, float wn_eps,
                                        nf_stream_t stream) {
+    if (nf_solo_plan(N, D) && steps_dev != nullptr && S >= 1 && S <= NF_GLOW_FLOW_MAX_STEPS && z0 != nullptr && ys != nullptr &&
+        ld != nullptr && saves != nullptr)
+        return nf_solo_fwd(steps_dev, S, z0, ys, ld, saves, NF_REALNVP_SAVE_FLOATS, N, bn_eps, bn_momentum, wn_eps, (hipStream_t)stream);
     return nf_flow_launch_fwd<2>(steps_dev, S, z0, ys, ld, saves, NF_REALNVP_SAVE_FLOATS, ws_zero, N, D, 1, bn_eps, bn_momentum, wn_eps,
                                  stream);
 }
