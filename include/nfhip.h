@@ -876,10 +876,15 @@ int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* 
                                      const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero, float* slabs_all,
                                      float* head_rec, int64_t N, int D, float bn_eps, float wn_eps, nf_stream_t stream);
 
-/* RealNVP runs with D = 2 and N <= 256 (training mode: nf_realnvp_flow_vec_fwd / nf_realnvp_flow_vec_bwd_deferred) are served by ONE
- * workgroup that holds the whole batch (csrc/flow_solo.hip): no meeting in global memory.  on = 1 / 0 switches that path (the
- * environment variable NF_FLOW_SOLO=0 switches it off at load); returns 0.                                                        */
-int nf_flow_solo_config(int on);
+/* RealNVP runs with D = 2 and N <= 256 (training mode: nf_realnvp_flow_vec_fwd / nf_realnvp_flow_vec_bwd_deferred) can be served by
+ * ONE workgroup that holds the whole batch (csrc/flow_solo.hip): no meeting in global memory.  mode bit 0 = the forward run, bit 1 =
+ * the backward run (default 1: forward only, the measured optimum; the environment variable NF_FLOW_SOLO sets it at load; mode < 0
+ * changes nothing); returns 0.  The one-workgroup backward's eight waves each leave a weight-gradient partial: for D = 2, N <= 256
+ * the slabs_all / head_rec of nf_realnvp_flow_vec_bwd_deferred must hold NF_FLOW_SOLO_REGIONS regions per step (not
+ * ceil(N / NF_MLP_ROWS_PER_BLOCK)), whichever kernel serves the call.                                                              */
+#define NF_FLOW_SOLO_MAX_ROWS 256
+#define NF_FLOW_SOLO_REGIONS 4
+int nf_flow_solo_config(int mode);
 
 /* The persistent kernels above wait on each other with BOUNDED spin loops (a grid of <= NF_MLP_MAX_BLOCKS workgroups is
  * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some

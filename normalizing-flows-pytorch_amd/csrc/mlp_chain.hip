@@ -1928,18 +1928,17 @@ extern "C" int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, co
                                                 const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
                                                 float* slabs_all, float* head_rec, int64_t N, int D, float bn_eps, float wn_eps,
                                                 nf_stream_t stream) {
-    if (nf_solo_plan(N, D) && steps_dev != nullptr && S >= 1 && S <= NF_GLOW_FLOW_MAX_STEPS && z0 != nullptr && ys != nullptr &&
+    if (nf_solo_plan(N, D, 1) && steps_dev != nullptr && S >= 1 && S <= NF_GLOW_FLOW_MAX_STEPS && z0 != nullptr && ys != nullptr &&
         g_y != nullptr && gzs != nullptr && saves != nullptr && slabs_all != nullptr && head_rec != nullptr) {
         // the whole batch in one workgroup (flow_solo.hip); its slabs and head sums are folded by the same launch as the grid kernel's
         const int rc = nf_solo_bwd(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, slabs_all, head_rec, N,
                                    wn_eps, (hipStream_t)stream);
         if (rc != 0) return rc;
-        const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
         const size_t lds_fold = nf_mc_lds_bytes(1);
         hipError_t e = hipFuncSetAttribute((const void*)k_glow_fold_all<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fold);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k_glow_fold_all<2>, dim3(NF_GF_FOLD_BLOCKS, S), dim3(NF_MC_THREADS), lds_fold, (hipStream_t)stream,
-                           (const NfGlowFlowStep*)steps_dev, slabs_all, head_rec, (int)grid, accumulate, D, wn_eps);
+                           (const NfGlowFlowStep*)steps_dev, slabs_all, head_rec, NF_FLOW_SOLO_REGIONS, accumulate, D, wn_eps);
         NF_CHECK_LAUNCH();
         return 0;
     }
@@ -1984,7 +1983,7 @@ extern "C" int nf_realnvp_flow_vec_inv(const void* steps_dev, int S, const float
 extern "C" int nf_realnvp_flow_vec_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves,
                                        float* ws_zero, int64_t N, int D, float bn_eps, float bn_momentum, float wn_eps,
                                        nf_stream_t stream) {
-    if (nf_solo_plan(N, D) && steps_dev != nullptr && S >= 1 && S <= NF_GLOW_FLOW_MAX_STEPS && z0 != nullptr && ys != nullptr &&
+    if (nf_solo_plan(N, D, 0) && steps_dev != nullptr && S >= 1 && S <= NF_GLOW_FLOW_MAX_STEPS && z0 != nullptr && ys != nullptr &&
         ld != nullptr && saves != nullptr)
         return nf_solo_fwd(steps_dev, S, z0, ys, ld, saves, NF_REALNVP_SAVE_FLOATS, N, bn_eps, bn_momentum, wn_eps, (hipStream_t)stream);
     return nf_flow_launch_fwd<2>(steps_dev, S, z0, ys, ld, saves, NF_REALNVP_SAVE_FLOATS, ws_zero, N, D, 1, bn_eps, bn_momentum, wn_eps,

@@ -44,7 +44,7 @@ struct NfGlowFlowStep { NfMlpP p; NfMlpG g; NfGlowV h; };     // the static poin
 #define NF_MC_SLAB (NF_MC_NLS * NF_MC_SLAB_L)
 
 // the whole-batch kernels of flow_solo.hip (RealNVP steps, D = 2, N <= 256, training mode); 0 from the plan = not taken
-int nf_solo_plan(int64_t N, int D);
+int nf_solo_plan(int64_t N, int D, int backward);
 int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, int save_stride, int64_t N, float bn_eps,
                 float bn_momentum, float wn_eps, hipStream_t stream);
 int nf_solo_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld, float* gzs,

@@ -1059,7 +1059,10 @@ class _RealNVPFlowVec(torch.autograd.Function):
                    _p(g_ld), N.ptr(gzs), N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, BN_EPS, WN_EPS, N.stream())
         elif FLOW_DEFER_FOLD:
             rpb = N.header_constant('NF_MLP_ROWS_PER_BLOCK')
-            slabs, rec = _glow_steps_scratch(S, (Nrows + rpb - 1) // rpb, dev)
+            regions = (Nrows + rpb - 1) // rpb
+            if D == 2 and Nrows <= N.header_constant('NF_FLOW_SOLO_MAX_ROWS'):      # (the one-workgroup kernel's eight partials per step)
+                regions = max(regions, N.header_constant('NF_FLOW_SOLO_REGIONS'))
+            slabs, rec = _glow_steps_scratch(S, regions, dev)
             N.call('nf_realnvp_flow_vec_bwd_deferred', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs),
                    N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, BN_EPS, WN_EPS, N.stream())
         else:

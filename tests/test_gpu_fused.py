@@ -871,7 +871,7 @@ def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
         G.assert_close(z1, z2, tz, rtol=tz, what='z, step %d' % step)
         G.assert_close(l1, l2, tz, rtol=tz, what='loss, step %d' % step)
         # (same step bodies; with <= 32 workgroups the fold adds by float atomics, whose order is not fixed)
-        G.assert_close(t1.bucket.flat, t2.bucket.flat, (1e-5 if mode is True else 5e-5) * (5.0 if solo else 1.0) * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
+        G.assert_close(t1.bucket.flat, t2.bucket.flat, (1e-5 if mode is True else 5e-5) * (20.0 if solo else 1.0) * max(1.0, float(t2.bucket.flat.abs().max())), what='flat grads')
         b1, b2 = dict(net1.named_buffers()), dict(net2.named_buffers())
         for name in b2:
             G.assert_close(b1[name].float(), b2[name].float(), 2e-5 if solo else 1e-6, rtol=2e-5 if solo else 1e-6, what='buffer ' + name)
@@ -881,3 +881,38 @@ def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
     assert calls['n'] == 2, 'the whole-flow launch was not taken'
     assert fused.N.persistent_timeouts() == 0
 
+
+
+@pytest.mark.parametrize('mode', [1, 2, 3])
+@pytest.mark.parametrize('B,K,seed', [(256, 4, 11), (256, 6, 12), (100, 3, 13), (17, 2, 14), (64, 2, 15)])
+def test_realnvp_one_workgroup_kernels_match_the_grid_kernels(pkg, B, K, seed, mode):
+    """csrc/flow_solo.hip (the whole batch of a 2-D RealNVP run in ONE workgroup: features x batch tiles, sums over the batch through LDS
+    transposition tiles, per-wave weight-gradient partials) in its three settings -- forward only (the default), backward only, both --
+    against the grid kernels of csrc/mlp_chain.hip on the same weights and batch: outputs, loss, every gradient, the BatchNorm1d and
+    flow-BatchNorm buffers; full batches, ragged ones (100 = three full waves + 4 columns, 17) and one that leaves waves empty.  Short
+    runs: two fp32 paths drift apart by the same factor per step as either does from float64 (1e-3 at 32 steps, tools/probes/
+    solo_dbg.py: the one-workgroup forward is the closer one); the full-depth case is tests/test_gpu_fullsize_parity.py's, against the oracle."""
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    N = pkg._native
+    torch.manual_seed(seed)
+    net0 = pkg.RealNVP((2, ), 'density', NS(layers=K, mixtures=8)).to(DEV)
+    y = (torch.randn(B, 2) * 0.7).to(DEV)
+    outs = []
+    try:
+        for m in (0, mode):
+            N.call('nf_flow_solo_config', m)
+            net = copy.deepcopy(net0).train()
+            tr = train.FlowTrainer(net, graph=False)
+            z, loss = tr._forward_backward(y)
+            torch.cuda.synchronize()
+            outs.append((z.detach().clone(), float(loss), tr.bucket.flat.detach().clone(), {k: v.detach().clone() for k, v in net.named_buffers()}))
+    finally:
+        N.call('nf_flow_solo_config', 1)
+    (z0, l0, g0, b0), (z1, l1, g1, b1) = outs
+    G.assert_close(z1, z0, 5e-5, rtol=5e-5, what='z')
+    assert abs(l1 - l0) <= 5e-5 * max(1.0, abs(l0)), (l1, l0)
+    G.assert_close(g1, g0, 2e-4 * max(1.0, float(g0.abs().max())), rtol=0.0, what='flat gradients')
+    for name in b0:
+        G.assert_close(b1[name].float(), b0[name].float(), 2e-5, rtol=2e-5, what='buffer ' + name)
+    assert N.persistent_timeouts() == 0

@@ -35,7 +35,7 @@ def run(on):
     return z.detach().cpu(), torch.as_tensor(float(loss.detach())), g
 
 
-z1, l1, g1 = run(1)
+z1, l1, g1 = run(3)
 z0, l0, g0 = run(0)
 sd64 = {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
 ora = om.FlowOracle('realnvp', (2, ), 'density', K, sd64, training=True).requires_grad_(True)
