@@ -8,6 +8,8 @@ reference materialises a D x D covariance (3072 x 3072 for CIFAR), here it is a 
 """
 import math
 
+import os
+
 import torch
 
 from . import dist as nfdist
@@ -100,8 +102,10 @@ class FlowTrainer:
     The call that captures also takes one extra eager step on its batch (allocator warm-up on the capture stream)."""
 
     def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None,
-                 fused_adam=True, sampler=None, sync_stats=False, graph_factory=None):
+                 fused_adam=True, sampler=None, sync_stats=False, graph_factory=None, one_graph=None):
         self.net = net
+        self.one_graph = (os.environ.get('NF_DP_ONE_GRAPH', '0') == '1') if one_graph is None else bool(one_graph)
+        self._g_whole = False
         # parity mode (SURVEY.md section 8e): every batch statistic over the GLOBAL batch -- W-way data parallelism then reproduces
         # the single-process result on the concatenated batch.  Layer-by-layer launches with collectives in between: no hipGraph.
         self.sync_stats = bool(sync_stats)
@@ -213,19 +217,40 @@ class FlowTrainer:
             self.bucket.all_reduce_mean_()
             self.optim.step()
         single = self.bucket.world == 1                 # no all-reduce between backward and Adam: one graph, one replay
+        # N > 1 with one_graph: the flat bucket's all-reduce is captured BETWEEN backward and Adam (ProcessGroupNCCL enqueues the RCCL
+        # kernel on the capturing stream): one replay per step instead of two graph launches and an eager collective in between.
+        # Opt-in (FlowTrainer(one_graph=True) / NF_DP_ONE_GRAPH=1): no multi-GPU node was available to measure it; a capture that
+        # fails falls back to the two-graph form below.
+        whole = single
 
         def forward_backward():
             z, loss = self._forward_backward(self._static_y)
-            if single:
+            if whole:
+                self.bucket.all_reduce_mean_()          # (no-op at world size 1)
                 self.optim.step()
             return z.detach(), loss.detach()
-        g_fb = self._graph_factory()
-        self._static_z, self._static_loss = g_fb.capture(forward_backward)
+        g_fb = None
+        if not single and self.one_graph:
+            whole = True
+            try:
+                g_fb = self._graph_factory()
+                self._static_z, self._static_loss = g_fb.capture(forward_backward)
+            except Exception as e:
+                import warnings
+                warnings.warn('the data-parallel step could not be captured as ONE hipGraph (%s: %s); two graphs with the all-reduce '
+                              'between them' % (type(e).__name__, e))
+                g_fb, whole = None, False
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+        if g_fb is None:
+            g_fb = self._graph_factory()
+            self._static_z, self._static_loss = g_fb.capture(forward_backward)
         g_opt = None
-        if not single:                                  # N > 1: graph A, the flat bucket's all-reduce (eager, RCCL), graph B = Adam
+        if not whole:                                   # N > 1: graph A, the flat bucket's all-reduce (eager, RCCL), graph B = Adam
             g_opt = self._graph_factory()
             g_opt.capture(self.optim.step)
         self._g_fb, self._g_opt = g_fb, g_opt
+        self._g_whole = whole
 
     def train_on_batch(self, y=None):
         """returns (z, loss) like main.py:78-92; with graph=True the returned tensors are the graph's static outputs.
@@ -252,7 +277,7 @@ class FlowTrainer:
                 self._sync_replicas_after_first_step()
             if self._static_y is not None:
                 self._static_y.copy_(y, non_blocking=True)
-            self._g_fb.replay()
+            self._g_fb.replay()                         # (world size 1, or one_graph: the whole step)
             if self._g_opt is not None:
                 self.bucket.all_reduce_mean_()
                 self._g_opt.replay()

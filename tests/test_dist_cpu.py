@@ -316,7 +316,7 @@ class _RerunGraph:
                 o.copy_(n)
 
 
-def _graph_worker(rank, world, port, q, use_graph):
+def _graph_worker(rank, world, port, q, use_graph, one_graph=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     nfdist = importlib.import_module(PKG + '.dist')
@@ -329,7 +329,7 @@ def _graph_worker(rank, world, port, q, use_graph):
     np.random.seed(3 + rank)
     net = _OracleBackedGlow(4).train()
     n_coll = nfdist.broadcast_parameters(net)
-    tr = train.FlowTrainer(net, lr=1e-3, graph=use_graph, warmup=2, graph_factory=_RerunGraph)
+    tr = train.FlowTrainer(net, lr=1e-3, graph=use_graph, warmup=2, graph_factory=_RerunGraph, one_graph=one_graph)
     _RerunGraph.trainer = tr
     y_global = nfdata.sample('moons', 256, 77)
     y = nfdist.shard(y_global, rank, world)
@@ -345,11 +345,11 @@ def _graph_worker(rank, world, port, q, use_graph):
     torch.distributed.destroy_process_group()
 
 
-def _run_graph(use_graph):
+def _run_graph(use_graph, one_graph=False):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q, use_graph)) for r in range(2)]
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q, use_graph, one_graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
@@ -376,3 +376,18 @@ def test_trainer_two_graph_path_matches_eager_over_two_ranks():
         assert np.allclose(graph[r][2], eager[r][2], rtol=1e-5, atol=1e-6), float(np.abs(graph[r][2] - eager[r][2]).max())
     assert np.array_equal(graph[0][2], graph[1][2]), 'replicas diverged on the graph path'
     assert graph[0][1][0] != graph[1][1][0]              # (the ranks really trained on different shards)
+
+
+def test_trainer_one_graph_path_matches_eager_over_two_ranks():
+    """FlowTrainer(graph=True, one_graph=True) at world size 2: zero + forward + NLL + backward, the flat bucket's all-reduce and Adam
+    captured as ONE graph (one replay per step; the collective sits between backward and Adam inside the capture) -- same losses, step
+    count and final parameters as the eager two-rank run, identical replicas, and no second graph."""
+    import numpy as np
+    eager = _run_graph(False)
+    graph = _run_graph(True, one_graph=True)
+    for r in range(2):
+        assert graph[r][4] and not graph[r][5], 'the one-graph path was not taken at world size 2'
+        assert graph[r][6] == eager[r][6] == 7, (graph[r][6], eager[r][6])
+        assert np.allclose(graph[r][1], eager[r][1], rtol=1e-6, atol=1e-6), (graph[r][1], eager[r][1])
+        assert np.allclose(graph[r][2], eager[r][2], rtol=1e-5, atol=1e-6), float(np.abs(graph[r][2] - eager[r][2]).max())
+    assert np.array_equal(graph[0][2], graph[1][2]), 'replicas diverged on the one-graph path'

@@ -46,7 +46,25 @@ for c in c4 c1; do
   python $GRAFT_REPO_ROOT/tools/step_kernels.py --by-grid $T chain >> $OUT/${R}_${c}_step_kernels.txt
   python $GRAFT_REPO_ROOT/tools/step_kernels.py --by-grid $T head >> $OUT/${R}_${c}_step_kernels.txt
 done
+# config 4's literal batch (512) on one GPU: per-step census (large-batch kernels of csrc/conv_bulk.hip), and the sampling pass of the
+# image Flow++ object (inverse census: the forward / inverse gap of round 3)
+rm -rf /tmp/sk_b512 /tmp/fi_inv
+NF_BATCH=512 NF_STEPS=4 rocprofv3 --kernel-trace --output-format csv -d /tmp/sk_b512 -o st -- python $GRAFT_REPO_ROOT/tools/step_kernels.py c4 > /dev/null 2> $OUT/sk_b512.err
+T=$(find /tmp/sk_b512 -name "st_kernel_trace.csv" | head -1)
+NF_STEPS=4 TOP=45 python $GRAFT_REPO_ROOT/tools/step_kernels.py --census $T > $OUT/${R}_c4_b512_step_kernels.txt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/fi_inv -o st -- python $GRAFT_REPO_ROOT/tools/probes/fpp_img_inverse.py 5 > $OUT/fpp_inv.log 2>&1
+T=$(find /tmp/fi_inv -name "st_kernel_trace.csv" | head -1)
+NF_STEPS=5 TOP=30 python $GRAFT_REPO_ROOT/tools/step_kernels.py --census $T > $OUT/${R}_fpp_img_inverse_kernels.txt
+grep -E "round trip|pass:" $OUT/fpp_inv.log >> $OUT/${R}_fpp_img_inverse_kernels.txt
 cd $GRAFT_REPO_ROOT
+# large-batch kernels in isolation (conv_bulk.hip): forward / data gradient per layer, weight gradient per 16 layers, and its phase stamps
+python tools/probes/bulk_time.py 512 16 > $OUT/${R}_conv_bulk_times.txt 2>&1
+python tools/probes/bulk_time.py 512 8 >> $OUT/${R}_conv_bulk_times.txt 2>&1
+for h in 16 8; do python tools/probes/wgrad_time.py $h 512 16 >> $OUT/${R}_conv_bulk_times.txt 2>&1; NF_CONV_BULK_WGRAD=0 python tools/probes/wgrad_time.py $h 512 16 >> $OUT/${R}_conv_bulk_times.txt 2>&1; done
+# C1: the one-workgroup kernels (flow_solo.hip) in their settings, same box
+for m in 0 1 3; do echo "NF_FLOW_SOLO=$m" >> $OUT/${R}_c1_solo_modes.txt; NF_FLOW_SOLO=$m python bench.py --config c1 --skip-cpu --steps 50 | cut -c1-330 >> $OUT/${R}_c1_solo_modes.txt; done
+# model-level asymptotic sweep: CIFAR-shape Glow at B = 512, 2048 per GPU; 2-D models up to 2^22 rows
+python tools/model_sweep.py > $OUT/${R}_model_sweep.txt 2> $OUT/model_sweep.err
 # the reference path's own spread under row permutations and the per-step error profile of C1; the kink census runs on the host
 python tools/probes/parity_depth.py c1 > $OUT/${R}_c1_parity_depth.txt 2>&1
 python tools/cpu_threads.py c4 8 16 32 64 > $OUT/${R}_cpu_threads.txt 2>&1
