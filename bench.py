@@ -57,6 +57,7 @@ def parse():
     ap.add_argument('--config', default=None, choices=sorted(CONFIGS),
                     help='one workload; default: c4 (Glow CIFAR-10) on the top level + c1 (RealNVP moons) under "also"')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (asymptotic sweeps)')
+    ap.add_argument('--layers', type=int, default=None, help='flow steps per level override (e.g. the reference default 32 for fpp_img)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--skip-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -371,6 +372,8 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
     nftrain = importlib.import_module(PKG + '.train')
     nfdata = importlib.import_module(PKG + '.data')
     cfg = CONFIGS[name]
+    if getattr(args, 'layers', None):
+        cfg = dict(cfg, layers=args.layers, desc=cfg['desc'] + ' -- measured with layers=%d' % args.layers)
     B = args.batch or cfg['batch']
 
     torch.manual_seed(0)                                     # identical initial weights on every rank
@@ -550,7 +553,7 @@ def main():
     # line's top level is c4 (the larger one), c1 rides along as a second object of the same shape under "also"
     primary = args.config or 'c4'
     out = run_workload(primary, args, pkg, rank, world, dev, args.steps, args.warmup, args.cpu_seconds)
-    if args.config is None and args.batch is None:
+    if args.config is None and args.batch is None and args.layers is None:
         also = run_workload('c1', args, pkg, rank, world, dev, max(args.steps, 50), args.warmup, min(args.cpu_seconds, 6.0))
         # config 4's literal batch (512) on ONE GPU: informational -- the 4 x 4 level runs the persistent chain, the 8 x 8 and 16 x 16
         # levels exceed its co-residency limit at this batch and run one launch per layer (single-GPU runs only: the DP runs shard 512)

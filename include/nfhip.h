@@ -195,6 +195,20 @@ int nf_logit_fwd(const float* x, float* y, float* ld, float eps, int inverse, in
 int nf_logit_bwd(const float* g_y, const float* g_ld, const float* x, float* g_x, float eps, int64_t B, int64_t n,
                  nf_stream_t stream);
 
+/* The other elementwise bijector modules (flows/modules.py:125-183: Sigmoid, Tanh, Arctanh; no reference model builds them), one pass per
+ * direction with ld[b] += the per-sample log-det.  kind 0: sigmoid (Sigmoid.forward), 1: logit of clamp(x, 1e-8, 1 - 1e-8)
+ * (Sigmoid.backward), 2: tanh (Tanh.forward = Arctanh.backward), 3: arctanh (Tanh.backward = Arctanh.forward).  nf_bijector_bwd: the
+ * autograd of kinds 0, 2, 3 as forward directions (g_x written).                                                                 */
+#define NF_BIJ_SIGMOID 0
+#define NF_BIJ_SIGMOID_INV 1
+#define NF_BIJ_TANH 2
+#define NF_BIJ_ARCTANH 3
+int nf_bijector_fwd(const float* x, float* y, float* ld, int kind, int64_t B, int64_t n, nf_stream_t stream);
+int nf_bijector_bwd(const float* g_y, const float* g_ld, const float* x, float* g_x, int kind, int64_t B, int64_t n, nf_stream_t stream);
+/* Squeeze1d / Unsqueeze1d as flow layers (flows/squeeze.py:114-151): out (B, D) = cat(z[:, odd::2], z[:, 1 - odd::2]); inverse != 0: the
+ * inverse map (in = the concatenated halves, out = the interleaved row).  D even.                                                 */
+int nf_squeeze1d(const float* in, float* out, int64_t B, int D, int odd, int inverse, nf_stream_t stream);
+
 /* ---- Flow++ mixture-of-logistics coupling  coupling.py:172-210, modules.py:64-97, :186-212 ---------------------
  * params: conditioner output (B, (2+3K)*Ch, h, w) with channel sections [a | b | logit(pi) | mu | s]
  * (coupling.py:140,177); mixture k of transformed channel m lives at section channel k*Ch + m (coupling.py:180-182).

@@ -10,10 +10,11 @@ The directory name is not a Python identifier; import it with
 from . import _native, functional  # noqa: F401
 from ._build import build  # noqa: F401
 from .layers import (MADE, ActNorm, AbstractCoupling, AdditiveCoupling, AffineCoupling, AutoregressiveTransfrom, BatchNorm, Compose, Identity,
-                     InvertibleConv1x1, Logit, MixLogAttnCoupling, MixLogCDF, Squeeze2d, Unsqueeze2d)
+                     InvertibleConv1x1, Logit, MixLogAttnCoupling, MixLogCDF, Squeeze2d, Unsqueeze2d, Sigmoid, Tanh, Arctanh, Squeeze1d,
+                     Unsqueeze1d)
 from .models import MAF, Flowpp, Glow, RealNVP
 from .resflow import InvertibleResLinear, LipSwish, ResFlow, SpectralNorm
 
 __all__ = ['ActNorm', 'AbstractCoupling', 'AdditiveCoupling', 'AffineCoupling', 'BatchNorm', 'Compose', 'Identity', 'InvertibleConv1x1',
            'Logit', 'Squeeze2d', 'Unsqueeze2d', 'Glow', 'RealNVP', 'Flowpp', 'MAF', 'MADE', 'AutoregressiveTransfrom',
-           'MixLogAttnCoupling', 'MixLogCDF', 'ResFlow', 'InvertibleResLinear', 'SpectralNorm', 'LipSwish', 'build', 'functional']
+           'MixLogAttnCoupling', 'MixLogCDF', 'Sigmoid', 'Tanh', 'Arctanh', 'Squeeze1d', 'Unsqueeze1d', 'ResFlow', 'InvertibleResLinear', 'SpectralNorm', 'LipSwish', 'build', 'functional']

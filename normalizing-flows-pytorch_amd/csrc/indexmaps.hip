@@ -193,3 +193,25 @@ extern "C" int nf_unsqueeze2d(const float* z, float* out, int64_t B, int C, int 
     NF_CHECK_LAUNCH();
     return 0;
 }
+
+// Squeeze1d / Unsqueeze1d as flow layers (flows/squeeze.py:114-151): out = cat(z[:, odd::2], z[:, 1 - odd::2]) and its inverse map --
+// a permutation of the D columns (squeeze.py:63-83), one element per thread.
+__global__ void __launch_bounds__(NF_BLOCK) k_squeeze1d(const float* __restrict__ in, float* __restrict__ out, int64_t total, int D, int odd,
+                                                        int inverse) {
+    const int h = D >> 1;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / D;
+        const int j = (int)(t - b * D);                        // position in the squeezed (concatenated) row
+        const int src = j < h ? 2 * j + odd : 2 * (j - h) + 1 - odd;       // its column in the interleaved row
+        if (inverse) out[b * D + src] = in[t];
+        else out[t] = in[b * D + src];
+    }
+}
+extern "C" int nf_squeeze1d(const float* in, float* out, int64_t B, int D, int odd, int inverse, nf_stream_t stream) {
+    if (D < 2 || (D & 1) || in == nullptr || out == nullptr) return NF_E_BADARG;
+    if (B <= 0) return B == 0 ? 0 : NF_E_BADARG;
+    hipLaunchKernelGGL(k_squeeze1d, dim3(nf_grid_for(B * D)), dim3(NF_BLOCK), 0, (hipStream_t)stream, in, out, B * D, D, odd ? 1 : 0,
+                       inverse ? 1 : 0);
+    NF_CHECK_LAUNCH();
+    return 0;
+}

@@ -9,3 +9,4 @@ Identity, Logit, ActNorm, BatchNorm, Compose, InvertibleConv1x1 = (_pkg.Identity
 MLP, ConvNet, ResBlockLinear, ResBlock2d = _cond.MLP, _cond.ConvNet, _cond.ResBlockLinear, _cond.ResBlock2d
 GatedLinear, GatedConv2d, GatedAttn, WeightNorm = _cond.GatedLinear, _cond.GatedConv2d, _cond.GatedAttn, _cond.WeightNorm
 MixLogCDF = _pkg.MixLogCDF
+Sigmoid, Tanh, Arctanh = _pkg.Sigmoid, _pkg.Tanh, _pkg.Arctanh

@@ -3,3 +3,4 @@ import importlib
 
 _pkg = importlib.import_module('normalizing-flows-pytorch_amd')
 Squeeze2d, Unsqueeze2d = _pkg.Squeeze2d, _pkg.Unsqueeze2d
+Squeeze1d, Unsqueeze1d = _pkg.Squeeze1d, _pkg.Unsqueeze1d

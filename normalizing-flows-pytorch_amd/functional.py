@@ -661,6 +661,72 @@ def logit(x, ld, eps, inverse=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# Sigmoid / Tanh / Arctanh (flows/modules.py:125-183) and Squeeze1d / Unsqueeze1d (flows/squeeze.py:114-151)
+# ----------------------------------------------------------------------------------------------------------------------
+BIJ_SIGMOID, BIJ_SIGMOID_INV, BIJ_TANH, BIJ_ARCTANH = 0, 1, 2, 3
+
+
+class _Bijector(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ld, kind):
+        B = x.shape[0]
+        n = x.numel() // B if B else 1
+        y = torch.empty_like(x)
+        N.call('nf_bijector_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), kind, B, n, N.stream())
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        ctx.mark_dirty(ld)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, g_y, g_ld):
+        (x, ) = ctx.saved_tensors
+        g_y, g_ld = _contig(g_y), _contig(g_ld)
+        g_x = torch.empty_like(x)
+        N.call('nf_bijector_bwd', N.ptr(g_y), N.ptr(g_ld), N.ptr(x), N.ptr(g_x), ctx.kind, x.shape[0], x.numel() // max(x.shape[0], 1),
+               N.stream())
+        return g_x, g_ld, None
+
+
+def bijector(x, ld, kind):
+    """one elementwise bijector pass, ld[b] += its per-sample log-det.  The modules' forward directions (sigmoid, tanh, arctanh) build an
+    autograd graph; the Sigmoid module's inverse (kind BIJ_SIGMOID_INV) builds none, like every inverse direction here."""
+    x = _contig(x)
+    ld = _owned_ld(ld)
+    if kind != BIJ_SIGMOID_INV and torch.is_grad_enabled() and (x.requires_grad or ld.requires_grad):
+        return _Bijector.apply(x, ld, kind)
+    with torch.no_grad():
+        y = torch.empty_like(x)
+        N.call('nf_bijector_fwd', N.ptr(x), N.ptr(y), N.ptr(ld), kind, x.shape[0], x.numel() // max(x.shape[0], 1), N.stream())
+    return y, ld
+
+
+class _Squeeze1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, odd, inverse):
+        z = _contig(z)
+        out = torch.empty_like(z)
+        N.call('nf_squeeze1d', N.ptr(z), N.ptr(out), z.shape[0], z.shape[1], int(odd), int(inverse), N.stream())
+        ctx.meta = (int(odd), int(inverse))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        odd, inverse = ctx.meta
+        g = _contig(g)
+        out = torch.empty_like(g)
+        N.call('nf_squeeze1d', N.ptr(g), N.ptr(out), g.shape[0], g.shape[1], odd, 1 - inverse, N.stream())
+        return out, None, None
+
+
+def squeeze1d(z, odd=False, inverse=False):
+    """(B, D) -> cat(z[:, odd::2], z[:, 1 - odd::2]) (flows/squeeze.py:63-83, :124-127); inverse=True: the inverse map."""
+    if z.dim() != 2 or z.shape[1] % 2:
+        raise ValueError('squeeze1d takes (B, D) data with even D, got %s' % (tuple(z.shape), ))
+    return _Squeeze1d.apply(z, bool(odd), bool(inverse))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # Flow++ mixture-of-logistics coupling
 # ----------------------------------------------------------------------------------------------------------------------
 class _MixLogCoupling(torch.autograd.Function):

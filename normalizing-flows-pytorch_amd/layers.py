@@ -313,6 +313,66 @@ class Logit(nn.Module):
         return NF.logit(x, log_df_dz, self.eps, inverse=True)
 
 
+class Sigmoid(nn.Module):
+    """flows/modules.py:125-138"""
+
+    def forward(self, x, log_df_dz):
+        return NF.bijector(x, log_df_dz, NF.BIJ_SIGMOID)
+
+    def backward(self, x, log_df_dz):
+        return NF.bijector(x, log_df_dz, NF.BIJ_SIGMOID_INV)
+
+
+class Tanh(nn.Module):
+    """flows/modules.py:158-170"""
+
+    def forward(self, x, log_df_dz):
+        return NF.bijector(x, log_df_dz, NF.BIJ_TANH)
+
+    def backward(self, x, log_df_dz):
+        with torch.no_grad():
+            return NF.bijector(x, log_df_dz, NF.BIJ_ARCTANH)
+
+
+class Arctanh(nn.Module):
+    """flows/modules.py:173-183 (its log-det sums over dim 1: vector data)"""
+
+    def forward(self, x, log_df_dz):
+        return NF.bijector(x, log_df_dz, NF.BIJ_ARCTANH)
+
+    def backward(self, x, log_df_dz):
+        with torch.no_grad():
+            return NF.bijector(x, log_df_dz, NF.BIJ_TANH)
+
+
+class Squeeze1d(nn.Module):
+    """flows/squeeze.py:114-132: the alternating entries of a vector as two concatenated halves"""
+
+    def __init__(self, odd=False):
+        super().__init__()
+        self.odd = bool(odd)
+
+    def forward(self, z, log_df_dz):
+        return NF.squeeze1d(z, self.odd), log_df_dz
+
+    def backward(self, z, log_df_dz):
+        return NF.squeeze1d(z, self.odd, inverse=True), log_df_dz
+
+
+class Unsqueeze1d(nn.Module):
+    """flows/squeeze.py:135-151: the inverse map of Squeeze1d as a forward layer"""
+
+    def __init__(self, odd=False):
+        super().__init__()
+        self.odd = bool(odd)
+
+    def forward(self, z, log_df_dz):
+        return NF.squeeze1d(z, self.odd, inverse=True), log_df_dz
+
+    def backward(self, z, log_df_dz):
+        return NF.squeeze1d(z, self.odd), log_df_dz
+
+
 class MixLogCDF(nn.Module):
     """flows/modules.py:186-212: CDF of a mixture of logistics as a bijector of x given (log_pi, mu, s); the inverse is the
     reference's bisection (25 or 100 iterations by its batch-global exit rule).  One HIP launch forward, two inverse."""

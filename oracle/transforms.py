@@ -151,6 +151,39 @@ def logit_inverse(y, ld):
 # a8 / a9  mixture-of-logistics CDF and its bisection inverse               flows/modules.py:64-97, :186-212
 # ---------------------------------------------------------------------------------------------------------------------
 
+def sigmoid(x, ld, inverse=False):
+    """Sigmoid.forward / .backward (flows/modules.py:125-138; helpers :19-32)"""
+    if not inverse:
+        return torch.sigmoid(x), ld + _per_sample_sum(_log_deriv_sigmoid(x))
+    x = torch.clamp(x, 1.0e-8, 1.0 - 1.0e-8)                                   # modules.py:135
+    y = torch.logit(torch.clamp(x, 1.0e-8, 1.0 - 1.0e-8))                      # log_deriv_logit's own clamp, modules.py:29-32
+    return torch.logit(x), ld + _per_sample_sum(-_log_deriv_sigmoid(y))
+
+
+def tanh(x, ld, inverse=False):
+    """Tanh.forward / .backward (flows/modules.py:158-170; deriv_tanh :40-43, deriv_arctanh :58-61); Arctanh is the same pair swapped"""
+    if not inverse:
+        y = torch.tanh(x)
+        return y, ld + _per_sample_sum(torch.log(1.0 - y * y))
+    xc = torch.clamp(x, -1.0 + 1.0e-8, 1.0 - 1.0e-8)
+    return torch.arctanh(x), ld + _per_sample_sum(torch.log(1.0 / (1.0 - xc * xc)))
+
+
+def squeeze1d_layer(z, odd=False, inverse=False):
+    """Squeeze1d.forward / .backward (flows/squeeze.py:63-83, :114-132)"""
+    B, C = z.shape
+    if not inverse:
+        v = z.view(B, C // 2, 2)
+        z0, z1 = v[:, :, 0], v[:, :, 1]
+        if odd:
+            z0, z1 = z1, z0
+        return torch.cat([z0, z1], dim=1)
+    z0, z1 = torch.split(z, C // 2, dim=1)
+    if odd:
+        z0, z1 = z1, z0
+    return torch.stack([z0, z1], dim=-1).view(B, -1).contiguous()
+
+
 def _mix_logpdf(x, logpi, mu, s):
     u = (x.unsqueeze(1) - mu) * torch.exp(-s)                      # modules.py:64-67
     return torch.logsumexp(logpi + (u - s - 2.0 * F.softplus(u)), dim=1)    # modules.py:76-85

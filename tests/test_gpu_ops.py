@@ -720,3 +720,51 @@ def test_bf16_split_is_no_precision_reduction(nf, K):
         assert e_split <= 1.25 * e_fp32 + 1e-7 * mag, (K, seed, e_fp32, e_split, mag)
         assert e_split <= 1e-5 * mag and e_fp32 <= 1e-5 * mag, (K, seed, e_fp32, e_split, mag)
     print('K = %d: max |fp32 MFMA - f64| %.3e   max |bf16 x 3 - f64| %.3e' % (K, max(w[0] for w in worst), max(w[1] for w in worst)))
+
+
+@pytest.mark.parametrize('shape', [(64, 2), (7, 6), (5, 3, 8, 8), (3, 5000)])
+def test_sigmoid_tanh_arctanh_modules_match_the_oracle(nf, shape):
+    """Sigmoid / Tanh / Arctanh (flows/modules.py:125-183) on csrc/logit.hip: both directions against the oracle's restatement (pinned
+    against the live reference in tests/test_oracle_vs_reference.py), values, log-dets and the autograd of the forward directions."""
+    from oracle import transforms as tf
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape) * 1.5
+    u = torch.rand(*shape)
+    t = torch.rand(*shape) * 1.96 - 0.98
+    ld0 = torch.randn(shape[0])
+    cases = [(nf.Sigmoid(), 'forward', x, lambda a, l: tf.sigmoid(a, l)), (nf.Sigmoid(), 'backward', u, lambda a, l: tf.sigmoid(a, l, inverse=True)),
+             (nf.Tanh(), 'forward', x, lambda a, l: tf.tanh(a, l)), (nf.Tanh(), 'backward', t, lambda a, l: tf.tanh(a, l, inverse=True)),
+             (nf.Arctanh(), 'forward', t, lambda a, l: tf.tanh(a, l, inverse=True)), (nf.Arctanh(), 'backward', x, lambda a, l: tf.tanh(a, l))]
+    n = float(x[0].numel())
+    for mod, direction, inp, ora in cases:
+        a_g = inp.to(DEV).requires_grad_(direction == 'forward')
+        y, ld = getattr(mod, direction)(a_g, ld0.to(DEV).clone())
+        a_c = inp.clone().requires_grad_(direction == 'forward')
+        yo, ldo = ora(a_c, ld0.clone())
+        G.assert_close(y, yo, 2e-6 * max(1.0, float(yo.abs().max())), rtol=2e-6, what='%s.%s y' % (type(mod).__name__, direction))
+        G.assert_close(ld, ldo, 2e-6 * n * max(1.0, float(ldo.abs().max()) / n), rtol=1e-5, what='%s.%s ld' % (type(mod).__name__, direction))
+        if direction == 'forward':
+            wy, wl = torch.randn_like(yo), torch.randn_like(ldo)
+            ((y * wy.to(DEV)).sum() + (ld * wl.to(DEV)).sum()).backward()
+            ((yo * wy).sum() + (ldo * wl).sum()).backward()
+            G.assert_close(a_g.grad, a_c.grad, 1e-5 * max(1.0, float(a_c.grad.abs().max())), rtol=1e-5, what='%s grad' % type(mod).__name__)
+
+
+@pytest.mark.parametrize('B,D', [(1, 2), (33, 6), (1000, 2), (5, 64)])
+def test_squeeze1d_modules_bit_exact(nf, B, D):
+    """Squeeze1d / Unsqueeze1d (flows/squeeze.py:114-151): bit-exact against the oracle's index map, both layers, both directions, odd and
+    even; the gradient of the forward direction is the inverse permutation."""
+    from oracle import transforms as tf
+    z = torch.randn(B, D)
+    ld = torch.zeros(B, device=DEV)
+    for odd in (False, True):
+        zg = z.to(DEV).requires_grad_(True)
+        out, ld2 = nf.Squeeze1d(odd).forward(zg, ld)
+        assert ld2 is ld
+        assert torch.equal(out.detach().cpu(), tf.squeeze1d_layer(z, odd))
+        w = torch.randn(B, D)
+        (out * w.to(DEV)).sum().backward()
+        assert torch.equal(zg.grad.cpu(), tf.squeeze1d_layer(w, odd, inverse=True))
+        assert torch.equal(nf.Squeeze1d(odd).backward(z.to(DEV), ld)[0].cpu(), tf.squeeze1d_layer(z, odd, inverse=True))
+        assert torch.equal(nf.Unsqueeze1d(odd).forward(z.to(DEV), ld)[0].cpu(), tf.squeeze1d_layer(z, odd, inverse=True))
+        assert torch.equal(nf.Unsqueeze1d(odd).backward(z.to(DEV), ld)[0].cpu(), tf.squeeze1d_layer(z, odd))

@@ -192,3 +192,31 @@ def test_product_additive_coupling_and_odd_squeeze_match_reference_construction(
     full = im.squeeze2d(z)
     h = full.shape[1] // 2
     assert torch.equal(torch.cat([z0, z1], 1), torch.cat([full[:, h:], full[:, :h]], 1))
+
+
+def test_elementwise_bijectors_and_squeeze1d_match_reference(ref_flows):
+    """the bijector modules no reference model builds (flows/modules.py:125-183) and Squeeze1d / Unsqueeze1d (flows/squeeze.py:114-151):
+    the oracle's restatements against the live modules, both directions, values and log-dets; the index maps bit-exact."""
+    import importlib
+    rm = importlib.import_module(ref_flows.__name__ + '.modules')
+    rs = importlib.import_module(ref_flows.__name__ + '.squeeze')
+    torch.manual_seed(5)
+    x = torch.randn(16, 6) * 2.0
+    u = torch.rand(16, 6)
+    u[0, 0], u[1, 1] = 0.0, 1.0                                        # the clamp's edges
+    t = torch.rand(16, 6) * 1.98 - 0.99
+    ld0 = torch.randn(16)
+    for got, want in ((tf.sigmoid(x, ld0.clone()), rm.Sigmoid().forward(x, ld0.clone())),
+                      (tf.sigmoid(u, ld0.clone(), inverse=True), rm.Sigmoid().backward(u, ld0.clone())),
+                      (tf.tanh(x, ld0.clone()), rm.Tanh().forward(x, ld0.clone())),
+                      (tf.tanh(t, ld0.clone(), inverse=True), rm.Tanh().backward(t, ld0.clone())),
+                      (tf.tanh(t, ld0.clone(), inverse=True), rm.Arctanh().forward(t, ld0.clone())),
+                      (tf.tanh(x, ld0.clone()), rm.Arctanh().backward(x, ld0.clone()))):
+        assert torch.equal(got[0], want[0]) or torch.allclose(got[0], want[0], atol=1e-6, rtol=1e-6)
+        assert torch.allclose(got[1], want[1], atol=1e-5, rtol=1e-6, equal_nan=True)     # (x = 1 is clamped to 1.0f: the reference itself yields nan)
+    z = torch.arange(5 * 8, dtype=torch.float32).view(5, 8)
+    for odd in (False, True):
+        assert torch.equal(tf.squeeze1d_layer(z, odd), rs.Squeeze1d(odd).forward(z, ld0[:5])[0])
+        assert torch.equal(tf.squeeze1d_layer(z, odd, inverse=True), rs.Squeeze1d(odd).backward(z, ld0[:5])[0])
+        assert torch.equal(tf.squeeze1d_layer(z, odd, inverse=True), rs.Unsqueeze1d(odd).forward(z, ld0[:5])[0])
+        assert torch.equal(tf.squeeze1d_layer(tf.squeeze1d_layer(z, odd), odd, inverse=True), z)
