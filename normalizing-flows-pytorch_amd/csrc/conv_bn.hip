@@ -246,6 +246,8 @@ extern "C" int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O,
     if (desc->residual != nullptr && ksize != 3) return NF_E_BADARG;
     if (nf_conv_bulk_fwd_plan(desc, B, I, O, H, W, ksize))          // large batches: independent waves on the bf16 matrix pipe (conv_bulk.hip)
         return nf_conv_bulk_fwd(desc, B, I, H, W, training, bn_eps, bn_momentum, (hipStream_t)stream);
+    if (nf_conv1_bulk_fwd_plan(desc, B, I, O, H, W, ksize))         // ... and the 1x1 output convolution: operands straight from global memory
+        return nf_conv1_bulk_fwd(desc, B, O, H, W, training, bn_eps, bn_momentum, (hipStream_t)stream);
     const int OCB = (O + 31) / 32;
     const int T = ksize * ksize;
     size_t tiles_f = (size_t)T * 32 * (32 * OCB + 1) + (size_t)32 * g.CS;
@@ -967,6 +969,8 @@ extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, in
     if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
     if (nf_conv_bulk_bwd_plan(desc, B, I, O, H, W, ksize))          // large batches, data pass: conv_bulk.hip
         return nf_conv_bulk_bwd(desc, B, I, H, W, (hipStream_t)stream);
+    if (nf_conv1_bulk_bwd_plan(desc, B, I, O, H, W, ksize))
+        return nf_conv1_bulk_bwd(desc, B, O, H, W, (hipStream_t)stream);
     const int ICB = (I + 31) / 32, OCB = (O + 31) / 32;
     const int T = ksize * ksize;
     size_t body = (size_t)T * 32 * OCB * NF_CV_WS + (size_t)32 * g.CS + (size_t)32 * OCB * g.CS;

@@ -1049,6 +1049,278 @@ static int nf_cb_cus() {
     }
     return cus;
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 1x1 output convolution of the conditioner (flows/modules.py:429-434: BatchNorm2d, ReLU, 32 -> O channels) at large batches.
+// No tap reaches a neighbour, so there is no frame and no LDS traffic at all: lane (pixel c32 of a 32-pixel block, K half hs) loads
+// the eight channels of the octets 2 p + hs of ITS pixel straight into the B-operand layout (eight dword loads per octet, 32 lanes =
+// 128 consecutive bytes each), applies BatchNorm + ReLU and the three-way split in registers; the weights are A operands held in
+// registers for the whole launch.  A wave owns units of 64 pixels, the next unit's loads in flight under the current one's products.
+// The launches move whole tensors for 1.2 GFLOP: HBM-bound (forward 23 MB, data gradient 40 MB at 16 x 16, B = 512).
+//   k_conv1_bulk_fwd<OB>: out rows 32 ob .. of O <= 32 OB channels;  k_conv1_bulk_bwd<NP>: G = g_direct (O <= 16 NP channels),
+//   gn_out = (W^T G) [act > 0] with its two batch sums.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// eight fp32 values -> the three bf16x8 planes of an operand
+__device__ __forceinline__ void nf_c1_split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        bf16x2 h2, m2, l2;
+        nf_cc_split2(f32x2{v[j], v[j + 1]}, h2, m2, l2);
+        h[j] = h2[0]; h[j + 1] = h2[1]; m[j] = m2[0]; m[j + 1] = m2[1]; l[j] = l2[0]; l[j + 1] = l2[1];
+    }
+}
+#define NF_C1_MFMA6(ACC, A, B)                                                           \
+    do {                                                                                 \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);         \
+    } while (0)
+struct NfC1Geo { int HW, lgHW; int64_t B, Npx, units; };
+// byte offset of (sample of pixel p, channel 0, pixel) in a (B, C, H, W) tensor, or out of range
+__device__ __forceinline__ unsigned nf_c1_off(const NfC1Geo& g, int64_t p, int C) {
+    const int64_t b = p >> g.lgHW;
+    const int q = (int)(p & (g.HW - 1));
+    return p < g.Npx ? 4u * (unsigned)(b * C * g.HW + q) : NF_CB_OOB;
+}
+
+template <int OB>
+__global__ void __launch_bounds__(NF_CB_THREADS) k_conv1_bulk_fwd(nf_conv_desc d, NfC1Geo g, int O, int training, float eps, float mom) {
+    __shared__ float kc[64];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c32 = lane & 31, hs = lane >> 5;
+    // A operands: rows = output channels 32 ob + c32, K = input channels of the octets 2 p + hs (p = 0, 1)
+    bf16x8 a[OB][2][3];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float v[8];
+            const int oc = 32 * ob + c32;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = oc < O ? d.weight[(size_t)oc * 32 + 8 * (2 * p + hs) + j] : 0.f;
+            nf_c1_split8(v, a[ob][p][0], a[ob][p][1], a[ob][p][2]);
+        }
+    nf_cv_bn_consts_fwd(kc, d, 32, g.Npx, training, eps, mom);
+    float bias_r[OB][16];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = 32 * ob + nf_cv_cd_row(r, hs);
+            bias_r[ob][r] = oc < O ? d.bias[oc] : 0.f;
+        }
+    __syncthreads();
+    float sc[2][8], sh[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[p][j] = kc[8 * (2 * p + hs) + j]; sh[p][j] = kc[32 + 8 * (2 * p + hs) + j]; }
+    const __amdgpu_buffer_rsrc_t ri = nf_cb_rsrc(d.in), ro = nf_cb_rsrc(d.out);
+    const int cstride = 4 * g.HW;
+    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
+    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
+    float raw[2][2][8];
+    auto issue = [&](int64_t un) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const unsigned off = nf_c1_off(g, un * 64 + 32 * nb + c32, 32);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[nb][p][j] = nf_cb_ld(ri, off, (8 * (2 * p + hs) + j) * cstride);
+        }
+    };
+    if (u < g.units) issue(u);
+    for (; u < g.units; u += stride) {
+        bf16x8 b[2][2][3];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(raw[nb][p][j], sc[p][j], sh[p][j]), 0.f);
+                nf_c1_split8(v, b[nb][p][0], b[nb][p][1], b[nb][p][2]);
+            }
+        if (u + stride < g.units) issue(u + stride);
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) NF_C1_MFMA6(acc[nb], a[ob][p], b[nb][p]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const unsigned off = nf_c1_off(g, u * 64 + 32 * nb + c32, O);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = 32 * ob + nf_cv_cd_row(r, hs);
+                    nf_cb_st(ro, oc < O ? off : NF_CB_OOB, oc * cstride, acc[nb][r] + bias_r[ob][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(NF_CB_THREADS) k_conv1_bulk_bwd(nf_conv_bwd_desc d, NfC1Geo g, int O) {
+    __shared__ float kc[4 * 32];
+    __shared__ float red[2 * 4 * 32];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c32 = lane & 31, hs = lane >> 5;
+    // A operands: rows = input channels c32, K = output channels of the octets 2 p + hs (the transposed weight)
+    bf16x8 a[NP][3];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int oc = 8 * (2 * p + hs) + j;
+            v[j] = oc < O ? d.weight[(size_t)oc * 32 + c32] : 0.f;
+        }
+        nf_c1_split8(v, a[p][0], a[p][1], a[p][2]);
+    }
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x;
+        const float mean = d.bn_save_mean[k], invstd = d.bn_save_invstd[k];
+        const float scv = d.bn_gamma[k] * invstd;
+        kc[k] = scv; kc[32 + k] = d.bn_beta[k] - mean * scv; kc[64 + k] = mean; kc[96 + k] = invstd;
+    }
+    __syncthreads();
+    float ksc[16], ksh[16], kmean[16], kinv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ic = nf_cv_cd_row(r, hs);
+        ksc[r] = kc[ic]; ksh[r] = kc[32 + ic]; kmean[r] = kc[64 + ic]; kinv[r] = kc[96 + ic];
+    }
+    const __amdgpu_buffer_rsrc_t rg = nf_cb_rsrc(d.g_direct), ri = nf_cb_rsrc(d.in), rn = nf_cb_rsrc(d.gn_out);
+    const int cstride = 4 * g.HW;
+    const int64_t stride = (int64_t)gridDim.x * NF_CB_WAVES;
+    int64_t u = (int64_t)blockIdx.x * NF_CB_WAVES + wid;
+    float raw[2][NP][8], xin[2][16];
+    auto issue = [&](int64_t un) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int64_t p0 = un * 64 + 32 * nb + c32;
+            const unsigned og = nf_c1_off(g, p0, O), oi = nf_c1_off(g, p0, 32);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int oc = 8 * (2 * p + hs) + j;
+                    raw[nb][p][j] = nf_cb_ld(rg, oc < O ? og : NF_CB_OOB, oc * cstride);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xin[nb][r] = nf_cb_ld(ri, oi, nf_cv_cd_row(r, hs) * cstride);
+        }
+    };
+    float sg[16], sgx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sg[r] = 0.f; sgx[r] = 0.f; }
+    if (u < g.units) issue(u);
+    for (; u < g.units; u += stride) {
+        bf16x8 b[2][NP][3];
+        float x[2][16];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) nf_c1_split8(raw[nb][p], b[nb][p][0], b[nb][p][1], b[nb][p][2]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[nb][r] = xin[nb][r];
+        }
+        if (u + stride < g.units) issue(u + stride);
+        f32x16 acc[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) NF_C1_MFMA6(acc[nb], a[p], b[nb][p]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const unsigned off = nf_c1_off(g, u * 64 + 32 * nb + c32, 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float gn = fmaf(x[nb][r], ksc[r], ksh[r]) > 0.f ? acc[nb][r] : 0.f;
+                gn = off != NF_CB_OOB ? gn : 0.f;
+                sg[r] += gn;
+                sgx[r] = fmaf(gn, (x[nb][r] - kmean[r]) * kinv[r], sgx[r]);
+                nf_cb_st(rn, off, nf_cv_cd_row(r, hs) * cstride, gn);
+            }
+        }
+    }
+    if (d.sum_g != nullptr) {                          // block-uniform
+        const float t1 = nf_cv_butterfly16(sg, c32), t2 = nf_cv_butterfly16(sgx, c32);
+        if ((c32 & 1) == 0) {
+            const int ic = nf_cv_cd_row(c32 >> 1, hs);
+            red[(0 * 4 + wid) * 32 + ic] = t1;
+            red[(1 * 4 + wid) * 32 + ic] = t2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
+            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+            atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
+        }
+    }
+}
+
+static bool nf_c1_geometry(NfC1Geo& g, int64_t B, int H, int W) {
+    g.HW = H * W; g.lgHW = nf_cv_log2(g.HW); g.B = B; g.Npx = B * g.HW;
+    g.units = (g.Npx + 63) / 64;
+    return g.lgHW >= 5 && B * 192 * (int64_t)g.HW < ((int64_t)1 << 29);      // whole 32-pixel blocks inside a sample; 32-bit byte offsets
+}
+static int nf_c1_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("NF_CONV_BULK_1X1"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
+    return on;
+}
+int nf_conv1_bulk_fwd_plan(const nf_conv_desc* d, int64_t B, int I, int O, int H, int W, int ksize) {
+    NfC1Geo g;
+    if (!nf_c1_on() || !nf_cb_on() || ksize != 1 || I != 32 || O < 1 || O > 64 || B * H * W < nf_cb_min_px()) return 0;
+    if (d->bn_gamma == nullptr || d->residual != nullptr || d->stat_sum != nullptr) return 0;
+    return nf_c1_geometry(g, B, H, W) ? 1 : 0;
+}
+int nf_conv1_bulk_fwd(const nf_conv_desc* desc, int64_t B, int O, int H, int W, int training, float eps, float mom, hipStream_t st) {
+    NfC1Geo g;
+    if (!nf_c1_geometry(g, B, H, W)) return NF_E_BADARG;
+    const int64_t wgs = (g.units + NF_CB_WAVES - 1) / NF_CB_WAVES;
+    const unsigned grid = (unsigned)(wgs < nf_cb_cus() ? wgs : nf_cb_cus());
+    if (O <= 32) hipLaunchKernelGGL((k_conv1_bulk_fwd<1>), dim3(grid), dim3(NF_CB_THREADS), 0, st, *desc, g, O, training, eps, mom);
+    else hipLaunchKernelGGL((k_conv1_bulk_fwd<2>), dim3(grid), dim3(NF_CB_THREADS), 0, st, *desc, g, O, training, eps, mom);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+int nf_conv1_bulk_bwd_plan(const nf_conv_bwd_desc* d, int64_t B, int I, int O, int H, int W, int ksize) {
+    NfC1Geo g;
+    if (!nf_c1_on() || !nf_cb_on() || ksize != 1 || I != 32 || O < 1 || O > 48 || B * H * W < nf_cb_min_px()) return 0;
+    if (d->bn_gamma == nullptr || d->g_direct == nullptr || d->gn_src != nullptr || d->g_skip != nullptr || d->g_weff != nullptr ||
+        d->g_bias != nullptr || d->g_store != nullptr || d->gn_out == nullptr)
+        return 0;
+    return nf_c1_geometry(g, B, H, W) ? 1 : 0;
+}
+int nf_conv1_bulk_bwd(const nf_conv_bwd_desc* desc, int64_t B, int O, int H, int W, hipStream_t st) {
+    NfC1Geo g;
+    if (!nf_c1_geometry(g, B, H, W)) return NF_E_BADARG;
+    const int64_t wgs = (g.units + NF_CB_WAVES - 1) / NF_CB_WAVES;
+    const unsigned grid = (unsigned)(wgs < nf_cb_cus() ? wgs : nf_cb_cus());
+    const int np = (O + 15) / 16;
+    if (np == 1) hipLaunchKernelGGL((k_conv1_bulk_bwd<1>), dim3(grid), dim3(NF_CB_THREADS), 0, st, *desc, g, O);
+    else if (np == 2) hipLaunchKernelGGL((k_conv1_bulk_bwd<2>), dim3(grid), dim3(NF_CB_THREADS), 0, st, *desc, g, O);
+    else hipLaunchKernelGGL((k_conv1_bulk_bwd<3>), dim3(grid), dim3(NF_CB_THREADS), 0, st, *desc, g, O);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
 // does the large-batch kernel take this forward launch?  (called by nf_conv_bn_fwd; 0 = no, else NBLK)
 int nf_conv_bulk_fwd_plan(const nf_conv_desc* d, int64_t B, int I, int O, int H, int W, int ksize) {
     if (!nf_cb_on() || ksize != 3 || O != 32 || I < 1 || I > 32 || B * H * W < nf_cb_min_px()) return 0;

@@ -317,3 +317,78 @@ def test_bulk_weight_gradient_matches_float64_and_the_per_layer_kernel(bulk, B, 
         magb = float(Gd.abs().sum((0, 2, 3)).max())
         assert float((gb.double() - want_b).abs().max()) <= 2e-5 * max(1.0, magb), ('g_bias vs float64', float((gb.double() - want_b).abs().max()), magb)
         assert float((gb - ob).abs().max()) <= 2e-5 * max(1.0, magb)
+
+
+ONE = [(72, 12, 16, 16), (300, 48, 8, 8), (37, 24, 8, 8), (5, 12, 32, 32), (3, 64, 16, 16), (1, 7, 8, 8)]
+
+
+@pytest.mark.parametrize('B,O,H,W', ONE)
+def test_bulk_1x1_forward_and_data_gradient_match_float64_and_the_per_layer_kernel(bulk, B, O, H, W):
+    """the conditioner's 1x1 output convolution at large batches (k_conv1_bulk_fwd / _bwd: BatchNorm + ReLU and the split in registers,
+    operands straight from global memory): forward against float64 and the per-layer kernel; the data pass (G = g_direct) -- gn_out with
+    its ReLU mask and the two batch sums -- likewise."""
+    fc = importlib.import_module(bulk.__name__ + '.fused_conv')
+    torch.manual_seed(B + O)
+    I = 32
+    n = B * H * W
+    x = torch.randn(B, I, H, W, device=DEV) * 1.5 + 0.3
+    w = torch.randn(O, I, 1, 1, device=DEV) * 0.2
+    bias = torch.randn(O, device=DEV) * 0.2
+    gamma, beta = torch.rand(I, device=DEV) + 0.5, torch.randn(I, device=DEV) * 0.3
+    center = torch.randn(I, device=DEV) * 0.1
+    xs = (x - center.view(1, -1, 1, 1)).double()
+    s1, s2 = torch.zeros(R, 32, device=DEV), torch.zeros(R, 32, device=DEV)
+    s1[2] = xs.sum((0, 2, 3)).float()
+    s2[5] = (xs * xs).sum((0, 2, 3)).float()
+    xd = x.double()
+    mean = xd.mean((0, 2, 3))
+    var = xd.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    pre = (xd - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gamma.double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)
+    act = torch.relu(pre)
+    want = TF.conv2d(act, w.double(), bias.double())
+
+    def fwd(on):
+        _cfg(bulk, on, 0, 0)
+        out = torch.full((B, O, H, W), float('nan'), device=DEV)
+        rm, rv = torch.zeros(I, device=DEV), torch.ones(I, device=DEV)
+        sm, si = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+        fc._fwd((B, H, W), I, O, 1, True, in_=x, weight=w, bias=bias, out=out, bn_gamma=gamma, bn_beta=beta, bn_sum=s1.view(-1),
+                bn_sqsum=s2.view(-1), bn_center=center, bn_running_mean=rm, bn_running_var=rv, bn_save_mean=sm, bn_save_invstd=si)
+        torch.cuda.synchronize()
+        return out, rm, rv, sm, si
+
+    got, old = fwd(1), fwd(0)
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got[0].double() - want).abs().max()) <= 3e-5 * scale, float((got[0].double() - want).abs().max())
+    assert float((got[0] - old[0]).abs().max()) <= 1e-5 * scale
+    for a, b in zip(got[1:], old[1:]):
+        G.assert_close(a, b, 1e-6, rtol=1e-6)
+
+    g_direct = torch.randn(B, O, H, W, device=DEV)
+
+    def bwd(on):
+        _cfg(bulk, on, 0, 0)
+        gn_out = torch.full((B, I, H, W), float('nan'), device=DEV)
+        sg, sgx = _replicas(), _replicas()
+        fc._bwd((B, H, W), I, O, 1, in_=x, weight=w, g_direct=g_direct, gn_out=gn_out, bn_gamma=gamma, bn_beta=beta, bn_save_mean=mean.float(),
+                bn_save_invstd=invstd.float(), sum_g=sg, sum_gx=sgx)
+        torch.cuda.synchronize()
+        return gn_out, sg.view(R, 32).sum(0), sgx.view(R, 32).sum(0)
+
+    gb, ob = bwd(1), bwd(0)
+    gin = TF.conv_transpose2d(g_direct.double(), w.double())
+    risky = pre.abs() < 1e-5
+    gn = torch.where(pre > 0, gin, torch.zeros_like(gin))
+    sg_ = max(1.0, float(gn.abs().max()))
+    err = (gb[0].double() - gn).abs()
+    err[risky] = 0.0
+    assert float(err.max()) <= 1e-5 * sg_, float(err.max())
+    err = (gb[0] - ob[0]).abs()
+    err[risky] = 0.0
+    assert float(err.max()) <= 1e-5 * sg_
+    xhat = (xd - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    slack = int(risky.sum()) * sg_ * 4.0
+    G.assert_close(gb[1], gn.sum((0, 2, 3)).float(), 2e-5 * max(1.0, float(gn.abs().sum((0, 2, 3)).max())) + slack, what='sum_g')
+    G.assert_close(gb[2], (gn * xhat).sum((0, 2, 3)).float(), 2e-5 * max(1.0, float((gn * xhat).abs().sum((0, 2, 3)).max())) + slack, what='sum_gx')
+    assert n == B * H * W
