@@ -28,12 +28,31 @@ __global__ void __launch_bounds__(NF_BLOCK) k_nll_loss(const float* __restrict__
     const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float acc = 0.f;
-    for (int64_t t = gtid; t < B * D; t += gstride) {
-        const float v = z[t];
-        acc = fmaf(-0.5f * v, v, acc);
+    const int64_t n = B * D;
+    // 16 bytes per load where the tensors allow it (one 4-byte load per thread and trip left this pass at 36 % of the HBM rate)
+    if ((((uintptr_t)z | (uintptr_t)ld) & 15) == 0) {
+        const int64_t n4 = n >> 2, b4 = B >> 2;
+        const float4* z4 = reinterpret_cast<const float4*>(z);
+        const float4* l4 = reinterpret_cast<const float4*>(ld);
+        for (int64_t t = gtid; t < n4; t += gstride) {
+            const float4 v = z4[t];
+            acc -= 0.5f * ((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+        }
+        for (int64_t t = 4 * n4 + gtid; t < n; t += gstride) acc = fmaf(-0.5f * z[t], z[t], acc);
+        for (int64_t b = gtid; b < b4; b += gstride) {
+            const float4 v = l4[b];
+            acc += (v.x + v.y) + (v.z + v.w);
+        }
+        for (int64_t b = 4 * b4 + gtid; b < B; b += gstride) acc += ld[b];
+    } else {
+        for (int64_t t = gtid; t < n; t += gstride) {
+            const float v = z[t];
+            acc = fmaf(-0.5f * v, v, acc);
+        }
+        for (int64_t b = gtid; b < B; b += gstride) acc += ld[b];
     }
     const float cst = -0.5f * (float)D * 1.8378770664093453f;   // log(2 pi)
-    for (int64_t b = gtid; b < B; b += gstride) acc += ld[b] + cst;
+    if (gtid == 0) acc += cst * (float)B;
     const float tot = nf_block_sum(acc, scratch);
     if (threadIdx.x == 0) atomicAdd(loss, -tot / (float)B);
 }
@@ -41,6 +60,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_nll_loss(const float* __restrict__
 extern "C" int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream) {
     if (B <= 0 || D <= 0) return NF_E_BADARG;
     unsigned g = nf_grid_for(B * D, NF_BLOCK * 8);
+    if (g > 2048) g = 2048;                         // (one same-address atomic per workgroup: 24 k of them were the whole launch at 2^24 rows)
     hipLaunchKernelGGL(k_nll_loss, dim3(g), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, ld, loss, B, D);
     NF_CHECK_LAUNCH();
     return 0;
