@@ -413,6 +413,10 @@ typedef struct nf_conv_desc {
     float* stat_sqsum;
     const float* wpk;         /* optional: the weight's LDS images (nf_conv_weight_pack of this very weight); read by the large-batch
                                * 3x3 kernels (csrc/conv_bulk.hip), which split the weight themselves when it is NULL */
+    int valid_h, valid_w;     /* 0 = the whole map.  Else the VALID extent of a map kept in power-of-two storage (H, W of the call):
+                               * pixels with y >= valid_h or x >= valid_w are dead -- read as zero like the outside of the image,
+                               * absent from every batch statistic (whose count is B * valid_h * valid_w), never written.  This is
+                               * how maps whose sides are no powers of two (MNIST: 14 x 14, 7 x 7) run on these kernels.             */
 } nf_conv_desc;
 int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksize);
 /* Large batches (B*H*W > min_pixels, default 16384: beyond the persistent chain's 128 tiles): the 3x3 layers with <= 32 input and 32
@@ -565,6 +569,7 @@ typedef struct nf_conv_bwd_desc {
     float* sum_g;               /* NF_STAT_REPL x 32, += (with input BatchNorm) */
     float* sum_gx;
     const float* wpk;           /* optional, as in nf_conv_desc (the data gradient reads the transposed image of the same buffer) */
+    int valid_h, valid_w;       /* as in nf_conv_desc (0 = the whole map) */
 } nf_conv_bwd_desc;
 int nf_conv_bwd_slabs(int64_t B, int H, int W);
 int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, nf_stream_t stream);

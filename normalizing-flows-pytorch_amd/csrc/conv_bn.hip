@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, N
     const int nchunks = (I + 31) / 32;
 
     NF_CV_STAMP(0);
-    nf_cv_bn_consts_fwd(kc, d, I, Npx, training, eps, mom);
+    nf_cv_bn_consts_fwd(kc, d, I, g.Nvalid, training, eps, mom);
     const bool want_stats = d.stat_sum != nullptr;      // O <= 32 by contract
     const bool has_res = d.residual != nullptr;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};      // 3x3: this wave's four channels
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, N
         NF_CV_STAMP(20);
         const float* in0 = d.in + b0 * I * g.HW;
         const int64_t P = tile * NF_CV_PX + px;
-        const bool pv = P < Npx;
+        const bool pv = P < Npx && nf_cv_px_ok(g, P & (g.HW - 1));       // (dead pixels of a masked map: not stored, not summed)
         const int64_t b = pv ? P >> g.lgHW : 0;
         const int64_t q = pv ? P & (g.HW - 1) : 0;
         float rres[4], bias_r[4];                      // 3x3 epilogue operands, fetched under the staging and the K loop
@@ -244,9 +244,11 @@ extern "C" int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O,
     if (desc->bn_gamma != nullptr && I > 32) return NF_E_BADARG;          // statistics vectors are 32 wide
     if (desc->stat_sum != nullptr && (O > 32 || ksize != 3)) return NF_E_BADARG;
     if (desc->residual != nullptr && ksize != 3) return NF_E_BADARG;
-    if (nf_conv_bulk_fwd_plan(desc, B, I, O, H, W, ksize))          // large batches: independent waves on the bf16 matrix pipe (conv_bulk.hip)
+    if (!nf_cv_set_valid(g, desc->valid_h, desc->valid_w)) return NF_E_BADARG;
+    const bool masked = nf_cv_masked(g);               // a map in power-of-two storage: the per-layer kernels below only
+    if (!masked && nf_conv_bulk_fwd_plan(desc, B, I, O, H, W, ksize))          // large batches: independent waves on the bf16 matrix pipe (conv_bulk.hip)
         return nf_conv_bulk_fwd(desc, B, I, H, W, training, bn_eps, bn_momentum, (hipStream_t)stream);
-    if (nf_conv1_bulk_fwd_plan(desc, B, I, O, H, W, ksize))         // ... and the 1x1 output convolution: operands straight from global memory
+    if (!masked && nf_conv1_bulk_fwd_plan(desc, B, I, O, H, W, ksize))         // ... and the 1x1 output convolution: operands straight from global memory
         return nf_conv1_bulk_fwd(desc, B, O, H, W, training, bn_eps, bn_momentum, (hipStream_t)stream);
     const int OCB = (O + 31) / 32;
     const int T = ksize * ksize;
@@ -328,7 +330,7 @@ __device__ __forceinline__ void nf_cv_bwd_body(const nf_conv_bwd_desc& d, const 
     const bool has_bn = d.bn_gamma != nullptr;         // => ICB == 1
     const bool has_src = d.gn_src != nullptr;          // => OCB == 1
     const int64_t Npx = g.B * g.HW;
-    const float invN = 1.f / (float)Npx;
+    const float invN = 1.f / (float)g.Nvalid;           // (a masked map: the valid pixels only)
 
     NF_CV_STAMP(8);
     if (threadIdx.x < 32) {
@@ -386,7 +388,7 @@ __device__ __forceinline__ void nf_cv_bwd_body(const nf_conv_bwd_desc& d, const 
         const float* in0 = d.in + b0 * I * g.HW;
         const int64_t go0 = b0 * O * g.HW;             // sample b0 of the (B, O, H, W) tensors
         const int64_t P = tile * NF_CV_PX + px;
-        const bool pv = P < Npx;
+        const bool pv = P < Npx && nf_cv_px_ok(g, P & (g.HW - 1));
         const int64_t pb64 = pv ? P >> g.lgHW : 0;
         const int64_t pq = pv ? P & (g.HW - 1) : 0;
 #pragma unroll
@@ -967,9 +969,11 @@ extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, in
     if (desc->bn_gamma != nullptr && I > 32) return NF_E_BADARG;
     if (desc->gn_src != nullptr && O > 32) return NF_E_BADARG;            // consumer BatchNorm sums are 32 wide
     if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
-    if (nf_conv_bulk_bwd_plan(desc, B, I, O, H, W, ksize))          // large batches, data pass: conv_bulk.hip
+    if (!nf_cv_set_valid(g, desc->valid_h, desc->valid_w)) return NF_E_BADARG;
+    const bool masked = nf_cv_masked(g);
+    if (!masked && nf_conv_bulk_bwd_plan(desc, B, I, O, H, W, ksize))          // large batches, data pass: conv_bulk.hip
         return nf_conv_bulk_bwd(desc, B, I, H, W, (hipStream_t)stream);
-    if (nf_conv1_bulk_bwd_plan(desc, B, I, O, H, W, ksize))
+    if (!masked && nf_conv1_bulk_bwd_plan(desc, B, I, O, H, W, ksize))
         return nf_conv1_bulk_bwd(desc, B, O, H, W, (hipStream_t)stream);
     const int ICB = (I + 31) / 32, OCB = (O + 31) / 32;
     const int T = ksize * ksize;
@@ -1020,7 +1024,10 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
     if (!nf_cv_geometry(g, B, H, W, ksize)) return NF_E_BADARG;
     if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
     NfCvBwdMulti m{};
+    if (!nf_cv_set_valid(g, descs[0].valid_h, descs[0].valid_w)) return NF_E_BADARG;      // (one shape per launch: layer 0's extent)
+    const bool masked = nf_cv_masked(g);
     for (int k = 0; k < n; ++k) {
+        if (descs[k].valid_h != descs[0].valid_h || descs[k].valid_w != descs[0].valid_w) return NF_E_BADARG;
         if (descs[k].g_weff == nullptr || descs[k].in == nullptr) return NF_E_BADARG;
         if (descs[k].bn_gamma != nullptr && I > 32) return NF_E_BADARG;
         if (descs[k].gn_src != nullptr && O > 32) return NF_E_BADARG;
@@ -1033,15 +1040,15 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
     const unsigned grid = (unsigned)nf_conv_wgrad_slabs(B, H, W, n);
     bool one_plain = true;                             // (conv_bulk.hip keeps ONE plain gradient tensor per layer in flight)
     for (int k = 0; k < n; ++k) one_plain = one_plain && !(m.d[k].g_direct != nullptr && m.d[k].g_skip != nullptr);
-    if (one_plain && nf_conv_bulk_wgrad_plan(B, I, O, H, W, ksize))  // large batches: the pixel-contraction kernel of conv_bulk.hip (bf16 matrix pipe)
+    if (!masked && one_plain && nf_conv_bulk_wgrad_plan(B, I, O, H, W, ksize))  // large batches: the pixel-contraction kernel of conv_bulk.hip (bf16 matrix pipe)
         return nf_conv_bulk_wgrad(m.d, n, B, I, H, W, (int)grid, (hipStream_t)stream);
     const int iters = (int)((g.tiles + grid - 1) / grid);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     // the lean body addresses with 32-bit byte offsets (3x3, one input chunk: every hidden layer)
     const size_t lds_lean = sizeof(float) * ((size_t)2 * 64 * g.CS + 5 * 32 + 2 * 32);       // two frame pairs
-    const bool lean = ICB == 1 && OCB == 1 && B * (int64_t)(I > O ? I : O) * H * W < ((int64_t)1 << 30) && 64 * g.CS >= T * 1024 &&
-                      lds_lean <= 160 * 1024;
+    const bool lean = !masked && ICB == 1 && OCB == 1 && B * (int64_t)(I > O ? I : O) * H * W < ((int64_t)1 << 30) && 64 * g.CS >= T * 1024 &&
+                      lds_lean <= 160 * 1024;      // (the lean body classifies frame rows per tile, not per pixel: masked maps take the general one)
 #define NF_LAUNCH(T_, IB_, OB_, LEAN_)                                                                                 \
     do {                                                                                                               \
         const size_t lds_ = LEAN_ ? lds_lean : lds;                                                                    \

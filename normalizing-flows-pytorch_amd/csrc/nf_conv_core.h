@@ -30,6 +30,10 @@ struct NfCvGeo {
     float invFS, invFW;
     int64_t B;
     int64_t tiles;
+    int VH, VW;    // valid extent (<= H, W): pixels beyond it are DEAD -- zero on load like the outside of the image, absent from every
+                   // batch sum, never stored.  Maps whose sides are no powers of two (MNIST's 14 x 14, 7 x 7) live in power-of-two
+                   // storage (16 x 16, 8 x 8) this way: the tile arithmetic stays shifts, the mask is two compares in nf_cv_decode
+    int64_t Nvalid;  // B * VH * VW: the count of a batch statistic
 };
 
 static inline int nf_cv_log2(int v) {
@@ -62,8 +66,18 @@ static inline bool nf_cv_geometry(NfCvGeo& g, int64_t B, int H, int W, int ksize
     g.invFS = 1.f / (float)g.FS;
     g.invFW = 1.f / (float)g.FW;
     g.tiles = (B * g.HW + PX - 1) / PX;
+    g.VH = H; g.VW = W; g.Nvalid = B * g.HW;
     return true;
 }
+static inline bool nf_cv_set_valid(NfCvGeo& g, int vh, int vw) {      // 0 = the whole map
+    if (vh < 0 || vh > g.H || vw < 0 || vw > g.W) return false;
+    g.VH = vh > 0 ? vh : g.H; g.VW = vw > 0 ? vw : g.W;
+    g.Nvalid = g.B * g.VH * g.VW;
+    return true;
+}
+static inline bool nf_cv_masked(const NfCvGeo& g) { return g.VH != g.H || g.VW != g.W; }
+// pixel q of a sample (q = y W + x) inside the valid extent
+__device__ __forceinline__ bool nf_cv_px_ok(const NfCvGeo& g, int64_t q) { return (int)(q >> g.lgW) < g.VH && (int)(q & (g.W - 1)) < g.VW; }
 
 __device__ __forceinline__ int nf_cv_cd_row(int r, int hs) { return (r & 3) + 8 * (r >> 2) + 4 * hs; }
 
@@ -83,7 +97,7 @@ __device__ __forceinline__ int nf_cv_decode(const NfCvGeo& g, int64_t b0, int y0
     const int s = (int)(((float)f + 0.5f) * g.invFS), q = f - s * g.FS;
     const int fy = (int)(((float)q + 0.5f) * g.invFW), fx = q - fy * g.FW;
     const int gy = y0 + fy - g.halo, gx = fx - g.halo;
-    const bool ok = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W && (b0 + s) < g.B;
+    const bool ok = gy >= 0 && gy < g.VH && gx >= 0 && gx < g.VW && (b0 + s) < g.B;
     const bool owned = fy >= g.halo && fy < g.TH + g.halo && fx >= g.halo && fx < g.W + g.halo;
     return ok ? (((int)owned << 30) | (s << 16) | (gy * g.W + gx)) : -1;
 }

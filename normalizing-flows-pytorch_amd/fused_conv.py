@@ -30,11 +30,11 @@ _BWD_FIELDS = ['in_', 'weight', 'bn_gamma', 'bn_beta', 'bn_save_mean', 'bn_save_
 
 
 class ConvDesc(ctypes.Structure):
-    _fields_ = [(f, ctypes.c_void_p) for f in _FWD_FIELDS]
+    _fields_ = [(f, ctypes.c_void_p) for f in _FWD_FIELDS] + [('valid_h', ctypes.c_int), ('valid_w', ctypes.c_int)]
 
 
 class ConvBwdDesc(ctypes.Structure):
-    _fields_ = [(f, ctypes.c_void_p) for f in _BWD_FIELDS]
+    _fields_ = [(f, ctypes.c_void_p) for f in _BWD_FIELDS] + [('valid_h', ctypes.c_int), ('valid_w', ctypes.c_int)]
 
 
 class SlabSumDesc(ctypes.Structure):
@@ -231,7 +231,7 @@ class ConvDefer:
         for e in layers:
             groups.setdefault(e[0], []).append(e)
         for key, es in groups.items():
-            (B, Hh, Ww), I, O, k = key
+            (B, Hh, Ww), I, O, k = key[:4]           # (key[4]: the valid extent of maps in power-of-two storage, one per launch)
             for k0 in range(0, len(es), step):
                 chunk = es[k0:k0 + step]
                 slabs = _wgrad_slabs(B, Hh, Ww, len(chunk))       # (per launch: one workgroup per compute unit over all its layers)
@@ -328,15 +328,33 @@ def _convnet_modules(net):
     return convs, bns
 
 
+def _pow2_ceil(n):
+    return 1 << max(int(n) - 1, 0).bit_length()
+
+
+@functools.lru_cache(maxsize=None)
+def _storage_dims(B, I, O_out, Hv, Wv):
+    """(Hs, Ws, masked): the extent the per-layer kernels run a (Hv, Wv) map at.  The kernels tile maps whose sides are powers
+    of two (the CIFAR pyramid: 16, 8, 4); any other map (the 28 x 28 pyramid: 14, 7) is held in the next power-of-two storage
+    with its valid extent in the descriptors (nf_conv_desc.valid_h / valid_w): the dead border reads as zero padding and stays
+    out of every sum.  None when neither fits."""
+    lib = N.load()
+    ok = lambda h, w: bool(lib.nf_conv_bn_usable(B, I, H, h, w, 3) and lib.nf_conv_bn_usable(B, H, O_out, h, w, 1))
+    if ok(Hv, Wv):
+        return Hv, Wv, False
+    Hs, Ws = _pow2_ceil(Hv), _pow2_ceil(Wv)
+    return (Hs, Ws, True) if ok(Hs, Ws) else None
+
+
 def convnet_usable(net, x):
     """ConvNet with two residual blocks of 32 filters on an input whose spatial size tiles into the kernels' 128-pixel
-    groups (every level of the reference's CIFAR / MNIST-style pyramids does)."""
+    groups (every level of the reference's CIFAR pyramid does) or fits such a map with a dead border (the 28 x 28 pyramid)."""
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
         return False
-    return _convnet_usable_shape(net, tuple(x.shape))
+    return _convnet_usable_shape(net, tuple(x.shape), padded=True)
 
 
-def _convnet_usable_shape(net, shape):
+def _convnet_usable_shape(net, shape, padded=False):
     if not (shape[0] > 0 and len(net.mid_block) == 2):
         return False
     convs, _ = _convnet_modules(net)
@@ -345,8 +363,8 @@ def _convnet_usable_shape(net, shape):
     if c0.out_channels != H or c5.in_channels != H or c0.kernel_size != (3, 3) or c5.kernel_size != (1, 1):
         return False
     B, I, Hh, Ww = shape
-    lib = N.load()
-    return bool(lib.nf_conv_bn_usable(B, I, H, Hh, Ww, 3) and lib.nf_conv_bn_usable(B, H, c5.out_channels, Hh, Ww, 1))
+    dims = _storage_dims(B, I, c5.out_channels, Hh, Ww)
+    return dims is not None and (padded or not dims[2])
 
 
 def _convnet_tensors(net):
@@ -369,9 +387,15 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
     conv = [tensors[2 * i:2 * i + 2] for i in range(nl)]
     bns = [tensors[2 * nl + 5 * i:2 * nl + 5 * i + 5] for i in range(nb)]
     x = x.contiguous()
-    B, I0, Hh, Ww = x.shape
-    shape = (B, Hh, Ww)
+    B, I0, Hv, Wv = x.shape
     O_out = conv[-1][0].shape[0]
+    Hh, Ww, masked = _storage_dims(B, I0, O_out, Hv, Wv)
+    vk = dict(valid_h=Hv, valid_w=Wv) if masked else {}
+    if masked:                                # power-of-two storage; the kernels never read the dead border of the activations
+        xs = x.new_zeros(B, I0, Hh, Ww)
+        xs[:, :, :Hv, :Wv] = x
+        x = xs
+    shape = (B, Hh, Ww)
     dev = x.device
     ws = WS.zeros(nb * WS_ROWS * H, dev).view(nb, WS_ROWS, H)
     acts = [torch.empty(B, H, Hh, Ww, dtype=torch.float32, device=dev) for _ in range(nb)]
@@ -387,7 +411,7 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
     def stats(j):                             # evaluation mode normalises with running statistics: no batch sums
         return dict(stat_sum=ws[j, 0], stat_sqsum=ws[j, R]) if training else {}
 
-    if _chain_usable(B, I0, O_out, Hh, Ww):   # the whole conditioner: ONE persistent launch (csrc/conv_chain.hip)
+    if not masked and _chain_usable(B, I0, O_out, Hh, Ww):   # the whole conditioner: ONE persistent launch (csrc/conv_chain.hip)
         d = ConvNetDesc()
         d.x = x.data_ptr()
         for i in range(nl):
@@ -418,13 +442,13 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
             raise RuntimeError('the fused coupling needs the chain kernel (coupling_fusable was not consulted)')
         # (large batches: the 3x3 layers run on csrc/conv_bulk.hip, which reads the pass's weight images when they exist)
         pk = (lambda i: packs[i].buf) if packs is not None else (lambda i: None)
-        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], wpk=pk(0), **stats(0))
+        _fwd(shape, I0, H, 3, training, in_=x, weight=w[0], bias=conv[0][1], out=acts[0], wpk=pk(0), **stats(0), **vk)
         for j in range(1, nb):                # convolution j consumes acts[j-1] through BatchNorm j-1
             res = acts[j - 2] if j % 2 == 0 else None
             _fwd(shape, H, H, 3, training, in_=acts[j - 1], weight=w[j], bias=conv[j][1], residual=res, out=acts[j], wpk=pk(j),
-                 **stats(j), **bn_kw(j - 1))
+                 **stats(j), **bn_kw(j - 1), **vk)
         _fwd(shape, H, O_out, 1, training, in_=acts[nb - 1], weight=w[nl - 1], bias=conv[nl - 1][1], out=out,
-             **bn_kw(nb - 1))
+             **bn_kw(nb - 1), **vk)
     from .functional import _sinks
     extra = ()
     if cpl is not None:
@@ -433,9 +457,12 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
         ctx.cpl_sinks = _sinks(cpl[2], cpl[3])
     ctx.save_for_backward(x, ws, *acts, *w, *[t for b in bns for t in b[:2]], *extra)
     ctx.meta = (shape, I0, O_out, bool(training))
+    ctx.valid = (Hv, Wv) if masked else None
     ctx.packs = packs
     ctx.sinks = _sinks(*[c[1] for c in conv], *[t for b in bns for t in b[:2]])
     ctx.defer = bool(defer) and ctx.sinks is not None
+    if masked:
+        out = out[:, :, :Hv, :Wv].contiguous()
     return out if cpl is None else y
 
 
@@ -489,9 +516,16 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
     beta = [gb[2 * i + 1] for i in range(nb)]
     dev = x.device
     B, Hh, Ww = shape
+    valid = getattr(ctx, 'valid', None)
+    vk = dict(valid_h=valid[0], valid_w=valid[1]) if valid else {}
+    if valid:                                  # (the dead border of the gradient is never read)
+        gs = g_out.new_empty(B, O_out, Hh, Ww)
+        gs[:, :, :valid[0], :valid[1]] = g_out
+        g_out = gs
     g_out = g_out.contiguous() if cpl is None else torch.empty_like(cpl[1])    # fused coupling: written by the chain launch
     slabs = int(N.load().nf_conv_bwd_slabs(B, Hh, Ww))
-    g_weff = [None] * nl if ((ctx.defer and CONV_DEFER.active) or (CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww))) else \
+    chained = CONV_CHAIN_BWD_ON and not valid and _chain_usable(B, I0, O_out, Hh, Ww)
+    g_weff = [None] * nl if ((ctx.defer and CONV_DEFER.active) or chained) else \
         [torch.empty(slabs, t.numel(), dtype=torch.float32, device=dev) for t in w]
     acc = WS.zeros(nl * R * GB + nb * 2 * R * H, dev)
     g_bias = [acc[i * R * GB:(i + 1) * R * GB] for i in range(nl)]
@@ -510,7 +544,6 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
     defer = ctx.defer and CONV_DEFER.active
     # the data gradient of the whole conditioner in ONE persistent launch (csrc/conv_chain.hip); the weight passes follow as
     # deferred (or, outside a trainer step, immediate) nf_conv_bn_wgrad_multi launches over the same descriptors
-    chained = CONV_CHAIN_BWD_ON and _chain_usable(B, I0, O_out, Hh, Ww)
     if cpl is not None and not chained:
         raise RuntimeError('the fused coupling needs the chain kernels in both directions')
     queued = []
@@ -519,6 +552,7 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
     def layer(I, O, k, i, **kw):
         """convolution i's backward: both passes now, or the data pass now (unless the chain launch covers it) and the weight
         pass queued"""
+        kw.update(vk)
         if not defer and not chained:
             _bwd(shape, I, O, k, g_bias=g_bias[i], g_weff=g_weff[i], **kw)
             return
@@ -531,7 +565,7 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
             wkw = {f: v for f, v in wkw.items() if f not in ('gn_src', 'out', 'g_skip') and not f.startswith('cbn_')}
             wkw['g_direct'] = kw['g_store']
         wkw['g_bias'] = g_bias[i]
-        queued.append(((shape, I, O, k), wkw, i))
+        queued.append(((shape, I, O, k, valid), wkw, i))
 
     if chained:
         d = ConvNetBwdDesc()
@@ -615,6 +649,8 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         grads += [g_w[i], None if direct else d_bias[i]]
     for j in range(nb):
         grads += [None if direct else d_bn[j][0], None if direct else d_bn[j][1], None, None, None]
+    if valid and g_x is not None:
+        g_x = g_x[:, :, :valid[0], :valid[1]].contiguous()
     return ((g_x, ) if cpl is None else (g_z, g_a, g_c)), tuple(grads)
 
 

@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 # (in_channels, out_channels, H, W): the five conditioner shapes of Glow / RealNVP / Flow++ on CIFAR (checkerboard halves
-# are (C, H, W/2), channel halves (C/2, H, W)), plus an MNIST-like level
-SHAPES = [(3, 6, 32, 16), (6, 12, 16, 16), (12, 24, 16, 8), (24, 48, 8, 8), (48, 96, 8, 4), (96, 192, 4, 4), (1, 2, 28, 14)]
+# are (C, H, W/2), channel halves (C/2, H, W)); the levels of the 28 x 28 (MNIST-shape) pyramid, which the kernels run in
+# power-of-two storage with a dead border (nf_conv_desc.valid_h / valid_w); and one map nothing fits (module path)
+SHAPES = [(3, 6, 32, 16), (6, 12, 16, 16), (12, 24, 16, 8), (24, 48, 8, 8), (48, 96, 8, 4), (96, 192, 4, 4),
+          (1, 2, 28, 14), (2, 4, 14, 14), (4, 8, 14, 7), (8, 16, 7, 7), (16, 32, 7, 7), (1, 2, 6, 200)]
 
 
 def _risky_samples(net, x):
@@ -63,8 +65,8 @@ def test_convnet_fused_vs_modules(pkg, I, O, H, W, B, training):
     b.train(training)
     x1 = torch.randn(B, I, H, W, device=DEV).requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
-    if (H, W) == (28, 14):
-        assert not fc.convnet_usable(a, x1)            # 392 pixels do not tile: the module path serves it
+    if (H, W) == (6, 200):
+        assert not fc.convnet_usable(a, x1)            # wider than a tile even in power-of-two storage: the module path serves it
         G.assert_close(a(x1), b(x2), 1e-6, what='fallback')
         return
     assert fc.convnet_usable(a, x1)
@@ -286,3 +288,139 @@ def test_packed_weight_images_give_the_same_bits(pkg, I, O, H, W, B, training):
     for u, v in zip(gw0 + gb0, gw1 + gb1):
         assert torch.equal(u, v), float((u - v).abs().max())
     assert N.persistent_timeouts() == 0
+
+
+@pytest.mark.parametrize('B,I,VH,VW,k', [(9, 32, 14, 14, 3), (5, 6, 14, 14, 3), (20, 32, 7, 7, 3), (9, 32, 14, 14, 1), (33, 32, 7, 7, 1), (4, 12, 13, 10, 3)])
+def test_masked_maps_on_the_per_layer_kernels(pkg, B, I, VH, VW, k):
+    """maps whose sides are no powers of two (MNIST's 14 x 14 and 7 x 7 levels, flows/dataset.py:67-79) kept in power-of-two storage with a
+    VALID extent (nf_conv_desc.valid_h / valid_w): dead pixels read as zero, count in no statistic, are never written.  Forward (output,
+    batch sums), data gradient (gn_out, its two sums) and weight / bias gradient of a layer against float64 on the CROPPED problem, with
+    garbage in the dead region of every input."""
+    import torch.nn.functional as TF
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    N = pkg._native
+    torch.manual_seed(B + I + VH)
+    HS = 16 if VH > 8 else 8
+    WS_ = 16 if VW > 8 else 8
+    O = 32 if k == 3 else 12
+    has_bn = I == 32
+    R = 8
+
+    def padded(t, fill):
+        out = torch.full(t.shape[:2] + (HS, WS_), fill, device=DEV)
+        out[:, :, :VH, :VW] = t
+        return out
+
+    x = torch.randn(B, I, VH, VW, device=DEV) * 1.5 + 0.3
+    w = torch.randn(O, I, k, k, device=DEV) * 0.1
+    bias = torch.randn(O, device=DEV) * 0.2
+    gamma, beta = torch.rand(I, device=DEV) + 0.5, torch.randn(I, device=DEV) * 0.3
+    center = torch.randn(I, device=DEV) * 0.1
+    xd = x.double()
+    n = B * VH * VW
+    mean = xd.mean((0, 2, 3))
+    var = xd.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    pre = (xd - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gamma.double().view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)
+    act = torch.relu(pre) if has_bn else xd
+    want = TF.conv2d(act, w.double(), bias.double(), padding=k // 2)
+    xs = (xd - center.double().view(1, -1, 1, 1))
+    s1, s2 = torch.zeros(R, 32, device=DEV), torch.zeros(R, 32, device=DEV)
+    s1[1, :I] = xs.sum((0, 2, 3)).float()
+    s2[4, :I] = (xs * xs).sum((0, 2, 3)).float()
+    xp = padded(x, 1.0e3)
+    out = torch.full((B, O, HS, WS_), 777.0, device=DEV)
+    st1, st2 = torch.zeros(R * 32, device=DEV), torch.zeros(R * 32, device=DEV)
+    kw = dict(in_=xp, weight=w, bias=bias, out=out, valid_h=VH, valid_w=VW)
+    if k == 3:
+        kw.update(stat_sum=st1, stat_sqsum=st2)
+    if has_bn:
+        kw.update(bn_gamma=gamma, bn_beta=beta, bn_sum=s1.view(-1), bn_sqsum=s2.view(-1), bn_center=center, bn_running_mean=torch.zeros(I, device=DEV),
+                  bn_running_var=torch.ones(I, device=DEV), bn_save_mean=torch.zeros(32, device=DEV), bn_save_invstd=torch.zeros(32, device=DEV))
+    fc._fwd((B, HS, WS_), I, O, k, True, **kw)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(want.abs().max()))
+    assert float((out[:, :, :VH, :VW].double() - want).abs().max()) <= 3e-5 * scale
+    dead = out.clone()
+    dead[:, :, :VH, :VW] = 777.0
+    assert bool((dead == 777.0).all()), 'a dead pixel was written'
+    if k == 3:
+        dv = want - bias.double().view(1, -1, 1, 1)
+        G.assert_close(st1.view(R, 32).sum(0)[:O], dv.sum((0, 2, 3)).float(), 2e-5 * max(1.0, float(dv.abs().sum((0, 2, 3)).max())), what='stat_sum')
+        G.assert_close(st2.view(R, 32).sum(0)[:O], (dv * dv).sum((0, 2, 3)).float(), 2e-5 * float((dv * dv).sum((0, 2, 3)).max()), what='stat_sqsum')
+    # backward: G = g_direct on the valid pixels (garbage elsewhere), both passes in one launch
+    g = torch.randn(B, O, VH, VW, device=DEV)
+    gp = padded(g, -5.0e2)
+    gn_out = torch.full((B, I, HS, WS_), 555.0, device=DEV)
+    slabs = int(N.load().nf_conv_bwd_slabs(B, HS, WS_))
+    g_weff = torch.zeros(slabs, O * I * k * k, device=DEV)
+    g_bias = torch.zeros(R * 256, device=DEV)
+    sg, sgx = torch.zeros(R * 32, device=DEV), torch.zeros(R * 32, device=DEV)
+    kw = dict(in_=xp, weight=w, g_direct=gp, gn_out=gn_out, g_weff=g_weff, g_bias=g_bias, valid_h=VH, valid_w=VW)
+    if has_bn:
+        kw.update(bn_gamma=gamma, bn_beta=beta, bn_save_mean=mean.float(), bn_save_invstd=invstd.float(), sum_g=sg, sum_gx=sgx)
+    fc._bwd((B, HS, WS_), I, O, k, **kw)
+    torch.cuda.synchronize()
+    gin = TF.conv_transpose2d(g.double(), w.double(), padding=k // 2)
+    risky = (pre.abs() < 1e-5) if has_bn else torch.zeros_like(gin, dtype=torch.bool)
+    gn = torch.where(pre > 0, gin, torch.zeros_like(gin)) if has_bn else gin
+    sgs = max(1.0, float(gn.abs().max()))
+    err = (gn_out[:, :, :VH, :VW].double() - gn).abs()
+    err[risky] = 0.0
+    assert float(err.max()) <= 1e-5 * sgs, float(err.max())
+    want_w = torch.nn.grad.conv2d_weight(act, (O, I, k, k), g.double(), padding=k // 2)
+    got_w = g_weff.sum(0).view(k * k, O, I).permute(1, 2, 0).reshape(O, I, k, k)
+    mag = float(torch.nn.grad.conv2d_weight(act.abs(), (O, I, k, k), g.double().abs(), padding=k // 2).max())
+    assert float((got_w.double() - want_w).abs().max()) <= 1e-5 * max(1.0, mag), float((got_w.double() - want_w).abs().max())
+    G.assert_close(g_bias.view(R, 256).sum(0)[:O], g.double().sum((0, 2, 3)).float(), 2e-5 * max(1.0, float(g.double().abs().sum((0, 2, 3)).max())), what='g_bias')
+    if has_bn:
+        xhat = (xd - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        slack = int(risky.sum()) * sgs * 4.0
+        G.assert_close(sg.view(R, 32).sum(0)[:I], gn.sum((0, 2, 3)).float(), 2e-5 * max(1.0, float(gn.abs().sum((0, 2, 3)).max())) + slack, what='sum_g')
+        G.assert_close(sgx.view(R, 32).sum(0)[:I], (gn * xhat).sum((0, 2, 3)).float(), 2e-5 * max(1.0, float((gn * xhat).abs().sum((0, 2, 3)).max())) + slack, what='sum_gx')
+    assert n == B * VH * VW
+
+
+def test_mnist_shape_conditioner_dispatches_no_framework_convolution(pkg):
+    """the conditioners of the 28 x 28 pyramid (maps 14 x 14 and 7 x 7) run on the HIP kernels, forward and backward: no ATen /
+    MIOpen convolution or batch norm is dispatched (the module path, profiled the same way, does dispatch them)"""
+    a, b = _nets(pkg, 2, 4)
+    a.train()
+    b.train()
+    x = torch.randn(16, 2, 14, 14, device=DEV)
+    banned = ('conv', 'batch_norm', 'relu', 'mm')
+
+    def ops(net):
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            net(x.clone().requires_grad_(True)).sum().backward()
+            torch.cuda.synchronize()
+        names = {e.key for e in prof.key_averages()}
+        return sorted(n for n in names if n.startswith('aten::') and any(t in n.split('::')[1] for t in banned))
+
+    assert ops(a) == []
+    assert any('conv' in n for n in ops(b))
+
+
+@pytest.mark.parametrize('cls,dims,layers,mix', [('Glow', (1, 32, 32), 2, None), ('RealNVP', (1, 32, 32), 2, None), ('Flowpp', (1, 32, 32), 1, 4),
+                                                 ('Glow', (1, 24, 24), 2, None), ('RealNVP', (1, 24, 24), 2, None)])
+def test_single_channel_image_models_dispatch_no_framework_convolution(pkg, cls, dims, layers, mix):
+    """the reference's MNIST shape ((1, 32, 32) after its loader's padding, flows/dataset.py:67-73) and a pyramid without power-of-two
+    maps (24 -> 12 -> 6), second training pass (ActNorm initialised): no ATen / MIOpen convolution, batch norm, layer norm, softmax or
+    batched matmul anywhere in forward + backward"""
+    from types import SimpleNamespace as NS
+    torch.manual_seed(1)
+    net = getattr(pkg, cls)(dims, 'image', NS(layers=layers, mixtures=mix)).to(DEV)
+    net.train()
+    y = torch.rand(16, *dims, device=DEV)
+    banned = ('conv', 'batch_norm', 'layer_norm', 'softmax', 'bmm')
+
+    def step():
+        z, ld = net(y.clone())
+        (z.square().sum() - ld.sum()).backward()
+        torch.cuda.synchronize()
+
+    step()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        step()
+    names = {e.key for e in prof.key_averages()}
+    assert sorted(n for n in names if n.startswith('aten::') and any(t in n.split('::')[1] for t in banned)) == []

@@ -400,6 +400,14 @@ IMAGE_CASES = [
     # the image stacks of the two other flows north_star names, CIFAR shape, B = 64 (realnvp.py:17-47, flowpp.py:17-62)
     ('realnvp_cifar', 'realnvp', 'RealNVP', (3, 32, 32), 'image', 4, None, 64),
     ('flowpp_cifar', 'flowpp', 'Flowpp', (3, 32, 32), 'image', 2, 8, 64),
+    # the reference's MNIST shape (flows/dataset.py:67-73 pads 28 x 28 to (1, 32, 32)): conditioner maps 32 x 16 ... 8 x 4
+    ('glow_mnist', 'glow', 'Glow', (1, 32, 32), 'image', 2, None, 64),
+    ('realnvp_mnist', 'realnvp', 'RealNVP', (1, 32, 32), 'image', 2, None, 64),
+    ('flowpp_mnist', 'flowpp', 'Flowpp', (1, 32, 32), 'image', 1, 4, 64),
+    # an image whose pyramid has no power-of-two map (24 -> 12 -> 6; the reference's stacks themselves stop at odd sides, so 28 x 28
+    # cannot run there: its 7 x 7 level has no checkerboard): conditioners in power-of-two storage with a dead border (fused_conv.py)
+    ('glow_24', 'glow', 'Glow', (1, 24, 24), 'image', 2, None, 64),
+    ('realnvp_24', 'realnvp', 'RealNVP', (1, 24, 24), 'image', 2, None, 64),
 ]
 
 
@@ -415,7 +423,7 @@ def test_image_realnvp_and_flowpp_steps_match_oracle_at_cifar_shape(pkg, cfg):
     torch.manual_seed(0)
     np.random.seed(0)
     net = getattr(pkg, cls)(dims, datatype, NS(layers=layers, mixtures=mix))
-    y = nfdata.sample('cifar', B, 1234).reshape((B, ) + dims)
+    y = nfdata.sample('cifar', B, 1234).reshape(B, -1)[:, :int(np.prod(dims))].reshape((B, ) + dims).contiguous()
     net = net.to(DEV)
     trainer = nftrain.FlowTrainer(net, graph=False)
     yd = y.to(DEV)
