@@ -950,8 +950,14 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
 
 /* ---- Flow++ conditioner for IMAGE data (csrc/flowpp_img.hip)  coupling.py:159-166, modules.py:519-578 ------------------------
  * net = Conv2d(I0, 32, 3) -> GatedConv2d(32) -> LayerNorm(32,H,W) -> GatedAttn(32, 4 heads) -> LayerNorm -> Conv2d(32, O, 3) on
- * H = W in {4, 8, 16} maps (nf_flowpp_img_usable != 0; the mid shapes of flows/flowpp.py:22-57 on 16 x 16 and 32 x 32 images).
+ * square maps of side 1 .. 16 (nf_flowpp_img_usable != 0; the mid shapes of flows/flowpp.py:22-57 on images up to 32 x 32).
  * Per-sample work throughout (no batch statistics): four launches forward, nine backward, all NCHW fp32.
+ * STORAGE: (H, W) in every call below is the IMAGE; the activation / gradient tensors of these calls are (B, C, S, S) with
+ * S = nf_flowpp_img_storage(H, W) = the next power of two >= H, at least 4 (S = H for the CIFAR / MNIST pyramids: 16, 8, 4), the image
+ * in the top-left corner.  Pixels outside the image are DEAD: the convolutions read zero there (as outside the map), LayerNorm and
+ * the attention run over the H * W live positions only, what the kernels leave there is meaningless (the caller pads its input
+ * with anything and crops the output).  The (32, H, W) parameters (LayerNorm affines, position embedding) and their gradients keep
+ * the reference's layout.  nf_flowpp_img_celu_bwd is elementwise: pass it the storage extent.
  *
  * nf_flowpp_img_conv: out (B, Co, H, W) = conv3x3(in, pad 1) + bias (bias nullable), exact-fp32 matrix-core GEMM.
  *   in_mode 0: in is (B, Ci, H, W);   in_mode 1: in is (B, Ci / 2, H, W) and the convolution sees concat_elu(in) = elu([in, -in])
@@ -973,6 +979,7 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
 #define NF_FLOWPP_IMG_MAX_KSPLIT 64
 #define NF_FLOWPP_IMG_MAX_SLABS 64
 int nf_flowpp_img_usable(int64_t B, int Ci, int Co, int H, int W);
+int nf_flowpp_img_storage(int H, int W);                     /* side S of the storage map, 0 if the map is not served */
 int nf_flowpp_img_conv_ksplit(int64_t B, int Ci, int Co, int H, int W);
 int nf_flowpp_img_conv(const float* in, const float* weight, const float* bias, float* out, int64_t B, int Ci, int Co, int H, int W,
                        int in_mode, int transposed, int ksplit, nf_stream_t stream);

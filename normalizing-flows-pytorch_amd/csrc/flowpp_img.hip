@@ -35,6 +35,12 @@ struct NfFiGeo {
     static constexpr int W = 1 << LGW, N = W * W, S = 256 / N, PW = W + 2, FS = PW * PW, CS = (S * FS) | 1;
 };
 
+// Maps whose side V is no power of two live in the next power-of-two storage map (side W = 1 << LGW): pixel q = y W + x of the
+// storage map belongs to the image iff y < V and x < V.  Everything outside is DEAD: never read as data (the convolutions load zero
+// there, exactly as for their halo), left out of the LayerNorm statistics and the attention, its stored values are meaningless.
+template <int LGW>
+__device__ __forceinline__ bool nf_fi_live(int q, int V) { return (q >> LGW) < V && (q & ((1 << LGW) - 1)) < V; }
+
 template <int LGW>
 __device__ __forceinline__ int nf_fi_fpos(int p) {          // frame position of pixel p (0..255) of the tile
     using G = NfFiGeo<LGW>;
@@ -63,11 +69,12 @@ __device__ __forceinline__ void nf_fi_zero_frame(float* F) {
 
 // INMODE 1: the convolution sees concat_elu(in) = elu([in, -in]) of a (B, Ci / 2, H, W) tensor (flows/modules.py:500-517)
 template <int LGW, int INMODE>
-__device__ __forceinline__ void nf_fi_frame_load(float (&tmp)[16], const float* __restrict__ in, int64_t b0, int64_t B, int Ci, int c0) {
+__device__ __forceinline__ void nf_fi_frame_load(float (&tmp)[16], const float* __restrict__ in, int64_t b0, int64_t B, int Ci, int c0,
+                                                 int V) {
     using G = NfFiGeo<LGW>;
     const int p = threadIdx.x & 255, ch = threadIdx.x >> 8;
     const int bs = (int)b0 + (p >> (2 * LGW)), q = p & (G::N - 1), Ch = Ci >> 1;
-    const bool bok = bs < B;
+    const bool bok = bs < B && nf_fi_live<LGW>(q, V);        // (a dead pixel of the storage map reads as zero, like the halo)
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int cc = c0 + ch + 2 * u;
@@ -140,7 +147,7 @@ __device__ __forceinline__ void nf_fi_kchunk(f32x16& acc, const float* Wl, const
 template <int LGW, int INMODE, bool TR>
 __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restrict__ in, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int64_t B, int Ci,
-                                                           int Co) {
+                                                           int Co, int V) {
     using G = NfFiGeo<LGW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* F = smem;                       // [32][CS]
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restri
     const int ch0 = (int)blockIdx.z * cps, ch1 = min(nchunks, ch0 + cps);
     float tf[16], tw[18];
     if (ch0 < ch1) {
-        nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, 32 * ch0);
+        nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, 32 * ch0, V);
         nf_fi_w_load<TR>(tw, w, Ci, Co, o0, 32 * ch0);
     }
     nf_fi_zero_frame<LGW>(F);                                // (under the first loads' latency)
@@ -169,7 +176,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv(const float* __restri
         nf_fi_w_store<TR>(Wl, tw);
         __syncthreads();
         if (ch + 1 < ch1) {                                  // the next chunk's operands travel while this chunk's products issue
-            nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, c0 + 32);
+            nf_fi_frame_load<LGW, INMODE>(tf, in, b0, B, Ci, c0 + 32, V);
             nf_fi_w_load<TR>(tw, w, Ci, Co, o0, c0 + 32);
         }
         nf_fi_kchunk<LGW>(acc, Wl, F, (min(32, Ci - c0) + 7) >> 3, fpos, r32, hs);
@@ -204,7 +211,7 @@ struct NfFiGeo64 {
 template <int LGW, int INMODE, bool TR>
 __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv64(const float* __restrict__ in, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out, int64_t B, int Ci,
-                                                             int Co) {
+                                                             int Co, int V) {
     using G = NfFiGeo64<LGW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* F = smem;                       // [32][CS]
@@ -225,7 +232,8 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv64(const float* __rest
     // (t >> 5) + 16 u, u < 2
     const int hx = threadIdx.x & 15, hbot = (threadIdx.x >> 4) & 1, hch = threadIdx.x >> 5;
     const int hy = hbot ? G::ROWS * rb + G::ROWS : G::ROWS * rb - 1;
-    const bool hrow = G::TPS > 1 && hy >= 0 && hy < G::W;
+    const bool hrow = G::TPS > 1 && hy >= 0 && hy < V && hx < V;      // (V <= W: inside the image)
+    const bool slive = nf_fi_live<LGW>(sq, V);
     const int hfpos = (hbot ? G::ROWS + 1 : 0) * G::PW + hx + 1;
     f32x16 acc;
 #pragma unroll
@@ -237,7 +245,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv64(const float* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cc = c0 + sch + 8 * u;
-            const bool ok = sbs < B && cc < Ci;
+            const bool ok = sbs < B && cc < Ci && slive;
             const unsigned idx = INMODE == 0 ? (unsigned)((sbs * Ci + cc) * G::N + sq) : (unsigned)((sbs * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + sq);
             const float v = in[ok ? idx : 0u];
             tf[u] = ok ? v : 0.f;
@@ -331,7 +339,7 @@ struct NfFiGeoW {
 template <int LGW, int INMODE>
 __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* __restrict__ in, const float* __restrict__ g,
                                                                   float* __restrict__ slab_w, float* __restrict__ slab_b, int64_t B, int Ci,
-                                                                  int Co) {
+                                                                  int Co, int V) {
     using G = NfFiGeoW<LGW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* F = smem;                       // [32][CS]
@@ -347,6 +355,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* _
     const int sp = threadIdx.x % G::TPX, sch = threadIdx.x / G::TPX;
     const int ss = sp >> (2 * LGW), sq = sp & (G::N - 1);
     const int sfpos = ss * G::FS + (((sp >> LGW) & (G::W - 1)) + 1) * G::PW + (sp & (G::W - 1)) + 1;
+    const bool slive = nf_fi_live<LGW>(sq, V);              // dead pixels: zero activation AND zero gradient (bias sums included)
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* _
 #pragma unroll
         for (int u = 0; u < G::NU; ++u) {
             const int cc = c0 + sch + G::CPT * u, o = o0 + sch + G::CPT * u;
-            const bool okf = bs < B && cc < Ci, okg = bs < B && o < Co;
+            const bool okf = bs < B && cc < Ci && slive, okg = bs < B && o < Co && slive;
             const unsigned fi = INMODE == 0 ? (unsigned)((bs * Ci + cc) * G::N + sq) : (unsigned)((bs * Ch + (cc < Ch ? cc : cc - Ch)) * G::N + sq);
             const float vf = in[okf ? fi : 0u], vg = g[okg ? (unsigned)((bs * Co + o) * G::N + sq) : 0u];
             tf[u] = okf ? vf : 0.f;
@@ -436,6 +445,7 @@ struct NfFiMid {
     int g_slabs;
     int64_t g_slab_stride;
     float *g_x, *g_a, *g_ln1g, *g_ln1b, *g_pos, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2g, *g_ln2b;
+    int V;               // side of the image inside the storage map (MK variants; the (32, V, V) parameters keep the reference's layout)
 };
 
 template <int NT>
@@ -482,9 +492,12 @@ __device__ __forceinline__ void nf_fi_pair_mfma(const float* GP, const float* T,
     if (hs == 0) atomicAdd(gb + r32, bs);
 }
 
-template <int N, bool BWD>
+// MK: the image is V x V inside the W x W storage map (V < W).  Thread j < V * V works on image pixel (j / V, j % V) -- the positions are
+// COMPACT in the planes, the sweeps over the keys run to V * V -- and the remaining threads carry zeros through every sum and plane.
+template <int N, bool BWD, bool MK>
 __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     constexpr int NT = 4 * N, PL = 32 * N;
+    constexpr int WS = N == 256 ? 16 : (N == 64 ? 8 : 4);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* PA = smem;
     float* PB = PA + PL;
@@ -498,34 +511,41 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     float* DL = W2s + NT;
     const int tid = threadIdx.x, h = tid / N, j = tid & (N - 1);
     const int64_t b = blockIdx.x;
-    const float invn = 1.f / (float)(32 * N);
+    const int NV = MK ? m.V * m.V : N;                   // live positions = stride of the (32, V, V) parameters
+    const bool ok = !MK || j < NV;
+    int spx = j;                                         // this thread's pixel of the storage map
+    if (MK) {
+        const int jy = ok ? j / m.V : 0;
+        spx = jy * WS + (ok ? j - jy * m.V : 0);
+    }
+    const float invn = 1.f / (float)(32 * NV);
     const float scale = 0.35355339059327373f;            // 1 / sqrt(D), D = 8 (flows/modules.py:571)
 
     for (int e = tid; e < 3072; e += NT) W1s[(e & 31) * 96 + (e >> 5)] = m.w1[e];      // transposed: [c][o], o contiguous
     for (int e = tid; e < 2048; e += NT) W2s[(e & 31) * 64 + (e >> 5)] = m.w2[e];
     for (int e = tid; e < 160; e += NT) Bs[e] = e < 96 ? m.b1[e] : m.b2[e - 96];
 
-    const int64_t base = (b * 32 + 8 * h) * N + j;         // this thread's elements: base + d * N
-    const int pbase = 8 * h * N + j;                       // the same inside a (32, H, W) parameter
+    const int64_t base = (b * 32 + 8 * h) * N + spx;       // this thread's elements: base + d * N
+    const int pbase = 8 * h * NV + (ok ? j : 0);           // the same inside a (32, H, W) parameter: pbase + d * NV
     float m1, r1;
     // u = x + elu(a) * sigmoid(elu(-a))  (GatedConv2d, flows/modules.py:519-538), LayerNorm 1
     auto ln1 = [&](float* xh1, float* x2) {
         float u[8], s = 0.f;
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            const float av = m.a[base + d * N];
-            u[d] = m.x[base + d * N] + nf_fi_elu(av) * nf_fi_sigmoid(nf_fi_elu(-av));
+            const float av = m.a[base + d * N], xv = m.x[base + d * N];
+            u[d] = ok ? xv + nf_fi_elu(av) * nf_fi_sigmoid(nf_fi_elu(-av)) : 0.f;
             s += u[d];
         }
         m1 = nf_fi_block_sum_all<NT>(s, scr) * invn;
         float s2 = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) s2 += (u[d] - m1) * (u[d] - m1);
+        for (int d = 0; d < 8; ++d) s2 += ok ? (u[d] - m1) * (u[d] - m1) : 0.f;
         r1 = 1.f / sqrtf(nf_fi_block_sum_all<NT>(s2, scr) * invn + NF_FI_LNEPS);
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            xh1[d] = (u[d] - m1) * r1;
-            x2[d] = xh1[d] * m.ln1g[pbase + d * N] + m.ln1b[pbase + d * N];
+            xh1[d] = ok ? (u[d] - m1) * r1 : 0.f;
+            x2[d] = ok ? xh1[d] * m.ln1g[pbase + d * NV] + m.ln1b[pbase + d * NV] : 0.f;
         }
     };
     float x2[8], v[8], k[8], q[8];
@@ -535,7 +555,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     }
     // tokens = x2 + pos_emb -> PA ; proj = conv1 (1x1, 32 -> 96): rows 8 h + d of the three groups ("V", "K", "Q" in the reference's naming)
 #pragma unroll
-    for (int d = 0; d < 8; ++d) PA[NF_FI_IDX(8 * h + d, j)] = x2[d] + m.pos[pbase + d * N];
+    for (int d = 0; d < 8; ++d) PA[NF_FI_IDX(8 * h + d, j)] = ok ? x2[d] + m.pos[pbase + d * NV] : 0.f;
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
@@ -565,11 +585,11 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     __syncthreads();
     float mx = -INFINITY, l = 0.f, mix[8];
 #pragma unroll 2
-    for (int i = 0; i < N; ++i) mx = fmaxf(mx, nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], k) * scale);
+    for (int i = 0; i < NV; ++i) mx = fmaxf(mx, nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], k) * scale);
 #pragma unroll
     for (int d = 0; d < 8; ++d) mix[d] = 0.f;
 #pragma unroll 2
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const float p = __expf(nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], k) * scale - mx);
         const f32x4 q0 = PC4[(h * N + i) * 2], q1 = PC4[(h * N + i) * 2 + 1];
         l += p;
@@ -613,19 +633,21 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
         float x3[8], s = 0.f, s2 = 0.f;
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            x3[d] = x2[d] + y[d] * sg[d];
+            x3[d] = ok ? x2[d] + y[d] * sg[d] : 0.f;
             s += x3[d];
         }
         m2 = nf_fi_block_sum_all<NT>(s, scr) * invn;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) s2 += (x3[d] - m2) * (x3[d] - m2);
+        for (int d = 0; d < 8; ++d) s2 += ok ? (x3[d] - m2) * (x3[d] - m2) : 0.f;
         r2 = 1.f / sqrtf(nf_fi_block_sum_all<NT>(s2, scr) * invn + NF_FI_LNEPS);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) xh2[d] = (x3[d] - m2) * r2;
+        for (int d = 0; d < 8; ++d) xh2[d] = ok ? (x3[d] - m2) * r2 : 0.f;
     }
     if (!BWD) {
+        if (ok) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) m.out[base + d * N] = xh2[d] * m.ln2g[pbase + d * N] + m.ln2b[pbase + d * N];
+            for (int d = 0; d < 8; ++d) m.out[base + d * N] = xh2[d] * m.ln2g[pbase + d * NV] + m.ln2b[pbase + d * NV];
+        }
         return;
     }
 
@@ -645,16 +667,18 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
         }
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            const float g4 = g4v[d];
-            atomicAdd(m.g_ln2g + pbase + d * N, g4 * xh2[d]);
-            atomicAdd(m.g_ln2b + pbase + d * N, g4);
-            gh[d] = g4 * m.ln2g[pbase + d * N];
+            const float g4 = ok ? g4v[d] : 0.f;
+            if (ok) {
+                atomicAdd(m.g_ln2g + pbase + d * NV, g4 * xh2[d]);
+                atomicAdd(m.g_ln2b + pbase + d * NV, g4);
+            }
+            gh[d] = g4 * m.ln2g[pbase + d * NV];
             s1 += gh[d];
             s2 += gh[d] * xh2[d];
         }
         const float S1 = nf_fi_block_sum_all<NT>(s1, scr) * invn, S2 = nf_fi_block_sum_all<NT>(s2, scr) * invn;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) g3[d] = r2 * (gh[d] - S1 - xh2[d] * S2);
+        for (int d = 0; d < 8; ++d) g3[d] = ok ? r2 * (gh[d] - S1 - xh2[d] * S2) : 0.f;
     }
     // conv2 backward in two rounds through PB (y rows, then gate rows); PA still holds `mixed`
     float gm[8];
@@ -702,7 +726,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) gk[d] = gv[d] = gq[d] = 0.f;
 #pragma unroll 2
-    for (int i = 0; i < N; ++i) {                        // this thread as the column j: gradient of K_j
+    for (int i = 0; i < NV; ++i) {                       // this thread as the column j: gradient of K_j
         const f32x4 v0 = PA4[(h * N + i) * 2], v1 = PA4[(h * N + i) * 2 + 1];
         const float p = __expf(nf_fi_dot8(v0, v1, k) * scale - cj);
         const float gs = p * (nf_fi_dot8(PB4[(h * N + i) * 2], PB4[(h * N + i) * 2 + 1], gm) - delta);
@@ -713,7 +737,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
         }
     }
 #pragma unroll 2
-    for (int jj = 0; jj < N; ++jj) {                     // this thread as the row i = j: gradients of V_i and Q_i
+    for (int jj = 0; jj < NV; ++jj) {                    // this thread as the row i = j: gradients of V_i and Q_i
         const f32x4 k0 = PC4[(h * N + jj) * 2], k1 = PC4[(h * N + jj) * 2 + 1];
         const f32x4 g0 = PD4[(h * N + jj) * 2], g1 = PD4[(h * N + jj) * 2 + 1];
         const float p = __expf(nf_fi_dot8(k0, k1, v) * scale - CJ[h * N + jj]);
@@ -732,10 +756,10 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-        PA[NF_FI_IDX(8 * h + d, j)] = gv[d] * scale;
-        PB[NF_FI_IDX(8 * h + d, j)] = gk[d] * scale;
-        PC[NF_FI_IDX(8 * h + d, j)] = gq[d];
-        PD[NF_FI_IDX(8 * h + d, j)] = x2[d] + m.pos[pbase + d * N];
+        PA[NF_FI_IDX(8 * h + d, j)] = ok ? gv[d] * scale : 0.f;
+        PB[NF_FI_IDX(8 * h + d, j)] = ok ? gk[d] * scale : 0.f;
+        PC[NF_FI_IDX(8 * h + d, j)] = ok ? gq[d] : 0.f;
+        PD[NF_FI_IDX(8 * h + d, j)] = ok ? x2[d] + m.pos[pbase + d * NV] : 0.f;
     }
     __syncthreads();
     float gt[8];
@@ -762,10 +786,12 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             const float g2_ = g3[d] + gt[d];
-            atomicAdd(m.g_pos + pbase + d * N, gt[d]);
-            atomicAdd(m.g_ln1g + pbase + d * N, g2_ * xh1[d]);
-            atomicAdd(m.g_ln1b + pbase + d * N, g2_);
-            gh[d] = g2_ * m.ln1g[pbase + d * N];
+            if (ok) {
+                atomicAdd(m.g_pos + pbase + d * NV, gt[d]);
+                atomicAdd(m.g_ln1g + pbase + d * NV, g2_ * xh1[d]);
+                atomicAdd(m.g_ln1b + pbase + d * NV, g2_);
+            }
+            gh[d] = g2_ * m.ln1g[pbase + d * NV];
             s1 += gh[d];
             s2 += gh[d] * xh1[d];
         }
@@ -775,8 +801,10 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
             const float gu = r1 * (gh[d] - S1 - xh1[d] * S2);
             const float av = m.a[base + d * N];
             const float e1 = nf_fi_elu(av), s2_ = nf_fi_sigmoid(nf_fi_elu(-av));
-            m.g_x[base + d * N] = gu;
-            m.g_a[base + d * N] = gu * (nf_fi_elu_grad(av) * s2_ - e1 * s2_ * (1.f - s2_) * nf_fi_elu_grad(-av));
+            if (ok) {
+                m.g_x[base + d * N] = gu;
+                m.g_a[base + d * N] = gu * (nf_fi_elu_grad(av) * s2_ - e1 * s2_ * (1.f - s2_) * nf_fi_elu_grad(-av));
+            }
         }
     }
 }
@@ -799,20 +827,28 @@ static inline int nf_fi_optin(K kernel, size_t lds) {
     return 0;
 }
 
+// (H, W) of every entry point = the IMAGE (square, side 1 .. 16); the activation tensors are (B, C, S, S) with S = the storage side:
+// the next power of two, at least 4 (nf_flowpp_img_storage).  The (32, H, W) parameters keep the reference's layout.
 static inline int nf_fi_lgw(int H, int W) {
-    if (H != W) return -1;
-    return W == 16 ? 4 : (W == 8 ? 3 : (W == 4 ? 2 : -1));
+    if (H != W || W < 1 || W > 16) return -1;
+    return W > 8 ? 4 : (W > 4 ? 3 : 2);
+}
+
+extern "C" int nf_flowpp_img_storage(int H, int W) {
+    const int lg = nf_fi_lgw(H, W);
+    return lg < 0 ? 0 : 1 << lg;
 }
 
 extern "C" int nf_flowpp_img_usable(int64_t B, int Ci, int Co, int H, int W) {
     if (B < 1 || Ci < 1 || Co < 1 || nf_fi_lgw(H, W) < 0) return 0;
-    const int64_t tiles = (B * H * W + 255) / 256;
-    if (tiles > 65535 * 32 || (Co + 31) / 32 > 65535 || B * (int64_t)(Ci > Co ? Ci : Co) * H * W >= ((int64_t)1 << 31)) return 0;
+    const int64_t SN = (int64_t)nf_flowpp_img_storage(H, W) * nf_flowpp_img_storage(H, W);
+    const int64_t tiles = (B * SN + 255) / 256;
+    if (tiles > 65535 * 32 || (Co + 31) / 32 > 65535 || B * (int64_t)(Ci > Co ? Ci : Co) * SN >= ((int64_t)1 << 31)) return 0;
     return 1;
 }
 
 template <int LGW>
-static int nf_fi_conv_launch(const float* in, const float* w, const float* bias, float* out, int64_t B, int Ci, int Co, int in_mode,
+static int nf_fi_conv_launch(const float* in, const float* w, const float* bias, float* out, int64_t B, int Ci, int Co, int V, int in_mode,
                              int transposed, int ksplit, hipStream_t st) {
     using G = NfFiGeo<LGW>;
     int rc;
@@ -828,7 +864,7 @@ static int nf_fi_conv_launch(const float* in, const float* w, const float* bias,
 #define NF_FI_GO6(M_, T_)                                                                                             \
     do {                                                                                                              \
         if ((rc = nf_fi_optin(k_fi_conv64<LGW, M_, T_>, lds6)) != 0) return rc;                                       \
-        hipLaunchKernelGGL((k_fi_conv64<LGW, M_, T_>), grid6, dim3(NF_FI_THREADS), lds6, st, in, w, bias, out, B, Ci, Co); \
+        hipLaunchKernelGGL((k_fi_conv64<LGW, M_, T_>), grid6, dim3(NF_FI_THREADS), lds6, st, in, w, bias, out, B, Ci, Co, V); \
     } while (0)
             if (transposed) NF_FI_GO6(0, true);
             else if (in_mode == 1) NF_FI_GO6(1, false);
@@ -843,7 +879,7 @@ static int nf_fi_conv_launch(const float* in, const float* w, const float* bias,
 #define NF_FI_GO(M_, T_)                                                                                            \
     do {                                                                                                            \
         if ((rc = nf_fi_optin(k_fi_conv<LGW, M_, T_>, lds)) != 0) return rc;                                        \
-        hipLaunchKernelGGL((k_fi_conv<LGW, M_, T_>), grid, dim3(NF_FI_THREADS), lds, st, in, w, bias, out, B, Ci, Co); \
+        hipLaunchKernelGGL((k_fi_conv<LGW, M_, T_>), grid, dim3(NF_FI_THREADS), lds, st, in, w, bias, out, B, Ci, Co, V); \
     } while (0)
     if (transposed) NF_FI_GO(0, true);
     else if (in_mode == 1) NF_FI_GO(1, false);
@@ -856,7 +892,8 @@ static int nf_fi_conv_launch(const float* in, const float* w, const float* bias,
 // K slabs a launch of nf_flowpp_img_conv may be cut into: enough workgroups for the chip, never more than the 32-channel chunks
 extern "C" int nf_flowpp_img_conv_ksplit(int64_t B, int Ci, int Co, int H, int W) {
     if (!nf_flowpp_img_usable(B, Ci, Co, H, W)) return 0;
-    const int64_t wgs = ((B * H * W + 255) / 256) * ((Co + 31) / 32);
+    const int S = nf_flowpp_img_storage(H, W);
+    const int64_t wgs = ((B * S * S + 255) / 256) * ((Co + 31) / 32);
     const int nchunks = (Ci + 31) / 32;
     int64_t k = (256 + wgs - 1) / wgs;
     if (k > nchunks) k = nchunks;
@@ -871,25 +908,25 @@ extern "C" int nf_flowpp_img_conv(const float* in, const float* weight, const fl
     if (ksplit < 1 || ksplit > NF_FLOWPP_IMG_MAX_KSPLIT || ksplit > (Ci + 31) / 32) return NF_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
-        case 4: return nf_fi_conv_launch<4>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, ksplit, st);
-        case 3: return nf_fi_conv_launch<3>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, ksplit, st);
-        default: return nf_fi_conv_launch<2>(in, weight, bias, out, B, Ci, Co, in_mode, transposed, ksplit, st);
+        case 4: return nf_fi_conv_launch<4>(in, weight, bias, out, B, Ci, Co, W, in_mode, transposed, ksplit, st);
+        case 3: return nf_fi_conv_launch<3>(in, weight, bias, out, B, Ci, Co, W, in_mode, transposed, ksplit, st);
+        default: return nf_fi_conv_launch<2>(in, weight, bias, out, B, Ci, Co, W, in_mode, transposed, ksplit, st);
     }
 }
 
 template <int LGW>
-static int nf_fi_wgrad_launch(const float* in, const float* g, float* sw, float* sb, int n_slabs, int64_t B, int Ci, int Co, int in_mode,
-                              hipStream_t st) {
+static int nf_fi_wgrad_launch(const float* in, const float* g, float* sw, float* sb, int n_slabs, int64_t B, int Ci, int Co, int V,
+                              int in_mode, hipStream_t st) {
     using G = NfFiGeoW<LGW>;
     const size_t lds = (size_t)(32 * G::CS + 32 * G::GS + 4 * 3 * 1024) * sizeof(float);
     const dim3 grid((unsigned)n_slabs, (unsigned)((Co + 31) / 32), (unsigned)((Ci + 31) / 32));
     int rc;
     if (in_mode == 1) {
         if ((rc = nf_fi_optin(k_fi_conv_wgrad2<LGW, 1>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
+        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co, V);
     } else {
         if ((rc = nf_fi_optin(k_fi_conv_wgrad2<LGW, 0>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co);
+        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co, V);
     }
     NF_CHECK_LAUNCH();
     return 0;
@@ -899,8 +936,9 @@ static int nf_fi_wgrad_launch(const float* in, const float* g, float* sw, float*
 // than the pixel tiles
 extern "C" int nf_flowpp_img_wgrad_slabs(int64_t B, int Ci, int Co, int H, int W) {
     if (!nf_flowpp_img_usable(B, Ci, Co, H, W)) return 0;
-    const int tpx = H * W <= 64 ? 64 : 256;                  // pixels per tile of k_fi_conv_wgrad2
-    const int64_t tiles = (B * H * W + tpx - 1) / tpx, blocks = (int64_t)((Co + 31) / 32) * ((Ci + 31) / 32);
+    const int SN = nf_flowpp_img_storage(H, W) * nf_flowpp_img_storage(H, W);
+    const int tpx = SN <= 64 ? 64 : 256;                     // pixels per tile of k_fi_conv_wgrad2
+    const int64_t tiles = (B * SN + tpx - 1) / tpx, blocks = (int64_t)((Co + 31) / 32) * ((Ci + 31) / 32);
     int64_t k = (256 + blocks - 1) / blocks;                 // (512 / 1024 workgroups measured no better)
     if (k > tiles) k = tiles;
     if (k > NF_FLOWPP_IMG_MAX_SLABS) k = NF_FLOWPP_IMG_MAX_SLABS;
@@ -913,9 +951,9 @@ extern "C" int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, flo
     if (in_mode < 0 || in_mode > 1 || (in_mode == 1 && (Ci & 1)) || n_slabs < 1 || n_slabs > NF_FLOWPP_IMG_MAX_SLABS) return NF_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
-        case 4: return nf_fi_wgrad_launch<4>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, in_mode, st);
-        case 3: return nf_fi_wgrad_launch<3>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, in_mode, st);
-        default: return nf_fi_wgrad_launch<2>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, in_mode, st);
+        case 4: return nf_fi_wgrad_launch<4>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, W, in_mode, st);
+        case 3: return nf_fi_wgrad_launch<3>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, W, in_mode, st);
+        default: return nf_fi_wgrad_launch<2>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, W, in_mode, st);
     }
 }
 
@@ -930,11 +968,17 @@ extern "C" int nf_flowpp_img_celu_bwd(const float* x, const float* g_cat, float*
 }
 
 template <int N, bool BWD>
-static int nf_fi_mid_launch(const NfFiMid& m, int64_t B, hipStream_t st) {
+static int nf_fi_mid_launch(NfFiMid m, int V, int64_t B, hipStream_t st) {
     const size_t lds = (size_t)(4 * 32 * N + 3072 + 2048 + 160 + 16) * sizeof(float);
     int rc;
-    if ((rc = nf_fi_optin(k_fi_mid<N, BWD>, lds)) != 0) return rc;
-    hipLaunchKernelGGL((k_fi_mid<N, BWD>), dim3((unsigned)B), dim3(4 * N), lds, st, m);
+    m.V = V;
+    if (V * V == N) {
+        if ((rc = nf_fi_optin(k_fi_mid<N, BWD, false>, lds)) != 0) return rc;
+        hipLaunchKernelGGL((k_fi_mid<N, BWD, false>), dim3((unsigned)B), dim3(4 * N), lds, st, m);
+    } else {                                                 // the image inside a larger storage map
+        if ((rc = nf_fi_optin(k_fi_mid<N, BWD, true>, lds)) != 0) return rc;
+        hipLaunchKernelGGL((k_fi_mid<N, BWD, true>), dim3((unsigned)B), dim3(4 * N), lds, st, m);
+    }
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -951,9 +995,9 @@ extern "C" int nf_flowpp_img_mid_fwd(const float* x, const float* a, const float
                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
-        case 4: return nf_fi_mid_launch<256, false>(m, B, st);
-        case 3: return nf_fi_mid_launch<64, false>(m, B, st);
-        default: return nf_fi_mid_launch<16, false>(m, B, st);
+        case 4: return nf_fi_mid_launch<256, false>(m, W, B, st);
+        case 3: return nf_fi_mid_launch<64, false>(m, W, B, st);
+        default: return nf_fi_mid_launch<16, false>(m, W, B, st);
     }
 }
 
@@ -969,12 +1013,12 @@ extern "C" int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float
         g_conv1_b == nullptr || g_conv2_w == nullptr || g_conv2_b == nullptr || g_ln2_g == nullptr || g_ln2_b == nullptr)
         return NF_E_BADARG;
     if (!nf_flowpp_img_usable(B, 32, 32, H, W) || B > 0x7fffffff || g_out_slabs < 1 || g_out_slabs > NF_FLOWPP_IMG_MAX_KSPLIT) return NF_E_BADARG;
-    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, nullptr, g_out, g_out_slabs, B * 32 * H * W, g_x, g_a, g_ln1_g,
+    NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, nullptr, g_out, g_out_slabs, B * 32 * (int64_t)nf_flowpp_img_storage(H, W) * nf_flowpp_img_storage(H, W), g_x, g_a, g_ln1_g,
                  g_ln1_b, g_pos, g_conv1_w, g_conv1_b, g_conv2_w, g_conv2_b, g_ln2_g, g_ln2_b};
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
-        case 4: return nf_fi_mid_launch<256, true>(m, B, st);
-        case 3: return nf_fi_mid_launch<64, true>(m, B, st);
-        default: return nf_fi_mid_launch<16, true>(m, B, st);
+        case 4: return nf_fi_mid_launch<256, true>(m, W, B, st);
+        case 3: return nf_fi_mid_launch<64, true>(m, W, B, st);
+        default: return nf_fi_mid_launch<16, true>(m, W, B, st);
     }
 }

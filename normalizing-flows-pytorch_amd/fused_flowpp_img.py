@@ -39,7 +39,8 @@ def _tensors(net):
 
 def flowpp_img_fusable(net, x):
     """net: the nn.Sequential of MixLogAttnCoupling for image data (coupling.py:159-166) with the reference's widths (32 filters,
-    4 heads) on an H = W in {4, 8, 16} map."""
+    4 heads) on a square map of side <= 16.  Sides that are no powers of two (a 24 x 24 image: 12, 6, 3) run in the next power-of-two
+    storage map with a dead border (include/nfhip.h, "STORAGE")."""
     if not (FLOWPP_IMG_ON and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0):
         return False
     try:
@@ -78,10 +79,15 @@ class _FusedFlowppImg(torch.autograd.Function):
         B, I0, Hh, Ww = x_in.shape
         O = W5.shape[0]
         dev, st = x_in.device, N.stream()
-        x = torch.empty(B, HID, Hh, Ww, dtype=torch.float32, device=dev)
+        S = int(N.load().nf_flowpp_img_storage(Hh, Ww))          # side of the storage map (= Hh on the CIFAR / MNIST pyramids)
+        if S != Hh:                                              # the kernels never read the dead border: left uninitialised
+            xs = x_in.new_empty(B, I0, S, S)
+            xs[:, :, :Hh, :Ww] = x_in
+            x_in = xs
+        x = torch.empty(B, HID, S, S, dtype=torch.float32, device=dev)
         a = torch.empty_like(x)
         x4 = torch.empty_like(x)
-        out = torch.empty(B, O, Hh, Ww, dtype=torch.float32, device=dev)
+        out = torch.empty(B, O, S, S, dtype=torch.float32, device=dev)
         N.call('nf_flowpp_img_conv', N.ptr(x_in), N.ptr(W0), N.ptr(b0), N.ptr(x), B, I0, HID, Hh, Ww, 0, 0, 1, st)
         N.call('nf_flowpp_img_conv', N.ptr(x), N.ptr(Wg), N.ptr(bg), N.ptr(a), B, 2 * HID, HID, Hh, Ww, 1, 0, 1, st)
         # (8 x 8 maps: measured slower cut by head -- 64-thread workgroups, one wave per SIMD -- than one workgroup per sample)
@@ -100,16 +106,22 @@ class _FusedFlowppImg(torch.autograd.Function):
         N.call('nf_flowpp_img_conv', N.ptr(x4), N.ptr(W5), N.ptr(b5), N.ptr(out), B, HID, O, Hh, Ww, 0, 0, 1, st)
         ctx.save_for_backward(x_in, x, a, x4, mixed, cj, *ts)
         ctx.split = split
-        return out
+        ctx.image = (Hh, Ww)
+        return out if S == Hh else out[:, :, :Hh, :Ww].contiguous()
 
     @staticmethod
     def backward(ctx, g_out):
         x_in, x, a, x4, mixed, cj, *ts = ctx.saved_tensors
         (W0, b0, Wg, bg, l1g, l1b, pos, c1w, c1b, c2w, c2b, l2g, l2b, W5, b5) = [t.detach() for t in ts]
-        B, I0, Hh, Ww = x_in.shape
+        B, I0, S, _ = x_in.shape
+        Hh, Ww = ctx.image
         O = W5.shape[0]
         dev, st = x_in.device, N.stream()
         g_out = g_out.contiguous()
+        if S != Hh:
+            gs = g_out.new_empty(B, O, S, S)
+            gs[:, :, :Hh, :Ww] = g_out
+            g_out = gs
         sinks = _sinks(*ts)
         if sinks is not None:
             dst, direct = sinks, True
@@ -145,7 +157,7 @@ class _FusedFlowppImg(torch.autograd.Function):
 
         # last convolution: K = 9 O is cut into slabs that the next kernel sums on load
         ks = int(lib.nf_flowpp_img_conv_ksplit(B, O, HID, Hh, Ww))
-        g4 = torch.empty(ks, B, HID, Hh, Ww, dtype=torch.float32, device=dev)
+        g4 = torch.empty(ks, B, HID, S, S, dtype=torch.float32, device=dev)
         N.call('nf_flowpp_img_conv', N.ptr(g_out), N.ptr(W5), None, N.ptr(g4), B, O, HID, Hh, Ww, 0, 1, ks, st)
         wgrad(x4, g_out, gW5, gb5, HID, O, 0)
         # gate / LayerNorm / attention / LayerNorm
@@ -172,10 +184,10 @@ class _FusedFlowppImg(torch.autograd.Function):
                    N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(g4), N.ptr(g_x), N.ptr(g_a), N.ptr(gl1g), N.ptr(gl1b), N.ptr(gpos),
                    N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), B, Hh, Ww, ks, st)
         # gated convolution (its input is concat_elu(x), applied while staging)
-        g_cat = torch.empty(B, 2 * HID, Hh, Ww, dtype=torch.float32, device=dev)
+        g_cat = torch.empty(B, 2 * HID, S, S, dtype=torch.float32, device=dev)
         N.call('nf_flowpp_img_conv', N.ptr(g_a), N.ptr(Wg), None, N.ptr(g_cat), B, HID, 2 * HID, Hh, Ww, 0, 1, 1, st)
         wgrad(x, g_a, gWg, gbg, 2 * HID, HID, 1)
-        N.call('nf_flowpp_img_celu_bwd', N.ptr(x), N.ptr(g_cat), N.ptr(g_x), B, HID, Hh, Ww, st)
+        N.call('nf_flowpp_img_celu_bwd', N.ptr(x), N.ptr(g_cat), N.ptr(g_x), B, HID, S, S, st)       # (elementwise: the storage extent)
         # first convolution
         wgrad(x_in, g_x, gW0, gb0, I0, HID, 0)
         g_in = None
@@ -190,6 +202,8 @@ class _FusedFlowppImg(torch.autograd.Function):
             cur.wait_stream(side)                                # joined before autograd (and the optimizer) see the gradients
         else:
             _slab_sum_all(jobs)
+        if g_in is not None and S != Hh:
+            g_in = g_in[:, :, :Hh, :Ww].contiguous()
         if direct:
             return (g_in, ) + (None, ) * len(ts)
         return (g_in, ) + tuple(dst)

@@ -402,7 +402,7 @@ def test_mnist_shape_conditioner_dispatches_no_framework_convolution(pkg):
 
 
 @pytest.mark.parametrize('cls,dims,layers,mix', [('Glow', (1, 32, 32), 2, None), ('RealNVP', (1, 32, 32), 2, None), ('Flowpp', (1, 32, 32), 1, 4),
-                                                 ('Glow', (1, 24, 24), 2, None), ('RealNVP', (1, 24, 24), 2, None)])
+                                                 ('Glow', (1, 24, 24), 2, None), ('RealNVP', (1, 24, 24), 2, None), ('Flowpp', (1, 24, 24), 1, 4)])
 def test_single_channel_image_models_dispatch_no_framework_convolution(pkg, cls, dims, layers, mix):
     """the reference's MNIST shape ((1, 32, 32) after its loader's padding, flows/dataset.py:67-73) and a pyramid without power-of-two
     maps (24 -> 12 -> 6), second training pass (ActNorm initialised): no ATen / MIOpen convolution, batch norm, layer norm, softmax or

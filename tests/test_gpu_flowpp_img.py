@@ -59,6 +59,46 @@ def test_conv_forward_data_and_weight_gradient_vs_torch(pkg, Ci, Co, HW, B):
         G.assert_close(sb.sum(0), gb_ref, _scaled(gb_ref), what='conv bias gradient, %d slabs' % ns)
 
 
+@pytest.mark.parametrize('Ci,Co,V,B', [(6, 32, 12, 3), (32, 84, 14, 5), (24, 32, 6, 9), (32, 336, 7, 64), (96, 32, 3, 33), (40, 70, 5, 16),
+                                       (32, 84, 13, 64), (6, 32, 9, 130), (32, 1344, 3, 64), (24, 32, 6, 520), (5, 7, 2, 3)])
+def test_conv_on_an_image_inside_a_storage_map(pkg, Ci, Co, V, B):
+    """(H, W) of the C ABI = the image; tensors in the next power-of-two storage map with GARBAGE in the dead border: forward, data
+    gradient (all K splits) and weight / bias gradient equal those of the V x V problem"""
+    N = _native(pkg)
+    lib = N.load()
+    S = int(lib.nf_flowpp_img_storage(V, V))
+    assert S >= V and S in (4, 8, 16) and S < 2 * max(V, 3)
+    g = torch.Generator().manual_seed(Ci * 1000 + Co + V)
+    x = torch.randn(B, Ci, V, V, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3.0 * Ci ** 0.5)).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    gy = torch.randn(B, Co, V, V, generator=g).to(DEV)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    y_ref = F.conv2d(xr, wr, br, padding=1)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [xr, wr, br], gy)
+
+    def stored(t):
+        big = torch.full((t.shape[0], t.shape[1], S, S), float('nan'), device=DEV)          # NaN: any read of the border shows
+        big[:, :, :V, :V] = t
+        return big
+
+    xs, gs = stored(x), stored(gy)
+    st = N.stream()
+    y = torch.empty(B, Co, S, S, device=DEV)
+    N.call('nf_flowpp_img_conv', N.ptr(xs), N.ptr(w), N.ptr(b), N.ptr(y), B, Ci, Co, V, V, 0, 0, 1, st)
+    G.assert_close(y[:, :, :V, :V], y_ref, _scaled(y_ref), what='conv forward')
+    for ks in sorted({1, int(lib.nf_flowpp_img_conv_ksplit(B, Co, Ci, V, V)), (Co + 31) // 32}):
+        gx = torch.full((ks, B, Ci, S, S), 7.0, device=DEV)
+        N.call('nf_flowpp_img_conv', N.ptr(gs), N.ptr(w), None, N.ptr(gx), B, Co, Ci, V, V, 0, 1, ks, st)
+        G.assert_close(gx.sum(0)[:, :, :V, :V], gx_ref, _scaled(gx_ref), what='conv data gradient, %d slabs' % ks)
+    for ns in sorted({1, int(lib.nf_flowpp_img_wgrad_slabs(B, Ci, Co, V, V))}):
+        sw = torch.full((ns, 9, Co, Ci), 7.0, device=DEV)
+        sb = torch.full((ns, Co), 7.0, device=DEV)
+        N.call('nf_flowpp_img_conv_wgrad', N.ptr(xs), N.ptr(gs), N.ptr(sw), N.ptr(sb), ns, B, Ci, Co, V, V, 0, st)
+        G.assert_close(sw.sum(0).permute(1, 2, 0).reshape(w.shape), gw_ref, _scaled(gw_ref), what='conv weight gradient, %d slabs' % ns)
+        G.assert_close(sb.sum(0), gb_ref, _scaled(gb_ref), what='conv bias gradient, %d slabs' % ns)
+
+
 @pytest.mark.parametrize('HW,B', [(16, 3), (8, 6), (4, 19)])
 def test_gated_convolution_applies_concat_elu_while_staging(pkg, HW, B):
     N = _native(pkg)
@@ -101,12 +141,15 @@ def _cond_pair(pkg, in_chs, n_out, HW, seed):
 
 
 @pytest.mark.parametrize('split', [True, False], ids=['by_head', 'per_sample'])
-@pytest.mark.parametrize('in_chs,n_out,HW,B', [(6, 84, 16, 5), (24, 336, 8, 7), (96, 1344, 4, 18), (4, 56, 4, 3), (6, 84, 8, 64)])
+@pytest.mark.parametrize('in_chs,n_out,HW,B', [(6, 84, 16, 5), (24, 336, 8, 7), (96, 1344, 4, 18), (4, 56, 4, 3), (6, 84, 8, 64),
+                                               # sides that are no powers of two: the image sits in a 16 / 8 / 4 storage map (nfhip.h "STORAGE")
+                                               (2, 28, 12, 5), (8, 112, 6, 7), (32, 448, 3, 18), (2, 28, 14, 64), (8, 112, 7, 3), (6, 84, 9, 2),
+                                               (6, 84, 5, 130), (4, 56, 2, 3), (4, 56, 1, 2)])
 def test_conditioner_vs_module_stack(pkg, monkeypatch, in_chs, n_out, HW, B, split):
     """split: the middle of the conditioner cut by attention head (csrc/flowpp_img_att.hip, H = W in {8, 16}) or one workgroup per sample"""
     fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
-    if split and HW == 4:
-        pytest.skip('4 x 4 maps always run one workgroup per sample')
+    if split and HW != 16 and HW != 8:
+        pytest.skip('only 16 x 16 maps are ever cut by head')
     monkeypatch.setattr(fpi, 'SPLIT_BELOW', 10 ** 9 if split else 0)
     net, ref = _cond_pair(pkg, in_chs, n_out, HW, seed=in_chs + HW)
     g = torch.Generator().manual_seed(B)

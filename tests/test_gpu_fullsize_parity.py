@@ -408,6 +408,7 @@ IMAGE_CASES = [
     # cannot run there: its 7 x 7 level has no checkerboard): conditioners in power-of-two storage with a dead border (fused_conv.py)
     ('glow_24', 'glow', 'Glow', (1, 24, 24), 'image', 2, None, 64),
     ('realnvp_24', 'realnvp', 'RealNVP', (1, 24, 24), 'image', 2, None, 64),
+    ('flowpp_24', 'flowpp', 'Flowpp', (1, 24, 24), 'image', 1, 4, 64),          # conditioner maps 12 x 12, 6 x 6, 3 x 3 (flowpp_img.hip)
 ]
 
 
