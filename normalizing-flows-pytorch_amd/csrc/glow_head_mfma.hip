@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd4(const float* __re
 // TP = pixels per staged tile: 128, or 64 where 128 would leave fewer than 64 workgroups (the 8 x 8 level at B = 64: 32 -> 64 workgroups,
 // each wave 16 pixels instead of 32 -- the launch is a latency chain, a wave's part of it halves)
 template <int RT, int KQ, int TP>
-__global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __restrict__ gh, const float* __restrict__ gld,
+__global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glow_head_w_bwd(const float* __restrict__ gh, const float* __restrict__ gld,
                                                               const float* __restrict__ x, const float* __restrict__ als,
                                                               const float* __restrict__ abias, const float* __restrict__ M,
                                                               float* __restrict__ gx, float* __restrict__ g_ls, float* __restrict__ g_b,
@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
     extern __shared__ __attribute__((aligned(16))) float lds[];
     NF_GH_STAMP(8);
     constexpr int PW = TP / 4;            // pixels per wave
+    constexpr bool THROUGH_TILE = RT >= 3;   // g_x leaves through the LDS tile (see below)
     const int RS = TP + 1;
     const int CP = RT * 16;
     float* gT = lds;                       // [CP][RS]  g_h
@@ -240,7 +241,19 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
     const int64_t npix = B * P;
     for (int c = threadIdx.x; c < CP; c += blockDim.x) {
         cst[c] = c < C ? abias[c] : 0.f;
-        cst[CP + c] = c < C ? expf(als[c]) : 1.f;
+        cst[CP + c] = c < C ? 1.f / expf(als[c]) : 1.f;     // 1 / exp(log_scale): the tile loop multiplies
+    }
+    // sum_b g_ld (every channel's log_scale gradient carries P times it): each block takes a slice of the batch, requested here and
+    // consumed at the very end (as a loop of dependent loads in block 0 it was 16 of 91 us at B = 8192)
+    float sg = 0.f;
+    {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += 4 * stride) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] += b + u * stride < B ? gld[b + u * stride] : 0.f;
+        }
+        sg = (part[0] + part[1]) + (part[2] + part[3]);
     }
     // A fragments of W^T: A[i = li][k = lk] of row tile rt, k-step q -> W[4 q + lk][16 rt + li]
     float wt[RT][KQ];
@@ -268,11 +281,13 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
     const int sq = threadIdx.x & (TP - 1), ph = threadIdx.x / TP;
     float rg[NCH], rx[NCH];
     const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_block;
+    int64_t fbase = 0, sbase = 0;          // element offset of this thread's pixel column: of the tile just fetched / of the tile at work
     auto fetch = [&](int64_t tile) {
         const int64_t t = tile * TP + sq;
         const bool ok = tile < tile0 + tiles_per_block && t < npix;
         const int64_t b = ok ? t / P : 0;
         const int64_t base = b * C * P + (ok ? t - b * P : 0);
+        fbase = base;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = ph + NPH * k;
@@ -292,10 +307,11 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
         for (int k = 0; k < NCH; ++k) {
             const int c = ph + NPH * k;
             gT[c * RS + sq] = rg[k];
-            aT[c * RS + sq] = (sq < np && c < C) ? (rx[k] - cst[c]) / cst[CP + c] : 0.f;
+            aT[c * RS + sq] = (sq < np && c < C) ? (rx[k] - cst[c]) * cst[CP + c] : 0.f;
         }
         __syncthreads();
         NF_GH_STAMP(10);
+        sbase = fbase;
         fetch(tile + 1);
         // ---- g_W: this wave's quarter of the tile, pixels [PW wid, PW wid + PW), k-steps of 4 pixels ----
 #pragma unroll
@@ -327,8 +343,13 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) ga[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[rt][q], bq, ga[rt], 0, 0, 0);
             }
+            // g_x leaves through the tile: the lane that finishes (row r, pixel) is the only reader of aT[r][pixel] (a wave touches its
+            // own pixel quarter only), so the value takes that cell and the block writes the tile out below with the mapping of the
+            // loads -- whole 256-byte runs per wave instruction (from the accumulator layout it was 64-byte pieces of four rows:
+            // 1.7 TB/s on (48, 8, 8) at large batches)
+            // (few channels: the extra barrier costs more than the pieces -- straight from the accumulator layout there)
             if (pix < np) {
-                const int64_t t = t0 + pix, b = t / P;
+                const int64_t t = t0 + pix, b = THROUGH_TILE ? 0 : t / P;
                 float* gxb = gx + b * C * P + (t - b * P);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
@@ -337,11 +358,22 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
                         const int r = 16 * rt + 4 * lk + j;
                         if (r < C) {
                             const float g = ga[rt][j];
-                            gxb[(int64_t)r * P] = g / cst[CP + r];
                             s1[rt][j] = fmaf(g, aT[r * RS + pix], s1[rt][j]);
                             s2[rt][j] += g;
+                            if (THROUGH_TILE) aT[r * RS + pix] = g * cst[CP + r];
+                            else gxb[(int64_t)r * P] = g * cst[CP + r];
                         }
                     }
+            }
+        }
+        if (THROUGH_TILE) {
+            __syncthreads();
+            if (sq < np) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int c = ph + NPH * k;
+                    if (c < C) gx[sbase + (int64_t)c * P] = aT[c * RS + sq];
+                }
             }
         }
     }
@@ -382,9 +414,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
                 rs[(1 * 4 + wid) * CP + 16 * i + 4 * lk + j] = v;
             }
         }
-    float sg = 0.f;                        // block 0: sum_b g_ld (every channel's log_scale gradient carries P times it)
-    if (blockIdx.x == 0) {
-        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) sg += gld[b];
+    {                                      // this block's slice of sum_b g_ld
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sg += __shfl_xor(sg, off, NF_WAVE);
         if (lane == 0) rs[2 * 4 * CP + wid] = sg;
@@ -393,10 +423,9 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_bwd(const float* __res
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float R2 = (rs[(0 * 4 + 0) * CP + c] + rs[(0 * 4 + 1) * CP + c]) + (rs[(0 * 4 + 2) * CP + c] + rs[(0 * 4 + 3) * CP + c]);
         const float R1 = (rs[(1 * 4 + 0) * CP + c] + rs[(1 * 4 + 1) * CP + c]) + (rs[(1 * 4 + 2) * CP + c] + rs[(1 * 4 + 3) * CP + c]);
-        float SG = 0.f;
-        if (blockIdx.x == 0) SG = (rs[8 * CP] + rs[8 * CP + 1]) + (rs[8 * CP + 2] + rs[8 * CP + 3]);
+        const float SG = (rs[8 * CP] + rs[8 * CP + 1]) + (rs[8 * CP + 2] + rs[8 * CP + 3]);
         atomicAdd(g_ls + c, -R2 - (float)P * SG);        // modules.py:246-249 differentiated
-        atomicAdd(g_b + c, -R1 / cst[CP + c]);
+        atomicAdd(g_b + c, -R1 * cst[CP + c]);
     }
     NF_GH_STAMP(14);
 }
@@ -469,9 +498,16 @@ extern "C" int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const flo
     const int P = H * W;
     const int rt = (C + 15) / 16, kq = (C + 3) / 4;
     const int64_t npix = B * P;
-    const int TP = (npix + 127) / 128 < 64 ? 64 : 128;
+    // Tile and grid by the kernel's register footprint (-Rpass-analysis=kernel-resource-usage): the 128-pixel tile of 33 .. 64 channels
+    // holds 388 registers -- one workgroup per compute unit, so 512 workgroups ran in two rounds (137 us on (48, 8, 8) x 8192; with the
+    // 64-pixel tile, two workgroups per unit, 99) -- and the grid is ONE round of what fits (12 channels: three per unit, 91 -> 83 us).
+    static int tp_force = -1, cap_force = -1;                // NF_GLOW_HEAD_BWD_TP (64 / 128), NF_GLOW_HEAD_BWD_BLOCKS: experiment knobs
+    if (tp_force < 0) { const char* e = getenv("NF_GLOW_HEAD_BWD_TP"); tp_force = e == nullptr ? 0 : atoi(e); }
+    if (cap_force < 0) { const char* e = getenv("NF_GLOW_HEAD_BWD_BLOCKS"); cap_force = e == nullptr ? 0 : atoi(e); }
+    const int TP = tp_force == 64 || tp_force == 128 ? tp_force : ((rt >= 3 || (npix + 127) / 128 < 64) ? 64 : 128);
+    const int cap = cap_force > 0 ? cap_force : (rt == 1 ? 768 : (rt <= 3 ? 512 : 256));
     const int64_t tiles = (npix + TP - 1) / TP;
-    int64_t blocks = tiles < 512 ? tiles : 512;              // ends in C * C + 2 C same-address atomics per block
+    int64_t blocks = tiles < cap ? tiles : cap;              // ends in C * C + 2 C same-address atomics per block
     const int64_t tpb = (tiles + blocks - 1) / blocks;
     blocks = (tiles + tpb - 1) / tpb;
     const size_t lds = ((size_t)2 * rt * 16 * (128 + 1) + 2 * rt * 16) * sizeof(float);   // (sized for either tile; the reductions alias it)

@@ -34,7 +34,12 @@ def timeit(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e-3
 
 
+ONLY = None
+
+
 def report(name, nbytes, fn, reps=20):
+    if ONLY and not any(o in name for o in ONLY):
+        return
     t = timeit(fn, reps)
     gbs = nbytes / t / 1e9
     print('%-46s %9.1f us %9.1f MB %8.1f GB/s  %5.1f%% of 8.0 TB/s  %5.1f%% of 6.29 TB/s copy' %
@@ -48,8 +53,11 @@ def st():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scale', type=float, default=1.0)
+    ap.add_argument('--only', default='', help='comma-separated substrings of the row names to measure')
     a = ap.parse_args()
     sc = a.scale
+    global ONLY
+    ONLY = [o for o in a.only.split(',') if o] or None
     print('# kernel sweep on', torch.cuda.get_device_name(0), '| scale', sc)
     one, zero = torch.full((1, ), 0.5, device=DEV), torch.zeros(1, device=DEV)
     g2 = torch.zeros(2, device=DEV)
