@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
 #pragma unroll
         for (int c = 0; c < CT; ++c) Wm[r][c] = Wsaved[r * CT + c];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) { es[c] = expf(ls[c]); bb[c] = bs[c]; }
+    for (int c = 0; c < CT; ++c) { es[c] = 1.f / expf(ls[c]); bb[c] = bs[c]; }      // (the loop multiplies)
     float aW[CT][CT], aB[CT], aL[CT];
 #pragma unroll
     for (int r = 0; r < CT; ++r) {
@@ -135,6 +135,8 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
     const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t npix = B * P;
+    float sg = 0.f;                                  // this block's share of sum_b g_ld: requested with the first pixels (behind the
+    for (int64_t b = gtid; b < B; b += gstride) sg += gld[b];     // loop it was a round trip of its own at the end of the launch)
     for (int64_t t = gtid; t < npix; t += 2 * gstride) {     // two pixels per trip: their loads are in flight together
         const int64_t t2 = t + gstride;
         const bool has2 = t2 < npix;
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
             if (u == 1 && !has2) break;
             float zn[CT];
 #pragma unroll
-            for (int c = 0; c < CT; ++c) zn[c] = (zr[u][c] - bb[c]) / es[c];
+            for (int c = 0; c < CT; ++c) zn[c] = (zr[u][c] - bb[c]) * es[c];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 float a = 0.f;
@@ -156,15 +158,13 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
                     a = fmaf(Wm[r][c], G[u][r], a);
                     aW[r][c] = fmaf(G[u][r], zn[c], aW[r][c]);
                 }
-                const float gzc = a / es[c];
+                const float gzc = a * es[c];
                 gz[base[u] + (int64_t)c * P] = gzc;
                 aB[c] -= gzc;
                 aL[c] = fmaf(-a, zn[c], aL[c]);
             }
         }
     }
-    float sg = 0.f;                                  // this block's share of sum_b g_ld
-    for (int64_t b = gtid; b < B; b += gstride) sg += gld[b];
     // the block's 1 + CT (2 + CT) sums in ONE pass: wave sums by shuffles, the sixteen wave partials of every value side by side in
     // LDS, one barrier, thread i finishes value i (one nf_block_sum per value was 2 barriers each: 32 in a row at CT = 3, ~8 of the
     // launch's 19 us); partials are added in wave order, as nf_block_sum does
@@ -235,10 +235,12 @@ extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const floa
     if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
     if (B == 0) return 0;
     const int Px = H * W;
-    unsigned g = nf_grid_for(B * Px, NF_GH_BIG * 2);
+    static int thr = -1;                                     // NF_GLOW_HEAD_BWD_THREADS: experiment knob (64 .. 1024)
+    if (thr < 0) { const char* e = getenv("NF_GLOW_HEAD_BWD_THREADS"); thr = e == nullptr ? 512 : atoi(e); if (thr < 64 || thr > NF_GH_BIG || (thr & 63)) thr = 512; }   // (B = 64, 32 x 32: 10.4 us at 1024 threads, 8.8 at 512, 9.1 at 256)
+    unsigned g = nf_grid_for(B * Px, thr * 2);
     if (g > 256) g = 256;
     hipStream_t st = (hipStream_t)stream;
-#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(NF_GH_BIG), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, s, B, Px); break;
+#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(thr), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, s, B, Px); break;
     switch (C) { NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) default: return NF_E_UNSUPPORTED; }
 #undef NF_CASE
     NF_CHECK_LAUNCH();

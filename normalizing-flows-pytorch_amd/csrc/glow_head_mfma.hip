@@ -43,15 +43,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
                                                               float* __restrict__ z1c, float* __restrict__ ld, NfSplit s, int64_t B,
                                                               int C, int P) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    // log-det first: its loads (and the read-modify-write of ld) travel under the matrix work instead of after it
-    {
-        float sl = lane < C ? log_s[lane] - als[lane] : 0.f;     // C <= 64: one value per lane, wave sum
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, NF_WAVE);
-        const float dl = (float)P * sl;
-        const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
-        for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += dl;
-    }
+    NF_GH_STAMP(0);
     // W through LDS: read from memory row by row (coalesced), fragments from LDS -- a lane's fragment elements M[16 rt + li][4 q + lk]
     // sit C floats apart across lanes: gathered straight from memory that was 64 cache lines per load instruction, 36 instructions
     // per wave, ~10 of the kernel's 14 us at C = 48
@@ -74,8 +66,32 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
             ad[q] = c < C ? als[c] : 0.f;
         }
     }
-    for (int e = threadIdx.x; e < C * C; e += blockDim.x) Ws[(e / C) * 65 + (e - (e / C) * C)] = M[e];
+    // the log-det behind them: its wave sum WAITS for its two loads, so anything requested after it starts a second round trip (in
+    // front of the x / W requests it was 1.7 of the launch's 8.2 us at C = 48, B = 64); the read-modify-write of ld travels under the
+    // matrix work
+    {
+        constexpr int NWR = (64 * 64 + NF_BLOCK - 1) / NF_BLOCK;
+        float sl = lane < C ? log_s[lane] - als[lane] : 0.f;     // C <= 64: one value per lane, wave sum
+        float wreg[NWR];                                         // W requested too before anything is waited for
+#pragma unroll
+        for (int u = 0; u < NWR; ++u) {
+            const int e = threadIdx.x + u * NF_BLOCK;
+            wreg[u] = (u * NF_BLOCK < C * C && e < C * C) ? M[e] : 0.f;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, NF_WAVE);
+        const float dl = (float)P * sl;
+        const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+        for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gstride) ld[b] += dl;
+        NF_GH_STAMP(1);
+#pragma unroll
+        for (int u = 0; u < NWR; ++u) {
+            const int e = threadIdx.x + u * NF_BLOCK;
+            if (e < C * C) Ws[(e / C) * 65 + (e - (e / C) * C)] = wreg[u];
+        }
+    }
     __syncthreads();
+    NF_GH_STAMP(2);
     float a[RT][KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
@@ -87,6 +103,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
             a[rt][q] = (r < C && c < C) ? Ws[r * 65 + c] : 0.f;
         }
     }
+    NF_GH_STAMP(3);
     for (int64_t blk = wave; blk < nblk; blk += nwaves) {
         const int64_t b = blk / bpp;
         const int p = (int)(blk - b * bpp) * 16 + li;
@@ -100,12 +117,13 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
         for (int q = 0; q < KQ; ++q) {                       // B[k = lk][j = li] = ActNorm(x)[c = 4q + lk][pixel]
             const int c = 4 * q + lk;
             const float xq = blk == wave ? xv[q] : (c < C ? xb[(int64_t)c * P] : 0.f);
-            bv[q] = c < C ? (xq - ab[q]) / ad[q] : 0.f;
+            bv[q] = c < C ? (xq - ab[q]) / ad[q] : 0.f;          // (the reference's own rounding: a true division)
         }
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], bv[q], acc[rt], 0, 0, 0);
+        NF_GH_STAMP(4);
         const int yy = p / s.W, xx = p - yy * s.W;
         float* zb = z1c + b * s.n_half;
 #pragma unroll
@@ -121,6 +139,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd(const float* __res
                 }
             }
     }
+    NF_GH_STAMP(5);
 }
 
 // The same forward on 64-PIXEL blocks (large batches): a wave's lane li owns the four pixels 4 li .. 4 li + 3 of the block -- 16-byte loads
@@ -239,10 +258,6 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
                                            // reductions at the end alias [0, 4 CP CP) of the buffer and still read it)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
     const int64_t npix = B * P;
-    for (int c = threadIdx.x; c < CP; c += blockDim.x) {
-        cst[c] = c < C ? abias[c] : 0.f;
-        cst[CP + c] = c < C ? 1.f / expf(als[c]) : 1.f;     // 1 / exp(log_scale): the tile loop multiplies
-    }
     // sum_b g_ld (every channel's log_scale gradient carries P times it): each block takes a slice of the batch, requested here and
     // consumed at the very end (as a loop of dependent loads in block 0 it was 16 of 91 us at B = 8192)
     float sg = 0.f;
@@ -297,6 +312,11 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
         }
     };
     fetch(tile0);
+    // (the constants LAST: their LDS stores wait for their loads -- in front of the tile request that was a round trip of its own)
+    for (int c = threadIdx.x; c < CP; c += blockDim.x) {
+        cst[c] = c < C ? abias[c] : 0.f;
+        cst[CP + c] = c < C ? 1.f / expf(als[c]) : 1.f;     // 1 / exp(log_scale): the tile loop multiplies
+    }
     NF_GH_STAMP(9);
     for (int64_t tile = tile0; tile < tile0 + tiles_per_block; ++tile) {
         const int64_t t0 = tile * TP;

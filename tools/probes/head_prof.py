@@ -33,3 +33,19 @@ t = [v / 100.0 for v in buf]
 print('C %d  %d x %d  B %d: constants, W fragments, first tile requested %.1f | staged, barriers %.1f | g_W MFMAs %.1f | g_a, g_x stores, sums %.1f | '
       'g_W reduction + atomics %.1f | channel sums + atomics %.1f   total %.1f us'
       % (C, H, H, B, t[9] - t[8], t[10] - t[9], t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[14] - t[8]))
+
+# ---- forward (stamps 0 .. 5) ----
+ff = N.load().nf_glow_head_w_fwd
+pff = prof.nf_glow_head_w_fwd
+pff.argtypes, pff.restype = ff.argtypes, ff.restype
+lsv = torch.zeros(C, device='cuda')
+h, z1c, ld = torch.empty_like(x), torch.empty(B, C // 2, H, H, device='cuda'), torch.zeros(B, device='cuda')
+for _ in range(3):
+    rc = pff(x.data_ptr(), ls.data_ptr(), bs.data_ptr(), W.data_ptr(), lsv.data_ptr(), h.data_ptr(), z1c.data_ptr(), ld.data_ptr(), 2, 0, B, C, H, H,
+             N.stream())
+    assert rc == 0, rc
+torch.cuda.synchronize()
+prof.nf_gh_prof_read(buf)
+t = [v / 100.0 for v in buf]
+print('   forward: log-det + loads issued %.1f | W staged (memory round trip, LDS, barrier) %.1f | fragments from LDS %.1f | ActNorm + MFMAs %.1f | '
+      'stores issued %.1f   total %.1f us' % (t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]))
