@@ -347,33 +347,43 @@ struct NfGlowRaw;
 __device__ __forceinline__ void nf_glow_head_phase_a(float* sm, const NfGlowV& h, const NfGlowRaw& raw);
 __device__ __forceinline__ void nf_glow_head_phase_b(float* sm);
 
-__device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, int O_out, float wn_eps, const NfGlowV* head = nullptr,
-                                            const NfGlowRaw* raw = nullptr) {
+// what a thread brings from global memory for the staging of one MLP: requested by nf_mc_stage_load, placed by nf_mc_stage_store --
+// together they are nf_mc_stage; apart, the whole-flow backward requests step s - 1's while step s computes (k_glow_flow_bwd)
+struct NfMcStageRegs {
+    float w[NF_MC_NL][32 * 32 / NF_MC_THREADS];
+    float gk, bk, ga, be;
+};
+__device__ __forceinline__ void nf_mc_stage_load(const NfMlpP& p, int I0, int O_out, NfMcStageRegs& r) {
     const int tid = threadIdx.x, k = tid & 31;
     constexpr int RPT = 32 * 32 / NF_MC_THREADS;           // rows of a 32 x 32 matrix per thread (1 or 2)
-    float w[NF_MC_NL][RPT];
 #pragma unroll
     for (int l = 0; l < NF_MC_NL; ++l) {                  // 6 * RPT independent loads in flight, one latency
         const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
 #pragma unroll
         for (int h = 0; h < RPT; ++h) {
             const int oo = (tid >> 5) + h * (NF_MC_THREADS / 32);
-            w[l][h] = (oo < O && k < I) ? p.v[l][oo * I + k] : 0.f;
+            r.w[l][h] = (oo < O && k < I) ? p.v[l][oo * I + k] : 0.f;
         }
     }
-    float gk = 0.f, bk = 0.f, ga = 0.f, be = 0.f;
+    r.gk = r.bk = r.ga = r.be = 0.f;
     if (tid < NF_MC_NL * 32) {
         const int l = tid >> 5;
         const int I = l == 0 ? I0 : 32, O = l == NF_MC_NL - 1 ? O_out : 32;
-        gk = k < I ? p.g[l][k] : 0.f;
-        bk = k < O ? p.b[l][k] : 0.f;
+        r.gk = k < I ? p.g[l][k] : 0.f;
+        r.bk = k < O ? p.b[l][k] : 0.f;
     }
-    if (tid < NF_MC_NB * 32) { ga = p.gamma[tid >> 5][k]; be = p.beta[tid >> 5][k]; }
+    if (tid < NF_MC_NB * 32) { r.ga = p.gamma[tid >> 5][k]; r.be = p.beta[tid >> 5][k]; }
+}
+__device__ __forceinline__ void nf_mc_stage_store(const NfMcStageRegs& r, float* sm, int I0, int O_out, float wn_eps,
+                                                  const NfGlowV* head = nullptr, const NfGlowRaw* raw = nullptr) {
+    const int tid = threadIdx.x, k = tid & 31;
+    constexpr int RPT = 32 * 32 / NF_MC_THREADS;
+    const float gk = r.gk, bk = r.bk, ga = r.ga, be = r.be;
 #pragma unroll
     for (int l = 0; l < NF_MC_NL; ++l)
 #pragma unroll
         for (int h = 0; h < RPT; ++h)
-            sm[NF_MC_W + l * 32 * NF_FP_ST + ((tid >> 5) + h * (NF_MC_THREADS / 32)) * NF_FP_ST + k] = w[l][h];
+            sm[NF_MC_W + l * 32 * NF_FP_ST + ((tid >> 5) + h * (NF_MC_THREADS / 32)) * NF_FP_ST + k] = r.w[l][h];
     if (tid < NF_MC_NL * 32) sm[NF_MC_B + tid] = bk;
     if (tid < NF_MC_NB * 32) { sm[NF_MC_GA + tid] = ga; sm[NF_MC_BE + tid] = be; }
     if (head != nullptr) nf_glow_head_phase_a(sm, *head, *raw);
@@ -389,6 +399,12 @@ __device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, 
         sm[NF_MC_G + tid] = gk;
     }
     __syncthreads();
+}
+__device__ __forceinline__ void nf_mc_stage(const NfMlpP& p, float* sm, int I0, int O_out, float wn_eps, const NfGlowV* head = nullptr,
+                                            const NfGlowRaw* raw = nullptr) {
+    NfMcStageRegs r;
+    nf_mc_stage_load(p, I0, O_out, r);
+    nf_mc_stage_store(r, sm, I0, O_out, wn_eps, head, raw);
 }
 
 // out^T = W_l act^T for a 32-wide (zero padded) layer
@@ -1128,13 +1144,25 @@ __device__ __forceinline__ void nf_mc_head_grads(const float* sm, const NfGlowV&
     }
 }
 
+// Whole-flow backward: everything a step reads from global memory before its first barrier -- weights, BatchNorm vectors and saved
+// statistics, the head's parameters, its input row -- is requested for step s - 1 right after step s has staged its own (NfMcNext
+// names where from), travels under step s's matrix work, and is placed at the top of step s - 1 without a wait: the start-of-step
+// round trip (2.7 of a step's 25 us at two workgroups, tools/probes/mlp_chain_prof.py) leaves the latency chain.
+struct NfMcPre {
+    NfMcStageRegs st;
+    NfGlowRaw raw;
+    float bn_mean, bn_istd_raw, fm, fv, zr[4], gld;
+    int have, have_gld;
+};
+struct NfMcNext { const NfGlowFlowStep* st; const float* save; const float* hz; };
+
 template <int HEAD>
 __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restrict__ x, const NfMlpP& p, const float* __restrict__ save,
                                                const float* __restrict__ g_out, float* __restrict__ g_x, const NfMlpG& gr,
                                                int accumulate, float* ws, float* __restrict__ slabs, int64_t N, int I0, int O_out,
                                                int training, float eps, float wn_eps, const NfGlowV& h, const float* hz,
                                                const float* hgy, const float* hgld, float* hgz, NfMcCarry* carry = nullptr,
-                                               float* head_rec = nullptr) {
+                                               float* head_rec = nullptr, NfMcPre* pre = nullptr, const NfMcNext* nx = nullptr) {
     constexpr bool GLOW = HEAD != 0, FBN = HEAD == 2;
     NF_MC_T(64);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
@@ -1144,20 +1172,36 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
     float zr[4], gy[4], gld = 0.f;                        // fused Glow step: this row of z and of the incoming gradients
     NfGlowRaw head_raw;
     float fm = 0.f, fv = 1.f;
-    if (FBN && threadIdx.x < 4) {
+    const bool pf = pre != nullptr && pre->have;          // (uniform over the grid: a step counter)
+    if (FBN && pf) {
+        fm = pre->fm; fv = pre->fv;
+    } else if (FBN && threadIdx.x < 4) {
         fm = (int)threadIdx.x < h.D ? save[2 * NF_MC_NB * 32 + threadIdx.x] : 0.f;
         fv = (int)threadIdx.x < h.D ? save[2 * NF_MC_NB * 32 + 4 + threadIdx.x] : 1.f;
     }
     if (GLOW) {
-        if (!FBN) nf_glow_head_load(h, head_raw);
-        nf_glow_load_row(hz, row, rv, h.D, zr);
+        if (!FBN) {
+            if (pf) head_raw = pre->raw;
+            else nf_glow_head_load(h, head_raw);
+        }
+        if (pf) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zr[c] = pre->zr[c];
+        } else {
+            nf_glow_load_row(hz, row, rv, h.D, zr);
+        }
         if (carry != nullptr && carry->have) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) gy[c] = carry->v[c];
         } else {
             nf_glow_load_row(hgy, row, rv, h.D, gy);
         }
-        if (hgld != nullptr && rv) gld = hgld[row];
+        if (pre != nullptr && pre->have_gld) {
+            gld = pre->gld;                               // (the same vector for every step of the run)
+        } else {
+            if (hgld != nullptr && rv) gld = hgld[row];
+            if (pre != nullptr) { pre->gld = gld; pre->have_gld = 1; }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) Gs[j] = 0.f;
     } else {
@@ -1171,16 +1215,48 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
         }
     }
     float bn_mean = 0.f, bn_invstd = 0.f;
-    if (threadIdx.x < NF_MC_NB * 32) {
-        const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
-        bn_mean = training ? save[(2 * j + 0) * 32 + k] : p.rmean[j][k];
-        bn_invstd = training ? save[(2 * j + 1) * 32 + k] : 1.f / sqrtf(p.rvar[j][k] + eps);
+    NfMcStageRegs sr;
+    if (pf) {
+        bn_mean = pre->bn_mean;
+        bn_invstd = training ? pre->bn_istd_raw : 1.f / sqrtf(pre->bn_istd_raw + eps);
+        sr = pre->st;
+    } else {
+        if (threadIdx.x < NF_MC_NB * 32) {
+            const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
+            bn_mean = training ? save[(2 * j + 0) * 32 + k] : p.rmean[j][k];
+            bn_invstd = training ? save[(2 * j + 1) * 32 + k] : 1.f / sqrtf(p.rvar[j][k] + eps);
+        }
+        nf_mc_stage_load(p, I0, O_out, sr);
     }
-    nf_mc_stage(p, sm, I0, O_out, wn_eps, (GLOW && !FBN) ? &h : nullptr, (GLOW && !FBN) ? &head_raw : nullptr);
+    nf_mc_stage_store(sr, sm, I0, O_out, wn_eps, (GLOW && !FBN) ? &h : nullptr, (GLOW && !FBN) ? &head_raw : nullptr);
     NF_MC_T(65);
     if (threadIdx.x < NF_MC_NB * 32) nf_mc_batchnorm_consts(sm, threadIdx.x >> 5, bn_mean, bn_invstd);
     if (FBN && threadIdx.x < 4) nf_fbn_head_consts(sm, h, threadIdx.x, fm, fv);
     __syncthreads();
+    if (pre != nullptr) {                                 // the next step's requests (NfMcPre): HERE, behind the last barrier of the staging --
+                                                          // a __syncthreads() waits for every outstanding load, and the next one is the first exchange, a recompute away
+        pre->have = 0;
+        if (nx != nullptr && nx->st != nullptr) {
+            const NfGlowFlowStep& ns = *nx->st;
+            nf_mc_stage_load(ns.p, I0, O_out, pre->st);
+            pre->bn_mean = 0.f; pre->bn_istd_raw = 1.f;
+            if (threadIdx.x < NF_MC_NB * 32) {
+                const int j = threadIdx.x >> 5, k = threadIdx.x & 31;
+                pre->bn_mean = training ? nx->save[(2 * j + 0) * 32 + k] : ns.p.rmean[j][k];
+                pre->bn_istd_raw = training ? nx->save[(2 * j + 1) * 32 + k] : ns.p.rvar[j][k];
+            }
+            pre->fm = 0.f; pre->fv = 1.f;
+            if (FBN && threadIdx.x < 4) {
+                pre->fm = (int)threadIdx.x < ns.h.D ? nx->save[2 * NF_MC_NB * 32 + threadIdx.x] : 0.f;
+                pre->fv = (int)threadIdx.x < ns.h.D ? nx->save[2 * NF_MC_NB * 32 + 4 + threadIdx.x] : 1.f;
+            }
+            if (GLOW) {
+                nf_glow_load_row(nx->hz, row, rv, ns.h.D, pre->zr);
+                if (!FBN) nf_glow_head_load(ns.h, pre->raw);
+            }
+            pre->have = 1;
+        }
+    }
     float zn[4], hh[4];
     if (GLOW) {
         nf_glow_head_row(sm, zr, zn, hh);
@@ -1666,24 +1742,35 @@ __global__ void __launch_bounds__(NF_MC_THREADS) k_glow_flow_bwd(const NfGlowFlo
     // head_rec != nullptr: deferred fold -- `slabs` then holds a region per step and workgroup (S x grid x NF_MC_SLAB), every step
     // leaves its slab and head sums behind and ONE k_glow_fold_all launch after this kernel turns them into parameter gradients (the
     // in-kernel fold is 8.4 of a step's 34 us at two workgroups: tools/probes/mlp_chain_prof.py)
-    if (rt) rec[(S - 1) & 1][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps + S - 1)[threadIdx.x];
+    // three records in LDS: step s (at work), step s - 1 (whose loads step s requests, NfMcPre) and the slot step s - 2 arrives in
+    if (rt) {
+        rec[(S - 1) % 3][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps + S - 1)[threadIdx.x];
+        if (S >= 2) rec[(S - 2) % 3][threadIdx.x] = reinterpret_cast<const unsigned long long*>(steps + S - 2)[threadIdx.x];
+    }
     __syncthreads();
     NfMcCarry carry;
     carry.have = 0;
+    NfMcPre pre;
+    pre.have = 0;
+    pre.have_gld = 0;
 #pragma unroll 1
     for (int s = S - 1; s >= 0; --s) {
         NF_MC_T(104);
         unsigned long long nxt = 0;
-        if (rt && s > 0) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 1)[threadIdx.x];
-        const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
+        if (rt && s > 1) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 2)[threadIdx.x];
+        const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s % 3]);
+        NfMcNext nx;
+        nx.st = s > 0 ? reinterpret_cast<const NfGlowFlowStep*>(rec[(s + 2) % 3]) : nullptr;      // (s - 1) mod 3
+        nx.save = saves + (int64_t)(s > 0 ? s - 1 : 0) * save_stride;
+        nx.hz = s > 1 ? ys + (int64_t)(s - 2) * ND : z0;
         nf_mc_bwd_body<HEAD>(sm, nullptr, st.p, saves + (int64_t)s * save_stride, nullptr, nullptr, st.g, accumulate,
                           ws + (int64_t)s * NF_MLP_WS_FLOATS,
                           head_rec != nullptr ? slabs + (size_t)s * gridDim.x * NF_MC_SLAB : slabs + (int64_t)(s & 1) * NF_MLP_BWD_SLAB_FLOATS,
                           N, D / 2, D, training, eps, wn_eps, st.h, s == 0 ? z0 : ys + (int64_t)(s - 1) * ND,
                           s == S - 1 ? g_y : gzs + (int64_t)(s + 1) * ND, g_ld, gzs + (int64_t)s * ND, &carry,
-                          head_rec != nullptr ? head_rec + (size_t)s * gridDim.x * 64 : nullptr);
+                          head_rec != nullptr ? head_rec + (size_t)s * gridDim.x * 64 : nullptr, &pre, &nx);
         NF_MC_T(105);
-        if (rt) rec[(s + 1) & 1][threadIdx.x] = nxt;    // parity of s - 1
+        if (rt && s > 1) rec[(s + 1) % 3][threadIdx.x] = nxt;    // step s - 2 takes the slot of step s + 1
         __syncthreads();
         NF_MC_T(106);
     }
@@ -1721,7 +1808,7 @@ static int nf_flow_launch_bwd(const void* steps_dev, int S, const float* z0, con
         return NF_E_BADARG;
     if (N <= 0) return N == 0 ? 0 : NF_E_BADARG;
     const unsigned grid = (unsigned)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
-    const size_t body_lds = nf_mc_lds_bytes(3), lds = body_lds + 2 * NF_GF_REC_WORDS * 8;
+    const size_t body_lds = nf_mc_lds_bytes(3), lds = body_lds + 3 * NF_GF_REC_WORDS * 8;     // (three records: see k_glow_flow_bwd)
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_glow_flow_bwd<HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2148,7 +2235,7 @@ extern "C" int nf_persistent_capacity(int* mlp_blocks, int* maf_blocks) {
     int dev = 0, cus = 0, per_cu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const size_t lds = nf_mc_lds_bytes(3) + 2 * NF_GF_REC_WORDS * 8;
+    const size_t lds = nf_mc_lds_bytes(3) + 3 * NF_GF_REC_WORDS * 8;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_glow_flow_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_glow_flow_bwd<1>, NF_MC_THREADS, lds);
     if (e != hipSuccess) return (int)e;
