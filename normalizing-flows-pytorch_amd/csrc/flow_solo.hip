@@ -97,8 +97,9 @@ __device__ __forceinline__ void so_gemm(const float (&a)[16], const float (&bv)[
     for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], bv[r], acc, 0, 0, 0);
 }
 // The workgroup's meetings order LDS traffic only (nothing in a step is handed from wave to wave through global memory): a barrier
-// that waits for the LDS counter alone.  __syncthreads() also drains the vector-memory counter, i.e. it waits for the parameter
-// prefetch of the next step and for every statistics / slab store in flight.
+// that waits for the LDS counter alone, written out so that it stays one whatever fence a later toolchain attaches to
+// __syncthreads() (hipcc of ROCm 7.2 emits exactly this pair for it on gfx950 -- checked on the ISA: no vmcnt wait -- so the
+// parameter prefetch and the statistics / slab stores in flight are not waited for at a meeting either way).
 __device__ __forceinline__ void so_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // sum over the 32 lanes of a wave half (every lane ends with the total)
 __device__ __forceinline__ float so_half_sum(float v) {
