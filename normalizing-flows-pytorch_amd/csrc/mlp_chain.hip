@@ -1233,8 +1233,7 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
     if (threadIdx.x < NF_MC_NB * 32) nf_mc_batchnorm_consts(sm, threadIdx.x >> 5, bn_mean, bn_invstd);
     if (FBN && threadIdx.x < 4) nf_fbn_head_consts(sm, h, threadIdx.x, fm, fv);
     __syncthreads();
-    if (pre != nullptr) {                                 // the next step's requests (NfMcPre): HERE, behind the last barrier of the staging --
-                                                          // a __syncthreads() waits for every outstanding load, and the next one is the first exchange, a recompute away
+    if (pre != nullptr) {                                 // the next step's requests (NfMcPre), behind this step's own staging
         pre->have = 0;
         if (nx != nullptr && nx->st != nullptr) {
             const NfGlowFlowStep& ns = *nx->st;
