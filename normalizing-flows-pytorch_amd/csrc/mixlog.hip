@@ -5,7 +5,9 @@
 //             batch-global exit rule, reproduced with a device flag) -> - log pdf;   coupling.py:192-210, modules.py:196-212
 //   backward: analytic gradients in the responsibilities form r_k = pi_k pdf_k / f, which
 //             stays finite in the tails where f underflows.
-// Bytes: (4+3K)*4 B per transformed element (112 B at K = 8) + 8 B pass-through; ~5 transcendentals per component.
+// Bytes: (4+3K)*4 B per transformed element (112 B at K = 8) + 8 B pass-through; ~7 transcendentals per component forward, ~13
+// backward, all in their hardware forms (v_exp_f32 / v_log_f32 / v_rcp_f32 through nf_mixlog_oct.h: the libm forms are 8 .. 30
+// instructions each and made these kernels instruction-bound at a tenth of the transcendental rate).
 //
 // Every element's 2+3K parameters are loaded ONCE into registers (template KT >= K, unused slots masked with
 // log pi = -inf), so the 25..100 bisection steps and the backward's second sweep never go back to memory.
@@ -41,12 +43,12 @@ __device__ __forceinline__ void nf_mix_load(const float* __restrict__ P, int64_t
     }
     float se = 0.f;
 #pragma unroll
-    for (int k = 0; k < KT; ++k) se += expf(m.lp[k] - mx);
-    const float lse = mx + logf(se);                                  // F.log_softmax over the mixture axis (coupling.py:180)
+    for (int k = 0; k < KT; ++k) se += nf_fexp(m.lp[k] - mx);
+    const float lse = mx + nf_flog(se);                                 // F.log_softmax over the mixture axis (coupling.py:180)
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         m.lp[k] -= lse;
-        m.es[k] = expf(-m.s[k]);
+        m.es[k] = nf_fexp(-m.s[k]);
     }
 }
 
@@ -58,7 +60,7 @@ __device__ __forceinline__ void nf_mix_eval(const NfMix<KT>& m, float x, float& 
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const float u = (x - m.mu[k]) * m.es[k];
-        const float l = log1pf(expf(-fabsf(u)));
+        const float l = nf_flog(1.f + nf_fexp(-fabsf(u)));
         c[k] = m.lp[k] + (fminf(u, 0.f) - l);
         d[k] = m.lp[k] + (u - m.s[k] - 2.f * (fmaxf(u, 0.f) + l));
         cm = fmaxf(cm, c[k]);
@@ -66,9 +68,9 @@ __device__ __forceinline__ void nf_mix_eval(const NfMix<KT>& m, float x, float& 
     }
     float sc = 0.f, sd = 0.f;
 #pragma unroll
-    for (int k = 0; k < KT; ++k) { sc += expf(c[k] - cm); sd += expf(d[k] - dm); }
-    lcdf = cm + logf(sc);
-    lpdf = dm + logf(sd);
+    for (int k = 0; k < KT; ++k) { sc += nf_fexp(c[k] - cm); sd += nf_fexp(d[k] - dm); }
+    lcdf = cm + nf_flog(sc);
+    lpdf = dm + nf_flog(sd);
 }
 
 // mixture CDF in linear space for the bisection: sum_k pi_k sigmoid(u_k) == exp(logsumexp(log pi + logsigmoid)) up to
@@ -77,7 +79,7 @@ template <int KT>
 __device__ __forceinline__ float nf_mix_cdf(const NfMix<KT>& m, const float (&pi)[KT], float x) {
     float F = 0.f;
 #pragma unroll
-    for (int k = 0; k < KT; ++k) F = fmaf(pi[k], 1.f / (1.f + expf(-(x - m.mu[k]) * m.es[k])), F);
+    for (int k = 0; k < KT; ++k) F = fmaf(pi[k], __builtin_amdgcn_rcpf(1.f + nf_fexp(-(x - m.mu[k]) * m.es[k])), F);
     return F;
 }
 
@@ -85,12 +87,12 @@ template <int KT>
 __device__ __forceinline__ float nf_mixlog_fwd_elem(const NfMix<KT>& m, float x, float A, float Cb, float eps, float& acc) {
     float lcdf, lpdf;
     nf_mix_eval<KT>(m, x, lcdf, lpdf);
-    const float F = expf(lcdf);                                   // modules.py:194
+    const float F = nf_fexp(lcdf);                                // modules.py:194
     const float xc = fminf(fmaxf(F, eps), 1.f - eps);             // modules.py:147
-    const float la = logf(xc), lb = logf(1.f - xc);               // logit and its log-det share the two logs
-    const float a = tanhf(m.a_raw) * A + Cb;                      // coupling.py:178
+    const float la = nf_flog(xc), lb = nf_flog(1.f - xc);               // logit and its log-det share the two logs
+    const float a = nf_ftanh(m.a_raw) * A + Cb;                   // coupling.py:178
     acc += lpdf - (la + lb) + a;                                  // coupling.py:184-188
-    return (la - lb) * expf(a) + m.b;                             // coupling.py:187
+    return (la - lb) * nf_fexp(a) + m.b;                             // coupling.py:187
 }
 
 // backward element (appendix B6, responsibilities form); writes the 2+3K parameter gradients through GP (stride gnh)
@@ -100,34 +102,35 @@ __device__ __forceinline__ float nf_mixlog_bwd_elem(const NfMix<KT>& m, float* _
                                                     float& acc_C) {
     float lcdf, lpdf;
     nf_mix_eval<KT>(m, x, lcdf, lpdf);
-    const float F = expf(lcdf), f = expf(lpdf);
+    const float F = nf_fexp(lcdf), f = nf_fexp(lpdf);
     const bool inside = (F >= eps) && (F <= 1.f - eps);          // torch.clamp passes the gradient on [min, max]
     const float xc = fminf(fmaxf(F, eps), 1.f - eps);
-    const float y1 = logf(xc) - logf(1.f - xc);
-    const float th = tanhf(m.a_raw);
-    const float ea = expf(th * A + Cb);
+    const float y1 = nf_flog(xc) - nf_flog(1.f - xc);
+    const float th = nf_ftanh(m.a_raw);
+    const float ea = nf_fexp(th * A + Cb);
     const float g_y1 = gy * ea;                                  // y = y1 * exp(a) + b ; ld += a
     const float g_a = gy * y1 * ea + gld;
     GP[0] = g_a * A * (1.f - th * th);
     GP[gnh] = gy;
     acc_A += g_a * th;
     acc_C += g_a;
-    const float gF = inside ? (g_y1 - gld * (1.f - 2.f * xc)) / (xc * (1.f - xc)) : 0.f;   // logit + its log-det
+    const float gF = inside ? (g_y1 - gld * (1.f - 2.f * xc)) * __builtin_amdgcn_rcpf(xc * (1.f - xc)) : 0.f;   // logit + its log-det
     const float tot = gF * F + gld;                              // sum_j g_logpi_j
     float gx = gF * f;
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         if (k < K) {
             const float u = (x - m.mu[k]) * m.es[k];
-            const float l = log1pf(expf(-fabsf(u)));
-            const float r = expf(m.lp[k] + (u - m.s[k] - 2.f * (fmaxf(u, 0.f) + l)) - lpdf);   // pi_k pdf_k / f
-            const float omt = -tanhf(0.5f * u);                                            // 1 - 2 sigmoid(u)
+            const float eu = nf_fexp(-fabsf(u)), ru = __builtin_amdgcn_rcpf(1.f + eu);
+            const float l = nf_flog(1.f + eu);
+            const float r = nf_fexp(m.lp[k] + (u - m.s[k] - 2.f * (fmaxf(u, 0.f) + l)) - lpdf);   // pi_k pdf_k / f
+            const float omt = copysignf((1.f - eu) * ru, -u);                              // 1 - 2 sigmoid(u) = -tanh(u / 2)
             const float w = gld * r * omt * m.es[k];
             gx += w;
             GP[(2 + K + k) * gnh] = -gF * f * r - w;                                            // g_mu_k
             GP[(2 + 2 * K + k) * gnh] = -gF * f * r * (x - m.mu[k]) + gld * r * (-omt * u - 1.f);   // g_s_k
-            const float g_logpi = gF * expf(m.lp[k] + (fminf(u, 0.f) - l)) + gld * r;
-            GP[(2 + k) * gnh] = g_logpi - expf(m.lp[k]) * tot;                                   // through log_softmax
+            const float g_logpi = gF * nf_fexp(m.lp[k] + (fminf(u, 0.f) - l)) + gld * r;
+            GP[(2 + k) * gnh] = g_logpi - nf_fexp(m.lp[k]) * tot;                                  // through log_softmax
         }
     }
     return gx;

@@ -81,6 +81,13 @@ class GradBucket:
     def world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    @property
+    def collective(self):
+        """does a step issue the gradient all-reduce?  World size > 1 -- or a ONE-rank group with NF_DP_FORCE_COLLECTIVE=1, which
+        sends the trainer down the N > 1 control flow (eager or captured RCCL all-reduce between backward and Adam, start-up
+        broadcast) on a single GPU: how the 1-GPU box exercises the RCCL path (tests/test_gpu_rccl.py)."""
+        return self.world > 1 or (dist.is_initialized() and os.environ.get('NF_DP_FORCE_COLLECTIVE', '0') == '1')
+
     def zero_(self):
         self.flat.zero_()
 
@@ -89,15 +96,16 @@ class GradBucket:
 
     def all_reduce_mean_(self):
         """sum over ranks, then 1/world (the loss is a per-shard mean, main.py:85)."""
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.flat.mul_(1.0 / self.world)
         return self.flat
 
 
-def broadcast_parameters(module, src=0, group=None):
-    """make every replica start from rank ``src``'s parameters and buffers."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def broadcast_parameters(module, src=0, group=None, force=False):
+    """make every replica start from rank ``src``'s parameters and buffers (``force``: also in a one-rank group)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return 0
     return broadcast_coalesced([t.data for t in list(module.parameters()) + list(module.buffers())], src=src, group=group)
 

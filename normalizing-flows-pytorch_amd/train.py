@@ -216,7 +216,7 @@ class FlowTrainer:
             self._forward_backward(self._static_y)
             self.bucket.all_reduce_mean_()
             self.optim.step()
-        single = self.bucket.world == 1                 # no all-reduce between backward and Adam: one graph, one replay
+        single = not self.bucket.collective            # no all-reduce between backward and Adam: one graph, one replay
         # N > 1 with one_graph: the flat bucket's all-reduce is captured BETWEEN backward and Adam (ProcessGroupNCCL enqueues the RCCL
         # kernel on the capturing stream): one replay per step instead of two graph launches and an eager collective in between.
         # Opt-in (FlowTrainer(one_graph=True) / NF_DP_ONE_GRAPH=1): no multi-GPU node was available to measure it; a capture that
@@ -296,10 +296,10 @@ class FlowTrainer:
         rank 0's parameters and buffers win (policy 2); afterwards running statistics evolve per replica
         unless the trainer runs in sync-statistics mode."""
         self._replicas_synced = True
-        if self.bucket.world > 1:
+        if self.bucket.collective:
             # every parameter AND buffer: the frozen PLU constants (P, pivots, sign_s), MAF's perm and the running statistics
             # too, so that replicas built from different seeds cannot keep private copies of those
-            nfdist.broadcast_parameters(self.net, src=0, group=self.bucket.group)
+            nfdist.broadcast_parameters(self.net, src=0, group=self.bucket.group, force=True)
 
     # -- evaluation -----------------------------------------------------------------------------------------------------
     @torch.no_grad()

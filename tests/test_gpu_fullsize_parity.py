@@ -107,7 +107,10 @@ def _check(gaps, what, gpu, r32, r64, scale=None):
     if r64 is not None:
         gaps[what] = float((a - r64.detach().double().reshape(-1)).abs().max())
     ref = gaps[what]
-    ulp = 4.0 * 1.2e-7 * float(a.abs().max())                # the values are fp32 numbers (loss ~ 1.5e4 for CIFAR)
+    # the values are fp32 numbers (loss ~ 1.5e4 for CIFAR): 16 eps ~ 8 ulp of the largest entry -- two fp32 sums over 2e5 terms in
+    # different orders; the measured gap |cpu32 - cpu64| is itself a sample (flowpp_cifar step 2: 7.9e-5 in one run, 3.6e-4 in another,
+    # with the GPU loss bit-identical and 1.95e-3 = 8 ulp from either cpu32 value)
+    ulp = 16.0 * 1.2e-7 * float(a.abs().max())
     return err <= TOL * s + SLACK * ref + ulp, err, ref, s
 
 
@@ -204,7 +207,10 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         gaps['flat'] = max(rel_ens)
         _report('%-18s %-14s flat gradient distance to float64: gpu %.3e  cpu32 %.3e  fp32 oracle on %d row permutations: %s'
                 % (name, tag, rel_gpu, rel_ens[0], len(members) - 1, ' '.join('%.2e' % v for v in rel_ens[1:])))
-        if rel_gpu > 4.0 * max(rel_ens) + 1.0e-6:
+        # (floor 2 x TOL: a one- or two-member ensemble's distance is itself a sample -- the fp32 oracle of realnvp_cifar measured 1.3e-6
+        # at step 2 of one run and 3.0e-5 at the same step of another, the GPU 1.3e-5 / 3.0e-5: north_star's fp32 tolerance carries the bar
+        # where the yard-stick happens to be lucky)
+        if rel_gpu > 4.0 * max(rel_ens) + 2.0 * TOL:
             bad.append(('flat gradient distance to float64', rel_gpu, max(rel_ens)))
         pg = _step_profile(grads, r64, per_step)
         pe = [_step_profile(m['grads'], r64, per_step) for m in members]
@@ -241,7 +247,7 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         rel = _flat_distance(grads, rec32)
         _report('%-18s %-14s flat gradient distance gpu to cpu32 %.3e (bar: 4 x %.3e measured at the last float64 pass)'
                 % (name, tag, rel, gaps.get('flat', float('nan'))))
-        if 'flat' in gaps and rel > 4.0 * gaps['flat'] + 1.0e-6:
+        if 'flat' in gaps and rel > 4.0 * gaps['flat'] + 2.0 * TOL:
             bad.append(('flat gradient distance to cpu32', rel, gaps['flat']))
     assert not bad, '%s %s: %d quantities outside their bar, first %s' % (name, tag, len(bad), bad[:6])
 
