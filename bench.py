@@ -394,18 +394,18 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
     for _ in range(max(warmup, 4) - 1):                      # >= 4 so that graph capture happens before timing
         trainer.train_on_batch(y)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():   # (initialised at one rank: NF_DP_FORCE_COLLECTIVE=1, the DP control flow on one GPU)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         z, loss = trainer.train_on_batch(y)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():   # (initialised at one rank: NF_DP_FORCE_COLLECTIVE=1, the DP control flow on one GPU)
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():   # (initialised at one rank: NF_DP_FORCE_COLLECTIVE=1, the DP control flow on one GPU)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -476,7 +476,7 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
         'dtype': 'f32',
         'data': 'synthetic (seeded %s restatement, random-init weights)' % cfg['data'],
         'config': {'workload': cfg['desc'] if not args.batch else cfg['desc'] + ' -- measured at per-GPU batch %d' % B, 'name': name, 'per_gpu_batch': B, 'global_batch': B * world,
-                   'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None, 'dp_one_graph': bool(getattr(trainer, '_g_whole', False)) and world > 1, 'collective': collective_info(world)},
+                   'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None, 'dp_one_graph': bool(getattr(trainer, '_g_whole', False)) and trainer.bucket.collective, 'collective': collective_info(world)},
         'loss_nats': round(loss_val, 5),
         'bits_per_dim': round(nftrain.bits_per_dim(loss_val, cfg['dims']), 5),
         'forward_samples_per_s': round(B * world / (fwd_ms * 1e-3), 1),
@@ -507,7 +507,7 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
 
 def collective_info(world):
     """what the gradient exchange ran on: the process group's backend and size as torch.distributed reports them (N = 1: none)"""
-    if world == 1 or not torch.distributed.is_initialized():
+    if not torch.distributed.is_initialized():
         return {'ranks': 1, 'backend': None}
     info = {'ranks': torch.distributed.get_world_size(), 'backend': torch.distributed.get_backend()}
     try:
@@ -534,10 +534,32 @@ def self_spawn(args):
     os.execve(sys.executable, cmd, env)
 
 
+def _claim_stdout():
+    """stdout carries exactly ONE line, the JSON: RCCL prints its start-up banner (version, host name, library path) through C stdio on
+    stdout, and when stdout is a pipe or file that buffer is flushed at process exit -- AFTER the JSON line python printed (measured on
+    the GPU box with a one-rank group: five banner lines behind the line).  Everything written to fd 1 from here on goes to stderr; the
+    line itself is written to the saved descriptor at the very end."""
+    sys.stdout.flush()
+    fd = os.dup(1)
+    os.dup2(2, 1)
+    return fd
+
+
+def _emit_line(fd, line):
+    sys.stdout.flush()
+    sys.stderr.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)                       # every C stdio buffer out (to stderr) before the line: it is the last output
+    except Exception:
+        pass
+    os.write(fd, (line + '\n').encode())
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_spawn(args)                                     # does not return
+    json_fd = _claim_stdout()
     pkg = importlib.import_module(PKG)
     nfdist = importlib.import_module(PKG + '.dist')
     rank, world, local_rank = nfdist.init_from_env()
@@ -571,11 +593,11 @@ def main():
             out['also'].update(more)
             if b512 is not None:
                 out['also']['c4_b512'] = b512
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or torch.distributed.is_initialized():   # (initialised at one rank: NF_DP_FORCE_COLLECTIVE=1, the DP control flow on one GPU)
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        _emit_line(json_fd, json.dumps(out))
 
 
 if __name__ == '__main__':

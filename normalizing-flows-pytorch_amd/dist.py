@@ -22,7 +22,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    # (NF_DP_FORCE_COLLECTIVE=1: a ONE-rank group too -- bench.py / the trainer then run the N > 1 control flow on real RCCL on one GPU)
+    if (world > 1 or os.environ.get('NF_DP_FORCE_COLLECTIVE', '0') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:

@@ -178,3 +178,31 @@ def test_image_flowpp_conditioner_is_not_taken_off_the_gpu_or_for_other_shapes(p
     assert not fpi.flowpp_img_fusable(net, torch.zeros(2, 6))                           # density data
     wide = cond.flowpp_conditioner(6, 84, (64, 8, 8), 64, conv=True)
     assert not fpi.flowpp_img_fusable(wide, torch.zeros(2, 6, 8, 8))
+
+
+def test_bench_stdout_carries_only_the_json_line(tmp_path):
+    """bench.py's contract: rank 0 prints ONE JSON line.  RCCL writes its start-up banner to stdout through C stdio, which a pipe
+    flushes at process exit -- behind the line python printed (seen on the GPU box with a one-rank nccl group).  bench._claim_stdout
+    sends everything else that reaches fd 1 to stderr; bench._emit_line writes the line to the saved descriptor last."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'emit.py'
+    script.write_text(
+        "import ctypes, importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('bench', %r)\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "fd = b._claim_stdout()\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.printf(b'banner from C stdio\\n')\n"
+        "print('python print')\n"
+        "b._emit_line(fd, '{\"ok\": 1}')\n"
+        "libc.printf(b'late C output\\n')\n" % os.path.join(ROOT, 'bench.py'))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"ok": 1}\n'
+    assert 'banner from C stdio' in r.stderr and 'python print' in r.stderr
+    merged = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300).stdout
+    lines = [ln for ln in merged.splitlines() if ln.strip()]
+    assert lines.index('{"ok": 1}') > lines.index('banner from C stdio')        # buffered C output is flushed BEFORE the line
