@@ -69,6 +69,14 @@ python tools/model_sweep.py > $OUT/${R}_model_sweep.txt 2> $OUT/model_sweep.err
 python tools/probes/parity_depth.py c1 > $OUT/${R}_c1_parity_depth.txt 2>&1
 python tools/cpu_threads.py c4 8 16 32 64 > $OUT/${R}_cpu_threads.txt 2>&1
 SECONDS_PER=4 python tools/cpu_threads.py c1 1 4 8 16 32 >> $OUT/${R}_cpu_threads.txt 2>&1
+# the data-parallel control flow on REAL RCCL with a one-rank group (NF_DP_FORCE_COLLECTIVE=1: barriers, start-up broadcast, graph A + eager
+# all-reduce + graph B, or -- NF_DP_ONE_GRAPH=1 -- the all-reduce captured inside the step graph) against the plain single-process step
+for c in c4 c1 c5; do for m in "NF_DP_FORCE_COLLECTIVE=0" "NF_DP_FORCE_COLLECTIVE=1" "NF_DP_FORCE_COLLECTIVE=1 NF_DP_ONE_GRAPH=1"; do
+  echo "== $c $m" >> $OUT/${R}_dp_one_rank.txt
+  env $m python bench.py --config $c --skip-cpu --steps 50 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('samples/s', d['value'], 'ms/step', d['ms_per_step'], 'event median', d.get('ms_per_step_event_median'), 'one_graph', d['config'].get('dp_one_graph'), d['config'].get('collective'))" >> $OUT/${R}_dp_one_rank.txt 2>&1
+done; done
+# issue rate of the transcendental VALU instructions (the roof quoted for the mixture-of-logistics kernels)
+hipcc --offload-arch=gfx950 -O3 -o /tmp/vexp_rate_probe tools/probes/vexp_rate_probe.hip 2> /dev/null && /tmp/vexp_rate_probe > $OUT/${R}_vexp_rate.txt 2>&1
 python -m pytest tests/test_gpu_fullsize_parity.py -q > $OUT/pytest_fullsize.log 2>&1
 cp gpurun_out/fullsize_parity.txt $OUT/${R}_fullsize_parity.txt
 ls -la $OUT
