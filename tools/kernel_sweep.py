@@ -37,13 +37,18 @@ def timeit(fn, reps=20):
 ONLY = None
 
 
-def report(name, nbytes, fn, reps=20):
+TRANS_PEAK = 20.0e12   # v_exp_f32 / v_log_f32 / v_rcp_f32 lane-operations per second chip-wide (tools/probes/vexp_rate_probe.hip, profiles/rNN_vexp_rate.txt)
+
+
+def report(name, nbytes, fn, reps=20, trans=None):
+    """``trans``: hardware transcendental lane-operations the launch executes (the mixture kernels): printed against TRANS_PEAK"""
     if ONLY and not any(o in name for o in ONLY):
         return
     t = timeit(fn, reps)
     gbs = nbytes / t / 1e9
-    print('%-46s %9.1f us %9.1f MB %8.1f GB/s  %5.1f%% of 8.0 TB/s  %5.1f%% of 6.29 TB/s copy' %
-          (name, t * 1e6, nbytes / 1e6, gbs, 100 * gbs / PEAK, 100 * gbs / COPY))
+    tr = '' if trans is None else '  %5.2f T transcendental/s = %4.1f%% of %.0f T/s' % (trans / t / 1e12, 100 * trans / t / TRANS_PEAK, TRANS_PEAK / 1e12)
+    print('%-46s %9.1f us %9.1f MB %8.1f GB/s  %5.1f%% of 8.0 TB/s  %5.1f%% of 6.29 TB/s copy%s' %
+          (name, t * 1e6, nbytes / 1e6, gbs, 100 * gbs / PEAK, 100 * gbs / COPY, tr))
 
 
 def st():
@@ -180,14 +185,14 @@ def main():
     nb = B * ((4 + 3 * K) * 4 + 8)
     report('mixlog_coupling_fwd 2d K=8', nb + B * 8,
            lambda: N.call('nf_mixlog_coupling_fwd', z.data_ptr(), params.data_ptr(), one.data_ptr(), zero.data_ptr(),
-                          yv.data_ptr(), ld.data_ptr(), K, 1e-5, 0, 0, B, 2, 1, 1, st()))
+                          yv.data_ptr(), ld.data_ptr(), K, 1e-5, 0, 0, B, 2, 1, 1, st()), trans=B * 8 * 15)
     report('mixlog_coupling_bwd 2d K=8', 2 * nb + B * 12,
            lambda: N.call('nf_mixlog_coupling_bwd', yv.data_ptr(), ld.data_ptr(), z.data_ptr(), params.data_ptr(),
                           one.data_ptr(), zero.data_ptr(), gz.data_ptr(), gp.data_ptr(), g2.data_ptr(), g2.data_ptr() + 4, K,
-                          1e-5, 0, 0, B, 2, 1, 1, st()))
+                          1e-5, 0, 0, B, 2, 1, 1, st()), trans=B * 8 * 25)
     report('mixlog_coupling_inv 2d K=8 (25 it)', nb + B * 8 + B * 24,
            lambda: N.call('nf_mixlog_coupling_inv', yv.data_ptr(), params.data_ptr(), one.data_ptr(), zero.data_ptr(),
-                          gz.data_ptr(), ld.data_ptr(), scratch.data_ptr(), flag.data_ptr(), K, 0, 0, B, 2, 1, 1, st()), reps=5)
+                          gz.data_ptr(), ld.data_ptr(), scratch.data_ptr(), flag.data_ptr(), K, 0, 0, B, 2, 1, 1, st()), reps=5, trans=B * 8 * (3 + 25 * 2 + 8))
     del z, params, yv, gz, gp, scratch
 
     # ---- fused linear + BatchNorm (MFMA) ------------------------------------------------------------------------------------------------
