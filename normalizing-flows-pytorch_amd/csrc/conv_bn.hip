@@ -953,7 +953,16 @@ extern "C" int nf_conv_wgrad_slabs(int64_t B, int H, int W, int n_layers) {
         const int v = e != nullptr ? atoi(e) : 0;
         forced = (v >= 1 && v <= NF_CV_BWD_MAX_SLABS) ? v : 0;
     }
-    int64_t want = forced > 0 ? forced : 256 / n_layers;
+    // NF_CONV_WGRAD_BLOCKS: workgroups of the whole launch (default 256 = one per compute unit).  With the launches on a side stream
+    // (NF_CONV_OVERLAP=1) next to the persistent chain -- whose workgroups need a WHOLE compute unit each, at most 128 of them -- a cap of
+    // 128 leaves the chain its compute units instead of making every chain launch wait for weight-gradient workgroups to retire.
+    static int cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("NF_CONV_WGRAD_BLOCKS");
+        const int v = e != nullptr ? atoi(e) : 0;
+        cap = (v >= 1 && v <= 1024) ? v : 256;
+    }
+    int64_t want = forced > 0 ? forced : cap / n_layers;
     if (want < 1) want = 1;
     if (want > NF_CV_BWD_MAX_SLABS) want = NF_CV_BWD_MAX_SLABS;
     return (int)(tiles < want ? tiles : want);
