@@ -73,6 +73,7 @@ AMP = 1.3          # amplification of a gradient perturbation per flow step of t
 ENSEMBLE = 6       # row permutations of the batch the fp32 oracle is run on where that is cheap (C1, C2, C5)
 ENSEMBLE_SLOW = 2  # ... and for C3 / C4 (one fp32 oracle step is 3 - 6 s there)
 KINK_CAP = 0.05    # the per-step kink allowance never exceeds this
+KINK_FLAT = 3.0e-2  # flat-gradient (relative L2) footprint of one kink event, times the batch size (measured: <= 1.9e-4 at B = 64)
 WIDE = 0.2         # ensemble envelope beyond which the bar is 1.25 x the envelope instead of 2 x
 
 CONFIGS = [
@@ -210,7 +211,12 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         # (floor 2 x TOL: a one- or two-member ensemble's distance is itself a sample -- the fp32 oracle of realnvp_cifar measured 1.3e-6
         # at step 2 of one run and 3.0e-5 at the same step of another, the GPU 1.3e-5 / 3.0e-5: north_star's fp32 tolerance carries the bar
         # where the yard-stick happens to be lucky)
-        if rel_gpu > 4.0 * max(rel_ens) + 2.0 * TOL:
+        # KINK_FLAT / B: the footprint of ONE ReLU decision that falls on the other side of its kink.  Measured from identical state
+        # (tools/probes/img_step2_dbg.py, RealNVP (1, 24, 24) and (1, 32, 32), B = 64): the fused path lands 2.2e-7 from float64 in one
+        # run and 1.7e-5 / 1.6e-4 in the next (float atomics order the batch sums), the fp32 oracle 1.5e-7 or 6.3e-5 / 1.5e-4, the ATen
+        # module path 1.1e-4 -- every implementation, and every RUN of one, picks its side; the per-step profile below has the same
+        # allowance (KINK_CAP).  3e-2 / B = 4.7e-4 at B = 64, 7e-6 at B = 4096.
+        if rel_gpu > 4.0 * max(rel_ens) + 2.0 * TOL + KINK_FLAT / B:
             bad.append(('flat gradient distance to float64', rel_gpu, max(rel_ens)))
         pg = _step_profile(grads, r64, per_step)
         pe = [_step_profile(m['grads'], r64, per_step) for m in members]
@@ -247,7 +253,7 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         rel = _flat_distance(grads, rec32)
         _report('%-18s %-14s flat gradient distance gpu to cpu32 %.3e (bar: 4 x %.3e measured at the last float64 pass)'
                 % (name, tag, rel, gaps.get('flat', float('nan'))))
-        if 'flat' in gaps and rel > 4.0 * gaps['flat'] + 2.0 * TOL:
+        if 'flat' in gaps and rel > 4.0 * gaps['flat'] + 2.0 * TOL + KINK_FLAT / B:
             bad.append(('flat gradient distance to cpu32', rel, gaps['flat']))
     assert not bad, '%s %s: %d quantities outside their bar, first %s' % (name, tag, len(bad), bad[:6])
 
