@@ -1,7 +1,8 @@
 """
 Model-level asymptotic sweep: the train step of the bench configs at batches far beyond the latency regime --
-Glow on CIFAR-shape batches B = 512, 2048 (8192 samples of 32 x 32 x 3 keep ~ 0.4 GB per saved activation: run on request),
-the 2-D models up to 2^22 rows -- samples/s and, for the image model, the whole-step matrix-pipe and HBM fractions.
+Glow on CIFAR-shape batches B = 512, 2048, 4096 (8192 samples of 32 x 32 x 3 keep ~ 0.27 GB per saved 16 x 16 activation, ~ 10 of them per
+conditioner, 64 such conditioners: past what 288 GB hold next to the 8 x 8 and 4 x 4 levels -- run on request), the 2-D models up to 2^22 rows
+(2^24 rows of a 32-step model keep 24.6 KB per row for the backward: 412 GB) -- samples/s and, for the image model, the whole-step matrix-pipe and HBM fractions.
 
     python tools/model_sweep.py [--big]   > profiles/rNN_model_sweep.txt
 """
@@ -11,10 +12,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RUNS = [('c4', 512, 6), ('c4', 2048, 3), ('c1', 65536, 10), ('c1', 1 << 20, 5), ('c2', 65536, 10), ('c2', 1 << 20, 5), ('c2', 1 << 22, 3),
+RUNS = [('c4', 512, 6), ('c4', 2048, 3), ('c4', 4096, 2), ('c1', 65536, 10), ('c1', 1 << 20, 5), ('c2', 65536, 10), ('c2', 1 << 20, 5), ('c2', 1 << 22, 3),
         ('c3', 1 << 20, 5), ('c5', 1 << 20, 5), ('c5', 1 << 22, 3)]
 if '--big' in sys.argv:
-    RUNS.insert(2, ('c4', 8192, 2))
+    RUNS.insert(3, ('c4', 8192, 2))
 print('%-6s %10s %14s %12s %10s %10s   %s' % ('config', 'batch', 'samples/s', 'ms/step', 'mfma', 'hbm', 'dominant kernel (us per launch)'))
 for cfg, B, steps in RUNS:
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', cfg, '--batch', str(B), '--steps', str(steps), '--warmup', '2',
