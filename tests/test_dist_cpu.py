@@ -391,3 +391,56 @@ def test_trainer_one_graph_path_matches_eager_over_two_ranks():
         assert np.allclose(graph[r][1], eager[r][1], rtol=1e-6, atol=1e-6), (graph[r][1], eager[r][1])
         assert np.allclose(graph[r][2], eager[r][2], rtol=1e-5, atol=1e-6), float(np.abs(graph[r][2] - eager[r][2]).max())
     assert np.array_equal(graph[0][2], graph[1][2]), 'replicas diverged on the one-graph path'
+
+
+# ---- a ONE-rank group sent down the N > 1 control flow (NF_DP_FORCE_COLLECTIVE=1): what tests/test_gpu_rccl.py runs on RCCL ---------------
+def _one_rank_worker(port, q, force, one_graph):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      NF_DP_FORCE_COLLECTIVE='1' if force else '0')
+    nfdist = importlib.import_module(PKG + '.dist')
+    train = importlib.import_module(PKG + '.train')
+    nfdata = importlib.import_module(PKG + '.data')
+    nfdist.init_from_env(backend='gloo')                 # initialises a one-rank group only when forced
+    torch.set_num_threads(2)
+    torch.manual_seed(3)
+    import numpy as np
+    np.random.seed(3)
+    net = _OracleBackedGlow(3).train()
+    tr = train.FlowTrainer(net, lr=1e-3, graph=True, warmup=2, graph_factory=_RerunGraph, one_graph=one_graph)
+    _RerunGraph.trainer = tr
+    y = nfdata.sample('moons', 128, 77)
+    losses = [float(tr.train_on_batch(y + 0.01 * i)[1]) for i in range(5)]
+    params = torch.cat([p.detach().reshape(-1) for p in net.parameters() if p.requires_grad]).numpy().copy()
+    q.put((losses, params, torch.distributed.is_initialized(), tr.bucket.collective, tr._g_fb is not None, tr._g_opt is not None,
+           bool(tr._g_whole)))
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _run_one_rank(force, one_graph=False):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q, force, one_graph))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    return res
+
+
+def test_one_rank_group_takes_the_data_parallel_control_flow_when_forced():
+    """NF_DP_FORCE_COLLECTIVE=1 (dist.GradBucket.collective, dist.init_from_env): a one-rank process group runs graph A, the flat bucket's
+    all-reduce and graph B -- or, with one_graph, the collective inside the one graph -- and, the one-rank all-reduce being the identity,
+    reproduces the plain single-process trainer exactly (CPU: deterministic).  Unforced, one rank initialises no group at all."""
+    import numpy as np
+    plain = _run_one_rank(False)
+    two = _run_one_rank(True)
+    one = _run_one_rank(True, one_graph=True)
+    assert plain[2:] == (False, False, True, False, True)
+    assert two[2:] == (True, True, True, True, False)
+    assert one[2:] == (True, True, True, False, True)
+    for r in (two, one):
+        assert r[0] == plain[0], (r[0], plain[0])
+        assert np.array_equal(r[1], plain[1])
