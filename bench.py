@@ -174,7 +174,8 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
     delay (so the host is ahead of the device and the launches queue back to back, as in the hipGraph replay), with HIP events on the
     launch stream around every launch of the dominant entry point (_native.timed_launches).
       c1      -> nf_realnvp_flow_vec_bwd: k_glow_flow_bwd<2>, the backward of all 32 RealNVP flow steps in one launch (csrc/mlp_chain.hip)
-      c2      -> nf_glow_flow_steps_bwd: 32 x k_mlp_chain_bwd<1> + 1 x k_glow_fold_all per call (average over the 33 launches)
+      c2      -> nf_glow_flow_vec_bwd_deferred: k_glow_flow_bwd<1>, the backward of all 32 Glow flow steps in one launch (+ the one fold launch);
+                 with NF_GLOW_FLOW=steps: nf_glow_flow_steps_bwd, 32 x k_mlp_chain_bwd<1> + 1 x k_glow_fold_all per call (average over the 33)
       c3      -> nf_flowpp_vec_step_bwd: k_flowpp_cond_bwd<2, true> (gated-attention conditioner + mixture coupling, backward)
       c4      -> nf_convnet_chain_bwd at 16 x 16: the data gradient of a whole image conditioner + coupling backward, one persistent launch
       c5      -> nf_maf_step_bwd_partial: k_maf_step_bwd, the backward of a whole MAF flow step
@@ -229,7 +230,7 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
             per_call = 1
             flop = S * 17 * 2 * 32 * 32 * B
             kname = 'k_glow_flow_bwd<%d> (backward of all %d %s flow steps, one launch)' % (1 if glow else 2, S, 'Glow' if glow else 'RealNVP')
-            pmc = ('k_glow_flow_bwd', '')
+            pmc = ('k_glow_flow_bwd', '<1>' if glow else '<2>')      # (C1 and C2 run two instantiations of the same kernel)
             nbytes = S * B * (3 * D + 1) * 4
         match = None
         note = ('neither MFMA- nor HBM-bound at this batch: per flow step six grid-wide (or workgroup-wide) BatchNorm reductions and '

@@ -694,11 +694,14 @@ def glow_step_vec(z, ld, actnorm, conv, coupling):
 # ----------------------------------------------------------------------------------------------------------------------
 # a whole flow of fused vector Glow steps in one launch per direction (csrc/mlp_chain.hip: k_glow_flow_fwd / _bwd)
 # ----------------------------------------------------------------------------------------------------------------------
-# whole-flow launches: 'auto' = batches of at most GLOW_FLOW_AUTO_ROWS rows, where they are a measured win (C2 at B = 512:
-# 1.89 -> 1.78 ms, B = 1024: 1.80 -> 1.72 ms); from 32 workgroups on the in-kernel exchanges get slower than the launch
-# gaps they replace (B = 4096: 1.91 -> 1.94 ms, B = 16384: 3.05 -> 3.66 ms), DESIGN.md section 3.11.  '1' / '0' force it.
+# whole-flow launches: 'auto' = batches of at most GLOW_FLOW_AUTO_ROWS rows, where they are a measured win over the per-step
+# launches with the deferred fold.  Round 3: up to 1024 rows (from 32 workgroups on the in-kernel exchanges were slower than the
+# launch gaps they replace: B = 4096 1.91 -> 1.94 ms).  Round 4, after the whole-flow backward got its next-step loads a step ahead
+# (tools/probes/flow_rows_sweep.sh, profiles/r04_flow_rows_sweep.txt, ms per train step whole-flow | steps): Glow 2-D B = 2048
+# 1.809 | 1.875, 4096 (C2) 1.888 | 1.935, 8192 2.192 | 2.207, 16384 2.820 | 2.780; RealNVP 2-D 2048 1.804 | 1.959, 4096 1.879 | 2.025,
+# 16384 2.880 | 2.936.  DESIGN.md section 3.11.  '1' / '0' / 'steps' force a path.
 GLOW_FLOW = _os.environ.get('NF_GLOW_FLOW', 'auto')
-GLOW_FLOW_AUTO_ROWS = 1024
+GLOW_FLOW_AUTO_ROWS = 8192
 # larger batches: the same run as ONE autograd node of S single-step launches per direction whose backward defers every
 # step's grid barrier + gradient fold to one launch at the end (nf_glow_flow_steps_*; C2 at B = 2048 / 4096 / 16384:
 # 1.77 -> 1.63 / 1.88 -> 1.71 / 3.02 -> 2.50 ms per train step)
