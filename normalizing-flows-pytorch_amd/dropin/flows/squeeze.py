@@ -4,3 +4,12 @@ import importlib
 _pkg = importlib.import_module('normalizing-flows-pytorch_amd')
 Squeeze2d, Unsqueeze2d = _pkg.Squeeze2d, _pkg.Unsqueeze2d
 Squeeze1d, Unsqueeze1d = _pkg.Squeeze1d, _pkg.Unsqueeze1d
+
+
+def __getattr__(name):
+    """Names the engine does not replace (helpers such as flows/squeeze.py's free functions) come from the reference checkout."""
+    from . import reference_module
+    try:
+        return getattr(reference_module('squeeze'), name)
+    except ImportError as e:
+        raise AttributeError('flows.squeeze has no %r in the engine and no reference checkout is reachable (%s)' % (name, e))

@@ -12,6 +12,7 @@ Files (np.savez_compressed, all fp32 unless integer):
   ops.npz         G2-G8, G10  per-layer forward / inverse / log-det / autograd gradients with stub conditioners
   model_<name>.npz G9  small end-to-end models: initial state_dict, input, (z, ld) train+eval, loss, all grads,
                         mutated state, inverse
+  mainloop_<name>.npz G11 main.py's train_on_batch (Adam + StepLR) for 3 steps: per-step batch, z, loss; final state_dict
 """
 import importlib
 import os
@@ -360,15 +361,56 @@ def make_models(only=None):
         np.savez_compressed(os.path.join(HERE, 'model_%s.npz' % name), **out)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+MAINLOOP = [('glow2d', 'Glow', (2, ), '2d', 2, None, 64), ('realnvp2d', 'RealNVP', (2, ), '2d', 2, None, 64),
+            ('glow_img', 'Glow', (3, 16, 16), 'image', 1, None, 4)]
+MAINLOOP_STEPS = 3
+
+
+def make_mainloop():
+    """G11: ``Model.train_on_batch`` of the reference's main.py (:78-92) run for a few steps with main.py's own optimizer set-up
+    (:56-71, configs/default.yaml: Adam lr 1e-4, betas (0.9, 0.999), StepLR) on the reference's classes.  The drop-in test replays it
+    on the shim's classes (dropin/flows) and compares z / loss per step and the final parameters."""
+    for name, cls, dims, datatype, layers, mix, B in MAINLOOP:
+        torch.manual_seed(100)
+        np.random.seed(100)
+        net = getattr(ref, cls)(dims, datatype, NS(layers=layers, mixtures=mix, logdet='exact', spnorm_coeff=0.9))
+        out = {'meta/dims': np.array(dims), 'meta/layers': np.array(layers), 'meta/steps': np.array(MAINLOOP_STEPS)}
+        for k, v in net.state_dict().items():
+            out['sd0/' + k] = npy(v)
+        D = int(np.prod(dims))
+        normal = torch.distributions.MultivariateNormal(torch.zeros(D), torch.eye(D))
+        optim = torch.optim.Adam(net.parameters(), lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0)
+        sched = torch.optim.lr_scheduler.StepLR(optim, step_size=10000, gamma=0.5)
+        net.train()
+        g = gen(202)
+        for s in range(MAINLOOP_STEPS):
+            y = torch.rand((B, ) + dims, generator=g) if datatype == 'image' else torch.randn((B, ) + dims, generator=g) * 0.5
+            z, ld = net(y.contiguous())
+            z = z.view(y.size(0), -1)
+            loss = -1.0 * torch.mean(normal.log_prob(z) + ld)
+            optim.zero_grad()
+            loss.backward()
+            optim.step()
+            sched.step()
+            out['step%d/y' % s], out['step%d/z' % s], out['step%d/loss' % s] = npy(y), npy(z), npy(loss)
+        for k, v in net.state_dict().items():
+            out['sdN/' + k] = npy(v)
+        np.savez_compressed(os.path.join(HERE, 'mainloop_%s.npz' % name), **out)
+
+
 if __name__ == '__main__':
     import warnings
     warnings.filterwarnings('ignore')
-    if len(sys.argv) > 1:                                          # python make_goldens.py realnvp_img flowpp_img: only these models
+    if sys.argv[1:] == ['mainloop']:
+        make_mainloop()
+    elif len(sys.argv) > 1:                                        # python make_goldens.py realnvp_img flowpp_img: only these models
         make_models(set(sys.argv[1:]))
     else:
         make_indexmaps()
         make_ops()
         make_models()
+        make_mainloop()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print('%-24s %8.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
