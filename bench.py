@@ -32,19 +32,24 @@ PKG = 'normalizing-flows-pytorch_amd'
 
 CONFIGS = {
     # name: model class, oracle kind, dims, datatype, layers, mixtures, data, per-GPU batch
-    'c1': dict(cls='RealNVP', kind='realnvp', dims=(2, ), datatype='2d', layers=32, mixtures=None, data='moons', batch=256,
+    # `batch` = per-GPU batch of the weak-scaling runs (the default); `global_batch` = the fixed job batch of --scaling strong (BASELINE.json's
+    # literal figure where it names one: C4 "batch 512 ... over 8", C5 "batch 131072, 8 x"), per GPU = global_batch / N there
+    'c1': dict(cls='RealNVP', kind='realnvp', dims=(2, ), datatype='2d', layers=32, mixtures=None, data='moons', batch=256, global_batch=256,
                desc='RealNVP moons-2D K=32 batch 256', cpu_threads=1),
-    'c2': dict(cls='Glow', kind='glow', dims=(2, ), datatype='2d', layers=32, mixtures=None, data='moons', batch=4096,
+    'c2': dict(cls='Glow', kind='glow', dims=(2, ), datatype='2d', layers=32, mixtures=None, data='moons', batch=4096, global_batch=4096,
                desc='Glow moons-2D K=32 batch 4096 per GPU'),
-    'c3': dict(cls='Flowpp', kind='flowpp', dims=(2, ), datatype='2d', layers=32, mixtures=8, data='circles', batch=65536,
+    'c3': dict(cls='Flowpp', kind='flowpp', dims=(2, ), datatype='2d', layers=32, mixtures=8, data='circles', batch=65536, global_batch=65536,
                desc='Flow++ circles-2D K=32 mixtures=8 batch 65536 per GPU'),
     'c4': dict(cls='Glow', kind='glow', dims=(3, 32, 32), datatype='image', layers=32, mixtures=None, data='cifar',
-               batch=64, desc='Glow CIFAR-shape (3,32,32) L=3 K=32 batch 64 per GPU (512 over 8)', cpu_threads=16),
-    'c5': dict(cls='MAF', kind='maf', dims=(2, ), datatype='2d', layers=10, mixtures=None, data='normals', batch=16384,
+               batch=64, global_batch=512, desc='Glow CIFAR-shape (3,32,32) L=3 K=32 batch 64 per GPU (512 over 8)', cpu_threads=16),
+    'c5': dict(cls='MAF', kind='maf', dims=(2, ), datatype='2d', layers=10, mixtures=None, data='normals', batch=16384, global_batch=131072,
                desc='MAF normals-2D 10 AR layers batch 16384 per GPU (131072 over 8)'),
-    # not a BASELINE.json config: the third model north_star names on CIFAR-shape batches (flows/flowpp.py:17-62), --config fpp_img only
-    'fpp_img': dict(cls='Flowpp', kind='flowpp', dims=(3, 32, 32), datatype='image', layers=2, mixtures=8, data='cifar', batch=64,
-                    desc='Flow++ CIFAR-shape (3,32,32) layers=2 mixtures=8 batch 64 per GPU', cpu_threads=16),
+    # not BASELINE.json configs: the two other models north_star names on CIFAR-shape batches, at the reference's default depth
+    # (configs/default.yaml: network.layers = 32): flows/flowpp.py:17-62 and flows/realnvp.py:17-47.  Measured in the default line under "also"
+    'fpp_img': dict(cls='Flowpp', kind='flowpp', dims=(3, 32, 32), datatype='image', layers=32, mixtures=8, data='cifar', batch=64,
+                    global_batch=512, desc='Flow++ CIFAR-shape (3,32,32) layers=32 mixtures=8 batch 64 per GPU', cpu_threads=16),
+    'rnvp_img': dict(cls='RealNVP', kind='realnvp', dims=(3, 32, 32), datatype='image', layers=32, mixtures=None, data='cifar', batch=64,
+                     global_batch=512, desc='RealNVP CIFAR-shape (3,32,32) layers=32 batch 64 per GPU', cpu_threads=16),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -58,6 +63,9 @@ def parse():
                     help='one workload; default: c4 (Glow CIFAR-10) on the top level + c1 (RealNVP moons) under "also"')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (asymptotic sweeps)')
     ap.add_argument('--layers', type=int, default=None, help='flow steps per level override (e.g. the reference default 32 for fpp_img)')
+    ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
+                    help='weak (default): the per-GPU batch is fixed as N grows; strong: the GLOBAL batch is fixed (C4 512, C5 131072, ...), '
+                         'per GPU = global / N')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--skip-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -126,6 +134,12 @@ def pmc_traffic(kernel, B, contains=''):
     except (OSError, ValueError, IndexError):
         pass
     return None
+
+
+def pmc_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc.json')))
+    return os.path.relpath(files[-1], ROOT) if files else None
 
 
 MFMA_F32_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
@@ -290,6 +304,8 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
     tf = flop / (us * 1e-6) / 1e12
     out = {'bound': 'mfma', 'kernel': kname, 'achieved': round(tf, 3), 'peak': MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(tf / MFMA_F32_TFLOPS, 5), 'traffic': pmc_traffic(pmc[0], B, pmc[1]), 'flop_per_launch': int(flop),
+           'traffic_source': 'rocprofv3 PMC passes of the same train step, committed as %s (separate profiler runs; not measured in this '
+                             'process)' % (pmc_file() or 'profiles/rNN_pmc.json -- none found'),
            'bytes_per_launch': int(nbytes), 'us_per_launch': round(us, 3), 'launches_timed': len(d) * per_call,
            'us_min_max': [round(min(d) / per_call, 2), round(max(d) / per_call, 2)],
            'how': 'HIP events on the launch stream around every %s call of %d eager train steps of the timed trainer (real weights, '
@@ -366,6 +382,21 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
              'threads_note': 'fastest of the per-round thread sweep for this config (profiles/r04_cpu_threads.txt)'}, first)
 
 
+def resolve_batch(cfg, scaling, batch_override, world):
+    """(per-GPU batch, config, strong?) of one workload on `world` ranks.  weak: the per-GPU batch is the config's `batch` whatever N is (the
+    job's batch grows with N); strong: the config's `global_batch` is the JOB's batch and every rank takes global / N rows of it
+    (the minibatch is sharded, no data-path collective; per-replica batch statistics as in DESIGN.md section 5)."""
+    strong = scaling == 'strong'
+    if strong and not batch_override:
+        G = cfg['global_batch']
+        if G % world:
+            raise SystemExit('--scaling strong: the global batch %d does not divide over %d ranks' % (G, world))
+        B = G // world
+        cfg = dict(cfg, desc=cfg['desc'].split(' batch ')[0] + ' GLOBAL batch %d, %d per GPU (strong scaling)' % (G, B))
+        return B, cfg, True
+    return batch_override or cfg['batch'], cfg, strong
+
+
 def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
     """one workload: W warm-up steps, K timed steps (barrier + synchronize on both sides, max over ranks), then on rank 0
     the dominant kernel's roofline, the CPU baseline and the step-1 parity; returns the JSON object (None off rank 0)."""
@@ -375,7 +406,7 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
     cfg = CONFIGS[name]
     if getattr(args, 'layers', None):
         cfg = dict(cfg, layers=args.layers, desc=cfg['desc'] + ' -- measured with layers=%d' % args.layers)
-    B = args.batch or cfg['batch']
+    B, cfg, strong = resolve_batch(cfg, getattr(args, 'scaling', 'weak'), args.batch, world)
 
     torch.manual_seed(0)                                     # identical initial weights on every rank
     np.random.seed(0)
@@ -456,10 +487,22 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
                          'weight gradient) over the fp32-MFMA peak, and SURVEY 8(d)\'s ideal fused traffic over 8 TB/s'}
     elif len(cfg['dims']) == 1:
         per_row = {'glow': 17 * 2 * 32 * 32, 'realnvp': 17 * 2 * 32 * 32, 'maf': 2 * 2 * 3 * (64 * cfg['dims'][0] + 2048)}.get(cfg['kind'])
+        if cfg['kind'] == 'flowpp':
+            # gated-attention conditioner of one coupling (coupling.py:159-166 at one position per sample): Linear(I0,32), the gate (32 -> 64),
+            # the attention's value / output rows that survive (32 -> 32 + 32 -> 64), Linear(32, O); forward + data gradient + weight gradient
+            Dd, Kk = cfg['dims'][0], cfg['mixtures']
+            Oo, Ii = (2 + 3 * Kk) * (Dd - Dd // 2), Dd // 2
+            per_row = 3 * 2 * (32 * Ii + 2048 + 1024 + 2048 + 32 * Oo)
         if per_row is not None:
             flops = per_row * B * cfg['layers']
             whole = {'flop_per_step': int(flops), 'mfma_tflops': round(flops / (ms_step * 1e-3) / 1e12, 3),
                      'mfma_frac': round(flops / (ms_step * 1e-3) / 1e12 / MFMA_F32_TFLOPS, 5)}
+            if cfg['kind'] == 'flowpp':
+                # the mixture coupling itself is transcendental VALU work on (2 + 3K) parameters per element: its HBM side (SURVEY 8(d):
+                # parameters read once per direction, 4 B each, three passes) is the larger roof fraction of this config
+                nb = 3 * 4 * (Oo + 4 * Dd) * B * cfg['layers']
+                whole.update({'hbm_bytes_per_step': int(nb), 'hbm_gbs': round(nb / (ms_step * 1e-3) / 1e9, 2),
+                              'hbm_frac': round(nb / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
     out = {
         'metric': 'samples/sec (train step: forward flow + log-det + NLL + backward + Adam)',
         'value': round(B * world * steps / elapsed, 1),
@@ -472,12 +515,12 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
         'ms_per_step_event_min': round(ev_min, 4),
         'samples_per_s_event_median': round(B * world / (ev_median * 1e-3), 1),
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if strong else 'weak',
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic (seeded %s restatement, random-init weights)' % cfg['data'],
         'config': {'workload': cfg['desc'] if not args.batch else cfg['desc'] + ' -- measured at per-GPU batch %d' % B, 'name': name, 'per_gpu_batch': B, 'global_batch': B * world,
-                   'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None, 'dp_one_graph': bool(getattr(trainer, '_g_whole', False)) and trainer.bucket.collective, 'collective': collective_info(world)},
+                   'scaling': 'strong (global batch fixed, per GPU = global / N)' if strong else 'weak (per-GPU batch fixed)', 'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None, 'dp_one_graph': bool(getattr(trainer, '_g_whole', False)) and trainer.bucket.collective, 'collective': collective_info(world)},
         'loss_nats': round(loss_val, 5),
         'bits_per_dim': round(nftrain.bits_per_dim(loss_val, cfg['dims']), 5),
         'forward_samples_per_s': round(B * world / (fwd_ms * 1e-3), 1),
@@ -504,6 +547,22 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
     del trainer, net
     torch.cuda.empty_cache()
     return out
+
+
+def summary_of(out):
+    """the LAST key of the line: one short row per measured workload -- [samples/s, ms per step, roofline fraction of the dominant kernel,
+    whole-step fp32-MFMA fraction, CPU baseline samples/s, |dloss| per dim at step 1, max |dz| at step 1] -- so that a record which keeps only
+    the end of the line still holds every workload's numbers (the full objects are under "also")."""
+    def row(o):
+        if not o:
+            return None
+        r, w, c, p = o.get('roofline') or {}, o.get('whole_step') or {}, o.get('cpu_baseline') or {}, o.get('parity') or {}
+        return [o['value'], o['ms_per_step'], r.get('frac'), w.get('mfma_frac'), c.get('value'), p.get('abs_dloss_per_dim'), p.get('max_abs_dz')]
+    rows = {out['config']['name']: row(out)}
+    for k, o in (out.get('also') or {}).items():
+        rows[k] = row(o)
+    return {'columns': ['samples_per_s', 'ms_per_step', 'roofline_frac', 'whole_step_mfma_frac', 'cpu_samples_per_s', 'dloss_per_dim', 'max_abs_dz'],
+            'rows': rows}
 
 
 def collective_info(world):
@@ -583,7 +642,7 @@ def main():
         # config 4's literal batch (512) on ONE GPU: informational -- the 4 x 4 level runs the persistent chain, the 8 x 8 and 16 x 16
         # levels exceed its co-residency limit at this batch and run one launch per layer (single-GPU runs only: the DP runs shard 512)
         b512 = None
-        if world == 1:
+        if world == 1 and args.scaling == 'weak':                # (--scaling strong at N = 1 IS this workload: the top level of the line)
             args.batch = 512
             b512 = run_workload('c4', args, pkg, rank, world, dev, min(args.steps, 8), args.warmup, min(args.cpu_seconds, 12.0))
             args.batch = None
@@ -591,11 +650,16 @@ def main():
         more = {}
         for extra_cfg in ('c2', 'c3', 'c5'):
             more[extra_cfg] = run_workload(extra_cfg, args, pkg, rank, world, dev, max(args.steps, 200), args.warmup, min(args.cpu_seconds, 5.0))
+        # row (g): the two other models north_star names on CIFAR-shape batches, at the reference's default depth (layers = 32)
+        for extra_cfg in ('rnvp_img', 'fpp_img'):
+            more[extra_cfg] = run_workload(extra_cfg, args, pkg, rank, world, dev, min(args.steps, 10), args.warmup, min(args.cpu_seconds, 8.0))
         if rank == 0:
             out['also'] = {'c1': also}
             out['also'].update(more)
             if b512 is not None:
                 out['also']['c4_b512'] = b512
+    if rank == 0:
+        out['summary'] = summary_of(out)
     if world > 1 or torch.distributed.is_initialized():   # (initialised at one rank: NF_DP_FORCE_COLLECTIVE=1, the DP control flow on one GPU)
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -206,3 +206,35 @@ def test_bench_stdout_carries_only_the_json_line(tmp_path):
     merged = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300).stdout
     lines = [ln for ln in merged.splitlines() if ln.strip()]
     assert lines.index('{"ok": 1}') > lines.index('banner from C stdio')        # buffered C output is flushed BEFORE the line
+
+
+def test_bench_scaling_modes_resolve_the_per_gpu_batch():
+    """bench.py --scaling: weak keeps the per-GPU batch whatever N is, strong keeps the GLOBAL batch (C4: the literal 512 of BASELINE.json,
+    C5: 131072) and gives every rank global / N rows; both report what they did in the config object."""
+    import importlib.util
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for n in (1, 2, 4, 8):
+        B, cfg, strong = b.resolve_batch(b.CONFIGS['c4'], 'weak', None, n)
+        assert (B, strong) == (64, False) and cfg is b.CONFIGS['c4']
+        B, cfg, strong = b.resolve_batch(b.CONFIGS['c4'], 'strong', None, n)
+        assert (B, strong) == (512 // n, True) and 'GLOBAL batch 512' in cfg['desc'] and '%d per GPU' % (512 // n) in cfg['desc']
+        B, _, _ = b.resolve_batch(b.CONFIGS['c5'], 'strong', None, n)
+        assert B * n == 131072
+        B, _, _ = b.resolve_batch(b.CONFIGS['c5'], 'weak', None, n)
+        assert B == 16384
+    assert b.resolve_batch(b.CONFIGS['c1'], 'strong', None, 8)[0] == 32
+    with pytest.raises(SystemExit):
+        b.resolve_batch(b.CONFIGS['c1'], 'strong', None, 3)
+    assert b.resolve_batch(b.CONFIGS['c4'], 'strong', 128, 2)[0] == 128                 # an explicit --batch is always the per-GPU batch
+    # the bench configs north_star's model list asks for beyond BASELINE.json's five: both image stacks at the reference's default depth
+    assert b.CONFIGS['rnvp_img']['layers'] == 32 and b.CONFIGS['fpp_img']['layers'] == 32
+    # the summary (last key of the line) has one row per workload
+    o = {'value': 1.0, 'ms_per_step': 2.0, 'config': {'name': 'c4'}, 'roofline': {'frac': 0.1}, 'whole_step': None, 'cpu_baseline': {'value': 3.0},
+         'parity': {'abs_dloss_per_dim': 1e-7, 'max_abs_dz': 1e-4}}
+    o['also'] = {'c1': dict(o, config={'name': 'c1'})}
+    s = b.summary_of(o)
+    assert set(s['rows']) == {'c4', 'c1'} and s['rows']['c4'] == [1.0, 2.0, 0.1, None, 3.0, 1e-7, 1e-4] and len(s['columns']) == 7
