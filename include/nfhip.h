@@ -916,6 +916,16 @@ int nf_persistent_timeouts(int* count);
  * (_native.call and FlowTrainer.train_on_batch raise when it is non-zero).                                                */
 int nf_persistent_config(int64_t spin_limit, int reset, void** host_error_word);
 
+/* Deterministic mode (csrc/nf_det.h; main.py:308-311 has the reference's switch).  on != 0: every batch sum that meets at one address
+ * through float atomics -- per-sample log-dets of slab kernels, per-channel statistics and parameter gradients of the layerwise kernels,
+ * the folds of the persistent kernels -- is added in a FIXED order (workgroups in linear block order through a turnstile, waves in wave
+ * order inside one), so that two runs of a launch from identical inputs are bit-identical.  A verification mode: the ordered tails
+ * serialise (~1 us per workgroup).  Synchronises the device.  The Python binding calls it with 1 when NF_DETERMINISTIC=1.
+ * nf_deterministic_timeouts: turnstile waits that gave up (must be 0; a non-zero count means a launch finished unordered).          */
+int nf_deterministic(int on);
+int nf_deterministic_enabled(void);
+int nf_deterministic_timeouts(int* count);
+
 /* Launch-time residency check: how many workgroups of the largest persistent kernel of the MLP-chain family / the MAF-step
  * family the current device holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units).  The host side
  * keeps grids within it (min with NF_MLP_MAX_BLOCKS / NF_MAF_MAX_BLOCKS), else it takes the multi-launch path.           */

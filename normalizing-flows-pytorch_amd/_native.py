@@ -138,7 +138,41 @@ def _arm_device():
         if rc != 0:
             raise NativeLibraryError('nf_persistent_config failed with code %d on device %d' % (rc, dev))
         _err_word = ctypes.c_uint.from_address(p.value)     # ONE pinned, portable host word shared by all devices
+        if _det:
+            rc = load().nf_deterministic(1)                  # (device globals as well: per device)
+            if rc != 0:
+                raise NativeLibraryError('nf_deterministic failed with code %d on device %d' % (rc, dev))
         _armed.add(dev)
+
+
+_det = os.environ.get('NF_DETERMINISTIC', '0') == '1'   # deterministic mode wanted (applied to every device when it is armed)
+
+
+def deterministic(on=None):
+    """deterministic mode of the kernels (csrc/nf_det.h, include/nfhip.h:nf_deterministic): batch sums that meet at one address by
+    float atomics are added in a fixed order, two runs from identical inputs are bit-identical.  ``deterministic()`` returns the
+    current setting, ``deterministic(True / False)`` switches it (synchronises the device).  NF_DETERMINISTIC=1 switches it on at
+    start-up.  A verification mode: the ordered tails of the kernels serialise."""
+    global _det
+    if on is None:
+        return _det
+    _det = bool(on)
+    if torch.cuda.is_available():
+        for dev in sorted(_armed):
+            with torch.cuda.device(dev):
+                rc = load().nf_deterministic(1 if _det else 0)
+                if rc != 0:
+                    raise NativeLibraryError('nf_deterministic failed with code %d on device %d' % (rc, dev))
+    return _det
+
+
+def deterministic_timeouts():
+    """turnstile waits of the deterministic mode that gave up (must be 0); synchronises the device."""
+    v = ctypes.c_int(0)
+    rc = load().nf_deterministic_timeouts(ctypes.byref(v))
+    if rc != 0:
+        raise NativeLibraryError('nf_deterministic_timeouts failed with code %d' % rc)
+    return int(v.value)
 
 
 def _error_word():

@@ -6,6 +6,10 @@
 // block, chosen so that the operation ORDER is the reference's (division where it divides, multiply where it
 // multiplies) -- keeps us within an ulp of the CPU path instead of relying on the 1e-5 budget.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_ca)
+NF_DET_HOST_API(nf_ca)
 
 struct NfCoef { float A, D, M, S; };
 
@@ -112,6 +116,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd(int op, const floa
     const float R2 = nf_block_sum(r2, scratch);
     const float SG = nf_block_sum(sg, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_ca);      // (one thread per workgroup adds; the blocks of a channel meet in block order when the mode is on)
         if (op == NF_ACTNORM) {   // g_log_scale = -sum g*y - P*sum g_ld ; g_bias = -sum g / exp(log_scale)
             atomicAdd(g_pa + c, -R2 - (float)P * SG);
             atomicAdd(g_pb + c, -R1 / k.D);
@@ -119,6 +124,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd(int op, const floa
             atomicAdd(g_pa + c, R2 + (float)P * SG);
             atomicAdd(g_pb + c, R1);
         }
+        NF_DET_LEAVE(nf_ca);
     }
 }
 
@@ -138,7 +144,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_stat(const float* __restrict_
         acc += SQDEV ? v * v : v;
     }
     const float tot = nf_block_sum(acc, scratch);
-    if (threadIdx.x == 0) atomicAdd(out + c, tot);
+    if (threadIdx.x == 0) { NF_DET_ENTER(nf_ca); atomicAdd(out + c, tot); NF_DET_LEAVE(nf_ca); }
 }
 
 __global__ void k_flowbn_finalize(const float* __restrict__ sum, const float* __restrict__ sqdev,
@@ -264,6 +270,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd_img(int op, const 
     const float R2 = nf_block_sum(r2, scratch);
     const float SG = nf_block_sum(sg, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_ca);
         if (op == NF_ACTNORM) {
             atomicAdd(g_pa + c, -R2 - (float)P * SG);
             atomicAdd(g_pb + c, -R1 / k.D);
@@ -271,6 +278,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd_img(int op, const 
             atomicAdd(g_pa + c, R2 + (float)P * SG);
             atomicAdd(g_pb + c, R1);
         }
+        NF_DET_LEAVE(nf_ca);
     }
 }
 
@@ -303,6 +311,8 @@ __global__ void __launch_bounds__(NF_BIG) k_chan_affine_bwd_row(int op, const fl
     float sg = 0.f;
     for (int64_t b = gtid; b < B; b += gstride) sg += gld[b];
     const float SG = nf_block_sum(sg, scratch);
+    const bool det = nf_det_on(nf_ca_det);           // thread 0 adds for the workgroup: it holds the turn across the C channels
+    if (det && threadIdx.x == 0) nf_det_wait(nf_ca_det);
     for (int c = 0; c < C; ++c) {                    // component j belongs to channel j % C
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -321,6 +331,7 @@ __global__ void __launch_bounds__(NF_BIG) k_chan_affine_bwd_row(int op, const fl
             }
         }
     }
+    if (det && threadIdx.x == 0) nf_det_pass(nf_ca_det);
 }
 
 // statistics, vectorised.  IMG: block (c, chunk) over the channel's float4 items; ROW: all channels per block.
@@ -345,7 +356,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_stat_img(const float4* __rest
         acc1 += SQDEV ? (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3) : (c0 + c1) + (c2 + c3);
     }
     const float tot = nf_block_sum(acc0 + acc1, scratch);
-    if (threadIdx.x == 0) atomicAdd(out + c, tot);
+    if (threadIdx.x == 0) { NF_DET_ENTER(nf_ca); atomicAdd(out + c, tot); NF_DET_LEAVE(nf_ca); }
 }
 template <bool SQDEV>
 __global__ void __launch_bounds__(NF_BIG) k_chan_stat_row(const float4* __restrict__ x, const float* __restrict__ sum,
@@ -360,6 +371,8 @@ __global__ void __launch_bounds__(NF_BIG) k_chan_stat_row(const float4* __restri
         const float d0 = v.x - mean[0], d1 = v.y - mean[1], d2 = v.z - mean[2], d3 = v.w - mean[3];
         acc[0] += SQDEV ? d0 * d0 : d0; acc[1] += SQDEV ? d1 * d1 : d1; acc[2] += SQDEV ? d2 * d2 : d2; acc[3] += SQDEV ? d3 * d3 : d3;
     }
+    const bool det = nf_det_on(nf_ca_det);
+    if (det && threadIdx.x == 0) nf_det_wait(nf_ca_det);
     for (int c = 0; c < C; ++c) {
         float a = 0.f;
 #pragma unroll
@@ -368,6 +381,7 @@ __global__ void __launch_bounds__(NF_BIG) k_chan_stat_row(const float4* __restri
         const float tot = nf_block_sum(a, scratch);
         if (threadIdx.x == 0) atomicAdd(out + c, tot);
     }
+    if (det && threadIdx.x == 0) nf_det_pass(nf_ca_det);
 }
 
 static inline bool nf_al16(const void* a, const void* b = nullptr, const void* c = nullptr) {

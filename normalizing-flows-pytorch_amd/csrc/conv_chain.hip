@@ -20,6 +20,10 @@
 #include <mutex>
 #include <unordered_set>
 #include "nf_conv_core.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_ccd)
+NF_DET_HOST_API(nf_ccd)
 #include "nf_bf16x3.h"
 
 #define NF_CC_NL 6
@@ -1298,8 +1302,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
         if (cpl && l == NF_CC_NB - 1 && threadIdx.x == 0) {
             float ta = 0.f, tc = 0.f;
             for (int k = 0; k < NF_CV_WAVES; ++k) { ta += red[k]; tc += red[NF_CV_WAVES + k]; }
+            // (deterministic mode: the workgroups add in block order.  Safe inside the persistent loop: a workgroup with a smaller
+            // index needs nothing from this one to get here -- every grid exchange before this point has been published by all)
+            NF_DET_ENTER(nf_ccd);
             atomicAdd(d.cp_g_a, ta);
             atomicAdd(d.cp_g_c, tc);
+            NF_DET_LEAVE(nf_ccd);
         }
         nf_cc_ksplit_exchange<NKQ>(own, acc, RS, pb, kq, lane);
         NF_CC_STAMP(67 + 6 * (4 - l));

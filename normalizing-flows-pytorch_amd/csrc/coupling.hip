@@ -8,6 +8,10 @@
 //   slab : images -> grid (sample, slab); 256 threads stride over a slab of the sample's half tensor; the
 //          per-sample sum(s) is a wave64 shuffle + LDS reduction and ONE write (or one atomic when slabs > 1).
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_cpl)
+NF_DET_HOST_API(nf_cpl)
 
 #define NF_ROWS_MAX 16
 #define NF_SLAB 2048
@@ -76,7 +80,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_slab_fwd(const float* __res
     if (threadIdx.x == 0) {
         const float d = INVERSE ? -tot : tot;
         if (gridDim.y == 1) ld[b] += d;
-        else atomicAdd(ld + b, d);
+        else { NF_DET_ENTER(nf_cpl); atomicAdd(ld + b, d); NF_DET_LEAVE(nf_cpl); }
     }
 }
 
@@ -124,8 +128,10 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_rows_bwd(const float* __res
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_cpl);
         atomicAdd(g_scale, ta);
         atomicAdd(g_bias, tc);
+        NF_DET_LEAVE(nf_cpl);
     }
 }
 
@@ -164,8 +170,10 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_slab_bwd(const float* __res
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_cpl);
         atomicAdd(g_scale, ta);
         atomicAdd(g_bias, tc);
+        NF_DET_LEAVE(nf_cpl);
     }
 }
 
@@ -248,7 +256,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_img_fwd(const float* __rest
     if (threadIdx.x == 0) {
         const float dd = INVERSE ? -tot : tot;
         if (gridDim.y == 1) ld[b] += dd;
-        else atomicAdd(ld + b, dd);
+        else { NF_DET_ENTER(nf_cpl); atomicAdd(ld + b, dd); NF_DET_LEAVE(nf_cpl); }
     }
 }
 
@@ -326,8 +334,10 @@ __global__ void __launch_bounds__(NF_BIG) k_affine_img_bwd(const float* __restri
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_cpl);
         atomicAdd(g_scale, ta);
         atomicAdd(g_bias, tc);
+        NF_DET_LEAVE(nf_cpl);
     }
 }
 
@@ -379,8 +389,10 @@ __global__ void __launch_bounds__(NF_BIG) k_affine_d2_bwd(const float4* __restri
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_cpl);
         atomicAdd(g_scale, ta);
         atomicAdd(g_bias, tc);
+        NF_DET_LEAVE(nf_cpl);
     }
 }
 

@@ -8,6 +8,10 @@
 // 2 launches instead of 6 (sum, sqdev, finalize, apply, zero-fill, gather); backward (affine=False: statistics are
 // constants for autograd) = scale + scatter-add of the conditioner-input gradient in 1 launch instead of 3.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_fbh)
+NF_DET_HOST_API(nf_fbh)
 
 __global__ void __launch_bounds__(NF_BLOCK) k_flowbn_stats(const float* __restrict__ x, const float* __restrict__ center,
                                                            float* __restrict__ ws, int64_t B, int C, int P,
@@ -28,8 +32,10 @@ __global__ void __launch_bounds__(NF_BLOCK) k_flowbn_stats(const float* __restri
     const float t1 = nf_block_sum(s1, scratch);
     const float t2 = nf_block_sum(s2, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_fbh);
         atomicAdd(ws + c, t1);
         atomicAdd(ws + C + c, t2);
+        NF_DET_LEAVE(nf_fbh);
         if (blockIdx.y == 0) ws[2 * C + c] = k;       // the centre that was used (running_mean changes in the next launch)
     }
 }

@@ -21,6 +21,10 @@
 #include <type_traits>
 
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_fpc)
+NF_DET_HOST_API(nf_fpc)
 #include "nf_mfma16.h"
 #include "nf_mixlog_oct.h"
 
@@ -865,9 +869,12 @@ __device__ __forceinline__ void nf_fpp_finalize_body(const float* __restrict__ s
     for (int k = 0; k < 16; ++k) s += p[k];
     red[grp][el] = s;
     __syncthreads();
-    if (grp != 0 || blockIdx.y * 64 >= nblk) return;
+    if (grp != 0) return;                                 // wave 0 adds for the workgroup: one lane per slab entry (deterministic mode: the
+    NF_DET_ENTER_WAVE(nf_fpc);                            // workgroups of the four slab quarters -- and of every step of a multi launch -- in block order)
+    const bool live = blockIdx.y * 64 < nblk;
     s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-    if (e < NF_S_W2) { if ((e >> 5) < O) atomicAdd(gr.g_W5 + e, s); }
+    if (!live) {}
+    else if (e < NF_S_W2) { if ((e >> 5) < O) atomicAdd(gr.g_W5 + e, s); }
     else if (e < NF_S_WQ) atomicAdd(gr.g_W2 + e - NF_S_W2, s);
     else if (e < NF_S_WG) atomicAdd(gr.g_Wq + e - NF_S_WQ, s);
     else if (e < NF_S_W0) atomicAdd(gr.g_Wg + e - NF_S_WG, s);
@@ -894,6 +901,7 @@ __device__ __forceinline__ void nf_fpp_finalize_body(const float* __restrict__ s
             else { atomicAdd(mx.g_nls + o0, -s); atomicAdd(mx.g_nls + o1, -s); }
         }
     }
+    NF_DET_LEAVE_WAVE(nf_fpc);
 }
 
 __global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,

@@ -21,6 +21,10 @@
 #include <unordered_set>
 
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_fpi)
+NF_DET_HOST_API(nf_fpi)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -652,6 +656,9 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
     }
 
     // ================================================= backward =================================================
+    // parameter gradients are added straight into their buffers, one thread (LayerNorm / position parameters) or one wave (the 1 x 1
+    // convolutions' blocks) of the workgroup per address: deterministic mode takes the samples' workgroups one after the other
+    NF_DET_ENTER_ALL(nf_fpi);
     float g3[8];                                         // gradient of x3 (= of the attention block's residual input and of y * sg)
     {
         float gh[8], s1 = 0.f, s2 = 0.f;
@@ -807,6 +814,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
             }
         }
     }
+    NF_DET_LEAVE_ALL(nf_fpi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

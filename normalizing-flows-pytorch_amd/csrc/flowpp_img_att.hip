@@ -9,6 +9,10 @@
 // Same arithmetic per element as k_fi_mid (the per-sample LayerNorm statistics are summed in a different order: rounding only); every
 // kernel recomputes what it needs from x and a, the only tensors carried from the forward to the backward are `mixed` and c_j.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_fpa)
+NF_DET_HOST_API(nf_fpa)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -296,7 +300,11 @@ __global__ void __launch_bounds__(4 * N) k_fi_att_bwd(NfFiAtt m) {
         for (int d = 0; d < 8; ++d) m.gt_part[((b * 4 + h) * 32 + 8 * qz + d) * N + j] = gt[d];
     }
     __syncthreads();
-    if (threadIdx.x < 64) nf_fa_pair_head<N>(GP, TP, m.g_w1, m.g_b1, h);
+    if (threadIdx.x < 64) {                // wave 0 adds this (sample, head)'s block: the workgroups in block order in deterministic mode
+        NF_DET_ENTER_WAVE(nf_fpa);
+        nf_fa_pair_head<N>(GP, TP, m.g_w1, m.g_b1, h);
+        NF_DET_LEAVE_WAVE(nf_fpa);
+    }
 }
 
 // ---- per sample, thread = (head h, position j) owning channels 8 h .. 8 h + 7 of position j ----------------------------------------------
@@ -392,6 +400,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_post(NfFiAtt m) {
         for (int d = 0; d < 8; ++d) m.out[base + d * N] = xh2[d] * m.ln2g[pbase + d * N] + m.ln2b[pbase + d * N];
         return;
     }
+    NF_DET_ENTER_ALL(nf_fpa);              // (one thread / one wave of the workgroup per address; the samples' workgroups in block order)
     float g3[8];
     {
         float gh[8], s1 = 0.f, s2 = 0.f;
@@ -467,6 +476,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_post(NfFiAtt m) {
     }
 #pragma unroll
     for (int d = 0; d < 8; ++d) m.g_mixed[base + d * N] = gm[d];
+    NF_DET_LEAVE_ALL(nf_fpa);
 }
 
 template <int N>
@@ -482,6 +492,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_pre_bwd(NfFiAtt m) {
     NfFaS<N> st;
     st.run(m, base, pbase, scr, xh1, x2);
     float gh[8], s1 = 0.f, s2 = 0.f;
+    NF_DET_ENTER_ALL(nf_fpa);
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         float gt = 0.f;
@@ -510,6 +521,7 @@ __global__ void __launch_bounds__(4 * N) k_fi_pre_bwd(NfFiAtt m) {
         m.g_x[base + d * N] = gu;
         m.g_a[base + d * N] = gu * (nf_fa_elu_grad(av) * s2_ - e1 * s2_ * (1.f - s2_) * nf_fa_elu_grad(-av));
     }
+    NF_DET_LEAVE_ALL(nf_fpa);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

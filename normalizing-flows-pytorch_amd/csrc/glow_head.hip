@@ -5,6 +5,10 @@
 //   reduction) in ONE launch followed by the PLU backward.  At these sizes every launch is pure latency (~4 us for a
 //   131 KB problem), so the four launches forward / seven backward this replaces are the cost.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_gh)
+NF_DET_HOST_API(nf_gh)
 
 #define NF_HEAD_MAXC 4
 
@@ -190,6 +194,7 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
         }
     }
     __syncthreads();
+    NF_DET_ENTER_ALL(nf_gh);               // (thread i of the workgroup owns value i)
     if (threadIdx.x < NV) {
         const int i = threadIdx.x;
         const int nw = (blockDim.x + NF_WAVE - 1) >> 6;
@@ -204,6 +209,7 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
             else atomicAdd(gW + r * CT + (k - 2), t);
         }
     }
+    NF_DET_LEAVE_ALL(nf_gh);
 }
 
 extern "C" int nf_glow_head_fwd(const float* z, const float* log_scale, const float* bias, const float* P,

@@ -9,6 +9,10 @@
 //              the pixels),  g_a = W^T g_h,  g_x = g_a / exp(log_scale),  g_log_scale -= sum g_a a (+ P sum g_ld),
 //              g_bias -= sum g_a / exp(log_scale)
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_ghm)
+NF_DET_HOST_API(nf_ghm)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -409,6 +413,7 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
             for (int e = 0; e < 4; ++e)              // D: row = 4 lk + e (r), col = li (c)
                 red[(wid * CP + 16 * i + 4 * lk + e) * CP + 16 * j + li] = acc[i][j][e];
     __syncthreads();
+    NF_DET_ENTER_ALL(nf_ghm);              // (one thread per entry / channel and workgroup; the turn is held over both groups of sums)
     for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
         const int r = e / C, c = e - r * C;
         const float t = red[(0 * CP + r) * CP + c] + red[(1 * CP + r) * CP + c] + red[(2 * CP + r) * CP + c] +
@@ -447,6 +452,7 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
         atomicAdd(g_ls + c, -R2 - (float)P * SG);        // modules.py:246-249 differentiated
         atomicAdd(g_b + c, -R1 * cst[CP + c]);
     }
+    NF_DET_LEAVE_ALL(nf_ghm);
     NF_GH_STAMP(14);
 }
 

@@ -5,6 +5,10 @@
 // read through wave-uniform addresses, so the compiler keeps it on the scalar path (s_load -> SGPR operands of
 // v_fmac) and the vector memory pipe carries only z and y, coalesced along the pixel axis of NCHW.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_ic)
+NF_DET_HOST_API(nf_ic)
 
 template <int CT, bool TRANSPOSE>
 __global__ void __launch_bounds__(NF_BLOCK) k_invconv_apply(const float* __restrict__ z, const float* __restrict__ M,
@@ -110,11 +114,13 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad(const float* __restr
             }
         }
     }
+    NF_DET_ENTER_ALL(nf_ic);               // (one thread per entry and workgroup)
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
         const int e = threadIdx.x + k * NF_BLOCK;
         if (e < n_ent) atomicAdd(gM + e, acc[k]);
     }
+    NF_DET_LEAVE_ALL(nf_ic);
 }
 
 // small C (<= 4): every thread keeps the whole C x C partial in registers, one block reduction + C*C atomics per block.
@@ -152,7 +158,7 @@ __global__ void __launch_bounds__(NF_IW_BIG) k_invconv_wgrad_small(const float* 
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const float t = nf_block_sum(acc[r][c], scratch);
-            if (threadIdx.x == 0) atomicAdd(gM + r * CT + c, t);
+            if (threadIdx.x == 0) { NF_DET_ENTER(nf_ic); atomicAdd(gM + r * CT + c, t); NF_DET_LEAVE(nf_ic); }
         }
 }
 

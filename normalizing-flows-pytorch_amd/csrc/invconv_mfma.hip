@@ -7,6 +7,10 @@
 // kernel spends its time on 2304 scalar-operand FMAs + s_loads per pixel at C = 48 (1.1 TB/s), the MFMA form leaves the
 // kernel HBM-bound (8 B/element).
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_icm)
+NF_DET_HOST_API(nf_icm)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -215,12 +219,14 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_wgrad_mfma(const float* __
             for (int e = 0; e < 4; ++e)              // D: row = 4 lk + e (r), col = li (c)
                 red[(wid * CP + 16 * i + 4 * lk + e) * CP + 16 * j + li] = acc[i][j][e];
     __syncthreads();
+    NF_DET_ENTER_ALL(nf_icm);              // (one thread per entry and workgroup)
     for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
         const int r = e / C, c = e - r * C;
         const float t = red[(0 * CP + r) * CP + c] + red[(1 * CP + r) * CP + c] + red[(2 * CP + r) * CP + c] +
                         red[(3 * CP + r) * CP + c];
         atomicAdd(gM + e, t);
     }
+    NF_DET_LEAVE_ALL(nf_icm);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

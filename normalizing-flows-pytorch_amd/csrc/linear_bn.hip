@@ -11,6 +11,10 @@
 // At the sizes of the reference models these launches are latency-bound (a 4096 x 32 x 32 layer is 8 MFLOP); the win
 // is the launch count and the removed HBM round trips of the intermediate tensors.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_lb)
+NF_DET_HOST_API(nf_lb)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -168,13 +172,17 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_fwd(NfLinAr
         s2 += __shfl_xor(s2, 32, NF_WAVE);
         if (hs == 0) { red[0][wid][o] = s1; red[1][wid][o] = s2; }
         __syncthreads();
-        if (wid == 0 && hs == 0 && o < O) {
-            float t1 = 0.f, t2 = 0.f;
+        if (wid == 0) {
+            NF_DET_ENTER_WAVE(nf_lb);                          // (wave 0 adds for the workgroup, one lane per feature)
+            if (hs == 0 && o < O) {
+                float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < NF_LB_WAVES; ++w) { t1 += red[0][w][o]; t2 += red[1][w][o]; }
-            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
-            atomicAdd(d.stat_sum + rep + o, t1);
-            atomicAdd(d.stat_sqsum + rep + o, t2);
+                for (int w = 0; w < NF_LB_WAVES; ++w) { t1 += red[0][w][o]; t2 += red[1][w][o]; }
+                const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+                atomicAdd(d.stat_sum + rep + o, t1);
+                atomicAdd(d.stat_sqsum + rep + o, t2);
+            }
+            NF_DET_LEAVE_WAVE(nf_lb);
         }
     }
 }
@@ -395,16 +403,20 @@ __global__ void __launch_bounds__(NF_LB_WAVES * NF_WAVE) k_linear_bn_bwd(NfLinBw
             d.g_weff[((int64_t)blockIdx.x * O + oo) * I + ii] = t;       // this workgroup's slab (no atomics, no zero-fill)
         }
     }
-    if (wid == 0 && hs == 0) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    if (wid == 0) {
+        NF_DET_ENTER_WAVE(nf_lb);                              // (wave 0 adds for the workgroup, one lane per feature)
+        if (hs == 0) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < NF_LB_WAVES; ++w) { t0 += red[0][w][c32]; t1 += red[1][w][c32]; t2 += red[2][w][c32]; }
-        const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
-        if (c32 < O && d.g_bias != nullptr) atomicAdd(d.g_bias + rep + c32, t0);
-        if (has_bn && c32 < I && d.sum_g != nullptr) {
-            atomicAdd(d.sum_g + rep + c32, t1);
-            atomicAdd(d.sum_gx + rep + c32, t2);
+            for (int w = 0; w < NF_LB_WAVES; ++w) { t0 += red[0][w][c32]; t1 += red[1][w][c32]; t2 += red[2][w][c32]; }
+            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+            if (c32 < O && d.g_bias != nullptr) atomicAdd(d.g_bias + rep + c32, t0);
+            if (has_bn && c32 < I && d.sum_g != nullptr) {
+                atomicAdd(d.sum_g + rep + c32, t1);
+                atomicAdd(d.sum_gx + rep + c32, t2);
+            }
         }
+        NF_DET_LEAVE_WAVE(nf_lb);
     }
 }
 

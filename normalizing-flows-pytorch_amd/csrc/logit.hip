@@ -1,6 +1,10 @@
 // Logit bijector (flows/modules.py:141-156, helpers :19-32) with the per-sample log-det reduction fused in.
 // HBM-bound, 8 B/element.  forward: clamp -> log(x/(1-x)), ld += sum -(y - 2 softplus(y)); inverse: sigmoid.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_lg)
+NF_DET_HOST_API(nf_lg)
 
 #define NF_LG_SLAB 4096
 
@@ -35,7 +39,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_logit_fwd(const float* __restrict_
     const float tot = nf_block_sum(acc, scratch);
     if (threadIdx.x == 0) {
         if (gridDim.y == 1) ld[b] += tot;
-        else atomicAdd(ld + b, tot);
+        else { NF_DET_ENTER(nf_lg); atomicAdd(ld + b, tot); NF_DET_LEAVE(nf_lg); }
     }
 }
 
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_bijector_fwd(const float* __restri
     const float tot = nf_block_sum(acc, scratch);
     if (threadIdx.x == 0) {
         if (gridDim.y == 1) ld[b] += tot;
-        else atomicAdd(ld + b, tot);
+        else { NF_DET_ENTER(nf_lg); atomicAdd(ld + b, tot); NF_DET_LEAVE(nf_lg); }
     }
 }
 // autograd of the modules' forward directions (kinds 0, 2, 3): g_x = g_y dy/dx + g_ld d(ld term)/dx

@@ -11,6 +11,10 @@
 // Replaces 7 launches forward (statistics, head, rocBLAS permutation matmul, 4 linear+BN launches, transform) and 13
 // backward per flow step; numerics are those of linear_bn.hip / flowbn_head.hip.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_mdc)
+NF_DET_HOST_API(nf_mdc)
 #include "nf_mfma16.h"
 
 #define NF_MD_WAVES (NF_MAF_ROWS_PER_BLOCK / 16)
@@ -887,10 +891,12 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_step_bwd(NfMadeP p, NfMaf
         {
             const int o = threadIdx.x & 31;
             const int G_ = gridDim.x;
-            const int chunk = (G_ + 7) / 8;
+            // deterministic mode: ONE half wave sums all slabs of a column in workgroup order (no eighths that meet by atomics)
+            const int parts = nf_det_on(nf_mdc_det) ? 1 : 8;
+            const int chunk = (G_ + parts - 1) / parts;
             constexpr int HW = NF_MD_THREADS / 32;
-            for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * 8; u += G_ * HW) {
-                const int part = u & 7, uu = u >> 3;
+            for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * parts; u += G_ * HW) {
+                const int part = u % parts, uu = u / parts;
                 const int nl = uu / 33, i = uu - nl * 33;     // i == 32: the bias
                 const int n = nl >> 2, l = nl & 3;
                 const int I = l == 0 ? D : 32, O = l == NF_MD_NL - 1 ? D : 32;
@@ -1056,10 +1062,12 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_fold_all(NfMafFoldArgs ar
     const NfMafFoldStep& st = args.st[blockIdx.y];
     const float* slabs = slabs_all + (size_t)blockIdx.y * G * NF_MD_SLAB;
     const int o = threadIdx.x & 31;
-    const int chunk = (G + NF_MD_FOLD_PARTS - 1) / NF_MD_FOLD_PARTS;
+    // deterministic mode: ONE half wave sums all G slabs of a column in workgroup order (no parts that meet by atomics)
+    const int parts = nf_det_on(nf_mdc_det) ? 1 : NF_MD_FOLD_PARTS;
+    const int chunk = (G + parts - 1) / parts;
     constexpr int HW = NF_MD_THREADS / 32;
-    for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * NF_MD_FOLD_PARTS; u += gridDim.x * HW) {
-        const int part = u % NF_MD_FOLD_PARTS, uu = u / NF_MD_FOLD_PARTS;
+    for (int u = blockIdx.x * HW + (threadIdx.x >> 5); u < 2 * NF_MD_NL * 33 * parts; u += gridDim.x * HW) {
+        const int part = u % parts, uu = u / parts;
         const int nl = uu / 33, i = uu - nl * 33;         // i == 32: the bias
         const int n = nl >> 2, l = nl & 3;
         const int I = l == 0 ? D : 32, O = l == NF_MD_NL - 1 ? D : 32;
@@ -1091,7 +1099,7 @@ __global__ void __launch_bounds__(NF_MD_THREADS) k_maf_fold_all(NfMafFoldArgs ar
         float s0 = 0.f, s1 = 0.f;
         for (int e = threadIdx.x; e < G * NF_MD_WAVES; e += 64) { s0 += r[2 * e]; s1 += r[2 * e + 1]; }
         s0 = nf_wave_sum(s0); s1 = nf_wave_sum(s1);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0) {                           // (one writer per address and launch: += into the gradient, no race)
             atomicAdd(st.g_c, s0);                        // d/d s_bias
             atomicAdd(st.g_a, s1);                        // d/d s_log_scale
         }

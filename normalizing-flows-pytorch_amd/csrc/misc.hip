@@ -2,6 +2,10 @@
 #include <string.h>
 
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_ms)
+NF_DET_HOST_API(nf_ms)
 
 extern "C" int nf_version(void) { return 100; }
 
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_nll_loss(const float* __restrict__
     const float cst = -0.5f * (float)D * 1.8378770664093453f;   // log(2 pi)
     if (gtid == 0) acc += cst * (float)B;
     const float tot = nf_block_sum(acc, scratch);
-    if (threadIdx.x == 0) atomicAdd(loss, -tot / (float)B);
+    if (threadIdx.x == 0) { NF_DET_ENTER(nf_ms); atomicAdd(loss, -tot / (float)B); NF_DET_LEAVE(nf_ms); }
 }
 
 extern "C" int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream) {
@@ -83,5 +87,109 @@ extern "C" int nf_nll_loss_bwd(const float* z, const float* g_loss, float* g_z, 
     hipLaunchKernelGGL(k_nll_loss_bwd, dim3(nf_grid_for(B * D)), dim3(NF_BLOCK), 0, (hipStream_t)stream, z, g_loss, g_z,
                        g_ld, B, D);
     NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// deterministic mode (nf_det.h): the switch reaches every translation unit that orders batch sums by float atomics
+__attribute__((visibility("hidden"))) int nf_ca_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_ca_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_cpl_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_cpl_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_lg_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_lg_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_fbh_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_fbh_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_ic_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_ic_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_icm_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_icm_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_gh_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_gh_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_ghm_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_ghm_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_ml_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_ml_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_lb_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_lb_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_cvb_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_cvb_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_cbk_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_cbk_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_ccd_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_ccd_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_fpc_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_fpc_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_fpi_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_fpi_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_fpa_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_fpa_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_mdc_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_mdc_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_mcd_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_mcd_det_timeouts(unsigned* out);
+__attribute__((visibility("hidden"))) int nf_rsm_det_set(int on);
+__attribute__((visibility("hidden"))) int nf_rsm_det_timeouts(unsigned* out);
+
+static int g_nf_det_on = 0;
+
+extern "C" int nf_deterministic(int on) {
+    // (synchronises: the mode words live in device globals, and a launch in flight must not see the turn reset under it)
+    hipError_t se = hipDeviceSynchronize();
+    if (se != hipSuccess) return (int)se;
+    int e = nf_ms_det_set(on);
+    if (e == 0) e = nf_ca_det_set(on);
+    if (e == 0) e = nf_cpl_det_set(on);
+    if (e == 0) e = nf_lg_det_set(on);
+    if (e == 0) e = nf_fbh_det_set(on);
+    if (e == 0) e = nf_ic_det_set(on);
+    if (e == 0) e = nf_icm_det_set(on);
+    if (e == 0) e = nf_gh_det_set(on);
+    if (e == 0) e = nf_ghm_det_set(on);
+    if (e == 0) e = nf_ml_det_set(on);
+    if (e == 0) e = nf_lb_det_set(on);
+    if (e == 0) e = nf_cvb_det_set(on);
+    if (e == 0) e = nf_cbk_det_set(on);
+    if (e == 0) e = nf_ccd_det_set(on);
+    if (e == 0) e = nf_fpc_det_set(on);
+    if (e == 0) e = nf_fpi_det_set(on);
+    if (e == 0) e = nf_fpa_det_set(on);
+    if (e == 0) e = nf_mdc_det_set(on);
+    if (e == 0) e = nf_mcd_det_set(on);
+    if (e == 0) e = nf_rsm_det_set(on);
+    if (e == 0) g_nf_det_on = on ? 1 : 0;
+    return e;
+}
+
+extern "C" int nf_deterministic_enabled(void) { return g_nf_det_on; }
+
+extern "C" int nf_deterministic_timeouts(int* count) {
+    if (count == nullptr) return NF_E_BADARG;
+    hipError_t se = hipDeviceSynchronize();
+    if (se != hipSuccess) return (int)se;
+    unsigned total = 0, v = 0;
+    int e = nf_ms_det_timeouts(&v);
+    total += v;
+    if (e == 0) { e = nf_ca_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_cpl_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_lg_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_fbh_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_ic_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_icm_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_gh_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_ghm_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_ml_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_lb_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_cvb_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_cbk_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_ccd_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_fpc_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_fpi_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_fpa_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_mdc_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_mcd_det_timeouts(&v); total += v; }
+    if (e == 0) { e = nf_rsm_det_timeouts(&v); total += v; }
+    if (e != 0) return e;
+    *count = (int)total;
     return 0;
 }

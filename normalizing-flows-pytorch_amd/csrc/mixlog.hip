@@ -17,6 +17,10 @@
 // contiguous row: the block stages its rows through LDS (row stride 2+3K+1 words) so that global traffic is coalesced
 // both for the parameters and for their gradients.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_ml)
+NF_DET_HOST_API(nf_ml)
 #include "nf_mixlog_oct.h"
 
 #define NF_MX_ROWS_MAX 16
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_slab_fwd(const float* __res
     const float tot = nf_block_sum(acc, scratch);
     if (threadIdx.x == 0) {
         if (gridDim.y == 1) ld[b] += tot;
-        else atomicAdd(ld + b, tot);
+        else { NF_DET_ENTER(nf_ml); atomicAdd(ld + b, tot); NF_DET_LEAVE(nf_ml); }
     }
 }
 
@@ -254,8 +258,10 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_bwd(const float* __restrict
     const float ta = nf_block_sum(acc_A, scratch);
     const float tc = nf_block_sum(acc_C, scratch);
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_ml);
         atomicAdd(g_scale, ta);
         atomicAdd(g_bias, tc);
+        NF_DET_LEAVE(nf_ml);
     }
 }
 
@@ -273,6 +279,13 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_inv(const float* __restrict
     const bool staged = s.n_half == 1;
     const int steps = PHASE == 1 ? 25 : (flag[0] ? 75 : 0);
     bool stuck = false;
+    // image data adds per-wave log-det sums into ld[b] by atomics: in deterministic mode the workgroup holds the turn over its whole walk
+    // and its waves (and, in a wave that straddles two samples, its lanes) add one after the other
+    const bool det_img = s.n_half != 1 && nf_det_on(nf_ml_det);
+    if (det_img) {
+        if (threadIdx.x == 0) nf_det_wait(nf_ml_det);
+        __syncthreads();
+    }
     for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x; t0 < total; t0 += (int64_t)gridDim.x * blockDim.x) {
         if (staged) nf_stage_rows_in(prm, tile, t0, total, PS1);
         const int64_t t = t0 + threadIdx.x;
@@ -328,14 +341,37 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_inv(const float* __restrict
             // image data: a sample's n_half elements all add into ld[b].  One atomic per element was 98 k atomics on 64 addresses per
             // launch (650 us of a 16 ms sampling pass of the CIFAR-shape Flow++); a wave whose lanes share the sample adds ONE sum.
             const int64_t bw = __shfl(b, 0, NF_WAVE);
-            if (__all(b == bw)) {
-                float v = dld;
+            const bool one = __all(b == bw);
+            float v = dld;
+            if (one) {
 #pragma unroll
                 for (int off = NF_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, NF_WAVE);
-                if ((threadIdx.x & (NF_WAVE - 1)) == 0) atomicAdd(ld + bw, v);
-            } else if (t < total) atomicAdd(ld + b, dld);
+            }
+            if (!det_img) {
+                if (one) {
+                    if ((threadIdx.x & (NF_WAVE - 1)) == 0) atomicAdd(ld + bw, v);
+                } else if (t < total) atomicAdd(ld + b, dld);
+            } else {
+                for (int w_ = 0; w_ < (int)(blockDim.x >> 6); ++w_) {
+                    if ((int)(threadIdx.x >> 6) == w_) {
+                        if (one) {
+                            if ((threadIdx.x & (NF_WAVE - 1)) == 0) atomicAdd(ld + bw, v);
+                        } else {
+                            for (int l_ = 0; l_ < NF_WAVE; ++l_)
+                                if ((int)(threadIdx.x & (NF_WAVE - 1)) == l_ && t < total) { atomicAdd(ld + b, dld); __threadfence(); }
+                        }
+                        __threadfence();
+                    }
+                    __syncthreads();
+                }
+            }
         }
         if (staged) __syncthreads();
+    }
+    if (det_img) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) nf_det_pass(nf_ml_det);
     }
     if (PHASE == 1 && __any(stuck) && (threadIdx.x & (NF_WAVE - 1)) == 0) atomicOr(flag, 1);
 }
@@ -578,6 +614,7 @@ __global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const flo
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_ml);
         atomicAdd(g_scale, scratch[0][0]);
         atomicAdd(g_bias, scratch[0][1]);
         if (POST) {
@@ -588,6 +625,7 @@ __global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const flo
             atomicAdd(g_nb + o0, -t0 / D0);
             atomicAdd(g_nb + o1, -t1 / D1);
         }
+        NF_DET_LEAVE(nf_ml);
     }
 }
 
@@ -747,10 +785,17 @@ __device__ __forceinline__ void nf_cdf_load(const float* __restrict__ lp, const 
     }
 }
 
+// the active lanes of ONE wave add in lane order (the wave walks the lane index in lockstep: one atomic in flight per iteration)
+__device__ __forceinline__ void nf_lanes_in_turn_add(float* p, float v) {
+    for (int l = 0; l < NF_WAVE; ++l)
+        if ((int)(threadIdx.x & (NF_WAVE - 1)) == l) { atomicAdd(p, v); __threadfence(); }
+}
+
 template <int KT>
 __global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_fwd(const float* __restrict__ x, const float* __restrict__ lp, const float* __restrict__ mu,
                                                             const float* __restrict__ s, float* __restrict__ out, float* __restrict__ ld,
-                                                            int64_t n, int K, int64_t total) {
+                                                            int64_t n, int K, int64_t total, int det) {
+    // det (deterministic mode, n > 1): the launch is ONE wave and its lanes add one after the other -- element order
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = t / n, e = t - b * n, p = b * K * n + e;
         NfMix<KT> m;
@@ -759,7 +804,8 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_fwd(const float* __restr
         nf_mix_eval<KT>(m, x[t], lcdf, lpdf);
         out[t] = expf(lcdf);                                                                        // modules.py:193-194
         if (n == 1) ld[b] += lpdf;
-        else atomicAdd(ld + b, lpdf);
+        else if (!det) atomicAdd(ld + b, lpdf);
+        else nf_lanes_in_turn_add(ld + b, lpdf);
     }
 }
 
@@ -798,7 +844,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_bwd(const float* __restr
 template <int KT, int PHASE>
 __global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_inv(const float* __restrict__ target, const float* __restrict__ lp, const float* __restrict__ mu,
                                                             const float* __restrict__ s, float* __restrict__ x, float* __restrict__ ld,
-                                                            float* __restrict__ lohi, int* __restrict__ flag, int64_t n, int K, int64_t total) {
+                                                            float* __restrict__ lohi, int* __restrict__ flag, int64_t n, int K, int64_t total, int det) {
     const int steps = PHASE == 1 ? 25 : (flag[0] ? 75 : 0);
     bool stuck = false;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -827,7 +873,8 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlogcdf_inv(const float* __restr
             nf_mix_eval<KT>(m, xv, lcdf, lpdf);
             x[t] = xv;
             if (n == 1) ld[b] -= lpdf;                                                              // modules.py:209-212
-            else atomicAdd(ld + b, -lpdf);
+            else if (!det) atomicAdd(ld + b, -lpdf);
+            else nf_lanes_in_turn_add(ld + b, -lpdf);
         }
     }
     if (PHASE == 1 && __any(stuck) && (threadIdx.x & (NF_WAVE - 1)) == 0) atomicOr(flag, 1);
@@ -838,8 +885,9 @@ extern "C" int nf_mixlogcdf_fwd(const float* x, const float* log_pi, const float
     if (K < 1 || K > 32 || B < 0 || n < 0) return NF_E_BADARG;
     const int64_t total = B * n;
     if (total == 0) return 0;
-    const unsigned g = nf_grid_for(total, NF_BLOCK);
-#define CALL(KT) hipLaunchKernelGGL(k_mixlogcdf_fwd<KT>, dim3(g), dim3(NF_BLOCK), 0, (hipStream_t)stream, x, log_pi, mu, s, out, ld, n, K, total)
+    const int det = (n > 1 && nf_ml_det_host) ? 1 : 0;     // per-element atomics into ld[b]: deterministic mode runs ONE wave, lanes in turn
+    const unsigned g = det ? 1u : nf_grid_for(total, NF_BLOCK);
+#define CALL(KT) hipLaunchKernelGGL(k_mixlogcdf_fwd<KT>, dim3(g), dim3(det ? NF_WAVE : NF_BLOCK), 0, (hipStream_t)stream, x, log_pi, mu, s, out, ld, n, K, total, det)
     NF_MX_DISPATCH(K, CALL);
 #undef CALL
     NF_CHECK_LAUNCH();
@@ -868,10 +916,12 @@ extern "C" int nf_mixlogcdf_inv(const float* target, const float* log_pi, const 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(stuck_flag, 0, sizeof(int), st);
     if (e != hipSuccess) return (int)e;
-    const unsigned g = nf_grid_for(total, NF_BLOCK);
+    const int det = (n > 1 && nf_ml_det_host) ? 1 : 0;
+    const unsigned g = det ? 1u : nf_grid_for(total, NF_BLOCK);
+    const unsigned bt = det ? NF_WAVE : NF_BLOCK;
 #define CALL(KT)                                                                                                                     \
-    hipLaunchKernelGGL((k_mixlogcdf_inv<KT, 1>), dim3(g), dim3(NF_BLOCK), 0, st, target, log_pi, mu, s, x, ld, scratch, stuck_flag, n, K, total); \
-    hipLaunchKernelGGL((k_mixlogcdf_inv<KT, 2>), dim3(g), dim3(NF_BLOCK), 0, st, target, log_pi, mu, s, x, ld, scratch, stuck_flag, n, K, total)
+    hipLaunchKernelGGL((k_mixlogcdf_inv<KT, 1>), dim3(g), dim3(bt), 0, st, target, log_pi, mu, s, x, ld, scratch, stuck_flag, n, K, total, det); \
+    hipLaunchKernelGGL((k_mixlogcdf_inv<KT, 2>), dim3(g), dim3(bt), 0, st, target, log_pi, mu, s, x, ld, scratch, stuck_flag, n, K, total, det)
     NF_MX_DISPATCH(K, CALL);
 #undef CALL
     NF_CHECK_LAUNCH();

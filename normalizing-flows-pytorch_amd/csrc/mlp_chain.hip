@@ -14,6 +14,10 @@
 // producing linear's bias, biased variance for normalisation, unbiased for the running estimate, weight-norm as a scale of
 // the activation column (weight_norm.py:40).
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_mcd)
+NF_DET_HOST_API(nf_mcd)
 #include "nf_mfma16.h"
 #include "nf_flow_rec.h"
 
@@ -1388,7 +1392,9 @@ __device__ __forceinline__ void nf_mc_bwd_body(float* sm, const float* __restric
     // of ~27 at 32 workgroups).  The workgroup leaves its slab and its 64 head sums in memory and ends; ONE launch after the
     // last step folds every step of the run at once (k_glow_fold_all).
     const bool defer = GLOW && head_rec != nullptr;
-    const bool afold = !defer && accumulate != 0 && gridDim.x <= NF_MC_AFOLD_MAX_BLOCKS;
+    // (deterministic mode: no barrier-free atomic fold -- with two workgroups adding into a NON-zero gradient the order of the two adds
+    // shows in the last bit; the grid fold behind the barrier has one writer per address)
+    const bool afold = !defer && accumulate != 0 && gridDim.x <= NF_MC_AFOLD_MAX_BLOCKS && !nf_det_on(nf_mcd_det);
     const float* head_tot = nullptr;
     if (defer) {
         __syncthreads();                                  // red rows of the head product

@@ -16,10 +16,13 @@
 
 // per translation unit: [0] mode on / off, [1] the turn, [2] waits that gave up (a workgroup that never passed: a bug -- the launch then
 // finishes unordered instead of hanging the device, and nf_deterministic_timeouts() reports it)
-#define NF_DET_STATE(p) __device__ unsigned p##_det[3];
+#define NF_DET_STATE(p)             \
+    __device__ unsigned p##_det[3]; \
+    static int p##_det_host = 0;    /* host mirror of [0]: launchers that change their launch shape in the mode read it */
 #define NF_DET_HOST_API(p)                                                                       \
     __attribute__((visibility("hidden"))) int p##_det_set(int on) {                              \
         const unsigned w[3] = {on ? 1u : 0u, 0u, 0u};                                            \
+        p##_det_host = on ? 1 : 0;                                                               \
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(p##_det), w, sizeof(w));                        \
     }                                                                                            \
     __attribute__((visibility("hidden"))) int p##_det_timeouts(unsigned* out) {                  \
@@ -72,13 +75,25 @@ __device__ __forceinline__ void nf_det_pass(unsigned* w) {
         if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) nf_det_pass(p##_det); \
     }
 // (3) inside (2): waves of the workgroup that add to the SAME addresses take turns in wave order (uniform control flow, `nw` waves):
-//         NF_DET_WAVES(nw, wid, { atomics of this wave });
-#define NF_DET_WAVES(nw, wid, ...)                                             \
-    do {                                                                       \
-        if (nf_det_) {                                                         \
-            for (int w_ = 0; w_ < (nw); ++w_) {                                \
-                if ((wid) == w_) { __VA_ARGS__; __threadfence(); }             \
-                __syncthreads();                                               \
-            }                                                                  \
-        } else { __VA_ARGS__; }                                                \
-    } while (0)
+//         nf_det_waves(nf_det_, nw, wid, [&] { atomics of this wave });
+template <class F>
+__device__ __forceinline__ void nf_det_waves(bool det, int nw, int wid, F&& f) {
+    if (det) {
+        for (int w_ = 0; w_ < nw; ++w_) {
+            if (wid == w_) { f(); __threadfence(); }
+            __syncthreads();
+        }
+    } else {
+        f();
+    }
+}
+// (1b) ONE WAVE of the workgroup issues all of the workgroup's atomics (lanes to addresses no two of them share); reached by the whole
+//      wave (lane 0 included) in wave-uniform control flow:   NF_DET_ENTER_WAVE(p);  if (mine) atomicAdd(...);  NF_DET_LEAVE_WAVE(p);
+#define NF_DET_ENTER_WAVE(p)                      \
+    const bool nf_det_ = nf_det_on(p##_det);      \
+    if (nf_det_ && (threadIdx.x & 63) == 0) nf_det_wait(p##_det)
+#define NF_DET_LEAVE_WAVE(p)                                     \
+    if (nf_det_) {                                               \
+        __threadfence();                                         \
+        if ((threadIdx.x & 63) == 0) nf_det_pass(p##_det);       \
+    }

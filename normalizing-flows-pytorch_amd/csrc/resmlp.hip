@@ -10,6 +10,10 @@
 // inverse (iresblock.py:236-255) is a chain of single-iteration launches gated by a device flag that reproduces the
 // reference's batch-global exit without a host round trip.
 #include "nf_common.h"
+#include "nf_det.h"
+
+NF_DET_STATE(nf_rsm)
+NF_DET_HOST_API(nf_rsm)
 
 #define NF_RES_H 32
 #define NF_RES_MAXD 4
@@ -471,25 +475,34 @@ __global__ void __launch_bounds__(NF_RT_THREADS) k_resmlp_train_bwd(NfResW w, co
     float* gW3 = gb2 + NF_RES_H;
     float* gb3 = gW3 + D * NF_RES_H;
     float* gbe = gb3 + D;
+    // every wave of every workgroup adds to the same entries: deterministic mode takes the workgroups in block order and, inside one,
+    // the waves in wave order (within a wave no two lanes share an address)
+    NF_DET_ENTER_ALL(nf_rsm);
+    nf_det_waves(nf_det_, NF_RT_WAVES, wid, [&] {
 #pragma unroll
-    for (int i = 0; i < NF_RES_H; ++i) {
-        const float t = accW2[i] + __shfl_xor(accW2[i], 32, NF_WAVE);
-        if (slot == 0) atomicAdd(gW2 + u * NF_RES_H + i, t);
-    }
+        for (int i = 0; i < NF_RES_H; ++i) {
+            const float t = accW2[i] + __shfl_xor(accW2[i], 32, NF_WAVE);
+            if (slot == 0) atomicAdd(gW2 + u * NF_RES_H + i, t);
+        }
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const float t1 = accW1[d] + __shfl_xor(accW1[d], 32, NF_WAVE), t3 = accW3[d] + __shfl_xor(accW3[d], 32, NF_WAVE);
-        if (slot == 0) { atomicAdd(gW1 + u * D + d, t1); atomicAdd(gW3 + d * NF_RES_H + u, t3); }
-    }
-    {
-        const float tb1 = acc_b1 + __shfl_xor(acc_b1, 32, NF_WAVE), tb2 = acc_b2 + __shfl_xor(acc_b2, 32, NF_WAVE);
-        const float tb3 = acc_b3 + __shfl_xor(acc_b3, 32, NF_WAVE);
-        if (slot == 0) { atomicAdd(gb1 + u, tb1); atomicAdd(gb2 + u, tb2); if (u < D) atomicAdd(gb3 + u, tb3); }
-        float e1 = nf_half_allsum(acc_be1), e2 = nf_half_allsum(acc_be2);
-        e1 += __shfl_xor(e1, 32, NF_WAVE);
-        e2 += __shfl_xor(e2, 32, NF_WAVE);
-        if (lane == 0) { atomicAdd(gbe, e1); atomicAdd(gbe + 1, e2); }
-    }
+        for (int d = 0; d < D; ++d) {
+            const float t1 = accW1[d] + __shfl_xor(accW1[d], 32, NF_WAVE);
+            const float t3 = accW3[d] + __shfl_xor(accW3[d], 32, NF_WAVE);
+            if (slot == 0) { atomicAdd(gW1 + u * D + d, t1); atomicAdd(gW3 + d * NF_RES_H + u, t3); }
+        }
+        {
+            const float tb1 = acc_b1 + __shfl_xor(acc_b1, 32, NF_WAVE);
+            const float tb2 = acc_b2 + __shfl_xor(acc_b2, 32, NF_WAVE);
+            const float tb3 = acc_b3 + __shfl_xor(acc_b3, 32, NF_WAVE);
+            if (slot == 0) { atomicAdd(gb1 + u, tb1); atomicAdd(gb2 + u, tb2); if (u < D) atomicAdd(gb3 + u, tb3); }
+            float e1 = nf_half_allsum(acc_be1);
+            float e2 = nf_half_allsum(acc_be2);
+            e1 += __shfl_xor(e1, 32, NF_WAVE);
+            e2 += __shfl_xor(e2, 32, NF_WAVE);
+            if (lane == 0) { atomicAdd(gbe, e1); atomicAdd(gbe + 1, e2); }
+        }
+    });
+    NF_DET_LEAVE_ALL(nf_rsm);
 }
 
 extern "C" int nf_resmlp_train_bwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,

@@ -97,6 +97,8 @@ def main():
         print(lines[-1] if not diffs else '\n'.join(lines[-(len(kinds) + 1):]), flush=True)
         del trainer, net
         torch.cuda.empty_cache()
+    lines.append('turnstile waits that gave up: %d; persistent-kernel timeouts: %d' % (pkg._native.deterministic_timeouts(), pkg._native.persistent_timeouts()))
+    print(lines[-1])
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, 'a') as f:
         f.write('\n'.join(lines) + '\n')
