@@ -295,7 +295,7 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
     with N.timed_launches(entry, match) as t:
         for _ in range(reps):
             torch.cuda.synchronize()
-            gpu_delay(float(os.environ.get('NF_BENCH_DELAY_MS', '250' if len(dims) == 3 else '40')))
+            gpu_delay(250.0 if len(dims) == 3 else 40.0)
             trainer._forward_backward(y)
         d = t.durations_us()
     if not d:
@@ -338,7 +338,7 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
     # 2703 / 7002 ms per step at 8 / 16 / 32 / 64 threads, C1 32 / 47 / 55 / 60 / 128 ms at 1 / 4 / 8 / 16 / 32 -- the baseline runs
     # at the FASTEST setting of its config (C4: 16, C1: 1; the others 8, what the reference was probed with in BASELINE.md);
     # `cores` reports what ran
-    cores = min(os.cpu_count() or 1, int(os.environ.get('NF_CPU_THREADS', cfg.get('cpu_threads', 8))))
+    cores = min(os.cpu_count() or 1, int(cfg.get('cpu_threads', 8)))
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in state.items()}
     ora = om.FlowOracle(cfg['kind'], cfg['dims'], cfg['datatype'], cfg['layers'], sd, mixtures=cfg['mixtures'],
@@ -629,8 +629,6 @@ def main():
     torch.cuda.set_device(local_rank)                        # BEFORE the library is loaded / armed: one device per process
     pkg._native.load()
     dev = torch.device('cuda', local_rank)
-    if os.environ.get('NF_MIOPEN_FIND', '0') == '1':
-        torch.backends.cudnn.benchmark = True                # MIOpen find mode for the image conditioner's convolutions
     # BASELINE.json quotes the metric on RealNVP moons-2D (c1) and Glow CIFAR-10 (c4): the default run measures both -- the
     # line's top level is c4 (the larger one), c1 rides along as a second object of the same shape under "also"
     primary = args.config or 'c4'

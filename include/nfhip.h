@@ -422,7 +422,7 @@ int nf_conv_bn_usable(int64_t B, int I, int O, int H, int W, int ksize);
 /* Large batches (B*H*W > min_pixels, default 16384: beyond the persistent chain's 128 tiles): the 3x3 layers with <= 32 input and 32
  * output channels run on csrc/conv_bulk.hip -- independent waves, three-way bf16 split on the matrix pipe -- behind nf_conv_bn_fwd /
  * nf_conv_bn_bwd (data pass); same results to fp32 rounding.  Switches for tests and A/B runs (-1 = keep): on, min_pixels, nblk
- * (pixel blocks per wave: 0 automatic, 1, 2).  Environment: NF_CONV_BULK=0, NF_CONV_BULK_MIN_PX, NF_CONV_BULK_NBLK.                */
+ * (pixel blocks per wave: 0 automatic, 1, 2).  Environment: NF_CONV_BULK=0 (off).                                                  */
 int nf_conv_bulk_config(int on, int64_t min_pixels, int nblk);
 int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int W, int ksize, int training, float bn_eps,
                    float bn_momentum, nf_stream_t stream);
@@ -438,7 +438,7 @@ int nf_conv_bn_fwd(const nf_conv_desc* desc, int64_t B, int I, int O, int H, int
  * (128 when 64-pixel tiles would exceed the co-residency limit).
  * ws_zero: nf_convnet_chain_ws_floats(...) floats that are ZERO at launch (exchange slots: NF_CONVNET_WS_FLOATS for the BatchNorm
  * statistics; 16 x 16 maps at 2 B <= 128 split every sample over two workgroups, which hand their boundary rows to each other through
- * further slots -- then ws_zero is needed in evaluation mode too).  NF_CONV_HALO=0 in the environment selects one workgroup per sample. */
+ * further slots -- then ws_zero is needed in evaluation mode too).  */
 #define NF_CONVNET_MAX_BLOCKS 128
 #define NF_CONVNET_WS_FLOATS (5 * (128 + 8) * 64 * 2)     /* a row of 64 eight-byte slots per workgroup and per group of 16, per BatchNorm */
 int nf_convnet_chain_ws_floats(int64_t B, int I0, int O_out, int H, int W);

@@ -134,7 +134,7 @@ def _arm_device():
     dev = torch.cuda.current_device()
     if dev not in _armed:
         p = ctypes.c_void_p()
-        rc = load().nf_persistent_config(int(os.environ.get('NF_SPIN_LIMIT', 1 << 22)), 0, ctypes.byref(p))
+        rc = load().nf_persistent_config(SPIN_LIMIT, 0, ctypes.byref(p))
         if rc != 0:
             raise NativeLibraryError('nf_persistent_config failed with code %d on device %d' % (rc, dev))
         _err_word = ctypes.c_uint.from_address(p.value)     # ONE pinned, portable host word shared by all devices
@@ -145,6 +145,7 @@ def _arm_device():
         _armed.add(dev)
 
 
+SPIN_LIMIT = 1 << 22        # poll budget of one spin loop of a persistent kernel (persistent_reset(spin_limit=...) changes it)
 _det = os.environ.get('NF_DETERMINISTIC', '0') == '1'   # deterministic mode wanted (applied to every device when it is armed)
 
 
@@ -197,7 +198,7 @@ def persistent_reset(spin_limit=None):
     """clear the counters and the error word (synchronises); optionally set the poll budget of the spin loops."""
     global _err_word
     p = ctypes.c_void_p()
-    lim = int(spin_limit) if spin_limit is not None else int(os.environ.get('NF_SPIN_LIMIT', 1 << 22))
+    lim = int(spin_limit) if spin_limit is not None else SPIN_LIMIT
     rc = load().nf_persistent_config(lim, 1, ctypes.byref(p))
     if rc != 0:
         raise NativeLibraryError('nf_persistent_config failed with code %d' % rc)

@@ -957,26 +957,12 @@ extern "C" int nf_conv_bwd_slabs(int64_t B, int H, int W) {
 
 // Slabs per layer of a deferred weight-gradient launch of n_layers layers: one workgroup per compute unit over the whole launch
 // (a workgroup keeps its tap tiles in registers over its tiles and pays launch, constants and the slab once; more, shorter-lived
-// workgroups measured slower: 16 layers at 16 x 16, 128 / 32 / 16 / 8 slabs: 123 / 94 / 81 / 198 us).  NF_CONV_WGRAD_SLABS overrides.
+// workgroups measured slower: 16 layers at 16 x 16, 128 / 32 / 16 / 8 slabs: 123 / 94 / 81 / 198 us).  (The overrides of rounds 2 - 4, NF_CONV_WGRAD_SLABS / _BLOCKS, are gone: no setting beat this rule.)
 extern "C" int nf_conv_wgrad_slabs(int64_t B, int H, int W, int n_layers) {
     if (B <= 0 || H <= 0 || W <= 0 || n_layers < 1) return 0;
     const int64_t tiles = (B * H * W + NF_CV_PX - 1) / NF_CV_PX;
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("NF_CONV_WGRAD_SLABS");
-        const int v = e != nullptr ? atoi(e) : 0;
-        forced = (v >= 1 && v <= NF_CV_BWD_MAX_SLABS) ? v : 0;
-    }
-    // NF_CONV_WGRAD_BLOCKS: workgroups of the whole launch (default 256 = one per compute unit).  With the launches on a side stream
-    // (NF_CONV_OVERLAP=1) next to the persistent chain -- whose workgroups need a WHOLE compute unit each, at most 128 of them -- a cap of
-    // 128 leaves the chain its compute units instead of making every chain launch wait for weight-gradient workgroups to retire.
-    static int cap = -1;
-    if (cap < 0) {
-        const char* e = getenv("NF_CONV_WGRAD_BLOCKS");
-        const int v = e != nullptr ? atoi(e) : 0;
-        cap = (v >= 1 && v <= 1024) ? v : 256;
-    }
-    int64_t want = forced > 0 ? forced : cap / n_layers;
+    const int cap = 256;                               // workgroups of the whole launch: one per compute unit
+    int64_t want = cap / n_layers;
     if (want < 1) want = 1;
     if (want > NF_CV_BWD_MAX_SLABS) want = NF_CV_BWD_MAX_SLABS;
     return (int)(tiles < want ? tiles : want);

@@ -60,16 +60,14 @@ struct NfCbGeo {
     int C;              // channels of the tensors the frame is built from (forward: I, backward: O = 32)
 };
 
-// switches: the environment (NF_CONV_BULK=0 off, NF_CONV_BULK_MIN_PX, NF_CONV_BULK_NBLK) at first use, nf_conv_bulk_config afterwards
+// switch: the environment (NF_CONV_BULK=0: off) at first use; nf_conv_bulk_config afterwards (tests: threshold and block count too)
 static int nf_cb_cfg_on = -1, nf_cb_cfg_nblk = -1;
 static int64_t nf_cb_cfg_min_px = -1;
 static void nf_cb_cfg_init() {
     if (nf_cb_cfg_on >= 0) return;
     const char* e = getenv("NF_CONV_BULK");
-    const char* m = getenv("NF_CONV_BULK_MIN_PX");
-    const char* n = getenv("NF_CONV_BULK_NBLK");
-    nf_cb_cfg_min_px = m != nullptr ? atoll(m) : 16384 + 1;      // beyond 128 tiles of 128 pixels: where the persistent chain ends
-    nf_cb_cfg_nblk = n != nullptr ? atoi(n) : 0;
+    nf_cb_cfg_min_px = 16384 + 1;                      // beyond 128 tiles of 128 pixels: where the persistent chain ends
+    nf_cb_cfg_nblk = 0;
     nf_cb_cfg_on = (e == nullptr || e[0] != '0') ? 1 : 0;
 }
 static int nf_cb_on() { nf_cb_cfg_init(); return nf_cb_cfg_on; }
@@ -1293,11 +1291,7 @@ static bool nf_c1_geometry(NfC1Geo& g, int64_t B, int H, int W) {
     g.units = (g.Npx + 63) / 64;
     return g.lgHW >= 5 && B * 192 * (int64_t)g.HW < ((int64_t)1 << 29);      // whole 32-pixel blocks inside a sample; 32-bit byte offsets
 }
-static int nf_c1_on() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("NF_CONV_BULK_1X1"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
-    return on;
-}
+static int nf_c1_on() { return 1; }
 int nf_conv1_bulk_fwd_plan(const nf_conv_desc* d, int64_t B, int I, int O, int H, int W, int ksize) {
     NfC1Geo g;
     if (!nf_c1_on() || !nf_cb_on() || ksize != 1 || I != 32 || O < 1 || O > 64 || B * H * W < nf_cb_min_px()) return 0;
@@ -1396,8 +1390,7 @@ int nf_conv_bulk_fwd(const nf_conv_desc* desc, int64_t B, int I, int H, int W, i
 
 // weight-gradient pass of up to NF_CONV_WGRAD_MAX layers of one shape (called by nf_conv_bn_wgrad_multi; 0 = the kernels of conv_bn.hip)
 int nf_conv_bulk_wgrad_plan(int64_t B, int I, int O, int H, int W, int ksize) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("NF_CONV_BULK_WGRAD"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
+    const int on = 1;
     // (the weight pass starts one tile count earlier than the data passes: at exactly 16 384 pixels -- config 4's per-GPU shard at
     // the 16 x 16 level, whose data passes run the persistent chain -- it measured 24.56 against 24.9 ms per step)
     if (!on || !nf_cb_on() || ksize != 3 || O != 32 || I < 1 || I > 32 || B * H * W < nf_cb_min_px() - 1) return 0;

@@ -1547,24 +1547,12 @@ static inline int nf_cc_optin(K kernel) {
 static int nf_cc_capacity();
 // 16 x 16 maps split a sample over two 128-pixel tiles (halo rows handed over between the two workgroups: 2 B <= 128 workgroups on twice
 // the compute units) when the grid fits, else one 256-pixel tile per sample
-static int nf_cc_halo_on() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("NF_CONV_HALO"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
-    return on;
-}
+static int nf_cc_halo_on() { return 1; }
 // maps below 16 x 16 run on 64-pixel tiles (<2, 8>: two pixel blocks x eight K splits) where that doubles the workgroups within the
 // co-residency limits -- the prologue / epilogue phases of a launch (input frame, 1 x 1 convolution, the coupling and its backward) are
-// per-pixel work of 8 .. 32 compute units at the 4 x 4 and 8 x 8 levels; NF_CONV_TILE64=0 keeps 128-pixel tiles
-static int nf_cc_tile64_on() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("NF_CONV_TILE64"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
-    return on;
-}
-static int nf_cc_tile32_on() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("NF_CONV_TILE32"); on = (e == nullptr || e[0] != '0') ? 1 : 0; }
-    return on;
-}
+// per-pixel work of 8 .. 32 compute units at the 4 x 4 and 8 x 8 levels
+static int nf_cc_tile64_on() { return 1; }
+static int nf_cc_tile32_on() { return 1; }
 static inline int nf_cc_tile_px(int64_t B, int H, int W) {
     if (H * W <= 64 && nf_cc_tile64_on()) {
         const int64_t t64 = (B * H * W + 63) / 64, t32 = (B * H * W + 31) / 32;

@@ -862,8 +862,7 @@ static int nf_fi_conv_launch(const float* in, const float* w, const float* bias,
     int rc;
     {
         // 64-pixel tiles while 256-pixel ones hold at most 128 workgroups (measured at B = 64: 129 best, wider launches gain nothing)
-        static int t64 = -1;                            // NF_FLOWPP_IMG_TILE64 = the workgroup count below which the small tiles run
-        if (t64 < 0) { const char* e = getenv("NF_FLOWPP_IMG_TILE64"); t64 = e == nullptr ? 129 : atoi(e); }
+        const int t64 = 129;                            // the workgroup count below which the small tiles run
         const int64_t wgs = ((B + G::S - 1) / G::S) * ((Co + 31) / 32) * ksplit;
         if (wgs < t64) {
             using G6 = NfFiGeo64<LGW>;

@@ -241,8 +241,7 @@ extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const floa
     if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
     if (B == 0) return 0;
     const int Px = H * W;
-    static int thr = -1;                                     // NF_GLOW_HEAD_BWD_THREADS: experiment knob (64 .. 1024)
-    if (thr < 0) { const char* e = getenv("NF_GLOW_HEAD_BWD_THREADS"); thr = e == nullptr ? 512 : atoi(e); if (thr < 64 || thr > NF_GH_BIG || (thr & 63)) thr = 512; }   // (B = 64, 32 x 32: 10.4 us at 1024 threads, 8.8 at 512, 9.1 at 256)
+    const int thr = 512;                                     // (B = 64, 32 x 32: 10.4 us at 1024 threads, 8.8 at 512, 9.1 at 256)
     unsigned g = nf_grid_for(B * Px, thr * 2);
     if (g > 256) g = 256;
     hipStream_t st = (hipStream_t)stream;

@@ -527,15 +527,12 @@ extern "C" int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const flo
     // Tile and grid by the kernel's register footprint (-Rpass-analysis=kernel-resource-usage): the 128-pixel tile of 33 .. 64 channels
     // holds 388 registers -- one workgroup per compute unit, so 512 workgroups ran in two rounds (137 us on (48, 8, 8) x 8192; with the
     // 64-pixel tile, two workgroups per unit, 99) -- and the grid is ONE round of what fits (12 channels: three per unit, 91 -> 83 us).
-    static int tp_force = -1, cap_force = -1;                // NF_GLOW_HEAD_BWD_TP (64 / 128), NF_GLOW_HEAD_BWD_BLOCKS: experiment knobs
-    if (tp_force < 0) { const char* e = getenv("NF_GLOW_HEAD_BWD_TP"); tp_force = e == nullptr ? 0 : atoi(e); }
-    if (cap_force < 0) { const char* e = getenv("NF_GLOW_HEAD_BWD_BLOCKS"); cap_force = e == nullptr ? 0 : atoi(e); }
     // 33 .. 64 channels: the 128-pixel tile while its tiles are ONE round of one workgroup per compute unit (B = 512 at (48, 8, 8): 256 tiles,
     // 27.5 us against 36.7 with 512 64-pixel tiles -- profiles/r04_c4_b512_step_kernels.txt before / after the tile rule above), the 64-pixel
     // tile beyond (two workgroups per unit instead of a second round) and below 64 tiles (latency: a wave's share of the chain halves)
     const int64_t t128 = (npix + 127) / 128;
-    const int TP = tp_force == 64 || tp_force == 128 ? tp_force : ((t128 < 64 || (rt >= 3 && t128 > 256)) ? 64 : 128);
-    const int cap = cap_force > 0 ? cap_force : (rt == 1 ? 768 : (rt <= 3 ? 512 : 256));
+    const int TP = (t128 < 64 || (rt >= 3 && t128 > 256)) ? 64 : 128;
+    const int cap = rt == 1 ? 768 : (rt <= 3 ? 512 : 256);
     const int64_t tiles = (npix + TP - 1) / TP;
     int64_t blocks = tiles < cap ? tiles : cap;              // ends in C * C + 2 C same-address atomics per block
     const int64_t tpb = (tiles + blocks - 1) / blocks;

@@ -272,8 +272,7 @@ __attribute__((visibility("hidden"))) int nf_invconv_wgrad_mfma_try(const float*
     const int rt = (C + 15) / 16;
     const int64_t npix = B * P;
     const int64_t tiles = (npix + NF_WTP - 1) / NF_WTP;
-    static int cap = -1;                                     // NF_INVCONV_WGRAD_BLOCKS: experiment knob
-    if (cap < 0) { const char* e = getenv("NF_INVCONV_WGRAD_BLOCKS"); cap = e == nullptr ? 512 : atoi(e); if (cap < 1) cap = 512; }
+    const int cap = 512;
     int64_t blocks = tiles < cap ? tiles : cap;             // (the kernel ends in C * C same-address atomics per block)
     const int64_t tpb = (tiles + blocks - 1) / blocks;
     blocks = (tiles + tpb - 1) / tpb;

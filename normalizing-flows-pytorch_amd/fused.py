@@ -550,7 +550,7 @@ class FlowppDefer:
             i = j
 
 
-FLOWPP_DEFER = _os.environ.get('NF_FLOWPP_DEFER', '1') != '0'
+FLOWPP_DEFER = True             # (internal: tests compare the deferred finalize with the per-step one)
 FPP_DEFER = FlowppDefer()
 
 
@@ -705,15 +705,15 @@ GLOW_FLOW_AUTO_ROWS = 8192
 # larger batches: the same run as ONE autograd node of S single-step launches per direction whose backward defers every
 # step's grid barrier + gradient fold to one launch at the end (nf_glow_flow_steps_*; C2 at B = 2048 / 4096 / 16384:
 # 1.77 -> 1.63 / 1.88 -> 1.71 / 3.02 -> 2.50 ms per train step)
-GLOW_FLOW_STEPS = _os.environ.get('NF_GLOW_FLOW_STEPS', '1') != '0'
+GLOW_FLOW_STEPS = True          # (internal: deferred fold of the per-step launches)
 # the whole-flow backward leaves every step's weight-gradient slabs behind and ONE launch folds them all (nf_*_flow_vec_bwd_deferred):
-# the in-kernel fold is 8.4 of a step's 34 us at two workgroups (C1 1.89 -> 1.6 ms per train step); NF_FLOW_DEFER_FOLD=0: in-kernel
-FLOW_DEFER_FOLD = _os.environ.get('NF_FLOW_DEFER_FOLD', '1') != '0'
+# the in-kernel fold is 8.4 of a step's 34 us at two workgroups (C1 1.89 -> 1.6 ms per train step); FLOW_DEFER_FOLD = False: in-kernel
+FLOW_DEFER_FOLD = True          # (internal: deferred fold inside the whole-flow launch)
 # Device tables of per-step pointer records, keyed by the addresses they contain (if a later model lands on the same addresses
 # the entry is, by construction, still correct).  A captured hipGraph (FlowTrainer._capture) has the table's address baked into its
 # kernel arguments, so an entry that was looked up or created WHILE A STREAM WAS CAPTURING is pinned for the life of the process;
 # everything else (eager models that come and go: tests, bench.py running several workloads) is least-recently-used beyond
-# NF_FLOW_TABLE_CACHE entries (~25 KB each for 32 steps).
+# 32 entries (~25 KB each for 32 steps).
 def _capturing():
     try:
         return bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
@@ -752,7 +752,7 @@ class _FlowTableCache:
         return len(self.entries)
 
 
-_GLOW_FLOW_TABLES = _FlowTableCache(_os.environ.get('NF_FLOW_TABLE_CACHE', '32'))
+_GLOW_FLOW_TABLES = _FlowTableCache(32)
 _GLOW_FLOW_HOST = _GLOW_FLOW_TABLES.host          # device table pointer -> the host copy of the same records
 _GLOW_FLOW_SLABS = {}
 
@@ -932,7 +932,7 @@ def glow_flow_vec_nograd(z, ld, steps):
 
 
 # ---- the INVERSE of vector Glow steps (sampling: net.backward), one launch per step or per run --------------------------------
-GLOW_INVERSE = _os.environ.get('NF_GLOW_INVERSE', '1') != '0'
+GLOW_INVERSE = True             # (internal: fused inverse / no-grad launches)
 
 
 def _glow_inverse_head(a, c, k):

@@ -73,7 +73,7 @@ class ConvPackDesc(ctypes.Structure):
                 ('reserved', ctypes.c_int)]
 
 
-CONV_PACK_ON = __import__('os').environ.get('NF_CONV_PACK', '1') != '0'
+CONV_PACK_ON = True
 
 
 def pack_conv_weights(wn_modules, w_effs):
@@ -136,9 +136,9 @@ class _Pack:
 
 
 CONV_CHAIN_ON = __import__('os').environ.get('NF_CONV_CHAIN', '1') != '0'
-CONV_CHAIN_BWD_ON = __import__('os').environ.get('NF_CONV_CHAIN_BWD', '1') != '0'
-CONV_COUPLING_ON = __import__('os').environ.get('NF_CONV_COUPLING', '1') != '0'
-CONV_COUPLING_MIN_PX = int(__import__('os').environ.get('NF_CONV_COUPLING_MIN_PX', '0'))
+CONV_CHAIN_BWD_ON = True
+CONV_COUPLING_ON = True
+CONV_COUPLING_MIN_PX = 0
 
 
 @functools.lru_cache(maxsize=None)
@@ -196,15 +196,11 @@ class ConvDefer:
         self.layers = []        # (key, desc kwargs, dst weight gradient, n_slabs)
         self.sums = []          # slab-sum jobs that read accumulators the deferred passes fill, or that can wait as well
         self.scratch = {}
-        self.side = {}          # device -> the stream the overlapped weight-gradient launches run on
-        self.forked = False
-        self.keep = []          # operands of launches in flight on the side stream (alive until the join)
         self.plu_jobs = []      # PLU weight backward of the C <= 4 heads (functional._GlowHead): batched at the flush
 
     def begin(self):
         self.layers, self.sums = [], []
         self.active, self.armed = CONV_DEFER_ON, False
-        self.forked, self.keep = False, []
         self.plu_jobs = []
 
     def arm(self, weights):
@@ -252,50 +248,9 @@ class ConvDefer:
                 N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
                 _slab_sum_all(jobs)                  # before the next chunk overwrites the scratch (stream order)
 
-    def offload(self):
-        """Overlap (NF_CONV_OVERLAP=1; OFF by default since the round-2 measurement below): as soon as sixteen queued layers share
-        a shape, their weight-gradient launch goes to a side stream, behind everything the main stream has issued so far, joined in
-        flush.  The idea -- the data-gradient chain occupies 8 .. 128 of the 256 compute units, the bulk launches fill the rest --
-        does not survive the hardware's placement: a chain workgroup needs a WHOLE compute unit (1024 threads, > 80 KB of LDS, every
-        VGPR), so each chain launch waits until the weight-gradient workgroups that took its compute units have retired, and the
-        persistent chain pays that wait on its latency chain 161 times per backward.  Glow CIFAR-shape, B = 64, one box: no weight
-        gradients at all 30.5 ms / step; side stream 34.5 - 34.8; everything behind the last data gradient (this flag off) 34.0."""
-        if not (CONV_OVERLAP_ON and self.active and self.layers):
-            return
-        step = N.header_constant('NF_CONV_WGRAD_MAX')
-        groups = {}
-        for e in self.layers:
-            groups.setdefault(e[0], []).append(e)
-        ready = [es[:step] for es in groups.values() if len(es) >= min(step, CONV_OFFLOAD_MIN)]
-        if not ready:
-            return
-        main = torch.cuda.current_stream()
-        dev = main.device
-        side = self.side.get(dev)
-        if side is None:
-            side = self.side[dev] = torch.cuda.Stream(device=dev)
-        for chunk in ready:                         # (the slab scratch is grown on the main stream, never inside the side context)
-            (B, Hh, Ww) = chunk[0][0][0]
-            self._slab_scratch(_wgrad_slabs(B, Hh, Ww, len(chunk)) * sum(e[2].numel() for e in chunk), dev)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for chunk in ready:
-                self.launch_layers(chunk)
-        done = set(id(e) for chunk in ready for e in chunk)
-        self.keep += [e for e in self.layers if id(e) in done]
-        self.layers = [e for e in self.layers if id(e) not in done]
-        self.forked = True
-
     def flush(self):
         layers, sums = self.layers, self.sums
-        forked, keep = self.forked, self.keep
         self.layers, self.sums, self.active, self.armed = [], [], False, False
-        self.forked, self.keep = False, []
-        if forked:                                  # the tail runs behind the side stream's launches (they share the slab scratch)
-            main = torch.cuda.current_stream()
-            side = self.side[main.device]
-            main.wait_stream(side)
-        del keep
         plu, self.plu_jobs = self.plu_jobs, []
         if plu:
             from .fused import PluDesc, _plu_launch
@@ -310,10 +265,11 @@ class ConvDefer:
         _slab_sum_all(sums)
 
 
-WGRAD_FROM_STORE = __import__('os').environ.get('NF_CONV_WGRAD_FROM_STORE', '1') != '0'
-CONV_DEFER_ON = __import__('os').environ.get('NF_CONV_DEFER', '1') != '0'
-CONV_OVERLAP_ON = __import__('os').environ.get('NF_CONV_OVERLAP', '0') != '0'
-CONV_OFFLOAD_MIN = int(__import__('os').environ.get('NF_CONV_OFFLOAD_MIN', '16'))   # layers of one shape queued before a launch leaves
+# internal constants (tests flip them to compare the paths; they are not environment switches any more -- round 5 pruned the switchboard:
+# every setting measured slower than the default in rounds 2 - 4 lost its switch, the side-stream overlap of the weight-gradient launches
+# lost its code as well: profiles/r04_overlap_ab.txt)
+WGRAD_FROM_STORE = True
+CONV_DEFER_ON = True
 CONV_DEFER = ConvDefer()
 
 
@@ -637,7 +593,6 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         for key, wkw, i in queued:             # (the tensors in wkw keep every operand alive until the flush)
             CONV_DEFER.layers.append((key, wkw, g_w[i], slabs, jobs[nl + i]))
         CONV_DEFER.sums += bn_jobs
-        CONV_DEFER.offload()
     elif chained:
         CONV_DEFER.launch_layers([(key, wkw, g_w[i], slabs, jobs[nl + i]) for key, wkw, i in queued])
         if bn_jobs:

@@ -15,19 +15,9 @@ from .functional import _sinks
 
 FLOWPP_IMG_ON = os.environ.get('NF_FLOWPP_IMG', '1') != '0'
 # the middle cut by attention head (B x 4 workgroups) for batches below this many samples; 0 = never (csrc/flowpp_img_att.hip)
-SPLIT_BELOW = int(os.environ.get('NF_FLOWPP_IMG_SPLIT_BELOW', '160'))
-# weight gradients (and the slab fold) on a side stream: nothing but the optimizer waits for them, and the data path's launches hold
-# 64 .. 256 workgroups each at B = 64.  Measured: 5.79 ms per Flowpp CIFAR-shape step against 5.57 on one stream (hipGraph replay; the
-# fork / join edges cost more than the overlap returns), so it is off unless asked for
-OVERLAP = os.environ.get('NF_FLOWPP_IMG_OVERLAP', '0') != '0'
-_SIDE = {}
-
-
-def _side_stream(dev):
-    s = _SIDE.get(dev)
-    if s is None:
-        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return s
+SPLIT_BELOW = 160
+# (the weight gradients on a side stream were tried and removed: 5.79 ms per Flowpp CIFAR-shape step against 5.57 on one stream -- the
+# fork / join edges of the hipGraph cost more than the overlap returns)
 HID = 32
 
 
@@ -135,23 +125,13 @@ class _FusedFlowppImg(torch.autograd.Function):
         (gW0, gb0, gWg, gbg, gl1g, gl1b, gpos, gc1w, gc1b, gc2w, gc2b, gl2g, gl2b, gW5, gb5) = dst
         lib = N.load()
         jobs = []
-        cur = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if OVERLAP else None
-        keep = []                                                # slabs written on the side stream stay alive until it is joined
 
         def wgrad(inp, g, gw, gb, Ci, Co, mode):
-            """slabs of one convolution's weight / bias gradient; folded into gw / gb (+=) by the one nf_slab_sum below.  With OVERLAP
-            the launch goes to the side stream, behind everything the main stream has enqueued so far (its operands)."""
+            """slabs of one convolution's weight / bias gradient; folded into gw / gb (+=) by the one nf_slab_sum below"""
             ns = int(lib.nf_flowpp_img_wgrad_slabs(B, Ci, Co, Hh, Ww))
             sw = torch.empty(ns * Co * Ci * 9 + ns * Co, dtype=torch.float32, device=dev)
             sb = sw[ns * Co * Ci * 9:]
-            keep.append(sw)
-            if side is not None:
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    N.call('nf_flowpp_img_conv_wgrad', N.ptr(inp), N.ptr(g), N.ptr(sw), sb.data_ptr(), ns, B, Ci, Co, Hh, Ww, mode, N.stream())
-            else:
-                N.call('nf_flowpp_img_conv_wgrad', N.ptr(inp), N.ptr(g), N.ptr(sw), sb.data_ptr(), ns, B, Ci, Co, Hh, Ww, mode, st)
+            N.call('nf_flowpp_img_conv_wgrad', N.ptr(inp), N.ptr(g), N.ptr(sw), sb.data_ptr(), ns, B, Ci, Co, Hh, Ww, mode, st)
             jobs.append((sw, gw, Co * Ci * 9, Co * Ci * 9, ns, True, 9))              # the slabs are tap-major (9, Co, Ci)
             jobs.append((sb, gb, Co, Co, ns, True, 1))
 
@@ -195,13 +175,7 @@ class _FusedFlowppImg(torch.autograd.Function):
             g_in = torch.empty_like(x_in)
             N.call('nf_flowpp_img_conv', N.ptr(g_x), N.ptr(W0), None, N.ptr(g_in), B, HID, I0, Hh, Ww, 0, 1, 1, st)
         from .fused_conv import _slab_sum_all
-        if side is not None:
-            side.wait_stream(cur)                                # the per-sample slabs of the middle, the last operands
-            with torch.cuda.stream(side):
-                _slab_sum_all(jobs)
-            cur.wait_stream(side)                                # joined before autograd (and the optimizer) see the gradients
-        else:
-            _slab_sum_all(jobs)
+        _slab_sum_all(jobs)
         if g_in is not None and S != Hh:
             g_in = g_in[:, :, :Hh, :Ww].contiguous()
         if direct:

@@ -30,7 +30,7 @@ class Identity(nn.Module):
         return x, log_df_dz
 
 
-GLOW_HEAD_W_ON = os.environ.get('NF_GLOW_HEAD_W', '1') != '0'
+GLOW_HEAD_W_ON = True           # (internal: the MFMA head of image flow steps, csrc/glow_head_mfma.hip)
 
 
 class Compose(nn.Module):

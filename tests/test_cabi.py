@@ -148,10 +148,6 @@ def test_conv_wgrad_slabs_host_logic(pkg):
     lib = pkg._native.load()
     f = lib.nf_conv_wgrad_slabs
     f.argtypes, f.restype = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int], ctypes.c_int
-    import os
-    if os.environ.get('NF_CONV_WGRAD_SLABS'):
-        import pytest
-        pytest.skip('NF_CONV_WGRAD_SLABS overrides the rule')
     assert f(64, 16, 16, 16) == 16          # 128 tiles, 16 layers
     assert f(64, 8, 8, 16) == 16            # 32 tiles
     assert f(64, 4, 4, 16) == 8             # 8 tiles in all

@@ -205,12 +205,20 @@ def test_convnet_beyond_the_chain_matches_modules(bulk, I, O, H, W, B, training)
     a, b = _nets(bulk, I, O)
     a.train(training)
     b.train(training)
-    x1 = (torch.randn(B, I, H, W, device=DEV)).requires_grad_(True)
+    # a batch WITHOUT a ReLU input inside rounding of zero (about four draws in five are): both paths then take the same ~5 M ReLU
+    # decisions and every gradient must agree to rounding.  (Round 4 took whatever draw came and multiplied the parameter tolerance by
+    # 2500 when it held a unit at risk.)
+    state = copy.deepcopy(b.state_dict())
+    for draw in range(32):
+        x1 = torch.randn(B, I, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1000 * B + draw))
+        risky = _risky_samples(b, x1)
+        b.load_state_dict(state)
+        if not bool(risky.any()):
+            break
+    assert not bool(risky.any()), 'no kink-free batch in 32 draws'
+    x1.requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
     assert fc.convnet_usable(a, x1) and not fc._chain_usable(B, I, O, H, W)
-    state = copy.deepcopy(b.state_dict())
-    risky = _risky_samples(b, x1)
-    b.load_state_dict(state)
     y1, y2 = a(x1), b(x2)
     G.assert_close(y1, y2, 2e-4, rtol=1e-4, what='output')
     wgt = torch.randn_like(y2)
@@ -218,7 +226,7 @@ def test_convnet_beyond_the_chain_matches_modules(bulk, I, O, H, W, B, training)
     (y2 * wgt).sum().backward()
     tol = lambda t: 2e-4 * max(1.0, float(t.abs().max()))
     _close_but_for(x1.grad, x2.grad, tol(x2.grad), risky, 'input grad')
-    loose = 2500.0 if bool(risky.any()) else 5.0
+    loose = 5.0
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     for name, p in pb.items():
         assert pa[name].grad is not None, name

@@ -50,7 +50,7 @@ def _nets(pkg, I, O):
                 m.weight.uniform_(0.5, 1.5)
                 m.bias.normal_(0, 0.3)
     b = copy.deepcopy(a)
-    a.fused = True                  # the fused kernels are opt-in (NF_FUSED_CONV=1); the tests always exercise them
+    a.fused = True                  # the HIP conditioner (the default: NF_FUSED_CONV=0 selects the module path); b = the module stack
     b.fused = False
     return a, b
 

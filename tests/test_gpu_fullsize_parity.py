@@ -70,11 +70,13 @@ TOL = 1.0e-5
 SLACK = 4.0
 FLIPS = 4          # kink events per pass whose footprint the per-step profile may carry (see the docstring)
 AMP = 1.3          # amplification of a gradient perturbation per flow step of the backward pass (measured)
-ENSEMBLE = 6       # row permutations of the batch the fp32 oracle is run on where that is cheap (C1, C2, C5)
+ENSEMBLE = 12      # row permutations of the batch the fp32 oracle AND the GPU path are run on where that is cheap (C1, C2, C5)
 ENSEMBLE_SLOW = 6  # ... and for C3 / C4 as well since the oracle's threads are capped (conftest.py: an fp32 step is ~1 s there, was 3 - 6 s)
 ENSEMBLE_IMAGE = 4 # row permutations for the image stacks of the second test (CIFAR / MNIST shape, (1, 24, 24))
 KINK_CAP = 0.05    # the per-step kink allowance never exceeds this
 KINK_FLAT = 3.0e-2  # flat-gradient (relative L2) footprint of one kink event, times the batch size (measured: <= 1.9e-4 at B = 64)
+ENS_RATIO = 3.0    # GPU ensemble vs fp32-oracle ensemble (flat gradient distance to float64): median and max within this factor
+BIMODAL = 8.0      # an oracle ensemble whose max exceeds this multiple of its median is treated as bimodal (see _compare_step)
 WIDE = 0.2         # ensemble envelope beyond which the bar is 1.25 x the envelope instead of 2 x
 
 CONFIGS = [
@@ -219,17 +221,26 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         # THE GPU HAS AN ENSEMBLE OF ITS OWN (round 5): the trainer's launch path run from the same weights on the same row permutations
         # as the fp32 oracle.  A single run of either implementation is one draw from a heavy-tailed distribution (which ReLU decisions
         # land on the other side of their kink); the two DISTRIBUTIONS must agree:
-        #     median(gpu) <= 2 x median(oracle) + 2 TOL        max(gpu) <= 1.5 x max(oracle) + 2 TOL
-        # (this replaces the round-4 bar `gpu <= 4 x max(oracle) + KINK_FLAT / B`, which one bad member of the yard-stick could carry)
+        #     median(gpu) <= ENS_RATIO x median(oracle) + 2 TOL        max(gpu) <= ENS_RATIO x max(oracle) + 2 TOL
+        # (this replaces the round-4 bar `gpu <= 4 x max(oracle) + KINK_FLAT / B`, which one bad member of the yard-stick could carry).
+        # Where the yard-stick itself is BIMODAL (max > BIMODAL x median: C1, whose distance is ~7e-3 or ~0.16 depending on ONE early-step
+        # unit -- tools/kink_odds.py: torch's own F.batch_norm path lands on the far side in 58 % of 48 row permutations on one x86 host
+        # and in 1 of 7 on another, profiles/r05_c1_kink_odds.txt) the median only says which mode has the majority on this host; there
+        # the GPU must REACH the near mode (its best member inside ENS_RATIO x the oracle's median) and stay inside the far one (max).
         if gpu_ensemble:
             rel_gpu_all = [rel_gpu] + [_flat_distance(m, r64) for m in gpu_ensemble]
             med_g, med_o = float(np.median(rel_gpu_all)), float(np.median(rel_ens))
+            bimodal = max(rel_ens) > BIMODAL * med_o
             _report('%-18s %-14s flat gradient distance to float64, GPU on the same %d row permutations: %s | median gpu %.3e oracle %.3e | '
-                    'max gpu %.3e oracle %.3e' % (name, tag, len(gpu_ensemble), ' '.join('%.2e' % v for v in rel_gpu_all[1:]), med_g, med_o,
-                                                  max(rel_gpu_all), max(rel_ens)))
-            if med_g > 2.0 * med_o + 2.0 * TOL:
+                    'max gpu %.3e oracle %.3e | min gpu %.3e oracle %.3e%s'
+                    % (name, tag, len(gpu_ensemble), ' '.join('%.2e' % v for v in rel_gpu_all[1:]), med_g, med_o, max(rel_gpu_all), max(rel_ens),
+                       min(rel_gpu_all), min(rel_ens), '  (oracle ensemble bimodal)' if bimodal else ''))
+            if bimodal:
+                if min(rel_gpu_all) > ENS_RATIO * med_o + 2.0 * TOL:
+                    bad.append(('best flat gradient distance to float64 over the ensemble (bimodal yard-stick)', min(rel_gpu_all), med_o))
+            elif med_g > ENS_RATIO * med_o + 2.0 * TOL:
                 bad.append(('median flat gradient distance to float64 over the ensemble', med_g, med_o))
-            if max(rel_gpu_all) > 1.5 * max(rel_ens) + 2.0 * TOL:
+            if max(rel_gpu_all) > ENS_RATIO * max(rel_ens) + 2.0 * TOL:
                 bad.append(('largest flat gradient distance to float64 over the ensemble', max(rel_gpu_all), max(rel_ens)))
         elif rel_gpu > 4.0 * max(rel_ens) + 2.0 * TOL + (0.0 if DETERMINISTIC() else KINK_FLAT / B):
             bad.append(('flat gradient distance to float64', rel_gpu, max(rel_ens)))

@@ -1,0 +1,75 @@
+"""
+Every environment switch of the engine (README.md: 12 after the round-5 pruning) at its NON-DEFAULT value against the default path: the
+same small model, weights and batch, two train steps, z / loss / every gradient tensor.  The switch is set in the ENVIRONMENT of a
+subprocess (that is what a user does), the default path runs in this process.  Both paths compute the same function; they differ in the
+order of fp32 sums, so z and the loss agree to 1e-5 (north_star's bar) and the flat gradient to 2e-5 relative (+ the cancelling
+zero-gradient biases in front of a BatchNorm, which are rounding noise on either path and are compared against the model's largest entry).
+NF_DROPIN / NF_REFERENCE_FLOWS are host-side (tests/test_dropin.py), NF_DP_* need a process group (tests/test_gpu_rccl.py).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import _switch_case as SC
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SWITCHES = [
+    # (switch, non-default value, case that runs through the code it selects)
+    ('NF_GLOW_FLOW', '0', 'glow2d'),
+    ('NF_GLOW_FLOW', 'steps', 'glow2d'),
+    ('NF_GLOW_FLOW', '0', 'realnvp2d'),
+    ('NF_FLOW_SOLO', '0', 'realnvp2d'),
+    ('NF_FLOW_SOLO', '3', 'realnvp2d'),
+    ('NF_MAF_FLOW', '0', 'maf2d'),
+    ('NF_FUSED_CONV', '0', 'glow_img'),
+    ('NF_CONV_CHAIN', '0', 'glow_img'),
+    ('NF_CONV_BULK', '0', 'glow_img_b320'),
+    ('NF_FLOWPP_IMG', '0', 'flowpp_img'),
+    ('NF_DETERMINISTIC', '1', 'glow_img'),
+    ('NF_DETERMINISTIC', '1', 'maf2d'),
+]
+_default = {}
+
+
+def _default_run(case):
+    if case not in _default:
+        for name, _, _ in SWITCHES:
+            assert name not in os.environ, '%s is set in the environment of the test run: the default path is not the default' % name
+        _default[case] = SC.run(case)
+    return _default[case]
+
+
+@pytest.mark.parametrize('switch,value,case', SWITCHES, ids=['%s=%s-%s' % s for s in SWITCHES])
+def test_switch_at_its_non_default_value_matches_the_default_path(tmp_path, switch, value, case):
+    want = _default_run(case)
+    out = tmp_path / 'out.npz'
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    env[switch] = value
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_switch_case.py'), case, str(out)], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = dict(np.load(str(out)))
+    assert set(got) == set(want)
+    for step in (0, 1):
+        z0, z1 = want['step%d/z' % step], got['step%d/z' % step]
+        assert np.abs(z1 - z0).max() <= 1e-5 * max(1.0, np.abs(z0).max()), ('z', step, np.abs(z1 - z0).max())
+        l0, l1 = float(want['step%d/loss' % step]), float(got['step%d/loss' % step])
+        assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0) / 16), ('loss', step, l0, l1)
+        keys = [k for k in want if k.startswith('step%d/grad/' % step)]
+        gmax = max(float(np.abs(want[k]).max()) for k in keys)
+        num = den = 0.0
+        for k in keys:
+            a, b = want[k].astype(np.float64).ravel(), got[k].astype(np.float64).ravel()
+            noise = k.endswith('module.bias') and 'out_block' not in k          # analytically zero (the bias feeds a BatchNorm)
+            if noise:
+                assert np.abs(a - b).max() <= 4e-5 * gmax, (k, step)
+                continue
+            num += float(((a - b) ** 2).sum())
+            den += float((a ** 2).sum())
+        rel = (num / max(den, 1e-300)) ** 0.5
+        assert rel <= 2.0e-5, ('flat gradient', step, rel)

@@ -60,7 +60,7 @@ cd $GRAFT_REPO_ROOT
 # large-batch kernels in isolation (conv_bulk.hip): forward / data gradient per layer, weight gradient per 16 layers, and its phase stamps
 python tools/probes/bulk_time.py 512 16 > $OUT/${R}_conv_bulk_times.txt 2>&1
 python tools/probes/bulk_time.py 512 8 >> $OUT/${R}_conv_bulk_times.txt 2>&1
-for h in 16 8; do python tools/probes/wgrad_time.py $h 512 16 >> $OUT/${R}_conv_bulk_times.txt 2>&1; NF_CONV_BULK_WGRAD=0 python tools/probes/wgrad_time.py $h 512 16 >> $OUT/${R}_conv_bulk_times.txt 2>&1; done
+for h in 16 8; do python tools/probes/wgrad_time.py $h 512 16 >> $OUT/${R}_conv_bulk_times.txt 2>&1; done
 # C1: the one-workgroup kernels (flow_solo.hip) in their settings, same box
 for m in 0 1 3; do echo "NF_FLOW_SOLO=$m" >> $OUT/${R}_c1_solo_modes.txt; NF_FLOW_SOLO=$m python bench.py --config c1 --skip-cpu --steps 50 | cut -c1-330 >> $OUT/${R}_c1_solo_modes.txt; done
 # model-level asymptotic sweep: CIFAR-shape Glow at B = 512, 2048 per GPU; 2-D models up to 2^22 rows

@@ -1,5 +1,5 @@
 """cpu_baseline thread sweep: the oracle's full train step (same workload as bench.py's cpu_baseline leg) at several intra-op
-thread counts on this box's host cores.  One measurement per round; bench.py keeps the fastest setting (NF_CPU_THREADS).
+thread counts on this box's host cores.  One measurement per round; bench.py keeps the fastest setting (`cpu_threads` of its CONFIGS).
 
     python tools/cpu_threads.py c4 8 16 32 64
 """

@@ -1,6 +1,6 @@
 """the deferred weight-gradient launch in isolation: sixteen 3x3 32->32 layers of one pyramid level per nf_conv_bn_wgrad_multi call,
 operands as the chain backward leaves them; checked against torch autograd's conv2d weight gradient, timed with events.
-    python tools/probes/wgrad_time.py H [B] [layers]          (NF_CONV_WGRAD_SLABS caps the slabs per layer)"""
+    python tools/probes/wgrad_time.py H [B] [layers]"""
 import ctypes, importlib, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
