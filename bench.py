@@ -233,7 +233,7 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
         per_step = glow and F._glow_steps_on(y)
         if per_step:
             entry, per_call = 'nf_glow_flow_steps_bwd', S + 1
-            flop = 17 * 2 * 32 * 32 * B                                   # 5 recomputed + 6 data-gradient + 6 weight-gradient 32x32 products
+            flop = 12 * 2 * 32 * 32 * B                                   # ALGORITHMIC: 6 data-gradient + 6 weight-gradient 32x32 products (the 5 recomputed forward ones are not counted)
             kname = 'k_mlp_chain_bwd<1> (whole Glow flow step, one launch, gradient fold deferred; average over %d step launches + 1 k_glow_fold_all)' % S
             pmc = ('k_mlp_chain_bwd', '')
             nbytes = B * (3 * D + 1) * 4
@@ -242,10 +242,20 @@ def dominant_kernel_roofline(pkg, name, cfg, B, dev, trainer, y, reps=3):
             if F.FLOW_DEFER_FOLD:
                 entry += '_deferred'                         # (+ the one k_glow_fold_all launch behind it, inside the bracket)
             per_call = 1
-            flop = S * 17 * 2 * 32 * 32 * B
-            kname = 'k_glow_flow_bwd<%d> (backward of all %d %s flow steps, one launch)' % (1 if glow else 2, S, 'Glow' if glow else 'RealNVP')
-            pmc = ('k_glow_flow_bwd', '<1>' if glow else '<2>')      # (C1 and C2 run two instantiations of the same kernel)
-            nbytes = S * B * (3 * D + 1) * 4
+            solo = (not glow) and D == 2 and B <= N.header_constant('NF_FLOW_SOLO_MAX_ROWS') and F.FLOW_DEFER_FOLD
+            if solo:
+                # C1: the one-workgroup backward (csrc/flow_solo.hip) reads the activations the forward stashed -- 12 products of 32 x 32 per
+                # row and step (6 data-gradient + 6 weight-gradient), no recomputed ones
+                flop = S * 12 * 2 * 32 * 32 * B
+                kname = 'k_solo_bwd (backward of all %d RealNVP flow steps in ONE workgroup, activations from the forward\'s stash; + k_glow_fold_all)' % S
+                pmc = ('k_solo_bwd', '')
+                nbytes = S * B * ((3 * D + 1) * 4 + 5 * 32 * 4)       # rows in / out + the stash read back
+                extra['workgroups'] = 1
+            else:
+                flop = S * 12 * 2 * 32 * 32 * B                  # ALGORITHMIC: 6 data-gradient + 6 weight-gradient products (the kernel also recomputes 5 forward ones: not counted)
+                kname = 'k_glow_flow_bwd<%d> (backward of all %d %s flow steps, one launch)' % (1 if glow else 2, S, 'Glow' if glow else 'RealNVP')
+                pmc = ('k_glow_flow_bwd', '<1>' if glow else '<2>')      # (C1 and C2 run two instantiations of the same kernel)
+                nbytes = S * B * (3 * D + 1) * 4
         match = None
         note = ('neither MFMA- nor HBM-bound at this batch: per flow step six grid-wide (or workgroup-wide) BatchNorm reductions and '
                 'single-tile issue latency serialise the launch (DESIGN.md sections 2 and 3.11)')
@@ -486,7 +496,9 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
                  'note': 'whole train step against both roofs: 2 x MACs of every conditioner convolution (forward + data gradient + '
                          'weight gradient) over the fp32-MFMA peak, and SURVEY 8(d)\'s ideal fused traffic over 8 TB/s'}
     elif len(cfg['dims']) == 1:
-        per_row = {'glow': 17 * 2 * 32 * 32, 'realnvp': 17 * 2 * 32 * 32, 'maf': 2 * 2 * 3 * (64 * cfg['dims'][0] + 2048)}.get(cfg['kind'])
+        # (products of 32 x 32 per row and flow step: 6 forward + 6 data-gradient + 6 weight-gradient; the kernels that recompute the
+        #  forward in their backward execute 5 more, which are not algorithmic work)
+        per_row = {'glow': 18 * 2 * 32 * 32, 'realnvp': 18 * 2 * 32 * 32, 'maf': 2 * 2 * 3 * (64 * cfg['dims'][0] + 2048)}.get(cfg['kind'])
         if cfg['kind'] == 'flowpp':
             # gated-attention conditioner of one coupling (coupling.py:159-166 at one position per sample): Linear(I0,32), the gate (32 -> 64),
             # the attention's value / output rows that survive (32 -> 32 + 32 -> 64), Linear(32, O); forward + data gradient + weight gradient

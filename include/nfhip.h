@@ -897,13 +897,21 @@ int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* 
 
 /* RealNVP runs with D = 2 and N <= 256 (training mode: nf_realnvp_flow_vec_fwd / nf_realnvp_flow_vec_bwd_deferred) can be served by
  * ONE workgroup that holds the whole batch (csrc/flow_solo.hip): no meeting in global memory.  mode bit 0 = the forward run, bit 1 =
- * the backward run (default 1: forward only, the measured optimum; the environment variable NF_FLOW_SOLO sets it at load; mode < 0
- * changes nothing); returns 0.  The one-workgroup backward's eight waves each leave a weight-gradient partial: for D = 2, N <= 256
- * the slabs_all / head_rec of nf_realnvp_flow_vec_bwd_deferred must hold NF_FLOW_SOLO_REGIONS regions per step (not
- * ceil(N / NF_MLP_ROWS_PER_BLOCK)), whichever kernel serves the call.                                                              */
+ * the backward run (it reads the activations the one-workgroup forward stashed, so it needs bit 0 as well; the environment variable
+ * NF_FLOW_SOLO sets the mode at load; mode < 0 changes nothing); returns 0.
+ * Buffer sizes of such a run do NOT follow the grid kernels' rule; ask, whichever kernel ends up serving the call:
+ *   nf_realnvp_flow_save_floats(N, D)  floats PER STEP of `saves`: the S statistics records (S x NF_REALNVP_SAVE_FLOATS, stride
+ *                                      NF_REALNVP_SAVE_FLOATS) are followed by S x NF_FLOW_SOLO_STASH_FLOATS floats of stashed
+ *                                      BatchNorm inputs for the shapes the one-workgroup kernels take (16-byte aligned base);
+ *   nf_realnvp_flow_bwd_regions(N, D)  regions per step of slabs_all / head_rec of nf_realnvp_flow_vec_bwd_deferred
+ *                                      (NF_FLOW_SOLO_REGIONS for those shapes, ceil(N / NF_MLP_ROWS_PER_BLOCK) otherwise).
+ * Both return the count (> 0), not an error code.                                                                                  */
 #define NF_FLOW_SOLO_MAX_ROWS 256
 #define NF_FLOW_SOLO_REGIONS 4
+#define NF_FLOW_SOLO_STASH_FLOATS (5 * 32 * 256)
 int nf_flow_solo_config(int mode);
+int nf_realnvp_flow_save_floats(int64_t N, int D);
+int nf_realnvp_flow_bwd_regions(int64_t N, int D);
 
 /* The persistent kernels above wait on each other with BOUNDED spin loops (a grid of <= NF_MLP_MAX_BLOCKS workgroups is
  * co-resident on an otherwise idle MI355X by construction).  A loop that gives up is counted; a non-zero count means some

@@ -305,12 +305,27 @@ __device__ __forceinline__ void so_batchnorm_train(float* sm, int j, const float
     so_barrier();
 }
 
+// the step's stash of BatchNorm inputs: [layer 0 .. 4][quad of registers 0 .. 3][thread] 16-byte words
+__device__ __forceinline__ void so_stash_put(f32x4s* st4, int l, const float (&a)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st4[(l * 4 + q) * NF_SO_THREADS] = f32x4s{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+}
+__device__ __forceinline__ void so_stash_get(const f32x4s* st4, int l, float (&a)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4s v = st4[(l * 4 + q) * NF_SO_THREADS];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[4 * q + k] = v[k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // forward, training mode
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_fwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* __restrict__ z0,
                                                             float* __restrict__ ys, float* __restrict__ ld, float* __restrict__ saves,
-                                                            int save_stride, int N, float eps, float mom, float wn_eps) {
+                                                            int save_stride, f32x4s* __restrict__ stash, int N, float eps, float mom,
+                                                            float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), c32 = lane & 31, hs = lane >> 5;
     unsigned long long (*rec)[SO_REC_WORDS] = reinterpret_cast<unsigned long long (*)[SO_REC_WORDS]>(sm + SO_REC);
@@ -391,6 +406,10 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_fwd(const NfGlowFlowStep
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[0][r] = fmaf(w0[r], x, 0.f) + b0[r];
         }
+        // the five BatchNorm inputs of the step are kept for the backward (no recompute there): 16-byte stores in register order,
+        // consecutive lanes consecutive addresses (160 KB per step, resident in L2 / the Infinity Cache until the backward reads them)
+        f32x4s* const st4 = stash + (size_t)s * (5 * 4 * NF_SO_THREADS) + t;
+        so_stash_put(st4, 0, a[0]);
         NF_SO_STAMP(s == 1, 2);
         so_batchnorm_train(sm, 0, a[0], N, eps, mom, rm_old, rv_old, nbt_old, st, save, c32, hs, wid);
         NF_SO_STAMP(s == 1, 3);
@@ -413,6 +432,7 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_fwd(const NfGlowFlowStep
                 if ((l & 1) == 0) v += a[l - 2][r];
                 a[l][r] = v + bias[r];
             }
+            so_stash_put(st4, l, a[l]);
             NF_SO_STAMP(s == 1, 2 + 2 * l);
             so_batchnorm_train(sm, l, a[l], N, eps, mom, rm_old, rv_old, nbt_old, st, save, c32, hs, wid);
             NF_SO_STAMP(s == 1, 3 + 2 * l);
@@ -507,7 +527,8 @@ __device__ __forceinline__ void so_wgrad(float* sm, float* slab_l, const float (
 __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* __restrict__ z0,
                                                             const float* __restrict__ ys, const float* __restrict__ g_y,
                                                             const float* __restrict__ g_ld, float* __restrict__ gzs,
-                                                            const float* __restrict__ saves, int save_stride, int accumulate,
+                                                            const float* __restrict__ saves, int save_stride,
+                                                            const f32x4s* __restrict__ stash, int accumulate,
                                                             float* __restrict__ slabs, float* __restrict__ head_rec, int N, float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), c32 = lane & 31, hs = lane >> 5;
@@ -544,6 +565,14 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
 #pragma unroll 1
     for (int s = S - 1; s >= 0; --s) {
         const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
+        // the step's five BatchNorm inputs, as the forward left them (no recompute), through a SLIDING WINDOW: stage J of the backward
+        // needs a[J] (ReLU mask, xhat) and a[J - 1] (what linear J multiplied with), so a[4] and a[3] are requested here -- the staging
+        // below covers their latency -- and a[J - 2] at the start of stage J: three of the five arrays are live at any time (48 registers
+        // instead of 80: with all five held from step to step the kernel spilled 85 registers)
+        const f32x4s* const st4 = stash + (size_t)s * (5 * 4 * NF_SO_THREADS) + t;
+        float a[5][16];
+        so_stash_get(st4, 4, a[4]);
+        so_stash_get(st4, 3, a[3]);
         NF_SO_STAMP(s == S - 2, 32);
         so_stage(sm, P, t);
         if (t < 160) {                                 // BatchNorm constants from the saved statistics
@@ -573,7 +602,7 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
         so_barrier();
         float* slab = slabs + ((size_t)s * regions + (wid >> 1)) * NF_MC_SLAB + (wid & 1) * NF_MC_SLAB_Q;   // + l * NF_MC_SLAB_L
         NF_SO_STAMP(s == S - 2, 33);
-        // ---- head and conditioner, recomputed ----
+        // ---- head (recomputed: two values per lane); the conditioner's activations come from the stash ----
         const int sel = st.h.odd ? 1 : 0;
         float h[2];
 #pragma unroll
@@ -581,36 +610,7 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
             const float zn = (zin[c] - sm[SO_HD + 4 + c]) / sm[SO_HD + 6 + c];
             h[c] = fmaf(sm[SO_HD + c], zn, 0.f) + sm[SO_HD + 2 + c];
         }
-        float a[5][16];
         const float xw = sel ? h[0] : h[1];
-        {
-            float w0[16], b0[16];
-            so_ldvec(sm + SO_V0, hs, w0);
-            so_ldvec(sm + SO_B, hs, b0);
-            const float x = xw * sm[SO_WS];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[0][r] = fmaf(w0[r], x, 0.f) + b0[r];
-        }
-#pragma unroll
-        for (int l = 1; l < 5; ++l) {
-            __builtin_amdgcn_sched_barrier(0);         // (no hoisting of a later layer's operand reads: the registers are full)
-            float sc[16], sh[16], ws[16], bias[16], A[16], act[16];
-            so_ldvec(sm + SO_BNC + (4 * (l - 1) + 0) * 32, hs, sc);
-            so_ldvec(sm + SO_BNC + (4 * (l - 1) + 1) * 32, hs, sh);
-            so_ldvec(sm + SO_WS + l * 32, hs, ws);
-            so_ldvec(sm + SO_B + l * 32, hs, bias);
-            so_ld_afwd(sm, l, c32, hs, A);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(a[l - 1][r], sc[r], sh[r]), 0.f) * ws[r];
-            f32x16 acc;
-            so_gemm(A, act, acc);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[r];
-                if ((l & 1) == 0) v += a[l - 2][r];
-                a[l][r] = v + bias[r];
-            }
-        }
         NF_SO_STAMP(s == S - 2, 34);
         // ---- linear 5 and the coupling's backward (coupling.py:104-113) -> G of the conditioner output, gradient of h ----
         float tg[16];                                  // in turn: the gradient of a ReLU output, its masked form gn, G_J
@@ -672,6 +672,8 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
         float gx = 0.f;
 #pragma unroll
         for (int J = 4; J >= 0; --J) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (J >= 2) so_stash_get(st4, J - 2, a[J - 2]);    // (needed one stage on: a stage is ~4 us, an L2 round trip well under 2)
             __builtin_amdgcn_sched_barrier(0);
             {
                 // the meeting: sum gn, sum gn xhat over the batch (+ the head sums of the step on its first round); one array at a time
@@ -751,6 +753,7 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
                     if (J == 2 || J == 4) Gs[r] = v;
                 }
             }
+
             NF_SO_STAMP(s == S - 2, 38 + 4 * (4 - J));
             __builtin_amdgcn_sched_barrier(0);
             if (J >= 1) {
@@ -811,12 +814,24 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
 static int nf_so_mode = -1;                           // bit 0: forward, bit 1: backward; the environment (NF_FLOW_SOLO) at first use, nf_flow_solo_config afterwards
 static int nf_so_enabled() {
     if (nf_so_mode < 0) {
-        // default 1 = forward only: measured at N = 256, S = 32 the one-workgroup forward takes 471 us against the two-workgroup grid
-        // kernel's 650, the one-workgroup backward 1035 against 796
+        // default 3 = both directions.  N = 256, S = 32: the one-workgroup forward takes 455 us against the two-workgroup grid kernel's
+        // 650; the one-workgroup backward took 1035 against 796 while it recomputed the forward -- since round 5 it reads the five
+        // BatchNorm inputs the forward stashed through a three-array sliding window (no recompute, 20 instead of 35 spilled registers):
+        // ~780 us, C1 1.312 -> 1.298 ms per step
         const char* e = getenv("NF_FLOW_SOLO");
-        nf_so_mode = e != nullptr ? (atoi(e) & 3) : 1;
+        nf_so_mode = e != nullptr ? (atoi(e) & 3) : 3;
     }
     return nf_so_mode;
+}
+// sizes a caller needs for a RealNVP run of N rows x D features in training mode (whichever kernel serves it)
+extern "C" int nf_realnvp_flow_save_floats(int64_t N, int D) {
+    const bool solo_shape = D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS;
+    return NF_REALNVP_SAVE_FLOATS + (solo_shape ? NF_FLOW_SOLO_STASH_FLOATS : 0);
+}
+extern "C" int nf_realnvp_flow_bwd_regions(int64_t N, int D) {
+    const int grid = (int)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
+    const bool solo_shape = D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS;
+    return solo_shape && grid < NF_FLOW_SOLO_REGIONS ? NF_FLOW_SOLO_REGIONS : grid;
 }
 extern "C" int nf_flow_solo_config(int mode) {
     nf_so_enabled();
@@ -824,7 +839,10 @@ extern "C" int nf_flow_solo_config(int mode) {
     return 0;
 }
 int nf_solo_plan(int64_t N, int D, int backward) {
-    return ((nf_so_enabled() >> (backward ? 1 : 0)) & 1) && D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS ? 1 : 0;
+    // (the one-workgroup backward reads the activations the one-workgroup forward stashed: it needs the forward bit as well)
+    const int m = nf_so_enabled();
+    const bool on = backward ? (m & 3) == 3 : (m & 1) != 0;
+    return on && D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS ? 1 : 0;
 }
 int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, int save_stride, int64_t N, float bn_eps,
                 float bn_momentum, float wn_eps, hipStream_t stream) {
@@ -835,8 +853,10 @@ int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float*
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
+    // the stash of BatchNorm inputs follows the S statistics records (include/nfhip.h: nf_realnvp_flow_save_floats)
+    f32x4s* stash = reinterpret_cast<f32x4s*>(saves + (size_t)S * save_stride);
     hipLaunchKernelGGL(k_solo_fwd, dim3(1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, ld, saves, save_stride,
-                       (int)N, bn_eps, bn_momentum, wn_eps);
+                       stash, (int)N, bn_eps, bn_momentum, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -850,8 +870,9 @@ int nf_solo_bwd(const void* steps_dev, int S, const float* z0, const float* ys, 
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
+    const f32x4s* stash = reinterpret_cast<const f32x4s*>(saves + (size_t)S * save_stride);
     hipLaunchKernelGGL(k_solo_bwd, dim3(1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y, g_ld, gzs, saves,
-                       save_stride, accumulate, slabs_all, head_rec, (int)N, wn_eps);
+                       save_stride, stash, accumulate, slabs_all, head_rec, (int)N, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -1031,7 +1031,8 @@ class _RealNVPFlowVec(torch.autograd.Function):
         dev = z.device
         table = _realnvp_flow_table(steps, sinks, D, dev)
         ys = torch.empty(S, Nrows, D, dtype=torch.float32, device=dev)
-        saves = torch.empty(S, N.header_constant('NF_REALNVP_SAVE_FLOATS'), dtype=torch.float32, device=dev)
+        # (S statistics records, then -- for the shapes the one-workgroup kernels take -- the stash of BatchNorm inputs: the library says how much)
+        saves = torch.empty(S * int(N.load().nf_realnvp_flow_save_floats(Nrows, D)), dtype=torch.float32, device=dev)
         ws = WS.zeros(S * N.header_constant('NF_MLP_WS_FLOATS'), dev)
         ctx.host = _GLOW_FLOW_HOST[table.data_ptr()] if per_step else None
         if per_step:       # one launch per step, the backward's gradient folds deferred to one launch (as for the Glow steps)
@@ -1061,10 +1062,7 @@ class _RealNVPFlowVec(torch.autograd.Function):
             N.call('nf_realnvp_flow_steps_bwd', ctypes.addressof(ctx.host), table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y),
                    _p(g_ld), N.ptr(gzs), N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, BN_EPS, WN_EPS, N.stream())
         elif FLOW_DEFER_FOLD:
-            rpb = N.header_constant('NF_MLP_ROWS_PER_BLOCK')
-            regions = (Nrows + rpb - 1) // rpb
-            if D == 2 and Nrows <= N.header_constant('NF_FLOW_SOLO_MAX_ROWS'):      # (the one-workgroup kernel's eight partials per step)
-                regions = max(regions, N.header_constant('NF_FLOW_SOLO_REGIONS'))
+            regions = int(N.load().nf_realnvp_flow_bwd_regions(Nrows, D))      # (the one-workgroup kernel leaves its own number of partials)
             slabs, rec = _glow_steps_scratch(S, regions, dev)
             N.call('nf_realnvp_flow_vec_bwd_deferred', table.data_ptr(), S, N.ptr(z), N.ptr(ys), N.ptr(g_y), _p(g_ld), N.ptr(gzs),
                    N.ptr(saves), 1, N.ptr(ws), N.ptr(slabs), N.ptr(rec), Nrows, D, BN_EPS, WN_EPS, N.stream())

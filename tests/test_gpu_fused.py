@@ -883,11 +883,12 @@ def test_realnvp_flow_vec_matches_step_by_step(pkg, D, B, K, mode, monkeypatch):
 
 
 
-@pytest.mark.parametrize('mode', [1, 2, 3])
+@pytest.mark.parametrize('mode', [1, 3])
 @pytest.mark.parametrize('B,K,seed', [(256, 4, 11), (256, 6, 12), (100, 3, 13), (17, 2, 14), (64, 2, 15)])
 def test_realnvp_one_workgroup_kernels_match_the_grid_kernels(pkg, B, K, seed, mode):
     """csrc/flow_solo.hip (the whole batch of a 2-D RealNVP run in ONE workgroup: features x batch tiles, sums over the batch through LDS
-    transposition tiles, per-wave weight-gradient partials) in its three settings -- forward only (the default), backward only, both --
+    transposition tiles, per-wave weight-gradient partials) in its two settings -- forward only, both directions (the default since
+    round 5: the backward reads the BatchNorm inputs the forward stashed, so it cannot run behind the grid forward) --
     against the grid kernels of csrc/mlp_chain.hip on the same weights and batch: outputs, loss, every gradient, the BatchNorm1d and
     flow-BatchNorm buffers; full batches, ragged ones (100 = three full waves + 4 columns, 17) and one that leaves waves empty.  Short
     runs: two fp32 paths drift apart by the same factor per step as either does from float64 (1e-3 at 32 steps, tools/probes/
@@ -908,7 +909,7 @@ def test_realnvp_one_workgroup_kernels_match_the_grid_kernels(pkg, B, K, seed, m
             torch.cuda.synchronize()
             outs.append((z.detach().clone(), float(loss), tr.bucket.flat.detach().clone(), {k: v.detach().clone() for k, v in net.named_buffers()}))
     finally:
-        N.call('nf_flow_solo_config', 1)
+        N.call('nf_flow_solo_config', 3)
     (z0, l0, g0, b0), (z1, l1, g1, b1) = outs
     G.assert_close(z1, z0, 5e-5, rtol=5e-5, what='z')
     assert abs(l1 - l0) <= 5e-5 * max(1.0, abs(l0)), (l1, l0)

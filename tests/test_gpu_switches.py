@@ -24,7 +24,7 @@ SWITCHES = [
     ('NF_GLOW_FLOW', 'steps', 'glow2d'),
     ('NF_GLOW_FLOW', '0', 'realnvp2d'),
     ('NF_FLOW_SOLO', '0', 'realnvp2d'),
-    ('NF_FLOW_SOLO', '3', 'realnvp2d'),
+    ('NF_FLOW_SOLO', '1', 'realnvp2d'),
     ('NF_MAF_FLOW', '0', 'maf2d'),
     ('NF_FUSED_CONV', '0', 'glow_img'),
     ('NF_CONV_CHAIN', '0', 'glow_img'),
