@@ -471,6 +471,18 @@ typedef struct nf_convnet_desc {
     /* Optional: the weights of layer l as LDS images (nf_conv_weight_pack below), NULL = the kernel splits w[l] itself.  With the
      * images a layer's weights reach LDS as direct global -> LDS loads issued under the previous layer's exchanges.            */
     const float* wpk[6];
+    /* Optional (hd_x != NULL; needs the coupling, cp_z != NULL): the HEAD of an image Glow step -- ActNorm and the invertible 1 x 1
+     * convolution in front of the coupling (flows/glow.py:24-46, flows/modules.py:246-249, 471-480) -- in the prologue of the launch, the
+     * work of nf_glow_head_w_fwd without its launch:  h = W ((hd_x - hd_bias) / exp(hd_ls)) per pixel.  cp_z is then an OUTPUT (the
+     * head's result h, (B, cp_C, Hf, Wf), kept for the backward), hd_x1 receives the conditioning half of h -- the conditioner's input:
+     * `x` must point to the same buffer -- and cp_ld[b] += Hf Wf sum_c (hd_log_s[c] - hd_ls[c]).  9 <= cp_C <= 64 (hd_W is the
+     * assembled cp_C x cp_C weight of the 1 x 1 convolution, nf_invconv_weight_fwd_multi).                                          */
+    const float* hd_x;        /* (B, cp_C, Hf, Wf) the step's input */
+    const float* hd_ls;       /* (cp_C,) ActNorm log_scale */
+    const float* hd_bias;     /* (cp_C,) ActNorm bias */
+    const float* hd_W;        /* (cp_C, cp_C) */
+    const float* hd_log_s;    /* (cp_C,) log |diagonal of U| of the PLU factors */
+    float* hd_x1;             /* (B, I0, H, W) written */
 } nf_convnet_desc;
 int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W);
 int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training, float bn_eps,

@@ -50,7 +50,9 @@ class ConvNetDesc(ctypes.Structure):
                 ('save_mean', ctypes.c_void_p * 5), ('save_invstd', ctypes.c_void_p * 5), ('ws_zero', ctypes.c_void_p),
                 ('cp_z', ctypes.c_void_p), ('cp_y', ctypes.c_void_p), ('cp_ld', ctypes.c_void_p), ('cp_a', ctypes.c_void_p),
                 ('cp_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int), ('cp_C', ctypes.c_int),
-                ('cp_inverse', ctypes.c_int), ('wpk', ctypes.c_void_p * 6)]
+                ('cp_inverse', ctypes.c_int), ('wpk', ctypes.c_void_p * 6),
+                ('hd_x', ctypes.c_void_p), ('hd_ls', ctypes.c_void_p), ('hd_bias', ctypes.c_void_p), ('hd_W', ctypes.c_void_p),
+                ('hd_log_s', ctypes.c_void_p), ('hd_x1', ctypes.c_void_p)]
 
 
 class ConvNetBwdDesc(ctypes.Structure):

@@ -191,13 +191,11 @@ def test_trainer_keeps_direct_gradient_sinks(pkg):
 
 
 
-@pytest.mark.parametrize('overlap', [False, True])
 @pytest.mark.parametrize('dims,B,K', [((3, 32, 32), 16, 2), ((3, 16, 16), 5, 3)])
-def test_trainer_deferred_conv_weight_gradients(pkg, dims, B, K, overlap, monkeypatch):
+def test_trainer_deferred_conv_weight_gradients(pkg, dims, B, K, monkeypatch):
     """inside a trainer step the image conditioners' backward launches only the data-gradient passes and the weight-gradient
     passes of all layers run sixteen per launch when the weight-norm backward asks for them (nf_conv_bn_bwd with g_weff =
-    NULL + nf_conv_bn_wgrad_multi): same loss and the same flat gradient as the unsplit launches.  ``overlap``: full groups of
-    sixteen layers leave for a side stream while the backward pass is still under way (ConvDefer.offload), joined in the flush."""
+    NULL + nf_conv_bn_wgrad_multi): same loss and the same flat gradient as the unsplit launches."""
     import copy
     import importlib
     from types import SimpleNamespace as NS
@@ -216,7 +214,6 @@ def test_trainer_deferred_conv_weight_gradients(pkg, dims, B, K, overlap, monkey
         return real_flush(self)
 
     monkeypatch.setattr(fc.ConvDefer, 'flush', flush)
-    monkeypatch.setattr(fc, 'CONV_OVERLAP_ON', overlap)
     for step in range(3):                                   # step 0 initialises the ActNorms (atomics: replicas re-synced below)
         monkeypatch.setattr(fc, 'CONV_DEFER_ON', True)
         z1, l1 = t1._forward_backward(y)
