@@ -640,6 +640,151 @@ __device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots,
     return (s == 0 ? 0 : (g.TH + 1) * g.FW) + x + 1;             // frame row 0 / TH + 1, column x + halo
 }
 
+// ---- the head of an image Glow step in the prologue of the forward launch ------------------------------------------------------------
+// h = W ((x - bias) / exp(ls)) per full-resolution pixel (ActNorm, flows/modules.py:246-249; invertible 1 x 1 convolution with its weight
+// assembled, :471-480), the arithmetic of k_glow_head_w_fwd (csrc/glow_head_mfma.hip): 16-pixel blocks, one per wave at a time, on
+// v_mfma_f32_16x16x4_f32 with the pixels as columns -- A[i = li][k = lk] = W[16 rt + li][4 q + lk] from LDS, B[k = lk][j = li] = the
+// normalised input -- and the reference's own rounding of the normalisation (a true division).
+// The workgroup computes the pixels it OWNS (whole samples; with the halo hand-over its rows of the sample) -> h (= cp_z, kept for the
+// backward) and y (= cp_y: the coupling's epilogue overwrites the transformed half), plus the rows its layer-0 frame reads from the
+// NEIGHBOUR tile (full rows fr_lo .. fr_hi - 1 around the owned fo_lo .. fo_hi - 1): of those only the conditioning half x1 is produced.
+// x1 goes to memory (the weight-gradient pass of convolution 0 reads it) AND into an LDS buffer X1 [sample][channel][half pixel - sp0]
+// from which the layer-0 frame is built: no store -> load round trip, no workgroup waits for another before its first convolution.
+// What made a first version cost as much as the launch it replaced (24.37 ms per C4 step either way) was its latency chain -- W and x
+// requested one after the other, the frame read back from memory: here the first block's pixels, W and the ActNorm vectors are
+// requested up front (nf_cc_head_request, before the frame is zeroed) and arrive under that work.
+// LDS (region RS, free until the first K-split exchange): Ws [64][65] | An [2][64] | X1.
+#define NF_CC_HD_WS 0
+#define NF_CC_HD_AN (64 * 65)
+#define NF_CC_HD_X1 (NF_CC_HD_AN + 128)
+#define NF_CC_HD_X1_MAX 3840                             // floats: the 4 x 4 level holds 2 samples x 96 channels x 16 pixels
+static_assert(NF_CC_HD_X1 + NF_CC_HD_X1_MAX <= NF_CC_MAX_BLOCKS * 65, "the head's LDS fits the exchange region");
+struct NfCcHeadReq {                                    // what a thread has in flight for the head
+    float w[3];                                         // W elements t, t + 1024, t + 2048
+    float an0, an1;                                     // threads < 64: bias, log_scale of channel t
+    float xv[16];                                       // the wave's first block: channel 4 q + lk at pixel li
+};
+template <int RT>
+__device__ __forceinline__ void nf_cc_head_request(NfCcHeadReq& R, const nf_convnet_desc& d, const NfSplit& cs, int64_t b0, int fr_lo,
+                                                   int per, int nblk, int64_t B) {
+    constexpr int KQ = 4 * RT;
+    const int C = cs.C, P = cs.H * cs.W;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int e = threadIdx.x + u * NF_CV_THREADS;
+        R.w[u] = e < C * C ? d.hd_W[e] : 0.f;
+    }
+    {
+        const int c = threadIdx.x < C ? threadIdx.x : 0;
+        R.an0 = d.hd_bias[c];
+        R.an1 = d.hd_ls[c];
+    }
+    {
+        const int blk = wid < nblk ? wid : 0, sidx = blk / per, rem = blk - sidx * per;
+        const int64_t b = (b0 + sidx) < B ? b0 + sidx : b0;
+        const float* xb = d.hd_x + b * cs.n_full + fr_lo * cs.W + (rem << 4) + li;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            R.xv[q] = xb[(int64_t)(c < C ? c : 0) * P];
+        }
+    }
+}
+template <int RT>
+__device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_convnet_desc& d, const NfSplit& cs, float* hl, int64_t b0,
+                                               int nsamp, int fr_lo, int fo_lo, int fo_hi, int per, int nblk, int sp0, int np1,
+                                               int64_t B, bool add_ld) {
+    constexpr int KQ = 4 * RT;
+    const int C = cs.C, P = cs.H * cs.W;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+    float* const hout = const_cast<float*>(d.cp_z);
+    float* const Ws = hl + NF_CC_HD_WS;
+    float* const An = hl + NF_CC_HD_AN;
+    float* const X1 = hl + NF_CC_HD_X1;
+    const int lgWf = 31 - __clz(cs.W);
+    {
+        const float rc = 1.f / (float)C;               // e / C for e < 4096 by reciprocal multiplication (the half-integer offset keeps the
+#pragma unroll                                          // quotient away from every integer)
+        for (int u = 0; u < 3; ++u) {
+            const int e = threadIdx.x + u * NF_CV_THREADS;
+            const int er = (int)(((float)e + 0.5f) * rc);
+            if (e < C * C) Ws[er * 65 + (e - er * C)] = R.w[u];
+        }
+    }
+    if (threadIdx.x < 64) {
+        An[threadIdx.x] = threadIdx.x < C ? R.an0 : 0.f;
+        An[64 + threadIdx.x] = threadIdx.x < C ? expf(R.an1) : 1.f;
+    }
+    if (wid == 1 && add_ld) {                           // log-det of the two layers: P (sum log_s - sum ls), one add per owned sample
+        float sl = lane < C ? d.hd_log_s[lane] - d.hd_ls[lane] : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, NF_WAVE);
+        if (lane < nsamp && b0 + lane < B) atomicAdd(d.cp_ld + b0 + lane, (float)P * sl);      // (one writer per sample: this workgroup)
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int blk = wid; blk < nblk; blk += NF_CV_WAVES) {
+        const int sidx = blk / per, rem = blk - sidx * per;
+        const int64_t b = b0 + sidx;
+        if (b >= B) continue;                           // (wave-uniform)
+        const int p = fr_lo * cs.W + (rem << 4) + li;
+        const int row = p >> lgWf, xx = p & (cs.W - 1);          // (power-of-two maps: no division anywhere in the element loop -- an integer
+        const bool own = row >= fo_lo && row < fo_hi;            //  division is ~40 instructions, two per output element were 8 us per launch)
+        const float* xb = d.hd_x + b * cs.n_full + p;
+        float xv[KQ];                                   // the block's pixels: the first block's came with the request
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            xv[q] = blk == wid ? R.xv[q] : xb[(int64_t)(c < C ? c : 0) * P];
+        }
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            const float bv = c < C ? (xv[q] - An[c]) / An[64 + c] : 0.f;     // (the reference's own rounding: a true division)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int r = 16 * rt + li;
+                const float a = (r < C && c < C) ? Ws[r * 65 + c] : 0.f;
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[rt], 0, 0, 0);
+            }
+        }
+        float* hb = hout + b * cs.n_full + p;
+        float* yb = d.cp_y + b * cs.n_full + p;
+        float* zb = d.hd_x1 + b * cs.n_half;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {               // D: column = li (pixel), row = 4 lk + j
+                const int r = 16 * rt + 4 * lk + j;
+                if (r < C) {
+                    const float v = acc[rt][j];
+                    if (own) { hb[(int64_t)r * P] = v; yb[(int64_t)r * P] = v; }
+                    // full element (channel r, pixel (row, xx)) -> half `which`, half channel m, half pixel sp  (squeeze.py:5-10, 32-44)
+                    int which, m, sp;
+                    if (cs.mode == NF_SPLIT_CHANNEL) {
+                        const int hc = C >> 1, sel = r >= hc ? 1 : 0;
+                        which = sel ^ cs.odd; m = r - sel * hc; sp = p;
+                    } else {
+                        const int k = 4 * r + 2 * (row & 1) + (xx & 1);
+                        const int qd = (k >= C ? 1 : 0) + (k >= 2 * C ? 1 : 0) + (k >= 3 * C ? 1 : 0);
+                        const int sel = (qd == 1 || qd == 2) ? 1 : 0;
+                        which = sel ^ cs.odd; m = sel ? k - C : (qd == 0 ? k : k - 2 * C);
+                        sp = (row >> 1) * cs.w + (xx >> 1);
+                    }
+                    if (which == 1) {
+                        zb[m * (cs.h * cs.w) + sp] = v;
+                        X1[(sidx * cs.Ch + m) * np1 + (sp - sp0)] = v;
+                    }
+                }
+            }
+    }
+    __syncthreads();                                    // X1 is complete (LDS); the stores to memory travel on their own
+}
+
 // LDS: ONE frame F8 (three bf16 planes) | W8 (three planes; aliased by the K-split exchange and the gather buffer of the grid exchange) |
 //      kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
 template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc, bool PK>
@@ -677,12 +822,34 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     unsigned long long* slots = (unsigned long long*)d.ws_zero;
 
     constexpr bool packed = PK;                         // compile-time: the weights arrive as LDS images (nf_conv_weight_pack)
+    constexpr bool cpl = CPL;                           // the coupling rides the epilogue of the output convolution (d.cp_z != NULL)
     NF_CC_STAMP(0);
+    // ---- the step's head (ActNorm + 1 x 1 convolution) rides the prologue: its operands are requested before anything else ----------
+    const bool headed = cpl && d.hd_x != nullptr;       // (block-uniform)
+    // the full-resolution rows of this workgroup: whole samples, or (halo hand-over) its rows of sample b0 plus the rows of the
+    // neighbours that its layer-0 frame reads (one half-map row each side: two full rows under the checkerboard split)
+    const int hf = cs.mode == NF_SPLIT_CHECKER ? 2 : 1;
+    const int h_ns = halo ? 1 : (g.HW < PXW ? PXW >> g.lgHW : 1);
+    const int h_olo = halo ? hf * y0 : 0, h_ohi = halo ? hf * (y0 + g.TH) : cs.H;
+    const int h_rlo = halo ? max(h_olo - hf, 0) : 0, h_rhi = halo ? min(h_ohi + hf, cs.H) : cs.H;
+    const int h_per = ((h_rhi - h_rlo) * cs.W) >> 4, h_nblk = h_ns * h_per;
+    const int h_sp0 = (h_rlo / hf) * g.W, h_np1 = ((h_rhi - h_rlo) / hf) * g.W;        // X1: half-map pixels sp0 .. sp0 + np1 - 1 per channel
+    NfCcHeadReq hreq;
+    if (headed) {
+        if (cs.C <= 16) nf_cc_head_request<1>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
+        else if (cs.C <= 48) nf_cc_head_request<3>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
+        else nf_cc_head_request<4>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
+    }
     // ---- zero the frame (halo and padding stay zero for the whole launch) ---------------------------------------------------
     for (int e = threadIdx.x; e < 3 * NF_CC_FP(g.CS); e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fr = sm + L.FA;
-    constexpr bool cpl = CPL;                           // the coupling rides the epilogue of the output convolution (d.cp_z != NULL)
-    if (cpl) {
+    if (headed) {
+        const bool add_ld = !halo || y0 == 0;
+        if (cs.C <= 16) nf_cc_head_fwd<1>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
+        else if (cs.C <= 48) nf_cc_head_fwd<3>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
+        else nf_cc_head_fwd<4>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
+    }
+    if (cpl && !headed) {
         // y <- z for this workgroup's (contiguous) samples, whole 16-byte vectors, no index arithmetic; the transformed half is
         // overwritten by the epilogue at the far end of the launch (same workgroup, barriers in between).  Nothing waits for it.
         if (!halo) {
@@ -735,8 +902,14 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
                 const int t = nf_cv_decode(g, b0, y0, f);
                 const int sp = t >= 0 ? NF_CV_SP(t) : 0, sg_ = t >= 0 ? NF_CV_SEG(t) : 0;
                 float v[8];
+                if (headed) {                           // (block-uniform) the conditioning half as the head left it in LDS
+                    const float* X1 = RS + NF_CC_HD_X1 + (sg_ * I0 + i0 + 8 * o) * h_np1 + (sp - h_sp0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (t >= 0 && 8 * o + j < IC) ? in0[(sg_ * I0 + i0 + 8 * o + j) * g.HW + sp] : 0.f;
+                    for (int j = 0; j < 8; ++j) v[j] = (t >= 0 && 8 * o + j < IC) ? X1[j * h_np1] : 0.f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (t >= 0 && 8 * o + j < IC) ? in0[(sg_ * I0 + i0 + 8 * o + j) * g.HW + sp] : 0.f;
+                }
                 nf_cc_frame_store8(Fr, CSr, o, f, v);
             }
             if (packed) nf_cc_dma_wait();
@@ -1625,10 +1798,21 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
         if (desc->cp_y == nullptr || desc->cp_ld == nullptr || desc->cp_a == nullptr || desc->cp_c == nullptr) return NF_E_BADARG;
         if (!nf_cc_coupling_split(cs, desc->cp_mode, desc->cp_odd, desc->cp_C, I0, O_out, H, W)) return NF_E_BADARG;
     }
+    if (desc->hd_x != nullptr) {                        // the step's head in the prologue: needs the coupling, 9 .. 64 channels, 16-pixel blocks
+        if (desc->cp_z == nullptr || desc->cp_inverse || desc->hd_ls == nullptr || desc->hd_bias == nullptr || desc->hd_W == nullptr ||
+            desc->hd_log_s == nullptr || desc->hd_x1 == nullptr || desc->hd_x1 != desc->x || desc->cp_C < 9 || desc->cp_C > 64 ||
+            ((cs.H * cs.W) & 15) != 0)
+            return NF_E_BADARG;
+    }
     NfCvGeo g;
     const int PX = nf_cc_tile_px(B, H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
     if ((training || H * W > PX) && desc->ws_zero == nullptr) return NF_E_BADARG;     // exchange slots (statistics; halo rows)
+    if (desc->hd_x != nullptr) {
+        // the conditioning half of a tile (+ its halo rows) must fit the head's LDS buffer; the halo hand-over is two tiles per sample
+        const int rows = H * W > PX ? PX / W + 2 : H, ns = H * W > PX ? 1 : PX / (H * W);
+        if ((int64_t)ns * I0 * rows * W > NF_CC_HD_X1_MAX || (H * W > PX && cs.W < 16)) return NF_E_BADARG;
+    }
     const int OCB = (O_out + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;

@@ -563,12 +563,17 @@ class _GlowHeadW(torch.autograd.Function):
     channels of image data: one MFMA launch per direction (csrc/glow_head_mfma.hip)."""
 
     @staticmethod
-    def forward(ctx, x, ld, log_scale, bias, W, log_s, holder, idx, mode, odd):
+    def forward(ctx, x, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=False):
         B, C, H, Wd = x.shape
         h = torch.empty_like(x)
         z1c = torch.empty(_half_shape(x, mode), dtype=x.dtype, device=x.device)
-        N.call('nf_glow_head_w_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(log_s), N.ptr(h), N.ptr(z1c),
-               N.ptr(ld), mode, int(odd), B, C, H, Wd, N.stream())
+        if defer:
+            # the launch is left to the coupling's chain kernel, whose prologue does this head's work (csrc/conv_chain.hip:
+            # nf_cc_head_fwd): it finds the operands under the address of h, which it receives as its z
+            PENDING_HEADS[h.data_ptr()] = (x, log_scale, bias, W, log_s, h, z1c, ld, mode, int(odd))
+        else:
+            N.call('nf_glow_head_w_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(log_s), N.ptr(h), N.ptr(z1c),
+                   N.ptr(ld), mode, int(odd), B, C, H, Wd, N.stream())
         ctx.save_for_backward(x, log_scale, bias, W)
         ctx.holder, ctx.idx, ctx.meta = holder, idx, (mode, int(odd))
         holder.meta[idx] = (B, H * Wd)
@@ -603,7 +608,23 @@ class _GlowHeadW(torch.autograd.Function):
         N.call('nf_glow_head_w_bwd', N.ptr(g_h), N.ptr(g_ld), N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(g_x), p_ls,
                p_b, N.ptr(g_W), B, C, H, Wd, N.stream())
         ctx.holder.g_ld[ctx.idx] = g_ld
-        return g_x, g_ld, g_ls, g_b, g_W, None, None, None, None, None
+        return g_x, g_ld, g_ls, g_b, g_W, None, None, None, None, None, None
+
+
+PENDING_HEADS = {}      # address of h -> operands of a head forward that its coupling's chain launch performs (_GlowHeadW.forward(defer=True))
+
+
+def flush_pending_head(h):
+    """launch the head whose output buffer is ``h`` on its own kernel, if it is still pending (a coupling that did not take the chain
+    launch after all); returns True if there was one"""
+    pend = PENDING_HEADS.pop(h.data_ptr(), None)
+    if pend is None:
+        return False
+    x, log_scale, bias, W, log_s, h_, z1c, ld, mode, odd = pend
+    B, C, H, Wd = x.shape
+    N.call('nf_glow_head_w_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(log_s), N.ptr(h_), N.ptr(z1c), N.ptr(ld), mode,
+           odd, B, C, H, Wd, N.stream())
+    return True
 
 
 def glow_head_w_usable(z, mode):
@@ -611,9 +632,10 @@ def glow_head_w_usable(z, mode):
             and bool(N.load().nf_glow_head_w_usable(z.shape[0], z.shape[1], z.shape[2], z.shape[3], int(mode))))
 
 
-def glow_head_w(z, ld, log_scale, bias, W, log_s, holder, idx, mode, odd):
-    """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward (weight given) -> conditioning half of the split, fused."""
-    return _GlowHeadW.apply(_contig(z), _owned_ld(ld), log_scale, bias, W, log_s, holder, idx, mode, odd)
+def glow_head_w(z, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=False):
+    """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward (weight given) -> conditioning half of the split, fused.
+    defer: no launch -- the caller guarantees that the coupling's chain launch follows and performs it (fused_conv._cn_forward)."""
+    return _GlowHeadW.apply(_contig(z), _owned_ld(ld), log_scale, bias, W, log_s, holder, idx, mode, odd, defer)
 
 
 HEAD_MAX_C = 4

@@ -394,6 +394,20 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
             y = torch.empty_like(z)
             d.cp_z, d.cp_y, d.cp_ld, d.cp_a, d.cp_c = z.data_ptr(), y.data_ptr(), ld.data_ptr(), a.data_ptr(), c.data_ptr()
             d.cp_mode, d.cp_odd, d.cp_C, d.cp_inverse = int(mode), int(odd), z.shape[1], int(inverse)
+            from . import functional as NF
+            pend = NF.PENDING_HEADS.pop(z.data_ptr(), None)
+            if pend is not None:
+                # the step's ActNorm + 1 x 1 convolution were left to this launch (functional._GlowHeadW.forward(defer=True)): z is the
+                # head's OUTPUT buffer, x its conditioning half -- both written by the prologue
+                hx, hls, hb, hW, hlog_s, h_, z1c_, ld_, hmode, hodd = pend
+                if (h_.data_ptr() == z.data_ptr() and z1c_.data_ptr() == x.data_ptr() and ld_.data_ptr() == ld.data_ptr() and not inverse
+                        and (hmode, hodd) == (int(mode), int(odd))):
+                    d.hd_x, d.hd_ls, d.hd_bias, d.hd_W, d.hd_log_s = (hx.data_ptr(), hls.data_ptr(), hb.data_ptr(), hW.data_ptr(),
+                                                                      hlog_s.data_ptr())
+                    d.hd_x1 = x.data_ptr()
+                else:                          # (not the tensors this launch works on: the head runs on its own kernel first)
+                    NF.PENDING_HEADS[z.data_ptr()] = pend
+                    NF.flush_pending_head(z)
         N.call('nf_convnet_chain_fwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), BN_EPS, BN_MOMENTUM, N.stream())
     else:
         if cpl is not None:
@@ -639,6 +653,25 @@ def coupling_fusable(net, z, mode):
     if B * half[2] * half[3] < CONV_COUPLING_MIN_PX:       # (experiment knob: a level whose launch has very few workgroups)
         return False
     return c0.in_channels == half[1] and c5.out_channels == 2 * half[1] and _chain_usable(B, half[1], 2 * half[1], half[2], half[3])
+
+
+def head_in_chain_ok(net, z, mode):
+    """the forward of the Glow head in front of this coupling can ride the coupling's chain launch (csrc/conv_chain.hip: nf_cc_head_fwd):
+    the coupling takes that launch, 9 .. 64 channels, and the conditioning half of one tile fits the head's LDS buffer"""
+    if not coupling_fusable(net, z, mode):
+        return False
+    B, C, Hf, Wf = z.shape
+    if C < 9 or C > 64 or (Hf * Wf) % 16:
+        return False
+    I0, Hh, Ww = (C // 2, Hf, Wf) if mode == N.SPLIT_CHANNEL else (2 * C, Hf // 2, Wf // 2)
+    blocks = int(N.load().nf_convnet_chain_blocks(B, I0, 2 * I0, Hh, Ww))
+    if blocks <= 0:
+        return False
+    px = -(-B * Hh * Ww // blocks)                           # pixels of a tile
+    px = 1 << (px - 1).bit_length()
+    if Hh * Ww > px:                                         # a sample over two tiles: its rows + one halo row each side
+        return Hh * Ww == 2 * px and Wf >= 16 and I0 * (px // Ww + 2) * Ww <= 3840
+    return (px // (Hh * Ww)) * I0 * Hh * Ww <= 3840
 
 
 def convnet_coupling(net, x, z, ld, a, c, mode, odd, inverse=False):

@@ -31,6 +31,7 @@ class Identity(nn.Module):
 
 
 GLOW_HEAD_W_ON = True           # (internal: the MFMA head of image flow steps, csrc/glow_head_mfma.hip)
+HEAD_IN_CHAIN = True            # (internal: that head's forward in the prologue of the coupling's chain launch, csrc/conv_chain.hip)
 
 
 class Compose(nn.Module):
@@ -203,8 +204,13 @@ class Compose(nn.Module):
                     NF.actnorm_init_(z, a.log_scale, a.bias, a.eps)
                     a.initialized = True
                 W, holder, idx = c._W_eff
-                h, z1c, log_df_dz = NF.glow_head_w(z, log_df_dz, a.log_scale, a.bias, W, c.log_s, holder, idx, k.mode, k.odd)
+                # the head's forward rides the prologue of the coupling's chain launch when that launch follows (round 5)
+                from . import fused_conv as FC
+                defer = HEAD_IN_CHAIN and isinstance(k.net, ConvNet) and z.is_contiguous() and FC.head_in_chain_ok(k.net, z, k.mode)
+                h, z1c, log_df_dz = NF.glow_head_w(z, log_df_dz, a.log_scale, a.bias, W, c.log_s, holder, idx, k.mode, k.odd, defer=defer)
                 z, log_df_dz = k.couple(h, z1c, log_df_dz)
+                if defer and NF.flush_pending_head(h):
+                    raise RuntimeError('a deferred Glow head was not performed by its coupling launch')
                 i += 3
             elif self._flowpp_pair_at(i, z):
                 z, log_df_dz = FUSED.flowpp_coupling_vec(z, log_df_dz, L[i], post=L[i + 1])   # coupling + next ActNorm

@@ -210,20 +210,28 @@ def test_convnet_beyond_the_chain_matches_modules(bulk, I, O, H, W, B, training)
     # and beta = +8 on the even channels (always on) / -8 on the odd ones (always off): both mask values and every code path are exercised,
     # no decision is ambiguous, and every gradient of the two paths must agree to rounding.
     x1 = torch.randn(B, I, H, W, device=DEV)
-    for beta in (8.0, 16.0, 32.0, 64.0):                  # (evaluation mode normalises with the initial running statistics: wider values)
-        with torch.no_grad():
-            for net in (a, b):
-                for m in net.modules():
-                    if isinstance(m, torch.nn.BatchNorm2d):
-                        m.weight.copy_(torch.linspace(0.5, 1.0, m.weight.numel(), device=DEV))
-                        m.bias.copy_(torch.where(torch.arange(m.bias.numel(), device=DEV) % 2 == 0, beta, -beta))
-        state = copy.deepcopy(b.state_dict())
-        risky = _risky_samples(b, x1)
-        b.load_state_dict(state)
-        a.load_state_dict(state)
-        if not bool(risky.any()):
-            break
-    assert not bool(risky.any()), 'a pre-activation within rounding of zero despite |beta| = 64'
+    with torch.no_grad():
+        for net in (a, b):
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.copy_(torch.linspace(0.5, 1.0, m.weight.numel(), device=DEV))
+                    m.bias.copy_(torch.where(torch.arange(m.bias.numel(), device=DEV) % 2 == 0, 8.0, -8.0))
+        if not training:
+            # evaluation mode normalises with the RUNNING statistics: give them this batch's (momentum 1 for one training-mode pass of
+            # the module stack), so that the normalised values are O(1) here as well
+            bns = [m for m in b.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+            for m in bns:
+                m.momentum = 1.0
+            b.train(True)
+            b.forward_reference(x1)
+            b.train(False)
+            for m in bns:
+                m.momentum = 0.1
+    state = copy.deepcopy(b.state_dict())
+    a.load_state_dict(state)
+    risky = _risky_samples(b, x1)
+    b.load_state_dict(state)
+    assert not bool(risky.any()), 'a pre-activation within rounding of zero despite |beta| = 8'
     x1.requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
     assert fc.convnet_usable(a, x1) and not fc._chain_usable(B, I, O, H, W)

@@ -233,10 +233,7 @@ def test_trainer_deferred_conv_weight_gradients(pkg, dims, B, K, monkeypatch):
         net2.load_state_dict(net1.state_dict())
         t2.bucket.flat_params.copy_(t1.bucket.flat_params)
     n_cond = sum(1 for m in net1.modules() if type(m).__name__ == 'ConvNet')
-    if overlap:
-        assert 0 < max(queued) < 6 * n_cond, 'no weight-gradient launch left early (queue lengths %r)' % (queued, )
-    else:
-        assert max(queued) == 6 * n_cond, 'weight-gradient passes were not deferred (queue lengths %r)' % (queued, )
+    assert max(queued) == 6 * n_cond, 'weight-gradient passes were not deferred (queue lengths %r)' % (queued, )
 
 
 @pytest.mark.parametrize('name,dims,datatype,B,K', [('Glow', (2, ), 'density', 4096, 4), ('Glow', (2, ), 'density', 512, 3),

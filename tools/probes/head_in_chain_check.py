@@ -16,3 +16,21 @@ for on in (True, False):
         z, loss = tr._forward_backward(y)
         n = len(t.durations_us())
     print('HEAD_IN_CHAIN', on, 'head fwd launches', n, 'loss', float(loss), float(z.abs().sum()))
+
+# durations of the chain forward launches per level, with and without the head in the prologue (HIP events around every launch)
+import collections
+for on in (True, False):
+    L.HEAD_IN_CHAIN = on
+    per = collections.defaultdict(list)
+    shapes = []
+    with N.timed_launches('nf_convnet_chain_fwd') as t:
+        orig = N.call
+        for _ in range(3):
+            tr._forward_backward(y)
+        d = t.durations_us()
+    with N.timed_launches('nf_glow_head_w_fwd') as t2:
+        for _ in range(3):
+            tr._forward_backward(y)
+        dh = t2.durations_us()
+    print('HEAD_IN_CHAIN', on, 'chain fwd launches %d, mean %.1f us, sum per step %.1f us | separate head launches %d, sum per step %.1f us'
+          % (len(d) // 3, sum(d) / len(d), sum(d) / 3, len(dh) // 3, sum(dh) / 3))
