@@ -755,6 +755,7 @@ class _FlowTableCache:
 _GLOW_FLOW_TABLES = _FlowTableCache(32)
 _GLOW_FLOW_HOST = _GLOW_FLOW_TABLES.host          # device table pointer -> the host copy of the same records
 _GLOW_FLOW_SLABS = {}
+_GRAPH_SEEN = [False]      # a hipGraph capture has asked for the deferred-fold scratch at least once (only then can a graph hold its address)
 
 
 def _glow_steps_scratch(S, blocks, device):
@@ -762,8 +763,12 @@ def _glow_steps_scratch(S, blocks, device):
     key = ('steps', device)
     n = S * blocks * N.header_constant('NF_MLP_BWD_SLAB_WG_FLOATS')
     t = _GLOW_FLOW_SLABS.get(key)
+    if torch.cuda.is_current_stream_capturing():
+        _GRAPH_SEEN[0] = True
     if t is None or t[0].numel() < n or t[1].numel() < S * blocks * 64:
-        if t is not None:
+        if t is not None and torch.cuda.is_current_stream_capturing() is False and not _GRAPH_SEEN[0]:
+            pass                                   # nothing captured yet can hold its address: the outgrown pair is simply freed
+        elif t is not None:
             # an outgrown pair may be in the kernel arguments of a captured hipGraph (the whole-flow backward with its deferred fold):
             # it is retired, not freed -- a later replay must not scribble over whatever the allocator placed there
             _GLOW_FLOW_SLABS.setdefault(('retired', device), []).append(t)

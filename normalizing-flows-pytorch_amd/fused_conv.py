@@ -491,7 +491,7 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
     valid = getattr(ctx, 'valid', None)
     vk = dict(valid_h=valid[0], valid_w=valid[1]) if valid else {}
     if valid:                                  # (the dead border of the gradient is never read)
-        gs = g_out.new_empty(B, O_out, Hh, Ww)
+        gs = g_out.new_zeros(B, O_out, Hh, Ww)      # (zero border: a kernel that forgets the mask reads zeros, not garbage)
         gs[:, :, :valid[0], :valid[1]] = g_out
         g_out = gs
     g_out = g_out.contiguous() if cpl is None else torch.empty_like(cpl[1])    # fused coupling: written by the chain launch

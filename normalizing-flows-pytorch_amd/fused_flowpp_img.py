@@ -71,7 +71,7 @@ class _FusedFlowppImg(torch.autograd.Function):
         dev, st = x_in.device, N.stream()
         S = int(N.load().nf_flowpp_img_storage(Hh, Ww))          # side of the storage map (= Hh on the CIFAR / MNIST pyramids)
         if S != Hh:                                              # the kernels never read the dead border: left uninitialised
-            xs = x_in.new_empty(B, I0, S, S)
+            xs = x_in.new_zeros(B, I0, S, S)                      # (zero border: nothing uninitialised can reach a batch sum)
             xs[:, :, :Hh, :Ww] = x_in
             x_in = xs
         x = torch.empty(B, HID, S, S, dtype=torch.float32, device=dev)
@@ -109,7 +109,7 @@ class _FusedFlowppImg(torch.autograd.Function):
         dev, st = x_in.device, N.stream()
         g_out = g_out.contiguous()
         if S != Hh:
-            gs = g_out.new_empty(B, O, S, S)
+            gs = g_out.new_zeros(B, O, S, S)
             gs[:, :, :Hh, :Ww] = g_out
             g_out = gs
         sinks = _sinks(*ts)

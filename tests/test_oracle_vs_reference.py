@@ -220,3 +220,21 @@ def test_elementwise_bijectors_and_squeeze1d_match_reference(ref_flows):
         assert torch.equal(tf.squeeze1d_layer(z, odd, inverse=True), rs.Squeeze1d(odd).backward(z, ld0[:5])[0])
         assert torch.equal(tf.squeeze1d_layer(z, odd, inverse=True), rs.Unsqueeze1d(odd).forward(z, ld0[:5])[0])
         assert torch.equal(tf.squeeze1d_layer(tf.squeeze1d_layer(z, odd), odd, inverse=True), z)
+
+
+def test_reference_invertible_res_conv2d_cannot_run(ref_flows):
+    """Why the engine has no InvertibleResConv2d (flows/iresblock.py:281-301): the reference's own block raises on its first call, in
+    training and in evaluation mode alike -- every log-det estimator reduces ``torch.sum(w * v, dim=1)`` (iresblock.py:76, 107), which for
+    (B, C, H, W) tensors leaves (B, H, W) and cannot be added to the (B,) log-det (iresblock.py:233); the exact estimator indexes
+    ``g[:, i]`` over ``z.size(1)`` channels.  No reference model reaches the class either (flows/resflow.py:19 builds the image branch as an
+    un-raised NotImplementedError).  There is no behaviour to reproduce; should upstream repair it, this test
+    turns red and the row is re-opened."""
+    import importlib
+    ib = importlib.import_module('ref_flows.iresblock')
+    torch.manual_seed(0)
+    blk = ib.InvertibleResConv2d(3, 3)
+    x = torch.rand(2, 3, 8, 8)
+    for mode in ('train', 'eval'):
+        getattr(blk, mode)()
+        with pytest.raises(RuntimeError):
+            blk(x, torch.zeros(2))
