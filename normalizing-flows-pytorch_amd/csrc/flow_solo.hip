@@ -495,6 +495,9 @@ __device__ __forceinline__ void so_saved(float& sv_mean, float& sv_inv, float& s
 
 // transposes G and act (sixteen registers each) through the wave's tiles and leaves the wave's partial of g_Weff[l] ([i][o]) + bias sums
 __device__ __forceinline__ void so_wgrad(float* sm, float* slab_l, const float (&act)[16], const float (&G)[16], int c32, int hs, int wid) {
+#ifdef NF_SO_NO_WGRAD                                  // (tools/probes/solo_prof.py --no-wgrad: what the backward costs WITHOUT its six
+    if (slab_l != nullptr) return;                     //  weight-gradient products -- the bound of handing them to a second workgroup)
+#endif
     float* TA = sm + SO_TILES + (wid * 2 + 0) * 32 * NF_SO_TS;
     float* TG = sm + SO_TILES + (wid * 2 + 1) * 32 * NF_SO_TS;
 #pragma unroll
@@ -524,14 +527,115 @@ __device__ __forceinline__ void so_wgrad(float* sm, float* slab_l, const float (
     if (hs == 0) slab_l[1024 + c32] = bsum;
 }
 
+// ---- the weight-gradient workgroup of the backward ------------------------------------------------------------------------------------
+// Wave w forms, step by step, the six products g_Weff[l] = sum over ITS 32 columns of act_l (x) G_l that wave w of the data path used
+// to form between its meetings: G_0 .. G_4, the two rows of G_5 and the conditioner's input x arrive through gbuf (written by the data
+// path's wave w, announced per step through flags[w]), what the linears multiplied with -- ReLU(BatchNorm(a_{l-1})) -- is recomputed
+// from the forward's stash and the saved statistics.  The BatchNorm constants of ALL steps are staged once (S x 5 x [scale | shift] x
+// 32 floats: 40 KB at S = 32), so the waves never meet: each one only follows its counterpart, a whole step behind at most by choice
+// of nobody -- the data path never waits for this workgroup.  Slabs and bias sums in the format the data path wrote (k_glow_fold_all).
+#define NF_SO_B_BLOCK 8                               // workgroups are dealt round-robin to the 8 XCDs: block 8 shares block 0's L2
+#define NF_SO_XCC_REG ((3 << 11) | 20)                // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4): the XCD this wave runs on
+#define SO_WK_BN 0                                    // worker LDS: [S][5][2][32] BatchNorm scale | shift, then the transposition tiles
+#define NF_SO_WK_MAX_STEPS 48                         // ... which bounds the run length the pair of workgroups takes (61 KB of tables)
+NF_PERSIST_STATE(nf_so)                               // (a worker wave that gave up waiting for its counterpart: counted and reported like
+NF_PERSIST_HOST_API(nf_so)                            //  every other bounded spin loop of the library, nf_persistent_timeouts)
+__device__ __forceinline__ void so_wgrad_worker(float* sm, const NfGlowFlowStep* __restrict__ steps, int S, const f32x4s* __restrict__ stash,
+                                                const f32x4s* __restrict__ gbuf, const unsigned* __restrict__ flags,
+                                                const float* __restrict__ saves, int save_stride, float* __restrict__ slabs, int N) {
+    const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), c32 = lane & 31, hs = lane >> 5;
+    constexpr int regions = NF_FLOW_SOLO_REGIONS;
+    float* const bn = sm + SO_WK_BN;
+    float* const tiles = sm + SO_WK_BN + S * 5 * 64;                           // so_wgrad addresses sm + SO_TILES: rebased below
+    for (int e = t; e < S * 160; e += NF_SO_THREADS) {                        // (step, BatchNorm j, feature f)
+        const int s = e / 160, jf = e - s * 160, j = jf >> 5, f = jf & 31;
+        const float* save = saves + (size_t)s * save_stride;
+        const float sc = steps[s].p.gamma[j][f] * save[(2 * j + 1) * 32 + f];
+        bn[(s * 5 + j) * 64 + f] = sc;
+        bn[(s * 5 + j) * 64 + 32 + f] = steps[s].p.beta[j][f] - save[(2 * j) * 32 + f] * sc;
+    }
+    if (t == 0) {
+        // both workgroups must share an XCD (its L2 is the only point of coherence the hand-over uses): the hardware deals workgroups to
+        // the XCDs round-robin, so block 8 sits where block 0 does -- a launch for which that does not hold fails LOUDLY (the sticky error
+        // word every persistent kernel of the library reports through), it does not return stale numbers
+        unsigned a = 0, spins = 0;
+        while (((a = __hip_atomic_load(flags + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x100u) == 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > nf_so_spin_limit) break;
+        }
+        if ((a & 0x100u) == 0u || (a & 15u) != (__builtin_amdgcn_s_getreg(NF_SO_XCC_REG) & 15u)) NF_PERSIST_GIVE_UP(nf_so);
+    }
+    so_barrier();
+    const int col = 32 * wid + c32;
+    const bool cv = col < N;
+    float* const smt = tiles - SO_TILES;                // so_wgrad(smt, ...) finds this wave's tiles at smt + SO_TILES
+#pragma unroll 1
+    for (int s = S - 1; s >= 0; --s) {
+        {                                               // the data path's wave of the same columns is through with step s
+            unsigned spins = 0;
+            while (__hip_atomic_load(flags + wid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(S - s)) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > nf_so_spin_limit) { NF_PERSIST_GIVE_UP(nf_so); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (orders the loads below behind the flag for the compiler; every
+                                                                        //  address is read once per launch: no stale line in this CU's L1)
+        }
+        const f32x4s* const st4 = stash + (size_t)s * (5 * 4 * NF_SO_THREADS) + t;
+        const f32x4s* const gb4 = gbuf + (size_t)s * (6 * 4 * NF_SO_THREADS) + t;
+        float* slab = slabs + ((size_t)s * regions + (wid >> 1)) * NF_MC_SLAB + (wid & 1) * NF_MC_SLAB_Q;   // + l * NF_MC_SLAB_L
+        const f32x4s g5x = gb4[(5 * 4) * NF_SO_THREADS];
+        float G[16], act[16], araw[16];
+        // linear 5: rows o = 0 (t), 1 (s_raw) of G, the rest zero; it multiplied with ReLU(BatchNorm 4)
+        so_stash_get(st4, 4, araw);
+        {
+            float sc[16], sh[16];
+            so_ldvec(bn + (s * 5 + 4) * 64, hs, sc);
+            so_ldvec(bn + (s * 5 + 4) * 64 + 32, hs, sh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                act[r] = fmaxf(fmaf(araw[r], sc[r], sh[r]), 0.f);
+                G[r] = (cv && hs == 0 && r == 0) ? g5x[0] : ((cv && hs == 0 && r == 1) ? g5x[1] : 0.f);
+            }
+        }
+        so_wgrad(smt, slab + 5 * NF_MC_SLAB_L, act, G, c32, hs, wid);
+#pragma unroll
+        for (int J = 4; J >= 1; --J) {
+            so_stash_get(gb4, J, G);
+            so_stash_get(st4, J - 1, araw);
+            float sc[16], sh[16];
+            so_ldvec(bn + (s * 5 + J - 1) * 64, hs, sc);
+            so_ldvec(bn + (s * 5 + J - 1) * 64 + 32, hs, sh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(araw[r], sc[r], sh[r]), 0.f);
+            so_wgrad(smt, slab + J * NF_MC_SLAB_L, act, G, c32, hs, wid);
+        }
+        // linear 0 (1 -> 32): row i = 0 of [i][o], the transposed product with x in feature row 0
+        so_stash_get(gb4, 0, G);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[r] = (hs == 0 && r == 0) ? g5x[2] : 0.f;
+        so_wgrad(smt, slab + 0 * NF_MC_SLAB_L, act, G, c32, hs, wid);
+    }
+}
+
 __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* __restrict__ z0,
                                                             const float* __restrict__ ys, const float* __restrict__ g_y,
                                                             const float* __restrict__ g_ld, float* __restrict__ gzs,
                                                             const float* __restrict__ saves, int save_stride,
-                                                            const f32x4s* __restrict__ stash, int accumulate,
+                                                            const f32x4s* __restrict__ stash, f32x4s* __restrict__ gbuf,
+                                                            unsigned* __restrict__ flags, int accumulate,
                                                             float* __restrict__ slabs, float* __restrict__ head_rec, int N, float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), c32 = lane & 31, hs = lane >> 5;
+    // TWO workgroups share the backward (round 5): block 0 walks the data path -- the serial chain of meetings and data-gradient
+    // products --, block NF_SO_B_BLOCK forms the six weight-gradient products of every step from what block 0 leaves in memory
+    // (so_wgrad_worker).  Nothing on the data path waits for a weight gradient: handing them over took 8.5 of the 24.7 us of a step off
+    // the chain (tools/probes/solo_prof.py --no-wgrad).  The blocks in between exit at once.
+    if (blockIdx.x == NF_SO_B_BLOCK) {
+        so_wgrad_worker(sm, steps, S, stash, gbuf, flags, saves, save_stride, slabs, N);
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    if (t == 0) __hip_atomic_store(flags + 8, 0x100u | (__builtin_amdgcn_s_getreg(NF_SO_XCC_REG) & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long (*rec)[SO_REC_WORDS] = reinterpret_cast<unsigned long long (*)[SO_REC_WORDS]>(sm + SO_REC);
     const bool rt = t < SO_REC_WORDS;
     constexpr int regions = NF_FLOW_SOLO_REGIONS;       // slab / head-sum regions per step: wave w writes region w >> 1, row group w & 1
@@ -565,14 +669,13 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
 #pragma unroll 1
     for (int s = S - 1; s >= 0; --s) {
         const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
-        // the step's five BatchNorm inputs, as the forward left them (no recompute), through a SLIDING WINDOW: stage J of the backward
-        // needs a[J] (ReLU mask, xhat) and a[J - 1] (what linear J multiplied with), so a[4] and a[3] are requested here -- the staging
-        // below covers their latency -- and a[J - 2] at the start of stage J: three of the five arrays are live at any time (48 registers
-        // instead of 80: with all five held from step to step the kernel spilled 85 registers)
+        // the step's five BatchNorm inputs, as the forward left them (no recompute), through a SLIDING WINDOW: stage J of the data path
+        // needs a[J] only (ReLU mask, xhat), so a[4] is requested here -- the staging below covers its latency -- and a[J - 1] at the
+        // start of stage J: two of the five arrays are live at any time (32 registers instead of 80)
         const f32x4s* const st4 = stash + (size_t)s * (5 * 4 * NF_SO_THREADS) + t;
+        f32x4s* const gb4 = gbuf + (size_t)s * (6 * 4 * NF_SO_THREADS) + t;      // what the worker reads of this step: G_0 .. G_4, (g5, x)
         float a[5][16];
         so_stash_get(st4, 4, a[4]);
-        so_stash_get(st4, 3, a[3]);
         NF_SO_STAMP(s == S - 2, 32);
         so_stage(sm, P, t);
         if (t < 160) {                                 // BatchNorm constants from the saved statistics
@@ -600,7 +703,6 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
         }
         so_weight_norm(sm, t, wn_eps);
         so_barrier();
-        float* slab = slabs + ((size_t)s * regions + (wid >> 1)) * NF_MC_SLAB + (wid & 1) * NF_MC_SLAB_Q;   // + l * NF_MC_SLAB_L
         NF_SO_STAMP(s == S - 2, 33);
         // ---- head (recomputed: two values per lane); the conditioner's activations come from the stash ----
         const int sel = st.h.odd ? 1 : 0;
@@ -650,19 +752,9 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
                 for (int r = 0; r < 16; ++r) tg[r] = (v50[r] * gy0 + v51[r] * gsraw) * ws[r];
             }
             __builtin_amdgcn_sched_barrier(0);
-            {
-                // linear 5's partial [i][o] and bias sums: the same transposed product as the hidden layers -- rows o = 0 (t), 1 (s_raw)
-                // of G, the rest zero
-                float sc[16], sh[16], pre[16], g5[16];
-                so_ldvec(sm + SO_BNC + (4 * 4 + 0) * 32, hs, sc);
-                so_ldvec(sm + SO_BNC + (4 * 4 + 1) * 32, hs, sh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    pre[r] = fmaxf(fmaf(a[4][r], sc[r], sh[r]), 0.f);
-                    g5[r] = (hs == 0 && r == 0) ? gy0 : ((hs == 0 && r == 1) ? gsraw : 0.f);
-                }
-                so_wgrad(sm, slab + 5 * NF_MC_SLAB_L, pre, g5, c32, hs, wid);
-            }
+            // linear 5's and linear 0's weight gradients are the worker's: it needs the two rows of G_5 (t, s_raw) and the conditioner's
+            // input of this column
+            gb4[(5 * 4) * NF_SO_THREADS] = f32x4s{gy0, gsraw, xw, 0.f};
         }
         NF_SO_STAMP(s == S - 2, 35);
         // ---- BatchNorm J backward, then linear J: J = 4 .. 0 ----
@@ -673,7 +765,7 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
 #pragma unroll
         for (int J = 4; J >= 0; --J) {
             __builtin_amdgcn_sched_barrier(0);
-            if (J >= 2) so_stash_get(st4, J - 2, a[J - 2]);    // (needed one stage on: a stage is ~4 us, an L2 round trip well under 2)
+            if (J >= 1) so_stash_get(st4, J - 1, a[J - 1]);    // (needed one stage on: a stage is ~3 us, an L2 round trip well under 2)
             __builtin_amdgcn_sched_barrier(0);
             {
                 // the meeting: sum gn, sum gn xhat over the batch (+ the head sums of the step on its first round); one array at a time
@@ -753,19 +845,12 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
                     if (J == 2 || J == 4) Gs[r] = v;
                 }
             }
+            so_stash_put(gb4, J, tg);                          // G_J for the worker (16-byte stores in register order; nothing waits for them)
 
             NF_SO_STAMP(s == S - 2, 38 + 4 * (4 - J));
             __builtin_amdgcn_sched_barrier(0);
             if (J >= 1) {
-                // linear J: what it multiplied with (before the weight-norm scale), its weight-gradient partial, its data gradient
-                {
-                    float scp[16], shp[16], act[16];
-                    so_ldvec(sm + SO_BNC + (4 * (J - 1) + 0) * 32, hs, scp);
-                    so_ldvec(sm + SO_BNC + (4 * (J - 1) + 1) * 32, hs, shp);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) act[r] = fmaxf(fmaf(a[J - 1][r], scp[r], shp[r]), 0.f);
-                    so_wgrad(sm, slab + J * NF_MC_SLAB_L, act, tg, c32, hs, wid);
-                }
+                // linear J's data gradient (its weight gradient is the worker's)
                 NF_SO_STAMP(s == S - 2, 39 + 4 * (4 - J));
                 __builtin_amdgcn_sched_barrier(0);
                 float ws[16], A[16];
@@ -776,18 +861,14 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tg[r] = acc[r] * ws[r];
             } else {
-                // linear 0 (1 -> 32): its partial is row i = 0 of [i][o] (the transposed product with x in feature row 0), g_x on the vector ALU
-                float w0[16], x0v[16];
+                // linear 0 (1 -> 32): g_x on the vector ALU
+                float w0[16];
                 so_ldvec(sm + SO_V0, hs, w0);
                 float gp = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    gp = fmaf(tg[r], w0[r], gp);
-                    x0v[r] = (hs == 0 && r == 0) ? xw : 0.f;
-                }
+                for (int r = 0; r < 16; ++r) gp = fmaf(tg[r], w0[r], gp);
                 gp += __shfl_xor(gp, 32, NF_WAVE);
                 gx = gp * sm[SO_WS];
-                so_wgrad(sm, slab + 0 * NF_MC_SLAB_L, x0v, tg, c32, hs, wid);
             }
         }
         NF_SO_STAMP(s == S - 2, 56);
@@ -803,6 +884,11 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
             gr[0] = gy[0]; gr[1] = gy[1];
         }
         zin[0] = zn_[0]; zin[1] = zn_[1];
+        // the step's G arrays are out: tell the worker's wave of the same columns (one flag per wave).  The two workgroups sit on the SAME
+        // XCD (checked below), whose L2 is the point of coherence of both: this wave's stores only have to have arrived there (vmcnt) --
+        // an agent-scope release would write the whole L2 back (buffer_wbl2), 3.5 us per step on the data path
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(flags + wid, (unsigned)(S - s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         NF_SO_STAMP(s == S - 2, 57);
         so_barrier();
         NF_SO_STAMP(s == S - 2, 58);
@@ -826,7 +912,7 @@ static int nf_so_enabled() {
 // sizes a caller needs for a RealNVP run of N rows x D features in training mode (whichever kernel serves it)
 extern "C" int nf_realnvp_flow_save_floats(int64_t N, int D) {
     const bool solo_shape = D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS;
-    return NF_REALNVP_SAVE_FLOATS + (solo_shape ? NF_FLOW_SOLO_STASH_FLOATS : 0);
+    return NF_REALNVP_SAVE_FLOATS + (solo_shape ? NF_FLOW_SOLO_STASH_FLOATS + NF_FLOW_SOLO_GBUF_FLOATS : 0);
 }
 extern "C" int nf_realnvp_flow_bwd_regions(int64_t N, int D) {
     const int grid = (int)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
@@ -844,6 +930,7 @@ int nf_solo_plan(int64_t N, int D, int backward) {
     const bool on = backward ? (m & 3) == 3 : (m & 1) != 0;
     return on && D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS ? 1 : 0;
 }
+int nf_solo_bwd_steps_ok(int S) { return S >= 1 && S <= NF_SO_WK_MAX_STEPS; }
 int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, int save_stride, int64_t N, float bn_eps,
                 float bn_momentum, float wn_eps, hipStream_t stream) {
     const size_t lds = nf_so_lds_bytes(false);
@@ -861,18 +948,26 @@ int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float*
     return 0;
 }
 int nf_solo_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld, float* gzs,
-                const float* saves, int save_stride, int accumulate, float* slabs_all, float* head_rec, int64_t N, float wn_eps,
-                hipStream_t stream) {
-    const size_t lds = nf_so_lds_bytes(true);
-    static bool attr = false;
-    if (!attr) {
+                const float* saves, int save_stride, int accumulate, float* ws_zero, float* slabs_all, float* head_rec, int64_t N,
+                float wn_eps, hipStream_t stream) {
+    if (!nf_solo_bwd_steps_ok(S) || ws_zero == nullptr) return NF_E_BADARG;
+    // the data path's tables, or the worker's (BatchNorm constants of all steps + the transposition tiles): whichever is larger
+    size_t lds = nf_so_lds_bytes(true);
+    const size_t lds_w = sizeof(float) * ((size_t)S * 5 * 64 + (size_t)NF_SO_WAVES * 2 * 32 * NF_SO_TS);
+    if (lds_w > lds) lds = lds_w;
+    static size_t attr = 0;
+    if (lds > attr) {
         hipError_t e = hipFuncSetAttribute((const void*)k_solo_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        attr = lds;
     }
+    // saves: S statistics records | S stashes of BatchNorm inputs (forward) | S hand-over areas data path -> worker (this launch);
+    // flags: the first eight words of the zeroed exchange workspace
     const f32x4s* stash = reinterpret_cast<const f32x4s*>(saves + (size_t)S * save_stride);
-    hipLaunchKernelGGL(k_solo_bwd, dim3(1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y, g_ld, gzs, saves,
-                       save_stride, stash, accumulate, slabs_all, head_rec, (int)N, wn_eps);
+    f32x4s* gbuf = const_cast<f32x4s*>(stash) + (size_t)S * (NF_FLOW_SOLO_STASH_FLOATS / 4);
+    hipLaunchKernelGGL(k_solo_bwd, dim3(NF_SO_B_BLOCK + 1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y,
+                       g_ld, gzs, saves, save_stride, stash, gbuf, reinterpret_cast<unsigned*>(ws_zero), accumulate, slabs_all, head_rec,
+                       (int)N, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
 }

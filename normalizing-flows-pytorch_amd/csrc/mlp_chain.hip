@@ -2020,11 +2020,12 @@ extern "C" int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, co
                                                 const float* g_ld, float* gzs, const float* saves, int accumulate, float* ws_zero,
                                                 float* slabs_all, float* head_rec, int64_t N, int D, float bn_eps, float wn_eps,
                                                 nf_stream_t stream) {
-    if (nf_solo_plan(N, D, 1) && steps_dev != nullptr && S >= 1 && S <= NF_GLOW_FLOW_MAX_STEPS && z0 != nullptr && ys != nullptr &&
-        g_y != nullptr && gzs != nullptr && saves != nullptr && slabs_all != nullptr && head_rec != nullptr) {
-        // the whole batch in one workgroup (flow_solo.hip); its slabs and head sums are folded by the same launch as the grid kernel's
-        const int rc = nf_solo_bwd(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, slabs_all, head_rec, N,
-                                   wn_eps, (hipStream_t)stream);
+    if (nf_solo_plan(N, D, 1) && nf_solo_bwd_steps_ok(S) && steps_dev != nullptr && z0 != nullptr && ys != nullptr &&
+        g_y != nullptr && gzs != nullptr && saves != nullptr && ws_zero != nullptr && slabs_all != nullptr && head_rec != nullptr) {
+        // the whole batch in one workgroup + one for the weight gradients (flow_solo.hip); their slabs and head sums are folded by the
+        // same launch as the grid kernel's
+        const int rc = nf_solo_bwd(steps_dev, S, z0, ys, g_y, g_ld, gzs, saves, NF_REALNVP_SAVE_FLOATS, accumulate, ws_zero, slabs_all,
+                                   head_rec, N, wn_eps, (hipStream_t)stream);
         if (rc != 0) return rc;
         const size_t lds_fold = nf_mc_lds_bytes(1);
         hipError_t e = hipFuncSetAttribute((const void*)k_glow_fold_all<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fold);
@@ -2189,15 +2190,18 @@ __attribute__((visibility("hidden"))) int nf_md_persist_read(unsigned* v);      
 __attribute__((visibility("hidden"))) int nf_md_persist_set(unsigned limit, unsigned* flag_dev, int reset);
 __attribute__((visibility("hidden"))) int nf_cc_persist_read(unsigned* v);                                 // conv_chain.hip
 __attribute__((visibility("hidden"))) int nf_cc_persist_set(unsigned limit, unsigned* flag_dev, int reset);
+__attribute__((visibility("hidden"))) int nf_so_persist_read(unsigned* v);                                 // flow_solo.hip
+__attribute__((visibility("hidden"))) int nf_so_persist_set(unsigned limit, unsigned* flag_dev, int reset);
 
 extern "C" int nf_persistent_timeouts(int* count) {
     if (count == nullptr) return NF_E_BADARG;
-    unsigned v = 0, v2 = 0, v3 = 0;
+    unsigned v = 0, v2 = 0, v3 = 0, v4 = 0;
     int e = nf_mc_persist_read(&v);
     if (e == 0) e = nf_md_persist_read(&v2);
     if (e == 0) e = nf_cc_persist_read(&v3);
+    if (e == 0) e = nf_so_persist_read(&v4);
     if (e != 0) return e;
-    *count = (int)(v + v2 + v3);
+    *count = (int)(v + v2 + v3 + v4);
     return 0;
 }
 
@@ -2226,6 +2230,7 @@ extern "C" int nf_persistent_config(int64_t spin_limit, int reset, void** host_e
     int e = nf_mc_persist_set(lim, g_persist_dev_word, reset);
     if (e == 0) e = nf_md_persist_set(lim, g_persist_dev_word, reset);
     if (e == 0) e = nf_cc_persist_set(lim, g_persist_dev_word, reset);
+    if (e == 0) e = nf_so_persist_set(lim, g_persist_dev_word, reset);
     if (e != 0) return e;
     if (host_error_word != nullptr) *host_error_word = (void*)g_persist_host_word;
     return 0;

@@ -47,6 +47,7 @@ struct NfGlowFlowStep { NfMlpP p; NfMlpG g; NfGlowV h; };     // the static poin
 int nf_solo_plan(int64_t N, int D, int backward);
 int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float* ld, float* saves, int save_stride, int64_t N, float bn_eps,
                 float bn_momentum, float wn_eps, hipStream_t stream);
+int nf_solo_bwd_steps_ok(int S);
 int nf_solo_bwd(const void* steps_dev, int S, const float* z0, const float* ys, const float* g_y, const float* g_ld, float* gzs,
-                const float* saves, int save_stride, int accumulate, float* slabs_all, float* head_rec, int64_t N, float wn_eps,
-                hipStream_t stream);
+                const float* saves, int save_stride, int accumulate, float* ws_zero, float* slabs_all, float* head_rec, int64_t N,
+                float wn_eps, hipStream_t stream);

@@ -433,6 +433,16 @@ def test_c1_kink_free_seed_meets_the_strict_bar_on_every_tensor(pkg):
     assert sum(e['flips'] for e in st.values()) == 0 and sum(e['risk'] for e in st.values()) == 0, st
     r32 = traj.run('realnvp', (2, ), '2d', L, sd, y, 1, dtype=torch.float32)[0][1]
     r64 = traj.run('realnvp', (2, ), '2d', L, sd, y, 1, dtype=torch.float64)[0][1]
+    # the fp32 yard-stick as an ENVELOPE: the oracle on six row permutations of the batch (a symmetry of the exact problem, another
+    # rounding order; the case stays kink-free under them -- the census margin is 8 x the fp32 / fp64 difference).  A single run's
+    # |cpu32 - cpu64| of a two-element bias gradient that is a sum of 256 cancelling terms is one draw, the envelope is the scale.
+    gp = torch.Generator().manual_seed(99)
+    env = {k: float((r32['grads'][k].double() - v).abs().max()) for k, v in r64['grads'].items()}
+    for _ in range(6):
+        pm = torch.randperm(B, generator=gp)
+        rp = traj.run('realnvp', (2, ), '2d', L, sd, y[pm], 1, dtype=torch.float32)[0][1]
+        for k, v in r64['grads'].items():
+            env[k] = max(env[k], float((rp['grads'][k].double() - v).abs().max()))
     net = net.to(DEV)
     assert F._flow_on(torch.empty(B, 2, device=DEV)), 'B = 256 must take the whole-flow launch (the C1 path)'
     trainer = nftrain.FlowTrainer(net, graph=False)
@@ -457,11 +467,10 @@ def test_c1_kink_free_seed_meets_the_strict_bar_on_every_tensor(pkg):
         # implementation returns there is rounding noise around zero -- bounded against the largest gradient
         # entry of the model, not matched
         noise = k.endswith('module.bias') and 'out_block' not in k
-        # (2 x SLACK on the float64 gap since round 4: the forward is the one-workgroup kernel of csrc/flow_solo.hip, whose summation
-        # order differs from the oracle's in every product and statistic -- z is CLOSER to float64 than with the grid kernel (4.1e-5
-        # against 5.8e-5 here), but the sums behind the two-element out_block biases no longer share the oracle's rounding: 8.8e-5
-        # of the tensor's largest entry against a bar of 7.5e-5 at SLACK)
-        if err > (2.0 * TOL * G if noise else 2.0 * TOL * s + 2.0 * SLACK * gap):
+        # (1 x SLACK on the ENVELOPE of the fp32 oracle over row permutations -- round 4 took 2 x SLACK on the single unpermuted run, whose
+        # gap is one draw: the one-workgroup kernels of csrc/flow_solo.hip sum in another order than the oracle in every product and statistic)
+        gap = max(gap, env[k])
+        if err > (2.0 * TOL * G if noise else 2.0 * TOL * s + SLACK * gap):
             bad.append((k, err / s, gap / s))
         worst = max(worst, (err / s, k))
         n += 1

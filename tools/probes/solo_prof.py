@@ -9,7 +9,8 @@ N = pkg._native
 here = os.path.dirname(os.path.abspath(pkg.__file__))
 lib_path = os.path.join(here, 'build', 'libsoprof.so')
 if '--build' in sys.argv:
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-DNF_SO_PROF=1',
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on',
+                           '-DNF_SO_NO_WGRAD=1' if '--no-wgrad' in sys.argv else '-DNF_SO_PROF=1',
                            '-I' + os.path.join(here, '..', 'include'), '-shared', '-o', lib_path] +
                           [os.path.join(here, 'csrc', f) for f in ('flow_solo.hip', 'mlp_chain.hip', 'made_chain.hip', 'conv_chain.hip')])
     print('built', lib_path)
@@ -29,6 +30,14 @@ y = (torch.randn(B, 2) * 0.7).to('cuda')
 for _ in range(3):
     tr._forward_backward(y)
 torch.cuda.synchronize()
+if not hasattr(prof, 'nf_so_prof_read'):                 # the --no-wgrad build: device time of the two launches (HIP events), no stamps
+    for name in ('nf_realnvp_flow_vec_fwd', 'nf_realnvp_flow_vec_bwd_deferred'):
+        with N.timed_launches(name) as tl:
+            for _ in range(10):
+                tr._forward_backward(y)
+            d = tl.durations_us()
+        print('%-36s %d launches of %d steps: median %.1f us (%.2f us per flow step)' % (name, len(d), 16, sorted(d)[len(d) // 2], sorted(d)[len(d) // 2] / 16))
+    sys.exit(0)
 buf = (ctypes.c_longlong * 64)()
 prof.nf_so_prof_read(buf)
 t = [v / 100.0 for v in buf]
