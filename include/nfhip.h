@@ -914,8 +914,9 @@ int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* 
  * Buffer sizes of such a run do NOT follow the grid kernels' rule; ask, whichever kernel ends up serving the call:
  *   nf_realnvp_flow_save_floats(N, D)  floats PER STEP of `saves`: the S statistics records (S x NF_REALNVP_SAVE_FLOATS, stride
  *                                      NF_REALNVP_SAVE_FLOATS) are followed by S x NF_FLOW_SOLO_STASH_FLOATS floats of stashed
- *                                      BatchNorm inputs and S x NF_FLOW_SOLO_GBUF_FLOATS floats of backward scratch for the shapes the
- *                                      one-workgroup kernels take (16-byte aligned base; the backward WRITES the last part);
+ *                                      BatchNorm inputs, S x NF_FLOW_SOLO_GBUF_FLOATS floats of backward scratch (the backward WRITES
+ *                                      them) and S x NF_FLOW_SOLO_TAB_FLOATS floats of table images for the shapes the one-workgroup
+ *                                      kernels take (16-byte aligned base);
  *   nf_realnvp_flow_bwd_regions(N, D)  regions per step of slabs_all / head_rec of nf_realnvp_flow_vec_bwd_deferred
  *                                      (NF_FLOW_SOLO_REGIONS for those shapes, ceil(N / NF_MLP_ROWS_PER_BLOCK) otherwise).
  * Both return the count (> 0), not an error code.                                                                                  */
@@ -923,6 +924,7 @@ int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* 
 #define NF_FLOW_SOLO_REGIONS 4
 #define NF_FLOW_SOLO_STASH_FLOATS (5 * 32 * 256)
 #define NF_FLOW_SOLO_GBUF_FLOATS (6 * 4 * 512 * 4)   /* per step: what the backward's data-path workgroup hands to its weight-gradient workgroup */
+#define NF_FLOW_SOLO_TAB_FLOATS 5888                 /* per step: the forward's parameter / constant tables as an LDS image for the backward */
 int nf_flow_solo_config(int mode);
 int nf_realnvp_flow_save_floats(int64_t N, int D);
 int nf_realnvp_flow_bwd_regions(int64_t N, int D);

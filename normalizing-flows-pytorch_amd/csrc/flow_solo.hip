@@ -58,12 +58,17 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 #define SO_BE (SO_GA + 160)                           // [5][32] BatchNorm beta
 #define SO_BNC (SO_BE + 160)                          // [5][4][32] scale, shift, mean, invstd
 #define SO_HD (SO_BNC + 640)                          // head: [0..1] exp(log_gamma) [2..3] beta [4..5] mean [6..7] sqrt(var) [8] log-det [9] a [10] c [12..15] raw ls, bs
+#define SO_PAR (SO_HD + 32)                           // floats of ONE set of parameter tables (a multiple of 4: 16-byte words).  The forward
+                                                      // leaves every step's set in memory as it used it (weight-norm scales, BatchNorm constants
+                                                      // and flow-BatchNorm statistics included): the backward's data path loads that IMAGE straight
+                                                      // into LDS (global_load_lds), a step ahead, into the set it is not reading -- no staging pass
 #define SO_GROUPS (2 * NF_SO_WAVES)                   // a meeting's partials: one per wave half = 16 columns
-#define SO_RED (SO_HD + 32)                           // [16 groups][3][32] partial sums of a meeting (sum, squares / second sum, centre)
+#define SO_RED (2 * SO_PAR)                           // [16 groups][3][32] partial sums of a meeting (sum, squares / second sum, centre)
 #define SO_TOT (SO_RED + SO_GROUPS * 3 * 32)                  // [3][32] totals of a meeting
 #define SO_REC (SO_TOT + 96)                          // [2][record words as floats x 2]
 #define SO_REC_WORDS ((int)((sizeof(NfGlowFlowStep) + 7) / 8))
 #define SO_TILES (SO_REC + 2 * 2 * SO_REC_WORDS)      // [8 waves][2][32 * 36] transposition tiles (forward: the first of a wave's pair only)
+static_assert((SO_PAR & 3) == 0 && SO_PAR == NF_FLOW_SOLO_TAB_FLOATS, "the table image: 16-byte words, the size of include/nfhip.h");
 static_assert(SO_REC_WORDS <= NF_SO_THREADS, "one 8-byte word of a step record per thread");
 static inline size_t nf_so_lds_bytes(bool bwd) { (void)bwd; return sizeof(float) * (size_t)(SO_TILES + NF_SO_WAVES * 2 * 32 * NF_SO_TS); }
 
@@ -324,8 +329,8 @@ __device__ __forceinline__ void so_stash_get(const f32x4s* st4, int l, float (&a
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_fwd(const NfGlowFlowStep* __restrict__ steps, int S, const float* __restrict__ z0,
                                                             float* __restrict__ ys, float* __restrict__ ld, float* __restrict__ saves,
-                                                            int save_stride, f32x4s* __restrict__ stash, int N, float eps, float mom,
-                                                            float wn_eps) {
+                                                            int save_stride, f32x4s* __restrict__ stash, f32x4s* __restrict__ tabs, int N,
+                                                            float eps, float mom, float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), c32 = lane & 31, hs = lane >> 5;
     unsigned long long (*rec)[SO_REC_WORDS] = reinterpret_cast<unsigned long long (*)[SO_REC_WORDS]>(sm + SO_REC);
@@ -467,6 +472,12 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_fwd(const NfGlowFlowStep
                 yr[0] = z[0]; yr[1] = z[1];
             }
         }
+        // the step's table set as it stands -- parameters, weight-norm scales, the BatchNorm constants the finalising threads wrote, the flow
+        // BatchNorm's statistics -- for the backward's data path (three 16-byte words per thread; every writer of the set passed a barrier)
+        {
+            f32x4s* const img = tabs + (size_t)s * (SO_PAR / 4);
+            for (int i = t; i < SO_PAR / 4; i += NF_SO_THREADS) img[i] = reinterpret_cast<const f32x4s*>(sm)[i];
+        }
         NF_SO_STAMP(s == 1, 12);
         so_barrier();                               // the tables are restaged by the next step; every reader of record s is through
         NF_SO_STAMP(s == 1, 13);
@@ -525,6 +536,25 @@ __device__ __forceinline__ void so_wgrad(float* sm, float* slab_l, const float (
     for (int r = 0; r < 16; ++r) slab_l[so_fm(r, hs) * 32 + c32] = acc[r];       // D[i = fm][o = c32]
     bsum += __shfl_xor(bsum, 32, NF_WAVE);
     if (hs == 0) slab_l[1024 + c32] = bsum;
+}
+
+// the backward's table set of a step: the image the forward left in memory (SO_PAR floats), straight into LDS -- lane i's 16 bytes land
+// at base + 16 i, one KiB per wave instruction, 23 of them over the eight waves; completion: s_waitcnt vmcnt(0) + a barrier
+__device__ __forceinline__ void so_tables_dma(float* set, const float* __restrict__ img, int wid, int lane) {
+    constexpr int CH = SO_PAR / 256;                  // whole KiB chunks ...
+    for (int c = wid; c < CH; c += NF_SO_WAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(set + c * 256), 16, 0, 0);
+    if (wid == NF_SO_WAVES - 1 && lane < (SO_PAR - CH * 256) / 4)      // ... and the tail
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + CH * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(set + CH * 256), 16, 0, 0);
+}
+// (accumulate) the old values of a step's BatchNorm gradient sinks, threads 32 j + f: unconditional loads from clamped addresses
+__device__ __forceinline__ void so_sinks_old(float& gb_old, float& gg_old, const NfGlowFlowStep& st, int t, int accumulate) {
+    const int j = min(t >> 5, 4), f = t & 31;
+    const float b0 = st.g.beta[j][f], g0 = st.g.gamma[j][f];
+    gb_old = accumulate ? b0 : 0.f;
+    gg_old = accumulate ? g0 : 0.f;
 }
 
 // ---- the weight-gradient workgroup of the backward ------------------------------------------------------------------------------------
@@ -621,8 +651,8 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
                                                             const float* __restrict__ ys, const float* __restrict__ g_y,
                                                             const float* __restrict__ g_ld, float* __restrict__ gzs,
                                                             const float* __restrict__ saves, int save_stride,
-                                                            const f32x4s* __restrict__ stash, f32x4s* __restrict__ gbuf,
-                                                            unsigned* __restrict__ flags, int accumulate,
+                                                            const f32x4s* __restrict__ stash, const float* __restrict__ tabs,
+                                                            f32x4s* __restrict__ gbuf, unsigned* __restrict__ flags, int accumulate,
                                                             float* __restrict__ slabs, float* __restrict__ head_rec, int N, float wn_eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6), c32 = lane & 31, hs = lane >> 5;
@@ -656,61 +686,50 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
         zin[1] = cv ? zr[2 * cc + 1] : 0.f;
     }
     so_barrier();
-    SoParams P;
-    so_prefetch(P, *reinterpret_cast<const NfGlowFlowStep*>(rec[(S - 1) & 1]), t, steps);
-    float sv_mean = 0.f, sv_inv = 0.f, sv_h = 0.f;     // saved statistics of the step, prefetched with its parameters
-    float gb_old = 0.f, gg_old = 0.f;                  // threads 32 J + f: the BatchNorm gradient sinks' old values (accumulate)
-    {
-        const float* save = saves + (size_t)(S - 1) * save_stride;
-        const NfGlowFlowStep& st0 = *reinterpret_cast<const NfGlowFlowStep*>(rec[(S - 1) & 1]);
-        so_saved(sv_mean, sv_inv, sv_h, gb_old, gg_old, st0, save, t, accumulate);
-    }
+    // the BatchNorm gradient sinks' old values (accumulate): threads 32 J + f, a step ahead like everything else
+    float gb_old = 0.f, gg_old = 0.f;
+    so_sinks_old(gb_old, gg_old, *reinterpret_cast<const NfGlowFlowStep*>(rec[(S - 1) & 1]), t, accumulate);
+    // the last step's table image -> set (S - 1) & 1; every later one is requested a step ahead (below)
+    so_tables_dma(sm + ((S - 1) & 1) * SO_PAR, tabs + (size_t)(S - 1) * SO_PAR, wid, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const float invN = 1.f / (float)N;
+    so_barrier();
 #pragma unroll 1
     for (int s = S - 1; s >= 0; --s) {
         const NfGlowFlowStep& st = *reinterpret_cast<const NfGlowFlowStep*>(rec[s & 1]);
+        // this step's parameter tables, weight-norm scales, BatchNorm constants and flow-BatchNorm statistics: the image the forward left,
+        // loaded straight into this set during the previous step (no staging pass, no prefetch registers, no weight-norm pass: the
+        // step's top was 3.1 of its 17 us)
+        float* const tb = sm + (s & 1) * SO_PAR;
         // the step's five BatchNorm inputs, as the forward left them (no recompute), through a SLIDING WINDOW: stage J of the data path
-        // needs a[J] only (ReLU mask, xhat), so a[4] is requested here -- the staging below covers its latency -- and a[J - 1] at the
-        // start of stage J: two of the five arrays are live at any time (32 registers instead of 80)
+        // needs a[J] only (ReLU mask, xhat), so a[4] is requested here and a[J - 1] at the start of stage J: two of the five arrays are
+        // live at any time (32 registers instead of 80)
         const f32x4s* const st4 = stash + (size_t)s * (5 * 4 * NF_SO_THREADS) + t;
         f32x4s* const gb4 = gbuf + (size_t)s * (6 * 4 * NF_SO_THREADS) + t;      // what the worker reads of this step: G_0 .. G_4, (g5, x)
         float a[5][16];
         so_stash_get(st4, 4, a[4]);
         NF_SO_STAMP(s == S - 2, 32);
-        so_stage(sm, P, t);
-        if (t < 160) {                                 // BatchNorm constants from the saved statistics
-            const int j = t >> 5, f = t & 31;
-            const float sc = P.ga * sv_inv;
-            sm[SO_BNC + (4 * j + 0) * 32 + f] = sc;
-            sm[SO_BNC + (4 * j + 1) * 32 + f] = P.be - sv_mean * sc;
-            sm[SO_BNC + (4 * j + 2) * 32 + f] = sv_mean;
-            sm[SO_BNC + (4 * j + 3) * 32 + f] = sv_inv;
-        } else if (t < 162) sm[SO_HD + 4 + (t - 160)] = sv_h;            // flow BatchNorm: mean
-        else if (t < 164) sm[SO_HD + 6 + (t - 162)] = sqrtf(sv_h);       // sqrt(var)
-        so_barrier();
-        // next step's record, parameters, statistics and input rows: in flight under this step
+        // next step's record, table image, sinks and input rows: in flight under this step
         unsigned long long nxt = 0;
         if (rt && s >= 2) nxt = reinterpret_cast<const unsigned long long*>(steps + s - 2)[t];
         float zn_[2] = {0.f, 0.f};
         const float gb_cur = gb_old, gg_cur = gg_old;
         if (s >= 1) {
             const NfGlowFlowStep& stn = *reinterpret_cast<const NfGlowFlowStep*>(rec[(s - 1) & 1]);
-            so_prefetch(P, stn, t, steps);
-            so_saved(sv_mean, sv_inv, sv_h, gb_old, gg_old, stn, saves + (size_t)(s - 1) * save_stride, t, accumulate);
+            so_tables_dma(sm + ((s - 1) & 1) * SO_PAR, tabs + (size_t)(s - 1) * SO_PAR, wid, lane);   // (that set's readers left at the last barrier)
+            so_sinks_old(gb_old, gg_old, stn, t, accumulate);
             const float* zr = s == 1 ? z0 : ys + (size_t)(s - 2) * N * 2;
             zn_[0] = cv ? zr[2 * cc] : 0.f;
             zn_[1] = cv ? zr[2 * cc + 1] : 0.f;
         }
-        so_weight_norm(sm, t, wn_eps);
-        so_barrier();
         NF_SO_STAMP(s == S - 2, 33);
         // ---- head (recomputed: two values per lane); the conditioner's activations come from the stash ----
         const int sel = st.h.odd ? 1 : 0;
         float h[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float zn = (zin[c] - sm[SO_HD + 4 + c]) / sm[SO_HD + 6 + c];
-            h[c] = fmaf(sm[SO_HD + c], zn, 0.f) + sm[SO_HD + 2 + c];
+            const float zn = (zin[c] - tb[SO_HD + 4 + c]) / tb[SO_HD + 6 + c];
+            h[c] = fmaf(tb[SO_HD + c], zn, 0.f) + tb[SO_HD + 2 + c];
         }
         const float xw = sel ? h[0] : h[1];
         NF_SO_STAMP(s == S - 2, 34);
@@ -720,14 +739,14 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
         {
             // (three short passes over the lane's sixteen features instead of one that keeps eight arrays alive: the five
             // activations already hold 80 of the lane's registers)
-            const float b51 = sm[SO_B + 5 * 32 + 1], ca = sm[SO_HD + 9], cc2 = sm[SO_HD + 10];
+            const float b51 = tb[SO_B + 5 * 32 + 1], ca = tb[SO_HD + 9], cc2 = tb[SO_HD + 10];
             float sp = 0.f;
             {
                 float sc[16], sh[16], ws[16], v51[16];
-                so_ldvec(sm + SO_BNC + (4 * 4 + 0) * 32, hs, sc);
-                so_ldvec(sm + SO_BNC + (4 * 4 + 1) * 32, hs, sh);
-                so_ldvec(sm + SO_WS + 5 * 32, hs, ws);
-                so_ldvec(sm + SO_V5 + 32, hs, v51);
+                so_ldvec(tb + SO_BNC + (4 * 4 + 0) * 32, hs, sc);
+                so_ldvec(tb + SO_BNC + (4 * 4 + 1) * 32, hs, sh);
+                so_ldvec(tb + SO_WS + 5 * 32, hs, ws);
+                so_ldvec(tb + SO_V5 + 32, hs, v51);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sp = fmaf(v51[r], fmaxf(fmaf(a[4][r], sc[r], sh[r]), 0.f) * ws[r], sp);
             }
@@ -745,9 +764,9 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
             __builtin_amdgcn_sched_barrier(0);
             {
                 float ws[16], v50[16], v51[16];
-                so_ldvec(sm + SO_WS + 5 * 32, hs, ws);
-                so_ldvec(sm + SO_V5, hs, v50);
-                so_ldvec(sm + SO_V5 + 32, hs, v51);
+                so_ldvec(tb + SO_WS + 5 * 32, hs, ws);
+                so_ldvec(tb + SO_V5, hs, v50);
+                so_ldvec(tb + SO_V5 + 32, hs, v51);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tg[r] = (v50[r] * gy0 + v51[r] * gsraw) * ws[r];
             }
@@ -777,8 +796,8 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
                 }
                 {
                     float sc[16], sh[16], x[16];
-                    so_ldvec(sm + SO_BNC + (4 * J + 0) * 32, hs, sc);
-                    so_ldvec(sm + SO_BNC + (4 * J + 1) * 32, hs, sh);
+                    so_ldvec(tb + SO_BNC + (4 * J + 0) * 32, hs, sc);
+                    so_ldvec(tb + SO_BNC + (4 * J + 1) * 32, hs, sh);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) tg[r] = (cv && fmaf(a[J][r], sc[r], sh[r]) > 0.f) ? tg[r] : 0.f;      // = gn
                     so_transpose(tile, tg, x, c32, hs);
@@ -790,8 +809,8 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     float mean[16], invstd[16], gx_[16], x[16];
-                    so_ldvec(sm + SO_BNC + (4 * J + 2) * 32, hs, mean);
-                    so_ldvec(sm + SO_BNC + (4 * J + 3) * 32, hs, invstd);
+                    so_ldvec(tb + SO_BNC + (4 * J + 2) * 32, hs, mean);
+                    so_ldvec(tb + SO_BNC + (4 * J + 3) * 32, hs, invstd);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) gx_[r] = tg[r] * ((a[J][r] - mean[r]) * invstd[r]);
                     so_transpose(tile, gx_, x, c32, hs);
@@ -830,9 +849,9 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
             }
             {
                 float sc[16], mean[16], invstd[16], mg[16], mgx[16];
-                so_ldvec(sm + SO_BNC + (4 * J + 0) * 32, hs, sc);
-                so_ldvec(sm + SO_BNC + (4 * J + 2) * 32, hs, mean);
-                so_ldvec(sm + SO_BNC + (4 * J + 3) * 32, hs, invstd);
+                so_ldvec(tb + SO_BNC + (4 * J + 0) * 32, hs, sc);
+                so_ldvec(tb + SO_BNC + (4 * J + 2) * 32, hs, mean);
+                so_ldvec(tb + SO_BNC + (4 * J + 3) * 32, hs, invstd);
                 so_ldvec(sm + SO_TOT, hs, mg);
                 so_ldvec(sm + SO_TOT + 32, hs, mgx);
 #pragma unroll
@@ -854,8 +873,8 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
                 NF_SO_STAMP(s == S - 2, 39 + 4 * (4 - J));
                 __builtin_amdgcn_sched_barrier(0);
                 float ws[16], A[16];
-                so_ld_abwd(sm, J, c32, hs, A);
-                so_ldvec(sm + SO_WS + J * 32, hs, ws);
+                so_ld_abwd(tb, J, c32, hs, A);
+                so_ldvec(tb + SO_WS + J * 32, hs, ws);
                 f32x16 acc;
                 so_gemm(A, tg, acc);
 #pragma unroll
@@ -863,12 +882,12 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
             } else {
                 // linear 0 (1 -> 32): g_x on the vector ALU
                 float w0[16];
-                so_ldvec(sm + SO_V0, hs, w0);
+                so_ldvec(tb + SO_V0, hs, w0);
                 float gp = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gp = fmaf(tg[r], w0[r], gp);
                 gp += __shfl_xor(gp, 32, NF_WAVE);
-                gx = gp * sm[SO_WS];
+                gx = gp * tb[SO_WS];
             }
         }
         NF_SO_STAMP(s == S - 2, 56);
@@ -876,8 +895,8 @@ __global__ void __launch_bounds__(NF_SO_THREADS) k_solo_bwd(const NfGlowFlowStep
         Gh[1 - sel] += gx;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float gzn = fmaf(sm[SO_HD + c], Gh[c], 0.f);
-            gy[c] = cv ? gzn / sm[SO_HD + 6 + c] : 0.f;
+            const float gzn = fmaf(tb[SO_HD + c], Gh[c], 0.f);
+            gy[c] = cv ? gzn / tb[SO_HD + 6 + c] : 0.f;
         }
         if (cv && hs == 0) {
             float* gr = gzs + ((size_t)s * N + col) * 2;
@@ -912,7 +931,7 @@ static int nf_so_enabled() {
 // sizes a caller needs for a RealNVP run of N rows x D features in training mode (whichever kernel serves it)
 extern "C" int nf_realnvp_flow_save_floats(int64_t N, int D) {
     const bool solo_shape = D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS;
-    return NF_REALNVP_SAVE_FLOATS + (solo_shape ? NF_FLOW_SOLO_STASH_FLOATS + NF_FLOW_SOLO_GBUF_FLOATS : 0);
+    return NF_REALNVP_SAVE_FLOATS + (solo_shape ? NF_FLOW_SOLO_STASH_FLOATS + NF_FLOW_SOLO_GBUF_FLOATS + NF_FLOW_SOLO_TAB_FLOATS : 0);
 }
 extern "C" int nf_realnvp_flow_bwd_regions(int64_t N, int D) {
     const int grid = (int)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
@@ -940,10 +959,12 @@ int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float*
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    // the stash of BatchNorm inputs follows the S statistics records (include/nfhip.h: nf_realnvp_flow_save_floats)
+    // saves: S statistics records | S stashes of BatchNorm inputs | S hand-over areas of the backward | S table images
+    // (include/nfhip.h: nf_realnvp_flow_save_floats)
     f32x4s* stash = reinterpret_cast<f32x4s*>(saves + (size_t)S * save_stride);
+    f32x4s* tabs = stash + (size_t)S * ((NF_FLOW_SOLO_STASH_FLOATS + NF_FLOW_SOLO_GBUF_FLOATS) / 4);
     hipLaunchKernelGGL(k_solo_fwd, dim3(1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, ld, saves, save_stride,
-                       stash, (int)N, bn_eps, bn_momentum, wn_eps);
+                       stash, tabs, (int)N, bn_eps, bn_momentum, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
 }
@@ -965,9 +986,10 @@ int nf_solo_bwd(const void* steps_dev, int S, const float* z0, const float* ys, 
     // flags: the first eight words of the zeroed exchange workspace
     const f32x4s* stash = reinterpret_cast<const f32x4s*>(saves + (size_t)S * save_stride);
     f32x4s* gbuf = const_cast<f32x4s*>(stash) + (size_t)S * (NF_FLOW_SOLO_STASH_FLOATS / 4);
+    const float* tabs = reinterpret_cast<const float*>(gbuf + (size_t)S * (NF_FLOW_SOLO_GBUF_FLOATS / 4));
     hipLaunchKernelGGL(k_solo_bwd, dim3(NF_SO_B_BLOCK + 1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y,
-                       g_ld, gzs, saves, save_stride, stash, gbuf, reinterpret_cast<unsigned*>(ws_zero), accumulate, slabs_all, head_rec,
-                       (int)N, wn_eps);
+                       g_ld, gzs, saves, save_stride, stash, tabs, gbuf, reinterpret_cast<unsigned*>(ws_zero), accumulate, slabs_all,
+                       head_rec, (int)N, wn_eps);
     NF_CHECK_LAUNCH();
     return 0;
 }
