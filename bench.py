@@ -532,7 +532,7 @@ def run_workload(name, args, pkg, rank, world, dev, steps, warmup, cpu_seconds):
         'dtype': 'f32',
         'data': 'synthetic (seeded %s restatement, random-init weights)' % cfg['data'],
         'config': {'workload': cfg['desc'] if not args.batch else cfg['desc'] + ' -- measured at per-GPU batch %d' % B, 'name': name, 'per_gpu_batch': B, 'global_batch': B * world,
-                   'scaling': 'strong (global batch fixed, per GPU = global / N)' if strong else 'weak (per-GPU batch fixed)', 'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None, 'dp_one_graph': bool(getattr(trainer, '_g_whole', False)) and trainer.bucket.collective, 'collective': collective_info(world)},
+                   'scaling': 'strong (global batch fixed, per GPU = global / N)' if strong else 'weak (per-GPU batch fixed)', 'parallelism': 'dp%d' % world, 'hipgraph': trainer._g_fb is not None, 'deterministic': bool(pkg._native.deterministic()), 'dp_one_graph': bool(getattr(trainer, '_g_whole', False)) and trainer.bucket.collective, 'collective': collective_info(world)},
         'loss_nats': round(loss_val, 5),
         'bits_per_dim': round(nftrain.bits_per_dim(loss_val, cfg['dims']), 5),
         'forward_samples_per_s': round(B * world / (fwd_ms * 1e-3), 1),

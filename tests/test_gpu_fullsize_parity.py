@@ -72,11 +72,12 @@ FLIPS = 4          # kink events per pass whose footprint the per-step profile m
 AMP = 1.3          # amplification of a gradient perturbation per flow step of the backward pass (measured)
 ENSEMBLE = 12      # row permutations of the batch the fp32 oracle AND the GPU path are run on where that is cheap (C1, C2, C5)
 ENSEMBLE_SLOW = 6  # ... and for C3 / C4 as well since the oracle's threads are capped (conftest.py: an fp32 step is ~1 s there, was 3 - 6 s)
+ENSEMBLE_BIG = 2   # ... and for config 4 at batch 512 (an fp32 oracle step is ~10 s, a float64 one ~25 s)
 ENSEMBLE_IMAGE = 4 # row permutations for the image stacks of the second test (CIFAR / MNIST shape, (1, 24, 24))
 KINK_CAP = 0.05    # the per-step kink allowance never exceeds this
 KINK_FLAT = 3.0e-2  # flat-gradient (relative L2) footprint of one kink event, times the batch size (measured: <= 1.9e-4 at B = 64)
 ENS_RATIO = 3.0    # GPU ensemble vs fp32-oracle ensemble (flat gradient distance to float64): median and max within this factor
-BIMODAL = 8.0      # an oracle ensemble whose max exceeds this multiple of its median is treated as bimodal (see _compare_step)
+BIMODAL = 5.0      # an oracle ensemble whose max exceeds this multiple of its lower quartile is treated as bimodal (see _compare_step)
 WIDE = 0.2         # ensemble envelope beyond which the bar is 1.25 x the envelope instead of 2 x
 
 CONFIGS = [
@@ -86,6 +87,8 @@ CONFIGS = [
     ('c3_flowpp_circles', 'flowpp', 'Flowpp', (2, ), '2d', 32, 8, 65536, 'circles'),
     ('c4_glow_cifar', 'glow', 'Glow', (3, 32, 32), 'image', 32, None, 64, 'cifar'),
     ('c5_maf_normals', 'maf', 'MAF', (2, ), '2d', 10, None, 16384, 'normals'),
+    # config 4's LITERAL batch on one GPU: the large-batch kernels of csrc/conv_bulk.hip (three-way bf16 split in throughput form) at full depth
+    ('c4_glow_cifar_b512', 'glow', 'Glow', (3, 32, 32), 'image', 32, None, 512, 'cifar'),
 ]
 
 
@@ -223,21 +226,24 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         # land on the other side of their kink); the two DISTRIBUTIONS must agree:
         #     median(gpu) <= ENS_RATIO x median(oracle) + 2 TOL        max(gpu) <= ENS_RATIO x max(oracle) + 2 TOL
         # (this replaces the round-4 bar `gpu <= 4 x max(oracle) + KINK_FLAT / B`, which one bad member of the yard-stick could carry).
-        # Where the yard-stick itself is BIMODAL (max > BIMODAL x median: C1, whose distance is ~7e-3 or ~0.16 depending on ONE early-step
+        # Where the yard-stick itself is BIMODAL (max > BIMODAL x its lower quartile: C1, whose distance is ~7e-3 or ~0.16 depending on ONE early-step
         # unit -- tools/kink_odds.py: torch's own F.batch_norm path lands on the far side in 58 % of 48 row permutations on one x86 host
-        # and in 1 of 7 on another, profiles/r05_c1_kink_odds.txt) the median only says which mode has the majority on this host; there
-        # the GPU must REACH the near mode (its best member inside ENS_RATIO x the oracle's median) and stay inside the far one (max).
+        # and in 1 of 7 on another, profiles/r05_c1_kink_odds.txt) the median only says which mode has the majority on this host (C5's
+        # graph-replay step on one box: 5 of 13 oracle members and 8 of 13 GPU members at 1.7e-2, the others at 2e-3: medians 3.9e-3 / 1.6e-2
+        # from the SAME two modes); there the GPU must REACH the near mode (its best member inside ENS_RATIO x the oracle's lower
+        # quartile) and stay inside the far one (max).
         if gpu_ensemble:
             rel_gpu_all = [rel_gpu] + [_flat_distance(m, r64) for m in gpu_ensemble]
             med_g, med_o = float(np.median(rel_gpu_all)), float(np.median(rel_ens))
-            bimodal = max(rel_ens) > BIMODAL * med_o
+            low_o = float(np.percentile(rel_ens, 25))          # the near mode's representative when the ensemble has two
+            bimodal = max(rel_ens) > BIMODAL * low_o
             _report('%-18s %-14s flat gradient distance to float64, GPU on the same %d row permutations: %s | median gpu %.3e oracle %.3e | '
-                    'max gpu %.3e oracle %.3e | min gpu %.3e oracle %.3e%s'
+                    'max gpu %.3e oracle %.3e | min gpu %.3e oracle %.3e | lower quartile oracle %.3e%s'
                     % (name, tag, len(gpu_ensemble), ' '.join('%.2e' % v for v in rel_gpu_all[1:]), med_g, med_o, max(rel_gpu_all), max(rel_ens),
-                       min(rel_gpu_all), min(rel_ens), '  (oracle ensemble bimodal)' if bimodal else ''))
+                       min(rel_gpu_all), min(rel_ens), low_o, '  (oracle ensemble bimodal)' if bimodal else ''))
             if bimodal:
-                if min(rel_gpu_all) > ENS_RATIO * med_o + 2.0 * TOL:
-                    bad.append(('best flat gradient distance to float64 over the ensemble (bimodal yard-stick)', min(rel_gpu_all), med_o))
+                if min(rel_gpu_all) > ENS_RATIO * low_o + 2.0 * TOL:
+                    bad.append(('best flat gradient distance to float64 over the ensemble (bimodal yard-stick)', min(rel_gpu_all), low_o))
             elif med_g > ENS_RATIO * med_o + 2.0 * TOL:
                 bad.append(('median flat gradient distance to float64 over the ensemble', med_g, med_o))
             if max(rel_gpu_all) > ENS_RATIO * max(rel_ens) + 2.0 * TOL:
@@ -308,7 +314,7 @@ def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg):
     gaps = {}
 
     gp = torch.Generator().manual_seed(99)
-    perms = [torch.randperm(B, generator=gp) for _ in range(ENSEMBLE_SLOW if slow64 else ENSEMBLE)]
+    perms = [torch.randperm(B, generator=gp) for _ in range(ENSEMBLE_BIG if name.endswith('_b512') else ENSEMBLE_SLOW if slow64 else ENSEMBLE)]
 
     def gpu_members(sd, initialised):
         """the trainer's own launch path (eager launches of the same kernels the step just took) from the SAME weights on the row
