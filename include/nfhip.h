@@ -186,6 +186,19 @@ int nf_glow_head_w_fwd(const float* x, const float* act_log_scale, const float* 
 int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const float* x, const float* act_log_scale, const float* act_bias,
                        const float* Wm, float* g_x, float* g_log_scale, float* g_bias, float* g_W, int64_t B, int C, int H, int W,
                        nf_stream_t stream);
+/* The same backward in two parts (flows/modules.py:246-256, 478-487 differentiated; bit for bit what nf_glow_head_w_bwd computes):
+ *   nf_glow_head_w_bwd_data          g_x alone -- the only result the rest of the backward pass waits for;
+ *   nf_glow_head_w_bwd_params_multi  g_W, g_log_scale, g_bias (+=) of n <= NF_GLOW_HEAD_MULTI_MAX heads of ONE shape in one launch,
+ *                                    from the g_h / g_ld / x the caller kept -- where the pass ends, in front of
+ *                                    nf_invconv_weight_bwd_multi, which reads g_W.                                              */
+#define NF_GLOW_HEAD_MULTI_MAX 32
+typedef struct nf_glow_head_params_desc {
+    const float *g_h, *g_ld, *x, *act_log_scale, *act_bias, *W;
+    float *g_log_scale, *g_bias, *g_W;
+} nf_glow_head_params_desc;
+int nf_glow_head_w_bwd_data(const float* g_h, const float* act_log_scale, const float* Wm, float* g_x, int64_t B, int C, int H, int W,
+                            nf_stream_t stream);
+int nf_glow_head_w_bwd_params_multi(const nf_glow_head_params_desc* descs, int n, int64_t B, int C, int H, int W, nf_stream_t stream);
 
 /* ---- Logit  modules.py:141-156 --------------------------------------------------------------------------------
  * forward: xc = clamp(x, eps, 1-eps); y = log(xc/(1-xc)); ld[b] += sum -(y - 2 softplus(y))

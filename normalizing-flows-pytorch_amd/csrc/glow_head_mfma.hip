@@ -243,14 +243,16 @@ __global__ void __launch_bounds__(NF_BLOCK) k_glow_head_w_fwd4(const float* __re
 
 // TP = pixels per staged tile: 128, or 64 where 128 would leave fewer than 64 workgroups (the 8 x 8 level at B = 64: 32 -> 64 workgroups,
 // each wave 16 pixels instead of 32 -- the launch is a latency chain, a wave's part of it halves)
-template <int RT, int KQ, int TP>
-__global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glow_head_w_bwd(const float* __restrict__ gh, const float* __restrict__ gld,
-                                                              const float* __restrict__ x, const float* __restrict__ als,
-                                                              const float* __restrict__ abias, const float* __restrict__ M,
-                                                              float* __restrict__ gx, float* __restrict__ g_ls, float* __restrict__ g_b,
-                                                              float* __restrict__ gM, int64_t B, int C, int P,
-                                                              int64_t tiles_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// PART: 0 = everything; 1 = the DATA gradient g_x only (what the backward pass waits for); 2 = the PARAMETER gradients only (g_W, g_log_scale,
+// g_bias: contractions over the batch that nothing but the optimizer waits for -- run for many steps per launch where the pass ends,
+// k_glow_head_w_params_multi).  Same arithmetic per element in the same order, so 1 + 2 reproduce 0 bit for bit.
+template <int RT, int KQ, int TP, int PART>
+__device__ __forceinline__ void nf_gh_w_bwd_body(float* lds, const float* __restrict__ gh, const float* __restrict__ gld,
+                                                 const float* __restrict__ x, const float* __restrict__ als,
+                                                 const float* __restrict__ abias, const float* __restrict__ M,
+                                                 float* __restrict__ gx, float* __restrict__ g_ls, float* __restrict__ g_b,
+                                                 float* __restrict__ gM, int64_t B, int C, int P, int64_t tiles_per_block) {
+    constexpr bool DATA = PART != 2, PARAMS = PART != 1;
     NF_GH_STAMP(8);
     constexpr int PW = TP / 4;            // pixels per wave
     constexpr bool THROUGH_TILE = RT >= 3;   // g_x leaves through the LDS tile (see below)
@@ -265,7 +267,7 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
     // sum_b g_ld (every channel's log_scale gradient carries P times it): each block takes a slice of the batch, requested here and
     // consumed at the very end (as a loop of dependent loads in block 0 it was 16 of 91 us at B = 8192)
     float sg = 0.f;
-    {
+    if (PARAMS) {
         float part[4] = {0.f, 0.f, 0.f, 0.f};
         const int64_t stride = (int64_t)gridDim.x * blockDim.x;
         for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += 4 * stride) {
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
             const int c = ph + NPH * k;
             const bool in = ok && c < C;
             rg[k] = in ? gh[base + (int64_t)c * P] : 0.f;
-            rx[k] = in ? x[base + (int64_t)c * P] : 0.f;
+            rx[k] = (PARAMS && in) ? x[base + (int64_t)c * P] : 0.f;
         }
     };
     fetch(tile0);
@@ -331,7 +333,7 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
         for (int k = 0; k < NCH; ++k) {
             const int c = ph + NPH * k;
             gT[c * RS + sq] = rg[k];
-            aT[c * RS + sq] = (sq < np && c < C) ? (rx[k] - cst[c]) * cst[CP + c] : 0.f;
+            if (PARAMS) aT[c * RS + sq] = (sq < np && c < C) ? (rx[k] - cst[c]) * cst[CP + c] : 0.f;
         }
         __syncthreads();
         NF_GH_STAMP(10);
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
         fetch(tile + 1);
         // ---- g_W: this wave's quarter of the tile, pixels [PW wid, PW wid + PW), k-steps of 4 pixels ----
 #pragma unroll
-        for (int ks = 0; ks < PW / 4; ++ks) {
+        for (int ks = 0; ks < (PARAMS ? PW / 4 : 0); ++ks) {
             const int pix = PW * wid + 4 * ks + lk;
             float av[RT], bv[RT];
 #pragma unroll
@@ -382,15 +384,19 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
                         const int r = 16 * rt + 4 * lk + j;
                         if (r < C) {
                             const float g = ga[rt][j];
-                            s1[rt][j] = fmaf(g, aT[r * RS + pix], s1[rt][j]);
-                            s2[rt][j] += g;
-                            if (THROUGH_TILE) aT[r * RS + pix] = g * cst[CP + r];
-                            else gxb[(int64_t)r * P] = g * cst[CP + r];
+                            if (PARAMS) {
+                                s1[rt][j] = fmaf(g, aT[r * RS + pix], s1[rt][j]);
+                                s2[rt][j] += g;
+                            }
+                            if (DATA) {
+                                if (THROUGH_TILE) aT[r * RS + pix] = g * cst[CP + r];
+                                else gxb[(int64_t)r * P] = g * cst[CP + r];
+                            }
                         }
                     }
             }
         }
-        if (THROUGH_TILE) {
+        if (DATA && THROUGH_TILE) {
             __syncthreads();
             if (sq < np) {
 #pragma unroll
@@ -402,6 +408,7 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
         }
     }
     NF_GH_STAMP(12);
+    if (!PARAMS) return;
     // ---- cross-wave reductions through LDS, then one atomic per entry per block ----
     __syncthreads();
     float* red = lds;                      // [4][CP][CP]  (CP*CP*4 <= 2*CP*RS for CP <= 64)
@@ -454,6 +461,28 @@ __global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glo
     }
     NF_DET_LEAVE_ALL(nf_ghm);
     NF_GH_STAMP(14);
+}
+
+template <int RT, int KQ, int TP, int PART>
+__global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glow_head_w_bwd(const float* __restrict__ gh, const float* __restrict__ gld,
+                                                              const float* __restrict__ x, const float* __restrict__ als,
+                                                              const float* __restrict__ abias, const float* __restrict__ M,
+                                                              float* __restrict__ gx, float* __restrict__ g_ls, float* __restrict__ g_b,
+                                                              float* __restrict__ gM, int64_t B, int C, int P,
+                                                              int64_t tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    nf_gh_w_bwd_body<RT, KQ, TP, PART>(lds, gh, gld, x, als, abias, M, gx, g_ls, g_b, gM, B, C, P, tiles_per_block);
+}
+
+// the parameter gradients of up to NF_GLOW_HEAD_MULTI_MAX heads of one shape in one launch: blockIdx.y = head
+struct NfGhMulti { nf_glow_head_params_desc d[NF_GLOW_HEAD_MULTI_MAX]; };
+template <int RT, int KQ, int TP>
+__global__ void __launch_bounds__(NF_BLOCK, (TP == 64 && RT <= 3) ? 2 : 1) k_glow_head_w_params_multi(NfGhMulti m, int64_t B, int C, int P,
+                                                                                                        int64_t tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const nf_glow_head_params_desc& d = m.d[blockIdx.y];
+    nf_gh_w_bwd_body<RT, KQ, TP, 2>(lds, d.g_h, d.g_ld, d.x, d.act_log_scale, d.act_bias, d.W, nullptr, d.g_log_scale, d.g_bias, d.g_W, B, C, P,
+                                    tiles_per_block);
 }
 
 static inline bool nf_gh_shape_ok(int64_t B, int C, int H, int W) {
@@ -514,6 +543,53 @@ extern "C" int nf_glow_head_w_fwd(const float* x, const float* act_log_scale, co
     return NF_E_BADARG;
 }
 
+// Tile and grid by the kernel's register footprint (-Rpass-analysis=kernel-resource-usage): the 128-pixel tile of 33 .. 64 channels
+// holds 388 registers -- one workgroup per compute unit, so 512 workgroups ran in two rounds (137 us on (48, 8, 8) x 8192; with the
+// 64-pixel tile, two workgroups per unit, 99) -- and the grid is ONE round of what fits (12 channels: three per unit, 91 -> 83 us).
+// 33 .. 64 channels: the 128-pixel tile while its tiles are ONE round of one workgroup per compute unit (B = 512 at (48, 8, 8): 256 tiles,
+// 27.5 us against 36.7 with 512 64-pixel tiles -- profiles/r04_c4_b512_step_kernels.txt before / after the tile rule above), the 64-pixel
+// tile beyond (two workgroups per unit instead of a second round) and below 64 tiles (latency: a wave's share of the chain halves)
+struct NfGhPlan { int rt, kq, TP; int64_t blocks, tpb; size_t lds; };
+static NfGhPlan nf_gh_bwd_plan(int64_t B, int C, int P, int heads) {
+    NfGhPlan p;
+    p.rt = (C + 15) / 16; p.kq = (C + 3) / 4;
+    const int64_t npix = B * P;
+    const int64_t t128 = (npix + 127) / 128;
+    p.TP = (t128 < 64 || (p.rt >= 3 && t128 > 256)) ? 64 : 128;
+    int cap = p.rt == 1 ? 768 : (p.rt <= 3 ? 512 : 256);
+    if (heads > 1) cap = cap / heads > 8 ? cap / heads : 8;      // many heads per launch: the round is shared
+    const int64_t tiles = (npix + p.TP - 1) / p.TP;
+    p.blocks = tiles < cap ? tiles : cap;                    // ends in C * C + 2 C same-address atomics per block
+    p.tpb = (tiles + p.blocks - 1) / p.blocks;
+    p.blocks = (tiles + p.tpb - 1) / p.tpb;
+    p.lds = ((size_t)2 * p.rt * 16 * (128 + 1) + 2 * p.rt * 16) * sizeof(float);   // (sized for either tile; the reductions alias it)
+    return p;
+}
+
+template <int PART>
+static int nf_gh_w_bwd_launch(const float* g_h, const float* g_ld, const float* x, const float* act_log_scale, const float* act_bias,
+                              const float* Wm, float* g_x, float* g_log_scale, float* g_bias, float* g_W, int64_t B, int C, int H, int W,
+                              nf_stream_t stream) {
+    const int P = H * W;
+    const NfGhPlan p = nf_gh_bwd_plan(B, C, P, 1);
+    hipStream_t st = (hipStream_t)stream;
+#define NF_CASE(RT, KQ)                                                                                                                 \
+    if (p.rt == RT && p.kq == KQ) {                                                                                                     \
+        if (p.TP == 64)                                                                                                                 \
+            hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ, 64, PART>), dim3((unsigned)p.blocks), dim3(NF_BLOCK), p.lds, st, g_h, g_ld, x,  \
+                               act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, p.tpb);                             \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ, 128, PART>), dim3((unsigned)p.blocks), dim3(NF_BLOCK), p.lds, st, g_h, g_ld, x, \
+                               act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, p.tpb);                             \
+        NF_CHECK_LAUNCH();                                                                                                              \
+        return 0;                                                                                                                       \
+    }
+    NF_CASE(1, 3) NF_CASE(1, 4) NF_CASE(2, 5) NF_CASE(2, 6) NF_CASE(2, 7) NF_CASE(2, 8) NF_CASE(3, 9) NF_CASE(3, 10)
+    NF_CASE(3, 11) NF_CASE(3, 12) NF_CASE(4, 13) NF_CASE(4, 14) NF_CASE(4, 15) NF_CASE(4, 16)
+#undef NF_CASE
+    return NF_E_BADARG;
+}
+
 extern "C" int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const float* x, const float* act_log_scale,
                                   const float* act_bias, const float* Wm, float* g_x, float* g_log_scale, float* g_bias, float* g_W,
                                   int64_t B, int C, int H, int W, nf_stream_t stream) {
@@ -521,34 +597,43 @@ extern "C" int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const flo
     if (g_h == nullptr || g_ld == nullptr || x == nullptr || act_log_scale == nullptr || act_bias == nullptr || Wm == nullptr ||
         g_x == nullptr || g_log_scale == nullptr || g_bias == nullptr || g_W == nullptr)
         return NF_E_BADARG;
+    return nf_gh_w_bwd_launch<0>(g_h, g_ld, x, act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, H, W, stream);
+}
+
+// the data gradient alone: g_x = diag(exp(-log_scale)) W^T g_h -- what the backward pass waits for (the parameter gradients of the same
+// head follow through nf_glow_head_w_bwd_params_multi, many heads per launch)
+extern "C" int nf_glow_head_w_bwd_data(const float* g_h, const float* act_log_scale, const float* Wm, float* g_x, int64_t B, int C, int H,
+                                       int W, nf_stream_t stream) {
+    if (!nf_gh_shape_ok(B, C, H, W)) return NF_E_BADARG;
+    if (g_h == nullptr || act_log_scale == nullptr || Wm == nullptr || g_x == nullptr) return NF_E_BADARG;
+    return nf_gh_w_bwd_launch<1>(g_h, nullptr, nullptr, act_log_scale, act_log_scale, Wm, g_x, nullptr, nullptr, nullptr, B, C, H, W, stream);
+}
+
+// g_W, g_log_scale, g_bias (accumulated: += like every sink) of n heads of ONE shape (B, C, H, W) in one launch
+extern "C" int nf_glow_head_w_bwd_params_multi(const nf_glow_head_params_desc* descs, int n, int64_t B, int C, int H, int W,
+                                               nf_stream_t stream) {
+    if (!nf_gh_shape_ok(B, C, H, W) || descs == nullptr || n < 1 || n > NF_GLOW_HEAD_MULTI_MAX) return NF_E_BADARG;
+    NfGhMulti m;
+    for (int i = 0; i < n; ++i) {
+        const nf_glow_head_params_desc& d = descs[i];
+        if (d.g_h == nullptr || d.g_ld == nullptr || d.x == nullptr || d.act_log_scale == nullptr || d.act_bias == nullptr || d.W == nullptr ||
+            d.g_log_scale == nullptr || d.g_bias == nullptr || d.g_W == nullptr)
+            return NF_E_BADARG;
+        m.d[i] = d;
+    }
     const int P = H * W;
-    const int rt = (C + 15) / 16, kq = (C + 3) / 4;
-    const int64_t npix = B * P;
-    // Tile and grid by the kernel's register footprint (-Rpass-analysis=kernel-resource-usage): the 128-pixel tile of 33 .. 64 channels
-    // holds 388 registers -- one workgroup per compute unit, so 512 workgroups ran in two rounds (137 us on (48, 8, 8) x 8192; with the
-    // 64-pixel tile, two workgroups per unit, 99) -- and the grid is ONE round of what fits (12 channels: three per unit, 91 -> 83 us).
-    // 33 .. 64 channels: the 128-pixel tile while its tiles are ONE round of one workgroup per compute unit (B = 512 at (48, 8, 8): 256 tiles,
-    // 27.5 us against 36.7 with 512 64-pixel tiles -- profiles/r04_c4_b512_step_kernels.txt before / after the tile rule above), the 64-pixel
-    // tile beyond (two workgroups per unit instead of a second round) and below 64 tiles (latency: a wave's share of the chain halves)
-    const int64_t t128 = (npix + 127) / 128;
-    const int TP = (t128 < 64 || (rt >= 3 && t128 > 256)) ? 64 : 128;
-    const int cap = rt == 1 ? 768 : (rt <= 3 ? 512 : 256);
-    const int64_t tiles = (npix + TP - 1) / TP;
-    int64_t blocks = tiles < cap ? tiles : cap;              // ends in C * C + 2 C same-address atomics per block
-    const int64_t tpb = (tiles + blocks - 1) / blocks;
-    blocks = (tiles + tpb - 1) / tpb;
-    const size_t lds = ((size_t)2 * rt * 16 * (128 + 1) + 2 * rt * 16) * sizeof(float);   // (sized for either tile; the reductions alias it)
+    const NfGhPlan p = nf_gh_bwd_plan(B, C, P, n);
     hipStream_t st = (hipStream_t)stream;
-#define NF_CASE(RT, KQ)                                                                                                         \
-    if (rt == RT && kq == KQ) {                                                                                                 \
-        if (TP == 64)                                                                                                           \
-            hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ, 64>), dim3((unsigned)blocks), dim3(NF_BLOCK), lds, st, g_h, g_ld, x,  \
-                               act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, tpb);                       \
-        else                                                                                                                    \
-            hipLaunchKernelGGL((k_glow_head_w_bwd<RT, KQ, 128>), dim3((unsigned)blocks), dim3(NF_BLOCK), lds, st, g_h, g_ld, x, \
-                               act_log_scale, act_bias, Wm, g_x, g_log_scale, g_bias, g_W, B, C, P, tpb);                       \
-        NF_CHECK_LAUNCH();                                                                                                      \
-        return 0;                                                                                                               \
+#define NF_CASE(RT, KQ)                                                                                                                   \
+    if (p.rt == RT && p.kq == KQ) {                                                                                                       \
+        if (p.TP == 64)                                                                                                                   \
+            hipLaunchKernelGGL((k_glow_head_w_params_multi<RT, KQ, 64>), dim3((unsigned)p.blocks, (unsigned)n), dim3(NF_BLOCK), p.lds, st, m, B, \
+                               C, P, p.tpb);                                                                                              \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((k_glow_head_w_params_multi<RT, KQ, 128>), dim3((unsigned)p.blocks, (unsigned)n), dim3(NF_BLOCK), p.lds, st, m, B, \
+                               C, P, p.tpb);                                                                                              \
+        NF_CHECK_LAUNCH();                                                                                                                \
+        return 0;                                                                                                                         \
     }
     NF_CASE(1, 3) NF_CASE(1, 4) NF_CASE(2, 5) NF_CASE(2, 6) NF_CASE(2, 7) NF_CASE(2, 8) NF_CASE(3, 9) NF_CASE(3, 10)
     NF_CASE(3, 11) NF_CASE(3, 12) NF_CASE(4, 13) NF_CASE(4, 14) NF_CASE(4, 15) NF_CASE(4, 16)

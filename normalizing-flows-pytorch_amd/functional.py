@@ -7,6 +7,8 @@ own ``torch.no_grad`` inverse of the invertible 1x1 convolution (flows/modules.p
 ``ld`` (``log_df_dz``) is updated IN PLACE and returned, as the reference does (coupling.py:110,
 modules.py:249,305,480); only the returned tensor is contractual.
 """
+import ctypes
+
 import torch
 
 from . import _native as N
@@ -414,6 +416,7 @@ class PluHolder:
     def __init__(self, n):
         self.g_ld = [None] * n
         self.meta = [None] * n
+        self.pending = []       # heads whose parameter gradients wait for the batched launch (_GlowHeadW.backward -> flush_head_params)
 
 
 class _InvConvApplyW(torch.autograd.Function):
@@ -600,6 +603,14 @@ class _GlowHeadW(torch.autograd.Function):
         direct = ctx.sinks is not None
         tmp = WS.zeros(C * C + (0 if direct else 2 * C), x.device)
         g_W = tmp[:C * C].view_as(W)
+        if HEAD_PARAMS_DEFER and direct and ctx.needs_input_grad[4]:
+            # only g_x is on the way of the backward pass: the contractions over the batch (g_W, g_log_scale, g_bias) of all heads of one
+            # shape run in one launch where the pass ends -- in front of the PLU backward that reads g_W (fused._PLUWeightsMulti.backward).
+            # What they read is kept alive here: g_h, g_ld (nothing writes to a gradient autograd has handed over), x.
+            N.call('nf_glow_head_w_bwd_data', N.ptr(g_h), N.ptr(log_scale), N.ptr(W), N.ptr(g_x), B, C, H, Wd, N.stream())
+            ctx.holder.pending.append(((B, C, H, Wd), g_h, g_ld, x, log_scale, bias, W, ctx.sinks[0], ctx.sinks[1], g_W))
+            ctx.holder.g_ld[ctx.idx] = g_ld
+            return g_x, g_ld, None, None, g_W, None, None, None, None, None, None
         if direct:
             p_ls, p_b, g_ls, g_b = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
         else:
@@ -609,6 +620,34 @@ class _GlowHeadW(torch.autograd.Function):
                p_b, N.ptr(g_W), B, C, H, Wd, N.stream())
         ctx.holder.g_ld[ctx.idx] = g_ld
         return g_x, g_ld, g_ls, g_b, g_W, None, None, None, None, None, None
+
+
+HEAD_PARAMS_DEFER = True      # (internal constant: tests flip it to compare the two forms of the head backward)
+
+
+class GlowHeadParamsDesc(ctypes.Structure):
+    """include/nfhip.h: nf_glow_head_params_desc"""
+    _fields_ = [(f, ctypes.c_void_p) for f in ('g_h', 'g_ld', 'x', 'act_log_scale', 'act_bias', 'W', 'g_log_scale', 'g_bias', 'g_W')]
+
+
+def flush_head_params(holder):
+    """the parameter gradients of the heads queued on ``holder``: heads of one shape share launches of NF_GLOW_HEAD_MULTI_MAX"""
+    pend, holder.pending = holder.pending, []
+    if not pend:
+        return
+    step = N.header_constant('NF_GLOW_HEAD_MULTI_MAX')
+    groups = {}
+    for e in pend:
+        groups.setdefault(e[0], []).append(e)
+    for (B, C, H, Wd), es in groups.items():
+        for k0 in range(0, len(es), step):
+            chunk = es[k0:k0 + step]
+            arr = (GlowHeadParamsDesc * len(chunk))()
+            for i, (_, g_h, g_ld, x, ls, bs, W, s_ls, s_b, g_W) in enumerate(chunk):
+                d = arr[i]
+                d.g_h, d.g_ld, d.x, d.act_log_scale, d.act_bias, d.W = g_h.data_ptr(), g_ld.data_ptr(), x.data_ptr(), ls.data_ptr(), bs.data_ptr(), W.data_ptr()
+                d.g_log_scale, d.g_bias, d.g_W = s_ls.data_ptr(), s_b.data_ptr(), g_W.data_ptr()
+            N.call('nf_glow_head_w_bwd_params_multi', ctypes.addressof(arr), len(chunk), B, C, H, Wd, N.stream())
 
 
 PENDING_HEADS = {}      # address of h -> operands of a head forward that its coupling's chain launch performs (_GlowHeadW.forward(defer=True))

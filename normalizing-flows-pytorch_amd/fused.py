@@ -1784,6 +1784,8 @@ class _PLUWeightsMulti(torch.autograd.Function):
         tensors = ctx.saved_tensors
         n = len(tensors) // 7
         holder = ctx.holder
+        from .functional import flush_head_params
+        flush_head_params(holder)                 # the heads' deferred parameter gradients fill g_Ws
         descs, grads = [], [None]
         for i in range(n):
             P, L, U, Lm, Um, sg, ls = tensors[7 * i:7 * i + 7]

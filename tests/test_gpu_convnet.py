@@ -211,6 +211,83 @@ def test_glow_head_w_matches_the_three_layers(pkg, C, H, W, mode_name, odd, B):
         G.assert_close(g1, g2, 2e-5 * max(1.0, float(g2.abs().max())), rtol=1e-5, what='grad ' + what)
 
 
+@pytest.mark.parametrize('C,H,W,B,heads', [(12, 16, 16, 64, 33), (48, 8, 8, 64, 5), (48, 8, 8, 512, 3), (12, 16, 16, 512, 2), (10, 4, 8, 3, 1),
+                                          (64, 4, 4, 9, 4), (33, 8, 8, 1030, 2)])
+def test_glow_head_backward_in_two_parts(pkg, C, H, W, B, heads):
+    """nf_glow_head_w_bwd_data (g_x alone) + nf_glow_head_w_bwd_params_multi (g_W, g_log_scale, g_bias of many heads per launch, +=) against
+    nf_glow_head_w_bwd: g_x BITWISE, the parameter gradients to the rounding of their atomics' order (bitwise in deterministic mode)."""
+    import ctypes
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    Nn = pkg._native
+    torch.manual_seed(11)
+    step = Nn.header_constant('NF_GLOW_HEAD_MULTI_MAX')
+    for det in (False, True):
+        was = Nn.deterministic()
+        Nn.deterministic(det)
+        try:
+            cases = []
+            for i in range(heads):
+                g_h, x = torch.randn(B, C, H, W, device=DEV), torch.randn(B, C, H, W, device=DEV)
+                g_ld = torch.randn(B, device=DEV)
+                ls, bs = 0.3 * torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+                Wm = (torch.linalg.qr(torch.randn(C, C, device=DEV))[0] + 0.05 * torch.randn(C, C, device=DEV)).contiguous()
+                ref = [torch.empty_like(x), torch.full((C, ), 0.5, device=DEV), torch.full((C, ), -0.25, device=DEV), torch.full((C, C), 2.0, device=DEV)]
+                Nn.call('nf_glow_head_w_bwd', Nn.ptr(g_h), Nn.ptr(g_ld), Nn.ptr(x), Nn.ptr(ls), Nn.ptr(bs), Nn.ptr(Wm), Nn.ptr(ref[0]), Nn.ptr(ref[1]),
+                        Nn.ptr(ref[2]), Nn.ptr(ref[3]), B, C, H, W, Nn.stream())
+                two = [torch.empty_like(x), torch.full((C, ), 0.5, device=DEV), torch.full((C, ), -0.25, device=DEV), torch.full((C, C), 2.0, device=DEV)]
+                Nn.call('nf_glow_head_w_bwd_data', Nn.ptr(g_h), Nn.ptr(ls), Nn.ptr(Wm), Nn.ptr(two[0]), B, C, H, W, Nn.stream())
+                cases.append((g_h, g_ld, x, ls, bs, Wm, ref, two))
+            for k0 in range(0, heads, step):
+                chunk = cases[k0:k0 + step]
+                arr = (NF.GlowHeadParamsDesc * len(chunk))()
+                for i, (g_h, g_ld, x, ls, bs, Wm, ref, two) in enumerate(chunk):
+                    d = arr[i]
+                    d.g_h, d.g_ld, d.x, d.act_log_scale, d.act_bias, d.W = (t.data_ptr() for t in (g_h, g_ld, x, ls, bs, Wm))
+                    d.g_log_scale, d.g_bias, d.g_W = two[1].data_ptr(), two[2].data_ptr(), two[3].data_ptr()
+                Nn.call('nf_glow_head_w_bwd_params_multi', ctypes.addressof(arr), len(chunk), B, C, H, W, Nn.stream())
+            torch.cuda.synchronize()
+            for i, c in enumerate(cases):
+                ref, two = c[6], c[7]
+                assert torch.equal(ref[0], two[0]), ('g_x', i, float((ref[0] - two[0]).abs().max()))
+                for what, a, b in (('g_log_scale', ref[1], two[1]), ('g_bias', ref[2], two[2]), ('g_W', ref[3], two[3])):
+                    if det and heads == 1:
+                        assert torch.equal(a, b), (what, i, float((a - b).abs().max()))
+                    else:
+                        # (in the mode both forms add workgroup by workgroup, but a launch of many heads walks fewer tiles per workgroup)
+                        G.assert_close(b, a, 2e-5 * max(1.0, float(a.abs().max())), rtol=1e-5, what='%s of head %d' % (what, i))
+            assert Nn.deterministic_timeouts() == 0
+        finally:
+            Nn.deterministic(was)
+
+
+def test_cifar_glow_head_parameter_gradients_deferred_or_not(pkg, monkeypatch):
+    """a trainer step of a (3, 32, 32) Glow with the heads' parameter gradients deferred to the batched launch (the default) and with every
+    head's backward whole: z and the loss BITWISE (the forward is untouched), the flat gradient to the rounding of the atomics' order."""
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    from types import SimpleNamespace as NS
+    outs = []
+    y = torch.rand(16, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    torch.manual_seed(2)
+    net = pkg.Glow((3, 32, 32), 'image', NS(layers=3, mixtures=None)).to(DEV)
+    tr = nftrain.FlowTrainer(net, graph=False)
+    tr.train_on_batch(y)                                # data-dependent initialisation
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for on in (True, False):
+        monkeypatch.setattr(NF, 'HEAD_PARAMS_DEFER', on)
+        net.load_state_dict(sd)
+        z, loss = tr._forward_backward(y)
+        torch.cuda.synchronize()
+        outs.append((z.detach().clone(), loss.detach().clone(), tr.bucket.flat.detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    d = (outs[0][2] - outs[1][2]).double()
+    rel = float(d.norm() / outs[1][2].double().norm())
+    assert rel <= 1e-5, rel
+    assert float(outs[0][2].abs().max()) > 0
+    assert pkg._native.persistent_timeouts() == 0
+
+
 def test_cifar_glow_with_and_without_the_fused_heads(pkg, monkeypatch):
     """a (3, 32, 32) Glow with two steps per level: the fused heads (C = 12, 48) and the fused couplings against the per-layer
     launches -- z, log-det and every parameter gradient of one training-mode pass."""
