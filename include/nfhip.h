@@ -174,6 +174,17 @@ int nf_glow_head_fwd(const float* z, const float* log_scale, const float* bias, 
 int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z, const float* log_scale,
                      const float* bias, const float* W_saved, float* g_z, float* g_log_scale, float* g_bias, float* g_W,
                      float* sum_g_ld, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+/* nf_glow_head_bwd in two parts (same arithmetic): the data gradient on the pass, the parameter sums of n <= NF_GLOW_HEAD_MULTI_MAX heads
+ * of one shape and split mode in one launch where the pass ends (in front of nf_invconv_weight_bwd_multi, which reads g_W, sum_g_ld). */
+typedef struct nf_glow_head_small_params_desc {
+    const float *g_h, *g_z1c /* nullable */, *g_ld, *z, *log_scale, *bias, *W_saved;
+    float *g_log_scale, *g_bias, *g_W, *sum_g_ld /* nullable */;
+    int odd, reserved;
+} nf_glow_head_small_params_desc;
+int nf_glow_head_bwd_data(const float* g_h, const float* g_z1c, const float* log_scale, const float* W_saved, float* g_z, int mode, int odd,
+                          int64_t B, int C, int H, int W, nf_stream_t stream);
+int nf_glow_head_bwd_params_multi(const nf_glow_head_small_params_desc* descs, int n, int mode, int64_t B, int C, int H, int W,
+                                  nf_stream_t stream);
 /* The same head for 9 <= C <= 64 channels of image data with the 1x1 weight W given assembled (nf_invconv_weight_fwd_multi), on
  * the fp32 matrix cores; (H * W) % 16 == 0, mode NF_SPLIT_CHANNEL | NF_SPLIT_CHECKER.  (flows/modules.py:246-249, :470-482,
  * flows/coupling.py:33)

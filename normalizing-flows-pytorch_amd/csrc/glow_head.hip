@@ -115,13 +115,16 @@ __device__ __forceinline__ void nf_gh_bwd_load(const float* __restrict__ gh, con
     }
 }
 
-template <int CT>
-__global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __restrict__ gh, const float* __restrict__ gz1c,
-                                                             const float* __restrict__ gld, const float* __restrict__ z,
-                                                             const float* __restrict__ ls, const float* __restrict__ bs,
-                                                             const float* __restrict__ Wsaved, float* __restrict__ gz,
-                                                             float* __restrict__ g_ls, float* __restrict__ g_bias,
-                                                             float* __restrict__ gW, float* __restrict__ sum_gld, NfSplit s, int64_t B, int P) {
+// PART: 0 = everything; 1 = the data gradient g_z alone; 2 = the parameter sums alone (many heads per launch: k_glow_head_params_multi).
+// Same per-pixel arithmetic, same block partition: 1 + 2 reproduce 0.
+template <int CT, int PART>
+__device__ __forceinline__ void nf_gh_bwd_body(const float* __restrict__ gh, const float* __restrict__ gz1c,
+                                               const float* __restrict__ gld, const float* __restrict__ z,
+                                               const float* __restrict__ ls, const float* __restrict__ bs,
+                                               const float* __restrict__ Wsaved, float* __restrict__ gz,
+                                               float* __restrict__ g_ls, float* __restrict__ g_bias,
+                                               float* __restrict__ gW, float* __restrict__ sum_gld, const NfSplit& s, int64_t B, int P) {
+    constexpr bool DATA = PART != 2, PARAMS = PART != 1;
     float Wm[CT][CT], es[CT], bb[CT];
 #pragma unroll
     for (int r = 0; r < CT; ++r)
@@ -140,7 +143,8 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t npix = B * P;
     float sg = 0.f;                                  // this block's share of sum_b g_ld: requested with the first pixels (behind the
-    for (int64_t b = gtid; b < B; b += gstride) sg += gld[b];     // loop it was a round trip of its own at the end of the launch)
+    if (PARAMS)
+        for (int64_t b = gtid; b < B; b += gstride) sg += gld[b]; // loop it was a round trip of its own at the end of the launch)
     for (int64_t t = gtid; t < npix; t += 2 * gstride) {     // two pixels per trip: their loads are in flight together
         const int64_t t2 = t + gstride;
         const bool has2 = t2 < npix;
@@ -160,15 +164,18 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
 #pragma unroll
                 for (int r = 0; r < CT; ++r) {
                     a = fmaf(Wm[r][c], G[u][r], a);
-                    aW[r][c] = fmaf(G[u][r], zn[c], aW[r][c]);
+                    if (PARAMS) aW[r][c] = fmaf(G[u][r], zn[c], aW[r][c]);
                 }
                 const float gzc = a * es[c];
-                gz[base[u] + (int64_t)c * P] = gzc;
-                aB[c] -= gzc;
-                aL[c] = fmaf(-a, zn[c], aL[c]);
+                if (DATA) gz[base[u] + (int64_t)c * P] = gzc;
+                if (PARAMS) {
+                    aB[c] -= gzc;
+                    aL[c] = fmaf(-a, zn[c], aL[c]);
+                }
             }
         }
     }
+    if (!PARAMS) return;
     // the block's 1 + CT (2 + CT) sums in ONE pass: wave sums by shuffles, the sixteen wave partials of every value side by side in
     // LDS, one barrier, thread i finishes value i (one nf_block_sum per value was 2 barriers each: 32 in a row at CT = 3, ~8 of the
     // launch's 19 us); partials are added in wave order, as nf_block_sum does
@@ -212,6 +219,25 @@ __global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __rest
     NF_DET_LEAVE_ALL(nf_gh);
 }
 
+template <int CT, int PART>
+__global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_bwd(const float* __restrict__ gh, const float* __restrict__ gz1c,
+                                                             const float* __restrict__ gld, const float* __restrict__ z,
+                                                             const float* __restrict__ ls, const float* __restrict__ bs,
+                                                             const float* __restrict__ Wsaved, float* __restrict__ gz,
+                                                             float* __restrict__ g_ls, float* __restrict__ g_bias,
+                                                             float* __restrict__ gW, float* __restrict__ sum_gld, NfSplit s, int64_t B, int P) {
+    nf_gh_bwd_body<CT, PART>(gh, gz1c, gld, z, ls, bs, Wsaved, gz, g_ls, g_bias, gW, sum_gld, s, B, P);
+}
+
+struct NfGhsMulti { nf_glow_head_small_params_desc d[NF_GLOW_HEAD_MULTI_MAX]; };
+template <int CT>
+__global__ void __launch_bounds__(NF_GH_BIG) k_glow_head_params_multi(NfGhsMulti m, NfSplit s, int64_t B, int P) {
+    const nf_glow_head_small_params_desc& d = m.d[blockIdx.y];
+    NfSplit sd = s;
+    sd.odd = d.odd;
+    nf_gh_bwd_body<CT, 2>(d.g_h, d.g_z1c, d.g_ld, d.z, d.log_scale, d.bias, d.W_saved, nullptr, d.g_log_scale, d.g_bias, d.g_W, d.sum_g_ld, sd, B, P);
+}
+
 extern "C" int nf_glow_head_fwd(const float* z, const float* log_scale, const float* bias, const float* P,
                                 const float* L, const float* U, const float* L_mask, const float* U_mask,
                                 const float* sign_s, const float* log_s, float* h, float* z1c, float* W_out, float* ld,
@@ -232,10 +258,10 @@ extern "C" int nf_glow_head_fwd(const float* z, const float* log_scale, const fl
     return 0;
 }
 
-extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z,
-                                const float* log_scale, const float* bias, const float* W_saved, float* g_z,
-                                float* g_log_scale, float* g_bias, float* g_W, float* sum_g_ld, int mode, int odd,
-                                int64_t B, int C, int H, int W, nf_stream_t stream) {
+template <int PART>
+static int nf_gh_bwd_launch(const float* g_h, const float* g_z1c, const float* g_ld, const float* z, const float* log_scale, const float* bias,
+                            const float* W_saved, float* g_z, float* g_log_scale, float* g_bias, float* g_W, float* sum_g_ld, int mode, int odd,
+                            int64_t B, int C, int H, int W, nf_stream_t stream) {
     NfSplit s;
     if (!nf_make_split(s, mode, odd, C, H, W) || mode == NF_SPLIT_NONE) return NF_E_BADARG;
     if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
@@ -245,7 +271,52 @@ extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const floa
     unsigned g = nf_grid_for(B * Px, thr * 2);
     if (g > 256) g = 256;
     hipStream_t st = (hipStream_t)stream;
-#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_bwd<CT>, dim3(g), dim3(thr), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, s, B, Px); break;
+#define NF_CASE(CT) case CT: hipLaunchKernelGGL((k_glow_head_bwd<CT, PART>), dim3(g), dim3(thr), 0, st, g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, s, B, Px); break;
+    switch (C) { NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) default: return NF_E_UNSUPPORTED; }
+#undef NF_CASE
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nf_glow_head_bwd(const float* g_h, const float* g_z1c, const float* g_ld, const float* z,
+                                const float* log_scale, const float* bias, const float* W_saved, float* g_z,
+                                float* g_log_scale, float* g_bias, float* g_W, float* sum_g_ld, int mode, int odd,
+                                int64_t B, int C, int H, int W, nf_stream_t stream) {
+    return nf_gh_bwd_launch<0>(g_h, g_z1c, g_ld, z, log_scale, bias, W_saved, g_z, g_log_scale, g_bias, g_W, sum_g_ld, mode, odd, B, C, H, W, stream);
+}
+
+// the data gradient alone (the backward pass waits for nothing else) ...
+extern "C" int nf_glow_head_bwd_data(const float* g_h, const float* g_z1c, const float* log_scale, const float* W_saved, float* g_z, int mode,
+                                     int odd, int64_t B, int C, int H, int W, nf_stream_t stream) {
+    if (g_h == nullptr || log_scale == nullptr || W_saved == nullptr || g_z == nullptr) return NF_E_BADARG;
+    // (z and bias are not read for the data gradient: the compiler drops their loads; any valid address serves)
+    return nf_gh_bwd_launch<1>(g_h, g_z1c, nullptr, g_h, log_scale, log_scale, W_saved, g_z, nullptr, nullptr, nullptr, nullptr, mode, odd, B, C, H,
+                               W, stream);
+}
+
+// ... and g_log_scale, g_bias, g_W, sum_g_ld (+=) of n heads of one shape and split mode in one launch (their `odd` per head)
+extern "C" int nf_glow_head_bwd_params_multi(const nf_glow_head_small_params_desc* descs, int n, int mode, int64_t B, int C, int H, int W,
+                                             nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_make_split(s, mode, 0, C, H, W) || mode == NF_SPLIT_NONE) return NF_E_BADARG;
+    if (C > NF_HEAD_MAXC) return NF_E_UNSUPPORTED;
+    if (descs == nullptr || n < 1 || n > NF_GLOW_HEAD_MULTI_MAX) return NF_E_BADARG;
+    if (B == 0) return 0;
+    NfGhsMulti m;
+    for (int i = 0; i < n; ++i) {
+        const nf_glow_head_small_params_desc& d = descs[i];
+        if (d.g_h == nullptr || d.g_ld == nullptr || d.z == nullptr || d.log_scale == nullptr || d.bias == nullptr || d.W_saved == nullptr ||
+            d.g_log_scale == nullptr || d.g_bias == nullptr || d.g_W == nullptr)
+            return NF_E_BADARG;
+        m.d[i] = d;
+    }
+    const int Px = H * W;
+    const int thr = 512;
+    unsigned g = nf_grid_for(B * Px, thr * 2);
+    const unsigned cap = 256u / (unsigned)n > 8u ? 256u / (unsigned)n : 8u;
+    if (g > cap) g = cap;
+    hipStream_t st = (hipStream_t)stream;
+#define NF_CASE(CT) case CT: hipLaunchKernelGGL(k_glow_head_params_multi<CT>, dim3(g, (unsigned)n), dim3(thr), 0, st, m, s, B, Px); break;
     switch (C) { NF_CASE(1) NF_CASE(2) NF_CASE(3) NF_CASE(4) default: return NF_E_UNSUPPORTED; }
 #undef NF_CASE
     NF_CHECK_LAUNCH();

@@ -544,10 +544,15 @@ class _GlowHead(torch.autograd.Function):
         else:
             g_ls, g_b = tmp[C * C + 4:C * C + 4 + C].view_as(log_scale), tmp[C * C + 4 + C:].view_as(bias)
             g_L, g_U, g_logs = torch.empty_like(L), torch.empty_like(U), torch.empty_like(log_s)
-        N.call('nf_glow_head_bwd', N.ptr(g_h), N.ptr(g_z1c), N.ptr(g_ld), N.ptr(z), N.ptr(log_scale), N.ptr(bias),
-               N.ptr(Wm), N.ptr(g_z), N.ptr(g_ls), N.ptr(g_b), N.ptr(g_W), N.ptr(sum_gld), mode, odd, B, C, H, W,
-               N.stream())
         from .fused_conv import CONV_DEFER
+        if direct and CONV_DEFER.active and HEAD_PARAMS_DEFER:
+            # the data gradient now; the parameter sums of all such heads in one launch at the end-of-pass flush, in front of their PLU jobs
+            N.call('nf_glow_head_bwd_data', N.ptr(g_h), N.ptr(g_z1c), N.ptr(log_scale), N.ptr(Wm), N.ptr(g_z), mode, odd, B, C, H, W, N.stream())
+            CONV_DEFER.head_jobs.append(((mode, B, C, H, W), g_h, g_z1c, g_ld, z, log_scale, bias, Wm, g_ls, g_b, g_W, sum_gld, int(odd)))
+        else:
+            N.call('nf_glow_head_bwd', N.ptr(g_h), N.ptr(g_z1c), N.ptr(g_ld), N.ptr(z), N.ptr(log_scale), N.ptr(bias),
+                   N.ptr(Wm), N.ptr(g_z), N.ptr(g_ls), N.ptr(g_b), N.ptr(g_W), N.ptr(sum_gld), mode, odd, B, C, H, W,
+                   N.stream())
         if direct and CONV_DEFER.active:
             # inside a trainer step the PLU backward (8 us per layer on the backward pass's latency chain, nothing but Adam waits for
             # it) joins the end-of-pass flush: all queued layers in one nf_invconv_weight_bwd_multi launch per 24
@@ -628,6 +633,30 @@ HEAD_PARAMS_DEFER = True      # (internal constant: tests flip it to compare the
 class GlowHeadParamsDesc(ctypes.Structure):
     """include/nfhip.h: nf_glow_head_params_desc"""
     _fields_ = [(f, ctypes.c_void_p) for f in ('g_h', 'g_ld', 'x', 'act_log_scale', 'act_bias', 'W', 'g_log_scale', 'g_bias', 'g_W')]
+
+
+class GlowHeadSmallParamsDesc(ctypes.Structure):
+    """include/nfhip.h: nf_glow_head_small_params_desc"""
+    _fields_ = [(f, ctypes.c_void_p) for f in ('g_h', 'g_z1c', 'g_ld', 'z', 'log_scale', 'bias', 'W_saved', 'g_log_scale', 'g_bias', 'g_W',
+                                                'sum_g_ld')] + [('odd', ctypes.c_int), ('reserved', ctypes.c_int)]
+
+
+def launch_small_head_params(jobs):
+    """the parameter sums of the C <= 4 heads queued by _GlowHead.backward (fused_conv.ConvDefer.flush)"""
+    step = N.header_constant('NF_GLOW_HEAD_MULTI_MAX')
+    groups = {}
+    for e in jobs:
+        groups.setdefault(e[0], []).append(e)
+    for (mode, B, C, H, W), es in groups.items():
+        for k0 in range(0, len(es), step):
+            chunk = es[k0:k0 + step]
+            arr = (GlowHeadSmallParamsDesc * len(chunk))()
+            for i, (_, g_h, g_z1c, g_ld, z, ls, bs, Wm, g_ls, g_b, g_W, sum_gld, odd) in enumerate(chunk):
+                d = arr[i]
+                d.g_h, d.g_z1c, d.g_ld, d.z = g_h.data_ptr(), (g_z1c.data_ptr() if g_z1c is not None else None), g_ld.data_ptr(), z.data_ptr()
+                d.log_scale, d.bias, d.W_saved = ls.data_ptr(), bs.data_ptr(), Wm.data_ptr()
+                d.g_log_scale, d.g_bias, d.g_W, d.sum_g_ld, d.odd = g_ls.data_ptr(), g_b.data_ptr(), g_W.data_ptr(), sum_gld.data_ptr(), odd
+            N.call('nf_glow_head_bwd_params_multi', ctypes.addressof(arr), len(chunk), mode, B, C, H, W, N.stream())
 
 
 def flush_head_params(holder):

@@ -199,11 +199,13 @@ class ConvDefer:
         self.sums = []          # slab-sum jobs that read accumulators the deferred passes fill, or that can wait as well
         self.scratch = {}
         self.plu_jobs = []      # PLU weight backward of the C <= 4 heads (functional._GlowHead): batched at the flush
+        self.head_jobs = []     # ... and their parameter sums, which those PLU jobs read (functional.launch_small_head_params)
 
     def begin(self):
         self.layers, self.sums = [], []
         self.active, self.armed = CONV_DEFER_ON, False
         self.plu_jobs = []
+        self.head_jobs = []
 
     def arm(self, weights):
         """fused.weight_norm_all: these effective weights' gradients are consumed by a backward that flushes first"""
@@ -254,6 +256,10 @@ class ConvDefer:
         layers, sums = self.layers, self.sums
         self.layers, self.sums, self.active, self.armed = [], [], False, False
         plu, self.plu_jobs = self.plu_jobs, []
+        heads, self.head_jobs = self.head_jobs, []
+        if heads:
+            from .functional import launch_small_head_params
+            launch_small_head_params(heads)
         if plu:
             from .fused import PluDesc, _plu_launch
             from .fused import _desc as _fdesc

@@ -260,6 +260,39 @@ def test_glow_head_backward_in_two_parts(pkg, C, H, W, B, heads):
             Nn.deterministic(was)
 
 
+@pytest.mark.parametrize('C,H,W,B,mode_name,heads,with_z1c', [(3, 32, 32, 64, 'checkerboard', 32, False), (4, 8, 8, 7, 'channelwise', 3, True),
+                                                             (2, 4, 4, 1, 'channelwise', 1, False), (3, 32, 32, 512, 'checkerboard', 2, True)])
+def test_small_glow_head_backward_in_two_parts(pkg, C, H, W, B, mode_name, heads, with_z1c):
+    """the C <= 4 head: nf_glow_head_bwd_data + nf_glow_head_bwd_params_multi against nf_glow_head_bwd (g_z bitwise, the sums to rounding)"""
+    import ctypes
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    Nn = pkg._native
+    mode = Nn.SPLIT_CHANNEL if mode_name == 'channelwise' else Nn.SPLIT_CHECKER
+    torch.manual_seed(12)
+    cases = []
+    for i in range(heads):
+        odd = i & 1
+        g_h, z = torch.randn(B, C, H, W, device=DEV), torch.randn(B, C, H, W, device=DEV)
+        g_z1c = torch.randn(NF._half_shape(z, mode), device=DEV) if with_z1c else None
+        g_ld = torch.randn(B, device=DEV)
+        ls, bs = 0.3 * torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        Wm = (torch.linalg.qr(torch.randn(C, C, device=DEV))[0] + 0.05 * torch.randn(C, C, device=DEV)).contiguous()
+        mk = lambda: [torch.empty_like(z), torch.full((C, ), 0.5, device=DEV), torch.full((C, ), -0.25, device=DEV), torch.full((C, C), 2.0, device=DEV),
+                      torch.full((1, ), 3.0, device=DEV)]
+        ref, two = mk(), mk()
+        Nn.call('nf_glow_head_bwd', Nn.ptr(g_h), Nn.ptr(g_z1c), Nn.ptr(g_ld), Nn.ptr(z), Nn.ptr(ls), Nn.ptr(bs), Nn.ptr(Wm), Nn.ptr(ref[0]), Nn.ptr(ref[1]),
+                Nn.ptr(ref[2]), Nn.ptr(ref[3]), Nn.ptr(ref[4]), mode, odd, B, C, H, W, Nn.stream())
+        Nn.call('nf_glow_head_bwd_data', Nn.ptr(g_h), Nn.ptr(g_z1c), Nn.ptr(ls), Nn.ptr(Wm), Nn.ptr(two[0]), mode, odd, B, C, H, W, Nn.stream())
+        cases.append(((mode, B, C, H, W), g_h, g_z1c, g_ld, z, ls, bs, Wm, two[1], two[2], two[3], two[4], odd, ref, two))
+    NF.launch_small_head_params([c[:13] for c in cases])
+    torch.cuda.synchronize()
+    for i, c in enumerate(cases):
+        ref, two = c[13], c[14]
+        assert torch.equal(ref[0], two[0]), ('g_z', i, float((ref[0] - two[0]).abs().max()))
+        for what, a, b in zip(('g_log_scale', 'g_bias', 'g_W', 'sum_g_ld'), ref[1:], two[1:]):
+            G.assert_close(b, a, 2e-5 * max(1.0, float(a.abs().max())), rtol=1e-5, what='%s of head %d' % (what, i))
+
+
 def test_cifar_glow_head_parameter_gradients_deferred_or_not(pkg, monkeypatch):
     """a trainer step of a (3, 32, 32) Glow with the heads' parameter gradients deferred to the batched launch (the default) and with every
     head's backward whole: z and the loss BITWISE (the forward is untouched), the flat gradient to the rounding of the atomics' order."""
@@ -274,12 +307,17 @@ def test_cifar_glow_head_parameter_gradients_deferred_or_not(pkg, monkeypatch):
     tr.train_on_batch(y)                                # data-dependent initialisation
     torch.cuda.synchronize()
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    for on in (True, False):
-        monkeypatch.setattr(NF, 'HEAD_PARAMS_DEFER', on)
-        net.load_state_dict(sd)
-        z, loss = tr._forward_backward(y)
-        torch.cuda.synchronize()
-        outs.append((z.detach().clone(), loss.detach().clone(), tr.bucket.flat.detach().clone()))
+    was = pkg._native.deterministic()
+    pkg._native.deterministic(True)                     # (the forward's log-det sums are ordered: z and the loss reproduce bit for bit)
+    try:
+        for on in (True, False):
+            monkeypatch.setattr(NF, 'HEAD_PARAMS_DEFER', on)
+            net.load_state_dict(sd)
+            z, loss = tr._forward_backward(y)
+            torch.cuda.synchronize()
+            outs.append((z.detach().clone(), loss.detach().clone(), tr.bucket.flat.detach().clone()))
+    finally:
+        pkg._native.deterministic(was)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     d = (outs[0][2] - outs[1][2]).double()
     rel = float(d.norm() / outs[1][2].double().norm())
