@@ -1044,6 +1044,14 @@ int nf_flowpp_img_conv(const float* in, const float* weight, const float* bias, 
 int nf_flowpp_img_wgrad_slabs(int64_t B, int Ci, int Co, int H, int W);
 int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* slab_w, float* slab_b, int n_slabs, int64_t B, int Ci, int Co,
                              int H, int W, int in_mode, nf_stream_t stream);
+/* ... of n <= NF_FLOWPP_IMG_WGRAD_MAX convolutions of ONE shape in one launch (each with its own slabs; slab_b nullable) */
+#define NF_FLOWPP_IMG_WGRAD_MAX 16
+typedef struct nf_flowpp_img_wgrad_desc {
+    const float *in, *g_out;
+    float *slab_w, *slab_b;
+} nf_flowpp_img_wgrad_desc;
+int nf_flowpp_img_conv_wgrad_multi(const nf_flowpp_img_wgrad_desc* descs, int n, int n_slabs, int64_t B, int Ci, int Co, int H, int W,
+                                   int in_mode, nf_stream_t stream);
 int nf_flowpp_img_celu_bwd(const float* x, const float* g_cat, float* g_x, int64_t B, int C, int H, int W, nf_stream_t stream);
 int nf_flowpp_img_mid_fwd(const float* x, const float* a, const float* ln1_g, const float* ln1_b, const float* pos,
                           const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,

@@ -340,11 +340,18 @@ struct NfFiGeoW {
                          GS = TPX + 1, CPT = NF_FI_THREADS / TPX, NU = 32 / CPT;     // staging: thread = (pixel t % TPX, channels t / TPX + CPT u)
 };
 
+// Up to NF_FLOWPP_IMG_WGRAD_MAX convolutions of ONE shape per launch: blockIdx.x = layer * n_slabs + slab.  (A launch of one layer is
+// a single tile's latency chain on 64 .. 192 workgroups at B = 64; the weight gradients of a pass are independent of each other and
+// only the optimizer waits for them: fused_flowpp_img.FlowppImgDefer runs them 16 layers per launch where the pass ends.)
+struct NfFiWgMulti { nf_flowpp_img_wgrad_desc d[NF_FLOWPP_IMG_WGRAD_MAX]; };
 template <int LGW, int INMODE>
-__global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* __restrict__ in, const float* __restrict__ g,
-                                                                  float* __restrict__ slab_w, float* __restrict__ slab_b, int64_t B, int Ci,
-                                                                  int Co, int V) {
+__global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(NfFiWgMulti m, int n_slabs, int64_t B, int Ci, int Co, int V) {
     using G = NfFiGeoW<LGW>;
+    const int layer = blockIdx.x / n_slabs, slab = blockIdx.x - layer * n_slabs;
+    const float* __restrict__ in = m.d[layer].in;
+    const float* __restrict__ g = m.d[layer].g_out;
+    float* __restrict__ slab_w = m.d[layer].slab_w;
+    float* __restrict__ slab_b = m.d[layer].slab_b;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* F = smem;                       // [32][CS]
     float* Gt = F + 32 * G::CS;            // [32][GS]
@@ -367,7 +374,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* _
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
     for (int e = threadIdx.x; e < 32 * G::CS; e += NF_FI_THREADS) F[e] = 0.f;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int64_t tile = slab; tile < tiles; tile += n_slabs) {
         const int bs = (int)(tile * G::S) + ss;
         float tf[G::NU], tgv[G::NU];
 #pragma unroll
@@ -405,7 +412,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* _
             for (int p = 0; p < G::TPX; ++p) bsum += Gt[threadIdx.x * G::GS + p];
     }
     if (slab_b != nullptr && blockIdx.z == 0 && threadIdx.x < 32 && o0 + (int)threadIdx.x < Co)
-        slab_b[(int64_t)blockIdx.x * Co + o0 + threadIdx.x] = bsum;
+        slab_b[(int64_t)slab * Co + o0 + threadIdx.x] = bsum;
     if (ph == 1) {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -414,7 +421,7 @@ __global__ void __launch_bounds__(NF_FI_THREADS) k_fi_conv_wgrad2(const float* _
     }
     __syncthreads();
     if (ph == 0) {
-        float* sw = slab_w + (int64_t)blockIdx.x * Co * Ci * 9;
+        float* sw = slab_w + (int64_t)slab * Co * Ci * 9;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if (t < nt) {
@@ -922,18 +929,17 @@ extern "C" int nf_flowpp_img_conv(const float* in, const float* weight, const fl
 }
 
 template <int LGW>
-static int nf_fi_wgrad_launch(const float* in, const float* g, float* sw, float* sb, int n_slabs, int64_t B, int Ci, int Co, int V,
-                              int in_mode, hipStream_t st) {
+static int nf_fi_wgrad_launch(const NfFiWgMulti& m, int n, int n_slabs, int64_t B, int Ci, int Co, int V, int in_mode, hipStream_t st) {
     using G = NfFiGeoW<LGW>;
     const size_t lds = (size_t)(32 * G::CS + 32 * G::GS + 4 * 3 * 1024) * sizeof(float);
-    const dim3 grid((unsigned)n_slabs, (unsigned)((Co + 31) / 32), (unsigned)((Ci + 31) / 32));
+    const dim3 grid((unsigned)(n_slabs * n), (unsigned)((Co + 31) / 32), (unsigned)((Ci + 31) / 32));
     int rc;
     if (in_mode == 1) {
         if ((rc = nf_fi_optin(k_fi_conv_wgrad2<LGW, 1>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co, V);
+        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 1>), grid, dim3(NF_FI_THREADS), lds, st, m, n_slabs, B, Ci, Co, V);
     } else {
         if ((rc = nf_fi_optin(k_fi_conv_wgrad2<LGW, 0>, lds)) != 0) return rc;
-        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, in, g, sw, sb, B, Ci, Co, V);
+        hipLaunchKernelGGL((k_fi_conv_wgrad2<LGW, 0>), grid, dim3(NF_FI_THREADS), lds, st, m, n_slabs, B, Ci, Co, V);
     }
     NF_CHECK_LAUNCH();
     return 0;
@@ -952,16 +958,27 @@ extern "C" int nf_flowpp_img_wgrad_slabs(int64_t B, int Ci, int Co, int H, int W
     return (int)(k < 1 ? 1 : k);
 }
 
-extern "C" int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* slab_w, float* slab_b, int n_slabs, int64_t B,
-                                        int Ci, int Co, int H, int W, int in_mode, nf_stream_t stream) {
-    if (in == nullptr || g_out == nullptr || slab_w == nullptr || !nf_flowpp_img_usable(B, Ci, Co, H, W)) return NF_E_BADARG;
+extern "C" int nf_flowpp_img_conv_wgrad_multi(const nf_flowpp_img_wgrad_desc* descs, int n, int n_slabs, int64_t B, int Ci, int Co, int H,
+                                              int W, int in_mode, nf_stream_t stream) {
+    if (descs == nullptr || n < 1 || n > NF_FLOWPP_IMG_WGRAD_MAX || !nf_flowpp_img_usable(B, Ci, Co, H, W)) return NF_E_BADARG;
     if (in_mode < 0 || in_mode > 1 || (in_mode == 1 && (Ci & 1)) || n_slabs < 1 || n_slabs > NF_FLOWPP_IMG_MAX_SLABS) return NF_E_BADARG;
+    NfFiWgMulti m{};
+    for (int i = 0; i < n; ++i) {
+        if (descs[i].in == nullptr || descs[i].g_out == nullptr || descs[i].slab_w == nullptr) return NF_E_BADARG;
+        m.d[i] = descs[i];
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
-        case 4: return nf_fi_wgrad_launch<4>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, W, in_mode, st);
-        case 3: return nf_fi_wgrad_launch<3>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, W, in_mode, st);
-        default: return nf_fi_wgrad_launch<2>(in, g_out, slab_w, slab_b, n_slabs, B, Ci, Co, W, in_mode, st);
+        case 4: return nf_fi_wgrad_launch<4>(m, n, n_slabs, B, Ci, Co, W, in_mode, st);
+        case 3: return nf_fi_wgrad_launch<3>(m, n, n_slabs, B, Ci, Co, W, in_mode, st);
+        default: return nf_fi_wgrad_launch<2>(m, n, n_slabs, B, Ci, Co, W, in_mode, st);
     }
+}
+
+extern "C" int nf_flowpp_img_conv_wgrad(const float* in, const float* g_out, float* slab_w, float* slab_b, int n_slabs, int64_t B,
+                                        int Ci, int Co, int H, int W, int in_mode, nf_stream_t stream) {
+    const nf_flowpp_img_wgrad_desc d = {in, g_out, slab_w, slab_b};
+    return nf_flowpp_img_conv_wgrad_multi(&d, 1, n_slabs, B, Ci, Co, H, W, in_mode, stream);
 }
 
 extern "C" int nf_flowpp_img_celu_bwd(const float* x, const float* g_cat, float* g_x, int64_t B, int C, int H, int W,

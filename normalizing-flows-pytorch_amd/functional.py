@@ -933,7 +933,7 @@ class _NLL(torch.autograd.Function):
     def forward(ctx, z, ld):
         B = z.shape[0]
         D = z.numel() // B
-        loss = torch.zeros((), dtype=z.dtype, device=z.device)
+        loss = WS.zeros_owned((), z.device) if z.dtype == torch.float32 else torch.zeros((), dtype=z.dtype, device=z.device)
         N.call('nf_nll_loss', N.ptr(z), N.ptr(ld), N.ptr(loss), B, D, N.stream())
         ctx.save_for_backward(z)
         return loss

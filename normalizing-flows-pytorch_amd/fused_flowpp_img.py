@@ -8,6 +8,8 @@ convolution's output): everything between the gate and the last convolution is r
 """
 import os
 
+import ctypes
+
 import torch
 
 from . import _native as N
@@ -126,8 +128,13 @@ class _FusedFlowppImg(torch.autograd.Function):
         lib = N.load()
         jobs = []
 
+        defer = direct and FPP_IMG_DEFER.active
+
         def wgrad(inp, g, gw, gb, Ci, Co, mode):
             """slabs of one convolution's weight / bias gradient; folded into gw / gb (+=) by the one nf_slab_sum below"""
+            if defer:                                            # sixteen convolutions of this shape per launch where the pass ends
+                FPP_IMG_DEFER.layers.append(((B, Ci, Co, Hh, Ww, mode), inp, g, gw, gb))
+                return
             ns = int(lib.nf_flowpp_img_wgrad_slabs(B, Ci, Co, Hh, Ww))
             sw = torch.empty(ns * Co * Ci * 9 + ns * Co, dtype=torch.float32, device=dev)
             sb = sw[ns * Co * Ci * 9:]
@@ -174,13 +181,75 @@ class _FusedFlowppImg(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_in = torch.empty_like(x_in)
             N.call('nf_flowpp_img_conv', N.ptr(g_x), N.ptr(W0), None, N.ptr(g_in), B, HID, I0, Hh, Ww, 0, 1, 1, st)
-        from .fused_conv import _slab_sum_all
-        _slab_sum_all(jobs)
+        if defer:
+            FPP_IMG_DEFER.sums += jobs                           # (the per-sample LayerNorm / position-embedding sums wait as well)
+        else:
+            from .fused_conv import _slab_sum_all
+            _slab_sum_all(jobs)
         if g_in is not None and S != Hh:
             g_in = g_in[:, :, :Hh, :Ww].contiguous()
         if direct:
             return (g_in, ) + (None, ) * len(ts)
         return (g_in, ) + tuple(dst)
+
+
+class WgradDesc(ctypes.Structure):
+    """include/nfhip.h: nf_flowpp_img_wgrad_desc"""
+    _fields_ = [(f, ctypes.c_void_p) for f in ('inp', 'g_out', 'slab_w', 'slab_b')]
+
+
+class FlowppImgDefer:
+    """Deferred weight gradients of the image Flow++ conditioners.  One convolution's weight-gradient launch is a single tile's latency
+    chain on 64 .. 192 workgroups at B = 64 (20 .. 31 us, three per coupling, 483 per step at layers = 32) and only the optimizer waits
+    for it.  Inside a trainer step (FlowTrainer opens it; closed -- the default -- nothing is deferred) a conditioner's backward queues
+    (input, gradient, sinks) and ``flush`` runs the queued convolutions of one shape NF_FLOWPP_IMG_WGRAD_MAX per launch
+    (nf_flowpp_img_conv_wgrad_multi), then every slab sum of the pass in launches of NF_SLAB_SUM_MAX jobs."""
+
+    def __init__(self):
+        self.active = False
+        self.layers = []        # (key, input, gradient, weight sink, bias sink): the tensors are kept alive until the flush
+        self.sums = []
+
+    def begin(self):
+        self.layers, self.sums = [], []
+        self.active = FPP_IMG_DEFER_ON
+
+    def flush(self):
+        layers, sums = self.layers, self.sums
+        self.layers, self.sums, self.active = [], [], False
+        if not layers and not sums:
+            return
+        lib = N.load()
+        step = N.header_constant('NF_FLOWPP_IMG_WGRAD_MAX')
+        groups = {}
+        for e in layers:
+            groups.setdefault(e[0], []).append(e)
+        jobs = []
+        for (B, Ci, Co, Hh, Ww, mode), es in groups.items():
+            single = int(lib.nf_flowpp_img_wgrad_slabs(B, Ci, Co, Hh, Ww))
+            blocks = ((Co + 31) // 32) * ((Ci + 31) // 32)
+            for k0 in range(0, len(es), step):
+                chunk = es[k0:k0 + step]
+                # slabs per layer: the launch as a whole fills the chip WGRAD_ROUNDS times over, a layer alone need not
+                ns = max(1, min(single, (WGRAD_ROUNDS * 256 + len(chunk) * blocks - 1) // (len(chunk) * blocks)))
+                per = ns * Co * Ci * 9 + ns * Co
+                dev = chunk[0][1].device
+                slab = torch.empty(len(chunk) * per, dtype=torch.float32, device=dev)
+                arr = (WgradDesc * len(chunk))()
+                for i, (_, inp, g, gw, gb) in enumerate(chunk):
+                    sw = slab[i * per:(i + 1) * per]
+                    sb = sw[ns * Co * Ci * 9:]
+                    arr[i].inp, arr[i].g_out, arr[i].slab_w, arr[i].slab_b = inp.data_ptr(), g.data_ptr(), sw.data_ptr(), sb.data_ptr()
+                    jobs.append((sw, gw, Co * Ci * 9, Co * Ci * 9, ns, True, 9))      # the slabs are tap-major (9, Co, Ci)
+                    jobs.append((sb, gb, Co, Co, ns, True, 1))
+                N.call('nf_flowpp_img_conv_wgrad_multi', ctypes.addressof(arr), len(chunk), ns, B, Ci, Co, Hh, Ww, mode, N.stream())
+        from .fused_conv import _slab_sum_all
+        _slab_sum_all(jobs + sums)
+
+
+FPP_IMG_DEFER_ON = True         # (internal: tests compare the deferred weight gradients with the per-coupling ones)
+WGRAD_ROUNDS = 2
+FPP_IMG_DEFER = FlowppImgDefer()
 
 
 def flowpp_img_forward(net, x):

@@ -50,6 +50,9 @@ class _FlowModel(nn.Module):
         return layers
 
     def _zero_ld(self, z):
+        if z.dtype == torch.float32:
+            from .workspace import zeros_owned
+            return zeros_owned((z.size(0), ), z.device)      # (inside a trainer step: part of the step's one memset, no fill launch)
         return torch.zeros(z.size(0), dtype=z.dtype, device=z.device)
 
     def _wn_convs(self):

@@ -167,12 +167,15 @@ class FlowTrainer:
         from .fused_conv import CONV_DEFER
         ARENA.begin(device)                             # one memset for every zero-initialised accumulator of the step
         FPP_DEFER.begin()                               # the Flow++ steps' slab finalizes: all of them in one go after backward
+        from .fused_flowpp_img import FPP_IMG_DEFER
+        FPP_IMG_DEFER.begin()                           # the image Flow++ conditioners' weight gradients: sixteen convolutions per launch
         CONV_DEFER.begin()                              # the image conditioners' weight-gradient passes: sixteen layers per launch
         try:
             z, loss = forward_loss()
             loss.backward()
         finally:
             FPP_DEFER.flush()
+            FPP_IMG_DEFER.flush()
             CONV_DEFER.flush()
             ARENA.end()
             for h in hooks:
@@ -181,7 +184,10 @@ class FlowTrainer:
             self._indirect = sorted(seen)
         elif self._indirect:
             self._gather_indirect()
-        return z, loss
+        from .workspace import _capturing, in_arena
+        if not _capturing() and isinstance(loss, torch.Tensor) and in_arena(loss):
+            loss = loss.clone()                         # (the arena is zeroed again when the next step begins; inside a capture the loss is
+        return z, loss                                  #  the graph's static output, rewritten by every replay)
 
     def _gather_indirect(self):
         """copy the framework-produced gradients into their bucket slots (nf_multi_copy) and re-attach the views."""

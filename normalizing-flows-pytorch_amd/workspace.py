@@ -67,3 +67,23 @@ ARENA = ZeroArena()
 
 def zeros(n, device):
     return ARENA.zeros(n, device)
+
+
+def zeros_owned(shape, device):
+    """zero-filled fp32 tensor of ``shape`` for a value that travels through autograd (the log-det accumulator the layers update in place,
+    the loss): inside a trainer step a piece of the arena -- as a tensor of its own over the arena's storage, NOT a view of the arena
+    tensor (autograd would rebase the whole arena behind an in-place update of a view) -- else ``torch.zeros``.  It lives until the next
+    step's memset: FlowTrainer hands a copy to its caller outside hipGraph capture."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if ARENA.active and ARENA.buf is not None and ARENA.buf.device == device:
+        t = ARENA.zeros(n, device)
+        if t.untyped_storage().data_ptr() == ARENA.buf.untyped_storage().data_ptr():
+            return torch.empty(0, dtype=torch.float32, device=device).set_(t.untyped_storage(), t.storage_offset(), tuple(shape))
+        return t.reshape(tuple(shape)) if len(shape) != 1 else t
+    return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+
+
+def in_arena(t):
+    return ARENA.buf is not None and t.is_cuda == ARENA.buf.is_cuda and t.untyped_storage().data_ptr() == ARENA.buf.untyped_storage().data_ptr()

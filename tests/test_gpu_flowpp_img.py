@@ -167,6 +167,69 @@ def test_conditioner_vs_module_stack(pkg, monkeypatch, in_chs, n_out, HW, B, spl
         G.assert_close(a, b, _scaled(b, 8.0), rtol=1e-4, what='gradient of ' + n)
 
 
+@pytest.mark.parametrize('Ci,Co,HW,B,mode,layers,ns', [(6, 32, 16, 64, 0, 16, 4), (64, 32, 16, 5, 1, 3, 5), (32, 84, 16, 64, 0, 5, 2), (24, 32, 8, 64, 0, 16, 8),
+                                                       (32, 1344, 4, 64, 0, 3, 1), (96, 32, 4, 33, 0, 2, 9), (40, 70, 4, 16, 0, 7, 1)])
+def test_weight_gradients_of_many_convolutions_in_one_launch(pkg, Ci, Co, HW, B, mode, layers, ns):
+    """nf_flowpp_img_conv_wgrad_multi == one nf_flowpp_img_conv_wgrad per layer with the same slab count: the slabs BITWISE"""
+    import ctypes
+    N = _native(pkg)
+    fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    g = torch.Generator().manual_seed(Ci * 1000 + Co + layers)
+    Cin = Ci // 2 if mode == 1 else Ci                          # (mode 1: the kernel applies concat-ELU to a tensor of Ci / 2 channels)
+    st = N.stream()
+    singles, multi = [], []
+    arr = (fpi.WgradDesc * layers)()
+    keep = []
+    for i in range(layers):
+        x = torch.randn(B, Cin, HW, HW, generator=g).to(DEV)
+        gy = torch.randn(B, Co, HW, HW, generator=g).to(DEV)
+        sw1, sb1 = torch.full((ns, 9, Co, Ci), 7.0, device=DEV), torch.full((ns, Co), 7.0, device=DEV)
+        N.call('nf_flowpp_img_conv_wgrad', N.ptr(x), N.ptr(gy), N.ptr(sw1), N.ptr(sb1), ns, B, Ci, Co, HW, HW, mode, st)
+        sw2, sb2 = torch.full((ns, 9, Co, Ci), -3.0, device=DEV), torch.full((ns, Co), -3.0, device=DEV)
+        arr[i].inp, arr[i].g_out, arr[i].slab_w, arr[i].slab_b = x.data_ptr(), gy.data_ptr(), sw2.data_ptr(), sb2.data_ptr()
+        singles.append((sw1, sb1))
+        multi.append((sw2, sb2))
+        keep.append((x, gy))
+    N.call('nf_flowpp_img_conv_wgrad_multi', ctypes.addressof(arr), layers, ns, B, Ci, Co, HW, HW, mode, st)
+    torch.cuda.synchronize()
+    for i, ((a, b), (c, d)) in enumerate(zip(singles, multi)):
+        assert torch.equal(a, c), ('weight slabs of layer %d' % i, float((a - c).abs().max()))
+        assert torch.equal(b, d), ('bias slabs of layer %d' % i, float((b - d).abs().max()))
+
+
+def test_trainer_step_with_deferred_weight_gradients_matches_the_per_coupling_launches(pkg, monkeypatch):
+    """a Flowpp((3, 32, 32)) trainer step with the conditioners' weight gradients deferred to launches of sixteen convolutions (the
+    default) and with every coupling launching its own: z and the loss bitwise (deterministic mode), the flat gradient to rounding
+    (the slab partition of a launch of many layers differs: another summation order)."""
+    fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    from types import SimpleNamespace as NS
+    torch.manual_seed(3)
+    net = pkg.Flowpp((3, 32, 32), 'image', NS(layers=3, mixtures=4)).to(DEV)
+    y = torch.rand(16, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    tr = nftrain.FlowTrainer(net, graph=False)
+    tr.train_on_batch(y)                                # data-dependent initialisation
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    outs = []
+    was = pkg._native.deterministic()
+    pkg._native.deterministic(True)
+    try:
+        for on in (True, False):
+            monkeypatch.setattr(fpi, 'FPP_IMG_DEFER_ON', on)
+            net.load_state_dict(sd)
+            z, loss = tr._forward_backward(y)
+            torch.cuda.synchronize()
+            outs.append((z.detach().clone(), loss.detach().clone(), tr.bucket.flat.detach().clone()))
+    finally:
+        pkg._native.deterministic(was)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    d = (outs[0][2] - outs[1][2]).double()
+    rel = float(d.norm() / outs[1][2].double().norm())
+    assert rel <= 1e-5, rel
+    assert float(outs[0][2].abs().max()) > 0
+
+
 def test_direct_gradient_sinks_accumulate(pkg):
     """with a GradBucket the backward adds straight into p.grad (same += as AccumulateGrad)"""
     fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')
