@@ -57,6 +57,9 @@ int nf_half_gather(const float* z, float* half, int which, int mode, int odd, in
 /* full[b, src(m,i,j)] = half[b,m,i,j]; every other position of `full` is set to 0 (autograd of the gather).  */
 int nf_half_scatter(const float* half, float* full, int which, int mode, int odd, int64_t B, int C, int H, int W,
                     nf_stream_t stream);
+/* out = base + scatter(half): the gradient of a tensor consumed whole and through the gather of one half (image splits only).        */
+int nf_half_scatter_add(const float* half, const float* base, float* out, int which, int mode, int odd, int64_t B, int C, int H, int W,
+                        nf_stream_t stream);
 /* Squeeze2d.forward / Unsqueeze2d.backward: (B,C,H,W) -> (B,4C,H/2,W/2)  squeeze.py:86-96, :162-165, :186-189 */
 int nf_squeeze2d(const float* z, float* out, int64_t B, int C, int H, int W, nf_stream_t stream);
 /* Unsqueeze2d.forward / Squeeze2d.backward: (B,4C,h,w) -> (B,C,2h,2w)    squeeze.py:99-111, :167-170, :181-184 */

@@ -51,9 +51,11 @@ __device__ __forceinline__ void nf_ck_sel(const NfSplit& s, int k, int i, int j0
     e = (m * s.h + i) * s.w + j0;
 }
 
-// MODE 0: gather half `which` (rows that hold none of it are not read); 1: scatter half `which`, zeros elsewhere
+// MODE 0: gather half `which` (rows that hold none of it are not read); 1: scatter half `which`, zeros elsewhere; 2: scatter on top of
+// `base` (full tensor): dst = base + scatter(src)
 template <int MODE, bool CHECKER>
-__global__ void __launch_bounds__(NF_BLOCK) k_half_move_v4(const float* __restrict__ src, float* __restrict__ dst, NfSplit s, int which) {
+__global__ void __launch_bounds__(NF_BLOCK) k_half_move_v4(const float* __restrict__ src, float* __restrict__ dst, NfSplit s, int which,
+                                                           const float* __restrict__ base = nullptr) {
     const int64_t b = blockIdx.x;
     const int n4 = s.n_full >> 2, W4 = s.W >> 2, h4 = s.n_half >> 2;
     const float* full_r = src + b * s.n_full;            // MODE 0: source is the full tensor
@@ -69,7 +71,12 @@ __global__ void __launch_bounds__(NF_BLOCK) k_half_move_v4(const float* __restri
             if (MODE == 0) {
                 if (mine) reinterpret_cast<float4*>(half_w)[e4] = reinterpret_cast<const float4*>(full_r)[v];
             } else {
-                reinterpret_cast<float4*>(full_w)[v] = mine ? reinterpret_cast<const float4*>(half_r)[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 o = mine ? reinterpret_cast<const float4*>(half_r)[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MODE == 2) {
+                    const float4 bv = reinterpret_cast<const float4*>(base + b * s.n_full)[v];
+                    o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+                }
+                reinterpret_cast<float4*>(full_w)[v] = o;
             }
         } else {
             const int r = v / W4, x4 = v - r * W4;
@@ -88,6 +95,10 @@ __global__ void __launch_bounds__(NF_BLOCK) k_half_move_v4(const float* __restri
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (w0 == which) { const float2 t = *reinterpret_cast<const float2*>(half_r + e0); o.x = t.x; o.z = t.y; }
                 if (w1 == which) { const float2 t = *reinterpret_cast<const float2*>(half_r + e1); o.y = t.x; o.w = t.y; }
+                if (MODE == 2) {
+                    const float4 bv = reinterpret_cast<const float4*>(base + b * s.n_full)[v];
+                    o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+                }
                 reinterpret_cast<float4*>(full_w)[v] = o;
             }
         }
@@ -156,6 +167,38 @@ extern "C" int nf_half_scatter(const float* half, float* full, int which, int mo
     }
     hipLaunchKernelGGL(k_half_scatter, dim3(nf_grid_for(total)), dim3(NF_BLOCK), 0, (hipStream_t)stream, half, full, s,
                        which, total);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
+// out = base + scatter(half): the gradient of a tensor that was consumed whole AND through a gather of one of its halves, in one pass
+__global__ void __launch_bounds__(NF_BLOCK) k_half_scatter_add(const float* __restrict__ half, const float* __restrict__ base, float* __restrict__ out,
+                                                               NfSplit s, int which, int64_t total) {
+    const int P = s.H * s.W;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / s.n_full;
+        const int r = (int)(t - b * s.n_full), c = r / P, p = r - c * P;
+        int w, e;
+        nf_full_to_half(s, c, p, w, e);
+        out[t] = base[t] + (w == which ? half[b * s.n_half + e] : 0.f);
+    }
+}
+
+extern "C" int nf_half_scatter_add(const float* half, const float* base, float* out, int which, int mode, int odd, int64_t B, int C, int H,
+                                   int W, nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_make_split(s, mode, odd, C, H, W) || (mode != NF_SPLIT_CHANNEL && mode != NF_SPLIT_CHECKER) || (which & ~1)) return NF_E_BADARG;
+    if (half == nullptr || base == nullptr || out == nullptr) return NF_E_BADARG;
+    const int64_t total = B * s.n_full;
+    if (total == 0) return 0;
+    if (nf_iv_ok(half, out, W, s.n_full, s.n_half, B) && ((uintptr_t)base & 15) == 0) {
+        dim3 grid((unsigned)B, (unsigned)((s.n_full / 4 + NF_IVSLAB - 1) / NF_IVSLAB));
+        if (mode == NF_SPLIT_CHECKER) hipLaunchKernelGGL((k_half_move_v4<2, true>), grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, half, out, s, which, base);
+        else hipLaunchKernelGGL((k_half_move_v4<2, false>), grid, dim3(NF_BLOCK), 0, (hipStream_t)stream, half, out, s, which, base);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(k_half_scatter_add, dim3(nf_grid_for(total)), dim3(NF_BLOCK), 0, (hipStream_t)stream, half, base, out, s, which, total);
     NF_CHECK_LAUNCH();
     return 0;
 }

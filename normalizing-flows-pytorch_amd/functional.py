@@ -600,10 +600,10 @@ class _GlowHeadW(torch.autograd.Function):
         if g_ld is None:
             g_ld = torch.zeros(B, dtype=x.dtype, device=x.device)
         g_h, g_ld = _contig(g_h), _contig(g_ld)
-        if g_z1c is not None:                       # (a coupling that was not fused into its conditioner's launches)
+        if g_z1c is not None:                       # (a coupling that was not fused into its conditioner's launches: image Flow++)
             full = torch.empty_like(x)
-            N.call('nf_half_scatter', N.ptr(_contig(g_z1c)), N.ptr(full), 1, mode, odd, B, C, H, Wd, N.stream())
-            g_h = g_h + full
+            N.call('nf_half_scatter_add', N.ptr(_contig(g_z1c)), N.ptr(g_h), N.ptr(full), 1, mode, odd, B, C, H, Wd, N.stream())
+            g_h = full
         g_x = torch.empty_like(x)
         direct = ctx.sinks is not None
         tmp = WS.zeros(C * C + (0 if direct else 2 * C), x.device)

@@ -32,6 +32,7 @@ class Identity(nn.Module):
 
 GLOW_HEAD_W_ON = True           # (internal: the MFMA head of image flow steps, csrc/glow_head_mfma.hip)
 HEAD_IN_CHAIN = True            # (internal: that head's forward in the prologue of the coupling's chain launch, csrc/conv_chain.hip)
+FLOWPP_HEAD_ON = True           # (internal: image Flow++ steps take the fused Glow heads too; tests compare with the three layers' own launches)
 
 
 class Compose(nn.Module):
@@ -58,10 +59,16 @@ class Compose(nn.Module):
         if not (self._fuse_now and z.is_cuda and i + 2 < len(L) and z.shape[1] <= NF.HEAD_MAX_C):
             return False
         a, c, k = L[i], L[i + 1], L[i + 2]
-        if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and type(k) is AffineCoupling):
+        if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and (type(k) is AffineCoupling or self._flowpp_image_coupling(k, z))):
             return False
         return not (a._forward_hooks or c._forward_hooks or k._forward_hooks or a._forward_pre_hooks
                     or c._forward_pre_hooks or k._forward_pre_hooks)
+
+    @staticmethod
+    def _flowpp_image_coupling(k, z):
+        """an image Flow++ step [ActNorm, InvertibleConv1x1, MixLogAttnCoupling] (flows/flowpp.py:64-70) takes the same fused head as a Glow
+        step: ActNorm + 1x1 + the conditioner-input gather in one launch, its backward in two parts (round 5)"""
+        return FLOWPP_HEAD_ON and type(k) is MixLogAttnCoupling and z.dim() == 4 and k.mode in (N.SPLIT_CHANNEL, N.SPLIT_CHECKER)
 
     def _glow_step_w_at(self, i, z):
         """[ActNorm, InvertibleConv1x1 (weight assembled by the model's batched PLU pre-pass), AffineCoupling] on image data with
@@ -70,7 +77,7 @@ class Compose(nn.Module):
         if not (GLOW_HEAD_W_ON and self._fuse_now and z.is_cuda and z.dim() == 4 and i + 2 < len(L) and z.shape[1] > NF.HEAD_MAX_C):
             return False
         a, c, k = L[i], L[i + 1], L[i + 2]
-        if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and type(k) is AffineCoupling):
+        if not (type(a) is ActNorm and type(c) is InvertibleConv1x1 and (type(k) is AffineCoupling or self._flowpp_image_coupling(k, z))):
             return False
         if c._W_eff is None or k.mode not in (N.SPLIT_CHANNEL, N.SPLIT_CHECKER) or not NF.glow_head_w_usable(z, k.mode):
             return False
@@ -206,7 +213,8 @@ class Compose(nn.Module):
                 W, holder, idx = c._W_eff
                 # the head's forward rides the prologue of the coupling's chain launch when that launch follows (round 5)
                 from . import fused_conv as FC
-                defer = HEAD_IN_CHAIN and isinstance(k.net, ConvNet) and z.is_contiguous() and FC.head_in_chain_ok(k.net, z, k.mode)
+                defer = (HEAD_IN_CHAIN and type(k) is AffineCoupling and isinstance(k.net, ConvNet) and z.is_contiguous()
+                         and FC.head_in_chain_ok(k.net, z, k.mode))
                 h, z1c, log_df_dz = NF.glow_head_w(z, log_df_dz, a.log_scale, a.bias, W, c.log_s, holder, idx, k.mode, k.odd, defer=defer)
                 z, log_df_dz = k.couple(h, z1c, log_df_dz)
                 if defer and NF.flush_pending_head(h):
@@ -700,7 +708,14 @@ class MixLogAttnCoupling(AbstractCoupling):
         """coupling parameters from the untouched half; density data runs the whole gated-attention stack as one
         launch per direction (csrc/flowpp_cond.hip), image data on the per-sample kernels of csrc/flowpp_img.hip (4 launches
         forward, 9 backward); the module stack remains for shapes neither takes and off the GPU."""
-        x = self.conditioner_input(z)
+        return self.conditioner_of(self.conditioner_input(z))
+
+    def couple(self, z, x, log_df_dz):
+        """the coupling given the conditioner's input ``x`` (the untouched half of z, gathered by the fused head of the step)"""
+        return NF.mixlog_coupling(z, self.conditioner_of(x), self.a_log_scale, self.a_bias, log_df_dz, self.n_mixtures, self.mode,
+                                  self.odd, logit_eps=self.logit_eps)
+
+    def conditioner_of(self, x):
         if FUSED.flowpp_cond_fusable(self.net, x):
             return FUSED.flowpp_cond_forward(self.net, x)
         if FPI.flowpp_img_fusable(self.net, x):

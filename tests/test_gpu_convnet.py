@@ -293,6 +293,23 @@ def test_small_glow_head_backward_in_two_parts(pkg, C, H, W, B, mode_name, heads
             G.assert_close(b, a, 2e-5 * max(1.0, float(a.abs().max())), rtol=1e-5, what='%s of head %d' % (what, i))
 
 
+@pytest.mark.parametrize('C,H,W,B,mode_name,odd', [(12, 16, 16, 5, 'channelwise', False), (12, 16, 16, 64, 'checkerboard', True), (48, 8, 8, 3, 'checkerboard', False),
+                                                   (10, 4, 6, 3, 'channelwise', True), (3, 6, 6, 2, 'checkerboard', False)])
+def test_half_scatter_add_is_scatter_plus_add(pkg, C, H, W, B, mode_name, odd):
+    """nf_half_scatter_add (one pass) == nf_half_scatter + an add, bit for bit: the vectorised and the generic form"""
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    Nn = pkg._native
+    mode = Nn.SPLIT_CHANNEL if mode_name == 'channelwise' else Nn.SPLIT_CHECKER
+    torch.manual_seed(3)
+    base = torch.randn(B, C, H, W, device=DEV)
+    half = torch.randn(NF._half_shape(base, mode), device=DEV)
+    full = torch.empty_like(base)
+    Nn.call('nf_half_scatter', Nn.ptr(half), Nn.ptr(full), 1, mode, int(odd), B, C, H, W, Nn.stream())
+    out = torch.full_like(base, 7.0)
+    Nn.call('nf_half_scatter_add', Nn.ptr(half), Nn.ptr(base), Nn.ptr(out), 1, mode, int(odd), B, C, H, W, Nn.stream())
+    assert torch.equal(out, base + full)
+
+
 def test_cifar_glow_head_parameter_gradients_deferred_or_not(pkg, monkeypatch):
     """a trainer step of a (3, 32, 32) Glow with the heads' parameter gradients deferred to the batched launch (the default) and with every
     head's backward whole: z and the loss BITWISE (the forward is untouched), the flat gradient to the rounding of the atomics' order."""

@@ -230,6 +230,48 @@ def test_trainer_step_with_deferred_weight_gradients_matches_the_per_coupling_la
     assert float(outs[0][2].abs().max()) > 0
 
 
+def test_image_flowpp_steps_with_and_without_the_fused_heads(pkg, monkeypatch):
+    """a Flowpp((3, 32, 32)) with two steps per level: [ActNorm, InvertibleConv1x1] + the conditioner-input gather as the fused Glow heads
+    (C = 3: glow_head.hip, C = 12 / 48: glow_head_mfma.hip; their backward in two parts inside a trainer step) against the three layers'
+    own launches -- z, log-det and every parameter gradient of one training-mode pass, bare and through the trainer."""
+    layers_mod = importlib.import_module(pkg.__name__ + '.layers')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    from types import SimpleNamespace as NS
+    torch.manual_seed(2)
+    net1 = pkg.Flowpp((3, 32, 32), 'image', NS(layers=2, mixtures=4)).to(DEV)
+    y = torch.rand(8, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        net1(y)                                         # data-dependent ActNorm initialisation
+    net2 = copy.deepcopy(net1)
+    outs = []
+    for net, on in ((net1, True), (net2, False)):
+        monkeypatch.setattr(layers_mod, 'FLOWPP_HEAD_ON', on)
+        net.train()
+        z, ld = net(y)
+        (0.5 * (z ** 2).sum() - ld.sum()).backward()
+        outs.append((z.detach(), ld.detach()))
+    G.assert_close(outs[0][0], outs[1][0], 5e-5, rtol=1e-5, what='z')
+    G.assert_close(outs[0][1], outs[1][1], 2e-3, rtol=1e-5, what='log-det')
+    for (n, p1), (_, p2) in zip(net1.named_parameters(), net2.named_parameters()):
+        if p2.grad is None:                             # (the pivot matrices and masks)
+            assert p1.grad is None, n
+            continue
+        assert p1.grad is not None, n
+        G.assert_close(p1.grad, p2.grad, _scaled(p2.grad, 8.0), rtol=1e-4, what='gradient of ' + n)
+    # ... and inside a trainer step (gradient sinks, deferred parameter gradients of the heads), from identical state
+    flats = []
+    for net, on in ((net1, True), (net2, False)):
+        monkeypatch.setattr(layers_mod, 'FLOWPP_HEAD_ON', on)
+        tr = nftrain.FlowTrainer(net, graph=False)
+        z, loss = tr._forward_backward(y)
+        torch.cuda.synchronize()
+        flats.append((z.detach().clone(), float(loss), tr.bucket.flat.detach().clone()))
+    G.assert_close(flats[0][0], flats[1][0], 5e-5, rtol=1e-5, what='z (trainer)')
+    assert abs(flats[0][1] - flats[1][1]) <= 1e-5 * max(1.0, abs(flats[1][1]))
+    d = (flats[0][2] - flats[1][2]).double()
+    assert float(d.norm() / flats[1][2].double().norm()) <= 2e-5
+
+
 def test_direct_gradient_sinks_accumulate(pkg):
     """with a GradBucket the backward adds straight into p.grad (same += as AccumulateGrad)"""
     fpi = importlib.import_module(pkg.__name__ + '.fused_flowpp_img')

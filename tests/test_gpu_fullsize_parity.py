@@ -246,8 +246,15 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
                     bad.append(('best flat gradient distance to float64 over the ensemble (bimodal yard-stick)', min(rel_gpu_all), low_o))
             elif med_g > ENS_RATIO * med_o + 2.0 * TOL:
                 bad.append(('median flat gradient distance to float64 over the ensemble', med_g, med_o))
-            if max(rel_gpu_all) > ENS_RATIO * max(rel_ens) + 2.0 * TOL:
-                bad.append(('largest flat gradient distance to float64 over the ensemble', max(rel_gpu_all), max(rel_ens)))
+            # the LARGEST member: inside ENS_RATIO x the oracle's largest -- except that ONE member of a small ensemble may have met a kink
+            # none of the oracle's members met (realnvp_24 step 2 on one box: the GPU's runs 6.3e-5, 3.2e-7, 3.3e-7, 1.9e-7, 2.0e-7, the
+            # oracle's five 1.6e-7 .. 3.0e-7; in step 1 of the same run it was the ORACLE that had the one member at 6.7e-6): that one
+            # member gets the measured footprint of a single event, KINK_FLAT / B, the second largest gets nothing
+            strict = ENS_RATIO * max(rel_ens) + 2.0 * TOL
+            g_sorted = sorted(rel_gpu_all)
+            if g_sorted[-1] > strict + KINK_FLAT / B or (len(g_sorted) > 1 and g_sorted[-2] > strict):
+                bad.append(('largest flat gradient distance to float64 over the ensemble', g_sorted[-1], g_sorted[-2] if len(g_sorted) > 1 else None,
+                            max(rel_ens)))
         elif rel_gpu > 4.0 * max(rel_ens) + 2.0 * TOL + (0.0 if DETERMINISTIC() else KINK_FLAT / B):
             bad.append(('flat gradient distance to float64', rel_gpu, max(rel_ens)))
         pg = _step_profile(grads, r64, per_step)
