@@ -88,6 +88,24 @@ python tools/probes/solo_time.py > $OUT/${R}_c1_solo_kernel_times.txt 2>&1
 python tools/probes/host_step_cost.py > $OUT/${R}_c1_host_step_cost.txt 2>&1
 python bench.py --config c4 --scaling strong --skip-cpu --steps 20 > $OUT/${R}_bench_c4_strong_one_rank.json 2> /dev/null
 python bench.py --config fpp_img --steps 20 --skip-cpu > $OUT/${R}_bench_fpp_img_skipcpu.json 2> /dev/null
+# image Flow++: weight gradients per coupling / deferred with several slab rules; the exchange probe (why XCD placement does not help)
+python tools/probes/fpp_img_wgrad_rounds.py 32 64 10 2>&1 | grep -v amdgpu > $OUT/${R}_fpp_img_wgrad_defer.txt
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/xcd_probe tools/probes/xcd_exchange_probe.hip 2> /dev/null && timeout 300 /tmp/xcd_probe > $OUT/${R}_xcd_exchange_probe.txt 2>&1
+# head backward in two parts: whole / deferred, on the two configs that have heads
+python - > $OUT/${R}_head_params_defer.txt 2>&1 <<'PYEOF'
+import importlib, subprocess, sys, json
+for cfg, extra in (('c4', []), ('c4', ['--batch', '512']), ('fpp_img', [])):
+    for on in (1, 0):
+        code = ("import importlib,sys; sys.argv=['bench.py','--config','%s','--skip-cpu','--steps','20'%s]; "
+                "F=importlib.import_module('normalizing-flows-pytorch_amd.functional'); F.HEAD_PARAMS_DEFER=bool(%d); "
+                "import runpy; runpy.run_path('bench.py', run_name='__main__')") % (cfg, ''.join(",'%s'" % e for e in extra), on)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            print('%-8s %-14s HEAD_PARAMS_DEFER=%d  %9.1f samples/s  %8.3f ms/step' % (cfg, ' '.join(extra), on, d['value'], d['ms_per_step']))
+        except Exception as e:
+            print(cfg, extra, on, 'failed', r.stderr[-300:])
+PYEOF
 python -m pytest tests/test_gpu_fullsize_parity.py -q > $OUT/pytest_fullsize.log 2>&1
 cp gpurun_out/fullsize_parity.txt $OUT/${R}_fullsize_parity.txt
 ls -la $OUT
