@@ -114,6 +114,11 @@ def ptr(t):
         raise NativeLibraryError('nfhip kernels need contiguous tensors')
     if t.dtype not in (torch.float32, torch.int32):
         raise NativeLibraryError('nfhip kernels are fp32 (int32 for flags), got %s' % t.dtype)
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's stream and read that device's copy of the library's globals (spin limit, error word,
+        # deterministic mode): a tensor of another GPU would be dereferenced from the wrong device
+        raise NativeLibraryError('tensor on cuda:%s but the current device is cuda:%d: one process per GPU (torch.cuda.set_device) or '
+                                 'wrap the call in torch.cuda.device(...)' % (t.device.index, torch.cuda.current_device()))
     return t.data_ptr()
 
 

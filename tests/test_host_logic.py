@@ -238,3 +238,15 @@ def test_bench_scaling_modes_resolve_the_per_gpu_batch():
     o['also'] = {'c1': dict(o, config={'name': 'c1'})}
     s = b.summary_of(o)
     assert set(s['rows']) == {'c4', 'c1'} and s['rows']['c4'] == [1.0, 2.0, 0.1, None, 3.0, 1e-7, 1e-4] and len(s['columns']) == 7
+
+
+def test_tensor_of_another_gpu_is_refused(pkg, monkeypatch):
+    """_native.ptr: launches go to the current device's stream -- a tensor of another GPU is an error, not a wild pointer"""
+    from types import SimpleNamespace as NS
+    N = pkg._native
+    fake = NS(is_cuda=True, is_contiguous=lambda: True, dtype=torch.float32, device=NS(index=1), data_ptr=lambda: 4096)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 0)
+    with pytest.raises(N.NativeLibraryError, match='current device'):
+        N.ptr(fake)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 1)
+    assert N.ptr(fake) == 4096
