@@ -255,9 +255,6 @@ int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, 
                            const float* a_log_scale, const float* a_bias, float* g_z, float* g_params,
                            float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
                            int C, int H, int W, nf_stream_t stream);
-/* image data's backward kernel: 1 (default) = one mixture component per lane, an element per octet of lanes; 0 = an element per
- * thread.  Same formulas (flows/modules.py:64-97, flows/coupling.py:172-210 differentiated), another order of the sums over components. */
-int nf_mixlog_config(int image_octets);
 
 /* ---- standalone MixLogCDF  modules.py:186-212 (module surface forward / backward(x, log_pi, mu, s, log_df_dz)) -----
  * x, out (B, n); log_pi, mu, s (B, K, n) with n = the non-batch extent of x and log_pi already normalised over K

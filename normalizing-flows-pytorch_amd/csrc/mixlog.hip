@@ -629,88 +629,6 @@ __global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const flo
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// backward on IMAGE data, one mixture component per lane (round 5).  k_mixlog_bwd gives an element to a thread: 98 k threads for a
-// CIFAR-shape coupling at B = 64 -- six waves per compute unit, each a dependent chain of ~110 transcendentals and 26 strided stores:
-// 18.7 us per launch, 161 launches per Flow++ step.  Here an element is an OCTET of lanes (helpers of nf_mixlog_oct.h): eight times the
-// waves, an eighth of the chain per lane, the sums over the components three DPP steps each.  The parameter planes are (2 + 3 K) x n_half
-// per sample, so the eight lanes of a load touch eight planes at eight consecutive elements each (32-byte pieces).
-// Same formulas as k_mixlog_oct_bwd's inner body; the sums over components are taken in tree order instead of k_mixlog_bwd's sequence.
-#define NF_OCT_IMG_THREADS 256
-__global__ void __launch_bounds__(NF_OCT_IMG_THREADS) k_mixlog_oct_img_bwd(const float* __restrict__ gy, const float* __restrict__ gld,
-                                                                           const float* __restrict__ z, const float* __restrict__ prm,
-                                                                           const float* __restrict__ pA, const float* __restrict__ pC,
-                                                                           float* __restrict__ gz, float* __restrict__ gprm,
-                                                                           float* __restrict__ g_scale, float* __restrict__ g_bias, NfSplit s,
-                                                                           int K, float eps, int64_t total) {
-    __shared__ float scratch[NF_OCT_IMG_THREADS / NF_WAVE][2];
-    const float A = pA[0], Cb = pC[0];
-    const int kk = threadIdx.x & 7;
-    const bool on = kk < K;
-    const int64_t PS = (int64_t)(2 + 3 * K) * s.n_half, gnh = s.n_half;
-    const int64_t per = (int64_t)gridDim.x * (NF_OCT_IMG_THREADS >> 3);
-    const int64_t rounds = (total + per - 1) / per;            // uniform trip count: the DPP steps want whole octets in step
-    float acc_A = 0.f, acc_C = 0.f;
-    for (int64_t r = 0; r < rounds; ++r) {
-        const int64_t t = r * per + (int64_t)blockIdx.x * (NF_OCT_IMG_THREADS >> 3) + (threadIdx.x >> 3);
-        const bool live = t < total;
-        const int64_t tt = live ? t : total - 1;
-        const int64_t b = tt / s.n_half;
-        const int e = (int)(tt - b * s.n_half);
-        const int64_t fb = b * s.n_full;
-        NfOct m;
-        nf_oct_load(prm + b * PS + e, gnh, K, kk, m);
-        float* GP = gprm + b * PS + e;
-        const int o0 = nf_half_to_full(s, 0, e), o1 = nf_half_to_full(s, 1, e);
-        const float x = z[fb + o0], g_y = gy[fb + o0], g_ld = gld[b];
-        float lcdf, lpdf, u, l;
-        nf_oct_eval(m, x, lcdf, lpdf, u, l);
-        const float F = nf_fexp(lcdf), f = nf_fexp(lpdf);
-        const bool inside = (F >= eps) && (F <= 1.f - eps);          // torch.clamp passes the gradient on [min, max]
-        const float xc = fminf(fmaxf(F, eps), 1.f - eps);
-        const float y1 = nf_flog(xc) - nf_flog(1.f - xc);
-        const float th = nf_ftanh(m.a_raw);
-        const float ea = nf_fexp(th * A + Cb);
-        const float g_y1 = g_y * ea;                                 // y = y1 * exp(a) + b ; ld += a
-        const float g_a = g_y * y1 * ea + g_ld;
-        const float gF = inside ? (g_y1 - g_ld * (1.f - 2.f * xc)) * __builtin_amdgcn_rcpf(xc * (1.f - xc)) : 0.f;   // logit + its log-det
-        const float tot = gF * F + g_ld;                             // sum_j g_logpi_j
-        const float rk = on ? nf_fexp(m.lp + (u - m.s - 2.f * (fmaxf(u, 0.f) + l)) - lpdf) : 0.f;   // responsibility pi_k pdf_k / f
-        const float eu = nf_fexp(-fabsf(u));
-        const float omt = copysignf((1.f - eu) * __builtin_amdgcn_rcpf(1.f + eu), -u);               // 1 - 2 sigmoid(u)
-        const float w = g_ld * rk * omt * m.es;
-        const float gx = gF * f + nf_oct_sum(w);
-        if (live) {
-            if (on) {
-                GP[(2 + K + kk) * gnh] = -gF * f * rk - w;                                             // g_mu_k
-                GP[(2 + 2 * K + kk) * gnh] = -gF * f * rk * (x - m.mu) + g_ld * rk * (-omt * u - 1.f);   // g_s_k
-                const float g_logpi = gF * nf_fexp(m.lp + (fminf(u, 0.f) - l)) + g_ld * rk;
-                GP[(2 + kk) * gnh] = g_logpi - nf_fexp(m.lp) * tot;                                     // through log_softmax
-            }
-            if (kk == 0) {
-                GP[0] = g_a * A * (1.f - th * th);
-                GP[gnh] = g_y;
-                gz[fb + o0] = gx;
-                gz[fb + o1] = gy[fb + o1];
-                acc_A += g_a * th;
-                acc_C += g_a;
-            }
-        }
-    }
-    const int lane = threadIdx.x & (NF_WAVE - 1), wid = threadIdx.x >> 6;
-    const float va = nf_wave_sum(acc_A), vc = nf_wave_sum(acc_C);
-    if (lane == 0) { scratch[wid][0] = va; scratch[wid][1] = vc; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float ta = 0.f, tc = 0.f;
-        for (int w2 = 0; w2 < NF_OCT_IMG_THREADS / NF_WAVE; ++w2) { ta += scratch[w2][0]; tc += scratch[w2][1]; }
-        NF_DET_ENTER(nf_ml);
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
-        NF_DET_LEAVE(nf_ml);
-    }
-}
-
 static inline int nf_mx_threads(int K) { return (2 + 3 * K) <= 50 ? 256 : 128; }        // rows tile <= 52 KB of LDS
 static inline size_t nf_mx_lds(const NfSplit& s, int K, int threads) {
     return s.n_half == 1 ? (size_t)threads * (2 + 3 * K + 1) * sizeof(float) : 0;
@@ -753,13 +671,6 @@ extern "C" int nf_mixlog_coupling_fwd(const float* z, const float* params, const
     return 0;
 }
 
-static int nf_mx_img_oct = 1;
-// which backward kernel image data takes: 1 (default) = an element per octet of lanes, 0 = an element per thread (tests compare the two)
-extern "C" int nf_mixlog_config(int image_octets) {
-    nf_mx_img_oct = image_octets ? 1 : 0;
-    return 0;
-}
-
 extern "C" int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, const float* params,
                                       const float* a_log_scale, const float* a_bias, float* g_z, float* g_params,
                                       float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
@@ -774,14 +685,6 @@ extern "C" int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const
         if (g2 > NF_OCT_BWD_MAX_BLOCKS) g2 = NF_OCT_BWD_MAX_BLOCKS;
         hipLaunchKernelGGL(k_mixlog_oct_bwd<false>, dim3(g2), dim3(NF_OCT_BWD_THREADS), 0, st, g_y, g_ld, z, params, a_log_scale,
                            a_bias, nullptr, nullptr, g_z, g_params, g_scale, g_bias, nullptr, nullptr, s, K, logit_eps, B);
-        NF_CHECK_LAUNCH();
-        return 0;
-    }
-    if (K <= 8 && nf_mx_img_oct) {                         // image data: one component per lane, an element per octet
-        unsigned g3 = nf_grid_for(total * 8, NF_OCT_IMG_THREADS);
-        if (g3 > 2048) g3 = 2048;
-        hipLaunchKernelGGL(k_mixlog_oct_img_bwd, dim3(g3), dim3(NF_OCT_IMG_THREADS), 0, st, g_y, g_ld, z, params, a_log_scale, a_bias, g_z,
-                           g_params, g_scale, g_bias, s, K, logit_eps, total);
         NF_CHECK_LAUNCH();
         return 0;
     }

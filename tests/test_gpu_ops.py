@@ -319,22 +319,8 @@ def test_mixlog_coupling_golden(nf, tag, mode, odd):
     G.assert_close(ldi, want_ld.float(), _scaled(want_ld) + 1.0e-6 * n_per, what='log-det of the inverse at its own x (float64 restatement)')
 
 
-@pytest.mark.parametrize('octets', [1, 0], ids=['octets', 'threads'])
-@pytest.mark.parametrize('dims,mode,B,K', [((2, ), 0, 65536, 8), ((3, 8, 8), 1, 4, 4), ((8, 8, 8), 2, 4, 8), ((12, 16, 16), 2, 5, 8), ((3, 6, 6), 1, 3, 8),
-                                           ((4, 4, 4), 2, 1, 1)])
-def test_mixlog_coupling_vs_oracle(nf, dims, mode, B, K, octets):
-    """(image data: the backward with a mixture component per lane -- csrc/mixlog.hip k_mixlog_oct_img_bwd, the default -- and with an
-    element per thread, nf_mixlog_config)"""
-    if len(dims) == 1 and not octets:
-        pytest.skip('nf_mixlog_config only concerns image data')
-    nf._native.call('nf_mixlog_config', octets)
-    try:
-        _mixlog_coupling_vs_oracle(nf, dims, mode, B, K)
-    finally:
-        nf._native.call('nf_mixlog_config', 1)
-
-
-def _mixlog_coupling_vs_oracle(nf, dims, mode, B, K):
+@pytest.mark.parametrize('dims,mode,B,K', [((2, ), 0, 65536, 8), ((3, 8, 8), 1, 4, 4), ((8, 8, 8), 2, 4, 8)])
+def test_mixlog_coupling_vs_oracle(nf, dims, mode, B, K):
     NF = nf.functional
     g = torch.Generator().manual_seed(21)
     z = torch.randn((B, ) + dims, generator=g)
