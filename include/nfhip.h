@@ -255,6 +255,12 @@ int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, 
                            const float* a_log_scale, const float* a_bias, float* g_z, float* g_params,
                            float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
                            int C, int H, int W, nf_stream_t stream);
+/* image data: the same with g_scale / g_bias left as per-workgroup partial sums partials[0 .. n) | partials[n .. 2 n), n =
+ * nf_mixlog_bwd_blocks(...) (0: the shape is served by a kernel without this form), for the caller's nf_slab_sum.              */
+int nf_mixlog_bwd_blocks(int K, int mode, int64_t B, int C, int H, int W);
+int nf_mixlog_coupling_bwd_partials(const float* g_y, const float* g_ld, const float* z, const float* params,
+                                    const float* a_log_scale, const float* a_bias, float* g_z, float* g_params, float* partials,
+                                    int K, float logit_eps, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
 
 /* ---- standalone MixLogCDF  modules.py:186-212 (module surface forward / backward(x, log_pi, mu, s, log_df_dz)) -----
  * x, out (B, n); log_pi, mu, s (B, K, n) with n = the non-batch extent of x and log_pi already normalised over K
@@ -628,7 +634,7 @@ int nf_conv_wgrad_slabs(int64_t B, int H, int W, int n_layers);
 
 /* dst[e] (+)= sum_{s < n_slabs} src[s * stride + e], e < n: every slab / replica sum of one conditioner backward in ONE
  * launch (weight-gradient slabs, bias and BatchNorm-parameter replicas).                                                */
-#define NF_SLAB_SUM_MAX 32
+#define NF_SLAB_SUM_MAX 80       /* (80 x 48 bytes of kernel arguments) */
 typedef struct nf_slab_sum_desc {
     const float* src;
     float* dst;

@@ -229,7 +229,7 @@ template <int KT>
 __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_bwd(const float* __restrict__ gy, const float* __restrict__ gld, const float* __restrict__ z,
                              const float* __restrict__ prm, const float* __restrict__ pA, const float* __restrict__ pC,
                              float* __restrict__ gz, float* __restrict__ gprm, float* __restrict__ g_scale,
-                             float* __restrict__ g_bias, NfSplit s, int K, float eps, int64_t total) {
+                             float* __restrict__ g_bias, NfSplit s, int K, float eps, int64_t total, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ float scratch[NF_BLOCK / NF_WAVE];
     const float A = pA[0], Cb = pC[0];
@@ -258,10 +258,15 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_bwd(const float* __restrict
     const float ta = nf_block_sum(acc_A, scratch);
     const float tc = nf_block_sum(acc_C, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_ml);
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
-        NF_DET_LEAVE(nf_ml);
+        if (partials != nullptr) {         // the caller folds them (nf_slab_sum): same-address float atomics retire at ~10 ns apiece, 384
+            partials[blockIdx.x] = ta;     // workgroups of a CIFAR-shape launch spent ~4 of their 18.7 us queueing for two addresses
+            partials[gridDim.x + blockIdx.x] = tc;
+        } else {
+            NF_DET_ENTER(nf_ml);
+            atomicAdd(g_scale, ta);
+            atomicAdd(g_bias, tc);
+            NF_DET_LEAVE(nf_ml);
+        }
     }
 }
 
@@ -671,16 +676,26 @@ extern "C" int nf_mixlog_coupling_fwd(const float* z, const float* params, const
     return 0;
 }
 
-extern "C" int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, const float* params,
-                                      const float* a_log_scale, const float* a_bias, float* g_z, float* g_params,
-                                      float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
-                                      int C, int H, int W, nf_stream_t stream) {
+// workgroups of the element-per-thread backward launch (image data), 0 where another kernel serves the shape
+extern "C" int nf_mixlog_bwd_blocks(int K, int mode, int64_t B, int C, int H, int W) {
+    NfSplit s;
+    if (!nf_mixlog_args(s, mode, 0, C, H, W, K)) return 0;
+    const int64_t total = B * s.n_half;
+    if (total == 0 || (s.n_half <= NF_MX_ROWS_MAX && K <= 8)) return 0;
+    unsigned g = nf_grid_for(total, nf_mx_threads(K));
+    return (int)(g > NF_MX_GRID ? NF_MX_GRID : g);
+}
+
+static int nf_mixlog_bwd_launch(const float* g_y, const float* g_ld, const float* z, const float* params, const float* a_log_scale,
+                                const float* a_bias, float* g_z, float* g_params, float* g_scale, float* g_bias, float* partials, int K,
+                                float logit_eps, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream) {
     NfSplit s;
     if (!nf_mixlog_args(s, mode, odd, C, H, W, K)) return NF_E_BADARG;
     const int64_t total = B * s.n_half;
     if (total == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane
+        if (partials != nullptr) return NF_E_UNSUPPORTED;
         unsigned g2 = nf_grid_for(B * 8, NF_OCT_BWD_THREADS);
         if (g2 > NF_OCT_BWD_MAX_BLOCKS) g2 = NF_OCT_BWD_MAX_BLOCKS;
         hipLaunchKernelGGL(k_mixlog_oct_bwd<false>, dim3(g2), dim3(NF_OCT_BWD_THREADS), 0, st, g_y, g_ld, z, params, a_log_scale,
@@ -691,11 +706,30 @@ extern "C" int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const
     const int th = nf_mx_threads(K);
     unsigned g = nf_grid_for(total, th);
     if (g > NF_MX_GRID) g = NF_MX_GRID;
-#define CALL(KT) hipLaunchKernelGGL(k_mixlog_bwd<KT>, dim3(g), dim3(th), nf_mx_lds(s, K, th), st, g_y, g_ld, z, params, a_log_scale, a_bias, g_z, g_params, g_scale, g_bias, s, K, logit_eps, total)
+#define CALL(KT) hipLaunchKernelGGL(k_mixlog_bwd<KT>, dim3(g), dim3(th), nf_mx_lds(s, K, th), st, g_y, g_ld, z, params, a_log_scale, a_bias, g_z, g_params, g_scale, g_bias, s, K, logit_eps, total, partials)
     NF_MX_DISPATCH(K, CALL);
 #undef CALL
     NF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int nf_mixlog_coupling_bwd(const float* g_y, const float* g_ld, const float* z, const float* params,
+                                      const float* a_log_scale, const float* a_bias, float* g_z, float* g_params,
+                                      float* g_scale, float* g_bias, int K, float logit_eps, int mode, int odd, int64_t B,
+                                      int C, int H, int W, nf_stream_t stream) {
+    return nf_mixlog_bwd_launch(g_y, g_ld, z, params, a_log_scale, a_bias, g_z, g_params, g_scale, g_bias, nullptr, K, logit_eps, mode, odd, B,
+                                C, H, W, stream);
+}
+
+// the same with the gradients of the coupling's scale / shift LEFT as per-workgroup partial sums, partials[0 .. n) | partials[n .. 2 n),
+// n = nf_mixlog_bwd_blocks(...) > 0: the caller folds them (nf_slab_sum) with whatever else it folds
+extern "C" int nf_mixlog_coupling_bwd_partials(const float* g_y, const float* g_ld, const float* z, const float* params,
+                                               const float* a_log_scale, const float* a_bias, float* g_z, float* g_params, float* partials,
+                                               int K, float logit_eps, int mode, int odd, int64_t B, int C, int H, int W,
+                                               nf_stream_t stream) {
+    if (partials == nullptr || nf_mixlog_bwd_blocks(K, mode, B, C, H, W) == 0) return NF_E_BADARG;
+    return nf_mixlog_bwd_launch(g_y, g_ld, z, params, a_log_scale, a_bias, g_z, g_params, nullptr, nullptr, partials, K, logit_eps, mode, odd, B,
+                                C, H, W, stream);
 }
 
 extern "C" int nf_mixlog_coupling_inv(const float* z, const float* params, const float* a_log_scale,

@@ -217,19 +217,23 @@ class ConvDefer:
     def usable(self, weights):
         return self.active and self.armed and all(getattr(w, '_nf_deferred_grad_ok', False) for w in weights)
 
-    def _slab_scratch(self, n, device):
-        t = self.scratch.get(device)
+    SCRATCH_RING = 3            # scratch buffers in rotation: the slab sums of up to SCRATCH_RING - 1 launches share one nf_slab_sum
+
+    def _slab_scratch(self, n, device, slot=0):
+        t = self.scratch.get((device, slot))
         if t is None or t.numel() < n:
-            t = self.scratch[device] = torch.empty(n, dtype=torch.float32, device=device)
+            t = self.scratch[(device, slot)] = torch.empty(n, dtype=torch.float32, device=device)
         return t
 
     def launch_layers(self, layers):
         """the weight-gradient passes of ``layers`` (entries as in self.layers), sixteen layers of one shape per launch, then their
         slab sums"""
         step = N.header_constant('NF_CONV_WGRAD_MAX')
+        sum_max = N.header_constant('NF_SLAB_SUM_MAX')
         groups = {}
         for e in layers:
             groups.setdefault(e[0], []).append(e)
+        pending, launches = [], 0        # slab-sum jobs of the launches whose scratch buffers are still untouched
         for key, es in groups.items():
             (B, Hh, Ww), I, O, k = key[:4]           # (key[4]: the valid extent of maps in power-of-two storage, one per launch)
             for k0 in range(0, len(es), step):
@@ -237,7 +241,11 @@ class ConvDefer:
                 slabs = _wgrad_slabs(B, Hh, Ww, len(chunk))       # (per launch: one workgroup per compute unit over all its layers)
                 per = [slabs * e[2].numel() for e in chunk]
                 dev = chunk[0][2].device
-                scratch = self._slab_scratch(sum(per), dev)
+                if pending and (launches % self.SCRATCH_RING == 0 or len(pending) + 2 * len(chunk) > sum_max):
+                    _slab_sum_all(pending)           # before this launch takes the oldest scratch buffer (stream order)
+                    pending, launches = [], 0
+                scratch = self._slab_scratch(sum(per), dev, launches % self.SCRATCH_RING)
+                launches += 1
                 arr = (ConvBwdDesc * len(chunk))()
                 jobs, off = [], 0
                 for i, e in enumerate(chunk):
@@ -250,7 +258,9 @@ class ConvDefer:
                     if len(e) > 4 and e[4] is not None:      # the layer's bias sums (filled by this very launch) ride the same slab sum
                         jobs.append(e[4])
                 N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
-                _slab_sum_all(jobs)                  # before the next chunk overwrites the scratch (stream order)
+                pending += jobs
+        if pending:
+            _slab_sum_all(pending)
 
     def flush(self):
         layers, sums = self.layers, self.sums
