@@ -150,18 +150,6 @@ class _AffineCoupling(torch.autograd.Function):
         g_z = torch.empty_like(z)
         g_t = torch.empty_like(t)
         g_s = torch.empty_like(s_raw)
-        if ctx.sinks is not None and z.dim() == 4:
-            # image data inside a trainer step: the coupling's scale / shift gradients leave as per-workgroup partial sums and are folded
-            # with the conditioners' slabs where the pass ends (fused_flowpp_img.FlowppImgDefer) -- no same-address atomics
-            from .fused_flowpp_img import FPP_IMG_DEFER
-            n = int(N.load().nf_mixlog_bwd_blocks(K, mode, B, C, H, W)) if FPP_IMG_DEFER.active else 0
-            if n > 0:
-                part = torch.empty(2 * n, dtype=torch.float32, device=z.device)
-                N.call('nf_mixlog_coupling_bwd_partials', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(g_z),
-                       N.ptr(g_p), N.ptr(part), K, eps, mode, odd, B, C, H, W, N.stream())
-                FPP_IMG_DEFER.sums.append((part[:n], ctx.sinks[0], 1, 1, n, True, 1))
-                FPP_IMG_DEFER.sums.append((part[n:], ctx.sinks[1], 1, 1, n, True, 1))
-                return g_z, g_p, None, None, g_ld, None, None, None, None
         if ctx.sinks is not None:
             pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
         else:
@@ -197,18 +185,6 @@ class _AffineCouplingPacked(torch.autograd.Function):
         g_y, g_ld = _contig(g_y), _contig(g_ld)
         g_z = torch.empty_like(z)
         g_p = torch.empty_like(params)
-        if ctx.sinks is not None and z.dim() == 4:
-            # image data inside a trainer step: the coupling's scale / shift gradients leave as per-workgroup partial sums and are folded
-            # with the conditioners' slabs where the pass ends (fused_flowpp_img.FlowppImgDefer) -- no same-address atomics
-            from .fused_flowpp_img import FPP_IMG_DEFER
-            n = int(N.load().nf_mixlog_bwd_blocks(K, mode, B, C, H, W)) if FPP_IMG_DEFER.active else 0
-            if n > 0:
-                part = torch.empty(2 * n, dtype=torch.float32, device=z.device)
-                N.call('nf_mixlog_coupling_bwd_partials', N.ptr(g_y), N.ptr(g_ld), N.ptr(z), N.ptr(params), N.ptr(a), N.ptr(c), N.ptr(g_z),
-                       N.ptr(g_p), N.ptr(part), K, eps, mode, odd, B, C, H, W, N.stream())
-                FPP_IMG_DEFER.sums.append((part[:n], ctx.sinks[0], 1, 1, n, True, 1))
-                FPP_IMG_DEFER.sums.append((part[n:], ctx.sinks[1], 1, 1, n, True, 1))
-                return g_z, g_p, None, None, g_ld, None, None, None, None
         if ctx.sinks is not None:
             pa, pc, ga, gc = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
         else:
