@@ -1095,6 +1095,19 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
 struct NfSlabArgs { nf_slab_sum_desc d[NF_SLAB_SUM_MAX]; };
 __global__ void __launch_bounds__(NF_BLOCK) k_slab_sum(NfSlabArgs args) {
     const nf_slab_sum_desc& d = args.d[blockIdx.y];
+    if (d.n <= 4 && d.taps <= 1 && d.n_slabs >= 64) {
+        // a few elements over MANY slabs (per-workgroup partial sums of a scalar gradient: csrc/mixlog.hip): a wave per element, lane l
+        // takes the slabs l, l + 64, ... and the lanes meet in a fixed order -- one thread walking 384 slabs was 24 us of dependent loads
+        if (blockIdx.x != 0) return;
+        const int lane = threadIdx.x & (NF_WAVE - 1);
+        for (int64_t e = threadIdx.x >> 6; e < d.n; e += blockDim.x >> 6) {
+            float t = 0.f;
+            for (int sl = lane; sl < d.n_slabs; sl += NF_WAVE) t += d.src[(int64_t)sl * d.stride + e];
+            t = nf_wave_sum(t);
+            if (lane == 0) d.dst[e] = d.accumulate ? d.dst[e] + t : t;
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < d.n; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t se = e;                                 // dst is (O, I, T), the slabs are (T, O, I) when taps > 1
         if (d.taps > 1) {

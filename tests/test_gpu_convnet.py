@@ -310,6 +310,22 @@ def test_half_scatter_add_is_scatter_plus_add(pkg, C, H, W, B, mode_name, odd):
     assert torch.equal(out, base + full)
 
 
+@pytest.mark.parametrize('n,n_slabs,acc', [(1, 384, True), (1, 64, False), (3, 1000, True), (1, 63, True), (5, 384, True), (9216, 16, True)])
+def test_slab_sum_of_a_few_elements_over_many_slabs(pkg, n, n_slabs, acc):
+    """nf_slab_sum: the wave-per-element form for scalar gradients left as per-workgroup partial sums (and the plain form around it)
+    against a float64 sum"""
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    torch.manual_seed(n + n_slabs)
+    src = torch.randn(n_slabs, n, device=DEV)
+    dst = torch.randn(n, device=DEV)
+    want = (dst.double() if acc else 0.0) + src.double().sum(0)
+    other_src, other_dst = torch.randn(16, 300, device=DEV), torch.zeros(300, device=DEV)       # a second job in the same launch
+    fc._slab_sum_all([(src, dst, n, n, n_slabs, acc, 1), (other_src, other_dst, 300, 300, 16, False, 1)])
+    torch.cuda.synchronize()
+    assert float((dst.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * (n_slabs ** 0.5)
+    assert float((other_dst.double() - other_src.double().sum(0)).abs().max()) <= 1e-5
+
+
 def test_cifar_glow_head_parameter_gradients_deferred_or_not(pkg, monkeypatch):
     """a trainer step of a (3, 32, 32) Glow with the heads' parameter gradients deferred to the batched launch (the default) and with every
     head's backward whole: z and the loss BITWISE (the forward is untouched), the flat gradient to the rounding of the atomics' order."""
