@@ -38,7 +38,7 @@ done
 python bench.py > $OUT/${R}_bench_default.json 2> $OUT/bench_default.err
 # per-step launch census of the two metric configs (steady-state window between marker launches) and per-grid chain launch times
 cd /tmp
-for c in c4 c1; do
+for c in c4 c1 fpp_img rnvp_img; do
   rm -rf /tmp/sk_$c
   rocprofv3 --kernel-trace --output-format csv -d /tmp/sk_$c -o st -- python $GRAFT_REPO_ROOT/tools/step_kernels.py $c > /dev/null 2> $OUT/sk_$c.err
   T=$(find /tmp/sk_$c -name "st_kernel_trace.csv" | head -1)
