@@ -242,7 +242,11 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
                     % (name, tag, len(gpu_ensemble), ' '.join('%.2e' % v for v in rel_gpu_all[1:]), med_g, med_o, max(rel_gpu_all), max(rel_ens),
                        min(rel_gpu_all), min(rel_ens), low_o, '  (oracle ensemble bimodal)' if bimodal else ''))
             if bimodal:
-                if min(rel_gpu_all) > ENS_RATIO * low_o + 2.0 * TOL:
+                # (+ the footprint of ONE kink event, KINK_FLAT / B: where the two modes are a single event apart -- realnvp_24 step 2 on
+                # one box: the oracle's five runs 2.0e-7, 2.8e-7, 1.80e-4, 1.80e-4, 1.89e-4, the GPU's five all 1.80e-4 .. 1.89e-4 -- five
+                # members on the far side are one chance in three at the oracle's own odds; C1's modes are 20 x further apart than
+                # its allowance, there the near mode must be reached)
+                if min(rel_gpu_all) > ENS_RATIO * low_o + 2.0 * TOL + KINK_FLAT / B:
                     bad.append(('best flat gradient distance to float64 over the ensemble (bimodal yard-stick)', min(rel_gpu_all), low_o))
             elif med_g > ENS_RATIO * med_o + 2.0 * TOL:
                 bad.append(('median flat gradient distance to float64 over the ensemble', med_g, med_o))
