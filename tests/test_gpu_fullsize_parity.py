@@ -248,7 +248,10 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
                 # its allowance, there the near mode must be reached)
                 if min(rel_gpu_all) > ENS_RATIO * low_o + 2.0 * TOL + KINK_FLAT / B:
                     bad.append(('best flat gradient distance to float64 over the ensemble (bimodal yard-stick)', min(rel_gpu_all), low_o))
-            elif med_g > ENS_RATIO * med_o + 2.0 * TOL:
+            elif med_g > ENS_RATIO * med_o + 2.0 * TOL + KINK_FLAT / B:
+                # (the same single-event footprint: an oracle ensemble that happens to hold no event at all is not "bimodal", yet the
+                # GPU's majority may sit one event away -- the allowance is 4.7e-4 at B = 64 and 7e-6 at C2's batch, i.e. it only
+                # matters where the distances themselves are 1e-7 .. 1e-4)
                 bad.append(('median flat gradient distance to float64 over the ensemble', med_g, med_o))
             # the LARGEST member: inside ENS_RATIO x the oracle's largest -- except that ONE member of a small ensemble may have met a kink
             # none of the oracle's members met (realnvp_24 step 2 on one box: the GPU's runs 6.3e-5, 3.2e-7, 3.3e-7, 1.9e-7, 2.0e-7, the
