@@ -1041,7 +1041,8 @@ int nf_flowpp_cond_bwd(const float* x, const float* W0, const float* b0, const f
  * nf_flowpp_img_celu_bwd: g_x += elu'(x) * g_cat[:, :C] - elu'(-x) * g_cat[:, C:]  (x (B, C, H, W), g_cat (B, 2 C, H, W)).
  * nf_flowpp_img_mid_fwd: x = conv0 output, a = the gated convolution's output (both (B, 32, H, W)) ->
  *   LN2( A(LN1(x + elu(a) * sigmoid(elu(-a)))) ),  A(t) = t + y * sigmoid(gate), [y, gate] = conv2(attention(conv1(t + pos))).
- * nf_flowpp_img_mid_bwd: its autograd, recomputing the forward from x and a; g_x / g_a written, parameter gradients ACCUMULATED;
+ * nf_flowpp_img_mid_bwd: its autograd, recomputing the forward from x and a; g_x / g_a written, parameter gradients ACCUMULATED (with
+ *   per_sample != 0 the (32, H, W) ones -- LayerNorm affines, position embedding -- are instead WRITTEN per sample, (B, 32, H, W));
  *   g_out may be g_out_slabs partial-sum slabs (g_out_slabs, B, 32, H, W) of a K-split nf_flowpp_img_conv, summed on load.          */
 #define NF_FLOWPP_IMG_MAX_KSPLIT 64
 #define NF_FLOWPP_IMG_MAX_SLABS 64
@@ -1069,7 +1070,7 @@ int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float* ln1_g, co
                           const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
                           const float* ln2_g, const float* ln2_b, const float* g_out, float* g_x, float* g_a, float* g_ln1_g,
                           float* g_ln1_b, float* g_pos, float* g_conv1_w, float* g_conv1_b, float* g_conv2_w, float* g_conv2_b,
-                          float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W, int g_out_slabs, nf_stream_t stream);
+                          float* g_ln2_g, float* g_ln2_b, int per_sample, int64_t B, int H, int W, int g_out_slabs, nf_stream_t stream);
 
 /* The same middle cut BY ATTENTION HEAD (csrc/flowpp_img_att.hip), for batches that leave most of the chip idle with one workgroup per
  * sample: H = W = 16 (nf_flowpp_img_att_usable != 0).  Forward = att_fwd (B x 4 workgroups: gate, LayerNorm 1, a head's rows of

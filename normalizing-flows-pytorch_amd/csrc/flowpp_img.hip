@@ -457,7 +457,8 @@ struct NfFiMid {
     int64_t g_slab_stride;
     float *g_x, *g_a, *g_ln1g, *g_ln1b, *g_pos, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2g, *g_ln2b;
     int V;               // side of the image inside the storage map (MK variants; the (32, V, V) parameters keep the reference's layout)
-};
+    int per_sample;      // the (32, V, V) parameter gradients (LayerNorm affines, position embedding) are WRITTEN per sample, (B, 32, V, V), for
+};                       // nf_slab_sum to fold (64 workgroups x 10 240 same-address atomics were ~9 of the 66 us of an 8 x 8 launch at B = 64)
 
 template <int NT>
 __device__ __forceinline__ float nf_fi_block_sum_all(float v, float* scr) {
@@ -683,8 +684,13 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
         for (int d = 0; d < 8; ++d) {
             const float g4 = ok ? g4v[d] : 0.f;
             if (ok) {
-                atomicAdd(m.g_ln2g + pbase + d * NV, g4 * xh2[d]);
-                atomicAdd(m.g_ln2b + pbase + d * NV, g4);
+                if (m.per_sample) {
+                    m.g_ln2g[b * 32 * NV + pbase + d * NV] = g4 * xh2[d];
+                    m.g_ln2b[b * 32 * NV + pbase + d * NV] = g4;
+                } else {
+                    atomicAdd(m.g_ln2g + pbase + d * NV, g4 * xh2[d]);
+                    atomicAdd(m.g_ln2b + pbase + d * NV, g4);
+                }
             }
             gh[d] = g4 * m.ln2g[pbase + d * NV];
             s1 += gh[d];
@@ -801,9 +807,15 @@ __global__ void __launch_bounds__(4 * N) k_fi_mid(NfFiMid m) {
         for (int d = 0; d < 8; ++d) {
             const float g2_ = g3[d] + gt[d];
             if (ok) {
-                atomicAdd(m.g_pos + pbase + d * NV, gt[d]);
-                atomicAdd(m.g_ln1g + pbase + d * NV, g2_ * xh1[d]);
-                atomicAdd(m.g_ln1b + pbase + d * NV, g2_);
+                if (m.per_sample) {
+                    m.g_pos[b * 32 * NV + pbase + d * NV] = gt[d];
+                    m.g_ln1g[b * 32 * NV + pbase + d * NV] = g2_ * xh1[d];
+                    m.g_ln1b[b * 32 * NV + pbase + d * NV] = g2_;
+                } else {
+                    atomicAdd(m.g_pos + pbase + d * NV, gt[d]);
+                    atomicAdd(m.g_ln1g + pbase + d * NV, g2_ * xh1[d]);
+                    atomicAdd(m.g_ln1b + pbase + d * NV, g2_);
+                }
             }
             gh[d] = g2_ * m.ln1g[pbase + d * NV];
             s1 += gh[d];
@@ -1029,8 +1041,8 @@ extern "C" int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float
                                      const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
                                      const float* ln2_g, const float* ln2_b, const float* g_out, float* g_x, float* g_a,
                                      float* g_ln1_g, float* g_ln1_b, float* g_pos, float* g_conv1_w, float* g_conv1_b,
-                                     float* g_conv2_w, float* g_conv2_b, float* g_ln2_g, float* g_ln2_b, int64_t B, int H, int W,
-                                     int g_out_slabs, nf_stream_t stream) {
+                                     float* g_conv2_w, float* g_conv2_b, float* g_ln2_g, float* g_ln2_b, int per_sample, int64_t B, int H,
+                                     int W, int g_out_slabs, nf_stream_t stream) {
     if (x == nullptr || a == nullptr || ln1_g == nullptr || ln1_b == nullptr || pos == nullptr || conv1_w == nullptr ||
         conv1_b == nullptr || conv2_w == nullptr || conv2_b == nullptr || ln2_g == nullptr || ln2_b == nullptr || g_out == nullptr ||
         g_x == nullptr || g_a == nullptr || g_ln1_g == nullptr || g_ln1_b == nullptr || g_pos == nullptr || g_conv1_w == nullptr ||
@@ -1039,6 +1051,7 @@ extern "C" int nf_flowpp_img_mid_bwd(const float* x, const float* a, const float
     if (!nf_flowpp_img_usable(B, 32, 32, H, W) || B > 0x7fffffff || g_out_slabs < 1 || g_out_slabs > NF_FLOWPP_IMG_MAX_KSPLIT) return NF_E_BADARG;
     NfFiMid m = {x, a, ln1_g, ln1_b, pos, conv1_w, conv1_b, conv2_w, conv2_b, ln2_g, ln2_b, nullptr, g_out, g_out_slabs, B * 32 * (int64_t)nf_flowpp_img_storage(H, W) * nf_flowpp_img_storage(H, W), g_x, g_a, g_ln1_g,
                  g_ln1_b, g_pos, g_conv1_w, g_conv1_b, g_conv2_w, g_conv2_b, g_ln2_g, g_ln2_b};
+    m.per_sample = per_sample ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     switch (nf_fi_lgw(H, W)) {
         case 4: return nf_fi_mid_launch<256, true>(m, W, B, st);

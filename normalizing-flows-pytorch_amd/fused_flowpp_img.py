@@ -166,10 +166,19 @@ class _FusedFlowppImg(torch.autograd.Function):
                    N.ptr(cj), N.ptr(g_mixed), N.ptr(gt_part), N.ptr(gc1w), N.ptr(gc1b), B, Hh, Ww, st)
             N.call('nf_flowpp_img_pre_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(g3), N.ptr(gt_part), N.ptr(g_x), N.ptr(g_a),
                    N.ptr(ps[2]), N.ptr(ps[3]), N.ptr(ps[4]), 1, B, Hh, Ww, st)
+        elif defer:
+            # one workgroup per sample: its (32, H, W) parameter gradients leave per sample as well and join the end-of-pass fold
+            n = HID * Hh * Ww
+            ps = torch.empty(5, B, n, dtype=torch.float32, device=dev)
+            for k_, dst_ in enumerate((gl2g, gl2b, gl1g, gl1b, gpos)):
+                jobs.append((ps[k_], dst_, n, n, B, True, 1))
+            N.call('nf_flowpp_img_mid_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
+                   N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(g4), N.ptr(g_x), N.ptr(g_a), N.ptr(ps[2]), N.ptr(ps[3]), N.ptr(ps[4]),
+                   N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(ps[0]), N.ptr(ps[1]), 1, B, Hh, Ww, ks, st)
         else:
             N.call('nf_flowpp_img_mid_bwd', N.ptr(x), N.ptr(a), N.ptr(l1g), N.ptr(l1b), N.ptr(pos), N.ptr(c1w), N.ptr(c1b), N.ptr(c2w),
                    N.ptr(c2b), N.ptr(l2g), N.ptr(l2b), N.ptr(g4), N.ptr(g_x), N.ptr(g_a), N.ptr(gl1g), N.ptr(gl1b), N.ptr(gpos),
-                   N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), B, Hh, Ww, ks, st)
+                   N.ptr(gc1w), N.ptr(gc1b), N.ptr(gc2w), N.ptr(gc2b), N.ptr(gl2g), N.ptr(gl2b), 0, B, Hh, Ww, ks, st)
         # gated convolution (its input is concat_elu(x), applied while staging)
         g_cat = torch.empty(B, 2 * HID, S, S, dtype=torch.float32, device=dev)
         N.call('nf_flowpp_img_conv', N.ptr(g_a), N.ptr(Wg), None, N.ptr(g_cat), B, HID, 2 * HID, Hh, Ww, 0, 1, 1, st)

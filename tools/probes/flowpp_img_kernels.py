@@ -52,7 +52,7 @@ for I0, O, HW in ((6, 84, 16), (24, 336, 8), (96, 1344, 4)):
     tot += timed('last conv wgrad (%d slabs)' % ns, lambda: N.call('nf_flowpp_img_conv_wgrad', p(x4), p(out), p(sw), p(sb), ns, B, 32, O, HW, HW, 0, N.stream()))
     tot += timed('mid bwd', lambda: N.call('nf_flowpp_img_mid_bwd', p(x), p(a), p(l1g), p(l1b), p(pos), p(c1w), p(c1b), p(c2w), p(c2b),
                                            p(l2g), p(l2b), p(g4), p(x4), p(out), p(gz[4]), p(gz[5]), p(gz[6]), p(gz[7]), p(gz[8]),
-                                           p(gz[9]), p(gz[10]), p(gz[11]), p(gz[12]), B, HW, HW, ks, N.stream()))
+                                           p(gz[9]), p(gz[10]), p(gz[11]), p(gz[12]), 0, B, HW, HW, ks, N.stream()))
     tot += timed('gated conv dgrad', lambda: N.call('nf_flowpp_img_conv', p(a), p(Wg), None, p(gcat), B, 32, 64, HW, HW, 0, 1, 1, N.stream()))
     ns = int(lib.nf_flowpp_img_wgrad_slabs(B, 64, 32, HW, HW)); sw = r(ns * 32 * 64 * 9); sb = r(ns * 32)
     tot += timed('gated conv wgrad (%d slabs)' % ns, lambda: N.call('nf_flowpp_img_conv_wgrad', p(x), p(a), p(sw), p(sb), ns, B, 64, 32, HW, HW, 1, N.stream()))
