@@ -270,15 +270,18 @@ __global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd(const float* __
 
 // ---- every invertible 1x1 convolution of a model in a few launches: workgroup = layer (an image Glow has 129 of them, and a
 //      single-workgroup launch of three C x C x C products is 14 + 24 us of pure latency each) -------------------------------------
+// (1 024 threads per layer since round 5: the products are C^3 / threads dependent LDS -> FMA steps per thread -- 432 at C = 48 with 256
+//  threads, 19 / 23.5 us per launch, 14 launches per CIFAR Glow step -- and the other 230 compute units have nothing to do meanwhile)
+#define NF_PLU_MULTI_THREADS 1024
 struct NfPluArgs { nf_plu_desc d[NF_PLU_MAX_LAYERS]; };
-__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_fwd_multi(NfPluArgs args) {
+__global__ void __launch_bounds__(NF_PLU_MULTI_THREADS) k_invconv_weight_fwd_multi(NfPluArgs args) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const nf_plu_desc& d = args.d[blockIdx.x];
     nf_plu_weight_fwd_body(sm, d.P, d.L, d.U, d.L_mask, d.U_mask, d.sign_s, d.log_s, d.W, d.C);
 }
-__global__ void __launch_bounds__(NF_BLOCK) k_invconv_weight_bwd_multi(NfPluArgs args) {
+__global__ void __launch_bounds__(NF_PLU_MULTI_THREADS) k_invconv_weight_bwd_multi(NfPluArgs args) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ float scratch[NF_BLOCK / NF_WAVE];
+    __shared__ float scratch[NF_PLU_MULTI_THREADS / NF_WAVE];
     __shared__ float sum_gld;
     const nf_plu_desc& d = args.d[blockIdx.x];
     nf_plu_weight_bwd_body(sm, scratch, &sum_gld, d.g_W, d.P, d.L, d.U, d.L_mask, d.U_mask, d.sign_s, d.log_s, d.g_ld, d.g_L, d.g_U,
@@ -406,7 +409,7 @@ extern "C" int nf_invconv_weight_fwd_multi(const nf_plu_desc* descs, int n_layer
     if (rc) return rc;
     NfPluArgs args;
     for (int i = 0; i < n_layers; ++i) args.d[i] = descs[i];
-    hipLaunchKernelGGL(k_invconv_weight_fwd_multi, dim3((unsigned)n_layers), dim3(NF_BLOCK), (size_t)3 * cmax * cmax * sizeof(float),
+    hipLaunchKernelGGL(k_invconv_weight_fwd_multi, dim3((unsigned)n_layers), dim3(NF_PLU_MULTI_THREADS), (size_t)3 * cmax * cmax * sizeof(float),
                        (hipStream_t)stream, args);
     NF_CHECK_LAUNCH();
     return 0;
@@ -425,7 +428,7 @@ extern "C" int nf_invconv_weight_bwd_multi(const nf_plu_desc* descs, int n_layer
     }
     NfPluArgs args;
     for (int i = 0; i < n_layers; ++i) args.d[i] = descs[i];
-    hipLaunchKernelGGL(k_invconv_weight_bwd_multi, dim3((unsigned)n_layers), dim3(NF_BLOCK), (size_t)5 * cmax * cmax * sizeof(float),
+    hipLaunchKernelGGL(k_invconv_weight_bwd_multi, dim3((unsigned)n_layers), dim3(NF_PLU_MULTI_THREADS), (size_t)5 * cmax * cmax * sizeof(float),
                        (hipStream_t)stream, args);
     NF_CHECK_LAUNCH();
     return 0;
