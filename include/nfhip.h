@@ -634,7 +634,7 @@ int nf_conv_wgrad_slabs(int64_t B, int H, int W, int n_layers);
 
 /* dst[e] (+)= sum_{s < n_slabs} src[s * stride + e], e < n: every slab / replica sum of one conditioner backward in ONE
  * launch (weight-gradient slabs, bias and BatchNorm-parameter replicas).                                                */
-#define NF_SLAB_SUM_MAX 80       /* (80 x 48 bytes of kernel arguments) */
+#define NF_SLAB_SUM_MAX 72       /* (72 x 48 bytes of descriptors + the per-job workgroup ranges: under the 4 KB of kernel arguments) */
 typedef struct nf_slab_sum_desc {
     const float* src;
     float* dst;

@@ -1092,13 +1092,20 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
 // ---------------------------------------------------------------------------------------------------------------
 // dst[e] (+)= sum_s src[s * stride + e]: the slab / replica sums of one conditioner backward in one launch
 // ---------------------------------------------------------------------------------------------------------------
-struct NfSlabArgs { nf_slab_sum_desc d[NF_SLAB_SUM_MAX]; };
+// The grid is ONE dimension cut into per-job ranges (first[j] .. first[j + 1]): a job gets the workgroups ITS size asks for.  (As a
+// (max blocks, jobs) grid a launch that mixed a 387 k-element weight gradient with 79 small jobs started 82 k workgroups, 80 k of them
+// with nothing to do: 43 us per launch in the image Flow++ step.)
+struct NfSlabArgs { nf_slab_sum_desc d[NF_SLAB_SUM_MAX]; unsigned short first[NF_SLAB_SUM_MAX + 1]; int n_jobs; };
 __global__ void __launch_bounds__(NF_BLOCK) k_slab_sum(NfSlabArgs args) {
-    const nf_slab_sum_desc& d = args.d[blockIdx.y];
+    int job = 0;
+    for (int step = 64; step > 0; step >>= 1)               // the last job whose first workgroup is <= blockIdx.x
+        if (job + step < args.n_jobs && args.first[job + step] <= blockIdx.x) job += step;
+    const nf_slab_sum_desc& d = args.d[job];
+    const unsigned local = blockIdx.x - args.first[job], nblk = args.first[job + 1] - args.first[job];
     if (d.n <= 4 && d.taps <= 1 && d.n_slabs >= 64) {
         // a few elements over MANY slabs (per-workgroup partial sums of a scalar gradient: csrc/mixlog.hip): a wave per element, lane l
         // takes the slabs l, l + 64, ... and the lanes meet in a fixed order -- one thread walking 384 slabs was 24 us of dependent loads
-        if (blockIdx.x != 0) return;
+        if (local != 0) return;
         const int lane = threadIdx.x & (NF_WAVE - 1);
         for (int64_t e = threadIdx.x >> 6; e < d.n; e += blockDim.x >> 6) {
             float t = 0.f;
@@ -1108,7 +1115,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_slab_sum(NfSlabArgs args) {
         }
         return;
     }
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < d.n; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = (int64_t)local * blockDim.x + threadIdx.x; e < d.n; e += (int64_t)nblk * blockDim.x) {
         int64_t se = e;                                 // dst is (O, I, T), the slabs are (T, O, I) when taps > 1
         if (d.taps > 1) {
             const int64_t oi = e / d.taps;
@@ -1133,15 +1140,18 @@ __global__ void __launch_bounds__(NF_BLOCK) k_slab_sum(NfSlabArgs args) {
 extern "C" int nf_slab_sum(const nf_slab_sum_desc* descs, int n_jobs, nf_stream_t stream) {
     if (descs == nullptr || n_jobs < 1 || n_jobs > NF_SLAB_SUM_MAX) return NF_E_BADARG;
     NfSlabArgs args;
-    int64_t nmax = 1;
+    unsigned total = 0;
     for (int i = 0; i < n_jobs; ++i) {
         if (descs[i].src == nullptr || descs[i].dst == nullptr || descs[i].n < 0 || descs[i].n_slabs < 0) return NF_E_BADARG;
         args.d[i] = descs[i];
-        if (descs[i].n > nmax) nmax = descs[i].n;
+        args.first[i] = (unsigned short)total;
+        unsigned nb = nf_grid_for(descs[i].n > 0 ? descs[i].n : 1);
+        if (nb > 512) nb = 512;                         // (72 jobs x 512 < 65 536: the ranges fit 16 bits; a large job walks with a stride)
+        total += nb;
     }
-    unsigned gx = nf_grid_for(nmax);
-    if (gx > 1024) gx = 1024;                           // (128 until round 3: the 387 k-element weight gradients of the image Flow++ output convolution took 27 us)
-    hipLaunchKernelGGL(k_slab_sum, dim3(gx, (unsigned)n_jobs), dim3(NF_BLOCK), 0, (hipStream_t)stream, args);
+    args.first[n_jobs] = (unsigned short)total;
+    args.n_jobs = n_jobs;
+    hipLaunchKernelGGL(k_slab_sum, dim3(total), dim3(NF_BLOCK), 0, (hipStream_t)stream, args);
     NF_CHECK_LAUNCH();
     return 0;
 }
