@@ -344,7 +344,7 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
     from oracle import models as om
     from oracle import transforms as tf
     # the flow step is thousands of tiny ops: torch's intra-op pool stops scaling (and then collapses) beyond a few threads.
-    # Measured once per round on the GPU box's 256 host cores (tools/cpu_threads.py, profiles/r04_cpu_threads.txt): C4 1297 / 1239 /
+    # Measured once per round on the GPU box's 256 host cores (tools/cpu_threads.py, profiles/r05_cpu_threads.txt): C4 1297 / 1239 /
     # 2703 / 7002 ms per step at 8 / 16 / 32 / 64 threads, C1 32 / 47 / 55 / 60 / 128 ms at 1 / 4 / 8 / 16 / 32 -- the baseline runs
     # at the FASTEST setting of its config (C4: 16, C1: 1; the others 8, what the reference was probed with in BASELINE.md);
     # `cores` reports what ran
@@ -389,7 +389,7 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
     return ({'value': round(B * n / el, 1), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
              'sample': '%d train steps of the same workload (batch %d, same initial weights) in %.1f s on %s' % (n, B, el, model),
              'ms_per_step': round(1e3 * el / n, 2), 'host_cores': os.cpu_count(),
-             'threads_note': 'fastest of the per-round thread sweep for this config (profiles/r04_cpu_threads.txt)'}, first)
+             'threads_note': 'fastest of the per-round thread sweep for this config (profiles/r05_cpu_threads.txt)'}, first)
 
 
 def resolve_batch(cfg, scaling, batch_override, world):
@@ -577,6 +577,65 @@ def summary_of(out):
             'rows': rows}
 
 
+LINE_CAP = 4000             # bytes of the ONE stdout line: the round-5 line (23 150 B) was not parsed by the driver, the round-4 one (15 189 B) was;
+                            # the driver keeps an 8 081-character tail of stdout, so the whole line has to fit inside that with room to spare
+HEAD_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+             'data', 'config', 'roofline', 'cpu_baseline', 'parity', 'whole_step', 'loss_nats', 'bits_per_dim', 'summary', 'detail')
+ROOF_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'flop_per_launch', 'bytes_per_launch', 'us_per_launch',
+             'launches_timed', 'workgroups', 'traffic_source')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample', 'ms_per_step', 'host_cores')
+PARITY_KEYS = ('loss_gpu_step1', 'loss_cpu_step1', 'abs_dloss_per_dim', 'max_abs_dz', 'max_abs_z')
+WHOLE_KEYS = ('flop_per_step', 'mfma_tflops', 'mfma_frac', 'hbm_bytes_per_step', 'hbm_gbs', 'hbm_frac')
+CONFIG_KEYS = ('workload', 'name', 'per_gpu_batch', 'global_batch', 'parallelism', 'hipgraph', 'deterministic', 'dp_one_graph', 'collective')
+
+
+def _clip(v, n):
+    """strings of the headline are phrases, not paragraphs (the paragraphs are in the detail file)"""
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3].rstrip() + '...'
+
+
+def _pick(obj, keys, n=100):
+    return None if obj is None else {k: _clip(obj[k], n) for k in keys if k in obj}
+
+
+def headline_of(out, detail_path=None):
+    """the ONE stdout line: the primary workload's contract keys + `roofline`, `cpu_baseline`, `parity`, `whole_step` cut to their numbers
+    and a phrase each, + one `summary` row per other workload measured in the same run.  The complete objects (every note, every `also`
+    workload) are the DETAIL, written to a side file and to stderr -- never to stdout.  Raises if the line would pass LINE_CAP."""
+    head = {k: out[k] for k in HEAD_KEYS if k in out}
+    head['metric'] = _clip(head['metric'], 90)
+    head['data'] = _clip(head.get('data'), 70)
+    head['config'] = _pick(out.get('config'), CONFIG_KEYS, 110)
+    head['roofline'] = _pick(out.get('roofline'), ROOF_KEYS, 120)
+    head['cpu_baseline'] = _pick(out.get('cpu_baseline'), CPU_KEYS, 130)
+    head['parity'] = _pick(out.get('parity'), PARITY_KEYS)
+    head['whole_step'] = _pick(out.get('whole_step'), WHOLE_KEYS)
+    head['summary'] = summary_of(out)
+    if detail_path:
+        head['detail'] = detail_path
+    line = json.dumps(head, separators=(', ', ': '))
+    if len(line.encode()) >= LINE_CAP:
+        raise AssertionError('bench.py: the stdout line is %d bytes (cap %d): trim headline_of, do not grow the line' % (len(line.encode()), LINE_CAP))
+    json.loads(line)
+    return line
+
+
+def write_detail(out):
+    """the full objects of every workload of this run: gpurun_out/bench_detail.json (merged back from the GPU box) and, when that
+    directory cannot be made, next to bench.py; returns the path relative to the repo root (None if nothing could be written)"""
+    text = json.dumps(out, indent=1)
+    for rel in (os.path.join('gpurun_out', 'bench_detail.json'), 'bench_detail.json'):
+        path = os.path.join(ROOT, rel)
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, 'w') as f:
+                f.write(text + '\n')
+            return rel
+        except OSError:
+            continue
+    return None
+
+
 def collective_info(world):
     """what the gradient exchange ran on: the process group's backend and size as torch.distributed reports them (N = 1: none)"""
     if not torch.distributed.is_initialized():
@@ -668,13 +727,13 @@ def main():
             out['also'].update(more)
             if b512 is not None:
                 out['also']['c4_b512'] = b512
-    if rank == 0:
-        out['summary'] = summary_of(out)
     if world > 1 or torch.distributed.is_initialized():   # (initialised at one rank: NF_DP_FORCE_COLLECTIVE=1, the DP control flow on one GPU)
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
-        _emit_line(json_fd, json.dumps(out))
+        detail = write_detail(out)
+        sys.stderr.write('bench detail (every workload, full notes):\n' + json.dumps(out) + '\n')
+        _emit_line(json_fd, headline_of(out, detail))
 
 
 if __name__ == '__main__':
