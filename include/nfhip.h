@@ -943,13 +943,15 @@ int nf_realnvp_flow_vec_bwd_deferred(const void* steps_dev, int S, const float* 
 /* RealNVP runs with D = 2 and N <= 256 (training mode: nf_realnvp_flow_vec_fwd / nf_realnvp_flow_vec_bwd_deferred) can be served by
  * ONE workgroup that holds the whole batch (csrc/flow_solo.hip): no meeting in global memory.  mode bit 0 = the forward run, bit 1 =
  * the backward run (it reads the activations the one-workgroup forward stashed, so it needs bit 0 as well; the environment variable
- * NF_FLOW_SOLO sets the mode at load; mode < 0 changes nothing); returns 0.
+ * NF_FLOW_SOLO sets the mode at load; mode < 0 changes nothing); returns 0.  The backward run is a PAIR of workgroups that must share an
+ * XCD: it is taken only on devices whose XCC count divides 8 (hipDeviceAttributeNumberOfXccs), the grid kernels serve the others.
  * Buffer sizes of such a run do NOT follow the grid kernels' rule; ask, whichever kernel ends up serving the call:
  *   nf_realnvp_flow_save_floats(N, D)  floats PER STEP of `saves`: the S statistics records (S x NF_REALNVP_SAVE_FLOATS, stride
- *                                      NF_REALNVP_SAVE_FLOATS) are followed by S x NF_FLOW_SOLO_STASH_FLOATS floats of stashed
- *                                      BatchNorm inputs, S x NF_FLOW_SOLO_GBUF_FLOATS floats of backward scratch (the backward WRITES
- *                                      them) and S x NF_FLOW_SOLO_TAB_FLOATS floats of table images for the shapes the one-workgroup
- *                                      kernels take (16-byte aligned base);
+ *                                      NF_REALNVP_SAVE_FLOATS) are followed -- at the next multiple of 32 floats, so that the regions
+ *                                      start on a 128-byte line -- by S x NF_FLOW_SOLO_STASH_FLOATS floats of stashed BatchNorm
+ *                                      inputs, S x NF_FLOW_SOLO_GBUF_FLOATS floats of backward scratch (the backward WRITES them) and
+ *                                      S x NF_FLOW_SOLO_TAB_FLOATS floats of table images for the shapes the one-workgroup kernels
+ *                                      take (`saves` itself on a 128-byte line: the kernels return NF_E_BADARG otherwise);
  *   nf_realnvp_flow_bwd_regions(N, D)  regions per step of slabs_all / head_rec of nf_realnvp_flow_vec_bwd_deferred
  *                                      (NF_FLOW_SOLO_REGIONS for those shapes, ceil(N / NF_MLP_ROWS_PER_BLOCK) otherwise).
  * Both return the count (> 0), not an error code.                                                                                  */

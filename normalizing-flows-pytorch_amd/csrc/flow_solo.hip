@@ -928,10 +928,17 @@ static int nf_so_enabled() {
     }
     return nf_so_mode;
 }
+// The stash / hand-over / table regions behind the S statistics records start on a 128-byte line (S x 328 floats is one only for
+// S % 4 == 0): the backward's worker reads the hand-over area with plain L1-cached loads on the argument that every line is read once
+// per launch -- a line shared by the regions of two waves (a misaligned base) would break that argument.  NF_FLOW_SOLO_PAD_FLOATS
+// per step pays for the padding whatever S is.
+#define NF_FLOW_SOLO_PAD_FLOATS 32
+static inline size_t nf_so_stash_offset(int S, int save_stride) { return (((size_t)S * save_stride + 31) / 32) * 32; }
 // sizes a caller needs for a RealNVP run of N rows x D features in training mode (whichever kernel serves it)
 extern "C" int nf_realnvp_flow_save_floats(int64_t N, int D) {
     const bool solo_shape = D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS;
-    return NF_REALNVP_SAVE_FLOATS + (solo_shape ? NF_FLOW_SOLO_STASH_FLOATS + NF_FLOW_SOLO_GBUF_FLOATS + NF_FLOW_SOLO_TAB_FLOATS : 0);
+    return NF_REALNVP_SAVE_FLOATS +
+           (solo_shape ? NF_FLOW_SOLO_PAD_FLOATS + NF_FLOW_SOLO_STASH_FLOATS + NF_FLOW_SOLO_GBUF_FLOATS + NF_FLOW_SOLO_TAB_FLOATS : 0);
 }
 extern "C" int nf_realnvp_flow_bwd_regions(int64_t N, int D) {
     const int grid = (int)((N + NF_MLP_ROWS_PER_BLOCK - 1) / NF_MLP_ROWS_PER_BLOCK);
@@ -943,10 +950,25 @@ extern "C" int nf_flow_solo_config(int mode) {
     if (mode >= 0) nf_so_mode = mode & 3;
     return 0;
 }
+// The two-workgroup backward needs blocks 0 and NF_SO_B_BLOCK of a launch on ONE XCD (its L2 is the hand-over's only point of coherence).
+// Workgroups are dealt round-robin over the device's XCCs, so that holds exactly when the XCC count of the (partition of the) device
+// divides NF_SO_B_BLOCK: 8 (MI355X / MI300X in SPX mode), 4, 2 or 1 (DPX / QPX / CPX partitions).  Asked once per device; a device that
+// does not answer, or answers anything else (a 6-XCD part), runs the grid kernels' backward -- the in-kernel check stays as the backstop.
+static int nf_so_pair_ok() {
+    static int cache[64];                             // 0: not asked, 1: yes, 2: no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev] == 0) {
+        int xcc = 0;
+        const bool got = hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess;
+        cache[dev] = (got && xcc >= 1 && NF_SO_B_BLOCK % xcc == 0) ? 1 : 2;
+    }
+    return cache[dev] == 1;
+}
 int nf_solo_plan(int64_t N, int D, int backward) {
     // (the one-workgroup backward reads the activations the one-workgroup forward stashed: it needs the forward bit as well)
     const int m = nf_so_enabled();
-    const bool on = backward ? (m & 3) == 3 : (m & 1) != 0;
+    const bool on = backward ? ((m & 3) == 3 && nf_so_pair_ok()) : (m & 1) != 0;
     return on && D == 2 && N >= 1 && N <= NF_FLOW_SOLO_MAX_ROWS ? 1 : 0;
 }
 int nf_solo_bwd_steps_ok(int S) { return S >= 1 && S <= NF_SO_WK_MAX_STEPS; }
@@ -961,7 +983,8 @@ int nf_solo_fwd(const void* steps_dev, int S, const float* z0, float* ys, float*
     }
     // saves: S statistics records | S stashes of BatchNorm inputs | S hand-over areas of the backward | S table images
     // (include/nfhip.h: nf_realnvp_flow_save_floats)
-    f32x4s* stash = reinterpret_cast<f32x4s*>(saves + (size_t)S * save_stride);
+    f32x4s* stash = reinterpret_cast<f32x4s*>(saves + nf_so_stash_offset(S, save_stride));
+    if ((reinterpret_cast<uintptr_t>(stash) & 127) != 0) return NF_E_BADARG;          // (`saves` itself must sit on a 128-byte line)
     f32x4s* tabs = stash + (size_t)S * ((NF_FLOW_SOLO_STASH_FLOATS + NF_FLOW_SOLO_GBUF_FLOATS) / 4);
     hipLaunchKernelGGL(k_solo_fwd, dim3(1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, ld, saves, save_stride,
                        stash, tabs, (int)N, bn_eps, bn_momentum, wn_eps);
@@ -984,8 +1007,11 @@ int nf_solo_bwd(const void* steps_dev, int S, const float* z0, const float* ys, 
     }
     // saves: S statistics records | S stashes of BatchNorm inputs (forward) | S hand-over areas data path -> worker (this launch);
     // flags: the first eight words of the zeroed exchange workspace
-    const f32x4s* stash = reinterpret_cast<const f32x4s*>(saves + (size_t)S * save_stride);
+    const f32x4s* stash = reinterpret_cast<const f32x4s*>(saves + nf_so_stash_offset(S, save_stride));
     f32x4s* gbuf = const_cast<f32x4s*>(stash) + (size_t)S * (NF_FLOW_SOLO_STASH_FLOATS / 4);
+    // every worker wave's 1 KB of a hand-over array starts on a cache line of its own (see nf_so_stash_offset)
+    static_assert((NF_FLOW_SOLO_STASH_FLOATS * 4) % 128 == 0 && (NF_FLOW_SOLO_GBUF_FLOATS * 4) % 128 == 0, "regions: whole 128-byte lines");
+    if ((reinterpret_cast<uintptr_t>(gbuf) & 127) != 0) return NF_E_BADARG;
     const float* tabs = reinterpret_cast<const float*>(gbuf + (size_t)S * (NF_FLOW_SOLO_GBUF_FLOATS / 4));
     hipLaunchKernelGGL(k_solo_bwd, dim3(NF_SO_B_BLOCK + 1), dim3(NF_SO_THREADS), lds, stream, (const NfGlowFlowStep*)steps_dev, S, z0, ys, g_y,
                        g_ld, gzs, saves, save_stride, stash, tabs, gbuf, reinterpret_cast<unsigned*>(ws_zero), accumulate, slabs_all,
