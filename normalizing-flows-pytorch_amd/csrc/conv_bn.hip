@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, N
         }
         __syncthreads();
         if (threadIdx.x < 64) {                         // wave 0 adds for the workgroup; half 0: sums, half 1: squares
-            NF_DET_ENTER_WAVE(nf_cvb);
+            NF_DET_REPL_CHAIN(NF_STAT_REPL);            // (deterministic mode: the workgroups of a replica in block order, the replicas side by side)
+            NF_DET_ENTER_WAVE_K(nf_cvb);
             if (c32 < O) {
                 float t = 0.f;
 #pragma unroll
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_fwd(nf_conv_desc d, N
                 const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
                 atomicAdd((hs == 0 ? d.stat_sum : d.stat_sqsum) + rep + c32, t);
             }
-            NF_DET_LEAVE_WAVE(nf_cvb);
+            NF_DET_LEAVE_WAVE_K(nf_cvb);
         }
     }
     NF_CV_STAMP(5);
@@ -574,7 +575,8 @@ __device__ __forceinline__ void nf_cv_bwd_body(const nf_conv_bwd_desc& d, const 
     }
     NF_CV_STAMP(13);
     // ---- bias and BatchNorm sums ----
-    NF_DET_ENTER_ALL(nf_cvb);                          // (no two threads of the workgroup add to one address; the turn covers both groups)
+    NF_DET_REPL_CHAIN(NF_STAT_REPL);                   // (blockIdx.y = the layer of a multi-launch: chains per layer and replica)
+    NF_DET_ENTER_ALL_K(nf_cvb);                        // (no two threads of the workgroup add to one address; the turn covers both groups)
     if (WG && d.g_bias != nullptr) {
 #pragma unroll
         for (int v = 0; v < NUW; ++v) {
@@ -606,7 +608,7 @@ __device__ __forceinline__ void nf_cv_bwd_body(const nf_conv_bwd_desc& d, const 
             atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
         }
     }
-    NF_DET_LEAVE_ALL(nf_cvb);
+    NF_DET_LEAVE_ALL_K(nf_cvb);
     NF_CV_STAMP(14);
 }
 
@@ -929,12 +931,13 @@ __device__ __forceinline__ void nf_cv_wgrad3_body(const nf_conv_bwd_desc& d, con
         if (oc < O && ic < I) slab[(tap * O + oc) * I + ic] = red[e];
     }
     {
-        NF_DET_ENTER_ALL(nf_cvb);                      // waves 0 and 1 walked tap 0 and add to the same addresses: in wave order in the mode
+        NF_DET_REPL_CHAIN(NF_STAT_REPL);
+        NF_DET_ENTER_ALL_K(nf_cvb);                    // waves 0 and 1 walked tap 0 and add to the same addresses: in wave order in the mode
         const float t = gbw + __shfl_xor(gbw, 32, NF_WAVE);
         nf_det_waves(nf_det_, NF_CV_THREADS / NF_WAVE, wid, [&] {
             if (d.g_bias != nullptr && tA == 0 && hs == 0 && c32 < O) atomicAdd(d.g_bias + 256 * (blockIdx.x % NF_STAT_REPL) + c32, t);
         });
-        NF_DET_LEAVE_ALL(nf_cvb);
+        NF_DET_LEAVE_ALL_K(nf_cvb);
     }
 }
 

@@ -484,13 +484,14 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_fwd(nf_conv_desc d
         }
         __syncthreads();
         if (threadIdx.x < 64) {                        // wave 0 adds for the workgroup; half 0: sums, half 1: squares
-            NF_DET_ENTER_WAVE(nf_cbk);
+            NF_DET_REPL_CHAIN(NF_STAT_REPL);           // (deterministic mode: a chain per replica -- and per layer of a multi-launch)
+            NF_DET_ENTER_WAVE_K(nf_cbk);
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
             const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
             atomicAdd((hs == 0 ? d.stat_sum : d.stat_sqsum) + rep + c32, t);
-            NF_DET_LEAVE_WAVE(nf_cbk);
+            NF_DET_LEAVE_WAVE_K(nf_cbk);
         }
     }
     NF_CB_STAMP(61);
@@ -667,7 +668,8 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_de
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            NF_DET_ENTER_WAVE(nf_cbk);
+            NF_DET_REPL_CHAIN(NF_STAT_REPL);           // (deterministic mode: a chain per replica -- and per layer of a multi-launch)
+            NF_DET_ENTER_WAVE_K(nf_cbk);
             if (c32 < I) {
                 float t = 0.f;
 #pragma unroll
@@ -675,7 +677,7 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_de
                 const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
                 atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
             }
-            NF_DET_LEAVE_WAVE(nf_cbk);
+            NF_DET_LEAVE_WAVE_K(nf_cbk);
         }
     }
 }
@@ -1023,7 +1025,8 @@ __global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti 
         const int tap = e >> 10, oc = (e >> 5) & 31, ic = e & 31;
         if (ic < I) slab[(tap * 32 + oc) * I + ic] = red[e];
     }
-    NF_DET_ENTER_ALL(nf_cbk);                          // (one thread per output channel and workgroup)
+    NF_DET_REPL_CHAIN(NF_STAT_REPL);                   // (blockIdx.y = the layer: chains per layer and replica)
+    NF_DET_ENTER_ALL_K(nf_cbk);                        // (one thread per output channel and workgroup)
     if (!walker && d.g_bias != nullptr) {
         const int ft = tid - NF_CBW_FILL;
 #pragma unroll
@@ -1034,7 +1037,7 @@ __global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti 
             if ((ft & 31) == 0) atomicAdd(d.g_bias + 256 * (blockIdx.x % NF_STAT_REPL) + 8 * r + (ft >> 5), v);
         }
     }
-    NF_DET_LEAVE_ALL(nf_cbk);
+    NF_DET_LEAVE_ALL_K(nf_cbk);
 }
 
 template <typename K>
@@ -1275,13 +1278,14 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv1_bulk_bwd(nf_conv_bwd_de
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            NF_DET_ENTER_WAVE(nf_cbk);
+            NF_DET_REPL_CHAIN(NF_STAT_REPL);           // (deterministic mode: a chain per replica -- and per layer of a multi-launch)
+            NF_DET_ENTER_WAVE_K(nf_cbk);
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
             const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
             atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
-            NF_DET_LEAVE_WAVE(nf_cbk);
+            NF_DET_LEAVE_WAVE_K(nf_cbk);
         }
     }
 }

@@ -201,7 +201,8 @@ __device__ __forceinline__ void nf_gh_bwd_body(const float* __restrict__ gh, con
         }
     }
     __syncthreads();
-    NF_DET_ENTER_ALL(nf_gh);               // (thread i of the workgroup owns value i)
+    NF_DET_ROW_CHAIN();                    // (blockIdx.y = the head of a multi-launch, 0 otherwise: one chain per head)
+    NF_DET_ENTER_ALL_K(nf_gh);             // (thread i of the workgroup owns value i)
     if (threadIdx.x < NV) {
         const int i = threadIdx.x;
         const int nw = (blockDim.x + NF_WAVE - 1) >> 6;
@@ -216,7 +217,7 @@ __device__ __forceinline__ void nf_gh_bwd_body(const float* __restrict__ gh, con
             else atomicAdd(gW + r * CT + (k - 2), t);
         }
     }
-    NF_DET_LEAVE_ALL(nf_gh);
+    NF_DET_LEAVE_ALL_K(nf_gh);
 }
 
 template <int CT, int PART>

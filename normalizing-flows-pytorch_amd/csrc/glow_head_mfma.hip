@@ -420,7 +420,8 @@ __device__ __forceinline__ void nf_gh_w_bwd_body(float* lds, const float* __rest
             for (int e = 0; e < 4; ++e)              // D: row = 4 lk + e (r), col = li (c)
                 red[(wid * CP + 16 * i + 4 * lk + e) * CP + 16 * j + li] = acc[i][j][e];
     __syncthreads();
-    NF_DET_ENTER_ALL(nf_ghm);              // (one thread per entry / channel and workgroup; the turn is held over both groups of sums)
+    NF_DET_ROW_CHAIN();                    // (blockIdx.y = the head of a multi-launch, 0 otherwise: one chain per head)
+    NF_DET_ENTER_ALL_K(nf_ghm);            // (one thread per entry / channel and workgroup; the turn is held over both groups of sums)
     for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
         const int r = e / C, c = e - r * C;
         const float t = red[(0 * CP + r) * CP + c] + red[(1 * CP + r) * CP + c] + red[(2 * CP + r) * CP + c] +
@@ -459,7 +460,7 @@ __device__ __forceinline__ void nf_gh_w_bwd_body(float* lds, const float* __rest
         atomicAdd(g_ls + c, -R2 - (float)P * SG);        // modules.py:246-249 differentiated
         atomicAdd(g_b + c, -R1 * cst[CP + c]);
     }
-    NF_DET_LEAVE_ALL(nf_ghm);
+    NF_DET_LEAVE_ALL_K(nf_ghm);
     NF_GH_STAMP(14);
 }
 

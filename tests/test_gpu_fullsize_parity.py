@@ -70,14 +70,20 @@ TOL = 1.0e-5
 SLACK = 4.0
 FLIPS = 4          # kink events per pass whose footprint the per-step profile may carry (see the docstring)
 AMP = 1.3          # amplification of a gradient perturbation per flow step of the backward pass (measured)
-ENSEMBLE = 12      # row permutations of the batch the fp32 oracle AND the GPU path are run on where that is cheap (C1, C2, C5)
+ENSEMBLE = 32      # row permutations of the batch the fp32 oracle AND the GPU path are run on where that is cheap (C1, C2, C5)
 ENSEMBLE_SLOW = 6  # ... and for C3 / C4 as well since the oracle's threads are capped (conftest.py: an fp32 step is ~1 s there, was 3 - 6 s)
 ENSEMBLE_BIG = 2   # ... and for config 4 at batch 512 (an fp32 oracle step is ~10 s, a float64 one ~25 s)
 ENSEMBLE_IMAGE = 4 # row permutations for the image stacks of the second test (CIFAR / MNIST shape, (1, 24, 24))
 KINK_CAP = 0.05    # the per-step kink allowance never exceeds this
 KINK_FLAT = 3.0e-2  # flat-gradient (relative L2) footprint of one kink event, times the batch size (measured: <= 1.9e-4 at B = 64)
-ENS_RATIO = 3.0    # GPU ensemble vs fp32-oracle ensemble (flat gradient distance to float64): median and max within this factor
-BIMODAL = 5.0      # an oracle ensemble whose max exceeds this multiple of its lower quartile is treated as bimodal (see _compare_step)
+ENS_RATIO = 2.0    # GPU ensemble vs fp32-oracle ensemble (flat gradient distance to float64): median and upper quartile within this factor
+TAIL_RATIO = 3.0   # ... and the GPU's 90th percentile within this factor of the oracle's LARGEST member (the tail is heavy: see _compare_step)
+NEAR = 3.0         # a member is "in the near mode" inside NEAR x the oracle ensemble's lower quartile
+SHARE = 1.0 / 3.0  # multi-modal yard-stick: the GPU's share of near-mode members must be at least SHARE x the oracle's own.  Why a third and not
+                   # a half: five equally valid fp32 formulations of training-mode BatchNorm on ONE host have near-mode shares of 0.25 .. 0.81 on
+                   # C1 (tools/kink_odds.py, profiles/r05_c1_kink_odds.txt: a factor 3.2 between two correct CPU implementations); at 64
+                   # permutations a side the GPU paths measure 0.30 / 0.42 / 0.38 against the oracle's 0.59 (profiles/r06_parity_modes_c1*.txt)
+BIMODAL = 2.5      # an oracle ensemble whose max exceeds this multiple of its lower quartile has more than one mode (see _compare_step)
 WIDE = 0.2         # ensemble envelope beyond which the bar is 1.25 x the envelope instead of 2 x
 
 CONFIGS = [
@@ -221,47 +227,47 @@ def _compare_step(name, tag, net, z, loss, rec32, rec64, dims, gaps, B, ensemble
         gaps['flat'] = max(rel_ens)
         _report('%-18s %-14s flat gradient distance to float64: gpu %.3e  cpu32 %.3e  fp32 oracle on %d row permutations: %s'
                 % (name, tag, rel_gpu, rel_ens[0], len(members) - 1, ' '.join('%.2e' % v for v in rel_ens[1:])))
-        # THE GPU HAS AN ENSEMBLE OF ITS OWN (round 5): the trainer's launch path run from the same weights on the same row permutations
-        # as the fp32 oracle.  A single run of either implementation is one draw from a heavy-tailed distribution (which ReLU decisions
-        # land on the other side of their kink); the two DISTRIBUTIONS must agree:
-        #     median(gpu) <= ENS_RATIO x median(oracle) + 2 TOL        max(gpu) <= ENS_RATIO x max(oracle) + 2 TOL
-        # (this replaces the round-4 bar `gpu <= 4 x max(oracle) + KINK_FLAT / B`, which one bad member of the yard-stick could carry).
-        # Where the yard-stick itself is BIMODAL (max > BIMODAL x its lower quartile: C1, whose distance is ~7e-3 or ~0.16 depending on ONE early-step
-        # unit -- tools/kink_odds.py: torch's own F.batch_norm path lands on the far side in 58 % of 48 row permutations on one x86 host
-        # and in 1 of 7 on another, profiles/r05_c1_kink_odds.txt) the median only says which mode has the majority on this host (C5's
-        # graph-replay step on one box: 5 of 13 oracle members and 8 of 13 GPU members at 1.7e-2, the others at 2e-3: medians 3.9e-3 / 1.6e-2
-        # from the SAME two modes); there the GPU must REACH the near mode (its best member inside ENS_RATIO x the oracle's lower
-        # quartile) and stay inside the far one (max).
+        # THE GPU HAS AN ENSEMBLE OF ITS OWN: the trainer's launch path run from the same weights on the same row permutations as the fp32
+        # oracle.  A single run of either implementation is one draw from a heavy-tailed distribution (which ReLU decisions land on the
+        # other side of their kink); the two DISTRIBUTIONS must agree (round 6: ENS_RATIO = 2 on the median AND the upper quartile, the
+        # largest member inside TAIL_RATIO x the oracle's largest).  Where the yard-stick itself is BIMODAL (max > BIMODAL x its lower
+        # quartile: C1, whose distance is ~7e-3 or ~0.16 depending on ONE early-step unit -- tools/kink_odds.py: torch's own F.batch_norm
+        # path lands on the far side in 58 % of 48 row permutations on one x86 host and in 1 of 7 on another) the quantiles only say which
+        # mode has the majority on this host; there the SHARES of the near mode are compared (see below).
         if gpu_ensemble:
             rel_gpu_all = [rel_gpu] + [_flat_distance(m, r64) for m in gpu_ensemble]
             med_g, med_o = float(np.median(rel_gpu_all)), float(np.median(rel_ens))
+            q75_g, q75_o = float(np.percentile(rel_gpu_all, 75)), float(np.percentile(rel_ens, 75))
             low_o = float(np.percentile(rel_ens, 25))          # the near mode's representative when the ensemble has two
             bimodal = max(rel_ens) > BIMODAL * low_o
+            one_event = 0.0 if DETERMINISTIC() else KINK_FLAT / B      # racing mode only: the footprint of ONE decision that varies run to run
+            near = NEAR * low_o + 2.0 * TOL + one_event
+            share_o = float(np.mean(np.array(rel_ens) <= near))
+            share_g = float(np.mean(np.array(rel_gpu_all) <= near))
             _report('%-18s %-14s flat gradient distance to float64, GPU on the same %d row permutations: %s | median gpu %.3e oracle %.3e | '
-                    'max gpu %.3e oracle %.3e | min gpu %.3e oracle %.3e | lower quartile oracle %.3e%s'
-                    % (name, tag, len(gpu_ensemble), ' '.join('%.2e' % v for v in rel_gpu_all[1:]), med_g, med_o, max(rel_gpu_all), max(rel_ens),
-                       min(rel_gpu_all), min(rel_ens), low_o, '  (oracle ensemble bimodal)' if bimodal else ''))
+                    'upper quartile gpu %.3e oracle %.3e | max gpu %.3e oracle %.3e | min gpu %.3e oracle %.3e | lower quartile oracle %.3e | '
+                    'share inside %.0f x that: gpu %.2f oracle %.2f%s'
+                    % (name, tag, len(gpu_ensemble), ' '.join('%.2e' % v for v in rel_gpu_all[1:]), med_g, med_o, q75_g, q75_o, max(rel_gpu_all),
+                       max(rel_ens), min(rel_gpu_all), min(rel_ens), low_o, NEAR, share_g, share_o, '  (oracle ensemble multi-modal)' if bimodal else ''))
             if bimodal:
-                # (+ the footprint of ONE kink event, KINK_FLAT / B: where the two modes are a single event apart -- realnvp_24 step 2 on
-                # one box: the oracle's five runs 2.0e-7, 2.8e-7, 1.80e-4, 1.80e-4, 1.89e-4, the GPU's five all 1.80e-4 .. 1.89e-4 -- five
-                # members on the far side are one chance in three at the oracle's own odds; C1's modes are 20 x further apart than
-                # its allowance, there the near mode must be reached)
-                if min(rel_gpu_all) > ENS_RATIO * low_o + 2.0 * TOL + KINK_FLAT / B:
-                    bad.append(('best flat gradient distance to float64 over the ensemble (bimodal yard-stick)', min(rel_gpu_all), low_o))
-            elif med_g > ENS_RATIO * med_o + 2.0 * TOL + KINK_FLAT / B:
-                # (the same single-event footprint: an oracle ensemble that happens to hold no event at all is not "bimodal", yet the
-                # GPU's majority may sit one event away -- the allowance is 4.7e-4 at B = 64 and 7e-6 at C2's batch, i.e. it only
-                # matters where the distances themselves are 1e-7 .. 1e-4)
-                bad.append(('median flat gradient distance to float64 over the ensemble', med_g, med_o))
-            # the LARGEST member: inside ENS_RATIO x the oracle's largest -- except that ONE member of a small ensemble may have met a kink
-            # none of the oracle's members met (realnvp_24 step 2 on one box: the GPU's runs 6.3e-5, 3.2e-7, 3.3e-7, 1.9e-7, 2.0e-7, the
-            # oracle's five 1.6e-7 .. 3.0e-7; in step 1 of the same run it was the ORACLE that had the one member at 6.7e-6): that one
-            # member gets the measured footprint of a single event, KINK_FLAT / B, the second largest gets nothing
-            strict = ENS_RATIO * max(rel_ens) + 2.0 * TOL
-            g_sorted = sorted(rel_gpu_all)
-            if g_sorted[-1] > strict + KINK_FLAT / B or (len(g_sorted) > 1 and g_sorted[-2] > strict):
-                bad.append(('largest flat gradient distance to float64 over the ensemble', g_sorted[-1], g_sorted[-2] if len(g_sorted) > 1 else None,
-                            max(rel_ens)))
+                # A FRACTION test (round 6; the round-5 rule -- the BEST GPU member reaches the near mode -- could not fail a path that is
+                # wrong most of the time): where the yard-stick has two modes the medians only say which mode holds the majority on this
+                # host, so the SHARES of the near mode are compared: the GPU must be in the oracle's near mode at least SHARE x as often
+                # as the oracle itself.  (tools/parity_modes.py, 64 permutations a side: profiles/r06_parity_modes_*.txt.)
+                if share_g < SHARE * share_o:
+                    bad.append(('share of the GPU ensemble inside %.0f x the oracle\'s lower quartile (bimodal yard-stick)' % NEAR, share_g, share_o))
+            else:
+                if med_g > ENS_RATIO * med_o + 2.0 * TOL + one_event:
+                    bad.append(('median flat gradient distance to float64 over the ensemble', med_g, med_o))
+                if q75_g > ENS_RATIO * q75_o + 2.0 * TOL + one_event:
+                    bad.append(('upper quartile of the flat gradient distance to float64 over the ensemble', q75_g, q75_o))
+            # THE TAIL is heavy (C1 at 64 permutations a side: the oracle's largest of 64 is 1.4e-1 .. 1.8, the GPU's 1.8e-1 .. 4.8e-1 over three states and
+            # three launch paths, profiles/r06_parity_modes_c1*.txt), the largest member of a small ensemble is one draw from it: at most a tenth
+            # of the GPU's members may lie beyond TAIL_RATIO x the oracle's LARGEST member
+            strict = TAIL_RATIO * max(rel_ens) + 2.0 * TOL + one_event
+            p90 = float(np.percentile(rel_gpu_all, 90))
+            if p90 > strict:
+                bad.append(('90th percentile of the GPU ensemble\'s flat gradient distance to float64', p90, max(rel_ens)))
         elif rel_gpu > 4.0 * max(rel_ens) + 2.0 * TOL + (0.0 if DETERMINISTIC() else KINK_FLAT / B):
             bad.append(('flat gradient distance to float64', rel_gpu, max(rel_ens)))
         pg = _step_profile(grads, r64, per_step)
@@ -310,9 +316,24 @@ def _snapshot(net):
     return {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
 
 
+@pytest.fixture(params=[False, True], ids=['racing', 'ordered'])
+def mode(request, pkg):
+    """both modes of the engine (round 6): `racing` is what bench.py times (float atomics meet in arrival order: the bars carry the
+    run-to-run allowances -- x 1.1 on the profile, the footprint of one decision KINK_FLAT / B); `ordered` is the deterministic mode
+    (csrc/nf_det.h: every batch sum in a fixed order), where a run reproduces itself and those allowances are OFF -- DETERMINISTIC() is
+    true for the whole test, so the driver's run exercises the bare bars as well."""
+    N = pkg._native
+    was = N.deterministic()
+    N.deterministic(bool(request.param))
+    yield bool(request.param)
+    N.deterministic(was)
+
+
 @pytest.mark.parametrize('cfg', CONFIGS, ids=[c[0] for c in CONFIGS])
-def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg):
+def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg, mode):
     name, kind, cls, dims, datatype, layers, mix, B, data = cfg
+    assert DETERMINISTIC() == mode
+    name = name + ('/ordered' if mode else '')
     nfdata = importlib.import_module(pkg.__name__ + '.data')
     nftrain = importlib.import_module(pkg.__name__ + '.train')
     torch.manual_seed(0)
@@ -328,7 +349,7 @@ def test_trainer_launch_paths_match_oracle_at_full_size(pkg, cfg):
     gaps = {}
 
     gp = torch.Generator().manual_seed(99)
-    perms = [torch.randperm(B, generator=gp) for _ in range(ENSEMBLE_BIG if name.endswith('_b512') else ENSEMBLE_SLOW if slow64 else ENSEMBLE)]
+    perms = [torch.randperm(B, generator=gp) for _ in range(ENSEMBLE_BIG if cfg[0].endswith('_b512') else ENSEMBLE_SLOW if slow64 else ENSEMBLE)]
 
     def gpu_members(sd, initialised):
         """the trainer's own launch path (eager launches of the same kernels the step just took) from the SAME weights on the row
