@@ -344,7 +344,7 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
     from oracle import models as om
     from oracle import transforms as tf
     # the flow step is thousands of tiny ops: torch's intra-op pool stops scaling (and then collapses) beyond a few threads.
-    # Measured once per round on the GPU box's 256 host cores (tools/cpu_threads.py, profiles/r05_cpu_threads.txt): C4 1297 / 1239 /
+    # Measured once per round on the GPU box's 256 host cores (tools/cpu_threads.py, profiles/r06_cpu_threads.txt): C4 1297 / 1239 /
     # 2703 / 7002 ms per step at 8 / 16 / 32 / 64 threads, C1 32 / 47 / 55 / 60 / 128 ms at 1 / 4 / 8 / 16 / 32 -- the baseline runs
     # at the FASTEST setting of its config (C4: 16, C1: 1; the others 8, what the reference was probed with in BASELINE.md);
     # `cores` reports what ran
@@ -389,7 +389,7 @@ def cpu_baseline(cfg, state, y_cpu, seconds):
     return ({'value': round(B * n / el, 1), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
              'sample': '%d train steps of the same workload (batch %d, same initial weights) in %.1f s on %s' % (n, B, el, model),
              'ms_per_step': round(1e3 * el / n, 2), 'host_cores': os.cpu_count(),
-             'threads_note': 'fastest of the per-round thread sweep for this config (profiles/r05_cpu_threads.txt)'}, first)
+             'threads_note': 'fastest of the per-round thread sweep for this config (profiles/r06_cpu_threads.txt)'}, first)
 
 
 def resolve_batch(cfg, scaling, batch_override, world):

@@ -248,6 +248,10 @@ int nf_squeeze1d(const float* in, float* out, int64_t B, int D, int odd, int inv
 int nf_mixlog_coupling_fwd(const float* z, const float* params, const float* a_log_scale, const float* a_bias,
                            float* y, float* ld, int K, float logit_eps, int mode, int odd, int64_t B, int C, int H,
                            int W, nf_stream_t stream);
+/* Density data (two features, K <= 8): batches of at least `min_rows` rows take the one-row-per-thread kernels of the three
+ * calls around this comment (shared transcendentals, staged 16-byte traffic: the bandwidth form), smaller ones the
+ * one-component-per-lane kernels (the latency form).  Default 262 144 rows; min_rows < 0 restores it; returns 0.               */
+int nf_mixlog_rows_config(int64_t min_rows);
 int nf_mixlog_coupling_inv(const float* z, const float* params, const float* a_log_scale, const float* a_bias,
                            float* y, float* ld, float* scratch, int* stuck_flag, int K, int mode, int odd, int64_t B,
                            int C, int H, int W, nf_stream_t stream);

@@ -140,6 +140,132 @@ __device__ __forceinline__ float nf_mixlog_bwd_elem(const NfMix<KT>& m, float* _
     return gx;
 }
 
+// ---- the shared-transcendental form of one element (round 6; the comment in front of the row kernels below says why) ----------------
+#define NF_MR_TINY 1.0e-30f
+// the row's parameters and everything of them that does not depend on x
+template <int KT>
+struct NfMixLin {
+    float a_raw, b, inv_se;
+    float w[KT], mu[KT], es[KT];       // exp(lp - max lp) (0 beyond K), mu, exp(-s)
+};
+template <int KT>
+__device__ __forceinline__ void nf_mr_load(const float* __restrict__ row, int64_t nh, int K, NfMixLin<KT>& m, float (&lp)[KT], float (&sv)[KT]) {
+    m.a_raw = row[0];
+    m.b = row[nh];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        lp[k] = k < K ? row[(2 + k) * nh] : -INFINITY;
+        m.mu[k] = k < K ? row[(2 + K + k) * nh] : 0.f;
+        sv[k] = k < K ? row[(2 + 2 * K + k) * nh] : 0.f;
+        mx = fmaxf(mx, lp[k]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        m.w[k] = nf_fexp(lp[k] - mx);
+        m.es[k] = nf_fexp(-sv[k]);
+        se += m.w[k];
+    }
+    m.inv_se = __builtin_amdgcn_rcpf(se);
+}
+// Fs = sum w sigma, fs = sum w es sigma (1 - sigma) (both still to be divided by sum w); t, r of every component kept for the backward
+template <int KT>
+__device__ __forceinline__ void nf_mr_eval(const NfMixLin<KT>& m, float x, float& Fs, float& fs, float (&u)[KT], float (&t)[KT], float (&r)[KT]) {
+    Fs = 0.f; fs = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        u[k] = (x - m.mu[k]) * m.es[k];
+        t[k] = nf_fexp(-fabsf(u[k]));
+        r[k] = __builtin_amdgcn_rcpf(1.f + t[k]);
+        const float sig = (u[k] >= 0.f ? 1.f : t[k]) * r[k];
+        Fs = fmaf(m.w[k], sig, Fs);
+        fs = fmaf(m.w[k] * m.es[k], t[k] * r[k] * r[k], fs);
+    }
+}
+// the log-space record of the same row for the rare rows whose linear-space density underflows
+template <int KT>
+__device__ __forceinline__ void nf_mr_logspace(const NfMixLin<KT>& m, const float (&lp)[KT], const float (&sv)[KT], NfMix<KT>& q) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) mx = fmaxf(mx, lp[k]);
+    const float lse = mx - nf_flog(m.inv_se);
+    q.a_raw = m.a_raw; q.b = m.b;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { q.lp[k] = lp[k] - lse; q.mu[k] = m.mu[k]; q.s[k] = sv[k]; q.es[k] = m.es[k]; }
+}
+
+
+// one transformed element, forward and backward, in the shared-transcendental form (parameters at stride nh / gradients at stride gnh)
+template <int KT>
+__device__ __forceinline__ float nf_mr_fwd_elem(const float* __restrict__ P, int64_t nh, int K, float x, float A, float Cb, float eps, float& acc) {
+    NfMixLin<KT> m;
+    float lp[KT], sv[KT], u[KT], t[KT], r[KT], Fs, fs;
+    nf_mr_load<KT>(P, nh, K, m, lp, sv);
+    nf_mr_eval<KT>(m, x, Fs, fs, u, t, r);
+    float F = Fs * m.inv_se, lpdf;
+    if (fs > NF_MR_TINY) {
+        lpdf = nf_flog(fs * m.inv_se);
+    } else {
+        NfMix<KT> q;
+        nf_mr_logspace<KT>(m, lp, sv, q);
+        float lcdf;
+        nf_mix_eval<KT>(q, x, lcdf, lpdf);
+        F = nf_fexp(lcdf);
+    }
+    const float xc = fminf(fmaxf(F, eps), 1.f - eps);                  // modules.py:147
+    const float la = nf_flog(xc), lb = nf_flog(1.f - xc);
+    const float a = nf_ftanh(m.a_raw) * A + Cb;                        // coupling.py:178
+    acc += lpdf - (la + lb) + a;                                       // coupling.py:184-188
+    return (la - lb) * nf_fexp(a) + m.b;                               // coupling.py:187
+}
+template <int KT>
+__device__ __forceinline__ float nf_mr_bwd_elem(const float* P, int64_t nh, float* GP, int64_t gnh,   /* (P may BE GP: every parameter is loaded before the first store) */ int K, float x, float g_y,
+                                                float g_ld, float A, float Cb, float eps, float& acc_A, float& acc_C) {
+    NfMixLin<KT> m;
+    float lp[KT], sv[KT], u[KT], t[KT], r[KT], Fs, fs;
+    nf_mr_load<KT>(P, nh, K, m, lp, sv);
+    nf_mr_eval<KT>(m, x, Fs, fs, u, t, r);
+    if (!(fs > NF_MR_TINY)) {
+        NfMix<KT> q;
+        nf_mr_logspace<KT>(m, lp, sv, q);
+        return nf_mixlog_bwd_elem<KT>(q, GP, gnh, K, x, g_y, g_ld, A, Cb, eps, acc_A, acc_C);
+    }
+    const float F = Fs * m.inv_se, f = fs * m.inv_se;
+    const bool inside = (F >= eps) && (F <= 1.f - eps);                 // torch.clamp passes the gradient on [min, max]
+    const float xc = fminf(fmaxf(F, eps), 1.f - eps);
+    const float y1 = nf_flog(xc) - nf_flog(1.f - xc);
+    const float th = nf_ftanh(m.a_raw);
+    const float ea = nf_fexp(th * A + Cb);
+    const float g_y1 = g_y * ea;                                        // y = y1 * exp(a) + b ; ld += a
+    const float g_a = g_y * y1 * ea + g_ld;
+    const float gF = inside ? (g_y1 - g_ld * (1.f - 2.f * xc)) * __builtin_amdgcn_rcpf(xc * (1.f - xc)) : 0.f;
+    const float tot = gF * F + g_ld;                                    // sum_j g_logpi_j
+    const float inv_fs = __builtin_amdgcn_rcpf(fs);
+    const float gFf = gF * f;
+    float gx = gFf;
+    GP[0] = g_a * A * (1.f - th * th);
+    GP[gnh] = g_y;
+    acc_A += g_a * th;
+    acc_C += g_a;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+        if (k < K) {
+            const float wes = m.w[k] * m.es[k];
+            const float rk = wes * t[k] * r[k] * r[k] * inv_fs;                       // responsibility pi_k pdf_k / f
+            const float omt = copysignf((1.f - t[k]) * r[k], -u[k]);                  // 1 - 2 sigmoid(u)
+            const float wk = g_ld * rk * omt * m.es[k];
+            gx += wk;
+            const float pik = m.w[k] * m.inv_se;
+            const float sig = (u[k] >= 0.f ? 1.f : t[k]) * r[k];
+            GP[(2 + K + k) * gnh] = -gFf * rk - wk;                                           // g_mu_k
+            GP[(2 + 2 * K + k) * gnh] = -gFf * rk * (x - m.mu[k]) + g_ld * rk * (-omt * u[k] - 1.f);   // g_s_k
+            GP[(2 + k) * gnh] = gF * pik * sig + g_ld * rk - pik * tot;                       // g_logit_k through log_softmax
+        }
+    return gx;
+}
+
+
 // ---- LDS staging of parameter rows (2-D data: nh == 1) ----------------------------------------------------------
 __device__ __forceinline__ void nf_stage_rows_in(const float* __restrict__ g, float* __restrict__ tile, int64_t row0,
                                                  int64_t B, int PS) {
@@ -210,10 +336,8 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_slab_fwd(const float* __res
     float* yb = y + b * s.n_full;
     float acc = 0.f;
     for (int e = e0 + threadIdx.x; e < e1; e += NF_BLOCK) {
-        NfMix<KT> m;
-        nf_mix_load<KT>(prm + b * PS + e, s.n_half, K, m);
         const int o0 = nf_half_to_full(s, 0, e), o1 = nf_half_to_full(s, 1, e);
-        yb[o0] = nf_mixlog_fwd_elem<KT>(m, zb[o0], A, Cb, eps, acc);
+        yb[o0] = nf_mr_fwd_elem<KT>(prm + b * PS + e, s.n_half, K, zb[o0], A, Cb, eps, acc);
         yb[o1] = zb[o1];
     }
     const float tot = nf_block_sum(acc, scratch);
@@ -244,13 +368,11 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_bwd(const float* __restrict
             const int64_t b = t / s.n_half;
             const int e = (int)(t - b * s.n_half);
             const int64_t fb = b * s.n_full;
-            NfMix<KT> m;
             float* rowp = tile + threadIdx.x * (PS1 + 1);
-            nf_mix_load<KT>(staged ? rowp : prm + b * PS + e, s.n_half, K, m);
             const int o0 = nf_half_to_full(s, 0, e), o1 = nf_half_to_full(s, 1, e);
-            // the gradient row overwrites this thread's own (already consumed) parameter row in the tile
-            gz[fb + o0] = nf_mixlog_bwd_elem<KT>(m, staged ? rowp : gprm + b * PS + e, s.n_half, K, z[fb + o0], gy[fb + o0],
-                                                 gld[b], A, Cb, eps, acc_A, acc_C);
+            // the gradient row overwrites this thread's own parameter row in the tile (every parameter is in registers before the first store)
+            gz[fb + o0] = nf_mr_bwd_elem<KT>(staged ? rowp : prm + b * PS + e, s.n_half, staged ? rowp : gprm + b * PS + e, s.n_half, K,
+                                              z[fb + o0], gy[fb + o0], gld[b], A, Cb, eps, acc_A, acc_C);
             gz[fb + o1] = gy[fb + o1];
         }
         if (staged) nf_stage_rows_out(gprm, tile, t0, total, PS1);
@@ -634,6 +756,197 @@ __global__ void __launch_bounds__(NF_OCT_BWD_THREADS) k_mixlog_oct_bwd(const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LARGE BATCHES of density data (two features, K <= 8): ONE ROW PER THREAD, shared transcendentals (round 6).
+// The octet kernels above are latency designs for the reference's batch (65 536 rows: one element per eight lanes shortens the chain);
+// every lane of an octet repeats the element's scalar work, and the log-space form spends ~15 transcendentals per LANE (120 per row):
+// at 2 M rows they ran at 10 % of the transcendental rate and 28 / 18 / 8 % of HBM (profiles/r05_kernel_sweep.txt).  With enough rows for
+// >= 4 waves per SIMD of one row per thread the chain length does not matter and the work per row does:
+//   * per component only   w_k = exp(lp_k - max lp)   es_k = exp(-s_k)   t_k = exp(-|u_k|)   r_k = 1 / (1 + t_k)   are transcendental;
+//     sigma(u_k) = (u_k >= 0 ? 1 : t_k) r_k,  sigma (1 - sigma) = t_k r_k^2,  so
+//         F = sum_k w_k sigma_k / sum_k w_k          f = sum_k w_k es_k t_k r_k^2 / sum_k w_k
+//     and every gradient term of the backward is a product of these (4 K + 8 transcendental-rate instructions per row, not ~25 K);
+//   * F is what the reference forms anyway (modules.py:194: exp(log cdf)); log f is needed to full RELATIVE accuracy where f underflows --
+//     a row whose linear-space f falls below NF_MR_TINY takes the log-space path of the element kernels (nf_mix_eval / nf_mixlog_bwd_elem);
+//   * a workgroup's 256 parameter rows are staged through LDS with 16-byte coalesced loads (row stride 2 + 3 K + 1 words: conflict-free
+//     per-thread reads), the backward writes its 2 + 3 K gradients over its own row and the tile leaves with 16-byte stores.
+#define NF_MR_ROWS 256
+#define NF_MR_MIN_ROWS (int64_t)(4 * 256 * 256)       // >= 4 waves per SIMD of one row per thread; below: the octet kernels
+
+// flat element e of a tile of rows (PS1 words each) -> LDS word e + e / PS1 (one pad word per row); magic = ceil(2^20 / PS1): exact for
+// e < 2^13 and PS1 <= 26 (the quotient's error e / 2^20 < 1 / PS1), and e * magic < 2^31
+__device__ __forceinline__ int nf_mr_lds_index(int e, int magic) { return e + (int)(((unsigned)e * (unsigned)magic) >> 20); }
+
+// rows [row0, row0 + NF_MR_ROWS) of a (B, PS1) tensor <-> the LDS tile; 16-byte global accesses when the tile is whole and aligned
+template <bool OUT>
+__device__ __forceinline__ void nf_mr_stage(float* __restrict__ g, float* __restrict__ tile, int64_t row0, int64_t B, int PS1, int magic) {
+    const int rows = (int)min((int64_t)NF_MR_ROWS, B - row0);
+    const int total = rows * PS1;
+    float* src = g + row0 * PS1;
+    const bool vec = (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    if (vec) {
+        for (int q = threadIdx.x; q < (total >> 2); q += NF_MR_ROWS) {
+            const int e = 4 * q;
+            if (!OUT) {
+                const float4 v = reinterpret_cast<const float4*>(src)[q];
+                tile[nf_mr_lds_index(e, magic)] = v.x; tile[nf_mr_lds_index(e + 1, magic)] = v.y;
+                tile[nf_mr_lds_index(e + 2, magic)] = v.z; tile[nf_mr_lds_index(e + 3, magic)] = v.w;
+            } else {
+                float4 v;
+                v.x = tile[nf_mr_lds_index(e, magic)]; v.y = tile[nf_mr_lds_index(e + 1, magic)];
+                v.z = tile[nf_mr_lds_index(e + 2, magic)]; v.w = tile[nf_mr_lds_index(e + 3, magic)];
+                reinterpret_cast<float4*>(src)[q] = v;
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += NF_MR_ROWS) {
+            if (!OUT) tile[nf_mr_lds_index(e, magic)] = src[e];
+            else src[e] = tile[nf_mr_lds_index(e, magic)];
+        }
+    }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(NF_MR_ROWS) k_mixlog_row_fwd(const float* __restrict__ z, const float* __restrict__ prm, const float* __restrict__ pA,
+                                                               const float* __restrict__ pC, float* __restrict__ y, float* __restrict__ ld, int odd,
+                                                               int K, int magic, float eps, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const float A = pA[0], Cb = pC[0];
+    const int PS1 = 2 + 3 * K;
+    for (int64_t row0 = (int64_t)blockIdx.x * NF_MR_ROWS; row0 < B; row0 += (int64_t)gridDim.x * NF_MR_ROWS) {
+        nf_mr_stage<false>(const_cast<float*>(prm), tile, row0, B, PS1, magic);
+        __syncthreads();
+        const int64_t b = row0 + threadIdx.x;
+        if (b < B) {
+            const float2 zz = reinterpret_cast<const float2*>(z)[b];
+            const float x = odd ? zz.y : zz.x, pass = odd ? zz.x : zz.y;      // squeeze1d: the transformed feature is feature `odd`
+            float acc = 0.f;
+            const float yt = nf_mr_fwd_elem<KT>(tile + threadIdx.x * (PS1 + 1), 1, K, x, A, Cb, eps, acc);
+            reinterpret_cast<float2*>(y)[b] = odd ? make_float2(pass, yt) : make_float2(yt, pass);
+            ld[b] += acc;
+        }
+        __syncthreads();
+    }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(NF_MR_ROWS) k_mixlog_row_bwd(const float* __restrict__ gy, const float* __restrict__ gld, const float* __restrict__ z,
+                                                               const float* __restrict__ prm, const float* __restrict__ pA, const float* __restrict__ pC,
+                                                               float* __restrict__ gz, float* __restrict__ gprm, float* __restrict__ g_scale,
+                                                               float* __restrict__ g_bias, int odd, int K, int magic, float eps, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    __shared__ float scratch[NF_MR_ROWS / NF_WAVE];
+    const float A = pA[0], Cb = pC[0];
+    const int PS1 = 2 + 3 * K;
+    float acc_A = 0.f, acc_C = 0.f;
+    for (int64_t row0 = (int64_t)blockIdx.x * NF_MR_ROWS; row0 < B; row0 += (int64_t)gridDim.x * NF_MR_ROWS) {
+        nf_mr_stage<false>(const_cast<float*>(prm), tile, row0, B, PS1, magic);
+        __syncthreads();
+        const int64_t b = row0 + threadIdx.x;
+        if (b < B) {
+            float* GP = tile + threadIdx.x * (PS1 + 1);                        // the gradient row overwrites this thread's own parameter row
+            const float2 zz = reinterpret_cast<const float2*>(z)[b], gg = reinterpret_cast<const float2*>(gy)[b];
+            const float x = odd ? zz.y : zz.x, g_y = odd ? gg.y : gg.x, g_pass = odd ? gg.x : gg.y;
+            const float gx = nf_mr_bwd_elem<KT>(GP, 1, GP, 1, K, x, g_y, gld[b], A, Cb, eps, acc_A, acc_C);
+            reinterpret_cast<float2*>(gz)[b] = odd ? make_float2(g_pass, gx) : make_float2(gx, g_pass);
+        }
+        __syncthreads();
+        nf_mr_stage<true>(gprm, tile, row0, B, PS1, magic);
+        __syncthreads();
+    }
+    const float ta = nf_block_sum(acc_A, scratch);
+    const float tc = nf_block_sum(acc_C, scratch);
+    if (threadIdx.x == 0) {
+        NF_DET_ENTER(nf_ml);
+        atomicAdd(g_scale, ta);
+        atomicAdd(g_bias, tc);
+        NF_DET_LEAVE(nf_ml);
+    }
+}
+
+// inverse: phase 1 = affine^-1, sigmoid, 25 bisection steps, x = mid, ld += the affine / sigmoid terms - log pdf(x), brackets saved and the
+// flag raised while some bracket is still >= 1e-4; phase 2 (returns at once unless the flag is set) takes them 75 steps further
+template <int KT, int PHASE>
+__global__ void __launch_bounds__(NF_MR_ROWS) k_mixlog_row_inv(const float* __restrict__ yin, const float* __restrict__ prm, const float* __restrict__ pA,
+                                                               const float* __restrict__ pC, float* __restrict__ y, float* __restrict__ ld,
+                                                               float* __restrict__ lohi, int* __restrict__ flag, int odd, int K, int magic, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    if (PHASE == 2 && flag[0] == 0) return;
+    const float A = pA[0], Cb = pC[0];
+    const int PS1 = 2 + 3 * K;
+    bool stuck = false;
+    for (int64_t row0 = (int64_t)blockIdx.x * NF_MR_ROWS; row0 < B; row0 += (int64_t)gridDim.x * NF_MR_ROWS) {
+        nf_mr_stage<false>(const_cast<float*>(prm), tile, row0, B, PS1, magic);
+        __syncthreads();
+        const int64_t b = row0 + threadIdx.x;
+        if (b < B) {
+            NfMixLin<KT> m;
+            float lp[KT], sv[KT];
+            nf_mr_load<KT>(tile + threadIdx.x * (PS1 + 1), 1, K, m, lp, sv);
+            float pi[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) pi[k] = m.w[k] * m.inv_se;
+            NfMix<KT> q;
+            nf_mr_logspace<KT>(m, lp, sv, q);
+            const float2 zz = reinterpret_cast<const float2*>(yin)[b];
+            float lo, hi, target, acc = 0.f, lpdf_old = 0.f;
+            if (PHASE == 1) {
+                const float a = tanhf(m.a_raw) * A + Cb;
+                const float v = expf(-a) * ((odd ? zz.y : zz.x) - m.b);        // coupling.py:204
+                target = 1.f / (1.f + expf(-v));                               // modules.py:155
+                acc = -a + (v - 2.f * nf_softplus(v));                         // coupling.py:205, modules.py:153
+                lo = -1.0e3f;                                                  // modules.py:197-198
+                hi = 1.0e3f;
+            } else {
+                lo = lohi[b]; hi = lohi[B + b]; target = lohi[2 * B + b];
+                float lcdf;
+                nf_mix_eval<KT>(q, (lo + hi) * 0.5f, lcdf, lpdf_old);          // what phase 1 subtracted
+            }
+            for (int it = 0; it < (PHASE == 1 ? 25 : 75); ++it) {
+                const float mid = (lo + hi) * 0.5f;
+                const float val = nf_mix_cdf<KT>(q, pi, mid);
+                if (PHASE == 2 && (mid == lo || mid == hi || val == target)) break;   // collapsed: the rest are no-ops
+                lo = val < target ? mid : lo;                                  // modules.py:202-203
+                hi = val > target ? mid : hi;
+            }
+            const float x = (lo + hi) * 0.5f;                                  // modules.py:208
+            float lcdf, lpdf;
+            nf_mix_eval<KT>(q, x, lcdf, lpdf);
+            acc += PHASE == 1 ? -lpdf : lpdf_old - lpdf;                       // modules.py:209-212
+            if (PHASE == 1) {
+                stuck |= !(fabsf(hi - lo) < 1.0e-4f);                          // modules.py:205
+                lohi[b] = lo; lohi[B + b] = hi; lohi[2 * B + b] = target;
+            }
+            const float pass = odd ? zz.x : zz.y;
+            if (PHASE == 1) reinterpret_cast<float2*>(y)[b] = odd ? make_float2(pass, x) : make_float2(x, pass);
+            else y[2 * b + (odd ? 1 : 0)] = x;
+            ld[b] += acc;
+        }
+        __syncthreads();
+    }
+    if (PHASE == 1 && __any(stuck) && (threadIdx.x & (NF_WAVE - 1)) == 0) atomicOr(flag, 1);
+}
+
+// the row kernels take a launch: two features, K <= 8, enough rows to fill the machine with one row per thread
+static int nf_mr_min_rows = -1;                          // (tests lower it through nf_mixlog_rows_config to run the row kernels on small batches)
+extern "C" int nf_mixlog_rows_config(int64_t min_rows) {
+    nf_mr_min_rows = min_rows < 0 ? -1 : (int)(min_rows > 0x7fffffff ? 0x7fffffff : min_rows);
+    return 0;
+}
+static inline bool nf_mr_takes(const NfSplit& s, int K, int64_t B) {
+    const int64_t lim = nf_mr_min_rows >= 0 ? (int64_t)nf_mr_min_rows : NF_MR_MIN_ROWS;
+    return s.n_half == 1 && s.n_full == 2 && K >= 1 && K <= 8 && B >= lim;
+}
+static inline int nf_mr_magic(int K) { return ((1 << 20) + (2 + 3 * K) - 1) / (2 + 3 * K); }
+static inline size_t nf_mr_lds(int K) { return (size_t)NF_MR_ROWS * (2 + 3 * K + 1) * sizeof(float); }
+static inline unsigned nf_mr_grid(int64_t B, int64_t cap = 8192) {
+    const int64_t g = (B + NF_MR_ROWS - 1) / NF_MR_ROWS;
+    return (unsigned)(g > cap ? cap : g);
+}
+// the backward ends in two same-address float atomics per workgroup (coupling scale / shift), which the L2 retires one after the other:
+// 8 192 workgroups would queue for ~100 us there; 1 024 persistent ones (four per compute unit) keep the tail at ~10 us
+#define NF_MR_BWD_GRID 1024
+
 static inline int nf_mx_threads(int K) { return (2 + 3 * K) <= 50 ? 256 : 128; }        // rows tile <= 52 KB of LDS
 static inline size_t nf_mx_lds(const NfSplit& s, int K, int threads) {
     return s.n_half == 1 ? (size_t)threads * (2 + 3 * K + 1) * sizeof(float) : 0;
@@ -653,7 +966,13 @@ extern "C" int nf_mixlog_coupling_fwd(const float* z, const float* params, const
     if (!nf_mixlog_args(s, mode, odd, C, H, W, K)) return NF_E_BADARG;
     if (B == 0 || s.n_half == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane (see k_mixlog_oct_fwd)
+    if (nf_mr_takes(s, K, B)) {                            // large density batches: one row per thread, shared transcendentals
+        const int od = s.odd;
+        if (K <= 4) hipLaunchKernelGGL(k_mixlog_row_fwd<4>, dim3(nf_mr_grid(B)), dim3(NF_MR_ROWS), nf_mr_lds(K), st, z, params, a_log_scale, a_bias, y, ld,
+                                       od, K, nf_mr_magic(K), logit_eps, B);
+        else hipLaunchKernelGGL(k_mixlog_row_fwd<8>, dim3(nf_mr_grid(B)), dim3(NF_MR_ROWS), nf_mr_lds(K), st, z, params, a_log_scale, a_bias, y, ld, od, K,
+                                nf_mr_magic(K), logit_eps, B);
+    } else if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {     // one component per lane (see k_mixlog_oct_fwd)
         unsigned g = nf_grid_for(B * 8, NF_BLOCK);
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(k_mixlog_oct_fwd<false>, dim3(g), dim3(NF_BLOCK), 0, st, z, params, a_log_scale, a_bias, nullptr, nullptr, y, ld, s, K,
@@ -694,6 +1013,15 @@ static int nf_mixlog_bwd_launch(const float* g_y, const float* g_ld, const float
     const int64_t total = B * s.n_half;
     if (total == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (partials == nullptr && nf_mr_takes(s, K, B)) {     // large density batches: one row per thread
+        const int od = s.odd;
+        if (K <= 4) hipLaunchKernelGGL(k_mixlog_row_bwd<4>, dim3(nf_mr_grid(B, NF_MR_BWD_GRID)), dim3(NF_MR_ROWS), nf_mr_lds(K), st, g_y, g_ld, z, params, a_log_scale,
+                                       a_bias, g_z, g_params, g_scale, g_bias, od, K, nf_mr_magic(K), logit_eps, B);
+        else hipLaunchKernelGGL(k_mixlog_row_bwd<8>, dim3(nf_mr_grid(B, NF_MR_BWD_GRID)), dim3(NF_MR_ROWS), nf_mr_lds(K), st, g_y, g_ld, z, params, a_log_scale, a_bias,
+                                g_z, g_params, g_scale, g_bias, od, K, nf_mr_magic(K), logit_eps, B);
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane
         if (partials != nullptr) return NF_E_UNSUPPORTED;
         unsigned g2 = nf_grid_for(B * 8, NF_OCT_BWD_THREADS);
@@ -742,6 +1070,23 @@ extern "C" int nf_mixlog_coupling_inv(const float* z, const float* params, const
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(stuck_flag, 0, sizeof(int), st);
     if (e != hipSuccess) return (int)e;
+    if (nf_mr_takes(s, K, B)) {                            // large density batches: one row per thread
+        const int od = s.odd;
+        const dim3 gr(nf_mr_grid(B));
+        if (K <= 4) {
+            hipLaunchKernelGGL((k_mixlog_row_inv<4, 1>), gr, dim3(NF_MR_ROWS), nf_mr_lds(K), st, z, params, a_log_scale, a_bias, y, ld, scratch, stuck_flag,
+                               od, K, nf_mr_magic(K), B);
+            hipLaunchKernelGGL((k_mixlog_row_inv<4, 2>), gr, dim3(NF_MR_ROWS), nf_mr_lds(K), st, z, params, a_log_scale, a_bias, y, ld, scratch, stuck_flag,
+                               od, K, nf_mr_magic(K), B);
+        } else {
+            hipLaunchKernelGGL((k_mixlog_row_inv<8, 1>), gr, dim3(NF_MR_ROWS), nf_mr_lds(K), st, z, params, a_log_scale, a_bias, y, ld, scratch, stuck_flag,
+                               od, K, nf_mr_magic(K), B);
+            hipLaunchKernelGGL((k_mixlog_row_inv<8, 2>), gr, dim3(NF_MR_ROWS), nf_mr_lds(K), st, z, params, a_log_scale, a_bias, y, ld, scratch, stuck_flag,
+                               od, K, nf_mr_magic(K), B);
+        }
+        NF_CHECK_LAUNCH();
+        return 0;
+    }
     if (s.n_half <= NF_MX_ROWS_MAX && K <= 8) {            // one component per lane (see k_mixlog_oct_inv)
         unsigned go = nf_grid_for(B * 8, NF_BLOCK);
         if (go > 2048) go = 2048;

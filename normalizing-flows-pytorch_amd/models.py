@@ -143,9 +143,15 @@ class _FlowModel(nn.Module):
                 m._W_eff = None
 
     def forward(self, z):
+        if z.is_cuda and z.device.index != torch.cuda.current_device():
+            with torch.cuda.device(z.device):      # (a model on another GPU than the current one: launch on ITS device, as torch's own ops do)
+                return self._with_weight_norms(self.net, z)
         return self._with_weight_norms(self.net, z)
 
     def backward(self, z):
+        if z.is_cuda and z.device.index != torch.cuda.current_device():
+            with torch.cuda.device(z.device):
+                return self._with_weight_norms(self.net.backward, z)
         return self._with_weight_norms(self.net.backward, z)
 
 

@@ -101,6 +101,8 @@ class FlowTrainer:
     ``warmup`` eager steps that also perform the data-dependent ActNorm initialisation.  The batch shape is then fixed.
     The call that captures also takes one extra eager step on its batch (allocator warm-up on the capture stream)."""
 
+    TRAIN_MODE_RECHECK = 256        # calls of train_on_batch between two walks over the submodules' training flags
+
     def __init__(self, net, lr=1.0e-4, betas=(0.9, 0.999), weight_decay=0.0, graph=False, warmup=3, process_group=None,
                  fused_adam=True, sampler=None, sync_stats=False, graph_factory=None, one_graph=None):
         self.net = net
@@ -136,6 +138,8 @@ class FlowTrainer:
         # parameter) are replaced by one gather launch per 128 tensors
         self._gather = on_gpu
         self._indirect = None
+        self._calls_since_mode_walk = self.TRAIN_MODE_RECHECK          # the first call walks the tree
+        self._captured_det = None
 
     # -- one step, eager --------------------------------------------------------------------------------------------
     def _forward_backward(self, y):
@@ -257,6 +261,8 @@ class FlowTrainer:
             g_opt.capture(self.optim.step)
         self._g_fb, self._g_opt = g_fb, g_opt
         self._g_whole = whole
+        from . import _native as N_
+        self._captured_det = N_.deterministic()
 
     def train_on_batch(self, y=None):
         """returns (z, loss) like main.py:78-92; with graph=True the returned tensors are the graph's static outputs.
@@ -265,10 +271,27 @@ class FlowTrainer:
         from . import _native as N
         if y is None and self.sampler is None:
             raise ValueError('train_on_batch() without a batch needs FlowTrainer(..., sampler=data.DeviceSampler(...))')
+        if y is not None and y.is_cuda and y.device.index != torch.cuda.current_device():
+            # a model / batch on another GPU than the current one (net.to('cuda:1') without torch.cuda.set_device works in the reference):
+            # the launches must go to THAT device's stream and read its copy of the library's globals
+            with torch.cuda.device(y.device):
+                return self.train_on_batch(y)
         if y is None or y.is_cuda:
             N.check_persistent()
-        if not self.net.training:                       # (Module.train() walks every submodule: 1.24 ms of host time per call on C1's
-            self.net.train()                            #  ~1 000 modules -- more than the 1.05 ms the whole step takes on the device)
+        # Module.train() walks every submodule: 1.24 ms of host time per call on C1's ~1 000 modules -- more than the 1.05 ms the whole
+        # step takes on the device.  The root's flag answers for the tree on most calls; a CHILD put into eval() on its own (the root stays
+        # in training mode) is found by a walk on the first call and every TRAIN_MODE_RECHECK calls after it
+        self._calls_since_mode_walk += 1
+        if not self.net.training or self._calls_since_mode_walk >= self.TRAIN_MODE_RECHECK:
+            if not self.net.training or any(not m_.training for m_ in self.net.modules()):
+                if self._g_fb is not None:
+                    raise RuntimeError('FlowTrainer: a submodule was switched to eval() after the step was captured in a hipGraph (the graph '
+                                       'replays training-mode launches); build a new FlowTrainer')
+                self.net.train()
+            self._calls_since_mode_walk = 0
+        if self._g_fb is not None and self._captured_det != N.deterministic():
+            raise RuntimeError('FlowTrainer: _native.deterministic() was switched after the step was captured in a hipGraph -- the graph holds '
+                               'the launch shapes of the mode it was captured in; build a new FlowTrainer')
         if self.graph and self._g_fb is None and self._eager_steps >= self.warmup:
             try:
                 self._capture(y)

@@ -319,6 +319,56 @@ def test_mixlog_coupling_golden(nf, tag, mode, odd):
     G.assert_close(ldi, want_ld.float(), _scaled(want_ld) + 1.0e-6 * n_per, what='log-det of the inverse at its own x (float64 restatement)')
 
 
+@pytest.mark.parametrize('B,K', [(999, 8), (1024, 3), (2051, 8), (517, 1), (4096, 5)])
+def test_mixlog_row_kernels_match_oracle_and_the_octet_kernels(nf, B, K):
+    """the large-batch kernels of the 2-D mixture coupling (csrc/mixlog.hip, round 6: one row per thread, linear-space sums with shared
+    transcendentals, LDS-staged 16-byte traffic; they serve batches >= 262 144 rows) forced onto small RAGGED batches by
+    nf_mixlog_rows_config(0): forward, backward and inverse against the float64 oracle with the fp32 oracle's own distance as slack, and against
+    the one-component-per-lane kernels on the same inputs.  Rows far in the tails (|x - mu| / scale ~ 100: the linear-space density underflows)
+    take the kernels' log-space path and must come out as finite and as close."""
+    NF = nf.functional
+    lib = nf._native.load()
+    g = torch.Generator().manual_seed(100 + B + K)
+    z = torch.randn(B, 2, generator=g)
+    z[::37] *= 40.0                                        # far tails on both sides
+    params = torch.randn(B, 2 + 3 * K, generator=g) * 0.7
+    sections = [1] * 2 + [K] * 3
+    a, c = torch.tensor([0.5]), torch.tensor([0.05])
+    ld0 = torch.randn(B, generator=g)
+    gy, gld = torch.randn(z.shape, generator=g), torch.randn(B, generator=g)
+    for odd in (False, True):
+        l64 = [t.double().clone().requires_grad_(True) for t in (z, params, a, c)]
+        y64, ld64 = tf.mixlog_coupling(l64[0], ld0.double(), l64[1], sections, K, l64[2], l64[3], 0, odd)
+        want64 = torch.autograd.grad([y64, ld64], l64, [gy.double(), gld.double()])
+        l32 = [t.clone().requires_grad_(True) for t in (z, params, a, c)]
+        y32, ld32 = tf.mixlog_coupling(l32[0], ld0, l32[1], sections, K, l32[2], l32[3], 0, odd)
+        want32 = torch.autograd.grad([y32, ld32], l32, [gy, gld])
+        res = {}
+        for which, lim in (('rows', 0), ('octets', 1 << 40)):
+            assert lib.nf_mixlog_rows_config(lim) == 0
+            try:
+                dl = [t.clone().to(DEV).requires_grad_(True) for t in (z, params, a, c)]
+                yd, ldd = NF.mixlog_coupling(dl[0], dl[1], dl[2], dl[3], ld0.to(DEV), K, 0, odd)
+                got = torch.autograd.grad([yd, ldd], dl, [gy.to(DEV), gld.to(DEV)])
+                xi, ldi = NF.mixlog_coupling(yd.detach(), dl[1].detach(), dl[2].detach(), dl[3].detach(), ldd.detach().clone(), K, 0, odd,
+                                             inverse=True)
+                torch.cuda.synchronize()
+            finally:
+                lib.nf_mixlog_rows_config(-1)
+            res[which] = (yd.detach(), ldd.detach(), [t.detach() for t in got], xi, ldi)
+            assert all(bool(torch.isfinite(t).all()) for t in [yd, ldd, xi, ldi] + list(got)), which
+            G.assert_close(yd, y32, _scaled(y32.detach()) + SLACK * _gap(y32, y64), what=which + ' y')
+            G.assert_close(ldd, ld32, _scaled(ld32.detach()) + SLACK * _gap(ld32, ld64), what=which + ' ld')
+            for gg, ww, w64, n in zip(got, want32, want64, ('g_z', 'g_params', 'g_a', 'g_c')):
+                G.assert_close(gg, ww, _scaled(ww) + SLACK * _gap(ww, w64), what=which + ' ' + n)
+            body = torch.ones(B, dtype=torch.bool)
+            body[::37] = False                              # (the planted tail rows sit where the clamped CDF is flat: no round trip there)
+            G.assert_close(xi[body.to(DEV)], z[body], 2e-4, what=which + ' round trip')
+        # the two kernel families on identical inputs: the same numbers to rounding (y, ld) and to the bisection bracket (inverse)
+        G.assert_close(res['rows'][0], res['octets'][0].cpu(), _scaled(y32.detach()) + SLACK * _gap(y32, y64), what='rows vs octets y')
+        G.assert_close(res['rows'][3], res['octets'][3].cpu(), 2e-4, what='rows vs octets inverse')
+
+
 @pytest.mark.parametrize('dims,mode,B,K', [((2, ), 0, 65536, 8), ((3, 8, 8), 1, 4, 4), ((8, 8, 8), 2, 4, 8)])
 def test_mixlog_coupling_vs_oracle(nf, dims, mode, B, K):
     NF = nf.functional

@@ -185,14 +185,14 @@ def main():
     nb = B * ((4 + 3 * K) * 4 + 8)
     report('mixlog_coupling_fwd 2d K=8', nb + B * 8,
            lambda: N.call('nf_mixlog_coupling_fwd', z.data_ptr(), params.data_ptr(), one.data_ptr(), zero.data_ptr(),
-                          yv.data_ptr(), ld.data_ptr(), K, 1e-5, 0, 0, B, 2, 1, 1, st()), trans=B * 8 * 15)
+                          yv.data_ptr(), ld.data_ptr(), K, 1e-5, 0, 0, B, 2, 1, 1, st()), trans=B * (4 * 8 + 8))      # (round 6 row kernels: 4 K + 8 per row)
     report('mixlog_coupling_bwd 2d K=8', 2 * nb + B * 12,
            lambda: N.call('nf_mixlog_coupling_bwd', yv.data_ptr(), ld.data_ptr(), z.data_ptr(), params.data_ptr(),
                           one.data_ptr(), zero.data_ptr(), gz.data_ptr(), gp.data_ptr(), g2.data_ptr(), g2.data_ptr() + 4, K,
-                          1e-5, 0, 0, B, 2, 1, 1, st()), trans=B * 8 * 25)
+                          1e-5, 0, 0, B, 2, 1, 1, st()), trans=B * (4 * 8 + 10))
     report('mixlog_coupling_inv 2d K=8 (25 it)', nb + B * 8 + B * 24,
            lambda: N.call('nf_mixlog_coupling_inv', yv.data_ptr(), params.data_ptr(), one.data_ptr(), zero.data_ptr(),
-                          gz.data_ptr(), ld.data_ptr(), scratch.data_ptr(), flag.data_ptr(), K, 0, 0, B, 2, 1, 1, st()), reps=5, trans=B * 8 * (3 + 25 * 2 + 8))
+                          gz.data_ptr(), ld.data_ptr(), scratch.data_ptr(), flag.data_ptr(), K, 0, 0, B, 2, 1, 1, st()), reps=5, trans=B * (2 * 8 + 25 * 2 * 8 + 4 * 8 + 8))
     del z, params, yv, gz, gp, scratch
 
     # ---- fused linear + BatchNorm (MFMA) ------------------------------------------------------------------------------------------------
