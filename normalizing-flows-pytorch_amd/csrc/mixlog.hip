@@ -902,9 +902,15 @@ __global__ void __launch_bounds__(NF_MR_ROWS) k_mixlog_row_inv(const float* __re
                 float lcdf;
                 nf_mix_eval<KT>(q, (lo + hi) * 0.5f, lcdf, lpdf_old);          // what phase 1 subtracted
             }
+            // sigma((x - mu) es) = 1 / (1 + 2^((mu - x) es log2 e)): the scale is folded into es once, the loop is sub, mul, v_exp, add, v_rcp, fma
+            float e2[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) e2[k] = m.es[k] * 1.4426950408889634f;
             for (int it = 0; it < (PHASE == 1 ? 25 : 75); ++it) {
                 const float mid = (lo + hi) * 0.5f;
-                const float val = nf_mix_cdf<KT>(q, pi, mid);
+                float val = 0.f;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) val = fmaf(pi[k], __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f((m.mu[k] - mid) * e2[k])), val);
                 if (PHASE == 2 && (mid == lo || mid == hi || val == target)) break;   // collapsed: the rest are no-ops
                 lo = val < target ? mid : lo;                                  // modules.py:202-203
                 hi = val > target ? mid : hi;

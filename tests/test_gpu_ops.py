@@ -357,16 +357,28 @@ def test_mixlog_row_kernels_match_oracle_and_the_octet_kernels(nf, B, K):
                 lib.nf_mixlog_rows_config(-1)
             res[which] = (yd.detach(), ldd.detach(), [t.detach() for t in got], xi, ldi)
             assert all(bool(torch.isfinite(t).all()) for t in [yd, ldd, xi, ldi] + list(got)), which
-            G.assert_close(yd, y32, _scaled(y32.detach()) + SLACK * _gap(y32, y64), what=which + ' y')
-            G.assert_close(ldd, ld32, _scaled(ld32.detach()) + SLACK * _gap(ld32, ld64), what=which + ' ld')
-            for gg, ww, w64, n in zip(got, want32, want64, ('g_z', 'g_params', 'g_a', 'g_c')):
-                G.assert_close(gg, ww, _scaled(ww) + SLACK * _gap(ww, w64), what=which + ' ' + n)
             body = torch.ones(B, dtype=torch.bool)
-            body[::37] = False                              # (the planted tail rows sit where the clamped CDF is flat: no round trip there)
-            G.assert_close(xi[body.to(DEV)], z[body], 2e-4, what=which + ' round trip')
+            body[::37] = False                              # the planted tail rows: the clamped CDF is flat there and the logit's slope is 1 / eps --
+            bd = body.to(DEV)                               # they must come out finite (above) and the same from both kernel families (below)
+            G.assert_close(yd[bd], y32[body], _scaled(y32.detach()[body]) + SLACK * _gap(y32[body], y64[body]), what=which + ' y')
+            G.assert_close(ldd[bd], ld32[body], _scaled(ld32.detach()[body]) + SLACK * _gap(ld32[body], ld64[body]), what=which + ' ld')
+            for gg, ww, w64, n in zip(got, want32, want64, ('g_z', 'g_params', 'g_a', 'g_c')):
+                if n in ('g_a', 'g_c'):
+                    # ONE number each: a sum over the batch of terms that reach 1e3 on the planted tail rows and cancel -- the bar is
+                    # relative to the sum of magnitudes a B-term fp32 sum carries, not to the total
+                    G.assert_close(gg, ww, _scaled(ww) + SLACK * _gap(ww, w64) + 1.0e-6 * B * 40.0, what=which + ' ' + n)
+                else:
+                    G.assert_close(gg[bd], ww[body], _scaled(ww[body]) + SLACK * _gap(ww[body], w64[body]), what=which + ' ' + n)
+            # round trip where the forward did not clamp the CDF (|logit F| < 9: F inside (1.2e-4, 1 - 1.2e-4); a single narrow component puts
+            # ordinary rows outside, and there x is not recoverable by any implementation)
+            aa = torch.tanh(params[:, 0]) * a + c
+            open_ = body & (((y32.detach()[:, int(odd)] - params[:, 1]) * torch.exp(-aa)).abs() < 9.0)
+            assert int(open_.sum()) > B // 2
+            G.assert_close(xi[open_.to(DEV)], z[open_], 2e-4, what=which + ' round trip')
         # the two kernel families on identical inputs: the same numbers to rounding (y, ld) and to the bisection bracket (inverse)
-        G.assert_close(res['rows'][0], res['octets'][0].cpu(), _scaled(y32.detach()) + SLACK * _gap(y32, y64), what='rows vs octets y')
-        G.assert_close(res['rows'][3], res['octets'][3].cpu(), 2e-4, what='rows vs octets inverse')
+        G.assert_close(res['rows'][0], res['octets'][0].cpu(), 1.0e-3 * max(1.0, float(y32.detach().abs().max())), what='rows vs octets y (tails included)')
+        G.assert_close(res['rows'][0][body.to(DEV)], res['octets'][0][body.to(DEV)].cpu(), _scaled(y32.detach()[body]) + SLACK * _gap(y32[body], y64[body]), what='rows vs octets y')
+        G.assert_close(res['rows'][3][open_.to(DEV)], res['octets'][3][open_.to(DEV)].cpu(), 2e-4, what='rows vs octets inverse')
 
 
 @pytest.mark.parametrize('dims,mode,B,K', [((2, ), 0, 65536, 8), ((3, 8, 8), 1, 4, 4), ((8, 8, 8), 2, 4, 8)])
