@@ -12,9 +12,10 @@ from ._build import build  # noqa: F401
 from .layers import (MADE, ActNorm, AbstractCoupling, AdditiveCoupling, AffineCoupling, AutoregressiveTransfrom, BatchNorm, Compose, Identity,
                      InvertibleConv1x1, Logit, MixLogAttnCoupling, MixLogCDF, Squeeze2d, Unsqueeze2d, Sigmoid, Tanh, Arctanh, Squeeze1d,
                      Unsqueeze1d)
+from .inverse_grad import differentiable_inverse  # noqa: F401
 from .models import MAF, Flowpp, Glow, RealNVP
 from .resflow import InvertibleResLinear, LipSwish, ResFlow, SpectralNorm
 
 __all__ = ['ActNorm', 'AbstractCoupling', 'AdditiveCoupling', 'AffineCoupling', 'BatchNorm', 'Compose', 'Identity', 'InvertibleConv1x1',
            'Logit', 'Squeeze2d', 'Unsqueeze2d', 'Glow', 'RealNVP', 'Flowpp', 'MAF', 'MADE', 'AutoregressiveTransfrom',
-           'MixLogAttnCoupling', 'MixLogCDF', 'Sigmoid', 'Tanh', 'Arctanh', 'Squeeze1d', 'Unsqueeze1d', 'ResFlow', 'InvertibleResLinear', 'SpectralNorm', 'LipSwish', 'build', 'functional']
+           'MixLogAttnCoupling', 'MixLogCDF', 'Sigmoid', 'Tanh', 'Arctanh', 'Squeeze1d', 'Unsqueeze1d', 'ResFlow', 'InvertibleResLinear', 'SpectralNorm', 'LipSwish', 'build', 'functional', 'differentiable_inverse']

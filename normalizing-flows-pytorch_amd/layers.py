@@ -282,13 +282,14 @@ class Compose(nn.Module):
         return run if run and FUSED.realnvp_eval_usable(z, run) else None
 
     def backward(self, z, log_df_dz):
-        """INVERSE flow (sampling).  The inverse kernels build no autograd graph: asking for gradients
-        THROUGH the inverse (an input that requires grad, e.g. a reverse-KL loss) raises instead of silently returning
-        constants; otherwise the whole pass runs under no_grad, so the conditioners do not record a graph nobody can use."""
+        """INVERSE flow (sampling).  The sampling kernels build no autograd graph: without a request for one the whole pass runs under
+        no_grad (the reference's ``sample_y``, main.py:113, leaves autograd on and never uses the graph).  An input that requires grad --
+        or the ``differentiable_inverse()`` context, for gradients of the parameters alone -- takes the graph-building form of every
+        layer's inverse instead (inverse_grad.py: the reference's formulas over the engine's own conditioners and gathers)."""
         if torch.is_grad_enabled():
-            if z.requires_grad or log_df_dz.requires_grad:
-                raise NotImplementedError('the inverse flow (net.backward) is not differentiable in this engine: its kernels '
-                                          'build no autograd graph; detach the input or differentiate the forward direction')
+            from . import inverse_grad as IG
+            if IG.wanted(z, log_df_dz):
+                return IG.layer_inverse(self, z, log_df_dz)
             with torch.no_grad():
                 return self.backward(z, log_df_dz)
         i = len(self.layers) - 1
