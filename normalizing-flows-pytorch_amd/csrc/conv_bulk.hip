@@ -47,6 +47,35 @@ extern "C" int nf_cb_prof_read(long long* out) { return (int)hipMemcpyFromSymbol
 #define NF_CBW_STAMP(T, i)
 #endif
 
+
+// Deterministic mode, the per-layer launches (one-dimensional grids of <= 256 persistent workgroups): wave 0 of every workgroup holds the
+// workgroup's 2 x 32 batch sums (lane half hs = which sum, c32 = channel) for replica blockIdx.x % NF_STAT_REPL.  A chain per replica is 32
+// hand-overs of ~5 us behind workgroups that all finish together (200 us per launch against 30); instead the sums go to a slab and the
+// workgroup that arrives LAST adds every replica's members in block order -- nobody waits (the vector form of nf_det_fold_add).
+#define NF_CBK_FOLD_MAX 256
+__device__ float nf_cbk_vslab[NF_CBK_FOLD_MAX * 64];
+__device__ unsigned nf_cbk_vcnt[1];
+__device__ __forceinline__ bool nf_cbk_det_fold64(float t, bool valid, float* __restrict__ dst0, float* __restrict__ dst1) {
+    if (gridDim.y != 1 || gridDim.z != 1 || gridDim.x > NF_CBK_FOLD_MAX) return false;        // (block-uniform)
+    const int lane = threadIdx.x & 63, hs = lane >> 5, c32 = lane & 31;
+    const unsigned n = gridDim.x;
+    __hip_atomic_store(nf_cbk_vslab + blockIdx.x * 64 + lane, valid ? t : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(nf_cbk_vcnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    old = __shfl(old, 0, NF_WAVE);
+    if (old + 1 == n) {
+        __threadfence();
+        for (unsigned r = 0; r < NF_STAT_REPL && r < n; ++r) {
+            float acc = 0.f;
+            for (unsigned b = r; b < n; b += NF_STAT_REPL) acc += __hip_atomic_load(nf_cbk_vslab + b * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (valid) atomicAdd((hs == 0 ? dst0 : dst1) + 32 * r + c32, acc);
+        }
+        if (lane == 0) __hip_atomic_store(nf_cbk_vcnt, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
+
 #define NF_CB_WAVES 4
 #define NF_CB_THREADS (NF_CB_WAVES * NF_WAVE)
 #define NF_CB_MAXIT 7                                 // items (channel octet, frame position) per lane: ceil(4 * FSZ / 64), FSZ <= 112
@@ -484,14 +513,16 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_fwd(nf_conv_desc d
         }
         __syncthreads();
         if (threadIdx.x < 64) {                        // wave 0 adds for the workgroup; half 0: sums, half 1: squares
-            NF_DET_REPL_CHAIN(NF_STAT_REPL);           // (deterministic mode: a chain per replica -- and per layer of a multi-launch)
-            NF_DET_ENTER_WAVE_K(nf_cbk);
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
-            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
-            atomicAdd((hs == 0 ? d.stat_sum : d.stat_sqsum) + rep + c32, t);
-            NF_DET_LEAVE_WAVE_K(nf_cbk);
+            if (!(nf_det_on(nf_cbk_det) && nf_cbk_det_fold64(t, true, d.stat_sum, d.stat_sqsum))) {
+                NF_DET_REPL_CHAIN(NF_STAT_REPL);       // (deterministic mode beyond the fold's slab: a chain per replica)
+                NF_DET_ENTER_WAVE_K(nf_cbk);
+                const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+                atomicAdd((hs == 0 ? d.stat_sum : d.stat_sqsum) + rep + c32, t);
+                NF_DET_LEAVE_WAVE_K(nf_cbk);
+            }
         }
     }
     NF_CB_STAMP(61);
@@ -668,16 +699,18 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv3_bulk_bwd(nf_conv_bwd_de
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            NF_DET_REPL_CHAIN(NF_STAT_REPL);           // (deterministic mode: a chain per replica -- and per layer of a multi-launch)
-            NF_DET_ENTER_WAVE_K(nf_cbk);
-            if (c32 < I) {
-                float t = 0.f;
+            float t = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
-                const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
-                atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
+            for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
+            if (!(nf_det_on(nf_cbk_det) && nf_cbk_det_fold64(t, c32 < I, d.sum_g, d.sum_gx))) {
+                NF_DET_REPL_CHAIN(NF_STAT_REPL);       // (deterministic mode beyond the fold's slab: a chain per replica)
+                NF_DET_ENTER_WAVE_K(nf_cbk);
+                if (c32 < I) {
+                    const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+                    atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
+                }
+                NF_DET_LEAVE_WAVE_K(nf_cbk);
             }
-            NF_DET_LEAVE_WAVE_K(nf_cbk);
         }
     }
 }
@@ -1278,14 +1311,16 @@ __global__ void __launch_bounds__(NF_CB_THREADS) k_conv1_bulk_bwd(nf_conv_bwd_de
         }
         __syncthreads();
         if (threadIdx.x < 64) {
-            NF_DET_REPL_CHAIN(NF_STAT_REPL);           // (deterministic mode: a chain per replica -- and per layer of a multi-launch)
-            NF_DET_ENTER_WAVE_K(nf_cbk);
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) t += red[(hs * 4 + w) * 32 + c32];
-            const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
-            atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
-            NF_DET_LEAVE_WAVE_K(nf_cbk);
+            if (!(nf_det_on(nf_cbk_det) && nf_cbk_det_fold64(t, true, d.sum_g, d.sum_gx))) {
+                NF_DET_REPL_CHAIN(NF_STAT_REPL);       // (deterministic mode beyond the fold's slab: a chain per replica)
+                NF_DET_ENTER_WAVE_K(nf_cbk);
+                const int rep = 32 * (blockIdx.x % NF_STAT_REPL);
+                atomicAdd((hs == 0 ? d.sum_g : d.sum_gx) + rep + c32, t);
+                NF_DET_LEAVE_WAVE_K(nf_cbk);
+            }
         }
     }
 }

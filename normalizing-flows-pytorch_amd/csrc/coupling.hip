@@ -128,10 +128,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_rows_bwd(const float* __res
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_cpl);
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
-        NF_DET_LEAVE(nf_cpl);
+        NF_DET_ADD2(nf_cpl, g_scale, ta, g_bias, tc);
     }
 }
 
@@ -170,10 +167,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_slab_bwd(const float* __res
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_cpl);
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
-        NF_DET_LEAVE(nf_cpl);
+        NF_DET_ADD2(nf_cpl, g_scale, ta, g_bias, tc);
     }
 }
 
@@ -334,10 +328,7 @@ __global__ void __launch_bounds__(NF_BIG) k_affine_img_bwd(const float* __restri
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_cpl);
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
-        NF_DET_LEAVE(nf_cpl);
+        NF_DET_ADD2(nf_cpl, g_scale, ta, g_bias, tc);
     }
 }
 
@@ -389,10 +380,7 @@ __global__ void __launch_bounds__(NF_BIG) k_affine_d2_bwd(const float4* __restri
     const float ta = nf_block_sum(acc_a, scratch);
     const float tc = nf_block_sum(acc_c, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_cpl);
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
-        NF_DET_LEAVE(nf_cpl);
+        NF_DET_ADD2(nf_cpl, g_scale, ta, g_bias, tc);
     }
 }
 

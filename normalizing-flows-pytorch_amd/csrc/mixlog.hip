@@ -384,10 +384,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_bwd(const float* __restrict
             partials[blockIdx.x] = ta;     // workgroups of a CIFAR-shape launch spent ~4 of their 18.7 us queueing for two addresses
             partials[gridDim.x + blockIdx.x] = tc;
         } else {
-            NF_DET_ENTER(nf_ml);
-            atomicAdd(g_scale, ta);
-            atomicAdd(g_bias, tc);
-            NF_DET_LEAVE(nf_ml);
+            NF_DET_ADD2(nf_ml, g_scale, ta, g_bias, tc);
         }
     }
 }
@@ -857,10 +854,7 @@ __global__ void __launch_bounds__(NF_MR_ROWS) k_mixlog_row_bwd(const float* __re
     const float ta = nf_block_sum(acc_A, scratch);
     const float tc = nf_block_sum(acc_C, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_ml);
-        atomicAdd(g_scale, ta);
-        atomicAdd(g_bias, tc);
-        NF_DET_LEAVE(nf_ml);
+        NF_DET_ADD2(nf_ml, g_scale, ta, g_bias, tc);
     }
 }
 

@@ -193,3 +193,22 @@ __device__ __forceinline__ bool nf_det_fold_add(float* slab, unsigned* cnt, cons
     }
     return true;
 }
+
+// the commonest site: ONE thread of every workgroup of the grid adds the workgroup's pair of partial sums to two scalars (a coupling's
+// scale / shift gradients).  Racing: two atomics.  Ordered: the last-workgroup fold, the grid-wide turnstile beyond its slab.
+#define NF_DET_ADD2(p, d0, v0, d1, v1)                                                         \
+    do {                                                                                       \
+        if (nf_det_on(p##_det)) {                                                              \
+            const float nf_v_[2] = {(v0), (v1)};                                               \
+            float* const nf_d_[2] = {(d0), (d1)};                                              \
+            if (!nf_det_fold_add<2>(p##_det_slab, p##_det_cnt, nf_v_, nf_d_)) {                \
+                nf_det_wait(p##_det);                                                          \
+                atomicAdd((d0), (v0));                                                         \
+                atomicAdd((d1), (v1));                                                         \
+                nf_det_pass(p##_det);                                                          \
+            }                                                                                  \
+        } else {                                                                               \
+            atomicAdd((d0), (v0));                                                             \
+            atomicAdd((d1), (v1));                                                             \
+        }                                                                                      \
+    } while (0)
