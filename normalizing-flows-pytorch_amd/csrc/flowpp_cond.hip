@@ -870,7 +870,8 @@ __device__ __forceinline__ void nf_fpp_finalize_body(const float* __restrict__ s
     red[grp][el] = s;
     __syncthreads();
     if (grp != 0) return;                                 // wave 0 adds for the workgroup: one lane per slab entry (deterministic mode: the
-    NF_DET_ENTER_WAVE(nf_fpc);                            // workgroups of the four slab quarters -- and of every step of a multi launch -- in block order)
+    NF_DET_COL_CHAIN();                                   // the <= 4 workgroups of the slab quarters of (entries blockIdx.x, step blockIdx.z): a chain
+    NF_DET_ENTER_WAVE_K(nf_fpc);                          // of their own (round 6; one grid-wide chain of 3 840 workgroups before)
     const bool live = blockIdx.y * 64 < nblk;
     s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
     if (!live) {}
@@ -901,7 +902,7 @@ __device__ __forceinline__ void nf_fpp_finalize_body(const float* __restrict__ s
             else { atomicAdd(mx.g_nls + o0, -s); atomicAdd(mx.g_nls + o1, -s); }
         }
     }
-    NF_DET_LEAVE_WAVE(nf_fpc);
+    NF_DET_LEAVE_WAVE_K(nf_fpc);
 }
 
 __global__ void __launch_bounds__(256) k_flowpp_cond_finalize(const float* __restrict__ slabs, int nblk, NfFppG gr, int I0,

@@ -139,7 +139,12 @@ __device__ __forceinline__ void nf_det_pass_k(unsigned* turns, unsigned key, uns
 // the chain of an UNREPLICATED sum of a (workgroups, layers) launch: key blockIdx.y, rank blockIdx.x
 #define NF_DET_ROW_CHAIN()                                                                                    \
     const unsigned nf_det_key_ = blockIdx.y, nf_det_rank_ = blockIdx.x, nf_det_cnt_ = gridDim.x
-// forms (1), (2), (1b) on the chain declared just before (NF_DET_REPL_CHAIN / NF_DET_ROW_CHAIN)
+// the chain of a sum whose addresses are picked by blockIdx.x (and blockIdx.z), met by the blockIdx.y workgroups of a (x, y, z) launch:
+// key (blockIdx.z, blockIdx.x), rank blockIdx.y.  More chains than turn words: key = NF_DET_KEYS (out of range: counted, unordered) -- the
+// launchers of such sites keep gridDim.x * gridDim.z <= NF_DET_KEYS or use the grid-wide form.
+#define NF_DET_COL_CHAIN()                                                                                    \
+    const unsigned nf_det_key_ = blockIdx.z * gridDim.x + blockIdx.x, nf_det_rank_ = blockIdx.y, nf_det_cnt_ = gridDim.y
+// forms (1), (2), (1b) on the chain declared just before (NF_DET_REPL_CHAIN / NF_DET_ROW_CHAIN / NF_DET_COL_CHAIN)
 #define NF_DET_ENTER_K(p)                         \
     const bool nf_det_ = nf_det_on(p##_det);      \
     if (nf_det_) nf_det_wait_k(p##_det, p##_det_turns, nf_det_key_, nf_det_rank_)
