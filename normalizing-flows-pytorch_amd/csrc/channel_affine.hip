@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd(int op, const floa
     const float R2 = nf_block_sum(r2, scratch);
     const float SG = nf_block_sum(sg, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_ca);      // (one thread per workgroup adds; the blocks of a channel meet in block order when the mode is on)
+        NF_DET_ENTER_COL(nf_ca);      // (one thread per workgroup adds; the blocks of a channel meet in block order when the mode is on)
         if (op == NF_ACTNORM) {   // g_log_scale = -sum g*y - P*sum g_ld ; g_bias = -sum g / exp(log_scale)
             atomicAdd(g_pa + c, -R2 - (float)P * SG);
             atomicAdd(g_pb + c, -R1 / k.D);
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd(int op, const floa
             atomicAdd(g_pa + c, R2 + (float)P * SG);
             atomicAdd(g_pb + c, R1);
         }
-        NF_DET_LEAVE(nf_ca);
+        NF_DET_LEAVE_COL(nf_ca);
     }
 }
 
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_stat(const float* __restrict_
         acc += SQDEV ? v * v : v;
     }
     const float tot = nf_block_sum(acc, scratch);
-    if (threadIdx.x == 0) { NF_DET_ENTER(nf_ca); atomicAdd(out + c, tot); NF_DET_LEAVE(nf_ca); }
+    if (threadIdx.x == 0) { NF_DET_ENTER_COL(nf_ca); atomicAdd(out + c, tot); NF_DET_LEAVE_COL(nf_ca); }
 }
 
 __global__ void k_flowbn_finalize(const float* __restrict__ sum, const float* __restrict__ sqdev,
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd_img(int op, const 
     const float R2 = nf_block_sum(r2, scratch);
     const float SG = nf_block_sum(sg, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_ca);
+        NF_DET_ENTER_COL(nf_ca);
         if (op == NF_ACTNORM) {
             atomicAdd(g_pa + c, -R2 - (float)P * SG);
             atomicAdd(g_pb + c, -R1 / k.D);
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_affine_bwd_img(int op, const 
             atomicAdd(g_pa + c, R2 + (float)P * SG);
             atomicAdd(g_pb + c, R1);
         }
-        NF_DET_LEAVE(nf_ca);
+        NF_DET_LEAVE_COL(nf_ca);
     }
 }
 
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_chan_stat_img(const float4* __rest
         acc1 += SQDEV ? (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3) : (c0 + c1) + (c2 + c3);
     }
     const float tot = nf_block_sum(acc0 + acc1, scratch);
-    if (threadIdx.x == 0) { NF_DET_ENTER(nf_ca); atomicAdd(out + c, tot); NF_DET_LEAVE(nf_ca); }
+    if (threadIdx.x == 0) { NF_DET_ENTER_COL(nf_ca); atomicAdd(out + c, tot); NF_DET_LEAVE_COL(nf_ca); }
 }
 template <bool SQDEV>
 __global__ void __launch_bounds__(NF_BIG) k_chan_stat_row(const float4* __restrict__ x, const float* __restrict__ sum,

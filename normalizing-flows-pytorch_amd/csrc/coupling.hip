@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_slab_fwd(const float* __res
     if (threadIdx.x == 0) {
         const float d = INVERSE ? -tot : tot;
         if (gridDim.y == 1) ld[b] += d;
-        else { NF_DET_ENTER(nf_cpl); atomicAdd(ld + b, d); NF_DET_LEAVE(nf_cpl); }
+        else { NF_DET_ENTER_COL(nf_cpl); atomicAdd(ld + b, d); NF_DET_LEAVE_COL(nf_cpl); }      // (grid (sample, slab): a chain per sample)
     }
 }
 
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_affine_img_fwd(const float* __rest
     if (threadIdx.x == 0) {
         const float dd = INVERSE ? -tot : tot;
         if (gridDim.y == 1) ld[b] += dd;
-        else { NF_DET_ENTER(nf_cpl); atomicAdd(ld + b, dd); NF_DET_LEAVE(nf_cpl); }
+        else { NF_DET_ENTER_COL(nf_cpl); atomicAdd(ld + b, dd); NF_DET_LEAVE_COL(nf_cpl); }
     }
 }
 

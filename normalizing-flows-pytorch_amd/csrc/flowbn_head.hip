@@ -32,10 +32,10 @@ __global__ void __launch_bounds__(NF_BLOCK) k_flowbn_stats(const float* __restri
     const float t1 = nf_block_sum(s1, scratch);
     const float t2 = nf_block_sum(s2, scratch);
     if (threadIdx.x == 0) {
-        NF_DET_ENTER(nf_fbh);
+        NF_DET_ENTER_COL(nf_fbh);     // (grid (channel, block): the blocks of a channel take turns, the channels side by side)
         atomicAdd(ws + c, t1);
         atomicAdd(ws + C + c, t2);
-        NF_DET_LEAVE(nf_fbh);
+        NF_DET_LEAVE_COL(nf_fbh);
         if (blockIdx.y == 0) ws[2 * C + c] = k;       // the centre that was used (running_mean changes in the next launch)
     }
 }

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_logit_fwd(const float* __restrict_
     const float tot = nf_block_sum(acc, scratch);
     if (threadIdx.x == 0) {
         if (gridDim.y == 1) ld[b] += tot;
-        else { NF_DET_ENTER(nf_lg); atomicAdd(ld + b, tot); NF_DET_LEAVE(nf_lg); }
+        else { NF_DET_ENTER_COL(nf_lg); atomicAdd(ld + b, tot); NF_DET_LEAVE_COL(nf_lg); }
     }
 }
 
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_bijector_fwd(const float* __restri
     const float tot = nf_block_sum(acc, scratch);
     if (threadIdx.x == 0) {
         if (gridDim.y == 1) ld[b] += tot;
-        else { NF_DET_ENTER(nf_lg); atomicAdd(ld + b, tot); NF_DET_LEAVE(nf_lg); }
+        else { NF_DET_ENTER_COL(nf_lg); atomicAdd(ld + b, tot); NF_DET_LEAVE_COL(nf_lg); }
     }
 }
 // autograd of the modules' forward directions (kinds 0, 2, 3): g_x = g_y dy/dx + g_ld d(ld term)/dx

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_nll_loss(const float* __restrict__
     const float cst = -0.5f * (float)D * 1.8378770664093453f;   // log(2 pi)
     if (gtid == 0) acc += cst * (float)B;
     const float tot = nf_block_sum(acc, scratch);
-    if (threadIdx.x == 0) { NF_DET_ENTER(nf_ms); atomicAdd(loss, -tot / (float)B); NF_DET_LEAVE(nf_ms); }
+    if (threadIdx.x == 0) NF_DET_ADD1(nf_ms, loss, -tot / (float)B);
 }
 
 extern "C" int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream) {

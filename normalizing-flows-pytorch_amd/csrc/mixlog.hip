@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(NF_BLOCK) k_mixlog_slab_fwd(const float* __res
     const float tot = nf_block_sum(acc, scratch);
     if (threadIdx.x == 0) {
         if (gridDim.y == 1) ld[b] += tot;
-        else { NF_DET_ENTER(nf_ml); atomicAdd(ld + b, tot); NF_DET_LEAVE(nf_ml); }
+        else { NF_DET_ENTER_COL(nf_ml); atomicAdd(ld + b, tot); NF_DET_LEAVE_COL(nf_ml); }
     }
 }
 

@@ -217,3 +217,33 @@ __device__ __forceinline__ bool nf_det_fold_add(float* slab, unsigned* cnt, cons
             atomicAdd((d1), (v1));                                                             \
         }                                                                                      \
     } while (0)
+
+// form (1) on a COLUMN chain with the grid-wide turnstile as the fallback when the launch has more columns than turn words: ONE thread of
+// every workgroup of an (x, y, z) launch adds to addresses picked by (blockIdx.x, blockIdx.z) -- a sample's log-det, a channel's sums
+#define NF_DET_ENTER_COL(p)                                                                                   \
+    const bool nf_det_ = nf_det_on(p##_det);                                                                  \
+    const bool nf_det_col_ = gridDim.x * gridDim.z <= NF_DET_KEYS;                                            \
+    if (nf_det_) {                                                                                            \
+        if (nf_det_col_) nf_det_wait_k(p##_det, p##_det_turns, blockIdx.z * gridDim.x + blockIdx.x, blockIdx.y); \
+        else nf_det_wait(p##_det);                                                                            \
+    }
+#define NF_DET_LEAVE_COL(p)                                                                                   \
+    if (nf_det_) {                                                                                            \
+        if (nf_det_col_) nf_det_pass_k(p##_det_turns, blockIdx.z * gridDim.x + blockIdx.x, blockIdx.y, gridDim.y); \
+        else nf_det_pass(p##_det);                                                                            \
+    }
+// ... and ONE scalar of a whole grid (the loss): the last-workgroup fold, the turnstile beyond its slab
+#define NF_DET_ADD1(p, d0, v0)                                                                 \
+    do {                                                                                       \
+        if (nf_det_on(p##_det)) {                                                              \
+            const float nf_v_[1] = {(v0)};                                                     \
+            float* const nf_d_[1] = {(d0)};                                                    \
+            if (!nf_det_fold_add<1>(p##_det_slab, p##_det_cnt, nf_v_, nf_d_)) {                \
+                nf_det_wait(p##_det);                                                          \
+                atomicAdd((d0), (v0));                                                         \
+                nf_det_pass(p##_det);                                                          \
+            }                                                                                  \
+        } else {                                                                               \
+            atomicAdd((d0), (v0));                                                             \
+        }                                                                                      \
+    } while (0)
