@@ -635,6 +635,14 @@ int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int64_t B, int 
  * nf_conv_bwd_slabs): one workgroup per compute unit over the whole launch, each keeping its tap tiles in registers over
  * tiles / slabs tiles.                                                                                                     */
 int nf_conv_wgrad_slabs(int64_t B, int H, int W, int n_layers);
+/* The same pass for ANY number of layers of one shape in ONE launch (round 6: config 4 at 64 samples per GPU queues 320 hidden layers per
+ * resolution; sixteen per launch were 2 .. 8 tiles per workgroup -- prologue, slab write and launch gap outweighed the tiles).  The
+ * descriptors do not fit the kernel arguments: they are written to the device table `table_dev` (n descriptors, caller's scratch) by tiny
+ * launches of 21 in front of the pass (by-value arguments: a captured hipGraph replays them without touching host memory) and read
+ * there by the workgroups.  `slabs` workgroups per layer (1 .. 128, <= tiles of 128 pixels); g_weff of each descriptor holds that many.  */
+#define NF_CONV_WGRAD_TABLE_MAX 4096
+int nf_conv_bn_wgrad_table(const nf_conv_bwd_desc* descs, nf_conv_bwd_desc* table_dev, int n, int slabs, int64_t B, int I, int O, int H,
+                           int W, int ksize, nf_stream_t stream);
 
 /* dst[e] (+)= sum_{s < n_slabs} src[s * stride + e], e < n: every slab / replica sum of one conditioner backward in ONE
  * launch (weight-gradient slabs, bias and BatchNorm-parameter replicas).                                                */

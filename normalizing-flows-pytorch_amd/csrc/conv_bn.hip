@@ -19,6 +19,8 @@
 // statistic instead of 80).
 #include <mutex>
 #include <unordered_set>
+#include <vector>
+
 #include "nf_common.h"
 #include "nf_det.h"
 
@@ -946,9 +948,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_bwd(nf_conv_bwd_desc 
     nf_cv_bwd_body<T, ICB, OCB, MODE>(d, g, I, O, iters);
 }
 template <int T, int ICB, int OCB, bool LEAN>
-__global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_wgrad_multi(NfCvBwdMulti m, NfCvGeo g, int I, int O, int iters) {
-    if constexpr (LEAN) nf_cv_wgrad3_body<T>(m.d[blockIdx.y], g, I, O, iters);
-    else nf_cv_bwd_body<T, ICB, OCB, 2>(m.d[blockIdx.y], g, I, O, iters);
+__global__ void __launch_bounds__(NF_CV_THREADS) k_conv_bn_wgrad_multi(NfCvBwdMulti m, const nf_conv_bwd_desc* __restrict__ tab, NfCvGeo g,
+                                                                       int I, int O, int iters) {
+    // tab != NULL: the layers' descriptors are a TABLE in device memory (nf_conv_bn_wgrad_table: any number of layers per launch)
+    const nf_conv_bwd_desc& d = tab != nullptr ? tab[blockIdx.y] : m.d[blockIdx.y];
+    if constexpr (LEAN) nf_cv_wgrad3_body<T>(d, g, I, O, iters);
+    else nf_cv_bwd_body<T, ICB, OCB, 2>(d, g, I, O, iters);
 }
 
 #define NF_CV_BWD_MAX_SLABS 128
@@ -1028,34 +1033,62 @@ extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, in
     return 0;
 }
 
-extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int O, int H, int W, int ksize,
-                                      nf_stream_t stream) {
+// a chunk of descriptors from the kernel arguments into a device table (nf_conv_bn_wgrad_table): by-value arguments are part of a captured
+// launch, so a hipGraph replays the table's construction without re-reading host memory
+#define NF_CV_DESC_WRITE 21                             // descriptors per writer launch: 21 x 184 B + the tail < 4 KB of kernel arguments
+struct NfCvDescChunk { nf_conv_bwd_desc d[NF_CV_DESC_WRITE]; };
+static_assert(sizeof(NfCvDescChunk) + 16 <= 4096, "kernel-argument segment");
+__global__ void k_conv_desc_write(NfCvDescChunk m, nf_conv_bwd_desc* __restrict__ dst, int cnt) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(&m);
+    unsigned* out = reinterpret_cast<unsigned*>(dst);
+    const int words = cnt * (int)(sizeof(nf_conv_bwd_desc) / sizeof(unsigned));
+    for (int i = threadIdx.x; i < words; i += blockDim.x) out[i] = src[i];
+}
+static_assert(sizeof(nf_conv_bwd_desc) % sizeof(unsigned) == 0, "descriptor: whole words");
+
+// descs: n descriptors on the host (sanitised in place).  tab == NULL: n <= NF_CV_WG_MAX, they travel in the kernel arguments.  tab != NULL:
+// the table form -- written to `tab` sixteen per tiny launch in front of the pass, then read by the workgroups.
+static int nf_conv_bn_wgrad_launch(nf_conv_bwd_desc* descs, const nf_conv_bwd_desc* tab, int n, int slabs, int64_t B, int I, int O, int H,
+                                   int W, int ksize, nf_stream_t stream) {
     NfCvGeo g;
-    if (descs == nullptr || n < 1 || n > NF_CV_WG_MAX || !nf_conv_bn_usable(B > 0 ? B : 1, I, O, H, W, ksize)) return NF_E_BADARG;
+    if (descs == nullptr || n < 1 || (tab == nullptr && n > NF_CV_WG_MAX) || n > NF_CONV_WGRAD_TABLE_MAX ||
+        !nf_conv_bn_usable(B > 0 ? B : 1, I, O, H, W, ksize))
+        return NF_E_BADARG;
     if (B == 0) return 0;
     if (!nf_cv_geometry(g, B, H, W, ksize)) return NF_E_BADARG;
     if (!nf_cv_fits_int32(B, I > O ? I : O, H * W)) return NF_E_BADARG;
-    NfCvBwdMulti m{};
     if (!nf_cv_set_valid(g, descs[0].valid_h, descs[0].valid_w)) return NF_E_BADARG;      // (one shape per launch: layer 0's extent)
     const bool masked = nf_cv_masked(g);
+    bool one_plain = true;                             // (conv_bulk.hip keeps ONE plain gradient tensor per layer in flight)
     for (int k = 0; k < n; ++k) {
         if (descs[k].valid_h != descs[0].valid_h || descs[k].valid_w != descs[0].valid_w) return NF_E_BADARG;
         if (descs[k].g_weff == nullptr || descs[k].in == nullptr) return NF_E_BADARG;
         if (descs[k].bn_gamma != nullptr && I > 32) return NF_E_BADARG;
         if (descs[k].gn_src != nullptr && O > 32) return NF_E_BADARG;
-        m.d[k] = descs[k];
-        m.d[k].g_store = nullptr; m.d[k].gn_out = nullptr; m.d[k].sum_g = nullptr; m.d[k].sum_gx = nullptr;   // the data pass did those
+        descs[k].g_store = nullptr; descs[k].gn_out = nullptr; descs[k].sum_g = nullptr; descs[k].sum_gx = nullptr;   // the data pass did those
+        one_plain = one_plain && !(descs[k].g_direct != nullptr && descs[k].g_skip != nullptr);
+    }
+    NfCvBwdMulti m{};
+    hipStream_t st = (hipStream_t)stream;
+    if (tab == nullptr) {
+        for (int k = 0; k < n; ++k) m.d[k] = descs[k];
+    } else {
+        for (int k0 = 0; k0 < n; k0 += NF_CV_DESC_WRITE) {
+            const int cnt = n - k0 < NF_CV_DESC_WRITE ? n - k0 : NF_CV_DESC_WRITE;
+            NfCvDescChunk w{};
+            for (int k = 0; k < cnt; ++k) w.d[k] = descs[k0 + k];
+            hipLaunchKernelGGL(k_conv_desc_write, dim3(1), dim3(256), 0, st, w, const_cast<nf_conv_bwd_desc*>(tab) + k0, cnt);
+        }
+        m = NfCvBwdMulti{};
     }
     const int ICB = (I + 31) / 32, OCB = (O + 31) / 32;
     const int T = ksize * ksize;
     const size_t lds = sizeof(float) * ((size_t)32 * g.CS + (size_t)32 * OCB * g.CS + 5 * 32 + 4 * 32 + 2 * 4 * 32);
-    const unsigned grid = (unsigned)nf_conv_wgrad_slabs(B, H, W, n);
-    bool one_plain = true;                             // (conv_bulk.hip keeps ONE plain gradient tensor per layer in flight)
-    for (int k = 0; k < n; ++k) one_plain = one_plain && !(m.d[k].g_direct != nullptr && m.d[k].g_skip != nullptr);
+    if (slabs < 1 || slabs > NF_CV_BWD_MAX_SLABS || slabs > g.tiles) return NF_E_BADARG;
+    const unsigned grid = (unsigned)slabs;
     if (!masked && one_plain && nf_conv_bulk_wgrad_plan(B, I, O, H, W, ksize))  // large batches: the pixel-contraction kernel of conv_bulk.hip (bf16 matrix pipe)
-        return nf_conv_bulk_wgrad(m.d, n, B, I, H, W, (int)grid, (hipStream_t)stream);
+        return nf_conv_bulk_wgrad(tab == nullptr ? m.d : nullptr, tab, n, B, I, H, W, (int)grid, st);
     const int iters = (int)((g.tiles + grid - 1) / grid);
-    hipStream_t st = (hipStream_t)stream;
     int rc;
     // the lean body addresses with 32-bit byte offsets (3x3, one input chunk: every hidden layer)
     const size_t lds_lean = sizeof(float) * ((size_t)2 * 64 * g.CS + 5 * 32 + 2 * 32);       // two frame pairs
@@ -1067,7 +1100,7 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
         rc = nf_cv_optin(k_conv_bn_wgrad_multi<T_, IB_, OB_, LEAN_>, lds_);                                            \
         if (rc) return rc;                                                                                             \
         hipLaunchKernelGGL((k_conv_bn_wgrad_multi<T_, IB_, OB_, LEAN_>), dim3(grid, (unsigned)n), dim3(NF_CV_THREADS), lds_, st, m, \
-                           g, I, O, iters);                                                                            \
+                           tab, g, I, O, iters);                                                                       \
     } while (0)
     if (T == 9) {
         if (ICB == 1 && lean) NF_LAUNCH(9, 1, 1, true);
@@ -1090,6 +1123,21 @@ extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int6
 #undef NF_LAUNCH
     NF_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int nf_conv_bn_wgrad_multi(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int O, int H, int W, int ksize,
+                                      nf_stream_t stream) {
+    if (descs == nullptr || n < 1 || n > NF_CV_WG_MAX) return NF_E_BADARG;
+    nf_conv_bwd_desc local[NF_CV_WG_MAX];
+    for (int k = 0; k < n; ++k) local[k] = descs[k];
+    const int slabs = nf_conv_wgrad_slabs(B, H, W, n);
+    return nf_conv_bn_wgrad_launch(local, nullptr, n, slabs > 0 ? slabs : 1, B, I, O, H, W, ksize, stream);
+}
+extern "C" int nf_conv_bn_wgrad_table(const nf_conv_bwd_desc* descs, nf_conv_bwd_desc* table_dev, int n, int slabs, int64_t B, int I, int O,
+                                      int H, int W, int ksize, nf_stream_t stream) {
+    if (table_dev == nullptr || descs == nullptr || n < 1 || n > NF_CONV_WGRAD_TABLE_MAX) return NF_E_BADARG;
+    static thread_local std::vector<nf_conv_bwd_desc> local;                 // (the launcher sanitises its copy, not the caller's array)
+    local.assign(descs, descs + n);
+    return nf_conv_bn_wgrad_launch(local.data(), table_dev, n, slabs, B, I, O, H, W, ksize, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

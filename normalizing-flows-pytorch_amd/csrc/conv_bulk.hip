@@ -781,9 +781,9 @@ __device__ __forceinline__ void nf_cbw_put4(char* p, int plane_bytes, const floa
     *(bf16x4*)(p + 2 * plane_bytes) = bf16x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
-__global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti m, NfCbwGeo g, int I) {
+__global__ void __launch_bounds__(NF_CBW_THREADS) k_conv3_bulk_wgrad(NfCbwMulti m, const nf_conv_bwd_desc* __restrict__ tab, NfCbwGeo g, int I) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const nf_conv_bwd_desc& d = m.d[blockIdx.y];
+    const nf_conv_bwd_desc& d = tab != nullptr ? tab[blockIdx.y] : m.d[blockIdx.y];     // (tab: the descriptor table of nf_conv_bn_wgrad_table)
     char* const lds = (char*)smem;
     const int PA = 32 * g.ACH, PG = 32 * NF_CBW_GCH;  // bytes per activation / G plane
     const int BUF = 3 * (PA + PG);                     // a frame pair: act planes h | m | l, G planes h | m | l
@@ -1436,19 +1436,22 @@ int nf_conv_bulk_wgrad_plan(int64_t B, int I, int O, int H, int W, int ksize) {
     NfCbwGeo g;
     return nf_cbw_geometry(g, B, H, W) ? 1 : 0;
 }
-int nf_conv_bulk_wgrad(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int H, int W, int slabs, hipStream_t st) {
+// descs (host, n <= NF_CONV_WGRAD_MAX) travel in the kernel arguments, or tab (device, any n; descs == NULL) is read by the workgroups;
+// the caller has checked that every layer has ONE plain gradient tensor
+int nf_conv_bulk_wgrad(const nf_conv_bwd_desc* descs, const nf_conv_bwd_desc* tab, int n, int64_t B, int I, int H, int W, int slabs,
+                       hipStream_t st) {
     NfCbwGeo g;
-    if (!nf_cbw_geometry(g, B, H, W) || n < 1 || n > NF_CONV_WGRAD_MAX || slabs < 1) return NF_E_BADARG;
-    for (int k = 0; k < n; ++k)
-        if (descs[k].g_direct != nullptr && descs[k].g_skip != nullptr) return NF_E_BADARG;   // (one plain gradient per layer: the caller checks)
+    if (!nf_cbw_geometry(g, B, H, W) || n < 1 || slabs < 1 || (descs == nullptr) == (tab == nullptr)) return NF_E_BADARG;
+    if (descs != nullptr && n > NF_CONV_WGRAD_MAX) return NF_E_BADARG;
     NfCbwMulti m{};
-    for (int k = 0; k < n; ++k) m.d[k] = descs[k];
+    if (descs != nullptr)
+        for (int k = 0; k < n; ++k) m.d[k] = descs[k];
     const size_t lds = nf_cbw_lds_bytes(g);
     int rc = nf_cb_optin(k_conv3_bulk_wgrad);
     if (rc) return rc;
     const unsigned gx = (unsigned)(g.tiles < slabs ? g.tiles : slabs);
     if ((int)gx != slabs) return NF_E_BADARG;          // (every slab the caller sums must be written)
-    hipLaunchKernelGGL(k_conv3_bulk_wgrad, dim3(gx, (unsigned)n), dim3(NF_CBW_THREADS), lds, st, m, g, I);
+    hipLaunchKernelGGL(k_conv3_bulk_wgrad, dim3(gx, (unsigned)n), dim3(NF_CBW_THREADS), lds, st, m, tab, g, I);
     NF_CHECK_LAUNCH();
     return 0;
 }

@@ -342,7 +342,7 @@ int nf_conv_bulk_fwd(const nf_conv_desc* desc, int64_t B, int I, int H, int W, i
 int nf_conv_bulk_bwd_plan(const nf_conv_bwd_desc* d, int64_t B, int I, int O, int H, int W, int ksize);
 int nf_conv_bulk_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, int H, int W, hipStream_t st);
 int nf_conv_bulk_wgrad_plan(int64_t B, int I, int O, int H, int W, int ksize);
-int nf_conv_bulk_wgrad(const nf_conv_bwd_desc* descs, int n, int64_t B, int I, int H, int W, int slabs, hipStream_t st);
+int nf_conv_bulk_wgrad(const nf_conv_bwd_desc* descs, const nf_conv_bwd_desc* tab, int n, int64_t B, int I, int H, int W, int slabs, hipStream_t st);
 // the 1x1 output convolution at large batches (conv_bulk.hip: operands straight from global memory, no LDS)
 int nf_conv1_bulk_fwd_plan(const nf_conv_desc* d, int64_t B, int I, int O, int H, int W, int ksize);
 int nf_conv1_bulk_fwd(const nf_conv_desc* desc, int64_t B, int O, int H, int W, int training, float eps, float mom, hipStream_t st);

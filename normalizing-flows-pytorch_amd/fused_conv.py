@@ -225,9 +225,16 @@ class ConvDefer:
             t = self.scratch[(device, slot)] = torch.empty(n, dtype=torch.float32, device=device)
         return t
 
+    TABLE_MIN = 17              # more layers of one shape than the by-value launch takes: ONE launch over a device table of descriptors
+    TABLE_MAX = 512             # (x NF_STAT_REPL chains of the ordered mode = its 4 096 turn words)
+    TABLE_WGS = 256             # workgroups the table launch aims at: ONE per layer once there are 256 layers (C4, ms per step at 256 / 512 / 1024 /
+                                # 2048 / 4096: 22.41 / 22.42 / 22.53 / 22.89 / 23.47 -- every extra slab is a 36 KB write, a fold and fewer tiles per prologue)
+
     def launch_layers(self, layers):
-        """the weight-gradient passes of ``layers`` (entries as in self.layers), sixteen layers of one shape per launch, then their
-        slab sums"""
+        """the weight-gradient passes of ``layers`` (entries as in self.layers) and their slab sums.  Up to sixteen layers of one shape
+        travel in the kernel arguments of one launch (nf_conv_bn_wgrad_multi); MORE of one shape -- config 4 queues 320 hidden layers per
+        resolution -- run as ONE launch over a descriptor table in device memory (nf_conv_bn_wgrad_table, round 6): sixteen per launch
+        were 2 .. 8 tiles per workgroup, i.e. prologue + slab write + launch gap."""
         step = N.header_constant('NF_CONV_WGRAD_MAX')
         sum_max = N.header_constant('NF_SLAB_SUM_MAX')
         groups = {}
@@ -236,9 +243,17 @@ class ConvDefer:
         pending, launches = [], 0        # slab-sum jobs of the launches whose scratch buffers are still untouched
         for key, es in groups.items():
             (B, Hh, Ww), I, O, k = key[:4]           # (key[4]: the valid extent of maps in power-of-two storage, one per launch)
-            for k0 in range(0, len(es), step):
-                chunk = es[k0:k0 + step]
-                slabs = _wgrad_slabs(B, Hh, Ww, len(chunk))       # (per launch: one workgroup per compute unit over all its layers)
+            table = WGRAD_TABLE and len(es) >= self.TABLE_MIN
+            per_launch = self.TABLE_MAX if table else step
+            for k0 in range(0, len(es), per_launch):
+                chunk = es[k0:k0 + per_launch]
+                if table:
+                    tiles = (B * Hh * Ww + 127) // 128
+                    # (... and no workgroup with more than 64 tiles: at config 4's literal batch a 16 x 16 layer is 1 024 tiles, which one
+                    #  workgroup per layer would walk in two uneven rounds over the 256 compute units)
+                    slabs = max(1, min(tiles, 128, max(-(-self.TABLE_WGS // len(chunk)), -(-tiles // 64))))
+                else:
+                    slabs = _wgrad_slabs(B, Hh, Ww, len(chunk))       # (per launch: one workgroup per compute unit over all its layers)
                 per = [slabs * e[2].numel() for e in chunk]
                 dev = chunk[0][2].device
                 if pending and (launches % self.SCRATCH_RING == 0 or len(pending) + 2 * len(chunk) > sum_max):
@@ -257,7 +272,11 @@ class ConvDefer:
                     jobs.append((region, g_w, g_w.numel(), g_w.numel(), slabs, False, k * k))
                     if len(e) > 4 and e[4] is not None:      # the layer's bias sums (filled by this very launch) ride the same slab sum
                         jobs.append(e[4])
-                N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
+                if table:
+                    tab = torch.empty(len(chunk) * ctypes.sizeof(ConvBwdDesc), dtype=torch.uint8, device=dev)
+                    N.call('nf_conv_bn_wgrad_table', ctypes.addressof(arr), tab.data_ptr(), len(chunk), slabs, B, I, O, Hh, Ww, k, N.stream())
+                else:
+                    N.call('nf_conv_bn_wgrad_multi', ctypes.addressof(arr), len(chunk), B, I, O, Hh, Ww, k, N.stream())
                 pending += jobs
         if pending:
             _slab_sum_all(pending)
@@ -287,6 +306,7 @@ class ConvDefer:
 # every setting measured slower than the default in rounds 2 - 4 lost its switch, the side-stream overlap of the weight-gradient launches
 # lost its code as well: profiles/r04_overlap_ab.txt)
 WGRAD_FROM_STORE = True
+WGRAD_TABLE = True         # False: at most NF_CONV_WGRAD_MAX layers per weight-gradient launch (the round-2 .. 5 form; tests compare the two)
 CONV_DEFER_ON = True
 CONV_DEFER = ConvDefer()
 

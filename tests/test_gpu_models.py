@@ -236,6 +236,56 @@ def test_trainer_deferred_conv_weight_gradients(pkg, dims, B, K, monkeypatch):
     assert max(queued) == 6 * n_cond, 'weight-gradient passes were not deferred (queue lengths %r)' % (queued, )
 
 
+@pytest.mark.parametrize('dims,B,K', [((3, 32, 32), 8, 5), ((3, 16, 16), 64, 6)])
+def test_weight_gradient_table_launch_matches_the_sixteen_layer_launches(pkg, dims, B, K, monkeypatch):
+    """more than sixteen queued layers of one shape run as ONE launch over a descriptor table in device memory (nf_conv_bn_wgrad_table, round 6:
+    config 4 queues 320 hidden layers per resolution) instead of sixteen per launch (nf_conv_bn_wgrad_multi): same kernels and operands,
+    another number of slabs per layer -- the flat gradient agrees to the rounding of a differently grouped sum, in eager steps and in a
+    captured hipGraph (the table is written by by-value launches: nothing of the host is re-read at replay)."""
+    import copy
+    import importlib
+    from types import SimpleNamespace as NS
+    train = importlib.import_module(pkg.__name__ + '.train')
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    torch.manual_seed(3)
+    net1 = pkg.Glow(dims, 'image', NS(layers=K, mixtures=8)).to(DEV)
+    net2 = copy.deepcopy(net1)
+    y = torch.rand(B, *dims, device=DEV)
+    t1, t2 = train.FlowTrainer(net1, graph=True, warmup=2), train.FlowTrainer(net2, graph=False)
+    calls = {'table': 0, 'multi': 0}
+    real_call = fc.N.call
+
+    def call(name, *a):
+        if name == 'nf_conv_bn_wgrad_table':
+            calls['table'] += 1
+        elif name == 'nf_conv_bn_wgrad_multi':
+            calls['multi'] += 1
+        return real_call(name, *a)
+    monkeypatch.setattr(fc.N, 'call', call)
+    for step in range(5):                                   # steps 0, 1 eager, step 2 captures (+ one eager step), steps 3, 4 replay
+        monkeypatch.setattr(fc, 'WGRAD_TABLE', True)
+        z1, l1 = t1.train_on_batch(y)
+        n_table = calls['table']
+        monkeypatch.setattr(fc, 'WGRAD_TABLE', False)
+        if step == 2:
+            t2.train_on_batch(y)                            # (the capturing call takes one extra eager step on its batch)
+        z2, l2 = t2.train_on_batch(y)
+        assert calls['table'] == n_table, 'the sixteen-layer form launched a table'
+        if step == 0:                                       # ActNorm init by atomics: identical parameters from here on
+            net2.load_state_dict(net1.state_dict())
+            t2.bucket.flat_params.copy_(t1.bucket.flat_params)
+            t2.optim.load_state_dict(t1.optim.state_dict())
+            continue
+        G.assert_close(l1, l2, 1e-5 * max(1.0, abs(float(l2))), what='loss, step %d' % step)
+        scale = float(t2.bucket.flat.abs().max())
+        bad = ((t1.bucket.flat - t2.bucket.flat).abs() > 2e-5 * max(1.0, scale)).float().mean()
+        assert float(bad) <= 2e-3, 'flat gradients differ in %.2e of the entries (step %d)' % (float(bad), step)
+        net2.load_state_dict(net1.state_dict())             # (Adam on rounding-different gradients: re-align the replicas)
+        t2.bucket.flat_params.copy_(t1.bucket.flat_params)
+        t2.optim.load_state_dict(t1.optim.state_dict())
+    assert t1._g_fb is not None and calls['table'] >= 3 and calls['multi'] >= 3, calls
+
+
 @pytest.mark.parametrize('name,dims,datatype,B,K', [('Glow', (2, ), 'density', 4096, 4), ('Glow', (2, ), 'density', 512, 3),
                                                     ('RealNVP', (2, ), 'density', 256, 4), ('MAF', (2, ), 'density', 2048, 3),
                                                     ('Flowpp', (2, ), 'density', 4096, 3), ('Glow', (3, 16, 16), 'image', 8, 2)])
