@@ -1141,6 +1141,8 @@ typedef struct nf_copy_desc {
     int64_t n;
 } nf_copy_desc;
 int nf_multi_copy(const nf_copy_desc* descs, int n_tensors, nf_stream_t stream);
+/* dst[0 .. n) = 0 (the train step's memsets: the flat gradient bucket of main.py:84's optimizer.zero_grad(), the scratch arena)          */
+int nf_zero_fill(float* dst, int64_t n, nf_stream_t stream);
 
 #ifdef __cplusplus
 }

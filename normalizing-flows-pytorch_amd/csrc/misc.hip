@@ -61,6 +61,31 @@ __global__ void __launch_bounds__(NF_BLOCK) k_nll_loss(const float* __restrict__
     if (threadIdx.x == 0) NF_DET_ADD1(nf_ms, loss, -tot / (float)B);
 }
 
+// dst[0 .. n) = 0: the step's two memsets (gradient bucket, scratch arena).  16-byte stores from 2 048 workgroups: 33.5 MB (the CIFAR Glow's
+// bucket) in ~10 us; the framework's fill kernel took 48 us for it (profiles/r06_c4_step_kernels.txt: three fills, 0.145 ms of a 23 ms step).
+__global__ void __launch_bounds__(NF_BLOCK) k_zero_fill(float* __restrict__ dst, int64_t n, int64_t head, int64_t n4) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    if (t < head) dst[t] = 0.f;                                    // (unaligned head, < 4 elements)
+    float4* d4 = reinterpret_cast<float4*>(dst + head);
+    for (int64_t i = t; i < n4; i += stride) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t tail0 = head + 4 * n4;
+    if (t < n - tail0) dst[tail0 + t] = 0.f;
+}
+extern "C" int nf_zero_fill(float* dst, int64_t n, nf_stream_t stream) {
+    if (n < 0 || (dst == nullptr && n > 0)) return NF_E_BADARG;
+    if (n == 0) return 0;
+    const int64_t mis = (int64_t)((reinterpret_cast<uintptr_t>(dst) & 15) / 4);
+    int64_t head = mis ? 4 - mis : 0;
+    if (head > n) head = n;
+    const int64_t n4 = (n - head) / 4;
+    int64_t g = (n4 + NF_BLOCK - 1) / NF_BLOCK;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)g), dim3(NF_BLOCK), 0, (hipStream_t)stream, dst, n, head, n4);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int nf_nll_loss(const float* z, const float* ld, float* loss, int64_t B, int64_t D, nf_stream_t stream) {
     if (B <= 0 || D <= 0) return NF_E_BADARG;
     unsigned g = nf_grid_for(B * D, NF_BLOCK * 8);

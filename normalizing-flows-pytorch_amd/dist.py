@@ -90,7 +90,11 @@ class GradBucket:
         return self.world > 1 or (dist.is_initialized() and os.environ.get('NF_DP_FORCE_COLLECTIVE', '0') == '1')
 
     def zero_(self):
-        self.flat.zero_()
+        if self.flat.is_cuda and self.flat.dtype == torch.float32:
+            from . import _native as N
+            N.call('nf_zero_fill', self.flat.data_ptr(), self.flat.numel(), N.stream())
+        else:
+            self.flat.zero_()
 
     def nbytes(self):
         return self.flat.numel() * self.flat.element_size()

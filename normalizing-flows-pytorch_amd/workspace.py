@@ -33,7 +33,11 @@ class ZeroArena:
             self.zeroed = need
         else:
             self.zeroed = min(need, self.buf.numel())
-            self.buf[:self.zeroed].zero_()
+            if self.buf.is_cuda:
+                from . import _native as N
+                N.call('nf_zero_fill', self.buf.data_ptr(), self.zeroed, N.stream())
+            else:
+                self.buf[:self.zeroed].zero_()
         if _capturing():
             self.captured = True
         self.off = 0
