@@ -227,6 +227,7 @@ class ConvDefer:
 
     TABLE_MIN = 17              # more layers of one shape than the by-value launch takes: ONE launch over a device table of descriptors
     TABLE_MAX = 512             # (x NF_STAT_REPL chains of the ordered mode = its 4 096 turn words)
+    TABLE_TILES = 64            # ... and at most this many 128-pixel tiles per workgroup
     TABLE_WGS = 256             # workgroups the table launch aims at: ONE per layer once there are 256 layers (C4, ms per step at 256 / 512 / 1024 /
                                 # 2048 / 4096: 22.41 / 22.42 / 22.53 / 22.89 / 23.47 -- every extra slab is a 36 KB write, a fold and fewer tiles per prologue)
 
@@ -251,7 +252,7 @@ class ConvDefer:
                     tiles = (B * Hh * Ww + 127) // 128
                     # (... and no workgroup with more than 64 tiles: at config 4's literal batch a 16 x 16 layer is 1 024 tiles, which one
                     #  workgroup per layer would walk in two uneven rounds over the 256 compute units)
-                    slabs = max(1, min(tiles, 128, max(-(-self.TABLE_WGS // len(chunk)), -(-tiles // 64))))
+                    slabs = max(1, min(tiles, 128, max(-(-self.TABLE_WGS // len(chunk)), -(-tiles // self.TABLE_TILES))))
                 else:
                     slabs = _wgrad_slabs(B, Hh, Ww, len(chunk))       # (per launch: one workgroup per compute unit over all its layers)
                 per = [slabs * e[2].numel() for e in chunk]
