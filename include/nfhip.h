@@ -143,7 +143,7 @@ int nf_invconv_weight_bwd(const float* g_W, const float* P, const float* L, cons
 /* the same for up to NF_PLU_MAX_LAYERS layers per launch, one workgroup per layer (an image Glow has 129 of these single-
  * workgroup, latency-bound launches per direction).  forward uses P .. log_s, W, C; backward additionally g_W, g_ld (nullable),
  * g_L, g_U, g_log_s, accumulate, B, pixels.                                                                               */
-#define NF_PLU_MAX_LAYERS 24
+#define NF_PLU_MAX_LAYERS 192     /* (x 128 bytes of descriptor = 24 KB of kernel arguments; see NF_SLAB_SUM_MAX) */
 typedef struct nf_plu_desc {
     const float* P; const float* L; const float* U; const float* L_mask; const float* U_mask; const float* sign_s;
     const float* log_s;
@@ -205,7 +205,7 @@ int nf_glow_head_w_bwd(const float* g_h, const float* g_ld, const float* x, cons
  *   nf_glow_head_w_bwd_params_multi  g_W, g_log_scale, g_bias (+=) of n <= NF_GLOW_HEAD_MULTI_MAX heads of ONE shape in one launch,
  *                                    from the g_h / g_ld / x the caller kept -- where the pass ends, in front of
  *                                    nf_invconv_weight_bwd_multi, which reads g_W.                                              */
-#define NF_GLOW_HEAD_MULTI_MAX 32
+#define NF_GLOW_HEAD_MULTI_MAX 128
 typedef struct nf_glow_head_params_desc {
     const float *g_h, *g_ld, *x, *act_log_scale, *act_bias, *W;
     float *g_log_scale, *g_bias, *g_W;
@@ -575,7 +575,7 @@ int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, int I0, int
  *                             scale channel), one transposed image.
  * dst: nf_conv_weight_pack_images(O, I, ksize) * NF_CONV_PACK_IMAGE_FLOATS floats per weight (0 images = shape not packable).       */
 #define NF_CONV_PACK_IMAGE_FLOATS (3 * 36 * 128)
-#define NF_CONV_PACK_MAX_LAYERS 64
+#define NF_CONV_PACK_MAX_LAYERS 1024
 typedef struct nf_conv_pack_desc {
     const float* w;             /* (O, I, k, k) effective weight */
     float* dst;
@@ -638,7 +638,7 @@ int nf_conv_wgrad_slabs(int64_t B, int H, int W, int n_layers);
 /* The same pass for ANY number of layers of one shape in ONE launch (round 6: config 4 at 64 samples per GPU queues 320 hidden layers per
  * resolution; sixteen per launch were 2 .. 8 tiles per workgroup -- prologue, slab write and launch gap outweighed the tiles).  The
  * descriptors do not fit the kernel arguments: they are written to the device table `table_dev` (n descriptors, caller's scratch) by tiny
- * launches of 21 in front of the pass (by-value arguments: a captured hipGraph replays them without touching host memory) and read
+ * launches of up to 320 in front of the pass (by-value arguments: a captured hipGraph replays them without touching host memory) and read
  * there by the workgroups.  `slabs` workgroups per layer (1 .. 128, <= tiles of 128 pixels); g_weff of each descriptor holds that many.  */
 #define NF_CONV_WGRAD_TABLE_MAX 4096
 int nf_conv_bn_wgrad_table(const nf_conv_bwd_desc* descs, nf_conv_bwd_desc* table_dev, int n, int slabs, int64_t B, int I, int O, int H,
@@ -646,7 +646,9 @@ int nf_conv_bn_wgrad_table(const nf_conv_bwd_desc* descs, nf_conv_bwd_desc* tabl
 
 /* dst[e] (+)= sum_{s < n_slabs} src[s * stride + e], e < n: every slab / replica sum of one conditioner backward in ONE
  * launch (weight-gradient slabs, bias and BatchNorm-parameter replicas).                                                */
-#define NF_SLAB_SUM_MAX 72       /* (72 x 48 bytes of descriptors + the per-job workgroup ranges: under the 4 KB of kernel arguments) */
+#define NF_SLAB_SUM_MAX 1024     /* (1024 x 48 bytes of descriptors + the per-job workgroup ranges = 52 KB of kernel arguments.  Rounds 1 - 5 kept every
+                                  * descriptor array of a multi-launch under 4 KB; gfx950 / ROCm 7.2 takes 64 KB -- measured -- and a launch costs ~4.5 us
+                                  * inside a hipGraph whatever it does: the C4 step went from 693 to ~560 launches by raising these caps alone)            */
 typedef struct nf_slab_sum_desc {
     const float* src;
     float* dst;
@@ -698,7 +700,7 @@ int nf_spectral_weights_bwd(const float* const* W_bar, const float* const* u, co
 /* ---- weight normalisation of many layers per launch  flows/weight_norm.py:35-41 ----------------------------------------
  * w[o, m] = v[o, m] * g[m] / (||v[:, m]|| + eps), m = (input channel, ky, kx) flattened, O = output channels.
  * forward writes w; backward writes (accumulate = 0) or adds to (1) g_v, g_g from g_w.  <= NF_WN_MAX_LAYERS layers per call. */
-#define NF_WN_MAX_LAYERS 64
+#define NF_WN_MAX_LAYERS 896
 typedef struct nf_wn_desc {
     const float* v;        /* (O, M) weight_v */
     const float* g;        /* (M,) weight_g */

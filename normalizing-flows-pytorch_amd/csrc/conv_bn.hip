@@ -1035,9 +1035,9 @@ extern "C" int nf_conv_bn_bwd(const nf_conv_bwd_desc* desc, int64_t B, int I, in
 
 // a chunk of descriptors from the kernel arguments into a device table (nf_conv_bn_wgrad_table): by-value arguments are part of a captured
 // launch, so a hipGraph replays the table's construction without re-reading host memory
-#define NF_CV_DESC_WRITE 21                             // descriptors per writer launch: 21 x 184 B + the tail < 4 KB of kernel arguments
+#define NF_CV_DESC_WRITE 320                            // descriptors per writer launch: 320 x 184 B = 58 KB of kernel arguments (64 KB are taken)
 struct NfCvDescChunk { nf_conv_bwd_desc d[NF_CV_DESC_WRITE]; };
-static_assert(sizeof(NfCvDescChunk) + 16 <= 4096, "kernel-argument segment");
+static_assert(sizeof(NfCvDescChunk) + 16 <= 60 * 1024, "kernel-argument segment");
 __global__ void k_conv_desc_write(NfCvDescChunk m, nf_conv_bwd_desc* __restrict__ dst, int cnt) {
     const unsigned* src = reinterpret_cast<const unsigned*>(&m);
     unsigned* out = reinterpret_cast<unsigned*>(dst);
@@ -1146,10 +1146,11 @@ extern "C" int nf_conv_bn_wgrad_table(const nf_conv_bwd_desc* descs, nf_conv_bwd
 // The grid is ONE dimension cut into per-job ranges (first[j] .. first[j + 1]): a job gets the workgroups ITS size asks for.  (As a
 // (max blocks, jobs) grid a launch that mixed a 387 k-element weight gradient with 79 small jobs started 82 k workgroups, 80 k of them
 // with nothing to do: 43 us per launch in the image Flow++ step.)
-struct NfSlabArgs { nf_slab_sum_desc d[NF_SLAB_SUM_MAX]; unsigned short first[NF_SLAB_SUM_MAX + 1]; int n_jobs; };
+struct NfSlabArgs { nf_slab_sum_desc d[NF_SLAB_SUM_MAX]; unsigned first[NF_SLAB_SUM_MAX + 1]; int n_jobs; };
+static_assert(sizeof(NfSlabArgs) < 60 * 1024, "kernel-argument segment");
 __global__ void __launch_bounds__(NF_BLOCK) k_slab_sum(NfSlabArgs args) {
     int job = 0;
-    for (int step = 64; step > 0; step >>= 1)               // the last job whose first workgroup is <= blockIdx.x
+    for (int step = 1024; step > 0; step >>= 1)             // the last job whose first workgroup is <= blockIdx.x
         if (job + step < args.n_jobs && args.first[job + step] <= blockIdx.x) job += step;
     const nf_slab_sum_desc& d = args.d[job];
     const unsigned local = blockIdx.x - args.first[job], nblk = args.first[job + 1] - args.first[job];
@@ -1195,12 +1196,12 @@ extern "C" int nf_slab_sum(const nf_slab_sum_desc* descs, int n_jobs, nf_stream_
     for (int i = 0; i < n_jobs; ++i) {
         if (descs[i].src == nullptr || descs[i].dst == nullptr || descs[i].n < 0 || descs[i].n_slabs < 0) return NF_E_BADARG;
         args.d[i] = descs[i];
-        args.first[i] = (unsigned short)total;
+        args.first[i] = total;
         unsigned nb = nf_grid_for(descs[i].n > 0 ? descs[i].n : 1);
-        if (nb > 512) nb = 512;                         // (72 jobs x 512 < 65 536: the ranges fit 16 bits; a large job walks with a stride)
+        if (nb > 512) nb = 512;                         // (a large job walks with a stride)
         total += nb;
     }
-    args.first[n_jobs] = (unsigned short)total;
+    args.first[n_jobs] = total;
     args.n_jobs = n_jobs;
     hipLaunchKernelGGL(k_slab_sum, dim3(total), dim3(NF_BLOCK), 0, (hipStream_t)stream, args);
     NF_CHECK_LAUNCH();
