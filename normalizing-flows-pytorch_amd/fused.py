@@ -1678,7 +1678,7 @@ def realnvp_step_vec(z, ld, bn, coupling):
 # ----------------------------------------------------------------------------------------------------------------------
 # weight normalisation of every weight-normed layer of a model in a handful of launches (csrc/weight_norm.hip)
 # ----------------------------------------------------------------------------------------------------------------------
-WN_MAX = 64
+WN_MAX = N.header_constant("NF_WN_MAX_LAYERS")      # layers per weight-norm launch (round 6: 896, one launch for a CIFAR Glow's 966 is two)
 
 
 class _WeightNormMulti(torch.autograd.Function):
