@@ -785,6 +785,168 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
     __syncthreads();                                    // X1 is complete (LDS); the stores to memory travel on their own
 }
 
+// ---- the data gradient of the NEXT step's head in the prologue of the backward launch --------------------------------------------------
+// Backward order: chain launch of step k -> g_h (gradient at the output of head k) -> head k transposed -> g_y of coupling k - 1 ->
+// chain launch of step k - 1.  The middle link was a launch of its own (k_glow_head_w_bwd<PART = 1>: 129 per C4 step, ~6 us each on the
+// serial chain); here the chain launch of step k - 1 computes ITS OWN g_y first: g_y[c][p] = (sum_r W[r][c] g_h[r][p]) / exp(ls[c]) for
+// the full-resolution pixels its tile owns (the same set the forward prologue owns), with the arithmetic of the stand-alone kernel
+// (v_mfma_f32_16x16x4_f32, K ascending, one multiplication by 1 / exp(ls) at the end: bit-identical), written to the cp_g_y buffer
+// and read back by the same workgroup after a barrier.  The parameter sums of head k (g_W, g_log_scale, g_bias) read g_h and x only and
+// stay where they were (k_glow_head_w_params_multi at the end of the pass).
+struct NfCcHeadBwdReq {                                 // what a thread has in flight for the head
+    float w[3];                                         // W elements t, t + 1024, t + 2048
+    float ls;                                           // threads < 64: log_scale of channel t
+    float gv[2][16];                                    // the wave's first TWO work items (all there are at the CIFAR levels): g_h of channel
+};                                                      // 4 q + lk at pixel li -- a load inside the item loop is ~2 us of exposed latency
+// Work items: (16-pixel block, row tile of 16 output channels) -- a 48-channel head on the 4 x 4 level is 8 blocks x 3 row tiles over the
+// sixteen waves, not 8 waves with three tiles each: the fp32 MFMA is the slow pipe (32 cycles per 16 x 16 x 4), four waves share a
+// SIMD's.  KQ = K steps of four input channels (a template parameter: the operand registers), the row tile is a run-time index.
+template <int KQ>
+__device__ __forceinline__ void nf_cc_head_bwd_request(NfCcHeadBwdReq& R, const nf_convnet_bwd_desc& d, const NfSplit& cs, int64_t b0,
+                                                       int fo_lo, int per, int nblk, int64_t B) {
+    const int C = cs.C, P = cs.H * cs.W, RT = (C + 15) >> 4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int e = threadIdx.x + u * NF_CV_THREADS;
+        R.w[u] = e < C * C ? d.hd_W[e] : 0.f;
+    }
+    R.ls = d.hd_ls[threadIdx.x < C ? threadIdx.x : 0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = wid + u * NF_CV_WAVES;
+        const int item = it < nblk * RT ? it : 0, blk = item / RT, sidx = blk / per, rem = blk - sidx * per;
+        const int64_t b = (b0 + sidx) < B ? b0 + sidx : b0;
+        const float* gb = d.hd_g_h + b * cs.n_full + fo_lo * cs.W + (rem << 4) + li;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            R.gv[u][q] = gb[(int64_t)(c < C ? c : 0) * P];
+        }
+    }
+}
+// hv: the results of the wave's first two items, stored to memory by nf_cc_head_bwd_store BEHIND the loads of the first transposed
+// convolution: on gfx9 a store counts in vmcnt like a load and the counter is in order, so a store issued here made every later wait for
+// a load wait for its acknowledgement as well (~1 us; the second item's operands, then the K loop's: 3.6 of 5.1 us at the 4 x 4 level).
+template <int KQ>
+__device__ __forceinline__ void nf_cc_head_bwd(const NfCcHeadBwdReq& R, const nf_convnet_bwd_desc& d, const NfSplit& cs, float* hl,
+                                               int64_t b0, int fo_lo, int per, int nblk, int64_t B, int PXW, int HWh, int sp0,
+                                               float (&hv)[2][4]) {
+    const int C = cs.C, P = cs.H * cs.W, RT = (C + 15) >> 4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+    float* const gx = const_cast<float*>(d.cp_g_y);
+    float* const Ws = hl + NF_CC_HD_WS;                 // W TRANSPOSED: Ws[c][r] = W[r][c]
+    float* const An = hl + NF_CC_HD_AN;
+    float* const G0 = hl + NF_CC_HD_X1;                 // the TRANSFORMED half of the result, [half channel m][tile pixel]: what the first
+    const int lgWf = 31 - __clz(cs.W);                  // transposed convolution reads (the other half is read at the launch's far end)
+    {
+        const float rc = 1.f / (float)C;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = threadIdx.x + u * NF_CV_THREADS;
+            const int er = (int)(((float)e + 0.5f) * rc);
+            if (e < C * C) Ws[(e - er * C) * 65 + er] = R.w[u];
+        }
+    }
+    if (threadIdx.x < 64) An[64 + threadIdx.x] = threadIdx.x < C ? 1.f / expf(R.ls) : 1.f;
+    NF_CC_STAMP(102);
+    __syncthreads();
+    NF_CC_STAMP(103);
+    const int nitem = nblk * RT;
+    // one work item: gv = its operand column (g_h of channel 4 q + lk at pixel li), keep = where the four results wait for their store
+    // (NULL: stored here).  Every LDS read is unconditional (clamped index, then a select): behind a branch each read was a round trip of
+    // its own in front of its MFMA -- twelve in a row, 0.7 us per item.
+    auto run = [&](int item, const float* gv, float* keep) {
+        const int blk = item / RT, rt = item - blk * RT;
+        const int sidx = blk / per, rem = blk - sidx * per;
+        const int64_t b = b0 + sidx;
+        const int p = fo_lo * cs.W + (rem << 4) + li;
+        const int ra = 16 * rt + li;                    // A[i = li][k = lk] = W[c][r]
+        const float* wrow = Ws + min(ra, C - 1) * 65;
+        float av[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) av[q] = wrow[min(4 * q + lk, C - 1)];
+        float sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j] = An[64 + min(16 * rt + 4 * lk + j, C - 1)];
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            const float bv = c < C ? gv[q] : 0.f;       // B[k = lk][j = li] = g_h[c][pixel]
+            const float a = (ra < C && c < C) ? av[q] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
+        }
+        float* gxb = gx + b * cs.n_full + p;
+        const int row = p >> lgWf, xx = p & (cs.W - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 16 * rt + 4 * lk + j;
+            const float v = acc[j] * sc[j];
+            if (keep != nullptr) keep[j] = v;
+            else if (r < C) gxb[(int64_t)r * P] = v;
+            int which, m, sp;                           // (the forward prologue's map: squeeze.py:5-10, 32-44)
+            if (cs.mode == NF_SPLIT_CHANNEL) {
+                const int hc = C >> 1, sel = r >= hc ? 1 : 0;
+                which = sel ^ cs.odd; m = r - sel * hc; sp = p;
+            } else {
+                const int k = 4 * r + 2 * (row & 1) + (xx & 1);
+                const int qd = (k >= C ? 1 : 0) + (k >= 2 * C ? 1 : 0) + (k >= 3 * C ? 1 : 0);
+                const int sel = (qd == 1 || qd == 2) ? 1 : 0;
+                which = sel ^ cs.odd; m = sel ? k - C : (qd == 0 ? k : k - 2 * C);
+                sp = (row >> 1) * cs.w + (xx >> 1);
+            }
+            if (r < C && which == 0) G0[m * PXW + sidx * HWh + (sp - sp0)] = v;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                       // the two items whose operands came with the request
+        const int item = wid + u * NF_CV_WAVES;
+        if (item < nitem && b0 + (item / RT) / per < B) run(item, R.gv[u], hv[u]);      // (wave-uniform)
+    }
+#pragma unroll 1
+    for (int item = wid + 2 * NF_CV_WAVES; item < nitem; item += NF_CV_WAVES) {           // (none at the CIFAR levels)
+        const int blk = item / RT, sidx = blk / per, rem = blk - sidx * per;
+        const int64_t b = b0 + sidx;
+        if (b >= B) continue;                           // (wave-uniform)
+        const float* gb = d.hd_g_h + b * cs.n_full + fo_lo * cs.W + (rem << 4) + li;
+        float gv[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int c = 4 * q + lk;
+            gv[q] = gb[(int64_t)(c < C ? c : 0) * P];
+        }
+        run(item, gv, nullptr);
+    }
+    NF_CC_STAMP(104);
+    // The transformed half travels through LDS: waiting for the stores and reading them back from L2 was ~2 us of the launch's serial
+    // chain.  The other half IS read back from memory, ~40 us later, by the workgroup that wrote it: the barriers' workgroup-scope
+    // release / acquire is all that takes (one CU, one L1).  NOT __threadfence(): an agent-scope release writes the XCD's whole L2
+    // back -- +20 us per launch, measured.  Nor does this barrier wait for the stores (0.6 .. 1.0 us): the LDS writes only.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void nf_cc_head_bwd_store(const float (&hv)[2][4], const nf_convnet_bwd_desc& d, const NfSplit& cs, int64_t b0,
+                                                     int fo_lo, int per, int nblk, int64_t B) {
+    const int C = cs.C, P = cs.H * cs.W, RT = (C + 15) >> 4;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+    float* const gx = const_cast<float*>(d.cp_g_y);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int item = wid + u * NF_CV_WAVES;
+        if (item >= nblk * RT) continue;                // (wave-uniform)
+        const int blk = item / RT, rt = item - blk * RT;
+        const int sidx = blk / per, rem = blk - sidx * per;
+        const int64_t b = b0 + sidx;
+        if (b >= B) continue;
+        float* gxb = gx + b * cs.n_full + fo_lo * cs.W + (rem << 4) + li;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 16 * rt + 4 * lk + j;
+            if (r < C) gxb[(int64_t)r * P] = hv[u][j];
+        }
+    }
+}
+
 // LDS: ONE frame F8 (three bf16 planes) | W8 (three planes; aliased by the K-split exchange and the gather buffer of the grid exchange) |
 //      kc[4][32] | kb[32] | red[2][NPB][32] | tot[64]
 template <int NPB, int NKQ, bool HALO, bool CPL, int FWc, int CSc, bool PK>
@@ -1343,6 +1505,19 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     float gstream_h[2] = {0.f, 0.f};                    // halo rows of the residual stream's gradient (threads < 32 W)
 
     NF_CC_STAMP(64);
+    // ---- the head between this step and the next: its data gradient IS this launch's cp_g_y (nf_cc_head_bwd, above) ----
+    const bool hbw = CPL && d.hd_g_h != nullptr;        // (block-uniform)
+    const int hb_hf = cs.mode == NF_SPLIT_CHECKER ? 2 : 1;
+    const int hb_ns = halo ? 1 : (g.HW < PXW ? PXW >> g.lgHW : 1);
+    const int hb_lo = halo ? hb_hf * y0 : 0, hb_hi = halo ? hb_hf * (y0 + g.TH) : cs.H;
+    const int hb_per = ((hb_hi - hb_lo) * cs.W) >> 4, hb_nblk = hb_ns * hb_per;
+    NfCcHeadBwdReq hbreq;
+    if (hbw) {
+        if (cs.C <= 16) nf_cc_head_bwd_request<4>(hbreq, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);
+        else if (cs.C <= 24) nf_cc_head_bwd_request<6>(hbreq, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);
+        else if (cs.C <= 48) nf_cc_head_bwd_request<12>(hbreq, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);
+        else nf_cc_head_bwd_request<16>(hbreq, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);
+    }
     for (int e = threadIdx.x; e < 3 * NF_CC_FP(g.CS); e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fr = sm + L.FA;                              // ONE frame: G_l is written over G_{l+1} after every wave has left the K loop
     const bool bnv = L.BNV >= 0;                        // block-uniform
@@ -1358,6 +1533,16 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     // ---- the 1 x 1 output convolution, transposed: acc[ic][pixel] = sum_oc W5[oc][ic] g_out[oc][pixel].  No halo: the B operand comes
     //      straight from global memory (a lane's own pixel; 4 x 128-byte segments per K group), K = oc split over the NKQ waves ----
     constexpr bool cpl = CPL;                           // (d.cp_g_y != NULL)
+    NF_CC_STAMP(100);
+    float hbv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (hbw) {                                          // (the weight image and the BatchNorm vectors requested above are in flight)
+        const int hb_sp0 = halo ? y0 * g.W : 0;
+        if (cs.C <= 16) nf_cc_head_bwd<4>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
+        else if (cs.C <= 24) nf_cc_head_bwd<6>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
+        else if (cs.C <= 48) nf_cc_head_bwd<12>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
+        else nf_cc_head_bwd<16>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
+    }
+    NF_CC_STAMP(101);
     const int Ch = O_out >> 1;
     const int lgw = cpl ? 31 - __clz(cs.w) : 0;
     const float ca = cpl ? d.cp_a[0] : 0.f;
@@ -1394,7 +1579,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                     const bool is_s = oc >= Ch;
                     const int m = is_s ? oc - Ch : oc;
                     const int64_t o = b * cs.n_full + nf_cc_half_to_full(cs, 0, m, (int)q, lgw);
-                    const float gy0 = d.cp_g_y[o];
+                    const float gy0 = hbw ? RS[NF_CC_HD_X1 + m * PXW + px] : d.cp_g_y[o];
                     v = gy0;                            // gradient of the shift
                     if (is_s) {                         // cp_out = [exp(s) | tanh(raw)], left by the forward launch
                         const float th = d.cp_out[(b * O_out + oc) * g.HW + q];
@@ -1430,6 +1615,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             }
             if (lane == 0) { red[wid] = acc_a; red[NF_CV_WAVES + wid] = acc_c; }
         }
+        if (hbw) nf_cc_head_bwd_store(hbv, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);      // (behind the K loop's loads: see nf_cc_head_bwd)
     }
 
     float gstream[OWN], own[OWN];
@@ -1883,6 +2069,11 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
     NfCvGeo g;
     const int PX = nf_cc_tile_px(B, H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
+    if (desc->hd_g_h != nullptr) {                      // the next step's head transposed in the prologue (same shapes as the forward's)
+        if (desc->cp_g_y == nullptr || desc->hd_W == nullptr || desc->hd_ls == nullptr || desc->cp_C < 9 || desc->cp_C > 64 ||
+            ((cs.H * cs.W) & 15) != 0 || (H * W > PX && cs.W < 16) || (int64_t)(O_out >> 1) * PX > NF_CC_HD_X1_MAX)
+            return NF_E_BADARG;
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     const bool cp = desc->cp_g_y != nullptr;

@@ -571,8 +571,9 @@ class _GlowHeadW(torch.autograd.Function):
     channels of image data: one MFMA launch per direction (csrc/glow_head_mfma.hip)."""
 
     @staticmethod
-    def forward(ctx, x, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=False):
+    def forward(ctx, x, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=False, bwd_defer=False):
         B, C, H, Wd = x.shape
+        ctx.bwd_defer = bool(bwd_defer)
         h = torch.empty_like(x)
         z1c = torch.empty(_half_shape(x, mode), dtype=x.dtype, device=x.device)
         if defer:
@@ -612,10 +613,17 @@ class _GlowHeadW(torch.autograd.Function):
             # only g_x is on the way of the backward pass: the contractions over the batch (g_W, g_log_scale, g_bias) of all heads of one
             # shape run in one launch where the pass ends -- in front of the PLU backward that reads g_W (fused._PLUWeightsMulti.backward).
             # What they read is kept alive here: g_h, g_ld (nothing writes to a gradient autograd has handed over), x.
-            N.call('nf_glow_head_w_bwd_data', N.ptr(g_h), N.ptr(log_scale), N.ptr(W), N.ptr(g_x), B, C, H, Wd, N.stream())
+            from .fused_conv import CONV_DEFER
+            if ctx.bwd_defer and HEAD_BWD_IN_CHAIN and CONV_DEFER.active:
+                # x is the output of a fused image coupling: g_x is the g_y of that coupling's chain launch, which autograd runs next and
+                # which computes it in its own prologue (csrc/conv_chain.hip: nf_cc_head_bwd) -- no launch here.  Inside a trainer step
+                # only: the flush at the end of the pass performs whatever was not picked up (fused_conv.ConvDefer.flush).
+                PENDING_HEAD_BWD[g_x.data_ptr()] = (g_h, log_scale, W, g_x)
+            else:
+                N.call('nf_glow_head_w_bwd_data', N.ptr(g_h), N.ptr(log_scale), N.ptr(W), N.ptr(g_x), B, C, H, Wd, N.stream())
             ctx.holder.pending.append(((B, C, H, Wd), g_h, g_ld, x, log_scale, bias, W, ctx.sinks[0], ctx.sinks[1], g_W))
             ctx.holder.g_ld[ctx.idx] = g_ld
-            return g_x, g_ld, None, None, g_W, None, None, None, None, None, None
+            return g_x, g_ld, None, None, g_W, None, None, None, None, None, None, None
         if direct:
             p_ls, p_b, g_ls, g_b = ctx.sinks[0].data_ptr(), ctx.sinks[1].data_ptr(), None, None
         else:
@@ -624,10 +632,24 @@ class _GlowHeadW(torch.autograd.Function):
         N.call('nf_glow_head_w_bwd', N.ptr(g_h), N.ptr(g_ld), N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(g_x), p_ls,
                p_b, N.ptr(g_W), B, C, H, Wd, N.stream())
         ctx.holder.g_ld[ctx.idx] = g_ld
-        return g_x, g_ld, g_ls, g_b, g_W, None, None, None, None, None, None
+        return g_x, g_ld, g_ls, g_b, g_W, None, None, None, None, None, None, None
 
 
 HEAD_PARAMS_DEFER = True      # (internal constant: tests flip it to compare the two forms of the head backward)
+HEAD_BWD_IN_CHAIN = True      # (internal: the head's data gradient in the prologue of the previous coupling's backward chain launch)
+PENDING_HEAD_BWD = {}         # address of g_x -> (g_h, log_scale, W, g_x) of a head whose data gradient the next chain launch computes
+
+
+def flush_pending_head_bwd(entry):
+    """the data gradient of a head left to a chain launch (``entry`` of PENDING_HEAD_BWD) on its own kernel after all"""
+    g_h, log_scale, W, g_x = entry
+    B, C, H, Wd = g_x.shape
+    N.call('nf_glow_head_w_bwd_data', N.ptr(g_h), N.ptr(log_scale), N.ptr(W), N.ptr(g_x), B, C, H, Wd, N.stream())
+
+
+def flush_all_pending_head_bwd():
+    while PENDING_HEAD_BWD:
+        flush_pending_head_bwd(PENDING_HEAD_BWD.pop(next(iter(PENDING_HEAD_BWD))))
 
 
 class GlowHeadParamsDesc(ctypes.Structure):
@@ -700,10 +722,12 @@ def glow_head_w_usable(z, mode):
             and bool(N.load().nf_glow_head_w_usable(z.shape[0], z.shape[1], z.shape[2], z.shape[3], int(mode))))
 
 
-def glow_head_w(z, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=False):
+def glow_head_w(z, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=False, bwd_defer=False):
     """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward (weight given) -> conditioning half of the split, fused.
-    defer: no launch -- the caller guarantees that the coupling's chain launch follows and performs it (fused_conv._cn_forward)."""
-    return _GlowHeadW.apply(_contig(z), _owned_ld(ld), log_scale, bias, W, log_s, holder, idx, mode, odd, defer)
+    defer: no launch -- the caller guarantees that the coupling's chain launch follows and performs it (fused_conv._cn_forward).
+    bwd_defer: the caller guarantees that z IS the output of a fused image coupling (fused_conv._FusedConvCoupling) of the same
+    shape: inside a trainer step the backward leaves this head's data gradient to that coupling's backward launch."""
+    return _GlowHeadW.apply(_contig(z), _owned_ld(ld), log_scale, bias, W, log_s, holder, idx, mode, odd, defer, bwd_defer)
 
 
 HEAD_MAX_C = 4

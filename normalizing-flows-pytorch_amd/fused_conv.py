@@ -66,7 +66,7 @@ class ConvNetBwdDesc(ctypes.Structure):
                 ('cp_a', ctypes.c_void_p), ('cp_c', ctypes.c_void_p), ('cp_g_z', ctypes.c_void_p), ('cp_g_out', ctypes.c_void_p),
                 ('cp_g_a', ctypes.c_void_p), ('cp_g_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int),
                 ('cp_C', ctypes.c_int), ('cp_reserved', ctypes.c_int), ('g_gamma', ctypes.c_void_p * 5), ('g_beta', ctypes.c_void_p * 5),
-                ('wpk', ctypes.c_void_p * 6)]
+                ('wpk', ctypes.c_void_p * 6), ('hd_g_h', ctypes.c_void_p), ('hd_W', ctypes.c_void_p), ('hd_ls', ctypes.c_void_p)]
 
 
 class ConvPackDesc(ctypes.Structure):
@@ -287,6 +287,8 @@ class ConvDefer:
         self.layers, self.sums, self.active, self.armed = [], [], False, False
         plu, self.plu_jobs = self.plu_jobs, []
         heads, self.head_jobs = self.head_jobs, []
+        from .functional import flush_all_pending_head_bwd
+        flush_all_pending_head_bwd()            # (a head gradient that no chain launch picked up)
         if heads:
             from .functional import launch_small_head_params
             launch_small_head_params(heads)
@@ -611,6 +613,16 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
             d.cp_a, d.cp_c, d.cp_g_z, d.cp_g_out, d.cp_g_a, d.cp_g_c = a.data_ptr(), c.data_ptr(), g_z.data_ptr(), g_out.data_ptr(), pa, pc
             d.cp_mode, d.cp_odd = ctx.cpl_meta
             d.cp_C = z.shape[1]
+            from . import functional as NF
+            pend = NF.PENDING_HEAD_BWD.pop(g_y.data_ptr(), None)
+            if pend is not None:
+                # g_y has not been computed yet: it is the data gradient of the NEXT step's head, left to this launch's prologue
+                # (functional._GlowHeadW.backward)
+                hg, hls, hW, hgx = pend
+                if hgx.shape == z.shape and hg.shape == z.shape and hg.is_contiguous() and 9 <= z.shape[1] <= 64:
+                    d.hd_g_h, d.hd_W, d.hd_ls = hg.data_ptr(), hW.data_ptr(), hls.data_ptr()
+                else:
+                    NF.flush_pending_head_bwd(pend)
         N.call('nf_convnet_chain_bwd', ctypes.addressof(d), B, I0, O_out, Hh, Ww, int(training), N.stream())
 
     layer(H, O_out, 1, nl - 1, in_=acts[nb - 1], weight=w[nl - 1], g_direct=g_out, gn_out=gn[nb - 1], sum_g=sums[nb - 1, 0],

@@ -359,6 +359,47 @@ def test_cifar_glow_head_parameter_gradients_deferred_or_not(pkg, monkeypatch):
     assert pkg._native.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('B', [16, 5, 64])
+def test_cifar_glow_head_data_gradient_in_the_chain_prologue(pkg, monkeypatch, B):
+    """a trainer step of a (3, 32, 32) Glow with the data gradient of every second and later head of a level computed in the prologue of
+    the previous coupling's backward chain launch (the default) and on its own kernel: same arithmetic in the same order, so in the
+    ordered mode the flat gradient reproduces BIT FOR BIT; the stand-alone kernel must have run for the first head of a level only."""
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    Nn = pkg._native
+    from types import SimpleNamespace as NS
+    outs, counts = [], []
+    y = torch.rand(B, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    torch.manual_seed(2)
+    net = pkg.Glow((3, 32, 32), 'image', NS(layers=3, mixtures=None)).to(DEV)
+    tr = nftrain.FlowTrainer(net, graph=False)
+    tr.train_on_batch(y)                                # data-dependent initialisation
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    was = Nn.deterministic()
+    Nn.deterministic(True)
+    real_call = Nn.call
+    try:
+        for on in (True, False):
+            monkeypatch.setattr(NF, 'HEAD_BWD_IN_CHAIN', on)
+            seen = []
+            monkeypatch.setattr(Nn, 'call', lambda name, *a, _s=seen: (_s.append(name), real_call(name, *a))[1])
+            net.load_state_dict(sd)
+            z, loss = tr._forward_backward(y)
+            torch.cuda.synchronize()
+            monkeypatch.setattr(Nn, 'call', real_call)
+            outs.append((z.detach().clone(), loss.detach().clone(), tr.bucket.flat.detach().clone()))
+            counts.append(seen.count('nf_glow_head_w_bwd_data'))
+            assert not NF.PENDING_HEAD_BWD
+    finally:
+        Nn.deterministic(was)
+    assert counts[1] > 2 * counts[0] > 0, counts       # only the first head of a level (no fused coupling in front of it) keeps its launch
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][2]).all() and float(outs[0][2].abs().max()) > 0
+    assert torch.equal(outs[0][2], outs[1][2]), float((outs[0][2] - outs[1][2]).abs().max())
+    assert Nn.persistent_timeouts() == 0
+
+
 def test_cifar_glow_with_and_without_the_fused_heads(pkg, monkeypatch):
     """a (3, 32, 32) Glow with two steps per level: the fused heads (C = 12, 48) and the fused couplings against the per-layer
     launches -- z, log-det and every parameter gradient of one training-mode pass."""

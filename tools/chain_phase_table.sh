@@ -6,5 +6,5 @@ cd $GRAFT_REPO_ROOT
 python tools/probes/chain_prof.py --build > /dev/null 2>&1
 for shape in "6 12 16 16" "24 48 8 8" "96 192 4 4"; do
   echo "=== level: $shape  (I O H W), B = 64, coupling in the launch, forward + backward"
-  python tools/probes/chain_prof.py $shape 64 --cpl --bwd 2>&1 | grep -v Warning | grep -v amdgpu.ids
+  python tools/probes/chain_prof.py $shape 64 --cpl --bwd $HEAD 2>&1 | grep -v Warning | grep -v amdgpu.ids
 done

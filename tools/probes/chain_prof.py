@@ -39,6 +39,20 @@ if CPL:
     z = torch.randn(B, I // 2, 2 * H, 2 * W, device='cuda')
     a, c = torch.full((1, ), 0.5, device='cuda'), torch.zeros(1, device='cuda')
     BWD = '--bwd' in sys.argv
+    HEAD = '--head' in sys.argv                      # the next step's head transposed in the backward launch's prologue (nf_cc_head_bwd)
+    Cf = I // 2
+    hW, hls = torch.randn(Cf, Cf, device='cuda') / Cf ** 0.5, torch.randn(Cf, device='cuda') * 0.1
+
+    class FakeHead(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y):
+            return y.clone()
+
+        @staticmethod
+        def backward(ctx, g_h):
+            g_x = torch.empty_like(g_h)
+            NF.PENDING_HEAD_BWD[g_x.data_ptr()] = (g_h.contiguous(), hls, hW, g_x)
+            return g_x
     for _ in range(3):
         with torch.set_grad_enabled(BWD):
             zz = z.clone().requires_grad_(BWD)
@@ -46,7 +60,10 @@ if CPL:
             ld = torch.zeros(B, device='cuda')
             y, ld2 = fc.convnet_coupling(net, xx, zz, ld, a, c, N.SPLIT_CHECKER, 0)
             if BWD:
+                if HEAD:
+                    y = FakeHead.apply(y)
                 (y.square().sum() * 1e-3 + ld2.sum()).backward()
+                assert not NF.PENDING_HEAD_BWD
 else:
     with torch.no_grad():
         for _ in range(3):
@@ -73,6 +90,8 @@ if '--bwd' in sys.argv:
               % (l, t[o] - prev, t[o + 1] - t[o], t[o + 2] - t[o + 1], t[o + 3] - t[o + 2], (t[o + 4] - t[o + 3]) if l >= 1 else 0.0,
                  (t[o + 5] - t[o + 4]) if l >= 1 else 0.0))
     print('  conv0^T chunks + stores %.1f' % (t[97] - t[96]))
+    print('  prologue: start -> head (zero, requests) %.1f | head %.1f [W to LDS %.1f | barrier %.1f | items %.1f | barrier %.1f] | 1x1^T %.1f'
+          % (t[100] - t[64], t[101] - t[100], t[102] - t[100], t[103] - t[102], t[104] - t[103], t[101] - t[104], t[65] - t[101]))
 arr = (ctypes.c_longlong * 128)()
 prof.nf_cc_arrive_read(arr)
 G = (B * H * W + (255 if H * W >= 256 else 127)) // (256 if H * W >= 256 else 128)

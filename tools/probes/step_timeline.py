@@ -11,6 +11,15 @@ for e in ev[1:]:
     cur.append(e)
 steps.append(cur)
 print('%d clusters; sizes %s' % (len(steps), [len(s) for s in steps][-8:]))
+if len(steps[-1]) > 2 * len(steps[-2]) and any('k_adam_step' in e[2] for e in steps[-1]):
+    # (the host came back within 200 us: the replays form one cluster -- cut it behind every optimizer launch instead)
+    cut, cur = [], []
+    for e in steps[-1]:
+        cur.append(e)
+        if 'k_adam_step' in e[2]:
+            cut.append(cur); cur = []
+    steps = cut + [cur]
+    print('cut behind k_adam_step: sizes %s' % [len(s) for s in steps][-8:])
 st = steps[-2]
 wall = (max(e[1] for e in st) - st[0][0]) / 1e3
 busy, gaps, end = 0.0, collections.Counter(), st[0][0]
