@@ -716,6 +716,7 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
         An[threadIdx.x] = threadIdx.x < C ? R.an0 : 0.f;
         An[64 + threadIdx.x] = threadIdx.x < C ? expf(R.an1) : 1.f;
     }
+    NF_CC_STAMP(108);
     if (wid == 1 && add_ld) {                           // log-det of the two layers: P (sum log_s - sum ls), one add per owned sample
         float sl = lane < C ? d.hd_log_s[lane] - d.hd_ls[lane] : 0.f;
 #pragma unroll
@@ -723,6 +724,7 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
         if (lane < nsamp && b0 + lane < B) atomicAdd(d.cp_ld + b0 + lane, (float)P * sl);      // (one writer per sample: this workgroup)
     }
     __syncthreads();
+    NF_CC_STAMP(109);
 #pragma unroll 1
     for (int blk = wid; blk < nblk; blk += NF_CV_WAVES) {
         const int sidx = blk / per, rem = blk - sidx * per;
@@ -741,6 +743,7 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        NF_CC_STAMP(111);
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const int c = 4 * q + lk;
@@ -752,6 +755,7 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
                 acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[rt], 0, 0, 0);
             }
         }
+        NF_CC_STAMP(112);
         float* hb = hout + b * cs.n_full + p;
         float* yb = d.cp_y + b * cs.n_full + p;
         float* zb = d.hd_x1 + b * cs.n_half;
@@ -782,6 +786,7 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
                 }
             }
     }
+    NF_CC_STAMP(110);
     __syncthreads();                                    // X1 is complete (LDS); the stores to memory travel on their own
 }
 
@@ -1002,15 +1007,18 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
         else if (cs.C <= 48) nf_cc_head_request<3>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
         else nf_cc_head_request<4>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
     }
+    NF_CC_STAMP(105);
     // ---- zero the frame (halo and padding stay zero for the whole launch) ---------------------------------------------------
     for (int e = threadIdx.x; e < 3 * NF_CC_FP(g.CS); e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fr = sm + L.FA;
+    NF_CC_STAMP(106);
     if (headed) {
         const bool add_ld = !halo || y0 == 0;
         if (cs.C <= 16) nf_cc_head_fwd<1>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
         else if (cs.C <= 48) nf_cc_head_fwd<3>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
         else nf_cc_head_fwd<4>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
     }
+    NF_CC_STAMP(107);
     if (cpl && !headed) {
         // y <- z for this workgroup's (contiguous) samples, whole 16-byte vectors, no index arithmetic; the transformed half is
         // overwritten by the epilogue at the far end of the launch (same workgroup, barriers in between).  Nothing waits for it.

@@ -53,12 +53,20 @@ if CPL:
             g_x = torch.empty_like(g_h)
             NF.PENDING_HEAD_BWD[g_x.data_ptr()] = (g_h.contiguous(), hls, hW, g_x)
             return g_x
+    from types import SimpleNamespace as NS
+    holder = NS(meta={}, pending=[], g_ld={})
+    h_b, h_logs = torch.randn(Cf, device='cuda') * 0.1, torch.randn(Cf, device='cuda') * 0.1
+    FWD_HEAD = HEAD and not BWD and 9 <= Cf <= 64    # the step's head in the forward launch's prologue (nf_cc_head_fwd)
     for _ in range(3):
         with torch.set_grad_enabled(BWD):
             zz = z.clone().requires_grad_(BWD)
-            xx = NF.half_gather(zz.detach(), 1, N.SPLIT_CHECKER, 0)
             ld = torch.zeros(B, device='cuda')
+            if FWD_HEAD:
+                zz, xx, ld = NF.glow_head_w(zz, ld, hls, h_b, hW, h_logs, holder, 0, N.SPLIT_CHECKER, 0, defer=True)
+            else:
+                xx = NF.half_gather(zz.detach(), 1, N.SPLIT_CHECKER, 0)
             y, ld2 = fc.convnet_coupling(net, xx, zz, ld, a, c, N.SPLIT_CHECKER, 0)
+            assert not NF.PENDING_HEADS
             if BWD:
                 if HEAD:
                     y = FakeHead.apply(y)
@@ -81,6 +89,9 @@ for l in range(5):
 print('  1x1 out conv %.1f' % (t[51] - t[50]))
 print('  exchange of layer 1: sync %.1f | combine+publish %.1f | poll %.1f | sync %.1f | merge %.1f' % (
     t[56] - t[12], t[57] - t[56], t[58] - t[57], t[59] - t[58], t[13] - t[59]))
+if '--head' in sys.argv and '--bwd' not in sys.argv:
+    print('  prologue: requests %.1f | zero %.1f | head %.1f [W, An to LDS %.1f | barrier %.1f | blocks %.1f (loads %.1f, normalise + MFMA %.1f, outputs %.1f) | barrier %.1f] | rest of conv0 %.1f'
+          % (t[105] - t[0], t[106] - t[105], t[107] - t[106], t[108] - t[106], t[109] - t[108], t[110] - t[109], t[111] - t[109], t[112] - t[111], t[110] - t[112], t[107] - t[110], t[1] - t[107]))
 if '--bwd' in sys.argv:
     print('backward total %.1f us: zero + 1x1^T (coupling backward on the fly) %.1f' % (t[97] - t[64], t[65] - t[64]))
     for l in range(4, -1, -1):
