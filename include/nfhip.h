@@ -561,7 +561,7 @@ typedef struct nf_convnet_bwd_desc {
     float* g_gamma[5];
     float* g_beta[5];
     const float* wpk[6];        /* optional, as in nf_convnet_desc (the backward reads the transposed images of the same buffers) */
-    /* Optional (hd_g_h != NULL, with the fused coupling, 9 <= cp_C <= 64): the data gradient of the head that FOLLOWS this coupling
+    /* Optional (hd_g_h != NULL, with the fused coupling, 2 <= cp_C <= 4 or 9 <= cp_C <= 64): the data gradient of the head that FOLLOWS this coupling
      * (ActNorm + 1 x 1 convolution of the next step, nf_glow_head_w_bwd_data) in the prologue -- cp_g_y is then WRITTEN first,
      * cp_g_y[c] = (sum_r hd_W[r][c] hd_g_h[r]) / exp(hd_ls[c]) per pixel, and read afterwards as usual.                        */
     const float* hd_g_h;        /* (B, cp_C, Hf, Wf) gradient at that head's output */

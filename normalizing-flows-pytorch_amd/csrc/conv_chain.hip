@@ -664,10 +664,14 @@ struct NfCcHeadReq {                                    // what a thread has in 
     float an0, an1;                                     // threads < 64: bias, log_scale of channel t
     float xv[16];                                       // the wave's first block: channel 4 q + lk at pixel li
 };
-template <int RT>
+// Work items: (row tile of 16 output channels, 16-pixel block), item = rt * nblk + blk, a wave takes items wid, wid + 16, ...: at the
+// CIFAR levels a wave's items share their block (nblk = 8 | 16 | 40), whose pixels are loaded and normalised once.  One accumulator
+// tile per item: the form with all row tiles of a block in registers at once (RT x 4 accumulators, RT x KQ weights, two copies of the
+// pixels) cost the WHOLE kernel ~50 spilled registers -- 1 us per launch even with the head elsewhere (round 6, same-box A/B).
+// KQ = K steps of four input channels (template parameter: the operand registers); the row tile is a run-time index.
+template <int KQ>
 __device__ __forceinline__ void nf_cc_head_request(NfCcHeadReq& R, const nf_convnet_desc& d, const NfSplit& cs, int64_t b0, int fr_lo,
                                                    int per, int nblk, int64_t B) {
-    constexpr int KQ = 4 * RT;
     const int C = cs.C, P = cs.H * cs.W;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
 #pragma unroll
@@ -681,7 +685,7 @@ __device__ __forceinline__ void nf_cc_head_request(NfCcHeadReq& R, const nf_conv
         R.an1 = d.hd_ls[c];
     }
     {
-        const int blk = wid < nblk ? wid : 0, sidx = blk / per, rem = blk - sidx * per;
+        const int blk = wid % nblk, sidx = blk / per, rem = blk - sidx * per;      // (item wid: row tile wid / nblk of block wid % nblk)
         const int64_t b = (b0 + sidx) < B ? b0 + sidx : b0;
         const float* xb = d.hd_x + b * cs.n_full + fr_lo * cs.W + (rem << 4) + li;
 #pragma unroll
@@ -691,12 +695,11 @@ __device__ __forceinline__ void nf_cc_head_request(NfCcHeadReq& R, const nf_conv
         }
     }
 }
-template <int RT>
+template <int KQ>
 __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_convnet_desc& d, const NfSplit& cs, float* hl, int64_t b0,
                                                int nsamp, int fr_lo, int fo_lo, int fo_hi, int per, int nblk, int sp0, int np1,
                                                int64_t B, bool add_ld) {
-    constexpr int KQ = 4 * RT;
-    const int C = cs.C, P = cs.H * cs.W;
+    const int C = cs.C, P = cs.H * cs.W, RT = (C + 15) >> 4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
     float* const hout = const_cast<float*>(d.cp_z);
     float* const Ws = hl + NF_CC_HD_WS;
@@ -725,66 +728,70 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
     }
     __syncthreads();
     NF_CC_STAMP(109);
+    const int nitem = nblk * RT;
+    int have = -1;                                      // the block whose normalised pixels bv holds
+    float bv[KQ];
 #pragma unroll 1
-    for (int blk = wid; blk < nblk; blk += NF_CV_WAVES) {
+    for (int item = wid; item < nitem; item += NF_CV_WAVES) {
+        const int rt = item / nblk, blk = item - rt * nblk;
         const int sidx = blk / per, rem = blk - sidx * per;
         const int64_t b = b0 + sidx;
         if (b >= B) continue;                           // (wave-uniform)
         const int p = fr_lo * cs.W + (rem << 4) + li;
         const int row = p >> lgWf, xx = p & (cs.W - 1);          // (power-of-two maps: no division anywhere in the element loop -- an integer
         const bool own = row >= fo_lo && row < fo_hi;            //  division is ~40 instructions, two per output element were 8 us per launch)
-        const float* xb = d.hd_x + b * cs.n_full + p;
-        float xv[KQ];                                   // the block's pixels: the first block's came with the request
+        if (blk != have) {                              // (wave-uniform) the block's pixels: the first item's came with the request
+            const float* xb = d.hd_x + b * cs.n_full + p;
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const int c = 4 * q + lk;
-            xv[q] = blk == wid ? R.xv[q] : xb[(int64_t)(c < C ? c : 0) * P];
-        }
-        f32x4 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        NF_CC_STAMP(111);
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const int c = 4 * q + lk;
-            const float bv = c < C ? (xv[q] - An[c]) / An[64 + c] : 0.f;     // (the reference's own rounding: a true division)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int r = 16 * rt + li;
-                const float a = (r < C && c < C) ? Ws[r * 65 + c] : 0.f;
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[rt], 0, 0, 0);
+            for (int q = 0; q < KQ; ++q) {
+                const int c = 4 * q + lk, cc = min(c, C - 1);
+                const float x = item == wid ? R.xv[q] : xb[(int64_t)cc * P];
+                const float v = (x - An[cc]) / An[64 + cc];                  // (the reference's own rounding: a true division)
+                bv[q] = c < C ? v : 0.f;
             }
+            have = blk;
+        }
+        // every LDS read unconditional (clamped index, then a select): behind a branch each is a round trip of its own in front of its MFMA
+        const int ra = 16 * rt + li;
+        const float* wrow = Ws + min(ra, C - 1) * 65;
+        float av[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) av[q] = wrow[min(4 * q + lk, C - 1)];
+        NF_CC_STAMP(111);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const float a = (ra < C && 4 * q + lk < C) ? av[q] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[q], acc, 0, 0, 0);
         }
         NF_CC_STAMP(112);
         float* hb = hout + b * cs.n_full + p;
         float* yb = d.cp_y + b * cs.n_full + p;
         float* zb = d.hd_x1 + b * cs.n_half;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {               // D: column = li (pixel), row = 4 lk + j
-                const int r = 16 * rt + 4 * lk + j;
-                if (r < C) {
-                    const float v = acc[rt][j];
-                    if (own) { hb[(int64_t)r * P] = v; yb[(int64_t)r * P] = v; }
-                    // full element (channel r, pixel (row, xx)) -> half `which`, half channel m, half pixel sp  (squeeze.py:5-10, 32-44)
-                    int which, m, sp;
-                    if (cs.mode == NF_SPLIT_CHANNEL) {
-                        const int hc = C >> 1, sel = r >= hc ? 1 : 0;
-                        which = sel ^ cs.odd; m = r - sel * hc; sp = p;
-                    } else {
-                        const int k = 4 * r + 2 * (row & 1) + (xx & 1);
-                        const int qd = (k >= C ? 1 : 0) + (k >= 2 * C ? 1 : 0) + (k >= 3 * C ? 1 : 0);
-                        const int sel = (qd == 1 || qd == 2) ? 1 : 0;
-                        which = sel ^ cs.odd; m = sel ? k - C : (qd == 0 ? k : k - 2 * C);
-                        sp = (row >> 1) * cs.w + (xx >> 1);
-                    }
-                    if (which == 1) {
-                        zb[m * (cs.h * cs.w) + sp] = v;
-                        X1[(sidx * cs.Ch + m) * np1 + (sp - sp0)] = v;
-                    }
+        for (int j = 0; j < 4; ++j) {                   // D: column = li (pixel), row = 4 lk + j
+            const int r = 16 * rt + 4 * lk + j;
+            if (r < C) {
+                const float v = acc[j];
+                if (own) { hb[(int64_t)r * P] = v; yb[(int64_t)r * P] = v; }
+                // full element (channel r, pixel (row, xx)) -> half `which`, half channel m, half pixel sp  (squeeze.py:5-10, 32-44)
+                int which, m, sp;
+                if (cs.mode == NF_SPLIT_CHANNEL) {
+                    const int hc = C >> 1, sel = r >= hc ? 1 : 0;
+                    which = sel ^ cs.odd; m = r - sel * hc; sp = p;
+                } else {
+                    const int k = 4 * r + 2 * (row & 1) + (xx & 1);
+                    const int qd = (k >= C ? 1 : 0) + (k >= 2 * C ? 1 : 0) + (k >= 3 * C ? 1 : 0);
+                    const int sel = (qd == 1 || qd == 2) ? 1 : 0;
+                    which = sel ^ cs.odd; m = sel ? k - C : (qd == 0 ? k : k - 2 * C);
+                    sp = (row >> 1) * cs.w + (xx >> 1);
+                }
+                if (which == 1) {
+                    zb[m * (cs.h * cs.w) + sp] = v;
+                    X1[(sidx * cs.Ch + m) * np1 + (sp - sp0)] = v;
                 }
             }
+        }
     }
     NF_CC_STAMP(110);
     __syncthreads();                                    // X1 is complete (LDS); the stores to memory travel on their own
@@ -830,13 +837,12 @@ __device__ __forceinline__ void nf_cc_head_bwd_request(NfCcHeadBwdReq& R, const 
         }
     }
 }
-// hv: the results of the wave's first two items, stored to memory by nf_cc_head_bwd_store BEHIND the loads of the first transposed
-// convolution: on gfx9 a store counts in vmcnt like a load and the counter is in order, so a store issued here made every later wait for
-// a load wait for its acknowledgement as well (~1 us; the second item's operands, then the K loop's: 3.6 of 5.1 us at the 4 x 4 level).
+// (Carrying the results in registers to store them behind the first K loop's loads -- on gfx9 a store counts in the in-order vmcnt, so
+// later waits for loads include its acknowledgement -- measured nothing here, and eight more live registers through the launch's first
+// phase cost every launch 1.5 us in spills: the stores are issued where the values are produced.)
 template <int KQ>
 __device__ __forceinline__ void nf_cc_head_bwd(const NfCcHeadBwdReq& R, const nf_convnet_bwd_desc& d, const NfSplit& cs, float* hl,
-                                               int64_t b0, int fo_lo, int per, int nblk, int64_t B, int PXW, int HWh, int sp0,
-                                               float (&hv)[2][4]) {
+                                               int64_t b0, int fo_lo, int per, int nblk, int64_t B, int PXW, int HWh, int sp0) {
     const int C = cs.C, P = cs.H * cs.W, RT = (C + 15) >> 4;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
     float* const gx = const_cast<float*>(d.cp_g_y);
@@ -858,10 +864,9 @@ __device__ __forceinline__ void nf_cc_head_bwd(const NfCcHeadBwdReq& R, const nf
     __syncthreads();
     NF_CC_STAMP(103);
     const int nitem = nblk * RT;
-    // one work item: gv = its operand column (g_h of channel 4 q + lk at pixel li), keep = where the four results wait for their store
-    // (NULL: stored here).  Every LDS read is unconditional (clamped index, then a select): behind a branch each read was a round trip of
+    // one work item: gv = its operand column (g_h of channel 4 q + lk at pixel li).  Every LDS read is unconditional (clamped index, then a select): behind a branch each read was a round trip of
     // its own in front of its MFMA -- twelve in a row, 0.7 us per item.
-    auto run = [&](int item, const float* gv, float* keep) {
+    auto run = [&](int item, const float* gv) {
         const int blk = item / RT, rt = item - blk * RT;
         const int sidx = blk / per, rem = blk - sidx * per;
         const int64_t b = b0 + sidx;
@@ -888,8 +893,7 @@ __device__ __forceinline__ void nf_cc_head_bwd(const NfCcHeadBwdReq& R, const nf
         for (int j = 0; j < 4; ++j) {
             const int r = 16 * rt + 4 * lk + j;
             const float v = acc[j] * sc[j];
-            if (keep != nullptr) keep[j] = v;
-            else if (r < C) gxb[(int64_t)r * P] = v;
+            if (r < C) gxb[(int64_t)r * P] = v;
             int which, m, sp;                           // (the forward prologue's map: squeeze.py:5-10, 32-44)
             if (cs.mode == NF_SPLIT_CHANNEL) {
                 const int hc = C >> 1, sel = r >= hc ? 1 : 0;
@@ -907,7 +911,7 @@ __device__ __forceinline__ void nf_cc_head_bwd(const NfCcHeadBwdReq& R, const nf
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                       // the two items whose operands came with the request
         const int item = wid + u * NF_CV_WAVES;
-        if (item < nitem && b0 + (item / RT) / per < B) run(item, R.gv[u], hv[u]);      // (wave-uniform)
+        if (item < nitem && b0 + (item / RT) / per < B) run(item, R.gv[u]);             // (wave-uniform)
     }
 #pragma unroll 1
     for (int item = wid + 2 * NF_CV_WAVES; item < nitem; item += NF_CV_WAVES) {           // (none at the CIFAR levels)
@@ -921,7 +925,7 @@ __device__ __forceinline__ void nf_cc_head_bwd(const NfCcHeadBwdReq& R, const nf
             const int c = 4 * q + lk;
             gv[q] = gb[(int64_t)(c < C ? c : 0) * P];
         }
-        run(item, gv, nullptr);
+        run(item, gv);
     }
     NF_CC_STAMP(104);
     // The transformed half travels through LDS: waiting for the stores and reading them back from L2 was ~2 us of the launch's serial
@@ -930,26 +934,74 @@ __device__ __forceinline__ void nf_cc_head_bwd(const NfCcHeadBwdReq& R, const nf
     // back -- +20 us per launch, measured.  Nor does this barrier wait for the stores (0.6 .. 1.0 us): the LDS writes only.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-__device__ __forceinline__ void nf_cc_head_bwd_store(const float (&hv)[2][4], const nf_convnet_bwd_desc& d, const NfSplit& cs, int64_t b0,
-                                                     int fo_lo, int per, int nblk, int64_t B) {
-    const int C = cs.C, P = cs.H * cs.W, RT = (C + 15) >> 4;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+// The same for a head of 2 .. 4 channels (the first level of an image Glow: (3, 32, 32) under the checkerboard split): no matrix pipe,
+// a thread per pixel with the arithmetic of the stand-alone kernel (k_glow_head_bwd<CT, 1>, csrc/glow_head.hip: fmaf over r ascending, one
+// multiplication by 1 / exp(ls)) -- bit-identical.  hd_W is the weight the forward assembled from the PLU factors and saved.
+template <int CT>
+__device__ __forceinline__ void nf_cc_head_small_bwd(const nf_convnet_bwd_desc& d, const NfSplit& cs, float* hl, int64_t b0, int nsamp,
+                                                     int fo_lo, int fo_hi, int64_t B, int PXW, int HWh, int sp0) {
+    const int P = cs.H * cs.W, npx = (fo_hi - fo_lo) * cs.W;
     float* const gx = const_cast<float*>(d.cp_g_y);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int item = wid + u * NF_CV_WAVES;
-        if (item >= nblk * RT) continue;                // (wave-uniform)
-        const int blk = item / RT, rt = item - blk * RT;
-        const int sidx = blk / per, rem = blk - sidx * per;
-        const int64_t b = b0 + sidx;
-        if (b >= B) continue;
-        float* gxb = gx + b * cs.n_full + fo_lo * cs.W + (rem << 4) + li;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 16 * rt + 4 * lk + j;
-            if (r < C) gxb[(int64_t)r * P] = hv[u][j];
-        }
+    float* const G0 = hl + NF_CC_HD_X1;
+    const int lgWf = 31 - __clz(cs.W);
+    // (the first pixel's operands are requested before the constants: one round trip for both)
+    float G[CT];
+    int idx = threadIdx.x;
+    auto place = [&](int i, int& sidx, int& p, int64_t& base) {
+        sidx = i / npx;
+        p = fo_lo * cs.W + (i - sidx * npx);
+        base = (b0 + sidx) * cs.n_full + p;
+    };
+    int sidx = 0, p = 0;
+    int64_t base = 0;
+    bool ok = idx < nsamp * npx;
+    if (ok) {
+        place(idx, sidx, p, base);
+        ok = b0 + sidx < B;
     }
+#pragma unroll
+    for (int r = 0; r < CT; ++r) G[r] = ok ? d.hd_g_h[base + (int64_t)r * P] : 0.f;
+    float Wm[CT][CT], es[CT];
+#pragma unroll
+    for (int r = 0; r < CT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) Wm[r][c] = d.hd_W[r * CT + c];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) es[c] = 1.f / expf(d.hd_ls[c]);
+    while (idx < nsamp * npx) {                          // (block-uniform trip count up to the ragged end)
+        if (ok) {
+            const int row = p >> lgWf, xx = p & (cs.W - 1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < CT; ++r) a = fmaf(Wm[r][c], G[r], a);
+                const float v = a * es[c];
+                gx[base + (int64_t)c * P] = v;
+                int which, m, sp;                       // (the forward prologue's map: squeeze.py:5-10, 32-44)
+                if (cs.mode == NF_SPLIT_CHANNEL) {
+                    const int hc = CT >> 1, sel = c >= hc ? 1 : 0;
+                    which = sel ^ cs.odd; m = c - sel * hc; sp = p;
+                } else {
+                    const int k = 4 * c + 2 * (row & 1) + (xx & 1);
+                    const int qd = (k >= CT ? 1 : 0) + (k >= 2 * CT ? 1 : 0) + (k >= 3 * CT ? 1 : 0);
+                    const int sel = (qd == 1 || qd == 2) ? 1 : 0;
+                    which = sel ^ cs.odd; m = sel ? k - CT : (qd == 0 ? k : k - 2 * CT);
+                    sp = (row >> 1) * cs.w + (xx >> 1);
+                }
+                if (which == 0) G0[m * PXW + sidx * HWh + (sp - sp0)] = v;
+            }
+        }
+        idx += NF_CV_THREADS;
+        ok = idx < nsamp * npx;
+        if (ok) {
+            place(idx, sidx, p, base);
+            ok = b0 + sidx < B;
+        }
+#pragma unroll
+        for (int r = 0; r < CT; ++r) G[r] = ok ? d.hd_g_h[base + (int64_t)r * P] : 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (the LDS writes; see nf_cc_head_bwd)
 }
 
 // LDS: ONE frame F8 (three bf16 planes) | W8 (three planes; aliased by the K-split exchange and the gather buffer of the grid exchange) |
@@ -992,7 +1044,11 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     constexpr bool cpl = CPL;                           // the coupling rides the epilogue of the output convolution (d.cp_z != NULL)
     NF_CC_STAMP(0);
     // ---- the step's head (ActNorm + 1 x 1 convolution) rides the prologue: its operands are requested before anything else ----------
+#ifdef NF_CC_NO_HEAD_FWD                                 // (probe builds: what the prologue's code costs the rest of the kernel in registers)
+    const bool headed = false;
+#else
     const bool headed = cpl && d.hd_x != nullptr;       // (block-uniform)
+#endif
     // the full-resolution rows of this workgroup: whole samples, or (halo hand-over) its rows of sample b0 plus the rows of the
     // neighbours that its layer-0 frame reads (one half-map row each side: two full rows under the checkerboard split)
     const int hf = cs.mode == NF_SPLIT_CHECKER ? 2 : 1;
@@ -1003,9 +1059,10 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     const int h_sp0 = (h_rlo / hf) * g.W, h_np1 = ((h_rhi - h_rlo) / hf) * g.W;        // X1: half-map pixels sp0 .. sp0 + np1 - 1 per channel
     NfCcHeadReq hreq;
     if (headed) {
-        if (cs.C <= 16) nf_cc_head_request<1>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
-        else if (cs.C <= 48) nf_cc_head_request<3>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
-        else nf_cc_head_request<4>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
+        if (cs.C <= 16) nf_cc_head_request<4>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
+        else if (cs.C <= 24) nf_cc_head_request<6>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
+        else if (cs.C <= 48) nf_cc_head_request<12>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
+        else nf_cc_head_request<16>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
     }
     NF_CC_STAMP(105);
     // ---- zero the frame (halo and padding stay zero for the whole launch) ---------------------------------------------------
@@ -1014,9 +1071,10 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     NF_CC_STAMP(106);
     if (headed) {
         const bool add_ld = !halo || y0 == 0;
-        if (cs.C <= 16) nf_cc_head_fwd<1>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
-        else if (cs.C <= 48) nf_cc_head_fwd<3>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
-        else nf_cc_head_fwd<4>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
+        if (cs.C <= 16) nf_cc_head_fwd<4>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
+        else if (cs.C <= 24) nf_cc_head_fwd<6>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
+        else if (cs.C <= 48) nf_cc_head_fwd<12>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
+        else nf_cc_head_fwd<16>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
     }
     NF_CC_STAMP(107);
     if (cpl && !headed) {
@@ -1520,7 +1578,8 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     const int hb_lo = halo ? hb_hf * y0 : 0, hb_hi = halo ? hb_hf * (y0 + g.TH) : cs.H;
     const int hb_per = ((hb_hi - hb_lo) * cs.W) >> 4, hb_nblk = hb_ns * hb_per;
     NfCcHeadBwdReq hbreq;
-    if (hbw) {
+    const bool hbs = hbw && cs.C <= 4;                  // the thread-per-pixel form of a 2 .. 4 channel head
+    if (hbw && !hbs) {
         if (cs.C <= 16) nf_cc_head_bwd_request<4>(hbreq, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);
         else if (cs.C <= 24) nf_cc_head_bwd_request<6>(hbreq, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);
         else if (cs.C <= 48) nf_cc_head_bwd_request<12>(hbreq, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);
@@ -1542,13 +1601,17 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     //      straight from global memory (a lane's own pixel; 4 x 128-byte segments per K group), K = oc split over the NKQ waves ----
     constexpr bool cpl = CPL;                           // (d.cp_g_y != NULL)
     NF_CC_STAMP(100);
-    float hbv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (hbw) {                                          // (the weight image and the BatchNorm vectors requested above are in flight)
+    if (hbs) {
         const int hb_sp0 = halo ? y0 * g.W : 0;
-        if (cs.C <= 16) nf_cc_head_bwd<4>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
-        else if (cs.C <= 24) nf_cc_head_bwd<6>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
-        else if (cs.C <= 48) nf_cc_head_bwd<12>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
-        else nf_cc_head_bwd<16>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0, hbv);
+        if (cs.C == 3) nf_cc_head_small_bwd<3>(d, cs, RS, b0, hb_ns, hb_lo, hb_hi, g.B, PXW, g.HW, hb_sp0);
+        else if (cs.C == 4) nf_cc_head_small_bwd<4>(d, cs, RS, b0, hb_ns, hb_lo, hb_hi, g.B, PXW, g.HW, hb_sp0);
+        else nf_cc_head_small_bwd<2>(d, cs, RS, b0, hb_ns, hb_lo, hb_hi, g.B, PXW, g.HW, hb_sp0);
+    } else if (hbw) {                                   // (the weight image and the BatchNorm vectors requested above are in flight)
+        const int hb_sp0 = halo ? y0 * g.W : 0;
+        if (cs.C <= 16) nf_cc_head_bwd<4>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0);
+        else if (cs.C <= 24) nf_cc_head_bwd<6>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0);
+        else if (cs.C <= 48) nf_cc_head_bwd<12>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0);
+        else nf_cc_head_bwd<16>(hbreq, d, cs, RS, b0, hb_lo, hb_per, hb_nblk, g.B, PXW, g.HW, hb_sp0);
     }
     NF_CC_STAMP(101);
     const int Ch = O_out >> 1;
@@ -1623,7 +1686,6 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             }
             if (lane == 0) { red[wid] = acc_a; red[NF_CV_WAVES + wid] = acc_c; }
         }
-        if (hbw) nf_cc_head_bwd_store(hbv, d, cs, b0, hb_lo, hb_per, hb_nblk, g.B);      // (behind the K loop's loads: see nf_cc_head_bwd)
     }
 
     float gstream[OWN], own[OWN];
@@ -2078,7 +2140,8 @@ extern "C" int nf_convnet_chain_bwd(const nf_convnet_bwd_desc* desc, int64_t B, 
     const int PX = nf_cc_tile_px(B, H, W);
     if (!nf_cv_geometry(g, B, H, W, 3, PX)) return NF_E_BADARG;
     if (desc->hd_g_h != nullptr) {                      // the next step's head transposed in the prologue (same shapes as the forward's)
-        if (desc->cp_g_y == nullptr || desc->hd_W == nullptr || desc->hd_ls == nullptr || desc->cp_C < 9 || desc->cp_C > 64 ||
+        const bool small = desc->cp_C >= 2 && desc->cp_C <= 4;      // (thread per pixel; hd_W = the weight the forward saved)
+        if (desc->cp_g_y == nullptr || desc->hd_W == nullptr || desc->hd_ls == nullptr || (!small && (desc->cp_C < 9 || desc->cp_C > 64)) ||
             ((cs.H * cs.W) & 15) != 0 || (H * W > PX && cs.W < 16) || (int64_t)(O_out >> 1) * PX > NF_CC_HD_X1_MAX)
             return NF_E_BADARG;
     }

@@ -510,8 +510,9 @@ class _GlowHead(torch.autograd.Function):
     """ActNorm + invertible 1x1 (PLU assembled in-kernel) + conditioning-half gather: 1 launch forward, 2 backward."""
 
     @staticmethod
-    def forward(ctx, z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd):
+    def forward(ctx, z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer=False):
         B, C, H, W = _bchw(z)
+        ctx.bwd_defer = bool(bwd_defer)
         h = torch.empty_like(z)
         z1c = torch.empty(_half_shape(z, mode), dtype=z.dtype, device=z.device)
         Wm = torch.empty((C, C), dtype=z.dtype, device=z.device)
@@ -547,7 +548,11 @@ class _GlowHead(torch.autograd.Function):
         from .fused_conv import CONV_DEFER
         if direct and CONV_DEFER.active and HEAD_PARAMS_DEFER:
             # the data gradient now; the parameter sums of all such heads in one launch at the end-of-pass flush, in front of their PLU jobs
-            N.call('nf_glow_head_bwd_data', N.ptr(g_h), N.ptr(g_z1c), N.ptr(log_scale), N.ptr(Wm), N.ptr(g_z), mode, odd, B, C, H, W, N.stream())
+            if ctx.bwd_defer and HEAD_BWD_IN_CHAIN and g_z1c is None and z.dim() == 4 and 2 <= C <= 4:
+                # (as in _GlowHeadW.backward: the previous step's chain launch computes g_z in its prologue -- nf_cc_head_small_bwd)
+                PENDING_HEAD_BWD[g_z.data_ptr()] = (g_h, log_scale, Wm, g_z, (mode, odd))
+            else:
+                N.call('nf_glow_head_bwd_data', N.ptr(g_h), N.ptr(g_z1c), N.ptr(log_scale), N.ptr(Wm), N.ptr(g_z), mode, odd, B, C, H, W, N.stream())
             CONV_DEFER.head_jobs.append(((mode, B, C, H, W), g_h, g_z1c, g_ld, z, log_scale, bias, Wm, g_ls, g_b, g_W, sum_gld, int(odd)))
         else:
             N.call('nf_glow_head_bwd', N.ptr(g_h), N.ptr(g_z1c), N.ptr(g_ld), N.ptr(z), N.ptr(log_scale), N.ptr(bias),
@@ -562,8 +567,8 @@ class _GlowHead(torch.autograd.Function):
                    N.ptr(sign_s), N.ptr(log_s), N.ptr(sum_gld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_logs), int(direct), C, 1,
                    H * W, N.stream())
         if direct:
-            return (g_z, g_ld) + (None, ) * 11
-        return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None
+            return (g_z, g_ld) + (None, ) * 12
+        return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None, None
 
 
 class _GlowHeadW(torch.autograd.Function):
@@ -618,7 +623,7 @@ class _GlowHeadW(torch.autograd.Function):
                 # x is the output of a fused image coupling: g_x is the g_y of that coupling's chain launch, which autograd runs next and
                 # which computes it in its own prologue (csrc/conv_chain.hip: nf_cc_head_bwd) -- no launch here.  Inside a trainer step
                 # only: the flush at the end of the pass performs whatever was not picked up (fused_conv.ConvDefer.flush).
-                PENDING_HEAD_BWD[g_x.data_ptr()] = (g_h, log_scale, W, g_x)
+                PENDING_HEAD_BWD[g_x.data_ptr()] = (g_h, log_scale, W, g_x, None)
             else:
                 N.call('nf_glow_head_w_bwd_data', N.ptr(g_h), N.ptr(log_scale), N.ptr(W), N.ptr(g_x), B, C, H, Wd, N.stream())
             ctx.holder.pending.append(((B, C, H, Wd), g_h, g_ld, x, log_scale, bias, W, ctx.sinks[0], ctx.sinks[1], g_W))
@@ -637,14 +642,18 @@ class _GlowHeadW(torch.autograd.Function):
 
 HEAD_PARAMS_DEFER = True      # (internal constant: tests flip it to compare the two forms of the head backward)
 HEAD_BWD_IN_CHAIN = True      # (internal: the head's data gradient in the prologue of the previous coupling's backward chain launch)
-PENDING_HEAD_BWD = {}         # address of g_x -> (g_h, log_scale, W, g_x) of a head whose data gradient the next chain launch computes
+PENDING_HEAD_BWD = {}         # address of g_x -> (g_h, log_scale, W, g_x, small) of a head whose data gradient the next chain launch computes
+                              # (small: None for the MFMA head, (mode, odd) for the 2 .. 4 channel head with its saved weight)
 
 
 def flush_pending_head_bwd(entry):
     """the data gradient of a head left to a chain launch (``entry`` of PENDING_HEAD_BWD) on its own kernel after all"""
-    g_h, log_scale, W, g_x = entry
+    g_h, log_scale, W, g_x, small = entry
     B, C, H, Wd = g_x.shape
-    N.call('nf_glow_head_w_bwd_data', N.ptr(g_h), N.ptr(log_scale), N.ptr(W), N.ptr(g_x), B, C, H, Wd, N.stream())
+    if small is None:
+        N.call('nf_glow_head_w_bwd_data', N.ptr(g_h), N.ptr(log_scale), N.ptr(W), N.ptr(g_x), B, C, H, Wd, N.stream())
+    else:
+        N.call('nf_glow_head_bwd_data', N.ptr(g_h), None, N.ptr(log_scale), N.ptr(W), N.ptr(g_x), small[0], small[1], B, C, H, Wd, N.stream())
 
 
 def flush_all_pending_head_bwd():
@@ -733,9 +742,17 @@ def glow_head_w(z, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=
 HEAD_MAX_C = 4
 
 
-def glow_head(z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd):
-    """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward -> conditioning half of the split, fused (C <= 4)."""
-    return _GlowHead.apply(_contig(z), _owned_ld(ld), log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd)
+def glow_head(z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer=False):
+    """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward -> conditioning half of the split, fused (C <= 4).
+    bwd_defer: as in glow_head_w."""
+    return _GlowHead.apply(_contig(z), _owned_ld(ld), log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer)
+
+
+def from_fused_coupling(z):
+    """z is the (first) output of a fused image coupling's chain launch (fused_conv._FusedConvCoupling): the gradient a head returns for it
+    is consumed by that launch's backward and by nothing else"""
+    fn = z.grad_fn
+    return fn is not None and type(fn).__name__ == '_FusedConvCouplingBackward' and not z._backward_hooks and z.is_contiguous()
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -618,8 +618,10 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
             if pend is not None:
                 # g_y has not been computed yet: it is the data gradient of the NEXT step's head, left to this launch's prologue
                 # (functional._GlowHeadW.backward)
-                hg, hls, hW, hgx = pend
-                if hgx.shape == z.shape and hg.shape == z.shape and hg.is_contiguous() and 9 <= z.shape[1] <= 64:
+                hg, hls, hW, hgx, small = pend
+                Cz = z.shape[1]
+                fits = (9 <= Cz <= 64) if small is None else (2 <= Cz <= 4)       # (MFMA head | thread-per-pixel head with its saved weight)
+                if hgx.shape == z.shape and hg.shape == z.shape and hg.is_contiguous() and fits:
                     d.hd_g_h, d.hd_W, d.hd_ls = hg.data_ptr(), hW.data_ptr(), hls.data_ptr()
                 else:
                     NF.flush_pending_head_bwd(pend)

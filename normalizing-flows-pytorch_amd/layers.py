@@ -150,7 +150,6 @@ class Compose(nn.Module):
 
     def forward(self, z, log_df_dz):
         L, n, i = self.layers, len(self.layers), 0
-        chain_y = None                                             # the output of the previous step's fused image coupling, if it was one
         while i < n:
             run = self._realnvp_eval_run_at(i, z) if not torch.is_grad_enabled() else None
             if run is not None:                                    # density evaluation: the run in one launch, no exchange
@@ -203,7 +202,8 @@ class Compose(nn.Module):
                     z, log_df_dz = FUSED.glow_step_vec(z, log_df_dz, a, c, k)        # the whole step: one launch
                 else:
                     h, z1c, log_df_dz = NF.glow_head(z, log_df_dz, a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask,
-                                                     c.U_mask, c.sign_s, c.log_s, k.mode, k.odd)
+                                                     c.U_mask, c.sign_s, c.log_s, k.mode, k.odd,
+                                                     bwd_defer=z.dim() == 4 and NF.from_fused_coupling(z))
                     z, log_df_dz = k.couple(h, z1c, log_df_dz)
                 i += 3
             elif self._glow_step_w_at(i, z):                      # image data, 9 .. 64 channels: head in one MFMA launch
@@ -217,13 +217,12 @@ class Compose(nn.Module):
                 defer = (HEAD_IN_CHAIN and type(k) is AffineCoupling and isinstance(k.net, ConvNet) and z.is_contiguous()
                          and FC.head_in_chain_ok(k.net, z, k.mode))
                 # ... and its data gradient the prologue of the PREVIOUS step's backward chain launch, when z is that launch's output (round 6)
-                bwd_defer = defer and chain_y is z and not z._backward_hooks
+                bwd_defer = defer and NF.from_fused_coupling(z)
                 h, z1c, log_df_dz = NF.glow_head_w(z, log_df_dz, a.log_scale, a.bias, W, c.log_s, holder, idx, k.mode, k.odd, defer=defer,
                                                    bwd_defer=bwd_defer)
                 z, log_df_dz = k.couple(h, z1c, log_df_dz)
                 if defer and NF.flush_pending_head(h):
                     raise RuntimeError('a deferred Glow head was not performed by its coupling launch')
-                chain_y = z if defer else None          # (defer: the coupling took the fused chain launch, z is its output)
                 i += 3
             elif self._flowpp_pair_at(i, z):
                 z, log_df_dz = FUSED.flowpp_coupling_vec(z, log_df_dz, L[i], post=L[i + 1])   # coupling + next ActNorm

@@ -368,7 +368,7 @@ def test_cifar_glow_head_data_gradient_in_the_chain_prologue(pkg, monkeypatch, B
     nftrain = importlib.import_module(pkg.__name__ + '.train')
     Nn = pkg._native
     from types import SimpleNamespace as NS
-    outs, counts = [], []
+    outs, counts, small = [], [], []
     y = torch.rand(B, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
     torch.manual_seed(2)
     net = pkg.Glow((3, 32, 32), 'image', NS(layers=3, mixtures=None)).to(DEV)
@@ -390,10 +390,12 @@ def test_cifar_glow_head_data_gradient_in_the_chain_prologue(pkg, monkeypatch, B
             monkeypatch.setattr(Nn, 'call', real_call)
             outs.append((z.detach().clone(), loss.detach().clone(), tr.bucket.flat.detach().clone()))
             counts.append(seen.count('nf_glow_head_w_bwd_data'))
+            small.append(seen.count('nf_glow_head_bwd_data'))
             assert not NF.PENDING_HEAD_BWD
     finally:
         Nn.deterministic(was)
     assert counts[1] > 2 * counts[0] > 0, counts       # only the first head of a level (no fused coupling in front of it) keeps its launch
+    assert small[1] == 3 and small[0] == 1, small      # ... the (3, 32, 32) level's thread-per-pixel heads as well (nf_cc_head_small_bwd)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.isfinite(outs[0][2]).all() and float(outs[0][2].abs().max()) > 0
     assert torch.equal(outs[0][2], outs[1][2]), float((outs[0][2] - outs[1][2]).abs().max())
