@@ -520,6 +520,15 @@ typedef struct nf_convnet_desc {
     const float* hd_W;        /* (cp_C, cp_C) */
     const float* hd_log_s;    /* (cp_C,) log |diagonal of U| of the PLU factors */
     float* hd_x1;             /* (B, I0, H, W) written */
+    /* ... of 2 <= cp_C <= 4 channels (hd_W == NULL): the weight is assembled in the launch from its PLU factors, as nf_glow_head_fwd
+     * does, and saved to hs_Wout for the backward pass                                                                          */
+    const float* hs_P;        /* (cp_C, cp_C) each: P, L, U, L_mask, U_mask; (cp_C,) sign_s */
+    const float* hs_L;
+    const float* hs_U;
+    const float* hs_Lm;
+    const float* hs_Um;
+    const float* hs_sign;
+    float* hs_Wout;           /* (cp_C, cp_C) written, or NULL */
 } nf_convnet_desc;
 int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W);
 int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training, float bn_eps,

@@ -25,6 +25,7 @@
 NF_DET_STATE(nf_ccd)
 NF_DET_HOST_API(nf_ccd)
 #include "nf_bf16x3.h"
+#include "nf_small_plu.h"
 
 #define NF_CC_NL 6
 #define NF_CC_NB 5
@@ -797,6 +798,94 @@ __device__ __forceinline__ void nf_cc_head_fwd(const NfCcHeadReq& R, const nf_co
     __syncthreads();                                    // X1 is complete (LDS); the stores to memory travel on their own
 }
 
+// The same for a head of 2 .. 4 channels (the first level of an image Glow: (3, 32, 32) under the checkerboard split): a thread per
+// pixel with the arithmetic of the stand-alone kernel (k_glow_head_fwd<CT>, csrc/glow_head.hip: the weight assembled from its PLU factors
+// by every thread, a true division, fmaf over c ascending, the log-det term summed in channel order) -- bit-identical.  The assembled
+// weight is saved for the backward pass by thread 0 of workgroup 0 (hs_Wout).
+template <int CT>
+__device__ __forceinline__ void nf_cc_head_small_fwd(const nf_convnet_desc& d, const NfSplit& cs, float* hl, int64_t b0, int nsamp,
+                                                     int fr_lo, int fr_hi, int fo_lo, int fo_hi, int sp0, int np1, int64_t B, bool add_ld) {
+    const int P = cs.H * cs.W, npx = (fr_hi - fr_lo) * cs.W;
+    float* const hout = const_cast<float*>(d.cp_z);
+    float* const X1 = hl + NF_CC_HD_X1;
+    const int lgWf = 31 - __clz(cs.W);
+    int idx = threadIdx.x, sidx = 0, p = 0;
+    int64_t base = 0;
+    auto place = [&](int i) {
+        sidx = i / npx;
+        p = fr_lo * cs.W + (i - sidx * npx);
+        base = (b0 + sidx) * cs.n_full + p;
+    };
+    bool ok = idx < nsamp * npx;
+    if (ok) {
+        place(idx);
+        ok = b0 + sidx < B;
+    }
+    float zr[CT];                                       // (the first pixel's operands are requested before the constants)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) zr[c] = ok ? d.hd_x[base + (int64_t)c * P] : 0.f;
+    float Wm[CT][CT], es[CT], bb[CT];
+    nf_small_plu<CT>(d.hs_P, d.hs_L, d.hs_U, d.hs_Lm, d.hs_Um, d.hs_sign, d.hd_log_s, Wm);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        es[c] = expf(d.hd_ls[c]);
+        bb[c] = d.hd_bias[c];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.hs_Wout != nullptr) {
+#pragma unroll
+        for (int r = 0; r < CT; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) d.hs_Wout[r * CT + c] = Wm[r][c];
+    }
+    if (add_ld && threadIdx.x >= NF_WAVE && threadIdx.x < NF_WAVE + nsamp && b0 + (threadIdx.x - NF_WAVE) < B) {
+        float dld = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) dld += d.hd_log_s[c] - d.hd_ls[c];                       // modules.py:249, :480
+        atomicAdd(d.cp_ld + b0 + (threadIdx.x - NF_WAVE), dld * (float)P);                     // (one writer per sample: this workgroup)
+    }
+    while (idx < nsamp * npx) {
+        if (ok) {
+            const int row = p >> lgWf, xx = p & (cs.W - 1);
+            const bool own = row >= fo_lo && row < fo_hi;
+            float zn[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) zn[c] = (zr[c] - bb[c]) / es[c];                      // modules.py:246
+            float* zb = d.hd_x1 + (b0 + sidx) * cs.n_half;
+#pragma unroll
+            for (int r = 0; r < CT; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) a = fmaf(Wm[r][c], zn[c], a);                     // modules.py:477
+                if (own) { hout[base + (int64_t)r * P] = a; d.cp_y[base + (int64_t)r * P] = a; }
+                int which, m, sp;                       // (squeeze.py:5-10, 32-44)
+                if (cs.mode == NF_SPLIT_CHANNEL) {
+                    const int hc = CT >> 1, sel = r >= hc ? 1 : 0;
+                    which = sel ^ cs.odd; m = r - sel * hc; sp = p;
+                } else {
+                    const int k = 4 * r + 2 * (row & 1) + (xx & 1);
+                    const int qd = (k >= CT ? 1 : 0) + (k >= 2 * CT ? 1 : 0) + (k >= 3 * CT ? 1 : 0);
+                    const int sel = (qd == 1 || qd == 2) ? 1 : 0;
+                    which = sel ^ cs.odd; m = sel ? k - CT : (qd == 0 ? k : k - 2 * CT);
+                    sp = (row >> 1) * cs.w + (xx >> 1);
+                }
+                if (which == 1) {
+                    zb[m * (cs.h * cs.w) + sp] = a;
+                    X1[(sidx * cs.Ch + m) * np1 + (sp - sp0)] = a;
+                }
+            }
+        }
+        idx += NF_CV_THREADS;
+        ok = idx < nsamp * npx;
+        if (ok) {
+            place(idx);
+            ok = b0 + sidx < B;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) zr[c] = ok ? d.hd_x[base + (int64_t)c * P] : 0.f;
+    }
+    __syncthreads();                                    // X1 is complete (LDS); the stores to memory travel on their own
+}
+
 // ---- the data gradient of the NEXT step's head in the prologue of the backward launch --------------------------------------------------
 // Backward order: chain launch of step k -> g_h (gradient at the output of head k) -> head k transposed -> g_y of coupling k - 1 ->
 // chain launch of step k - 1.  The middle link was a launch of its own (k_glow_head_w_bwd<PART = 1>: 129 per C4 step, ~6 us each on the
@@ -1057,8 +1146,9 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     const int h_rlo = halo ? max(h_olo - hf, 0) : 0, h_rhi = halo ? min(h_ohi + hf, cs.H) : cs.H;
     const int h_per = ((h_rhi - h_rlo) * cs.W) >> 4, h_nblk = h_ns * h_per;
     const int h_sp0 = (h_rlo / hf) * g.W, h_np1 = ((h_rhi - h_rlo) / hf) * g.W;        // X1: half-map pixels sp0 .. sp0 + np1 - 1 per channel
+    const bool hsmall = headed && cs.C <= 4;            // the thread-per-pixel form of a 2 .. 4 channel head
     NfCcHeadReq hreq;
-    if (headed) {
+    if (headed && !hsmall) {
         if (cs.C <= 16) nf_cc_head_request<4>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
         else if (cs.C <= 24) nf_cc_head_request<6>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
         else if (cs.C <= 48) nf_cc_head_request<12>(hreq, d, cs, b0, h_rlo, h_per, h_nblk, g.B);
@@ -1069,7 +1159,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     for (int e = threadIdx.x; e < 3 * NF_CC_FP(g.CS); e += NF_CV_THREADS) sm[L.FA + e] = 0.f;
     float* Fr = sm + L.FA;
     NF_CC_STAMP(106);
-    if (headed) {
+    if (hsmall) {
+        const bool add_ld = !halo || y0 == 0;
+        if (cs.C == 3) nf_cc_head_small_fwd<3>(d, cs, RS, b0, h_ns, h_rlo, h_rhi, h_olo, h_ohi, h_sp0, h_np1, g.B, add_ld);
+        else if (cs.C == 4) nf_cc_head_small_fwd<4>(d, cs, RS, b0, h_ns, h_rlo, h_rhi, h_olo, h_ohi, h_sp0, h_np1, g.B, add_ld);
+        else nf_cc_head_small_fwd<2>(d, cs, RS, b0, h_ns, h_rlo, h_rhi, h_olo, h_ohi, h_sp0, h_np1, g.B, add_ld);
+    } else if (headed) {
         const bool add_ld = !halo || y0 == 0;
         if (cs.C <= 16) nf_cc_head_fwd<4>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
         else if (cs.C <= 24) nf_cc_head_fwd<6>(hreq, d, cs, RS, b0, h_ns, h_rlo, h_olo, h_ohi, h_per, h_nblk, h_sp0, h_np1, g.B, add_ld);
@@ -2066,9 +2161,13 @@ extern "C" int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int 
         if (!nf_cc_coupling_split(cs, desc->cp_mode, desc->cp_odd, desc->cp_C, I0, O_out, H, W)) return NF_E_BADARG;
     }
     if (desc->hd_x != nullptr) {                        // the step's head in the prologue: needs the coupling, 9 .. 64 channels, 16-pixel blocks
-        if (desc->cp_z == nullptr || desc->cp_inverse || desc->hd_ls == nullptr || desc->hd_bias == nullptr || desc->hd_W == nullptr ||
-            desc->hd_log_s == nullptr || desc->hd_x1 == nullptr || desc->hd_x1 != desc->x || desc->cp_C < 9 || desc->cp_C > 64 ||
-            ((cs.H * cs.W) & 15) != 0)
+        const bool small = desc->cp_C >= 2 && desc->cp_C <= 4;      // thread per pixel, the weight assembled from its PLU factors
+        if (desc->cp_z == nullptr || desc->cp_inverse || desc->hd_ls == nullptr || desc->hd_bias == nullptr ||
+            desc->hd_log_s == nullptr || desc->hd_x1 == nullptr || desc->hd_x1 != desc->x || ((cs.H * cs.W) & 15) != 0)
+            return NF_E_BADARG;
+        if (small ? (desc->hs_P == nullptr || desc->hs_L == nullptr || desc->hs_U == nullptr || desc->hs_Lm == nullptr ||
+                     desc->hs_Um == nullptr || desc->hs_sign == nullptr)
+                  : (desc->hd_W == nullptr || desc->cp_C < 9 || desc->cp_C > 64))
             return NF_E_BADARG;
     }
     NfCvGeo g;

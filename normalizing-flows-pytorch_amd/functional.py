@@ -510,15 +510,19 @@ class _GlowHead(torch.autograd.Function):
     """ActNorm + invertible 1x1 (PLU assembled in-kernel) + conditioning-half gather: 1 launch forward, 2 backward."""
 
     @staticmethod
-    def forward(ctx, z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer=False):
+    def forward(ctx, z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer=False, defer=False):
         B, C, H, W = _bchw(z)
         ctx.bwd_defer = bool(bwd_defer)
         h = torch.empty_like(z)
         z1c = torch.empty(_half_shape(z, mode), dtype=z.dtype, device=z.device)
         Wm = torch.empty((C, C), dtype=z.dtype, device=z.device)
-        N.call('nf_glow_head_fwd', N.ptr(z), N.ptr(log_scale), N.ptr(bias), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask),
-               N.ptr(U_mask), N.ptr(sign_s), N.ptr(log_s), N.ptr(h), N.ptr(z1c), N.ptr(Wm), N.ptr(ld), mode, int(odd), B,
-               C, H, W, N.stream())
+        if defer:
+            # (as in _GlowHeadW.forward: the coupling's chain launch performs this head in its prologue -- nf_cc_head_small_fwd)
+            PENDING_HEADS[h.data_ptr()] = (z, log_scale, bias, None, log_s, h, z1c, ld, mode, int(odd), (P, L, U, L_mask, U_mask, sign_s, Wm))
+        else:
+            N.call('nf_glow_head_fwd', N.ptr(z), N.ptr(log_scale), N.ptr(bias), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(L_mask),
+                   N.ptr(U_mask), N.ptr(sign_s), N.ptr(log_s), N.ptr(h), N.ptr(z1c), N.ptr(Wm), N.ptr(ld), mode, int(odd), B,
+                   C, H, W, N.stream())
         ctx.save_for_backward(z, log_scale, bias, Wm, P, L, U, L_mask, U_mask, sign_s, log_s)
         ctx.meta = (mode, int(odd))
         ctx.sinks = _sinks(log_scale, bias, L, U, log_s)
@@ -567,8 +571,8 @@ class _GlowHead(torch.autograd.Function):
                    N.ptr(sign_s), N.ptr(log_s), N.ptr(sum_gld), N.ptr(g_L), N.ptr(g_U), N.ptr(g_logs), int(direct), C, 1,
                    H * W, N.stream())
         if direct:
-            return (g_z, g_ld) + (None, ) * 12
-        return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None, None
+            return (g_z, g_ld) + (None, ) * 13
+        return g_z, g_ld, g_ls, g_b, None, g_L, g_U, None, None, None, g_logs, None, None, None, None
 
 
 class _GlowHeadW(torch.autograd.Function):
@@ -584,7 +588,7 @@ class _GlowHeadW(torch.autograd.Function):
         if defer:
             # the launch is left to the coupling's chain kernel, whose prologue does this head's work (csrc/conv_chain.hip:
             # nf_cc_head_fwd): it finds the operands under the address of h, which it receives as its z
-            PENDING_HEADS[h.data_ptr()] = (x, log_scale, bias, W, log_s, h, z1c, ld, mode, int(odd))
+            PENDING_HEADS[h.data_ptr()] = (x, log_scale, bias, W, log_s, h, z1c, ld, mode, int(odd), None)
         else:
             N.call('nf_glow_head_w_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(log_s), N.ptr(h), N.ptr(z1c),
                    N.ptr(ld), mode, int(odd), B, C, H, Wd, N.stream())
@@ -719,10 +723,15 @@ def flush_pending_head(h):
     pend = PENDING_HEADS.pop(h.data_ptr(), None)
     if pend is None:
         return False
-    x, log_scale, bias, W, log_s, h_, z1c, ld, mode, odd = pend
+    x, log_scale, bias, W, log_s, h_, z1c, ld, mode, odd, small = pend
     B, C, H, Wd = x.shape
-    N.call('nf_glow_head_w_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(log_s), N.ptr(h_), N.ptr(z1c), N.ptr(ld), mode,
-           odd, B, C, H, Wd, N.stream())
+    if small is None:
+        N.call('nf_glow_head_w_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(W), N.ptr(log_s), N.ptr(h_), N.ptr(z1c), N.ptr(ld), mode,
+               odd, B, C, H, Wd, N.stream())
+    else:
+        P, L, U, Lm, Um, sign_s, Wm = small
+        N.call('nf_glow_head_fwd', N.ptr(x), N.ptr(log_scale), N.ptr(bias), N.ptr(P), N.ptr(L), N.ptr(U), N.ptr(Lm), N.ptr(Um), N.ptr(sign_s),
+               N.ptr(log_s), N.ptr(h_), N.ptr(z1c), N.ptr(Wm), N.ptr(ld), mode, odd, B, C, H, Wd, N.stream())
     return True
 
 
@@ -742,10 +751,10 @@ def glow_head_w(z, ld, log_scale, bias, W, log_s, holder, idx, mode, odd, defer=
 HEAD_MAX_C = 4
 
 
-def glow_head(z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer=False):
+def glow_head(z, ld, log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer=False, defer=False):
     """(h, z1c, ld): ActNorm.forward -> InvertibleConv1x1.forward -> conditioning half of the split, fused (C <= 4).
-    bwd_defer: as in glow_head_w."""
-    return _GlowHead.apply(_contig(z), _owned_ld(ld), log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer)
+    defer, bwd_defer: as in glow_head_w."""
+    return _GlowHead.apply(_contig(z), _owned_ld(ld), log_scale, bias, P, L, U, L_mask, U_mask, sign_s, log_s, mode, odd, bwd_defer, defer)
 
 
 def from_fused_coupling(z):

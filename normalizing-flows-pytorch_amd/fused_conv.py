@@ -52,7 +52,9 @@ class ConvNetDesc(ctypes.Structure):
                 ('cp_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int), ('cp_C', ctypes.c_int),
                 ('cp_inverse', ctypes.c_int), ('wpk', ctypes.c_void_p * 6),
                 ('hd_x', ctypes.c_void_p), ('hd_ls', ctypes.c_void_p), ('hd_bias', ctypes.c_void_p), ('hd_W', ctypes.c_void_p),
-                ('hd_log_s', ctypes.c_void_p), ('hd_x1', ctypes.c_void_p)]
+                ('hd_log_s', ctypes.c_void_p), ('hd_x1', ctypes.c_void_p),
+                ('hs_P', ctypes.c_void_p), ('hs_L', ctypes.c_void_p), ('hs_U', ctypes.c_void_p), ('hs_Lm', ctypes.c_void_p),
+                ('hs_Um', ctypes.c_void_p), ('hs_sign', ctypes.c_void_p), ('hs_Wout', ctypes.c_void_p)]
 
 
 class ConvNetBwdDesc(ctypes.Structure):
@@ -438,12 +440,15 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
             if pend is not None:
                 # the step's ActNorm + 1 x 1 convolution were left to this launch (functional._GlowHeadW.forward(defer=True)): z is the
                 # head's OUTPUT buffer, x its conditioning half -- both written by the prologue
-                hx, hls, hb, hW, hlog_s, h_, z1c_, ld_, hmode, hodd = pend
+                hx, hls, hb, hW, hlog_s, h_, z1c_, ld_, hmode, hodd, hsmall = pend
                 if (h_.data_ptr() == z.data_ptr() and z1c_.data_ptr() == x.data_ptr() and ld_.data_ptr() == ld.data_ptr() and not inverse
                         and (hmode, hodd) == (int(mode), int(odd))):
-                    d.hd_x, d.hd_ls, d.hd_bias, d.hd_W, d.hd_log_s = (hx.data_ptr(), hls.data_ptr(), hb.data_ptr(), hW.data_ptr(),
-                                                                      hlog_s.data_ptr())
+                    d.hd_x, d.hd_ls, d.hd_bias, d.hd_log_s = hx.data_ptr(), hls.data_ptr(), hb.data_ptr(), hlog_s.data_ptr()
                     d.hd_x1 = x.data_ptr()
+                    if hsmall is None:
+                        d.hd_W = hW.data_ptr()
+                    else:                      # 2 .. 4 channels: the weight is assembled in the launch from its PLU factors
+                        (d.hs_P, d.hs_L, d.hs_U, d.hs_Lm, d.hs_Um, d.hs_sign, d.hs_Wout) = [t.data_ptr() for t in hsmall]
                 else:                          # (not the tensors this launch works on: the head runs on its own kernel first)
                     NF.PENDING_HEADS[z.data_ptr()] = pend
                     NF.flush_pending_head(z)
@@ -712,7 +717,7 @@ def head_in_chain_ok(net, z, mode):
     if not coupling_fusable(net, z, mode):
         return False
     B, C, Hf, Wf = z.shape
-    if C < 9 or C > 64 or (Hf * Wf) % 16:
+    if not (2 <= C <= 4 or 9 <= C <= 64) or (Hf * Wf) % 16:      # (thread-per-pixel head | MFMA head)
         return False
     I0, Hh, Ww = (C // 2, Hf, Wf) if mode == N.SPLIT_CHANNEL else (2 * C, Hf // 2, Wf // 2)
     blocks = int(N.load().nf_convnet_chain_blocks(B, I0, 2 * I0, Hh, Ww))

@@ -201,10 +201,16 @@ class Compose(nn.Module):
                 if k.mode == N.SPLIT_1D and isinstance(k.net, MLP) and FUSED.glow_step_vec_usable(z, k.net):
                     z, log_df_dz = FUSED.glow_step_vec(z, log_df_dz, a, c, k)        # the whole step: one launch
                 else:
+                    # (image data: the head rides the chain launches of the fused couplings on either side, as the MFMA head below)
+                    from . import fused_conv as FC
+                    defer = (HEAD_IN_CHAIN and z.dim() == 4 and type(k) is AffineCoupling and isinstance(k.net, ConvNet)
+                             and z.is_contiguous() and FC.head_in_chain_ok(k.net, z, k.mode))
                     h, z1c, log_df_dz = NF.glow_head(z, log_df_dz, a.log_scale, a.bias, c.P, c.L, c.U, c.L_mask,
                                                      c.U_mask, c.sign_s, c.log_s, k.mode, k.odd,
-                                                     bwd_defer=z.dim() == 4 and NF.from_fused_coupling(z))
+                                                     bwd_defer=defer and NF.from_fused_coupling(z), defer=defer)
                     z, log_df_dz = k.couple(h, z1c, log_df_dz)
+                    if defer and NF.flush_pending_head(h):
+                        raise RuntimeError('a deferred Glow head was not performed by its coupling launch')
                 i += 3
             elif self._glow_step_w_at(i, z):                      # image data, 9 .. 64 channels: head in one MFMA launch
                 a, c, k = L[i], L[i + 1], L[i + 2]

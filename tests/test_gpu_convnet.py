@@ -402,6 +402,49 @@ def test_cifar_glow_head_data_gradient_in_the_chain_prologue(pkg, monkeypatch, B
     assert Nn.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('B', [16, 5])
+def test_cifar_glow_heads_in_the_forward_chain_prologue(pkg, monkeypatch, B):
+    """the forward of every head (the thread-per-pixel form on 3 channels, the MFMA form on 12 .. 48) in the prologue of its coupling's
+    chain launch (the default) and on its own kernel: the same arithmetic in the same order -- z BITWISE in the ordered mode, the loss
+    and the gradients to the rounding of the log-det sums (the prologue adds a head's term per sample in a different order)."""
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    layers_mod = importlib.import_module(pkg.__name__ + '.layers')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    Nn = pkg._native
+    from types import SimpleNamespace as NS
+    outs, counts = [], []
+    y = torch.rand(B, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    torch.manual_seed(3)
+    net = pkg.Glow((3, 32, 32), 'image', NS(layers=3, mixtures=None)).to(DEV)
+    tr = nftrain.FlowTrainer(net, graph=False)
+    tr.train_on_batch(y)                                # data-dependent initialisation
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    was = Nn.deterministic()
+    Nn.deterministic(True)
+    real_call = Nn.call
+    try:
+        for on in (True, False):
+            monkeypatch.setattr(layers_mod, 'HEAD_IN_CHAIN', on)
+            seen = []
+            monkeypatch.setattr(Nn, 'call', lambda name, *a, _s=seen: (_s.append(name), real_call(name, *a))[1])
+            net.load_state_dict(sd)
+            z, loss = tr._forward_backward(y)
+            torch.cuda.synchronize()
+            monkeypatch.setattr(Nn, 'call', real_call)
+            outs.append((z.detach().clone(), loss.detach().clone(), tr.bucket.flat.detach().clone()))
+            counts.append((seen.count('nf_glow_head_fwd'), seen.count('nf_glow_head_w_fwd')))
+            assert not NF.PENDING_HEADS and not NF.PENDING_HEAD_BWD
+    finally:
+        Nn.deterministic(was)
+    assert counts[0] == (0, 0) and counts[1][0] == 3 and counts[1][1] >= 6, counts
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert abs(float(outs[0][1]) - float(outs[1][1])) <= 1e-6 * abs(float(outs[1][1]))
+    d = (outs[0][2] - outs[1][2]).double()
+    assert float(d.norm() / outs[1][2].double().norm()) <= 1e-5
+    assert Nn.persistent_timeouts() == 0
+
+
 def test_cifar_glow_with_and_without_the_fused_heads(pkg, monkeypatch):
     """a (3, 32, 32) Glow with two steps per level: the fused heads (C = 12, 48) and the fused couplings against the per-layer
     launches -- z, log-det and every parameter gradient of one training-mode pass."""
