@@ -529,6 +529,10 @@ typedef struct nf_convnet_desc {
     const float* hs_Um;
     const float* hs_sign;
     float* hs_Wout;           /* (cp_C, cp_C) written, or NULL */
+    /* ws_gen = 0: ws_zero holds zeros.  ws_gen = k > 0: ws_zero was zero when the FIRST launch that shares it began and every launch
+     * since (either direction, serialised on one stream) came with its own k: the launch tags its slots 8 k + 1 .. 8 k + 7 and takes
+     * nothing else for an arrival (one buffer per train step instead of one per launch: fused_conv._chain_slots).                 */
+    int ws_gen, ws_reserved;
 } nf_convnet_desc;
 int nf_convnet_chain_usable(int64_t B, int I0, int O_out, int H, int W);
 int nf_convnet_chain_fwd(const nf_convnet_desc* desc, int64_t B, int I0, int O_out, int H, int W, int training, float bn_eps,
@@ -565,7 +569,8 @@ typedef struct nf_convnet_bwd_desc {
     float* cp_g_out;            /* (B, O, H, W) written */
     float* cp_g_a;              /* scalars, += (atomic) */
     float* cp_g_c;
-    int cp_mode, cp_odd, cp_C, cp_reserved;
+    int cp_mode, cp_odd, cp_C;
+    int ws_gen;                 /* as in nf_convnet_desc */
     /* Optional: gradient accumulators of the BatchNorm parameters, (32,) each, += (one workgroup adds: no atomics). */
     float* g_gamma[5];
     float* g_beta[5];

@@ -495,7 +495,7 @@ __device__ __forceinline__ void nf_cc_merge_rows(const float* xs, int XS, int n,
 // Returns true in the ONE lane per channel that holds the channel's totals (ci, S, M2) -- the caller finishes the BatchNorm constants
 // there and then synchronises: no barrier between the merge and the constants.
 template <int NPB>
-__device__ __forceinline__ bool nf_cc_stats_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, int round,
+__device__ __forceinline__ bool nf_cc_stats_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, unsigned gbase, int round,
                                                      int64_t Npx, int PXW, int& ci_out, float& S_out, float& M2_out) {
     float* red = sm + L.RED;
     float* xs = sm + L.RS;
@@ -530,15 +530,15 @@ __device__ __forceinline__ bool nf_cc_stats_exchange(float* sm, const NfCcLds& L
             ci_out = i; S_out = S; M2_out = M2;
         } else {
             unsigned long long* dst = slots + ((size_t)round * NF_CC_MAX_BLOCKS + blockIdx.x) * 64 + i;
-            __hip_atomic_store(dst, ((unsigned long long)(round + 1) << 32) | (unsigned long long)__float_as_uint(S), __ATOMIC_RELAXED,
+            __hip_atomic_store(dst, ((unsigned long long)(gbase + round + 1) << 32) | (unsigned long long)__float_as_uint(S), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 32, ((unsigned long long)(round + 1) << 32) | (unsigned long long)__float_as_uint(M2),
+            __hip_atomic_store(dst + 32, ((unsigned long long)(gbase + round + 1) << 32) | (unsigned long long)__float_as_uint(M2),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (G == 1) return threadIdx.x < 32;
     const unsigned long long* rs = slots + (size_t)round * NF_CC_MAX_BLOCKS * 64;
-    const unsigned gen = (unsigned)(round + 1);
+    const unsigned gen = gbase + (unsigned)(round + 1);
     if (round == 1) NF_CC_STAMP(57);
 #ifdef NF_CC_PROF
     if (round == 1 && threadIdx.x == 0) nf_cc_arrive[blockIdx.x] = wall_clock64();
@@ -606,15 +606,15 @@ __device__ __forceinline__ int nf_cc_half_to_full(const NfSplit& s, int which, i
 
 #define NF_CC_HALO_SLOTS(W) (2 * 32 * (W))                                  // per layer and destination tile
 template <int OWN>
-__device__ __forceinline__ void nf_cc_halo_publish(unsigned long long* hslots, int layer, const NfCvGeo& g, int tile, int y0, int px, int kq,
-                                                   int hs, const float (&v)[OWN]) {
+__device__ __forceinline__ void nf_cc_halo_publish(unsigned long long* hslots, unsigned gbase, int layer, const NfCvGeo& g, int tile, int y0,
+                                                   int px, int kq, int hs, const float (&v)[OWN]) {
     const int row = px >> g.lgW, x = px & (g.W - 1);
     const bool first = row == 0 && y0 > 0;                       // our first row is the row BELOW the previous tile's last row
     const bool last = row == g.TH - 1 && y0 + g.TH < g.H;        // our last row is the row ABOVE the next tile's first row
     if (!(first || last)) return;
     const int dst = first ? tile - 1 : tile + 1, s = first ? 1 : 0;
     unsigned long long* base = hslots + ((size_t)layer * NF_CC_MAX_BLOCKS + dst) * NF_CC_HALO_SLOTS(g.W) + s * 32 * g.W + x;
-    const unsigned long long gen = (unsigned long long)(layer + 1) << 32;
+    const unsigned long long gen = (unsigned long long)(gbase + layer + 1) << 32;
 #pragma unroll
     for (int rr = 0; rr < OWN; ++rr) {
         const int c = nf_cv_cd_row(OWN * kq + rr, hs);
@@ -623,12 +623,13 @@ __device__ __forceinline__ void nf_cc_halo_publish(unsigned long long* hslots, i
 }
 // thread t < 32 W: channel t / W, column t % W of BOTH halo rows (s = 0, 1; an image border has none).  Returns the frame position of
 // the value this call delivers in `v`, or -1; call once per row s.
-__device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots, int layer, const NfCvGeo& g, int tile, int y0, int s, float& v) {
+__device__ __forceinline__ int nf_cc_halo_poll(const unsigned long long* hslots, unsigned gbase, int layer, const NfCvGeo& g, int tile, int y0,
+                                               int s, float& v) {
     const bool has = s == 0 ? y0 > 0 : y0 + g.TH < g.H;
     if (!has) return -1;
     const int t = threadIdx.x, x = t & (g.W - 1);
     const unsigned long long* p = hslots + ((size_t)layer * NF_CC_MAX_BLOCKS + tile) * NF_CC_HALO_SLOTS(g.W) + s * 32 * g.W + t;
-    const unsigned gen = (unsigned)(layer + 1);
+    const unsigned gen = gbase + (unsigned)(layer + 1);
     unsigned long long w;
     unsigned spins = 0;
     do {
@@ -1128,6 +1129,10 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
     const int64_t q = pv ? P & (g.HW - 1) : 0;
     const int npb = nf_cc_valid_px(Npx, tile * PXW + 32 * pb, 32);
     unsigned long long* slots = (unsigned long long*)d.ws_zero;
+    // generation tags of this launch's slots: 8 ws_gen + (1 .. 7).  ws_gen = 0: the slots are fresh zeros; > 0: every launch of a train
+    // step shares ONE slot buffer, zeroed where the step begins -- a launch never matches what an earlier one left (round 6: the fresh
+    // buffers were 795 MB of memset per C4 step, 0.17 ms)
+    const unsigned gbase = 8u * (unsigned)d.ws_gen;
 
     constexpr bool packed = PK;                         // compile-time: the weights arrive as LDS images (nf_conv_weight_pack)
     constexpr bool cpl = CPL;                           // the coupling rides the epilogue of the output convolution (d.cp_z != NULL)
@@ -1287,12 +1292,12 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
             if (pv) act[(b * 32 + oc) * g.HW + q] = a;
             if ((l & 1) == 0) stream[rr] = a;           // acts[0], acts[2] are the residual stream
         }
-        if (halo) nf_cc_halo_publish<OWN>(hslots, l, g, (int)tile, y0, px, kq, hs, own);
+        if (halo) nf_cc_halo_publish<OWN>(hslots, gbase, l, g, (int)tile, y0, px, kq, hs, own);
         NF_CC_STAMP(4 + 8 * l);
         if (training) {
             int k;
             float tS, tM2;
-            const bool fin = nf_cc_stats_exchange<NPB>(sm, L, slots, l, Npx, PXW, k, tS, tM2);
+            const bool fin = nf_cc_stats_exchange<NPB>(sm, L, slots, gbase, l, Npx, PXW, k, tS, tM2);
             NF_CC_STAMP(5 + 8 * l);
             if (fin) {                                  // the lane that holds channel k's totals finishes its constants
                 const float invN = 1.f / (float)Npx;
@@ -1332,7 +1337,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float v = 0.f;
-                const int f = nf_cc_halo_poll(hslots, l, g, (int)tile, y0, s2, v);
+                const int f = nf_cc_halo_poll(hslots, gbase, l, g, (int)tile, y0, s2, v);
                 if (f >= 0) nf_cc_frame_store1(Fr, CSr, c, f, fmaxf(fmaf(v, kc[c], kc[32 + c]), 0.f));
             }
         }
@@ -1467,7 +1472,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
                     // the first one through never-used layer-0 halo slots of that tile (its upper border has no neighbour)
                     const int nparts = g.HW / PXW, part = (int)((tile * PXW) & (g.HW - 1)) / PXW;
                     unsigned long long* hs0 = hslots + (size_t)(tile - part) * NF_CC_HALO_SLOTS(g.W);
-                    const unsigned long long gen = 7ull << 32;
+                    const unsigned long long gen = (unsigned long long)(gbase + 7u) << 32;
                     if (part > 0) {
                         __hip_atomic_store(hs0 + part, gen | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         v = 0.f;
@@ -1477,7 +1482,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_fwd(nf_convnet_
                             unsigned spins = 0;
                             do {
                                 w = __hip_atomic_load(hs0 + p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if ((w >> 32) == 7ull) break;
+                                if ((unsigned)(w >> 32) == gbase + 7u) break;
                                 if (++spins > nf_cc_spin_limit) { NF_PERSIST_GIVE_UP(nf_cc); break; }
                                 __builtin_amdgcn_s_sleep(1);
                             } while (true);
@@ -1571,7 +1576,7 @@ __device__ __forceinline__ void nf_cc_half_sums2(const float (&u)[OWN], const fl
 
 // grid-wide plain sums of 2 x 32 values: red[h][pb][c] -> tot[32 h + c]; fixed summation order
 template <int NPB>
-__device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, int round) {
+__device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCcLds& L, unsigned long long* slots, unsigned gbase, int round) {
     float* red = sm + L.RED;
     float* xs = sm + L.RS;
     float* tot = sm + L.TOT;
@@ -1589,7 +1594,7 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
         if (G == 1) tot[threadIdx.x] = sv[0];
         else
             __hip_atomic_store(slots + ((size_t)round * NF_CC_MAX_BLOCKS + blockIdx.x) * 64 + threadIdx.x,
-                               ((unsigned long long)(round + 1) << 32) | (unsigned long long)__float_as_uint(sv[0]), __ATOMIC_RELAXED,
+                               ((unsigned long long)(gbase + round + 1) << 32) | (unsigned long long)__float_as_uint(sv[0]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
     if (G == 1) {
@@ -1597,7 +1602,7 @@ __device__ __forceinline__ const float* nf_cc_sum_exchange(float* sm, const NfCc
         return tot;
     }
     const int XS = 65;
-    const unsigned gen = (unsigned)(round + 1);
+    const unsigned gen = gbase + (unsigned)(round + 1);
     const unsigned long long* rs = slots + (size_t)round * NF_CC_MAX_BLOCKS * 64;
     const int lane = threadIdx.x & 63, ci = 2 * (threadIdx.x >> 6) + (lane >> 5), l = lane & 31;
     int nrows = G;
@@ -1659,6 +1664,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
     const int64_t q = pv ? P & (g.HW - 1) : 0;
     const float invN = 1.f / (float)Npx;
     unsigned long long* slots = (unsigned long long*)d.ws_zero;
+    const unsigned gbase = 8u * (unsigned)d.ws_gen;     // (generation tags of this launch: see the forward kernel)
     const int64_t b0 = (tile * PXW) >> g.lgHW;
     constexpr bool halo = HALO;                         // compile-time: the whole-sample variants carry none of its registers                       // a sample split over several workgroups (see the forward kernel)
     const int y0 = halo ? (int)((tile * PXW) & (g.HW - 1)) >> g.lgW : 0;
@@ -1857,7 +1863,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
             xh[rr] = (a - kc[64 + oc]) * kc[96 + oc];
             if (pv) gn[(b * 32 + oc) * g.HW + q] = v;
         }
-        if (halo) nf_cc_halo_publish<OWN>(hslots, l, g, (int)tile, y0, px, kq, hs, own);   // gn of our boundary rows, to the neighbours
+        if (halo) nf_cc_halo_publish<OWN>(hslots, gbase, l, g, (int)tile, y0, px, kq, hs, own);   // gn of our boundary rows, to the neighbours
         float mg[OWN], mgx[OWN];
         {   // batch sums of gn and gn * xhat: the gradients of beta and gamma in either mode, the mean terms of the BatchNorm backward
             // in training mode (evaluation mode normalises with constants: no mean terms)
@@ -1871,7 +1877,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
                 red[pb * 32 + oc] = S1;
                 red[NPB * 32 + pb * 32 + oc] = S2;
             }
-            const float* tot = nf_cc_sum_exchange<NPB>(sm, L, slots, l);
+            const float* tot = nf_cc_sum_exchange<NPB>(sm, L, slots, gbase, l);
             NF_CC_STAMP(68 + 6 * (4 - l));
             if (blockIdx.x == 0 && threadIdx.x < 64) {
                 (threadIdx.x < 32 ? d.sum_g[l] : d.sum_gx[l])[threadIdx.x & 31] = tot[threadIdx.x];
@@ -1891,7 +1897,7 @@ __global__ void __launch_bounds__(NF_CV_THREADS) k_convnet_chain_bwd(nf_convnet_
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float v = 0.f;
-                    const int f = nf_cc_halo_poll(hslots, l, g, (int)tile, y0, s2, v);
+                    const int f = nf_cc_halo_poll(hslots, gbase, l, g, (int)tile, y0, s2, v);
                     if (f >= 0) {
                         const float xhh = (a_h[s2] - kc[64 + c]) * kc[96 + c];
                         float G = kc[c] * (v - mgc - xhh * mgxc);

@@ -54,7 +54,8 @@ class ConvNetDesc(ctypes.Structure):
                 ('hd_x', ctypes.c_void_p), ('hd_ls', ctypes.c_void_p), ('hd_bias', ctypes.c_void_p), ('hd_W', ctypes.c_void_p),
                 ('hd_log_s', ctypes.c_void_p), ('hd_x1', ctypes.c_void_p),
                 ('hs_P', ctypes.c_void_p), ('hs_L', ctypes.c_void_p), ('hs_U', ctypes.c_void_p), ('hs_Lm', ctypes.c_void_p),
-                ('hs_Um', ctypes.c_void_p), ('hs_sign', ctypes.c_void_p), ('hs_Wout', ctypes.c_void_p)]
+                ('hs_Um', ctypes.c_void_p), ('hs_sign', ctypes.c_void_p), ('hs_Wout', ctypes.c_void_p),
+                ('ws_gen', ctypes.c_int), ('ws_reserved', ctypes.c_int)]
 
 
 class ConvNetBwdDesc(ctypes.Structure):
@@ -67,7 +68,7 @@ class ConvNetBwdDesc(ctypes.Structure):
                 ('cp_g_y', ctypes.c_void_p), ('cp_g_ld', ctypes.c_void_p), ('cp_z', ctypes.c_void_p), ('cp_out', ctypes.c_void_p),
                 ('cp_a', ctypes.c_void_p), ('cp_c', ctypes.c_void_p), ('cp_g_z', ctypes.c_void_p), ('cp_g_out', ctypes.c_void_p),
                 ('cp_g_a', ctypes.c_void_p), ('cp_g_c', ctypes.c_void_p), ('cp_mode', ctypes.c_int), ('cp_odd', ctypes.c_int),
-                ('cp_C', ctypes.c_int), ('cp_reserved', ctypes.c_int), ('g_gamma', ctypes.c_void_p * 5), ('g_beta', ctypes.c_void_p * 5),
+                ('cp_C', ctypes.c_int), ('ws_gen', ctypes.c_int), ('g_gamma', ctypes.c_void_p * 5), ('g_beta', ctypes.c_void_p * 5),
                 ('wpk', ctypes.c_void_p * 6), ('hd_g_h', ctypes.c_void_p), ('hd_W', ctypes.c_void_p), ('hd_ls', ctypes.c_void_p)]
 
 
@@ -316,6 +317,26 @@ CONV_DEFER_ON = True
 CONV_DEFER = ConvDefer()
 
 
+CHAIN_SLOTS_SHARED = True      # (internal: False = a fresh zeroed slot buffer per chain launch, the round 2 .. 5 form; tests compare)
+
+
+def _chain_slots(n, dev):
+    """(exchange slots of one chain launch, its generation number).  Inside a trainer step every launch shares ONE buffer from the
+    step's zero arena -- zeroed once where the step begins -- and comes with its own generation (nf_convnet_desc.ws_gen): the launches
+    are serialised on the stream and a launch takes only its own tags for an arrival.  A fresh buffer per launch (5.6 MB each at the
+    16 x 16 levels) was 795 MB of memset per config-4 step.  Outside a step: fresh zeros, generation 0."""
+    A = WS.ARENA
+    if not (CHAIN_SLOTS_SHARED and A.active and A.buf is not None and A.buf.device == dev):
+        return WS.zeros(n, dev), 0
+    t = A.step_state.get('chain_slots')
+    if t is None or t.numel() < n:
+        t = A.step_state['chain_slots'] = WS.zeros(n, dev)
+    A.step_state['chain_gen'] = gen = A.step_state.get('chain_gen', 0) + 1
+    if gen >= (1 << 28):                                      # (8 gen + 7 stays a 32-bit tag)
+        return WS.zeros(n, dev), 0
+    return t, gen
+
+
 def _convnet_modules(net):
     convs = [net.in_block[0]]
     bns = []
@@ -428,7 +449,7 @@ def _cn_forward(ctx, x, training, defer, tensors, cpl=None, packs=None):
         # (the slots' tensor must outlive every allocation up to the launch: a freed block is handed to the next torch.empty)
         nws = _chain_ws_floats(B, I0, O_out, Hh, Ww)
         need = training or nws > N.header_constant('NF_CONVNET_WS_FLOATS')           # (halo hand-over: in evaluation mode too)
-        slots = WS.zeros(nws, dev) if need else None
+        slots, d.ws_gen = _chain_slots(nws, dev) if need else (None, 0)
         d.ws_zero = slots.data_ptr() if need else None
         if cpl is not None:
             z, ld, a, c, mode, odd, inverse = cpl
@@ -598,7 +619,7 @@ def _cn_backward(ctx, g_out, cpl_grads=None):
         if getattr(ctx, 'packs', None) is not None and all(p.current() for p in ctx.packs):
             for i in range(nl):                     # (stale images: the kernel splits the saved weights itself, bitwise the same)
                 d.wpk[i] = ctx.packs[i].data_ptr()
-        slots = WS.zeros(_chain_ws_floats(B, I0, O_out, Hh, Ww), dev)        # (kept alive up to the launch, see the forward)
+        slots, d.ws_gen = _chain_slots(_chain_ws_floats(B, I0, O_out, Hh, Ww), dev)      # (kept alive up to the launch, see the forward)
         d.ws_zero = slots.data_ptr()
         if ctx.sinks is not None:                   # BatchNorm parameter gradients: added by the launch itself
             for j in range(nb):

@@ -19,6 +19,7 @@ class ZeroArena:
         self.active = False
         self.retired = []       # outgrown buffers a hipGraph was captured against: its kernel arguments still point into them
         self.captured = False   # a capture happened while the CURRENT buffer was the arena
+        self.step_state = {}    # per-step values of the arena's clients (fused_conv._chain_slots: one exchange-slot buffer per step)
 
     def begin(self, device):
         """start a step: zero as much of the arena as the PREVIOUS step used (+ 25 %).  Sizing by the all-time maximum would make a
@@ -42,6 +43,7 @@ class ZeroArena:
             self.captured = True
         self.off = 0
         self.active = True
+        self.step_state = {}
 
     def end(self):
         self.last = self.off

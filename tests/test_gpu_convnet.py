@@ -445,6 +445,37 @@ def test_cifar_glow_heads_in_the_forward_chain_prologue(pkg, monkeypatch, B):
     assert Nn.persistent_timeouts() == 0
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_chain_launches_share_one_slot_buffer_per_step(pkg, monkeypatch, graph):
+    """Inside a trainer step every chain launch takes its exchange slots (BatchNorm statistics, halo rows, log-det hand-over) from ONE
+    buffer zeroed where the step begins, told apart by a per-launch generation tag; the round 2 .. 5 form gave every launch fresh
+    zeros.  Three steps of a (3, 32, 32) Glow either way, eager and as a replayed hipGraph (the tags are constants of the capture, the
+    memset is part of it): the same bits in the ordered mode, no exchange timed out."""
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    nftrain = importlib.import_module(pkg.__name__ + '.train')
+    Nn = pkg._native
+    from types import SimpleNamespace as NS
+    y = torch.rand(64, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    was = Nn.deterministic()
+    Nn.deterministic(True)
+    outs = []
+    try:
+        for shared in (True, False):
+            monkeypatch.setattr(fc, 'CHAIN_SLOTS_SHARED', shared)
+            torch.manual_seed(4)
+            net = pkg.Glow((3, 32, 32), 'image', NS(layers=2, mixtures=None)).to(DEV)
+            tr = nftrain.FlowTrainer(net, graph=graph, warmup=1)
+            losses = [float(tr.train_on_batch(y)[1]) for _ in range(4)]
+            torch.cuda.synchronize()
+            outs.append((losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()))
+    finally:
+        Nn.deterministic(was)
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert all(l == l and abs(l) < 1e6 for l in outs[0][0])
+    assert Nn.persistent_timeouts() == 0
+
+
 def test_cifar_glow_with_and_without_the_fused_heads(pkg, monkeypatch):
     """a (3, 32, 32) Glow with two steps per level: the fused heads (C = 12, 48) and the fused couplings against the per-layer
     launches -- z, log-det and every parameter gradient of one training-mode pass."""
