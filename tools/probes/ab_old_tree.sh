@@ -1,4 +1,4 @@
-# same-box A/B of two trees: the repository and a second checkout under _ab_old/ (a scratch worktree, not committed);
+# same-box A/B of two trees: the repository and a second checkout under _ab_old/ (a scratch `git worktree add _ab_old <commit>`, built there, removed afterwards);
 #   HEAD_IN_CHAIN=0|1 sets layers.HEAD_IN_CHAIN in both
 for rep in 1 2 3; do
   for d in . _ab_old; do
