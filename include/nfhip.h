@@ -118,6 +118,14 @@ int nf_flowbn_stats(const float* x, const float* center, float* ws, int64_t B, i
 int nf_flowbn_head_fwd(const float* x, const float* ws, const float* log_gamma, const float* beta, float* batch_mean,
                        float* batch_var, float* running_mean, float* running_var, float eps, float momentum, float* y,
                        float* z1c, float* ld, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
+/* The two launches above in ONE persistent launch (csrc/flowbn_head.hip: k_flowbn_head_fused): the workgroups exchange their
+ * per-plane shifted sums through ws_zero -- nf_flowbn_head_fused_ws_floats(B, C, H, W) floats of ZEROS; 0 = the shape is not
+ * taken (more workgroups of 1 024 elements than compute units, C > 64, B C > 3 072, H W not a power of two in 16 .. 1 024): use the
+ * two launches -- and add them in sample order (bit-reproducible without the ordered mode).  Replaces the same reference lines (flows/modules.py:283-307).  */
+int nf_flowbn_head_fused_ws_floats(int64_t B, int C, int H, int W);
+int nf_flowbn_head_fused(const float* x, const float* log_gamma, const float* beta, float* batch_mean, float* batch_var,
+                         float* running_mean, float* running_var, float eps, float momentum, float* y, float* z1c, float* ld,
+                         float* ws_zero, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
 int nf_flowbn_head_bwd(const float* g_h, const float* g_z1c, const float* var, const float* log_gamma, float* g_x,
                        int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream);
 

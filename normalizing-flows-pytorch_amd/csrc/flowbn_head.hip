@@ -93,6 +93,163 @@ __global__ void __launch_bounds__(NF_BLOCK) k_flowbn_head_fwd(const float* __res
     for (int64_t b = gtid; b < B; b += gstride) ld[b] += dld;
 }
 
+// ---- statistics AND apply in ONE persistent launch (round 6) ---------------------------------------------------------------------------
+// The two launches above are ~7 + ~5 us for a tensor of a few hundred KB (196 608 elements at the CIFAR levels): launch latency twice,
+// the tensor read twice.  Here a thread keeps four consecutive elements of one channel plane in registers (a workgroup = 1 024
+// elements = whole planes, or a whole number of workgroups per plane), every (sample, channel) plane's shifted sums go through ONE
+// {generation : value} slot pair (zeroed by the caller), every workgroup gathers the B C pairs and adds each channel's B rows in
+// sample order -- the same bits in every workgroup and in every run, no float atomics: nothing for the ordered mode to do -- and
+// normalises what it holds.  Grid <= the compute units (co-resident by construction: 256 threads, 25 KB of LDS); a workgroup that
+// never arrives ends the wait after the spin limit, counted in nf_persistent_timeouts like every bounded wait of the library.
+// Workgroup 0 updates running_mean -- the centre every workgroup has read by the time its planes are published.
+NF_PERSIST_STATE(nf_fbh)
+NF_PERSIST_HOST_API(nf_fbh)
+#define NF_FBF_EPT 4                        // elements per thread
+#define NF_FBF_WGE (NF_BLOCK * NF_FBF_EPT)  // elements per workgroup
+#define NF_FBF_MAX_VALUES 6144              // 2 B C values gathered in LDS
+__global__ void __launch_bounds__(NF_BLOCK) k_flowbn_head_fused(const float* __restrict__ x, const float* __restrict__ log_gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ bmean,
+                                                                float* __restrict__ bvar, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, float eps, float mom, float* __restrict__ y,
+                                                                float* __restrict__ z1c, float* __restrict__ ld,
+                                                                unsigned long long* __restrict__ slots, NfSplit s, int B, int P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int C = s.C, G = gridDim.x, tid = threadIdx.x, lane = tid & (NF_WAVE - 1);
+    float* val = lds;                                   // [B][C][2] gathered plane sums; before that: [waves][2] of this workgroup
+    NfBnCoef* coef = reinterpret_cast<NfBnCoef*>(lds + NF_FBF_MAX_VALUES);
+    float* ldt = lds + NF_FBF_MAX_VALUES + 4 * C;       // [C] log-det terms
+    float* cen = ldt + C;                               // [C] the centres (running_mean as it was when the launch began)
+    if (tid < C) cen[tid] = rmean[tid];
+    const int total = B * C * P;                        // (< 2^31: checked by the host)
+    const int e0 = (blockIdx.x * NF_BLOCK + tid) * NF_FBF_EPT;
+    const bool valid = e0 < total;
+    const int lgP = 31 - __clz(P);
+    const int plane = valid ? e0 >> lgP : 0;            // = b C + c
+    const int bb = plane / C, c = plane - bb * C;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(x + e0);
+    const float k = rmean[c];
+    float s1 = 0.f, s2 = 0.f;
+    if (valid) {
+        const float d0 = v.x - k, d1 = v.y - k, d2 = v.z - k, d3 = v.w - k;
+        s1 = (d0 + d1) + (d2 + d3);
+        s2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3)));
+    }
+    // the threads of one plane are L = P / 4 consecutive ones (a power of two): a butterfly over min(L, 64) lanes; a plane of 512 or
+    // 1 024 elements spans two or four waves of this workgroup (or, beyond 1 024, several workgroups: their partial sums share the slot
+    // pair -- not taken, see nf_fbf_grid)
+    const int L = P / NF_FBF_EPT, Lw = L < NF_WAVE ? L : NF_WAVE;
+    for (int off = 1; off < Lw; off <<= 1) { s1 += __shfl_xor(s1, off, NF_WAVE); s2 += __shfl_xor(s2, off, NF_WAVE); }
+    if (L > NF_WAVE) {                                  // (block-uniform) wave sums -> LDS, the first thread of the plane adds them in wave order
+        if (lane == 0) { val[2 * (tid >> 6)] = s1; val[2 * (tid >> 6) + 1] = s2; }
+        __syncthreads();
+        if ((tid & (L - 1)) == 0) {
+            s1 = 0.f; s2 = 0.f;
+            for (int w = 0; w < L / NF_WAVE; ++w) { s1 += val[2 * ((tid >> 6) + w)]; s2 += val[2 * ((tid >> 6) + w) + 1]; }
+        }
+    }
+    if (valid && (tid & (L - 1)) == 0) {
+        unsigned long long* dst = slots + (size_t)plane * 2;
+        __hip_atomic_store(dst, (1ull << 32) | (unsigned long long)__float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, (1ull << 32) | (unsigned long long)__float_as_uint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                    // (val was read above, is rewritten below; cen is written)
+    const int nval = 2 * B * C;
+    for (int e0v = tid; e0v < nval; e0v += 4 * NF_BLOCK) {      // four polls in flight per trip
+        unsigned long long w[4];
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0v + q * NF_BLOCK;
+                w[q] = __hip_atomic_load(slots + (e < nval ? e : e0v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ok = ok && (unsigned)(w[q] >> 32) == 1u;
+            if (ok) break;
+            if (++spins > nf_fbh_spin_limit) { NF_PERSIST_GIVE_UP(nf_fbh); break; }
+            __builtin_amdgcn_s_sleep(1);
+        } while (true);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0v + q * NF_BLOCK;
+            if (e < nval) val[e] = __uint_as_float((unsigned)w[q]);
+        }
+    }
+    __syncthreads();
+    const float n = (float)B * (float)P;
+    if (tid < C) {
+        float S1 = 0.f, S2 = 0.f;
+        for (int b = 0; b < B; ++b) { S1 += val[(b * C + tid) * 2]; S2 += val[(b * C + tid) * 2 + 1]; }
+        const float kc = cen[tid];
+        const float m1 = S1 / n;
+        const float mean = kc + m1;
+        const float var = fmaxf(S2 / n - m1 * m1, 0.f) + eps;                    // biased, eps inside (modules.py:287)
+        NfBnCoef kf;
+        kf.mean = mean; kf.sd = sqrtf(var); kf.eg = expf(log_gamma[tid]); kf.beta = beta[tid];
+        coef[tid] = kf;
+        ldt[tid] = log_gamma[tid] - 0.5f * logf(var);
+        if (blockIdx.x == 0) {
+            bmean[tid] = mean;
+            bvar[tid] = var;
+            rmean[tid] = kc * (1.f - mom) + mean * mom;                          // modules.py:291-294
+            rvar[tid] = rvar[tid] * (1.f - mom) + var * mom;
+        }
+    }
+    __syncthreads();
+    float dld = 0.f;
+    for (int cc = 0; cc < C; ++cc) dld += ldt[cc];
+    dld *= (float)P;                                                             // modules.py:303-305
+    if (valid) {
+        const NfBnCoef kf = coef[c];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ((o[j] - kf.mean) / kf.sd) * kf.eg + kf.beta;      // modules.py:300-301
+        *reinterpret_cast<float4*>(y + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (z1c != nullptr) {
+            const int p0 = e0 & (P - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int which, e;
+                nf_full_to_half(s, c, p0 + j, which, e);
+                if (which == 1) z1c[(int64_t)bb * s.n_half + e] = o[j];
+            }
+        }
+    }
+    for (int b = blockIdx.x * NF_BLOCK + tid; b < B; b += G * NF_BLOCK) ld[b] += dld;
+}
+
+static int nf_fbf_grid(int64_t B, int C, int P) {       // 0: the fused launch does not take this shape
+    if (B < 1 || C < 1 || C > 64 || P < 16 || P > NF_FBF_WGE || (P & (P - 1)) != 0) return 0;
+    const int64_t total = B * C * P;
+    if (total >= ((int64_t)1 << 30) || 2 * B * C > NF_FBF_MAX_VALUES) return 0;
+    const int64_t G = (total + NF_FBF_WGE - 1) / NF_FBF_WGE;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (G > cus) return 0;
+    return (int)G;
+}
+// floats of zeroed slot memory the fused launch needs (0: not usable for this shape -> nf_flowbn_stats + nf_flowbn_head_fwd)
+extern "C" int nf_flowbn_head_fused_ws_floats(int64_t B, int C, int H, int W) {
+    return nf_fbf_grid(B, C, H * W) > 0 ? (int)(4 * B * C) : 0;
+}
+extern "C" int nf_flowbn_head_fused(const float* x, const float* log_gamma, const float* beta, float* batch_mean, float* batch_var,
+                                    float* running_mean, float* running_var, float eps, float momentum, float* y, float* z1c, float* ld,
+                                    float* ws_zero, int mode, int odd, int64_t B, int C, int H, int W, nf_stream_t stream) {
+    NfSplit s;
+    if (!nf_make_split(s, z1c != nullptr ? mode : NF_SPLIT_NONE, odd, C, H, W) || ws_zero == nullptr) return NF_E_BADARG;
+    const int G = nf_fbf_grid(B, C, H * W);
+    if (G <= 0) return NF_E_BADARG;
+    const size_t lds = sizeof(float) * (NF_FBF_MAX_VALUES + 6 * (size_t)C);
+    hipLaunchKernelGGL(k_flowbn_head_fused, dim3((unsigned)G), dim3(NF_BLOCK), lds, (hipStream_t)stream, x, log_gamma, beta, batch_mean,
+                       batch_var, running_mean, running_var, eps, momentum, y, z1c, ld, reinterpret_cast<unsigned long long*>(ws_zero), s,
+                       (int)B, H * W);
+    NF_CHECK_LAUNCH();
+    return 0;
+}
+
 // g_x = (g_h + scatter(g_z1c)) * exp(log_gamma) / sqrt(var)         (appendix B4, affine=False)
 __global__ void __launch_bounds__(NF_BLOCK) k_flowbn_head_bwd(const float* __restrict__ gh, const float* __restrict__ gz1c,
                                                               const float* __restrict__ var,

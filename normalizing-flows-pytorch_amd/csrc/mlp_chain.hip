@@ -2192,16 +2192,19 @@ __attribute__((visibility("hidden"))) int nf_cc_persist_read(unsigned* v);      
 __attribute__((visibility("hidden"))) int nf_cc_persist_set(unsigned limit, unsigned* flag_dev, int reset);
 __attribute__((visibility("hidden"))) int nf_so_persist_read(unsigned* v);                                 // flow_solo.hip
 __attribute__((visibility("hidden"))) int nf_so_persist_set(unsigned limit, unsigned* flag_dev, int reset);
+__attribute__((visibility("hidden"))) int nf_fbh_persist_read(unsigned* v);                                // flowbn_head.hip
+__attribute__((visibility("hidden"))) int nf_fbh_persist_set(unsigned limit, unsigned* flag_dev, int reset);
 
 extern "C" int nf_persistent_timeouts(int* count) {
     if (count == nullptr) return NF_E_BADARG;
-    unsigned v = 0, v2 = 0, v3 = 0, v4 = 0;
+    unsigned v = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
     int e = nf_mc_persist_read(&v);
     if (e == 0) e = nf_md_persist_read(&v2);
     if (e == 0) e = nf_cc_persist_read(&v3);
     if (e == 0) e = nf_so_persist_read(&v4);
+    if (e == 0) e = nf_fbh_persist_read(&v5);
     if (e != 0) return e;
-    *count = (int)(v + v2 + v3 + v4);
+    *count = (int)(v + v2 + v3 + v4 + v5);
     return 0;
 }
 
@@ -2231,6 +2234,7 @@ extern "C" int nf_persistent_config(int64_t spin_limit, int reset, void** host_e
     if (e == 0) e = nf_md_persist_set(lim, g_persist_dev_word, reset);
     if (e == 0) e = nf_cc_persist_set(lim, g_persist_dev_word, reset);
     if (e == 0) e = nf_so_persist_set(lim, g_persist_dev_word, reset);
+    if (e == 0) e = nf_fbh_persist_set(lim, g_persist_dev_word, reset);
     if (e != 0) return e;
     if (host_error_word != nullptr) *host_error_word = (void*)g_persist_host_word;
     return 0;

@@ -458,6 +458,9 @@ def invconv_plu(z, ld, P, L, U, L_mask, U_mask, sign_s, log_s):
     return _InvConvPLU.apply(_contig(z), _owned_ld(ld), P, L, U, L_mask, U_mask, sign_s, log_s)
 
 
+FLOWBN_FUSED = True           # (internal: image data's flow BatchNorm head in one persistent launch; False = statistics + apply launches)
+
+
 class _FlowBNHead(torch.autograd.Function):
     """training-mode flow BatchNorm (affine=False) + optional conditioning-half gather: 2 launches forward, 1 backward."""
 
@@ -465,13 +468,21 @@ class _FlowBNHead(torch.autograd.Function):
     def forward(ctx, x, ld, log_gamma, beta, batch_mean, batch_var, running_mean, running_var, eps, momentum, mode, odd,
                 gather):
         B, C, H, W = _bchw(x)
-        ws = WS.zeros(3 * C, x.device)
-        N.call('nf_flowbn_stats', N.ptr(x), N.ptr(running_mean), N.ptr(ws), B, C, H * W, N.stream())
         y = torch.empty_like(x)
         z1c = torch.empty(_half_shape(x, mode), dtype=x.dtype, device=x.device) if gather else None
-        N.call('nf_flowbn_head_fwd', N.ptr(x), N.ptr(ws), N.ptr(log_gamma), N.ptr(beta), N.ptr(batch_mean),
-               N.ptr(batch_var), N.ptr(running_mean), N.ptr(running_var), float(eps), float(momentum), N.ptr(y),
-               N.ptr(z1c), N.ptr(ld), mode, int(odd), B, C, H, W, N.stream())
+        nws = int(N.load().nf_flowbn_head_fused_ws_floats(B, C, H, W)) if (FLOWBN_FUSED and x.dim() == 4) else 0
+        if nws > 0:
+            # statistics and apply in ONE persistent launch: the workgroups exchange their per-channel sums (csrc/flowbn_head.hip)
+            ws = WS.zeros(nws, x.device)
+            N.call('nf_flowbn_head_fused', N.ptr(x), N.ptr(log_gamma), N.ptr(beta), N.ptr(batch_mean), N.ptr(batch_var),
+                   N.ptr(running_mean), N.ptr(running_var), float(eps), float(momentum), N.ptr(y), N.ptr(z1c), N.ptr(ld), N.ptr(ws),
+                   mode, int(odd), B, C, H, W, N.stream())
+        else:
+            ws = WS.zeros(3 * C, x.device)
+            N.call('nf_flowbn_stats', N.ptr(x), N.ptr(running_mean), N.ptr(ws), B, C, H * W, N.stream())
+            N.call('nf_flowbn_head_fwd', N.ptr(x), N.ptr(ws), N.ptr(log_gamma), N.ptr(beta), N.ptr(batch_mean),
+                   N.ptr(batch_var), N.ptr(running_mean), N.ptr(running_var), float(eps), float(momentum), N.ptr(y),
+                   N.ptr(z1c), N.ptr(ld), mode, int(odd), B, C, H, W, N.stream())
         ctx.save_for_backward(batch_var, log_gamma)
         ctx.meta = (mode, int(odd), tuple(x.shape), gather)
         ctx.mark_dirty(ld)

@@ -437,6 +437,52 @@ def test_maf_step_vec_vs_unfused(pkg, D, N, direct):
         G.assert_close(b2[name].float(), b1[name].float(), 2e-6, rtol=1e-5, what='buffer ' + name)
 
 
+@pytest.mark.parametrize('gather', [True, False])
+@pytest.mark.parametrize('shape,mode_name', [((64, 3, 32, 32), 'checker'), ((64, 12, 16, 16), 'channel'), ((64, 48, 4, 4), 'channel'),
+                                             ((5, 6, 16, 16), 'checker'), ((1, 24, 8, 8), 'channel'), ((64, 24, 8, 8), 'checker')])
+def test_flowbn_head_one_persistent_launch(pkg, monkeypatch, shape, mode_name, gather):
+    """the flow BatchNorm head of image data (statistics + normalise + log-det + running buffers + conditioning-half gather) in ONE
+    persistent launch (k_flowbn_head_fused: the workgroups exchange their per-channel sums) against the two launches it replaces and
+    against float64: outputs to 1e-5, statistics to 1e-6 relative, the same bits from two runs (no float atomics), backward intact."""
+    NF = importlib.import_module(pkg.__name__ + '.functional')
+    Nn = pkg._native
+    mode = Nn.SPLIT_CHECKER if mode_name == 'checker' else Nn.SPLIT_CHANNEL
+    B, C, H, W = shape
+    assert int(Nn.load().nf_flowbn_head_fused_ws_floats(B, C, H, W)) > 0
+    torch.manual_seed(B * 7 + C)
+    x = (torch.randn(shape, device=DEV) * 1.3 + 0.4 * torch.arange(C, device=DEV).view(1, C, 1, 1) / C)
+    ld0 = torch.randn(B, device=DEV)
+
+    def run(fused_on):
+        monkeypatch.setattr(NF, 'FLOWBN_FUSED', fused_on)
+        torch.manual_seed(1)
+        bn = pkg.BatchNorm((C, H, W), affine=False).to(DEV).train()
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.2)
+            bn.running_var.uniform_(0.5, 2.0)
+        xi = x.clone().requires_grad_(True)
+        out = NF.flowbn_head(xi, ld0.clone(), bn, mode, False, gather=gather)
+        y, ld = out[0], out[-1]
+        loss = (y * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum() + ld.sum()
+        if gather:
+            loss = loss + (out[1] ** 2).sum() * 0.5
+        loss.backward()
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in out] + [xi.grad.clone(), bn.running_mean.clone(), bn.running_var.clone(), bn.batch_mean.clone(), bn.batch_var.clone()]
+
+    a, a2, b = run(True), run(True), run(False)
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)                         # (fixed-order sums: bit-reproducible without the ordered mode)
+    names = (['y', 'z1c', 'ld'] if gather else ['y', 'ld']) + ['grad x', 'running_mean', 'running_var', 'batch_mean', 'batch_var']
+    for n, u, v in zip(names, a, b):
+        G.assert_close(u, v, 2e-5, rtol=2e-5, what=n)
+    xd = x.double()
+    mean, var = xd.mean(dim=(0, 2, 3)), xd.var(dim=(0, 2, 3), unbiased=False)
+    G.assert_close(a[-2].reshape(-1), mean.float(), 1e-6, rtol=1e-6, what='batch mean vs float64')
+    assert float(((a[-1].double().reshape(-1) - (var + 1e-5)) / var).abs().max()) < 2e-6      # (eps inside: modules.py:287)
+    assert Nn.persistent_timeouts() == 0
+
+
 @pytest.mark.parametrize('direct', [False, True])
 @pytest.mark.parametrize('D,odd,N', [(2, False, 256), (2, True, 300), (4, False, 1000), (4, True, 77), (2, False, 4096)])
 def test_realnvp_step_vec_vs_unfused(pkg, D, odd, N, direct):
