@@ -1432,7 +1432,10 @@ int nf_conv_bulk_wgrad_plan(int64_t B, int I, int O, int H, int W, int ksize) {
     const int on = 1;
     // (the weight pass starts one tile count earlier than the data passes: at exactly 16 384 pixels -- config 4's per-GPU shard at
     // the 16 x 16 level, whose data passes run the persistent chain -- it measured 24.56 against 24.9 ms per step)
-    if (!on || !nf_cb_on() || ksize != 3 || O != 32 || I < 1 || I > 32 || B * H * W < nf_cb_min_px() - 1) return 0;
+    // Round 6: from 4 096 pixels (config 4's 8 x 8 level) when the data passes' threshold is at its default -- the contraction over
+    // pixels on the bf16 x 3 pipe against conv_bn.hip's fp32 MFMA: 20.94 -> 20.83 ms per step (tools/probes/ab_bulk_wgrad_8x8.sh).
+    const int64_t min_px = nf_cb_min_px() == 16384 + 1 ? 4096 : nf_cb_min_px() - 1;
+    if (!on || !nf_cb_on() || ksize != 3 || O != 32 || I < 1 || I > 32 || B * H * W < min_px) return 0;
     NfCbwGeo g;
     return nf_cbw_geometry(g, B, H, W) ? 1 : 0;
 }
