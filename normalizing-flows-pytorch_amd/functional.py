@@ -672,8 +672,16 @@ def flush_pending_head_bwd(entry):
 
 
 def flush_all_pending_head_bwd():
+    """end of a trainer's backward pass: nothing may be left.  An entry that no chain launch picked up means the gradient autograd handed
+    to the coupling was not the tensor the head returned (the coupling's output has a second consumer, so autograd summed two gradients
+    first; or only part of the graph was differentiated): the pass consumed a tensor that had not been computed -- loud, not silent."""
+    n = len(PENDING_HEAD_BWD)
     while PENDING_HEAD_BWD:
         flush_pending_head_bwd(PENDING_HEAD_BWD.pop(next(iter(PENDING_HEAD_BWD))))
+    if n:
+        raise RuntimeError('%d Glow head(s) left their data gradient to the previous coupling\'s backward launch, which never asked for it: '
+                           'the output of a fused image coupling must feed the next flow step only (functional.HEAD_BWD_IN_CHAIN = False '
+                           'restores the stand-alone launches)' % n)
 
 
 class GlowHeadParamsDesc(ctypes.Structure):
