@@ -155,6 +155,38 @@ def test_zero_arena_retires_only_buffers_a_graph_was_captured_against(pkg):
     assert arena.buf is not second and arena.retired == [second]
 
 
+def test_chain_launches_of_a_step_share_one_slot_buffer_with_rising_generations(pkg, monkeypatch):
+    """fused_conv._chain_slots (host logic of the shared exchange slots): inside a step of the zero arena every request returns the SAME
+    zeroed buffer with the next generation number (a larger request replaces the buffer, the numbers keep rising); a new step starts the
+    numbers again on a re-zeroed arena; outside a step -- and with the switch off -- fresh zeros and generation 0."""
+    import importlib
+    import torch
+    fc = importlib.import_module(pkg.__name__ + '.fused_conv')
+    ws = importlib.import_module(pkg.__name__ + '.workspace')
+    dev = torch.device('cpu')
+    arena = ws.ZeroArena()
+    monkeypatch.setattr(ws, 'ARENA', arena)
+    t0, g0 = fc._chain_slots(1000, dev)
+    assert g0 == 0 and float(t0.abs().sum()) == 0.0 and t0.numel() == 1000
+    for _ in range(2):                                   # two steps: the second finds the arena sized by the first
+        arena.begin(dev)
+        a, ga = fc._chain_slots(1000, dev)
+        a[:10] = 7.0                                     # (what a launch leaves behind)
+        b, gb = fc._chain_slots(600, dev)
+        assert b.data_ptr() == a.data_ptr() and (ga, gb) == (1, 2) and float(b[0]) == 7.0
+        c, gc = fc._chain_slots(5000, dev)               # larger than the shared buffer: a new zeroed one, the count goes on
+        assert gc == 3 and c.numel() >= 5000 and float(c.abs().sum()) == 0.0
+        d, gd = fc._chain_slots(1000, dev)
+        assert d.data_ptr() == c.data_ptr() and gd == 4
+        arena.end()
+    monkeypatch.setattr(fc, 'CHAIN_SLOTS_SHARED', False)
+    arena.begin(dev)
+    e, ge = fc._chain_slots(1000, dev)
+    f, gf = fc._chain_slots(1000, dev)
+    arena.end()
+    assert (ge, gf) == (0, 0) and e.data_ptr() != f.data_ptr()
+
+
 def test_trainer_keeps_models_with_host_drawn_masks_off_the_graph(pkg):
     """MADE draws its masks from np.random on every call (flows/maf.py:50,72): constant for D = 2, varying for D > 2 -- a replayed
     graph would freeze the draw of the captured step, so FlowTrainer(graph=True) falls back to eager launches for such a model"""
