@@ -51,7 +51,7 @@ if CPL:
         @staticmethod
         def backward(ctx, g_h):
             g_x = torch.empty_like(g_h)
-            NF.PENDING_HEAD_BWD[g_x.data_ptr()] = (g_h.contiguous(), hls, hW, g_x)
+            NF.PENDING_HEAD_BWD[g_x.data_ptr()] = (g_h.contiguous(), hls, hW, g_x, None if Cf >= 9 else (N.SPLIT_CHECKER, 0))
             return g_x
     from types import SimpleNamespace as NS
     holder = NS(meta={}, pending=[], g_ld={})
